@@ -1,0 +1,61 @@
+/*
+ * memory.h -- C ABI of librmm.so, the device-memory manager libgdf.so allocates
+ * its outputs and scratch from.  Binary compatible with the reference's
+ * libgdf/include/memory.h:25-184 (same enum values, same rmmOptions_t layout,
+ * same eleven entry points), so librmm_cffi can dlopen it unchanged.
+ *
+ * Backing store is HIP: "CudaDefaultAllocation" maps to hipMalloc/hipFree and
+ * "PoolAllocation" to a size-binned free-list pool carved from hipMalloc (the
+ * reference used cnmem, an un-vendored submodule).  The stream argument is an
+ * opaque pointer in the reference ABI; a hipStream_t has the same width.
+ */
+#ifndef GDF_AMD_MEMORY_H
+#define GDF_AMD_MEMORY_H
+
+#include <stddef.h>
+#ifndef __cplusplus
+#include <stdbool.h>
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct CUstream_st *cudaStream_t;   /* memory.h:25: opaque; == hipStream_t here */
+typedef long int offset_t;
+
+typedef enum {                              /* memory.h:29-39 */
+  RMM_SUCCESS = 0,
+  RMM_ERROR_CUDA_ERROR,          /* a HIP runtime error                        */
+  RMM_ERROR_INVALID_ARGUMENT,
+  RMM_ERROR_NOT_INITIALIZED,
+  RMM_ERROR_OUT_OF_MEMORY,
+  RMM_ERROR_UNKNOWN,
+  RMM_ERROR_IO,
+  N_RMM_ERROR
+} rmmError_t;
+
+typedef enum { CudaDefaultAllocation = 0, PoolAllocation = 1 } rmmAllocationMode_t;   /* memory.h:41-45 */
+
+typedef struct {                            /* memory.h:50-56 */
+  rmmAllocationMode_t allocation_mode;
+  size_t              initial_pool_size;   /* 0 = half of the free device memory   */
+  bool                enable_logging;      /* record every alloc/realloc/free      */
+} rmmOptions_t;
+
+rmmError_t  rmmInitialize(rmmOptions_t *options);           /* memory.h:65  */
+rmmError_t  rmmFinalize(void);                              /* memory.h:72  */
+const char *rmmGetErrorString(rmmError_t errcode);          /* memory.h:80  */
+rmmError_t  rmmAlloc(void **ptr, size_t size, cudaStream_t stream);          /* memory.h:96  */
+rmmError_t  rmmRealloc(void **ptr, size_t new_size, cudaStream_t stream);    /* memory.h:112 */
+rmmError_t  rmmFree(void *ptr, cudaStream_t stream);                         /* memory.h:124 */
+rmmError_t  rmmGetAllocationOffset(offset_t *offset, void *ptr, cudaStream_t stream);  /* memory.h:138 */
+rmmError_t  rmmGetInfo(size_t *freeSize, size_t *totalSize, cudaStream_t stream);      /* memory.h:152 */
+rmmError_t  rmmWriteLog(const char *filename);              /* memory.h:164 */
+size_t      rmmLogSize(void);                               /* memory.h:171 */
+rmmError_t  rmmGetLog(char *buffer, size_t buffer_size);    /* memory.h:184 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GDF_AMD_MEMORY_H */

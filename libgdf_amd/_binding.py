@@ -1,0 +1,214 @@
+"""ctypes binding of libgdf.so / librmm.so (the C ABI of include/gdf/gdf.h and include/memory.h).
+
+Mirrors /root/reference/libgdf/python/libgdf_cffi/wrapper.py:13-52: every ``gdf_*`` function that
+returns a ``gdf_error`` is wrapped so that a non-zero code raises ``GDFError(<error name>)``; for
+``GDF_CUDA_ERROR`` the message carries the runtime's own error name and string
+(``gdf_cuda_last_error`` / ``gdf_cuda_error_name`` / ``gdf_cuda_error_string``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
+
+
+class GDFError(Exception):
+    def __init__(self, errcode, msg):
+        self.errcode = errcode
+        super().__init__(msg)
+
+
+class RMMError(Exception):
+    def __init__(self, errcode, msg):
+        self.errcode = errcode
+        super().__init__(msg)
+
+
+class gdf_dtype_extra_info(C.Structure):
+    _fields_ = [("time_unit", C.c_int)]
+
+
+class gdf_column(C.Structure):
+    """56-byte POD, reference include/gdf/cffi/types.h:84-92."""
+    _fields_ = [
+        ("data", C.c_void_p),
+        ("valid", C.c_void_p),
+        ("size", C.c_size_t),
+        ("dtype", C.c_int),
+        ("null_count", C.c_size_t),
+        ("dtype_info", gdf_dtype_extra_info),
+        ("col_name", C.c_char_p),
+    ]
+
+
+class gdf_context(C.Structure):
+    """20-byte POD, reference include/gdf/cffi/types.h:161-167."""
+    _fields_ = [
+        ("flag_sorted", C.c_int),
+        ("flag_method", C.c_int),
+        ("flag_distinct", C.c_int),
+        ("flag_sort_result", C.c_int),
+        ("flag_sort_inplace", C.c_int),
+    ]
+
+
+class rmmOptions_t(C.Structure):
+    _fields_ = [("allocation_mode", C.c_int), ("initial_pool_size", C.c_size_t), ("enable_logging", C.c_bool)]
+
+
+_COLP = C.POINTER(gdf_column)
+_COLPP = C.POINTER(_COLP)
+_CTXP = C.POINTER(gdf_context)
+_INTP = C.POINTER(C.c_int)
+
+_JOIN = [_COLPP, C.c_int, _INTP, _COLPP, C.c_int, _INTP, C.c_int, C.c_int, _COLPP, _COLP, _COLP, _CTXP]
+_GROUPBY = [C.c_int, _COLPP, _COLP, _COLP, _COLPP, _COLP, _CTXP]
+
+# name -> (restype, argtypes); restype None means gdf_error (int, checked)
+_PROTOTYPES = {
+    "gdf_column_sizeof": (C.c_size_t, []),
+    "gdf_column_view": (None, [_COLP, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
+    "gdf_column_view_augmented": (None, [_COLP, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t]),
+    "gdf_column_free": (None, [_COLP]),
+    "gdf_column_concat": (None, [_COLP, _COLPP, C.c_int]),
+    "get_column_byte_width": (None, [_COLP, _INTP]),
+    "gdf_context_view": (None, [_CTXP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "gdf_error_get_name": (C.c_char_p, [C.c_int]),
+    "gdf_cuda_last_error": (C.c_int, []),
+    "gdf_cuda_error_string": (C.c_char_p, [C.c_int]),
+    "gdf_cuda_error_name": (C.c_char_p, [C.c_int]),
+    "gdf_nvtx_range_push": (None, [C.c_char_p, C.c_int]),
+    "gdf_nvtx_range_push_hex": (None, [C.c_char_p, C.c_uint]),
+    "gdf_nvtx_range_pop": (None, []),
+    "gdf_count_nonzero_mask": (None, [C.c_void_p, C.c_int, _INTP]),
+    "gdf_validity_and": (None, [_COLP, _COLP, _COLP]),
+    "gdf_inner_join": (None, _JOIN),
+    "gdf_left_join": (None, _JOIN),
+    "gdf_full_join": (None, _JOIN),
+    "gdf_group_by_sum": (None, _GROUPBY),
+    "gdf_group_by_min": (None, _GROUPBY),
+    "gdf_group_by_max": (None, _GROUPBY),
+    "gdf_group_by_avg": (None, _GROUPBY),
+    "gdf_group_by_count": (None, _GROUPBY),
+    "gdf_hash": (None, [C.c_int, _COLPP, C.c_int, _COLP]),
+    "gdf_hash_partition": (None, [C.c_int, _COLPP, _INTP, C.c_int, C.c_int, _COLPP, _INTP, C.c_int]),
+    "gdf_prefixsum_generic": (None, [_COLP, _COLP, C.c_int]),
+    "gdf_prefixsum_i8": (None, [_COLP, _COLP, C.c_int]),
+    "gdf_prefixsum_i32": (None, [_COLP, _COLP, C.c_int]),
+    "gdf_prefixsum_i64": (None, [_COLP, _COLP, C.c_int]),
+    "gpu_comparison_static_i8": (None, [_COLP, C.c_int8, _COLP, C.c_int]),
+    "gpu_comparison_static_i16": (None, [_COLP, C.c_int16, _COLP, C.c_int]),
+    "gpu_comparison_static_i32": (None, [_COLP, C.c_int32, _COLP, C.c_int]),
+    "gpu_comparison_static_i64": (None, [_COLP, C.c_int64, _COLP, C.c_int]),
+    "gpu_comparison_static_f32": (None, [_COLP, C.c_float, _COLP, C.c_int]),
+    "gpu_comparison_static_f64": (None, [_COLP, C.c_double, _COLP, C.c_int]),
+    "gpu_comparison": (None, [_COLP, _COLP, _COLP, C.c_int]),
+    "gpu_apply_stencil": (None, [_COLP, _COLP, _COLP]),
+    "gdf_filter": (None, [C.c_size_t, _COLP, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                          C.POINTER(C.c_size_t)]),
+}
+
+_RMM_PROTOTYPES = {
+    "rmmInitialize": (None, [C.POINTER(rmmOptions_t)]),
+    "rmmFinalize": (None, []),
+    "rmmGetErrorString": (C.c_char_p, [C.c_int]),
+    "rmmAlloc": (None, [C.POINTER(C.c_void_p), C.c_size_t, C.c_void_p]),
+    "rmmRealloc": (None, [C.POINTER(C.c_void_p), C.c_size_t, C.c_void_p]),
+    "rmmFree": (None, [C.c_void_p, C.c_void_p]),
+    "rmmGetAllocationOffset": (None, [C.POINTER(C.c_long), C.c_void_p, C.c_void_p]),
+    "rmmGetInfo": (None, [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_void_p]),
+    "rmmWriteLog": (None, [C.c_char_p]),
+    "rmmLogSize": (C.c_size_t, []),
+    "rmmGetLog": (None, [C.c_char_p, C.c_size_t]),
+}
+
+GDF_CUDA_ERROR = 1
+
+
+def _load(name):
+    path = os.path.join(LIB_DIR, name)
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"(or `make -C libgdf_amd/csrc`).  libgdf_amd has no CPU fallback.")
+    return C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
+class _Wrapper:
+    """Attribute access -> checked C call (reference wrapper.py:13-52)."""
+
+    def __init__(self, cdll, prototypes, check):
+        self._cdll = cdll
+        self._prototypes = prototypes
+        self._check = check
+        self._cache = {}
+
+    def __getattr__(self, name):
+        if name.startswith("_"):
+            raise AttributeError(name)
+        fn = self._cache.get(name)
+        if fn is not None:
+            return fn
+        try:
+            cfn = getattr(self._cdll, name)
+        except AttributeError:
+            raise AttributeError(f"{name} is not exported by the library") from None
+        restype, argtypes = self._prototypes.get(name, (None, None))
+        if argtypes is not None:
+            cfn.argtypes = argtypes
+        if restype is None:
+            cfn.restype = C.c_int
+            check = self._check
+
+            def wrapped(*args, _cfn=cfn, _name=name):
+                rc = _cfn(*args)
+                if rc != 0:
+                    check(rc, _name)
+                return rc
+
+            fn = wrapped
+        else:
+            cfn.restype = restype
+            fn = cfn
+        self._cache[name] = fn
+        return fn
+
+    def raw(self, name):
+        """The unchecked ctypes function (returns the error code instead of raising)."""
+        cfn = getattr(self._cdll, name)
+        restype, argtypes = self._prototypes.get(name, (None, None))
+        if argtypes is not None:
+            cfn.argtypes = argtypes
+        cfn.restype = C.c_int if restype is None else restype
+        return cfn
+
+
+_rmm_cdll = _load("librmm.so")
+_gdf_cdll = _load("libgdf.so")
+
+_gdf_cdll.gdf_error_get_name.restype = C.c_char_p
+_gdf_cdll.gdf_error_get_name.argtypes = [C.c_int]
+_gdf_cdll.gdf_cuda_error_name.restype = C.c_char_p
+_gdf_cdll.gdf_cuda_error_name.argtypes = [C.c_int]
+_gdf_cdll.gdf_cuda_error_string.restype = C.c_char_p
+_gdf_cdll.gdf_cuda_error_string.argtypes = [C.c_int]
+_rmm_cdll.rmmGetErrorString.restype = C.c_char_p
+_rmm_cdll.rmmGetErrorString.argtypes = [C.c_int]
+
+
+def _check_gdf(rc, fname):
+    name = _gdf_cdll.gdf_error_get_name(rc).decode()
+    if rc == GDF_CUDA_ERROR:
+        code = _gdf_cdll.gdf_cuda_last_error()
+        name = "CUDA ERROR. {}: {}".format(_gdf_cdll.gdf_cuda_error_name(code).decode(),
+                                           _gdf_cdll.gdf_cuda_error_string(code).decode())
+    raise GDFError(rc, name)
+
+
+def _check_rmm(rc, fname):
+    raise RMMError(rc, _rmm_cdll.rmmGetErrorString(rc).decode())
+
+
+libgdf = _Wrapper(_gdf_cdll, _PROTOTYPES, _check_gdf)
+librmm = _Wrapper(_rmm_cdll, _RMM_PROTOTYPES, _check_rmm)

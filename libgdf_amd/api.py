@@ -1,0 +1,152 @@
+"""Convenience calls over the C ABI for tests, the benchmark and the multi-GPU layer.
+
+Every function here is a few lines of argument marshalling around ONE ``gdf_*`` entry point of
+libgdf.so -- the computation happens in the HIP library, never in Python.  Join index columns are
+allocated by the library (reference ownership rule, join_compute_api.h:525-548); they are copied into
+torch tensors with a device-to-device hipMemcpy and released with ``gdf_column_free``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from ._binding import gdf_column, libgdf
+from .columns import (GDF_HASH, GDF_HASH_MURMUR3, GDF_TO_NP, Column, column_array, new_context)
+
+_hip = None
+
+
+def _hipMemcpyDtoD(dst_ptr: int, src_ptr: int, nbytes: int):
+    global _hip
+    if _hip is None:
+        _hip = C.CDLL("libamdhip64.so.7")     # already in the process (libgdf.so links it): same handle
+        _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        _hip.hipMemcpy.restype = C.c_int
+    rc = _hip.hipMemcpy(dst_ptr, src_ptr, nbytes, 3)   # hipMemcpyDeviceToDevice
+    if rc != 0:
+        raise RuntimeError(f"hipMemcpy failed with {rc}")
+
+
+def _take_library_column(col: gdf_column, torch_dtype):
+    """Copy a library-allocated column into a torch tensor and free the library's buffer."""
+    import torch
+    n = int(col.size)
+    out = torch.empty(n, dtype=torch_dtype, device="cuda")
+    if n:
+        _hipMemcpyDtoD(out.data_ptr(), col.data, n * out.element_size())
+    libgdf.gdf_column_free(C.byref(col))
+    return out
+
+
+def _int_array(values):
+    return (C.c_int * len(values))(*values)
+
+
+def join(left, right, left_on=None, right_on=None, how="inner", method=GDF_HASH):
+    """gdf_{inner,left,full}_join over lists of Column -> (left_idx, right_idx) int32 tensors."""
+    import torch
+    left_on = list(range(len(left))) if left_on is None else list(left_on)
+    right_on = list(range(len(right))) if right_on is None else list(right_on)
+    fn = {"inner": libgdf.gdf_inner_join, "left": libgdf.gdf_left_join, "full": libgdf.gdf_full_join}[how]
+    ctx = new_context(method=method)
+    li, ri = gdf_column(), gdf_column()
+    la, ra = column_array(left), column_array(right)
+    fn(la, len(left), _int_array(left_on), ra, len(right), _int_array(right_on), len(left_on), 0, None,
+       C.byref(li), C.byref(ri), C.byref(ctx))
+    return _take_library_column(li, torch.int32), _take_library_column(ri, torch.int32)
+
+
+_GROUPBY = {"sum": "gdf_group_by_sum", "min": "gdf_group_by_min", "max": "gdf_group_by_max",
+            "avg": "gdf_group_by_avg", "count": "gdf_group_by_count"}
+
+
+def group_by(op, keys, values, out_dtype: int | None = None, sort_result=False, method=GDF_HASH, capacity=None):
+    """gdf_group_by_<op> -> (list of key tensors, aggregate tensor), trimmed to the number of groups.
+
+    Outputs are preallocated by the caller with capacity N rows, as the reference's tests do
+    (tests/groupby/groupby-test.cu:127).
+    """
+    import torch
+    n = keys[0].size if capacity is None else capacity
+    torch_of = {1: torch.int8, 2: torch.int16, 3: torch.int32, 4: torch.int64, 5: torch.float32, 6: torch.float64,
+                7: torch.int32, 8: torch.int64, 9: torch.int64}
+    out_keys = [Column(torch.empty(max(n, 1), dtype=torch_of[k.c.dtype], device="cuda"), None, k.c.dtype, size=n) for k in keys]
+    if out_dtype is None:
+        out_dtype = values.c.dtype
+    out_agg = Column(torch.empty(max(n, 1), dtype=torch_of[out_dtype], device="cuda"), None, out_dtype, size=n)
+    ctx = new_context(method=method, flag_sort_result=1 if sort_result else 0)
+    ka, oa = column_array(keys), column_array(out_keys)
+    getattr(libgdf, _GROUPBY[op])(len(keys), ka, values.ptr, None, oa, out_agg.ptr, C.byref(ctx))
+    g = out_agg.size
+    return [k.data[:g] for k in out_keys], out_agg.data[:g]
+
+
+def hash_rows(cols, hash_func=GDF_HASH_MURMUR3):
+    import torch
+    n = cols[0].size
+    out = Column(torch.empty(max(n, 1), dtype=torch.int32, device="cuda"), None, 3, size=n)
+    libgdf.gdf_hash(len(cols), column_array(cols), hash_func, out.ptr)
+    return out.data[:n]
+
+
+def hash_partition(cols, cols_to_hash, num_partitions, hash_func=GDF_HASH_MURMUR3, with_masks=False):
+    """gdf_hash_partition -> (list of output Columns, offsets list)."""
+    import torch
+    n = cols[0].size
+    outs = []
+    for c in cols:
+        data = torch.empty_like(c.data)
+        valid = torch.zeros_like(c.valid) if (with_masks and c.valid is not None) else None
+        outs.append(Column(data, valid, c.c.dtype, size=n))
+    offsets = (C.c_int * num_partitions)()
+    libgdf.gdf_hash_partition(len(cols), column_array(cols), _int_array(cols_to_hash), len(cols_to_hash),
+                              num_partitions, column_array(outs), offsets, hash_func)
+    return outs, list(offsets)
+
+
+def prefixsum(col: Column, inclusive=True):
+    import torch
+    out = Column(torch.empty_like(col.data), None, col.c.dtype, size=col.size)
+    libgdf.gdf_prefixsum_generic(col.ptr, out.ptr, 1 if inclusive else 0)
+    return out.data
+
+
+def comparison(lhs: Column, rhs, op: int):
+    """gpu_comparison (column rhs) or gpu_comparison_static_* (python scalar tagged with a numpy dtype)."""
+    import torch
+    n = lhs.size
+    out = Column(torch.empty(max(n, 1), dtype=torch.int8, device="cuda"),
+                 torch.zeros(((n + 7) // 8 + 63) // 64 * 64 or 64, dtype=torch.uint8, device="cuda"), 1, size=n)
+    if isinstance(rhs, Column):
+        libgdf.gpu_comparison(lhs.ptr, rhs.ptr, out.ptr, op)
+    else:
+        suffix = {np.dtype(np.int8): "i8", np.dtype(np.int16): "i16", np.dtype(np.int32): "i32",
+                  np.dtype(np.int64): "i64", np.dtype(np.float32): "f32", np.dtype(np.float64): "f64"}[np.asarray(rhs).dtype]
+        getattr(libgdf, "gpu_comparison_static_" + suffix)(lhs.ptr, np.asarray(rhs).item(), out.ptr, op)
+    return out
+
+
+def apply_stencil(lhs: Column, stencil: Column):
+    import torch
+    n = lhs.size
+    out = Column(torch.empty_like(lhs.data), torch.zeros(((n + 7) // 8 + 63) // 64 * 64 or 64, dtype=torch.uint8, device="cuda"),
+                 lhs.c.dtype, size=n)
+    libgdf.gpu_apply_stencil(lhs.ptr, stencil.ptr, out.ptr)
+    return out
+
+
+def filter_rows(cols, values):
+    """gdf_filter: indices (int64 tensor) of the rows whose every column equals the matching scalar."""
+    import torch
+    n, k = cols[0].size, len(cols)
+    col_structs = (gdf_column * k)(*[c.c for c in cols])
+    d_cols = torch.zeros(k, dtype=torch.int64, device="cuda")
+    d_types = torch.zeros(k, dtype=torch.int32, device="cuda")
+    val_bufs = [torch.from_numpy(np.asarray([v], dtype=GDF_TO_NP[c.c.dtype])).cuda() for c, v in zip(cols, values)]
+    d_vals = torch.tensor([b.data_ptr() for b in val_bufs], dtype=torch.int64, device="cuda")
+    d_indx = torch.empty(max(n, 1), dtype=torch.int64, device="cuda")
+    new_sz = C.c_size_t(0)
+    libgdf.gdf_filter(n, col_structs, k, d_cols.data_ptr(), d_types.data_ptr(), d_vals.data_ptr(), d_indx.data_ptr(),
+                      C.byref(new_sz))
+    return d_indx[: new_sz.value]

@@ -1,0 +1,187 @@
+// common.h -- internal helpers shared by the host dispatch code and the CDNA4 kernels.
+//
+// Nothing in here is part of the ABI.  Kernels are written for gfx950 only:
+// 64-wide wavefronts (ballots are 64-bit), 160 KiB LDS per CU, 256 CUs in 8 XCDs.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <limits.h>
+#include <new>
+
+#include "gdf/gdf.h"
+#include "memory.h"
+
+// ---------------------------------------------------------------------------
+// error plumbing (same contract as the reference's errorutils.h:8-30:
+// a failed runtime call -> GDF_CUDA_ERROR, a failed allocation ->
+// GDF_MEMORYMANAGER_ERROR; no exception ever crosses the C boundary)
+// ---------------------------------------------------------------------------
+#define HIP_TRY(call)                                                        \
+  do {                                                                       \
+    hipError_t _e = (call);                                                  \
+    if (_e != hipSuccess) { gdf_amd::note_hip_error(_e, #call, __FILE__, __LINE__); return GDF_CUDA_ERROR; } \
+  } while (0)
+#define RMM_TRY(call)   do { if ((call) != RMM_SUCCESS) return GDF_MEMORYMANAGER_ERROR; } while (0)
+#define GDF_TRY(call)   do { gdf_error _g = (call); if (_g != GDF_SUCCESS) return _g; } while (0)
+#define GDF_REQUIRE(cond, err) do { if (!(cond)) return (err); } while (0)
+#define HIP_CHECK_LAST() HIP_TRY(hipGetLastError())
+
+namespace gdf_amd {
+
+void note_hip_error(hipError_t e, const char *what, const char *file, int line);
+
+constexpr int WAVE = 64;          // gfx950 wavefront width
+constexpr int NUM_CU = 256;       // MI355X
+constexpr int MAX_KEY_COLS = 16;  // key columns per relational call (reference tests use <= 5)
+
+// all library work runs on the legacy default stream, like the reference
+// (SURVEY.md 8b "Threading / streams").
+static inline hipStream_t stream0() { return (hipStream_t)0; }
+
+// ---- device scratch RAII over librmm ---------------------------------------
+struct DevBuf {
+  void *p = nullptr;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() { reset(); }
+  rmmError_t alloc(size_t bytes) { reset(); return rmmAlloc(&p, bytes ? bytes : 1, (cudaStream_t)0); }
+  void reset() { if (p) { rmmFree(p, (cudaStream_t)0); p = nullptr; } }
+  void *release() { void *q = p; p = nullptr; return q; }
+  template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+// ---- dtype helpers ----------------------------------------------------------
+// Storage class of a column element: what the bytes are, ignoring date/time tags
+// (gdf_table.cuh:704-854 maps DATE32->int32, DATE64/TIMESTAMP->int64 the same way).
+enum ElemKind : int { K_I8 = 0, K_I16, K_I32, K_I64, K_F32, K_F64, K_BAD };
+
+static inline ElemKind elem_kind(gdf_dtype t) {
+  switch (t) {
+    case GDF_INT8: return K_I8;
+    case GDF_INT16: return K_I16;
+    case GDF_INT32: case GDF_DATE32: return K_I32;
+    case GDF_INT64: case GDF_DATE64: case GDF_TIMESTAMP: return K_I64;
+    case GDF_FLOAT32: return K_F32;
+    case GDF_FLOAT64: return K_F64;
+    default: return K_BAD;
+  }
+}
+static inline int kind_width(ElemKind k) {
+  switch (k) { case K_I8: return 1; case K_I16: return 2; case K_I32: case K_F32: return 4;
+               case K_I64: case K_F64: return 8; default: return -1; }
+}
+static inline int dtype_width(gdf_dtype t) { return kind_width(elem_kind(t)); }
+
+static inline size_t mask_bytes(size_t rows) { return (rows + 7) / 8; }
+
+// POD view of the key columns of one table, passed to kernels BY VALUE (the
+// reference passed host-constructed C++ objects through unified memory,
+// gdf_table.cuh:242; we never do that).
+struct ColView {
+  const void    *data;
+  const uint8_t *valid;   // may be null
+  int            kind;    // ElemKind
+  int            width;   // bytes
+};
+struct KeyTable {
+  int     ncols;
+  int     any_valid;      // 1 if some column carries a mask
+  int64_t nrows;
+  ColView col[MAX_KEY_COLS];
+};
+
+gdf_error make_key_table(gdf_column **cols, int ncols, KeyTable *out);
+
+// grid sizing for streaming kernels: enough blocks to fill 256 CUs several
+// times over, capped so per-block partial state stays small.
+static inline int stream_grid(size_t items, int per_block, int max_blocks = NUM_CU * 8) {
+  size_t b = (items + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > (size_t)max_blocks) b = max_blocks;
+  return (int)b;
+}
+
+#ifdef __HIPCC__
+// ---------------------------------------------------------------------------
+// wave64 primitives
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return __lane_id(); }
+
+// number of set bits of `m` strictly below this lane
+__device__ __forceinline__ int mask_rank(unsigned long long m) {
+  return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+}
+
+template <class T>
+__device__ __forceinline__ T wave_reduce_add(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+  return v;
+}
+
+// inclusive scan across the 64 lanes of a wave
+template <class T>
+__device__ __forceinline__ T wave_scan_incl(T v) {
+  const int l = lane_id();
+#pragma unroll
+  for (int o = 1; o < WAVE; o <<= 1) {
+    T n = __shfl_up(v, o, WAVE);
+    if (l >= o) v += n;
+  }
+  return v;
+}
+
+__device__ __forceinline__ bool bit_is_set(const uint8_t *mask, int64_t i) {
+  return (mask[i >> 3] >> (i & 7)) & 1;   // LSB-first, include/gdf/utils.h:9-16
+}
+
+// row validity = AND over the key columns' masks (gdf_table.cuh:62-98), computed
+// inline instead of materialising a row mask per call.
+__device__ __forceinline__ bool row_valid(const KeyTable &t, int64_t i) {
+  if (!t.any_valid) return true;
+  bool ok = true;
+  for (int c = 0; c < t.ncols; ++c)
+    if (t.col[c].valid) ok = ok && bit_is_set(t.col[c].valid, i);
+  return ok;
+}
+
+// raw element bits zero-extended to 64 (exact for equality on integer kinds)
+__device__ __forceinline__ uint64_t load_bits(const ColView &c, int64_t i) {
+  switch (c.width) {
+    case 1: return ((const uint8_t *)c.data)[i];
+    case 2: return ((const uint16_t *)c.data)[i];
+    case 4: return ((const uint32_t *)c.data)[i];
+    default: return ((const uint64_t *)c.data)[i];
+  }
+}
+
+// typed equality of one element pair; floats compare with ==, so NaN never
+// equals anything and -0.0 == +0.0 (gdf_table.cuh:580-691 rows_equal).
+__device__ __forceinline__ bool elem_equal(const ColView &a, int64_t i, const ColView &b, int64_t j) {
+  switch (a.kind) {
+    case K_F32: return ((const float *)a.data)[i] == ((const float *)b.data)[j];
+    case K_F64: return ((const double *)a.data)[i] == ((const double *)b.data)[j];
+    default: return load_bits(a, i) == load_bits(b, j);
+  }
+}
+__device__ __forceinline__ bool rows_equal(const KeyTable &a, int64_t i, const KeyTable &b, int64_t j) {
+  for (int c = 0; c < a.ncols; ++c)
+    if (!elem_equal(a.col[c], i, b.col[c], j)) return false;
+  return true;
+}
+
+// 64-bit finaliser (bijective xorshift-multiply mix) used for INTERNAL partition
+// ids and LDS slot numbers.  Not visible through the ABI: the public hash is
+// Murmur3_32 in hash.cuh.
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdULL;
+  x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL;
+  x ^= x >> 33;
+  return x;
+}
+#endif  // __HIPCC__
+
+}  // namespace gdf_amd

@@ -1,0 +1,622 @@
+// groupby.hip -- gdf_group_by_{sum,min,max,avg,count}, HASH method.
+//
+// Reference path being replaced: src/sqls_ops.cu:1085-1363 ->
+// groupby/groupby.cuh:86-419 -> groupby/hash/groupby_compute_api.h:140-225 with the
+// kernels of groupby_kernels.cuh:42-160 over concurrent_unordered_map.cuh (a
+// 2*N-slot global table keyed by ROW INDEX: every row pays a CAS on a hot slot
+// plus a rows_equal gather of the group's first row, and init + extract sweep
+// 2*N slots).  Here:
+//
+//   gb_aggregate  every workgroup pre-aggregates its rows in an LDS
+//                 open-addressing table keyed by the packed 64-bit key
+//                 (ds_cmpst_b64 claim, ds_add/min/max on the accumulator), so hot
+//                 keys never leave the CU; LDS entries are merged into a global
+//                 table sized to the number of GROUPS, not rows, when the
+//                 workgroup finishes.  Keys that do not fit 64 bits (or float
+//                 keys, which must compare with ==) use a global table keyed by
+//                 first-row index like the reference, without the LDS stage.
+//   gb_extract    wave-ballot compaction of the occupied slots into the caller's
+//                 preallocated outputs, finishing AVG = SUM / COUNT in the same pass.
+//   gb_sort_*     optional lexicographic sort of the result rows
+//                 (flag_sort_result, and always for AVG as in groupby.cuh:345-386).
+//
+// Semantics kept: aggregation in the INPUT dtype with wrap-around for integers
+// (aggregation_operations.cuh:30-86), COUNT in the OUTPUT column's dtype
+// (groupby.cuh:102-109), AVG = sum_in_input_dtype / (avg_type)count with avg_type =
+// output dtype (groupby.cuh:308-328), any valid mask -> GDF_VALIDITY_UNSUPPORTED
+// (sqls_ops.cu:1103-1106), empty input -> all output sizes 0, out_col_indices ignored.
+#include "internal.h"
+
+#include <vector>
+
+namespace gdf_amd {
+
+constexpr int GB_THREADS = 512;
+constexpr uint32_t GB_LDS_SLOTS = 4096;            // keys 32 KiB + acc 32 KiB (+ cnt 32 KiB for AVG)
+constexpr uint32_t GB_LDS_LIMIT = GB_LDS_SLOTS * 3 / 4;
+constexpr uint64_t GB_EMPTY_KEY = 0x8000000000000000ULL;   // reserved packed key; a real key with these bits uses slot T
+constexpr int32_t GB_EMPTY_ROW = -1;
+
+enum GbOp : int { OP_SUM = 0, OP_MIN, OP_MAX, OP_AVG, OP_COUNT };
+
+struct GbKeyPlan {
+  int packed;                  // 1: exact 64-bit packed key, 0: first-row table + rows_equal
+  int shift[MAX_KEY_COLS];
+};
+
+static GbKeyPlan gb_plan_keys(const KeyTable &t) {
+  GbKeyPlan p{};
+  int total = 0;
+  bool all_int = true;
+  for (int c = 0; c < t.ncols; ++c) {
+    if (t.col[c].kind == K_F32 || t.col[c].kind == K_F64) all_int = false;
+    p.shift[c] = total * 8;
+    total += t.col[c].width;
+  }
+  p.packed = (all_int && total <= 8) ? 1 : 0;
+  return p;
+}
+
+__device__ __forceinline__ uint64_t gb_pack(const KeyTable &t, const GbKeyPlan &p, int64_t i) {
+  uint64_t k = 0;
+  for (int c = 0; c < t.ncols; ++c) k |= load_bits(t.col[c], i) << p.shift[c];
+  return k;
+}
+
+// hash of a row for the first-row table: equal rows (under ==) must hash equally, so
+// -0.0 is folded onto +0.0; NaN rows hash by bit pattern and never compare equal.
+__device__ __forceinline__ uint64_t gb_hash_row(const KeyTable &t, int64_t i) {
+  uint64_t h = 0x9e3779b97f4a7c15ULL;
+  for (int c = 0; c < t.ncols; ++c) {
+    uint64_t b = load_bits(t.col[c], i);
+    if (t.col[c].kind == K_F32 && (uint32_t)(b << 1) == 0) b = 0;
+    if (t.col[c].kind == K_F64 && (b << 1) == 0) b = 0;
+    h = mix64(h ^ b) + 0x9e3779b97f4a7c15ULL * (uint64_t)(c + 1);
+  }
+  return h;
+}
+
+// ---- 64-bit accumulator encoding ---------------------------------------------
+// SUM/AVG: integers as wrapped uint64, floats as double.  MIN/MAX: order-preserving
+// unsigned image so one unsigned atomic serves every dtype.  COUNT: uint64.
+__device__ __forceinline__ uint64_t ord_i64(int64_t v) { return (uint64_t)v ^ 0x8000000000000000ULL; }
+__device__ __forceinline__ uint64_t ord_f64(double d) {
+  const uint64_t b = (uint64_t)__double_as_longlong(d);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
+}
+__device__ __forceinline__ double unord_f64(uint64_t u) {
+  const uint64_t b = (u >> 63) ? (u & 0x7fffffffffffffffULL) : ~u;
+  return __longlong_as_double((long long)b);
+}
+
+struct GbVal { const void *data; int kind; };
+
+__device__ __forceinline__ int64_t load_int(const GbVal &v, int64_t i) {
+  switch (v.kind) {
+    case K_I8: return ((const int8_t *)v.data)[i];
+    case K_I16: return ((const int16_t *)v.data)[i];
+    case K_I32: return ((const int32_t *)v.data)[i];
+    default: return ((const int64_t *)v.data)[i];
+  }
+}
+__device__ __forceinline__ double load_flt(const GbVal &v, int64_t i) {
+  return v.kind == K_F32 ? (double)((const float *)v.data)[i] : ((const double *)v.data)[i];
+}
+__device__ __forceinline__ bool is_flt(int kind) { return kind == K_F32 || kind == K_F64; }
+
+__device__ __forceinline__ uint64_t acc_identity(int op) { return op == OP_MIN ? ~0ULL : 0ULL; }
+
+// image of row i's value that is folded into the accumulator
+__device__ __forceinline__ uint64_t acc_image(int op, const GbVal &v, int64_t i) {
+  switch (op) {
+    case OP_COUNT: return 1;
+    case OP_MIN: case OP_MAX: return is_flt(v.kind) ? ord_f64(load_flt(v, i)) : ord_i64(load_int(v, i));
+    default: return is_flt(v.kind) ? (uint64_t)__double_as_longlong(load_flt(v, i)) : (uint64_t)load_int(v, i);
+  }
+}
+
+// fold `img` into *acc (LDS or global; the compiler picks ds_ / global_ atomics)
+__device__ __forceinline__ void acc_fold(int op, bool flt, unsigned long long *acc, uint64_t img) {
+  switch (op) {
+    case OP_MIN: atomicMin(acc, (unsigned long long)img); break;
+    case OP_MAX: atomicMax(acc, (unsigned long long)img); break;
+    case OP_COUNT: atomicAdd(acc, (unsigned long long)img); break;
+    default:
+      if (flt) atomicAdd((double *)acc, __longlong_as_double((long long)img));
+      else atomicAdd(acc, (unsigned long long)img);
+  }
+}
+// merging two partial accumulators uses the same fold (sum of sums, min of mins, ...)
+
+struct GbTable {            // global table; slot T is reserved for the key GB_EMPTY_KEY (packed mode)
+  uint32_t T;               // power of two
+  unsigned long long *keys; // packed mode
+  int32_t *first;           // first-row mode
+  unsigned long long *acc;
+  unsigned long long *cnt;  // AVG only
+  unsigned int *occupied;   // number of claimed slots
+  unsigned int *overflow;   // set when the table passes its fill limit
+  unsigned int *special;    // set when some row carries the reserved key (slot T is live)
+  uint32_t limit;
+};
+
+// returns slot index, or 0xffffffff on overflow
+__device__ __forceinline__ uint32_t gtable_find_packed(const GbTable &g, uint64_t key) {
+  if (key == GB_EMPTY_KEY) { *g.special = 1u; return g.T; }
+  uint32_t slot = (uint32_t)(mix64(key) >> 32) & (g.T - 1);
+  for (uint32_t probes = 0; probes < g.T; ++probes) {
+    unsigned long long cur = g.keys[slot];
+    if (cur == key) return slot;
+    if (cur == GB_EMPTY_KEY) {
+      const unsigned long long old = atomicCAS(&g.keys[slot], (unsigned long long)GB_EMPTY_KEY, (unsigned long long)key);
+      if (old == GB_EMPTY_KEY) {
+        if (atomicAdd(g.occupied, 1u) >= g.limit) atomicExch(g.overflow, 1u);
+        return slot;
+      }
+      if (old == key) return slot;
+    }
+    slot = (slot + 1) & (g.T - 1);
+  }
+  return 0xffffffffu;
+}
+
+__device__ __forceinline__ uint32_t gtable_find_rows(const GbTable &g, const KeyTable &t, int64_t row) {
+  uint32_t slot = (uint32_t)(gb_hash_row(t, row) >> 32) & (g.T - 1);
+  for (uint32_t probes = 0; probes < g.T; ++probes) {
+    int32_t cur = g.first[slot];
+    if (cur == GB_EMPTY_ROW) {
+      const int32_t old = atomicCAS(&g.first[slot], GB_EMPTY_ROW, (int32_t)row);
+      if (old == GB_EMPTY_ROW) {
+        if (atomicAdd(g.occupied, 1u) >= g.limit) atomicExch(g.overflow, 1u);
+        return slot;
+      }
+      cur = old;
+    }
+    if (rows_equal(t, row, t, cur)) return slot;
+    slot = (slot + 1) & (g.T - 1);
+  }
+  return 0xffffffffu;
+}
+
+__global__ __launch_bounds__(256) void gb_init_table(GbTable g, int op, int packed) {
+  const uint32_t n = g.T + 1;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    if (packed) g.keys[i] = GB_EMPTY_KEY; else g.first[i] = GB_EMPTY_ROW;
+    g.acc[i] = acc_identity(op);
+    if (g.cnt) g.cnt[i] = 0;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// aggregation
+// ---------------------------------------------------------------------------
+template <bool PACKED>
+__global__ __launch_bounds__(GB_THREADS) void gb_aggregate(KeyTable t, GbKeyPlan plan, GbVal val, int op, GbTable g,
+                                                           int64_t chunk) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gb_lds[];
+  unsigned long long *lkey = (unsigned long long *)gb_lds;
+  unsigned long long *lacc = lkey + GB_LDS_SLOTS;
+  unsigned long long *lcnt = lacc + GB_LDS_SLOTS;            // AVG only
+  unsigned int *lfill = (unsigned int *)(lcnt + (op == OP_AVG ? GB_LDS_SLOTS : 0));
+  const bool flt = is_flt(val.kind);
+  const bool avg = op == OP_AVG;
+  const int fold_op = avg ? OP_SUM : op;
+
+  if (PACKED) {
+    for (uint32_t i = threadIdx.x; i < GB_LDS_SLOTS; i += GB_THREADS) {
+      lkey[i] = GB_EMPTY_KEY;
+      lacc[i] = acc_identity(op);
+      if (avg) lcnt[i] = 0;
+    }
+    if (threadIdx.x == 0) *lfill = 0;
+    __syncthreads();
+  }
+
+  const int64_t begin = (int64_t)blockIdx.x * chunk;
+  const int64_t end = begin + chunk < t.nrows ? begin + chunk : t.nrows;
+  for (int64_t i = begin + threadIdx.x; i < end; i += GB_THREADS) {
+    if (*(volatile unsigned int *)g.overflow) break;     // another workgroup filled the table: the host retries larger
+    const uint64_t img = acc_image(fold_op, val, i);
+    if (PACKED) {
+      const uint64_t key = gb_pack(t, plan, i);
+      bool done = false;
+      if (key != GB_EMPTY_KEY) {
+        uint32_t slot = (uint32_t)mix64(key) & (GB_LDS_SLOTS - 1);
+        for (int probes = 0; probes < 32; ++probes) {
+          unsigned long long cur = lkey[slot];
+          if (cur == GB_EMPTY_KEY) {
+            if (*(volatile unsigned int *)lfill >= GB_LDS_LIMIT) break;      // LDS table full: new keys go to HBM
+            const unsigned long long old = atomicCAS(&lkey[slot], (unsigned long long)GB_EMPTY_KEY, (unsigned long long)key);
+            if (old == GB_EMPTY_KEY) { atomicAdd(lfill, 1u); cur = key; } else cur = old;
+          }
+          if (cur == key) {
+            acc_fold(fold_op, flt, &lacc[slot], img);
+            if (avg) atomicAdd(&lcnt[slot], 1ULL);
+            done = true;
+            break;
+          }
+          slot = (slot + 1) & (GB_LDS_SLOTS - 1);
+        }
+      }
+      if (!done) {
+        const uint32_t s = gtable_find_packed(g, key);
+        if (s == 0xffffffffu) { atomicExch(g.overflow, 1u); break; }
+        acc_fold(fold_op, flt, &g.acc[s], img);
+        if (avg) atomicAdd(&g.cnt[s], 1ULL);
+      }
+    } else {
+      const uint32_t s = gtable_find_rows(g, t, i);
+      if (s == 0xffffffffu) { atomicExch(g.overflow, 1u); break; }
+      acc_fold(fold_op, flt, &g.acc[s], img);
+      if (avg) atomicAdd(&g.cnt[s], 1ULL);
+    }
+  }
+
+  if (PACKED) {
+    __syncthreads();
+    // merge this workgroup's partial aggregates into the global table
+    for (uint32_t i = threadIdx.x; i < GB_LDS_SLOTS; i += GB_THREADS) {
+      const uint64_t key = lkey[i];
+      if (key == GB_EMPTY_KEY) continue;
+      const uint32_t s = gtable_find_packed(g, key);
+      if (s == 0xffffffffu) { atomicExch(g.overflow, 1u); continue; }
+      acc_fold(fold_op, flt, &g.acc[s], lacc[i]);
+      if (avg) atomicAdd(&g.cnt[s], lcnt[i]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// extraction
+// ---------------------------------------------------------------------------
+struct GbOut {
+  int ncols;
+  void *key_out[MAX_KEY_COLS];
+  void *agg_out;
+  int agg_kind;      // kind the aggregate is WRITTEN as
+  int in_kind;       // kind of the input values (decides the accumulator encoding)
+};
+
+__device__ __forceinline__ void store_int(void *out, int kind, int64_t pos, int64_t v) {
+  switch (kind) {
+    case K_I8: ((int8_t *)out)[pos] = (int8_t)v; break;
+    case K_I16: ((int16_t *)out)[pos] = (int16_t)v; break;
+    case K_I32: ((int32_t *)out)[pos] = (int32_t)v; break;
+    case K_I64: ((int64_t *)out)[pos] = v; break;
+    case K_F32: ((float *)out)[pos] = (float)v; break;
+    default: ((double *)out)[pos] = (double)v; break;
+  }
+}
+__device__ __forceinline__ void store_flt(void *out, int kind, int64_t pos, double v) {
+  switch (kind) {
+    case K_I8: ((int8_t *)out)[pos] = (int8_t)v; break;
+    case K_I16: ((int16_t *)out)[pos] = (int16_t)v; break;
+    case K_I32: ((int32_t *)out)[pos] = (int32_t)v; break;
+    case K_I64: ((int64_t *)out)[pos] = (int64_t)v; break;
+    case K_F32: ((float *)out)[pos] = (float)v; break;
+    default: ((double *)out)[pos] = v; break;
+  }
+}
+// wrap a 64-bit integer sum to the width of `kind` (sum_op adds in the input dtype)
+__device__ __forceinline__ int64_t wrap_int(int kind, uint64_t v) {
+  switch (kind) {
+    case K_I8: return (int8_t)v;
+    case K_I16: return (int16_t)v;
+    case K_I32: return (int32_t)v;
+    default: return (int64_t)v;
+  }
+}
+// (avg_type)count, then the division in the usual-arithmetic-conversion type of
+// (sum_type, avg_type), then the cast to avg_type: groupby.cuh:308-328.
+__device__ __forceinline__ void store_avg(const GbOut &o, int64_t pos, uint64_t acc, uint64_t count) {
+  const int sk = o.in_kind, ak = o.agg_kind;
+  if (!is_flt(sk) && !is_flt(ak)) {
+    const int64_t s = wrap_int(sk, acc);
+    const int64_t c = wrap_int(ak, count);            // static_cast<avg_type>(count)
+    // both operands promote to int (narrow types) or to the wider of the two: an int64 divide covers every case
+    store_int(o.agg_out, ak, pos, c == 0 ? 0 : s / c);
+    return;
+  }
+  if (is_flt(sk)) {
+    double s = __longlong_as_double((long long)acc);
+    if (sk == K_F32) s = (double)(float)s;             // the sum lives in a float column
+    if (is_flt(ak)) {
+      const double c = ak == K_F32 ? (double)(float)count : (double)count;
+      const bool in_float = (sk == K_F32 && ak == K_F32);
+      store_flt(o.agg_out, ak, pos, in_float ? (double)((float)s / (float)c) : s / c);
+    } else {
+      const int64_t c = wrap_int(ak, count);
+      // float / integer -> computed in the float type of the sum
+      const double q = sk == K_F32 ? (double)((float)s / (float)c) : s / (double)c;
+      store_flt(o.agg_out, ak, pos, q);
+    }
+    return;
+  }
+  // integer sum, float avg_type: computed in avg_type
+  const int64_t s = wrap_int(sk, acc);
+  if (ak == K_F32) store_flt(o.agg_out, ak, pos, (double)((float)s / (float)count));
+  else store_flt(o.agg_out, ak, pos, (double)s / (double)count);
+}
+
+__device__ __forceinline__ void store_result(const GbOut &o, int op, int64_t pos, uint64_t acc, uint64_t cnt) {
+  switch (op) {
+    case OP_COUNT: store_int(o.agg_out, o.agg_kind, pos, (int64_t)acc); break;   // count_op<out dtype>
+    case OP_AVG: store_avg(o, pos, acc, cnt); break;
+    case OP_SUM:
+      if (is_flt(o.in_kind)) store_flt(o.agg_out, o.in_kind, pos, __longlong_as_double((long long)acc));
+      else store_int(o.agg_out, o.in_kind, pos, wrap_int(o.in_kind, acc));
+      break;
+    default:   // MIN / MAX
+      if (is_flt(o.in_kind)) store_flt(o.agg_out, o.in_kind, pos, unord_f64(acc));
+      else store_int(o.agg_out, o.in_kind, pos, (int64_t)(acc ^ 0x8000000000000000ULL));
+  }
+}
+
+template <bool PACKED>
+__global__ __launch_bounds__(256) void gb_extract(KeyTable t, GbKeyPlan plan, GbTable g, GbOut o, int op,
+                                                  unsigned int special_used, unsigned long long *out_count) {
+  const uint32_t n = g.T + 1;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  const uint32_t rounds = (n + stride - 1) / stride;
+  for (uint32_t rnd = 0; rnd < rounds; ++rnd) {
+    const uint32_t i = rnd * stride + blockIdx.x * blockDim.x + threadIdx.x;
+    bool live = false;
+    uint64_t key = 0;
+    int32_t row = 0;
+    if (i < n) {
+      if (PACKED) {
+        if (i == g.T) { live = special_used != 0; key = GB_EMPTY_KEY; }
+        else { key = g.keys[i]; live = key != GB_EMPTY_KEY; }
+      } else if (i < g.T) {
+        row = g.first[i];
+        live = row != GB_EMPTY_ROW;
+      }
+    }
+    const unsigned long long m = __ballot(live);
+    unsigned long long base = 0;
+    if (lane_id() == 0 && m) base = atomicAdd(out_count, (unsigned long long)__popcll(m));
+    base = __shfl(base, 0, WAVE);
+    if (live) {
+      const int64_t pos = (int64_t)(base + mask_rank(m));
+      for (int c = 0; c < t.ncols; ++c) {
+        uint64_t bits = PACKED ? (key >> plan.shift[c]) : load_bits(t.col[c], row);
+        switch (t.col[c].width) {
+          case 1: ((uint8_t *)o.key_out[c])[pos] = (uint8_t)bits; break;
+          case 2: ((uint16_t *)o.key_out[c])[pos] = (uint16_t)bits; break;
+          case 4: ((uint32_t *)o.key_out[c])[pos] = (uint32_t)bits; break;
+          default: ((uint64_t *)o.key_out[c])[pos] = bits; break;
+        }
+      }
+      store_result(o, op, pos, g.acc[i], g.cnt ? g.cnt[i] : 0);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// result sort: bitonic network over a row permutation, comparing the OUTPUT key
+// columns lexicographically with typed < (LesserRTTI, sqls_rtti_comp.hpp:33-279).
+// Result sets are small next to the input (one row per group).
+// ---------------------------------------------------------------------------
+struct SortCols { int ncols; const void *data[MAX_KEY_COLS]; int kind[MAX_KEY_COLS]; };
+
+__device__ __forceinline__ int cmp_rows(const SortCols &s, uint32_t a, uint32_t b) {
+  for (int c = 0; c < s.ncols; ++c) {
+    switch (s.kind[c]) {
+      case K_F32: { float x = ((const float *)s.data[c])[a], y = ((const float *)s.data[c])[b]; if (x < y) return -1; if (y < x) return 1; break; }
+      case K_F64: { double x = ((const double *)s.data[c])[a], y = ((const double *)s.data[c])[b]; if (x < y) return -1; if (y < x) return 1; break; }
+      case K_I8: { int x = ((const int8_t *)s.data[c])[a], y = ((const int8_t *)s.data[c])[b]; if (x < y) return -1; if (y < x) return 1; break; }
+      case K_I16: { int x = ((const int16_t *)s.data[c])[a], y = ((const int16_t *)s.data[c])[b]; if (x < y) return -1; if (y < x) return 1; break; }
+      case K_I32: { int x = ((const int32_t *)s.data[c])[a], y = ((const int32_t *)s.data[c])[b]; if (x < y) return -1; if (y < x) return 1; break; }
+      default: { int64_t x = ((const int64_t *)s.data[c])[a], y = ((const int64_t *)s.data[c])[b]; if (x < y) return -1; if (y < x) return 1; break; }
+    }
+  }
+  return 0;
+}
+
+__global__ void gb_sort_iota(uint32_t *perm, uint32_t npad) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npad; i += gridDim.x * blockDim.x) perm[i] = i;
+}
+// indices >= n are padding and sort last
+__global__ void gb_sort_step(uint32_t *perm, uint32_t npad, uint32_t n, uint32_t j, uint32_t k, SortCols s) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npad; i += gridDim.x * blockDim.x) {
+    const uint32_t l = i ^ j;
+    if (l <= i) continue;
+    const uint32_t a = perm[i], b = perm[l];
+    int c;
+    if (a >= n || b >= n) c = (a >= n) ? ((b >= n) ? 0 : 1) : -1;
+    else { c = cmp_rows(s, a, b); if (c == 0) c = a < b ? -1 : (a > b ? 1 : 0); }
+    const bool ascending = (i & k) == 0;
+    if ((ascending && c > 0) || (!ascending && c < 0)) { perm[i] = b; perm[l] = a; }
+  }
+}
+__global__ void gb_sort_gather(const uint32_t *perm, uint32_t n, int width, const void *in, void *out) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint32_t s = perm[i];
+    switch (width) {
+      case 1: ((uint8_t *)out)[i] = ((const uint8_t *)in)[s]; break;
+      case 2: ((uint16_t *)out)[i] = ((const uint16_t *)in)[s]; break;
+      case 4: ((uint32_t *)out)[i] = ((const uint32_t *)in)[s]; break;
+      default: ((uint64_t *)out)[i] = ((const uint64_t *)in)[s]; break;
+    }
+  }
+}
+
+static gdf_error sort_result_rows(int ncols, gdf_column **key_cols, const int *key_kind, void *agg, int agg_width, uint32_t n) {
+  if (n < 2) return GDF_SUCCESS;
+  uint32_t npad = 1;
+  while (npad < n) npad <<= 1;
+  DevBuf perm, tmp;
+  RMM_TRY(perm.alloc(sizeof(uint32_t) * npad));
+  RMM_TRY(tmp.alloc((size_t)8 * n));
+  SortCols s{};
+  s.ncols = ncols;
+  for (int c = 0; c < ncols; ++c) { s.data[c] = key_cols[c]->data; s.kind[c] = key_kind[c]; }
+  const int grid = stream_grid(npad, 256 * 4);
+  hipLaunchKernelGGL(gb_sort_iota, dim3(grid), dim3(256), 0, stream0(), perm.as<uint32_t>(), npad);
+  for (uint32_t k = 2; k <= npad; k <<= 1)
+    for (uint32_t j = k >> 1; j > 0; j >>= 1)
+      hipLaunchKernelGGL(gb_sort_step, dim3(grid), dim3(256), 0, stream0(), perm.as<uint32_t>(), npad, n, j, k, s);
+  HIP_CHECK_LAST();
+  auto permute = [&](void *data, int width) -> gdf_error {
+    hipLaunchKernelGGL(gb_sort_gather, dim3(grid), dim3(256), 0, stream0(), perm.as<uint32_t>(), n, width, data, tmp.p);
+    HIP_TRY(hipMemcpyAsync(data, tmp.p, (size_t)width * n, hipMemcpyDeviceToDevice, stream0()));
+    return GDF_SUCCESS;
+  };
+  for (int c = 0; c < ncols; ++c) GDF_TRY(permute(key_cols[c]->data, kind_width((ElemKind)key_kind[c])));
+  GDF_TRY(permute(agg, agg_width));
+  HIP_CHECK_LAST();
+  HIP_TRY(hipStreamSynchronize(stream0()));
+  return GDF_SUCCESS;
+}
+
+// ---------------------------------------------------------------------------
+// host driver
+// ---------------------------------------------------------------------------
+static gdf_error group_by_hash(int ncols, gdf_column **cols, gdf_column *col_agg, gdf_column **out_keys,
+                               gdf_column *out_agg, int op, bool sort_result) {
+  // groupby.cuh:218-238
+  if (0 == ncols || nullptr == cols || nullptr == col_agg) return GDF_DATASET_EMPTY;
+  if (nullptr == out_keys || nullptr == out_agg) return GDF_DATASET_EMPTY;
+  if (0 == cols[0]->size || 0 == col_agg->size) return GDF_SUCCESS;
+  KeyTable t;
+  GDF_TRY(make_key_table(cols, ncols, &t));
+  const int64_t n = t.nrows;
+  if (n >= (int64_t)INT_MAX) return GDF_COLUMN_SIZE_TOO_BIG;
+
+  // dtype dispatch (groupby.cuh:86-190): COUNT is typed by the OUTPUT column, the rest by the input
+  const ElemKind in_kind = elem_kind(col_agg->dtype);
+  const ElemKind out_kind = elem_kind(out_agg->dtype);
+  if (op == OP_COUNT) { if (out_kind == K_BAD) return GDF_UNSUPPORTED_DTYPE; }
+  else if (in_kind == K_BAD) return GDF_UNSUPPORTED_DTYPE;
+  if (op == OP_AVG && (out_kind == K_BAD || out_agg->dtype == GDF_DATE32 || out_agg->dtype == GDF_DATE64 ||
+                       out_agg->dtype == GDF_TIMESTAMP || col_agg->dtype == GDF_DATE32 ||
+                       col_agg->dtype == GDF_DATE64 || col_agg->dtype == GDF_TIMESTAMP))
+    return GDF_UNSUPPORTED_DTYPE;   // groupby.cuh:376-385,409-418 list only the six numeric types
+  for (int c = 0; c < ncols; ++c)
+    if (!out_keys[c] || !out_keys[c]->data) return GDF_DATASET_EMPTY;
+  if (!out_agg->data) return GDF_DATASET_EMPTY;
+
+  const GbKeyPlan plan = gb_plan_keys(t);
+  GbVal val{col_agg->data, (int)(op == OP_COUNT ? K_I8 : in_kind)};
+  const bool avg = op == OP_AVG;
+
+  // workgroup geometry: one contiguous chunk of rows per workgroup
+  const int grid = stream_grid((size_t)n, GB_THREADS * 32, NUM_CU * 4);
+  int64_t chunk = (n + grid - 1) / grid;
+  const size_t lds = plan.packed ? (size_t)GB_LDS_SLOTS * 8 * (avg ? 3 : 2) + 16 : 0;
+
+  // The table is sized by GROUPS.  Start small (the common case) and grow x16 on
+  // overflow, up to the 2*N slots the reference always allocates.
+  uint64_t cap_max = 1;
+  while (cap_max < 2 * (uint64_t)n) cap_max <<= 1;
+  uint64_t T = cap_max < (1u << 18) ? cap_max : (1u << 18);
+  for (;;) {
+    DevBuf keys, first, acc, cnt, flags, out_count;
+    if (plan.packed) RMM_TRY(keys.alloc(sizeof(uint64_t) * (T + 1))); else RMM_TRY(first.alloc(sizeof(int32_t) * (T + 1)));
+    RMM_TRY(acc.alloc(sizeof(uint64_t) * (T + 1)));
+    if (avg) RMM_TRY(cnt.alloc(sizeof(uint64_t) * (T + 1)));
+    RMM_TRY(flags.alloc(sizeof(unsigned int) * 4));
+    RMM_TRY(out_count.alloc(sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(flags.p, 0, sizeof(unsigned int) * 4, stream0()));
+    HIP_TRY(hipMemsetAsync(out_count.p, 0, sizeof(unsigned long long), stream0()));
+    GbTable g{};
+    g.T = (uint32_t)T;
+    g.keys = keys.as<unsigned long long>();
+    g.first = first.as<int32_t>();
+    g.acc = acc.as<unsigned long long>();
+    g.cnt = cnt.as<unsigned long long>();
+    g.occupied = flags.as<unsigned int>();
+    g.overflow = flags.as<unsigned int>() + 1;
+    g.special = flags.as<unsigned int>() + 2;
+    g.limit = T >= cap_max ? 0xffffffffu : (uint32_t)(T / 2);   // at 2*N slots the table can never fill
+    hipLaunchKernelGGL(gb_init_table, dim3(stream_grid(T + 1, 256 * 8)), dim3(256), 0, stream0(), g, avg ? OP_SUM : op, plan.packed);
+    if (plan.packed) {
+      HIP_TRY(hipFuncSetAttribute((const void *)gb_aggregate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(gb_aggregate<true>, dim3(grid), dim3(GB_THREADS), lds, stream0(), t, plan, val, op, g, chunk);
+    } else {
+      hipLaunchKernelGGL(gb_aggregate<false>, dim3(grid), dim3(GB_THREADS), 0, stream0(), t, plan, val, op, g, chunk);
+    }
+    HIP_CHECK_LAST();
+    unsigned int h_flags[3] = {0, 0, 0};
+    HIP_TRY(hipMemcpy(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost));
+    if (h_flags[1]) {                       // too many groups for this table
+      if (T >= cap_max) return GDF_HASH_TABLE_INSERT_FAILURE;
+      T = T * 16 < cap_max ? T * 16 : cap_max;
+      continue;
+    }
+    const unsigned int special_used = h_flags[2];   // slot T (reserved key) is live iff some row used it
+    GbOut o{};
+    o.ncols = ncols;
+    for (int c = 0; c < ncols; ++c) o.key_out[c] = out_keys[c]->data;
+    o.agg_out = out_agg->data;
+    o.in_kind = (int)in_kind;
+    o.agg_kind = (int)((op == OP_COUNT || op == OP_AVG) ? out_kind : in_kind);
+    const int egrid = stream_grid(T + 1, 256 * 4);
+    if (plan.packed)
+      hipLaunchKernelGGL(gb_extract<true>, dim3(egrid), dim3(256), 0, stream0(), t, plan, g, o, op, special_used, out_count.as<unsigned long long>());
+    else
+      hipLaunchKernelGGL(gb_extract<false>, dim3(egrid), dim3(256), 0, stream0(), t, plan, g, o, op, special_used, out_count.as<unsigned long long>());
+    HIP_CHECK_LAST();
+    unsigned long long ngroups = 0;
+    HIP_TRY(hipMemcpy(&ngroups, out_count.p, sizeof(ngroups), hipMemcpyDeviceToHost));
+    for (int c = 0; c < ncols; ++c) out_keys[c]->size = (gdf_size_type)ngroups;   // gdf_table.cuh:334-342
+    out_agg->size = (gdf_size_type)ngroups;
+    if (sort_result || avg) {
+      int kinds[MAX_KEY_COLS];
+      for (int c = 0; c < ncols; ++c) kinds[c] = t.col[c].kind;
+      GDF_TRY(sort_result_rows(ncols, out_keys, kinds, out_agg->data, kind_width((ElemKind)o.agg_kind), (uint32_t)ngroups));
+    }
+    return GDF_SUCCESS;
+  }
+}
+
+// sqls_ops.cu:1085-1363 gdf_group_by_single
+static gdf_error group_by_single(int ncols, gdf_column **cols, gdf_column *col_agg, gdf_column *out_col_indices,
+                                 gdf_column **out_col_values, gdf_column *out_col_agg, gdf_context *ctxt, int op) {
+  if (0 == ncols || nullptr == cols || nullptr == col_agg || nullptr == out_col_agg || nullptr == ctxt)
+    return GDF_DATASET_EMPTY;
+  for (int i = 0; i < ncols; ++i) GDF_REQUIRE(!cols[i]->valid, GDF_VALIDITY_UNSUPPORTED);
+  GDF_REQUIRE(!col_agg->valid, GDF_VALIDITY_UNSUPPORTED);
+  if (0 == cols[0]->size || 0 == col_agg->size) {
+    out_col_agg->size = 0;
+    if (out_col_indices) out_col_indices->size = 0;
+    if (out_col_values)
+      for (int c = 0; c < ncols; ++c)
+        if (out_col_values[c]) out_col_values[c]->size = 0;
+    return GDF_SUCCESS;
+  }
+  if (ctxt->flag_method == GDF_SORT) return GDF_UNSUPPORTED_METHOD;   // sort-based path: SURVEY.md 8f rank 2
+  if (ctxt->flag_method != GDF_HASH) return GDF_UNSUPPORTED_METHOD;
+  gdf_nvtx_range_push("LIBGDF_GROUPBY", GDF_ORANGE);   // sqls_ops.cu:1132
+  struct Pop { ~Pop() { gdf_nvtx_range_pop(); } } pop;
+  return group_by_hash(ncols, cols, col_agg, out_col_values, out_col_agg, op, ctxt->flag_sort_result == 1);
+}
+
+}  // namespace gdf_amd
+
+using namespace gdf_amd;
+
+extern "C" {
+
+gdf_error gdf_group_by_sum(int ncols, gdf_column **cols, gdf_column *col_agg, gdf_column *out_col_indices,
+                           gdf_column **out_col_values, gdf_column *out_col_agg, gdf_context *ctxt) {
+  return group_by_single(ncols, cols, col_agg, out_col_indices, out_col_values, out_col_agg, ctxt, OP_SUM);
+}
+gdf_error gdf_group_by_min(int ncols, gdf_column **cols, gdf_column *col_agg, gdf_column *out_col_indices,
+                           gdf_column **out_col_values, gdf_column *out_col_agg, gdf_context *ctxt) {
+  return group_by_single(ncols, cols, col_agg, out_col_indices, out_col_values, out_col_agg, ctxt, OP_MIN);
+}
+gdf_error gdf_group_by_max(int ncols, gdf_column **cols, gdf_column *col_agg, gdf_column *out_col_indices,
+                           gdf_column **out_col_values, gdf_column *out_col_agg, gdf_context *ctxt) {
+  return group_by_single(ncols, cols, col_agg, out_col_indices, out_col_values, out_col_agg, ctxt, OP_MAX);
+}
+gdf_error gdf_group_by_avg(int ncols, gdf_column **cols, gdf_column *col_agg, gdf_column *out_col_indices,
+                           gdf_column **out_col_values, gdf_column *out_col_agg, gdf_context *ctxt) {
+  return group_by_single(ncols, cols, col_agg, out_col_indices, out_col_values, out_col_agg, ctxt, OP_AVG);
+}
+gdf_error gdf_group_by_count(int ncols, gdf_column **cols, gdf_column *col_agg, gdf_column *out_col_indices,
+                             gdf_column **out_col_values, gdf_column *out_col_agg, gdf_context *ctxt) {
+  return group_by_single(ncols, cols, col_agg, out_col_indices, out_col_values, out_col_agg, ctxt, OP_COUNT);
+}
+
+}  // extern "C"

@@ -1,0 +1,249 @@
+// hashing.hip -- gdf_hash and gdf_hash_partition.
+//
+// Replaces the reference's src/hashing.cu: row hash via thrust::tabulate
+// (:83-154) and the four-pass partitioner (:259-377, :401-536 -- hash+LDS
+// histogram, two thrust scans, LDS-cursor offsets, one thrust::scatter + stream
+// per column).  Here:
+//   hash_rows_kernel     : one coalesced pass, 8 B in / 4 B out per row.
+//   part_hist_kernel     : per-chunk partition histogram in LDS (wave-aggregated
+//                          for small P), written partition-major so that ONE
+//                          exclusive scan yields every (partition, chunk) base.
+//   part_scatter_kernel  : re-hashes the chunk (cheaper than storing and
+//                          re-reading a 4 B partition id per row), claims
+//                          destinations from LDS cursors and moves EVERY column
+//                          (data + valid bit) in the same pass.
+// Partition rule is the reference's: p = hash & (P-1) when P is a power of two,
+// else hash % P (hashing.cu:193-237,434-468); partitions are laid out in
+// increasing p; order inside a partition is unspecified.
+#include "hash.cuh"
+#include "internal.h"
+
+#include <vector>
+
+namespace gdf_amd {
+
+constexpr int HP_THREADS = 256;
+constexpr int HP_MAX_CHUNKS = 1024;
+constexpr int HP_MAX_LDS_PARTS = 16384;     // 64 KiB of LDS counters
+constexpr int HP_MAX_PAYLOAD_COLS = 32;     // columns moved per scatter launch
+
+template <bool MURMUR>
+__global__ __launch_bounds__(HP_THREADS) void hash_rows_kernel(KeyTable t, uint32_t *__restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * HP_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * HP_THREADS)
+    out[i] = hash_row<MURMUR>(t, i);
+}
+
+__device__ __forceinline__ uint32_t part_of(uint32_t h, uint32_t nparts, uint32_t pow2mask) {
+  return pow2mask ? (h & pow2mask) : (h % nparts);
+}
+
+// hist layout: hist[p * nchunks + chunk]
+template <bool MURMUR>
+__global__ __launch_bounds__(HP_THREADS) void part_hist_kernel(KeyTable t, int64_t n, int64_t chunk, int nchunks,
+                                                               uint32_t nparts, uint32_t pow2mask,
+                                                               uint32_t *__restrict__ hist) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_cnt[];
+  for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    for (uint32_t p = threadIdx.x; p < nparts; p += HP_THREADS) lds_cnt[p] = 0;
+    __syncthreads();
+    const int64_t begin = (int64_t)c * chunk;
+    const int64_t end = begin + chunk < n ? begin + chunk : n;
+    for (int64_t i = begin + threadIdx.x; i < end; i += HP_THREADS) {
+      const uint32_t p = part_of(hash_row<MURMUR>(t, i), nparts, pow2mask);
+      atomicAdd(&lds_cnt[p], 1u);
+    }
+    __syncthreads();
+    for (uint32_t p = threadIdx.x; p < nparts; p += HP_THREADS) hist[(size_t)p * nchunks + c] = lds_cnt[p];
+    __syncthreads();
+  }
+}
+
+struct PayloadCols {
+  int ncols;
+  const void *in[HP_MAX_PAYLOAD_COLS];
+  void *out[HP_MAX_PAYLOAD_COLS];
+  const uint8_t *in_valid[HP_MAX_PAYLOAD_COLS];   // null -> skip mask
+  uint32_t *out_valid[HP_MAX_PAYLOAD_COLS];       // zero-initialised words
+  int width[HP_MAX_PAYLOAD_COLS];
+  uint32_t *dst_map;                              // optional: destination of every row (wide tables)
+};
+
+__device__ __forceinline__ void move_elem(const void *in, void *out, int width, int64_t src, int64_t dst) {
+  switch (width) {
+    case 1: ((uint8_t *)out)[dst] = ((const uint8_t *)in)[src]; break;
+    case 2: ((uint16_t *)out)[dst] = ((const uint16_t *)in)[src]; break;
+    case 4: ((uint32_t *)out)[dst] = ((const uint32_t *)in)[src]; break;
+    default: ((uint64_t *)out)[dst] = ((const uint64_t *)in)[src]; break;
+  }
+}
+
+// offs: the scanned histogram (exclusive), same layout as hist
+template <bool MURMUR>
+__global__ __launch_bounds__(HP_THREADS) void part_scatter_kernel(KeyTable t, PayloadCols pc, int64_t n, int64_t chunk,
+                                                                  int nchunks, uint32_t nparts, uint32_t pow2mask,
+                                                                  const uint32_t *__restrict__ offs) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_cur[];
+  for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    for (uint32_t p = threadIdx.x; p < nparts; p += HP_THREADS) lds_cur[p] = offs[(size_t)p * nchunks + c];
+    __syncthreads();
+    const int64_t begin = (int64_t)c * chunk;
+    const int64_t end = begin + chunk < n ? begin + chunk : n;
+    for (int64_t i = begin + threadIdx.x; i < end; i += HP_THREADS) {
+      const uint32_t p = part_of(hash_row<MURMUR>(t, i), nparts, pow2mask);
+      const int64_t dst = atomicAdd(&lds_cur[p], 1u);
+      if (pc.dst_map) pc.dst_map[i] = (uint32_t)dst;
+      for (int k = 0; k < pc.ncols; ++k) {
+        move_elem(pc.in[k], pc.out[k], pc.width[k], i, dst);
+        if (pc.out_valid[k]) {
+          const bool v = pc.in_valid[k] ? bit_is_set(pc.in_valid[k], i) : true;
+          if (v) atomicOr(&pc.out_valid[k][dst >> 5], 1u << (dst & 31));
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// columns beyond the first HP_MAX_PAYLOAD_COLS follow the recorded row -> destination map
+__global__ __launch_bounds__(HP_THREADS) void part_apply_map_kernel(PayloadCols pc, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * HP_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * HP_THREADS) {
+    const int64_t dst = pc.dst_map[i];
+    for (int k = 0; k < pc.ncols; ++k) {
+      move_elem(pc.in[k], pc.out[k], pc.width[k], i, dst);
+      if (pc.out_valid[k]) {
+        const bool v = pc.in_valid[k] ? bit_is_set(pc.in_valid[k], i) : true;
+        if (v) atomicOr(&pc.out_valid[k][dst >> 5], 1u << (dst & 31));
+      }
+    }
+  }
+}
+
+__global__ void gather_strided_u32(const uint32_t *in, uint32_t *out, int count, size_t stride) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) out[i] = in[(size_t)i * stride];
+}
+
+}  // namespace gdf_amd
+
+using namespace gdf_amd;
+
+extern "C" {
+
+gdf_error gdf_hash(int num_cols, gdf_column **input, gdf_hash_func hash, gdf_column *output) {
+  // argument checks in the order of hashing.cu:85-110
+  if (0 == num_cols || nullptr == input || nullptr == output) return GDF_DATASET_EMPTY;
+  if (output->dtype != GDF_INT32) return GDF_UNSUPPORTED_DTYPE;
+  if (nullptr != input[0] && 0 == input[0]->size) return GDF_SUCCESS;
+  if (0 == output->size) return GDF_SUCCESS;
+  if (nullptr == output->data) return GDF_DATASET_EMPTY;
+  if (hash != GDF_HASH_MURMUR3 && hash != GDF_HASH_IDENTITY) return GDF_INVALID_HASH_FUNCTION;
+
+  KeyTable t;
+  GDF_TRY(make_key_table(input, num_cols, &t));
+  const int64_t n = t.nrows;
+  const int grid = stream_grid((size_t)n, HP_THREADS * 8);
+  if (hash == GDF_HASH_MURMUR3)
+    hipLaunchKernelGGL(hash_rows_kernel<true>, dim3(grid), dim3(HP_THREADS), 0, stream0(), t, (uint32_t *)output->data, n);
+  else
+    hipLaunchKernelGGL(hash_rows_kernel<false>, dim3(grid), dim3(HP_THREADS), 0, stream0(), t, (uint32_t *)output->data, n);
+  HIP_CHECK_LAST();
+  HIP_TRY(hipStreamSynchronize(stream0()));
+  return GDF_SUCCESS;
+}
+
+gdf_error gdf_hash_partition(int num_input_cols, gdf_column *input[], int columns_to_hash[], int num_cols_to_hash,
+                             int num_partitions, gdf_column *partitioned_output[], int partition_offsets[],
+                             gdf_hash_func hash) {
+  // checks in the order of hashing.cu:573-607
+  if (0 == num_input_cols || 0 == num_cols_to_hash || 0 == num_partitions || nullptr == input ||
+      nullptr == partitioned_output || nullptr == columns_to_hash || nullptr == partition_offsets)
+    return GDF_INVALID_API_CALL;
+  const size_t num_rows = input[0]->size;
+  if (0 == num_rows) return GDF_SUCCESS;
+  for (int i = 0; i < num_input_cols; ++i) {
+    if (nullptr == input[i]->data || nullptr == partitioned_output[i]->data) return GDF_DATASET_EMPTY;
+    if (input[i]->dtype != partitioned_output[i]->dtype) return GDF_PARTITION_DTYPE_MISMATCH;
+    if (num_rows != input[i]->size || num_rows != partitioned_output[i]->size) return GDF_COLUMN_SIZE_MISMATCH;
+  }
+  if (hash != GDF_HASH_MURMUR3 && hash != GDF_HASH_IDENTITY) return GDF_INVALID_HASH_FUNCTION;
+  if (num_partitions < 0 || num_partitions > HP_MAX_LDS_PARTS) return GDF_INVALID_API_CALL;
+  if (num_rows >= (size_t)INT_MAX) return GDF_COLUMN_SIZE_TOO_BIG;   // int offsets in the ABI
+
+  gdf_nvtx_range_push("LIBGDF_HASH_PARTITION", GDF_PURPLE);   // hashing.cu:609
+  struct Pop { ~Pop() { gdf_nvtx_range_pop(); } } pop;
+
+  std::vector<gdf_column *> key_cols(num_cols_to_hash);
+  for (int i = 0; i < num_cols_to_hash; ++i) {
+    if (columns_to_hash[i] < 0 || columns_to_hash[i] >= num_input_cols) return GDF_INVALID_API_CALL;
+    key_cols[i] = input[columns_to_hash[i]];
+  }
+  KeyTable t;
+  GDF_TRY(make_key_table(key_cols.data(), num_cols_to_hash, &t));
+  for (int i = 0; i < num_input_cols; ++i)
+    if (dtype_width(input[i]->dtype) < 0) return GDF_UNSUPPORTED_DTYPE;
+
+  const int64_t n = (int64_t)num_rows;
+  const uint32_t P = (uint32_t)num_partitions;
+  const uint32_t pow2mask = (P & (P - 1)) == 0 ? P - 1 : 0;   // P==1 -> mask 0 -> h % 1 == 0, same result
+  // chunking: at most HP_MAX_CHUNKS chunks, each a multiple of the block size
+  int64_t chunk = (n + HP_MAX_CHUNKS - 1) / HP_MAX_CHUNKS;
+  chunk = ((chunk + HP_THREADS * 8 - 1) / (HP_THREADS * 8)) * (HP_THREADS * 8);
+  const int nchunks = (int)((n + chunk - 1) / chunk);
+  const size_t lds = sizeof(uint32_t) * P;
+  const int grid = nchunks < NUM_CU * 4 ? nchunks : NUM_CU * 4;
+
+  DevBuf hist, starts;
+  RMM_TRY(hist.alloc(sizeof(uint32_t) * (size_t)P * nchunks));
+  RMM_TRY(starts.alloc(sizeof(uint32_t) * P));
+  const bool murmur = hash == GDF_HASH_MURMUR3;
+  if (murmur)
+    hipLaunchKernelGGL(part_hist_kernel<true>, dim3(grid), dim3(HP_THREADS), lds, stream0(), t, n, chunk, nchunks, P, pow2mask, hist.as<uint32_t>());
+  else
+    hipLaunchKernelGGL(part_hist_kernel<false>, dim3(grid), dim3(HP_THREADS), lds, stream0(), t, n, chunk, nchunks, P, pow2mask, hist.as<uint32_t>());
+  HIP_CHECK_LAST();
+  GDF_TRY(scan_u32(hist.as<uint32_t>(), hist.as<uint32_t>(), (size_t)P * nchunks, false));
+  hipLaunchKernelGGL(gather_strided_u32, dim3((P + 255) / 256), dim3(256), 0, stream0(), hist.as<uint32_t>(),
+                     starts.as<uint32_t>(), (int)P, (size_t)nchunks);
+  HIP_CHECK_LAST();
+
+  // move the columns, HP_MAX_PAYLOAD_COLS per launch; a wider table records the
+  // row -> destination map in the first launch and replays it for the rest
+  DevBuf dst_map;
+  if (num_input_cols > HP_MAX_PAYLOAD_COLS) RMM_TRY(dst_map.alloc(sizeof(uint32_t) * num_rows));
+  for (int first = 0; first < num_input_cols; first += HP_MAX_PAYLOAD_COLS) {
+    PayloadCols pc{};
+    pc.ncols = num_input_cols - first < HP_MAX_PAYLOAD_COLS ? num_input_cols - first : HP_MAX_PAYLOAD_COLS;
+    for (int k = 0; k < pc.ncols; ++k) {
+      gdf_column *ci = input[first + k], *co = partitioned_output[first + k];
+      pc.in[k] = ci->data;
+      pc.out[k] = co->data;
+      pc.width[k] = dtype_width(ci->dtype);
+      // masks travel only when both sides carry one (gdf_table.cuh:1101-1116)
+      if (ci->valid && co->valid) {
+        pc.in_valid[k] = ci->valid;
+        pc.out_valid[k] = (uint32_t *)co->valid;
+        // atomicOr works on 4-byte words: clear the mask rounded up to a word.  Arrow
+        // buffers are padded to 64 bytes, so the trailing bytes belong to the column.
+        HIP_TRY(hipMemsetAsync(co->valid, 0, ((mask_bytes(num_rows) + 3) / 4) * 4, stream0()));
+        co->null_count = ci->null_count;
+      } else {
+        pc.in_valid[k] = nullptr;
+        pc.out_valid[k] = nullptr;
+      }
+    }
+    pc.dst_map = dst_map.as<uint32_t>();
+    if (first > 0)
+      hipLaunchKernelGGL(part_apply_map_kernel, dim3(stream_grid(num_rows, HP_THREADS * 4)), dim3(HP_THREADS), 0, stream0(), pc, n);
+    else if (murmur)
+      hipLaunchKernelGGL(part_scatter_kernel<true>, dim3(grid), dim3(HP_THREADS), lds, stream0(), t, pc, n, chunk, nchunks, P, pow2mask, hist.as<uint32_t>());
+    else
+      hipLaunchKernelGGL(part_scatter_kernel<false>, dim3(grid), dim3(HP_THREADS), lds, stream0(), t, pc, n, chunk, nchunks, P, pow2mask, hist.as<uint32_t>());
+    HIP_CHECK_LAST();
+  }
+  // partition_offsets is a HOST array (hashing.cu:499-503)
+  HIP_TRY(hipMemcpyAsync(partition_offsets, starts.p, sizeof(int) * P, hipMemcpyDeviceToHost, stream0()));
+  HIP_TRY(hipStreamSynchronize(stream0()));
+  return GDF_SUCCESS;
+}
+
+}  // extern "C"

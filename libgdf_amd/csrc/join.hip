@@ -1,0 +1,1049 @@
+// join.hip -- gdf_inner_join / gdf_left_join / gdf_full_join, HASH method.
+//
+// Reference path being replaced: src/join/joining.cu:282-653 ->
+// join/joining.h:46-74 -> join/hash/join_compute_api.h:341-551 with the kernels of
+// join/hash/join_kernels.cuh:46-455 over the global-memory multimap of
+// src/hashmap/concurrent_unordered_multimap.cuh.  That design does one dependent
+// random HBM read per probe step into a 2*N_build-slot table plus a second random
+// read of the build key; here NO random HBM access remains:
+//
+//   1. jk_hist      both relations are turned into (key64, row) tuples and radix
+//                   partitioned on the top FB bits of mix64(key64), FB <= 15, so
+//   2. jk_scatter1  that one build partition fits an LDS hash table.  Two scatter
+//   3. jk_scatter2  levels (<= 256-way each); tiles are regrouped in LDS so the
+//                   global writes are runs of consecutive addresses.
+//   4. jk_probe<COUNT>  one workgroup per (partition, probe chunk): builds the
+//                   partition's open-addressing table in LDS, streams the probe
+//                   tuples past it, counts matches.
+//   5. scan of the per-unit counts -> exact output size and per-unit offsets
+//   6. jk_probe<WRITE>  same walk, wave-ballot compaction of the (probe, build)
+//                   index pairs into the unit's private output range.
+//
+// key64 is the exact key for one <=8-byte column (or several integer columns
+// packed into 8 bytes); wider / mixed keys use a 64-bit hash and every LDS hit is
+// verified against the original columns.  Semantics kept from the reference:
+// rows with a null in any key column never match (join_kernels.cuh:58-66,314),
+// float keys compare with == (NaN matches nothing), LEFT emits (l,-1) for
+// unmatched probe rows, FULL appends (-1,r) for unmatched build rows
+// (join_compute_api.h:54-186), INNER builds on the smaller side and flips
+// (joining.h:58-66), outputs are library-allocated int32 columns of exactly the
+// joined size, pair order unspecified.
+#include "internal.h"
+
+#include <algorithm>
+#include <vector>
+
+namespace gdf_amd {
+
+// ---------------------------------------------------------------------------
+// key construction
+// ---------------------------------------------------------------------------
+enum KeyMode : int { KM_RAW_INT = 0, KM_RAW_FLOAT, KM_PACKED, KM_HASHED };
+
+struct KeyPlan {
+  int mode;
+  int verify;                 // 1: key64 is a hash, confirm hits with rows_equal
+  int shift[MAX_KEY_COLS];    // KM_PACKED bit offsets
+};
+
+static KeyPlan plan_keys(const KeyTable &t) {
+  KeyPlan p{};
+  bool all_int = true;
+  int total = 0;
+  for (int c = 0; c < t.ncols; ++c) {
+    if (t.col[c].kind == K_F32 || t.col[c].kind == K_F64) all_int = false;
+    p.shift[c] = total * 8;
+    total += t.col[c].width;
+  }
+  if (t.ncols == 1) p.mode = all_int ? KM_RAW_INT : KM_RAW_FLOAT;
+  else if (all_int && total <= 8) p.mode = KM_PACKED;
+  else { p.mode = KM_HASHED; p.verify = 1; }
+  return p;
+}
+
+// canonical bits of a float element for equality-by-==: -0.0 -> +0.0; NaN -> not joinable
+__device__ __forceinline__ bool float_bits(const ColView &c, int64_t i, uint64_t &bits) {
+  if (c.kind == K_F32) {
+    uint32_t b = ((const uint32_t *)c.data)[i];
+    if ((b & 0x7fffffffu) > 0x7f800000u) return false;
+    if ((b << 1) == 0) b = 0;
+    bits = b;
+  } else {
+    uint64_t b = ((const uint64_t *)c.data)[i];
+    if ((b & 0x7fffffffffffffffULL) > 0x7ff0000000000000ULL) return false;
+    if ((b << 1) == 0) b = 0;
+    bits = b;
+  }
+  return true;
+}
+
+// returns false when the row cannot match anything (null or NaN key)
+__device__ __forceinline__ bool make_key(const KeyTable &t, const KeyPlan &p, int64_t i, uint64_t &key) {
+  if (!row_valid(t, i)) return false;
+  switch (p.mode) {
+    case KM_RAW_INT: key = load_bits(t.col[0], i); return true;
+    case KM_RAW_FLOAT: return float_bits(t.col[0], i, key);
+    case KM_PACKED: {
+      uint64_t k = 0;
+      for (int c = 0; c < t.ncols; ++c) k |= load_bits(t.col[c], i) << p.shift[c];
+      key = k;
+      return true;
+    }
+    default: {
+      uint64_t h = 0x9e3779b97f4a7c15ULL;
+      for (int c = 0; c < t.ncols; ++c) {
+        uint64_t b;
+        if (t.col[c].kind == K_F32 || t.col[c].kind == K_F64) { if (!float_bits(t.col[c], i, b)) return false; }
+        else b = load_bits(t.col[c], i);
+        h = mix64(h ^ b) + 0x9e3779b97f4a7c15ULL * (uint64_t)(c + 1);
+      }
+      key = h;
+      return true;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// partition geometry
+// ---------------------------------------------------------------------------
+constexpr int JK_MAX_FB = 15;               // 32768 fine partitions: 128 KiB of LDS counters in jk_hist
+constexpr int JK_HIST_THREADS = 1024;
+constexpr int JK_SC_THREADS = 256;
+constexpr int JK_SC_ITEMS = 16;
+constexpr int JK_TILE = JK_SC_THREADS * JK_SC_ITEMS;   // 4096 tuples per LDS tile
+constexpr int JK_MAX_CHUNKS = 2048;
+constexpr int JK_PROBE_THREADS = 512;
+constexpr int JK_TARGET_BUILD = 3072;       // build tuples per fine partition the geometry aims at
+constexpr int JK_MAX_SLOTS = 8192;          // 96 KiB LDS table at most
+constexpr int JK_MAX_BUILD = 6144;          // 75 % load of JK_MAX_SLOTS; larger partitions take the global-table path
+constexpr uint32_t JK_PROBE_CHUNK = 1u << 17;   // probe tuples per work unit
+constexpr int32_t JK_EMPTY = -1;
+
+struct PartGeom {
+  int fb, b1, b2;        // fine bits = b1 (level 1) + b2 (level 2)
+  int nchunks;           // level-1 chunks (one histogram column each)
+  int64_t chunk;         // rows per chunk (multiple of JK_TILE)
+};
+
+__device__ __forceinline__ uint32_t fine_of(uint64_t key, int fb) {
+  return fb ? (uint32_t)(mix64(key) >> (64 - fb)) : 0u;
+}
+// slot hash uses the LOW half of the mix so it is independent of the partition bits
+__device__ __forceinline__ uint32_t slot_of(uint64_t key, uint32_t nslots) {
+  return (uint32_t)(((uint64_t)(uint32_t)mix64(key) * nslots) >> 32);
+}
+
+// ---------------------------------------------------------------------------
+// 1. histogram: fine histogram (global, LDS-accumulated) + per-chunk coarse histogram
+//    H1[c * nchunks + chunk]
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(JK_HIST_THREADS) void jk_hist(KeyTable t, KeyPlan plan, PartGeom g,
+                                                           uint32_t *__restrict__ fine_hist,
+                                                           uint32_t *__restrict__ H1) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  uint32_t *fine = lds;
+  uint32_t *coarse = lds + (1u << g.fb);
+  const uint32_t nfine = 1u << g.fb, ncoarse = 1u << g.b1;
+  for (uint32_t f = threadIdx.x; f < nfine; f += JK_HIST_THREADS) fine[f] = 0;
+  for (int chunk = blockIdx.x; chunk < g.nchunks; chunk += gridDim.x) {
+    for (uint32_t c = threadIdx.x; c < ncoarse; c += JK_HIST_THREADS) coarse[c] = 0;
+    __syncthreads();
+    const int64_t begin = (int64_t)chunk * g.chunk;
+    const int64_t end = begin + g.chunk < t.nrows ? begin + g.chunk : t.nrows;
+    for (int64_t i = begin + threadIdx.x; i < end; i += JK_HIST_THREADS) {
+      uint64_t key;
+      if (make_key(t, plan, i, key)) {
+        const uint32_t f = fine_of(key, g.fb);
+        atomicAdd(&fine[f], 1u);
+        atomicAdd(&coarse[f >> g.b2], 1u);
+      }
+    }
+    __syncthreads();
+    for (uint32_t c = threadIdx.x; c < ncoarse; c += JK_HIST_THREADS) H1[(size_t)c * g.nchunks + chunk] = coarse[c];
+    __syncthreads();
+  }
+  for (uint32_t f = threadIdx.x; f < nfine; f += JK_HIST_THREADS)
+    if (fine[f]) atomicAdd(&fine_hist[f], fine[f]);
+}
+
+// ---------------------------------------------------------------------------
+// LDS tile regroup shared by both scatter levels.
+//   phase A (caller): every thread has up to ITEMS tuples with bin + rank (rank
+//            from an LDS atomic on hist[bin]);
+//   phase B: exclusive scan of hist -> start; caller supplies the global base of
+//            every bin; tuples are written to LDS at start[bin] + rank;
+//   phase C: LDS position j goes to global base[bin(j)] + (j - start[bin(j)]), so a
+//            wave writes runs of consecutive addresses.
+// ---------------------------------------------------------------------------
+struct TileLds {
+  uint64_t key[JK_TILE];
+  int32_t idx[JK_TILE];
+  uint32_t hist[256];
+  uint32_t start[256];
+  int64_t gbase[256];     // global base minus start[bin]
+  uint32_t cursor[256];   // level 1: running global cursor of this chunk
+  uint32_t wave_tot[JK_SC_THREADS / WAVE];
+  uint32_t total;
+};
+
+// block-wide exclusive scan of hist[0..nbins) (nbins <= 256 == blockDim) into start[]
+__device__ __forceinline__ void tile_scan_bins(TileLds &s, uint32_t nbins) {
+  const uint32_t v = threadIdx.x < nbins ? s.hist[threadIdx.x] : 0;
+  const uint32_t incl = wave_scan_incl(v);
+  if (lane_id() == WAVE - 1) s.wave_tot[threadIdx.x / WAVE] = incl;
+  __syncthreads();
+  uint32_t woff = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < JK_SC_THREADS / WAVE; ++w) {
+    if (w < (int)(threadIdx.x / WAVE)) woff += s.wave_tot[w];
+    tot += s.wave_tot[w];
+  }
+  if (threadIdx.x < nbins) s.start[threadIdx.x] = woff + incl - v;
+  if (threadIdx.x == 0) s.total = tot;
+}
+
+// 2. level-1 scatter: raw key columns -> (key64, row) tuples grouped by coarse partition
+__global__ __launch_bounds__(JK_SC_THREADS) void jk_scatter1(KeyTable t, KeyPlan plan, PartGeom g,
+                                                             const uint32_t *__restrict__ H1off,   // scanned H1
+                                                             uint64_t *__restrict__ out_key, int32_t *__restrict__ out_idx) {
+  __shared__ TileLds s;
+  const int chunk = blockIdx.x;
+  const uint32_t ncoarse = 1u << g.b1;
+  if (threadIdx.x < ncoarse) s.cursor[threadIdx.x] = H1off[(size_t)threadIdx.x * g.nchunks + chunk];
+  const int64_t begin = (int64_t)chunk * g.chunk;
+  const int64_t end = begin + g.chunk < t.nrows ? begin + g.chunk : t.nrows;
+  for (int64_t tile = begin; tile < end; tile += JK_TILE) {
+    if (threadIdx.x < 256) s.hist[threadIdx.x] = 0;
+    __syncthreads();
+    uint64_t key[JK_SC_ITEMS];
+    uint32_t binrank[JK_SC_ITEMS];   // bin << 16 | rank ; 0xffffffff = skip
+#pragma unroll
+    for (int k = 0; k < JK_SC_ITEMS; ++k) {
+      const int64_t i = tile + (int64_t)k * JK_SC_THREADS + threadIdx.x;
+      binrank[k] = 0xffffffffu;
+      if (i < end && make_key(t, plan, i, key[k])) {
+        const uint32_t bin = fine_of(key[k], g.fb) >> g.b2;
+        const uint32_t r = atomicAdd(&s.hist[bin], 1u);
+        binrank[k] = (bin << 16) | r;
+      }
+    }
+    __syncthreads();
+    tile_scan_bins(s, ncoarse);
+    __syncthreads();
+    if (threadIdx.x < ncoarse) {
+      s.gbase[threadIdx.x] = (int64_t)s.cursor[threadIdx.x] - (int64_t)s.start[threadIdx.x];
+      s.cursor[threadIdx.x] += s.hist[threadIdx.x];
+    }
+#pragma unroll
+    for (int k = 0; k < JK_SC_ITEMS; ++k) {
+      if (binrank[k] != 0xffffffffu) {
+        const uint32_t pos = s.start[binrank[k] >> 16] + (binrank[k] & 0xffffu);
+        s.key[pos] = key[k];
+        s.idx[pos] = (int32_t)(tile + (int64_t)k * JK_SC_THREADS + threadIdx.x);
+      }
+    }
+    __syncthreads();
+    const uint32_t total = s.total;
+    for (uint32_t j = threadIdx.x; j < total; j += JK_SC_THREADS) {
+      const uint64_t kk = s.key[j];
+      const uint32_t bin = fine_of(kk, g.fb) >> g.b2;
+      const int64_t dst = s.gbase[bin] + j;
+      out_key[dst] = kk;
+      out_idx[dst] = s.idx[j];
+    }
+    __syncthreads();
+  }
+}
+
+// 3. level-2 scatter: tuples of one coarse partition -> fine partitions.  A tile
+// never crosses a coarse boundary; bins claim their global range with one
+// atomicAdd per (tile, non-empty bin) on the fine cursors.
+struct Level2Map {                     // small host-built tables, device resident
+  const uint32_t *coarse_off;          // [ncoarse+1] tuple offset of each coarse partition
+  const uint32_t *tile_prefix;         // [ncoarse+1] tiles before each coarse partition
+};
+
+__global__ __launch_bounds__(JK_SC_THREADS) void jk_scatter2(PartGeom g, Level2Map m,
+                                                             const uint64_t *__restrict__ in_key,
+                                                             const int32_t *__restrict__ in_idx,
+                                                             uint32_t *__restrict__ fine_cursor,
+                                                             uint64_t *__restrict__ out_key, int32_t *__restrict__ out_idx) {
+  __shared__ TileLds s;
+  const uint32_t ncoarse = 1u << g.b1, nsub = 1u << g.b2;
+  // locate the coarse partition that owns this tile (binary search over <= 257 entries)
+  uint32_t lo = 0, hi = ncoarse;
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (m.tile_prefix[mid] <= blockIdx.x) lo = mid; else hi = mid;
+  }
+  const uint32_t p = lo;
+  const uint32_t begin = m.coarse_off[p] + (blockIdx.x - m.tile_prefix[p]) * JK_TILE;
+  const uint32_t pend = m.coarse_off[p + 1];
+  const uint32_t end = begin + JK_TILE < pend ? begin + JK_TILE : pend;
+  const uint32_t submask = nsub - 1;
+
+  if (threadIdx.x < 256) s.hist[threadIdx.x] = 0;
+  __syncthreads();
+  uint64_t key[JK_SC_ITEMS];
+  int32_t idx[JK_SC_ITEMS];
+  uint32_t binrank[JK_SC_ITEMS];
+#pragma unroll
+  for (int k = 0; k < JK_SC_ITEMS; ++k) {
+    const uint32_t i = begin + k * JK_SC_THREADS + threadIdx.x;
+    binrank[k] = 0xffffffffu;
+    if (i < end) {
+      key[k] = in_key[i];
+      idx[k] = in_idx[i];
+      const uint32_t bin = fine_of(key[k], g.fb) & submask;
+      const uint32_t r = atomicAdd(&s.hist[bin], 1u);
+      binrank[k] = (bin << 16) | r;
+    }
+  }
+  __syncthreads();
+  tile_scan_bins(s, nsub);
+  __syncthreads();
+  if (threadIdx.x < nsub) {
+    const uint32_t cnt = s.hist[threadIdx.x];
+    if (cnt) {
+      const uint32_t gb = atomicAdd(&fine_cursor[(p << g.b2) | threadIdx.x], cnt);
+      s.gbase[threadIdx.x] = (int64_t)gb - (int64_t)s.start[threadIdx.x];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < JK_SC_ITEMS; ++k) {
+    if (binrank[k] != 0xffffffffu) {
+      const uint32_t pos = s.start[binrank[k] >> 16] + (binrank[k] & 0xffffu);
+      s.key[pos] = key[k];
+      s.idx[pos] = idx[k];
+    }
+  }
+  __syncthreads();
+  const uint32_t total = s.total;
+  for (uint32_t j = threadIdx.x; j < total; j += JK_SC_THREADS) {
+    const uint64_t kk = s.key[j];
+    const uint32_t bin = fine_of(kk, g.fb) & submask;
+    const int64_t dst = s.gbase[bin] + j;
+    out_key[dst] = kk;
+    out_idx[dst] = s.idx[j];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// 4/6. probe: one workgroup per work unit
+// ---------------------------------------------------------------------------
+struct Unit {
+  uint32_t build_begin, build_count;   // tuple range of the fine partition on the build side
+  uint32_t probe_begin, probe_count;   // this unit's slice of the partition on the probe side
+};
+
+struct ProbeArgs {
+  const uint64_t *bkey; const int32_t *bidx;    // partitioned build tuples
+  const uint64_t *pkey; const int32_t *pidx;    // partitioned probe tuples
+  const Unit *units;
+  uint32_t nslots;
+  int keep_unmatched_probe;     // LEFT / FULL: emit (probe, -1)
+  int verify;                   // confirm hits on the original columns
+  uint8_t *build_matched;       // FULL: byte per build ROW, set when matched (may be null)
+  uint64_t *counts;             // COUNT pass output / WRITE pass: exclusive offsets
+  int32_t *out_probe; int32_t *out_build;
+};
+
+template <bool WRITE>
+__global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTable probe_t, KeyTable build_t) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  // one dynamic region (keeps every carve 16-byte aligned; nslots is a multiple of 64):
+  //   [keys: nslots x 8][rows: nslots x 4][wave counts: 8 x 8][unit cursor: 8]
+  uint64_t *tkey = (uint64_t *)lds_raw;
+  int32_t *tidx = (int32_t *)(lds_raw + (size_t)a.nslots * 8);
+  unsigned long long *wave_cnt = (unsigned long long *)(lds_raw + (size_t)a.nslots * 12);
+  unsigned long long &unit_cursor = wave_cnt[JK_PROBE_THREADS / WAVE];   // WRITE: next free output position
+
+  const Unit u = a.units[blockIdx.x];
+  const uint32_t S = a.nslots;
+  for (uint32_t i = threadIdx.x; i < S; i += JK_PROBE_THREADS) tidx[i] = JK_EMPTY;
+  if (threadIdx.x == 0) unit_cursor = WRITE ? a.counts[blockIdx.x] : 0ull;
+  __syncthreads();
+
+  // build: linear probing, slot claimed by CAS on the row word, key written by the owner
+  for (uint32_t i = threadIdx.x; i < u.build_count; i += JK_PROBE_THREADS) {
+    const uint64_t k = a.bkey[u.build_begin + i];
+    const int32_t r = a.bidx[u.build_begin + i];
+    uint32_t slot = slot_of(k, S);
+    while (atomicCAS(&tidx[slot], JK_EMPTY, r) != JK_EMPTY) slot = (slot + 1 == S) ? 0 : slot + 1;
+    tkey[slot] = k;
+  }
+  __syncthreads();
+
+  unsigned long long my_count = 0;
+  const uint32_t rounds = (u.probe_count + JK_PROBE_THREADS - 1) / JK_PROBE_THREADS;
+  for (uint32_t rnd = 0; rnd < rounds; ++rnd) {
+    const uint32_t i = rnd * JK_PROBE_THREADS + threadIdx.x;
+    const bool active = i < u.probe_count;
+    uint64_t k = 0;
+    int32_t prow = 0;
+    uint32_t cnt = 0;
+    int32_t first_build = JK_EMPTY;
+    uint32_t slot0 = 0;
+    if (active) {
+      k = a.pkey[u.probe_begin + i];
+      prow = a.pidx[u.probe_begin + i];
+      slot0 = slot_of(k, S);
+      uint32_t slot = slot0;
+      for (;;) {
+        const int32_t r = tidx[slot];
+        if (r == JK_EMPTY) break;
+        if (tkey[slot] == k && (!a.verify || rows_equal(probe_t, prow, build_t, r))) {
+          if (cnt == 0) first_build = r;
+          ++cnt;
+          if (a.build_matched) a.build_matched[r] = 1;
+        }
+        slot = (slot + 1 == S) ? 0 : slot + 1;
+      }
+      if (cnt == 0 && a.keep_unmatched_probe) cnt = 1;   // first_build stays -1
+    }
+    if (!WRITE) {
+      my_count += cnt;
+    } else {
+      // wave-level compaction: exclusive scan of cnt gives each lane its offset,
+      // one LDS atomic per wave claims the range
+      const uint32_t incl = wave_scan_incl(cnt);
+      const uint32_t wave_total = __shfl(incl, WAVE - 1, WAVE);
+      unsigned long long base = 0;
+      if (lane_id() == 0 && wave_total) base = atomicAdd(&unit_cursor, (unsigned long long)wave_total);
+      base = __shfl(base, 0, WAVE);
+      unsigned long long pos = base + incl - cnt;
+      if (cnt == 1) {
+        a.out_probe[pos] = prow;
+        a.out_build[pos] = first_build;
+      } else if (cnt > 1) {
+        uint32_t slot = slot0;
+        for (;;) {
+          const int32_t r = tidx[slot];
+          if (r == JK_EMPTY) break;
+          if (tkey[slot] == k && (!a.verify || rows_equal(probe_t, prow, build_t, r))) {
+            a.out_probe[pos] = prow;
+            a.out_build[pos] = r;
+            ++pos;
+          }
+          slot = (slot + 1 == S) ? 0 : slot + 1;
+        }
+      }
+    }
+  }
+  if (!WRITE) {
+    my_count = wave_reduce_add(my_count);
+    if (lane_id() == 0) wave_cnt[threadIdx.x / WAVE] = my_count;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned long long t = 0;
+      for (int w = 0; w < JK_PROBE_THREADS / WAVE; ++w) t += wave_cnt[w];
+      a.counts[blockIdx.x] = t;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// global-table path for partitions whose build side exceeds the LDS table
+// (heavy key duplication / build sides beyond 32768 * JK_MAX_BUILD rows).
+// Same walk, table in HBM, one thread per tuple.
+// ---------------------------------------------------------------------------
+__global__ void gj_fill(int32_t *tidx, uint32_t nslots) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nslots; i += gridDim.x * blockDim.x) tidx[i] = JK_EMPTY;
+}
+__global__ void gj_build(const uint64_t *bkey, const int32_t *bidx, uint32_t n, uint64_t *tkey, int32_t *tidx,
+                         uint32_t S) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint64_t k = bkey[i];
+    uint32_t slot = slot_of(k, S);
+    while (atomicCAS(&tidx[slot], JK_EMPTY, bidx[i]) != JK_EMPTY) slot = (slot + 1 == S) ? 0 : slot + 1;
+    tkey[slot] = k;
+  }
+}
+template <bool WRITE>
+__global__ void gj_probe(ProbeArgs a, KeyTable probe_t, KeyTable build_t, const uint64_t *tkey, const int32_t *tidx,
+                         uint32_t probe_begin, uint32_t probe_count, unsigned long long *cursor) {
+  const uint32_t S = a.nslots;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  const uint32_t rounds = (probe_count + stride - 1) / stride;
+  unsigned long long my_count = 0;
+  for (uint32_t rnd = 0; rnd < rounds; ++rnd) {
+    const uint32_t i = rnd * stride + blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t cnt = 0;
+    uint64_t k = 0;
+    int32_t prow = 0;
+    if (i < probe_count) {
+      k = a.pkey[probe_begin + i];
+      prow = a.pidx[probe_begin + i];
+      uint32_t slot = slot_of(k, S);
+      for (;;) {
+        const int32_t r = tidx[slot];
+        if (r == JK_EMPTY) break;
+        if (tkey[slot] == k && (!a.verify || rows_equal(probe_t, prow, build_t, r))) {
+          ++cnt;
+          if (a.build_matched) a.build_matched[r] = 1;
+        }
+        slot = (slot + 1 == S) ? 0 : slot + 1;
+      }
+    }
+    const bool pad = (i < probe_count) && cnt == 0 && a.keep_unmatched_probe;
+    if (!WRITE) {
+      my_count += pad ? 1 : cnt;
+    } else {
+      const uint32_t emit = pad ? 1 : cnt;
+      const uint32_t incl = wave_scan_incl(emit);
+      const uint32_t wave_total = __shfl(incl, WAVE - 1, WAVE);
+      unsigned long long base = 0;
+      if (lane_id() == 0 && wave_total) base = atomicAdd(cursor, (unsigned long long)wave_total);
+      base = __shfl(base, 0, WAVE);
+      unsigned long long pos = base + incl - emit;
+      if (pad) {
+        a.out_probe[pos] = prow;
+        a.out_build[pos] = JK_EMPTY;
+      } else if (cnt) {
+        uint32_t slot = slot_of(k, S);
+        for (;;) {
+          const int32_t r = tidx[slot];
+          if (r == JK_EMPTY) break;
+          if (tkey[slot] == k && (!a.verify || rows_equal(probe_t, prow, build_t, r))) {
+            a.out_probe[pos] = prow;
+            a.out_build[pos] = r;
+            ++pos;
+          }
+          slot = (slot + 1 == S) ? 0 : slot + 1;
+        }
+      }
+    }
+  }
+  if (!WRITE) {
+    my_count = wave_reduce_add(my_count);
+    if (lane_id() == 0 && my_count) atomicAdd(cursor, my_count);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// tails: rows that never entered the partitioned path
+// ---------------------------------------------------------------------------
+// rows of `t` whose key is null/NaN, compacted in ascending order behind *cursor
+// as (row, -1) pairs (LEFT / FULL probe side)
+__global__ __launch_bounds__(256) void jk_emit_unjoinable(KeyTable t, KeyPlan plan, int32_t *out_row, int32_t *out_none,
+                                                          unsigned long long *cursor) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t rounds = (t.nrows + stride - 1) / stride;
+  for (int64_t rnd = 0; rnd < rounds; ++rnd) {
+    const int64_t i = rnd * stride + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t key;
+    const bool emit = i < t.nrows && !make_key(t, plan, i, key);
+    const unsigned long long m = __ballot(emit);
+    unsigned long long base = 0;
+    if (lane_id() == 0 && m) base = atomicAdd(cursor, (unsigned long long)__popcll(m));
+    base = __shfl(base, 0, WAVE);
+    if (emit) {
+      const unsigned long long pos = base + mask_rank(m);
+      out_row[pos] = (int32_t)i;
+      out_none[pos] = JK_EMPTY;
+    }
+  }
+}
+// FULL join: build rows no probe row matched -> (-1, row)
+__global__ __launch_bounds__(256) void jk_emit_unmatched_build(const uint8_t *matched, int64_t nrows, int32_t *out_none,
+                                                               int32_t *out_row, unsigned long long *cursor) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t rounds = (nrows + stride - 1) / stride;
+  for (int64_t rnd = 0; rnd < rounds; ++rnd) {
+    const int64_t i = rnd * stride + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool emit = i < nrows && !matched[i];
+    const unsigned long long m = __ballot(emit);
+    unsigned long long base = 0;
+    if (lane_id() == 0 && m) base = atomicAdd(cursor, (unsigned long long)__popcll(m));
+    base = __shfl(base, 0, WAVE);
+    if (emit) {
+      const unsigned long long pos = base + mask_rank(m);
+      out_none[pos] = JK_EMPTY;
+      out_row[pos] = (int32_t)i;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void jk_count_unmatched(const uint8_t *matched, int64_t nrows, unsigned long long *count) {
+  unsigned long long c = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrows; i += (int64_t)gridDim.x * blockDim.x)
+    c += matched[i] ? 0 : 1;
+  c = wave_reduce_add(c);
+  if (lane_id() == 0 && c) atomicAdd(count, c);
+}
+__global__ void jk_fill_pairs(int32_t *a, int32_t av, int32_t *b, int32_t bv, int64_t n, int iota_a, int iota_b) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    a[i] = iota_a ? (int32_t)i : av;
+    b[i] = iota_b ? (int32_t)i : bv;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+enum JoinKind { JOIN_INNER, JOIN_LEFT, JOIN_FULL };
+
+struct SideBufs {            // partitioned tuples of one relation
+  DevBuf key[2], idx[2];
+  int final_buf = 0;         // which ping-pong buffer holds the fine-partitioned tuples
+  std::vector<uint32_t> fine_off;   // [nfine+1] on the host
+  uint32_t joinable = 0;     // tuples that entered the partitioned path
+};
+
+static PartGeom choose_geometry(int64_t build_rows, int64_t max_rows) {
+  PartGeom g{};
+  int fb = 0;
+  while (fb < JK_MAX_FB && (build_rows >> fb) > JK_TARGET_BUILD) ++fb;
+  g.fb = fb;
+  g.b1 = fb <= 8 ? fb : (fb + 1) / 2;
+  g.b2 = fb - g.b1;
+  (void)max_rows;
+  return g;
+}
+
+// partitions one relation into g.fb-bit fine partitions
+static gdf_error partition_side(const KeyTable &t, const KeyPlan &plan, PartGeom g, SideBufs *sb) {
+  const int64_t n = t.nrows;
+  // level-1 chunking (one histogram column per chunk)
+  int64_t chunk = (n + JK_MAX_CHUNKS - 1) / JK_MAX_CHUNKS;
+  chunk = ((chunk + JK_TILE - 1) / JK_TILE) * JK_TILE;
+  if (chunk == 0) chunk = JK_TILE;
+  g.chunk = chunk;
+  g.nchunks = (int)((n + chunk - 1) / chunk);
+  if (g.nchunks == 0) g.nchunks = 1;
+  const uint32_t nfine = 1u << g.fb, ncoarse = 1u << g.b1;
+
+  DevBuf fine_hist, H1;
+  RMM_TRY(fine_hist.alloc(sizeof(uint32_t) * nfine));
+  RMM_TRY(H1.alloc(sizeof(uint32_t) * (size_t)ncoarse * g.nchunks));
+  HIP_TRY(hipMemsetAsync(fine_hist.p, 0, sizeof(uint32_t) * nfine, stream0()));
+  const size_t hist_lds = sizeof(uint32_t) * (nfine + ncoarse);
+  HIP_TRY(hipFuncSetAttribute((const void *)jk_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_lds));
+  const int hist_grid = g.nchunks < NUM_CU ? g.nchunks : NUM_CU;
+  hipLaunchKernelGGL(jk_hist, dim3(hist_grid), dim3(JK_HIST_THREADS), hist_lds, stream0(), t, plan, g,
+                     fine_hist.as<uint32_t>(), H1.as<uint32_t>());
+  HIP_CHECK_LAST();
+  GDF_TRY(scan_u32(H1.as<uint32_t>(), H1.as<uint32_t>(), (size_t)ncoarse * g.nchunks, false));
+
+  std::vector<uint32_t> fh(nfine);
+  HIP_TRY(hipMemcpy(fh.data(), fine_hist.p, sizeof(uint32_t) * nfine, hipMemcpyDeviceToHost));
+  sb->fine_off.assign(nfine + 1, 0);
+  for (uint32_t f = 0; f < nfine; ++f) sb->fine_off[f + 1] = sb->fine_off[f] + fh[f];
+  sb->joinable = sb->fine_off[nfine];
+  const size_t cap = sb->joinable ? sb->joinable : 1;
+
+  RMM_TRY(sb->key[0].alloc(sizeof(uint64_t) * cap));
+  RMM_TRY(sb->idx[0].alloc(sizeof(int32_t) * cap));
+  hipLaunchKernelGGL(jk_scatter1, dim3(g.nchunks), dim3(JK_SC_THREADS), 0, stream0(), t, plan, g, H1.as<uint32_t>(),
+                     sb->key[0].as<uint64_t>(), sb->idx[0].as<int32_t>());
+  HIP_CHECK_LAST();
+  sb->final_buf = 0;
+  if (g.b2 > 0 && sb->joinable > 0) {
+    // level 2
+    std::vector<uint32_t> coarse_off(ncoarse + 1), tile_prefix(ncoarse + 1);
+    for (uint32_t c = 0; c <= ncoarse; ++c) coarse_off[c] = sb->fine_off[(size_t)c << g.b2];
+    tile_prefix[0] = 0;
+    for (uint32_t c = 0; c < ncoarse; ++c)
+      tile_prefix[c + 1] = tile_prefix[c] + (coarse_off[c + 1] - coarse_off[c] + JK_TILE - 1) / JK_TILE;
+    const uint32_t ntiles = tile_prefix[ncoarse];
+    DevBuf d_coarse, d_tiles, cursor;
+    RMM_TRY(d_coarse.alloc(sizeof(uint32_t) * (ncoarse + 1)));
+    RMM_TRY(d_tiles.alloc(sizeof(uint32_t) * (ncoarse + 1)));
+    RMM_TRY(cursor.alloc(sizeof(uint32_t) * nfine));
+    HIP_TRY(hipMemcpyAsync(d_coarse.p, coarse_off.data(), sizeof(uint32_t) * (ncoarse + 1), hipMemcpyHostToDevice, stream0()));
+    HIP_TRY(hipMemcpyAsync(d_tiles.p, tile_prefix.data(), sizeof(uint32_t) * (ncoarse + 1), hipMemcpyHostToDevice, stream0()));
+    HIP_TRY(hipMemcpyAsync(cursor.p, sb->fine_off.data(), sizeof(uint32_t) * nfine, hipMemcpyHostToDevice, stream0()));
+    RMM_TRY(sb->key[1].alloc(sizeof(uint64_t) * cap));
+    RMM_TRY(sb->idx[1].alloc(sizeof(int32_t) * cap));
+    Level2Map m{d_coarse.as<uint32_t>(), d_tiles.as<uint32_t>()};
+    if (ntiles)
+      hipLaunchKernelGGL(jk_scatter2, dim3(ntiles), dim3(JK_SC_THREADS), 0, stream0(), g, m, sb->key[0].as<uint64_t>(),
+                         sb->idx[0].as<int32_t>(), cursor.as<uint32_t>(), sb->key[1].as<uint64_t>(),
+                         sb->idx[1].as<int32_t>());
+    HIP_CHECK_LAST();
+    HIP_TRY(hipStreamSynchronize(stream0()));   // host vectors + scratch go out of scope
+    sb->key[0].reset();
+    sb->idx[0].reset();
+    sb->final_buf = 1;
+  } else {
+    HIP_TRY(hipStreamSynchronize(stream0()));
+  }
+  return GDF_SUCCESS;
+}
+
+static inline int small_grid(int64_t n) { return stream_grid((size_t)(n > 0 ? n : 1), 256 * 8); }
+
+// The join proper.  probe_t / build_t already reflect the INNER-join swap.
+// On success *out_probe / *out_build own rmm allocations of *out_n int32 each.
+static gdf_error hash_join_core(const KeyTable &probe_t, const KeyTable &build_t, JoinKind kind, int32_t **out_probe,
+                                int32_t **out_build, int64_t *out_n) {
+  const KeyPlan plan = plan_keys(probe_t);
+  const PartGeom g = choose_geometry(build_t.nrows, probe_t.nrows);
+  const uint32_t nfine = 1u << g.fb;
+  const bool keep_probe = kind != JOIN_INNER;
+
+  SideBufs B, P;
+  GDF_TRY(partition_side(build_t, plan, g, &B));
+  GDF_TRY(partition_side(probe_t, plan, g, &P));
+
+  // ---- work units ----
+  std::vector<Unit> units;
+  std::vector<uint32_t> oversize;     // fine partitions that need the global-table path
+  uint32_t max_build = 0;
+  for (uint32_t f = 0; f < nfine; ++f) {
+    const uint32_t bn = B.fine_off[f + 1] - B.fine_off[f];
+    const uint32_t pn = P.fine_off[f + 1] - P.fine_off[f];
+    if (pn == 0) continue;
+    if (bn == 0 && !keep_probe) continue;
+    if (bn > (uint32_t)JK_MAX_BUILD) { oversize.push_back(f); continue; }
+    max_build = std::max(max_build, bn);
+    for (uint32_t off = 0; off < pn; off += JK_PROBE_CHUNK)
+      units.push_back(Unit{B.fine_off[f], bn, P.fine_off[f] + off, std::min(JK_PROBE_CHUNK, pn - off)});
+  }
+  const size_t nunits = units.size();
+  const size_t nslots_all = nunits + oversize.size();     // one count slot per LDS unit + one per oversize partition
+  uint32_t nslots_lds = std::max<uint32_t>(2 * max_build, 64);
+  nslots_lds = (nslots_lds + 63) & ~63u;
+  if (nslots_lds > (uint32_t)JK_MAX_SLOTS) nslots_lds = JK_MAX_SLOTS;
+
+  DevBuf d_units, d_counts, d_matched, d_tail;
+  RMM_TRY(d_units.alloc(sizeof(Unit) * (nunits ? nunits : 1)));
+  RMM_TRY(d_counts.alloc(sizeof(uint64_t) * (nslots_all + 1)));
+  RMM_TRY(d_tail.alloc(sizeof(unsigned long long) * 4));
+  HIP_TRY(hipMemsetAsync(d_counts.p, 0, sizeof(uint64_t) * (nslots_all + 1), stream0()));
+  HIP_TRY(hipMemsetAsync(d_tail.p, 0, sizeof(unsigned long long) * 4, stream0()));
+  if (nunits) HIP_TRY(hipMemcpyAsync(d_units.p, units.data(), sizeof(Unit) * nunits, hipMemcpyHostToDevice, stream0()));
+  if (kind == JOIN_FULL) {
+    RMM_TRY(d_matched.alloc((size_t)(build_t.nrows ? build_t.nrows : 1)));
+    HIP_TRY(hipMemsetAsync(d_matched.p, 0, (size_t)(build_t.nrows ? build_t.nrows : 1), stream0()));
+  }
+
+  ProbeArgs a{};
+  a.bkey = B.key[B.final_buf].as<uint64_t>(); a.bidx = B.idx[B.final_buf].as<int32_t>();
+  a.pkey = P.key[P.final_buf].as<uint64_t>(); a.pidx = P.idx[P.final_buf].as<int32_t>();
+  a.units = d_units.as<Unit>();
+  a.nslots = nslots_lds;
+  a.keep_unmatched_probe = keep_probe ? 1 : 0;
+  a.verify = plan.verify;
+  a.build_matched = d_matched.as<uint8_t>();
+  a.counts = d_counts.as<uint64_t>();
+  const size_t probe_lds = (size_t)nslots_lds * 12 + sizeof(unsigned long long) * (JK_PROBE_THREADS / WAVE + 2);
+
+  HIP_TRY(hipFuncSetAttribute((const void *)jk_probe<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)probe_lds));
+  HIP_TRY(hipFuncSetAttribute((const void *)jk_probe<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)probe_lds));
+
+  // ---- count pass ----
+  if (nunits) {
+    hipLaunchKernelGGL(jk_probe<false>, dim3((unsigned)nunits), dim3(JK_PROBE_THREADS), probe_lds, stream0(), a, probe_t, build_t);
+    HIP_CHECK_LAST();
+  }
+  // oversize partitions: one global table each, kept for the write pass
+  struct GTable { DevBuf key, idx; uint32_t nslots; };
+  std::vector<GTable> gt(oversize.size());
+  for (size_t o = 0; o < oversize.size(); ++o) {
+    const uint32_t f = oversize[o];
+    const uint32_t bn = B.fine_off[f + 1] - B.fine_off[f], pn = P.fine_off[f + 1] - P.fine_off[f];
+    gt[o].nslots = bn * 2;
+    RMM_TRY(gt[o].key.alloc(sizeof(uint64_t) * gt[o].nslots));
+    RMM_TRY(gt[o].idx.alloc(sizeof(int32_t) * gt[o].nslots));
+    hipLaunchKernelGGL(gj_fill, dim3(small_grid(gt[o].nslots)), dim3(256), 0, stream0(), gt[o].idx.as<int32_t>(), gt[o].nslots);
+    hipLaunchKernelGGL(gj_build, dim3(small_grid(bn)), dim3(256), 0, stream0(), a.bkey + B.fine_off[f], a.bidx + B.fine_off[f], bn,
+                       gt[o].key.as<uint64_t>(), gt[o].idx.as<int32_t>(), gt[o].nslots);
+    ProbeArgs ga = a;
+    ga.nslots = gt[o].nslots;
+    hipLaunchKernelGGL(gj_probe<false>, dim3(small_grid(pn)), dim3(256), 0, stream0(), ga, probe_t, build_t,
+                       gt[o].key.as<uint64_t>(), gt[o].idx.as<int32_t>(), P.fine_off[f], pn,
+                       (unsigned long long *)(d_counts.as<uint64_t>() + nunits + o));
+    HIP_CHECK_LAST();
+  }
+
+  // ---- sizes ----
+  GDF_TRY(scan_u64(d_counts.as<uint64_t>(), d_counts.as<uint64_t>(), nslots_all + 1, false));
+  uint64_t matched_total = 0;
+  HIP_TRY(hipMemcpy(&matched_total, d_counts.as<uint64_t>() + nslots_all, sizeof(uint64_t), hipMemcpyDeviceToHost));
+  const uint64_t probe_tail = keep_probe ? (uint64_t)probe_t.nrows - P.joinable : 0;   // null / NaN probe rows
+  uint64_t build_tail = 0;
+  if (kind == JOIN_FULL) {
+    unsigned long long *d_cnt = d_tail.as<unsigned long long>() + 2;
+    hipLaunchKernelGGL(jk_count_unmatched, dim3(small_grid(build_t.nrows)), dim3(256), 0, stream0(), d_matched.as<uint8_t>(),
+                       build_t.nrows, d_cnt);
+    HIP_CHECK_LAST();
+    unsigned long long h = 0;
+    HIP_TRY(hipMemcpy(&h, d_cnt, sizeof(h), hipMemcpyDeviceToHost));
+    build_tail = h;
+  }
+  const uint64_t total = matched_total + probe_tail + build_tail;
+  if (total >= (uint64_t)INT_MAX) return GDF_COLUMN_SIZE_TOO_BIG;   // int32 index columns
+  *out_n = (int64_t)total;
+  if (total == 0) { *out_probe = nullptr; *out_build = nullptr; return GDF_SUCCESS; }
+
+  DevBuf op, ob;
+  RMM_TRY(op.alloc(sizeof(int32_t) * total));
+  RMM_TRY(ob.alloc(sizeof(int32_t) * total));
+  a.out_probe = op.as<int32_t>();
+  a.out_build = ob.as<int32_t>();
+  a.build_matched = nullptr;   // marks were taken in the count pass
+
+  // ---- write pass ----
+  if (nunits) {
+    hipLaunchKernelGGL(jk_probe<true>, dim3((unsigned)nunits), dim3(JK_PROBE_THREADS), probe_lds, stream0(), a, probe_t, build_t);
+    HIP_CHECK_LAST();
+  }
+  for (size_t o = 0; o < oversize.size(); ++o) {
+    const uint32_t f = oversize[o];
+    const uint32_t pn = P.fine_off[f + 1] - P.fine_off[f];
+    ProbeArgs ga = a;
+    ga.nslots = gt[o].nslots;
+    // the exclusive offset of this partition doubles as its write cursor
+    hipLaunchKernelGGL(gj_probe<true>, dim3(small_grid(pn)), dim3(256), 0, stream0(), ga, probe_t, build_t,
+                       gt[o].key.as<uint64_t>(), gt[o].idx.as<int32_t>(), P.fine_off[f], pn,
+                       (unsigned long long *)(d_counts.as<uint64_t>() + nunits + o));
+    HIP_CHECK_LAST();
+  }
+  if (probe_tail) {
+    unsigned long long *cur = d_tail.as<unsigned long long>();
+    hipLaunchKernelGGL(jk_emit_unjoinable, dim3(small_grid(probe_t.nrows)), dim3(256), 0, stream0(), probe_t, plan,
+                       a.out_probe + matched_total, a.out_build + matched_total, cur);
+    HIP_CHECK_LAST();
+  }
+  if (build_tail) {
+    unsigned long long *cur = d_tail.as<unsigned long long>() + 1;
+    hipLaunchKernelGGL(jk_emit_unmatched_build, dim3(small_grid(build_t.nrows)), dim3(256), 0, stream0(),
+                       d_matched.as<uint8_t>(), build_t.nrows, a.out_probe + matched_total + probe_tail,
+                       a.out_build + matched_total + probe_tail, cur);
+    HIP_CHECK_LAST();
+  }
+  HIP_TRY(hipStreamSynchronize(stream0()));
+  *out_probe = (int32_t *)op.release();
+  *out_build = (int32_t *)ob.release();
+  return GDF_SUCCESS;
+}
+
+// FULL join with an empty side (joining.cu:214-280 trivial_full_join): every row of
+// the non-empty side paired with -1.
+static gdf_error trivial_full_join(int64_t left_rows, int64_t right_rows, gdf_column *left_result, gdf_column *right_result) {
+  const int64_t n = left_rows > 0 ? left_rows : right_rows;
+  DevBuf l, r;
+  RMM_TRY(l.alloc(sizeof(int32_t) * (size_t)n));
+  RMM_TRY(r.alloc(sizeof(int32_t) * (size_t)n));
+  hipLaunchKernelGGL(jk_fill_pairs, dim3(small_grid(n)), dim3(256), 0, stream0(), l.as<int32_t>(), -1, r.as<int32_t>(), -1, n,
+                     left_rows > 0 ? 1 : 0, left_rows > 0 ? 0 : 1);
+  HIP_CHECK_LAST();
+  HIP_TRY(hipStreamSynchronize(stream0()));
+  gdf_column_view(left_result, l.release(), nullptr, (gdf_size_type)n, GDF_INT32);
+  gdf_column_view(right_result, r.release(), nullptr, (gdf_size_type)n, GDF_INT32);
+  return GDF_SUCCESS;
+}
+
+// joining.cu:282-373 join_call: validation + method dispatch
+static gdf_error join_call(JoinKind kind, int num_cols, gdf_column **leftcol, gdf_column **rightcol,
+                           gdf_column *left_result, gdf_column *right_result, gdf_context *ctx) {
+  if (0 == num_cols || nullptr == leftcol || nullptr == rightcol) return GDF_DATASET_EMPTY;
+  if (nullptr == ctx) return GDF_INVALID_API_CALL;
+  const size_t left_size = leftcol[0]->size, right_size = rightcol[0]->size;
+  if (left_size >= (size_t)INT_MAX) return GDF_COLUMN_SIZE_TOO_BIG;
+  if (right_size >= (size_t)INT_MAX) return GDF_COLUMN_SIZE_TOO_BIG;
+  if (0 == left_size && 0 == right_size) return GDF_SUCCESS;
+  if (kind == JOIN_LEFT && 0 == left_size) return GDF_SUCCESS;
+  if (kind == JOIN_INNER && (0 == left_size || 0 == right_size)) return GDF_SUCCESS;
+  if (kind == JOIN_FULL && (0 == left_size || 0 == right_size))
+    return trivial_full_join((int64_t)left_size, (int64_t)right_size, left_result, right_result);
+  for (int i = 0; i < num_cols; ++i) {
+    if (right_size > 0 && nullptr == rightcol[i]->data) return GDF_DATASET_EMPTY;
+    if (left_size > 0 && nullptr == leftcol[i]->data) return GDF_DATASET_EMPTY;
+    if (rightcol[i]->dtype != leftcol[i]->dtype) return GDF_JOIN_DTYPE_MISMATCH;
+    if (left_size != leftcol[i]->size) return GDF_COLUMN_SIZE_MISMATCH;
+    if (right_size != rightcol[i]->size) return GDF_COLUMN_SIZE_MISMATCH;
+  }
+  if (ctx->flag_method == GDF_SORT) {
+    // the sort-merge path (join/sort/sort-join.cuh) is outside this library's scope
+    return num_cols == 1 ? GDF_UNSUPPORTED_METHOD : GDF_JOIN_TOO_MANY_COLUMNS;
+  }
+  if (ctx->flag_method != GDF_HASH) return GDF_UNSUPPORTED_METHOD;
+
+  gdf_nvtx_range_push("LIBGDF_JOIN", GDF_CYAN);   // joining.cu:343
+  struct Pop { ~Pop() { gdf_nvtx_range_pop(); } } pop;
+
+  KeyTable lt, rt;
+  GDF_TRY(make_key_table(leftcol, num_cols, &lt));
+  GDF_TRY(make_key_table(rightcol, num_cols, &rt));
+  // compute_hash_join starts by clearing both outputs (join_compute_api.h:353-354)
+  gdf_column_view(left_result, nullptr, nullptr, 0, N_GDF_TYPES);
+  gdf_column_view(right_result, nullptr, nullptr, 0, N_GDF_TYPES);
+
+  // the table is built on the RIGHT relation; INNER builds on the smaller one (joining.h:58-66)
+  const bool flip = kind == JOIN_INNER && right_size > left_size;
+  int32_t *o_probe = nullptr, *o_build = nullptr;
+  int64_t n = 0;
+  GDF_TRY(hash_join_core(flip ? rt : lt, flip ? lt : rt, kind, &o_probe, &o_build, &n));
+  if (n == 0) return GDF_SUCCESS;   // size-0 outputs with dtype N_GDF_TYPES (join_compute_api.h:439-441)
+  gdf_column_view(left_result, flip ? o_build : o_probe, nullptr, (gdf_size_type)n, GDF_INT32);
+  gdf_column_view(right_result, flip ? o_probe : o_build, nullptr, (gdf_size_type)n, GDF_INT32);
+  return GDF_SUCCESS;
+}
+
+// ---------------------------------------------------------------------------
+// optional materialisation of the joined rows (joining.cu:375-479 + the gathers of
+// gdf_table.cuh:873-963): out = [left non-key..., key..., right non-key...]
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void jk_gather(const void *in, const uint8_t *in_valid, const int32_t *map, int64_t n,
+                                                 int width, void *out, uint32_t *out_valid) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t rounds = (n + stride - 1) / stride;
+  for (int64_t rnd = 0; rnd < rounds; ++rnd) {
+    const int64_t i = rnd * stride + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool valid = false;
+    if (i < n) {
+      const int32_t src = map[i];
+      if (src >= 0) {
+        valid = in_valid ? bit_is_set(in_valid, src) : true;
+        switch (width) {
+          case 1: ((uint8_t *)out)[i] = ((const uint8_t *)in)[src]; break;
+          case 2: ((uint16_t *)out)[i] = ((const uint16_t *)in)[src]; break;
+          case 4: ((uint32_t *)out)[i] = ((const uint32_t *)in)[src]; break;
+          default: ((uint64_t *)out)[i] = ((const uint64_t *)in)[src]; break;
+        }
+      }
+    }
+    // 64 consecutive rows -> two whole mask words, written without atomics
+    const unsigned long long m = __ballot(valid);
+    if (i < n) {
+      if (lane_id() == 0) out_valid[i >> 5] = (uint32_t)m;
+      if (lane_id() == 32) out_valid[i >> 5] = (uint32_t)(m >> 32);
+    }
+  }
+}
+
+static gdf_error gather_column(const gdf_column *src, const int32_t *map, int64_t n, gdf_column *dst) {
+  const int w = dtype_width(src->dtype);
+  if (w < 0) return GDF_UNSUPPORTED_DTYPE;
+  DevBuf data, valid;
+  RMM_TRY(data.alloc((size_t)w * (size_t)(n ? n : 1)));
+  const size_t vbytes = ((mask_bytes((size_t)n) + 7) / 8) * 8;   // whole 64-bit groups
+  RMM_TRY(valid.alloc(vbytes ? vbytes : 8));
+  HIP_TRY(hipMemsetAsync(valid.p, 0, vbytes ? vbytes : 8, stream0()));
+  if (n) {
+    // grid covers whole waves of 64 consecutive rows so the ballot words line up
+    hipLaunchKernelGGL(jk_gather, dim3(small_grid(n)), dim3(256), 0, stream0(), src->data, src->valid, map, n, w, data.p,
+                       valid.as<uint32_t>());
+    HIP_CHECK_LAST();
+  }
+  HIP_TRY(hipStreamSynchronize(stream0()));
+  gdf_column_view(dst, data.release(), (gdf_valid_type *)valid.release(), (gdf_size_type)n, src->dtype);
+  dst->dtype_info = src->dtype_info;
+  return GDF_SUCCESS;
+}
+
+__global__ __launch_bounds__(256) void jk_merge_neg(const int32_t *map, int64_t n, int width, void *dst, uint32_t *dst_valid,
+                                                    const void *src, const uint32_t *src_valid) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    if (map[i] >= 0) continue;
+    switch (width) {
+      case 1: ((uint8_t *)dst)[i] = ((const uint8_t *)src)[i]; break;
+      case 2: ((uint16_t *)dst)[i] = ((const uint16_t *)src)[i]; break;
+      case 4: ((uint32_t *)dst)[i] = ((const uint32_t *)src)[i]; break;
+      default: ((uint64_t *)dst)[i] = ((const uint64_t *)src)[i]; break;
+    }
+    if ((src_valid[i >> 5] >> (i & 31)) & 1) atomicOr(&dst_valid[i >> 5], 1u << (i & 31));
+  }
+}
+
+static gdf_error merge_where_negative(const int32_t *map, int64_t n, int width, gdf_column *dst, gdf_column *src) {
+  if (n == 0) return GDF_SUCCESS;
+  hipLaunchKernelGGL(jk_merge_neg, dim3(small_grid(n)), dim3(256), 0, stream0(), map, n, width, dst->data,
+                     (uint32_t *)dst->valid, src->data, (const uint32_t *)src->valid);
+  HIP_CHECK_LAST();
+  HIP_TRY(hipStreamSynchronize(stream0()));
+  return GDF_SUCCESS;
+}
+
+static gdf_error join_entry(JoinKind kind, gdf_column **left_cols, int num_left_cols, int left_join_cols[],
+                            gdf_column **right_cols, int num_right_cols, int right_join_cols[], int num_cols_to_join,
+                            int result_num_cols, gdf_column **result_cols, gdf_column *left_indices,
+                            gdf_column *right_indices, gdf_context *ctx) {
+  // joining.cu:495-511
+  if (nullptr == left_cols || nullptr == right_cols) return GDF_DATASET_EMPTY;
+  if (0 == num_cols_to_join) return GDF_SUCCESS;
+  if (nullptr == left_join_cols || nullptr == right_join_cols) return GDF_DATASET_EMPTY;
+  const bool compute_df = result_cols != nullptr;
+  if ((nullptr == left_indices || nullptr == right_indices) && !compute_df) return GDF_DATASET_EMPTY;
+  if (nullptr == ctx) return GDF_INVALID_API_CALL;
+
+  gdf_column tmp_l{}, tmp_r{};
+  gdf_column *lout = left_indices ? left_indices : &tmp_l;
+  gdf_column *rout = right_indices ? right_indices : &tmp_r;
+  struct Cleanup {   // temporaries created for the materialisation only
+    gdf_column *l, *r;
+    ~Cleanup() { if (l) gdf_column_free(l); if (r) gdf_column_free(r); }
+  } cleanup{left_indices ? nullptr : &tmp_l, right_indices ? nullptr : &tmp_r};
+
+  std::vector<gdf_column *> lj(num_cols_to_join), rj(num_cols_to_join);
+  for (int i = 0; i < num_cols_to_join; ++i) {
+    lj[i] = left_cols[left_join_cols[i]];
+    rj[i] = right_cols[right_join_cols[i]];
+  }
+  gdf_error err = join_call(kind, num_cols_to_join, lj.data(), rj.data(), lout, rout, ctx);
+  if (!compute_df || err != GDF_SUCCESS) return err;
+
+  // ---- materialise: [left non-key..., key columns..., right non-key...] ----
+  const int expect = num_left_cols + num_right_cols - num_cols_to_join;
+  if (result_num_cols != expect) return GDF_INVALID_API_CALL;
+  gdf_nvtx_range_push("LIBGDF_JOIN_OUTPUT", GDF_CYAN);   // joining.cu:391
+  struct Pop { ~Pop() { gdf_nvtx_range_pop(); } } pop;
+  const int64_t n = (int64_t)lout->size;
+  const int32_t *lmap = (const int32_t *)lout->data, *rmap = (const int32_t *)rout->data;
+  std::vector<char> l_is_key(num_left_cols, 0), r_is_key(num_right_cols, 0);
+  for (int i = 0; i < num_cols_to_join; ++i) { l_is_key[left_join_cols[i]] = 1; r_is_key[right_join_cols[i]] = 1; }
+  int o = 0;
+  for (int c = 0; c < num_left_cols; ++c)
+    if (!l_is_key[c]) GDF_TRY(gather_column(left_cols[c], lmap, n, result_cols[o++]));
+  for (int i = 0; i < num_cols_to_join; ++i) {
+    // key values come from the left row when there is one, else from the right (full join tail)
+    gdf_column *dst = result_cols[o++];
+    GDF_TRY(gather_column(left_cols[left_join_cols[i]], lmap, n, dst));
+    if (kind == JOIN_FULL) {
+      // rows with l == -1 take the right key: second gather into a scratch column, merged below
+      gdf_column scratch{};
+      GDF_TRY(gather_column(right_cols[right_join_cols[i]], rmap, n, &scratch));
+      // merge on device: where lmap < 0 copy scratch -> dst (data + valid bit)
+      gdf_error me = merge_where_negative(lmap, n, dtype_width(dst->dtype), dst, &scratch);
+      gdf_column_free(&scratch);
+      if (me != GDF_SUCCESS) return me;
+    }
+  }
+  for (int c = 0; c < num_right_cols; ++c)
+    if (!r_is_key[c]) GDF_TRY(gather_column(right_cols[c], rmap, n, result_cols[o++]));
+  HIP_CHECK_LAST();
+  return GDF_SUCCESS;
+}
+
+}  // namespace gdf_amd
+
+using namespace gdf_amd;
+
+extern "C" {
+
+gdf_error gdf_inner_join(gdf_column **left_cols, int num_left_cols, int left_join_cols[], gdf_column **right_cols,
+                         int num_right_cols, int right_join_cols[], int num_cols_to_join, int result_num_cols,
+                         gdf_column **result_cols, gdf_column *left_indices, gdf_column *right_indices,
+                         gdf_context *join_context) {
+  return join_entry(JOIN_INNER, left_cols, num_left_cols, left_join_cols, right_cols, num_right_cols, right_join_cols,
+                    num_cols_to_join, result_num_cols, result_cols, left_indices, right_indices, join_context);
+}
+
+gdf_error gdf_left_join(gdf_column **left_cols, int num_left_cols, int left_join_cols[], gdf_column **right_cols,
+                        int num_right_cols, int right_join_cols[], int num_cols_to_join, int result_num_cols,
+                        gdf_column **result_cols, gdf_column *left_indices, gdf_column *right_indices,
+                        gdf_context *join_context) {
+  return join_entry(JOIN_LEFT, left_cols, num_left_cols, left_join_cols, right_cols, num_right_cols, right_join_cols,
+                    num_cols_to_join, result_num_cols, result_cols, left_indices, right_indices, join_context);
+}
+
+gdf_error gdf_full_join(gdf_column **left_cols, int num_left_cols, int left_join_cols[], gdf_column **right_cols,
+                        int num_right_cols, int right_join_cols[], int num_cols_to_join, int result_num_cols,
+                        gdf_column **result_cols, gdf_column *left_indices, gdf_column *right_indices,
+                        gdf_context *join_context) {
+  return join_entry(JOIN_FULL, left_cols, num_left_cols, left_join_cols, right_cols, num_right_cols, right_join_cols,
+                    num_cols_to_join, result_num_cols, result_cols, left_indices, right_indices, join_context);
+}
+
+}  // extern "C"

@@ -1,0 +1,119 @@
+// plumbing.cpp -- host-only ABI helpers: column / context views, error names,
+// runtime error passthrough and profiler ranges.
+//
+// Behaviour follows the reference's src/column.cpp:160-275, src/context.cpp:3-11,
+// src/errorhandling.cpp:5-35, src/cudautils.cu:4-14 and src/nvtx_utils.cpp:19-71
+// (ranges are forwarded to roctx so they show up in rocprofv3 --marker-trace).
+#include "common.h"
+
+#include <cstdio>
+#include <roctracer/roctx.h>
+
+namespace gdf_amd {
+
+void note_hip_error(hipError_t e, const char *what, const char *file, int line) {
+  std::fprintf(stderr, "ERROR: HIP runtime call %s in line %d of file %s failed with %s (%d).\n", what, line, file,
+               hipGetErrorString(e), (int)e);
+}
+
+gdf_error make_key_table(gdf_column **cols, int ncols, KeyTable *out) {
+  if (ncols > MAX_KEY_COLS) return GDF_JOIN_TOO_MANY_COLUMNS;
+  out->ncols = ncols;
+  out->any_valid = 0;
+  out->nrows = ncols > 0 ? (int64_t)cols[0]->size : 0;
+  for (int c = 0; c < ncols; ++c) {
+    const ElemKind k = elem_kind(cols[c]->dtype);
+    if (k == K_BAD) return GDF_UNSUPPORTED_DTYPE;
+    out->col[c].data = cols[c]->data;
+    out->col[c].valid = cols[c]->valid;
+    out->col[c].kind = (int)k;
+    out->col[c].width = kind_width(k);
+    if (cols[c]->valid) out->any_valid = 1;
+  }
+  return GDF_SUCCESS;
+}
+
+}  // namespace gdf_amd
+
+extern "C" {
+
+gdf_size_type gdf_column_sizeof(void) { return sizeof(gdf_column); }
+
+gdf_error gdf_column_view(gdf_column *column, void *data, gdf_valid_type *valid, gdf_size_type size,
+                          gdf_dtype dtype) {
+  // dtype_info and col_name are deliberately left untouched (column.cpp:176-188)
+  column->data = data;
+  column->valid = valid;
+  column->size = size;
+  column->dtype = dtype;
+  column->null_count = 0;
+  return GDF_SUCCESS;
+}
+
+gdf_error gdf_column_view_augmented(gdf_column *column, void *data, gdf_valid_type *valid, gdf_size_type size,
+                                    gdf_dtype dtype, gdf_size_type null_count) {
+  column->data = data;
+  column->valid = valid;
+  column->size = size;
+  column->dtype = dtype;
+  column->null_count = null_count;
+  return GDF_SUCCESS;
+}
+
+gdf_error gdf_column_free(gdf_column *column) {
+  RMM_TRY(rmmFree(column->data, (cudaStream_t)0));
+  RMM_TRY(rmmFree(column->valid, (cudaStream_t)0));
+  return GDF_SUCCESS;
+}
+
+gdf_error get_column_byte_width(gdf_column *col, int *width) {
+  const int w = gdf_amd::dtype_width(col->dtype);
+  *width = w;   // -1 for unsupported, as column.cpp:268-271
+  return w > 0 ? GDF_SUCCESS : GDF_UNSUPPORTED_DTYPE;
+}
+
+gdf_error gdf_context_view(gdf_context *context, int flag_sorted, gdf_method flag_method, int flag_distinct,
+                           int flag_sort_result, int flag_sort_inplace) {
+  context->flag_sorted = flag_sorted;
+  context->flag_method = flag_method;
+  context->flag_distinct = flag_distinct;
+  context->flag_sort_result = flag_sort_result;
+  context->flag_sort_inplace = flag_sort_inplace;
+  return GDF_SUCCESS;
+}
+
+const char *gdf_error_get_name(gdf_error errcode) {
+  static const char *const names[N_GDF_ERRORS] = {
+      "GDF_SUCCESS", "GDF_CUDA_ERROR", "GDF_UNSUPPORTED_DTYPE", "GDF_COLUMN_SIZE_MISMATCH",
+      "GDF_COLUMN_SIZE_TOO_BIG", "GDF_DATASET_EMPTY", "GDF_VALIDITY_MISSING", "GDF_VALIDITY_UNSUPPORTED",
+      "GDF_INVALID_API_CALL", "GDF_JOIN_DTYPE_MISMATCH", "GDF_JOIN_TOO_MANY_COLUMNS", "GDF_DTYPE_MISMATCH",
+      "GDF_UNSUPPORTED_METHOD", "GDF_INVALID_AGGREGATOR", "GDF_INVALID_HASH_FUNCTION",
+      "GDF_PARTITION_DTYPE_MISMATCH", "GDF_HASH_TABLE_INSERT_FAILURE", "GDF_UNSUPPORTED_JOIN_TYPE", "GDF_C_ERROR",
+      "GDF_FILE_ERROR", "GDF_MEMORYMANAGER_ERROR", "GDF_UNDEFINED_NVTX_COLOR", "GDF_NULL_NVTX_NAME"};
+  if ((int)errcode < 0 || (int)errcode >= (int)N_GDF_ERRORS) return "Internal error. Unknown error code.";
+  return names[(int)errcode];
+}
+
+int gdf_cuda_last_error(void) { return (int)hipGetLastError(); }
+const char *gdf_cuda_error_string(int cuda_error) { return hipGetErrorString((hipError_t)cuda_error); }
+const char *gdf_cuda_error_name(int cuda_error) { return hipGetErrorName((hipError_t)cuda_error); }
+
+gdf_error gdf_nvtx_range_push(char const *const name, gdf_color color) {
+  if ((int)color < 0 || (int)color > (int)GDF_NUM_COLORS) return GDF_UNDEFINED_NVTX_COLOR;
+  if (!name) return GDF_NULL_NVTX_NAME;
+  roctxRangePushA(name);
+  return GDF_SUCCESS;
+}
+
+gdf_error gdf_nvtx_range_push_hex(char const *const name, unsigned int) {
+  if (!name) return GDF_NULL_NVTX_NAME;
+  roctxRangePushA(name);
+  return GDF_SUCCESS;
+}
+
+gdf_error gdf_nvtx_range_pop(void) {
+  roctxRangePop();
+  return GDF_SUCCESS;
+}
+
+}  // extern "C"

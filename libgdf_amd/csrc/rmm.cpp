@@ -1,0 +1,282 @@
+// rmm.cpp -- librmm.so: the device-memory manager behind include/memory.h.
+//
+// Same C ABI and error behaviour as the reference's src/memory/memory.cpp:138-298
+// (+ memory_manager.cpp:31-70 for the CSV event log), re-built on HIP:
+//   * CudaDefaultAllocation -> hipMalloc / hipFree per call;
+//   * PoolAllocation        -> a caching allocator: freed blocks are kept in a
+//     size-ordered free list and handed back to the next request that fits
+//     (the reference used cnmem, an absent submodule).  A relational call
+//     allocates and frees multi-GB scratch (partition buffers, join indices);
+//     with 288 GB of HBM per GPU holding on to those blocks is the right trade.
+// Thread safety: one mutex around the pool and one around the log, as the
+// reference's Manager (memory_manager.h:119-144).
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <mutex>
+#include <set>
+#include <sstream>
+#include <unordered_map>
+#include <vector>
+
+#include "memory.h"
+
+namespace {
+
+using Clock = std::chrono::system_clock;
+
+struct Event {
+  int kind;  // 0 alloc, 1 realloc, 2 free
+  int device;
+  void *ptr;
+  size_t size;
+  void *stream;
+  size_t free_mem, total_mem, live;
+  Clock::time_point t0, t1;
+};
+
+struct Manager {
+  std::mutex mu;
+  rmmOptions_t opt{CudaDefaultAllocation, 0, false};
+  bool initialized = false;
+
+  // pool state
+  std::multimap<size_t, void *> free_blocks;        // capacity -> block
+  std::unordered_map<void *, size_t> live_blocks;   // block -> capacity
+  size_t cached_bytes = 0, live_bytes = 0;
+
+  // log state
+  std::mutex log_mu;
+  std::vector<Event> events;
+  std::set<void *> current;
+  Clock::time_point base = Clock::now();
+
+  static Manager &get() { static Manager m; return m; }
+};
+
+inline bool pool_mode(Manager &m) { return m.opt.allocation_mode == PoolAllocation; }
+
+// round requests so that near-equal sizes recycle the same cached blocks
+inline size_t round_size(size_t n) {
+  if (n < 256) return 256;
+  if (n < (1u << 20)) return (n + 255) & ~size_t(255);          // 256 B granules below 1 MiB
+  return (n + ((size_t(1) << 20) - 1)) & ~((size_t(1) << 20) - 1);  // 1 MiB granules above
+}
+
+rmmError_t map_hip(hipError_t e) {
+  if (e == hipSuccess) return RMM_SUCCESS;
+  (void)hipGetLastError();   // do not leave a sticky error behind
+  return e == hipErrorOutOfMemory ? RMM_ERROR_OUT_OF_MEMORY : RMM_ERROR_CUDA_ERROR;
+}
+
+void release_cache_locked(Manager &m) {
+  for (auto &kv : m.free_blocks) (void)hipFree(kv.second);
+  m.free_blocks.clear();
+  m.cached_bytes = 0;
+}
+
+rmmError_t pool_alloc(Manager &m, void **ptr, size_t size) {
+  const size_t want = round_size(size);
+  std::lock_guard<std::mutex> g(m.mu);
+  auto it = m.free_blocks.lower_bound(want);
+  // accept a cached block only if it wastes at most half of itself
+  if (it != m.free_blocks.end() && it->first <= 2 * want) {
+    *ptr = it->second;
+    m.live_blocks[*ptr] = it->first;
+    m.cached_bytes -= it->first;
+    m.live_bytes += it->first;
+    m.free_blocks.erase(it);
+    return RMM_SUCCESS;
+  }
+  void *p = nullptr;
+  hipError_t e = hipMalloc(&p, want);
+  if (e == hipErrorOutOfMemory) {       // give cached blocks back and retry once
+    (void)hipGetLastError();
+    release_cache_locked(m);
+    e = hipMalloc(&p, want);
+  }
+  if (e != hipSuccess) return map_hip(e);
+  m.live_blocks[p] = want;
+  m.live_bytes += want;
+  *ptr = p;
+  return RMM_SUCCESS;
+}
+
+rmmError_t pool_free(Manager &m, void *ptr) {
+  if (!ptr) return RMM_SUCCESS;
+  std::lock_guard<std::mutex> g(m.mu);
+  auto it = m.live_blocks.find(ptr);
+  if (it == m.live_blocks.end()) return RMM_ERROR_INVALID_ARGUMENT;   // not ours
+  m.free_blocks.emplace(it->second, ptr);
+  m.cached_bytes += it->second;
+  m.live_bytes -= it->second;
+  m.live_blocks.erase(it);
+  return RMM_SUCCESS;
+}
+
+struct LogScope {   // mirrors the reference's rmm::LogIt (memory.cpp:52-108)
+  Manager &m; int kind; void *ptr; size_t size; void *stream; int dev = 0; Clock::time_point t0;
+  LogScope(Manager &m_, int k, void *p, size_t s, void *st) : m(m_), kind(k), ptr(p), size(s), stream(st) {
+    if (m.opt.enable_logging) { (void)hipGetDevice(&dev); t0 = Clock::now(); }
+  }
+  ~LogScope() {
+    if (!m.opt.enable_logging) return;
+    auto t1 = Clock::now();
+    size_t f = 0, t = 0;
+    (void)hipMemGetInfo(&f, &t);
+    std::lock_guard<std::mutex> g(m.log_mu);
+    if (kind == 0) m.current.insert(ptr); else if (kind == 2) m.current.erase(ptr);
+    m.events.push_back({kind, dev, ptr, size, stream, f, t, m.current.size(), t0, t1});
+  }
+};
+
+void write_csv(Manager &m, std::ostream &os) {
+  // header string is pinned by the reference's python/tests/test_rmm.py:52
+  os << "Event Type,Device ID,Address,Stream,Size (bytes),Free Memory,Total Memory,Current Allocs,Start,End,Elapsed\n";
+  std::lock_guard<std::mutex> g(m.log_mu);
+  for (auto &e : m.events) {
+    const char *name = e.kind == 0 ? "Alloc" : (e.kind == 1 ? "Realloc" : "Free");
+    std::chrono::duration<double> a = e.t0 - m.base, b = e.t1 - m.base, d = e.t1 - e.t0;
+    os << name << "," << e.device << "," << e.ptr << "," << e.stream << "," << e.size << "," << e.free_mem << ","
+       << e.total_mem << "," << e.live << "," << a.count() << "," << b.count() << "," << d.count() << std::endl;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+rmmError_t rmmInitialize(rmmOptions_t *options) {
+  Manager &m = Manager::get();
+  std::lock_guard<std::mutex> g(m.mu);
+  if (options) m.opt = *options;
+  m.initialized = true;
+  if (pool_mode(m) && m.opt.initial_pool_size > 0) {
+    // pre-warm the cache with one block of the requested size (cnmem reserved it up front)
+    void *p = nullptr;
+    const size_t want = round_size(m.opt.initial_pool_size);
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) return map_hip(e);
+    m.free_blocks.emplace(want, p);
+    m.cached_bytes += want;
+  }
+  return RMM_SUCCESS;
+}
+
+rmmError_t rmmFinalize(void) {
+  Manager &m = Manager::get();
+  {
+    std::lock_guard<std::mutex> g(m.mu);
+    release_cache_locked(m);
+    for (auto &kv : m.live_blocks) (void)hipFree(kv.first);   // leaked by the caller; the pool dies with us
+    m.live_blocks.clear();
+    m.live_bytes = 0;
+    m.initialized = false;
+  }
+  std::lock_guard<std::mutex> g(m.log_mu);
+  m.events.clear();
+  m.current.clear();
+  return RMM_SUCCESS;
+}
+
+const char *rmmGetErrorString(rmmError_t errcode) {
+  switch (errcode) {
+    case RMM_SUCCESS: return "RMM_SUCCESS";
+    case RMM_ERROR_CUDA_ERROR: return "RMM_ERROR_CUDA_ERROR";
+    case RMM_ERROR_INVALID_ARGUMENT: return "RMM_ERROR_INVALID_ARGUMENT";
+    case RMM_ERROR_NOT_INITIALIZED: return "RMM_ERROR_NOT_INITIALIZED";
+    case RMM_ERROR_OUT_OF_MEMORY: return "RMM_ERROR_OUT_OF_MEMORY";
+    case RMM_ERROR_UNKNOWN: return "RMM_ERROR_UNKNOWN";
+    case RMM_ERROR_IO: return "RMM_ERROR_IO";
+    default: return "Internal error. Unknown error code.";
+  }
+}
+
+rmmError_t rmmAlloc(void **ptr, size_t size, cudaStream_t stream) {
+  Manager &m = Manager::get();
+  LogScope log(m, 0, nullptr, size, stream);
+  if (!ptr && !size) return RMM_SUCCESS;
+  if (!ptr) return RMM_ERROR_INVALID_ARGUMENT;
+  rmmError_t r;
+  if (pool_mode(m)) r = pool_alloc(m, ptr, size);
+  else r = map_hip(hipMalloc(ptr, size));
+  if (r == RMM_SUCCESS) log.ptr = *ptr;
+  return r;
+}
+
+rmmError_t rmmFree(void *ptr, cudaStream_t stream) {
+  Manager &m = Manager::get();
+  LogScope log(m, 2, ptr, 0, stream);
+  if (pool_mode(m)) {
+    rmmError_t r = pool_free(m, ptr);
+    if (r != RMM_ERROR_INVALID_ARGUMENT) return r;
+    // a pointer allocated before the pool was switched on: release it directly
+  }
+  return map_hip(hipFree(ptr));
+}
+
+rmmError_t rmmRealloc(void **ptr, size_t new_size, cudaStream_t stream) {
+  Manager &m = Manager::get();
+  LogScope log(m, 1, nullptr, new_size, stream);
+  if (!ptr && !new_size) return RMM_SUCCESS;
+  if (!ptr) return RMM_ERROR_INVALID_ARGUMENT;
+  // like the reference (memory.cpp:207-231): free then allocate, contents are NOT preserved
+  rmmError_t r = pool_mode(m) ? pool_free(m, *ptr) : map_hip(hipFree(*ptr));
+  if (r == RMM_ERROR_INVALID_ARGUMENT && pool_mode(m)) r = map_hip(hipFree(*ptr));
+  if (r != RMM_SUCCESS) return r;
+  r = pool_mode(m) ? pool_alloc(m, ptr, new_size) : map_hip(hipMalloc(ptr, new_size));
+  if (r == RMM_SUCCESS) log.ptr = *ptr;
+  return r;
+}
+
+rmmError_t rmmGetAllocationOffset(offset_t *offset, void *ptr, cudaStream_t) {
+  if (!offset) return RMM_ERROR_INVALID_ARGUMENT;
+  hipDeviceptr_t base = nullptr;
+  size_t extent = 0;
+  if (hipMemGetAddressRange(&base, &extent, (hipDeviceptr_t)ptr) != hipSuccess) {
+    (void)hipGetLastError();
+    return RMM_ERROR_INVALID_ARGUMENT;
+  }
+  *offset = (offset_t)((char *)ptr - (char *)base);
+  return RMM_SUCCESS;
+}
+
+rmmError_t rmmGetInfo(size_t *freeSize, size_t *totalSize, cudaStream_t) {
+  if (!freeSize || !totalSize) return RMM_ERROR_INVALID_ARGUMENT;
+  Manager &m = Manager::get();
+  hipError_t e = hipMemGetInfo(freeSize, totalSize);
+  if (e != hipSuccess) return map_hip(e);
+  if (pool_mode(m)) {   // cached blocks are available to the next rmmAlloc
+    std::lock_guard<std::mutex> g(m.mu);
+    *freeSize += m.cached_bytes;
+  }
+  return RMM_SUCCESS;
+}
+
+rmmError_t rmmWriteLog(const char *filename) {
+  if (!filename) return RMM_ERROR_IO;
+  std::ofstream f(filename);
+  if (!f.good()) return RMM_ERROR_IO;
+  write_csv(Manager::get(), f);
+  return f.good() ? RMM_SUCCESS : RMM_ERROR_IO;
+}
+
+size_t rmmLogSize(void) {
+  std::ostringstream s;
+  write_csv(Manager::get(), s);
+  return s.str().size();
+}
+
+rmmError_t rmmGetLog(char *buffer, size_t buffer_size) {
+  if (!buffer) return RMM_ERROR_INVALID_ARGUMENT;
+  std::ostringstream s;
+  write_csv(Manager::get(), s);
+  const std::string str = s.str();
+  std::memcpy(buffer, str.data(), std::min(buffer_size, str.size()));
+  return RMM_SUCCESS;
+}
+
+}  // extern "C"

@@ -1,0 +1,47 @@
+// unsupported.cpp -- exported stubs for the reference entry points that are
+// outside the relational hot path.  The cffi
+// binding resolves symbols lazily (python/libgdf_cffi/wrapper.py:13-34), so a
+// caller only meets these when it actually calls one; it then gets
+// GDF_UNSUPPORTED_METHOD (or a null handle) instead of a missing-symbol crash.
+#include "gdf/gdf.h"
+
+extern "C" {
+
+#define GDF_DECL_UNARY(name)     gdf_error name(gdf_column *, gdf_column *) { return GDF_UNSUPPORTED_METHOD; }
+#define GDF_DECL_UNARY_TU(name)  gdf_error name(gdf_column *, gdf_column *, gdf_time_unit) { return GDF_UNSUPPORTED_METHOD; }
+#define GDF_DECL_BINARY(name)    gdf_error name(gdf_column *, gdf_column *, gdf_column *) { return GDF_UNSUPPORTED_METHOD; }
+#define GDF_DECL_REDUCE(name, T) gdf_error name(gdf_column *, T *, gdf_size_type) { return GDF_UNSUPPORTED_METHOD; }
+#define GDF_DECL_RSORT(name)     gdf_error name(gdf_radixsort_plan_type *, gdf_column *, gdf_column *) { return GDF_UNSUPPORTED_METHOD; }
+#define GDF_DECL_SEGSORT(name)                                                                        \
+  gdf_error name(gdf_segmented_radixsort_plan_type *, gdf_column *, gdf_column *, unsigned, unsigned *, \
+                 unsigned *) { return GDF_UNSUPPORTED_METHOD; }
+#include "gdf/gdf_unsupported.def"
+
+gdf_ipc_parser_type *gdf_ipc_parser_open(const uint8_t *, size_t) { return nullptr; }
+void gdf_ipc_parser_open_recordbatches(gdf_ipc_parser_type *, const uint8_t *, size_t) {}
+void gdf_ipc_parser_close(gdf_ipc_parser_type *) {}
+int gdf_ipc_parser_failed(gdf_ipc_parser_type *) { return 1; }
+const char *gdf_ipc_parser_to_json(gdf_ipc_parser_type *) { return "{}"; }
+const char *gdf_ipc_parser_get_error(gdf_ipc_parser_type *) { return "Arrow IPC parsing is not part of this library"; }
+const void *gdf_ipc_parser_get_data(gdf_ipc_parser_type *) { return nullptr; }
+int64_t gdf_ipc_parser_get_data_offset(gdf_ipc_parser_type *) { return 0; }
+const char *gdf_ipc_parser_get_schema_json(gdf_ipc_parser_type *) { return "{}"; }
+const char *gdf_ipc_parser_get_layout_json(gdf_ipc_parser_type *) { return "{}"; }
+
+gdf_radixsort_plan_type *gdf_radixsort_plan(size_t, int, unsigned, unsigned) { return nullptr; }
+gdf_error gdf_radixsort_plan_setup(gdf_radixsort_plan_type *, size_t, size_t) { return GDF_UNSUPPORTED_METHOD; }
+gdf_error gdf_radixsort_plan_free(gdf_radixsort_plan_type *) { return GDF_UNSUPPORTED_METHOD; }
+gdf_segmented_radixsort_plan_type *gdf_segmented_radixsort_plan(size_t, int, unsigned, unsigned) { return nullptr; }
+gdf_error gdf_segmented_radixsort_plan_setup(gdf_segmented_radixsort_plan_type *, size_t, size_t) { return GDF_UNSUPPORTED_METHOD; }
+gdf_error gdf_segmented_radixsort_plan_free(gdf_segmented_radixsort_plan_type *) { return GDF_UNSUPPORTED_METHOD; }
+
+unsigned int gdf_reduce_optimal_output_size(void) { return 0; }
+gdf_error gpu_concat(gdf_column *, gdf_column *, gdf_column *) { return GDF_UNSUPPORTED_METHOD; }
+gdf_error gpu_hash_columns(gdf_column **, int, gdf_column *, void *) { return GDF_UNSUPPORTED_METHOD; }
+gdf_error gdf_order_by(size_t, gdf_column *, size_t, void **, int *, size_t *) { return GDF_UNSUPPORTED_METHOD; }
+gdf_error gdf_quantile_exact(gdf_column *, gdf_quantile_method, double, void *, gdf_context *) { return GDF_UNSUPPORTED_METHOD; }
+gdf_error gdf_quantile_aprrox(gdf_column *, double, void *, gdf_context *) { return GDF_UNSUPPORTED_METHOD; }
+gdf_error read_csv(csv_read_arg *) { return GDF_UNSUPPORTED_METHOD; }
+gdf_error gdf_to_csr(gdf_column **, int, csr_gdf *) { return GDF_UNSUPPORTED_METHOD; }
+
+}  // extern "C"

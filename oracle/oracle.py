@@ -1,0 +1,190 @@
+"""Python face of the CPU oracle (TEST INFRASTRUCTURE -- see gdf_oracle.c's header).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+Byte/integer algorithms live in gdf_oracle.c (gcc); element-wise expectations that the reference's own
+Python tests state as numpy expressions (np.cumsum for prefix sums, python/tests/test_prefixsum.py:55;
+``&`` of mask bytes, test_validity.py:59-74) are numpy here as well.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_DIR, "liboracle.so")
+
+K_OF = {np.dtype(np.int8): 0, np.dtype(np.int16): 1, np.dtype(np.int32): 2, np.dtype(np.int64): 3,
+        np.dtype(np.float32): 4, np.dtype(np.float64): 5, np.dtype(np.bool_): 0}
+NP_OF_KIND = {0: np.int8, 1: np.int16, 2: np.int32, 3: np.int64, 4: np.float32, 5: np.float64}
+OPS = {"sum": 0, "min": 1, "max": 2, "avg": 3, "count": 4}
+JOINS = {"inner": 0, "left": 1, "full": 2}
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(os.path.join(_DIR, "gdf_oracle.c")):
+        subprocess.check_call(["make", "-C", _DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.orc_murmur3_32.restype = C.c_uint32
+        _lib.orc_murmur3_32.argtypes = [C.c_void_p, C.c_int]
+        _lib.orc_hash_combine.restype = C.c_uint32
+        _lib.orc_hash_combine.argtypes = [C.c_uint32, C.c_uint32]
+        _lib.orc_identity_hash.restype = C.c_uint32
+        _lib.orc_identity_hash.argtypes = [C.c_void_p, C.c_int]
+        _lib.orc_join.restype = C.c_int64
+        _lib.orc_group_by.restype = C.c_int64
+        _lib.orc_free.argtypes = [C.c_void_p]
+    return _lib
+
+
+def _ptr_array(arrays):
+    return (C.c_void_p * len(arrays))(*[a.ctypes.data if a is not None else None for a in arrays])
+
+
+def _kinds(arrays):
+    return (C.c_int * len(arrays))(*[K_OF[a.dtype] for a in arrays])
+
+
+def _contig(arrays):
+    return [np.ascontiguousarray(a) for a in arrays]
+
+
+def murmur3_32(value: np.generic | np.ndarray) -> int:
+    a = np.ascontiguousarray(value)
+    return int(lib().orc_murmur3_32(a.ctypes.data, a.dtype.itemsize))
+
+
+def hash_combine(l: int, r: int) -> int:
+    return int(lib().orc_hash_combine(l, r))
+
+
+def identity_hash(value) -> int:
+    a = np.ascontiguousarray(value)
+    return int(lib().orc_identity_hash(a.ctypes.data, K_OF[a.dtype]))
+
+
+def hash_rows(cols, identity=False) -> np.ndarray:
+    """gdf_hash expectation: uint32 row hash (hashing.cu:83-154)."""
+    cols = _contig(cols)
+    n = len(cols[0])
+    out = np.empty(n, dtype=np.uint32)
+    lib().orc_hash_rows(len(cols), _ptr_array(cols), _kinds(cols), C.c_int64(n), int(identity), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def partition_ids(cols, nparts, identity=False) -> np.ndarray:
+    cols = _contig(cols)
+    n = len(cols[0])
+    out = np.empty(n, dtype=np.uint32)
+    lib().orc_partition_ids(len(cols), _ptr_array(cols), _kinds(cols), C.c_int64(n), int(identity), C.c_uint32(nparts),
+                            out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def hash_partition(cols, cols_to_hash, nparts, identity=False):
+    """Stable reference partitioning: (permutation, offsets).  The reference leaves the order inside a
+    partition unspecified; tests compare partition CONTENTS as multisets plus the offsets."""
+    pid = partition_ids([cols[i] for i in cols_to_hash], nparts, identity)
+    perm = np.argsort(pid, kind="stable")
+    counts = np.bincount(pid, minlength=nparts)
+    offsets = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int64)
+    return perm, offsets, pid
+
+
+def _mask_bytes(valid):
+    return None if valid is None else np.ascontiguousarray(np.packbits(np.asarray(valid, dtype=bool), bitorder="little"))
+
+
+def join(left, right, how="inner", left_valid=None, right_valid=None):
+    """Sorted (l, r) index pairs of the equi-join on all given columns.  *_valid: per-column bool arrays or None."""
+    left, right = _contig(left), _contig(right)
+    nl, nr = len(left[0]), len(right[0])
+    lv = [_mask_bytes(v) for v in (left_valid or [None] * len(left))]
+    rv = [_mask_bytes(v) for v in (right_valid or [None] * len(right))]
+    ol, orr = C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)()
+    n = lib().orc_join(JOINS[how], len(left), _kinds(left), _ptr_array(left), _ptr_array(lv), C.c_int64(nl),
+                       _ptr_array(right), _ptr_array(rv), C.c_int64(nr), C.byref(ol), C.byref(orr))
+    l = np.ctypeslib.as_array(ol, shape=(max(n, 1),))[:n].copy()
+    r = np.ctypeslib.as_array(orr, shape=(max(n, 1),))[:n].copy()
+    lib().orc_free(ol)
+    lib().orc_free(orr)
+    return l, r
+
+
+def group_by(op, keys, values, out_dtype=None):
+    """(sorted key arrays, aggregate array).  Aggregation in the input dtype; COUNT / AVG in out_dtype."""
+    keys = _contig(keys)
+    values = np.ascontiguousarray(values)
+    n = len(keys[0])
+    out_dtype = np.dtype(values.dtype if out_dtype is None else out_dtype)
+    agg_dtype = out_dtype if op in ("count", "avg") else values.dtype
+    out_keys = [np.empty(n, dtype=k.dtype) for k in keys]
+    out_agg = np.empty(n, dtype=agg_dtype)
+    g = lib().orc_group_by(OPS[op], len(keys), _kinds(keys), _ptr_array(keys), C.c_int64(n), values.ctypes.data_as(C.c_void_p),
+                           K_OF[values.dtype], K_OF[out_dtype], _ptr_array(out_keys), out_agg.ctypes.data_as(C.c_void_p))
+    return [k[:g] for k in out_keys], out_agg[:g]
+
+
+# ---- numpy expectations -------------------------------------------------------------------------
+def prefixsum(a: np.ndarray, inclusive=True) -> np.ndarray:
+    """np.cumsum in the column dtype (wraps), reference python/tests/test_prefixsum.py:55."""
+    inc = np.cumsum(a, dtype=a.dtype)
+    if inclusive:
+        return inc
+    out = np.empty_like(inc)
+    out[0:1] = 0
+    out[1:] = inc[:-1]
+    return out
+
+
+_CMP = [np.equal, np.not_equal, np.less, np.less_equal, np.greater, np.greater_equal]
+
+
+def comparison(lhs: np.ndarray, rhs, op: int) -> np.ndarray:
+    """int8 stencil of op(lhs, rhs) under the usual arithmetic conversions (filterops.cu:17-75, with the
+    reference's swapped </<= functors corrected -- SURVEY.md 8a quirk 1)."""
+    l = np.asarray(lhs)
+    r = np.asarray(rhs)
+    common = np.result_type(l.dtype, r.dtype)
+    # C promotes (int64, float32) to float32; numpy would pick float64
+    if {l.dtype.kind, r.dtype.kind} == {"i", "f"}:
+        common = l.dtype if l.dtype.kind == "f" else r.dtype
+    return _CMP[op](l.astype(common), r.astype(common)).astype(np.int8)
+
+
+def apply_stencil(lhs: np.ndarray, stencil: np.ndarray, stencil_valid=None) -> np.ndarray:
+    keep = np.asarray(stencil) != 0
+    if stencil_valid is not None:
+        keep &= np.asarray(stencil_valid, dtype=bool)
+    return np.asarray(lhs)[keep]
+
+
+def filter_rows(cols, values) -> np.ndarray:
+    keep = np.ones(len(cols[0]), dtype=bool)
+    for c, v in zip(cols, values):
+        keep &= np.asarray(c) == np.asarray(v, dtype=np.asarray(c).dtype)
+    return np.nonzero(keep)[0].astype(np.uint64)
+
+
+def count_nonzero_mask(mask_bytes: np.ndarray, nrows: int) -> int:
+    return int(np.unpackbits(np.asarray(mask_bytes, dtype=np.uint8), bitorder="little")[:nrows].sum())
+
+
+# ---- synthetic generators shared by tests and bench (pure functions of (seed, i)) -----------------
+def splitmix64(x: np.ndarray) -> np.ndarray:
+    x = (np.asarray(x, dtype=np.uint64) + np.uint64(0x9E3779B97F4A7C15))
+    z = x
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))

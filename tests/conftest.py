@@ -1,0 +1,29 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(autouse=True)
+def _seed():
+    # the reference seeds its python tests with 0xabcdef (python/tests/conftest.py:14-20, utils.py:31-33)
+    np.random.seed(0xabcdef)
+    yield
+
+
+@pytest.fixture(scope="session")
+def gdf():
+    """The GPU-side package.  Imports torch first so one HIP runtime serves torch and libgdf.so."""
+    import torch
+    assert torch.cuda.is_available(), "-m gpu tests need a GPU"
+    import libgdf_amd
+    return libgdf_amd

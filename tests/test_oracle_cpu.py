@@ -1,0 +1,91 @@
+"""The oracle against independent CPU formulations (pandas / numpy), including BASELINE config C1:
+1M-row int32 group-by-sum through the pandas reference path (plumbing, no GPU)."""
+import numpy as np
+import pandas as pd
+import pytest
+
+from oracle import oracle
+from util import gen_rand, random_valid, sort_pairs
+
+
+@pytest.mark.parametrize("how", ["inner", "left", "full"])
+@pytest.mark.parametrize("dtype", [np.int32, np.int64, np.float64])
+def test_join_matches_pandas(how, dtype):
+    l = gen_rand(dtype, 2000, low=0, high=300) if np.dtype(dtype).kind == "i" else np.round(gen_rand(dtype, 2000) * 50)
+    r = gen_rand(dtype, 700, low=0, high=300) if np.dtype(dtype).kind == "i" else np.round(gen_rand(dtype, 700) * 50)
+    li, ri = oracle.join([l], [r], how)
+    ldf = pd.DataFrame({"k": l, "l": np.arange(len(l))})
+    rdf = pd.DataFrame({"k": r, "r": np.arange(len(r))})
+    m = ldf.merge(rdf, on="k", how={"inner": "inner", "left": "left", "full": "outer"}[how])
+    el = m["l"].fillna(-1).astype(np.int64).to_numpy()
+    er = m["r"].fillna(-1).astype(np.int64).to_numpy()
+    a, b = sort_pairs(li, ri)
+    c, d = sort_pairs(el, er)
+    np.testing.assert_array_equal(a, c)
+    np.testing.assert_array_equal(b, d)
+
+
+def test_join_nulls_never_match():
+    l = np.array([1, 2, 3, 4], dtype=np.int32)
+    r = np.array([2, 3, 4, 4], dtype=np.int32)
+    lv = [np.array([1, 1, 0, 1], dtype=bool)]
+    rv = [np.array([1, 1, 1, 0], dtype=bool)]
+    li, ri = oracle.join([l], [r], "inner", lv, rv)
+    assert list(zip(li, ri)) == [(1, 0), (3, 2)]
+    li, ri = oracle.join([l], [r], "left", lv, rv)
+    assert list(zip(li, ri)) == [(0, -1), (1, 0), (2, -1), (3, 2)]
+    li, ri = oracle.join([l], [r], "full", lv, rv)
+    assert list(zip(li, ri)) == [(-1, 1), (-1, 3), (0, -1), (1, 0), (2, -1), (3, 2)]
+
+
+def test_join_multi_column():
+    a0 = gen_rand(np.int32, 500, 0, 8); a1 = gen_rand(np.int64, 500, 0, 8)
+    b0 = gen_rand(np.int32, 300, 0, 8); b1 = gen_rand(np.int64, 300, 0, 8)
+    li, ri = oracle.join([a0, a1], [b0, b1], "inner")
+    m = pd.DataFrame({"x": a0, "y": a1, "l": np.arange(500)}).merge(pd.DataFrame({"x": b0, "y": b1, "r": np.arange(300)}), on=["x", "y"])
+    a, b = sort_pairs(li, ri)
+    c, d = sort_pairs(m["l"].to_numpy(), m["r"].to_numpy())
+    np.testing.assert_array_equal(a, c)
+    np.testing.assert_array_equal(b, d)
+
+
+def test_c1_one_million_row_int32_groupby_sum_vs_pandas():
+    """BASELINE.json configs[0]."""
+    n = 1_000_000
+    k = np.random.randint(0, 1000, size=n).astype(np.int32)
+    v = np.random.randint(-10000, 10000, size=n).astype(np.int32)
+    keys, agg = oracle.group_by("sum", [k], v)
+    exp = pd.DataFrame({"k": k, "v": v.astype(np.int64)}).groupby("k")["v"].sum()
+    np.testing.assert_array_equal(keys[0], exp.index.to_numpy().astype(np.int32))
+    np.testing.assert_array_equal(agg, exp.to_numpy().astype(np.int32))     # int32 wrap-around semantics
+
+
+@pytest.mark.parametrize("op", ["sum", "min", "max", "count", "avg"])
+def test_groupby_ops_vs_pandas(op):
+    n = 20000
+    k0 = gen_rand(np.int32, n, 0, 40); k1 = gen_rand(np.int64, n, 0, 5)
+    v = gen_rand(np.float64, n)
+    out_dtype = np.int64 if op == "count" else np.float64
+    keys, agg = oracle.group_by(op, [k0, k1], v, out_dtype=out_dtype)
+    g = pd.DataFrame({"a": k0, "b": k1, "v": v}).groupby(["a", "b"])["v"]
+    exp = {"sum": g.sum, "min": g.min, "max": g.max, "count": g.count, "avg": g.mean}[op]()
+    np.testing.assert_array_equal(keys[0], exp.index.get_level_values(0).to_numpy())
+    np.testing.assert_array_equal(keys[1], exp.index.get_level_values(1).to_numpy())
+    np.testing.assert_allclose(agg, exp.to_numpy(), rtol=1e-9)
+
+
+def test_partition_ids_rule():
+    k = gen_rand(np.int64, 5000)
+    h = oracle.hash_rows([k])
+    for p in (1, 5, 8, 10, 257):
+        pid = oracle.partition_ids([k], p)
+        exp = h & np.uint32(p - 1) if p & (p - 1) == 0 else h % np.uint32(p)
+        np.testing.assert_array_equal(pid, exp)
+
+
+def test_comparison_uses_c_promotions():
+    l = np.array([2**24 + 1, 5], dtype=np.int64)
+    r = np.array([2**24, 5], dtype=np.float32)
+    # int64 vs float32 compares in float32: 2^24+1 rounds to 2^24 -> "equal"
+    assert list(oracle.comparison(l, r, 0)) == [1, 1]
+    assert list(oracle.comparison(np.array([1, 2, 3], dtype=np.int8), np.int32(2), 2)) == [1, 0, 0]     # correct '<'

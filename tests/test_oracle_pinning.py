@@ -1,0 +1,133 @@
+"""Pins the CPU oracle before anything is compared against it (no GPU needed):
+  * Murmur3_32 / hash_combine / IdentityHash against golden vectors captured from the reference's own
+    header (tests/golden/murmur3_32.json, made by tests/golden/make_golden.py), and -- when the build
+    container's oracle/_ref/libref_hash.so is present -- against the reference functors live;
+  * group-by and filter semantics against the known-answer vectors of the reference's sqls tests
+    (tests/golden/sqls_known_answers.json);
+  * the numpy expectations against the statements in the reference's python tests."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+NP = {"i8": np.int8, "i16": np.int16, "i32": np.int32, "i64": np.int64, "f32": np.float32, "f64": np.float64}
+
+
+@pytest.fixture(scope="module")
+def golden():
+    with open(os.path.join(GOLD, "murmur3_32.json")) as f:
+        return json.load(f)
+
+
+def test_murmur3_golden(golden):
+    n = 0
+    for name, entries in golden["murmur3_32"].items():
+        for e in entries:
+            v = np.frombuffer(bytes.fromhex(e["bytes"]), dtype=NP[name])
+            assert oracle.murmur3_32(v) == e["hash"], (name, e)
+            n += 1
+    assert n >= 180
+
+
+def test_survey_table_values():
+    # SURVEY.md 8c table (captured from the reference header during the survey)
+    assert oracle.murmur3_32(np.int32(0)) == 593689054
+    assert oracle.murmur3_32(np.int32(1)) == 4226891818
+    assert oracle.murmur3_32(np.int32(-1)) == 1982413648
+    assert oracle.murmur3_32(np.int64(0)) == 1669671676
+    assert oracle.murmur3_32(np.int64(1)) == 1392991556
+    assert oracle.murmur3_32(np.int64(-1)) == 1651860712
+    assert oracle.murmur3_32(np.int64(123456789012345)) == 3825968124
+    assert oracle.murmur3_32(np.float64(1.5)) == 4034560987
+    assert oracle.murmur3_32(np.float32(1.5)) == 376679366
+    assert oracle.murmur3_32(np.int8(7)) == 1753412482
+    assert oracle.murmur3_32(np.int16(300)) == 3578234270
+    assert oracle.hash_combine(oracle.murmur3_32(np.int32(1)), oracle.murmur3_32(np.int32(2))) == 3787935720
+    assert oracle.identity_hash(np.int64(0x1FFFFFFFF)) == 4294967295
+
+
+def test_hash_combine_and_identity_golden(golden):
+    for e in golden["hash_combine"]:
+        assert oracle.hash_combine(e["l"], e["r"]) == e["out"]
+    for e in golden["identity"]["i64"]:
+        assert oracle.identity_hash(np.int64(e["v"])) == e["out"]
+    for e in golden["identity"]["i32"]:
+        assert oracle.identity_hash(np.int32(e["v"])) == e["out"]
+
+
+def test_against_live_reference_header():
+    path = os.path.join(HERE, "..", "oracle", "_ref", "libref_hash.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref not built (reference tree absent)")
+    ref = C.CDLL(path)
+    rng = np.random.RandomState(7)
+    for name, dt in NP.items():
+        fn = getattr(ref, "ref_murmur_" + name)
+        fn.restype = C.c_uint32
+        fn.argtypes = [C.c_void_p]
+        raw = rng.randint(0, 256, size=(500, np.dtype(dt).itemsize), dtype=np.uint8)
+        vals = raw.view(dt).reshape(-1)
+        for i in range(len(vals)):
+            assert oracle.murmur3_32(vals[i:i + 1]) == fn(vals[i:i + 1].ctypes.data)
+    ref.ref_hash_combine.restype = C.c_uint32
+    ref.ref_hash_combine.argtypes = [C.c_uint32, C.c_uint32]
+    for l, r in rng.randint(0, 2**32, size=(500, 2), dtype=np.int64):
+        assert oracle.hash_combine(int(l), int(r)) == ref.ref_hash_combine(int(l), int(r))
+
+
+def test_row_hash_folds_columns_left_to_right():
+    a = np.array([1, 5, 1], dtype=np.int32)
+    b = np.array([2, 6, 2], dtype=np.int32)
+    h = oracle.hash_rows([a, b])
+    assert h[0] == 3787935720 and h[0] == h[2] and h[0] != h[1]
+    assert oracle.hash_rows([a])[0] == 4226891818          # first column is not combined (gdf_table.cuh:730-733)
+
+
+@pytest.fixture(scope="module")
+def sqls():
+    with open(os.path.join(GOLD, "sqls_known_answers.json")) as f:
+        return json.load(f)
+
+
+def test_group_by_known_answers(sqls):
+    g = sqls["group_by"]
+    keys = [np.array(g["keys"][c]["values"], dtype=g["keys"][c]["dtype"]) for c in ("c0", "c1", "c2")]
+    for case in g["cases"]:
+        vals = np.array(case["agg"]["values"], dtype=case["agg"]["dtype"])
+        out_keys, agg = oracle.group_by(case["op"], keys, vals, out_dtype=case["out_dtype"])
+        for c, name in zip(out_keys, ("c0", "c1", "c2")):
+            assert list(c) == g["expected_keys"][name], case["ref"]
+        assert list(agg) == case["expected"], case["ref"]
+
+
+def test_filter_known_answer(sqls):
+    f = sqls["filter"]
+    cols = [np.array(f["cols"][c]["values"], dtype=f["cols"][c]["dtype"]) for c in ("c0", "c1", "c2")]
+    idx = oracle.filter_rows(cols, f["tuple"])
+    assert len(idx) == f["expected_size"] and list(idx) == f["expected_indices"]
+
+
+def test_prefixsum_matches_numpy_statement():
+    for dt in (np.int8, np.int32, np.int64):
+        for n in (1, 2, 13, 64, 100, 1000):           # python/tests/test_prefixsum.py:16-62
+            a = np.random.randint(-100, 100, size=n).astype(dt)
+            np.testing.assert_array_equal(oracle.prefixsum(a, True), np.cumsum(a, dtype=dt))
+            ex = oracle.prefixsum(a, False)
+            assert ex[0] == 0 and np.array_equal(ex[1:], np.cumsum(a, dtype=dt)[:-1])
+
+
+def test_int8_sum_wraps_in_input_dtype():
+    keys = [np.zeros(4, dtype=np.int32)]
+    vals = np.array([100, 100, 100, 27], dtype=np.int8)          # 327 -> 71 (mod 256)
+    _, agg = oracle.group_by("sum", keys, vals)
+    assert agg.dtype == np.int8 and agg[0] == np.int8(71)
+    _, avg = oracle.group_by("avg", keys, vals, out_dtype=np.float64)
+    assert avg[0] == 71 / 4.0                                      # sum wraps BEFORE the division (groupby.cuh:308-328)
+    _, avgi = oracle.group_by("avg", keys, vals, out_dtype=np.int32)
+    assert avgi[0] == 71 // 4

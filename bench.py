@@ -1,0 +1,230 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json metric: hash-join probe rows/s (+ HBM roofline fraction), 1 B int64 rows.
+
+A "step" is ONE gdf_inner_join call (HASH method) through the C ABI of libgdf.so over synthetic columns
+that are already resident in HBM:
+  N = 1  : config C3 (BASELINE.json configs[2]) -- probe 1,000,000,000 int64 rows, build 100,000,000
+           unique int64 keys (a seeded permutation of [0, N_b)), probe key = splitmix64(seed + i) % N_b, so
+           every probe row matches exactly once and N_out = N_p; indices only (result_cols = NULL).
+  N > 1  : config C4 -- the same per-rank shard sizes (1e9 probe + 1.25e8 build rows per GPU over a global
+           key space), both relations hash-partitioned on key across the ranks and exchanged with one RCCL
+           all-to-all each (libgdf_amd/multigpu.py), then joined locally.  Weak scaling.
+value = probe rows of all ranks / max-over-ranks time.  The roofline object prices the dominant kernel
+(live HIP-event timing inside libgdf.so, see csrc/prof.h); roofline_e2e prices the whole call with the
+algorithmic bytes of SURVEY.md 8d (8*N_p + 8*N_b + 8*N_out).  cpu_baseline times oracle/gdf_oracle.c (a
+single-threaded C port of the reference algorithm) on a bounded sample of the same workload.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+# per-kernel algorithmic bytes per unit (DESIGN.md "Kernels"): what the kernel must move by its own contract
+KERNEL_BYTES = {
+    "jk_hist": lambda npr, nb: 8.0 * (npr + nb),                   # reads every key once
+    "jk_scatter1": lambda npr, nb: (8.0 + 12.0) * (npr + nb),      # key in, (key,row) tuple out
+    "jk_scatter2": lambda npr, nb: (12.0 + 12.0) * (npr + nb),     # tuple in, tuple out
+    "jk_probe_count": lambda npr, nb: 12.0 * (npr + nb),           # tuples in
+    "jk_probe_write": lambda npr, nb: 12.0 * (npr + nb) + 8.0 * npr,   # tuples in, index pair out
+}
+
+
+def splitmix64_torch(x):
+    """splitmix64 on int64 tensors (two's-complement wrap == uint64 arithmetic); logical shifts emulated."""
+    import torch
+
+    def lsr(v, k):
+        return (v >> k) & ((1 << (64 - k)) - 1)
+    z = x + (-7046029254386353131)            # 0x9E3779B97F4A7C15
+    z = (z ^ lsr(z, 30)) * (-4658895280553007687)    # 0xBF58476D1CE4E5B9
+    z = (z ^ lsr(z, 27)) * (-7723592293110705685)    # 0x94D049BB133111EB
+    return z ^ lsr(z, 31)
+
+
+def make_probe_keys(n, key_space, seed, device, offset=0):
+    """probe[i] = (splitmix64(seed + offset + i) >> 1) % key_space, generated in slices to bound temporaries."""
+    import torch
+    out = torch.empty(n, dtype=torch.int64, device=device)
+    step = 1 << 27
+    for s in range(0, n, step):
+        e = min(n, s + step)
+        i = torch.arange(s + offset, e + offset, dtype=torch.int64, device=device) + seed
+        out[s:e] = ((splitmix64_torch(i) >> 1) & 0x7FFFFFFFFFFFFFFF) % key_space
+    return out
+
+
+def make_build_keys(n, seed, device):
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    return torch.randperm(n, dtype=torch.int64, device=device, generator=g)
+
+
+def read_profile(gdf):
+    lib = gdf._binding._gdf_cdll
+    names = ((C.c_char * 64) * 64)()
+    ms = (C.c_double * 64)()
+    cnt = (C.c_int * 64)()
+    lib.gdf_amd_profile_read.restype = C.c_int
+    k = lib.gdf_amd_profile_read(names, ms, cnt, 64)
+    return {names[i].value.decode(): (ms[i], cnt[i]) for i in range(min(k, 64))}
+
+
+def cpu_baseline(sample_probe, sample_build):
+    """oracle join (single-threaded C port of the reference algorithm) on a bounded sample of C3."""
+    import numpy as np
+    from oracle import oracle
+    rng = np.random.RandomState(0x5EED)
+    build = rng.permutation(sample_build).astype(np.int64)
+    probe = (oracle.splitmix64(np.arange(sample_probe, dtype=np.uint64) + np.uint64(0x5EED0002)) >> np.uint64(1)) % np.uint64(sample_build)
+    probe = probe.astype(np.int64)
+    oracle.lib()
+    t0 = time.perf_counter()
+    li, ri = oracle.join([probe], [build], "inner")
+    dt = time.perf_counter() - t0
+    assert len(li) == sample_probe
+    return {"value": sample_probe / dt, "unit": "rows/s", "cores": 1, "kind": "port",
+            "sample": f"oracle/gdf_oracle.c orc_join, {sample_probe} probe x {sample_build} build int64 rows, "
+                      f"{dt:.1f} s on 1 of {os.cpu_count()} host cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--probe-rows", type=int, default=1_000_000_000)
+    ap.add_argument("--build-rows", type=int, default=None)
+    ap.add_argument("--cpu-sample", type=int, default=20_000_000, help="probe rows of the CPU baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import libgdf_amd as gdf
+    from libgdf_amd._binding import rmmOptions_t
+    from libgdf_amd.columns import Column
+    # pool mode: the multi-GB partition buffers are recycled between steps instead of hipMalloc'ed
+    opts = rmmOptions_t(1, 0, False)
+    gdf.librmm.rmmInitialize(C.byref(opts))
+
+    npr = args.probe_rows
+    nb = args.build_rows if args.build_rows is not None else (npr // 10 if world == 1 else npr // 8)
+    key_space = nb * world
+    lib = gdf._binding._gdf_cdll
+
+    if world == 1:
+        build = make_build_keys(nb, 0x5EED0001, dev)
+        probe = make_probe_keys(npr, key_space, 0x5EED0002, dev)
+        pcol, bcol = Column(probe), Column(build)
+
+        from libgdf_amd import gdf_column, libgdf, new_context
+        from libgdf_amd.columns import column_array
+        ctx = new_context()                       # {0, GDF_HASH, 0, 0, 0}
+        la, ra = column_array([pcol]), column_array([bcol])
+        on = (C.c_int * 1)(0)
+
+        def step():
+            # exactly one C-ABI call; the library-allocated index columns are released, not copied
+            li, ri = gdf_column(), gdf_column()
+            libgdf.gdf_inner_join(la, 1, on, ra, 1, on, 1, 0, None, C.byref(li), C.byref(ri), C.byref(ctx))
+            n = int(li.size)
+            libgdf.gdf_column_free(C.byref(li))
+            libgdf.gdf_column_free(C.byref(ri))
+            return n
+        workload = f"C3 gdf_inner_join HASH: {npr} probe x {nb} build int64 rows, unique build keys, 100% hit, indices only"
+    else:
+        from libgdf_amd import multigpu
+        # rank r owns build keys r, r+world, ... of a global permutation-free key space: key = perm_r * world + r
+        build = make_build_keys(nb, 0x5EED0001 + rank, dev) * world + rank
+        probe = make_probe_keys(npr, key_space, 0x5EED0002, dev, offset=rank * npr)
+
+        def step():
+            li, ri = multigpu.distributed_inner_join(probe, build)
+            return li.numel()
+        workload = (f"C4 partitioned hash join: {npr} probe + {nb} build int64 rows per GPU, key space {key_space}, "
+                    f"RCCL all-to-all shuffle + local gdf_inner_join")
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    out_rows = 0
+    for _ in range(args.warmup):
+        out_rows = step()
+    lib.gdf_amd_profile_reset()
+    lib.gdf_amd_profile_enable(1)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out_rows = step()
+    sync()
+    dt = time.perf_counter() - t0
+    lib.gdf_amd_profile_enable(0)
+    prof = read_profile(gdf)
+
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    rows = torch.tensor([float(out_rows)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(rows, op=dist.ReduceOp.SUM)
+    dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+
+    if rank == 0:
+        total_probe = npr * world
+        value = total_probe * args.steps / dt
+        # dominant kernel by total time inside the timed region
+        roofline = None
+        if prof:
+            name, (tot_ms, launches) = max(prof.items(), key=lambda kv: kv[1][0])
+            per_launch_ms = tot_ms / max(launches, 1)
+            launches_per_step = launches / args.steps
+            # jk_* kernels run once per relation per step: the per-step byte count is split over those launches
+            fn = KERNEL_BYTES.get(name)
+            if fn is not None:
+                step_bytes = fn(float(npr), float(nb if world == 1 else nb))
+                bytes_per_launch = step_bytes / launches_per_step
+                achieved = bytes_per_launch / (per_launch_ms * 1e-3) / 1e9
+                roofline = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                            "avg_launch_ms": per_launch_ms, "launches_per_step": launches_per_step}
+        e2e_bytes = 8.0 * npr + 8.0 * nb + 8.0 * (rows.item() / world)
+        e2e = e2e_bytes / (ms_per_step * 1e-3) / 1e9
+        result = {
+            "metric": "hash-join probe rows/s", "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+            "config": {"workload": workload, "probe_rows_per_gpu": npr, "build_rows_per_gpu": nb,
+                       "out_rows": int(rows.item()), "parallelism": f"key-partitioned x{world}"},
+            "roofline": roofline,
+            "roofline_e2e": {"bound": "hbm", "achieved": e2e, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": e2e / HBM_PEAK_GBS,
+                             "algorithmic_bytes_per_gpu": e2e_bytes},
+            "kernels_ms_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
+        }
+        if world == 1 and args.cpu_sample > 0:
+            result["cpu_baseline"] = cpu_baseline(args.cpu_sample, max(args.cpu_sample // 10, 1))
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -29,6 +29,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)   /* the library itself is built with -fvisibility=hidden */
+#endif
 
 /* ---- scalar typedefs (types.h:3-8) ------------------------------------- */
 typedef size_t         gdf_size_type;
@@ -300,6 +303,9 @@ gdf_error   gdf_quantile_aprrox(gdf_column *col_in, double q, void *t_erased_res
 gdf_error   read_csv(csv_read_arg *args);
 gdf_error   gdf_to_csr(gdf_column **gdfData, int num_cols, csr_gdf *csrReturn);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }  /* extern "C" */
 #endif

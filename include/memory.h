@@ -20,6 +20,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)   /* the library itself is built with -fvisibility=hidden */
+#endif
 
 typedef struct CUstream_st *cudaStream_t;   /* memory.h:25: opaque; == hipStream_t here */
 typedef long int offset_t;
@@ -55,6 +58,9 @@ rmmError_t  rmmWriteLog(const char *filename);              /* memory.h:164 */
 size_t      rmmLogSize(void);                               /* memory.h:171 */
 rmmError_t  rmmGetLog(char *buffer, size_t buffer_size);    /* memory.h:184 */
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

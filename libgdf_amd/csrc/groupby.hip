@@ -529,12 +529,12 @@ static gdf_error group_by_hash(int ncols, gdf_column **cols, gdf_column *col_agg
     g.overflow = flags.as<unsigned int>() + 1;
     g.special = flags.as<unsigned int>() + 2;
     g.limit = T >= cap_max ? 0xffffffffu : (uint32_t)(T / 2);   // at 2*N slots the table can never fill
-    hipLaunchKernelGGL(gb_init_table, dim3(stream_grid(T + 1, 256 * 8)), dim3(256), 0, stream0(), g, avg ? OP_SUM : op, plan.packed);
+    GDF_LAUNCH("gb_init_table", gb_init_table, dim3(stream_grid(T + 1, 256 * 8)), dim3(256), 0, stream0(), g, avg ? OP_SUM : op, plan.packed);
     if (plan.packed) {
       HIP_TRY(hipFuncSetAttribute((const void *)gb_aggregate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(gb_aggregate<true>, dim3(grid), dim3(GB_THREADS), lds, stream0(), t, plan, val, op, g, chunk);
+      GDF_LAUNCH("gb_aggregate_packed", gb_aggregate<true>, dim3(grid), dim3(GB_THREADS), lds, stream0(), t, plan, val, op, g, chunk);
     } else {
-      hipLaunchKernelGGL(gb_aggregate<false>, dim3(grid), dim3(GB_THREADS), 0, stream0(), t, plan, val, op, g, chunk);
+      GDF_LAUNCH("gb_aggregate_rows", gb_aggregate<false>, dim3(grid), dim3(GB_THREADS), 0, stream0(), t, plan, val, op, g, chunk);
     }
     HIP_CHECK_LAST();
     unsigned int h_flags[3] = {0, 0, 0};
@@ -553,9 +553,9 @@ static gdf_error group_by_hash(int ncols, gdf_column **cols, gdf_column *col_agg
     o.agg_kind = (int)((op == OP_COUNT || op == OP_AVG) ? out_kind : in_kind);
     const int egrid = stream_grid(T + 1, 256 * 4);
     if (plan.packed)
-      hipLaunchKernelGGL(gb_extract<true>, dim3(egrid), dim3(256), 0, stream0(), t, plan, g, o, op, special_used, out_count.as<unsigned long long>());
+      GDF_LAUNCH("gb_extract", gb_extract<true>, dim3(egrid), dim3(256), 0, stream0(), t, plan, g, o, op, special_used, out_count.as<unsigned long long>());
     else
-      hipLaunchKernelGGL(gb_extract<false>, dim3(egrid), dim3(256), 0, stream0(), t, plan, g, o, op, special_used, out_count.as<unsigned long long>());
+      GDF_LAUNCH("gb_extract", gb_extract<false>, dim3(egrid), dim3(256), 0, stream0(), t, plan, g, o, op, special_used, out_count.as<unsigned long long>());
     HIP_CHECK_LAST();
     unsigned long long ngroups = 0;
     HIP_TRY(hipMemcpy(&ngroups, out_count.p, sizeof(ngroups), hipMemcpyDeviceToHost));

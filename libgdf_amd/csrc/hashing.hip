@@ -143,7 +143,7 @@ gdf_error gdf_hash(int num_cols, gdf_column **input, gdf_hash_func hash, gdf_col
   const int64_t n = t.nrows;
   const int grid = stream_grid((size_t)n, HP_THREADS * 8);
   if (hash == GDF_HASH_MURMUR3)
-    hipLaunchKernelGGL(hash_rows_kernel<true>, dim3(grid), dim3(HP_THREADS), 0, stream0(), t, (uint32_t *)output->data, n);
+    GDF_LAUNCH("hash_rows", hash_rows_kernel<true>, dim3(grid), dim3(HP_THREADS), 0, stream0(), t, (uint32_t *)output->data, n);
   else
     hipLaunchKernelGGL(hash_rows_kernel<false>, dim3(grid), dim3(HP_THREADS), 0, stream0(), t, (uint32_t *)output->data, n);
   HIP_CHECK_LAST();
@@ -197,7 +197,7 @@ gdf_error gdf_hash_partition(int num_input_cols, gdf_column *input[], int column
   RMM_TRY(starts.alloc(sizeof(uint32_t) * P));
   const bool murmur = hash == GDF_HASH_MURMUR3;
   if (murmur)
-    hipLaunchKernelGGL(part_hist_kernel<true>, dim3(grid), dim3(HP_THREADS), lds, stream0(), t, n, chunk, nchunks, P, pow2mask, hist.as<uint32_t>());
+    GDF_LAUNCH("part_hist", part_hist_kernel<true>, dim3(grid), dim3(HP_THREADS), lds, stream0(), t, n, chunk, nchunks, P, pow2mask, hist.as<uint32_t>());
   else
     hipLaunchKernelGGL(part_hist_kernel<false>, dim3(grid), dim3(HP_THREADS), lds, stream0(), t, n, chunk, nchunks, P, pow2mask, hist.as<uint32_t>());
   HIP_CHECK_LAST();
@@ -235,7 +235,7 @@ gdf_error gdf_hash_partition(int num_input_cols, gdf_column *input[], int column
     if (first > 0)
       hipLaunchKernelGGL(part_apply_map_kernel, dim3(stream_grid(num_rows, HP_THREADS * 4)), dim3(HP_THREADS), 0, stream0(), pc, n);
     else if (murmur)
-      hipLaunchKernelGGL(part_scatter_kernel<true>, dim3(grid), dim3(HP_THREADS), lds, stream0(), t, pc, n, chunk, nchunks, P, pow2mask, hist.as<uint32_t>());
+      GDF_LAUNCH("part_scatter", part_scatter_kernel<true>, dim3(grid), dim3(HP_THREADS), lds, stream0(), t, pc, n, chunk, nchunks, P, pow2mask, hist.as<uint32_t>());
     else
       hipLaunchKernelGGL(part_scatter_kernel<false>, dim3(grid), dim3(HP_THREADS), lds, stream0(), t, pc, n, chunk, nchunks, P, pow2mask, hist.as<uint32_t>());
     HIP_CHECK_LAST();

@@ -619,7 +619,7 @@ static gdf_error partition_side(const KeyTable &t, const KeyPlan &plan, PartGeom
   const size_t hist_lds = sizeof(uint32_t) * (nfine + ncoarse);
   HIP_TRY(hipFuncSetAttribute((const void *)jk_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_lds));
   const int hist_grid = g.nchunks < NUM_CU ? g.nchunks : NUM_CU;
-  hipLaunchKernelGGL(jk_hist, dim3(hist_grid), dim3(JK_HIST_THREADS), hist_lds, stream0(), t, plan, g,
+  GDF_LAUNCH("jk_hist", jk_hist, dim3(hist_grid), dim3(JK_HIST_THREADS), hist_lds, stream0(), t, plan, g,
                      fine_hist.as<uint32_t>(), H1.as<uint32_t>());
   HIP_CHECK_LAST();
   GDF_TRY(scan_u32(H1.as<uint32_t>(), H1.as<uint32_t>(), (size_t)ncoarse * g.nchunks, false));
@@ -633,7 +633,7 @@ static gdf_error partition_side(const KeyTable &t, const KeyPlan &plan, PartGeom
 
   RMM_TRY(sb->key[0].alloc(sizeof(uint64_t) * cap));
   RMM_TRY(sb->idx[0].alloc(sizeof(int32_t) * cap));
-  hipLaunchKernelGGL(jk_scatter1, dim3(g.nchunks), dim3(JK_SC_THREADS), 0, stream0(), t, plan, g, H1.as<uint32_t>(),
+  GDF_LAUNCH("jk_scatter1", jk_scatter1, dim3(g.nchunks), dim3(JK_SC_THREADS), 0, stream0(), t, plan, g, H1.as<uint32_t>(),
                      sb->key[0].as<uint64_t>(), sb->idx[0].as<int32_t>());
   HIP_CHECK_LAST();
   sb->final_buf = 0;
@@ -656,7 +656,7 @@ static gdf_error partition_side(const KeyTable &t, const KeyPlan &plan, PartGeom
     RMM_TRY(sb->idx[1].alloc(sizeof(int32_t) * cap));
     Level2Map m{d_coarse.as<uint32_t>(), d_tiles.as<uint32_t>()};
     if (ntiles)
-      hipLaunchKernelGGL(jk_scatter2, dim3(ntiles), dim3(JK_SC_THREADS), 0, stream0(), g, m, sb->key[0].as<uint64_t>(),
+      GDF_LAUNCH("jk_scatter2", jk_scatter2, dim3(ntiles), dim3(JK_SC_THREADS), 0, stream0(), g, m, sb->key[0].as<uint64_t>(),
                          sb->idx[0].as<int32_t>(), cursor.as<uint32_t>(), sb->key[1].as<uint64_t>(),
                          sb->idx[1].as<int32_t>());
     HIP_CHECK_LAST();
@@ -733,7 +733,7 @@ static gdf_error hash_join_core(const KeyTable &probe_t, const KeyTable &build_t
 
   // ---- count pass ----
   if (nunits) {
-    hipLaunchKernelGGL(jk_probe<false>, dim3((unsigned)nunits), dim3(JK_PROBE_THREADS), probe_lds, stream0(), a, probe_t, build_t);
+    GDF_LAUNCH("jk_probe_count", jk_probe<false>, dim3((unsigned)nunits), dim3(JK_PROBE_THREADS), probe_lds, stream0(), a, probe_t, build_t);
     HIP_CHECK_LAST();
   }
   // oversize partitions: one global table each, kept for the write pass
@@ -785,7 +785,7 @@ static gdf_error hash_join_core(const KeyTable &probe_t, const KeyTable &build_t
 
   // ---- write pass ----
   if (nunits) {
-    hipLaunchKernelGGL(jk_probe<true>, dim3((unsigned)nunits), dim3(JK_PROBE_THREADS), probe_lds, stream0(), a, probe_t, build_t);
+    GDF_LAUNCH("jk_probe_write", jk_probe<true>, dim3((unsigned)nunits), dim3(JK_PROBE_THREADS), probe_lds, stream0(), a, probe_t, build_t);
     HIP_CHECK_LAST();
   }
   for (size_t o = 0; o < oversize.size(); ++o) {

@@ -13,7 +13,7 @@
 // Inside a block a tile is 256 threads x ITEMS consecutive elements: per-thread
 // serial scan, wave64 shuffle scan of the thread totals, one LDS hop across the
 // four waves.  Algorithmic bytes are 2*w per element; this shape moves 3*w.
-#include "common.h"
+#include "internal.h"
 
 namespace gdf_amd {
 
@@ -114,10 +114,10 @@ gdf_error device_scan(const ELEM *in, ELEM *out, size_t n, bool inclusive) {
   const int nchunks = (int)((n + chunk - 1) / chunk);
   DevBuf sums;
   RMM_TRY(sums.alloc(sizeof(ACC) * nchunks));
-  hipLaunchKernelGGL((scan_reduce<ACC, ELEM, ITEMS>), dim3(nchunks), dim3(SCAN_THREADS), 0, stream0(), in,
+  GDF_LAUNCH("scan_reduce", (scan_reduce<ACC, ELEM, ITEMS>), dim3(nchunks), dim3(SCAN_THREADS), 0, stream0(), in,
                      sums.as<ACC>(), n, chunk);
   hipLaunchKernelGGL((scan_spine<ACC>), dim3(1), dim3(SCAN_THREADS), 0, stream0(), sums.as<ACC>(), nchunks);
-  hipLaunchKernelGGL((scan_apply<ACC, ELEM, ITEMS>), dim3(nchunks), dim3(SCAN_THREADS), 0, stream0(), in, out,
+  GDF_LAUNCH("scan_apply", (scan_apply<ACC, ELEM, ITEMS>), dim3(nchunks), dim3(SCAN_THREADS), 0, stream0(), in, out,
                      sums.as<ACC>(), n, chunk, inclusive ? 1 : 0);
   HIP_CHECK_LAST();
   HIP_TRY(hipStreamSynchronize(stream0()));   // scratch is released on return

@@ -1,0 +1,166 @@
+"""-m gpu: gpu_comparison*, gpu_apply_stencil, gdf_filter and the mask helpers vs numpy expectations."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from util import ALL_DTYPES, gen_rand, random_valid
+
+pytestmark = pytest.mark.gpu
+
+
+def _col(a, v=None):
+    from libgdf_amd.columns import column_from_numpy
+    return column_from_numpy(a, v)
+
+
+@pytest.mark.parametrize("ldt", ALL_DTYPES, ids=lambda d: np.dtype(d).name)
+@pytest.mark.parametrize("rdt", ALL_DTYPES, ids=lambda d: np.dtype(d).name)
+def test_comparison_all_dtype_pairs(gdf, ldt, rdt):
+    """tests/filterops_numeric/test_filterops.cu:79-178 covers GDF_EQUALS over the 36 pairs, sizes 0-9; we run all six operators."""
+    for n in (1, 9, 1000):
+        l = gen_rand(ldt, n, -5, 5) if np.dtype(ldt).kind == "i" else np.round(gen_rand(ldt, n) * 5).astype(ldt)
+        r = gen_rand(rdt, n, -5, 5) if np.dtype(rdt).kind == "i" else np.round(gen_rand(rdt, n) * 5).astype(rdt)
+        for op in range(6):
+            out = gdf.api.comparison(_col(l), _col(r), op)
+            np.testing.assert_array_equal(out.to_numpy(), oracle.comparison(l, r, op))
+            assert out.valid_bits().all() and out.c.null_count == 0
+
+
+@pytest.mark.parametrize("ldt", ALL_DTYPES, ids=lambda d: np.dtype(d).name)
+@pytest.mark.parametrize("sdt", ALL_DTYPES, ids=lambda d: np.dtype(d).name)
+def test_comparison_static(gdf, ldt, sdt):
+    n = 5000
+    l = gen_rand(ldt, n, -20, 20) if np.dtype(ldt).kind == "i" else np.round(gen_rand(ldt, n) * 20).astype(ldt)
+    s = np.dtype(sdt).type(3)
+    for op in range(6):
+        out = gdf.api.comparison(_col(l), s, op)
+        np.testing.assert_array_equal(out.to_numpy(), oracle.comparison(l, s, op))
+
+
+def test_comparison_masks(gdf):
+    n = 1003
+    l, r = gen_rand(np.int32, n), gen_rand(np.int32, n)
+    lv, rv = random_valid(n), random_valid(n)
+    out = gdf.api.comparison(_col(l, lv), _col(r, rv), 0)
+    np.testing.assert_array_equal(out.valid_bits(), lv & rv)      # filterops.cu:139-153: AND + recount
+    assert out.c.null_count == n - (lv & rv).sum()
+    out = gdf.api.comparison(_col(l, lv), np.int32(0), 4)
+    np.testing.assert_array_equal(out.valid_bits(), lv)
+    assert out.c.null_count == n - lv.sum()
+
+
+@pytest.mark.parametrize("dtype", ALL_DTYPES, ids=lambda d: np.dtype(d).name)
+@pytest.mark.parametrize("n", [1, 7, 64, 1000, 300007])
+def test_apply_stencil(gdf, dtype, n):
+    a = gen_rand(dtype, n)
+    st = (np.random.random(n) < 0.4).astype(np.int8)
+    sv = random_valid(n)
+    out = gdf.api.apply_stencil(_col(a), _col(st, sv))
+    exp = oracle.apply_stencil(a, st, sv)
+    assert out.size == len(exp)
+    np.testing.assert_array_equal(out.to_numpy(), exp)           # stable: input order kept
+    bits = out.valid_bits(n)
+    assert bits[: len(exp)].all() and not bits[len(exp):].any()
+
+
+def test_filter_then_compact_pipeline_large(gdf):
+    """SURVEY 8d micro-metric shape at 20M rows: col > v, then compaction; ~10 % selectivity."""
+    n = 20_000_000
+    a = np.random.randint(0, 1000, size=n).astype(np.int64)
+    st = gdf.api.comparison(_col(a), np.int64(899), 4)
+    out = gdf.api.apply_stencil(_col(a), st)
+    exp = a[a > 899]
+    assert out.size == len(exp)
+    np.testing.assert_array_equal(out.to_numpy(), exp)
+
+
+def test_apply_stencil_errors(gdf):
+    from libgdf_amd import GDFError
+    a = _col(gen_rand(np.int32, 10), np.ones(10, dtype=bool))
+    st = _col(np.ones(10, dtype=np.int8))
+    with pytest.raises(GDFError, match="GDF_VALIDITY_UNSUPPORTED"):
+        gdf.api.apply_stencil(a, st)
+
+
+def test_gdf_filter_known_answer_and_random(gdf):
+    with open(os.path.join(os.path.dirname(__file__), "golden", "sqls_known_answers.json")) as f:
+        fx = json.load(f)["filter"]
+    cols = [np.array(fx["cols"][c]["values"], dtype=fx["cols"][c]["dtype"]) for c in ("c0", "c1", "c2")]
+    idx = gdf.api.filter_rows([_col(c) for c in cols], fx["tuple"]).cpu().numpy()
+    assert len(idx) == fx["expected_size"] and list(idx) == fx["expected_indices"]
+    n = 200000
+    cols = [gen_rand(np.int32, n, 0, 4), gen_rand(np.int64, n, 0, 3), np.round(gen_rand(np.float64, n) * 2)]
+    vals = [2, 1, 1.0]
+    idx = gdf.api.filter_rows([_col(c) for c in cols], vals).cpu().numpy()
+    np.testing.assert_array_equal(idx.astype(np.uint64), oracle.filter_rows(cols, vals))     # ascending (stable copy_if)
+
+
+@pytest.mark.parametrize("n", [1, 8, 31, 32, 33, 1000, 100003])
+def test_count_nonzero_mask(gdf, n):
+    """tests/validops/valids-tests.cu: device popcount vs host popcount."""
+    import torch
+    from libgdf_amd import libgdf
+    from libgdf_amd.columns import mask_from_bools
+    v = np.random.randint(0, 2, size=n).astype(bool)
+    mask = mask_from_bools(v)
+    mask[(n + 7) // 8:] = 0xFF               # garbage after the last row must not count
+    if n % 8:
+        mask[n // 8] |= np.uint8(0xFF << (n % 8) & 0xFF)
+    d = torch.from_numpy(mask).cuda()
+    cnt = C.c_int(0)
+    libgdf.gdf_count_nonzero_mask(d.data_ptr(), n, C.byref(cnt))
+    assert cnt.value == int(v.sum())
+
+
+def test_validity_and(gdf):
+    """python/tests/test_validity.py:19-74."""
+    import torch
+    from libgdf_amd import Column, libgdf
+    n = 1001
+    a, b = random_valid(n), random_valid(n)
+    ca, cb = _col(gen_rand(np.int32, n), a), _col(gen_rand(np.int32, n), b)
+    out = Column(torch.empty(n, dtype=torch.int32, device="cuda"), torch.zeros(128, dtype=torch.uint8, device="cuda"), 3)
+    libgdf.gdf_validity_and(ca.ptr, cb.ptr, out.ptr)
+    np.testing.assert_array_equal(out.valid_bits(), a & b)
+    assert out.c.null_count == n - (a & b).sum()
+
+
+def test_column_concat(gdf):
+    """tests/column/column-test.cu: data + masks, a missing mask counts as all valid."""
+    import torch
+    from libgdf_amd import Column, libgdf
+    from libgdf_amd.columns import column_array
+    parts = [gen_rand(np.int64, n) for n in (5, 64, 1, 1000)]
+    valids = [random_valid(5), None, np.array([False]), random_valid(1000)]
+    cols = [_col(p, v) for p, v in zip(parts, valids)]
+    total = sum(len(p) for p in parts)
+    out = Column(torch.empty(total, dtype=torch.int64, device="cuda"), torch.zeros(192, dtype=torch.uint8, device="cuda"), 4)
+    libgdf.gdf_column_concat(out.ptr, column_array(cols), len(cols))
+    np.testing.assert_array_equal(out.to_numpy(), np.concatenate(parts))
+    exp_valid = np.concatenate([v if v is not None else np.ones(len(p), dtype=bool) for p, v in zip(parts, valids)])
+    np.testing.assert_array_equal(out.valid_bits(), exp_valid)
+    assert out.c.null_count == total - exp_valid.sum()
+
+
+def test_rmm_roundtrip_and_log(gdf):
+    """librmm ABI: alloc/free/realloc/getinfo, CSV log header (python/tests/test_rmm.py:52)."""
+    from libgdf_amd import librmm
+    p = C.c_void_p()
+    librmm.rmmAlloc(C.byref(p), 1 << 20, None)
+    assert p.value
+    off = C.c_long(-1)
+    librmm.rmmGetAllocationOffset(C.byref(off), p, None)
+    assert off.value == 0
+    librmm.rmmRealloc(C.byref(p), 1 << 21, None)
+    f, t = C.c_size_t(0), C.c_size_t(0)
+    librmm.rmmGetInfo(C.byref(f), C.byref(t), None)
+    assert 0 < f.value <= t.value
+    librmm.rmmFree(p, None)
+    n = librmm.rmmLogSize()
+    buf = C.create_string_buffer(n + 1)
+    librmm.rmmGetLog(buf, n)
+    assert buf.value.decode().startswith("Event Type,Device ID,Address,Stream,Size (bytes),Free Memory,Total Memory,Current Allocs,Start,End,Elapsed")

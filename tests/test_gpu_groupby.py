@@ -1,0 +1,173 @@
+"""-m gpu: gdf_group_by_{sum,min,max,avg,count} (HASH) through the C ABI vs the oracle.
+
+Cases follow tests/groupby/groupby-test.cu:369-445 and test_parameters.cuh:126-153 (1-3 key columns,
+all aggregation dtypes; AllKeysSame, AllKeysDifferent, WarpKeysSame, BlockKeysSame, EmptyInput) plus the
+reference's known-answer vectors.  Integer aggregates are bit-exact; float sums/averages within 1e-6
+relative (the reference's own test allows 1 %, groupby-test.cu:346-364)."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from util import gen_rand, sort_groups
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-6
+
+
+def _cols(arrs):
+    from libgdf_amd.columns import column_from_numpy
+    return [column_from_numpy(a) for a in arrs]
+
+
+def _run(gdf, op, keys, vals, out_dtype=None, sort_result=False):
+    from libgdf_amd.columns import get_dtype
+    od = None if out_dtype is None else get_dtype(out_dtype)
+    k, a = gdf.api.group_by(op, _cols(keys), _cols([vals])[0], out_dtype=od, sort_result=sort_result)
+    return [x.cpu().numpy() for x in k], a.cpu().numpy()
+
+
+def _check(gdf, op, keys, vals, out_dtype=None):
+    gk, ga = _run(gdf, op, keys, vals, out_dtype)
+    ek, ea = oracle.group_by(op, keys, vals, out_dtype)
+    gk, ga = sort_groups(gk, ga)
+    assert len(ga) == len(ea)
+    for g, e in zip(gk, ek):
+        np.testing.assert_array_equal(g, e)
+    if op in ("sum", "avg") and (ea.dtype.kind == "f" or np.asarray(vals).dtype.kind == "f"):
+        # floating-point sums are order dependent (atomics here, atomics in the reference): the bound is
+        # 1e-6 relative to the group's sum of magnitudes -- the plain relative bound whenever the values
+        # do not cancel, and the standard summation error bound when they do
+        _, mag = oracle.group_by("sum", keys, np.abs(np.asarray(vals, dtype=np.float64)))
+        if op == "avg":
+            _, cnt = oracle.group_by("count", keys, vals, np.int64)
+            mag = mag / cnt
+        assert np.all(np.abs(ga.astype(np.float64) - ea.astype(np.float64)) <= RTOL * mag + 1e-300), \
+            np.max(np.abs(ga.astype(np.float64) - ea.astype(np.float64)) / (mag + 1e-300))
+    elif ea.dtype.kind == "f":
+        np.testing.assert_array_equal(ga, ea)          # min / max / count pick or count values: exact
+    else:
+        np.testing.assert_array_equal(ga, ea)
+
+
+OPS = ["sum", "min", "max", "count", "avg"]
+AGG_DTYPES = [np.int8, np.int16, np.int32, np.int64, np.float32, np.float64]
+
+
+@pytest.mark.parametrize("op", OPS)
+@pytest.mark.parametrize("agg_dtype", AGG_DTYPES, ids=lambda d: np.dtype(d).name)
+def test_single_int32_key(gdf, op, agg_dtype):
+    n = 30000
+    keys = [gen_rand(np.int32, n, 0, 200)]
+    vals = gen_rand(agg_dtype, n, -100, 100)
+    out = np.int64 if op == "count" else (np.float64 if op == "avg" else None)
+    _check(gdf, op, keys, vals, out)
+
+
+@pytest.mark.parametrize("op", OPS)
+@pytest.mark.parametrize("key_dtypes", [[np.int64], [np.int32, np.int32], [np.int64, np.int32], [np.int8, np.int16, np.int32],
+                                        [np.float64], [np.int32, np.float32], [np.int64, np.int64, np.int64]],
+                         ids=lambda d: "-".join(np.dtype(x).name for x in d))
+def test_key_shapes(gdf, op, key_dtypes):
+    n = 20000
+    keys = [gen_rand(dt, n, 0, 12) if np.dtype(dt).kind == "i" else np.round(gen_rand(dt, n) * 6).astype(dt) for dt in key_dtypes]
+    vals = gen_rand(np.float64 if op != "count" else np.int32, n)
+    out = np.int32 if op == "count" else None
+    _check(gdf, op, keys, vals, out)
+
+
+@pytest.mark.parametrize("op", OPS)
+@pytest.mark.parametrize("groups,per", [(1, 16384), (16384, 1), (1024, 32), (1024, 256)],
+                         ids=["AllKeysSame", "AllKeysDifferent", "WarpKeysSame", "BlockKeysSame"])
+def test_reference_key_patterns(gdf, op, groups, per):
+    keys = [np.repeat(np.arange(groups, dtype=np.int64), per)]
+    vals = gen_rand(np.int64, groups * per, -1000, 1000)
+    _check(gdf, op, keys, vals, np.int64 if op in ("count", "avg") else None)
+
+
+def test_empty_input_sets_sizes_to_zero(gdf):
+    import torch
+    from libgdf_amd import Column, libgdf, new_context
+    from libgdf_amd.columns import column_array
+    k = Column(torch.empty(1, dtype=torch.int32, device="cuda"), None, 3, size=0)
+    v = Column(torch.empty(1, dtype=torch.int32, device="cuda"), None, 3, size=0)
+    ok = Column(torch.empty(4, dtype=torch.int32, device="cuda"), None, 3, size=4)
+    oa = Column(torch.empty(4, dtype=torch.int32, device="cuda"), None, 3, size=4)
+    ctx = new_context()
+    libgdf.gdf_group_by_sum(1, column_array([k]), v.ptr, None, column_array([ok]), oa.ptr, C.byref(ctx))
+    assert ok.size == 0 and oa.size == 0
+
+
+def test_integer_wraparound_and_avg_typing(gdf):
+    keys = [np.zeros(4, dtype=np.int32)]
+    vals = np.array([100, 100, 100, 27], dtype=np.int8)
+    _check(gdf, "sum", keys, vals)
+    _check(gdf, "avg", keys, vals, np.float64)
+    _check(gdf, "avg", keys, vals, np.int32)
+    big = np.array([2**62, 2**62, 2**62, 5], dtype=np.int64)
+    _check(gdf, "sum", keys, big)
+    _check(gdf, "count", keys, vals, np.int8)
+    _check(gdf, "count", keys, vals, np.float32)
+
+
+def test_reserved_key_pattern_is_a_normal_key(gdf):
+    keys = [np.array([-2**63, 5, -2**63, 5, 0], dtype=np.int64)]
+    vals = np.array([1, 2, 3, 4, 5], dtype=np.int64)
+    for op in OPS:
+        _check(gdf, op, keys, vals, np.int64 if op in ("count", "avg") else None)
+
+
+def test_sorted_output_and_avg_are_ordered(gdf):
+    n = 50000
+    keys = [gen_rand(np.int32, n, -50, 50), gen_rand(np.int64, n, -3, 3)]
+    vals = gen_rand(np.float64, n)
+    gk, ga = _run(gdf, "sum", keys, vals, sort_result=True)
+    ek, ea = oracle.group_by("sum", keys, vals)
+    for g, e in zip(gk, ek):
+        np.testing.assert_array_equal(g, e)               # already in lexicographic order
+    np.testing.assert_allclose(ga, ea, rtol=RTOL)
+    gk, ga = _run(gdf, "avg", keys, vals, np.float64)    # AVG output is always sorted (groupby.cuh:345-386)
+    ek, ea = oracle.group_by("avg", keys, vals, np.float64)
+    for g, e in zip(gk, ek):
+        np.testing.assert_array_equal(g, e)
+    np.testing.assert_allclose(ga, ea, rtol=RTOL)
+
+
+def test_many_groups_grow_the_table(gdf):
+    n = 3_000_000
+    keys = [np.random.permutation(n).astype(np.int64)]        # every row its own group: forces table growth
+    vals = gen_rand(np.int32, n)
+    _check(gdf, "sum", keys, vals)
+
+
+def test_config_c2_shape_reduced(gdf):
+    """BASELINE configs[1] at 10M rows: int64 keys = splitmix64 % 10000, int64 values; integers bit-exact."""
+    n = 10_000_000
+    i = np.arange(n, dtype=np.uint64)
+    keys = [(oracle.splitmix64(i + np.uint64(0x5EED0003)) % np.uint64(10000)).astype(np.int64)]
+    vals = (oracle.splitmix64(i + np.uint64(0x5EED0004)) % np.uint64(1000)).astype(np.int64)
+    _check(gdf, "sum", keys, vals)
+
+
+def test_known_answer_vectors(gdf):
+    with open(os.path.join(os.path.dirname(__file__), "golden", "sqls_known_answers.json")) as f:
+        g = json.load(f)["group_by"]
+    keys = [np.array(g["keys"][c]["values"], dtype=g["keys"][c]["dtype"]) for c in ("c0", "c1", "c2")]
+    for case in g["cases"]:
+        vals = np.array(case["agg"]["values"], dtype=case["agg"]["dtype"])
+        gk, ga = _run(gdf, case["op"], keys, vals, np.dtype(case["out_dtype"]), sort_result=True)
+        for c, name in zip(gk, ("c0", "c1", "c2")):
+            assert list(c) == g["expected_keys"][name], case["ref"]
+        assert list(ga) == case["expected"], case["ref"]
+
+
+def test_validity_rejected_like_the_reference(gdf):
+    from libgdf_amd import GDFError
+    from libgdf_amd.columns import column_from_numpy
+    k = column_from_numpy(gen_rand(np.int32, 100), np.ones(100, dtype=bool))
+    v = column_from_numpy(gen_rand(np.int32, 100))
+    with pytest.raises(GDFError, match="GDF_VALIDITY_UNSUPPORTED"):
+        gdf.api.group_by("sum", [k], v)

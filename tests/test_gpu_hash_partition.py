@@ -1,0 +1,122 @@
+"""-m gpu: gdf_hash / gdf_hash_partition / gdf_prefixsum_* through the C ABI vs the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from util import ALL_DTYPES, gen_rand, random_valid
+
+pytestmark = pytest.mark.gpu
+
+
+def _col(gdf, arr, valid=None):
+    from libgdf_amd.columns import column_from_numpy
+    return column_from_numpy(arr, valid)
+
+
+@pytest.mark.parametrize("dtype", ALL_DTYPES)
+@pytest.mark.parametrize("n", [1, 63, 1000, 100003])
+def test_hash_single_column_bit_exact(gdf, dtype, n):
+    a = gen_rand(dtype, n)
+    got = gdf.api.hash_rows([_col(gdf, a)]).cpu().numpy().view(np.uint32)
+    np.testing.assert_array_equal(got, oracle.hash_rows([a]))
+
+
+def test_hash_multi_column_and_identity(gdf):
+    n = 50000
+    cols = [gen_rand(np.int32, n), gen_rand(np.int64, n), gen_rand(np.float64, n), gen_rand(np.int8, n), gen_rand(np.float32, n)]
+    dev = [_col(gdf, c) for c in cols]
+    got = gdf.api.hash_rows(dev).cpu().numpy().view(np.uint32)
+    np.testing.assert_array_equal(got, oracle.hash_rows(cols))
+    ints = [cols[0], cols[1], cols[3]]
+    got = gdf.api.hash_rows([dev[0], dev[1], dev[3]], hash_func=1).cpu().numpy().view(np.uint32)
+    np.testing.assert_array_equal(got, oracle.hash_rows(ints, identity=True))
+
+
+def test_hash_equal_rows_equal_hashes(gdf):
+    """reference tests/hashing/hash-test.cu:35-158 / python/tests/test_hashing.py:61-85."""
+    cols = [gen_rand(dt, 8) for dt in ALL_DTYPES]
+    for c in cols:
+        c[4] = c[0]
+    h = gdf.api.hash_rows([_col(gdf, c) for c in cols]).cpu().numpy()
+    assert h[0] == h[4]
+
+
+def test_hash_errors(gdf):
+    import torch
+    from libgdf_amd import Column, libgdf, GDFError
+    from libgdf_amd.columns import column_array
+    a = _col(gdf, gen_rand(np.int32, 10))
+    out64 = Column(torch.empty(10, dtype=torch.int64, device="cuda"))
+    with pytest.raises(GDFError, match="GDF_UNSUPPORTED_DTYPE"):
+        libgdf.gdf_hash(1, column_array([a]), 0, out64.ptr)
+    out32 = Column(torch.empty(10, dtype=torch.int32, device="cuda"))
+    with pytest.raises(GDFError, match="GDF_INVALID_HASH_FUNCTION"):
+        libgdf.gdf_hash(1, column_array([a]), 7, out32.ptr)
+
+
+@pytest.mark.parametrize("nparts", [1, 5, 8, 10, 257])          # tests/hashing/hash-partition-test.cu:279-289
+@pytest.mark.parametrize("n", [100, 100000, 1000000])
+def test_hash_partition_membership_and_offsets(gdf, nparts, n):
+    k0 = gen_rand(np.int64, n)
+    k1 = gen_rand(np.int32, n)
+    payload = gen_rand(np.float64, n)
+    cols = [k0, payload, k1]
+    outs, offsets = gdf.api.hash_partition([_col(gdf, c) for c in cols], [0, 2], nparts)
+    perm, exp_off, pid = oracle.hash_partition(cols, [0, 2], nparts)
+    assert offsets == [int(x) for x in exp_off]
+    got = [o.to_numpy() for o in outs]
+    # every partition holds exactly the reference's rows (as a multiset), and rows stay intact
+    bounds = list(exp_off) + [n]
+    got_pid = oracle.partition_ids([got[0], got[2]], nparts)
+    for p in range(nparts):
+        lo, hi = bounds[p], bounds[p + 1]
+        assert np.all(got_pid[lo:hi] == p)
+    exp_rows = np.stack([c[perm].astype(np.float64) for c in cols], axis=1)
+    got_rows = np.stack([g.astype(np.float64) for g in got], axis=1)
+    for p in range(nparts):
+        lo, hi = bounds[p], bounds[p + 1]
+        e = exp_rows[lo:hi]; g = got_rows[lo:hi]
+        np.testing.assert_array_equal(e[np.lexsort(e.T[::-1])], g[np.lexsort(g.T[::-1])])
+
+
+def test_hash_partition_moves_valid_masks(gdf):
+    n, nparts = 20000, 16
+    k = gen_rand(np.int32, n)
+    v = gen_rand(np.int64, n)
+    kv, vv = random_valid(n), random_valid(n)
+    outs, offsets = gdf.api.hash_partition([_col(gdf, k, kv), _col(gdf, v, vv)], [0], nparts, with_masks=True)
+    gk, gv = outs[0].to_numpy(), outs[1].to_numpy()
+    gkv, gvv = outs[0].valid_bits(), outs[1].valid_bits()
+    # rows (key, key_valid, value, value_valid) are preserved as a multiset
+    exp = np.stack([k, kv, v, vv], axis=1).astype(np.int64)
+    got = np.stack([gk, gkv, gv, gvv], axis=1).astype(np.int64)
+    np.testing.assert_array_equal(exp[np.lexsort(exp.T[::-1])], got[np.lexsort(got.T[::-1])])
+    assert outs[0].c.null_count == n - kv.sum()
+
+
+def test_hash_partition_errors(gdf):
+    from libgdf_amd import GDFError
+    a = _col(gdf, gen_rand(np.int32, 100))
+    b = _col(gdf, gen_rand(np.int32, 50))
+    with pytest.raises(GDFError, match="GDF_COLUMN_SIZE_MISMATCH"):
+        gdf.api.hash_partition([a, b], [0], 4)
+    with pytest.raises(GDFError, match="GDF_INVALID_HASH_FUNCTION"):
+        gdf.api.hash_partition([a], [0], 4, hash_func=9)
+
+
+@pytest.mark.parametrize("dtype", [np.int8, np.int32, np.int64])
+@pytest.mark.parametrize("n", [1, 2, 13, 64, 100, 1000, 2048, 2049, 1000003])      # python/tests/test_prefixsum.py:16-62 + tile edges
+@pytest.mark.parametrize("inclusive", [True, False])
+def test_prefixsum(gdf, dtype, n, inclusive):
+    a = np.random.randint(-100, 100, size=n).astype(dtype)
+    got = gdf.api.prefixsum(_col(gdf, a), inclusive).cpu().numpy()
+    np.testing.assert_array_equal(got, oracle.prefixsum(a, inclusive))
+
+
+def test_prefixsum_large_wraps_like_numpy(gdf):
+    n = 20_000_000
+    a = np.random.randint(-2**31, 2**31 - 1, size=n, dtype=np.int64).astype(np.int32)
+    got = gdf.api.prefixsum(_col(gdf, a), True).cpu().numpy()
+    np.testing.assert_array_equal(got, np.cumsum(a, dtype=np.int32))

@@ -1,0 +1,212 @@
+"""-m gpu: gdf_inner_join / gdf_left_join / gdf_full_join through the C ABI vs the oracle.
+
+Cases follow the reference's gtest suite (tests/join/join-tests.cu:516-760): 1-5 key columns of every
+numeric dtype, EqualValues, MaxRandomValues, Left/RightColumnsBigger, Empty*, random valid masks on the
+inputs, and the size-limit checks.  Results are compared as SORTED (l, r) pair lists (:342-345)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from util import gen_rand, random_valid, sort_pairs
+
+pytestmark = pytest.mark.gpu
+
+
+def _cols(arrs, valids=None):
+    from libgdf_amd.columns import column_from_numpy
+    valids = valids or [None] * len(arrs)
+    return [column_from_numpy(a, v) for a, v in zip(arrs, valids)]
+
+
+def _check(gdf, left, right, how, lvalid=None, rvalid=None):
+    li, ri = gdf.api.join(_cols(left, lvalid), _cols(right, rvalid), how=how)
+    el, er = oracle.join(left, right, how, lvalid, rvalid)
+    a, b = sort_pairs(li.cpu().numpy(), ri.cpu().numpy())
+    c, d = sort_pairs(el, er)
+    assert len(a) == len(c), (len(a), len(c))
+    np.testing.assert_array_equal(a, c)
+    np.testing.assert_array_equal(b, d)
+    return len(a)
+
+
+KEYSETS = [
+    [np.int32], [np.int64], [np.float32], [np.float64], [np.int8], [np.int16],
+    [np.int32, np.int32], [np.int64, np.int32], [np.int32, np.float64],
+    [np.int32, np.int64, np.int16], [np.int64, np.int64], [np.float32, np.float64, np.int8, np.int64, np.int32],
+]
+
+
+def _gen(dtypes, n, rng):
+    out = []
+    for dt in dtypes:
+        if np.dtype(dt).kind == "f":
+            out.append(np.round(gen_rand(dt, n) * rng).astype(dt))
+        else:
+            info = np.iinfo(dt)
+            out.append(gen_rand(dt, n, low=0, high=min(rng, info.max)))
+    return out
+
+
+@pytest.mark.parametrize("how", ["inner", "left", "full"])
+@pytest.mark.parametrize("dtypes", KEYSETS, ids=lambda d: "-".join(np.dtype(x).name for x in d))
+def test_random_values(gdf, how, dtypes):
+    """MaxRandomValues-style: 10k x 10k rows (join-tests.cu:617-633), value range tuned for a non-trivial result."""
+    rng = 2000 if len(dtypes) == 1 else 12
+    _check(gdf, _gen(dtypes, 10000, rng), _gen(dtypes, 10000, rng), how)
+
+
+@pytest.mark.parametrize("how", ["inner", "left", "full"])
+def test_equal_values(gdf, how):
+    """EqualValues: 100 x 1000 rows, every key identical -> full cross product (join-tests.cu:597-615)."""
+    n = _check(gdf, [np.ones(100, dtype=np.int32)], [np.ones(1000, dtype=np.int32)], how)
+    assert n == 100 * 1000
+
+
+@pytest.mark.parametrize("how", ["inner", "left", "full"])
+@pytest.mark.parametrize("nl,nr", [(10000, 100), (100, 10000)])
+def test_one_side_bigger(gdf, how, nl, nr):
+    """Left/RightColumnsBigger: range 100 (join-tests.cu:635-671); exercises the build-side swap of INNER."""
+    _check(gdf, _gen([np.int64], nl, 100), _gen([np.int64], nr, 100), how)
+
+
+@pytest.mark.parametrize("how", ["inner", "left", "full"])
+@pytest.mark.parametrize("dtypes", [[np.int32], [np.int64, np.int32], [np.float64]], ids=["i32", "i64-i32", "f64"])
+def test_random_valid_masks(gdf, how, dtypes):
+    """join-tests.cu HASH inputs carry masks: first half valid, second half coin flips (valid_vectors.h:32-50)."""
+    left, right = _gen(dtypes, 5000, 60), _gen(dtypes, 3000, 60)
+    lv = [random_valid(5000) for _ in dtypes]
+    rv = [random_valid(3000) for _ in dtypes]
+    _check(gdf, left, right, how, lv, rv)
+
+
+def test_float_nan_and_signed_zero(gdf):
+    l = np.array([0.0, -0.0, np.nan, 1.5, np.nan], dtype=np.float64)
+    r = np.array([-0.0, np.nan, 1.5, 0.0], dtype=np.float64)
+    for how in ("inner", "left", "full"):
+        _check(gdf, [l], [r], how)      # NaN matches nothing, -0.0 == +0.0 (rows_equal uses ==)
+
+
+@pytest.mark.parametrize("how", ["inner", "left", "full"])
+@pytest.mark.parametrize("nl,nr", [(0, 100), (100, 0), (0, 0)])
+def test_empty_inputs(gdf, how, nl, nr):
+    """EmptyLeft / EmptyRight / EmptyBoth (join-tests.cu:673-714 with the rules of joining.cu:304-323)."""
+    import torch
+    from libgdf_amd import Column, gdf_column, libgdf, new_context
+    from libgdf_amd.columns import column_array
+    L = [Column(torch.arange(max(nl, 1), dtype=torch.int32, device="cuda"), None, 3, size=nl)]
+    R = [Column(torch.arange(max(nr, 1), dtype=torch.int32, device="cuda"), None, 3, size=nr)]
+    li, ri = gdf_column(), gdf_column()
+    ctx = new_context()
+    fn = getattr(libgdf, f"gdf_{how}_join")
+    idx = (C.c_int * 1)(0)
+    fn(column_array(L), 1, idx, column_array(R), 1, idx, 1, 0, None, C.byref(li), C.byref(ri), C.byref(ctx))
+    if how == "full" and (nl or nr):
+        n = max(nl, nr)
+        assert li.size == n and ri.size == n
+        import ctypes
+        a = gdf.api._take_library_column(li, torch.int32).cpu().numpy()
+        b = gdf.api._take_library_column(ri, torch.int32).cpu().numpy()
+        if nl:
+            assert list(a) == list(range(nl)) and np.all(b == -1)
+        else:
+            assert list(b) == list(range(nr)) and np.all(a == -1)
+    elif how == "left" and nl and not nr:
+        # joining.cu:304-323 has no early return for LEFT with an empty right side: every left row pairs with -1
+        assert li.size == nl and ri.size == nl
+        a = gdf.api._take_library_column(li, torch.int32).cpu().numpy()
+        b = gdf.api._take_library_column(ri, torch.int32).cpu().numpy()
+        assert sorted(a) == list(range(nl)) and np.all(b == -1)
+    else:
+        assert li.size == 0 and ri.size == 0
+
+
+def test_no_match_returns_empty_columns(gdf):
+    li, ri = gdf.api.join(_cols([np.arange(1000, dtype=np.int64)]), _cols([np.arange(5000, 6000, dtype=np.int64)]))
+    assert li.numel() == 0 and ri.numel() == 0
+
+
+def test_error_codes(gdf):
+    import torch
+    from libgdf_amd import GDFError, gdf_column, libgdf, new_context
+    from libgdf_amd.columns import GDF_SORT, column_array
+    a = _cols([gen_rand(np.int32, 10)])
+    b = _cols([gen_rand(np.int64, 10)])
+    with pytest.raises(GDFError, match="GDF_JOIN_DTYPE_MISMATCH"):
+        gdf.api.join(a, b)
+    two_l = _cols([gen_rand(np.int32, 10), gen_rand(np.int32, 10)])
+    two_r = _cols([gen_rand(np.int32, 10), gen_rand(np.int32, 10)])
+    with pytest.raises(GDFError, match="GDF_JOIN_TOO_MANY_COLUMNS"):
+        gdf.api.join(two_l, two_r, method=GDF_SORT)
+    short = _cols([gen_rand(np.int32, 10), gen_rand(np.int32, 9)])
+    with pytest.raises(GDFError, match="GDF_COLUMN_SIZE_MISMATCH"):
+        gdf.api.join(short, two_r)
+    li, ri = gdf_column(), gdf_column()
+    idx = (C.c_int * 1)(0)
+    with pytest.raises(GDFError, match="GDF_INVALID_API_CALL"):
+        libgdf.gdf_inner_join(column_array(a), 1, idx, column_array(a), 1, idx, 1, 0, None, C.byref(li), C.byref(ri), None)
+
+
+def test_medium_fk_pk_join_uses_two_partition_levels(gdf):
+    """4M build rows -> 11 fine bits (two scatter levels); unique build keys, every probe row matches once."""
+    nb, npr = 4_000_000, 6_000_000
+    build = np.random.permutation(nb).astype(np.int64)
+    probe = (oracle.splitmix64(np.arange(npr, dtype=np.uint64) + np.uint64(0x5EED0002)) % np.uint64(nb)).astype(np.int64)
+    li, ri = gdf.api.join(_cols([probe]), _cols([build]))
+    li, ri = li.cpu().numpy(), ri.cpu().numpy()
+    assert len(li) == npr
+    assert np.array_equal(np.sort(li), np.arange(npr))
+    assert np.array_equal(build[ri], probe[li])          # every emitted pair really joins
+
+
+def test_skewed_build_side_takes_global_table_path(gdf):
+    """One key repeated 20k times on the build side exceeds the LDS table (JK_MAX_BUILD = 6144)."""
+    build = np.concatenate([np.full(20000, 7, dtype=np.int32), np.arange(100, 3000, dtype=np.int32)])
+    probe = np.concatenate([np.full(30, 7, dtype=np.int32), np.arange(0, 4000, 3, dtype=np.int32)])
+    for how in ("inner", "left", "full"):
+        _check(gdf, [probe], [build], how)
+
+
+def test_result_cols_materialisation(gdf):
+    """gdf_*_join with result_cols: [left non-key..., key..., right non-key...] (joining.cu:413-439)."""
+    import torch
+    from libgdf_amd import Column, gdf_column, libgdf, new_context
+    from libgdf_amd.columns import column_array
+    nl, nr = 3000, 2000
+    lk, lp = gen_rand(np.int32, nl, 0, 500), gen_rand(np.float64, nl)
+    rk, rp = gen_rand(np.int32, nr, 0, 500), gen_rand(np.int64, nr)
+    lpv = random_valid(nl)
+    L = _cols([lp, lk], [lpv, None])
+    R = _cols([rk, rp])
+    res = [gdf_column(), gdf_column(), gdf_column()]
+    res_arr = (C.POINTER(gdf_column) * 3)(*[C.pointer(r) for r in res])
+    li, ri = gdf_column(), gdf_column()
+    ctx = new_context()
+    libgdf.gdf_left_join(column_array(L), 2, (C.c_int * 1)(1), column_array(R), 2, (C.c_int * 1)(0), 1, 3, res_arr,
+                         C.byref(li), C.byref(ri), C.byref(ctx))
+    n = li.size
+    a = gdf.api._take_library_column(li, torch.int32).cpu().numpy()
+    b = gdf.api._take_library_column(ri, torch.int32).cpu().numpy()
+    assert [r.size for r in res] == [n, n, n] and [r.dtype for r in res] == [6, 3, 4]
+
+    def pull(col, tdtype):
+        import torch
+        nbytes_valid = (n + 7) // 8
+        data = torch.empty(n, dtype=tdtype, device="cuda")
+        valid = torch.empty(nbytes_valid, dtype=torch.uint8, device="cuda")
+        gdf.api._hipMemcpyDtoD(data.data_ptr(), col.data, n * data.element_size())
+        gdf.api._hipMemcpyDtoD(valid.data_ptr(), col.valid, nbytes_valid)
+        libgdf.gdf_column_free(C.byref(col))
+        bits = np.unpackbits(valid.cpu().numpy(), bitorder="little")[:n].astype(bool)
+        return data.cpu().numpy(), bits
+
+    d0, v0 = pull(res[0], torch.float64)
+    d1, v1 = pull(res[1], torch.int32)
+    d2, v2 = pull(res[2], torch.int64)
+    np.testing.assert_array_equal(d0[v0], lp[a][v0])
+    np.testing.assert_array_equal(v0, lpv[a])
+    np.testing.assert_array_equal(d1, lk[a]); assert v1.all()
+    m = b >= 0
+    np.testing.assert_array_equal(v2, m)
+    np.testing.assert_array_equal(d2[m], rp[b[m]])

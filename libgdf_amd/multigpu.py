@@ -1,0 +1,89 @@
+"""Key-partitioned multi-GPU join / group-by: one process per GPU, RCCL all-to-all over xGMI.
+
+The reference is single-GPU (no NCCL/MPI anywhere), so this layer has no
+counterpart there; it sits ABOVE the unchanged per-GPU ``gdf_*`` C ABI:
+
+  1. every rank hash-partitions each relation on the join key into ``world`` partitions with the public
+     ``gdf_hash_partition`` (Murmur3 & (P-1) / % P) -- a different hash from the mix64 the local join
+     partitions on, so rank placement and local partitioning are uncorrelated;
+  2. the ``world x world`` send-count matrix is exchanged (one tiny all-to-all);
+  3. one ``all_to_all_single`` per column moves partition r to rank r (xGMI is point-to-point, an
+     all-to-all drives all 7 links of a GPU at once, so each column goes out as ONE large collective);
+  4. every rank joins what it received with ``gdf_inner_join`` and maps the local row numbers back to the
+     global row ids that travelled with the keys.
+
+Global row ids are int64 (8 B rows x 8 ranks exceeds the int32 index ABI of a single ``gdf_*`` call).
+``partition_fn`` / ``join_fn`` are injectable so the exchange logic is testable on CPU with the gloo
+backend (tests/test_multigpu_gloo.py): there they are numpy oracle functions, here the C ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+
+def _device_partition(keys, payload, world):
+    """gdf_hash_partition over (key, payload) on the key column -> (keys_out, payload_out, offsets list)."""
+    from . import api
+    from .columns import Column
+    outs, offsets = api.hash_partition([Column(keys), Column(payload)], [0], world)
+    return outs[0].data, outs[1].data, offsets
+
+
+def _device_inner_join(probe_keys, build_keys):
+    from . import api
+    from .columns import Column
+    return api.join([Column(probe_keys)], [Column(build_keys)], how="inner")
+
+
+def exchange_by_key(keys, payload, partition_fn=_device_partition, group=None):
+    """Send every (key, payload) row to rank ``hash(key) mod world``.  Returns (keys, payload) received."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    pk, pp, offsets = partition_fn(keys, payload, world)
+    n = keys.numel()
+    bounds = list(offsets) + [n]
+    send_counts = torch.tensor([bounds[r + 1] - bounds[r] for r in range(world)], dtype=torch.int64, device=keys.device)
+    recv_counts = torch.empty_like(send_counts)
+    dist.all_to_all_single(recv_counts, send_counts, group=group)          # the count matrix, one row per rank
+    send_split = send_counts.tolist()
+    recv_split = recv_counts.tolist()
+    total = int(sum(recv_split))
+    rk = torch.empty(total, dtype=keys.dtype, device=keys.device)
+    rp = torch.empty(total, dtype=payload.dtype, device=keys.device)
+    dist.all_to_all_single(rk, pk, recv_split, send_split, group=group)
+    dist.all_to_all_single(rp, pp, recv_split, send_split, group=group)
+    return rk, rp
+
+
+def distributed_inner_join(probe_keys, build_keys, partition_fn=_device_partition, join_fn=_device_inner_join, group=None):
+    """Inner join of two row-sharded relations on one integer key column.
+
+    Every rank passes its shard of both relations; the result is this rank's share of the join as GLOBAL
+    row ids ``(probe_global_row, build_global_row)``, where global row = (owner rank << 40) | local row.
+    """
+    import torch
+    import torch.distributed as dist
+    rank = dist.get_rank(group)
+    dev = probe_keys.device
+    base = rank << 40
+    probe_ids = torch.arange(probe_keys.numel(), dtype=torch.int64, device=dev) + base
+    build_ids = torch.arange(build_keys.numel(), dtype=torch.int64, device=dev) + base
+    pk, pid = exchange_by_key(probe_keys, probe_ids, partition_fn, group)
+    bk, bid = exchange_by_key(build_keys, build_ids, partition_fn, group)
+    li, ri = join_fn(pk, bk)
+    return pid[li.long()], bid[ri.long()]
+
+
+def distributed_group_by_sum(keys, values, group_fn=None, partition_fn=_device_partition, group=None):
+    """Group-by-sum of a row-sharded (key, value) relation: local pre-aggregation, exchange of the partial
+    aggregates by key hash (far fewer rows than the input), final aggregation on the owner rank."""
+    if group_fn is None:
+        def group_fn(k, v):
+            from . import api
+            from .columns import Column
+            gk, ga = api.group_by("sum", [Column(k)], Column(v))
+            return gk[0].clone(), ga.clone()
+    k1, v1 = group_fn(keys, values)
+    k2, v2 = exchange_by_key(k1, v1, partition_fn, group)
+    return group_fn(k2, v2)

@@ -1,0 +1,93 @@
+"""world_size-2 gloo test of the multi-GPU layer's exchange logic on CPU (no GPU needed).
+
+libgdf_amd/multigpu.py is exercised with its injectable partition / join functions bound to the numpy
+oracle (the C ABI needs a GPU); what is under test is the count exchange, the all-to-all splits, the
+global-row-id bookkeeping and that the union over ranks equals the single-process join."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import oracle
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _np_partition(keys, payload, world):
+    k = keys.numpy()
+    perm, offsets, _ = oracle.hash_partition([k], [0], world)
+    return torch.from_numpy(k[perm]), torch.from_numpy(payload.numpy()[perm]), [int(o) for o in offsets]
+
+
+def _np_join(pk, bk):
+    li, ri = oracle.join([pk.numpy()], [bk.numpy()], "inner")
+    return torch.from_numpy(li), torch.from_numpy(ri)
+
+
+def _np_group_sum(k, v):
+    keys, agg = oracle.group_by("sum", [k.numpy()], v.numpy())
+    return torch.from_numpy(keys[0].copy()), torch.from_numpy(agg.copy())
+
+
+def _shards(world):
+    rng = np.random.RandomState(1234)
+    probes = [rng.randint(0, 500, size=3000 + 17 * r).astype(np.int64) for r in range(world)]
+    builds = [rng.randint(0, 500, size=400 + 5 * r).astype(np.int64) for r in range(world)]
+    return probes, builds
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from libgdf_amd import multigpu
+    probes, builds = _shards(world)
+    pg, bg = multigpu.distributed_inner_join(torch.from_numpy(probes[rank]), torch.from_numpy(builds[rank]),
+                                             partition_fn=_np_partition, join_fn=_np_join)
+    k = torch.from_numpy(probes[rank])
+    v = torch.from_numpy((probes[rank] * 3 + rank).astype(np.int64))
+    gk, gv = multigpu.distributed_group_by_sum(k, v, group_fn=_np_group_sum, partition_fn=_np_partition)
+    q.put((rank, pg.numpy(), bg.numpy(), gk.numpy(), gv.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_join_and_groupby_match_single_process():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    probes, builds = _shards(world)
+    # expected: join of the concatenated relations, expressed in the same global row ids
+    gp = np.concatenate([(r << 40) + np.arange(len(probes[r]), dtype=np.int64) for r in range(world)])
+    gb = np.concatenate([(r << 40) + np.arange(len(builds[r]), dtype=np.int64) for r in range(world)])
+    li, ri = oracle.join([np.concatenate(probes)], [np.concatenate(builds)], "inner")
+    exp = np.stack([gp[li], gb[ri]], axis=1)
+    got = np.concatenate([np.stack([r[1], r[2]], axis=1) for r in results])
+    exp = exp[np.lexsort(exp.T[::-1])]
+    got = got[np.lexsort(got.T[::-1])]
+    np.testing.assert_array_equal(got, exp)
+    # every joined pair was produced by exactly one rank, and keys are disjoint between ranks
+    ek, ea = oracle.group_by("sum", [np.concatenate(probes)],
+                             np.concatenate([(probes[r] * 3 + r).astype(np.int64) for r in range(world)]))
+    gk = np.concatenate([r[3] for r in results])
+    gv = np.concatenate([r[4] for r in results])
+    o = np.argsort(gk)
+    np.testing.assert_array_equal(gk[o], ek[0])
+    np.testing.assert_array_equal(gv[o], ea)

@@ -110,6 +110,18 @@ static inline int stream_grid(size_t items, int per_block, int max_blocks = NUM_
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return __lane_id(); }
 
+// Workgroup barrier that also drains this wave's outstanding LDS operations.
+// hipcc (ROCm 7.2, gfx950) lowers __syncthreads() after NON-RETURNING LDS atomics
+// (ds_add_u32 ...) to a bare s_barrier: no s_waitcnt lgkmcnt(0).  A wave can then
+// pass the barrier with its last wave-instruction of LDS atomics still in flight and
+// another wave reads the counters 64 increments short (seen as a ~1 % flaky
+// histogram in jk_hist; scratch/dbg3.py reproduces it).  The explicit wait is free
+// when nothing is outstanding.
+__device__ __forceinline__ void block_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
 // number of set bits of `m` strictly below this lane
 __device__ __forceinline__ int mask_rank(unsigned long long m) {
   return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));

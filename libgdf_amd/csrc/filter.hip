@@ -191,7 +191,7 @@ __global__ __launch_bounds__(FL_THREADS) void compact_count_kernel(Pred pred, in
   for (int64_t i = begin + threadIdx.x; i < end; i += FL_THREADS) c += pred(i) ? 1u : 0u;
   c = wave_reduce_add(c);
   if (lane_id() == 0) wsum[threadIdx.x / WAVE] = c;
-  __syncthreads();
+  block_sync();
   if (threadIdx.x == 0) {
     unsigned int t = 0;
     for (int w = 0; w < FL_THREADS / WAVE; ++w) t += wsum[w];
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(FL_THREADS) void compact_write_kernel(Pred pred, in
     const bool keep = i < end && pred(i);
     const unsigned long long m = __ballot(keep);
     if (lane_id() == 0) wcount[wave] = (unsigned)__popcll(m);
-    __syncthreads();
+    block_sync();
     unsigned int before = 0, total = 0;
 #pragma unroll
     for (int w = 0; w < FL_THREADS / WAVE; ++w) {
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(FL_THREADS) void compact_write_kernel(Pred pred, in
       else ((uint64_t *)out)[pos] = ((const uint64_t *)in)[i];
     }
     base += total;
-    __syncthreads();
+    block_sync();
   }
 }
 

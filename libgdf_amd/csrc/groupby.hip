@@ -209,7 +209,7 @@ __global__ __launch_bounds__(GB_THREADS) void gb_aggregate(KeyTable t, GbKeyPlan
       if (avg) lcnt[i] = 0;
     }
     if (threadIdx.x == 0) *lfill = 0;
-    __syncthreads();
+    block_sync();
   }
 
   const int64_t begin = (int64_t)blockIdx.x * chunk;
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(GB_THREADS) void gb_aggregate(KeyTable t, GbKeyPlan
   }
 
   if (PACKED) {
-    __syncthreads();
+    block_sync();
     // merge this workgroup's partial aggregates into the global table
     for (uint32_t i = threadIdx.x; i < GB_LDS_SLOTS; i += GB_THREADS) {
       const uint64_t key = lkey[i];

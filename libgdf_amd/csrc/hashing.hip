@@ -45,16 +45,16 @@ __global__ __launch_bounds__(HP_THREADS) void part_hist_kernel(KeyTable t, int64
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_cnt[];
   for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
     for (uint32_t p = threadIdx.x; p < nparts; p += HP_THREADS) lds_cnt[p] = 0;
-    __syncthreads();
+    block_sync();
     const int64_t begin = (int64_t)c * chunk;
     const int64_t end = begin + chunk < n ? begin + chunk : n;
     for (int64_t i = begin + threadIdx.x; i < end; i += HP_THREADS) {
       const uint32_t p = part_of(hash_row<MURMUR>(t, i), nparts, pow2mask);
       atomicAdd(&lds_cnt[p], 1u);
     }
-    __syncthreads();
+    block_sync();
     for (uint32_t p = threadIdx.x; p < nparts; p += HP_THREADS) hist[(size_t)p * nchunks + c] = lds_cnt[p];
-    __syncthreads();
+    block_sync();
   }
 }
 
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(HP_THREADS) void part_scatter_kernel(KeyTable t, Pa
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_cur[];
   for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
     for (uint32_t p = threadIdx.x; p < nparts; p += HP_THREADS) lds_cur[p] = offs[(size_t)p * nchunks + c];
-    __syncthreads();
+    block_sync();
     const int64_t begin = (int64_t)c * chunk;
     const int64_t end = begin + chunk < n ? begin + chunk : n;
     for (int64_t i = begin + threadIdx.x; i < end; i += HP_THREADS) {
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(HP_THREADS) void part_scatter_kernel(KeyTable t, Pa
         }
       }
     }
-    __syncthreads();
+    block_sync();
   }
 }
 

@@ -134,9 +134,26 @@ __device__ __forceinline__ uint32_t slot_of(uint64_t key, uint32_t nslots) {
 }
 
 // ---------------------------------------------------------------------------
+// key fetch.  FAST = one 8-byte integer column without a mask: the key IS the
+// column word and every row is joinable, so the kernels read the column directly
+// (the BASELINE configuration).  Otherwise make_key() builds the key.
+// All kernels below first issue a BATCH of independent loads, then consume them:
+// with one dependent load per loop trip a wave has 512 B in flight and the kernels
+// are latency-bound at ~25 % of HBM bandwidth (profiles/r1_a_kernel_stats.md).
+// ---------------------------------------------------------------------------
+template <bool FAST>
+__device__ __forceinline__ bool fetch_key(const KeyTable &t, const KeyPlan &p, int64_t i, uint64_t &key) {
+  if (FAST) { key = ((const uint64_t *)t.col[0].data)[i]; return true; }
+  return make_key(t, p, i, key);
+}
+
+// ---------------------------------------------------------------------------
 // 1. histogram: fine histogram (global, LDS-accumulated) + per-chunk coarse histogram
 //    H1[c * nchunks + chunk]
 // ---------------------------------------------------------------------------
+constexpr int JK_HIST_ITEMS = 8;
+
+template <bool FAST>
 __global__ __launch_bounds__(JK_HIST_THREADS) void jk_hist(KeyTable t, KeyPlan plan, PartGeom g,
                                                            uint32_t *__restrict__ fine_hist,
                                                            uint32_t *__restrict__ H1) {
@@ -147,20 +164,31 @@ __global__ __launch_bounds__(JK_HIST_THREADS) void jk_hist(KeyTable t, KeyPlan p
   for (uint32_t f = threadIdx.x; f < nfine; f += JK_HIST_THREADS) fine[f] = 0;
   for (int chunk = blockIdx.x; chunk < g.nchunks; chunk += gridDim.x) {
     for (uint32_t c = threadIdx.x; c < ncoarse; c += JK_HIST_THREADS) coarse[c] = 0;
-    __syncthreads();
+    block_sync();
     const int64_t begin = (int64_t)chunk * g.chunk;
     const int64_t end = begin + g.chunk < t.nrows ? begin + g.chunk : t.nrows;
-    for (int64_t i = begin + threadIdx.x; i < end; i += JK_HIST_THREADS) {
-      uint64_t key;
-      if (make_key(t, plan, i, key)) {
-        const uint32_t f = fine_of(key, g.fb);
-        atomicAdd(&fine[f], 1u);
-        atomicAdd(&coarse[f >> g.b2], 1u);
+    for (int64_t base = begin; base < end; base += (int64_t)JK_HIST_THREADS * JK_HIST_ITEMS) {
+      uint64_t key[JK_HIST_ITEMS];
+      bool ok[JK_HIST_ITEMS];
+#pragma unroll
+      for (int k = 0; k < JK_HIST_ITEMS; ++k) {
+        const int64_t i = base + (int64_t)k * JK_HIST_THREADS + threadIdx.x;
+        ok[k] = i < end;
+        key[k] = 0;
+        if (ok[k]) ok[k] = fetch_key<FAST>(t, plan, i, key[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < JK_HIST_ITEMS; ++k) {
+        if (ok[k]) {
+          const uint32_t f = fine_of(key[k], g.fb);
+          atomicAdd(&fine[f], 1u);
+          atomicAdd(&coarse[f >> g.b2], 1u);
+        }
       }
     }
-    __syncthreads();
+    block_sync();
     for (uint32_t c = threadIdx.x; c < ncoarse; c += JK_HIST_THREADS) H1[(size_t)c * g.nchunks + chunk] = coarse[c];
-    __syncthreads();
+    block_sync();
   }
   for (uint32_t f = threadIdx.x; f < nfine; f += JK_HIST_THREADS)
     if (fine[f]) atomicAdd(&fine_hist[f], fine[f]);
@@ -168,10 +196,10 @@ __global__ __launch_bounds__(JK_HIST_THREADS) void jk_hist(KeyTable t, KeyPlan p
 
 // ---------------------------------------------------------------------------
 // LDS tile regroup shared by both scatter levels.
-//   phase A (caller): every thread has up to ITEMS tuples with bin + rank (rank
-//            from an LDS atomic on hist[bin]);
-//   phase B: exclusive scan of hist -> start; caller supplies the global base of
-//            every bin; tuples are written to LDS at start[bin] + rank;
+//   phase A: every thread holds up to ITEMS tuples with bin + rank (rank from an
+//            LDS atomic on hist[bin]);
+//   phase B: exclusive scan of hist -> start; the global base of every bin is
+//            fixed; tuples are written to LDS at start[bin] + rank;
 //   phase C: LDS position j goes to global base[bin(j)] + (j - start[bin(j)]), so a
 //            wave writes runs of consecutive addresses.
 // ---------------------------------------------------------------------------
@@ -180,7 +208,7 @@ struct TileLds {
   int32_t idx[JK_TILE];
   uint32_t hist[256];
   uint32_t start[256];
-  int64_t gbase[256];     // global base minus start[bin]
+  uint32_t gbase[256];    // (global base - start[bin]) mod 2^32; destinations are < 2^31
   uint32_t cursor[256];   // level 1: running global cursor of this chunk
   uint32_t wave_tot[JK_SC_THREADS / WAVE];
   uint32_t total;
@@ -191,7 +219,7 @@ __device__ __forceinline__ void tile_scan_bins(TileLds &s, uint32_t nbins) {
   const uint32_t v = threadIdx.x < nbins ? s.hist[threadIdx.x] : 0;
   const uint32_t incl = wave_scan_incl(v);
   if (lane_id() == WAVE - 1) s.wave_tot[threadIdx.x / WAVE] = incl;
-  __syncthreads();
+  block_sync();
   uint32_t woff = 0, tot = 0;
 #pragma unroll
   for (int w = 0; w < JK_SC_THREADS / WAVE; ++w) {
@@ -202,7 +230,41 @@ __device__ __forceinline__ void tile_scan_bins(TileLds &s, uint32_t nbins) {
   if (threadIdx.x == 0) s.total = tot;
 }
 
+// phase C: write the regrouped tile out.  LEVEL1 bins are the coarse id, LEVEL2 the sub id.
+template <bool LEVEL1>
+__device__ __forceinline__ void tile_flush(TileLds &s, const PartGeom &g, uint64_t *__restrict__ out_key,
+                                           int32_t *__restrict__ out_idx) {
+  const uint32_t total = s.total;
+  const uint32_t submask = (1u << g.b2) - 1;
+  constexpr int U = 4;
+  for (uint32_t j0 = threadIdx.x; j0 < total; j0 += JK_SC_THREADS * U) {
+    uint64_t kk[U];
+    int32_t ii[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t j = j0 + u * JK_SC_THREADS;
+      kk[u] = j < total ? s.key[j] : 0;
+      ii[u] = j < total ? s.idx[j] : 0;
+    }
+    uint32_t dst[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t f = fine_of(kk[u], g.fb);
+      const uint32_t bin = LEVEL1 ? (f >> g.b2) : (f & submask);
+      dst[u] = s.gbase[bin] + j0 + u * JK_SC_THREADS;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (j0 + u * JK_SC_THREADS < total) {
+        out_key[dst[u]] = kk[u];
+        out_idx[dst[u]] = ii[u];
+      }
+    }
+  }
+}
+
 // 2. level-1 scatter: raw key columns -> (key64, row) tuples grouped by coarse partition
+template <bool FAST>
 __global__ __launch_bounds__(JK_SC_THREADS) void jk_scatter1(KeyTable t, KeyPlan plan, PartGeom g,
                                                              const uint32_t *__restrict__ H1off,   // scanned H1
                                                              uint64_t *__restrict__ out_key, int32_t *__restrict__ out_idx) {
@@ -213,25 +275,31 @@ __global__ __launch_bounds__(JK_SC_THREADS) void jk_scatter1(KeyTable t, KeyPlan
   const int64_t begin = (int64_t)chunk * g.chunk;
   const int64_t end = begin + g.chunk < t.nrows ? begin + g.chunk : t.nrows;
   for (int64_t tile = begin; tile < end; tile += JK_TILE) {
-    if (threadIdx.x < 256) s.hist[threadIdx.x] = 0;
-    __syncthreads();
+    s.hist[threadIdx.x] = 0;
+    block_sync();
     uint64_t key[JK_SC_ITEMS];
+    bool ok[JK_SC_ITEMS];
+#pragma unroll
+    for (int k = 0; k < JK_SC_ITEMS; ++k) {       // all loads first
+      const int64_t i = tile + (int64_t)k * JK_SC_THREADS + threadIdx.x;
+      ok[k] = i < end;
+      key[k] = 0;
+      if (ok[k]) ok[k] = fetch_key<FAST>(t, plan, i, key[k]);
+    }
     uint32_t binrank[JK_SC_ITEMS];   // bin << 16 | rank ; 0xffffffff = skip
 #pragma unroll
     for (int k = 0; k < JK_SC_ITEMS; ++k) {
-      const int64_t i = tile + (int64_t)k * JK_SC_THREADS + threadIdx.x;
       binrank[k] = 0xffffffffu;
-      if (i < end && make_key(t, plan, i, key[k])) {
+      if (ok[k]) {
         const uint32_t bin = fine_of(key[k], g.fb) >> g.b2;
-        const uint32_t r = atomicAdd(&s.hist[bin], 1u);
-        binrank[k] = (bin << 16) | r;
+        binrank[k] = (bin << 16) | atomicAdd(&s.hist[bin], 1u);
       }
     }
-    __syncthreads();
+    block_sync();
     tile_scan_bins(s, ncoarse);
-    __syncthreads();
+    block_sync();
     if (threadIdx.x < ncoarse) {
-      s.gbase[threadIdx.x] = (int64_t)s.cursor[threadIdx.x] - (int64_t)s.start[threadIdx.x];
+      s.gbase[threadIdx.x] = s.cursor[threadIdx.x] - s.start[threadIdx.x];
       s.cursor[threadIdx.x] += s.hist[threadIdx.x];
     }
 #pragma unroll
@@ -242,16 +310,9 @@ __global__ __launch_bounds__(JK_SC_THREADS) void jk_scatter1(KeyTable t, KeyPlan
         s.idx[pos] = (int32_t)(tile + (int64_t)k * JK_SC_THREADS + threadIdx.x);
       }
     }
-    __syncthreads();
-    const uint32_t total = s.total;
-    for (uint32_t j = threadIdx.x; j < total; j += JK_SC_THREADS) {
-      const uint64_t kk = s.key[j];
-      const uint32_t bin = fine_of(kk, g.fb) >> g.b2;
-      const int64_t dst = s.gbase[bin] + j;
-      out_key[dst] = kk;
-      out_idx[dst] = s.idx[j];
-    }
-    __syncthreads();
+    block_sync();
+    tile_flush<true>(s, g, out_key, out_idx);
+    block_sync();
   }
 }
 
@@ -282,32 +343,32 @@ __global__ __launch_bounds__(JK_SC_THREADS) void jk_scatter2(PartGeom g, Level2M
   const uint32_t end = begin + JK_TILE < pend ? begin + JK_TILE : pend;
   const uint32_t submask = nsub - 1;
 
-  if (threadIdx.x < 256) s.hist[threadIdx.x] = 0;
-  __syncthreads();
+  s.hist[threadIdx.x] = 0;
+  block_sync();
   uint64_t key[JK_SC_ITEMS];
   int32_t idx[JK_SC_ITEMS];
+#pragma unroll
+  for (int k = 0; k < JK_SC_ITEMS; ++k) {         // all loads first
+    const uint32_t i = begin + k * JK_SC_THREADS + threadIdx.x;
+    key[k] = i < end ? in_key[i] : 0;
+    idx[k] = i < end ? in_idx[i] : 0;
+  }
   uint32_t binrank[JK_SC_ITEMS];
 #pragma unroll
   for (int k = 0; k < JK_SC_ITEMS; ++k) {
     const uint32_t i = begin + k * JK_SC_THREADS + threadIdx.x;
     binrank[k] = 0xffffffffu;
     if (i < end) {
-      key[k] = in_key[i];
-      idx[k] = in_idx[i];
       const uint32_t bin = fine_of(key[k], g.fb) & submask;
-      const uint32_t r = atomicAdd(&s.hist[bin], 1u);
-      binrank[k] = (bin << 16) | r;
+      binrank[k] = (bin << 16) | atomicAdd(&s.hist[bin], 1u);
     }
   }
-  __syncthreads();
+  block_sync();
   tile_scan_bins(s, nsub);
-  __syncthreads();
+  block_sync();
   if (threadIdx.x < nsub) {
     const uint32_t cnt = s.hist[threadIdx.x];
-    if (cnt) {
-      const uint32_t gb = atomicAdd(&fine_cursor[(p << g.b2) | threadIdx.x], cnt);
-      s.gbase[threadIdx.x] = (int64_t)gb - (int64_t)s.start[threadIdx.x];
-    }
+    if (cnt) s.gbase[threadIdx.x] = atomicAdd(&fine_cursor[(p << g.b2) | threadIdx.x], cnt) - s.start[threadIdx.x];
   }
 #pragma unroll
   for (int k = 0; k < JK_SC_ITEMS; ++k) {
@@ -317,15 +378,8 @@ __global__ __launch_bounds__(JK_SC_THREADS) void jk_scatter2(PartGeom g, Level2M
       s.idx[pos] = idx[k];
     }
   }
-  __syncthreads();
-  const uint32_t total = s.total;
-  for (uint32_t j = threadIdx.x; j < total; j += JK_SC_THREADS) {
-    const uint64_t kk = s.key[j];
-    const uint32_t bin = fine_of(kk, g.fb) & submask;
-    const int64_t dst = s.gbase[bin] + j;
-    out_key[dst] = kk;
-    out_idx[dst] = s.idx[j];
-  }
+  block_sync();
+  tile_flush<false>(s, g, out_key, out_idx);
 }
 
 // ---------------------------------------------------------------------------
@@ -348,6 +402,8 @@ struct ProbeArgs {
   int32_t *out_probe; int32_t *out_build;
 };
 
+constexpr int JK_PROBE_BATCH = 4;
+
 template <bool WRITE>
 __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTable probe_t, KeyTable build_t) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -362,70 +418,94 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
   const uint32_t S = a.nslots;
   for (uint32_t i = threadIdx.x; i < S; i += JK_PROBE_THREADS) tidx[i] = JK_EMPTY;
   if (threadIdx.x == 0) unit_cursor = WRITE ? a.counts[blockIdx.x] : 0ull;
-  __syncthreads();
+  block_sync();
 
   // build: linear probing, slot claimed by CAS on the row word, key written by the owner
-  for (uint32_t i = threadIdx.x; i < u.build_count; i += JK_PROBE_THREADS) {
-    const uint64_t k = a.bkey[u.build_begin + i];
-    const int32_t r = a.bidx[u.build_begin + i];
-    uint32_t slot = slot_of(k, S);
-    while (atomicCAS(&tidx[slot], JK_EMPTY, r) != JK_EMPTY) slot = (slot + 1 == S) ? 0 : slot + 1;
-    tkey[slot] = k;
-  }
-  __syncthreads();
-
-  unsigned long long my_count = 0;
-  const uint32_t rounds = (u.probe_count + JK_PROBE_THREADS - 1) / JK_PROBE_THREADS;
-  for (uint32_t rnd = 0; rnd < rounds; ++rnd) {
-    const uint32_t i = rnd * JK_PROBE_THREADS + threadIdx.x;
-    const bool active = i < u.probe_count;
-    uint64_t k = 0;
-    int32_t prow = 0;
-    uint32_t cnt = 0;
-    int32_t first_build = JK_EMPTY;
-    uint32_t slot0 = 0;
-    if (active) {
-      k = a.pkey[u.probe_begin + i];
-      prow = a.pidx[u.probe_begin + i];
-      slot0 = slot_of(k, S);
-      uint32_t slot = slot0;
-      for (;;) {
-        const int32_t r = tidx[slot];
-        if (r == JK_EMPTY) break;
-        if (tkey[slot] == k && (!a.verify || rows_equal(probe_t, prow, build_t, r))) {
-          if (cnt == 0) first_build = r;
-          ++cnt;
-          if (a.build_matched) a.build_matched[r] = 1;
-        }
-        slot = (slot + 1 == S) ? 0 : slot + 1;
-      }
-      if (cnt == 0 && a.keep_unmatched_probe) cnt = 1;   // first_build stays -1
+  for (uint32_t base = 0; base < u.build_count; base += JK_PROBE_THREADS * JK_PROBE_BATCH) {
+    uint64_t k[JK_PROBE_BATCH];
+    int32_t r[JK_PROBE_BATCH];
+#pragma unroll
+    for (int b = 0; b < JK_PROBE_BATCH; ++b) {
+      const uint32_t i = base + b * JK_PROBE_THREADS + threadIdx.x;
+      k[b] = i < u.build_count ? a.bkey[u.build_begin + i] : 0;
+      r[b] = i < u.build_count ? a.bidx[u.build_begin + i] : 0;
     }
-    if (!WRITE) {
-      my_count += cnt;
-    } else {
-      // wave-level compaction: exclusive scan of cnt gives each lane its offset,
-      // one LDS atomic per wave claims the range
-      const uint32_t incl = wave_scan_incl(cnt);
-      const uint32_t wave_total = __shfl(incl, WAVE - 1, WAVE);
-      unsigned long long base = 0;
-      if (lane_id() == 0 && wave_total) base = atomicAdd(&unit_cursor, (unsigned long long)wave_total);
-      base = __shfl(base, 0, WAVE);
-      unsigned long long pos = base + incl - cnt;
-      if (cnt == 1) {
-        a.out_probe[pos] = prow;
-        a.out_build[pos] = first_build;
-      } else if (cnt > 1) {
+#pragma unroll
+    for (int b = 0; b < JK_PROBE_BATCH; ++b) {
+      if (base + b * JK_PROBE_THREADS + threadIdx.x < u.build_count) {
+        uint32_t slot = slot_of(k[b], S);
+        while (atomicCAS(&tidx[slot], JK_EMPTY, r[b]) != JK_EMPTY) slot = (slot + 1 == S) ? 0 : slot + 1;
+        tkey[slot] = k[b];
+      }
+    }
+  }
+  block_sync();
+
+  const bool need_row = WRITE || a.verify;
+  unsigned long long my_count = 0;
+  for (uint32_t base = 0; base < u.probe_count; base += JK_PROBE_THREADS * JK_PROBE_BATCH) {
+    uint64_t k[JK_PROBE_BATCH];
+    int32_t prow[JK_PROBE_BATCH];
+#pragma unroll
+    for (int b = 0; b < JK_PROBE_BATCH; ++b) {      // all loads first
+      const uint32_t i = base + b * JK_PROBE_THREADS + threadIdx.x;
+      k[b] = i < u.probe_count ? a.pkey[u.probe_begin + i] : 0;
+      prow[b] = (need_row && i < u.probe_count) ? a.pidx[u.probe_begin + i] : 0;
+    }
+#pragma unroll
+    for (int b = 0; b < JK_PROBE_BATCH; ++b) {
+      const bool active = base + b * JK_PROBE_THREADS + threadIdx.x < u.probe_count;
+      uint32_t cnt = 0;
+      int32_t first_build = JK_EMPTY;
+      uint32_t slot0 = 0;
+      if (active) {
+        slot0 = slot_of(k[b], S);
         uint32_t slot = slot0;
         for (;;) {
           const int32_t r = tidx[slot];
           if (r == JK_EMPTY) break;
-          if (tkey[slot] == k && (!a.verify || rows_equal(probe_t, prow, build_t, r))) {
-            a.out_probe[pos] = prow;
-            a.out_build[pos] = r;
-            ++pos;
+          if (tkey[slot] == k[b] && (!a.verify || rows_equal(probe_t, prow[b], build_t, r))) {
+            if (cnt == 0) first_build = r;
+            ++cnt;
+            if (a.build_matched) a.build_matched[r] = 1;
           }
           slot = (slot + 1 == S) ? 0 : slot + 1;
+        }
+        if (cnt == 0 && a.keep_unmatched_probe) cnt = 1;   // first_build stays -1
+      }
+      if (!WRITE) {
+        my_count += cnt;
+      } else {
+        // wave-level compaction.  Common case (every lane emits 0 or 1 pair): ballot + popcount;
+        // otherwise an exclusive scan of the per-lane counts.  One LDS atomic per wave claims the range.
+        unsigned long long pos;
+        if (__all(cnt <= 1)) {
+          const unsigned long long m = __ballot(cnt == 1);
+          unsigned long long wbase = 0;
+          if (lane_id() == 0 && m) wbase = atomicAdd(&unit_cursor, (unsigned long long)__popcll(m));
+          pos = __shfl(wbase, 0, WAVE) + mask_rank(m);
+        } else {
+          const uint32_t incl = wave_scan_incl(cnt);
+          const uint32_t wave_total = __shfl(incl, WAVE - 1, WAVE);
+          unsigned long long wbase = 0;
+          if (lane_id() == 0) wbase = atomicAdd(&unit_cursor, (unsigned long long)wave_total);
+          pos = __shfl(wbase, 0, WAVE) + incl - cnt;
+        }
+        if (cnt == 1) {
+          a.out_probe[pos] = prow[b];
+          a.out_build[pos] = first_build;
+        } else if (cnt > 1) {
+          uint32_t slot = slot0;
+          for (;;) {
+            const int32_t r = tidx[slot];
+            if (r == JK_EMPTY) break;
+            if (tkey[slot] == k[b] && (!a.verify || rows_equal(probe_t, prow[b], build_t, r))) {
+              a.out_probe[pos] = prow[b];
+              a.out_build[pos] = r;
+              ++pos;
+            }
+            slot = (slot + 1 == S) ? 0 : slot + 1;
+          }
         }
       }
     }
@@ -433,7 +513,7 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
   if (!WRITE) {
     my_count = wave_reduce_add(my_count);
     if (lane_id() == 0) wave_cnt[threadIdx.x / WAVE] = my_count;
-    __syncthreads();
+    block_sync();
     if (threadIdx.x == 0) {
       unsigned long long t = 0;
       for (int w = 0; w < JK_PROBE_THREADS / WAVE; ++w) t += wave_cnt[w];
@@ -617,10 +697,17 @@ static gdf_error partition_side(const KeyTable &t, const KeyPlan &plan, PartGeom
   RMM_TRY(H1.alloc(sizeof(uint32_t) * (size_t)ncoarse * g.nchunks));
   HIP_TRY(hipMemsetAsync(fine_hist.p, 0, sizeof(uint32_t) * nfine, stream0()));
   const size_t hist_lds = sizeof(uint32_t) * (nfine + ncoarse);
-  HIP_TRY(hipFuncSetAttribute((const void *)jk_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_lds));
+  // FAST: one 8-byte integer key column, no mask -> kernels read the column words directly
+  const bool fast = t.ncols == 1 && t.col[0].width == 8 && plan.mode == KM_RAW_INT && !t.any_valid;
+  HIP_TRY(hipFuncSetAttribute((const void *)jk_hist<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_lds));
+  HIP_TRY(hipFuncSetAttribute((const void *)jk_hist<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_lds));
   const int hist_grid = g.nchunks < NUM_CU ? g.nchunks : NUM_CU;
-  GDF_LAUNCH("jk_hist", jk_hist, dim3(hist_grid), dim3(JK_HIST_THREADS), hist_lds, stream0(), t, plan, g,
-                     fine_hist.as<uint32_t>(), H1.as<uint32_t>());
+  if (fast)
+    GDF_LAUNCH("jk_hist", jk_hist<true>, dim3(hist_grid), dim3(JK_HIST_THREADS), hist_lds, stream0(), t, plan, g,
+               fine_hist.as<uint32_t>(), H1.as<uint32_t>());
+  else
+    GDF_LAUNCH("jk_hist", jk_hist<false>, dim3(hist_grid), dim3(JK_HIST_THREADS), hist_lds, stream0(), t, plan, g,
+               fine_hist.as<uint32_t>(), H1.as<uint32_t>());
   HIP_CHECK_LAST();
   GDF_TRY(scan_u32(H1.as<uint32_t>(), H1.as<uint32_t>(), (size_t)ncoarse * g.nchunks, false));
 
@@ -633,8 +720,12 @@ static gdf_error partition_side(const KeyTable &t, const KeyPlan &plan, PartGeom
 
   RMM_TRY(sb->key[0].alloc(sizeof(uint64_t) * cap));
   RMM_TRY(sb->idx[0].alloc(sizeof(int32_t) * cap));
-  GDF_LAUNCH("jk_scatter1", jk_scatter1, dim3(g.nchunks), dim3(JK_SC_THREADS), 0, stream0(), t, plan, g, H1.as<uint32_t>(),
-                     sb->key[0].as<uint64_t>(), sb->idx[0].as<int32_t>());
+  if (fast)
+    GDF_LAUNCH("jk_scatter1", jk_scatter1<true>, dim3(g.nchunks), dim3(JK_SC_THREADS), 0, stream0(), t, plan, g, H1.as<uint32_t>(),
+               sb->key[0].as<uint64_t>(), sb->idx[0].as<int32_t>());
+  else
+    GDF_LAUNCH("jk_scatter1", jk_scatter1<false>, dim3(g.nchunks), dim3(JK_SC_THREADS), 0, stream0(), t, plan, g, H1.as<uint32_t>(),
+               sb->key[0].as<uint64_t>(), sb->idx[0].as<int32_t>());
   HIP_CHECK_LAST();
   sb->final_buf = 0;
   if (g.b2 > 0 && sb->joinable > 0) {
@@ -1016,11 +1107,42 @@ static gdf_error join_entry(JoinKind kind, gdf_column **left_cols, int num_left_
   return GDF_SUCCESS;
 }
 
+// ---------------------------------------------------------------------------
+// test hook: run the radix partitioner alone and hand back the fine-partitioned tuples
+// (tests/test_gpu_join_internals.py checks them against a numpy restatement of fine_of)
+// ---------------------------------------------------------------------------
+gdf_error debug_partition(gdf_column *col, int fb, uint64_t *out_key, int32_t *out_idx, uint32_t *out_fine_off,
+                          uint32_t *out_joinable) {
+  gdf_column *cols[1] = {col};
+  KeyTable t;
+  GDF_TRY(make_key_table(cols, 1, &t));
+  const KeyPlan plan = plan_keys(t);
+  PartGeom g{};
+  g.fb = fb;
+  g.b1 = fb <= 8 ? fb : (fb + 1) / 2;
+  g.b2 = fb - g.b1;
+  SideBufs sb;
+  GDF_TRY(partition_side(t, plan, g, &sb));
+  if (sb.joinable) {
+    HIP_TRY(hipMemcpy(out_key, sb.key[sb.final_buf].p, sizeof(uint64_t) * sb.joinable, hipMemcpyDeviceToDevice));
+    HIP_TRY(hipMemcpy(out_idx, sb.idx[sb.final_buf].p, sizeof(int32_t) * sb.joinable, hipMemcpyDeviceToDevice));
+  }
+  for (size_t f = 0; f < sb.fine_off.size(); ++f) out_fine_off[f] = sb.fine_off[f];
+  *out_joinable = sb.joinable;
+  return GDF_SUCCESS;
+}
+
 }  // namespace gdf_amd
 
 using namespace gdf_amd;
 
 extern "C" {
+
+// non-reference export, test hook only (out_fine_off is a HOST array of 2^fb + 1 entries)
+__attribute__((visibility("default"))) gdf_error gdf_amd_debug_partition(gdf_column *col, int fb, uint64_t *out_key, int32_t *out_idx,
+                                                                        uint32_t *out_fine_off, uint32_t *out_joinable) {
+  return debug_partition(col, fb, out_key, out_idx, out_fine_off, out_joinable);
+}
 
 gdf_error gdf_inner_join(gdf_column **left_cols, int num_left_cols, int left_join_cols[], gdf_column **right_cols,
                          int num_right_cols, int right_join_cols[], int num_cols_to_join, int result_num_cols,

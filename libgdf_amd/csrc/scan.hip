@@ -32,7 +32,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce(const ELEM *__restri
   for (size_t i = begin + threadIdx.x; i < end; i += SCAN_THREADS) acc += (ACC)in[i];
   acc = wave_reduce_add(acc);
   if (lane_id() == 0) wsum[threadIdx.x / WAVE] = acc;
-  __syncthreads();
+  block_sync();
   if (threadIdx.x == 0) {
     ACC s = 0;
     for (int w = 0; w < SCAN_THREADS / WAVE; ++w) s += wsum[w];
@@ -46,20 +46,20 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_spine(ACC *chunk_sum, int n
   __shared__ ACC wsum[SCAN_THREADS / WAVE];
   __shared__ ACC carry;
   if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
+  block_sync();
   for (int base = 0; base < nchunks; base += SCAN_THREADS) {
     const int i = base + threadIdx.x;
     ACC v = i < nchunks ? chunk_sum[i] : 0;
     ACC incl = wave_scan_incl(v);
     if (lane_id() == WAVE - 1) wsum[threadIdx.x / WAVE] = incl;
-    __syncthreads();
+    block_sync();
     ACC woff = 0;
     for (int w = 0; w < (int)(threadIdx.x / WAVE); ++w) woff += wsum[w];
     const ACC c = carry;
     if (i < nchunks) chunk_sum[i] = c + woff + incl - v;
-    __syncthreads();
+    block_sync();
     if (threadIdx.x == SCAN_THREADS - 1) carry = c + woff + incl;
-    __syncthreads();
+    block_sync();
   }
 }
 
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply(const ELEM *in, ELEM 
     }
     const ACC incl = wave_scan_incl(run);
     if (lane_id() == WAVE - 1) wsum[threadIdx.x / WAVE] = incl;
-    __syncthreads();
+    block_sync();
     ACC woff = 0, total = 0;
 #pragma unroll
     for (int w = 0; w < SCAN_THREADS / WAVE; ++w) {
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply(const ELEM *in, ELEM 
       pre += v[k];
     }
     carry += total;
-    __syncthreads();
+    block_sync();
   }
 }
 

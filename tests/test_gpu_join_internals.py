@@ -1,0 +1,64 @@
+"""-m gpu: the join's radix partitioner in isolation (test hook gdf_amd_debug_partition).
+
+Checks the invariants the probe kernels rely on: every joinable row appears exactly once, each tuple
+carries its own key, and fine partition f holds exactly the rows whose mix64 bits say f -- repeated many
+times because the failure this guards against (a barrier that did not drain LDS atomics, see
+csrc/common.h block_sync) corrupted about one run in a hundred."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from util import gen_rand
+
+pytestmark = pytest.mark.gpu
+
+
+def mix64(x):
+    x = x.astype(np.uint64)
+    x ^= x >> np.uint64(33); x *= np.uint64(0xff51afd7ed558ccd)
+    x ^= x >> np.uint64(33); x *= np.uint64(0xc4ceb9fe1a85ec53)
+    x ^= x >> np.uint64(33)
+    return x
+
+
+def _partition(gdf, col, n, fb):
+    import torch
+    lib = gdf._binding._gdf_cdll
+    lib.gdf_amd_debug_partition.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    ok = torch.full((n,), -7, dtype=torch.int64, device="cuda")
+    oi = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+    off = (C.c_uint32 * ((1 << fb) + 1))()
+    nj = C.c_uint32(0)
+    assert lib.gdf_amd_debug_partition(C.byref(col.c), fb, ok.data_ptr(), oi.data_ptr(), off, C.byref(nj)) == 0
+    return ok.cpu().numpy(), oi.cpu().numpy(), np.array(list(off), dtype=np.int64), nj.value
+
+
+@pytest.mark.parametrize("dtype,fb,n,reps", [(np.int32, 2, 10000, 300), (np.int64, 2, 10000, 300), (np.int64, 11, 3_000_000, 5),
+                                             (np.int32, 9, 1_000_000, 10)])
+def test_partition_invariants(gdf, dtype, fb, n, reps):
+    from libgdf_amd.columns import column_from_numpy
+    keys = gen_rand(dtype, n, low=0, high=2000 if n <= 10000 else 2_000_000)
+    col = column_from_numpy(keys)
+    width_mask = np.uint64((1 << (8 * np.dtype(dtype).itemsize)) - 1)
+    key64 = keys.astype(np.int64).view(np.uint64) & width_mask             # zero-extended raw bits
+    fine = (mix64(key64) >> np.uint64(64 - fb)).astype(np.int64)
+    exp_off = np.concatenate([[0], np.cumsum(np.bincount(fine, minlength=1 << fb))])
+    for _ in range(reps):
+        k, i, off, nj = _partition(gdf, col, n, fb)
+        assert nj == n
+        np.testing.assert_array_equal(off, exp_off)
+        assert np.array_equal(np.sort(i), np.arange(n)), "every row exactly once"
+        assert np.array_equal(k.view(np.uint64), key64[i]), "tuple carries its own key"
+        assert np.array_equal(fine[i], np.repeat(np.arange(1 << fb), np.diff(exp_off))), "rows sit in their partition"
+
+
+def test_partition_skips_null_rows(gdf):
+    from libgdf_amd.columns import column_from_numpy
+    n = 50000
+    keys = gen_rand(np.int64, n)
+    valid = np.random.randint(0, 2, size=n).astype(bool)
+    col = column_from_numpy(keys, valid)
+    k, i, off, nj = _partition(gdf, col, n, 4)
+    assert nj == valid.sum()
+    assert np.array_equal(np.sort(i[:nj]), np.nonzero(valid)[0])

@@ -31,6 +31,7 @@
 #include "internal.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 namespace gdf_amd {
@@ -114,8 +115,8 @@ constexpr int JK_TILE = JK_SC_THREADS * JK_SC_ITEMS;   // 4096 tuples per LDS ti
 constexpr int JK_MAX_CHUNKS = 2048;
 constexpr int JK_PROBE_THREADS = 512;
 constexpr int JK_TARGET_BUILD = 3072;       // build tuples per fine partition the geometry aims at
-constexpr int JK_MAX_SLOTS = 8192;          // 96 KiB LDS table at most
-constexpr int JK_MAX_BUILD = 6144;          // 75 % load of JK_MAX_SLOTS; larger partitions take the global-table path
+constexpr int JK_MAX_BUILD = 6144;          // largest build partition kept in LDS (72 KiB of tuples + 64 KiB of table);
+                                            // larger ones take the global-table path
 constexpr uint32_t JK_PROBE_CHUNK = 1u << 17;   // probe tuples per work unit
 constexpr int32_t JK_EMPTY = -1;
 
@@ -394,52 +395,106 @@ struct ProbeArgs {
   const uint64_t *bkey; const int32_t *bidx;    // partitioned build tuples
   const uint64_t *pkey; const int32_t *pidx;    // partitioned probe tuples
   const Unit *units;
-  uint32_t nslots;
+  uint32_t nslots;              // LDS units: H (slots per cuckoo table, power of two); global-table path: slot count
+  uint32_t cap;                 // LDS units: capacity of the staged build partition (multiple of 64)
   int keep_unmatched_probe;     // LEFT / FULL: emit (probe, -1)
   int verify;                   // confirm hits on the original columns
   uint8_t *build_matched;       // FULL: byte per build ROW, set when matched (may be null)
   uint64_t *counts;             // COUNT pass output / WRITE pass: exclusive offsets
   int32_t *out_probe; int32_t *out_build;
+  int dbg;                      // experiment switch (env GDF_JK_DBG), 0 in production
 };
 
 constexpr int JK_PROBE_BATCH = 4;
+constexpr uint32_t JK_NOPOS = 0xffffffffu;
+constexpr int JK_CUCKOO_MAX_MOVES = 24;
+
+// LDS image of one work unit's build partition (dynamic region, every carve 16-byte aligned):
+//   bk[cap]   build keys, staged linearly from HBM (position p = index inside the partition)
+//   T[2*H]    table of POSITIONS.  Cuckoo mode: T[0..H) is table 0 (slot h0), T[H..2H) table 1 (slot h1);
+//             linear-probing mode: one table of 2*H slots.
+//   bi[cap]   build row numbers (only staged when a pass needs them)
+//   misc      per-wave counters, the unit's output cursor, mode flags
+//
+// Why positions and two tables: a lookup in a cuckoo table is TWO independent reads at slots known up
+// front -- straight-line code, no data-dependent loop.  With one lane per probe tuple the open-addressing
+// walk of the first version ran, per wave, as many trips as the LONGEST chain among its 256 tuples and
+// spent ~80 % of the kernel in that loop (profiles/r1_b_probe_ablation.md).  Cuckoo needs unique-ish keys
+// (at most two copies of a key64 fit); partitions where the insertion does not settle (duplicate build
+// keys, or plain bad luck) fall back, per unit, to linear probing over the same LDS image, which keeps
+// the multimap semantics of the reference (join_kernels.cuh:259-455).
+struct ProbeLds {
+  uint64_t *bk;
+  uint32_t *T;
+  int32_t *bi;
+  unsigned long long *wave_cnt;      // [JK_PROBE_THREADS / WAVE]
+  unsigned long long *unit_cursor;
+  unsigned int *cuckoo_failed;
+};
+
+__device__ __forceinline__ ProbeLds carve_probe_lds(unsigned char *raw, uint32_t cap, uint32_t H) {
+  ProbeLds l;
+  l.bk = (uint64_t *)raw;
+  l.T = (uint32_t *)(raw + (size_t)cap * 8);
+  l.bi = (int32_t *)(raw + (size_t)cap * 8 + (size_t)H * 8);
+  l.wave_cnt = (unsigned long long *)(raw + (size_t)cap * 12 + (size_t)H * 8);
+  l.unit_cursor = l.wave_cnt + JK_PROBE_THREADS / WAVE;
+  l.cuckoo_failed = (unsigned int *)(l.unit_cursor + 1);
+  return l;
+}
+static size_t probe_lds_bytes(uint32_t cap, uint32_t H) {
+  return (size_t)cap * 12 + (size_t)H * 8 + sizeof(unsigned long long) * (JK_PROBE_THREADS / WAVE + 2);
+}
+
+// two slot hashes from bits of mix64 that the partition id (top fb <= 15 bits) does not use
+__device__ __forceinline__ uint32_t slot_h0(uint64_t m, uint32_t H) { return (uint32_t)m & (H - 1); }
+__device__ __forceinline__ uint32_t slot_h1(uint64_t m, uint32_t H) { return (uint32_t)(m >> 24) & (H - 1); }
 
 template <bool WRITE>
 __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTable probe_t, KeyTable build_t) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  // one dynamic region (keeps every carve 16-byte aligned; nslots is a multiple of 64):
-  //   [keys: nslots x 8][rows: nslots x 4][wave counts: 8 x 8][unit cursor: 8]
-  uint64_t *tkey = (uint64_t *)lds_raw;
-  int32_t *tidx = (int32_t *)(lds_raw + (size_t)a.nslots * 8);
-  unsigned long long *wave_cnt = (unsigned long long *)(lds_raw + (size_t)a.nslots * 12);
-  unsigned long long &unit_cursor = wave_cnt[JK_PROBE_THREADS / WAVE];   // WRITE: next free output position
-
+  const uint32_t H = a.nslots, cap = a.cap;
+  const ProbeLds l = carve_probe_lds(lds_raw, cap, H);
   const Unit u = a.units[blockIdx.x];
-  const uint32_t S = a.nslots;
-  for (uint32_t i = threadIdx.x; i < S; i += JK_PROBE_THREADS) tidx[i] = JK_EMPTY;
-  if (threadIdx.x == 0) unit_cursor = WRITE ? a.counts[blockIdx.x] : 0ull;
+  const bool need_bi = WRITE || a.verify || a.build_matched != nullptr;
+
+  // ---- stage the build partition, clear the table ----
+  for (uint32_t i = threadIdx.x; i < u.build_count; i += JK_PROBE_THREADS) {
+    l.bk[i] = a.bkey[u.build_begin + i];
+    if (need_bi) l.bi[i] = a.bidx[u.build_begin + i];
+  }
+  for (uint32_t i = threadIdx.x; i < 2 * H; i += JK_PROBE_THREADS) l.T[i] = JK_NOPOS;
+  if (threadIdx.x == 0) { *l.unit_cursor = WRITE ? a.counts[blockIdx.x] : 0ull; *l.cuckoo_failed = 0; }
   block_sync();
 
-  // build: linear probing, slot claimed by CAS on the row word, key written by the owner
-  for (uint32_t base = 0; base < u.build_count; base += JK_PROBE_THREADS * JK_PROBE_BATCH) {
-    uint64_t k[JK_PROBE_BATCH];
-    int32_t r[JK_PROBE_BATCH];
-#pragma unroll
-    for (int b = 0; b < JK_PROBE_BATCH; ++b) {
-      const uint32_t i = base + b * JK_PROBE_THREADS + threadIdx.x;
-      k[b] = i < u.build_count ? a.bkey[u.build_begin + i] : 0;
-      r[b] = i < u.build_count ? a.bidx[u.build_begin + i] : 0;
+  // ---- cuckoo build: exchange positions until an empty slot absorbs the chain ----
+  for (uint32_t p0 = threadIdx.x; p0 < u.build_count; p0 += JK_PROBE_THREADS) {
+    uint32_t cur = p0, table = 0;
+    int moves = 0;
+    for (; moves < JK_CUCKOO_MAX_MOVES; ++moves) {
+      const uint64_t m = mix64(l.bk[cur]);
+      const uint32_t slot = table ? H + slot_h1(m, H) : slot_h0(m, H);
+      const uint32_t old = atomicExch(&l.T[slot], cur);
+      if (old == JK_NOPOS) break;
+      cur = old;          // the evicted tuple moves to its other table
+      table ^= 1;
     }
-#pragma unroll
-    for (int b = 0; b < JK_PROBE_BATCH; ++b) {
-      if (base + b * JK_PROBE_THREADS + threadIdx.x < u.build_count) {
-        uint32_t slot = slot_of(k[b], S);
-        while (atomicCAS(&tidx[slot], JK_EMPTY, r[b]) != JK_EMPTY) slot = (slot + 1 == S) ? 0 : slot + 1;
-        tkey[slot] = k[b];
-      }
-    }
+    if (moves == JK_CUCKOO_MAX_MOVES) *l.cuckoo_failed = 1;   // `cur` is homeless: rebuild below
   }
   block_sync();
+  const bool cuckoo = *l.cuckoo_failed == 0 && !(a.dbg & 8);
+  if (!cuckoo) {
+    // ---- linear-probing rebuild over the same 2*H slots (multimap: duplicates simply chain) ----
+    block_sync();
+    for (uint32_t i = threadIdx.x; i < 2 * H; i += JK_PROBE_THREADS) l.T[i] = JK_NOPOS;
+    block_sync();
+    const uint32_t mask = 2 * H - 1;
+    for (uint32_t p = threadIdx.x; p < u.build_count; p += JK_PROBE_THREADS) {
+      uint32_t slot = (uint32_t)mix64(l.bk[p]) & mask;
+      while (atomicCAS(&l.T[slot], JK_NOPOS, p) != JK_NOPOS) slot = (slot + 1) & mask;
+    }
+    block_sync();
+  }
 
   const bool need_row = WRITE || a.verify;
   unsigned long long my_count = 0;
@@ -447,64 +502,111 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
     uint64_t k[JK_PROBE_BATCH];
     int32_t prow[JK_PROBE_BATCH];
 #pragma unroll
-    for (int b = 0; b < JK_PROBE_BATCH; ++b) {      // all loads first
+    for (int b = 0; b < JK_PROBE_BATCH; ++b) {      // all HBM loads first
       const uint32_t i = base + b * JK_PROBE_THREADS + threadIdx.x;
       k[b] = i < u.probe_count ? a.pkey[u.probe_begin + i] : 0;
       prow[b] = (need_row && i < u.probe_count) ? a.pidx[u.probe_begin + i] : 0;
     }
+    uint32_t cnt[JK_PROBE_BATCH];
+    uint32_t hit_a[JK_PROBE_BATCH], hit_b[JK_PROBE_BATCH];   // matching build positions (cuckoo mode: at most two)
+    if (cuckoo) {
+      uint32_t pa[JK_PROBE_BATCH], pb[JK_PROBE_BATCH];
+#pragma unroll
+      for (int b = 0; b < JK_PROBE_BATCH; ++b) {    // 8 independent table reads
+        const uint64_t m = mix64(k[b]);
+        pa[b] = l.T[slot_h0(m, H)];
+        pb[b] = l.T[H + slot_h1(m, H)];
+      }
+      uint64_t ka[JK_PROBE_BATCH], kb[JK_PROBE_BATCH];
+#pragma unroll
+      for (int b = 0; b < JK_PROBE_BATCH; ++b) {    // 8 independent key reads (position 0 stands in for "empty")
+        ka[b] = l.bk[pa[b] == JK_NOPOS ? 0 : pa[b]];
+        kb[b] = l.bk[pb[b] == JK_NOPOS ? 0 : pb[b]];
+      }
+#pragma unroll
+      for (int b = 0; b < JK_PROBE_BATCH; ++b) {
+        const bool active = base + b * JK_PROBE_THREADS + threadIdx.x < u.probe_count;
+        bool ha = active && pa[b] != JK_NOPOS && ka[b] == k[b];
+        bool hb = active && pb[b] != JK_NOPOS && kb[b] == k[b];
+        if (a.verify) {
+          if (ha) ha = rows_equal(probe_t, prow[b], build_t, l.bi[pa[b]]);
+          if (hb) hb = rows_equal(probe_t, prow[b], build_t, l.bi[pb[b]]);
+        }
+        hit_a[b] = ha ? pa[b] : (hb ? pb[b] : JK_NOPOS);
+        hit_b[b] = (ha && hb) ? pb[b] : JK_NOPOS;
+        cnt[b] = (uint32_t)ha + (uint32_t)hb;
+        if (a.build_matched) {
+          if (ha) a.build_matched[l.bi[pa[b]]] = 1;
+          if (hb) a.build_matched[l.bi[pb[b]]] = 1;
+        }
+      }
+    } else {
+      const uint32_t mask = 2 * H - 1;
+#pragma unroll
+      for (int b = 0; b < JK_PROBE_BATCH; ++b) {
+        cnt[b] = 0;
+        hit_a[b] = hit_b[b] = JK_NOPOS;
+        if (base + b * JK_PROBE_THREADS + threadIdx.x < u.probe_count) {
+          uint32_t slot = (uint32_t)mix64(k[b]) & mask;
+          for (;;) {
+            const uint32_t p = l.T[slot];
+            if (p == JK_NOPOS) break;
+            if (l.bk[p] == k[b] && (!a.verify || rows_equal(probe_t, prow[b], build_t, l.bi[p]))) {
+              if (cnt[b] == 0) hit_a[b] = p;
+              ++cnt[b];
+              if (a.build_matched) a.build_matched[l.bi[p]] = 1;
+            }
+            slot = (slot + 1) & mask;
+          }
+        }
+      }
+    }
 #pragma unroll
     for (int b = 0; b < JK_PROBE_BATCH; ++b) {
       const bool active = base + b * JK_PROBE_THREADS + threadIdx.x < u.probe_count;
-      uint32_t cnt = 0;
-      int32_t first_build = JK_EMPTY;
-      uint32_t slot0 = 0;
-      if (active) {
-        slot0 = slot_of(k[b], S);
-        uint32_t slot = slot0;
-        for (;;) {
-          const int32_t r = tidx[slot];
-          if (r == JK_EMPTY) break;
-          if (tkey[slot] == k[b] && (!a.verify || rows_equal(probe_t, prow[b], build_t, r))) {
-            if (cnt == 0) first_build = r;
-            ++cnt;
-            if (a.build_matched) a.build_matched[r] = 1;
-          }
-          slot = (slot + 1 == S) ? 0 : slot + 1;
-        }
-        if (cnt == 0 && a.keep_unmatched_probe) cnt = 1;   // first_build stays -1
-      }
+      uint32_t c = cnt[b];
+      const bool pad = active && c == 0 && a.keep_unmatched_probe;   // LEFT / FULL: (probe, -1)
+      if (pad) c = 1;
       if (!WRITE) {
-        my_count += cnt;
+        my_count += c;
       } else {
         // wave-level compaction.  Common case (every lane emits 0 or 1 pair): ballot + popcount;
         // otherwise an exclusive scan of the per-lane counts.  One LDS atomic per wave claims the range.
         unsigned long long pos;
-        if (__all(cnt <= 1)) {
-          const unsigned long long m = __ballot(cnt == 1);
+        if (__all(c <= 1)) {
+          const unsigned long long mm = __ballot(c == 1);
           unsigned long long wbase = 0;
-          if (lane_id() == 0 && m) wbase = atomicAdd(&unit_cursor, (unsigned long long)__popcll(m));
-          pos = __shfl(wbase, 0, WAVE) + mask_rank(m);
+          if (lane_id() == 0 && mm) wbase = atomicAdd(l.unit_cursor, (unsigned long long)__popcll(mm));
+          pos = __shfl(wbase, 0, WAVE) + mask_rank(mm);
         } else {
-          const uint32_t incl = wave_scan_incl(cnt);
+          const uint32_t incl = wave_scan_incl(c);
           const uint32_t wave_total = __shfl(incl, WAVE - 1, WAVE);
           unsigned long long wbase = 0;
-          if (lane_id() == 0) wbase = atomicAdd(&unit_cursor, (unsigned long long)wave_total);
-          pos = __shfl(wbase, 0, WAVE) + incl - cnt;
+          if (lane_id() == 0) wbase = atomicAdd(l.unit_cursor, (unsigned long long)wave_total);
+          pos = __shfl(wbase, 0, WAVE) + incl - c;
         }
-        if (cnt == 1) {
+        if (pad) {
           a.out_probe[pos] = prow[b];
-          a.out_build[pos] = first_build;
-        } else if (cnt > 1) {
-          uint32_t slot = slot0;
+          a.out_build[pos] = JK_EMPTY;
+        } else if (c >= 1 && (cuckoo || c == 1)) {
+          a.out_probe[pos] = prow[b];
+          a.out_build[pos] = l.bi[hit_a[b]];
+          if (c == 2) {
+            a.out_probe[pos + 1] = prow[b];
+            a.out_build[pos + 1] = l.bi[hit_b[b]];
+          }
+        } else if (c > 1) {      // linear-probing mode with several matches: walk the chain again
+          const uint32_t mask = 2 * H - 1;
+          uint32_t slot = (uint32_t)mix64(k[b]) & mask;
           for (;;) {
-            const int32_t r = tidx[slot];
-            if (r == JK_EMPTY) break;
-            if (tkey[slot] == k[b] && (!a.verify || rows_equal(probe_t, prow[b], build_t, r))) {
+            const uint32_t p = l.T[slot];
+            if (p == JK_NOPOS) break;
+            if (l.bk[p] == k[b] && (!a.verify || rows_equal(probe_t, prow[b], build_t, l.bi[p]))) {
               a.out_probe[pos] = prow[b];
-              a.out_build[pos] = r;
+              a.out_build[pos] = l.bi[p];
               ++pos;
             }
-            slot = (slot + 1 == S) ? 0 : slot + 1;
+            slot = (slot + 1) & mask;
           }
         }
       }
@@ -512,11 +614,11 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
   }
   if (!WRITE) {
     my_count = wave_reduce_add(my_count);
-    if (lane_id() == 0) wave_cnt[threadIdx.x / WAVE] = my_count;
+    if (lane_id() == 0) l.wave_cnt[threadIdx.x / WAVE] = my_count;
     block_sync();
     if (threadIdx.x == 0) {
       unsigned long long t = 0;
-      for (int w = 0; w < JK_PROBE_THREADS / WAVE; ++w) t += wave_cnt[w];
+      for (int w = 0; w < JK_PROBE_THREADS / WAVE; ++w) t += l.wave_cnt[w];
       a.counts[blockIdx.x] = t;
     }
   }
@@ -792,9 +894,10 @@ static gdf_error hash_join_core(const KeyTable &probe_t, const KeyTable &build_t
   }
   const size_t nunits = units.size();
   const size_t nslots_all = nunits + oversize.size();     // one count slot per LDS unit + one per oversize partition
-  uint32_t nslots_lds = std::max<uint32_t>(2 * max_build, 64);
-  nslots_lds = (nslots_lds + 63) & ~63u;
-  if (nslots_lds > (uint32_t)JK_MAX_SLOTS) nslots_lds = JK_MAX_SLOTS;
+  // LDS geometry shared by all units: room for the largest in-LDS build partition, H = slots per cuckoo table
+  const uint32_t cap_lds = (std::max<uint32_t>(max_build, 64) + 63) & ~63u;
+  uint32_t H_lds = 64;
+  while (H_lds < max_build) H_lds <<= 1;
 
   DevBuf d_units, d_counts, d_matched, d_tail;
   RMM_TRY(d_units.alloc(sizeof(Unit) * (nunits ? nunits : 1)));
@@ -812,12 +915,14 @@ static gdf_error hash_join_core(const KeyTable &probe_t, const KeyTable &build_t
   a.bkey = B.key[B.final_buf].as<uint64_t>(); a.bidx = B.idx[B.final_buf].as<int32_t>();
   a.pkey = P.key[P.final_buf].as<uint64_t>(); a.pidx = P.idx[P.final_buf].as<int32_t>();
   a.units = d_units.as<Unit>();
-  a.nslots = nslots_lds;
+  a.nslots = H_lds;
+  a.cap = cap_lds;
   a.keep_unmatched_probe = keep_probe ? 1 : 0;
   a.verify = plan.verify;
   a.build_matched = d_matched.as<uint8_t>();
   a.counts = d_counts.as<uint64_t>();
-  const size_t probe_lds = (size_t)nslots_lds * 12 + sizeof(unsigned long long) * (JK_PROBE_THREADS / WAVE + 2);
+  a.dbg = getenv("GDF_JK_DBG") ? atoi(getenv("GDF_JK_DBG")) : 0;
+  const size_t probe_lds = probe_lds_bytes(cap_lds, H_lds);
 
   HIP_TRY(hipFuncSetAttribute((const void *)jk_probe<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)probe_lds));
   HIP_TRY(hipFuncSetAttribute((const void *)jk_probe<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)probe_lds));

@@ -7,27 +7,36 @@
 // random HBM read per probe step into a 2*N_build-slot table plus a second random
 // read of the build key; here NO random HBM access remains:
 //
-//   1. jk_hist      both relations are turned into (key64, row) tuples and radix
-//                   partitioned on the top FB bits of mix64(key64), FB <= 15, so
-//   2. jk_scatter1  that one build partition fits an LDS hash table.  Two scatter
-//   3. jk_scatter2  levels (<= 256-way each); tiles are regrouped in LDS so the
-//                   global writes are runs of consecutive addresses.
-//   4. jk_probe<COUNT>  one workgroup per (partition, probe chunk): builds the
-//                   partition's open-addressing table in LDS, streams the probe
-//                   tuples past it, counts matches.
-//   5. scan of the per-unit counts -> exact output size and per-unit offsets
-//   6. jk_probe<WRITE>  same walk, wave-ballot compaction of the (probe, build)
-//                   index pairs into the unit's private output range.
+//   1. jk_hist      both relations are turned into (key, row) tuples and radix
+//   2. jk_scatter1  partitioned on the top FB <= 15 bits of mix64(key), so that one
+//   3. jk_scatter2  build partition fits LDS.  Two scatter levels (<= 256-way each);
+//                   tiles are regrouped in LDS so a wave writes runs of consecutive
+//                   addresses.
+//   4. jk_probe     one workgroup per (partition, probe chunk): stages the build
+//                   partition in LDS, builds a cuckoo table of POSITIONS over it
+//                   (lookup = two independent reads, no data-dependent loop; linear
+//                   probing per unit when the keys repeat), streams the probe tuples
+//                   past it and writes the (probe row, build row) pairs with
+//                   wave-ballot compaction into the unit's private output range.
+//   Output sizing: foreign-key -> primary-key joins (one pair per probe tuple, checked
+//   on a sample of units) run jk_probe<WRITE> once into slots laid out by the probe
+//   counts; everything else runs jk_probe<COUNT>, scans the unit counts to exact
+//   offsets, then jk_probe<WRITE>.
 //
-// key64 is the exact key for one <=8-byte column (or several integer columns
-// packed into 8 bytes); wider / mixed keys use a 64-bit hash and every LDS hit is
-// verified against the original columns.  Semantics kept from the reference:
-// rows with a null in any key column never match (join_kernels.cuh:58-66,314),
-// float keys compare with == (NaN matches nothing), LEFT emits (l,-1) for
-// unmatched probe rows, FULL appends (-1,r) for unmatched build rows
+// Tuple formats.  NARROW (8 bytes): key32 << 32 | row -- used whenever the key fits 32
+// bits: every key of <= 4 bytes, and 8-byte integer keys whose build-side range
+// (max - min, one extra reduction over the build keys) is below 2^32; probe keys outside
+// that range cannot match and are treated like null keys.  WIDE (12 bytes): key64 + row
+// in two arrays.  key64 is the exact key for one <= 8-byte column (or several integer
+// columns packed into 8 bytes); wider / mixed keys use a 64-bit hash and every hit is
+// verified against the original columns.
+//
+// Semantics kept from the reference: rows with a null in any key column never match
+// (join_kernels.cuh:58-66,314), float keys compare with == (NaN matches nothing), LEFT
+// emits (l,-1) for unmatched probe rows, FULL appends (-1,r) for unmatched build rows
 // (join_compute_api.h:54-186), INNER builds on the smaller side and flips
-// (joining.h:58-66), outputs are library-allocated int32 columns of exactly the
-// joined size, pair order unspecified.
+// (joining.h:58-66), outputs are library-allocated int32 columns of exactly the joined
+// size, pair order unspecified.
 #include "internal.h"
 
 #include <algorithm>
@@ -44,6 +53,8 @@ enum KeyMode : int { KM_RAW_INT = 0, KM_RAW_FLOAT, KM_PACKED, KM_HASHED };
 struct KeyPlan {
   int mode;
   int verify;                 // 1: key64 is a hash, confirm hits with rows_equal
+  int narrow;                 // 1: every joinable key is < 2^32 after subtracting kmin
+  uint64_t kmin;              // subtracted from 8-byte integer keys in narrow mode (two's complement)
   int shift[MAX_KEY_COLS];    // KM_PACKED bit offsets
 };
 
@@ -59,6 +70,8 @@ static KeyPlan plan_keys(const KeyTable &t) {
   if (t.ncols == 1) p.mode = all_int ? KM_RAW_INT : KM_RAW_FLOAT;
   else if (all_int && total <= 8) p.mode = KM_PACKED;
   else { p.mode = KM_HASHED; p.verify = 1; }
+  // zero-extended raw bits of <= 4 bytes are below 2^32 by construction
+  if (p.mode != KM_HASHED && total <= 4) p.narrow = 1;
   return p;
 }
 
@@ -78,11 +91,15 @@ __device__ __forceinline__ bool float_bits(const ColView &c, int64_t i, uint64_t
   return true;
 }
 
-// returns false when the row cannot match anything (null or NaN key)
+// returns false when the row cannot match anything (null / NaN key, or outside the build range)
 __device__ __forceinline__ bool make_key(const KeyTable &t, const KeyPlan &p, int64_t i, uint64_t &key) {
   if (!row_valid(t, i)) return false;
   switch (p.mode) {
-    case KM_RAW_INT: key = load_bits(t.col[0], i); return true;
+    case KM_RAW_INT: {
+      const uint64_t k = load_bits(t.col[0], i) - p.kmin;
+      key = k;
+      return !p.narrow || (k >> 32) == 0;
+    }
     case KM_RAW_FLOAT: return float_bits(t.col[0], i, key);
     case KM_PACKED: {
       uint64_t k = 0;
@@ -104,56 +121,119 @@ __device__ __forceinline__ bool make_key(const KeyTable &t, const KeyPlan &p, in
   }
 }
 
+// FAST = one 8-byte integer column without a mask (the BASELINE configuration): the
+// kernels read the column words directly.  All kernels below first issue a BATCH of
+// independent loads, then consume them: with one dependent load per loop trip a wave has
+// 512 B in flight and the kernels are latency-bound at ~25 % of HBM bandwidth
+// (profiles/r1_a_kernel_stats.md).
+template <bool FAST>
+__device__ __forceinline__ bool fetch_key(const KeyTable &t, const KeyPlan &p, int64_t i, uint64_t &key) {
+  if (FAST) {
+    const uint64_t k = ((const uint64_t *)t.col[0].data)[i] - p.kmin;
+    key = k;
+    return !p.narrow || (k >> 32) == 0;
+  }
+  return make_key(t, p, i, key);
+}
+
+// Batched key fetch for rows i0 + k * stride (k < N), rows >= end are inactive.  FAST issues N
+// UNCONDITIONAL loads from clamped addresses -- a load under `if (i < end)` gets its own basic block and
+// its own s_waitcnt vmcnt(0) from hipcc, which serialises the batch (seen in the ISA of jk_hist).
+template <bool FAST, int N>
+__device__ __forceinline__ void fetch_keys(const KeyTable &t, const KeyPlan &p, int64_t i0, int64_t stride, int64_t end,
+                                           uint64_t (&key)[N], bool (&ok)[N]) {
+  if (FAST) {
+    const uint64_t *col = (const uint64_t *)t.col[0].data;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const int64_t i = i0 + k * stride;
+      key[k] = col[i < end ? i : end - 1];
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      key[k] -= p.kmin;
+      ok[k] = (i0 + k * stride < end) && (!p.narrow || (key[k] >> 32) == 0);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const int64_t i = i0 + k * stride;
+      ok[k] = i < end;
+      key[k] = 0;
+      if (ok[k]) ok[k] = make_key(t, p, i, key[k]);
+    }
+  }
+}
+
+// signed min / max of an 8-byte integer key column over its valid rows
+__global__ __launch_bounds__(256) void jk_minmax(KeyTable t, long long *out_min, long long *out_max) {
+  long long lo = LLONG_MAX, hi = LLONG_MIN;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < t.nrows; i += (int64_t)gridDim.x * 256) {
+    if (row_valid(t, i)) {
+      const long long v = ((const long long *)t.col[0].data)[i];
+      lo = v < lo ? v : lo;
+      hi = v > hi ? v : hi;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const long long l2 = __shfl_xor(lo, o, WAVE), h2 = __shfl_xor(hi, o, WAVE);
+    lo = l2 < lo ? l2 : lo;
+    hi = h2 > hi ? h2 : hi;
+  }
+  if (lane_id() == 0) { atomicMin(out_min, lo); atomicMax(out_max, hi); }
+}
+
 // ---------------------------------------------------------------------------
-// partition geometry
+// partition geometry and tuple storage
 // ---------------------------------------------------------------------------
 constexpr int JK_MAX_FB = 15;               // 32768 fine partitions: 128 KiB of LDS counters in jk_hist
 constexpr int JK_HIST_THREADS = 1024;
-constexpr int JK_SC_THREADS = 256;
-constexpr int JK_SC_ITEMS = 16;
-constexpr int JK_TILE = JK_SC_THREADS * JK_SC_ITEMS;   // 4096 tuples per LDS tile
-constexpr int JK_MAX_CHUNKS = 2048;
+constexpr int JK_HIST_ITEMS = 8;
+constexpr int JK_SC_ITEMS = 16;             // tuples per thread per LDS tile; a tile is THREADS * 16 tuples
+constexpr int JK_MAX_CHUNKS = 1 << 16;     // level-1 chunks (histogram columns) at most
+constexpr int64_t JK_CHUNK_ROWS = 131072;  // rows per level-1 chunk (swept 8k..512k on C3: profiles/r1_c_sweeps.md)
 constexpr int JK_PROBE_THREADS = 512;
+constexpr int JK_PROBE_BATCH = 4;
 constexpr int JK_TARGET_BUILD = 3072;       // build tuples per fine partition the geometry aims at
-constexpr int JK_MAX_BUILD = 6144;          // largest build partition kept in LDS (72 KiB of tuples + 64 KiB of table);
-                                            // larger ones take the global-table path
+constexpr int JK_MAX_BUILD = 6144;          // largest build partition kept in LDS; larger ones take the global-table path
 constexpr uint32_t JK_PROBE_CHUNK = 1u << 17;   // probe tuples per work unit
 constexpr int32_t JK_EMPTY = -1;
+constexpr uint32_t JK_NOPOS = 0xffffffffu;
+constexpr int JK_CUCKOO_MAX_MOVES = 24;
 
 struct PartGeom {
   int fb, b1, b2;        // fine bits = b1 (level 1) + b2 (level 2)
   int nchunks;           // level-1 chunks (one histogram column each)
-  int64_t chunk;         // rows per chunk (multiple of JK_TILE)
+  int64_t chunk;         // rows per chunk (multiple of the scatter tile)
+  int dbg;               // experiment switch (env GDF_JK_SDBG), 0 in production
 };
+
+// NARROW: w[i] = key32 << 32 | row, idx unused.  WIDE: w[i] = key64, idx[i] = row.
+struct Tuples {
+  uint64_t *w;
+  int32_t *idx;
+};
+template <bool NARROW>
+__device__ __forceinline__ uint64_t tup_key(uint64_t w) { return NARROW ? (w >> 32) : w; }
+template <bool NARROW>
+__device__ __forceinline__ uint64_t tup_make(uint64_t key, int32_t row) { return NARROW ? ((key << 32) | (uint32_t)row) : key; }
 
 __device__ __forceinline__ uint32_t fine_of(uint64_t key, int fb) {
   return fb ? (uint32_t)(mix64(key) >> (64 - fb)) : 0u;
 }
-// slot hash uses the LOW half of the mix so it is independent of the partition bits
+// two slot hashes from bits of mix64 that the partition id (top fb <= 15 bits) does not use
+__device__ __forceinline__ uint32_t slot_h0(uint64_t m, uint32_t H) { return (uint32_t)m & (H - 1); }
+__device__ __forceinline__ uint32_t slot_h1(uint64_t m, uint32_t H) { return (uint32_t)(m >> 24) & (H - 1); }
+// slot of the global-table path (any table size)
 __device__ __forceinline__ uint32_t slot_of(uint64_t key, uint32_t nslots) {
   return (uint32_t)(((uint64_t)(uint32_t)mix64(key) * nslots) >> 32);
-}
-
-// ---------------------------------------------------------------------------
-// key fetch.  FAST = one 8-byte integer column without a mask: the key IS the
-// column word and every row is joinable, so the kernels read the column directly
-// (the BASELINE configuration).  Otherwise make_key() builds the key.
-// All kernels below first issue a BATCH of independent loads, then consume them:
-// with one dependent load per loop trip a wave has 512 B in flight and the kernels
-// are latency-bound at ~25 % of HBM bandwidth (profiles/r1_a_kernel_stats.md).
-// ---------------------------------------------------------------------------
-template <bool FAST>
-__device__ __forceinline__ bool fetch_key(const KeyTable &t, const KeyPlan &p, int64_t i, uint64_t &key) {
-  if (FAST) { key = ((const uint64_t *)t.col[0].data)[i]; return true; }
-  return make_key(t, p, i, key);
 }
 
 // ---------------------------------------------------------------------------
 // 1. histogram: fine histogram (global, LDS-accumulated) + per-chunk coarse histogram
 //    H1[c * nchunks + chunk]
 // ---------------------------------------------------------------------------
-constexpr int JK_HIST_ITEMS = 8;
-
 template <bool FAST>
 __global__ __launch_bounds__(JK_HIST_THREADS) void jk_hist(KeyTable t, KeyPlan plan, PartGeom g,
                                                            uint32_t *__restrict__ fine_hist,
@@ -171,13 +251,7 @@ __global__ __launch_bounds__(JK_HIST_THREADS) void jk_hist(KeyTable t, KeyPlan p
     for (int64_t base = begin; base < end; base += (int64_t)JK_HIST_THREADS * JK_HIST_ITEMS) {
       uint64_t key[JK_HIST_ITEMS];
       bool ok[JK_HIST_ITEMS];
-#pragma unroll
-      for (int k = 0; k < JK_HIST_ITEMS; ++k) {
-        const int64_t i = base + (int64_t)k * JK_HIST_THREADS + threadIdx.x;
-        ok[k] = i < end;
-        key[k] = 0;
-        if (ok[k]) ok[k] = fetch_key<FAST>(t, plan, i, key[k]);
-      }
+      fetch_keys<FAST, JK_HIST_ITEMS>(t, plan, base + threadIdx.x, JK_HIST_THREADS, end, key, ok);
 #pragma unroll
       for (int k = 0; k < JK_HIST_ITEMS; ++k) {
         if (ok[k]) {
@@ -204,26 +278,28 @@ __global__ __launch_bounds__(JK_HIST_THREADS) void jk_hist(KeyTable t, KeyPlan p
 //   phase C: LDS position j goes to global base[bin(j)] + (j - start[bin(j)]), so a
 //            wave writes runs of consecutive addresses.
 // ---------------------------------------------------------------------------
+template <bool NARROW, int THREADS>
 struct TileLds {
-  uint64_t key[JK_TILE];
-  int32_t idx[JK_TILE];
+  uint64_t w[THREADS * JK_SC_ITEMS];
+  int32_t idx[NARROW ? 4 : THREADS * JK_SC_ITEMS];
   uint32_t hist[256];
   uint32_t start[256];
   uint32_t gbase[256];    // (global base - start[bin]) mod 2^32; destinations are < 2^31
   uint32_t cursor[256];   // level 1: running global cursor of this chunk
-  uint32_t wave_tot[JK_SC_THREADS / WAVE];
+  uint32_t wave_tot[THREADS / WAVE];
   uint32_t total;
 };
 
 // block-wide exclusive scan of hist[0..nbins) (nbins <= 256 == blockDim) into start[]
-__device__ __forceinline__ void tile_scan_bins(TileLds &s, uint32_t nbins) {
+template <bool NARROW, int THREADS>
+__device__ __forceinline__ void tile_scan_bins(TileLds<NARROW, THREADS> &s, uint32_t nbins) {
   const uint32_t v = threadIdx.x < nbins ? s.hist[threadIdx.x] : 0;
   const uint32_t incl = wave_scan_incl(v);
   if (lane_id() == WAVE - 1) s.wave_tot[threadIdx.x / WAVE] = incl;
   block_sync();
   uint32_t woff = 0, tot = 0;
 #pragma unroll
-  for (int w = 0; w < JK_SC_THREADS / WAVE; ++w) {
+  for (int w = 0; w < THREADS / WAVE; ++w) {
     if (w < (int)(threadIdx.x / WAVE)) woff += s.wave_tot[w];
     tot += s.wave_tot[w];
   }
@@ -232,61 +308,56 @@ __device__ __forceinline__ void tile_scan_bins(TileLds &s, uint32_t nbins) {
 }
 
 // phase C: write the regrouped tile out.  LEVEL1 bins are the coarse id, LEVEL2 the sub id.
-template <bool LEVEL1>
-__device__ __forceinline__ void tile_flush(TileLds &s, const PartGeom &g, uint64_t *__restrict__ out_key,
-                                           int32_t *__restrict__ out_idx) {
+template <bool LEVEL1, bool NARROW, int THREADS>
+__device__ __forceinline__ void tile_flush(TileLds<NARROW, THREADS> &s, const PartGeom &g, Tuples out) {
   const uint32_t total = s.total;
   const uint32_t submask = (1u << g.b2) - 1;
   constexpr int U = 4;
-  for (uint32_t j0 = threadIdx.x; j0 < total; j0 += JK_SC_THREADS * U) {
-    uint64_t kk[U];
+  for (uint32_t j0 = threadIdx.x; j0 < total; j0 += THREADS * U) {
+    uint64_t ww[U];
     int32_t ii[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const uint32_t j = j0 + u * JK_SC_THREADS;
-      kk[u] = j < total ? s.key[j] : 0;
-      ii[u] = j < total ? s.idx[j] : 0;
+      const uint32_t j = j0 + u * THREADS;
+      ww[u] = j < total ? s.w[j] : 0;
+      ii[u] = (!NARROW && j < total) ? s.idx[j] : 0;
     }
     uint32_t dst[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const uint32_t f = fine_of(kk[u], g.fb);
+      const uint32_t f = fine_of(tup_key<NARROW>(ww[u]), g.fb);
       const uint32_t bin = LEVEL1 ? (f >> g.b2) : (f & submask);
-      dst[u] = s.gbase[bin] + j0 + u * JK_SC_THREADS;
+      dst[u] = s.gbase[bin] + j0 + u * THREADS;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      if (j0 + u * JK_SC_THREADS < total) {
-        out_key[dst[u]] = kk[u];
-        out_idx[dst[u]] = ii[u];
+      if (j0 + u * THREADS < total && !(g.dbg & 1)) {
+        out.w[dst[u]] = ww[u];
+        if (!NARROW) out.idx[dst[u]] = ii[u];
       }
     }
   }
 }
 
-// 2. level-1 scatter: raw key columns -> (key64, row) tuples grouped by coarse partition
-template <bool FAST>
-__global__ __launch_bounds__(JK_SC_THREADS) void jk_scatter1(KeyTable t, KeyPlan plan, PartGeom g,
+// 2. level-1 scatter: raw key columns -> tuples grouped by coarse partition
+template <bool FAST, bool NARROW, int THREADS>
+__global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan, PartGeom g,
                                                              const uint32_t *__restrict__ H1off,   // scanned H1
-                                                             uint64_t *__restrict__ out_key, int32_t *__restrict__ out_idx) {
-  __shared__ TileLds s;
+                                                             Tuples out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
+  TileLds<NARROW, THREADS> &s = *reinterpret_cast<TileLds<NARROW, THREADS> *>(tile_raw);
+  constexpr int JK_TILE = THREADS * JK_SC_ITEMS;
   const int chunk = blockIdx.x;
   const uint32_t ncoarse = 1u << g.b1;
   if (threadIdx.x < ncoarse) s.cursor[threadIdx.x] = H1off[(size_t)threadIdx.x * g.nchunks + chunk];
   const int64_t begin = (int64_t)chunk * g.chunk;
   const int64_t end = begin + g.chunk < t.nrows ? begin + g.chunk : t.nrows;
   for (int64_t tile = begin; tile < end; tile += JK_TILE) {
-    s.hist[threadIdx.x] = 0;
+    if (threadIdx.x < 256) s.hist[threadIdx.x] = 0;
     block_sync();
     uint64_t key[JK_SC_ITEMS];
     bool ok[JK_SC_ITEMS];
-#pragma unroll
-    for (int k = 0; k < JK_SC_ITEMS; ++k) {       // all loads first
-      const int64_t i = tile + (int64_t)k * JK_SC_THREADS + threadIdx.x;
-      ok[k] = i < end;
-      key[k] = 0;
-      if (ok[k]) ok[k] = fetch_key<FAST>(t, plan, i, key[k]);
-    }
+    fetch_keys<FAST, JK_SC_ITEMS>(t, plan, tile + threadIdx.x, THREADS, end, key, ok);   // all loads first
     uint32_t binrank[JK_SC_ITEMS];   // bin << 16 | rank ; 0xffffffff = skip
 #pragma unroll
     for (int k = 0; k < JK_SC_ITEMS; ++k) {
@@ -307,12 +378,13 @@ __global__ __launch_bounds__(JK_SC_THREADS) void jk_scatter1(KeyTable t, KeyPlan
     for (int k = 0; k < JK_SC_ITEMS; ++k) {
       if (binrank[k] != 0xffffffffu) {
         const uint32_t pos = s.start[binrank[k] >> 16] + (binrank[k] & 0xffffu);
-        s.key[pos] = key[k];
-        s.idx[pos] = (int32_t)(tile + (int64_t)k * JK_SC_THREADS + threadIdx.x);
+        const int32_t row = (int32_t)(tile + (int64_t)k * THREADS + threadIdx.x);
+        s.w[pos] = tup_make<NARROW>(key[k], row);
+        if (!NARROW) s.idx[pos] = row;
       }
     }
     block_sync();
-    tile_flush<true>(s, g, out_key, out_idx);
+    tile_flush<true, NARROW, THREADS>(s, g, out);
     block_sync();
   }
 }
@@ -325,12 +397,12 @@ struct Level2Map {                     // small host-built tables, device reside
   const uint32_t *tile_prefix;         // [ncoarse+1] tiles before each coarse partition
 };
 
-__global__ __launch_bounds__(JK_SC_THREADS) void jk_scatter2(PartGeom g, Level2Map m,
-                                                             const uint64_t *__restrict__ in_key,
-                                                             const int32_t *__restrict__ in_idx,
-                                                             uint32_t *__restrict__ fine_cursor,
-                                                             uint64_t *__restrict__ out_key, int32_t *__restrict__ out_idx) {
-  __shared__ TileLds s;
+template <bool NARROW, int THREADS>
+__global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, Tuples in,
+                                                             uint32_t *__restrict__ fine_cursor, Tuples out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
+  TileLds<NARROW, THREADS> &s = *reinterpret_cast<TileLds<NARROW, THREADS> *>(tile_raw);
+  constexpr int JK_TILE = THREADS * JK_SC_ITEMS;
   const uint32_t ncoarse = 1u << g.b1, nsub = 1u << g.b2;
   // locate the coarse partition that owns this tile (binary search over <= 257 entries)
   uint32_t lo = 0, hi = ncoarse;
@@ -344,23 +416,24 @@ __global__ __launch_bounds__(JK_SC_THREADS) void jk_scatter2(PartGeom g, Level2M
   const uint32_t end = begin + JK_TILE < pend ? begin + JK_TILE : pend;
   const uint32_t submask = nsub - 1;
 
-  s.hist[threadIdx.x] = 0;
+  if (threadIdx.x < 256) s.hist[threadIdx.x] = 0;
   block_sync();
-  uint64_t key[JK_SC_ITEMS];
+  uint64_t w[JK_SC_ITEMS];
   int32_t idx[JK_SC_ITEMS];
 #pragma unroll
   for (int k = 0; k < JK_SC_ITEMS; ++k) {         // all loads first
-    const uint32_t i = begin + k * JK_SC_THREADS + threadIdx.x;
-    key[k] = i < end ? in_key[i] : 0;
-    idx[k] = i < end ? in_idx[i] : 0;
+    const uint32_t i = begin + k * THREADS + threadIdx.x;
+    const uint32_t ic = i < end ? i : end - 1;        // clamped, unconditional: see fetch_keys
+    w[k] = in.w[ic];
+    idx[k] = NARROW ? 0 : in.idx[ic];
   }
   uint32_t binrank[JK_SC_ITEMS];
 #pragma unroll
   for (int k = 0; k < JK_SC_ITEMS; ++k) {
-    const uint32_t i = begin + k * JK_SC_THREADS + threadIdx.x;
+    const uint32_t i = begin + k * THREADS + threadIdx.x;
     binrank[k] = 0xffffffffu;
     if (i < end) {
-      const uint32_t bin = fine_of(key[k], g.fb) & submask;
+      const uint32_t bin = fine_of(tup_key<NARROW>(w[k]), g.fb) & submask;
       binrank[k] = (bin << 16) | atomicAdd(&s.hist[bin], 1u);
     }
   }
@@ -375,16 +448,16 @@ __global__ __launch_bounds__(JK_SC_THREADS) void jk_scatter2(PartGeom g, Level2M
   for (int k = 0; k < JK_SC_ITEMS; ++k) {
     if (binrank[k] != 0xffffffffu) {
       const uint32_t pos = s.start[binrank[k] >> 16] + (binrank[k] & 0xffffu);
-      s.key[pos] = key[k];
-      s.idx[pos] = idx[k];
+      s.w[pos] = w[k];
+      if (!NARROW) s.idx[pos] = idx[k];
     }
   }
   block_sync();
-  tile_flush<false>(s, g, out_key, out_idx);
+  tile_flush<false, NARROW, THREADS>(s, g, out);
 }
 
 // ---------------------------------------------------------------------------
-// 4/6. probe: one workgroup per work unit
+// 4. probe: one workgroup per work unit
 // ---------------------------------------------------------------------------
 struct Unit {
   uint32_t build_begin, build_count;   // tuple range of the fine partition on the build side
@@ -392,8 +465,7 @@ struct Unit {
 };
 
 struct ProbeArgs {
-  const uint64_t *bkey; const int32_t *bidx;    // partitioned build tuples
-  const uint64_t *pkey; const int32_t *pidx;    // partitioned probe tuples
+  Tuples build, probe;          // fine-partitioned tuples
   const Unit *units;
   uint32_t nslots;              // LDS units: H (slots per cuckoo table, power of two); global-table path: slot count
   uint32_t cap;                 // LDS units: capacity of the staged build partition (multiple of 64)
@@ -403,28 +475,27 @@ struct ProbeArgs {
   uint64_t *counts;             // COUNT pass output / WRITE pass: exclusive offsets
   int32_t *out_probe; int32_t *out_build;
   int dbg;                      // experiment switch (env GDF_JK_DBG), 0 in production
+  int optimistic;               // WRITE pass without a count pass: unit u may write at most probe_count pairs
+  unsigned long long *opt_state; // [0] = pairs written by all units, [1] = some unit needed more room
 };
 
-constexpr int JK_PROBE_BATCH = 4;
-constexpr uint32_t JK_NOPOS = 0xffffffffu;
-constexpr int JK_CUCKOO_MAX_MOVES = 24;
-
 // LDS image of one work unit's build partition (dynamic region, every carve 16-byte aligned):
-//   bk[cap]   build keys, staged linearly from HBM (position p = index inside the partition)
+//   bw[cap]   build tuples staged linearly from HBM (position p = index inside the partition);
+//             NARROW: the packed word, WIDE: the key
 //   T[2*H]    table of POSITIONS.  Cuckoo mode: T[0..H) is table 0 (slot h0), T[H..2H) table 1 (slot h1);
 //             linear-probing mode: one table of 2*H slots.
-//   bi[cap]   build row numbers (only staged when a pass needs them)
-//   misc      per-wave counters, the unit's output cursor, mode flags
+//   bi[cap]   WIDE only: build row numbers
+//   misc      per-wave counters, the unit's output cursor, mode flag
 //
 // Why positions and two tables: a lookup in a cuckoo table is TWO independent reads at slots known up
 // front -- straight-line code, no data-dependent loop.  With one lane per probe tuple the open-addressing
 // walk of the first version ran, per wave, as many trips as the LONGEST chain among its 256 tuples and
 // spent ~80 % of the kernel in that loop (profiles/r1_b_probe_ablation.md).  Cuckoo needs unique-ish keys
-// (at most two copies of a key64 fit); partitions where the insertion does not settle (duplicate build
+// (at most two copies of a key fit); partitions where the insertion does not settle (duplicate build
 // keys, or plain bad luck) fall back, per unit, to linear probing over the same LDS image, which keeps
 // the multimap semantics of the reference (join_kernels.cuh:259-455).
 struct ProbeLds {
-  uint64_t *bk;
+  uint64_t *bw;
   uint32_t *T;
   int32_t *bi;
   unsigned long long *wave_cnt;      // [JK_PROBE_THREADS / WAVE]
@@ -432,36 +503,39 @@ struct ProbeLds {
   unsigned int *cuckoo_failed;
 };
 
+template <bool NARROW>
 __device__ __forceinline__ ProbeLds carve_probe_lds(unsigned char *raw, uint32_t cap, uint32_t H) {
   ProbeLds l;
-  l.bk = (uint64_t *)raw;
+  l.bw = (uint64_t *)raw;
   l.T = (uint32_t *)(raw + (size_t)cap * 8);
-  l.bi = (int32_t *)(raw + (size_t)cap * 8 + (size_t)H * 8);
-  l.wave_cnt = (unsigned long long *)(raw + (size_t)cap * 12 + (size_t)H * 8);
+  unsigned char *after = raw + (size_t)cap * 8 + (size_t)H * 8;
+  l.bi = (int32_t *)after;
+  if (!NARROW) after += (size_t)cap * 4;
+  l.wave_cnt = (unsigned long long *)after;
   l.unit_cursor = l.wave_cnt + JK_PROBE_THREADS / WAVE;
   l.cuckoo_failed = (unsigned int *)(l.unit_cursor + 1);
   return l;
 }
-static size_t probe_lds_bytes(uint32_t cap, uint32_t H) {
-  return (size_t)cap * 12 + (size_t)H * 8 + sizeof(unsigned long long) * (JK_PROBE_THREADS / WAVE + 2);
+static size_t probe_lds_bytes(bool narrow, uint32_t cap, uint32_t H) {
+  return (size_t)cap * (narrow ? 8 : 12) + (size_t)H * 8 + sizeof(unsigned long long) * (JK_PROBE_THREADS / WAVE + 2);
 }
 
-// two slot hashes from bits of mix64 that the partition id (top fb <= 15 bits) does not use
-__device__ __forceinline__ uint32_t slot_h0(uint64_t m, uint32_t H) { return (uint32_t)m & (H - 1); }
-__device__ __forceinline__ uint32_t slot_h1(uint64_t m, uint32_t H) { return (uint32_t)(m >> 24) & (H - 1); }
+template <bool NARROW>
+__device__ __forceinline__ int32_t build_row(const ProbeLds &l, uint32_t p) {
+  return NARROW ? (int32_t)(uint32_t)l.bw[p] : l.bi[p];
+}
 
-template <bool WRITE>
+template <bool WRITE, bool NARROW>
 __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTable probe_t, KeyTable build_t) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const uint32_t H = a.nslots, cap = a.cap;
-  const ProbeLds l = carve_probe_lds(lds_raw, cap, H);
+  const ProbeLds l = carve_probe_lds<NARROW>(lds_raw, cap, H);
   const Unit u = a.units[blockIdx.x];
-  const bool need_bi = WRITE || a.verify || a.build_matched != nullptr;
 
   // ---- stage the build partition, clear the table ----
   for (uint32_t i = threadIdx.x; i < u.build_count; i += JK_PROBE_THREADS) {
-    l.bk[i] = a.bkey[u.build_begin + i];
-    if (need_bi) l.bi[i] = a.bidx[u.build_begin + i];
+    l.bw[i] = a.build.w[u.build_begin + i];
+    if (!NARROW) l.bi[i] = a.build.idx[u.build_begin + i];
   }
   for (uint32_t i = threadIdx.x; i < 2 * H; i += JK_PROBE_THREADS) l.T[i] = JK_NOPOS;
   if (threadIdx.x == 0) { *l.unit_cursor = WRITE ? a.counts[blockIdx.x] : 0ull; *l.cuckoo_failed = 0; }
@@ -472,7 +546,7 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
     uint32_t cur = p0, table = 0;
     int moves = 0;
     for (; moves < JK_CUCKOO_MAX_MOVES; ++moves) {
-      const uint64_t m = mix64(l.bk[cur]);
+      const uint64_t m = mix64(tup_key<NARROW>(l.bw[cur]));
       const uint32_t slot = table ? H + slot_h1(m, H) : slot_h0(m, H);
       const uint32_t old = atomicExch(&l.T[slot], cur);
       if (old == JK_NOPOS) break;
@@ -490,12 +564,15 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
     block_sync();
     const uint32_t mask = 2 * H - 1;
     for (uint32_t p = threadIdx.x; p < u.build_count; p += JK_PROBE_THREADS) {
-      uint32_t slot = (uint32_t)mix64(l.bk[p]) & mask;
+      uint32_t slot = (uint32_t)mix64(tup_key<NARROW>(l.bw[p])) & mask;
       while (atomicCAS(&l.T[slot], JK_NOPOS, p) != JK_NOPOS) slot = (slot + 1) & mask;
     }
     block_sync();
   }
 
+  // optimistic pass: the unit owns exactly probe_count output slots starting at its offset
+  const unsigned long long unit_base = WRITE ? a.counts[blockIdx.x] : 0ull;
+  const unsigned long long unit_end = (WRITE && a.optimistic) ? unit_base + u.probe_count : ~0ull;
   const bool need_row = WRITE || a.verify;
   unsigned long long my_count = 0;
   for (uint32_t base = 0; base < u.probe_count; base += JK_PROBE_THREADS * JK_PROBE_BATCH) {
@@ -504,8 +581,11 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
 #pragma unroll
     for (int b = 0; b < JK_PROBE_BATCH; ++b) {      // all HBM loads first
       const uint32_t i = base + b * JK_PROBE_THREADS + threadIdx.x;
-      k[b] = i < u.probe_count ? a.pkey[u.probe_begin + i] : 0;
-      prow[b] = (need_row && i < u.probe_count) ? a.pidx[u.probe_begin + i] : 0;
+      const uint32_t ic = u.probe_begin + (i < u.probe_count ? i : u.probe_count - 1);   // clamped, unconditional
+      const uint64_t w = a.probe.w[ic];
+      k[b] = tup_key<NARROW>(w);
+      if (NARROW) prow[b] = (int32_t)(uint32_t)w;
+      else prow[b] = need_row ? a.probe.idx[ic] : 0;
     }
     uint32_t cnt[JK_PROBE_BATCH];
     uint32_t hit_a[JK_PROBE_BATCH], hit_b[JK_PROBE_BATCH];   // matching build positions (cuckoo mode: at most two)
@@ -520,8 +600,8 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
       uint64_t ka[JK_PROBE_BATCH], kb[JK_PROBE_BATCH];
 #pragma unroll
       for (int b = 0; b < JK_PROBE_BATCH; ++b) {    // 8 independent key reads (position 0 stands in for "empty")
-        ka[b] = l.bk[pa[b] == JK_NOPOS ? 0 : pa[b]];
-        kb[b] = l.bk[pb[b] == JK_NOPOS ? 0 : pb[b]];
+        ka[b] = tup_key<NARROW>(l.bw[pa[b] == JK_NOPOS ? 0 : pa[b]]);
+        kb[b] = tup_key<NARROW>(l.bw[pb[b] == JK_NOPOS ? 0 : pb[b]]);
       }
 #pragma unroll
       for (int b = 0; b < JK_PROBE_BATCH; ++b) {
@@ -529,15 +609,15 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
         bool ha = active && pa[b] != JK_NOPOS && ka[b] == k[b];
         bool hb = active && pb[b] != JK_NOPOS && kb[b] == k[b];
         if (a.verify) {
-          if (ha) ha = rows_equal(probe_t, prow[b], build_t, l.bi[pa[b]]);
-          if (hb) hb = rows_equal(probe_t, prow[b], build_t, l.bi[pb[b]]);
+          if (ha) ha = rows_equal(probe_t, prow[b], build_t, build_row<NARROW>(l, pa[b]));
+          if (hb) hb = rows_equal(probe_t, prow[b], build_t, build_row<NARROW>(l, pb[b]));
         }
         hit_a[b] = ha ? pa[b] : (hb ? pb[b] : JK_NOPOS);
         hit_b[b] = (ha && hb) ? pb[b] : JK_NOPOS;
         cnt[b] = (uint32_t)ha + (uint32_t)hb;
         if (a.build_matched) {
-          if (ha) a.build_matched[l.bi[pa[b]]] = 1;
-          if (hb) a.build_matched[l.bi[pb[b]]] = 1;
+          if (ha) a.build_matched[build_row<NARROW>(l, pa[b])] = 1;
+          if (hb) a.build_matched[build_row<NARROW>(l, pb[b])] = 1;
         }
       }
     } else {
@@ -551,10 +631,11 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
           for (;;) {
             const uint32_t p = l.T[slot];
             if (p == JK_NOPOS) break;
-            if (l.bk[p] == k[b] && (!a.verify || rows_equal(probe_t, prow[b], build_t, l.bi[p]))) {
+            if (tup_key<NARROW>(l.bw[p]) == k[b] &&
+                (!a.verify || rows_equal(probe_t, prow[b], build_t, build_row<NARROW>(l, p)))) {
               if (cnt[b] == 0) hit_a[b] = p;
               ++cnt[b];
-              if (a.build_matched) a.build_matched[l.bi[p]] = 1;
+              if (a.build_matched) a.build_matched[build_row<NARROW>(l, p)] = 1;
             }
             slot = (slot + 1) & mask;
           }
@@ -585,15 +666,17 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
           if (lane_id() == 0) wbase = atomicAdd(l.unit_cursor, (unsigned long long)wave_total);
           pos = __shfl(wbase, 0, WAVE) + incl - c;
         }
-        if (pad) {
+        if (pos + c > unit_end) {
+          if (c) a.opt_state[1] = 1;     // would spill into the next unit's slots: the host redoes the join two-pass
+        } else if (pad) {
           a.out_probe[pos] = prow[b];
           a.out_build[pos] = JK_EMPTY;
         } else if (c >= 1 && (cuckoo || c == 1)) {
           a.out_probe[pos] = prow[b];
-          a.out_build[pos] = l.bi[hit_a[b]];
+          a.out_build[pos] = build_row<NARROW>(l, hit_a[b]);
           if (c == 2) {
             a.out_probe[pos + 1] = prow[b];
-            a.out_build[pos + 1] = l.bi[hit_b[b]];
+            a.out_build[pos + 1] = build_row<NARROW>(l, hit_b[b]);
           }
         } else if (c > 1) {      // linear-probing mode with several matches: walk the chain again
           const uint32_t mask = 2 * H - 1;
@@ -601,9 +684,10 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
           for (;;) {
             const uint32_t p = l.T[slot];
             if (p == JK_NOPOS) break;
-            if (l.bk[p] == k[b] && (!a.verify || rows_equal(probe_t, prow[b], build_t, l.bi[p]))) {
+            if (tup_key<NARROW>(l.bw[p]) == k[b] &&
+                (!a.verify || rows_equal(probe_t, prow[b], build_t, build_row<NARROW>(l, p)))) {
               a.out_probe[pos] = prow[b];
-              a.out_build[pos] = l.bi[p];
+              a.out_build[pos] = build_row<NARROW>(l, p);
               ++pos;
             }
             slot = (slot + 1) & mask;
@@ -611,6 +695,10 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
         }
       }
     }
+  }
+  if (WRITE && a.optimistic) {
+    block_sync();
+    if (threadIdx.x == 0) atomicAdd(&a.opt_state[0], *l.unit_cursor - unit_base);
   }
   if (!WRITE) {
     my_count = wave_reduce_add(my_count);
@@ -625,23 +713,25 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
 }
 
 // ---------------------------------------------------------------------------
-// global-table path for partitions whose build side exceeds the LDS table
-// (heavy key duplication / build sides beyond 32768 * JK_MAX_BUILD rows).
-// Same walk, table in HBM, one thread per tuple.
+// global-table path for partitions whose build side exceeds the LDS image (heavy key
+// duplication / build sides beyond 32768 * JK_MAX_BUILD rows).  Same semantics, table
+// of (key, row) slots in HBM, one thread per tuple.
 // ---------------------------------------------------------------------------
 __global__ void gj_fill(int32_t *tidx, uint32_t nslots) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nslots; i += gridDim.x * blockDim.x) tidx[i] = JK_EMPTY;
 }
-__global__ void gj_build(const uint64_t *bkey, const int32_t *bidx, uint32_t n, uint64_t *tkey, int32_t *tidx,
-                         uint32_t S) {
+template <bool NARROW>
+__global__ void gj_build(Tuples b, uint32_t begin, uint32_t n, uint64_t *tkey, int32_t *tidx, uint32_t S) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const uint64_t k = bkey[i];
+    const uint64_t w = b.w[begin + i];
+    const uint64_t k = tup_key<NARROW>(w);
+    const int32_t row = NARROW ? (int32_t)(uint32_t)w : b.idx[begin + i];
     uint32_t slot = slot_of(k, S);
-    while (atomicCAS(&tidx[slot], JK_EMPTY, bidx[i]) != JK_EMPTY) slot = (slot + 1 == S) ? 0 : slot + 1;
+    while (atomicCAS(&tidx[slot], JK_EMPTY, row) != JK_EMPTY) slot = (slot + 1 == S) ? 0 : slot + 1;
     tkey[slot] = k;
   }
 }
-template <bool WRITE>
+template <bool WRITE, bool NARROW>
 __global__ void gj_probe(ProbeArgs a, KeyTable probe_t, KeyTable build_t, const uint64_t *tkey, const int32_t *tidx,
                          uint32_t probe_begin, uint32_t probe_count, unsigned long long *cursor) {
   const uint32_t S = a.nslots;
@@ -654,8 +744,9 @@ __global__ void gj_probe(ProbeArgs a, KeyTable probe_t, KeyTable build_t, const 
     uint64_t k = 0;
     int32_t prow = 0;
     if (i < probe_count) {
-      k = a.pkey[probe_begin + i];
-      prow = a.pidx[probe_begin + i];
+      const uint64_t w = a.probe.w[probe_begin + i];
+      k = tup_key<NARROW>(w);
+      prow = NARROW ? (int32_t)(uint32_t)w : a.probe.idx[probe_begin + i];
       uint32_t slot = slot_of(k, S);
       for (;;) {
         const int32_t r = tidx[slot];
@@ -705,8 +796,8 @@ __global__ void gj_probe(ProbeArgs a, KeyTable probe_t, KeyTable build_t, const 
 // ---------------------------------------------------------------------------
 // tails: rows that never entered the partitioned path
 // ---------------------------------------------------------------------------
-// rows of `t` whose key is null/NaN, compacted in ascending order behind *cursor
-// as (row, -1) pairs (LEFT / FULL probe side)
+// rows of `t` that cannot match (null / NaN key, outside the build range), compacted
+// behind *cursor as (row, -1) pairs (LEFT / FULL probe side)
 __global__ __launch_bounds__(256) void jk_emit_unjoinable(KeyTable t, KeyPlan plan, int32_t *out_row, int32_t *out_none,
                                                           unsigned long long *cursor) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -765,28 +856,85 @@ __global__ void jk_fill_pairs(int32_t *a, int32_t av, int32_t *b, int32_t bv, in
 enum JoinKind { JOIN_INNER, JOIN_LEFT, JOIN_FULL };
 
 struct SideBufs {            // partitioned tuples of one relation
-  DevBuf key[2], idx[2];
+  DevBuf w[2], idx[2];
   int final_buf = 0;         // which ping-pong buffer holds the fine-partitioned tuples
   std::vector<uint32_t> fine_off;   // [nfine+1] on the host
   uint32_t joinable = 0;     // tuples that entered the partitioned path
+  Tuples tuples(int b) const { return Tuples{w[b].as<uint64_t>(), idx[b].as<int32_t>()}; }
+  Tuples final() const { return tuples(final_buf); }
 };
 
-static PartGeom choose_geometry(int64_t build_rows, int64_t max_rows) {
+static PartGeom choose_geometry(int64_t build_rows) {
   PartGeom g{};
+  g.dbg = getenv("GDF_JK_SDBG") ? atoi(getenv("GDF_JK_SDBG")) : 0;
   int fb = 0;
   while (fb < JK_MAX_FB && (build_rows >> fb) > JK_TARGET_BUILD) ++fb;
   g.fb = fb;
   g.b1 = fb <= 8 ? fb : (fb + 1) / 2;
   g.b2 = fb - g.b1;
-  (void)max_rows;
   return g;
+}
+
+static inline int small_grid(int64_t n) { return stream_grid((size_t)(n > 0 ? n : 1), 256 * 8); }
+
+template <bool FAST, bool NARROW, int THREADS>
+static gdf_error launch_scatter1_t(const KeyTable &t, const KeyPlan &plan, const PartGeom &g, const uint32_t *H1off, Tuples out) {
+  const size_t lds = sizeof(TileLds<NARROW, THREADS>);
+  HIP_TRY(hipFuncSetAttribute((const void *)jk_scatter1<FAST, NARROW, THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  GDF_LAUNCH("jk_scatter1", (jk_scatter1<FAST, NARROW, THREADS>), dim3(g.nchunks), dim3(THREADS), lds, stream0(), t, plan, g, H1off, out);
+  HIP_CHECK_LAST();
+  return GDF_SUCCESS;
+}
+template <bool FAST, bool NARROW>
+static gdf_error launch_scatter1_n(int threads, const KeyTable &t, const KeyPlan &plan, const PartGeom &g, const uint32_t *H1off, Tuples out) {
+  if (threads == 1024) { if constexpr (NARROW) return launch_scatter1_t<FAST, NARROW, 1024>(t, plan, g, H1off, out); }
+  if (threads >= 512) return launch_scatter1_t<FAST, NARROW, 512>(t, plan, g, H1off, out);
+  return launch_scatter1_t<FAST, NARROW, 256>(t, plan, g, H1off, out);
+}
+static gdf_error launch_scatter1(bool fast, bool narrow, int threads, const KeyTable &t, const KeyPlan &plan, const PartGeom &g,
+                                 const uint32_t *H1off, Tuples out) {
+  if (fast) return narrow ? launch_scatter1_n<true, true>(threads, t, plan, g, H1off, out)
+                          : launch_scatter1_n<true, false>(threads, t, plan, g, H1off, out);
+  return narrow ? launch_scatter1_n<false, true>(threads, t, plan, g, H1off, out)
+                : launch_scatter1_n<false, false>(threads, t, plan, g, H1off, out);
+}
+template <bool NARROW, int THREADS>
+static gdf_error launch_scatter2_t(uint32_t ntiles, const PartGeom &g, Level2Map m, Tuples in, uint32_t *cursor, Tuples out) {
+  const size_t lds = sizeof(TileLds<NARROW, THREADS>);
+  HIP_TRY(hipFuncSetAttribute((const void *)jk_scatter2<NARROW, THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  GDF_LAUNCH("jk_scatter2", (jk_scatter2<NARROW, THREADS>), dim3(ntiles), dim3(THREADS), lds, stream0(), g, m, in, cursor, out);
+  HIP_CHECK_LAST();
+  return GDF_SUCCESS;
+}
+static gdf_error launch_scatter2(bool narrow, int threads, uint32_t ntiles, const PartGeom &g, Level2Map m, Tuples in,
+                                 uint32_t *cursor, Tuples out) {
+  if (narrow) {
+    if (threads == 1024) return launch_scatter2_t<true, 1024>(ntiles, g, m, in, cursor, out);
+    if (threads == 512) return launch_scatter2_t<true, 512>(ntiles, g, m, in, cursor, out);
+    return launch_scatter2_t<true, 256>(ntiles, g, m, in, cursor, out);
+  }
+  if (threads >= 512) return launch_scatter2_t<false, 512>(ntiles, g, m, in, cursor, out);
+  return launch_scatter2_t<false, 256>(ntiles, g, m, in, cursor, out);
 }
 
 // partitions one relation into g.fb-bit fine partitions
 static gdf_error partition_side(const KeyTable &t, const KeyPlan &plan, PartGeom g, SideBufs *sb) {
   const int64_t n = t.nrows;
+  const bool narrow = plan.narrow != 0;
+  // scatter tile: THREADS * 16 tuples regrouped in LDS per step.  Bigger tiles mean longer runs per
+  // (tile, bin) -- DRAM-friendlier writes -- at the price of fewer resident workgroups.
+  static const int sc_threads_env = getenv("GDF_JK_SC_THREADS") ? atoi(getenv("GDF_JK_SC_THREADS")) : 0;
+  int sc_threads = sc_threads_env ? sc_threads_env : (narrow ? 512 : 256);
+  if (sc_threads != 256 && sc_threads != 512 && sc_threads != 1024) sc_threads = 256;
+  if (!narrow && sc_threads == 1024) sc_threads = 512;       // 16384 x 12 B would not fit 160 KiB
+  const int64_t JK_TILE = (int64_t)sc_threads * JK_SC_ITEMS;
   // level-1 chunking (one histogram column per chunk)
-  int64_t chunk = (n + JK_MAX_CHUNKS - 1) / JK_MAX_CHUNKS;
+  // Chunks are SMALL (a few tiles) and processed in blockIdx order, so that the workgroups resident at
+  // any moment write into a narrow window of every partition's output range: with a few thousand
+  // 2 MiB pages live the scatter ran ~1.5x slower per row at 1e9 rows than at 5e8 (TLB reach).
+  static const int64_t chunk_rows_env = getenv("GDF_JK_CHUNK_ROWS") ? atoll(getenv("GDF_JK_CHUNK_ROWS")) : 0;
+  int64_t chunk = chunk_rows_env ? chunk_rows_env : JK_CHUNK_ROWS;
+  if (n / chunk > JK_MAX_CHUNKS) chunk = (n + JK_MAX_CHUNKS - 1) / JK_MAX_CHUNKS;
   chunk = ((chunk + JK_TILE - 1) / JK_TILE) * JK_TILE;
   if (chunk == 0) chunk = JK_TILE;
   g.chunk = chunk;
@@ -820,14 +968,10 @@ static gdf_error partition_side(const KeyTable &t, const KeyPlan &plan, PartGeom
   sb->joinable = sb->fine_off[nfine];
   const size_t cap = sb->joinable ? sb->joinable : 1;
 
-  RMM_TRY(sb->key[0].alloc(sizeof(uint64_t) * cap));
-  RMM_TRY(sb->idx[0].alloc(sizeof(int32_t) * cap));
-  if (fast)
-    GDF_LAUNCH("jk_scatter1", jk_scatter1<true>, dim3(g.nchunks), dim3(JK_SC_THREADS), 0, stream0(), t, plan, g, H1.as<uint32_t>(),
-               sb->key[0].as<uint64_t>(), sb->idx[0].as<int32_t>());
-  else
-    GDF_LAUNCH("jk_scatter1", jk_scatter1<false>, dim3(g.nchunks), dim3(JK_SC_THREADS), 0, stream0(), t, plan, g, H1.as<uint32_t>(),
-               sb->key[0].as<uint64_t>(), sb->idx[0].as<int32_t>());
+  RMM_TRY(sb->w[0].alloc(sizeof(uint64_t) * cap));
+  if (!narrow) RMM_TRY(sb->idx[0].alloc(sizeof(int32_t) * cap));
+  const Tuples t0 = sb->tuples(0);
+  GDF_TRY(launch_scatter1(fast, narrow, sc_threads, t, plan, g, H1.as<uint32_t>(), t0));
   HIP_CHECK_LAST();
   sb->final_buf = 0;
   if (g.b2 > 0 && sb->joinable > 0) {
@@ -845,16 +989,13 @@ static gdf_error partition_side(const KeyTable &t, const KeyPlan &plan, PartGeom
     HIP_TRY(hipMemcpyAsync(d_coarse.p, coarse_off.data(), sizeof(uint32_t) * (ncoarse + 1), hipMemcpyHostToDevice, stream0()));
     HIP_TRY(hipMemcpyAsync(d_tiles.p, tile_prefix.data(), sizeof(uint32_t) * (ncoarse + 1), hipMemcpyHostToDevice, stream0()));
     HIP_TRY(hipMemcpyAsync(cursor.p, sb->fine_off.data(), sizeof(uint32_t) * nfine, hipMemcpyHostToDevice, stream0()));
-    RMM_TRY(sb->key[1].alloc(sizeof(uint64_t) * cap));
-    RMM_TRY(sb->idx[1].alloc(sizeof(int32_t) * cap));
+    RMM_TRY(sb->w[1].alloc(sizeof(uint64_t) * cap));
+    if (!narrow) RMM_TRY(sb->idx[1].alloc(sizeof(int32_t) * cap));
     Level2Map m{d_coarse.as<uint32_t>(), d_tiles.as<uint32_t>()};
-    if (ntiles)
-      GDF_LAUNCH("jk_scatter2", jk_scatter2, dim3(ntiles), dim3(JK_SC_THREADS), 0, stream0(), g, m, sb->key[0].as<uint64_t>(),
-                         sb->idx[0].as<int32_t>(), cursor.as<uint32_t>(), sb->key[1].as<uint64_t>(),
-                         sb->idx[1].as<int32_t>());
+    if (ntiles) GDF_TRY(launch_scatter2(narrow, sc_threads, ntiles, g, m, sb->tuples(0), cursor.as<uint32_t>(), sb->tuples(1)));
     HIP_CHECK_LAST();
     HIP_TRY(hipStreamSynchronize(stream0()));   // host vectors + scratch go out of scope
-    sb->key[0].reset();
+    sb->w[0].reset();
     sb->idx[0].reset();
     sb->final_buf = 1;
   } else {
@@ -863,14 +1004,53 @@ static gdf_error partition_side(const KeyTable &t, const KeyPlan &plan, PartGeom
   return GDF_SUCCESS;
 }
 
-static inline int small_grid(int64_t n) { return stream_grid((size_t)(n > 0 ? n : 1), 256 * 8); }
+// narrow mode for an 8-byte integer key: the build side's value range decides
+static gdf_error plan_narrow_range(const KeyTable &build_t, KeyPlan *plan) {
+  if (plan->narrow || plan->mode != KM_RAW_INT || build_t.col[0].width != 8 || build_t.nrows == 0) return GDF_SUCCESS;
+  if (getenv("GDF_JK_WIDE")) return GDF_SUCCESS;     // experiment switch: force the 12-byte tuple format
+  DevBuf mm;
+  RMM_TRY(mm.alloc(sizeof(long long) * 2));
+  const long long init[2] = {LLONG_MAX, LLONG_MIN};
+  HIP_TRY(hipMemcpy(mm.p, init, sizeof(init), hipMemcpyHostToDevice));
+  GDF_LAUNCH("jk_minmax", jk_minmax, dim3(small_grid(build_t.nrows)), dim3(256), 0, stream0(), build_t, mm.as<long long>(),
+             mm.as<long long>() + 1);
+  HIP_CHECK_LAST();
+  long long h[2];
+  HIP_TRY(hipMemcpy(h, mm.p, sizeof(h), hipMemcpyDeviceToHost));
+  if (h[0] > h[1]) return GDF_SUCCESS;               // no valid build row: nothing can match anyway
+  const uint64_t range = (uint64_t)h[1] - (uint64_t)h[0];
+  if (range < 0xffffffffULL) { plan->narrow = 1; plan->kmin = (uint64_t)h[0]; }
+  return GDF_SUCCESS;
+}
+
+template <bool NARROW>
+static gdf_error run_probe(bool write, const char *name, size_t nunits, size_t lds, const ProbeArgs &a, const KeyTable &probe_t,
+                           const KeyTable &build_t) {
+  if (!nunits) return GDF_SUCCESS;
+  if (write) {
+    HIP_TRY(hipFuncSetAttribute((const void *)jk_probe<true, NARROW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    GDF_LAUNCH(name, (jk_probe<true, NARROW>), dim3((unsigned)nunits), dim3(JK_PROBE_THREADS), lds, stream0(), a, probe_t, build_t);
+  } else {
+    HIP_TRY(hipFuncSetAttribute((const void *)jk_probe<false, NARROW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    GDF_LAUNCH(name, (jk_probe<false, NARROW>), dim3((unsigned)nunits), dim3(JK_PROBE_THREADS), lds, stream0(), a, probe_t, build_t);
+  }
+  HIP_CHECK_LAST();
+  return GDF_SUCCESS;
+}
+static gdf_error run_probe(bool narrow, bool write, const char *name, size_t nunits, size_t lds, const ProbeArgs &a,
+                           const KeyTable &probe_t, const KeyTable &build_t) {
+  return narrow ? run_probe<true>(write, name, nunits, lds, a, probe_t, build_t)
+                : run_probe<false>(write, name, nunits, lds, a, probe_t, build_t);
+}
 
 // The join proper.  probe_t / build_t already reflect the INNER-join swap.
 // On success *out_probe / *out_build own rmm allocations of *out_n int32 each.
 static gdf_error hash_join_core(const KeyTable &probe_t, const KeyTable &build_t, JoinKind kind, int32_t **out_probe,
                                 int32_t **out_build, int64_t *out_n) {
-  const KeyPlan plan = plan_keys(probe_t);
-  const PartGeom g = choose_geometry(build_t.nrows, probe_t.nrows);
+  KeyPlan plan = plan_keys(probe_t);
+  GDF_TRY(plan_narrow_range(build_t, &plan));
+  const bool narrow = plan.narrow != 0;
+  const PartGeom g = choose_geometry(build_t.nrows);
   const uint32_t nfine = 1u << g.fb;
   const bool keep_probe = kind != JOIN_INNER;
 
@@ -912,8 +1092,8 @@ static gdf_error hash_join_core(const KeyTable &probe_t, const KeyTable &build_t
   }
 
   ProbeArgs a{};
-  a.bkey = B.key[B.final_buf].as<uint64_t>(); a.bidx = B.idx[B.final_buf].as<int32_t>();
-  a.pkey = P.key[P.final_buf].as<uint64_t>(); a.pidx = P.idx[P.final_buf].as<int32_t>();
+  a.build = B.final();
+  a.probe = P.final();
   a.units = d_units.as<Unit>();
   a.nslots = H_lds;
   a.cap = cap_lds;
@@ -922,16 +1102,75 @@ static gdf_error hash_join_core(const KeyTable &probe_t, const KeyTable &build_t
   a.build_matched = d_matched.as<uint8_t>();
   a.counts = d_counts.as<uint64_t>();
   a.dbg = getenv("GDF_JK_DBG") ? atoi(getenv("GDF_JK_DBG")) : 0;
-  const size_t probe_lds = probe_lds_bytes(cap_lds, H_lds);
+  const size_t probe_lds = probe_lds_bytes(narrow, cap_lds, H_lds);
 
-  HIP_TRY(hipFuncSetAttribute((const void *)jk_probe<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)probe_lds));
-  HIP_TRY(hipFuncSetAttribute((const void *)jk_probe<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)probe_lds));
+  // ---- optimistic single pass ----
+  // A foreign-key -> primary-key join whose every probe row finds its key emits exactly one pair per
+  // probe tuple.  Then unit u's output is its probe_count slots at the prefix sum of the probe counts
+  // and no count pass is needed.  Tried when a count over a sample of units shows one pair per tuple;
+  // any surprise during the pass (a unit short of its slots, or needing more) falls back to count + write.
+  if (nunits && oversize.empty() && kind != JOIN_FULL && !(a.dbg & 16)) {
+    const size_t nsample = std::min<size_t>(nunits, 64);
+    std::vector<Unit> sample(nsample);
+    uint64_t sample_tuples = 0;
+    for (size_t i = 0; i < nsample; ++i) { sample[i] = units[i * nunits / nsample]; sample_tuples += sample[i].probe_count; }
+    DevBuf d_sample, d_scount, d_off, d_state;
+    RMM_TRY(d_sample.alloc(sizeof(Unit) * nsample));
+    RMM_TRY(d_scount.alloc(sizeof(uint64_t) * nsample));
+    HIP_TRY(hipMemcpyAsync(d_sample.p, sample.data(), sizeof(Unit) * nsample, hipMemcpyHostToDevice, stream0()));
+    ProbeArgs sa = a;
+    sa.units = d_sample.as<Unit>();
+    sa.counts = d_scount.as<uint64_t>();
+    sa.build_matched = nullptr;
+    GDF_TRY(run_probe(narrow, false, "jk_probe_sample", nsample, probe_lds, sa, probe_t, build_t));
+    std::vector<uint64_t> scount(nsample);
+    HIP_TRY(hipMemcpy(scount.data(), d_scount.p, sizeof(uint64_t) * nsample, hipMemcpyDeviceToHost));
+    uint64_t sample_pairs = 0;
+    for (uint64_t c : scount) sample_pairs += c;
+    if (sample_pairs == sample_tuples) {
+      std::vector<uint64_t> off(nunits + 1);
+      off[0] = 0;
+      for (size_t i = 0; i < nunits; ++i) off[i + 1] = off[i] + units[i].probe_count;
+      const uint64_t cap_pairs = off[nunits];
+      const uint64_t probe_tail = keep_probe ? (uint64_t)probe_t.nrows - P.joinable : 0;
+      const uint64_t total = cap_pairs + probe_tail;
+      if (total >= (uint64_t)INT_MAX) return GDF_COLUMN_SIZE_TOO_BIG;
+      DevBuf op, ob;
+      RMM_TRY(op.alloc(sizeof(int32_t) * (total ? total : 1)));
+      RMM_TRY(ob.alloc(sizeof(int32_t) * (total ? total : 1)));
+      RMM_TRY(d_off.alloc(sizeof(uint64_t) * (nunits + 1)));
+      RMM_TRY(d_state.alloc(sizeof(unsigned long long) * 2));
+      HIP_TRY(hipMemcpyAsync(d_off.p, off.data(), sizeof(uint64_t) * (nunits + 1), hipMemcpyHostToDevice, stream0()));
+      HIP_TRY(hipMemsetAsync(d_state.p, 0, sizeof(unsigned long long) * 2, stream0()));
+      ProbeArgs oa = a;
+      oa.counts = d_off.as<uint64_t>();
+      oa.out_probe = op.as<int32_t>();
+      oa.out_build = ob.as<int32_t>();
+      oa.build_matched = nullptr;
+      oa.optimistic = 1;
+      oa.opt_state = d_state.as<unsigned long long>();
+      GDF_TRY(run_probe(narrow, true, "jk_probe_write", nunits, probe_lds, oa, probe_t, build_t));
+      unsigned long long st[2] = {0, 0};
+      HIP_TRY(hipMemcpy(st, d_state.p, sizeof(st), hipMemcpyDeviceToHost));
+      if (st[1] == 0 && st[0] == cap_pairs) {       // dense: every slot of every unit was written
+        if (probe_tail) {
+          hipLaunchKernelGGL(jk_emit_unjoinable, dim3(small_grid(probe_t.nrows)), dim3(256), 0, stream0(), probe_t, plan,
+                             oa.out_probe + cap_pairs, oa.out_build + cap_pairs, d_tail.as<unsigned long long>());
+          HIP_CHECK_LAST();
+        }
+        HIP_TRY(hipStreamSynchronize(stream0()));
+        *out_n = (int64_t)total;
+        if (total == 0) { *out_probe = nullptr; *out_build = nullptr; return GDF_SUCCESS; }
+        *out_probe = (int32_t *)op.release();
+        *out_build = (int32_t *)ob.release();
+        return GDF_SUCCESS;
+      }
+      // otherwise: fall through to the exact two-pass path (buffers above are released here)
+    }
+  }
 
   // ---- count pass ----
-  if (nunits) {
-    GDF_LAUNCH("jk_probe_count", jk_probe<false>, dim3((unsigned)nunits), dim3(JK_PROBE_THREADS), probe_lds, stream0(), a, probe_t, build_t);
-    HIP_CHECK_LAST();
-  }
+  GDF_TRY(run_probe(narrow, false, "jk_probe_count", nunits, probe_lds, a, probe_t, build_t));
   // oversize partitions: one global table each, kept for the write pass
   struct GTable { DevBuf key, idx; uint32_t nslots; };
   std::vector<GTable> gt(oversize.size());
@@ -942,13 +1181,20 @@ static gdf_error hash_join_core(const KeyTable &probe_t, const KeyTable &build_t
     RMM_TRY(gt[o].key.alloc(sizeof(uint64_t) * gt[o].nslots));
     RMM_TRY(gt[o].idx.alloc(sizeof(int32_t) * gt[o].nslots));
     hipLaunchKernelGGL(gj_fill, dim3(small_grid(gt[o].nslots)), dim3(256), 0, stream0(), gt[o].idx.as<int32_t>(), gt[o].nslots);
-    hipLaunchKernelGGL(gj_build, dim3(small_grid(bn)), dim3(256), 0, stream0(), a.bkey + B.fine_off[f], a.bidx + B.fine_off[f], bn,
-                       gt[o].key.as<uint64_t>(), gt[o].idx.as<int32_t>(), gt[o].nslots);
     ProbeArgs ga = a;
     ga.nslots = gt[o].nslots;
-    hipLaunchKernelGGL(gj_probe<false>, dim3(small_grid(pn)), dim3(256), 0, stream0(), ga, probe_t, build_t,
-                       gt[o].key.as<uint64_t>(), gt[o].idx.as<int32_t>(), P.fine_off[f], pn,
-                       (unsigned long long *)(d_counts.as<uint64_t>() + nunits + o));
+    unsigned long long *cnt = (unsigned long long *)(d_counts.as<uint64_t>() + nunits + o);
+    if (narrow) {
+      hipLaunchKernelGGL(gj_build<true>, dim3(small_grid(bn)), dim3(256), 0, stream0(), a.build, B.fine_off[f], bn,
+                         gt[o].key.as<uint64_t>(), gt[o].idx.as<int32_t>(), gt[o].nslots);
+      hipLaunchKernelGGL((gj_probe<false, true>), dim3(small_grid(pn)), dim3(256), 0, stream0(), ga, probe_t, build_t,
+                         gt[o].key.as<uint64_t>(), gt[o].idx.as<int32_t>(), P.fine_off[f], pn, cnt);
+    } else {
+      hipLaunchKernelGGL(gj_build<false>, dim3(small_grid(bn)), dim3(256), 0, stream0(), a.build, B.fine_off[f], bn,
+                         gt[o].key.as<uint64_t>(), gt[o].idx.as<int32_t>(), gt[o].nslots);
+      hipLaunchKernelGGL((gj_probe<false, false>), dim3(small_grid(pn)), dim3(256), 0, stream0(), ga, probe_t, build_t,
+                         gt[o].key.as<uint64_t>(), gt[o].idx.as<int32_t>(), P.fine_off[f], pn, cnt);
+    }
     HIP_CHECK_LAST();
   }
 
@@ -956,7 +1202,7 @@ static gdf_error hash_join_core(const KeyTable &probe_t, const KeyTable &build_t
   GDF_TRY(scan_u64(d_counts.as<uint64_t>(), d_counts.as<uint64_t>(), nslots_all + 1, false));
   uint64_t matched_total = 0;
   HIP_TRY(hipMemcpy(&matched_total, d_counts.as<uint64_t>() + nslots_all, sizeof(uint64_t), hipMemcpyDeviceToHost));
-  const uint64_t probe_tail = keep_probe ? (uint64_t)probe_t.nrows - P.joinable : 0;   // null / NaN probe rows
+  const uint64_t probe_tail = keep_probe ? (uint64_t)probe_t.nrows - P.joinable : 0;   // rows that cannot match
   uint64_t build_tail = 0;
   if (kind == JOIN_FULL) {
     unsigned long long *d_cnt = d_tail.as<unsigned long long>() + 2;
@@ -980,19 +1226,20 @@ static gdf_error hash_join_core(const KeyTable &probe_t, const KeyTable &build_t
   a.build_matched = nullptr;   // marks were taken in the count pass
 
   // ---- write pass ----
-  if (nunits) {
-    GDF_LAUNCH("jk_probe_write", jk_probe<true>, dim3((unsigned)nunits), dim3(JK_PROBE_THREADS), probe_lds, stream0(), a, probe_t, build_t);
-    HIP_CHECK_LAST();
-  }
+  GDF_TRY(run_probe(narrow, true, "jk_probe_write", nunits, probe_lds, a, probe_t, build_t));
   for (size_t o = 0; o < oversize.size(); ++o) {
     const uint32_t f = oversize[o];
     const uint32_t pn = P.fine_off[f + 1] - P.fine_off[f];
     ProbeArgs ga = a;
     ga.nslots = gt[o].nslots;
     // the exclusive offset of this partition doubles as its write cursor
-    hipLaunchKernelGGL(gj_probe<true>, dim3(small_grid(pn)), dim3(256), 0, stream0(), ga, probe_t, build_t,
-                       gt[o].key.as<uint64_t>(), gt[o].idx.as<int32_t>(), P.fine_off[f], pn,
-                       (unsigned long long *)(d_counts.as<uint64_t>() + nunits + o));
+    unsigned long long *cur = (unsigned long long *)(d_counts.as<uint64_t>() + nunits + o);
+    if (narrow)
+      hipLaunchKernelGGL((gj_probe<true, true>), dim3(small_grid(pn)), dim3(256), 0, stream0(), ga, probe_t, build_t,
+                         gt[o].key.as<uint64_t>(), gt[o].idx.as<int32_t>(), P.fine_off[f], pn, cur);
+    else
+      hipLaunchKernelGGL((gj_probe<true, false>), dim3(small_grid(pn)), dim3(256), 0, stream0(), ga, probe_t, build_t,
+                         gt[o].key.as<uint64_t>(), gt[o].idx.as<int32_t>(), P.fine_off[f], pn, cur);
     HIP_CHECK_LAST();
   }
   if (probe_tail) {
@@ -1214,14 +1461,24 @@ static gdf_error join_entry(JoinKind kind, gdf_column **left_cols, int num_left_
 
 // ---------------------------------------------------------------------------
 // test hook: run the radix partitioner alone and hand back the fine-partitioned tuples
-// (tests/test_gpu_join_internals.py checks them against a numpy restatement of fine_of)
+// (tests/test_gpu_join_internals.py checks them against a numpy restatement of fine_of).
+// out_info[0] = 1 when the narrow 8-byte tuple format was used, out_info[1] = kmin; the
+// returned keys are the STORED keys (raw bits minus kmin).
 // ---------------------------------------------------------------------------
+__global__ void jk_unpack_narrow(const uint64_t *w, uint32_t n, uint64_t *key, int32_t *idx) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    key[i] = w[i] >> 32;
+    idx[i] = (int32_t)(uint32_t)w[i];
+  }
+}
+
 gdf_error debug_partition(gdf_column *col, int fb, uint64_t *out_key, int32_t *out_idx, uint32_t *out_fine_off,
-                          uint32_t *out_joinable) {
+                          uint32_t *out_joinable, uint64_t *out_info) {
   gdf_column *cols[1] = {col};
   KeyTable t;
   GDF_TRY(make_key_table(cols, 1, &t));
-  const KeyPlan plan = plan_keys(t);
+  KeyPlan plan = plan_keys(t);
+  GDF_TRY(plan_narrow_range(t, &plan));
   PartGeom g{};
   g.fb = fb;
   g.b1 = fb <= 8 ? fb : (fb + 1) / 2;
@@ -1229,11 +1486,20 @@ gdf_error debug_partition(gdf_column *col, int fb, uint64_t *out_key, int32_t *o
   SideBufs sb;
   GDF_TRY(partition_side(t, plan, g, &sb));
   if (sb.joinable) {
-    HIP_TRY(hipMemcpy(out_key, sb.key[sb.final_buf].p, sizeof(uint64_t) * sb.joinable, hipMemcpyDeviceToDevice));
-    HIP_TRY(hipMemcpy(out_idx, sb.idx[sb.final_buf].p, sizeof(int32_t) * sb.joinable, hipMemcpyDeviceToDevice));
+    const Tuples f = sb.final();
+    if (plan.narrow) {
+      hipLaunchKernelGGL(jk_unpack_narrow, dim3(small_grid(sb.joinable)), dim3(256), 0, stream0(), f.w, sb.joinable, out_key, out_idx);
+      HIP_CHECK_LAST();
+      HIP_TRY(hipStreamSynchronize(stream0()));
+    } else {
+      HIP_TRY(hipMemcpy(out_key, f.w, sizeof(uint64_t) * sb.joinable, hipMemcpyDeviceToDevice));
+      HIP_TRY(hipMemcpy(out_idx, f.idx, sizeof(int32_t) * sb.joinable, hipMemcpyDeviceToDevice));
+    }
   }
   for (size_t f = 0; f < sb.fine_off.size(); ++f) out_fine_off[f] = sb.fine_off[f];
   *out_joinable = sb.joinable;
+  out_info[0] = (uint64_t)plan.narrow;
+  out_info[1] = plan.kmin;
   return GDF_SUCCESS;
 }
 
@@ -1245,8 +1511,9 @@ extern "C" {
 
 // non-reference export, test hook only (out_fine_off is a HOST array of 2^fb + 1 entries)
 __attribute__((visibility("default"))) gdf_error gdf_amd_debug_partition(gdf_column *col, int fb, uint64_t *out_key, int32_t *out_idx,
-                                                                        uint32_t *out_fine_off, uint32_t *out_joinable) {
-  return debug_partition(col, fb, out_key, out_idx, out_fine_off, out_joinable);
+                                                                        uint32_t *out_fine_off, uint32_t *out_joinable,
+                                                                        uint64_t *out_info) {
+  return debug_partition(col, fb, out_key, out_idx, out_fine_off, out_joinable, out_info);
 }
 
 gdf_error gdf_inner_join(gdf_column **left_cols, int num_left_cols, int left_join_cols[], gdf_column **right_cols,

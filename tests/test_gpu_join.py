@@ -210,3 +210,14 @@ def test_result_cols_materialisation(gdf):
     m = b >= 0
     np.testing.assert_array_equal(v2, m)
     np.testing.assert_array_equal(d2[m], rp[b[m]])
+
+
+@pytest.mark.parametrize("how", ["inner", "left", "full"])
+def test_int64_keys_wider_than_32_bits(gdf, how):
+    """Build keys spanning more than 2^32 use the 12-byte tuple format; a narrower build range uses packed
+    8-byte tuples and probe keys outside it must simply not match."""
+    wide = (gen_rand(np.int64, 6000, 0, 400) * np.int64(1 << 34)) - np.int64(7)
+    _check(gdf, [np.random.permutation(wide)], [wide[:3000]], how)
+    build = gen_rand(np.int64, 3000, -50, 50)
+    probe = np.concatenate([gen_rand(np.int64, 3000, -80, 80), np.array([2**40, -2**40, 2**63 - 1, -2**63], dtype=np.int64)])
+    _check(gdf, [probe], [build], how)

@@ -25,27 +25,38 @@ def mix64(x):
 def _partition(gdf, col, n, fb):
     import torch
     lib = gdf._binding._gdf_cdll
-    lib.gdf_amd_debug_partition.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.gdf_amd_debug_partition.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     ok = torch.full((n,), -7, dtype=torch.int64, device="cuda")
     oi = torch.full((n,), -7, dtype=torch.int32, device="cuda")
     off = (C.c_uint32 * ((1 << fb) + 1))()
     nj = C.c_uint32(0)
-    assert lib.gdf_amd_debug_partition(C.byref(col.c), fb, ok.data_ptr(), oi.data_ptr(), off, C.byref(nj)) == 0
-    return ok.cpu().numpy(), oi.cpu().numpy(), np.array(list(off), dtype=np.int64), nj.value
+    info = (C.c_uint64 * 2)()
+    assert lib.gdf_amd_debug_partition(C.byref(col.c), fb, ok.data_ptr(), oi.data_ptr(), off, C.byref(nj), info) == 0
+    return ok.cpu().numpy(), oi.cpu().numpy(), np.array(list(off), dtype=np.int64), nj.value, (int(info[0]), int(info[1]))
 
 
-@pytest.mark.parametrize("dtype,fb,n,reps", [(np.int32, 2, 10000, 300), (np.int64, 2, 10000, 300), (np.int64, 11, 3_000_000, 5),
-                                             (np.int32, 9, 1_000_000, 10)])
-def test_partition_invariants(gdf, dtype, fb, n, reps):
+@pytest.mark.parametrize("dtype,fb,n,reps,wide", [(np.int32, 2, 10000, 300, False), (np.int64, 2, 10000, 300, False),
+                                                  (np.int64, 11, 3_000_000, 5, False), (np.int32, 9, 1_000_000, 10, False),
+                                                  (np.int64, 2, 10000, 100, True), (np.int64, 10, 2_000_000, 5, True)])
+def test_partition_invariants(gdf, dtype, fb, n, reps, wide):
+    """wide=True spreads the int64 keys over more than 2^32 so the 12-byte (key64, row) tuple format is used;
+    otherwise the keys fit 32 bits after subtracting the minimum and the packed 8-byte format is used."""
     from libgdf_amd.columns import column_from_numpy
     keys = gen_rand(dtype, n, low=0, high=2000 if n <= 10000 else 2_000_000)
+    if wide:
+        keys = keys * np.int64(1 << 33) - np.int64(5)
     col = column_from_numpy(keys)
     width_mask = np.uint64((1 << (8 * np.dtype(dtype).itemsize)) - 1)
-    key64 = keys.astype(np.int64).view(np.uint64) & width_mask             # zero-extended raw bits
+    raw = keys.astype(np.int64).view(np.uint64) & width_mask                # zero-extended raw bits
+    _, _, _, _, (narrow, kmin) = _partition(gdf, col, n, fb)
+    assert narrow == (0 if wide else 1)
+    if np.dtype(dtype).itemsize == 8 and narrow:
+        assert kmin == int(keys.min()) & 0xFFFFFFFFFFFFFFFF
+    key64 = raw - np.uint64(kmin)                                           # what the tuples store
     fine = (mix64(key64) >> np.uint64(64 - fb)).astype(np.int64)
     exp_off = np.concatenate([[0], np.cumsum(np.bincount(fine, minlength=1 << fb))])
     for _ in range(reps):
-        k, i, off, nj = _partition(gdf, col, n, fb)
+        k, i, off, nj, _ = _partition(gdf, col, n, fb)
         assert nj == n
         np.testing.assert_array_equal(off, exp_off)
         assert np.array_equal(np.sort(i), np.arange(n)), "every row exactly once"
@@ -59,6 +70,6 @@ def test_partition_skips_null_rows(gdf):
     keys = gen_rand(np.int64, n)
     valid = np.random.randint(0, 2, size=n).astype(bool)
     col = column_from_numpy(keys, valid)
-    k, i, off, nj = _partition(gdf, col, n, 4)
+    k, i, off, nj, _ = _partition(gdf, col, n, 4)
     assert nj == valid.sum()
     assert np.array_equal(np.sort(i[:nj]), np.nonzero(valid)[0])

@@ -26,13 +26,14 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
 
-# per-kernel algorithmic bytes per unit (DESIGN.md "Kernels"): what the kernel must move by its own contract
+# per-kernel algorithmic bytes per step (DESIGN.md "Kernels"): what the kernel must move by its own contract.
+# tb = bytes per (key, row) tuple: 8 when the keys fit 32 bits (C3/C4: key space <= 2^32), else 12.
 KERNEL_BYTES = {
-    "jk_hist": lambda npr, nb: 8.0 * (npr + nb),                   # reads every key once
-    "jk_scatter1": lambda npr, nb: (8.0 + 12.0) * (npr + nb),      # key in, (key,row) tuple out
-    "jk_scatter2": lambda npr, nb: (12.0 + 12.0) * (npr + nb),     # tuple in, tuple out
-    "jk_probe_count": lambda npr, nb: 12.0 * (npr + nb),           # tuples in
-    "jk_probe_write": lambda npr, nb: 12.0 * (npr + nb) + 8.0 * npr,   # tuples in, index pair out
+    "jk_hist": lambda npr, nb, tb: 8.0 * (npr + nb),                   # reads every key once
+    "jk_scatter1": lambda npr, nb, tb: (8.0 + tb) * (npr + nb),        # key in, tuple out
+    "jk_scatter2": lambda npr, nb, tb: (tb + tb) * (npr + nb),         # tuple in, tuple out
+    "jk_probe_count": lambda npr, nb, tb: tb * (npr + nb),             # tuples in
+    "jk_probe_write": lambda npr, nb, tb: tb * (npr + nb) + 8.0 * npr, # tuples in, one int32 index pair per probe row out
 }
 
 
@@ -200,7 +201,8 @@ def main():
             # jk_* kernels run once per relation per step: the per-step byte count is split over those launches
             fn = KERNEL_BYTES.get(name)
             if fn is not None:
-                step_bytes = fn(float(npr), float(nb if world == 1 else nb))
+                tb = 8.0 if key_space < 2 ** 32 else 12.0
+                step_bytes = fn(float(npr), float(nb), tb)
                 bytes_per_launch = step_bytes / launches_per_step
                 achieved = bytes_per_launch / (per_launch_ms * 1e-3) / 1e9
                 roofline = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -924,7 +924,7 @@ static gdf_error partition_side(const KeyTable &t, const KeyPlan &plan, PartGeom
   // scatter tile: THREADS * 16 tuples regrouped in LDS per step.  Bigger tiles mean longer runs per
   // (tile, bin) -- DRAM-friendlier writes -- at the price of fewer resident workgroups.
   static const int sc_threads_env = getenv("GDF_JK_SC_THREADS") ? atoi(getenv("GDF_JK_SC_THREADS")) : 0;
-  int sc_threads = sc_threads_env ? sc_threads_env : (narrow ? 512 : 256);
+  int sc_threads = sc_threads_env ? sc_threads_env : (narrow ? 1024 : 256);   // swept on C3: profiles/r1_c_sweeps.md
   if (sc_threads != 256 && sc_threads != 512 && sc_threads != 1024) sc_threads = 256;
   if (!narrow && sc_threads == 1024) sc_threads = 512;       // 16384 x 12 B would not fit 160 KiB
   const int64_t JK_TILE = (int64_t)sc_threads * JK_SC_ITEMS;

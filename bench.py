@@ -78,6 +78,21 @@ def read_profile(gdf):
     return {names[i].value.decode(): (ms[i], cnt[i]) for i in range(min(k, 64))}
 
 
+def pmc_traffic(kernel, launches_per_step):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary (profiles/*_pmc_hbm.json).
+    bench.py cannot collect counters itself; the file states how they were collected and corrected."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        data = json.load(f)
+    k = data.get("kernels", {}).get(kernel)
+    if not k or not launches_per_step:
+        return None, None
+    return k["hbm_bytes_per_join_corrected"] / launches_per_step, os.path.relpath(files[-1], ROOT)
+
+
 def cpu_baseline(sample_probe, sample_build):
     """oracle join (single-threaded C port of the reference algorithm) on a bounded sample of C3."""
     import numpy as np
@@ -205,8 +220,10 @@ def main():
                 step_bytes = fn(float(npr), float(nb), tb)
                 bytes_per_launch = step_bytes / launches_per_step
                 achieved = bytes_per_launch / (per_launch_ms * 1e-3) / 1e9
+                traffic, src = (pmc_traffic(name, launches_per_step) if (world == 1 and npr == 1_000_000_000) else (None, None))
                 roofline = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
+                            "algorithmic_bytes_per_launch": bytes_per_launch,
                             "avg_launch_ms": per_launch_ms, "launches_per_step": launches_per_step}
         e2e_bytes = 8.0 * npr + 8.0 * nb + 8.0 * (rows.item() / world)
         e2e = e2e_bytes / (ms_per_step * 1e-3) / 1e9

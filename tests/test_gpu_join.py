@@ -221,3 +221,36 @@ def test_int64_keys_wider_than_32_bits(gdf, how):
     build = gen_rand(np.int64, 3000, -50, 50)
     probe = np.concatenate([gen_rand(np.int64, 3000, -80, 80), np.array([2**40, -2**40, 2**63 - 1, -2**63], dtype=np.int64)])
     _check(gdf, [probe], [build], how)
+
+
+def test_multigpu_layer_world_size_one(gdf):
+    """libgdf_amd/multigpu.py end to end on the GPU with a 1-rank RCCL group: device-side gdf_hash_partition,
+    all_to_all_single, local gdf_inner_join, global row ids.  (2-rank exchange logic: tests/test_multigpu_gloo.py.)"""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from libgdf_amd import multigpu
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        probe = gen_rand(np.int64, 200000, 0, 5000)
+        build = np.random.permutation(5000).astype(np.int64)[:4000]
+        pg, bg = multigpu.distributed_inner_join(torch.from_numpy(probe).cuda(), torch.from_numpy(build).cuda())
+        el, er = oracle.join([probe], [build], "inner")
+        a, b = sort_pairs(pg.cpu().numpy(), bg.cpu().numpy())
+        c, d = sort_pairs(el, er)
+        np.testing.assert_array_equal(a, c)
+        np.testing.assert_array_equal(b, d)
+        k = torch.from_numpy(probe).cuda()
+        v = torch.from_numpy((probe * 2 + 1).astype(np.int64)).cuda()
+        gk, gv = multigpu.distributed_group_by_sum(k, v)
+        ek, ea = oracle.group_by("sum", [probe], (probe * 2 + 1).astype(np.int64))
+        o = np.argsort(gk.cpu().numpy())
+        np.testing.assert_array_equal(gk.cpu().numpy()[o], ek[0])
+        np.testing.assert_array_equal(gv.cpu().numpy()[o], ea)
+    finally:
+        dist.destroy_process_group()

@@ -171,8 +171,7 @@ def main():
         probe = make_probe_keys(npr, key_space, 0x5EED0002, dev, offset=rank * npr)
 
         def step():
-            li, ri = multigpu.distributed_inner_join(probe, build)
-            return li.numel()
+            return multigpu.distributed_inner_join(probe, build).numel()
         workload = (f"C4 partitioned hash join: {npr} probe + {nb} build int64 rows per GPU, key space {key_space}, "
                     f"RCCL all-to-all shuffle + local gdf_inner_join")
 

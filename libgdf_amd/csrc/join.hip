@@ -165,25 +165,6 @@ __device__ __forceinline__ void fetch_keys(const KeyTable &t, const KeyPlan &p, 
   }
 }
 
-// signed min / max of an 8-byte integer key column over its valid rows
-__global__ __launch_bounds__(256) void jk_minmax(KeyTable t, long long *out_min, long long *out_max) {
-  long long lo = LLONG_MAX, hi = LLONG_MIN;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < t.nrows; i += (int64_t)gridDim.x * 256) {
-    if (row_valid(t, i)) {
-      const long long v = ((const long long *)t.col[0].data)[i];
-      lo = v < lo ? v : lo;
-      hi = v > hi ? v : hi;
-    }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const long long l2 = __shfl_xor(lo, o, WAVE), h2 = __shfl_xor(hi, o, WAVE);
-    lo = l2 < lo ? l2 : lo;
-    hi = h2 > hi ? h2 : hi;
-  }
-  if (lane_id() == 0) { atomicMin(out_min, lo); atomicMax(out_max, hi); }
-}
-
 // ---------------------------------------------------------------------------
 // partition geometry and tuple storage
 // ---------------------------------------------------------------------------
@@ -207,6 +188,8 @@ struct PartGeom {
   int nchunks;           // level-1 chunks (one histogram column each)
   int64_t chunk;         // rows per chunk (multiple of the scatter tile)
   int dbg;               // experiment switch (env GDF_JK_SDBG), 0 in production
+  uint64_t kbias;        // added back to a stored key before hashing (= KeyPlan::kmin): partition ids and slots are
+                         // functions of the RAW key, so the build-side histogram can run before kmin is known
 };
 
 // NARROW: w[i] = key32 << 32 | row, idx unused.  WIDE: w[i] = key64, idx[i] = row.
@@ -219,8 +202,8 @@ __device__ __forceinline__ uint64_t tup_key(uint64_t w) { return NARROW ? (w >> 
 template <bool NARROW>
 __device__ __forceinline__ uint64_t tup_make(uint64_t key, int32_t row) { return NARROW ? ((key << 32) | (uint32_t)row) : key; }
 
-__device__ __forceinline__ uint32_t fine_of(uint64_t key, int fb) {
-  return fb ? (uint32_t)(mix64(key) >> (64 - fb)) : 0u;
+__device__ __forceinline__ uint32_t fine_of(uint64_t raw_key, int fb) {
+  return fb ? (uint32_t)(mix64(raw_key) >> (64 - fb)) : 0u;
 }
 // two slot hashes from bits of mix64 that the partition id (top fb <= 15 bits) does not use
 __device__ __forceinline__ uint32_t slot_h0(uint64_t m, uint32_t H) { return (uint32_t)m & (H - 1); }
@@ -234,10 +217,13 @@ __device__ __forceinline__ uint32_t slot_of(uint64_t key, uint32_t nslots) {
 // 1. histogram: fine histogram (global, LDS-accumulated) + per-chunk coarse histogram
 //    H1[c * nchunks + chunk]
 // ---------------------------------------------------------------------------
+// minmax (may be null): signed min / max of the raw 8-byte keys of the joinable rows, gathered on the
+// build side in the same pass so that the narrow tuple format can be decided without another read.
 template <bool FAST>
 __global__ __launch_bounds__(JK_HIST_THREADS) void jk_hist(KeyTable t, KeyPlan plan, PartGeom g,
                                                            uint32_t *__restrict__ fine_hist,
-                                                           uint32_t *__restrict__ H1) {
+                                                           uint32_t *__restrict__ H1, long long *minmax) {
+  long long lo = LLONG_MAX, hi = LLONG_MIN;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   uint32_t *fine = lds;
   uint32_t *coarse = lds + (1u << g.fb);
@@ -255,9 +241,12 @@ __global__ __launch_bounds__(JK_HIST_THREADS) void jk_hist(KeyTable t, KeyPlan p
 #pragma unroll
       for (int k = 0; k < JK_HIST_ITEMS; ++k) {
         if (ok[k]) {
-          const uint32_t f = fine_of(key[k], g.fb);
+          const uint64_t raw = key[k] + plan.kmin;
+          const uint32_t f = fine_of(raw, g.fb);
           atomicAdd(&fine[f], 1u);
           atomicAdd(&coarse[f >> g.b2], 1u);
+          lo = (long long)raw < lo ? (long long)raw : lo;
+          hi = (long long)raw > hi ? (long long)raw : hi;
         }
       }
     }
@@ -267,6 +256,15 @@ __global__ __launch_bounds__(JK_HIST_THREADS) void jk_hist(KeyTable t, KeyPlan p
   }
   for (uint32_t f = threadIdx.x; f < nfine; f += JK_HIST_THREADS)
     if (fine[f]) atomicAdd(&fine_hist[f], fine[f]);
+  if (minmax) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const long long l2 = __shfl_xor(lo, o, WAVE), h2 = __shfl_xor(hi, o, WAVE);
+      lo = l2 < lo ? l2 : lo;
+      hi = h2 > hi ? h2 : hi;
+    }
+    if (lane_id() == 0 && lo <= hi) { atomicMin(&minmax[0], lo); atomicMax(&minmax[1], hi); }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -325,7 +323,7 @@ __device__ __forceinline__ void tile_flush(TileLds<NARROW, THREADS> &s, const Pa
     uint32_t dst[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const uint32_t f = fine_of(tup_key<NARROW>(ww[u]), g.fb);
+      const uint32_t f = fine_of(tup_key<NARROW>(ww[u]) + g.kbias, g.fb);
       const uint32_t bin = LEVEL1 ? (f >> g.b2) : (f & submask);
       dst[u] = s.gbase[bin] + j0 + u * THREADS;
     }
@@ -363,7 +361,7 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
     for (int k = 0; k < JK_SC_ITEMS; ++k) {
       binrank[k] = 0xffffffffu;
       if (ok[k]) {
-        const uint32_t bin = fine_of(key[k], g.fb) >> g.b2;
+        const uint32_t bin = fine_of(key[k] + g.kbias, g.fb) >> g.b2;
         binrank[k] = (bin << 16) | atomicAdd(&s.hist[bin], 1u);
       }
     }
@@ -433,7 +431,7 @@ __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, 
     const uint32_t i = begin + k * THREADS + threadIdx.x;
     binrank[k] = 0xffffffffu;
     if (i < end) {
-      const uint32_t bin = fine_of(tup_key<NARROW>(w[k]), g.fb) & submask;
+      const uint32_t bin = fine_of(tup_key<NARROW>(w[k]) + g.kbias, g.fb) & submask;
       binrank[k] = (bin << 16) | atomicAdd(&s.hist[bin], 1u);
     }
   }
@@ -475,6 +473,7 @@ struct ProbeArgs {
   uint64_t *counts;             // COUNT pass output / WRITE pass: exclusive offsets
   int32_t *out_probe; int32_t *out_build;
   int dbg;                      // experiment switch (env GDF_JK_DBG), 0 in production
+  uint64_t kbias;               // see PartGeom::kbias
   int optimistic;               // WRITE pass without a count pass: unit u may write at most probe_count pairs
   unsigned long long *opt_state; // [0] = pairs written by all units, [1] = some unit needed more room
 };
@@ -546,7 +545,7 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
     uint32_t cur = p0, table = 0;
     int moves = 0;
     for (; moves < JK_CUCKOO_MAX_MOVES; ++moves) {
-      const uint64_t m = mix64(tup_key<NARROW>(l.bw[cur]));
+      const uint64_t m = mix64(tup_key<NARROW>(l.bw[cur]) + a.kbias);
       const uint32_t slot = table ? H + slot_h1(m, H) : slot_h0(m, H);
       const uint32_t old = atomicExch(&l.T[slot], cur);
       if (old == JK_NOPOS) break;
@@ -564,7 +563,7 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
     block_sync();
     const uint32_t mask = 2 * H - 1;
     for (uint32_t p = threadIdx.x; p < u.build_count; p += JK_PROBE_THREADS) {
-      uint32_t slot = (uint32_t)mix64(tup_key<NARROW>(l.bw[p])) & mask;
+      uint32_t slot = (uint32_t)mix64(tup_key<NARROW>(l.bw[p]) + a.kbias) & mask;
       while (atomicCAS(&l.T[slot], JK_NOPOS, p) != JK_NOPOS) slot = (slot + 1) & mask;
     }
     block_sync();
@@ -593,7 +592,7 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
       uint32_t pa[JK_PROBE_BATCH], pb[JK_PROBE_BATCH];
 #pragma unroll
       for (int b = 0; b < JK_PROBE_BATCH; ++b) {    // 8 independent table reads
-        const uint64_t m = mix64(k[b]);
+        const uint64_t m = mix64(k[b] + a.kbias);
         pa[b] = l.T[slot_h0(m, H)];
         pb[b] = l.T[H + slot_h1(m, H)];
       }
@@ -627,7 +626,7 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
         cnt[b] = 0;
         hit_a[b] = hit_b[b] = JK_NOPOS;
         if (base + b * JK_PROBE_THREADS + threadIdx.x < u.probe_count) {
-          uint32_t slot = (uint32_t)mix64(k[b]) & mask;
+          uint32_t slot = (uint32_t)mix64(k[b] + a.kbias) & mask;
           for (;;) {
             const uint32_t p = l.T[slot];
             if (p == JK_NOPOS) break;
@@ -680,7 +679,7 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
           }
         } else if (c > 1) {      // linear-probing mode with several matches: walk the chain again
           const uint32_t mask = 2 * H - 1;
-          uint32_t slot = (uint32_t)mix64(k[b]) & mask;
+          uint32_t slot = (uint32_t)mix64(k[b] + a.kbias) & mask;
           for (;;) {
             const uint32_t p = l.T[slot];
             if (p == JK_NOPOS) break;
@@ -918,25 +917,19 @@ static gdf_error launch_scatter2(bool narrow, int threads, uint32_t ntiles, cons
 }
 
 // partitions one relation into g.fb-bit fine partitions
-static gdf_error partition_side(const KeyTable &t, const KeyPlan &plan, PartGeom g, SideBufs *sb) {
+// decide_narrow: this is the BUILD side of an 8-byte integer key: the histogram pass also returns the key
+// range, and when it spans < 2^32 the plan switches to the narrow tuple format (for both relations).
+static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, SideBufs *sb, bool decide_narrow) {
   const int64_t n = t.nrows;
-  const bool narrow = plan.narrow != 0;
-  // scatter tile: THREADS * 16 tuples regrouped in LDS per step.  Bigger tiles mean longer runs per
-  // (tile, bin) -- DRAM-friendlier writes -- at the price of fewer resident workgroups.
-  static const int sc_threads_env = getenv("GDF_JK_SC_THREADS") ? atoi(getenv("GDF_JK_SC_THREADS")) : 0;
-  int sc_threads = sc_threads_env ? sc_threads_env : (narrow ? 1024 : 256);   // swept on C3: profiles/r1_c_sweeps.md
-  if (sc_threads != 256 && sc_threads != 512 && sc_threads != 1024) sc_threads = 256;
-  if (!narrow && sc_threads == 1024) sc_threads = 512;       // 16384 x 12 B would not fit 160 KiB
-  const int64_t JK_TILE = (int64_t)sc_threads * JK_SC_ITEMS;
-  // level-1 chunking (one histogram column per chunk)
+  bool narrow = plan.narrow != 0;
   // Chunks are SMALL (a few tiles) and processed in blockIdx order, so that the workgroups resident at
   // any moment write into a narrow window of every partition's output range: with a few thousand
   // 2 MiB pages live the scatter ran ~1.5x slower per row at 1e9 rows than at 5e8 (TLB reach).
   static const int64_t chunk_rows_env = getenv("GDF_JK_CHUNK_ROWS") ? atoll(getenv("GDF_JK_CHUNK_ROWS")) : 0;
   int64_t chunk = chunk_rows_env ? chunk_rows_env : JK_CHUNK_ROWS;
   if (n / chunk > JK_MAX_CHUNKS) chunk = (n + JK_MAX_CHUNKS - 1) / JK_MAX_CHUNKS;
-  chunk = ((chunk + JK_TILE - 1) / JK_TILE) * JK_TILE;
-  if (chunk == 0) chunk = JK_TILE;
+  constexpr int64_t MAX_TILE = 1024 * JK_SC_ITEMS;      // chunks are whole tiles for every tile size in use
+  chunk = ((chunk + MAX_TILE - 1) / MAX_TILE) * MAX_TILE;
   g.chunk = chunk;
   g.nchunks = (int)((n + chunk - 1) / chunk);
   if (g.nchunks == 0) g.nchunks = 1;
@@ -952,12 +945,20 @@ static gdf_error partition_side(const KeyTable &t, const KeyPlan &plan, PartGeom
   HIP_TRY(hipFuncSetAttribute((const void *)jk_hist<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_lds));
   HIP_TRY(hipFuncSetAttribute((const void *)jk_hist<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_lds));
   const int hist_grid = g.nchunks < NUM_CU ? g.nchunks : NUM_CU;
+  DevBuf mm;
+  long long *d_mm = nullptr;
+  if (decide_narrow && !getenv("GDF_JK_WIDE")) {       // GDF_JK_WIDE: experiment switch, force 12-byte tuples
+    RMM_TRY(mm.alloc(sizeof(long long) * 2));
+    const long long init[2] = {LLONG_MAX, LLONG_MIN};
+    HIP_TRY(hipMemcpyAsync(mm.p, init, sizeof(init), hipMemcpyHostToDevice, stream0()));
+    d_mm = mm.as<long long>();
+  }
   if (fast)
     GDF_LAUNCH("jk_hist", jk_hist<true>, dim3(hist_grid), dim3(JK_HIST_THREADS), hist_lds, stream0(), t, plan, g,
-               fine_hist.as<uint32_t>(), H1.as<uint32_t>());
+               fine_hist.as<uint32_t>(), H1.as<uint32_t>(), d_mm);
   else
     GDF_LAUNCH("jk_hist", jk_hist<false>, dim3(hist_grid), dim3(JK_HIST_THREADS), hist_lds, stream0(), t, plan, g,
-               fine_hist.as<uint32_t>(), H1.as<uint32_t>());
+               fine_hist.as<uint32_t>(), H1.as<uint32_t>(), d_mm);
   HIP_CHECK_LAST();
   GDF_TRY(scan_u32(H1.as<uint32_t>(), H1.as<uint32_t>(), (size_t)ncoarse * g.nchunks, false));
 
@@ -967,6 +968,23 @@ static gdf_error partition_side(const KeyTable &t, const KeyPlan &plan, PartGeom
   for (uint32_t f = 0; f < nfine; ++f) sb->fine_off[f + 1] = sb->fine_off[f] + fh[f];
   sb->joinable = sb->fine_off[nfine];
   const size_t cap = sb->joinable ? sb->joinable : 1;
+  if (d_mm) {
+    long long h[2];
+    HIP_TRY(hipMemcpy(h, d_mm, sizeof(h), hipMemcpyDeviceToHost));
+    if (h[0] <= h[1] && (uint64_t)h[1] - (uint64_t)h[0] < 0xffffffffULL) {
+      plan.narrow = 1;
+      plan.kmin = (uint64_t)h[0];
+      narrow = true;
+    }
+  }
+  g.kbias = plan.kmin;
+  // scatter tile: THREADS * 16 tuples regrouped in LDS per step.  Bigger tiles mean longer runs per
+  // (tile, bin) -- DRAM-friendlier writes -- at the price of fewer resident workgroups.
+  static const int sc_threads_env = getenv("GDF_JK_SC_THREADS") ? atoi(getenv("GDF_JK_SC_THREADS")) : 0;
+  int sc_threads = sc_threads_env ? sc_threads_env : (narrow ? 1024 : 256);   // swept on C3: profiles/r1_c_sweeps.md
+  if (sc_threads != 256 && sc_threads != 512 && sc_threads != 1024) sc_threads = 256;
+  if (!narrow && sc_threads == 1024) sc_threads = 512;       // 16384 x 12 B would not fit 160 KiB
+  const int64_t JK_TILE = (int64_t)sc_threads * JK_SC_ITEMS;
 
   RMM_TRY(sb->w[0].alloc(sizeof(uint64_t) * cap));
   if (!narrow) RMM_TRY(sb->idx[0].alloc(sizeof(int32_t) * cap));
@@ -1004,25 +1022,6 @@ static gdf_error partition_side(const KeyTable &t, const KeyPlan &plan, PartGeom
   return GDF_SUCCESS;
 }
 
-// narrow mode for an 8-byte integer key: the build side's value range decides
-static gdf_error plan_narrow_range(const KeyTable &build_t, KeyPlan *plan) {
-  if (plan->narrow || plan->mode != KM_RAW_INT || build_t.col[0].width != 8 || build_t.nrows == 0) return GDF_SUCCESS;
-  if (getenv("GDF_JK_WIDE")) return GDF_SUCCESS;     // experiment switch: force the 12-byte tuple format
-  DevBuf mm;
-  RMM_TRY(mm.alloc(sizeof(long long) * 2));
-  const long long init[2] = {LLONG_MAX, LLONG_MIN};
-  HIP_TRY(hipMemcpy(mm.p, init, sizeof(init), hipMemcpyHostToDevice));
-  GDF_LAUNCH("jk_minmax", jk_minmax, dim3(small_grid(build_t.nrows)), dim3(256), 0, stream0(), build_t, mm.as<long long>(),
-             mm.as<long long>() + 1);
-  HIP_CHECK_LAST();
-  long long h[2];
-  HIP_TRY(hipMemcpy(h, mm.p, sizeof(h), hipMemcpyDeviceToHost));
-  if (h[0] > h[1]) return GDF_SUCCESS;               // no valid build row: nothing can match anyway
-  const uint64_t range = (uint64_t)h[1] - (uint64_t)h[0];
-  if (range < 0xffffffffULL) { plan->narrow = 1; plan->kmin = (uint64_t)h[0]; }
-  return GDF_SUCCESS;
-}
-
 template <bool NARROW>
 static gdf_error run_probe(bool write, const char *name, size_t nunits, size_t lds, const ProbeArgs &a, const KeyTable &probe_t,
                            const KeyTable &build_t) {
@@ -1048,26 +1047,31 @@ static gdf_error run_probe(bool narrow, bool write, const char *name, size_t nun
 static gdf_error hash_join_core(const KeyTable &probe_t, const KeyTable &build_t, JoinKind kind, int32_t **out_probe,
                                 int32_t **out_build, int64_t *out_n) {
   KeyPlan plan = plan_keys(probe_t);
-  GDF_TRY(plan_narrow_range(build_t, &plan));
-  const bool narrow = plan.narrow != 0;
   const PartGeom g = choose_geometry(build_t.nrows);
   const uint32_t nfine = 1u << g.fb;
   const bool keep_probe = kind != JOIN_INNER;
 
   SideBufs B, P;
-  GDF_TRY(partition_side(build_t, plan, g, &B));
-  GDF_TRY(partition_side(probe_t, plan, g, &P));
+  const bool range_candidate = !plan.narrow && plan.mode == KM_RAW_INT && build_t.col[0].width == 8;
+  GDF_TRY(partition_side(build_t, plan, g, &B, range_candidate));   // may switch plan to the narrow format
+  GDF_TRY(partition_side(probe_t, plan, g, &P, false));
+  const bool narrow = plan.narrow != 0;
 
   // ---- work units ----
   std::vector<Unit> units;
-  std::vector<uint32_t> oversize;     // fine partitions that need the global-table path
+  struct Run { uint32_t f0, f1; };    // [f0, f1): consecutive fine partitions that need the global-table path
+  std::vector<Run> oversize;
   uint32_t max_build = 0;
   for (uint32_t f = 0; f < nfine; ++f) {
     const uint32_t bn = B.fine_off[f + 1] - B.fine_off[f];
     const uint32_t pn = P.fine_off[f + 1] - P.fine_off[f];
     if (pn == 0) continue;
     if (bn == 0 && !keep_probe) continue;
-    if (bn > (uint32_t)JK_MAX_BUILD) { oversize.push_back(f); continue; }
+    if (bn > (uint32_t)JK_MAX_BUILD) {
+      if (!oversize.empty() && oversize.back().f1 == f) oversize.back().f1 = f + 1;   // one table per RUN, not per partition
+      else oversize.push_back(Run{f, f + 1});
+      continue;
+    }
     max_build = std::max(max_build, bn);
     for (uint32_t off = 0; off < pn; off += JK_PROBE_CHUNK)
       units.push_back(Unit{B.fine_off[f], bn, P.fine_off[f] + off, std::min(JK_PROBE_CHUNK, pn - off)});
@@ -1102,6 +1106,7 @@ static gdf_error hash_join_core(const KeyTable &probe_t, const KeyTable &build_t
   a.build_matched = d_matched.as<uint8_t>();
   a.counts = d_counts.as<uint64_t>();
   a.dbg = getenv("GDF_JK_DBG") ? atoi(getenv("GDF_JK_DBG")) : 0;
+  a.kbias = plan.kmin;
   const size_t probe_lds = probe_lds_bytes(narrow, cap_lds, H_lds);
 
   // ---- optimistic single pass ----
@@ -1175,8 +1180,8 @@ static gdf_error hash_join_core(const KeyTable &probe_t, const KeyTable &build_t
   struct GTable { DevBuf key, idx; uint32_t nslots; };
   std::vector<GTable> gt(oversize.size());
   for (size_t o = 0; o < oversize.size(); ++o) {
-    const uint32_t f = oversize[o];
-    const uint32_t bn = B.fine_off[f + 1] - B.fine_off[f], pn = P.fine_off[f + 1] - P.fine_off[f];
+    const uint32_t f = oversize[o].f0, fe = oversize[o].f1;
+    const uint32_t bn = B.fine_off[fe] - B.fine_off[f], pn = P.fine_off[fe] - P.fine_off[f];
     gt[o].nslots = bn * 2;
     RMM_TRY(gt[o].key.alloc(sizeof(uint64_t) * gt[o].nslots));
     RMM_TRY(gt[o].idx.alloc(sizeof(int32_t) * gt[o].nslots));
@@ -1228,8 +1233,8 @@ static gdf_error hash_join_core(const KeyTable &probe_t, const KeyTable &build_t
   // ---- write pass ----
   GDF_TRY(run_probe(narrow, true, "jk_probe_write", nunits, probe_lds, a, probe_t, build_t));
   for (size_t o = 0; o < oversize.size(); ++o) {
-    const uint32_t f = oversize[o];
-    const uint32_t pn = P.fine_off[f + 1] - P.fine_off[f];
+    const uint32_t f = oversize[o].f0, fe = oversize[o].f1;
+    const uint32_t pn = P.fine_off[fe] - P.fine_off[f];
     ProbeArgs ga = a;
     ga.nslots = gt[o].nslots;
     // the exclusive offset of this partition doubles as its write cursor
@@ -1478,13 +1483,12 @@ gdf_error debug_partition(gdf_column *col, int fb, uint64_t *out_key, int32_t *o
   KeyTable t;
   GDF_TRY(make_key_table(cols, 1, &t));
   KeyPlan plan = plan_keys(t);
-  GDF_TRY(plan_narrow_range(t, &plan));
   PartGeom g{};
   g.fb = fb;
   g.b1 = fb <= 8 ? fb : (fb + 1) / 2;
   g.b2 = fb - g.b1;
   SideBufs sb;
-  GDF_TRY(partition_side(t, plan, g, &sb));
+  GDF_TRY(partition_side(t, plan, g, &sb, !plan.narrow && plan.mode == KM_RAW_INT && t.col[0].width == 8));
   if (sb.joinable) {
     const Tuples f = sb.final();
     if (plan.narrow) {

@@ -239,7 +239,8 @@ def test_multigpu_layer_world_size_one(gdf):
     try:
         probe = gen_rand(np.int64, 200000, 0, 5000)
         build = np.random.permutation(5000).astype(np.int64)[:4000]
-        pg, bg = multigpu.distributed_inner_join(torch.from_numpy(probe).cuda(), torch.from_numpy(build).cuda())
+        pairs = multigpu.distributed_inner_join(torch.from_numpy(probe).cuda(), torch.from_numpy(build).cuda())
+        pg, bg = pairs.global_ids()
         el, er = oracle.join([probe], [build], "inner")
         a, b = sort_pairs(pg.cpu().numpy(), bg.cpu().numpy())
         c, d = sort_pairs(el, er)
@@ -254,3 +255,18 @@ def test_multigpu_layer_world_size_one(gdf):
         np.testing.assert_array_equal(gv.cpu().numpy()[o], ea)
     finally:
         dist.destroy_process_group()
+
+
+def test_every_partition_oversize_uses_one_global_table(gdf):
+    """A build side beyond 32768 x 6144 rows makes EVERY fine partition exceed the LDS image: the global-table
+    path must handle them as one run (one table, three launches), not one launch per partition."""
+    import torch
+    from libgdf_amd.columns import Column
+    nb, npr = 210_000_000, 2_000_000
+    build = torch.randperm(nb, dtype=torch.int32, device="cuda")
+    probe = torch.randint(0, nb + nb // 4, (npr,), dtype=torch.int32, device="cuda")
+    li, ri = gdf.api.join([Column(probe)], [Column(build)])
+    hits = int((probe < nb).sum().item())
+    assert li.numel() == hits
+    assert torch.equal(build[ri.long()], probe[li.long()])
+    assert torch.unique(li).numel() == hits

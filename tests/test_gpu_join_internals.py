@@ -53,7 +53,7 @@ def test_partition_invariants(gdf, dtype, fb, n, reps, wide):
     if np.dtype(dtype).itemsize == 8 and narrow:
         assert kmin == int(keys.min()) & 0xFFFFFFFFFFFFFFFF
     key64 = raw - np.uint64(kmin)                                           # what the tuples store
-    fine = (mix64(key64) >> np.uint64(64 - fb)).astype(np.int64)
+    fine = (mix64(raw) >> np.uint64(64 - fb)).astype(np.int64)              # partition id: a function of the RAW key
     exp_off = np.concatenate([[0], np.cumsum(np.bincount(fine, minlength=1 << fb))])
     for _ in range(reps):
         k, i, off, nj, _ = _partition(gdf, col, n, fb)

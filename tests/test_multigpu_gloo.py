@@ -50,8 +50,10 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from libgdf_amd import multigpu
     probes, builds = _shards(world)
-    pg, bg = multigpu.distributed_inner_join(torch.from_numpy(probes[rank]), torch.from_numpy(builds[rank]),
-                                             partition_fn=_np_partition, join_fn=_np_join)
+    pairs = multigpu.distributed_inner_join(torch.from_numpy(probes[rank]), torch.from_numpy(builds[rank]),
+                                            partition_fn=_np_partition, join_fn=_np_join)
+    pg, bg = pairs.global_ids()
+    assert pairs.numel() == pg.numel()
     k = torch.from_numpy(probes[rank])
     v = torch.from_numpy((probes[rank] * 3 + rank).astype(np.int64))
     gk, gv = multigpu.distributed_group_by_sum(k, v, group_fn=_np_group_sum, partition_fn=_np_partition)

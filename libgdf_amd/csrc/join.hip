@@ -202,15 +202,31 @@ __device__ __forceinline__ uint64_t tup_key(uint64_t w) { return NARROW ? (w >> 
 template <bool NARROW>
 __device__ __forceinline__ uint64_t tup_make(uint64_t key, int32_t row) { return NARROW ? ((key << 32) | (uint32_t)row) : key; }
 
-__device__ __forceinline__ uint32_t fine_of(uint64_t raw_key, int fb) {
-  return fb ? (uint32_t)(mix64(raw_key) >> (64 - fb)) : 0u;
+// Internal hashes (never visible through the ABI -- the public row hash is Murmur3_32 in hash.cuh).
+// All of them are functions of the RAW key.  32-bit arithmetic on purpose: gfx950 has no 64-bit integer
+// multiplier, a 64-bit xorshift-multiply mixer costs ~4x the VALU cycles of this one, and the regroup
+// passes are VALU/LDS-bound, not HBM-bound (profiles/r1_e_scatter_ablation.md).
+//   key_fold : 64 -> 32 bits (injective on any key range below 2^32, i.e. on NARROW keys)
+//   hash_a   : partition id = top fb bits; cuckoo table-0 slot = low bits (fb + log2 H <= 28: disjoint)
+//   hash_b   : cuckoo table-1 slot, linear-probing slot, global-table slot
+__device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du;
+  x ^= x >> 15; x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
 }
-// two slot hashes from bits of mix64 that the partition id (top fb <= 15 bits) does not use
-__device__ __forceinline__ uint32_t slot_h0(uint64_t m, uint32_t H) { return (uint32_t)m & (H - 1); }
-__device__ __forceinline__ uint32_t slot_h1(uint64_t m, uint32_t H) { return (uint32_t)(m >> 24) & (H - 1); }
+__device__ __forceinline__ uint32_t key_fold(uint64_t raw_key) {
+  return (uint32_t)raw_key ^ ((uint32_t)(raw_key >> 32) * 0x9e3779b1u);
+}
+__device__ __forceinline__ uint32_t hash_a(uint64_t raw_key) { return lowbias32(key_fold(raw_key)); }
+__device__ __forceinline__ uint32_t hash_b(uint64_t raw_key) { return lowbias32(key_fold(raw_key) ^ 0x68e31da4u); }
+
+__device__ __forceinline__ uint32_t fine_of(uint64_t raw_key, int fb) {
+  return fb ? hash_a(raw_key) >> (32 - fb) : 0u;
+}
 // slot of the global-table path (any table size)
 __device__ __forceinline__ uint32_t slot_of(uint64_t key, uint32_t nslots) {
-  return (uint32_t)(((uint64_t)(uint32_t)mix64(key) * nslots) >> 32);
+  return (uint32_t)(((uint64_t)hash_b(key) * nslots) >> 32);
 }
 
 // ---------------------------------------------------------------------------
@@ -329,6 +345,7 @@ __device__ __forceinline__ void tile_flush(TileLds<NARROW, THREADS> &s, const Pa
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
+      if (g.dbg & 4) dst[u] &= 0xffffu;        // experiment: all stores land in a 512 KiB window
       if (j0 + u * THREADS < total && !(g.dbg & 1)) {
         out.w[dst[u]] = ww[u];
         if (!NARROW) out.idx[dst[u]] = ii[u];
@@ -350,12 +367,31 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
   if (threadIdx.x < ncoarse) s.cursor[threadIdx.x] = H1off[(size_t)threadIdx.x * g.nchunks + chunk];
   const int64_t begin = (int64_t)chunk * g.chunk;
   const int64_t end = begin + g.chunk < t.nrows ? begin + g.chunk : t.nrows;
+  // FAST: the raw column words of the NEXT tile are requested while the current tile is flushed, so the
+  // HBM read latency hides behind the LDS regroup + store phase (one workgroup per CU: nothing else would)
+  uint64_t nxt[JK_SC_ITEMS];
+  const uint64_t *col = (const uint64_t *)t.col[0].data;
+  if (FAST) {
+#pragma unroll
+    for (int k = 0; k < JK_SC_ITEMS; ++k) {
+      const int64_t i = begin + (int64_t)k * THREADS + threadIdx.x;
+      nxt[k] = col[i < end ? i : end - 1];
+    }
+  }
   for (int64_t tile = begin; tile < end; tile += JK_TILE) {
     if (threadIdx.x < 256) s.hist[threadIdx.x] = 0;
     block_sync();
     uint64_t key[JK_SC_ITEMS];
     bool ok[JK_SC_ITEMS];
-    fetch_keys<FAST, JK_SC_ITEMS>(t, plan, tile + threadIdx.x, THREADS, end, key, ok);   // all loads first
+    if (FAST) {
+#pragma unroll
+      for (int k = 0; k < JK_SC_ITEMS; ++k) {
+        key[k] = nxt[k] - plan.kmin;
+        ok[k] = (tile + (int64_t)k * THREADS + threadIdx.x < end) && (!plan.narrow || (key[k] >> 32) == 0);
+      }
+    } else {
+      fetch_keys<FAST, JK_SC_ITEMS>(t, plan, tile + threadIdx.x, THREADS, end, key, ok);   // all loads first
+    }
     uint32_t binrank[JK_SC_ITEMS];   // bin << 16 | rank ; 0xffffffff = skip
 #pragma unroll
     for (int k = 0; k < JK_SC_ITEMS; ++k) {
@@ -379,6 +415,13 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
         const int32_t row = (int32_t)(tile + (int64_t)k * THREADS + threadIdx.x);
         s.w[pos] = tup_make<NARROW>(key[k], row);
         if (!NARROW) s.idx[pos] = row;
+      }
+    }
+    if (FAST && tile + JK_TILE < end) {
+#pragma unroll
+      for (int k = 0; k < JK_SC_ITEMS; ++k) {
+        const int64_t i = tile + JK_TILE + (int64_t)k * THREADS + threadIdx.x;
+        nxt[k] = col[i < end ? i : end - 1];
       }
     }
     block_sync();
@@ -545,8 +588,8 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
     uint32_t cur = p0, table = 0;
     int moves = 0;
     for (; moves < JK_CUCKOO_MAX_MOVES; ++moves) {
-      const uint64_t m = mix64(tup_key<NARROW>(l.bw[cur]) + a.kbias);
-      const uint32_t slot = table ? H + slot_h1(m, H) : slot_h0(m, H);
+      const uint64_t raw = tup_key<NARROW>(l.bw[cur]) + a.kbias;
+      const uint32_t slot = table ? H + (hash_b(raw) & (H - 1)) : (hash_a(raw) & (H - 1));
       const uint32_t old = atomicExch(&l.T[slot], cur);
       if (old == JK_NOPOS) break;
       cur = old;          // the evicted tuple moves to its other table
@@ -563,7 +606,7 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
     block_sync();
     const uint32_t mask = 2 * H - 1;
     for (uint32_t p = threadIdx.x; p < u.build_count; p += JK_PROBE_THREADS) {
-      uint32_t slot = (uint32_t)mix64(tup_key<NARROW>(l.bw[p]) + a.kbias) & mask;
+      uint32_t slot = hash_b(tup_key<NARROW>(l.bw[p]) + a.kbias) & mask;
       while (atomicCAS(&l.T[slot], JK_NOPOS, p) != JK_NOPOS) slot = (slot + 1) & mask;
     }
     block_sync();
@@ -592,9 +635,9 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
       uint32_t pa[JK_PROBE_BATCH], pb[JK_PROBE_BATCH];
 #pragma unroll
       for (int b = 0; b < JK_PROBE_BATCH; ++b) {    // 8 independent table reads
-        const uint64_t m = mix64(k[b] + a.kbias);
-        pa[b] = l.T[slot_h0(m, H)];
-        pb[b] = l.T[H + slot_h1(m, H)];
+        const uint64_t raw = k[b] + a.kbias;
+        pa[b] = l.T[hash_a(raw) & (H - 1)];
+        pb[b] = l.T[H + (hash_b(raw) & (H - 1))];
       }
       uint64_t ka[JK_PROBE_BATCH], kb[JK_PROBE_BATCH];
 #pragma unroll
@@ -626,7 +669,7 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
         cnt[b] = 0;
         hit_a[b] = hit_b[b] = JK_NOPOS;
         if (base + b * JK_PROBE_THREADS + threadIdx.x < u.probe_count) {
-          uint32_t slot = (uint32_t)mix64(k[b] + a.kbias) & mask;
+          uint32_t slot = hash_b(k[b] + a.kbias) & mask;
           for (;;) {
             const uint32_t p = l.T[slot];
             if (p == JK_NOPOS) break;
@@ -679,7 +722,7 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
           }
         } else if (c > 1) {      // linear-probing mode with several matches: walk the chain again
           const uint32_t mask = 2 * H - 1;
-          uint32_t slot = (uint32_t)mix64(k[b] + a.kbias) & mask;
+          uint32_t slot = hash_b(k[b] + a.kbias) & mask;
           for (;;) {
             const uint32_t p = l.T[slot];
             if (p == JK_NOPOS) break;
@@ -1484,6 +1527,7 @@ gdf_error debug_partition(gdf_column *col, int fb, uint64_t *out_key, int32_t *o
   GDF_TRY(make_key_table(cols, 1, &t));
   KeyPlan plan = plan_keys(t);
   PartGeom g{};
+  g.dbg = getenv("GDF_JK_SDBG") ? atoi(getenv("GDF_JK_SDBG")) : 0;
   g.fb = fb;
   g.b1 = fb <= 8 ? fb : (fb + 1) / 2;
   g.b2 = fb - g.b1;

@@ -14,11 +14,13 @@ from util import gen_rand
 pytestmark = pytest.mark.gpu
 
 
-def mix64(x):
-    x = x.astype(np.uint64)
-    x ^= x >> np.uint64(33); x *= np.uint64(0xff51afd7ed558ccd)
-    x ^= x >> np.uint64(33); x *= np.uint64(0xc4ceb9fe1a85ec53)
-    x ^= x >> np.uint64(33)
+def hash_a(raw):
+    """numpy restatement of csrc/join.hip hash_a(): lowbias32(key_fold(raw key))."""
+    raw = raw.astype(np.uint64)
+    x = (raw & np.uint64(0xFFFFFFFF)).astype(np.uint32) ^ ((raw >> np.uint64(32)).astype(np.uint32) * np.uint32(0x9e3779b1))
+    x ^= x >> np.uint32(16); x *= np.uint32(0x7feb352d)
+    x ^= x >> np.uint32(15); x *= np.uint32(0x846ca68b)
+    x ^= x >> np.uint32(16)
     return x
 
 
@@ -53,7 +55,7 @@ def test_partition_invariants(gdf, dtype, fb, n, reps, wide):
     if np.dtype(dtype).itemsize == 8 and narrow:
         assert kmin == int(keys.min()) & 0xFFFFFFFFFFFFFFFF
     key64 = raw - np.uint64(kmin)                                           # what the tuples store
-    fine = (mix64(raw) >> np.uint64(64 - fb)).astype(np.int64)              # partition id: a function of the RAW key
+    fine = (hash_a(raw) >> np.uint32(32 - fb)).astype(np.int64)             # partition id: a function of the RAW key
     exp_off = np.concatenate([[0], np.cumsum(np.bincount(fine, minlength=1 << fb))])
     for _ in range(reps):
         k, i, off, nj, _ = _partition(gdf, col, n, fb)

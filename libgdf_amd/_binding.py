@@ -105,6 +105,7 @@ _PROTOTYPES = {
     "gpu_comparison_static_f64": (None, [_COLP, C.c_double, _COLP, C.c_int]),
     "gpu_comparison": (None, [_COLP, _COLP, _COLP, C.c_int]),
     "gpu_apply_stencil": (None, [_COLP, _COLP, _COLP]),
+    "gdf_order_by": (None, [C.c_size_t, _COLP, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gdf_filter": (None, [C.c_size_t, _COLP, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                           C.POINTER(C.c_size_t)]),
 }

@@ -12,7 +12,7 @@ import ctypes as C
 import numpy as np
 
 from ._binding import gdf_column, libgdf
-from .columns import (GDF_HASH, GDF_HASH_MURMUR3, GDF_TO_NP, Column, column_array, new_context)
+from .columns import (GDF_HASH, GDF_HASH_MURMUR3, GDF_SORT, GDF_TO_NP, Column, column_array, new_context)
 
 _hip = None
 
@@ -61,11 +61,13 @@ _GROUPBY = {"sum": "gdf_group_by_sum", "min": "gdf_group_by_min", "max": "gdf_gr
             "avg": "gdf_group_by_avg", "count": "gdf_group_by_count"}
 
 
-def group_by(op, keys, values, out_dtype: int | None = None, sort_result=False, method=GDF_HASH, capacity=None):
+def group_by(op, keys, values, out_dtype: int | None = None, sort_result=False, method=GDF_HASH, capacity=None,
+             with_indices=False, distinct=False, presorted=False):
     """gdf_group_by_<op> -> (list of key tensors, aggregate tensor), trimmed to the number of groups.
 
     Outputs are preallocated by the caller with capacity N rows, as the reference's tests do
-    (tests/groupby/groupby-test.cu:127).
+    (tests/groupby/groupby-test.cu:127).  ``with_indices`` also passes ``out_col_indices`` (size_t row
+    numbers, filled by the GDF_SORT method only) and returns it as a third int64 tensor.
     """
     import torch
     n = keys[0].size if capacity is None else capacity
@@ -75,11 +77,28 @@ def group_by(op, keys, values, out_dtype: int | None = None, sort_result=False, 
     if out_dtype is None:
         out_dtype = values.c.dtype
     out_agg = Column(torch.empty(max(n, 1), dtype=torch_of[out_dtype], device="cuda"), None, out_dtype, size=n)
-    ctx = new_context(method=method, flag_sort_result=1 if sort_result else 0)
+    out_idx = Column(torch.full((max(n, 1),), -1, dtype=torch.int64, device="cuda"), None, 4, size=n) if with_indices else None
+    ctx = new_context(method=method, flag_sort_result=1 if sort_result else 0, flag_distinct=1 if distinct else 0,
+                      flag_sorted=1 if presorted else 0)
     ka, oa = column_array(keys), column_array(out_keys)
-    getattr(libgdf, _GROUPBY[op])(len(keys), ka, values.ptr, None, oa, out_agg.ptr, C.byref(ctx))
+    getattr(libgdf, _GROUPBY[op])(len(keys), ka, values.ptr, out_idx.ptr if with_indices else None, oa, out_agg.ptr, C.byref(ctx))
     g = out_agg.size
+    if with_indices:
+        return [k.data[:g] for k in out_keys], out_agg.data[:g], out_idx.data[:out_idx.size]
     return [k.data[:g] for k in out_keys], out_agg.data[:g]
+
+
+def order_by(cols):
+    """gdf_order_by -> int64 tensor with the sorted row permutation (the library writes size_t)."""
+    import torch
+    n = cols[0].size
+    arr = (gdf_column * len(cols))(*[c.c for c in cols])       # the entry point takes an ARRAY of structs
+    d_cols = torch.empty(len(cols), dtype=torch.int64, device="cuda")
+    d_types = torch.empty(len(cols), dtype=torch.int32, device="cuda")
+    d_indx = torch.empty(max(n, 1), dtype=torch.int64, device="cuda")
+    libgdf.gdf_order_by(n, arr, len(cols), d_cols.data_ptr(), d_types.data_ptr(), d_indx.data_ptr())
+    assert d_cols.tolist() == [int(c.c.data or 0) for c in cols] and d_types.tolist() == [int(c.c.dtype) for c in cols]
+    return d_indx[:n]
 
 
 def hash_rows(cols, hash_func=GDF_HASH_MURMUR3):

@@ -17,8 +17,8 @@
 //                 first-row index like the reference, without the LDS stage.
 //   gb_extract    wave-ballot compaction of the occupied slots into the caller's
 //                 preallocated outputs, finishing AVG = SUM / COUNT in the same pass.
-//   gb_sort_*     optional lexicographic sort of the result rows
-//                 (flag_sort_result, and always for AVG as in groupby.cuh:345-386).
+//   sort_result_rows  optional lexicographic sort of the result rows through sort.hip's
+//                 radix sort (flag_sort_result, and always for AVG as in groupby.cuh:345-386).
 //
 // Semantics kept: aggregation in the INPUT dtype with wrap-around for integers
 // (aggregation_operations.cuh:30-86), COUNT in the OUTPUT column's dtype
@@ -38,7 +38,7 @@ constexpr uint32_t GB_LDS_LIMIT = GB_LDS_SLOTS * 3 / 4;
 constexpr uint64_t GB_EMPTY_KEY = 0x8000000000000000ULL;   // reserved packed key; a real key with these bits uses slot T
 constexpr int32_t GB_EMPTY_ROW = -1;
 
-enum GbOp : int { OP_SUM = 0, OP_MIN, OP_MAX, OP_AVG, OP_COUNT };
+enum GbOp : int { OP_SUM = 0, OP_MIN, OP_MAX, OP_AVG, OP_COUNT, OP_COUNT_DISTINCT };   // sort.hip's SgOp has the same order
 
 struct GbKeyPlan {
   int packed;                  // 1: exact 64-bit packed key, 0: first-row table + rows_equal
@@ -394,42 +394,10 @@ __global__ __launch_bounds__(256) void gb_extract(KeyTable t, GbKeyPlan plan, Gb
 }
 
 // ---------------------------------------------------------------------------
-// result sort: bitonic network over a row permutation, comparing the OUTPUT key
-// columns lexicographically with typed < (LesserRTTI, sqls_rtti_comp.hpp:33-279).
-// Result sets are small next to the input (one row per group).
+// result sort: the OUTPUT key columns are ordered lexicographically with typed <
+// (LesserRTTI, sqls_rtti_comp.hpp:33-279) by sort.hip's radix sort of a row
+// permutation, then every output column is gathered through it.
 // ---------------------------------------------------------------------------
-struct SortCols { int ncols; const void *data[MAX_KEY_COLS]; int kind[MAX_KEY_COLS]; };
-
-__device__ __forceinline__ int cmp_rows(const SortCols &s, uint32_t a, uint32_t b) {
-  for (int c = 0; c < s.ncols; ++c) {
-    switch (s.kind[c]) {
-      case K_F32: { float x = ((const float *)s.data[c])[a], y = ((const float *)s.data[c])[b]; if (x < y) return -1; if (y < x) return 1; break; }
-      case K_F64: { double x = ((const double *)s.data[c])[a], y = ((const double *)s.data[c])[b]; if (x < y) return -1; if (y < x) return 1; break; }
-      case K_I8: { int x = ((const int8_t *)s.data[c])[a], y = ((const int8_t *)s.data[c])[b]; if (x < y) return -1; if (y < x) return 1; break; }
-      case K_I16: { int x = ((const int16_t *)s.data[c])[a], y = ((const int16_t *)s.data[c])[b]; if (x < y) return -1; if (y < x) return 1; break; }
-      case K_I32: { int x = ((const int32_t *)s.data[c])[a], y = ((const int32_t *)s.data[c])[b]; if (x < y) return -1; if (y < x) return 1; break; }
-      default: { int64_t x = ((const int64_t *)s.data[c])[a], y = ((const int64_t *)s.data[c])[b]; if (x < y) return -1; if (y < x) return 1; break; }
-    }
-  }
-  return 0;
-}
-
-__global__ void gb_sort_iota(uint32_t *perm, uint32_t npad) {
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npad; i += gridDim.x * blockDim.x) perm[i] = i;
-}
-// indices >= n are padding and sort last
-__global__ void gb_sort_step(uint32_t *perm, uint32_t npad, uint32_t n, uint32_t j, uint32_t k, SortCols s) {
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npad; i += gridDim.x * blockDim.x) {
-    const uint32_t l = i ^ j;
-    if (l <= i) continue;
-    const uint32_t a = perm[i], b = perm[l];
-    int c;
-    if (a >= n || b >= n) c = (a >= n) ? ((b >= n) ? 0 : 1) : -1;
-    else { c = cmp_rows(s, a, b); if (c == 0) c = a < b ? -1 : (a > b ? 1 : 0); }
-    const bool ascending = (i & k) == 0;
-    if ((ascending && c > 0) || (!ascending && c < 0)) { perm[i] = b; perm[l] = a; }
-  }
-}
 __global__ void gb_sort_gather(const uint32_t *perm, uint32_t n, int width, const void *in, void *out) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const uint32_t s = perm[i];
@@ -444,20 +412,19 @@ __global__ void gb_sort_gather(const uint32_t *perm, uint32_t n, int width, cons
 
 static gdf_error sort_result_rows(int ncols, gdf_column **key_cols, const int *key_kind, void *agg, int agg_width, uint32_t n) {
   if (n < 2) return GDF_SUCCESS;
-  uint32_t npad = 1;
-  while (npad < n) npad <<= 1;
+  KeyTable t{};
+  t.ncols = ncols;
+  t.nrows = n;
+  for (int c = 0; c < ncols; ++c) {
+    t.col[c].data = key_cols[c]->data;
+    t.col[c].valid = nullptr;
+    t.col[c].kind = key_kind[c];
+    t.col[c].width = kind_width((ElemKind)key_kind[c]);
+  }
   DevBuf perm, tmp;
-  RMM_TRY(perm.alloc(sizeof(uint32_t) * npad));
+  GDF_TRY(order_rows(t, n, perm, nullptr, nullptr));
   RMM_TRY(tmp.alloc((size_t)8 * n));
-  SortCols s{};
-  s.ncols = ncols;
-  for (int c = 0; c < ncols; ++c) { s.data[c] = key_cols[c]->data; s.kind[c] = key_kind[c]; }
-  const int grid = stream_grid(npad, 256 * 4);
-  hipLaunchKernelGGL(gb_sort_iota, dim3(grid), dim3(256), 0, stream0(), perm.as<uint32_t>(), npad);
-  for (uint32_t k = 2; k <= npad; k <<= 1)
-    for (uint32_t j = k >> 1; j > 0; j >>= 1)
-      hipLaunchKernelGGL(gb_sort_step, dim3(grid), dim3(256), 0, stream0(), perm.as<uint32_t>(), npad, n, j, k, s);
-  HIP_CHECK_LAST();
+  const int grid = stream_grid(n, 256 * 4);
   auto permute = [&](void *data, int width) -> gdf_error {
     hipLaunchKernelGGL(gb_sort_gather, dim3(grid), dim3(256), 0, stream0(), perm.as<uint32_t>(), n, width, data, tmp.p);
     HIP_TRY(hipMemcpyAsync(data, tmp.p, (size_t)width * n, hipMemcpyDeviceToDevice, stream0()));
@@ -870,10 +837,12 @@ static gdf_error group_by_single(int ncols, gdf_column **cols, gdf_column *col_a
         if (out_col_values[c]) out_col_values[c]->size = 0;
     return GDF_SUCCESS;
   }
-  if (ctxt->flag_method == GDF_SORT) return GDF_UNSUPPORTED_METHOD;   // sort-based path: SURVEY.md 8f rank 2
-  if (ctxt->flag_method != GDF_HASH) return GDF_UNSUPPORTED_METHOD;
+  if (ctxt->flag_method != GDF_HASH && ctxt->flag_method != GDF_SORT) return GDF_UNSUPPORTED_METHOD;
   gdf_nvtx_range_push("LIBGDF_GROUPBY", GDF_ORANGE);   // sqls_ops.cu:1132
   struct Pop { ~Pop() { gdf_nvtx_range_pop(); } } pop;
+  if (ctxt->flag_method == GDF_SORT)                    // sort.hip; sqls_ops.cu:1134-1289
+    return group_by_sort(ncols, cols, col_agg, out_col_indices, out_col_values, out_col_agg, ctxt, op);
+  if (op == OP_COUNT_DISTINCT) return GDF_UNSUPPORTED_METHOD;   // hash branch's default case, sqls_ops.cu:1347-1349
   return group_by_hash(ncols, cols, col_agg, out_col_values, out_col_agg, op, ctxt->flag_sort_result == 1);
 }
 
@@ -901,7 +870,10 @@ gdf_error gdf_group_by_avg(int ncols, gdf_column **cols, gdf_column *col_agg, gd
 }
 gdf_error gdf_group_by_count(int ncols, gdf_column **cols, gdf_column *col_agg, gdf_column *out_col_indices,
                              gdf_column **out_col_values, gdf_column *out_col_agg, gdf_context *ctxt) {
-  return group_by_single(ncols, cols, col_agg, out_col_indices, out_col_values, out_col_agg, ctxt, OP_COUNT);
+  if (nullptr == ctxt) return GDF_DATASET_EMPTY;
+  // flag_distinct selects COUNT_DISTINCT (sqls_ops.cu:1483-1486), which only the SORT method implements
+  return group_by_single(ncols, cols, col_agg, out_col_indices, out_col_values, out_col_agg, ctxt,
+                         ctxt->flag_distinct ? OP_COUNT_DISTINCT : OP_COUNT);
 }
 
 }  // extern "C"

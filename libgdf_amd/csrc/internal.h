@@ -11,4 +11,11 @@ namespace gdf_amd {
 gdf_error scan_u32(const uint32_t *in, uint32_t *out, size_t n, bool inclusive);
 gdf_error scan_u64(const uint64_t *in, uint64_t *out, size_t n, bool inclusive);
 
+// sort.hip: stable ascending lexicographic row order of t's first n rows -> perm (n x uint32).
+// sorted_keys / keys_exact are optional (see sort.hip).
+gdf_error order_rows(const KeyTable &t, uint32_t n, DevBuf &perm, DevBuf *sorted_keys, bool *keys_exact);
+// sort.hip: SORT-method group-by (op = GbOp of groupby.hip, 5 = COUNT_DISTINCT)
+gdf_error group_by_sort(int ncols, gdf_column **cols, gdf_column *col_agg, gdf_column *out_col_indices,
+                        gdf_column **out_col_values, gdf_column *out_col_agg, gdf_context *ctxt, int op);
+
 }  // namespace gdf_amd

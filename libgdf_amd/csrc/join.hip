@@ -1345,11 +1345,24 @@ static gdf_error join_call(JoinKind kind, int num_cols, gdf_column **leftcol, gd
     if (left_size != leftcol[i]->size) return GDF_COLUMN_SIZE_MISMATCH;
     if (right_size != rightcol[i]->size) return GDF_COLUMN_SIZE_MISMATCH;
   }
-  if (ctx->flag_method == GDF_SORT) {
-    // the sort-merge path (join/sort/sort-join.cuh) is outside this library's scope
-    return num_cols == 1 ? GDF_UNSUPPORTED_METHOD : GDF_JOIN_TOO_MANY_COLUMNS;
+  const bool sort_method = ctx->flag_method == GDF_SORT;
+  if (sort_method) {
+    // GDF_SORT (joining.cu:100-159, 352-365): one key column, no masks, floats compared by BIT
+    // PATTERN (sort_join dispatches FLOAT32/64 to int32_t/int64_t).  The set of index pairs
+    // an equi-join produces does not depend on the algorithm, so the request runs on the same
+    // partitioned join as GDF_HASH; only the pair ORDER differs from a merge join's, and no
+    // caller contract covers it.  FULL has no sort implementation in the reference: the
+    // generic SortJoin returns two empty columns and success (joining.cu:66-75).
+    if (num_cols != 1) return GDF_JOIN_TOO_MANY_COLUMNS;
+    GDF_REQUIRE(!leftcol[0]->valid && !rightcol[0]->valid, GDF_VALIDITY_UNSUPPORTED);
+    if (kind == JOIN_FULL) {
+      gdf_column_view(left_result, nullptr, nullptr, 0, N_GDF_TYPES);
+      gdf_column_view(right_result, nullptr, nullptr, 0, N_GDF_TYPES);
+      return GDF_SUCCESS;
+    }
+  } else if (ctx->flag_method != GDF_HASH) {
+    return GDF_UNSUPPORTED_METHOD;
   }
-  if (ctx->flag_method != GDF_HASH) return GDF_UNSUPPORTED_METHOD;
 
   gdf_nvtx_range_push("LIBGDF_JOIN", GDF_CYAN);   // joining.cu:343
   struct Pop { ~Pop() { gdf_nvtx_range_pop(); } } pop;
@@ -1357,6 +1370,11 @@ static gdf_error join_call(JoinKind kind, int num_cols, gdf_column **leftcol, gd
   KeyTable lt, rt;
   GDF_TRY(make_key_table(leftcol, num_cols, &lt));
   GDF_TRY(make_key_table(rightcol, num_cols, &rt));
+  if (sort_method)
+    for (KeyTable *t : {&lt, &rt}) {
+      if (t->col[0].kind == K_F32) t->col[0].kind = K_I32;
+      if (t->col[0].kind == K_F64) t->col[0].kind = K_I64;
+    }
   // compute_hash_join starts by clearing both outputs (join_compute_api.h:353-354)
   gdf_column_view(left_result, nullptr, nullptr, 0, N_GDF_TYPES);
   gdf_column_view(right_result, nullptr, nullptr, 0, N_GDF_TYPES);

@@ -1,0 +1,583 @@
+// sort.hip -- gdf_order_by and the SORT-method group-by.
+//
+// Reference path being replaced: src/sqls_ops.cu:1134-1289 (gdf_group_by_single, GDF_SORT
+// branch), :1373-1392 (gdf_order_by) over src/sqls_rtti_comp.hpp:299-320 (thrust::sort of
+// a row permutation with the RTTI comparator LesserRTTI::less: one dtype switch per
+// column per comparison, ~log2(N) dependent gathers per row) and :397-662
+// (thrust::gather + thrust::reduce_by_key with LesserRTTI::equal).  Here:
+//
+//   order_rows    The key columns are folded, last column group first, into 64-bit
+//                 ORDER-PRESERVING unsigned images (sign bit flipped for integers;
+//                 IEEE total-order trick for floats with -0.0 folded onto +0.0 so that
+//                 rows that compare == are adjacent) and the (image, row) pairs go
+//                 through a stable LSD radix sort, 8 bits per pass.  Digits on which
+//                 every key agrees are skipped (the OR of key ^ key[0], reduced while the
+//                 images are built, decides), so int64 keys < 2^32 cost 4 passes, not 8.  Columns
+//                 that do not fit one 64-bit image are handled as further stable sorts
+//                 (LSD over column groups), gathering through the current permutation.
+//   rs_scatter    one pass: every wave owns a CONTIGUOUS run of the tile (so stability
+//                 is (wave, round, lane) order), ranks its keys with 8 ballots per key
+//                 (match-any) against a per-wave LDS digit counter, the tile is
+//                 regrouped by digit in LDS and leaves as runs of equal digit, at
+//                 offsets from one exclusive scan over the (digit, tile) count matrix.
+//   sg_*          group boundaries from adjacent-row equality (typed ==, so NaN rows
+//                 stay singletons and -0.0 == +0.0, as LesserRTTI::equal), group ids by
+//                 prefix sum, and a wave-level SEGMENTED reduction of the gathered
+//                 aggregation column: segmented shuffle scan per 64 sorted rows, the open
+//                 segment carried in registers across rounds, one atomic per
+//                 (wave, group) pair.  COUNT and the AVG divisor are differences of
+//                 group start offsets -- no accumulation at all.
+//
+// Semantics kept: output rows in ascending lexicographic key order; aggregation in the
+// INPUT dtype (sum/static_cast<ValsT>(n) for AVG, sqls_rtti_comp.hpp:651-657); COUNT
+// in the OUTPUT column's dtype (sqls_ops.cu:272-400); COUNT_DISTINCT (flag_distinct)
+// writes the number of groups into element 0 and reports size 1 (:440-446 of the
+// rtti header); out_col_indices receives size_t row numbers (quirk 7) and
+// gdf_order_by's d_indx is size_t as well; valid masks -> GDF_VALIDITY_UNSUPPORTED.
+// The reference's sort is unstable, so which row of a group out_col_indices names is
+// unspecified there; this implementation names the LAST row of the group in input
+// order, which is what the reference's own known-answer test expects
+// (tests/sqls/sqls_g_tester.cu:250-256: indices {5,0,2,4}).  flag_sorted == 1 means the
+// caller promises the rows are already ordered: the permutation is the identity.
+// NaN keys order after +inf (the reference's comparator leaves them unordered).
+#include "internal.h"
+
+#include <vector>
+
+namespace gdf_amd {
+
+constexpr int RS_THREADS = 512;
+constexpr int RS_WAVES = RS_THREADS / WAVE;
+constexpr int RS_ITEMS = 8;
+constexpr int RS_TILE = RS_THREADS * RS_ITEMS;      // 4096 pairs: 48 KiB of LDS
+constexpr int RS_BINS = 256;
+constexpr int RS_DIGITS = 8;
+constexpr int SG_THREADS = 256;
+constexpr int SG_ROUNDS = 16;                        // 64 x 16 sorted rows per wave
+
+enum SgOp : int { SG_SUM = 0, SG_MIN, SG_MAX, SG_AVG, SG_COUNT, SG_COUNT_DISTINCT };
+
+// one group of adjacent key columns whose widths sum to <= 8 bytes
+struct SortGroup {
+  int ncols;
+  const void *data[8];
+  int kind[8];
+  int shift[8];
+};
+
+// order-preserving unsigned image of one element, `width` bytes wide
+__device__ __forceinline__ uint64_t ordered_bits(const void *data, int kind, int64_t i) {
+  switch (kind) {
+    case K_I8: return (uint64_t)(((const uint8_t *)data)[i] ^ 0x80u);
+    case K_I16: return (uint64_t)(((const uint16_t *)data)[i] ^ 0x8000u);
+    case K_I32: return (uint64_t)(((const uint32_t *)data)[i] ^ 0x80000000u);
+    case K_F32: {
+      uint32_t b = ((const uint32_t *)data)[i];
+      if ((b << 1) == 0) b = 0;                                   // -0.0 == +0.0
+      if ((b & 0x7fffffffu) > 0x7f800000u) return 0xffffffffu;    // NaN: after +inf
+      return (b >> 31) ? (uint32_t)~b : (b | 0x80000000u);
+    }
+    case K_F64: {
+      uint64_t b = ((const uint64_t *)data)[i];
+      if ((b << 1) == 0) b = 0;
+      if ((b & 0x7fffffffffffffffULL) > 0x7ff0000000000000ULL) return ~0ULL;
+      return (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
+    }
+    default: return ((const uint64_t *)data)[i] ^ 0x8000000000000000ULL;
+  }
+}
+
+// perm may alias vals (row numbers are rewritten in place).  *varying collects the bits
+// on which some key differs from key 0: a digit with no varying bit needs no pass.
+__global__ __launch_bounds__(256) void rs_make_keys(SortGroup g, const uint32_t *perm, uint64_t *__restrict__ keys, uint32_t *vals,
+                                                    uint32_t n, unsigned long long *__restrict__ varying) {
+  uint64_t k0 = 0, diff = 0;
+  {
+    const uint32_t row0 = perm ? perm[0] : 0;
+    for (int c = 0; c < g.ncols; ++c) k0 |= ordered_bits(g.data[c], g.kind[c], row0) << g.shift[c];
+  }
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const uint32_t row = perm ? perm[i] : i;
+    uint64_t k = 0;
+    for (int c = 0; c < g.ncols; ++c) k |= ordered_bits(g.data[c], g.kind[c], row) << g.shift[c];
+    keys[i] = k;
+    vals[i] = row;
+    diff |= k ^ k0;
+  }
+#pragma unroll
+  for (int d = 1; d < WAVE; d <<= 1) {
+    const uint32_t lo = __shfl_xor((uint32_t)diff, d), hi = __shfl_xor((uint32_t)(diff >> 32), d);
+    diff |= ((uint64_t)hi << 32) | lo;
+  }
+  if (lane_id() == 0 && diff) atomicOr(varying, (unsigned long long)diff);
+}
+
+// counts[v * ntiles + tile] = number of keys of the tile whose digit is v
+__global__ __launch_bounds__(RS_THREADS) void rs_count(const uint64_t *__restrict__ keys, uint32_t n, int shift,
+                                                       uint32_t *__restrict__ counts, uint32_t ntiles) {
+  __shared__ uint32_t h[RS_BINS];
+  if (threadIdx.x < RS_BINS) h[threadIdx.x] = 0;
+  block_sync();
+  const uint32_t base = blockIdx.x * RS_TILE;
+#pragma unroll
+  for (int r = 0; r < RS_ITEMS; ++r) {
+    const uint32_t i = base + r * RS_THREADS + threadIdx.x;
+    if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & 255u], 1u);
+  }
+  block_sync();
+  if (threadIdx.x < RS_BINS) counts[threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
+}
+
+__global__ __launch_bounds__(RS_THREADS) void rs_scatter(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+                                                         uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
+                                                         uint32_t n, int shift, const uint32_t *__restrict__ offsets,
+                                                         uint32_t ntiles) {
+  __shared__ uint64_t skey[RS_TILE];
+  __shared__ uint32_t sval[RS_TILE];
+  __shared__ uint32_t wcnt[RS_WAVES * RS_BINS];   // per-wave digit counts, then exclusive prefix over waves
+  __shared__ uint32_t binstart[RS_BINS];          // first LDS position of a digit
+  __shared__ uint32_t gbase[RS_BINS];             // global position of LDS position 0 of a digit (mod 2^32)
+  __shared__ uint32_t wtot[RS_BINS / WAVE];
+  const int wave = threadIdx.x / WAVE, lane = lane_id();
+  for (int j = threadIdx.x; j < RS_WAVES * RS_BINS; j += RS_THREADS) wcnt[j] = 0;
+  block_sync();
+  const uint32_t tile_base = blockIdx.x * RS_TILE;
+  const uint32_t wbase = tile_base + wave * (RS_ITEMS * WAVE);
+  const uint32_t last = n - 1;
+  uint64_t key[RS_ITEMS];
+  uint32_t val[RS_ITEMS], rank[RS_ITEMS];
+#pragma unroll
+  for (int r = 0; r < RS_ITEMS; ++r) {       // clamped, unconditional: the loads of a wave stay in flight together
+    const uint32_t i = wbase + r * WAVE + lane;
+    const uint32_t j = i < n ? i : last;
+    key[r] = keys_in[j];
+    val[r] = vals_in[j];
+  }
+  const unsigned long long lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
+#pragma unroll
+  for (int r = 0; r < RS_ITEMS; ++r) {
+    const bool live = wbase + r * WAVE + lane < n;
+    const uint32_t digit = (uint32_t)(key[r] >> shift) & 255u;
+    unsigned long long peers = __ballot(live);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const bool bit = (digit >> b) & 1;
+      const unsigned long long m = __ballot(bit);
+      peers &= bit ? m : ~m;
+    }
+    const int leader = __ffsll((long long)peers) - 1;   // peers of a dead lane is junk; it is never used
+    uint32_t old = 0;
+    if (live && lane == leader) old = atomicAdd(&wcnt[wave * RS_BINS + digit], (uint32_t)__popcll(peers));
+    old = __shfl(old, live ? leader : lane);
+    rank[r] = old + (uint32_t)__popcll(peers & lt);
+  }
+  block_sync();
+  uint32_t total = 0;
+  if (threadIdx.x < RS_BINS) {
+    for (int w = 0; w < RS_WAVES; ++w) {
+      const uint32_t c = wcnt[w * RS_BINS + threadIdx.x];
+      wcnt[w * RS_BINS + threadIdx.x] = total;
+      total += c;
+    }
+    const uint32_t incl = wave_scan_incl(total);
+    if (lane == WAVE - 1) wtot[wave] = incl;
+    binstart[threadIdx.x] = incl - total;        // wave-local for now
+  }
+  block_sync();
+  if (threadIdx.x < RS_BINS) {
+    uint32_t before = 0;
+    for (int w = 0; w < wave; ++w) before += wtot[w];
+    const uint32_t start = binstart[threadIdx.x] + before;
+    binstart[threadIdx.x] = start;
+    gbase[threadIdx.x] = offsets[threadIdx.x * ntiles + blockIdx.x] - start;
+  }
+  block_sync();
+#pragma unroll
+  for (int r = 0; r < RS_ITEMS; ++r) {
+    if (wbase + r * WAVE + lane < n) {
+      const uint32_t digit = (uint32_t)(key[r] >> shift) & 255u;
+      const uint32_t pos = binstart[digit] + wcnt[wave * RS_BINS + digit] + rank[r];
+      skey[pos] = key[r];
+      sval[pos] = val[r];
+    }
+  }
+  block_sync();
+  const uint32_t count = n - tile_base < (uint32_t)RS_TILE ? n - tile_base : (uint32_t)RS_TILE;
+  for (uint32_t j = threadIdx.x; j < count; j += RS_THREADS) {
+    const uint64_t k = skey[j];
+    const uint32_t dst = gbase[(uint32_t)(k >> shift) & 255u] + j;
+    keys_out[dst] = k;
+    vals_out[dst] = sval[j];
+  }
+}
+
+__global__ __launch_bounds__(256) void rs_iota(uint32_t *p, uint32_t n) {
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) p[i] = i;
+}
+__global__ __launch_bounds__(256) void rs_widen(const uint32_t *__restrict__ in, size_t *__restrict__ out, uint32_t n) {
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) out[i] = in[i];
+}
+
+// Sorted row permutation of table t (ascending, lexicographic, stable).  On return
+// perm holds n uint32 row numbers; if sorted_keys is non-null and the whole key fitted
+// one integer-only image, *sorted_keys keeps the sorted images (adjacent-equal test
+// without gathers) and *keys_exact is set.
+gdf_error order_rows(const KeyTable &t, uint32_t n, DevBuf &perm, DevBuf *sorted_keys, bool *keys_exact) {
+  if (keys_exact) *keys_exact = false;
+  // column groups, last columns first
+  std::vector<SortGroup> groups;
+  {
+    int c = t.ncols - 1;
+    while (c >= 0) {
+      SortGroup g{};
+      int bytes = 0, first = c;
+      while (first >= 0 && bytes + t.col[first].width <= 8 && c - first < 8) { bytes += t.col[first].width; --first; }
+      ++first;
+      int shift = bytes * 8;
+      for (int k = first; k <= c; ++k) {
+        shift -= t.col[k].width * 8;
+        g.data[g.ncols] = t.col[k].data;
+        g.kind[g.ncols] = t.col[k].kind;
+        g.shift[g.ncols] = shift;
+        ++g.ncols;
+      }
+      groups.push_back(g);
+      c = first - 1;
+    }
+  }
+  bool any_float = false;
+  for (int c = 0; c < t.ncols; ++c) any_float |= (t.col[c].kind == K_F32 || t.col[c].kind == K_F64);
+
+  DevBuf ka, kb, va, vb, counts, ghist;
+  RMM_TRY(ka.alloc(sizeof(uint64_t) * (size_t)n));
+  RMM_TRY(kb.alloc(sizeof(uint64_t) * (size_t)n));
+  RMM_TRY(va.alloc(sizeof(uint32_t) * (size_t)n));
+  RMM_TRY(vb.alloc(sizeof(uint32_t) * (size_t)n));
+  const uint32_t ntiles = (n + RS_TILE - 1) / RS_TILE;
+  RMM_TRY(counts.alloc(sizeof(uint32_t) * (size_t)ntiles * RS_BINS));
+  RMM_TRY(ghist.alloc(sizeof(unsigned long long)));
+  uint64_t *kin = ka.as<uint64_t>(), *kout = kb.as<uint64_t>();
+  uint32_t *vin = va.as<uint32_t>(), *vout = vb.as<uint32_t>();
+  const int sgrid = stream_grid(n, 256 * 8);
+  bool have_perm = false;
+  for (size_t gi = 0; gi < groups.size(); ++gi) {
+    // after the first group the current permutation lives in vin; keys are rebuilt in kin
+    // reading it, and the row numbers are rewritten in place (vals[i] = perm[i])
+    HIP_TRY(hipMemsetAsync(ghist.p, 0, sizeof(unsigned long long), stream0()));
+    GDF_LAUNCH("rs_make_keys", rs_make_keys, dim3(sgrid), dim3(256), 0, stream0(), groups[gi],
+               have_perm ? (const uint32_t *)vin : (const uint32_t *)nullptr, kin, vin, n, ghist.as<unsigned long long>());
+    have_perm = true;
+    unsigned long long varying = 0;
+    HIP_TRY(hipMemcpyAsync(&varying, ghist.p, sizeof(varying), hipMemcpyDeviceToHost, stream0()));
+    HIP_TRY(hipStreamSynchronize(stream0()));
+    for (int d = 0; d < RS_DIGITS; ++d) {
+      if (((varying >> (8 * d)) & 255ULL) == 0) continue;      // every key has the same digit d
+      GDF_LAUNCH("rs_count", rs_count, dim3(ntiles), dim3(RS_THREADS), 0, stream0(), kin, n, 8 * d, counts.as<uint32_t>(), ntiles);
+      GDF_TRY(scan_u32(counts.as<uint32_t>(), counts.as<uint32_t>(), (size_t)ntiles * RS_BINS, false));
+      GDF_LAUNCH("rs_scatter", rs_scatter, dim3(ntiles), dim3(RS_THREADS), 0, stream0(), kin, vin, kout, vout, n, 8 * d,
+                 counts.as<uint32_t>(), ntiles);
+      std::swap(kin, kout);
+      std::swap(vin, vout);
+    }
+  }
+  HIP_CHECK_LAST();
+  HIP_TRY(hipStreamSynchronize(stream0()));
+  // hand the buffers that ended up holding the result to the caller
+  if (vin == va.as<uint32_t>()) perm.p = va.release(); else perm.p = vb.release();
+  if (sorted_keys && groups.size() == 1 && !any_float) {
+    if (kin == ka.as<uint64_t>()) sorted_keys->p = ka.release(); else sorted_keys->p = kb.release();
+    *keys_exact = true;
+  }
+  return GDF_SUCCESS;
+}
+
+// ---------------------------------------------------------------------------
+// segmented reduction over the sorted rows
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sg_heads(KeyTable t, const uint32_t *__restrict__ perm, const uint64_t *__restrict__ sorted_keys,
+                                                uint32_t *__restrict__ head, uint32_t n) {
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    uint32_t hd = 1;
+    if (i > 0) {
+      if (sorted_keys) hd = sorted_keys[i] != sorted_keys[i - 1];
+      else hd = !rows_equal(t, perm[i - 1], t, perm[i]);
+    }
+    head[i] = hd;
+  }
+}
+// gid = inclusive scan of head (1-based); start[g] = first sorted position of group g
+__global__ __launch_bounds__(256) void sg_starts(const uint32_t *__restrict__ gid, uint32_t *__restrict__ start, uint32_t n, uint32_t ngroups) {
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+    if (i == 0 || gid[i] != gid[i - 1]) start[gid[i] - 1] = i;
+  if (blockIdx.x == 0 && threadIdx.x == 0) start[ngroups] = n;
+}
+
+__device__ __forceinline__ uint64_t sg_ord_i64(int64_t v) { return (uint64_t)v ^ 0x8000000000000000ULL; }
+__device__ __forceinline__ uint64_t sg_ord_f64(double d) {
+  const uint64_t b = (uint64_t)__double_as_longlong(d);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
+}
+__device__ __forceinline__ double sg_unord_f64(uint64_t u) {
+  const uint64_t b = (u >> 63) ? (u & 0x7fffffffffffffffULL) : ~u;
+  return __longlong_as_double((long long)b);
+}
+__device__ __forceinline__ bool sg_is_flt(int kind) { return kind == K_F32 || kind == K_F64; }
+
+// 64-bit image of one value: SUM/AVG integers as wrapped uint64, floats as double;
+// MIN/MAX as an order-preserving unsigned image
+__device__ __forceinline__ uint64_t sg_image(int op, const void *data, int kind, int64_t i) {
+  if (sg_is_flt(kind)) {
+    const double d = kind == K_F32 ? (double)((const float *)data)[i] : ((const double *)data)[i];
+    return (op == SG_MIN || op == SG_MAX) ? sg_ord_f64(d) : (uint64_t)__double_as_longlong(d);
+  }
+  int64_t v;
+  switch (kind) {
+    case K_I8: v = ((const int8_t *)data)[i]; break;
+    case K_I16: v = ((const int16_t *)data)[i]; break;
+    case K_I32: v = ((const int32_t *)data)[i]; break;
+    default: v = ((const int64_t *)data)[i]; break;
+  }
+  return (op == SG_MIN || op == SG_MAX) ? sg_ord_i64(v) : (uint64_t)v;
+}
+__device__ __forceinline__ uint64_t sg_fold(int op, bool flt, uint64_t a, uint64_t b) {
+  if (op == SG_MIN) return a < b ? a : b;
+  if (op == SG_MAX) return a > b ? a : b;
+  if (flt) return (uint64_t)__double_as_longlong(__longlong_as_double((long long)a) + __longlong_as_double((long long)b));
+  return a + b;
+}
+__device__ __forceinline__ void sg_flush(int op, bool flt, unsigned long long *acc, uint64_t v) {
+  if (op == SG_MIN) atomicMin(acc, (unsigned long long)v);
+  else if (op == SG_MAX) atomicMax(acc, (unsigned long long)v);
+  else if (flt) atomicAdd((double *)acc, __longlong_as_double((long long)v));
+  else atomicAdd(acc, (unsigned long long)v);
+}
+__device__ __forceinline__ uint64_t shfl_up64(uint64_t v, int d) {
+  const uint32_t lo = __shfl_up((uint32_t)v, d), hi = __shfl_up((uint32_t)(v >> 32), d);
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
+  const uint32_t lo = __shfl((uint32_t)v, l), hi = __shfl((uint32_t)(v >> 32), l);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+__global__ __launch_bounds__(256) void sg_fill(unsigned long long *p, unsigned long long v, uint32_t n) {
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) p[i] = v;
+}
+
+// acc[g] op= value of every sorted row of group g.  A wave walks 64 x SG_ROUNDS
+// consecutive sorted rows; per round a segmented inclusive shuffle scan on the group
+// id folds equal-id lanes, closed segments leave with one atomic, and the segment that
+// is still open at lane 63 rides along in (carry_gid, carry) into the next round.
+__global__ __launch_bounds__(SG_THREADS) void sg_reduce(const uint32_t *__restrict__ perm, const uint32_t *__restrict__ gid,
+                                                        const void *__restrict__ val, int kind, int op,
+                                                        unsigned long long *__restrict__ acc, uint32_t n) {
+  const bool flt = sg_is_flt(kind);
+  const int lane = lane_id();
+  const uint64_t wave_global = (uint64_t)blockIdx.x * (SG_THREADS / WAVE) + threadIdx.x / WAVE;
+  const uint64_t begin = wave_global * (uint64_t)(WAVE * SG_ROUNDS);
+  if (begin >= n) return;
+  uint32_t carry_gid = 0;      // 0 = no open segment (ids are 1-based)
+  uint64_t carry = 0;
+  for (int r = 0; r < SG_ROUNDS; ++r) {
+    const uint64_t i = begin + (uint64_t)r * WAVE + lane;
+    if (begin + (uint64_t)r * WAVE >= n) break;                 // wave-uniform
+    const bool live = i < n;
+    const uint32_t j = live ? (uint32_t)i : n - 1;
+    const uint32_t g = live ? gid[j] : 0xffffffffu;             // dead lanes form their own trailing segment
+    uint64_t v = sg_image(op, val, kind, perm[j]);
+    // segmented inclusive scan: fold lane-d's value when it belongs to the same group
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+      const uint64_t up = shfl_up64(v, d);
+      const uint32_t ug = __shfl_up(g, d);
+      if (lane >= d && ug == g) v = sg_fold(op, flt, v, up);
+    }
+    const uint32_t gnext = __shfl_down(g, 1);
+    const bool tail = (lane == WAVE - 1) || (gnext != g);       // last lane of its segment in this round
+    const uint32_t g0 = __shfl(g, 0);
+    // the carried segment either continues into lane 0's group or is finished
+    if (carry_gid != 0 && carry_gid != g0) {
+      if (lane == 0) sg_flush(op, flt, &acc[carry_gid - 1], carry);
+      carry_gid = 0;
+    }
+    if (tail && carry_gid != 0 && g == carry_gid) v = sg_fold(op, flt, v, carry);
+    const uint32_t glast = __shfl(g, WAVE - 1);
+    const uint64_t vlast = readlane64(v, WAVE - 1);
+    if (tail && live && lane != WAVE - 1) sg_flush(op, flt, &acc[g - 1], v);
+    if (glast != 0xffffffffu) { carry_gid = glast; carry = vlast; }
+    else carry_gid = 0;
+  }
+  if (carry_gid != 0 && lane == 0) sg_flush(op, flt, &acc[carry_gid - 1], carry);
+}
+
+struct SgOut {
+  void *agg;            // aggregation output
+  int agg_kind;         // dtype it is written in
+  size_t *indices;      // out_col_indices->data or null
+};
+
+template <class T>
+__device__ __forceinline__ void sg_store(void *out, uint32_t g, int op, bool flt, uint64_t a, uint32_t count) {
+  T r;
+  if (op == SG_COUNT || op == SG_COUNT_DISTINCT) r = (T)count;
+  else if (op == SG_MIN || op == SG_MAX) r = flt ? (T)sg_unord_f64(a) : (T)(int64_t)(a ^ 0x8000000000000000ULL);
+  else {
+    const T s = flt ? (T)__longlong_as_double((long long)a) : (T)(int64_t)a;
+    if (op == SG_AVG) { const T c = (T)count; r = (c != (T)0) ? (T)(s / c) : (T)0; }   // sum/static_cast<ValsT>(n)
+    else r = s;
+  }
+  ((T *)out)[g] = r;
+}
+
+__global__ __launch_bounds__(256) void sg_finalize(const unsigned long long *__restrict__ acc, const uint32_t *__restrict__ start,
+                                                   const uint32_t *__restrict__ perm, uint32_t ngroups, int op, int in_kind, SgOut o) {
+  for (uint32_t g = blockIdx.x * 256 + threadIdx.x; g < ngroups; g += gridDim.x * 256) {
+    const uint32_t s = start[g], e = start[g + 1];
+    if (o.indices) o.indices[g] = (size_t)perm[e - 1];
+    const uint64_t a = acc ? acc[g] : 0;
+    const bool flt = sg_is_flt(in_kind);
+    switch (o.agg_kind) {
+      case K_I8: sg_store<int8_t>(o.agg, g, op, flt, a, e - s); break;
+      case K_I16: sg_store<int16_t>(o.agg, g, op, flt, a, e - s); break;
+      case K_I32: sg_store<int32_t>(o.agg, g, op, flt, a, e - s); break;
+      case K_I64: sg_store<int64_t>(o.agg, g, op, flt, a, e - s); break;
+      case K_F32: sg_store<float>(o.agg, g, op, flt, a, e - s); break;
+      default: sg_store<double>(o.agg, g, op, flt, a, e - s); break;
+    }
+  }
+}
+
+// out[g] = in[perm[start[g + 1] - 1]]: the multi_gather_host of sqls_ops.cu:232-252
+__global__ __launch_bounds__(256) void sg_gather(const uint32_t *__restrict__ start, const uint32_t *__restrict__ perm, uint32_t ngroups,
+                                                 int width, const void *__restrict__ in, void *__restrict__ out) {
+  for (uint32_t g = blockIdx.x * 256 + threadIdx.x; g < ngroups; g += gridDim.x * 256) {
+    const uint32_t s = perm[start[g + 1] - 1];
+    switch (width) {
+      case 1: ((uint8_t *)out)[g] = ((const uint8_t *)in)[s]; break;
+      case 2: ((uint16_t *)out)[g] = ((const uint16_t *)in)[s]; break;
+      case 4: ((uint32_t *)out)[g] = ((const uint32_t *)in)[s]; break;
+      default: ((uint64_t *)out)[g] = ((const uint64_t *)in)[s]; break;
+    }
+  }
+}
+__global__ void sg_store_count(void *out, int kind, uint32_t v) {
+  switch (kind) {
+    case K_I8: *(int8_t *)out = (int8_t)v; break;
+    case K_I16: *(int16_t *)out = (int16_t)v; break;
+    case K_I32: *(int32_t *)out = (int32_t)v; break;
+    case K_I64: *(int64_t *)out = (int64_t)v; break;
+    case K_F32: *(float *)out = (float)v; break;
+    default: *(double *)out = (double)v; break;
+  }
+}
+
+// sqls_ops.cu:1134-1289.  Inputs were validated by group_by_single (groupby.hip).
+gdf_error group_by_sort(int ncols, gdf_column **cols, gdf_column *col_agg, gdf_column *out_col_indices,
+                        gdf_column **out_col_values, gdf_column *out_col_agg, gdf_context *ctxt, int op) {
+  KeyTable t;
+  GDF_TRY(make_key_table(cols, ncols, &t));
+  for (int c = 0; c < ncols; ++c) GDF_REQUIRE(cols[c]->size == cols[0]->size, GDF_COLUMN_SIZE_MISMATCH);
+  GDF_REQUIRE(cols[0]->size < (size_t)0x7fffffff, GDF_COLUMN_SIZE_TOO_BIG);
+  const uint32_t n = (uint32_t)cols[0]->size;
+  const bool counting = (op == SG_COUNT || op == SG_COUNT_DISTINCT);
+  const ElemKind in_kind = elem_kind(col_agg->dtype);
+  // SUM/MIN/MAX/AVG dispatch on the input dtype and write that dtype (sqls_ops.cu:411-1083);
+  // COUNT dispatches on the output column's dtype (:272-400)
+  const ElemKind out_kind = counting ? elem_kind(out_col_agg->dtype) : in_kind;
+  if (counting) GDF_REQUIRE(out_kind != K_BAD && out_col_agg->dtype <= GDF_FLOAT64, GDF_UNSUPPORTED_DTYPE);
+  else {
+    GDF_REQUIRE(in_kind != K_BAD && col_agg->dtype <= GDF_FLOAT64, GDF_UNSUPPORTED_DTYPE);
+    GDF_REQUIRE(col_agg->size == cols[0]->size, GDF_COLUMN_SIZE_MISMATCH);
+  }
+  GDF_REQUIRE(out_col_agg->data != nullptr, GDF_DATASET_EMPTY);
+
+  DevBuf perm, sorted_keys;
+  bool keys_exact = false;
+  if (ctxt->flag_sorted) {
+    RMM_TRY(perm.alloc(sizeof(uint32_t) * (size_t)n));
+    GDF_LAUNCH("rs_iota", rs_iota, dim3(stream_grid(n, 1024)), dim3(256), 0, stream0(), perm.as<uint32_t>(), n);
+  } else {
+    GDF_TRY(order_rows(t, n, perm, &sorted_keys, &keys_exact));
+  }
+  DevBuf gid, start, acc;
+  RMM_TRY(gid.alloc(sizeof(uint32_t) * (size_t)n));
+  const int grid = stream_grid(n, 256 * 4);
+  GDF_LAUNCH("sg_heads", sg_heads, dim3(grid), dim3(256), 0, stream0(), t, perm.as<uint32_t>(),
+             keys_exact ? sorted_keys.as<uint64_t>() : (const uint64_t *)nullptr, gid.as<uint32_t>(), n);
+  GDF_TRY(scan_u32(gid.as<uint32_t>(), gid.as<uint32_t>(), n, true));
+  uint32_t ngroups = 0;
+  HIP_TRY(hipMemcpyAsync(&ngroups, gid.as<uint32_t>() + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream0()));
+  HIP_TRY(hipStreamSynchronize(stream0()));
+  sorted_keys.reset();
+  RMM_TRY(start.alloc(sizeof(uint32_t) * ((size_t)ngroups + 1)));
+  GDF_LAUNCH("sg_starts", sg_starts, dim3(grid), dim3(256), 0, stream0(), gid.as<uint32_t>(), start.as<uint32_t>(), n, ngroups);
+  if (!counting) {
+    RMM_TRY(acc.alloc(sizeof(unsigned long long) * (size_t)ngroups));
+    GDF_LAUNCH("sg_fill", sg_fill, dim3(stream_grid(ngroups, 1024)), dim3(256), 0, stream0(), acc.as<unsigned long long>(),
+               op == SG_MIN ? ~0ULL : 0ULL, ngroups);
+    const uint32_t per_block = WAVE * SG_ROUNDS * (SG_THREADS / WAVE);
+    GDF_LAUNCH("sg_reduce", sg_reduce, dim3((n + per_block - 1) / per_block), dim3(SG_THREADS), 0, stream0(), perm.as<uint32_t>(),
+               gid.as<uint32_t>(), (const void *)col_agg->data, (int)in_kind, op, acc.as<unsigned long long>(), n);
+  }
+  SgOut o{out_col_agg->data, (int)out_kind, out_col_indices ? (size_t *)out_col_indices->data : nullptr};
+  const int ggrid = stream_grid(ngroups, 256);
+  GDF_LAUNCH("sg_finalize", sg_finalize, dim3(ggrid), dim3(256), 0, stream0(),
+             counting ? (const unsigned long long *)nullptr : acc.as<unsigned long long>(), start.as<uint32_t>(),
+             perm.as<uint32_t>(), ngroups, op, (int)in_kind, o);
+  size_t reported = ngroups;
+  if (op == SG_COUNT_DISTINCT) {
+    hipLaunchKernelGGL(sg_store_count, dim3(1), dim3(1), 0, stream0(), out_col_agg->data, (int)out_kind, ngroups);
+    reported = 1;
+  }
+  if (out_col_values)
+    for (int c = 0; c < ncols; ++c) {
+      if (!out_col_values[c] || !out_col_values[c]->data) continue;
+      GDF_LAUNCH("sg_gather", sg_gather, dim3(ggrid), dim3(256), 0, stream0(), start.as<uint32_t>(), perm.as<uint32_t>(),
+                 (uint32_t)reported, t.col[c].width, t.col[c].data, out_col_values[c]->data);
+      out_col_values[c]->size = reported;
+    }
+  HIP_CHECK_LAST();
+  HIP_TRY(hipStreamSynchronize(stream0()));
+  out_col_agg->size = reported;
+  if (out_col_indices) out_col_indices->size = reported;
+  return GDF_SUCCESS;
+}
+
+}  // namespace gdf_amd
+
+using namespace gdf_amd;
+
+extern "C" {
+
+// sqls_ops.cu:1373-1392.  `cols` is a host ARRAY of gdf_column (not pointers); d_cols /
+// d_types are caller-provided device scratch that the reference fills with the data
+// pointers / dtypes, and so do we; d_indx receives the sorted row numbers as size_t.
+gdf_error gdf_order_by(size_t nrows, gdf_column *cols, size_t ncols, void **d_cols, int *d_types, size_t *d_indx) {
+  GDF_REQUIRE(cols != nullptr && ncols > 0, GDF_DATASET_EMPTY);
+  GDF_REQUIRE(!cols->valid, GDF_VALIDITY_UNSUPPORTED);
+  GDF_REQUIRE(ncols <= (size_t)MAX_KEY_COLS, GDF_JOIN_TOO_MANY_COLUMNS);
+  GDF_REQUIRE(nrows < (size_t)0x7fffffff, GDF_COLUMN_SIZE_TOO_BIG);
+  std::vector<gdf_column *> ptrs(ncols);
+  std::vector<void *> h_cols(ncols);
+  std::vector<int> h_types(ncols);
+  for (size_t c = 0; c < ncols; ++c) {
+    ptrs[c] = &cols[c];
+    h_cols[c] = cols[c].data;
+    h_types[c] = (int)cols[c].dtype;
+  }
+  if (d_cols) HIP_TRY(hipMemcpy(d_cols, h_cols.data(), sizeof(void *) * ncols, hipMemcpyHostToDevice));
+  if (d_types) HIP_TRY(hipMemcpy(d_types, h_types.data(), sizeof(int) * ncols, hipMemcpyHostToDevice));
+  if (nrows == 0) return GDF_SUCCESS;
+  GDF_REQUIRE(d_indx != nullptr, GDF_DATASET_EMPTY);
+  for (size_t c = 0; c < ncols; ++c) GDF_REQUIRE(cols[c].data != nullptr, GDF_DATASET_EMPTY);
+  KeyTable t;
+  GDF_TRY(make_key_table(ptrs.data(), (int)ncols, &t));
+  DevBuf perm;
+  GDF_TRY(order_rows(t, (uint32_t)nrows, perm, nullptr, nullptr));
+  GDF_LAUNCH("rs_widen", rs_widen, dim3(stream_grid(nrows, 1024)), dim3(256), 0, stream0(), perm.as<uint32_t>(), d_indx, (uint32_t)nrows);
+  HIP_CHECK_LAST();
+  HIP_TRY(hipStreamSynchronize(stream0()));
+  return GDF_SUCCESS;
+}
+
+}  // extern "C"

@@ -136,6 +136,66 @@ def group_by(op, keys, values, out_dtype=None):
     return [k[:g] for k in out_keys], out_agg[:g]
 
 
+# ---- SORT method (sqls_ops.cu:1134-1289, 1373-1392; sqls_rtti_comp.hpp:299-320, 397-662) --------------
+def order_by(cols) -> np.ndarray:
+    """Row permutation that orders the rows lexicographically by (cols[0], cols[1], ...) with typed ``<``
+    (LesserRTTI::less, sqls_rtti_comp.hpp:99-126; multi_col_order_by :299-320).  thrust::sort is unstable, so
+    the order of equal rows is unspecified in the reference; this restatement (like the library) is stable."""
+    return np.lexsort(tuple(np.ascontiguousarray(c) for c in reversed(list(cols)))).astype(np.int64)
+
+
+def group_by_sort(op, keys, values, out_dtype=None, distinct=False):
+    """GDF_SORT group-by: (key arrays in ascending order, aggregate, row index per group).
+
+    sort (multi_col_order_by) -> gather of the aggregation column -> reduce_by_key with LesserRTTI::equal
+    (sqls_rtti_comp.hpp:487-522).  SUM/MIN/MAX/AVG compute in the INPUT dtype, AVG = sum / (ValsT)count
+    (:651-657, C++ division: truncating for integers); COUNT counts in the OUTPUT dtype (sqls_ops.cu:272-400);
+    COUNT_DISTINCT stores the number of groups in element 0 and reports one row (rtti header :440-446).  The
+    row index of a group is its LAST row in input order (reference known-answer: sqls_g_tester.cu:250-256)."""
+    keys = _contig(keys)
+    values = np.ascontiguousarray(values)
+    n = len(keys[0])
+    perm = order_by(keys)
+    if n == 0:
+        return [k[:0] for k in keys], values[:0], perm
+    head = np.zeros(n, dtype=bool)
+    head[0] = True
+    for k in keys:
+        ks = k[perm]
+        head[1:] |= ~(ks[1:] == ks[:-1])             # typed ==: NaN never equal, -0.0 == +0.0
+    starts = np.flatnonzero(head)
+    ends = np.append(starts[1:], n)
+    counts = ends - starts
+    idx = perm[ends - 1]
+    out_keys = [k[idx] for k in keys]
+    vs = values[perm]
+    T = values.dtype
+    with np.errstate(over="ignore", invalid="ignore"):
+        if op == "count":
+            out_dtype = np.dtype(T if out_dtype is None else out_dtype)
+            if distinct:
+                return [k[:1] for k in out_keys], np.array([len(starts)]).astype(out_dtype), idx[:1]
+            agg = counts.astype(out_dtype)
+        elif op == "sum":
+            agg = np.add.reduceat(vs, starts, dtype=T)
+        elif op == "min":
+            agg = np.minimum.reduceat(vs, starts)
+        elif op == "max":
+            agg = np.maximum.reduceat(vs, starts)
+        elif op == "avg":
+            sums = np.add.reduceat(vs, starts, dtype=T)
+            c = counts.astype(T)
+            if T.kind == "f":
+                agg = (sums / c).astype(T)
+            else:                                    # C++ integer division truncates toward zero
+                si, ci = sums.astype(np.int64), c.astype(np.int64)
+                q = np.where(ci != 0, np.abs(si) // np.maximum(np.abs(ci), 1), 0) * np.sign(si) * np.sign(ci)
+                agg = q.astype(T)
+        else:
+            raise ValueError(op)
+    return out_keys, agg, idx
+
+
 # ---- numpy expectations -------------------------------------------------------------------------
 def prefixsum(a: np.ndarray, inclusive=True) -> np.ndarray:
     """np.cumsum in the column dtype (wraps), reference python/tests/test_prefixsum.py:55."""

@@ -270,3 +270,34 @@ def test_every_partition_oversize_uses_one_global_table(gdf):
     assert li.numel() == hits
     assert torch.equal(build[ri.long()], probe[li.long()])
     assert torch.unique(li).numel() == hits
+
+
+@pytest.mark.parametrize("how", ["inner", "left"])
+@pytest.mark.parametrize("dtype", [np.int8, np.int16, np.int32, np.int64, np.float32, np.float64], ids=lambda d: np.dtype(d).name)
+def test_sort_method_single_column(gdf, how, dtype):
+    """GDF_SORT joins (joining.cu:100-159): one column, same pair SET as the hash method; floats compare by bit
+    pattern there (FLOAT32/64 dispatch to int32_t/int64_t), so +0.0 != -0.0 and equal-bit NaNs match."""
+    from libgdf_amd.columns import GDF_SORT
+    l = _gen([dtype], 8000, 1500)[0]
+    r = _gen([dtype], 6000, 1500)[0]
+    if np.dtype(dtype).kind == "f":
+        l[:4] = [0.0, -0.0, np.nan, 1.0]
+        r[:3] = [-0.0, np.nan, 0.0]
+    li, ri = gdf.api.join(_cols([l]), _cols([r]), how=how, method=GDF_SORT)
+    as_int = {4: np.int32, 8: np.int64}.get(np.dtype(dtype).itemsize) if np.dtype(dtype).kind == "f" else None
+    el, er = oracle.join([l.view(as_int) if as_int else l], [r.view(as_int) if as_int else r], how)
+    a, b = sort_pairs(li.cpu().numpy(), ri.cpu().numpy())
+    c, d = sort_pairs(el, er)
+    np.testing.assert_array_equal(a, c)
+    np.testing.assert_array_equal(b, d)
+
+
+def test_sort_method_rules(gdf):
+    from libgdf_amd import GDFError
+    from libgdf_amd.columns import GDF_SORT, column_from_numpy
+    k = gen_rand(np.int32, 50, 0, 10)
+    masked = column_from_numpy(k, np.ones(50, dtype=bool))
+    with pytest.raises(GDFError, match="GDF_VALIDITY_UNSUPPORTED"):      # joining.cu:105-106
+        gdf.api.join([masked], _cols([k]), method=GDF_SORT)
+    li, ri = gdf.api.join(_cols([k]), _cols([k]), how="full", method=GDF_SORT)   # generic SortJoin: empty result (joining.cu:66-75)
+    assert li.numel() == 0 and ri.numel() == 0

@@ -1,0 +1,228 @@
+"""-m gpu: gdf_order_by and the GDF_SORT group-by (sort.hip) through the C ABI vs the oracle.
+
+Cases follow the reference's tests/sqls/sqls_g_tester.cu:114-865 and tests/cpp/sqls_tester.cu:834-895 (their
+known-answer vectors are replayed bit for bit, including the row index per group) plus randomized inputs
+checked against oracle.group_by_sort / oracle.order_by.  Integer results are bit-exact and so is the output
+ORDER (ascending lexicographic); float sums within 1e-6 of the group's sum of magnitudes."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from util import gen_rand
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-6
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _cols(arrs):
+    from libgdf_amd.columns import column_from_numpy
+    return [column_from_numpy(a) for a in arrs]
+
+
+def _run(gdf, op, keys, vals, out_dtype=None, **kw):
+    from libgdf_amd.columns import GDF_SORT, get_dtype
+    od = None if out_dtype is None else get_dtype(out_dtype)
+    k, a, i = gdf.api.group_by(op, _cols(keys), _cols([vals])[0], out_dtype=od, method=GDF_SORT, with_indices=True, **kw)
+    return [x.cpu().numpy() for x in k], a.cpu().numpy(), i.cpu().numpy()
+
+
+def _check(gdf, op, keys, vals, out_dtype=None):
+    gk, ga, gi = _run(gdf, op, keys, vals, out_dtype)
+    ek, ea, ei = oracle.group_by_sort(op, keys, vals, out_dtype)
+    assert len(ga) == len(ea)
+    for g, e in zip(gk, ek):
+        np.testing.assert_array_equal(g, e)                    # same rows in the same (sorted) order
+    np.testing.assert_array_equal(gi, ei)
+    assert ga.dtype == ea.dtype
+    if op in ("sum", "avg") and np.asarray(vals).dtype.kind == "f":
+        _, mag, _ = oracle.group_by_sort("sum", keys, np.abs(np.asarray(vals, dtype=np.float64)))
+        if op == "avg":
+            _, cnt, _ = oracle.group_by_sort("count", keys, vals, np.int64)
+            mag = mag / cnt
+        err = np.abs(ga.astype(np.float64) - ea.astype(np.float64))
+        assert np.all(err <= RTOL * mag + 1e-300), np.max(err / (mag + 1e-300))
+    else:
+        np.testing.assert_array_equal(ga, ea)
+
+
+@pytest.fixture(scope="module")
+def sqls():
+    with open(os.path.join(GOLD, "sqls_known_answers.json")) as f:
+        return json.load(f)
+
+
+def test_reference_known_answers(gdf, sqls):
+    g = sqls["group_by"]
+    keys = [np.array(g["keys"][c]["values"], dtype=g["keys"][c]["dtype"]) for c in ("c0", "c1", "c2")]
+    for case in g["cases"]:
+        vals = np.array(case["agg"]["values"], dtype=case["agg"]["dtype"])
+        gk, ga, gi = _run(gdf, case["op"], keys, vals, case["out_dtype"])
+        for c, name in zip(gk, ("c0", "c1", "c2")):
+            assert list(c) == g["expected_keys"][name], case["ref"]
+        assert list(ga) == case["expected"], case["ref"]
+        assert list(gi) == g["expected_first_rows"], case["ref"]
+
+
+def test_order_by_known_answer(gdf, sqls):
+    ob = sqls["order_by"]
+    cols = [np.array(ob["cols"]["c0"], dtype=np.int32), np.array(ob["cols"]["c1"], dtype=np.int32),
+            np.array(ob["cols"]["c2"], dtype=np.float64)]
+    assert gdf.api.order_by(_cols(cols)).cpu().tolist() == ob["expected_permutation"]
+
+
+OPS = ["sum", "min", "max", "count", "avg"]
+AGG_DTYPES = [np.int8, np.int16, np.int32, np.int64, np.float32, np.float64]
+
+
+@pytest.mark.parametrize("op", OPS)
+@pytest.mark.parametrize("agg_dtype", AGG_DTYPES, ids=lambda d: np.dtype(d).name)
+def test_single_int32_key(gdf, op, agg_dtype):
+    n = 30000
+    keys = [gen_rand(np.int32, n, 0, 200)]
+    vals = gen_rand(agg_dtype, n, -100, 100)
+    _check(gdf, op, keys, vals, np.int64 if op == "count" else None)
+
+
+@pytest.mark.parametrize("op", OPS)
+@pytest.mark.parametrize("key_dtypes", [[np.int64], [np.int32, np.int32], [np.int64, np.int32], [np.int8, np.int16, np.int32],
+                                        [np.float64], [np.int32, np.float32], [np.int64, np.int64, np.int64],
+                                        [np.float32, np.int8, np.float64, np.int16]],
+                         ids=lambda d: "-".join(np.dtype(x).name for x in d))
+def test_key_shapes(gdf, op, key_dtypes):
+    n = 20000
+    keys = [gen_rand(dt, n, -6, 6) if np.dtype(dt).kind == "i" else np.round(gen_rand(dt, n) * 6).astype(dt) for dt in key_dtypes]
+    vals = gen_rand(np.float64 if op != "count" else np.int32, n)
+    _check(gdf, op, keys, vals, np.int32 if op == "count" else None)
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 4095, 4096, 4097, 100000])
+def test_sizes_and_tile_edges(gdf, n):
+    keys = [gen_rand(np.int64, n, -50, 50)]
+    _check(gdf, "sum", keys, gen_rand(np.int64, n))
+    _check(gdf, "min", keys, gen_rand(np.int32, n))
+
+
+@pytest.mark.parametrize("shape", ["all_same", "all_different", "wave_same", "block_same", "two_big_groups"])
+def test_group_shapes(gdf, shape):
+    """tests/groupby/groupby-test.cu:369-445 (AllKeysSame / AllKeysDifferent / WarpKeysSame / BlockKeysSame)."""
+    n = 50000
+    i = np.arange(n)
+    k = {"all_same": np.zeros(n), "all_different": np.random.permutation(n), "wave_same": i // 64, "block_same": i // 256,
+         "two_big_groups": (np.random.random(n) < 0.5)}[shape].astype(np.int32)
+    np.random.shuffle(k)
+    for op in OPS:
+        _check(gdf, op, [k], gen_rand(np.float64, n), np.int32 if op == "count" else None)
+        _check(gdf, op, [k], gen_rand(np.int32, n), np.int32 if op == "count" else None)
+
+
+def test_full_range_keys_all_eight_digits(gdf):
+    n = 200000
+    k = np.random.randint(np.iinfo(np.int64).min, np.iinfo(np.int64).max, size=n, dtype=np.int64)
+    k[::7] = k[3]                                              # some duplicates
+    _check(gdf, "sum", [k], gen_rand(np.int64, n))
+    perm = gdf.api.order_by(_cols([k])).cpu().numpy()
+    np.testing.assert_array_equal(perm, oracle.order_by([k]))
+
+
+@pytest.mark.parametrize("dtypes", [[np.int8], [np.int16], [np.int32], [np.int64], [np.float32], [np.float64],
+                                    [np.int32, np.float64], [np.int8, np.int8, np.int64, np.float32]],
+                         ids=lambda d: "-".join(np.dtype(x).name for x in d))
+def test_order_by_random(gdf, dtypes):
+    n = 70001
+    cols = [gen_rand(dt, n, -40, 40) if np.dtype(dt).kind == "i" else np.round(gen_rand(dt, n) * 20).astype(dt) / 4 for dt in dtypes]
+    perm = gdf.api.order_by(_cols(cols)).cpu().numpy()
+    np.testing.assert_array_equal(perm, oracle.order_by(cols))   # stable on both sides: identical, not just equivalent
+
+
+def test_order_by_float_specials(gdf):
+    c = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1.5, -1.5, -0.0, 0.0, np.nan, 3e300, -3e300, 5e-324, -5e-324])
+    for dt in (np.float64, np.float32):
+        with np.errstate(over="ignore"):
+            col = c.astype(dt)
+        perm = gdf.api.order_by(_cols([col])).cpu().numpy()
+        np.testing.assert_array_equal(perm, oracle.order_by([col]))   # -0.0 == +0.0 keep input order; NaN last
+
+
+def test_nan_keys_are_singleton_groups(gdf):
+    k = np.array([1.0, np.nan, 1.0, np.nan, -0.0, 0.0], dtype=np.float64)
+    v = np.arange(6, dtype=np.int32)
+    gk, ga, gi = _run(gdf, "sum", [k], v)
+    assert len(ga) == 4 and list(ga) == [4 + 5, 0 + 2, 1, 3] and list(gi) == [5, 2, 1, 3]
+    _check(gdf, "count", [k], v, np.int32)
+
+
+def test_count_distinct(gdf):
+    n = 10000
+    keys = [gen_rand(np.int32, n, 0, 37), gen_rand(np.int16, n, 0, 3)]
+    vals = gen_rand(np.int32, n)
+    gk, ga, gi = _run(gdf, "count", keys, vals, np.int64, distinct=True)
+    ek, ea, ei = oracle.group_by_sort("count", keys, vals, np.int64, distinct=True)
+    assert len(ga) == 1 and ga[0] == ea[0] == len(set(zip(*[k.tolist() for k in keys])))
+    assert len(gi) == 1 and gi[0] == ei[0]
+    for g, e in zip(gk, ek):
+        np.testing.assert_array_equal(g, e)
+
+
+def test_count_distinct_is_sort_only(gdf):
+    from libgdf_amd import GDFError
+    keys, vals = _cols([gen_rand(np.int32, 100)]), _cols([gen_rand(np.int32, 100)])[0]
+    with pytest.raises(GDFError, match="GDF_UNSUPPORTED_METHOD"):       # sqls_ops.cu:1347-1349
+        gdf.api.group_by("count", keys, vals, distinct=True)
+
+
+def test_presorted_input_skips_the_sort(gdf):
+    n = 5000
+    k = np.sort(gen_rand(np.int32, n, 0, 50))
+    v = gen_rand(np.int64, n)
+    gk, ga, gi = _run(gdf, "sum", [k], v, presorted=True)
+    ek, ea, ei = oracle.group_by_sort("sum", [k], v)
+    np.testing.assert_array_equal(gk[0], ek[0])
+    np.testing.assert_array_equal(ga, ea)
+    np.testing.assert_array_equal(gi, ei)
+
+
+def test_int8_wraps_and_integer_average_truncates(gdf):
+    keys = [np.zeros(5, dtype=np.int32)]
+    vals = np.array([100, 100, 100, 27, -3], dtype=np.int8)             # 324 -> 68 (mod 256); 68 / 5 = 13
+    _, s, _ = _run(gdf, "sum", keys, vals)
+    _, a, _ = _run(gdf, "avg", keys, vals)
+    assert s.dtype == np.int8 and s[0] == 68 and a.dtype == np.int8 and a[0] == 13
+    neg = np.array([-7, -8], dtype=np.int32)                            # -15 / 2 = -7 in C++ (truncation), not -8
+    _, a, _ = _run(gdf, "avg", [np.zeros(2, dtype=np.int32)], neg)
+    assert a[0] == -7
+    _check(gdf, "avg", [gen_rand(np.int32, 3000, 0, 9)], gen_rand(np.int32, 3000, -50, 50))
+
+
+def test_errors_and_empty(gdf):
+    from libgdf_amd import GDFError
+    from libgdf_amd.columns import GDF_SORT, column_from_numpy
+    k = gen_rand(np.int32, 10)
+    masked = column_from_numpy(k, np.ones(10, dtype=bool))
+    with pytest.raises(GDFError, match="GDF_VALIDITY_UNSUPPORTED"):
+        gdf.api.group_by("sum", [masked], _cols([k])[0], method=GDF_SORT)
+    with pytest.raises(GDFError, match="GDF_VALIDITY_UNSUPPORTED"):
+        gdf.api.order_by([masked])
+    gk, ga, gi = _run(gdf, "sum", [np.zeros(0, dtype=np.int32)], np.zeros(0, dtype=np.int32))
+    assert len(ga) == 0 and len(gi) == 0 and len(gk[0]) == 0
+    assert gdf.api.order_by(_cols([np.zeros(0, dtype=np.int64)])).numel() == 0
+
+
+def test_large_sort_properties(gdf):
+    """1e7 rows: sortedness, permutation and checksum properties (size-independent), plus SORT == HASH aggregates."""
+    import torch
+    n = 10_000_000
+    k = torch.randint(0, 1 << 40, (n,), dtype=torch.int64, device="cuda")
+    from libgdf_amd.columns import GDF_SORT, Column
+    perm = gdf.api.order_by([Column(k)])
+    s = k[perm]
+    assert bool((s[1:] >= s[:-1]).all())
+    assert int(perm.sum()) == n * (n - 1) // 2 and int(torch.unique(perm).numel()) == n
+    kk = k % 100_003
+    v = torch.randint(-1000, 1000, (n,), dtype=torch.int64, device="cuda")
+    sk, sa = gdf.api.group_by("sum", [Column(kk)], Column(v), method=GDF_SORT)
+    hk, ha = gdf.api.group_by("sum", [Column(kk)], Column(v), sort_result=True)
+    assert torch.equal(sk[0], hk[0]) and torch.equal(sa, ha) and int(sa.sum()) == int(v.sum())

@@ -106,6 +106,35 @@ def test_group_by_known_answers(sqls):
         assert list(agg) == case["expected"], case["ref"]
 
 
+def test_sort_method_known_answers(sqls):
+    """GDF_SORT restatement (oracle.group_by_sort / order_by) vs the reference's own vectors, INCLUDING the row
+    index per group (sqls_g_tester.cu:250-256) and the order-by permutation (sqls_tests_new_api.dat:1-2)."""
+    g = sqls["group_by"]
+    keys = [np.array(g["keys"][c]["values"], dtype=g["keys"][c]["dtype"]) for c in ("c0", "c1", "c2")]
+    for case in g["cases"]:
+        vals = np.array(case["agg"]["values"], dtype=case["agg"]["dtype"])
+        out_keys, agg, idx = oracle.group_by_sort(case["op"], keys, vals, out_dtype=case["out_dtype"])
+        for c, name in zip(out_keys, ("c0", "c1", "c2")):
+            assert list(c) == g["expected_keys"][name], case["ref"]
+        assert list(agg) == case["expected"], case["ref"]
+        assert list(idx) == g["expected_first_rows"], case["ref"]
+    ob = sqls["order_by"]
+    cols = [np.array(ob["cols"]["c0"], dtype=np.int32), np.array(ob["cols"]["c1"], dtype=np.int32),
+            np.array(ob["cols"]["c2"], dtype=np.float64)]
+    assert list(oracle.order_by(cols)) == ob["expected_permutation"]
+
+
+def test_sort_and_hash_restatements_agree():
+    keys = [np.random.randint(0, 7, 500).astype(np.int32), np.random.randint(-3, 3, 500).astype(np.int8)]
+    for op, dt, od in (("sum", np.int64, None), ("min", np.float32, None), ("max", np.int16, None), ("count", np.int32, np.int64)):
+        vals = (np.random.random(500) * 200 - 100).astype(dt)
+        hk, ha = oracle.group_by(op, keys, vals, od)
+        sk, sa, _ = oracle.group_by_sort(op, keys, vals, od)
+        for a, b in zip(hk, sk):
+            np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(ha, sa)
+
+
 def test_filter_known_answer(sqls):
     f = sqls["filter"]
     cols = [np.array(f["cols"][c]["values"], dtype=f["cols"][c]["dtype"]) for c in ("c0", "c1", "c2")]

@@ -17,7 +17,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=100_000_000)
     ap.add_argument("--groups", type=int, default=10_000)
-    ap.add_argument("--ops", default="groupby,partition,scan,filter,hash")
+    ap.add_argument("--ops", default="groupby,partition,scan,filter,hash,sort")
     ap.add_argument("--reps", type=int, default=5)
     a = ap.parse_args()
     import torch
@@ -52,6 +52,15 @@ def main():
         kc, vc = Column(keys), Column(vals)
         for op in ("sum", "avg"):
             timed(f"gdf_group_by_{op} int64 keys, {a.groups} groups, int64 values", lambda: gdf.api.group_by(op, [kc], vc, capacity=1 << 20), 16.0 * n)
+    if "sort" in ops:
+        from libgdf_amd.columns import GDF_SORT
+        kc, vc = Column(keys), Column(vals)
+        wide = Column(make_probe_keys(n, 1 << 62, 0x5EED0005, dev))
+        timed(f"gdf_order_by int64, {a.groups} distinct values", lambda: gdf.api.order_by([kc]), 16.0 * n,
+              {"note": "bytes = keys read + size_t permutation written"})
+        timed("gdf_order_by int64, 62-bit keys (8 digit passes)", lambda: gdf.api.order_by([wide]), 16.0 * n)
+        timed(f"gdf_group_by_sum GDF_SORT int64 keys, {a.groups} groups, int64 values",
+              lambda: gdf.api.group_by("sum", [kc], vc, capacity=1 << 20, method=GDF_SORT), 16.0 * n)
     if "hash" in ops:
         kc = Column(keys)
         timed("gdf_hash int64 -> int32", lambda: gdf.api.hash_rows([kc]), 12.0 * n)

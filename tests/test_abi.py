@@ -96,7 +96,7 @@ def test_out_of_scope_entry_points_report_unsupported(libs):
     gdf, _ = libs
     assert gdf.gdf_sin_f32(None, None) == 12          # GDF_UNSUPPORTED_METHOD
     assert gdf.gdf_add_i32(None, None, None) == 12
-    assert gdf.gdf_order_by(0, None, 0, None, None, None) == 12
+    assert gdf.gdf_radixsort_i32(None, None, None) == 12
 
 
 def test_host_side_argument_errors_need_no_gpu(libs):
@@ -108,6 +108,7 @@ def test_host_side_argument_errors_need_no_gpu(libs):
     assert gdf.gdf_group_by_sum(0, None, None, None, None, None, None) == 5
     assert gdf.gdf_hash_partition(0, None, None, 0, 0, None, None, 0) == 8                            # GDF_INVALID_API_CALL
     assert gdf.gdf_hash(0, None, 0, None) == 5
+    assert gdf.gdf_order_by(0, None, 0, None, None, None) == 5
     a, b = gdf_column(), gdf_column()
     a.size, b.size, a.dtype, b.dtype = 4, 5, 3, 3
     assert gdf.gdf_prefixsum_i32(C.byref(a), C.byref(b), 1) == 3                                      # GDF_COLUMN_SIZE_MISMATCH

@@ -62,27 +62,37 @@ _GROUPBY = {"sum": "gdf_group_by_sum", "min": "gdf_group_by_min", "max": "gdf_gr
 
 
 def group_by(op, keys, values, out_dtype: int | None = None, sort_result=False, method=GDF_HASH, capacity=None,
-             with_indices=False, distinct=False, presorted=False):
+             with_indices=False, distinct=False, presorted=False, with_masks=False):
     """gdf_group_by_<op> -> (list of key tensors, aggregate tensor), trimmed to the number of groups.
 
     Outputs are preallocated by the caller with capacity N rows, as the reference's tests do
     (tests/groupby/groupby-test.cu:127).  ``with_indices`` also passes ``out_col_indices`` (size_t row
-    numbers, filled by the GDF_SORT method only) and returns it as a third int64 tensor.
+    numbers, filled by the GDF_SORT method only) and returns it as a third int64 tensor.  ``with_masks`` gives
+    every output column a validity buffer and returns the aggregate's valid bits as a bool tensor (the
+    mask-aware HASH group-by, an extension over the reference).
     """
     import torch
     n = keys[0].size if capacity is None else capacity
     torch_of = {1: torch.int8, 2: torch.int16, 3: torch.int32, 4: torch.int64, 5: torch.float32, 6: torch.float64,
                 7: torch.int32, 8: torch.int64, 9: torch.int64}
-    out_keys = [Column(torch.empty(max(n, 1), dtype=torch_of[k.c.dtype], device="cuda"), None, k.c.dtype, size=n) for k in keys]
+    def mask():
+        return torch.zeros(((n + 7) // 8 + 63) // 64 * 64 or 64, dtype=torch.uint8, device="cuda") if with_masks else None
+    out_keys = [Column(torch.empty(max(n, 1), dtype=torch_of[k.c.dtype], device="cuda"), mask(), k.c.dtype, size=n) for k in keys]
     if out_dtype is None:
         out_dtype = values.c.dtype
-    out_agg = Column(torch.empty(max(n, 1), dtype=torch_of[out_dtype], device="cuda"), None, out_dtype, size=n)
+    out_agg = Column(torch.empty(max(n, 1), dtype=torch_of[out_dtype], device="cuda"), mask(), out_dtype, size=n)
     out_idx = Column(torch.full((max(n, 1),), -1, dtype=torch.int64, device="cuda"), None, 4, size=n) if with_indices else None
     ctx = new_context(method=method, flag_sort_result=1 if sort_result else 0, flag_distinct=1 if distinct else 0,
                       flag_sorted=1 if presorted else 0)
     ka, oa = column_array(keys), column_array(out_keys)
     getattr(libgdf, _GROUPBY[op])(len(keys), ka, values.ptr, out_idx.ptr if with_indices else None, oa, out_agg.ptr, C.byref(ctx))
     g = out_agg.size
+    if with_masks:
+        bits = np.unpackbits(out_agg.valid.cpu().numpy(), bitorder="little")[:g].astype(bool)
+        assert int(out_agg.c.null_count) == int(g - bits.sum())
+        for k in out_keys:
+            assert np.unpackbits(k.valid.cpu().numpy(), bitorder="little")[:g].all() and int(k.c.null_count) == 0
+        return [k.data[:g] for k in out_keys], out_agg.data[:g], torch.from_numpy(bits)
     if with_indices:
         return [k.data[:g] for k in out_keys], out_agg.data[:g], out_idx.data[:out_idx.size]
     return [k.data[:g] for k in out_keys], out_agg.data[:g]

@@ -40,9 +40,16 @@ constexpr int32_t GB_EMPTY_ROW = -1;
 
 enum GbOp : int { OP_SUM = 0, OP_MIN, OP_MAX, OP_AVG, OP_COUNT, OP_COUNT_DISTINCT };   // sort.hip's SgOp has the same order
 
+// Column c occupies bits [shift, shift + bits) of the packed key and holds (value - bias).
+// Natural layout: bias 0, bits = 8 * width (the raw element bits).  Range layout (integer
+// key columns whose widths sum to more than 8 bytes): bias = column minimum, bits =
+// bit length of (max - min), found by one min/max pass -- C5's (int64, int32) key with
+// 1e6 x 16 distinct values packs into 24 bits this way and keeps the LDS / dense paths.
 struct GbKeyPlan {
   int packed;                  // 1: exact 64-bit packed key, 0: first-row table + rows_equal
   int shift[MAX_KEY_COLS];
+  int bits[MAX_KEY_COLS];
+  int64_t bias[MAX_KEY_COLS];
 };
 
 static GbKeyPlan gb_plan_keys(const KeyTable &t) {
@@ -52,16 +59,39 @@ static GbKeyPlan gb_plan_keys(const KeyTable &t) {
   for (int c = 0; c < t.ncols; ++c) {
     if (t.col[c].kind == K_F32 || t.col[c].kind == K_F64) all_int = false;
     p.shift[c] = total * 8;
+    p.bits[c] = t.col[c].width * 8;
+    p.bias[c] = 0;
     total += t.col[c].width;
   }
   p.packed = (all_int && total <= 8) ? 1 : 0;
   return p;
 }
 
+__device__ __forceinline__ int64_t load_signed(const ColView &c, int64_t i) {
+  switch (c.width) {
+    case 1: return ((const int8_t *)c.data)[i];
+    case 2: return ((const int16_t *)c.data)[i];
+    case 4: return ((const int32_t *)c.data)[i];
+    default: return ((const int64_t *)c.data)[i];
+  }
+}
+__device__ __forceinline__ uint64_t low_mask(int bits) { return bits >= 64 ? ~0ULL : ((1ULL << bits) - 1ULL); }
+
 __device__ __forceinline__ uint64_t gb_pack(const KeyTable &t, const GbKeyPlan &p, int64_t i) {
   uint64_t k = 0;
-  for (int c = 0; c < t.ncols; ++c) k |= load_bits(t.col[c], i) << p.shift[c];
+  for (int c = 0; c < t.ncols; ++c)
+    k |= ((uint64_t)(load_signed(t.col[c], i) - p.bias[c]) & low_mask(p.bits[c])) << p.shift[c];
   return k;
+}
+// inverse of gb_pack for column c, stored at the column's width
+__device__ __forceinline__ void gb_unpack_store(const KeyTable &t, const GbKeyPlan &p, uint64_t key, int c, void *out, int64_t pos) {
+  const uint64_t bits = ((key >> p.shift[c]) & low_mask(p.bits[c])) + (uint64_t)p.bias[c];
+  switch (t.col[c].width) {
+    case 1: ((uint8_t *)out)[pos] = (uint8_t)bits; break;
+    case 2: ((uint16_t *)out)[pos] = (uint16_t)bits; break;
+    case 4: ((uint32_t *)out)[pos] = (uint32_t)bits; break;
+    default: ((uint64_t *)out)[pos] = bits; break;
+  }
 }
 
 // hash of a row for the first-row table: equal rows (under ==) must hash equally, so
@@ -90,7 +120,7 @@ __device__ __forceinline__ double unord_f64(uint64_t u) {
   return __longlong_as_double((long long)b);
 }
 
-struct GbVal { const void *data; int kind; };
+struct GbVal { const void *data; int kind; const uint8_t *valid; };   // valid: null values are skipped (C5 semantics)
 
 __device__ __forceinline__ int64_t load_int(const GbVal &v, int64_t i) {
   switch (v.kind) {
@@ -146,6 +176,8 @@ __device__ __forceinline__ uint32_t gtable_find_packed(const GbTable &g, uint64_
   if (key == GB_EMPTY_KEY) { *g.special = 1u; return g.T; }
   uint32_t slot = (uint32_t)(mix64(key) >> 32) & (g.T - 1);
   for (uint32_t probes = 0; probes < g.T; ++probes) {
+    // a table that overflowed keeps filling until every workgroup has noticed: do not walk a full table
+    if ((probes & 63u) == 63u && *(volatile unsigned int *)g.overflow) return 0xffffffffu;
     unsigned long long cur = g.keys[slot];
     if (cur == key) return slot;
     if (cur == GB_EMPTY_KEY) {
@@ -164,6 +196,7 @@ __device__ __forceinline__ uint32_t gtable_find_packed(const GbTable &g, uint64_
 __device__ __forceinline__ uint32_t gtable_find_rows(const GbTable &g, const KeyTable &t, int64_t row) {
   uint32_t slot = (uint32_t)(gb_hash_row(t, row) >> 32) & (g.T - 1);
   for (uint32_t probes = 0; probes < g.T; ++probes) {
+    if ((probes & 63u) == 63u && *(volatile unsigned int *)g.overflow) return 0xffffffffu;
     int32_t cur = g.first[slot];
     if (cur == GB_EMPTY_ROW) {
       const int32_t old = atomicCAS(&g.first[slot], GB_EMPTY_ROW, (int32_t)row);
@@ -194,14 +227,16 @@ __global__ __launch_bounds__(256) void gb_init_table(GbTable g, int op, int pack
 template <bool PACKED>
 __global__ __launch_bounds__(GB_THREADS) void gb_aggregate(KeyTable t, GbKeyPlan plan, GbVal val, int op, GbTable g,
                                                            int64_t chunk) {
+  // g.cnt != null: the number of (valid) values per group is tracked -- AVG, or any op over a masked column
   extern __shared__ __attribute__((aligned(16))) unsigned char gb_lds[];
   unsigned long long *lkey = (unsigned long long *)gb_lds;
   unsigned long long *lacc = lkey + GB_LDS_SLOTS;
   unsigned long long *lcnt = lacc + GB_LDS_SLOTS;            // AVG only
-  unsigned int *lfill = (unsigned int *)(lcnt + (op == OP_AVG ? GB_LDS_SLOTS : 0));
+  const bool counted = g.cnt != nullptr;
+  unsigned int *lfill = (unsigned int *)(lcnt + (counted ? GB_LDS_SLOTS : 0));
   const bool flt = is_flt(val.kind);
-  const bool avg = op == OP_AVG;
-  const int fold_op = avg ? OP_SUM : op;
+  const bool avg = counted;            // below, "avg" means: keep a per-group count next to the accumulator
+  const int fold_op = op == OP_AVG ? OP_SUM : op;
 
   if (PACKED) {
     for (uint32_t i = threadIdx.x; i < GB_LDS_SLOTS; i += GB_THREADS) {
@@ -217,6 +252,8 @@ __global__ __launch_bounds__(GB_THREADS) void gb_aggregate(KeyTable t, GbKeyPlan
   const int64_t end = begin + chunk < t.nrows ? begin + chunk : t.nrows;
   for (int64_t i = begin + threadIdx.x; i < end; i += GB_THREADS) {
     if (*(volatile unsigned int *)g.overflow) break;     // another workgroup filled the table: the host retries larger
+    if (!row_valid(t, i)) continue;                       // a null in any key column drops the row
+    const bool vok = !val.valid || bit_is_set(val.valid, i);   // a null value keeps its group but adds nothing
     const uint64_t img = acc_image(fold_op, val, i);
     if (PACKED) {
       const uint64_t key = gb_pack(t, plan, i);
@@ -231,8 +268,10 @@ __global__ __launch_bounds__(GB_THREADS) void gb_aggregate(KeyTable t, GbKeyPlan
             if (old == GB_EMPTY_KEY) { atomicAdd(lfill, 1u); cur = key; } else cur = old;
           }
           if (cur == key) {
-            acc_fold(fold_op, flt, &lacc[slot], img);
-            if (avg) atomicAdd(&lcnt[slot], 1ULL);
+            if (vok) {
+              acc_fold(fold_op, flt, &lacc[slot], img);
+              if (avg) atomicAdd(&lcnt[slot], 1ULL);
+            }
             done = true;
             break;
           }
@@ -242,14 +281,18 @@ __global__ __launch_bounds__(GB_THREADS) void gb_aggregate(KeyTable t, GbKeyPlan
       if (!done) {
         const uint32_t s = gtable_find_packed(g, key);
         if (s == 0xffffffffu) { atomicExch(g.overflow, 1u); break; }
-        acc_fold(fold_op, flt, &g.acc[s], img);
-        if (avg) atomicAdd(&g.cnt[s], 1ULL);
+        if (vok) {
+          acc_fold(fold_op, flt, &g.acc[s], img);
+          if (avg) atomicAdd(&g.cnt[s], 1ULL);
+        }
       }
     } else {
       const uint32_t s = gtable_find_rows(g, t, i);
       if (s == 0xffffffffu) { atomicExch(g.overflow, 1u); break; }
-      acc_fold(fold_op, flt, &g.acc[s], img);
-      if (avg) atomicAdd(&g.cnt[s], 1ULL);
+      if (vok) {
+        acc_fold(fold_op, flt, &g.acc[s], img);
+        if (avg) atomicAdd(&g.cnt[s], 1ULL);
+      }
     }
   }
 
@@ -276,6 +319,8 @@ struct GbOut {
   void *agg_out;
   int agg_kind;      // kind the aggregate is WRITTEN as
   int in_kind;       // kind of the input values (decides the accumulator encoding)
+  uint8_t *agg_ok;   // optional: 1 byte per group, 0 = the group had no valid value (output is null)
+  int counted;       // the count passed to store_result is the number of VALID values
 };
 
 __device__ __forceinline__ void store_int(void *out, int kind, int64_t pos, int64_t v) {
@@ -340,6 +385,9 @@ __device__ __forceinline__ void store_avg(const GbOut &o, int64_t pos, uint64_t 
 }
 
 __device__ __forceinline__ void store_result(const GbOut &o, int op, int64_t pos, uint64_t acc, uint64_t cnt) {
+  const bool empty = o.counted && cnt == 0 && op != OP_COUNT;    // every value of the group was null
+  if (o.agg_ok) o.agg_ok[pos] = empty ? 0 : 1;
+  if (empty) { store_int(o.agg_out, o.agg_kind, pos, 0); return; }
   switch (op) {
     case OP_COUNT: store_int(o.agg_out, o.agg_kind, pos, (int64_t)acc); break;   // count_op<out dtype>
     case OP_AVG: store_avg(o, pos, acc, cnt); break;
@@ -380,7 +428,8 @@ __global__ __launch_bounds__(256) void gb_extract(KeyTable t, GbKeyPlan plan, Gb
     if (live) {
       const int64_t pos = (int64_t)(base + mask_rank(m));
       for (int c = 0; c < t.ncols; ++c) {
-        uint64_t bits = PACKED ? (key >> plan.shift[c]) : load_bits(t.col[c], row);
+        if (PACKED) { gb_unpack_store(t, plan, key, c, o.key_out[c], pos); continue; }
+        const uint64_t bits = load_bits(t.col[c], row);
         switch (t.col[c].width) {
           case 1: ((uint8_t *)o.key_out[c])[pos] = (uint8_t)bits; break;
           case 2: ((uint16_t *)o.key_out[c])[pos] = (uint16_t)bits; break;
@@ -410,7 +459,8 @@ __global__ void gb_sort_gather(const uint32_t *perm, uint32_t n, int width, cons
   }
 }
 
-static gdf_error sort_result_rows(int ncols, gdf_column **key_cols, const int *key_kind, void *agg, int agg_width, uint32_t n) {
+static gdf_error sort_result_rows(int ncols, gdf_column **key_cols, const int *key_kind, void *agg, int agg_width, uint32_t n,
+                                  uint8_t *agg_ok = nullptr) {
   if (n < 2) return GDF_SUCCESS;
   KeyTable t{};
   t.ncols = ncols;
@@ -432,6 +482,7 @@ static gdf_error sort_result_rows(int ncols, gdf_column **key_cols, const int *k
   };
   for (int c = 0; c < ncols; ++c) GDF_TRY(permute(key_cols[c]->data, kind_width((ElemKind)key_kind[c])));
   GDF_TRY(permute(agg, agg_width));
+  if (agg_ok) GDF_TRY(permute(agg_ok, 1));
   HIP_CHECK_LAST();
   HIP_TRY(hipStreamSynchronize(stream0()));
   return GDF_SUCCESS;
@@ -472,6 +523,7 @@ __device__ __forceinline__ bool dict_insert(const GbDict &d, uint64_t key) {
   if (key == GB_EMPTY_KEY) { *d.special = 1u; return true; }
   uint32_t slot = (uint32_t)(mix64(key) >> 32) & (d.T - 1);
   for (uint32_t probes = 0; probes < d.T; ++probes) {
+    if ((probes & 63u) == 63u && *(volatile unsigned int *)d.overflow) return false;
     const unsigned long long cur = d.e[slot].key;
     if (cur == key) return true;
     if (cur == GB_EMPTY_KEY) {
@@ -493,7 +545,8 @@ __device__ __forceinline__ bool dict_insert(const GbDict &d, uint64_t key) {
 // table at 4 % load answers almost every row with one independent read.)
 constexpr int GB_DICT_THREADS = 512;
 
-template <bool FASTKEY>
+// MASKED: rows with a null key element are skipped (their lanes re-find the reserved key, which costs nothing)
+template <bool FASTKEY, bool MASKED>
 __global__ __launch_bounds__(GB_DICT_THREADS) void gb_dict_build(KeyTable t, GbKeyPlan plan, GbDict g, int64_t chunk) {
   const int64_t begin = (int64_t)blockIdx.x * chunk;
   const int64_t end = begin + chunk < t.nrows ? begin + chunk : t.nrows;
@@ -506,6 +559,12 @@ __global__ __launch_bounds__(GB_DICT_THREADS) void gb_dict_build(KeyTable t, GbK
       const int64_t ic = i < end ? i : end - 1;                  // clamped: finished lanes re-find a real key
       key[k] = FASTKEY ? ((const uint64_t *)t.col[0].data)[ic] : gb_pack(t, plan, ic);
     }
+    bool skip[GB_DENSE_BATCH];
+#pragma unroll
+    for (int k = 0; k < GB_DENSE_BATCH; ++k) {
+      const int64_t i = base + (int64_t)k * GB_DICT_THREADS + threadIdx.x;
+      skip[k] = MASKED && !row_valid(t, i < end ? i : end - 1);
+    }
     // almost every row finds its key already present in its home slot: probe all BATCH home slots
     // first (independent reads), insert only the misses
     unsigned long long home[GB_DENSE_BATCH];
@@ -513,7 +572,7 @@ __global__ __launch_bounds__(GB_DICT_THREADS) void gb_dict_build(KeyTable t, GbK
     for (int k = 0; k < GB_DENSE_BATCH; ++k) home[k] = g.e[(uint32_t)(mix64(key[k]) >> 32) & (g.T - 1)].key;
 #pragma unroll
     for (int k = 0; k < GB_DENSE_BATCH; ++k)
-      if ((home[k] != key[k] || key[k] == GB_EMPTY_KEY) && !dict_insert(g, key[k])) atomicExch(g.overflow, 1u);
+      if (!skip[k] && (home[k] != key[k] || key[k] == GB_EMPTY_KEY) && !dict_insert(g, key[k])) atomicExch(g.overflow, 1u);
   }
 }
 
@@ -558,17 +617,17 @@ __device__ __forceinline__ uint32_t dict_lookup(const GbDict &d, uint64_t key) {
 
 // FASTVAL: 8-byte values (int64 / float64): the raw word is loaded branch-free and turned into the
 // accumulator image afterwards
-template <bool FASTKEY, bool FASTVAL>
+template <bool FASTKEY, bool FASTVAL, bool MASKED>
 __global__ __launch_bounds__(GB_DENSE_THREADS) void gb_dense_aggregate(KeyTable t, GbKeyPlan plan, GbVal val, int op, GbDict g,
                                                                        uint32_t ngroups,
                                                                        unsigned long long *gacc, unsigned long long *gcnt,
                                                                        int64_t chunk) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gb_lds[];
   unsigned long long *lacc = (unsigned long long *)gb_lds;
-  unsigned int *lcnt = (unsigned int *)(lacc + ngroups);            // AVG only
+  unsigned int *lcnt = (unsigned int *)(lacc + ngroups);            // counted only
   const bool flt = is_flt(val.kind);
-  const bool avg = op == OP_AVG;
-  const int fold_op = avg ? OP_SUM : op;
+  const bool avg = gcnt != nullptr;     // "avg" = a count of (valid) values is kept per group: AVG, or a masked value column
+  const int fold_op = op == OP_AVG ? OP_SUM : op;
   for (uint32_t i = threadIdx.x; i < ngroups; i += GB_DENSE_THREADS) {
     lacc[i] = acc_identity(fold_op);
     if (avg) lcnt[i] = 0;
@@ -598,6 +657,17 @@ __global__ __launch_bounds__(GB_DENSE_THREADS) void gb_dense_aggregate(KeyTable 
     // is not in its home slot finishes with the scalar walk
     uint32_t gid[GB_DENSE_BATCH];
     uint4 w[GB_DENSE_BATCH];
+    bool use[GB_DENSE_BATCH];
+#pragma unroll
+    for (int k = 0; k < GB_DENSE_BATCH; ++k) {
+      const int64_t i = base + (int64_t)k * GB_DENSE_THREADS + threadIdx.x;
+      use[k] = i < end;
+      if (MASKED) {
+        const int64_t ic = i < end ? i : end - 1;
+        if (!row_valid(t, ic)) { use[k] = false; key[k] = GB_EMPTY_KEY; }      // never looked up in the table proper
+        else if (val.valid && !bit_is_set(val.valid, ic)) use[k] = false;      // null value: the group exists, nothing to add
+      }
+    }
 #pragma unroll
     for (int k = 0; k < GB_DENSE_BATCH; ++k) {
       const uint32_t slot = (uint32_t)(mix64(key[k]) >> 32) & (g.T - 1);
@@ -606,11 +676,12 @@ __global__ __launch_bounds__(GB_DENSE_THREADS) void gb_dense_aggregate(KeyTable 
 #pragma unroll
     for (int k = 0; k < GB_DENSE_BATCH; ++k) {
       if ((((unsigned long long)w[k].y << 32) | w[k].x) == key[k] && key[k] != GB_EMPTY_KEY) gid[k] = w[k].z;
+      else if (MASKED && !use[k]) gid[k] = 0;
       else gid[k] = dict_lookup(g, key[k]);
     }
 #pragma unroll
     for (int k = 0; k < GB_DENSE_BATCH; ++k) {
-      if (base + (int64_t)k * GB_DENSE_THREADS + threadIdx.x < end) {
+      if (use[k]) {
         acc_fold(fold_op, flt, &lacc[gid[k]], img[k]);
         if (avg) atomicAdd(&lcnt[gid[k]], 1u);
       }
@@ -621,7 +692,7 @@ __global__ __launch_bounds__(GB_DENSE_THREADS) void gb_dense_aggregate(KeyTable 
     const unsigned long long v = lacc[i];
     if (avg) {
       const unsigned int c = lcnt[i];
-      if (c) { acc_fold(OP_SUM, flt, &gacc[i], v); atomicAdd(&gcnt[i], (unsigned long long)c); }
+      if (c) { acc_fold(fold_op, flt, &gacc[i], v); atomicAdd(&gcnt[i], (unsigned long long)c); }
     } else if (v != acc_identity(fold_op) || fold_op == OP_SUM) {
       // an untouched MIN/MAX/COUNT cell equals the identity and contributes nothing; SUM cells are folded
       // unconditionally only when non-zero (adding 0 is a no-op, skip the atomic)
@@ -636,17 +707,76 @@ __global__ __launch_bounds__(256) void gb_dense_extract(KeyTable t, GbKeyPlan pl
   for (uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x; gi < ngroups; gi += gridDim.x * blockDim.x) {
     const uint32_t slot = group_slot[gi];
     const uint64_t key = slot == g.T ? GB_EMPTY_KEY : g.e[slot].key;
-    for (int c = 0; c < t.ncols; ++c) {
-      const uint64_t bits = key >> plan.shift[c];
-      switch (t.col[c].width) {
-        case 1: ((uint8_t *)o.key_out[c])[gi] = (uint8_t)bits; break;
-        case 2: ((uint16_t *)o.key_out[c])[gi] = (uint16_t)bits; break;
-        case 4: ((uint32_t *)o.key_out[c])[gi] = (uint32_t)bits; break;
-        default: ((uint64_t *)o.key_out[c])[gi] = bits; break;
-      }
-    }
+    for (int c = 0; c < t.ncols; ++c) gb_unpack_store(t, plan, key, c, o.key_out[c], gi);
     store_result(o, op, gi, gacc[gi], gcnt ? gcnt[gi] : 0);
   }
+}
+
+// out mask byte b covers groups 8b..8b+7 (LSB first); ok == null means every group is valid
+__global__ __launch_bounds__(256) void gb_write_mask(const uint8_t *ok, uint32_t n, uint8_t *mask, unsigned int *nulls) {
+  const uint32_t nbytes = (n + 7) / 8;
+  for (uint32_t b = blockIdx.x * 256 + threadIdx.x; b < nbytes; b += gridDim.x * 256) {
+    uint8_t m = 0;
+    unsigned int missing = 0;
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t g = b * 8 + k;
+      if (g >= n) break;
+      if (!ok || ok[g]) m |= (uint8_t)(1u << k); else ++missing;
+    }
+    mask[b] = m;
+    if (missing) atomicAdd(nulls, missing);
+  }
+}
+
+// write the output validity masks the caller supplied buffers for: keys are never null
+// (rows with a null key were dropped), the aggregate is null for an all-null group
+static gdf_error write_output_masks(int ncols, gdf_column **out_keys, gdf_column *out_agg, const uint8_t *agg_ok, uint32_t ngroups) {
+  DevBuf nulls;
+  RMM_TRY(nulls.alloc(sizeof(unsigned int)));
+  HIP_TRY(hipMemsetAsync(nulls.p, 0, sizeof(unsigned int), stream0()));
+  const int grid = stream_grid((ngroups + 7) / 8 + 1, 256);
+  for (int c = 0; c < ncols; ++c) {
+    out_keys[c]->null_count = 0;
+    if (out_keys[c]->valid && ngroups)
+      hipLaunchKernelGGL(gb_write_mask, dim3(grid), dim3(256), 0, stream0(), (const uint8_t *)nullptr, ngroups,
+                         (uint8_t *)out_keys[c]->valid, nulls.as<unsigned int>());
+  }
+  out_agg->null_count = 0;
+  if (out_agg->valid && ngroups) {
+    hipLaunchKernelGGL(gb_write_mask, dim3(grid), dim3(256), 0, stream0(), agg_ok, ngroups, (uint8_t *)out_agg->valid,
+                       nulls.as<unsigned int>());
+    unsigned int h = 0;
+    HIP_TRY(hipMemcpy(&h, nulls.p, sizeof(h), hipMemcpyDeviceToHost));
+    out_agg->null_count = h;
+  }
+  HIP_CHECK_LAST();
+  HIP_TRY(hipStreamSynchronize(stream0()));
+  return GDF_SUCCESS;
+}
+
+// integer key columns too wide for the natural layout: try (value - min) in bit_length(max - min) bits
+static gdf_error gb_plan_range(const KeyTable &t, GbKeyPlan *plan) {
+  for (int c = 0; c < t.ncols; ++c)
+    if (t.col[c].kind == K_F32 || t.col[c].kind == K_F64) return GDF_SUCCESS;
+  std::vector<long long> h(2 * t.ncols);
+  GDF_TRY(key_ranges(t, h.data()));
+  int total = 0;
+  GbKeyPlan p{};
+  for (int c = 0; c < t.ncols; ++c) {
+    long long lo = h[2 * c], hi = h[2 * c + 1];
+    if (lo > hi) lo = hi = 0;                                 // the column has no valid element
+    const uint64_t span = (uint64_t)hi - (uint64_t)lo;
+    int bits = 0;
+    while (bits < 64 && (span >> bits) != 0) ++bits;
+    p.shift[c] = total;
+    p.bits[c] = bits;
+    p.bias[c] = lo;
+    total += bits;
+    if (total > 63) return GDF_SUCCESS;                       // does not fit: keep the first-row table
+  }
+  p.packed = 1;                                               // <= 63 bits: the reserved key 1 << 63 cannot occur
+  *plan = p;
+  return GDF_SUCCESS;
 }
 
 // ---------------------------------------------------------------------------
@@ -676,16 +806,24 @@ static gdf_error group_by_hash(int ncols, gdf_column **cols, gdf_column *col_agg
     if (!out_keys[c] || !out_keys[c]->data) return GDF_DATASET_EMPTY;
   if (!out_agg->data) return GDF_DATASET_EMPTY;
 
-  const GbKeyPlan plan = gb_plan_keys(t);
-  GbVal val{col_agg->data, (int)(op == OP_COUNT ? K_I8 : in_kind)};
-  const bool avg = op == OP_AVG;
+  GbKeyPlan plan = gb_plan_keys(t);
+  if (!plan.packed) GDF_TRY(gb_plan_range(t, &plan));
+  GbVal val{col_agg->data, (int)(op == OP_COUNT ? K_I8 : in_kind), (const uint8_t *)col_agg->valid};
+  // Validity masks (beyond the reference, which rejects them: sqls_ops.cu:1103-1106; semantics of
+  // SURVEY.md 8d C5 = pandas dropna): a row with a null in any key column is dropped; a null value is
+  // skipped, so SUM/MIN/MAX/AVG/COUNT run over the valid values of each group; a group without any
+  // valid value is reported with value 0 and, if the caller gave out_col_agg a mask, a cleared bit.
+  const bool masked = t.any_valid || val.valid != nullptr;
+  const bool avg = op == OP_AVG || (val.valid != nullptr && op != OP_COUNT);   // keep a per-group count of valid values
+  DevBuf agg_ok;
+  const bool want_ok = val.valid != nullptr && op != OP_COUNT && out_agg->valid != nullptr;
 
   // workgroup geometry: one contiguous chunk of rows per workgroup
   const int grid = stream_grid((size_t)n, GB_THREADS * 32, NUM_CU * 4);
   int64_t chunk = (n + grid - 1) / grid;
   const size_t lds = plan.packed ? (size_t)GB_LDS_SLOTS * 8 * (avg ? 3 : 2) + 16 : 0;
 
-  // The table is sized by GROUPS.  Start small (the common case) and grow x16 on
+  // The table is sized by GROUPS.  Start small (the common case) and grow x256 on
   // overflow, up to the 2*N slots the reference always allocates.
   uint64_t cap_max = 1;
   while (cap_max < 2 * (uint64_t)n) cap_max <<= 1;
@@ -704,13 +842,14 @@ static gdf_error group_by_hash(int ncols, gdf_column **cols, gdf_column *col_agg
     g.overflow = flags.as<unsigned int>() + 1;
     g.special = flags.as<unsigned int>() + 2;
     const uint32_t max_groups = avg ? GB_DENSE_MAX_GROUPS_AVG : GB_DENSE_MAX_GROUPS;
+    const bool fastkey = !masked && t.ncols == 1 && t.col[0].width == 8 && plan.bits[0] == 64 && plan.bias[0] == 0;
     g.limit = max_groups;                       // more distinct keys than this: stop early, use the general path
     GDF_LAUNCH("gb_fill", gb_dict_clear, dim3(stream_grid(T + 1, 256 * 8)), dim3(256), 0, stream0(), g.e, (uint32_t)(T + 1));
     const int bgrid = stream_grid((size_t)n, GB_DICT_THREADS * GB_DENSE_BATCH * 4, NUM_CU * 8);
     const int64_t bchunk = (((n + bgrid - 1) / bgrid) + GB_DICT_THREADS - 1) / GB_DICT_THREADS * GB_DICT_THREADS;
-    const bool fastkey = t.ncols == 1 && t.col[0].width == 8;
-    if (fastkey) GDF_LAUNCH("gb_dict_build", gb_dict_build<true>, dim3(bgrid), dim3(GB_DICT_THREADS), 0, stream0(), t, plan, g, bchunk);
-    else GDF_LAUNCH("gb_dict_build", gb_dict_build<false>, dim3(bgrid), dim3(GB_DICT_THREADS), 0, stream0(), t, plan, g, bchunk);
+    if (fastkey) GDF_LAUNCH("gb_dict_build", (gb_dict_build<true, false>), dim3(bgrid), dim3(GB_DICT_THREADS), 0, stream0(), t, plan, g, bchunk);
+    else if (!t.any_valid) GDF_LAUNCH("gb_dict_build", (gb_dict_build<false, false>), dim3(bgrid), dim3(GB_DICT_THREADS), 0, stream0(), t, plan, g, bchunk);
+    else GDF_LAUNCH("gb_dict_build", (gb_dict_build<false, true>), dim3(bgrid), dim3(GB_DICT_THREADS), 0, stream0(), t, plan, g, bchunk);
     HIP_CHECK_LAST();
     unsigned int h_flags[3] = {0, 0, 0};
     HIP_TRY(hipMemcpy(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost));
@@ -729,17 +868,18 @@ static gdf_error group_by_hash(int ncols, gdf_column **cols, gdf_column *col_agg
       const int agrid = stream_grid((size_t)n, GB_DENSE_THREADS * GB_DENSE_BATCH, NUM_CU);
       const int64_t achunk = (((n + agrid - 1) / agrid) + GB_DENSE_THREADS - 1) / GB_DENSE_THREADS * GB_DENSE_THREADS;
       const size_t dlds = (size_t)ngroups * (avg ? 12 : 8) + 16;
-      const bool fastval = op != OP_COUNT && kind_width(in_kind) == 8;
-#define GB_DENSE_LAUNCH(FK, FV)                                                                                              \
+      const bool fastval = !masked && op != OP_COUNT && kind_width(in_kind) == 8;
+#define GB_DENSE_LAUNCH(FK, FV, MK)                                                                                          \
   do {                                                                                                                       \
-    HIP_TRY(hipFuncSetAttribute((const void *)gb_dense_aggregate<FK, FV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds)); \
-    GDF_LAUNCH("gb_dense_aggregate", (gb_dense_aggregate<FK, FV>), dim3(agrid), dim3(GB_DENSE_THREADS), dlds, stream0(), t, plan, val, \
+    HIP_TRY(hipFuncSetAttribute((const void *)gb_dense_aggregate<FK, FV, MK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds)); \
+    GDF_LAUNCH("gb_dense_aggregate", (gb_dense_aggregate<FK, FV, MK>), dim3(agrid), dim3(GB_DENSE_THREADS), dlds, stream0(), t, plan, val, \
                op, g, ngroups, gacc.as<unsigned long long>(), gcnt.as<unsigned long long>(), achunk);                        \
   } while (0)
-      if (fastkey && fastval) GB_DENSE_LAUNCH(true, true);
-      else if (fastkey) GB_DENSE_LAUNCH(true, false);
-      else if (fastval) GB_DENSE_LAUNCH(false, true);
-      else GB_DENSE_LAUNCH(false, false);
+      if (masked) GB_DENSE_LAUNCH(false, false, true);
+      else if (fastkey && fastval) GB_DENSE_LAUNCH(true, true, false);
+      else if (fastkey) GB_DENSE_LAUNCH(true, false, false);
+      else if (fastval) GB_DENSE_LAUNCH(false, true, false);
+      else GB_DENSE_LAUNCH(false, false, false);
 #undef GB_DENSE_LAUNCH
       GbOut o{};
       o.ncols = ncols;
@@ -747,18 +887,21 @@ static gdf_error group_by_hash(int ncols, gdf_column **cols, gdf_column *col_agg
       o.agg_out = out_agg->data;
       o.in_kind = (int)in_kind;
       o.agg_kind = (int)((op == OP_COUNT || op == OP_AVG) ? out_kind : in_kind);
+      if (want_ok) RMM_TRY(agg_ok.alloc(ngroups ? ngroups : 1));
+      o.agg_ok = agg_ok.as<uint8_t>();
+      o.counted = val.valid != nullptr;
       GDF_LAUNCH("gb_extract", gb_dense_extract, dim3(stream_grid(ngroups ? ngroups : 1, 256)), dim3(256), 0, stream0(), t, plan, g,
                  group_slot.as<uint32_t>(), ngroups, o, op, gacc.as<unsigned long long>(), gcnt.as<unsigned long long>());
       HIP_CHECK_LAST();
       HIP_TRY(hipStreamSynchronize(stream0()));
       for (int c = 0; c < ncols; ++c) out_keys[c]->size = (gdf_size_type)ngroups;
       out_agg->size = (gdf_size_type)ngroups;
-      if (sort_result || avg) {
+      if (sort_result || op == OP_AVG) {
         int kinds[MAX_KEY_COLS];
         for (int c = 0; c < ncols; ++c) kinds[c] = t.col[c].kind;
-        GDF_TRY(sort_result_rows(ncols, out_keys, kinds, out_agg->data, kind_width((ElemKind)o.agg_kind), ngroups));
+        GDF_TRY(sort_result_rows(ncols, out_keys, kinds, out_agg->data, kind_width((ElemKind)o.agg_kind), ngroups, o.agg_ok));
       }
-      return GDF_SUCCESS;
+      return write_output_masks(ncols, out_keys, out_agg, o.agg_ok, ngroups);
     }
     // too many groups for LDS accumulators: general path below
   }
@@ -781,7 +924,7 @@ static gdf_error group_by_hash(int ncols, gdf_column **cols, gdf_column *col_agg
     g.overflow = flags.as<unsigned int>() + 1;
     g.special = flags.as<unsigned int>() + 2;
     g.limit = T >= cap_max ? 0xffffffffu : (uint32_t)(T / 2);   // at 2*N slots the table can never fill
-    GDF_LAUNCH("gb_init_table", gb_init_table, dim3(stream_grid(T + 1, 256 * 8)), dim3(256), 0, stream0(), g, avg ? OP_SUM : op, plan.packed);
+    GDF_LAUNCH("gb_init_table", gb_init_table, dim3(stream_grid(T + 1, 256 * 8)), dim3(256), 0, stream0(), g, op == OP_AVG ? OP_SUM : op, plan.packed);
     if (plan.packed) {
       HIP_TRY(hipFuncSetAttribute((const void *)gb_aggregate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       GDF_LAUNCH("gb_aggregate_packed", gb_aggregate<true>, dim3(grid), dim3(GB_THREADS), lds, stream0(), t, plan, val, op, g, chunk);
@@ -793,7 +936,7 @@ static gdf_error group_by_hash(int ncols, gdf_column **cols, gdf_column *col_agg
     HIP_TRY(hipMemcpy(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost));
     if (h_flags[1]) {                       // too many groups for this table
       if (T >= cap_max) return GDF_HASH_TABLE_INSERT_FAILURE;
-      T = T * 16 < cap_max ? T * 16 : cap_max;
+      T = T * 256 < cap_max ? T * 256 : cap_max;     // 2^18 -> 2^26 -> 2N: at most two retries
       continue;
     }
     const unsigned int special_used = h_flags[2];   // slot T (reserved key) is live iff some row used it
@@ -803,6 +946,9 @@ static gdf_error group_by_hash(int ncols, gdf_column **cols, gdf_column *col_agg
     o.agg_out = out_agg->data;
     o.in_kind = (int)in_kind;
     o.agg_kind = (int)((op == OP_COUNT || op == OP_AVG) ? out_kind : in_kind);
+    if (want_ok) RMM_TRY(agg_ok.alloc((size_t)h_flags[0] + 2));
+    o.agg_ok = agg_ok.as<uint8_t>();
+    o.counted = val.valid != nullptr;
     const int egrid = stream_grid(T + 1, 256 * 4);
     if (plan.packed)
       GDF_LAUNCH("gb_extract", gb_extract<true>, dim3(egrid), dim3(256), 0, stream0(), t, plan, g, o, op, special_used, out_count.as<unsigned long long>());
@@ -813,12 +959,12 @@ static gdf_error group_by_hash(int ncols, gdf_column **cols, gdf_column *col_agg
     HIP_TRY(hipMemcpy(&ngroups, out_count.p, sizeof(ngroups), hipMemcpyDeviceToHost));
     for (int c = 0; c < ncols; ++c) out_keys[c]->size = (gdf_size_type)ngroups;   // gdf_table.cuh:334-342
     out_agg->size = (gdf_size_type)ngroups;
-    if (sort_result || avg) {
+    if (sort_result || op == OP_AVG) {
       int kinds[MAX_KEY_COLS];
       for (int c = 0; c < ncols; ++c) kinds[c] = t.col[c].kind;
-      GDF_TRY(sort_result_rows(ncols, out_keys, kinds, out_agg->data, kind_width((ElemKind)o.agg_kind), (uint32_t)ngroups));
+      GDF_TRY(sort_result_rows(ncols, out_keys, kinds, out_agg->data, kind_width((ElemKind)o.agg_kind), (uint32_t)ngroups, o.agg_ok));
     }
-    return GDF_SUCCESS;
+    return write_output_masks(ncols, out_keys, out_agg, o.agg_ok, (uint32_t)ngroups);
   }
 }
 
@@ -827,8 +973,12 @@ static gdf_error group_by_single(int ncols, gdf_column **cols, gdf_column *col_a
                                  gdf_column **out_col_values, gdf_column *out_col_agg, gdf_context *ctxt, int op) {
   if (0 == ncols || nullptr == cols || nullptr == col_agg || nullptr == out_col_agg || nullptr == ctxt)
     return GDF_DATASET_EMPTY;
-  for (int i = 0; i < ncols; ++i) GDF_REQUIRE(!cols[i]->valid, GDF_VALIDITY_UNSUPPORTED);
-  GDF_REQUIRE(!col_agg->valid, GDF_VALIDITY_UNSUPPORTED);
+  // The reference rejects every mask here (sqls_ops.cu:1103-1106).  The HASH method accepts them with the
+  // semantics documented in group_by_hash (BASELINE config C5); the SORT method keeps the reference's answer.
+  if (ctxt->flag_method != GDF_HASH) {
+    for (int i = 0; i < ncols; ++i) GDF_REQUIRE(!cols[i]->valid, GDF_VALIDITY_UNSUPPORTED);
+    GDF_REQUIRE(!col_agg->valid, GDF_VALIDITY_UNSUPPORTED);
+  }
   if (0 == cols[0]->size || 0 == col_agg->size) {
     out_col_agg->size = 0;
     if (out_col_indices) out_col_indices->size = 0;

@@ -14,6 +14,12 @@ gdf_error scan_u64(const uint64_t *in, uint64_t *out, size_t n, bool inclusive);
 // sort.hip: stable ascending lexicographic row order of t's first n rows -> perm (n x uint32).
 // sorted_keys / keys_exact are optional (see sort.hip).
 gdf_error order_rows(const KeyTable &t, uint32_t n, DevBuf &perm, DevBuf *sorted_keys, bool *keys_exact);
+// sort.hip: lo_hi[2c] / lo_hi[2c+1] = min / max (as signed 64-bit) of integer key column c over its valid
+// elements of rows [0, t.nrows); lo > hi when the column has none; float columns are not touched
+gdf_error key_ranges(const KeyTable &t, long long *lo_hi);
+// sort.hip: stable LSD radix sort of n (key, 64-bit payload) pairs on the key bits set in `varying`; the
+// pairs ping-pong between the two buffer sets and kin / vin point at the sorted data on return
+gdf_error radix_sort_pairs_u64(uint64_t *&kin, uint64_t *&kout, uint64_t *&vin, uint64_t *&vout, uint32_t n, uint64_t varying);
 // sort.hip: SORT-method group-by (op = GbOp of groupby.hip, 5 = COUNT_DISTINCT)
 gdf_error group_by_sort(int ncols, gdf_column **cols, gdf_column *col_agg, gdf_column *out_col_indices,
                         gdf_column **out_col_values, gdf_column *out_col_agg, gdf_context *ctxt, int op);

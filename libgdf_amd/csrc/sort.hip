@@ -46,60 +46,97 @@
 
 namespace gdf_amd {
 
-constexpr int RS_THREADS = 512;
-constexpr int RS_WAVES = RS_THREADS / WAVE;
-constexpr int RS_ITEMS = 8;
-constexpr int RS_TILE = RS_THREADS * RS_ITEMS;      // 4096 pairs: 48 KiB of LDS
-constexpr int RS_BINS = 256;
-constexpr int RS_DIGITS = 8;
 constexpr int SG_THREADS = 256;
 constexpr int SG_ROUNDS = 16;                        // 64 x 16 sorted rows per wave
 
 enum SgOp : int { SG_SUM = 0, SG_MIN, SG_MAX, SG_AVG, SG_COUNT, SG_COUNT_DISTINCT };
 
-// one group of adjacent key columns whose widths sum to <= 8 bytes
+// one group of adjacent key columns whose images together fit 64 bits.  An integer
+// column contributes (value - bias) in `bits` bits (bias = the column minimum, from
+// key_ranges); a float column (bits == 0) its full-width total-order image.
 struct SortGroup {
   int ncols;
   const void *data[8];
   int kind[8];
   int shift[8];
+  int bits[8];
+  long long bias[8];
 };
 
-// order-preserving unsigned image of one element, `width` bytes wide
-__device__ __forceinline__ uint64_t ordered_bits(const void *data, int kind, int64_t i) {
+// order-preserving unsigned image of one float element
+__device__ __forceinline__ uint64_t ordered_float_bits(const void *data, int kind, int64_t i) {
+  if (kind == K_F32) {
+    uint32_t b = ((const uint32_t *)data)[i];
+    if ((b << 1) == 0) b = 0;                                   // -0.0 == +0.0
+    if ((b & 0x7fffffffu) > 0x7f800000u) return 0xffffffffu;    // NaN: after +inf
+    return (b >> 31) ? (uint32_t)~b : (b | 0x80000000u);
+  }
+  uint64_t b = ((const uint64_t *)data)[i];
+  if ((b << 1) == 0) b = 0;
+  if ((b & 0x7fffffffffffffffULL) > 0x7ff0000000000000ULL) return ~0ULL;
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
+}
+__device__ __forceinline__ long long load_signed_kind(const void *data, int kind, int64_t i) {
   switch (kind) {
-    case K_I8: return (uint64_t)(((const uint8_t *)data)[i] ^ 0x80u);
-    case K_I16: return (uint64_t)(((const uint16_t *)data)[i] ^ 0x8000u);
-    case K_I32: return (uint64_t)(((const uint32_t *)data)[i] ^ 0x80000000u);
-    case K_F32: {
-      uint32_t b = ((const uint32_t *)data)[i];
-      if ((b << 1) == 0) b = 0;                                   // -0.0 == +0.0
-      if ((b & 0x7fffffffu) > 0x7f800000u) return 0xffffffffu;    // NaN: after +inf
-      return (b >> 31) ? (uint32_t)~b : (b | 0x80000000u);
+    case K_I8: return ((const int8_t *)data)[i];
+    case K_I16: return ((const int16_t *)data)[i];
+    case K_I32: return ((const int32_t *)data)[i];
+    default: return ((const int64_t *)data)[i];
+  }
+}
+__device__ __forceinline__ uint64_t group_image(const SortGroup &g, int64_t row) {
+  uint64_t k = 0;
+  for (int c = 0; c < g.ncols; ++c) {
+    const uint64_t f = g.bits[c] ? ((uint64_t)(load_signed_kind(g.data[c], g.kind[c], row) - g.bias[c]) &
+                                    (g.bits[c] >= 64 ? ~0ULL : ((1ULL << g.bits[c]) - 1ULL)))
+                                 : ordered_float_bits(g.data[c], g.kind[c], row);
+    k |= f << g.shift[c];
+  }
+  return k;
+}
+
+// per-column minimum / maximum over the rows whose element is valid: out[2c], out[2c+1]
+__global__ __launch_bounds__(256) void rs_minmax(KeyTable t, long long *out) {
+  for (int c = 0; c < t.ncols; ++c) {
+    if (t.col[c].kind == K_F32 || t.col[c].kind == K_F64) continue;
+    long long lo = 0x7fffffffffffffffLL, hi = (long long)0x8000000000000000ULL;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < t.nrows; i += (int64_t)gridDim.x * 256) {
+      if (t.col[c].valid && !bit_is_set(t.col[c].valid, i)) continue;
+      const long long v = load_signed_kind(t.col[c].data, t.col[c].kind, i);
+      lo = v < lo ? v : lo;
+      hi = v > hi ? v : hi;
     }
-    case K_F64: {
-      uint64_t b = ((const uint64_t *)data)[i];
-      if ((b << 1) == 0) b = 0;
-      if ((b & 0x7fffffffffffffffULL) > 0x7ff0000000000000ULL) return ~0ULL;
-      return (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
+    for (int d = 1; d < WAVE; d <<= 1) {
+      const long long l2 = ((long long)__shfl_xor((int)(lo >> 32), d) << 32) | (unsigned int)__shfl_xor((int)lo, d);
+      const long long h2 = ((long long)__shfl_xor((int)(hi >> 32), d) << 32) | (unsigned int)__shfl_xor((int)hi, d);
+      lo = l2 < lo ? l2 : lo;
+      hi = h2 > hi ? h2 : hi;
     }
-    default: return ((const uint64_t *)data)[i] ^ 0x8000000000000000ULL;
+    if (lane_id() == 0) { atomicMin(&out[2 * c], lo); atomicMax(&out[2 * c + 1], hi); }
   }
 }
 
+// host: lo_hi[2c], lo_hi[2c+1] = min / max of integer column c over its valid elements
+// (lo > hi: no valid element); float columns are left at (max, min)
+gdf_error key_ranges(const KeyTable &t, long long *lo_hi) {
+  for (int c = 0; c < t.ncols; ++c) { lo_hi[2 * c] = 0x7fffffffffffffffLL; lo_hi[2 * c + 1] = (long long)0x8000000000000000ULL; }
+  DevBuf mm;
+  RMM_TRY(mm.alloc(sizeof(long long) * 2 * t.ncols));
+  HIP_TRY(hipMemcpyAsync(mm.p, lo_hi, sizeof(long long) * 2 * t.ncols, hipMemcpyHostToDevice, stream0()));
+  GDF_LAUNCH("rs_minmax", rs_minmax, dim3(stream_grid((size_t)t.nrows, 256 * 16)), dim3(256), 0, stream0(), t, mm.as<long long>());
+  HIP_TRY(hipMemcpy(lo_hi, mm.p, sizeof(long long) * 2 * t.ncols, hipMemcpyDeviceToHost));
+  return GDF_SUCCESS;
+}
+
 // perm may alias vals (row numbers are rewritten in place).  *varying collects the bits
-// on which some key differs from key 0: a digit with no varying bit needs no pass.
+// on which some key differs from key 0: a digit window with no varying bit needs no pass.
 __global__ __launch_bounds__(256) void rs_make_keys(SortGroup g, const uint32_t *perm, uint64_t *__restrict__ keys, uint32_t *vals,
                                                     uint32_t n, unsigned long long *__restrict__ varying) {
-  uint64_t k0 = 0, diff = 0;
-  {
-    const uint32_t row0 = perm ? perm[0] : 0;
-    for (int c = 0; c < g.ncols; ++c) k0 |= ordered_bits(g.data[c], g.kind[c], row0) << g.shift[c];
-  }
+  const uint64_t k0 = group_image(g, perm ? perm[0] : 0);
+  uint64_t diff = 0;
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const uint32_t row = perm ? perm[i] : i;
-    uint64_t k = 0;
-    for (int c = 0; c < g.ncols; ++c) k |= ordered_bits(g.data[c], g.kind[c], row) << g.shift[c];
+    const uint64_t k = group_image(g, row);
     keys[i] = k;
     vals[i] = row;
     diff |= k ^ k0;
@@ -112,42 +149,58 @@ __global__ __launch_bounds__(256) void rs_make_keys(SortGroup g, const uint32_t 
   if (lane_id() == 0 && diff) atomicOr(varying, (unsigned long long)diff);
 }
 
+// ---------------------------------------------------------------------------
+// stable LSD radix sort of (uint64 key, V payload) pairs; V = uint32 (row numbers)
+// or uint64 (aggregation values riding with their keys)
+// ---------------------------------------------------------------------------
+constexpr int RS_THREADS = 512;
+constexpr int RS_WAVES = RS_THREADS / WAVE;
+template <class V> struct RsGeom { static constexpr int ITEMS = sizeof(V) == 4 ? 8 : 6; static constexpr int TILE = RS_THREADS * ITEMS; };
+
 // counts[v * ntiles + tile] = number of keys of the tile whose digit is v
+template <int BITS, int TILE>
 __global__ __launch_bounds__(RS_THREADS) void rs_count(const uint64_t *__restrict__ keys, uint32_t n, int shift,
                                                        uint32_t *__restrict__ counts, uint32_t ntiles) {
-  __shared__ uint32_t h[RS_BINS];
-  if (threadIdx.x < RS_BINS) h[threadIdx.x] = 0;
+  constexpr int BINS = 1 << BITS;
+  __shared__ uint32_t h[BINS];
+  for (int j = threadIdx.x; j < BINS; j += RS_THREADS) h[j] = 0;
   block_sync();
-  const uint32_t base = blockIdx.x * RS_TILE;
+  const uint32_t base = blockIdx.x * TILE;
 #pragma unroll
-  for (int r = 0; r < RS_ITEMS; ++r) {
+  for (int r = 0; r < TILE / RS_THREADS; ++r) {
     const uint32_t i = base + r * RS_THREADS + threadIdx.x;
-    if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & 255u], 1u);
+    if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & (BINS - 1)], 1u);
   }
   block_sync();
-  if (threadIdx.x < RS_BINS) counts[threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
+  for (int j = threadIdx.x; j < BINS; j += RS_THREADS) counts[(uint32_t)j * ntiles + blockIdx.x] = h[j];
 }
 
-__global__ __launch_bounds__(RS_THREADS) void rs_scatter(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
-                                                         uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
+template <class V, int BITS>
+__global__ __launch_bounds__(RS_THREADS) void rs_scatter(const uint64_t *__restrict__ keys_in, const V *__restrict__ vals_in,
+                                                         uint64_t *__restrict__ keys_out, V *__restrict__ vals_out,
                                                          uint32_t n, int shift, const uint32_t *__restrict__ offsets,
                                                          uint32_t ntiles) {
-  __shared__ uint64_t skey[RS_TILE];
-  __shared__ uint32_t sval[RS_TILE];
-  __shared__ uint32_t wcnt[RS_WAVES * RS_BINS];   // per-wave digit counts, then exclusive prefix over waves
-  __shared__ uint32_t binstart[RS_BINS];          // first LDS position of a digit
-  __shared__ uint32_t gbase[RS_BINS];             // global position of LDS position 0 of a digit (mod 2^32)
-  __shared__ uint32_t wtot[RS_BINS / WAVE];
+  constexpr int BINS = 1 << BITS;
+  constexpr int ITEMS = RsGeom<V>::ITEMS;
+  constexpr int TILE = RsGeom<V>::TILE;
+  static_assert(BINS <= RS_THREADS, "one thread per bin");
+  __shared__ uint64_t skey[TILE];
+  __shared__ V sval[TILE];
+  __shared__ uint32_t wcnt[RS_WAVES * BINS];   // per-wave digit counts, then exclusive prefix over waves
+  __shared__ uint32_t binstart[BINS];          // first LDS position of a digit
+  __shared__ uint32_t gbase[BINS];             // global position of LDS position 0 of a digit (mod 2^32)
+  __shared__ uint32_t wtot[RS_WAVES];
   const int wave = threadIdx.x / WAVE, lane = lane_id();
-  for (int j = threadIdx.x; j < RS_WAVES * RS_BINS; j += RS_THREADS) wcnt[j] = 0;
+  for (int j = threadIdx.x; j < RS_WAVES * BINS; j += RS_THREADS) wcnt[j] = 0;
   block_sync();
-  const uint32_t tile_base = blockIdx.x * RS_TILE;
-  const uint32_t wbase = tile_base + wave * (RS_ITEMS * WAVE);
+  const uint32_t tile_base = blockIdx.x * TILE;
+  const uint32_t wbase = tile_base + wave * (ITEMS * WAVE);
   const uint32_t last = n - 1;
-  uint64_t key[RS_ITEMS];
-  uint32_t val[RS_ITEMS], rank[RS_ITEMS];
+  uint64_t key[ITEMS];
+  V val[ITEMS];
+  uint32_t rank[ITEMS];
 #pragma unroll
-  for (int r = 0; r < RS_ITEMS; ++r) {       // clamped, unconditional: the loads of a wave stay in flight together
+  for (int r = 0; r < ITEMS; ++r) {       // clamped, unconditional: the loads of a wave stay in flight together
     const uint32_t i = wbase + r * WAVE + lane;
     const uint32_t j = i < n ? i : last;
     key[r] = keys_in[j];
@@ -155,28 +208,28 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter(const uint64_t *__restr
   }
   const unsigned long long lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
 #pragma unroll
-  for (int r = 0; r < RS_ITEMS; ++r) {
+  for (int r = 0; r < ITEMS; ++r) {
     const bool live = wbase + r * WAVE + lane < n;
-    const uint32_t digit = (uint32_t)(key[r] >> shift) & 255u;
+    const uint32_t digit = (uint32_t)(key[r] >> shift) & (BINS - 1);
     unsigned long long peers = __ballot(live);
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
+    for (int b = 0; b < BITS; ++b) {
       const bool bit = (digit >> b) & 1;
       const unsigned long long m = __ballot(bit);
       peers &= bit ? m : ~m;
     }
     const int leader = __ffsll((long long)peers) - 1;   // peers of a dead lane is junk; it is never used
     uint32_t old = 0;
-    if (live && lane == leader) old = atomicAdd(&wcnt[wave * RS_BINS + digit], (uint32_t)__popcll(peers));
+    if (live && lane == leader) old = atomicAdd(&wcnt[wave * BINS + digit], (uint32_t)__popcll(peers));
     old = __shfl(old, live ? leader : lane);
     rank[r] = old + (uint32_t)__popcll(peers & lt);
   }
   block_sync();
   uint32_t total = 0;
-  if (threadIdx.x < RS_BINS) {
+  if (threadIdx.x < BINS) {
     for (int w = 0; w < RS_WAVES; ++w) {
-      const uint32_t c = wcnt[w * RS_BINS + threadIdx.x];
-      wcnt[w * RS_BINS + threadIdx.x] = total;
+      const uint32_t c = wcnt[w * BINS + threadIdx.x];
+      wcnt[w * BINS + threadIdx.x] = total;
       total += c;
     }
     const uint32_t incl = wave_scan_incl(total);
@@ -184,7 +237,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter(const uint64_t *__restr
     binstart[threadIdx.x] = incl - total;        // wave-local for now
   }
   block_sync();
-  if (threadIdx.x < RS_BINS) {
+  if (threadIdx.x < BINS) {
     uint32_t before = 0;
     for (int w = 0; w < wave; ++w) before += wtot[w];
     const uint32_t start = binstart[threadIdx.x] + before;
@@ -193,22 +246,63 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter(const uint64_t *__restr
   }
   block_sync();
 #pragma unroll
-  for (int r = 0; r < RS_ITEMS; ++r) {
+  for (int r = 0; r < ITEMS; ++r) {
     if (wbase + r * WAVE + lane < n) {
-      const uint32_t digit = (uint32_t)(key[r] >> shift) & 255u;
-      const uint32_t pos = binstart[digit] + wcnt[wave * RS_BINS + digit] + rank[r];
+      const uint32_t digit = (uint32_t)(key[r] >> shift) & (BINS - 1);
+      const uint32_t pos = binstart[digit] + wcnt[wave * BINS + digit] + rank[r];
       skey[pos] = key[r];
       sval[pos] = val[r];
     }
   }
   block_sync();
-  const uint32_t count = n - tile_base < (uint32_t)RS_TILE ? n - tile_base : (uint32_t)RS_TILE;
+  const uint32_t count = n - tile_base < (uint32_t)TILE ? n - tile_base : (uint32_t)TILE;
   for (uint32_t j = threadIdx.x; j < count; j += RS_THREADS) {
     const uint64_t k = skey[j];
-    const uint32_t dst = gbase[(uint32_t)(k >> shift) & 255u] + j;
+    const uint32_t dst = gbase[(uint32_t)(k >> shift) & (BINS - 1)] + j;
     keys_out[dst] = k;
     vals_out[dst] = sval[j];
   }
+}
+
+// Sorts n pairs by the key bits set in `varying` (bits on which all keys agree need no
+// pass).  The pairs ping-pong between (kin, vin) and (kout, vout); on return kin / vin
+// point at the sorted data.  The varying bits [lo, hi) are covered by ceil(span / 9)
+// windows of at most 9 bits (8-bit digits for wide keys, 9 when that saves a pass:
+// 25 bits sort in 3 passes); windows may overlap upward, which a stable LSD sort tolerates.
+template <class V>
+gdf_error radix_sort_pairs(uint64_t *&kin, uint64_t *&kout, V *&vin, V *&vout, uint32_t n, uint64_t varying) {
+  if (varying == 0 || n < 2) return GDF_SUCCESS;
+  constexpr int TILE = RsGeom<V>::TILE;
+  const uint32_t ntiles = (n + TILE - 1) / TILE;
+  const int lo = __builtin_ctzll(varying), hi = 64 - __builtin_clzll(varying);
+  const int span = hi - lo;
+  const int passes = (span + 8) / 9;
+  const int bpp = (span + passes - 1) / passes;          // <= 9
+  DevBuf counts;
+  RMM_TRY(counts.alloc(sizeof(uint32_t) * (size_t)ntiles * 512));
+  for (int p = 0; p < passes; ++p) {
+    const int shift = lo + p * bpp;
+    const int bits = bpp > 8 ? 9 : 8;
+    if (((varying >> shift) & ((1ULL << bits) - 1)) == 0) continue;
+    if (bits == 9) {
+      GDF_LAUNCH("rs_count", (rs_count<9, TILE>), dim3(ntiles), dim3(RS_THREADS), 0, stream0(), (const uint64_t *)kin, n, shift, counts.as<uint32_t>(), ntiles);
+      GDF_TRY(scan_u32(counts.as<uint32_t>(), counts.as<uint32_t>(), (size_t)ntiles * 512, false));
+      GDF_LAUNCH("rs_scatter", (rs_scatter<V, 9>), dim3(ntiles), dim3(RS_THREADS), 0, stream0(), (const uint64_t *)kin, (const V *)vin, kout, vout, n,
+                 shift, (const uint32_t *)counts.as<uint32_t>(), ntiles);
+    } else {
+      GDF_LAUNCH("rs_count", (rs_count<8, TILE>), dim3(ntiles), dim3(RS_THREADS), 0, stream0(), (const uint64_t *)kin, n, shift, counts.as<uint32_t>(), ntiles);
+      GDF_TRY(scan_u32(counts.as<uint32_t>(), counts.as<uint32_t>(), (size_t)ntiles * 256, false));
+      GDF_LAUNCH("rs_scatter", (rs_scatter<V, 8>), dim3(ntiles), dim3(RS_THREADS), 0, stream0(), (const uint64_t *)kin, (const V *)vin, kout, vout, n,
+                 shift, (const uint32_t *)counts.as<uint32_t>(), ntiles);
+    }
+    std::swap(kin, kout);
+    std::swap(vin, vout);
+  }
+  HIP_CHECK_LAST();
+  return GDF_SUCCESS;
+}
+gdf_error radix_sort_pairs_u64(uint64_t *&kin, uint64_t *&kout, uint64_t *&vin, uint64_t *&vout, uint32_t n, uint64_t varying) {
+  return radix_sort_pairs<uint64_t>(kin, kout, vin, vout, n, varying);
 }
 
 __global__ __launch_bounds__(256) void rs_iota(uint32_t *p, uint32_t n) {
@@ -218,44 +312,63 @@ __global__ __launch_bounds__(256) void rs_widen(const uint32_t *__restrict__ in,
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) out[i] = in[i];
 }
 
+static int bit_length(uint64_t v) { return v ? 64 - __builtin_clzll(v) : 0; }
+
 // Sorted row permutation of table t (ascending, lexicographic, stable).  On return
 // perm holds n uint32 row numbers; if sorted_keys is non-null and the whole key fitted
 // one integer-only image, *sorted_keys keeps the sorted images (adjacent-equal test
 // without gathers) and *keys_exact is set.
 gdf_error order_rows(const KeyTable &t, uint32_t n, DevBuf &perm, DevBuf *sorted_keys, bool *keys_exact) {
   if (keys_exact) *keys_exact = false;
-  // column groups, last columns first
+  // image width of every column: integers (value - min) in bit_length(max - min) bits, floats full width
+  std::vector<long long> lo_hi(2 * t.ncols);
+  bool any_float = false, any_int = false;
+  for (int c = 0; c < t.ncols; ++c) {
+    const bool f = (t.col[c].kind == K_F32 || t.col[c].kind == K_F64);
+    any_float |= f;
+    any_int |= !f;
+  }
+  KeyTable tn = t;
+  tn.nrows = n;
+  if (any_int) GDF_TRY(key_ranges(tn, lo_hi.data()));
+  std::vector<int> width(t.ncols);
+  for (int c = 0; c < t.ncols; ++c) {
+    if (t.col[c].kind == K_F32 || t.col[c].kind == K_F64) { width[c] = t.col[c].width * 8; continue; }
+    if (lo_hi[2 * c] > lo_hi[2 * c + 1]) lo_hi[2 * c] = lo_hi[2 * c + 1] = 0;
+    width[c] = bit_length((uint64_t)lo_hi[2 * c + 1] - (uint64_t)lo_hi[2 * c]);
+    if (width[c] == 0) width[c] = 1;                       // a constant column still owns one (never varying) bit
+  }
+  // column groups of <= 64 image bits, last columns first (LSD over groups)
   std::vector<SortGroup> groups;
   {
     int c = t.ncols - 1;
     while (c >= 0) {
       SortGroup g{};
-      int bytes = 0, first = c;
-      while (first >= 0 && bytes + t.col[first].width <= 8 && c - first < 8) { bytes += t.col[first].width; --first; }
+      int bits = 0, first = c;
+      while (first >= 0 && bits + width[first] <= 64 && c - first < 8) { bits += width[first]; --first; }
       ++first;
-      int shift = bytes * 8;
+      int shift = bits;
       for (int k = first; k <= c; ++k) {
-        shift -= t.col[k].width * 8;
+        shift -= width[k];
+        const bool f = (t.col[k].kind == K_F32 || t.col[k].kind == K_F64);
         g.data[g.ncols] = t.col[k].data;
         g.kind[g.ncols] = t.col[k].kind;
         g.shift[g.ncols] = shift;
+        g.bits[g.ncols] = f ? 0 : width[k];
+        g.bias[g.ncols] = f ? 0 : lo_hi[2 * k];
         ++g.ncols;
       }
       groups.push_back(g);
       c = first - 1;
     }
   }
-  bool any_float = false;
-  for (int c = 0; c < t.ncols; ++c) any_float |= (t.col[c].kind == K_F32 || t.col[c].kind == K_F64);
 
-  DevBuf ka, kb, va, vb, counts, ghist;
+  DevBuf ka, kb, va, vb, vary;
   RMM_TRY(ka.alloc(sizeof(uint64_t) * (size_t)n));
   RMM_TRY(kb.alloc(sizeof(uint64_t) * (size_t)n));
   RMM_TRY(va.alloc(sizeof(uint32_t) * (size_t)n));
   RMM_TRY(vb.alloc(sizeof(uint32_t) * (size_t)n));
-  const uint32_t ntiles = (n + RS_TILE - 1) / RS_TILE;
-  RMM_TRY(counts.alloc(sizeof(uint32_t) * (size_t)ntiles * RS_BINS));
-  RMM_TRY(ghist.alloc(sizeof(unsigned long long)));
+  RMM_TRY(vary.alloc(sizeof(unsigned long long)));
   uint64_t *kin = ka.as<uint64_t>(), *kout = kb.as<uint64_t>();
   uint32_t *vin = va.as<uint32_t>(), *vout = vb.as<uint32_t>();
   const int sgrid = stream_grid(n, 256 * 8);
@@ -263,22 +376,14 @@ gdf_error order_rows(const KeyTable &t, uint32_t n, DevBuf &perm, DevBuf *sorted
   for (size_t gi = 0; gi < groups.size(); ++gi) {
     // after the first group the current permutation lives in vin; keys are rebuilt in kin
     // reading it, and the row numbers are rewritten in place (vals[i] = perm[i])
-    HIP_TRY(hipMemsetAsync(ghist.p, 0, sizeof(unsigned long long), stream0()));
+    HIP_TRY(hipMemsetAsync(vary.p, 0, sizeof(unsigned long long), stream0()));
     GDF_LAUNCH("rs_make_keys", rs_make_keys, dim3(sgrid), dim3(256), 0, stream0(), groups[gi],
-               have_perm ? (const uint32_t *)vin : (const uint32_t *)nullptr, kin, vin, n, ghist.as<unsigned long long>());
+               have_perm ? (const uint32_t *)vin : (const uint32_t *)nullptr, kin, vin, n, vary.as<unsigned long long>());
     have_perm = true;
     unsigned long long varying = 0;
-    HIP_TRY(hipMemcpyAsync(&varying, ghist.p, sizeof(varying), hipMemcpyDeviceToHost, stream0()));
+    HIP_TRY(hipMemcpyAsync(&varying, vary.p, sizeof(varying), hipMemcpyDeviceToHost, stream0()));
     HIP_TRY(hipStreamSynchronize(stream0()));
-    for (int d = 0; d < RS_DIGITS; ++d) {
-      if (((varying >> (8 * d)) & 255ULL) == 0) continue;      // every key has the same digit d
-      GDF_LAUNCH("rs_count", rs_count, dim3(ntiles), dim3(RS_THREADS), 0, stream0(), kin, n, 8 * d, counts.as<uint32_t>(), ntiles);
-      GDF_TRY(scan_u32(counts.as<uint32_t>(), counts.as<uint32_t>(), (size_t)ntiles * RS_BINS, false));
-      GDF_LAUNCH("rs_scatter", rs_scatter, dim3(ntiles), dim3(RS_THREADS), 0, stream0(), kin, vin, kout, vout, n, 8 * d,
-                 counts.as<uint32_t>(), ntiles);
-      std::swap(kin, kout);
-      std::swap(vin, vout);
-    }
+    GDF_TRY(radix_sort_pairs<uint32_t>(kin, kout, vin, vout, n, varying));
   }
   HIP_CHECK_LAST();
   HIP_TRY(hipStreamSynchronize(stream0()));

@@ -136,6 +136,35 @@ def group_by(op, keys, values, out_dtype=None):
     return [k[:g] for k in out_keys], out_agg[:g]
 
 
+# ---- validity-mask aware group-by (beyond the reference; BASELINE config C5) -------------
+def group_by_masked(op, keys, values, key_valids=None, value_valid=None, out_dtype=None):
+    """(sorted key arrays, aggregate, aggregate-valid bools) with pandas ``dropna=True`` semantics: rows with a
+    null in any key column are dropped; null values are skipped; a group without a valid value reports 0 and
+    valid=False (COUNT reports 0 and valid=True).  The arithmetic per group is the reference's
+    (group_by above): aggregation in the input dtype, AVG = sum / (out dtype)count."""
+    keys = _contig(keys)
+    values = np.ascontiguousarray(values)
+    n = len(values)
+    kv = np.ones(n, dtype=bool)
+    for v in (key_valids or []):
+        if v is not None:
+            kv &= np.asarray(v, dtype=bool)
+    vv = kv if value_valid is None else (kv & np.asarray(value_valid, dtype=bool))
+    all_keys, _ = group_by("count", [k[kv] for k in keys], values[kv], np.int64)
+    sub_keys, sub_agg = group_by(op, [k[vv] for k in keys], values[vv], out_dtype)
+    g = len(all_keys[0])
+    agg = np.zeros(g, dtype=sub_agg.dtype)
+    ok = np.zeros(g, dtype=bool)
+    where = {tuple(k[i].item() for k in all_keys): i for i in range(g)}
+    for j in range(len(sub_agg)):
+        i = where[tuple(k[j].item() for k in sub_keys)]
+        agg[i] = sub_agg[j]
+        ok[i] = True
+    if op == "count":
+        ok[:] = True
+    return all_keys, agg, ok
+
+
 # ---- SORT method (sqls_ops.cu:1134-1289, 1373-1392; sqls_rtti_comp.hpp:299-320, 397-662) --------------
 def order_by(cols) -> np.ndarray:
     """Row permutation that orders the rows lexicographically by (cols[0], cols[1], ...) with typed ``<``

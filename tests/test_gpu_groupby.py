@@ -164,10 +164,98 @@ def test_known_answer_vectors(gdf):
         assert list(ga) == case["expected"], case["ref"]
 
 
-def test_validity_rejected_like_the_reference(gdf):
-    from libgdf_amd import GDFError
+def test_all_valid_masks_change_nothing(gdf):
+    """The reference rejects masks (sqls_ops.cu:1103-1106); here an all-ones mask gives the unmasked answer."""
     from libgdf_amd.columns import column_from_numpy
-    k = column_from_numpy(gen_rand(np.int32, 100), np.ones(100, dtype=bool))
-    v = column_from_numpy(gen_rand(np.int32, 100))
-    with pytest.raises(GDFError, match="GDF_VALIDITY_UNSUPPORTED"):
-        gdf.api.group_by("sum", [k], v)
+    k, v = gen_rand(np.int32, 1000, 0, 30), gen_rand(np.int32, 1000)
+    gk, ga = gdf.api.group_by("sum", [column_from_numpy(k, np.ones(1000, dtype=bool))], column_from_numpy(v, np.ones(1000, dtype=bool)))
+    gk, ga = sort_groups([x.cpu().numpy() for x in gk], ga.cpu().numpy())
+    ek, ea = oracle.group_by("sum", [k], v)
+    np.testing.assert_array_equal(gk[0], ek[0])
+    np.testing.assert_array_equal(ga, ea)
+
+
+# ---- validity masks (BASELINE config C5; beyond the reference, which rejects every mask) ------------------------
+def _check_masked(gdf, op, keys, vals, key_valids, val_valid, out_dtype=None, sort_result=False):
+    from libgdf_amd.columns import column_from_numpy, get_dtype
+    kc = [column_from_numpy(k, v) for k, v in zip(keys, key_valids)]
+    vc = column_from_numpy(vals, val_valid)
+    od = None if out_dtype is None else get_dtype(out_dtype)
+    gk, ga, gok = gdf.api.group_by(op, kc, vc, out_dtype=od, sort_result=sort_result, with_masks=True)
+    gk, ga, gok = [x.cpu().numpy() for x in gk], ga.cpu().numpy(), gok.numpy()
+    ek, ea, eok = oracle.group_by_masked(op, keys, vals, key_valids, val_valid, out_dtype)
+    if not (sort_result or op == "avg"):
+        order = np.lexsort(tuple(reversed(gk)))
+        gk, ga, gok = [k[order] for k in gk], ga[order], gok[order]
+    assert len(ga) == len(ea)
+    for g, e in zip(gk, ek):
+        np.testing.assert_array_equal(g, e)
+    np.testing.assert_array_equal(gok, eok)
+    assert (ga[~gok] == 0).all()
+    if op in ("sum", "avg") and np.asarray(vals).dtype.kind == "f":
+        np.testing.assert_allclose(ga[gok].astype(np.float64), ea[eok].astype(np.float64), rtol=1e-6, atol=1e-9)
+    else:
+        np.testing.assert_array_equal(ga[gok], ea[eok])
+
+
+@pytest.mark.parametrize("op", OPS)
+@pytest.mark.parametrize("val_dtype", [np.int32, np.int64, np.float32, np.float64], ids=lambda d: np.dtype(d).name)
+def test_masked_values_and_keys(gdf, op, val_dtype):
+    n = 50000
+    k0 = gen_rand(np.int64, n, 0, 300)
+    k1 = gen_rand(np.int32, n, 0, 5)
+    vals = gen_rand(val_dtype, n, 0, 100) if np.dtype(val_dtype).kind == "i" else gen_rand(val_dtype, n, positive_only=True)
+    k0_ok = np.random.random(n) > 0.01
+    v_ok = np.random.random(n) > 0.5
+    v_ok[k0 < 6] = False                                         # all-null groups
+    out = np.int64 if op == "count" else (np.float64 if op == "avg" else None)
+    _check_masked(gdf, op, [k0, k1], vals, [k0_ok, None], v_ok, out)
+    _check_masked(gdf, op, [k0, k1], vals, [None, None], v_ok, out, sort_result=True)
+    _check_masked(gdf, op, [k0], vals, [k0_ok], None, out)
+
+
+@pytest.mark.parametrize("op", ["sum", "avg", "min"])
+def test_masked_many_groups_general_path(gdf, op):
+    """More groups than the LDS-accumulator path holds (16384): the global-table path with masks."""
+    n = 400000
+    k0 = gen_rand(np.int64, n, 0, 50000)
+    k1 = gen_rand(np.int32, n, 0, 3)
+    vals = gen_rand(np.float64, n, positive_only=True)
+    v_ok = np.random.random(n) > 0.5
+    k1_ok = np.random.random(n) > 0.01
+    _check_masked(gdf, op, [k0, k1], vals, [None, k1_ok], v_ok, np.float64 if op == "avg" else None)
+
+
+def test_masked_float_keys_first_row_path(gdf):
+    n = 30000
+    k = np.round(gen_rand(np.float64, n) * 40)
+    vals = gen_rand(np.int64, n)
+    _check_masked(gdf, "sum", [k], vals, [np.random.random(n) > 0.1], np.random.random(n) > 0.3)
+
+
+def test_all_rows_null(gdf):
+    n = 1000
+    k = gen_rand(np.int32, n, 0, 10)
+    v = gen_rand(np.int32, n)
+    _check_masked(gdf, "sum", [k], v, [np.zeros(n, dtype=bool)], None)        # every key null: no groups
+    _check_masked(gdf, "max", [k], v, [None], np.zeros(n, dtype=bool))          # every value null: groups, all null
+
+
+@pytest.mark.parametrize("op", OPS)
+def test_wide_integer_keys_pack_by_range(gdf, op):
+    """(int64, int32, int16) is 14 bytes of key: packed as (value - min) bit fields after a min/max pass."""
+    n = 60000
+    keys = [gen_rand(np.int64, n, -20, 20) + (1 << 40), gen_rand(np.int32, n, -3, 3), gen_rand(np.int16, n, 100, 104)]
+    vals = gen_rand(np.int64, n)
+    _check(gdf, op, keys, vals, np.int64 if op == "count" else (np.float64 if op == "avg" else None))
+    spread = [np.random.randint(-2**62, 2**62, n, dtype=np.int64), gen_rand(np.int32, n, -3, 3)]   # does not fit 63 bits
+    spread[0][::3] = spread[0][0]
+    _check(gdf, op, spread, vals, np.int64 if op == "count" else (np.float64 if op == "avg" else None))
+
+
+def test_sort_method_still_rejects_masks(gdf):
+    from libgdf_amd import GDFError
+    from libgdf_amd.columns import GDF_SORT, column_from_numpy
+    k = gen_rand(np.int32, 10)
+    with pytest.raises(GDFError, match="GDF_VALIDITY_UNSUPPORTED"):            # sqls_ops.cu:1103-1106
+        gdf.api.group_by("sum", [column_from_numpy(k, np.ones(10, dtype=bool))], column_from_numpy(k), method=GDF_SORT)

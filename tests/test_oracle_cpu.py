@@ -89,3 +89,32 @@ def test_comparison_uses_c_promotions():
     # int64 vs float32 compares in float32: 2^24+1 rounds to 2^24 -> "equal"
     assert list(oracle.comparison(l, r, 0)) == [1, 1]
     assert list(oracle.comparison(np.array([1, 2, 3], dtype=np.int8), np.int32(2), 2)) == [1, 0, 0]     # correct '<'
+
+
+@pytest.mark.parametrize("op", ["sum", "min", "max", "avg", "count"])
+def test_masked_group_by_semantics_match_pandas(op):
+    """BASELINE config C5: rows with a null key are dropped, null values are skipped, an
+    all-null group is reported as null -- pandas' ``groupby(dropna=True)`` is the stated oracle."""
+    import pandas as pd
+    n = 4000
+    k0 = np.random.randint(0, 40, n).astype(np.int64)
+    k1 = np.random.randint(0, 4, n).astype(np.int32)
+    v = np.random.random(n)
+    k0_ok = np.random.random(n) > 0.05
+    v_ok = np.random.random(n) > 0.5
+    v_ok[k0 == 7] = False                                      # some groups without a single valid value
+    keys, agg, ok = oracle.group_by_masked(op, [k0, k1], v, [k0_ok, None], v_ok, np.float64 if op == "avg" else (np.int64 if op == "count" else None))
+    df = pd.DataFrame({"k0": pd.array(np.where(k0_ok, k0, 0), dtype="Int64"), "k1": k1, "v": np.where(v_ok, v, np.nan)})
+    df.loc[~k0_ok, "k0"] = pd.NA
+    gb = df.groupby(["k0", "k1"], dropna=True)["v"]
+    exp = {"sum": gb.sum(min_count=1), "min": gb.min(), "max": gb.max(), "avg": gb.mean(), "count": gb.count()}[op]
+    exp = exp.sort_index()
+    np.testing.assert_array_equal(keys[0], exp.index.get_level_values(0).to_numpy(dtype=np.int64))
+    np.testing.assert_array_equal(keys[1], exp.index.get_level_values(1).to_numpy(dtype=np.int32))
+    if op == "count":
+        np.testing.assert_array_equal(agg, exp.to_numpy())
+        assert ok.all()
+    else:
+        np.testing.assert_array_equal(ok, ~np.isnan(exp.to_numpy()))
+        np.testing.assert_allclose(agg[ok], exp.to_numpy()[ok], rtol=1e-12)
+        assert (agg[~ok] == 0).all() and (~ok).sum() >= 4

@@ -116,12 +116,13 @@ def test_host_side_argument_errors_need_no_gpu(libs):
     assert gdf.gdf_prefixsum_i32(C.byref(a), C.byref(b), 1) == 2                                      # GDF_UNSUPPORTED_DTYPE
     b.dtype, a.valid = 3, 0x10
     assert gdf.gdf_prefixsum_i32(C.byref(a), C.byref(b), 1) == 7                                      # GDF_VALIDITY_UNSUPPORTED
-    # group-by rejects valid masks before touching the device
+    # the SORT group-by rejects valid masks before touching the device (sqls_ops.cu:1103-1106); the HASH method
+    # accepts them (BASELINE config C5), see tests/test_gpu_groupby.py
     key, agg, out = gdf_column(), gdf_column(), gdf_column()
     key.size = agg.size = 3
     key.valid = 0x10
     ctx = gdf_context()
-    ctx.flag_method = 1
+    ctx.flag_method = 0
     keys = (C.POINTER(gdf_column) * 1)(C.pointer(key))
     assert gdf.gdf_group_by_sum(1, keys, C.byref(agg), None, keys, C.byref(out), C.byref(ctx)) == 7
     # joins: INT_MAX rows is refused (tests/join/join-tests.cu:750-760)

@@ -47,6 +47,8 @@ enum GbOp : int { OP_SUM = 0, OP_MIN, OP_MAX, OP_AVG, OP_COUNT, OP_COUNT_DISTINC
 // 1e6 x 16 distinct values packs into 24 bits this way and keeps the LDS / dense paths.
 struct GbKeyPlan {
   int packed;                  // 1: exact 64-bit packed key, 0: first-row table + rows_equal
+  int ordered;                 // 1: unsigned order of the packed key == lexicographic typed order of the rows
+  int total_bits;
   int shift[MAX_KEY_COLS];
   int bits[MAX_KEY_COLS];
   int64_t bias[MAX_KEY_COLS];
@@ -64,6 +66,7 @@ static GbKeyPlan gb_plan_keys(const KeyTable &t) {
     total += t.col[c].width;
   }
   p.packed = (all_int && total <= 8) ? 1 : 0;
+  p.total_bits = total * 8;
   return p;
 }
 
@@ -133,9 +136,10 @@ __device__ __forceinline__ int64_t load_int(const GbVal &v, int64_t i) {
 __device__ __forceinline__ double load_flt(const GbVal &v, int64_t i) {
   return v.kind == K_F32 ? (double)((const float *)v.data)[i] : ((const double *)v.data)[i];
 }
-__device__ __forceinline__ bool is_flt(int kind) { return kind == K_F32 || kind == K_F64; }
+__host__ __device__ __forceinline__ bool is_flt(int kind) { return kind == K_F32 || kind == K_F64; }
 
-__device__ __forceinline__ uint64_t acc_identity(int op) { return op == OP_MIN ? ~0ULL : 0ULL; }
+__host__ __device__ __forceinline__ uint64_t acc_identity(int op) { return op == OP_MIN ? ~0ULL : 0ULL; }
+static inline uint64_t acc_identity_host(int op) { return op == OP_MIN ? ~0ULL : 0ULL; }
 
 // image of row i's value that is folded into the accumulator
 __device__ __forceinline__ uint64_t acc_image(int op, const GbVal &v, int64_t i) {
@@ -519,24 +523,23 @@ struct GbDict {
   uint32_t limit;
 };
 
-__device__ __forceinline__ bool dict_insert(const GbDict &d, uint64_t key) {
-  if (key == GB_EMPTY_KEY) { *d.special = 1u; return true; }
+// returns 0: gave up (table overflowed), 1: key present, 2: key newly inserted (the caller counts these,
+// one atomic per wave instead of one per key)
+__device__ __forceinline__ int dict_insert(const GbDict &d, uint64_t key) {
+  if (key == GB_EMPTY_KEY) { *d.special = 1u; return 1; }
   uint32_t slot = (uint32_t)(mix64(key) >> 32) & (d.T - 1);
   for (uint32_t probes = 0; probes < d.T; ++probes) {
-    if ((probes & 63u) == 63u && *(volatile unsigned int *)d.overflow) return false;
+    if ((probes & 7u) == 7u && *(volatile unsigned int *)d.overflow) return 0;
     const unsigned long long cur = d.e[slot].key;
-    if (cur == key) return true;
+    if (cur == key) return 1;
     if (cur == GB_EMPTY_KEY) {
       const unsigned long long old = atomicCAS(&d.e[slot].key, (unsigned long long)GB_EMPTY_KEY, (unsigned long long)key);
-      if (old == GB_EMPTY_KEY) {
-        if (atomicAdd(d.occupied, 1u) >= d.limit) atomicExch(d.overflow, 1u);
-        return true;
-      }
-      if (old == key) return true;
+      if (old == GB_EMPTY_KEY) return 2;
+      if (old == key) return 1;
     }
     slot = (slot + 1) & (d.T - 1);
   }
-  return false;
+  return 0;
 }
 
 // FASTKEY: one 8-byte integer key column -> the key IS the column word, loaded without any branch.
@@ -570,9 +573,16 @@ __global__ __launch_bounds__(GB_DICT_THREADS) void gb_dict_build(KeyTable t, GbK
     unsigned long long home[GB_DENSE_BATCH];
 #pragma unroll
     for (int k = 0; k < GB_DENSE_BATCH; ++k) home[k] = g.e[(uint32_t)(mix64(key[k]) >> 32) & (g.T - 1)].key;
+    unsigned int fresh = 0;
 #pragma unroll
     for (int k = 0; k < GB_DENSE_BATCH; ++k)
-      if (!skip[k] && (home[k] != key[k] || key[k] == GB_EMPTY_KEY) && !dict_insert(g, key[k])) atomicExch(g.overflow, 1u);
+      if (!skip[k] && (home[k] != key[k] || key[k] == GB_EMPTY_KEY)) {
+        const int r = dict_insert(g, key[k]);
+        if (r == 0) atomicExch(g.overflow, 1u);
+        fresh += (r == 2);
+      }
+    fresh = wave_reduce_add(fresh);
+    if (lane_id() == 0 && fresh && atomicAdd(g.occupied, fresh) + fresh > g.limit) atomicExch(g.overflow, 1u);
   }
 }
 
@@ -768,15 +778,147 @@ static gdf_error gb_plan_range(const KeyTable &t, GbKeyPlan *plan) {
     const uint64_t span = (uint64_t)hi - (uint64_t)lo;
     int bits = 0;
     while (bits < 64 && (span >> bits) != 0) ++bits;
-    p.shift[c] = total;
     p.bits[c] = bits;
     p.bias[c] = lo;
     total += bits;
-    if (total > 63) return GDF_SUCCESS;                       // does not fit: keep the first-row table
+    if (total > 63) return GDF_SUCCESS;                       // does not fit: keep what the caller had
   }
+  for (int c = 0, below = total; c < t.ncols; ++c) { below -= p.bits[c]; p.shift[c] = below; }   // column 0 on top
   p.packed = 1;                                               // <= 63 bits: the reserved key 1 << 63 cannot occur
+  p.ordered = 1;
+  p.total_bits = total;
   *plan = p;
   return GDF_SUCCESS;
+}
+
+// ---------------------------------------------------------------------------
+// sorted path (packed keys, MANY groups -- C5 has ~1.6e7): a global hash table of that
+// size lives in HBM and every row pays dependent random atomics on it (measured:
+// 85 ms per 1e8 rows at 1e7 groups).  Instead the (packed key, value image) pairs are
+// radix sorted on the few key bits the range layout needs (C5: 25 bits = 3 passes of
+// streaming HBM traffic) and reduced by segments; nothing is random-access.
+//   key     = packed << vbit | value_valid      (vbit = 1 only when the value column has a mask;
+//             a row with a null key gets the bit just above the packed field and sorts behind every real key)
+//   payload = accumulator image of the value (identity if the value is null)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gb_sorted_make_pairs(KeyTable t, GbKeyPlan plan, GbVal val, int fold_op, int vbit,
+                                                            uint64_t null_key, uint64_t *__restrict__ keys, uint64_t *__restrict__ payload,
+                                                            unsigned long long *__restrict__ varying, unsigned int *__restrict__ dropped) {
+  uint64_t diff = 0;
+  unsigned int drop = 0;
+  const uint64_t k0 = gb_pack(t, plan, 0) << vbit;      // any common reference value serves the OR-reduction
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < t.nrows; i += (int64_t)gridDim.x * 256) {
+    uint64_t k, p;
+    if (!row_valid(t, i)) { k = null_key; p = 0; ++drop; }
+    else {
+      const bool vok = !val.valid || bit_is_set(val.valid, i);
+      k = (gb_pack(t, plan, i) << vbit) | (uint64_t)(vbit && vok);
+      p = vok ? acc_image(fold_op, val, i) : acc_identity(fold_op);
+    }
+    keys[i] = k;
+    payload[i] = p;
+    diff |= k ^ k0;
+  }
+  for (int d = 1; d < WAVE; d <<= 1) {
+    const uint32_t lo = __shfl_xor((uint32_t)diff, d), hi = __shfl_xor((uint32_t)(diff >> 32), d);
+    diff |= ((uint64_t)hi << 32) | lo;
+  }
+  drop = wave_reduce_add(drop);
+  if (lane_id() == 0) {
+    if (diff) atomicOr(varying, (unsigned long long)diff);
+    if (drop) atomicAdd(dropped, drop);
+  }
+}
+
+__global__ __launch_bounds__(256) void gb_sorted_heads(const uint64_t *__restrict__ keys, int vbit, uint32_t *__restrict__ head, uint32_t n) {
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+    head[i] = (i == 0 || (keys[i] >> vbit) != (keys[i - 1] >> vbit)) ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void gb_sorted_starts(const uint32_t *__restrict__ gid, uint32_t *__restrict__ start, uint32_t n, uint32_t ngroups) {
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+    if (i == 0 || gid[i] != gid[i - 1]) start[gid[i] - 1] = i;
+  if (blockIdx.x == 0 && threadIdx.x == 0) start[ngroups] = n;
+}
+
+__device__ __forceinline__ uint64_t img_merge(int op, bool flt, uint64_t a, uint64_t b) {
+  if (op == OP_MIN) return a < b ? a : b;
+  if (op == OP_MAX) return a > b ? a : b;
+  if (flt && op != OP_COUNT) return (uint64_t)__double_as_longlong(__longlong_as_double((long long)a) + __longlong_as_double((long long)b));
+  return a + b;
+}
+__device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int d) {
+  return ((uint64_t)__shfl_up((uint32_t)(v >> 32), d) << 32) | __shfl_up((uint32_t)v, d);
+}
+__device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int l) {
+  return ((uint64_t)__shfl((uint32_t)(v >> 32), l) << 32) | __shfl((uint32_t)v, l);
+}
+
+// acc[g] (and cnt[g] = number of valid values, COUNTED) over the sorted pairs: every wave walks
+// 64 x GB_SEG_ROUNDS consecutive pairs; per round a segmented shuffle scan on the group id folds the
+// lanes of one group, closed segments leave with one atomic, the open one rides in registers.
+constexpr int GB_SEG_ROUNDS = 16;
+template <bool COUNTED>
+__global__ __launch_bounds__(256) void gb_sorted_reduce(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ payload,
+                                                        const uint32_t *__restrict__ gid, int op, bool flt,
+                                                        unsigned long long *__restrict__ acc, unsigned long long *__restrict__ cnt,
+                                                        uint32_t n) {
+  const int lane = lane_id();
+  const uint64_t begin = ((uint64_t)blockIdx.x * 4 + threadIdx.x / WAVE) * (uint64_t)(WAVE * GB_SEG_ROUNDS);
+  if (begin >= n) return;
+  uint32_t carry_gid = 0, carry_c = 0;      // gid 0 = no open segment (ids are 1-based)
+  uint64_t carry = 0;
+  for (int r = 0; r < GB_SEG_ROUNDS; ++r) {
+    if (begin + (uint64_t)r * WAVE >= n) break;                 // wave-uniform
+    const uint64_t i = begin + (uint64_t)r * WAVE + lane;
+    const bool live = i < n;
+    const uint32_t j = live ? (uint32_t)i : n - 1;
+    const uint32_t g = live ? gid[j] : 0xffffffffu;             // dead lanes form their own trailing segment
+    uint64_t v = payload[j];
+    uint32_t c = COUNTED ? (uint32_t)(keys[j] & 1ULL) : 0u;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+      const uint64_t uv = shfl_up_u64(v, d);
+      const uint32_t ug = __shfl_up(g, d);
+      const uint32_t uc = COUNTED ? __shfl_up(c, d) : 0u;
+      if (lane >= d && ug == g) { v = img_merge(op, flt, v, uv); c += uc; }
+    }
+    const uint32_t gnext = __shfl_down(g, 1);
+    const bool tail = (lane == WAVE - 1) || (gnext != g);
+    const uint32_t g0 = __shfl(g, 0);
+    if (carry_gid != 0 && carry_gid != g0) {                    // the open segment ended with the previous round
+      if (lane == 0) {
+        acc_fold(op, flt && op != OP_COUNT, &acc[carry_gid - 1], carry);
+        if (COUNTED && carry_c) atomicAdd(&cnt[carry_gid - 1], (unsigned long long)carry_c);
+      }
+      carry_gid = 0;
+    }
+    if (tail && carry_gid != 0 && g == carry_gid) { v = img_merge(op, flt, v, carry); c += carry_c; }
+    const uint32_t glast = __shfl(g, WAVE - 1);
+    const uint64_t vlast = shfl_u64(v, WAVE - 1);
+    const uint32_t clast = COUNTED ? __shfl(c, WAVE - 1) : 0u;
+    if (tail && live && lane != WAVE - 1) {
+      acc_fold(op, flt && op != OP_COUNT, &acc[g - 1], v);
+      if (COUNTED && c) atomicAdd(&cnt[g - 1], (unsigned long long)c);
+    }
+    if (glast != 0xffffffffu) { carry_gid = glast; carry = vlast; carry_c = clast; }
+    else carry_gid = 0;
+  }
+  if (carry_gid != 0 && lane == 0) {
+    acc_fold(op, flt && op != OP_COUNT, &acc[carry_gid - 1], carry);
+    if (COUNTED && carry_c) atomicAdd(&cnt[carry_gid - 1], (unsigned long long)carry_c);
+  }
+}
+
+__global__ __launch_bounds__(256) void gb_sorted_extract(KeyTable t, GbKeyPlan plan, const uint64_t *__restrict__ keys, int vbit,
+                                                         const uint32_t *__restrict__ start, uint32_t ngroups, GbOut o, int op,
+                                                         const unsigned long long *__restrict__ acc,
+                                                         const unsigned long long *__restrict__ cnt) {
+  for (uint32_t g = blockIdx.x * 256 + threadIdx.x; g < ngroups; g += gridDim.x * 256) {
+    const uint32_t s = start[g], e = start[g + 1];
+    const uint64_t key = keys[s] >> vbit;
+    for (int c = 0; c < t.ncols; ++c) gb_unpack_store(t, plan, key, c, o.key_out[c], g);
+    store_result(o, op, g, acc[g], cnt ? cnt[g] : (unsigned long long)(e - s));
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -847,12 +989,27 @@ static gdf_error group_by_hash(int ncols, gdf_column **cols, gdf_column *col_agg
     GDF_LAUNCH("gb_fill", gb_dict_clear, dim3(stream_grid(T + 1, 256 * 8)), dim3(256), 0, stream0(), g.e, (uint32_t)(T + 1));
     const int bgrid = stream_grid((size_t)n, GB_DICT_THREADS * GB_DENSE_BATCH * 4, NUM_CU * 8);
     const int64_t bchunk = (((n + bgrid - 1) / bgrid) + GB_DICT_THREADS - 1) / GB_DICT_THREADS * GB_DICT_THREADS;
-    if (fastkey) GDF_LAUNCH("gb_dict_build", (gb_dict_build<true, false>), dim3(bgrid), dim3(GB_DICT_THREADS), 0, stream0(), t, plan, g, bchunk);
-    else if (!t.any_valid) GDF_LAUNCH("gb_dict_build", (gb_dict_build<false, false>), dim3(bgrid), dim3(GB_DICT_THREADS), 0, stream0(), t, plan, g, bchunk);
-    else GDF_LAUNCH("gb_dict_build", (gb_dict_build<false, true>), dim3(bgrid), dim3(GB_DICT_THREADS), 0, stream0(), t, plan, g, bchunk);
-    HIP_CHECK_LAST();
+    auto dict_build = [&](const KeyTable &tt, int grid_, int64_t chunk_) -> gdf_error {
+      if (fastkey) GDF_LAUNCH("gb_dict_build", (gb_dict_build<true, false>), dim3(grid_), dim3(GB_DICT_THREADS), 0, stream0(), tt, plan, g, chunk_);
+      else if (!t.any_valid) GDF_LAUNCH("gb_dict_build", (gb_dict_build<false, false>), dim3(grid_), dim3(GB_DICT_THREADS), 0, stream0(), tt, plan, g, chunk_);
+      else GDF_LAUNCH("gb_dict_build", (gb_dict_build<false, true>), dim3(grid_), dim3(GB_DICT_THREADS), 0, stream0(), tt, plan, g, chunk_);
+      return GDF_SUCCESS;
+    };
     unsigned int h_flags[3] = {0, 0, 0};
-    HIP_TRY(hipMemcpy(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost));
+    const int64_t sample = 1 << 16;      // a quarter of the table's slots: the prefix cannot crowd it
+    if (n > 16 * sample) {
+      // a 65536-row prefix already tells "far too many groups" apart (C5) without paying for a
+      // full pass that fills the table and gives up
+      KeyTable ts = t;
+      ts.nrows = sample;
+      GDF_TRY(dict_build(ts, (int)(sample / (GB_DICT_THREADS * GB_DENSE_BATCH)), GB_DICT_THREADS * GB_DENSE_BATCH));
+      HIP_TRY(hipMemcpy(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost));
+    }
+    if (!h_flags[1]) {
+      GDF_TRY(dict_build(t, bgrid, bchunk));
+      HIP_CHECK_LAST();
+      HIP_TRY(hipMemcpy(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost));
+    }
     const uint32_t ngroups = h_flags[0] + (h_flags[2] ? 1u : 0u);
     if (!h_flags[1] && ngroups <= max_groups) {
       RMM_TRY(group_slot.alloc(sizeof(uint32_t) * (ngroups ? ngroups : 1)));
@@ -903,7 +1060,79 @@ static gdf_error group_by_hash(int ncols, gdf_column **cols, gdf_column *col_agg
       }
       return write_output_masks(ncols, out_keys, out_agg, o.agg_ok, ngroups);
     }
-    // too many groups for LDS accumulators: general path below
+    // too many groups for LDS accumulators
+  }
+
+  // ---- sorted path: packed keys, many groups ----
+  if (plan.packed && !getenv("GDF_GB_NO_SORTED")) {
+    GbKeyPlan sp = plan;
+    if (!sp.ordered) GDF_TRY(gb_plan_range(t, &sp));          // fewer key bits = fewer radix passes, and sorted output for free
+    const int vbit = (val.valid != nullptr && op != OP_COUNT) ? 1 : 0;
+    const int null_bit = t.any_valid ? 1 : 0;
+    if (sp.total_bits + vbit + null_bit <= 64) {
+      const uint32_t nn = (uint32_t)n;
+      DevBuf ka, kb, pa, pb, fl, gid, start, acc, cnt;
+      RMM_TRY(ka.alloc(sizeof(uint64_t) * (size_t)nn));
+      RMM_TRY(kb.alloc(sizeof(uint64_t) * (size_t)nn));
+      RMM_TRY(pa.alloc(sizeof(uint64_t) * (size_t)nn));
+      RMM_TRY(pb.alloc(sizeof(uint64_t) * (size_t)nn));
+      RMM_TRY(fl.alloc(16));
+      HIP_TRY(hipMemsetAsync(fl.p, 0, 16, stream0()));
+      const int fold_op = op == OP_AVG ? OP_SUM : op;
+      const bool flt = is_flt(val.kind);
+      const uint64_t null_key = null_bit ? (1ULL << (sp.total_bits + vbit)) : 0ULL;
+      uint64_t *kin = ka.as<uint64_t>(), *kout = kb.as<uint64_t>(), *pin = pa.as<uint64_t>(), *pout = pb.as<uint64_t>();
+      GDF_LAUNCH("gb_sorted_make_pairs", gb_sorted_make_pairs, dim3(stream_grid((size_t)n, 256 * 8)), dim3(256), 0, stream0(), t, sp, val,
+                 fold_op, vbit, null_key, kin, pin, fl.as<unsigned long long>(), (unsigned int *)(fl.as<unsigned long long>() + 1));
+      struct { unsigned long long varying; unsigned int dropped, pad; } hf;
+      HIP_TRY(hipMemcpy(&hf, fl.p, 16, hipMemcpyDeviceToHost));
+      GDF_TRY(radix_sort_pairs_u64(kin, kout, pin, pout, nn, hf.varying));
+      const uint32_t nvalid = nn - hf.dropped;
+      uint32_t ngroups = 0;
+      GbOut o{};
+      o.ncols = ncols;
+      for (int c = 0; c < ncols; ++c) o.key_out[c] = out_keys[c]->data;
+      o.agg_out = out_agg->data;
+      o.in_kind = (int)in_kind;
+      o.agg_kind = (int)((op == OP_COUNT || op == OP_AVG) ? out_kind : in_kind);
+      o.counted = val.valid != nullptr;
+      if (nvalid) {
+        RMM_TRY(gid.alloc(sizeof(uint32_t) * (size_t)nvalid));
+        const int hgrid = stream_grid(nvalid, 256 * 4);
+        GDF_LAUNCH("gb_sorted_heads", gb_sorted_heads, dim3(hgrid), dim3(256), 0, stream0(), (const uint64_t *)kin, vbit, gid.as<uint32_t>(), nvalid);
+        GDF_TRY(scan_u32(gid.as<uint32_t>(), gid.as<uint32_t>(), nvalid, true));
+        HIP_TRY(hipMemcpy(&ngroups, gid.as<uint32_t>() + (nvalid - 1), sizeof(uint32_t), hipMemcpyDeviceToHost));
+        RMM_TRY(start.alloc(sizeof(uint32_t) * ((size_t)ngroups + 1)));
+        RMM_TRY(acc.alloc(sizeof(uint64_t) * (size_t)ngroups));
+        if (vbit) RMM_TRY(cnt.alloc(sizeof(uint64_t) * (size_t)ngroups));
+        GDF_LAUNCH("gb_sorted_starts", gb_sorted_starts, dim3(hgrid), dim3(256), 0, stream0(), (const uint32_t *)gid.as<uint32_t>(), start.as<uint32_t>(),
+                   nvalid, ngroups);
+        GDF_LAUNCH("gb_fill", gb_fill_u64, dim3(stream_grid(ngroups, 1024)), dim3(256), 0, stream0(), acc.as<unsigned long long>(),
+                   (unsigned long long)acc_identity_host(fold_op), ngroups);
+        if (vbit) HIP_TRY(hipMemsetAsync(cnt.p, 0, sizeof(uint64_t) * (size_t)ngroups, stream0()));
+        const uint32_t per_block = WAVE * GB_SEG_ROUNDS * 4;
+        const dim3 rgrid((nvalid + per_block - 1) / per_block);
+        if (vbit) GDF_LAUNCH("gb_sorted_reduce", gb_sorted_reduce<true>, rgrid, dim3(256), 0, stream0(), (const uint64_t *)kin, (const uint64_t *)pin,
+                             (const uint32_t *)gid.as<uint32_t>(), fold_op, flt, acc.as<unsigned long long>(), cnt.as<unsigned long long>(), nvalid);
+        else GDF_LAUNCH("gb_sorted_reduce", gb_sorted_reduce<false>, rgrid, dim3(256), 0, stream0(), (const uint64_t *)kin, (const uint64_t *)pin,
+                        (const uint32_t *)gid.as<uint32_t>(), fold_op, flt, acc.as<unsigned long long>(), cnt.as<unsigned long long>(), nvalid);
+        if (want_ok) RMM_TRY(agg_ok.alloc(ngroups));
+        o.agg_ok = agg_ok.as<uint8_t>();
+        GDF_LAUNCH("gb_extract", gb_sorted_extract, dim3(stream_grid(ngroups, 256)), dim3(256), 0, stream0(), t, sp, (const uint64_t *)kin, vbit,
+                   (const uint32_t *)start.as<uint32_t>(), ngroups, o, op, (const unsigned long long *)acc.as<unsigned long long>(),
+                   (const unsigned long long *)cnt.as<unsigned long long>());
+        HIP_CHECK_LAST();
+        HIP_TRY(hipStreamSynchronize(stream0()));
+      }
+      for (int c = 0; c < ncols; ++c) out_keys[c]->size = (gdf_size_type)ngroups;
+      out_agg->size = (gdf_size_type)ngroups;
+      if ((sort_result || op == OP_AVG) && !sp.ordered) {
+        int kinds[MAX_KEY_COLS];
+        for (int c = 0; c < ncols; ++c) kinds[c] = t.col[c].kind;
+        GDF_TRY(sort_result_rows(ncols, out_keys, kinds, out_agg->data, kind_width((ElemKind)o.agg_kind), ngroups, o.agg_ok));
+      }
+      return write_output_masks(ncols, out_keys, out_agg, o.agg_ok, ngroups);
+    }
   }
   for (;;) {
     DevBuf keys, first, acc, cnt, flags, out_count;

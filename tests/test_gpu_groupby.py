@@ -259,3 +259,20 @@ def test_sort_method_still_rejects_masks(gdf):
     k = gen_rand(np.int32, 10)
     with pytest.raises(GDFError, match="GDF_VALIDITY_UNSUPPORTED"):            # sqls_ops.cu:1103-1106
         gdf.api.group_by("sum", [column_from_numpy(k, np.ones(10, dtype=bool))], column_from_numpy(k), method=GDF_SORT)
+
+
+@pytest.mark.parametrize("op", OPS)
+@pytest.mark.parametrize("path", ["sorted", "hash_table"])
+def test_many_groups_both_large_paths(gdf, op, path, monkeypatch):
+    """Beyond 16384 groups the packed-key group-by sorts (key, value) pairs and reduces segments; GDF_GB_NO_SORTED=1
+    keeps the global hash table.  Both must give the oracle's answer, masked or not."""
+    if path == "hash_table":
+        monkeypatch.setenv("GDF_GB_NO_SORTED", "1")
+    n = 300000
+    keys = [gen_rand(np.int64, n, -40000, 40000), gen_rand(np.int16, n, 0, 2)]
+    vals = gen_rand(np.float64, n)
+    out = np.int64 if op == "count" else (np.float64 if op == "avg" else None)
+    _check(gdf, op, keys, vals, out)
+    _check(gdf, op, [np.random.randint(-2**62, 2**62, n, dtype=np.int64) // 1000 * 1000], gen_rand(np.int32, n), out)   # 64-bit natural layout
+    _check_masked(gdf, op, keys, vals, [np.random.random(n) > 0.02, None], np.random.random(n) > 0.5, out)
+    _check_masked(gdf, op, keys, gen_rand(np.int64, n), [None, np.random.random(n) > 0.02], None, out)

@@ -39,6 +39,8 @@
 // size, pair order unspecified.
 #include "internal.h"
 
+#include <cmath>
+
 #include <algorithm>
 #include <cstdlib>
 #include <vector>
@@ -190,6 +192,13 @@ struct PartGeom {
   int dbg;               // experiment switch (env GDF_JK_SDBG), 0 in production
   uint64_t kbias;        // added back to a stored key before hashing (= KeyPlan::kmin): partition ids and slots are
                          // functions of the RAW key, so the build-side histogram can run before kmin is known
+  // SPECULATIVE layout (cap1 != 0): no histogram pass.  Coarse partition c owns tuples [c * cap1, (c+1) * cap1),
+  // fine partition f owns [f * cap2, (f+1) * cap2); (tile, bin) runs claim their place with one atomicAdd on
+  // the partition's fill counter.  A partition that outgrows its capacity raises *spec_flag and its run is
+  // written to the dump area instead (memory safe); the host then repeats the side with the exact layout.
+  uint32_t cap1, cap2, dump;
+  uint32_t *spec_cursor1;   // [2^b1] fill counters, zero-initialised
+  uint32_t *spec_flag;
 };
 
 // NARROW: w[i] = key32 << 32 | row, idx unused.  WIDE: w[i] = key64, idx[i] = row.
@@ -364,7 +373,7 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
   constexpr int JK_TILE = THREADS * JK_SC_ITEMS;
   const int chunk = blockIdx.x;
   const uint32_t ncoarse = 1u << g.b1;
-  if (threadIdx.x < ncoarse) s.cursor[threadIdx.x] = H1off[(size_t)threadIdx.x * g.nchunks + chunk];
+  if (!g.cap1 && threadIdx.x < ncoarse) s.cursor[threadIdx.x] = H1off[(size_t)threadIdx.x * g.nchunks + chunk];
   const int64_t begin = (int64_t)chunk * g.chunk;
   const int64_t end = begin + g.chunk < t.nrows ? begin + g.chunk : t.nrows;
   // FAST: the raw column words of the NEXT tile are requested while the current tile is flushed, so the
@@ -405,8 +414,15 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
     tile_scan_bins(s, ncoarse);
     block_sync();
     if (threadIdx.x < ncoarse) {
-      s.gbase[threadIdx.x] = s.cursor[threadIdx.x] - s.start[threadIdx.x];
-      s.cursor[threadIdx.x] += s.hist[threadIdx.x];
+      if (g.cap1) {
+        const uint32_t cnt = s.hist[threadIdx.x];
+        uint32_t base = cnt ? atomicAdd(&g.spec_cursor1[threadIdx.x], cnt) : 0u;
+        if (base + cnt > g.cap1) { atomicExch(g.spec_flag, 1u); s.gbase[threadIdx.x] = g.dump - s.start[threadIdx.x]; }
+        else s.gbase[threadIdx.x] = threadIdx.x * g.cap1 + base - s.start[threadIdx.x];
+      } else {
+        s.gbase[threadIdx.x] = s.cursor[threadIdx.x] - s.start[threadIdx.x];
+        s.cursor[threadIdx.x] += s.hist[threadIdx.x];
+      }
     }
 #pragma unroll
     for (int k = 0; k < JK_SC_ITEMS; ++k) {
@@ -434,7 +450,8 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
 // never crosses a coarse boundary; bins claim their global range with one
 // atomicAdd per (tile, non-empty bin) on the fine cursors.
 struct Level2Map {                     // small host-built tables, device resident
-  const uint32_t *coarse_off;          // [ncoarse+1] tuple offset of each coarse partition
+  const uint32_t *coarse_off;          // [ncoarse] first tuple of each coarse partition
+  const uint32_t *coarse_end;          // [ncoarse] one past its last tuple (== the next partition's first in the exact layout)
   const uint32_t *tile_prefix;         // [ncoarse+1] tiles before each coarse partition
 };
 
@@ -453,7 +470,7 @@ __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, 
   }
   const uint32_t p = lo;
   const uint32_t begin = m.coarse_off[p] + (blockIdx.x - m.tile_prefix[p]) * JK_TILE;
-  const uint32_t pend = m.coarse_off[p + 1];
+  const uint32_t pend = m.coarse_end[p];
   const uint32_t end = begin + JK_TILE < pend ? begin + JK_TILE : pend;
   const uint32_t submask = nsub - 1;
 
@@ -483,7 +500,12 @@ __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, 
   block_sync();
   if (threadIdx.x < nsub) {
     const uint32_t cnt = s.hist[threadIdx.x];
-    if (cnt) s.gbase[threadIdx.x] = atomicAdd(&fine_cursor[(p << g.b2) | threadIdx.x], cnt) - s.start[threadIdx.x];
+    if (cnt) {
+      const uint32_t f = (p << g.b2) | threadIdx.x;
+      const uint32_t base = atomicAdd(&fine_cursor[f], cnt);
+      if (g.cap2 && base + cnt > (f + 1) * g.cap2) { atomicExch(g.spec_flag, 1u); s.gbase[threadIdx.x] = g.dump - s.start[threadIdx.x]; }
+      else s.gbase[threadIdx.x] = base - s.start[threadIdx.x];
+    }
   }
 #pragma unroll
   for (int k = 0; k < JK_SC_ITEMS; ++k) {
@@ -900,7 +922,9 @@ enum JoinKind { JOIN_INNER, JOIN_LEFT, JOIN_FULL };
 struct SideBufs {            // partitioned tuples of one relation
   DevBuf w[2], idx[2];
   int final_buf = 0;         // which ping-pong buffer holds the fine-partitioned tuples
-  std::vector<uint32_t> fine_off;   // [nfine+1] on the host
+  std::vector<uint32_t> fine_off;   // [nfine+1] on the host; EXACT layout only (partitions are contiguous)
+  std::vector<uint32_t> fine_begin, fine_cnt;   // [nfine] first tuple / tuple count of every fine partition, both layouts
+  bool speculative = false;
   uint32_t joinable = 0;     // tuples that entered the partitioned path
   Tuples tuples(int b) const { return Tuples{w[b].as<uint64_t>(), idx[b].as<int32_t>()}; }
   Tuples final() const { return tuples(final_buf); }
@@ -1010,6 +1034,9 @@ static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, Si
   sb->fine_off.assign(nfine + 1, 0);
   for (uint32_t f = 0; f < nfine; ++f) sb->fine_off[f + 1] = sb->fine_off[f] + fh[f];
   sb->joinable = sb->fine_off[nfine];
+  sb->fine_begin.assign(sb->fine_off.begin(), sb->fine_off.begin() + nfine);
+  sb->fine_cnt = fh;
+  sb->speculative = false;
   const size_t cap = sb->joinable ? sb->joinable : 1;
   if (d_mm) {
     long long h[2];
@@ -1052,7 +1079,7 @@ static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, Si
     HIP_TRY(hipMemcpyAsync(cursor.p, sb->fine_off.data(), sizeof(uint32_t) * nfine, hipMemcpyHostToDevice, stream0()));
     RMM_TRY(sb->w[1].alloc(sizeof(uint64_t) * cap));
     if (!narrow) RMM_TRY(sb->idx[1].alloc(sizeof(int32_t) * cap));
-    Level2Map m{d_coarse.as<uint32_t>(), d_tiles.as<uint32_t>()};
+    Level2Map m{d_coarse.as<uint32_t>(), d_coarse.as<uint32_t>() + 1, d_tiles.as<uint32_t>()};
     if (ntiles) GDF_TRY(launch_scatter2(narrow, sc_threads, ntiles, g, m, sb->tuples(0), cursor.as<uint32_t>(), sb->tuples(1)));
     HIP_CHECK_LAST();
     HIP_TRY(hipStreamSynchronize(stream0()));   // host vectors + scratch go out of scope
@@ -1062,6 +1089,104 @@ static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, Si
   } else {
     HIP_TRY(hipStreamSynchronize(stream0()));
   }
+  return GDF_SUCCESS;
+}
+
+// Histogram-free partitioning of one relation (PartGeom's SPECULATIVE layout): the 8 B/row histogram read is
+// skipped, every partition gets room for its expected size + 8 standard deviations under a uniform hash.
+// *ok = false: some partition outgrew its room (skewed keys); the caller repeats the side with
+// partition_side().  The plan's tuple format must be final (the build side decides it).
+// dup: expected rows per distinct key (probe rows / build rows): a partition's load is a sum over its keys, so
+// its variance grows with the multiplicity -- measured on C3 (10 probe rows per key) before this term existed:
+// the plain sqrt(mean) slack overflowed.
+static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, PartGeom g, double dup, SideBufs *sb, bool *ok) {
+  *ok = false;
+  const int64_t n = t.nrows;
+  const bool narrow = plan.narrow != 0;
+  static const int64_t chunk_rows_env = getenv("GDF_JK_CHUNK_ROWS") ? atoll(getenv("GDF_JK_CHUNK_ROWS")) : 0;
+  int64_t chunk = chunk_rows_env ? chunk_rows_env : JK_CHUNK_ROWS;
+  if (n / chunk > JK_MAX_CHUNKS) chunk = (n + JK_MAX_CHUNKS - 1) / JK_MAX_CHUNKS;
+  constexpr int64_t MAX_TILE = 1024 * JK_SC_ITEMS;
+  chunk = ((chunk + MAX_TILE - 1) / MAX_TILE) * MAX_TILE;
+  g.chunk = chunk;
+  g.nchunks = (int)((n + chunk - 1) / chunk);
+  if (g.nchunks == 0) g.nchunks = 1;
+  const uint32_t nfine = 1u << g.fb, ncoarse = 1u << g.b1;
+  const bool fast = t.ncols == 1 && t.col[0].width == 8 && plan.mode == KM_RAW_INT && !t.any_valid;
+  static const int sc_threads_env = getenv("GDF_JK_SC_THREADS") ? atoi(getenv("GDF_JK_SC_THREADS")) : 0;
+  int sc_threads = sc_threads_env ? sc_threads_env : (narrow ? 1024 : 256);
+  if (sc_threads != 256 && sc_threads != 512 && sc_threads != 1024) sc_threads = 256;
+  if (!narrow && sc_threads == 1024) sc_threads = 512;
+  const int64_t JK_TILE = (int64_t)sc_threads * JK_SC_ITEMS;
+  auto room = [dup](double mean, uint32_t align) {
+    const double c = mean + 8.0 * std::sqrt(mean * (1.0 + dup)) + 64.0;
+    return (uint32_t)(((uint64_t)c + align - 1) / align * align);
+  };
+  const uint32_t cap1 = room((double)n / ncoarse, 64), cap2 = g.b2 ? room((double)n / nfine, 8) : 0;
+  const uint64_t size1 = (uint64_t)ncoarse * cap1 + JK_TILE, size2 = (uint64_t)nfine * cap2 + JK_TILE;
+  if (size1 >= 0x7fffffffULL || size2 >= 0x7fffffffULL) return GDF_SUCCESS;      // tuple positions are 31-bit
+
+  DevBuf spec;
+  RMM_TRY(spec.alloc(sizeof(uint32_t) * (ncoarse + 1)));
+  HIP_TRY(hipMemsetAsync(spec.p, 0, sizeof(uint32_t) * (ncoarse + 1), stream0()));
+  g.kbias = plan.kmin;
+  g.cap1 = cap1;
+  g.cap2 = 0;
+  g.dump = ncoarse * cap1;
+  g.spec_cursor1 = spec.as<uint32_t>();
+  g.spec_flag = spec.as<uint32_t>() + ncoarse;
+  RMM_TRY(sb->w[0].alloc(sizeof(uint64_t) * size1));
+  if (!narrow) RMM_TRY(sb->idx[0].alloc(sizeof(int32_t) * size1));
+  GDF_TRY(launch_scatter1(fast, narrow, sc_threads, t, plan, g, nullptr, sb->tuples(0)));
+  std::vector<uint32_t> c1(ncoarse + 1);
+  HIP_TRY(hipMemcpy(c1.data(), spec.p, sizeof(uint32_t) * (ncoarse + 1), hipMemcpyDeviceToHost));
+  if (c1[ncoarse]) return GDF_SUCCESS;
+  sb->final_buf = 0;
+  sb->fine_off.clear();
+  if (g.b2 == 0) {
+    sb->fine_begin.resize(nfine);
+    for (uint32_t f = 0; f < nfine; ++f) sb->fine_begin[f] = f * cap1;
+    sb->fine_cnt.assign(c1.begin(), c1.begin() + nfine);
+  } else {
+    std::vector<uint32_t> coarse_off(2 * ncoarse), tile_prefix(ncoarse + 1), cur(nfine);
+    tile_prefix[0] = 0;
+    for (uint32_t c = 0; c < ncoarse; ++c) {
+      coarse_off[c] = c * cap1;
+      coarse_off[ncoarse + c] = c * cap1 + c1[c];
+      tile_prefix[c + 1] = tile_prefix[c] + (uint32_t)((c1[c] + JK_TILE - 1) / JK_TILE);
+    }
+    for (uint32_t f = 0; f < nfine; ++f) cur[f] = f * cap2;
+    const uint32_t ntiles = tile_prefix[ncoarse];
+    DevBuf d_coarse, d_tiles, cursor;
+    RMM_TRY(d_coarse.alloc(sizeof(uint32_t) * 2 * ncoarse));
+    RMM_TRY(d_tiles.alloc(sizeof(uint32_t) * (ncoarse + 1)));
+    RMM_TRY(cursor.alloc(sizeof(uint32_t) * nfine));
+    HIP_TRY(hipMemcpyAsync(d_coarse.p, coarse_off.data(), sizeof(uint32_t) * 2 * ncoarse, hipMemcpyHostToDevice, stream0()));
+    HIP_TRY(hipMemcpyAsync(d_tiles.p, tile_prefix.data(), sizeof(uint32_t) * (ncoarse + 1), hipMemcpyHostToDevice, stream0()));
+    HIP_TRY(hipMemcpyAsync(cursor.p, cur.data(), sizeof(uint32_t) * nfine, hipMemcpyHostToDevice, stream0()));
+    RMM_TRY(sb->w[1].alloc(sizeof(uint64_t) * size2));
+    if (!narrow) RMM_TRY(sb->idx[1].alloc(sizeof(int32_t) * size2));
+    PartGeom g2 = g;
+    g2.cap2 = cap2;
+    g2.dump = nfine * cap2;
+    Level2Map m{d_coarse.as<uint32_t>(), d_coarse.as<uint32_t>() + ncoarse, d_tiles.as<uint32_t>()};
+    if (ntiles) GDF_TRY(launch_scatter2(narrow, sc_threads, ntiles, g2, m, sb->tuples(0), cursor.as<uint32_t>(), sb->tuples(1)));
+    uint32_t flag = 0;
+    HIP_TRY(hipMemcpy(cur.data(), cursor.p, sizeof(uint32_t) * nfine, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&flag, g.spec_flag, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    sb->w[0].reset();
+    sb->idx[0].reset();
+    if (flag) return GDF_SUCCESS;
+    sb->fine_begin.resize(nfine);
+    sb->fine_cnt.resize(nfine);
+    for (uint32_t f = 0; f < nfine; ++f) { sb->fine_begin[f] = f * cap2; sb->fine_cnt[f] = cur[f] - f * cap2; }
+    sb->final_buf = 1;
+  }
+  uint64_t total = 0;
+  for (uint32_t c : sb->fine_cnt) total += c;
+  sb->joinable = (uint32_t)total;
+  sb->speculative = true;
+  *ok = true;
   return GDF_SUCCESS;
 }
 
@@ -1097,7 +1222,18 @@ static gdf_error hash_join_core(const KeyTable &probe_t, const KeyTable &build_t
   SideBufs B, P;
   const bool range_candidate = !plan.narrow && plan.mode == KM_RAW_INT && build_t.col[0].width == 8;
   GDF_TRY(partition_side(build_t, plan, g, &B, range_candidate));   // may switch plan to the narrow format
-  GDF_TRY(partition_side(probe_t, plan, g, &P, false));
+  // The probe side is the big one (C3: 10x the build side): it is partitioned WITHOUT a histogram pass
+  // when the build partitions all fit LDS (the global-table path wants contiguous partition runs).
+  uint32_t largest_build = 0;
+  for (uint32_t c : B.fine_cnt) largest_build = std::max(largest_build, c);
+  const int64_t spec_min = getenv("GDF_JK_SPEC_MIN") ? atoll(getenv("GDF_JK_SPEC_MIN")) : (int64_t)1 << 22;   // test switch
+  bool spec_ok = false;
+  if (g.fb > 0 && probe_t.nrows >= spec_min && largest_build <= (uint32_t)JK_MAX_BUILD && !getenv("GDF_JK_NO_SPEC"))
+    GDF_TRY(partition_side_spec(probe_t, plan, g, std::max(1.0, (double)probe_t.nrows / std::max<uint32_t>(B.joinable, 1)), &P, &spec_ok));
+  if (!spec_ok) {
+    P.w[0].reset(); P.w[1].reset(); P.idx[0].reset(); P.idx[1].reset();
+    GDF_TRY(partition_side(probe_t, plan, g, &P, false));
+  }
   const bool narrow = plan.narrow != 0;
 
   // ---- work units ----
@@ -1106,8 +1242,8 @@ static gdf_error hash_join_core(const KeyTable &probe_t, const KeyTable &build_t
   std::vector<Run> oversize;
   uint32_t max_build = 0;
   for (uint32_t f = 0; f < nfine; ++f) {
-    const uint32_t bn = B.fine_off[f + 1] - B.fine_off[f];
-    const uint32_t pn = P.fine_off[f + 1] - P.fine_off[f];
+    const uint32_t bn = B.fine_cnt[f];
+    const uint32_t pn = P.fine_cnt[f];
     if (pn == 0) continue;
     if (bn == 0 && !keep_probe) continue;
     if (bn > (uint32_t)JK_MAX_BUILD) {
@@ -1117,7 +1253,7 @@ static gdf_error hash_join_core(const KeyTable &probe_t, const KeyTable &build_t
     }
     max_build = std::max(max_build, bn);
     for (uint32_t off = 0; off < pn; off += JK_PROBE_CHUNK)
-      units.push_back(Unit{B.fine_off[f], bn, P.fine_off[f] + off, std::min(JK_PROBE_CHUNK, pn - off)});
+      units.push_back(Unit{B.fine_begin[f], bn, P.fine_begin[f] + off, std::min(JK_PROBE_CHUNK, pn - off)});
   }
   const size_t nunits = units.size();
   const size_t nslots_all = nunits + oversize.size();     // one count slot per LDS unit + one per oversize partition

@@ -301,3 +301,45 @@ def test_sort_method_rules(gdf):
         gdf.api.join([masked], _cols([k]), method=GDF_SORT)
     li, ri = gdf.api.join(_cols([k]), _cols([k]), how="full", method=GDF_SORT)   # generic SortJoin: empty result (joining.cu:66-75)
     assert li.numel() == 0 and ri.numel() == 0
+
+
+# ---- histogram-free (speculative) partitioning of the probe side -------------------------------------------------
+@pytest.mark.parametrize("how", ["inner", "left", "full"])
+@pytest.mark.parametrize("dtypes", [[np.int64], [np.int32], [np.int32, np.int64], [np.float64]], ids=lambda d: "-".join(np.dtype(x).name for x in d))
+def test_speculative_partitioning_small_inputs(gdf, how, dtypes, monkeypatch):
+    """GDF_JK_SPEC_MIN=1 sends even small probe sides through the capacity-slack layout (normally >= 4M rows)."""
+    monkeypatch.setenv("GDF_JK_SPEC_MIN", "1")
+    rng = 20000 if len(dtypes) == 1 else 150
+    _check(gdf, _gen(dtypes, 300000, rng), _gen(dtypes, 40000, rng), how)
+    lv = [random_valid(300000) for _ in dtypes]
+    rv = [random_valid(40000) for _ in dtypes]
+    _check(gdf, _gen(dtypes, 300000, rng), _gen(dtypes, 40000, rng), how, lv, rv)
+
+
+def test_speculative_partitioning_falls_back_on_skew(gdf, monkeypatch):
+    """Half of the probe rows carry ONE key: its partition outgrows the slack, the flag is raised and the exact
+    (histogram) layout takes over.  Same answer, checked against the oracle and by count."""
+    monkeypatch.setenv("GDF_JK_SPEC_MIN", "1")
+    n = 400000
+    l = gen_rand(np.int64, n, 0, 50000)
+    l[::2] = 777
+    r = np.arange(50000, dtype=np.int64)
+    np.random.shuffle(r)
+    assert _check(gdf, [l], [r], "inner") == n
+
+
+def test_speculative_matches_exact_at_scale(gdf, monkeypatch):
+    """3e7 x 3e6 uniform keys: speculative (default at this size) and exact (GDF_JK_NO_SPEC) give the same pair set."""
+    import torch
+    from libgdf_amd.columns import Column
+    nb, npr = 3_000_000, 30_000_000
+    b = torch.randperm(nb, device="cuda")
+    p = torch.randint(0, nb + nb // 10, (npr,), device="cuda")
+    li, ri = gdf.api.join([Column(p)], [Column(b)])
+    monkeypatch.setenv("GDF_JK_NO_SPEC", "1")
+    le, re_ = gdf.api.join([Column(p)], [Column(b)])
+    assert li.numel() == le.numel() == int((p < nb).sum())
+    assert bool((p[li.long()] == b[ri.long()]).all())
+    a = torch.sort(li.long() * nb + ri.long()).values
+    c = torch.sort(le.long() * nb + re_.long()).values
+    assert torch.equal(a, c)

@@ -8,10 +8,13 @@
 // read of the build key; here NO random HBM access remains:
 //
 //   1. jk_hist      both relations are turned into (key, row) tuples and radix
-//   2. jk_scatter1  partitioned on the top FB <= 15 bits of mix64(key), so that one
-//   3. jk_scatter2  build partition fits LDS.  Two scatter levels (<= 256-way each);
-//                   tiles are regrouped in LDS so a wave writes runs of consecutive
-//                   addresses.
+//   2. jk_scatter1  partitioned on the top FB <= 15 bits of hash_a(raw key) (a 32-bit
+//   3. jk_scatter2  internal hash), so that one build partition fits LDS.  Two scatter
+//                   levels (<= 256-way each); tiles are regrouped in LDS so a wave
+//                   writes runs of consecutive addresses.  The histogram pass runs on
+//                   the build side only: the probe side is laid out with per-partition
+//                   slack and atomic fill counters (partition_side_spec), falling back
+//                   to the exact histogram layout when a partition outgrows its room.
 //   4. jk_probe     one workgroup per (partition, probe chunk): stages the build
 //                   partition in LDS, builds a cuckoo table of POSITIONS over it
 //                   (lookup = two independent reads, no data-dependent loop; linear

@@ -121,6 +121,8 @@ def main():
     ap.add_argument("--probe-rows", type=int, default=1_000_000_000)
     ap.add_argument("--build-rows", type=int, default=None)
     ap.add_argument("--cpu-sample", type=int, default=20_000_000, help="probe rows of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--force-distributed", action="store_true",
+                    help="run the multi-GPU (C4) code path even at world size 1 (1-rank RCCL group): measures its local passes")
     args = ap.parse_args()
 
     import torch
@@ -131,8 +133,14 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    distributed = world > 1 or args.force_distributed
+    if distributed:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import libgdf_amd as gdf
     from libgdf_amd._binding import rmmOptions_t
@@ -142,11 +150,11 @@ def main():
     gdf.librmm.rmmInitialize(C.byref(opts))
 
     npr = args.probe_rows
-    nb = args.build_rows if args.build_rows is not None else (npr // 10 if world == 1 else npr // 8)
+    nb = args.build_rows if args.build_rows is not None else (npr // 8 if distributed else npr // 10)
     key_space = nb * world
     lib = gdf._binding._gdf_cdll
 
-    if world == 1:
+    if not distributed:
         build = make_build_keys(nb, 0x5EED0001, dev)
         probe = make_probe_keys(npr, key_space, 0x5EED0002, dev)
         pcol, bcol = Column(probe), Column(build)
@@ -179,7 +187,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if distributed:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -242,7 +250,7 @@ def main():
         if world == 1 and args.cpu_sample > 0:
             result["cpu_baseline"] = cpu_baseline(args.cpu_sample, max(args.cpu_sample // 10, 1))
         print(json.dumps(result))
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 

@@ -13,14 +13,15 @@ counterpart there; it sits ABOVE the unchanged per-GPU ``gdf_*`` C ABI (SURVEY.m
   4. every rank joins what it received with ``gdf_inner_join``.  The result is a :class:`ShardedPairs`:
      index pairs into the RECEIVED tables plus what is needed to name the original rows
      (``(owner rank, local row)``), resolved lazily -- an 8-byte global id per output row would double the
-     output traffic of the timed path.
+     output traffic of the timed path;
+  5. the probe relation goes through steps 1-4 in slices, software-pipelined: the all-to-all of slice c runs
+     on RCCL's stream while slice c+1 is partitioned and slice c-1 is joined on the library's stream.
 
 ``partition_fn`` / ``join_fn`` are injectable so the exchange logic is testable on CPU with the gloo
 backend (tests/test_multigpu_gloo.py): there they are numpy oracle functions, here the C ABI.
 
 Not done yet: fusing the rank split into the join's own radix partitioning (the
-receiver would continue from 8-byte packed tuples instead of re-reading raw keys) and pipelining the
-exchange against it; by the volume arithmetic that is what >= 6x at 8 GPUs needs.
+receiver would continue from 8-byte packed tuples instead of re-reading raw keys).
 """
 from __future__ import annotations
 
@@ -58,56 +59,137 @@ class Received:
 
 
 class ShardedPairs:
-    """This rank's share of a distributed join: ``probe_pos[i]`` / ``build_pos[i]`` index the received tables."""
+    """This rank's share of a distributed join, one entry per probe chunk: ``probe_pos[c][i]`` / ``build_pos[c][i]``
+    index chunk c's received probe table / the received build table."""
 
-    def __init__(self, probe, build, probe_pos, build_pos):
-        self.probe, self.build, self.probe_pos, self.build_pos = probe, build, probe_pos, build_pos
+    def __init__(self, probes, build, probe_pos, build_pos):
+        self.probes, self.build, self.probe_pos, self.build_pos = probes, build, probe_pos, build_pos
 
     def numel(self):
-        return self.probe_pos.numel()
+        return sum(int(p.numel()) for p in self.probe_pos)
 
     def global_ids(self):
-        return self.probe.global_ids(self.probe_pos), self.build.global_ids(self.build_pos)
+        import torch
+        pg = [r.global_ids(p) for r, p in zip(self.probes, self.probe_pos)]
+        bg = [self.build.global_ids(b) for b in self.build_pos]
+        return torch.cat(pg), torch.cat(bg)
+
+
+# Largest single message handed to RCCL.  Measured on this image (RCCL 2.26.6 inside torch 2.10, 1 rank sending to
+# itself): a send/recv pair of 2.0e9 bytes or more delivers only its first half, 2^30 bytes are fine
+# (scratch/dbg_a2a.py).  Every message therefore travels in pieces of at most 2^29 bytes, and a rank's own
+# segment never enters RCCL at all.
+_MAX_MESSAGE_BYTES = 1 << 29
+
+
+def _all_to_all_v(recv, send, recv_split, send_split, group, async_op):
+    """Variable all-to-all of one column: the local segment is a device copy, every remote segment a sequence of
+    bounded isend / irecv pairs issued as one batch.  Returns the list of in-flight works (empty if none)."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    me = dist.get_rank(group)
+    piece = max(1, _MAX_MESSAGE_BYTES // send.element_size())
+    ops = []
+    so = ro = 0
+    for r in range(world):
+        ns, nr = int(send_split[r]), int(recv_split[r])
+        if r == me:
+            recv[ro:ro + nr].copy_(send[so:so + ns])
+        else:
+            peer = dist.get_global_rank(group, r) if group is not None else r
+            for a in range(0, ns, piece):
+                ops.append(dist.P2POp(dist.isend, send[so + a:so + min(ns, a + piece)], peer, group))
+            for a in range(0, nr, piece):
+                ops.append(dist.P2POp(dist.irecv, recv[ro + a:ro + min(nr, a + piece)], peer, group))
+        so += ns
+        ro += nr
+    if not ops:
+        return []
+    works = dist.batch_isend_irecv(ops)
+    if not async_op:
+        for w in works:
+            w.wait()
+        return []
+    return list(works)
+
+
+class _Exchange:
+    """One relation (or one chunk of it) on its way to its owner ranks: the partitioned send buffers, the receive
+    buffers and the in-flight collectives.  ``finish()`` waits for them and returns the :class:`Received`."""
+
+    def __init__(self, keys, payload, partition_fn, group, async_op):
+        import torch
+        import torch.distributed as dist
+        world = dist.get_world_size(group)
+        pk, pp, offsets = partition_fn(keys, payload, world)
+        n = keys.numel()
+        bounds = list(offsets) + [n]
+        send_counts = torch.tensor([bounds[r + 1] - bounds[r] for r in range(world)], dtype=torch.int64, device=keys.device)
+        recv_counts = torch.empty_like(send_counts)
+        dist.all_to_all_single(recv_counts, send_counts, group=group)          # the count matrix, one row per rank
+        send_split = send_counts.tolist()
+        recv_split = recv_counts.tolist()
+        total = int(sum(recv_split))
+        self.keep = (pk, pp)                                                   # send buffers stay alive until finish()
+        self.rk = torch.empty(total, dtype=keys.dtype, device=keys.device)
+        self.rp = torch.empty(total, dtype=payload.dtype, device=keys.device)
+        self.works = (_all_to_all_v(self.rk, pk, recv_split, send_split, group, async_op) +
+                      _all_to_all_v(self.rp, pp, recv_split, send_split, group, async_op))
+        self.bounds = [0]
+        for c in recv_split:
+            self.bounds.append(self.bounds[-1] + int(c))
+
+    def finish(self):
+        for w in self.works:
+            if w is not None:
+                w.wait()
+        self.keep = None
+        return Received(self.rk, self.rp, self.bounds)
 
 
 def exchange_by_key(keys, payload, partition_fn=_device_partition, group=None):
     """Send every (key, payload) row to rank ``hash(key) mod world``.  Returns (keys, payload, bounds)."""
-    import torch
-    import torch.distributed as dist
-    world = dist.get_world_size(group)
-    pk, pp, offsets = partition_fn(keys, payload, world)
-    n = keys.numel()
-    bounds = list(offsets) + [n]
-    send_counts = torch.tensor([bounds[r + 1] - bounds[r] for r in range(world)], dtype=torch.int64, device=keys.device)
-    recv_counts = torch.empty_like(send_counts)
-    dist.all_to_all_single(recv_counts, send_counts, group=group)          # the count matrix, one row per rank
-    send_split = send_counts.tolist()
-    recv_split = recv_counts.tolist()
-    total = int(sum(recv_split))
-    rk = torch.empty(total, dtype=keys.dtype, device=keys.device)
-    rp = torch.empty(total, dtype=payload.dtype, device=keys.device)
-    dist.all_to_all_single(rk, pk, recv_split, send_split, group=group)
-    dist.all_to_all_single(rp, pp, recv_split, send_split, group=group)
-    rb = [0]
-    for c in recv_split:
-        rb.append(rb[-1] + int(c))
-    return rk, rp, rb
+    r = _Exchange(keys, payload, partition_fn, group, async_op=False).finish()
+    return r.keys, r.rows, r.bounds
 
 
-def distributed_inner_join(probe_keys, build_keys, partition_fn=_device_partition, join_fn=_device_inner_join, group=None):
+def distributed_inner_join(probe_keys, build_keys, partition_fn=_device_partition, join_fn=_device_inner_join, group=None,
+                           chunks=4):
     """Inner join of two row-sharded relations on one integer key column.
 
     Every rank passes its shard of both relations and gets back a :class:`ShardedPairs` with its share of
-    the join.  ``len(result.probe_pos)`` summed over the ranks is the size of the global join.
+    the join; ``result.numel()`` summed over the ranks is the size of the global join.
+
+    The probe relation travels in ``chunks`` slices: while slice c is on the links (asynchronous all-to-all on
+    RCCL's own stream), slice c+1 is being hash-partitioned and slice c-1 joined against the received build
+    relation on the library's stream, so that the exchange hides behind the local HBM passes instead of adding
+    to them.
     """
     import torch
     dev = probe_keys.device
-    probe_rows = torch.arange(probe_keys.numel(), dtype=torch.int32, device=dev)
+    n = probe_keys.numel()
     build_rows = torch.arange(build_keys.numel(), dtype=torch.int32, device=dev)
-    pk, prow, pb = exchange_by_key(probe_keys, probe_rows, partition_fn, group)
-    bk, brow, bb = exchange_by_key(build_keys, build_rows, partition_fn, group)
-    li, ri = join_fn(pk, bk)
-    return ShardedPairs(Received(pk, prow, pb), Received(bk, brow, bb), li, ri)
+    build_x = _Exchange(build_keys, build_rows, partition_fn, group, async_op=True)
+    chunks = max(1, min(int(chunks), n)) if n else 1
+    step = (n + chunks - 1) // chunks if n else 0
+    build = None
+    probes, ppos, bpos = [], [], []
+    pending = None
+    for c in range(chunks):
+        lo, hi = c * step, min(n, (c + 1) * step)
+        rows = torch.arange(lo, hi, dtype=torch.int32, device=dev)
+        x = _Exchange(probe_keys[lo:hi], rows, partition_fn, group, async_op=True)     # partition c, then start moving it
+        if build is None:
+            build = build_x.finish()
+        if pending is not None:                                                       # join c-1 while c moves
+            r = pending.finish()
+            li, ri = join_fn(r.keys, build.keys)
+            probes.append(r); ppos.append(li); bpos.append(ri)
+        pending = x
+    r = pending.finish()
+    li, ri = join_fn(r.keys, build.keys)
+    probes.append(r); ppos.append(li); bpos.append(ri)
+    return ShardedPairs(probes, build, ppos, bpos)
 
 
 def distributed_group_by_sum(keys, values, group_fn=None, partition_fn=_device_partition, group=None):

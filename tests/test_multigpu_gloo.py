@@ -49,6 +49,7 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from libgdf_amd import multigpu
+    multigpu._MAX_MESSAGE_BYTES = 1024          # force the multi-piece send / recv path (production: 2^29 bytes)
     probes, builds = _shards(world)
     pairs = multigpu.distributed_inner_join(torch.from_numpy(probes[rank]), torch.from_numpy(builds[rank]),
                                             partition_fn=_np_partition, join_fn=_np_join)

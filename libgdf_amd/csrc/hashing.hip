@@ -63,6 +63,38 @@ __global__ __launch_bounds__(HP_THREADS) void part_hist_kernel(KeyTable t, int64
   }
 }
 
+// FAST8 variants: ONE 8-byte key column hashed with Murmur3 (the common shape: an int64 / float64 / date64 key).
+// The key words of HP_BATCH rows per thread are requested together from clamped addresses -- the generic
+// hash_row() walks the column list through a switch, which puts every load in its own basic block behind an
+// s_waitcnt and leaves one load in flight per wave.
+constexpr int HP_BATCH = 8;
+
+__global__ __launch_bounds__(HP_THREADS) void part_hist_fast8_kernel(const uint64_t *__restrict__ key, int64_t n, int64_t chunk,
+                                                                     int nchunks, uint32_t nparts, uint32_t pow2mask,
+                                                                     uint32_t *__restrict__ hist) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_cnt[];
+  for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    for (uint32_t p = threadIdx.x; p < nparts; p += HP_THREADS) lds_cnt[p] = 0;
+    block_sync();
+    const int64_t begin = (int64_t)c * chunk;
+    const int64_t end = begin + chunk < n ? begin + chunk : n;
+    for (int64_t base = begin; base < end; base += HP_THREADS * HP_BATCH) {
+      uint64_t k[HP_BATCH];
+#pragma unroll
+      for (int j = 0; j < HP_BATCH; ++j) {
+        const int64_t i = base + (int64_t)j * HP_THREADS + threadIdx.x;
+        k[j] = key[i < end ? i : end - 1];
+      }
+#pragma unroll
+      for (int j = 0; j < HP_BATCH; ++j)
+        if (base + (int64_t)j * HP_THREADS + threadIdx.x < end) atomicAdd(&lds_cnt[part_of(murmur3_32(k[j], 8), nparts, pow2mask)], 1u);
+    }
+    block_sync();
+    for (uint32_t p = threadIdx.x; p < nparts; p += HP_THREADS) hist[(size_t)p * nchunks + c] = lds_cnt[p];
+    block_sync();
+  }
+}
+
 struct PayloadCols {
   int ncols;
   const void *in[HP_MAX_PAYLOAD_COLS];
@@ -109,12 +141,76 @@ __global__ __launch_bounds__(HP_THREADS) void part_scatter_kernel(KeyTable t, Pa
   }
 }
 
+__global__ __launch_bounds__(HP_THREADS) void part_scatter_fast8_kernel(const uint64_t *__restrict__ key, PayloadCols pc, int64_t n,
+                                                                        int64_t chunk, int nchunks, uint32_t nparts,
+                                                                        uint32_t pow2mask, const uint32_t *__restrict__ offs) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_cur[];
+  for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    for (uint32_t p = threadIdx.x; p < nparts; p += HP_THREADS) lds_cur[p] = offs[(size_t)p * nchunks + c];
+    block_sync();
+    const int64_t begin = (int64_t)c * chunk;
+    const int64_t end = begin + chunk < n ? begin + chunk : n;
+    for (int64_t base = begin; base < end; base += HP_THREADS * HP_BATCH) {
+      uint64_t k[HP_BATCH];
+      int64_t src[HP_BATCH];
+      uint32_t dst[HP_BATCH];
+#pragma unroll
+      for (int j = 0; j < HP_BATCH; ++j) {
+        const int64_t i = base + (int64_t)j * HP_THREADS + threadIdx.x;
+        src[j] = i < end ? i : end - 1;
+        k[j] = key[src[j]];
+      }
+#pragma unroll
+      for (int j = 0; j < HP_BATCH; ++j) {
+        const bool live = base + (int64_t)j * HP_THREADS + threadIdx.x < end;
+        dst[j] = live ? atomicAdd(&lds_cur[part_of(murmur3_32(k[j], 8), nparts, pow2mask)], 1u) : 0xffffffffu;
+        if (live && pc.dst_map) pc.dst_map[src[j]] = dst[j];
+      }
+      for (int col = 0; col < pc.ncols; ++col) {
+        uint64_t v[HP_BATCH];
+        switch (pc.width[col]) {      // loads of the batch first, then its stores
+          case 1:
+#pragma unroll
+            for (int j = 0; j < HP_BATCH; ++j) v[j] = ((const uint8_t *)pc.in[col])[src[j]];
+#pragma unroll
+            for (int j = 0; j < HP_BATCH; ++j) if (dst[j] != 0xffffffffu) ((uint8_t *)pc.out[col])[dst[j]] = (uint8_t)v[j];
+            break;
+          case 2:
+#pragma unroll
+            for (int j = 0; j < HP_BATCH; ++j) v[j] = ((const uint16_t *)pc.in[col])[src[j]];
+#pragma unroll
+            for (int j = 0; j < HP_BATCH; ++j) if (dst[j] != 0xffffffffu) ((uint16_t *)pc.out[col])[dst[j]] = (uint16_t)v[j];
+            break;
+          case 4:
+#pragma unroll
+            for (int j = 0; j < HP_BATCH; ++j) v[j] = ((const uint32_t *)pc.in[col])[src[j]];
+#pragma unroll
+            for (int j = 0; j < HP_BATCH; ++j) if (dst[j] != 0xffffffffu) ((uint32_t *)pc.out[col])[dst[j]] = (uint32_t)v[j];
+            break;
+          default:
+#pragma unroll
+            for (int j = 0; j < HP_BATCH; ++j) v[j] = ((const uint64_t *)pc.in[col])[src[j]];
+#pragma unroll
+            for (int j = 0; j < HP_BATCH; ++j) if (dst[j] != 0xffffffffu) ((uint64_t *)pc.out[col])[dst[j]] = v[j];
+        }
+        if (pc.out_valid[col]) {
+#pragma unroll
+          for (int j = 0; j < HP_BATCH; ++j)
+            if (dst[j] != 0xffffffffu && (!pc.in_valid[col] || bit_is_set(pc.in_valid[col], src[j])))
+              atomicOr(&pc.out_valid[col][dst[j] >> 5], 1u << (dst[j] & 31));
+        }
+      }
+    }
+    block_sync();
+  }
+}
+
 // P <= 256: LDS-regrouped scatter.  Same offsets contract as part_scatter_kernel.
 constexpr int HPT_ITEMS = 8;
 constexpr int HPT_TILE = HP_THREADS * HPT_ITEMS;
 constexpr int HPT_MAX_PARTS = 256;
 
-template <bool MURMUR>
+template <bool MURMUR, bool FAST8>
 __global__ __launch_bounds__(HP_THREADS) void part_scatter_tile_kernel(KeyTable t, PayloadCols pc, int64_t n, int64_t chunk,
                                                                        int nchunks, uint32_t nparts, uint32_t pow2mask,
                                                                        const uint32_t *__restrict__ offs) {
@@ -130,12 +226,20 @@ __global__ __launch_bounds__(HP_THREADS) void part_scatter_tile_kernel(KeyTable 
       if (threadIdx.x < HPT_MAX_PARTS) hist[threadIdx.x] = 0;
       block_sync();
       uint32_t pr[HPT_ITEMS];          // partition << 16 | rank within (tile, partition)
+      int64_t src[HPT_ITEMS];          // clamped row number: loads are unconditional and stay in flight together
+      uint64_t kk[HPT_ITEMS];
+#pragma unroll
+      for (int k = 0; k < HPT_ITEMS; ++k) {
+        const int64_t i = tile + (int64_t)k * HP_THREADS + threadIdx.x;
+        src[k] = i < end ? i : end - 1;
+        kk[k] = FAST8 ? ((const uint64_t *)t.col[0].data)[src[k]] : 0;
+      }
 #pragma unroll
       for (int k = 0; k < HPT_ITEMS; ++k) {
         const int64_t i = tile + (int64_t)k * HP_THREADS + threadIdx.x;
         pr[k] = 0xffffffffu;
         if (i < end) {
-          const uint32_t p = part_of(hash_row<MURMUR>(t, i), nparts, pow2mask);
+          const uint32_t p = part_of(FAST8 ? murmur3_32(kk[k], 8) : hash_row<MURMUR>(t, i), nparts, pow2mask);
           pr[k] = (p << 16) | atomicAdd(&hist[p], 1u);
         }
       }
@@ -176,20 +280,27 @@ __global__ __launch_bounds__(HP_THREADS) void part_scatter_tile_kernel(KeyTable 
       }
       for (int col = 0; col < pc.ncols; ++col) {
         const int width = pc.width[col];
+        uint64_t v[HPT_ITEMS];
+        switch (width) {
+          case 1:
 #pragma unroll
-        for (int k = 0; k < HPT_ITEMS; ++k) {
-          if (pr[k] != 0xffffffffu) {
-            const int64_t i = tile + (int64_t)k * HP_THREADS + threadIdx.x;
-            uint64_t v;
-            switch (width) {
-              case 1: v = ((const uint8_t *)pc.in[col])[i]; break;
-              case 2: v = ((const uint16_t *)pc.in[col])[i]; break;
-              case 4: v = ((const uint32_t *)pc.in[col])[i]; break;
-              default: v = ((const uint64_t *)pc.in[col])[i]; break;
-            }
-            stage[pos[k]] = v;
-          }
+            for (int k = 0; k < HPT_ITEMS; ++k) v[k] = ((const uint8_t *)pc.in[col])[src[k]];
+            break;
+          case 2:
+#pragma unroll
+            for (int k = 0; k < HPT_ITEMS; ++k) v[k] = ((const uint16_t *)pc.in[col])[src[k]];
+            break;
+          case 4:
+#pragma unroll
+            for (int k = 0; k < HPT_ITEMS; ++k) v[k] = ((const uint32_t *)pc.in[col])[src[k]];
+            break;
+          default:
+#pragma unroll
+            for (int k = 0; k < HPT_ITEMS; ++k) v[k] = ((const uint64_t *)pc.in[col])[src[k]];
         }
+#pragma unroll
+        for (int k = 0; k < HPT_ITEMS; ++k)
+          if (pr[k] != 0xffffffffu) stage[pos[k]] = v[k];
         block_sync();
         for (uint32_t j = threadIdx.x; j < total; j += HP_THREADS) {
           const uint32_t dst = gbase[bin_of[j]] + j;
@@ -300,7 +411,11 @@ gdf_error gdf_hash_partition(int num_input_cols, gdf_column *input[], int column
   RMM_TRY(hist.alloc(sizeof(uint32_t) * (size_t)P * nchunks));
   RMM_TRY(starts.alloc(sizeof(uint32_t) * P));
   const bool murmur = hash == GDF_HASH_MURMUR3;
-  if (murmur)
+  const bool fast8 = murmur && t.ncols == 1 && t.col[0].width == 8 && !getenv("GDF_HP_NO_FAST");
+  if (fast8)
+    GDF_LAUNCH("part_hist", part_hist_fast8_kernel, dim3(grid), dim3(HP_THREADS), lds, stream0(), (const uint64_t *)t.col[0].data, n, chunk, nchunks, P,
+               pow2mask, hist.as<uint32_t>());
+  else if (murmur)
     GDF_LAUNCH("part_hist", part_hist_kernel<true>, dim3(grid), dim3(HP_THREADS), lds, stream0(), t, n, chunk, nchunks, P, pow2mask, hist.as<uint32_t>());
   else
     hipLaunchKernelGGL(part_hist_kernel<false>, dim3(grid), dim3(HP_THREADS), lds, stream0(), t, n, chunk, nchunks, P, pow2mask, hist.as<uint32_t>());
@@ -341,11 +456,16 @@ gdf_error gdf_hash_partition(int num_input_cols, gdf_column *input[], int column
     else if (P > 16 && P <= (uint32_t)HPT_MAX_PARTS && !getenv("GDF_HP_NO_TILE")) {
       // measured at 1e8 rows x 2 int64 columns: P=256 1.47 ms vs 2.83 ms direct; at P=8 the direct kernel's runs are
       // long enough already (1.10 vs 1.19 ms), so small fan-outs keep it
-      if (murmur)
-        GDF_LAUNCH("part_scatter", part_scatter_tile_kernel<true>, dim3(grid), dim3(HP_THREADS), 0, stream0(), t, pc, n, chunk, nchunks, P, pow2mask, hist.as<uint32_t>());
+      if (fast8)
+        GDF_LAUNCH("part_scatter", (part_scatter_tile_kernel<true, true>), dim3(grid), dim3(HP_THREADS), 0, stream0(), t, pc, n, chunk, nchunks, P, pow2mask, hist.as<uint32_t>());
+      else if (murmur)
+        GDF_LAUNCH("part_scatter", (part_scatter_tile_kernel<true, false>), dim3(grid), dim3(HP_THREADS), 0, stream0(), t, pc, n, chunk, nchunks, P, pow2mask, hist.as<uint32_t>());
       else
-        hipLaunchKernelGGL(part_scatter_tile_kernel<false>, dim3(grid), dim3(HP_THREADS), 0, stream0(), t, pc, n, chunk, nchunks, P, pow2mask, hist.as<uint32_t>());
-    } else if (murmur)
+        hipLaunchKernelGGL((part_scatter_tile_kernel<false, false>), dim3(grid), dim3(HP_THREADS), 0, stream0(), t, pc, n, chunk, nchunks, P, pow2mask, hist.as<uint32_t>());
+    } else if (fast8)
+      GDF_LAUNCH("part_scatter", part_scatter_fast8_kernel, dim3(grid), dim3(HP_THREADS), lds, stream0(), (const uint64_t *)t.col[0].data, pc, n, chunk,
+                 nchunks, P, pow2mask, hist.as<uint32_t>());
+    else if (murmur)
       GDF_LAUNCH("part_scatter", part_scatter_kernel<true>, dim3(grid), dim3(HP_THREADS), lds, stream0(), t, pc, n, chunk, nchunks, P, pow2mask, hist.as<uint32_t>());
     else
       hipLaunchKernelGGL(part_scatter_kernel<false>, dim3(grid), dim3(HP_THREADS), lds, stream0(), t, pc, n, chunk, nchunks, P, pow2mask, hist.as<uint32_t>());

@@ -105,6 +105,16 @@ _PROTOTYPES = {
     "gpu_comparison_static_f64": (None, [_COLP, C.c_double, _COLP, C.c_int]),
     "gpu_comparison": (None, [_COLP, _COLP, _COLP, C.c_int]),
     "gpu_apply_stencil": (None, [_COLP, _COLP, _COLP]),
+    "gdf_ipc_parser_open": (C.c_void_p, [C.c_void_p, C.c_size_t]),
+    "gdf_ipc_parser_open_recordbatches": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),   # void in C; the value is ignored
+    "gdf_ipc_parser_close": (C.c_int, [C.c_void_p]),                                        # void in C
+    "gdf_ipc_parser_failed": (C.c_int, [C.c_void_p]),
+    "gdf_ipc_parser_to_json": (C.c_char_p, [C.c_void_p]),
+    "gdf_ipc_parser_get_error": (C.c_char_p, [C.c_void_p]),
+    "gdf_ipc_parser_get_data": (C.c_void_p, [C.c_void_p]),
+    "gdf_ipc_parser_get_data_offset": (C.c_int64, [C.c_void_p]),
+    "gdf_ipc_parser_get_schema_json": (C.c_char_p, [C.c_void_p]),
+    "gdf_ipc_parser_get_layout_json": (C.c_char_p, [C.c_void_p]),
     "gdf_order_by": (None, [C.c_size_t, _COLP, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gdf_filter": (None, [C.c_size_t, _COLP, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                           C.POINTER(C.c_size_t)]),

@@ -17,17 +17,6 @@ extern "C" {
                  unsigned *) { return GDF_UNSUPPORTED_METHOD; }
 #include "gdf/gdf_unsupported.def"
 
-gdf_ipc_parser_type *gdf_ipc_parser_open(const uint8_t *, size_t) { return nullptr; }
-void gdf_ipc_parser_open_recordbatches(gdf_ipc_parser_type *, const uint8_t *, size_t) {}
-void gdf_ipc_parser_close(gdf_ipc_parser_type *) {}
-int gdf_ipc_parser_failed(gdf_ipc_parser_type *) { return 1; }
-const char *gdf_ipc_parser_to_json(gdf_ipc_parser_type *) { return "{}"; }
-const char *gdf_ipc_parser_get_error(gdf_ipc_parser_type *) { return "Arrow IPC parsing is not part of this library"; }
-const void *gdf_ipc_parser_get_data(gdf_ipc_parser_type *) { return nullptr; }
-int64_t gdf_ipc_parser_get_data_offset(gdf_ipc_parser_type *) { return 0; }
-const char *gdf_ipc_parser_get_schema_json(gdf_ipc_parser_type *) { return "{}"; }
-const char *gdf_ipc_parser_get_layout_json(gdf_ipc_parser_type *) { return "{}"; }
-
 gdf_radixsort_plan_type *gdf_radixsort_plan(size_t, int, unsigned, unsigned) { return nullptr; }
 gdf_error gdf_radixsort_plan_setup(gdf_radixsort_plan_type *, size_t, size_t) { return GDF_UNSUPPORTED_METHOD; }
 gdf_error gdf_radixsort_plan_free(gdf_radixsort_plan_type *) { return GDF_UNSUPPORTED_METHOD; }

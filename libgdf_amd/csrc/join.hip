@@ -43,6 +43,7 @@
 #include "internal.h"
 
 #include <cmath>
+#include <cstdio>
 
 #include <algorithm>
 #include <cstdlib>
@@ -186,7 +187,7 @@ constexpr int JK_MAX_BUILD = 6144;          // largest build partition kept in L
 constexpr uint32_t JK_PROBE_CHUNK = 1u << 17;   // probe tuples per work unit
 constexpr int32_t JK_EMPTY = -1;
 constexpr uint32_t JK_NOPOS = 0xffffffffu;
-constexpr int JK_CUCKOO_MAX_MOVES = 24;
+constexpr int JK_CUCKOO_MAX_MOVES = 32;
 
 struct PartGeom {
   int fb, b1, b2;        // fine bits = b1 (level 1) + b2 (level 2)
@@ -543,7 +544,10 @@ struct ProbeArgs {
   int dbg;                      // experiment switch (env GDF_JK_DBG), 0 in production
   uint64_t kbias;               // see PartGeom::kbias
   int optimistic;               // WRITE pass without a count pass: unit u may write at most probe_count pairs
-  unsigned long long *opt_state; // [0] = pairs written by all units, [1] = some unit needed more room
+  unsigned long long *opt_state; // [0] = pairs written by all units, [1] = some unit needed more room,
+                                 // [2] = units jk_probe_fast left to the general kernel (cuckoo build did not settle)
+  uint32_t *unit_todo;           // jk_probe_fast appends the ids of such units here (opt_state[2] = how many);
+                                 // jk_probe: when non-null, workgroup b handles unit unit_todo[b]
 };
 
 // LDS image of one work unit's build partition (dynamic region, every carve 16-byte aligned):
@@ -597,7 +601,8 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const uint32_t H = a.nslots, cap = a.cap;
   const ProbeLds l = carve_probe_lds<NARROW>(lds_raw, cap, H);
-  const Unit u = a.units[blockIdx.x];
+  const uint32_t uid = a.unit_todo ? a.unit_todo[blockIdx.x] : blockIdx.x;     // second launch after jk_probe_fast: leftovers only
+  const Unit u = a.units[uid];
 
   // ---- stage the build partition, clear the table ----
   for (uint32_t i = threadIdx.x; i < u.build_count; i += JK_PROBE_THREADS) {
@@ -605,7 +610,7 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
     if (!NARROW) l.bi[i] = a.build.idx[u.build_begin + i];
   }
   for (uint32_t i = threadIdx.x; i < 2 * H; i += JK_PROBE_THREADS) l.T[i] = JK_NOPOS;
-  if (threadIdx.x == 0) { *l.unit_cursor = WRITE ? a.counts[blockIdx.x] : 0ull; *l.cuckoo_failed = 0; }
+  if (threadIdx.x == 0) { *l.unit_cursor = WRITE ? a.counts[uid] : 0ull; *l.cuckoo_failed = 0; }
   block_sync();
 
   // ---- cuckoo build: exchange positions until an empty slot absorbs the chain ----
@@ -637,42 +642,64 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
     block_sync();
   }
 
+  if (a.dbg & 128) return;      // experiment: build phase only
   // optimistic pass: the unit owns exactly probe_count output slots starting at its offset
-  const unsigned long long unit_base = WRITE ? a.counts[blockIdx.x] : 0ull;
+  const unsigned long long unit_base = WRITE ? a.counts[uid] : 0ull;
   const unsigned long long unit_end = (WRITE && a.optimistic) ? unit_base + u.probe_count : ~0ull;
   const bool need_row = WRITE || a.verify;
   unsigned long long my_count = 0;
-  for (uint32_t base = 0; base < u.probe_count; base += JK_PROBE_THREADS * JK_PROBE_BATCH) {
-    uint64_t k[JK_PROBE_BATCH];
-    int32_t prow[JK_PROBE_BATCH];
+  // NARROW tuples are fetched two at a time (16-byte loads from an even tuple index: `lead` is 1 when the unit starts on an
+  // odd one), which doubles the bytes every wave keeps in flight: with the loop streaming 8-byte words the kernel
+  // sat at 2.8 TB/s on the read side alone -- latency-bound at two workgroups per CU (profiles/r1_g_probe_ablation.md).
+  constexpr int VEC = NARROW ? 2 : 1;
+  constexpr int NB = JK_PROBE_BATCH * VEC;
+  const uint32_t lead = NARROW ? (u.probe_begin & 1u) : 0u;
+  const uint32_t vbegin = u.probe_begin - lead;
+  const uint32_t vtotal = lead + u.probe_count;
+  for (uint32_t base = 0; base < vtotal; base += JK_PROBE_THREADS * NB) {
+    uint64_t k[NB];
+    int32_t prow[NB];
+    bool act[NB];
 #pragma unroll
     for (int b = 0; b < JK_PROBE_BATCH; ++b) {      // all HBM loads first
-      const uint32_t i = base + b * JK_PROBE_THREADS + threadIdx.x;
-      const uint32_t ic = u.probe_begin + (i < u.probe_count ? i : u.probe_count - 1);   // clamped, unconditional
-      const uint64_t w = a.probe.w[ic];
-      k[b] = tup_key<NARROW>(w);
-      if (NARROW) prow[b] = (int32_t)(uint32_t)w;
-      else prow[b] = need_row ? a.probe.idx[ic] : 0;
+      if constexpr (NARROW) {
+        const uint32_t v = base + (b * JK_PROBE_THREADS + threadIdx.x) * 2;
+        const uint32_t last_pair = (vtotal - 1) & ~1u;
+        const ulonglong2 ww = *reinterpret_cast<const ulonglong2 *>(a.probe.w + vbegin + (v < last_pair ? v : last_pair));   // clamped, unconditional
+        k[2 * b] = tup_key<NARROW>(ww.x);
+        prow[2 * b] = (int32_t)(uint32_t)ww.x;
+        act[2 * b] = v >= lead && v < vtotal;
+        k[2 * b + VEC - 1] = tup_key<NARROW>(ww.y);
+        prow[2 * b + VEC - 1] = (int32_t)(uint32_t)ww.y;
+        act[2 * b + VEC - 1] = v + 1 < vtotal;
+      } else {
+        const uint32_t i = base + b * JK_PROBE_THREADS + threadIdx.x;
+        const uint32_t ic = u.probe_begin + (i < u.probe_count ? i : u.probe_count - 1);   // clamped, unconditional
+        k[b] = a.probe.w[ic];
+        prow[b] = need_row ? a.probe.idx[ic] : 0;
+        act[b] = i < u.probe_count;
+      }
     }
-    uint32_t cnt[JK_PROBE_BATCH];
-    uint32_t hit_a[JK_PROBE_BATCH], hit_b[JK_PROBE_BATCH];   // matching build positions (cuckoo mode: at most two)
+    uint32_t cnt[NB];
+    uint32_t hit_a[NB], hit_b[NB];   // matching build positions (cuckoo mode: at most two)
     if (cuckoo) {
-      uint32_t pa[JK_PROBE_BATCH], pb[JK_PROBE_BATCH];
+      uint32_t pa[NB], pb[NB];
 #pragma unroll
-      for (int b = 0; b < JK_PROBE_BATCH; ++b) {    // 8 independent table reads
+      for (int b = 0; b < NB; ++b) {    // 8 independent table reads
         const uint64_t raw = k[b] + a.kbias;
         pa[b] = l.T[hash_a(raw) & (H - 1)];
         pb[b] = l.T[H + (hash_b(raw) & (H - 1))];
+        if (a.dbg & 64) { pa[b] = (uint32_t)k[b] & 1023u; pb[b] = JK_NOPOS; }      // experiment: no table lookups
       }
-      uint64_t ka[JK_PROBE_BATCH], kb[JK_PROBE_BATCH];
+      uint64_t ka[NB], kb[NB];
 #pragma unroll
-      for (int b = 0; b < JK_PROBE_BATCH; ++b) {    // 8 independent key reads (position 0 stands in for "empty")
+      for (int b = 0; b < NB; ++b) {    // 8 independent key reads (position 0 stands in for "empty")
         ka[b] = tup_key<NARROW>(l.bw[pa[b] == JK_NOPOS ? 0 : pa[b]]);
         kb[b] = tup_key<NARROW>(l.bw[pb[b] == JK_NOPOS ? 0 : pb[b]]);
       }
 #pragma unroll
-      for (int b = 0; b < JK_PROBE_BATCH; ++b) {
-        const bool active = base + b * JK_PROBE_THREADS + threadIdx.x < u.probe_count;
+      for (int b = 0; b < NB; ++b) {
+        const bool active = act[b];
         bool ha = active && pa[b] != JK_NOPOS && ka[b] == k[b];
         bool hb = active && pb[b] != JK_NOPOS && kb[b] == k[b];
         if (a.verify) {
@@ -690,10 +717,10 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
     } else {
       const uint32_t mask = 2 * H - 1;
 #pragma unroll
-      for (int b = 0; b < JK_PROBE_BATCH; ++b) {
+      for (int b = 0; b < NB; ++b) {
         cnt[b] = 0;
         hit_a[b] = hit_b[b] = JK_NOPOS;
-        if (base + b * JK_PROBE_THREADS + threadIdx.x < u.probe_count) {
+        if (act[b]) {
           uint32_t slot = hash_b(k[b] + a.kbias) & mask;
           for (;;) {
             const uint32_t p = l.T[slot];
@@ -710,8 +737,8 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
       }
     }
 #pragma unroll
-    for (int b = 0; b < JK_PROBE_BATCH; ++b) {
-      const bool active = base + b * JK_PROBE_THREADS + threadIdx.x < u.probe_count;
+    for (int b = 0; b < NB; ++b) {
+      const bool active = act[b];
       uint32_t c = cnt[b];
       const bool pad = active && c == 0 && a.keep_unmatched_probe;   // LEFT / FULL: (probe, -1)
       if (pad) c = 1;
@@ -739,6 +766,7 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
           a.out_probe[pos] = prow[b];
           a.out_build[pos] = JK_EMPTY;
         } else if (c >= 1 && (cuckoo || c == 1)) {
+          if (a.dbg & 32) continue;                  // experiment: no output stores
           a.out_probe[pos] = prow[b];
           a.out_build[pos] = build_row<NARROW>(l, hit_a[b]);
           if (c == 2) {
@@ -774,8 +802,130 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
     if (threadIdx.x == 0) {
       unsigned long long t = 0;
       for (int w = 0; w < JK_PROBE_THREADS / WAVE; ++w) t += l.wave_cnt[w];
-      a.counts[blockIdx.x] = t;
+      a.counts[uid] = t;
     }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// 4b. The same write pass for the PLAIN case -- INNER join, NARROW tuples, exact keys (no verification on the
+// original columns), no FULL-join marks -- which is what C3 and every foreign-key join on <= 32-bit-range keys
+// runs.  jk_probe carries all the other cases in one body; per probe tuple it issued ~98 VALU + ~60 SALU
+// instructions and the kernel was VALU-bound at 4.2 ms (profiles/r1_g_probe_ablation.md).  Here: 32-bit keys and
+// unit-local 32-bit output positions (one scalar base pointer per array), the build tuple is read from LDS once
+// (key and row in one 64-bit word), no runtime switches in the loop.  A unit whose cuckoo build does not settle
+// is not handled here: it is flagged in unit_todo and the host runs jk_probe over the flagged units.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_fast(ProbeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const uint32_t H = a.nslots, cap = a.cap;
+  const ProbeLds l = carve_probe_lds<true>(lds_raw, cap, H);
+  unsigned int *lcur = (unsigned int *)l.unit_cursor;      // pairs written so far by this unit
+  const Unit u = a.units[blockIdx.x];
+  for (uint32_t i = threadIdx.x; i < u.build_count; i += JK_PROBE_THREADS) l.bw[i] = a.build.w[u.build_begin + i];
+  for (uint32_t i = threadIdx.x; i < 2 * H; i += JK_PROBE_THREADS) l.T[i] = JK_NOPOS;
+  if (threadIdx.x == 0) { *lcur = 0; *l.cuckoo_failed = 0; }
+  block_sync();
+  const uint32_t kb_lo = (uint32_t)a.kbias, kb_hi = (uint32_t)(a.kbias >> 32);
+  // raw key = key32 + kbias; fold = lo ^ hi * C (key_fold)
+  auto fold_of = [&](uint32_t key) -> uint32_t {
+    const uint32_t lo = key + kb_lo;
+    const uint32_t hi = kb_hi + (lo < key ? 1u : 0u);
+    return lo ^ (hi * 0x9e3779b1u);
+  };
+  // A cuckoo build that runs into a cycle (17 of C3's 32768 partitions with one fixed pair of hash functions) is
+  // repeated with another pair: `seed` perturbs the folded key before both slot hashes.  What still fails after
+  // four attempts holds a key more than twice and belongs to the general kernel's linear probing.
+  uint32_t seed = 0;
+  for (int attempt = 0; attempt < 4; ++attempt) {
+    for (uint32_t p0 = threadIdx.x; p0 < u.build_count; p0 += JK_PROBE_THREADS) {
+      uint32_t cur = p0, table = 0;
+      int moves = 0;
+      for (; moves < JK_CUCKOO_MAX_MOVES; ++moves) {
+        const uint32_t f = fold_of((uint32_t)(l.bw[cur] >> 32)) ^ seed;
+        const uint32_t slot = table ? H + (lowbias32(f ^ 0x68e31da4u) & (H - 1)) : (lowbias32(f) & (H - 1));
+        const uint32_t old = atomicExch(&l.T[slot], cur);
+        if (old == JK_NOPOS) break;
+        cur = old;
+        table ^= 1;
+      }
+      if (moves == JK_CUCKOO_MAX_MOVES) *l.cuckoo_failed = 1;
+    }
+    block_sync();
+    if (!*l.cuckoo_failed || attempt == 3) break;
+    block_sync();                                           // everyone has read the flag
+    for (uint32_t i = threadIdx.x; i < 2 * H; i += JK_PROBE_THREADS) l.T[i] = JK_NOPOS;
+    if (threadIdx.x == 0) *l.cuckoo_failed = 0;
+    seed += 0x9e3779b9u;
+    block_sync();
+  }
+  if (*l.cuckoo_failed || (a.dbg & 8)) {
+    if (threadIdx.x == 0) a.unit_todo[atomicAdd(&a.opt_state[2], 1ull)] = blockIdx.x;
+    return;
+  }
+  const unsigned long long unit_base = a.counts[blockIdx.x];
+  const uint32_t unit_cap = a.optimistic ? u.probe_count : 0xffffffffu;
+  int32_t *__restrict__ op = a.out_probe + unit_base;
+  int32_t *__restrict__ ob = a.out_build + unit_base;
+  constexpr int NB = JK_PROBE_BATCH * 2;
+  const uint32_t lead = u.probe_begin & 1u;
+  const uint64_t *__restrict__ src = a.probe.w + (u.probe_begin - lead);
+  const uint32_t vtotal = lead + u.probe_count;
+  const uint32_t last_pair = (vtotal - 1) & ~1u;
+  for (uint32_t base = 0; base < vtotal; base += JK_PROBE_THREADS * NB) {
+    uint32_t key[NB], prow[NB];
+    bool act[NB];
+#pragma unroll
+    for (int b = 0; b < JK_PROBE_BATCH; ++b) {      // all HBM loads first, 16 bytes each, clamped and unconditional
+      const uint32_t v = base + (b * JK_PROBE_THREADS + threadIdx.x) * 2;
+      const ulonglong2 ww = *reinterpret_cast<const ulonglong2 *>(src + (v < last_pair ? v : last_pair));
+      key[2 * b] = (uint32_t)(ww.x >> 32); prow[2 * b] = (uint32_t)ww.x; act[2 * b] = v >= lead && v < vtotal;
+      key[2 * b + 1] = (uint32_t)(ww.y >> 32); prow[2 * b + 1] = (uint32_t)ww.y; act[2 * b + 1] = v + 1 < vtotal;
+    }
+    uint32_t pa[NB], pb[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {                  // 2 independent table reads per tuple
+      const uint32_t f = fold_of(key[b]) ^ seed;
+      pa[b] = l.T[lowbias32(f) & (H - 1)];
+      pb[b] = l.T[H + (lowbias32(f ^ 0x68e31da4u) & (H - 1))];
+    }
+    uint64_t wa[NB], wb[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {                  // 2 independent tuple reads (position 0 stands in for "empty")
+      wa[b] = l.bw[pa[b] == JK_NOPOS ? 0 : pa[b]];
+      wb[b] = l.bw[pb[b] == JK_NOPOS ? 0 : pb[b]];
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const bool ha = act[b] && pa[b] != JK_NOPOS && (uint32_t)(wa[b] >> 32) == key[b];
+      const bool hb = act[b] && pb[b] != JK_NOPOS && (uint32_t)(wb[b] >> 32) == key[b];
+      const uint32_t c = (uint32_t)ha + (uint32_t)hb;
+      uint32_t pos;
+      if (__all(c <= 1)) {
+        const unsigned long long mm = __ballot(c == 1);
+        uint32_t wbase = 0;
+        if (lane_id() == 0 && mm) wbase = atomicAdd(lcur, (unsigned int)__popcll(mm));
+        pos = __shfl(wbase, 0, WAVE) + mask_rank(mm);
+      } else {
+        const uint32_t incl = wave_scan_incl(c);
+        const uint32_t wave_total = __shfl(incl, WAVE - 1, WAVE);
+        uint32_t wbase = 0;
+        if (lane_id() == 0) wbase = atomicAdd(lcur, wave_total);
+        pos = __shfl(wbase, 0, WAVE) + incl - c;
+      }
+      if (c) {
+        if (pos + c > unit_cap) a.opt_state[1] = 1;   // would spill into the next unit's slots: the host redoes the join two-pass
+        else if (!(a.dbg & 32)) {
+          op[pos] = (int32_t)prow[b];
+          ob[pos] = (int32_t)(uint32_t)(ha ? wa[b] : wb[b]);
+          if (c == 2) { op[pos + 1] = (int32_t)prow[b]; ob[pos + 1] = (int32_t)(uint32_t)wb[b]; }
+        }
+      }
+    }
+  }
+  if (a.optimistic) {
+    block_sync();
+    if (threadIdx.x == 0) atomicAdd(&a.opt_state[0], (unsigned long long)*lcur);
   }
 }
 
@@ -1059,7 +1209,7 @@ static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, Si
   if (!narrow && sc_threads == 1024) sc_threads = 512;       // 16384 x 12 B would not fit 160 KiB
   const int64_t JK_TILE = (int64_t)sc_threads * JK_SC_ITEMS;
 
-  RMM_TRY(sb->w[0].alloc(sizeof(uint64_t) * cap));
+  RMM_TRY(sb->w[0].alloc(sizeof(uint64_t) * (cap + 2)));      // + slack: the probe kernel's last 16-byte load may touch one tuple past the end
   if (!narrow) RMM_TRY(sb->idx[0].alloc(sizeof(int32_t) * cap));
   const Tuples t0 = sb->tuples(0);
   GDF_TRY(launch_scatter1(fast, narrow, sc_threads, t, plan, g, H1.as<uint32_t>(), t0));
@@ -1080,7 +1230,7 @@ static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, Si
     HIP_TRY(hipMemcpyAsync(d_coarse.p, coarse_off.data(), sizeof(uint32_t) * (ncoarse + 1), hipMemcpyHostToDevice, stream0()));
     HIP_TRY(hipMemcpyAsync(d_tiles.p, tile_prefix.data(), sizeof(uint32_t) * (ncoarse + 1), hipMemcpyHostToDevice, stream0()));
     HIP_TRY(hipMemcpyAsync(cursor.p, sb->fine_off.data(), sizeof(uint32_t) * nfine, hipMemcpyHostToDevice, stream0()));
-    RMM_TRY(sb->w[1].alloc(sizeof(uint64_t) * cap));
+    RMM_TRY(sb->w[1].alloc(sizeof(uint64_t) * (cap + 2)));
     if (!narrow) RMM_TRY(sb->idx[1].alloc(sizeof(int32_t) * cap));
     Level2Map m{d_coarse.as<uint32_t>(), d_coarse.as<uint32_t>() + 1, d_tiles.as<uint32_t>()};
     if (ntiles) GDF_TRY(launch_scatter2(narrow, sc_threads, ntiles, g, m, sb->tuples(0), cursor.as<uint32_t>(), sb->tuples(1)));
@@ -1213,6 +1363,26 @@ static gdf_error run_probe(bool narrow, bool write, const char *name, size_t nun
                 : run_probe<false>(write, name, nunits, lds, a, probe_t, build_t);
 }
 
+// WRITE pass over all units.  PLAIN joins (see jk_probe_fast) run the lean kernel first and hand the units whose
+// cuckoo build did not settle to the general one.  a.opt_state must point at 3 zeroed counters.
+static gdf_error run_write_pass(bool narrow, bool plain, size_t nunits, size_t lds, ProbeArgs a, const KeyTable &probe_t,
+                                const KeyTable &build_t) {
+  if (!nunits) return GDF_SUCCESS;
+  if (!(narrow && plain) || getenv("GDF_JK_NO_FAST")) return run_probe(narrow, true, "jk_probe_write", nunits, lds, a, probe_t, build_t);
+  DevBuf todo;
+  RMM_TRY(todo.alloc(sizeof(uint32_t) * nunits));
+  a.unit_todo = todo.as<uint32_t>();
+  HIP_TRY(hipFuncSetAttribute((const void *)jk_probe_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  GDF_LAUNCH("jk_probe_write", jk_probe_fast, dim3((unsigned)nunits), dim3(JK_PROBE_THREADS), lds, stream0(), a);
+  HIP_CHECK_LAST();
+  unsigned long long left = 0;
+  HIP_TRY(hipMemcpy(&left, a.opt_state + 2, sizeof(left), hipMemcpyDeviceToHost));
+  if (a.dbg & 256) fprintf(stderr, "jk_probe_fast: %llu of %zu units left to the general kernel\n", left, nunits);
+  if (left) GDF_TRY(run_probe(narrow, true, "jk_probe_write_general", (size_t)left, lds, a, probe_t, build_t));
+  HIP_TRY(hipStreamSynchronize(stream0()));      // `todo` goes out of scope
+  return GDF_SUCCESS;
+}
+
 // The join proper.  probe_t / build_t already reflect the INNER-join swap.
 // On success *out_probe / *out_build own rmm allocations of *out_n int32 each.
 static gdf_error hash_join_core(const KeyTable &probe_t, const KeyTable &build_t, JoinKind kind, int32_t **out_probe,
@@ -1290,6 +1460,7 @@ static gdf_error hash_join_core(const KeyTable &probe_t, const KeyTable &build_t
   a.dbg = getenv("GDF_JK_DBG") ? atoi(getenv("GDF_JK_DBG")) : 0;
   a.kbias = plan.kmin;
   const size_t probe_lds = probe_lds_bytes(narrow, cap_lds, H_lds);
+  const bool plain = kind == JOIN_INNER && !plan.verify;      // see jk_probe_fast
 
   // ---- optimistic single pass ----
   // A foreign-key -> primary-key join whose every probe row finds its key emits exactly one pair per
@@ -1326,9 +1497,9 @@ static gdf_error hash_join_core(const KeyTable &probe_t, const KeyTable &build_t
       RMM_TRY(op.alloc(sizeof(int32_t) * (total ? total : 1)));
       RMM_TRY(ob.alloc(sizeof(int32_t) * (total ? total : 1)));
       RMM_TRY(d_off.alloc(sizeof(uint64_t) * (nunits + 1)));
-      RMM_TRY(d_state.alloc(sizeof(unsigned long long) * 2));
+      RMM_TRY(d_state.alloc(sizeof(unsigned long long) * 4));
       HIP_TRY(hipMemcpyAsync(d_off.p, off.data(), sizeof(uint64_t) * (nunits + 1), hipMemcpyHostToDevice, stream0()));
-      HIP_TRY(hipMemsetAsync(d_state.p, 0, sizeof(unsigned long long) * 2, stream0()));
+      HIP_TRY(hipMemsetAsync(d_state.p, 0, sizeof(unsigned long long) * 4, stream0()));
       ProbeArgs oa = a;
       oa.counts = d_off.as<uint64_t>();
       oa.out_probe = op.as<int32_t>();
@@ -1336,7 +1507,7 @@ static gdf_error hash_join_core(const KeyTable &probe_t, const KeyTable &build_t
       oa.build_matched = nullptr;
       oa.optimistic = 1;
       oa.opt_state = d_state.as<unsigned long long>();
-      GDF_TRY(run_probe(narrow, true, "jk_probe_write", nunits, probe_lds, oa, probe_t, build_t));
+      GDF_TRY(run_write_pass(narrow, plain, nunits, probe_lds, oa, probe_t, build_t));
       unsigned long long st[2] = {0, 0};
       HIP_TRY(hipMemcpy(st, d_state.p, sizeof(st), hipMemcpyDeviceToHost));
       if (st[1] == 0 && st[0] == cap_pairs) {       // dense: every slot of every unit was written
@@ -1413,7 +1584,11 @@ static gdf_error hash_join_core(const KeyTable &probe_t, const KeyTable &build_t
   a.build_matched = nullptr;   // marks were taken in the count pass
 
   // ---- write pass ----
-  GDF_TRY(run_probe(narrow, true, "jk_probe_write", nunits, probe_lds, a, probe_t, build_t));
+  DevBuf d_wstate;
+  RMM_TRY(d_wstate.alloc(sizeof(unsigned long long) * 4));
+  HIP_TRY(hipMemsetAsync(d_wstate.p, 0, sizeof(unsigned long long) * 4, stream0()));
+  a.opt_state = d_wstate.as<unsigned long long>();
+  GDF_TRY(run_write_pass(narrow, plain, nunits, probe_lds, a, probe_t, build_t));
   for (size_t o = 0; o < oversize.size(); ++o) {
     const uint32_t f = oversize[o].f0, fe = oversize[o].f1;
     const uint32_t pn = P.fine_off[fe] - P.fine_off[f];

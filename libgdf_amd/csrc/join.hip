@@ -833,6 +833,11 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_fast(ProbeArgs a) {
     const uint32_t hi = kb_hi + (lo < key ? 1u : 0u);
     return lo ^ (hi * 0x9e3779b1u);
   };
+  // Slot hashes: the TOP log2(H) bits of two multiplicative hashes of the folded key.  One quarter-rate 32-bit
+  // multiply each instead of lowbias32's two multiplies and three xor-shifts: the keys of one partition are
+  // already a pseudo-random subset (the partition id comes from lowbias32), so the tables only need two
+  // different well-spread maps, and a build that does not settle is retried with another seed anyway.
+  const int hshift = 32 - (__ffs((int)H) - 1);
   // A cuckoo build that runs into a cycle (17 of C3's 32768 partitions with one fixed pair of hash functions) is
   // repeated with another pair: `seed` perturbs the folded key before both slot hashes.  What still fails after
   // four attempts holds a key more than twice and belongs to the general kernel's linear probing.
@@ -843,7 +848,7 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_fast(ProbeArgs a) {
       int moves = 0;
       for (; moves < JK_CUCKOO_MAX_MOVES; ++moves) {
         const uint32_t f = fold_of((uint32_t)(l.bw[cur] >> 32)) ^ seed;
-        const uint32_t slot = table ? H + (lowbias32(f ^ 0x68e31da4u) & (H - 1)) : (lowbias32(f) & (H - 1));
+        const uint32_t slot = table ? H + ((f * 0xc2b2ae35u) >> hshift) : ((f * 0x9e3779b1u) >> hshift);
         const uint32_t old = atomicExch(&l.T[slot], cur);
         if (old == JK_NOPOS) break;
         cur = old;
@@ -886,8 +891,8 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_fast(ProbeArgs a) {
 #pragma unroll
     for (int b = 0; b < NB; ++b) {                  // 2 independent table reads per tuple
       const uint32_t f = fold_of(key[b]) ^ seed;
-      pa[b] = l.T[lowbias32(f) & (H - 1)];
-      pb[b] = l.T[H + (lowbias32(f ^ 0x68e31da4u) & (H - 1))];
+      pa[b] = l.T[(f * 0x9e3779b1u) >> hshift];
+      pb[b] = l.T[H + ((f * 0xc2b2ae35u) >> hshift)];
     }
     uint64_t wa[NB], wb[NB];
 #pragma unroll
@@ -1090,6 +1095,7 @@ static PartGeom choose_geometry(int64_t build_rows) {
   while (fb < JK_MAX_FB && (build_rows >> fb) > JK_TARGET_BUILD) ++fb;
   g.fb = fb;
   g.b1 = fb <= 8 ? fb : (fb + 1) / 2;
+  if (getenv("GDF_JK_B1") && fb > 8) { const int b1 = atoi(getenv("GDF_JK_B1")); if (b1 >= fb - 8 && b1 <= 8) g.b1 = b1; }   // experiment switch
   g.b2 = fb - g.b1;
   return g;
 }
@@ -1862,6 +1868,7 @@ gdf_error debug_partition(gdf_column *col, int fb, uint64_t *out_key, int32_t *o
   g.dbg = getenv("GDF_JK_SDBG") ? atoi(getenv("GDF_JK_SDBG")) : 0;
   g.fb = fb;
   g.b1 = fb <= 8 ? fb : (fb + 1) / 2;
+  if (getenv("GDF_JK_B1") && fb > 8) { const int b1 = atoi(getenv("GDF_JK_B1")); if (b1 >= fb - 8 && b1 <= 8) g.b1 = b1; }   // experiment switch
   g.b2 = fb - g.b1;
   SideBufs sb;
   GDF_TRY(partition_side(t, plan, g, &sb, !plan.narrow && plan.mode == KM_RAW_INT && t.col[0].width == 8));

@@ -23,6 +23,8 @@ def collect(path, counter):
             short = m.group(1) if m else name.split("(")[0][-48:]
             if short == "jk_probe":       # jk_probe<WRITE, NARROW>: the label bench.py / GDF_LAUNCH use
                 short = "jk_probe_write" if (m.group(2) or "") == "<true" else "jk_probe_count"
+            if short == "jk_probe_fast":  # the plain-join write pass is launched under the same label
+                short = "jk_probe_write"
             tot[short] += float(r["Counter_Value"])
             disp[short].add(r["Dispatch_Id"])
     return tot, {k: len(v) for k, v in disp.items()}

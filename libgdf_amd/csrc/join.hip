@@ -42,6 +42,7 @@
 // size, pair order unspecified.
 #include "internal.h"
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 
@@ -1391,8 +1392,24 @@ static gdf_error run_write_pass(bool narrow, bool plain, size_t nunits, size_t l
 
 // The join proper.  probe_t / build_t already reflect the INNER-join swap.
 // On success *out_probe / *out_build own rmm allocations of *out_n int32 each.
+// host-side stage clock (GDF_JK_DBG & 512): where the time between the kernels goes
+struct StageClock {
+  bool on;
+  std::chrono::steady_clock::time_point t0, last;
+  explicit StageClock(bool enable) : on(enable), t0(std::chrono::steady_clock::now()), last(t0) {}
+  void mark(const char *what) {
+    if (!on) return;
+    (void)hipStreamSynchronize(stream0());
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "  [join] %-28s %8.3f ms (total %8.3f)\n", what, std::chrono::duration<double, std::milli>(now - last).count(),
+            std::chrono::duration<double, std::milli>(now - t0).count());
+    last = now;
+  }
+};
+
 static gdf_error hash_join_core(const KeyTable &probe_t, const KeyTable &build_t, JoinKind kind, int32_t **out_probe,
                                 int32_t **out_build, int64_t *out_n) {
+  StageClock clk(getenv("GDF_JK_DBG") && (atoi(getenv("GDF_JK_DBG")) & 512));
   KeyPlan plan = plan_keys(probe_t);
   const PartGeom g = choose_geometry(build_t.nrows);
   const uint32_t nfine = 1u << g.fb;
@@ -1401,6 +1418,7 @@ static gdf_error hash_join_core(const KeyTable &probe_t, const KeyTable &build_t
   SideBufs B, P;
   const bool range_candidate = !plan.narrow && plan.mode == KM_RAW_INT && build_t.col[0].width == 8;
   GDF_TRY(partition_side(build_t, plan, g, &B, range_candidate));   // may switch plan to the narrow format
+  clk.mark("partition build side");
   // The probe side is the big one (C3: 10x the build side): it is partitioned WITHOUT a histogram pass
   // when the build partitions all fit LDS (the global-table path wants contiguous partition runs).
   uint32_t largest_build = 0;
@@ -1414,6 +1432,7 @@ static gdf_error hash_join_core(const KeyTable &probe_t, const KeyTable &build_t
     GDF_TRY(partition_side(probe_t, plan, g, &P, false));
   }
   const bool narrow = plan.narrow != 0;
+  clk.mark("partition probe side");
 
   // ---- work units ----
   std::vector<Unit> units;
@@ -1468,6 +1487,7 @@ static gdf_error hash_join_core(const KeyTable &probe_t, const KeyTable &build_t
   const size_t probe_lds = probe_lds_bytes(narrow, cap_lds, H_lds);
   const bool plain = kind == JOIN_INNER && !plan.verify;      // see jk_probe_fast
 
+  clk.mark("units + argument setup");
   // ---- optimistic single pass ----
   // A foreign-key -> primary-key join whose every probe row finds its key emits exactly one pair per
   // probe tuple.  Then unit u's output is its probe_count slots at the prefix sum of the probe counts
@@ -1489,6 +1509,7 @@ static gdf_error hash_join_core(const KeyTable &probe_t, const KeyTable &build_t
     GDF_TRY(run_probe(narrow, false, "jk_probe_sample", nsample, probe_lds, sa, probe_t, build_t));
     std::vector<uint64_t> scount(nsample);
     HIP_TRY(hipMemcpy(scount.data(), d_scount.p, sizeof(uint64_t) * nsample, hipMemcpyDeviceToHost));
+    clk.mark("sample count");
     uint64_t sample_pairs = 0;
     for (uint64_t c : scount) sample_pairs += c;
     if (sample_pairs == sample_tuples) {
@@ -1513,9 +1534,11 @@ static gdf_error hash_join_core(const KeyTable &probe_t, const KeyTable &build_t
       oa.build_matched = nullptr;
       oa.optimistic = 1;
       oa.opt_state = d_state.as<unsigned long long>();
+      clk.mark("output allocation");
       GDF_TRY(run_write_pass(narrow, plain, nunits, probe_lds, oa, probe_t, build_t));
       unsigned long long st[2] = {0, 0};
       HIP_TRY(hipMemcpy(st, d_state.p, sizeof(st), hipMemcpyDeviceToHost));
+      clk.mark("write pass");
       if (st[1] == 0 && st[0] == cap_pairs) {       // dense: every slot of every unit was written
         if (probe_tail) {
           hipLaunchKernelGGL(jk_emit_unjoinable, dim3(small_grid(probe_t.nrows)), dim3(256), 0, stream0(), probe_t, plan,

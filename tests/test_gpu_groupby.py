@@ -57,9 +57,18 @@ OPS = ["sum", "min", "max", "count", "avg"]
 AGG_DTYPES = [np.int8, np.int16, np.int32, np.int64, np.float32, np.float64]
 
 
+@pytest.fixture(params=["direct", "dense"])
+def small_range_path(request, monkeypatch):
+    """Integer keys with a small value range take the direct-index path; GDF_GB_NO_DIRECT=1 keeps the dictionary
+    (dense) path covered on the same inputs."""
+    if request.param == "dense":
+        monkeypatch.setenv("GDF_GB_NO_DIRECT", "1")
+    return request.param
+
+
 @pytest.mark.parametrize("op", OPS)
 @pytest.mark.parametrize("agg_dtype", AGG_DTYPES, ids=lambda d: np.dtype(d).name)
-def test_single_int32_key(gdf, op, agg_dtype):
+def test_single_int32_key(gdf, op, agg_dtype, small_range_path):
     n = 30000
     keys = [gen_rand(np.int32, n, 0, 200)]
     vals = gen_rand(agg_dtype, n, -100, 100)
@@ -71,7 +80,7 @@ def test_single_int32_key(gdf, op, agg_dtype):
 @pytest.mark.parametrize("key_dtypes", [[np.int64], [np.int32, np.int32], [np.int64, np.int32], [np.int8, np.int16, np.int32],
                                         [np.float64], [np.int32, np.float32], [np.int64, np.int64, np.int64]],
                          ids=lambda d: "-".join(np.dtype(x).name for x in d))
-def test_key_shapes(gdf, op, key_dtypes):
+def test_key_shapes(gdf, op, key_dtypes, small_range_path):
     n = 20000
     keys = [gen_rand(dt, n, 0, 12) if np.dtype(dt).kind == "i" else np.round(gen_rand(dt, n) * 6).astype(dt) for dt in key_dtypes]
     vals = gen_rand(np.float64 if op != "count" else np.int32, n)
@@ -276,3 +285,33 @@ def test_many_groups_both_large_paths(gdf, op, path, monkeypatch):
     _check(gdf, op, [np.random.randint(-2**62, 2**62, n, dtype=np.int64) // 1000 * 1000], gen_rand(np.int32, n), out)   # 64-bit natural layout
     _check_masked(gdf, op, keys, vals, [np.random.random(n) > 0.02, None], np.random.random(n) > 0.5, out)
     _check_masked(gdf, op, keys, gen_rand(np.int64, n), [None, np.random.random(n) > 0.02], None, out)
+
+
+@pytest.mark.parametrize("op", OPS)
+def test_direct_path_ranges(gdf, op):
+    """Direct-index path edge cases: negative minima, several columns in mixed radix, a range just inside and just
+    outside the 12288-id limit, ids that never occur, constant columns."""
+    n = 100000
+    out = np.int64 if op == "count" else (np.float64 if op == "avg" else None)
+    _check(gdf, op, [gen_rand(np.int64, n, -6000, 6000)], gen_rand(np.int64, n), out)                  # span 12000: direct
+    _check(gdf, op, [gen_rand(np.int64, n, -6200, 6200)], gen_rand(np.int64, n), out)                  # span 12400: not direct
+    _check(gdf, op, [gen_rand(np.int8, n, -128, 127), gen_rand(np.int16, n, -20, 20)], gen_rand(np.float64, n), out)
+    k = (gen_rand(np.int32, n, 0, 50) * 97).astype(np.int32)                                           # sparse ids
+    _check(gdf, op, [k, np.full(n, 7, dtype=np.int64)], gen_rand(np.int32, n), out)
+    _check(gdf, op, [np.full(n, -(2 ** 62), dtype=np.int64) + gen_rand(np.int64, n, 0, 9)], gen_rand(np.float32, n), out)
+
+
+@pytest.mark.parametrize("case", ["inside_widened_window", "exact_range_after_bad_guess", "too_wide_after_bad_guess"])
+def test_direct_path_guessed_window(gdf, case):
+    """Above 2^20 rows a single key column's id window is guessed from the first 65536 rows and widened to the id
+    space; rows outside it make the library repeat with the exact range (or leave the direct path)."""
+    n = 1_300_000
+    k = gen_rand(np.int64, n, 0, 10)
+    if case == "inside_widened_window":
+        k[100_000:] = gen_rand(np.int64, n - 100_000, -3000, 3000)
+    elif case == "exact_range_after_bad_guess":
+        k[100_000:] = gen_rand(np.int64, n - 100_000, 0, 12000)
+    else:
+        k[100_000:] = gen_rand(np.int64, n - 100_000, 0, 50000)
+    for op in ("sum", "avg", "min"):
+        _check(gdf, op, [k], gen_rand(np.int64, n), np.float64 if op == "avg" else None)

@@ -1036,57 +1036,38 @@ __global__ __launch_bounds__(256) void gb_sorted_extract(KeyTable t, GbKeyPlan p
   }
 }
 
-// ---------------------------------------------------------------------------
-// host driver
-// ---------------------------------------------------------------------------
-static gdf_error group_by_hash(int ncols, gdf_column **cols, gdf_column *col_agg, gdf_column **out_keys,
-                               gdf_column *out_agg, int op, bool sort_result) {
-  // groupby.cuh:218-238
-  if (0 == ncols || nullptr == cols || nullptr == col_agg) return GDF_DATASET_EMPTY;
-  if (nullptr == out_keys || nullptr == out_agg) return GDF_DATASET_EMPTY;
-  if (0 == cols[0]->size || 0 == col_agg->size) return GDF_SUCCESS;
+// Everything the four aggregation paths share about one gdf_group_by_* call.
+struct GbJob {
+  int ncols;
+  gdf_column **out_keys;
+  gdf_column *out_agg;
+  int op;
+  bool sort_result;
   KeyTable t;
-  GDF_TRY(make_key_table(cols, ncols, &t));
-  const int64_t n = t.nrows;
-  if (n >= (int64_t)INT_MAX) return GDF_COLUMN_SIZE_TOO_BIG;
-
-  // dtype dispatch (groupby.cuh:86-190): COUNT is typed by the OUTPUT column, the rest by the input
-  const ElemKind in_kind = elem_kind(col_agg->dtype);
-  const ElemKind out_kind = elem_kind(out_agg->dtype);
-  if (op == OP_COUNT) { if (out_kind == K_BAD) return GDF_UNSUPPORTED_DTYPE; }
-  else if (in_kind == K_BAD) return GDF_UNSUPPORTED_DTYPE;
-  if (op == OP_AVG && (out_kind == K_BAD || out_agg->dtype == GDF_DATE32 || out_agg->dtype == GDF_DATE64 ||
-                       out_agg->dtype == GDF_TIMESTAMP || col_agg->dtype == GDF_DATE32 ||
-                       col_agg->dtype == GDF_DATE64 || col_agg->dtype == GDF_TIMESTAMP))
-    return GDF_UNSUPPORTED_DTYPE;   // groupby.cuh:376-385,409-418 list only the six numeric types
-  for (int c = 0; c < ncols; ++c)
-    if (!out_keys[c] || !out_keys[c]->data) return GDF_DATASET_EMPTY;
-  if (!out_agg->data) return GDF_DATASET_EMPTY;
-
-  GbKeyPlan plan = gb_plan_keys(t);
-  if (!plan.packed) GDF_TRY(gb_plan_range(t, &plan));
-  GbVal val{col_agg->data, (int)(op == OP_COUNT ? K_I8 : in_kind), (const uint8_t *)col_agg->valid};
-  // Validity masks (beyond the reference, which rejects them: sqls_ops.cu:1103-1106; semantics of
-  // SURVEY.md 8d C5 = pandas dropna): a row with a null in any key column is dropped; a null value is
-  // skipped, so SUM/MIN/MAX/AVG/COUNT run over the valid values of each group; a group without any
-  // valid value is reported with value 0 and, if the caller gave out_col_agg a mask, a cleared bit.
-  const bool masked = t.any_valid || val.valid != nullptr;
-  const bool avg = op == OP_AVG || (val.valid != nullptr && op != OP_COUNT);   // keep a per-group count of valid values
+  ElemKind in_kind, out_kind;
+  GbKeyPlan plan;
+  GbVal val;
+  bool masked;      // some key column or the value column carries a validity mask
+  bool counted;     // a per-group count of (valid) values is kept: AVG, or a masked value column
+  bool want_ok;     // the caller supplied out_col_agg->valid and groups can come out null
   DevBuf agg_ok;
-  const bool want_ok = val.valid != nullptr && op != OP_COUNT && out_agg->valid != nullptr;
+};
 
-  // workgroup geometry: one contiguous chunk of rows per workgroup
-  const int grid = stream_grid((size_t)n, GB_THREADS * 32, NUM_CU * 4);
-  int64_t chunk = (n + grid - 1) / grid;
-  const size_t lds = plan.packed ? (size_t)GB_LDS_SLOTS * 8 * (avg ? 3 : 2) + 16 : 0;
-
-  // The table is sized by GROUPS.  Start small (the common case) and grow x256 on
-  // overflow, up to the 2*N slots the reference always allocates.
-  uint64_t cap_max = 1;
-  while (cap_max < 2 * (uint64_t)n) cap_max <<= 1;
-  uint64_t T = cap_max < (1u << 18) ? cap_max : (1u << 18);
-
-  // ---- direct path: integer keys with a small value range, no masks ----
+// Path 1 -- direct index: integer keys with a small value range, no masks.  *done = false: not applicable.
+static gdf_error gb_path_direct(GbJob &j, bool *done) {
+  *done = false;
+  [[maybe_unused]] const int ncols = j.ncols;
+  [[maybe_unused]] gdf_column **out_keys = j.out_keys;
+  [[maybe_unused]] gdf_column *out_agg = j.out_agg;
+  [[maybe_unused]] const int op = j.op;
+  [[maybe_unused]] const bool sort_result = j.sort_result;
+  [[maybe_unused]] const KeyTable &t = j.t;
+  [[maybe_unused]] const int64_t n = j.t.nrows;
+  [[maybe_unused]] const ElemKind in_kind = j.in_kind, out_kind = j.out_kind;
+  [[maybe_unused]] const GbKeyPlan &plan = j.plan;
+  [[maybe_unused]] const GbVal &val = j.val;
+  [[maybe_unused]] const bool masked = j.masked, avg = j.counted, want_ok = j.want_ok;
+  [[maybe_unused]] DevBuf &agg_ok = j.agg_ok;
   bool all_int = true;
   for (int c = 0; c < ncols; ++c) all_int = all_int && t.col[c].kind != K_F32 && t.col[c].kind != K_F64;
   if (all_int && !masked && n >= 4096 && !getenv("GDF_GB_NO_DIRECT")) {
@@ -1160,11 +1141,35 @@ static gdf_error group_by_hash(int ncols, gdf_column **cols, gdf_column *col_agg
       if (res[1]) continue;                                                          // guessed window too small: exact ranges next
       for (int c = 0; c < ncols; ++c) out_keys[c]->size = (gdf_size_type)res[0];
       out_agg->size = (gdf_size_type)res[0];
+      *done = true;
       return write_output_masks(ncols, out_keys, out_agg, nullptr, res[0]);          // ids ascend: the output is already sorted
     }
   }
 
-  // ---- dense path: packed keys and few enough groups for per-workgroup LDS accumulators ----
+  return GDF_SUCCESS;
+}
+
+// Path 2 -- dense ids: packed keys and few enough groups for per-workgroup LDS accumulators.
+static gdf_error gb_path_dense(GbJob &j, bool *done) {
+  *done = false;
+  [[maybe_unused]] const int ncols = j.ncols;
+  [[maybe_unused]] gdf_column **out_keys = j.out_keys;
+  [[maybe_unused]] gdf_column *out_agg = j.out_agg;
+  [[maybe_unused]] const int op = j.op;
+  [[maybe_unused]] const bool sort_result = j.sort_result;
+  [[maybe_unused]] const KeyTable &t = j.t;
+  [[maybe_unused]] const int64_t n = j.t.nrows;
+  [[maybe_unused]] const ElemKind in_kind = j.in_kind, out_kind = j.out_kind;
+  [[maybe_unused]] const GbKeyPlan &plan = j.plan;
+  [[maybe_unused]] const GbVal &val = j.val;
+  [[maybe_unused]] const bool masked = j.masked, avg = j.counted, want_ok = j.want_ok;
+  [[maybe_unused]] DevBuf &agg_ok = j.agg_ok;
+  // The table is sized by GROUPS.  Start small (the common case) and grow x256 on
+  // overflow, up to the 2*N slots the reference always allocates.
+  uint64_t cap_max = 1;
+  while (cap_max < 2 * (uint64_t)n) cap_max <<= 1;
+  uint64_t T = cap_max < (1u << 18) ? cap_max : (1u << 18);
+  (void)cap_max;
   if (plan.packed && !getenv("GDF_GB_NO_DENSE")) {
     DevBuf dict, flags, group_slot;
     RMM_TRY(dict.alloc(sizeof(GbDictEntry) * (T + 1)));
@@ -1251,12 +1256,30 @@ static gdf_error group_by_hash(int ncols, gdf_column **cols, gdf_column *col_agg
         for (int c = 0; c < ncols; ++c) kinds[c] = t.col[c].kind;
         GDF_TRY(sort_result_rows(ncols, out_keys, kinds, out_agg->data, kind_width((ElemKind)o.agg_kind), ngroups, o.agg_ok));
       }
+      *done = true;
       return write_output_masks(ncols, out_keys, out_agg, o.agg_ok, ngroups);
     }
     // too many groups for LDS accumulators
   }
 
-  // ---- sorted path: packed keys, many groups ----
+  return GDF_SUCCESS;
+}
+
+// Path 3 -- sorted: packed keys, many groups.
+static gdf_error gb_path_sorted(GbJob &j, bool *done) {
+  *done = false;
+  [[maybe_unused]] const int ncols = j.ncols;
+  [[maybe_unused]] gdf_column **out_keys = j.out_keys;
+  [[maybe_unused]] gdf_column *out_agg = j.out_agg;
+  [[maybe_unused]] const int op = j.op;
+  [[maybe_unused]] const bool sort_result = j.sort_result;
+  [[maybe_unused]] const KeyTable &t = j.t;
+  [[maybe_unused]] const int64_t n = j.t.nrows;
+  [[maybe_unused]] const ElemKind in_kind = j.in_kind, out_kind = j.out_kind;
+  [[maybe_unused]] const GbKeyPlan &plan = j.plan;
+  [[maybe_unused]] const GbVal &val = j.val;
+  [[maybe_unused]] const bool masked = j.masked, avg = j.counted, want_ok = j.want_ok;
+  [[maybe_unused]] DevBuf &agg_ok = j.agg_ok;
   if (plan.packed && !getenv("GDF_GB_NO_SORTED")) {
     GbKeyPlan sp = plan;
     if (!sp.ordered) GDF_TRY(gb_plan_range(t, &sp));          // fewer key bits = fewer radix passes, and sorted output for free
@@ -1324,9 +1347,36 @@ static gdf_error group_by_hash(int ncols, gdf_column **cols, gdf_column *col_agg
         for (int c = 0; c < ncols; ++c) kinds[c] = t.col[c].kind;
         GDF_TRY(sort_result_rows(ncols, out_keys, kinds, out_agg->data, kind_width((ElemKind)o.agg_kind), ngroups, o.agg_ok));
       }
+      *done = true;
       return write_output_masks(ncols, out_keys, out_agg, o.agg_ok, ngroups);
     }
   }
+  return GDF_SUCCESS;
+}
+
+// Path 4 -- hash table: LDS pre-aggregation in front of a global table (float keys, keys that do not pack).
+static gdf_error gb_path_table(GbJob &j) {
+  [[maybe_unused]] const int ncols = j.ncols;
+  [[maybe_unused]] gdf_column **out_keys = j.out_keys;
+  [[maybe_unused]] gdf_column *out_agg = j.out_agg;
+  [[maybe_unused]] const int op = j.op;
+  [[maybe_unused]] const bool sort_result = j.sort_result;
+  [[maybe_unused]] const KeyTable &t = j.t;
+  [[maybe_unused]] const int64_t n = j.t.nrows;
+  [[maybe_unused]] const ElemKind in_kind = j.in_kind, out_kind = j.out_kind;
+  [[maybe_unused]] const GbKeyPlan &plan = j.plan;
+  [[maybe_unused]] const GbVal &val = j.val;
+  [[maybe_unused]] const bool masked = j.masked, avg = j.counted, want_ok = j.want_ok;
+  [[maybe_unused]] DevBuf &agg_ok = j.agg_ok;
+  // The table is sized by GROUPS.  Start small (the common case) and grow x256 on
+  // overflow, up to the 2*N slots the reference always allocates.
+  uint64_t cap_max = 1;
+  while (cap_max < 2 * (uint64_t)n) cap_max <<= 1;
+  uint64_t T = cap_max < (1u << 18) ? cap_max : (1u << 18);
+  // workgroup geometry: one contiguous chunk of rows per workgroup
+  const int grid = stream_grid((size_t)n, GB_THREADS * 32, NUM_CU * 4);
+  int64_t chunk = (n + grid - 1) / grid;
+  const size_t lds = plan.packed ? (size_t)GB_LDS_SLOTS * 8 * (avg ? 3 : 2) + 16 : 0;
   for (;;) {
     DevBuf keys, first, acc, cnt, flags, out_count;
     if (plan.packed) RMM_TRY(keys.alloc(sizeof(uint64_t) * (T + 1))); else RMM_TRY(first.alloc(sizeof(int32_t) * (T + 1)));
@@ -1388,6 +1438,66 @@ static gdf_error group_by_hash(int ncols, gdf_column **cols, gdf_column *col_agg
     }
     return write_output_masks(ncols, out_keys, out_agg, o.agg_ok, (uint32_t)ngroups);
   }
+}
+
+// ---------------------------------------------------------------------------
+// host driver
+// ---------------------------------------------------------------------------
+static gdf_error group_by_hash(int ncols, gdf_column **cols, gdf_column *col_agg, gdf_column **out_keys,
+                               gdf_column *out_agg, int op, bool sort_result) {
+  // groupby.cuh:218-238
+  if (0 == ncols || nullptr == cols || nullptr == col_agg) return GDF_DATASET_EMPTY;
+  if (nullptr == out_keys || nullptr == out_agg) return GDF_DATASET_EMPTY;
+  if (0 == cols[0]->size || 0 == col_agg->size) return GDF_SUCCESS;
+  KeyTable t;
+  GDF_TRY(make_key_table(cols, ncols, &t));
+  const int64_t n = t.nrows;
+  if (n >= (int64_t)INT_MAX) return GDF_COLUMN_SIZE_TOO_BIG;
+
+  // dtype dispatch (groupby.cuh:86-190): COUNT is typed by the OUTPUT column, the rest by the input
+  const ElemKind in_kind = elem_kind(col_agg->dtype);
+  const ElemKind out_kind = elem_kind(out_agg->dtype);
+  if (op == OP_COUNT) { if (out_kind == K_BAD) return GDF_UNSUPPORTED_DTYPE; }
+  else if (in_kind == K_BAD) return GDF_UNSUPPORTED_DTYPE;
+  if (op == OP_AVG && (out_kind == K_BAD || out_agg->dtype == GDF_DATE32 || out_agg->dtype == GDF_DATE64 ||
+                       out_agg->dtype == GDF_TIMESTAMP || col_agg->dtype == GDF_DATE32 ||
+                       col_agg->dtype == GDF_DATE64 || col_agg->dtype == GDF_TIMESTAMP))
+    return GDF_UNSUPPORTED_DTYPE;   // groupby.cuh:376-385,409-418 list only the six numeric types
+  for (int c = 0; c < ncols; ++c)
+    if (!out_keys[c] || !out_keys[c]->data) return GDF_DATASET_EMPTY;
+  if (!out_agg->data) return GDF_DATASET_EMPTY;
+
+  GbJob j{};
+  j.ncols = ncols;
+  j.out_keys = out_keys;
+  j.out_agg = out_agg;
+  j.op = op;
+  j.sort_result = sort_result;
+  j.t = t;
+  j.in_kind = in_kind;
+  j.out_kind = out_kind;
+  j.plan = gb_plan_keys(t);
+  if (!j.plan.packed) GDF_TRY(gb_plan_range(t, &j.plan));
+  j.val = GbVal{col_agg->data, (int)(op == OP_COUNT ? K_I8 : in_kind), (const uint8_t *)col_agg->valid};
+  // Validity masks (beyond the reference, which rejects them: sqls_ops.cu:1103-1106; semantics of
+  // SURVEY.md 8d C5 = pandas dropna): a row with a null in any key column is dropped; a null value is
+  // skipped, so SUM/MIN/MAX/AVG/COUNT run over the valid values of each group; a group without any
+  // valid value is reported with value 0 and, if the caller gave out_col_agg a mask, a cleared bit.
+  j.masked = t.any_valid || j.val.valid != nullptr;
+  j.counted = op == OP_AVG || (j.val.valid != nullptr && op != OP_COUNT);
+  j.want_ok = j.val.valid != nullptr && op != OP_COUNT && out_agg->valid != nullptr;
+
+  // the four paths, cheapest first; each declines (done == false) what it cannot take
+  bool done = false;
+  GDF_TRY(gb_path_direct(j, &done));
+  if (done) return GDF_SUCCESS;
+  if (j.plan.packed) {
+    GDF_TRY(gb_path_dense(j, &done));
+    if (done) return GDF_SUCCESS;
+    GDF_TRY(gb_path_sorted(j, &done));
+    if (done) return GDF_SUCCESS;
+  }
+  return gb_path_table(j);
 }
 
 // sqls_ops.cu:1085-1363 gdf_group_by_single

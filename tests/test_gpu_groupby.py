@@ -271,12 +271,16 @@ def test_sort_method_still_rejects_masks(gdf):
 
 
 @pytest.mark.parametrize("op", OPS)
-@pytest.mark.parametrize("path", ["sorted", "hash_table"])
+@pytest.mark.parametrize("path", ["partitioned", "sorted", "hash_table"])
 def test_many_groups_both_large_paths(gdf, op, path, monkeypatch):
-    """Beyond 16384 groups the packed-key group-by sorts (key, value) pairs and reduces segments; GDF_GB_NO_SORTED=1
-    keeps the global hash table.  Both must give the oracle's answer, masked or not."""
+    """Beyond the LDS-resident paths the packed-key group-by radix sorts (key, value) pairs: only the high key bits
+    when the low 13 can index LDS accumulators directly ("partitioned"), the whole key otherwise ("sorted",
+    forced here with GDF_GB_NO_PART=1); GDF_GB_NO_SORTED=1 keeps the global hash table.  All three must give the
+    oracle's answer, masked or not."""
     if path == "hash_table":
         monkeypatch.setenv("GDF_GB_NO_SORTED", "1")
+    if path == "sorted":
+        monkeypatch.setenv("GDF_GB_NO_PART", "1")
     n = 300000
     keys = [gen_rand(np.int64, n, -40000, 40000), gen_rand(np.int16, n, 0, 2)]
     vals = gen_rand(np.float64, n)

@@ -343,3 +343,30 @@ def test_speculative_matches_exact_at_scale(gdf, monkeypatch):
     a = torch.sort(li.long() * nb + ri.long()).values
     c = torch.sort(le.long() * nb + re_.long()).values
     assert torch.equal(a, c)
+
+
+def test_randomized_inner_join_properties(gdf):
+    """60 random shapes (sizes, key ranges, duplicate rates, int32 / int64 keys) checked by properties that do not
+    need the oracle: the number of pairs equals sum_probe multiplicity_in_build(key), every pair joins equal keys,
+    and no pair occurs twice.  Exercises the lean and the general write kernels, cuckoo retries, the
+    linear-probing fallback (duplicate build keys) and both partition layouts."""
+    import torch
+    from libgdf_amd.columns import Column
+    g = torch.Generator(device="cuda")
+    g.manual_seed(20260928)
+    for it in range(60):
+        nb = int(torch.randint(1_000, 300_000, (1,), generator=g, device="cuda"))
+        npr = int(torch.randint(10_000, 2_000_000, (1,), generator=g, device="cuda"))
+        spread = [0.3, 1.0, 3.0, 1000.0][it % 4]                       # < 1: duplicate build keys; > 1: probes that miss
+        space = max(2, int(nb * spread))
+        dtype = torch.int64 if it % 3 else torch.int32
+        base = 0 if it % 5 else (1 << 40 if dtype == torch.int64 else -1_000_000)
+        build = (torch.randint(0, space, (nb,), generator=g, device="cuda") + base).to(dtype)
+        probe = (torch.randint(0, space, (npr,), generator=g, device="cuda") + base).to(dtype)
+        li, ri = gdf.api.join([Column(probe)], [Column(build)])
+        mult = torch.bincount((build.long() - base), minlength=space)
+        expected = int(mult[(probe.long() - base)].sum())
+        assert li.numel() == expected, (it, nb, npr, space, li.numel(), expected)
+        assert bool((probe[li.long()] == build[ri.long()]).all()), it
+        pair = li.long() * nb + ri.long()
+        assert int(torch.unique(pair).numel()) == expected, it

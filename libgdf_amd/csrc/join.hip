@@ -817,6 +817,9 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
 // (key and row in one 64-bit word), no runtime switches in the loop.  A unit whose cuckoo build does not settle
 // is not handled here: it is flagged in unit_todo and the host runs jk_probe over the flagged units.
 // ---------------------------------------------------------------------------
+// POW2: H is a power of two and a slot is the top log2(H) bits of the hash product; otherwise H is any size
+// (chosen by the host for a 40 % table load) and a slot is mulhi(hash product, H).
+template <bool POW2>
 __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_fast(ProbeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const uint32_t H = a.nslots, cap = a.cap;
@@ -838,7 +841,7 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_fast(ProbeArgs a) {
   // multiply each instead of lowbias32's two multiplies and three xor-shifts: the keys of one partition are
   // already a pseudo-random subset (the partition id comes from lowbias32), so the tables only need two
   // different well-spread maps, and a build that does not settle is retried with another seed anyway.
-  const int hshift = 32 - (__ffs((int)H) - 1);
+  const int hshift = POW2 ? 32 - (__ffs((int)H) - 1) : 0;
   // A cuckoo build that runs into a cycle (17 of C3's 32768 partitions with one fixed pair of hash functions) is
   // repeated with another pair: `seed` perturbs the folded key before both slot hashes.  What still fails after
   // four attempts holds a key more than twice and belongs to the general kernel's linear probing.
@@ -849,7 +852,8 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_fast(ProbeArgs a) {
       int moves = 0;
       for (; moves < JK_CUCKOO_MAX_MOVES; ++moves) {
         const uint32_t f = fold_of((uint32_t)(l.bw[cur] >> 32)) ^ seed;
-        const uint32_t slot = table ? H + ((f * 0xc2b2ae35u) >> hshift) : ((f * 0x9e3779b1u) >> hshift);
+        const uint32_t slot = table ? H + (POW2 ? (f * 0xc2b2ae35u) >> hshift : __umulhi(f * 0xc2b2ae35u, H))
+                                    : (POW2 ? (f * 0x9e3779b1u) >> hshift : __umulhi(f * 0x9e3779b1u, H));
         const uint32_t old = atomicExch(&l.T[slot], cur);
         if (old == JK_NOPOS) break;
         cur = old;
@@ -892,8 +896,8 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_fast(ProbeArgs a) {
 #pragma unroll
     for (int b = 0; b < NB; ++b) {                  // 2 independent table reads per tuple
       const uint32_t f = fold_of(key[b]) ^ seed;
-      pa[b] = l.T[(f * 0x9e3779b1u) >> hshift];
-      pb[b] = l.T[H + ((f * 0xc2b2ae35u) >> hshift)];
+      pa[b] = l.T[POW2 ? (f * 0x9e3779b1u) >> hshift : __umulhi(f * 0x9e3779b1u, H)];
+      pb[b] = l.T[H + (POW2 ? (f * 0xc2b2ae35u) >> hshift : __umulhi(f * 0xc2b2ae35u, H))];
     }
     uint64_t wa[NB], wb[NB];
 #pragma unroll
@@ -1372,15 +1376,30 @@ static gdf_error run_probe(bool narrow, bool write, const char *name, size_t nun
 
 // WRITE pass over all units.  PLAIN joins (see jk_probe_fast) run the lean kernel first and hand the units whose
 // cuckoo build did not settle to the general one.  a.opt_state must point at 3 zeroed counters.
-static gdf_error run_write_pass(bool narrow, bool plain, size_t nunits, size_t lds, ProbeArgs a, const KeyTable &probe_t,
-                                const KeyTable &build_t) {
+static gdf_error run_write_pass(bool narrow, bool plain, size_t nunits, size_t lds, ProbeArgs a, uint32_t max_build,
+                                const KeyTable &probe_t, const KeyTable &build_t) {
   if (!nunits) return GDF_SUCCESS;
   if (!(narrow && plain) || getenv("GDF_JK_NO_FAST")) return run_probe(narrow, true, "jk_probe_write", nunits, lds, a, probe_t, build_t);
   DevBuf todo;
   RMM_TRY(todo.alloc(sizeof(uint32_t) * nunits));
   a.unit_todo = todo.as<uint32_t>();
-  HIP_TRY(hipFuncSetAttribute((const void *)jk_probe_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  GDF_LAUNCH("jk_probe_write", jk_probe_fast, dim3((unsigned)nunits), dim3(JK_PROBE_THREADS), lds, stream0(), a);
+  // The general kernel's H is the power of two >= the largest build partition: between 25 % and 50 % table load.
+  // A cuckoo build above ~42 % runs into cycles often (measured at 1.25e8 build rows: 3814 tuples per partition in
+  // 2 x 4096 slots), so the lean kernel then sizes its tables for 40 % and takes slots with a mulhi.
+  ProbeArgs fa = a;
+  size_t flds = lds;
+  const bool pow2 = (double)max_build <= 0.42 * 2.0 * (double)a.nslots;
+  if (!pow2) {
+    fa.nslots = ((uint32_t)(max_build * 1.25) + 63) & ~63u;
+    flds = probe_lds_bytes(true, a.cap, fa.nslots);
+  }
+  if (pow2) {
+    HIP_TRY(hipFuncSetAttribute((const void *)jk_probe_fast<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
+    GDF_LAUNCH("jk_probe_write", jk_probe_fast<true>, dim3((unsigned)nunits), dim3(JK_PROBE_THREADS), flds, stream0(), fa);
+  } else {
+    HIP_TRY(hipFuncSetAttribute((const void *)jk_probe_fast<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
+    GDF_LAUNCH("jk_probe_write", jk_probe_fast<false>, dim3((unsigned)nunits), dim3(JK_PROBE_THREADS), flds, stream0(), fa);
+  }
   HIP_CHECK_LAST();
   unsigned long long left = 0;
   HIP_TRY(hipMemcpy(&left, a.opt_state + 2, sizeof(left), hipMemcpyDeviceToHost));
@@ -1535,7 +1554,7 @@ static gdf_error hash_join_core(const KeyTable &probe_t, const KeyTable &build_t
       oa.optimistic = 1;
       oa.opt_state = d_state.as<unsigned long long>();
       clk.mark("output allocation");
-      GDF_TRY(run_write_pass(narrow, plain, nunits, probe_lds, oa, probe_t, build_t));
+      GDF_TRY(run_write_pass(narrow, plain, nunits, probe_lds, oa, max_build, probe_t, build_t));
       unsigned long long st[2] = {0, 0};
       HIP_TRY(hipMemcpy(st, d_state.p, sizeof(st), hipMemcpyDeviceToHost));
       clk.mark("write pass");
@@ -1617,7 +1636,7 @@ static gdf_error hash_join_core(const KeyTable &probe_t, const KeyTable &build_t
   RMM_TRY(d_wstate.alloc(sizeof(unsigned long long) * 4));
   HIP_TRY(hipMemsetAsync(d_wstate.p, 0, sizeof(unsigned long long) * 4, stream0()));
   a.opt_state = d_wstate.as<unsigned long long>();
-  GDF_TRY(run_write_pass(narrow, plain, nunits, probe_lds, a, probe_t, build_t));
+  GDF_TRY(run_write_pass(narrow, plain, nunits, probe_lds, a, max_build, probe_t, build_t));
   for (size_t o = 0; o < oversize.size(); ++o) {
     const uint32_t f = oversize[o].f0, fe = oversize[o].f1;
     const uint32_t pn = P.fine_off[fe] - P.fine_off[f];

@@ -43,8 +43,33 @@ def _int_array(values):
     return (C.c_int * len(values))(*values)
 
 
-def join(left, right, left_on=None, right_on=None, how="inner", method=GDF_HASH):
-    """gdf_{inner,left,full}_join over lists of Column -> (left_idx, right_idx) int32 tensors."""
+class LibraryIndexColumn:
+    """A join index column still owned by the library (int32, device memory): ``numel()`` is free, ``tensor()``
+    copies it into a torch tensor on first use; the library buffer is released when this object dies."""
+
+    def __init__(self, col: gdf_column):
+        self._col = col
+        self._tensor = None
+
+    def numel(self) -> int:
+        return int(self._col.size) if self._tensor is None else int(self._tensor.numel())
+
+    def tensor(self):
+        import torch
+        if self._tensor is None:
+            self._tensor = _take_library_column(self._col, torch.int32)
+            self._col = None
+        return self._tensor
+
+    def __del__(self):
+        if getattr(self, "_col", None) is not None and self._col.data:
+            libgdf.gdf_column_free(C.byref(self._col))
+            self._col = None
+
+
+def join(left, right, left_on=None, right_on=None, how="inner", method=GDF_HASH, copy=True):
+    """gdf_{inner,left,full}_join over lists of Column -> (left_idx, right_idx) int32 tensors, or, with
+    ``copy=False``, two :class:`LibraryIndexColumn` that leave the pairs in the library's buffers."""
     import torch
     left_on = list(range(len(left))) if left_on is None else list(left_on)
     right_on = list(range(len(right))) if right_on is None else list(right_on)
@@ -54,6 +79,8 @@ def join(left, right, left_on=None, right_on=None, how="inner", method=GDF_HASH)
     la, ra = column_array(left), column_array(right)
     fn(la, len(left), _int_array(left_on), ra, len(right), _int_array(right_on), len(left_on), 0, None,
        C.byref(li), C.byref(ri), C.byref(ctx))
+    if not copy:
+        return LibraryIndexColumn(li), LibraryIndexColumn(ri)
     return _take_library_column(li, torch.int32), _take_library_column(ri, torch.int32)
 
 

@@ -21,6 +21,7 @@
 // increasing p; order inside a partition is unspecified.
 #include "hash.cuh"
 #include "internal.h"
+#include "gdf/gdf_amd_ext.h"
 
 #include <cstdlib>
 #include <vector>
@@ -63,13 +64,15 @@ __global__ __launch_bounds__(HP_THREADS) void part_hist_kernel(KeyTable t, int64
   }
 }
 
-// FAST8 variants: ONE 8-byte key column hashed with Murmur3 (the common shape: an int64 / float64 / date64 key).
+// FAST variants (K = uint64_t / uint32_t): ONE 8- or 4-byte key column hashed with Murmur3 (the common shapes:
+// an int64 / float64 / date64 or an int32 / float32 / date32 key).
 // The key words of HP_BATCH rows per thread are requested together from clamped addresses -- the generic
 // hash_row() walks the column list through a switch, which puts every load in its own basic block behind an
 // s_waitcnt and leaves one load in flight per wave.
 constexpr int HP_BATCH = 8;
 
-__global__ __launch_bounds__(HP_THREADS) void part_hist_fast8_kernel(const uint64_t *__restrict__ key, int64_t n, int64_t chunk,
+template <class K>
+__global__ __launch_bounds__(HP_THREADS) void part_hist_fast_kernel(const K *__restrict__ key, int64_t n, int64_t chunk,
                                                                      int nchunks, uint32_t nparts, uint32_t pow2mask,
                                                                      uint32_t *__restrict__ hist) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_cnt[];
@@ -79,7 +82,7 @@ __global__ __launch_bounds__(HP_THREADS) void part_hist_fast8_kernel(const uint6
     const int64_t begin = (int64_t)c * chunk;
     const int64_t end = begin + chunk < n ? begin + chunk : n;
     for (int64_t base = begin; base < end; base += HP_THREADS * HP_BATCH) {
-      uint64_t k[HP_BATCH];
+      K k[HP_BATCH];
 #pragma unroll
       for (int j = 0; j < HP_BATCH; ++j) {
         const int64_t i = base + (int64_t)j * HP_THREADS + threadIdx.x;
@@ -87,7 +90,8 @@ __global__ __launch_bounds__(HP_THREADS) void part_hist_fast8_kernel(const uint6
       }
 #pragma unroll
       for (int j = 0; j < HP_BATCH; ++j)
-        if (base + (int64_t)j * HP_THREADS + threadIdx.x < end) atomicAdd(&lds_cnt[part_of(murmur3_32(k[j], 8), nparts, pow2mask)], 1u);
+        if (base + (int64_t)j * HP_THREADS + threadIdx.x < end)
+          atomicAdd(&lds_cnt[part_of(murmur3_32((uint64_t)k[j], (int)sizeof(K)), nparts, pow2mask)], 1u);
     }
     block_sync();
     for (uint32_t p = threadIdx.x; p < nparts; p += HP_THREADS) hist[(size_t)p * nchunks + c] = lds_cnt[p];
@@ -141,7 +145,8 @@ __global__ __launch_bounds__(HP_THREADS) void part_scatter_kernel(KeyTable t, Pa
   }
 }
 
-__global__ __launch_bounds__(HP_THREADS) void part_scatter_fast8_kernel(const uint64_t *__restrict__ key, PayloadCols pc, int64_t n,
+template <class K>
+__global__ __launch_bounds__(HP_THREADS) void part_scatter_fast_kernel(const K *__restrict__ key, PayloadCols pc, int64_t n,
                                                                         int64_t chunk, int nchunks, uint32_t nparts,
                                                                         uint32_t pow2mask, const uint32_t *__restrict__ offs) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_cur[];
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(HP_THREADS) void part_scatter_fast8_kernel(const ui
     const int64_t begin = (int64_t)c * chunk;
     const int64_t end = begin + chunk < n ? begin + chunk : n;
     for (int64_t base = begin; base < end; base += HP_THREADS * HP_BATCH) {
-      uint64_t k[HP_BATCH];
+      K k[HP_BATCH];
       int64_t src[HP_BATCH];
       uint32_t dst[HP_BATCH];
 #pragma unroll
@@ -163,7 +168,7 @@ __global__ __launch_bounds__(HP_THREADS) void part_scatter_fast8_kernel(const ui
 #pragma unroll
       for (int j = 0; j < HP_BATCH; ++j) {
         const bool live = base + (int64_t)j * HP_THREADS + threadIdx.x < end;
-        dst[j] = live ? atomicAdd(&lds_cur[part_of(murmur3_32(k[j], 8), nparts, pow2mask)], 1u) : 0xffffffffu;
+        dst[j] = live ? atomicAdd(&lds_cur[part_of(murmur3_32((uint64_t)k[j], (int)sizeof(K)), nparts, pow2mask)], 1u) : 0xffffffffu;
         if (live && pc.dst_map) pc.dst_map[src[j]] = dst[j];
       }
       for (int col = 0; col < pc.ncols; ++col) {
@@ -210,7 +215,7 @@ constexpr int HPT_ITEMS = 8;
 constexpr int HPT_TILE = HP_THREADS * HPT_ITEMS;
 constexpr int HPT_MAX_PARTS = 256;
 
-template <bool MURMUR, bool FAST8>
+template <bool MURMUR, int FASTW>      // FASTW = 8 / 4: one key column of that width read directly; 0: generic hash_row
 __global__ __launch_bounds__(HP_THREADS) void part_scatter_tile_kernel(KeyTable t, PayloadCols pc, int64_t n, int64_t chunk,
                                                                        int nchunks, uint32_t nparts, uint32_t pow2mask,
                                                                        const uint32_t *__restrict__ offs) {
@@ -232,14 +237,14 @@ __global__ __launch_bounds__(HP_THREADS) void part_scatter_tile_kernel(KeyTable 
       for (int k = 0; k < HPT_ITEMS; ++k) {
         const int64_t i = tile + (int64_t)k * HP_THREADS + threadIdx.x;
         src[k] = i < end ? i : end - 1;
-        kk[k] = FAST8 ? ((const uint64_t *)t.col[0].data)[src[k]] : 0;
+        kk[k] = FASTW == 8 ? ((const uint64_t *)t.col[0].data)[src[k]] : (FASTW == 4 ? (uint64_t)((const uint32_t *)t.col[0].data)[src[k]] : 0);
       }
 #pragma unroll
       for (int k = 0; k < HPT_ITEMS; ++k) {
         const int64_t i = tile + (int64_t)k * HP_THREADS + threadIdx.x;
         pr[k] = 0xffffffffu;
         if (i < end) {
-          const uint32_t p = part_of(FAST8 ? murmur3_32(kk[k], 8) : hash_row<MURMUR>(t, i), nparts, pow2mask);
+          const uint32_t p = part_of(FASTW ? murmur3_32(kk[k], FASTW) : hash_row<MURMUR>(t, i), nparts, pow2mask);
           pr[k] = (p << 16) | atomicAdd(&hist[p], 1u);
         }
       }
@@ -333,6 +338,26 @@ __global__ __launch_bounds__(HP_THREADS) void part_apply_map_kernel(PayloadCols 
   }
 }
 
+// gdf_amd_narrow_keys (include/gdf/gdf_amd_ext.h): 8 loads in flight per thread, 8 B in / 4 B out per row
+__global__ __launch_bounds__(HP_THREADS) void narrow_keys_kernel(const long long *__restrict__ in, long long lo, unsigned long long span,
+                                                                 int32_t *__restrict__ out, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * HP_THREADS * 8;
+  for (int64_t base = (int64_t)blockIdx.x * HP_THREADS * 8; base < n; base += stride) {
+    long long v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int64_t i = base + (int64_t)k * HP_THREADS + threadIdx.x;
+      v[k] = in[i < n ? i : n - 1];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int64_t i = base + (int64_t)k * HP_THREADS + threadIdx.x;
+      const unsigned long long off = (unsigned long long)(v[k] - lo);
+      if (i < n) out[i] = off <= span ? (int32_t)off : -1;
+    }
+  }
+}
+
 __global__ void gather_strided_u32(const uint32_t *in, uint32_t *out, int count, size_t stride) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < count) out[i] = in[(size_t)i * stride];
@@ -361,6 +386,22 @@ gdf_error gdf_hash(int num_cols, gdf_column **input, gdf_hash_func hash, gdf_col
     GDF_LAUNCH("hash_rows", hash_rows_kernel<true>, dim3(grid), dim3(HP_THREADS), 0, stream0(), t, (uint32_t *)output->data, n);
   else
     hipLaunchKernelGGL(hash_rows_kernel<false>, dim3(grid), dim3(HP_THREADS), 0, stream0(), t, (uint32_t *)output->data, n);
+  HIP_CHECK_LAST();
+  HIP_TRY(hipStreamSynchronize(stream0()));
+  return GDF_SUCCESS;
+}
+
+gdf_error gdf_amd_narrow_keys(gdf_column *in, int64_t lo, int64_t hi, gdf_column *out) {
+  GDF_REQUIRE(in && out, GDF_DATASET_EMPTY);
+  GDF_REQUIRE(elem_kind(in->dtype) == K_I64 && out->dtype == GDF_INT32, GDF_UNSUPPORTED_DTYPE);
+  GDF_REQUIRE(in->size == out->size, GDF_COLUMN_SIZE_MISMATCH);
+  GDF_REQUIRE(!in->valid && !out->valid, GDF_VALIDITY_UNSUPPORTED);
+  GDF_REQUIRE(hi >= lo && (uint64_t)hi - (uint64_t)lo < 0x7fffffffULL, GDF_INVALID_API_CALL);
+  if (in->size == 0) return GDF_SUCCESS;
+  GDF_REQUIRE(in->data && out->data, GDF_DATASET_EMPTY);
+  const int64_t n = (int64_t)in->size;
+  GDF_LAUNCH("narrow_keys", narrow_keys_kernel, dim3(stream_grid((size_t)n, HP_THREADS * 8 * 4)), dim3(HP_THREADS), 0, stream0(),
+             (const long long *)in->data, (long long)lo, (unsigned long long)((uint64_t)hi - (uint64_t)lo), (int32_t *)out->data, n);
   HIP_CHECK_LAST();
   HIP_TRY(hipStreamSynchronize(stream0()));
   return GDF_SUCCESS;
@@ -411,10 +452,13 @@ gdf_error gdf_hash_partition(int num_input_cols, gdf_column *input[], int column
   RMM_TRY(hist.alloc(sizeof(uint32_t) * (size_t)P * nchunks));
   RMM_TRY(starts.alloc(sizeof(uint32_t) * P));
   const bool murmur = hash == GDF_HASH_MURMUR3;
-  const bool fast8 = murmur && t.ncols == 1 && t.col[0].width == 8 && !getenv("GDF_HP_NO_FAST");
-  if (fast8)
-    GDF_LAUNCH("part_hist", part_hist_fast8_kernel, dim3(grid), dim3(HP_THREADS), lds, stream0(), (const uint64_t *)t.col[0].data, n, chunk, nchunks, P,
-               pow2mask, hist.as<uint32_t>());
+  const int fastw = (murmur && t.ncols == 1 && (t.col[0].width == 8 || t.col[0].width == 4) && !getenv("GDF_HP_NO_FAST")) ? t.col[0].width : 0;
+  if (fastw == 8)
+    GDF_LAUNCH("part_hist", part_hist_fast_kernel<uint64_t>, dim3(grid), dim3(HP_THREADS), lds, stream0(), (const uint64_t *)t.col[0].data, n, chunk,
+               nchunks, P, pow2mask, hist.as<uint32_t>());
+  else if (fastw == 4)
+    GDF_LAUNCH("part_hist", part_hist_fast_kernel<uint32_t>, dim3(grid), dim3(HP_THREADS), lds, stream0(), (const uint32_t *)t.col[0].data, n, chunk,
+               nchunks, P, pow2mask, hist.as<uint32_t>());
   else if (murmur)
     GDF_LAUNCH("part_hist", part_hist_kernel<true>, dim3(grid), dim3(HP_THREADS), lds, stream0(), t, n, chunk, nchunks, P, pow2mask, hist.as<uint32_t>());
   else
@@ -456,15 +500,20 @@ gdf_error gdf_hash_partition(int num_input_cols, gdf_column *input[], int column
     else if (P > 16 && P <= (uint32_t)HPT_MAX_PARTS && !getenv("GDF_HP_NO_TILE")) {
       // measured at 1e8 rows x 2 int64 columns: P=256 1.47 ms vs 2.83 ms direct; at P=8 the direct kernel's runs are
       // long enough already (1.10 vs 1.19 ms), so small fan-outs keep it
-      if (fast8)
-        GDF_LAUNCH("part_scatter", (part_scatter_tile_kernel<true, true>), dim3(grid), dim3(HP_THREADS), 0, stream0(), t, pc, n, chunk, nchunks, P, pow2mask, hist.as<uint32_t>());
+      if (fastw == 8)
+        GDF_LAUNCH("part_scatter", (part_scatter_tile_kernel<true, 8>), dim3(grid), dim3(HP_THREADS), 0, stream0(), t, pc, n, chunk, nchunks, P, pow2mask, hist.as<uint32_t>());
+      else if (fastw == 4)
+        GDF_LAUNCH("part_scatter", (part_scatter_tile_kernel<true, 4>), dim3(grid), dim3(HP_THREADS), 0, stream0(), t, pc, n, chunk, nchunks, P, pow2mask, hist.as<uint32_t>());
       else if (murmur)
-        GDF_LAUNCH("part_scatter", (part_scatter_tile_kernel<true, false>), dim3(grid), dim3(HP_THREADS), 0, stream0(), t, pc, n, chunk, nchunks, P, pow2mask, hist.as<uint32_t>());
+        GDF_LAUNCH("part_scatter", (part_scatter_tile_kernel<true, 0>), dim3(grid), dim3(HP_THREADS), 0, stream0(), t, pc, n, chunk, nchunks, P, pow2mask, hist.as<uint32_t>());
       else
-        hipLaunchKernelGGL((part_scatter_tile_kernel<false, false>), dim3(grid), dim3(HP_THREADS), 0, stream0(), t, pc, n, chunk, nchunks, P, pow2mask, hist.as<uint32_t>());
-    } else if (fast8)
-      GDF_LAUNCH("part_scatter", part_scatter_fast8_kernel, dim3(grid), dim3(HP_THREADS), lds, stream0(), (const uint64_t *)t.col[0].data, pc, n, chunk,
-                 nchunks, P, pow2mask, hist.as<uint32_t>());
+        hipLaunchKernelGGL((part_scatter_tile_kernel<false, 0>), dim3(grid), dim3(HP_THREADS), 0, stream0(), t, pc, n, chunk, nchunks, P, pow2mask, hist.as<uint32_t>());
+    } else if (fastw == 8)
+      GDF_LAUNCH("part_scatter", part_scatter_fast_kernel<uint64_t>, dim3(grid), dim3(HP_THREADS), lds, stream0(), (const uint64_t *)t.col[0].data, pc, n,
+                 chunk, nchunks, P, pow2mask, hist.as<uint32_t>());
+    else if (fastw == 4)
+      GDF_LAUNCH("part_scatter", part_scatter_fast_kernel<uint32_t>, dim3(grid), dim3(HP_THREADS), lds, stream0(), (const uint32_t *)t.col[0].data, pc, n,
+                 chunk, nchunks, P, pow2mask, hist.as<uint32_t>());
     else if (murmur)
       GDF_LAUNCH("part_scatter", part_scatter_kernel<true>, dim3(grid), dim3(HP_THREADS), lds, stream0(), t, pc, n, chunk, nchunks, P, pow2mask, hist.as<uint32_t>());
     else

@@ -41,6 +41,7 @@
 // (joining.h:58-66), outputs are library-allocated int32 columns of exactly the joined
 // size, pair order unspecified.
 #include "internal.h"
+#include "gdf/gdf_amd_ext.h"
 
 #include <chrono>
 #include <cmath>
@@ -128,15 +129,19 @@ __device__ __forceinline__ bool make_key(const KeyTable &t, const KeyPlan &p, in
   }
 }
 
-// FAST = one 8-byte integer column without a mask (the BASELINE configuration): the
-// kernels read the column words directly.  All kernels below first issue a BATCH of
+// FAST = 8 / 4: one 8-byte (the BASELINE configuration) / 4-byte integer column without a mask: the
+// kernels read the column words directly (4-byte keys are zero-extended raw bits, always NARROW).  FAST = 0: generic.  All kernels below first issue a BATCH of
 // independent loads, then consume them: with one dependent load per loop trip a wave has
 // 512 B in flight and the kernels are latency-bound at ~25 % of HBM bandwidth
 // (profiles/r1_a_kernel_stats.md).
-template <bool FAST>
+template <int FAST>
+__device__ __forceinline__ uint64_t fast_word(const void *col, int64_t i) {
+  return FAST == 4 ? (uint64_t)((const uint32_t *)col)[i] : ((const uint64_t *)col)[i];
+}
+template <int FAST>
 __device__ __forceinline__ bool fetch_key(const KeyTable &t, const KeyPlan &p, int64_t i, uint64_t &key) {
   if (FAST) {
-    const uint64_t k = ((const uint64_t *)t.col[0].data)[i] - p.kmin;
+    const uint64_t k = fast_word<FAST>(t.col[0].data, i) - p.kmin;
     key = k;
     return !p.narrow || (k >> 32) == 0;
   }
@@ -146,15 +151,15 @@ __device__ __forceinline__ bool fetch_key(const KeyTable &t, const KeyPlan &p, i
 // Batched key fetch for rows i0 + k * stride (k < N), rows >= end are inactive.  FAST issues N
 // UNCONDITIONAL loads from clamped addresses -- a load under `if (i < end)` gets its own basic block and
 // its own s_waitcnt vmcnt(0) from hipcc, which serialises the batch (seen in the ISA of jk_hist).
-template <bool FAST, int N>
+template <int FAST, int N>
 __device__ __forceinline__ void fetch_keys(const KeyTable &t, const KeyPlan &p, int64_t i0, int64_t stride, int64_t end,
                                            uint64_t (&key)[N], bool (&ok)[N]) {
   if (FAST) {
-    const uint64_t *col = (const uint64_t *)t.col[0].data;
+    const void *col = t.col[0].data;
 #pragma unroll
     for (int k = 0; k < N; ++k) {
       const int64_t i = i0 + k * stride;
-      key[k] = col[i < end ? i : end - 1];
+      key[k] = fast_word<FAST>(col, i < end ? i : end - 1);
     }
 #pragma unroll
     for (int k = 0; k < N; ++k) {
@@ -249,7 +254,7 @@ __device__ __forceinline__ uint32_t slot_of(uint64_t key, uint32_t nslots) {
 // ---------------------------------------------------------------------------
 // minmax (may be null): signed min / max of the raw 8-byte keys of the joinable rows, gathered on the
 // build side in the same pass so that the narrow tuple format can be decided without another read.
-template <bool FAST>
+template <int FAST>
 __global__ __launch_bounds__(JK_HIST_THREADS) void jk_hist(KeyTable t, KeyPlan plan, PartGeom g,
                                                            uint32_t *__restrict__ fine_hist,
                                                            uint32_t *__restrict__ H1, long long *minmax) {
@@ -369,7 +374,7 @@ __device__ __forceinline__ void tile_flush(TileLds<NARROW, THREADS> &s, const Pa
 }
 
 // 2. level-1 scatter: raw key columns -> tuples grouped by coarse partition
-template <bool FAST, bool NARROW, int THREADS>
+template <int FAST, bool NARROW, int THREADS>
 __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan, PartGeom g,
                                                              const uint32_t *__restrict__ H1off,   // scanned H1
                                                              Tuples out) {
@@ -384,12 +389,12 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
   // FAST: the raw column words of the NEXT tile are requested while the current tile is flushed, so the
   // HBM read latency hides behind the LDS regroup + store phase (one workgroup per CU: nothing else would)
   uint64_t nxt[JK_SC_ITEMS];
-  const uint64_t *col = (const uint64_t *)t.col[0].data;
+  const void *col = t.col[0].data;
   if (FAST) {
 #pragma unroll
     for (int k = 0; k < JK_SC_ITEMS; ++k) {
       const int64_t i = begin + (int64_t)k * THREADS + threadIdx.x;
-      nxt[k] = col[i < end ? i : end - 1];
+      nxt[k] = fast_word<FAST>(col, i < end ? i : end - 1);
     }
   }
   for (int64_t tile = begin; tile < end; tile += JK_TILE) {
@@ -442,7 +447,7 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
 #pragma unroll
       for (int k = 0; k < JK_SC_ITEMS; ++k) {
         const int64_t i = tile + JK_TILE + (int64_t)k * THREADS + threadIdx.x;
-        nxt[k] = col[i < end ? i : end - 1];
+        nxt[k] = fast_word<FAST>(col, i < end ? i : end - 1);
       }
     }
     block_sync();
@@ -1107,7 +1112,7 @@ static PartGeom choose_geometry(int64_t build_rows) {
 
 static inline int small_grid(int64_t n) { return stream_grid((size_t)(n > 0 ? n : 1), 256 * 8); }
 
-template <bool FAST, bool NARROW, int THREADS>
+template <int FAST, bool NARROW, int THREADS>
 static gdf_error launch_scatter1_t(const KeyTable &t, const KeyPlan &plan, const PartGeom &g, const uint32_t *H1off, Tuples out) {
   const size_t lds = sizeof(TileLds<NARROW, THREADS>);
   HIP_TRY(hipFuncSetAttribute((const void *)jk_scatter1<FAST, NARROW, THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1115,18 +1120,26 @@ static gdf_error launch_scatter1_t(const KeyTable &t, const KeyPlan &plan, const
   HIP_CHECK_LAST();
   return GDF_SUCCESS;
 }
-template <bool FAST, bool NARROW>
+template <int FAST, bool NARROW>
 static gdf_error launch_scatter1_n(int threads, const KeyTable &t, const KeyPlan &plan, const PartGeom &g, const uint32_t *H1off, Tuples out) {
   if (threads == 1024) { if constexpr (NARROW) return launch_scatter1_t<FAST, NARROW, 1024>(t, plan, g, H1off, out); }
   if (threads >= 512) return launch_scatter1_t<FAST, NARROW, 512>(t, plan, g, H1off, out);
   return launch_scatter1_t<FAST, NARROW, 256>(t, plan, g, H1off, out);
 }
-static gdf_error launch_scatter1(bool fast, bool narrow, int threads, const KeyTable &t, const KeyPlan &plan, const PartGeom &g,
+static gdf_error launch_scatter1(int fast, bool narrow, int threads, const KeyTable &t, const KeyPlan &plan, const PartGeom &g,
                                  const uint32_t *H1off, Tuples out) {
-  if (fast) return narrow ? launch_scatter1_n<true, true>(threads, t, plan, g, H1off, out)
-                          : launch_scatter1_n<true, false>(threads, t, plan, g, H1off, out);
-  return narrow ? launch_scatter1_n<false, true>(threads, t, plan, g, H1off, out)
-                : launch_scatter1_n<false, false>(threads, t, plan, g, H1off, out);
+  if (fast == 4) return launch_scatter1_n<4, true>(threads, t, plan, g, H1off, out);      // 4-byte keys are always narrow
+  if (fast == 8) return narrow ? launch_scatter1_n<8, true>(threads, t, plan, g, H1off, out)
+                               : launch_scatter1_n<8, false>(threads, t, plan, g, H1off, out);
+  return narrow ? launch_scatter1_n<0, true>(threads, t, plan, g, H1off, out)
+                : launch_scatter1_n<0, false>(threads, t, plan, g, H1off, out);
+}
+// 8 / 4: the relation is one unmasked raw integer column of that width (direct column reads); 0: generic key construction
+static int fast_key_width(const KeyTable &t, const KeyPlan &plan) {
+  if (t.ncols != 1 || plan.mode != KM_RAW_INT || t.any_valid) return 0;
+  if (t.col[0].width == 8) return 8;
+  if (t.col[0].width == 4 && plan.narrow && plan.kmin == 0) return 4;
+  return 0;
 }
 template <bool NARROW, int THREADS>
 static gdf_error launch_scatter2_t(uint32_t ntiles, const PartGeom &g, Level2Map m, Tuples in, uint32_t *cursor, Tuples out) {
@@ -1172,9 +1185,10 @@ static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, Si
   HIP_TRY(hipMemsetAsync(fine_hist.p, 0, sizeof(uint32_t) * nfine, stream0()));
   const size_t hist_lds = sizeof(uint32_t) * (nfine + ncoarse);
   // FAST: one 8-byte integer key column, no mask -> kernels read the column words directly
-  const bool fast = t.ncols == 1 && t.col[0].width == 8 && plan.mode == KM_RAW_INT && !t.any_valid;
-  HIP_TRY(hipFuncSetAttribute((const void *)jk_hist<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_lds));
-  HIP_TRY(hipFuncSetAttribute((const void *)jk_hist<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_lds));
+  const int fast = fast_key_width(t, plan);
+  HIP_TRY(hipFuncSetAttribute((const void *)jk_hist<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_lds));
+  HIP_TRY(hipFuncSetAttribute((const void *)jk_hist<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_lds));
+  HIP_TRY(hipFuncSetAttribute((const void *)jk_hist<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_lds));
   const int hist_grid = g.nchunks < NUM_CU ? g.nchunks : NUM_CU;
   DevBuf mm;
   long long *d_mm = nullptr;
@@ -1184,11 +1198,14 @@ static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, Si
     HIP_TRY(hipMemcpyAsync(mm.p, init, sizeof(init), hipMemcpyHostToDevice, stream0()));
     d_mm = mm.as<long long>();
   }
-  if (fast)
-    GDF_LAUNCH("jk_hist", jk_hist<true>, dim3(hist_grid), dim3(JK_HIST_THREADS), hist_lds, stream0(), t, plan, g,
+  if (fast == 8)
+    GDF_LAUNCH("jk_hist", jk_hist<8>, dim3(hist_grid), dim3(JK_HIST_THREADS), hist_lds, stream0(), t, plan, g,
+               fine_hist.as<uint32_t>(), H1.as<uint32_t>(), d_mm);
+  else if (fast == 4)
+    GDF_LAUNCH("jk_hist", jk_hist<4>, dim3(hist_grid), dim3(JK_HIST_THREADS), hist_lds, stream0(), t, plan, g,
                fine_hist.as<uint32_t>(), H1.as<uint32_t>(), d_mm);
   else
-    GDF_LAUNCH("jk_hist", jk_hist<false>, dim3(hist_grid), dim3(JK_HIST_THREADS), hist_lds, stream0(), t, plan, g,
+    GDF_LAUNCH("jk_hist", jk_hist<0>, dim3(hist_grid), dim3(JK_HIST_THREADS), hist_lds, stream0(), t, plan, g,
                fine_hist.as<uint32_t>(), H1.as<uint32_t>(), d_mm);
   HIP_CHECK_LAST();
   GDF_TRY(scan_u32(H1.as<uint32_t>(), H1.as<uint32_t>(), (size_t)ncoarse * g.nchunks, false));
@@ -1276,7 +1293,7 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
   g.nchunks = (int)((n + chunk - 1) / chunk);
   if (g.nchunks == 0) g.nchunks = 1;
   const uint32_t nfine = 1u << g.fb, ncoarse = 1u << g.b1;
-  const bool fast = t.ncols == 1 && t.col[0].width == 8 && plan.mode == KM_RAW_INT && !t.any_valid;
+  const int fast = fast_key_width(t, plan);
   static const int sc_threads_env = getenv("GDF_JK_SC_THREADS") ? atoi(getenv("GDF_JK_SC_THREADS")) : 0;
   int sc_threads = sc_threads_env ? sc_threads_env : (narrow ? 1024 : 256);
   if (sc_threads != 256 && sc_threads != 512 && sc_threads != 1024) sc_threads = 256;

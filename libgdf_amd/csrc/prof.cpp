@@ -1,5 +1,6 @@
 // prof.cpp -- see prof.h
 #include "prof.h"
+#include "gdf/gdf_amd_ext.h"
 
 #include <cstring>
 #include <map>

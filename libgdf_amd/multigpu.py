@@ -42,6 +42,43 @@ def _device_inner_join(probe_keys, build_keys):
     return api.join([Column(probe_keys)], [Column(build_keys)], how="inner", copy=False)
 
 
+def _device_narrow(keys, lo, hi):
+    """gdf_amd_narrow_keys: int64 keys -> int32 (key - lo), -1 outside [lo, hi]."""
+    import ctypes as C
+    import torch
+    from ._binding import _gdf_cdll
+    from .columns import Column
+    out = torch.empty(keys.numel(), dtype=torch.int32, device=keys.device)
+    fn = _gdf_cdll.gdf_amd_narrow_keys
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+    cin, cout = Column(keys), Column(out)                              # keep the structs alive across the call
+    rc = fn(C.addressof(cin.c), lo, hi, C.addressof(cout.c))
+    if rc != 0:
+        raise RuntimeError(f"gdf_amd_narrow_keys failed with {rc}")
+    return out
+
+
+def _narrow_if_possible(probe_keys, build_keys, narrow_fn, group):
+    """8-byte keys whose GLOBAL build-side range fits 31 bits travel and join as 4-byte keys (a third less to
+    partition, ship and re-read).  Probe keys outside that range cannot match any build key and become -1."""
+    import torch
+    import torch.distributed as dist
+    if probe_keys.dtype != torch.int64 or build_keys.dtype != torch.int64 or narrow_fn is None:
+        return probe_keys, build_keys
+    big = torch.iinfo(torch.int64).max
+    if build_keys.numel():
+        lo, hi = torch.aminmax(build_keys)
+        mm = torch.stack([lo, -hi])
+    else:
+        mm = torch.tensor([big, big], dtype=torch.int64, device=build_keys.device)
+    dist.all_reduce(mm, op=dist.ReduceOp.MIN, group=group)            # [global min, -(global max)]
+    lo, hi = int(mm[0]), -int(mm[1])
+    if lo > hi or hi - lo >= (1 << 31) - 1:
+        return probe_keys, build_keys
+    return narrow_fn(probe_keys, lo, hi), narrow_fn(build_keys, lo, hi)
+
+
 class Received:
     """One relation after the exchange: keys, the senders' local row numbers, and the segment bounds
     (rows ``bounds[r]:bounds[r+1]`` came from rank r)."""
@@ -157,7 +194,7 @@ def exchange_by_key(keys, payload, partition_fn=_device_partition, group=None):
 
 
 def distributed_inner_join(probe_keys, build_keys, partition_fn=_device_partition, join_fn=_device_inner_join, group=None,
-                           chunks=4):
+                           chunks=4, narrow_fn=_device_narrow):
     """Inner join of two row-sharded relations on one integer key column.
 
     Every rank passes its shard of both relations and gets back a :class:`ShardedPairs` with its share of
@@ -171,6 +208,7 @@ def distributed_inner_join(probe_keys, build_keys, partition_fn=_device_partitio
     import torch
     dev = probe_keys.device
     n = probe_keys.numel()
+    probe_keys, build_keys = _narrow_if_possible(probe_keys, build_keys, narrow_fn, group)
     build_rows = torch.arange(build_keys.numel(), dtype=torch.int32, device=dev)
     build_x = _Exchange(build_keys, build_rows, partition_fn, group, async_op=True)
     chunks = max(1, min(int(chunks), n)) if n else 1

@@ -120,3 +120,16 @@ def test_prefixsum_large_wraps_like_numpy(gdf):
     a = np.random.randint(-2**31, 2**31 - 1, size=n, dtype=np.int64).astype(np.int32)
     got = gdf.api.prefixsum(_col(gdf, a), True).cpu().numpy()
     np.testing.assert_array_equal(got, np.cumsum(a, dtype=np.int32))
+
+
+def test_narrow_keys_extension(gdf):
+    """gdf_amd_narrow_keys (include/gdf/gdf_amd_ext.h): what the multi-GPU layer ships instead of 8-byte keys."""
+    import torch
+    from libgdf_amd import multigpu
+    k = torch.randint(-1000, 5000, (300_001,), dtype=torch.int64, device="cuda") + (1 << 45)
+    lo, hi = (1 << 45), (1 << 45) + 3999
+    out = multigpu._device_narrow(k, lo, hi)
+    exp = torch.where((k >= lo) & (k <= hi), k - lo, torch.full_like(k, -1)).to(torch.int32)
+    assert out.dtype == torch.int32 and torch.equal(out, exp)
+    with pytest.raises(RuntimeError):
+        multigpu._device_narrow(k, 0, 1 << 40)                       # range too wide for 31 bits

@@ -32,6 +32,11 @@ def _np_join(pk, bk):
     return torch.from_numpy(li), torch.from_numpy(ri)
 
 
+def _np_narrow(keys, lo, hi):
+    k = keys.numpy()
+    return torch.from_numpy(np.where((k >= lo) & (k <= hi), k - lo, -1).astype(np.int32))
+
+
 def _np_group_sum(k, v):
     keys, agg = oracle.group_by("sum", [k.numpy()], v.numpy())
     return torch.from_numpy(keys[0].copy()), torch.from_numpy(agg.copy())
@@ -39,8 +44,9 @@ def _np_group_sum(k, v):
 
 def _shards(world):
     rng = np.random.RandomState(1234)
-    probes = [rng.randint(0, 500, size=3000 + 17 * r).astype(np.int64) for r in range(world)]
-    builds = [rng.randint(0, 500, size=400 + 5 * r).astype(np.int64) for r in range(world)]
+    # probe keys range beyond the build keys on both sides: the narrowed exchange must drop exactly those
+    probes = [(rng.randint(-50, 600, size=3000 + 17 * r) + (1 << 40)).astype(np.int64) for r in range(world)]
+    builds = [(rng.randint(0, 500, size=400 + 5 * r) + (1 << 40)).astype(np.int64) for r in range(world)]
     return probes, builds
 
 
@@ -52,7 +58,7 @@ def _worker(rank, world, port, q):
     multigpu._MAX_MESSAGE_BYTES = 1024          # force the multi-piece send / recv path (production: 2^29 bytes)
     probes, builds = _shards(world)
     pairs = multigpu.distributed_inner_join(torch.from_numpy(probes[rank]), torch.from_numpy(builds[rank]),
-                                            partition_fn=_np_partition, join_fn=_np_join)
+                                            partition_fn=_np_partition, join_fn=_np_join, narrow_fn=_np_narrow)
     pg, bg = pairs.global_ids()
     assert pairs.numel() == pg.numel()
     k = torch.from_numpy(probes[rank])

@@ -3,6 +3,8 @@
 The reference is single-GPU (no NCCL/MPI anywhere), so this layer has no
 counterpart there; it sits ABOVE the unchanged per-GPU ``gdf_*`` C ABI:
 
+  0. 8-byte keys whose global build-side range fits 31 bits are narrowed to 4 bytes (``gdf_amd_narrow_keys``;
+     one all-reduce of the build min / max decides);
   1. every rank hash-partitions each relation on the join key into ``world`` partitions with the public
      ``gdf_hash_partition`` (Murmur3 & (P-1) / % P) -- a different hash from the mix64 the local join
      partitions on, so rank placement and local partitioning are uncorrelated.  The payload that travels

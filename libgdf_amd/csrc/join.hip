@@ -397,9 +397,9 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
       nxt[k] = fast_word<FAST>(col, i < end ? i : end - 1);
     }
   }
-  for (int64_t tile = begin; tile < end; tile += JK_TILE) {
-    if (threadIdx.x < 256) s.hist[threadIdx.x] = 0;
-    block_sync();
+  if (threadIdx.x < 256) s.hist[threadIdx.x] = 0;
+  block_sync();
+  for (int64_t tile = begin; tile < end; tile += JK_TILE) {      // 5 barriers per tile; hist is re-zeroed by its last reader
     uint64_t key[JK_SC_ITEMS];
     bool ok[JK_SC_ITEMS];
     if (FAST) {
@@ -434,6 +434,7 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
         s.cursor[threadIdx.x] += s.hist[threadIdx.x];
       }
     }
+    if (threadIdx.x < 256) s.hist[threadIdx.x] = 0;      // nobody reads hist again before the next tile's ranking, two barriers away
 #pragma unroll
     for (int k = 0; k < JK_SC_ITEMS; ++k) {
       if (binrank[k] != 0xffffffffu) {

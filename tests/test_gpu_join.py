@@ -370,3 +370,25 @@ def test_randomized_inner_join_properties(gdf):
         assert bool((probe[li.long()] == build[ri.long()]).all()), it
         pair = li.long() * nb + ri.long()
         assert int(torch.unique(pair).numel()) == expected, it
+
+
+def test_headline_configuration_properties(gdf):
+    """BASELINE config C3 at FULL size (1e9 probe x 1e8 build int64 rows, unique build keys, every probe row
+    matches once), through the same C-ABI call bench.py times.  Size-independent properties: exactly 1e9 pairs,
+    every pair joins equal keys, every probe row appears exactly once."""
+    import torch
+    from bench import make_build_keys, make_probe_keys
+    from libgdf_amd.columns import Column
+    dev = torch.device("cuda", 0)
+    nb, npr = 100_000_000, 1_000_000_000
+    build = make_build_keys(nb, 0x5EED0001, dev)
+    probe = make_probe_keys(npr, nb, 0x5EED0002, dev)
+    li, ri = gdf.api.join([Column(probe)], [Column(build)])
+    assert li.numel() == npr and ri.numel() == npr
+    step = 1 << 27
+    seen = torch.zeros(npr, dtype=torch.bool, device=dev)
+    for s in range(0, npr, step):                                   # in slices: bounded temporaries
+        l, r = li[s:s + step].long(), ri[s:s + step].long()
+        assert bool((probe[l] == build[r]).all())
+        seen[l] = True
+    assert bool(seen.all())                                         # 1e9 pairs, all probe rows covered: each exactly once

@@ -22,6 +22,7 @@
 //     (streamcompactionops.cu:99-105 reads it MSB-first through an uninitialised field).
 #include "internal.h"
 
+#include <cstdlib>
 #include <type_traits>
 #include <vector>
 
@@ -234,6 +235,80 @@ __global__ __launch_bounds__(FL_THREADS) void stencil_count_kernel(const int8_t 
   }
 }
 
+// The matching write pass: a thread owns 16 CONSECUTIVE rows (one 16-byte stencil load, its data elements in
+// registers), thread totals are scanned once per 4096-row tile (two barriers per tile instead of two per 256 rows),
+// and every thread stores its kept elements one after the other -- adjacent lanes write adjacent ranges.
+template <int WIDTH>
+__global__ __launch_bounds__(FL_THREADS) void stencil_write_kernel(const int8_t *__restrict__ stencil, const uint8_t *__restrict__ valid,
+                                                                   int64_t n, int64_t chunk, const uint64_t *__restrict__ chunk_base,
+                                                                   const void *__restrict__ in, void *__restrict__ out) {
+  __shared__ unsigned int wsum[FL_THREADS / WAVE];
+  const int64_t begin = (int64_t)blockIdx.x * chunk;
+  const int64_t end = begin + chunk < n ? begin + chunk : n;
+  uint64_t base = chunk_base[blockIdx.x];
+  const int wave = threadIdx.x / WAVE;
+  for (int64_t tile = begin; tile < end; tile += (int64_t)FL_THREADS * 16) {
+    const int64_t i = tile + (int64_t)threadIdx.x * 16;
+    uint32_t keep = 0;
+    if (i + 16 <= end) {
+      const uint4 w = *reinterpret_cast<const uint4 *>(stencil + i);
+      const uint32_t words[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) keep |= ((words[q] >> (8 * b)) & 0xffu) ? (1u << (4 * q + b)) : 0u;
+      if (valid) keep &= (uint32_t)valid[i >> 3] | ((uint32_t)valid[(i >> 3) + 1] << 8);
+    } else {
+      for (int r = 0; r < 16; ++r)
+        if (i + r < end && stencil[i + r] != 0 && (valid ? bit_is_set(valid, i + r) : true)) keep |= 1u << r;
+    }
+    const unsigned int mine = (unsigned)__popc(keep);
+    const unsigned int incl = wave_scan_incl(mine);
+    if (lane_id() == WAVE - 1) wsum[wave] = incl;
+    block_sync();
+    unsigned int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < FL_THREADS / WAVE; ++w) {
+      if (w < wave) before += wsum[w];
+      total += wsum[w];
+    }
+    uint64_t pos = base + before + incl - mine;
+    if (mine > 4 && i + 16 <= end) {
+      // many keepers: fetch the thread's 16 elements with independent loads first, then store the kept ones
+      uint64_t v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (WIDTH == 1) v[r] = ((const uint8_t *)in)[i + r];
+        else if (WIDTH == 2) v[r] = ((const uint16_t *)in)[i + r];
+        else if (WIDTH == 4) v[r] = ((const uint32_t *)in)[i + r];
+        else v[r] = ((const uint64_t *)in)[i + r];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (keep & (1u << r)) {
+          if (WIDTH == 1) ((uint8_t *)out)[pos] = (uint8_t)v[r];
+          else if (WIDTH == 2) ((uint16_t *)out)[pos] = (uint16_t)v[r];
+          else if (WIDTH == 4) ((uint32_t *)out)[pos] = (uint32_t)v[r];
+          else ((uint64_t *)out)[pos] = v[r];
+          ++pos;
+        }
+      }
+    } else {
+      while (keep) {
+        const int r = __ffs((int)keep) - 1;
+        keep &= keep - 1;
+        if (WIDTH == 1) ((uint8_t *)out)[pos] = ((const uint8_t *)in)[i + r];
+        else if (WIDTH == 2) ((uint16_t *)out)[pos] = ((const uint16_t *)in)[i + r];
+        else if (WIDTH == 4) ((uint32_t *)out)[pos] = ((const uint32_t *)in)[i + r];
+        else ((uint64_t *)out)[pos] = ((const uint64_t *)in)[i + r];
+        ++pos;
+      }
+    }
+    base += total;
+    block_sync();
+  }
+}
+
 // WIDTH == 0: emit the row index as size_t (gdf_filter); else move WIDTH-byte elements
 template <class Pred, int WIDTH>
 __global__ __launch_bounds__(FL_THREADS) void compact_write_kernel(Pred pred, int64_t n, int64_t chunk, const uint64_t *chunk_base,
@@ -300,6 +375,22 @@ static gdf_error compact(Pred pred, int64_t n, int width, const void *in, void *
   HIP_CHECK_LAST();
   GDF_TRY(scan_u64(counts.as<uint64_t>(), counts.as<uint64_t>(), (size_t)nchunks + 1, false));
   const dim3 g(nchunks), b(FL_THREADS);
+  if constexpr (std::is_same<Pred, StencilPred>::value) {
+    // thread-consecutive rows win while few rows survive (10 % kept: 0.19 vs 0.33 ms per 1e8 rows); at 50 % the
+    // ballot kernel below is ahead again (0.39 vs 0.42 ms), so the number of keepers -- known after the scan -- decides
+    HIP_TRY(hipMemcpy(kept, counts.as<uint64_t>() + nchunks, sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (((uintptr_t)pred.stencil & 15) == 0 && chunk % 16 == 0 && width != 0 && *kept * 3 < (uint64_t)n && !getenv("GDF_FL_NO_VEC")) {
+      switch (width) {
+        case 1: GDF_LAUNCH("compact_write", stencil_write_kernel<1>, g, b, 0, stream0(), pred.stencil, pred.valid, n, chunk, counts.as<uint64_t>(), in, out); break;
+        case 2: GDF_LAUNCH("compact_write", stencil_write_kernel<2>, g, b, 0, stream0(), pred.stencil, pred.valid, n, chunk, counts.as<uint64_t>(), in, out); break;
+        case 4: GDF_LAUNCH("compact_write", stencil_write_kernel<4>, g, b, 0, stream0(), pred.stencil, pred.valid, n, chunk, counts.as<uint64_t>(), in, out); break;
+        default: GDF_LAUNCH("compact_write", stencil_write_kernel<8>, g, b, 0, stream0(), pred.stencil, pred.valid, n, chunk, counts.as<uint64_t>(), in, out); break;
+      }
+      HIP_CHECK_LAST();
+      HIP_TRY(hipMemcpy(kept, counts.as<uint64_t>() + nchunks, sizeof(uint64_t), hipMemcpyDeviceToHost));
+      return GDF_SUCCESS;
+    }
+  }
   switch (width) {
     case 0: GDF_LAUNCH("compact_write", (compact_write_kernel<Pred, 0>), g, b, 0, stream0(), pred, n, chunk, counts.as<uint64_t>(), in, out); break;
     case 1: GDF_LAUNCH("compact_write", (compact_write_kernel<Pred, 1>), g, b, 0, stream0(), pred, n, chunk, counts.as<uint64_t>(), in, out); break;

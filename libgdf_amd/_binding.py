@@ -105,6 +105,7 @@ _PROTOTYPES = {
     "gpu_comparison_static_f64": (None, [_COLP, C.c_double, _COLP, C.c_int]),
     "gpu_comparison": (None, [_COLP, _COLP, _COLP, C.c_int]),
     "gpu_apply_stencil": (None, [_COLP, _COLP, _COLP]),
+    "gpu_concat": (None, [_COLP, _COLP, _COLP]),
     "gdf_ipc_parser_open": (C.c_void_p, [C.c_void_p, C.c_size_t]),
     "gdf_ipc_parser_open_recordbatches": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),   # void in C; the value is ignored
     "gdf_ipc_parser_close": (C.c_int, [C.c_void_p]),                                        # void in C

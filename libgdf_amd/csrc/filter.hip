@@ -594,4 +594,16 @@ gdf_error gdf_column_concat(gdf_column *output, gdf_column *columns_to_concat[],
   return GDF_SUCCESS;
 }
 
+// streamcompactionops.cu:389-494: output = lhs ++ rhs, data and validity.  The reference stitches the two masks
+// together byte by byte on the host side of thrust with MSB-first helpers; here it is gdf_column_concat's bit-exact
+// LSB-first mask concatenation (the layout of every other mask in libgdf).  The reference
+// returns GDF_VALIDITY_MISSING for a dtype mismatch (sic, :391) and so does this.
+gdf_error gpu_concat(gdf_column *lhs, gdf_column *rhs, gdf_column *output) {
+  GDF_REQUIRE(lhs && rhs && output, GDF_DATASET_EMPTY);
+  GDF_REQUIRE(lhs->dtype == output->dtype && rhs->dtype == output->dtype, GDF_VALIDITY_MISSING);
+  GDF_REQUIRE(output->size == lhs->size + rhs->size, GDF_COLUMN_SIZE_MISMATCH);
+  gdf_column *both[2] = {lhs, rhs};
+  return gdf_column_concat(output, both, 2);
+}
+
 }  // extern "C"

@@ -129,6 +129,29 @@ def test_validity_and(gdf):
     assert out.c.null_count == n - (a & b).sum()
 
 
+@pytest.mark.parametrize("nl,nr", [(0, 5), (5, 0), (8, 8), (13, 70), (1000, 1), (129, 255)])
+@pytest.mark.parametrize("dtype", [np.int8, np.int32, np.float64], ids=lambda d: np.dtype(d).name)
+def test_gpu_concat(gdf, nl, nr, dtype):
+    """tests/filterops_numeric/test_gpu_concat.cu: output = lhs ++ rhs, data and validity bits, for left sizes that
+    end inside a mask byte and on a byte boundary."""
+    import ctypes as C
+    import torch
+    from libgdf_amd import Column, GDFError, libgdf
+    from libgdf_amd.columns import get_dtype
+    l, r = gen_rand(dtype, nl), gen_rand(dtype, nr)
+    lv, rv = random_valid(nl) if nl else np.zeros(0, dtype=bool), random_valid(nr) if nr else np.zeros(0, dtype=bool)
+    cl, cr = _col(l, lv), _col(r, rv)
+    tdt = {np.dtype(np.int8): torch.int8, np.dtype(np.int32): torch.int32, np.dtype(np.float64): torch.float64}[np.dtype(dtype)]
+    out = Column(torch.empty(max(nl + nr, 1), dtype=tdt, device="cuda"), torch.zeros(192, dtype=torch.uint8, device="cuda"),
+                 get_dtype(np.dtype(dtype)), size=nl + nr)
+    libgdf.gpu_concat(cl.ptr, cr.ptr, out.ptr)
+    np.testing.assert_array_equal(out.to_numpy(), np.concatenate([l, r]))
+    np.testing.assert_array_equal(out.valid_bits(), np.concatenate([lv, rv]))
+    bad = Column(torch.empty(nl + nr + 1, dtype=tdt, device="cuda"), None, get_dtype(np.dtype(dtype)))
+    with pytest.raises(GDFError, match="GDF_COLUMN_SIZE_MISMATCH"):            # streamcompactionops.cu:392
+        libgdf.gpu_concat(cl.ptr, cr.ptr, bad.ptr)
+
+
 def test_column_concat(gdf):
     """tests/column/column-test.cu: data + masks, a missing mask counts as all valid."""
     import torch

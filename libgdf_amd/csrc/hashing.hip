@@ -358,6 +358,30 @@ __global__ __launch_bounds__(HP_THREADS) void narrow_keys_kernel(const long long
   }
 }
 
+// gpu_hash_columns (src/hashops.cu:25-151): 64-bit FNV-1a over the little-endian bytes of every column's element,
+// columns in order.  The reference XORs each byte as a (signed) `char`, so a byte >= 0x80 is sign-extended to 64
+// bits before the XOR (hashops.cu:46-75) -- kept, it is what callers of the reference see.
+struct FnvCols { int ncols; const void *data[MAX_KEY_COLS]; int width[MAX_KEY_COLS]; };
+__global__ __launch_bounds__(HP_THREADS) void fnv_rows_kernel(FnvCols c, unsigned long long *__restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * HP_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * HP_THREADS) {
+    unsigned long long h = 14695981039346656037ull;
+    for (int k = 0; k < c.ncols; ++k) {
+      uint64_t bits;
+      switch (c.width[k]) {
+        case 1: bits = ((const uint8_t *)c.data[k])[i]; break;
+        case 2: bits = ((const uint16_t *)c.data[k])[i]; break;
+        case 4: bits = ((const uint32_t *)c.data[k])[i]; break;
+        default: bits = ((const uint64_t *)c.data[k])[i]; break;
+      }
+      for (int b = 0; b < c.width[k]; ++b) {
+        h ^= (unsigned long long)(long long)(signed char)(bits >> (8 * b));
+        h *= 1099511628211ull;
+      }
+    }
+    out[i] = h;
+  }
+}
+
 __global__ void gather_strided_u32(const uint32_t *in, uint32_t *out, int count, size_t stride) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < count) out[i] = in[(size_t)i * stride];
@@ -387,6 +411,37 @@ gdf_error gdf_hash(int num_cols, gdf_column **input, gdf_hash_func hash, gdf_col
   else
     hipLaunchKernelGGL(hash_rows_kernel<false>, dim3(grid), dim3(HP_THREADS), 0, stream0(), t, (uint32_t *)output->data, n);
   HIP_CHECK_LAST();
+  HIP_TRY(hipStreamSynchronize(stream0()));
+  return GDF_SUCCESS;
+}
+
+gdf_error gpu_hash_columns(gdf_column **columns_to_hash, int num_columns, gdf_column *output_column, void *stream) {
+  (void)stream;      // a cudaStream_t* in the reference; the work is complete on return either way
+  GDF_REQUIRE(columns_to_hash && num_columns > 0 && output_column && columns_to_hash[0], GDF_DATASET_EMPTY);
+  GDF_REQUIRE(num_columns <= MAX_KEY_COLS, GDF_JOIN_TOO_MANY_COLUMNS);
+  const int64_t n = (int64_t)columns_to_hash[0]->size;
+  FnvCols c{};
+  c.ncols = num_columns;
+  for (int k = 0; k < num_columns; ++k) {
+    GDF_REQUIRE(columns_to_hash[k] && (int64_t)columns_to_hash[k]->size == n, GDF_COLUMN_SIZE_MISMATCH);
+    int w = 0;
+    GDF_TRY(get_column_byte_width(columns_to_hash[k], &w));
+    c.data[k] = columns_to_hash[k]->data;
+    c.width[k] = w;
+    GDF_REQUIRE(n == 0 || c.data[k], GDF_DATASET_EMPTY);
+  }
+  if (n == 0) return GDF_SUCCESS;
+  GDF_REQUIRE(output_column->data, GDF_DATASET_EMPTY);
+  GDF_LAUNCH("fnv_rows", fnv_rows_kernel, dim3(stream_grid((size_t)n, HP_THREADS * 8)), dim3(HP_THREADS), 0, stream0(), c,
+             (unsigned long long *)output_column->data, n);
+  HIP_CHECK_LAST();
+  // output validity = AND of the masks of the inputs that have nulls (hashops.cu:124-134)
+  output_column->null_count = 0;
+  if (output_column->valid) {
+    HIP_TRY(hipMemsetAsync(output_column->valid, 0xff, mask_bytes((size_t)n), stream0()));
+    for (int k = 0; k < num_columns; ++k)
+      if (columns_to_hash[k]->null_count > 0 && columns_to_hash[k]->valid) GDF_TRY(gdf_validity_and(output_column, columns_to_hash[k], output_column));
+  }
   HIP_TRY(hipStreamSynchronize(stream0()));
   return GDF_SUCCESS;
 }

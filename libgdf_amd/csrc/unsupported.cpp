@@ -25,7 +25,6 @@ gdf_error gdf_segmented_radixsort_plan_setup(gdf_segmented_radixsort_plan_type *
 gdf_error gdf_segmented_radixsort_plan_free(gdf_segmented_radixsort_plan_type *) { return GDF_UNSUPPORTED_METHOD; }
 
 unsigned int gdf_reduce_optimal_output_size(void) { return 0; }
-gdf_error gpu_hash_columns(gdf_column **, int, gdf_column *, void *) { return GDF_UNSUPPORTED_METHOD; }
 gdf_error gdf_quantile_exact(gdf_column *, gdf_quantile_method, double, void *, gdf_context *) { return GDF_UNSUPPORTED_METHOD; }
 gdf_error gdf_quantile_aprrox(gdf_column *, double, void *, gdf_context *) { return GDF_UNSUPPORTED_METHOD; }
 gdf_error read_csv(csv_read_arg *) { return GDF_UNSUPPORTED_METHOD; }

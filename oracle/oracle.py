@@ -136,6 +136,24 @@ def group_by(op, keys, values, out_dtype=None):
     return [k[:g] for k in out_keys], out_agg[:g]
 
 
+# ---- gpu_hash_columns (src/hashops.cu:25-151) -----------------------------------------------------------
+def fnv1a_rows(cols) -> np.ndarray:
+    """64-bit FNV-1a over the little-endian bytes of each column's element, columns in order, one hash per row
+    (as uint64).  The reference XORs every byte as a signed ``char`` (hashops.cu:46-75), so bytes >= 0x80 are
+    sign-extended before the XOR; for 7-bit data this is the published FNV-1a."""
+    cols = _contig(cols)
+    n = len(cols[0])
+    h = np.full(n, 14695981039346656037, dtype=np.uint64)
+    prime = np.uint64(1099511628211)
+    with np.errstate(over="ignore"):
+        for c in cols:
+            raw = c.view(np.uint8).reshape(n, c.dtype.itemsize)
+            for b in range(c.dtype.itemsize):
+                h ^= raw[:, b].astype(np.int8).astype(np.int64).view(np.uint64)
+                h *= prime
+    return h
+
+
 # ---- validity-mask aware group-by (beyond the reference; BASELINE config C5, SURVEY.md 8d) -------------
 def group_by_masked(op, keys, values, key_valids=None, value_valid=None, out_dtype=None):
     """(sorted key arrays, aggregate, aggregate-valid bools) with pandas ``dropna=True`` semantics: rows with a

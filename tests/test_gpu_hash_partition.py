@@ -133,3 +133,31 @@ def test_narrow_keys_extension(gdf):
     assert out.dtype == torch.int32 and torch.equal(out, exp)
     with pytest.raises(RuntimeError):
         multigpu._device_narrow(k, 0, 1 << 40)                       # range too wide for 31 bits
+
+
+@pytest.mark.parametrize("dtypes", [[np.int8], [np.int64], [np.int32, np.float64, np.int16], [np.float32, np.int8, np.int64, np.int64]],
+                         ids=lambda d: "-".join(np.dtype(x).name for x in d))
+def test_gpu_hash_columns_fnv1a(gdf, dtypes):
+    """gpu_hash_columns (src/hashops.cu): FNV-1a 64 per row, bit-exact vs the oracle; output mask = AND of the input masks."""
+    import ctypes as C
+    import torch
+    from libgdf_amd import Column, libgdf
+    from libgdf_amd._binding import _gdf_cdll
+    from libgdf_amd.columns import column_array, column_from_numpy
+    from util import gen_rand, random_valid
+    n = 10007
+    arrs = [gen_rand(dt, n) for dt in dtypes]
+    valids = [random_valid(n) if i % 2 == 0 else None for i in range(len(arrs))]
+    cols = [column_from_numpy(a, v) for a, v in zip(arrs, valids)]
+    out = Column(torch.empty(n, dtype=torch.int64, device="cuda"), torch.zeros((n + 7) // 8 + 64, dtype=torch.uint8, device="cuda"), 4)
+    fn = _gdf_cdll.gpu_hash_columns
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    assert fn(column_array(cols), len(cols), C.addressof(out.c), None) == 0
+    np.testing.assert_array_equal(out.to_numpy().view(np.uint64), oracle.fnv1a_rows(arrs))
+    exp_valid = np.ones(n, dtype=bool)
+    for v in valids:
+        if v is not None and not v.all():
+            exp_valid &= v
+    np.testing.assert_array_equal(out.valid_bits(), exp_valid)
+    assert out.c.null_count == n - exp_valid.sum()

@@ -160,3 +160,23 @@ def test_int8_sum_wraps_in_input_dtype():
     assert avg[0] == 71 / 4.0                                      # sum wraps BEFORE the division (groupby.cuh:308-328)
     _, avgi = oracle.group_by("avg", keys, vals, out_dtype=np.int32)
     assert avgi[0] == 71 // 4
+
+
+def test_fnv1a_restatement_against_published_vectors():
+    """gpu_hash_columns is FNV-1a 64 (hashops.cu:40-75).  The reference source cannot be compiled here (thrust +
+    CUDA runtime headers), so the restatement is pinned on the PUBLISHED FNV-1a test vectors (Fowler/Noll/Vo, isthe.com
+    test suite): "" -> cbf29ce484222325, "a" -> af63dc4c8601ec8c, "foobar" -> 85944171f73967e8; each character is
+    one int8 column, which is exactly how the reference folds columns."""
+    def h(text):
+        cols = [np.array([ord(ch)], dtype=np.int8) for ch in text] or [np.zeros((1, 0), dtype=np.int8).reshape(1, 0)[:, :0].ravel()]
+        return int(oracle.fnv1a_rows(cols)[0]) if text else 14695981039346656037
+    assert h("") == 0xcbf29ce484222325
+    assert h("a") == 0xaf63dc4c8601ec8c
+    assert h("foobar") == 0x85944171f73967e8
+    # one int32 column holding "foob" little-endian hashes like the four characters
+    word = np.array([int.from_bytes(b"foob", "little")], dtype=np.int32)
+    assert int(oracle.fnv1a_rows([word])[0]) == h("foob")
+    # the reference's signed-char quirk: a byte >= 0x80 is sign-extended before the XOR
+    x = np.array([-1], dtype=np.int8)
+    exp = ((14695981039346656037 ^ 0xFFFFFFFFFFFFFFFF) * 1099511628211) % (1 << 64)
+    assert int(oracle.fnv1a_rows([x])[0]) == exp

@@ -288,6 +288,19 @@ const void *gdf_ipc_parser_get_data(gdf_ipc_parser_type *handle);
 int64_t     gdf_ipc_parser_get_data_offset(gdf_ipc_parser_type *handle);
 const char *gdf_ipc_parser_get_schema_json(gdf_ipc_parser_type *handle);
 const char *gdf_ipc_parser_get_layout_json(gdf_ipc_parser_type *handle);
+/* radix-sort wrappers (reference functions.h:108-224, src/sorting.cu, src/segmented_sorting.cu): csrc/sort.hip */
+gdf_error   gdf_radixsort_i8(gdf_radixsort_plan_type *hdl, gdf_column *keycol, gdf_column *valcol);
+gdf_error   gdf_radixsort_i32(gdf_radixsort_plan_type *hdl, gdf_column *keycol, gdf_column *valcol);
+gdf_error   gdf_radixsort_i64(gdf_radixsort_plan_type *hdl, gdf_column *keycol, gdf_column *valcol);
+gdf_error   gdf_radixsort_f32(gdf_radixsort_plan_type *hdl, gdf_column *keycol, gdf_column *valcol);
+gdf_error   gdf_radixsort_f64(gdf_radixsort_plan_type *hdl, gdf_column *keycol, gdf_column *valcol);
+gdf_error   gdf_radixsort_generic(gdf_radixsort_plan_type *hdl, gdf_column *keycol, gdf_column *valcol);
+gdf_error   gdf_segmented_radixsort_i8(gdf_segmented_radixsort_plan_type *hdl, gdf_column *keycol, gdf_column *valcol, unsigned num_segments, unsigned *d_begin_offsets, unsigned *d_end_offsets);
+gdf_error   gdf_segmented_radixsort_i32(gdf_segmented_radixsort_plan_type *hdl, gdf_column *keycol, gdf_column *valcol, unsigned num_segments, unsigned *d_begin_offsets, unsigned *d_end_offsets);
+gdf_error   gdf_segmented_radixsort_i64(gdf_segmented_radixsort_plan_type *hdl, gdf_column *keycol, gdf_column *valcol, unsigned num_segments, unsigned *d_begin_offsets, unsigned *d_end_offsets);
+gdf_error   gdf_segmented_radixsort_f32(gdf_segmented_radixsort_plan_type *hdl, gdf_column *keycol, gdf_column *valcol, unsigned num_segments, unsigned *d_begin_offsets, unsigned *d_end_offsets);
+gdf_error   gdf_segmented_radixsort_f64(gdf_segmented_radixsort_plan_type *hdl, gdf_column *keycol, gdf_column *valcol, unsigned num_segments, unsigned *d_begin_offsets, unsigned *d_end_offsets);
+gdf_error   gdf_segmented_radixsort_generic(gdf_segmented_radixsort_plan_type *hdl, gdf_column *keycol, gdf_column *valcol, unsigned num_segments, unsigned *d_begin_offsets, unsigned *d_end_offsets);
 gdf_radixsort_plan_type *gdf_radixsort_plan(size_t num_items, int descending, unsigned begin_bit, unsigned end_bit);
 gdf_error   gdf_radixsort_plan_setup(gdf_radixsort_plan_type *hdl, size_t sizeof_key, size_t sizeof_val);
 gdf_error   gdf_radixsort_plan_free(gdf_radixsort_plan_type *hdl);

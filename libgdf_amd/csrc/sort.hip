@@ -42,6 +42,8 @@
 // NaN keys order after +inf (the reference's comparator leaves them unordered).
 #include "internal.h"
 
+#include <algorithm>
+#include <new>
 #include <vector>
 
 namespace gdf_amd {
@@ -675,11 +677,215 @@ gdf_error group_by_sort(int ncols, gdf_column **cols, gdf_column *col_agg, gdf_c
   return GDF_SUCCESS;
 }
 
+// ---------------------------------------------------------------------------
+// gdf_radixsort_* / gdf_segmented_radixsort_* (reference src/sorting.cu, src/segmented_sorting.cu: thin wrappers
+// over cub::DeviceRadixSort / DeviceSegmentedRadixSort with a plan object that owns the back buffers).  Here the
+// plan only records its parameters: the keys' order-preserving images (complemented for a descending sort) and
+// their row numbers go through the LSD radix sort above, then keys and values are gathered through the
+// permutation.  Stable like CUB's (equal keys keep their input order, ascending and descending alike);
+// begin_bit / end_bit restrict the sort to those bits of the image.  -0.0 and +0.0 compare equal and NaN orders
+// after +inf (numpy's order; CUB orders by the raw bit pattern there).
+// ---------------------------------------------------------------------------
+struct RadixPlan {
+  size_t num_items;
+  int descending;
+  unsigned begin_bit, end_bit;
+  size_t sizeof_key, sizeof_val;
+};
+
+__device__ __forceinline__ uint64_t rsw_image(const void *key, int kind, int descending, const uint32_t *region,
+                                              const uint8_t *region_sorted, uint32_t i) {
+  const int bits = (kind == K_I8 ? 8 : (kind == K_I16 ? 16 : ((kind == K_I32 || kind == K_F32) ? 32 : 64)));
+  const uint64_t mask = bits >= 64 ? ~0ULL : ((1ULL << bits) - 1ULL);
+  uint64_t k;
+  if (kind == K_F32 || kind == K_F64) k = ordered_float_bits(key, kind, i);
+  else k = ((uint64_t)load_signed_kind(key, kind, i) ^ (1ULL << (bits - 1))) & mask;
+  if (descending) k = ~k & mask;
+  if (region && !region_sorted[region[i]]) k = 0;          // rows outside every segment keep their order
+  return k;
+}
+__global__ __launch_bounds__(256) void rsw_images(const void *key, int kind, int descending, const uint32_t *__restrict__ region,
+                                                  const uint8_t *__restrict__ region_sorted, uint64_t *__restrict__ img,
+                                                  uint32_t *__restrict__ row, uint32_t n, unsigned long long *__restrict__ varying) {
+  const uint64_t k0 = rsw_image(key, kind, descending, region, region_sorted, 0);
+  uint64_t diff = 0;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const uint64_t k = rsw_image(key, kind, descending, region, region_sorted, i);
+    img[i] = k;
+    row[i] = i;
+    diff |= k ^ k0;
+  }
+  for (int d = 1; d < WAVE; d <<= 1) {
+    const uint32_t lo = __shfl_xor((uint32_t)diff, d), hi = __shfl_xor((uint32_t)(diff >> 32), d);
+    diff |= ((uint64_t)hi << 32) | lo;
+  }
+  if (lane_id() == 0 && diff) atomicOr(varying, (unsigned long long)diff);
+}
+__global__ __launch_bounds__(256) void rsw_region_keys(const uint32_t *__restrict__ region, const uint32_t *__restrict__ perm,
+                                                       uint64_t *__restrict__ img, uint32_t n) {
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) img[i] = region[perm[i]];
+}
+// region[i] = number of boundary points <= i (binary search over the sorted boundary list)
+__global__ __launch_bounds__(256) void rsw_regions(const uint32_t *__restrict__ bounds, uint32_t nbounds, uint32_t *__restrict__ region, uint32_t n) {
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    uint32_t lo = 0, hi = nbounds;
+    while (lo < hi) { const uint32_t mid = (lo + hi) / 2; if (bounds[mid] <= i) lo = mid + 1; else hi = mid; }
+    region[i] = lo;
+  }
+}
+__global__ __launch_bounds__(256) void rsw_gather(const uint32_t *__restrict__ perm, uint32_t n, int width, const void *in, void *out) {
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const uint32_t s = perm[i];
+    switch (width) {
+      case 1: ((uint8_t *)out)[i] = ((const uint8_t *)in)[s]; break;
+      case 2: ((uint16_t *)out)[i] = ((const uint16_t *)in)[s]; break;
+      case 4: ((uint32_t *)out)[i] = ((const uint32_t *)in)[s]; break;
+      default: ((uint64_t *)out)[i] = ((const uint64_t *)in)[s]; break;
+    }
+  }
+}
+
+// keycol (and valcol, int64) are sorted IN PLACE.  nseg < 0: whole column; otherwise only inside the nseg segments
+// [begin[s], end[s]) given as DEVICE arrays of uint32.
+static gdf_error radixsort_api(const RadixPlan *plan, gdf_column *keycol, gdf_column *valcol, gdf_dtype expect, int nseg,
+                               const unsigned *d_begin, const unsigned *d_end) {
+  GDF_REQUIRE(plan && keycol && valcol, GDF_DATASET_EMPTY);
+  GDF_REQUIRE(!keycol->valid, GDF_VALIDITY_UNSUPPORTED);                    // sorting.cu:196-197
+  GDF_REQUIRE(!valcol->valid, GDF_VALIDITY_UNSUPPORTED);
+  GDF_REQUIRE(keycol->size == valcol->size, GDF_COLUMN_SIZE_MISMATCH);      // :199
+  GDF_REQUIRE(plan->num_items == keycol->size, GDF_COLUMN_SIZE_MISMATCH);   // :202
+  const int kw = dtype_width(expect);
+  GDF_REQUIRE((size_t)kw == plan->sizeof_key && plan->sizeof_val == sizeof(int64_t), GDF_COLUMN_SIZE_MISMATCH);   // :204-207
+  GDF_REQUIRE(plan->num_items < (size_t)0x7fffffff, GDF_COLUMN_SIZE_TOO_BIG);
+  const uint32_t n = (uint32_t)plan->num_items;
+  if (n < 2) return GDF_SUCCESS;
+  GDF_REQUIRE(keycol->data && valcol->data, GDF_DATASET_EMPTY);
+  const ElemKind kind = elem_kind(expect);
+  const int bits = kw * 8;
+  const unsigned b0 = plan->begin_bit < (unsigned)bits ? plan->begin_bit : bits, b1 = plan->end_bit < (unsigned)bits ? plan->end_bit : bits;
+  const uint64_t range = (b1 <= b0) ? 0ULL : ((b1 >= 64 ? ~0ULL : ((1ULL << b1) - 1ULL)) & ~((1ULL << b0) - 1ULL));
+
+  DevBuf region, rflags, dbounds;
+  uint32_t nbounds = 0;
+  if (nseg >= 0) {
+    // regions: maximal runs between consecutive boundary points; a region is sorted iff it starts at the begin of a
+    // non-empty segment.  Segments are disjoint (as DeviceSegmentedRadixSort requires).
+    std::vector<unsigned> hb(nseg), he(nseg);
+    if (nseg) {
+      HIP_TRY(hipMemcpy(hb.data(), d_begin, sizeof(unsigned) * nseg, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(he.data(), d_end, sizeof(unsigned) * nseg, hipMemcpyDeviceToHost));
+    }
+    std::vector<uint32_t> bounds;
+    for (int s = 0; s < nseg; ++s) { bounds.push_back(hb[s]); bounds.push_back(he[s]); }
+    std::sort(bounds.begin(), bounds.end());
+    bounds.erase(std::unique(bounds.begin(), bounds.end()), bounds.end());
+    nbounds = (uint32_t)bounds.size();
+    std::vector<uint8_t> sorted_flag(nbounds + 1, 0);           // region r starts at bounds[r-1] (region 0 at row 0)
+    for (int s = 0; s < nseg; ++s) {
+      if (he[s] <= hb[s]) continue;
+      const uint32_t r = (uint32_t)(std::upper_bound(bounds.begin(), bounds.end(), hb[s]) - bounds.begin());
+      sorted_flag[r] = 1;
+    }
+    RMM_TRY(region.alloc(sizeof(uint32_t) * (size_t)n));
+    RMM_TRY(rflags.alloc(sorted_flag.size()));
+    RMM_TRY(dbounds.alloc(sizeof(uint32_t) * (nbounds ? nbounds : 1)));
+    HIP_TRY(hipMemcpy(rflags.p, sorted_flag.data(), sorted_flag.size(), hipMemcpyHostToDevice));
+    if (nbounds) HIP_TRY(hipMemcpy(dbounds.p, bounds.data(), sizeof(uint32_t) * nbounds, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(rsw_regions, dim3(stream_grid(n, 1024)), dim3(256), 0, stream0(), dbounds.as<uint32_t>(), nbounds, region.as<uint32_t>(), n);
+  }
+
+  DevBuf ka, kb, va, vb, vary, back;
+  RMM_TRY(ka.alloc(sizeof(uint64_t) * (size_t)n));
+  RMM_TRY(kb.alloc(sizeof(uint64_t) * (size_t)n));
+  RMM_TRY(va.alloc(sizeof(uint32_t) * (size_t)n));
+  RMM_TRY(vb.alloc(sizeof(uint32_t) * (size_t)n));
+  RMM_TRY(vary.alloc(sizeof(unsigned long long)));
+  HIP_TRY(hipMemsetAsync(vary.p, 0, sizeof(unsigned long long), stream0()));
+  uint64_t *kin = ka.as<uint64_t>(), *kout = kb.as<uint64_t>();
+  uint32_t *vin = va.as<uint32_t>(), *vout = vb.as<uint32_t>();
+  const int grid = stream_grid(n, 1024);
+  GDF_LAUNCH("rsw_images", rsw_images, dim3(grid), dim3(256), 0, stream0(), (const void *)keycol->data, (int)kind, plan->descending,
+             (const uint32_t *)region.as<uint32_t>(), (const uint8_t *)rflags.as<uint8_t>(), kin, vin, n, vary.as<unsigned long long>());
+  unsigned long long varying = 0;
+  HIP_TRY(hipMemcpy(&varying, vary.p, sizeof(varying), hipMemcpyDeviceToHost));
+  GDF_TRY(radix_sort_pairs<uint32_t>(kin, kout, vin, vout, n, varying & range));
+  if (nseg >= 0 && nbounds) {
+    // second, stable sort on the region number puts every row back into its own region
+    hipLaunchKernelGGL(rsw_region_keys, dim3(grid), dim3(256), 0, stream0(), (const uint32_t *)region.as<uint32_t>(), (const uint32_t *)vin, kin, n);
+    uint64_t rbits = 0;
+    for (uint32_t v = nbounds; v; v >>= 1) rbits = (rbits << 1) | 1ULL;
+    GDF_TRY(radix_sort_pairs<uint32_t>(kin, kout, vin, vout, n, rbits));
+  }
+  RMM_TRY(back.alloc((size_t)8 * n));
+  hipLaunchKernelGGL(rsw_gather, dim3(grid), dim3(256), 0, stream0(), (const uint32_t *)vin, n, kw, (const void *)keycol->data, back.p);
+  HIP_TRY(hipMemcpyAsync(keycol->data, back.p, (size_t)kw * n, hipMemcpyDeviceToDevice, stream0()));
+  hipLaunchKernelGGL(rsw_gather, dim3(grid), dim3(256), 0, stream0(), (const uint32_t *)vin, n, 8, (const void *)valcol->data, back.p);
+  HIP_TRY(hipMemcpyAsync(valcol->data, back.p, (size_t)8 * n, hipMemcpyDeviceToDevice, stream0()));
+  HIP_CHECK_LAST();
+  HIP_TRY(hipStreamSynchronize(stream0()));
+  return GDF_SUCCESS;
+}
+
+static gdf_error radixsort_generic(const RadixPlan *plan, gdf_column *keycol, gdf_column *valcol, int nseg, const unsigned *b, const unsigned *e) {
+  GDF_REQUIRE(keycol && valcol, GDF_DATASET_EMPTY);
+  GDF_REQUIRE(valcol->dtype == GDF_INT64, GDF_UNSUPPORTED_DTYPE);          // sorting.cu:224
+  switch (keycol->dtype) {
+    case GDF_INT8: case GDF_INT32: case GDF_INT64: case GDF_FLOAT32: case GDF_FLOAT64:
+      return radixsort_api(plan, keycol, valcol, keycol->dtype, nseg, b, e);
+    default: return GDF_UNSUPPORTED_DTYPE;
+  }
+}
+
 }  // namespace gdf_amd
 
 using namespace gdf_amd;
 
 extern "C" {
+
+gdf_radixsort_plan_type *gdf_radixsort_plan(size_t num_items, int descending, unsigned begin_bit, unsigned end_bit) {
+  return reinterpret_cast<gdf_radixsort_plan_type *>(new (std::nothrow) RadixPlan{num_items, descending, begin_bit, end_bit, 0, 0});
+}
+gdf_error gdf_radixsort_plan_setup(gdf_radixsort_plan_type *hdl, size_t sizeof_key, size_t sizeof_val) {
+  GDF_REQUIRE(hdl, GDF_DATASET_EMPTY);
+  RadixPlan *p = reinterpret_cast<RadixPlan *>(hdl);
+  p->sizeof_key = sizeof_key;
+  p->sizeof_val = sizeof_val;
+  return GDF_SUCCESS;
+}
+gdf_error gdf_radixsort_plan_free(gdf_radixsort_plan_type *hdl) { delete reinterpret_cast<RadixPlan *>(hdl); return GDF_SUCCESS; }
+gdf_segmented_radixsort_plan_type *gdf_segmented_radixsort_plan(size_t num_items, int descending, unsigned begin_bit, unsigned end_bit) {
+  return reinterpret_cast<gdf_segmented_radixsort_plan_type *>(new (std::nothrow) RadixPlan{num_items, descending, begin_bit, end_bit, 0, 0});
+}
+gdf_error gdf_segmented_radixsort_plan_setup(gdf_segmented_radixsort_plan_type *hdl, size_t sizeof_key, size_t sizeof_val) {
+  return gdf_radixsort_plan_setup(reinterpret_cast<gdf_radixsort_plan_type *>(hdl), sizeof_key, sizeof_val);
+}
+gdf_error gdf_segmented_radixsort_plan_free(gdf_segmented_radixsort_plan_type *hdl) {
+  delete reinterpret_cast<RadixPlan *>(hdl);
+  return GDF_SUCCESS;
+}
+
+#define GDF_RSORT_IMPL(suffix, dtype_)                                                                                       \
+  gdf_error gdf_radixsort_##suffix(gdf_radixsort_plan_type *hdl, gdf_column *keycol, gdf_column *valcol) {                    \
+    return radixsort_api(reinterpret_cast<RadixPlan *>(hdl), keycol, valcol, dtype_, -1, nullptr, nullptr);                   \
+  }                                                                                                                           \
+  gdf_error gdf_segmented_radixsort_##suffix(gdf_segmented_radixsort_plan_type *hdl, gdf_column *keycol, gdf_column *valcol,  \
+                                             unsigned num_segments, unsigned *d_begin_offsets, unsigned *d_end_offsets) {     \
+    return radixsort_api(reinterpret_cast<RadixPlan *>(hdl), keycol, valcol, dtype_, (int)num_segments, d_begin_offsets,      \
+                         d_end_offsets);                                                                                      \
+  }
+GDF_RSORT_IMPL(i8, GDF_INT8)
+GDF_RSORT_IMPL(i32, GDF_INT32)
+GDF_RSORT_IMPL(i64, GDF_INT64)
+GDF_RSORT_IMPL(f32, GDF_FLOAT32)
+GDF_RSORT_IMPL(f64, GDF_FLOAT64)
+#undef GDF_RSORT_IMPL
+gdf_error gdf_radixsort_generic(gdf_radixsort_plan_type *hdl, gdf_column *keycol, gdf_column *valcol) {
+  return radixsort_generic(reinterpret_cast<RadixPlan *>(hdl), keycol, valcol, -1, nullptr, nullptr);
+}
+gdf_error gdf_segmented_radixsort_generic(gdf_segmented_radixsort_plan_type *hdl, gdf_column *keycol, gdf_column *valcol,
+                                          unsigned num_segments, unsigned *d_begin_offsets, unsigned *d_end_offsets) {
+  return radixsort_generic(reinterpret_cast<RadixPlan *>(hdl), keycol, valcol, (int)num_segments, d_begin_offsets, d_end_offsets);
+}
 
 // sqls_ops.cu:1373-1392.  `cols` is a host ARRAY of gdf_column (not pointers); d_cols /
 // d_types are caller-provided device scratch that the reference fills with the data

@@ -17,13 +17,6 @@ extern "C" {
                  unsigned *) { return GDF_UNSUPPORTED_METHOD; }
 #include "gdf/gdf_unsupported.def"
 
-gdf_radixsort_plan_type *gdf_radixsort_plan(size_t, int, unsigned, unsigned) { return nullptr; }
-gdf_error gdf_radixsort_plan_setup(gdf_radixsort_plan_type *, size_t, size_t) { return GDF_UNSUPPORTED_METHOD; }
-gdf_error gdf_radixsort_plan_free(gdf_radixsort_plan_type *) { return GDF_UNSUPPORTED_METHOD; }
-gdf_segmented_radixsort_plan_type *gdf_segmented_radixsort_plan(size_t, int, unsigned, unsigned) { return nullptr; }
-gdf_error gdf_segmented_radixsort_plan_setup(gdf_segmented_radixsort_plan_type *, size_t, size_t) { return GDF_UNSUPPORTED_METHOD; }
-gdf_error gdf_segmented_radixsort_plan_free(gdf_segmented_radixsort_plan_type *) { return GDF_UNSUPPORTED_METHOD; }
-
 unsigned int gdf_reduce_optimal_output_size(void) { return 0; }
 gdf_error gdf_quantile_exact(gdf_column *, gdf_quantile_method, double, void *, gdf_context *) { return GDF_UNSUPPORTED_METHOD; }
 gdf_error gdf_quantile_aprrox(gdf_column *, double, void *, gdf_context *) { return GDF_UNSUPPORTED_METHOD; }

@@ -96,7 +96,7 @@ def test_out_of_scope_entry_points_report_unsupported(libs):
     gdf, _ = libs
     assert gdf.gdf_sin_f32(None, None) == 12          # GDF_UNSUPPORTED_METHOD
     assert gdf.gdf_add_i32(None, None, None) == 12
-    assert gdf.gdf_quantile_aprrox(None, 0.5, None, None) == 12
+    assert gdf.gdf_cast_i32_to_f64(None, None) == 12
 
 
 def test_host_side_argument_errors_need_no_gpu(libs):

@@ -815,9 +815,9 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
 }
 
 // ---------------------------------------------------------------------------
-// 4b. The same write pass for the PLAIN case -- INNER join, NARROW tuples, exact keys (no verification on the
-// original columns), no FULL-join marks -- which is what C3 and every foreign-key join on <= 32-bit-range keys
-// runs.  jk_probe carries all the other cases in one body; per probe tuple it issued ~98 VALU + ~60 SALU
+// 4b. The same write pass for the PLAIN case -- INNER or LEFT join, NARROW tuples, exact keys (no verification on
+// the original columns), no FULL-join marks -- which is what C3 and every foreign-key join on <= 32-bit-range
+// keys runs.  jk_probe carries all the other cases in one body; per probe tuple it issued ~98 VALU + ~60 SALU
 // instructions and the kernel was VALU-bound at 4.2 ms (profiles/r1_g_probe_ablation.md).  Here: 32-bit keys and
 // unit-local 32-bit output positions (one scalar base pointer per array), the build tuple is read from LDS once
 // (key and row in one 64-bit word), no runtime switches in the loop.  A unit whose cuckoo build does not settle
@@ -825,7 +825,8 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
 // ---------------------------------------------------------------------------
 // POW2: H is a power of two and a slot is the top log2(H) bits of the hash product; otherwise H is any size
 // (chosen by the host for a 40 % table load) and a slot is mulhi(hash product, H).
-template <bool POW2>
+// KEEP: LEFT join -- a probe tuple without a match emits (probe row, -1).
+template <bool POW2, bool KEEP>
 __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_fast(ProbeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const uint32_t H = a.nslots, cap = a.cap;
@@ -915,7 +916,8 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_fast(ProbeArgs a) {
     for (int b = 0; b < NB; ++b) {
       const bool ha = act[b] && pa[b] != JK_NOPOS && (uint32_t)(wa[b] >> 32) == key[b];
       const bool hb = act[b] && pb[b] != JK_NOPOS && (uint32_t)(wb[b] >> 32) == key[b];
-      const uint32_t c = (uint32_t)ha + (uint32_t)hb;
+      const bool pad = KEEP && act[b] && !ha && !hb;
+      const uint32_t c = (uint32_t)ha + (uint32_t)hb + (uint32_t)pad;
       uint32_t pos;
       if (__all(c <= 1)) {
         const unsigned long long mm = __ballot(c == 1);
@@ -933,7 +935,7 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_fast(ProbeArgs a) {
         if (pos + c > unit_cap) a.opt_state[1] = 1;   // would spill into the next unit's slots: the host redoes the join two-pass
         else if (!(a.dbg & 32)) {
           op[pos] = (int32_t)prow[b];
-          ob[pos] = (int32_t)(uint32_t)(ha ? wa[b] : wb[b]);
+          ob[pos] = pad ? JK_EMPTY : (int32_t)(uint32_t)(ha ? wa[b] : wb[b]);
           if (c == 2) { op[pos + 1] = (int32_t)prow[b]; ob[pos + 1] = (int32_t)(uint32_t)wb[b]; }
         }
       }
@@ -1411,13 +1413,17 @@ static gdf_error run_write_pass(bool narrow, bool plain, size_t nunits, size_t l
     fa.nslots = ((uint32_t)(max_build * 1.25) + 63) & ~63u;
     flds = probe_lds_bytes(true, a.cap, fa.nslots);
   }
-  if (pow2) {
-    HIP_TRY(hipFuncSetAttribute((const void *)jk_probe_fast<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
-    GDF_LAUNCH("jk_probe_write", jk_probe_fast<true>, dim3((unsigned)nunits), dim3(JK_PROBE_THREADS), flds, stream0(), fa);
-  } else {
-    HIP_TRY(hipFuncSetAttribute((const void *)jk_probe_fast<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
-    GDF_LAUNCH("jk_probe_write", jk_probe_fast<false>, dim3((unsigned)nunits), dim3(JK_PROBE_THREADS), flds, stream0(), fa);
-  }
+#define JK_FAST_LAUNCH(P2, KP)                                                                                               \
+  do {                                                                                                                       \
+    HIP_TRY(hipFuncSetAttribute((const void *)jk_probe_fast<P2, KP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds)); \
+    GDF_LAUNCH("jk_probe_write", (jk_probe_fast<P2, KP>), dim3((unsigned)nunits), dim3(JK_PROBE_THREADS), flds, stream0(), fa); \
+  } while (0)
+  const bool keep = a.keep_unmatched_probe != 0;
+  if (pow2 && keep) JK_FAST_LAUNCH(true, true);
+  else if (pow2) JK_FAST_LAUNCH(true, false);
+  else if (keep) JK_FAST_LAUNCH(false, true);
+  else JK_FAST_LAUNCH(false, false);
+#undef JK_FAST_LAUNCH
   HIP_CHECK_LAST();
   unsigned long long left = 0;
   HIP_TRY(hipMemcpy(&left, a.opt_state + 2, sizeof(left), hipMemcpyDeviceToHost));
@@ -1522,7 +1528,7 @@ static gdf_error hash_join_core(const KeyTable &probe_t, const KeyTable &build_t
   a.dbg = getenv("GDF_JK_DBG") ? atoi(getenv("GDF_JK_DBG")) : 0;
   a.kbias = plan.kmin;
   const size_t probe_lds = probe_lds_bytes(narrow, cap_lds, H_lds);
-  const bool plain = kind == JOIN_INNER && !plan.verify;      // see jk_probe_fast
+  const bool plain = kind != JOIN_FULL && !plan.verify;       // INNER and LEFT with exact keys: see jk_probe_fast
 
   clk.mark("units + argument setup");
   // ---- optimistic single pass ----

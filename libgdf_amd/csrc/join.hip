@@ -1235,7 +1235,7 @@ static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, Si
   // scatter tile: THREADS * 16 tuples regrouped in LDS per step.  Bigger tiles mean longer runs per
   // (tile, bin) -- DRAM-friendlier writes -- at the price of fewer resident workgroups.
   static const int sc_threads_env = getenv("GDF_JK_SC_THREADS") ? atoi(getenv("GDF_JK_SC_THREADS")) : 0;
-  int sc_threads = sc_threads_env ? sc_threads_env : (narrow ? 1024 : 256);   // swept on C3: profiles/r1_c_sweeps.md
+  int sc_threads = sc_threads_env ? sc_threads_env : (narrow ? 1024 : 512);   // swept on C3: profiles/r1_c_sweeps.md
   if (sc_threads != 256 && sc_threads != 512 && sc_threads != 1024) sc_threads = 256;
   if (!narrow && sc_threads == 1024) sc_threads = 512;       // 16384 x 12 B would not fit 160 KiB
   const int64_t JK_TILE = (int64_t)sc_threads * JK_SC_ITEMS;
@@ -1298,7 +1298,7 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
   const uint32_t nfine = 1u << g.fb, ncoarse = 1u << g.b1;
   const int fast = fast_key_width(t, plan);
   static const int sc_threads_env = getenv("GDF_JK_SC_THREADS") ? atoi(getenv("GDF_JK_SC_THREADS")) : 0;
-  int sc_threads = sc_threads_env ? sc_threads_env : (narrow ? 1024 : 256);
+  int sc_threads = sc_threads_env ? sc_threads_env : (narrow ? 1024 : 512);
   if (sc_threads != 256 && sc_threads != 512 && sc_threads != 1024) sc_threads = 256;
   if (!narrow && sc_threads == 1024) sc_threads = 512;
   const int64_t JK_TILE = (int64_t)sc_threads * JK_SC_ITEMS;

@@ -916,8 +916,9 @@ __global__ __launch_bounds__(1024) void gb_direct_extract(KeyTable t, GbDirect d
 //             a row with a null key gets the bit just above the packed field and sorts behind every real key)
 //   payload = accumulator image of the value (identity if the value is null)
 // ---------------------------------------------------------------------------
+template <class K>      // K = uint32_t when key bits + valid bit + null bit fit 32 (12-byte pairs), else uint64_t
 __global__ __launch_bounds__(256) void gb_sorted_make_pairs(KeyTable t, GbKeyPlan plan, GbVal val, int fold_op, int vbit,
-                                                            uint64_t null_key, uint64_t *__restrict__ keys, uint64_t *__restrict__ payload,
+                                                            uint64_t null_key, K *__restrict__ keys, uint64_t *__restrict__ payload,
                                                             unsigned long long *__restrict__ varying, unsigned int *__restrict__ dropped) {
   uint64_t diff = 0;
   unsigned int drop = 0;
@@ -930,7 +931,7 @@ __global__ __launch_bounds__(256) void gb_sorted_make_pairs(KeyTable t, GbKeyPla
       k = (gb_pack(t, plan, i) << vbit) | (uint64_t)(vbit && vok);
       p = vok ? acc_image(fold_op, val, i) : acc_identity(fold_op);
     }
-    keys[i] = k;
+    keys[i] = (K)k;
     payload[i] = p;
     diff |= k ^ k0;
   }
@@ -1049,20 +1050,21 @@ constexpr uint32_t GB_PART_UNIT_ROWS = 1u << 18;
 struct GbPartUnit { uint32_t begin, count, part, pad; };
 
 // pstart[p] = first sorted position whose partition id (key >> low) is >= p, for p in [0, P]
-__global__ __launch_bounds__(256) void gb_part_bounds(const uint64_t *__restrict__ keys, uint32_t n, int low, uint32_t P,
+template <class K>
+__global__ __launch_bounds__(256) void gb_part_bounds(const K *__restrict__ keys, uint32_t n, int low, uint32_t P,
                                                       uint32_t *__restrict__ pstart) {
   for (uint32_t p = blockIdx.x * 256 + threadIdx.x; p <= P; p += gridDim.x * 256) {
     uint32_t lo = 0, hi = n;
     while (lo < hi) {
       const uint32_t mid = lo + (hi - lo) / 2;
-      if ((keys[mid] >> low) < (uint64_t)p) lo = mid + 1; else hi = mid;
+      if (((uint64_t)keys[mid] >> low) < (uint64_t)p) lo = mid + 1; else hi = mid;
     }
     pstart[p] = lo;
   }
 }
 
-template <bool VBIT>
-__global__ __launch_bounds__(GB_DENSE_THREADS) void gb_part_aggregate(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ payload,
+template <bool VBIT, class K>
+__global__ __launch_bounds__(GB_DENSE_THREADS) void gb_part_aggregate(const K *__restrict__ keys, const uint64_t *__restrict__ payload,
                                                                       const GbPartUnit *__restrict__ units, int id_bits, int op, bool flt,
                                                                       unsigned long long *gacc, unsigned int *grows, unsigned int *gvalid) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gb_lds[];
@@ -1079,7 +1081,8 @@ __global__ __launch_bounds__(GB_DENSE_THREADS) void gb_part_aggregate(const uint
   const GbPartUnit u = units[blockIdx.x];
   const uint32_t mask = ids - 1;
   for (uint32_t base = 0; base < u.count; base += GB_DENSE_THREADS * GB_DENSE_BATCH) {
-    uint64_t k[GB_DENSE_BATCH], v[GB_DENSE_BATCH];
+    K k[GB_DENSE_BATCH];
+    uint64_t v[GB_DENSE_BATCH];
 #pragma unroll
     for (int b = 0; b < GB_DENSE_BATCH; ++b) {                       // all HBM loads first, from clamped addresses
       const uint32_t i = base + b * GB_DENSE_THREADS + threadIdx.x;
@@ -1092,7 +1095,7 @@ __global__ __launch_bounds__(GB_DENSE_THREADS) void gb_part_aggregate(const uint
       if (base + b * GB_DENSE_THREADS + threadIdx.x < u.count) {
         const uint32_t id = (uint32_t)(k[b] >> (VBIT ? 1 : 0)) & mask;
         atomicAdd(&lrows[id], 1u);
-        if (!VBIT || (k[b] & 1ULL)) {
+        if (!VBIT || (k[b] & 1)) {
           acc_fold(op, flt, &lacc[id], v[b]);
           if (VBIT) atomicAdd(&lvalid[id], 1u);
         }
@@ -1376,6 +1379,109 @@ static gdf_error gb_path_dense(GbJob &j, bool *done) {
   return GDF_SUCCESS;
 }
 
+// The partitioned variant of the sorted path (see the kernels above), for key type K = uint32_t (12-byte pairs,
+// when key bits + valid bit + null bit fit 32) or uint64_t.
+template <class K>
+static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, int null_bit, bool *done) {
+  [[maybe_unused]] const int ncols = j.ncols;
+  [[maybe_unused]] gdf_column **out_keys = j.out_keys;
+  [[maybe_unused]] gdf_column *out_agg = j.out_agg;
+  [[maybe_unused]] const int op = j.op;
+  [[maybe_unused]] const bool sort_result = j.sort_result;
+  [[maybe_unused]] const KeyTable &t = j.t;
+  [[maybe_unused]] const int64_t n = j.t.nrows;
+  [[maybe_unused]] const ElemKind in_kind = j.in_kind, out_kind = j.out_kind;
+  [[maybe_unused]] const GbKeyPlan &plan = j.plan;
+  [[maybe_unused]] const GbVal &val = j.val;
+  [[maybe_unused]] const bool masked = j.masked, avg = j.counted, want_ok = j.want_ok;
+  [[maybe_unused]] DevBuf &agg_ok = j.agg_ok;
+  const uint32_t nn = (uint32_t)n;
+  DevBuf ka, kb, pa, pb, fl;
+  RMM_TRY(ka.alloc(sizeof(K) * (size_t)nn));
+  RMM_TRY(kb.alloc(sizeof(K) * (size_t)nn));
+  RMM_TRY(pa.alloc(sizeof(uint64_t) * (size_t)nn));
+  RMM_TRY(pb.alloc(sizeof(uint64_t) * (size_t)nn));
+  RMM_TRY(fl.alloc(16));
+  HIP_TRY(hipMemsetAsync(fl.p, 0, 16, stream0()));
+  const int fold_op = op == OP_AVG ? OP_SUM : op;
+  const bool flt = is_flt(val.kind);
+  const uint64_t null_key = null_bit ? (1ULL << (sp.total_bits + vbit)) : 0ULL;
+  K *kin = ka.as<K>(), *kout = kb.as<K>();
+  uint64_t *pin = pa.as<uint64_t>(), *pout = pb.as<uint64_t>();
+  GDF_LAUNCH("gb_sorted_make_pairs", gb_sorted_make_pairs<K>, dim3(stream_grid((size_t)n, 256 * 8)), dim3(256), 0, stream0(), t, sp, val,
+             fold_op, vbit, null_key, kin, pin, fl.as<unsigned long long>(), (unsigned int *)(fl.as<unsigned long long>() + 1));
+  struct { unsigned long long varying; unsigned int dropped, pad; } hf;
+  HIP_TRY(hipMemcpy(&hf, fl.p, 16, hipMemcpyDeviceToHost));
+  const uint32_t nvalid = nn - hf.dropped;
+  uint32_t ngroups = 0;
+  GbOut o{};
+  o.ncols = ncols;
+  for (int c = 0; c < ncols; ++c) o.key_out[c] = out_keys[c]->data;
+  o.agg_out = out_agg->data;
+  o.in_kind = (int)in_kind;
+  o.agg_kind = (int)((op == OP_COUNT || op == OP_AVG) ? out_kind : in_kind);
+  o.counted = val.valid != nullptr;
+  const int id_bits = sp.total_bits < GB_PART_ID_BITS ? sp.total_bits : GB_PART_ID_BITS;
+  const int part_bits = sp.total_bits - id_bits;
+  if (nvalid) {
+    const int low = vbit + id_bits;
+    const uint64_t himask = low >= 64 ? 0ULL : ~((1ULL << low) - 1ULL);
+    if constexpr (sizeof(K) == 4) GDF_TRY(radix_sort_pairs_k32_u64(kin, kout, pin, pout, nn, hf.varying & himask));
+    else GDF_TRY(radix_sort_pairs_u64(kin, kout, pin, pout, nn, hf.varying & himask));
+    const uint32_t P = 1u << part_bits;
+    const size_t cells = (size_t)P << id_bits;
+    const size_t cells_pad = (cells + 1023) / 1024 * 1024;
+    DevBuf pstart, d_units, gacc, grows, gvalid, bcnt, ng;
+    RMM_TRY(pstart.alloc(sizeof(uint32_t) * ((size_t)P + 1)));
+    GDF_LAUNCH("gb_part_bounds", gb_part_bounds<K>, dim3(stream_grid((size_t)P + 1, 256)), dim3(256), 0, stream0(), (const K *)kin, nvalid, low, P,
+               pstart.as<uint32_t>());
+    std::vector<uint32_t> hp((size_t)P + 1);
+    HIP_TRY(hipMemcpy(hp.data(), pstart.p, sizeof(uint32_t) * ((size_t)P + 1), hipMemcpyDeviceToHost));
+    std::vector<GbPartUnit> units;
+    for (uint32_t p = 0; p < P; ++p)
+      for (uint32_t b = hp[p]; b < hp[p + 1]; b += GB_PART_UNIT_ROWS)
+        units.push_back(GbPartUnit{b, std::min(GB_PART_UNIT_ROWS, hp[p + 1] - b), p, 0u});
+    RMM_TRY(d_units.alloc(sizeof(GbPartUnit) * (units.size() ? units.size() : 1)));
+    HIP_TRY(hipMemcpyAsync(d_units.p, units.data(), sizeof(GbPartUnit) * units.size(), hipMemcpyHostToDevice, stream0()));
+    RMM_TRY(gacc.alloc(sizeof(uint64_t) * cells_pad));
+    RMM_TRY(grows.alloc(sizeof(unsigned int) * cells_pad));
+    if (vbit) RMM_TRY(gvalid.alloc(sizeof(unsigned int) * cells_pad));
+    RMM_TRY(bcnt.alloc(sizeof(uint32_t) * (cells_pad / 1024)));
+    RMM_TRY(ng.alloc(sizeof(unsigned int)));
+    GDF_LAUNCH("gb_fill", gb_fill_u64, dim3(stream_grid(cells_pad, 1024)), dim3(256), 0, stream0(), gacc.as<unsigned long long>(),
+               (unsigned long long)acc_identity_host(fold_op), (uint32_t)cells_pad);
+    HIP_TRY(hipMemsetAsync(grows.p, 0, sizeof(unsigned int) * cells_pad, stream0()));
+    if (vbit) HIP_TRY(hipMemsetAsync(gvalid.p, 0, sizeof(unsigned int) * cells_pad, stream0()));
+    const size_t plds = ((size_t)1 << id_bits) * (vbit ? 16 : 12) + 16;
+    if (vbit) {
+      HIP_TRY(hipFuncSetAttribute((const void *)gb_part_aggregate<true, K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
+      GDF_LAUNCH("gb_part_aggregate", (gb_part_aggregate<true, K>), dim3((unsigned)units.size()), dim3(GB_DENSE_THREADS), plds, stream0(), (const K *)kin,
+                 (const uint64_t *)pin, (const GbPartUnit *)d_units.as<GbPartUnit>(), id_bits, fold_op, flt, gacc.as<unsigned long long>(),
+                 grows.as<unsigned int>(), gvalid.as<unsigned int>());
+    } else {
+      HIP_TRY(hipFuncSetAttribute((const void *)gb_part_aggregate<false, K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
+      GDF_LAUNCH("gb_part_aggregate", (gb_part_aggregate<false, K>), dim3((unsigned)units.size()), dim3(GB_DENSE_THREADS), plds, stream0(), (const K *)kin,
+                 (const uint64_t *)pin, (const GbPartUnit *)d_units.as<GbPartUnit>(), id_bits, fold_op, flt, gacc.as<unsigned long long>(),
+                 grows.as<unsigned int>(), (unsigned int *)nullptr);
+    }
+    const unsigned nblocks = (unsigned)(cells_pad / 1024);
+    GDF_LAUNCH("gb_part_count", gb_part_count, dim3(nblocks), dim3(1024), 0, stream0(), (const unsigned int *)grows.as<unsigned int>(), bcnt.as<uint32_t>());
+    GDF_TRY(scan_u32(bcnt.as<uint32_t>(), bcnt.as<uint32_t>(), nblocks, false));
+    // the number of groups is needed before the outputs can be written only for the optional ok-bytes
+    if (want_ok) RMM_TRY(agg_ok.alloc(cells_pad < (size_t)nvalid ? cells_pad : (size_t)nvalid));
+    o.agg_ok = agg_ok.as<uint8_t>();
+    GDF_LAUNCH("gb_extract", gb_part_extract, dim3(nblocks), dim3(1024), 0, stream0(), t, sp, o, op, (const unsigned long long *)gacc.as<unsigned long long>(),
+               (const unsigned int *)grows.as<unsigned int>(), (const unsigned int *)gvalid.as<unsigned int>(), (const uint32_t *)bcnt.as<uint32_t>(),
+               ng.as<unsigned int>());
+    HIP_CHECK_LAST();
+    HIP_TRY(hipMemcpy(&ngroups, ng.p, sizeof(ngroups), hipMemcpyDeviceToHost));
+  }
+  for (int c = 0; c < ncols; ++c) out_keys[c]->size = (gdf_size_type)ngroups;
+  out_agg->size = (gdf_size_type)ngroups;
+  *done = true;
+  return write_output_masks(ncols, out_keys, out_agg, o.agg_ok, ngroups);     // cells ascend: already sorted
+}
+
 // Path 3 -- sorted: packed keys, many groups.
 static gdf_error gb_path_sorted(GbJob &j, bool *done) {
   *done = false;
@@ -1396,6 +1502,14 @@ static gdf_error gb_path_sorted(GbJob &j, bool *done) {
     if (!sp.ordered) GDF_TRY(gb_plan_range(t, &sp));          // fewer key bits = fewer radix passes, and sorted output for free
     const int vbit = (val.valid != nullptr && op != OP_COUNT) ? 1 : 0;
     const int null_bit = t.any_valid ? 1 : 0;
+    // partitioned variant: sort the high key bits only, index LDS accumulators with the low ones
+    {
+      const int id_bits = sp.total_bits < GB_PART_ID_BITS ? sp.total_bits : GB_PART_ID_BITS;
+      if (sp.ordered && sp.total_bits - id_bits <= GB_PART_MAX_BITS && !getenv("GDF_GB_NO_PART")) {
+        if (sp.total_bits + vbit + null_bit <= 32 && !getenv("GDF_GB_NO_K32")) return gb_sorted_partitioned<uint32_t>(j, sp, vbit, null_bit, done);
+        return gb_sorted_partitioned<uint64_t>(j, sp, vbit, null_bit, done);
+      }
+    }
     if (sp.total_bits + vbit + null_bit <= 64) {
       const uint32_t nn = (uint32_t)n;
       DevBuf ka, kb, pa, pb, fl, gid, start, acc, cnt;
@@ -1409,7 +1523,7 @@ static gdf_error gb_path_sorted(GbJob &j, bool *done) {
       const bool flt = is_flt(val.kind);
       const uint64_t null_key = null_bit ? (1ULL << (sp.total_bits + vbit)) : 0ULL;
       uint64_t *kin = ka.as<uint64_t>(), *kout = kb.as<uint64_t>(), *pin = pa.as<uint64_t>(), *pout = pb.as<uint64_t>();
-      GDF_LAUNCH("gb_sorted_make_pairs", gb_sorted_make_pairs, dim3(stream_grid((size_t)n, 256 * 8)), dim3(256), 0, stream0(), t, sp, val,
+      GDF_LAUNCH("gb_sorted_make_pairs", gb_sorted_make_pairs<uint64_t>, dim3(stream_grid((size_t)n, 256 * 8)), dim3(256), 0, stream0(), t, sp, val,
                  fold_op, vbit, null_key, kin, pin, fl.as<unsigned long long>(), (unsigned int *)(fl.as<unsigned long long>() + 1));
       struct { unsigned long long varying; unsigned int dropped, pad; } hf;
       HIP_TRY(hipMemcpy(&hf, fl.p, 16, hipMemcpyDeviceToHost));
@@ -1422,65 +1536,6 @@ static gdf_error gb_path_sorted(GbJob &j, bool *done) {
       o.in_kind = (int)in_kind;
       o.agg_kind = (int)((op == OP_COUNT || op == OP_AVG) ? out_kind : in_kind);
       o.counted = val.valid != nullptr;
-      // ---- partitioned direct variant: sort the high key bits only, index LDS accumulators with the low ones ----
-      const int id_bits = sp.total_bits < GB_PART_ID_BITS ? sp.total_bits : GB_PART_ID_BITS;
-      const int part_bits = sp.total_bits - id_bits;
-      if (sp.ordered && part_bits <= GB_PART_MAX_BITS && nvalid && !getenv("GDF_GB_NO_PART")) {
-        const int low = vbit + id_bits;
-        const uint64_t himask = low >= 64 ? 0ULL : ~((1ULL << low) - 1ULL);
-        GDF_TRY(radix_sort_pairs_u64(kin, kout, pin, pout, nn, hf.varying & himask));
-        const uint32_t P = 1u << part_bits;
-        const size_t cells = (size_t)P << id_bits;
-        const size_t cells_pad = (cells + 1023) / 1024 * 1024;
-        DevBuf pstart, d_units, gacc, grows, gvalid, bcnt, ng;
-        RMM_TRY(pstart.alloc(sizeof(uint32_t) * ((size_t)P + 1)));
-        GDF_LAUNCH("gb_part_bounds", gb_part_bounds, dim3(stream_grid((size_t)P + 1, 256)), dim3(256), 0, stream0(), (const uint64_t *)kin, nvalid, low, P,
-                   pstart.as<uint32_t>());
-        std::vector<uint32_t> hp((size_t)P + 1);
-        HIP_TRY(hipMemcpy(hp.data(), pstart.p, sizeof(uint32_t) * ((size_t)P + 1), hipMemcpyDeviceToHost));
-        std::vector<GbPartUnit> units;
-        for (uint32_t p = 0; p < P; ++p)
-          for (uint32_t b = hp[p]; b < hp[p + 1]; b += GB_PART_UNIT_ROWS)
-            units.push_back(GbPartUnit{b, std::min(GB_PART_UNIT_ROWS, hp[p + 1] - b), p, 0u});
-        RMM_TRY(d_units.alloc(sizeof(GbPartUnit) * (units.size() ? units.size() : 1)));
-        HIP_TRY(hipMemcpyAsync(d_units.p, units.data(), sizeof(GbPartUnit) * units.size(), hipMemcpyHostToDevice, stream0()));
-        RMM_TRY(gacc.alloc(sizeof(uint64_t) * cells_pad));
-        RMM_TRY(grows.alloc(sizeof(unsigned int) * cells_pad));
-        if (vbit) RMM_TRY(gvalid.alloc(sizeof(unsigned int) * cells_pad));
-        RMM_TRY(bcnt.alloc(sizeof(uint32_t) * (cells_pad / 1024)));
-        RMM_TRY(ng.alloc(sizeof(unsigned int)));
-        GDF_LAUNCH("gb_fill", gb_fill_u64, dim3(stream_grid(cells_pad, 1024)), dim3(256), 0, stream0(), gacc.as<unsigned long long>(),
-                   (unsigned long long)acc_identity_host(fold_op), (uint32_t)cells_pad);
-        HIP_TRY(hipMemsetAsync(grows.p, 0, sizeof(unsigned int) * cells_pad, stream0()));
-        if (vbit) HIP_TRY(hipMemsetAsync(gvalid.p, 0, sizeof(unsigned int) * cells_pad, stream0()));
-        const size_t plds = ((size_t)1 << id_bits) * (vbit ? 16 : 12) + 16;
-        if (vbit) {
-          HIP_TRY(hipFuncSetAttribute((const void *)gb_part_aggregate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
-          GDF_LAUNCH("gb_part_aggregate", gb_part_aggregate<true>, dim3((unsigned)units.size()), dim3(GB_DENSE_THREADS), plds, stream0(), (const uint64_t *)kin,
-                     (const uint64_t *)pin, (const GbPartUnit *)d_units.as<GbPartUnit>(), id_bits, fold_op, flt, gacc.as<unsigned long long>(),
-                     grows.as<unsigned int>(), gvalid.as<unsigned int>());
-        } else {
-          HIP_TRY(hipFuncSetAttribute((const void *)gb_part_aggregate<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
-          GDF_LAUNCH("gb_part_aggregate", gb_part_aggregate<false>, dim3((unsigned)units.size()), dim3(GB_DENSE_THREADS), plds, stream0(), (const uint64_t *)kin,
-                     (const uint64_t *)pin, (const GbPartUnit *)d_units.as<GbPartUnit>(), id_bits, fold_op, flt, gacc.as<unsigned long long>(),
-                     grows.as<unsigned int>(), (unsigned int *)nullptr);
-        }
-        const unsigned nblocks = (unsigned)(cells_pad / 1024);
-        GDF_LAUNCH("gb_part_count", gb_part_count, dim3(nblocks), dim3(1024), 0, stream0(), (const unsigned int *)grows.as<unsigned int>(), bcnt.as<uint32_t>());
-        GDF_TRY(scan_u32(bcnt.as<uint32_t>(), bcnt.as<uint32_t>(), nblocks, false));
-        // the number of groups is needed before the outputs can be written only for the optional ok-bytes
-        if (want_ok) RMM_TRY(agg_ok.alloc(cells_pad < (size_t)nvalid ? cells_pad : (size_t)nvalid));
-        o.agg_ok = agg_ok.as<uint8_t>();
-        GDF_LAUNCH("gb_extract", gb_part_extract, dim3(nblocks), dim3(1024), 0, stream0(), t, sp, o, op, (const unsigned long long *)gacc.as<unsigned long long>(),
-                   (const unsigned int *)grows.as<unsigned int>(), (const unsigned int *)gvalid.as<unsigned int>(), (const uint32_t *)bcnt.as<uint32_t>(),
-                   ng.as<unsigned int>());
-        HIP_CHECK_LAST();
-        HIP_TRY(hipMemcpy(&ngroups, ng.p, sizeof(ngroups), hipMemcpyDeviceToHost));
-        for (int c = 0; c < ncols; ++c) out_keys[c]->size = (gdf_size_type)ngroups;
-        out_agg->size = (gdf_size_type)ngroups;
-        *done = true;
-        return write_output_masks(ncols, out_keys, out_agg, o.agg_ok, ngroups);     // cells ascend: already sorted
-      }
       GDF_TRY(radix_sort_pairs_u64(kin, kout, pin, pout, nn, hf.varying));
       if (nvalid) {
         RMM_TRY(gid.alloc(sizeof(uint32_t) * (size_t)nvalid));

@@ -20,6 +20,8 @@ gdf_error key_ranges(const KeyTable &t, long long *lo_hi);
 // sort.hip: stable LSD radix sort of n (key, 64-bit payload) pairs on the key bits set in `varying`; the
 // pairs ping-pong between the two buffer sets and kin / vin point at the sorted data on return
 gdf_error radix_sort_pairs_u64(uint64_t *&kin, uint64_t *&kout, uint64_t *&vin, uint64_t *&vout, uint32_t n, uint64_t varying);
+// the same with 32-bit keys (12-byte pairs): a quarter less traffic per pass when the key bits fit
+gdf_error radix_sort_pairs_k32_u64(uint32_t *&kin, uint32_t *&kout, uint64_t *&vin, uint64_t *&vout, uint32_t n, uint64_t varying);
 // sort.hip: SORT-method group-by (op = GbOp of groupby.hip, 5 = COUNT_DISTINCT)
 gdf_error group_by_sort(int ncols, gdf_column **cols, gdf_column *col_agg, gdf_column *out_col_indices,
                         gdf_column **out_col_values, gdf_column *out_col_agg, gdf_context *ctxt, int op);

@@ -187,33 +187,53 @@ constexpr int RS_WAVES = RS_THREADS / WAVE;
 template <class V> struct RsGeom { static constexpr int ITEMS = sizeof(V) == 4 ? 8 : 6; static constexpr int TILE = RS_THREADS * ITEMS; };
 
 // counts[v * ntiles + tile] = number of keys of the tile whose digit is v
-template <int BITS, int TILE>
-__global__ __launch_bounds__(RS_THREADS) void rs_count(const uint64_t *__restrict__ keys, uint32_t n, int shift,
+template <class K, int BITS, int TILE>
+__global__ __launch_bounds__(RS_THREADS) void rs_count(const K *__restrict__ keys, uint32_t n, int shift,
                                                        uint32_t *__restrict__ counts, uint32_t ntiles) {
   constexpr int BINS = 1 << BITS;
+  constexpr int ITEMS = TILE / RS_THREADS;
   __shared__ uint32_t h[BINS];
   for (int j = threadIdx.x; j < BINS; j += RS_THREADS) h[j] = 0;
   block_sync();
-  const uint32_t base = blockIdx.x * TILE;
+  // counting needs no order: a thread takes ITEMS CONSECUTIVE keys with wide loads (a 4-byte key per load kept one
+  // wave at 256 B in flight and this kernel at 1.6 TB/s on 32-bit keys)
+  const uint32_t first = blockIdx.x * TILE + threadIdx.x * ITEMS;
+  if (first + ITEMS <= n) {
+    K k[ITEMS];
+    constexpr int WORDS = ITEMS * (int)sizeof(K) / 8;              // ITEMS * sizeof(K) is a multiple of 8 for both geometries
+    const uint2 *src = reinterpret_cast<const uint2 *>(keys + first);
+    uint2 w[WORDS];
 #pragma unroll
-  for (int r = 0; r < TILE / RS_THREADS; ++r) {
-    const uint32_t i = base + r * RS_THREADS + threadIdx.x;
-    if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & (BINS - 1)], 1u);
+    for (int q = 0; q < WORDS; ++q) w[q] = src[q];
+    __builtin_memcpy(k, w, sizeof(k));
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+      // skewed digits (C5: half of the rows share one partition digit) would serialise 64 same-address LDS
+      // atomics per wave: the lanes that agree with lane 0's digit are counted with one ballot instead
+      const uint32_t d = (uint32_t)(k[r] >> shift) & (BINS - 1);
+      const uint32_t d0 = __shfl(d, 0);
+      const unsigned long long m = __ballot(d == d0);
+      if (d != d0) atomicAdd(&h[d], 1u);
+      else if (lane_id() == 0) atomicAdd(&h[d0], (uint32_t)__popcll(m));
+    }
+  } else {
+    for (int r = 0; r < ITEMS; ++r)
+      if (first + r < n) atomicAdd(&h[(uint32_t)(keys[first + r] >> shift) & (BINS - 1)], 1u);
   }
   block_sync();
   for (int j = threadIdx.x; j < BINS; j += RS_THREADS) counts[(uint32_t)j * ntiles + blockIdx.x] = h[j];
 }
 
-template <class V, int BITS>
-__global__ __launch_bounds__(RS_THREADS) void rs_scatter(const uint64_t *__restrict__ keys_in, const V *__restrict__ vals_in,
-                                                         uint64_t *__restrict__ keys_out, V *__restrict__ vals_out,
+template <class K, class V, int BITS>
+__global__ __launch_bounds__(RS_THREADS) void rs_scatter(const K *__restrict__ keys_in, const V *__restrict__ vals_in,
+                                                         K *__restrict__ keys_out, V *__restrict__ vals_out,
                                                          uint32_t n, int shift, const uint32_t *__restrict__ offsets,
                                                          uint32_t ntiles) {
   constexpr int BINS = 1 << BITS;
   constexpr int ITEMS = RsGeom<V>::ITEMS;
   constexpr int TILE = RsGeom<V>::TILE;
   static_assert(BINS <= RS_THREADS, "one thread per bin");
-  __shared__ uint64_t skey[TILE];
+  __shared__ K skey[TILE];
   __shared__ V sval[TILE];
   __shared__ uint32_t wcnt[RS_WAVES * BINS];   // per-wave digit counts, then exclusive prefix over waves
   __shared__ uint32_t binstart[BINS];          // first LDS position of a digit
@@ -225,7 +245,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter(const uint64_t *__restr
   const uint32_t tile_base = blockIdx.x * TILE;
   const uint32_t wbase = tile_base + wave * (ITEMS * WAVE);
   const uint32_t last = n - 1;
-  uint64_t key[ITEMS];
+  K key[ITEMS];
   V val[ITEMS];
   uint32_t rank[ITEMS];
 #pragma unroll
@@ -286,7 +306,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter(const uint64_t *__restr
   block_sync();
   const uint32_t count = n - tile_base < (uint32_t)TILE ? n - tile_base : (uint32_t)TILE;
   for (uint32_t j = threadIdx.x; j < count; j += RS_THREADS) {
-    const uint64_t k = skey[j];
+    const K k = skey[j];
     const uint32_t dst = gbase[(uint32_t)(k >> shift) & (BINS - 1)] + j;
     keys_out[dst] = k;
     vals_out[dst] = sval[j];
@@ -298,8 +318,8 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter(const uint64_t *__restr
 // point at the sorted data.  The varying bits [lo, hi) are covered by ceil(span / 9)
 // windows of at most 9 bits (8-bit digits for wide keys, 9 when that saves a pass:
 // 25 bits sort in 3 passes); windows may overlap upward, which a stable LSD sort tolerates.
-template <class V>
-gdf_error radix_sort_pairs(uint64_t *&kin, uint64_t *&kout, V *&vin, V *&vout, uint32_t n, uint64_t varying) {
+template <class K, class V>
+gdf_error radix_sort_pairs(K *&kin, K *&kout, V *&vin, V *&vout, uint32_t n, uint64_t varying) {
   if (varying == 0 || n < 2) return GDF_SUCCESS;
   constexpr int TILE = RsGeom<V>::TILE;
   const uint32_t ntiles = (n + TILE - 1) / TILE;
@@ -314,14 +334,14 @@ gdf_error radix_sort_pairs(uint64_t *&kin, uint64_t *&kout, V *&vin, V *&vout, u
     const int bits = bpp > 8 ? 9 : 8;
     if (((varying >> shift) & ((1ULL << bits) - 1)) == 0) continue;
     if (bits == 9) {
-      GDF_LAUNCH("rs_count", (rs_count<9, TILE>), dim3(ntiles), dim3(RS_THREADS), 0, stream0(), (const uint64_t *)kin, n, shift, counts.as<uint32_t>(), ntiles);
+      GDF_LAUNCH("rs_count", (rs_count<K, 9, TILE>), dim3(ntiles), dim3(RS_THREADS), 0, stream0(), (const K *)kin, n, shift, counts.as<uint32_t>(), ntiles);
       GDF_TRY(scan_u32(counts.as<uint32_t>(), counts.as<uint32_t>(), (size_t)ntiles * 512, false));
-      GDF_LAUNCH("rs_scatter", (rs_scatter<V, 9>), dim3(ntiles), dim3(RS_THREADS), 0, stream0(), (const uint64_t *)kin, (const V *)vin, kout, vout, n,
+      GDF_LAUNCH("rs_scatter", (rs_scatter<K, V, 9>), dim3(ntiles), dim3(RS_THREADS), 0, stream0(), (const K *)kin, (const V *)vin, kout, vout, n,
                  shift, (const uint32_t *)counts.as<uint32_t>(), ntiles);
     } else {
-      GDF_LAUNCH("rs_count", (rs_count<8, TILE>), dim3(ntiles), dim3(RS_THREADS), 0, stream0(), (const uint64_t *)kin, n, shift, counts.as<uint32_t>(), ntiles);
+      GDF_LAUNCH("rs_count", (rs_count<K, 8, TILE>), dim3(ntiles), dim3(RS_THREADS), 0, stream0(), (const K *)kin, n, shift, counts.as<uint32_t>(), ntiles);
       GDF_TRY(scan_u32(counts.as<uint32_t>(), counts.as<uint32_t>(), (size_t)ntiles * 256, false));
-      GDF_LAUNCH("rs_scatter", (rs_scatter<V, 8>), dim3(ntiles), dim3(RS_THREADS), 0, stream0(), (const uint64_t *)kin, (const V *)vin, kout, vout, n,
+      GDF_LAUNCH("rs_scatter", (rs_scatter<K, V, 8>), dim3(ntiles), dim3(RS_THREADS), 0, stream0(), (const K *)kin, (const V *)vin, kout, vout, n,
                  shift, (const uint32_t *)counts.as<uint32_t>(), ntiles);
     }
     std::swap(kin, kout);
@@ -331,7 +351,10 @@ gdf_error radix_sort_pairs(uint64_t *&kin, uint64_t *&kout, V *&vin, V *&vout, u
   return GDF_SUCCESS;
 }
 gdf_error radix_sort_pairs_u64(uint64_t *&kin, uint64_t *&kout, uint64_t *&vin, uint64_t *&vout, uint32_t n, uint64_t varying) {
-  return radix_sort_pairs<uint64_t>(kin, kout, vin, vout, n, varying);
+  return radix_sort_pairs<uint64_t, uint64_t>(kin, kout, vin, vout, n, varying);
+}
+gdf_error radix_sort_pairs_k32_u64(uint32_t *&kin, uint32_t *&kout, uint64_t *&vin, uint64_t *&vout, uint32_t n, uint64_t varying) {
+  return radix_sort_pairs<uint32_t, uint64_t>(kin, kout, vin, vout, n, varying);
 }
 
 __global__ __launch_bounds__(256) void rs_iota(uint32_t *p, uint32_t n) {
@@ -412,7 +435,7 @@ gdf_error order_rows(const KeyTable &t, uint32_t n, DevBuf &perm, DevBuf *sorted
     unsigned long long varying = 0;
     HIP_TRY(hipMemcpyAsync(&varying, vary.p, sizeof(varying), hipMemcpyDeviceToHost, stream0()));
     HIP_TRY(hipStreamSynchronize(stream0()));
-    GDF_TRY(radix_sort_pairs<uint32_t>(kin, kout, vin, vout, n, varying));
+    GDF_TRY((radix_sort_pairs<uint64_t, uint32_t>(kin, kout, vin, vout, n, varying)));
   }
   HIP_CHECK_LAST();
   HIP_TRY(hipStreamSynchronize(stream0()));
@@ -808,13 +831,13 @@ static gdf_error radixsort_api(const RadixPlan *plan, gdf_column *keycol, gdf_co
              (const uint32_t *)region.as<uint32_t>(), (const uint8_t *)rflags.as<uint8_t>(), kin, vin, n, vary.as<unsigned long long>());
   unsigned long long varying = 0;
   HIP_TRY(hipMemcpy(&varying, vary.p, sizeof(varying), hipMemcpyDeviceToHost));
-  GDF_TRY(radix_sort_pairs<uint32_t>(kin, kout, vin, vout, n, varying & range));
+  GDF_TRY((radix_sort_pairs<uint64_t, uint32_t>(kin, kout, vin, vout, n, varying & range)));
   if (nseg >= 0 && nbounds) {
     // second, stable sort on the region number puts every row back into its own region
     hipLaunchKernelGGL(rsw_region_keys, dim3(grid), dim3(256), 0, stream0(), (const uint32_t *)region.as<uint32_t>(), (const uint32_t *)vin, kin, n);
     uint64_t rbits = 0;
     for (uint32_t v = nbounds; v; v >>= 1) rbits = (rbits << 1) | 1ULL;
-    GDF_TRY(radix_sort_pairs<uint32_t>(kin, kout, vin, vout, n, rbits));
+    GDF_TRY((radix_sort_pairs<uint64_t, uint32_t>(kin, kout, vin, vout, n, rbits)));
   }
   RMM_TRY(back.alloc((size_t)8 * n));
   hipLaunchKernelGGL(rsw_gather, dim3(grid), dim3(256), 0, stream0(), (const uint32_t *)vin, n, kw, (const void *)keycol->data, back.p);

@@ -31,6 +31,30 @@ gdf_error gdf_amd_debug_partition(gdf_column *col, int fb, uint64_t *out_key, in
  */
 gdf_error gdf_amd_narrow_keys(gdf_column *in, int64_t lo, int64_t hi, gdf_column *out);
 
+/*
+ * A build relation partitioned ONCE and probed many times.  gdf_amd_join_build_probe(b, 0, probe...) returns exactly what
+ * gdf_inner_join(probe, build) with GDF_HASH returns (probe_indices = left, build_indices = right; library-allocated
+ * int32 columns, gdf_column_free them), left_join != 0 what gdf_left_join returns -- except that the table is always on
+ * the prepared relation, never on the smaller one.  The build columns' DATA is not copied: it must stay alive and
+ * unchanged until gdf_amd_join_build_free.  The multi-GPU join probes the received build relation once per slice of
+ * the probe relation.
+ */
+typedef struct gdf_amd_join_build gdf_amd_join_build;
+gdf_error gdf_amd_join_build_create(gdf_column **build_cols, int num_cols, gdf_amd_join_build **out);
+gdf_error gdf_amd_join_build_probe(gdf_amd_join_build *build, int left_join, gdf_column **probe_cols, int num_cols,
+                                   gdf_column *probe_indices, gdf_column *build_indices);
+void gdf_amd_join_build_free(gdf_amd_join_build *build);
+
+/*
+ * The sender side of the multi-GPU shuffle in ONE pass over the keys (instead of narrow + row-number column +
+ * gdf_hash_partition): partitions (key', row) on Murmur3(key') into num_partitions partitions exactly as
+ * gdf_hash_partition(GDF_HASH_MURMUR3) places them, where row = row_base + i and key' = keys[i], or, with narrow != 0
+ * (keys GDF_INT64-like, out_keys GDF_INT32), the gdf_amd_narrow_keys(lo, hi) image of it.  out_keys / out_rows
+ * (GDF_INT32) are caller-preallocated with keys->size rows; partition_offsets is a HOST array of num_partitions ints.
+ */
+gdf_error gdf_amd_shuffle_partition(gdf_column *keys, int narrow, int64_t lo, int64_t hi, int32_t row_base, int num_partitions,
+                                    gdf_column *out_keys, gdf_column *out_rows, int partition_offsets[]);
+
 #if defined(__GNUC__)
 #pragma GCC visibility pop
 #endif

@@ -161,6 +161,46 @@ def hash_partition(cols, cols_to_hash, num_partitions, hash_func=GDF_HASH_MURMUR
     return outs, list(offsets)
 
 
+def shuffle_partition(keys: Column, num_partitions, row_base=0, narrow=None):
+    """gdf_amd_shuffle_partition (include/gdf/gdf_amd_ext.h) -> (keys tensor, int32 row-number tensor, offsets list).
+    ``narrow=(lo, hi)`` ships int64 keys as their int32 ``gdf_amd_narrow_keys`` image."""
+    import torch
+    n = keys.size
+    out_k = Column(torch.empty(n, dtype=torch.int32 if narrow else keys.data.dtype, device=keys.data.device))
+    out_r = Column(torch.empty(n, dtype=torch.int32, device=keys.data.device))
+    offsets = (C.c_int * num_partitions)()
+    lo, hi = narrow if narrow else (0, 0)
+    libgdf.gdf_amd_shuffle_partition(keys.ptr, 1 if narrow else 0, int(lo), int(hi), int(row_base), num_partitions,
+                                     out_k.ptr, out_r.ptr, offsets)
+    return out_k.data, out_r.data, list(offsets)
+
+
+class JoinBuild:
+    """gdf_amd_join_build_* (include/gdf/gdf_amd_ext.h): the build relation partitioned once, probed many times."""
+
+    def __init__(self, build):
+        self._cols = list(build)                                   # the library reads the build DATA on every probe
+        self._h = C.c_void_p()
+        libgdf.gdf_amd_join_build_create(column_array(self._cols), len(self._cols), C.byref(self._h))
+
+    def probe(self, probe, how="inner", copy=True):
+        """-> (probe_idx, build_idx): what ``join(probe, build, how=how)`` returns with the table on ``build``."""
+        import torch
+        li, ri = gdf_column(), gdf_column()
+        pa = column_array(probe)
+        libgdf.gdf_amd_join_build_probe(self._h, {"inner": 0, "left": 1}[how], pa, len(probe), C.byref(li), C.byref(ri))
+        if not copy:
+            return LibraryIndexColumn(li), LibraryIndexColumn(ri)
+        return _take_library_column(li, torch.int32), _take_library_column(ri, torch.int32)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            libgdf.gdf_amd_join_build_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+
 def prefixsum(col: Column, inclusive=True):
     import torch
     out = Column(torch.empty_like(col.data), None, col.c.dtype, size=col.size)

@@ -358,6 +358,84 @@ __global__ __launch_bounds__(HP_THREADS) void narrow_keys_kernel(const long long
   }
 }
 
+// gdf_amd_shuffle_partition (include/gdf/gdf_amd_ext.h): the sender side of the multi-GPU shuffle.  Same two passes and the
+// same chunk / offsets layout as the FAST hash partition above, but the key is narrowed on the fly (KOUT narrower than
+// KIN: the gdf_amd_narrow_keys image) and the travelling payload is the row NUMBER, which needs no input column:
+// 8 B read per row in the histogram, 8 B read + 8 B written in the scatter, instead of narrow (12 B) + row-number
+// column (4 B) + gdf_hash_partition over two 4-byte columns (4 B + 16 B).
+template <class KIN, class KOUT>
+__device__ __forceinline__ KOUT shuffle_key(KIN raw, long long lo, unsigned long long span) {
+  if constexpr (sizeof(KOUT) < sizeof(KIN)) {
+    const unsigned long long off = (unsigned long long)((long long)raw - lo);
+    return off <= span ? (KOUT)off : (KOUT)0xffffffffu;
+  } else {
+    return (KOUT)raw;
+  }
+}
+
+template <class KIN, class KOUT>
+__global__ __launch_bounds__(HP_THREADS) void shuffle_hist_kernel(const KIN *__restrict__ key, long long lo, unsigned long long span,
+                                                                   int64_t n, int64_t chunk, int nchunks, uint32_t nparts,
+                                                                   uint32_t pow2mask, uint32_t *__restrict__ hist) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_cnt[];
+  for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    for (uint32_t p = threadIdx.x; p < nparts; p += HP_THREADS) lds_cnt[p] = 0;
+    block_sync();
+    const int64_t begin = (int64_t)c * chunk;
+    const int64_t end = begin + chunk < n ? begin + chunk : n;
+    for (int64_t base = begin; base < end; base += HP_THREADS * HP_BATCH) {
+      KIN k[HP_BATCH];
+#pragma unroll
+      for (int j = 0; j < HP_BATCH; ++j) {
+        const int64_t i = base + (int64_t)j * HP_THREADS + threadIdx.x;
+        k[j] = key[i < end ? i : end - 1];
+      }
+#pragma unroll
+      for (int j = 0; j < HP_BATCH; ++j)
+        if (base + (int64_t)j * HP_THREADS + threadIdx.x < end) {
+          const KOUT kk = shuffle_key<KIN, KOUT>(k[j], lo, span);
+          atomicAdd(&lds_cnt[part_of(murmur3_32((uint64_t)kk, (int)sizeof(KOUT)), nparts, pow2mask)], 1u);
+        }
+    }
+    block_sync();
+    for (uint32_t p = threadIdx.x; p < nparts; p += HP_THREADS) hist[(size_t)p * nchunks + c] = lds_cnt[p];
+    block_sync();
+  }
+}
+
+template <class KIN, class KOUT>
+__global__ __launch_bounds__(HP_THREADS) void shuffle_scatter_kernel(const KIN *__restrict__ key, long long lo, unsigned long long span,
+                                                                      int32_t row_base, int64_t n, int64_t chunk, int nchunks,
+                                                                      uint32_t nparts, uint32_t pow2mask, const uint32_t *__restrict__ offs,
+                                                                      KOUT *__restrict__ out_key, int32_t *__restrict__ out_row) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_cur[];
+  for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    for (uint32_t p = threadIdx.x; p < nparts; p += HP_THREADS) lds_cur[p] = offs[(size_t)p * nchunks + c];
+    block_sync();
+    const int64_t begin = (int64_t)c * chunk;
+    const int64_t end = begin + chunk < n ? begin + chunk : n;
+    for (int64_t base = begin; base < end; base += HP_THREADS * HP_BATCH) {
+      KIN k[HP_BATCH];
+#pragma unroll
+      for (int j = 0; j < HP_BATCH; ++j) {
+        const int64_t i = base + (int64_t)j * HP_THREADS + threadIdx.x;
+        k[j] = key[i < end ? i : end - 1];
+      }
+#pragma unroll
+      for (int j = 0; j < HP_BATCH; ++j) {
+        const int64_t i = base + (int64_t)j * HP_THREADS + threadIdx.x;
+        if (i < end) {
+          const KOUT kk = shuffle_key<KIN, KOUT>(k[j], lo, span);
+          const uint32_t dst = atomicAdd(&lds_cur[part_of(murmur3_32((uint64_t)kk, (int)sizeof(KOUT)), nparts, pow2mask)], 1u);
+          out_key[dst] = kk;
+          out_row[dst] = row_base + (int32_t)i;
+        }
+      }
+    }
+    block_sync();
+  }
+}
+
 // gpu_hash_columns (src/hashops.cu:25-151): 64-bit FNV-1a over the little-endian bytes of every column's element,
 // columns in order.  The reference XORs each byte as a (signed) `char`, so a byte >= 0x80 is sign-extended to 64
 // bits before the XOR (hashops.cu:46-75) -- kept, it is what callers of the reference see.
@@ -458,6 +536,63 @@ gdf_error gdf_amd_narrow_keys(gdf_column *in, int64_t lo, int64_t hi, gdf_column
   GDF_LAUNCH("narrow_keys", narrow_keys_kernel, dim3(stream_grid((size_t)n, HP_THREADS * 8 * 4)), dim3(HP_THREADS), 0, stream0(),
              (const long long *)in->data, (long long)lo, (unsigned long long)((uint64_t)hi - (uint64_t)lo), (int32_t *)out->data, n);
   HIP_CHECK_LAST();
+  HIP_TRY(hipStreamSynchronize(stream0()));
+  return GDF_SUCCESS;
+}
+
+gdf_error gdf_amd_shuffle_partition(gdf_column *keys, int narrow, int64_t lo, int64_t hi, int32_t row_base, int num_partitions,
+                                    gdf_column *out_keys, gdf_column *out_rows, int partition_offsets[]) {
+  GDF_REQUIRE(keys && out_keys && out_rows && partition_offsets, GDF_DATASET_EMPTY);
+  GDF_REQUIRE(num_partitions > 0 && num_partitions <= HP_MAX_LDS_PARTS, GDF_INVALID_API_CALL);
+  GDF_REQUIRE(!keys->valid && !out_keys->valid && !out_rows->valid, GDF_VALIDITY_UNSUPPORTED);
+  const int win = dtype_width(keys->dtype), wout = dtype_width(out_keys->dtype);
+  GDF_REQUIRE((win == 8 || win == 4) && elem_kind(keys->dtype) != K_F32 && elem_kind(keys->dtype) != K_F64, GDF_UNSUPPORTED_DTYPE);
+  if (narrow) {
+    GDF_REQUIRE(elem_kind(keys->dtype) == K_I64 && out_keys->dtype == GDF_INT32, GDF_UNSUPPORTED_DTYPE);
+    GDF_REQUIRE(hi >= lo && (uint64_t)hi - (uint64_t)lo < 0x7fffffffULL, GDF_INVALID_API_CALL);
+  } else {
+    GDF_REQUIRE(out_keys->dtype == keys->dtype, GDF_PARTITION_DTYPE_MISMATCH);
+  }
+  GDF_REQUIRE(out_rows->dtype == GDF_INT32, GDF_UNSUPPORTED_DTYPE);
+  GDF_REQUIRE(keys->size == out_keys->size && keys->size == out_rows->size, GDF_COLUMN_SIZE_MISMATCH);
+  const size_t num_rows = keys->size;
+  GDF_REQUIRE(num_rows < (size_t)INT_MAX && (int64_t)row_base + (int64_t)num_rows <= (int64_t)INT_MAX, GDF_COLUMN_SIZE_TOO_BIG);
+  const uint32_t P = (uint32_t)num_partitions;
+  if (num_rows == 0) {
+    for (uint32_t p = 0; p < P; ++p) partition_offsets[p] = 0;
+    return GDF_SUCCESS;
+  }
+  GDF_REQUIRE(keys->data && out_keys->data && out_rows->data, GDF_DATASET_EMPTY);
+  (void)wout;
+
+  const int64_t n = (int64_t)num_rows;
+  const uint32_t pow2mask = (P & (P - 1)) == 0 ? P - 1 : 0;
+  int64_t chunk = (n + HP_MAX_CHUNKS - 1) / HP_MAX_CHUNKS;             // same chunking as gdf_hash_partition
+  chunk = ((chunk + HP_THREADS * 8 - 1) / (HP_THREADS * 8)) * (HP_THREADS * 8);
+  const int nchunks = (int)((n + chunk - 1) / chunk);
+  const size_t lds = sizeof(uint32_t) * P;
+  const int grid = nchunks < NUM_CU * 4 ? nchunks : NUM_CU * 4;
+  DevBuf hist, starts;
+  RMM_TRY(hist.alloc(sizeof(uint32_t) * (size_t)P * nchunks));
+  RMM_TRY(starts.alloc(sizeof(uint32_t) * P));
+  const long long llo = narrow ? (long long)lo : 0;
+  const unsigned long long span = narrow ? (unsigned long long)((uint64_t)hi - (uint64_t)lo) : 0;
+#define SHUFFLE_PASSES(KIN, KOUT)                                                                                                  \
+  GDF_LAUNCH("shuffle_hist", (shuffle_hist_kernel<KIN, KOUT>), dim3(grid), dim3(HP_THREADS), lds, stream0(), (const KIN *)keys->data, \
+             llo, span, n, chunk, nchunks, P, pow2mask, hist.as<uint32_t>());                                                       \
+  HIP_CHECK_LAST();                                                                                                                \
+  GDF_TRY(scan_u32(hist.as<uint32_t>(), hist.as<uint32_t>(), (size_t)P * nchunks, false));                                         \
+  hipLaunchKernelGGL(gather_strided_u32, dim3((P + 255) / 256), dim3(256), 0, stream0(), hist.as<uint32_t>(), starts.as<uint32_t>(), \
+                     (int)P, (size_t)nchunks);                                                                                     \
+  GDF_LAUNCH("shuffle_scatter", (shuffle_scatter_kernel<KIN, KOUT>), dim3(grid), dim3(HP_THREADS), lds, stream0(),                   \
+             (const KIN *)keys->data, llo, span, row_base, n, chunk, nchunks, P, pow2mask, hist.as<uint32_t>(),                      \
+             (KOUT *)out_keys->data, (int32_t *)out_rows->data);                                                                     \
+  HIP_CHECK_LAST();
+  if (narrow) { SHUFFLE_PASSES(uint64_t, uint32_t) }
+  else if (win == 8) { SHUFFLE_PASSES(uint64_t, uint64_t) }
+  else { SHUFFLE_PASSES(uint32_t, uint32_t) }
+#undef SHUFFLE_PASSES
+  HIP_TRY(hipMemcpyAsync(partition_offsets, starts.p, sizeof(int) * P, hipMemcpyDeviceToHost, stream0()));
   HIP_TRY(hipStreamSynchronize(stream0()));
   return GDF_SUCCESS;
 }

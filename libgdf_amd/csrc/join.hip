@@ -49,6 +49,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <memory>
 #include <vector>
 
 namespace gdf_amd {
@@ -1450,18 +1451,30 @@ struct StageClock {
   }
 };
 
-static gdf_error hash_join_core(const KeyTable &probe_t, const KeyTable &build_t, JoinKind kind, int32_t **out_probe,
-                                int32_t **out_build, int64_t *out_n) {
-  StageClock clk(getenv("GDF_JK_DBG") && (atoi(getenv("GDF_JK_DBG")) & 512));
-  KeyPlan plan = plan_keys(probe_t);
-  const PartGeom g = choose_geometry(build_t.nrows);
+// The build relation after partitioning: everything a probe pass needs besides the probe relation itself.  Made
+// once per gdf_*_join call, or once per gdf_amd_join_build (include/gdf/gdf_amd_ext.h) and probed many times.
+struct BuildSide {
+  KeyPlan plan;              // key format BOTH relations are brought into (the build side decides narrow / kmin)
+  PartGeom g;
+  SideBufs B;
+};
+
+static gdf_error prepare_build(const KeyTable &build_t, BuildSide *bs) {
+  bs->plan = plan_keys(build_t);           // a function of the key dtypes only: the probe relation has the same ones
+  bs->g = choose_geometry(build_t.nrows);
+  const bool range_candidate = !bs->plan.narrow && bs->plan.mode == KM_RAW_INT && build_t.col[0].width == 8;
+  return partition_side(build_t, bs->plan, bs->g, &bs->B, range_candidate);   // may switch plan to the narrow format
+}
+
+static gdf_error probe_prepared(const KeyTable &probe_t, const KeyTable &build_t, const BuildSide &bs, JoinKind kind,
+                                int32_t **out_probe, int32_t **out_build, int64_t *out_n, StageClock &clk) {
+  const KeyPlan &plan = bs.plan;
+  const PartGeom &g = bs.g;
+  const SideBufs &B = bs.B;
   const uint32_t nfine = 1u << g.fb;
   const bool keep_probe = kind != JOIN_INNER;
 
-  SideBufs B, P;
-  const bool range_candidate = !plan.narrow && plan.mode == KM_RAW_INT && build_t.col[0].width == 8;
-  GDF_TRY(partition_side(build_t, plan, g, &B, range_candidate));   // may switch plan to the narrow format
-  clk.mark("partition build side");
+  SideBufs P;
   // The probe side is the big one (C3: 10x the build side): it is partitioned WITHOUT a histogram pass
   // when the build partitions all fit LDS (the global-table path wants contiguous partition runs).
   uint32_t largest_build = 0;
@@ -1472,7 +1485,8 @@ static gdf_error hash_join_core(const KeyTable &probe_t, const KeyTable &build_t
     GDF_TRY(partition_side_spec(probe_t, plan, g, std::max(1.0, (double)probe_t.nrows / std::max<uint32_t>(B.joinable, 1)), &P, &spec_ok));
   if (!spec_ok) {
     P.w[0].reset(); P.w[1].reset(); P.idx[0].reset(); P.idx[1].reset();
-    GDF_TRY(partition_side(probe_t, plan, g, &P, false));
+    KeyPlan probe_plan = plan;             // partition_side only rewrites the plan when asked to decide the format
+    GDF_TRY(partition_side(probe_t, probe_plan, g, &P, false));
   }
   const bool narrow = plan.narrow != 0;
   clk.mark("partition probe side");
@@ -1695,6 +1709,15 @@ static gdf_error hash_join_core(const KeyTable &probe_t, const KeyTable &build_t
   return GDF_SUCCESS;
 }
 
+static gdf_error hash_join_core(const KeyTable &probe_t, const KeyTable &build_t, JoinKind kind, int32_t **out_probe,
+                                int32_t **out_build, int64_t *out_n) {
+  StageClock clk(getenv("GDF_JK_DBG") && (atoi(getenv("GDF_JK_DBG")) & 512));
+  BuildSide bs;
+  GDF_TRY(prepare_build(build_t, &bs));
+  clk.mark("partition build side");
+  return probe_prepared(probe_t, build_t, bs, kind, out_probe, out_build, out_n, clk);
+}
+
 // FULL join with an empty side (joining.cu:214-280 trivial_full_join): every row of
 // the non-empty side paired with -1.
 static gdf_error trivial_full_join(int64_t left_rows, int64_t right_rows, gdf_column *left_result, gdf_column *right_result) {
@@ -1722,7 +1745,9 @@ static gdf_error join_call(JoinKind kind, int num_cols, gdf_column **leftcol, gd
   if (0 == left_size && 0 == right_size) return GDF_SUCCESS;
   if (kind == JOIN_LEFT && 0 == left_size) return GDF_SUCCESS;
   if (kind == JOIN_INNER && (0 == left_size || 0 == right_size)) return GDF_SUCCESS;
-  if (kind == JOIN_FULL && (0 == left_size || 0 == right_size))
+  // LEFT with an empty right relation has no early return in the reference (joining.cu:304-323): every left row pairs
+  // with -1, which is the FULL join's answer too; no kernel here ever sees a zero-row relation (its data may be null)
+  if ((kind == JOIN_FULL && (0 == left_size || 0 == right_size)) || (kind == JOIN_LEFT && 0 == right_size))
     return trivial_full_join((int64_t)left_size, (int64_t)right_size, left_result, right_result);
   for (int i = 0; i < num_cols; ++i) {
     if (right_size > 0 && nullptr == rightcol[i]->data) return GDF_DATASET_EMPTY;
@@ -1956,6 +1981,71 @@ gdf_error debug_partition(gdf_column *col, int fb, uint64_t *out_key, int32_t *o
   return GDF_SUCCESS;
 }
 
+// ---------------------------------------------------------------------------
+// gdf_amd_join_build_* (include/gdf/gdf_amd_ext.h): partition the build relation once, probe it many times.
+// The multi-GPU join receives the probe relation in slices while the build relation is already complete.
+// ---------------------------------------------------------------------------
+struct PreparedBuild {
+  int ncols = 0;
+  gdf_column cols[MAX_KEY_COLS];        // copies of the caller's structs; the DATA stays the caller's and must outlive this
+  gdf_column *colp[MAX_KEY_COLS];
+  KeyTable table;
+  BuildSide side;
+  bool partitioned = false;             // false: empty build relation, probes take the generic entry point
+};
+
+static gdf_error build_create(gdf_column **build_cols, int num_cols, PreparedBuild **out) {
+  GDF_REQUIRE(build_cols && out && num_cols > 0, GDF_DATASET_EMPTY);
+  GDF_REQUIRE(num_cols <= MAX_KEY_COLS, GDF_JOIN_TOO_MANY_COLUMNS);
+  for (int i = 0; i < num_cols; ++i) {
+    GDF_REQUIRE(build_cols[i], GDF_DATASET_EMPTY);
+    GDF_REQUIRE(build_cols[i]->size == build_cols[0]->size, GDF_COLUMN_SIZE_MISMATCH);
+    GDF_REQUIRE(build_cols[i]->size == 0 || build_cols[i]->data, GDF_DATASET_EMPTY);
+  }
+  GDF_REQUIRE(build_cols[0]->size < (size_t)INT_MAX, GDF_COLUMN_SIZE_TOO_BIG);
+  std::unique_ptr<PreparedBuild> pb(new PreparedBuild());
+  pb->ncols = num_cols;
+  for (int i = 0; i < num_cols; ++i) { pb->cols[i] = *build_cols[i]; pb->colp[i] = &pb->cols[i]; }
+  if (build_cols[0]->size > 0) {
+    GDF_TRY(make_key_table(pb->colp, num_cols, &pb->table));
+    GDF_TRY(prepare_build(pb->table, &pb->side));
+    HIP_TRY(hipStreamSynchronize(stream0()));
+    pb->partitioned = true;
+  }
+  *out = pb.release();
+  return GDF_SUCCESS;
+}
+
+static gdf_error build_probe(PreparedBuild *pb, int left_join, gdf_column **probe_cols, int num_cols, gdf_column *probe_indices,
+                             gdf_column *build_indices) {
+  GDF_REQUIRE(pb && probe_cols && probe_indices && build_indices, GDF_DATASET_EMPTY);
+  GDF_REQUIRE(num_cols == pb->ncols, GDF_JOIN_DTYPE_MISMATCH);
+  const JoinKind kind = left_join ? JOIN_LEFT : JOIN_INNER;
+  const size_t probe_size = probe_cols[0] ? probe_cols[0]->size : 0;
+  if (!pb->partitioned || probe_size == 0) {      // an empty side: nothing to reuse, same results as gdf_{inner,left}_join
+    gdf_context ctx{0, GDF_HASH, 0, 0, 0};
+    return join_call(kind, num_cols, probe_cols, pb->colp, probe_indices, build_indices, &ctx);
+  }
+  GDF_REQUIRE(probe_size < (size_t)INT_MAX, GDF_COLUMN_SIZE_TOO_BIG);
+  for (int i = 0; i < num_cols; ++i) {
+    GDF_REQUIRE(probe_cols[i] && probe_cols[i]->data, GDF_DATASET_EMPTY);
+    GDF_REQUIRE(probe_cols[i]->dtype == pb->cols[i].dtype, GDF_JOIN_DTYPE_MISMATCH);
+    GDF_REQUIRE(probe_cols[i]->size == probe_size, GDF_COLUMN_SIZE_MISMATCH);
+  }
+  KeyTable pt;
+  GDF_TRY(make_key_table(probe_cols, num_cols, &pt));
+  gdf_column_view(probe_indices, nullptr, nullptr, 0, N_GDF_TYPES);
+  gdf_column_view(build_indices, nullptr, nullptr, 0, N_GDF_TYPES);
+  StageClock clk(getenv("GDF_JK_DBG") && (atoi(getenv("GDF_JK_DBG")) & 512));
+  int32_t *o_probe = nullptr, *o_build = nullptr;
+  int64_t n = 0;
+  GDF_TRY(probe_prepared(pt, pb->table, pb->side, kind, &o_probe, &o_build, &n, clk));
+  if (n == 0) return GDF_SUCCESS;
+  gdf_column_view(probe_indices, o_probe, nullptr, (gdf_size_type)n, GDF_INT32);
+  gdf_column_view(build_indices, o_build, nullptr, (gdf_size_type)n, GDF_INT32);
+  return GDF_SUCCESS;
+}
+
 }  // namespace gdf_amd
 
 using namespace gdf_amd;
@@ -1967,6 +2057,18 @@ __attribute__((visibility("default"))) gdf_error gdf_amd_debug_partition(gdf_col
                                                                         uint32_t *out_fine_off, uint32_t *out_joinable,
                                                                         uint64_t *out_info) {
   return debug_partition(col, fb, out_key, out_idx, out_fine_off, out_joinable, out_info);
+}
+
+// non-reference exports (include/gdf/gdf_amd_ext.h): a build relation partitioned once and probed many times
+__attribute__((visibility("default"))) gdf_error gdf_amd_join_build_create(gdf_column **build_cols, int num_cols, gdf_amd_join_build **out) {
+  return build_create(build_cols, num_cols, reinterpret_cast<PreparedBuild **>(out));
+}
+__attribute__((visibility("default"))) gdf_error gdf_amd_join_build_probe(gdf_amd_join_build *build, int left_join, gdf_column **probe_cols,
+                                                                         int num_cols, gdf_column *probe_indices, gdf_column *build_indices) {
+  return build_probe(reinterpret_cast<PreparedBuild *>(build), left_join, probe_cols, num_cols, probe_indices, build_indices);
+}
+__attribute__((visibility("default"))) void gdf_amd_join_build_free(gdf_amd_join_build *build) {
+  delete reinterpret_cast<PreparedBuild *>(build);
 }
 
 gdf_error gdf_inner_join(gdf_column **left_cols, int num_left_cols, int left_join_cols[], gdf_column **right_cols,

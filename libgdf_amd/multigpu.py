@@ -3,24 +3,28 @@
 The reference is single-GPU (no NCCL/MPI anywhere), so this layer has no
 counterpart there; it sits ABOVE the unchanged per-GPU ``gdf_*`` C ABI:
 
-  0. 8-byte keys whose global build-side range fits 31 bits are narrowed to 4 bytes (``gdf_amd_narrow_keys``;
+  0. 8-byte keys whose global build-side range fits 31 bits travel as 4 bytes (the ``gdf_amd_narrow_keys`` image;
      one all-reduce of the build min / max decides);
-  1. every rank hash-partitions each relation on the join key into ``world`` partitions with the public
-     ``gdf_hash_partition`` (Murmur3 & (P-1) / % P) -- a different hash from the mix64 the local join
-     partitions on, so rank placement and local partitioning are uncorrelated.  The payload that travels
-     with a key is its 4-byte LOCAL row number; the owner rank is implied by the segment it arrives in;
+  1. every rank hash-partitions each relation on the join key into ``world`` partitions, placed exactly as the
+     public ``gdf_hash_partition`` places them (Murmur3 & (P-1) / % P) -- a different hash from the one the local
+     join partitions on, so rank placement and local partitioning are uncorrelated.  The payload that travels
+     with a key is its 4-byte LOCAL row number; the owner rank is implied by the segment it arrives in.
+     Narrowing, row numbering and partitioning are ONE pass pair over the raw keys (``gdf_amd_shuffle_partition``);
   2. the ``world x world`` send-count matrix is exchanged (one tiny all-to-all);
   3. one ``all_to_all_single`` per column moves partition r to rank r (xGMI is point-to-point, an
      all-to-all drives all 7 links of a GPU at once, so each column goes out as ONE large collective);
-  4. every rank joins what it received with ``gdf_inner_join``.  The result is a :class:`ShardedPairs`:
+  4. every rank joins what it received: the received build relation is partitioned once
+     (``gdf_amd_join_build_create``) and probed by every received probe slice; the pairs are those of
+     ``gdf_inner_join``.  The result is a :class:`ShardedPairs`:
      index pairs into the RECEIVED tables plus what is needed to name the original rows
      (``(owner rank, local row)``), resolved lazily -- an 8-byte global id per output row would double the
      output traffic of the timed path;
   5. the probe relation goes through steps 1-4 in slices, software-pipelined: the all-to-all of slice c runs
      on RCCL's stream while slice c+1 is partitioned and slice c-1 is joined on the library's stream.
 
-``partition_fn`` / ``join_fn`` are injectable so the exchange logic is testable on CPU with the gloo
-backend (tests/test_multigpu_gloo.py): there they are numpy oracle functions, here the C ABI.
+``shuffle_fn`` / ``prepare_fn`` / ``join_fn`` (and ``partition_fn`` of the group-by) are injectable so the exchange
+logic is testable on CPU with the gloo backend (tests/test_multigpu_gloo.py): there they are numpy oracle functions,
+here the C ABI.
 
 Not done yet: fusing the rank split into the join's own radix partitioning (the
 receiver would continue from 8-byte packed tuples instead of re-reading raw keys).
@@ -36,38 +40,46 @@ def _device_partition(keys, payload, world):
     return outs[0].data, outs[1].data, offsets
 
 
-def _device_inner_join(probe_keys, build_keys):
+def _device_shuffle(keys, row_base, world, narrow):
+    """gdf_amd_shuffle_partition: (keys [narrowed to int32 when narrow=(lo, hi)], int32 row numbers from row_base,
+    offsets list), partitioned on the key as gdf_hash_partition would place them."""
     from . import api
+    from .columns import Column
+    return api.shuffle_partition(Column(keys), world, row_base=row_base, narrow=narrow)
+
+
+def _device_prepare(build_keys):
+    """The received build relation, partitioned once (gdf_amd_join_build_create)."""
+    from . import api
+    from .columns import Column
+    return api.JoinBuild([Column(build_keys)])
+
+
+def _device_inner_join(probe_keys, build):
     from .columns import Column
     # the pairs stay in the library's buffers until somebody asks for them (ShardedPairs.global_ids): copying 8 B per
     # output row into torch tensors would add a quarter to the local HBM traffic of a slice join
-    return api.join([Column(probe_keys)], [Column(build_keys)], how="inner", copy=False)
+    return build.probe([Column(probe_keys)], how="inner", copy=False)
 
 
 def _device_narrow(keys, lo, hi):
     """gdf_amd_narrow_keys: int64 keys -> int32 (key - lo), -1 outside [lo, hi]."""
-    import ctypes as C
     import torch
-    from ._binding import _gdf_cdll
+    from ._binding import libgdf
     from .columns import Column
     out = torch.empty(keys.numel(), dtype=torch.int32, device=keys.device)
-    fn = _gdf_cdll.gdf_amd_narrow_keys
-    fn.restype = C.c_int
-    fn.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
     cin, cout = Column(keys), Column(out)                              # keep the structs alive across the call
-    rc = fn(C.addressof(cin.c), lo, hi, C.addressof(cout.c))
-    if rc != 0:
-        raise RuntimeError(f"gdf_amd_narrow_keys failed with {rc}")
+    libgdf.gdf_amd_narrow_keys(cin.ptr, int(lo), int(hi), cout.ptr)
     return out
 
 
-def _narrow_if_possible(probe_keys, build_keys, narrow_fn, group):
-    """8-byte keys whose GLOBAL build-side range fits 31 bits travel and join as 4-byte keys (a third less to
-    partition, ship and re-read).  Probe keys outside that range cannot match any build key and become -1."""
+def _narrow_range(probe_keys, build_keys, group):
+    """(lo, hi) when 8-byte keys can travel and join as 4-byte ones (a third less to ship and re-read): the GLOBAL
+    build-side range fits 31 bits.  Probe keys outside it cannot match any build key and become -1.  Else None."""
     import torch
     import torch.distributed as dist
-    if probe_keys.dtype != torch.int64 or build_keys.dtype != torch.int64 or narrow_fn is None:
-        return probe_keys, build_keys
+    if probe_keys.dtype != torch.int64 or build_keys.dtype != torch.int64:
+        return None
     big = torch.iinfo(torch.int64).max
     if build_keys.numel():
         lo, hi = torch.aminmax(build_keys)
@@ -77,8 +89,8 @@ def _narrow_if_possible(probe_keys, build_keys, narrow_fn, group):
     dist.all_reduce(mm, op=dist.ReduceOp.MIN, group=group)            # [global min, -(global max)]
     lo, hi = int(mm[0]), -int(mm[1])
     if lo > hi or hi - lo >= (1 << 31) - 1:
-        return probe_keys, build_keys
-    return narrow_fn(probe_keys, lo, hi), narrow_fn(build_keys, lo, hi)
+        return None
+    return lo, hi
 
 
 class Received:
@@ -159,12 +171,13 @@ class _Exchange:
     """One relation (or one chunk of it) on its way to its owner ranks: the partitioned send buffers, the receive
     buffers and the in-flight collectives.  ``finish()`` waits for them and returns the :class:`Received`."""
 
-    def __init__(self, keys, payload, partition_fn, group, async_op):
+    def __init__(self, partitioned, group, async_op):
         import torch
         import torch.distributed as dist
         world = dist.get_world_size(group)
-        pk, pp, offsets = partition_fn(keys, payload, world)
-        n = keys.numel()
+        pk, pp, offsets = partitioned                                          # partition r = rows offsets[r]:offsets[r+1]
+        keys, payload = pk, pp
+        n = pk.numel()
         bounds = list(offsets) + [n]
         send_counts = torch.tensor([bounds[r + 1] - bounds[r] for r in range(world)], dtype=torch.int64, device=keys.device)
         recv_counts = torch.empty_like(send_counts)
@@ -191,12 +204,13 @@ class _Exchange:
 
 def exchange_by_key(keys, payload, partition_fn=_device_partition, group=None):
     """Send every (key, payload) row to rank ``hash(key) mod world``.  Returns (keys, payload, bounds)."""
-    r = _Exchange(keys, payload, partition_fn, group, async_op=False).finish()
+    import torch.distributed as dist
+    r = _Exchange(partition_fn(keys, payload, dist.get_world_size(group)), group, async_op=False).finish()
     return r.keys, r.rows, r.bounds
 
 
-def distributed_inner_join(probe_keys, build_keys, partition_fn=_device_partition, join_fn=_device_inner_join, group=None,
-                           chunks=4, narrow_fn=_device_narrow):
+def distributed_inner_join(probe_keys, build_keys, shuffle_fn=_device_shuffle, join_fn=_device_inner_join, group=None,
+                           chunks=4, prepare_fn=_device_prepare):
     """Inner join of two row-sharded relations on one integer key column.
 
     Every rank passes its shard of both relations and gets back a :class:`ShardedPairs` with its share of
@@ -206,32 +220,36 @@ def distributed_inner_join(probe_keys, build_keys, partition_fn=_device_partitio
     RCCL's own stream), slice c+1 is being hash-partitioned and slice c-1 joined against the received build
     relation on the library's stream, so that the exchange hides behind the local HBM passes instead of adding
     to them.
+
+    ``shuffle_fn(keys, row_base, world, narrow)`` -> (partitioned keys, their row numbers, offsets);
+    ``prepare_fn(build_keys)`` -> whatever ``join_fn(probe_keys, prepared)`` takes as its build side (None: the keys).
     """
-    import torch
-    dev = probe_keys.device
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
     n = probe_keys.numel()
-    probe_keys, build_keys = _narrow_if_possible(probe_keys, build_keys, narrow_fn, group)
-    build_rows = torch.arange(build_keys.numel(), dtype=torch.int32, device=dev)
-    build_x = _Exchange(build_keys, build_rows, partition_fn, group, async_op=True)
+    narrow = _narrow_range(probe_keys, build_keys, group)
+    build_x = _Exchange(shuffle_fn(build_keys, 0, world, narrow), group, async_op=True)
     chunks = max(1, min(int(chunks), n)) if n else 1
     step = (n + chunks - 1) // chunks if n else 0
-    build = None
+    build = prepared = None
     probes, ppos, bpos = [], [], []
     pending = None
     for c in range(chunks):
         lo, hi = c * step, min(n, (c + 1) * step)
-        rows = torch.arange(lo, hi, dtype=torch.int32, device=dev)
-        x = _Exchange(probe_keys[lo:hi], rows, partition_fn, group, async_op=True)     # partition c, then start moving it
+        x = _Exchange(shuffle_fn(probe_keys[lo:hi], lo, world, narrow), group, async_op=True)   # partition c, then start moving it
         if build is None:
             build = build_x.finish()
+            prepared = prepare_fn(build.keys) if prepare_fn is not None else build.keys
         if pending is not None:                                                       # join c-1 while c moves
             r = pending.finish()
-            li, ri = join_fn(r.keys, build.keys)
+            li, ri = join_fn(r.keys, prepared)
             probes.append(r); ppos.append(li); bpos.append(ri)
         pending = x
     r = pending.finish()
-    li, ri = join_fn(r.keys, build.keys)
+    li, ri = join_fn(r.keys, prepared)
     probes.append(r); ppos.append(li); bpos.append(ri)
+    if hasattr(prepared, "close"):
+        prepared.close()
     return ShardedPairs(probes, build, ppos, bpos)
 
 

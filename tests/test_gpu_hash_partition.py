@@ -131,8 +131,48 @@ def test_narrow_keys_extension(gdf):
     out = multigpu._device_narrow(k, lo, hi)
     exp = torch.where((k >= lo) & (k <= hi), k - lo, torch.full_like(k, -1)).to(torch.int32)
     assert out.dtype == torch.int32 and torch.equal(out, exp)
-    with pytest.raises(RuntimeError):
+    from libgdf_amd import GDFError
+    with pytest.raises(GDFError, match="GDF_INVALID_API_CALL"):
         multigpu._device_narrow(k, 0, 1 << 40)                       # range too wide for 31 bits
+
+
+@pytest.mark.parametrize("nparts", [1, 2, 7, 8, 64])
+@pytest.mark.parametrize("mode", ["narrow", "int64", "int32"])
+@pytest.mark.parametrize("n", [0, 1, 5000, 700_003])
+def test_shuffle_partition_extension(gdf, nparts, mode, n):
+    """gdf_amd_shuffle_partition == narrow + row numbers + gdf_hash_partition(MURMUR3) of the oracle: same offsets, same
+    (key, row) multiset in every partition."""
+    from libgdf_amd import Column
+    import torch
+    base = 1 << 41 if mode != "int32" else 0
+    k = (np.random.randint(-300, 4000, size=n) + base).astype(np.int32 if mode == "int32" else np.int64)
+    narrow = (base, base + 3500) if mode == "narrow" else None
+    row_base = 123456
+    pk, pr, off = gdf.api.shuffle_partition(Column(torch.from_numpy(k).cuda()), nparts, row_base=row_base, narrow=narrow)
+    kk = np.where((k >= narrow[0]) & (k <= narrow[1]), k - narrow[0], -1).astype(np.int32) if narrow else k
+    perm, eoff, _ = oracle.hash_partition([kk], [0], nparts)
+    assert off == [int(o) for o in eoff]
+    pk, pr = pk.cpu().numpy(), pr.cpu().numpy()
+    assert pk.dtype == kk.dtype and pr.dtype == np.int32
+    bounds = list(off) + [n]
+    for p in range(nparts):
+        a, b = bounds[p], bounds[p + 1]
+        rows = np.sort(pr[a:b])
+        np.testing.assert_array_equal(rows, np.sort(perm[a:b]) + row_base)
+    if n:
+        np.testing.assert_array_equal(kk[pr - row_base], pk)          # every key travels with ITS row number
+
+
+def test_shuffle_partition_errors(gdf):
+    import torch
+    from libgdf_amd import Column, GDFError
+    k = Column(torch.zeros(10, dtype=torch.int64, device="cuda"))
+    with pytest.raises(GDFError, match="GDF_INVALID_API_CALL"):
+        gdf.api.shuffle_partition(k, 4, narrow=(0, 1 << 40))           # range too wide for 31 bits
+    with pytest.raises(GDFError, match="GDF_COLUMN_SIZE_TOO_BIG"):
+        gdf.api.shuffle_partition(k, 4, row_base=2**31 - 5)            # row numbers must stay int32
+    with pytest.raises(GDFError, match="GDF_UNSUPPORTED_DTYPE"):
+        gdf.api.shuffle_partition(Column(torch.zeros(10, dtype=torch.float64, device="cuda")), 4)
 
 
 @pytest.mark.parametrize("dtypes", [[np.int8], [np.int64], [np.int32, np.float64, np.int16], [np.float32, np.int8, np.int64, np.int64]],

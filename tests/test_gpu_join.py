@@ -257,6 +257,51 @@ def test_multigpu_layer_world_size_one(gdf):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("how", ["inner", "left"])
+@pytest.mark.parametrize("dtypes", [[np.int64], [np.int32], [np.float64], [np.int32, np.int64, np.int16]],
+                         ids=lambda d: "-".join(np.dtype(x).name for x in d))
+def test_prepared_build_probed_in_slices(gdf, how, dtypes):
+    """gdf_amd_join_build_* (include/gdf/gdf_amd_ext.h): one partitioned build relation probed by several probe
+    relations gives, for each, exactly the pairs of gdf_{inner,left}_join(probe, build)."""
+    rng = 3000 if len(dtypes) == 1 else 12
+    build = _gen(dtypes, 20000, rng)
+    jb = gdf.api.JoinBuild(_cols(build))
+    for n in (0, 1, 777, 50000):
+        probe = _gen(dtypes, n, rng * 2 if len(dtypes) == 1 else rng)
+        li, ri = jb.probe(_cols(probe), how=how)
+        el, er = oracle.join(probe, build, how)
+        a, b = sort_pairs(li.cpu().numpy(), ri.cpu().numpy())
+        c, d = sort_pairs(el, er)
+        np.testing.assert_array_equal(a, c)
+        np.testing.assert_array_equal(b, d)
+    jb.close()
+
+
+def test_prepared_build_edge_cases(gdf, monkeypatch):
+    import torch
+    from libgdf_amd import Column, GDFError
+    empty = gdf.api.JoinBuild(_cols([np.zeros(0, dtype=np.int64)]))
+    li, ri = empty.probe(_cols([np.arange(5, dtype=np.int64)]), how="inner")
+    assert li.numel() == 0 and ri.numel() == 0
+    li, ri = empty.probe(_cols([np.arange(5, dtype=np.int64)]), how="left")
+    assert sorted(li.cpu().tolist()) == [0, 1, 2, 3, 4] and ri.cpu().tolist() == [-1] * 5
+    jb = gdf.api.JoinBuild(_cols([np.arange(100, dtype=np.int64)]))
+    with pytest.raises(GDFError, match="GDF_JOIN_DTYPE_MISMATCH"):
+        jb.probe(_cols([np.arange(5, dtype=np.int32)]))
+    # a probe relation larger than the build relation keeps the table on the prepared side, at speculative-partition size
+    monkeypatch.setenv("GDF_JK_SPEC_MIN", "1000")
+    build = torch.randperm(3_000_000, dtype=torch.int64, device="cuda")[:2_000_000]
+    jb2 = gdf.api.JoinBuild([Column(build)])
+    for seed in range(2):
+        probe = torch.randint(0, 3_000_000, (5_000_000,), dtype=torch.int64, device="cuda")
+        li, ri = jb2.probe([Column(probe)])
+        present = torch.zeros(3_000_000, dtype=torch.bool, device="cuda")
+        present[build] = True
+        assert li.numel() == int(present[probe].sum().item())
+        assert torch.equal(build[ri.long()], probe[li.long()])
+        assert torch.unique(li).numel() == li.numel()
+
+
 def test_every_partition_oversize_uses_one_global_table(gdf):
     """A build side beyond 32768 x 6144 rows makes EVERY fine partition exceed the LDS image: the global-table
     path must handle them as one run (one table, three launches), not one launch per partition."""

@@ -37,6 +37,13 @@ def _np_narrow(keys, lo, hi):
     return torch.from_numpy(np.where((k >= lo) & (k <= hi), k - lo, -1).astype(np.int32))
 
 
+def _np_shuffle(keys, row_base, world, narrow):
+    """What gdf_amd_shuffle_partition computes: narrow, number the rows from row_base, partition on Murmur3(key)."""
+    k = _np_narrow(keys, *narrow) if narrow else keys
+    rows = torch.arange(row_base, row_base + k.numel(), dtype=torch.int32)
+    return _np_partition(k, rows, world)
+
+
 def _np_group_sum(k, v):
     keys, agg = oracle.group_by("sum", [k.numpy()], v.numpy())
     return torch.from_numpy(keys[0].copy()), torch.from_numpy(agg.copy())
@@ -58,7 +65,7 @@ def _worker(rank, world, port, q):
     multigpu._MAX_MESSAGE_BYTES = 1024          # force the multi-piece send / recv path (production: 2^29 bytes)
     probes, builds = _shards(world)
     pairs = multigpu.distributed_inner_join(torch.from_numpy(probes[rank]), torch.from_numpy(builds[rank]),
-                                            partition_fn=_np_partition, join_fn=_np_join, narrow_fn=_np_narrow)
+                                            shuffle_fn=_np_shuffle, join_fn=_np_join, prepare_fn=None)
     pg, bg = pairs.global_ids()
     assert pairs.numel() == pg.numel()
     k = torch.from_numpy(probes[rank])

@@ -30,12 +30,16 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
 # tb = bytes per (key, row) tuple: 8 when the keys fit 32 bits (C3/C4: key space <= 2^32), else 12.
 # lps = launches per step: jk_hist runs on the build side only (1 launch) when the probe side takes the
 # histogram-free layout, on both relations (2 launches) otherwise.
+# kb = bytes per key the join reads: 8 (C3: the caller's int64 column), 4 on the multi-GPU path (keys travel narrowed).
 KERNEL_BYTES = {
-    "jk_hist": lambda npr, nb, tb, lps: 8.0 * nb + (8.0 * npr if lps > 1.5 else 0.0),   # reads every key once
-    "jk_scatter1": lambda npr, nb, tb, lps: (8.0 + tb) * (npr + nb),        # key in, tuple out
-    "jk_scatter2": lambda npr, nb, tb, lps: (tb + tb) * (npr + nb),         # tuple in, tuple out
-    "jk_probe_count": lambda npr, nb, tb, lps: tb * (npr + nb),             # tuples in
-    "jk_probe_write": lambda npr, nb, tb, lps: tb * (npr + nb) + 8.0 * npr, # tuples in, one int32 index pair per probe row out
+    "jk_hist": lambda npr, nb, tb, lps, kb: kb * nb + (kb * npr if lps > 1.5 else 0.0),   # reads every key once
+    "jk_scatter1": lambda npr, nb, tb, lps, kb: (kb + tb) * (npr + nb),         # key in, tuple out
+    "jk_scatter2": lambda npr, nb, tb, lps, kb: (tb + tb) * (npr + nb),         # tuple in, tuple out
+    "jk_probe_count": lambda npr, nb, tb, lps, kb: tb * (npr + nb),             # tuples in
+    "jk_probe_write": lambda npr, nb, tb, lps, kb: tb * (npr + nb) + 8.0 * npr, # tuples in, one int32 index pair per probe row out
+    # the sender side of the shuffle (multi-GPU only): int64 keys in; narrowed key + int32 row number out
+    "shuffle_hist": lambda npr, nb, tb, lps, kb: 8.0 * (npr + nb),
+    "shuffle_scatter": lambda npr, nb, tb, lps, kb: (8.0 + kb + 4.0) * (npr + nb),
 }
 
 
@@ -226,10 +230,11 @@ def main():
             fn = KERNEL_BYTES.get(name)
             if fn is not None:
                 tb = 8.0 if key_space < 2 ** 32 else 12.0
-                step_bytes = fn(float(npr), float(nb), tb, launches_per_step)
+                kb = 8.0 if not distributed else (4.0 if key_space < 2 ** 31 - 1 else 8.0)
+                step_bytes = fn(float(npr), float(nb), tb, launches_per_step, kb)
                 bytes_per_launch = step_bytes / launches_per_step
                 achieved = bytes_per_launch / (per_launch_ms * 1e-3) / 1e9
-                traffic, src = (pmc_traffic(name, launches_per_step) if (world == 1 and npr == 1_000_000_000) else (None, None))
+                traffic, src = (pmc_traffic(name, launches_per_step) if (not distributed and npr == 1_000_000_000) else (None, None))
                 roofline = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
                             "algorithmic_bytes_per_launch": bytes_per_launch,

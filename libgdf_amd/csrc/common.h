@@ -127,6 +127,31 @@ __device__ __forceinline__ int mask_rank(unsigned long long m) {
   return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
 }
 
+// match-any over the low `bits` bits of v: the live lanes of the wave that hold this lane's value (junk for a dead
+// lane).  Every lane of the wave must call it.
+__device__ __forceinline__ unsigned long long wave_match(uint32_t v, int bits, bool live) {
+  unsigned long long peers = __ballot(live);
+  for (int b = 0; b < bits; ++b) {
+    const bool bit = (v >> b) & 1;
+    const unsigned long long m = __ballot(bit);
+    peers &= bit ? m : ~m;
+  }
+  return peers;
+}
+
+// One LDS atomic per DISTINCT counter per wave instead of one per lane: `counter[idx] += 1` for every live lane;
+// returns the value a per-lane atomicAdd would have returned (lane order within the wave).  Few counters (a partition
+// fan-out of 2..16) make 64 lanes queue on the same LDS address otherwise.
+__device__ __forceinline__ uint32_t wave_aggregated_inc(uint32_t *counter, uint32_t idx, int bits, bool live) {
+  const unsigned long long peers = wave_match(idx, bits, live);
+  const int lane = lane_id();
+  const int leader = __ffsll((long long)peers) - 1;
+  uint32_t old = 0;
+  if (live && lane == leader) old = atomicAdd(&counter[idx], (uint32_t)__popcll(peers));
+  old = __shfl(old, live ? leader : lane);
+  return old + (uint32_t)mask_rank(peers);
+}
+
 template <class T>
 __device__ __forceinline__ T wave_reduce_add(T v) {
 #pragma unroll

@@ -50,6 +50,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <memory>
+#include <type_traits>
 #include <vector>
 
 namespace gdf_amd {
@@ -138,6 +139,15 @@ __device__ __forceinline__ bool make_key(const KeyTable &t, const KeyPlan &p, in
 template <int FAST>
 __device__ __forceinline__ uint64_t fast_word(const void *col, int64_t i) {
   return FAST == 4 ? (uint64_t)((const uint32_t *)col)[i] : ((const uint64_t *)col)[i];
+}
+// two consecutive key words with one load (8-byte keys: 16 bytes, 4-byte keys: 8 bytes); only the element alignment
+// is promised (a column may be a slice of a larger buffer)
+struct __attribute__((packed, aligned(8))) KeyPair8 { uint64_t a, b; };
+struct __attribute__((packed, aligned(4))) KeyPair4 { uint32_t a, b; };
+template <int FAST>
+__device__ __forceinline__ void fast_pair(const void *col, int64_t i, uint64_t &a, uint64_t &b) {
+  if (FAST == 4) { const KeyPair4 v = *(const KeyPair4 *)((const uint32_t *)col + i); a = v.a; b = v.b; }
+  else { const KeyPair8 v = *(const KeyPair8 *)((const uint64_t *)col + i); a = v.a; b = v.b; }
 }
 template <int FAST>
 __device__ __forceinline__ bool fetch_key(const KeyTable &t, const KeyPlan &p, int64_t i, uint64_t &key) {
@@ -242,7 +252,7 @@ __device__ __forceinline__ uint32_t hash_a(uint64_t raw_key) { return lowbias32(
 __device__ __forceinline__ uint32_t hash_b(uint64_t raw_key) { return lowbias32(key_fold(raw_key) ^ 0x68e31da4u); }
 
 __device__ __forceinline__ uint32_t fine_of(uint64_t raw_key, int fb) {
-  return fb ? hash_a(raw_key) >> (32 - fb) : 0u;
+  return (uint32_t)((uint64_t)hash_a(raw_key) >> (32 - fb));      // 64-bit shift: fb == 0 gives 0 without a branch
 }
 // slot of the global-table path (any table size)
 __device__ __forceinline__ uint32_t slot_of(uint64_t key, uint32_t nslots) {
@@ -314,9 +324,9 @@ __global__ __launch_bounds__(JK_HIST_THREADS) void jk_hist(KeyTable t, KeyPlan p
 // ---------------------------------------------------------------------------
 template <bool NARROW, int THREADS>
 struct TileLds {
-  uint64_t w[THREADS * JK_SC_ITEMS];
-  int32_t idx[NARROW ? 4 : THREADS * JK_SC_ITEMS];
-  uint32_t hist[256];
+  uint64_t w[THREADS * JK_SC_ITEMS + 2];                  // + a trash slot: tuples that do not travel are written there
+  int32_t idx[NARROW ? 4 : THREADS * JK_SC_ITEMS + 4];
+  uint32_t hist[256 + 4];                                 // + a trash counter, same reason (never zeroed, never read)
   uint32_t start[256];
   uint32_t gbase[256];    // (global base - start[bin]) mod 2^32; destinations are < 2^31
   uint32_t cursor[256];   // level 1: running global cursor of this chunk
@@ -326,19 +336,31 @@ struct TileLds {
 
 // block-wide exclusive scan of hist[0..nbins) (nbins <= 256 == blockDim) into start[]
 template <bool NARROW, int THREADS>
-__device__ __forceinline__ void tile_scan_bins(TileLds<NARROW, THREADS> &s, uint32_t nbins) {
-  const uint32_t v = threadIdx.x < nbins ? s.hist[threadIdx.x] : 0;
+__device__ __forceinline__ void tile_scan_bins(TileLds<NARROW, THREADS> &s, uint32_t nbins, uint32_t tid) {
+  const uint32_t v = tid < nbins ? s.hist[tid] : 0;
   const uint32_t incl = wave_scan_incl(v);
-  if (lane_id() == WAVE - 1) s.wave_tot[threadIdx.x / WAVE] = incl;
+  if (lane_id() == WAVE - 1) s.wave_tot[tid / WAVE] = incl;
   block_sync();
   uint32_t woff = 0, tot = 0;
 #pragma unroll
   for (int w = 0; w < THREADS / WAVE; ++w) {
-    if (w < (int)(threadIdx.x / WAVE)) woff += s.wave_tot[w];
+    if (w < (int)(tid / WAVE)) woff += s.wave_tot[w];
     tot += s.wave_tot[w];
   }
-  if (threadIdx.x < nbins) s.start[threadIdx.x] = woff + incl - v;
-  if (threadIdx.x == 0) s.total = tot;
+  if (tid < nbins) s.start[tid] = woff + incl - v;
+  if (tid == 0) s.total = tot;
+}
+template <bool NARROW, int THREADS>
+__device__ __forceinline__ void tile_scan_bins(TileLds<NARROW, THREADS> &s, uint32_t nbins) {
+  tile_scan_bins(s, nbins, threadIdx.x);
+}
+// threadIdx.x through an opaque move: addresses derived from the result cannot be hoisted out of the enclosing loop
+// (hipcc hoists a dozen per-thread LDS addresses out of jk_scatter1's tile loop and then spills them; every reload is
+// a scratch load, i.e. an s_waitcnt vmcnt(0) that also waits for the tile's stores)
+__device__ __forceinline__ uint32_t opaque_tid() {
+  uint32_t tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  return tid;
 }
 
 // phase C: write the regrouped tile out.  LEVEL1 bins are the coarse id, LEVEL2 the sub id.
@@ -385,76 +407,143 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
   const int chunk = blockIdx.x;
   const uint32_t ncoarse = 1u << g.b1;
   if (!g.cap1 && threadIdx.x < ncoarse) s.cursor[threadIdx.x] = H1off[(size_t)threadIdx.x * g.nchunks + chunk];
-  const int64_t begin = (int64_t)chunk * g.chunk;
-  const int64_t end = begin + g.chunk < t.nrows ? begin + g.chunk : t.nrows;
+  // row numbers are below 2^31 (positions are int32 in the ABI): 32-bit arithmetic throughout, half the registers
+  const uint32_t begin = (uint32_t)((int64_t)chunk * g.chunk);
+  const uint32_t end = (int64_t)begin + g.chunk < t.nrows ? (uint32_t)(begin + g.chunk) : (uint32_t)t.nrows;
   // FAST: the raw column words of the NEXT tile are requested while the current tile is flushed, so the
   // HBM read latency hides behind the LDS regroup + store phase (one workgroup per CU: nothing else would)
+  // Row of item k of this thread within a tile.  FAST: thread t owns the row PAIRS t, t + THREADS, ... (one 16- / 8-byte
+  // load per pair: half the address arithmetic and load instructions of one load per row); generic: rows t + k * THREADS.
+  // (tid comes from opaque_tid() inside the tile loop: sixteen hoisted row numbers are sixteen registers)
+  auto item_row = [](int k, uint32_t tid) -> uint32_t {
+    return FAST ? 2u * ((uint32_t)(k >> 1) * THREADS + tid) + (k & 1) : (uint32_t)k * THREADS + tid;
+  };
   uint64_t nxt[JK_SC_ITEMS];
   const void *col = t.col[0].data;
-  if (FAST) {
+  auto prefetch = [&](uint32_t tile) {           // a pair that would cross `end` is read from the last two rows instead:
+    const uint32_t tid = opaque_tid();           // its first row, if it is row end - 1, is then the SECOND word loaded (consume)
 #pragma unroll
-    for (int k = 0; k < JK_SC_ITEMS; ++k) {
-      const int64_t i = begin + (int64_t)k * THREADS + threadIdx.x;
-      nxt[k] = fast_word<FAST>(col, i < end ? i : end - 1);
+    for (int k = 0; k < JK_SC_ITEMS; k += 2) {
+      const uint32_t i = tile + item_row(k, tid);
+      fast_pair<FAST>(col, (int64_t)(i + 2 <= end ? i : end - 2), nxt[k], nxt[k + 1]);
     }
-  }
+  };
+  if (FAST) prefetch(begin);
   if (threadIdx.x < 256) s.hist[threadIdx.x] = 0;
   block_sync();
-  for (int64_t tile = begin; tile < end; tile += JK_TILE) {      // 5 barriers per tile; hist is re-zeroed by its last reader
-    uint64_t key[JK_SC_ITEMS];
-    bool ok[JK_SC_ITEMS];
-    if (FAST) {
-#pragma unroll
-      for (int k = 0; k < JK_SC_ITEMS; ++k) {
-        key[k] = nxt[k] - plan.kmin;
-        ok[k] = (tile + (int64_t)k * THREADS + threadIdx.x < end) && (!plan.narrow || (key[k] >> 32) == 0);
-      }
-    } else {
-      fetch_keys<FAST, JK_SC_ITEMS>(t, plan, tile + threadIdx.x, THREADS, end, key, ok);   // all loads first
-    }
-    uint32_t binrank[JK_SC_ITEMS];   // bin << 16 | rank ; 0xffffffff = skip
-#pragma unroll
-    for (int k = 0; k < JK_SC_ITEMS; ++k) {
-      binrank[k] = 0xffffffffu;
-      if (ok[k]) {
-        const uint32_t bin = fine_of(key[k] + g.kbias, g.fb) >> g.b2;
-        binrank[k] = (bin << 16) | atomicAdd(&s.hist[bin], 1u);
-      }
-    }
-    block_sync();
-    tile_scan_bins(s, ncoarse);
-    block_sync();
-    if (threadIdx.x < ncoarse) {
-      if (g.cap1) {
-        const uint32_t cnt = s.hist[threadIdx.x];
-        uint32_t base = cnt ? atomicAdd(&g.spec_cursor1[threadIdx.x], cnt) : 0u;
-        if (base + cnt > g.cap1) { atomicExch(g.spec_flag, 1u); s.gbase[threadIdx.x] = g.dump - s.start[threadIdx.x]; }
-        else s.gbase[threadIdx.x] = threadIdx.x * g.cap1 + base - s.start[threadIdx.x];
-      } else {
-        s.gbase[threadIdx.x] = s.cursor[threadIdx.x] - s.start[threadIdx.x];
-        s.cursor[threadIdx.x] += s.hist[threadIdx.x];
-      }
-    }
-    if (threadIdx.x < 256) s.hist[threadIdx.x] = 0;      // nobody reads hist again before the next tile's ranking, two barriers away
+  // Per tile: rank (LDS atomics) | scan | claim + regroup in LDS | flush.  Four barriers; the waves that finish their
+  // share of a flush go on to rank the next tile (they touch only hist, which the flush does not read).
+  // Everything between two barriers is straight-line code: a `if (ok) atomicAdd` per item compiled to sixteen
+  // branches with an s_waitcnt lgkmcnt(0) each (one LDS round trip at a time), and a flush loop with a dynamic trip
+  // count made the compiler wait for vmcnt(0) -- i.e. for the completion of the previous tile's STORES -- before the
+  // prefetched keys could be used (gfx9 counts loads and stores in the one in-order vmcnt).  Rows that do not travel
+  // (beyond the chunk, null, outside the narrow range) go to a trash counter / LDS slot / global dump slot instead.
+  using KeyReg = typename std::conditional<NARROW, uint32_t, uint64_t>::type;    // NARROW: joinable keys are < 2^32
+  KeyReg key[JK_SC_ITEMS];
+  uint32_t okmask = 0;          // bit k: item k travels.  One VGPR; sixteen loop-carried bools cost 32 SGPRs and spills
+  auto consume = [&](uint32_t tile) {
+    const uint32_t tid = opaque_tid();
+    okmask = 0;
 #pragma unroll
     for (int k = 0; k < JK_SC_ITEMS; ++k) {
-      if (binrank[k] != 0xffffffffu) {
-        const uint32_t pos = s.start[binrank[k] >> 16] + (binrank[k] & 0xffffu);
-        const int32_t row = (int32_t)(tile + (int64_t)k * THREADS + threadIdx.x);
-        s.w[pos] = tup_make<NARROW>(key[k], row);
+      const uint64_t raw = ((k & 1) == 0 && tile + item_row(k, tid) + 1 == end) ? nxt[k + 1] : nxt[k];
+      const uint64_t k64 = raw - plan.kmin;
+      key[k] = (KeyReg)k64;
+      okmask |= (uint32_t)((tile + item_row(k, tid) < end) && (!plan.narrow || (k64 >> 32) == 0)) << k;
+    }
+  };
+  if (FAST) consume(begin);
+  for (uint32_t tile = begin; tile < end; tile += JK_TILE) {        // end + JK_TILE < 2^32
+    if (!FAST) {
+      uint64_t k64[JK_SC_ITEMS];
+      bool ok[JK_SC_ITEMS];
+      fetch_keys<FAST, JK_SC_ITEMS>(t, plan, (int64_t)tile + threadIdx.x, THREADS, (int64_t)end, k64, ok);   // all loads first
+      okmask = 0;
+#pragma unroll
+      for (int k = 0; k < JK_SC_ITEMS; ++k) { key[k] = (KeyReg)k64[k]; okmask |= (uint32_t)ok[k] << k; }
+    }
+    uint32_t binrank[JK_SC_ITEMS];             // bin << 16 | rank within (tile, bin); bin 256 = does not travel
+#pragma unroll
+    for (int h = 0; h < JK_SC_ITEMS; h += 4) {
+#pragma unroll
+      for (int k = h; k < h + 4; ++k) {
+        const uint32_t b = fine_of((uint64_t)key[k] + g.kbias, g.fb) >> g.b2;     // hashed whether it travels or not: no branch
+        binrank[k] = (okmask >> k) & 1u ? b : 256u;
+      }
+      __builtin_amdgcn_sched_barrier(0);       // four hashes at a time: sixteen interleaved ones spill
+    }
+#pragma unroll
+    for (int k = 0; k < JK_SC_ITEMS; ++k)      // sixteen atomics in flight, one wait
+      binrank[k] = (binrank[k] << 16) | atomicAdd(&s.hist[binrank[k]], 1u);
+    block_sync();
+    {
+      const uint32_t tid = opaque_tid();
+      tile_scan_bins(s, ncoarse, tid);
+      block_sync();
+      if (tid < ncoarse) {
+        if (g.cap1) {
+          const uint32_t cnt = s.hist[tid];
+          uint32_t base = cnt ? atomicAdd(&g.spec_cursor1[tid], cnt) : 0u;
+          if (base + cnt > g.cap1) { atomicExch(g.spec_flag, 1u); s.gbase[tid] = g.dump - s.start[tid]; }
+          else s.gbase[tid] = tid * g.cap1 + base - s.start[tid];
+        } else {
+          s.gbase[tid] = s.cursor[tid] - s.start[tid];
+          s.cursor[tid] += s.hist[tid];
+        }
+      }
+      if (tid < 256) s.hist[tid] = 0;      // nobody reads hist again before the next tile's ranking
+    }
+    const uint32_t wtid = opaque_tid();
+#pragma unroll
+    for (int h = 0; h < JK_SC_ITEMS; h += 8) {           // eight at a time: reads of start[] first (no branch), then the writes
+      uint32_t st[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) st[k] = s.start[(binrank[h + k] >> 16) & 255u];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t pos = (okmask >> (h + k)) & 1u ? st[k] + (binrank[h + k] & 0xffffu) : (uint32_t)JK_TILE;
+        const int32_t row = (int32_t)(tile + item_row(h + k, wtid));
+        s.w[pos] = tup_make<NARROW>((uint64_t)key[h + k], row);
         if (!NARROW) s.idx[pos] = row;
       }
     }
-    if (FAST && tile + JK_TILE < end) {
+    const bool more = tile + JK_TILE < end;
+    __builtin_amdgcn_sched_barrier(0);         // keep the prefetch BELOW the regroup: hoisted, its 32 registers spill
+    if (FAST && more) prefetch(tile + JK_TILE);
+    block_sync();
+    // flush: JK_SC_ITEMS unconditional stores per thread (dead slots -> this thread's dump slot), four at a time to
+    // keep the register count under the 128 a 1024-thread workgroup gets (the prefetched keys stay in registers)
+    const uint32_t total = s.total;
+    const uint32_t ftid = opaque_tid();
+    constexpr int HALF = 4;
 #pragma unroll
-      for (int k = 0; k < JK_SC_ITEMS; ++k) {
-        const int64_t i = tile + JK_TILE + (int64_t)k * THREADS + threadIdx.x;
-        nxt[k] = fast_word<FAST>(col, i < end ? i : end - 1);
+    for (int h = 0; h < JK_SC_ITEMS / HALF; ++h) {
+      uint64_t ww[HALF];
+      int32_t ii[HALF];
+      uint32_t gb[HALF];
+#pragma unroll
+      for (int k = 0; k < HALF; ++k) {
+        const uint32_t j = ftid + (h * HALF + k) * THREADS;
+        ww[k] = s.w[j];
+        ii[k] = NARROW ? 0 : s.idx[j];
       }
+#pragma unroll
+      for (int k = 0; k < HALF; ++k)
+        gb[k] = s.gbase[(fine_of(tup_key<NARROW>(ww[k]) + g.kbias, g.fb) >> g.b2) & 255u];
+#pragma unroll
+      for (int k = 0; k < HALF; ++k) {
+        const uint32_t j = ftid + (h * HALF + k) * THREADS;
+        uint32_t dst = j < total ? gb[k] + j : g.dump + ftid;
+        if (g.dbg & 4) dst &= 0xffffu;           // experiment: all stores land in a 512 KiB window
+        if (g.dbg & 1) dst = g.dump + ftid;      // experiment: no useful stores
+        out.w[dst] = ww[k];
+        if (!NARROW) out.idx[dst] = ii[k];
+      }
+      __builtin_amdgcn_sched_barrier(0);       // one group's LDS reads at a time: hoisted together they spill
     }
-    block_sync();
-    tile_flush<true, NARROW, THREADS>(s, g, out);
-    block_sync();
+    // the stores above stay in flight: this waits for the LOADS only.  Unconditional: keeping the old keys alive for the
+    // `no more tiles` case would cost 16 registers across the flush
+    if (FAST) consume(tile + JK_TILE);
   }
 }
 
@@ -488,6 +577,8 @@ __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, 
 
   if (threadIdx.x < 256) s.hist[threadIdx.x] = 0;
   block_sync();
+  // straight-line phases as in jk_scatter1: tuples beyond the tile's end are ranked on a trash counter (bin 256) and
+  // written to the trash slot of the LDS tile instead of being skipped by a branch per item
   uint64_t w[JK_SC_ITEMS];
   int32_t idx[JK_SC_ITEMS];
 #pragma unroll
@@ -501,12 +592,12 @@ __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, 
 #pragma unroll
   for (int k = 0; k < JK_SC_ITEMS; ++k) {
     const uint32_t i = begin + k * THREADS + threadIdx.x;
-    binrank[k] = 0xffffffffu;
-    if (i < end) {
-      const uint32_t bin = fine_of(tup_key<NARROW>(w[k]) + g.kbias, g.fb) & submask;
-      binrank[k] = (bin << 16) | atomicAdd(&s.hist[bin], 1u);
-    }
+    const uint32_t bin = fine_of(tup_key<NARROW>(w[k]) + g.kbias, g.fb) & submask;
+    binrank[k] = i < end ? bin : 256u;
   }
+#pragma unroll
+  for (int k = 0; k < JK_SC_ITEMS; ++k)            // sixteen atomics in flight, one wait
+    binrank[k] = (binrank[k] << 16) | atomicAdd(&s.hist[binrank[k]], 1u);
   block_sync();
   tile_scan_bins(s, nsub);
   block_sync();
@@ -520,11 +611,15 @@ __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, 
     }
   }
 #pragma unroll
-  for (int k = 0; k < JK_SC_ITEMS; ++k) {
-    if (binrank[k] != 0xffffffffu) {
-      const uint32_t pos = s.start[binrank[k] >> 16] + (binrank[k] & 0xffffu);
-      s.w[pos] = w[k];
-      if (!NARROW) s.idx[pos] = idx[k];
+  for (int h = 0; h < JK_SC_ITEMS; h += 8) {
+    uint32_t st[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) st[k] = s.start[(binrank[h + k] >> 16) & 255u];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t pos = (binrank[h + k] >> 24) ? (uint32_t)JK_TILE : st[k] + (binrank[h + k] & 0xffffu);
+      s.w[pos] = w[h + k];
+      if (!NARROW) s.idx[pos] = idx[h + k];
     }
   }
   block_sync();
@@ -1140,7 +1235,7 @@ static gdf_error launch_scatter1(int fast, bool narrow, int threads, const KeyTa
 }
 // 8 / 4: the relation is one unmasked raw integer column of that width (direct column reads); 0: generic key construction
 static int fast_key_width(const KeyTable &t, const KeyPlan &plan) {
-  if (t.ncols != 1 || plan.mode != KM_RAW_INT || t.any_valid) return 0;
+  if (t.ncols != 1 || plan.mode != KM_RAW_INT || t.any_valid || t.nrows < 2) return 0;   // jk_scatter1 loads row pairs
   if (t.col[0].width == 8) return 8;
   if (t.col[0].width == 4 && plan.narrow && plan.kmin == 0) return 4;
   return 0;
@@ -1241,8 +1336,10 @@ static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, Si
   if (!narrow && sc_threads == 1024) sc_threads = 512;       // 16384 x 12 B would not fit 160 KiB
   const int64_t JK_TILE = (int64_t)sc_threads * JK_SC_ITEMS;
 
-  RMM_TRY(sb->w[0].alloc(sizeof(uint64_t) * (cap + 2)));      // + slack: the probe kernel's last 16-byte load may touch one tuple past the end
-  if (!narrow) RMM_TRY(sb->idx[0].alloc(sizeof(int32_t) * cap));
+  // + 2: the probe kernel's last 16-byte load may touch one tuple past the end; + 1024: jk_scatter1's per-thread dump slots
+  g.dump = (uint32_t)(cap + 2);
+  RMM_TRY(sb->w[0].alloc(sizeof(uint64_t) * (cap + 2 + 1024)));
+  if (!narrow) RMM_TRY(sb->idx[0].alloc(sizeof(int32_t) * (cap + 2 + 1024)));
   const Tuples t0 = sb->tuples(0);
   GDF_TRY(launch_scatter1(fast, narrow, sc_threads, t, plan, g, H1.as<uint32_t>(), t0));
   HIP_CHECK_LAST();

@@ -218,8 +218,15 @@ struct PartGeom {
   // the partition's fill counter.  A partition that outgrows its capacity raises *spec_flag and its run is
   // written to the dump area instead (memory safe); the host then repeats the side with the exact layout.
   uint32_t cap1, cap2, dump;
-  uint32_t *spec_cursor1;   // [2^b1] fill counters, zero-initialised
+  uint32_t *spec_cursor1;   // [2^b1 << xs] fill counters, zero-initialised
   uint32_t *spec_flag;
+  // Level 1 of the speculative layout splits every coarse partition into 2^xs REGIONS of cap1 tuples, one per XCD
+  // (block b runs on XCD b % 8, MI355X_MICROARCH.md "Workgroup dispatch"): the 512-byte (tile, bin) runs start at
+  // arbitrary 8-byte offsets, so neighbouring runs share their first / last 128-byte line.  With one fill counter per
+  // partition those neighbours come from different XCDs, whose L2s are not coherent: both write the shared line back
+  // partially.  With one counter per (partition, XCD) the neighbours meet in ONE L2, which merges them into whole
+  // lines before they reach HBM.  Level 2 walks the regions as 2^(b1+xs) segments.
+  int xs;
 };
 
 // NARROW: w[i] = key32 << 32 | row, idx unused.  WIDE: w[i] = key64, idx[i] = row.
@@ -478,14 +485,24 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
     block_sync();
     {
       const uint32_t tid = opaque_tid();
+      // speculative layout: the claim (a returning global atomic, ~2 us) is issued as soon as the counts are final and
+      // collected after the scan, instead of sitting between two barriers on its own
+      // (not with 1024 threads: at its 128-register limit the carried value costs more in spills than the latency)
+      constexpr bool EARLY_CLAIM = THREADS < 1024;
+      uint32_t base = 0;
+      if (EARLY_CLAIM && g.cap1 && tid < ncoarse) {
+        const uint32_t cnt = s.hist[tid];
+        if (cnt) base = atomicAdd(&g.spec_cursor1[(tid << g.xs) | (blockIdx.x & ((1u << g.xs) - 1u))], cnt);
+      }
       tile_scan_bins(s, ncoarse, tid);
       block_sync();
       if (tid < ncoarse) {
         if (g.cap1) {
           const uint32_t cnt = s.hist[tid];
-          uint32_t base = cnt ? atomicAdd(&g.spec_cursor1[tid], cnt) : 0u;
+          const uint32_t region = (tid << g.xs) | (blockIdx.x & ((1u << g.xs) - 1u));
+          if (!EARLY_CLAIM && cnt) base = atomicAdd(&g.spec_cursor1[region], cnt);
           if (base + cnt > g.cap1) { atomicExch(g.spec_flag, 1u); s.gbase[tid] = g.dump - s.start[tid]; }
-          else s.gbase[tid] = tid * g.cap1 + base - s.start[tid];
+          else s.gbase[tid] = region * g.cap1 + base - s.start[tid];
         } else {
           s.gbase[tid] = s.cursor[tid] - s.start[tid];
           s.cursor[tid] += s.hist[tid];
@@ -554,6 +571,9 @@ struct Level2Map {                     // small host-built tables, device reside
   const uint32_t *coarse_off;          // [ncoarse] first tuple of each coarse partition
   const uint32_t *coarse_end;          // [ncoarse] one past its last tuple (== the next partition's first in the exact layout)
   const uint32_t *tile_prefix;         // [ncoarse+1] tiles before each coarse partition
+  int xs;                              // the arrays describe 2^(b1+xs) SEGMENTS, segment >> xs = coarse partition (PartGeom::xs)
+  uint32_t ntiles;                     // set by the launcher
+  int xcd_order;                       // set by the launcher: the grid is 8 * ceil(ntiles / 8) blocks, see jk_scatter2
 };
 
 template <bool NARROW, int THREADS>
@@ -564,14 +584,20 @@ __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, 
   constexpr int JK_TILE = THREADS * JK_SC_ITEMS;
   const uint32_t ncoarse = 1u << g.b1, nsub = 1u << g.b2;
   // locate the coarse partition that owns this tile (binary search over <= 257 entries)
-  uint32_t lo = 0, hi = ncoarse;
+  // XCD x (= blockIdx.x % 8) takes the x-th EIGHTH of the tiles, in order: every writer of a fine partition -- the tiles
+  // of its coarse partition -- then shares one L2, which merges the partial first / last lines of neighbouring
+  // (tile, bin) runs before they reach HBM (PartGeom::xs has the level-1 half of this)
+  const uint32_t per_xcd = gridDim.x >> 3;
+  const uint32_t tile_id = m.xcd_order ? (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
+  if (tile_id >= m.ntiles) return;
+  uint32_t lo = 0, hi = ncoarse << m.xs;
   while (hi - lo > 1) {
     const uint32_t mid = (lo + hi) >> 1;
-    if (m.tile_prefix[mid] <= blockIdx.x) lo = mid; else hi = mid;
+    if (m.tile_prefix[mid] <= tile_id) lo = mid; else hi = mid;
   }
-  const uint32_t p = lo;
-  const uint32_t begin = m.coarse_off[p] + (blockIdx.x - m.tile_prefix[p]) * JK_TILE;
-  const uint32_t pend = m.coarse_end[p];
+  const uint32_t p = lo >> m.xs;
+  const uint32_t begin = m.coarse_off[lo] + (tile_id - m.tile_prefix[lo]) * JK_TILE;
+  const uint32_t pend = m.coarse_end[lo];
   const uint32_t end = begin + JK_TILE < pend ? begin + JK_TILE : pend;
   const uint32_t submask = nsub - 1;
 
@@ -1244,7 +1270,10 @@ template <bool NARROW, int THREADS>
 static gdf_error launch_scatter2_t(uint32_t ntiles, const PartGeom &g, Level2Map m, Tuples in, uint32_t *cursor, Tuples out) {
   const size_t lds = sizeof(TileLds<NARROW, THREADS>);
   HIP_TRY(hipFuncSetAttribute((const void *)jk_scatter2<NARROW, THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  GDF_LAUNCH("jk_scatter2", (jk_scatter2<NARROW, THREADS>), dim3(ntiles), dim3(THREADS), lds, stream0(), g, m, in, cursor, out);
+  m.ntiles = ntiles;
+  m.xcd_order = (ntiles >= 64 && !getenv("GDF_JK_NO_XCD_ORDER")) ? 1 : 0;
+  const uint32_t grid = m.xcd_order ? ((ntiles + 7) / 8) * 8 : ntiles;
+  GDF_LAUNCH("jk_scatter2", (jk_scatter2<NARROW, THREADS>), dim3(grid), dim3(THREADS), lds, stream0(), g, m, in, cursor, out);
   HIP_CHECK_LAST();
   return GDF_SUCCESS;
 }
@@ -1262,6 +1291,16 @@ static gdf_error launch_scatter2(bool narrow, int threads, uint32_t ntiles, cons
 // partitions one relation into g.fb-bit fine partitions
 // decide_narrow: this is the BUILD side of an 8-byte integer key: the histogram pass also returns the key
 // range, and when it spans < 2^32 the plan switches to the narrow tuple format (for both relations).
+// Level 2 regroups 4096-tuple tiles, four workgroups per CU whose load / LDS / store phases overlap: since every fine
+// partition is written from one XCD (jk_scatter2), the partial lines of its short (tile, bin) runs merge in that L2.
+// Measured on C3, jk_scatter2 with 1024 / 512 / 256 threads: 3.6 / 3.3 / 3.2 ms.  Level 1 goes the other way
+// (3.9 vs 4.7 ms with 512 threads): its claims are on the critical path of a tile loop, it keeps one big tile per CU.
+static int level2_threads(int sc_threads) {
+  static const int env = getenv("GDF_JK_SC2_THREADS") ? atoi(getenv("GDF_JK_SC2_THREADS")) : 0;
+  if (env == 256 || env == 512 || env == 1024) return env < sc_threads ? env : sc_threads;
+  return sc_threads > 256 ? 256 : sc_threads;
+}
+
 static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, SideBufs *sb, bool decide_narrow) {
   const int64_t n = t.nrows;
   bool narrow = plan.narrow != 0;
@@ -1334,7 +1373,8 @@ static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, Si
   int sc_threads = sc_threads_env ? sc_threads_env : (narrow ? 1024 : 512);   // swept on C3: profiles/r1_c_sweeps.md
   if (sc_threads != 256 && sc_threads != 512 && sc_threads != 1024) sc_threads = 256;
   if (!narrow && sc_threads == 1024) sc_threads = 512;       // 16384 x 12 B would not fit 160 KiB
-  const int64_t JK_TILE = (int64_t)sc_threads * JK_SC_ITEMS;
+  const int sc2_threads = level2_threads(sc_threads);
+  const int64_t JK_TILE2 = (int64_t)sc2_threads * JK_SC_ITEMS;
 
   // + 2: the probe kernel's last 16-byte load may touch one tuple past the end; + 1024: jk_scatter1's per-thread dump slots
   g.dump = (uint32_t)(cap + 2);
@@ -1350,7 +1390,7 @@ static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, Si
     for (uint32_t c = 0; c <= ncoarse; ++c) coarse_off[c] = sb->fine_off[(size_t)c << g.b2];
     tile_prefix[0] = 0;
     for (uint32_t c = 0; c < ncoarse; ++c)
-      tile_prefix[c + 1] = tile_prefix[c] + (coarse_off[c + 1] - coarse_off[c] + JK_TILE - 1) / JK_TILE;
+      tile_prefix[c + 1] = tile_prefix[c] + (coarse_off[c + 1] - coarse_off[c] + JK_TILE2 - 1) / JK_TILE2;
     const uint32_t ntiles = tile_prefix[ncoarse];
     DevBuf d_coarse, d_tiles, cursor;
     RMM_TRY(d_coarse.alloc(sizeof(uint32_t) * (ncoarse + 1)));
@@ -1362,7 +1402,7 @@ static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, Si
     RMM_TRY(sb->w[1].alloc(sizeof(uint64_t) * (cap + 2)));
     if (!narrow) RMM_TRY(sb->idx[1].alloc(sizeof(int32_t) * cap));
     Level2Map m{d_coarse.as<uint32_t>(), d_coarse.as<uint32_t>() + 1, d_tiles.as<uint32_t>()};
-    if (ntiles) GDF_TRY(launch_scatter2(narrow, sc_threads, ntiles, g, m, sb->tuples(0), cursor.as<uint32_t>(), sb->tuples(1)));
+    if (ntiles) GDF_TRY(launch_scatter2(narrow, sc2_threads, ntiles, g, m, sb->tuples(0), cursor.as<uint32_t>(), sb->tuples(1)));
     HIP_CHECK_LAST();
     HIP_TRY(hipStreamSynchronize(stream0()));   // host vectors + scratch go out of scope
     sb->w[0].reset();
@@ -1400,29 +1440,35 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
   if (sc_threads != 256 && sc_threads != 512 && sc_threads != 1024) sc_threads = 256;
   if (!narrow && sc_threads == 1024) sc_threads = 512;
   const int64_t JK_TILE = (int64_t)sc_threads * JK_SC_ITEMS;
+  const int sc2_threads = level2_threads(sc_threads);
+  const int64_t JK_TILE2 = (int64_t)sc2_threads * JK_SC_ITEMS;
   auto room = [dup](double mean, uint32_t align) {
     const double c = mean + 8.0 * std::sqrt(mean * (1.0 + dup)) + 64.0;
     return (uint32_t)(((uint64_t)c + align - 1) / align * align);
   };
-  const uint32_t cap1 = room((double)n / ncoarse, 64), cap2 = g.b2 ? room((double)n / nfine, 8) : 0;
-  const uint64_t size1 = (uint64_t)ncoarse * cap1 + JK_TILE, size2 = (uint64_t)nfine * cap2 + JK_TILE;
+  // one region per (coarse partition, XCD) when a second level follows (PartGeom::xs); a single level needs its
+  // partitions contiguous for the probe units
+  g.xs = (g.b2 > 0 && n >= ((int64_t)1 << 26) && !getenv("GDF_JK_NO_XCD_SPLIT")) ? 3 : 0;
+  const uint32_t nseg = ncoarse << g.xs;
+  const uint32_t cap1 = room((double)n / nseg, 64), cap2 = g.b2 ? room((double)n / nfine, 8) : 0;
+  const uint64_t size1 = (uint64_t)nseg * cap1 + JK_TILE, size2 = (uint64_t)nfine * cap2 + JK_TILE;
   if (size1 >= 0x7fffffffULL || size2 >= 0x7fffffffULL) return GDF_SUCCESS;      // tuple positions are 31-bit
 
   DevBuf spec;
-  RMM_TRY(spec.alloc(sizeof(uint32_t) * (ncoarse + 1)));
-  HIP_TRY(hipMemsetAsync(spec.p, 0, sizeof(uint32_t) * (ncoarse + 1), stream0()));
+  RMM_TRY(spec.alloc(sizeof(uint32_t) * (nseg + 1)));
+  HIP_TRY(hipMemsetAsync(spec.p, 0, sizeof(uint32_t) * (nseg + 1), stream0()));
   g.kbias = plan.kmin;
   g.cap1 = cap1;
   g.cap2 = 0;
-  g.dump = ncoarse * cap1;
+  g.dump = nseg * cap1;
   g.spec_cursor1 = spec.as<uint32_t>();
-  g.spec_flag = spec.as<uint32_t>() + ncoarse;
+  g.spec_flag = spec.as<uint32_t>() + nseg;
   RMM_TRY(sb->w[0].alloc(sizeof(uint64_t) * size1));
   if (!narrow) RMM_TRY(sb->idx[0].alloc(sizeof(int32_t) * size1));
   GDF_TRY(launch_scatter1(fast, narrow, sc_threads, t, plan, g, nullptr, sb->tuples(0)));
-  std::vector<uint32_t> c1(ncoarse + 1);
-  HIP_TRY(hipMemcpy(c1.data(), spec.p, sizeof(uint32_t) * (ncoarse + 1), hipMemcpyDeviceToHost));
-  if (c1[ncoarse]) return GDF_SUCCESS;
+  std::vector<uint32_t> c1(nseg + 1);
+  HIP_TRY(hipMemcpy(c1.data(), spec.p, sizeof(uint32_t) * (nseg + 1), hipMemcpyDeviceToHost));
+  if (c1[nseg]) return GDF_SUCCESS;
   sb->final_buf = 0;
   sb->fine_off.clear();
   if (g.b2 == 0) {
@@ -1430,29 +1476,29 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
     for (uint32_t f = 0; f < nfine; ++f) sb->fine_begin[f] = f * cap1;
     sb->fine_cnt.assign(c1.begin(), c1.begin() + nfine);
   } else {
-    std::vector<uint32_t> coarse_off(2 * ncoarse), tile_prefix(ncoarse + 1), cur(nfine);
+    std::vector<uint32_t> coarse_off(2 * nseg), tile_prefix(nseg + 1), cur(nfine);     // per SEGMENT (Level2Map::xs)
     tile_prefix[0] = 0;
-    for (uint32_t c = 0; c < ncoarse; ++c) {
+    for (uint32_t c = 0; c < nseg; ++c) {
       coarse_off[c] = c * cap1;
-      coarse_off[ncoarse + c] = c * cap1 + c1[c];
-      tile_prefix[c + 1] = tile_prefix[c] + (uint32_t)((c1[c] + JK_TILE - 1) / JK_TILE);
+      coarse_off[nseg + c] = c * cap1 + c1[c];
+      tile_prefix[c + 1] = tile_prefix[c] + (uint32_t)((c1[c] + JK_TILE2 - 1) / JK_TILE2);
     }
     for (uint32_t f = 0; f < nfine; ++f) cur[f] = f * cap2;
-    const uint32_t ntiles = tile_prefix[ncoarse];
+    const uint32_t ntiles = tile_prefix[nseg];
     DevBuf d_coarse, d_tiles, cursor;
-    RMM_TRY(d_coarse.alloc(sizeof(uint32_t) * 2 * ncoarse));
-    RMM_TRY(d_tiles.alloc(sizeof(uint32_t) * (ncoarse + 1)));
+    RMM_TRY(d_coarse.alloc(sizeof(uint32_t) * 2 * nseg));
+    RMM_TRY(d_tiles.alloc(sizeof(uint32_t) * (nseg + 1)));
     RMM_TRY(cursor.alloc(sizeof(uint32_t) * nfine));
-    HIP_TRY(hipMemcpyAsync(d_coarse.p, coarse_off.data(), sizeof(uint32_t) * 2 * ncoarse, hipMemcpyHostToDevice, stream0()));
-    HIP_TRY(hipMemcpyAsync(d_tiles.p, tile_prefix.data(), sizeof(uint32_t) * (ncoarse + 1), hipMemcpyHostToDevice, stream0()));
+    HIP_TRY(hipMemcpyAsync(d_coarse.p, coarse_off.data(), sizeof(uint32_t) * 2 * nseg, hipMemcpyHostToDevice, stream0()));
+    HIP_TRY(hipMemcpyAsync(d_tiles.p, tile_prefix.data(), sizeof(uint32_t) * (nseg + 1), hipMemcpyHostToDevice, stream0()));
     HIP_TRY(hipMemcpyAsync(cursor.p, cur.data(), sizeof(uint32_t) * nfine, hipMemcpyHostToDevice, stream0()));
     RMM_TRY(sb->w[1].alloc(sizeof(uint64_t) * size2));
     if (!narrow) RMM_TRY(sb->idx[1].alloc(sizeof(int32_t) * size2));
     PartGeom g2 = g;
     g2.cap2 = cap2;
     g2.dump = nfine * cap2;
-    Level2Map m{d_coarse.as<uint32_t>(), d_coarse.as<uint32_t>() + ncoarse, d_tiles.as<uint32_t>()};
-    if (ntiles) GDF_TRY(launch_scatter2(narrow, sc_threads, ntiles, g2, m, sb->tuples(0), cursor.as<uint32_t>(), sb->tuples(1)));
+    Level2Map m{d_coarse.as<uint32_t>(), d_coarse.as<uint32_t>() + nseg, d_tiles.as<uint32_t>(), g.xs};
+    if (ntiles) GDF_TRY(launch_scatter2(narrow, sc2_threads, ntiles, g2, m, sb->tuples(0), cursor.as<uint32_t>(), sb->tuples(1)));
     uint32_t flag = 0;
     HIP_TRY(hipMemcpy(cur.data(), cursor.p, sizeof(uint32_t) * nfine, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(&flag, g.spec_flag, sizeof(uint32_t), hipMemcpyDeviceToHost));

@@ -240,9 +240,15 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter(const K *__restrict__ k
   __shared__ uint32_t gbase[BINS];             // global position of LDS position 0 of a digit (mod 2^32)
   __shared__ uint32_t wtot[RS_WAVES];
   const int wave = threadIdx.x / WAVE, lane = lane_id();
+  // XCD x (= blockIdx.x % 8, MI355X_MICROARCH.md "Workgroup dispatch") takes the x-th eighth of the tiles, in order.  A
+  // tile leaves a few keys per digit (4096 keys over 512 digits), so a 128-byte line of the output is filled by several
+  // CONSECUTIVE tiles; in dispatch order those run on different XCDs, whose L2s each write their part of the line back
+  // separately.  From one XCD the parts merge in its L2 and the line reaches HBM once.  The grid is 8 * ceil(ntiles / 8).
+  const uint32_t tile = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  if (tile >= ntiles) return;
   for (int j = threadIdx.x; j < RS_WAVES * BINS; j += RS_THREADS) wcnt[j] = 0;
   block_sync();
-  const uint32_t tile_base = blockIdx.x * TILE;
+  const uint32_t tile_base = tile * TILE;
   const uint32_t wbase = tile_base + wave * (ITEMS * WAVE);
   const uint32_t last = n - 1;
   K key[ITEMS];
@@ -291,7 +297,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter(const K *__restrict__ k
     for (int w = 0; w < wave; ++w) before += wtot[w];
     const uint32_t start = binstart[threadIdx.x] + before;
     binstart[threadIdx.x] = start;
-    gbase[threadIdx.x] = offsets[threadIdx.x * ntiles + blockIdx.x] - start;
+    gbase[threadIdx.x] = offsets[threadIdx.x * ntiles + tile] - start;
   }
   block_sync();
 #pragma unroll
@@ -323,6 +329,7 @@ gdf_error radix_sort_pairs(K *&kin, K *&kout, V *&vin, V *&vout, uint32_t n, uin
   if (varying == 0 || n < 2) return GDF_SUCCESS;
   constexpr int TILE = RsGeom<V>::TILE;
   const uint32_t ntiles = (n + TILE - 1) / TILE;
+  const uint32_t xcd_grid = (ntiles + 7) / 8 * 8;        // rs_scatter: every XCD takes a contiguous eighth of the tiles
   const int lo = __builtin_ctzll(varying), hi = 64 - __builtin_clzll(varying);
   const int span = hi - lo;
   const int passes = (span + 8) / 9;
@@ -336,12 +343,12 @@ gdf_error radix_sort_pairs(K *&kin, K *&kout, V *&vin, V *&vout, uint32_t n, uin
     if (bits == 9) {
       GDF_LAUNCH("rs_count", (rs_count<K, 9, TILE>), dim3(ntiles), dim3(RS_THREADS), 0, stream0(), (const K *)kin, n, shift, counts.as<uint32_t>(), ntiles);
       GDF_TRY(scan_u32(counts.as<uint32_t>(), counts.as<uint32_t>(), (size_t)ntiles * 512, false));
-      GDF_LAUNCH("rs_scatter", (rs_scatter<K, V, 9>), dim3(ntiles), dim3(RS_THREADS), 0, stream0(), (const K *)kin, (const V *)vin, kout, vout, n,
+      GDF_LAUNCH("rs_scatter", (rs_scatter<K, V, 9>), dim3(xcd_grid), dim3(RS_THREADS), 0, stream0(), (const K *)kin, (const V *)vin, kout, vout, n,
                  shift, (const uint32_t *)counts.as<uint32_t>(), ntiles);
     } else {
       GDF_LAUNCH("rs_count", (rs_count<K, 8, TILE>), dim3(ntiles), dim3(RS_THREADS), 0, stream0(), (const K *)kin, n, shift, counts.as<uint32_t>(), ntiles);
       GDF_TRY(scan_u32(counts.as<uint32_t>(), counts.as<uint32_t>(), (size_t)ntiles * 256, false));
-      GDF_LAUNCH("rs_scatter", (rs_scatter<K, V, 8>), dim3(ntiles), dim3(RS_THREADS), 0, stream0(), (const K *)kin, (const V *)vin, kout, vout, n,
+      GDF_LAUNCH("rs_scatter", (rs_scatter<K, V, 8>), dim3(xcd_grid), dim3(RS_THREADS), 0, stream0(), (const K *)kin, (const V *)vin, kout, vout, n,
                  shift, (const uint32_t *)counts.as<uint32_t>(), ntiles);
     }
     std::swap(kin, kout);

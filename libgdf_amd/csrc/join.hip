@@ -561,6 +561,7 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
     // the stores above stay in flight: this waits for the LOADS only.  Unconditional: keeping the old keys alive for the
     // `no more tiles` case would cost 16 registers across the flush
     if (FAST) consume(tile + JK_TILE);
+    __builtin_amdgcn_sched_barrier(0);         // narrow the keys HERE: sunk into the next ranking, the 64-bit words stay live
   }
 }
 

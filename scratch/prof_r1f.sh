@@ -1,7 +1,7 @@
-# final-state artifacts of round 1 -> gpurun_out/r1f (copied into profiles/ afterwards)
+# final-state artifacts of round 1 -> gpurun_out/r1k (copied into profiles/ afterwards)
 set -x
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r1f
+O=$R/gpurun_out/r1k
 mkdir -p $O
 cd $R
 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed" > $O/pytest_gpu.txt

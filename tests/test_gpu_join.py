@@ -390,6 +390,29 @@ def test_speculative_matches_exact_at_scale(gdf, monkeypatch):
     assert torch.equal(a, c)
 
 
+@pytest.mark.parametrize("how", ["inner", "left"])
+def test_xcd_regions_match_plain_layout(gdf, how, monkeypatch):
+    """1e8 x 1e7 rows (above the 2^26-row threshold): the per-XCD level-1 regions and the XCD-ordered level-2 tiles
+    (default) give the same pair set as the plain speculative layout (GDF_JK_NO_XCD_SPLIT / GDF_JK_NO_XCD_ORDER)."""
+    import torch
+    from libgdf_amd.columns import Column
+    nb, npr = 10_000_000, 100_000_000
+    b = torch.randperm(nb + nb // 8, device="cuda")[:nb]
+    p = torch.randint(0, nb + nb // 4, (npr,), device="cuda")
+    li, ri = gdf.api.join([Column(p)], [Column(b)], how=how)
+    monkeypatch.setenv("GDF_JK_NO_XCD_SPLIT", "1")
+    monkeypatch.setenv("GDF_JK_NO_XCD_ORDER", "1")
+    le, re_ = gdf.api.join([Column(p)], [Column(b)], how=how)
+    assert li.numel() == le.numel()
+    if how == "left":
+        assert li.numel() == npr and torch.equal(torch.sort(li).values, torch.arange(npr, dtype=torch.int32, device="cuda"))
+    hit = ri >= 0
+    assert bool((p[li[hit].long()] == b[ri[hit].long()]).all())
+    a = torch.sort(li.long() * (nb + 1) + (ri.long() + 1)).values
+    c = torch.sort(le.long() * (nb + 1) + (re_.long() + 1)).values
+    assert torch.equal(a, c)
+
+
 def test_randomized_inner_join_properties(gdf):
     """60 random shapes (sizes, key ranges, duplicate rates, int32 / int64 keys) checked by properties that do not
     need the oracle: the number of pairs equals sum_probe multiplicity_in_build(key), every pair joins equal keys,

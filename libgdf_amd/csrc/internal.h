@@ -7,6 +7,9 @@
 
 namespace gdf_amd {
 
+// plumbing.cpp: blocking device -> host copy of a few bytes to a few hundred KB through a pinned staging buffer
+hipError_t read_back(void *host_dst, const void *dev_src, size_t bytes);
+
 // scan.hip: device-wide prefix sums (in == out allowed)
 gdf_error scan_u32(const uint32_t *in, uint32_t *out, size_t n, bool inclusive);
 gdf_error scan_u64(const uint64_t *in, uint64_t *out, size_t n, bool inclusive);

@@ -1350,7 +1350,7 @@ static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, Si
   GDF_TRY(scan_u32(H1.as<uint32_t>(), H1.as<uint32_t>(), (size_t)ncoarse * g.nchunks, false));
 
   std::vector<uint32_t> fh(nfine);
-  HIP_TRY(hipMemcpy(fh.data(), fine_hist.p, sizeof(uint32_t) * nfine, hipMemcpyDeviceToHost));
+  HIP_TRY(read_back(fh.data(), fine_hist.p, sizeof(uint32_t) * nfine));
   sb->fine_off.assign(nfine + 1, 0);
   for (uint32_t f = 0; f < nfine; ++f) sb->fine_off[f + 1] = sb->fine_off[f] + fh[f];
   sb->joinable = sb->fine_off[nfine];
@@ -1360,7 +1360,7 @@ static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, Si
   const size_t cap = sb->joinable ? sb->joinable : 1;
   if (d_mm) {
     long long h[2];
-    HIP_TRY(hipMemcpy(h, d_mm, sizeof(h), hipMemcpyDeviceToHost));
+    HIP_TRY(read_back(h, d_mm, sizeof(h)));
     if (h[0] <= h[1] && (uint64_t)h[1] - (uint64_t)h[0] < 0xffffffffULL) {
       plan.narrow = 1;
       plan.kmin = (uint64_t)h[0];
@@ -1468,7 +1468,7 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
   if (!narrow) RMM_TRY(sb->idx[0].alloc(sizeof(int32_t) * size1));
   GDF_TRY(launch_scatter1(fast, narrow, sc_threads, t, plan, g, nullptr, sb->tuples(0)));
   std::vector<uint32_t> c1(nseg + 1);
-  HIP_TRY(hipMemcpy(c1.data(), spec.p, sizeof(uint32_t) * (nseg + 1), hipMemcpyDeviceToHost));
+  HIP_TRY(read_back(c1.data(), spec.p, sizeof(uint32_t) * (nseg + 1)));
   if (c1[nseg]) return GDF_SUCCESS;
   sb->final_buf = 0;
   sb->fine_off.clear();
@@ -1501,8 +1501,8 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
     Level2Map m{d_coarse.as<uint32_t>(), d_coarse.as<uint32_t>() + nseg, d_tiles.as<uint32_t>(), g.xs};
     if (ntiles) GDF_TRY(launch_scatter2(narrow, sc2_threads, ntiles, g2, m, sb->tuples(0), cursor.as<uint32_t>(), sb->tuples(1)));
     uint32_t flag = 0;
-    HIP_TRY(hipMemcpy(cur.data(), cursor.p, sizeof(uint32_t) * nfine, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(&flag, g.spec_flag, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(read_back(cur.data(), cursor.p, sizeof(uint32_t) * nfine));
+    HIP_TRY(read_back(&flag, g.spec_flag, sizeof(uint32_t)));
     sb->w[0].reset();
     sb->idx[0].reset();
     if (flag) return GDF_SUCCESS;
@@ -1571,7 +1571,7 @@ static gdf_error run_write_pass(bool narrow, bool plain, size_t nunits, size_t l
 #undef JK_FAST_LAUNCH
   HIP_CHECK_LAST();
   unsigned long long left = 0;
-  HIP_TRY(hipMemcpy(&left, a.opt_state + 2, sizeof(left), hipMemcpyDeviceToHost));
+  HIP_TRY(read_back(&left, a.opt_state + 2, sizeof(left)));
   if (a.dbg & 256) fprintf(stderr, "jk_probe_fast: %llu of %zu units left to the general kernel\n", left, nunits);
   if (left) GDF_TRY(run_probe(narrow, true, "jk_probe_write_general", (size_t)left, lds, a, probe_t, build_t));
   HIP_TRY(hipStreamSynchronize(stream0()));      // `todo` goes out of scope
@@ -1709,7 +1709,7 @@ static gdf_error probe_prepared(const KeyTable &probe_t, const KeyTable &build_t
     sa.build_matched = nullptr;
     GDF_TRY(run_probe(narrow, false, "jk_probe_sample", nsample, probe_lds, sa, probe_t, build_t));
     std::vector<uint64_t> scount(nsample);
-    HIP_TRY(hipMemcpy(scount.data(), d_scount.p, sizeof(uint64_t) * nsample, hipMemcpyDeviceToHost));
+    HIP_TRY(read_back(scount.data(), d_scount.p, sizeof(uint64_t) * nsample));
     clk.mark("sample count");
     uint64_t sample_pairs = 0;
     for (uint64_t c : scount) sample_pairs += c;
@@ -1738,7 +1738,7 @@ static gdf_error probe_prepared(const KeyTable &probe_t, const KeyTable &build_t
       clk.mark("output allocation");
       GDF_TRY(run_write_pass(narrow, plain, nunits, probe_lds, oa, max_build, probe_t, build_t));
       unsigned long long st[2] = {0, 0};
-      HIP_TRY(hipMemcpy(st, d_state.p, sizeof(st), hipMemcpyDeviceToHost));
+      HIP_TRY(read_back(st, d_state.p, sizeof(st)));
       clk.mark("write pass");
       if (st[1] == 0 && st[0] == cap_pairs) {       // dense: every slot of every unit was written
         if (probe_tail) {
@@ -1789,7 +1789,7 @@ static gdf_error probe_prepared(const KeyTable &probe_t, const KeyTable &build_t
   // ---- sizes ----
   GDF_TRY(scan_u64(d_counts.as<uint64_t>(), d_counts.as<uint64_t>(), nslots_all + 1, false));
   uint64_t matched_total = 0;
-  HIP_TRY(hipMemcpy(&matched_total, d_counts.as<uint64_t>() + nslots_all, sizeof(uint64_t), hipMemcpyDeviceToHost));
+  HIP_TRY(read_back(&matched_total, d_counts.as<uint64_t>() + nslots_all, sizeof(uint64_t)));
   const uint64_t probe_tail = keep_probe ? (uint64_t)probe_t.nrows - P.joinable : 0;   // rows that cannot match
   uint64_t build_tail = 0;
   if (kind == JOIN_FULL) {
@@ -1798,7 +1798,7 @@ static gdf_error probe_prepared(const KeyTable &probe_t, const KeyTable &build_t
                        build_t.nrows, d_cnt);
     HIP_CHECK_LAST();
     unsigned long long h = 0;
-    HIP_TRY(hipMemcpy(&h, d_cnt, sizeof(h), hipMemcpyDeviceToHost));
+    HIP_TRY(read_back(&h, d_cnt, sizeof(h)));
     build_tail = h;
   }
   const uint64_t total = matched_total + probe_tail + build_tail;

@@ -7,6 +7,7 @@
 #include "common.h"
 
 #include <cstdio>
+#include <cstring>
 #include <roctracer/roctx.h>
 
 namespace gdf_amd {
@@ -31,6 +32,29 @@ gdf_error make_key_table(gdf_column **cols, int ncols, KeyTable *out) {
     if (cols[c]->valid) out->any_valid = 1;
   }
   return GDF_SUCCESS;
+}
+
+// Small device -> host read-backs (counters, flags, histograms) through a pinned staging buffer: hipMemcpy into
+// pageable memory takes the runtime's slow path, and a C3 join does eight of them between its kernels.
+hipError_t read_back(void *host_dst, const void *dev_src, size_t bytes) {
+  static thread_local void *pinned = nullptr;
+  static thread_local size_t capacity = 0;
+  if (bytes == 0) return hipSuccess;
+  if (bytes > capacity) {
+    if (pinned) (void)hipHostFree(pinned);
+    pinned = nullptr;
+    capacity = 0;
+    const size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
+    hipError_t e = hipHostMalloc(&pinned, want, hipHostMallocPortable);
+    if (e != hipSuccess) { pinned = nullptr; return hipMemcpy(host_dst, dev_src, bytes, hipMemcpyDeviceToHost); }   // still correct
+    capacity = want;
+  }
+  hipError_t e = hipMemcpyAsync(pinned, dev_src, bytes, hipMemcpyDeviceToHost, stream0());
+  if (e != hipSuccess) return e;
+  e = hipStreamSynchronize(stream0());
+  if (e != hipSuccess) return e;
+  std::memcpy(host_dst, pinned, bytes);
+  return hipSuccess;
 }
 
 }  // namespace gdf_amd

@@ -146,8 +146,17 @@ struct __attribute__((packed, aligned(8))) KeyPair8 { uint64_t a, b; };
 struct __attribute__((packed, aligned(4))) KeyPair4 { uint32_t a, b; };
 template <int FAST>
 __device__ __forceinline__ void fast_pair(const void *col, int64_t i, uint64_t &a, uint64_t &b) {
-  if (FAST == 4) { const KeyPair4 v = *(const KeyPair4 *)((const uint32_t *)col + i); a = v.a; b = v.b; }
-  else { const KeyPair8 v = *(const KeyPair8 *)((const uint64_t *)col + i); a = v.a; b = v.b; }
+  // read-once data: non-temporal, so that the key stream does not push the partially written lines of the scatter's
+  // write fronts out of L2 before the neighbouring run completes them
+  if (FAST == 4) {
+    const uint32_t *p = (const uint32_t *)col + i;
+    a = __builtin_nontemporal_load(p);
+    b = __builtin_nontemporal_load(p + 1);
+  } else {
+    const uint64_t *p = (const uint64_t *)col + i;
+    a = __builtin_nontemporal_load(p);
+    b = __builtin_nontemporal_load(p + 1);
+  }
 }
 template <int FAST>
 __device__ __forceinline__ bool fetch_key(const KeyTable &t, const KeyPlan &p, int64_t i, uint64_t &key) {
@@ -612,7 +621,7 @@ __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, 
   for (int k = 0; k < JK_SC_ITEMS; ++k) {         // all loads first
     const uint32_t i = begin + k * THREADS + threadIdx.x;
     const uint32_t ic = i < end ? i : end - 1;        // clamped, unconditional: see fetch_keys
-    w[k] = in.w[ic];
+    w[k] = in.w[ic];                                  // (non-temporal loads, which help jk_scatter1, cost 2 % here)
     idx[k] = NARROW ? 0 : in.idx[ic];
   }
   uint32_t binrank[JK_SC_ITEMS];

@@ -246,6 +246,14 @@ def test_multigpu_layer_world_size_one(gdf):
         c, d = sort_pairs(el, er)
         np.testing.assert_array_equal(a, c)
         np.testing.assert_array_equal(b, d)
+        # a rank may hold no rows of a relation
+        empty = torch.zeros(0, dtype=torch.int64, device="cuda")
+        assert multigpu.distributed_inner_join(empty, torch.from_numpy(build).cuda()).numel() == 0
+        assert multigpu.distributed_inner_join(torch.from_numpy(probe).cuda(), empty).numel() == 0
+        # keys too far apart for the 4-byte narrowing travel as 8 bytes
+        wide_b = torch.from_numpy(build).cuda() * (1 << 33)
+        wide_p = torch.from_numpy(probe).cuda() * (1 << 33)
+        assert multigpu.distributed_inner_join(wide_p, wide_b).numel() == len(el)
         k = torch.from_numpy(probe).cuda()
         v = torch.from_numpy((probe * 2 + 1).astype(np.int64)).cuda()
         gk, gv = multigpu.distributed_group_by_sum(k, v)

@@ -541,24 +541,24 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
     // keep the register count under the 128 a 1024-thread workgroup gets (the prefetched keys stay in registers)
     const uint32_t total = s.total;
     const uint32_t ftid = opaque_tid();
-    constexpr int HALF = 4;
+    constexpr int GROUP = 4;
 #pragma unroll
-    for (int h = 0; h < JK_SC_ITEMS / HALF; ++h) {
-      uint64_t ww[HALF];
-      int32_t ii[HALF];
-      uint32_t gb[HALF];
+    for (int h = 0; h < JK_SC_ITEMS / GROUP; ++h) {
+      uint64_t ww[GROUP];
+      int32_t ii[GROUP];
+      uint32_t gb[GROUP];
 #pragma unroll
-      for (int k = 0; k < HALF; ++k) {
-        const uint32_t j = ftid + (h * HALF + k) * THREADS;
+      for (int k = 0; k < GROUP; ++k) {
+        const uint32_t j = ftid + (h * GROUP + k) * THREADS;
         ww[k] = s.w[j];
         ii[k] = NARROW ? 0 : s.idx[j];
       }
 #pragma unroll
-      for (int k = 0; k < HALF; ++k)
+      for (int k = 0; k < GROUP; ++k)
         gb[k] = s.gbase[(fine_of(tup_key<NARROW>(ww[k]) + g.kbias, g.fb) >> g.b2) & 255u];
 #pragma unroll
-      for (int k = 0; k < HALF; ++k) {
-        const uint32_t j = ftid + (h * HALF + k) * THREADS;
+      for (int k = 0; k < GROUP; ++k) {
+        const uint32_t j = ftid + (h * GROUP + k) * THREADS;
         uint32_t dst = j < total ? gb[k] + j : g.dump + ftid;
         if (g.dbg & 4) dst &= 0xffffu;           // experiment: all stores land in a 512 KiB window
         if (g.dbg & 1) dst = g.dump + ftid;      // experiment: no useful stores

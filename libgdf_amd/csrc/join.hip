@@ -496,10 +496,8 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
       const uint32_t tid = opaque_tid();
       // speculative layout: the claim (a returning global atomic, ~2 us) is issued as soon as the counts are final and
       // collected after the scan, instead of sitting between two barriers on its own
-      // (not with 1024 threads: at its 128-register limit the carried value costs more in spills than the latency)
-      constexpr bool EARLY_CLAIM = THREADS < 1024;
       uint32_t base = 0;
-      if (EARLY_CLAIM && g.cap1 && tid < ncoarse) {
+      if (g.cap1 && tid < ncoarse) {
         const uint32_t cnt = s.hist[tid];
         if (cnt) base = atomicAdd(&g.spec_cursor1[(tid << g.xs) | (blockIdx.x & ((1u << g.xs) - 1u))], cnt);
       }
@@ -509,7 +507,6 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
         if (g.cap1) {
           const uint32_t cnt = s.hist[tid];
           const uint32_t region = (tid << g.xs) | (blockIdx.x & ((1u << g.xs) - 1u));
-          if (!EARLY_CLAIM && cnt) base = atomicAdd(&g.spec_cursor1[region], cnt);
           if (base + cnt > g.cap1) { atomicExch(g.spec_flag, 1u); s.gbase[tid] = g.dump - s.start[tid]; }
           else s.gbase[tid] = region * g.cap1 + base - s.start[tid];
         } else {
@@ -1304,7 +1301,7 @@ static gdf_error launch_scatter2(bool narrow, int threads, uint32_t ntiles, cons
 // Level 2 regroups 4096-tuple tiles, four workgroups per CU whose load / LDS / store phases overlap: since every fine
 // partition is written from one XCD (jk_scatter2), the partial lines of its short (tile, bin) runs merge in that L2.
 // Measured on C3, jk_scatter2 with 1024 / 512 / 256 threads: 3.6 / 3.3 / 3.2 ms.  Level 1 goes the other way
-// (3.9 vs 4.7 ms with 512 threads): its claims are on the critical path of a tile loop, it keeps one big tile per CU.
+// (3.7 vs 4.2 ms with 512 threads): its claims sit in a tile loop, it keeps one big tile per CU.
 static int level2_threads(int sc_threads) {
   static const int env = getenv("GDF_JK_SC2_THREADS") ? atoi(getenv("GDF_JK_SC2_THREADS")) : 0;
   if (env == 256 || env == 512 || env == 1024) return env < sc_threads ? env : sc_threads;

@@ -207,11 +207,15 @@ __global__ __launch_bounds__(RS_THREADS) void rs_count(const K *__restrict__ key
   constexpr int BINS = 1 << BITS;
   constexpr int ITEMS = TILE / RS_THREADS;
   __shared__ uint32_t h[BINS];
+  // same tile order as rs_scatter: XCD x counts the x-th eighth of the tiles.  counts[v][*] is written 4 bytes per
+  // tile; 32 consecutive tiles fill one of its 128-byte lines, and they meet in one L2 instead of eight
+  const uint32_t tile = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  if (tile >= ntiles) return;
   for (int j = threadIdx.x; j < BINS; j += RS_THREADS) h[j] = 0;
   block_sync();
   // counting needs no order: a thread takes ITEMS CONSECUTIVE keys with wide loads (a 4-byte key per load kept one
   // wave at 256 B in flight and this kernel at 1.6 TB/s on 32-bit keys)
-  const uint32_t first = blockIdx.x * TILE + threadIdx.x * ITEMS;
+  const uint32_t first = tile * TILE + threadIdx.x * ITEMS;
   if (first + ITEMS <= n) {
     K k[ITEMS];
     constexpr int WORDS = ITEMS * (int)sizeof(K) / 8;              // ITEMS * sizeof(K) is a multiple of 8 for both geometries
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_count(const K *__restrict__ key
       if (first + r < n) atomicAdd(&h[(uint32_t)(keys[first + r] >> shift) & (BINS - 1)], 1u);
   }
   block_sync();
-  for (int j = threadIdx.x; j < BINS; j += RS_THREADS) counts[(uint32_t)j * ntiles + blockIdx.x] = h[j];
+  for (int j = threadIdx.x; j < BINS; j += RS_THREADS) counts[(uint32_t)j * ntiles + tile] = h[j];
 }
 
 template <class K, class V, int BITS>
@@ -343,7 +347,7 @@ gdf_error radix_sort_pairs(K *&kin, K *&kout, V *&vin, V *&vout, uint32_t n, uin
   if (varying == 0 || n < 2) return GDF_SUCCESS;
   constexpr int TILE = RsGeom<V>::TILE;
   const uint32_t ntiles = (n + TILE - 1) / TILE;
-  const uint32_t xcd_grid = (ntiles + 7) / 8 * 8;        // rs_scatter: every XCD takes a contiguous eighth of the tiles
+  const uint32_t xcd_grid = (ntiles + 7) / 8 * 8;        // rs_count / rs_scatter: every XCD takes a contiguous eighth of the tiles
   const int lo = __builtin_ctzll(varying), hi = 64 - __builtin_clzll(varying);
   const int span = hi - lo;
   const int passes = (span + 8) / 9;
@@ -355,12 +359,12 @@ gdf_error radix_sort_pairs(K *&kin, K *&kout, V *&vin, V *&vout, uint32_t n, uin
     const int bits = bpp > 8 ? 9 : 8;
     if (((varying >> shift) & ((1ULL << bits) - 1)) == 0) continue;
     if (bits == 9) {
-      GDF_LAUNCH("rs_count", (rs_count<K, 9, TILE>), dim3(ntiles), dim3(RS_THREADS), 0, stream0(), (const K *)kin, n, shift, counts.as<uint32_t>(), ntiles);
+      GDF_LAUNCH("rs_count", (rs_count<K, 9, TILE>), dim3(xcd_grid), dim3(RS_THREADS), 0, stream0(), (const K *)kin, n, shift, counts.as<uint32_t>(), ntiles);
       GDF_TRY(scan_u32(counts.as<uint32_t>(), counts.as<uint32_t>(), (size_t)ntiles * 512, false));
       GDF_LAUNCH("rs_scatter", (rs_scatter<K, V, 9>), dim3(xcd_grid), dim3(RS_THREADS), 0, stream0(), (const K *)kin, (const V *)vin, kout, vout, n,
                  shift, (const uint32_t *)counts.as<uint32_t>(), ntiles);
     } else {
-      GDF_LAUNCH("rs_count", (rs_count<K, 8, TILE>), dim3(ntiles), dim3(RS_THREADS), 0, stream0(), (const K *)kin, n, shift, counts.as<uint32_t>(), ntiles);
+      GDF_LAUNCH("rs_count", (rs_count<K, 8, TILE>), dim3(xcd_grid), dim3(RS_THREADS), 0, stream0(), (const K *)kin, n, shift, counts.as<uint32_t>(), ntiles);
       GDF_TRY(scan_u32(counts.as<uint32_t>(), counts.as<uint32_t>(), (size_t)ntiles * 256, false));
       GDF_LAUNCH("rs_scatter", (rs_scatter<K, V, 8>), dim3(xcd_grid), dim3(RS_THREADS), 0, stream0(), (const K *)kin, (const V *)vin, kout, vout, n,
                  shift, (const uint32_t *)counts.as<uint32_t>(), ntiles);

@@ -448,6 +448,77 @@ __global__ __launch_bounds__(HP_THREADS) void shuffle_scatter_kernel(const KIN *
   }
 }
 
+// The same scatter with the batch regrouped by partition in LDS first (4-byte output keys: an LDS slot is the packed
+// (key, row) pair): a wave then stores 64 consecutive slots of ONE partition per instruction instead of a handful of
+// 4-byte pieces of every partition.  Same chunks and offsets as above.
+constexpr int SHT_ITEMS = 8;
+constexpr int SHT_TILE = HP_THREADS * SHT_ITEMS;
+constexpr int SHT_MAX_PARTS = 64;         // one wave scans the per-partition counts
+template <class KIN>
+__global__ __launch_bounds__(HP_THREADS) void shuffle_scatter_tile_kernel(const KIN *__restrict__ key, long long lo, unsigned long long span,
+                                                                           int32_t row_base, int64_t n, int64_t chunk, int nchunks,
+                                                                           uint32_t nparts, uint32_t pow2mask, int agg_bits,
+                                                                           const uint32_t *__restrict__ offs, uint32_t *__restrict__ out_key,
+                                                                           int32_t *__restrict__ out_row) {
+  __shared__ uint64_t stage[SHT_TILE];
+  __shared__ uint8_t bin_of[SHT_TILE];
+  __shared__ uint32_t cnt[SHT_MAX_PARTS], start[SHT_MAX_PARTS], gbase[SHT_MAX_PARTS], cursor[SHT_MAX_PARTS];
+  for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    if (threadIdx.x < nparts) cursor[threadIdx.x] = offs[(size_t)threadIdx.x * nchunks + c];
+    const int64_t begin = (int64_t)c * chunk;
+    const int64_t end = begin + chunk < n ? begin + chunk : n;
+    for (int64_t base = begin; base < end; base += SHT_TILE) {
+      if (threadIdx.x < SHT_MAX_PARTS) cnt[threadIdx.x] = 0;
+      KIN k[SHT_ITEMS];
+#pragma unroll
+      for (int j = 0; j < SHT_ITEMS; ++j) {
+        const int64_t i = base + (int64_t)j * HP_THREADS + threadIdx.x;
+        k[j] = key[i < end ? i : end - 1];
+      }
+      block_sync();
+      uint32_t kk[SHT_ITEMS], pr[SHT_ITEMS];          // narrowed key; partition << 16 | rank within (batch, partition)
+#pragma unroll
+      for (int j = 0; j < SHT_ITEMS; ++j) {
+        const bool live = base + (int64_t)j * HP_THREADS + threadIdx.x < end;
+        kk[j] = shuffle_key<KIN, uint32_t>(k[j], lo, span);
+        const uint32_t part = part_of(murmur3_32((uint64_t)kk[j], 4), nparts, pow2mask);
+        const uint32_t r = wave_aggregated_inc(cnt, part, agg_bits, live);
+        pr[j] = live ? (part << 16) | r : 0xffffffffu;
+      }
+      block_sync();
+      if (threadIdx.x < WAVE) {                       // exclusive scan of the counts by one wave
+        const uint32_t v = threadIdx.x < nparts ? cnt[threadIdx.x] : 0;
+        const uint32_t st = wave_scan_incl(v) - v;
+        if (threadIdx.x < nparts) {
+          start[threadIdx.x] = st;
+          gbase[threadIdx.x] = cursor[threadIdx.x] - st;
+          cursor[threadIdx.x] += v;
+        }
+      }
+      block_sync();
+#pragma unroll
+      for (int j = 0; j < SHT_ITEMS; ++j) {
+        if (pr[j] != 0xffffffffu) {
+          const uint32_t part = pr[j] >> 16, pos = start[part] + (pr[j] & 0xffffu);
+          const uint32_t row = (uint32_t)(row_base + (int32_t)(base + (int64_t)j * HP_THREADS + threadIdx.x));
+          stage[pos] = ((uint64_t)kk[j] << 32) | row;
+          bin_of[pos] = (uint8_t)part;
+        }
+      }
+      block_sync();
+      const uint32_t total = (uint32_t)(end - base < SHT_TILE ? end - base : SHT_TILE);
+      for (uint32_t j = threadIdx.x; j < total; j += HP_THREADS) {
+        const uint64_t tup = stage[j];
+        const uint32_t dst = gbase[bin_of[j]] + j;
+        out_key[dst] = (uint32_t)(tup >> 32);
+        out_row[dst] = (int32_t)(uint32_t)tup;
+      }
+      // the next batch's first barrier (after its loads) separates this flush from the next regroup
+    }
+    block_sync();
+  }
+}
+
 // gpu_hash_columns (src/hashops.cu:25-151): 64-bit FNV-1a over the little-endian bytes of every column's element,
 // columns in order.  The reference XORs each byte as a (signed) `char`, so a byte >= 0x80 is sign-extended to 64
 // bits before the XOR (hashops.cu:46-75) -- kept, it is what callers of the reference see.
@@ -612,10 +683,28 @@ gdf_error gdf_amd_shuffle_partition(gdf_column *keys, int narrow, int64_t lo, in
              (const KIN *)keys->data, llo, span, row_base, n, chunk, nchunks, P, pow2mask, agg_bits, hist.as<uint32_t>(),            \
              (KOUT *)out_keys->data, (int32_t *)out_rows->data);                                                                     \
   HIP_CHECK_LAST();
-  if (narrow) { SHUFFLE_PASSES(uint64_t, uint32_t) }
+  // 4-byte output keys and a fan-out of at most 64: the LDS-regrouped scatter (see shuffle_scatter_tile_kernel)
+  const bool tile_scatter = (narrow || win == 4) && P <= (uint32_t)SHT_MAX_PARTS && !getenv("GDF_HP_NO_SHUFFLE_TILE");
+  int tile_bits = 0;
+  while ((1u << tile_bits) < P) ++tile_bits;
+#define SHUFFLE_TILE_PASSES(KIN)                                                                                                    \
+  GDF_LAUNCH("shuffle_hist", (shuffle_hist_kernel<KIN, uint32_t>), dim3(grid), dim3(HP_THREADS), lds, stream0(),                     \
+             (const KIN *)keys->data, llo, span, n, chunk, nchunks, P, pow2mask, agg_bits, hist.as<uint32_t>());                    \
+  HIP_CHECK_LAST();                                                                                                                \
+  GDF_TRY(scan_u32(hist.as<uint32_t>(), hist.as<uint32_t>(), (size_t)P * nchunks, false));                                         \
+  hipLaunchKernelGGL(gather_strided_u32, dim3((P + 255) / 256), dim3(256), 0, stream0(), hist.as<uint32_t>(), starts.as<uint32_t>(), \
+                     (int)P, (size_t)nchunks);                                                                                     \
+  GDF_LAUNCH("shuffle_scatter", (shuffle_scatter_tile_kernel<KIN>), dim3(grid), dim3(HP_THREADS), 0, stream0(),                      \
+             (const KIN *)keys->data, llo, span, row_base, n, chunk, nchunks, P, pow2mask, tile_bits, hist.as<uint32_t>(),          \
+             (uint32_t *)out_keys->data, (int32_t *)out_rows->data);                                                               \
+  HIP_CHECK_LAST();
+  if (tile_scatter && narrow) { SHUFFLE_TILE_PASSES(uint64_t) }
+  else if (tile_scatter) { SHUFFLE_TILE_PASSES(uint32_t) }
+  else if (narrow) { SHUFFLE_PASSES(uint64_t, uint32_t) }
   else if (win == 8) { SHUFFLE_PASSES(uint64_t, uint64_t) }
   else { SHUFFLE_PASSES(uint32_t, uint32_t) }
 #undef SHUFFLE_PASSES
+#undef SHUFFLE_TILE_PASSES
   HIP_TRY(hipMemcpyAsync(partition_offsets, starts.p, sizeof(int) * P, hipMemcpyDeviceToHost, stream0()));
   HIP_TRY(hipStreamSynchronize(stream0()));
   return GDF_SUCCESS;

@@ -4,6 +4,7 @@ Cases follow the reference's gtest suite (tests/join/join-tests.cu:516-760): 1-5
 numeric dtype, EqualValues, MaxRandomValues, Left/RightColumnsBigger, Empty*, random valid masks on the
 inputs, and the size-limit checks.  Results are compared as SORTED (l, r) pair lists (:342-345)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -396,6 +397,37 @@ def test_speculative_matches_exact_at_scale(gdf, monkeypatch):
     a = torch.sort(li.long() * nb + ri.long()).values
     c = torch.sort(le.long() * nb + re_.long()).values
     assert torch.equal(a, c)
+
+
+@pytest.mark.parametrize("how", ["inner", "left", "full"])
+@pytest.mark.parametrize("dtypes", [[np.int64, np.int32], [np.int32, np.int16, np.int8], [np.int64, np.int64], [np.int8, np.int64]],
+                         ids=lambda d: "-".join(np.dtype(x).name for x in d))
+def test_range_packed_multi_column_keys(gdf, how, dtypes):
+    """Several integer key columns are packed as (value - build minimum) fields (plan_ranged in csrc/join.hip): probe
+    values below / above the build range of a column, negative values and nulls must behave exactly as in the oracle;
+    GDF_JK_NO_RANGED (hashed key + row comparison) is the same join."""
+    rs = np.random.RandomState(11)
+    nb, npr = 6000, 20000
+    build, probe = [], []
+    for i, dt in enumerate(dtypes):
+        info = np.iinfo(dt)
+        lo, hi = max(info.min, -40 - 10 * i), min(info.max, 45 + 10 * i)
+        build.append(rs.randint(lo + 10, hi - 10, size=nb).astype(dt))            # build range strictly inside the probe range
+        probe.append(rs.randint(lo, hi, size=npr).astype(dt))
+    bvalid = [None if i else (rs.rand(nb) > 0.05) for i in range(len(dtypes))]
+    pvalid = [(rs.rand(npr) > 0.05) if i == len(dtypes) - 1 else None for i in range(len(dtypes))]
+    n1 = _check(gdf, probe, build, how, pvalid, bvalid)
+    assert n1 > 0
+    os.environ["GDF_JK_NO_RANGED"] = "1"
+    try:
+        assert _check(gdf, probe, build, how, pvalid, bvalid) == n1
+    finally:
+        del os.environ["GDF_JK_NO_RANGED"]
+    if dtypes == [np.int64, np.int64]:
+        # ranges that do not fit 64 bits together keep the hashed plan
+        wide_b = [b.astype(np.int64) * (1 << 40) for b in build]
+        wide_p = [q.astype(np.int64) * (1 << 40) for q in probe]
+        _check(gdf, wide_p, wide_b, how)
 
 
 @pytest.mark.parametrize("how", ["inner", "left"])

@@ -210,6 +210,53 @@ __device__ __forceinline__ void fetch_keys(const KeyTable &t, const KeyPlan &p, 
       key[k] -= p.kmin;
       ok[k] = (i0 + k * stride < end) && (!p.narrow || (key[k] >> 32) == 0);
     }
+  } else if (p.mode == KM_PACKED && p.ranged) {
+    // several integer columns packed by range (plan_ranged): column by column, the N elements of a column requested
+    // together from clamped row numbers -- make_key() row by row is one dependent load at a time
+    int64_t row[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const int64_t i = i0 + k * stride;
+      ok[k] = i < end;
+      row[k] = ok[k] ? i : end - 1;
+      key[k] = 0;
+    }
+    for (int c = 0; c < t.ncols; ++c) {
+      long long v[N];
+      const void *data = t.col[c].data;
+      switch (t.col[c].width) {
+        case 1:
+#pragma unroll
+          for (int k = 0; k < N; ++k) v[k] = ((const int8_t *)data)[row[k]];
+          break;
+        case 2:
+#pragma unroll
+          for (int k = 0; k < N; ++k) v[k] = ((const int16_t *)data)[row[k]];
+          break;
+        case 4:
+#pragma unroll
+          for (int k = 0; k < N; ++k) v[k] = ((const int32_t *)data)[row[k]];
+          break;
+        default:
+#pragma unroll
+          for (int k = 0; k < N; ++k) v[k] = ((const long long *)data)[row[k]];
+      }
+      const int bits = p.bits[c], shift = p.shift[c];
+      const long long bias = p.bias[c];
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        const uint64_t u = (uint64_t)(v[k] - bias);
+        ok[k] = ok[k] && (bits >= 64 || (u >> bits) == 0);
+        key[k] |= u << shift;
+      }
+      if (t.col[c].valid) {
+        uint8_t m[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) m[k] = t.col[c].valid[row[k] >> 3];
+#pragma unroll
+        for (int k = 0; k < N; ++k) ok[k] = ok[k] && ((m[k] >> (row[k] & 7)) & 1);
+      }
+    }
   } else {
 #pragma unroll
     for (int k = 0; k < N; ++k) {

@@ -765,11 +765,12 @@ static gdf_error write_output_masks(int ncols, gdf_column **out_keys, gdf_column
 }
 
 // integer key columns too wide for the natural layout: try (value - min) in bit_length(max - min) bits
-static gdf_error gb_plan_range(const KeyTable &t, GbKeyPlan *plan) {
+static gdf_error gb_plan_range(const KeyTable &t, GbKeyPlan *plan, std::vector<long long> *ranges_out = nullptr) {
   for (int c = 0; c < t.ncols; ++c)
     if (t.col[c].kind == K_F32 || t.col[c].kind == K_F64) return GDF_SUCCESS;
   std::vector<long long> h(2 * t.ncols);
   GDF_TRY(key_ranges(t, h.data()));
+  if (ranges_out) *ranges_out = h;          // the direct path wants the same numbers: one pass over the keys, not two
   int total = 0;
   GbKeyPlan p{};
   for (int c = 0; c < t.ncols; ++c) {
@@ -821,7 +822,7 @@ __device__ __forceinline__ uint32_t direct_id(const KeyTable &t, const GbDirect 
   return inside ? id : 0xffffffffu;
 }
 
-template <bool FASTKEY, bool FASTVAL>
+template <int FASTKEY, bool FASTVAL>      // FASTKEY = 8 / 4: one int64 / int32 key column read directly, 0: direct_id()
 __global__ __launch_bounds__(GB_DENSE_THREADS) void gb_direct_aggregate(KeyTable t, GbDirect d, GbVal val, int op,
                                                                         unsigned long long *gacc, unsigned long long *gcnt,
                                                                         int64_t chunk, unsigned int *outside) {
@@ -843,7 +844,8 @@ __global__ __launch_bounds__(GB_DENSE_THREADS) void gb_direct_aggregate(KeyTable
       const int64_t i = base + (int64_t)k * GB_DENSE_THREADS + threadIdx.x;
       const int64_t ic = i < end ? i : end - 1;
       if (FASTKEY) {
-        const uint64_t off = (uint64_t)(((const long long *)t.col[0].data)[ic] - lo0);
+        const long long kv = FASTKEY == 8 ? ((const long long *)t.col[0].data)[ic] : (long long)((const int32_t *)t.col[0].data)[ic];
+        const uint64_t off = (uint64_t)(kv - lo0);
         id[k] = off < d.total ? (uint32_t)off : 0xffffffffu;
       } else {
         id[k] = direct_id(t, d, ic);
@@ -1165,6 +1167,7 @@ struct GbJob {
   bool counted;     // a per-group count of (valid) values is kept: AVG, or a masked value column
   bool want_ok;     // the caller supplied out_col_agg->valid and groups can come out null
   DevBuf agg_ok;
+  std::vector<long long> ranges;   // [2 * ncols] exact min / max per key column when gb_plan_range already took them
 };
 
 // Path 1 -- direct index: integer keys with a small value range, no masks.  *done = false: not applicable.
@@ -1193,7 +1196,8 @@ static gdf_error gb_path_direct(GbJob &j, bool *done) {
       std::vector<long long> h(2 * ncols);
       KeyTable tr = t;
       if (attempt == 0) tr.nrows = 1 << 16;
-      GDF_TRY(key_ranges(tr, h.data()));
+      if (attempt == 1 && j.ranges.size() == h.size()) h = j.ranges;
+      else GDF_TRY(key_ranges(tr, h.data()));
       GbDirect d{};
       d.ncols = ncols;
       uint64_t total = 1;
@@ -1228,7 +1232,7 @@ static gdf_error gb_path_direct(GbJob &j, bool *done) {
       const int agrid = stream_grid((size_t)n, GB_DENSE_THREADS * GB_DENSE_BATCH, NUM_CU);
       const int64_t achunk = (((n + agrid - 1) / agrid) + GB_DENSE_THREADS - 1) / GB_DENSE_THREADS * GB_DENSE_THREADS;
       const size_t dlds = (size_t)d.total * 12 + 16;
-      const bool fastkey = ncols == 1 && t.col[0].width == 8;
+      const int fastkey = ncols == 1 && (t.col[0].width == 8 || t.col[0].width == 4) ? t.col[0].width : 0;
       const bool fastval = op != OP_COUNT && kind_width(in_kind) == 8;
 #define GB_DIRECT_LAUNCH(FK, FV)                                                                                             \
   do {                                                                                                                       \
@@ -1236,10 +1240,12 @@ static gdf_error gb_path_direct(GbJob &j, bool *done) {
     GDF_LAUNCH("gb_direct_aggregate", (gb_direct_aggregate<FK, FV>), dim3(agrid), dim3(GB_DENSE_THREADS), dlds, stream0(), t, d, val, op, \
                gacc.as<unsigned long long>(), gcnt.as<unsigned long long>(), achunk, ng.as<unsigned int>() + 1);             \
   } while (0)
-      if (fastkey && fastval) GB_DIRECT_LAUNCH(true, true);
-      else if (fastkey) GB_DIRECT_LAUNCH(true, false);
-      else if (fastval) GB_DIRECT_LAUNCH(false, true);
-      else GB_DIRECT_LAUNCH(false, false);
+      if (fastkey == 8 && fastval) GB_DIRECT_LAUNCH(8, true);
+      else if (fastkey == 8) GB_DIRECT_LAUNCH(8, false);
+      else if (fastkey == 4 && fastval) GB_DIRECT_LAUNCH(4, true);
+      else if (fastkey == 4) GB_DIRECT_LAUNCH(4, false);
+      else if (fastval) GB_DIRECT_LAUNCH(0, true);
+      else GB_DIRECT_LAUNCH(0, false);
 #undef GB_DIRECT_LAUNCH
       GbOut o{};
       o.ncols = ncols;
@@ -1702,7 +1708,7 @@ static gdf_error group_by_hash(int ncols, gdf_column **cols, gdf_column *col_agg
   j.in_kind = in_kind;
   j.out_kind = out_kind;
   j.plan = gb_plan_keys(t);
-  if (!j.plan.packed) GDF_TRY(gb_plan_range(t, &j.plan));
+  if (!j.plan.packed) GDF_TRY(gb_plan_range(t, &j.plan, &j.ranges));
   j.val = GbVal{col_agg->data, (int)(op == OP_COUNT ? K_I8 : in_kind), (const uint8_t *)col_agg->valid};
   // Validity masks (beyond the reference, which rejects them: sqls_ops.cu:1103-1106; semantics of
   // SURVEY.md 8d C5 = pandas dropna): a row with a null in any key column is dropped; a null value is

@@ -80,15 +80,37 @@ __device__ __forceinline__ int64_t load_signed(const ColView &c, int64_t i) {
 }
 __device__ __forceinline__ uint64_t low_mask(int bits) { return bits >= 64 ? ~0ULL : ((1ULL << bits) - 1ULL); }
 
+// Float key columns take part in the packed-key paths through a signed integer IMAGE that orders like the values
+// and equals iff the values are == : -0.0 is folded onto +0.0, negative values have their magnitude bits flipped.
+// NaN has no such image (NaN != NaN: every NaN row is its own group): gb_plan_range declines when it meets one.
+__host__ __device__ __forceinline__ long long f64_image(uint64_t b) {
+  if ((b << 1) == 0) b = 0;
+  const long long s = (long long)b;
+  return s ^ ((s >> 63) & 0x7fffffffffffffffLL);
+}
+__host__ __device__ __forceinline__ long long f32_image(uint32_t b) {
+  if ((uint32_t)(b << 1) == 0) b = 0;
+  const int32_t s = (int32_t)b;
+  return (long long)(s ^ ((s >> 31) & 0x7fffffff));
+}
+// the element of key column c at row i as a signed 64-bit number (integers: the value; floats: the image)
+__device__ __forceinline__ long long load_key_image(const ColView &c, int64_t i) {
+  if (c.kind == K_F64) return f64_image(((const uint64_t *)c.data)[i]);
+  if (c.kind == K_F32) return f32_image(((const uint32_t *)c.data)[i]);
+  return load_signed(c, i);
+}
+
 __device__ __forceinline__ uint64_t gb_pack(const KeyTable &t, const GbKeyPlan &p, int64_t i) {
   uint64_t k = 0;
   for (int c = 0; c < t.ncols; ++c)
-    k |= ((uint64_t)(load_signed(t.col[c], i) - p.bias[c]) & low_mask(p.bits[c])) << p.shift[c];
+    k |= ((uint64_t)(load_key_image(t.col[c], i) - p.bias[c]) & low_mask(p.bits[c])) << p.shift[c];
   return k;
 }
 // inverse of gb_pack for column c, stored at the column's width
 __device__ __forceinline__ void gb_unpack_store(const KeyTable &t, const GbKeyPlan &p, uint64_t key, int c, void *out, int64_t pos) {
-  const uint64_t bits = ((key >> p.shift[c]) & low_mask(p.bits[c])) + (uint64_t)p.bias[c];
+  uint64_t bits = ((key >> p.shift[c]) & low_mask(p.bits[c])) + (uint64_t)p.bias[c];
+  if (t.col[c].kind == K_F64) { const long long img = (long long)bits; bits = (uint64_t)(img ^ ((img >> 63) & 0x7fffffffffffffffLL)); }
+  if (t.col[c].kind == K_F32) { const int32_t img = (int32_t)(long long)bits; bits = (uint32_t)(img ^ ((img >> 31) & 0x7fffffff)); }
   switch (t.col[c].width) {
     case 1: ((uint8_t *)out)[pos] = (uint8_t)bits; break;
     case 2: ((uint16_t *)out)[pos] = (uint16_t)bits; break;
@@ -765,12 +787,52 @@ static gdf_error write_output_masks(int ncols, gdf_column **out_keys, gdf_column
 }
 
 // integer key columns too wide for the natural layout: try (value - min) in bit_length(max - min) bits
+// min / max of the key IMAGES of every column over the rows whose element is valid, and whether a NaN was seen
+__global__ __launch_bounds__(256) void gb_image_ranges(KeyTable t, long long *out, unsigned int *has_nan) {
+  for (int c = 0; c < t.ncols; ++c) {
+    long long lo = 0x7fffffffffffffffLL, hi = (long long)0x8000000000000000ULL;
+    bool nan = false;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < t.nrows; i += (int64_t)gridDim.x * 256) {
+      if (t.col[c].valid && !bit_is_set(t.col[c].valid, i)) continue;
+      if (t.col[c].kind == K_F64) nan = nan || (((const uint64_t *)t.col[c].data)[i] & 0x7fffffffffffffffULL) > 0x7ff0000000000000ULL;
+      if (t.col[c].kind == K_F32) nan = nan || (((const uint32_t *)t.col[c].data)[i] & 0x7fffffffu) > 0x7f800000u;
+      const long long v = load_key_image(t.col[c], i);
+      lo = v < lo ? v : lo;
+      hi = v > hi ? v : hi;
+    }
+    for (int d = 1; d < WAVE; d <<= 1) {
+      const long long l2 = ((long long)__shfl_xor((int)(lo >> 32), d) << 32) | (unsigned int)__shfl_xor((int)lo, d);
+      const long long h2 = ((long long)__shfl_xor((int)(hi >> 32), d) << 32) | (unsigned int)__shfl_xor((int)hi, d);
+      lo = l2 < lo ? l2 : lo;
+      hi = h2 > hi ? h2 : hi;
+    }
+    if (lane_id() == 0) { atomicMin(&out[2 * c], lo); atomicMax(&out[2 * c + 1], hi); }
+    if (__ballot(nan) && lane_id() == 0) atomicExch(has_nan, 1u);
+  }
+}
+
 static gdf_error gb_plan_range(const KeyTable &t, GbKeyPlan *plan, std::vector<long long> *ranges_out = nullptr) {
-  for (int c = 0; c < t.ncols; ++c)
-    if (t.col[c].kind == K_F32 || t.col[c].kind == K_F64) return GDF_SUCCESS;
+  bool any_float = false;
+  for (int c = 0; c < t.ncols; ++c) any_float = any_float || t.col[c].kind == K_F32 || t.col[c].kind == K_F64;
   std::vector<long long> h(2 * t.ncols);
-  GDF_TRY(key_ranges(t, h.data()));
-  if (ranges_out) *ranges_out = h;          // the direct path wants the same numbers: one pass over the keys, not two
+  if (any_float) {
+    if (getenv("GDF_GB_NO_FLOAT_IMAGE") || t.nrows == 0) return GDF_SUCCESS;
+    for (int c = 0; c < t.ncols; ++c) { h[2 * c] = 0x7fffffffffffffffLL; h[2 * c + 1] = (long long)0x8000000000000000ULL; }
+    DevBuf mm;
+    RMM_TRY(mm.alloc(sizeof(long long) * 2 * t.ncols + sizeof(unsigned int)));
+    HIP_TRY(hipMemcpyAsync(mm.p, h.data(), sizeof(long long) * 2 * t.ncols, hipMemcpyHostToDevice, stream0()));
+    unsigned int *d_nan = (unsigned int *)(mm.as<long long>() + 2 * t.ncols);
+    HIP_TRY(hipMemsetAsync(d_nan, 0, sizeof(unsigned int), stream0()));
+    GDF_LAUNCH("gb_image_ranges", gb_image_ranges, dim3(stream_grid((size_t)t.nrows, 256 * 16)), dim3(256), 0, stream0(), t, mm.as<long long>(), d_nan);
+    HIP_CHECK_LAST();
+    unsigned int has_nan = 0;
+    HIP_TRY(hipMemcpy(h.data(), mm.p, sizeof(long long) * 2 * t.ncols, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&has_nan, d_nan, sizeof(has_nan), hipMemcpyDeviceToHost));
+    if (has_nan) return GDF_SUCCESS;        // NaN keys: every NaN row is a group of its own, only the row-comparing path does that
+  } else {
+    GDF_TRY(key_ranges(t, h.data()));
+    if (ranges_out) *ranges_out = h;        // the direct path wants the same numbers: one pass over the keys, not two
+  }
   int total = 0;
   GbKeyPlan p{};
   for (int c = 0; c < t.ncols; ++c) {
@@ -1302,7 +1364,7 @@ static gdf_error gb_path_dense(GbJob &j, bool *done) {
     g.overflow = flags.as<unsigned int>() + 1;
     g.special = flags.as<unsigned int>() + 2;
     const uint32_t max_groups = avg ? GB_DENSE_MAX_GROUPS_AVG : GB_DENSE_MAX_GROUPS;
-    const bool fastkey = !masked && t.ncols == 1 && t.col[0].width == 8 && plan.bits[0] == 64 && plan.bias[0] == 0;
+    const bool fastkey = !masked && t.ncols == 1 && t.col[0].kind == K_I64 && plan.bits[0] == 64 && plan.bias[0] == 0;
     g.limit = max_groups;                       // more distinct keys than this: stop early, use the general path
     GDF_LAUNCH("gb_fill", gb_dict_clear, dim3(stream_grid(T + 1, 256 * 8)), dim3(256), 0, stream0(), g.e, (uint32_t)(T + 1));
     const int bgrid = stream_grid((size_t)n, GB_DICT_THREADS * GB_DENSE_BATCH * 4, NUM_CU * 8);

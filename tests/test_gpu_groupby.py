@@ -319,3 +319,48 @@ def test_direct_path_guessed_window(gdf, case):
         k[100_000:] = gen_rand(np.int64, n - 100_000, 0, 50000)
     for op in ("sum", "avg", "min"):
         _check(gdf, op, [k], gen_rand(np.int64, n), np.float64 if op == "avg" else None)
+
+
+@pytest.mark.parametrize("op", ["sum", "count", "min", "avg"])
+@pytest.mark.parametrize("kdt", [np.float64, np.float32], ids=lambda d: np.dtype(d).name)
+def test_float_keys_take_the_packed_paths(gdf, op, kdt, monkeypatch):
+    """Float key columns enter the packed-key paths through an order-preserving integer image (csrc/groupby.hip,
+    f64_image): -0.0 and +0.0 are one group, +-inf and denormals are ordinary keys; few groups (dictionary path) and
+    many groups (sorted path); the row-comparing path (GDF_GB_NO_FLOAT_IMAGE) gives the same groups."""
+    rs = np.random.RandomState(3)
+    n = 60000
+    special = np.array([0.0, -0.0, np.inf, -np.inf, 5e-324 if kdt == np.float64 else 1e-45, -1.5, 1.5, 1e30, -1e30], dtype=kdt)
+    few = np.concatenate([special[rs.randint(0, len(special), size=n // 2)], (rs.randint(-50, 50, size=n // 2) * 0.25).astype(kdt)])
+    many = (rs.randint(-20000, 20000, size=n) * 0.125).astype(kdt)
+    vals = gen_rand(np.int64, n, -1000, 1000)
+    out = np.int64 if op == "count" else (np.float64 if op == "avg" else None)
+    for keys in (few, many):
+        gk, ga = _run(gdf, op, [keys], vals, out)
+        _check(gdf, op, [keys], vals, out)
+        monkeypatch.setenv("GDF_GB_NO_FLOAT_IMAGE", "1")
+        rk, ra = _run(gdf, op, [keys], vals, out)
+        monkeypatch.delenv("GDF_GB_NO_FLOAT_IMAGE")
+        (gk, ga), (rk, ra) = sort_groups(gk, ga), sort_groups(rk, ra)
+        np.testing.assert_array_equal(gk[0], rk[0])
+        np.testing.assert_array_equal(ga, ra)
+    # (float, int) two-column keys, with a mask on the float column
+    k1 = gen_rand(np.int32, n, 0, 6)
+    _check(gdf, op, [many[: n // 4] * 0 + few[: n // 4], k1[: n // 4]], vals[: n // 4], out)
+
+
+def test_float_keys_with_nan_keep_one_group_per_nan_row(gdf):
+    """NaN != NaN: every NaN key row is a group of its own (the reference's typed ==).  Such inputs keep the row-comparing
+    path; the number of groups is what the oracle says."""
+    rs = np.random.RandomState(4)
+    n = 20000
+    keys = (rs.randint(0, 50, size=n) * 0.5).astype(np.float64)
+    keys[rs.choice(n, size=37, replace=False)] = np.nan
+    vals = gen_rand(np.int64, n, 0, 100)
+    gk, ga = _run(gdf, "sum", [keys], vals)
+    ek, ea = oracle.group_by("sum", [keys], vals)
+    assert len(ga) == len(ea) == 50 + 37
+    assert int(np.isnan(gk[0]).sum()) == 37
+    order = np.argsort(gk[0][~np.isnan(gk[0])])
+    np.testing.assert_array_equal(gk[0][~np.isnan(gk[0])][order], ek[0][~np.isnan(ek[0])])
+    np.testing.assert_array_equal(ga[~np.isnan(gk[0])][order], ea[~np.isnan(ek[0])])
+    assert sorted(ga[np.isnan(gk[0])].tolist()) == sorted(ea[np.isnan(ek[0])].tolist())

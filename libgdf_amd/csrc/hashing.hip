@@ -216,17 +216,18 @@ __global__ __launch_bounds__(HP_THREADS) void part_scatter_fast_kernel(const K *
 }
 
 // P <= 256: LDS-regrouped scatter.  Same offsets contract as part_scatter_kernel.
-constexpr int HPT_ITEMS = 8;
-constexpr int HPT_TILE = HP_THREADS * HPT_ITEMS;
+constexpr int HPT_MAX_ITEMS = 16;         // rows per thread and tile: 16 with a directly read key column, 8 with the generic row hash
 constexpr int HPT_MAX_PARTS = 256;
 
 template <bool MURMUR, int FASTW>      // FASTW = 8 / 4: one key column of that width read directly; 0: generic hash_row
 __global__ __launch_bounds__(HP_THREADS) void part_scatter_tile_kernel(KeyTable t, PayloadCols pc, int64_t n, int64_t chunk,
                                                                        int nchunks, uint32_t nparts, uint32_t pow2mask,
                                                                        const uint32_t *__restrict__ offs) {
+  constexpr int HPT_ITEMS = FASTW ? HPT_MAX_ITEMS : HPT_MAX_ITEMS / 2;      // (16 generic hashes per thread spill)
+  constexpr int HPT_TILE = HP_THREADS * HPT_ITEMS;
   __shared__ uint64_t stage[HPT_TILE];
   __shared__ uint16_t bin_of[HPT_TILE];
-  __shared__ uint32_t hist[HPT_MAX_PARTS], start[HPT_MAX_PARTS], gbase[HPT_MAX_PARTS], cursor[HPT_MAX_PARTS];
+  __shared__ uint32_t hist[HPT_MAX_PARTS + 1], start[HPT_MAX_PARTS], gbase[HPT_MAX_PARTS], cursor[HPT_MAX_PARTS];
   __shared__ uint32_t wave_tot[HP_THREADS / WAVE];
   for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
     if (threadIdx.x < nparts) cursor[threadIdx.x] = offs[(size_t)threadIdx.x * nchunks + c];
@@ -245,13 +246,15 @@ __global__ __launch_bounds__(HP_THREADS) void part_scatter_tile_kernel(KeyTable 
         kk[k] = FASTW == 8 ? ((const uint64_t *)t.col[0].data)[src[k]] : (FASTW == 4 ? (uint64_t)((const uint32_t *)t.col[0].data)[src[k]] : 0);
       }
 #pragma unroll
+      for (int k = 0; k < HPT_ITEMS; ++k) {      // rows beyond the chunk are ranked on a trash counter: no branch around the
+        const int64_t i = tile + (int64_t)k * HP_THREADS + threadIdx.x;       // atomic, all of them in flight together
+        const uint32_t p = part_of(FASTW ? murmur3_32(kk[k], FASTW) : hash_row<MURMUR>(t, src[k]), nparts, pow2mask);
+        pr[k] = i < end ? p : (uint32_t)HPT_MAX_PARTS;
+      }
+#pragma unroll
       for (int k = 0; k < HPT_ITEMS; ++k) {
-        const int64_t i = tile + (int64_t)k * HP_THREADS + threadIdx.x;
-        pr[k] = 0xffffffffu;
-        if (i < end) {
-          const uint32_t p = part_of(FASTW ? murmur3_32(kk[k], FASTW) : hash_row<MURMUR>(t, i), nparts, pow2mask);
-          pr[k] = (p << 16) | atomicAdd(&hist[p], 1u);
-        }
+        const uint32_t r = atomicAdd(&hist[pr[k]], 1u);
+        pr[k] = pr[k] == (uint32_t)HPT_MAX_PARTS ? 0xffffffffu : (pr[k] << 16) | r;
       }
       block_sync();
       {   // exclusive scan of hist[0..nparts) by the 256 threads

@@ -77,8 +77,8 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_join_and_groupby_match_single_process():
-    world = 2
+@pytest.mark.parametrize("world", [2, 3])           # 3: the rank of a key is hash % world, not a mask
+def test_multi_rank_join_and_groupby_match_single_process(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

@@ -182,12 +182,27 @@ __device__ __forceinline__ void fast_pair(const void *col, int64_t i, uint64_t &
     b = __builtin_nontemporal_load(p + 1);
   }
 }
+// FAST reads of a float key column (KM_RAW_FLOAT): the raw word becomes the canonical bits of float_bits() --
+// -0.0 -> +0.0 -- and the return value says whether it can join at all (NaN cannot)
+template <int FAST>
+__device__ __forceinline__ bool fast_float_word(uint64_t &w) {
+  if (FAST == 4) {
+    if (((uint32_t)w & 0x7fffffffu) > 0x7f800000u) return false;
+    if ((uint32_t)((uint32_t)w << 1) == 0) w = 0;
+  } else {
+    if ((w & 0x7fffffffffffffffULL) > 0x7ff0000000000000ULL) return false;
+    if ((w << 1) == 0) w = 0;
+  }
+  return true;
+}
 template <int FAST>
 __device__ __forceinline__ bool fetch_key(const KeyTable &t, const KeyPlan &p, int64_t i, uint64_t &key) {
   if (FAST) {
-    const uint64_t k = fast_word<FAST>(t.col[0].data, i) - p.kmin;
+    uint64_t w = fast_word<FAST>(t.col[0].data, i);
+    const bool joinable = p.mode != KM_RAW_FLOAT || fast_float_word<FAST>(w);
+    const uint64_t k = w - p.kmin;
     key = k;
-    return !p.narrow || (k >> 32) == 0;
+    return joinable && (!p.narrow || (k >> 32) == 0);
   }
   return make_key(t, p, i, key);
 }
@@ -207,8 +222,9 @@ __device__ __forceinline__ void fetch_keys(const KeyTable &t, const KeyPlan &p, 
     }
 #pragma unroll
     for (int k = 0; k < N; ++k) {
+      const bool joinable = p.mode != KM_RAW_FLOAT || fast_float_word<FAST>(key[k]);
       key[k] -= p.kmin;
-      ok[k] = (i0 + k * stride < end) && (!p.narrow || (key[k] >> 32) == 0);
+      ok[k] = joinable && (i0 + k * stride < end) && (!p.narrow || (key[k] >> 32) == 0);
     }
   } else if (p.mode == KM_PACKED && p.ranged) {
     // several integer columns packed by range (plan_ranged): column by column, the N elements of a column requested
@@ -533,10 +549,11 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
     okmask = 0;
 #pragma unroll
     for (int k = 0; k < JK_SC_ITEMS; ++k) {
-      const uint64_t raw = ((k & 1) == 0 && tile + item_row(k, tid) + 1 == end) ? nxt[k + 1] : nxt[k];
+      uint64_t raw = ((k & 1) == 0 && tile + item_row(k, tid) + 1 == end) ? nxt[k + 1] : nxt[k];
+      const bool joinable = plan.mode != KM_RAW_FLOAT || fast_float_word<FAST ? FAST : 8>(raw);
       const uint64_t k64 = raw - plan.kmin;
       key[k] = (KeyReg)k64;
-      okmask |= (uint32_t)((tile + item_row(k, tid) < end) && (!plan.narrow || (k64 >> 32) == 0)) << k;
+      okmask |= (uint32_t)(joinable && (tile + item_row(k, tid) < end) && (!plan.narrow || (k64 >> 32) == 0)) << k;
     }
   };
   if (FAST) consume(begin);
@@ -1374,7 +1391,7 @@ static gdf_error launch_scatter1(int fast, bool narrow, int threads, const KeyTa
 }
 // 8 / 4: the relation is one unmasked raw integer column of that width (direct column reads); 0: generic key construction
 static int fast_key_width(const KeyTable &t, const KeyPlan &plan) {
-  if (t.ncols != 1 || plan.mode != KM_RAW_INT || t.any_valid || t.nrows < 2) return 0;   // jk_scatter1 loads row pairs
+  if (t.ncols != 1 || (plan.mode != KM_RAW_INT && plan.mode != KM_RAW_FLOAT) || t.any_valid || t.nrows < 2) return 0;   // jk_scatter1 loads row pairs
   if (t.col[0].width == 8) return 8;
   if (t.col[0].width == 4 && plan.narrow && plan.kmin == 0) return 4;
   return 0;

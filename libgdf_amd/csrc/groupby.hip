@@ -884,7 +884,9 @@ __device__ __forceinline__ uint32_t direct_id(const KeyTable &t, const GbDirect 
   return inside ? id : 0xffffffffu;
 }
 
-template <int FASTKEY, bool FASTVAL>      // FASTKEY = 8 / 4: one int64 / int32 key column read directly, 0: direct_id()
+// FASTKEY = 8 / 4: one int64 / int32 key column read directly, 0: direct_id().  FASTVAL = 8 / 4: an 8- / 4-byte value
+// column read directly (integer or float by val.kind) and widened to the 64-bit accumulator image in registers, 0: acc_image()
+template <int FASTKEY, int FASTVAL>
 __global__ __launch_bounds__(GB_DENSE_THREADS) void gb_direct_aggregate(KeyTable t, GbDirect d, GbVal val, int op,
                                                                         unsigned long long *gacc, unsigned long long *gcnt,
                                                                         int64_t chunk, unsigned int *outside) {
@@ -912,11 +914,13 @@ __global__ __launch_bounds__(GB_DENSE_THREADS) void gb_direct_aggregate(KeyTable
       } else {
         id[k] = direct_id(t, d, ic);
       }
-      img[k] = FASTVAL ? ((const uint64_t *)val.data)[ic] : acc_image(fold_op, val, ic);
+      img[k] = FASTVAL == 8 ? ((const uint64_t *)val.data)[ic] : (FASTVAL == 4 ? (uint64_t)((const uint32_t *)val.data)[ic] : acc_image(fold_op, val, ic));
     }
     if (FASTVAL) {
 #pragma unroll
       for (int k = 0; k < GB_DENSE_BATCH; ++k) {
+        if (FASTVAL == 4)     // widen: float -> the bits of its double, int32 -> sign-extended
+          img[k] = flt ? (uint64_t)__double_as_longlong((double)__uint_as_float((uint32_t)img[k])) : (uint64_t)(int64_t)(int32_t)(uint32_t)img[k];
         if (fold_op == OP_COUNT) img[k] = 1;
         else if (fold_op == OP_MIN || fold_op == OP_MAX)
           img[k] = flt ? ord_f64(__longlong_as_double((long long)img[k])) : ord_i64((int64_t)img[k]);
@@ -1295,19 +1299,22 @@ static gdf_error gb_path_direct(GbJob &j, bool *done) {
       const int64_t achunk = (((n + agrid - 1) / agrid) + GB_DENSE_THREADS - 1) / GB_DENSE_THREADS * GB_DENSE_THREADS;
       const size_t dlds = (size_t)d.total * 12 + 16;
       const int fastkey = ncols == 1 && (t.col[0].width == 8 || t.col[0].width == 4) ? t.col[0].width : 0;
-      const bool fastval = op != OP_COUNT && kind_width(in_kind) == 8;
+      const int fastval = (op != OP_COUNT && (in_kind == K_I64 || in_kind == K_F64)) ? 8 : ((op != OP_COUNT && (in_kind == K_I32 || in_kind == K_F32)) ? 4 : 0);
 #define GB_DIRECT_LAUNCH(FK, FV)                                                                                             \
   do {                                                                                                                       \
     HIP_TRY(hipFuncSetAttribute((const void *)gb_direct_aggregate<FK, FV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds)); \
     GDF_LAUNCH("gb_direct_aggregate", (gb_direct_aggregate<FK, FV>), dim3(agrid), dim3(GB_DENSE_THREADS), dlds, stream0(), t, d, val, op, \
                gacc.as<unsigned long long>(), gcnt.as<unsigned long long>(), achunk, ng.as<unsigned int>() + 1);             \
   } while (0)
-      if (fastkey == 8 && fastval) GB_DIRECT_LAUNCH(8, true);
-      else if (fastkey == 8) GB_DIRECT_LAUNCH(8, false);
-      else if (fastkey == 4 && fastval) GB_DIRECT_LAUNCH(4, true);
-      else if (fastkey == 4) GB_DIRECT_LAUNCH(4, false);
-      else if (fastval) GB_DIRECT_LAUNCH(0, true);
-      else GB_DIRECT_LAUNCH(0, false);
+      if (fastkey == 8 && fastval == 8) GB_DIRECT_LAUNCH(8, 8);
+      else if (fastkey == 8 && fastval == 4) GB_DIRECT_LAUNCH(8, 4);
+      else if (fastkey == 8) GB_DIRECT_LAUNCH(8, 0);
+      else if (fastkey == 4 && fastval == 8) GB_DIRECT_LAUNCH(4, 8);
+      else if (fastkey == 4 && fastval == 4) GB_DIRECT_LAUNCH(4, 4);
+      else if (fastkey == 4) GB_DIRECT_LAUNCH(4, 0);
+      else if (fastval == 8) GB_DIRECT_LAUNCH(0, 8);
+      else if (fastval == 4) GB_DIRECT_LAUNCH(0, 4);
+      else GB_DIRECT_LAUNCH(0, 0);
 #undef GB_DIRECT_LAUNCH
       GbOut o{};
       o.ncols = ncols;

@@ -1800,6 +1800,7 @@ static gdf_error probe_prepared(const KeyTable &probe_t, const KeyTable &build_t
 
   // ---- work units ----
   std::vector<Unit> units;
+  units.reserve((size_t)nfine + (size_t)(probe_t.nrows / JK_PROBE_CHUNK) + 1);     // the GPU idles while this list is made
   struct Run { uint32_t f0, f1; };    // [f0, f1): consecutive fine partitions that need the global-table path
   std::vector<Run> oversize;
   uint32_t max_build = 0;

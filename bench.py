@@ -125,6 +125,9 @@ def main():
     ap.add_argument("--probe-rows", type=int, default=1_000_000_000)
     ap.add_argument("--build-rows", type=int, default=None)
     ap.add_argument("--cpu-sample", type=int, default=20_000_000, help="probe rows of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--strategy", choices=["shuffle", "broadcast"], default="shuffle",
+                    help="multi-GPU join: shuffle both relations by key (C4 as BASELINE.json names it, the default) or gather the "
+                         "build keys on every GPU and leave the probe relation where it is (libgdf_amd/multigpu.py)")
     ap.add_argument("--force-distributed", action="store_true",
                     help="run the multi-GPU (C4) code path even at world size 1 (1-rank RCCL group): measures its local passes")
     args = ap.parse_args()
@@ -184,10 +187,16 @@ def main():
         build = make_build_keys(nb, 0x5EED0001 + rank, dev) * world + rank
         probe = make_probe_keys(npr, key_space, 0x5EED0002, dev, offset=rank * npr)
 
-        def step():
-            return multigpu.distributed_inner_join(probe, build).numel()
-        workload = (f"C4 partitioned hash join: {npr} probe + {nb} build int64 rows per GPU, key space {key_space}, "
-                    f"RCCL all-to-all shuffle + local gdf_inner_join")
+        if args.strategy == "broadcast":
+            def step():
+                return multigpu.broadcast_inner_join(probe, build).numel()
+            workload = (f"C4 rows, broadcast variant: {npr} probe + {nb} build int64 rows per GPU, key space {key_space}, "
+                        f"RCCL all-gather of the build keys + local gdf_inner_join")
+        else:
+            def step():
+                return multigpu.distributed_inner_join(probe, build).numel()
+            workload = (f"C4 partitioned hash join: {npr} probe + {nb} build int64 rows per GPU, key space {key_space}, "
+                        f"RCCL all-to-all shuffle + local gdf_inner_join")
 
     def sync():
         torch.cuda.synchronize()

@@ -247,6 +247,12 @@ def test_multigpu_layer_world_size_one(gdf):
         c, d = sort_pairs(el, er)
         np.testing.assert_array_equal(a, c)
         np.testing.assert_array_equal(b, d)
+        # the broadcast variant: same pairs
+        bpairs = multigpu.broadcast_inner_join(torch.from_numpy(probe).cuda(), torch.from_numpy(build).cuda())
+        bpg, bbg = bpairs.global_ids()
+        a2, b2 = sort_pairs(bpg.cpu().numpy(), bbg.cpu().numpy())
+        np.testing.assert_array_equal(a2, c)
+        np.testing.assert_array_equal(b2, d)
         # a rank may hold no rows of a relation
         empty = torch.zeros(0, dtype=torch.int64, device="cuda")
         assert multigpu.distributed_inner_join(empty, torch.from_numpy(build).cuda()).numel() == 0

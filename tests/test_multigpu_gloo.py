@@ -68,10 +68,14 @@ def _worker(rank, world, port, q):
                                             shuffle_fn=_np_shuffle, join_fn=_np_join, prepare_fn=None)
     pg, bg = pairs.global_ids()
     assert pairs.numel() == pg.numel()
+    # the broadcast variant must produce the same global pair set (each rank: its own probe rows)
+    bpairs = multigpu.broadcast_inner_join(torch.from_numpy(probes[rank]), torch.from_numpy(builds[rank]),
+                                           join_fn=_np_join, narrow_fn=_np_narrow)
+    bpg, bbg = bpairs.global_ids()
     k = torch.from_numpy(probes[rank])
     v = torch.from_numpy((probes[rank] * 3 + rank).astype(np.int64))
     gk, gv = multigpu.distributed_group_by_sum(k, v, group_fn=_np_group_sum, partition_fn=_np_partition)
-    q.put((rank, pg.numpy(), bg.numpy(), gk.numpy(), gv.numpy()))
+    q.put((rank, pg.numpy(), bg.numpy(), gk.numpy(), gv.numpy(), bpg.numpy(), bbg.numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -99,6 +103,11 @@ def test_multi_rank_join_and_groupby_match_single_process(world):
     exp = exp[np.lexsort(exp.T[::-1])]
     got = got[np.lexsort(got.T[::-1])]
     np.testing.assert_array_equal(got, exp)
+    gotb = np.concatenate([np.stack([r[5], r[6]], axis=1) for r in results])
+    gotb = gotb[np.lexsort(gotb.T[::-1])]
+    np.testing.assert_array_equal(gotb, exp)
+    for r in results:                                   # broadcast: a rank reports pairs of ITS probe rows only
+        assert np.all((r[5] >> 40) == r[0])
     # every joined pair was produced by exactly one rank, and keys are disjoint between ranks
     ek, ea = oracle.group_by("sum", [np.concatenate(probes)],
                              np.concatenate([(probes[r] * 3 + r).astype(np.int64) for r in range(world)]))

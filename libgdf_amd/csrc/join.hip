@@ -323,6 +323,9 @@ struct PartGeom {
   // partially.  With one counter per (partition, XCD) the neighbours meet in ONE L2, which merges them into whole
   // lines before they reach HBM.  Level 2 walks the regions as 2^(b1+xs) segments.
   int xs;
+  // Build relations beyond 2^15 x JK_TARGET_BUILD rows: b3 more partition bits, split off by a THIRD regrouping pass
+  // over the level-2 output of both relations (refine_side); fb + b3 bits in all.  Host-side only.
+  int b3;
 };
 
 // NARROW: w[i] = key32 << 32 | row, idx unused.  WIDE: w[i] = key64, idx[i] = row.
@@ -1341,6 +1344,8 @@ __global__ void jk_fill_pairs(int32_t *a, int32_t av, int32_t *b, int32_t bv, in
 // host side
 // ---------------------------------------------------------------------------
 enum JoinKind { JOIN_INNER, JOIN_LEFT, JOIN_FULL };
+// internal only, never returned through the ABI: probe_prepared asks for a build side without the third level
+constexpr gdf_error GDF_AMD_RETRY_WITHOUT_LEVEL3 = (gdf_error)31;     // above every code of gdf_error
 
 struct SideBufs {            // partitioned tuples of one relation
   DevBuf w[2], idx[2];
@@ -1362,6 +1367,11 @@ static PartGeom choose_geometry(int64_t build_rows) {
   g.b1 = fb <= 8 ? fb : (fb + 1) / 2;
   if (getenv("GDF_JK_B1") && fb > 8) { const int b1 = atoi(getenv("GDF_JK_B1")); if (b1 >= fb - 8 && b1 <= 8) g.b1 = b1; }   // experiment switch
   g.b2 = fb - g.b1;
+  // more rows than 2^15 LDS-sized partitions hold: a third level (at most 256-way), decided here, applied by refine_side
+  g.b3 = 0;
+  // (only when the 2^15 partitions would not fit LDS with some room for their spread: C4's 1.25e8-row shards stay two-level)
+  if (fb == JK_MAX_FB && !getenv("GDF_JK_NO_LEVEL3"))
+    while (g.b3 < 8 && (build_rows >> (fb + g.b3)) > JK_MAX_BUILD - JK_MAX_BUILD / 5) ++g.b3;
   return g;
 }
 
@@ -1724,6 +1734,73 @@ struct StageClock {
   }
 };
 
+// Third level: every one of the 2^fb partitions of `sb` (either layout) is split 2^b3-way by the next hash bits into a
+// new buffer in the speculative layout (partition f owns [f * cap3, (f + 1) * cap3), fill counters); jk_scatter2 does
+// the work, with the level-2 partitions as its segments.  *ok = false leaves `sb` untouched (a partition outgrew its
+// room: skewed keys -- the caller continues with the 2^fb partitions and the global-table path).
+static gdf_error refine_side(const PartGeom &g, bool narrow, double dup, SideBufs *sb, bool *ok) {
+  *ok = false;
+  const uint32_t nseg = 1u << g.fb, nsub = 1u << g.b3;
+  const uint64_t nfine3 = (uint64_t)nseg << g.b3;
+  const int64_t n = sb->joinable;
+  if (n == 0) return GDF_SUCCESS;
+  const int threads = level2_threads(narrow ? 1024 : 512);
+  const int64_t TILE = (int64_t)threads * JK_SC_ITEMS;
+  const double mean = (double)n / (double)nfine3;
+  const uint32_t cap3 = (uint32_t)(((uint64_t)(mean + 8.0 * std::sqrt(mean * (1.0 + dup)) + 64.0) + 7) / 8 * 8);
+  const uint64_t size3 = nfine3 * cap3 + TILE;
+  if (size3 >= 0x7fffffffULL) return GDF_SUCCESS;                      // tuple positions are 31-bit
+  std::vector<uint32_t> seg(2 * (size_t)nseg), tile_prefix((size_t)nseg + 1), cur((size_t)nfine3);
+  tile_prefix[0] = 0;
+  for (uint32_t c = 0; c < nseg; ++c) {
+    seg[c] = sb->fine_begin[c];
+    seg[nseg + c] = sb->fine_begin[c] + sb->fine_cnt[c];
+    tile_prefix[c + 1] = tile_prefix[c] + (uint32_t)((sb->fine_cnt[c] + TILE - 1) / TILE);
+  }
+  for (uint64_t f = 0; f < nfine3; ++f) cur[f] = (uint32_t)(f * cap3);
+  const uint32_t ntiles = tile_prefix[nseg];
+  DevBuf d_seg, d_tiles, cursor, flag, nw, nidx;
+  RMM_TRY(d_seg.alloc(sizeof(uint32_t) * 2 * nseg));
+  RMM_TRY(d_tiles.alloc(sizeof(uint32_t) * ((size_t)nseg + 1)));
+  RMM_TRY(cursor.alloc(sizeof(uint32_t) * nfine3));
+  RMM_TRY(flag.alloc(sizeof(uint32_t)));
+  RMM_TRY(nw.alloc(sizeof(uint64_t) * size3));
+  if (!narrow) RMM_TRY(nidx.alloc(sizeof(int32_t) * size3));
+  HIP_TRY(hipMemcpyAsync(d_seg.p, seg.data(), sizeof(uint32_t) * 2 * nseg, hipMemcpyHostToDevice, stream0()));
+  HIP_TRY(hipMemcpyAsync(d_tiles.p, tile_prefix.data(), sizeof(uint32_t) * ((size_t)nseg + 1), hipMemcpyHostToDevice, stream0()));
+  HIP_TRY(hipMemcpyAsync(cursor.p, cur.data(), sizeof(uint32_t) * nfine3, hipMemcpyHostToDevice, stream0()));
+  HIP_TRY(hipMemsetAsync(flag.p, 0, sizeof(uint32_t), stream0()));
+  PartGeom g3 = g;                      // jk_scatter2 sees 2^fb "coarse" segments and 2^b3 sub-bins of an (fb + b3)-bit id
+  g3.b1 = g.fb;
+  g3.b2 = g.b3;
+  g3.fb = g.fb + g.b3;
+  g3.cap1 = 0;
+  g3.cap2 = cap3;
+  g3.dump = (uint32_t)(nfine3 * cap3);
+  g3.spec_flag = flag.as<uint32_t>();
+  g3.xs = 0;
+  Level2Map m{d_seg.as<uint32_t>(), d_seg.as<uint32_t>() + nseg, d_tiles.as<uint32_t>(), 0};
+  if (ntiles) GDF_TRY(launch_scatter2(narrow, threads, ntiles, g3, m, sb->final(), cursor.as<uint32_t>(), Tuples{nw.as<uint64_t>(), nidx.as<int32_t>()}));
+  uint32_t overflow = 0;
+  HIP_TRY(read_back(cur.data(), cursor.p, sizeof(uint32_t) * nfine3));
+  HIP_TRY(read_back(&overflow, flag.p, sizeof(uint32_t)));
+  if (overflow) return GDF_SUCCESS;
+  (void)nsub;
+  // commit: the refined tuples replace the level-2 ones
+  const int o = sb->final_buf ^ 1;
+  sb->w[0].reset(); sb->w[1].reset(); sb->idx[0].reset(); sb->idx[1].reset();
+  sb->w[o].p = nw.release();
+  if (!narrow) sb->idx[o].p = nidx.release();
+  sb->final_buf = o;
+  sb->fine_off.clear();
+  sb->fine_begin.resize(nfine3);
+  sb->fine_cnt.resize(nfine3);
+  for (uint64_t f = 0; f < nfine3; ++f) { sb->fine_begin[f] = (uint32_t)(f * cap3); sb->fine_cnt[f] = cur[f] - (uint32_t)(f * cap3); }
+  sb->speculative = true;
+  *ok = true;
+  return GDF_SUCCESS;
+}
+
 // The build relation after partitioning: everything a probe pass needs besides the probe relation itself.  Made
 // once per gdf_*_join call, or once per gdf_amd_join_build (include/gdf/gdf_amd_ext.h) and probed many times.
 struct BuildSide {
@@ -1765,12 +1842,30 @@ static gdf_error plan_ranged(const KeyTable &build_t, KeyPlan *plan) {
   return GDF_SUCCESS;
 }
 
-static gdf_error prepare_build(const KeyTable &build_t, BuildSide *bs) {
+static gdf_error prepare_build(const KeyTable &build_t, BuildSide *bs, bool no_level3 = false) {
   bs->plan = plan_keys(build_t);           // a function of the key dtypes only: the probe relation has the same ones
   GDF_TRY(plan_ranged(build_t, &bs->plan));
   bs->g = choose_geometry(build_t.nrows);
   const bool range_candidate = !bs->plan.narrow && bs->plan.mode == KM_RAW_INT && build_t.col[0].width == 8;
-  return partition_side(build_t, bs->plan, bs->g, &bs->B, range_candidate);   // may switch plan to the narrow format
+  GDF_TRY(partition_side(build_t, bs->plan, bs->g, &bs->B, range_candidate));   // may switch plan to the narrow format
+  if (bs->g.b3 > 0 && !no_level3) {
+    bool ok = false;
+    GDF_TRY(refine_side(bs->g, bs->plan.narrow != 0, 0.0, &bs->B, &ok));
+    uint32_t largest = 0;
+    if (ok) for (uint32_t c : bs->B.fine_cnt) largest = std::max(largest, c);
+    // a refined partition that still does not fit LDS (skew) needs the global-table path, which wants the exact layout:
+    // such a relation is partitioned again without the third level
+    if (ok && largest > (uint32_t)JK_MAX_BUILD) {
+      bs->B.w[0].reset(); bs->B.w[1].reset(); bs->B.idx[0].reset(); bs->B.idx[1].reset();
+      bs->g.b3 = 0;
+      GDF_TRY(partition_side(build_t, bs->plan, bs->g, &bs->B, false));
+    } else if (!ok) {
+      bs->g.b3 = 0;
+    }
+  } else {
+    bs->g.b3 = 0;
+  }
+  return GDF_SUCCESS;
 }
 
 static gdf_error probe_prepared(const KeyTable &probe_t, const KeyTable &build_t, const BuildSide &bs, JoinKind kind,
@@ -1778,7 +1873,7 @@ static gdf_error probe_prepared(const KeyTable &probe_t, const KeyTable &build_t
   const KeyPlan &plan = bs.plan;
   const PartGeom &g = bs.g;
   const SideBufs &B = bs.B;
-  const uint32_t nfine = 1u << g.fb;
+  const uint32_t nfine = 1u << (g.fb + g.b3);
   const bool keep_probe = kind != JOIN_INNER;
 
   SideBufs P;
@@ -1796,6 +1891,11 @@ static gdf_error probe_prepared(const KeyTable &probe_t, const KeyTable &build_t
     GDF_TRY(partition_side(probe_t, probe_plan, g, &P, false));
   }
   const bool narrow = plan.narrow != 0;
+  if (g.b3 > 0) {
+    bool ok = false;
+    GDF_TRY(refine_side(g, narrow, std::max(1.0, (double)probe_t.nrows / std::max<uint32_t>(B.joinable, 1)), &P, &ok));
+    if (!ok) return GDF_AMD_RETRY_WITHOUT_LEVEL3;     // skewed probe keys: the caller repeats with a 2^fb-partition build side
+  }
   clk.mark("partition probe side");
 
   // ---- work units ----
@@ -2023,7 +2123,11 @@ static gdf_error hash_join_core(const KeyTable &probe_t, const KeyTable &build_t
   BuildSide bs;
   GDF_TRY(prepare_build(build_t, &bs));
   clk.mark("partition build side");
-  return probe_prepared(probe_t, build_t, bs, kind, out_probe, out_build, out_n, clk);
+  gdf_error e = probe_prepared(probe_t, build_t, bs, kind, out_probe, out_build, out_n, clk);
+  if (e != GDF_AMD_RETRY_WITHOUT_LEVEL3) return e;
+  BuildSide plain;
+  GDF_TRY(prepare_build(build_t, &plain, true));
+  return probe_prepared(probe_t, build_t, plain, kind, out_probe, out_build, out_n, clk);
 }
 
 // FULL join with an empty side (joining.cu:214-280 trivial_full_join): every row of
@@ -2347,7 +2451,13 @@ static gdf_error build_probe(PreparedBuild *pb, int left_join, gdf_column **prob
   StageClock clk(getenv("GDF_JK_DBG") && (atoi(getenv("GDF_JK_DBG")) & 512));
   int32_t *o_probe = nullptr, *o_build = nullptr;
   int64_t n = 0;
-  GDF_TRY(probe_prepared(pt, pb->table, pb->side, kind, &o_probe, &o_build, &n, clk));
+  gdf_error e = probe_prepared(pt, pb->table, pb->side, kind, &o_probe, &o_build, &n, clk);
+  if (e == GDF_AMD_RETRY_WITHOUT_LEVEL3) {           // skewed probe keys against a three-level build side: rebuild it plainly, once
+    BuildSide plain;
+    GDF_TRY(prepare_build(pb->table, &plain, true));
+    e = probe_prepared(pt, pb->table, plain, kind, &o_probe, &o_build, &n, clk);
+  }
+  GDF_TRY(e);
   if (n == 0) return GDF_SUCCESS;
   gdf_column_view(probe_indices, o_probe, nullptr, (gdf_size_type)n, GDF_INT32);
   gdf_column_view(build_indices, o_build, nullptr, (gdf_size_type)n, GDF_INT32);

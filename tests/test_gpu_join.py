@@ -317,10 +317,12 @@ def test_prepared_build_edge_cases(gdf, monkeypatch):
         assert torch.unique(li).numel() == li.numel()
 
 
-def test_every_partition_oversize_uses_one_global_table(gdf):
+def test_every_partition_oversize_uses_one_global_table(gdf, monkeypatch):
     """A build side beyond 32768 x 6144 rows makes EVERY fine partition exceed the LDS image: the global-table
-    path must handle them as one run (one table, three launches), not one launch per partition."""
+    path (third partitioning level switched off) must handle them as one run (one table, three launches), not one
+    launch per partition."""
     import torch
+    monkeypatch.setenv("GDF_JK_NO_LEVEL3", "1")
     from libgdf_amd.columns import Column
     nb, npr = 210_000_000, 2_000_000
     build = torch.randperm(nb, dtype=torch.int32, device="cuda")
@@ -434,6 +436,34 @@ def test_range_packed_multi_column_keys(gdf, how, dtypes):
         wide_b = [b.astype(np.int64) * (1 << 40) for b in build]
         wide_p = [q.astype(np.int64) * (1 << 40) for q in probe]
         _check(gdf, wide_p, wide_b, how)
+
+
+@pytest.mark.parametrize("shape", ["uniform", "hot probe key", "hot build key"])
+def test_third_partition_level_for_large_build_sides(gdf, shape):
+    """Build relations beyond 2^15 LDS-sized partitions (here 2.6e8 rows) get a third regrouping pass (refine_side in
+    csrc/join.hip).  A probe key hot enough to outgrow its refined partition makes the call repeat with the plain
+    two-level build side; a hot BUILD key keeps the two-level layout and the global-table path from the start."""
+    import torch
+    from libgdf_amd.columns import Column
+    nb, npr = 260_000_000, 300_000_000
+    b = torch.randperm(nb, dtype=torch.int32, device="cuda")
+    p = torch.randint(0, nb + nb // 8, (npr,), dtype=torch.int32, device="cuda")
+    if shape == "hot probe key":
+        p[: npr // 3] = 12345
+    if shape == "hot build key":
+        b[: 200_000] = 777                                         # 2e5 equal build keys: far beyond one LDS partition
+        p[:1000] = 777
+    li, ri = gdf.api.join([Column(p)], [Column(b)])
+    expect = int((p < nb).sum().item())
+    if shape == "hot build key":
+        first = torch.zeros(nb + nb // 8 + 1, dtype=torch.int32, device="cuda")
+        first.scatter_add_(0, b.long(), torch.ones_like(b))          # multiplicity of every build key
+        expect = int(first[p.long()].sum().item())
+        del first
+    assert li.numel() == expect
+    assert torch.equal(b[ri.long()], p[li.long()])
+    if shape != "hot build key":
+        assert torch.unique(li).numel() == expect
 
 
 @pytest.mark.parametrize("how", ["inner", "left"])

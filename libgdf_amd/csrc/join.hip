@@ -1363,6 +1363,9 @@ static PartGeom choose_geometry(int64_t build_rows) {
   g.dbg = getenv("GDF_JK_SDBG") ? atoi(getenv("GDF_JK_SDBG")) : 0;
   int fb = 0;
   while (fb < JK_MAX_FB && (build_rows >> fb) > JK_TARGET_BUILD) ++fb;
+  // never fewer than 32 partitions: with one or a few, every tuple of a tile ranks on the same LDS counter and the
+  // probe side has to take the histogram pass (5e8 x 3000 rows: 8.0 ms with one partition, see the notes in profiles/)
+  if (fb < 5 && !getenv("GDF_JK_ALLOW_FEW_PARTS")) fb = 5;
   g.fb = fb;
   g.b1 = fb <= 8 ? fb : (fb + 1) / 2;
   if (getenv("GDF_JK_B1") && fb > 8) { const int b1 = atoi(getenv("GDF_JK_B1")); if (b1 >= fb - 8 && b1 <= 8) g.b1 = b1; }   // experiment switch

@@ -55,6 +55,16 @@ void gdf_amd_join_build_free(gdf_amd_join_build *build);
 gdf_error gdf_amd_shuffle_partition(gdf_column *keys, int narrow, int64_t lo, int64_t hi, int32_t row_base, int num_partitions,
                                     gdf_column *out_keys, gdf_column *out_rows, int partition_offsets[]);
 
+/*
+ * The same split as gdf_amd_shuffle_partition without a row-number column: the partition is STABLE (the keys of a
+ * partition keep their input order) and bitmap p -- ceil(rows / 64) 64-bit words at bitmaps + p * ceil(rows / 64), DEVICE
+ * memory, bit i of word i / 64 -- has bit i set iff input row i went to partition p.  The j-th key of partition p is
+ * therefore input row select(bitmap p, j): a receiver names the original row of a joined key from one bit per row
+ * instead of a 4-byte row number (4.125 instead of 8 bytes per row on the links).  num_partitions <= 64.
+ */
+gdf_error gdf_amd_shuffle_partition_stable(gdf_column *keys, int narrow, int64_t lo, int64_t hi, int num_partitions,
+                                           gdf_column *out_keys, uint64_t *bitmaps, int partition_offsets[]);
+
 #if defined(__GNUC__)
 #pragma GCC visibility pop
 #endif

@@ -119,6 +119,7 @@ _PROTOTYPES = {
     # include/gdf/gdf_amd_ext.h
     "gdf_amd_narrow_keys": (None, [_COLP, C.c_int64, C.c_int64, _COLP]),
     "gdf_amd_shuffle_partition": (None, [_COLP, C.c_int, C.c_int64, C.c_int64, C.c_int32, C.c_int, _COLP, _COLP, C.POINTER(C.c_int)]),
+    "gdf_amd_shuffle_partition_stable": (None, [_COLP, C.c_int, C.c_int64, C.c_int64, C.c_int, _COLP, C.c_void_p, C.POINTER(C.c_int)]),
     "gdf_amd_join_build_create": (None, [C.POINTER(_COLP), C.c_int, C.POINTER(C.c_void_p)]),
     "gdf_amd_join_build_probe": (None, [C.c_void_p, C.c_int, C.POINTER(_COLP), C.c_int, _COLP, _COLP]),
     "gdf_amd_join_build_free": (C.c_int, [C.c_void_p]),                                       # void in C

@@ -175,6 +175,21 @@ def shuffle_partition(keys: Column, num_partitions, row_base=0, narrow=None):
     return out_k.data, out_r.data, list(offsets)
 
 
+def shuffle_partition_stable(keys: Column, num_partitions, narrow=None):
+    """gdf_amd_shuffle_partition_stable -> (keys tensor, bitmaps int64 tensor [num_partitions, ceil(n / 64)], offsets).
+    Partition p holds its keys in input order; bit i of bitmap p says that input row i went there."""
+    import torch
+    n = keys.size
+    out_k = Column(torch.empty(n, dtype=torch.int32 if narrow else keys.data.dtype, device=keys.data.device))
+    words = (n + 63) // 64
+    bitmaps = torch.empty((num_partitions, max(words, 1)), dtype=torch.int64, device=keys.data.device)
+    offsets = (C.c_int * num_partitions)()
+    lo, hi = narrow if narrow else (0, 0)
+    libgdf.gdf_amd_shuffle_partition_stable(keys.ptr, 1 if narrow else 0, int(lo), int(hi), num_partitions, out_k.ptr,
+                                            bitmaps.data_ptr(), offsets)
+    return out_k.data, bitmaps[:, :words], list(offsets)
+
+
 class JoinBuild:
     """gdf_amd_join_build_* (include/gdf/gdf_amd_ext.h): the build relation partitioned once, probed many times."""
 

@@ -522,6 +522,127 @@ __global__ __launch_bounds__(HP_THREADS) void shuffle_scatter_tile_kernel(const 
   }
 }
 
+// ---------------------------------------------------------------------------
+// gdf_amd_shuffle_partition_stable (include/gdf/gdf_amd_ext.h): the sender side of the multi-GPU shuffle WITHOUT a
+// row-number column.  The partition is stable -- the keys of a partition keep their input order -- and for every
+// partition a bitmap says which input rows it took, so the j-th key of partition p is row select(bitmap p, j): the
+// receiver can name the original row of anything it joins from 1 bit per row instead of a 4-byte row number, and
+// the exchange moves 4.125 bytes per row instead of 8.
+// Tile = 4 waves x 8 rounds x 64 rows; wave w owns rows [512 w, 512 (w + 1)) of the tile, so input order is (wave,
+// round, lane) order and ranks come from per-wave counts, as in the radix sort's rs_scatter.  Tiles are dealt to the XCDs
+// in contiguous eighths (rs_scatter again): the partitions' output lines are filled by consecutive tiles.
+// ---------------------------------------------------------------------------
+constexpr int ST_ROUNDS = 8;
+constexpr int ST_WAVES = HP_THREADS / WAVE;
+constexpr int ST_TILE = HP_THREADS * ST_ROUNDS;
+
+template <class KIN, class KOUT>
+__global__ __launch_bounds__(HP_THREADS) void stable_count_kernel(const KIN *__restrict__ key, long long lo, unsigned long long span,
+                                                                   int64_t n, uint32_t ntiles, uint32_t nparts, uint32_t pow2mask,
+                                                                   uint32_t *__restrict__ counts) {
+  __shared__ uint32_t cnt[SHT_MAX_PARTS];
+  const uint32_t tile = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  if (tile >= ntiles) return;
+  if (threadIdx.x < SHT_MAX_PARTS) cnt[threadIdx.x] = 0;
+  block_sync();
+  const int wave = threadIdx.x / WAVE, lane = lane_id();
+  const int64_t wbase = (int64_t)tile * ST_TILE + (int64_t)wave * (ST_ROUNDS * WAVE);
+  KIN k[ST_ROUNDS];
+#pragma unroll
+  for (int r = 0; r < ST_ROUNDS; ++r) {
+    const int64_t i = wbase + r * WAVE + lane;
+    k[r] = key[i < n ? i : n - 1];
+  }
+  uint32_t mine = 0;                     // lane p: rows of this wave that go to partition p
+#pragma unroll
+  for (int r = 0; r < ST_ROUNDS; ++r) {
+    const bool live = wbase + r * WAVE + lane < n;
+    const KOUT kk = shuffle_key<KIN, KOUT>(k[r], lo, span);
+    const uint32_t part = live ? part_of(murmur3_32((uint64_t)kk, (int)sizeof(KOUT)), nparts, pow2mask) : 0xffffffffu;
+    for (uint32_t q = 0; q < nparts; ++q) {
+      const unsigned long long m = __ballot(part == q);
+      if ((uint32_t)lane == q) mine += (uint32_t)__popcll(m);
+    }
+  }
+  if ((uint32_t)lane < nparts && mine) atomicAdd(&cnt[lane], mine);
+  block_sync();
+  if (threadIdx.x < nparts) counts[(size_t)threadIdx.x * ntiles + tile] = cnt[threadIdx.x];
+}
+
+template <class KIN, class KOUT>
+__global__ __launch_bounds__(HP_THREADS) void stable_scatter_kernel(const KIN *__restrict__ key, long long lo, unsigned long long span,
+                                                                     int64_t n, uint32_t ntiles, uint32_t nparts, uint32_t pow2mask,
+                                                                     const uint32_t *__restrict__ offsets, KOUT *__restrict__ out_key,
+                                                                     unsigned long long *__restrict__ bitmaps, uint64_t words) {
+  __shared__ KOUT stage[ST_TILE];
+  __shared__ uint8_t bin_of[ST_TILE];
+  __shared__ uint32_t wtot[ST_WAVES * SHT_MAX_PARTS];     // rows of wave w for partition p, then: rows of earlier waves
+  __shared__ uint32_t start[SHT_MAX_PARTS], gbase[SHT_MAX_PARTS];
+  const uint32_t tile = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  if (tile >= ntiles) return;
+  const int wave = threadIdx.x / WAVE, lane = lane_id();
+  const int64_t wbase = (int64_t)tile * ST_TILE + (int64_t)wave * (ST_ROUNDS * WAVE);
+  KIN k[ST_ROUNDS];
+#pragma unroll
+  for (int r = 0; r < ST_ROUNDS; ++r) {
+    const int64_t i = wbase + r * WAVE + lane;
+    k[r] = key[i < n ? i : n - 1];
+  }
+  KOUT kk[ST_ROUNDS];
+  uint32_t part[ST_ROUNDS];
+  uint32_t before[ST_ROUNDS];             // lane p: rows of partition p in the EARLIER rounds of this wave
+  unsigned long long same[ST_ROUNDS];     // the lanes of this round that share this lane's partition
+  uint32_t run = 0;
+#pragma unroll
+  for (int r = 0; r < ST_ROUNDS; ++r) {
+    const int64_t row0 = wbase + r * WAVE;
+    const bool live = row0 + lane < n;
+    kk[r] = shuffle_key<KIN, KOUT>(k[r], lo, span);
+    part[r] = live ? part_of(murmur3_32((uint64_t)kk[r], (int)sizeof(KOUT)), nparts, pow2mask) : 0xffffffffu;
+    before[r] = run;
+    same[r] = 0;
+    unsigned long long word = 0;
+    for (uint32_t q = 0; q < nparts; ++q) {
+      const unsigned long long m = __ballot(part[r] == q);
+      if ((uint32_t)lane == q) { word = m; run += (uint32_t)__popcll(m); }
+      if (part[r] == q) same[r] = m;
+    }
+    if ((uint32_t)lane < nparts && row0 < n) bitmaps[(size_t)lane * words + (uint64_t)(row0 >> 6)] = word;
+  }
+  if ((uint32_t)lane < nparts) wtot[wave * SHT_MAX_PARTS + lane] = run;
+  block_sync();
+  if (threadIdx.x < WAVE) {               // one wave: per partition, rows of the earlier waves and the tile total; then the starts
+    uint32_t total = 0;
+    if ((uint32_t)lane < nparts)
+      for (int w = 0; w < ST_WAVES; ++w) {
+        const uint32_t c = wtot[w * SHT_MAX_PARTS + lane];
+        wtot[w * SHT_MAX_PARTS + lane] = total;
+        total += c;
+      }
+    const uint32_t st = wave_scan_incl(total) - total;
+    if ((uint32_t)lane < nparts) {
+      start[lane] = st;
+      gbase[lane] = offsets[(size_t)lane * ntiles + tile] - st;
+    }
+  }
+  block_sync();
+  const unsigned long long lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
+#pragma unroll
+  for (int r = 0; r < ST_ROUNDS; ++r) {
+    const uint32_t q = part[r] == 0xffffffffu ? 0u : part[r];
+    const uint32_t earlier = __shfl(before[r], (int)q);          // every lane takes part in the shuffle
+    if (part[r] != 0xffffffffu) {
+      const uint32_t pos = start[q] + wtot[wave * SHT_MAX_PARTS + q] + earlier + (uint32_t)__popcll(same[r] & lt);
+      stage[pos] = kk[r];
+      bin_of[pos] = (uint8_t)q;
+    }
+  }
+  block_sync();
+  const int64_t tile_rows = n - (int64_t)tile * ST_TILE;
+  const uint32_t total = (uint32_t)(tile_rows < ST_TILE ? tile_rows : ST_TILE);
+  for (uint32_t j = threadIdx.x; j < total; j += HP_THREADS) out_key[gbase[bin_of[j]] + j] = stage[j];
+}
+
 // gpu_hash_columns (src/hashops.cu:25-151): 64-bit FNV-1a over the little-endian bytes of every column's element,
 // columns in order.  The reference XORs each byte as a (signed) `char`, so a byte >= 0x80 is sign-extended to 64
 // bits before the XOR (hashops.cu:46-75) -- kept, it is what callers of the reference see.
@@ -708,6 +829,58 @@ gdf_error gdf_amd_shuffle_partition(gdf_column *keys, int narrow, int64_t lo, in
   else { SHUFFLE_PASSES(uint32_t, uint32_t) }
 #undef SHUFFLE_PASSES
 #undef SHUFFLE_TILE_PASSES
+  HIP_TRY(hipMemcpyAsync(partition_offsets, starts.p, sizeof(int) * P, hipMemcpyDeviceToHost, stream0()));
+  HIP_TRY(hipStreamSynchronize(stream0()));
+  return GDF_SUCCESS;
+}
+
+gdf_error gdf_amd_shuffle_partition_stable(gdf_column *keys, int narrow, int64_t lo, int64_t hi, int num_partitions,
+                                           gdf_column *out_keys, uint64_t *bitmaps, int partition_offsets[]) {
+  GDF_REQUIRE(keys && out_keys && bitmaps && partition_offsets, GDF_DATASET_EMPTY);
+  GDF_REQUIRE(num_partitions > 0 && num_partitions <= SHT_MAX_PARTS, GDF_INVALID_API_CALL);
+  GDF_REQUIRE(!keys->valid && !out_keys->valid, GDF_VALIDITY_UNSUPPORTED);
+  const int win = dtype_width(keys->dtype);
+  GDF_REQUIRE((win == 8 || win == 4) && elem_kind(keys->dtype) != K_F32 && elem_kind(keys->dtype) != K_F64, GDF_UNSUPPORTED_DTYPE);
+  if (narrow) {
+    GDF_REQUIRE(elem_kind(keys->dtype) == K_I64 && out_keys->dtype == GDF_INT32, GDF_UNSUPPORTED_DTYPE);
+    GDF_REQUIRE(hi >= lo && (uint64_t)hi - (uint64_t)lo < 0x7fffffffULL, GDF_INVALID_API_CALL);
+  } else {
+    GDF_REQUIRE(out_keys->dtype == keys->dtype, GDF_PARTITION_DTYPE_MISMATCH);
+  }
+  GDF_REQUIRE(keys->size == out_keys->size, GDF_COLUMN_SIZE_MISMATCH);
+  const size_t num_rows = keys->size;
+  GDF_REQUIRE(num_rows < (size_t)INT_MAX, GDF_COLUMN_SIZE_TOO_BIG);
+  const uint32_t P = (uint32_t)num_partitions;
+  if (num_rows == 0) {
+    for (uint32_t p = 0; p < P; ++p) partition_offsets[p] = 0;
+    return GDF_SUCCESS;
+  }
+  GDF_REQUIRE(keys->data && out_keys->data, GDF_DATASET_EMPTY);
+  const int64_t n = (int64_t)num_rows;
+  const uint32_t pow2mask = (P & (P - 1)) == 0 ? P - 1 : 0;
+  const uint32_t ntiles = (uint32_t)((n + ST_TILE - 1) / ST_TILE);
+  const uint32_t grid = (ntiles + 7) / 8 * 8;
+  const uint64_t words = (uint64_t)((n + 63) / 64);
+  DevBuf counts, starts;
+  RMM_TRY(counts.alloc(sizeof(uint32_t) * (size_t)P * ntiles));
+  RMM_TRY(starts.alloc(sizeof(uint32_t) * P));
+  const long long llo = narrow ? (long long)lo : 0;
+  const unsigned long long span = narrow ? (unsigned long long)((uint64_t)hi - (uint64_t)lo) : 0;
+#define STABLE_PASSES(KIN, KOUT)                                                                                                    \
+  GDF_LAUNCH("stable_count", (stable_count_kernel<KIN, KOUT>), dim3(grid), dim3(HP_THREADS), 0, stream0(), (const KIN *)keys->data, llo, \
+             span, n, ntiles, P, pow2mask, counts.as<uint32_t>());                                                                  \
+  HIP_CHECK_LAST();                                                                                                                \
+  GDF_TRY(scan_u32(counts.as<uint32_t>(), counts.as<uint32_t>(), (size_t)P * ntiles, false));                                      \
+  hipLaunchKernelGGL(gather_strided_u32, dim3((P + 255) / 256), dim3(256), 0, stream0(), counts.as<uint32_t>(), starts.as<uint32_t>(), \
+                     (int)P, (size_t)ntiles);                                                                                      \
+  GDF_LAUNCH("stable_scatter", (stable_scatter_kernel<KIN, KOUT>), dim3(grid), dim3(HP_THREADS), 0, stream0(), (const KIN *)keys->data, \
+             llo, span, n, ntiles, P, pow2mask, (const uint32_t *)counts.as<uint32_t>(), (KOUT *)out_keys->data,                    \
+             (unsigned long long *)bitmaps, words);                                                                                \
+  HIP_CHECK_LAST();
+  if (narrow) { STABLE_PASSES(uint64_t, uint32_t) }
+  else if (win == 8) { STABLE_PASSES(uint64_t, uint64_t) }
+  else { STABLE_PASSES(uint32_t, uint32_t) }
+#undef STABLE_PASSES
   HIP_TRY(hipMemcpyAsync(partition_offsets, starts.p, sizeof(int) * P, hipMemcpyDeviceToHost, stream0()));
   HIP_TRY(hipStreamSynchronize(stream0()));
   return GDF_SUCCESS;

@@ -8,8 +8,10 @@ counterpart there; it sits ABOVE the unchanged per-GPU ``gdf_*`` C ABI (SURVEY.m
   1. every rank hash-partitions each relation on the join key into ``world`` partitions, placed exactly as the
      public ``gdf_hash_partition`` places them (Murmur3 & (P-1) / % P) -- a different hash from the one the local
      join partitions on, so rank placement and local partitioning are uncorrelated.  The payload that travels
-     with a key is its 4-byte LOCAL row number; the owner rank is implied by the segment it arrives in.
-     Narrowing, row numbering and partitioning are ONE pass pair over the raw keys (``gdf_amd_shuffle_partition``);
+     with the keys of a (sender, receiver) pair is ONE BITMAP of the sender's rows: the partition is stable, so the
+     j-th key of the segment is the j-th set bit -- 1 bit instead of a 4-byte row number per row on the links; the
+     owner rank is implied by the segment.
+     Narrowing and partitioning are ONE pass pair over the raw keys (``gdf_amd_shuffle_partition_stable``);
   2. the ``world x world`` send-count matrix is exchanged (one tiny all-to-all);
   3. one ``all_to_all_single`` per column moves partition r to rank r (xGMI is point-to-point, an
      all-to-all drives all 7 links of a GPU at once, so each column goes out as ONE large collective);
@@ -41,10 +43,13 @@ def _device_partition(keys, payload, world):
 
 
 def _device_shuffle(keys, row_base, world, narrow):
-    """gdf_amd_shuffle_partition: (keys [narrowed to int32 when narrow=(lo, hi)], int32 row numbers from row_base,
-    offsets list), partitioned on the key as gdf_hash_partition would place them."""
+    """gdf_amd_shuffle_partition_stable: (keys [narrowed to int32 when narrow=(lo, hi)] partitioned on the key as
+    gdf_hash_partition would place them, each partition in input order; the bitmaps that say which rows each partition
+    took; offsets list).  Beyond 64 ranks: gdf_amd_shuffle_partition with a row-number column."""
     from . import api
     from .columns import Column
+    if world <= 64:
+        return api.shuffle_partition_stable(Column(keys), world, narrow=narrow)
     return api.shuffle_partition(Column(keys), world, row_base=row_base, narrow=narrow)
 
 
@@ -94,11 +99,14 @@ def _narrow_range(probe_keys, build_keys, group):
 
 
 class Received:
-    """One relation after the exchange: keys, the senders' local row numbers, and the segment bounds
-    (rows ``bounds[r]:bounds[r+1]`` came from rank r)."""
+    """One relation after the exchange: keys and the segment bounds (rows ``bounds[r]:bounds[r+1]`` came from rank r),
+    plus what names the senders' local rows: either their row numbers (``rows``, 4 bytes per row on the links) or, from a
+    STABLE partition, one bitmap per sender (``bitmaps[r]``: bit i set iff row ``row_base[r] + i`` of rank r came here;
+    the j-th key of segment r is the j-th set bit -- 1 bit per row on the links)."""
 
-    def __init__(self, keys, rows, bounds):
-        self.keys, self.rows, self.bounds = keys, rows, bounds
+    def __init__(self, keys, rows, bounds, bitmaps=None, row_base=None):
+        self.keys, self.rows, self.bounds, self.bitmaps, self.row_base = keys, rows, bounds, bitmaps, row_base
+        self._rows_cache = {}
 
     def owner_of(self, positions):
         """Owner rank of received positions (int64 tensor)."""
@@ -106,9 +114,31 @@ class Received:
         b = torch.tensor(self.bounds[1:], dtype=torch.int64, device=positions.device)
         return torch.bucketize(positions.long(), b, right=True)
 
+    def _rows_of(self, r):
+        """Local row numbers of segment r in arrival order (= input order of the sender): the positions of the set bits."""
+        import torch
+        if r not in self._rows_cache:
+            bits = self.bitmaps[r].contiguous().view(torch.uint8)                     # little-endian words: byte b holds rows 8b .. 8b+7
+            shifts = torch.arange(8, dtype=torch.uint8, device=bits.device)
+            ones = ((bits.unsqueeze(1) >> shifts) & 1).flatten()
+            self._rows_cache[r] = torch.nonzero(ones).flatten() + int(self.row_base[r])
+        return self._rows_cache[r]
+
     def global_ids(self, positions):
         """(owner rank << 40) | local row, as int64."""
-        return (self.owner_of(positions) << 40) | self.rows[positions.long()].long()
+        import torch
+        pos = positions.long()
+        owner = self.owner_of(pos)
+        if self.bitmaps is None:
+            return (owner << 40) | self.rows[pos].long()
+        starts = torch.tensor(self.bounds, dtype=torch.int64, device=pos.device)
+        within = pos - starts[owner]
+        rows = torch.empty_like(pos)
+        for r in range(len(self.bounds) - 1):
+            sel = owner == r
+            if bool(sel.any()):
+                rows[sel] = self._rows_of(r)[within[sel]]
+        return (owner << 40) | rows
 
 
 class ShardedPairs:
@@ -169,27 +199,48 @@ def _all_to_all_v(recv, send, recv_split, send_split, group, async_op):
 
 class _Exchange:
     """One relation (or one chunk of it) on its way to its owner ranks: the partitioned send buffers, the receive
-    buffers and the in-flight collectives.  ``finish()`` waits for them and returns the :class:`Received`."""
+    buffers and the in-flight collectives.  ``finish()`` waits for them and returns the :class:`Received`.
 
-    def __init__(self, partitioned, group, async_op):
+    ``partitioned`` = (keys, payload, offsets).  A 1-D payload travels row by row next to its key (row numbers, group-by
+    values).  A 2-D payload is the bitmap set of a STABLE partition (``payload[r]`` = the rows that go to rank r): rank r
+    gets ``payload[r]`` whole, and ``row_base`` (the first row of this chunk in the sender's shard) with it."""
+
+    def __init__(self, partitioned, group, async_op, row_base=0):
         import torch
         import torch.distributed as dist
         world = dist.get_world_size(group)
-        pk, pp, offsets = partitioned                                          # partition r = rows offsets[r]:offsets[r+1]
-        keys, payload = pk, pp
+        pk, pp, offsets = partitioned
         n = pk.numel()
         bounds = list(offsets) + [n]
-        send_counts = torch.tensor([bounds[r + 1] - bounds[r] for r in range(world)], dtype=torch.int64, device=keys.device)
-        recv_counts = torch.empty_like(send_counts)
-        dist.all_to_all_single(recv_counts, send_counts, group=group)          # the count matrix, one row per rank
-        send_split = send_counts.tolist()
-        recv_split = recv_counts.tolist()
+        stable = pp.dim() == 2
+        words = int(pp.shape[1]) if stable else 0
+        # the count matrix, one row per rank: keys for you, and (stable) the length of my bitmap and my chunk's first row
+        mine = [[bounds[r + 1] - bounds[r], words, int(row_base)] for r in range(world)]
+        send_info = torch.tensor(mine, dtype=torch.int64, device=pk.device).flatten()
+        recv_info = torch.empty_like(send_info)
+        dist.all_to_all_single(recv_info, send_info, group=group)
+        send_split = [m[0] for m in mine]
+        info = recv_info.view(world, 3).tolist()
+        recv_split = [int(i[0]) for i in info]
         total = int(sum(recv_split))
         self.keep = (pk, pp)                                                   # send buffers stay alive until finish()
-        self.rk = torch.empty(total, dtype=keys.dtype, device=keys.device)
-        self.rp = torch.empty(total, dtype=payload.dtype, device=keys.device)
-        self.works = (_all_to_all_v(self.rk, pk, recv_split, send_split, group, async_op) +
-                      _all_to_all_v(self.rp, pp, recv_split, send_split, group, async_op))
+        self.rk = torch.empty(total, dtype=pk.dtype, device=pk.device)
+        self.works = _all_to_all_v(self.rk, pk, recv_split, send_split, group, async_op)
+        self.bitmaps = self.row_base = self.rp = None
+        if stable:
+            rwords = [int(i[1]) for i in info]
+            self.row_base = [int(i[2]) for i in info]
+            flat = torch.empty(int(sum(rwords)), dtype=pp.dtype, device=pk.device)
+            send_bits = pp.reshape(-1)                                         # a copy unless pp is contiguous
+            self.keep = (pk, pp, send_bits)
+            self.works += _all_to_all_v(flat, send_bits, rwords, [words] * world, group, async_op)
+            self.bitmaps, at = [], 0
+            for w in rwords:
+                self.bitmaps.append(flat[at:at + w])
+                at += w
+        else:
+            self.rp = torch.empty(total, dtype=pp.dtype, device=pk.device)
+            self.works += _all_to_all_v(self.rp, pp, recv_split, send_split, group, async_op)
         self.bounds = [0]
         for c in recv_split:
             self.bounds.append(self.bounds[-1] + int(c))
@@ -199,7 +250,7 @@ class _Exchange:
             if w is not None:
                 w.wait()
         self.keep = None
-        return Received(self.rk, self.rp, self.bounds)
+        return Received(self.rk, self.rp, self.bounds, self.bitmaps, self.row_base)
 
 
 def exchange_by_key(keys, payload, partition_fn=_device_partition, group=None):
@@ -221,14 +272,15 @@ def distributed_inner_join(probe_keys, build_keys, shuffle_fn=_device_shuffle, j
     relation on the library's stream, so that the exchange hides behind the local HBM passes instead of adding
     to them.
 
-    ``shuffle_fn(keys, row_base, world, narrow)`` -> (partitioned keys, their row numbers, offsets);
+    ``shuffle_fn(keys, row_base, world, narrow)`` -> (partitioned keys, their row numbers or the bitmaps of a stable
+    partition, offsets);
     ``prepare_fn(build_keys)`` -> whatever ``join_fn(probe_keys, prepared)`` takes as its build side (None: the keys).
     """
     import torch.distributed as dist
     world = dist.get_world_size(group)
     n = probe_keys.numel()
     narrow = _narrow_range(probe_keys, build_keys, group)
-    build_x = _Exchange(shuffle_fn(build_keys, 0, world, narrow), group, async_op=True)
+    build_x = _Exchange(shuffle_fn(build_keys, 0, world, narrow), group, async_op=True, row_base=0)
     chunks = max(1, min(int(chunks), n)) if n else 1
     step = (n + chunks - 1) // chunks if n else 0
     build = prepared = None
@@ -236,7 +288,7 @@ def distributed_inner_join(probe_keys, build_keys, shuffle_fn=_device_shuffle, j
     pending = None
     for c in range(chunks):
         lo, hi = c * step, min(n, (c + 1) * step)
-        x = _Exchange(shuffle_fn(probe_keys[lo:hi], lo, world, narrow), group, async_op=True)   # partition c, then start moving it
+        x = _Exchange(shuffle_fn(probe_keys[lo:hi], lo, world, narrow), group, async_op=True, row_base=lo)   # partition c, then start moving it
         if build is None:
             build = build_x.finish()
             prepared = prepare_fn(build.keys) if prepare_fn is not None else build.keys

@@ -29,7 +29,7 @@ for it in range(4):
     chunks = 4; step = npr // chunks; total = 0
     for c in range(chunks):
         pk, pp, off = timed("shuffle", lambda: multigpu._device_shuffle(probe[c * step:(c + 1) * step], c * step, W, (lo, hi)), acc)
-        rk = timed("recv stand-in", lambda: pk.clone(), acc); rp = timed("recv stand-in", lambda: pp.clone(), acc)
+        rk = timed("recv stand-in", lambda: pk.clone(), acc); rp = timed("recv stand-in", lambda: pp[0].clone(), acc)
         li, ri = timed("probe", lambda: multigpu._device_inner_join(rk, prepared), acc)
         total += li.numel()
         del li, ri

@@ -163,6 +163,31 @@ def test_shuffle_partition_extension(gdf, nparts, mode, n):
         np.testing.assert_array_equal(kk[pr - row_base], pk)          # every key travels with ITS row number
 
 
+@pytest.mark.parametrize("nparts", [1, 2, 3, 8, 64])
+@pytest.mark.parametrize("mode", ["narrow", "int64", "int32"])
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 5000, 700_003])
+def test_shuffle_partition_stable_extension(gdf, nparts, mode, n):
+    """gdf_amd_shuffle_partition_stable: same partition assignment as gdf_hash_partition (oracle), keys of a partition in
+    INPUT order, and bitmap p marks exactly the input rows of partition p."""
+    from libgdf_amd import Column
+    import torch
+    base = 1 << 41 if mode != "int32" else 0
+    k = (np.random.randint(-300, 4000, size=n) + base).astype(np.int32 if mode == "int32" else np.int64)
+    narrow = (base, base + 3500) if mode == "narrow" else None
+    pk, bm, off = gdf.api.shuffle_partition_stable(Column(torch.from_numpy(k).cuda()), nparts, narrow=narrow)
+    kk = np.where((k >= narrow[0]) & (k <= narrow[1]), k - narrow[0], -1).astype(np.int32) if narrow else k
+    part = (oracle.hash_rows([kk]).astype(np.uint64) % np.uint64(nparts)).astype(np.int64) if n else np.zeros(0, np.int64)
+    pk = pk.cpu().numpy()
+    bits = np.unpackbits(bm.cpu().numpy().view(np.uint8).reshape(nparts, -1), axis=1, bitorder="little")[:, :n].astype(bool)
+    bounds = list(off) + [n]
+    for p in range(nparts):
+        rows = np.flatnonzero(part == p)
+        assert bounds[p + 1] - bounds[p] == len(rows)
+        np.testing.assert_array_equal(pk[bounds[p]:bounds[p + 1]], kk[rows])          # input order
+        np.testing.assert_array_equal(np.flatnonzero(bits[p]), rows)
+    assert bits.sum() == n
+
+
 def test_shuffle_partition_errors(gdf):
     import torch
     from libgdf_amd import Column, GDFError

@@ -38,10 +38,22 @@ def _np_narrow(keys, lo, hi):
 
 
 def _np_shuffle(keys, row_base, world, narrow):
-    """What gdf_amd_shuffle_partition computes: narrow, number the rows from row_base, partition on Murmur3(key)."""
-    k = _np_narrow(keys, *narrow) if narrow else keys
-    rows = torch.arange(row_base, row_base + k.numel(), dtype=torch.int32)
-    return _np_partition(k, rows, world)
+    """What gdf_amd_shuffle_partition_stable computes: narrow, partition on Murmur3(key) keeping the input order inside
+    every partition, and one bitmap per partition of the rows it took (little-endian 64-bit words)."""
+    k = (_np_narrow(keys, *narrow) if narrow else keys).numpy()
+    n = len(k)
+    part = oracle.partition_ids([k], world).astype(np.int64) if n else np.zeros(0, np.int64)
+    order = np.argsort(part, kind="stable")
+    counts = np.bincount(part, minlength=world)
+    offsets = [int(x) for x in np.concatenate([[0], np.cumsum(counts)[:-1]])]
+    words = (n + 63) // 64
+    bitmaps = np.zeros((world, max(words, 1) * 8), dtype=np.uint8)
+    for p in range(world):
+        bits = np.zeros(max(words, 1) * 64, dtype=np.uint8)
+        bits[:n] = part == p
+        bitmaps[p] = np.packbits(bits, bitorder="little")
+    bm = torch.from_numpy(bitmaps.view(np.int64).reshape(world, -1)[:, :words].copy())
+    return torch.from_numpy(k[order]), bm, offsets
 
 
 def _np_group_sum(k, v):

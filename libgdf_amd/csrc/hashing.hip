@@ -553,15 +553,21 @@ __global__ __launch_bounds__(HP_THREADS) void stable_count_kernel(const KIN *__r
     const int64_t i = wbase + r * WAVE + lane;
     k[r] = key[i < n ? i : n - 1];
   }
-  uint32_t mine = 0;                     // lane p: rows of this wave that go to partition p
+  // counting needs no order: one LDS atomic per row (one ballot per partition instead when there are only one or two
+  // counters for 64 lanes to queue on -- see partition_agg_bits)
+  uint32_t mine = 0;                     // lane p: rows of this wave that go to partition p (ballot variant)
 #pragma unroll
   for (int r = 0; r < ST_ROUNDS; ++r) {
     const bool live = wbase + r * WAVE + lane < n;
     const KOUT kk = shuffle_key<KIN, KOUT>(k[r], lo, span);
     const uint32_t part = live ? part_of(murmur3_32((uint64_t)kk, (int)sizeof(KOUT)), nparts, pow2mask) : 0xffffffffu;
-    for (uint32_t q = 0; q < nparts; ++q) {
-      const unsigned long long m = __ballot(part == q);
-      if ((uint32_t)lane == q) mine += (uint32_t)__popcll(m);
+    if (nparts <= 2) {
+      for (uint32_t q = 0; q < nparts; ++q) {
+        const unsigned long long m = __ballot(part == q);
+        if ((uint32_t)lane == q) mine += (uint32_t)__popcll(m);
+      }
+    } else if (live) {
+      atomicAdd(&cnt[part], 1u);
     }
   }
   if ((uint32_t)lane < nparts && mine) atomicAdd(&cnt[lane], mine);

@@ -46,6 +46,20 @@ gdf_error gdf_amd_join_build_probe(gdf_amd_join_build *build, int left_join, gdf
 void gdf_amd_join_build_free(gdf_amd_join_build *build);
 
 /*
+ * A probe relation that arrives in slices (the multi-GPU join receives it that way), partitioned slice by slice and
+ * probed ONCE: probe_indices number the rows across the slices in the order they were added; the result is what
+ * gdf_amd_join_build_probe(build, 0, all slices concatenated) returns.  INNER joins on one unmasked integer key column
+ * whose values fit the 32-bit tuple format only, and expected_rows >= 2^22 (an estimate of the total; a few percent of
+ * head-room are built in): anything else -- and a slice sequence so skewed that a partition outgrows its room --
+ * returns GDF_UNSUPPORTED_METHOD from _begin / _add / _finish, and the caller probes its slices one by one instead.
+ * _finish releases the object whatever it returns.
+ */
+typedef struct gdf_amd_join_probe gdf_amd_join_probe;
+gdf_error gdf_amd_join_probe_begin(gdf_amd_join_build *build, size_t expected_rows, gdf_amd_join_probe **out);
+gdf_error gdf_amd_join_probe_add(gdf_amd_join_probe *probe, gdf_column **probe_cols, int num_cols);
+gdf_error gdf_amd_join_probe_finish(gdf_amd_join_probe *probe, gdf_column *probe_indices, gdf_column *build_indices);
+
+/*
  * The sender side of the multi-GPU shuffle in ONE pass over the keys (instead of narrow + row-number column +
  * gdf_hash_partition): partitions (key', row) on Murmur3(key') into num_partitions partitions exactly as
  * gdf_hash_partition(GDF_HASH_MURMUR3) places them, where row = row_base + i and key' = keys[i], or, with narrow != 0

@@ -123,6 +123,9 @@ _PROTOTYPES = {
     "gdf_amd_join_build_create": (None, [C.POINTER(_COLP), C.c_int, C.POINTER(C.c_void_p)]),
     "gdf_amd_join_build_probe": (None, [C.c_void_p, C.c_int, C.POINTER(_COLP), C.c_int, _COLP, _COLP]),
     "gdf_amd_join_build_free": (C.c_int, [C.c_void_p]),                                       # void in C
+    "gdf_amd_join_probe_begin": (None, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "gdf_amd_join_probe_add": (None, [C.c_void_p, C.POINTER(_COLP), C.c_int]),
+    "gdf_amd_join_probe_finish": (None, [C.c_void_p, _COLP, _COLP]),
     "gdf_order_by": (None, [C.c_size_t, _COLP, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gdf_filter": (None, [C.c_size_t, _COLP, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                           C.POINTER(C.c_size_t)]),

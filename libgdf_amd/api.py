@@ -208,12 +208,47 @@ class JoinBuild:
             return LibraryIndexColumn(li), LibraryIndexColumn(ri)
         return _take_library_column(li, torch.int32), _take_library_column(ri, torch.int32)
 
+    def accumulate(self, expected_rows):
+        """gdf_amd_join_probe_begin: a probe relation added slice by slice and probed once.  Raises GDFError
+        (GDF_UNSUPPORTED_METHOD) when this build side / key type cannot do it: probe the slices one by one then."""
+        return ProbeAccumulator(self, expected_rows)
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             libgdf.gdf_amd_join_build_free(self._h)
             self._h = None
 
     __del__ = close
+
+
+class ProbeAccumulator:
+    """gdf_amd_join_probe_* (include/gdf/gdf_amd_ext.h)."""
+
+    def __init__(self, build: JoinBuild, expected_rows):
+        self._build = build                                            # keeps the build side alive
+        self._h = C.c_void_p()
+        libgdf.gdf_amd_join_probe_begin(build._h, int(expected_rows), C.byref(self._h))
+
+    def add(self, probe):
+        libgdf.gdf_amd_join_probe_add(self._h, column_array(probe), len(probe))
+
+    def finish(self, copy=True):
+        """-> (probe_idx, build_idx); probe rows are numbered across the slices in the order they were added."""
+        import torch
+        h, self._h = self._h, None                                     # _finish releases the object whatever it returns
+        li, ri = gdf_column(), gdf_column()
+        libgdf.gdf_amd_join_probe_finish(h, C.byref(li), C.byref(ri))
+        if not copy:
+            return LibraryIndexColumn(li), LibraryIndexColumn(ri)
+        return _take_library_column(li, torch.int32), _take_library_column(ri, torch.int32)
+
+    def __del__(self):
+        if getattr(self, "_h", None) is not None and self._h.value:     # abandoned: finish into the void to free it
+            try:
+                li, ri = self.finish(copy=False)
+                del li, ri
+            except Exception:
+                pass
 
 
 def prefixsum(col: Column, inclusive=True):

@@ -326,6 +326,9 @@ struct PartGeom {
   // Build relations beyond 2^15 x JK_TARGET_BUILD rows: b3 more partition bits, split off by a THIRD regrouping pass
   // over the level-2 output of both relations (refine_side); fb + b3 bits in all.  Host-side only.
   int b3;
+  // added to the row number a level-1 tuple carries: a probe relation that arrives in slices (gdf_amd_join_probe_add)
+  // is numbered across the slices
+  int32_t row_base;
 };
 
 // NARROW: w[i] = key32 << 32 | row, idx unused.  WIDE: w[i] = key64, idx[i] = row.
@@ -616,7 +619,7 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const uint32_t pos = (okmask >> (h + k)) & 1u ? st[k] + (binrank[h + k] & 0xffffu) : (uint32_t)JK_TILE;
-        const int32_t row = (int32_t)(tile + item_row(h + k, wtid));
+        const int32_t row = g.row_base + (int32_t)(tile + item_row(h + k, wtid));
         s.w[pos] = tup_make<NARROW>((uint64_t)key[h + k], row);
         if (!NARROW) s.idx[pos] = row;
       }
@@ -1564,8 +1567,19 @@ static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, Si
 // dup: expected rows per distinct key (probe rows / build rows): a partition's load is a sum over its keys, so
 // its variance grows with the multiplicity -- measured on C3 (10 probe rows per key) before this term existed:
 // the plain sqrt(mean) slack overflowed.
-static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, PartGeom g, double dup, SideBufs *sb, bool *ok) {
+// A probe relation accumulated slice by slice (gdf_amd_join_probe_*): the level-2 buffer, its fill counters and the
+// capacity of a fine partition persist across the slices; every slice gets its own level-1 pass.
+struct SpecAppend {
+  DevBuf cursor;               // [nfine] fill counters of the fine partitions
+  uint32_t cap2 = 0;           // room per fine partition, from the EXPECTED total
+  bool started = false;
+  int64_t rows = 0;            // rows added so far = row number of the next slice's first row
+};
+
+static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, PartGeom g, double dup, SideBufs *sb, bool *ok,
+                                     SpecAppend *app = nullptr) {
   *ok = false;
+  if (app) g.row_base = (int32_t)app->rows;
   const int64_t n = t.nrows;
   const bool narrow = plan.narrow != 0;
   static const int64_t chunk_rows_env = getenv("GDF_JK_CHUNK_ROWS") ? atoll(getenv("GDF_JK_CHUNK_ROWS")) : 0;
@@ -1593,7 +1607,7 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
   // partitions contiguous for the probe units
   g.xs = (g.b2 > 0 && n >= ((int64_t)1 << 26) && !getenv("GDF_JK_NO_XCD_SPLIT")) ? 3 : 0;
   const uint32_t nseg = ncoarse << g.xs;
-  const uint32_t cap1 = room((double)n / nseg, 64), cap2 = g.b2 ? room((double)n / nfine, 8) : 0;
+  const uint32_t cap1 = room((double)n / nseg, 64), cap2 = app ? app->cap2 : (g.b2 ? room((double)n / nfine, 8) : 0);
   const uint64_t size1 = (uint64_t)nseg * cap1 + JK_TILE, size2 = (uint64_t)nfine * cap2 + JK_TILE;
   if (size1 >= 0x7fffffffULL || size2 >= 0x7fffffffULL) return GDF_SUCCESS;      // tuple positions are 31-bit
 
@@ -1614,6 +1628,7 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
   if (c1[nseg]) return GDF_SUCCESS;
   sb->final_buf = 0;
   sb->fine_off.clear();
+  if (app && g.b2 == 0) return GDF_SUCCESS;      // (the caller never asks: accumulation needs the two-level layout)
   if (g.b2 == 0) {
     sb->fine_begin.resize(nfine);
     for (uint32_t f = 0; f < nfine; ++f) sb->fine_begin[f] = f * cap1;
@@ -1628,26 +1643,35 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
     }
     for (uint32_t f = 0; f < nfine; ++f) cur[f] = f * cap2;
     const uint32_t ntiles = tile_prefix[nseg];
-    DevBuf d_coarse, d_tiles, cursor;
+    DevBuf d_coarse, d_tiles, own_cursor;
+    DevBuf &cursor = app ? app->cursor : own_cursor;
     RMM_TRY(d_coarse.alloc(sizeof(uint32_t) * 2 * nseg));
     RMM_TRY(d_tiles.alloc(sizeof(uint32_t) * (nseg + 1)));
-    RMM_TRY(cursor.alloc(sizeof(uint32_t) * nfine));
     HIP_TRY(hipMemcpyAsync(d_coarse.p, coarse_off.data(), sizeof(uint32_t) * 2 * nseg, hipMemcpyHostToDevice, stream0()));
     HIP_TRY(hipMemcpyAsync(d_tiles.p, tile_prefix.data(), sizeof(uint32_t) * (nseg + 1), hipMemcpyHostToDevice, stream0()));
-    HIP_TRY(hipMemcpyAsync(cursor.p, cur.data(), sizeof(uint32_t) * nfine, hipMemcpyHostToDevice, stream0()));
-    RMM_TRY(sb->w[1].alloc(sizeof(uint64_t) * size2));
-    if (!narrow) RMM_TRY(sb->idx[1].alloc(sizeof(int32_t) * size2));
+    if (!app || !app->started) {        // the first (or only) slice sets up the level-2 buffer and its fill counters
+      RMM_TRY(cursor.alloc(sizeof(uint32_t) * nfine));
+      HIP_TRY(hipMemcpyAsync(cursor.p, cur.data(), sizeof(uint32_t) * nfine, hipMemcpyHostToDevice, stream0()));
+      RMM_TRY(sb->w[1].alloc(sizeof(uint64_t) * size2));
+      if (!narrow) RMM_TRY(sb->idx[1].alloc(sizeof(int32_t) * size2));
+      if (app) app->started = true;
+    }
     PartGeom g2 = g;
     g2.cap2 = cap2;
     g2.dump = nfine * cap2;
     Level2Map m{d_coarse.as<uint32_t>(), d_coarse.as<uint32_t>() + nseg, d_tiles.as<uint32_t>(), g.xs};
     if (ntiles) GDF_TRY(launch_scatter2(narrow, sc2_threads, ntiles, g2, m, sb->tuples(0), cursor.as<uint32_t>(), sb->tuples(1)));
     uint32_t flag = 0;
-    HIP_TRY(read_back(cur.data(), cursor.p, sizeof(uint32_t) * nfine));
+    if (!app) HIP_TRY(read_back(cur.data(), cursor.p, sizeof(uint32_t) * nfine));
     HIP_TRY(read_back(&flag, g.spec_flag, sizeof(uint32_t)));
     sb->w[0].reset();
     sb->idx[0].reset();
     if (flag) return GDF_SUCCESS;
+    if (app) {                          // the fill counters are read once, by spec_append_finish
+      app->rows += n;
+      *ok = true;
+      return GDF_SUCCESS;
+    }
     sb->fine_begin.resize(nfine);
     sb->fine_cnt.resize(nfine);
     for (uint32_t f = 0; f < nfine; ++f) { sb->fine_begin[f] = f * cap2; sb->fine_cnt[f] = cur[f] - f * cap2; }
@@ -1658,6 +1682,26 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
   sb->joinable = (uint32_t)total;
   sb->speculative = true;
   *ok = true;
+  return GDF_SUCCESS;
+}
+
+// the fine partitions of an accumulated probe relation, once all slices are in
+static gdf_error spec_append_finish(const PartGeom &g, SpecAppend *app, SideBufs *sb) {
+  const uint32_t nfine = 1u << g.fb;
+  std::vector<uint32_t> cur(nfine);
+  HIP_TRY(read_back(cur.data(), app->cursor.p, sizeof(uint32_t) * nfine));
+  sb->fine_off.clear();
+  sb->fine_begin.resize(nfine);
+  sb->fine_cnt.resize(nfine);
+  uint64_t total = 0;
+  for (uint32_t f = 0; f < nfine; ++f) {
+    sb->fine_begin[f] = f * app->cap2;
+    sb->fine_cnt[f] = cur[f] - f * app->cap2;
+    total += sb->fine_cnt[f];
+  }
+  sb->final_buf = 1;
+  sb->joinable = (uint32_t)total;
+  sb->speculative = true;
   return GDF_SUCCESS;
 }
 
@@ -1871,13 +1915,14 @@ static gdf_error prepare_build(const KeyTable &build_t, BuildSide *bs, bool no_l
   return GDF_SUCCESS;
 }
 
+static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &build_t, const BuildSide &bs, SideBufs &P, JoinKind kind,
+                                   int32_t **out_probe, int32_t **out_build, int64_t *out_n, StageClock &clk);
+
 static gdf_error probe_prepared(const KeyTable &probe_t, const KeyTable &build_t, const BuildSide &bs, JoinKind kind,
                                 int32_t **out_probe, int32_t **out_build, int64_t *out_n, StageClock &clk) {
   const KeyPlan &plan = bs.plan;
   const PartGeom &g = bs.g;
   const SideBufs &B = bs.B;
-  const uint32_t nfine = 1u << (g.fb + g.b3);
-  const bool keep_probe = kind != JOIN_INNER;
 
   SideBufs P;
   // The probe side is the big one (C3: 10x the build side): it is partitioned WITHOUT a histogram pass
@@ -1900,6 +1945,18 @@ static gdf_error probe_prepared(const KeyTable &probe_t, const KeyTable &build_t
     if (!ok) return GDF_AMD_RETRY_WITHOUT_LEVEL3;     // skewed probe keys: the caller repeats with a 2^fb-partition build side
   }
   clk.mark("partition probe side");
+  return probe_partitioned(probe_t, build_t, bs, P, kind, out_probe, out_build, out_n, clk);
+}
+
+// the part of a join after both relations are partitioned: work units, optimistic single pass or count + write, tails
+static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &build_t, const BuildSide &bs, SideBufs &P, JoinKind kind,
+                                   int32_t **out_probe, int32_t **out_build, int64_t *out_n, StageClock &clk) {
+  const KeyPlan &plan = bs.plan;
+  const PartGeom &g = bs.g;
+  const SideBufs &B = bs.B;
+  const uint32_t nfine = 1u << (g.fb + g.b3);
+  const bool keep_probe = kind != JOIN_INNER;
+  const bool narrow = plan.narrow != 0;
 
   // ---- work units ----
   std::vector<Unit> units;
@@ -2467,6 +2524,83 @@ static gdf_error build_probe(PreparedBuild *pb, int left_join, gdf_column **prob
   return GDF_SUCCESS;
 }
 
+// ---------------------------------------------------------------------------
+// gdf_amd_join_probe_* (include/gdf/gdf_amd_ext.h): a probe relation that arrives in slices is partitioned slice by
+// slice into ONE set of fine partitions and probed once.  (Probing every slice on its own re-inserts the LDS tables of
+// all build partitions per slice: 0.65 ms per slice at C4's shard sizes.)  INNER joins on plain NARROW keys with a
+// two-level build side only; everything else reports GDF_UNSUPPORTED_METHOD and the caller probes slice by slice.
+// ---------------------------------------------------------------------------
+struct ProbeAccum {
+  PreparedBuild *pb = nullptr;
+  SideBufs P;
+  SpecAppend app;
+  double dup = 1.0;
+  bool failed = false;
+};
+
+static gdf_error accum_begin(PreparedBuild *pb, size_t expected_rows, ProbeAccum **out) {
+  GDF_REQUIRE(pb && out, GDF_DATASET_EMPTY);
+  const KeyPlan &plan = pb->side.plan;
+  const PartGeom &g = pb->side.g;
+  uint32_t largest_build = 0;
+  for (uint32_t c : pb->side.B.fine_cnt) largest_build = std::max(largest_build, c);
+  if (!pb->partitioned || plan.verify || !plan.narrow || g.b2 == 0 || g.b3 != 0 || largest_build > (uint32_t)JK_MAX_BUILD ||
+      expected_rows < ((size_t)1 << 22) || getenv("GDF_JK_NO_ACCUM"))
+    return GDF_UNSUPPORTED_METHOD;
+  std::unique_ptr<ProbeAccum> a(new ProbeAccum());
+  a->pb = pb;
+  a->dup = std::max(1.0, (double)expected_rows / std::max<uint32_t>(pb->side.B.joinable, 1));
+  const double mean = (double)expected_rows / (double)(1u << g.fb);
+  // room per fine partition for the EXPECTED total plus 3 % (the slices' sizes are the senders' business) and the usual spread
+  a->app.cap2 = (uint32_t)(((uint64_t)(mean * 1.03 + 8.0 * std::sqrt(mean * (1.0 + a->dup)) + 64.0) + 7) / 8 * 8);
+  if ((uint64_t)(1u << g.fb) * a->app.cap2 + 16384 >= 0x7fffffffULL) return GDF_UNSUPPORTED_METHOD;
+  *out = a.release();
+  return GDF_SUCCESS;
+}
+
+static gdf_error accum_add(ProbeAccum *a, gdf_column **probe_cols, int num_cols) {
+  GDF_REQUIRE(a && probe_cols, GDF_DATASET_EMPTY);
+  GDF_REQUIRE(num_cols == a->pb->ncols, GDF_JOIN_DTYPE_MISMATCH);
+  if (a->failed) return GDF_UNSUPPORTED_METHOD;
+  const size_t n = probe_cols[0] ? probe_cols[0]->size : 0;
+  if (n == 0) return GDF_SUCCESS;
+  for (int i = 0; i < num_cols; ++i) {
+    GDF_REQUIRE(probe_cols[i] && probe_cols[i]->data, GDF_DATASET_EMPTY);
+    GDF_REQUIRE(probe_cols[i]->dtype == a->pb->cols[i].dtype, GDF_JOIN_DTYPE_MISMATCH);
+    GDF_REQUIRE(probe_cols[i]->size == n, GDF_COLUMN_SIZE_MISMATCH);
+    GDF_REQUIRE(!probe_cols[i]->valid, GDF_VALIDITY_UNSUPPORTED);
+  }
+  GDF_REQUIRE((uint64_t)a->app.rows + n < (uint64_t)INT_MAX, GDF_COLUMN_SIZE_TOO_BIG);
+  KeyTable pt;
+  GDF_TRY(make_key_table(probe_cols, num_cols, &pt));
+  bool ok = false;
+  GDF_TRY(partition_side_spec(pt, a->pb->side.plan, a->pb->side.g, a->dup, &a->P, &ok, &a->app));
+  if (!ok) { a->failed = true; return GDF_UNSUPPORTED_METHOD; }     // a partition outgrew its room: probe the slices one by one
+  return GDF_SUCCESS;
+}
+
+static gdf_error accum_finish(ProbeAccum *a, gdf_column *probe_indices, gdf_column *build_indices) {
+  std::unique_ptr<ProbeAccum> own(a);
+  GDF_REQUIRE(a && probe_indices && build_indices, GDF_DATASET_EMPTY);
+  if (a->failed) return GDF_UNSUPPORTED_METHOD;
+  gdf_column_view(probe_indices, nullptr, nullptr, 0, N_GDF_TYPES);
+  gdf_column_view(build_indices, nullptr, nullptr, 0, N_GDF_TYPES);
+  if (!a->app.started) return GDF_SUCCESS;                            // no rows were added
+  GDF_TRY(spec_append_finish(a->pb->side.g, &a->app, &a->P));
+  KeyTable all = a->pb->table;            // stands for the accumulated relation: same key columns, no data (never read on this path)
+  all.nrows = a->app.rows;
+  for (int c = 0; c < all.ncols; ++c) { all.col[c].data = nullptr; all.col[c].valid = nullptr; }
+  all.any_valid = 0;
+  StageClock clk(false);
+  int32_t *o_probe = nullptr, *o_build = nullptr;
+  int64_t n = 0;
+  GDF_TRY(probe_partitioned(all, a->pb->table, a->pb->side, a->P, JOIN_INNER, &o_probe, &o_build, &n, clk));
+  if (n == 0) return GDF_SUCCESS;
+  gdf_column_view(probe_indices, o_probe, nullptr, (gdf_size_type)n, GDF_INT32);
+  gdf_column_view(build_indices, o_build, nullptr, (gdf_size_type)n, GDF_INT32);
+  return GDF_SUCCESS;
+}
+
 }  // namespace gdf_amd
 
 using namespace gdf_amd;
@@ -2490,6 +2624,16 @@ __attribute__((visibility("default"))) gdf_error gdf_amd_join_build_probe(gdf_am
 }
 __attribute__((visibility("default"))) void gdf_amd_join_build_free(gdf_amd_join_build *build) {
   delete reinterpret_cast<PreparedBuild *>(build);
+}
+__attribute__((visibility("default"))) gdf_error gdf_amd_join_probe_begin(gdf_amd_join_build *build, size_t expected_rows, gdf_amd_join_probe **out) {
+  return accum_begin(reinterpret_cast<PreparedBuild *>(build), expected_rows, reinterpret_cast<ProbeAccum **>(out));
+}
+__attribute__((visibility("default"))) gdf_error gdf_amd_join_probe_add(gdf_amd_join_probe *probe, gdf_column **probe_cols, int num_cols) {
+  return accum_add(reinterpret_cast<ProbeAccum *>(probe), probe_cols, num_cols);
+}
+__attribute__((visibility("default"))) gdf_error gdf_amd_join_probe_finish(gdf_amd_join_probe *probe, gdf_column *probe_indices,
+                                                                          gdf_column *build_indices) {
+  return accum_finish(reinterpret_cast<ProbeAccum *>(probe), probe_indices, build_indices);
 }
 
 gdf_error gdf_inner_join(gdf_column **left_cols, int num_left_cols, int left_join_cols[], gdf_column **right_cols,

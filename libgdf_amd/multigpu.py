@@ -16,8 +16,9 @@ counterpart there; it sits ABOVE the unchanged per-GPU ``gdf_*`` C ABI (SURVEY.m
   3. one ``all_to_all_single`` per column moves partition r to rank r (xGMI is point-to-point, an
      all-to-all drives all 7 links of a GPU at once, so each column goes out as ONE large collective);
   4. every rank joins what it received: the received build relation is partitioned once
-     (``gdf_amd_join_build_create``) and probed by every received probe slice; the pairs are those of
-     ``gdf_inner_join``.  The result is a :class:`ShardedPairs`:
+     (``gdf_amd_join_build_create``), every received probe slice is partitioned as it arrives into ONE set of fine
+     partitions (``gdf_amd_join_probe_add``) and the lot is probed once at the end; the pairs are those of
+     ``gdf_inner_join``.  (Shapes the accumulator declines are probed slice by slice.)  The result is a :class:`ShardedPairs`:
      index pairs into the RECEIVED tables plus what is needed to name the original rows
      (``(owner rank, local row)``), resolved lazily -- an 8-byte global id per output row would double the
      output traffic of the timed path;
@@ -139,6 +140,28 @@ class Received:
             if bool(sel.any()):
                 rows[sel] = self._rows_of(r)[within[sel]]
         return (owner << 40) | rows
+
+
+class _ConcatReceived:
+    """Several received slices seen as one relation: position p belongs to the slice whose range holds it."""
+
+    def __init__(self, parts):
+        self.parts = parts
+        self.starts = [0]
+        for r in parts:
+            self.starts.append(self.starts[-1] + int(r.keys.numel()))
+
+    def global_ids(self, positions):
+        import torch
+        pos = positions.long()
+        starts = torch.tensor(self.starts, dtype=torch.int64, device=pos.device)
+        which = torch.bucketize(pos, starts[1:], right=True)
+        out = torch.empty_like(pos)
+        for i, r in enumerate(self.parts):
+            sel = which == i
+            if bool(sel.any()):
+                out[sel] = r.global_ids(pos[sel] - self.starts[i])
+        return out
 
 
 class ShardedPairs:
@@ -276,6 +299,7 @@ def distributed_inner_join(probe_keys, build_keys, shuffle_fn=_device_shuffle, j
     partition, offsets);
     ``prepare_fn(build_keys)`` -> whatever ``join_fn(probe_keys, prepared)`` takes as its build side (None: the keys).
     """
+    import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
     n = probe_keys.numel()
@@ -283,8 +307,26 @@ def distributed_inner_join(probe_keys, build_keys, shuffle_fn=_device_shuffle, j
     build_x = _Exchange(shuffle_fn(build_keys, 0, world, narrow), group, async_op=True, row_base=0)
     chunks = max(1, min(int(chunks), n)) if n else 1
     step = (n + chunks - 1) // chunks if n else 0
-    build = prepared = None
+    build = prepared = acc = None
     probes, ppos, bpos = [], [], []
+
+    def join_slice(r):
+        """One received probe slice against the prepared build side: added to the accumulator (one probe pass at the
+        very end) when the library can do that, joined on its own otherwise."""
+        nonlocal acc
+        probes.append(r)
+        if acc is not None:
+            try:
+                acc.add([_as_column(r.keys)])
+                return
+            except Exception:                       # a partition outgrew its room (skew): every slice on its own after all
+                acc = None
+                for earlier in probes[:-1]:
+                    li, ri = join_fn(earlier.keys, prepared)
+                    ppos.append(li); bpos.append(ri)
+        li, ri = join_fn(r.keys, prepared)
+        ppos.append(li); bpos.append(ri)
+
     pending = None
     for c in range(chunks):
         lo, hi = c * step, min(n, (c + 1) * step)
@@ -292,17 +334,38 @@ def distributed_inner_join(probe_keys, build_keys, shuffle_fn=_device_shuffle, j
         if build is None:
             build = build_x.finish()
             prepared = prepare_fn(build.keys) if prepare_fn is not None else build.keys
+            if hasattr(prepared, "accumulate"):
+                # what this rank will receive: its share of all probe rows (the key hash spreads them evenly)
+                total = torch.tensor([n], dtype=torch.int64, device=probe_keys.device)
+                dist.all_reduce(total, group=group)
+                try:
+                    acc = prepared.accumulate(int(total.item()) // world + 1)
+                except Exception:
+                    acc = None
         if pending is not None:                                                       # join c-1 while c moves
-            r = pending.finish()
-            li, ri = join_fn(r.keys, prepared)
-            probes.append(r); ppos.append(li); bpos.append(ri)
+            join_slice(pending.finish())
         pending = x
-    r = pending.finish()
-    li, ri = join_fn(r.keys, prepared)
-    probes.append(r); ppos.append(li); bpos.append(ri)
+    join_slice(pending.finish())
+    if acc is not None:
+        try:
+            li, ri = acc.finish(copy=False)
+            result = ShardedPairs([_ConcatReceived(probes)], build, [li], [ri])
+        except Exception:
+            acc = None
+            for r in probes:
+                li, ri = join_fn(r.keys, prepared)
+                ppos.append(li); bpos.append(ri)
+            result = ShardedPairs(probes, build, ppos, bpos)
+    else:
+        result = ShardedPairs(probes, build, ppos, bpos)
     if hasattr(prepared, "close"):
         prepared.close()
-    return ShardedPairs(probes, build, ppos, bpos)
+    return result
+
+
+def _as_column(t):
+    from .columns import Column
+    return Column(t)
 
 
 class _LocalRows:

@@ -27,12 +27,14 @@ for it in range(4):
     bk, bp, boff = timed("shuffle", lambda: multigpu._device_shuffle(build, 0, W, (lo, hi)), acc)
     prepared = timed("prepare", lambda: multigpu._device_prepare(bk), acc)
     chunks = 4; step = npr // chunks; total = 0
+    acc_obj = prepared.accumulate(npr)
     for c in range(chunks):
         pk, pp, off = timed("shuffle", lambda: multigpu._device_shuffle(probe[c * step:(c + 1) * step], c * step, W, (lo, hi)), acc)
         rk = timed("recv stand-in", lambda: pk.clone(), acc); rp = timed("recv stand-in", lambda: pp[0].clone(), acc)
-        li, ri = timed("probe", lambda: multigpu._device_inner_join(rk, prepared), acc)
-        total += li.numel()
-        del li, ri
+        timed("probe", lambda: acc_obj.add([multigpu._as_column(rk)]), acc)
+    li, ri = timed("probe", lambda: acc_obj.finish(copy=False), acc)
+    total += li.numel()
+    del li, ri
     prepared.close()
     sync(); wall = (time.perf_counter() - t0) * 1e3
     print("iter", it, "pairs", total, "wall ms %.1f" % wall, {k: round(v, 2) for k, v in acc.items()}, flush=True)

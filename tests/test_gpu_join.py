@@ -247,6 +247,15 @@ def test_multigpu_layer_world_size_one(gdf):
         c, d = sort_pairs(el, er)
         np.testing.assert_array_equal(a, c)
         np.testing.assert_array_equal(b, d)
+        # shard sizes at which the received probe slices are accumulated and probed once (gdf_amd_join_probe_*)
+        big_b = torch.randperm(1_300_000, device="cuda")[:1_000_000]
+        big_p = torch.randint(0, 1_300_000, (6_000_000,), device="cuda")
+        bp = multigpu.distributed_inner_join(big_p, big_b)
+        assert len(bp.probe_pos) == 1                      # one pair list: the accumulator took all four slices
+        g1, g2 = bp.global_ids()
+        assert g1.numel() == int(torch.isin(big_p, big_b).sum().item())
+        assert torch.equal(big_p[g1], big_b[g2])           # rank 0: a global id is the local row
+        assert torch.unique(g1).numel() == g1.numel()
         # the broadcast variant: same pairs
         bpairs = multigpu.broadcast_inner_join(torch.from_numpy(probe).cuda(), torch.from_numpy(build).cuda())
         bpg, bbg = bpairs.global_ids()
@@ -290,6 +299,42 @@ def test_prepared_build_probed_in_slices(gdf, how, dtypes):
         np.testing.assert_array_equal(a, c)
         np.testing.assert_array_equal(b, d)
     jb.close()
+
+
+@pytest.mark.parametrize("dtype", [np.int64, np.int32], ids=lambda d: np.dtype(d).name)
+def test_probe_relation_accumulated_in_slices(gdf, dtype):
+    """gdf_amd_join_probe_* (include/gdf/gdf_amd_ext.h): slices partitioned as they arrive, one probe pass at the end
+    == the join of the concatenated slices; unsupported shapes say so instead of computing something else."""
+    import torch
+    from libgdf_amd import Column, GDFError
+    nb = 3_000_000
+    tdt = torch.int64 if dtype == np.int64 else torch.int32
+    build = torch.randperm(nb + nb // 5, device="cuda")[:nb].to(tdt)
+    jb = gdf.api.JoinBuild([Column(build)])
+    slices = [torch.randint(0, nb + nb // 5, (n,), device="cuda").to(tdt) for n in (2_500_000, 1, 3_000_001, 0, 1_700_000)]
+    acc = jb.accumulate(sum(int(x.numel()) for x in slices))
+    for x in slices:
+        acc.add([Column(x)])
+    li, ri = acc.finish()
+    allp = torch.cat(slices)
+    el, er = jb.probe([Column(allp)])
+    assert li.numel() == el.numel()
+    assert torch.equal(build[ri.long()], allp[li.long()])
+    a = torch.sort(li.long() * (nb + 1) + ri.long()).values
+    b = torch.sort(el.long() * (nb + 1) + er.long()).values
+    assert torch.equal(a, b)
+    # too small an estimate: the slices do not fit the room reserved for them -> the accumulator gives up, loudly
+    acc = jb.accumulate(1 << 22)
+    with pytest.raises(GDFError, match="GDF_UNSUPPORTED_METHOD"):
+        for _ in range(4):
+            acc.add([Column(torch.randint(0, nb, (4_000_000,), device="cuda").to(tdt))])
+    with pytest.raises(GDFError, match="GDF_UNSUPPORTED_METHOD"):
+        acc.finish()
+    # a small build side (single partition level) and a small expected size are not accumulated at all
+    with pytest.raises(GDFError, match="GDF_UNSUPPORTED_METHOD"):
+        gdf.api.JoinBuild([Column(build[:1000])]).accumulate(1 << 24)
+    with pytest.raises(GDFError, match="GDF_UNSUPPORTED_METHOD"):
+        jb.accumulate(1000)
 
 
 def test_prepared_build_edge_cases(gdf, monkeypatch):

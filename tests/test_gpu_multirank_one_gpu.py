@@ -83,7 +83,10 @@ def _worker(rank, world, port, big, q):
     pg, bg = pairs.global_ids()
     bpairs = multigpu.broadcast_inner_join(p, b)
     bpg, bbg = bpairs.global_ids()
-    q.put((rank, len(pairs.probe_pos), pg.cpu().numpy(), bg.cpu().numpy(), bpg.cpu().numpy(), bbg.cpu().numpy()))
+    # group-by-sum of (key % 1000, key): local pre-aggregation, exchange of the partial sums, final aggregation
+    gk, gv = multigpu.distributed_group_by_sum(p % 1000, p)
+    q.put((rank, len(pairs.probe_pos), pg.cpu().numpy(), bg.cpu().numpy(), bpg.cpu().numpy(), bbg.cpu().numpy(),
+           gk.cpu().numpy(), gv.cpu().numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -103,15 +106,16 @@ def test_device_path_at_world_sizes_2_and_3(world, big):
         assert p.exitcode == 0
     probes, builds = _shards(world, big)
     # expected pairs in global ids: (rank << 40 | row) of every probe row whose key some rank's build relation holds
-    where = {}
-    for r, bk in enumerate(builds):
-        for i, k in enumerate(bk.tolist()):
-            where[k] = (r << 40) | i
+    allb = np.concatenate(builds)
+    bid = np.concatenate([(r << 40) + np.arange(len(bk), dtype=np.int64) for r, bk in enumerate(builds)])
+    order = np.argsort(allb)
+    sb, sid = allb[order], bid[order]
     exp = []
     for r, pk in enumerate(probes):
-        hit = np.isin(pk, np.concatenate(builds))
-        rows = np.flatnonzero(hit)
-        exp.append(np.stack([(r << 40) + rows, np.array([where[k] for k in pk[rows].tolist()], dtype=np.int64)], axis=1))
+        at = np.searchsorted(sb, pk)
+        at[at == len(sb)] = 0
+        rows = np.flatnonzero(sb[at] == pk)
+        exp.append(np.stack([(r << 40) + rows, sid[at[rows]]], axis=1))
     exp = np.concatenate(exp)
     exp = exp[np.lexsort(exp.T[::-1])]
     for a, b in ((2, 3), (4, 5)):
@@ -120,3 +124,13 @@ def test_device_path_at_world_sizes_2_and_3(world, big):
         np.testing.assert_array_equal(got, exp)
     if big:
         assert all(res[1] == 1 for res in results)          # the received slices were accumulated and probed once
+    allp = np.concatenate(probes)
+    sums = np.zeros(1000, dtype=np.int64)
+    np.add.at(sums, allp % 1000, allp)
+    ek = np.unique(allp % 1000)
+    ev = sums[ek]
+    gk = np.concatenate([res[6] for res in results])
+    gv = np.concatenate([res[7] for res in results])
+    order = np.argsort(gk)
+    np.testing.assert_array_equal(gk[order], ek)             # every group on exactly one rank
+    np.testing.assert_array_equal(gv[order], ev)

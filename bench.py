@@ -40,6 +40,9 @@ KERNEL_BYTES = {
     # the sender side of the shuffle (multi-GPU only): int64 keys in; narrowed key + int32 row number out
     "shuffle_hist": lambda npr, nb, tb, lps, kb: 8.0 * (npr + nb),
     "shuffle_scatter": lambda npr, nb, tb, lps, kb: (8.0 + kb + 4.0) * (npr + nb),
+    # the stable variant the join uses: keys out, one bit per row and destination instead of a row number
+    "stable_count": lambda npr, nb, tb, lps, kb: 8.0 * (npr + nb),
+    "stable_scatter": lambda npr, nb, tb, lps, kb: (8.0 + kb + 0.125) * (npr + nb),
 }
 
 

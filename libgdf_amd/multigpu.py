@@ -462,3 +462,31 @@ def distributed_group_by_sum(keys, values, group_fn=None, partition_fn=_device_p
     k1, v1 = group_fn(keys, values)
     k2, v2, _ = exchange_by_key(k1, v1, partition_fn, group)
     return group_fn(k2, v2)
+
+
+def _device_group(op, k, v, out_dtype=None):
+    from . import api
+    from .columns import Column
+    gk, ga = api.group_by(op, [Column(k)], Column(v), out_dtype=out_dtype)
+    return gk[0].clone(), ga.clone()
+
+
+def distributed_group_by(op, keys, values, group_fn=_device_group, partition_fn=_device_partition, group=None):
+    """``gdf_group_by_<op>`` (sum, min, max, count, avg) of a row-sharded (key, value) relation on one key column:
+    every rank pre-aggregates its shard, the partial aggregates travel to the rank ``hash(key) % world`` owns, and are
+    combined there -- partial sums / minima / maxima by the same operator, partial counts by a sum, AVG as the quotient of
+    the combined sums and counts (a float64 column).  Returns this rank's groups: (keys, aggregates)."""
+    if op in ("sum", "min", "max"):
+        k1, v1 = group_fn(op, keys, values)
+        k2, v2, _ = exchange_by_key(k1, v1, partition_fn, group)
+        return group_fn(op, k2, v2)
+    if op == "count":
+        k1, c1 = group_fn("count", keys, values)
+        k2, c2, _ = exchange_by_key(k1, c1, partition_fn, group)
+        return group_fn("sum", k2, c2)
+    if op == "avg":
+        ks, ss = distributed_group_by("sum", keys, values, group_fn, partition_fn, group)
+        kc, cc = distributed_group_by("count", keys, values, group_fn, partition_fn, group)
+        os_, oc = ks.argsort(), kc.argsort()               # the two results name the same groups; align them by key
+        return ks[os_], ss[os_].double() / cc[oc].double()
+    raise ValueError(f"unknown aggregation {op!r}")

@@ -85,8 +85,12 @@ def _worker(rank, world, port, big, q):
     bpg, bbg = bpairs.global_ids()
     # group-by-sum of (key % 1000, key): local pre-aggregation, exchange of the partial sums, final aggregation
     gk, gv = multigpu.distributed_group_by_sum(p % 1000, p)
+    others = {}
+    for op in ("min", "max", "count", "avg"):
+        ok, ov = multigpu.distributed_group_by(op, p % 1000, p)
+        others[op] = (ok.cpu().numpy(), ov.cpu().numpy())
     q.put((rank, len(pairs.probe_pos), pg.cpu().numpy(), bg.cpu().numpy(), bpg.cpu().numpy(), bbg.cpu().numpy(),
-           gk.cpu().numpy(), gv.cpu().numpy()))
+           gk.cpu().numpy(), gv.cpu().numpy(), others))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -134,3 +138,14 @@ def test_device_path_at_world_sizes_2_and_3(world, big):
     order = np.argsort(gk)
     np.testing.assert_array_equal(gk[order], ek)             # every group on exactly one rank
     np.testing.assert_array_equal(gv[order], ev)
+    import pandas as pd
+    ref = pd.DataFrame({"k": allp % 1000, "v": allp}).groupby("k")["v"]
+    for op, exp_col in (("min", ref.min()), ("max", ref.max()), ("count", ref.count()), ("avg", ref.mean())):
+        k = np.concatenate([res[8][op][0] for res in results])
+        v = np.concatenate([res[8][op][1] for res in results])
+        o = np.argsort(k)
+        np.testing.assert_array_equal(k[o], exp_col.index.values)
+        if op == "avg":
+            np.testing.assert_allclose(v[o], exp_col.values, rtol=1e-12)
+        else:
+            np.testing.assert_array_equal(v[o], exp_col.values)

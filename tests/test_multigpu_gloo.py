@@ -61,6 +61,11 @@ def _np_group_sum(k, v):
     return torch.from_numpy(keys[0].copy()), torch.from_numpy(agg.copy())
 
 
+def _np_group(op, k, v, out_dtype=None):
+    keys, agg = oracle.group_by(op, [k.numpy()], v.numpy(), np.int64 if op == "count" else None)
+    return torch.from_numpy(keys[0].copy()), torch.from_numpy(agg.copy())
+
+
 def _shards(world):
     rng = np.random.RandomState(1234)
     # probe keys range beyond the build keys on both sides: the narrowed exchange must drop exactly those
@@ -87,7 +92,11 @@ def _worker(rank, world, port, q):
     k = torch.from_numpy(probes[rank])
     v = torch.from_numpy((probes[rank] * 3 + rank).astype(np.int64))
     gk, gv = multigpu.distributed_group_by_sum(k, v, group_fn=_np_group_sum, partition_fn=_np_partition)
-    q.put((rank, pg.numpy(), bg.numpy(), gk.numpy(), gv.numpy(), bpg.numpy(), bbg.numpy()))
+    others = {}
+    for op in ("min", "max", "count", "avg"):
+        ok, ov = multigpu.distributed_group_by(op, k, v, group_fn=_np_group, partition_fn=_np_partition)
+        others[op] = (ok.numpy(), ov.numpy())
+    q.put((rank, pg.numpy(), bg.numpy(), gk.numpy(), gv.numpy(), bpg.numpy(), bbg.numpy(), others))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -128,3 +137,15 @@ def test_multi_rank_join_and_groupby_match_single_process(world):
     o = np.argsort(gk)
     np.testing.assert_array_equal(gk[o], ek[0])
     np.testing.assert_array_equal(gv[o], ea)
+    allk = np.concatenate(probes)
+    allv = np.concatenate([(probes[r] * 3 + r).astype(np.int64) for r in range(world)])
+    for op in ("min", "max", "count", "avg"):
+        xk, xa = oracle.group_by(op, [allk], allv, np.int64 if op == "count" else (np.float64 if op == "avg" else None))
+        k = np.concatenate([r[7][op][0] for r in results])
+        a = np.concatenate([r[7][op][1] for r in results])
+        o = np.argsort(k)
+        np.testing.assert_array_equal(k[o], xk[0])
+        if op == "avg":
+            np.testing.assert_allclose(a[o], xa, rtol=1e-12)
+        else:
+            np.testing.assert_array_equal(a[o], xa)

@@ -1650,8 +1650,10 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
     HIP_TRY(hipMemcpyAsync(d_coarse.p, coarse_off.data(), sizeof(uint32_t) * 2 * nseg, hipMemcpyHostToDevice, stream0()));
     HIP_TRY(hipMemcpyAsync(d_tiles.p, tile_prefix.data(), sizeof(uint32_t) * (nseg + 1), hipMemcpyHostToDevice, stream0()));
     if (!app || !app->started) {        // the first (or only) slice sets up the level-2 buffer and its fill counters
-      RMM_TRY(cursor.alloc(sizeof(uint32_t) * nfine));
-      HIP_TRY(hipMemcpyAsync(cursor.p, cur.data(), sizeof(uint32_t) * nfine, hipMemcpyHostToDevice, stream0()));
+      RMM_TRY(cursor.alloc(sizeof(uint32_t) * ((size_t)nfine + 1)));      // + the level-2 overflow flag: one read-back for both
+      cur.push_back(0u);
+      HIP_TRY(hipMemcpyAsync(cursor.p, cur.data(), sizeof(uint32_t) * ((size_t)nfine + 1), hipMemcpyHostToDevice, stream0()));
+      cur.pop_back();
       RMM_TRY(sb->w[1].alloc(sizeof(uint64_t) * size2));
       if (!narrow) RMM_TRY(sb->idx[1].alloc(sizeof(int32_t) * size2));
       if (app) app->started = true;
@@ -1659,11 +1661,18 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
     PartGeom g2 = g;
     g2.cap2 = cap2;
     g2.dump = nfine * cap2;
+    g2.spec_flag = cursor.as<uint32_t>() + nfine;
     Level2Map m{d_coarse.as<uint32_t>(), d_coarse.as<uint32_t>() + nseg, d_tiles.as<uint32_t>(), g.xs};
     if (ntiles) GDF_TRY(launch_scatter2(narrow, sc2_threads, ntiles, g2, m, sb->tuples(0), cursor.as<uint32_t>(), sb->tuples(1)));
     uint32_t flag = 0;
-    if (!app) HIP_TRY(read_back(cur.data(), cursor.p, sizeof(uint32_t) * nfine));
-    HIP_TRY(read_back(&flag, g.spec_flag, sizeof(uint32_t)));
+    if (!app) {
+      cur.resize((size_t)nfine + 1);
+      HIP_TRY(read_back(cur.data(), cursor.p, sizeof(uint32_t) * ((size_t)nfine + 1)));
+      flag = cur[nfine];
+      cur.pop_back();
+    } else {
+      HIP_TRY(read_back(&flag, cursor.as<uint32_t>() + nfine, sizeof(uint32_t)));
+    }
     sb->w[0].reset();
     sb->idx[0].reset();
     if (flag) return GDF_SUCCESS;

@@ -2036,20 +2036,25 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
     RMM_TRY(d_sample.alloc(sizeof(Unit) * nsample));
     RMM_TRY(d_scount.alloc(sizeof(uint64_t) * nsample));
     HIP_TRY(hipMemcpyAsync(d_sample.p, sample.data(), sizeof(Unit) * nsample, hipMemcpyHostToDevice, stream0()));
+    // the slots of the optimistic pass are laid out and uploaded now, under the sample kernel, not after its read-back
+    std::vector<uint64_t> off(nunits + 1);
+    off[0] = 0;
+    for (size_t i = 0; i < nunits; ++i) off[i + 1] = off[i] + units[i].probe_count;
+    RMM_TRY(d_off.alloc(sizeof(uint64_t) * (nunits + 1)));
+    RMM_TRY(d_state.alloc(sizeof(unsigned long long) * 4));
     ProbeArgs sa = a;
     sa.units = d_sample.as<Unit>();
     sa.counts = d_scount.as<uint64_t>();
     sa.build_matched = nullptr;
     GDF_TRY(run_probe(narrow, false, "jk_probe_sample", nsample, probe_lds, sa, probe_t, build_t));
+    HIP_TRY(hipMemcpyAsync(d_off.p, off.data(), sizeof(uint64_t) * (nunits + 1), hipMemcpyHostToDevice, stream0()));
+    HIP_TRY(hipMemsetAsync(d_state.p, 0, sizeof(unsigned long long) * 4, stream0()));
     std::vector<uint64_t> scount(nsample);
     HIP_TRY(read_back(scount.data(), d_scount.p, sizeof(uint64_t) * nsample));
     clk.mark("sample count");
     uint64_t sample_pairs = 0;
     for (uint64_t c : scount) sample_pairs += c;
     if (sample_pairs == sample_tuples) {
-      std::vector<uint64_t> off(nunits + 1);
-      off[0] = 0;
-      for (size_t i = 0; i < nunits; ++i) off[i + 1] = off[i] + units[i].probe_count;
       const uint64_t cap_pairs = off[nunits];
       const uint64_t probe_tail = keep_probe ? (uint64_t)probe_t.nrows - P.joinable : 0;
       const uint64_t total = cap_pairs + probe_tail;
@@ -2057,10 +2062,7 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
       DevBuf op, ob;
       RMM_TRY(op.alloc(sizeof(int32_t) * (total ? total : 1)));
       RMM_TRY(ob.alloc(sizeof(int32_t) * (total ? total : 1)));
-      RMM_TRY(d_off.alloc(sizeof(uint64_t) * (nunits + 1)));
-      RMM_TRY(d_state.alloc(sizeof(unsigned long long) * 4));
-      HIP_TRY(hipMemcpyAsync(d_off.p, off.data(), sizeof(uint64_t) * (nunits + 1), hipMemcpyHostToDevice, stream0()));
-      HIP_TRY(hipMemsetAsync(d_state.p, 0, sizeof(unsigned long long) * 4, stream0()));
+
       ProbeArgs oa = a;
       oa.counts = d_off.as<uint64_t>();
       oa.out_probe = op.as<int32_t>();

@@ -75,6 +75,9 @@ gdf_error gdf_amd_shuffle_partition(gdf_column *keys, int narrow, int64_t lo, in
  * memory, bit i of word i / 64 -- has bit i set iff input row i went to partition p.  The j-th key of partition p is
  * therefore input row select(bitmap p, j): a receiver names the original row of a joined key from one bit per row
  * instead of a 4-byte row number (4.125 instead of 8 bytes per row on the links).  num_partitions <= 64.
+ * narrow = 2: as narrow = 1, and a row whose key lies outside [lo, hi] -- it cannot match any build key of an inner
+ * join -- is DROPPED: it goes to no partition and sets no bitmap bit (with narrow = 1 all such rows become the key -1 and
+ * pile up on one rank).  partition_offsets then has num_partitions + 1 entries, the last one = rows that travel.
  */
 gdf_error gdf_amd_shuffle_partition_stable(gdf_column *keys, int narrow, int64_t lo, int64_t hi, int num_partitions,
                                            gdf_column *out_keys, uint64_t *bitmaps, int partition_offsets[]);

@@ -146,6 +146,8 @@ _RMM_PROTOTYPES = {
 }
 
 GDF_CUDA_ERROR = 1
+GDF_UNSUPPORTED_METHOD = 12          # include/gdf/gdf.h gdf_error
+GDF_INT64 = 4                        # include/gdf/gdf.h gdf_dtype
 
 
 def _load(name):

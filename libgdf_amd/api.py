@@ -177,17 +177,20 @@ def shuffle_partition(keys: Column, num_partitions, row_base=0, narrow=None):
 
 def shuffle_partition_stable(keys: Column, num_partitions, narrow=None):
     """gdf_amd_shuffle_partition_stable -> (keys tensor, bitmaps int64 tensor [num_partitions, ceil(n / 64)], offsets).
-    Partition p holds its keys in input order; bit i of bitmap p says that input row i went there."""
+    Partition p holds its keys in input order; bit i of bitmap p says that input row i went there.  With ``narrow`` =
+    (lo, hi) the keys travel as int32 (key - lo) and rows whose key lies outside [lo, hi] -- they can join nothing --
+    stay home: they are in no partition and in no bitmap, and the returned key tensor is shorter than the input."""
     import torch
     n = keys.size
     out_k = Column(torch.empty(n, dtype=torch.int32 if narrow else keys.data.dtype, device=keys.data.device))
     words = (n + 63) // 64
     bitmaps = torch.empty((num_partitions, max(words, 1)), dtype=torch.int64, device=keys.data.device)
-    offsets = (C.c_int * num_partitions)()
+    offsets = (C.c_int * (num_partitions + 1))()
     lo, hi = narrow if narrow else (0, 0)
-    libgdf.gdf_amd_shuffle_partition_stable(keys.ptr, 1 if narrow else 0, int(lo), int(hi), num_partitions, out_k.ptr,
+    libgdf.gdf_amd_shuffle_partition_stable(keys.ptr, 2 if narrow else 0, int(lo), int(hi), num_partitions, out_k.ptr,
                                             bitmaps.data_ptr(), offsets)
-    return out_k.data, bitmaps[:, :words], list(offsets)
+    total = int(offsets[num_partitions]) if narrow else n
+    return out_k.data[:total], bitmaps[:, :words], list(offsets)[:num_partitions]
 
 
 class JoinBuild:

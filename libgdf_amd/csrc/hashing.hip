@@ -539,7 +539,7 @@ constexpr int ST_TILE = HP_THREADS * ST_ROUNDS;
 template <class KIN, class KOUT>
 __global__ __launch_bounds__(HP_THREADS) void stable_count_kernel(const KIN *__restrict__ key, long long lo, unsigned long long span,
                                                                    int64_t n, uint32_t ntiles, uint32_t nparts, uint32_t pow2mask,
-                                                                   uint32_t *__restrict__ counts) {
+                                                                   uint32_t drop, uint32_t *__restrict__ counts) {
   __shared__ uint32_t cnt[SHT_MAX_PARTS];
   const uint32_t tile = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   if (tile >= ntiles) return;
@@ -558,8 +558,9 @@ __global__ __launch_bounds__(HP_THREADS) void stable_count_kernel(const KIN *__r
   uint32_t mine = 0;                     // lane p: rows of this wave that go to partition p (ballot variant)
 #pragma unroll
   for (int r = 0; r < ST_ROUNDS; ++r) {
-    const bool live = wbase + r * WAVE + lane < n;
     const KOUT kk = shuffle_key<KIN, KOUT>(k[r], lo, span);
+    // drop: a key outside the build range joins nothing -- it stays home (no partition, no bitmap bit)
+    const bool live = wbase + r * WAVE + lane < n && !(drop && (uint32_t)kk == 0xffffffffu);
     const uint32_t part = live ? part_of(murmur3_32((uint64_t)kk, (int)sizeof(KOUT)), nparts, pow2mask) : 0xffffffffu;
     if (nparts <= 2) {
       for (uint32_t q = 0; q < nparts; ++q) {
@@ -578,12 +579,13 @@ __global__ __launch_bounds__(HP_THREADS) void stable_count_kernel(const KIN *__r
 template <class KIN, class KOUT>
 __global__ __launch_bounds__(HP_THREADS) void stable_scatter_kernel(const KIN *__restrict__ key, long long lo, unsigned long long span,
                                                                      int64_t n, uint32_t ntiles, uint32_t nparts, uint32_t pow2mask,
-                                                                     const uint32_t *__restrict__ offsets, KOUT *__restrict__ out_key,
+                                                                     uint32_t drop, const uint32_t *__restrict__ offsets, KOUT *__restrict__ out_key,
                                                                      unsigned long long *__restrict__ bitmaps, uint64_t words) {
   __shared__ KOUT stage[ST_TILE];
   __shared__ uint8_t bin_of[ST_TILE];
   __shared__ uint32_t wtot[ST_WAVES * SHT_MAX_PARTS];     // rows of wave w for partition p, then: rows of earlier waves
   __shared__ uint32_t start[SHT_MAX_PARTS], gbase[SHT_MAX_PARTS];
+  __shared__ uint32_t tile_total;
   const uint32_t tile = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   if (tile >= ntiles) return;
   const int wave = threadIdx.x / WAVE, lane = lane_id();
@@ -602,8 +604,8 @@ __global__ __launch_bounds__(HP_THREADS) void stable_scatter_kernel(const KIN *_
 #pragma unroll
   for (int r = 0; r < ST_ROUNDS; ++r) {
     const int64_t row0 = wbase + r * WAVE;
-    const bool live = row0 + lane < n;
     kk[r] = shuffle_key<KIN, KOUT>(k[r], lo, span);
+    const bool live = row0 + lane < n && !(drop && (uint32_t)kk[r] == 0xffffffffu);
     part[r] = live ? part_of(murmur3_32((uint64_t)kk[r], (int)sizeof(KOUT)), nparts, pow2mask) : 0xffffffffu;
     before[r] = run;
     same[r] = 0;
@@ -625,11 +627,13 @@ __global__ __launch_bounds__(HP_THREADS) void stable_scatter_kernel(const KIN *_
         wtot[w * SHT_MAX_PARTS + lane] = total;
         total += c;
       }
-    const uint32_t st = wave_scan_incl(total) - total;
+    const uint32_t incl = wave_scan_incl(total);
+    const uint32_t st = incl - total;
     if ((uint32_t)lane < nparts) {
       start[lane] = st;
       gbase[lane] = offsets[(size_t)lane * ntiles + tile] - st;
     }
+    if (lane == WAVE - 1) tile_total = incl;          // rows of this tile that travel (all of them unless some are dropped)
   }
   block_sync();
   const unsigned long long lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
@@ -644,8 +648,7 @@ __global__ __launch_bounds__(HP_THREADS) void stable_scatter_kernel(const KIN *_
     }
   }
   block_sync();
-  const int64_t tile_rows = n - (int64_t)tile * ST_TILE;
-  const uint32_t total = (uint32_t)(tile_rows < ST_TILE ? tile_rows : ST_TILE);
+  const uint32_t total = tile_total;
   for (uint32_t j = threadIdx.x; j < total; j += HP_THREADS) out_key[gbase[bin_of[j]] + j] = stage[j];
 }
 
@@ -857,8 +860,9 @@ gdf_error gdf_amd_shuffle_partition_stable(gdf_column *keys, int narrow, int64_t
   const size_t num_rows = keys->size;
   GDF_REQUIRE(num_rows < (size_t)INT_MAX, GDF_COLUMN_SIZE_TOO_BIG);
   const uint32_t P = (uint32_t)num_partitions;
+  const uint32_t drop = narrow == 2 ? 1u : 0u;
   if (num_rows == 0) {
-    for (uint32_t p = 0; p < P; ++p) partition_offsets[p] = 0;
+    for (uint32_t p = 0; p < P + drop; ++p) partition_offsets[p] = 0;
     return GDF_SUCCESS;
   }
   GDF_REQUIRE(keys->data && out_keys->data, GDF_DATASET_EMPTY);
@@ -868,26 +872,27 @@ gdf_error gdf_amd_shuffle_partition_stable(gdf_column *keys, int narrow, int64_t
   const uint32_t grid = (ntiles + 7) / 8 * 8;
   const uint64_t words = (uint64_t)((n + 63) / 64);
   DevBuf counts, starts;
-  RMM_TRY(counts.alloc(sizeof(uint32_t) * (size_t)P * ntiles));
-  RMM_TRY(starts.alloc(sizeof(uint32_t) * P));
+  RMM_TRY(counts.alloc(sizeof(uint32_t) * ((size_t)P * ntiles + 1)));     // + the grand total, which the scan leaves behind the matrix
+  RMM_TRY(starts.alloc(sizeof(uint32_t) * (P + 1)));
   const long long llo = narrow ? (long long)lo : 0;
   const unsigned long long span = narrow ? (unsigned long long)((uint64_t)hi - (uint64_t)lo) : 0;
 #define STABLE_PASSES(KIN, KOUT)                                                                                                    \
   GDF_LAUNCH("stable_count", (stable_count_kernel<KIN, KOUT>), dim3(grid), dim3(HP_THREADS), 0, stream0(), (const KIN *)keys->data, llo, \
-             span, n, ntiles, P, pow2mask, counts.as<uint32_t>());                                                                  \
+             span, n, ntiles, P, pow2mask, drop, counts.as<uint32_t>());                                                            \
   HIP_CHECK_LAST();                                                                                                                \
-  GDF_TRY(scan_u32(counts.as<uint32_t>(), counts.as<uint32_t>(), (size_t)P * ntiles, false));                                      \
-  hipLaunchKernelGGL(gather_strided_u32, dim3((P + 255) / 256), dim3(256), 0, stream0(), counts.as<uint32_t>(), starts.as<uint32_t>(), \
-                     (int)P, (size_t)ntiles);                                                                                      \
+  HIP_TRY(hipMemsetAsync(counts.as<uint32_t>() + (size_t)P * ntiles, 0, sizeof(uint32_t), stream0()));                              \
+  GDF_TRY(scan_u32(counts.as<uint32_t>(), counts.as<uint32_t>(), (size_t)P * ntiles + 1, false));                                  \
+  hipLaunchKernelGGL(gather_strided_u32, dim3((P + 256) / 256), dim3(256), 0, stream0(), counts.as<uint32_t>(), starts.as<uint32_t>(), \
+                     (int)P + 1, (size_t)ntiles);                                                                                  \
   GDF_LAUNCH("stable_scatter", (stable_scatter_kernel<KIN, KOUT>), dim3(grid), dim3(HP_THREADS), 0, stream0(), (const KIN *)keys->data, \
-             llo, span, n, ntiles, P, pow2mask, (const uint32_t *)counts.as<uint32_t>(), (KOUT *)out_keys->data,                    \
+             llo, span, n, ntiles, P, pow2mask, drop, (const uint32_t *)counts.as<uint32_t>(), (KOUT *)out_keys->data,              \
              (unsigned long long *)bitmaps, words);                                                                                \
   HIP_CHECK_LAST();
   if (narrow) { STABLE_PASSES(uint64_t, uint32_t) }
   else if (win == 8) { STABLE_PASSES(uint64_t, uint64_t) }
   else { STABLE_PASSES(uint32_t, uint32_t) }
 #undef STABLE_PASSES
-  HIP_TRY(hipMemcpyAsync(partition_offsets, starts.p, sizeof(int) * P, hipMemcpyDeviceToHost, stream0()));
+  HIP_TRY(hipMemcpyAsync(partition_offsets, starts.p, sizeof(int) * (P + drop), hipMemcpyDeviceToHost, stream0()));
   HIP_TRY(hipStreamSynchronize(stream0()));
   return GDF_SUCCESS;
 }

@@ -45,7 +45,7 @@ struct Buf {
   const uint8_t *p;
   size_t n;
   template <class T> T at(size_t off) const {
-    if (off + sizeof(T) > n) throw ParseError("flatbuffer field outside the message");
+    if (off > n || sizeof(T) > n - off) throw ParseError("flatbuffer field outside the message");   // no wrap-around
     T v;
     std::memcpy(&v, p + off, sizeof(T));
     return v;
@@ -58,7 +58,9 @@ struct Table {
   // byte position of field `id`, or 0 when the field is absent (default value applies)
   size_t field(int id) const {
     const int32_t so = b->at<int32_t>(pos);
-    const size_t vt = (size_t)((int64_t)pos - so);
+    const int64_t vt64 = (int64_t)pos - so;
+    if (vt64 < 0 || (uint64_t)vt64 >= b->n) throw ParseError("vtable outside the message");   // a crafted soffset must not wrap
+    const size_t vt = (size_t)vt64;
     const uint16_t vsize = b->at<uint16_t>(vt);
     const size_t slot = 4 + 2 * (size_t)id;
     if (slot + 2 > vsize) return 0;
@@ -72,7 +74,7 @@ struct Table {
     const size_t s = indirect(id);
     if (!s) return std::string();
     const uint32_t len = b->at<uint32_t>(s);
-    if (s + 4 + len > b->n) throw ParseError("string outside the message");
+    if (s > b->n || b->n - s < 4 || len > b->n - s - 4) throw ParseError("string outside the message");
     return std::string((const char *)b->p + s + 4, len);
   }
   // vector field: position of element 0 and the element count

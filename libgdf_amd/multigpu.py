@@ -34,6 +34,8 @@ receiver would continue from 8-byte packed tuples instead of re-reading raw keys
 """
 from __future__ import annotations
 
+from ._binding import GDFError, GDF_UNSUPPORTED_METHOD
+
 
 def _device_partition(keys, payload, world):
     """gdf_hash_partition over (key, payload) on the key column -> (keys_out, payload_out, offsets list)."""
@@ -304,9 +306,16 @@ def distributed_inner_join(probe_keys, build_keys, shuffle_fn=_device_shuffle, j
     world = dist.get_world_size(group)
     n = probe_keys.numel()
     narrow = _narrow_range(probe_keys, build_keys, group)
+    # Every slice is a collective (count matrix + batched point-to-point), so ALL ranks must run the same number of
+    # them whatever their own row count: the slice count follows the LARGEST shard, and a rank that runs out of rows
+    # sends empty slices.
+    sizes = torch.empty(world, dtype=torch.int64, device=probe_keys.device)
+    dist.all_gather_into_tensor(sizes, torch.tensor([n], dtype=torch.int64, device=probe_keys.device), group=group)
+    sizes = [int(x) for x in sizes.tolist()]
+    n_total = sum(sizes)
     build_x = _Exchange(shuffle_fn(build_keys, 0, world, narrow), group, async_op=True, row_base=0)
-    chunks = max(1, min(int(chunks), n)) if n else 1
-    step = (n + chunks - 1) // chunks if n else 0
+    chunks = max(1, min(int(chunks), max(sizes)))
+    step = (n + chunks - 1) // chunks
     build = prepared = acc = None
     probes, ppos, bpos = [], [], []
 
@@ -319,7 +328,9 @@ def distributed_inner_join(probe_keys, build_keys, shuffle_fn=_device_shuffle, j
             try:
                 acc.add([_as_column(r.keys)])
                 return
-            except Exception:                       # a partition outgrew its room (skew): every slice on its own after all
+            except GDFError as e:                   # a partition outgrew its room (skew): every slice on its own after all
+                if e.errcode != GDF_UNSUPPORTED_METHOD:
+                    raise                           # a real fault (HIP error, out of memory ...) is not a plan change
                 acc = None
                 for earlier in probes[:-1]:
                     li, ri = join_fn(earlier.keys, prepared)
@@ -329,18 +340,18 @@ def distributed_inner_join(probe_keys, build_keys, shuffle_fn=_device_shuffle, j
 
     pending = None
     for c in range(chunks):
-        lo, hi = c * step, min(n, (c + 1) * step)
+        lo, hi = min(n, c * step), min(n, (c + 1) * step)
         x = _Exchange(shuffle_fn(probe_keys[lo:hi], lo, world, narrow), group, async_op=True, row_base=lo)   # partition c, then start moving it
         if build is None:
             build = build_x.finish()
             prepared = prepare_fn(build.keys) if prepare_fn is not None else build.keys
             if hasattr(prepared, "accumulate"):
                 # what this rank will receive: its share of all probe rows (the key hash spreads them evenly)
-                total = torch.tensor([n], dtype=torch.int64, device=probe_keys.device)
-                dist.all_reduce(total, group=group)
                 try:
-                    acc = prepared.accumulate(int(total.item()) // world + 1)
-                except Exception:
+                    acc = prepared.accumulate(n_total // world + 1)
+                except GDFError as e:
+                    if e.errcode != GDF_UNSUPPORTED_METHOD:
+                        raise
                     acc = None
         if pending is not None:                                                       # join c-1 while c moves
             join_slice(pending.finish())
@@ -350,7 +361,9 @@ def distributed_inner_join(probe_keys, build_keys, shuffle_fn=_device_shuffle, j
         try:
             li, ri = acc.finish(copy=False)
             result = ShardedPairs([_ConcatReceived(probes)], build, [li], [ri])
-        except Exception:
+        except GDFError as e:
+            if e.errcode != GDF_UNSUPPORTED_METHOD:
+                raise
             acc = None
             for r in probes:
                 li, ri = join_fn(r.keys, prepared)
@@ -465,10 +478,24 @@ def distributed_group_by_sum(keys, values, group_fn=None, partition_fn=_device_p
 
 
 def _device_group(op, k, v, out_dtype=None):
+    """One local gdf_group_by_<op>.  COUNT is typed by its OUTPUT column in the library (the reference's rule), so the
+    partial counts are asked for as int64 -- in the value dtype an int8 column would wrap at 128 rows per group."""
     from . import api
+    from ._binding import GDF_INT64
     from .columns import Column
+    if op == "count" and out_dtype is None:
+        out_dtype = GDF_INT64
     gk, ga = api.group_by(op, [Column(k)], Column(v), out_dtype=out_dtype)
     return gk[0].clone(), ga.clone()
+
+
+def _widen(values):
+    """The accumulator type of a distributed AVG: int64 for integer values, float64 for floating-point ones (what the
+    single-GPU gdf_group_by_avg accumulates in) -- partial SUMs in a narrow value dtype would wrap before they meet."""
+    import torch
+    if values.dtype in (torch.float32, torch.float64):
+        return values if values.dtype == torch.float64 else values.double()
+    return values if values.dtype == torch.int64 else values.long()
 
 
 def distributed_group_by(op, keys, values, group_fn=_device_group, partition_fn=_device_partition, group=None):
@@ -485,6 +512,7 @@ def distributed_group_by(op, keys, values, group_fn=_device_group, partition_fn=
         k2, c2, _ = exchange_by_key(k1, c1, partition_fn, group)
         return group_fn("sum", k2, c2)
     if op == "avg":
+        values = _widen(values)
         ks, ss = distributed_group_by("sum", keys, values, group_fn, partition_fn, group)
         kc, cc = distributed_group_by("count", keys, values, group_fn, partition_fn, group)
         os_, oc = ks.argsort(), kc.argsort()               # the two results name the same groups; align them by key

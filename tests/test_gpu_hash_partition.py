@@ -168,7 +168,7 @@ def test_shuffle_partition_extension(gdf, nparts, mode, n):
 @pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 5000, 700_003])
 def test_shuffle_partition_stable_extension(gdf, nparts, mode, n):
     """gdf_amd_shuffle_partition_stable: same partition assignment as gdf_hash_partition (oracle), keys of a partition in
-    INPUT order, and bitmap p marks exactly the input rows of partition p."""
+    INPUT order, and bitmap p marks exactly the input rows of partition p.  Narrowed: rows outside the range stay home."""
     from libgdf_amd import Column
     import torch
     base = 1 << 41 if mode != "int32" else 0
@@ -177,15 +177,19 @@ def test_shuffle_partition_stable_extension(gdf, nparts, mode, n):
     pk, bm, off = gdf.api.shuffle_partition_stable(Column(torch.from_numpy(k).cuda()), nparts, narrow=narrow)
     kk = np.where((k >= narrow[0]) & (k <= narrow[1]), k - narrow[0], -1).astype(np.int32) if narrow else k
     part = (oracle.hash_rows([kk]).astype(np.uint64) % np.uint64(nparts)).astype(np.int64) if n else np.zeros(0, np.int64)
+    if narrow:
+        part[kk == -1] = -1                                              # dropped: in no partition, in no bitmap
+    kept = int((part >= 0).sum())
     pk = pk.cpu().numpy()
+    assert len(pk) == kept
     bits = np.unpackbits(bm.cpu().numpy().view(np.uint8).reshape(nparts, -1), axis=1, bitorder="little")[:, :n].astype(bool)
-    bounds = list(off) + [n]
+    bounds = list(off) + [kept]
     for p in range(nparts):
         rows = np.flatnonzero(part == p)
         assert bounds[p + 1] - bounds[p] == len(rows)
         np.testing.assert_array_equal(pk[bounds[p]:bounds[p + 1]], kk[rows])          # input order
         np.testing.assert_array_equal(np.flatnonzero(bits[p]), rows)
-    assert bits.sum() == n
+    assert bits.sum() == kept
 
 
 def test_shuffle_partition_errors(gdf):

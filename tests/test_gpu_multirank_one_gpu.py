@@ -25,7 +25,12 @@ def _free_port():
 def _stage_through_host():
     """gloo moves host tensors: wrap the collectives multigpu.py uses so that device tensors take a detour."""
     from libgdf_amd import multigpu
-    a2a, allred = dist.all_to_all_single, dist.all_reduce
+    a2a, allred, allgat = dist.all_to_all_single, dist.all_reduce, dist.all_gather_into_tensor
+
+    def all_gather_into_tensor(out, inp, group=None):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        allgat(o, inp.cpu(), group=group)
+        out.copy_(o)
 
     def all_to_all_single(out, inp, group=None):
         o = torch.empty(out.shape, dtype=out.dtype)
@@ -58,6 +63,7 @@ def _stage_through_host():
         return []
 
     dist.all_to_all_single, dist.all_reduce, multigpu._all_to_all_v = all_to_all_single, all_reduce, all_to_all_v
+    dist.all_gather_into_tensor = all_gather_into_tensor
 
 
 def _shards(world, big):
@@ -149,3 +155,81 @@ def test_device_path_at_world_sizes_2_and_3(world, big):
             np.testing.assert_allclose(v[o], exp_col.values, rtol=1e-12)
         else:
             np.testing.assert_array_equal(v[o], exp_col.values)
+
+
+def _uneven_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from libgdf_amd import multigpu
+    _stage_through_host()
+    probes, builds, vals = _uneven_shards(world)
+    p = torch.from_numpy(probes[rank]).cuda()
+    b = torch.from_numpy(builds[rank]).cuda()
+    pairs = multigpu.distributed_inner_join(p, b, chunks=4)
+    pg, bg = pairs.global_ids()
+    t = torch.tensor([rank + 1], dtype=torch.int64, device="cuda")
+    dist.all_reduce(t)                                   # pairs with a stray exchange if a rank ran fewer slices
+    assert int(t) == world * (world + 1) // 2
+    out = {}
+    k = (p % 7)
+    for name, v in vals[rank].items():
+        tv = torch.from_numpy(v).cuda()
+        for op in ("count", "avg"):
+            ok, ov = multigpu.distributed_group_by(op, k, tv)
+            out[(name, op)] = (ok.cpu().numpy(), ov.cpu().numpy())
+    q.put((rank, pg.cpu().numpy(), bg.cpu().numpy(), out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _uneven_shards(world):
+    rs = np.random.RandomState(5)
+    sizes = [0, 2, 40_000][:world]
+    probes = [(rs.randint(-500, 6000, size=n) + (1 << 35)).astype(np.int64) for n in sizes]     # a fifth outside the build range
+    builds = [(rs.permutation(5000)[: 1500 if r else 0] + (1 << 35)).astype(np.int64) for r in range(world)]
+    # value columns whose partial sums / counts overflow their own dtype: 40000 rows over 7 groups
+    vals = [{"int8": rs.randint(100, 127, size=n).astype(np.int8), "int32": rs.randint(2**30, 2**31 - 1, size=n).astype(np.int32),
+             "float32": (rs.rand(n) * 1e3 + 2**24).astype(np.float32)} for n in sizes]
+    return probes, builds, vals
+
+
+@pytest.mark.timeout(600)
+def test_uneven_shards_and_narrow_value_dtypes():
+    """(high) ranks with 0 and 2 probe rows run as many exchanges as the rank with 40000; (medium) partial
+    COUNTs are int64 and the partial SUMs of an AVG are widened, so int8 / int32 / float32 value columns aggregate like
+    the single-GPU call; (medium) probe keys outside the build range stay home instead of piling up on one rank."""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_uneven_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=500) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    probes, builds, vals = _uneven_shards(world)
+    from oracle import oracle
+    gp = np.concatenate([(r << 40) + np.arange(len(probes[r]), dtype=np.int64) for r in range(world)])
+    gb = np.concatenate([(r << 40) + np.arange(len(builds[r]), dtype=np.int64) for r in range(world)])
+    li, ri = oracle.join([np.concatenate(probes)], [np.concatenate(builds)], "inner")
+    exp = np.stack([gp[li], gb[ri]], axis=1)
+    got = np.concatenate([np.stack([r[1], r[2]], axis=1) for r in results])
+    np.testing.assert_array_equal(got[np.lexsort(got.T[::-1])], exp[np.lexsort(exp.T[::-1])])
+    import pandas as pd
+    allk = np.concatenate(probes) % 7
+    for name in ("int8", "int32", "float32"):
+        allv = np.concatenate([v[name] for v in vals])
+        ref = pd.DataFrame({"k": allk, "v": allv.astype(np.float64)}).groupby("k")["v"]
+        for op, exp_col in (("count", ref.count()), ("avg", ref.mean())):
+            k = np.concatenate([r[3][(name, op)][0] for r in results])
+            v = np.concatenate([r[3][(name, op)][1] for r in results])
+            o = np.argsort(k)
+            np.testing.assert_array_equal(k[o], exp_col.index.values)
+            if op == "count":
+                np.testing.assert_array_equal(v[o], exp_col.values)
+            else:
+                np.testing.assert_allclose(v[o], exp_col.values, rtol=1e-6 if name == "float32" else 1e-12)

@@ -104,6 +104,17 @@ def test_malformed_input_sets_the_failure_flag():
     assert lib.gdf_ipc_parser_failed(h) == 1 and b"expecting schema" in lib.gdf_ipc_parser_get_error(h)
     lib.gdf_ipc_parser_close(h)
     sb = batch.schema.serialize().to_pybytes()
+    # a crafted vtable offset (soffset = position + 1 / + 2, i.e. a vtable "before" the buffer) must be a
+    # ParseError, not a read in front of the heap block
+    body = bytearray(sb[8:])                                 # continuation marker + length, then the flatbuffer
+    root = int.from_bytes(body[0:4], "little")
+    for delta in (1, 2, 1 << 20):
+        evil = bytearray(body)
+        evil[root:root + 4] = (root + delta).to_bytes(4, "little", signed=True)
+        msg = sb[:8] + bytes(evil)
+        h = _open(lib, msg)
+        assert lib.gdf_ipc_parser_failed(h) == 1 and lib.gdf_ipc_parser_get_error(h).decode().startswith("ParseError")
+        lib.gdf_ipc_parser_close(h)
     h = _open(lib, sb)
     lib.gdf_ipc_parser_open(sb, len(sb))                     # unrelated second parser: fine
     assert not lib.gdf_ipc_parser_failed(h)

@@ -43,8 +43,11 @@ def _np_shuffle(keys, row_base, world, narrow):
     k = (_np_narrow(keys, *narrow) if narrow else keys).numpy()
     n = len(k)
     part = oracle.partition_ids([k], world).astype(np.int64) if n else np.zeros(0, np.int64)
+    if narrow:
+        part[k == -1] = world                       # outside the build range: joins nothing, stays home
     order = np.argsort(part, kind="stable")
-    counts = np.bincount(part, minlength=world)
+    order = order[:int((part < world).sum())]
+    counts = np.bincount(part, minlength=world + 1)[:world]
     offsets = [int(x) for x in np.concatenate([[0], np.cumsum(counts)[:-1]])]
     words = (n + 63) // 64
     bitmaps = np.zeros((world, max(words, 1) * 8), dtype=np.uint8)
@@ -149,3 +152,52 @@ def test_multi_rank_join_and_groupby_match_single_process(world):
             np.testing.assert_allclose(a[o], xa, rtol=1e-12)
         else:
             np.testing.assert_array_equal(a[o], xa)
+
+
+def _uneven_shards(world):
+    rng = np.random.RandomState(99)
+    sizes = [0, 2, 3000][:world] if world <= 3 else [0, 2] + [3000] * (world - 2)
+    probes = [(rng.randint(-20, 300, size=n) + (1 << 33)).astype(np.int64) for n in sizes]
+    builds = [(rng.randint(0, 250, size=100 if r else 0) + (1 << 33)).astype(np.int64) for r in range(world)]   # rank 0 holds nothing at all
+    return probes, builds
+
+
+def _uneven_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from libgdf_amd import multigpu
+    probes, builds = _uneven_shards(world)
+    pairs = multigpu.distributed_inner_join(torch.from_numpy(probes[rank]), torch.from_numpy(builds[rank]),
+                                            shuffle_fn=_np_shuffle, join_fn=_np_join, prepare_fn=None, chunks=4)
+    pg, bg = pairs.global_ids()
+    # a collective right behind the join: a rank that ran fewer exchanges than its peers would pair it with their slices
+    t = torch.tensor([rank + 1], dtype=torch.int64)
+    dist.all_reduce(t)
+    assert int(t) == world * (world + 1) // 2
+    q.put((rank, pg.numpy(), bg.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_ranks_with_zero_and_two_probe_rows_run_the_same_number_of_exchanges():
+    """the slice count must not depend on the LOCAL row count -- every slice is a collective."""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_uneven_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    probes, builds = _uneven_shards(world)
+    gp = np.concatenate([(r << 40) + np.arange(len(probes[r]), dtype=np.int64) for r in range(world)])
+    gb = np.concatenate([(r << 40) + np.arange(len(builds[r]), dtype=np.int64) for r in range(world)])
+    li, ri = oracle.join([np.concatenate(probes)], [np.concatenate(builds)], "inner")
+    exp = np.stack([gp[li], gb[ri]], axis=1)
+    got = np.concatenate([np.stack([r[1], r[2]], axis=1) for r in results])
+    np.testing.assert_array_equal(got[np.lexsort(got.T[::-1])], exp[np.lexsort(exp.T[::-1])])

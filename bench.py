@@ -87,19 +87,65 @@ def read_profile(gdf):
     return {names[i].value.decode(): (ms[i], cnt[i]) for i in range(min(k, 64))}
 
 
+def library_build_id():
+    """sha256 of the kernel SOURCES libgdf.so is built from (csrc/*): the same value here and on the GPU box, and it
+    changes whenever a kernel changes -- unlike a hash of the .so, which would differ between two builds of one source."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "libgdf_amd", "csrc", "*"))):
+        if os.path.isfile(f):
+            h.update(os.path.basename(f).encode())
+            with open(f, "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel, launches_per_step):
     """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary (profiles/*_pmc_hbm.json).
-    bench.py cannot collect counters itself; the file states how they were collected and corrected."""
+    bench.py cannot collect counters itself (separate --pmc passes, tools/pmc_hbm_json.py); the file states how they were
+    collected and corrected and carries the build id of the kernels it measured -- counters of OTHER kernel sources are
+    refused (traffic = null) instead of silently going stale."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json")), key=os.path.getmtime)
     if not files:
-        return None, None
+        return None, "no profiles/*_pmc_hbm.json"
     with open(files[-1]) as f:
         data = json.load(f)
+    rel = os.path.relpath(files[-1], ROOT)
+    if data.get("build_id") != library_build_id():
+        return None, f"{rel} measured build {data.get('build_id')}, this is {library_build_id()}: refused"
     k = data.get("kernels", {}).get(kernel)
     if not k or not launches_per_step:
-        return None, None
-    return k["hbm_bytes_per_join_corrected"] / launches_per_step, os.path.relpath(files[-1], ROOT)
+        return None, rel
+    return k["hbm_bytes_per_join_corrected"] / launches_per_step, rel
+
+
+def cpu_baseline_pandas(sample_probe, sample_build, budget_s=60.0):
+    """The CPU path BASELINE.json's north_star names: pandas.merge(how="inner") on int64 keys, the same key
+    distribution as C3 at a tenth of its size.  Median of up to three runs (stops early once `budget_s` is spent:
+    pandas joins ~2-5 M rows/s on one core)."""
+    import numpy as np
+    import pandas as pd
+    from oracle import oracle
+    rng = np.random.RandomState(0x5EED)
+    build = rng.permutation(sample_build).astype(np.int64)
+    probe = ((oracle.splitmix64(np.arange(sample_probe, dtype=np.uint64) + np.uint64(0x5EED0002)) >> np.uint64(1))
+             % np.uint64(sample_build)).astype(np.int64)
+    left = pd.DataFrame({"k": probe, "l": np.arange(sample_probe, dtype=np.int32)})
+    right = pd.DataFrame({"k": build, "r": np.arange(sample_build, dtype=np.int32)})
+    times = []
+    while len(times) < 3 and sum(times) < budget_s:
+        t0 = time.perf_counter()
+        m = left.merge(right, on="k", how="inner")
+        times.append(time.perf_counter() - t0)
+        assert len(m) == sample_probe
+        del m
+    dt = sorted(times)[len(times) // 2]
+    return {"value": sample_probe / dt, "unit": "rows/s", "cores": 1, "kind": "port", "impl": f"pandas {pd.__version__} DataFrame.merge",
+            "sample": f"pandas.merge(how='inner') of {sample_probe} probe x {sample_build} build int64 rows (C3 / "
+                      f"{1_000_000_000 // max(sample_probe, 1)}), median of {len(times)} run(s) = {dt:.1f} s; pandas' hash join is "
+                      f"single-threaded: 1 of the host's {os.cpu_count()} cores"}
 
 
 def cpu_baseline(sample_probe, sample_build):
@@ -127,7 +173,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--probe-rows", type=int, default=1_000_000_000)
     ap.add_argument("--build-rows", type=int, default=None)
-    ap.add_argument("--cpu-sample", type=int, default=20_000_000, help="probe rows of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=20_000_000, help="probe rows of the oracle-port CPU baseline sample (0 = skip)")
+    ap.add_argument("--pandas-sample", type=int, default=100_000_000, help="probe rows of the pandas.merge CPU baseline (0 = skip)")
     ap.add_argument("--strategy", choices=["shuffle", "broadcast"], default="shuffle",
                     help="multi-GPU join: shuffle both relations by key (C4 as BASELINE.json names it, the default) or gather the "
                          "build keys on every GPU and leave the probe relation where it is (libgdf_amd/multigpu.py)")
@@ -135,12 +182,24 @@ def main():
                     help="run the multi-GPU (C4) code path even at world size 1 (1-rank RCCL group): measures its local passes")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher -- one rank per GPU under torch.distributed.run, exactly
+        # the command line the driver would have used; rank 0 of the children prints the JSON line
+        import socket
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
+
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.device_count() > local_rank, f"rank {rank} needs cuda:{local_rank}, this node has {torch.cuda.device_count()} GPU(s)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     distributed = world > 1 or args.force_distributed
@@ -264,8 +323,12 @@ def main():
                              "algorithmic_bytes_per_gpu": e2e_bytes},
             "kernels_ms_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
         }
+        if world == 1 and args.pandas_sample > 0:
+            result["cpu_baseline"] = cpu_baseline_pandas(args.pandas_sample, max(args.pandas_sample // 10, 1))
         if world == 1 and args.cpu_sample > 0:
-            result["cpu_baseline"] = cpu_baseline(args.cpu_sample, max(args.cpu_sample // 10, 1))
+            port = cpu_baseline(args.cpu_sample, max(args.cpu_sample // 10, 1))
+            result["cpu_baseline_oracle_port"] = port
+            result.setdefault("cpu_baseline", port)
         print(json.dumps(result))
     if distributed:
         dist.destroy_process_group()

@@ -1,0 +1,128 @@
+"""-m gpu: BASELINE config C5 -- multi-key gdf_group_by_avg, fp64 values with a validity mask, 50 % nulls, Zipf-skewed keys --
+and the reference's MaxJoinTest (tests/join/join-tests.cu:732-748).
+
+C5 has no counterpart in the reference (it rejects every mask, sqls_ops.cu:1103-1106); the mask semantics are those of
+oracle.group_by_masked, which tests/test_oracle_cpu.py pins against pandas.groupby(dropna=True).
+  (i)  up to 4e6 rows against the oracle, PLAIN relative tolerance 1e-6 (BASELINE.json north_star) -- the values are in
+       [0, 1), nothing cancels, so no tolerance relative to a sum of magnitudes is needed;
+  (ii) the full 1e9-row relation through size-independent properties (tools/bench_c5.py: c5_property_checks)."""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-6          # north_star: "within 1e-6 relative for fp32/fp64 sum/avg"
+
+
+def _c5_numpy(n, zipf_values, seed):
+    rs = np.random.RandomState(seed)
+    u = rs.random_sample(n)
+    k0 = np.clip(np.exp(u * math.log(zipf_values + 1.0)).astype(np.int64) - 1, 0, zipf_values - 1)   # p(r) ~ 1 / r
+    k1 = rs.randint(0, 16, size=n).astype(np.int32)
+    v = rs.random_sample(n)
+    ok = rs.random_sample(n) < 0.5
+    return k0, k1, v, ok
+
+
+@pytest.mark.parametrize("n,zipf_values", [(200_000, 1_000), (4_000_000, 1_000_000), (3_000_000, 50)],
+                         ids=["dense-path", "partitioned-sorted-path", "direct-path-heavy-skew"])
+@pytest.mark.parametrize("op", ["avg", "sum", "count"])
+def test_c5_shape_against_the_oracle(gdf, n, zipf_values, op):
+    from libgdf_amd.columns import column_from_numpy, get_dtype
+    k0, k1, v, ok = _c5_numpy(n, zipf_values, 17)
+    top = np.bincount(k0).max() / n
+    assert top > 0.05                                            # Zipf(s=1): the hottest key holds > 5 % of the rows
+    kc = [column_from_numpy(k0), column_from_numpy(k1)]
+    vc = column_from_numpy(v, ok)
+    out = np.int64 if op == "count" else np.float64
+    gk, ga, gok = gdf.api.group_by(op, kc, vc, out_dtype=get_dtype(out), with_masks=True)
+    gk, ga, gok = [x.cpu().numpy() for x in gk], ga.cpu().numpy(), gok.numpy()
+    ek, ea, eok = oracle.group_by_masked(op, [k0, k1], v, [None, None], ok, out)
+    if op != "avg":                                              # AVG comes out sorted (groupby.cuh:345-386); the others need not
+        order = np.lexsort((gk[1], gk[0]))
+        gk, ga, gok = [k[order] for k in gk], ga[order], gok[order]
+    assert len(ga) == len(ea)
+    np.testing.assert_array_equal(gk[0], ek[0])
+    np.testing.assert_array_equal(gk[1], ek[1])
+    np.testing.assert_array_equal(gok, eok)                       # a group is null iff it has no valid value
+    assert (ga[~gok] == 0).all()
+    if op == "count":
+        np.testing.assert_array_equal(ga, ea)
+    else:
+        np.testing.assert_allclose(ga[gok], ea[eok], rtol=RTOL, atol=0.0)        # plain relative
+
+
+def test_c5_full_size_properties(gdf):
+    """1e9 rows, 1e6 Zipf values x 16: ~1.6e7 groups, the hottest key pair holds ~0.4 % of the rows."""
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from bench_c5 import c5_property_checks, make_c5
+    dev = torch.device("cuda", 0)
+    k0, k1, v, ok, mask = make_c5(1_000_000_000, dev)
+    checks, good = c5_property_checks(gdf, k0, k1, v, ok, mask, cap=20_000_000)
+    assert good, checks
+    assert checks["groups"] > 15_000_000
+    del k0, k1, v, ok, mask
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("how", ["inner", "left"])
+def test_max_join_size_2_to_the_29(gdf, how):
+    """MaxJoinTest.HugeJoinSize (join-tests.cu:732-748): a 100-row left table against 2^29 int32 rows on the right must
+    succeed.  LEFT keeps the 2^29-row table on the build side; INNER may flip (joining.h:58-66).  Checked against a
+    brute-force count of every left key in the right column."""
+    import torch
+    from libgdf_amd.columns import Column
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(29)
+    nr = 1 << 29
+    right = torch.randint(0, 2**31 - 1, (nr,), generator=g, device=dev, dtype=torch.int32)        # rand() % RAND_MAX
+    left = torch.randint(0, 2**31 - 1, (100,), generator=g, device=dev, dtype=torch.int32)
+    left[:40] = right[torch.randint(0, nr, (40,), generator=g, device=dev)]                       # make sure something matches
+    li, ri = gdf.api.join([Column(left)], [Column(right)], how=how)
+    li, ri = li.long(), ri.long()
+    counts = torch.stack([(right == k).sum() for k in left])
+    matched = ri >= 0
+    assert bool((left[li[matched]] == right[ri[matched]]).all())
+    assert int(matched.sum()) == int(counts.sum())
+    assert int(torch.unique(li[matched] * nr + ri[matched]).numel()) == int(matched.sum())        # no pair twice
+    got = torch.bincount(li[matched], minlength=100)
+    assert torch.equal(got, counts)
+    if how == "left":
+        assert int((~matched).sum()) == int((counts == 0).sum())                                  # (l, -1) once per unmatched row
+        assert torch.equal(torch.sort(li[~matched]).values, torch.nonzero(counts == 0).flatten())
+    else:
+        assert bool(matched.all())
+    del right, li, ri
+    torch.cuda.empty_cache()
+
+
+def test_inner_join_with_a_2_to_the_29_row_build_side(gdf):
+    """The same size with the big table forced onto the BUILD side of an inner join (the probe side is larger): 2^29 unique
+    build keys, 6e8 probe rows that all hit -- the third partitioning level of csrc/join.hip."""
+    import torch
+    from bench import make_probe_keys
+    from libgdf_amd.columns import Column
+    dev = torch.device("cuda", 0)
+    nb, npr = 1 << 29, 600_000_000
+    g = torch.Generator(device=dev)
+    g.manual_seed(31)
+    build = torch.randperm(nb, generator=g, device=dev, dtype=torch.int64).to(torch.int32)
+    probe = make_probe_keys(npr, nb, 0x5EED0009, dev).to(torch.int32)
+    li, ri = gdf.api.join([Column(probe)], [Column(build)])
+    assert li.numel() == npr
+    seen = torch.zeros(npr, dtype=torch.bool, device=dev)
+    step = 1 << 27
+    for s in range(0, npr, step):
+        l, r = li[s:s + step].long(), ri[s:s + step].long()
+        assert bool((probe[l] == build[r]).all())
+        seen[l] = True
+    assert bool(seen.all())
+    del build, probe, li, ri, seen
+    torch.cuda.empty_cache()

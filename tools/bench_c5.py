@@ -16,6 +16,69 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def make_c5(n, dev, zipf_values=1_000_000):
+    """The C5 relation: k0 int64 Zipf(s=1) over `zipf_values` values (inverse CDF of p(r) ~ 1/r), k1 int32 uniform [0, 16),
+    fp64 values uniform [0, 1), value validity 50 % -> (k0, k1, v, ok bool tensor, LSB-first mask bytes)."""
+    import torch
+    from bench import splitmix64_torch
+    k0 = torch.empty(n, dtype=torch.int64, device=dev)
+    k1 = torch.empty(n, dtype=torch.int32, device=dev)
+    v = torch.empty(n, dtype=torch.float64, device=dev)
+    ok = torch.empty(n, dtype=torch.bool, device=dev)
+    step = 1 << 26
+    M = zipf_values
+    for s in range(0, n, step):
+        e = min(n, s + step)
+        i = torch.arange(s, e, dtype=torch.int64, device=dev)
+        u = ((splitmix64_torch(i + 0x5EED0005) >> 11) & ((1 << 53) - 1)).double() / float(1 << 53)
+        k0[s:e] = torch.clamp(torch.exp(u * math.log(M + 1.0)).long() - 1, 0, M - 1)
+        k1[s:e] = ((splitmix64_torch(i + 0x5EED0006) >> 1) % 16).int()
+        v[s:e] = ((splitmix64_torch(i + 0x5EED0007) >> 11) & ((1 << 53) - 1)).double() / float(1 << 53)
+        ok[s:e] = (splitmix64_torch(i + 0x5EED0008) >> 63) == 0
+        del i, u
+    pad = (-n) % 8
+    bits = torch.cat([ok, torch.zeros(pad, dtype=torch.bool, device=dev)]).view(-1, 8).to(torch.uint8)
+    weights = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.uint8, device=dev)
+    mask = (bits * weights).sum(dim=1, dtype=torch.int32).to(torch.uint8)
+    mask = torch.cat([mask, torch.zeros((-mask.numel()) % 64, dtype=torch.uint8, device=dev)])
+    return k0, k1, v, ok, mask
+
+
+def c5_property_checks(gdf, k0, k1, v, ok, mask, cap):
+    """Size-independent properties of gdf_group_by_avg / _count over the C5 relation (what a 1e9-row run can be held to):
+    group count = number of distinct key pairs, AVG output sorted by key, AVG and COUNT name the same groups, the counts
+    add up to the number of valid values, a group is null exactly when its count is 0, and sum(avg * count) = sum of
+    the valid values.  -> (checks dict, all good)"""
+    import torch
+    from libgdf_amd.columns import Column
+    n = k0.numel()
+    kc = [Column(k0), Column(k1)]
+    vc = Column(v, mask, null_count=int(n - ok.sum().item()))
+    gk, avg, avg_ok = gdf.api.group_by("avg", kc, vc, out_dtype=6, capacity=cap, with_masks=True)
+    ck, cnt, _ = gdf.api.group_by("count", kc, vc, out_dtype=4, capacity=cap, with_masks=True)
+    pk_avg = gk[0] * 16 + gk[1].long()
+    pk_cnt = ck[0] * 16 + ck[1].long()
+    order = torch.argsort(pk_cnt)
+    cnt_sorted = cnt[order]
+    avg_ok = avg_ok.to(avg.device)
+    checks = {
+        "groups": int(avg.numel()),
+        "groups_expected": int(torch.unique(k0 * 16 + k1.long()).numel()),
+        "avg_keys_sorted": bool((pk_avg[1:] > pk_avg[:-1]).all().item()),
+        "same_keys_avg_and_count": bool(torch.equal(pk_avg, pk_cnt[order])),
+        "sum_of_counts": int(cnt.sum().item()), "valid_values": int(ok.sum().item()),
+        "null_groups": int((~avg_ok).sum().item()), "zero_count_groups": int((cnt == 0).sum().item()),
+        "null_iff_zero_count": bool(torch.equal(~avg_ok, cnt_sorted == 0)),
+    }
+    total = float((avg.double() * cnt_sorted.double()).sum().item())
+    expect = float(v[ok].sum().item())
+    checks["sum_avg_times_count_rel_err"] = abs(total - expect) / expect
+    good = (checks["groups"] == checks["groups_expected"] and checks["avg_keys_sorted"] and checks["same_keys_avg_and_count"]
+            and checks["sum_of_counts"] == checks["valid_values"] and checks["null_iff_zero_count"]
+            and checks["sum_avg_times_count_rel_err"] < 1e-9)
+    return checks, good
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=1_000_000_000)
@@ -23,42 +86,18 @@ def main():
     a = ap.parse_args()
     import torch
     import libgdf_amd as gdf
-    from bench import read_profile, splitmix64_torch
+    from bench import read_profile
     from libgdf_amd._binding import rmmOptions_t
     from libgdf_amd.columns import Column
     gdf.librmm.rmmInitialize(C.byref(rmmOptions_t(1, 0, False)))
     lib = gdf._binding._gdf_cdll
     dev = torch.device("cuda", 0)
     n = a.rows
-    k0 = torch.empty(n, dtype=torch.int64, device=dev)
-    k1 = torch.empty(n, dtype=torch.int32, device=dev)
-    v = torch.empty(n, dtype=torch.float64, device=dev)
-    ok = torch.empty(n, dtype=torch.bool, device=dev)
-    step = 1 << 26
-    M = 1_000_000
-    for s in range(0, n, step):
-        e = min(n, s + step)
-        i = torch.arange(s, e, dtype=torch.int64, device=dev)
-        u = ((splitmix64_torch(i + 0x5EED0005) >> 11) & ((1 << 53) - 1)).double() / float(1 << 53)
-        k0[s:e] = torch.clamp(torch.exp(u * math.log(M + 1.0)).long() - 1, 0, M - 1)     # inverse CDF of p(r) ~ 1/r
-        k1[s:e] = ((splitmix64_torch(i + 0x5EED0006) >> 1) % 16).int()
-        v[s:e] = ((splitmix64_torch(i + 0x5EED0007) >> 11) & ((1 << 53) - 1)).double() / float(1 << 53)
-        ok[s:e] = (splitmix64_torch(i + 0x5EED0008) >> 63) == 0
-        del i, u
-    # LSB-first validity mask of the value column
-    pad = (-n) % 8
-    bits = torch.cat([ok, torch.zeros(pad, dtype=torch.bool, device=dev)]).view(-1, 8).to(torch.uint8)
-    weights = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.uint8, device=dev)
-    mask = (bits * weights).sum(dim=1, dtype=torch.int32).to(torch.uint8)
-    mask = torch.cat([mask, torch.zeros((-mask.numel()) % 64, dtype=torch.uint8, device=dev)])
-    del bits
+    k0, k1, v, ok, mask = make_c5(n, dev)
     kc = [Column(k0), Column(k1)]
     vc = Column(v, mask, null_count=int(n - ok.sum().item()))
     cap = 20_000_000
     alg = n * 20.0 + n / 8.0
-
-    def run(op, out_dtype):
-        return gdf.api.group_by(op, kc, vc, out_dtype=out_dtype, capacity=cap, with_masks=True)
 
     # the timed region is the C call alone: outputs are preallocated once (capacity rows + masks), as a caller would
     from libgdf_amd.columns import column_array, new_context
@@ -76,27 +115,8 @@ def main():
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.reps
     lib.gdf_amd_profile_enable(0)
     prof = read_profile(gdf)
-    gk, avg, avg_ok = run("avg", 6)
-    ck, cnt, _ = run("count", 4)
-    # properties: AVG output is sorted by key (groupby.cuh:345-386), COUNT is not: align through the packed key
-    pk_avg = gk[0] * 16 + gk[1].long()
-    pk_cnt = ck[0] * 16 + ck[1].long()
-    order = torch.argsort(pk_cnt)
-    cnt_sorted = cnt[order]
-    checks = {
-        "groups": int(avg.numel()),
-        "groups_expected": int(torch.unique(k0 * 16 + k1.long()).numel()),
-        "avg_keys_sorted": bool((pk_avg[1:] > pk_avg[:-1]).all().item()),
-        "same_keys_avg_and_count": bool(torch.equal(pk_avg, pk_cnt[order])),
-        "sum_of_counts": int(cnt.sum().item()), "valid_values": int(ok.sum().item()),
-        "null_groups": int((~avg_ok).sum().item()), "zero_count_groups": int((cnt == 0).sum().item()),
-    }
-    total = float((avg.double() * cnt_sorted.double()).sum().item())
-    expect = float(v[ok].sum().item())
-    checks["sum_avg_times_count_rel_err"] = abs(total - expect) / expect
-    good = (checks["groups"] == checks["groups_expected"] and checks["avg_keys_sorted"] and checks["same_keys_avg_and_count"]
-            and checks["sum_of_counts"] == checks["valid_values"] and checks["null_groups"] == checks["zero_count_groups"]
-            and checks["sum_avg_times_count_rel_err"] < 1e-9)
+    del ok0, ok1, oagg
+    checks, good = c5_property_checks(gdf, k0, k1, v, ok, mask, cap)
     print(json.dumps({"op": "C5 gdf_group_by_avg (int64 Zipf x int32) keys, fp64 values, 50% null", "rows": n, "ms": dt * 1e3,
                       "rows_per_s": n / dt, "algorithmic_GBps": alg / dt / 1e9, "frac_of_8TBps": alg / dt / 8e12,
                       "kernels_ms": {k: round(x[0] / a.reps, 3) for k, x in prof.items()}, "checks": checks, "checks_pass": good}))

@@ -39,7 +39,11 @@ def main():
             continue
         kernels[k] = {"fetch_kb_reported": fetch[k], "write_kb_reported": write.get(k, 0.0), "launches": nf[k],
                       "hbm_bytes_per_join_corrected": 2.0 * fetch[k] * 1024.0 + write.get(k, 0.0) * 1024.0}
-    out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, each with --kernel-trace only), "
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from bench import library_build_id
+    out = {"build_id": library_build_id(),      # the kernel sources these counters belong to; bench.py refuses any other
+           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, each with --kernel-trace only), "
                      + (sys.argv[4] if len(sys.argv) > 4 else "python bench.py --steps 1 --warmup 0 --cpu-sample 0 (one C3 join)"),
            "units": "FETCH_SIZE/WRITE_SIZE in KB as reported; corrected bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 "
                     "(gfx950: FETCH_SIZE counts half of a coalesced streaming read; calibrated on jk_hist)",

@@ -441,6 +441,7 @@ struct TileLds {
   uint32_t cursor[256];   // level 1: running global cursor of this chunk
   uint32_t wave_tot[THREADS / WAVE];
   uint32_t total;
+  uint32_t total_abort;   // level 1, speculative layout: the overflow flag as thread 0 saw it during this tile
 };
 
 // block-wide exclusive scan of hist[0..nbins) (nbins <= 256 == blockDim) into start[]
@@ -609,6 +610,10 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
         }
       }
       if (tid < 256) s.hist[tid] = 0;      // nobody reads hist again before the next tile's ranking
+      // speculative layout: once ANY workgroup has seen a partition outgrow its room the host will repeat the side with
+      // the exact layout -- the rest of this pass is wasted work (and, with skewed keys, slow work: every overflowing run
+      // of every workgroup lands on the same dump lines).  Thread 0 looks at the flag, everybody acts on it after the barrier.
+      if (g.cap1 && tid == 0) s.total_abort = __hip_atomic_load(g.spec_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     const uint32_t wtid = opaque_tid();
 #pragma unroll
@@ -628,6 +633,7 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
     __builtin_amdgcn_sched_barrier(0);         // keep the prefetch BELOW the regroup: hoisted, its 32 registers spill
     if (FAST && more) prefetch(tile + JK_TILE);
     block_sync();
+    if (g.cap1 && s.total_abort) return;       // workgroup-uniform (read after the barrier)
     // flush: JK_SC_ITEMS unconditional stores per thread (dead slots -> this thread's dump slot), four at a time to
     // keep the register count under the 128 a 1024-thread workgroup gets (the prefetched keys stay in registers)
     const uint32_t total = s.total;
@@ -775,7 +781,8 @@ struct ProbeArgs {
   uint64_t kbias;               // see PartGeom::kbias
   int optimistic;               // WRITE pass without a count pass: unit u may write at most probe_count pairs
   unsigned long long *opt_state; // [0] = pairs written by all units, [1] = some unit needed more room,
-                                 // [2] = units jk_probe_fast left to the general kernel (cuckoo build did not settle)
+                                 // [2] = units jk_probe_fast left to the general kernel (cuckoo build did not settle),
+                                 // [3] = COUNT pass: units whose cuckoo build did not settle (linear probing)
   uint32_t *unit_todo;           // jk_probe_fast appends the ids of such units here (opt_state[2] = how many);
                                  // jk_probe: when non-null, workgroup b handles unit unit_todo[b]
 };
@@ -859,6 +866,7 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
   }
   block_sync();
   const bool cuckoo = *l.cuckoo_failed == 0 && !(a.dbg & 8);
+  if (!cuckoo && !WRITE && a.opt_state && threadIdx.x == 0) atomicAdd(&a.opt_state[3], 1ull);   // sample pass: units with repeated build keys
   if (!cuckoo) {
     // ---- linear-probing rebuild over the same 2*H slots (multimap: duplicates simply chain) ----
     block_sync();
@@ -1156,7 +1164,11 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_fast(ProbeArgs a) {
       }
       if (c) {
         if (pos + c > unit_cap) a.opt_state[1] = 1;   // would spill into the next unit's slots: the host redoes the join two-pass
-        else if (!(a.dbg & 32)) {
+        else if (a.dbg & 1024) {                     // experiment: non-temporal stores of the index pairs
+          __builtin_nontemporal_store((int32_t)prow[b], &op[pos]);
+          __builtin_nontemporal_store(pad ? JK_EMPTY : (int32_t)(uint32_t)(ha ? wa[b] : wb[b]), &ob[pos]);
+          if (c == 2) { op[pos + 1] = (int32_t)prow[b]; ob[pos + 1] = (int32_t)(uint32_t)wb[b]; }
+        } else if (!(a.dbg & 32)) {
           op[pos] = (int32_t)prow[b];
           ob[pos] = pad ? JK_EMPTY : (int32_t)(uint32_t)(ha ? wa[b] : wb[b]);
           if (c == 2) { op[pos + 1] = (int32_t)prow[b]; ob[pos + 1] = (int32_t)(uint32_t)wb[b]; }
@@ -2021,6 +2033,10 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
   const size_t probe_lds = probe_lds_bytes(narrow, cap_lds, H_lds);
   const bool plain = kind != JOIN_FULL && !plan.verify;       // INNER and LEFT with exact keys: see jk_probe_fast
 
+  // set by the sample below: most sampled units hold repeated build keys (their cuckoo build fell back to linear probing).
+  // The lean write kernel would give up on nearly every unit after four cuckoo attempts (5.7 of 31 ms on a join whose
+  // build keys all occur four times, profiles/r2_b_bench_shapes.jsonl) -- such joins go to the general kernel directly.
+  bool dup_heavy = false;
   clk.mark("units + argument setup");
   // ---- optimistic single pass ----
   // A foreign-key -> primary-key join whose every probe row finds its key emits exactly one pair per
@@ -2032,7 +2048,7 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
     std::vector<Unit> sample(nsample);
     uint64_t sample_tuples = 0;
     for (size_t i = 0; i < nsample; ++i) { sample[i] = units[i * nunits / nsample]; sample_tuples += sample[i].probe_count; }
-    DevBuf d_sample, d_scount, d_off, d_state;
+    DevBuf d_sample, d_scount, d_off, d_state, d_sstate;
     RMM_TRY(d_sample.alloc(sizeof(Unit) * nsample));
     RMM_TRY(d_scount.alloc(sizeof(uint64_t) * nsample));
     HIP_TRY(hipMemcpyAsync(d_sample.p, sample.data(), sizeof(Unit) * nsample, hipMemcpyHostToDevice, stream0()));
@@ -2046,11 +2062,17 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
     sa.units = d_sample.as<Unit>();
     sa.counts = d_scount.as<uint64_t>();
     sa.build_matched = nullptr;
+    RMM_TRY(d_sstate.alloc(sizeof(unsigned long long) * 4));
+    HIP_TRY(hipMemsetAsync(d_sstate.p, 0, sizeof(unsigned long long) * 4, stream0()));
+    sa.opt_state = d_sstate.as<unsigned long long>();
     GDF_TRY(run_probe(narrow, false, "jk_probe_sample", nsample, probe_lds, sa, probe_t, build_t));
     HIP_TRY(hipMemcpyAsync(d_off.p, off.data(), sizeof(uint64_t) * (nunits + 1), hipMemcpyHostToDevice, stream0()));
     HIP_TRY(hipMemsetAsync(d_state.p, 0, sizeof(unsigned long long) * 4, stream0()));
     std::vector<uint64_t> scount(nsample);
     HIP_TRY(read_back(scount.data(), d_scount.p, sizeof(uint64_t) * nsample));
+    unsigned long long sstate[4] = {0, 0, 0, 0};
+    HIP_TRY(read_back(sstate, d_sstate.p, sizeof(sstate)));
+    dup_heavy = sstate[3] * 4 >= nsample;
     clk.mark("sample count");
     uint64_t sample_pairs = 0;
     for (uint64_t c : scount) sample_pairs += c;
@@ -2071,7 +2093,7 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
       oa.optimistic = 1;
       oa.opt_state = d_state.as<unsigned long long>();
       clk.mark("output allocation");
-      GDF_TRY(run_write_pass(narrow, plain, nunits, probe_lds, oa, max_build, probe_t, build_t));
+      GDF_TRY(run_write_pass(narrow, plain && !dup_heavy, nunits, probe_lds, oa, max_build, probe_t, build_t));
       unsigned long long st[2] = {0, 0};
       HIP_TRY(read_back(st, d_state.p, sizeof(st)));
       clk.mark("write pass");
@@ -2153,7 +2175,7 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
   RMM_TRY(d_wstate.alloc(sizeof(unsigned long long) * 4));
   HIP_TRY(hipMemsetAsync(d_wstate.p, 0, sizeof(unsigned long long) * 4, stream0()));
   a.opt_state = d_wstate.as<unsigned long long>();
-  GDF_TRY(run_write_pass(narrow, plain, nunits, probe_lds, a, max_build, probe_t, build_t));
+  GDF_TRY(run_write_pass(narrow, plain && !dup_heavy, nunits, probe_lds, a, max_build, probe_t, build_t));
   for (size_t o = 0; o < oversize.size(); ++o) {
     const uint32_t f = oversize[o].f0, fe = oversize[o].f1;
     const uint32_t pn = P.fine_off[fe] - P.fine_off[f];
@@ -2288,74 +2310,107 @@ static gdf_error join_call(JoinKind kind, int num_cols, gdf_column **leftcol, gd
 // optional materialisation of the joined rows (joining.cu:375-479 + the gathers of
 // gdf_table.cuh:873-963): out = [left non-key..., key..., right non-key...]
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void jk_gather(const void *in, const uint8_t *in_valid, const int32_t *map, int64_t n,
-                                                 int width, void *out, uint32_t *out_valid) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  const int64_t rounds = (n + stride - 1) / stride;
-  for (int64_t rnd = 0; rnd < rounds; ++rnd) {
-    const int64_t i = rnd * stride + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool valid = false;
-    if (i < n) {
-      const int32_t src = map[i];
-      if (src >= 0) {
-        valid = in_valid ? bit_is_set(in_valid, src) : true;
-        switch (width) {
-          case 1: ((uint8_t *)out)[i] = ((const uint8_t *)in)[src]; break;
-          case 2: ((uint16_t *)out)[i] = ((const uint16_t *)in)[src]; break;
-          case 4: ((uint32_t *)out)[i] = ((const uint32_t *)in)[src]; break;
-          default: ((uint64_t *)out)[i] = ((const uint64_t *)in)[src]; break;
-        }
-      }
+// One launch gathers up to GS_MAX_COLS columns through ONE index map (the map is read once per row, not once per
+// column), GS_ROWS rows per thread so that every column has GS_ROWS independent random reads in flight per lane, and the
+// validity words come from ballots over 64 consecutive rows (two whole 32-bit words per wave, no atomics).
+// A column may name a second source (FULL join key columns): rows whose map entry is negative take alt[alt_map[i]].
+constexpr int GS_MAX_COLS = 8;
+constexpr int GS_ROWS = 4;
+struct GatherSet {
+  int ncols;
+  int width[GS_MAX_COLS];
+  const void *in[GS_MAX_COLS];
+  const uint8_t *in_valid[GS_MAX_COLS];      // may be null: every source row valid
+  const void *alt[GS_MAX_COLS];              // may be null
+  const uint8_t *alt_valid[GS_MAX_COLS];
+  void *out[GS_MAX_COLS];
+  uint32_t *out_valid[GS_MAX_COLS];
+};
+template <class T>
+__device__ __forceinline__ void gather_one_column(const GatherSet &s, int c, const int32_t (&src)[GS_ROWS], const int32_t (&asrc)[GS_ROWS],
+                                                  int64_t i0, int64_t n) {
+  const T *in = (const T *)s.in[c], *alt = (const T *)s.alt[c];
+  T v[GS_ROWS];
+  bool valid[GS_ROWS];
+#pragma unroll
+  for (int r = 0; r < GS_ROWS; ++r) {       // all random reads first (clamped row 0 stands in for "no source row")
+    const bool from_alt = src[r] < 0 && alt != nullptr && asrc[r] >= 0;
+    const T *base = from_alt ? alt : in;
+    const int32_t row = from_alt ? asrc[r] : src[r];
+    v[r] = base[row >= 0 ? row : 0];
+    const uint8_t *vb = from_alt ? s.alt_valid[c] : s.in_valid[c];
+    valid[r] = row >= 0 && (vb == nullptr || ((vb[row >> 3] >> (row & 7)) & 1));
+  }
+  T *out = (T *)s.out[c];
+#pragma unroll
+  for (int r = 0; r < GS_ROWS; ++r) {
+    const int64_t i = i0 + (int64_t)r * 256;
+    const bool live = i < n;
+    if (live && (src[r] >= 0 || (alt != nullptr && asrc[r] >= 0))) out[i] = v[r];
+    const unsigned long long m = __ballot(live && valid[r]);
+    if (live) {
+      if (lane_id() == 0) s.out_valid[c][i >> 5] = (uint32_t)m;
+      if (lane_id() == 32) s.out_valid[c][i >> 5] = (uint32_t)(m >> 32);
     }
-    // 64 consecutive rows -> two whole mask words, written without atomics
-    const unsigned long long m = __ballot(valid);
-    if (i < n) {
-      if (lane_id() == 0) out_valid[i >> 5] = (uint32_t)m;
-      if (lane_id() == 32) out_valid[i >> 5] = (uint32_t)(m >> 32);
+  }
+}
+__global__ __launch_bounds__(256) void jk_gather_multi(GatherSet s, const int32_t *__restrict__ map, const int32_t *__restrict__ alt_map,
+                                                       int64_t n) {
+  const int64_t i0 = (int64_t)blockIdx.x * (256 * GS_ROWS) + threadIdx.x;
+  int32_t src[GS_ROWS], asrc[GS_ROWS];
+#pragma unroll
+  for (int r = 0; r < GS_ROWS; ++r) {
+    const int64_t i = i0 + (int64_t)r * 256;
+    src[r] = map[i < n ? i : n - 1];
+    asrc[r] = alt_map ? alt_map[i < n ? i : n - 1] : -1;
+  }
+  for (int c = 0; c < s.ncols; ++c) {
+    switch (s.width[c]) {
+      case 1: gather_one_column<uint8_t>(s, c, src, asrc, i0, n); break;
+      case 2: gather_one_column<uint16_t>(s, c, src, asrc, i0, n); break;
+      case 4: gather_one_column<uint32_t>(s, c, src, asrc, i0, n); break;
+      default: gather_one_column<uint64_t>(s, c, src, asrc, i0, n); break;
     }
   }
 }
 
-static gdf_error gather_column(const gdf_column *src, const int32_t *map, int64_t n, gdf_column *dst) {
-  const int w = dtype_width(src->dtype);
-  if (w < 0) return GDF_UNSUPPORTED_DTYPE;
-  DevBuf data, valid;
-  RMM_TRY(data.alloc((size_t)w * (size_t)(n ? n : 1)));
-  const size_t vbytes = ((mask_bytes((size_t)n) + 7) / 8) * 8;   // whole 64-bit groups
-  RMM_TRY(valid.alloc(vbytes ? vbytes : 8));
-  HIP_TRY(hipMemsetAsync(valid.p, 0, vbytes ? vbytes : 8, stream0()));
-  if (n) {
-    // grid covers whole waves of 64 consecutive rows so the ballot words line up
-    hipLaunchKernelGGL(jk_gather, dim3(small_grid(n)), dim3(256), 0, stream0(), src->data, src->valid, map, n, w, data.p,
-                       valid.as<uint32_t>());
-    HIP_CHECK_LAST();
-  }
-  HIP_TRY(hipStreamSynchronize(stream0()));
-  gdf_column_view(dst, data.release(), (gdf_valid_type *)valid.release(), (gdf_size_type)n, src->dtype);
-  dst->dtype_info = src->dtype_info;
-  return GDF_SUCCESS;
-}
-
-__global__ __launch_bounds__(256) void jk_merge_neg(const int32_t *map, int64_t n, int width, void *dst, uint32_t *dst_valid,
-                                                    const void *src, const uint32_t *src_valid) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    if (map[i] >= 0) continue;
-    switch (width) {
-      case 1: ((uint8_t *)dst)[i] = ((const uint8_t *)src)[i]; break;
-      case 2: ((uint16_t *)dst)[i] = ((const uint16_t *)src)[i]; break;
-      case 4: ((uint32_t *)dst)[i] = ((const uint32_t *)src)[i]; break;
-      default: ((uint64_t *)dst)[i] = ((const uint64_t *)src)[i]; break;
+// what one output column of the materialisation is made from
+struct GatherJob {
+  const gdf_column *src;
+  const gdf_column *alt;      // FULL join key columns: the right key where there is no left row
+  gdf_column *dst;
+};
+// allocates the outputs of `jobs` and gathers them through `map` (and `alt_map`), GS_MAX_COLS columns per launch; no
+// synchronisation -- the caller waits once for all sides
+static gdf_error gather_columns(const std::vector<GatherJob> &jobs, const int32_t *map, const int32_t *alt_map, int64_t n) {
+  for (size_t j0 = 0; j0 < jobs.size(); j0 += GS_MAX_COLS) {
+    GatherSet s{};
+    for (size_t j = j0; j < jobs.size() && j < j0 + GS_MAX_COLS; ++j) {
+      const GatherJob &job = jobs[j];
+      const int w = dtype_width(job.src->dtype);
+      if (w < 0) return GDF_UNSUPPORTED_DTYPE;
+      DevBuf data, valid;
+      RMM_TRY(data.alloc((size_t)w * (size_t)(n ? n : 1)));
+      const size_t vbytes = ((mask_bytes((size_t)n) + 7) / 8) * 8;   // whole 64-bit groups
+      RMM_TRY(valid.alloc(vbytes ? vbytes : 8));
+      HIP_TRY(hipMemsetAsync(valid.p, 0, vbytes ? vbytes : 8, stream0()));
+      const int c = s.ncols++;
+      s.width[c] = w;
+      s.in[c] = job.src->data;
+      s.in_valid[c] = job.src->valid;
+      s.alt[c] = job.alt ? job.alt->data : nullptr;
+      s.alt_valid[c] = job.alt ? job.alt->valid : nullptr;
+      s.out[c] = data.p;
+      s.out_valid[c] = valid.as<uint32_t>();
+      gdf_column_view(job.dst, data.release(), (gdf_valid_type *)valid.release(), (gdf_size_type)n, job.src->dtype);
+      job.dst->dtype_info = job.src->dtype_info;
     }
-    if ((src_valid[i >> 5] >> (i & 31)) & 1) atomicOr(&dst_valid[i >> 5], 1u << (i & 31));
+    if (n) {
+      const unsigned grid = (unsigned)((n + 256 * GS_ROWS - 1) / (256 * GS_ROWS));
+      GDF_LAUNCH("jk_gather_multi", jk_gather_multi, dim3(grid), dim3(256), 0, stream0(), s, map, alt_map, n);
+      HIP_CHECK_LAST();
+    }
   }
-}
-
-static gdf_error merge_where_negative(const int32_t *map, int64_t n, int width, gdf_column *dst, gdf_column *src) {
-  if (n == 0) return GDF_SUCCESS;
-  hipLaunchKernelGGL(jk_merge_neg, dim3(small_grid(n)), dim3(256), 0, stream0(), map, n, width, dst->data,
-                     (uint32_t *)dst->valid, src->data, (const uint32_t *)src->valid);
-  HIP_CHECK_LAST();
-  HIP_TRY(hipStreamSynchronize(stream0()));
   return GDF_SUCCESS;
 }
 
@@ -2396,25 +2451,21 @@ static gdf_error join_entry(JoinKind kind, gdf_column **left_cols, int num_left_
   const int32_t *lmap = (const int32_t *)lout->data, *rmap = (const int32_t *)rout->data;
   std::vector<char> l_is_key(num_left_cols, 0), r_is_key(num_right_cols, 0);
   for (int i = 0; i < num_cols_to_join; ++i) { l_is_key[left_join_cols[i]] = 1; r_is_key[right_join_cols[i]] = 1; }
+  // Two launches (per 8 columns): everything that follows the LEFT index map -- the left non-key columns and the key
+  // columns, whose values come from the left row when there is one, else from the right one (FULL join tail) -- and
+  // the right non-key columns.  Round 1 ran one gather kernel + one stream synchronisation per output column and a
+  // second gather + merge pass per FULL-join key column.
+  std::vector<GatherJob> left_jobs, right_jobs;
   int o = 0;
   for (int c = 0; c < num_left_cols; ++c)
-    if (!l_is_key[c]) GDF_TRY(gather_column(left_cols[c], lmap, n, result_cols[o++]));
-  for (int i = 0; i < num_cols_to_join; ++i) {
-    // key values come from the left row when there is one, else from the right (full join tail)
-    gdf_column *dst = result_cols[o++];
-    GDF_TRY(gather_column(left_cols[left_join_cols[i]], lmap, n, dst));
-    if (kind == JOIN_FULL) {
-      // rows with l == -1 take the right key: second gather into a scratch column, merged below
-      gdf_column scratch{};
-      GDF_TRY(gather_column(right_cols[right_join_cols[i]], rmap, n, &scratch));
-      // merge on device: where lmap < 0 copy scratch -> dst (data + valid bit)
-      gdf_error me = merge_where_negative(lmap, n, dtype_width(dst->dtype), dst, &scratch);
-      gdf_column_free(&scratch);
-      if (me != GDF_SUCCESS) return me;
-    }
-  }
+    if (!l_is_key[c]) left_jobs.push_back(GatherJob{left_cols[c], nullptr, result_cols[o++]});
+  for (int i = 0; i < num_cols_to_join; ++i)
+    left_jobs.push_back(GatherJob{left_cols[left_join_cols[i]], kind == JOIN_FULL ? right_cols[right_join_cols[i]] : nullptr, result_cols[o++]});
   for (int c = 0; c < num_right_cols; ++c)
-    if (!r_is_key[c]) GDF_TRY(gather_column(right_cols[c], rmap, n, result_cols[o++]));
+    if (!r_is_key[c]) right_jobs.push_back(GatherJob{right_cols[c], nullptr, result_cols[o++]});
+  GDF_TRY(gather_columns(left_jobs, lmap, kind == JOIN_FULL ? rmap : nullptr, n));
+  GDF_TRY(gather_columns(right_jobs, rmap, nullptr, n));
+  HIP_TRY(hipStreamSynchronize(stream0()));
   HIP_CHECK_LAST();
   return GDF_SUCCESS;
 }

@@ -107,12 +107,33 @@ def test_hash_partition_errors(gdf):
 
 
 @pytest.mark.parametrize("dtype", [np.int8, np.int32, np.int64])
-@pytest.mark.parametrize("n", [1, 2, 13, 64, 100, 1000, 2048, 2049, 1000003])      # python/tests/test_prefixsum.py:16-62 + tile edges
+@pytest.mark.parametrize("n", [1, 2, 13, 64, 100, 1000, 2048, 2049, 4095, 4096, 4097, 8192, 1000003])      # python/tests/test_prefixsum.py:16-62 + tile edges
 @pytest.mark.parametrize("inclusive", [True, False])
 def test_prefixsum(gdf, dtype, n, inclusive):
     a = np.random.randint(-100, 100, size=n).astype(dtype)
     got = gdf.api.prefixsum(_col(gdf, a), inclusive).cpu().numpy()
     np.testing.assert_array_equal(got, oracle.prefixsum(a, inclusive))
+
+
+@pytest.mark.parametrize("dtype", [np.int8, np.int32, np.int64])
+def test_prefixsum_many_tiles_unaligned_and_in_place(gdf, dtype):
+    """The single-pass (decoupled look-back) scan over thousands of tiles -- every tile waits for its predecessors, in
+    whatever order the hardware runs them -- repeated, so that a lost or torn publication would show; a column that starts
+    1 element into a buffer (no 16-byte alignment: the three-pass kernels); and in == out."""
+    import torch
+    from libgdf_amd import Column, libgdf
+    n = 30_000_001
+    a = np.random.randint(-100, 100, size=n).astype(dtype)
+    exp = np.cumsum(a, dtype=dtype)
+    dev = torch.from_numpy(a).cuda()
+    for _ in range(5):
+        got = gdf.api.prefixsum(Column(dev), True)
+        assert torch.equal(got.cpu(), torch.from_numpy(exp))
+    got = gdf.api.prefixsum(Column(dev[1:]), False).cpu().numpy()                # unaligned slice, exclusive
+    np.testing.assert_array_equal(got, (np.cumsum(a[1:], dtype=dtype) - a[1:]).astype(dtype))
+    col = Column(dev)
+    libgdf.gdf_prefixsum_generic(col.ptr, col.ptr, 1)                            # in place
+    assert torch.equal(dev.cpu(), torch.from_numpy(exp))
 
 
 def test_prefixsum_large_wraps_like_numpy(gdf):

@@ -169,48 +169,63 @@ def test_skewed_build_side_takes_global_table_path(gdf):
         _check(gdf, [probe], [build], how)
 
 
-def test_result_cols_materialisation(gdf):
-    """gdf_*_join with result_cols: [left non-key..., key..., right non-key...] (joining.cu:413-439)."""
+@pytest.mark.parametrize("how", ["inner", "left", "full"])
+def test_result_cols_materialisation(gdf, how):
+    """gdf_*_join with result_cols: [left non-key..., key..., right non-key...] (joining.cu:413-439), gathered by one
+    multi-column kernel per side (csrc/join.hip jk_gather_multi).  Payload widths 1 / 2 / 4 / 8 bytes, masked payload and
+    masked right key; the key of a FULL join's unmatched right rows comes from the right table."""
     import torch
     from libgdf_amd import Column, gdf_column, libgdf, new_context
     from libgdf_amd.columns import column_array
-    nl, nr = 3000, 2000
-    lk, lp = gen_rand(np.int32, nl, 0, 500), gen_rand(np.float64, nl)
-    rk, rp = gen_rand(np.int32, nr, 0, 500), gen_rand(np.int64, nr)
-    lpv = random_valid(nl)
-    L = _cols([lp, lk], [lpv, None])
-    R = _cols([rk, rp])
-    res = [gdf_column(), gdf_column(), gdf_column()]
-    res_arr = (C.POINTER(gdf_column) * 3)(*[C.pointer(r) for r in res])
+    nl, nr = 30_000, 20_000
+    lk = gen_rand(np.int32, nl, 0, 5000)
+    rk = gen_rand(np.int32, nr, 2500, 7500)
+    lp = [gen_rand(np.float64, nl), gen_rand(np.int8, nl), gen_rand(np.int16, nl)]
+    rp = [gen_rand(np.int64, nr), gen_rand(np.float32, nr)]
+    lpv = [random_valid(nl), None, random_valid(nl)]
+    rpv = [None, random_valid(nr)]
+    L = _cols([lp[0], lk, lp[1], lp[2]], [lpv[0], None, lpv[1], lpv[2]])          # key is column 1 on the left
+    R = _cols([rk, rp[0], rp[1]], [None, rpv[0], rpv[1]])                          # and column 0 on the right
+    nres = 3 + 1 + 2
+    res = [gdf_column() for _ in range(nres)]
+    res_arr = (C.POINTER(gdf_column) * nres)(*[C.pointer(r) for r in res])
     li, ri = gdf_column(), gdf_column()
     ctx = new_context()
-    libgdf.gdf_left_join(column_array(L), 2, (C.c_int * 1)(1), column_array(R), 2, (C.c_int * 1)(0), 1, 3, res_arr,
-                         C.byref(li), C.byref(ri), C.byref(ctx))
+    fn = {"inner": libgdf.gdf_inner_join, "left": libgdf.gdf_left_join, "full": libgdf.gdf_full_join}[how]
+    fn(column_array(L), 4, (C.c_int * 1)(1), column_array(R), 3, (C.c_int * 1)(0), 1, nres, res_arr, C.byref(li), C.byref(ri), C.byref(ctx))
     n = li.size
     a = gdf.api._take_library_column(li, torch.int32).cpu().numpy()
     b = gdf.api._take_library_column(ri, torch.int32).cpu().numpy()
-    assert [r.size for r in res] == [n, n, n] and [r.dtype for r in res] == [6, 3, 4]
+    el, er = oracle.join([lk], [rk], how)
+    assert n == len(el)
+    assert [r.size for r in res] == [n] * nres
+    assert [r.dtype for r in res] == [6, 1, 2, 3, 4, 5]                             # f64, i8, i16 | i32 key | i64, f32
 
-    def pull(col, tdtype):
-        import torch
+    def pull(col, npdtype):
         nbytes_valid = (n + 7) // 8
-        data = torch.empty(n, dtype=tdtype, device="cuda")
+        data = torch.empty(n * np.dtype(npdtype).itemsize, dtype=torch.uint8, device="cuda")
         valid = torch.empty(nbytes_valid, dtype=torch.uint8, device="cuda")
-        gdf.api._hipMemcpyDtoD(data.data_ptr(), col.data, n * data.element_size())
+        gdf.api._hipMemcpyDtoD(data.data_ptr(), col.data, data.numel())
         gdf.api._hipMemcpyDtoD(valid.data_ptr(), col.valid, nbytes_valid)
         libgdf.gdf_column_free(C.byref(col))
         bits = np.unpackbits(valid.cpu().numpy(), bitorder="little")[:n].astype(bool)
-        return data.cpu().numpy(), bits
+        return data.cpu().numpy().view(npdtype), bits
 
-    d0, v0 = pull(res[0], torch.float64)
-    d1, v1 = pull(res[1], torch.int32)
-    d2, v2 = pull(res[2], torch.int64)
-    np.testing.assert_array_equal(d0[v0], lp[a][v0])
-    np.testing.assert_array_equal(v0, lpv[a])
-    np.testing.assert_array_equal(d1, lk[a]); assert v1.all()
-    m = b >= 0
-    np.testing.assert_array_equal(v2, m)
-    np.testing.assert_array_equal(d2[m], rp[b[m]])
+    has_l, has_r = a >= 0, b >= 0
+    for j, (src, sv) in enumerate(zip(lp, lpv)):
+        d, v = pull(res[j], src.dtype)
+        exp_valid = has_l & (sv[np.where(has_l, a, 0)] if sv is not None else True)
+        np.testing.assert_array_equal(v, exp_valid)
+        np.testing.assert_array_equal(d[v], src[a[v]])
+    d, v = pull(res[3], np.int32)
+    np.testing.assert_array_equal(v, has_l | has_r)
+    exp_key = np.where(has_l, lk[np.where(has_l, a, 0)], rk[np.where(has_r, b, 0)])
+    np.testing.assert_array_equal(d[v], exp_key[v])
+    for j, (src, sv) in enumerate(zip(rp, rpv)):
+        d, v = pull(res[4 + j], src.dtype)
+        exp_valid = has_r & (sv[np.where(has_r, b, 0)] if sv is not None else True)
+        np.testing.assert_array_equal(v, exp_valid)
+        np.testing.assert_array_equal(d[v], src[b[v]])
 
 
 @pytest.mark.parametrize("how", ["inner", "left", "full"])

@@ -175,9 +175,10 @@ def main():
     ap.add_argument("--build-rows", type=int, default=None)
     ap.add_argument("--cpu-sample", type=int, default=20_000_000, help="probe rows of the oracle-port CPU baseline sample (0 = skip)")
     ap.add_argument("--pandas-sample", type=int, default=100_000_000, help="probe rows of the pandas.merge CPU baseline (0 = skip)")
-    ap.add_argument("--strategy", choices=["shuffle", "broadcast"], default="shuffle",
-                    help="multi-GPU join: shuffle both relations by key (C4 as BASELINE.json names it, the default) or gather the "
-                         "build keys on every GPU and leave the probe relation where it is (libgdf_amd/multigpu.py)")
+    ap.add_argument("--strategy", choices=["auto", "shuffle", "broadcast"], default="auto",
+                    help="multi-GPU join: shuffle both relations by key with an RCCL all-to-all (C4 as BASELINE.json names it), "
+                         "gather the build keys on every GPU and leave the probe relation where it is, or (default) whichever "
+                         "libgdf_amd.multigpu.choose_join_strategy expects to be faster: broadcast at 2 GPUs, shuffle at 4 and 8")
     ap.add_argument("--force-distributed", action="store_true",
                     help="run the multi-GPU (C4) code path even at world size 1 (1-rank RCCL group): measures its local passes")
     args = ap.parse_args()
@@ -249,7 +250,8 @@ def main():
         build = make_build_keys(nb, 0x5EED0001 + rank, dev) * world + rank
         probe = make_probe_keys(npr, key_space, 0x5EED0002, dev, offset=rank * npr)
 
-        if args.strategy == "broadcast":
+        strategy = args.strategy if args.strategy != "auto" else multigpu.choose_join_strategy(world, npr, nb)
+        if strategy == "broadcast":
             def step():
                 return multigpu.broadcast_inner_join(probe, build).numel()
             workload = (f"C4 rows, broadcast variant: {npr} probe + {nb} build int64 rows per GPU, key space {key_space}, "
@@ -269,6 +271,8 @@ def main():
     out_rows = 0
     for _ in range(args.warmup):
         out_rows = step()
+    if distributed:
+        multigpu.reset_stats()
     lib.gdf_amd_profile_reset()
     lib.gdf_amd_profile_enable(1)
     sync()
@@ -288,10 +292,8 @@ def main():
     dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
 
-    if rank == 0:
-        total_probe = npr * world
-        value = total_probe * args.steps / dt
-        # dominant kernel by total time inside the timed region
+    def kernel_roofline():
+        """this rank's dominant kernel (by total HIP-event time inside the timed region) priced against the HBM peak"""
         roofline = None
         if prof:
             name, (tot_ms, launches) = max(prof.items(), key=lambda kv: kv[1][0])
@@ -310,6 +312,22 @@ def main():
                             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
                             "algorithmic_bytes_per_launch": bytes_per_launch,
                             "avg_launch_ms": per_launch_ms, "launches_per_step": launches_per_step}
+        return roofline
+
+    mine = {"rank": rank, "roofline": kernel_roofline(),
+            "kernels_ms_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}}
+    if distributed:
+        mine["exchange_bytes_sent_per_step"] = multigpu.STATS["bytes_sent"] / args.steps
+        mine["exchange_messages_per_step"] = multigpu.STATS["messages"] / args.steps
+    per_rank = [mine]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+
+    if rank == 0:
+        total_probe = npr * world
+        value = total_probe * args.steps / dt
+        roofline = mine["roofline"]
         e2e_bytes = 8.0 * npr + 8.0 * nb + 8.0 * (rows.item() / world)
         e2e = e2e_bytes / (ms_per_step * 1e-3) / 1e9
         result = {
@@ -321,8 +339,18 @@ def main():
             "roofline": roofline,
             "roofline_e2e": {"bound": "hbm", "achieved": e2e, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": e2e / HBM_PEAK_GBS,
                              "algorithmic_bytes_per_gpu": e2e_bytes},
-            "kernels_ms_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
+            "kernels_ms_per_step": mine["kernels_ms_per_step"],
         }
+        if distributed:
+            # the exchange, per GPU and step: what went to RCCL, and what the busiest xGMI link would need for it at the rate the
+            # planner assumes (a rank reaches each peer over ONE link) -- an estimate, the links cannot be timed from in here
+            sent = max(r["exchange_bytes_sent_per_step"] for r in per_rank)
+            result["config"]["strategy"] = strategy
+            result["exchange"] = {"bytes_sent_per_gpu_per_step": sent, "messages_per_gpu_per_step": max(r["exchange_messages_per_step"] for r in per_rank),
+                                  "busiest_link_ms_at_assumed_rate": sent / max(world - 1, 1) / multigpu.XGMI_LINK_BYTES_PER_S * 1e3,
+                                  "assumed_link_GBps": multigpu.XGMI_LINK_BYTES_PER_S / 1e9,
+                                  "planner_estimate_ms": {k: v * 1e3 for k, v in multigpu.estimate_join_seconds(world, npr, nb).items()}}
+            result["per_rank"] = per_rank
         if world == 1 and args.pandas_sample > 0:
             result["cpu_baseline"] = cpu_baseline_pandas(args.pandas_sample, max(args.pandas_sample // 10, 1))
         if world == 1 and args.cpu_sample > 0:

@@ -215,20 +215,37 @@ __global__ __launch_bounds__(HP_THREADS) void part_scatter_fast_kernel(const K *
   }
 }
 
-// P <= 256: LDS-regrouped scatter.  Same offsets contract as part_scatter_kernel.
-constexpr int HPT_MAX_ITEMS = 16;         // rows per thread and tile: 16 with a directly read key column, 8 with the generic row hash
+// LDS-regrouped scatter.  Same offsets contract as part_scatter_kernel.  Two shapes:
+//   P <= 256  : 256 threads x 16 rows (4096-row tiles, 41 KB of LDS, several workgroups per CU);
+//   P <= 1024 : 1024 threads x 12 rows (12288-row tiles, 137 KB, one workgroup per CU) -- a (tile, partition) run is still
+//               12 rows = 96 bytes at P = 1024.  The direct scatter that served every fan-out beyond 256 in round 1 issues
+//               one store request per row and column: 4.0 ms per 1e8 rows of (int64, float64, int8) at P = 1000.
 constexpr int HPT_MAX_PARTS = 256;
+constexpr int HPT_BIG_PARTS = 1024;
+// TH threads, at most MAXP partitions, FI rows per thread with a directly read key column (half that with the generic row hash:
+// that many generic hashes per thread spill)
+template <int TH, int MAXP, int FI, bool FAST>
+struct HptShape {
+  static constexpr int ITEMS = FAST ? FI : FI / 2;
+  static constexpr int TILE = TH * ITEMS;
+  static constexpr size_t lds_bytes() { return 8 * (size_t)TILE + 2 * (size_t)TILE + 4 * (size_t)(4 * MAXP + 4 + TH / WAVE) + 16; }
+};
 
-template <bool MURMUR, int FASTW>      // FASTW = 8 / 4: one key column of that width read directly; 0: generic hash_row
-__global__ __launch_bounds__(HP_THREADS) void part_scatter_tile_kernel(KeyTable t, PayloadCols pc, int64_t n, int64_t chunk,
-                                                                       int nchunks, uint32_t nparts, uint32_t pow2mask,
-                                                                       const uint32_t *__restrict__ offs) {
-  constexpr int HPT_ITEMS = FASTW ? HPT_MAX_ITEMS : HPT_MAX_ITEMS / 2;      // (16 generic hashes per thread spill)
-  constexpr int HPT_TILE = HP_THREADS * HPT_ITEMS;
-  __shared__ uint64_t stage[HPT_TILE];
-  __shared__ uint16_t bin_of[HPT_TILE];
-  __shared__ uint32_t hist[HPT_MAX_PARTS + 1], start[HPT_MAX_PARTS], gbase[HPT_MAX_PARTS], cursor[HPT_MAX_PARTS];
-  __shared__ uint32_t wave_tot[HP_THREADS / WAVE];
+template <bool MURMUR, int FASTW, int TH, int MAXP, int FI>      // FASTW = 8 / 4: one key column of that width read directly; 0: generic hash_row
+__global__ __launch_bounds__(TH) void part_scatter_tile_kernel(KeyTable t, PayloadCols pc, int64_t n, int64_t chunk,
+                                                               int nchunks, uint32_t nparts, uint32_t pow2mask,
+                                                               const uint32_t *__restrict__ offs) {
+  using Shape = HptShape<TH, MAXP, FI, FASTW != 0>;
+  constexpr int HPT_ITEMS = Shape::ITEMS;
+  constexpr int HPT_TILE = Shape::TILE;
+  constexpr int HP_THREADS = TH;             // shadows the file-wide 256 inside this kernel
+  constexpr int HPT_MAX_PARTS = MAXP;
+  extern __shared__ __attribute__((aligned(16))) unsigned char hpt_lds[];
+  uint64_t *stage = reinterpret_cast<uint64_t *>(hpt_lds);                 // [TILE]
+  uint32_t *hist = reinterpret_cast<uint32_t *>(stage + HPT_TILE);         // [MAXP + 4]
+  uint32_t *start = hist + MAXP + 4, *gbase = start + MAXP, *cursor = gbase + MAXP;
+  uint32_t *wave_tot = cursor + MAXP;                                      // [TH / WAVE]
+  uint16_t *bin_of = reinterpret_cast<uint16_t *>(wave_tot + TH / WAVE);   // [TILE]
   for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
     if (threadIdx.x < nparts) cursor[threadIdx.x] = offs[(size_t)threadIdx.x * nchunks + c];
     const int64_t begin = (int64_t)c * chunk;
@@ -263,7 +280,7 @@ __global__ __launch_bounds__(HP_THREADS) void part_scatter_tile_kernel(KeyTable 
         if (lane_id() == WAVE - 1) wave_tot[threadIdx.x / WAVE] = incl;
         block_sync();
         uint32_t woff = 0;
-        for (int w = 0; w < (int)(threadIdx.x / WAVE); ++w) woff += wave_tot[w];
+        for (int w = 0; w < (int)(threadIdx.x / WAVE); ++w) woff += wave_tot[w];     // (HP_THREADS / WAVE entries)
         if (threadIdx.x < nparts) {
           const uint32_t st = woff + incl - v;
           start[threadIdx.x] = st;
@@ -988,17 +1005,28 @@ gdf_error gdf_hash_partition(int num_input_cols, gdf_column *input[], int column
     pc.dst_map = dst_map.as<uint32_t>();
     if (first > 0)
       hipLaunchKernelGGL(part_apply_map_kernel, dim3(stream_grid(num_rows, HP_THREADS * 4)), dim3(HP_THREADS), 0, stream0(), pc, n);
-    else if (P > 16 && P <= (uint32_t)HPT_MAX_PARTS && !getenv("GDF_HP_NO_TILE")) {
+    else if (P > 16 && P <= (uint32_t)HPT_BIG_PARTS && !getenv("GDF_HP_NO_TILE")) {
       // measured at 1e8 rows x 2 int64 columns: P=256 1.47 ms vs 2.83 ms direct; at P=8 the direct kernel's runs are
       // long enough already (1.10 vs 1.19 ms), so small fan-outs keep it
-      if (fastw == 8)
-        GDF_LAUNCH("part_scatter", (part_scatter_tile_kernel<true, 8>), dim3(grid), dim3(HP_THREADS), 0, stream0(), t, pc, n, chunk, nchunks, P, pow2mask, hist.as<uint32_t>());
-      else if (fastw == 4)
-        GDF_LAUNCH("part_scatter", (part_scatter_tile_kernel<true, 4>), dim3(grid), dim3(HP_THREADS), 0, stream0(), t, pc, n, chunk, nchunks, P, pow2mask, hist.as<uint32_t>());
-      else if (murmur)
-        GDF_LAUNCH("part_scatter", (part_scatter_tile_kernel<true, 0>), dim3(grid), dim3(HP_THREADS), 0, stream0(), t, pc, n, chunk, nchunks, P, pow2mask, hist.as<uint32_t>());
-      else
-        hipLaunchKernelGGL((part_scatter_tile_kernel<false, 0>), dim3(grid), dim3(HP_THREADS), 0, stream0(), t, pc, n, chunk, nchunks, P, pow2mask, hist.as<uint32_t>());
+#define HPT_LAUNCH(MUR, FW, TH, MAXP, FI)                                                                                              \
+  do {                                                                                                                                 \
+    const size_t tl = HptShape<TH, MAXP, FI, (FW) != 0>::lds_bytes();                                                                  \
+    HIP_TRY(hipFuncSetAttribute((const void *)part_scatter_tile_kernel<MUR, FW, TH, MAXP, FI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl)); \
+    GDF_LAUNCH("part_scatter", (part_scatter_tile_kernel<MUR, FW, TH, MAXP, FI>), dim3(grid), dim3(TH), tl, stream0(), t, pc, n, chunk, \
+               nchunks, P, pow2mask, hist.as<uint32_t>());                                                                             \
+  } while (0)
+      if (P <= (uint32_t)HPT_MAX_PARTS) {
+        if (fastw == 8) HPT_LAUNCH(true, 8, 256, 256, 16);
+        else if (fastw == 4) HPT_LAUNCH(true, 4, 256, 256, 16);
+        else if (murmur) HPT_LAUNCH(true, 0, 256, 256, 16);
+        else HPT_LAUNCH(false, 0, 256, 256, 16);
+      } else {
+        if (fastw == 8) HPT_LAUNCH(true, 8, 1024, 1024, 12);
+        else if (fastw == 4) HPT_LAUNCH(true, 4, 1024, 1024, 12);
+        else if (murmur) HPT_LAUNCH(true, 0, 1024, 1024, 12);
+        else HPT_LAUNCH(false, 0, 1024, 1024, 12);
+      }
+#undef HPT_LAUNCH
     } else if (fastw == 8)
       GDF_LAUNCH("part_scatter", part_scatter_fast_kernel<uint64_t>, dim3(grid), dim3(HP_THREADS), lds, stream0(), (const uint64_t *)t.col[0].data, pc, n,
                  chunk, nchunks, P, pow2mask, agg_bits, hist.as<uint32_t>());

@@ -357,8 +357,16 @@ __device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
 __device__ __forceinline__ uint32_t key_fold(uint64_t raw_key) {
   return (uint32_t)raw_key ^ ((uint32_t)(raw_key >> 32) * 0x9e3779b1u);
 }
+// a second, independent 64 -> 32 fold (also injective below 2^32: an odd multiplier permutes the low word).  Keys wider
+// than 32 bits collide in ONE fold about n^2 / 2^33 times -- 1e8 keys spread over 2^60: a million pairs and ~9000 triples
+// with the same key_fold, which land in the same partition AND, if both cuckoo tables hashed that fold, in the same two
+// slots: a triple can never settle, a quarter of C3-sized WIDE joins' units fell back to linear probing
+// (profiles/r2_b_bench_shapes.jsonl, c3_wide_keys).  Everything that has to tell keys of one partition apart uses this one.
+__device__ __forceinline__ uint32_t key_fold2(uint64_t raw_key) {
+  return (uint32_t)(raw_key >> 32) ^ ((uint32_t)raw_key * 0x85ebca6bu);
+}
 __device__ __forceinline__ uint32_t hash_a(uint64_t raw_key) { return lowbias32(key_fold(raw_key)); }
-__device__ __forceinline__ uint32_t hash_b(uint64_t raw_key) { return lowbias32(key_fold(raw_key) ^ 0x68e31da4u); }
+__device__ __forceinline__ uint32_t hash_b(uint64_t raw_key) { return lowbias32(key_fold2(raw_key) ^ 0x68e31da4u); }
 
 __device__ __forceinline__ uint32_t fine_of(uint64_t raw_key, int fb) {
   return (uint32_t)((uint64_t)hash_a(raw_key) >> (32 - fb));      // 64-bit shift: fb == 0 gives 0 without a branch
@@ -1057,23 +1065,43 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
 // POW2: H is a power of two and a slot is the top log2(H) bits of the hash product; otherwise H is any size
 // (chosen by the host for a 40 % table load) and a slot is mulhi(hash product, H).
 // KEEP: LEFT join -- a probe tuple without a match emits (probe row, -1).
-template <bool POW2, bool KEEP>
+// NARROW = false: the same lean pass over WIDE tuples (exact 64-bit keys: one 8-byte integer / float column, or several
+// columns packed into 64 bits) -- keys spread over more than 2^32 used to take the general kernel at 8.9 ms per 1e9 probe
+// tuples (profiles/r2_b_bench_shapes.jsonl, c3_wide_keys).
+template <bool POW2, bool KEEP, bool NARROW>
 __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_fast(ProbeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const uint32_t H = a.nslots, cap = a.cap;
-  const ProbeLds l = carve_probe_lds<true>(lds_raw, cap, H);
+  const ProbeLds l = carve_probe_lds<NARROW>(lds_raw, cap, H);
   unsigned int *lcur = (unsigned int *)l.unit_cursor;      // pairs written so far by this unit
   const Unit u = a.units[blockIdx.x];
-  for (uint32_t i = threadIdx.x; i < u.build_count; i += JK_PROBE_THREADS) l.bw[i] = a.build.w[u.build_begin + i];
+  for (uint32_t i = threadIdx.x; i < u.build_count; i += JK_PROBE_THREADS) {
+    l.bw[i] = a.build.w[u.build_begin + i];
+    if (!NARROW) l.bi[i] = a.build.idx[u.build_begin + i];
+  }
   for (uint32_t i = threadIdx.x; i < 2 * H; i += JK_PROBE_THREADS) l.T[i] = JK_NOPOS;
   if (threadIdx.x == 0) { *lcur = 0; *l.cuckoo_failed = 0; }
   block_sync();
   const uint32_t kb_lo = (uint32_t)a.kbias, kb_hi = (uint32_t)(a.kbias >> 32);
-  // raw key = key32 + kbias; fold = lo ^ hi * C (key_fold)
-  auto fold_of = [&](uint32_t key) -> uint32_t {
-    const uint32_t lo = key + kb_lo;
-    const uint32_t hi = kb_hi + (lo < key ? 1u : 0u);
-    return lo ^ (hi * 0x9e3779b1u);
+  // raw key = stored key + kbias; fold = lo ^ hi * C (key_fold).  NARROW keys are 32 bits, WIDE keys 64.
+  using Key = typename std::conditional<NARROW, uint32_t, uint64_t>::type;
+  auto fold_of = [&](Key key) -> uint32_t {
+    if constexpr (NARROW) {
+      const uint32_t lo = key + kb_lo;
+      const uint32_t hi = kb_hi + (lo < key ? 1u : 0u);
+      return lo ^ (hi * 0x9e3779b1u);
+    } else {
+      return key_fold(key + a.kbias);
+    }
+  };
+  // the fold table 1 hashes: NARROW keys are told apart by the one fold (it is injective on them), WIDE keys need the second
+  auto fold2_of = [&](Key key, uint32_t f1) -> uint32_t {
+    if constexpr (NARROW) return f1;
+    else return key_fold2(key + a.kbias);
+  };
+  auto staged_key = [&](uint32_t p) -> Key {
+    if constexpr (NARROW) return (uint32_t)(l.bw[p] >> 32);
+    else return l.bw[p];
   };
   // Slot hashes: the TOP log2(H) bits of two multiplicative hashes of the folded key.  One quarter-rate 32-bit
   // multiply each instead of lowbias32's two multiplies and three xor-shifts: the keys of one partition are
@@ -1089,8 +1117,9 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_fast(ProbeArgs a) {
       uint32_t cur = p0, table = 0;
       int moves = 0;
       for (; moves < JK_CUCKOO_MAX_MOVES; ++moves) {
-        const uint32_t f = fold_of((uint32_t)(l.bw[cur] >> 32)) ^ seed;
-        const uint32_t slot = table ? H + (POW2 ? (f * 0xc2b2ae35u) >> hshift : __umulhi(f * 0xc2b2ae35u, H))
+        const Key ck = staged_key(cur);
+        const uint32_t f = fold_of(ck) ^ seed, f2 = fold2_of(ck, fold_of(ck)) ^ seed;
+        const uint32_t slot = table ? H + (POW2 ? (f2 * 0xc2b2ae35u) >> hshift : __umulhi(f2 * 0xc2b2ae35u, H))
                                     : (POW2 ? (f * 0x9e3779b1u) >> hshift : __umulhi(f * 0x9e3779b1u, H));
         const uint32_t old = atomicExch(&l.T[slot], cur);
         if (old == JK_NOPOS) break;
@@ -1118,24 +1147,35 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_fast(ProbeArgs a) {
   constexpr int NB = JK_PROBE_BATCH * 2;
   const uint32_t lead = u.probe_begin & 1u;
   const uint64_t *__restrict__ src = a.probe.w + (u.probe_begin - lead);
+  const int32_t *__restrict__ src_row = NARROW ? nullptr : a.probe.idx + (u.probe_begin - lead);
   const uint32_t vtotal = lead + u.probe_count;
   const uint32_t last_pair = (vtotal - 1) & ~1u;
   for (uint32_t base = 0; base < vtotal; base += JK_PROBE_THREADS * NB) {
-    uint32_t key[NB], prow[NB];
+    Key key[NB];
+    uint32_t prow[NB];
     bool act[NB];
 #pragma unroll
-    for (int b = 0; b < JK_PROBE_BATCH; ++b) {      // all HBM loads first, 16 bytes each, clamped and unconditional
+    for (int b = 0; b < JK_PROBE_BATCH; ++b) {      // all HBM loads first, 16 bytes each (WIDE: + 8 bytes of row numbers), clamped and unconditional
       const uint32_t v = base + (b * JK_PROBE_THREADS + threadIdx.x) * 2;
-      const ulonglong2 ww = *reinterpret_cast<const ulonglong2 *>(src + (v < last_pair ? v : last_pair));
-      key[2 * b] = (uint32_t)(ww.x >> 32); prow[2 * b] = (uint32_t)ww.x; act[2 * b] = v >= lead && v < vtotal;
-      key[2 * b + 1] = (uint32_t)(ww.y >> 32); prow[2 * b + 1] = (uint32_t)ww.y; act[2 * b + 1] = v + 1 < vtotal;
+      const uint32_t vc = v < last_pair ? v : last_pair;
+      const ulonglong2 ww = *reinterpret_cast<const ulonglong2 *>(src + vc);
+      if constexpr (NARROW) {
+        key[2 * b] = (uint32_t)(ww.x >> 32); prow[2 * b] = (uint32_t)ww.x;
+        key[2 * b + 1] = (uint32_t)(ww.y >> 32); prow[2 * b + 1] = (uint32_t)ww.y;
+      } else {
+        const uint2 rr = *reinterpret_cast<const uint2 *>(src_row + vc);
+        key[2 * b] = ww.x; prow[2 * b] = rr.x;
+        key[2 * b + 1] = ww.y; prow[2 * b + 1] = rr.y;
+      }
+      act[2 * b] = v >= lead && v < vtotal;
+      act[2 * b + 1] = v + 1 < vtotal;
     }
     uint32_t pa[NB], pb[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {                  // 2 independent table reads per tuple
-      const uint32_t f = fold_of(key[b]) ^ seed;
+      const uint32_t f = fold_of(key[b]) ^ seed, f2 = fold2_of(key[b], fold_of(key[b])) ^ seed;
       pa[b] = l.T[POW2 ? (f * 0x9e3779b1u) >> hshift : __umulhi(f * 0x9e3779b1u, H)];
-      pb[b] = l.T[H + (POW2 ? (f * 0xc2b2ae35u) >> hshift : __umulhi(f * 0xc2b2ae35u, H))];
+      pb[b] = l.T[H + (POW2 ? (f2 * 0xc2b2ae35u) >> hshift : __umulhi(f2 * 0xc2b2ae35u, H))];
     }
     uint64_t wa[NB], wb[NB];
 #pragma unroll
@@ -1145,8 +1185,8 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_fast(ProbeArgs a) {
     }
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-      const bool ha = act[b] && pa[b] != JK_NOPOS && (uint32_t)(wa[b] >> 32) == key[b];
-      const bool hb = act[b] && pb[b] != JK_NOPOS && (uint32_t)(wb[b] >> 32) == key[b];
+      const bool ha = act[b] && pa[b] != JK_NOPOS && (NARROW ? (uint32_t)(wa[b] >> 32) == (uint32_t)key[b] : wa[b] == (uint64_t)key[b]);
+      const bool hb = act[b] && pb[b] != JK_NOPOS && (NARROW ? (uint32_t)(wb[b] >> 32) == (uint32_t)key[b] : wb[b] == (uint64_t)key[b]);
       const bool pad = KEEP && act[b] && !ha && !hb;
       const uint32_t c = (uint32_t)ha + (uint32_t)hb + (uint32_t)pad;
       uint32_t pos;
@@ -1164,14 +1204,14 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_fast(ProbeArgs a) {
       }
       if (c) {
         if (pos + c > unit_cap) a.opt_state[1] = 1;   // would spill into the next unit's slots: the host redoes the join two-pass
-        else if (a.dbg & 1024) {                     // experiment: non-temporal stores of the index pairs
-          __builtin_nontemporal_store((int32_t)prow[b], &op[pos]);
-          __builtin_nontemporal_store(pad ? JK_EMPTY : (int32_t)(uint32_t)(ha ? wa[b] : wb[b]), &ob[pos]);
-          if (c == 2) { op[pos + 1] = (int32_t)prow[b]; ob[pos + 1] = (int32_t)(uint32_t)wb[b]; }
-        } else if (!(a.dbg & 32)) {
+        else if (!(a.dbg & 32)) {
+          // build row of a hit: NARROW carries it in the low half of the staged word, WIDE reads it from the staged row numbers
+          int32_t ra, rb;
+          if constexpr (NARROW) { ra = (int32_t)(uint32_t)wa[b]; rb = (int32_t)(uint32_t)wb[b]; }
+          else { ra = ha ? l.bi[pa[b]] : 0; rb = hb ? l.bi[pb[b]] : 0; }
           op[pos] = (int32_t)prow[b];
-          ob[pos] = pad ? JK_EMPTY : (int32_t)(uint32_t)(ha ? wa[b] : wb[b]);
-          if (c == 2) { op[pos + 1] = (int32_t)prow[b]; ob[pos + 1] = (int32_t)(uint32_t)wb[b]; }
+          ob[pos] = pad ? JK_EMPTY : (ha ? ra : rb);
+          if (c == 2) { op[pos + 1] = (int32_t)prow[b]; ob[pos + 1] = rb; }
         }
       }
     }
@@ -1558,7 +1598,7 @@ static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, Si
     HIP_TRY(hipMemcpyAsync(d_tiles.p, tile_prefix.data(), sizeof(uint32_t) * (ncoarse + 1), hipMemcpyHostToDevice, stream0()));
     HIP_TRY(hipMemcpyAsync(cursor.p, sb->fine_off.data(), sizeof(uint32_t) * nfine, hipMemcpyHostToDevice, stream0()));
     RMM_TRY(sb->w[1].alloc(sizeof(uint64_t) * (cap + 2)));
-    if (!narrow) RMM_TRY(sb->idx[1].alloc(sizeof(int32_t) * cap));
+    if (!narrow) RMM_TRY(sb->idx[1].alloc(sizeof(int32_t) * (cap + 2)));     // + 2: the lean probe kernel reads row numbers in pairs
     Level2Map m{d_coarse.as<uint32_t>(), d_coarse.as<uint32_t>() + 1, d_tiles.as<uint32_t>()};
     if (ntiles) GDF_TRY(launch_scatter2(narrow, sc2_threads, ntiles, g, m, sb->tuples(0), cursor.as<uint32_t>(), sb->tuples(1)));
     HIP_CHECK_LAST();
@@ -1751,7 +1791,8 @@ static gdf_error run_probe(bool narrow, bool write, const char *name, size_t nun
 static gdf_error run_write_pass(bool narrow, bool plain, size_t nunits, size_t lds, ProbeArgs a, uint32_t max_build,
                                 const KeyTable &probe_t, const KeyTable &build_t) {
   if (!nunits) return GDF_SUCCESS;
-  if (!(narrow && plain) || getenv("GDF_JK_NO_FAST")) return run_probe(narrow, true, "jk_probe_write", nunits, lds, a, probe_t, build_t);
+  if (!plain || getenv("GDF_JK_NO_FAST") || (!narrow && getenv("GDF_JK_NO_FAST_WIDE")))
+    return run_probe(narrow, true, "jk_probe_write", nunits, lds, a, probe_t, build_t);
   DevBuf todo;
   RMM_TRY(todo.alloc(sizeof(uint32_t) * nunits));
   a.unit_todo = todo.as<uint32_t>();
@@ -1763,18 +1804,25 @@ static gdf_error run_write_pass(bool narrow, bool plain, size_t nunits, size_t l
   const bool pow2 = (double)max_build <= 0.42 * 2.0 * (double)a.nslots;
   if (!pow2) {
     fa.nslots = ((uint32_t)(max_build * 1.25) + 63) & ~63u;
-    flds = probe_lds_bytes(true, a.cap, fa.nslots);
+    flds = probe_lds_bytes(narrow, a.cap, fa.nslots);
   }
-#define JK_FAST_LAUNCH(P2, KP)                                                                                               \
-  do {                                                                                                                       \
-    HIP_TRY(hipFuncSetAttribute((const void *)jk_probe_fast<P2, KP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds)); \
-    GDF_LAUNCH("jk_probe_write", (jk_probe_fast<P2, KP>), dim3((unsigned)nunits), dim3(JK_PROBE_THREADS), flds, stream0(), fa); \
+#define JK_FAST_LAUNCH(P2, KP, NW)                                                                                               \
+  do {                                                                                                                           \
+    HIP_TRY(hipFuncSetAttribute((const void *)jk_probe_fast<P2, KP, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds)); \
+    GDF_LAUNCH("jk_probe_write", (jk_probe_fast<P2, KP, NW>), dim3((unsigned)nunits), dim3(JK_PROBE_THREADS), flds, stream0(), fa); \
   } while (0)
   const bool keep = a.keep_unmatched_probe != 0;
-  if (pow2 && keep) JK_FAST_LAUNCH(true, true);
-  else if (pow2) JK_FAST_LAUNCH(true, false);
-  else if (keep) JK_FAST_LAUNCH(false, true);
-  else JK_FAST_LAUNCH(false, false);
+  if (narrow) {
+    if (pow2 && keep) JK_FAST_LAUNCH(true, true, true);
+    else if (pow2) JK_FAST_LAUNCH(true, false, true);
+    else if (keep) JK_FAST_LAUNCH(false, true, true);
+    else JK_FAST_LAUNCH(false, false, true);
+  } else {
+    if (pow2 && keep) JK_FAST_LAUNCH(true, true, false);
+    else if (pow2) JK_FAST_LAUNCH(true, false, false);
+    else if (keep) JK_FAST_LAUNCH(false, true, false);
+    else JK_FAST_LAUNCH(false, false, false);
+  }
 #undef JK_FAST_LAUNCH
   HIP_CHECK_LAST();
   unsigned long long left = 0;

@@ -5,21 +5,22 @@
 // kept: sum in the column's own dtype with wrap-around, inclusive or exclusive,
 // equal size & dtype required, valid masks rejected.
 //
-// Shape: ONE pass with decoupled look-back (scan_lookback): 2*w bytes per element, the algorithmic minimum.
-//   * a tile is 256 threads x 16 elements (i8: 4 KB, i32: 16 KB, i64: 32 KB); tile ids come from a ticket counter, so
-//     every predecessor of a running tile is running or done (HIP promises no dispatch order);
-//   * the tile is read with coalesced 16-byte loads, wave w owning 1024 consecutive elements, and scanned in that
-//     (round, lane, element) order -- one wave scan per round of 64 vectors (16 consecutive elements per thread read
-//     directly are 64 separate 64-byte requests per wave instruction: the three-pass kernels below cap at ~4.9 TB/s on
-//     that; a transposition through LDS costs 37 KB per workgroup, i.e. half the occupancy);
-//   * the tile publishes its AGGREGATE, then the whole workgroup looks back over 256 predecessors per round -- thread t
-//     at tile - 1 - t -- for the nearest tile with a published INCLUSIVE prefix, summing the aggregates in between, and
-//     publishes its own inclusive prefix.  A published value is one 8-byte word {flag, 32 data bits} written by a
-//     single agent-scope store, so data and flag cannot be seen apart (64-bit sums are two such words).  Why 256-wide:
-//     a look-back round costs one cross-XCD round trip (~1.5-2 us), so tiles can only resolve at window / round-trip --
-//     with the usual one-wave window (64) that is ~35 tiles per us = 1.1 TB/s of 32 KB tiles; 256 lanes give 4x that.
-// The reduce-then-scan shape of round 1 (three launches, 3*w bytes: scan_reduce -> scan_spine -> scan_apply) stays for
-// unaligned columns and as the A/B reference (GDF_SCAN_3PASS=1).
+// Shape (default): reduce-then-scan, three launches on the default stream, 3*w bytes per element --
+//   1. scan_reduce_v : every block sums one contiguous chunk                  (read N)
+//   2. scan_spine    : one block scans the <= 2048 chunk sums
+//   3. scan_apply_v  : every block re-reads its chunk and writes the scan seeded with its chunk offset (read N, write N)
+// with coalesced 16-byte non-temporal accesses: wave w of a 256-thread tile owns 1024 consecutive elements and reads them
+// as vectors k * 64 + lane, so the element order inside a wave is (round, lane, element) and the local scan is one wave
+// scan per round.  (Round 1's scan_apply gave every thread 16 consecutive elements -- 64 separate 64-byte requests per
+// wave instruction -- and capped at ~4.9 TB/s.)  Columns that are not 16-byte aligned keep those element-wise kernels.
+//
+// The single-pass alternative (scan_lookback, GDF_SCAN_LOOKBACK=1: decoupled look-back, 2*w bytes) is in the file and
+// correct, but LOSES on this part: a tile has to learn the sum of everything before it from other workgroups, through
+// words that cross the XCDs' non-coherent L2s (agent-scope 8-byte {flag, data} stores / loads, ~2 us per round trip under
+// load), and it can only finish after the slowest load among the few hundred tiles in flight before it.  Measured on 1e8
+// int64 (profiles/r2_c_scan_ablation.md): the same kernel without the look-back 0.27 ms (5.9 TB/s), with ticket order
+// 0.32, with a one-wave / 256-wide / software-pipelined look-back 0.64 / 0.64 / 0.55 ms -- against 0.49 ms for round 1's
+// three launches.  The streaming half of that kernel is what the coalesced kernels above reuse.
 #include "internal.h"
 
 #include <cstdlib>
@@ -170,141 +171,201 @@ __device__ __forceinline__ bool lb_read(const unsigned long long *slot, ACC &v) 
 
 template <class ACC, class ELEM>
 __global__ __launch_bounds__(LB_THREADS) void scan_lookback(const ELEM *in, ELEM *out, size_t n, int inclusive,
-                                                            unsigned long long *state, uint32_t *ticket) {
+                                                            unsigned long long *state, uint32_t *ticket, uint32_t ntiles, int dbg) {
   constexpr int NW = sizeof(ACC) / 4;
   constexpr int VEC = 16 / sizeof(ELEM);           // elements per 16-byte vector
   constexpr int VPT = LB_ITEMS / VEC;              // vectors per thread (i8: 1, i32: 4, i64: 8)
   constexpr int NWAVES = LB_THREADS / WAVE;
   constexpr int SEG = WAVE * LB_ITEMS;             // elements per wave
+  union Vec { u32x4 q; ELEM e[VEC]; };
+  struct Round { uint32_t code; ACC partial; };    // code 0: this wave's 64 tiles hold aggregates only, 1: an inclusive prefix
+                                                   // among them (partial = sum up to it), 2: a tile before that has nothing yet
   __shared__ ACC wsum[NWAVES];
-  __shared__ unsigned long long s_m2[NWAVES], s_m0[NWAVES];
-  __shared__ uint32_t s_tile;
-  if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
-  block_sync();
-  const uint32_t tile = s_tile;
-  const size_t base = (size_t)tile * LB_TILE;
-  const bool full = base + LB_TILE <= n;
+  __shared__ Round s_round[NWAVES];
+  __shared__ uint32_t s_tile[2];
   const int wave = threadIdx.x / WAVE, lane = lane_id();
 
-  // ---- load + local scan.  No LDS transposition (its 37 KB per workgroup halved the occupancy of a kernel that lives on
-  // bytes in flight): wave w owns SEG consecutive elements and reads them as 16-byte vectors, vector k * 64 + lane in
-  // round k -- 1 KB contiguous per load instruction.  The order of the elements is then (round, lane, element within the
-  // vector): one wave scan of the per-vector sums per ROUND instead of one per tile.  Partial tiles (the last one) take
-  // plain guarded loads of 16 consecutive elements per thread, which is the same scheme with one round of 16-element
-  // "vectors" per wave.
-  union Vec { u32x4 q; ELEM e[VEC]; };
-  Vec vv[VPT];
-  ACC excl_in_wave[VPT];                            // prefix of vector (k, lane) inside the wave's segment
-  ACC wave_total = 0;
-  if (full) {
-    const u32x4 *src = reinterpret_cast<const u32x4 *>(in + base + (size_t)wave * SEG);     // 16-byte aligned: the host checked
+  // No LDS transposition (its 37 KB per workgroup halved the occupancy of a kernel that lives on bytes in flight): wave w
+  // owns SEG consecutive elements and reads them as 16-byte vectors, vector k * 64 + lane in round k -- 1 KB contiguous
+  // per load instruction.  The order of the elements is then (round, lane, element within the vector): one wave scan of
+  // the per-vector sums per ROUND.  The partial last tile takes guarded loads of 16 consecutive elements per thread.
+  auto load_tile = [&](Vec (&v)[VPT], uint32_t t) {
+    const size_t base = (size_t)t * LB_TILE;
+    if (base + LB_TILE <= n) {
+      const u32x4 *src = reinterpret_cast<const u32x4 *>(in + base + (size_t)wave * SEG);     // 16-byte aligned: the host checked
 #pragma unroll
-    for (int k = 0; k < VPT; ++k) vv[k].q = __builtin_nontemporal_load(src + k * WAVE + lane);
+      for (int k = 0; k < VPT; ++k) v[k].q = __builtin_nontemporal_load(src + k * WAVE + lane);
+    } else {
+      const size_t t0 = base + (size_t)threadIdx.x * LB_ITEMS;
 #pragma unroll
-    for (int k = 0; k < VPT; ++k) {
+      for (int k = 0; k < VPT; ++k)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const size_t i = t0 + k * VEC + e;
+          v[k].e[e] = i < n ? in[i] : (ELEM)0;
+        }
+    }
+  };
+
+  // Three tiles per workgroup are in flight, a software pipeline over the ticket sequence:
+  //   Z  loads issued (its ticket was taken one step ago)
+  //   Y  data arrived: scanned locally and its AGGREGATE published at once -- successors must not wait for it
+  //   X  aggregate published one step ago: look back, publish the inclusive prefix, write the outputs.
+  // X looks back a whole step (a tile's load latency) after its aggregate went out, so its predecessors -- older tickets
+  // -- have had that long to publish theirs: the poll rarely meets a tile with nothing published, and the round trip of the
+  // poll overlaps Z's loads.  (Looking back right after the local scan, every tile stalled on the slowest load among the
+  // ~200 tiles started just before it: 0.64 ms per 1e8 int64 against 0.32 ms for the same kernel without the look-back.)
+  struct Scanned {
+    uint32_t tile;
+    ACC excl_in_wave[VPT];      // prefix of vector (k, lane) inside the wave's segment
+    ACC woff, aggregate;
+  };
+  auto ticket_to = [&](int slot) {
+    if (threadIdx.x == 0) s_tile[slot] = atomicAdd(ticket, 1u);
+  };
+  // local scan of a loaded tile + publication of its aggregate; contains one block_sync (which also makes the ticket
+  // written just before it visible)
+  auto scan_and_publish = [&](const Vec (&v)[VPT], uint32_t t, Scanned &sc) {
+    const size_t base = (size_t)t * LB_TILE;
+    ACC wave_total = 0;
+    if (base + LB_TILE <= n) {
+#pragma unroll
+      for (int k = 0; k < VPT; ++k) {
+        ACC sum = 0;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) sum += (ACC)v[k].e[e];
+        const ACC inc = wave_scan_incl(sum);
+        sc.excl_in_wave[k] = wave_total + inc - sum;
+        wave_total += __shfl(inc, WAVE - 1, WAVE);
+      }
+    } else {
       ACC sum = 0;
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) sum += (ACC)vv[k].e[e];
+      for (int k = 0; k < VPT; ++k)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) sum += (ACC)v[k].e[e];
       const ACC inc = wave_scan_incl(sum);
-      excl_in_wave[k] = wave_total + inc - sum;
-      wave_total += __shfl(inc, WAVE - 1, WAVE);
+      sc.excl_in_wave[0] = inc - sum;
+      wave_total = __shfl(inc, WAVE - 1, WAVE);
     }
-  } else {
-    const size_t t0 = base + (size_t)threadIdx.x * LB_ITEMS;      // vv holds this thread's 16 consecutive elements
-    ACC sum = 0;
-#pragma unroll
-    for (int k = 0; k < VPT; ++k)
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        const size_t i = t0 + k * VEC + e;
-        vv[k].e[e] = i < n ? in[i] : (ELEM)0;
-        sum += (ACC)vv[k].e[e];
-      }
-    const ACC inc = wave_scan_incl(sum);
-    excl_in_wave[0] = inc - sum;
-    wave_total = __shfl(inc, WAVE - 1, WAVE);
-  }
-  if (lane == 0) wsum[wave] = wave_total;
-  block_sync();
-  ACC woff = 0, aggregate = 0;
-#pragma unroll
-  for (int w = 0; w < NWAVES; ++w) {
-    if (w < wave) woff += wsum[w];
-    aggregate += wsum[w];
-  }
-  unsigned long long *mine = state + (size_t)tile * 2 * NW;
-  if (threadIdx.x == 0) lb_publish<ACC>(mine, aggregate);
-
-  // ---- look-back, the whole workgroup: thread t examines tile - 1 - t (a tile before the first one has prefix 0) ----
-  ACC exclusive = 0;
-  long long nearest = (long long)tile - 1;
-  for (;;) {
-    const long long p = nearest - (long long)threadIdx.x;
-    int st = 2;
-    ACC val = 0;
-    if (p >= 0) {
-      const unsigned long long *theirs = state + (size_t)p * 2 * NW;
-      if (!lb_read<ACC>(theirs + NW, val)) st = lb_read<ACC>(theirs, val) ? 1 : 0;
-    }
-    const unsigned long long m2 = __ballot(st == 2), m0 = __ballot(st == 0);
-    block_sync();                 // the previous round's readers of s_m2 / s_m0 / wsum are done
-    if (lane == 0) { s_m2[wave] = m2; s_m0[wave] = m0; }
+    block_sync();                               // readers of wsum from the previous tile are done
+    if (lane == 0) wsum[wave] = wave_total;
     block_sync();
-    int first_incl = -1;          // thread index of the nearest published inclusive prefix in this window
-    bool wait = false;            // some tile nearer than that has published nothing yet
+    sc.woff = 0;
+    sc.aggregate = 0;
 #pragma unroll
     for (int w = 0; w < NWAVES; ++w) {
-      if (first_incl < 0 && !wait) {
-        const unsigned long long a = s_m2[w], z = s_m0[w];
-        if (a) {
-          const int c = __ffsll((long long)a) - 1;
-          if (z & ((1ull << c) - 1ull)) wait = true;
-          else first_incl = w * WAVE + c;
-        } else if (z) {
-          wait = true;
+      if (w < wave) sc.woff += wsum[w];
+      sc.aggregate += wsum[w];
+    }
+    sc.tile = t;
+    if (threadIdx.x == 0) lb_publish<ACC>(state + (size_t)t * 2 * NW, sc.aggregate);
+  };
+  // look-back for a scanned tile, the whole workgroup: thread t examines tile - 1 - t (a tile before the first one has
+  // prefix 0); both words of a predecessor are requested together -- one round trip, not two
+  auto resolve = [&](const Scanned &sc) -> ACC {
+    ACC exclusive = 0;
+    long long nearest = (long long)sc.tile - 1;
+    for (; !(dbg & 2);) {           // dbg & 2 (experiment): no look-back, wrong prefixes
+      const long long p = nearest - (long long)threadIdx.x;
+      int st = 2;
+      ACC val = 0;
+      if (p >= 0) {
+        const unsigned long long *theirs = state + (size_t)p * 2 * NW;
+        ACC agg, inc;
+        const bool has_agg = lb_read<ACC>(theirs, agg);
+        const bool has_inc = lb_read<ACC>(theirs + NW, inc);
+        st = has_inc ? 2 : (has_agg ? 1 : 0);
+        val = has_inc ? inc : agg;
+      }
+      const unsigned long long m2 = __ballot(st == 2), m0 = __ballot(st == 0);
+      const int c = m2 ? __ffsll((long long)m2) - 1 : WAVE;
+      const bool blocked = (m0 & (c == WAVE ? ~0ull : ((1ull << c) - 1ull))) != 0;
+      const ACC part = wave_reduce_add(lane <= c ? val : (ACC)0);
+      block_sync();                 // s_round's previous readers are done
+      if (lane == 0) s_round[wave] = Round{blocked ? 2u : (m2 ? 1u : 0u), part};
+      block_sync();
+      bool wait = false, found = false;
+      ACC add = 0;
+#pragma unroll
+      for (int w = 0; w < NWAVES; ++w) {
+        if (!wait && !found) {
+          const Round r = s_round[w];
+          if (r.code == 2) wait = true;
+          else { add += r.partial; found = r.code == 1; }
         }
       }
+      if (!wait) exclusive += add;
+      if (found) break;
+      if (wait) __builtin_amdgcn_s_sleep(2);
+      else nearest -= LB_THREADS;
     }
-    if (wait) { __builtin_amdgcn_s_sleep(4); continue; }      // workgroup-uniform
-    const ACC c = (first_incl < 0 || (int)threadIdx.x <= first_incl) ? val : (ACC)0;
-    const ACC part = wave_reduce_add(c);
-    if (lane == 0) wsum[wave] = part;
-    block_sync();
+    if (threadIdx.x == 0) lb_publish<ACC>(state + ((size_t)sc.tile * 2 + 1) * NW, (ACC)(exclusive + sc.aggregate));
+    return exclusive;
+  };
+  auto write_tile = [&](const Vec (&v)[VPT], const Scanned &sc, ACC exclusive) {
+    const size_t base = (size_t)sc.tile * LB_TILE;
+    const ACC wave_base = exclusive + sc.woff;
+    if (base + LB_TILE <= n) {
+      u32x4 *dst = reinterpret_cast<u32x4 *>(out + base + (size_t)wave * SEG);
 #pragma unroll
-    for (int w = 0; w < NWAVES; ++w) exclusive += wsum[w];
-    if (first_incl >= 0) break;
-    nearest -= LB_THREADS;
-  }
-  if (threadIdx.x == 0) lb_publish<ACC>(mine + NW, (ACC)(exclusive + aggregate));
+      for (int k = 0; k < VPT; ++k) {
+        ACC pre = wave_base + sc.excl_in_wave[k];
+        Vec o;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const ACC x = (ACC)v[k].e[e];
+          o.e[e] = (ELEM)(inclusive ? pre + x : pre);
+          pre += x;
+        }
+        __builtin_nontemporal_store(o.q, dst + k * WAVE + lane);
+      }
+    } else {
+      const size_t t0 = base + (size_t)threadIdx.x * LB_ITEMS;
+      ACC pre = wave_base + sc.excl_in_wave[0];
+#pragma unroll
+      for (int k = 0; k < VPT; ++k)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const size_t i = t0 + k * VEC + e;
+          const ACC x = (ACC)v[k].e[e];
+          if (i < n) out[i] = (ELEM)(inclusive ? pre + x : pre);
+          pre += x;
+        }
+    }
+  };
 
-  // ---- outputs ----
-  const ACC wave_base = exclusive + woff;
-  if (full) {
-    u32x4 *dst = reinterpret_cast<u32x4 *>(out + base + (size_t)wave * SEG);
-#pragma unroll
-    for (int k = 0; k < VPT; ++k) {
-      ACC pre = wave_base + excl_in_wave[k];
-      Vec o;
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        const ACC x = (ACC)vv[k].e[e];
-        o.e[e] = (ELEM)(inclusive ? pre + x : pre);
-        pre += x;
-      }
-      __builtin_nontemporal_store(o.q, dst + k * WAVE + lane);
+  // prologue: X loaded and scanned, Y's loads in flight
+  ticket_to(0);
+  block_sync();
+  uint32_t tx = s_tile[0];
+  if (tx >= ntiles) return;
+  Vec vx[VPT], vy[VPT];
+  Scanned sx, sy;
+  load_tile(vx, tx);
+  ticket_to(1);
+  scan_and_publish(vx, tx, sx);
+  uint32_t ty = s_tile[1];
+  if (ty < ntiles) load_tile(vy, ty);
+  int slot = 0;
+  for (;;) {
+    // ticket for Z; Y scanned and published (this waits for Y's data); Z's loads issued; then X resolved and written
+    uint32_t tz = ntiles;
+    Vec vz[VPT];
+    if (ty < ntiles) {
+      ticket_to(slot);
+      scan_and_publish(vy, ty, sy);
+      tz = s_tile[slot];
+      slot ^= 1;
+      if (tz < ntiles) load_tile(vz, tz);
     }
-  } else {
-    const size_t t0 = base + (size_t)threadIdx.x * LB_ITEMS;
-    ACC pre = wave_base + excl_in_wave[0];
+    const ACC exclusive = resolve(sx);
+    write_tile(vx, sx, exclusive);
+    if (ty >= ntiles) break;
 #pragma unroll
-    for (int k = 0; k < VPT; ++k)
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        const size_t i = t0 + k * VEC + e;
-        const ACC x = (ACC)vv[k].e[e];
-        if (i < n) out[i] = (ELEM)(inclusive ? pre + x : pre);
-        pre += x;
-      }
+    for (int k = 0; k < VPT; ++k) { vx[k] = vy[k]; vy[k] = vz[k]; }
+    sx = sy;
+    ty = tz;
   }
 }
 
@@ -312,13 +373,183 @@ template <class ACC, class ELEM>
 static gdf_error device_scan_lookback(const ELEM *in, ELEM *out, size_t n, bool inclusive) {
   constexpr int NW = sizeof(ACC) / 4;
   const size_t ntiles = (n + LB_TILE - 1) / LB_TILE;
+  static const int dbg = getenv("GDF_SCAN_DBG") ? atoi(getenv("GDF_SCAN_DBG")) : 0;
   DevBuf st;
   const size_t state_bytes = sizeof(unsigned long long) * ntiles * 2 * NW;
   RMM_TRY(st.alloc(state_bytes + sizeof(unsigned long long)));
   HIP_TRY(hipMemsetAsync(st.p, 0, state_bytes + sizeof(unsigned long long), stream0()));
   uint32_t *ticket = reinterpret_cast<uint32_t *>(st.as<unsigned char>() + state_bytes);
-  GDF_LAUNCH("scan_lookback", (scan_lookback<ACC, ELEM>), dim3((unsigned)ntiles), dim3(LB_THREADS), 0, stream0(), in, out, n,
-             inclusive ? 1 : 0, st.as<unsigned long long>(), ticket);
+  // persistent workgroups, each takes tiles from the ticket counter until they run out: a few per CU (every one keeps two
+  // tiles in flight).  With dbg & 1 every workgroup handles exactly the tile of its blockIdx.
+  static const int per_cu_env = getenv("GDF_SCAN_WGS_PER_CU") ? atoi(getenv("GDF_SCAN_WGS_PER_CU")) : 0;
+  int per_cu = per_cu_env;
+  if (per_cu <= 0) {
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)scan_lookback<ACC, ELEM>, LB_THREADS, 0));
+    if (per_cu < 1) per_cu = 1;
+  }
+  size_t grid = (dbg & 1) ? ntiles : (size_t)NUM_CU * (size_t)per_cu;
+  if (grid > ntiles) grid = ntiles;
+  GDF_LAUNCH("scan_lookback", (scan_lookback<ACC, ELEM>), dim3((unsigned)grid), dim3(LB_THREADS), 0, stream0(), in, out, n,
+             inclusive ? 1 : 0, st.as<unsigned long long>(), ticket, (uint32_t)ntiles, dbg);
+  HIP_CHECK_LAST();
+  HIP_TRY(hipStreamSynchronize(stream0()));   // scratch is released on return
+  return GDF_SUCCESS;
+}
+
+
+// ---------------------------------------------------------------------------
+// reduce-then-scan with COALESCED accesses (the default): the same three launches as scan_reduce / scan_spine / scan_apply
+// above, but every load and store is a 16-byte vector, lanes on consecutive vectors (1 KB contiguous per wave instruction),
+// non-temporal.  scan_apply's 16 consecutive elements per thread are 64 separate 64-byte requests per wave instruction and
+// cap that kernel at ~4.9 TB/s; the striped order needs one wave scan per round of 64 vectors instead of one per tile,
+// which is VALU time the kernel has to spare.
+// ---------------------------------------------------------------------------
+template <class ACC, class ELEM>
+__global__ __launch_bounds__(LB_THREADS) void scan_reduce_v(const ELEM *__restrict__ in, ACC *__restrict__ chunk_sum, size_t n, size_t chunk) {
+  constexpr int VEC = 16 / sizeof(ELEM);
+  union Vec { u32x4 q; ELEM e[VEC]; };
+  __shared__ ACC wsum[LB_THREADS / WAVE];
+  const size_t begin = (size_t)blockIdx.x * chunk;                 // a multiple of LB_TILE, so of VEC
+  const size_t end = begin + chunk < n ? begin + chunk : n;
+  const size_t nvec = (end - begin) / VEC;
+  const u32x4 *src = reinterpret_cast<const u32x4 *>(in + begin);
+  ACC acc = 0;
+  size_t i = threadIdx.x;
+  for (; i + 7 * LB_THREADS < nvec; i += 8 * LB_THREADS) {         // 8 independent 16-byte loads in flight per thread
+    Vec v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k].q = __builtin_nontemporal_load(src + i + (size_t)k * LB_THREADS);
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc += (ACC)v[k].e[e];
+  }
+  for (; i < nvec; i += LB_THREADS) {
+    Vec v;
+    v.q = __builtin_nontemporal_load(src + i);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc += (ACC)v.e[e];
+  }
+  if (threadIdx.x == 0)
+    for (size_t j = begin + nvec * VEC; j < end; ++j) acc += (ACC)in[j];      // fewer than VEC elements behind the last whole vector
+  acc = wave_reduce_add(acc);
+  if (lane_id() == 0) wsum[threadIdx.x / WAVE] = acc;
+  block_sync();
+  if (threadIdx.x == 0) {
+    ACC t = 0;
+    for (int w = 0; w < LB_THREADS / WAVE; ++w) t += wsum[w];
+    chunk_sum[blockIdx.x] = t;
+  }
+}
+
+template <class ACC, class ELEM>
+__global__ __launch_bounds__(LB_THREADS) void scan_apply_v(const ELEM *in, ELEM *out,   // in == out allowed
+                                                          const ACC *__restrict__ chunk_off, size_t n, size_t chunk, int inclusive) {
+  constexpr int VEC = 16 / sizeof(ELEM);
+  constexpr int VPT = LB_ITEMS / VEC;
+  constexpr int NWAVES = LB_THREADS / WAVE;
+  constexpr int SEG = WAVE * LB_ITEMS;
+  union Vec { u32x4 q; ELEM e[VEC]; };
+  __shared__ ACC wsum[NWAVES];
+  const size_t begin = (size_t)blockIdx.x * chunk;
+  const size_t end = begin + chunk < n ? begin + chunk : n;
+  const int wave = threadIdx.x / WAVE, lane = lane_id();
+  ACC carry = chunk_off[blockIdx.x];
+  Vec cur[VPT], nxt[VPT];
+  auto load_full = [&](Vec (&v)[VPT], size_t tile) {
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(in + tile + (size_t)wave * SEG);
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) v[k].q = __builtin_nontemporal_load(src + k * WAVE + lane);
+  };
+  if (begin + LB_TILE <= end) load_full(cur, begin);
+  for (size_t tile = begin; tile < end; tile += LB_TILE) {
+    const bool full = tile + LB_TILE <= end;
+    const bool next_full = tile + 2 * (size_t)LB_TILE <= end;
+    if (next_full) load_full(nxt, tile + LB_TILE);                // the next tile's loads fly over this tile's scan and stores
+    ACC excl_in_wave[VPT];
+    ACC wave_total = 0;
+    if (full) {
+#pragma unroll
+      for (int k = 0; k < VPT; ++k) {
+        ACC sum = 0;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) sum += (ACC)cur[k].e[e];
+        const ACC inc = wave_scan_incl(sum);
+        excl_in_wave[k] = wave_total + inc - sum;
+        wave_total += __shfl(inc, WAVE - 1, WAVE);
+      }
+    } else {                                                       // the chunk's partial last tile: 16 consecutive elements per thread
+      const size_t t0 = tile + (size_t)threadIdx.x * LB_ITEMS;
+      ACC sum = 0;
+#pragma unroll
+      for (int k = 0; k < VPT; ++k)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const size_t i = t0 + k * VEC + e;
+          cur[k].e[e] = i < end ? in[i] : (ELEM)0;
+          sum += (ACC)cur[k].e[e];
+        }
+      const ACC inc = wave_scan_incl(sum);
+      excl_in_wave[0] = inc - sum;
+      wave_total = __shfl(inc, WAVE - 1, WAVE);
+    }
+    block_sync();                                                  // the previous tile's readers of wsum are done
+    if (lane == 0) wsum[wave] = wave_total;
+    block_sync();
+    ACC woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < NWAVES; ++w) {
+      if (w < wave) woff += wsum[w];
+      total += wsum[w];
+    }
+    const ACC wave_base = carry + woff;
+    if (full) {
+      u32x4 *dst = reinterpret_cast<u32x4 *>(out + tile + (size_t)wave * SEG);
+#pragma unroll
+      for (int k = 0; k < VPT; ++k) {
+        ACC pre = wave_base + excl_in_wave[k];
+        Vec o;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const ACC x = (ACC)cur[k].e[e];
+          o.e[e] = (ELEM)(inclusive ? pre + x : pre);
+          pre += x;
+        }
+        __builtin_nontemporal_store(o.q, dst + k * WAVE + lane);
+      }
+    } else {
+      const size_t t0 = tile + (size_t)threadIdx.x * LB_ITEMS;
+      ACC pre = wave_base + excl_in_wave[0];
+#pragma unroll
+      for (int k = 0; k < VPT; ++k)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const size_t i = t0 + k * VEC + e;
+          const ACC x = (ACC)cur[k].e[e];
+          if (i < end) out[i] = (ELEM)(inclusive ? pre + x : pre);
+          pre += x;
+        }
+    }
+    carry += total;
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) cur[k] = nxt[k];
+  }
+}
+
+template <class ACC, class ELEM>
+static gdf_error device_scan_coalesced(const ELEM *in, ELEM *out, size_t n, bool inclusive) {
+  DevBuf sums, running;
+  RMM_TRY(sums.alloc(sizeof(ACC) * SCAN_MAX_CHUNKS));
+  RMM_TRY(running.alloc(sizeof(ACC)));
+  HIP_TRY(hipMemsetAsync(running.p, 0, sizeof(ACC), stream0()));
+  const size_t tiles = (n + LB_TILE - 1) / LB_TILE;
+  const size_t tiles_per_chunk = (tiles + SCAN_MAX_CHUNKS - 1) / SCAN_MAX_CHUNKS;
+  const size_t chunk = tiles_per_chunk * LB_TILE;
+  const int nchunks = (int)((n + chunk - 1) / chunk);
+  GDF_LAUNCH("scan_reduce", (scan_reduce_v<ACC, ELEM>), dim3(nchunks), dim3(LB_THREADS), 0, stream0(), in, sums.as<ACC>(), n, chunk);
+  hipLaunchKernelGGL((scan_spine<ACC>), dim3(1), dim3(SCAN_THREADS), 0, stream0(), sums.as<ACC>(), nchunks, running.as<ACC>());
+  GDF_LAUNCH("scan_apply", (scan_apply_v<ACC, ELEM>), dim3(nchunks), dim3(LB_THREADS), 0, stream0(), in, out, sums.as<ACC>(), n, chunk,
+             inclusive ? 1 : 0);
   HIP_CHECK_LAST();
   HIP_TRY(hipStreamSynchronize(stream0()));   // scratch is released on return
   return GDF_SUCCESS;
@@ -332,11 +563,14 @@ static gdf_error device_scan_lookback(const ELEM *in, ELEM *out, size_t n, bool 
 template <class ACC, class ELEM>
 gdf_error device_scan(const ELEM *in, ELEM *out, size_t n, bool inclusive) {
   if (n == 0) return GDF_SUCCESS;
-  // one pass whenever the columns allow 16-byte accesses (a column may be a slice of a larger buffer) and the tile count
-  // fits the 32-bit ticket
-  static const bool three_pass = getenv("GDF_SCAN_3PASS") != nullptr;
-  if (!three_pass && ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0) && n / LB_TILE < 0x7fffffffULL)
-    return device_scan_lookback<ACC, ELEM>(in, out, n, inclusive);
+  // 16-byte accesses need 16-byte-aligned columns (a column may be a slice of a larger buffer): those take the coalesced
+  // kernels, or -- GDF_SCAN_LOOKBACK=1, an experiment that lost, see the header -- the single-pass kernel; the rest, and
+  // GDF_SCAN_BLOCKED=1, the element-wise kernels of round 1
+  static const bool lookback = getenv("GDF_SCAN_LOOKBACK") != nullptr, blocked = getenv("GDF_SCAN_BLOCKED") != nullptr;
+  if (!blocked && ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0)) {
+    if (lookback && n / LB_TILE < 0x7fffffffULL) return device_scan_lookback<ACC, ELEM>(in, out, n, inclusive);
+    return device_scan_coalesced<ACC, ELEM>(in, out, n, inclusive);
+  }
   constexpr int ITEMS = 16 / sizeof(ELEM) >= 4 ? 8 : 4;
   constexpr size_t TILE = (size_t)SCAN_THREADS * ITEMS;
   static const size_t seg_bytes = getenv("GDF_SCAN_SEG_MB") ? (size_t)atoll(getenv("GDF_SCAN_SEG_MB")) << 20 : 0;

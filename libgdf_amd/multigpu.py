@@ -36,6 +36,15 @@ from __future__ import annotations
 
 from ._binding import GDFError, GDF_UNSUPPORTED_METHOD
 
+# bytes this rank handed to RCCL (remote segments only; a rank's own segment is a device copy) since the last reset --
+# bench.py reports them per step next to the link-bound estimate
+STATS = {"bytes_sent": 0, "messages": 0}
+
+
+def reset_stats():
+    STATS["bytes_sent"] = 0
+    STATS["messages"] = 0
+
 
 def _device_partition(keys, payload, world):
     """gdf_hash_partition over (key, payload) on the key column -> (keys_out, payload_out, offsets list)."""
@@ -208,6 +217,8 @@ def _all_to_all_v(recv, send, recv_split, send_split, group, async_op):
             peer = dist.get_global_rank(group, r) if group is not None else r
             for a in range(0, ns, piece):
                 ops.append(dist.P2POp(dist.isend, send[so + a:so + min(ns, a + piece)], peer, group))
+                STATS["messages"] += 1
+            STATS["bytes_sent"] += ns * send.element_size()
             for a in range(0, nr, piece):
                 ops.append(dist.P2POp(dist.irecv, recv[ro + a:ro + min(nr, a + piece)], peer, group))
         so += ns
@@ -430,6 +441,8 @@ def _all_gather_v(local, group):
         peer = dist.get_global_rank(group, r) if group is not None else r
         for a in range(0, local.numel(), limit):
             ops.append(dist.P2POp(dist.isend, local[a:min(local.numel(), a + limit)], peer, group))
+            STATS["messages"] += 1
+        STATS["bytes_sent"] += local.numel() * local.element_size()
         for a in range(0, counts[r], limit):
             ops.append(dist.P2POp(dist.irecv, out[bounds[r] + a:bounds[r] + min(counts[r], a + limit)], peer, group))
     if ops:
@@ -461,6 +474,61 @@ def broadcast_inner_join(probe_keys, build_keys, join_fn=_device_join_columns, g
     gathered, bounds = _all_gather_v(build_keys, group)
     li, ri = join_fn(probe_keys, gathered)
     return ShardedPairs([_LocalRows(me)], _GatheredRows(gathered, bounds), [li], [ri])
+
+
+# ---- planner ------------------------------------------------------------------------------------------------------------
+# Cost model of the two join strategies for one rank, in seconds.  Constants are measurements of this library on one
+# MI355X (profiles/): the local passes per row, and what one xGMI link sustains in one direction
+# (76.8 GB/s peak per link and direction; 60 GB/s assumed -- the links have never been measured from here, the 1-GPU
+# boxes have none).  xGMI is point-to-point: with `world` GPUs a rank talks to each peer over ONE link, so an all-to-all
+# of V bytes per rank puts V / world on every link, and the time is that of the busiest link, not of the aggregate.
+XGMI_LINK_BYTES_PER_S = 60e9
+_SHUFFLE_LOCAL_S_PER_ROW = 16.8e-12      # sender split + receiver partition + probe, per row of (probe + build): 18.9 ms at C4 shard sizes
+_JOIN_S_PER_PROBE_ROW = 9.6e-12          # gdf_inner_join, NARROW keys: 10.6 ms for 1e9 x 1e8
+_JOIN_S_PER_BUILD_ROW = 10e-12
+_LEVEL3_BUILD_ROWS = 1.6e8               # larger build relations take a third partitioning level (csrc/join.hip refine_side):
+_LEVEL3_S_PER_PROBE_ROW = 5e-12          # 1e9 x 2.5e8 / 5e8 / 1e9 rows: 17.2 / 20.6 / 29.1 ms
+_LEVEL3_S_PER_BUILD_ROW = 4e-12
+_NARROW_S_PER_ROW = 2.4e-12              # gdf_amd_narrow_keys over both relations (broadcast variant): 2.7 ms per 1.125e9 rows
+
+
+def estimate_join_seconds(world, probe_rows, build_rows, key_bytes=4.125):
+    """-> {"shuffle": s, "broadcast": s} for per-rank shard sizes `probe_rows` / `build_rows` (the larger of the exchange on
+    the busiest link and the local passes, i.e. assuming they overlap)."""
+    rows = probe_rows + build_rows
+    shuffle_link = rows * key_bytes / max(world, 1) / XGMI_LINK_BYTES_PER_S if world > 1 else 0.0
+    shuffle = max(shuffle_link, _SHUFFLE_LOCAL_S_PER_ROW * rows)
+    gathered = build_rows * world
+    bcast_link = build_rows * 4.0 / XGMI_LINK_BYTES_PER_S if world > 1 else 0.0        # every peer's shard arrives over its own link
+    local = _NARROW_S_PER_ROW * rows + _JOIN_S_PER_PROBE_ROW * probe_rows + _JOIN_S_PER_BUILD_ROW * gathered
+    if gathered > _LEVEL3_BUILD_ROWS:
+        local += _LEVEL3_S_PER_PROBE_ROW * probe_rows + _LEVEL3_S_PER_BUILD_ROW * gathered
+    return {"shuffle": shuffle, "broadcast": max(bcast_link, local)}
+
+
+def choose_join_strategy(world, probe_rows, build_rows):
+    """"shuffle" (hash-partition both relations, RCCL all-to-all) or "broadcast" (all-gather the build keys, probe rows stay
+    home) -- whichever the cost model above expects to finish first.  With C4's shard sizes: broadcast at 2 GPUs (the shuffle
+    would push 2.3 GB through the one link between them), shuffle at 4 and 8."""
+    est = estimate_join_seconds(world, probe_rows, build_rows)
+    return "broadcast" if est["broadcast"] < est["shuffle"] else "shuffle"
+
+
+def planned_inner_join(probe_keys, build_keys, group=None, shuffle_kw=None, broadcast_kw=None):
+    """distributed_inner_join or broadcast_inner_join, chosen by choose_join_strategy from the GLOBAL shard sizes (one
+    all-gather of two numbers, so that every rank takes the same branch)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    mine = torch.tensor([probe_keys.numel(), build_keys.numel()], dtype=torch.int64, device=probe_keys.device)
+    sizes = torch.empty(2 * world, dtype=torch.int64, device=probe_keys.device)
+    dist.all_gather_into_tensor(sizes, mine, group=group)
+    sizes = sizes.view(world, 2).tolist()
+    p = max(int(x[0]) for x in sizes)
+    b = max(int(x[1]) for x in sizes)
+    if choose_join_strategy(world, p, b) == "broadcast":
+        return broadcast_inner_join(probe_keys, build_keys, group=group, **(broadcast_kw or {}))
+    return distributed_inner_join(probe_keys, build_keys, group=group, **(shuffle_kw or {}))
 
 
 def distributed_group_by_sum(keys, values, group_fn=None, partition_fn=_device_partition, group=None):

@@ -1,6 +1,8 @@
 """-m gpu: gdf_hash / gdf_hash_partition / gdf_prefixsum_* through the C ABI vs the oracle."""
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 
@@ -56,7 +58,7 @@ def test_hash_errors(gdf):
         libgdf.gdf_hash(1, column_array([a]), 7, out32.ptr)
 
 
-@pytest.mark.parametrize("nparts", [1, 5, 8, 10, 257])          # tests/hashing/hash-partition-test.cu:279-289
+@pytest.mark.parametrize("nparts", [1, 5, 8, 10, 257, 1000, 1024, 1025])          # tests/hashing/hash-partition-test.cu:279-289; 257..1024: the 12288-row tile kernel
 @pytest.mark.parametrize("n", [100, 100000, 1000000])
 def test_hash_partition_membership_and_offsets(gdf, nparts, n):
     k0 = gen_rand(np.int64, n)
@@ -81,8 +83,9 @@ def test_hash_partition_membership_and_offsets(gdf, nparts, n):
         np.testing.assert_array_equal(e[np.lexsort(e.T[::-1])], g[np.lexsort(g.T[::-1])])
 
 
-def test_hash_partition_moves_valid_masks(gdf):
-    n, nparts = 20000, 16
+@pytest.mark.parametrize("nparts", [16, 700])
+def test_hash_partition_moves_valid_masks(gdf, nparts):
+    n = 200000
     k = gen_rand(np.int32, n)
     v = gen_rand(np.int64, n)
     kv, vv = random_valid(n), random_valid(n)
@@ -134,6 +137,31 @@ def test_prefixsum_many_tiles_unaligned_and_in_place(gdf, dtype):
     col = Column(dev)
     libgdf.gdf_prefixsum_generic(col.ptr, col.ptr, 1)                            # in place
     assert torch.equal(dev.cpu(), torch.from_numpy(exp))
+
+
+def test_prefixsum_single_pass_kernel_in_a_subprocess():
+    """The decoupled look-back kernel (GDF_SCAN_LOOKBACK=1, not the default: profiles/r2_c_scan_ablation.md) and the
+    element-wise kernels (GDF_SCAN_BLOCKED=1) against numpy, each in its own process (the switches are read once)."""
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, torch, libgdf_amd as gdf\n"
+        "from libgdf_amd import Column\n"
+        "rs = np.random.RandomState(3)\n"
+        "for dt in (np.int8, np.int32, np.int64):\n"
+        "    for n in (1, 4095, 4096, 4097, 10_000_019):\n"
+        "        a = rs.randint(-100, 100, size=n).astype(dt)\n"
+        "        for inc in (True, False):\n"
+        "            got = gdf.api.prefixsum(Column(torch.from_numpy(a).cuda()), inc).cpu().numpy()\n"
+        "            exp = np.cumsum(a, dtype=dt)\n"
+        "            exp = exp if inc else (exp - a).astype(dt)\n"
+        "            assert np.array_equal(got, exp), (dt, n, inc)\n"
+        "print('ok')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for switch in ("GDF_SCAN_LOOKBACK", "GDF_SCAN_BLOCKED"):
+        env = dict(os.environ, PYTHONPATH=root, **{switch: "1"})
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "ok" in r.stdout, (switch, r.stdout[-500:], r.stderr[-2000:])
 
 
 def test_prefixsum_large_wraps_like_numpy(gdf):

@@ -92,6 +92,12 @@ def _worker(rank, world, port, q):
     bpairs = multigpu.broadcast_inner_join(torch.from_numpy(probes[rank]), torch.from_numpy(builds[rank]),
                                            join_fn=_np_join, narrow_fn=_np_narrow)
     bpg, bbg = bpairs.global_ids()
+    # the planner's entry point takes one of the two branches on ALL ranks (it decides from the global shard sizes)
+    ppairs = multigpu.planned_inner_join(torch.from_numpy(probes[rank]), torch.from_numpy(builds[rank]),
+                                         shuffle_kw=dict(shuffle_fn=_np_shuffle, join_fn=_np_join, prepare_fn=None),
+                                         broadcast_kw=dict(join_fn=_np_join, narrow_fn=_np_narrow))
+    assert ppairs.numel() == (bpairs.numel() if multigpu.choose_join_strategy(world, 3000 + 17 * (world - 1), 400 + 5 * (world - 1)) == "broadcast"
+                              else pairs.numel())
     k = torch.from_numpy(probes[rank])
     v = torch.from_numpy((probes[rank] * 3 + rank).astype(np.int64))
     gk, gv = multigpu.distributed_group_by_sum(k, v, group_fn=_np_group_sum, partition_fn=_np_partition)
@@ -201,3 +207,16 @@ def test_ranks_with_zero_and_two_probe_rows_run_the_same_number_of_exchanges():
     exp = np.stack([gp[li], gb[ri]], axis=1)
     got = np.concatenate([np.stack([r[1], r[2]], axis=1) for r in results])
     np.testing.assert_array_equal(got[np.lexsort(got.T[::-1])], exp[np.lexsort(exp.T[::-1])])
+
+
+def test_planner_cost_model():
+    """C4 shard sizes: the shuffle at 2 GPUs pushes 2.3 GB through the one link between them -> broadcast; at 4 and 8 GPUs a
+    rank's egress spreads over 3 / 7 links and the gathered build relation outgrows its advantage -> shuffle."""
+    from libgdf_amd import multigpu
+    assert multigpu.choose_join_strategy(2, 10**9, 125 * 10**6) == "broadcast"
+    assert multigpu.choose_join_strategy(4, 10**9, 125 * 10**6) == "shuffle"
+    assert multigpu.choose_join_strategy(8, 10**9, 125 * 10**6) == "shuffle"
+    est = multigpu.estimate_join_seconds(8, 10**9, 125 * 10**6)
+    assert 0.015 < est["shuffle"] < 0.025                       # the local passes bound it (18.9 ms measured), not the links
+    # a tiny build relation is always cheaper to replicate than to shuffle the probe side
+    assert multigpu.choose_join_strategy(8, 10**9, 10**5) == "broadcast"

@@ -115,7 +115,7 @@ __device__ __forceinline__ int lane_id() { return __lane_id(); }
 // (ds_add_u32 ...) to a bare s_barrier: no s_waitcnt lgkmcnt(0).  A wave can then
 // pass the barrier with its last wave-instruction of LDS atomics still in flight and
 // another wave reads the counters 64 increments short (seen as a ~1 % flaky
-// histogram in jk_hist; scratch/dbg3.py reproduces it).  The explicit wait is free
+// histogram in jk_hist).  The explicit wait is free
 // when nothing is outstanding.
 __device__ __forceinline__ void block_sync() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

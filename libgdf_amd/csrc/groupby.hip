@@ -854,6 +854,41 @@ static gdf_error gb_plan_range(const KeyTable &t, GbKeyPlan *plan, std::vector<l
   return GDF_SUCCESS;
 }
 
+
+// The same layout GUESSED from a 65536-row prefix: every column's span is rounded up to the next power of two above the
+// sample's span (the same number of key bits as the exact plan unless the prefix is unrepresentative), its minimum taken from
+// the sample.  The full min / max pass (12 B per row: 2.1 of C5's 24 ms) is skipped; whoever packs keys with this plan
+// must check every value against it (gbp_count does) and fall back to the exact plan on a violation.
+static gdf_error gb_plan_range_sampled(const KeyTable &t, GbKeyPlan *plan, bool *ok) {
+  *ok = false;
+  for (int c = 0; c < t.ncols; ++c)
+    if (t.col[c].kind == K_F32 || t.col[c].kind == K_F64) return GDF_SUCCESS;
+  if (t.nrows < (1 << 16)) return GDF_SUCCESS;
+  KeyTable ts = t;
+  ts.nrows = 1 << 16;
+  std::vector<long long> h(2 * t.ncols);
+  GDF_TRY(key_ranges(ts, h.data()));
+  int total = 0;
+  GbKeyPlan p{};
+  for (int c = 0; c < t.ncols; ++c) {
+    long long lo = h[2 * c], hi = h[2 * c + 1];
+    if (lo > hi) return GDF_SUCCESS;                          // no valid element in the sample: no guess
+    const uint64_t span = (uint64_t)hi - (uint64_t)lo;
+    int bits = 0;
+    while (bits < 64 && (span >> bits) != 0) ++bits;
+    p.bits[c] = bits;
+    p.bias[c] = lo;
+    total += bits;
+    if (total > 63) return GDF_SUCCESS;
+  }
+  for (int c = 0, below = total; c < t.ncols; ++c) { below -= p.bits[c]; p.shift[c] = below; }
+  p.packed = 1;
+  p.ordered = 1;
+  p.total_bits = total;
+  *plan = p;
+  *ok = true;
+  return GDF_SUCCESS;
+}
 // ---------------------------------------------------------------------------
 // direct path (integer keys whose value RANGE is small -- C2: keys in [0, 10000)): no table at all.  The group id
 // is the mixed-radix number sum_c (key_c - min_c) * stride_c (column 0 most significant, so ids ascend in
@@ -1185,6 +1220,268 @@ __global__ __launch_bounds__(GB_DENSE_THREADS) void gb_part_aggregate(const K *_
   }
 }
 
+// ---------------------------------------------------------------------------
+// Fused partitioning for the partitioned path (32-bit sort keys, <= 2^GBP_MAX_PART_BITS partitions): ONE pass that reads the
+// raw key / value columns, builds the (packed key, accumulator image) pair and drops it into the partition named by the high
+// key bits -- instead of gb_sorted_make_pairs (20 B in, 12 B out) followed by two stable radix passes (2 x 24 B per row plus
+// their digit counts).  The pairs of a partition need no order: gb_part_aggregate indexes its LDS accumulators with the LOW
+// key bits.  Per row: gbp_count 12 B (keys), gbp_scatter 20.1 B in + 12 B out, aggregation 12 B = 56 B, against 116 B for C5
+// through the radix sort (24 -> ~12 ms).
+//   gbp_count    per-chunk partition histogram hist[p * nchunks + chunk] (LDS counters; lanes that share the first one or two
+//                partition ids of their wave are counted with a ballot each -- C5's Zipf keys put 45 % of the rows into
+//                partition 0), the number of rows dropped for a null key, and a flag when a key falls outside the plan's
+//                ranges (possible only with sample-guessed ranges);
+//   gbp_scatter  12288-row tiles, ranks from wave-wide match-any ballots (one LDS atomic per distinct partition and wave: the
+//                hot partition would otherwise serialise thousands of same-address atomics per tile), the key and then the
+//                payload staged through LDS in partition order so that a wave stores runs of consecutive addresses.
+// ---------------------------------------------------------------------------
+constexpr int GBP_MAX_PART_BITS = 11;
+constexpr int GBP_MAX_PARTS = 1 << GBP_MAX_PART_BITS;
+constexpr int GBP_THREADS = 1024;
+constexpr int GBP_ITEMS = 8;
+constexpr int GBP_TILE = GBP_THREADS * GBP_ITEMS;
+constexpr int GBP_MAX_CHUNKS = 1024;       // hist columns at most (chunks are whole tiles)
+
+// packed keys of N rows (clamped row numbers in src[]) with the loads of one column issued together; ok[k] = false when the
+// row has a null key element or a value outside the plan's range for its column
+template <int N>
+__device__ __forceinline__ void gbp_pack(const KeyTable &t, const GbKeyPlan &p, const uint32_t (&src)[N], uint64_t (&key)[N], bool (&ok)[N],
+                                         bool (&inside)[N]) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) { key[k] = 0; ok[k] = true; inside[k] = true; }
+  for (int c = 0; c < t.ncols; ++c) {
+    long long v[N];
+    const void *data = t.col[c].data;
+    switch (t.col[c].kind) {
+      case K_I8:
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] = ((const int8_t *)data)[src[k]];
+        break;
+      case K_I16:
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] = ((const int16_t *)data)[src[k]];
+        break;
+      case K_I32:
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] = ((const int32_t *)data)[src[k]];
+        break;
+      case K_F32:
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] = f32_image(((const uint32_t *)data)[src[k]]);
+        break;
+      case K_F64:
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] = f64_image(((const uint64_t *)data)[src[k]]);
+        break;
+      default:
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] = ((const long long *)data)[src[k]];
+    }
+    const int bits = p.bits[c], shift = p.shift[c];
+    const long long bias = p.bias[c];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const uint64_t u = (uint64_t)(v[k] - bias);
+      inside[k] = inside[k] && (bits >= 64 || (u >> bits) == 0);
+      key[k] |= (u & low_mask(bits)) << shift;
+    }
+    if (t.col[c].valid) {
+      uint8_t m[N];
+#pragma unroll
+      for (int k = 0; k < N; ++k) m[k] = t.col[c].valid[src[k] >> 3];
+#pragma unroll
+      for (int k = 0; k < N; ++k) ok[k] = ok[k] && ((m[k] >> (src[k] & 7)) & 1);
+    }
+  }
+}
+
+// flags[0] += rows dropped for a null key, flags[1] = 1 when a key lies outside the plan's ranges
+__global__ __launch_bounds__(GBP_THREADS) void gbp_count(KeyTable t, GbKeyPlan plan, int low, int vbit, uint32_t nparts, int64_t chunk,
+                                                         int nchunks, uint32_t *__restrict__ hist, unsigned int *__restrict__ flags) {
+  __shared__ uint32_t cnt[GBP_MAX_PARTS];
+  constexpr int B = 8;
+  unsigned int dropped = 0, outside = 0;
+  for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    for (uint32_t q = threadIdx.x; q < nparts; q += GBP_THREADS) cnt[q] = 0;
+    block_sync();
+    const int64_t begin = (int64_t)c * chunk;
+    const int64_t end = begin + chunk < t.nrows ? begin + chunk : t.nrows;
+    for (int64_t base = begin; base < end; base += (int64_t)GBP_THREADS * B) {
+      uint32_t src[B];                 // row numbers fit 31 bits (the entry point refuses INT_MAX rows)
+      uint64_t key[B];
+      bool ok[B], inside[B];
+#pragma unroll
+      for (int k = 0; k < B; ++k) {
+        const int64_t i = base + (int64_t)k * GBP_THREADS + threadIdx.x;
+        src[k] = (uint32_t)(i < end ? i : end - 1);
+      }
+      gbp_pack<B>(t, plan, src, key, ok, inside);
+#pragma unroll
+      for (int k = 0; k < B; ++k) {
+        const bool live = base + (int64_t)k * GBP_THREADS + threadIdx.x < end;
+        if (live && !ok[k]) ++dropped;
+        if (live && ok[k] && !inside[k]) outside = 1;
+        bool mine = live && ok[k];
+        const uint32_t part = (uint32_t)((key[k] << vbit) >> low);
+        // the first two distinct partition ids of the wave by ballot, the rest one LDS atomic each
+#pragma unroll
+        for (int round = 0; round < 2; ++round) {
+          const unsigned long long todo = __ballot(mine);
+          if (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const uint32_t lp = __shfl(part, leader);
+            const unsigned long long same = __ballot(mine && part == lp);
+            if (lane_id() == leader) atomicAdd(&cnt[lp], (uint32_t)__popcll(same));
+            if (part == lp) mine = false;
+          }
+        }
+        if (mine) atomicAdd(&cnt[part], 1u);
+      }
+    }
+    block_sync();
+    for (uint32_t q = threadIdx.x; q < nparts; q += GBP_THREADS) hist[(size_t)q * nchunks + c] = cnt[q];
+    block_sync();
+  }
+  dropped = wave_reduce_add(dropped);
+  if (lane_id() == 0 && dropped) atomicAdd(&flags[0], dropped);
+  if (outside) flags[1] = 1u;
+}
+
+template <bool VBIT>
+__global__ __launch_bounds__(GBP_THREADS) void gbp_scatter(KeyTable t, GbKeyPlan plan, GbVal val, int fold_op, int low, int part_bits,
+                                                           uint32_t nparts, int64_t chunk, int nchunks, const uint32_t *__restrict__ offs,
+                                                           uint32_t *__restrict__ keys_out, uint64_t *__restrict__ payload_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gbp_lds[];
+  uint64_t *stage = reinterpret_cast<uint64_t *>(gbp_lds);                   // [TILE]
+  uint32_t *hist = reinterpret_cast<uint32_t *>(stage + GBP_TILE);           // [MAX_PARTS + 4]
+  uint32_t *start = hist + GBP_MAX_PARTS + 4, *gbase = start + GBP_MAX_PARTS, *cursor = gbase + GBP_MAX_PARTS;
+  uint32_t *wave_tot = cursor + GBP_MAX_PARTS;                               // [THREADS / WAVE]
+  uint16_t *bin_of = reinterpret_cast<uint16_t *>(wave_tot + GBP_THREADS / WAVE);   // [TILE]
+  constexpr int PER = GBP_MAX_PARTS / GBP_THREADS;                           // partitions per thread in the scan (2)
+  constexpr int vbit = VBIT ? 1 : 0;
+  for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    for (uint32_t q = threadIdx.x; q < nparts; q += GBP_THREADS) cursor[q] = offs[(size_t)q * nchunks + c];
+    const int64_t begin = (int64_t)c * chunk;
+    const int64_t end = begin + chunk < t.nrows ? begin + chunk : t.nrows;
+    for (int64_t tile = begin; tile < end; tile += GBP_TILE) {
+      for (uint32_t q = threadIdx.x; q < GBP_MAX_PARTS; q += GBP_THREADS) hist[q] = 0;
+      block_sync();
+      uint32_t src[GBP_ITEMS];
+      uint64_t key[GBP_ITEMS];
+      bool ok[GBP_ITEMS], inside[GBP_ITEMS];
+#pragma unroll
+      for (int k = 0; k < GBP_ITEMS; ++k) {
+        const int64_t i = tile + (int64_t)k * GBP_THREADS + threadIdx.x;
+        src[k] = (uint32_t)(i < end ? i : end - 1);
+      }
+      // the value column is requested NOW, with the keys: one round of HBM latency per tile instead of two (as a second load
+      // phase behind the key flush this kernel ran at 2.9 TB/s on its 32 B per row)
+      uint64_t img[GBP_ITEMS];
+      switch (fold_op == OP_COUNT ? -1 : val.kind) {
+        case -1:
+#pragma unroll
+          for (int k = 0; k < GBP_ITEMS; ++k) img[k] = 1;
+          break;
+        case K_I8:
+#pragma unroll
+          for (int k = 0; k < GBP_ITEMS; ++k) img[k] = (uint64_t)(int64_t)((const int8_t *)val.data)[src[k]];
+          break;
+        case K_I16:
+#pragma unroll
+          for (int k = 0; k < GBP_ITEMS; ++k) img[k] = (uint64_t)(int64_t)((const int16_t *)val.data)[src[k]];
+          break;
+        case K_I32:
+#pragma unroll
+          for (int k = 0; k < GBP_ITEMS; ++k) img[k] = (uint64_t)(int64_t)((const int32_t *)val.data)[src[k]];
+          break;
+        case K_F32:
+#pragma unroll
+          for (int k = 0; k < GBP_ITEMS; ++k) img[k] = (uint64_t)__double_as_longlong((double)((const float *)val.data)[src[k]]);
+          break;
+        default:      // K_I64 and K_F64: the raw 64-bit word is the SUM image of both
+#pragma unroll
+          for (int k = 0; k < GBP_ITEMS; ++k) img[k] = ((const uint64_t *)val.data)[src[k]];
+      }
+      if (fold_op == OP_MIN || fold_op == OP_MAX) {
+        const bool flt = is_flt(val.kind);
+#pragma unroll
+        for (int k = 0; k < GBP_ITEMS; ++k)
+          img[k] = flt ? ord_f64(__longlong_as_double((long long)img[k])) : ord_i64((int64_t)img[k]);
+      }
+      gbp_pack<GBP_ITEMS>(t, plan, src, key, ok, inside);
+      // validity of the VALUE: rides as the key's lowest bit when the aggregation counts valid values (VBIT), and a null
+      // value always contributes the identity (COUNT of a masked column has no such bit but still must not count nulls)
+      uint32_t vmask = 0;               // bit k: the value of item k is valid
+      if (val.valid) {
+        uint8_t vb[GBP_ITEMS];
+#pragma unroll
+        for (int k = 0; k < GBP_ITEMS; ++k) vb[k] = val.valid[src[k] >> 3];
+#pragma unroll
+        for (int k = 0; k < GBP_ITEMS; ++k) vmask |= (uint32_t)((vb[k] >> (src[k] & 7)) & 1) << k;
+      } else {
+        vmask = 0xffffffffu;
+      }
+      uint32_t pr[GBP_ITEMS];          // partition << 16 | rank within (tile, partition); 0xffffffff: the row does not travel
+      uint32_t k32[GBP_ITEMS];
+#pragma unroll
+      for (int k = 0; k < GBP_ITEMS; ++k) {
+        const bool live = tile + (int64_t)k * GBP_THREADS + threadIdx.x < end && ok[k];
+        const bool vok = (vmask >> k) & 1u;
+        k32[k] = (uint32_t)((key[k] << vbit) | (uint64_t)(VBIT && vok));
+        const uint32_t part = k32[k] >> low;
+        const uint32_t r = wave_aggregated_inc(hist, part, part_bits, live);
+        pr[k] = live ? (part << 16) | r : 0xffffffffu;
+      }
+      block_sync();
+      {   // exclusive scan of hist[0..MAX_PARTS) by the 1024 threads, PER consecutive partitions each
+        uint32_t v[PER], sum = 0;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) { v[q] = hist[threadIdx.x * PER + q]; sum += v[q]; }
+        const uint32_t incl = wave_scan_incl(sum);
+        if (lane_id() == WAVE - 1) wave_tot[threadIdx.x / WAVE] = incl;
+        block_sync();
+        uint32_t run = incl - sum;
+        for (int w = 0; w < (int)(threadIdx.x / WAVE); ++w) run += wave_tot[w];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+          const uint32_t b = threadIdx.x * PER + q;
+          start[b] = run;
+          gbase[b] = cursor[b] - run;          // (only partitions < nparts are ever looked up)
+          cursor[b] += v[q];
+          run += v[q];
+        }
+      }
+      block_sync();
+      uint32_t total = 0;
+      for (int w = 0; w < GBP_THREADS / WAVE; ++w) total += wave_tot[w];
+      uint32_t pos[GBP_ITEMS];
+#pragma unroll
+      for (int k = 0; k < GBP_ITEMS; ++k) {
+        pos[k] = 0;
+        if (pr[k] != 0xffffffffu) {
+          const uint32_t q = pr[k] >> 16;
+          pos[k] = start[q] + (pr[k] & 0xffffu);
+          bin_of[pos[k]] = (uint16_t)q;
+          stage[pos[k]] = k32[k];
+        }
+      }
+      block_sync();
+      for (uint32_t j = threadIdx.x; j < total; j += GBP_THREADS) keys_out[gbase[bin_of[j]] + j] = (uint32_t)stage[j];
+      block_sync();
+      // (the value column was requested together with the keys, above)
+#pragma unroll
+      for (int k = 0; k < GBP_ITEMS; ++k)
+        if (pr[k] != 0xffffffffu) stage[pos[k]] = ((vmask >> k) & 1u) ? img[k] : acc_identity(fold_op);
+      block_sync();
+      for (uint32_t j = threadIdx.x; j < total; j += GBP_THREADS) payload_out[gbase[bin_of[j]] + j] = stage[j];
+      block_sync();
+    }
+  }
+}
+static constexpr size_t gbp_scatter_lds() {
+  return 8 * (size_t)GBP_TILE + 4 * (size_t)(4 * GBP_MAX_PARTS + 4 + GBP_THREADS / WAVE) + 2 * (size_t)GBP_TILE + 16;
+}
+
 // number of non-empty cells per block of 1024 cells
 __global__ __launch_bounds__(1024) void gb_part_count(const unsigned int *__restrict__ grows, uint32_t *__restrict__ block_count) {
   __shared__ uint32_t wcnt[1024 / WAVE];
@@ -1219,7 +1516,13 @@ __global__ __launch_bounds__(1024) void gb_part_extract(KeyTable t, GbKeyPlan pl
 }
 
 // Everything the four aggregation paths share about one gdf_group_by_* call.
+__global__ void gb_strided_u32(const uint32_t *in, uint32_t *out, int count, size_t stride) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) out[i] = in[(size_t)i * stride];
+}
+
 struct GbJob {
+  bool range_violated = false;     // set by a path that ran on sample-guessed key ranges and met a key outside them
   int ncols;
   gdf_column **out_keys;
   gdf_column *out_agg;
@@ -1462,7 +1765,7 @@ static gdf_error gb_path_dense(GbJob &j, bool *done) {
 // The partitioned variant of the sorted path (see the kernels above), for key type K = uint32_t (12-byte pairs,
 // when key bits + valid bit + null bit fit 32) or uint64_t.
 template <class K>
-static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, int null_bit, bool *done) {
+static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, int null_bit, bool *done, bool guessed = false) {
   [[maybe_unused]] const int ncols = j.ncols;
   [[maybe_unused]] gdf_column **out_keys = j.out_keys;
   [[maybe_unused]] gdf_column *out_agg = j.out_agg;
@@ -1476,22 +1779,71 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
   [[maybe_unused]] const bool masked = j.masked, avg = j.counted, want_ok = j.want_ok;
   [[maybe_unused]] DevBuf &agg_ok = j.agg_ok;
   const uint32_t nn = (uint32_t)n;
-  DevBuf ka, kb, pa, pb, fl;
-  RMM_TRY(ka.alloc(sizeof(K) * (size_t)nn));
-  RMM_TRY(kb.alloc(sizeof(K) * (size_t)nn));
-  RMM_TRY(pa.alloc(sizeof(uint64_t) * (size_t)nn));
-  RMM_TRY(pb.alloc(sizeof(uint64_t) * (size_t)nn));
-  RMM_TRY(fl.alloc(16));
-  HIP_TRY(hipMemsetAsync(fl.p, 0, 16, stream0()));
+  const int id_bits = sp.total_bits < GB_PART_ID_BITS ? sp.total_bits : GB_PART_ID_BITS;
+  const int part_bits = sp.total_bits - id_bits;
   const int fold_op = op == OP_AVG ? OP_SUM : op;
   const bool flt = is_flt(val.kind);
+  // FUSED: one partition pass straight from the raw columns (gbp_count / gbp_scatter) instead of pair build + radix sort
+  bool fused = false;
+  if constexpr (sizeof(K) == 4)
+    fused = part_bits >= 1 && part_bits <= GBP_MAX_PART_BITS && n >= ((int64_t)1 << 20) && !getenv("GDF_GB_NO_FUSED");
+  if (guessed && !fused) { *done = false; return GDF_SUCCESS; }      // only the fused kernels check keys against a guessed plan
+  DevBuf ka, kb, pa, pb, fl;
+  RMM_TRY(ka.alloc(sizeof(K) * (size_t)nn));
+  RMM_TRY(pa.alloc(sizeof(uint64_t) * (size_t)nn));
+  if (!fused) {
+    RMM_TRY(kb.alloc(sizeof(K) * (size_t)nn));
+    RMM_TRY(pb.alloc(sizeof(uint64_t) * (size_t)nn));
+  }
+  RMM_TRY(fl.alloc(16));
+  HIP_TRY(hipMemsetAsync(fl.p, 0, 16, stream0()));
   const uint64_t null_key = null_bit ? (1ULL << (sp.total_bits + vbit)) : 0ULL;
   K *kin = ka.as<K>(), *kout = kb.as<K>();
   uint64_t *pin = pa.as<uint64_t>(), *pout = pb.as<uint64_t>();
-  GDF_LAUNCH("gb_sorted_make_pairs", gb_sorted_make_pairs<K>, dim3(stream_grid((size_t)n, 256 * 8)), dim3(256), 0, stream0(), t, sp, val,
-             fold_op, vbit, null_key, kin, pin, fl.as<unsigned long long>(), (unsigned int *)(fl.as<unsigned long long>() + 1));
-  struct { unsigned long long varying; unsigned int dropped, pad; } hf;
-  HIP_TRY(hipMemcpy(&hf, fl.p, 16, hipMemcpyDeviceToHost));
+  struct { unsigned long long varying; unsigned int dropped, pad; } hf{};
+  std::vector<uint32_t> hp;             // partition starts (fused: from the scanned histogram)
+  if (fused) {
+    if constexpr (sizeof(K) == 4) {
+      const uint32_t P = 1u << part_bits;
+      const int low = vbit + id_bits;
+      int64_t chunk = (n + GBP_MAX_CHUNKS - 1) / GBP_MAX_CHUNKS;
+      chunk = (chunk + GBP_TILE - 1) / GBP_TILE * GBP_TILE;
+      const int nchunks = (int)((n + chunk - 1) / chunk);
+      DevBuf hist, d_start, d_flags;
+      RMM_TRY(hist.alloc(sizeof(uint32_t) * ((size_t)P * nchunks + 1)));
+      RMM_TRY(d_start.alloc(sizeof(uint32_t) * ((size_t)P + 1)));
+      RMM_TRY(d_flags.alloc(sizeof(unsigned int) * 2));
+      HIP_TRY(hipMemsetAsync(d_flags.p, 0, sizeof(unsigned int) * 2, stream0()));
+      HIP_TRY(hipMemsetAsync(hist.as<uint32_t>() + (size_t)P * nchunks, 0, sizeof(uint32_t), stream0()));
+      GDF_LAUNCH("gbp_count", gbp_count, dim3(nchunks < NUM_CU * 2 ? nchunks : NUM_CU * 2), dim3(GBP_THREADS), 0, stream0(), t, sp, low, vbit, P,
+                 chunk, nchunks, hist.as<uint32_t>(), d_flags.as<unsigned int>());
+      GDF_TRY(scan_u32(hist.as<uint32_t>(), hist.as<uint32_t>(), (size_t)P * nchunks + 1, false));
+      const size_t slds = gbp_scatter_lds();
+      if (vbit) {
+        HIP_TRY(hipFuncSetAttribute((const void *)gbp_scatter<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
+        GDF_LAUNCH("gbp_scatter", gbp_scatter<true>, dim3(nchunks < NUM_CU ? nchunks : NUM_CU), dim3(GBP_THREADS), slds, stream0(), t, sp, val, fold_op,
+                   low, part_bits, P, chunk, nchunks, (const uint32_t *)hist.as<uint32_t>(), (uint32_t *)kin, pin);
+      } else {
+        HIP_TRY(hipFuncSetAttribute((const void *)gbp_scatter<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
+        GDF_LAUNCH("gbp_scatter", gbp_scatter<false>, dim3(nchunks < NUM_CU ? nchunks : NUM_CU), dim3(GBP_THREADS), slds, stream0(), t, sp, val, fold_op,
+                   low, part_bits, P, chunk, nchunks, (const uint32_t *)hist.as<uint32_t>(), (uint32_t *)kin, pin);
+      }
+      hipLaunchKernelGGL(gb_strided_u32, dim3((P + 256) / 256), dim3(256), 0, stream0(), (const uint32_t *)hist.as<uint32_t>(), d_start.as<uint32_t>(),
+                         (int)P + 1, (size_t)nchunks);
+      HIP_CHECK_LAST();
+      hp.resize((size_t)P + 1);
+      HIP_TRY(hipMemcpy(hp.data(), d_start.p, sizeof(uint32_t) * ((size_t)P + 1), hipMemcpyDeviceToHost));
+      unsigned int hfl[2] = {0, 0};
+      HIP_TRY(hipMemcpy(hfl, d_flags.p, sizeof(hfl), hipMemcpyDeviceToHost));
+      hf.dropped = hfl[0];
+      j.range_violated = hfl[1] != 0;
+      if (j.range_violated) { *done = false; return GDF_SUCCESS; }      // sample-guessed ranges did not hold: the caller retries exactly
+    }
+  } else {
+    GDF_LAUNCH("gb_sorted_make_pairs", gb_sorted_make_pairs<K>, dim3(stream_grid((size_t)n, 256 * 8)), dim3(256), 0, stream0(), t, sp, val,
+               fold_op, vbit, null_key, kin, pin, fl.as<unsigned long long>(), (unsigned int *)(fl.as<unsigned long long>() + 1));
+    HIP_TRY(hipMemcpy(&hf, fl.p, 16, hipMemcpyDeviceToHost));
+  }
   const uint32_t nvalid = nn - hf.dropped;
   uint32_t ngroups = 0;
   GbOut o{};
@@ -1501,22 +1853,22 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
   o.in_kind = (int)in_kind;
   o.agg_kind = (int)((op == OP_COUNT || op == OP_AVG) ? out_kind : in_kind);
   o.counted = val.valid != nullptr;
-  const int id_bits = sp.total_bits < GB_PART_ID_BITS ? sp.total_bits : GB_PART_ID_BITS;
-  const int part_bits = sp.total_bits - id_bits;
   if (nvalid) {
     const int low = vbit + id_bits;
-    const uint64_t himask = low >= 64 ? 0ULL : ~((1ULL << low) - 1ULL);
-    if constexpr (sizeof(K) == 4) GDF_TRY(radix_sort_pairs_k32_u64(kin, kout, pin, pout, nn, hf.varying & himask));
-    else GDF_TRY(radix_sort_pairs_u64(kin, kout, pin, pout, nn, hf.varying & himask));
     const uint32_t P = 1u << part_bits;
     const size_t cells = (size_t)P << id_bits;
     const size_t cells_pad = (cells + 1023) / 1024 * 1024;
     DevBuf pstart, d_units, gacc, grows, gvalid, bcnt, ng;
-    RMM_TRY(pstart.alloc(sizeof(uint32_t) * ((size_t)P + 1)));
-    GDF_LAUNCH("gb_part_bounds", gb_part_bounds<K>, dim3(stream_grid((size_t)P + 1, 256)), dim3(256), 0, stream0(), (const K *)kin, nvalid, low, P,
-               pstart.as<uint32_t>());
-    std::vector<uint32_t> hp((size_t)P + 1);
-    HIP_TRY(hipMemcpy(hp.data(), pstart.p, sizeof(uint32_t) * ((size_t)P + 1), hipMemcpyDeviceToHost));
+    if (!fused) {
+      const uint64_t himask = low >= 64 ? 0ULL : ~((1ULL << low) - 1ULL);
+      if constexpr (sizeof(K) == 4) GDF_TRY(radix_sort_pairs_k32_u64(kin, kout, pin, pout, nn, hf.varying & himask));
+      else GDF_TRY(radix_sort_pairs_u64(kin, kout, pin, pout, nn, hf.varying & himask));
+      RMM_TRY(pstart.alloc(sizeof(uint32_t) * ((size_t)P + 1)));
+      GDF_LAUNCH("gb_part_bounds", gb_part_bounds<K>, dim3(stream_grid((size_t)P + 1, 256)), dim3(256), 0, stream0(), (const K *)kin, nvalid, low, P,
+                 pstart.as<uint32_t>());
+      hp.resize((size_t)P + 1);
+      HIP_TRY(hipMemcpy(hp.data(), pstart.p, sizeof(uint32_t) * ((size_t)P + 1), hipMemcpyDeviceToHost));
+    }
     std::vector<GbPartUnit> units;
     for (uint32_t p = 0; p < P; ++p)
       for (uint32_t b = hp[p]; b < hp[p + 1]; b += GB_PART_UNIT_ROWS)
@@ -1782,7 +2134,15 @@ static gdf_error group_by_hash(int ncols, gdf_column **cols, gdf_column *col_agg
   j.in_kind = in_kind;
   j.out_kind = out_kind;
   j.plan = gb_plan_keys(t);
-  if (!j.plan.packed) GDF_TRY(gb_plan_range(t, &j.plan, &j.ranges));
+  GbKeyPlan guess_plan{};
+  bool guess_plan_ok = false;
+  if (!j.plan.packed && n >= ((int64_t)1 << 24) && !getenv("GDF_GB_NO_GUESS_RANGES")) {
+    GDF_TRY(gb_plan_range_sampled(t, &guess_plan, &guess_plan_ok));
+    const int vb = (col_agg->valid != nullptr && op != OP_COUNT) ? 1 : 0, nb = t.any_valid ? 1 : 0;
+    guess_plan_ok = guess_plan_ok && guess_plan.total_bits >= 18 && guess_plan.total_bits - GB_PART_ID_BITS <= GBP_MAX_PART_BITS &&
+                    guess_plan.total_bits + vb + nb <= 32;
+  }
+  if (!j.plan.packed && !guess_plan_ok) GDF_TRY(gb_plan_range(t, &j.plan, &j.ranges));
   j.val = GbVal{col_agg->data, (int)(op == OP_COUNT ? K_I8 : in_kind), (const uint8_t *)col_agg->valid};
   // Validity masks (beyond the reference, which rejects them: sqls_ops.cu:1103-1106; semantics of
   // SURVEY.md 8d C5 = pandas dropna): a row with a null in any key column is dropped; a null value is
@@ -1792,8 +2152,22 @@ static gdf_error group_by_hash(int ncols, gdf_column **cols, gdf_column *col_agg
   j.counted = op == OP_AVG || (j.val.valid != nullptr && op != OP_COUNT);
   j.want_ok = j.val.valid != nullptr && op != OP_COUNT && out_agg->valid != nullptr;
 
-  // the four paths, cheapest first; each declines (done == false) what it cannot take
   bool done = false;
+  // Many rows, keys that only pack by range: try the partitioned path on ranges GUESSED from a prefix before paying for the
+  // exact min / max pass.  Taken only when the guessed layout says "more ids than LDS accumulators hold" (fewer: the direct /
+  // dictionary paths are the better ones and want exact ranges); its count kernel checks every key and reports a violation.
+  if (guess_plan_ok) {
+    const int vbit = (j.val.valid != nullptr && op != OP_COUNT) ? 1 : 0;
+    const int null_bit = t.any_valid ? 1 : 0;
+    const GbKeyPlan exact_later = j.plan;
+    j.plan = guess_plan;
+    j.range_violated = false;
+    GDF_TRY(gb_sorted_partitioned<uint32_t>(j, guess_plan, vbit, null_bit, &done, true));
+    if (done) return GDF_SUCCESS;
+    j.plan = exact_later;
+    GDF_TRY(gb_plan_range(t, &j.plan, &j.ranges));              // the guess did not hold (or did not qualify): exact ranges after all
+  }
+  // the four paths, cheapest first; each declines (done == false) what it cannot take
   GDF_TRY(gb_path_direct(j, &done));
   if (done) return GDF_SUCCESS;
   if (j.plan.packed) {

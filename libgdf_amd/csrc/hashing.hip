@@ -603,6 +603,7 @@ __global__ __launch_bounds__(HP_THREADS) void stable_scatter_kernel(const KIN *_
   __shared__ uint32_t wtot[ST_WAVES * SHT_MAX_PARTS];     // rows of wave w for partition p, then: rows of earlier waves
   __shared__ uint32_t start[SHT_MAX_PARTS], gbase[SHT_MAX_PARTS];
   __shared__ uint32_t tile_total;
+  __shared__ unsigned long long bm[SHT_MAX_PARTS * (ST_TILE / WAVE)];      // [partition][word of the tile]
   const uint32_t tile = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   if (tile >= ntiles) return;
   const int wave = threadIdx.x / WAVE, lane = lane_id();
@@ -632,7 +633,10 @@ __global__ __launch_bounds__(HP_THREADS) void stable_scatter_kernel(const KIN *_
       if ((uint32_t)lane == q) { word = m; run += (uint32_t)__popcll(m); }
       if (part[r] == q) same[r] = m;
     }
-    if ((uint32_t)lane < nparts && row0 < n) bitmaps[(size_t)lane * words + (uint64_t)(row0 >> 6)] = word;
+    // the tile's bitmap words meet in LDS and leave as 256-byte runs per partition below: written from here -- 8 bytes per
+    // (wave, round, partition), 1.4e8 separate store requests per 1.125e9 rows at fan-out 8 -- they cost this kernel more
+    // than its key traffic (3.7 TB/s on 12.1 B per row)
+    if ((uint32_t)lane < nparts) bm[lane * (ST_TILE / WAVE) + wave * ST_ROUNDS + r] = word;
   }
   if ((uint32_t)lane < nparts) wtot[wave * SHT_MAX_PARTS + lane] = run;
   block_sync();
@@ -667,6 +671,12 @@ __global__ __launch_bounds__(HP_THREADS) void stable_scatter_kernel(const KIN *_
   block_sync();
   const uint32_t total = tile_total;
   for (uint32_t j = threadIdx.x; j < total; j += HP_THREADS) out_key[gbase[bin_of[j]] + j] = stage[j];
+  constexpr uint32_t WPT = ST_TILE / WAVE;                    // bitmap words per tile and partition
+  const uint64_t word0 = (uint64_t)tile * WPT;
+  for (uint32_t j = threadIdx.x; j < nparts * WPT; j += HP_THREADS) {
+    const uint32_t q = j / WPT, w = j % WPT;
+    if (word0 + w < words) bitmaps[(size_t)q * words + word0 + w] = bm[q * WPT + w];
+  }
 }
 
 // gpu_hash_columns (src/hashops.cu:25-151): 64-bit FNV-1a over the little-endian bytes of every column's element,

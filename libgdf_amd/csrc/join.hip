@@ -430,6 +430,21 @@ __global__ __launch_bounds__(JK_HIST_THREADS) void jk_hist(KeyTable t, KeyPlan p
   }
 }
 
+// Skew probe for the histogram-free layout: JK_SKEW_SAMPLES evenly spaced rows of a FAST key column are binned by fine
+// partition; *max_count = the fullest bin.  A uniform column puts ~2 samples in a bin; a key that holds 0.1 % of the rows
+// puts 60 there.  (Zipf-distributed probe keys made the speculative level-1 pass overflow after ~8 % of the rows -- 1.4 ms
+// thrown away per 1e9 rows before the exact layout took over.)
+constexpr uint32_t JK_SKEW_SAMPLES = 1u << 16;
+template <int FAST>
+__global__ __launch_bounds__(256) void jk_sample_skew(const void *col, int64_t nrows, int fb, uint32_t *hist, uint32_t *max_count) {
+  const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= JK_SKEW_SAMPLES) return;
+  const int64_t i = (int64_t)(((unsigned __int128)s * (unsigned __int128)nrows) >> 16);
+  const uint32_t f = fine_of(fast_word<FAST>(col, i), fb);
+  const uint32_t old = atomicAdd(&hist[f], 1u);
+  atomicMax(max_count, old + 1u);
+}
+
 // ---------------------------------------------------------------------------
 // LDS tile regroup shared by both scatter levels.
 //   phase A: every thread holds up to ITEMS tuples with bin + rank (rank from an
@@ -689,6 +704,8 @@ struct Level2Map {                     // small host-built tables, device reside
   int xs;                              // the arrays describe 2^(b1+xs) SEGMENTS, segment >> xs = coarse partition (PartGeom::xs)
   uint32_t ntiles;                     // set by the launcher
   int xcd_order;                       // set by the launcher: the grid is 8 * ceil(ntiles / 8) blocks, see jk_scatter2
+  const uint32_t *ntiles_dev;          // non-null: the map was built on the device (jk_make_l2map); ntiles is then an upper bound
+                                       // for the grid and the real tile count is read from here
 };
 
 template <bool NARROW, int THREADS>
@@ -704,7 +721,7 @@ __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, 
   // (tile, bin) runs before they reach HBM (PartGeom::xs has the level-1 half of this)
   const uint32_t per_xcd = gridDim.x >> 3;
   const uint32_t tile_id = m.xcd_order ? (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
-  if (tile_id >= m.ntiles) return;
+  if (tile_id >= (m.ntiles_dev ? *m.ntiles_dev : m.ntiles)) return;
   uint32_t lo = 0, hi = ncoarse << m.xs;
   while (hi - lo > 1) {
     const uint32_t mid = (lo + hi) >> 1;
@@ -768,12 +785,97 @@ __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, 
 }
 
 // ---------------------------------------------------------------------------
+// Host-free bookkeeping of the histogram-free (speculative) layout.  Round 1 read the fill counters back after every
+// scatter level, built the level-2 segment map / the work units / the output offsets in host loops and uploaded them:
+// ~0.3 ms of idle GPU per C3 join in six gaps (tools/gpu/gaps.sh).  These single-workgroup kernels do the same on the device,
+// so that the probe side runs scatter1 -> map -> scatter2 -> units -> sample without a host round trip; the host reads ONE
+// small state block before the write pass.
+// ---------------------------------------------------------------------------
+constexpr int JK_BK_THREADS = 1024;
+// exclusive block scan of one value per thread (JK_BK_THREADS threads); returns the exclusive prefix, *total = the sum
+template <class T>
+__device__ __forceinline__ T bk_block_scan(T v, T *lds_wave, T *total) {
+  const T incl = wave_scan_incl(v);
+  block_sync();
+  if (lane_id() == WAVE - 1) lds_wave[threadIdx.x / WAVE] = incl;
+  block_sync();
+  T woff = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < JK_BK_THREADS / WAVE; ++w) {
+    if (w < (int)(threadIdx.x / WAVE)) woff += lds_wave[w];
+    tot += lds_wave[w];
+  }
+  *total = tot;
+  return woff + incl - v;
+}
+// level-2 segment map from the level-1 fill counters: segment c = [c * cap1, c * cap1 + fill[c]), tile_prefix = tiles before it
+__global__ __launch_bounds__(JK_BK_THREADS) void jk_make_l2map(const uint32_t *__restrict__ fill, uint32_t nseg, uint32_t cap1, uint32_t tile,
+                                                               uint32_t *__restrict__ seg_begin, uint32_t *__restrict__ seg_end,
+                                                               uint32_t *__restrict__ tile_prefix, uint32_t *__restrict__ ntiles) {
+  __shared__ uint32_t lds_wave[JK_BK_THREADS / WAVE];
+  const uint32_t per = (nseg + JK_BK_THREADS - 1) / JK_BK_THREADS;
+  const uint32_t c0 = threadIdx.x * per;
+  uint32_t mine = 0;
+  for (uint32_t c = c0; c < c0 + per && c < nseg; ++c) mine += (fill[c] + tile - 1) / tile;
+  uint32_t total;
+  uint32_t run = bk_block_scan<uint32_t>(mine, lds_wave, &total);
+  for (uint32_t c = c0; c < c0 + per && c < nseg; ++c) {
+    seg_begin[c] = c * cap1;
+    seg_end[c] = c * cap1 + fill[c];
+    tile_prefix[c] = run;
+    run += (fill[c] + tile - 1) / tile;
+  }
+  if (threadIdx.x == 0) { tile_prefix[nseg] = total; *ntiles = total; }
+}
+__global__ __launch_bounds__(256) void jk_init_cursor(uint32_t *cur, uint32_t nfine, uint32_t cap2) {
+  for (uint32_t f = blockIdx.x * 256 + threadIdx.x; f <= nfine; f += gridDim.x * 256) cur[f] = f < nfine ? f * cap2 : 0u;   // [nfine]: overflow flag
+}
+
+// ---------------------------------------------------------------------------
 // 4. probe: one workgroup per work unit
 // ---------------------------------------------------------------------------
 struct Unit {
   uint32_t build_begin, build_count;   // tuple range of the fine partition on the build side
   uint32_t probe_begin, probe_count;   // this unit's slice of the partition on the probe side
 };
+
+// work units + output offsets of the optimistic pass from the fine fill counters of a speculative probe side: one thread
+// per fine partition, JK_PROBE_CHUNK probe tuples per unit.  Unit numbers and output offsets are claimed per WAVE (a wave
+// scan inside, one atomicAdd per wave on each of the two running totals), so the units come out in wave order rather than
+// partition order -- nothing depends on it (the pair order of a join is unspecified).  A single workgroup walking the
+// partitions in order took 135-200 us (dependent, uncoalesced reads); this takes a few microseconds.
+// state[0] = units, [1] = sum of their probe counts, [2] = probe tuples in all fine partitions, [3] = an overflow flag was up
+__global__ __launch_bounds__(256) void jk_make_units(uint32_t nfine, uint32_t cap2, const uint32_t *__restrict__ cursor,
+                                                     const uint32_t *__restrict__ level1_flag,
+                                                     const uint32_t *__restrict__ build_begin, const uint32_t *__restrict__ build_cnt,
+                                                     int keep_probe, Unit *__restrict__ units, uint64_t *__restrict__ off,
+                                                     unsigned long long *__restrict__ state) {
+  const uint32_t f = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t fc = f < nfine ? f : nfine - 1;
+  const uint32_t cur = cursor[fc], bn = build_cnt[fc], bb = build_begin[fc];
+  const uint32_t all = f < nfine ? cur - f * cap2 : 0u;
+  const uint32_t pn = (all != 0 && (bn != 0 || keep_probe)) ? all : 0u;
+  const uint32_t nun = (pn + JK_PROBE_CHUNK - 1) / JK_PROBE_CHUNK;
+  const uint32_t incl_u = wave_scan_incl(nun);
+  const unsigned long long incl_t = wave_scan_incl((unsigned long long)pn);
+  const unsigned long long sum_all = wave_reduce_add((unsigned long long)all);
+  unsigned long long base_u = 0, base_t = 0;
+  if (lane_id() == WAVE - 1) {
+    if (incl_u) { base_u = atomicAdd(&state[0], (unsigned long long)incl_u); base_t = atomicAdd(&state[1], incl_t); }
+    if (sum_all) atomicAdd(&state[2], sum_all);
+  }
+  base_u = __shfl(base_u, WAVE - 1, WAVE);
+  base_t = __shfl(base_t, WAVE - 1, WAVE);
+  unsigned long long u = base_u + incl_u - nun, o = base_t + incl_t - pn;
+  for (uint32_t at = 0; at < pn; at += JK_PROBE_CHUNK) {
+    const uint32_t cnt = pn - at < JK_PROBE_CHUNK ? pn - at : JK_PROBE_CHUNK;
+    units[u] = Unit{bb, bn, f * cap2 + at, cnt};
+    off[u] = o;
+    ++u;
+    o += cnt;
+  }
+  if (f == 0) state[3] = (unsigned long long)(cursor[nfine] | (level1_flag ? *level1_flag : 0u));
+}
 
 struct ProbeArgs {
   Tuples build, probe;          // fine-partitioned tuples
@@ -793,6 +895,10 @@ struct ProbeArgs {
                                  // [3] = COUNT pass: units whose cuckoo build did not settle (linear probing)
   uint32_t *unit_todo;           // jk_probe_fast appends the ids of such units here (opt_state[2] = how many);
                                  // jk_probe: when non-null, workgroup b handles unit unit_todo[b]
+  // COUNT pass as a SAMPLE over device-built units (jk_make_units): workgroup b of sample_n takes unit b * *nunits_dev / sample_n
+  // and adds its pairs to opt_state[0] and its probe tuples to opt_state[1] instead of writing counts[]
+  uint32_t sample_n;
+  const unsigned long long *nunits_dev;
 };
 
 // LDS image of one work unit's build partition (dynamic region, every carve 16-byte aligned):
@@ -846,7 +952,12 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const uint32_t H = a.nslots, cap = a.cap;
   const ProbeLds l = carve_probe_lds<NARROW>(lds_raw, cap, H);
-  const uint32_t uid = a.unit_todo ? a.unit_todo[blockIdx.x] : blockIdx.x;     // second launch after jk_probe_fast: leftovers only
+  uint32_t uid = a.unit_todo ? a.unit_todo[blockIdx.x] : blockIdx.x;     // second launch after jk_probe_fast: leftovers only
+  if (a.sample_n) {
+    const unsigned long long nunits = *a.nunits_dev;
+    if (nunits == 0) return;
+    uid = (uint32_t)(((unsigned long long)blockIdx.x * nunits) / a.sample_n);
+  }
   const Unit u = a.units[uid];
 
   // ---- stage the build partition, clear the table ----
@@ -1048,7 +1159,8 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
     if (threadIdx.x == 0) {
       unsigned long long t = 0;
       for (int w = 0; w < JK_PROBE_THREADS / WAVE; ++w) t += l.wave_cnt[w];
-      a.counts[uid] = t;
+      if (a.sample_n) { atomicAdd(&a.opt_state[0], t); atomicAdd(&a.opt_state[1], (unsigned long long)u.probe_count); }
+      else a.counts[uid] = t;
     }
   }
 }
@@ -1401,6 +1513,7 @@ __global__ void jk_fill_pairs(int32_t *a, int32_t av, int32_t *b, int32_t bv, in
 enum JoinKind { JOIN_INNER, JOIN_LEFT, JOIN_FULL };
 // internal only, never returned through the ABI: probe_prepared asks for a build side without the third level
 constexpr gdf_error GDF_AMD_RETRY_WITHOUT_LEVEL3 = (gdf_error)31;     // above every code of gdf_error
+constexpr gdf_error GDF_AMD_RETRY_EXACT_PROBE = (gdf_error)30;        // probe_partitioned: the deferred probe side overflowed
 
 struct SideBufs {            // partitioned tuples of one relation
   DevBuf w[2], idx[2];
@@ -1409,6 +1522,17 @@ struct SideBufs {            // partitioned tuples of one relation
   std::vector<uint32_t> fine_begin, fine_cnt;   // [nfine] first tuple / tuple count of every fine partition, both layouts
   bool speculative = false;
   uint32_t joinable = 0;     // tuples that entered the partitioned path
+  // DEFERRED speculative layout (probe side of the main path): nothing was read back -- the fill counters, their overflow
+  // flags and the capacity stay on the device and probe_partitioned builds its units there (jk_make_units); the host
+  // vectors above are empty
+  bool deferred = false;
+  uint32_t cap2 = 0;
+  DevBuf d_level1;           // [nseg + 1] level-1 fill counters + overflow flag
+  uint32_t nseg = 0;
+  DevBuf d_cursor;           // [nfine + 1] level-2 fill cursors (f * cap2 + fill) + overflow flag
+  DevBuf d_map;              // the level-2 segment map jk_scatter2 may still be reading
+  // device copies of fine_begin / fine_cnt (build side: uploaded once by prepare_build for jk_make_units)
+  DevBuf d_begin, d_cnt;
   Tuples tuples(int b) const { return Tuples{w[b].as<uint64_t>(), idx[b].as<int32_t>()}; }
   Tuples final() const { return tuples(final_buf); }
 };
@@ -1629,7 +1753,7 @@ struct SpecAppend {
 };
 
 static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, PartGeom g, double dup, SideBufs *sb, bool *ok,
-                                     SpecAppend *app = nullptr) {
+                                     SpecAppend *app = nullptr, bool defer = false) {
   *ok = false;
   if (app) g.row_base = (int32_t)app->rows;
   const int64_t n = t.nrows;
@@ -1675,6 +1799,42 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
   RMM_TRY(sb->w[0].alloc(sizeof(uint64_t) * size1));
   if (!narrow) RMM_TRY(sb->idx[0].alloc(sizeof(int32_t) * size1));
   GDF_TRY(launch_scatter1(fast, narrow, sc_threads, t, plan, g, nullptr, sb->tuples(0)));
+  if (defer && !app && g.b2 > 0) {
+    // DEFERRED: the level-2 map and the fill cursors are made on the device, nothing is read back here; the overflow flags
+    // of both levels are looked at once, with the work units (jk_make_units / probe_partitioned)
+    DevBuf d_map, cursor;
+    RMM_TRY(d_map.alloc(sizeof(uint32_t) * (3 * (size_t)nseg + 2)));          // segment begins | segment ends | tile prefix [nseg + 1]
+    RMM_TRY(cursor.alloc(sizeof(uint32_t) * ((size_t)nfine + 2)));             // fill cursors | level-2 overflow flag | tile count
+    uint32_t *seg_begin = d_map.as<uint32_t>(), *seg_end = seg_begin + nseg, *tile_prefix = seg_end + nseg;
+    uint32_t *ntiles_dev = cursor.as<uint32_t>() + nfine + 1;
+    hipLaunchKernelGGL(jk_make_l2map, dim3(1), dim3(JK_BK_THREADS), 0, stream0(), (const uint32_t *)spec.as<uint32_t>(), nseg, cap1,
+                       (uint32_t)JK_TILE2, seg_begin, seg_end, tile_prefix, ntiles_dev);
+    hipLaunchKernelGGL(jk_init_cursor, dim3(32), dim3(256), 0, stream0(), cursor.as<uint32_t>(), nfine, cap2);
+    HIP_CHECK_LAST();
+    RMM_TRY(sb->w[1].alloc(sizeof(uint64_t) * size2));
+    if (!narrow) RMM_TRY(sb->idx[1].alloc(sizeof(int32_t) * size2));
+    PartGeom g2 = g;
+    g2.cap2 = cap2;
+    g2.dump = nfine * cap2;
+    g2.spec_flag = cursor.as<uint32_t>() + nfine;
+    Level2Map m{seg_begin, seg_end, tile_prefix, g.xs};
+    m.ntiles_dev = ntiles_dev;
+    // every segment ends in at most one partial tile: an upper bound of the tile count sizes the grid
+    const uint32_t tile_bound = (uint32_t)((uint64_t)n / (uint64_t)JK_TILE2) + nseg + 1;
+    GDF_TRY(launch_scatter2(narrow, sc2_threads, tile_bound, g2, m, sb->tuples(0), cursor.as<uint32_t>(), sb->tuples(1)));
+    // no synchronisation: the map and the level-1 tuples stay allocated until probe_partitioned has read its state block
+    sb->d_map.p = d_map.release();
+    sb->final_buf = 1;
+    sb->fine_off.clear(); sb->fine_begin.clear(); sb->fine_cnt.clear();
+    sb->deferred = true;
+    sb->speculative = true;
+    sb->cap2 = cap2;
+    sb->nseg = nseg;
+    sb->d_level1.p = spec.release();
+    sb->d_cursor.p = cursor.release();
+    *ok = true;
+    return GDF_SUCCESS;
+  }
   std::vector<uint32_t> c1(nseg + 1);
   HIP_TRY(read_back(c1.data(), spec.p, sizeof(uint32_t) * (nseg + 1)));
   if (c1[nseg]) return GDF_SUCCESS;
@@ -1981,6 +2141,14 @@ static gdf_error prepare_build(const KeyTable &build_t, BuildSide *bs, bool no_l
   } else {
     bs->g.b3 = 0;
   }
+  // the partition index once more on the device: jk_make_units builds the work units of a deferred probe side from it
+  const size_t nparts = bs->B.fine_cnt.size();
+  if (nparts) {
+    RMM_TRY(bs->B.d_begin.alloc(sizeof(uint32_t) * nparts));
+    RMM_TRY(bs->B.d_cnt.alloc(sizeof(uint32_t) * nparts));
+    HIP_TRY(hipMemcpyAsync(bs->B.d_begin.p, bs->B.fine_begin.data(), sizeof(uint32_t) * nparts, hipMemcpyHostToDevice, stream0()));
+    HIP_TRY(hipMemcpyAsync(bs->B.d_cnt.p, bs->B.fine_cnt.data(), sizeof(uint32_t) * nparts, hipMemcpyHostToDevice, stream0()));
+  }
   return GDF_SUCCESS;
 }
 
@@ -2000,8 +2168,33 @@ static gdf_error probe_prepared(const KeyTable &probe_t, const KeyTable &build_t
   for (uint32_t c : B.fine_cnt) largest_build = std::max(largest_build, c);
   const int64_t spec_min = getenv("GDF_JK_SPEC_MIN") ? atoll(getenv("GDF_JK_SPEC_MIN")) : (int64_t)1 << 22;   // test switch
   bool spec_ok = false;
-  if (g.fb > 0 && probe_t.nrows >= spec_min && largest_build <= (uint32_t)JK_MAX_BUILD && !getenv("GDF_JK_NO_SPEC"))
-    GDF_TRY(partition_side_spec(probe_t, plan, g, std::max(1.0, (double)probe_t.nrows / std::max<uint32_t>(B.joinable, 1)), &P, &spec_ok));
+  // skewed probe keys would overflow the speculative layout: ask a sample first (one small kernel and a 4-byte read-back)
+  bool skew = false;
+  const int probe_fast = fast_key_width(probe_t, plan);
+  if (g.fb >= 10 && probe_t.nrows >= ((int64_t)1 << 24) && probe_fast && plan.mode == KM_RAW_INT && !getenv("GDF_JK_NO_SKEW_SAMPLE")) {
+    DevBuf sh;
+    const size_t words = ((size_t)1 << g.fb) + 1;
+    RMM_TRY(sh.alloc(sizeof(uint32_t) * words));
+    HIP_TRY(hipMemsetAsync(sh.p, 0, sizeof(uint32_t) * words, stream0()));
+    if (probe_fast == 8)
+      hipLaunchKernelGGL(jk_sample_skew<8>, dim3(JK_SKEW_SAMPLES / 256), dim3(256), 0, stream0(), probe_t.col[0].data, probe_t.nrows, g.fb,
+                         sh.as<uint32_t>(), sh.as<uint32_t>() + (words - 1));
+    else
+      hipLaunchKernelGGL(jk_sample_skew<4>, dim3(JK_SKEW_SAMPLES / 256), dim3(256), 0, stream0(), probe_t.col[0].data, probe_t.nrows, g.fb,
+                         sh.as<uint32_t>(), sh.as<uint32_t>() + (words - 1));
+    HIP_CHECK_LAST();
+    uint32_t fullest = 0;
+    HIP_TRY(read_back(&fullest, sh.as<uint32_t>() + (words - 1), sizeof(uint32_t)));
+    // expected samples per bin: 2^16 / 2^fb (2 at fb = 15); a Poisson(2) bin reaches 16 with probability ~1e-10
+    const double expect = (double)JK_SKEW_SAMPLES / (double)((uint64_t)1 << g.fb);
+    skew = (double)fullest > 8.0 * expect + 12.0;
+  }
+  // the main path -- two-level speculative probe side, every build partition in LDS, no FULL-join marks -- keeps its
+  // bookkeeping on the device (see jk_make_units)
+  const bool defer = g.b2 > 0 && g.b3 == 0 && kind != JOIN_FULL && B.d_cnt.p != nullptr && !getenv("GDF_JK_NO_DEFER");
+  if (!skew && g.fb > 0 && probe_t.nrows >= spec_min && largest_build <= (uint32_t)JK_MAX_BUILD && !getenv("GDF_JK_NO_SPEC"))
+    GDF_TRY(partition_side_spec(probe_t, plan, g, std::max(1.0, (double)probe_t.nrows / std::max<uint32_t>(B.joinable, 1)), &P, &spec_ok,
+                                nullptr, defer));
   if (!spec_ok) {
     P.w[0].reset(); P.w[1].reset(); P.idx[0].reset(); P.idx[1].reset();
     KeyPlan probe_plan = plan;             // partition_side only rewrites the plan when asked to decide the format
@@ -2014,7 +2207,13 @@ static gdf_error probe_prepared(const KeyTable &probe_t, const KeyTable &build_t
     if (!ok) return GDF_AMD_RETRY_WITHOUT_LEVEL3;     // skewed probe keys: the caller repeats with a 2^fb-partition build side
   }
   clk.mark("partition probe side");
-  return probe_partitioned(probe_t, build_t, bs, P, kind, out_probe, out_build, out_n, clk);
+  gdf_error e = probe_partitioned(probe_t, build_t, bs, P, kind, out_probe, out_build, out_n, clk);
+  if (e != GDF_AMD_RETRY_EXACT_PROBE) return e;
+  // a deferred speculative probe side turned out to have overflowed (skewed keys): the exact layout, host bookkeeping
+  SideBufs Q;
+  KeyPlan probe_plan = plan;
+  GDF_TRY(partition_side(probe_t, probe_plan, g, &Q, false));
+  return probe_partitioned(probe_t, build_t, bs, Q, kind, out_probe, out_build, out_n, clk);
 }
 
 // the part of a join after both relations are partitioned: work units, optimistic single pass or count + write, tails
@@ -2028,39 +2227,56 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
   const bool narrow = plan.narrow != 0;
 
   // ---- work units ----
+  // DEFERRED probe side: units, output offsets and the sample are made on the device from the fill counters and ONE state
+  // block comes back; otherwise the host walks the partition index it already holds.
+  const bool deferred = P.deferred;
   std::vector<Unit> units;
-  units.reserve((size_t)nfine + (size_t)(probe_t.nrows / JK_PROBE_CHUNK) + 1);     // the GPU idles while this list is made
   struct Run { uint32_t f0, f1; };    // [f0, f1): consecutive fine partitions that need the global-table path
   std::vector<Run> oversize;
   uint32_t max_build = 0;
-  for (uint32_t f = 0; f < nfine; ++f) {
-    const uint32_t bn = B.fine_cnt[f];
-    const uint32_t pn = P.fine_cnt[f];
-    if (pn == 0) continue;
-    if (bn == 0 && !keep_probe) continue;
-    if (bn > (uint32_t)JK_MAX_BUILD) {
-      if (!oversize.empty() && oversize.back().f1 == f) oversize.back().f1 = f + 1;   // one table per RUN, not per partition
-      else oversize.push_back(Run{f, f + 1});
-      continue;
+  size_t nunits = 0;
+  DevBuf d_units, d_counts, d_matched, d_tail, d_off, d_bk;
+  unsigned long long bk[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // [0..3] jk_make_units state, [4..7] sample state (pairs, tuples, -, linear units)
+  constexpr size_t NSAMPLE = 64;
+  if (deferred) {
+    for (uint32_t f = 0; f < nfine; ++f) max_build = std::max(max_build, B.fine_cnt[f]);      // <= JK_MAX_BUILD: the caller checked
+    const size_t unit_bound = (size_t)nfine + (size_t)(probe_t.nrows / JK_PROBE_CHUNK) + 2;
+    RMM_TRY(d_units.alloc(sizeof(Unit) * unit_bound));
+    RMM_TRY(d_off.alloc(sizeof(uint64_t) * (unit_bound + 1)));
+    RMM_TRY(d_bk.alloc(sizeof(bk)));
+    HIP_TRY(hipMemsetAsync(d_bk.p, 0, sizeof(bk), stream0()));
+    hipLaunchKernelGGL(jk_make_units, dim3((nfine + 255) / 256), dim3(256), 0, stream0(), nfine, P.cap2, (const uint32_t *)P.d_cursor.as<uint32_t>(),
+                       (const uint32_t *)(P.d_level1.as<uint32_t>() + P.nseg), (const uint32_t *)B.d_begin.as<uint32_t>(),
+                       (const uint32_t *)B.d_cnt.as<uint32_t>(), keep_probe ? 1 : 0, d_units.as<Unit>(), d_off.as<uint64_t>(),
+                       d_bk.as<unsigned long long>());
+    HIP_CHECK_LAST();
+  } else {
+    units.reserve((size_t)nfine + (size_t)(probe_t.nrows / JK_PROBE_CHUNK) + 1);     // the GPU idles while this list is made
+    for (uint32_t f = 0; f < nfine; ++f) {
+      const uint32_t bn = B.fine_cnt[f];
+      const uint32_t pn = P.fine_cnt[f];
+      if (pn == 0) continue;
+      if (bn == 0 && !keep_probe) continue;
+      if (bn > (uint32_t)JK_MAX_BUILD) {
+        if (!oversize.empty() && oversize.back().f1 == f) oversize.back().f1 = f + 1;   // one table per RUN, not per partition
+        else oversize.push_back(Run{f, f + 1});
+        continue;
+      }
+      max_build = std::max(max_build, bn);
+      for (uint32_t off = 0; off < pn; off += JK_PROBE_CHUNK)
+        units.push_back(Unit{B.fine_begin[f], bn, P.fine_begin[f] + off, std::min(JK_PROBE_CHUNK, pn - off)});
     }
-    max_build = std::max(max_build, bn);
-    for (uint32_t off = 0; off < pn; off += JK_PROBE_CHUNK)
-      units.push_back(Unit{B.fine_begin[f], bn, P.fine_begin[f] + off, std::min(JK_PROBE_CHUNK, pn - off)});
+    nunits = units.size();
+    RMM_TRY(d_units.alloc(sizeof(Unit) * (nunits ? nunits : 1)));
+    if (nunits) HIP_TRY(hipMemcpyAsync(d_units.p, units.data(), sizeof(Unit) * nunits, hipMemcpyHostToDevice, stream0()));
   }
-  const size_t nunits = units.size();
-  const size_t nslots_all = nunits + oversize.size();     // one count slot per LDS unit + one per oversize partition
   // LDS geometry shared by all units: room for the largest in-LDS build partition, H = slots per cuckoo table
   const uint32_t cap_lds = (std::max<uint32_t>(max_build, 64) + 63) & ~63u;
   uint32_t H_lds = 64;
   while (H_lds < max_build) H_lds <<= 1;
 
-  DevBuf d_units, d_counts, d_matched, d_tail;
-  RMM_TRY(d_units.alloc(sizeof(Unit) * (nunits ? nunits : 1)));
-  RMM_TRY(d_counts.alloc(sizeof(uint64_t) * (nslots_all + 1)));
   RMM_TRY(d_tail.alloc(sizeof(unsigned long long) * 4));
-  HIP_TRY(hipMemsetAsync(d_counts.p, 0, sizeof(uint64_t) * (nslots_all + 1), stream0()));
   HIP_TRY(hipMemsetAsync(d_tail.p, 0, sizeof(unsigned long long) * 4, stream0()));
-  if (nunits) HIP_TRY(hipMemcpyAsync(d_units.p, units.data(), sizeof(Unit) * nunits, hipMemcpyHostToDevice, stream0()));
   if (kind == JOIN_FULL) {
     RMM_TRY(d_matched.alloc((size_t)(build_t.nrows ? build_t.nrows : 1)));
     HIP_TRY(hipMemsetAsync(d_matched.p, 0, (size_t)(build_t.nrows ? build_t.nrows : 1), stream0()));
@@ -2075,7 +2291,6 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
   a.keep_unmatched_probe = keep_probe ? 1 : 0;
   a.verify = plan.verify;
   a.build_matched = d_matched.as<uint8_t>();
-  a.counts = d_counts.as<uint64_t>();
   a.dbg = getenv("GDF_JK_DBG") ? atoi(getenv("GDF_JK_DBG")) : 0;
   a.kbias = plan.kmin;
   const size_t probe_lds = probe_lds_bytes(narrow, cap_lds, H_lds);
@@ -2091,12 +2306,34 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
   // probe tuple.  Then unit u's output is its probe_count slots at the prefix sum of the probe counts
   // and no count pass is needed.  Tried when a count over a sample of units shows one pair per tuple;
   // any surprise during the pass (a unit short of its slots, or needing more) falls back to count + write.
-  if (nunits && oversize.empty() && kind != JOIN_FULL && !(a.dbg & 16)) {
-    const size_t nsample = std::min<size_t>(nunits, 64);
+  bool try_optimistic = false;
+  uint64_t cap_pairs = 0;
+  if (deferred) {
+    // the sample runs over the device-built units (workgroup b takes unit b * units / 64) and leaves its sums next to
+    // jk_make_units' state: one read-back for everything
+    ProbeArgs sa = a;
+    sa.build_matched = nullptr;
+    sa.sample_n = (uint32_t)NSAMPLE;
+    sa.nunits_dev = d_bk.as<unsigned long long>();
+    sa.opt_state = d_bk.as<unsigned long long>() + 4;
+    if (!(a.dbg & 16)) GDF_TRY(run_probe(narrow, false, "jk_probe_sample", NSAMPLE, probe_lds, sa, probe_t, build_t));
+    HIP_TRY(read_back(bk, d_bk.p, sizeof(bk)));
+    P.w[0].reset();                        // level-1 tuples and the segment map: everything that read them has run
+    P.idx[0].reset();
+    P.d_map.reset();
+    if (bk[3]) return GDF_AMD_RETRY_EXACT_PROBE;
+    nunits = (size_t)bk[0];
+    cap_pairs = bk[1];
+    P.joinable = (uint32_t)bk[2];
+    dup_heavy = bk[7] * 4 >= NSAMPLE;
+    try_optimistic = nunits && !(a.dbg & 16) && bk[4] == bk[5];
+    clk.mark("sample count");
+  } else if (nunits && oversize.empty() && kind != JOIN_FULL && !(a.dbg & 16)) {
+    const size_t nsample = std::min<size_t>(nunits, NSAMPLE);
     std::vector<Unit> sample(nsample);
     uint64_t sample_tuples = 0;
     for (size_t i = 0; i < nsample; ++i) { sample[i] = units[i * nunits / nsample]; sample_tuples += sample[i].probe_count; }
-    DevBuf d_sample, d_scount, d_off, d_state, d_sstate;
+    DevBuf d_sample, d_scount, d_sstate;
     RMM_TRY(d_sample.alloc(sizeof(Unit) * nsample));
     RMM_TRY(d_scount.alloc(sizeof(uint64_t) * nsample));
     HIP_TRY(hipMemcpyAsync(d_sample.p, sample.data(), sizeof(Unit) * nsample, hipMemcpyHostToDevice, stream0()));
@@ -2105,7 +2342,6 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
     off[0] = 0;
     for (size_t i = 0; i < nunits; ++i) off[i + 1] = off[i] + units[i].probe_count;
     RMM_TRY(d_off.alloc(sizeof(uint64_t) * (nunits + 1)));
-    RMM_TRY(d_state.alloc(sizeof(unsigned long long) * 4));
     ProbeArgs sa = a;
     sa.units = d_sample.as<Unit>();
     sa.counts = d_scount.as<uint64_t>();
@@ -2115,7 +2351,6 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
     sa.opt_state = d_sstate.as<unsigned long long>();
     GDF_TRY(run_probe(narrow, false, "jk_probe_sample", nsample, probe_lds, sa, probe_t, build_t));
     HIP_TRY(hipMemcpyAsync(d_off.p, off.data(), sizeof(uint64_t) * (nunits + 1), hipMemcpyHostToDevice, stream0()));
-    HIP_TRY(hipMemsetAsync(d_state.p, 0, sizeof(unsigned long long) * 4, stream0()));
     std::vector<uint64_t> scount(nsample);
     HIP_TRY(read_back(scount.data(), d_scount.p, sizeof(uint64_t) * nsample));
     unsigned long long sstate[4] = {0, 0, 0, 0};
@@ -2124,43 +2359,51 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
     clk.mark("sample count");
     uint64_t sample_pairs = 0;
     for (uint64_t c : scount) sample_pairs += c;
-    if (sample_pairs == sample_tuples) {
-      const uint64_t cap_pairs = off[nunits];
-      const uint64_t probe_tail = keep_probe ? (uint64_t)probe_t.nrows - P.joinable : 0;
-      const uint64_t total = cap_pairs + probe_tail;
-      if (total >= (uint64_t)INT_MAX) return GDF_COLUMN_SIZE_TOO_BIG;
-      DevBuf op, ob;
-      RMM_TRY(op.alloc(sizeof(int32_t) * (total ? total : 1)));
-      RMM_TRY(ob.alloc(sizeof(int32_t) * (total ? total : 1)));
-
-      ProbeArgs oa = a;
-      oa.counts = d_off.as<uint64_t>();
-      oa.out_probe = op.as<int32_t>();
-      oa.out_build = ob.as<int32_t>();
-      oa.build_matched = nullptr;
-      oa.optimistic = 1;
-      oa.opt_state = d_state.as<unsigned long long>();
-      clk.mark("output allocation");
-      GDF_TRY(run_write_pass(narrow, plain && !dup_heavy, nunits, probe_lds, oa, max_build, probe_t, build_t));
-      unsigned long long st[2] = {0, 0};
-      HIP_TRY(read_back(st, d_state.p, sizeof(st)));
-      clk.mark("write pass");
-      if (st[1] == 0 && st[0] == cap_pairs) {       // dense: every slot of every unit was written
-        if (probe_tail) {
-          GDF_LAUNCH("jk_emit_unjoinable", jk_emit_unjoinable, dim3(small_grid(probe_t.nrows)), dim3(256), 0, stream0(), probe_t, plan,
-                             oa.out_probe + cap_pairs, oa.out_build + cap_pairs, d_tail.as<unsigned long long>());
-          HIP_CHECK_LAST();
-        }
-        HIP_TRY(hipStreamSynchronize(stream0()));
-        *out_n = (int64_t)total;
-        if (total == 0) { *out_probe = nullptr; *out_build = nullptr; return GDF_SUCCESS; }
-        *out_probe = (int32_t *)op.release();
-        *out_build = (int32_t *)ob.release();
-        return GDF_SUCCESS;
-      }
-      // otherwise: fall through to the exact two-pass path (buffers above are released here)
-    }
+    try_optimistic = sample_pairs == sample_tuples;
+    cap_pairs = off[nunits];
   }
+  if (try_optimistic) {
+    DevBuf d_state;
+    RMM_TRY(d_state.alloc(sizeof(unsigned long long) * 4));
+    HIP_TRY(hipMemsetAsync(d_state.p, 0, sizeof(unsigned long long) * 4, stream0()));
+    const uint64_t probe_tail = keep_probe ? (uint64_t)probe_t.nrows - P.joinable : 0;
+    const uint64_t total = cap_pairs + probe_tail;
+    if (total >= (uint64_t)INT_MAX) return GDF_COLUMN_SIZE_TOO_BIG;
+    DevBuf op, ob;
+    RMM_TRY(op.alloc(sizeof(int32_t) * (total ? total : 1)));
+    RMM_TRY(ob.alloc(sizeof(int32_t) * (total ? total : 1)));
+
+    ProbeArgs oa = a;
+    oa.counts = d_off.as<uint64_t>();
+    oa.out_probe = op.as<int32_t>();
+    oa.out_build = ob.as<int32_t>();
+    oa.build_matched = nullptr;
+    oa.optimistic = 1;
+    oa.opt_state = d_state.as<unsigned long long>();
+    clk.mark("output allocation");
+    GDF_TRY(run_write_pass(narrow, plain && !dup_heavy, nunits, probe_lds, oa, max_build, probe_t, build_t));
+    unsigned long long st[2] = {0, 0};
+    HIP_TRY(read_back(st, d_state.p, sizeof(st)));
+    clk.mark("write pass");
+    if (st[1] == 0 && st[0] == cap_pairs) {       // dense: every slot of every unit was written
+      if (probe_tail) {
+        GDF_LAUNCH("jk_emit_unjoinable", jk_emit_unjoinable, dim3(small_grid(probe_t.nrows)), dim3(256), 0, stream0(), probe_t, plan,
+                           oa.out_probe + cap_pairs, oa.out_build + cap_pairs, d_tail.as<unsigned long long>());
+        HIP_CHECK_LAST();
+      }
+      HIP_TRY(hipStreamSynchronize(stream0()));
+      *out_n = (int64_t)total;
+      if (total == 0) { *out_probe = nullptr; *out_build = nullptr; return GDF_SUCCESS; }
+      *out_probe = (int32_t *)op.release();
+      *out_build = (int32_t *)ob.release();
+      return GDF_SUCCESS;
+    }
+    // otherwise: fall through to the exact two-pass path (buffers above are released here)
+  }
+  const size_t nslots_all = nunits + oversize.size();     // one count slot per LDS unit + one per oversize partition
+  RMM_TRY(d_counts.alloc(sizeof(uint64_t) * (nslots_all + 1)));
+  HIP_TRY(hipMemsetAsync(d_counts.p, 0, sizeof(uint64_t) * (nslots_all + 1), stream0()));
+  a.counts = d_counts.as<uint64_t>();
 
   // ---- count pass ----
   GDF_TRY(run_probe(narrow, false, "jk_probe_count", nunits, probe_lds, a, probe_t, build_t));

@@ -195,7 +195,7 @@ class ShardedPairs:
 
 # Largest single message handed to RCCL.  Measured on this image (RCCL 2.26.6 inside torch 2.10, 1 rank sending to
 # itself): a send/recv pair of 2.0e9 bytes or more delivers only its first half, 2^30 bytes are fine
-# (scratch/dbg_a2a.py).  Every message therefore travels in pieces of at most 2^29 bytes, and a rank's own
+# (tools/rccl_message_size_check.py).  Every message therefore travels in pieces of at most 2^29 bytes, and a rank's own
 # segment never enters RCCL at all.
 _MAX_MESSAGE_BYTES = 1 << 29
 

@@ -57,6 +57,30 @@ def test_c5_shape_against_the_oracle(gdf, n, zipf_values, op):
         np.testing.assert_allclose(ga[gok], ea[eok], rtol=RTOL, atol=0.0)        # plain relative
 
 
+@pytest.mark.parametrize("order", ["sorted", "shuffled"])
+def test_guessed_key_ranges_are_verified(gdf, order):
+    """From 2^24 rows on, keys that only pack by range get their ranges GUESSED from a 65536-row prefix and the partitioned
+    path's count kernel checks every key against the guess (csrc/groupby.hip gb_plan_range_sampled / gbp_count).  Sorted
+    keys make the prefix see a sliver of the range: the call must notice and redo the plan exactly.  Shuffled keys keep
+    the guess.  Both against the oracle."""
+    from libgdf_amd.columns import column_from_numpy
+    n = (1 << 24) + 12345
+    rs = np.random.RandomState(5)
+    k0 = (np.arange(n, dtype=np.int64) // 40) - 1000            # 420 k values, ascending: the prefix spans ~1600 of them
+    k1 = rs.randint(-2, 3, size=n).astype(np.int32)
+    if order == "shuffled":
+        perm = rs.permutation(n)
+        k0, k1 = k0[perm], k1[perm]
+    v = rs.randint(-1000, 1000, size=n).astype(np.int64)
+    gk, ga = gdf.api.group_by("sum", [column_from_numpy(k0), column_from_numpy(k1)], column_from_numpy(v))
+    gk, ga = [x.cpu().numpy() for x in gk], ga.cpu().numpy()
+    ek, ea = oracle.group_by("sum", [k0, k1], v)
+    o = np.lexsort((gk[1], gk[0]))
+    np.testing.assert_array_equal(gk[0][o], ek[0])
+    np.testing.assert_array_equal(gk[1][o], ek[1])
+    np.testing.assert_array_equal(ga[o], ea)
+
+
 def test_c5_full_size_properties(gdf):
     """1e9 rows, 1e6 Zipf values x 16: ~1.6e7 groups, the hottest key pair holds ~0.4 % of the rows."""
     import torch

@@ -1,6 +1,6 @@
 # idle gaps between consecutive kernels of one C3 join (rocprofv3 kernel trace timestamps)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/gaps; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $O/t -o j -- python $R/bench.py --steps 2 --warmup 1 --cpu-sample 0 > $O/log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $O/t -o j -- python $R/bench.py --steps 2 --warmup 1 --cpu-sample 0 --pandas-sample 0 > $O/log 2>&1
 python - <<'PY'
 import csv, glob, os
 f = glob.glob(os.path.expandvars("$GRAFT_REPO_ROOT/gpurun_out/gaps/t/**/*kernel_trace.csv"), recursive=True)[0]

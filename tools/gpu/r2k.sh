@@ -1,0 +1,4 @@
+O=gpurun_out/r2k; mkdir -p $O
+timeout 1500 python -m pytest tests/test_gpu_join.py tests/test_gpu_join_internals.py tests/test_gpu_groupby.py -x -q -m gpu > $O/pytest.txt 2>&1; tail -4 $O/pytest.txt
+timeout 300 python bench.py --steps 10 --warmup 2 --cpu-sample 0 --pandas-sample 0 2>>$O/err.txt | cut -c1-100,600-1500
+bash tools/gpu/gaps.sh 2>&1 | tail -34 | head -26

@@ -1240,6 +1240,12 @@ constexpr int GBP_MAX_PARTS = 1 << GBP_MAX_PART_BITS;
 constexpr int GBP_THREADS = 1024;
 constexpr int GBP_ITEMS = 8;
 constexpr int GBP_TILE = GBP_THREADS * GBP_ITEMS;
+// the scatter kernel's shape: 1024 threads x 8 rows = 8192-row tiles, 115 KB of LDS, one workgroup per CU.  Two 512-thread
+// workgroups per CU on 4096-row tiles (72 KB each) overlap their phases but halve the run lengths: 13.9 instead of 11.9 ms on
+// C5 -- the store-REQUEST rate of the short (tile, partition) runs is the wall, not the phase structure; 12 rows per thread
+// (longer runs) spill
+constexpr int GBP_SC_THREADS = 1024;
+constexpr int GBP_SC_TILE = GBP_SC_THREADS * GBP_ITEMS;
 constexpr int GBP_MAX_CHUNKS = 1024;       // hist columns at most (chunks are whole tiles)
 
 // packed keys of N rows (clamped row numbers in src[]) with the loads of one column issued together; ok[k] = false when the
@@ -1348,30 +1354,30 @@ __global__ __launch_bounds__(GBP_THREADS) void gbp_count(KeyTable t, GbKeyPlan p
 }
 
 template <bool VBIT>
-__global__ __launch_bounds__(GBP_THREADS) void gbp_scatter(KeyTable t, GbKeyPlan plan, GbVal val, int fold_op, int low, int part_bits,
+__global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter(KeyTable t, GbKeyPlan plan, GbVal val, int fold_op, int low, int part_bits,
                                                            uint32_t nparts, int64_t chunk, int nchunks, const uint32_t *__restrict__ offs,
                                                            uint32_t *__restrict__ keys_out, uint64_t *__restrict__ payload_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gbp_lds[];
   uint64_t *stage = reinterpret_cast<uint64_t *>(gbp_lds);                   // [TILE]
-  uint32_t *hist = reinterpret_cast<uint32_t *>(stage + GBP_TILE);           // [MAX_PARTS + 4]
+  uint32_t *hist = reinterpret_cast<uint32_t *>(stage + GBP_SC_TILE);           // [MAX_PARTS + 4]
   uint32_t *start = hist + GBP_MAX_PARTS + 4, *gbase = start + GBP_MAX_PARTS, *cursor = gbase + GBP_MAX_PARTS;
   uint32_t *wave_tot = cursor + GBP_MAX_PARTS;                               // [THREADS / WAVE]
-  uint16_t *bin_of = reinterpret_cast<uint16_t *>(wave_tot + GBP_THREADS / WAVE);   // [TILE]
-  constexpr int PER = GBP_MAX_PARTS / GBP_THREADS;                           // partitions per thread in the scan (2)
+  uint16_t *bin_of = reinterpret_cast<uint16_t *>(wave_tot + GBP_SC_THREADS / WAVE);   // [TILE]
+  constexpr int PER = GBP_MAX_PARTS / GBP_SC_THREADS;                           // partitions per thread in the scan (2)
   constexpr int vbit = VBIT ? 1 : 0;
   for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
-    for (uint32_t q = threadIdx.x; q < nparts; q += GBP_THREADS) cursor[q] = offs[(size_t)q * nchunks + c];
+    for (uint32_t q = threadIdx.x; q < nparts; q += GBP_SC_THREADS) cursor[q] = offs[(size_t)q * nchunks + c];
     const int64_t begin = (int64_t)c * chunk;
     const int64_t end = begin + chunk < t.nrows ? begin + chunk : t.nrows;
-    for (int64_t tile = begin; tile < end; tile += GBP_TILE) {
-      for (uint32_t q = threadIdx.x; q < GBP_MAX_PARTS; q += GBP_THREADS) hist[q] = 0;
+    for (int64_t tile = begin; tile < end; tile += GBP_SC_TILE) {
+      for (uint32_t q = threadIdx.x; q < GBP_MAX_PARTS; q += GBP_SC_THREADS) hist[q] = 0;
       block_sync();
       uint32_t src[GBP_ITEMS];
       uint64_t key[GBP_ITEMS];
       bool ok[GBP_ITEMS], inside[GBP_ITEMS];
 #pragma unroll
       for (int k = 0; k < GBP_ITEMS; ++k) {
-        const int64_t i = tile + (int64_t)k * GBP_THREADS + threadIdx.x;
+        const int64_t i = tile + (int64_t)k * GBP_SC_THREADS + threadIdx.x;
         src[k] = (uint32_t)(i < end ? i : end - 1);
       }
       // the value column is requested NOW, with the keys: one round of HBM latency per tile instead of two (as a second load
@@ -1425,7 +1431,7 @@ __global__ __launch_bounds__(GBP_THREADS) void gbp_scatter(KeyTable t, GbKeyPlan
       uint32_t k32[GBP_ITEMS];
 #pragma unroll
       for (int k = 0; k < GBP_ITEMS; ++k) {
-        const bool live = tile + (int64_t)k * GBP_THREADS + threadIdx.x < end && ok[k];
+        const bool live = tile + (int64_t)k * GBP_SC_THREADS + threadIdx.x < end && ok[k];
         const bool vok = (vmask >> k) & 1u;
         k32[k] = (uint32_t)((key[k] << vbit) | (uint64_t)(VBIT && vok));
         const uint32_t part = k32[k] >> low;
@@ -1453,7 +1459,7 @@ __global__ __launch_bounds__(GBP_THREADS) void gbp_scatter(KeyTable t, GbKeyPlan
       }
       block_sync();
       uint32_t total = 0;
-      for (int w = 0; w < GBP_THREADS / WAVE; ++w) total += wave_tot[w];
+      for (int w = 0; w < GBP_SC_THREADS / WAVE; ++w) total += wave_tot[w];
       uint32_t pos[GBP_ITEMS];
 #pragma unroll
       for (int k = 0; k < GBP_ITEMS; ++k) {
@@ -1466,20 +1472,20 @@ __global__ __launch_bounds__(GBP_THREADS) void gbp_scatter(KeyTable t, GbKeyPlan
         }
       }
       block_sync();
-      for (uint32_t j = threadIdx.x; j < total; j += GBP_THREADS) keys_out[gbase[bin_of[j]] + j] = (uint32_t)stage[j];
+      for (uint32_t j = threadIdx.x; j < total; j += GBP_SC_THREADS) keys_out[gbase[bin_of[j]] + j] = (uint32_t)stage[j];
       block_sync();
       // (the value column was requested together with the keys, above)
 #pragma unroll
       for (int k = 0; k < GBP_ITEMS; ++k)
         if (pr[k] != 0xffffffffu) stage[pos[k]] = ((vmask >> k) & 1u) ? img[k] : acc_identity(fold_op);
       block_sync();
-      for (uint32_t j = threadIdx.x; j < total; j += GBP_THREADS) payload_out[gbase[bin_of[j]] + j] = stage[j];
+      for (uint32_t j = threadIdx.x; j < total; j += GBP_SC_THREADS) payload_out[gbase[bin_of[j]] + j] = stage[j];
       block_sync();
     }
   }
 }
 static constexpr size_t gbp_scatter_lds() {
-  return 8 * (size_t)GBP_TILE + 4 * (size_t)(4 * GBP_MAX_PARTS + 4 + GBP_THREADS / WAVE) + 2 * (size_t)GBP_TILE + 16;
+  return 8 * (size_t)GBP_SC_TILE + 4 * (size_t)(4 * GBP_MAX_PARTS + 4 + GBP_SC_THREADS / WAVE) + 2 * (size_t)GBP_SC_TILE + 16;
 }
 
 // number of non-empty cells per block of 1024 cells
@@ -1821,11 +1827,11 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
       const size_t slds = gbp_scatter_lds();
       if (vbit) {
         HIP_TRY(hipFuncSetAttribute((const void *)gbp_scatter<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
-        GDF_LAUNCH("gbp_scatter", gbp_scatter<true>, dim3(nchunks < NUM_CU ? nchunks : NUM_CU), dim3(GBP_THREADS), slds, stream0(), t, sp, val, fold_op,
+        GDF_LAUNCH("gbp_scatter", gbp_scatter<true>, dim3(nchunks < NUM_CU ? nchunks : NUM_CU), dim3(GBP_SC_THREADS), slds, stream0(), t, sp, val, fold_op,
                    low, part_bits, P, chunk, nchunks, (const uint32_t *)hist.as<uint32_t>(), (uint32_t *)kin, pin);
       } else {
         HIP_TRY(hipFuncSetAttribute((const void *)gbp_scatter<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
-        GDF_LAUNCH("gbp_scatter", gbp_scatter<false>, dim3(nchunks < NUM_CU ? nchunks : NUM_CU), dim3(GBP_THREADS), slds, stream0(), t, sp, val, fold_op,
+        GDF_LAUNCH("gbp_scatter", gbp_scatter<false>, dim3(nchunks < NUM_CU ? nchunks : NUM_CU), dim3(GBP_SC_THREADS), slds, stream0(), t, sp, val, fold_op,
                    low, part_bits, P, chunk, nchunks, (const uint32_t *)hist.as<uint32_t>(), (uint32_t *)kin, pin);
       }
       hipLaunchKernelGGL(gb_strided_u32, dim3((P + 256) / 256), dim3(256), 0, stream0(), (const uint32_t *)hist.as<uint32_t>(), d_start.as<uint32_t>(),

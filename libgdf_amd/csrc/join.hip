@@ -923,6 +923,7 @@ struct ProbeLds {
   unsigned long long *wave_cnt;      // [JK_PROBE_THREADS / WAVE]
   unsigned long long *unit_cursor;
   unsigned int *cuckoo_failed;
+  uint32_t *next;                    // [cap] general kernel only: chain of build tuples with the same key (JK_NOPOS ends it)
 };
 
 template <bool NARROW>
@@ -936,10 +937,12 @@ __device__ __forceinline__ ProbeLds carve_probe_lds(unsigned char *raw, uint32_t
   l.wave_cnt = (unsigned long long *)after;
   l.unit_cursor = l.wave_cnt + JK_PROBE_THREADS / WAVE;
   l.cuckoo_failed = (unsigned int *)(l.unit_cursor + 1);
+  l.next = (uint32_t *)(l.unit_cursor + 2);      // present only when the launch asked for probe_lds_bytes(..., chained = true)
   return l;
 }
-static size_t probe_lds_bytes(bool narrow, uint32_t cap, uint32_t H) {
-  return (size_t)cap * (narrow ? 8 : 12) + (size_t)H * 8 + sizeof(unsigned long long) * (JK_PROBE_THREADS / WAVE + 2);
+static size_t probe_lds_bytes(bool narrow, uint32_t cap, uint32_t H, bool chained = true) {
+  return (size_t)cap * (narrow ? 8 : 12) + (size_t)H * 8 + sizeof(unsigned long long) * (JK_PROBE_THREADS / WAVE + 2) +
+         (chained ? (size_t)cap * 4 : 0);
 }
 
 template <bool NARROW>
@@ -987,14 +990,28 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
   const bool cuckoo = *l.cuckoo_failed == 0 && !(a.dbg & 8);
   if (!cuckoo && !WRITE && a.opt_state && threadIdx.x == 0) atomicAdd(&a.opt_state[3], 1ull);   // sample pass: units with repeated build keys
   if (!cuckoo) {
-    // ---- linear-probing rebuild over the same 2*H slots (multimap: duplicates simply chain) ----
+    // ---- multimap rebuild over the same 2*H slots: open addressing over the DISTINCT keys, every key's tuples chained
+    // behind the one that took the slot (next[]).  Round 1 gave every tuple a slot of its own: a key that occurs four times
+    // made clusters four slots long, a lookup walked ~10 slots and, when it had more than one match, walked them again to
+    // emit -- 22 ms of LDS chain walking for a join whose build keys all occur four times (profiles/r2_b_bench_shapes.jsonl).
+    // Now a lookup finds its key's head in ~1 step (the table holds a quarter of the entries) and walks exactly its matches.
     block_sync();
     for (uint32_t i = threadIdx.x; i < 2 * H; i += JK_PROBE_THREADS) l.T[i] = JK_NOPOS;
+    for (uint32_t i = threadIdx.x; i < u.build_count; i += JK_PROBE_THREADS) l.next[i] = JK_NOPOS;
     block_sync();
     const uint32_t mask = 2 * H - 1;
     for (uint32_t p = threadIdx.x; p < u.build_count; p += JK_PROBE_THREADS) {
-      uint32_t slot = hash_b(tup_key<NARROW>(l.bw[p]) + a.kbias) & mask;
-      while (atomicCAS(&l.T[slot], JK_NOPOS, p) != JK_NOPOS) slot = (slot + 1) & mask;
+      const uint64_t kp = tup_key<NARROW>(l.bw[p]);
+      uint32_t slot = hash_b(kp + a.kbias) & mask;
+      for (;;) {
+        uint32_t q = atomicCAS(&l.T[slot], JK_NOPOS, p);
+        if (q == JK_NOPOS) break;                                   // p is the head of its key
+        if (tup_key<NARROW>(l.bw[q]) == kp) {                        // same key: p goes right behind the head
+          l.next[p] = atomicExch(&l.next[q], p);
+          break;
+        }
+        slot = (slot + 1) & mask;
+      }
     }
     block_sync();
   }
@@ -1079,16 +1096,20 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
         hit_a[b] = hit_b[b] = JK_NOPOS;
         if (act[b]) {
           uint32_t slot = hash_b(k[b] + a.kbias) & mask;
-          for (;;) {
+          uint32_t head = JK_NOPOS;
+          for (;;) {                                     // the head of this key, if the partition holds it
             const uint32_t p = l.T[slot];
             if (p == JK_NOPOS) break;
-            if (tup_key<NARROW>(l.bw[p]) == k[b] &&
-                (!a.verify || rows_equal(probe_t, prow[b], build_t, build_row<NARROW>(l, p)))) {
+            if (tup_key<NARROW>(l.bw[p]) == k[b]) { head = p; break; }
+            slot = (slot + 1) & mask;
+          }
+          hit_b[b] = head;                               // the write pass starts its walk here
+          for (uint32_t p = head; p != JK_NOPOS; p = l.next[p]) {
+            if (!a.verify || rows_equal(probe_t, prow[b], build_t, build_row<NARROW>(l, p))) {
               if (cnt[b] == 0) hit_a[b] = p;
               ++cnt[b];
               if (a.build_matched) a.build_matched[build_row<NARROW>(l, p)] = 1;
             }
-            slot = (slot + 1) & mask;
           }
         }
       }
@@ -1130,19 +1151,13 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
             a.out_probe[pos + 1] = prow[b];
             a.out_build[pos + 1] = build_row<NARROW>(l, hit_b[b]);
           }
-        } else if (c > 1) {      // linear-probing mode with several matches: walk the chain again
-          const uint32_t mask = 2 * H - 1;
-          uint32_t slot = hash_b(k[b] + a.kbias) & mask;
-          for (;;) {
-            const uint32_t p = l.T[slot];
-            if (p == JK_NOPOS) break;
-            if (tup_key<NARROW>(l.bw[p]) == k[b] &&
-                (!a.verify || rows_equal(probe_t, prow[b], build_t, build_row<NARROW>(l, p)))) {
+        } else if (c > 1) {      // multimap mode with several matches: walk the key's chain again
+          for (uint32_t p = hit_b[b]; p != JK_NOPOS; p = l.next[p]) {
+            if (!a.verify || rows_equal(probe_t, prow[b], build_t, build_row<NARROW>(l, p))) {
               a.out_probe[pos] = prow[b];
               a.out_build[pos] = build_row<NARROW>(l, p);
               ++pos;
             }
-            slot = (slot + 1) & mask;
           }
         }
       }
@@ -1964,7 +1979,7 @@ static gdf_error run_write_pass(bool narrow, bool plain, size_t nunits, size_t l
   const bool pow2 = (double)max_build <= 0.42 * 2.0 * (double)a.nslots;
   if (!pow2) {
     fa.nslots = ((uint32_t)(max_build * 1.25) + 63) & ~63u;
-    flds = probe_lds_bytes(narrow, a.cap, fa.nslots);
+    flds = probe_lds_bytes(narrow, a.cap, fa.nslots, false);
   }
 #define JK_FAST_LAUNCH(P2, KP, NW)                                                                                               \
   do {                                                                                                                           \

@@ -43,6 +43,8 @@ KERNEL_BYTES = {
     # the stable variant the join uses: keys out, one bit per row and destination instead of a row number
     "stable_count": lambda npr, nb, tb, lps, kb: 8.0 * (npr + nb),
     "stable_scatter": lambda npr, nb, tb, lps, kb: (8.0 + kb + 0.125) * (npr + nb),
+    # the fused variant: raw int64 key in, narrowed key + row number out (the row numbers stay with the sender)
+    "fj_scatter": lambda npr, nb, tb, lps, kb: (8.0 + 4.0 + 4.0) * (npr + nb),
 }
 
 
@@ -175,10 +177,12 @@ def main():
     ap.add_argument("--build-rows", type=int, default=None)
     ap.add_argument("--cpu-sample", type=int, default=20_000_000, help="probe rows of the oracle-port CPU baseline sample (0 = skip)")
     ap.add_argument("--pandas-sample", type=int, default=100_000_000, help="probe rows of the pandas.merge CPU baseline (0 = skip)")
-    ap.add_argument("--strategy", choices=["auto", "shuffle", "broadcast"], default="auto",
+    ap.add_argument("--strategy", choices=["auto", "fused", "shuffle", "broadcast"], default="auto",
                     help="multi-GPU join: shuffle both relations by key with an RCCL all-to-all (C4 as BASELINE.json names it), "
-                         "gather the build keys on every GPU and leave the probe relation where it is, or (default) whichever "
-                         "libgdf_amd.multigpu.choose_join_strategy expects to be faster: broadcast at 2 GPUs, shuffle at 4 and 8")
+                         "the same with the rank split fused into the join's level-1 regroup (4-byte keys in fixed-size blocks; falls back to "
+                         "the shuffle when the shape does not fit), gather the build keys on every GPU and leave the probe relation where it "
+                         "is, or (default) whichever libgdf_amd.multigpu.choose_join_strategy expects to be faster: broadcast at 2 GPUs, "
+                         "shuffle at 4, fused at 8")
     ap.add_argument("--force-distributed", action="store_true",
                     help="run the multi-GPU (C4) code path even at world size 1 (1-rank RCCL group): measures its local passes")
     args = ap.parse_args()
@@ -256,6 +260,14 @@ def main():
                 return multigpu.broadcast_inner_join(probe, build).numel()
             workload = (f"C4 rows, broadcast variant: {npr} probe + {nb} build int64 rows per GPU, key space {key_space}, "
                         f"RCCL all-gather of the build keys + local gdf_inner_join")
+        elif strategy == "fused":
+            def step():
+                pairs = multigpu.fused_inner_join(probe, build)
+                if pairs is None:                  # collectively None: the shape did not fit
+                    pairs = multigpu.distributed_inner_join(probe, build)
+                return pairs.numel()
+            workload = (f"C4 partitioned hash join: {npr} probe + {nb} build int64 rows per GPU, key space {key_space}, rank split fused into "
+                        f"the join's level-1 regroup at the sender, RCCL all-to-all of 4-byte keys, level 2 + LDS probe at the receiver")
         else:
             def step():
                 return multigpu.distributed_inner_join(probe, build).numel()

@@ -82,6 +82,34 @@ gdf_error gdf_amd_shuffle_partition(gdf_column *keys, int narrow, int64_t lo, in
 gdf_error gdf_amd_shuffle_partition_stable(gdf_column *keys, int narrow, int64_t lo, int64_t hi, int num_partitions,
                                            gdf_column *out_keys, uint64_t *bitmaps, int partition_offsets[]);
 
+/*
+ * FUSED multi-GPU join: the sender runs the join's level-1 regroup, the receiver continues at level 2 (csrc/join.hip "FUSED
+ * multi-GPU join"; libgdf_amd/multigpu.py fused_inner_join).  All ranks share one hash space; rank = mulhi(hash, world).
+ *
+ * gdf_amd_fj_plan    layout every rank derives from GLOBAL numbers only: fine / coarse partition bits of a rank's share of
+ *                    `build_rows_total`, and the room `cap` (keys per (bin, XCD) region) for calls of at most `rows_max` rows
+ *                    whose keys repeat `rows_per_key` times on average (all copies of a key share a region).
+ *                    GDF_UNSUPPORTED_METHOD: this world size / relation size does not fit the path (use the key shuffle).
+ * gdf_amd_fj_send    int64 / int32 keys -> out_keys: (world << coarse_bits) bins x 8 regions x cap 4-byte keys (key - lo; rows
+ *                    outside [lo, hi] are dropped), rank r's keys in the r-th contiguous block of (8 << coarse_bits) * cap
+ *                    elements (+ one tile of dump space behind the last block); out_rows: the rows' local numbers (+ row_base)
+ *                    at the same positions -- they stay with the sender; out_fill: DEVICE array of (world << coarse_bits) * 8
+ *                    fill counters + 1 word.  *overflowed = 1: some region outgrew cap (skewed keys), the buffers are unusable.
+ * gdf_amd_fj_build_create   receive buffer of the build relation (the blocks every sender made for this rank, sender-major,
+ *                    with their fill counters in the same order, both in DEVICE memory) -> a build handle
+ *                    (gdf_amd_join_probe_begin / gdf_amd_fj_probe_add / gdf_amd_join_probe_finish / gdf_amd_join_build_free).
+ * gdf_amd_fj_probe_add      one receive buffer of the probe relation; result indices are POSITIONS: position_base + offset in
+ *                    this buffer for the probe side, offset in the build receive buffer for the build side.
+ */
+gdf_error gdf_amd_fj_plan(int world, int64_t build_rows_total, int64_t rows_max, double rows_per_key, int *fine_bits, int *coarse_bits,
+                          uint32_t *cap);
+gdf_error gdf_amd_fj_send(gdf_column *keys, int64_t lo, int64_t hi, int world, int coarse_bits, uint32_t cap, int32_t row_base,
+                          uint32_t *out_keys, int32_t *out_rows, uint32_t *out_fill, int *overflowed);
+gdf_error gdf_amd_fj_build_create(const uint32_t *recv_keys, const uint32_t *recv_fill, int world, int64_t lo, int fine_bits,
+                                  int coarse_bits, uint32_t cap, int64_t expected_rows, gdf_amd_join_build **out);
+gdf_error gdf_amd_fj_probe_add(gdf_amd_join_probe *probe, const uint32_t *recv_keys, const uint32_t *recv_fill, uint32_t cap,
+                               int64_t position_base, int64_t buffer_elems);
+
 #if defined(__GNUC__)
 #pragma GCC visibility pop
 #endif

@@ -11,7 +11,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._binding import gdf_column, libgdf
+from ._binding import GDF_UNSUPPORTED_METHOD, GDFError, gdf_column, libgdf
 from .columns import (GDF_HASH, GDF_HASH_MURMUR3, GDF_SORT, GDF_TO_NP, Column, column_array, new_context)
 
 _hip = None
@@ -235,6 +235,13 @@ class ProbeAccumulator:
     def add(self, probe):
         libgdf.gdf_amd_join_probe_add(self._h, column_array(probe), len(probe))
 
+    def add_recv(self, recv_keys, recv_fill, layout, position_base):
+        """gdf_amd_fj_probe_add: one receive buffer of the probe relation (queued, not waited for); its tuples are numbered
+        position_base + offset in the buffer."""
+        self._keep = getattr(self, "_keep", []) + [recv_keys, recv_fill]
+        libgdf.gdf_amd_fj_probe_add(self._h, recv_keys.data_ptr(), recv_fill.data_ptr(), layout.cap, int(position_base),
+                                    layout.world * layout.block)
+
     def finish(self, copy=True):
         """-> (probe_idx, build_idx); probe rows are numbered across the slices in the order they were added."""
         import torch
@@ -252,6 +259,60 @@ class ProbeAccumulator:
                 del li, ri
             except Exception:
                 pass
+
+
+# ---- fused multi-GPU join (include/gdf/gdf_amd_ext.h gdf_amd_fj_*) -----------------------------------------------------
+FJ_DUMP_ELEMS = 16384          # one sender tile of dump space behind the regions (csrc/join.hip FJ_TILE)
+
+
+class FjLayout:
+    """What gdf_amd_fj_plan derives from GLOBAL numbers: partition bits of a rank's share and the room per region."""
+
+    def __init__(self, world, fine_bits, coarse_bits, cap):
+        self.world, self.fine_bits, self.coarse_bits, self.cap = world, fine_bits, coarse_bits, cap
+        self.regions_per_rank = 8 << coarse_bits
+        self.block = self.regions_per_rank * cap                 # elements every sender makes for one rank
+        self.nregions = world * self.regions_per_rank
+
+
+def fj_plan(world, build_rows_total, rows_max, rows_per_key=1.0):
+    """-> FjLayout, or None when this world size / relation size does not fit the fused path."""
+    fb, c1, cap = C.c_int(), C.c_int(), C.c_uint32()
+    try:
+        libgdf.gdf_amd_fj_plan(int(world), int(build_rows_total), int(rows_max), float(rows_per_key), C.byref(fb), C.byref(c1), C.byref(cap))
+    except GDFError as e:
+        if e.errcode == GDF_UNSUPPORTED_METHOD:
+            return None
+        raise
+    return FjLayout(int(world), fb.value, c1.value, cap.value)
+
+
+def fj_send(keys: Column, lo, hi, layout: FjLayout, row_base=0):
+    """gdf_amd_fj_send -> (keys buffer int32 [world * block (+ dump)], rows buffer int32 (same shape, stays with the sender),
+    fill counters int32 [world * regions_per_rank (+ 1)], overflowed)."""
+    import torch
+    dev = keys.data.device
+    total = layout.world * layout.block + FJ_DUMP_ELEMS
+    out_keys = torch.empty(total, dtype=torch.int32, device=dev)
+    out_rows = torch.empty(total, dtype=torch.int32, device=dev)
+    fill = torch.empty(layout.nregions + 1, dtype=torch.int32, device=dev)
+    over = C.c_int(0)
+    libgdf.gdf_amd_fj_send(keys.ptr, int(lo), int(hi), layout.world, layout.coarse_bits, layout.cap, int(row_base), out_keys.data_ptr(),
+                           out_rows.data_ptr(), fill.data_ptr(), C.byref(over))
+    return out_keys, out_rows, fill, bool(over.value)
+
+
+class FjBuild(JoinBuild):
+    """gdf_amd_fj_build_create: the build side made from a receive buffer (world blocks, sender-major) and its fill counters."""
+
+    def __init__(self, recv_keys, recv_fill, lo, layout: FjLayout, expected_rows):
+        self._cols = [recv_keys, recv_fill]                          # kept alive while the library reads them
+        self._h = C.c_void_p()
+        libgdf.gdf_amd_fj_build_create(recv_keys.data_ptr(), recv_fill.data_ptr(), layout.world, int(lo), layout.fine_bits, layout.coarse_bits,
+                                       layout.cap, int(expected_rows), C.byref(self._h))
+
+    def probe(self, *a, **k):
+        raise NotImplementedError("a receive-buffer build side is probed through accumulate() / add_recv()")
 
 
 def prefixsum(col: Column, inclusive=True):

@@ -603,7 +603,8 @@ __global__ __launch_bounds__(HP_THREADS) void stable_scatter_kernel(const KIN *_
   __shared__ uint32_t wtot[ST_WAVES * SHT_MAX_PARTS];     // rows of wave w for partition p, then: rows of earlier waves
   __shared__ uint32_t start[SHT_MAX_PARTS], gbase[SHT_MAX_PARTS];
   __shared__ uint32_t tile_total;
-  __shared__ unsigned long long bm[SHT_MAX_PARTS * (ST_TILE / WAVE)];      // [partition][word of the tile]
+  extern __shared__ __attribute__((aligned(16))) unsigned long long bm[];   // [nparts][ST_TILE / 64]: bitmap words of the tile (dynamic:
+                                                                            // 2 KB at fan-out 8; a static [64][32] cost most of the occupancy)
   const uint32_t tile = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   if (tile >= ntiles) return;
   const int wave = threadIdx.x / WAVE, lane = lane_id();
@@ -911,7 +912,8 @@ gdf_error gdf_amd_shuffle_partition_stable(gdf_column *keys, int narrow, int64_t
   GDF_TRY(scan_u32(counts.as<uint32_t>(), counts.as<uint32_t>(), (size_t)P * ntiles + 1, false));                                  \
   hipLaunchKernelGGL(gather_strided_u32, dim3((P + 256) / 256), dim3(256), 0, stream0(), counts.as<uint32_t>(), starts.as<uint32_t>(), \
                      (int)P + 1, (size_t)ntiles);                                                                                  \
-  GDF_LAUNCH("stable_scatter", (stable_scatter_kernel<KIN, KOUT>), dim3(grid), dim3(HP_THREADS), 0, stream0(), (const KIN *)keys->data, \
+  GDF_LAUNCH("stable_scatter", (stable_scatter_kernel<KIN, KOUT>), dim3(grid), dim3(HP_THREADS), sizeof(unsigned long long) * P * (ST_TILE / WAVE), \
+             stream0(), (const KIN *)keys->data, \
              llo, span, n, ntiles, P, pow2mask, drop, (const uint32_t *)counts.as<uint32_t>(), (KOUT *)out_keys->data,              \
              (unsigned long long *)bitmaps, words);                                                                                \
   HIP_CHECK_LAST();

@@ -49,6 +49,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <deque>
 #include <memory>
 #include <type_traits>
 #include <vector>
@@ -329,6 +330,10 @@ struct PartGeom {
   // added to the row number a level-1 tuple carries: a probe relation that arrives in slices (gdf_amd_join_probe_add)
   // is numbered across the slices
   int32_t row_base;
+  // FUSED multi-GPU join (fj_*, gdf_amd_ext.h): `world` ranks share one hash space -- rank = mulhi(hash_a, world), and the
+  // LOCAL partition id is taken from the low word of hash_a * world (uniform inside a rank).  0 / 1: single GPU, the id is
+  // hash_a's own top bits.
+  uint32_t world;
 };
 
 // NARROW: w[i] = key32 << 32 | row, idx unused.  WIDE: w[i] = key64, idx[i] = row.
@@ -370,6 +375,11 @@ __device__ __forceinline__ uint32_t hash_b(uint64_t raw_key) { return lowbias32(
 
 __device__ __forceinline__ uint32_t fine_of(uint64_t raw_key, int fb) {
   return (uint32_t)((uint64_t)hash_a(raw_key) >> (32 - fb));      // 64-bit shift: fb == 0 gives 0 without a branch
+}
+// the same with the rank remap of a fused multi-GPU join (PartGeom::world)
+struct PartGeom;
+__device__ __forceinline__ uint32_t local_hash(uint32_t h, uint32_t world) {
+  return world > 1 ? (uint32_t)((uint64_t)h * world) : h;
 }
 // slot of the global-table path (any table size)
 __device__ __forceinline__ uint32_t slot_of(uint64_t key, uint32_t nslots) {
@@ -514,7 +524,7 @@ __device__ __forceinline__ void tile_flush(TileLds<NARROW, THREADS> &s, const Pa
     uint32_t dst[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const uint32_t f = fine_of(tup_key<NARROW>(ww[u]) + g.kbias, g.fb);
+      const uint32_t f = (uint32_t)((uint64_t)local_hash(hash_a(tup_key<NARROW>(ww[u]) + g.kbias), g.world) >> (32 - g.fb));
       const uint32_t bin = LEVEL1 ? (f >> g.b2) : (f & submask);
       dst[u] = s.gbase[bin] + j0 + u * THREADS;
     }
@@ -706,6 +716,11 @@ struct Level2Map {                     // small host-built tables, device reside
   int xcd_order;                       // set by the launcher: the grid is 8 * ceil(ntiles / 8) blocks, see jk_scatter2
   const uint32_t *ntiles_dev;          // non-null: the map was built on the device (jk_make_l2map); ntiles is then an upper bound
                                        // for the grid and the real tile count is read from here
+  uint32_t nseg;                       // 0: ncoarse << xs segments, segment >> xs = coarse partition.  Otherwise (fused multi-GPU
+                                       // receive buffer): this many segments in the order (coarse partition, sender, XCD region) --
+                                       // jk_make_l2map's permutation of the buffer's sender-major regions -- the coarse partition of
+                                       // segment i is (i >> 3) / world
+  const uint32_t *keys32;              // non-null: the input is this array of 4-byte keys (a receive buffer), tuple = key << 32 | position
 };
 
 template <bool NARROW, int THREADS>
@@ -722,12 +737,12 @@ __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, 
   const uint32_t per_xcd = gridDim.x >> 3;
   const uint32_t tile_id = m.xcd_order ? (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
   if (tile_id >= (m.ntiles_dev ? *m.ntiles_dev : m.ntiles)) return;
-  uint32_t lo = 0, hi = ncoarse << m.xs;
+  uint32_t lo = 0, hi = m.nseg ? m.nseg : (ncoarse << m.xs);
   while (hi - lo > 1) {
     const uint32_t mid = (lo + hi) >> 1;
     if (m.tile_prefix[mid] <= tile_id) lo = mid; else hi = mid;
   }
-  const uint32_t p = lo >> m.xs;
+  const uint32_t p = m.nseg ? (lo >> 3) / g.world : (lo >> m.xs);          // fused receive buffer: segments are (coarse, sender, XCD)
   const uint32_t begin = m.coarse_off[lo] + (tile_id - m.tile_prefix[lo]) * JK_TILE;
   const uint32_t pend = m.coarse_end[lo];
   const uint32_t end = begin + JK_TILE < pend ? begin + JK_TILE : pend;
@@ -743,14 +758,15 @@ __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, 
   for (int k = 0; k < JK_SC_ITEMS; ++k) {         // all loads first
     const uint32_t i = begin + k * THREADS + threadIdx.x;
     const uint32_t ic = i < end ? i : end - 1;        // clamped, unconditional: see fetch_keys
-    w[k] = in.w[ic];                                  // (non-temporal loads, which help jk_scatter1, cost 2 % here)
+    if (NARROW && m.keys32) w[k] = ((uint64_t)m.keys32[ic] << 32) | (uint32_t)(g.row_base + (int32_t)ic);      // workgroup-uniform branch
+    else w[k] = in.w[ic];                             // (non-temporal loads, which help jk_scatter1, cost 2 % here)
     idx[k] = NARROW ? 0 : in.idx[ic];
   }
   uint32_t binrank[JK_SC_ITEMS];
 #pragma unroll
   for (int k = 0; k < JK_SC_ITEMS; ++k) {
     const uint32_t i = begin + k * THREADS + threadIdx.x;
-    const uint32_t bin = fine_of(tup_key<NARROW>(w[k]) + g.kbias, g.fb) & submask;
+    const uint32_t bin = (uint32_t)((uint64_t)local_hash(hash_a(tup_key<NARROW>(w[k]) + g.kbias), g.world) >> (32 - g.fb)) & submask;
     binrank[k] = i < end ? bin : 256u;
   }
 #pragma unroll
@@ -809,21 +825,32 @@ __device__ __forceinline__ T bk_block_scan(T v, T *lds_wave, T *total) {
   return woff + incl - v;
 }
 // level-2 segment map from the level-1 fill counters: segment c = [c * cap1, c * cap1 + fill[c]), tile_prefix = tiles before it
+// fj_world != 0 (receive buffer of a fused multi-GPU join): the buffer holds its regions sender-major -- region
+// ((s * ncoarse + c) << 3) | x -- but they are PROCESSED coarse-partition-major, segment ((c * world + s) << 3) | x: all tiles
+// of a coarse partition are then neighbours in the tile order, i.e. run on one XCD, whose L2 merges the short runs they
+// write into the same fine partitions (the reason for jk_scatter2's XCD-ordered tiles)
 __global__ __launch_bounds__(JK_BK_THREADS) void jk_make_l2map(const uint32_t *__restrict__ fill, uint32_t nseg, uint32_t cap1, uint32_t tile,
                                                                uint32_t *__restrict__ seg_begin, uint32_t *__restrict__ seg_end,
-                                                               uint32_t *__restrict__ tile_prefix, uint32_t *__restrict__ ntiles) {
+                                                               uint32_t *__restrict__ tile_prefix, uint32_t *__restrict__ ntiles,
+                                                               uint32_t fj_world, uint32_t ncoarse) {
   __shared__ uint32_t lds_wave[JK_BK_THREADS / WAVE];
   const uint32_t per = (nseg + JK_BK_THREADS - 1) / JK_BK_THREADS;
   const uint32_t c0 = threadIdx.x * per;
+  auto region_of = [&](uint32_t seg) -> uint32_t {
+    if (!fj_world) return seg;
+    const uint32_t cs = seg >> 3, c = cs / fj_world, sender = cs - c * fj_world;
+    return ((sender * ncoarse + c) << 3) | (seg & 7u);
+  };
   uint32_t mine = 0;
-  for (uint32_t c = c0; c < c0 + per && c < nseg; ++c) mine += (fill[c] + tile - 1) / tile;
+  for (uint32_t c = c0; c < c0 + per && c < nseg; ++c) mine += (fill[region_of(c)] + tile - 1) / tile;
   uint32_t total;
   uint32_t run = bk_block_scan<uint32_t>(mine, lds_wave, &total);
   for (uint32_t c = c0; c < c0 + per && c < nseg; ++c) {
-    seg_begin[c] = c * cap1;
-    seg_end[c] = c * cap1 + fill[c];
+    const uint32_t r = region_of(c), n = fill[r];
+    seg_begin[c] = r * cap1;
+    seg_end[c] = r * cap1 + n;
     tile_prefix[c] = run;
-    run += (fill[c] + tile - 1) / tile;
+    run += (n + tile - 1) / tile;
   }
   if (threadIdx.x == 0) { tile_prefix[nseg] = total; *ntiles = total; }
 }
@@ -1823,7 +1850,7 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
     uint32_t *seg_begin = d_map.as<uint32_t>(), *seg_end = seg_begin + nseg, *tile_prefix = seg_end + nseg;
     uint32_t *ntiles_dev = cursor.as<uint32_t>() + nfine + 1;
     hipLaunchKernelGGL(jk_make_l2map, dim3(1), dim3(JK_BK_THREADS), 0, stream0(), (const uint32_t *)spec.as<uint32_t>(), nseg, cap1,
-                       (uint32_t)JK_TILE2, seg_begin, seg_end, tile_prefix, ntiles_dev);
+                       (uint32_t)JK_TILE2, seg_begin, seg_end, tile_prefix, ntiles_dev, 0u, 0u);
     hipLaunchKernelGGL(jk_init_cursor, dim3(32), dim3(256), 0, stream0(), cursor.as<uint32_t>(), nfine, cap2);
     HIP_CHECK_LAST();
     RMM_TRY(sb->w[1].alloc(sizeof(uint64_t) * size2));
@@ -2832,6 +2859,7 @@ struct PreparedBuild {
   KeyTable table;
   BuildSide side;
   bool partitioned = false;             // false: empty build relation, probes take the generic entry point
+  bool fj = false;                      // made by gdf_amd_fj_build_create from a receive buffer: there are no key columns to re-read
 };
 
 static gdf_error build_create(gdf_column **build_cols, int num_cols, PreparedBuild **out) {
@@ -2859,6 +2887,7 @@ static gdf_error build_create(gdf_column **build_cols, int num_cols, PreparedBui
 static gdf_error build_probe(PreparedBuild *pb, int left_join, gdf_column **probe_cols, int num_cols, gdf_column *probe_indices,
                              gdf_column *build_indices) {
   GDF_REQUIRE(pb && probe_cols && probe_indices && build_indices, GDF_DATASET_EMPTY);
+  GDF_REQUIRE(!pb->fj, GDF_INVALID_API_CALL);
   GDF_REQUIRE(num_cols == pb->ncols, GDF_JOIN_DTYPE_MISMATCH);
   const JoinKind kind = left_join ? JOIN_LEFT : JOIN_INNER;
   const size_t probe_size = probe_cols[0] ? probe_cols[0]->size : 0;
@@ -2904,6 +2933,7 @@ struct ProbeAccum {
   SpecAppend app;
   double dup = 1.0;
   bool failed = false;
+  std::deque<DevBuf> keep;              // fj_probe_add: segment maps the queued level-2 kernels still read
 };
 
 static gdf_error accum_begin(PreparedBuild *pb, size_t expected_rows, ProbeAccum **out) {
@@ -2913,7 +2943,7 @@ static gdf_error accum_begin(PreparedBuild *pb, size_t expected_rows, ProbeAccum
   uint32_t largest_build = 0;
   for (uint32_t c : pb->side.B.fine_cnt) largest_build = std::max(largest_build, c);
   if (!pb->partitioned || plan.verify || !plan.narrow || g.b2 == 0 || g.b3 != 0 || largest_build > (uint32_t)JK_MAX_BUILD ||
-      expected_rows < ((size_t)1 << 22) || getenv("GDF_JK_NO_ACCUM"))
+      (!pb->fj && (expected_rows < ((size_t)1 << 22) || getenv("GDF_JK_NO_ACCUM"))))
     return GDF_UNSUPPORTED_METHOD;
   std::unique_ptr<ProbeAccum> a(new ProbeAccum());
   a->pb = pb;
@@ -2928,6 +2958,7 @@ static gdf_error accum_begin(PreparedBuild *pb, size_t expected_rows, ProbeAccum
 
 static gdf_error accum_add(ProbeAccum *a, gdf_column **probe_cols, int num_cols) {
   GDF_REQUIRE(a && probe_cols, GDF_DATASET_EMPTY);
+  GDF_REQUIRE(!a->pb->fj, GDF_INVALID_API_CALL);                      // a build side made from a receive buffer takes gdf_amd_fj_probe_add
   GDF_REQUIRE(num_cols == a->pb->ncols, GDF_JOIN_DTYPE_MISMATCH);
   if (a->failed) return GDF_UNSUPPORTED_METHOD;
   const size_t n = probe_cols[0] ? probe_cols[0]->size : 0;
@@ -2954,6 +2985,12 @@ static gdf_error accum_finish(ProbeAccum *a, gdf_column *probe_indices, gdf_colu
   gdf_column_view(probe_indices, nullptr, nullptr, 0, N_GDF_TYPES);
   gdf_column_view(build_indices, nullptr, nullptr, 0, N_GDF_TYPES);
   if (!a->app.started) return GDF_SUCCESS;                            // no rows were added
+  if (a->pb->fj) {                  // the level-2 passes of gdf_amd_fj_probe_add were only queued: their overflow flag is looked at now
+    uint32_t flag = 0;
+    HIP_TRY(read_back(&flag, a->app.cursor.as<uint32_t>() + (1u << a->pb->side.g.fb), sizeof(flag)));
+    a->keep.clear();
+    if (flag) return GDF_UNSUPPORTED_METHOD;
+  }
   GDF_TRY(spec_append_finish(a->pb->side.g, &a->app, &a->P));
   KeyTable all = a->pb->table;            // stands for the accumulated relation: same key columns, no data (never read on this path)
   all.nrows = a->app.rows;
@@ -2966,6 +3003,321 @@ static gdf_error accum_finish(ProbeAccum *a, gdf_column *probe_indices, gdf_colu
   if (n == 0) return GDF_SUCCESS;
   gdf_column_view(probe_indices, o_probe, nullptr, (gdf_size_type)n, GDF_INT32);
   gdf_column_view(build_indices, o_build, nullptr, (gdf_size_type)n, GDF_INT32);
+  return GDF_SUCCESS;
+}
+
+
+// ---------------------------------------------------------------------------
+// FUSED multi-GPU join (gdf_amd_fj_*, include/gdf/gdf_amd_ext.h): the SENDER runs the join's level-1 regroup, the receiver
+// continues at level 2.
+//
+// All ranks share one hash space: h = hash_a(key); rank = mulhi(h, world) owns the key; inside a rank the partition ids come
+// from the low word of h * world (uniform again).  The sender regroups its rows into world << c1 bins (bin = rank << c1 |
+// coarse partition on that rank; at most 1024), writing the NARROWED 4-byte keys into a send buffer laid out as regions of
+// `cap` keys per (bin, XCD) -- so everything for rank r is one contiguous, fixed-size block and no count exchange precedes
+// the data -- and the local row numbers into a second array of the same shape that never travels.  The receiver's buffer
+// (world blocks, sender-major) is exactly a level-1 output in the speculative layout with world << (c1 + 3) segments: the
+// level-2 regroup reads its 4-byte keys, numbers the tuples by their position in that buffer and drops them into the fine
+// partitions the LDS probe works on.  Per row: sender 8 B in + 8 B out, receiver 4 B in + 8 B out, probe 8 + 8 -- against
+// 8 + 8 + 4.125 (stable split, two passes) and 4 + 8, 8 + 8, 8 + 8 for the key-only shuffle of round 1 -- and 4 B on the links.
+// Global row ids: a result index is a position in a receive buffer, i.e. (sender, region, offset); the sender kept the row
+// number it put there (libgdf_amd/multigpu.py resolves them lazily, with a second exchange outside the timed path).
+// ---------------------------------------------------------------------------
+constexpr int FJ_THREADS = 1024;
+constexpr int FJ_ITEMS = 16;          // 16384-tuple tiles: a (tile, bin) run is 16 keys = 64 bytes at 1024 bins (12: 5.0 ms per 1e9 rows)
+constexpr int FJ_TILE = FJ_THREADS * FJ_ITEMS;
+constexpr int FJ_MAX_BINS = 1024;
+constexpr int64_t FJ_CHUNK = ((int64_t)131072 + FJ_TILE - 1) / FJ_TILE * FJ_TILE;     // rows per sender workgroup
+
+struct FjSend {
+  const void *keys;          // int64 or int32 column
+  uint32_t n;
+  long long lo;              // keys travel as (key - lo); a key outside [lo, lo + span] joins nothing and is dropped
+  unsigned long long span;
+  uint32_t world;
+  int c1;                    // coarse bits per rank: bins = world << c1
+  uint32_t cap;              // keys per (bin, XCD) region
+  int32_t row_base;
+  uint32_t chunk;            // rows per workgroup (a multiple of the tile)
+  uint32_t *out_keys;
+  int32_t *out_rows;
+  uint32_t *fill;            // [bins * 8] zero-initialised fill counters
+  uint32_t *overflow;        // set when a region outgrew `cap` (its run goes to the dump area behind the regions)
+};
+
+template <class K>
+__global__ __launch_bounds__(FJ_THREADS) void fj_scatter(FjSend a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fj_lds[];
+  uint64_t *tw = reinterpret_cast<uint64_t *>(fj_lds);                 // [TILE + 2]: key32 << 32 | row, regrouped by bin
+  uint32_t *hist = reinterpret_cast<uint32_t *>(tw + FJ_TILE + 2);      // [MAX_BINS + 4] counts, then exclusive starts
+  uint32_t *gbase = hist + FJ_MAX_BINS + 4;                             // [MAX_BINS] destination of LDS position 0 of a bin
+  uint32_t *wave_tot = gbase + FJ_MAX_BINS;                             // [THREADS / WAVE]
+  const uint32_t nbins = a.world << a.c1;
+  const uint32_t xcd = blockIdx.x & 7u;
+  const uint32_t begin = blockIdx.x * a.chunk;
+  const uint32_t end = begin + a.chunk < a.n ? begin + a.chunk : a.n;
+  const uint32_t dump = (nbins << 3) * a.cap;
+  const K *col = (const K *)a.keys;
+  auto bin_of_key = [&](uint32_t key32) -> uint32_t {
+    const uint64_t u = (uint64_t)hash_a((uint64_t)((long long)key32 + a.lo)) * a.world;
+    return ((uint32_t)(u >> 32) << a.c1) | (uint32_t)((uint64_t)(uint32_t)u >> (32 - a.c1));
+  };
+  for (uint32_t b = threadIdx.x; b < FJ_MAX_BINS + 4; b += FJ_THREADS) hist[b] = 0;
+  block_sync();
+  for (uint32_t tile = begin; tile < end; tile += FJ_TILE) {
+    K raw[FJ_ITEMS];
+#pragma unroll
+    for (int k = 0; k < FJ_ITEMS; ++k) {               // all loads first, clamped and unconditional
+      const uint32_t i = tile + k * FJ_THREADS + threadIdx.x;
+      raw[k] = __builtin_nontemporal_load(col + (i < end ? i : end - 1));
+    }
+    uint32_t key[FJ_ITEMS], br[FJ_ITEMS];
+#pragma unroll
+    for (int k = 0; k < FJ_ITEMS; ++k) {
+      const uint32_t i = tile + k * FJ_THREADS + threadIdx.x;
+      const unsigned long long off = (unsigned long long)((long long)raw[k] - a.lo);
+      key[k] = (uint32_t)off;
+      br[k] = (i < end && off <= a.span) ? bin_of_key(key[k]) : (uint32_t)FJ_MAX_BINS;      // MAX_BINS: trash counter, does not travel
+    }
+#pragma unroll
+    for (int k = 0; k < FJ_ITEMS; ++k) br[k] = (br[k] << 16) | atomicAdd(&hist[br[k]], 1u);
+    block_sync();
+    {   // claim the runs, exclusive scan of the counts (thread t owns bin t)
+      const uint32_t cnt = threadIdx.x < nbins ? hist[threadIdx.x] : 0;
+      uint32_t gb = 0;
+      if (cnt) {
+        const uint32_t region = (threadIdx.x << 3) | xcd;
+        const uint32_t at = atomicAdd(&a.fill[region], cnt);
+        if (at + cnt > a.cap) { atomicExch(a.overflow, 1u); gb = dump; }
+        else gb = region * a.cap + at;
+      }
+      const uint32_t incl = wave_scan_incl(cnt);
+      if (lane_id() == WAVE - 1) wave_tot[threadIdx.x / WAVE] = incl;
+      block_sync();
+      uint32_t start = incl - cnt;
+      for (int w = 0; w < (int)(threadIdx.x / WAVE); ++w) start += wave_tot[w];
+      hist[threadIdx.x] = start;
+      gbase[threadIdx.x] = gb - start;
+    }
+    block_sync();
+    uint32_t total = 0;
+    for (int w = 0; w < FJ_THREADS / WAVE; ++w) total += wave_tot[w];
+#pragma unroll
+    for (int k = 0; k < FJ_ITEMS; ++k) {
+      const uint32_t bin = br[k] >> 16;
+      if (bin < FJ_MAX_BINS) {
+        const uint32_t i = tile + k * FJ_THREADS + threadIdx.x;
+        tw[hist[bin] + (br[k] & 0xffffu)] = ((uint64_t)key[k] << 32) | (uint32_t)(a.row_base + (int32_t)i);
+      }
+    }
+    block_sync();
+#pragma unroll
+    for (int k = 0; k < FJ_ITEMS; ++k) {
+      const uint32_t j = threadIdx.x + k * FJ_THREADS;
+      if (j < total) {
+        const uint64_t w = tw[j];
+        const uint32_t dst = gbase[bin_of_key((uint32_t)(w >> 32))] + j;
+        a.out_keys[dst] = (uint32_t)(w >> 32);
+        a.out_rows[dst] = (int32_t)(uint32_t)w;
+      }
+    }
+    block_sync();
+    for (uint32_t b = threadIdx.x; b < FJ_MAX_BINS + 4; b += FJ_THREADS) hist[b] = 0;
+    block_sync();
+  }
+}
+static constexpr size_t fj_scatter_lds() { return 8 * (size_t)(FJ_TILE + 2) + 4 * (size_t)(2 * FJ_MAX_BINS + 4 + FJ_THREADS / WAVE) + 16; }
+
+// layout agreed by all ranks from global numbers only
+static gdf_error fj_plan(int world, int64_t build_rows_total, int64_t rows_max, double dup, int *fine_bits, int *coarse_bits, uint32_t *cap) {
+  GDF_REQUIRE(world >= 1 && fine_bits && coarse_bits && cap, GDF_INVALID_API_CALL);
+  const PartGeom g = choose_geometry((build_rows_total + world - 1) / world);
+  if (g.b3 != 0) return GDF_UNSUPPORTED_METHOD;                       // a rank's share needs a third level: not on this path
+  int cmax = 0;
+  while ((world << (cmax + 1)) <= FJ_MAX_BINS && cmax + 1 <= 8) ++cmax;
+  const int cmin = g.fb > 8 ? g.fb - 8 : 0;                            // the receiver's level 2 is at most 256-way
+  if (cmin > cmax || (world << cmax) > FJ_MAX_BINS) return GDF_UNSUPPORTED_METHOD;
+  int c1 = g.b1 < cmin ? cmin : (g.b1 > cmax ? cmax : g.b1);
+  if (c1 > g.fb - 1) c1 = g.fb - 1;                                    // the receiver's level 2 needs at least one bit
+  if (c1 < cmin || c1 < 0) return GDF_UNSUPPORTED_METHOD;
+  *fine_bits = g.fb;
+  *coarse_bits = c1;
+  // rows per (bin, XCD) region: workgroup b fills the regions of XCD b % 8, so a call with few workgroups spreads its rows
+  // over fewer than eight regions per bin (one workgroup: a single one)
+  const double nwg = std::ceil((double)(rows_max > 0 ? rows_max : 1) / (double)FJ_CHUNK);
+  const double per_xcd = std::max((double)rows_max / 8.0 * (1.0 + 8.0 / nwg), (double)std::min<int64_t>(rows_max, FJ_CHUNK));
+  const double mean = per_xcd / (double)((uint64_t)world << c1);
+  // + 6 standard deviations; `dup` = expected rows per distinct key (all copies of a key land in one region, so the
+  // variance grows with the multiplicity -- same term as the join's own speculative layout).  The slack travels: 6 sigma
+  // at C4's ten probe rows per key is +10 % on the links
+  if (!(dup >= 1.0)) dup = 1.0;
+  *cap = (uint32_t)(((uint64_t)(mean + 6.0 * std::sqrt(mean * (1.0 + dup)) + 64.0) + 63) / 64 * 64);
+  if ((uint64_t)(((uint64_t)world << c1) * 8) * *cap + FJ_TILE >= 0x7fffffffULL) return GDF_UNSUPPORTED_METHOD;
+  return GDF_SUCCESS;
+}
+
+static gdf_error fj_send(gdf_column *keys, int64_t lo, int64_t hi, int world, int coarse_bits, uint32_t cap, int32_t row_base,
+                         uint32_t *out_keys, int32_t *out_rows, uint32_t *out_fill, int *overflowed) {
+  GDF_REQUIRE(keys && out_keys && out_rows && out_fill && overflowed, GDF_DATASET_EMPTY);
+  GDF_REQUIRE(!keys->valid, GDF_VALIDITY_UNSUPPORTED);
+  const ElemKind kind = elem_kind(keys->dtype);
+  GDF_REQUIRE(kind == K_I64 || kind == K_I32, GDF_UNSUPPORTED_DTYPE);
+  GDF_REQUIRE(world >= 1 && coarse_bits >= 0 && ((uint64_t)world << coarse_bits) <= (uint64_t)FJ_MAX_BINS, GDF_INVALID_API_CALL);
+  GDF_REQUIRE(hi >= lo && (uint64_t)hi - (uint64_t)lo < 0xffffffffULL, GDF_INVALID_API_CALL);
+  GDF_REQUIRE(keys->size < (size_t)INT_MAX && (uint64_t)keys->size + (uint64_t)(uint32_t)row_base < (uint64_t)INT_MAX, GDF_COLUMN_SIZE_TOO_BIG);
+  const uint32_t nregions = ((uint32_t)world << coarse_bits) << 3;
+  HIP_TRY(hipMemsetAsync(out_fill, 0, sizeof(uint32_t) * ((size_t)nregions + 1), stream0()));      // [nregions]: the overflow flag
+  *overflowed = 0;
+  if (keys->size == 0) { HIP_TRY(hipStreamSynchronize(stream0())); return GDF_SUCCESS; }
+  GDF_REQUIRE(keys->data, GDF_DATASET_EMPTY);
+  FjSend a{};
+  a.keys = keys->data;
+  a.n = (uint32_t)keys->size;
+  a.lo = lo;
+  a.span = (unsigned long long)((uint64_t)hi - (uint64_t)lo);
+  a.world = (uint32_t)world;
+  a.c1 = coarse_bits;
+  a.cap = cap;
+  a.row_base = row_base;
+  a.chunk = (uint32_t)FJ_CHUNK;
+  a.out_keys = out_keys;
+  a.out_rows = out_rows;
+  a.fill = out_fill;
+  a.overflow = out_fill + nregions;
+  const unsigned grid = (unsigned)(((uint64_t)a.n + a.chunk - 1) / a.chunk);
+  const size_t lds = fj_scatter_lds();
+  if (kind == K_I64) {
+    HIP_TRY(hipFuncSetAttribute((const void *)fj_scatter<long long>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    GDF_LAUNCH("fj_scatter", fj_scatter<long long>, dim3(grid), dim3(FJ_THREADS), lds, stream0(), a);
+  } else {
+    HIP_TRY(hipFuncSetAttribute((const void *)fj_scatter<int>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    GDF_LAUNCH("fj_scatter", fj_scatter<int>, dim3(grid), dim3(FJ_THREADS), lds, stream0(), a);
+  }
+  HIP_CHECK_LAST();
+  uint32_t flag = 0;
+  HIP_TRY(read_back(&flag, out_fill + nregions, sizeof(flag)));
+  *overflowed = flag ? 1 : 0;
+  return GDF_SUCCESS;
+}
+
+// one level-2 pass over a receive buffer: `keys` = world blocks of (1 << (c1 + 3)) regions of `cap` keys, `fill` (device) the
+// matching fill counters, sender-major.  Appends into sb's level-2 buffer through `cursor` ([nfine + 2]: cursors | overflow flag
+// | tile count).  Launches only; `keep` receives the scratch that must outlive the kernels.
+static gdf_error fj_level2(const uint32_t *keys, const uint32_t *fill, uint32_t nseg, uint32_t cap, const PartGeom &g, uint32_t cap2,
+                           int32_t row_base, uint32_t *cursor, Tuples out, std::deque<DevBuf> *keep) {
+  const uint32_t nfine = 1u << g.fb;
+  const int sc2_threads = level2_threads(1024);
+  const int64_t TILE2 = (int64_t)sc2_threads * JK_SC_ITEMS;
+  keep->emplace_back();
+  DevBuf &d_map = keep->back();
+  RMM_TRY(d_map.alloc(sizeof(uint32_t) * (3 * (size_t)nseg + 2)));
+  uint32_t *seg_begin = d_map.as<uint32_t>(), *seg_end = seg_begin + nseg, *tile_prefix = seg_end + nseg;
+  uint32_t *ntiles_dev = cursor + nfine + 1;
+  hipLaunchKernelGGL(jk_make_l2map, dim3(1), dim3(JK_BK_THREADS), 0, stream0(), fill, nseg, cap, (uint32_t)TILE2, seg_begin, seg_end, tile_prefix,
+                     ntiles_dev, g.world, 1u << g.b1);
+  HIP_CHECK_LAST();
+  PartGeom g2 = g;
+  g2.cap1 = 0;
+  g2.cap2 = cap2;
+  g2.dump = nfine * cap2;
+  g2.spec_flag = cursor + nfine;
+  g2.row_base = row_base;
+  Level2Map m{seg_begin, seg_end, tile_prefix, 0};
+  m.ntiles_dev = ntiles_dev;
+  m.nseg = nseg;
+  m.keys32 = keys;
+  const uint32_t tile_bound = (uint32_t)(((uint64_t)nseg * cap) / (uint64_t)TILE2) + nseg + 1;
+  GDF_TRY(launch_scatter2(true, sc2_threads, tile_bound, g2, m, Tuples{nullptr, nullptr}, cursor, out));
+  return GDF_SUCCESS;
+}
+
+static PartGeom fj_geometry(int world, int fine_bits, int coarse_bits, int64_t lo) {
+  PartGeom g{};
+  g.fb = fine_bits;
+  g.b1 = coarse_bits;
+  g.b2 = fine_bits - coarse_bits;
+  g.kbias = (uint64_t)lo;
+  g.world = (uint32_t)world;
+  return g;
+}
+
+// the received build relation -> a PreparedBuild whose partitions live in the speculative layout
+static gdf_error fj_build_create(const uint32_t *recv_keys, const uint32_t *recv_fill, int world, int64_t lo, int fine_bits, int coarse_bits,
+                                 uint32_t cap, int64_t expected_rows, PreparedBuild **out) {
+  GDF_REQUIRE(recv_keys && recv_fill && out, GDF_DATASET_EMPTY);
+  GDF_REQUIRE(fine_bits >= 1 && fine_bits <= JK_MAX_FB && coarse_bits >= 0 && fine_bits - coarse_bits >= 1 && fine_bits - coarse_bits <= 8,
+              GDF_INVALID_API_CALL);
+  std::unique_ptr<PreparedBuild> pb(new PreparedBuild());
+  pb->ncols = 1;
+  pb->fj = true;
+  gdf_column_view(&pb->cols[0], nullptr, nullptr, 0, GDF_INT32);
+  pb->colp[0] = &pb->cols[0];
+  pb->table = KeyTable{};
+  pb->table.ncols = 1;
+  pb->table.col[0] = ColView{nullptr, nullptr, (int)K_I32, 4};
+  BuildSide &bs = pb->side;
+  bs.plan = KeyPlan{};
+  bs.plan.mode = KM_RAW_INT;
+  bs.plan.narrow = 1;
+  bs.plan.kmin = (uint64_t)lo;
+  bs.g = fj_geometry(world, fine_bits, coarse_bits, lo);
+  const uint32_t nfine = 1u << fine_bits, nseg = ((uint32_t)world << coarse_bits) << 3;
+  const double mean = (double)(expected_rows > 0 ? expected_rows : 1) / (double)nfine;
+  const uint32_t cap2 = (uint32_t)(((uint64_t)(mean * 1.03 + 8.0 * std::sqrt(mean * 2.0) + 64.0) + 7) / 8 * 8);
+  const uint64_t size2 = (uint64_t)nfine * cap2 + 16384;
+  if (size2 >= 0x7fffffffULL) return GDF_UNSUPPORTED_METHOD;
+  DevBuf cursor;
+  RMM_TRY(cursor.alloc(sizeof(uint32_t) * ((size_t)nfine + 2)));
+  hipLaunchKernelGGL(jk_init_cursor, dim3(32), dim3(256), 0, stream0(), cursor.as<uint32_t>(), nfine, cap2);
+  HIP_TRY(hipMemsetAsync(cursor.as<uint32_t>() + nfine + 1, 0, sizeof(uint32_t), stream0()));
+  RMM_TRY(bs.B.w[1].alloc(sizeof(uint64_t) * size2));
+  std::deque<DevBuf> keep;
+  GDF_TRY(fj_level2(recv_keys, recv_fill, nseg, cap, bs.g, cap2, 0, cursor.as<uint32_t>(), bs.B.tuples(1), &keep));
+  std::vector<uint32_t> cur((size_t)nfine + 1);
+  HIP_TRY(read_back(cur.data(), cursor.p, sizeof(uint32_t) * ((size_t)nfine + 1)));
+  if (cur[nfine]) return GDF_UNSUPPORTED_METHOD;                      // a fine partition outgrew its room (skewed build keys)
+  bs.B.final_buf = 1;
+  bs.B.fine_begin.resize(nfine);
+  bs.B.fine_cnt.resize(nfine);
+  uint64_t total = 0;
+  uint32_t largest = 0;
+  for (uint32_t f = 0; f < nfine; ++f) {
+    bs.B.fine_begin[f] = f * cap2;
+    bs.B.fine_cnt[f] = cur[f] - f * cap2;
+    total += bs.B.fine_cnt[f];
+    largest = std::max(largest, bs.B.fine_cnt[f]);
+  }
+  if (largest > (uint32_t)JK_MAX_BUILD) return GDF_UNSUPPORTED_METHOD;  // would need the global-table path, which wants the exact layout
+  bs.B.joinable = (uint32_t)total;
+  bs.B.speculative = true;
+  pb->table.nrows = (int64_t)total;
+  RMM_TRY(bs.B.d_begin.alloc(sizeof(uint32_t) * nfine));
+  RMM_TRY(bs.B.d_cnt.alloc(sizeof(uint32_t) * nfine));
+  HIP_TRY(hipMemcpyAsync(bs.B.d_begin.p, bs.B.fine_begin.data(), sizeof(uint32_t) * nfine, hipMemcpyHostToDevice, stream0()));
+  HIP_TRY(hipMemcpyAsync(bs.B.d_cnt.p, bs.B.fine_cnt.data(), sizeof(uint32_t) * nfine, hipMemcpyHostToDevice, stream0()));
+  HIP_TRY(hipStreamSynchronize(stream0()));
+  pb->partitioned = true;
+  *out = pb.release();
+  return GDF_SUCCESS;
+}
+
+static gdf_error fj_probe_add(ProbeAccum *a, const uint32_t *recv_keys, const uint32_t *recv_fill, uint32_t cap, int64_t position_base,
+                              int64_t buffer_elems) {
+  GDF_REQUIRE(a && recv_keys && recv_fill, GDF_DATASET_EMPTY);
+  GDF_REQUIRE(a->pb->fj, GDF_INVALID_API_CALL);
+  if (a->failed) return GDF_UNSUPPORTED_METHOD;
+  GDF_REQUIRE(position_base >= 0 && position_base + buffer_elems < (int64_t)INT_MAX, GDF_COLUMN_SIZE_TOO_BIG);
+  const PartGeom &g = a->pb->side.g;
+  const uint32_t nfine = 1u << g.fb, nseg = (g.world << g.b1) << 3;
+  if (!a->app.started) {
+    const uint64_t size2 = (uint64_t)nfine * a->app.cap2 + 16384;
+    RMM_TRY(a->app.cursor.alloc(sizeof(uint32_t) * ((size_t)nfine + 2)));
+    hipLaunchKernelGGL(jk_init_cursor, dim3(32), dim3(256), 0, stream0(), a->app.cursor.as<uint32_t>(), nfine, a->app.cap2);
+    RMM_TRY(a->P.w[1].alloc(sizeof(uint64_t) * size2));
+    a->app.started = true;
+  }
+  GDF_TRY(fj_level2(recv_keys, recv_fill, nseg, cap, g, a->app.cap2, (int32_t)position_base, a->app.cursor.as<uint32_t>(), a->P.tuples(1), &a->keep));
+  a->app.rows = position_base + buffer_elems;       // positions are numbered across the slices' receive buffers
   return GDF_SUCCESS;
 }
 
@@ -3002,6 +3354,26 @@ __attribute__((visibility("default"))) gdf_error gdf_amd_join_probe_add(gdf_amd_
 __attribute__((visibility("default"))) gdf_error gdf_amd_join_probe_finish(gdf_amd_join_probe *probe, gdf_column *probe_indices,
                                                                           gdf_column *build_indices) {
   return accum_finish(reinterpret_cast<ProbeAccum *>(probe), probe_indices, build_indices);
+}
+
+// fused multi-GPU join (include/gdf/gdf_amd_ext.h)
+__attribute__((visibility("default"))) gdf_error gdf_amd_fj_plan(int world, int64_t build_rows_total, int64_t rows_max, double rows_per_key,
+                                                                int *fine_bits, int *coarse_bits, uint32_t *cap) {
+  return fj_plan(world, build_rows_total, rows_max, rows_per_key, fine_bits, coarse_bits, cap);
+}
+__attribute__((visibility("default"))) gdf_error gdf_amd_fj_send(gdf_column *keys, int64_t lo, int64_t hi, int world, int coarse_bits, uint32_t cap,
+                                                                int32_t row_base, uint32_t *out_keys, int32_t *out_rows, uint32_t *out_fill,
+                                                                int *overflowed) {
+  return fj_send(keys, lo, hi, world, coarse_bits, cap, row_base, out_keys, out_rows, out_fill, overflowed);
+}
+__attribute__((visibility("default"))) gdf_error gdf_amd_fj_build_create(const uint32_t *recv_keys, const uint32_t *recv_fill, int world, int64_t lo,
+                                                                        int fine_bits, int coarse_bits, uint32_t cap, int64_t expected_rows,
+                                                                        gdf_amd_join_build **out) {
+  return fj_build_create(recv_keys, recv_fill, world, lo, fine_bits, coarse_bits, cap, expected_rows, reinterpret_cast<PreparedBuild **>(out));
+}
+__attribute__((visibility("default"))) gdf_error gdf_amd_fj_probe_add(gdf_amd_join_probe *probe, const uint32_t *recv_keys, const uint32_t *recv_fill,
+                                                                     uint32_t cap, int64_t position_base, int64_t buffer_elems) {
+  return fj_probe_add(reinterpret_cast<ProbeAccum *>(probe), recv_keys, recv_fill, cap, position_base, buffer_elems);
 }
 
 gdf_error gdf_inner_join(gdf_column **left_cols, int num_left_cols, int left_join_cols[], gdf_column **right_cols,

@@ -476,6 +476,167 @@ def broadcast_inner_join(probe_keys, build_keys, join_fn=_device_join_columns, g
     return ShardedPairs([_LocalRows(me)], _GatheredRows(gathered, bounds), [li], [ri])
 
 
+# ---- fused join: the sender runs the join's level-1 regroup -----------------------------------------------------------------
+class FusedPairs:
+    """This rank's share of a fused_inner_join: index pairs into its RECEIVE buffers (probe positions are numbered across
+    the slices' buffers).  ``global_ids()`` turns them into (owner rank << 40) | row; it is a COLLECTIVE -- the row numbers
+    stayed with the senders (they never travel in the timed path) and are fetched with one exchange per buffer."""
+
+    def __init__(self, probe_layout, build_layout, group, probe_pos, build_pos, build_rows_buf, probe_rows_bufs, keep=None):
+        self.probe_layout, self.build_layout, self.group = probe_layout, build_layout, group
+        self.probe_pos, self.build_pos = probe_pos, build_pos
+        self._build_rows, self._probe_rows = build_rows_buf, probe_rows_bufs
+        self._keep = keep                                            # the build handle: the pairs index its receive buffer
+
+    def numel(self):
+        return int(self.probe_pos.numel())
+
+    def _rows_of(self, rows_buf, layout):
+        """the row numbers of the keys this rank received from every sender: the senders' blocks for this rank, sender-major"""
+        import torch
+        import torch.distributed as dist
+        world = dist.get_world_size(self.group)
+        blk = layout.block
+        recv = torch.empty(world * blk, dtype=rows_buf.dtype, device=rows_buf.device)
+        _all_to_all_v(recv, rows_buf[:world * blk], [blk] * world, [blk] * world, self.group, async_op=False)
+        return recv
+
+    def global_ids(self):
+        import torch
+        as_tensor = lambda x: x.tensor() if hasattr(x, "tensor") else x
+        b = as_tensor(self.build_pos).long()
+        brows = self._rows_of(self._build_rows, self.build_layout)
+        bg = ((b // self.build_layout.block) << 40) | brows[b].long()
+        blk = self.probe_layout.block
+        per_buf = self.probe_layout.world * blk
+        p = as_tensor(self.probe_pos).long()
+        pg = torch.empty_like(p)
+        which = p // per_buf
+        for i, rows_buf in enumerate(self._probe_rows):            # every rank walks all slices: the exchange is collective
+            prow = self._rows_of(rows_buf, self.probe_layout)
+            sel = which == i
+            if bool(sel.any()):
+                q = p[sel] - i * per_buf
+                pg[sel] = ((q // blk) << 40) | prow[q].long()
+        return pg, bg
+
+
+def _fj_send(keys, lo, hi, layout, row_base):
+    from . import api
+    from .columns import Column
+    return api.fj_send(Column(keys), lo, hi, layout, row_base)
+
+
+def _fj_build(recv_keys, recv_fill, lo, layout, expected_rows):
+    from . import api
+    return api.FjBuild(recv_keys, recv_fill, lo, layout, expected_rows)
+
+
+def _fj_plan(world, build_total, rows_max, rows_per_key=1.0):
+    from . import api
+    return api.fj_plan(world, build_total, rows_max, rows_per_key)
+
+
+def fused_inner_join(probe_keys, build_keys, group=None, chunks=4, plan_fn=_fj_plan, send_fn=_fj_send, build_fn=_fj_build):
+    """Inner join of two row-sharded relations on one integer key column with the rank split FUSED into the join's own
+    partitioning (csrc/join.hip "FUSED multi-GPU join"): every rank regroups its rows by (owner rank, coarse partition on that
+    rank) -- the join's level-1 pass, writing narrowed 4-byte keys -- ships each rank its block (4 B per row on the links, fixed
+    block sizes: no count exchange before the data) and continues at level 2 on what it received.  Against the key shuffle
+    (distributed_inner_join) a rank saves one pass over its rows on each side of the links.
+
+    Returns a :class:`FusedPairs`, or ``None`` when the shape does not fit (keys that do not narrow to 32 bits, a world size /
+    relation size outside gdf_amd_fj_plan's range, skewed keys that overflow the fixed-size regions) -- ON ALL RANKS, so that
+    the caller can fall back to ``distributed_inner_join`` collectively."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    dev = probe_keys.device
+    narrow = _narrow_range(probe_keys, build_keys, group)
+    mine = torch.tensor([probe_keys.numel(), build_keys.numel()], dtype=torch.int64, device=dev)
+    sizes = torch.empty(2 * world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(sizes, mine, group=group)
+    sizes = sizes.view(world, 2).tolist()
+    p_max, b_max = max(int(x[0]) for x in sizes), max(int(x[1]) for x in sizes)
+    p_total, b_total = sum(int(x[0]) for x in sizes), sum(int(x[1]) for x in sizes)
+    if narrow is None or b_total == 0 or p_total == 0:
+        return None
+    lo, hi = narrow
+    chunks = max(1, min(int(chunks), p_max))
+    step_max = (p_max + chunks - 1) // chunks
+    lay_b = plan_fn(world, b_total, b_max, 1.0)
+    lay_p = plan_fn(world, b_total, step_max, max(1.0, p_total / max(b_total, 1)))
+    if lay_b is None or lay_p is None:
+        return None
+
+    def agree(flag):
+        """True on every rank iff `flag` is False on all of them (one tiny all-reduce): a region overflow anywhere sends
+        EVERY rank back to the shuffle"""
+        t = torch.tensor([1 if flag else 0], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        return int(t.item()) == 0
+
+    def exchange(keys_buf, fill, layout, async_op):
+        blk, rpr = layout.block, layout.regions_per_rank
+        rk = torch.empty(world * blk, dtype=keys_buf.dtype, device=dev)
+        rf = torch.empty(world * rpr + 2, dtype=fill.dtype, device=dev)        # (+ 2: the library's flag / tile-count words are elsewhere; slack)
+        works = _all_to_all_v(rk, keys_buf[:world * blk], [blk] * world, [blk] * world, group, async_op)
+        works += _all_to_all_v(rf[:world * rpr], fill[:world * rpr], [rpr] * world, [rpr] * world, group, async_op)
+        return rk, rf, works
+
+    def wait(works):
+        for w in works:
+            if w is not None:
+                w.wait()
+
+    # ---- build relation ----
+    bk, brows, bfill, over = send_fn(build_keys, lo, hi, lay_b, 0)
+    if not agree(over):
+        return None
+    rbk, rbf, works = exchange(bk, bfill, lay_b, async_op=True)
+    # ---- probe relation, sliced and software-pipelined as in distributed_inner_join ----
+    n = probe_keys.numel()
+    step = (n + chunks - 1) // chunks
+    build = acc = None
+    probe_rows, failed = [], False
+    pending = None
+    per_buf = world * lay_p.block
+    for c in range(chunks):
+        a, b = min(n, c * step), min(n, (c + 1) * step)
+        pk, prow, pfill, over = send_fn(probe_keys[a:b], lo, hi, lay_p, a)
+        failed = failed or over
+        probe_rows.append(prow)
+        x = exchange(pk, pfill, lay_p, async_op=True) + (pk, pfill)              # the send buffers stay alive with the works
+        if build is None:
+            wait(works)
+            try:
+                build = build_fn(rbk, rbf, lo, lay_b, b_total // world + 1)
+                acc = build.accumulate(p_total // world + 1)
+            except GDFError as e:
+                if e.errcode != GDF_UNSUPPORTED_METHOD:
+                    raise
+                failed = True
+        if pending is not None:
+            wait(pending[2])
+            if acc is not None and not failed:
+                acc.add_recv(pending[0], pending[1], lay_p, (c - 1) * per_buf)
+        pending = x
+    wait(pending[2])
+    if acc is not None and not failed:
+        acc.add_recv(pending[0], pending[1], lay_p, (chunks - 1) * per_buf)
+    li = ri = None
+    if acc is not None and not failed:
+        try:
+            li, ri = acc.finish(copy=False)
+        except GDFError as e:
+            if e.errcode != GDF_UNSUPPORTED_METHOD:
+                raise
+            failed = True
+    ok = agree(failed or li is None)
+    if build is not None and not ok:
+        build.close()
+    return FusedPairs(lay_p, lay_b, group, li, ri, brows, probe_rows, keep=build) if ok else None
+
+
 # ---- planner ------------------------------------------------------------------------------------------------------------
 # Cost model of the two join strategies for one rank, in seconds.  Constants are measurements of this library on one
 # MI355X (DESIGN.md section 6, profiles/): the local passes per row, and what one xGMI link sustains in one direction
@@ -483,7 +644,9 @@ def broadcast_inner_join(probe_keys, build_keys, join_fn=_device_join_columns, g
 # boxes have none).  xGMI is point-to-point: with `world` GPUs a rank talks to each peer over ONE link, so an all-to-all
 # of V bytes per rank puts V / world on every link, and the time is that of the busiest link, not of the aggregate.
 XGMI_LINK_BYTES_PER_S = 60e9
-_SHUFFLE_LOCAL_S_PER_ROW = 16.8e-12      # sender split + receiver partition + probe, per row of (probe + build): 18.9 ms at C4 shard sizes
+_SHUFFLE_LOCAL_S_PER_ROW = 15.1e-12      # sender split + receiver partition + probe, per row of (probe + build): 17.0 ms at C4 shard sizes
+_FUSED_LOCAL_S_PER_ROW = 11.8e-12        # sender level 1 + receiver level 2 + probe: 13.3 ms at C4 shard sizes (tools/sim_c4_fused.py)
+_FUSED_BYTES_PER_ROW = 4.45              # 4-byte keys in fixed-size regions: + 6 sigma of room (11 % at ten probe rows per key)
 _JOIN_S_PER_PROBE_ROW = 9.6e-12          # gdf_inner_join, NARROW keys: 10.6 ms for 1e9 x 1e8
 _JOIN_S_PER_BUILD_ROW = 10e-12
 _LEVEL3_BUILD_ROWS = 1.6e8               # larger build relations take a third partitioning level (csrc/join.hip refine_side):
@@ -498,23 +661,29 @@ def estimate_join_seconds(world, probe_rows, build_rows, key_bytes=4.125):
     rows = probe_rows + build_rows
     shuffle_link = rows * key_bytes / max(world, 1) / XGMI_LINK_BYTES_PER_S if world > 1 else 0.0
     shuffle = max(shuffle_link, _SHUFFLE_LOCAL_S_PER_ROW * rows)
+    fused_link = rows * _FUSED_BYTES_PER_ROW / max(world, 1) / XGMI_LINK_BYTES_PER_S if world > 1 else 0.0
+    fused = max(fused_link, _FUSED_LOCAL_S_PER_ROW * rows)
     gathered = build_rows * world
     bcast_link = build_rows * 4.0 / XGMI_LINK_BYTES_PER_S if world > 1 else 0.0        # every peer's shard arrives over its own link
     local = _NARROW_S_PER_ROW * rows + _JOIN_S_PER_PROBE_ROW * probe_rows + _JOIN_S_PER_BUILD_ROW * gathered
     if gathered > _LEVEL3_BUILD_ROWS:
         local += _LEVEL3_S_PER_PROBE_ROW * probe_rows + _LEVEL3_S_PER_BUILD_ROW * gathered
-    return {"shuffle": shuffle, "broadcast": max(bcast_link, local)}
+    return {"shuffle": shuffle, "fused": fused, "broadcast": max(bcast_link, local)}
 
 
 def choose_join_strategy(world, probe_rows, build_rows):
-    """"shuffle" (hash-partition both relations, RCCL all-to-all) or "broadcast" (all-gather the build keys, probe rows stay
-    home) -- whichever the cost model above expects to finish first.  With C4's shard sizes: broadcast at 2 GPUs (the shuffle
-    would push 2.3 GB through the one link between them), shuffle at 4 and 8."""
+    """"fused" (sender-side level 1, 4-byte keys in fixed-size blocks), "shuffle" (stable key split + bitmaps, RCCL all-to-all)
+    or "broadcast" (all-gather the build keys, probe rows stay home) -- whichever the cost model above expects to finish
+    first.  With C4's shard sizes: broadcast at 2 GPUs (either exchange of the probe side would push > 2 GB through the one
+    link between them), the shuffle at 4 (both exchanges are link-bound there and the shuffle sends exact sizes, the fused blocks
+    carry 11 % of room), the fused exchange at 8 (local passes bound both: 13.3 against 17.0 ms)."""
     est = estimate_join_seconds(world, probe_rows, build_rows)
-    return "broadcast" if est["broadcast"] < est["shuffle"] else "shuffle"
+    moving = min(("fused", "shuffle"), key=lambda k: est[k])                  # (fused falls back to the shuffle when its shape checks fail)
+    # moving the probe relation rests on the ASSUMED link rate; leaving it at home does not: the exchange has to win by 10 %
+    return moving if est[moving] < 0.9 * est["broadcast"] else "broadcast"
 
 
-def planned_inner_join(probe_keys, build_keys, group=None, shuffle_kw=None, broadcast_kw=None):
+def planned_inner_join(probe_keys, build_keys, group=None, shuffle_kw=None, broadcast_kw=None, fused_kw=None):
     """distributed_inner_join or broadcast_inner_join, chosen by choose_join_strategy from the GLOBAL shard sizes (one
     all-gather of two numbers, so that every rank takes the same branch)."""
     import torch
@@ -526,8 +695,13 @@ def planned_inner_join(probe_keys, build_keys, group=None, shuffle_kw=None, broa
     sizes = sizes.view(world, 2).tolist()
     p = max(int(x[0]) for x in sizes)
     b = max(int(x[1]) for x in sizes)
-    if choose_join_strategy(world, p, b) == "broadcast":
+    strategy = choose_join_strategy(world, p, b)
+    if strategy == "broadcast":
         return broadcast_inner_join(probe_keys, build_keys, group=group, **(broadcast_kw or {}))
+    if strategy == "fused":
+        pairs = fused_inner_join(probe_keys, build_keys, group=group, **(fused_kw or {}))
+        if pairs is not None:                          # None on ALL ranks: the shape did not fit, take the shuffle together
+            return pairs
     return distributed_inner_join(probe_keys, build_keys, group=group, **(shuffle_kw or {}))
 
 

@@ -1,0 +1,90 @@
+"""-m gpu: the FUSED multi-GPU join (gdf_amd_fj_*: the sender runs the join's level-1 regroup, the receiver continues at
+level 2) on one GPU.
+
+A rank's send buffer is `world` blocks, one per destination; a receive buffer is `world` blocks, one per sender, in the same
+layout.  Feeding a sender's whole buffer back as the receive buffer therefore emulates `world` senders on one device: the
+receiver does not look at the rank bits, so the result must be the plain join of the two relations -- for every world
+size, with the probe relation arriving in slices, against the oracle."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _fused_self_join(gdf, probe, build, world, slices):
+    import torch
+    from libgdf_amd import api
+    from libgdf_amd.columns import Column
+    lo, hi = int(build.min()), int(build.max())
+    nb, npr = len(build), len(probe)
+    step = (npr + slices - 1) // slices
+    lay_b = api.fj_plan(world, nb * world, nb)               # (a rank's share of world x nb rows is nb: this "rank" receives all of it)
+    lay_p = api.fj_plan(world, nb * world, step, max(1.0, npr / nb))
+    assert lay_b is not None and lay_p is not None
+    assert (world << lay_b.coarse_bits) <= 1024 and 1 <= lay_b.fine_bits - lay_b.coarse_bits <= 8
+    tb = torch.from_numpy(build).cuda()
+    tp = torch.from_numpy(probe).cuda()
+    bk, brows, bfill, over = api.fj_send(Column(tb), lo, hi, lay_b, 0)
+    assert not over
+    kept = int(bfill[:lay_b.nregions].sum())
+    assert kept == nb                                            # every build key is inside its own range
+    b = api.FjBuild(bk, bfill, lo, lay_b, nb)
+    acc = b.accumulate(npr)
+    prows = []
+    per_buf = world * lay_p.block
+    for i in range(slices):
+        a0, a1 = min(npr, i * step), min(npr, (i + 1) * step)
+        pk, prow, pfill, over = api.fj_send(Column(tp[a0:a1]), lo, hi, lay_p, a0)
+        assert not over
+        acc.add_recv(pk, pfill, lay_p, i * per_buf)
+        prows.append(prow)
+    li, ri = acc.finish()
+    li, ri = li.long(), ri.long()
+    rows_b = brows[ri].cpu().numpy().astype(np.int64)
+    which = li // per_buf
+    rows_p = np.empty(li.numel(), dtype=np.int64)
+    for i in range(slices):
+        sel = (which == i)
+        if bool(sel.any()):
+            rows_p[sel.cpu().numpy()] = prows[i][li[sel] - i * per_buf].cpu().numpy()
+    # the owner of a received key is the block it sits in: block index = mulhi(hash, world) of the key, checked on the build side
+    assert int((ri // lay_b.block).max()) < world
+    b.close()
+    return rows_p, rows_b
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+@pytest.mark.parametrize("dtype", [np.int64, np.int32])
+def test_fused_join_equals_plain_join(gdf, world, dtype):
+    rs = np.random.RandomState(100 + world)
+    nb, npr = 60_000, 400_000
+    base = (1 << 40) if dtype == np.int64 else -5000
+    build = (rs.permutation(nb * 2)[:nb] + base).astype(dtype)                   # unique keys
+    probe = (rs.randint(-1000, nb * 2 + 1000, size=npr) + base).astype(dtype)    # some outside the build range, some misses inside
+    gp, gb = _fused_self_join(gdf, probe, build, world, slices=3)
+    el, er = oracle.join([probe], [build], "inner")
+    got = np.stack([gp, gb], axis=1)
+    exp = np.stack([el, er], axis=1)
+    np.testing.assert_array_equal(got[np.lexsort(got.T[::-1])], exp[np.lexsort(exp.T[::-1])])
+
+
+def test_fused_join_duplicate_build_keys_and_large(gdf):
+    rs = np.random.RandomState(7)
+    nb, npr = 3_000_000, 9_000_000
+    build = rs.randint(0, nb // 2, size=nb).astype(np.int64)                     # every key ~2 times: multimap units
+    probe = rs.randint(0, nb // 2, size=npr).astype(np.int64)
+    gp, gb = _fused_self_join(gdf, probe, build, 8, slices=4)
+    assert bool((probe[gp] == build[gb]).all())
+    mult = np.bincount(build, minlength=nb // 2)
+    assert len(gp) == int(mult[probe].sum())
+    assert len(np.unique(gp * nb + gb)) == len(gp)
+
+
+def test_fused_plan_declines_what_it_cannot_take(gdf):
+    from libgdf_amd import api
+    assert api.fj_plan(64, 10**9, 10**8) is None                                 # 64 ranks x 128 coarse partitions > 1024 bins
+    assert api.fj_plan(8, 4 * 10**9, 5 * 10**8) is None                          # a rank's share needs a third partitioning level
+    lay = api.fj_plan(8, 10**9, 125 * 10**6)
+    assert lay is not None and lay.fine_bits == 15 and lay.coarse_bits == 7 and lay.world * (1 << lay.coarse_bits) == 1024

@@ -239,6 +239,29 @@ def test_int64_keys_wider_than_32_bits(gdf, how):
     _check(gdf, [probe], [build], how)
 
 
+@pytest.mark.parametrize("how", ["inner", "left"])
+def test_wide_keys_lean_kernel_and_fold_collisions(gdf, how, monkeypatch):
+    """64-bit keys spread over 2^60 take the WIDE tuples and (round 2) the lean write kernel; keys that share their 32-bit
+    fold (lo ^ hi * 0x9e3779b1) land in one partition and in the same slot of cuckoo table 0 -- six of them per fold value
+    here, which only settles because table 1 hashes an independent second fold (csrc/join.hip key_fold2)."""
+    monkeypatch.setenv("GDF_JK_SPEC_MIN", "1000")
+    rs = np.random.RandomState(11)
+    nb = 300_000
+    build = rs.randint(0, 2**60, size=nb, dtype=np.int64)
+    C = np.uint64(0x9e3779b1)
+    fam = []
+    for x in rs.randint(0, 2**32, size=400, dtype=np.int64):
+        for hi in rs.randint(1, 2**27, size=6, dtype=np.int64):
+            lo = (np.uint64(x) ^ ((np.uint64(hi) * C) & np.uint64(0xffffffff))) & np.uint64(0xffffffff)
+            fam.append(int((np.uint64(hi) << np.uint64(32)) | lo))
+    build = np.unique(np.concatenate([build, np.array(fam, dtype=np.int64)]))
+    rs.shuffle(build)
+    probe = np.concatenate([build[rs.randint(0, len(build), size=1_500_000)], np.array(fam * 3, dtype=np.int64),
+                            rs.randint(0, 2**60, size=200_000, dtype=np.int64)])
+    rs.shuffle(probe)
+    _check(gdf, [probe], [build], how)
+
+
 def test_multigpu_layer_world_size_one(gdf):
     """libgdf_amd/multigpu.py end to end on the GPU with a 1-rank RCCL group: device-side gdf_hash_partition,
     all_to_all_single, local gdf_inner_join, global row ids.  (2-rank exchange logic: tests/test_multigpu_gloo.py.)"""

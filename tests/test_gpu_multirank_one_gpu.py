@@ -89,6 +89,9 @@ def _worker(rank, world, port, big, q):
     pg, bg = pairs.global_ids()
     bpairs = multigpu.broadcast_inner_join(p, b)
     bpg, bbg = bpairs.global_ids()
+    # the fused variant (sender-side level 1, receiver continues at level 2): None on ALL ranks when the shape does not fit
+    fpairs = multigpu.fused_inner_join(p, b)
+    fpg, fbg = fpairs.global_ids() if fpairs is not None else (None, None)
     # group-by-sum of (key % 1000, key): local pre-aggregation, exchange of the partial sums, final aggregation
     gk, gv = multigpu.distributed_group_by_sum(p % 1000, p)
     others = {}
@@ -96,7 +99,8 @@ def _worker(rank, world, port, big, q):
         ok, ov = multigpu.distributed_group_by(op, p % 1000, p)
         others[op] = (ok.cpu().numpy(), ov.cpu().numpy())
     q.put((rank, len(pairs.probe_pos), pg.cpu().numpy(), bg.cpu().numpy(), bpg.cpu().numpy(), bbg.cpu().numpy(),
-           gk.cpu().numpy(), gv.cpu().numpy(), others))
+           gk.cpu().numpy(), gv.cpu().numpy(), others,
+           None if fpg is None else fpg.cpu().numpy(), None if fbg is None else fbg.cpu().numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -132,6 +136,9 @@ def test_device_path_at_world_sizes_2_and_3(world, big):
         got = np.concatenate([np.stack([res[a], res[b]], axis=1) for res in results])
         got = got[np.lexsort(got.T[::-1])]
         np.testing.assert_array_equal(got, exp)
+    assert all(res[9] is not None for res in results)          # these shapes fit the fused path on every rank
+    got = np.concatenate([np.stack([res[9], res[10]], axis=1) for res in results])
+    np.testing.assert_array_equal(got[np.lexsort(got.T[::-1])], exp)
     if big:
         assert all(res[1] == 1 for res in results)          # the received slices were accumulated and probed once
     allp = np.concatenate(probes)

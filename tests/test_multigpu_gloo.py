@@ -95,7 +95,8 @@ def _worker(rank, world, port, q):
     # the planner's entry point takes one of the two branches on ALL ranks (it decides from the global shard sizes)
     ppairs = multigpu.planned_inner_join(torch.from_numpy(probes[rank]), torch.from_numpy(builds[rank]),
                                          shuffle_kw=dict(shuffle_fn=_np_shuffle, join_fn=_np_join, prepare_fn=None),
-                                         broadcast_kw=dict(join_fn=_np_join, narrow_fn=_np_narrow))
+                                         broadcast_kw=dict(join_fn=_np_join, narrow_fn=_np_narrow),
+                                         fused_kw=dict(plan_fn=_np_fj_plan, send_fn=_np_fj_send, build_fn=_NpFjBuild))
     assert ppairs.numel() == (bpairs.numel() if multigpu.choose_join_strategy(world, 3000 + 17 * (world - 1), 400 + 5 * (world - 1)) == "broadcast"
                               else pairs.numel())
     k = torch.from_numpy(probes[rank])
@@ -214,9 +215,116 @@ def test_planner_cost_model():
     rank's egress spreads over 3 / 7 links and the gathered build relation outgrows its advantage -> shuffle."""
     from libgdf_amd import multigpu
     assert multigpu.choose_join_strategy(2, 10**9, 125 * 10**6) == "broadcast"
-    assert multigpu.choose_join_strategy(4, 10**9, 125 * 10**6) == "shuffle"
-    assert multigpu.choose_join_strategy(8, 10**9, 125 * 10**6) == "shuffle"
+    assert multigpu.choose_join_strategy(4, 10**9, 125 * 10**6) == "shuffle"      # link-bound at 4: the shuffle's exact sizes beat the fused blocks' 11 % of room
+    assert multigpu.choose_join_strategy(8, 10**9, 125 * 10**6) == "fused"
     est = multigpu.estimate_join_seconds(8, 10**9, 125 * 10**6)
-    assert 0.015 < est["shuffle"] < 0.025                       # the local passes bound it (18.9 ms measured), not the links
+    assert 0.015 < est["shuffle"] < 0.025                       # the local passes bound it (17 ms measured), not the links
+    assert est["fused"] < est["shuffle"]
     # a tiny build relation is always cheaper to replicate than to shuffle the probe side
     assert multigpu.choose_join_strategy(8, 10**9, 10**5) == "broadcast"
+
+
+# ---- fused_inner_join: the orchestration with numpy stand-ins for the gdf_amd_fj_* entry points ----------------------------
+class _NpLayout:
+    """one region per destination rank, room for every row of a call"""
+    def __init__(self, world, rows_max):
+        self.world, self.cap = world, rows_max + 1
+        self.regions_per_rank, self.block, self.nregions = 1, rows_max + 1, world
+
+
+def _np_fj_plan(world, build_total, rows_max, rows_per_key=1.0):
+    return _NpLayout(world, rows_max)
+
+
+def _np_fj_send(keys, lo, hi, layout, row_base):
+    k = keys.numpy()
+    inside = (k >= lo) & (k <= hi)
+    k32 = (k - lo).astype(np.int64)
+    rank = oracle.partition_ids([k32.astype(np.int32)], layout.world).astype(np.int64) if len(k) else np.zeros(0, np.int64)
+    kb = np.zeros(layout.world * layout.block, dtype=np.int32)
+    rb = np.full(layout.world * layout.block, -1, dtype=np.int32)
+    fill = np.zeros(layout.nregions + 1, dtype=np.int32)
+    for r in range(layout.world):
+        sel = np.flatnonzero(inside & (rank == r))
+        kb[r * layout.block:r * layout.block + len(sel)] = k32[sel]
+        rb[r * layout.block:r * layout.block + len(sel)] = sel + row_base
+        fill[r] = len(sel)
+    return torch.from_numpy(kb), torch.from_numpy(rb), torch.from_numpy(fill), False
+
+
+class _NpFjAcc:
+    def __init__(self, build):
+        self.build, self.keys, self.pos = build, [], []
+
+    def add_recv(self, rk, rf, layout, position_base):
+        rk, rf = rk.numpy(), rf.numpy()
+        for s in range(layout.world):
+            n = int(rf[s])
+            self.keys.append(rk[s * layout.block:s * layout.block + n])
+            self.pos.append(np.arange(s * layout.block, s * layout.block + n, dtype=np.int64) + position_base)
+
+    def finish(self, copy=True):
+        pk = np.concatenate(self.keys) if self.keys else np.zeros(0, np.int32)
+        pp = np.concatenate(self.pos) if self.pos else np.zeros(0, np.int64)
+        li, ri = oracle.join([pk], [self.build.keys], "inner")
+        return torch.from_numpy(pp[li]), torch.from_numpy(self.build.pos[ri])
+
+
+class _NpFjBuild:
+    def __init__(self, rk, rf, lo, layout, expected_rows):
+        rk, rf = rk.numpy(), rf.numpy()
+        ks, ps = [], []
+        for s in range(layout.world):
+            n = int(rf[s])
+            ks.append(rk[s * layout.block:s * layout.block + n])
+            ps.append(np.arange(s * layout.block, s * layout.block + n, dtype=np.int64))
+        self.keys, self.pos = np.concatenate(ks), np.concatenate(ps)
+
+    def accumulate(self, n):
+        return _NpFjAcc(self)
+
+    def close(self):
+        pass
+
+
+def _fused_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from libgdf_amd import multigpu
+    multigpu._MAX_MESSAGE_BYTES = 4096
+    probes, builds = _uneven_shards(world) if rank >= 0 and world == 3 and os.environ.get("FJ_UNEVEN") else _shards(world)
+    pairs = multigpu.fused_inner_join(torch.from_numpy(probes[rank]), torch.from_numpy(builds[rank]), chunks=3,
+                                      plan_fn=_np_fj_plan, send_fn=_np_fj_send, build_fn=_NpFjBuild)
+    assert pairs is not None
+    pg, bg = pairs.global_ids()
+    q.put((rank, pg.numpy(), bg.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world,uneven", [(2, False), (3, False), (3, True)])
+def test_fused_join_orchestration(world, uneven, monkeypatch):
+    """libgdf_amd.multigpu.fused_inner_join with numpy stand-ins for the device entry points: fixed-size blocks without a
+    count exchange, sliced probe relation, positions -> (owner, row) through the collective global_ids(); also with ranks
+    that hold 0 and 2 probe rows and no build rows."""
+    if uneven:
+        monkeypatch.setenv("FJ_UNEVEN", "1")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fused_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    probes, builds = _uneven_shards(world) if uneven else _shards(world)
+    gp = np.concatenate([(r << 40) + np.arange(len(probes[r]), dtype=np.int64) for r in range(world)])
+    gb = np.concatenate([(r << 40) + np.arange(len(builds[r]), dtype=np.int64) for r in range(world)])
+    li, ri = oracle.join([np.concatenate(probes)], [np.concatenate(builds)], "inner")
+    exp = np.stack([gp[li], gb[ri]], axis=1)
+    got = np.concatenate([np.stack([r[1], r[2]], axis=1) for r in results])
+    np.testing.assert_array_equal(got[np.lexsort(got.T[::-1])], exp[np.lexsort(exp.T[::-1])])

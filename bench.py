@@ -214,7 +214,9 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29511")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            # a lost peer must end the run, not hang it: RCCL's watchdog aborts a collective stuck for 5 minutes
+            import datetime
+            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(minutes=5))
 
     import libgdf_amd as gdf
     from libgdf_amd._binding import rmmOptions_t
@@ -254,25 +256,55 @@ def main():
         build = make_build_keys(nb, 0x5EED0001 + rank, dev) * world + rank
         probe = make_probe_keys(npr, key_space, 0x5EED0002, dev, offset=rank * npr)
 
-        strategy = args.strategy if args.strategy != "auto" else multigpu.choose_join_strategy(world, npr, nb)
-        if strategy == "broadcast":
-            def step():
-                return multigpu.broadcast_inner_join(probe, build).numel()
-            workload = (f"C4 rows, broadcast variant: {npr} probe + {nb} build int64 rows per GPU, key space {key_space}, "
-                        f"RCCL all-gather of the build keys + local gdf_inner_join")
-        elif strategy == "fused":
-            def step():
-                pairs = multigpu.fused_inner_join(probe, build)
-                if pairs is None:                  # collectively None: the shape did not fit
-                    pairs = multigpu.distributed_inner_join(probe, build)
-                return pairs.numel()
-            workload = (f"C4 partitioned hash join: {npr} probe + {nb} build int64 rows per GPU, key space {key_space}, rank split fused into "
-                        f"the join's level-1 regroup at the sender, RCCL all-to-all of 4-byte keys, level 2 + LDS probe at the receiver")
-        else:
-            def step():
-                return multigpu.distributed_inner_join(probe, build).numel()
-            workload = (f"C4 partitioned hash join: {npr} probe + {nb} build int64 rows per GPU, key space {key_space}, "
-                        f"RCCL all-to-all shuffle + local gdf_inner_join")
+        def step_broadcast():
+            return multigpu.broadcast_inner_join(probe, build).numel()
+
+        def step_fused():
+            pairs = multigpu.fused_inner_join(probe, build)
+            if pairs is None:                      # None on EVERY rank: the shape did not fit the fixed-size blocks
+                raise RuntimeError("fused_inner_join declined this shape")
+            return pairs.numel()
+
+        def step_shuffle():
+            return multigpu.distributed_inner_join(probe, build).numel()
+
+        steps = {"fused": (step_fused, f"C4 partitioned hash join: {npr} probe + {nb} build int64 rows per GPU, key space {key_space}, rank split "
+                                       f"fused into the join's level-1 regroup at the sender, RCCL exchange of 4-byte keys in fixed-size blocks, "
+                                       f"level 2 + LDS probe at the receiver"),
+                 "shuffle": (step_shuffle, f"C4 partitioned hash join: {npr} probe + {nb} build int64 rows per GPU, key space {key_space}, "
+                                           f"RCCL all-to-all shuffle + local gdf_inner_join"),
+                 "broadcast": (step_broadcast, f"C4 rows, broadcast variant: {npr} probe + {nb} build int64 rows per GPU, key space {key_space}, "
+                                               f"RCCL all-gather of the build keys + local gdf_inner_join")}
+        planned = args.strategy if args.strategy != "auto" else multigpu.choose_join_strategy(world, npr, nb)
+        # Preflight (untimed, before the warmup): one step of the planned strategy, checked against what this workload must
+        # produce -- every probe key is a build key on exactly one rank, so the ranks' pair counts add up to the probe rows.
+        # A strategy that raises or miscounts ON ANY RANK is dropped by all of them together and the next one is tried;
+        # the JSON line says which ran and why.  (A failure inside a collective can still take the job down: then RCCL's
+        # watchdog ends it.)
+        order = [planned] + [k for k in ("fused", "shuffle", "broadcast") if k != planned]
+        preflight = []
+        strategy = None
+        for cand in order:
+            err = None
+            got = 0
+            try:
+                got = steps[cand][0]()
+            except Exception as e:                 # noqa: BLE001 -- reported, not swallowed: see "preflight" in the output
+                err = f"{type(e).__name__}: {e}"
+            flags = torch.tensor([1.0 if err else 0.0, float(got)], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(flags)
+            bad, total = int(flags[0].item()), int(flags[1].item())
+            if not bad and total != npr * world:
+                err = f"pair count {total} != {npr * world} probe rows"
+                bad = 1
+            preflight.append({"strategy": cand, "ok": not bad, "error": err if err else (f"failed on {bad} other rank(s)" if bad else None)})
+            if not bad:
+                strategy = cand
+                break
+        if strategy is None:
+            raise SystemExit("bench.py: no multi-GPU join strategy passed its preflight: " + json.dumps(preflight))
+        step, workload = steps[strategy]
 
     def sync():
         torch.cuda.synchronize()
@@ -336,6 +368,7 @@ def main():
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
 
+    line = None
     if rank == 0:
         total_probe = npr * world
         value = total_probe * args.steps / dt
@@ -358,6 +391,8 @@ def main():
             # planner assumes (a rank reaches each peer over ONE link) -- an estimate, the links cannot be timed from in here
             sent = max(r["exchange_bytes_sent_per_step"] for r in per_rank)
             result["config"]["strategy"] = strategy
+            result["config"]["strategy_planned"] = planned
+            result["config"]["preflight"] = preflight
             result["exchange"] = {"bytes_sent_per_gpu_per_step": sent, "messages_per_gpu_per_step": max(r["exchange_messages_per_step"] for r in per_rank),
                                   "busiest_link_ms_at_assumed_rate": sent / max(world - 1, 1) / multigpu.XGMI_LINK_BYTES_PER_S * 1e3,
                                   "assumed_link_GBps": multigpu.XGMI_LINK_BYTES_PER_S / 1e9,
@@ -369,7 +404,15 @@ def main():
             port = cpu_baseline(args.cpu_sample, max(args.cpu_sample // 10, 1))
             result["cpu_baseline_oracle_port"] = port
             result.setdefault("cpu_baseline", port)
-        print(json.dumps(result))
+        line = json.dumps(result)
+    if distributed:
+        # RCCL's version banner (NCCL_DEBUG=VERSION on the GPU boxes) sits in C stdio's buffer since communicator creation and
+        # would otherwise come out AFTER the JSON line at exit: push it out now, on every rank, then print
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        dist.barrier()
+    if rank == 0:
+        print(line, flush=True)
     if distributed:
         dist.destroy_process_group()
 

@@ -572,7 +572,8 @@ constexpr int GB_DICT_THREADS = 512;
 
 // MASKED: rows with a null key element are skipped (their lanes re-find the reserved key, which costs nothing)
 template <bool FASTKEY, bool MASKED>
-__global__ __launch_bounds__(GB_DICT_THREADS) void gb_dict_build(KeyTable t, GbKeyPlan plan, GbDict g, int64_t chunk) {
+__global__ __launch_bounds__(GB_DICT_THREADS) void gb_dict_build(KeyTable t, GbKeyPlan plan, GbDict g, int64_t chunk, int64_t stride) {
+  // stride > 1: a strided SAMPLE -- t.nrows counts the sampled rows, row i of the sample is row i * stride of the table
   const int64_t begin = (int64_t)blockIdx.x * chunk;
   const int64_t end = begin + chunk < t.nrows ? begin + chunk : t.nrows;
   for (int64_t base = begin; base < end; base += GB_DICT_THREADS * GB_DENSE_BATCH) {
@@ -581,14 +582,14 @@ __global__ __launch_bounds__(GB_DICT_THREADS) void gb_dict_build(KeyTable t, GbK
 #pragma unroll
     for (int k = 0; k < GB_DENSE_BATCH; ++k) {
       const int64_t i = base + (int64_t)k * GB_DICT_THREADS + threadIdx.x;
-      const int64_t ic = i < end ? i : end - 1;                  // clamped: finished lanes re-find a real key
+      const int64_t ic = (i < end ? i : end - 1) * stride;       // clamped: finished lanes re-find a real key
       key[k] = FASTKEY ? ((const uint64_t *)t.col[0].data)[ic] : gb_pack(t, plan, ic);
     }
     bool skip[GB_DENSE_BATCH];
 #pragma unroll
     for (int k = 0; k < GB_DENSE_BATCH; ++k) {
       const int64_t i = base + (int64_t)k * GB_DICT_THREADS + threadIdx.x;
-      skip[k] = MASKED && !row_valid(t, i < end ? i : end - 1);
+      skip[k] = MASKED && !row_valid(t, (i < end ? i : end - 1) * stride);
     }
     // almost every row finds its key already present in its home slot: probe all BATCH home slots
     // first (independent reads), insert only the misses
@@ -611,20 +612,31 @@ __global__ __launch_bounds__(GB_DICT_THREADS) void gb_dict_build(KeyTable t, GbK
 // ids[slot] = dense id, group_slot[id] = slot; slot T stands for the reserved key
 __global__ __launch_bounds__(256) void gb_dict_number(GbDict g, unsigned int special_used, uint32_t *group_slot,
                                                       unsigned int *counter) {
+  if (special_used == 0xffffffffu) special_used = *g.special;        // not read back yet (LDS dictionary: no host round trip)
+  // ONE claim on the counter per workgroup: a claim per wave was 4096 atomics on one word = 45 us of a 2^18-entry table's
+  // numbering (the same-word atomic rate, ~90 per us), whatever the number of live entries
+  __shared__ uint32_t wave_tot[256 / WAVE];
+  __shared__ uint32_t block_base;
   const uint32_t n = g.T + 1;
-  const uint32_t stride = gridDim.x * blockDim.x;
-  const uint32_t rounds = (n + stride - 1) / stride;
-  for (uint32_t rnd = 0; rnd < rounds; ++rnd) {
-    const uint32_t i = rnd * stride + blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = i < n && (i == g.T ? special_used != 0 : g.e[i].key != GB_EMPTY_KEY);
-    const unsigned long long m = __ballot(live);
-    unsigned int base = 0;
-    if (lane_id() == 0 && m) base = atomicAdd(counter, (unsigned int)__popcll(m));
-    base = __shfl(base, 0, WAVE);
-    if (live) {
-      const uint32_t id = base + mask_rank(m);
+  const uint32_t per = (n + gridDim.x * 256 - 1) / (gridDim.x * 256);      // consecutive entries per thread
+  const uint32_t first = (blockIdx.x * 256 + threadIdx.x) * per;
+  auto live = [&](uint32_t i) { return i < n && (i == g.T ? special_used != 0 : g.e[i].key != GB_EMPTY_KEY); };
+  uint32_t mine = 0;
+  for (uint32_t k = 0; k < per; ++k) mine += live(first + k);
+  const uint32_t incl = wave_scan_incl(mine);
+  if (lane_id() == WAVE - 1) wave_tot[threadIdx.x / WAVE] = incl;
+  block_sync();
+  uint32_t before = 0, total = 0;
+  for (int w = 0; w < 256 / WAVE; ++w) { if (w < (int)(threadIdx.x / WAVE)) before += wave_tot[w]; total += wave_tot[w]; }
+  if (threadIdx.x == 0) block_base = total ? atomicAdd(counter, total) : 0;
+  block_sync();
+  uint32_t id = block_base + before + incl - mine;
+  for (uint32_t k = 0; k < per; ++k) {
+    const uint32_t i = first + k;
+    if (live(i)) {
       g.e[i].id = id;
-      group_slot[id] = i;
+      if (id <= g.limit) group_slot[id] = i;        // (a table that overflowed its limit is abandoned by the caller)
+      ++id;
     }
   }
 }
@@ -741,6 +753,208 @@ __global__ __launch_bounds__(256) void gb_dense_extract(KeyTable t, GbKeyPlan pl
     const uint64_t key = slot == g.T ? GB_EMPTY_KEY : g.e[slot].key;
     for (int c = 0; c < t.ncols; ++c) gb_unpack_store(t, plan, key, c, o.key_out[c], gi);
     store_result(o, op, gi, gacc[gi], gcnt ? gcnt[gi] : 0);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// LDS dictionary (few groups under SPARSE keys -- C2 with its 10 k keys scattered over 2^62).
+// The dense path above asks the L2-resident table twice per row (build: 0.62 ms, aggregate: 0.80 ms per 1e8 rows).  Here
+// the dictionary comes from a strided SAMPLE, is numbered, and its image -- a 2-choice, 2-slot-bucket cuckoo table of
+// 4-byte words (18-bit fingerprint << 14 | id) plus the 8-byte keys by id -- is copied into the LDS of every workgroup of
+//   gb_ld_encode     one pass over the KEY column(s): two independent 8-byte LDS reads give four candidate words, a
+//                    fingerprint match is confirmed against the full key (exact: no false merge), the row's 2-byte group
+//                    id is written out.  A key the sample never saw is inserted into the global table the slow way,
+//                    its rows get id 0xffff and the host numbers the (now complete) dictionary again and repeats the pass;
+//   gb_ld_aggregate  one pass over ids + values: LDS accumulators indexed by id, as in the direct path.
+// HBM bytes per row with 8-byte keys and values: 8 + 2 + 2 + 8 = 20 (dense path: 8 + 16).  A divergence-free lookup is
+// the point: a linear-probing LDS table at this load (a third of the keys off their home slot) was 2x slower than the L2
+// table (see gb_dict_build).
+// ---------------------------------------------------------------------------
+constexpr uint32_t GB_LD_BUCKETS = 8192;             // x 2 slots x 4 B = 64 KiB
+constexpr uint32_t GB_LD_SLOTS = 2 * GB_LD_BUCKETS;
+constexpr uint32_t GB_LD_MAX_GROUPS = 10922;         // two thirds of the slots; + 8 B per key = 150 KiB of LDS in gb_ld_encode
+constexpr uint32_t GB_LD_EMPTY = 0xffffffffu;        // id 16383 never exists
+constexpr uint32_t GB_LD_ID_MASK = 16383u;
+constexpr int GB_LD_THREADS = 1024;
+
+struct GbLdHash { uint32_t b1, b2, fp; };
+__device__ __forceinline__ GbLdHash ld_hash(uint64_t key) {
+  const uint64_t h = mix64(key);
+  return GbLdHash{(uint32_t)h & (GB_LD_BUCKETS - 1), (uint32_t)(h >> 13) & (GB_LD_BUCKETS - 1), (uint32_t)(h >> 46)};
+}
+
+// one workgroup: keys by id + the cuckoo table over them, built in LDS, written out as the image every encode workgroup loads
+// state: [1] set by gb_ld_encode when a row's key is not in the image, [2] this kernel gave up (too many groups for the
+// image, or the cuckoo walk did not end), [3] the group count the image was built for
+__global__ __launch_bounds__(GB_LD_THREADS) void gb_ld_image(GbDict g, const uint32_t *__restrict__ group_slot,
+                                                             uint32_t *tabimg, unsigned long long *keyimg, unsigned int *state) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gb_lds[];
+  uint32_t *tab = (uint32_t *)gb_lds;
+  unsigned long long *keys = (unsigned long long *)(tab + GB_LD_SLOTS);
+  unsigned int *fail = state + 2;
+  // the group count comes from the device: the host has not read the sample's result back (one round trip less per call)
+  const uint32_t ngroups = *g.occupied + (*g.special ? 1u : 0u);
+  if (threadIdx.x == 0) state[3] = ngroups;
+  if (*(volatile unsigned int *)g.overflow || ngroups == 0 || ngroups > GB_LD_MAX_GROUPS) {
+    if (threadIdx.x == 0) *fail = 1u;
+    return;
+  }
+  for (uint32_t i = threadIdx.x; i < GB_LD_SLOTS; i += GB_LD_THREADS) tab[i] = GB_LD_EMPTY;
+  for (uint32_t i = threadIdx.x; i < ngroups; i += GB_LD_THREADS) {
+    const uint32_t slot = group_slot[i];
+    keys[i] = slot == g.T ? GB_EMPTY_KEY : g.e[slot].key;
+  }
+  block_sync();
+  bool bad = false;
+  for (uint32_t i = threadIdx.x; i < ngroups; i += GB_LD_THREADS) {
+    GbLdHash h = ld_hash(keys[i]);
+    uint32_t cur = (h.fp << 14) | i, b = h.b1;
+    bool placed = false;
+    for (int it = 0; it < 256; ++it) {
+      if (atomicCAS(&tab[2 * b], GB_LD_EMPTY, cur) == GB_LD_EMPTY || atomicCAS(&tab[2 * b + 1], GB_LD_EMPTY, cur) == GB_LD_EMPTY) { placed = true; break; }
+      // both slots taken: evict one (slots never become empty again, so the exchange returns an entry) and move IT to its
+      // other bucket -- the random walk of cuckoo hashing, every token held by exactly one thread or one slot
+      const uint32_t pick = ((cur * 2654435761u) >> 31) ^ (uint32_t)(it & 1);
+      cur = atomicExch(&tab[2 * b + pick], cur);
+      h = ld_hash(keys[cur & GB_LD_ID_MASK]);
+      b = h.b1 == b ? h.b2 : h.b1;
+    }
+    bad = bad || !placed;
+  }
+  if (bad) *fail = 1u;
+  block_sync();
+  for (uint32_t i = threadIdx.x; i < GB_LD_SLOTS; i += GB_LD_THREADS) tabimg[i] = tab[i];
+  for (uint32_t i = threadIdx.x; i < ngroups; i += GB_LD_THREADS) keyimg[i] = keys[i];
+}
+
+template <bool FASTKEY>
+__global__ __launch_bounds__(GB_LD_THREADS) void gb_ld_encode(KeyTable t, GbKeyPlan plan, GbDict g, const uint32_t *__restrict__ tabimg,
+                                                              const unsigned long long *__restrict__ keyimg,
+                                                              uint16_t *__restrict__ ids, int64_t chunk, unsigned int *state) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gb_lds[];
+  uint2 *tab2 = (uint2 *)gb_lds;                                              // bucket = two slot words
+  unsigned long long *keys = (unsigned long long *)(gb_lds + sizeof(uint32_t) * GB_LD_SLOTS);
+  if (state[2]) return;                                                       // no image: the host takes the dense path
+  const uint32_t ngroups = state[3];
+  unsigned int *missed = state + 1;
+  {
+    uint4 *dst = (uint4 *)gb_lds;
+    const uint4 *src = (const uint4 *)tabimg;
+    for (uint32_t i = threadIdx.x; i < GB_LD_SLOTS / 4; i += GB_LD_THREADS) dst[i] = src[i];
+    for (uint32_t i = threadIdx.x; i < ngroups; i += GB_LD_THREADS) keys[i] = keyimg[i];
+  }
+  block_sync();
+  const int64_t begin = (int64_t)blockIdx.x * chunk;
+  const int64_t end = begin + chunk < t.nrows ? begin + chunk : t.nrows;
+  unsigned int fresh = 0;
+  for (int64_t base = begin; base < end; base += (int64_t)GB_LD_THREADS * GB_DENSE_BATCH) {
+    uint64_t key[GB_DENSE_BATCH];
+#pragma unroll
+    for (int k = 0; k < GB_DENSE_BATCH; ++k) {                       // all HBM loads first, from clamped addresses
+      const int64_t i = base + (int64_t)k * GB_LD_THREADS + threadIdx.x;
+      const int64_t ic = i < end ? i : end - 1;
+      key[k] = FASTKEY ? ((const uint64_t *)t.col[0].data)[ic] : gb_pack(t, plan, ic);
+    }
+    uint2 c1[GB_DENSE_BATCH], c2[GB_DENSE_BATCH];
+    uint32_t fp[GB_DENSE_BATCH];
+#pragma unroll
+    for (int k = 0; k < GB_DENSE_BATCH; ++k) {                       // sixteen independent LDS reads, one wait
+      const GbLdHash h = ld_hash(key[k]);
+      fp[k] = h.fp;
+      c1[k] = tab2[h.b1];
+      c2[k] = tab2[h.b2];
+    }
+#pragma unroll
+    for (int k = 0; k < GB_DENSE_BATCH; ++k) {
+      const int64_t i = base + (int64_t)k * GB_LD_THREADS + threadIdx.x;
+      const uint32_t cand[4] = {c1[k].x, c1[k].y, c2[k].x, c2[k].y};
+      uint32_t sel = 0, nmatch = 0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {                                  // (the empty word carries id 16383 >= ngroups)
+        const bool m = (cand[c] >> 14) == fp[k] && (cand[c] & GB_LD_ID_MASK) < ngroups;
+        sel = m ? (cand[c] & GB_LD_ID_MASK) : sel;
+        nmatch += m;
+      }
+      uint32_t id = 0xffffu;
+      if (nmatch == 1) {                                             // the common case: ONE dependent read confirms the key
+        if (keys[sel] == key[k]) id = sel;
+      } else if (nmatch > 1) {                                       // two fingerprints agree (or both buckets coincide): check them all
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const uint32_t cid = cand[c] & GB_LD_ID_MASK;
+          if ((cand[c] >> 14) == fp[k] && cid < ngroups && keys[cid] == key[k]) id = cid;
+        }
+      }
+      if (i < end) {
+        if (id == 0xffffu) {                                       // the sample never saw this key: the global table learns it
+          const int r = dict_insert(g, key[k]);
+          if (r == 0) atomicExch(g.overflow, 1u);
+          fresh += (r == 2);
+          *missed = 1u;
+        }
+        ids[i] = (uint16_t)id;
+      }
+    }
+  }
+  fresh = wave_reduce_add(fresh);
+  if (lane_id() == 0 && fresh && atomicAdd(g.occupied, fresh) + fresh > g.limit) atomicExch(g.overflow, 1u);
+}
+
+// FASTVAL = 8 / 4: an 8- / 4-byte value column read directly and widened in registers, 0: acc_image() (gb_direct_aggregate)
+template <int FASTVAL>
+__global__ __launch_bounds__(GB_LD_THREADS) void gb_ld_aggregate(GbVal val, int op, const uint16_t *__restrict__ ids, int64_t nrows,
+                                                                 uint32_t ngroups, unsigned long long *gacc, unsigned long long *gcnt,
+                                                                 int64_t chunk) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gb_lds[];
+  unsigned long long *lacc = (unsigned long long *)gb_lds;
+  unsigned int *lcnt = (unsigned int *)(lacc + ngroups);            // counted only
+  const bool flt = is_flt(val.kind);
+  const bool avg = gcnt != nullptr;
+  const int fold_op = op == OP_AVG ? OP_SUM : op;
+  for (uint32_t i = threadIdx.x; i < ngroups; i += GB_LD_THREADS) {
+    lacc[i] = acc_identity(fold_op);
+    if (avg) lcnt[i] = 0;
+  }
+  block_sync();
+  const int64_t begin = (int64_t)blockIdx.x * chunk;
+  const int64_t end = begin + chunk < nrows ? begin + chunk : nrows;
+  for (int64_t base = begin; base < end; base += (int64_t)GB_LD_THREADS * GB_DENSE_BATCH) {
+    uint32_t id[GB_DENSE_BATCH];
+    uint64_t img[GB_DENSE_BATCH];
+#pragma unroll
+    for (int k = 0; k < GB_DENSE_BATCH; ++k) {
+      const int64_t i = base + (int64_t)k * GB_LD_THREADS + threadIdx.x;
+      const int64_t ic = i < end ? i : end - 1;
+      id[k] = ids[ic];
+      img[k] = FASTVAL == 8 ? ((const uint64_t *)val.data)[ic] : (FASTVAL == 4 ? (uint64_t)((const uint32_t *)val.data)[ic] : acc_image(fold_op, val, ic));
+    }
+    if (FASTVAL) {
+#pragma unroll
+      for (int k = 0; k < GB_DENSE_BATCH; ++k) {
+        if (FASTVAL == 4)     // widen: float -> the bits of its double, int32 -> sign-extended
+          img[k] = flt ? (uint64_t)__double_as_longlong((double)__uint_as_float((uint32_t)img[k])) : (uint64_t)(int64_t)(int32_t)(uint32_t)img[k];
+        if (fold_op == OP_COUNT) img[k] = 1;
+        else if (fold_op == OP_MIN || fold_op == OP_MAX)
+          img[k] = flt ? ord_f64(__longlong_as_double((long long)img[k])) : ord_i64((int64_t)img[k]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < GB_DENSE_BATCH; ++k) {
+      if (base + (int64_t)k * GB_LD_THREADS + threadIdx.x < end) {
+        acc_fold(fold_op, flt, &lacc[id[k]], img[k]);
+        if (avg) atomicAdd(&lcnt[id[k]], 1u);
+      }
+    }
+  }
+  block_sync();
+  for (uint32_t i = threadIdx.x; i < ngroups; i += GB_LD_THREADS) {
+    const unsigned long long v = lacc[i];
+    if (avg) {
+      const unsigned int c = lcnt[i];
+      if (c) { acc_fold(fold_op, flt, &gacc[i], v); atomicAdd(&gcnt[i], (unsigned long long)c); }
+    } else if (v != acc_identity(fold_op) || fold_op == OP_SUM) {
+      if (!(fold_op == OP_SUM && v == 0 && !flt)) acc_fold(fold_op, flt, &gacc[i], v);
+    }
   }
 }
 
@@ -1676,8 +1890,8 @@ static gdf_error gb_path_dense(GbJob &j, bool *done) {
   if (plan.packed && !getenv("GDF_GB_NO_DENSE")) {
     DevBuf dict, flags, group_slot;
     RMM_TRY(dict.alloc(sizeof(GbDictEntry) * (T + 1)));
-    RMM_TRY(flags.alloc(sizeof(unsigned int) * 4));
-    HIP_TRY(hipMemsetAsync(flags.p, 0, sizeof(unsigned int) * 4, stream0()));
+    RMM_TRY(flags.alloc(sizeof(unsigned int) * 8));           // [0..2] the dictionary's, [4..7] the LDS dictionary's state (gb_ld_image)
+    HIP_TRY(hipMemsetAsync(flags.p, 0, sizeof(unsigned int) * 8, stream0()));
     GbDict g{};
     g.T = (uint32_t)T;
     g.e = dict.as<GbDictEntry>();
@@ -1690,15 +1904,60 @@ static gdf_error gb_path_dense(GbJob &j, bool *done) {
     GDF_LAUNCH("gb_fill", gb_dict_clear, dim3(stream_grid(T + 1, 256 * 8)), dim3(256), 0, stream0(), g.e, (uint32_t)(T + 1));
     const int bgrid = stream_grid((size_t)n, GB_DICT_THREADS * GB_DENSE_BATCH * 4, NUM_CU * 8);
     const int64_t bchunk = (((n + bgrid - 1) / bgrid) + GB_DICT_THREADS - 1) / GB_DICT_THREADS * GB_DICT_THREADS;
-    auto dict_build = [&](const KeyTable &tt, int grid_, int64_t chunk_) -> gdf_error {
-      if (fastkey) GDF_LAUNCH("gb_dict_build", (gb_dict_build<true, false>), dim3(grid_), dim3(GB_DICT_THREADS), 0, stream0(), tt, plan, g, chunk_);
-      else if (!t.any_valid) GDF_LAUNCH("gb_dict_build", (gb_dict_build<false, false>), dim3(grid_), dim3(GB_DICT_THREADS), 0, stream0(), tt, plan, g, chunk_);
-      else GDF_LAUNCH("gb_dict_build", (gb_dict_build<false, true>), dim3(grid_), dim3(GB_DICT_THREADS), 0, stream0(), tt, plan, g, chunk_);
+    auto dict_build = [&](const KeyTable &tt, int grid_, int64_t chunk_, int64_t stride_ = 1) -> gdf_error {
+      if (fastkey) GDF_LAUNCH("gb_dict_build", (gb_dict_build<true, false>), dim3(grid_), dim3(GB_DICT_THREADS), 0, stream0(), tt, plan, g, chunk_, stride_);
+      else if (!t.any_valid) GDF_LAUNCH("gb_dict_build", (gb_dict_build<false, false>), dim3(grid_), dim3(GB_DICT_THREADS), 0, stream0(), tt, plan, g, chunk_, stride_);
+      else GDF_LAUNCH("gb_dict_build", (gb_dict_build<false, true>), dim3(grid_), dim3(GB_DICT_THREADS), 0, stream0(), tt, plan, g, chunk_, stride_);
       return GDF_SUCCESS;
     };
     unsigned int h_flags[3] = {0, 0, 0};
+    // LDS dictionary (see gb_ld_encode): unmasked rows only, and enough of them to pay for four small kernels and a read-back.
+    // On success the rows' group ids are in `ids`, the dictionary is complete and numbered (group_slot).
+    DevBuf ids;
+    unsigned int *ld_state = flags.as<unsigned int>() + 4;
+    bool have_ids = false;
+    const bool try_ld = !masked && n >= ((int64_t)1 << 22) && !getenv("GDF_GB_NO_LDS_DICT");
     const int64_t sample = 1 << 16;      // a quarter of the table's slots: the prefix cannot crowd it
-    if (n > 16 * sample) {
+    if (try_ld) {
+      // sample -> number -> image -> encode, ONE read-back at the end: the kernels take the group count from the device and
+      // stand down by themselves when the sample overflows the table or holds more groups than the image can
+      const int64_t strided = 1 << 18;                 // every key that owns >= 1e-4 of the rows is in here with p > 1 - e^-26
+      KeyTable ts = t;
+      ts.nrows = strided;
+      GDF_TRY(dict_build(ts, (int)(strided / (GB_DICT_THREADS * GB_DENSE_BATCH)), GB_DICT_THREADS * GB_DENSE_BATCH, n / strided));
+      DevBuf tabimg, keyimg;
+      RMM_TRY(tabimg.alloc(sizeof(uint32_t) * GB_LD_SLOTS));
+      RMM_TRY(keyimg.alloc(sizeof(uint64_t) * GB_LD_MAX_GROUPS));
+      RMM_TRY(ids.alloc(sizeof(uint16_t) * (size_t)n));
+      RMM_TRY(group_slot.alloc(sizeof(uint32_t) * (size_t)(g.limit + 1)));     // the sample may hold up to `limit` groups (+ the reserved key)
+      const int egrid = stream_grid((size_t)n, GB_LD_THREADS * GB_DENSE_BATCH, NUM_CU);
+      const int64_t echunk = (((n + egrid - 1) / egrid) + GB_LD_THREADS - 1) / GB_LD_THREADS * GB_LD_THREADS;
+      const size_t ilds = sizeof(uint32_t) * GB_LD_SLOTS + sizeof(uint64_t) * GB_LD_MAX_GROUPS;
+      HIP_TRY(hipFuncSetAttribute((const void *)gb_ld_image, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ilds));
+      HIP_TRY(hipFuncSetAttribute((const void *)gb_ld_encode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ilds));
+      HIP_TRY(hipFuncSetAttribute((const void *)gb_ld_encode<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ilds));
+      for (int round = 0; round < 2; ++round) {                    // round 1 only if round 0 met keys the sample had not
+        if (round) HIP_TRY(hipMemsetAsync(ld_state, 0, sizeof(unsigned int) * 4, stream0()));      // [4] = the numbering counter
+        GDF_LAUNCH("gb_dict_number", gb_dict_number, dim3(stream_grid(T + 1, 256 * 4)), dim3(256), 0, stream0(), g, 0xffffffffu,
+                   group_slot.as<uint32_t>(), ld_state);
+        GDF_LAUNCH("gb_ld_image", gb_ld_image, dim3(1), dim3(GB_LD_THREADS), ilds, stream0(), g, group_slot.as<uint32_t>(),
+                   tabimg.as<uint32_t>(), keyimg.as<unsigned long long>(), ld_state);
+        if (fastkey)
+          GDF_LAUNCH("gb_ld_encode", gb_ld_encode<true>, dim3(egrid), dim3(GB_LD_THREADS), ilds, stream0(), t, plan, g, tabimg.as<uint32_t>(),
+                     keyimg.as<unsigned long long>(), ids.as<uint16_t>(), echunk, ld_state);
+        else
+          GDF_LAUNCH("gb_ld_encode", gb_ld_encode<false>, dim3(egrid), dim3(GB_LD_THREADS), ilds, stream0(), t, plan, g, tabimg.as<uint32_t>(),
+                     keyimg.as<unsigned long long>(), ids.as<uint16_t>(), echunk, ld_state);
+        HIP_CHECK_LAST();
+        unsigned int all[8];
+        HIP_TRY(hipMemcpy(all, flags.p, sizeof(all), hipMemcpyDeviceToHost));
+        for (int k = 0; k < 3; ++k) h_flags[k] = all[k];
+        const unsigned int *st = all + 4;
+        if (h_flags[1] || st[2]) break;          // table overflow: the general path.  No image (too many groups): the dense path.
+        if (!st[1]) { have_ids = true; break; }
+        // keys beyond the sample: every one of them is in the global table now (inserted by the rows that missed)
+      }
+    } else if (n > 16 * sample) {
       // a 65536-row prefix already tells "far too many groups" apart (C5) without paying for a
       // full pass that fills the table and gives up
       KeyTable ts = t;
@@ -1706,20 +1965,22 @@ static gdf_error gb_path_dense(GbJob &j, bool *done) {
       GDF_TRY(dict_build(ts, (int)(sample / (GB_DICT_THREADS * GB_DENSE_BATCH)), GB_DICT_THREADS * GB_DENSE_BATCH));
       HIP_TRY(hipMemcpy(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost));
     }
-    if (!h_flags[1]) {
+    if (!have_ids && !h_flags[1]) {
       GDF_TRY(dict_build(t, bgrid, bchunk));
       HIP_CHECK_LAST();
       HIP_TRY(hipMemcpy(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost));
     }
     const uint32_t ngroups = h_flags[0] + (h_flags[2] ? 1u : 0u);
     if (!h_flags[1] && ngroups <= max_groups) {
-      RMM_TRY(group_slot.alloc(sizeof(uint32_t) * (ngroups ? ngroups : 1)));
       DevBuf gacc, gcnt;
       RMM_TRY(gacc.alloc(sizeof(uint64_t) * (ngroups ? ngroups : 1)));
       if (avg) RMM_TRY(gcnt.alloc(sizeof(uint64_t) * (ngroups ? ngroups : 1)));
-      HIP_TRY(hipMemsetAsync(flags.p, 0, sizeof(unsigned int), stream0()));     // reuse [0] as the numbering counter
-      GDF_LAUNCH("gb_dict_number", gb_dict_number, dim3(stream_grid(T + 1, 256 * 4)), dim3(256), 0, stream0(), g, h_flags[2],
-                 group_slot.as<uint32_t>(), flags.as<unsigned int>());
+      if (!have_ids) {
+        RMM_TRY(group_slot.alloc(sizeof(uint32_t) * (ngroups ? ngroups : 1)));
+        HIP_TRY(hipMemsetAsync(flags.p, 0, sizeof(unsigned int), stream0()));     // reuse [0] as the numbering counter
+        GDF_LAUNCH("gb_dict_number", gb_dict_number, dim3(stream_grid(T + 1, 256 * 4)), dim3(256), 0, stream0(), g, h_flags[2],
+                   group_slot.as<uint32_t>(), flags.as<unsigned int>());
+      }
       GDF_LAUNCH("gb_fill", gb_fill_u64, dim3(stream_grid(ngroups, 256)), dim3(256), 0, stream0(), gacc.as<unsigned long long>(),
                  (unsigned long long)(op == OP_MIN ? ~0ULL : 0ULL), ngroups);
       if (avg) HIP_TRY(hipMemsetAsync(gcnt.p, 0, sizeof(uint64_t) * ngroups, stream0()));
@@ -1733,7 +1994,21 @@ static gdf_error gb_path_dense(GbJob &j, bool *done) {
     GDF_LAUNCH("gb_dense_aggregate", (gb_dense_aggregate<FK, FV, MK>), dim3(agrid), dim3(GB_DENSE_THREADS), dlds, stream0(), t, plan, val, \
                op, g, ngroups, gacc.as<unsigned long long>(), gcnt.as<unsigned long long>(), achunk);                        \
   } while (0)
-      if (masked) GB_DENSE_LAUNCH(false, false, true);
+      if (have_ids) {
+        const int fv = op == OP_COUNT ? 0 : (kind_width(in_kind) == 8 ? 8 : (kind_width(in_kind) == 4 ? 4 : 0));
+        const int lgrid = stream_grid((size_t)n, GB_LD_THREADS * GB_DENSE_BATCH, NUM_CU);
+        const int64_t lchunk = (((n + lgrid - 1) / lgrid) + GB_LD_THREADS - 1) / GB_LD_THREADS * GB_LD_THREADS;
+#define GB_LD_LAUNCH(FV)                                                                                                     \
+  do {                                                                                                                       \
+    HIP_TRY(hipFuncSetAttribute((const void *)gb_ld_aggregate<FV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds)); \
+    GDF_LAUNCH("gb_ld_aggregate", gb_ld_aggregate<FV>, dim3(lgrid), dim3(GB_LD_THREADS), dlds, stream0(), val, op, ids.as<uint16_t>(), n, \
+               ngroups, gacc.as<unsigned long long>(), gcnt.as<unsigned long long>(), lchunk);                               \
+  } while (0)
+        if (fv == 8) GB_LD_LAUNCH(8);
+        else if (fv == 4) GB_LD_LAUNCH(4);
+        else GB_LD_LAUNCH(0);
+#undef GB_LD_LAUNCH
+      } else if (masked) GB_DENSE_LAUNCH(false, false, true);
       else if (fastkey && fastval) GB_DENSE_LAUNCH(true, true, false);
       else if (fastkey) GB_DENSE_LAUNCH(true, false, false);
       else if (fastval) GB_DENSE_LAUNCH(false, true, false);

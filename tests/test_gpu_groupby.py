@@ -404,3 +404,76 @@ def test_float_keys_with_nan_keep_one_group_per_nan_row(gdf):
     np.testing.assert_array_equal(gk[0][~np.isnan(gk[0])][order], ek[0][~np.isnan(ek[0])])
     np.testing.assert_array_equal(ga[~np.isnan(gk[0])][order], ea[~np.isnan(ek[0])])
     assert sorted(ga[np.isnan(gk[0])].tolist()) == sorted(ea[np.isnan(ek[0])].tolist())
+
+
+# ---- LDS dictionary path (few groups under sparse keys, >= 2^22 rows: gb_ld_encode / gb_ld_aggregate) ------------------------
+def _sparse_lut(ngroups, seed):
+    rng = np.random.default_rng(seed)
+    lut = rng.integers(-2**62, 2**62, size=ngroups, dtype=np.int64)
+    lut[0] = -2**63                                    # the library's reserved key pattern is a normal key
+    return np.unique(lut)
+
+
+@pytest.mark.parametrize("op", OPS)
+@pytest.mark.parametrize("val_dtype", [np.int64, np.float64, np.int32, np.float32, np.int8], ids=lambda d: np.dtype(d).name)
+def test_lds_dictionary_sparse_keys(gdf, op, val_dtype):
+    """C2's sparse twin, reduced: 10 k int64 keys scattered over 2^63, 5M rows; integers bit-exact, float sums plain 1e-6."""
+    n = 5_000_000
+    lut = _sparse_lut(10_000, 1)
+    rng = np.random.default_rng(2)
+    keys = [lut[rng.integers(0, len(lut), size=n)]]
+    vals = gen_rand(val_dtype, n, positive_only=True) if np.dtype(val_dtype).kind == "f" else gen_rand(val_dtype, n)
+    _check(gdf, op, keys, vals, np.float64 if op == "avg" else (np.int64 if op == "count" else None))
+
+
+@pytest.mark.parametrize("shape", ["sorted", "late-keys", "rare-keys", "limit", "above-limit", "two-columns"])
+def test_lds_dictionary_sampling_and_limits(gdf, shape):
+    """The dictionary comes from a strided sample: keys it never saw (a sorted column's short runs, keys that only occur
+    late or only a few times) must reach the result through the second numbering round; group counts at and above the
+    path's limit (10922) and packed multi-column keys take it or leave it without changing the answer."""
+    n = 4_500_000
+    rng = np.random.default_rng(3)
+    if shape == "sorted":
+        k = [np.sort(_sparse_lut(9_000, 4)[rng.integers(0, 8_990, size=n)])]
+    elif shape == "late-keys":
+        lut = _sparse_lut(6_000, 5)
+        g = rng.integers(0, 3_000, size=n)
+        g[-1000:] = rng.integers(3_000, len(lut), size=1000)          # half of the keys appear in the last 1000 rows only
+        k = [lut[g]]
+    elif shape == "rare-keys":
+        lut = _sparse_lut(8_000, 6)
+        g = rng.integers(0, 4_000, size=n)
+        pos = rng.choice(n, size=4_000, replace=False)                # every key of the upper half occurs about once
+        g[pos] = rng.integers(4_000, len(lut), size=4_000)
+        k = [lut[g]]
+    elif shape == "limit":
+        lut = _sparse_lut(10_922, 7)[:10_922]
+        k = [lut[rng.integers(0, len(lut), size=n)]]
+    elif shape == "above-limit":
+        lut = _sparse_lut(11_500, 8)
+        k = [lut[rng.integers(0, len(lut), size=n)]]
+    else:
+        a = rng.integers(-2**31, 2**31 - 1, size=120, dtype=np.int64).astype(np.int32)
+        b = rng.integers(-2**15, 2**15 - 1, size=70, dtype=np.int64).astype(np.int16)
+        k = [a[rng.integers(0, 120, size=n)], b[rng.integers(0, 70, size=n)]]
+    vals = gen_rand(np.int64, n)
+    for op in ("sum", "count", "max"):
+        _check(gdf, op, k, vals, np.int64 if op == "count" else None)
+    _check(gdf, "avg", k, gen_rand(np.float64, n, positive_only=True), np.float64)
+
+
+def test_lds_dictionary_switch_matches_dense_path(gdf):
+    """GDF_GB_NO_LDS_DICT=1 (read per call) falls back to the L2 dictionary: identical integer results."""
+    n = 4_200_000
+    lut = _sparse_lut(3_000, 9)
+    rng = np.random.default_rng(10)
+    keys = [lut[rng.integers(0, len(lut), size=n)]]
+    vals = gen_rand(np.int64, n)
+    a = sort_groups(*_run(gdf, "sum", keys, vals))
+    os.environ["GDF_GB_NO_LDS_DICT"] = "1"
+    try:
+        b = sort_groups(*_run(gdf, "sum", keys, vals))
+    finally:
+        del os.environ["GDF_GB_NO_LDS_DICT"]
+    np.testing.assert_array_equal(a[0][0], b[0][0])
+    np.testing.assert_array_equal(a[1], b[1])

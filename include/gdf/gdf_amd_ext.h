@@ -92,9 +92,10 @@ gdf_error gdf_amd_shuffle_partition_stable(gdf_column *keys, int narrow, int64_t
  *                    GDF_UNSUPPORTED_METHOD: this world size / relation size does not fit the path (use the key shuffle).
  * gdf_amd_fj_send    int64 / int32 keys -> out_keys: (world << coarse_bits) bins x 8 regions x cap 4-byte keys (key - lo; rows
  *                    outside [lo, hi] are dropped), rank r's keys in the r-th contiguous block of (8 << coarse_bits) * cap
- *                    elements (+ one tile of dump space behind the last block); out_rows: the rows' local numbers (+ row_base)
- *                    at the same positions -- they stay with the sender; out_fill: DEVICE array of (world << coarse_bits) * 8
- *                    fill counters + 1 word.  *overflowed = 1: some region outgrew cap (skewed keys), the buffers are unusable.
+ *                    elements (+ one tile = 32768 elements of dump space behind the last block); out_pos[i]: the position in
+ *                    out_keys that row i's key went to (0xffffffff: dropped) -- it stays with the sender, who can tell from it
+ *                    which row a result position names; out_fill: DEVICE array of (world << coarse_bits) * 8 fill counters
+ *                    + 1 word.  *overflowed = 1: some region outgrew cap (skewed keys), the buffers are unusable.
  * gdf_amd_fj_build_create   receive buffer of the build relation (the blocks every sender made for this rank, sender-major,
  *                    with their fill counters in the same order, both in DEVICE memory) -> a build handle
  *                    (gdf_amd_join_probe_begin / gdf_amd_fj_probe_add / gdf_amd_join_probe_finish / gdf_amd_join_build_free).
@@ -103,8 +104,8 @@ gdf_error gdf_amd_shuffle_partition_stable(gdf_column *keys, int narrow, int64_t
  */
 gdf_error gdf_amd_fj_plan(int world, int64_t build_rows_total, int64_t rows_max, double rows_per_key, int *fine_bits, int *coarse_bits,
                           uint32_t *cap);
-gdf_error gdf_amd_fj_send(gdf_column *keys, int64_t lo, int64_t hi, int world, int coarse_bits, uint32_t cap, int32_t row_base,
-                          uint32_t *out_keys, int32_t *out_rows, uint32_t *out_fill, int *overflowed);
+gdf_error gdf_amd_fj_send(gdf_column *keys, int64_t lo, int64_t hi, int world, int coarse_bits, uint32_t cap,
+                          uint32_t *out_keys, uint32_t *out_pos, uint32_t *out_fill, int *overflowed);
 gdf_error gdf_amd_fj_build_create(const uint32_t *recv_keys, const uint32_t *recv_fill, int world, int64_t lo, int fine_bits,
                                   int coarse_bits, uint32_t cap, int64_t expected_rows, gdf_amd_join_build **out);
 gdf_error gdf_amd_fj_probe_add(gdf_amd_join_probe *probe, const uint32_t *recv_keys, const uint32_t *recv_fill, uint32_t cap,

@@ -127,7 +127,7 @@ _PROTOTYPES = {
     "gdf_amd_join_probe_add": (None, [C.c_void_p, C.POINTER(_COLP), C.c_int]),
     "gdf_amd_join_probe_finish": (None, [C.c_void_p, _COLP, _COLP]),
     "gdf_amd_fj_plan": (None, [C.c_int, C.c_int64, C.c_int64, C.c_double, _INTP, _INTP, C.POINTER(C.c_uint32)]),
-    "gdf_amd_fj_send": (None, [_COLP, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, _INTP]),
+    "gdf_amd_fj_send": (None, [_COLP, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, _INTP]),
     "gdf_amd_fj_build_create": (None, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_uint32, C.c_int64, C.POINTER(C.c_void_p)]),
     "gdf_amd_fj_probe_add": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int64, C.c_int64]),
     "gdf_order_by": (None, [C.c_size_t, _COLP, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -262,7 +262,7 @@ class ProbeAccumulator:
 
 
 # ---- fused multi-GPU join (include/gdf/gdf_amd_ext.h gdf_amd_fj_*) -----------------------------------------------------
-FJ_DUMP_ELEMS = 16384          # one sender tile of dump space behind the regions (csrc/join.hip FJ_TILE)
+FJ_DUMP_ELEMS = 32768          # one sender tile of dump space behind the regions (csrc/join.hip FJ_TILE)
 
 
 class FjLayout:
@@ -287,19 +287,37 @@ def fj_plan(world, build_rows_total, rows_max, rows_per_key=1.0):
     return FjLayout(int(world), fb.value, c1.value, cap.value)
 
 
+class FjRows:
+    """Which row sits at which position of a send buffer, kept as gdf_amd_fj_send wrote it: out_pos[i] = the position row i's key
+    went to.  ``materialize()`` inverts it on demand (global ids are resolved outside the timed path) into an int32 array of
+    the buffer's shape with ``row_base + i`` at position out_pos[i] and -1 elsewhere."""
+
+    def __init__(self, pos, row_base, total):
+        self.pos, self.row_base, self.total = pos, int(row_base), int(total)
+
+    def materialize(self):
+        import torch
+        dev = self.pos.device
+        rows = torch.full((self.total,), -1, dtype=torch.int32, device=dev)
+        p = self.pos.long() & 0xffffffff                          # the int32 storage holds uint32 positions
+        ok = p < self.total                                       # 0xffffffff: the row was dropped (key outside [lo, hi])
+        rows[p[ok]] = (torch.arange(self.pos.numel(), dtype=torch.int32, device=dev) + self.row_base)[ok]
+        return rows
+
+
 def fj_send(keys: Column, lo, hi, layout: FjLayout, row_base=0):
-    """gdf_amd_fj_send -> (keys buffer int32 [world * block (+ dump)], rows buffer int32 (same shape, stays with the sender),
-    fill counters int32 [world * regions_per_rank (+ 1)], overflowed)."""
+    """gdf_amd_fj_send -> (keys buffer int32 [world * block (+ dump)], FjRows (stays with the sender), fill counters int32
+    [world * regions_per_rank (+ 1)], overflowed)."""
     import torch
     dev = keys.data.device
     total = layout.world * layout.block + FJ_DUMP_ELEMS
     out_keys = torch.empty(total, dtype=torch.int32, device=dev)
-    out_rows = torch.empty(total, dtype=torch.int32, device=dev)
+    out_pos = torch.empty(max(keys.size, 1), dtype=torch.int32, device=dev)[:keys.size]
     fill = torch.empty(layout.nregions + 1, dtype=torch.int32, device=dev)
     over = C.c_int(0)
-    libgdf.gdf_amd_fj_send(keys.ptr, int(lo), int(hi), layout.world, layout.coarse_bits, layout.cap, int(row_base), out_keys.data_ptr(),
-                           out_rows.data_ptr(), fill.data_ptr(), C.byref(over))
-    return out_keys, out_rows, fill, bool(over.value)
+    libgdf.gdf_amd_fj_send(keys.ptr, int(lo), int(hi), layout.world, layout.coarse_bits, layout.cap, out_keys.data_ptr(),
+                           out_pos.data_ptr(), fill.data_ptr(), C.byref(over))
+    return out_keys, FjRows(out_pos, row_base, total), fill, bool(over.value)
 
 
 class FjBuild(JoinBuild):

@@ -1380,7 +1380,11 @@ __global__ __launch_bounds__(256) void gb_part_bounds(const K *__restrict__ keys
   }
 }
 
-template <bool VBIT, class K>
+// one (32-bit packed key, 64-bit accumulator image) pair as the fused partition pass writes it: 12 bytes, ONE store per row
+struct __attribute__((aligned(4))) GbRec { uint32_t key, lo, hi; };
+
+// REC: `keys` points to GbRec records (the fused partition pass), `payload` is unused
+template <bool VBIT, class K, bool REC = false>
 __global__ __launch_bounds__(GB_DENSE_THREADS) void gb_part_aggregate(const K *__restrict__ keys, const uint64_t *__restrict__ payload,
                                                                       const GbPartUnit *__restrict__ units, int id_bits, int op, bool flt,
                                                                       unsigned long long *gacc, unsigned int *grows, unsigned int *gvalid) {
@@ -1404,8 +1408,14 @@ __global__ __launch_bounds__(GB_DENSE_THREADS) void gb_part_aggregate(const K *_
     for (int b = 0; b < GB_DENSE_BATCH; ++b) {                       // all HBM loads first, from clamped addresses
       const uint32_t i = base + b * GB_DENSE_THREADS + threadIdx.x;
       const uint32_t ic = u.begin + (i < u.count ? i : u.count - 1);
-      k[b] = keys[ic];
-      v[b] = payload[ic];
+      if (REC) {
+        const GbRec r = reinterpret_cast<const GbRec *>(keys)[ic];
+        k[b] = (K)r.key;
+        v[b] = ((uint64_t)r.hi << 32) | r.lo;
+      } else {
+        k[b] = keys[ic];
+        v[b] = payload[ic];
+      }
     }
 #pragma unroll
     for (int b = 0; b < GB_DENSE_BATCH; ++b) {
@@ -1570,13 +1580,13 @@ __global__ __launch_bounds__(GBP_THREADS) void gbp_count(KeyTable t, GbKeyPlan p
 template <bool VBIT>
 __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter(KeyTable t, GbKeyPlan plan, GbVal val, int fold_op, int low, int part_bits,
                                                            uint32_t nparts, int64_t chunk, int nchunks, const uint32_t *__restrict__ offs,
-                                                           uint32_t *__restrict__ keys_out, uint64_t *__restrict__ payload_out) {
+                                                           GbRec *__restrict__ rec_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gbp_lds[];
-  uint64_t *stage = reinterpret_cast<uint64_t *>(gbp_lds);                   // [TILE]
-  uint32_t *hist = reinterpret_cast<uint32_t *>(stage + GBP_SC_TILE);           // [MAX_PARTS + 4]
+  uint64_t *stage = reinterpret_cast<uint64_t *>(gbp_lds);                   // [TILE] accumulator images, regrouped by partition
+  uint32_t *stage_k = reinterpret_cast<uint32_t *>(stage + GBP_SC_TILE);        // [TILE] their keys (the partition is key >> low)
+  uint32_t *hist = stage_k + GBP_SC_TILE;                                       // [MAX_PARTS + 4]
   uint32_t *start = hist + GBP_MAX_PARTS + 4, *gbase = start + GBP_MAX_PARTS, *cursor = gbase + GBP_MAX_PARTS;
   uint32_t *wave_tot = cursor + GBP_MAX_PARTS;                               // [THREADS / WAVE]
-  uint16_t *bin_of = reinterpret_cast<uint16_t *>(wave_tot + GBP_SC_THREADS / WAVE);   // [TILE]
   constexpr int PER = GBP_MAX_PARTS / GBP_SC_THREADS;                           // partitions per thread in the scan (2)
   constexpr int vbit = VBIT ? 1 : 0;
   for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
@@ -1674,32 +1684,29 @@ __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter(KeyTable t, GbKeyP
       block_sync();
       uint32_t total = 0;
       for (int w = 0; w < GBP_SC_THREADS / WAVE; ++w) total += wave_tot[w];
-      uint32_t pos[GBP_ITEMS];
+      // key and image are regrouped together and leave as ONE 12-byte record per row: written as a 4-byte and an 8-byte array
+      // (two LDS rounds, two flushes) every short (tile, partition) run cost two store requests -- and the request rate, not
+      // the bytes, bounds this kernel on C5, where half of the rows sit in runs of a few rows
 #pragma unroll
       for (int k = 0; k < GBP_ITEMS; ++k) {
-        pos[k] = 0;
         if (pr[k] != 0xffffffffu) {
-          const uint32_t q = pr[k] >> 16;
-          pos[k] = start[q] + (pr[k] & 0xffffu);
-          bin_of[pos[k]] = (uint16_t)q;
-          stage[pos[k]] = k32[k];
+          const uint32_t pos = start[pr[k] >> 16] + (pr[k] & 0xffffu);
+          stage_k[pos] = k32[k];
+          stage[pos] = ((vmask >> k) & 1u) ? img[k] : acc_identity(fold_op);
         }
       }
       block_sync();
-      for (uint32_t j = threadIdx.x; j < total; j += GBP_SC_THREADS) keys_out[gbase[bin_of[j]] + j] = (uint32_t)stage[j];
-      block_sync();
-      // (the value column was requested together with the keys, above)
-#pragma unroll
-      for (int k = 0; k < GBP_ITEMS; ++k)
-        if (pr[k] != 0xffffffffu) stage[pos[k]] = ((vmask >> k) & 1u) ? img[k] : acc_identity(fold_op);
-      block_sync();
-      for (uint32_t j = threadIdx.x; j < total; j += GBP_SC_THREADS) payload_out[gbase[bin_of[j]] + j] = stage[j];
+      for (uint32_t j = threadIdx.x; j < total; j += GBP_SC_THREADS) {
+        const uint32_t kk = stage_k[j];
+        const uint64_t vv = stage[j];
+        rec_out[gbase[kk >> low] + j] = GbRec{kk, (uint32_t)vv, (uint32_t)(vv >> 32)};
+      }
       block_sync();
     }
   }
 }
 static constexpr size_t gbp_scatter_lds() {
-  return 8 * (size_t)GBP_SC_TILE + 4 * (size_t)(4 * GBP_MAX_PARTS + 4 + GBP_SC_THREADS / WAVE) + 2 * (size_t)GBP_SC_TILE + 16;
+  return 12 * (size_t)GBP_SC_TILE + 4 * (size_t)(4 * GBP_MAX_PARTS + 4 + GBP_SC_THREADS / WAVE) + 16;
 }
 
 // number of non-empty cells per block of 1024 cells
@@ -2070,8 +2077,12 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
     fused = part_bits >= 1 && part_bits <= GBP_MAX_PART_BITS && n >= ((int64_t)1 << 20) && !getenv("GDF_GB_NO_FUSED");
   if (guessed && !fused) { *done = false; return GDF_SUCCESS; }      // only the fused kernels check keys against a guessed plan
   DevBuf ka, kb, pa, pb, fl;
-  RMM_TRY(ka.alloc(sizeof(K) * (size_t)nn));
-  RMM_TRY(pa.alloc(sizeof(uint64_t) * (size_t)nn));
+  if (fused) {
+    RMM_TRY(ka.alloc(sizeof(GbRec) * (size_t)nn));            // 12-byte records: key and image together
+  } else {
+    RMM_TRY(ka.alloc(sizeof(K) * (size_t)nn));
+    RMM_TRY(pa.alloc(sizeof(uint64_t) * (size_t)nn));
+  }
   if (!fused) {
     RMM_TRY(kb.alloc(sizeof(K) * (size_t)nn));
     RMM_TRY(pb.alloc(sizeof(uint64_t) * (size_t)nn));
@@ -2103,11 +2114,11 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
       if (vbit) {
         HIP_TRY(hipFuncSetAttribute((const void *)gbp_scatter<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
         GDF_LAUNCH("gbp_scatter", gbp_scatter<true>, dim3(nchunks < NUM_CU ? nchunks : NUM_CU), dim3(GBP_SC_THREADS), slds, stream0(), t, sp, val, fold_op,
-                   low, part_bits, P, chunk, nchunks, (const uint32_t *)hist.as<uint32_t>(), (uint32_t *)kin, pin);
+                   low, part_bits, P, chunk, nchunks, (const uint32_t *)hist.as<uint32_t>(), ka.as<GbRec>());
       } else {
         HIP_TRY(hipFuncSetAttribute((const void *)gbp_scatter<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
         GDF_LAUNCH("gbp_scatter", gbp_scatter<false>, dim3(nchunks < NUM_CU ? nchunks : NUM_CU), dim3(GBP_SC_THREADS), slds, stream0(), t, sp, val, fold_op,
-                   low, part_bits, P, chunk, nchunks, (const uint32_t *)hist.as<uint32_t>(), (uint32_t *)kin, pin);
+                   low, part_bits, P, chunk, nchunks, (const uint32_t *)hist.as<uint32_t>(), ka.as<GbRec>());
       }
       hipLaunchKernelGGL(gb_strided_u32, dim3((P + 256) / 256), dim3(256), 0, stream0(), (const uint32_t *)hist.as<uint32_t>(), d_start.as<uint32_t>(),
                          (int)P + 1, (size_t)nchunks);
@@ -2166,7 +2177,25 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
     HIP_TRY(hipMemsetAsync(grows.p, 0, sizeof(unsigned int) * cells_pad, stream0()));
     if (vbit) HIP_TRY(hipMemsetAsync(gvalid.p, 0, sizeof(unsigned int) * cells_pad, stream0()));
     const size_t plds = ((size_t)1 << id_bits) * (vbit ? 16 : 12) + 16;
-    if (vbit) {
+    bool launched = false;
+    if constexpr (sizeof(K) == 4) {
+      if (fused) {
+        launched = true;
+        if (vbit) {
+          HIP_TRY(hipFuncSetAttribute((const void *)gb_part_aggregate<true, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
+          GDF_LAUNCH("gb_part_aggregate", (gb_part_aggregate<true, K, true>), dim3((unsigned)units.size()), dim3(GB_DENSE_THREADS), plds, stream0(),
+                     (const K *)kin, (const uint64_t *)nullptr, (const GbPartUnit *)d_units.as<GbPartUnit>(), id_bits, fold_op, flt,
+                     gacc.as<unsigned long long>(), grows.as<unsigned int>(), gvalid.as<unsigned int>());
+        } else {
+          HIP_TRY(hipFuncSetAttribute((const void *)gb_part_aggregate<false, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
+          GDF_LAUNCH("gb_part_aggregate", (gb_part_aggregate<false, K, true>), dim3((unsigned)units.size()), dim3(GB_DENSE_THREADS), plds, stream0(),
+                     (const K *)kin, (const uint64_t *)nullptr, (const GbPartUnit *)d_units.as<GbPartUnit>(), id_bits, fold_op, flt,
+                     gacc.as<unsigned long long>(), grows.as<unsigned int>(), (unsigned int *)nullptr);
+        }
+      }
+    }
+    if (launched) {
+    } else if (vbit) {
       HIP_TRY(hipFuncSetAttribute((const void *)gb_part_aggregate<true, K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
       GDF_LAUNCH("gb_part_aggregate", (gb_part_aggregate<true, K>), dim3((unsigned)units.size()), dim3(GB_DENSE_THREADS), plds, stream0(), (const K *)kin,
                  (const uint64_t *)pin, (const GbPartUnit *)d_units.as<GbPartUnit>(), id_bits, fold_op, flt, gacc.as<unsigned long long>(),

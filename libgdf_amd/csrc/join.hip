@@ -3015,16 +3015,17 @@ static gdf_error accum_finish(ProbeAccum *a, gdf_column *probe_indices, gdf_colu
 // from the low word of h * world (uniform again).  The sender regroups its rows into world << c1 bins (bin = rank << c1 |
 // coarse partition on that rank; at most 1024), writing the NARROWED 4-byte keys into a send buffer laid out as regions of
 // `cap` keys per (bin, XCD) -- so everything for rank r is one contiguous, fixed-size block and no count exchange precedes
-// the data -- and the local row numbers into a second array of the same shape that never travels.  The receiver's buffer
+// the data -- and, per input row, the POSITION its key went to (out_pos, in row order; never travels).  The receiver's buffer
 // (world blocks, sender-major) is exactly a level-1 output in the speculative layout with world << (c1 + 3) segments: the
 // level-2 regroup reads its 4-byte keys, numbers the tuples by their position in that buffer and drops them into the fine
-// partitions the LDS probe works on.  Per row: sender 8 B in + 8 B out, receiver 4 B in + 8 B out, probe 8 + 8 -- against
+// partitions the LDS probe works on.  Per row: sender 8 B in + 4 + 4 B out, receiver 4 B in + 8 B out, probe 8 + 8 -- against
 // 8 + 8 + 4.125 (stable split, two passes) and 4 + 8, 8 + 8, 8 + 8 for the key-only shuffle of round 1 -- and 4 B on the links.
-// Global row ids: a result index is a position in a receive buffer, i.e. (sender, region, offset); the sender kept the row
-// number it put there (libgdf_amd/multigpu.py resolves them lazily, with a second exchange outside the timed path).
+// Global row ids: a result index is a position in a receive buffer, i.e. (sender, region, offset); the sender knows which
+// row it put there (out_pos inverted; libgdf_amd/multigpu.py resolves them lazily, with a second exchange outside the timed path).
 // ---------------------------------------------------------------------------
 constexpr int FJ_THREADS = 1024;
-constexpr int FJ_ITEMS = 16;          // 16384-tuple tiles: a (tile, bin) run is 16 keys = 64 bytes at 1024 bins (12: 5.0 ms per 1e9 rows)
+constexpr int FJ_ITEMS = 32;          // 32768-key tiles: a (tile, bin) run is 32 keys = 128 bytes at 1024 bins
+constexpr int FJ_ROUND = 8;           // keys loaded and ranked per round (64-bit raw keys cost two registers each: sixteen per round spilled)
 constexpr int FJ_TILE = FJ_THREADS * FJ_ITEMS;
 constexpr int FJ_MAX_BINS = 1024;
 constexpr int64_t FJ_CHUNK = ((int64_t)131072 + FJ_TILE - 1) / FJ_TILE * FJ_TILE;     // rows per sender workgroup
@@ -3037,21 +3038,34 @@ struct FjSend {
   uint32_t world;
   int c1;                    // coarse bits per rank: bins = world << c1
   uint32_t cap;              // keys per (bin, XCD) region
-  int32_t row_base;
   uint32_t chunk;            // rows per workgroup (a multiple of the tile)
   uint32_t *out_keys;
-  int32_t *out_rows;
+  uint32_t *out_pos;         // [n] where row i's key went in out_keys (0xffffffff: nowhere)
   uint32_t *fill;            // [bins * 8] zero-initialised fill counters
   uint32_t *overflow;        // set when a region outgrew `cap` (its run goes to the dump area behind the regions)
 };
 
+// The first version kept (key, row) pairs in the LDS tile and scattered BOTH as 4-byte arrays: two 64-byte runs per
+// (tile, bin), 5.05 ms per 1.125e9 rows (3.7 TB/s) -- the store-REQUEST wall of profiles/r2_a_single_pass_ablation.md.  Row
+// numbers do not need the scatter: a row's DESTINATION is known when its rank is, and goes out in row order as a plain
+// streaming store (out_pos); whoever wants "which row sits at position p" inverts that array later (global ids are
+// resolved lazily, outside the timed path).  The tile then holds 4-byte keys only: twice the keys per tile, 128-byte runs,
+// and half the scattered arrays.
+// base + a 32-bit BYTE offset (element index below 2^32 / sizeof(T)): the access is emitted with the uniform base in scalar
+// registers and one vector register of offset, instead of a 64-bit vector address
+template <class T>
+__device__ __forceinline__ T *at32(T *base, uint32_t index) {
+  using Byte = typename std::conditional<std::is_const<T>::value, const char, char>::type;
+  return reinterpret_cast<T *>(reinterpret_cast<Byte *>(base) + (uint32_t)(index * (uint32_t)sizeof(T)));
+}
+
 template <class K>
 __global__ __launch_bounds__(FJ_THREADS) void fj_scatter(FjSend a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fj_lds[];
-  uint64_t *tw = reinterpret_cast<uint64_t *>(fj_lds);                 // [TILE + 2]: key32 << 32 | row, regrouped by bin
-  uint32_t *hist = reinterpret_cast<uint32_t *>(tw + FJ_TILE + 2);      // [MAX_BINS + 4] counts, then exclusive starts
-  uint32_t *gbase = hist + FJ_MAX_BINS + 4;                             // [MAX_BINS] destination of LDS position 0 of a bin
-  uint32_t *wave_tot = gbase + FJ_MAX_BINS;                             // [THREADS / WAVE]
+  uint32_t *tk = reinterpret_cast<uint32_t *>(fj_lds);                  // [TILE + 4]: narrowed keys regrouped by bin; [TILE] = trash slot
+  uint32_t *hist = tk + FJ_TILE + 4;                                    // [MAX_BINS + 4] counts, then exclusive starts; [MAX_BINS] = trash bin
+  uint32_t *gbase = hist + FJ_MAX_BINS + 4;                             // [MAX_BINS + 4] destination of LDS position 0 of a bin
+  uint32_t *wave_tot = gbase + FJ_MAX_BINS + 4;                         // [THREADS / WAVE]
   const uint32_t nbins = a.world << a.c1;
   const uint32_t xcd = blockIdx.x & 7u;
   const uint32_t begin = blockIdx.x * a.chunk;
@@ -3064,69 +3078,137 @@ __global__ __launch_bounds__(FJ_THREADS) void fj_scatter(FjSend a) {
   };
   for (uint32_t b = threadIdx.x; b < FJ_MAX_BINS + 4; b += FJ_THREADS) hist[b] = 0;
   block_sync();
+  // Every address is the tile's (uniform) base plus a 32-bit offset below 2^18: one register per access instead of a 64-bit
+  // pointer each (with clamped 64-bit addresses for 32 loads and 32 stores the kernel spilled 380 bytes per lane).
+  // The first round of the NEXT tile is requested before this tile's flush (pre[]): its latency hides behind the stores,
+  // the one workgroup of a CU has nothing else to overlap it with.
+  K pre[FJ_ROUND];
+  // (UNCONDITIONAL: behind `if (there is a next tile)` pre[] stays live across the whole tile body -- the skipped case
+  // carries the old values around the loop -- and the allocator spills it, i.e. waits for each load right after issuing it.
+  // Without a next tile every lane re-reads the chunk's first key: one cache line.)
+  auto prefetch = [&](uint32_t tile) {
+    const uint32_t tid = opaque_tid();
+    const bool real = tile < end;
+    const K *base = col + (real ? tile : begin);
+    const uint32_t live = !real ? 1u : (end - tile < (uint32_t)FJ_TILE ? end - tile : (uint32_t)FJ_TILE);
+#pragma unroll
+    for (int k = 0; k < FJ_ROUND; ++k) {
+      const uint32_t o = k * FJ_THREADS + tid;
+      pre[k] = __builtin_nontemporal_load(at32(base, o < live ? o : live - 1));
+    }
+  };
+  if (begin >= end) return;
+  prefetch(begin);
   for (uint32_t tile = begin; tile < end; tile += FJ_TILE) {
-    K raw[FJ_ITEMS];
+    constexpr bool FULL = false;                      // (a separate instantiation for full tiles made the allocator spill pre[])
+    const K *tcol = col + tile;
+    uint32_t *tpos = a.out_pos + tile;
+    const uint32_t live = FULL ? (uint32_t)FJ_TILE : end - tile;
+    // per item: the narrowed key (32 registers), its rank within (tile, bin) as 16 bits (16 registers) and one bit "travels";
+    // the bin is hashed again where it is needed -- kept next to key and rank it is 32 more registers and the kernel spills
+    uint32_t key[FJ_ITEMS], rk[FJ_ITEMS / 2], okmask = 0;
 #pragma unroll
-    for (int k = 0; k < FJ_ITEMS; ++k) {               // all loads first, clamped and unconditional
-      const uint32_t i = tile + k * FJ_THREADS + threadIdx.x;
-      raw[k] = __builtin_nontemporal_load(col + (i < end ? i : end - 1));
+    for (int h = 0; h < FJ_ITEMS; h += FJ_ROUND) {
+      const uint32_t tid = opaque_tid();
+      K raw[FJ_ROUND];
+#pragma unroll
+      for (int k = 0; k < FJ_ROUND; ++k) {             // all loads of the round first, unconditional (round 0: prefetched)
+        const uint32_t o = (h + k) * FJ_THREADS + tid;
+        if (h == 0) raw[k] = pre[k];
+        else raw[k] = __builtin_nontemporal_load(at32(tcol, FULL || o < live ? o : live - 1));
+      }
+      uint32_t bin[FJ_ROUND];
+#pragma unroll
+      for (int q = 0; q < FJ_ROUND; q += 4) {          // four hashes at a time (interleaved by the dozen they spill)
+#pragma unroll
+        for (int k = q; k < q + 4; ++k) {
+          const uint32_t o = (h + k) * FJ_THREADS + tid;
+          const unsigned long long off = (unsigned long long)((long long)raw[k] - a.lo);
+          const bool travels = (FULL || o < live) && off <= a.span;
+          key[h + k] = (uint32_t)off;
+          okmask |= (uint32_t)travels << (h + k);
+          const uint32_t b = bin_of_key(key[h + k]);                 // hashed whether it travels or not: no branch
+          bin[k] = travels ? b : (uint32_t)FJ_MAX_BINS;              // MAX_BINS: the trash counter
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int k = 0; k < FJ_ROUND; ++k) bin[k] = atomicAdd(&hist[bin[k]], 1u);      // a round in flight, one wait
+#pragma unroll
+      for (int k = 0; k < FJ_ROUND; k += 2) {
+        rk[(h + k) / 2] = bin[k] | (bin[k + 1] << 16);               // a rank is below 32768
+        asm volatile("" : "+v"(rk[(h + k) / 2]));                    // packed HERE, not after the next round's loads
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    uint32_t key[FJ_ITEMS], br[FJ_ITEMS];
-#pragma unroll
-    for (int k = 0; k < FJ_ITEMS; ++k) {
-      const uint32_t i = tile + k * FJ_THREADS + threadIdx.x;
-      const unsigned long long off = (unsigned long long)((long long)raw[k] - a.lo);
-      key[k] = (uint32_t)off;
-      br[k] = (i < end && off <= a.span) ? bin_of_key(key[k]) : (uint32_t)FJ_MAX_BINS;      // MAX_BINS: trash counter, does not travel
-    }
-#pragma unroll
-    for (int k = 0; k < FJ_ITEMS; ++k) br[k] = (br[k] << 16) | atomicAdd(&hist[br[k]], 1u);
     block_sync();
     {   // claim the runs, exclusive scan of the counts (thread t owns bin t)
-      const uint32_t cnt = threadIdx.x < nbins ? hist[threadIdx.x] : 0;
+      const uint32_t tid = opaque_tid();
+      const uint32_t cnt = tid < nbins ? hist[tid] : 0;
       uint32_t gb = 0;
       if (cnt) {
-        const uint32_t region = (threadIdx.x << 3) | xcd;
+        const uint32_t region = (tid << 3) | xcd;
         const uint32_t at = atomicAdd(&a.fill[region], cnt);
         if (at + cnt > a.cap) { atomicExch(a.overflow, 1u); gb = dump; }
         else gb = region * a.cap + at;
       }
       const uint32_t incl = wave_scan_incl(cnt);
-      if (lane_id() == WAVE - 1) wave_tot[threadIdx.x / WAVE] = incl;
+      if (lane_id() == WAVE - 1) wave_tot[tid / WAVE] = incl;
       block_sync();
       uint32_t start = incl - cnt;
-      for (int w = 0; w < (int)(threadIdx.x / WAVE); ++w) start += wave_tot[w];
-      hist[threadIdx.x] = start;
-      gbase[threadIdx.x] = gb - start;
+      for (int w = 0; w < (int)(tid / WAVE); ++w) start += wave_tot[w];
+      hist[tid] = start;
+      gbase[tid] = gb - start;
     }
     block_sync();
     uint32_t total = 0;
     for (int w = 0; w < FJ_THREADS / WAVE; ++w) total += wave_tot[w];
+    // regroup in LDS; the row's destination leaves right away, in row order (coalesced, nobody re-reads it soon)
 #pragma unroll
-    for (int k = 0; k < FJ_ITEMS; ++k) {
-      const uint32_t bin = br[k] >> 16;
-      if (bin < FJ_MAX_BINS) {
-        const uint32_t i = tile + k * FJ_THREADS + threadIdx.x;
-        tw[hist[bin] + (br[k] & 0xffffu)] = ((uint64_t)key[k] << 32) | (uint32_t)(a.row_base + (int32_t)i);
+    for (int h = 0; h < FJ_ITEMS; h += 8) {
+      const uint32_t tid = opaque_tid();
+      uint32_t st[8], gbv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t b = bin_of_key(key[h + k]) & (FJ_MAX_BINS - 1);
+        st[k] = hist[b];
+        gbv[k] = gbase[b];
       }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t o = (h + k) * FJ_THREADS + tid;
+        const bool travels = (okmask >> (h + k)) & 1u;
+        const uint32_t rank = (rk[(h + k) / 2] >> (16 * (k & 1))) & 0xffffu;
+        const uint32_t pos = travels ? st[k] + rank : (uint32_t)FJ_TILE;
+        tk[pos] = key[h + k];
+        if (FULL || o < live) __builtin_nontemporal_store(travels ? pos + gbv[k] : 0xffffffffu, at32(tpos, o));
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     block_sync();
-#pragma unroll
-    for (int k = 0; k < FJ_ITEMS; ++k) {
-      const uint32_t j = threadIdx.x + k * FJ_THREADS;
-      if (j < total) {
-        const uint64_t w = tw[j];
-        const uint32_t dst = gbase[bin_of_key((uint32_t)(w >> 32))] + j;
-        a.out_keys[dst] = (uint32_t)(w >> 32);
-        a.out_rows[dst] = (int32_t)(uint32_t)w;
-      }
-    }
-    block_sync();
+    // the starts are used up: clear the counters for the next tile's ranking here instead of behind one more barrier pair
     for (uint32_t b = threadIdx.x; b < FJ_MAX_BINS + 4; b += FJ_THREADS) hist[b] = 0;
-    block_sync();
+    prefetch(tile + FJ_TILE);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int h = 0; h < FJ_ITEMS; h += 8) {              // unconditional stores: dead slots go to this thread's dump slot
+      const uint32_t tid = opaque_tid();
+      uint32_t w[8], gbv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) w[k] = tk[tid + (h + k) * FJ_THREADS];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) gbv[k] = gbase[bin_of_key(w[k]) & (FJ_MAX_BINS - 1)];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t j = tid + (h + k) * FJ_THREADS;
+        a.out_keys[j < total ? gbv[k] + j : dump + tid] = w[k];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    block_sync();                                        // the tile and gbase are free again
   }
 }
-static constexpr size_t fj_scatter_lds() { return 8 * (size_t)(FJ_TILE + 2) + 4 * (size_t)(2 * FJ_MAX_BINS + 4 + FJ_THREADS / WAVE) + 16; }
+static constexpr size_t fj_scatter_lds() { return 4 * (size_t)(FJ_TILE + 4) + 4 * (size_t)(2 * (FJ_MAX_BINS + 4) + FJ_THREADS / WAVE) + 16; }
 
 // layout agreed by all ranks from global numbers only
 static gdf_error fj_plan(int world, int64_t build_rows_total, int64_t rows_max, double dup, int *fine_bits, int *coarse_bits, uint32_t *cap) {
@@ -3156,15 +3238,15 @@ static gdf_error fj_plan(int world, int64_t build_rows_total, int64_t rows_max, 
   return GDF_SUCCESS;
 }
 
-static gdf_error fj_send(gdf_column *keys, int64_t lo, int64_t hi, int world, int coarse_bits, uint32_t cap, int32_t row_base,
-                         uint32_t *out_keys, int32_t *out_rows, uint32_t *out_fill, int *overflowed) {
-  GDF_REQUIRE(keys && out_keys && out_rows && out_fill && overflowed, GDF_DATASET_EMPTY);
+static gdf_error fj_send(gdf_column *keys, int64_t lo, int64_t hi, int world, int coarse_bits, uint32_t cap,
+                         uint32_t *out_keys, uint32_t *out_pos, uint32_t *out_fill, int *overflowed) {
+  GDF_REQUIRE(keys && out_keys && out_pos && out_fill && overflowed, GDF_DATASET_EMPTY);
   GDF_REQUIRE(!keys->valid, GDF_VALIDITY_UNSUPPORTED);
   const ElemKind kind = elem_kind(keys->dtype);
   GDF_REQUIRE(kind == K_I64 || kind == K_I32, GDF_UNSUPPORTED_DTYPE);
   GDF_REQUIRE(world >= 1 && coarse_bits >= 0 && ((uint64_t)world << coarse_bits) <= (uint64_t)FJ_MAX_BINS, GDF_INVALID_API_CALL);
   GDF_REQUIRE(hi >= lo && (uint64_t)hi - (uint64_t)lo < 0xffffffffULL, GDF_INVALID_API_CALL);
-  GDF_REQUIRE(keys->size < (size_t)INT_MAX && (uint64_t)keys->size + (uint64_t)(uint32_t)row_base < (uint64_t)INT_MAX, GDF_COLUMN_SIZE_TOO_BIG);
+  GDF_REQUIRE(keys->size < (size_t)INT_MAX, GDF_COLUMN_SIZE_TOO_BIG);
   const uint32_t nregions = ((uint32_t)world << coarse_bits) << 3;
   HIP_TRY(hipMemsetAsync(out_fill, 0, sizeof(uint32_t) * ((size_t)nregions + 1), stream0()));      // [nregions]: the overflow flag
   *overflowed = 0;
@@ -3178,10 +3260,9 @@ static gdf_error fj_send(gdf_column *keys, int64_t lo, int64_t hi, int world, in
   a.world = (uint32_t)world;
   a.c1 = coarse_bits;
   a.cap = cap;
-  a.row_base = row_base;
   a.chunk = (uint32_t)FJ_CHUNK;
   a.out_keys = out_keys;
-  a.out_rows = out_rows;
+  a.out_pos = out_pos;
   a.fill = out_fill;
   a.overflow = out_fill + nregions;
   const unsigned grid = (unsigned)(((uint64_t)a.n + a.chunk - 1) / a.chunk);
@@ -3362,9 +3443,8 @@ __attribute__((visibility("default"))) gdf_error gdf_amd_fj_plan(int world, int6
   return fj_plan(world, build_rows_total, rows_max, rows_per_key, fine_bits, coarse_bits, cap);
 }
 __attribute__((visibility("default"))) gdf_error gdf_amd_fj_send(gdf_column *keys, int64_t lo, int64_t hi, int world, int coarse_bits, uint32_t cap,
-                                                                int32_t row_base, uint32_t *out_keys, int32_t *out_rows, uint32_t *out_fill,
-                                                                int *overflowed) {
-  return fj_send(keys, lo, hi, world, coarse_bits, cap, row_base, out_keys, out_rows, out_fill, overflowed);
+                                                                uint32_t *out_keys, uint32_t *out_pos, uint32_t *out_fill, int *overflowed) {
+  return fj_send(keys, lo, hi, world, coarse_bits, cap, out_keys, out_pos, out_fill, overflowed);
 }
 __attribute__((visibility("default"))) gdf_error gdf_amd_fj_build_create(const uint32_t *recv_keys, const uint32_t *recv_fill, int world, int64_t lo,
                                                                         int fine_bits, int coarse_bits, uint32_t cap, int64_t expected_rows,

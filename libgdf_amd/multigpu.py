@@ -497,6 +497,8 @@ class FusedPairs:
         import torch.distributed as dist
         world = dist.get_world_size(self.group)
         blk = layout.block
+        if hasattr(rows_buf, "materialize"):                         # api.FjRows: position -> row, inverted only now
+            rows_buf = rows_buf.materialize()
         recv = torch.empty(world * blk, dtype=rows_buf.dtype, device=rows_buf.device)
         _all_to_all_v(recv, rows_buf[:world * blk], [blk] * world, [blk] * world, self.group, async_op=False)
         return recv
@@ -645,7 +647,7 @@ def fused_inner_join(probe_keys, build_keys, group=None, chunks=4, plan_fn=_fj_p
 # of V bytes per rank puts V / world on every link, and the time is that of the busiest link, not of the aggregate.
 XGMI_LINK_BYTES_PER_S = 60e9
 _SHUFFLE_LOCAL_S_PER_ROW = 15.1e-12      # sender split + receiver partition + probe, per row of (probe + build): 17.0 ms at C4 shard sizes
-_FUSED_LOCAL_S_PER_ROW = 11.8e-12        # sender level 1 + receiver level 2 + probe: 13.3 ms at C4 shard sizes (tools/sim_c4_fused.py)
+_FUSED_LOCAL_S_PER_ROW = 11.3e-12        # sender level 1 + receiver level 2 + probe: 12.7 ms at C4 shard sizes (tools/sim_c4_fused.py)
 _FUSED_BYTES_PER_ROW = 4.45              # 4-byte keys in fixed-size regions: + 6 sigma of room (11 % at ten probe rows per key)
 _JOIN_S_PER_PROBE_ROW = 9.6e-12          # gdf_inner_join, NARROW keys: 10.6 ms for 1e9 x 1e8
 _JOIN_S_PER_BUILD_ROW = 10e-12
@@ -676,7 +678,7 @@ def choose_join_strategy(world, probe_rows, build_rows):
     or "broadcast" (all-gather the build keys, probe rows stay home) -- whichever the cost model above expects to finish
     first.  With C4's shard sizes: broadcast at 2 GPUs (either exchange of the probe side would push > 2 GB through the one
     link between them), the shuffle at 4 (both exchanges are link-bound there and the shuffle sends exact sizes, the fused blocks
-    carry 11 % of room), the fused exchange at 8 (local passes bound both: 13.3 against 17.0 ms)."""
+    carry 11 % of room), the fused exchange at 8 (local passes bound both: 12.7 against 17.0 ms)."""
     est = estimate_join_seconds(world, probe_rows, build_rows)
     moving = min(("fused", "shuffle"), key=lambda k: est[k])                  # (fused falls back to the shuffle when its shape checks fail)
     # moving the probe relation rests on the ASSUMED link rate; leaving it at home does not: the exchange has to win by 10 %

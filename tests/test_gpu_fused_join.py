@@ -42,13 +42,13 @@ def _fused_self_join(gdf, probe, build, world, slices):
         prows.append(prow)
     li, ri = acc.finish()
     li, ri = li.long(), ri.long()
-    rows_b = brows[ri].cpu().numpy().astype(np.int64)
+    rows_b = brows.materialize()[ri].cpu().numpy().astype(np.int64)
     which = li // per_buf
     rows_p = np.empty(li.numel(), dtype=np.int64)
     for i in range(slices):
         sel = (which == i)
         if bool(sel.any()):
-            rows_p[sel.cpu().numpy()] = prows[i][li[sel] - i * per_buf].cpu().numpy()
+            rows_p[sel.cpu().numpy()] = prows[i].materialize()[li[sel] - i * per_buf].cpu().numpy()
     # the owner of a received key is the block it sits in: block index = mulhi(hash, world) of the key, checked on the build side
     assert int((ri // lay_b.block).max()) < world
     b.close()

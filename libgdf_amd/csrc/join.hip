@@ -2792,8 +2792,20 @@ static gdf_error join_entry(JoinKind kind, gdf_column **left_cols, int num_left_
   int o = 0;
   for (int c = 0; c < num_left_cols; ++c)
     if (!l_is_key[c]) left_jobs.push_back(GatherJob{left_cols[c], nullptr, result_cols[o++]});
-  for (int i = 0; i < num_cols_to_join; ++i)
-    left_jobs.push_back(GatherJob{left_cols[left_join_cols[i]], kind == JOIN_FULL ? right_cols[right_join_cols[i]] : nullptr, result_cols[o++]});
+  // INNER join, integer keys of one dtype: a matched pair's two key values are the same bits, so the key column may be read
+  // from EITHER side -- and the rows of the smaller relation are the ones the pair list revisits (all pairs of a build
+  // partition are neighbours in the output and name the same few thousand build rows: their gather mostly hits L2, while
+  // the other side's row numbers are a random permutation -- one 64-byte sector fetched per 8-byte value)
+  const bool right_is_smaller = num_right_cols > 0 && num_left_cols > 0 && right_cols[0]->size < left_cols[0]->size;
+  for (int i = 0; i < num_cols_to_join; ++i) {
+    const gdf_column *lk = left_cols[left_join_cols[i]], *rk = right_cols[right_join_cols[i]];
+    const ElemKind ek = elem_kind(lk->dtype);
+    const bool same_bits = kind == JOIN_INNER && lk->dtype == rk->dtype && lk->dtype_info.time_unit == rk->dtype_info.time_unit &&
+                           (ek == K_I8 || ek == K_I16 || ek == K_I32 || ek == K_I64) &&
+                           (lk->valid == nullptr || lk->null_count == 0) && (rk->valid == nullptr || rk->null_count == 0);
+    if (same_bits && right_is_smaller) right_jobs.push_back(GatherJob{rk, nullptr, result_cols[o++]});
+    else left_jobs.push_back(GatherJob{lk, kind == JOIN_FULL ? rk : nullptr, result_cols[o++]});
+  }
   for (int c = 0; c < num_right_cols; ++c)
     if (!r_is_key[c]) right_jobs.push_back(GatherJob{right_cols[c], nullptr, result_cols[o++]});
   GDF_TRY(gather_columns(left_jobs, lmap, kind == JOIN_FULL ? rmap : nullptr, n));

@@ -117,13 +117,13 @@ def main():
     bwide = (splitmix64_torch(i + 0x5EED0031) >> 4) & ((1 << 60) - 1)          # splitmix64 is a bijection: distinct before the shift;
     del i                                                                       # a handful of collisions after it do not matter
     pwide = gather_keys(bwide, npr, 0x5EED0032)
-    timed("c3_wide_keys", lambda: join(pwide, bwide), jb(npr, nb), npr, "int64 keys spread over 2^60: WIDE tuples (key64 + row), general probe kernel")
+    timed("c3_wide_keys", lambda: join(pwide, bwide), jb(npr, nb), npr, "int64 keys spread over 2^60: WIDE tuples (key64 + row), lean probe kernel with two independent 32-bit folds")
     del pwide, bwide
     # 5. every build key four times (multimap semantics): the probe side shrinks so that the output stays 1e9 pairs
     npd = npr // 4
     bdup = build % (nb // 4)
     pdup = make_probe_keys(npd, nb // 4, 0x5EED0042, dev)
-    timed("dup4_build_keys", lambda: join(pdup, bdup), jb(npd, nb), npd, f"{npd} probe rows x {nb} build rows, every build key 4 times: linear-probing units, count + write")
+    timed("dup4_build_keys", lambda: join(pdup, bdup), jb(npd, nb), npd, f"{npd} probe rows x {nb} build rows, every build key 4 times: chained multimap units, count + write")
     del pdup, bdup, build
 
     # C2 and its sparse twin
@@ -134,7 +134,7 @@ def main():
     lut = (splitmix64_torch(i + 0x5EED0051) >> 2)                                  # 10 k keys scattered over 2^62
     sparse = lut[dense]
     for name, k, note in (("c2_dense_keys", dense, "10 k keys in [0, 1e4): direct-index path"),
-                          ("c2_sparse_keys", sparse, "the same 10 k groups under keys scattered over 2^62: dictionary path")):
+                          ("c2_sparse_keys", sparse, "the same 10 k groups under keys scattered over 2^62: LDS dictionary path (sample -> image -> 2-byte ids -> LDS accumulators)")):
         kc, vc = Column(k), Column(vals)
         timed(name, lambda: int(gdf.api.group_by("sum", [kc], vc, capacity=1 << 20)[1].numel()), lambda out: 16.0 * n2, n2,
               "gdf_group_by_sum int64 keys / int64 values, " + note)

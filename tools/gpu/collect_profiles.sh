@@ -7,12 +7,15 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
 timeout 3000 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" > $O/pytest_gpu.txt
-python bench.py 2>$O/bench.err | tail -1 > $O/bench.json
+python bench.py 2>$O/bench.err | grep '^{' | tail -1 > $O/bench.json
 python tools/bench_ops.py > $O/bench_ops.jsonl 2>/dev/null
 python tools/bench_c5.py 2>/dev/null | tail -1 > $O/bench_c5.json
 python tools/bench_shapes.py > $O/bench_shapes.jsonl 2>/dev/null
-python bench.py --force-distributed --strategy shuffle --steps 5 --warmup 2 --cpu-sample 0 --pandas-sample 0 2>/dev/null | tail -1 > $O/bench_c4_local_shuffle.json
-python bench.py --force-distributed --strategy broadcast --steps 5 --warmup 2 --cpu-sample 0 --pandas-sample 0 2>/dev/null | tail -1 > $O/bench_c4_local_broadcast.json
+for s in fused shuffle broadcast; do
+  python bench.py --force-distributed --strategy $s --steps 5 --warmup 2 --probe-rows 1000000000 --build-rows 125000000 --cpu-sample 0 --pandas-sample 0 2>/dev/null | grep '^{' | tail -1 > $O/bench_c4_local_$s.json
+done
+python tools/sim_c4_fused.py 2>/dev/null | tail -8 > $O/sim_c4.txt
+python tools/sim_c4_local.py 2>/dev/null | tail -8 >> $O/sim_c4.txt
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o join -- python $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 --pandas-sample 0 > $O/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o join -- python $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 --pandas-sample 0 > $O/pmc_fetch.log 2>&1

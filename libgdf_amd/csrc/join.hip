@@ -532,7 +532,8 @@ __device__ __forceinline__ void tile_flush(TileLds<NARROW, THREADS> &s, const Pa
     for (int u = 0; u < U; ++u) {
       if (g.dbg & 4) dst[u] &= 0xffffu;        // experiment: all stores land in a 512 KiB window
       if (j0 + u * THREADS < total && !(g.dbg & 1)) {
-        out.w[dst[u]] = ww[u];
+        if (g.dbg & 16) __builtin_nontemporal_store(ww[u], out.w + dst[u]);      // experiment: streaming stores (level 2)
+        else out.w[dst[u]] = ww[u];
         if (!NARROW) out.idx[dst[u]] = ii[u];
       }
     }
@@ -692,7 +693,8 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
         uint32_t dst = j < total ? gb[k] + j : g.dump + ftid;
         if (g.dbg & 4) dst &= 0xffffu;           // experiment: all stores land in a 512 KiB window
         if (g.dbg & 1) dst = g.dump + ftid;      // experiment: no useful stores
-        out.w[dst] = ww[k];
+        if (g.dbg & 8) __builtin_nontemporal_store(ww[k], out.w + dst);      // experiment: streaming stores (level 1)
+        else out.w[dst] = ww[k];
         if (!NARROW) out.idx[dst] = ii[k];
       }
       __builtin_amdgcn_sched_barrier(0);       // one group's LDS reads at a time: hoisted together they spill

@@ -88,3 +88,48 @@ def test_fused_plan_declines_what_it_cannot_take(gdf):
     assert api.fj_plan(8, 4 * 10**9, 5 * 10**8) is None                          # a rank's share needs a third partitioning level
     lay = api.fj_plan(8, 10**9, 125 * 10**6)
     assert lay is not None and lay.fine_bits == 15 and lay.coarse_bits == 7 and lay.world * (1 << lay.coarse_bits) == 1024
+
+
+@pytest.mark.parametrize("n", [1, 777, 32768, 32769, 200_001])
+def test_send_buffer_and_positions_describe_the_same_rows(gdf, n):
+    """gdf_amd_fj_send's contract: out_pos[i] is where row i's narrowed key went (0xffffffff for rows outside [lo, hi]); the
+    fill counters add up to the rows sent; every region holds only keys of its (rank, coarse partition) bin -- checked through
+    the receiver: joining the buffer against the same keys finds every sent row exactly once."""
+    import torch
+    from libgdf_amd import api
+    from libgdf_amd.columns import Column
+    rs = np.random.RandomState(n)
+    keys = rs.permutation(4 * n + 10)[:n].astype(np.int64) + 10**12
+    lo, hi = int(keys.min()) + (1 if n > 2 else 0), int(keys.max())           # (n > 2: the smallest key lies outside the range)
+    world = 4
+    lay = api.fj_plan(world, max(n * world, 1), n)
+    assert lay is not None
+    kb, rows, fill, over = api.fj_send(Column(torch.from_numpy(keys).cuda()), lo, hi, lay, 5)
+    assert not over
+    pos = rows.pos.cpu().numpy().astype(np.int64) & 0xffffffff
+    sent = (keys >= lo) & (keys <= hi)
+    assert np.array_equal(pos != 0xffffffff, sent)
+    assert int(fill[:lay.nregions].sum()) == int(sent.sum())
+    assert len(np.unique(pos[sent])) == int(sent.sum())                         # no two rows share a position
+    buf = kb.cpu().numpy().astype(np.int64) & 0xffffffff
+    np.testing.assert_array_equal(buf[pos[sent]] + lo, keys[sent])              # the position holds the row's narrowed key
+    # positions lie inside the filled part of their region
+    region, off = pos[sent] // lay.cap, pos[sent] % lay.cap
+    assert bool((off < fill.cpu().numpy()[region]).all())
+    inv = rows.materialize().cpu().numpy()
+    np.testing.assert_array_equal(inv[pos[sent]], np.nonzero(sent)[0] + 5)      # row_base = 5
+    assert int((inv >= 0).sum()) == int(sent.sum())
+
+
+def test_send_reports_regions_that_overflow(gdf):
+    """Skewed keys: one key value repeated far beyond a region's capacity sets *overflowed (the caller then takes the shuffle)."""
+    import torch
+    from libgdf_amd import api
+    from libgdf_amd.columns import Column
+    n = 1_000_000
+    keys = np.full(n, 12345, dtype=np.int64)
+    keys[::3] = np.arange(0, n, 3)
+    lay = api.fj_plan(8, 8 * n, n)
+    assert lay is not None and lay.cap < n // 2
+    _, _, _, over = api.fj_send(Column(torch.from_numpy(keys).cuda()), 0, n, lay, 0)
+    assert over

@@ -109,18 +109,23 @@ def pmc_traffic(kernel, launches_per_step):
     collected and corrected and carries the build id of the kernels it measured -- counters of OTHER kernel sources are
     refused (traffic = null) instead of silently going stale."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json")), key=os.path.getmtime)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json")))      # by name: r1_a < r1_k < r2_z (mtimes do not survive a checkout)
     if not files:
         return None, "no profiles/*_pmc_hbm.json"
-    with open(files[-1]) as f:
-        data = json.load(f)
-    rel = os.path.relpath(files[-1], ROOT)
-    if data.get("build_id") != library_build_id():
-        return None, f"{rel} measured build {data.get('build_id')}, this is {library_build_id()}: refused"
-    k = data.get("kernels", {}).get(kernel)
-    if not k or not launches_per_step:
-        return None, rel
-    return k["hbm_bytes_per_join_corrected"] / launches_per_step, rel
+    mine = library_build_id()
+    seen = []
+    for path in reversed(files):
+        with open(path) as f:
+            data = json.load(f)
+        rel = os.path.relpath(path, ROOT)
+        if data.get("build_id") != mine:
+            seen.append(f"{rel} measured build {data.get('build_id')}")
+            continue
+        k = data.get("kernels", {}).get(kernel)
+        if not k or not launches_per_step:
+            return None, rel
+        return k["hbm_bytes_per_join_corrected"] / launches_per_step, rel
+    return None, f"this is build {mine}; " + "; ".join(seen[:2]) + ": refused"
 
 
 def cpu_baseline_pandas(sample_probe, sample_build, budget_s=60.0):

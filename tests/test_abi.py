@@ -33,6 +33,18 @@ def test_libgdf_exports_every_declared_symbol(libs):
     assert not missing, missing
 
 
+def test_libgdf_exports_every_extension_symbol(libs):
+    """include/gdf/gdf_amd_ext.h: the prepared-build / accumulated-probe handles, the shuffle partitions and the fused
+    multi-GPU join's four entry points -- what libgdf_amd/multigpu.py and a host in another language bind."""
+    gdf, _ = libs
+    names = _declared(os.path.join(ROOT, "include", "gdf", "gdf_amd_ext.h")) - _declared(os.path.join(ROOT, "include", "gdf", "gdf.h"))
+    assert {"gdf_amd_fj_plan", "gdf_amd_fj_send", "gdf_amd_fj_build_create", "gdf_amd_fj_probe_add", "gdf_amd_join_build_create",
+            "gdf_amd_join_probe_begin", "gdf_amd_shuffle_partition_stable", "gdf_amd_narrow_keys"} <= names, sorted(names)
+    missing = [n for n in sorted(names) if not hasattr(gdf, n)]
+    assert not missing, missing
+    assert hasattr(gdf, "gdf_amd_profile_read")           # (its array-pointer argument escapes the declaration regex)
+
+
 def test_librmm_exports_every_declared_symbol(libs):
     _, rmm = libs
     names = _declared(os.path.join(ROOT, "include", "memory.h"))

@@ -18,7 +18,8 @@
 // correct, but LOSES on this part: a tile has to learn the sum of everything before it from other workgroups, through
 // words that cross the XCDs' non-coherent L2s (agent-scope 8-byte {flag, data} stores / loads, ~2 us per round trip under
 // load), and it can only finish after the slowest load among the few hundred tiles in flight before it.  Measured on 1e8
-// int64 (profiles/r2_c_scan_ablation.md): the same kernel without the look-back 0.27 ms (5.9 TB/s), with ticket order
+// int64 (profiles/r2_c_scan_ablation.md; GDF_SCAN_LOOKBACK=2 replaces the look-back by a SPINE workgroup that publishes every
+// tile's exclusive prefix, one polled word per tile: 0.50 ms): the same kernel without the look-back 0.27 ms (5.9 TB/s), with ticket order
 // 0.32, with a one-wave / 256-wide / software-pipelined look-back 0.64 / 0.64 / 0.55 ms -- against 0.49 ms for round 1's
 // three launches.  The streaming half of that kernel is what the coalesced kernels above reuse.
 #include "internal.h"
@@ -183,7 +184,71 @@ __global__ __launch_bounds__(LB_THREADS) void scan_lookback(const ELEM *in, ELEM
   __shared__ ACC wsum[NWAVES];
   __shared__ Round s_round[NWAVES];
   __shared__ uint32_t s_tile[2];
+  __shared__ ACC s_excl;
+  __shared__ uint32_t s_first[NWAVES];
   const int wave = threadIdx.x / WAVE, lane = lane_id();
+
+  // dbg & 4: SPINE mode.  Workgroup 0 does nothing but turn tile aggregates into exclusive prefixes, in tile order: every
+  // round it reads the next 1024 aggregates (four per thread, all loads in flight together), takes the leading run that
+  // is already published, scans it and publishes the prefixes.  A worker then polls ONE word -- its own prefix -- instead
+  // of walking back over hundreds of predecessors, each round of which is a cross-XCD round trip.  The spine consumes up
+  // to 1024 tiles per round trip (~2.5 us): several times the ~80 tiles per us the data path needs.
+  if ((dbg & 4) && blockIdx.x == 0) {
+    constexpr int PT = 4;
+    ACC carry = 0;
+    uint32_t base = 0;
+    while (base < ntiles) {
+      ACC agg[PT];
+      bool have[PT];
+#pragma unroll
+      for (int k = 0; k < PT; ++k) {
+        const uint32_t t = base + threadIdx.x * PT + k;
+        agg[k] = 0;
+        have[k] = t < ntiles && lb_read<ACC>(state + (size_t)t * 2 * NW, agg[k]);
+      }
+      int lead = 0;
+      ACC mine = 0, part[PT];
+#pragma unroll
+      for (int k = 0; k < PT; ++k) {
+        part[k] = mine;                       // sum of this thread's published tiles before tile k
+        if (lead == k && have[k]) { mine += agg[k]; ++lead; }
+      }
+      const unsigned long long short_m = __ballot(lead < PT);
+      block_sync();                           // s_first / wsum readers of the previous round are done
+      if (lane == 0) s_first[wave] = short_m ? (uint32_t)(wave * WAVE + __ffsll((long long)short_m) - 1) : 0xffffffffu;
+      block_sync();
+      uint32_t tstar = 0xffffffffu;
+#pragma unroll
+      for (int w = NWAVES - 1; w >= 0; --w) if (s_first[w] != 0xffffffffu) tstar = s_first[w];
+      if (threadIdx.x > tstar) { mine = 0; lead = 0; }
+      const ACC inc = wave_scan_incl(mine);
+      if (lane == WAVE - 1) wsum[wave] = inc;
+      block_sync();
+      ACC woff = 0, total = 0;
+#pragma unroll
+      for (int w = 0; w < NWAVES; ++w) {
+        if (w < wave) woff += wsum[w];
+        total += wsum[w];
+      }
+      const ACC mybase = carry + woff + inc - mine;
+#pragma unroll
+      for (int k = 0; k < PT; ++k)
+        if (k < lead) lb_publish<ACC>(state + ((size_t)(base + threadIdx.x * PT + k) * 2 + 1) * NW, (ACC)(mybase + part[k]));
+      const uint32_t done = tstar == 0xffffffffu ? (uint32_t)(LB_THREADS * PT) : tstar * PT;
+      // (+ the leading tiles of thread tstar itself)
+      uint32_t extra = 0;
+      if (tstar != 0xffffffffu) {
+        block_sync();
+        if (threadIdx.x == tstar) s_first[0] = (uint32_t)lead;
+        block_sync();
+        extra = s_first[0];
+      }
+      carry += total;
+      base += done + extra;
+      if (done + extra == 0) __builtin_amdgcn_s_sleep(4);
+    }
+    return;
+  }
 
   // No LDS transposition (its 37 KB per workgroup halved the occupancy of a kernel that lives on bytes in flight): wave w
   // owns SEG consecutive elements and reads them as 16-byte vectors, vector k * 64 + lane in round k -- 1 KB contiguous
@@ -264,6 +329,16 @@ __global__ __launch_bounds__(LB_THREADS) void scan_lookback(const ELEM *in, ELEM
   // look-back for a scanned tile, the whole workgroup: thread t examines tile - 1 - t (a tile before the first one has
   // prefix 0); both words of a predecessor are requested together -- one round trip, not two
   auto resolve = [&](const Scanned &sc) -> ACC {
+    if (dbg & 4) {                  // spine mode: the tile's exclusive prefix arrives in its own slot
+      block_sync();                 // s_excl's previous readers are done
+      if (threadIdx.x == 0) {
+        ACC e = 0;
+        while (!lb_read<ACC>(state + ((size_t)sc.tile * 2 + 1) * NW, e)) __builtin_amdgcn_s_sleep(1);
+        s_excl = e;
+      }
+      block_sync();
+      return s_excl;
+    }
     ACC exclusive = 0;
     long long nearest = (long long)sc.tile - 1;
     for (; !(dbg & 2);) {           // dbg & 2 (experiment): no look-back, wrong prefixes
@@ -373,7 +448,8 @@ template <class ACC, class ELEM>
 static gdf_error device_scan_lookback(const ELEM *in, ELEM *out, size_t n, bool inclusive) {
   constexpr int NW = sizeof(ACC) / 4;
   const size_t ntiles = (n + LB_TILE - 1) / LB_TILE;
-  static const int dbg = getenv("GDF_SCAN_DBG") ? atoi(getenv("GDF_SCAN_DBG")) : 0;
+  static const int dbg = (getenv("GDF_SCAN_DBG") ? atoi(getenv("GDF_SCAN_DBG")) : 0) |
+                         (getenv("GDF_SCAN_LOOKBACK") && atoi(getenv("GDF_SCAN_LOOKBACK")) == 2 ? 4 : 0);      // 2: spine mode
   DevBuf st;
   const size_t state_bytes = sizeof(unsigned long long) * ntiles * 2 * NW;
   RMM_TRY(st.alloc(state_bytes + sizeof(unsigned long long)));
@@ -388,7 +464,8 @@ static gdf_error device_scan_lookback(const ELEM *in, ELEM *out, size_t n, bool 
     if (per_cu < 1) per_cu = 1;
   }
   size_t grid = (dbg & 1) ? ntiles : (size_t)NUM_CU * (size_t)per_cu;
-  if (grid > ntiles) grid = ntiles;
+  if (grid > ntiles + ((dbg & 4) ? 1 : 0)) grid = ntiles + ((dbg & 4) ? 1 : 0);      // spine mode: workgroup 0 takes no tiles
+  if ((dbg & 4) && grid < 2) grid = 2;
   GDF_LAUNCH("scan_lookback", (scan_lookback<ACC, ELEM>), dim3((unsigned)grid), dim3(LB_THREADS), 0, stream0(), in, out, n,
              inclusive ? 1 : 0, st.as<unsigned long long>(), ticket, (uint32_t)ntiles, dbg);
   HIP_CHECK_LAST();
@@ -566,7 +643,7 @@ gdf_error device_scan(const ELEM *in, ELEM *out, size_t n, bool inclusive) {
   // 16-byte accesses need 16-byte-aligned columns (a column may be a slice of a larger buffer): those take the coalesced
   // kernels, or -- GDF_SCAN_LOOKBACK=1, an experiment that lost, see the header -- the single-pass kernel; the rest, and
   // GDF_SCAN_BLOCKED=1, the element-wise kernels of round 1
-  static const bool lookback = getenv("GDF_SCAN_LOOKBACK") != nullptr, blocked = getenv("GDF_SCAN_BLOCKED") != nullptr;
+  static const bool lookback = getenv("GDF_SCAN_LOOKBACK") && atoi(getenv("GDF_SCAN_LOOKBACK")) > 0, blocked = getenv("GDF_SCAN_BLOCKED") != nullptr;
   if (!blocked && ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0)) {
     if (lookback && n / LB_TILE < 0x7fffffffULL) return device_scan_lookback<ACC, ELEM>(in, out, n, inclusive);
     return device_scan_coalesced<ACC, ELEM>(in, out, n, inclusive);

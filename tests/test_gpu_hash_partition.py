@@ -158,10 +158,10 @@ def test_prefixsum_single_pass_kernel_in_a_subprocess():
         "            assert np.array_equal(got, exp), (dt, n, inc)\n"
         "print('ok')\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for switch in ("GDF_SCAN_LOOKBACK", "GDF_SCAN_BLOCKED"):
-        env = dict(os.environ, PYTHONPATH=root, **{switch: "1"})
+    for switch, value in (("GDF_SCAN_LOOKBACK", "1"), ("GDF_SCAN_LOOKBACK", "2"), ("GDF_SCAN_LOOKBACK", "0"), ("GDF_SCAN_BLOCKED", "1")):
+        env = dict(os.environ, PYTHONPATH=root, **{switch: value})
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0 and "ok" in r.stdout, (switch, r.stdout[-500:], r.stderr[-2000:])
+        assert r.returncode == 0 and "ok" in r.stdout, (switch, value, r.stdout[-500:], r.stderr[-2000:])
 
 
 def test_prefixsum_large_wraps_like_numpy(gdf):

@@ -20,6 +20,16 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o join -- python $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 --pandas-sample 0 > $O/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o join -- python $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 --pandas-sample 0 > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o join -- python $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 --pandas-sample 0 > $O/pmc_write.log 2>&1
+# HBM bytes of the round's new kernels: C5's fused partition pass, the fused multi-GPU join, the LDS dictionary
+pmc2() {   # tag, command...
+  tag=$1; shift
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_${tag}_f -o x -- "$@" > $O/pmc_${tag}.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_${tag}_w -o x -- "$@" >> $O/pmc_${tag}.log 2>&1
+  (cd $R && python tools/pmc_hbm_json.py $(find $O/pmc_${tag}_f -name "*counter_collection.csv" | head -1) $(find $O/pmc_${tag}_w -name "*counter_collection.csv" | head -1) $O/pmc_${tag}_hbm_bytes.json "$*  (totals over all launches of the command: divide by launches)") > $O/pmc_${tag}.txt
+}
+pmc2 c5 python $R/tools/bench_c5.py --reps 1
+pmc2 fused python $R/tools/sim_c4_fused.py
+pmc2 c2sparse python $R/tools/bench_shapes.py --only c2_sparse_keys --reps 1
 cd $R
 python tools/rocprof_summary.py $O/trace $O/kernel_stats.md
 python tools/pmc_hbm_json.py $(find $O/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $O/pmc_write -name "*counter_collection.csv" | head -1) $O/pmc_hbm.json

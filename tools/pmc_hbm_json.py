@@ -35,7 +35,7 @@ def main():
     write, _ = collect(sys.argv[2], "WRITE_SIZE")
     kernels = {}
     for k in fetch:
-        if not k.startswith(("jk_", "gj_", "scan_", "gb_", "rs_", "sg_", "hp_")):
+        if not k.startswith(("jk_", "gj_", "scan_", "gb_", "gbp_", "rs_", "sg_", "hp_", "fj_", "stable_", "part_")):
             continue
         kernels[k] = {"fetch_kb_reported": fetch[k], "write_kb_reported": write.get(k, 0.0), "launches": nf[k],
                       "hbm_bytes_per_join_corrected": 2.0 * fetch[k] * 1024.0 + write.get(k, 0.0) * 1024.0}
@@ -51,7 +51,7 @@ def main():
     with open(sys.argv[3], "w") as f:
         json.dump(out, f, indent=1)
     for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["hbm_bytes_per_join_corrected"]):
-        print(f"{k:28s} launches {v['launches']:3d}  HBM bytes {v['hbm_bytes_per_join_corrected'] / 1e9:8.3f} GB")
+        print(f"{k:28s} launches {v['launches']:3d}  HBM bytes {v['hbm_bytes_per_join_corrected'] / 1e9:8.3f} GB  per launch {v['hbm_bytes_per_join_corrected'] / max(v['launches'], 1) / 1e9:8.3f} GB")
 
 
 if __name__ == "__main__":

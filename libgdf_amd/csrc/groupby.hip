@@ -800,9 +800,23 @@ __global__ __launch_bounds__(GB_LD_THREADS) void gb_ld_image(GbDict g, const uin
     return;
   }
   for (uint32_t i = threadIdx.x; i < GB_LD_SLOTS; i += GB_LD_THREADS) tab[i] = GB_LD_EMPTY;
-  for (uint32_t i = threadIdx.x; i < ngroups; i += GB_LD_THREADS) {
-    const uint32_t slot = group_slot[i];
-    keys[i] = slot == g.T ? GB_EMPTY_KEY : g.e[slot].key;
+  {   // the keys by id: two dependent gathers (id -> slot -> key), each as ONE round of loads (in a rolled loop they were
+      // eleven round trips in a row: most of this kernel's 33 us)
+    constexpr int PER = (GB_LD_MAX_GROUPS + GB_LD_THREADS - 1) / GB_LD_THREADS;
+    uint32_t slot[PER];
+    unsigned long long kv[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const uint32_t i = k * GB_LD_THREADS + threadIdx.x;
+      slot[k] = i < ngroups ? group_slot[i] : g.T;
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) kv[k] = slot[k] == g.T ? GB_EMPTY_KEY : g.e[slot[k]].key;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const uint32_t i = k * GB_LD_THREADS + threadIdx.x;
+      if (i < ngroups) keys[i] = kv[k];
+    }
   }
   block_sync();
   bool bad = false;
@@ -1194,20 +1208,35 @@ __global__ __launch_bounds__(GB_DENSE_THREADS) void gb_direct_aggregate(KeyTable
 // one workgroup: compacts the non-empty ids in ascending order (= lexicographic key order) and finishes the aggregates
 __global__ __launch_bounds__(1024) void gb_direct_extract(KeyTable t, GbDirect d, GbOut o, int op, const unsigned long long *gacc,
                                                           const unsigned long long *gcnt, unsigned int *out_groups) {
-  __shared__ uint32_t wave_tot[1024 / WAVE];
-  const uint32_t per = (d.total + 1023) / 1024;
-  const uint32_t first = threadIdx.x * per;
-  uint32_t mine = 0;
-  for (uint32_t k = 0; k < per; ++k) { const uint32_t id = first + k; if (id < d.total && gcnt[id]) ++mine; }
-  const uint32_t incl = wave_scan_incl(mine);
-  if (lane_id() == WAVE - 1) wave_tot[threadIdx.x / WAVE] = incl;
+  // Workgroup b writes the non-empty ids of [1024 b, 1024 b + 1024), one id per thread.  Where its output starts -- the number
+  // of non-empty ids before its block -- it counts itself: at most 11 more loads per thread, all in flight together.  (As ONE
+  // workgroup walking twelve ids per thread this kernel took 30-38 us of C2's 440.)
+  __shared__ uint32_t wave_tot[1024 / WAVE], wave_own[1024 / WAVE];
+  constexpr uint32_t MAXB = (GB_DIRECT_MAX_IDS + 1023) / 1024;
+  const uint32_t nblocks = (d.total + 1023) / 1024;
+  uint32_t before_blocks = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < MAXB; ++k) {
+    const uint32_t id = k * 1024 + threadIdx.x;
+    // blocks before mine count towards my base (the last workgroup's base + its own count is the number of groups)
+    const bool wanted = k < blockIdx.x && id < d.total;
+    before_blocks += (wanted && gcnt[id] != 0) ? 1u : 0u;
+  }
+  const uint32_t id = blockIdx.x * 1024 + threadIdx.x;
+  const unsigned long long cnt = id < d.total ? gcnt[id] : 0ULL;
+  const unsigned long long acc = id < d.total ? gacc[id] : 0ULL;
+  const unsigned long long m = __ballot(cnt != 0);
+  const uint32_t bsum = wave_reduce_add(before_blocks);
+  if (lane_id() == 0) { wave_tot[threadIdx.x / WAVE] = bsum; wave_own[threadIdx.x / WAVE] = (uint32_t)__popcll(m); }
   block_sync();
-  uint32_t before = 0, total = 0;
-  for (int w = 0; w < 1024 / WAVE; ++w) { if (w < (int)(threadIdx.x / WAVE)) before += wave_tot[w]; total += wave_tot[w]; }
-  uint32_t pos = before + incl - mine;
-  for (uint32_t k = 0; k < per; ++k) {
-    const uint32_t id = first + k;
-    if (id >= d.total || !gcnt[id]) continue;
+  uint32_t base = 0, own_before = 0, own_total = 0;
+  for (int w = 0; w < 1024 / WAVE; ++w) {
+    base += wave_tot[w];
+    if (w < (int)(threadIdx.x / WAVE)) own_before += wave_own[w];
+    own_total += wave_own[w];
+  }
+  if (cnt) {
+    const uint32_t pos = base + own_before + mask_rank(m);
     for (int c = 0; c < d.ncols; ++c) {
       const uint64_t bits = (uint64_t)(d.lo[c] + (long long)((id / d.stride[c]) % d.span[c]));
       switch (t.col[c].width) {
@@ -1217,10 +1246,9 @@ __global__ __launch_bounds__(1024) void gb_direct_extract(KeyTable t, GbDirect d
         default: ((uint64_t *)o.key_out[c])[pos] = bits; break;
       }
     }
-    store_result(o, op, pos, gacc[id], gcnt[id]);
-    ++pos;
+    store_result(o, op, pos, acc, cnt);
   }
-  if (threadIdx.x == 0) *out_groups = total;
+  if (blockIdx.x == nblocks - 1 && threadIdx.x == 0) *out_groups = base + own_total;
 }
 
 // ---------------------------------------------------------------------------
@@ -1852,7 +1880,7 @@ static gdf_error gb_path_direct(GbJob &j, bool *done) {
       o.agg_out = out_agg->data;
       o.in_kind = (int)in_kind;
       o.agg_kind = (int)((op == OP_COUNT || op == OP_AVG) ? out_kind : in_kind);
-      GDF_LAUNCH("gb_extract", gb_direct_extract, dim3(1), dim3(1024), 0, stream0(), t, d, o, op, (const unsigned long long *)gacc.as<unsigned long long>(),
+      GDF_LAUNCH("gb_extract", gb_direct_extract, dim3((d.total + 1023) / 1024), dim3(1024), 0, stream0(), t, d, o, op, (const unsigned long long *)gacc.as<unsigned long long>(),
                  (const unsigned long long *)gcnt.as<unsigned long long>(), ng.as<unsigned int>());
       HIP_CHECK_LAST();
       unsigned int res[2] = {0, 0};                                                   // {groups, some row outside the window}

@@ -1027,7 +1027,11 @@ gdf_error gdf_hash_partition(int num_input_cols, gdf_column *input[], int column
     GDF_LAUNCH("part_scatter", (part_scatter_tile_kernel<MUR, FW, TH, MAXP, FI>), dim3(grid), dim3(TH), tl, stream0(), t, pc, n, chunk, \
                nchunks, P, pow2mask, hist.as<uint32_t>());                                                                             \
   } while (0)
-      if (P <= (uint32_t)HPT_MAX_PARTS) {
+      // 12288-row tiles of a 1024-thread workgroup win over 4096-row tiles of 256 threads at EVERY fan-out they share (1e8 rows x
+      // 2 int64 columns, scatter kernel: P = 64 0.73 vs 0.88 ms, P = 256 0.82 vs 1.07 ms): three times the run length.  The small
+      // shape stays behind GDF_HP_BIG_FROM=256
+      static const uint32_t big_from = getenv("GDF_HP_BIG_FROM") ? (uint32_t)atoi(getenv("GDF_HP_BIG_FROM")) : 16u;
+      if (P <= big_from && P <= (uint32_t)HPT_MAX_PARTS) {
         if (fastw == 8) HPT_LAUNCH(true, 8, 256, 256, 16);
         else if (fastw == 4) HPT_LAUNCH(true, 4, 256, 256, 16);
         else if (murmur) HPT_LAUNCH(true, 0, 256, 256, 16);

@@ -66,7 +66,7 @@ def main():
         timed("gdf_hash int64 -> int32", lambda: gdf.api.hash_rows([kc]), 12.0 * n)
     if "partition" in ops:
         kc, vc = Column(keys), Column(vals)
-        for p in (8, 256, 1000, 12000):
+        for p in (8, 64, 256, 1000, 12000):
             timed(f"gdf_hash_partition 2 x int64 columns, P={p}", lambda: gdf.api.hash_partition([kc, vc], [0], p), (16.0 + 16.0 + 8.0) * n,
                   {"note": "bytes = 2 cols read + 2 cols written + key re-read for the histogram"})
     if "scan" in ops:

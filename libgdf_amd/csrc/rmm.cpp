@@ -82,8 +82,11 @@ rmmError_t pool_alloc(Manager &m, void **ptr, size_t size) {
   const size_t want = round_size(size);
   std::lock_guard<std::mutex> g(m.mu);
   auto it = m.free_blocks.lower_bound(want);
-  // accept a cached block only if it wastes at most half of itself
-  if (it != m.free_blocks.end() && it->first <= 2 * want) {
+  // accept a cached block only if it wastes at most a fifth of itself.  (Up to half was accepted at first: a 4 GB request
+  // then took the 7.6 GB block another buffer of the same call needs a moment later, that one went to hipMalloc -- milliseconds
+  // for a block of this size -- and a join's steady state took several calls of such swaps to settle, if it ever did:
+  // tools/bench_shapes.py saw 13 - 16 ms per C3 join around 10.6 ms of kernels.)
+  if (it != m.free_blocks.end() && it->first <= want + want / 4) {
     *ptr = it->second;
     m.live_blocks[*ptr] = it->first;
     m.cached_bytes -= it->first;

@@ -619,3 +619,32 @@ def test_headline_configuration_properties(gdf):
         assert bool((probe[l] == build[r]).all())
         seen[l] = True
     assert bool(seen.all())                                         # 1e9 pairs, all probe rows covered: each exactly once
+
+
+@pytest.mark.parametrize("hit", [0.0, 0.05, 0.3, 0.44])
+@pytest.mark.parametrize("size", ["small", "large"])
+def test_selective_inner_join_single_pass_then_compaction(gdf, hit, size, monkeypatch):
+    """Well under one pair per probe row: one optimistic write pass into per-unit slot ranges, then jk_compact_units closes the
+    holes (instead of a count pass).  Same pair set as the count + write path (GDF_JK_NO_SPARSE_OPT), at a size that takes the
+    host-built units and at one that takes the device-built ones; repeated build keys inside the units are fine as long as a
+    unit's pairs fit its probe tuples' slots."""
+    import torch
+    from libgdf_amd.columns import Column
+    nb, npr = (40_000, 500_000) if size == "small" else (3_000_000, 30_000_000)
+    g = torch.Generator(device="cuda").manual_seed(int(hit * 100) + len(size))
+    b = torch.randperm(nb, device="cuda", generator=g)
+    b[: nb // 50] = b[nb // 50: 2 * (nb // 50)]                                   # 2 % of the build keys twice
+    span = max(nb + 1, int(nb / max(hit, 1e-9))) if hit > 0 else nb
+    p = torch.randint(0, span, (npr,), device="cuda", generator=g) + (0 if hit > 0 else nb + 5)
+    li, ri = gdf.api.join([Column(p)], [Column(b)])
+    monkeypatch.setenv("GDF_JK_NO_SPARSE_OPT", "1")
+    le, re_ = gdf.api.join([Column(p)], [Column(b)])
+    assert li.numel() == le.numel()
+    if li.numel():
+        assert bool((p[li.long()] == b[ri.long()]).all())
+        a = torch.sort(li.long() * nb + ri.long()).values
+        c = torch.sort(le.long() * nb + re_.long()).values
+        assert torch.equal(a, c)
+    mult = torch.bincount(b, minlength=nb)
+    inside = p[p < nb]
+    assert li.numel() == int(mult[inside].sum())

@@ -97,6 +97,9 @@ def main():
     timed("c3_half_hit", lambda: join(probe_half, build), jb(npr, nb), npr, "probe keys in [0, 2e8): 50 % hit rate -> sample rejects the optimistic pass: count + write")
     timed("c3_left_half_hit", lambda: join(probe_half, build, how="left"), jb(npr, nb), npr, "the same as a LEFT join: unmatched probe rows emit (l, -1)")
     del probe_half
+    probe_tenth = make_probe_keys(npr, 10 * nb, 0x5EED0013, dev)
+    timed("c3_tenth_hit", lambda: join(probe_tenth, build), jb(npr, nb), npr, "probe keys in [0, 1e9): 10 % hit rate -> one optimistic write pass into per-unit slots + compaction of the pair list")
+    del probe_tenth
     # 2. int32 keys
     b32, p32 = build.to(torch.int32), probe.to(torch.int32)
     timed("c3_int32_keys", lambda: join(p32, b32), lambda out: 4.0 * npr + 4.0 * nb + 8.0 * out, npr, "int32 key columns")

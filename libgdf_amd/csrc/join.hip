@@ -843,12 +843,17 @@ __global__ __launch_bounds__(JK_BK_THREADS) void jk_make_l2map(const uint32_t *_
     const uint32_t cs = seg >> 3, c = cs / fj_world, sender = cs - c * fj_world;
     return ((sender * ncoarse + c) << 3) | (seg & 7u);
   };
+  // A region that overflowed (skewed keys: its runs went to the dump slot and the overflow flag is up, the host will repeat
+  // the side with the exact layout) has a fill counter ABOVE its capacity: clamped, or the segments -- and level 2's reads --
+  // run past the region and, for the last ones, past the buffer.  (Found by tools/stress_join.py: an illegal address on a
+  // probe side with a tenth of its rows on one key.)
+  auto filled = [&](uint32_t region) -> uint32_t { const uint32_t n = fill[region]; return n < cap1 ? n : cap1; };
   uint32_t mine = 0;
-  for (uint32_t c = c0; c < c0 + per && c < nseg; ++c) mine += (fill[region_of(c)] + tile - 1) / tile;
+  for (uint32_t c = c0; c < c0 + per && c < nseg; ++c) mine += (filled(region_of(c)) + tile - 1) / tile;
   uint32_t total;
   uint32_t run = bk_block_scan<uint32_t>(mine, lds_wave, &total);
   for (uint32_t c = c0; c < c0 + per && c < nseg; ++c) {
-    const uint32_t r = region_of(c), n = fill[r];
+    const uint32_t r = region_of(c), n = filled(r);
     seg_begin[c] = r * cap1;
     seg_end[c] = r * cap1 + n;
     tile_prefix[c] = run;
@@ -882,7 +887,10 @@ __global__ __launch_bounds__(256) void jk_make_units(uint32_t nfine, uint32_t ca
   const uint32_t f = blockIdx.x * 256 + threadIdx.x;
   const uint32_t fc = f < nfine ? f : nfine - 1;
   const uint32_t cur = cursor[fc], bn = build_cnt[fc], bb = build_begin[fc];
-  const uint32_t all = f < nfine ? cur - f * cap2 : 0u;
+  // (a fine partition that outgrew its room -- overflow flag up, the host repeats with the exact layout -- is cut at its
+  // capacity: its real count would make more units than the arrays hold)
+  const uint32_t grown = f < nfine ? cur - f * cap2 : 0u;
+  const uint32_t all = grown < cap2 ? grown : cap2;
   const uint32_t pn = (all != 0 && (bn != 0 || keep_probe)) ? all : 0u;
   const uint32_t nun = (pn + JK_PROBE_CHUNK - 1) / JK_PROBE_CHUNK;
   const uint32_t incl_u = wave_scan_incl(nun);

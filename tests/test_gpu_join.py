@@ -648,3 +648,29 @@ def test_selective_inner_join_single_pass_then_compaction(gdf, hit, size, monkey
     mult = torch.bincount(b, minlength=nb)
     inside = p[p < nb]
     assert li.numel() == int(mult[inside].sum())
+
+
+@pytest.mark.parametrize("how", ["inner", "left"])
+def test_skewed_probe_side_overflows_the_deferred_layout(gdf, how):
+    """A tenth of 2.5e7 probe rows on ONE key: the histogram-free layout overflows at both levels while the device-side
+    bookkeeping (segment map, work units) is already queued behind it -- the overflowed fill counters must be clamped there
+    (an illegal address before the fix, found by tools/stress_join.py --seed 21 --case 237), and the host then repeats the
+    side with the exact layout."""
+    import torch
+    from libgdf_amd.columns import Column
+    g = torch.Generator(device="cuda").manual_seed(2137)
+    nb, npr = 1_293_528, 25_478_136
+    build = torch.randint(0, nb, (nb,), generator=g, device="cuda")
+    probe = torch.randint(0, nb, (npr,), generator=g, device="cuda")
+    probe[torch.randint(0, npr, (npr // 10,), generator=g, device="cuda")] = int(build[0])
+    mult = torch.bincount(build, minlength=nb)
+    per_row = mult[probe]
+    expected = int(per_row.sum())
+    lonely = int((per_row == 0).sum()) if how == "left" else 0
+    li, ri = gdf.api.join([Column(probe)], [Column(build)], how=how)
+    assert li.numel() == expected + lonely
+    l, r = li.long(), ri.long()
+    hit = r >= 0
+    assert int((~hit).sum()) == lonely
+    assert bool((probe[l[hit]] == build[r[hit]]).all())
+    assert int(torch.unique(l[hit] * nb + r[hit]).numel()) == expected

@@ -18,6 +18,8 @@ def main():
     ap.add_argument("--seconds", type=float, default=240.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--case", type=int, default=-1, help="run only this case number of the seed (every case reseeds the generator)")
+    ap.add_argument("--max-build", type=int, default=4_000_000, help="largest build side of the 'big' cases (every third case)")
+    ap.add_argument("--max-probe", type=int, default=60_000_000)
     a = ap.parse_args()
     import torch
     import libgdf_amd as gdf
@@ -30,10 +32,10 @@ def main():
     while time.time() - t0 < a.seconds:
         g.manual_seed(a.seed * 1_000_003 + it)          # a failing case can be re-run alone: --seed S --case N
         big = it % 3 == 0
-        nb = r(1_000, 4_000_000 if big else 300_000)
-        npr = r(10_000, 60_000_000 if big else 2_000_000)
+        nb = r(1_000, a.max_build if big else 300_000)
+        npr = r(10_000, a.max_probe if big else 2_000_000)
         spread = [0.25, 0.5, 1.0, 1.5, 3.0, 12.0, 1000.0][r(0, 7)]        # < 1: repeated build keys; > 1: probes that miss
-        space = min(max(2, int(nb * spread)), 200_000_000)      # (bincount below allocates `space` counters)
+        space = min(max(2, int(nb * spread)), 600_000_000)      # (bincount below allocates `space` counters)
         dtype = torch.int64 if r(0, 3) else torch.int32
         base = [0, 0, 1 << 40, -1_000_000, (1 << 62) - space - 5][r(0, 5)]
         if dtype == torch.int32 and abs(base) > (1 << 30):
@@ -46,7 +48,7 @@ def main():
         mult = torch.bincount(build, minlength=space)
         per_row = mult[probe]
         expected = int(per_row.sum())
-        if expected >= 2**31 - 1 or expected > 400_000_000:
+        if expected >= 2**31 - 1 or expected > 900_000_000:
             it += 1
             if a.case >= 0:
                 break

@@ -1427,45 +1427,65 @@ __global__ __launch_bounds__(256) void jk_compact_units(const uint64_t *__restri
 // duplication / build sides beyond 32768 * JK_MAX_BUILD rows).  Same semantics, table
 // of (key, row) slots in HBM, one thread per tuple.
 // ---------------------------------------------------------------------------
-__global__ void gj_fill(int32_t *tidx, uint32_t nslots) {
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nslots; i += gridDim.x * blockDim.x) tidx[i] = JK_EMPTY;
+// The table holds DISTINCT keys; the build tuples of a key hang behind its slot as a chain of partition positions
+// (thead[slot] -> next[pos] -> ...).  Round 1 inserted every tuple with linear probing: k copies of one key cost k^2 / 2
+// probes to insert and k slots to walk for every probe row that hashes nearby -- a build side with 6e6 copies of one key
+// (tools/stress_join.py --seed 41 --case 174) did not finish in five minutes.
+constexpr unsigned long long GJ_NOKEY = ~0ull;        // never a NARROW key (< 2^32); a WIDE key with these bits uses slot S
+__global__ void gj_fill(unsigned long long *tkey, int32_t *thead, uint32_t nslots) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= nslots; i += gridDim.x * blockDim.x) { tkey[i] = GJ_NOKEY; thead[i] = -1; }
 }
 template <bool NARROW>
-__global__ void gj_build(Tuples b, uint32_t begin, uint32_t n, uint64_t *tkey, int32_t *tidx, uint32_t S) {
+__global__ void gj_build(Tuples b, uint32_t begin, uint32_t n, unsigned long long *tkey, int32_t *thead, int32_t *next, uint32_t S) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const uint64_t w = b.w[begin + i];
-    const uint64_t k = tup_key<NARROW>(w);
-    const int32_t row = NARROW ? (int32_t)(uint32_t)w : b.idx[begin + i];
-    uint32_t slot = slot_of(k, S);
-    while (atomicCAS(&tidx[slot], JK_EMPTY, row) != JK_EMPTY) slot = (slot + 1 == S) ? 0 : slot + 1;
-    tkey[slot] = k;
+    const unsigned long long k = tup_key<NARROW>(b.w[begin + i]);
+    uint32_t slot = S;                              // the reserved slot of the key that looks like "no key"
+    if (NARROW || k != GJ_NOKEY) {
+      slot = slot_of(k, S);
+      for (;;) {
+        const unsigned long long old = atomicCAS(&tkey[slot], GJ_NOKEY, k);
+        if (old == GJ_NOKEY || old == k) break;
+        slot = (slot + 1 == S) ? 0 : slot + 1;
+      }
+    }
+    next[i] = atomicExch(&thead[slot], (int32_t)i);
   }
 }
 template <bool WRITE, bool NARROW>
-__global__ void gj_probe(ProbeArgs a, KeyTable probe_t, KeyTable build_t, const uint64_t *tkey, const int32_t *tidx,
-                         uint32_t probe_begin, uint32_t probe_count, unsigned long long *cursor) {
+__global__ void gj_probe(ProbeArgs a, KeyTable probe_t, KeyTable build_t, const unsigned long long *tkey, const int32_t *thead,
+                         const int32_t *next, uint32_t build_begin, uint32_t probe_begin, uint32_t probe_count,
+                         unsigned long long *cursor) {
   const uint32_t S = a.nslots;
   const uint32_t stride = gridDim.x * blockDim.x;
   const uint32_t rounds = (probe_count + stride - 1) / stride;
+  auto build_row_at = [&](int32_t p) -> int32_t {
+    return NARROW ? (int32_t)(uint32_t)a.build.w[build_begin + p] : a.build.idx[build_begin + p];
+  };
   unsigned long long my_count = 0;
   for (uint32_t rnd = 0; rnd < rounds; ++rnd) {
     const uint32_t i = rnd * stride + blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t cnt = 0;
-    uint64_t k = 0;
-    int32_t prow = 0;
+    int32_t prow = 0, head = -1;
     if (i < probe_count) {
       const uint64_t w = a.probe.w[probe_begin + i];
-      k = tup_key<NARROW>(w);
+      const unsigned long long k = tup_key<NARROW>(w);
       prow = NARROW ? (int32_t)(uint32_t)w : a.probe.idx[probe_begin + i];
-      uint32_t slot = slot_of(k, S);
-      for (;;) {
-        const int32_t r = tidx[slot];
-        if (r == JK_EMPTY) break;
-        if (tkey[slot] == k && (!a.verify || rows_equal(probe_t, prow, build_t, r))) {
+      if (!NARROW && k == GJ_NOKEY) head = thead[S];
+      else {
+        uint32_t slot = slot_of(k, S);
+        for (;;) {
+          const unsigned long long t = tkey[slot];
+          if (t == k) { head = thead[slot]; break; }
+          if (t == GJ_NOKEY) break;
+          slot = (slot + 1 == S) ? 0 : slot + 1;
+        }
+      }
+      for (int32_t p = head; p >= 0; p = next[p]) {
+        const int32_t r = build_row_at(p);
+        if (!a.verify || rows_equal(probe_t, prow, build_t, r)) {
           ++cnt;
           if (a.build_matched) a.build_matched[r] = 1;
         }
-        slot = (slot + 1 == S) ? 0 : slot + 1;
       }
     }
     const bool pad = (i < probe_count) && cnt == 0 && a.keep_unmatched_probe;
@@ -1483,16 +1503,13 @@ __global__ void gj_probe(ProbeArgs a, KeyTable probe_t, KeyTable build_t, const 
         a.out_probe[pos] = prow;
         a.out_build[pos] = JK_EMPTY;
       } else if (cnt) {
-        uint32_t slot = slot_of(k, S);
-        for (;;) {
-          const int32_t r = tidx[slot];
-          if (r == JK_EMPTY) break;
-          if (tkey[slot] == k && (!a.verify || rows_equal(probe_t, prow, build_t, r))) {
+        for (int32_t p = head; p >= 0; p = next[p]) {
+          const int32_t r = build_row_at(p);
+          if (!a.verify || rows_equal(probe_t, prow, build_t, r)) {
             a.out_probe[pos] = prow;
             a.out_build[pos] = r;
             ++pos;
           }
-          slot = (slot + 1 == S) ? 0 : slot + 1;
         }
       }
     }
@@ -2532,28 +2549,32 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
   // ---- count pass ----
   GDF_TRY(run_probe(narrow, false, "jk_probe_count", nunits, probe_lds, a, probe_t, build_t));
   // oversize partitions: one global table each, kept for the write pass
-  struct GTable { DevBuf key, idx; uint32_t nslots; };
+  struct GTable { DevBuf key, idx, next; uint32_t nslots; };      // idx: chain heads per slot (+ the reserved slot), next: per build tuple
   std::vector<GTable> gt(oversize.size());
   for (size_t o = 0; o < oversize.size(); ++o) {
     const uint32_t f = oversize[o].f0, fe = oversize[o].f1;
     const uint32_t bn = B.fine_off[fe] - B.fine_off[f], pn = P.fine_off[fe] - P.fine_off[f];
     gt[o].nslots = bn * 2;
-    RMM_TRY(gt[o].key.alloc(sizeof(uint64_t) * gt[o].nslots));
-    RMM_TRY(gt[o].idx.alloc(sizeof(int32_t) * gt[o].nslots));
-    hipLaunchKernelGGL(gj_fill, dim3(small_grid(gt[o].nslots)), dim3(256), 0, stream0(), gt[o].idx.as<int32_t>(), gt[o].nslots);
+    RMM_TRY(gt[o].key.alloc(sizeof(uint64_t) * ((size_t)gt[o].nslots + 1)));
+    RMM_TRY(gt[o].idx.alloc(sizeof(int32_t) * ((size_t)gt[o].nslots + 1)));
+    RMM_TRY(gt[o].next.alloc(sizeof(int32_t) * (size_t)(bn ? bn : 1)));
+    hipLaunchKernelGGL(gj_fill, dim3(small_grid(gt[o].nslots + 1)), dim3(256), 0, stream0(), gt[o].key.as<unsigned long long>(),
+                       gt[o].idx.as<int32_t>(), gt[o].nslots);
     ProbeArgs ga = a;
     ga.nslots = gt[o].nslots;
     unsigned long long *cnt = (unsigned long long *)(d_counts.as<uint64_t>() + nunits + o);
     if (narrow) {
       hipLaunchKernelGGL(gj_build<true>, dim3(small_grid(bn)), dim3(256), 0, stream0(), a.build, B.fine_off[f], bn,
-                         gt[o].key.as<uint64_t>(), gt[o].idx.as<int32_t>(), gt[o].nslots);
+                         gt[o].key.as<unsigned long long>(), gt[o].idx.as<int32_t>(), gt[o].next.as<int32_t>(), gt[o].nslots);
       hipLaunchKernelGGL((gj_probe<false, true>), dim3(small_grid(pn)), dim3(256), 0, stream0(), ga, probe_t, build_t,
-                         gt[o].key.as<uint64_t>(), gt[o].idx.as<int32_t>(), P.fine_off[f], pn, cnt);
+                         (const unsigned long long *)gt[o].key.as<unsigned long long>(), (const int32_t *)gt[o].idx.as<int32_t>(),
+                         (const int32_t *)gt[o].next.as<int32_t>(), B.fine_off[f], P.fine_off[f], pn, cnt);
     } else {
       hipLaunchKernelGGL(gj_build<false>, dim3(small_grid(bn)), dim3(256), 0, stream0(), a.build, B.fine_off[f], bn,
-                         gt[o].key.as<uint64_t>(), gt[o].idx.as<int32_t>(), gt[o].nslots);
+                         gt[o].key.as<unsigned long long>(), gt[o].idx.as<int32_t>(), gt[o].next.as<int32_t>(), gt[o].nslots);
       hipLaunchKernelGGL((gj_probe<false, false>), dim3(small_grid(pn)), dim3(256), 0, stream0(), ga, probe_t, build_t,
-                         gt[o].key.as<uint64_t>(), gt[o].idx.as<int32_t>(), P.fine_off[f], pn, cnt);
+                         (const unsigned long long *)gt[o].key.as<unsigned long long>(), (const int32_t *)gt[o].idx.as<int32_t>(),
+                         (const int32_t *)gt[o].next.as<int32_t>(), B.fine_off[f], P.fine_off[f], pn, cnt);
     }
     HIP_CHECK_LAST();
   }
@@ -2600,10 +2621,12 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
     unsigned long long *cur = (unsigned long long *)(d_counts.as<uint64_t>() + nunits + o);
     if (narrow)
       hipLaunchKernelGGL((gj_probe<true, true>), dim3(small_grid(pn)), dim3(256), 0, stream0(), ga, probe_t, build_t,
-                         gt[o].key.as<uint64_t>(), gt[o].idx.as<int32_t>(), P.fine_off[f], pn, cur);
+                         (const unsigned long long *)gt[o].key.as<unsigned long long>(), (const int32_t *)gt[o].idx.as<int32_t>(),
+                         (const int32_t *)gt[o].next.as<int32_t>(), B.fine_off[f], P.fine_off[f], pn, cur);
     else
       hipLaunchKernelGGL((gj_probe<true, false>), dim3(small_grid(pn)), dim3(256), 0, stream0(), ga, probe_t, build_t,
-                         gt[o].key.as<uint64_t>(), gt[o].idx.as<int32_t>(), P.fine_off[f], pn, cur);
+                         (const unsigned long long *)gt[o].key.as<unsigned long long>(), (const int32_t *)gt[o].idx.as<int32_t>(),
+                         (const int32_t *)gt[o].next.as<int32_t>(), B.fine_off[f], P.fine_off[f], pn, cur);
     HIP_CHECK_LAST();
   }
   if (probe_tail) {

@@ -674,3 +674,40 @@ def test_skewed_probe_side_overflows_the_deferred_layout(gdf, how):
     assert int((~hit).sum()) == lonely
     assert bool((probe[l[hit]] == build[r[hit]]).all())
     assert int(torch.unique(l[hit] * nb + r[hit]).numel()) == expected
+
+
+@pytest.mark.parametrize("dtype", [np.int32, np.int64])
+def test_one_build_key_repeated_millions_of_times(gdf, dtype):
+    """The global-table path chains the copies of a key behind one slot: 3e6 copies of one build key (an oversize partition:
+    far beyond the LDS image) must not cost 3e6^2 / 2 probes to insert -- before the chains this shape did not finish in
+    minutes (tools/stress_join.py --seed 41 --case 174).  A handful of probe rows carry the hot key; 64-bit keys include the
+    table's own 'no key' pattern."""
+    import torch
+    from libgdf_amd.columns import Column
+    tdt = torch.int32 if dtype == np.int32 else torch.int64
+    g = torch.Generator(device="cuda").manual_seed(77)
+    nb, npr, hot_copies, hot_probes = 6_000_000, 3_000_000, 3_000_000, 3
+    space = 50_000_000
+    build = torch.randint(0, space, (nb,), generator=g, device="cuda")
+    hot = int(build[0])
+    build[torch.randperm(nb, device="cuda", generator=g)[:hot_copies]] = hot
+    probe = torch.randint(0, space, (npr,), generator=g, device="cuda")
+    probe[probe == hot] = hot + 1                      # exactly hot_probes probe rows carry the hot key
+    probe[:hot_probes] = hot
+    if dtype == np.int64:                              # -1 is the table's "no key" bit pattern for 64-bit keys
+        build = build - 1 - hot
+        probe = probe - 1 - hot
+        build = build * (1 << 33)                      # spread beyond 32 bits: WIDE tuples
+        probe = probe * (1 << 33)
+        build[build == -(1 << 33)] = -1
+        probe[probe == -(1 << 33)] = -1
+    bk, pk = build.to(tdt), probe.to(tdt)
+    li, ri = gdf.api.join([Column(pk)], [Column(bk)])
+    ub, inv, cnt = torch.unique(bk, return_inverse=True, return_counts=True)
+    pos = torch.searchsorted(ub, pk).clamp(max=ub.numel() - 1)
+    per_row = torch.where(ub[pos] == pk, cnt[pos], torch.zeros_like(cnt[pos]))
+    expected = int(per_row.sum())
+    assert expected >= hot_copies * hot_probes
+    assert li.numel() == expected
+    assert bool((pk[li.long()] == bk[ri.long()]).all())
+    assert int(torch.unique(li.long() * nb + ri.long()).numel()) == expected

@@ -1553,7 +1553,101 @@ __device__ __forceinline__ void gbp_pack(const KeyTable &t, const GbKeyPlan &p, 
   }
 }
 
+// raw 64-bit images of N rows of one key column (sign-extended integers, ordered float images), all loads issued together
+template <int N>
+__device__ __forceinline__ void gbp_load_col(const ColView &col, const uint32_t (&src)[N], long long (&v)[N]) {
+  const void *data = col.data;
+  switch (col.kind) {
+    case K_I8:
+#pragma unroll
+      for (int k = 0; k < N; ++k) v[k] = ((const int8_t *)data)[src[k]];
+      break;
+    case K_I16:
+#pragma unroll
+      for (int k = 0; k < N; ++k) v[k] = ((const int16_t *)data)[src[k]];
+      break;
+    case K_I32:
+#pragma unroll
+      for (int k = 0; k < N; ++k) v[k] = ((const int32_t *)data)[src[k]];
+      break;
+    case K_F32:
+#pragma unroll
+      for (int k = 0; k < N; ++k) v[k] = f32_image(((const uint32_t *)data)[src[k]]);
+      break;
+    case K_F64:
+#pragma unroll
+      for (int k = 0; k < N; ++k) v[k] = f64_image(((const uint64_t *)data)[src[k]]);
+      break;
+    default:
+#pragma unroll
+      for (int k = 0; k < N; ++k) v[k] = ((const long long *)data)[src[k]];
+  }
+}
+// gbp_pack for plans whose packed key fits 32 bits (the fused scatter's case), shaped for a kernel that sits at its register
+// limit: the words of the first TWO key columns are requested together (a second column otherwise waits for the first one's
+// round trip to HBM: the column loop cannot be unrolled), the key is accumulated in 32 bits, and the per-row flags are two bit
+// masks instead of sixteen bools.  okmask bit k: no null key element in row k; outside bit k: a value of row k lies outside the plan's range for its column
+// K0 / K1: the kinds of the first two key columns when the caller knows them at compile time (K_I32 or K_I64; K1 = -2: there
+// is no second column), -1: read t.col[c].kind.  The type switch of the dynamic form costs more than its branches: the
+// registers its cases load into are shared, so the waitcnt pass sees "maybe pending" loads on every path and makes the
+// requests of column 0 wait for everything issued before them (the value column) -- one HBM round trip per tile that the
+// static form does not have (all of a tile's requests leave together).
+template <int N, int K0 = -1, int K1 = -1>
+__device__ __forceinline__ void gbp_pack32(const KeyTable &t, const GbKeyPlan &p, const uint32_t (&src)[N], uint32_t (&key)[N], uint32_t &okmask,
+                                           uint32_t &outside) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) key[k] = 0;
+  okmask = (1u << N) - 1u;
+  outside = 0;
+  long long v0[N], v1[N];
+  if constexpr (K0 == K_I32) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) v0[k] = ((const int32_t *)t.col[0].data)[src[k]];
+  } else if constexpr (K0 == K_I64) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) v0[k] = ((const long long *)t.col[0].data)[src[k]];
+  } else {
+    gbp_load_col<N>(t.col[0], src, v0);
+  }
+  if constexpr (K1 == K_I32) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) v1[k] = ((const int32_t *)t.col[1].data)[src[k]];
+  } else if constexpr (K1 == K_I64) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) v1[k] = ((const long long *)t.col[1].data)[src[k]];
+  } else if constexpr (K1 == -1) {
+    if (t.ncols > 1) gbp_load_col<N>(t.col[1], src, v1);
+  }
+  auto fold = [&](int c, const long long (&v)[N]) {
+    const int bits = p.bits[c], shift = p.shift[c];
+    const long long bias = p.bias[c];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const uint64_t u = (uint64_t)(v[k] - bias);
+      outside |= (uint32_t)(bits < 64 && (u >> bits) != 0) << k;
+      key[k] |= (uint32_t)(u & low_mask(bits)) << shift;
+    }
+    if (t.col[c].valid) {
+      uint8_t m[N];
+#pragma unroll
+      for (int k = 0; k < N; ++k) m[k] = t.col[c].valid[src[k] >> 3];
+#pragma unroll
+      for (int k = 0; k < N; ++k) okmask &= ~((uint32_t)(((m[k] >> (src[k] & 7)) & 1) ^ 1) << k);
+    }
+  };
+  fold(0, v0);
+  if constexpr (K1 >= 0) fold(1, v1);
+  else if constexpr (K1 == -1) {
+    if (t.ncols > 1) fold(1, v1);
+    for (int c = 2; c < t.ncols; ++c) {
+      gbp_load_col<N>(t.col[c], src, v0);
+      fold(c, v0);
+    }
+  }
+}
+
 // flags[0] += rows dropped for a null key, flags[1] = 1 when a key lies outside the plan's ranges
+template <int K0 = -1, int K1 = -1>
 __global__ __launch_bounds__(GBP_THREADS) void gbp_count(KeyTable t, GbKeyPlan plan, int low, int vbit, uint32_t nparts, int64_t chunk,
                                                          int nchunks, uint32_t *__restrict__ hist, unsigned int *__restrict__ flags) {
   __shared__ uint32_t cnt[GBP_MAX_PARTS];
@@ -1566,21 +1660,30 @@ __global__ __launch_bounds__(GBP_THREADS) void gbp_count(KeyTable t, GbKeyPlan p
     const int64_t end = begin + chunk < t.nrows ? begin + chunk : t.nrows;
     for (int64_t base = begin; base < end; base += (int64_t)GBP_THREADS * B) {
       uint32_t src[B];                 // row numbers fit 31 bits (the entry point refuses INT_MAX rows)
-      uint64_t key[B];
-      bool ok[B], inside[B];
+      uint32_t key[B], okmask, outmask;          // (the fused path's keys fit 32 bits with their validity bit)
 #pragma unroll
       for (int k = 0; k < B; ++k) {
         const int64_t i = base + (int64_t)k * GBP_THREADS + threadIdx.x;
         src[k] = (uint32_t)(i < end ? i : end - 1);
       }
-      gbp_pack<B>(t, plan, src, key, ok, inside);
+      if constexpr (K0 >= 0) {
+        gbp_pack32<B, K0, K1>(t, plan, src, key, okmask, outmask);
+      } else {        // any number of columns of any kind: the column loop (two columns' words in flight at once cost it three spills)
+        uint64_t key64[B];
+        bool ok[B], inside[B];
+        gbp_pack<B>(t, plan, src, key64, ok, inside);
+        okmask = outmask = 0;
+#pragma unroll
+        for (int k = 0; k < B; ++k) { key[k] = (uint32_t)key64[k]; okmask |= (uint32_t)ok[k] << k; outmask |= (uint32_t)!inside[k] << k; }
+      }
 #pragma unroll
       for (int k = 0; k < B; ++k) {
         const bool live = base + (int64_t)k * GBP_THREADS + threadIdx.x < end;
-        if (live && !ok[k]) ++dropped;
-        if (live && ok[k] && !inside[k]) outside = 1;
-        bool mine = live && ok[k];
-        const uint32_t part = (uint32_t)((key[k] << vbit) >> low);
+        const bool okk = (okmask >> k) & 1u;
+        if (live && !okk) ++dropped;
+        if (live && okk && ((outmask >> k) & 1u)) outside = 1;
+        bool mine = live && okk;
+        const uint32_t part = (key[k] << vbit) >> low;
         // the first two distinct partition ids of the wave by ballot, the rest one LDS atomic each
 #pragma unroll
         for (int round = 0; round < 2; ++round) {
@@ -1605,7 +1708,10 @@ __global__ __launch_bounds__(GBP_THREADS) void gbp_count(KeyTable t, GbKeyPlan p
   if (outside) flags[1] = 1u;
 }
 
-template <bool VBIT>
+// LEAN = false: the load structure this kernel started with (kept as the A/B reference, GDF_GBP_OLD=1).  K0 / K1 as in
+// gbp_pack32; a static signature (K0 >= 0) also promises an 8-byte value column (K_I64 / K_F64, not COUNT) and says through
+// VMASK whether the value carries a validity mask: no data-dependent branch stands between the tile's HBM requests.
+template <bool VBIT, bool LEAN, int K0 = -1, int K1 = -1, bool VMASK = false>
 __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter(KeyTable t, GbKeyPlan plan, GbVal val, int fold_op, int low, int part_bits,
                                                            uint32_t nparts, int64_t chunk, int nchunks, const uint32_t *__restrict__ offs,
                                                            GbRec *__restrict__ rec_out) {
@@ -1617,25 +1723,41 @@ __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter(KeyTable t, GbKeyP
   uint32_t *wave_tot = cursor + GBP_MAX_PARTS;                               // [THREADS / WAVE]
   constexpr int PER = GBP_MAX_PARTS / GBP_SC_THREADS;                           // partitions per thread in the scan (2)
   constexpr int vbit = VBIT ? 1 : 0;
+  // LEAN: four barriers per tile instead of six.  The tile's counters are cleared by the scan that reads them (every thread its
+  // own two), and nothing closes the flush: a wave that has stored its share goes on to request and rank the next tile's rows --
+  // it touches only hist[], which the flush does not read, and stops at that tile's first barrier until every wave has left the
+  // flush.  One workgroup fills a CU here, so this is the only overlap of one tile's stores with the next tile's loads there is.
+  if (LEAN) {
+    for (uint32_t q = threadIdx.x; q < GBP_MAX_PARTS; q += GBP_SC_THREADS) hist[q] = 0;
+    block_sync();
+  }
   for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
     for (uint32_t q = threadIdx.x; q < nparts; q += GBP_SC_THREADS) cursor[q] = offs[(size_t)q * nchunks + c];
     const int64_t begin = (int64_t)c * chunk;
     const int64_t end = begin + chunk < t.nrows ? begin + chunk : t.nrows;
     for (int64_t tile = begin; tile < end; tile += GBP_SC_TILE) {
-      for (uint32_t q = threadIdx.x; q < GBP_MAX_PARTS; q += GBP_SC_THREADS) hist[q] = 0;
-      block_sync();
+      if (!LEAN) {
+        for (uint32_t q = threadIdx.x; q < GBP_MAX_PARTS; q += GBP_SC_THREADS) hist[q] = 0;
+        block_sync();
+      }
       uint32_t src[GBP_ITEMS];
-      uint64_t key[GBP_ITEMS];
-      bool ok[GBP_ITEMS], inside[GBP_ITEMS];
 #pragma unroll
       for (int k = 0; k < GBP_ITEMS; ++k) {
         const int64_t i = tile + (int64_t)k * GBP_SC_THREADS + threadIdx.x;
         src[k] = (uint32_t)(i < end ? i : end - 1);
       }
+      // LEAN: the bytes of the value's validity mask leave with the first requests as well (behind the key columns they were a
+      // third round trip to HBM per tile, with one workgroup per CU and nothing else to run meanwhile)
+      constexpr bool STATIC = K0 >= 0;
+      uint8_t vb[GBP_ITEMS];
+      if (STATIC ? VMASK : (LEAN && val.valid)) {
+#pragma unroll
+        for (int k = 0; k < GBP_ITEMS; ++k) vb[k] = val.valid[src[k] >> 3];
+      }
       // the value column is requested NOW, with the keys: one round of HBM latency per tile instead of two (as a second load
       // phase behind the key flush this kernel ran at 2.9 TB/s on its 32 B per row)
       uint64_t img[GBP_ITEMS];
-      switch (fold_op == OP_COUNT ? -1 : val.kind) {
+      switch (STATIC ? (int)K_I64 : (fold_op == OP_COUNT ? -1 : val.kind)) {
         case -1:
 #pragma unroll
           for (int k = 0; k < GBP_ITEMS; ++k) img[k] = 1;
@@ -1660,32 +1782,44 @@ __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter(KeyTable t, GbKeyP
 #pragma unroll
           for (int k = 0; k < GBP_ITEMS; ++k) img[k] = ((const uint64_t *)val.data)[src[k]];
       }
+      uint32_t k32[GBP_ITEMS];         // LEAN: the packed key, then (below) the key with the validity bit
+      uint32_t okmask = 0;              // bit k: row k has no null key element
+      if (LEAN) {
+        uint32_t outside;               // (gbp_count has already checked the plan's ranges)
+        gbp_pack32<GBP_ITEMS, K0, K1>(t, plan, src, k32, okmask, outside);
+      } else {
+        uint64_t key[GBP_ITEMS];
+        bool ok[GBP_ITEMS], inside[GBP_ITEMS];
+        gbp_pack<GBP_ITEMS>(t, plan, src, key, ok, inside);
+#pragma unroll
+        for (int k = 0; k < GBP_ITEMS; ++k) { k32[k] = (uint32_t)key[k]; okmask |= (uint32_t)ok[k] << k; }
+      }
+      // (below the key columns' requests: the conversion waits for the value words)
       if (fold_op == OP_MIN || fold_op == OP_MAX) {
         const bool flt = is_flt(val.kind);
 #pragma unroll
         for (int k = 0; k < GBP_ITEMS; ++k)
           img[k] = flt ? ord_f64(__longlong_as_double((long long)img[k])) : ord_i64((int64_t)img[k]);
       }
-      gbp_pack<GBP_ITEMS>(t, plan, src, key, ok, inside);
       // validity of the VALUE: rides as the key's lowest bit when the aggregation counts valid values (VBIT), and a null
       // value always contributes the identity (COUNT of a masked column has no such bit but still must not count nulls)
       uint32_t vmask = 0;               // bit k: the value of item k is valid
-      if (val.valid) {
-        uint8_t vb[GBP_ITEMS];
+      if (STATIC ? VMASK : val.valid != nullptr) {
+        if (!LEAN) {
 #pragma unroll
-        for (int k = 0; k < GBP_ITEMS; ++k) vb[k] = val.valid[src[k] >> 3];
+          for (int k = 0; k < GBP_ITEMS; ++k) vb[k] = val.valid[src[k] >> 3];
+        }
 #pragma unroll
         for (int k = 0; k < GBP_ITEMS; ++k) vmask |= (uint32_t)((vb[k] >> (src[k] & 7)) & 1) << k;
       } else {
         vmask = 0xffffffffu;
       }
       uint32_t pr[GBP_ITEMS];          // partition << 16 | rank within (tile, partition); 0xffffffff: the row does not travel
-      uint32_t k32[GBP_ITEMS];
 #pragma unroll
       for (int k = 0; k < GBP_ITEMS; ++k) {
-        const bool live = tile + (int64_t)k * GBP_SC_THREADS + threadIdx.x < end && ok[k];
+        const bool live = tile + (int64_t)k * GBP_SC_THREADS + threadIdx.x < end && ((okmask >> k) & 1u);
         const bool vok = (vmask >> k) & 1u;
-        k32[k] = (uint32_t)((key[k] << vbit) | (uint64_t)(VBIT && vok));
+        k32[k] = (k32[k] << vbit) | (uint32_t)(VBIT && vok);
         const uint32_t part = k32[k] >> low;
         const uint32_t r = wave_aggregated_inc(hist, part, part_bits, live);
         pr[k] = live ? (part << 16) | r : 0xffffffffu;
@@ -1694,7 +1828,11 @@ __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter(KeyTable t, GbKeyP
       {   // exclusive scan of hist[0..MAX_PARTS) by the 1024 threads, PER consecutive partitions each
         uint32_t v[PER], sum = 0;
 #pragma unroll
-        for (int q = 0; q < PER; ++q) { v[q] = hist[threadIdx.x * PER + q]; sum += v[q]; }
+        for (int q = 0; q < PER; ++q) {
+          v[q] = hist[threadIdx.x * PER + q];
+          sum += v[q];
+          if (LEAN) hist[threadIdx.x * PER + q] = 0;      // for the next tile's ranking (nobody else touches these two before it)
+        }
         const uint32_t incl = wave_scan_incl(sum);
         if (lane_id() == WAVE - 1) wave_tot[threadIdx.x / WAVE] = incl;
         block_sync();
@@ -1729,7 +1867,7 @@ __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter(KeyTable t, GbKeyP
         const uint64_t vv = stage[j];
         rec_out[gbase[kk >> low] + j] = GbRec{kk, (uint32_t)vv, (uint32_t)(vv >> 32)};
       }
-      block_sync();
+      if (!LEAN) block_sync();
     }
   }
 }
@@ -2135,19 +2273,45 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
       RMM_TRY(d_flags.alloc(sizeof(unsigned int) * 2));
       HIP_TRY(hipMemsetAsync(d_flags.p, 0, sizeof(unsigned int) * 2, stream0()));
       HIP_TRY(hipMemsetAsync(hist.as<uint32_t>() + (size_t)P * nchunks, 0, sizeof(uint32_t), stream0()));
-      GDF_LAUNCH("gbp_count", gbp_count, dim3(nchunks < NUM_CU * 2 ? nchunks : NUM_CU * 2), dim3(GBP_THREADS), 0, stream0(), t, sp, low, vbit, P,
-                 chunk, nchunks, hist.as<uint32_t>(), d_flags.as<unsigned int>());
+      // static key signature (gbp_pack32): one or two 4- / 8-byte integer key columns
+      static const bool no_static = getenv("GDF_GBP_DYNAMIC") != nullptr;
+      auto int_kind = [](int k) { return k == K_I32 || k == K_I64; };
+      const bool key_sig = !no_static && (t.ncols == 1 || t.ncols == 2) && int_kind(t.col[0].kind) && (t.ncols == 1 || int_kind(t.col[1].kind));
+      const int k0 = key_sig ? t.col[0].kind : -1, k1 = !key_sig ? -1 : (t.ncols == 2 ? t.col[1].kind : -2);
+      auto count = [&](auto kernel) {
+        GDF_LAUNCH("gbp_count", kernel, dim3(nchunks < NUM_CU * 2 ? nchunks : NUM_CU * 2), dim3(GBP_THREADS), 0, stream0(), t, sp, low, vbit, P,
+                   chunk, nchunks, hist.as<uint32_t>(), d_flags.as<unsigned int>());
+      };
+      if (k0 == K_I32 && k1 == -2) count(gbp_count<K_I32, -2>);
+      else if (k0 == K_I64 && k1 == -2) count(gbp_count<K_I64, -2>);
+      else if (k0 == K_I32 && k1 == K_I32) count(gbp_count<K_I32, K_I32>);
+      else if (k0 == K_I32 && k1 == K_I64) count(gbp_count<K_I32, K_I64>);
+      else if (k0 == K_I64 && k1 == K_I32) count(gbp_count<K_I64, K_I32>);
+      else if (k0 == K_I64 && k1 == K_I64) count(gbp_count<K_I64, K_I64>);
+      else count(gbp_count<-1, -1>);
       GDF_TRY(scan_u32(hist.as<uint32_t>(), hist.as<uint32_t>(), (size_t)P * nchunks + 1, false));
       const size_t slds = gbp_scatter_lds();
-      if (vbit) {
-        HIP_TRY(hipFuncSetAttribute((const void *)gbp_scatter<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
-        GDF_LAUNCH("gbp_scatter", gbp_scatter<true>, dim3(nchunks < NUM_CU ? nchunks : NUM_CU), dim3(GBP_SC_THREADS), slds, stream0(), t, sp, val, fold_op,
+      static const bool lean = !getenv("GDF_GBP_OLD");       // A/B switch: the round-1 load structure of the kernel
+      auto scatter = [&](auto kernel) -> gdf_error {
+        HIP_TRY(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
+        GDF_LAUNCH("gbp_scatter", kernel, dim3(nchunks < NUM_CU ? nchunks : NUM_CU), dim3(GBP_SC_THREADS), slds, stream0(), t, sp, val, fold_op,
                    low, part_bits, P, chunk, nchunks, (const uint32_t *)hist.as<uint32_t>(), ka.as<GbRec>());
-      } else {
-        HIP_TRY(hipFuncSetAttribute((const void *)gbp_scatter<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
-        GDF_LAUNCH("gbp_scatter", gbp_scatter<false>, dim3(nchunks < NUM_CU ? nchunks : NUM_CU), dim3(GBP_SC_THREADS), slds, stream0(), t, sp, val, fold_op,
-                   low, part_bits, P, chunk, nchunks, (const uint32_t *)hist.as<uint32_t>(), ka.as<GbRec>());
-      }
+        return GDF_SUCCESS;
+      };
+      // static signature: one or two key columns of 4- / 8-byte integers, an 8-byte value column, not COUNT
+      const bool sig = lean && key_sig && (val.kind == K_I64 || val.kind == K_F64) && fold_op != OP_COUNT && (!vbit || val.valid);
+      if (sig) {
+        const int vm = vbit ? 2 : (val.valid ? 1 : 0);        // 0: no mask, 1: mask, 2: mask + validity bit in the key
+#define GBP_SIG(K0, K1)                                                                                            \
+        if (k0 == K0 && k1 == K1) {                                                                                   \
+          if (vm == 2) GDF_TRY(scatter(gbp_scatter<true, true, K0, K1, true>));                                        \
+          else if (vm == 1) GDF_TRY(scatter(gbp_scatter<false, true, K0, K1, true>));                                  \
+          else GDF_TRY(scatter(gbp_scatter<false, true, K0, K1, false>));                                              \
+        }
+        GBP_SIG(K_I32, -2) GBP_SIG(K_I64, -2) GBP_SIG(K_I32, K_I32) GBP_SIG(K_I32, K_I64) GBP_SIG(K_I64, K_I32) GBP_SIG(K_I64, K_I64)
+#undef GBP_SIG
+      } else if (vbit) GDF_TRY(scatter(gbp_scatter<true, false>));       // other shapes: the column loop with its type switches.  (LEAN
+      else GDF_TRY(scatter(gbp_scatter<false, false>));                 // without static kinds spills inside the tile loop: not built)
       hipLaunchKernelGGL(gb_strided_u32, dim3((P + 256) / 256), dim3(256), 0, stream0(), (const uint32_t *)hist.as<uint32_t>(), d_start.as<uint32_t>(),
                          (int)P + 1, (size_t)nchunks);
       HIP_CHECK_LAST();

@@ -1708,10 +1708,52 @@ __global__ __launch_bounds__(GBP_THREADS) void gbp_count(KeyTable t, GbKeyPlan p
   if (outside) flags[1] = 1u;
 }
 
-// LEAN = false: the load structure this kernel started with (kept as the A/B reference, GDF_GBP_OLD=1).  K0 / K1 as in
-// gbp_pack32; a static signature (K0 >= 0) also promises an 8-byte value column (K_I64 / K_F64, not COUNT) and says through
-// VMASK whether the value carries a validity mask: no data-dependent branch stands between the tile's HBM requests.
-template <bool VBIT, bool LEAN, int K0 = -1, int K1 = -1, bool VMASK = false>
+// Ranks of N rows per lane within their (tile, partition) groups, hist[partition] += rows -- the fused scatter's replacement for
+// N x wave_aggregated_inc.  The 11-bit match-any behind that costs ~90 VALU instructions per row and lane (a quarter of the
+// kernel's time on C5) to protect against ONE hot counter; here the partitions of the first two still-unranked lanes of the wave
+// are settled by a ballot each (gbp_count's trick: a hot partition is almost always one of them), everybody else takes a plain
+// returning LDS atomic.  Phase 1 is ballots only, phase 2 issues every atomic of the N rows before anything waits.
+template <int N>
+__device__ __forceinline__ void gbp_rank(uint32_t *hist, const uint32_t (&part)[N], uint32_t livemask, uint32_t (&rank)[N]) {
+  const int lane = lane_id();
+  uint32_t inrank[N];            // lanes settled by a ballot: position within their group
+  uint32_t caught = 0;           // two bits per row: 0 = plain atomic, 1 / 2 = settled with the first / second leader's group
+  int lead[N][2];                // wave-uniform: the leaders' lanes (64: nobody)
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    bool mine = (livemask >> k) & 1u;
+    inrank[k] = 0;
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+      const unsigned long long todo = __ballot(mine);
+      const int leader = __builtin_amdgcn_readfirstlane(todo ? __ffsll((long long)todo) - 1 : 64);
+      const uint32_t lp = __builtin_amdgcn_readlane(part[k], leader & 63);
+      const bool grp = mine && leader < 64 && part[k] == lp;
+      const unsigned long long same = __ballot(grp);
+      lead[k][round] = leader;
+      if (grp) { inrank[k] = (uint32_t)mask_rank(same) | ((uint32_t)__popcll(same) << 16); caught |= (uint32_t)(round + 1) << (2 * k); mine = false; }
+    }
+  }
+  uint32_t res[N];               // leaders: their group's base; plain lanes: their own rank
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const uint32_t c = (caught >> (2 * k)) & 3u;
+    res[k] = 0;
+    // ONE atomic instruction per row: leaders add their group's size (a leader's inrank is 0 | size << 16), plain lanes add 1
+    const bool leads = lane == lead[k][0] || lane == lead[k][1];
+    if (leads || (c == 0 && ((livemask >> k) & 1u))) res[k] = atomicAdd(&hist[part[k]], leads ? inrank[k] >> 16 : 1u);
+  }
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const uint32_t c = (caught >> (2 * k)) & 3u;
+    const uint32_t b0 = __builtin_amdgcn_readlane(res[k], lead[k][0] & 63), b1 = __builtin_amdgcn_readlane(res[k], lead[k][1] & 63);
+    rank[k] = c == 0 ? res[k] : (c == 1 ? b0 : b1) + (inrank[k] & 0xffffu);
+  }
+}
+
+// The fused scatter for ANY key / value shape: the column loop with its type switches (gbp_pack), match-any ranks, six barriers
+// per tile.  Shapes with a static signature take gbp_scatter_static below.
+template <bool VBIT>
 __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter(KeyTable t, GbKeyPlan plan, GbVal val, int fold_op, int low, int part_bits,
                                                            uint32_t nparts, int64_t chunk, int nchunks, const uint32_t *__restrict__ offs,
                                                            GbRec *__restrict__ rec_out) {
@@ -1723,41 +1765,25 @@ __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter(KeyTable t, GbKeyP
   uint32_t *wave_tot = cursor + GBP_MAX_PARTS;                               // [THREADS / WAVE]
   constexpr int PER = GBP_MAX_PARTS / GBP_SC_THREADS;                           // partitions per thread in the scan (2)
   constexpr int vbit = VBIT ? 1 : 0;
-  // LEAN: four barriers per tile instead of six.  The tile's counters are cleared by the scan that reads them (every thread its
-  // own two), and nothing closes the flush: a wave that has stored its share goes on to request and rank the next tile's rows --
-  // it touches only hist[], which the flush does not read, and stops at that tile's first barrier until every wave has left the
-  // flush.  One workgroup fills a CU here, so this is the only overlap of one tile's stores with the next tile's loads there is.
-  if (LEAN) {
-    for (uint32_t q = threadIdx.x; q < GBP_MAX_PARTS; q += GBP_SC_THREADS) hist[q] = 0;
-    block_sync();
-  }
   for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
     for (uint32_t q = threadIdx.x; q < nparts; q += GBP_SC_THREADS) cursor[q] = offs[(size_t)q * nchunks + c];
     const int64_t begin = (int64_t)c * chunk;
     const int64_t end = begin + chunk < t.nrows ? begin + chunk : t.nrows;
     for (int64_t tile = begin; tile < end; tile += GBP_SC_TILE) {
-      if (!LEAN) {
-        for (uint32_t q = threadIdx.x; q < GBP_MAX_PARTS; q += GBP_SC_THREADS) hist[q] = 0;
-        block_sync();
-      }
+      for (uint32_t q = threadIdx.x; q < GBP_MAX_PARTS; q += GBP_SC_THREADS) hist[q] = 0;
+      block_sync();
       uint32_t src[GBP_ITEMS];
+      uint64_t key[GBP_ITEMS];
+      bool ok[GBP_ITEMS], inside[GBP_ITEMS];
 #pragma unroll
       for (int k = 0; k < GBP_ITEMS; ++k) {
         const int64_t i = tile + (int64_t)k * GBP_SC_THREADS + threadIdx.x;
         src[k] = (uint32_t)(i < end ? i : end - 1);
       }
-      // LEAN: the bytes of the value's validity mask leave with the first requests as well (behind the key columns they were a
-      // third round trip to HBM per tile, with one workgroup per CU and nothing else to run meanwhile)
-      constexpr bool STATIC = K0 >= 0;
-      uint8_t vb[GBP_ITEMS];
-      if (STATIC ? VMASK : (LEAN && val.valid)) {
-#pragma unroll
-        for (int k = 0; k < GBP_ITEMS; ++k) vb[k] = val.valid[src[k] >> 3];
-      }
       // the value column is requested NOW, with the keys: one round of HBM latency per tile instead of two (as a second load
       // phase behind the key flush this kernel ran at 2.9 TB/s on its 32 B per row)
       uint64_t img[GBP_ITEMS];
-      switch (STATIC ? (int)K_I64 : (fold_op == OP_COUNT ? -1 : val.kind)) {
+      switch (fold_op == OP_COUNT ? -1 : val.kind) {
         case -1:
 #pragma unroll
           for (int k = 0; k < GBP_ITEMS; ++k) img[k] = 1;
@@ -1782,57 +1808,45 @@ __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter(KeyTable t, GbKeyP
 #pragma unroll
           for (int k = 0; k < GBP_ITEMS; ++k) img[k] = ((const uint64_t *)val.data)[src[k]];
       }
-      uint32_t k32[GBP_ITEMS];         // LEAN: the packed key, then (below) the key with the validity bit
-      uint32_t okmask = 0;              // bit k: row k has no null key element
-      if (LEAN) {
-        uint32_t outside;               // (gbp_count has already checked the plan's ranges)
-        gbp_pack32<GBP_ITEMS, K0, K1>(t, plan, src, k32, okmask, outside);
-      } else {
-        uint64_t key[GBP_ITEMS];
-        bool ok[GBP_ITEMS], inside[GBP_ITEMS];
-        gbp_pack<GBP_ITEMS>(t, plan, src, key, ok, inside);
-#pragma unroll
-        for (int k = 0; k < GBP_ITEMS; ++k) { k32[k] = (uint32_t)key[k]; okmask |= (uint32_t)ok[k] << k; }
-      }
-      // (below the key columns' requests: the conversion waits for the value words)
       if (fold_op == OP_MIN || fold_op == OP_MAX) {
         const bool flt = is_flt(val.kind);
 #pragma unroll
         for (int k = 0; k < GBP_ITEMS; ++k)
           img[k] = flt ? ord_f64(__longlong_as_double((long long)img[k])) : ord_i64((int64_t)img[k]);
       }
+      gbp_pack<GBP_ITEMS>(t, plan, src, key, ok, inside);
       // validity of the VALUE: rides as the key's lowest bit when the aggregation counts valid values (VBIT), and a null
       // value always contributes the identity (COUNT of a masked column has no such bit but still must not count nulls)
       uint32_t vmask = 0;               // bit k: the value of item k is valid
-      if (STATIC ? VMASK : val.valid != nullptr) {
-        if (!LEAN) {
+      if (val.valid) {
+        uint8_t vb[GBP_ITEMS];
 #pragma unroll
-          for (int k = 0; k < GBP_ITEMS; ++k) vb[k] = val.valid[src[k] >> 3];
-        }
+        for (int k = 0; k < GBP_ITEMS; ++k) vb[k] = val.valid[src[k] >> 3];
 #pragma unroll
         for (int k = 0; k < GBP_ITEMS; ++k) vmask |= (uint32_t)((vb[k] >> (src[k] & 7)) & 1) << k;
       } else {
         vmask = 0xffffffffu;
       }
       uint32_t pr[GBP_ITEMS];          // partition << 16 | rank within (tile, partition); 0xffffffff: the row does not travel
+      uint32_t k32[GBP_ITEMS];
+      {
+        uint32_t part[GBP_ITEMS], rk[GBP_ITEMS], livemask = 0;
 #pragma unroll
-      for (int k = 0; k < GBP_ITEMS; ++k) {
-        const bool live = tile + (int64_t)k * GBP_SC_THREADS + threadIdx.x < end && ((okmask >> k) & 1u);
-        const bool vok = (vmask >> k) & 1u;
-        k32[k] = (k32[k] << vbit) | (uint32_t)(VBIT && vok);
-        const uint32_t part = k32[k] >> low;
-        const uint32_t r = wave_aggregated_inc(hist, part, part_bits, live);
-        pr[k] = live ? (part << 16) | r : 0xffffffffu;
+        for (int k = 0; k < GBP_ITEMS; ++k) {
+          const bool live = tile + (int64_t)k * GBP_SC_THREADS + threadIdx.x < end && ok[k];
+          k32[k] = (uint32_t)((key[k] << vbit) | (uint64_t)(VBIT && ((vmask >> k) & 1u)));
+          part[k] = k32[k] >> low;
+          livemask |= (uint32_t)live << k;
+        }
+        gbp_rank<GBP_ITEMS>(hist, part, livemask, rk);
+#pragma unroll
+        for (int k = 0; k < GBP_ITEMS; ++k) pr[k] = ((livemask >> k) & 1u) ? (part[k] << 16) | rk[k] : 0xffffffffu;
       }
       block_sync();
       {   // exclusive scan of hist[0..MAX_PARTS) by the 1024 threads, PER consecutive partitions each
         uint32_t v[PER], sum = 0;
 #pragma unroll
-        for (int q = 0; q < PER; ++q) {
-          v[q] = hist[threadIdx.x * PER + q];
-          sum += v[q];
-          if (LEAN) hist[threadIdx.x * PER + q] = 0;      // for the next tile's ranking (nobody else touches these two before it)
-        }
+        for (int q = 0; q < PER; ++q) { v[q] = hist[threadIdx.x * PER + q]; sum += v[q]; }
         const uint32_t incl = wave_scan_incl(sum);
         if (lane_id() == WAVE - 1) wave_tot[threadIdx.x / WAVE] = incl;
         block_sync();
@@ -1867,7 +1881,176 @@ __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter(KeyTable t, GbKeyP
         const uint64_t vv = stage[j];
         rec_out[gbase[kk >> low] + j] = GbRec{kk, (uint32_t)vv, (uint32_t)(vv >> 32)};
       }
-      if (!LEAN) block_sync();
+      block_sync();
+    }
+  }
+}
+
+// threadIdx.x through an opaque move: values derived from the result cannot be hoisted out of the enclosing loop (hipcc hoists a
+// dozen per-thread row offsets / LDS addresses out of the tile loop and then spills what has to stay live across it)
+__device__ __forceinline__ uint32_t gbp_opaque_tid() {
+  uint32_t tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  return tid;
+}
+// The fused scatter for one or two 4- / 8-byte integer key columns (K0, K1 as in gbp_pack32) and an 8-byte value column
+// (K_I64 / K_F64, not COUNT); VMASK: the value carries a validity mask.  What it does differently, and what each step bought on
+// C5 (1e9 rows, gbp_scatter 10.2 ms at the start; tools/gpu/r2bb.sh .. r2bg.sh):
+//   * no type switch between a tile's HBM requests (see gbp_pack32): value words, mask bytes and both key columns leave together;
+//   * four barriers per tile instead of six: the tile's counters are cleared by the scan that reads them (every thread its own
+//     two), and nothing closes the flush -- a wave that has stored its share goes on with the next tile's rows, touching only
+//     hist[], which the flush does not read, and stops at that tile's first barrier until every wave has left the flush
+//     (these two together: 10.2 -> 9.9 ms);
+//   * gbp_rank instead of an 11-bit match-any per row (9.7 -> 8.05 ms: the kernel was a quarter VALU);
+//   * the LDS reads of the regroup and of the flush are batched (one round trip per phase instead of one or two per row);
+// Tried and dropped (tools/gpu/r2be.sh, r2bg.sh): touching every 128-byte line of the next tile with a 4-byte load during the flush
+// (8.1 -> 12.9 ms: 64 lines per wave instruction are 64 requests), and jk_scatter1's pipeline -- the next tile's key words requested
+// before the flush and held in registers across it (9.34 against 9.40 ms, for 6 spilled registers).
+template <bool VBIT, int K0, int K1, bool VMASK>
+__global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter_static(KeyTable t, GbKeyPlan plan, GbVal val, int fold_op, int low,
+                                                                  uint32_t nparts, int64_t chunk, int nchunks, const uint32_t *__restrict__ offs,
+                                                                  GbRec *__restrict__ rec_out, unsigned int *__restrict__ flags) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gbp_lds[];
+  uint64_t *stage = reinterpret_cast<uint64_t *>(gbp_lds);
+  uint32_t *stage_k = reinterpret_cast<uint32_t *>(stage + GBP_SC_TILE);
+  uint32_t *hist = stage_k + GBP_SC_TILE;
+  uint32_t *start = hist + GBP_MAX_PARTS + 4, *gbase = start + GBP_MAX_PARTS, *cursor = gbase + GBP_MAX_PARTS;
+  uint32_t *wave_tot = cursor + GBP_MAX_PARTS;
+  constexpr int PER = GBP_MAX_PARTS / GBP_SC_THREADS;
+  constexpr int vbit = VBIT ? 1 : 0;
+  using W0 = typename std::conditional<K0 == K_I64, long long, int32_t>::type;
+  using W1 = typename std::conditional<K1 == K_I64, long long, int32_t>::type;
+  // the raw words of one tile: what is in flight between the request and the first use
+  W0 r0[GBP_ITEMS];
+  W1 r1[GBP_ITEMS];
+  uint64_t img[GBP_ITEMS];
+  uint8_t vb[GBP_ITEMS];
+  auto row_of = [&](int64_t tile, int64_t end, int k, uint32_t tid) -> uint32_t {        // clamped: requests are unconditional
+    const int64_t i = tile + (int64_t)k * GBP_SC_THREADS + tid;
+    return (uint32_t)(i < end ? i : end - 1);
+  };
+  auto request = [&](int64_t tile, int64_t end) {
+    const uint32_t tid = gbp_opaque_tid();
+#pragma unroll
+    for (int k = 0; k < GBP_ITEMS; ++k) if (VMASK) vb[k] = val.valid[row_of(tile, end, k, tid) >> 3];
+#pragma unroll
+    for (int k = 0; k < GBP_ITEMS; ++k) img[k] = ((const uint64_t *)val.data)[row_of(tile, end, k, tid)];
+#pragma unroll
+    for (int k = 0; k < GBP_ITEMS; ++k) r0[k] = ((const W0 *)t.col[0].data)[row_of(tile, end, k, tid)];
+    if (K1 >= 0) {
+#pragma unroll
+      for (int k = 0; k < GBP_ITEMS; ++k) r1[k] = ((const W1 *)t.col[1].data)[row_of(tile, end, k, tid)];
+    }
+  };
+  for (uint32_t q = threadIdx.x; q < GBP_MAX_PARTS; q += GBP_SC_THREADS) hist[q] = 0;
+  block_sync();
+  for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    for (uint32_t q = threadIdx.x; q < nparts; q += GBP_SC_THREADS) cursor[q] = offs[(size_t)q * nchunks + c];
+    const int64_t begin = (int64_t)c * chunk;
+    const int64_t end = begin + chunk < t.nrows ? begin + chunk : t.nrows;
+    for (int64_t tile = begin; tile < end; tile += GBP_SC_TILE) {
+      request(tile, end);
+      // ---- consume: packed 32-bit key, flags as bit masks ----
+      const uint32_t tid = gbp_opaque_tid();
+      uint32_t k32[GBP_ITEMS], okmask = (1u << GBP_ITEMS) - 1u, outside = 0, inrange = 0, vmask = VMASK ? 0u : 0xffffffffu;
+#pragma unroll
+      for (int k = 0; k < GBP_ITEMS; ++k) {
+        const uint64_t u0 = (uint64_t)((long long)r0[k] - plan.bias[0]);
+        outside |= (uint32_t)(plan.bits[0] < 64 && (u0 >> plan.bits[0]) != 0) << k;
+        k32[k] = (uint32_t)(u0 & low_mask(plan.bits[0])) << plan.shift[0];
+        if (K1 >= 0) {
+          const uint64_t u1 = (uint64_t)((long long)r1[k] - plan.bias[1]);
+          outside |= (uint32_t)(plan.bits[1] < 64 && (u1 >> plan.bits[1]) != 0) << k;
+          k32[k] |= (uint32_t)(u1 & low_mask(plan.bits[1])) << plan.shift[1];
+        }
+        inrange |= (uint32_t)(tile + (int64_t)k * GBP_SC_THREADS + tid < end) << k;
+        if (VMASK) vmask |= (uint32_t)((vb[k] >> (row_of(tile, end, k, tid) & 7)) & 1) << k;
+      }
+      // null key elements (rare: a late request of mask bytes)
+#pragma unroll
+      for (int c2 = 0; c2 < (K1 >= 0 ? 2 : 1); ++c2) {
+        if (t.col[c2].valid) {
+          uint8_t m[GBP_ITEMS];
+#pragma unroll
+          for (int k = 0; k < GBP_ITEMS; ++k) m[k] = t.col[c2].valid[row_of(tile, end, k, tid) >> 3];
+#pragma unroll
+          for (int k = 0; k < GBP_ITEMS; ++k) okmask &= ~((uint32_t)(((m[k] >> (row_of(tile, end, k, tid) & 7)) & 1) ^ 1) << k);
+        }
+      }
+      // gbp_count leaves out a last key column that cannot change the partition id (see the launch): every column's values are
+      // checked against the plan's ranges HERE as well, flags[1] as in gbp_count (the caller looks at it after this kernel)
+      if (outside & okmask & inrange) flags[1] = 1u;
+      uint64_t acc[GBP_ITEMS];         // the accumulator image that travels (the identity for a null value)
+      {
+        const bool minmax = fold_op == OP_MIN || fold_op == OP_MAX, flt = is_flt(val.kind);
+        const uint64_t ident = acc_identity(fold_op);
+#pragma unroll
+        for (int k = 0; k < GBP_ITEMS; ++k) {
+          uint64_t x = img[k];
+          if (minmax) x = flt ? ord_f64(__longlong_as_double((long long)x)) : ord_i64((int64_t)x);
+          acc[k] = ((vmask >> k) & 1u) ? x : ident;
+        }
+      }
+      uint32_t part[GBP_ITEMS], rk[GBP_ITEMS];
+      const uint32_t livemask = okmask & inrange;
+#pragma unroll
+      for (int k = 0; k < GBP_ITEMS; ++k) {
+        k32[k] = (k32[k] << vbit) | (uint32_t)(VBIT && ((vmask >> k) & 1u));
+        part[k] = k32[k] >> low;
+      }
+      gbp_rank<GBP_ITEMS>(hist, part, livemask, rk);
+      block_sync();
+      {   // exclusive scan of hist[0..MAX_PARTS) by the 1024 threads, PER consecutive partitions each; clears hist for the next tile
+        uint32_t v[PER], sum = 0;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) { v[q] = hist[threadIdx.x * PER + q]; sum += v[q]; hist[threadIdx.x * PER + q] = 0; }
+        const uint32_t incl = wave_scan_incl(sum);
+        if (lane_id() == WAVE - 1) wave_tot[threadIdx.x / WAVE] = incl;
+        block_sync();
+        uint32_t run = incl - sum;
+        for (int w = 0; w < (int)(threadIdx.x / WAVE); ++w) run += wave_tot[w];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+          const uint32_t b = threadIdx.x * PER + q;
+          start[b] = run;
+          gbase[b] = cursor[b] - run;
+          cursor[b] += v[q];
+          run += v[q];
+        }
+      }
+      block_sync();
+      uint32_t total = 0;
+      for (int w = 0; w < GBP_SC_THREADS / WAVE; ++w) total += wave_tot[w];
+      uint32_t st[GBP_ITEMS];          // all reads of start[] first (one LDS round trip, not one per row), then the writes
+#pragma unroll
+      for (int k = 0; k < GBP_ITEMS; ++k) st[k] = start[part[k] & (GBP_MAX_PARTS - 1)];
+#pragma unroll
+      for (int k = 0; k < GBP_ITEMS; ++k) {
+        if ((livemask >> k) & 1u) {
+          const uint32_t pos = st[k] + rk[k];
+          stage_k[pos] = k32[k];
+          stage[pos] = acc[k];
+        }
+      }
+      block_sync();
+      // flush: every LDS read first (the record, then its partition's base), then the stores; slots beyond `total` re-read slot 0
+      uint32_t kk[GBP_ITEMS], gb[GBP_ITEMS];
+      uint64_t vv[GBP_ITEMS];
+      const uint32_t ftid = gbp_opaque_tid();
+#pragma unroll
+      for (int k = 0; k < GBP_ITEMS; ++k) {
+        const uint32_t j = ftid + k * GBP_SC_THREADS;
+        const uint32_t jc = j < total ? j : 0u;
+        kk[k] = stage_k[jc];
+        vv[k] = stage[jc];
+      }
+#pragma unroll
+      for (int k = 0; k < GBP_ITEMS; ++k) gb[k] = gbase[(kk[k] >> low) & (GBP_MAX_PARTS - 1)];
+#pragma unroll
+      for (int k = 0; k < GBP_ITEMS; ++k) {
+        const uint32_t j = ftid + k * GBP_SC_THREADS;
+        if (j < total) rec_out[gb[k] + j] = GbRec{kk[k], (uint32_t)vv[k], (uint32_t)(vv[k] >> 32)};
+      }
     }
   }
 }
@@ -2264,7 +2447,9 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
     if constexpr (sizeof(K) == 4) {
       const uint32_t P = 1u << part_bits;
       const int low = vbit + id_bits;
-      int64_t chunk = (n + GBP_MAX_CHUNKS - 1) / GBP_MAX_CHUNKS;
+      int max_chunks = GBP_MAX_CHUNKS;
+      if (const char *e = getenv("GDF_GBP_CHUNKS")) max_chunks = atoi(e) > 0 ? atoi(e) : GBP_MAX_CHUNKS;      // experiment switch
+      int64_t chunk = (n + max_chunks - 1) / max_chunks;
       chunk = (chunk + GBP_TILE - 1) / GBP_TILE * GBP_TILE;
       const int nchunks = (int)((n + chunk - 1) / chunk);
       DevBuf hist, d_start, d_flags;
@@ -2274,44 +2459,60 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
       HIP_TRY(hipMemsetAsync(d_flags.p, 0, sizeof(unsigned int) * 2, stream0()));
       HIP_TRY(hipMemsetAsync(hist.as<uint32_t>() + (size_t)P * nchunks, 0, sizeof(uint32_t), stream0()));
       // static key signature (gbp_pack32): one or two 4- / 8-byte integer key columns
-      static const bool no_static = getenv("GDF_GBP_DYNAMIC") != nullptr;
+      const bool no_static = getenv("GDF_GBP_DYNAMIC") != nullptr;          // (read per call: the tests flip it)
       auto int_kind = [](int k) { return k == K_I32 || k == K_I64; };
       const bool key_sig = !no_static && (t.ncols == 1 || t.ncols == 2) && int_kind(t.col[0].kind) && (t.ncols == 1 || int_kind(t.col[1].kind));
       const int k0 = key_sig ? t.col[0].kind : -1, k1 = !key_sig ? -1 : (t.ncols == 2 ? t.col[1].kind : -2);
+      // The count only needs the partition id.  A second key column whose bit field lies entirely below the id bits that select the
+      // partition (C5: int32 values 0..15 under 2^13 ids) and that has no nulls cannot change a row's partition or drop the row:
+      // the count does not read it (8 instead of 12 B per row on C5) and the scatter kernel, which reads every column anyway,
+      // checks its values against a guessed range.  Only with the statically typed scatter kernels (they carry that check).
+      const bool val_sig = (val.kind == K_I64 || val.kind == K_F64) && fold_op != OP_COUNT && (!vbit || val.valid) && !getenv("GDF_GBP_OLD");
+      const bool skip_low = key_sig && val_sig && t.ncols == 2 && !t.col[1].valid && sp.shift[1] + sp.bits[1] + vbit <= low &&
+                            !getenv("GDF_GBP_COUNT_ALL");
+      const int ck1 = skip_low ? -2 : k1;
       auto count = [&](auto kernel) {
         GDF_LAUNCH("gbp_count", kernel, dim3(nchunks < NUM_CU * 2 ? nchunks : NUM_CU * 2), dim3(GBP_THREADS), 0, stream0(), t, sp, low, vbit, P,
                    chunk, nchunks, hist.as<uint32_t>(), d_flags.as<unsigned int>());
       };
-      if (k0 == K_I32 && k1 == -2) count(gbp_count<K_I32, -2>);
-      else if (k0 == K_I64 && k1 == -2) count(gbp_count<K_I64, -2>);
-      else if (k0 == K_I32 && k1 == K_I32) count(gbp_count<K_I32, K_I32>);
-      else if (k0 == K_I32 && k1 == K_I64) count(gbp_count<K_I32, K_I64>);
-      else if (k0 == K_I64 && k1 == K_I32) count(gbp_count<K_I64, K_I32>);
-      else if (k0 == K_I64 && k1 == K_I64) count(gbp_count<K_I64, K_I64>);
+      if (k0 == K_I32 && ck1 == -2) count(gbp_count<K_I32, -2>);
+      else if (k0 == K_I64 && ck1 == -2) count(gbp_count<K_I64, -2>);
+      else if (k0 == K_I32 && ck1 == K_I32) count(gbp_count<K_I32, K_I32>);
+      else if (k0 == K_I32 && ck1 == K_I64) count(gbp_count<K_I32, K_I64>);
+      else if (k0 == K_I64 && ck1 == K_I32) count(gbp_count<K_I64, K_I32>);
+      else if (k0 == K_I64 && ck1 == K_I64) count(gbp_count<K_I64, K_I64>);
       else count(gbp_count<-1, -1>);
       GDF_TRY(scan_u32(hist.as<uint32_t>(), hist.as<uint32_t>(), (size_t)P * nchunks + 1, false));
       const size_t slds = gbp_scatter_lds();
-      static const bool lean = !getenv("GDF_GBP_OLD");       // A/B switch: the round-1 load structure of the kernel
-      auto scatter = [&](auto kernel) -> gdf_error {
-        HIP_TRY(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
-        GDF_LAUNCH("gbp_scatter", kernel, dim3(nchunks < NUM_CU ? nchunks : NUM_CU), dim3(GBP_SC_THREADS), slds, stream0(), t, sp, val, fold_op,
-                   low, part_bits, P, chunk, nchunks, (const uint32_t *)hist.as<uint32_t>(), ka.as<GbRec>());
-        return GDF_SUCCESS;
-      };
-      // static signature: one or two key columns of 4- / 8-byte integers, an 8-byte value column, not COUNT
-      const bool sig = lean && key_sig && (val.kind == K_I64 || val.kind == K_F64) && fold_op != OP_COUNT && (!vbit || val.valid);
+      const bool lean = !getenv("GDF_GBP_OLD");              // A/B switch: the scatter kernel with the type switches for every shape
+      const bool sig = lean && key_sig && val_sig;
+      const dim3 sgrid(nchunks < NUM_CU ? nchunks : NUM_CU);
       if (sig) {
         const int vm = vbit ? 2 : (val.valid ? 1 : 0);        // 0: no mask, 1: mask, 2: mask + validity bit in the key
-#define GBP_SIG(K0, K1)                                                                                            \
-        if (k0 == K0 && k1 == K1) {                                                                                   \
-          if (vm == 2) GDF_TRY(scatter(gbp_scatter<true, true, K0, K1, true>));                                        \
-          else if (vm == 1) GDF_TRY(scatter(gbp_scatter<false, true, K0, K1, true>));                                  \
-          else GDF_TRY(scatter(gbp_scatter<false, true, K0, K1, false>));                                              \
+        auto scatter = [&](auto kernel) -> gdf_error {
+          HIP_TRY(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
+          GDF_LAUNCH("gbp_scatter", kernel, sgrid, dim3(GBP_SC_THREADS), slds, stream0(), t, sp, val, fold_op, low, P, chunk, nchunks,
+                     (const uint32_t *)hist.as<uint32_t>(), ka.as<GbRec>(), d_flags.as<unsigned int>());
+          return GDF_SUCCESS;
+        };
+#define GBP_SIG(K0, K1)                                                                                                          \
+        if (k0 == K0 && k1 == K1) {                                                                                                 \
+          if (vm == 2) GDF_TRY(scatter(gbp_scatter_static<true, K0, K1, true>));                                                   \
+          else if (vm == 1) GDF_TRY(scatter(gbp_scatter_static<false, K0, K1, true>));                                             \
+          else GDF_TRY(scatter(gbp_scatter_static<false, K0, K1, false>));                                                         \
         }
         GBP_SIG(K_I32, -2) GBP_SIG(K_I64, -2) GBP_SIG(K_I32, K_I32) GBP_SIG(K_I32, K_I64) GBP_SIG(K_I64, K_I32) GBP_SIG(K_I64, K_I64)
 #undef GBP_SIG
-      } else if (vbit) GDF_TRY(scatter(gbp_scatter<true, false>));       // other shapes: the column loop with its type switches.  (LEAN
-      else GDF_TRY(scatter(gbp_scatter<false, false>));                 // without static kinds spills inside the tile loop: not built)
+      } else {
+        auto scatter = [&](auto kernel) -> gdf_error {
+          HIP_TRY(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
+          GDF_LAUNCH("gbp_scatter", kernel, sgrid, dim3(GBP_SC_THREADS), slds, stream0(), t, sp, val, fold_op, low, part_bits, P, chunk, nchunks,
+                     (const uint32_t *)hist.as<uint32_t>(), ka.as<GbRec>());
+          return GDF_SUCCESS;
+        };
+        if (vbit) GDF_TRY(scatter(gbp_scatter<true>));
+        else GDF_TRY(scatter(gbp_scatter<false>));
+      }
       hipLaunchKernelGGL(gb_strided_u32, dim3((P + 256) / 256), dim3(256), 0, stream0(), (const uint32_t *)hist.as<uint32_t>(), d_start.as<uint32_t>(),
                          (int)P + 1, (size_t)nchunks);
       HIP_CHECK_LAST();

@@ -57,20 +57,25 @@ def test_c5_shape_against_the_oracle(gdf, n, zipf_values, op):
         np.testing.assert_allclose(ga[gok], ea[eok], rtol=RTOL, atol=0.0)        # plain relative
 
 
-@pytest.mark.parametrize("order", ["sorted", "shuffled"])
+@pytest.mark.parametrize("order", ["sorted", "shuffled", "second-column-outliers"])
 def test_guessed_key_ranges_are_verified(gdf, order):
     """From 2^24 rows on, keys that only pack by range get their ranges GUESSED from a 65536-row prefix and the partitioned
     path's count kernel checks every key against the guess (csrc/groupby.hip gb_plan_range_sampled / gbp_count).  Sorted
     keys make the prefix see a sliver of the range: the call must notice and redo the plan exactly.  Shuffled keys keep
-    the guess.  Both against the oracle."""
+    the guess; outliers in the SECOND column only are for the scatter kernel to notice.  All against the oracle."""
     from libgdf_amd.columns import column_from_numpy
     n = (1 << 24) + 12345
     rs = np.random.RandomState(5)
     k0 = (np.arange(n, dtype=np.int64) // 40) - 1000            # 420 k values, ascending: the prefix spans ~1600 of them
     k1 = rs.randint(-2, 3, size=n).astype(np.int32)
-    if order == "shuffled":
+    if order != "sorted":
         perm = rs.permutation(n)
         k0, k1 = k0[perm], k1[perm]
+    if order == "second-column-outliers":
+        # the count kernel skips a last key column that cannot change the partition id; its values are checked against the
+        # guess by the scatter kernel instead (gbp_scatter, flags[1]): values the prefix never showed, far behind it
+        k1[n - 5000::7] = 100
+        k1[3_000_000] = -77
     v = rs.randint(-1000, 1000, size=n).astype(np.int64)
     gk, ga = gdf.api.group_by("sum", [column_from_numpy(k0), column_from_numpy(k1)], column_from_numpy(v))
     gk, ga = [x.cpu().numpy() for x in gk], ga.cpu().numpy()

@@ -477,3 +477,30 @@ def test_lds_dictionary_switch_matches_dense_path(gdf):
         del os.environ["GDF_GB_NO_LDS_DICT"]
     np.testing.assert_array_equal(a[0][0], b[0][0])
     np.testing.assert_array_equal(a[1], b[1])
+
+
+# ---- fused partition pass: the statically typed kernels (csrc/groupby.hip gbp_count<K0, K1> / gbp_scatter<..., K0, K1, VMASK>) ----
+@pytest.mark.parametrize("key_dtypes", [(np.int32,), (np.int64,), (np.int32, np.int32), (np.int32, np.int64), (np.int64, np.int32),
+                                        (np.int64, np.int64)], ids=lambda ks: "+".join(np.dtype(k).name for k in ks))
+@pytest.mark.parametrize("op,val_dtype", [("sum", np.int64), ("avg", np.float64), ("min", np.float64), ("count", np.int64)],
+                         ids=lambda x: x if isinstance(x, str) else np.dtype(x).name)
+def test_fused_partition_pass_static_signatures(gdf, key_dtypes, val_dtype, op, monkeypatch):
+    """>= 2^20 rows and more groups than one set of LDS accumulators: the fused partition pass, whose count / scatter kernels
+    are instantiated per (key kinds, value mask) for one or two 4- / 8-byte integer key columns with an 8-byte value column
+    (COUNT and every other shape keep the kernels with the type switches; GDF_GBP_DYNAMIC=1 forces those: same answers).
+    Without masks, with a value mask (SUM / MIN: no validity bit in the key; AVG: with it), with null key elements."""
+    n = (1 << 20) + 4321
+    rs = np.random.RandomState(11)
+    first = rs.randint(-150_000, 150_000, size=n).astype(key_dtypes[0]) if len(key_dtypes) == 1 else \
+        rs.randint(-30_000, 30_000, size=n).astype(key_dtypes[0])
+    keys = [first] + [rs.randint(-3, 4, size=n).astype(dt) for dt in key_dtypes[1:]]
+    vals = rs.randint(-1000, 1000, size=n).astype(val_dtype) if np.dtype(val_dtype).kind == "i" else rs.random_sample(n)
+    out = np.int64 if op == "count" else (np.float64 if op == "avg" else None)
+    v_ok = rs.random_sample(n) > 0.5
+    k_ok = rs.random_sample(n) > 0.02
+    nokeys = [None] * len(keys)
+    _check(gdf, op, keys, vals, out)
+    _check_masked(gdf, op, keys, vals, nokeys, v_ok, out)
+    _check_masked(gdf, op, keys, vals, [k_ok] + nokeys[1:], v_ok, out)
+    monkeypatch.setenv("GDF_GBP_DYNAMIC", "1")
+    _check_masked(gdf, op, keys, vals, nokeys, v_ok, out)

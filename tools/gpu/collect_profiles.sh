@@ -28,8 +28,10 @@ pmc2() {   # tag, command...
   (cd $R && python tools/pmc_hbm_json.py $(find $O/pmc_${tag}_f -name "*counter_collection.csv" | head -1) $(find $O/pmc_${tag}_w -name "*counter_collection.csv" | head -1) $O/pmc_${tag}_hbm_bytes.json "$*  (totals over all launches of the command: divide by launches)") > $O/pmc_${tag}.txt
 }
 pmc2 c5 python $R/tools/bench_c5.py --reps 1
+if [ -z "$GDF_COLLECT_SHORT" ]; then      # (kernels untouched since the last full collection: GDF_COLLECT_SHORT=1 skips them)
 pmc2 fused python $R/tools/sim_c4_fused.py
 pmc2 c2sparse python $R/tools/bench_shapes.py --only c2_sparse_keys --reps 1
+fi
 cd $R
 python tools/rocprof_summary.py $O/trace $O/kernel_stats.md
 python tools/pmc_hbm_json.py $(find $O/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $O/pmc_write -name "*counter_collection.csv" | head -1) $O/pmc_hbm.json

@@ -112,7 +112,7 @@ static gdf_error mask_and(const uint8_t *a, const uint8_t *b, uint8_t *out, int6
                             z.as<unsigned long long>());
   HIP_CHECK_LAST();
   unsigned long long h = 0;
-  HIP_TRY(hipMemcpy(&h, z.p, sizeof(h), hipMemcpyDeviceToHost));
+  HIP_TRY(read_back(&h, z.p, sizeof(h)));
   *null_count = (gdf_size_type)h;
   return GDF_SUCCESS;
 }
@@ -378,7 +378,7 @@ static gdf_error compact(Pred pred, int64_t n, int width, const void *in, void *
   if constexpr (std::is_same<Pred, StencilPred>::value) {
     // thread-consecutive rows win while few rows survive (10 % kept: 0.19 vs 0.33 ms per 1e8 rows); at 50 % the
     // ballot kernel below is ahead again (0.39 vs 0.42 ms), so the number of keepers -- known after the scan -- decides
-    HIP_TRY(hipMemcpy(kept, counts.as<uint64_t>() + nchunks, sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIP_TRY(read_back(kept, counts.as<uint64_t>() + nchunks, sizeof(uint64_t)));
     if (((uintptr_t)pred.stencil & 15) == 0 && chunk % 16 == 0 && width != 0 && *kept * 3 < (uint64_t)n && !getenv("GDF_FL_NO_VEC")) {
       switch (width) {
         case 1: GDF_LAUNCH("compact_write", stencil_write_kernel<1>, g, b, 0, stream0(), pred.stencil, pred.valid, n, chunk, counts.as<uint64_t>(), in, out); break;
@@ -387,7 +387,7 @@ static gdf_error compact(Pred pred, int64_t n, int width, const void *in, void *
         default: GDF_LAUNCH("compact_write", stencil_write_kernel<8>, g, b, 0, stream0(), pred.stencil, pred.valid, n, chunk, counts.as<uint64_t>(), in, out); break;
       }
       HIP_CHECK_LAST();
-      HIP_TRY(hipMemcpy(kept, counts.as<uint64_t>() + nchunks, sizeof(uint64_t), hipMemcpyDeviceToHost));
+      HIP_TRY(read_back(kept, counts.as<uint64_t>() + nchunks, sizeof(uint64_t)));
       return GDF_SUCCESS;
     }
   }
@@ -399,7 +399,7 @@ static gdf_error compact(Pred pred, int64_t n, int width, const void *in, void *
     default: GDF_LAUNCH("compact_write", (compact_write_kernel<Pred, 8>), g, b, 0, stream0(), pred, n, chunk, counts.as<uint64_t>(), in, out); break;
   }
   HIP_CHECK_LAST();
-  HIP_TRY(hipMemcpy(kept, counts.as<uint64_t>() + nchunks, sizeof(uint64_t), hipMemcpyDeviceToHost));
+  HIP_TRY(read_back(kept, counts.as<uint64_t>() + nchunks, sizeof(uint64_t)));
   return GDF_SUCCESS;
 }
 
@@ -531,7 +531,7 @@ gdf_error gdf_count_nonzero_mask(gdf_valid_type const *masks, int num_rows, int 
                      stream0(), masks, (int64_t)num_rows, c.as<unsigned long long>());
   HIP_CHECK_LAST();
   unsigned long long h = 0;
-  HIP_TRY(hipMemcpy(&h, c.p, sizeof(h), hipMemcpyDeviceToHost));
+  HIP_TRY(read_back(&h, c.p, sizeof(h)));
   *count = (int)h;
   return GDF_SUCCESS;
 }

@@ -644,6 +644,12 @@ __global__ __launch_bounds__(256) void gb_dict_number(GbDict g, unsigned int spe
 __global__ __launch_bounds__(256) void gb_fill_u64(unsigned long long *p, unsigned long long v, uint32_t n) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = v;
 }
+// the direct path's three clears in one launch: accumulators to the identity, row counts and the two result words to zero
+__global__ __launch_bounds__(256) void gb_direct_init(unsigned long long *acc, unsigned long long identity, unsigned long long *cnt, uint32_t n,
+                                                      unsigned int *two_words) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { acc[i] = identity; cnt[i] = 0; }
+  if (blockIdx.x == 0 && threadIdx.x < 2) two_words[threadIdx.x] = 0;
+}
 __global__ __launch_bounds__(256) void gb_dict_clear(GbDictEntry *e, uint32_t n) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) e[i] = GbDictEntry{GB_EMPTY_KEY, 0u, 0u};
 }
@@ -991,9 +997,13 @@ __global__ __launch_bounds__(256) void gb_write_mask(const uint8_t *ok, uint32_t
 // write the output validity masks the caller supplied buffers for: keys are never null
 // (rows with a null key were dropped), the aggregate is null for an all-null group
 static gdf_error write_output_masks(int ncols, gdf_column **out_keys, gdf_column *out_agg, const uint8_t *agg_ok, uint32_t ngroups) {
+  // the null counter is only ever raised for an aggregate with all-null groups (agg_ok): without one, nothing is allocated,
+  // cleared or read back (one host round trip of a 0.4 ms C2 call)
   DevBuf nulls;
-  RMM_TRY(nulls.alloc(sizeof(unsigned int)));
-  HIP_TRY(hipMemsetAsync(nulls.p, 0, sizeof(unsigned int), stream0()));
+  if (agg_ok) {
+    RMM_TRY(nulls.alloc(sizeof(unsigned int)));
+    HIP_TRY(hipMemsetAsync(nulls.p, 0, sizeof(unsigned int), stream0()));
+  }
   const int grid = stream_grid((ngroups + 7) / 8 + 1, 256);
   for (int c = 0; c < ncols; ++c) {
     out_keys[c]->null_count = 0;
@@ -1006,7 +1016,7 @@ static gdf_error write_output_masks(int ncols, gdf_column **out_keys, gdf_column
     hipLaunchKernelGGL(gb_write_mask, dim3(grid), dim3(256), 0, stream0(), agg_ok, ngroups, (uint8_t *)out_agg->valid,
                        nulls.as<unsigned int>());
     unsigned int h = 0;
-    HIP_TRY(hipMemcpy(&h, nulls.p, sizeof(h), hipMemcpyDeviceToHost));
+    if (agg_ok) HIP_TRY(read_back(&h, nulls.p, sizeof(h)));
     out_agg->null_count = h;
   }
   HIP_CHECK_LAST();
@@ -1054,8 +1064,8 @@ static gdf_error gb_plan_range(const KeyTable &t, GbKeyPlan *plan, std::vector<l
     GDF_LAUNCH("gb_image_ranges", gb_image_ranges, dim3(stream_grid((size_t)t.nrows, 256 * 16)), dim3(256), 0, stream0(), t, mm.as<long long>(), d_nan);
     HIP_CHECK_LAST();
     unsigned int has_nan = 0;
-    HIP_TRY(hipMemcpy(h.data(), mm.p, sizeof(long long) * 2 * t.ncols, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(&has_nan, d_nan, sizeof(has_nan), hipMemcpyDeviceToHost));
+    HIP_TRY(read_back(h.data(), mm.p, sizeof(long long) * 2 * t.ncols));
+    HIP_TRY(read_back(&has_nan, d_nan, sizeof(has_nan)));
     if (has_nan) return GDF_SUCCESS;        // NaN keys: every NaN row is a group of its own, only the row-comparing path does that
   } else {
     GDF_TRY(key_ranges(t, h.data()));
@@ -1651,7 +1661,7 @@ template <int K0 = -1, int K1 = -1>
 __global__ __launch_bounds__(GBP_THREADS) void gbp_count(KeyTable t, GbKeyPlan plan, int low, int vbit, uint32_t nparts, int64_t chunk,
                                                          int nchunks, uint32_t *__restrict__ hist, unsigned int *__restrict__ flags) {
   __shared__ uint32_t cnt[GBP_MAX_PARTS];
-  constexpr int B = 8;
+  constexpr int B = (K0 >= 0 && K1 == -2) ? 12 : 8;       // one key column to read: half as many rows again in flight per thread (77 VGPRs at 8; 16 spill)
   unsigned int dropped = 0, outside = 0;
   for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
     for (uint32_t q = threadIdx.x; q < nparts; q += GBP_THREADS) cnt[q] = 0;
@@ -2169,11 +2179,9 @@ static gdf_error gb_path_direct(GbJob &j, bool *done) {
       RMM_TRY(gacc.alloc(sizeof(uint64_t) * d.total));
       RMM_TRY(gcnt.alloc(sizeof(uint64_t) * d.total));
       RMM_TRY(ng.alloc(sizeof(unsigned int) * 2));
-      HIP_TRY(hipMemsetAsync(ng.p, 0, sizeof(unsigned int) * 2, stream0()));
       const int fold_op = op == OP_AVG ? OP_SUM : op;
-      GDF_LAUNCH("gb_fill", gb_fill_u64, dim3(stream_grid(d.total, 256)), dim3(256), 0, stream0(), gacc.as<unsigned long long>(),
-                 (unsigned long long)acc_identity_host(fold_op), d.total);
-      HIP_TRY(hipMemsetAsync(gcnt.p, 0, sizeof(uint64_t) * d.total, stream0()));
+      GDF_LAUNCH("gb_fill", gb_direct_init, dim3(stream_grid(d.total, 256)), dim3(256), 0, stream0(), gacc.as<unsigned long long>(),
+                 (unsigned long long)acc_identity_host(fold_op), gcnt.as<unsigned long long>(), d.total, ng.as<unsigned int>());
       const int agrid = stream_grid((size_t)n, GB_DENSE_THREADS * GB_DENSE_BATCH, NUM_CU);
       const int64_t achunk = (((n + agrid - 1) / agrid) + GB_DENSE_THREADS - 1) / GB_DENSE_THREADS * GB_DENSE_THREADS;
       const size_t dlds = (size_t)d.total * 12 + 16;
@@ -2205,7 +2213,7 @@ static gdf_error gb_path_direct(GbJob &j, bool *done) {
                  (const unsigned long long *)gcnt.as<unsigned long long>(), ng.as<unsigned int>());
       HIP_CHECK_LAST();
       unsigned int res[2] = {0, 0};                                                   // {groups, some row outside the window}
-      HIP_TRY(hipMemcpy(res, ng.p, sizeof(res), hipMemcpyDeviceToHost));
+      HIP_TRY(read_back(res, ng.p, sizeof(res)));
       if (res[1]) continue;                                                          // guessed window too small: exact ranges next
       for (int c = 0; c < ncols; ++c) out_keys[c]->size = (gdf_size_type)res[0];
       out_agg->size = (gdf_size_type)res[0];
@@ -2306,7 +2314,7 @@ static gdf_error gb_path_dense(GbJob &j, bool *done) {
                      keyimg.as<unsigned long long>(), ids.as<uint16_t>(), echunk, ld_state);
         HIP_CHECK_LAST();
         unsigned int all[8];
-        HIP_TRY(hipMemcpy(all, flags.p, sizeof(all), hipMemcpyDeviceToHost));
+        HIP_TRY(read_back(all, flags.p, sizeof(all)));
         for (int k = 0; k < 3; ++k) h_flags[k] = all[k];
         const unsigned int *st = all + 4;
         if (h_flags[1] || st[2]) break;          // table overflow: the general path.  No image (too many groups): the dense path.
@@ -2319,12 +2327,12 @@ static gdf_error gb_path_dense(GbJob &j, bool *done) {
       KeyTable ts = t;
       ts.nrows = sample;
       GDF_TRY(dict_build(ts, (int)(sample / (GB_DICT_THREADS * GB_DENSE_BATCH)), GB_DICT_THREADS * GB_DENSE_BATCH));
-      HIP_TRY(hipMemcpy(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost));
+      HIP_TRY(read_back(h_flags, flags.p, sizeof(h_flags)));
     }
     if (!have_ids && !h_flags[1]) {
       GDF_TRY(dict_build(t, bgrid, bchunk));
       HIP_CHECK_LAST();
-      HIP_TRY(hipMemcpy(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost));
+      HIP_TRY(read_back(h_flags, flags.p, sizeof(h_flags)));
     }
     const uint32_t ngroups = h_flags[0] + (h_flags[2] ? 1u : 0u);
     if (!h_flags[1] && ngroups <= max_groups) {
@@ -2517,9 +2525,9 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
                          (int)P + 1, (size_t)nchunks);
       HIP_CHECK_LAST();
       hp.resize((size_t)P + 1);
-      HIP_TRY(hipMemcpy(hp.data(), d_start.p, sizeof(uint32_t) * ((size_t)P + 1), hipMemcpyDeviceToHost));
+      HIP_TRY(read_back(hp.data(), d_start.p, sizeof(uint32_t) * ((size_t)P + 1)));
       unsigned int hfl[2] = {0, 0};
-      HIP_TRY(hipMemcpy(hfl, d_flags.p, sizeof(hfl), hipMemcpyDeviceToHost));
+      HIP_TRY(read_back(hfl, d_flags.p, sizeof(hfl)));
       hf.dropped = hfl[0];
       j.range_violated = hfl[1] != 0;
       if (j.range_violated) { *done = false; return GDF_SUCCESS; }      // sample-guessed ranges did not hold: the caller retries exactly
@@ -2527,7 +2535,7 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
   } else {
     GDF_LAUNCH("gb_sorted_make_pairs", gb_sorted_make_pairs<K>, dim3(stream_grid((size_t)n, 256 * 8)), dim3(256), 0, stream0(), t, sp, val,
                fold_op, vbit, null_key, kin, pin, fl.as<unsigned long long>(), (unsigned int *)(fl.as<unsigned long long>() + 1));
-    HIP_TRY(hipMemcpy(&hf, fl.p, 16, hipMemcpyDeviceToHost));
+    HIP_TRY(read_back(&hf, fl.p, 16));
   }
   const uint32_t nvalid = nn - hf.dropped;
   uint32_t ngroups = 0;
@@ -2552,7 +2560,7 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
       GDF_LAUNCH("gb_part_bounds", gb_part_bounds<K>, dim3(stream_grid((size_t)P + 1, 256)), dim3(256), 0, stream0(), (const K *)kin, nvalid, low, P,
                  pstart.as<uint32_t>());
       hp.resize((size_t)P + 1);
-      HIP_TRY(hipMemcpy(hp.data(), pstart.p, sizeof(uint32_t) * ((size_t)P + 1), hipMemcpyDeviceToHost));
+      HIP_TRY(read_back(hp.data(), pstart.p, sizeof(uint32_t) * ((size_t)P + 1)));
     }
     std::vector<GbPartUnit> units;
     for (uint32_t p = 0; p < P; ++p)
@@ -2609,7 +2617,7 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
                (const unsigned int *)grows.as<unsigned int>(), (const unsigned int *)gvalid.as<unsigned int>(), (const uint32_t *)bcnt.as<uint32_t>(),
                ng.as<unsigned int>());
     HIP_CHECK_LAST();
-    HIP_TRY(hipMemcpy(&ngroups, ng.p, sizeof(ngroups), hipMemcpyDeviceToHost));
+    HIP_TRY(read_back(&ngroups, ng.p, sizeof(ngroups)));
   }
   for (int c = 0; c < ncols; ++c) out_keys[c]->size = (gdf_size_type)ngroups;
   out_agg->size = (gdf_size_type)ngroups;
@@ -2661,7 +2669,7 @@ static gdf_error gb_path_sorted(GbJob &j, bool *done) {
       GDF_LAUNCH("gb_sorted_make_pairs", gb_sorted_make_pairs<uint64_t>, dim3(stream_grid((size_t)n, 256 * 8)), dim3(256), 0, stream0(), t, sp, val,
                  fold_op, vbit, null_key, kin, pin, fl.as<unsigned long long>(), (unsigned int *)(fl.as<unsigned long long>() + 1));
       struct { unsigned long long varying; unsigned int dropped, pad; } hf;
-      HIP_TRY(hipMemcpy(&hf, fl.p, 16, hipMemcpyDeviceToHost));
+      HIP_TRY(read_back(&hf, fl.p, 16));
       const uint32_t nvalid = nn - hf.dropped;
       uint32_t ngroups = 0;
       GbOut o{};
@@ -2677,7 +2685,7 @@ static gdf_error gb_path_sorted(GbJob &j, bool *done) {
         const int hgrid = stream_grid(nvalid, 256 * 4);
         GDF_LAUNCH("gb_sorted_heads", gb_sorted_heads, dim3(hgrid), dim3(256), 0, stream0(), (const uint64_t *)kin, vbit, gid.as<uint32_t>(), nvalid);
         GDF_TRY(scan_u32(gid.as<uint32_t>(), gid.as<uint32_t>(), nvalid, true));
-        HIP_TRY(hipMemcpy(&ngroups, gid.as<uint32_t>() + (nvalid - 1), sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(read_back(&ngroups, gid.as<uint32_t>() + (nvalid - 1), sizeof(uint32_t)));
         RMM_TRY(start.alloc(sizeof(uint32_t) * ((size_t)ngroups + 1)));
         RMM_TRY(acc.alloc(sizeof(uint64_t) * (size_t)ngroups));
         if (vbit) RMM_TRY(cnt.alloc(sizeof(uint64_t) * (size_t)ngroups));
@@ -2765,7 +2773,7 @@ static gdf_error gb_path_table(GbJob &j) {
     }
     HIP_CHECK_LAST();
     unsigned int h_flags[3] = {0, 0, 0};
-    HIP_TRY(hipMemcpy(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost));
+    HIP_TRY(read_back(h_flags, flags.p, sizeof(h_flags)));
     if (h_flags[1]) {                       // too many groups for this table
       if (T >= cap_max) return GDF_HASH_TABLE_INSERT_FAILURE;
       T = T * 256 < cap_max ? T * 256 : cap_max;     // 2^18 -> 2^26 -> 2N: at most two retries
@@ -2788,7 +2796,7 @@ static gdf_error gb_path_table(GbJob &j) {
       GDF_LAUNCH("gb_extract", gb_extract<false>, dim3(egrid), dim3(256), 0, stream0(), t, plan, g, o, op, special_used, out_count.as<unsigned long long>());
     HIP_CHECK_LAST();
     unsigned long long ngroups = 0;
-    HIP_TRY(hipMemcpy(&ngroups, out_count.p, sizeof(ngroups), hipMemcpyDeviceToHost));
+    HIP_TRY(read_back(&ngroups, out_count.p, sizeof(ngroups)));
     for (int c = 0; c < ncols; ++c) out_keys[c]->size = (gdf_size_type)ngroups;   // gdf_table.cuh:334-342
     out_agg->size = (gdf_size_type)ngroups;
     if (sort_result || op == OP_AVG) {

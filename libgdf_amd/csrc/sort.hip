@@ -167,7 +167,7 @@ gdf_error key_ranges(const KeyTable &t, long long *lo_hi) {
   } else {
     GDF_LAUNCH("rs_minmax", rs_minmax, dim3(stream_grid((size_t)t.nrows, 256 * 16)), dim3(256), 0, stream0(), t, mm.as<long long>());
   }
-  HIP_TRY(hipMemcpy(lo_hi, mm.p, sizeof(long long) * 2 * t.ncols, hipMemcpyDeviceToHost));
+  HIP_TRY(read_back(lo_hi, mm.p, sizeof(long long) * 2 * t.ncols));
   return GDF_SUCCESS;
 }
 
@@ -820,8 +820,8 @@ static gdf_error radixsort_api(const RadixPlan *plan, gdf_column *keycol, gdf_co
     // non-empty segment.  Segments are disjoint (as DeviceSegmentedRadixSort requires).
     std::vector<unsigned> hb(nseg), he(nseg);
     if (nseg) {
-      HIP_TRY(hipMemcpy(hb.data(), d_begin, sizeof(unsigned) * nseg, hipMemcpyDeviceToHost));
-      HIP_TRY(hipMemcpy(he.data(), d_end, sizeof(unsigned) * nseg, hipMemcpyDeviceToHost));
+      HIP_TRY(read_back(hb.data(), d_begin, sizeof(unsigned) * nseg));
+      HIP_TRY(read_back(he.data(), d_end, sizeof(unsigned) * nseg));
     }
     std::vector<uint32_t> bounds;
     for (int s = 0; s < nseg; ++s) { bounds.push_back(hb[s]); bounds.push_back(he[s]); }
@@ -855,7 +855,7 @@ static gdf_error radixsort_api(const RadixPlan *plan, gdf_column *keycol, gdf_co
   GDF_LAUNCH("rsw_images", rsw_images, dim3(grid), dim3(256), 0, stream0(), (const void *)keycol->data, (int)kind, plan->descending,
              (const uint32_t *)region.as<uint32_t>(), (const uint8_t *)rflags.as<uint8_t>(), kin, vin, n, vary.as<unsigned long long>());
   unsigned long long varying = 0;
-  HIP_TRY(hipMemcpy(&varying, vary.p, sizeof(varying), hipMemcpyDeviceToHost));
+  HIP_TRY(read_back(&varying, vary.p, sizeof(varying)));
   GDF_TRY((radix_sort_pairs<uint64_t, uint32_t>(kin, kout, vin, vout, n, varying & range)));
   if (nseg >= 0 && nbounds) {
     // second, stable sort on the region number puts every row back into its own region

@@ -1352,36 +1352,67 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_fast(ProbeArgs a) {
       wa[b] = l.bw[pa[b] == JK_NOPOS ? 0 : pa[b]];
       wb[b] = l.bw[pb[b] == JK_NOPOS ? 0 : pb[b]];
     }
+    // hits as bit masks (bit b: tuple b of this lane): table 0 / table 1 / no partner but kept (LEFT)
+    uint32_t hamask = 0, hbmask = 0, padmask = 0;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       const bool ha = act[b] && pa[b] != JK_NOPOS && (NARROW ? (uint32_t)(wa[b] >> 32) == (uint32_t)key[b] : wa[b] == (uint64_t)key[b]);
       const bool hb = act[b] && pb[b] != JK_NOPOS && (NARROW ? (uint32_t)(wb[b] >> 32) == (uint32_t)key[b] : wb[b] == (uint64_t)key[b]);
-      const bool pad = KEEP && act[b] && !ha && !hb;
-      const uint32_t c = (uint32_t)ha + (uint32_t)hb + (uint32_t)pad;
-      uint32_t pos;
-      if (__all(c <= 1)) {
-        const unsigned long long mm = __ballot(c == 1);
-        uint32_t wbase = 0;
-        if (lane_id() == 0 && mm) wbase = atomicAdd(lcur, (unsigned int)__popcll(mm));
-        pos = __shfl(wbase, 0, WAVE) + mask_rank(mm);
-      } else {
-        const uint32_t incl = wave_scan_incl(c);
-        const uint32_t wave_total = __shfl(incl, WAVE - 1, WAVE);
-        uint32_t wbase = 0;
-        if (lane_id() == 0) wbase = atomicAdd(lcur, wave_total);
-        pos = __shfl(wbase, 0, WAVE) + incl - c;
+      hamask |= (uint32_t)ha << b;
+      hbmask |= (uint32_t)hb << b;
+      padmask |= (uint32_t)(KEEP && act[b] && !ha && !hb) << b;
+    }
+    auto emit = [&](int b, uint32_t pos, uint32_t c) {
+      const bool ha = (hamask >> b) & 1u, hb = (hbmask >> b) & 1u, pad = (padmask >> b) & 1u;
+      if (pos + c > unit_cap) a.opt_state[1] = 1;   // would spill into the next unit's slots: the host redoes the join two-pass
+      else if (!(a.dbg & 32)) {
+        // build row of a hit: NARROW carries it in the low half of the staged word, WIDE reads it from the staged row numbers
+        int32_t ra, rb;
+        if constexpr (NARROW) { ra = (int32_t)(uint32_t)wa[b]; rb = (int32_t)(uint32_t)wb[b]; }
+        else { ra = ha ? l.bi[pa[b]] : 0; rb = hb ? l.bi[pb[b]] : 0; }
+        op[pos] = (int32_t)prow[b];
+        ob[pos] = pad ? JK_EMPTY : (ha ? ra : rb);
+        if (c == 2) { op[pos + 1] = (int32_t)prow[b]; ob[pos + 1] = rb; }
       }
-      if (c) {
-        if (pos + c > unit_cap) a.opt_state[1] = 1;   // would spill into the next unit's slots: the host redoes the join two-pass
-        else if (!(a.dbg & 32)) {
-          // build row of a hit: NARROW carries it in the low half of the staged word, WIDE reads it from the staged row numbers
-          int32_t ra, rb;
-          if constexpr (NARROW) { ra = (int32_t)(uint32_t)wa[b]; rb = (int32_t)(uint32_t)wb[b]; }
-          else { ra = ha ? l.bi[pa[b]] : 0; rb = hb ? l.bi[pb[b]] : 0; }
-          op[pos] = (int32_t)prow[b];
-          ob[pos] = pad ? JK_EMPTY : (ha ? ra : rb);
-          if (c == 2) { op[pos + 1] = (int32_t)prow[b]; ob[pos + 1] = rb; }
+    };
+    if (__all((hamask & hbmask) == 0) && !(a.dbg & 2048)) {      // (GDF_JK_DBG=2048: one claim per tuple, as before)
+      // nobody has two pairs for one tuple (no key sits in both tables: the usual case).  ONE claim per wave and batch: the NB
+      // ballots give every tuple its offset inside the wave's range, lane 0 claims the sum, and the base comes back through
+      // readfirstlane -- per tuple a claim + a bpermute were two LDS round trips, sixteen per batch, on the critical path of a
+      // kernel that otherwise streams
+      const uint32_t onemask = hamask | hbmask | padmask;
+      unsigned long long mm[NB];
+      uint32_t off[NB], tot = 0;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        mm[b] = __ballot((onemask >> b) & 1u);
+        off[b] = tot;
+        tot += (uint32_t)__popcll(mm[b]);
+      }
+      uint32_t wbase = 0;
+      if (lane_id() == 0 && tot) wbase = atomicAdd(lcur, tot);
+      wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+        if ((onemask >> b) & 1u) emit(b, wbase + off[b] + (uint32_t)mask_rank(mm[b]), 1u);
+    } else {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const uint32_t c = ((hamask >> b) & 1u) + ((hbmask >> b) & 1u) + ((padmask >> b) & 1u);
+        uint32_t pos;
+        if (__all(c <= 1)) {
+          const unsigned long long mm = __ballot(c == 1);
+          uint32_t wbase = 0;
+          if (lane_id() == 0 && mm) wbase = atomicAdd(lcur, (unsigned int)__popcll(mm));
+          pos = __shfl(wbase, 0, WAVE) + mask_rank(mm);
+        } else {
+          const uint32_t incl = wave_scan_incl(c);
+          const uint32_t wave_total = __shfl(incl, WAVE - 1, WAVE);
+          uint32_t wbase = 0;
+          if (lane_id() == 0) wbase = atomicAdd(lcur, wave_total);
+          pos = __shfl(wbase, 0, WAVE) + incl - c;
         }
+        if (c) emit(b, pos, c);
       }
     }
   }

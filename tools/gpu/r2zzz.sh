@@ -1,7 +1,7 @@
 # after the last kernel-source change of the round: refresh what bench.py's roofline.traffic reads (the PMC summary is stamped with the
 # kernel build id), the kernel stats of the same command, the headline line and the small benches.  (The GPU suite ran on this build in
 # tools/gpu/r2bj.sh: 1309 passed.)
-TAG=r2zzz
+TAG=${1:-r2zzz}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -19,5 +19,6 @@ python tools/bench_c5.py 2>/dev/null | tail -1 > $O/bench_c5.json
 python tools/bench_ops.py > $O/bench_ops.jsonl 2>/dev/null
 python tools/bench_shapes.py > $O/bench_shapes.jsonl 2>/dev/null
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 tools/readback_lab.hip -o /tmp/readback_lab 2>/dev/null && /tmp/readback_lab > $O/readback_lab.txt 2>&1
+if [ -n "$GDF_REFRESH_PYTEST" ]; then timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | head -5 > $O/pytest_gpu.txt; cat $O/pytest_gpu.txt; fi
 rm -rf $O/trace/*/*.db; find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -size +8M -delete; find $O -name "*.db" -delete
 cut -c1-700 $O/bench.json; cut -c1-300 $O/bench_c5.json; cat $O/readback_lab.txt

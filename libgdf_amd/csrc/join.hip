@@ -2505,9 +2505,11 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
   // pass still works -- a unit's pairs fit the slots of its probe tuples -- it just leaves a hole at the end of every unit's
   // range; closing them (jk_compact_units, 16 B per PAIR) is cheaper than the count pass it replaces (8 B per probe TUPLE plus
   // a second build of every LDS table) when few probe rows hit: at 50 % the two are level (1e9 x 1e8 rows: compaction 1.8 ms
-  // against 2.3 ms of count pass, minus 8 GB of temporary pair slots), so the switch sits at 45 %.
+  // against 2.3 ms of count pass, minus 8 GB of temporary pair slots), so the switch sat at 45 %; with the lean write kernel's
+  // single claim per batch the single pass + compaction wins at 50 % (12.05 against 12.5 ms, tools/gpu/r2bp) and breaks even near
+  // 57 %: the switch sits at 55 % (GDF_JK_SPARSE_MAX overrides it).
   const bool try_sparse = !try_optimistic && d_off.p && nunits && oversize.empty() && kind == JOIN_INNER && !dup_heavy && !(a.dbg & 16) &&
-                          sample_hit < 0.45 && !getenv("GDF_JK_NO_SPARSE_OPT");
+                          sample_hit < (getenv("GDF_JK_SPARSE_MAX") ? atof(getenv("GDF_JK_SPARSE_MAX")) : 0.55) && !getenv("GDF_JK_NO_SPARSE_OPT");
   if (try_optimistic || try_sparse) {
     DevBuf d_state, d_upairs;
     RMM_TRY(d_state.alloc(sizeof(unsigned long long) * 4));

@@ -149,7 +149,7 @@ def cpu_baseline_pandas(sample_probe, sample_build, budget_s=60.0):
         assert len(m) == sample_probe
         del m
     dt = sorted(times)[len(times) // 2]
-    return {"value": sample_probe / dt, "unit": "rows/s", "cores": 1, "kind": "port", "impl": f"pandas {pd.__version__} DataFrame.merge",
+    return {"value": sample_probe / dt, "unit": "rows/s", "cores": 1, "kind": "reference-cpu-path", "impl": f"pandas {pd.__version__} DataFrame.merge",
             "sample": f"pandas.merge(how='inner') of {sample_probe} probe x {sample_build} build int64 rows (C3 / "
                       f"{1_000_000_000 // max(sample_probe, 1)}), median of {len(times)} run(s) = {dt:.1f} s; pandas' hash join is "
                       f"single-threaded: 1 of the host's {os.cpu_count()} cores"}

@@ -24,6 +24,13 @@ gdf_error gdf_amd_debug_partition(gdf_column *col, int fb, uint64_t *out_key, in
                                   uint32_t *out_joinable, uint64_t *out_info);
 
 /*
+ * test hook: force one of the library's alternative code paths (csrc/lab.h "path" switches, e.g. "GDF_JK_NO_SPEC") for
+ * the calls that follow in this process; value NULL clears the name.  libgdf.so reads NO environment variable -- the
+ * parity tests that push one request through two code paths select the second one here (tests/conftest.py force_path).
+ */
+gdf_error gdf_amd_debug_force(const char *name, const char *value);
+
+/*
  * out[i] = (int32)(in[i] - lo) when lo <= in[i] <= hi, else -1.   in: GDF_INT64 (or DATE64 / TIMESTAMP), no mask;
  * out: caller-preallocated GDF_INT32 of the same size; requires 0 <= hi - lo < 2^31 - 1.
  * The multi-GPU join ships 4-byte keys instead of 8-byte ones when the global build-key range allows it: probe keys

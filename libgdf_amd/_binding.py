@@ -130,6 +130,7 @@ _PROTOTYPES = {
     "gdf_amd_fj_send": (None, [_COLP, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, _INTP]),
     "gdf_amd_fj_build_create": (None, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_uint32, C.c_int64, C.POINTER(C.c_void_p)]),
     "gdf_amd_fj_probe_add": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int64, C.c_int64]),
+    "gdf_amd_debug_force": (None, [C.c_char_p, C.c_char_p]),
     "gdf_order_by": (None, [C.c_size_t, _COLP, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gdf_filter": (None, [C.c_size_t, _COLP, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                           C.POINTER(C.c_size_t)]),
@@ -154,8 +155,14 @@ GDF_UNSUPPORTED_METHOD = 12          # include/gdf/gdf.h gdf_error
 GDF_INT64 = 4                        # include/gdf/gdf.h gdf_dtype
 
 
+# LIBGDF_AMD_LAB=1: bind the LAB build of libgdf.so (lib/lab/, csrc/lab.h: experiment knobs compiled in and read from the
+# environment) instead of the shipped one.  Only the tuning scripts under tools/gpu/ set it; the choice is made HERE, in the
+# Python binding -- the shipped libgdf.so itself reads no environment variable.
+LAB_BUILD = os.environ.get("LIBGDF_AMD_LAB", "") not in ("", "0")
+
+
 def _load(name):
-    path = os.path.join(LIB_DIR, name)
+    path = os.path.join(LIB_DIR, "lab", name) if (LAB_BUILD and name == "libgdf.so") else os.path.join(LIB_DIR, name)
     if not os.path.exists(path):
         raise ImportError(
             f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -379,7 +379,7 @@ static gdf_error compact(Pred pred, int64_t n, int width, const void *in, void *
     // thread-consecutive rows win while few rows survive (10 % kept: 0.19 vs 0.33 ms per 1e8 rows); at 50 % the
     // ballot kernel below is ahead again (0.39 vs 0.42 ms), so the number of keepers -- known after the scan -- decides
     HIP_TRY(read_back(kept, counts.as<uint64_t>() + nchunks, sizeof(uint64_t)));
-    if (((uintptr_t)pred.stencil & 15) == 0 && chunk % 16 == 0 && width != 0 && *kept * 3 < (uint64_t)n && !getenv("GDF_FL_NO_VEC")) {
+    if (((uintptr_t)pred.stencil & 15) == 0 && chunk % 16 == 0 && width != 0 && *kept * 3 < (uint64_t)n && !lab::knob_on("GDF_FL_NO_VEC")) {
       switch (width) {
         case 1: GDF_LAUNCH("compact_write", stencil_write_kernel<1>, g, b, 0, stream0(), pred.stencil, pred.valid, n, chunk, counts.as<uint64_t>(), in, out); break;
         case 2: GDF_LAUNCH("compact_write", stencil_write_kernel<2>, g, b, 0, stream0(), pred.stencil, pred.valid, n, chunk, counts.as<uint64_t>(), in, out); break;

@@ -1054,7 +1054,7 @@ static gdf_error gb_plan_range(const KeyTable &t, GbKeyPlan *plan, std::vector<l
   for (int c = 0; c < t.ncols; ++c) any_float = any_float || t.col[c].kind == K_F32 || t.col[c].kind == K_F64;
   std::vector<long long> h(2 * t.ncols);
   if (any_float) {
-    if (getenv("GDF_GB_NO_FLOAT_IMAGE") || t.nrows == 0) return GDF_SUCCESS;
+    if (lab::path_on("GDF_GB_NO_FLOAT_IMAGE") || t.nrows == 0) return GDF_SUCCESS;
     for (int c = 0; c < t.ncols; ++c) { h[2 * c] = 0x7fffffffffffffffLL; h[2 * c + 1] = (long long)0x8000000000000000ULL; }
     DevBuf mm;
     RMM_TRY(mm.alloc(sizeof(long long) * 2 * t.ncols + sizeof(unsigned int)));
@@ -2142,11 +2142,11 @@ static gdf_error gb_path_direct(GbJob &j, bool *done) {
   [[maybe_unused]] DevBuf &agg_ok = j.agg_ok;
   bool all_int = true;
   for (int c = 0; c < ncols; ++c) all_int = all_int && t.col[c].kind != K_F32 && t.col[c].kind != K_F64;
-  if (all_int && !masked && n >= 4096 && !getenv("GDF_GB_NO_DIRECT")) {
+  if (all_int && !masked && n >= 4096 && !lab::path_on("GDF_GB_NO_DIRECT")) {
     // The exact ranges cost a pass over the keys (0.25 of C2's 0.66 ms).  With ONE key column the window is first
     // guessed from a 65536-row prefix and widened to the whole id space; a row outside it raises a flag and the
     // attempt is repeated with the exact range.
-    const bool guess_first = ncols == 1 && n > (1 << 20) && !getenv("GDF_GB_NO_GUESS");
+    const bool guess_first = ncols == 1 && n > (1 << 20) && !lab::knob_on("GDF_GB_NO_GUESS");
     for (int attempt = guess_first ? 0 : 1; attempt < 2; ++attempt) {
       std::vector<long long> h(2 * ncols);
       KeyTable tr = t;
@@ -2248,10 +2248,10 @@ static gdf_error gb_path_dense(GbJob &j, bool *done) {
   // locality and LOST -- C2's sparse twin, dict build + aggregate: 2^15 0.82 + 0.92 ms, 2^16 0.70 + 0.84, 2^17 0.64 + 0.80,
   // 2^18 0.61 + 0.77 -- a key that is not in its home slot costs a dependent walk, which matters more than the footprint.
   // GDF_GB_DICT_BITS: experiment switch.
-  static const int dict_bits = getenv("GDF_GB_DICT_BITS") ? atoi(getenv("GDF_GB_DICT_BITS")) : 18;
+  const int dict_bits = (int)lab::knob_int("GDF_GB_DICT_BITS", 18);
   const uint64_t tmax = 1ull << (dict_bits >= 15 && dict_bits <= 20 ? dict_bits : 18);
   uint64_t T = cap_max < tmax ? cap_max : tmax;
-  if (plan.packed && !getenv("GDF_GB_NO_DENSE")) {
+  if (plan.packed && !lab::knob_on("GDF_GB_NO_DENSE")) {
     DevBuf dict, flags, group_slot;
     RMM_TRY(dict.alloc(sizeof(GbDictEntry) * (T + 1)));
     RMM_TRY(flags.alloc(sizeof(unsigned int) * 8));           // [0..2] the dictionary's, [4..7] the LDS dictionary's state (gb_ld_image)
@@ -2280,7 +2280,7 @@ static gdf_error gb_path_dense(GbJob &j, bool *done) {
     DevBuf ids;
     unsigned int *ld_state = flags.as<unsigned int>() + 4;
     bool have_ids = false;
-    const bool try_ld = !masked && n >= ((int64_t)1 << 22) && !getenv("GDF_GB_NO_LDS_DICT");
+    const bool try_ld = !masked && n >= ((int64_t)1 << 22) && !lab::path_on("GDF_GB_NO_LDS_DICT");
     const int64_t sample = 1 << 16;      // a quarter of the table's slots: the prefix cannot crowd it
     if (try_ld) {
       // sample -> number -> image -> encode, ONE read-back at the end: the kernels take the group count from the device and
@@ -2431,7 +2431,7 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
   // FUSED: one partition pass straight from the raw columns (gbp_count / gbp_scatter) instead of pair build + radix sort
   bool fused = false;
   if constexpr (sizeof(K) == 4)
-    fused = part_bits >= 1 && part_bits <= GBP_MAX_PART_BITS && n >= ((int64_t)1 << 20) && !getenv("GDF_GB_NO_FUSED");
+    fused = part_bits >= 1 && part_bits <= GBP_MAX_PART_BITS && n >= ((int64_t)1 << 20) && !lab::knob_on("GDF_GB_NO_FUSED");
   if (guessed && !fused) { *done = false; return GDF_SUCCESS; }      // only the fused kernels check keys against a guessed plan
   DevBuf ka, kb, pa, pb, fl;
   if (fused) {
@@ -2456,7 +2456,7 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
       const uint32_t P = 1u << part_bits;
       const int low = vbit + id_bits;
       int max_chunks = GBP_MAX_CHUNKS;
-      if (const char *e = getenv("GDF_GBP_CHUNKS")) max_chunks = atoi(e) > 0 ? atoi(e) : GBP_MAX_CHUNKS;      // experiment switch
+      if (lab::knob_int("GDF_GBP_CHUNKS", 0) > 0) max_chunks = (int)lab::knob_int("GDF_GBP_CHUNKS", 0);      // experiment switch
       int64_t chunk = (n + max_chunks - 1) / max_chunks;
       chunk = (chunk + GBP_TILE - 1) / GBP_TILE * GBP_TILE;
       const int nchunks = (int)((n + chunk - 1) / chunk);
@@ -2467,7 +2467,7 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
       HIP_TRY(hipMemsetAsync(d_flags.p, 0, sizeof(unsigned int) * 2, stream0()));
       HIP_TRY(hipMemsetAsync(hist.as<uint32_t>() + (size_t)P * nchunks, 0, sizeof(uint32_t), stream0()));
       // static key signature (gbp_pack32): one or two 4- / 8-byte integer key columns
-      const bool no_static = getenv("GDF_GBP_DYNAMIC") != nullptr;          // (read per call: the tests flip it)
+      const bool no_static = lab::path_on("GDF_GBP_DYNAMIC");          // (read per call: the tests flip it)
       auto int_kind = [](int k) { return k == K_I32 || k == K_I64; };
       const bool key_sig = !no_static && (t.ncols == 1 || t.ncols == 2) && int_kind(t.col[0].kind) && (t.ncols == 1 || int_kind(t.col[1].kind));
       const int k0 = key_sig ? t.col[0].kind : -1, k1 = !key_sig ? -1 : (t.ncols == 2 ? t.col[1].kind : -2);
@@ -2475,9 +2475,9 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
       // partition (C5: int32 values 0..15 under 2^13 ids) and that has no nulls cannot change a row's partition or drop the row:
       // the count does not read it (8 instead of 12 B per row on C5) and the scatter kernel, which reads every column anyway,
       // checks its values against a guessed range.  Only with the statically typed scatter kernels (they carry that check).
-      const bool val_sig = (val.kind == K_I64 || val.kind == K_F64) && fold_op != OP_COUNT && (!vbit || val.valid) && !getenv("GDF_GBP_OLD");
+      const bool val_sig = (val.kind == K_I64 || val.kind == K_F64) && fold_op != OP_COUNT && (!vbit || val.valid) && !lab::knob_on("GDF_GBP_OLD");
       const bool skip_low = key_sig && val_sig && t.ncols == 2 && !t.col[1].valid && sp.shift[1] + sp.bits[1] + vbit <= low &&
-                            !getenv("GDF_GBP_COUNT_ALL");
+                            !lab::knob_on("GDF_GBP_COUNT_ALL");
       const int ck1 = skip_low ? -2 : k1;
       auto count = [&](auto kernel) {
         GDF_LAUNCH("gbp_count", kernel, dim3(nchunks < NUM_CU * 2 ? nchunks : NUM_CU * 2), dim3(GBP_THREADS), 0, stream0(), t, sp, low, vbit, P,
@@ -2492,7 +2492,7 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
       else count(gbp_count<-1, -1>);
       GDF_TRY(scan_u32(hist.as<uint32_t>(), hist.as<uint32_t>(), (size_t)P * nchunks + 1, false));
       const size_t slds = gbp_scatter_lds();
-      const bool lean = !getenv("GDF_GBP_OLD");              // A/B switch: the scatter kernel with the type switches for every shape
+      const bool lean = !lab::knob_on("GDF_GBP_OLD");              // A/B switch: the scatter kernel with the type switches for every shape
       const bool sig = lean && key_sig && val_sig;
       const dim3 sgrid(nchunks < NUM_CU ? nchunks : NUM_CU);
       if (sig) {
@@ -2640,7 +2640,7 @@ static gdf_error gb_path_sorted(GbJob &j, bool *done) {
   [[maybe_unused]] const GbVal &val = j.val;
   [[maybe_unused]] const bool masked = j.masked, avg = j.counted, want_ok = j.want_ok;
   [[maybe_unused]] DevBuf &agg_ok = j.agg_ok;
-  if (plan.packed && !getenv("GDF_GB_NO_SORTED")) {
+  if (plan.packed && !lab::path_on("GDF_GB_NO_SORTED")) {
     GbKeyPlan sp = plan;
     if (!sp.ordered) GDF_TRY(gb_plan_range(t, &sp));          // fewer key bits = fewer radix passes, and sorted output for free
     const int vbit = (val.valid != nullptr && op != OP_COUNT) ? 1 : 0;
@@ -2648,8 +2648,8 @@ static gdf_error gb_path_sorted(GbJob &j, bool *done) {
     // partitioned variant: sort the high key bits only, index LDS accumulators with the low ones
     {
       const int id_bits = sp.total_bits < GB_PART_ID_BITS ? sp.total_bits : GB_PART_ID_BITS;
-      if (sp.ordered && sp.total_bits - id_bits <= GB_PART_MAX_BITS && !getenv("GDF_GB_NO_PART")) {
-        if (sp.total_bits + vbit + null_bit <= 32 && !getenv("GDF_GB_NO_K32")) return gb_sorted_partitioned<uint32_t>(j, sp, vbit, null_bit, done);
+      if (sp.ordered && sp.total_bits - id_bits <= GB_PART_MAX_BITS && !lab::path_on("GDF_GB_NO_PART")) {
+        if (sp.total_bits + vbit + null_bit <= 32 && !lab::knob_on("GDF_GB_NO_K32")) return gb_sorted_partitioned<uint32_t>(j, sp, vbit, null_bit, done);
         return gb_sorted_partitioned<uint64_t>(j, sp, vbit, null_bit, done);
       }
     }
@@ -2847,7 +2847,7 @@ static gdf_error group_by_hash(int ncols, gdf_column **cols, gdf_column *col_agg
   j.plan = gb_plan_keys(t);
   GbKeyPlan guess_plan{};
   bool guess_plan_ok = false;
-  if (!j.plan.packed && n >= ((int64_t)1 << 24) && !getenv("GDF_GB_NO_GUESS_RANGES")) {
+  if (!j.plan.packed && n >= ((int64_t)1 << 24) && !lab::knob_on("GDF_GB_NO_GUESS_RANGES")) {
     GDF_TRY(gb_plan_range_sampled(t, &guess_plan, &guess_plan_ok));
     const int vb = (col_agg->valid != nullptr && op != OP_COUNT) ? 1 : 0, nb = t.any_valid ? 1 : 0;
     guess_plan_ok = guess_plan_ok && guess_plan.total_bits >= 18 && guess_plan.total_bits - GB_PART_ID_BITS <= GBP_MAX_PART_BITS &&

@@ -709,7 +709,7 @@ __global__ __launch_bounds__(HP_THREADS) void fnv_rows_kernel(FnvCols c, unsigne
 // P=1 0.47 vs 0.84 ms, P=2 0.43 vs 0.52, P=4 0.47 vs 0.37, P=8 0.51 vs 0.36 -- from 4 partitions on the ballots cost
 // more than the conflicts; the scatter pass does not care either way.  -1 = per-lane atomics.
 static int partition_agg_bits(uint32_t P) {
-  if (P > 2 || getenv("GDF_HP_NO_AGG")) return -1;
+  if (P > 2 || lab::knob_on("GDF_HP_NO_AGG")) return -1;
   int bits = 0;
   while ((1u << bits) < P) ++bits;
   return bits;
@@ -845,7 +845,7 @@ gdf_error gdf_amd_shuffle_partition(gdf_column *keys, int narrow, int64_t lo, in
              (KOUT *)out_keys->data, (int32_t *)out_rows->data);                                                                     \
   HIP_CHECK_LAST();
   // 4-byte output keys and a fan-out of at most 64: the LDS-regrouped scatter (see shuffle_scatter_tile_kernel)
-  const bool tile_scatter = (narrow || win == 4) && P <= (uint32_t)SHT_MAX_PARTS && !getenv("GDF_HP_NO_SHUFFLE_TILE");
+  const bool tile_scatter = (narrow || win == 4) && P <= (uint32_t)SHT_MAX_PARTS && !lab::knob_on("GDF_HP_NO_SHUFFLE_TILE");
   int tile_bits = 0;
   while ((1u << tile_bits) < P) ++tile_bits;
 #define SHUFFLE_TILE_PASSES(KIN)                                                                                                    \
@@ -972,7 +972,7 @@ gdf_error gdf_hash_partition(int num_input_cols, gdf_column *input[], int column
   RMM_TRY(starts.alloc(sizeof(uint32_t) * P));
   const bool murmur = hash == GDF_HASH_MURMUR3;
   const int agg_bits = partition_agg_bits(P);
-  const int fastw = (murmur && t.ncols == 1 && (t.col[0].width == 8 || t.col[0].width == 4) && !getenv("GDF_HP_NO_FAST")) ? t.col[0].width : 0;
+  const int fastw = (murmur && t.ncols == 1 && (t.col[0].width == 8 || t.col[0].width == 4) && !lab::knob_on("GDF_HP_NO_FAST")) ? t.col[0].width : 0;
   if (fastw == 8)
     GDF_LAUNCH("part_hist", part_hist_fast_kernel<uint64_t>, dim3(grid), dim3(HP_THREADS), lds, stream0(), (const uint64_t *)t.col[0].data, n, chunk,
                nchunks, P, pow2mask, agg_bits, hist.as<uint32_t>());
@@ -1017,7 +1017,7 @@ gdf_error gdf_hash_partition(int num_input_cols, gdf_column *input[], int column
     pc.dst_map = dst_map.as<uint32_t>();
     if (first > 0)
       hipLaunchKernelGGL(part_apply_map_kernel, dim3(stream_grid(num_rows, HP_THREADS * 4)), dim3(HP_THREADS), 0, stream0(), pc, n);
-    else if (P > 16 && P <= (uint32_t)HPT_BIG_PARTS && !getenv("GDF_HP_NO_TILE")) {
+    else if (P > 16 && P <= (uint32_t)HPT_BIG_PARTS && !lab::knob_on("GDF_HP_NO_TILE")) {
       // measured at 1e8 rows x 2 int64 columns: P=256 1.47 ms vs 2.83 ms direct; at P=8 the direct kernel's runs are
       // long enough already (1.10 vs 1.19 ms), so small fan-outs keep it
 #define HPT_LAUNCH(MUR, FW, TH, MAXP, FI)                                                                                              \
@@ -1030,7 +1030,7 @@ gdf_error gdf_hash_partition(int num_input_cols, gdf_column *input[], int column
       // 12288-row tiles of a 1024-thread workgroup win over 4096-row tiles of 256 threads at EVERY fan-out they share (1e8 rows x
       // 2 int64 columns, scatter kernel: P = 64 0.73 vs 0.88 ms, P = 256 0.82 vs 1.07 ms): three times the run length.  The small
       // shape stays behind GDF_HP_BIG_FROM=256
-      static const uint32_t big_from = getenv("GDF_HP_BIG_FROM") ? (uint32_t)atoi(getenv("GDF_HP_BIG_FROM")) : 16u;
+      const uint32_t big_from = (uint32_t)lab::knob_int("GDF_HP_BIG_FROM", 16);
       if (P <= big_from && P <= (uint32_t)HPT_MAX_PARTS) {
         if (fastw == 8) HPT_LAUNCH(true, 8, 256, 256, 16);
         else if (fastw == 4) HPT_LAUNCH(true, 4, 256, 256, 16);

@@ -3,6 +3,7 @@
 // the extern "C" ABI of include/gdf/gdf.h is marked default).
 #pragma once
 #include "common.h"
+#include "lab.h"
 #include "prof.h"
 
 namespace gdf_amd {

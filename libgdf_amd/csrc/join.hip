@@ -530,9 +530,9 @@ __device__ __forceinline__ void tile_flush(TileLds<NARROW, THREADS> &s, const Pa
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      if (g.dbg & 4) dst[u] &= 0xffffu;        // experiment: all stores land in a 512 KiB window
-      if (j0 + u * THREADS < total && !(g.dbg & 1)) {
-        if (g.dbg & 16) __builtin_nontemporal_store(ww[u], out.w + dst[u]);      // experiment: streaming stores (level 2)
+      if (LAB_BITS(g.dbg) & 4) dst[u] &= 0xffffu;        // experiment: all stores land in a 512 KiB window
+      if (j0 + u * THREADS < total && !(LAB_BITS(g.dbg) & 1)) {
+        if (LAB_BITS(g.dbg) & 16) __builtin_nontemporal_store(ww[u], out.w + dst[u]);      // experiment: streaming stores (level 2)
         else out.w[dst[u]] = ww[u];
         if (!NARROW) out.idx[dst[u]] = ii[u];
       }
@@ -691,9 +691,9 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
       for (int k = 0; k < GROUP; ++k) {
         const uint32_t j = ftid + (h * GROUP + k) * THREADS;
         uint32_t dst = j < total ? gb[k] + j : g.dump + ftid;
-        if (g.dbg & 4) dst &= 0xffffu;           // experiment: all stores land in a 512 KiB window
-        if (g.dbg & 1) dst = g.dump + ftid;      // experiment: no useful stores
-        if (g.dbg & 8) __builtin_nontemporal_store(ww[k], out.w + dst);      // experiment: streaming stores (level 1)
+        if (LAB_BITS(g.dbg) & 4) dst &= 0xffffu;           // experiment: all stores land in a 512 KiB window
+        if (LAB_BITS(g.dbg) & 1) dst = g.dump + ftid;      // experiment: no useful stores
+        if (LAB_BITS(g.dbg) & 8) __builtin_nontemporal_store(ww[k], out.w + dst);      // experiment: streaming stores (level 1)
         else out.w[dst] = ww[k];
         if (!NARROW) out.idx[dst] = ii[k];
       }
@@ -1026,7 +1026,7 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
     if (moves == JK_CUCKOO_MAX_MOVES) *l.cuckoo_failed = 1;   // `cur` is homeless: rebuild below
   }
   block_sync();
-  const bool cuckoo = *l.cuckoo_failed == 0 && !(a.dbg & 8);
+  const bool cuckoo = *l.cuckoo_failed == 0 && !(LAB_BITS(a.dbg) & 8);
   if (!cuckoo && !WRITE && a.opt_state && threadIdx.x == 0) atomicAdd(&a.opt_state[3], 1ull);   // sample pass: units with repeated build keys
   if (!cuckoo) {
     // ---- multimap rebuild over the same 2*H slots: open addressing over the DISTINCT keys, every key's tuples chained
@@ -1055,7 +1055,7 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
     block_sync();
   }
 
-  if (a.dbg & 128) return;      // experiment: build phase only
+  if (LAB_BITS(a.dbg) & 128) return;      // experiment: build phase only
   // optimistic pass: the unit owns exactly probe_count output slots starting at its offset
   const unsigned long long unit_base = WRITE ? a.counts[uid] : 0ull;
   const unsigned long long unit_end = (WRITE && a.optimistic) ? unit_base + u.probe_count : ~0ull;
@@ -1102,7 +1102,7 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
         const uint64_t raw = k[b] + a.kbias;
         pa[b] = l.T[hash_a(raw) & (H - 1)];
         pb[b] = l.T[H + (hash_b(raw) & (H - 1))];
-        if (a.dbg & 64) { pa[b] = (uint32_t)k[b] & 1023u; pb[b] = JK_NOPOS; }      // experiment: no table lookups
+        if (LAB_BITS(a.dbg) & 64) { pa[b] = (uint32_t)k[b] & 1023u; pb[b] = JK_NOPOS; }      // experiment: no table lookups
       }
       uint64_t ka[NB], kb[NB];
 #pragma unroll
@@ -1183,7 +1183,7 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
           a.out_probe[pos] = prow[b];
           a.out_build[pos] = JK_EMPTY;
         } else if (c >= 1 && (cuckoo || c == 1)) {
-          if (a.dbg & 32) continue;                  // experiment: no output stores
+          if (LAB_BITS(a.dbg) & 32) continue;                  // experiment: no output stores
           a.out_probe[pos] = prow[b];
           a.out_build[pos] = build_row<NARROW>(l, hit_a[b]);
           if (c == 2) {
@@ -1305,7 +1305,7 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_fast(ProbeArgs a) {
     seed += 0x9e3779b9u;
     block_sync();
   }
-  if (*l.cuckoo_failed || (a.dbg & 8)) {
+  if (*l.cuckoo_failed | (unsigned)(LAB_BITS(a.dbg) & 8)) {
     if (threadIdx.x == 0) a.unit_todo[atomicAdd(&a.opt_state[2], 1ull)] = blockIdx.x;
     return;
   }
@@ -1365,7 +1365,7 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_fast(ProbeArgs a) {
     auto emit = [&](int b, uint32_t pos, uint32_t c) {
       const bool ha = (hamask >> b) & 1u, hb = (hbmask >> b) & 1u, pad = (padmask >> b) & 1u;
       if (pos + c > unit_cap) a.opt_state[1] = 1;   // would spill into the next unit's slots: the host redoes the join two-pass
-      else if (!(a.dbg & 32)) {
+      else if (!(LAB_BITS(a.dbg) & 32)) {
         // build row of a hit: NARROW carries it in the low half of the staged word, WIDE reads it from the staged row numbers
         int32_t ra, rb;
         if constexpr (NARROW) { ra = (int32_t)(uint32_t)wa[b]; rb = (int32_t)(uint32_t)wb[b]; }
@@ -1375,7 +1375,7 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_fast(ProbeArgs a) {
         if (c == 2) { op[pos + 1] = (int32_t)prow[b]; ob[pos + 1] = rb; }
       }
     };
-    if (__all((hamask & hbmask) == 0) && !(a.dbg & 2048)) {      // (GDF_JK_DBG=2048: one claim per tuple, as before)
+    if (__all((hamask & hbmask) == 0) && !(LAB_BITS(a.dbg) & 2048)) {      // (GDF_JK_DBG=2048: one claim per tuple, as before)
       // nobody has two pairs for one tuple (no key sits in both tables: the usual case).  ONE claim per wave and batch: the NB
       // ballots give every tuple its offset inside the wave's range, lane 0 claims the sum, and the base comes back through
       // readfirstlane -- per tuple a claim + a bpermute were two LDS round trips, sixteen per batch, on the critical path of a
@@ -1675,20 +1675,20 @@ struct SideBufs {            // partitioned tuples of one relation
 
 static PartGeom choose_geometry(int64_t build_rows) {
   PartGeom g{};
-  g.dbg = getenv("GDF_JK_SDBG") ? atoi(getenv("GDF_JK_SDBG")) : 0;
+  g.dbg = (int)lab::knob_int("GDF_JK_SDBG", 0);
   int fb = 0;
   while (fb < JK_MAX_FB && (build_rows >> fb) > JK_TARGET_BUILD) ++fb;
   // never fewer than 32 partitions: with one or a few, every tuple of a tile ranks on the same LDS counter and the
   // probe side has to take the histogram pass (5e8 x 3000 rows: 8.0 ms with one partition, see the notes in profiles/)
-  if (fb < 5 && !getenv("GDF_JK_ALLOW_FEW_PARTS")) fb = 5;
+  if (fb < 5 && !lab::knob_on("GDF_JK_ALLOW_FEW_PARTS")) fb = 5;
   g.fb = fb;
   g.b1 = fb <= 8 ? fb : (fb + 1) / 2;
-  if (getenv("GDF_JK_B1") && fb > 8) { const int b1 = atoi(getenv("GDF_JK_B1")); if (b1 >= fb - 8 && b1 <= 8) g.b1 = b1; }   // experiment switch
+  if (lab::knob_on("GDF_JK_B1") && fb > 8) { const int b1 = (int)lab::knob_int("GDF_JK_B1", 0); if (b1 >= fb - 8 && b1 <= 8) g.b1 = b1; }   // experiment switch
   g.b2 = fb - g.b1;
   // more rows than 2^15 LDS-sized partitions hold: a third level (at most 256-way), decided here, applied by refine_side
   g.b3 = 0;
   // (only when the 2^15 partitions would not fit LDS with some room for their spread: C4's 1.25e8-row shards stay two-level)
-  if (fb == JK_MAX_FB && !getenv("GDF_JK_NO_LEVEL3"))
+  if (fb == JK_MAX_FB && !lab::path_on("GDF_JK_NO_LEVEL3"))
     while (g.b3 < 8 && (build_rows >> (fb + g.b3)) > JK_MAX_BUILD - JK_MAX_BUILD / 5) ++g.b3;
   return g;
 }
@@ -1729,7 +1729,7 @@ static gdf_error launch_scatter2_t(uint32_t ntiles, const PartGeom &g, Level2Map
   const size_t lds = sizeof(TileLds<NARROW, THREADS>);
   HIP_TRY(hipFuncSetAttribute((const void *)jk_scatter2<NARROW, THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   m.ntiles = ntiles;
-  m.xcd_order = (ntiles >= 64 && !getenv("GDF_JK_NO_XCD_ORDER")) ? 1 : 0;
+  m.xcd_order = (ntiles >= 64 && !lab::path_on("GDF_JK_NO_XCD_ORDER")) ? 1 : 0;
   const uint32_t grid = m.xcd_order ? ((ntiles + 7) / 8) * 8 : ntiles;
   GDF_LAUNCH("jk_scatter2", (jk_scatter2<NARROW, THREADS>), dim3(grid), dim3(THREADS), lds, stream0(), g, m, in, cursor, out);
   HIP_CHECK_LAST();
@@ -1754,7 +1754,7 @@ static gdf_error launch_scatter2(bool narrow, int threads, uint32_t ntiles, cons
 // Measured on C3, jk_scatter2 with 1024 / 512 / 256 threads: 3.6 / 3.3 / 3.2 ms.  Level 1 goes the other way
 // (3.7 vs 4.2 ms with 512 threads): its claims sit in a tile loop, it keeps one big tile per CU.
 static int level2_threads(int sc_threads) {
-  static const int env = getenv("GDF_JK_SC2_THREADS") ? atoi(getenv("GDF_JK_SC2_THREADS")) : 0;
+  const int env = (int)lab::knob_int("GDF_JK_SC2_THREADS", 0);
   if (env == 256 || env == 512 || env == 1024) return env < sc_threads ? env : sc_threads;
   return sc_threads > 256 ? 256 : sc_threads;
 }
@@ -1765,7 +1765,7 @@ static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, Si
   // Chunks are SMALL (a few tiles) and processed in blockIdx order, so that the workgroups resident at
   // any moment write into a narrow window of every partition's output range: with a few thousand
   // 2 MiB pages live the scatter ran ~1.5x slower per row at 1e9 rows than at 5e8 (TLB reach).
-  static const int64_t chunk_rows_env = getenv("GDF_JK_CHUNK_ROWS") ? atoll(getenv("GDF_JK_CHUNK_ROWS")) : 0;
+  const int64_t chunk_rows_env = lab::knob_int("GDF_JK_CHUNK_ROWS", 0);
   int64_t chunk = chunk_rows_env ? chunk_rows_env : JK_CHUNK_ROWS;
   if (n / chunk > JK_MAX_CHUNKS) chunk = (n + JK_MAX_CHUNKS - 1) / JK_MAX_CHUNKS;
   constexpr int64_t MAX_TILE = 1024 * JK_SC_ITEMS;      // chunks are whole tiles for every tile size in use
@@ -1788,7 +1788,7 @@ static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, Si
   const int hist_grid = g.nchunks < NUM_CU ? g.nchunks : NUM_CU;
   DevBuf mm;
   long long *d_mm = nullptr;
-  if (decide_narrow && !getenv("GDF_JK_WIDE")) {       // GDF_JK_WIDE: experiment switch, force 12-byte tuples
+  if (decide_narrow && !lab::knob_on("GDF_JK_WIDE")) {       // GDF_JK_WIDE: experiment switch, force 12-byte tuples
     RMM_TRY(mm.alloc(sizeof(long long) * 2));
     const long long init[2] = {LLONG_MAX, LLONG_MIN};
     HIP_TRY(hipMemcpyAsync(mm.p, init, sizeof(init), hipMemcpyHostToDevice, stream0()));
@@ -1827,7 +1827,7 @@ static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, Si
   g.kbias = plan.kmin;
   // scatter tile: THREADS * 16 tuples regrouped in LDS per step.  Bigger tiles mean longer runs per
   // (tile, bin) -- DRAM-friendlier writes -- at the price of fewer resident workgroups.
-  static const int sc_threads_env = getenv("GDF_JK_SC_THREADS") ? atoi(getenv("GDF_JK_SC_THREADS")) : 0;
+  const int sc_threads_env = (int)lab::knob_int("GDF_JK_SC_THREADS", 0);
   int sc_threads = sc_threads_env ? sc_threads_env : (narrow ? 1024 : 512);   // swept on C3: profiles/r1_c_sweeps.md
   if (sc_threads != 256 && sc_threads != 512 && sc_threads != 1024) sc_threads = 256;
   if (!narrow && sc_threads == 1024) sc_threads = 512;       // 16384 x 12 B would not fit 160 KiB
@@ -1894,7 +1894,7 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
   if (app) g.row_base = (int32_t)app->rows;
   const int64_t n = t.nrows;
   const bool narrow = plan.narrow != 0;
-  static const int64_t chunk_rows_env = getenv("GDF_JK_CHUNK_ROWS") ? atoll(getenv("GDF_JK_CHUNK_ROWS")) : 0;
+  const int64_t chunk_rows_env = lab::knob_int("GDF_JK_CHUNK_ROWS", 0);
   int64_t chunk = chunk_rows_env ? chunk_rows_env : JK_CHUNK_ROWS;
   if (n / chunk > JK_MAX_CHUNKS) chunk = (n + JK_MAX_CHUNKS - 1) / JK_MAX_CHUNKS;
   constexpr int64_t MAX_TILE = 1024 * JK_SC_ITEMS;
@@ -1904,7 +1904,7 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
   if (g.nchunks == 0) g.nchunks = 1;
   const uint32_t nfine = 1u << g.fb, ncoarse = 1u << g.b1;
   const int fast = fast_key_width(t, plan);
-  static const int sc_threads_env = getenv("GDF_JK_SC_THREADS") ? atoi(getenv("GDF_JK_SC_THREADS")) : 0;
+  const int sc_threads_env = (int)lab::knob_int("GDF_JK_SC_THREADS", 0);
   int sc_threads = sc_threads_env ? sc_threads_env : (narrow ? 1024 : 512);
   if (sc_threads != 256 && sc_threads != 512 && sc_threads != 1024) sc_threads = 256;
   if (!narrow && sc_threads == 1024) sc_threads = 512;
@@ -1917,7 +1917,7 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
   };
   // one region per (coarse partition, XCD) when a second level follows (PartGeom::xs); a single level needs its
   // partitions contiguous for the probe units
-  g.xs = (g.b2 > 0 && n >= ((int64_t)1 << 26) && !getenv("GDF_JK_NO_XCD_SPLIT")) ? 3 : 0;
+  g.xs = (g.b2 > 0 && n >= ((int64_t)1 << 26) && !lab::path_on("GDF_JK_NO_XCD_SPLIT")) ? 3 : 0;
   const uint32_t nseg = ncoarse << g.xs;
   const uint32_t cap1 = room((double)n / nseg, 64), cap2 = app ? app->cap2 : (g.b2 ? room((double)n / nfine, 8) : 0);
   const uint64_t size1 = (uint64_t)nseg * cap1 + JK_TILE, size2 = (uint64_t)nfine * cap2 + JK_TILE;
@@ -2087,7 +2087,7 @@ static gdf_error run_probe(bool narrow, bool write, const char *name, size_t nun
 static gdf_error run_write_pass(bool narrow, bool plain, size_t nunits, size_t lds, ProbeArgs a, uint32_t max_build,
                                 const KeyTable &probe_t, const KeyTable &build_t) {
   if (!nunits) return GDF_SUCCESS;
-  if (!plain || getenv("GDF_JK_NO_FAST") || (!narrow && getenv("GDF_JK_NO_FAST_WIDE")))
+  if (!plain || lab::knob_on("GDF_JK_NO_FAST") || (!narrow && lab::knob_on("GDF_JK_NO_FAST_WIDE")))
     return run_probe(narrow, true, "jk_probe_write", nunits, lds, a, probe_t, build_t);
   DevBuf todo;
   RMM_TRY(todo.alloc(sizeof(uint32_t) * nunits));
@@ -2123,7 +2123,7 @@ static gdf_error run_write_pass(bool narrow, bool plain, size_t nunits, size_t l
   HIP_CHECK_LAST();
   unsigned long long left = 0;
   HIP_TRY(read_back(&left, a.opt_state + 2, sizeof(left)));
-  if (a.dbg & 256) fprintf(stderr, "jk_probe_fast: %llu of %zu units left to the general kernel\n", left, nunits);
+  if (LAB_BITS(a.dbg) & 256) fprintf(stderr, "jk_probe_fast: %llu of %zu units left to the general kernel\n", left, nunits);
   if (left) GDF_TRY(run_probe(narrow, true, "jk_probe_write_general", (size_t)left, lds, a, probe_t, build_t));
   HIP_TRY(hipStreamSynchronize(stream0()));      // `todo` goes out of scope
   return GDF_SUCCESS;
@@ -2226,7 +2226,7 @@ struct BuildSide {
 // path reads both relations' rows at random and ran 8x slower on an (int64, int32) key), and when the fields fit 32
 // bits the join takes the NARROW tuples and the lean probe kernel of the single-column case.
 static gdf_error plan_ranged(const KeyTable &build_t, KeyPlan *plan) {
-  if (build_t.ncols < 2 || (plan->mode != KM_HASHED && plan->mode != KM_PACKED) || getenv("GDF_JK_NO_RANGED")) return GDF_SUCCESS;
+  if (build_t.ncols < 2 || (plan->mode != KM_HASHED && plan->mode != KM_PACKED) || lab::path_on("GDF_JK_NO_RANGED")) return GDF_SUCCESS;
   for (int c = 0; c < build_t.ncols; ++c)
     if (build_t.col[c].kind == K_F32 || build_t.col[c].kind == K_F64) return GDF_SUCCESS;
   std::vector<long long> h(2 * build_t.ncols);
@@ -2302,12 +2302,12 @@ static gdf_error probe_prepared(const KeyTable &probe_t, const KeyTable &build_t
   // when the build partitions all fit LDS (the global-table path wants contiguous partition runs).
   uint32_t largest_build = 0;
   for (uint32_t c : B.fine_cnt) largest_build = std::max(largest_build, c);
-  const int64_t spec_min = getenv("GDF_JK_SPEC_MIN") ? atoll(getenv("GDF_JK_SPEC_MIN")) : (int64_t)1 << 22;   // test switch
+  const int64_t spec_min = lab::path_int("GDF_JK_SPEC_MIN", (int64_t)1 << 22);   // test switch
   bool spec_ok = false;
   // skewed probe keys would overflow the speculative layout: ask a sample first (one small kernel and a 4-byte read-back)
   bool skew = false;
   const int probe_fast = fast_key_width(probe_t, plan);
-  if (g.fb >= 10 && probe_t.nrows >= ((int64_t)1 << 24) && probe_fast && plan.mode == KM_RAW_INT && !getenv("GDF_JK_NO_SKEW_SAMPLE")) {
+  if (g.fb >= 10 && probe_t.nrows >= ((int64_t)1 << 24) && probe_fast && plan.mode == KM_RAW_INT && !lab::knob_on("GDF_JK_NO_SKEW_SAMPLE")) {
     DevBuf sh;
     const size_t words = ((size_t)1 << g.fb) + 1;
     RMM_TRY(sh.alloc(sizeof(uint32_t) * words));
@@ -2327,8 +2327,8 @@ static gdf_error probe_prepared(const KeyTable &probe_t, const KeyTable &build_t
   }
   // the main path -- two-level speculative probe side, every build partition in LDS, no FULL-join marks -- keeps its
   // bookkeeping on the device (see jk_make_units)
-  const bool defer = g.b2 > 0 && g.b3 == 0 && kind != JOIN_FULL && B.d_cnt.p != nullptr && !getenv("GDF_JK_NO_DEFER");
-  if (!skew && g.fb > 0 && probe_t.nrows >= spec_min && largest_build <= (uint32_t)JK_MAX_BUILD && !getenv("GDF_JK_NO_SPEC"))
+  const bool defer = g.b2 > 0 && g.b3 == 0 && kind != JOIN_FULL && B.d_cnt.p != nullptr && !lab::knob_on("GDF_JK_NO_DEFER");
+  if (!skew && g.fb > 0 && probe_t.nrows >= spec_min && largest_build <= (uint32_t)JK_MAX_BUILD && !lab::path_on("GDF_JK_NO_SPEC"))
     GDF_TRY(partition_side_spec(probe_t, plan, g, std::max(1.0, (double)probe_t.nrows / std::max<uint32_t>(B.joinable, 1)), &P, &spec_ok,
                                 nullptr, defer));
   if (!spec_ok) {
@@ -2427,7 +2427,7 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
   a.keep_unmatched_probe = keep_probe ? 1 : 0;
   a.verify = plan.verify;
   a.build_matched = d_matched.as<uint8_t>();
-  a.dbg = getenv("GDF_JK_DBG") ? atoi(getenv("GDF_JK_DBG")) : 0;
+  a.dbg = (int)lab::knob_int("GDF_JK_DBG", 0);
   a.kbias = plan.kmin;
   const size_t probe_lds = probe_lds_bytes(narrow, cap_lds, H_lds);
   const bool plain = kind != JOIN_FULL && !plan.verify;       // INNER and LEFT with exact keys: see jk_probe_fast
@@ -2453,7 +2453,7 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
     sa.sample_n = (uint32_t)NSAMPLE;
     sa.nunits_dev = d_bk.as<unsigned long long>();
     sa.opt_state = d_bk.as<unsigned long long>() + 4;
-    if (!(a.dbg & 16)) GDF_TRY(run_probe(narrow, false, "jk_probe_sample", NSAMPLE, probe_lds, sa, probe_t, build_t));
+    if (!(LAB_BITS(a.dbg) & 16)) GDF_TRY(run_probe(narrow, false, "jk_probe_sample", NSAMPLE, probe_lds, sa, probe_t, build_t));
     HIP_TRY(read_back(bk, d_bk.p, sizeof(bk)));
     P.w[0].reset();                        // level-1 tuples and the segment map: everything that read them has run
     P.idx[0].reset();
@@ -2463,10 +2463,10 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
     cap_pairs = bk[1];
     P.joinable = (uint32_t)bk[2];
     dup_heavy = bk[7] * 4 >= NSAMPLE;
-    try_optimistic = nunits && !(a.dbg & 16) && bk[4] == bk[5];
+    try_optimistic = nunits && !(LAB_BITS(a.dbg) & 16) && bk[4] == bk[5];
     sample_hit = bk[5] ? (double)bk[4] / (double)bk[5] : 1.0;
     clk.mark("sample count");
-  } else if (nunits && oversize.empty() && kind != JOIN_FULL && !(a.dbg & 16)) {
+  } else if (nunits && oversize.empty() && kind != JOIN_FULL && !(LAB_BITS(a.dbg) & 16)) {
     const size_t nsample = std::min<size_t>(nunits, NSAMPLE);
     std::vector<Unit> sample(nsample);
     uint64_t sample_tuples = 0;
@@ -2508,8 +2508,8 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
   // against 2.3 ms of count pass, minus 8 GB of temporary pair slots), so the switch sat at 45 %; with the lean write kernel's
   // single claim per batch the single pass + compaction wins at 50 % (12.05 against 12.5 ms, tools/gpu/r2bp) and breaks even near
   // 57 %: the switch sits at 55 % (GDF_JK_SPARSE_MAX overrides it).
-  const bool try_sparse = !try_optimistic && d_off.p && nunits && oversize.empty() && kind == JOIN_INNER && !dup_heavy && !(a.dbg & 16) &&
-                          sample_hit < (getenv("GDF_JK_SPARSE_MAX") ? atof(getenv("GDF_JK_SPARSE_MAX")) : 0.55) && !getenv("GDF_JK_NO_SPARSE_OPT");
+  const bool try_sparse = !try_optimistic && d_off.p && nunits && oversize.empty() && kind == JOIN_INNER && !dup_heavy && !(LAB_BITS(a.dbg) & 16) &&
+                          sample_hit < lab::knob_float("GDF_JK_SPARSE_MAX", 0.55) && !lab::path_on("GDF_JK_NO_SPARSE_OPT");
   if (try_optimistic || try_sparse) {
     DevBuf d_state, d_upairs;
     RMM_TRY(d_state.alloc(sizeof(unsigned long long) * 4));
@@ -2683,7 +2683,7 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
 
 static gdf_error hash_join_core(const KeyTable &probe_t, const KeyTable &build_t, JoinKind kind, int32_t **out_probe,
                                 int32_t **out_build, int64_t *out_n) {
-  StageClock clk(getenv("GDF_JK_DBG") && (atoi(getenv("GDF_JK_DBG")) & 512));
+  StageClock clk((lab::knob_int("GDF_JK_DBG", 0) & 512) != 0);
   BuildSide bs;
   GDF_TRY(prepare_build(build_t, &bs));
   clk.mark("partition build side");
@@ -2973,10 +2973,10 @@ gdf_error debug_partition(gdf_column *col, int fb, uint64_t *out_key, int32_t *o
   GDF_TRY(make_key_table(cols, 1, &t));
   KeyPlan plan = plan_keys(t);
   PartGeom g{};
-  g.dbg = getenv("GDF_JK_SDBG") ? atoi(getenv("GDF_JK_SDBG")) : 0;
+  g.dbg = (int)lab::knob_int("GDF_JK_SDBG", 0);
   g.fb = fb;
   g.b1 = fb <= 8 ? fb : (fb + 1) / 2;
-  if (getenv("GDF_JK_B1") && fb > 8) { const int b1 = atoi(getenv("GDF_JK_B1")); if (b1 >= fb - 8 && b1 <= 8) g.b1 = b1; }   // experiment switch
+  if (lab::knob_on("GDF_JK_B1") && fb > 8) { const int b1 = (int)lab::knob_int("GDF_JK_B1", 0); if (b1 >= fb - 8 && b1 <= 8) g.b1 = b1; }   // experiment switch
   g.b2 = fb - g.b1;
   SideBufs sb;
   GDF_TRY(partition_side(t, plan, g, &sb, !plan.narrow && plan.mode == KM_RAW_INT && t.col[0].width == 8));
@@ -3055,7 +3055,7 @@ static gdf_error build_probe(PreparedBuild *pb, int left_join, gdf_column **prob
   GDF_TRY(make_key_table(probe_cols, num_cols, &pt));
   gdf_column_view(probe_indices, nullptr, nullptr, 0, N_GDF_TYPES);
   gdf_column_view(build_indices, nullptr, nullptr, 0, N_GDF_TYPES);
-  StageClock clk(getenv("GDF_JK_DBG") && (atoi(getenv("GDF_JK_DBG")) & 512));
+  StageClock clk((lab::knob_int("GDF_JK_DBG", 0) & 512) != 0);
   int32_t *o_probe = nullptr, *o_build = nullptr;
   int64_t n = 0;
   gdf_error e = probe_prepared(pt, pb->table, pb->side, kind, &o_probe, &o_build, &n, clk);
@@ -3093,7 +3093,7 @@ static gdf_error accum_begin(PreparedBuild *pb, size_t expected_rows, ProbeAccum
   uint32_t largest_build = 0;
   for (uint32_t c : pb->side.B.fine_cnt) largest_build = std::max(largest_build, c);
   if (!pb->partitioned || plan.verify || !plan.narrow || g.b2 == 0 || g.b3 != 0 || largest_build > (uint32_t)JK_MAX_BUILD ||
-      (!pb->fj && (expected_rows < ((size_t)1 << 22) || getenv("GDF_JK_NO_ACCUM"))))
+      (!pb->fj && (expected_rows < ((size_t)1 << 22) || lab::knob_on("GDF_JK_NO_ACCUM"))))
     return GDF_UNSUPPORTED_METHOD;
   std::unique_ptr<ProbeAccum> a(new ProbeAccum());
   a->pb = pb;

@@ -5,9 +5,13 @@
 // src/errorhandling.cpp:5-35, src/cudautils.cu:4-14 and src/nvtx_utils.cpp:19-71
 // (ranges are forwarded to roctx so they show up in rocprofv3 --marker-trace).
 #include "common.h"
+#include "lab.h"
 
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
 #include <roctracer/roctx.h>
 
 namespace gdf_amd {
@@ -56,6 +60,22 @@ hipError_t read_back(void *host_dst, const void *dev_src, size_t bytes) {
   std::memcpy(host_dst, pinned, bytes);
   return hipSuccess;
 }
+
+// lab.h: the registry behind gdf_amd_debug_force.  Empty in every process that never calls the hook, and then one
+// relaxed atomic load per lookup.
+namespace lab {
+namespace {
+std::mutex g_forced_mutex;
+std::map<std::string, std::string> &forced_map() { static std::map<std::string, std::string> m; return m; }
+int g_forced_count = 0;
+}  // namespace
+const char *forced(const char *name) {
+  if (__atomic_load_n(&g_forced_count, __ATOMIC_RELAXED) == 0) return nullptr;
+  std::lock_guard<std::mutex> lock(g_forced_mutex);
+  auto it = forced_map().find(name);
+  return it == forced_map().end() ? nullptr : it->second.c_str();
+}
+}  // namespace lab
 
 }  // namespace gdf_amd
 
@@ -141,3 +161,12 @@ gdf_error gdf_nvtx_range_pop(void) {
 }
 
 }  // extern "C"
+
+extern "C" __attribute__((visibility("default"))) gdf_error gdf_amd_debug_force(const char *name, const char *value) {
+  if (!name) return GDF_INVALID_API_CALL;
+  std::lock_guard<std::mutex> lock(gdf_amd::lab::g_forced_mutex);
+  auto &m = gdf_amd::lab::forced_map();
+  if (value) m[name] = value; else m.erase(name);
+  __atomic_store_n(&gdf_amd::lab::g_forced_count, (int)m.size(), __ATOMIC_RELAXED);
+  return GDF_SUCCESS;
+}

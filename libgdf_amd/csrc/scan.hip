@@ -341,7 +341,7 @@ __global__ __launch_bounds__(LB_THREADS) void scan_lookback(const ELEM *in, ELEM
     }
     ACC exclusive = 0;
     long long nearest = (long long)sc.tile - 1;
-    for (; !(dbg & 2);) {           // dbg & 2 (experiment): no look-back, wrong prefixes
+    for (; !(LAB_BITS(dbg) & 2);) {           // dbg & 2 (experiment): no look-back, wrong prefixes
       const long long p = nearest - (long long)threadIdx.x;
       int st = 2;
       ACC val = 0;
@@ -448,8 +448,7 @@ template <class ACC, class ELEM>
 static gdf_error device_scan_lookback(const ELEM *in, ELEM *out, size_t n, bool inclusive) {
   constexpr int NW = sizeof(ACC) / 4;
   const size_t ntiles = (n + LB_TILE - 1) / LB_TILE;
-  static const int dbg = (getenv("GDF_SCAN_DBG") ? atoi(getenv("GDF_SCAN_DBG")) : 0) |
-                         (getenv("GDF_SCAN_LOOKBACK") && atoi(getenv("GDF_SCAN_LOOKBACK")) == 2 ? 4 : 0);      // 2: spine mode
+  const int dbg = (int)lab::knob_int("GDF_SCAN_DBG", 0) | (lab::path_int("GDF_SCAN_LOOKBACK", 0) == 2 ? 4 : 0);      // 2: spine mode
   DevBuf st;
   const size_t state_bytes = sizeof(unsigned long long) * ntiles * 2 * NW;
   RMM_TRY(st.alloc(state_bytes + sizeof(unsigned long long)));
@@ -457,7 +456,7 @@ static gdf_error device_scan_lookback(const ELEM *in, ELEM *out, size_t n, bool 
   uint32_t *ticket = reinterpret_cast<uint32_t *>(st.as<unsigned char>() + state_bytes);
   // persistent workgroups, each takes tiles from the ticket counter until they run out: a few per CU (every one keeps two
   // tiles in flight).  With dbg & 1 every workgroup handles exactly the tile of its blockIdx.
-  static const int per_cu_env = getenv("GDF_SCAN_WGS_PER_CU") ? atoi(getenv("GDF_SCAN_WGS_PER_CU")) : 0;
+  const int per_cu_env = (int)lab::knob_int("GDF_SCAN_WGS_PER_CU", 0);
   int per_cu = per_cu_env;
   if (per_cu <= 0) {
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)scan_lookback<ACC, ELEM>, LB_THREADS, 0));
@@ -643,14 +642,14 @@ gdf_error device_scan(const ELEM *in, ELEM *out, size_t n, bool inclusive) {
   // 16-byte accesses need 16-byte-aligned columns (a column may be a slice of a larger buffer): those take the coalesced
   // kernels, or -- GDF_SCAN_LOOKBACK=1, an experiment that lost, see the header -- the single-pass kernel; the rest, and
   // GDF_SCAN_BLOCKED=1, the element-wise kernels of round 1
-  static const bool lookback = getenv("GDF_SCAN_LOOKBACK") && atoi(getenv("GDF_SCAN_LOOKBACK")) > 0, blocked = getenv("GDF_SCAN_BLOCKED") != nullptr;
+  const bool lookback = lab::path_int("GDF_SCAN_LOOKBACK", 0) > 0, blocked = lab::path_on("GDF_SCAN_BLOCKED");      // (read per call: the tests flip them)
   if (!blocked && ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0)) {
     if (lookback && n / LB_TILE < 0x7fffffffULL) return device_scan_lookback<ACC, ELEM>(in, out, n, inclusive);
     return device_scan_coalesced<ACC, ELEM>(in, out, n, inclusive);
   }
   constexpr int ITEMS = 16 / sizeof(ELEM) >= 4 ? 8 : 4;
   constexpr size_t TILE = (size_t)SCAN_THREADS * ITEMS;
-  static const size_t seg_bytes = getenv("GDF_SCAN_SEG_MB") ? (size_t)atoll(getenv("GDF_SCAN_SEG_MB")) << 20 : 0;
+  const size_t seg_bytes = (size_t)lab::knob_int("GDF_SCAN_SEG_MB", 0) << 20;
   size_t seg = seg_bytes ? seg_bytes / sizeof(ELEM) / TILE * TILE : (n + TILE - 1) / TILE * TILE;
   if (seg < TILE) seg = TILE;
   DevBuf sums, running;

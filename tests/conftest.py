@@ -27,3 +27,21 @@ def gdf():
     assert torch.cuda.is_available(), "-m gpu tests need a GPU"
     import libgdf_amd
     return libgdf_amd
+
+
+@pytest.fixture
+def force_path(gdf):
+    """Force one of the library's alternative code paths for the duration of a test: force_path("GDF_JK_NO_SPEC", "1").
+    The shipped libgdf.so reads no environment variable (csrc/lab.h); the parity tests that run one request through two
+    code paths select the second one through the exported test hook gdf_amd_debug_force, and this fixture clears every
+    name it set when the test ends."""
+    names = []
+
+    def force(name, value="1"):
+        gdf.libgdf.gdf_amd_debug_force(name.encode(), None if value is None else str(value).encode())
+        if value is not None:
+            names.append(name)
+
+    yield force
+    for name in names:
+        gdf.libgdf.gdf_amd_debug_force(name.encode(), None)

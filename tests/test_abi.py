@@ -145,3 +145,21 @@ def test_host_side_argument_errors_need_no_gpu(libs):
     R = (C.POINTER(gdf_column) * 1)(C.pointer(big_r))
     idx = (C.c_int * 1)(0)
     assert gdf.gdf_inner_join(L, 1, idx, R, 1, idx, 1, 0, None, C.byref(ol), C.byref(orr), C.byref(ctx)) == 4
+
+
+def test_shipped_library_reads_no_environment(libs):
+    """csrc/lab.h: the shipped libgdf.so / librmm.so import no getenv at all -- a stray GDF_* variable in a caller's
+    environment cannot change which algorithm runs.  Alternative code paths are selected only through the exported test
+    hook gdf_amd_debug_force (host-side registry: no GPU needed to set and clear a name)."""
+    for name in ("libgdf.so", "librmm.so"):
+        und = subprocess.check_output(["nm", "-D", "--undefined-only", os.path.join(LIBDIR, name)]).decode()
+        assert "getenv" not in und, name
+    gdf, _ = libs
+    gdf.gdf_amd_debug_force.restype = C.c_int
+    gdf.gdf_amd_debug_force.argtypes = [C.c_char_p, C.c_char_p]
+    assert gdf.gdf_amd_debug_force(b"GDF_JK_NO_SPEC", b"1") == 0
+    assert gdf.gdf_amd_debug_force(b"GDF_JK_NO_SPEC", None) == 0
+    assert gdf.gdf_amd_debug_force(None, None) != 0
+    lab = os.path.join(LIBDIR, "lab", "libgdf.so")
+    if os.path.exists(lab):        # the LAB build (experiment knobs) is the one that reads the environment
+        assert "getenv" in subprocess.check_output(["nm", "-D", "--undefined-only", lab]).decode()

@@ -65,11 +65,11 @@ AGG_DTYPES = [np.int8, np.int16, np.int32, np.int64, np.float32, np.float64]
 
 
 @pytest.fixture(params=["direct", "dense"])
-def small_range_path(request, monkeypatch):
+def small_range_path(request, force_path):
     """Integer keys with a small value range take the direct-index path; GDF_GB_NO_DIRECT=1 keeps the dictionary
     (dense) path covered on the same inputs."""
     if request.param == "dense":
-        monkeypatch.setenv("GDF_GB_NO_DIRECT", "1")
+        force_path("GDF_GB_NO_DIRECT")
     return request.param
 
 
@@ -312,15 +312,15 @@ def test_sort_method_still_rejects_masks(gdf):
 
 @pytest.mark.parametrize("op", OPS)
 @pytest.mark.parametrize("path", ["partitioned", "sorted", "hash_table"])
-def test_many_groups_both_large_paths(gdf, op, path, monkeypatch):
+def test_many_groups_both_large_paths(gdf, op, path, force_path):
     """Beyond the LDS-resident paths the packed-key group-by radix sorts (key, value) pairs: only the high key bits
     when the low 13 can index LDS accumulators directly ("partitioned"), the whole key otherwise ("sorted",
     forced here with GDF_GB_NO_PART=1); GDF_GB_NO_SORTED=1 keeps the global hash table.  All three must give the
     oracle's answer, masked or not."""
     if path == "hash_table":
-        monkeypatch.setenv("GDF_GB_NO_SORTED", "1")
+        force_path("GDF_GB_NO_SORTED")
     if path == "sorted":
-        monkeypatch.setenv("GDF_GB_NO_PART", "1")
+        force_path("GDF_GB_NO_PART")
     n = 300000
     keys = [gen_rand(np.int64, n, -40000, 40000), gen_rand(np.int16, n, 0, 2)]
     vals = gen_rand(np.float64, n)
@@ -363,7 +363,7 @@ def test_direct_path_guessed_window(gdf, case):
 
 @pytest.mark.parametrize("op", ["sum", "count", "min", "avg"])
 @pytest.mark.parametrize("kdt", [np.float64, np.float32], ids=lambda d: np.dtype(d).name)
-def test_float_keys_take_the_packed_paths(gdf, op, kdt, monkeypatch):
+def test_float_keys_take_the_packed_paths(gdf, op, kdt, force_path):
     """Float key columns enter the packed-key paths through an order-preserving integer image (csrc/groupby.hip,
     f64_image): -0.0 and +0.0 are one group, +-inf and denormals are ordinary keys; few groups (dictionary path) and
     many groups (sorted path); the row-comparing path (GDF_GB_NO_FLOAT_IMAGE) gives the same groups."""
@@ -377,9 +377,9 @@ def test_float_keys_take_the_packed_paths(gdf, op, kdt, monkeypatch):
     for keys in (few, many):
         gk, ga = _run(gdf, op, [keys], vals, out)
         _check(gdf, op, [keys], vals, out)
-        monkeypatch.setenv("GDF_GB_NO_FLOAT_IMAGE", "1")
+        force_path("GDF_GB_NO_FLOAT_IMAGE")
         rk, ra = _run(gdf, op, [keys], vals, out)
-        monkeypatch.delenv("GDF_GB_NO_FLOAT_IMAGE")
+        force_path("GDF_GB_NO_FLOAT_IMAGE", None)
         (gk, ga), (rk, ra) = sort_groups(gk, ga), sort_groups(rk, ra)
         np.testing.assert_array_equal(gk[0], rk[0])
         np.testing.assert_array_equal(ga, ra)
@@ -462,19 +462,16 @@ def test_lds_dictionary_sampling_and_limits(gdf, shape):
     _check(gdf, "avg", k, gen_rand(np.float64, n, positive_only=True), np.float64)
 
 
-def test_lds_dictionary_switch_matches_dense_path(gdf):
-    """GDF_GB_NO_LDS_DICT=1 (read per call) falls back to the L2 dictionary: identical integer results."""
+def test_lds_dictionary_switch_matches_dense_path(gdf, force_path):
+    """GDF_GB_NO_LDS_DICT (forced through gdf_amd_debug_force) falls back to the L2 dictionary: identical integer results."""
     n = 4_200_000
     lut = _sparse_lut(3_000, 9)
     rng = np.random.default_rng(10)
     keys = [lut[rng.integers(0, len(lut), size=n)]]
     vals = gen_rand(np.int64, n)
     a = sort_groups(*_run(gdf, "sum", keys, vals))
-    os.environ["GDF_GB_NO_LDS_DICT"] = "1"
-    try:
-        b = sort_groups(*_run(gdf, "sum", keys, vals))
-    finally:
-        del os.environ["GDF_GB_NO_LDS_DICT"]
+    force_path("GDF_GB_NO_LDS_DICT")
+    b = sort_groups(*_run(gdf, "sum", keys, vals))
     np.testing.assert_array_equal(a[0][0], b[0][0])
     np.testing.assert_array_equal(a[1], b[1])
 
@@ -484,7 +481,7 @@ def test_lds_dictionary_switch_matches_dense_path(gdf):
                                         (np.int64, np.int64)], ids=lambda ks: "+".join(np.dtype(k).name for k in ks))
 @pytest.mark.parametrize("op,val_dtype", [("sum", np.int64), ("avg", np.float64), ("min", np.float64), ("count", np.int64)],
                          ids=lambda x: x if isinstance(x, str) else np.dtype(x).name)
-def test_fused_partition_pass_static_signatures(gdf, key_dtypes, val_dtype, op, monkeypatch):
+def test_fused_partition_pass_static_signatures(gdf, key_dtypes, val_dtype, op, force_path):
     """>= 2^20 rows and more groups than one set of LDS accumulators: the fused partition pass, whose count / scatter kernels
     are instantiated per (key kinds, value mask) for one or two 4- / 8-byte integer key columns with an 8-byte value column
     (COUNT and every other shape keep the kernels with the type switches; GDF_GBP_DYNAMIC=1 forces those: same answers).
@@ -502,5 +499,5 @@ def test_fused_partition_pass_static_signatures(gdf, key_dtypes, val_dtype, op, 
     _check(gdf, op, keys, vals, out)
     _check_masked(gdf, op, keys, vals, nokeys, v_ok, out)
     _check_masked(gdf, op, keys, vals, [k_ok] + nokeys[1:], v_ok, out)
-    monkeypatch.setenv("GDF_GBP_DYNAMIC", "1")
+    force_path("GDF_GBP_DYNAMIC")
     _check_masked(gdf, op, keys, vals, nokeys, v_ok, out)

@@ -139,29 +139,22 @@ def test_prefixsum_many_tiles_unaligned_and_in_place(gdf, dtype):
     assert torch.equal(dev.cpu(), torch.from_numpy(exp))
 
 
-def test_prefixsum_single_pass_kernel_in_a_subprocess():
-    """The decoupled look-back kernel (GDF_SCAN_LOOKBACK=1, not the default: profiles/r2_c_scan_ablation.md) and the
-    element-wise kernels (GDF_SCAN_BLOCKED=1) against numpy, each in its own process (the switches are read once)."""
-    import subprocess
-    import sys
-    code = (
-        "import numpy as np, torch, libgdf_amd as gdf\n"
-        "from libgdf_amd import Column\n"
-        "rs = np.random.RandomState(3)\n"
-        "for dt in (np.int8, np.int32, np.int64):\n"
-        "    for n in (1, 4095, 4096, 4097, 10_000_019):\n"
-        "        a = rs.randint(-100, 100, size=n).astype(dt)\n"
-        "        for inc in (True, False):\n"
-        "            got = gdf.api.prefixsum(Column(torch.from_numpy(a).cuda()), inc).cpu().numpy()\n"
-        "            exp = np.cumsum(a, dtype=dt)\n"
-        "            exp = exp if inc else (exp - a).astype(dt)\n"
-        "            assert np.array_equal(got, exp), (dt, n, inc)\n"
-        "print('ok')\n")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for switch, value in (("GDF_SCAN_LOOKBACK", "1"), ("GDF_SCAN_LOOKBACK", "2"), ("GDF_SCAN_LOOKBACK", "0"), ("GDF_SCAN_BLOCKED", "1")):
-        env = dict(os.environ, PYTHONPATH=root, **{switch: value})
-        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0 and "ok" in r.stdout, (switch, value, r.stdout[-500:], r.stderr[-2000:])
+@pytest.mark.parametrize("switch,value", [("GDF_SCAN_LOOKBACK", "1"), ("GDF_SCAN_LOOKBACK", "2"), ("GDF_SCAN_BLOCKED", "1")])
+def test_prefixsum_alternative_kernels(gdf, force_path, switch, value):
+    """The decoupled look-back kernel (GDF_SCAN_LOOKBACK = 1, 2 = spine mode; not the default: profiles/r2_c_scan_ablation.md)
+    and the element-wise kernels (GDF_SCAN_BLOCKED) against numpy, selected through the test hook gdf_amd_debug_force."""
+    import torch
+    from libgdf_amd import Column
+    force_path(switch, value)
+    rs = np.random.RandomState(3)
+    for dt in (np.int8, np.int32, np.int64):
+        for n in (1, 4095, 4096, 4097, 10_000_019):
+            a = rs.randint(-100, 100, size=n).astype(dt)
+            for inc in (True, False):
+                got = gdf.api.prefixsum(Column(torch.from_numpy(a).cuda()), inc).cpu().numpy()
+                exp = np.cumsum(a, dtype=dt)
+                exp = exp if inc else (exp - a).astype(dt)
+                assert np.array_equal(got, exp), (dt, n, inc)
 
 
 def test_prefixsum_large_wraps_like_numpy(gdf):

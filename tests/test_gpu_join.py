@@ -240,11 +240,11 @@ def test_int64_keys_wider_than_32_bits(gdf, how):
 
 
 @pytest.mark.parametrize("how", ["inner", "left"])
-def test_wide_keys_lean_kernel_and_fold_collisions(gdf, how, monkeypatch):
+def test_wide_keys_lean_kernel_and_fold_collisions(gdf, how, force_path):
     """64-bit keys spread over 2^60 take the WIDE tuples and (round 2) the lean write kernel; keys that share their 32-bit
     fold (lo ^ hi * 0x9e3779b1) land in one partition and in the same slot of cuckoo table 0 -- six of them per fold value
     here, which only settles because table 1 hashes an independent second fold (csrc/join.hip key_fold2)."""
-    monkeypatch.setenv("GDF_JK_SPEC_MIN", "1000")
+    force_path("GDF_JK_SPEC_MIN", "1000")
     rs = np.random.RandomState(11)
     nb = 300_000
     build = rs.randint(0, 2**60, size=nb, dtype=np.int64)
@@ -375,7 +375,7 @@ def test_probe_relation_accumulated_in_slices(gdf, dtype):
         jb.accumulate(1000)
 
 
-def test_prepared_build_edge_cases(gdf, monkeypatch):
+def test_prepared_build_edge_cases(gdf, force_path):
     import torch
     from libgdf_amd import Column, GDFError
     empty = gdf.api.JoinBuild(_cols([np.zeros(0, dtype=np.int64)]))
@@ -387,7 +387,7 @@ def test_prepared_build_edge_cases(gdf, monkeypatch):
     with pytest.raises(GDFError, match="GDF_JOIN_DTYPE_MISMATCH"):
         jb.probe(_cols([np.arange(5, dtype=np.int32)]))
     # a probe relation larger than the build relation keeps the table on the prepared side, at speculative-partition size
-    monkeypatch.setenv("GDF_JK_SPEC_MIN", "1000")
+    force_path("GDF_JK_SPEC_MIN", "1000")
     build = torch.randperm(3_000_000, dtype=torch.int64, device="cuda")[:2_000_000]
     jb2 = gdf.api.JoinBuild([Column(build)])
     for seed in range(2):
@@ -400,12 +400,12 @@ def test_prepared_build_edge_cases(gdf, monkeypatch):
         assert torch.unique(li).numel() == li.numel()
 
 
-def test_every_partition_oversize_uses_one_global_table(gdf, monkeypatch):
+def test_every_partition_oversize_uses_one_global_table(gdf, force_path):
     """A build side beyond 32768 x 6144 rows makes EVERY fine partition exceed the LDS image: the global-table
     path (third partitioning level switched off) must handle them as one run (one table, three launches), not one
     launch per partition."""
     import torch
-    monkeypatch.setenv("GDF_JK_NO_LEVEL3", "1")
+    force_path("GDF_JK_NO_LEVEL3", "1")
     from libgdf_amd.columns import Column
     nb, npr = 210_000_000, 2_000_000
     build = torch.randperm(nb, dtype=torch.int32, device="cuda")
@@ -451,9 +451,9 @@ def test_sort_method_rules(gdf):
 # ---- histogram-free (speculative) partitioning of the probe side -------------------------------------------------
 @pytest.mark.parametrize("how", ["inner", "left", "full"])
 @pytest.mark.parametrize("dtypes", [[np.int64], [np.int32], [np.int32, np.int64], [np.float64]], ids=lambda d: "-".join(np.dtype(x).name for x in d))
-def test_speculative_partitioning_small_inputs(gdf, how, dtypes, monkeypatch):
+def test_speculative_partitioning_small_inputs(gdf, how, dtypes, force_path):
     """GDF_JK_SPEC_MIN=1 sends even small probe sides through the capacity-slack layout (normally >= 4M rows)."""
-    monkeypatch.setenv("GDF_JK_SPEC_MIN", "1")
+    force_path("GDF_JK_SPEC_MIN", "1")
     rng = 20000 if len(dtypes) == 1 else 150
     _check(gdf, _gen(dtypes, 300000, rng), _gen(dtypes, 40000, rng), how)
     lv = [random_valid(300000) for _ in dtypes]
@@ -461,10 +461,10 @@ def test_speculative_partitioning_small_inputs(gdf, how, dtypes, monkeypatch):
     _check(gdf, _gen(dtypes, 300000, rng), _gen(dtypes, 40000, rng), how, lv, rv)
 
 
-def test_speculative_partitioning_falls_back_on_skew(gdf, monkeypatch):
+def test_speculative_partitioning_falls_back_on_skew(gdf, force_path):
     """Half of the probe rows carry ONE key: its partition outgrows the slack, the flag is raised and the exact
     (histogram) layout takes over.  Same answer, checked against the oracle and by count."""
-    monkeypatch.setenv("GDF_JK_SPEC_MIN", "1")
+    force_path("GDF_JK_SPEC_MIN", "1")
     n = 400000
     l = gen_rand(np.int64, n, 0, 50000)
     l[::2] = 777
@@ -473,7 +473,7 @@ def test_speculative_partitioning_falls_back_on_skew(gdf, monkeypatch):
     assert _check(gdf, [l], [r], "inner") == n
 
 
-def test_speculative_matches_exact_at_scale(gdf, monkeypatch):
+def test_speculative_matches_exact_at_scale(gdf, force_path):
     """3e7 x 3e6 uniform keys: speculative (default at this size) and exact (GDF_JK_NO_SPEC) give the same pair set."""
     import torch
     from libgdf_amd.columns import Column
@@ -481,7 +481,7 @@ def test_speculative_matches_exact_at_scale(gdf, monkeypatch):
     b = torch.randperm(nb, device="cuda")
     p = torch.randint(0, nb + nb // 10, (npr,), device="cuda")
     li, ri = gdf.api.join([Column(p)], [Column(b)])
-    monkeypatch.setenv("GDF_JK_NO_SPEC", "1")
+    force_path("GDF_JK_NO_SPEC", "1")
     le, re_ = gdf.api.join([Column(p)], [Column(b)])
     assert li.numel() == le.numel() == int((p < nb).sum())
     assert bool((p[li.long()] == b[ri.long()]).all())
@@ -493,7 +493,7 @@ def test_speculative_matches_exact_at_scale(gdf, monkeypatch):
 @pytest.mark.parametrize("how", ["inner", "left", "full"])
 @pytest.mark.parametrize("dtypes", [[np.int64, np.int32], [np.int32, np.int16, np.int8], [np.int64, np.int64], [np.int8, np.int64]],
                          ids=lambda d: "-".join(np.dtype(x).name for x in d))
-def test_range_packed_multi_column_keys(gdf, how, dtypes):
+def test_range_packed_multi_column_keys(gdf, how, dtypes, force_path):
     """Several integer key columns are packed as (value - build minimum) fields (plan_ranged in csrc/join.hip): probe
     values below / above the build range of a column, negative values and nulls must behave exactly as in the oracle;
     GDF_JK_NO_RANGED (hashed key + row comparison) is the same join."""
@@ -509,11 +509,9 @@ def test_range_packed_multi_column_keys(gdf, how, dtypes):
     pvalid = [(rs.rand(npr) > 0.05) if i == len(dtypes) - 1 else None for i in range(len(dtypes))]
     n1 = _check(gdf, probe, build, how, pvalid, bvalid)
     assert n1 > 0
-    os.environ["GDF_JK_NO_RANGED"] = "1"
-    try:
-        assert _check(gdf, probe, build, how, pvalid, bvalid) == n1
-    finally:
-        del os.environ["GDF_JK_NO_RANGED"]
+    force_path("GDF_JK_NO_RANGED")
+    assert _check(gdf, probe, build, how, pvalid, bvalid) == n1
+    force_path("GDF_JK_NO_RANGED", None)
     if dtypes == [np.int64, np.int64]:
         # ranges that do not fit 64 bits together keep the hashed plan
         wide_b = [b.astype(np.int64) * (1 << 40) for b in build]
@@ -550,7 +548,7 @@ def test_third_partition_level_for_large_build_sides(gdf, shape):
 
 
 @pytest.mark.parametrize("how", ["inner", "left"])
-def test_xcd_regions_match_plain_layout(gdf, how, monkeypatch):
+def test_xcd_regions_match_plain_layout(gdf, how, force_path):
     """1e8 x 1e7 rows (above the 2^26-row threshold): the per-XCD level-1 regions and the XCD-ordered level-2 tiles
     (default) give the same pair set as the plain speculative layout (GDF_JK_NO_XCD_SPLIT / GDF_JK_NO_XCD_ORDER)."""
     import torch
@@ -559,8 +557,8 @@ def test_xcd_regions_match_plain_layout(gdf, how, monkeypatch):
     b = torch.randperm(nb + nb // 8, device="cuda")[:nb]
     p = torch.randint(0, nb + nb // 4, (npr,), device="cuda")
     li, ri = gdf.api.join([Column(p)], [Column(b)], how=how)
-    monkeypatch.setenv("GDF_JK_NO_XCD_SPLIT", "1")
-    monkeypatch.setenv("GDF_JK_NO_XCD_ORDER", "1")
+    force_path("GDF_JK_NO_XCD_SPLIT", "1")
+    force_path("GDF_JK_NO_XCD_ORDER", "1")
     le, re_ = gdf.api.join([Column(p)], [Column(b)], how=how)
     assert li.numel() == le.numel()
     if how == "left":
@@ -623,7 +621,7 @@ def test_headline_configuration_properties(gdf):
 
 @pytest.mark.parametrize("hit", [0.0, 0.05, 0.3, 0.44])
 @pytest.mark.parametrize("size", ["small", "large"])
-def test_selective_inner_join_single_pass_then_compaction(gdf, hit, size, monkeypatch):
+def test_selective_inner_join_single_pass_then_compaction(gdf, hit, size, force_path):
     """Well under one pair per probe row: one optimistic write pass into per-unit slot ranges, then jk_compact_units closes the
     holes (instead of a count pass).  Same pair set as the count + write path (GDF_JK_NO_SPARSE_OPT), at a size that takes the
     host-built units and at one that takes the device-built ones; repeated build keys inside the units are fine as long as a
@@ -637,7 +635,7 @@ def test_selective_inner_join_single_pass_then_compaction(gdf, hit, size, monkey
     span = max(nb + 1, int(nb / max(hit, 1e-9))) if hit > 0 else nb
     p = torch.randint(0, span, (npr,), device="cuda", generator=g) + (0 if hit > 0 else nb + 5)
     li, ri = gdf.api.join([Column(p)], [Column(b)])
-    monkeypatch.setenv("GDF_JK_NO_SPARSE_OPT", "1")
+    force_path("GDF_JK_NO_SPARSE_OPT", "1")
     le, re_ = gdf.api.join([Column(p)], [Column(b)])
     assert li.numel() == le.numel()
     if li.numel():

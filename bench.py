@@ -261,17 +261,45 @@ def main():
         build = make_build_keys(nb, 0x5EED0001 + rank, dev) * world + rank
         probe = make_probe_keys(npr, key_space, 0x5EED0002, dev, offset=rank * npr)
 
+        last_pairs = [None]                        # the preflight (only) looks at the pairs of the step it just ran
+        keep_pairs = [False]
+
+        def done(pairs):
+            if keep_pairs[0]:
+                last_pairs[0] = pairs
+            return pairs.numel()
+
         def step_broadcast():
-            return multigpu.broadcast_inner_join(probe, build).numel()
+            return done(multigpu.broadcast_inner_join(probe, build))
 
         def step_fused():
             pairs = multigpu.fused_inner_join(probe, build)
             if pairs is None:                      # None on EVERY rank: the shape did not fit the fixed-size blocks
                 raise RuntimeError("fused_inner_join declined this shape")
-            return pairs.numel()
+            return done(pairs)
 
         def step_shuffle():
-            return multigpu.distributed_inner_join(probe, build).numel()
+            return done(multigpu.distributed_inner_join(probe, build))
+
+        def sampled_pairs_join_equal_keys(pairs, k=1 << 20):
+            """About k of this rank's pairs, resolved to (owner rank << 40 | row) on both sides (a collective for the fused
+            join: every rank calls this), must name rows with EQUAL keys.  The keys are functions of (rank, row) -- the
+            generators above -- so any rank can recompute them without another exchange."""
+            pg, bg = pairs.sample_global_ids(k)
+            if pg.numel() == 0:
+                return None
+            pr, prow = pg >> 40, pg & ((1 << 40) - 1)
+            br, brow = bg >> 40, bg & ((1 << 40) - 1)
+            if int(prow.max()) >= npr or int(brow.max()) >= nb or int(pr.max()) >= world or int(br.max()) >= world:
+                return "a sampled pair names a row that does not exist"
+            pk = ((splitmix64_torch(prow + pr * npr + 0x5EED0002) >> 1) & 0x7FFFFFFFFFFFFFFF) % key_space
+            bk = torch.empty_like(pk)
+            for r in range(world):                 # rank r's build keys: its seeded permutation, regenerated here
+                sel = br == r
+                if bool(sel.any()):
+                    bk[sel] = make_build_keys(nb, 0x5EED0001 + r, dev)[brow[sel]] * world + r
+            bad = int((pk != bk).sum())
+            return None if bad == 0 else f"{bad} of {pg.numel()} sampled pairs join UNEQUAL keys"
 
         steps = {"fused": (step_fused, f"C4 partitioned hash join: {npr} probe + {nb} build int64 rows per GPU, key space {key_space}, rank split "
                                        f"fused into the join's level-1 regroup at the sender, RCCL exchange of 4-byte keys in fixed-size blocks, "
@@ -282,7 +310,8 @@ def main():
                                                f"RCCL all-gather of the build keys + local gdf_inner_join")}
         planned = args.strategy if args.strategy != "auto" else multigpu.choose_join_strategy(world, npr, nb)
         # Preflight (untimed, before the warmup): one step of the planned strategy, checked against what this workload must
-        # produce -- every probe key is a build key on exactly one rank, so the ranks' pair counts add up to the probe rows.
+        # produce -- every probe key is a build key on exactly one rank, so the ranks' pair counts add up to the probe rows --
+        # and a sample of 2^20 pairs per rank, resolved to global row ids, must join equal keys.
         # A strategy that raises or miscounts ON ANY RANK is dropped by all of them together and the next one is tried;
         # the JSON line says which ran and why.  (A failure inside a collective can still take the job down: then RCCL's
         # watchdog ends it.)
@@ -293,9 +322,14 @@ def main():
             err = None
             got = 0
             try:
+                keep_pairs[0] = True
                 got = steps[cand][0]()
+                keep_pairs[0] = False
+                err = sampled_pairs_join_equal_keys(last_pairs[0])
             except Exception as e:                 # noqa: BLE001 -- reported, not swallowed: see "preflight" in the output
                 err = f"{type(e).__name__}: {e}"
+            keep_pairs[0] = False
+            last_pairs[0] = None
             flags = torch.tensor([1.0 if err else 0.0, float(got)], dtype=torch.float64, device=dev)
             if world > 1:
                 dist.all_reduce(flags)

@@ -227,6 +227,18 @@ __device__ __forceinline__ void fetch_keys(const KeyTable &t, const KeyPlan &p, 
       key[k] -= p.kmin;
       ok[k] = joinable && (i0 + k * stride < end) && (!p.narrow || (key[k] >> 32) == 0);
     }
+    // the column's validity mask, paired with the data reads: one byte per row, requested together (a wave's 64 rows of
+    // one k share 8 bytes -- one request); workgroup-uniform branch, the unmasked column pays nothing
+    if (const uint8_t *valid = t.col[0].valid) {
+      uint8_t m[N];
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        const int64_t i = i0 + k * stride;
+        m[k] = valid[(i < end ? i : end - 1) >> 3];
+      }
+#pragma unroll
+      for (int k = 0; k < N; ++k) ok[k] = ok[k] && ((m[k] >> ((i0 + k * stride) & 7)) & 1);
+    }
   } else if (p.mode == KM_PACKED && p.ranged) {
     // several integer columns packed by range (plan_ranged): column by column, the N elements of a column requested
     // together from clamped row numbers -- make_key() row by row is one dependent load at a time
@@ -541,7 +553,22 @@ __device__ __forceinline__ void tile_flush(TileLds<NARROW, THREADS> &s, const Pa
 }
 
 // 2. level-1 scatter: raw key columns -> tuples grouped by coarse partition
-template <int FAST, bool NARROW, int THREADS>
+// MASKED (FAST only): the key column carries a validity mask.  The mask is read PAIRED with the data: per tile one 4-byte
+// word per lane (lanes 0..31 of a wave hold the 128 bytes that cover the wave's 16 rows per lane; all from at most two
+// cache lines), prefetched with the key words of the next tile and spread to the lanes by ds_bpermute when the keys are
+// consumed -- a null row is ranked on the trash counter like a row outside the narrow range.  No alignment is asked of
+// the mask pointer and nothing is read behind its ceil(rows / 8) bytes (load_mask_word).
+__device__ __forceinline__ uint32_t load_mask_word(const uint8_t *valid, uint32_t word_index, uint32_t mask_bytes) {
+  // branch-free (a load under a branch is a basic block of its own with an s_waitcnt vmcnt(0), see fetch_keys): the word
+  // that would reach past the mask is taken from its last four bytes and shifted down; mask_bytes >= 4
+  const uint32_t at = word_index * 4u;
+  const uint32_t from = at + 4u <= mask_bytes ? at : mask_bytes - 4u;
+  uint32_t w;
+  __builtin_memcpy(&w, valid + from, 4);               // gfx950 global loads need no alignment
+  const uint32_t drop = (at - from) * 8u;                // bits of earlier bytes in front of ours; >= 32: every row is behind the end
+  return drop < 32u ? w >> drop : 0u;
+}
+template <int FAST, bool NARROW, int THREADS, bool MASKED = false>
 __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan, PartGeom g,
                                                              const uint32_t *__restrict__ H1off,   // scanned H1
                                                              Tuples out) {
@@ -563,13 +590,23 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
     return FAST ? 2u * ((uint32_t)(k >> 1) * THREADS + tid) + (k & 1) : (uint32_t)k * THREADS + tid;
   };
   uint64_t nxt[JK_SC_ITEMS];
+  uint32_t nxtmask = 0;                          // MASKED: this lane's word of the tile's validity bits (see consume)
   const void *col = t.col[0].data;
+  const uint8_t *vmask = t.col[0].valid;
+  const uint32_t vbytes = (uint32_t)((t.nrows + 7) >> 3);
   auto prefetch = [&](uint32_t tile) {           // a pair that would cross `end` is read from the last two rows instead:
     const uint32_t tid = opaque_tid();           // its first row, if it is row end - 1, is then the SECOND word loaded (consume)
 #pragma unroll
     for (int k = 0; k < JK_SC_ITEMS; k += 2) {
       const uint32_t i = tile + item_row(k, tid);
       fast_pair<FAST>(col, (int64_t)(i + 2 <= end ? i : end - 2), nxt[k], nxt[k + 1]);
+    }
+    if (MASKED) {
+      // pair j of thread (wave w, lane L) is rows tile + 2 * (j * THREADS + 64 w + L) + {0, 1}: bit 2 L of the 128-bit group
+      // (j, w), i.e. of mask word (tile / 32) + j * THREADS / 16 + 4 w + L / 16.  Lane l (and l + 32) fetches word
+      // (j = l / 4 % 8, q = l % 4) of its wave; tile is a multiple of the largest tile, so of 32
+      const uint32_t l = tid & 31u, w = tid >> 6;
+      nxtmask = load_mask_word(vmask, (tile >> 5) + (uint32_t)(THREADS / 16) * (l >> 2) + 4u * w + (l & 3u), vbytes);
     }
   };
   if (FAST) prefetch(begin);
@@ -588,6 +625,16 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
   auto consume = [&](uint32_t tile) {
     const uint32_t tid = opaque_tid();
     okmask = 0;
+    uint32_t validbits = 0xffffffffu;            // bit k: row of item k is not null
+    if (MASKED) {
+      validbits = 0;
+      const uint32_t L = tid & 63u;
+#pragma unroll
+      for (int j = 0; j < JK_SC_ITEMS / 2; ++j) {
+        const uint32_t wj = (uint32_t)__shfl((int)nxtmask, (int)(4u * j + (L >> 4)), WAVE);
+        validbits |= ((wj >> ((2u * L) & 31u)) & 3u) << (2 * j);
+      }
+    }
 #pragma unroll
     for (int k = 0; k < JK_SC_ITEMS; ++k) {
       uint64_t raw = ((k & 1) == 0 && tile + item_row(k, tid) + 1 == end) ? nxt[k + 1] : nxt[k];
@@ -596,6 +643,7 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
       key[k] = (KeyReg)k64;
       okmask |= (uint32_t)(joinable && (tile + item_row(k, tid) < end) && (!plan.narrow || (k64 >> 32) == 0)) << k;
     }
+    okmask &= validbits;
   };
   if (FAST) consume(begin);
   for (uint32_t tile = begin; tile < end; tile += JK_TILE) {        // end + JK_TILE < 2^32
@@ -1695,31 +1743,40 @@ static PartGeom choose_geometry(int64_t build_rows) {
 
 static inline int small_grid(int64_t n) { return stream_grid((size_t)(n > 0 ? n : 1), 256 * 8); }
 
-template <int FAST, bool NARROW, int THREADS>
+template <int FAST, bool NARROW, int THREADS, bool MASKED>
 static gdf_error launch_scatter1_t(const KeyTable &t, const KeyPlan &plan, const PartGeom &g, const uint32_t *H1off, Tuples out) {
   const size_t lds = sizeof(TileLds<NARROW, THREADS>);
-  HIP_TRY(hipFuncSetAttribute((const void *)jk_scatter1<FAST, NARROW, THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  GDF_LAUNCH("jk_scatter1", (jk_scatter1<FAST, NARROW, THREADS>), dim3(g.nchunks), dim3(THREADS), lds, stream0(), t, plan, g, H1off, out);
+  HIP_TRY(hipFuncSetAttribute((const void *)jk_scatter1<FAST, NARROW, THREADS, MASKED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  GDF_LAUNCH("jk_scatter1", (jk_scatter1<FAST, NARROW, THREADS, MASKED>), dim3(g.nchunks), dim3(THREADS), lds, stream0(), t, plan, g, H1off, out);
   HIP_CHECK_LAST();
   return GDF_SUCCESS;
 }
-template <int FAST, bool NARROW>
+template <int FAST, bool NARROW, bool MASKED>
 static gdf_error launch_scatter1_n(int threads, const KeyTable &t, const KeyPlan &plan, const PartGeom &g, const uint32_t *H1off, Tuples out) {
-  if (threads == 1024) { if constexpr (NARROW) return launch_scatter1_t<FAST, NARROW, 1024>(t, plan, g, H1off, out); }
-  if (threads >= 512) return launch_scatter1_t<FAST, NARROW, 512>(t, plan, g, H1off, out);
-  return launch_scatter1_t<FAST, NARROW, 256>(t, plan, g, H1off, out);
+  if (threads == 1024) { if constexpr (NARROW) return launch_scatter1_t<FAST, NARROW, 1024, MASKED>(t, plan, g, H1off, out); }
+  if (threads >= 512) return launch_scatter1_t<FAST, NARROW, 512, MASKED>(t, plan, g, H1off, out);
+  if constexpr (MASKED) return launch_scatter1_t<FAST, NARROW, 512, MASKED>(t, plan, g, H1off, out);      // (masked: the two production tile sizes only)
+  else return launch_scatter1_t<FAST, NARROW, 256, MASKED>(t, plan, g, H1off, out);
 }
 static gdf_error launch_scatter1(int fast, bool narrow, int threads, const KeyTable &t, const KeyPlan &plan, const PartGeom &g,
                                  const uint32_t *H1off, Tuples out) {
-  if (fast == 4) return launch_scatter1_n<4, true>(threads, t, plan, g, H1off, out);      // 4-byte keys are always narrow
-  if (fast == 8) return narrow ? launch_scatter1_n<8, true>(threads, t, plan, g, H1off, out)
-                               : launch_scatter1_n<8, false>(threads, t, plan, g, H1off, out);
-  return narrow ? launch_scatter1_n<0, true>(threads, t, plan, g, H1off, out)
-                : launch_scatter1_n<0, false>(threads, t, plan, g, H1off, out);
+  const bool masked = fast != 0 && t.col[0].valid != nullptr;
+  if (masked) {
+    if (fast == 4) return launch_scatter1_n<4, true, true>(threads, t, plan, g, H1off, out);
+    return narrow ? launch_scatter1_n<8, true, true>(threads, t, plan, g, H1off, out)
+                  : launch_scatter1_n<8, false, true>(threads, t, plan, g, H1off, out);
+  }
+  if (fast == 4) return launch_scatter1_n<4, true, false>(threads, t, plan, g, H1off, out);      // 4-byte keys are always narrow
+  if (fast == 8) return narrow ? launch_scatter1_n<8, true, false>(threads, t, plan, g, H1off, out)
+                               : launch_scatter1_n<8, false, false>(threads, t, plan, g, H1off, out);
+  return narrow ? launch_scatter1_n<0, true, false>(threads, t, plan, g, H1off, out)
+                : launch_scatter1_n<0, false, false>(threads, t, plan, g, H1off, out);
 }
-// 8 / 4: the relation is one unmasked raw integer column of that width (direct column reads); 0: generic key construction
+// 8 / 4: the relation is one raw integer / float column of that width, with or without a validity mask (direct column
+// reads, the mask read paired with the data: jk_scatter1<MASKED>, fetch_keys); 0: generic key construction
 static int fast_key_width(const KeyTable &t, const KeyPlan &plan) {
-  if (t.ncols != 1 || (plan.mode != KM_RAW_INT && plan.mode != KM_RAW_FLOAT) || t.any_valid || t.nrows < 2) return 0;   // jk_scatter1 loads row pairs
+  if (t.ncols != 1 || (plan.mode != KM_RAW_INT && plan.mode != KM_RAW_FLOAT) || t.nrows < 2) return 0;   // jk_scatter1 loads row pairs
+  if (t.col[0].valid && t.nrows < 64) return 0;                                                          // ... and whole mask words
   if (t.col[0].width == 8) return 8;
   if (t.col[0].width == 4 && plan.narrow && plan.kmin == 0) return 4;
   return 0;

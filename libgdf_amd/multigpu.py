@@ -192,6 +192,27 @@ class ShardedPairs:
         bg = [self.build.global_ids(as_tensor(b)) for b in self.build_pos]
         return torch.cat(pg), torch.cat(bg)
 
+    def sample_global_ids(self, k):
+        """global ids of about ``k`` evenly spaced pairs of this rank's share (all of them when it has fewer): what a caller
+        needs to spot-check a billion-pair result without resolving every position (bench.py's preflight)."""
+        import torch
+        as_tensor = lambda x: x.tensor() if hasattr(x, "tensor") else x
+        total = max(self.numel(), 1)
+        pg, bg = [], []
+        for r, p, b in zip(self.probes, self.probe_pos, self.build_pos):
+            p, b = as_tensor(p), as_tensor(b)
+            n = int(p.numel())
+            if n == 0:
+                continue
+            take = min(n, max(1, int(k) * n // total))
+            at = torch.div(torch.arange(take, dtype=torch.int64, device=p.device) * n, take, rounding_mode="floor")
+            pg.append(r.global_ids(p[at]))
+            bg.append(self.build.global_ids(b[at]))
+        if not pg:
+            empty = torch.empty(0, dtype=torch.int64)
+            return empty, empty
+        return torch.cat(pg), torch.cat(bg)
+
 
 # Largest single message handed to RCCL.  Measured on this image (RCCL 2.26.6 inside torch 2.10, 1 rank sending to
 # itself): a send/recv pair of 2.0e9 bytes or more delivers only its first half, 2^30 bytes are fine
@@ -503,15 +524,24 @@ class FusedPairs:
         _all_to_all_v(recv, rows_buf[:world * blk], [blk] * world, [blk] * world, self.group, async_op=False)
         return recv
 
-    def global_ids(self):
+    def sample_global_ids(self, k):
+        """global ids of about ``k`` evenly spaced pairs (see ShardedPairs.sample_global_ids); COLLECTIVE like global_ids()."""
+        return self.global_ids(sample=int(k))
+
+    def global_ids(self, sample=None):
         import torch
         as_tensor = lambda x: x.tensor() if hasattr(x, "tensor") else x
-        b = as_tensor(self.build_pos).long()
+        build_pos, probe_pos = as_tensor(self.build_pos), as_tensor(self.probe_pos)
+        if sample is not None and int(probe_pos.numel()) > sample > 0:
+            n = int(probe_pos.numel())
+            at = torch.div(torch.arange(sample, dtype=torch.int64, device=probe_pos.device) * n, sample, rounding_mode="floor")
+            build_pos, probe_pos = build_pos[at], probe_pos[at]
+        b = build_pos.long()
         brows = self._rows_of(self._build_rows, self.build_layout)
         bg = ((b // self.build_layout.block) << 40) | brows[b].long()
         blk = self.probe_layout.block
         per_buf = self.probe_layout.world * blk
-        p = as_tensor(self.probe_pos).long()
+        p = probe_pos.long()
         pg = torch.empty_like(p)
         which = p // per_buf
         for i, rows_buf in enumerate(self._probe_rows):            # every rank walks all slices: the exchange is collective

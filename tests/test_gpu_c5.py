@@ -86,18 +86,46 @@ def test_guessed_key_ranges_are_verified(gdf, order):
     np.testing.assert_array_equal(ga[o], ea)
 
 
-def test_c5_full_size_properties(gdf):
-    """1e9 rows, 1e6 Zipf values x 16: ~1.6e7 groups, the hottest key pair holds ~0.4 % of the rows."""
+@pytest.mark.parametrize("null_keys", [0.0, 0.01], ids=["no-null-keys", "1pct-null-keys"])
+def test_c5_full_size_properties(gdf, null_keys):
+    """1e9 rows, 1e6 Zipf values x 16: ~1.6e7 groups, the hottest key pair holds ~0.4 % of the rows.  Second variant (SURVEY
+    8d): 1 % NULL KEYS -- a validity mask on key column 0; those rows belong to no group."""
     import torch
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
-    from bench_c5 import c5_property_checks, make_c5
+    from bench_c5 import c5_property_checks, make_c5, null_key_mask
     dev = torch.device("cuda", 0)
-    k0, k1, v, ok, mask = make_c5(1_000_000_000, dev)
-    checks, good = c5_property_checks(gdf, k0, k1, v, ok, mask, cap=20_000_000)
+    n = 1_000_000_000
+    k0, k1, v, ok, mask = make_c5(n, dev)
+    kok, kmask = null_key_mask(n, dev, null_keys) if null_keys > 0 else (None, None)
+    checks, good = c5_property_checks(gdf, k0, k1, v, ok, mask, 20_000_000, kok, kmask)
     assert good, checks
     assert checks["groups"] > 15_000_000
-    del k0, k1, v, ok, mask
+    del k0, k1, v, ok, mask, kok, kmask
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("op", ["avg", "count"])
+def test_c5_shape_with_null_keys_against_the_oracle(gdf, op):
+    """The 1 %-null-keys variant of C5 at a size the oracle finishes: null keys in either key column drop the row."""
+    from libgdf_amd.columns import column_from_numpy, get_dtype
+    n = 4_000_000
+    k0, k1, v, ok = _c5_numpy(n, 1_000_000, 23)
+    rs = np.random.RandomState(24)
+    kok0, kok1 = rs.random_sample(n) >= 0.01, rs.random_sample(n) >= 0.01
+    kc = [column_from_numpy(k0, kok0), column_from_numpy(k1, kok1)]
+    out = np.int64 if op == "count" else np.float64
+    gk, ga, gok = gdf.api.group_by(op, kc, column_from_numpy(v, ok), out_dtype=get_dtype(out), with_masks=True)
+    gk, ga, gok = [x.cpu().numpy() for x in gk], ga.cpu().numpy(), gok.numpy()
+    ek, ea, eok = oracle.group_by_masked(op, [k0, k1], v, [kok0, kok1], ok, out)
+    order = np.lexsort((gk[1], gk[0]))
+    gk, ga, gok = [k[order] for k in gk], ga[order], gok[order]
+    np.testing.assert_array_equal(gk[0], ek[0])
+    np.testing.assert_array_equal(gk[1], ek[1])
+    np.testing.assert_array_equal(gok, eok)
+    if op == "count":
+        np.testing.assert_array_equal(ga, ea)
+    else:
+        np.testing.assert_allclose(ga[gok], ea[eok], rtol=RTOL, atol=0.0)
 
 
 @pytest.mark.parametrize("how", ["inner", "left"])

@@ -619,6 +619,97 @@ def test_headline_configuration_properties(gdf):
     assert bool(seen.all())                                         # 1e9 pairs, all probe rows covered: each exactly once
 
 
+def _exact_mask_column(arr, valid):
+    """A column whose mask buffer is EXACTLY ceil(n / 8) bytes (column_from_numpy pads masks to 64 bytes): a read behind the
+    mask's last byte leaves the tensor."""
+    import torch
+    from libgdf_amd.columns import Column, get_dtype
+    bits = torch.from_numpy(np.packbits(np.asarray(valid, dtype=bool), bitorder="little").copy()).cuda()
+    return Column(torch.from_numpy(np.ascontiguousarray(arr)).cuda(), bits, get_dtype(arr.dtype), null_count=int(len(valid) - np.count_nonzero(valid)))
+
+
+@pytest.mark.parametrize("how", ["inner", "left", "full"])
+@pytest.mark.parametrize("dtype", [np.int64, np.int32, np.float64], ids=lambda d: np.dtype(d).name)
+@pytest.mark.parametrize("masks", ["probe", "build", "both", "all-ones"])
+def test_masked_single_key_column_takes_the_paired_reads(gdf, how, dtype, masks, force_path):
+    """One key column WITH a validity mask stays on the direct column reads (jk_scatter1<MASKED>, fetch_keys: the mask is read
+    paired with the data, north_star; reference semantics join_kernels.cuh:58-66, gdf_table.cuh:62-98: a null key matches
+    nothing).  Row counts that are not multiples of 8 / 32 / the tile, masks of exactly ceil(n / 8) bytes, the speculative
+    and the exact layout, both tile sizes."""
+    rs = np.random.RandomState(21)
+    for npr, nb, spec in ((70_001, 9_001, False), (1_000_003, 100_003, True), (333_337, 66_666, True)):
+        if spec:
+            force_path("GDF_JK_SPEC_MIN", "1000")
+        else:
+            force_path("GDF_JK_SPEC_MIN", None)
+        build = rs.permutation(nb * 2)[:nb].astype(dtype)
+        probe = rs.randint(0, nb * 2, size=npr).astype(dtype)
+        pv = np.ones(npr, bool) if masks in ("build", "all-ones") else rs.rand(npr) > 0.1
+        bv = np.ones(nb, bool) if masks in ("probe", "all-ones") else rs.rand(nb) > 0.1
+        pcol = _exact_mask_column(probe, pv) if masks != "build" else _cols([probe])[0]
+        bcol = _exact_mask_column(build, bv) if masks != "probe" else _cols([build])[0]
+        li, ri = gdf.api.join([pcol], [bcol], how=how)
+        el, er = oracle.join([probe], [build], how, [pv], [bv])
+        a, b = sort_pairs(li.cpu().numpy(), ri.cpu().numpy())
+        c, d = sort_pairs(el, er)
+        np.testing.assert_array_equal(a, c)
+        np.testing.assert_array_equal(b, d)
+
+
+@pytest.mark.parametrize("variant", ["all-ones", "bernoulli-0.99"])
+def test_headline_configuration_with_valid_masks(gdf, variant):
+    """BASELINE config C3, variant B ("all-ones masks to exercise paired mask reads"; north_star: "coalesced HBM
+    reads of the paired data+valid-mask buffers") at FULL size: 1e9 x 1e8 int64 rows with a validity mask on BOTH key
+    columns -- all ones, and Bernoulli(0.99).  Size-independent properties: the pair count is the number of valid probe rows
+    whose (unique) build row is valid, every pair joins equal keys of two VALID rows, no probe row appears twice."""
+    import torch
+    from bench import make_build_keys, make_probe_keys, splitmix64_torch
+    from libgdf_amd.columns import Column
+    dev = torch.device("cuda", 0)
+    nb, npr = 100_000_000, 1_000_000_000
+
+    def mask(n, seed):
+        """(bool tensor, LSB-first packed bytes); generated in slices"""
+        ok = torch.ones(n, dtype=torch.bool, device=dev)
+        if variant != "all-ones":
+            step = 1 << 27
+            for s in range(0, n, step):
+                e = min(n, s + step)
+                u = (splitmix64_torch(torch.arange(s, e, dtype=torch.int64, device=dev) + seed) >> 11) & ((1 << 53) - 1)
+                ok[s:e] = u >= (1 << 53) // 100
+        pad = (-n) % 8
+        bits = torch.cat([ok, torch.zeros(pad, dtype=torch.bool, device=dev)]) if pad else ok
+        weights = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.uint8, device=dev)
+        packed = torch.empty((n + 7) // 8, dtype=torch.uint8, device=dev)
+        step = 1 << 27
+        for s in range(0, packed.numel(), step):
+            e = min(packed.numel(), s + step)
+            packed[s:e] = (bits[8 * s:8 * e].view(-1, 8).to(torch.uint8) * weights).sum(dim=1, dtype=torch.uint8)
+        return ok, packed
+
+    build = make_build_keys(nb, 0x5EED0001, dev)
+    probe = make_probe_keys(npr, nb, 0x5EED0002, dev)
+    bok, bbits = mask(nb, 0x5EED0071)
+    pok, pbits = mask(npr, 0x5EED0072)
+    li, ri = gdf.api.join([Column(probe, pbits, null_count=int(npr - pok.sum()))], [Column(build, bbits, null_count=int(nb - bok.sum()))])
+    key_ok = torch.empty(nb, dtype=torch.bool, device=dev)
+    key_ok[build] = bok                                            # validity of the build row that holds key k
+    expected = 0
+    step = 1 << 27
+    for s in range(0, npr, step):
+        expected += int((pok[s:s + step] & key_ok[probe[s:s + step]]).sum())
+    assert li.numel() == expected and ri.numel() == expected, (li.numel(), expected)
+    if variant == "all-ones":
+        assert expected == npr
+    seen = torch.zeros(npr, dtype=torch.bool, device=dev)
+    for s in range(0, expected, step):
+        l, r = li[s:s + step].long(), ri[s:s + step].long()
+        assert bool((probe[l] == build[r]).all())
+        assert bool(pok[l].all()) and bool(bok[r].all())
+        seen[l] = True
+    assert int(seen.sum()) == expected                              # every pair names a different probe row
+
+
 @pytest.mark.parametrize("hit", [0.0, 0.05, 0.3, 0.44])
 @pytest.mark.parametrize("size", ["small", "large"])
 def test_selective_inner_join_single_pass_then_compaction(gdf, hit, size, force_path):

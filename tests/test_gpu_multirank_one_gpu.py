@@ -16,190 +16,27 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 
-def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+from multirank_common import _free_port, _uneven_worker, _worker, check_join_and_group_by, check_uneven
 
 
-def _stage_through_host():
-    """gloo moves host tensors: wrap the collectives multigpu.py uses so that device tensors take a detour."""
-    from libgdf_amd import multigpu
-    a2a, allred, allgat = dist.all_to_all_single, dist.all_reduce, dist.all_gather_into_tensor
-
-    def all_gather_into_tensor(out, inp, group=None):
-        o = torch.empty(out.shape, dtype=out.dtype)
-        allgat(o, inp.cpu(), group=group)
-        out.copy_(o)
-
-    def all_to_all_single(out, inp, group=None):
-        o = torch.empty(out.shape, dtype=out.dtype)
-        a2a(o, inp.cpu(), group=group)
-        out.copy_(o)
-
-    def all_reduce(t, op=dist.ReduceOp.SUM, group=None):
-        c = t.cpu()
-        allred(c, op=op, group=group)
-        t.copy_(c)
-
-    def all_to_all_v(recv, send, recv_split, send_split, group, async_op):
-        world, me = dist.get_world_size(group), dist.get_rank(group)
-        hs, hr = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)
-        ops, so, ro = [], 0, 0
-        for r in range(world):
-            ns, nr = int(send_split[r]), int(recv_split[r])
-            if r == me:
-                hr[ro:ro + nr].copy_(hs[so:so + ns])
-            else:
-                if ns:
-                    ops.append(dist.P2POp(dist.isend, hs[so:so + ns], r, group))
-                if nr:
-                    ops.append(dist.P2POp(dist.irecv, hr[ro:ro + nr], r, group))
-            so += ns
-            ro += nr
-        for w in (dist.batch_isend_irecv(ops) if ops else []):
-            w.wait()
-        recv.copy_(hr)
-        return []
-
-    dist.all_to_all_single, dist.all_reduce, multigpu._all_to_all_v = all_to_all_single, all_reduce, all_to_all_v
-    dist.all_gather_into_tensor = all_gather_into_tensor
-
-
-def _shards(world, big):
-    rs = np.random.RandomState(77)
-    npr, nb = (6_000_000, 1_200_000) if big else (30_000, 4_000)
-    space = nb * world * 5 // 4
-    builds = [rs.permutation(space)[: nb + 13 * r].astype(np.int64) * world + r for r in range(world)]      # disjoint key sets per rank
-    probes = [rs.randint(0, space * world, size=npr + 101 * r).astype(np.int64) for r in range(world)]
-    return probes, builds
-
-
-def _worker(rank, world, port, big, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.cuda.set_device(0)
-    from libgdf_amd import multigpu
-    _stage_through_host()
-    probes, builds = _shards(world, big)
-    p = torch.from_numpy(probes[rank]).cuda()
-    b = torch.from_numpy(builds[rank]).cuda()
-    pairs = multigpu.distributed_inner_join(p, b)
-    pg, bg = pairs.global_ids()
-    bpairs = multigpu.broadcast_inner_join(p, b)
-    bpg, bbg = bpairs.global_ids()
-    # the fused variant (sender-side level 1, receiver continues at level 2): None on ALL ranks when the shape does not fit
-    fpairs = multigpu.fused_inner_join(p, b)
-    fpg, fbg = fpairs.global_ids() if fpairs is not None else (None, None)
-    # group-by-sum of (key % 1000, key): local pre-aggregation, exchange of the partial sums, final aggregation
-    gk, gv = multigpu.distributed_group_by_sum(p % 1000, p)
-    others = {}
-    for op in ("min", "max", "count", "avg"):
-        ok, ov = multigpu.distributed_group_by(op, p % 1000, p)
-        others[op] = (ok.cpu().numpy(), ov.cpu().numpy())
-    q.put((rank, len(pairs.probe_pos), pg.cpu().numpy(), bg.cpu().numpy(), bpg.cpu().numpy(), bbg.cpu().numpy(),
-           gk.cpu().numpy(), gv.cpu().numpy(), others,
-           None if fpg is None else fpg.cpu().numpy(), None if fbg is None else fbg.cpu().numpy()))
-    dist.barrier()
-    dist.destroy_process_group()
-
-
-@pytest.mark.timeout(600)
-@pytest.mark.parametrize("world,big", [(2, False), (3, False), (2, True)])
-def test_device_path_at_world_sizes_2_and_3(world, big):
+def _run_ranks(target, world, extra):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, big, q)) for r in range(world)]
+    procs = [ctx.Process(target=target, args=(r, world, port) + extra + (q,)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=500) for _ in range(world)]
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    probes, builds = _shards(world, big)
-    # expected pairs in global ids: (rank << 40 | row) of every probe row whose key some rank's build relation holds
-    allb = np.concatenate(builds)
-    bid = np.concatenate([(r << 40) + np.arange(len(bk), dtype=np.int64) for r, bk in enumerate(builds)])
-    order = np.argsort(allb)
-    sb, sid = allb[order], bid[order]
-    exp = []
-    for r, pk in enumerate(probes):
-        at = np.searchsorted(sb, pk)
-        at[at == len(sb)] = 0
-        rows = np.flatnonzero(sb[at] == pk)
-        exp.append(np.stack([(r << 40) + rows, sid[at[rows]]], axis=1))
-    exp = np.concatenate(exp)
-    exp = exp[np.lexsort(exp.T[::-1])]
-    for a, b in ((2, 3), (4, 5)):
-        got = np.concatenate([np.stack([res[a], res[b]], axis=1) for res in results])
-        got = got[np.lexsort(got.T[::-1])]
-        np.testing.assert_array_equal(got, exp)
-    assert all(res[9] is not None for res in results)          # these shapes fit the fused path on every rank
-    got = np.concatenate([np.stack([res[9], res[10]], axis=1) for res in results])
-    np.testing.assert_array_equal(got[np.lexsort(got.T[::-1])], exp)
-    if big:
-        assert all(res[1] == 1 for res in results)          # the received slices were accumulated and probed once
-    allp = np.concatenate(probes)
-    sums = np.zeros(1000, dtype=np.int64)
-    np.add.at(sums, allp % 1000, allp)
-    ek = np.unique(allp % 1000)
-    ev = sums[ek]
-    gk = np.concatenate([res[6] for res in results])
-    gv = np.concatenate([res[7] for res in results])
-    order = np.argsort(gk)
-    np.testing.assert_array_equal(gk[order], ek)             # every group on exactly one rank
-    np.testing.assert_array_equal(gv[order], ev)
-    import pandas as pd
-    ref = pd.DataFrame({"k": allp % 1000, "v": allp}).groupby("k")["v"]
-    for op, exp_col in (("min", ref.min()), ("max", ref.max()), ("count", ref.count()), ("avg", ref.mean())):
-        k = np.concatenate([res[8][op][0] for res in results])
-        v = np.concatenate([res[8][op][1] for res in results])
-        o = np.argsort(k)
-        np.testing.assert_array_equal(k[o], exp_col.index.values)
-        if op == "avg":
-            np.testing.assert_allclose(v[o], exp_col.values, rtol=1e-12)
-        else:
-            np.testing.assert_array_equal(v[o], exp_col.values)
+    return results
 
 
-def _uneven_worker(rank, world, port, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.cuda.set_device(0)
-    from libgdf_amd import multigpu
-    _stage_through_host()
-    probes, builds, vals = _uneven_shards(world)
-    p = torch.from_numpy(probes[rank]).cuda()
-    b = torch.from_numpy(builds[rank]).cuda()
-    pairs = multigpu.distributed_inner_join(p, b, chunks=4)
-    pg, bg = pairs.global_ids()
-    t = torch.tensor([rank + 1], dtype=torch.int64, device="cuda")
-    dist.all_reduce(t)                                   # pairs with a stray exchange if a rank ran fewer slices
-    assert int(t) == world * (world + 1) // 2
-    out = {}
-    k = (p % 7)
-    for name, v in vals[rank].items():
-        tv = torch.from_numpy(v).cuda()
-        for op in ("count", "avg"):
-            ok, ov = multigpu.distributed_group_by(op, k, tv)
-            out[(name, op)] = (ok.cpu().numpy(), ov.cpu().numpy())
-    q.put((rank, pg.cpu().numpy(), bg.cpu().numpy(), out))
-    dist.barrier()
-    dist.destroy_process_group()
-
-
-def _uneven_shards(world):
-    rs = np.random.RandomState(5)
-    sizes = [0, 2, 40_000][:world]
-    probes = [(rs.randint(-500, 6000, size=n) + (1 << 35)).astype(np.int64) for n in sizes]     # a fifth outside the build range
-    builds = [(rs.permutation(5000)[: 1500 if r else 0] + (1 << 35)).astype(np.int64) for r in range(world)]
-    # value columns whose partial sums / counts overflow their own dtype: 40000 rows over 7 groups
-    vals = [{"int8": rs.randint(100, 127, size=n).astype(np.int8), "int32": rs.randint(2**30, 2**31 - 1, size=n).astype(np.int32),
-             "float32": (rs.rand(n) * 1e3 + 2**24).astype(np.float32)} for n in sizes]
-    return probes, builds, vals
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world,big", [(2, False), (3, False), (2, True)])
+def test_device_path_at_world_sizes_2_and_3(world, big):
+    check_join_and_group_by(world, big, _run_ranks(_worker, world, (big,)))
 
 
 @pytest.mark.timeout(600)
@@ -207,36 +44,4 @@ def test_uneven_shards_and_narrow_value_dtypes():
     """(high) ranks with 0 and 2 probe rows run as many exchanges as the rank with 40000; (medium) partial
     COUNTs are int64 and the partial SUMs of an AVG are widened, so int8 / int32 / float32 value columns aggregate like
     the single-GPU call; (medium) probe keys outside the build range stay home instead of piling up on one rank."""
-    world = 3
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_uneven_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    results = [q.get(timeout=500) for _ in range(world)]
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
-    probes, builds, vals = _uneven_shards(world)
-    from oracle import oracle
-    gp = np.concatenate([(r << 40) + np.arange(len(probes[r]), dtype=np.int64) for r in range(world)])
-    gb = np.concatenate([(r << 40) + np.arange(len(builds[r]), dtype=np.int64) for r in range(world)])
-    li, ri = oracle.join([np.concatenate(probes)], [np.concatenate(builds)], "inner")
-    exp = np.stack([gp[li], gb[ri]], axis=1)
-    got = np.concatenate([np.stack([r[1], r[2]], axis=1) for r in results])
-    np.testing.assert_array_equal(got[np.lexsort(got.T[::-1])], exp[np.lexsort(exp.T[::-1])])
-    import pandas as pd
-    allk = np.concatenate(probes) % 7
-    for name in ("int8", "int32", "float32"):
-        allv = np.concatenate([v[name] for v in vals])
-        ref = pd.DataFrame({"k": allk, "v": allv.astype(np.float64)}).groupby("k")["v"]
-        for op, exp_col in (("count", ref.count()), ("avg", ref.mean())):
-            k = np.concatenate([r[3][(name, op)][0] for r in results])
-            v = np.concatenate([r[3][(name, op)][1] for r in results])
-            o = np.argsort(k)
-            np.testing.assert_array_equal(k[o], exp_col.index.values)
-            if op == "count":
-                np.testing.assert_array_equal(v[o], exp_col.values)
-            else:
-                np.testing.assert_allclose(v[o], exp_col.values, rtol=1e-6 if name == "float32" else 1e-12)
+    check_uneven(3, _run_ranks(_uneven_worker, 3, ()))

@@ -88,6 +88,13 @@ def _worker(rank, world, port, q):
                                             shuffle_fn=_np_shuffle, join_fn=_np_join, prepare_fn=None)
     pg, bg = pairs.global_ids()
     assert pairs.numel() == pg.numel()
+    # sample_global_ids (bench.py's preflight): a subset of the resolved pairs, and every sampled pair joins equal keys
+    spg, sbg = pairs.sample_global_ids(50)
+    assert 0 < spg.numel() <= pg.numel()
+    have = set(zip(pg.tolist(), bg.tolist()))
+    assert all(pair in have for pair in zip(spg.tolist(), sbg.tolist()))
+    for g_p, g_b in zip(spg.tolist(), sbg.tolist()):
+        assert probes[g_p >> 40][g_p & ((1 << 40) - 1)] == builds[g_b >> 40][g_b & ((1 << 40) - 1)]
     # the broadcast variant must produce the same global pair set (each rank: its own probe rows)
     bpairs = multigpu.broadcast_inner_join(torch.from_numpy(probes[rank]), torch.from_numpy(builds[rank]),
                                            join_fn=_np_join, narrow_fn=_np_narrow)

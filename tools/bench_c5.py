@@ -3,7 +3,9 @@
 keys k0 int64 Zipf(s=1) over 1e6 values x k1 int32 uniform [0,16), through the C ABI with inputs resident in HBM.
 Algorithmic bytes = N * (8 + 4 + 8) + N / 8 (value mask).  Checks size-independent properties of the result
 (group count, sum of counts, sum of avg * count) against torch reductions over the same inputs.
-Usage: python tools/bench_c5.py [--rows N] [--reps R]"""
+--null-keys P: the variant with P (1 %) NULL KEYS -- a validity mask on key column 0; a row with a null key belongs
+to no group (the reference rejects masks altogether, sqls_ops.cu:1103-1106; semantics of DESIGN.md section 4).
+Usage: python tools/bench_c5.py [--rows N] [--reps R] [--null-keys P]"""
 import argparse
 import ctypes as C
 import json
@@ -44,7 +46,31 @@ def make_c5(n, dev, zipf_values=1_000_000):
     return k0, k1, v, ok, mask
 
 
-def c5_property_checks(gdf, k0, k1, v, ok, mask, cap):
+def pack_bits(okb):
+    """bool tensor -> LSB-first mask bytes, padded to a multiple of 64 bytes"""
+    import torch
+    n = okb.numel()
+    pad = (-n) % 8
+    bits = torch.cat([okb, torch.zeros(pad, dtype=torch.bool, device=okb.device)]).view(-1, 8).to(torch.uint8)
+    weights = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.uint8, device=okb.device)
+    mask = (bits * weights).sum(dim=1, dtype=torch.int32).to(torch.uint8)
+    return torch.cat([mask, torch.zeros((-mask.numel()) % 64, dtype=torch.uint8, device=okb.device)])
+
+
+def null_key_mask(n, dev, p):
+    """key validity: a row's key 0 is null with probability p -> (bool tensor, mask bytes)"""
+    import torch
+    from bench import splitmix64_torch
+    kok = torch.empty(n, dtype=torch.bool, device=dev)
+    step = 1 << 26
+    for s in range(0, n, step):
+        e = min(n, s + step)
+        u = (splitmix64_torch(torch.arange(s, e, dtype=torch.int64, device=dev) + 0x5EED0009) >> 11) & ((1 << 53) - 1)
+        kok[s:e] = u >= int((1 << 53) * p)
+    return kok, pack_bits(kok)
+
+
+def c5_property_checks(gdf, k0, k1, v, ok, mask, cap, kok=None, kmask=None):
     """Size-independent properties of gdf_group_by_avg / _count over the C5 relation (what a 1e9-row run can be held to):
     group count = number of distinct key pairs, AVG output sorted by key, AVG and COUNT name the same groups, the counts
     add up to the number of valid values, a group is null exactly when its count is 0, and sum(avg * count) = sum of
@@ -52,8 +78,10 @@ def c5_property_checks(gdf, k0, k1, v, ok, mask, cap):
     import torch
     from libgdf_amd.columns import Column
     n = k0.numel()
-    kc = [Column(k0), Column(k1)]
+    kc = [Column(k0, kmask, null_count=int(n - kok.sum().item())) if kok is not None else Column(k0), Column(k1)]
     vc = Column(v, mask, null_count=int(n - ok.sum().item()))
+    if kok is not None:                      # rows with a null key belong to no group: the expectations are taken over the others
+        k0, k1, v, ok = k0[kok], k1[kok], v[kok], ok[kok]
     gk, avg, avg_ok = gdf.api.group_by("avg", kc, vc, out_dtype=6, capacity=cap, with_masks=True)
     ck, cnt, _ = gdf.api.group_by("count", kc, vc, out_dtype=4, capacity=cap, with_masks=True)
     pk_avg = gk[0] * 16 + gk[1].long()
@@ -83,6 +111,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=1_000_000_000)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--null-keys", type=float, default=0.0)
     a = ap.parse_args()
     import torch
     import libgdf_amd as gdf
@@ -94,10 +123,13 @@ def main():
     dev = torch.device("cuda", 0)
     n = a.rows
     k0, k1, v, ok, mask = make_c5(n, dev)
-    kc = [Column(k0), Column(k1)]
+    kok = kmask = None
+    if a.null_keys > 0:
+        kok, kmask = null_key_mask(n, dev, a.null_keys)
+    kc = [Column(k0, kmask, null_count=int(n - kok.sum().item())) if kok is not None else Column(k0), Column(k1)]
     vc = Column(v, mask, null_count=int(n - ok.sum().item()))
     cap = 20_000_000
-    alg = n * 20.0 + n / 8.0
+    alg = n * 20.0 + n / 8.0 + (n / 8.0 if kok is not None else 0.0)
 
     # the timed region is the C call alone: outputs are preallocated once (capacity rows + masks), as a caller would
     from libgdf_amd.columns import column_array, new_context
@@ -116,8 +148,9 @@ def main():
     lib.gdf_amd_profile_enable(0)
     prof = read_profile(gdf)
     del ok0, ok1, oagg
-    checks, good = c5_property_checks(gdf, k0, k1, v, ok, mask, cap)
-    print(json.dumps({"op": "C5 gdf_group_by_avg (int64 Zipf x int32) keys, fp64 values, 50% null", "rows": n, "ms": dt * 1e3,
+    checks, good = c5_property_checks(gdf, k0, k1, v, ok, mask, cap, kok, kmask)
+    print(json.dumps({"op": "C5 gdf_group_by_avg (int64 Zipf x int32) keys, fp64 values, 50% null" + (f", {a.null_keys:g} null keys" if kok is not None else ""),
+                      "rows": n, "ms": dt * 1e3,
                       "rows_per_s": n / dt, "algorithmic_GBps": alg / dt / 1e9, "frac_of_8TBps": alg / dt / 8e12,
                       "kernels_ms": {k: round(x[0] / a.reps, 3) for k, x in prof.items()}, "checks": checks, "checks_pass": good}))
     sys.exit(0 if good else 1)

@@ -72,6 +72,40 @@ def main():
     build = make_build_keys(nb, 0x5EED0001, dev)
     probe = make_probe_keys(npr, nb, 0x5EED0002, dev)
     timed("c3_headline", lambda: join(probe, build), jb(npr, nb), npr, "int64 keys in [0, 1e8): NARROW tuples, histogram-free probe layout, optimistic write pass")
+    # 0a. C3 variant B: validity masks on BOTH key columns -- all ones (same pairs as the headline; + 2 x ceil(N / 8)
+    # bytes of mask reads) and Bernoulli(0.99) on both sides (98 % of the probe rows find a valid partner)
+    def packed_mask(n, seed, p_null):
+        ok = torch.ones(n, dtype=torch.bool, device=dev)
+        if p_null > 0:
+            step = 1 << 27
+            for s in range(0, n, step):
+                e = min(n, s + step)
+                u = (splitmix64_torch(torch.arange(s, e, dtype=torch.int64, device=dev) + seed) >> 11) & ((1 << 53) - 1)
+                ok[s:e] = u >= int((1 << 53) * p_null)
+        pad = (-n) % 8
+        bits = torch.cat([ok, torch.zeros(pad, dtype=torch.bool, device=dev)]) if pad else ok
+        weights = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.uint8, device=dev)
+        packed = torch.empty((n + 7) // 8, dtype=torch.uint8, device=dev)
+        step = 1 << 27
+        for s in range(0, packed.numel(), step):
+            e = min(packed.numel(), s + step)
+            packed[s:e] = (bits[8 * s:8 * e].view(-1, 8).to(torch.uint8) * weights).sum(dim=1, dtype=torch.uint8)
+        return packed, int(n - ok.sum())
+
+    def join_masked(pm, pn, bm, bn):
+        li, ri = gdf.api.join([Column(probe, pm, null_count=pn)], [Column(build, bm, null_count=bn)], how="inner", copy=False)
+        n = li.numel() if hasattr(li, "numel") else int(li.size)
+        del li, ri
+        return n
+    jbm = lambda out: 8.0 * npr + 8.0 * nb + 8.0 * out + (npr + 7) // 8 + (nb + 7) // 8
+    for name, p_null, note in (("c3_masked", 0.0, "C3 variant B: ALL-ONES validity masks on both key columns (paired data + mask reads; bytes = headline + 2 x ceil(N / 8))"),
+                               ("c3_masked_99pct_valid", 0.01, "the same with Bernoulli(0.99) masks on both sides: 98 % of the probe rows join")):
+        if only and name not in only:
+            continue
+        pm, pn = packed_mask(npr, 0x5EED0072, p_null)
+        bm, bn = packed_mask(nb, 0x5EED0071, p_null)
+        timed(name, lambda: join_masked(pm, pn, bm, bn), jbm, npr, note)
+        del pm, bm
     # 0b. the same join with result_cols: [probe payload, key, build payload] materialised (joining.cu:375-479)
     def join_materialise():
         from libgdf_amd import gdf_column, libgdf, new_context
@@ -98,6 +132,9 @@ def main():
     timed("c3_half_hit", lambda: join(probe_half, build), jb(npr, nb), npr, "probe keys in [0, 2e8): 50 % hit rate -> sample rejects the optimistic pass: count + write")
     timed("c3_left_half_hit", lambda: join(probe_half, build, how="left"), jb(npr, nb), npr, "the same as a LEFT join: unmatched probe rows emit (l, -1)")
     del probe_half
+    probe_80 = make_probe_keys(npr, nb + nb // 4, 0x5EED0014, dev)
+    timed("c3_80pct_hit", lambda: join(probe_80, build), jb(npr, nb), npr, "probe keys in [0, 1.25e8): 80 % hit rate")
+    del probe_80
     probe_tenth = make_probe_keys(npr, 10 * nb, 0x5EED0013, dev)
     timed("c3_tenth_hit", lambda: join(probe_tenth, build), jb(npr, nb), npr, "probe keys in [0, 1e9): 10 % hit rate -> one optimistic write pass into per-unit slots + compaction of the pair list")
     del probe_tenth

@@ -349,9 +349,15 @@ struct PartGeom {
 };
 
 // NARROW: w[i] = key32 << 32 | row, idx unused.  WIDE: w[i] = key64, idx[i] = row.
+// pay (NARROW probe sides of a join that materialises result_cols, see PayCarry): pay[i] = the row's PAYLOAD word -- the
+// probe relation's non-key column(s) travel through the regroup passes next to their tuple, as a parallel array (the way WIDE
+// tuples carry their row numbers), so that the probe kernel writes them out streaming instead of a later gather fetching
+// one random 64-byte sector per 8-byte value (C3: 1e9 of them, 55 ms).  Kernels that only need keys (count pass, sample,
+// cuckoo build) never touch it.
 struct Tuples {
   uint64_t *w;
   int32_t *idx;
+  uint64_t *pay;
 };
 template <bool NARROW>
 __device__ __forceinline__ uint64_t tup_key(uint64_t w) { return NARROW ? (w >> 32) : w; }
@@ -476,10 +482,11 @@ __global__ __launch_bounds__(256) void jk_sample_skew(const void *col, int64_t n
 //   phase C: LDS position j goes to global base[bin(j)] + (j - start[bin(j)]), so a
 //            wave writes runs of consecutive addresses.
 // ---------------------------------------------------------------------------
-template <bool NARROW, int THREADS>
+template <bool NARROW, int THREADS, bool PAY = false, int ITEMS = JK_SC_ITEMS>
 struct TileLds {
-  uint64_t w[THREADS * JK_SC_ITEMS + 2];                  // + a trash slot: tuples that do not travel are written there
-  int32_t idx[NARROW ? 4 : THREADS * JK_SC_ITEMS + 4];
+  uint64_t w[THREADS * ITEMS + 2];                        // + a trash slot: tuples that do not travel are written there
+  int32_t idx[NARROW ? 4 : THREADS * ITEMS + 4];
+  uint64_t pay[PAY ? THREADS * ITEMS + 2 : 2];            // payload words, regrouped with their tuples
   uint32_t hist[256 + 4];                                 // + a trash counter, same reason (never zeroed, never read)
   uint32_t start[256];
   uint32_t gbase[256];    // (global base - start[bin]) mod 2^32; destinations are < 2^31
@@ -490,8 +497,8 @@ struct TileLds {
 };
 
 // block-wide exclusive scan of hist[0..nbins) (nbins <= 256 == blockDim) into start[]
-template <bool NARROW, int THREADS>
-__device__ __forceinline__ void tile_scan_bins(TileLds<NARROW, THREADS> &s, uint32_t nbins, uint32_t tid) {
+template <bool NARROW, int THREADS, bool PAY, int ITEMS>
+__device__ __forceinline__ void tile_scan_bins(TileLds<NARROW, THREADS, PAY, ITEMS> &s, uint32_t nbins, uint32_t tid) {
   const uint32_t v = tid < nbins ? s.hist[tid] : 0;
   const uint32_t incl = wave_scan_incl(v);
   if (lane_id() == WAVE - 1) s.wave_tot[tid / WAVE] = incl;
@@ -505,8 +512,8 @@ __device__ __forceinline__ void tile_scan_bins(TileLds<NARROW, THREADS> &s, uint
   if (tid < nbins) s.start[tid] = woff + incl - v;
   if (tid == 0) s.total = tot;
 }
-template <bool NARROW, int THREADS>
-__device__ __forceinline__ void tile_scan_bins(TileLds<NARROW, THREADS> &s, uint32_t nbins) {
+template <bool NARROW, int THREADS, bool PAY, int ITEMS>
+__device__ __forceinline__ void tile_scan_bins(TileLds<NARROW, THREADS, PAY, ITEMS> &s, uint32_t nbins) {
   tile_scan_bins(s, nbins, threadIdx.x);
 }
 // threadIdx.x through an opaque move: addresses derived from the result cannot be hoisted out of the enclosing loop
@@ -519,19 +526,20 @@ __device__ __forceinline__ uint32_t opaque_tid() {
 }
 
 // phase C: write the regrouped tile out.  LEVEL1 bins are the coarse id, LEVEL2 the sub id.
-template <bool LEVEL1, bool NARROW, int THREADS>
-__device__ __forceinline__ void tile_flush(TileLds<NARROW, THREADS> &s, const PartGeom &g, Tuples out) {
+template <bool LEVEL1, bool NARROW, int THREADS, bool PAY>
+__device__ __forceinline__ void tile_flush(TileLds<NARROW, THREADS, PAY> &s, const PartGeom &g, Tuples out) {
   const uint32_t total = s.total;
   const uint32_t submask = (1u << g.b2) - 1;
   constexpr int U = 4;
   for (uint32_t j0 = threadIdx.x; j0 < total; j0 += THREADS * U) {
-    uint64_t ww[U];
+    uint64_t ww[U], pp[U];
     int32_t ii[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const uint32_t j = j0 + u * THREADS;
       ww[u] = j < total ? s.w[j] : 0;
       ii[u] = (!NARROW && j < total) ? s.idx[j] : 0;
+      pp[u] = (PAY && j < total) ? s.pay[j] : 0;
     }
     uint32_t dst[U];
 #pragma unroll
@@ -547,6 +555,7 @@ __device__ __forceinline__ void tile_flush(TileLds<NARROW, THREADS> &s, const Pa
         if (LAB_BITS(g.dbg) & 16) __builtin_nontemporal_store(ww[u], out.w + dst[u]);      // experiment: streaming stores (level 2)
         else out.w[dst[u]] = ww[u];
         if (!NARROW) out.idx[dst[u]] = ii[u];
+        if (PAY) out.pay[dst[u]] = pp[u];
       }
     }
   }
@@ -754,6 +763,161 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
   }
 }
 
+// 2b. level-1 scatter of a probe side that CARRIES A PAYLOAD (Tuples::pay, PayCarry): one FAST key column without a mask,
+// NARROW tuples, and per row one 64-bit payload word read from the relation's non-key column(s) in the same pass --
+//   PMODE 1: one 8-byte column; 2: one 4-byte column (zero-extended); 3: two 4-byte columns (column 0 in the low half).
+// The same phases as jk_scatter1 (rank | scan + claim | regroup in LDS | flush, next tile's words prefetched before the
+// flush) on 8192-tuple tiles: the tile holds 16 bytes per tuple, and key + payload + their prefetch registers of 8 items
+// fit the 128 VGPRs of a 1024-thread workgroup.  Tuples and payload words leave as two parallel streams of 256-byte runs.
+struct PaySrc { const void *col[2]; };
+constexpr int JK_PAY_ITEMS = 8;
+constexpr int JK_PAY_THREADS = 1024;
+template <int FAST, int PMODE>
+__global__ __launch_bounds__(JK_PAY_THREADS) void jk_scatter1_pay(KeyTable t, KeyPlan plan, PartGeom g, const uint32_t *__restrict__ H1off,
+                                                                  PaySrc ps, Tuples out) {
+  constexpr int THREADS = JK_PAY_THREADS, ITEMS = JK_PAY_ITEMS;
+  using Tile = TileLds<true, THREADS, true, ITEMS>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
+  Tile &s = *reinterpret_cast<Tile *>(tile_raw);
+  constexpr int TILE = THREADS * ITEMS;
+  const int chunk = blockIdx.x;
+  const uint32_t ncoarse = 1u << g.b1;
+  if (!g.cap1 && threadIdx.x < ncoarse) s.cursor[threadIdx.x] = H1off[(size_t)threadIdx.x * g.nchunks + chunk];
+  const uint32_t begin = (uint32_t)((int64_t)chunk * g.chunk);
+  const uint32_t end = (int64_t)begin + g.chunk < t.nrows ? (uint32_t)(begin + g.chunk) : (uint32_t)t.nrows;
+  auto item_row = [](int k, uint32_t tid) -> uint32_t { return 2u * ((uint32_t)(k >> 1) * THREADS + tid) + (k & 1); };
+  uint64_t nxt[ITEMS];                                   // raw key words of the next tile
+  uint64_t nxp[PMODE == 1 ? ITEMS : 1];                  // raw payload words, 8-byte column
+  uint32_t nxa[PMODE != 1 ? ITEMS : 1];                  // 4-byte column 0
+  uint32_t nxb[PMODE == 3 ? ITEMS : 1];                  // 4-byte column 1
+  const void *col = t.col[0].data;
+  auto prefetch = [&](uint32_t tile) {
+    const uint32_t tid = opaque_tid();
+#pragma unroll
+    for (int k = 0; k < ITEMS; k += 2) {
+      const uint32_t i = tile + item_row(k, tid);
+      const int64_t at = (int64_t)(i + 2 <= end ? i : end - 2);
+      fast_pair<FAST>(col, at, nxt[k], nxt[k + 1]);
+      if (PMODE == 1) fast_pair<8>(ps.col[0], at, nxp[k], nxp[k + 1]);
+      else {
+        uint64_t a0, a1;
+        fast_pair<4>(ps.col[0], at, a0, a1);
+        nxa[k] = (uint32_t)a0; nxa[k + 1] = (uint32_t)a1;
+        if (PMODE == 3) {
+          uint64_t b0, b1;
+          fast_pair<4>(ps.col[1], at, b0, b1);
+          nxb[k] = (uint32_t)b0; nxb[k + 1] = (uint32_t)b1;
+        }
+      }
+    }
+  };
+  prefetch(begin);
+  if (threadIdx.x < 256) s.hist[threadIdx.x] = 0;
+  block_sync();
+  uint32_t key[ITEMS];
+  uint64_t pay[ITEMS];
+  uint32_t okmask = 0;
+  auto consume = [&](uint32_t tile) {
+    const uint32_t tid = opaque_tid();
+    okmask = 0;
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+      const bool second = (k & 1) == 0 && tile + item_row(k, tid) + 1 == end;       // the pair was read one row early (prefetch)
+      uint64_t raw = second ? nxt[k + 1] : nxt[k];
+      const bool joinable = plan.mode != KM_RAW_FLOAT || fast_float_word<FAST>(raw);
+      const uint64_t k64 = raw - plan.kmin;
+      key[k] = (uint32_t)k64;
+      okmask |= (uint32_t)(joinable && (tile + item_row(k, tid) < end) && (k64 >> 32) == 0) << k;
+      if (PMODE == 1) pay[k] = second ? nxp[k + 1] : nxp[k];
+      else if (PMODE == 2) pay[k] = second ? nxa[k + 1] : nxa[k];
+      else pay[k] = (uint64_t)(second ? nxa[k + 1] : nxa[k]) | ((uint64_t)(second ? nxb[k + 1] : nxb[k]) << 32);
+    }
+  };
+  consume(begin);
+  for (uint32_t tile = begin; tile < end; tile += TILE) {
+    uint32_t binrank[ITEMS];                    // bin << 16 | rank within (tile, bin); bin 256 = does not travel
+#pragma unroll
+    for (int h = 0; h < ITEMS; h += 4) {
+#pragma unroll
+      for (int k = h; k < h + 4; ++k) {
+        const uint32_t b = fine_of((uint64_t)key[k] + g.kbias, g.fb) >> g.b2;
+        binrank[k] = (okmask >> k) & 1u ? b : 256u;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) binrank[k] = (binrank[k] << 16) | atomicAdd(&s.hist[binrank[k]], 1u);
+    block_sync();
+    {
+      const uint32_t tid = opaque_tid();
+      uint32_t base = 0;
+      if (g.cap1 && tid < ncoarse) {
+        const uint32_t cnt = s.hist[tid];
+        if (cnt) base = atomicAdd(&g.spec_cursor1[(tid << g.xs) | (blockIdx.x & ((1u << g.xs) - 1u))], cnt);
+      }
+      tile_scan_bins(s, ncoarse, tid);
+      block_sync();
+      if (tid < ncoarse) {
+        if (g.cap1) {
+          const uint32_t cnt = s.hist[tid];
+          const uint32_t region = (tid << g.xs) | (blockIdx.x & ((1u << g.xs) - 1u));
+          if (base + cnt > g.cap1) { atomicExch(g.spec_flag, 1u); s.gbase[tid] = g.dump - s.start[tid]; }
+          else s.gbase[tid] = region * g.cap1 + base - s.start[tid];
+        } else {
+          s.gbase[tid] = s.cursor[tid] - s.start[tid];
+          s.cursor[tid] += s.hist[tid];
+        }
+      }
+      if (tid < 256) s.hist[tid] = 0;
+      if (g.cap1 && tid == 0) s.total_abort = __hip_atomic_load(g.spec_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const uint32_t wtid = opaque_tid();
+    {
+      uint32_t st[ITEMS];
+#pragma unroll
+      for (int k = 0; k < ITEMS; ++k) st[k] = s.start[(binrank[k] >> 16) & 255u];
+#pragma unroll
+      for (int k = 0; k < ITEMS; ++k) {
+        const uint32_t pos = (okmask >> k) & 1u ? st[k] + (binrank[k] & 0xffffu) : (uint32_t)TILE;
+        const int32_t row = g.row_base + (int32_t)(tile + item_row(k, wtid));
+        s.w[pos] = ((uint64_t)key[k] << 32) | (uint32_t)row;
+        s.pay[pos] = pay[k];
+      }
+    }
+    const bool more = tile + TILE < end;
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) prefetch(tile + TILE);
+    block_sync();
+    if (g.cap1 && s.total_abort) return;
+    const uint32_t total = s.total;
+    const uint32_t ftid = opaque_tid();
+    constexpr int GROUP = 4;
+#pragma unroll
+    for (int h = 0; h < ITEMS / GROUP; ++h) {
+      uint64_t ww[GROUP], pp[GROUP];
+      uint32_t gb[GROUP];
+#pragma unroll
+      for (int k = 0; k < GROUP; ++k) {
+        const uint32_t j = ftid + (h * GROUP + k) * THREADS;
+        ww[k] = s.w[j];
+        pp[k] = s.pay[j];
+      }
+#pragma unroll
+      for (int k = 0; k < GROUP; ++k) gb[k] = s.gbase[(fine_of((ww[k] >> 32) + g.kbias, g.fb) >> g.b2) & 255u];
+#pragma unroll
+      for (int k = 0; k < GROUP; ++k) {
+        const uint32_t j = ftid + (h * GROUP + k) * THREADS;
+        const uint32_t dst = j < total ? gb[k] + j : g.dump + ftid;
+        out.w[dst] = ww[k];
+        out.pay[dst] = pp[k];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    consume(tile + TILE);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // 3. level-2 scatter: tuples of one coarse partition -> fine partitions.  A tile
 // never crosses a coarse boundary; bins claim their global range with one
 // atomicAdd per (tile, non-empty bin) on the fine cursors.
@@ -773,11 +937,11 @@ struct Level2Map {                     // small host-built tables, device reside
   const uint32_t *keys32;              // non-null: the input is this array of 4-byte keys (a receive buffer), tuple = key << 32 | position
 };
 
-template <bool NARROW, int THREADS>
+template <bool NARROW, int THREADS, bool PAY = false>
 __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, Tuples in,
                                                              uint32_t *__restrict__ fine_cursor, Tuples out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
-  TileLds<NARROW, THREADS> &s = *reinterpret_cast<TileLds<NARROW, THREADS> *>(tile_raw);
+  TileLds<NARROW, THREADS, PAY> &s = *reinterpret_cast<TileLds<NARROW, THREADS, PAY> *>(tile_raw);
   constexpr int JK_TILE = THREADS * JK_SC_ITEMS;
   const uint32_t ncoarse = 1u << g.b1, nsub = 1u << g.b2;
   // locate the coarse partition that owns this tile (binary search over <= 257 entries)
@@ -802,7 +966,7 @@ __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, 
   block_sync();
   // straight-line phases as in jk_scatter1: tuples beyond the tile's end are ranked on a trash counter (bin 256) and
   // written to the trash slot of the LDS tile instead of being skipped by a branch per item
-  uint64_t w[JK_SC_ITEMS];
+  uint64_t w[JK_SC_ITEMS], pay[PAY ? JK_SC_ITEMS : 1];
   int32_t idx[JK_SC_ITEMS];
 #pragma unroll
   for (int k = 0; k < JK_SC_ITEMS; ++k) {         // all loads first
@@ -811,6 +975,7 @@ __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, 
     if (NARROW && m.keys32) w[k] = ((uint64_t)m.keys32[ic] << 32) | (uint32_t)(g.row_base + (int32_t)ic);      // workgroup-uniform branch
     else w[k] = in.w[ic];                             // (non-temporal loads, which help jk_scatter1, cost 2 % here)
     idx[k] = NARROW ? 0 : in.idx[ic];
+    if (PAY) pay[k] = in.pay[ic];
   }
   uint32_t binrank[JK_SC_ITEMS];
 #pragma unroll
@@ -844,10 +1009,11 @@ __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, 
       const uint32_t pos = (binrank[h + k] >> 24) ? (uint32_t)JK_TILE : st[k] + (binrank[h + k] & 0xffffu);
       s.w[pos] = w[h + k];
       if (!NARROW) s.idx[pos] = idx[h + k];
+      if (PAY) s.pay[pos] = pay[h + k];
     }
   }
   block_sync();
-  tile_flush<false, NARROW, THREADS>(s, g, out);
+  tile_flush<false, NARROW, THREADS, PAY>(s, g, out);
 }
 
 // ---------------------------------------------------------------------------
@@ -986,7 +1152,21 @@ struct ProbeArgs {
   const unsigned long long *nunits_dev;
   uint32_t *unit_pairs;          // optimistic WRITE pass, non-null: unit u leaves the number of pairs it wrote here (sparse mode:
                                  // the host compacts the units' slot ranges afterwards, see jk_compact_units)
+  // carried payload (PayCarry): pay_mode != 0 -> every pair's probe-side payload column value(s) go to pay_out[c][pos].
+  // jk_probe_fast<PMODE> takes them from the payload word next to the probe tuple (probe.pay); the general kernels, which
+  // see only the few units the lean kernel left over (and oversize partitions), fetch them from the source columns by row
+  int pay_mode;                  // 0: none; 1: one 8-byte column; 2: one 4-byte column; 3: two 4-byte columns
+  const void *pay_src[2];
+  void *pay_out[2];
 };
+// the general kernels' payload write: a gather by probe row (rare units only)
+__device__ __forceinline__ void pay_gather(const ProbeArgs &a, unsigned long long pos, int32_t prow) {
+  if (a.pay_mode == 1) ((uint64_t *)a.pay_out[0])[pos] = ((const uint64_t *)a.pay_src[0])[prow];
+  else if (a.pay_mode) {
+    ((uint32_t *)a.pay_out[0])[pos] = ((const uint32_t *)a.pay_src[0])[prow];
+    if (a.pay_mode == 3) ((uint32_t *)a.pay_out[1])[pos] = ((const uint32_t *)a.pay_src[1])[prow];
+  }
+}
 
 // LDS image of one work unit's build partition (dynamic region, every carve 16-byte aligned):
 //   bw[cap]   build tuples staged linearly from HBM (position p = index inside the partition);
@@ -1230,19 +1410,23 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
         } else if (pad) {
           a.out_probe[pos] = prow[b];
           a.out_build[pos] = JK_EMPTY;
+          pay_gather(a, pos, prow[b]);
         } else if (c >= 1 && (cuckoo || c == 1)) {
           if (LAB_BITS(a.dbg) & 32) continue;                  // experiment: no output stores
           a.out_probe[pos] = prow[b];
           a.out_build[pos] = build_row<NARROW>(l, hit_a[b]);
+          pay_gather(a, pos, prow[b]);
           if (c == 2) {
             a.out_probe[pos + 1] = prow[b];
             a.out_build[pos + 1] = build_row<NARROW>(l, hit_b[b]);
+            pay_gather(a, pos + 1, prow[b]);
           }
         } else if (c > 1) {      // multimap mode with several matches: walk the key's chain again
           for (uint32_t p = hit_b[b]; p != JK_NOPOS; p = l.next[p]) {
             if (!a.verify || rows_equal(probe_t, prow[b], build_t, build_row<NARROW>(l, p))) {
               a.out_probe[pos] = prow[b];
               a.out_build[pos] = build_row<NARROW>(l, p);
+              pay_gather(a, pos, prow[b]);
               ++pos;
             }
           }
@@ -1285,7 +1469,9 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
 // NARROW = false: the same lean pass over WIDE tuples (exact 64-bit keys: one 8-byte integer / float column, or several
 // columns packed into 64 bits) -- keys spread over more than 2^32 used to take the general kernel at 8.9 ms per 1e9 probe
 // tuples (profiles/r2_b_bench_shapes.jsonl, c3_wide_keys).
-template <bool POW2, bool KEEP, bool NARROW>
+// PMODE != 0 (NARROW only): the probe tuples carry a payload word (Tuples::pay) and every pair writes its column value(s)
+// next to its index pair -- the streaming replacement of the probe-side gather of a materialising join.
+template <bool POW2, bool KEEP, bool NARROW, int PMODE = 0>
 __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_fast(ProbeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const uint32_t H = a.nslots, cap = a.cap;
@@ -1365,17 +1551,26 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_fast(ProbeArgs a) {
   const uint32_t lead = u.probe_begin & 1u;
   const uint64_t *__restrict__ src = a.probe.w + (u.probe_begin - lead);
   const int32_t *__restrict__ src_row = NARROW ? nullptr : a.probe.idx + (u.probe_begin - lead);
+  const uint64_t *__restrict__ src_pay = PMODE ? a.probe.pay + (u.probe_begin - lead) : nullptr;
+  uint64_t *__restrict__ po8 = PMODE == 1 ? (uint64_t *)a.pay_out[0] + unit_base : nullptr;
+  uint32_t *__restrict__ po4a = PMODE >= 2 ? (uint32_t *)a.pay_out[0] + unit_base : nullptr;
+  uint32_t *__restrict__ po4b = PMODE == 3 ? (uint32_t *)a.pay_out[1] + unit_base : nullptr;
   const uint32_t vtotal = lead + u.probe_count;
   const uint32_t last_pair = (vtotal - 1) & ~1u;
   for (uint32_t base = 0; base < vtotal; base += JK_PROBE_THREADS * NB) {
     Key key[NB];
     uint32_t prow[NB];
+    uint64_t pay[PMODE ? NB : 1];
     bool act[NB];
 #pragma unroll
     for (int b = 0; b < JK_PROBE_BATCH; ++b) {      // all HBM loads first, 16 bytes each (WIDE: + 8 bytes of row numbers), clamped and unconditional
       const uint32_t v = base + (b * JK_PROBE_THREADS + threadIdx.x) * 2;
       const uint32_t vc = v < last_pair ? v : last_pair;
       const ulonglong2 ww = *reinterpret_cast<const ulonglong2 *>(src + vc);
+      if constexpr (PMODE != 0) {
+        const ulonglong2 pp = *reinterpret_cast<const ulonglong2 *>(src_pay + vc);
+        pay[2 * b] = pp.x; pay[2 * b + 1] = pp.y;
+      }
       if constexpr (NARROW) {
         key[2 * b] = (uint32_t)(ww.x >> 32); prow[2 * b] = (uint32_t)ww.x;
         key[2 * b + 1] = (uint32_t)(ww.y >> 32); prow[2 * b + 1] = (uint32_t)ww.y;
@@ -1421,6 +1616,9 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_fast(ProbeArgs a) {
         op[pos] = (int32_t)prow[b];
         ob[pos] = pad ? JK_EMPTY : (ha ? ra : rb);
         if (c == 2) { op[pos + 1] = (int32_t)prow[b]; ob[pos + 1] = rb; }
+        if constexpr (PMODE == 1) { po8[pos] = pay[b]; if (c == 2) po8[pos + 1] = pay[b]; }
+        if constexpr (PMODE >= 2) { po4a[pos] = (uint32_t)pay[b]; if (c == 2) po4a[pos + 1] = (uint32_t)pay[b]; }
+        if constexpr (PMODE == 3) { po4b[pos] = (uint32_t)(pay[b] >> 32); if (c == 2) po4b[pos + 1] = (uint32_t)(pay[b] >> 32); }
       }
     };
     if (__all((hamask & hbmask) == 0) && !(LAB_BITS(a.dbg) & 2048)) {      // (GDF_JK_DBG=2048: one claim per tuple, as before)
@@ -1480,11 +1678,30 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_fast(ProbeArgs a) {
 __global__ __launch_bounds__(256) void jk_widen_counts(const uint32_t *__restrict__ in, uint64_t *__restrict__ out, uint32_t n) {
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i <= n; i += gridDim.x * 256) out[i] = i < n ? in[i] : 0;      // n + 1 entries
 }
+// (a carried payload column moves with its pairs: W = its element width, 0 = none)
+template <class T>
+__device__ __forceinline__ void compact_column(const void *src, void *dst, uint64_t from, uint64_t to, uint32_t n) {
+  const T *s = (const T *)src + from;
+  T *d = (T *)dst + to;
+  for (uint32_t i = threadIdx.x; i < n; i += 256 * 4) {
+    T v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = i + k * 256 < n ? s[i + k * 256] : T(0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (i + k * 256 < n) d[i + k * 256] = v[k];
+  }
+}
+struct PayMove { int mode; const void *src[2]; void *dst[2]; };
 __global__ __launch_bounds__(256) void jk_compact_units(const uint64_t *__restrict__ slot_off, const uint64_t *__restrict__ pair_off,
                                                         const int32_t *__restrict__ sp, const int32_t *__restrict__ sb,
-                                                        int32_t *__restrict__ dp, int32_t *__restrict__ db) {
+                                                        int32_t *__restrict__ dp, int32_t *__restrict__ db, PayMove pm) {
   const uint64_t from = slot_off[blockIdx.x], to = pair_off[blockIdx.x];
   const uint32_t n = (uint32_t)(pair_off[blockIdx.x + 1] - to);
+  if (pm.mode == 1) compact_column<uint64_t>(pm.src[0], pm.dst[0], from, to, n);
+  else if (pm.mode) {
+    compact_column<uint32_t>(pm.src[0], pm.dst[0], from, to, n);
+    if (pm.mode == 3) compact_column<uint32_t>(pm.src[1], pm.dst[1], from, to, n);
+  }
   for (uint32_t i = threadIdx.x; i < n; i += 256 * 4) {
     int32_t vp[4], vb[4];
 #pragma unroll
@@ -1581,12 +1798,14 @@ __global__ void gj_probe(ProbeArgs a, KeyTable probe_t, KeyTable build_t, const 
       if (pad) {
         a.out_probe[pos] = prow;
         a.out_build[pos] = JK_EMPTY;
+        pay_gather(a, pos, prow);
       } else if (cnt) {
         for (int32_t p = head; p >= 0; p = next[p]) {
           const int32_t r = build_row_at(p);
           if (!a.verify || rows_equal(probe_t, prow, build_t, r)) {
             a.out_probe[pos] = prow;
             a.out_build[pos] = r;
+            pay_gather(a, pos, prow);
             ++pos;
           }
         }
@@ -1635,8 +1854,9 @@ __device__ __forceinline__ void tile_claim(const bool (&flag)[JK_TAIL_ITEMS], un
   block_sync();                           // the LDS words are reused by the next tile
 }
 
+// pm (LEFT joins that carry a payload): the tail rows' payload values, read by row -- they leave in row order
 __global__ __launch_bounds__(256) void jk_emit_unjoinable(KeyTable t, KeyPlan plan, int32_t *out_row, int32_t *out_none,
-                                                          unsigned long long *cursor) {
+                                                          unsigned long long *cursor, PayMove pm) {
   constexpr int64_t TILE = 256 * JK_TAIL_ITEMS;
   for (int64_t tile = (int64_t)blockIdx.x * TILE; tile < t.nrows; tile += (int64_t)gridDim.x * TILE) {
     bool emit[JK_TAIL_ITEMS];
@@ -1651,8 +1871,14 @@ __global__ __launch_bounds__(256) void jk_emit_unjoinable(KeyTable t, KeyPlan pl
 #pragma unroll
     for (int k = 0; k < JK_TAIL_ITEMS; ++k)
       if (emit[k]) {
-        out_row[pos[k]] = (int32_t)(tile + k * 256 + threadIdx.x);
+        const int64_t row = tile + k * 256 + threadIdx.x;
+        out_row[pos[k]] = (int32_t)row;
         out_none[pos[k]] = JK_EMPTY;
+        if (pm.mode == 1) ((uint64_t *)pm.dst[0])[pos[k]] = ((const uint64_t *)pm.src[0])[row];
+        else if (pm.mode) {
+          ((uint32_t *)pm.dst[0])[pos[k]] = ((const uint32_t *)pm.src[0])[row];
+          if (pm.mode == 3) ((uint32_t *)pm.dst[1])[pos[k]] = ((const uint32_t *)pm.src[1])[row];
+        }
       }
   }
 }
@@ -1699,8 +1925,20 @@ enum JoinKind { JOIN_INNER, JOIN_LEFT, JOIN_FULL };
 constexpr gdf_error GDF_AMD_RETRY_WITHOUT_LEVEL3 = (gdf_error)31;     // above every code of gdf_error
 constexpr gdf_error GDF_AMD_RETRY_EXACT_PROBE = (gdf_error)30;        // probe_partitioned: the deferred probe side overflowed
 
+// A join that materialises result_cols may CARRY the probe relation's non-key column(s) through the partition passes as one
+// 64-bit payload word per row (Tuples::pay) instead of gathering them afterwards -- set up by join_entry, honoured by
+// probe_prepared when the join runs on NARROW tuples with exact keys from one FAST, unmasked key column (INNER / LEFT).
+struct PayCarry {
+  int mode = 0;                        // 1: one 8-byte column; 2: one 4-byte column; 3: two 4-byte columns
+  const void *src[2] = {nullptr, nullptr};
+  void *dst[2] = {nullptr, nullptr};   // OUT: rmm allocations of *out_n elements each, the caller's to free -- set iff carried
+  bool carried = false;                // OUT
+  int elem_bytes(int c) const { return mode == 1 ? 8 : 4; }
+  int ncols() const { return mode == 3 ? 2 : (mode ? 1 : 0); }
+};
+
 struct SideBufs {            // partitioned tuples of one relation
-  DevBuf w[2], idx[2];
+  DevBuf w[2], idx[2], pay[2];
   int final_buf = 0;         // which ping-pong buffer holds the fine-partitioned tuples
   std::vector<uint32_t> fine_off;   // [nfine+1] on the host; EXACT layout only (partitions are contiguous)
   std::vector<uint32_t> fine_begin, fine_cnt;   // [nfine] first tuple / tuple count of every fine partition, both layouts
@@ -1717,7 +1955,7 @@ struct SideBufs {            // partitioned tuples of one relation
   DevBuf d_map;              // the level-2 segment map jk_scatter2 may still be reading
   // device copies of fine_begin / fine_cnt (build side: uploaded once by prepare_build for jk_make_units)
   DevBuf d_begin, d_cnt;
-  Tuples tuples(int b) const { return Tuples{w[b].as<uint64_t>(), idx[b].as<int32_t>()}; }
+  Tuples tuples(int b) const { return Tuples{w[b].as<uint64_t>(), idx[b].as<int32_t>(), pay[b].as<uint64_t>()}; }
   Tuples final() const { return tuples(final_buf); }
 };
 
@@ -1794,6 +2032,16 @@ static gdf_error launch_scatter2_t(uint32_t ntiles, const PartGeom &g, Level2Map
 }
 static gdf_error launch_scatter2(bool narrow, int threads, uint32_t ntiles, const PartGeom &g, Level2Map m, Tuples in,
                                  uint32_t *cursor, Tuples out) {
+  if (narrow && in.pay) {            // a probe side that carries its payload words (PayCarry): the production tile size only
+    const size_t lds = sizeof(TileLds<true, 256, true>);
+    HIP_TRY(hipFuncSetAttribute((const void *)jk_scatter2<true, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    m.ntiles = ntiles;
+    m.xcd_order = (ntiles >= 64 && !lab::path_on("GDF_JK_NO_XCD_ORDER")) ? 1 : 0;
+    const uint32_t grid = m.xcd_order ? ((ntiles + 7) / 8) * 8 : ntiles;
+    GDF_LAUNCH("jk_scatter2", (jk_scatter2<true, 256, true>), dim3(grid), dim3(256), lds, stream0(), g, m, in, cursor, out);
+    HIP_CHECK_LAST();
+    return GDF_SUCCESS;
+  }
   if (narrow) {
     if (threads == 1024) return launch_scatter2_t<true, 1024>(ntiles, g, m, in, cursor, out);
     if (threads == 512) return launch_scatter2_t<true, 512>(ntiles, g, m, in, cursor, out);
@@ -1810,13 +2058,31 @@ static gdf_error launch_scatter2(bool narrow, int threads, uint32_t ntiles, cons
 // partition is written from one XCD (jk_scatter2), the partial lines of its short (tile, bin) runs merge in that L2.
 // Measured on C3, jk_scatter2 with 1024 / 512 / 256 threads: 3.6 / 3.3 / 3.2 ms.  Level 1 goes the other way
 // (3.7 vs 4.2 ms with 512 threads): its claims sit in a tile loop, it keeps one big tile per CU.
+// level-1 scatter of a payload-carrying probe side (jk_scatter1_pay)
+static gdf_error launch_scatter1_pay(int fast, int pmode, const KeyTable &t, const KeyPlan &plan, const PartGeom &g, const uint32_t *H1off,
+                                     const PaySrc &ps, Tuples out) {
+  const size_t lds = sizeof(TileLds<true, JK_PAY_THREADS, true, JK_PAY_ITEMS>);
+#define JK_PAY_LAUNCH(F, M)                                                                                                   \
+  do {                                                                                                                        \
+    HIP_TRY(hipFuncSetAttribute((const void *)jk_scatter1_pay<F, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    GDF_LAUNCH("jk_scatter1", (jk_scatter1_pay<F, M>), dim3(g.nchunks), dim3(JK_PAY_THREADS), lds, stream0(), t, plan, g, H1off, ps, out); \
+  } while (0)
+  if (fast == 8) { if (pmode == 1) JK_PAY_LAUNCH(8, 1); else if (pmode == 2) JK_PAY_LAUNCH(8, 2); else JK_PAY_LAUNCH(8, 3); }
+  else { if (pmode == 1) JK_PAY_LAUNCH(4, 1); else if (pmode == 2) JK_PAY_LAUNCH(4, 2); else JK_PAY_LAUNCH(4, 3); }
+#undef JK_PAY_LAUNCH
+  HIP_CHECK_LAST();
+  return GDF_SUCCESS;
+}
+
 static int level2_threads(int sc_threads) {
   const int env = (int)lab::knob_int("GDF_JK_SC2_THREADS", 0);
   if (env == 256 || env == 512 || env == 1024) return env < sc_threads ? env : sc_threads;
   return sc_threads > 256 ? 256 : sc_threads;
 }
 
-static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, SideBufs *sb, bool decide_narrow) {
+// pay (may be null) + pmode: the relation carries a payload word per row (PayCarry); NARROW tuples and a FAST key column only
+static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, SideBufs *sb, bool decide_narrow, const PaySrc *pay = nullptr,
+                                int pmode = 0) {
   const int64_t n = t.nrows;
   bool narrow = plan.narrow != 0;
   // Chunks are SMALL (a few tiles) and processed in blockIdx order, so that the workgroups resident at
@@ -1888,15 +2154,17 @@ static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, Si
   int sc_threads = sc_threads_env ? sc_threads_env : (narrow ? 1024 : 512);   // swept on C3: profiles/r1_c_sweeps.md
   if (sc_threads != 256 && sc_threads != 512 && sc_threads != 1024) sc_threads = 256;
   if (!narrow && sc_threads == 1024) sc_threads = 512;       // 16384 x 12 B would not fit 160 KiB
-  const int sc2_threads = level2_threads(sc_threads);
+  const int sc2_threads = pay ? 256 : level2_threads(sc_threads);
   const int64_t JK_TILE2 = (int64_t)sc2_threads * JK_SC_ITEMS;
 
   // + 2: the probe kernel's last 16-byte load may touch one tuple past the end; + 1024: jk_scatter1's per-thread dump slots
   g.dump = (uint32_t)(cap + 2);
   RMM_TRY(sb->w[0].alloc(sizeof(uint64_t) * (cap + 2 + 1024)));
   if (!narrow) RMM_TRY(sb->idx[0].alloc(sizeof(int32_t) * (cap + 2 + 1024)));
+  if (pay) RMM_TRY(sb->pay[0].alloc(sizeof(uint64_t) * (cap + 2 + 1024)));
   const Tuples t0 = sb->tuples(0);
-  GDF_TRY(launch_scatter1(fast, narrow, sc_threads, t, plan, g, H1.as<uint32_t>(), t0));
+  if (pay) GDF_TRY(launch_scatter1_pay(fast, pmode, t, plan, g, H1.as<uint32_t>(), *pay, t0));
+  else GDF_TRY(launch_scatter1(fast, narrow, sc_threads, t, plan, g, H1.as<uint32_t>(), t0));
   HIP_CHECK_LAST();
   sb->final_buf = 0;
   if (g.b2 > 0 && sb->joinable > 0) {
@@ -1916,12 +2184,14 @@ static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, Si
     HIP_TRY(hipMemcpyAsync(cursor.p, sb->fine_off.data(), sizeof(uint32_t) * nfine, hipMemcpyHostToDevice, stream0()));
     RMM_TRY(sb->w[1].alloc(sizeof(uint64_t) * (cap + 2)));
     if (!narrow) RMM_TRY(sb->idx[1].alloc(sizeof(int32_t) * (cap + 2)));     // + 2: the lean probe kernel reads row numbers in pairs
+    if (pay) RMM_TRY(sb->pay[1].alloc(sizeof(uint64_t) * (cap + 2)));
     Level2Map m{d_coarse.as<uint32_t>(), d_coarse.as<uint32_t>() + 1, d_tiles.as<uint32_t>()};
     if (ntiles) GDF_TRY(launch_scatter2(narrow, sc2_threads, ntiles, g, m, sb->tuples(0), cursor.as<uint32_t>(), sb->tuples(1)));
     HIP_CHECK_LAST();
     HIP_TRY(hipStreamSynchronize(stream0()));   // host vectors + scratch go out of scope
     sb->w[0].reset();
     sb->idx[0].reset();
+    sb->pay[0].reset();
     sb->final_buf = 1;
   } else {
     HIP_TRY(hipStreamSynchronize(stream0()));
@@ -1946,7 +2216,7 @@ struct SpecAppend {
 };
 
 static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, PartGeom g, double dup, SideBufs *sb, bool *ok,
-                                     SpecAppend *app = nullptr, bool defer = false) {
+                                     SpecAppend *app = nullptr, bool defer = false, const PaySrc *pay = nullptr, int pmode = 0) {
   *ok = false;
   if (app) g.row_base = (int32_t)app->rows;
   const int64_t n = t.nrows;
@@ -1966,7 +2236,7 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
   if (sc_threads != 256 && sc_threads != 512 && sc_threads != 1024) sc_threads = 256;
   if (!narrow && sc_threads == 1024) sc_threads = 512;
   const int64_t JK_TILE = (int64_t)sc_threads * JK_SC_ITEMS;
-  const int sc2_threads = level2_threads(sc_threads);
+  const int sc2_threads = pay ? 256 : level2_threads(sc_threads);
   const int64_t JK_TILE2 = (int64_t)sc2_threads * JK_SC_ITEMS;
   auto room = [dup](double mean, uint32_t align) {
     const double c = mean + 8.0 * std::sqrt(mean * (1.0 + dup)) + 64.0;
@@ -1991,7 +2261,9 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
   g.spec_flag = spec.as<uint32_t>() + nseg;
   RMM_TRY(sb->w[0].alloc(sizeof(uint64_t) * size1));
   if (!narrow) RMM_TRY(sb->idx[0].alloc(sizeof(int32_t) * size1));
-  GDF_TRY(launch_scatter1(fast, narrow, sc_threads, t, plan, g, nullptr, sb->tuples(0)));
+  if (pay) RMM_TRY(sb->pay[0].alloc(sizeof(uint64_t) * size1));
+  if (pay) GDF_TRY(launch_scatter1_pay(fast, pmode, t, plan, g, nullptr, *pay, sb->tuples(0)));
+  else GDF_TRY(launch_scatter1(fast, narrow, sc_threads, t, plan, g, nullptr, sb->tuples(0)));
   if (defer && !app && g.b2 > 0) {
     // DEFERRED: the level-2 map and the fill cursors are made on the device, nothing is read back here; the overflow flags
     // of both levels are looked at once, with the work units (jk_make_units / probe_partitioned)
@@ -2006,6 +2278,7 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
     HIP_CHECK_LAST();
     RMM_TRY(sb->w[1].alloc(sizeof(uint64_t) * size2));
     if (!narrow) RMM_TRY(sb->idx[1].alloc(sizeof(int32_t) * size2));
+    if (pay) RMM_TRY(sb->pay[1].alloc(sizeof(uint64_t) * size2));
     PartGeom g2 = g;
     g2.cap2 = cap2;
     g2.dump = nfine * cap2;
@@ -2061,6 +2334,7 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
       cur.pop_back();
       RMM_TRY(sb->w[1].alloc(sizeof(uint64_t) * size2));
       if (!narrow) RMM_TRY(sb->idx[1].alloc(sizeof(int32_t) * size2));
+      if (pay) RMM_TRY(sb->pay[1].alloc(sizeof(uint64_t) * size2));
       if (app) app->started = true;
     }
     PartGeom g2 = g;
@@ -2080,6 +2354,7 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
     }
     sb->w[0].reset();
     sb->idx[0].reset();
+    sb->pay[0].reset();
     if (flag) return GDF_SUCCESS;
     if (app) {                          // the fill counters are read once, by spec_append_finish
       app->rows += n;
@@ -2159,13 +2434,21 @@ static gdf_error run_write_pass(bool narrow, bool plain, size_t nunits, size_t l
     fa.nslots = ((uint32_t)(max_build * 1.25) + 63) & ~63u;
     flds = probe_lds_bytes(narrow, a.cap, fa.nslots, false);
   }
-#define JK_FAST_LAUNCH(P2, KP, NW)                                                                                               \
+#define JK_FAST_LAUNCH(...)                                                                                                      \
   do {                                                                                                                           \
-    HIP_TRY(hipFuncSetAttribute((const void *)jk_probe_fast<P2, KP, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds)); \
-    GDF_LAUNCH("jk_probe_write", (jk_probe_fast<P2, KP, NW>), dim3((unsigned)nunits), dim3(JK_PROBE_THREADS), flds, stream0(), fa); \
+    HIP_TRY(hipFuncSetAttribute((const void *)jk_probe_fast<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds)); \
+    GDF_LAUNCH("jk_probe_write", (jk_probe_fast<__VA_ARGS__>), dim3((unsigned)nunits), dim3(JK_PROBE_THREADS), flds, stream0(), fa); \
   } while (0)
   const bool keep = a.keep_unmatched_probe != 0;
-  if (narrow) {
+  if (narrow && a.pay_mode) {
+#define JK_FAST_PAY(M)                                                                                                             \
+  do {                                                                                                                             \
+    if (pow2 && keep) JK_FAST_LAUNCH(true, true, true, M); else if (pow2) JK_FAST_LAUNCH(true, false, true, M);                    \
+    else if (keep) JK_FAST_LAUNCH(false, true, true, M); else JK_FAST_LAUNCH(false, false, true, M);                                \
+  } while (0)
+    if (a.pay_mode == 1) JK_FAST_PAY(1); else if (a.pay_mode == 2) JK_FAST_PAY(2); else JK_FAST_PAY(3);
+#undef JK_FAST_PAY
+  } else if (narrow) {
     if (pow2 && keep) JK_FAST_LAUNCH(true, true, true);
     else if (pow2) JK_FAST_LAUNCH(true, false, true);
     else if (keep) JK_FAST_LAUNCH(false, true, true);
@@ -2213,7 +2496,7 @@ static gdf_error refine_side(const PartGeom &g, bool narrow, double dup, SideBuf
   const uint64_t nfine3 = (uint64_t)nseg << g.b3;
   const int64_t n = sb->joinable;
   if (n == 0) return GDF_SUCCESS;
-  const int threads = level2_threads(narrow ? 1024 : 512);
+  const int threads = sb->pay[sb->final_buf].p ? 256 : level2_threads(narrow ? 1024 : 512);
   const int64_t TILE = (int64_t)threads * JK_SC_ITEMS;
   const double mean = (double)n / (double)nfine3;
   const uint32_t cap3 = (uint32_t)(((uint64_t)(mean + 8.0 * std::sqrt(mean * (1.0 + dup)) + 64.0) + 7) / 8 * 8);
@@ -2228,13 +2511,15 @@ static gdf_error refine_side(const PartGeom &g, bool narrow, double dup, SideBuf
   }
   for (uint64_t f = 0; f < nfine3; ++f) cur[f] = (uint32_t)(f * cap3);
   const uint32_t ntiles = tile_prefix[nseg];
-  DevBuf d_seg, d_tiles, cursor, flag, nw, nidx;
+  DevBuf d_seg, d_tiles, cursor, flag, nw, nidx, npay;
+  const bool carries = sb->pay[sb->final_buf].p != nullptr;
   RMM_TRY(d_seg.alloc(sizeof(uint32_t) * 2 * nseg));
   RMM_TRY(d_tiles.alloc(sizeof(uint32_t) * ((size_t)nseg + 1)));
   RMM_TRY(cursor.alloc(sizeof(uint32_t) * nfine3));
   RMM_TRY(flag.alloc(sizeof(uint32_t)));
   RMM_TRY(nw.alloc(sizeof(uint64_t) * size3));
   if (!narrow) RMM_TRY(nidx.alloc(sizeof(int32_t) * size3));
+  if (carries) RMM_TRY(npay.alloc(sizeof(uint64_t) * size3));
   HIP_TRY(hipMemcpyAsync(d_seg.p, seg.data(), sizeof(uint32_t) * 2 * nseg, hipMemcpyHostToDevice, stream0()));
   HIP_TRY(hipMemcpyAsync(d_tiles.p, tile_prefix.data(), sizeof(uint32_t) * ((size_t)nseg + 1), hipMemcpyHostToDevice, stream0()));
   HIP_TRY(hipMemcpyAsync(cursor.p, cur.data(), sizeof(uint32_t) * nfine3, hipMemcpyHostToDevice, stream0()));
@@ -2249,7 +2534,7 @@ static gdf_error refine_side(const PartGeom &g, bool narrow, double dup, SideBuf
   g3.spec_flag = flag.as<uint32_t>();
   g3.xs = 0;
   Level2Map m{d_seg.as<uint32_t>(), d_seg.as<uint32_t>() + nseg, d_tiles.as<uint32_t>(), 0};
-  if (ntiles) GDF_TRY(launch_scatter2(narrow, threads, ntiles, g3, m, sb->final(), cursor.as<uint32_t>(), Tuples{nw.as<uint64_t>(), nidx.as<int32_t>()}));
+  if (ntiles) GDF_TRY(launch_scatter2(narrow, threads, ntiles, g3, m, sb->final(), cursor.as<uint32_t>(), Tuples{nw.as<uint64_t>(), nidx.as<int32_t>(), npay.as<uint64_t>()}));
   uint32_t overflow = 0;
   HIP_TRY(read_back(cur.data(), cursor.p, sizeof(uint32_t) * nfine3));
   HIP_TRY(read_back(&overflow, flag.p, sizeof(uint32_t)));
@@ -2257,9 +2542,10 @@ static gdf_error refine_side(const PartGeom &g, bool narrow, double dup, SideBuf
   (void)nsub;
   // commit: the refined tuples replace the level-2 ones
   const int o = sb->final_buf ^ 1;
-  sb->w[0].reset(); sb->w[1].reset(); sb->idx[0].reset(); sb->idx[1].reset();
+  sb->w[0].reset(); sb->w[1].reset(); sb->idx[0].reset(); sb->idx[1].reset(); sb->pay[0].reset(); sb->pay[1].reset();
   sb->w[o].p = nw.release();
   if (!narrow) sb->idx[o].p = nidx.release();
+  if (carries) sb->pay[o].p = npay.release();
   sb->final_buf = o;
   sb->fine_off.clear();
   sb->fine_begin.resize(nfine3);
@@ -2346,10 +2632,10 @@ static gdf_error prepare_build(const KeyTable &build_t, BuildSide *bs, bool no_l
 }
 
 static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &build_t, const BuildSide &bs, SideBufs &P, JoinKind kind,
-                                   int32_t **out_probe, int32_t **out_build, int64_t *out_n, StageClock &clk);
+                                   int32_t **out_probe, int32_t **out_build, int64_t *out_n, StageClock &clk, PayCarry *pc = nullptr);
 
 static gdf_error probe_prepared(const KeyTable &probe_t, const KeyTable &build_t, const BuildSide &bs, JoinKind kind,
-                                int32_t **out_probe, int32_t **out_build, int64_t *out_n, StageClock &clk) {
+                                int32_t **out_probe, int32_t **out_build, int64_t *out_n, StageClock &clk, PayCarry *pc = nullptr) {
   const KeyPlan &plan = bs.plan;
   const PartGeom &g = bs.g;
   const SideBufs &B = bs.B;
@@ -2385,13 +2671,21 @@ static gdf_error probe_prepared(const KeyTable &probe_t, const KeyTable &build_t
   // the main path -- two-level speculative probe side, every build partition in LDS, no FULL-join marks -- keeps its
   // bookkeeping on the device (see jk_make_units)
   const bool defer = g.b2 > 0 && g.b3 == 0 && kind != JOIN_FULL && B.d_cnt.p != nullptr && !lab::knob_on("GDF_JK_NO_DEFER");
+  // the probe relation's payload column(s) ride along (PayCarry) when the join runs on NARROW tuples with exact keys from
+  // one FAST, unmasked key column; everything else leaves pc->carried false and the caller gathers as before
+  PaySrc pay_src{};
+  const bool carry = pc && pc->mode && plan.narrow && !plan.verify && probe_fast && !probe_t.col[0].valid && kind != JOIN_FULL &&
+                     !lab::path_on("GDF_JK_NO_CARRY");
+  if (carry) { pay_src.col[0] = pc->src[0]; pay_src.col[1] = pc->src[1]; }
+  const PaySrc *pay = carry ? &pay_src : nullptr;
+  const int pmode = carry ? pc->mode : 0;
   if (!skew && g.fb > 0 && probe_t.nrows >= spec_min && largest_build <= (uint32_t)JK_MAX_BUILD && !lab::path_on("GDF_JK_NO_SPEC"))
     GDF_TRY(partition_side_spec(probe_t, plan, g, std::max(1.0, (double)probe_t.nrows / std::max<uint32_t>(B.joinable, 1)), &P, &spec_ok,
-                                nullptr, defer));
+                                nullptr, defer, pay, pmode));
   if (!spec_ok) {
-    P.w[0].reset(); P.w[1].reset(); P.idx[0].reset(); P.idx[1].reset();
+    P.w[0].reset(); P.w[1].reset(); P.idx[0].reset(); P.idx[1].reset(); P.pay[0].reset(); P.pay[1].reset();
     KeyPlan probe_plan = plan;             // partition_side only rewrites the plan when asked to decide the format
-    GDF_TRY(partition_side(probe_t, probe_plan, g, &P, false));
+    GDF_TRY(partition_side(probe_t, probe_plan, g, &P, false, pay, pmode));
   }
   const bool narrow = plan.narrow != 0;
   if (g.b3 > 0) {
@@ -2400,18 +2694,18 @@ static gdf_error probe_prepared(const KeyTable &probe_t, const KeyTable &build_t
     if (!ok) return GDF_AMD_RETRY_WITHOUT_LEVEL3;     // skewed probe keys: the caller repeats with a 2^fb-partition build side
   }
   clk.mark("partition probe side");
-  gdf_error e = probe_partitioned(probe_t, build_t, bs, P, kind, out_probe, out_build, out_n, clk);
+  gdf_error e = probe_partitioned(probe_t, build_t, bs, P, kind, out_probe, out_build, out_n, clk, carry ? pc : nullptr);
   if (e != GDF_AMD_RETRY_EXACT_PROBE) return e;
   // a deferred speculative probe side turned out to have overflowed (skewed keys): the exact layout, host bookkeeping
   SideBufs Q;
   KeyPlan probe_plan = plan;
-  GDF_TRY(partition_side(probe_t, probe_plan, g, &Q, false));
-  return probe_partitioned(probe_t, build_t, bs, Q, kind, out_probe, out_build, out_n, clk);
+  GDF_TRY(partition_side(probe_t, probe_plan, g, &Q, false, pay, pmode));
+  return probe_partitioned(probe_t, build_t, bs, Q, kind, out_probe, out_build, out_n, clk, carry ? pc : nullptr);
 }
 
 // the part of a join after both relations are partitioned: work units, optimistic single pass or count + write, tails
 static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &build_t, const BuildSide &bs, SideBufs &P, JoinKind kind,
-                                   int32_t **out_probe, int32_t **out_build, int64_t *out_n, StageClock &clk) {
+                                   int32_t **out_probe, int32_t **out_build, int64_t *out_n, StageClock &clk, PayCarry *pc) {
   const KeyPlan &plan = bs.plan;
   const PartGeom &g = bs.g;
   const SideBufs &B = bs.B;
@@ -2474,6 +2768,31 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
     RMM_TRY(d_matched.alloc((size_t)(build_t.nrows ? build_t.nrows : 1)));
     HIP_TRY(hipMemsetAsync(d_matched.p, 0, (size_t)(build_t.nrows ? build_t.nrows : 1), stream0()));
   }
+
+  // carried payload: the output columns, sized when the pair count is known
+  DevBuf pay_out[2];
+  auto alloc_pay = [&](uint64_t total) -> gdf_error {
+    if (!pc) return GDF_SUCCESS;
+    for (int c = 0; c < pc->ncols(); ++c) RMM_TRY(pay_out[c].alloc((size_t)pc->elem_bytes(c) * (size_t)(total ? total : 1)));
+    return GDF_SUCCESS;
+  };
+  auto set_pay = [&](ProbeArgs &x) {
+    if (!pc) return;
+    x.pay_mode = pc->mode;
+    for (int c = 0; c < 2; ++c) { x.pay_src[c] = pc->src[c]; x.pay_out[c] = pay_out[c].p; }
+  };
+  auto pay_move_at = [&](uint64_t first) -> PayMove {        // the payload columns from output position `first` on, filled from the source by row
+    PayMove pm{};
+    if (!pc) return pm;
+    pm.mode = pc->mode;
+    for (int c = 0; c < pc->ncols(); ++c) { pm.src[c] = pc->src[c]; pm.dst[c] = pay_out[c].as<char>() + first * (uint64_t)pc->elem_bytes(c); }
+    return pm;
+  };
+  auto commit_pay = [&]() {
+    if (!pc) return;
+    for (int c = 0; c < pc->ncols(); ++c) pc->dst[c] = pay_out[c].release();
+    pc->carried = true;
+  };
 
   ProbeArgs a{};
   a.build = B.final();
@@ -2577,8 +2896,10 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
     DevBuf op, ob;
     RMM_TRY(op.alloc(sizeof(int32_t) * (total ? total : 1)));
     RMM_TRY(ob.alloc(sizeof(int32_t) * (total ? total : 1)));
+    GDF_TRY(alloc_pay(total));
 
     ProbeArgs oa = a;
+    set_pay(oa);
     oa.counts = d_off.as<uint64_t>();
     oa.out_probe = op.as<int32_t>();
     oa.out_build = ob.as<int32_t>();
@@ -2598,7 +2919,7 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
     if (st[1] == 0 && st[0] == cap_pairs) {       // dense: every slot of every unit was written
       if (probe_tail) {
         GDF_LAUNCH("jk_emit_unjoinable", jk_emit_unjoinable, dim3(small_grid(probe_t.nrows)), dim3(256), 0, stream0(), probe_t, plan,
-                           oa.out_probe + cap_pairs, oa.out_build + cap_pairs, d_tail.as<unsigned long long>());
+                           oa.out_probe + cap_pairs, oa.out_build + cap_pairs, d_tail.as<unsigned long long>(), pay_move_at(cap_pairs));
         HIP_CHECK_LAST();
       }
       HIP_TRY(hipStreamSynchronize(stream0()));
@@ -2606,6 +2927,7 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
       if (total == 0) { *out_probe = nullptr; *out_build = nullptr; return GDF_SUCCESS; }
       *out_probe = (int32_t *)op.release();
       *out_build = (int32_t *)ob.release();
+      commit_pay();
       return GDF_SUCCESS;
     }
     if (try_sparse && st[1] == 0) {               // no unit ran out of slots: close the holes
@@ -2619,16 +2941,29 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
       GDF_TRY(scan_u64(d_poff.as<uint64_t>(), d_poff.as<uint64_t>(), nunits + 1, false));
       RMM_TRY(fp.alloc(sizeof(int32_t) * pairs));
       RMM_TRY(fb.alloc(sizeof(int32_t) * pairs));
+      DevBuf dense_pay[2];
+      PayMove pm{};
+      if (pc) {
+        pm.mode = pc->mode;
+        for (int c = 0; c < pc->ncols(); ++c) {
+          RMM_TRY(dense_pay[c].alloc((size_t)pc->elem_bytes(c) * pairs));
+          pm.src[c] = pay_out[c].p;
+          pm.dst[c] = dense_pay[c].p;
+        }
+      }
       GDF_LAUNCH("jk_compact_units", jk_compact_units, dim3((unsigned)nunits), dim3(256), 0, stream0(), (const uint64_t *)d_off.as<uint64_t>(),
                  (const uint64_t *)d_poff.as<uint64_t>(), (const int32_t *)op.as<int32_t>(), (const int32_t *)ob.as<int32_t>(), fp.as<int32_t>(),
-                 fb.as<int32_t>());
+                 fb.as<int32_t>(), pm);
       HIP_CHECK_LAST();
       HIP_TRY(hipStreamSynchronize(stream0()));
       clk.mark("compaction");
       *out_probe = (int32_t *)fp.release();
       *out_build = (int32_t *)fb.release();
+      if (pc) for (int c = 0; c < pc->ncols(); ++c) { pay_out[c].reset(); pay_out[c].p = dense_pay[c].release(); }
+      commit_pay();
       return GDF_SUCCESS;
     }
+    pay_out[0].reset(); pay_out[1].reset();      // the attempt is discarded: the two-pass path sizes its own columns
     // otherwise: fall through to the exact two-pass path (buffers above are released here)
   }
   const size_t nslots_all = nunits + oversize.size();     // one count slot per LDS unit + one per oversize partition
@@ -2692,6 +3027,8 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
   DevBuf op, ob;
   RMM_TRY(op.alloc(sizeof(int32_t) * total));
   RMM_TRY(ob.alloc(sizeof(int32_t) * total));
+  GDF_TRY(alloc_pay(total));
+  set_pay(a);
   a.out_probe = op.as<int32_t>();
   a.out_build = ob.as<int32_t>();
   a.build_matched = nullptr;   // marks were taken in the count pass
@@ -2722,7 +3059,7 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
   if (probe_tail) {
     unsigned long long *cur = d_tail.as<unsigned long long>();
     GDF_LAUNCH("jk_emit_unjoinable", jk_emit_unjoinable, dim3(small_grid(probe_t.nrows)), dim3(256), 0, stream0(), probe_t, plan,
-                       a.out_probe + matched_total, a.out_build + matched_total, cur);
+                       a.out_probe + matched_total, a.out_build + matched_total, cur, pay_move_at(matched_total));
     HIP_CHECK_LAST();
   }
   if (build_tail) {
@@ -2735,20 +3072,21 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
   HIP_TRY(hipStreamSynchronize(stream0()));
   *out_probe = (int32_t *)op.release();
   *out_build = (int32_t *)ob.release();
+  commit_pay();
   return GDF_SUCCESS;
 }
 
 static gdf_error hash_join_core(const KeyTable &probe_t, const KeyTable &build_t, JoinKind kind, int32_t **out_probe,
-                                int32_t **out_build, int64_t *out_n) {
+                                int32_t **out_build, int64_t *out_n, PayCarry *pc = nullptr) {
   StageClock clk((lab::knob_int("GDF_JK_DBG", 0) & 512) != 0);
   BuildSide bs;
   GDF_TRY(prepare_build(build_t, &bs));
   clk.mark("partition build side");
-  gdf_error e = probe_prepared(probe_t, build_t, bs, kind, out_probe, out_build, out_n, clk);
+  gdf_error e = probe_prepared(probe_t, build_t, bs, kind, out_probe, out_build, out_n, clk, pc);
   if (e != GDF_AMD_RETRY_WITHOUT_LEVEL3) return e;
   BuildSide plain;
   GDF_TRY(prepare_build(build_t, &plain, true));
-  return probe_prepared(probe_t, build_t, plain, kind, out_probe, out_build, out_n, clk);
+  return probe_prepared(probe_t, build_t, plain, kind, out_probe, out_build, out_n, clk, pc);
 }
 
 // FULL join with an empty side (joining.cu:214-280 trivial_full_join): every row of
@@ -2768,8 +3106,10 @@ static gdf_error trivial_full_join(int64_t left_rows, int64_t right_rows, gdf_co
 }
 
 // joining.cu:282-373 join_call: validation + method dispatch
+// pc (may be null): payload columns of the PROBE relation to carry (join_entry decides which relation that is, by the same
+// rule as below); *flipped tells the caller whether the probe relation was the right one
 static gdf_error join_call(JoinKind kind, int num_cols, gdf_column **leftcol, gdf_column **rightcol,
-                           gdf_column *left_result, gdf_column *right_result, gdf_context *ctx) {
+                           gdf_column *left_result, gdf_column *right_result, gdf_context *ctx, PayCarry *pc = nullptr) {
   if (0 == num_cols || nullptr == leftcol || nullptr == rightcol) return GDF_DATASET_EMPTY;
   if (nullptr == ctx) return GDF_INVALID_API_CALL;
   const size_t left_size = leftcol[0]->size, right_size = rightcol[0]->size;
@@ -2827,7 +3167,7 @@ static gdf_error join_call(JoinKind kind, int num_cols, gdf_column **leftcol, gd
   const bool flip = kind == JOIN_INNER && right_size > left_size;
   int32_t *o_probe = nullptr, *o_build = nullptr;
   int64_t n = 0;
-  GDF_TRY(hash_join_core(flip ? rt : lt, flip ? lt : rt, kind, &o_probe, &o_build, &n));
+  GDF_TRY(hash_join_core(flip ? rt : lt, flip ? lt : rt, kind, &o_probe, &o_build, &n, sort_method ? nullptr : pc));
   if (n == 0) return GDF_SUCCESS;   // size-0 outputs with dtype N_GDF_TYPES (join_compute_api.h:439-441)
   gdf_column_view(left_result, flip ? o_build : o_probe, nullptr, (gdf_size_type)n, GDF_INT32);
   gdf_column_view(right_result, flip ? o_probe : o_build, nullptr, (gdf_size_type)n, GDF_INT32);
@@ -2967,11 +3307,48 @@ static gdf_error join_entry(JoinKind kind, gdf_column **left_cols, int num_left_
     lj[i] = left_cols[left_join_cols[i]];
     rj[i] = right_cols[right_join_cols[i]];
   }
-  gdf_error err = join_call(kind, num_cols_to_join, lj.data(), rj.data(), lout, rout, ctx);
+  // ---- payload carrying (PayCarry): when result_cols are wanted and the PROBE relation -- the left one, or the larger one
+  // of an INNER join (join_call's rule) -- has one 8-byte, one 4-byte or two 4-byte non-key columns without masks, their
+  // values travel through the join's partition passes next to the (key, row) tuples and the probe kernel writes the
+  // result columns streaming.  The gather they replace reads one random 64-byte sector per value: 1e9 of them for C3.
+  const int expect = num_left_cols + num_right_cols - num_cols_to_join;
+  PayCarry pc;
+  int carried_col[2] = {-1, -1};       // column numbers in the probe relation
+  bool probe_is_right = false;
+  if (compute_df && result_num_cols == expect && kind != JOIN_FULL && ctx->flag_method == GDF_HASH && num_left_cols > 0 && num_right_cols > 0 &&
+      left_cols[0] && right_cols[0]) {
+    probe_is_right = kind == JOIN_INNER && lj[0] && rj[0] && rj[0]->size > lj[0]->size;
+    gdf_column **pcols = probe_is_right ? right_cols : left_cols;
+    const int npcols = probe_is_right ? num_right_cols : num_left_cols;
+    const int *pkeys = probe_is_right ? right_join_cols : left_join_cols;
+    std::vector<int> nonkey;
+    for (int c = 0; c < npcols; ++c) {
+      bool is_key = false;
+      for (int i = 0; i < num_cols_to_join; ++i) is_key = is_key || pkeys[i] == c;
+      if (!is_key) nonkey.push_back(c);
+    }
+    bool plain = nonkey.size() == 1 || nonkey.size() == 2;
+    int width[2] = {0, 0};
+    for (size_t j = 0; plain && j < nonkey.size(); ++j) {
+      const gdf_column *col = pcols[nonkey[j]];
+      width[j] = col ? dtype_width(col->dtype) : -1;
+      plain = col && col->data && !col->valid && col->size == pcols[pkeys[0]]->size && (width[j] == 8 || width[j] == 4);
+    }
+    if (plain && nonkey.size() == 2 && (width[0] != 4 || width[1] != 4)) plain = false;
+    if (plain) {
+      pc.mode = nonkey.size() == 2 ? 3 : (width[0] == 8 ? 1 : 2);
+      for (size_t j = 0; j < nonkey.size(); ++j) { pc.src[j] = pcols[nonkey[j]]->data; carried_col[j] = nonkey[j]; }
+    }
+  }
+  struct PayFree {     // carried columns that were not handed to result_cols (an error below): released here
+    PayCarry &pc;
+    ~PayFree() { for (int c = 0; c < 2; ++c) if (pc.dst[c]) rmmFree(pc.dst[c], (cudaStream_t)0); }
+  } pay_free{pc};
+
+  gdf_error err = join_call(kind, num_cols_to_join, lj.data(), rj.data(), lout, rout, ctx, pc.mode ? &pc : nullptr);
   if (!compute_df || err != GDF_SUCCESS) return err;
 
   // ---- materialise: [left non-key..., key columns..., right non-key...] ----
-  const int expect = num_left_cols + num_right_cols - num_cols_to_join;
   if (result_num_cols != expect) return GDF_INVALID_API_CALL;
   gdf_nvtx_range_push("LIBGDF_JOIN_OUTPUT", GDF_CYAN);   // joining.cu:391
   struct Pop { ~Pop() { gdf_nvtx_range_pop(); } } pop;
@@ -2984,9 +3361,37 @@ static gdf_error join_entry(JoinKind kind, gdf_column **left_cols, int num_left_
   // the right non-key columns.  Round 1 ran one gather kernel + one stream synchronisation per output column and a
   // second gather + merge pass per FULL-join key column.
   std::vector<GatherJob> left_jobs, right_jobs;
+  // a carried column is complete already: its data came out of the probe kernel, every row of it is valid (no input mask;
+  // the probe row of a pair always exists in an INNER / LEFT join)
+  auto take_carried = [&](bool right_side, int c, gdf_column *dst) -> int {      // 1: taken, 0: not a carried column, < 0: -(error)
+    if (!pc.carried || right_side != probe_is_right) return 0;
+    for (int j = 0; j < pc.ncols(); ++j) {
+      if (carried_col[j] != c) continue;
+      const gdf_column *src = (right_side ? right_cols : left_cols)[c];
+      DevBuf valid;
+      const size_t vbytes = ((mask_bytes((size_t)n) + 7) / 8) * 8;
+      if (valid.alloc(vbytes ? vbytes : 8) != RMM_SUCCESS) return -(int)GDF_MEMORYMANAGER_ERROR;
+      if (hipMemsetAsync(valid.p, 0, vbytes ? vbytes : 8, stream0()) != hipSuccess) return -(int)GDF_CUDA_ERROR;
+      if (n / 8 && hipMemsetAsync(valid.p, 0xff, (size_t)(n / 8), stream0()) != hipSuccess) return -(int)GDF_CUDA_ERROR;
+      if (n % 8) {
+        const uint8_t tail = (uint8_t)((1u << (n % 8)) - 1u);
+        if (hipMemcpy(valid.as<uint8_t>() + n / 8, &tail, 1, hipMemcpyHostToDevice) != hipSuccess) return -(int)GDF_CUDA_ERROR;
+      }
+      gdf_column_view(dst, pc.dst[j], (gdf_valid_type *)valid.release(), (gdf_size_type)n, src->dtype);
+      dst->dtype_info = src->dtype_info;
+      pc.dst[j] = nullptr;                       // owned by the result column now
+      return 1;
+    }
+    return 0;
+  };
   int o = 0;
   for (int c = 0; c < num_left_cols; ++c)
-    if (!l_is_key[c]) left_jobs.push_back(GatherJob{left_cols[c], nullptr, result_cols[o++]});
+    if (!l_is_key[c]) {
+      const int took = take_carried(false, c, result_cols[o]);
+      if (took < 0) return (gdf_error)(-took);
+      if (!took) left_jobs.push_back(GatherJob{left_cols[c], nullptr, result_cols[o]});
+      ++o;
+    }
   // INNER join, integer keys of one dtype: a matched pair's two key values are the same bits, so the key column may be read
   // from EITHER side -- and the rows of the smaller relation are the ones the pair list revisits (all pairs of a build
   // partition are neighbours in the output and name the same few thousand build rows: their gather mostly hits L2, while
@@ -3002,7 +3407,12 @@ static gdf_error join_entry(JoinKind kind, gdf_column **left_cols, int num_left_
     else left_jobs.push_back(GatherJob{lk, kind == JOIN_FULL ? rk : nullptr, result_cols[o++]});
   }
   for (int c = 0; c < num_right_cols; ++c)
-    if (!r_is_key[c]) right_jobs.push_back(GatherJob{right_cols[c], nullptr, result_cols[o++]});
+    if (!r_is_key[c]) {
+      const int took = take_carried(true, c, result_cols[o]);
+      if (took < 0) return (gdf_error)(-took);
+      if (!took) right_jobs.push_back(GatherJob{right_cols[c], nullptr, result_cols[o]});
+      ++o;
+    }
   GDF_TRY(gather_columns(left_jobs, lmap, kind == JOIN_FULL ? rmap : nullptr, n));
   GDF_TRY(gather_columns(right_jobs, rmap, nullptr, n));
   HIP_TRY(hipStreamSynchronize(stream0()));
@@ -3515,7 +3925,7 @@ static gdf_error fj_level2(const uint32_t *keys, const uint32_t *fill, uint32_t 
   m.nseg = nseg;
   m.keys32 = keys;
   const uint32_t tile_bound = (uint32_t)(((uint64_t)nseg * cap) / (uint64_t)TILE2) + nseg + 1;
-  GDF_TRY(launch_scatter2(true, sc2_threads, tile_bound, g2, m, Tuples{nullptr, nullptr}, cursor, out));
+  GDF_TRY(launch_scatter2(true, sc2_threads, tile_bound, g2, m, Tuples{nullptr, nullptr, nullptr}, cursor, out));
   return GDF_SUCCESS;
 }
 

@@ -228,6 +228,95 @@ def test_result_cols_materialisation(gdf, how):
         np.testing.assert_array_equal(d[v], src[b[v]])
 
 
+def _join_with_result_cols(gdf, how, left, lkey, right, rkey):
+    """gdf_{how}_join over numpy columns with result_cols -> (left idx, right idx, [(data, valid bits)] per result column)."""
+    import torch
+    from libgdf_amd import gdf_column, libgdf
+    from libgdf_amd.columns import column_array, new_context
+    L, R = _cols(left), _cols(right)
+    nres = len(left) + len(right) - 1
+    res = [gdf_column() for _ in range(nres)]
+    res_arr = (C.POINTER(gdf_column) * nres)(*[C.pointer(r) for r in res])
+    li, ri = gdf_column(), gdf_column()
+    ctx = new_context()
+    fn = {"inner": libgdf.gdf_inner_join, "left": libgdf.gdf_left_join, "full": libgdf.gdf_full_join}[how]
+    fn(column_array(L), len(left), (C.c_int * 1)(lkey), column_array(R), len(right), (C.c_int * 1)(rkey), 1, nres, res_arr,
+       C.byref(li), C.byref(ri), C.byref(ctx))
+    n = int(li.size)
+    a = gdf.api._take_library_column(li, torch.int32).cpu().numpy() if n else np.zeros(0, np.int32)
+    b = gdf.api._take_library_column(ri, torch.int32).cpu().numpy() if n else np.zeros(0, np.int32)
+    order = [c for i, c in enumerate(left) if i != lkey] + [left[lkey]] + [c for i, c in enumerate(right) if i != rkey]
+    out = []
+    for col, src in zip(res, order):
+        assert int(col.size) == n
+        if n == 0:
+            out.append((np.zeros(0, src.dtype), np.zeros(0, bool)))
+            continue
+        data = torch.empty(n * src.dtype.itemsize, dtype=torch.uint8, device="cuda")
+        valid = torch.empty((n + 7) // 8, dtype=torch.uint8, device="cuda")
+        gdf.api._hipMemcpyDtoD(data.data_ptr(), col.data, data.numel())
+        gdf.api._hipMemcpyDtoD(valid.data_ptr(), col.valid, valid.numel())
+        libgdf.gdf_column_free(C.byref(col))
+        out.append((data.cpu().numpy().view(src.dtype), np.unpackbits(valid.cpu().numpy(), bitorder="little")[:n].astype(bool)))
+    return a, b, out
+
+
+@pytest.mark.parametrize("how", ["inner", "left"])
+@pytest.mark.parametrize("payload", ["i64", "f64", "i32", "i32+f32", "i16"], ids=lambda p: p)
+@pytest.mark.parametrize("shape", ["all-hit", "half-hit", "80pct-hit", "dup-build-keys", "probe-is-right", "small-exact-layout", "skewed"])
+def test_carried_payload_matches_the_gather(gdf, how, payload, shape, force_path):
+    """result_cols of an INNER / LEFT join whose probe relation has one 8-byte, one 4-byte or two 4-byte non-key columns: the
+    values travel through the partition passes next to their tuples (csrc/join.hip PayCarry, jk_scatter1_pay, Tuples::pay)
+    and the probe kernel writes the result columns streaming.  Every pair's payload must be the probe row's value -- through
+    the optimistic single pass, the sparse pass + compaction, count + write, the general kernel (repeated build keys: payload
+    gathered by row), the exact layout and a skewed probe side; a 2-byte column is not carried and still gathers
+    (reference: joining.cu:375-479, gdf_table.cuh:873-963)."""
+    import zlib
+    rs = np.random.RandomState(zlib.crc32(f"{payload}/{shape}".encode()) % 100000)
+    npr, nb = (400_000, 40_000)
+    if shape != "small-exact-layout":
+        force_path("GDF_JK_SPEC_MIN", "1000")
+    else:
+        npr, nb = 3_000, 700
+    space = {"all-hit": nb, "half-hit": 2 * nb, "80pct-hit": nb + nb // 4}.get(shape, nb)
+    build = rs.permutation(max(space, nb))[:nb].astype(np.int64) if shape != "dup-build-keys" else (rs.permutation(nb) % (nb // 4)).astype(np.int64)
+    if shape == "all-hit":
+        build = rs.permutation(nb).astype(np.int64)
+    probe = rs.randint(0, space if shape != "dup-build-keys" else nb // 4, size=npr).astype(np.int64)
+    if shape == "skewed":
+        probe[rs.randint(0, npr, size=npr // 8)] = build[0]
+    pays = {"i64": [rs.randint(-2**62, 2**62, size=npr).astype(np.int64)], "f64": [rs.random_sample(npr)],
+            "i32": [rs.randint(-2**31, 2**31 - 1, size=npr).astype(np.int32)],
+            "i32+f32": [rs.randint(-2**31, 2**31 - 1, size=npr).astype(np.int32), rs.random_sample(npr).astype(np.float32)],
+            "i16": [rs.randint(-2**15, 2**15 - 1, size=npr).astype(np.int16)]}[payload]
+    bpay = rs.randint(0, 1000, size=nb).astype(np.int32)
+    if shape == "probe-is-right":
+        if how == "left":
+            pytest.skip("a LEFT join always probes with the left relation")
+        a, b, cols = _join_with_result_cols(gdf, how, [build, bpay], 0, pays + [probe], len(pays))      # smaller relation on the LEFT: INNER flips
+        el, er = oracle.join([build], [probe], how)
+        probe_idx, build_idx = b, a
+        res_build_pay, res_key, res_probe_pay = cols[0], cols[1], cols[2:]
+    else:
+        a, b, cols = _join_with_result_cols(gdf, how, pays + [probe], len(pays), [build, bpay], 0)
+        el, er = oracle.join([probe], [build], how)
+        probe_idx, build_idx = a, b
+        res_probe_pay, res_key, res_build_pay = cols[:len(pays)], cols[len(pays)], cols[len(pays) + 1]
+    x, y = sort_pairs(a, b)
+    ex, ey = sort_pairs(el, er)
+    np.testing.assert_array_equal(x, ex)
+    np.testing.assert_array_equal(y, ey)
+    for (d, v), src in zip(res_probe_pay, pays):
+        assert v.all()                                              # the probe row of an INNER / LEFT pair always exists
+        np.testing.assert_array_equal(d, src[probe_idx])
+    d, v = res_key
+    assert v.all()
+    np.testing.assert_array_equal(d, probe[probe_idx])
+    d, v = res_build_pay
+    np.testing.assert_array_equal(v, build_idx >= 0)
+    np.testing.assert_array_equal(d[v], bpay[build_idx[v]])
+
+
 @pytest.mark.parametrize("how", ["inner", "left", "full"])
 def test_int64_keys_wider_than_32_bits(gdf, how):
     """Build keys spanning more than 2^32 use the 12-byte tuple format; a narrower build range uses packed

@@ -158,11 +158,13 @@ GDF_INT64 = 4                        # include/gdf/gdf.h gdf_dtype
 # LIBGDF_AMD_LAB=1: bind the LAB build of libgdf.so (lib/lab/, csrc/lab.h: experiment knobs compiled in and read from the
 # environment) instead of the shipped one.  Only the tuning scripts under tools/gpu/ set it; the choice is made HERE, in the
 # Python binding -- the shipped libgdf.so itself reads no environment variable.
-LAB_BUILD = os.environ.get("LIBGDF_AMD_LAB", "") not in ("", "0")
+# (LIBGDF_AMD_LAB=<subdirectory of lib/>: any other side-by-side build, e.g. the previous commit's kernels for an A/B on one box.)
+LAB_BUILD = os.environ.get("LIBGDF_AMD_LAB", "")
+LAB_BUILD = "" if LAB_BUILD == "0" else ("lab" if LAB_BUILD == "1" else LAB_BUILD)
 
 
 def _load(name):
-    path = os.path.join(LIB_DIR, "lab", name) if (LAB_BUILD and name == "libgdf.so") else os.path.join(LIB_DIR, name)
+    path = os.path.join(LIB_DIR, LAB_BUILD, name) if (LAB_BUILD and name == "libgdf.so") else os.path.join(LIB_DIR, name)
     if not os.path.exists(path):
         raise ImportError(
             f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

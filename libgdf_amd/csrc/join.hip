@@ -526,8 +526,8 @@ __device__ __forceinline__ uint32_t opaque_tid() {
 }
 
 // phase C: write the regrouped tile out.  LEVEL1 bins are the coarse id, LEVEL2 the sub id.
-template <bool LEVEL1, bool NARROW, int THREADS, bool PAY>
-__device__ __forceinline__ void tile_flush(TileLds<NARROW, THREADS, PAY> &s, const PartGeom &g, Tuples out) {
+template <bool LEVEL1, bool NARROW, int THREADS, bool PAY, int ITEMS>
+__device__ __forceinline__ void tile_flush(TileLds<NARROW, THREADS, PAY, ITEMS> &s, const PartGeom &g, Tuples out) {
   const uint32_t total = s.total;
   const uint32_t submask = (1u << g.b2) - 1;
   constexpr int U = 4;
@@ -678,10 +678,11 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
     for (int k = 0; k < JK_SC_ITEMS; ++k)      // sixteen atomics in flight, one wait
       binrank[k] = (binrank[k] << 16) | atomicAdd(&s.hist[binrank[k]], 1u);
     block_sync();
+    uint32_t claimed = 0;
     {
       const uint32_t tid = opaque_tid();
       // speculative layout: the claim (a returning global atomic, ~2 us) is issued as soon as the counts are final and
-      // collected after the scan, instead of sitting between two barriers on its own
+      // collected after the regroup, instead of sitting between two barriers on its own
       uint32_t base = 0;
       if (g.cap1 && tid < ncoarse) {
         const uint32_t cnt = s.hist[tid];
@@ -689,22 +690,7 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
       }
       tile_scan_bins(s, ncoarse, tid);
       block_sync();
-      if (tid < ncoarse) {
-        if (g.cap1) {
-          const uint32_t cnt = s.hist[tid];
-          const uint32_t region = (tid << g.xs) | (blockIdx.x & ((1u << g.xs) - 1u));
-          if (base + cnt > g.cap1) { atomicExch(g.spec_flag, 1u); s.gbase[tid] = g.dump - s.start[tid]; }
-          else s.gbase[tid] = region * g.cap1 + base - s.start[tid];
-        } else {
-          s.gbase[tid] = s.cursor[tid] - s.start[tid];
-          s.cursor[tid] += s.hist[tid];
-        }
-      }
-      if (tid < 256) s.hist[tid] = 0;      // nobody reads hist again before the next tile's ranking
-      // speculative layout: once ANY workgroup has seen a partition outgrow its room the host will repeat the side with
-      // the exact layout -- the rest of this pass is wasted work (and, with skewed keys, slow work: every overflowing run
-      // of every workgroup lands on the same dump lines).  Thread 0 looks at the flag, everybody acts on it after the barrier.
-      if (g.cap1 && tid == 0) s.total_abort = __hip_atomic_load(g.spec_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      claimed = base;
     }
     const uint32_t wtid = opaque_tid();
 #pragma unroll
@@ -719,6 +705,28 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
         s.w[pos] = tup_make<NARROW>((uint64_t)key[h + k], row);
         if (!NARROW) s.idx[pos] = row;
       }
+    }
+    {
+      // the claim's answer is needed only now, for the flush behind the next barrier: the returning global atomic (~2 us, and
+      // behind the previous tile's stores in the in-order vmcnt) had the scan and the regroup to come back.  Consumed right
+      // after the scan, the waves that own the bins sat out that latency in front of their share of the regroup
+      const uint32_t tid = opaque_tid();
+      if (tid < ncoarse) {
+        if (g.cap1) {
+          const uint32_t cnt = s.hist[tid];
+          const uint32_t region = (tid << g.xs) | (blockIdx.x & ((1u << g.xs) - 1u));
+          if (claimed + cnt > g.cap1) { atomicExch(g.spec_flag, 1u); s.gbase[tid] = g.dump - s.start[tid]; }
+          else s.gbase[tid] = region * g.cap1 + claimed - s.start[tid];
+        } else {
+          s.gbase[tid] = s.cursor[tid] - s.start[tid];
+          s.cursor[tid] += s.hist[tid];
+        }
+      }
+      if (tid < 256) s.hist[tid] = 0;      // nobody reads hist again before the next tile's ranking
+      // speculative layout: once ANY workgroup has seen a partition outgrow its room the host will repeat the side with
+      // the exact layout -- the rest of this pass is wasted work (and, with skewed keys, slow work: every overflowing run
+      // of every workgroup lands on the same dump lines).  Thread 0 looks at the flag, everybody acts on it after the barrier.
+      if (g.cap1 && tid == 0) s.total_abort = __hip_atomic_load(g.spec_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     const bool more = tile + JK_TILE < end;
     __builtin_amdgcn_sched_barrier(0);         // keep the prefetch BELOW the regroup: hoisted, its 32 registers spill
@@ -848,28 +856,15 @@ __global__ __launch_bounds__(JK_PAY_THREADS) void jk_scatter1_pay(KeyTable t, Ke
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) binrank[k] = (binrank[k] << 16) | atomicAdd(&s.hist[binrank[k]], 1u);
     block_sync();
+    uint32_t claimed = 0;
     {
       const uint32_t tid = opaque_tid();
-      uint32_t base = 0;
       if (g.cap1 && tid < ncoarse) {
         const uint32_t cnt = s.hist[tid];
-        if (cnt) base = atomicAdd(&g.spec_cursor1[(tid << g.xs) | (blockIdx.x & ((1u << g.xs) - 1u))], cnt);
+        if (cnt) claimed = atomicAdd(&g.spec_cursor1[(tid << g.xs) | (blockIdx.x & ((1u << g.xs) - 1u))], cnt);
       }
       tile_scan_bins(s, ncoarse, tid);
       block_sync();
-      if (tid < ncoarse) {
-        if (g.cap1) {
-          const uint32_t cnt = s.hist[tid];
-          const uint32_t region = (tid << g.xs) | (blockIdx.x & ((1u << g.xs) - 1u));
-          if (base + cnt > g.cap1) { atomicExch(g.spec_flag, 1u); s.gbase[tid] = g.dump - s.start[tid]; }
-          else s.gbase[tid] = region * g.cap1 + base - s.start[tid];
-        } else {
-          s.gbase[tid] = s.cursor[tid] - s.start[tid];
-          s.cursor[tid] += s.hist[tid];
-        }
-      }
-      if (tid < 256) s.hist[tid] = 0;
-      if (g.cap1 && tid == 0) s.total_abort = __hip_atomic_load(g.spec_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     const uint32_t wtid = opaque_tid();
     {
@@ -883,6 +878,22 @@ __global__ __launch_bounds__(JK_PAY_THREADS) void jk_scatter1_pay(KeyTable t, Ke
         s.w[pos] = ((uint64_t)key[k] << 32) | (uint32_t)row;
         s.pay[pos] = pay[k];
       }
+    }
+    {   // the claim is looked at after the regroup (see jk_scatter1)
+      const uint32_t tid = opaque_tid();
+      if (tid < ncoarse) {
+        if (g.cap1) {
+          const uint32_t cnt = s.hist[tid];
+          const uint32_t region = (tid << g.xs) | (blockIdx.x & ((1u << g.xs) - 1u));
+          if (claimed + cnt > g.cap1) { atomicExch(g.spec_flag, 1u); s.gbase[tid] = g.dump - s.start[tid]; }
+          else s.gbase[tid] = region * g.cap1 + claimed - s.start[tid];
+        } else {
+          s.gbase[tid] = s.cursor[tid] - s.start[tid];
+          s.cursor[tid] += s.hist[tid];
+        }
+      }
+      if (tid < 256) s.hist[tid] = 0;
+      if (g.cap1 && tid == 0) s.total_abort = __hip_atomic_load(g.spec_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     const bool more = tile + TILE < end;
     __builtin_amdgcn_sched_barrier(0);
@@ -941,8 +952,11 @@ template <bool NARROW, int THREADS, bool PAY = false>
 __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, Tuples in,
                                                              uint32_t *__restrict__ fine_cursor, Tuples out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
-  TileLds<NARROW, THREADS, PAY> &s = *reinterpret_cast<TileLds<NARROW, THREADS, PAY> *>(tile_raw);
-  constexpr int JK_TILE = THREADS * JK_SC_ITEMS;
+  // a payload-carrying tile holds 16 bytes per tuple: half the tuples per thread keep it at four workgroups per CU
+  constexpr int ITEMS = PAY ? JK_PAY_ITEMS : JK_SC_ITEMS;
+  using Tile = TileLds<NARROW, THREADS, PAY, ITEMS>;
+  Tile &s = *reinterpret_cast<Tile *>(tile_raw);
+  constexpr int JK_TILE = THREADS * ITEMS;
   const uint32_t ncoarse = 1u << g.b1, nsub = 1u << g.b2;
   // locate the coarse partition that owns this tile (binary search over <= 257 entries)
   // XCD x (= blockIdx.x % 8) takes the x-th EIGHTH of the tiles, in order: every writer of a fine partition -- the tiles
@@ -966,10 +980,10 @@ __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, 
   block_sync();
   // straight-line phases as in jk_scatter1: tuples beyond the tile's end are ranked on a trash counter (bin 256) and
   // written to the trash slot of the LDS tile instead of being skipped by a branch per item
-  uint64_t w[JK_SC_ITEMS], pay[PAY ? JK_SC_ITEMS : 1];
-  int32_t idx[JK_SC_ITEMS];
+  uint64_t w[ITEMS], pay[PAY ? ITEMS : 1];
+  int32_t idx[ITEMS];
 #pragma unroll
-  for (int k = 0; k < JK_SC_ITEMS; ++k) {         // all loads first
+  for (int k = 0; k < ITEMS; ++k) {         // all loads first
     const uint32_t i = begin + k * THREADS + threadIdx.x;
     const uint32_t ic = i < end ? i : end - 1;        // clamped, unconditional: see fetch_keys
     if (NARROW && m.keys32) w[k] = ((uint64_t)m.keys32[ic] << 32) | (uint32_t)(g.row_base + (int32_t)ic);      // workgroup-uniform branch
@@ -977,30 +991,28 @@ __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, 
     idx[k] = NARROW ? 0 : in.idx[ic];
     if (PAY) pay[k] = in.pay[ic];
   }
-  uint32_t binrank[JK_SC_ITEMS];
+  uint32_t binrank[ITEMS];
 #pragma unroll
-  for (int k = 0; k < JK_SC_ITEMS; ++k) {
+  for (int k = 0; k < ITEMS; ++k) {
     const uint32_t i = begin + k * THREADS + threadIdx.x;
     const uint32_t bin = (uint32_t)((uint64_t)local_hash(hash_a(tup_key<NARROW>(w[k]) + g.kbias), g.world) >> (32 - g.fb)) & submask;
     binrank[k] = i < end ? bin : 256u;
   }
 #pragma unroll
-  for (int k = 0; k < JK_SC_ITEMS; ++k)            // sixteen atomics in flight, one wait
+  for (int k = 0; k < ITEMS; ++k)            // sixteen atomics in flight, one wait
     binrank[k] = (binrank[k] << 16) | atomicAdd(&s.hist[binrank[k]], 1u);
   block_sync();
+  // the claim -- a returning global atomic -- is issued as soon as the counts are final and looked at after the LDS regroup:
+  // its answer is only needed by the flush (see jk_scatter1)
+  uint32_t claimed = 0, mine = 0;
+  if (threadIdx.x < nsub) {
+    mine = s.hist[threadIdx.x];
+    if (mine) claimed = atomicAdd(&fine_cursor[(p << g.b2) | threadIdx.x], mine);
+  }
   tile_scan_bins(s, nsub);
   block_sync();
-  if (threadIdx.x < nsub) {
-    const uint32_t cnt = s.hist[threadIdx.x];
-    if (cnt) {
-      const uint32_t f = (p << g.b2) | threadIdx.x;
-      const uint32_t base = atomicAdd(&fine_cursor[f], cnt);
-      if (g.cap2 && base + cnt > (f + 1) * g.cap2) { atomicExch(g.spec_flag, 1u); s.gbase[threadIdx.x] = g.dump - s.start[threadIdx.x]; }
-      else s.gbase[threadIdx.x] = base - s.start[threadIdx.x];
-    }
-  }
 #pragma unroll
-  for (int h = 0; h < JK_SC_ITEMS; h += 8) {
+  for (int h = 0; h < ITEMS; h += 8) {
     uint32_t st[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) st[k] = s.start[(binrank[h + k] >> 16) & 255u];
@@ -1012,8 +1024,13 @@ __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, 
       if (PAY) s.pay[pos] = pay[h + k];
     }
   }
+  if (threadIdx.x < nsub && mine) {
+    const uint32_t f = (p << g.b2) | threadIdx.x;
+    if (g.cap2 && claimed + mine > (f + 1) * g.cap2) { atomicExch(g.spec_flag, 1u); s.gbase[threadIdx.x] = g.dump - s.start[threadIdx.x]; }
+    else s.gbase[threadIdx.x] = claimed - s.start[threadIdx.x];
+  }
   block_sync();
-  tile_flush<false, NARROW, THREADS, PAY>(s, g, out);
+  tile_flush<false, NARROW, THREADS, PAY, ITEMS>(s, g, out);
 }
 
 // ---------------------------------------------------------------------------
@@ -2033,7 +2050,7 @@ static gdf_error launch_scatter2_t(uint32_t ntiles, const PartGeom &g, Level2Map
 static gdf_error launch_scatter2(bool narrow, int threads, uint32_t ntiles, const PartGeom &g, Level2Map m, Tuples in,
                                  uint32_t *cursor, Tuples out) {
   if (narrow && in.pay) {            // a probe side that carries its payload words (PayCarry): the production tile size only
-    const size_t lds = sizeof(TileLds<true, 256, true>);
+    const size_t lds = sizeof(TileLds<true, 256, true, JK_PAY_ITEMS>);
     HIP_TRY(hipFuncSetAttribute((const void *)jk_scatter2<true, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     m.ntiles = ntiles;
     m.xcd_order = (ntiles >= 64 && !lab::path_on("GDF_JK_NO_XCD_ORDER")) ? 1 : 0;
@@ -2155,7 +2172,7 @@ static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, Si
   if (sc_threads != 256 && sc_threads != 512 && sc_threads != 1024) sc_threads = 256;
   if (!narrow && sc_threads == 1024) sc_threads = 512;       // 16384 x 12 B would not fit 160 KiB
   const int sc2_threads = pay ? 256 : level2_threads(sc_threads);
-  const int64_t JK_TILE2 = (int64_t)sc2_threads * JK_SC_ITEMS;
+  const int64_t JK_TILE2 = (int64_t)sc2_threads * (pay ? JK_PAY_ITEMS : JK_SC_ITEMS);
 
   // + 2: the probe kernel's last 16-byte load may touch one tuple past the end; + 1024: jk_scatter1's per-thread dump slots
   g.dump = (uint32_t)(cap + 2);
@@ -2237,7 +2254,7 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
   if (!narrow && sc_threads == 1024) sc_threads = 512;
   const int64_t JK_TILE = (int64_t)sc_threads * JK_SC_ITEMS;
   const int sc2_threads = pay ? 256 : level2_threads(sc_threads);
-  const int64_t JK_TILE2 = (int64_t)sc2_threads * JK_SC_ITEMS;
+  const int64_t JK_TILE2 = (int64_t)sc2_threads * (pay ? JK_PAY_ITEMS : JK_SC_ITEMS);
   auto room = [dup](double mean, uint32_t align) {
     const double c = mean + 8.0 * std::sqrt(mean * (1.0 + dup)) + 64.0;
     return (uint32_t)(((uint64_t)c + align - 1) / align * align);
@@ -2497,7 +2514,7 @@ static gdf_error refine_side(const PartGeom &g, bool narrow, double dup, SideBuf
   const int64_t n = sb->joinable;
   if (n == 0) return GDF_SUCCESS;
   const int threads = sb->pay[sb->final_buf].p ? 256 : level2_threads(narrow ? 1024 : 512);
-  const int64_t TILE = (int64_t)threads * JK_SC_ITEMS;
+  const int64_t TILE = (int64_t)threads * (sb->pay[sb->final_buf].p ? JK_PAY_ITEMS : JK_SC_ITEMS);
   const double mean = (double)n / (double)nfine3;
   const uint32_t cap3 = (uint32_t)(((uint64_t)(mean + 8.0 * std::sqrt(mean * (1.0 + dup)) + 64.0) + 7) / 8 * 8);
   const uint64_t size3 = nfine3 * cap3 + TILE;
@@ -3224,7 +3241,14 @@ __device__ __forceinline__ void gather_one_column(const GatherSet &s, int c, con
 }
 __global__ __launch_bounds__(256) void jk_gather_multi(GatherSet s, const int32_t *__restrict__ map, const int32_t *__restrict__ alt_map,
                                                        int64_t n) {
-  const int64_t i0 = (int64_t)blockIdx.x * (256 * GS_ROWS) + threadIdx.x;
+  // XCD x (= blockIdx % 8, round-robin dispatch) takes the x-th contiguous EIGHTH of the output: the pairs of one build
+  // partition are neighbours in a join's output and name the same few thousand build rows, so the gather of a build-side
+  // column re-reads each 64-byte sector ~10 times within a window of ~30 k pairs -- from ONE L2 when that window belongs to
+  // one XCD.  In dispatch order the window's blocks were dealt to all eight XCDs and every one of them fetched the
+  // partition's rows from HBM for itself (C3, two build-side columns: 28.9 ms of gathers)
+  const uint32_t per_xcd = gridDim.x >> 3;
+  const uint32_t block = (gridDim.x & 7u) ? blockIdx.x : (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  const int64_t i0 = (int64_t)block * (256 * GS_ROWS) + threadIdx.x;
   int32_t src[GS_ROWS], asrc[GS_ROWS];
 #pragma unroll
   for (int r = 0; r < GS_ROWS; ++r) {
@@ -3274,7 +3298,8 @@ static gdf_error gather_columns(const std::vector<GatherJob> &jobs, const int32_
       job.dst->dtype_info = job.src->dtype_info;
     }
     if (n) {
-      const unsigned grid = (unsigned)((n + 256 * GS_ROWS - 1) / (256 * GS_ROWS));
+      unsigned grid = (unsigned)((n + 256 * GS_ROWS - 1) / (256 * GS_ROWS));
+      if (grid >= 64) grid = (grid + 7u) & ~7u;          // a multiple of 8: the kernel's XCD-contiguous block order (blocks past the end do nothing)
       GDF_LAUNCH("jk_gather_multi", jk_gather_multi, dim3(grid), dim3(256), 0, stream0(), s, map, alt_map, n);
       HIP_CHECK_LAST();
     }

@@ -1175,6 +1175,11 @@ struct ProbeArgs {
   int pay_mode;                  // 0: none; 1: one 8-byte column; 2: one 4-byte column; 3: two 4-byte columns
   const void *pay_src[2];
   void *pay_out[2];
+  // with a carried payload, an INNER join on one integer key column also writes the KEY column of the result (key_width = 8 /
+  // 4, else 0): the value is the tuple's key + kbias, no gather; the general kernels read it from the probe column (key_src)
+  int key_width;
+  const void *key_src;
+  void *key_out;
 };
 // the general kernels' payload write: a gather by probe row (rare units only)
 __device__ __forceinline__ void pay_gather(const ProbeArgs &a, unsigned long long pos, int32_t prow) {
@@ -1183,6 +1188,8 @@ __device__ __forceinline__ void pay_gather(const ProbeArgs &a, unsigned long lon
     ((uint32_t *)a.pay_out[0])[pos] = ((const uint32_t *)a.pay_src[0])[prow];
     if (a.pay_mode == 3) ((uint32_t *)a.pay_out[1])[pos] = ((const uint32_t *)a.pay_src[1])[prow];
   }
+  if (a.key_width == 8) ((uint64_t *)a.key_out)[pos] = ((const uint64_t *)a.key_src)[prow];
+  else if (a.key_width == 4) ((uint32_t *)a.key_out)[pos] = ((const uint32_t *)a.key_src)[prow];
 }
 
 // LDS image of one work unit's build partition (dynamic region, every carve 16-byte aligned):
@@ -1572,6 +1579,8 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_fast(ProbeArgs a) {
   uint64_t *__restrict__ po8 = PMODE == 1 ? (uint64_t *)a.pay_out[0] + unit_base : nullptr;
   uint32_t *__restrict__ po4a = PMODE >= 2 ? (uint32_t *)a.pay_out[0] + unit_base : nullptr;
   uint32_t *__restrict__ po4b = PMODE == 3 ? (uint32_t *)a.pay_out[1] + unit_base : nullptr;
+  uint64_t *__restrict__ ko8 = (PMODE && a.key_width == 8) ? (uint64_t *)a.key_out + unit_base : nullptr;
+  uint32_t *__restrict__ ko4 = (PMODE && a.key_width == 4) ? (uint32_t *)a.key_out + unit_base : nullptr;
   const uint32_t vtotal = lead + u.probe_count;
   const uint32_t last_pair = (vtotal - 1) & ~1u;
   for (uint32_t base = 0; base < vtotal; base += JK_PROBE_THREADS * NB) {
@@ -1636,6 +1645,10 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_fast(ProbeArgs a) {
         if constexpr (PMODE == 1) { po8[pos] = pay[b]; if (c == 2) po8[pos + 1] = pay[b]; }
         if constexpr (PMODE >= 2) { po4a[pos] = (uint32_t)pay[b]; if (c == 2) po4a[pos + 1] = (uint32_t)pay[b]; }
         if constexpr (PMODE == 3) { po4b[pos] = (uint32_t)(pay[b] >> 32); if (c == 2) po4b[pos + 1] = (uint32_t)(pay[b] >> 32); }
+        if constexpr (PMODE != 0 && NARROW) {          // the result's key column (workgroup-uniform branches)
+          if (ko8) { ko8[pos] = (uint64_t)key[b] + a.kbias; if (c == 2) ko8[pos + 1] = (uint64_t)key[b] + a.kbias; }
+          if (ko4) { ko4[pos] = (uint32_t)key[b]; if (c == 2) ko4[pos + 1] = (uint32_t)key[b]; }
+        }
       }
     };
     if (__all((hamask & hbmask) == 0) && !(LAB_BITS(a.dbg) & 2048)) {      // (GDF_JK_DBG=2048: one claim per tuple, as before)
@@ -1688,6 +1701,131 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_fast(ProbeArgs a) {
   }
 }
 
+// The COUNT pass of the same plain case: jk_probe_fast's staging, cuckoo build and lookups, no output side (a unit that does not
+// settle here or there goes to the general kernel for that pass; either way it is counted / written completely).  Joins between ~55 % and 100 % hits (and LEFT joins) need exact output sizes before
+// they write; the general kernel's count pass is VALU-bound at 2.3 ms per 1e9 probe tuples, this one reads
+// its 8 bytes per tuple at the HBM rate.  Units it cannot settle go to unit_todo / opt_state[2] like the write kernel's.
+template <bool POW2, bool KEEP, bool NARROW>
+__global__ __launch_bounds__(JK_PROBE_THREADS) void jk_count_fast(ProbeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const uint32_t H = a.nslots, cap = a.cap;
+  const ProbeLds l = carve_probe_lds<NARROW>(lds_raw, cap, H);
+  const Unit u = a.units[blockIdx.x];
+  for (uint32_t i = threadIdx.x; i < u.build_count; i += JK_PROBE_THREADS) {
+    l.bw[i] = a.build.w[u.build_begin + i];
+    if (!NARROW) l.bi[i] = a.build.idx[u.build_begin + i];
+  }
+  for (uint32_t i = threadIdx.x; i < 2 * H; i += JK_PROBE_THREADS) l.T[i] = JK_NOPOS;
+  if (threadIdx.x == 0) *l.cuckoo_failed = 0;
+  block_sync();
+  const uint32_t kb_lo = (uint32_t)a.kbias, kb_hi = (uint32_t)(a.kbias >> 32);
+  // raw key = stored key + kbias; fold = lo ^ hi * C (key_fold).  NARROW keys are 32 bits, WIDE keys 64.
+  using Key = typename std::conditional<NARROW, uint32_t, uint64_t>::type;
+  auto fold_of = [&](Key key) -> uint32_t {
+    if constexpr (NARROW) {
+      const uint32_t lo = key + kb_lo;
+      const uint32_t hi = kb_hi + (lo < key ? 1u : 0u);
+      return lo ^ (hi * 0x9e3779b1u);
+    } else {
+      return key_fold(key + a.kbias);
+    }
+  };
+  // the fold table 1 hashes: NARROW keys are told apart by the one fold (it is injective on them), WIDE keys need the second
+  auto fold2_of = [&](Key key, uint32_t f1) -> uint32_t {
+    if constexpr (NARROW) return f1;
+    else return key_fold2(key + a.kbias);
+  };
+  auto staged_key = [&](uint32_t p) -> Key {
+    if constexpr (NARROW) return (uint32_t)(l.bw[p] >> 32);
+    else return l.bw[p];
+  };
+  // Slot hashes: the TOP log2(H) bits of two multiplicative hashes of the folded key.  One quarter-rate 32-bit
+  // multiply each instead of lowbias32's two multiplies and three xor-shifts: the keys of one partition are
+  // already a pseudo-random subset (the partition id comes from lowbias32), so the tables only need two
+  // different well-spread maps, and a build that does not settle is retried with another seed anyway.
+  const int hshift = POW2 ? 32 - (__ffs((int)H) - 1) : 0;
+  // A cuckoo build that runs into a cycle (17 of C3's 32768 partitions with one fixed pair of hash functions) is
+  // repeated with another pair: `seed` perturbs the folded key before both slot hashes.  What still fails after
+  // four attempts holds a key more than twice and belongs to the general kernel's linear probing.
+  uint32_t seed = 0;
+  for (int attempt = 0; attempt < 4; ++attempt) {
+    for (uint32_t p0 = threadIdx.x; p0 < u.build_count; p0 += JK_PROBE_THREADS) {
+      uint32_t cur = p0, table = 0;
+      int moves = 0;
+      for (; moves < JK_CUCKOO_MAX_MOVES; ++moves) {
+        const Key ck = staged_key(cur);
+        const uint32_t f = fold_of(ck) ^ seed, f2 = fold2_of(ck, fold_of(ck)) ^ seed;
+        const uint32_t slot = table ? H + (POW2 ? (f2 * 0xc2b2ae35u) >> hshift : __umulhi(f2 * 0xc2b2ae35u, H))
+                                    : (POW2 ? (f * 0x9e3779b1u) >> hshift : __umulhi(f * 0x9e3779b1u, H));
+        const uint32_t old = atomicExch(&l.T[slot], cur);
+        if (old == JK_NOPOS) break;
+        cur = old;
+        table ^= 1;
+      }
+      if (moves == JK_CUCKOO_MAX_MOVES) *l.cuckoo_failed = 1;
+    }
+    block_sync();
+    if (!*l.cuckoo_failed || attempt == 3) break;
+    block_sync();                                           // everyone has read the flag
+    for (uint32_t i = threadIdx.x; i < 2 * H; i += JK_PROBE_THREADS) l.T[i] = JK_NOPOS;
+    if (threadIdx.x == 0) *l.cuckoo_failed = 0;
+    seed += 0x9e3779b9u;
+    block_sync();
+  }
+  if (*l.cuckoo_failed | (unsigned)(LAB_BITS(a.dbg) & 8)) {
+    if (threadIdx.x == 0) a.unit_todo[atomicAdd(&a.opt_state[2], 1ull)] = blockIdx.x;
+    return;
+  }
+  // count: the write kernel's lookups without its output side
+  constexpr int NB = JK_PROBE_BATCH * 2;
+  const uint32_t lead = u.probe_begin & 1u;
+  const uint64_t *__restrict__ src = a.probe.w + (u.probe_begin - lead);
+  const uint32_t vtotal = lead + u.probe_count;
+  const uint32_t last_pair = (vtotal - 1) & ~1u;
+  uint32_t mine = 0;
+  for (uint32_t base = 0; base < vtotal; base += JK_PROBE_THREADS * NB) {
+    Key key[NB];
+    bool act[NB];
+#pragma unroll
+    for (int b = 0; b < JK_PROBE_BATCH; ++b) {
+      const uint32_t v = base + (b * JK_PROBE_THREADS + threadIdx.x) * 2;
+      const uint32_t vc = v < last_pair ? v : last_pair;
+      const ulonglong2 ww = *reinterpret_cast<const ulonglong2 *>(src + vc);
+      if constexpr (NARROW) { key[2 * b] = (uint32_t)(ww.x >> 32); key[2 * b + 1] = (uint32_t)(ww.y >> 32); }
+      else { key[2 * b] = ww.x; key[2 * b + 1] = ww.y; }
+      act[2 * b] = v >= lead && v < vtotal;
+      act[2 * b + 1] = v + 1 < vtotal;
+    }
+    uint32_t pa[NB], pb[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const uint32_t f = fold_of(key[b]) ^ seed, f2 = fold2_of(key[b], fold_of(key[b])) ^ seed;
+      pa[b] = l.T[POW2 ? (f * 0x9e3779b1u) >> hshift : __umulhi(f * 0x9e3779b1u, H)];
+      pb[b] = l.T[H + (POW2 ? (f2 * 0xc2b2ae35u) >> hshift : __umulhi(f2 * 0xc2b2ae35u, H))];
+    }
+    uint64_t wa[NB], wb[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      wa[b] = l.bw[pa[b] == JK_NOPOS ? 0 : pa[b]];
+      wb[b] = l.bw[pb[b] == JK_NOPOS ? 0 : pb[b]];
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const bool ha = act[b] && pa[b] != JK_NOPOS && (NARROW ? (uint32_t)(wa[b] >> 32) == (uint32_t)key[b] : wa[b] == (uint64_t)key[b]);
+      const bool hb = act[b] && pb[b] != JK_NOPOS && (NARROW ? (uint32_t)(wb[b] >> 32) == (uint32_t)key[b] : wb[b] == (uint64_t)key[b]);
+      mine += (uint32_t)ha + (uint32_t)hb + (uint32_t)(KEEP && act[b] && !ha && !hb);
+    }
+  }
+  mine = wave_reduce_add(mine);
+  if (lane_id() == 0) l.wave_cnt[threadIdx.x / WAVE] = mine;
+  block_sync();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+    for (int w = 0; w < JK_PROBE_THREADS / WAVE; ++w) t += l.wave_cnt[w];
+    a.counts[blockIdx.x] = t;
+  }
+}
+
 // Sparse optimistic pass: every unit wrote its pairs at the START of its own slot range (slot_off[u], room for one pair per
 // probe tuple); this moves them to their final, dense places (pair_off[u] = exclusive scan of the units' pair counts).
 // One workgroup per unit, 16 B per pair -- cheaper than a count pass (which reads every probe tuple and rebuilds every LDS
@@ -1708,16 +1846,15 @@ __device__ __forceinline__ void compact_column(const void *src, void *dst, uint6
     for (int k = 0; k < 4; ++k) if (i + k * 256 < n) d[i + k * 256] = v[k];
   }
 }
-struct PayMove { int mode; const void *src[2]; void *dst[2]; };
+struct PayMove { int ncols; int width[3]; const void *src[3]; void *dst[3]; };      // carried columns (payload, key): 8- or 4-byte elements
 __global__ __launch_bounds__(256) void jk_compact_units(const uint64_t *__restrict__ slot_off, const uint64_t *__restrict__ pair_off,
                                                         const int32_t *__restrict__ sp, const int32_t *__restrict__ sb,
                                                         int32_t *__restrict__ dp, int32_t *__restrict__ db, PayMove pm) {
   const uint64_t from = slot_off[blockIdx.x], to = pair_off[blockIdx.x];
   const uint32_t n = (uint32_t)(pair_off[blockIdx.x + 1] - to);
-  if (pm.mode == 1) compact_column<uint64_t>(pm.src[0], pm.dst[0], from, to, n);
-  else if (pm.mode) {
-    compact_column<uint32_t>(pm.src[0], pm.dst[0], from, to, n);
-    if (pm.mode == 3) compact_column<uint32_t>(pm.src[1], pm.dst[1], from, to, n);
+  for (int c = 0; c < pm.ncols; ++c) {
+    if (pm.width[c] == 8) compact_column<uint64_t>(pm.src[c], pm.dst[c], from, to, n);
+    else compact_column<uint32_t>(pm.src[c], pm.dst[c], from, to, n);
   }
   for (uint32_t i = threadIdx.x; i < n; i += 256 * 4) {
     int32_t vp[4], vb[4];
@@ -1891,10 +2028,9 @@ __global__ __launch_bounds__(256) void jk_emit_unjoinable(KeyTable t, KeyPlan pl
         const int64_t row = tile + k * 256 + threadIdx.x;
         out_row[pos[k]] = (int32_t)row;
         out_none[pos[k]] = JK_EMPTY;
-        if (pm.mode == 1) ((uint64_t *)pm.dst[0])[pos[k]] = ((const uint64_t *)pm.src[0])[row];
-        else if (pm.mode) {
-          ((uint32_t *)pm.dst[0])[pos[k]] = ((const uint32_t *)pm.src[0])[row];
-          if (pm.mode == 3) ((uint32_t *)pm.dst[1])[pos[k]] = ((const uint32_t *)pm.src[1])[row];
+        for (int c = 0; c < pm.ncols; ++c) {
+          if (pm.width[c] == 8) ((uint64_t *)pm.dst[c])[pos[k]] = ((const uint64_t *)pm.src[c])[row];
+          else ((uint32_t *)pm.dst[c])[pos[k]] = ((const uint32_t *)pm.src[c])[row];
         }
       }
   }
@@ -1950,6 +2086,10 @@ struct PayCarry {
   const void *src[2] = {nullptr, nullptr};
   void *dst[2] = {nullptr, nullptr};   // OUT: rmm allocations of *out_n elements each, the caller's to free -- set iff carried
   bool carried = false;                // OUT
+  // INNER joins on ONE integer key column: the result's key column comes out of the probe kernel as well (tuple key + kmin)
+  int key_width = 0;                   // 8 / 4; 0: the caller gathers the key column
+  const void *key_src = nullptr;       // the probe relation's key column
+  void *key_dst = nullptr;             // OUT, like dst[]
   int elem_bytes(int c) const { return mode == 1 ? 8 : 4; }
   int ncols() const { return mode == 3 ? 2 : (mode ? 1 : 0); }
 };
@@ -2486,6 +2626,45 @@ static gdf_error run_write_pass(bool narrow, bool plain, size_t nunits, size_t l
   return GDF_SUCCESS;
 }
 
+// COUNT pass over all units: the lean kernel for plain joins (jk_count_fast), the units it could not settle and every other
+// case through the general kernel.  a.counts must be zeroed; a.opt_state must point at 3 zeroed counters.
+static gdf_error run_count_pass(bool narrow, bool plain, size_t nunits, size_t lds, ProbeArgs a, uint32_t max_build,
+                                const KeyTable &probe_t, const KeyTable &build_t) {
+  if (!nunits) return GDF_SUCCESS;
+  if (!plain || a.build_matched || lab::knob_on("GDF_JK_NO_FAST") || lab::knob_on("GDF_JK_NO_FAST_COUNT"))
+    return run_probe(narrow, false, "jk_probe_count", nunits, lds, a, probe_t, build_t);
+  DevBuf todo;
+  RMM_TRY(todo.alloc(sizeof(uint32_t) * nunits));
+  a.unit_todo = todo.as<uint32_t>();
+  ProbeArgs fa = a;
+  size_t flds = lds;
+  const bool pow2 = (double)max_build <= 0.42 * 2.0 * (double)a.nslots;      // as run_write_pass
+  if (!pow2) {
+    fa.nslots = ((uint32_t)(max_build * 1.25) + 63) & ~63u;
+    flds = probe_lds_bytes(narrow, a.cap, fa.nslots, false);
+  }
+#define JK_COUNT_LAUNCH(P2, KP, NW)                                                                                               \
+  do {                                                                                                                            \
+    HIP_TRY(hipFuncSetAttribute((const void *)jk_count_fast<P2, KP, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds)); \
+    GDF_LAUNCH("jk_probe_count", (jk_count_fast<P2, KP, NW>), dim3((unsigned)nunits), dim3(JK_PROBE_THREADS), flds, stream0(), fa); \
+  } while (0)
+  const bool keep = a.keep_unmatched_probe != 0;
+  if (narrow) {
+    if (pow2 && keep) JK_COUNT_LAUNCH(true, true, true); else if (pow2) JK_COUNT_LAUNCH(true, false, true);
+    else if (keep) JK_COUNT_LAUNCH(false, true, true); else JK_COUNT_LAUNCH(false, false, true);
+  } else {
+    if (pow2 && keep) JK_COUNT_LAUNCH(true, true, false); else if (pow2) JK_COUNT_LAUNCH(true, false, false);
+    else if (keep) JK_COUNT_LAUNCH(false, true, false); else JK_COUNT_LAUNCH(false, false, false);
+  }
+#undef JK_COUNT_LAUNCH
+  HIP_CHECK_LAST();
+  unsigned long long left = 0;
+  HIP_TRY(read_back(&left, a.opt_state + 2, sizeof(left)));
+  if (left) GDF_TRY(run_probe(narrow, false, "jk_probe_count_general", (size_t)left, lds, a, probe_t, build_t));
+  HIP_TRY(hipStreamSynchronize(stream0()));      // `todo` goes out of scope
+  return GDF_SUCCESS;
+}
+
 // The join proper.  probe_t / build_t already reflect the INNER-join swap.
 // On success *out_probe / *out_build own rmm allocations of *out_n int32 each.
 // host-side stage clock (GDF_JK_DBG & 512): where the time between the kernels goes
@@ -2787,27 +2966,37 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
   }
 
   // carried payload: the output columns, sized when the pair count is known
-  DevBuf pay_out[2];
+  DevBuf pay_out[2], key_out;
+  const int key_width = (pc && kind == JOIN_INNER) ? pc->key_width : 0;
   auto alloc_pay = [&](uint64_t total) -> gdf_error {
     if (!pc) return GDF_SUCCESS;
     for (int c = 0; c < pc->ncols(); ++c) RMM_TRY(pay_out[c].alloc((size_t)pc->elem_bytes(c) * (size_t)(total ? total : 1)));
+    if (key_width) RMM_TRY(key_out.alloc((size_t)key_width * (size_t)(total ? total : 1)));
     return GDF_SUCCESS;
   };
   auto set_pay = [&](ProbeArgs &x) {
     if (!pc) return;
     x.pay_mode = pc->mode;
     for (int c = 0; c < 2; ++c) { x.pay_src[c] = pc->src[c]; x.pay_out[c] = pay_out[c].p; }
+    x.key_width = key_width;
+    x.key_src = pc->key_src;
+    x.key_out = key_out.p;
   };
   auto pay_move_at = [&](uint64_t first) -> PayMove {        // the payload columns from output position `first` on, filled from the source by row
-    PayMove pm{};
+    PayMove pm{};                                            // (LEFT-join tails; the key column is only carried by INNER joins, which have none)
     if (!pc) return pm;
-    pm.mode = pc->mode;
-    for (int c = 0; c < pc->ncols(); ++c) { pm.src[c] = pc->src[c]; pm.dst[c] = pay_out[c].as<char>() + first * (uint64_t)pc->elem_bytes(c); }
+    pm.ncols = pc->ncols();
+    for (int c = 0; c < pc->ncols(); ++c) {
+      pm.width[c] = pc->elem_bytes(c);
+      pm.src[c] = pc->src[c];
+      pm.dst[c] = pay_out[c].as<char>() + first * (uint64_t)pc->elem_bytes(c);
+    }
     return pm;
   };
   auto commit_pay = [&]() {
     if (!pc) return;
     for (int c = 0; c < pc->ncols(); ++c) pc->dst[c] = pay_out[c].release();
+    if (key_width) pc->key_dst = key_out.release();
     pc->carried = true;
   };
 
@@ -2958,14 +3147,20 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
       GDF_TRY(scan_u64(d_poff.as<uint64_t>(), d_poff.as<uint64_t>(), nunits + 1, false));
       RMM_TRY(fp.alloc(sizeof(int32_t) * pairs));
       RMM_TRY(fb.alloc(sizeof(int32_t) * pairs));
-      DevBuf dense_pay[2];
+      DevBuf dense_pay[3];
       PayMove pm{};
       if (pc) {
-        pm.mode = pc->mode;
         for (int c = 0; c < pc->ncols(); ++c) {
           RMM_TRY(dense_pay[c].alloc((size_t)pc->elem_bytes(c) * pairs));
-          pm.src[c] = pay_out[c].p;
-          pm.dst[c] = dense_pay[c].p;
+          pm.width[pm.ncols] = pc->elem_bytes(c);
+          pm.src[pm.ncols] = pay_out[c].p;
+          pm.dst[pm.ncols++] = dense_pay[c].p;
+        }
+        if (key_width) {
+          RMM_TRY(dense_pay[2].alloc((size_t)key_width * pairs));
+          pm.width[pm.ncols] = key_width;
+          pm.src[pm.ncols] = key_out.p;
+          pm.dst[pm.ncols++] = dense_pay[2].p;
         }
       }
       GDF_LAUNCH("jk_compact_units", jk_compact_units, dim3((unsigned)nunits), dim3(256), 0, stream0(), (const uint64_t *)d_off.as<uint64_t>(),
@@ -2977,10 +3172,11 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
       *out_probe = (int32_t *)fp.release();
       *out_build = (int32_t *)fb.release();
       if (pc) for (int c = 0; c < pc->ncols(); ++c) { pay_out[c].reset(); pay_out[c].p = dense_pay[c].release(); }
+      if (key_width) { key_out.reset(); key_out.p = dense_pay[2].release(); }
       commit_pay();
       return GDF_SUCCESS;
     }
-    pay_out[0].reset(); pay_out[1].reset();      // the attempt is discarded: the two-pass path sizes its own columns
+    pay_out[0].reset(); pay_out[1].reset(); key_out.reset();      // the attempt is discarded: the two-pass path sizes its own columns
     // otherwise: fall through to the exact two-pass path (buffers above are released here)
   }
   const size_t nslots_all = nunits + oversize.size();     // one count slot per LDS unit + one per oversize partition
@@ -2989,7 +3185,14 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
   a.counts = d_counts.as<uint64_t>();
 
   // ---- count pass ----
-  GDF_TRY(run_probe(narrow, false, "jk_probe_count", nunits, probe_lds, a, probe_t, build_t));
+  {
+    DevBuf d_cstate;
+    RMM_TRY(d_cstate.alloc(sizeof(unsigned long long) * 4));
+    HIP_TRY(hipMemsetAsync(d_cstate.p, 0, sizeof(unsigned long long) * 4, stream0()));
+    ProbeArgs ca = a;
+    ca.opt_state = d_cstate.as<unsigned long long>();
+    GDF_TRY(run_count_pass(narrow, plain && !dup_heavy, nunits, probe_lds, ca, max_build, probe_t, build_t));
+  }
   // oversize partitions: one global table each, kept for the write pass
   struct GTable { DevBuf key, idx, next; uint32_t nslots; };      // idx: chain heads per slot (+ the reserved slot), next: per build tuple
   std::vector<GTable> gt(oversize.size());
@@ -3363,11 +3566,25 @@ static gdf_error join_entry(JoinKind kind, gdf_column **left_cols, int num_left_
     if (plain) {
       pc.mode = nonkey.size() == 2 ? 3 : (width[0] == 8 ? 1 : 2);
       for (size_t j = 0; j < nonkey.size(); ++j) { pc.src[j] = pcols[nonkey[j]]->data; carried_col[j] = nonkey[j]; }
+      // the result's key column: an INNER join's matched pair holds the same key bits on both sides when the key is ONE
+      // integer column of one dtype without nulls -- the probe kernel then writes it from the tuple (no gather at all)
+      if (kind == JOIN_INNER && num_cols_to_join == 1 && lj[0] && rj[0]) {
+        const gdf_column *lk = lj[0], *rk = rj[0];
+        const ElemKind ek = elem_kind(lk->dtype);
+        if (lk->dtype == rk->dtype && lk->dtype_info.time_unit == rk->dtype_info.time_unit && (ek == K_I32 || ek == K_I64) &&
+            !lk->valid && !rk->valid) {
+          pc.key_width = kind_width(ek);
+          pc.key_src = (probe_is_right ? rk : lk)->data;
+        }
+      }
     }
   }
   struct PayFree {     // carried columns that were not handed to result_cols (an error below): released here
     PayCarry &pc;
-    ~PayFree() { for (int c = 0; c < 2; ++c) if (pc.dst[c]) rmmFree(pc.dst[c], (cudaStream_t)0); }
+    ~PayFree() {
+      for (int c = 0; c < 2; ++c) if (pc.dst[c]) rmmFree(pc.dst[c], (cudaStream_t)0);
+      if (pc.key_dst) rmmFree(pc.key_dst, (cudaStream_t)0);
+    }
   } pay_free{pc};
 
   gdf_error err = join_call(kind, num_cols_to_join, lj.data(), rj.data(), lout, rout, ctx, pc.mode ? &pc : nullptr);
@@ -3388,11 +3605,8 @@ static gdf_error join_entry(JoinKind kind, gdf_column **left_cols, int num_left_
   std::vector<GatherJob> left_jobs, right_jobs;
   // a carried column is complete already: its data came out of the probe kernel, every row of it is valid (no input mask;
   // the probe row of a pair always exists in an INNER / LEFT join)
-  auto take_carried = [&](bool right_side, int c, gdf_column *dst) -> int {      // 1: taken, 0: not a carried column, < 0: -(error)
-    if (!pc.carried || right_side != probe_is_right) return 0;
-    for (int j = 0; j < pc.ncols(); ++j) {
-      if (carried_col[j] != c) continue;
-      const gdf_column *src = (right_side ? right_cols : left_cols)[c];
+  auto adopt = [&](void *&data, const gdf_column *src, gdf_column *dst) -> int {     // 1: dst now owns `data`, all rows valid; < 0: -(error)
+    {
       DevBuf valid;
       const size_t vbytes = ((mask_bytes((size_t)n) + 7) / 8) * 8;
       if (valid.alloc(vbytes ? vbytes : 8) != RMM_SUCCESS) return -(int)GDF_MEMORYMANAGER_ERROR;
@@ -3402,11 +3616,16 @@ static gdf_error join_entry(JoinKind kind, gdf_column **left_cols, int num_left_
         const uint8_t tail = (uint8_t)((1u << (n % 8)) - 1u);
         if (hipMemcpy(valid.as<uint8_t>() + n / 8, &tail, 1, hipMemcpyHostToDevice) != hipSuccess) return -(int)GDF_CUDA_ERROR;
       }
-      gdf_column_view(dst, pc.dst[j], (gdf_valid_type *)valid.release(), (gdf_size_type)n, src->dtype);
+      gdf_column_view(dst, data, (gdf_valid_type *)valid.release(), (gdf_size_type)n, src->dtype);
       dst->dtype_info = src->dtype_info;
-      pc.dst[j] = nullptr;                       // owned by the result column now
+      data = nullptr;                            // owned by the result column now
       return 1;
     }
+  };
+  auto take_carried = [&](bool right_side, int c, gdf_column *dst) -> int {      // 1: taken, 0: not a carried column, < 0: -(error)
+    if (!pc.carried || right_side != probe_is_right) return 0;
+    for (int j = 0; j < pc.ncols(); ++j)
+      if (carried_col[j] == c) return adopt(pc.dst[j], (right_side ? right_cols : left_cols)[c], dst);
     return 0;
   };
   int o = 0;
@@ -3428,7 +3647,11 @@ static gdf_error join_entry(JoinKind kind, gdf_column **left_cols, int num_left_
     const bool same_bits = kind == JOIN_INNER && lk->dtype == rk->dtype && lk->dtype_info.time_unit == rk->dtype_info.time_unit &&
                            (ek == K_I8 || ek == K_I16 || ek == K_I32 || ek == K_I64) &&
                            (lk->valid == nullptr || lk->null_count == 0) && (rk->valid == nullptr || rk->null_count == 0);
-    if (same_bits && right_is_smaller) right_jobs.push_back(GatherJob{rk, nullptr, result_cols[o++]});
+    if (pc.carried && pc.key_dst) {               // came out of the probe kernel (one key column: i == 0)
+      const int took = adopt(pc.key_dst, lk, result_cols[o++]);
+      if (took < 0) return (gdf_error)(-took);
+    }
+    else if (same_bits && right_is_smaller) right_jobs.push_back(GatherJob{rk, nullptr, result_cols[o++]});
     else left_jobs.push_back(GatherJob{lk, kind == JOIN_FULL ? rk : nullptr, result_cols[o++]});
   }
   for (int c = 0; c < num_right_cols; ++c)

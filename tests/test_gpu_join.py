@@ -264,7 +264,8 @@ def _join_with_result_cols(gdf, how, left, lkey, right, rkey):
 @pytest.mark.parametrize("how", ["inner", "left"])
 @pytest.mark.parametrize("payload", ["i64", "f64", "i32", "i32+f32", "i16"], ids=lambda p: p)
 @pytest.mark.parametrize("shape", ["all-hit", "half-hit", "80pct-hit", "dup-build-keys", "probe-is-right", "small-exact-layout", "skewed"])
-def test_carried_payload_matches_the_gather(gdf, how, payload, shape, force_path):
+@pytest.mark.parametrize("kdt", [np.int64, np.int32], ids=["key-i64", "key-i32"])
+def test_carried_payload_matches_the_gather(gdf, how, payload, shape, kdt, force_path):
     """result_cols of an INNER / LEFT join whose probe relation has one 8-byte, one 4-byte or two 4-byte non-key columns: the
     values travel through the partition passes next to their tuples (csrc/join.hip PayCarry, jk_scatter1_pay, Tuples::pay)
     and the probe kernel writes the result columns streaming.  Every pair's payload must be the probe row's value -- through
@@ -285,6 +286,7 @@ def test_carried_payload_matches_the_gather(gdf, how, payload, shape, force_path
     probe = rs.randint(0, space if shape != "dup-build-keys" else nb // 4, size=npr).astype(np.int64)
     if shape == "skewed":
         probe[rs.randint(0, npr, size=npr // 8)] = build[0]
+    build, probe = build.astype(kdt), probe.astype(kdt)       # (an INNER join on one int64 / int32 key column also emits the KEY column from the kernel)
     pays = {"i64": [rs.randint(-2**62, 2**62, size=npr).astype(np.int64)], "f64": [rs.random_sample(npr)],
             "i32": [rs.randint(-2**31, 2**31 - 1, size=npr).astype(np.int32)],
             "i32+f32": [rs.randint(-2**31, 2**31 - 1, size=npr).astype(np.int32), rs.random_sample(npr).astype(np.float32)],

@@ -123,9 +123,10 @@ def main():
     if not only or "c3_materialise_2_payload_cols" in only:
         ppay = torch.arange(npr, dtype=torch.int64, device=dev)
         bpay = torch.arange(nb, dtype=torch.int64, device=dev)
-        timed("c3_materialise_2_payload_cols", join_materialise, lambda out: 8.0 * npr + 8.0 * nb + 8.0 * out + out * (2 * 4.0 + 3 * 16.0), npr,
-              "C3 + result_cols = [int64 probe payload, key, int64 build payload]: bytes = join + per output row two 4-byte map reads + "
-              "3 x (8 B gathered + 8 B written); the gathers are random 8-byte reads")
+        timed("c3_materialise_2_payload_cols", join_materialise, lambda out: 8.0 * npr + 8.0 * nb + 8.0 * out + 8.0 * npr + 8.0 * nb + 3 * 8.0 * out, npr,
+              "C3 + result_cols = [int64 probe payload, key, int64 build payload]: bytes = join + both payload columns read once + three "
+              "8-byte result columns written; the probe payload and the key are CARRIED through the partition passes (Tuples::pay), "
+              "the build payload is gathered (rows of the smaller relation, L2-friendly in XCD-contiguous output order)")
         del ppay, bpay
     # 1. half of the probe rows miss: count pass + write pass
     probe_half = make_probe_keys(npr, 2 * nb, 0x5EED0012, dev)

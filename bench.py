@@ -182,12 +182,13 @@ def main():
     ap.add_argument("--build-rows", type=int, default=None)
     ap.add_argument("--cpu-sample", type=int, default=20_000_000, help="probe rows of the oracle-port CPU baseline sample (0 = skip)")
     ap.add_argument("--pandas-sample", type=int, default=100_000_000, help="probe rows of the pandas.merge CPU baseline (0 = skip)")
-    ap.add_argument("--strategy", choices=["auto", "fused", "shuffle", "broadcast"], default="auto",
-                    help="multi-GPU join: shuffle both relations by key with an RCCL all-to-all (C4 as BASELINE.json names it), "
-                         "the same with the rank split fused into the join's level-1 regroup (4-byte keys in fixed-size blocks; falls back to "
-                         "the shuffle when the shape does not fit), gather the build keys on every GPU and leave the probe relation where it "
-                         "is, or (default) whichever libgdf_amd.multigpu.choose_join_strategy expects to be faster: broadcast at 2 GPUs, "
-                         "shuffle at 4, fused at 8")
+    ap.add_argument("--strategy", choices=["exchange", "auto", "fused", "shuffle", "broadcast"], default="exchange",
+                    help="multi-GPU join.  exchange (default): the key-partitioned all-to-all join BASELINE.json names, at EVERY world size -- "
+                         "the fused variant (rank split in the join's level-1 regroup, 4-byte keys in fixed-size blocks) and, where the shape does "
+                         "not fit it, the plain key shuffle -- so that a 1 -> 8 GPU curve measures one algorithm; what the planner "
+                         "(libgdf_amd.multigpu.choose_join_strategy: broadcast at 2 GPUs, shuffle at 4, fused at 8) would have run instead is timed "
+                         "after it and reported in the extra field planner_choice.  auto: the planner's choice as `value`.  fused / shuffle / "
+                         "broadcast: that strategy")
     ap.add_argument("--force-distributed", action="store_true",
                     help="run the multi-GPU (C4) code path even at world size 1 (1-rank RCCL group): measures its local passes")
     args = ap.parse_args()
@@ -308,7 +309,8 @@ def main():
                                            f"RCCL all-to-all shuffle + local gdf_inner_join"),
                  "broadcast": (step_broadcast, f"C4 rows, broadcast variant: {npr} probe + {nb} build int64 rows per GPU, key space {key_space}, "
                                                f"RCCL all-gather of the build keys + local gdf_inner_join")}
-        planned = args.strategy if args.strategy != "auto" else multigpu.choose_join_strategy(world, npr, nb)
+        planner = multigpu.choose_join_strategy(world, npr, nb)
+        planned = {"exchange": "fused", "auto": planner}.get(args.strategy, args.strategy)
         # Preflight (untimed, before the warmup): one step of the planned strategy, checked against what this workload must
         # produce -- every probe key is a build key on exactly one rank, so the ranks' pair counts add up to the probe rows --
         # and a sample of 2^20 pairs per rank, resolved to global row ids, must join equal keys.
@@ -316,6 +318,8 @@ def main():
         # the JSON line says which ran and why.  (A failure inside a collective can still take the job down: then RCCL's
         # watchdog ends it.)
         order = [planned] + [k for k in ("fused", "shuffle", "broadcast") if k != planned]
+        if args.strategy == "exchange":
+            order = ["fused", "shuffle"]           # never the broadcast: the curve is the all-to-all join at every N
         preflight = []
         strategy = None
         for cand in order:
@@ -366,6 +370,28 @@ def main():
     dt = time.perf_counter() - t0
     lib.gdf_amd_profile_enable(0)
     prof = read_profile(gdf)
+
+    # what the planner would have run at this world size, when that is another strategy than the one `value` reports
+    planner_choice = None
+    if distributed and args.strategy == "exchange" and planner != strategy:
+        pstep = steps[planner][0]
+        err = None
+        try:
+            pstep()
+            sync()
+            p0 = time.perf_counter()
+            for _ in range(args.steps):
+                pstep()
+            sync()
+            pdt = time.perf_counter() - p0
+        except Exception as e:                     # noqa: BLE001 -- reported in the JSON line
+            err, pdt = f"{type(e).__name__}: {e}", 0.0
+        pt = torch.tensor([pdt, 1.0 if err else 0.0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(pt, op=dist.ReduceOp.MAX)
+        planner_choice = {"strategy": planner, "ms_per_step": float(pt[0].item()) / args.steps * 1e3 if not pt[1].item() else None,
+                          "value": npr * world * args.steps / float(pt[0].item()) if (pt[0].item() > 0 and not pt[1].item()) else None,
+                          "error": err}
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     rows = torch.tensor([float(out_rows)], dtype=torch.float64, device=dev)
@@ -431,6 +457,9 @@ def main():
             sent = max(r["exchange_bytes_sent_per_step"] for r in per_rank)
             result["config"]["strategy"] = strategy
             result["config"]["strategy_planned"] = planned
+            result["config"]["planner_would_pick"] = planner
+            if planner_choice is not None:
+                result["planner_choice"] = planner_choice
             result["config"]["preflight"] = preflight
             result["exchange"] = {"bytes_sent_per_gpu_per_step": sent, "messages_per_gpu_per_step": max(r["exchange_messages_per_step"] for r in per_rank),
                                   "busiest_link_ms_at_assumed_rate": sent / max(world - 1, 1) / multigpu.XGMI_LINK_BYTES_PER_S * 1e3,

@@ -1659,7 +1659,8 @@ __device__ __forceinline__ void gbp_pack32(const KeyTable &t, const GbKeyPlan &p
 // flags[0] += rows dropped for a null key, flags[1] = 1 when a key lies outside the plan's ranges
 template <int K0 = -1, int K1 = -1>
 __global__ __launch_bounds__(GBP_THREADS) void gbp_count(KeyTable t, GbKeyPlan plan, int low, int vbit, uint32_t nparts, int64_t chunk,
-                                                         int nchunks, uint32_t *__restrict__ hist, unsigned int *__restrict__ flags) {
+                                                         int nchunks, uint32_t *__restrict__ hist, unsigned int *__restrict__ flags,
+                                                         uint32_t qstride, uint32_t cstride) {
   __shared__ uint32_t cnt[GBP_MAX_PARTS];
   constexpr int B = (K0 >= 0 && K1 == -2) ? 12 : 8;       // one key column to read: half as many rows again in flight per thread (77 VGPRs at 8; 16 spill)
   unsigned int dropped = 0, outside = 0;
@@ -1710,7 +1711,7 @@ __global__ __launch_bounds__(GBP_THREADS) void gbp_count(KeyTable t, GbKeyPlan p
       }
     }
     block_sync();
-    for (uint32_t q = threadIdx.x; q < nparts; q += GBP_THREADS) hist[(size_t)q * nchunks + c] = cnt[q];
+    for (uint32_t q = threadIdx.x; q < nparts; q += GBP_THREADS) hist[(size_t)q * qstride + (size_t)c * cstride] = cnt[q];
     block_sync();
   }
   dropped = wave_reduce_add(dropped);
@@ -1766,7 +1767,7 @@ __device__ __forceinline__ void gbp_rank(uint32_t *hist, const uint32_t (&part)[
 template <bool VBIT>
 __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter(KeyTable t, GbKeyPlan plan, GbVal val, int fold_op, int low, int part_bits,
                                                            uint32_t nparts, int64_t chunk, int nchunks, const uint32_t *__restrict__ offs,
-                                                           GbRec *__restrict__ rec_out) {
+                                                           GbRec *__restrict__ rec_out, uint32_t qstride, uint32_t cstride) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gbp_lds[];
   uint64_t *stage = reinterpret_cast<uint64_t *>(gbp_lds);                   // [TILE] accumulator images, regrouped by partition
   uint32_t *stage_k = reinterpret_cast<uint32_t *>(stage + GBP_SC_TILE);        // [TILE] their keys (the partition is key >> low)
@@ -1776,7 +1777,7 @@ __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter(KeyTable t, GbKeyP
   constexpr int PER = GBP_MAX_PARTS / GBP_SC_THREADS;                           // partitions per thread in the scan (2)
   constexpr int vbit = VBIT ? 1 : 0;
   for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
-    for (uint32_t q = threadIdx.x; q < nparts; q += GBP_SC_THREADS) cursor[q] = offs[(size_t)q * nchunks + c];
+    for (uint32_t q = threadIdx.x; q < nparts; q += GBP_SC_THREADS) cursor[q] = offs[(size_t)q * qstride + (size_t)c * cstride];
     const int64_t begin = (int64_t)c * chunk;
     const int64_t end = begin + chunk < t.nrows ? begin + chunk : t.nrows;
     for (int64_t tile = begin; tile < end; tile += GBP_SC_TILE) {
@@ -1919,7 +1920,8 @@ __device__ __forceinline__ uint32_t gbp_opaque_tid() {
 template <bool VBIT, int K0, int K1, bool VMASK>
 __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter_static(KeyTable t, GbKeyPlan plan, GbVal val, int fold_op, int low,
                                                                   uint32_t nparts, int64_t chunk, int nchunks, const uint32_t *__restrict__ offs,
-                                                                  GbRec *__restrict__ rec_out, unsigned int *__restrict__ flags) {
+                                                                  GbRec *__restrict__ rec_out, unsigned int *__restrict__ flags,
+                                                                  uint32_t qstride, uint32_t cstride) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gbp_lds[];
   uint64_t *stage = reinterpret_cast<uint64_t *>(gbp_lds);
   uint32_t *stage_k = reinterpret_cast<uint32_t *>(stage + GBP_SC_TILE);
@@ -1955,7 +1957,7 @@ __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter_static(KeyTable t,
   for (uint32_t q = threadIdx.x; q < GBP_MAX_PARTS; q += GBP_SC_THREADS) hist[q] = 0;
   block_sync();
   for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
-    for (uint32_t q = threadIdx.x; q < nparts; q += GBP_SC_THREADS) cursor[q] = offs[(size_t)q * nchunks + c];
+    for (uint32_t q = threadIdx.x; q < nparts; q += GBP_SC_THREADS) cursor[q] = offs[(size_t)q * qstride + (size_t)c * cstride];
     const int64_t begin = (int64_t)c * chunk;
     const int64_t end = begin + chunk < t.nrows ? begin + chunk : t.nrows;
     for (int64_t tile = begin; tile < end; tile += GBP_SC_TILE) {
@@ -2479,9 +2481,15 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
       const bool skip_low = key_sig && val_sig && t.ncols == 2 && !t.col[1].valid && sp.shift[1] + sp.bits[1] + vbit <= low &&
                             !lab::knob_on("GDF_GBP_COUNT_ALL");
       const int ck1 = skip_low ? -2 : k1;
+      // record layout: partition-major -- hist[p][chunk], one scan gives every (partition, chunk) its place inside the partition's
+      // contiguous range.  (LAB knob GDF_GBP_CHUNK_MAJOR: [chunk][partition] segments, every workgroup's 2048 write fronts inside
+      // its own ~12 MB window -- the layout experiment of profiles/r3_*_c5_layout.md; the aggregation does not read that layout,
+      // the knob only times the scatter.)
+      const bool chunk_major = lab::knob_on("GDF_GBP_CHUNK_MAJOR");
+      const uint32_t qstride = chunk_major ? 1u : (uint32_t)nchunks, cstride = chunk_major ? P : 1u;
       auto count = [&](auto kernel) {
         GDF_LAUNCH("gbp_count", kernel, dim3(nchunks < NUM_CU * 2 ? nchunks : NUM_CU * 2), dim3(GBP_THREADS), 0, stream0(), t, sp, low, vbit, P,
-                   chunk, nchunks, hist.as<uint32_t>(), d_flags.as<unsigned int>());
+                   chunk, nchunks, hist.as<uint32_t>(), d_flags.as<unsigned int>(), qstride, cstride);
       };
       if (k0 == K_I32 && ck1 == -2) count(gbp_count<K_I32, -2>);
       else if (k0 == K_I64 && ck1 == -2) count(gbp_count<K_I64, -2>);
@@ -2500,7 +2508,7 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
         auto scatter = [&](auto kernel) -> gdf_error {
           HIP_TRY(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
           GDF_LAUNCH("gbp_scatter", kernel, sgrid, dim3(GBP_SC_THREADS), slds, stream0(), t, sp, val, fold_op, low, P, chunk, nchunks,
-                     (const uint32_t *)hist.as<uint32_t>(), ka.as<GbRec>(), d_flags.as<unsigned int>());
+                     (const uint32_t *)hist.as<uint32_t>(), ka.as<GbRec>(), d_flags.as<unsigned int>(), qstride, cstride);
           return GDF_SUCCESS;
         };
 #define GBP_SIG(K0, K1)                                                                                                          \
@@ -2515,11 +2523,16 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
         auto scatter = [&](auto kernel) -> gdf_error {
           HIP_TRY(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
           GDF_LAUNCH("gbp_scatter", kernel, sgrid, dim3(GBP_SC_THREADS), slds, stream0(), t, sp, val, fold_op, low, part_bits, P, chunk, nchunks,
-                     (const uint32_t *)hist.as<uint32_t>(), ka.as<GbRec>());
+                     (const uint32_t *)hist.as<uint32_t>(), ka.as<GbRec>(), qstride, cstride);
           return GDF_SUCCESS;
         };
         if (vbit) GDF_TRY(scatter(gbp_scatter<true>));
         else GDF_TRY(scatter(gbp_scatter<false>));
+      }
+      if (chunk_major) {                 // (LAB) the scatter has been timed; the records are not in the layout the aggregation reads
+        HIP_TRY(hipStreamSynchronize(stream0()));
+        *done = false;
+        return GDF_SUCCESS;
       }
       hipLaunchKernelGGL(gb_strided_u32, dim3((P + 256) / 256), dim3(256), 0, stream0(), (const uint32_t *)hist.as<uint32_t>(), d_start.as<uint32_t>(),
                          (int)P + 1, (size_t)nchunks);

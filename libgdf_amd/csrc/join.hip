@@ -1872,6 +1872,59 @@ __global__ __launch_bounds__(256) void jk_compact_units(const uint64_t *__restri
   }
 }
 
+// The same single pass for joins where MOST probe rows hit (50 % .. 100 %): closing every unit's hole by moving all pairs is
+// 16 bytes per pair -- more than the count pass it would replace.  Instead only the pairs that sit BEHIND the final size N
+// move, into the holes in front of it: with hit rate h that is h (1 - h) of the slots (80 % hits: 0.16 pairs per slot instead
+// of 0.8), the pair order of a join being unspecified.  The columns keep their cap_pairs-slot allocation; their size is N.
+//   jk_hole_counts: per unit, its free slots below N and its pairs at or above N (the two sums are equal);
+//   jk_fill_holes:  after exclusive scans of both, tail pair number g goes to hole slot number g.
+__global__ __launch_bounds__(256) void jk_hole_counts(const Unit *__restrict__ units, const uint64_t *__restrict__ slot_off,
+                                                      const uint32_t *__restrict__ unit_pairs, uint32_t nunits, uint64_t N,
+                                                      uint64_t *__restrict__ holes, uint64_t *__restrict__ tails) {
+  const uint32_t u = blockIdx.x * 256 + threadIdx.x;
+  if (u > nunits) return;
+  uint64_t h = 0, t = 0;
+  if (u < nunits) {
+    const uint64_t o = slot_off[u], used_end = o + unit_pairs[u], slot_end = o + units[u].probe_count;
+    if (used_end < N) h = (slot_end < N ? slot_end : N) - used_end;
+    if (used_end > N) t = used_end - (o > N ? o : N);
+  }
+  holes[u] = h;
+  tails[u] = t;
+}
+__global__ __launch_bounds__(256) void jk_fill_holes(const uint64_t *__restrict__ slot_off, const uint32_t *__restrict__ unit_pairs, uint32_t nunits,
+                                                     uint64_t N, const uint64_t *__restrict__ hole_pre, const uint64_t *__restrict__ tail_pre,
+                                                     int32_t *__restrict__ op, int32_t *__restrict__ ob, PayMove pm) {
+  __shared__ uint32_t range[2];
+  const uint32_t u = blockIdx.x;
+  const uint64_t g0 = tail_pre[u];
+  const uint32_t cnt = (uint32_t)(tail_pre[u + 1] - g0);
+  if (!cnt) return;
+  const uint64_t o = slot_off[u], src0 = o > N ? o : N;
+  // last v with hole_pre[v] <= g (upper bound - 1): the unit whose hole holds slot number g
+  auto unit_of = [&](uint64_t g, uint32_t lo, uint32_t hi) -> uint32_t {        // searches [lo, hi]
+    while (lo < hi) {
+      const uint32_t mid = lo + (hi - lo + 1) / 2;
+      if (hole_pre[mid] <= g) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+  };
+  if (threadIdx.x < 2) range[threadIdx.x] = unit_of(threadIdx.x ? g0 + cnt - 1 : g0, 0, nunits - 1);
+  __syncthreads();
+  const uint32_t v0 = range[0], v1 = range[1];
+  for (uint32_t i = threadIdx.x; i < cnt; i += 256) {
+    const uint64_t g = g0 + i;
+    const uint32_t v = unit_of(g, v0, v1);
+    const uint64_t dst = slot_off[v] + unit_pairs[v] + (g - hole_pre[v]), src = src0 + i;
+    op[dst] = op[src];
+    ob[dst] = ob[src];
+    for (int c = 0; c < pm.ncols; ++c) {
+      if (pm.width[c] == 8) ((uint64_t *)pm.dst[c])[dst] = ((const uint64_t *)pm.src[c])[src];
+      else ((uint32_t *)pm.dst[c])[dst] = ((const uint32_t *)pm.src[c])[src];
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // global-table path for partitions whose build side exceeds the LDS image (heavy key
 // duplication / build sides beyond 32768 * JK_MAX_BUILD rows).  Same semantics, table
@@ -3083,15 +3136,15 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
     sample_hit = sample_tuples ? (double)sample_pairs / (double)sample_tuples : 1.0;
     cap_pairs = off[nunits];
   }
-  // SPARSE optimistic pass: the sample says well under one pair per probe tuple (a selective inner join).  The single write
-  // pass still works -- a unit's pairs fit the slots of its probe tuples -- it just leaves a hole at the end of every unit's
-  // range; closing them (jk_compact_units, 16 B per PAIR) is cheaper than the count pass it replaces (8 B per probe TUPLE plus
-  // a second build of every LDS table) when few probe rows hit: at 50 % the two are level (1e9 x 1e8 rows: compaction 1.8 ms
-  // against 2.3 ms of count pass, minus 8 GB of temporary pair slots), so the switch sat at 45 %; with the lean write kernel's
-  // single claim per batch the single pass + compaction wins at 50 % (12.05 against 12.5 ms, tools/gpu/r2bp) and breaks even near
-  // 57 %: the switch sits at 55 % (GDF_JK_SPARSE_MAX overrides it).
+  // SPARSE optimistic pass: the sample says fewer than one pair per probe tuple (some probe rows miss) and no repeated build
+  // keys.  The single write pass still works -- a unit's pairs fit the slots of its probe tuples -- it just leaves a hole at the
+  // end of every unit's range.  Closing the holes is cheaper than the count pass it replaces (8 B per probe TUPLE plus a second
+  // build of every LDS table) at EVERY hit rate: below 50 % by packing all pairs into exact-size columns (jk_compact_units,
+  // 16 B per pair), from 50 % on by moving only the pairs behind the final size into the holes in front of it (jk_fill_holes:
+  // h (1 - h) of the slots; the columns keep their allocation of one slot per probe tuple).  A unit that runs out of slots
+  // (a build key present more than once after all) sends the call to count + write.
   const bool try_sparse = !try_optimistic && d_off.p && nunits && oversize.empty() && kind == JOIN_INNER && !dup_heavy && !(LAB_BITS(a.dbg) & 16) &&
-                          sample_hit < lab::knob_float("GDF_JK_SPARSE_MAX", 0.55) && !lab::path_on("GDF_JK_NO_SPARSE_OPT");
+                          sample_hit <= lab::knob_float("GDF_JK_SPARSE_MAX", 1.0) && !lab::path_on("GDF_JK_NO_SPARSE_OPT");
   if (try_optimistic || try_sparse) {
     DevBuf d_state, d_upairs;
     RMM_TRY(d_state.alloc(sizeof(unsigned long long) * 4));
@@ -3132,6 +3185,34 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
       *out_n = (int64_t)total;
       if (total == 0) { *out_probe = nullptr; *out_build = nullptr; return GDF_SUCCESS; }
       *out_probe = (int32_t *)op.release();
+      *out_build = (int32_t *)ob.release();
+      commit_pay();
+      return GDF_SUCCESS;
+    }
+    if (try_sparse && st[1] == 0 && st[0] * 2 >= cap_pairs && !lab::knob_on("GDF_JK_NO_HOLE_FILL")) {
+      // most slots are taken: move only the pairs behind the final size into the holes in front of it (jk_fill_holes)
+      const uint64_t pairs = st[0];
+      DevBuf d_holes, d_tails;
+      RMM_TRY(d_holes.alloc(sizeof(uint64_t) * (nunits + 1)));
+      RMM_TRY(d_tails.alloc(sizeof(uint64_t) * (nunits + 1)));
+      GDF_LAUNCH("jk_hole_counts", jk_hole_counts, dim3((unsigned)(nunits / 256 + 1)), dim3(256), 0, stream0(), (const Unit *)d_units.as<Unit>(),
+                 (const uint64_t *)d_off.as<uint64_t>(), (const uint32_t *)d_upairs.as<uint32_t>(), (uint32_t)nunits, pairs, d_holes.as<uint64_t>(),
+                 d_tails.as<uint64_t>());
+      GDF_TRY(scan_u64(d_holes.as<uint64_t>(), d_holes.as<uint64_t>(), nunits + 1, false));
+      GDF_TRY(scan_u64(d_tails.as<uint64_t>(), d_tails.as<uint64_t>(), nunits + 1, false));
+      PayMove pm{};
+      if (pc) {
+        for (int c = 0; c < pc->ncols(); ++c) { pm.width[pm.ncols] = pc->elem_bytes(c); pm.src[pm.ncols] = pay_out[c].p; pm.dst[pm.ncols++] = pay_out[c].p; }
+        if (key_width) { pm.width[pm.ncols] = key_width; pm.src[pm.ncols] = key_out.p; pm.dst[pm.ncols++] = key_out.p; }
+      }
+      GDF_LAUNCH("jk_fill_holes", jk_fill_holes, dim3((unsigned)nunits), dim3(256), 0, stream0(), (const uint64_t *)d_off.as<uint64_t>(),
+                 (const uint32_t *)d_upairs.as<uint32_t>(), (uint32_t)nunits, pairs, (const uint64_t *)d_holes.as<uint64_t>(),
+                 (const uint64_t *)d_tails.as<uint64_t>(), op.as<int32_t>(), ob.as<int32_t>(), pm);
+      HIP_CHECK_LAST();
+      HIP_TRY(hipStreamSynchronize(stream0()));
+      clk.mark("hole filling");
+      *out_n = (int64_t)pairs;
+      *out_probe = (int32_t *)op.release();        // (allocated for cap_pairs slots, `pairs` of them in use)
       *out_build = (int32_t *)ob.release();
       commit_pay();
       return GDF_SUCCESS;

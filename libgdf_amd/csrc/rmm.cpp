@@ -86,7 +86,10 @@ rmmError_t pool_alloc(Manager &m, void **ptr, size_t size) {
   // then took the 7.6 GB block another buffer of the same call needs a moment later, that one went to hipMalloc -- milliseconds
   // for a block of this size -- and a join's steady state took several calls of such swaps to settle, if it ever did:
   // tools/bench_shapes.py saw 13 - 16 ms per C3 join around 10.6 ms of kernels.)
-  if (it != m.free_blocks.end() && it->first <= want + want / 4) {
+  // The tight window is for the multi-GB blocks that made that trouble; below 1 GiB a block up to twice the request is taken
+  // (slices of varying size, speculative capacities: a 25 % window sent most of them to hipMalloc and let the misfits pile up).
+  const size_t window = want >= (size_t(1) << 30) ? want + want / 4 : 2 * want;
+  if (it != m.free_blocks.end() && it->first <= window) {
     *ptr = it->second;
     m.live_blocks[*ptr] = it->first;
     m.cached_bytes -= it->first;
@@ -94,6 +97,9 @@ rmmError_t pool_alloc(Manager &m, void **ptr, size_t size) {
     m.free_blocks.erase(it);
     return RMM_SUCCESS;
   }
+  // a long-running process whose request sizes drift must not grow the cache without bound: past 64 GiB of cached blocks
+  // (more than any single relational call of the benchmarks keeps) the cache is returned to the runtime before growing further
+  if (m.cached_bytes > (size_t(64) << 30)) release_cache_locked(m);
   void *p = nullptr;
   hipError_t e = hipMalloc(&p, want);
   if (e == hipErrorOutOfMemory) {       // give cached blocks back and retry once

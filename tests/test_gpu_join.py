@@ -801,13 +801,15 @@ def test_headline_configuration_with_valid_masks(gdf, variant):
     assert int(seen.sum()) == expected                              # every pair names a different probe row
 
 
-@pytest.mark.parametrize("hit", [0.0, 0.05, 0.3, 0.44])
+@pytest.mark.parametrize("hit", [0.0, 0.05, 0.3, 0.44, 0.5, 0.62, 0.8, 0.97])
 @pytest.mark.parametrize("size", ["small", "large"])
 def test_selective_inner_join_single_pass_then_compaction(gdf, hit, size, force_path):
-    """Well under one pair per probe row: one optimistic write pass into per-unit slot ranges, then jk_compact_units closes the
-    holes (instead of a count pass).  Same pair set as the count + write path (GDF_JK_NO_SPARSE_OPT), at a size that takes the
-    host-built units and at one that takes the device-built ones; repeated build keys inside the units are fine as long as a
-    unit's pairs fit its probe tuples' slots."""
+    """Fewer than one pair per probe row: one optimistic write pass into per-unit slot ranges, then the holes are closed (instead of
+    a count pass) -- below 50 % hits jk_compact_units packs all pairs into exact-size columns, from 50 % on jk_fill_holes moves only
+    the pairs behind the final size into the holes in front of it.  Same pair set as the count + write path (GDF_JK_NO_SPARSE_OPT),
+    at a size that takes the host-built units and at one that takes the device-built ones; repeated build keys inside the units are
+    fine as long as a unit's pairs fit its probe tuples' slots (2 % of the keys twice: at 97 % hits some unit overflows and the call
+    must notice and take count + write)."""
     import torch
     from libgdf_amd.columns import Column
     nb, npr = (40_000, 500_000) if size == "small" else (3_000_000, 30_000_000)

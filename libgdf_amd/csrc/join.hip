@@ -1180,6 +1180,11 @@ struct ProbeArgs {
   int key_width;
   const void *key_src;
   void *key_out;
+  // the BUILD relation's payload word (INNER joins): bpay_mode as pay_mode; jk_probe_bp takes it from the LDS image of the build
+  // partition (build.pay staged next to the tuples), the general kernels from the source columns by build row
+  int bpay_mode;
+  const void *bpay_src[2];
+  void *bpay_out[2];
 };
 // the general kernels' payload write: a gather by probe row (rare units only)
 __device__ __forceinline__ void pay_gather(const ProbeArgs &a, unsigned long long pos, int32_t prow) {
@@ -1190,6 +1195,13 @@ __device__ __forceinline__ void pay_gather(const ProbeArgs &a, unsigned long lon
   }
   if (a.key_width == 8) ((uint64_t *)a.key_out)[pos] = ((const uint64_t *)a.key_src)[prow];
   else if (a.key_width == 4) ((uint32_t *)a.key_out)[pos] = ((const uint32_t *)a.key_src)[prow];
+}
+__device__ __forceinline__ void bpay_gather(const ProbeArgs &a, unsigned long long pos, int32_t brow) {
+  if (a.bpay_mode == 1) ((uint64_t *)a.bpay_out[0])[pos] = ((const uint64_t *)a.bpay_src[0])[brow];
+  else if (a.bpay_mode) {
+    ((uint32_t *)a.bpay_out[0])[pos] = ((const uint32_t *)a.bpay_src[0])[brow];
+    if (a.bpay_mode == 3) ((uint32_t *)a.bpay_out[1])[pos] = ((const uint32_t *)a.bpay_src[1])[brow];
+  }
 }
 
 // LDS image of one work unit's build partition (dynamic region, every carve 16-byte aligned):
@@ -1440,10 +1452,12 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
           a.out_probe[pos] = prow[b];
           a.out_build[pos] = build_row<NARROW>(l, hit_a[b]);
           pay_gather(a, pos, prow[b]);
+          bpay_gather(a, pos, build_row<NARROW>(l, hit_a[b]));
           if (c == 2) {
             a.out_probe[pos + 1] = prow[b];
             a.out_build[pos + 1] = build_row<NARROW>(l, hit_b[b]);
             pay_gather(a, pos + 1, prow[b]);
+            bpay_gather(a, pos + 1, build_row<NARROW>(l, hit_b[b]));
           }
         } else if (c > 1) {      // multimap mode with several matches: walk the key's chain again
           for (uint32_t p = hit_b[b]; p != JK_NOPOS; p = l.next[p]) {
@@ -1451,6 +1465,7 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
               a.out_probe[pos] = prow[b];
               a.out_build[pos] = build_row<NARROW>(l, p);
               pay_gather(a, pos, prow[b]);
+              bpay_gather(a, pos, build_row<NARROW>(l, p));
               ++pos;
             }
           }
@@ -1826,6 +1841,186 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_count_fast(ProbeArgs a) {
   }
 }
 
+// The plain INNER write pass with the BUILD relation's payload word in the LDS image (PayCarry::bmode): the build partition is
+// staged as (tuple, payload) pairs and every pair writes the build payload next to its index pair, the probe payload (PP: the
+// probe tuples carry one too) and the key -- a materialising join without a single gather.  NARROW tuples.  The image is
+// 16 bytes per build tuple: one 1024-thread workgroup per CU (86 KB at C3's partition size) instead of two 512-thread ones;
+// a unit's staging + cuckoo build is ~2 % of its time, so little is lost to the missing overlap.
+constexpr int JK_BP_THREADS = 1024;
+static size_t probe_bp_lds_bytes(uint32_t cap, uint32_t H) { return (size_t)cap * 16 + (size_t)H * 8 + 16; }
+template <bool POW2, bool PP>
+__global__ __launch_bounds__(JK_BP_THREADS) void jk_probe_bp(ProbeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const uint32_t H = a.nslots, cap = a.cap;
+  uint64_t *bw = (uint64_t *)lds_raw;                               // [cap] key32 << 32 | build row
+  uint64_t *bp = bw + cap;                                          // [cap] build payload word
+  uint32_t *T = (uint32_t *)(bp + cap);                             // [2 H] cuckoo tables of positions
+  unsigned int *lcur = (unsigned int *)(T + 2 * (size_t)H);         // pairs written so far by this unit
+  unsigned int *failed = lcur + 1;
+  const Unit u = a.units[blockIdx.x];
+  for (uint32_t i = threadIdx.x; i < u.build_count; i += JK_BP_THREADS) {
+    bw[i] = a.build.w[u.build_begin + i];
+    bp[i] = a.build.pay[u.build_begin + i];
+  }
+  for (uint32_t i = threadIdx.x; i < 2 * H; i += JK_BP_THREADS) T[i] = JK_NOPOS;
+  if (threadIdx.x == 0) { *lcur = 0; *failed = 0; }
+  block_sync();
+  const uint32_t kb_lo = (uint32_t)a.kbias, kb_hi = (uint32_t)(a.kbias >> 32);
+  auto fold_of = [&](uint32_t key) -> uint32_t {
+    const uint32_t lo = key + kb_lo;
+    const uint32_t hi = kb_hi + (lo < key ? 1u : 0u);
+    return lo ^ (hi * 0x9e3779b1u);
+  };
+  const int hshift = POW2 ? 32 - (__ffs((int)H) - 1) : 0;
+  uint32_t seed = 0;
+  for (int attempt = 0; attempt < 4; ++attempt) {
+    for (uint32_t p0 = threadIdx.x; p0 < u.build_count; p0 += JK_BP_THREADS) {
+      uint32_t cur = p0, table = 0;
+      int moves = 0;
+      for (; moves < JK_CUCKOO_MAX_MOVES; ++moves) {
+        const uint32_t f = fold_of((uint32_t)(bw[cur] >> 32)) ^ seed;
+        const uint32_t slot = table ? H + (POW2 ? (f * 0xc2b2ae35u) >> hshift : __umulhi(f * 0xc2b2ae35u, H))
+                                    : (POW2 ? (f * 0x9e3779b1u) >> hshift : __umulhi(f * 0x9e3779b1u, H));
+        const uint32_t old = atomicExch(&T[slot], cur);
+        if (old == JK_NOPOS) break;
+        cur = old;
+        table ^= 1;
+      }
+      if (moves == JK_CUCKOO_MAX_MOVES) *failed = 1;
+    }
+    block_sync();
+    if (!*failed || attempt == 3) break;
+    block_sync();
+    for (uint32_t i = threadIdx.x; i < 2 * H; i += JK_BP_THREADS) T[i] = JK_NOPOS;
+    if (threadIdx.x == 0) *failed = 0;
+    seed += 0x9e3779b9u;
+    block_sync();
+  }
+  if (*failed) {
+    if (threadIdx.x == 0) a.unit_todo[atomicAdd(&a.opt_state[2], 1ull)] = blockIdx.x;
+    return;
+  }
+  const unsigned long long unit_base = a.counts[blockIdx.x];
+  const uint32_t unit_cap = a.optimistic ? u.probe_count : 0xffffffffu;
+  int32_t *__restrict__ op = a.out_probe + unit_base;
+  int32_t *__restrict__ ob = a.out_build + unit_base;
+  // output columns: widths are workgroup-uniform run-time values (one kernel for every payload mode)
+  uint64_t *__restrict__ po8 = (PP && a.pay_mode == 1) ? (uint64_t *)a.pay_out[0] + unit_base : nullptr;
+  uint32_t *__restrict__ po4a = (PP && a.pay_mode >= 2) ? (uint32_t *)a.pay_out[0] + unit_base : nullptr;
+  uint32_t *__restrict__ po4b = (PP && a.pay_mode == 3) ? (uint32_t *)a.pay_out[1] + unit_base : nullptr;
+  uint64_t *__restrict__ bo8 = a.bpay_mode == 1 ? (uint64_t *)a.bpay_out[0] + unit_base : nullptr;
+  uint32_t *__restrict__ bo4a = a.bpay_mode >= 2 ? (uint32_t *)a.bpay_out[0] + unit_base : nullptr;
+  uint32_t *__restrict__ bo4b = a.bpay_mode == 3 ? (uint32_t *)a.bpay_out[1] + unit_base : nullptr;
+  uint64_t *__restrict__ ko8 = a.key_width == 8 ? (uint64_t *)a.key_out + unit_base : nullptr;
+  uint32_t *__restrict__ ko4 = a.key_width == 4 ? (uint32_t *)a.key_out + unit_base : nullptr;
+  // (with a probe payload as well a batch of 8 tuples per lane needs more than the 128 registers a 1024-thread workgroup gets)
+  constexpr int BATCH = PP ? 3 : JK_PROBE_BATCH, NB = BATCH * 2;
+  const uint32_t lead = u.probe_begin & 1u;
+  const uint64_t *__restrict__ src = a.probe.w + (u.probe_begin - lead);
+  const uint64_t *__restrict__ src_pay = PP ? a.probe.pay + (u.probe_begin - lead) : nullptr;
+  const uint32_t vtotal = lead + u.probe_count;
+  const uint32_t last_pair = (vtotal - 1) & ~1u;
+  for (uint32_t base = 0; base < vtotal; base += JK_BP_THREADS * NB) {
+    uint32_t key[NB], prow[NB];
+    uint64_t pay[PP ? NB : 1];
+    bool act[NB];
+#pragma unroll
+    for (int b = 0; b < BATCH; ++b) {
+      const uint32_t v = base + (b * JK_BP_THREADS + threadIdx.x) * 2;
+      const uint32_t vc = v < last_pair ? v : last_pair;
+      const ulonglong2 ww = *reinterpret_cast<const ulonglong2 *>(src + vc);
+      if constexpr (PP) {
+        const ulonglong2 pp = *reinterpret_cast<const ulonglong2 *>(src_pay + vc);
+        pay[2 * b] = pp.x; pay[2 * b + 1] = pp.y;
+      }
+      key[2 * b] = (uint32_t)(ww.x >> 32); prow[2 * b] = (uint32_t)ww.x;
+      key[2 * b + 1] = (uint32_t)(ww.y >> 32); prow[2 * b + 1] = (uint32_t)ww.y;
+      act[2 * b] = v >= lead && v < vtotal;
+      act[2 * b + 1] = v + 1 < vtotal;
+    }
+    uint32_t pa[NB], pb[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const uint32_t f = fold_of(key[b]) ^ seed;
+      pa[b] = T[POW2 ? (f * 0x9e3779b1u) >> hshift : __umulhi(f * 0x9e3779b1u, H)];
+      pb[b] = T[H + (POW2 ? (f * 0xc2b2ae35u) >> hshift : __umulhi(f * 0xc2b2ae35u, H))];
+    }
+    uint64_t wa[NB], wb[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      wa[b] = bw[pa[b] == JK_NOPOS ? 0 : pa[b]];
+      wb[b] = bw[pb[b] == JK_NOPOS ? 0 : pb[b]];
+    }
+    // per tuple ONE candidate survives in registers -- the position and build row of its hit (table 0 first); the rare tuple
+    // with a hit in both tables (a build key present twice) re-reads the second one from LDS when it is written
+    uint32_t hamask = 0, hbmask = 0, hpos[NB], hrow[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const bool ha = act[b] && pa[b] != JK_NOPOS && (uint32_t)(wa[b] >> 32) == key[b];
+      const bool hb = act[b] && pb[b] != JK_NOPOS && (uint32_t)(wb[b] >> 32) == key[b];
+      hamask |= (uint32_t)ha << b;
+      hbmask |= (uint32_t)hb << b;
+      hpos[b] = ha ? pa[b] : (hb ? pb[b] : 0u);
+      hrow[b] = ha ? (uint32_t)wa[b] : (uint32_t)wb[b];
+    }
+    uint64_t q[NB];                 // the build payload of the hit: one more LDS read per tuple, requested together
+#pragma unroll
+    for (int b = 0; b < NB; ++b) q[b] = bp[hpos[b]];
+    auto emit_one = [&](int b, uint32_t pos, uint32_t brow, uint64_t bpay) {
+      if (pos >= unit_cap) { a.opt_state[1] = 1; return; }   // would spill into the next unit's slots: the host redoes the join two-pass
+      op[pos] = (int32_t)prow[b];
+      ob[pos] = (int32_t)brow;
+      if (bo8) bo8[pos] = bpay;
+      if (bo4a) bo4a[pos] = (uint32_t)bpay;
+      if (bo4b) bo4b[pos] = (uint32_t)(bpay >> 32);
+      if (ko8) ko8[pos] = (uint64_t)key[b] + a.kbias;
+      if (ko4) ko4[pos] = key[b];
+      if constexpr (PP) {
+        if (po8) po8[pos] = pay[b];
+        if (po4a) po4a[pos] = (uint32_t)pay[b];
+        if (po4b) po4b[pos] = (uint32_t)(pay[b] >> 32);
+      }
+    };
+    if (__all((hamask & hbmask) == 0)) {
+      // nobody has two pairs for one tuple: ONE claim per wave and batch (see jk_probe_fast)
+      const uint32_t onemask = hamask | hbmask;
+      unsigned long long mm[NB];
+      uint32_t off[NB], tot = 0;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        mm[b] = __ballot((onemask >> b) & 1u);
+        off[b] = tot;
+        tot += (uint32_t)__popcll(mm[b]);
+      }
+      uint32_t wbase = 0;
+      if (lane_id() == 0 && tot) wbase = atomicAdd(lcur, tot);
+      wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+        if ((onemask >> b) & 1u) emit_one(b, wbase + off[b] + (uint32_t)mask_rank(mm[b]), hrow[b], q[b]);
+    } else {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const uint32_t c = ((hamask >> b) & 1u) + ((hbmask >> b) & 1u);
+        const uint32_t incl = wave_scan_incl(c);
+        const uint32_t wave_total = __shfl(incl, WAVE - 1, WAVE);
+        uint32_t wbase = 0;
+        if (lane_id() == 0 && wave_total) wbase = atomicAdd(lcur, wave_total);
+        uint32_t pos = __shfl(wbase, 0, WAVE) + incl - c;
+        if (c) emit_one(b, pos++, hrow[b], q[b]);
+        if (c == 2) emit_one(b, pos, (uint32_t)bw[pb[b]], bp[pb[b]]);      // the second copy of the key, from table 1
+      }
+    }
+  }
+  if (a.optimistic) {
+    block_sync();
+    if (threadIdx.x == 0) {
+      atomicAdd(&a.opt_state[0], (unsigned long long)*lcur);
+      if (a.unit_pairs) a.unit_pairs[blockIdx.x] = *lcur;
+    }
+  }
+}
+
 // Sparse optimistic pass: every unit wrote its pairs at the START of its own slot range (slot_off[u], room for one pair per
 // probe tuple); this moves them to their final, dense places (pair_off[u] = exclusive scan of the units' pair counts).
 // One workgroup per unit, 16 B per pair -- cheaper than a count pass (which reads every probe tuple and rebuilds every LDS
@@ -1846,7 +2041,7 @@ __device__ __forceinline__ void compact_column(const void *src, void *dst, uint6
     for (int k = 0; k < 4; ++k) if (i + k * 256 < n) d[i + k * 256] = v[k];
   }
 }
-struct PayMove { int ncols; int width[3]; const void *src[3]; void *dst[3]; };      // carried columns (payload, key): 8- or 4-byte elements
+struct PayMove { int ncols; int width[5]; const void *src[5]; void *dst[5]; };      // carried columns (probe payload, key, build payload): 8- or 4-byte elements
 __global__ __launch_bounds__(256) void jk_compact_units(const uint64_t *__restrict__ slot_off, const uint64_t *__restrict__ pair_off,
                                                         const int32_t *__restrict__ sp, const int32_t *__restrict__ sb,
                                                         int32_t *__restrict__ dp, int32_t *__restrict__ db, PayMove pm) {
@@ -2013,6 +2208,7 @@ __global__ void gj_probe(ProbeArgs a, KeyTable probe_t, KeyTable build_t, const 
             a.out_probe[pos] = prow;
             a.out_build[pos] = r;
             pay_gather(a, pos, prow);
+            bpay_gather(a, pos, r);
             ++pos;
           }
         }
@@ -2143,6 +2339,15 @@ struct PayCarry {
   int key_width = 0;                   // 8 / 4; 0: the caller gathers the key column
   const void *key_src = nullptr;       // the probe relation's key column
   void *key_dst = nullptr;             // OUT, like dst[]
+  // INNER joins: the BUILD relation's non-key column(s) as well (same modes): the word travels through the build side's
+  // partition passes, sits next to the build tuple in LDS and is written per pair (jk_probe_bp) -- instead of a gather that,
+  // L2-friendly or not, pays one request per value (8.9 ms per column and 1e9 pairs)
+  int bmode = 0;
+  const void *bsrc[2] = {nullptr, nullptr};
+  void *bdst[2] = {nullptr, nullptr};  // OUT, set iff build_carried
+  bool build_carried = false;          // OUT
+  int belem_bytes() const { return bmode == 1 ? 8 : 4; }
+  int bncols() const { return bmode == 3 ? 2 : (bmode ? 1 : 0); }
   int elem_bytes(int c) const { return mode == 1 ? 8 : 4; }
   int ncols() const { return mode == 3 ? 2 : (mode ? 1 : 0); }
 };
@@ -2364,6 +2569,9 @@ static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, Si
   int sc_threads = sc_threads_env ? sc_threads_env : (narrow ? 1024 : 512);   // swept on C3: profiles/r1_c_sweeps.md
   if (sc_threads != 256 && sc_threads != 512 && sc_threads != 1024) sc_threads = 256;
   if (!narrow && sc_threads == 1024) sc_threads = 512;       // 16384 x 12 B would not fit 160 KiB
+  // a payload word only travels with NARROW tuples from a FAST, unmasked key column (jk_scatter1_pay); a build side that turns out
+  // otherwise simply does not carry it (sb->pay stays empty and the caller gathers)
+  if (pay && !(narrow && fast && !t.col[0].valid)) pay = nullptr;
   const int sc2_threads = pay ? 256 : level2_threads(sc_threads);
   const int64_t JK_TILE2 = (int64_t)sc2_threads * (pay ? JK_PAY_ITEMS : JK_SC_ITEMS);
 
@@ -2650,7 +2858,17 @@ static gdf_error run_write_pass(bool narrow, bool plain, size_t nunits, size_t l
     GDF_LAUNCH("jk_probe_write", (jk_probe_fast<__VA_ARGS__>), dim3((unsigned)nunits), dim3(JK_PROBE_THREADS), flds, stream0(), fa); \
   } while (0)
   const bool keep = a.keep_unmatched_probe != 0;
-  if (narrow && a.pay_mode) {
+  if (narrow && a.bpay_mode && !keep) {        // the build relation's payload word rides in the LDS image (jk_probe_bp)
+    const size_t blds = probe_bp_lds_bytes(a.cap, fa.nslots);
+#define JK_BP_LAUNCH(P2, PPAY)                                                                                                    \
+  do {                                                                                                                            \
+    HIP_TRY(hipFuncSetAttribute((const void *)jk_probe_bp<P2, PPAY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds));    \
+    GDF_LAUNCH("jk_probe_write", (jk_probe_bp<P2, PPAY>), dim3((unsigned)nunits), dim3(JK_BP_THREADS), blds, stream0(), fa);      \
+  } while (0)
+    if (pow2 && a.pay_mode) JK_BP_LAUNCH(true, true); else if (pow2) JK_BP_LAUNCH(true, false);
+    else if (a.pay_mode) JK_BP_LAUNCH(false, true); else JK_BP_LAUNCH(false, false);
+#undef JK_BP_LAUNCH
+  } else if (narrow && a.pay_mode) {
 #define JK_FAST_PAY(M)                                                                                                             \
   do {                                                                                                                             \
     if (pow2 && keep) JK_FAST_LAUNCH(true, true, true, M); else if (pow2) JK_FAST_LAUNCH(true, false, true, M);                    \
@@ -2846,12 +3064,14 @@ static gdf_error plan_ranged(const KeyTable &build_t, KeyPlan *plan) {
   return GDF_SUCCESS;
 }
 
-static gdf_error prepare_build(const KeyTable &build_t, BuildSide *bs, bool no_level3 = false) {
+// bpay / bmode (PayCarry::bmode): the build relation's payload word travels with its tuples when the side ends up on NARROW
+// tuples from one FAST, unmasked key column (partition_side decides; B.pay stays empty otherwise)
+static gdf_error prepare_build(const KeyTable &build_t, BuildSide *bs, bool no_level3 = false, const PaySrc *bpay = nullptr, int bmode = 0) {
   bs->plan = plan_keys(build_t);           // a function of the key dtypes only: the probe relation has the same ones
   GDF_TRY(plan_ranged(build_t, &bs->plan));
   bs->g = choose_geometry(build_t.nrows);
   const bool range_candidate = !bs->plan.narrow && bs->plan.mode == KM_RAW_INT && build_t.col[0].width == 8;
-  GDF_TRY(partition_side(build_t, bs->plan, bs->g, &bs->B, range_candidate));   // may switch plan to the narrow format
+  GDF_TRY(partition_side(build_t, bs->plan, bs->g, &bs->B, range_candidate, bpay, bmode));   // may switch plan to the narrow format
   if (bs->g.b3 > 0 && !no_level3) {
     bool ok = false;
     GDF_TRY(refine_side(bs->g, bs->plan.narrow != 0, 0.0, &bs->B, &ok));
@@ -2860,9 +3080,9 @@ static gdf_error prepare_build(const KeyTable &build_t, BuildSide *bs, bool no_l
     // a refined partition that still does not fit LDS (skew) needs the global-table path, which wants the exact layout:
     // such a relation is partitioned again without the third level
     if (ok && largest > (uint32_t)JK_MAX_BUILD) {
-      bs->B.w[0].reset(); bs->B.w[1].reset(); bs->B.idx[0].reset(); bs->B.idx[1].reset();
+      bs->B.w[0].reset(); bs->B.w[1].reset(); bs->B.idx[0].reset(); bs->B.idx[1].reset(); bs->B.pay[0].reset(); bs->B.pay[1].reset();
       bs->g.b3 = 0;
-      GDF_TRY(partition_side(build_t, bs->plan, bs->g, &bs->B, false));
+      GDF_TRY(partition_side(build_t, bs->plan, bs->g, &bs->B, false, bpay, bmode));
     } else if (!ok) {
       bs->g.b3 = 0;
     }
@@ -2923,8 +3143,10 @@ static gdf_error probe_prepared(const KeyTable &probe_t, const KeyTable &build_t
   // the probe relation's payload column(s) ride along (PayCarry) when the join runs on NARROW tuples with exact keys from
   // one FAST, unmasked key column; everything else leaves pc->carried false and the caller gathers as before
   PaySrc pay_src{};
-  const bool carry = pc && pc->mode && plan.narrow && !plan.verify && probe_fast && !probe_t.col[0].valid && kind != JOIN_FULL &&
-                     !lab::path_on("GDF_JK_NO_CARRY");
+  const bool carry_any = pc && plan.narrow && !plan.verify && kind != JOIN_FULL && !lab::path_on("GDF_JK_NO_CARRY");
+  const bool carry = carry_any && pc->mode && probe_fast && !probe_t.col[0].valid;
+  // (what probe_partitioned gets: the carry request when the probe payload travels or the build payload did, see prepare_build)
+  PayCarry *pc_eff = (carry || (carry_any && kind == JOIN_INNER && pc->bmode && B.pay[B.final_buf].p)) ? pc : nullptr;
   if (carry) { pay_src.col[0] = pc->src[0]; pay_src.col[1] = pc->src[1]; }
   const PaySrc *pay = carry ? &pay_src : nullptr;
   const int pmode = carry ? pc->mode : 0;
@@ -2943,13 +3165,13 @@ static gdf_error probe_prepared(const KeyTable &probe_t, const KeyTable &build_t
     if (!ok) return GDF_AMD_RETRY_WITHOUT_LEVEL3;     // skewed probe keys: the caller repeats with a 2^fb-partition build side
   }
   clk.mark("partition probe side");
-  gdf_error e = probe_partitioned(probe_t, build_t, bs, P, kind, out_probe, out_build, out_n, clk, carry ? pc : nullptr);
+  gdf_error e = probe_partitioned(probe_t, build_t, bs, P, kind, out_probe, out_build, out_n, clk, pc_eff);
   if (e != GDF_AMD_RETRY_EXACT_PROBE) return e;
   // a deferred speculative probe side turned out to have overflowed (skewed keys): the exact layout, host bookkeeping
   SideBufs Q;
   KeyPlan probe_plan = plan;
   GDF_TRY(partition_side(probe_t, probe_plan, g, &Q, false, pay, pmode));
-  return probe_partitioned(probe_t, build_t, bs, Q, kind, out_probe, out_build, out_n, clk, carry ? pc : nullptr);
+  return probe_partitioned(probe_t, build_t, bs, Q, kind, out_probe, out_build, out_n, clk, pc_eff);
 }
 
 // the part of a join after both relations are partitioned: work units, optimistic single pass or count + write, tails
@@ -3018,40 +3240,62 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
     HIP_TRY(hipMemsetAsync(d_matched.p, 0, (size_t)(build_t.nrows ? build_t.nrows : 1), stream0()));
   }
 
-  // carried payload: the output columns, sized when the pair count is known
-  DevBuf pay_out[2], key_out;
-  const int key_width = (pc && kind == JOIN_INNER) ? pc->key_width : 0;
+  // carried columns (PayCarry): probe payload (<= 2), key, build payload (<= 2) -- sized when the pair count is known
+  struct Carried { int width; DevBuf buf; void **commit; };
+  Carried cc[5];
+  int ncc = 0, probe_cc = 0, key_cc = -1, build_cc = -1;
+  // (the BP image is 16 bytes per build tuple + the tables: with very full partitions it does not fit one CU's 160 KiB -- the
+  // build payload is then gathered like any other column)
+  const bool bp_pow2 = (double)max_build <= 0.42 * 2.0 * (double)H_lds;
+  const uint32_t bp_slots = bp_pow2 ? H_lds : (((uint32_t)(max_build * 1.25) + 63) & ~63u);
+  const bool build_pay = pc && kind == JOIN_INNER && pc->bmode && B.pay[B.final_buf].p != nullptr && narrow && !plan.verify &&
+                         oversize.empty() && probe_bp_lds_bytes(cap_lds, bp_slots) <= (size_t)160 * 1024;
+  const bool probe_pay = pc && pc->mode && P.pay[P.final_buf].p != nullptr;
+  if (pc) {
+    if (probe_pay) for (int c = 0; c < pc->ncols(); ++c) { cc[ncc].width = pc->elem_bytes(c); cc[ncc++].commit = &pc->dst[c]; }
+    probe_cc = ncc;
+    if (kind == JOIN_INNER && pc->key_width && (probe_pay || build_pay)) { key_cc = ncc; cc[ncc].width = pc->key_width; cc[ncc++].commit = &pc->key_dst; }
+    if (build_pay) { build_cc = ncc; for (int c = 0; c < pc->bncols(); ++c) { cc[ncc].width = pc->belem_bytes(); cc[ncc++].commit = &pc->bdst[c]; } }
+  }
   auto alloc_pay = [&](uint64_t total) -> gdf_error {
-    if (!pc) return GDF_SUCCESS;
-    for (int c = 0; c < pc->ncols(); ++c) RMM_TRY(pay_out[c].alloc((size_t)pc->elem_bytes(c) * (size_t)(total ? total : 1)));
-    if (key_width) RMM_TRY(key_out.alloc((size_t)key_width * (size_t)(total ? total : 1)));
+    for (int c = 0; c < ncc; ++c) RMM_TRY(cc[c].buf.alloc((size_t)cc[c].width * (size_t)(total ? total : 1)));
     return GDF_SUCCESS;
   };
   auto set_pay = [&](ProbeArgs &x) {
     if (!pc) return;
-    x.pay_mode = pc->mode;
-    for (int c = 0; c < 2; ++c) { x.pay_src[c] = pc->src[c]; x.pay_out[c] = pay_out[c].p; }
-    x.key_width = key_width;
-    x.key_src = pc->key_src;
-    x.key_out = key_out.p;
-  };
-  auto pay_move_at = [&](uint64_t first) -> PayMove {        // the payload columns from output position `first` on, filled from the source by row
-    PayMove pm{};                                            // (LEFT-join tails; the key column is only carried by INNER joins, which have none)
-    if (!pc) return pm;
-    pm.ncols = pc->ncols();
-    for (int c = 0; c < pc->ncols(); ++c) {
-      pm.width[c] = pc->elem_bytes(c);
-      pm.src[c] = pc->src[c];
-      pm.dst[c] = pay_out[c].as<char>() + first * (uint64_t)pc->elem_bytes(c);
+    if (probe_pay) {
+      x.pay_mode = pc->mode;
+      for (int c = 0; c < pc->ncols(); ++c) { x.pay_src[c] = pc->src[c]; x.pay_out[c] = cc[c].buf.p; }
     }
+    if (key_cc >= 0) { x.key_width = pc->key_width; x.key_src = pc->key_src; x.key_out = cc[key_cc].buf.p; }
+    if (build_cc >= 0) {
+      x.bpay_mode = pc->bmode;
+      for (int c = 0; c < pc->bncols(); ++c) { x.bpay_src[c] = pc->bsrc[c]; x.bpay_out[c] = cc[build_cc + c].buf.p; }
+    }
+  };
+  auto pay_move_at = [&](uint64_t first) -> PayMove {        // the probe payload columns from output position `first` on, filled from the source by row
+    PayMove pm{};                                            // (LEFT-join tails; key and build payload are only carried by INNER joins, which have none)
+    for (int c = 0; c < probe_cc; ++c) {
+      pm.width[c] = cc[c].width;
+      pm.src[c] = pc->src[c];
+      pm.dst[c] = cc[c].buf.as<char>() + first * (uint64_t)cc[c].width;
+    }
+    pm.ncols = probe_cc;
+    return pm;
+  };
+  auto pay_move_all = [&](DevBuf (*dense)[5]) -> PayMove {   // every carried column: from its buffer into dense[] (compaction) or in place (null)
+    PayMove pm{};
+    for (int c = 0; c < ncc; ++c) { pm.width[c] = cc[c].width; pm.src[c] = cc[c].buf.p; pm.dst[c] = dense ? (*dense)[c].p : cc[c].buf.p; }
+    pm.ncols = ncc;
     return pm;
   };
   auto commit_pay = [&]() {
     if (!pc) return;
-    for (int c = 0; c < pc->ncols(); ++c) pc->dst[c] = pay_out[c].release();
-    if (key_width) pc->key_dst = key_out.release();
-    pc->carried = true;
+    for (int c = 0; c < ncc; ++c) *cc[c].commit = cc[c].buf.release();
+    pc->carried = probe_pay;
+    pc->build_carried = build_cc >= 0;
   };
+  auto drop_pay = [&]() { for (int c = 0; c < ncc; ++c) cc[c].buf.reset(); };
 
   ProbeArgs a{};
   a.build = B.final();
@@ -3139,8 +3383,8 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
   // SPARSE optimistic pass: the sample says fewer than one pair per probe tuple (some probe rows miss) and no repeated build
   // keys.  The single write pass still works -- a unit's pairs fit the slots of its probe tuples -- it just leaves a hole at the
   // end of every unit's range.  Closing the holes is cheaper than the count pass it replaces (8 B per probe TUPLE plus a second
-  // build of every LDS table) at EVERY hit rate: below 50 % by packing all pairs into exact-size columns (jk_compact_units,
-  // 16 B per pair), from 50 % on by moving only the pairs behind the final size into the holes in front of it (jk_fill_holes:
+  // build of every LDS table) at EVERY hit rate: below a third by packing all pairs into exact-size columns (jk_compact_units,
+  // 16 B per pair), from a third on by moving only the pairs behind the final size into the holes in front of it (jk_fill_holes:
   // h (1 - h) of the slots; the columns keep their allocation of one slot per probe tuple).  A unit that runs out of slots
   // (a build key present more than once after all) sends the call to count + write.
   const bool try_sparse = !try_optimistic && d_off.p && nunits && oversize.empty() && kind == JOIN_INNER && !dup_heavy && !(LAB_BITS(a.dbg) & 16) &&
@@ -3189,7 +3433,7 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
       commit_pay();
       return GDF_SUCCESS;
     }
-    if (try_sparse && st[1] == 0 && st[0] * 2 >= cap_pairs && !lab::knob_on("GDF_JK_NO_HOLE_FILL")) {
+    if (try_sparse && st[1] == 0 && st[0] * 3 >= cap_pairs && !lab::knob_on("GDF_JK_NO_HOLE_FILL")) {
       // most slots are taken: move only the pairs behind the final size into the holes in front of it (jk_fill_holes)
       const uint64_t pairs = st[0];
       DevBuf d_holes, d_tails;
@@ -3200,11 +3444,7 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
                  d_tails.as<uint64_t>());
       GDF_TRY(scan_u64(d_holes.as<uint64_t>(), d_holes.as<uint64_t>(), nunits + 1, false));
       GDF_TRY(scan_u64(d_tails.as<uint64_t>(), d_tails.as<uint64_t>(), nunits + 1, false));
-      PayMove pm{};
-      if (pc) {
-        for (int c = 0; c < pc->ncols(); ++c) { pm.width[pm.ncols] = pc->elem_bytes(c); pm.src[pm.ncols] = pay_out[c].p; pm.dst[pm.ncols++] = pay_out[c].p; }
-        if (key_width) { pm.width[pm.ncols] = key_width; pm.src[pm.ncols] = key_out.p; pm.dst[pm.ncols++] = key_out.p; }
-      }
+      const PayMove pm = pay_move_all(nullptr);
       GDF_LAUNCH("jk_fill_holes", jk_fill_holes, dim3((unsigned)nunits), dim3(256), 0, stream0(), (const uint64_t *)d_off.as<uint64_t>(),
                  (const uint32_t *)d_upairs.as<uint32_t>(), (uint32_t)nunits, pairs, (const uint64_t *)d_holes.as<uint64_t>(),
                  (const uint64_t *)d_tails.as<uint64_t>(), op.as<int32_t>(), ob.as<int32_t>(), pm);
@@ -3228,22 +3468,9 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
       GDF_TRY(scan_u64(d_poff.as<uint64_t>(), d_poff.as<uint64_t>(), nunits + 1, false));
       RMM_TRY(fp.alloc(sizeof(int32_t) * pairs));
       RMM_TRY(fb.alloc(sizeof(int32_t) * pairs));
-      DevBuf dense_pay[3];
-      PayMove pm{};
-      if (pc) {
-        for (int c = 0; c < pc->ncols(); ++c) {
-          RMM_TRY(dense_pay[c].alloc((size_t)pc->elem_bytes(c) * pairs));
-          pm.width[pm.ncols] = pc->elem_bytes(c);
-          pm.src[pm.ncols] = pay_out[c].p;
-          pm.dst[pm.ncols++] = dense_pay[c].p;
-        }
-        if (key_width) {
-          RMM_TRY(dense_pay[2].alloc((size_t)key_width * pairs));
-          pm.width[pm.ncols] = key_width;
-          pm.src[pm.ncols] = key_out.p;
-          pm.dst[pm.ncols++] = dense_pay[2].p;
-        }
-      }
+      DevBuf dense_pay[5];
+      for (int c = 0; c < ncc; ++c) RMM_TRY(dense_pay[c].alloc((size_t)cc[c].width * pairs));
+      const PayMove pm = pay_move_all(&dense_pay);
       GDF_LAUNCH("jk_compact_units", jk_compact_units, dim3((unsigned)nunits), dim3(256), 0, stream0(), (const uint64_t *)d_off.as<uint64_t>(),
                  (const uint64_t *)d_poff.as<uint64_t>(), (const int32_t *)op.as<int32_t>(), (const int32_t *)ob.as<int32_t>(), fp.as<int32_t>(),
                  fb.as<int32_t>(), pm);
@@ -3252,12 +3479,11 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
       clk.mark("compaction");
       *out_probe = (int32_t *)fp.release();
       *out_build = (int32_t *)fb.release();
-      if (pc) for (int c = 0; c < pc->ncols(); ++c) { pay_out[c].reset(); pay_out[c].p = dense_pay[c].release(); }
-      if (key_width) { key_out.reset(); key_out.p = dense_pay[2].release(); }
+      for (int c = 0; c < ncc; ++c) { cc[c].buf.reset(); cc[c].buf.p = dense_pay[c].release(); }
       commit_pay();
       return GDF_SUCCESS;
     }
-    pay_out[0].reset(); pay_out[1].reset(); key_out.reset();      // the attempt is discarded: the two-pass path sizes its own columns
+    drop_pay();      // the attempt is discarded: the two-pass path sizes its own columns
     // otherwise: fall through to the exact two-pass path (buffers above are released here)
   }
   const size_t nslots_all = nunits + oversize.size();     // one count slot per LDS unit + one per oversize partition
@@ -3381,12 +3607,15 @@ static gdf_error hash_join_core(const KeyTable &probe_t, const KeyTable &build_t
                                 int32_t **out_build, int64_t *out_n, PayCarry *pc = nullptr) {
   StageClock clk((lab::knob_int("GDF_JK_DBG", 0) & 512) != 0);
   BuildSide bs;
-  GDF_TRY(prepare_build(build_t, &bs));
+  PaySrc bsrc{};
+  const bool bcarry = pc && pc->mode >= 0 && pc->bmode && kind == JOIN_INNER && !lab::path_on("GDF_JK_NO_CARRY");
+  if (bcarry) { bsrc.col[0] = pc->bsrc[0]; bsrc.col[1] = pc->bsrc[1]; }
+  GDF_TRY(prepare_build(build_t, &bs, false, bcarry ? &bsrc : nullptr, bcarry ? pc->bmode : 0));
   clk.mark("partition build side");
   gdf_error e = probe_prepared(probe_t, build_t, bs, kind, out_probe, out_build, out_n, clk, pc);
   if (e != GDF_AMD_RETRY_WITHOUT_LEVEL3) return e;
   BuildSide plain;
-  GDF_TRY(prepare_build(build_t, &plain, true));
+  GDF_TRY(prepare_build(build_t, &plain, true, bcarry ? &bsrc : nullptr, bcarry ? pc->bmode : 0));
   return probe_prepared(probe_t, build_t, plain, kind, out_probe, out_build, out_n, clk, pc);
 }
 
@@ -3623,6 +3852,7 @@ static gdf_error join_entry(JoinKind kind, gdf_column **left_cols, int num_left_
   const int expect = num_left_cols + num_right_cols - num_cols_to_join;
   PayCarry pc;
   int carried_col[2] = {-1, -1};       // column numbers in the probe relation
+  int bcarried_col[2] = {-1, -1};      // ... and in the build relation
   bool probe_is_right = false;
   if (compute_df && result_num_cols == expect && kind != JOIN_FULL && ctx->flag_method == GDF_HASH && num_left_cols > 0 && num_right_cols > 0 &&
       left_cols[0] && right_cols[0]) {
@@ -3636,17 +3866,34 @@ static gdf_error join_entry(JoinKind kind, gdf_column **left_cols, int num_left_
       for (int i = 0; i < num_cols_to_join; ++i) is_key = is_key || pkeys[i] == c;
       if (!is_key) nonkey.push_back(c);
     }
-    bool plain = nonkey.size() == 1 || nonkey.size() == 2;
-    int width[2] = {0, 0};
-    for (size_t j = 0; plain && j < nonkey.size(); ++j) {
-      const gdf_column *col = pcols[nonkey[j]];
-      width[j] = col ? dtype_width(col->dtype) : -1;
-      plain = col && col->data && !col->valid && col->size == pcols[pkeys[0]]->size && (width[j] == 8 || width[j] == 4);
+    // mode of a relation's non-key columns: 1 = one 8-byte column, 2 = one 4-byte, 3 = two 4-byte, 0 = not carried
+    auto payload_mode = [&](gdf_column **cols, const std::vector<int> &which, const gdf_column *keycol, int (&slot)[2], const void *(&src)[2]) -> int {
+      if (which.size() != 1 && which.size() != 2) return 0;
+      int w[2] = {0, 0};
+      for (size_t j = 0; j < which.size(); ++j) {
+        const gdf_column *col = cols[which[j]];
+        w[j] = col ? dtype_width(col->dtype) : -1;
+        if (!col || !col->data || col->valid || col->size != keycol->size || (w[j] != 8 && w[j] != 4)) return 0;
+      }
+      if (which.size() == 2 && (w[0] != 4 || w[1] != 4)) return 0;
+      for (size_t j = 0; j < which.size(); ++j) { src[j] = cols[which[j]]->data; slot[j] = which[j]; }
+      return which.size() == 2 ? 3 : (w[0] == 8 ? 1 : 2);
+    };
+    pc.mode = payload_mode(pcols, nonkey, pcols[pkeys[0]], carried_col, pc.src);
+    if (kind == JOIN_INNER) {            // the build relation's non-key columns (jk_probe_bp)
+      gdf_column **bcols = probe_is_right ? left_cols : right_cols;
+      const int nbcols = probe_is_right ? num_left_cols : num_right_cols;
+      const int *bkeys = probe_is_right ? left_join_cols : right_join_cols;
+      std::vector<int> bnonkey;
+      for (int c = 0; c < nbcols; ++c) {
+        bool is_key = false;
+        for (int i = 0; i < num_cols_to_join; ++i) is_key = is_key || bkeys[i] == c;
+        if (!is_key) bnonkey.push_back(c);
+      }
+      pc.bmode = payload_mode(bcols, bnonkey, bcols[bkeys[0]], bcarried_col, pc.bsrc);
     }
-    if (plain && nonkey.size() == 2 && (width[0] != 4 || width[1] != 4)) plain = false;
+    const bool plain = pc.mode != 0 || pc.bmode != 0;
     if (plain) {
-      pc.mode = nonkey.size() == 2 ? 3 : (width[0] == 8 ? 1 : 2);
-      for (size_t j = 0; j < nonkey.size(); ++j) { pc.src[j] = pcols[nonkey[j]]->data; carried_col[j] = nonkey[j]; }
       // the result's key column: an INNER join's matched pair holds the same key bits on both sides when the key is ONE
       // integer column of one dtype without nulls -- the probe kernel then writes it from the tuple (no gather at all)
       if (kind == JOIN_INNER && num_cols_to_join == 1 && lj[0] && rj[0]) {
@@ -3664,11 +3911,12 @@ static gdf_error join_entry(JoinKind kind, gdf_column **left_cols, int num_left_
     PayCarry &pc;
     ~PayFree() {
       for (int c = 0; c < 2; ++c) if (pc.dst[c]) rmmFree(pc.dst[c], (cudaStream_t)0);
+      for (int c = 0; c < 2; ++c) if (pc.bdst[c]) rmmFree(pc.bdst[c], (cudaStream_t)0);
       if (pc.key_dst) rmmFree(pc.key_dst, (cudaStream_t)0);
     }
   } pay_free{pc};
 
-  gdf_error err = join_call(kind, num_cols_to_join, lj.data(), rj.data(), lout, rout, ctx, pc.mode ? &pc : nullptr);
+  gdf_error err = join_call(kind, num_cols_to_join, lj.data(), rj.data(), lout, rout, ctx, (pc.mode || pc.bmode) ? &pc : nullptr);
   if (!compute_df || err != GDF_SUCCESS) return err;
 
   // ---- materialise: [left non-key..., key columns..., right non-key...] ----
@@ -3704,9 +3952,15 @@ static gdf_error join_entry(JoinKind kind, gdf_column **left_cols, int num_left_
     }
   };
   auto take_carried = [&](bool right_side, int c, gdf_column *dst) -> int {      // 1: taken, 0: not a carried column, < 0: -(error)
-    if (!pc.carried || right_side != probe_is_right) return 0;
-    for (int j = 0; j < pc.ncols(); ++j)
-      if (carried_col[j] == c) return adopt(pc.dst[j], (right_side ? right_cols : left_cols)[c], dst);
+    if (right_side == probe_is_right) {
+      if (!pc.carried) return 0;
+      for (int j = 0; j < pc.ncols(); ++j)
+        if (carried_col[j] == c && pc.dst[j]) return adopt(pc.dst[j], (right_side ? right_cols : left_cols)[c], dst);
+    } else {
+      if (!pc.build_carried) return 0;
+      for (int j = 0; j < pc.bncols(); ++j)
+        if (bcarried_col[j] == c && pc.bdst[j]) return adopt(pc.bdst[j], (right_side ? right_cols : left_cols)[c], dst);
+    }
     return 0;
   };
   int o = 0;
@@ -3728,7 +3982,7 @@ static gdf_error join_entry(JoinKind kind, gdf_column **left_cols, int num_left_
     const bool same_bits = kind == JOIN_INNER && lk->dtype == rk->dtype && lk->dtype_info.time_unit == rk->dtype_info.time_unit &&
                            (ek == K_I8 || ek == K_I16 || ek == K_I32 || ek == K_I64) &&
                            (lk->valid == nullptr || lk->null_count == 0) && (rk->valid == nullptr || rk->null_count == 0);
-    if (pc.carried && pc.key_dst) {               // came out of the probe kernel (one key column: i == 0)
+    if (pc.key_dst) {                             // came out of the probe kernel (one key column: i == 0)
       const int took = adopt(pc.key_dst, lk, result_cols[o++]);
       if (took < 0) return (gdf_error)(-took);
     }

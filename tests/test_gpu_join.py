@@ -291,19 +291,22 @@ def test_carried_payload_matches_the_gather(gdf, how, payload, shape, kdt, force
             "i32": [rs.randint(-2**31, 2**31 - 1, size=npr).astype(np.int32)],
             "i32+f32": [rs.randint(-2**31, 2**31 - 1, size=npr).astype(np.int32), rs.random_sample(npr).astype(np.float32)],
             "i16": [rs.randint(-2**15, 2**15 - 1, size=npr).astype(np.int16)]}[payload]
-    bpay = rs.randint(0, 1000, size=nb).astype(np.int32)
+    # the BUILD relation's non-key columns travel too (INNER joins, jk_probe_bp): one 8-byte, one 4-byte or two 4-byte columns
+    bpays = {"i64": [rs.randint(-2**62, 2**62, size=nb).astype(np.int64)], "f64": [rs.randint(0, 1000, size=nb).astype(np.int32), rs.random_sample(nb).astype(np.float32)],
+             "i32": [rs.randint(0, 1000, size=nb).astype(np.int32)], "i32+f32": [rs.random_sample(nb)],
+             "i16": [rs.randint(0, 1000, size=nb).astype(np.int16)]}[payload]
     if shape == "probe-is-right":
         if how == "left":
             pytest.skip("a LEFT join always probes with the left relation")
-        a, b, cols = _join_with_result_cols(gdf, how, [build, bpay], 0, pays + [probe], len(pays))      # smaller relation on the LEFT: INNER flips
+        a, b, cols = _join_with_result_cols(gdf, how, [build] + bpays, 0, pays + [probe], len(pays))      # smaller relation on the LEFT: INNER flips
         el, er = oracle.join([build], [probe], how)
         probe_idx, build_idx = b, a
-        res_build_pay, res_key, res_probe_pay = cols[0], cols[1], cols[2:]
+        res_build_pay, res_key, res_probe_pay = cols[:len(bpays)], cols[len(bpays)], cols[len(bpays) + 1:]
     else:
-        a, b, cols = _join_with_result_cols(gdf, how, pays + [probe], len(pays), [build, bpay], 0)
+        a, b, cols = _join_with_result_cols(gdf, how, pays + [probe], len(pays), [build] + bpays, 0)
         el, er = oracle.join([probe], [build], how)
         probe_idx, build_idx = a, b
-        res_probe_pay, res_key, res_build_pay = cols[:len(pays)], cols[len(pays)], cols[len(pays) + 1]
+        res_probe_pay, res_key, res_build_pay = cols[:len(pays)], cols[len(pays)], cols[len(pays) + 1:]
     x, y = sort_pairs(a, b)
     ex, ey = sort_pairs(el, er)
     np.testing.assert_array_equal(x, ex)
@@ -314,9 +317,9 @@ def test_carried_payload_matches_the_gather(gdf, how, payload, shape, kdt, force
     d, v = res_key
     assert v.all()
     np.testing.assert_array_equal(d, probe[probe_idx])
-    d, v = res_build_pay
-    np.testing.assert_array_equal(v, build_idx >= 0)
-    np.testing.assert_array_equal(d[v], bpay[build_idx[v]])
+    for (d, v), src in zip(res_build_pay, bpays):
+        np.testing.assert_array_equal(v, build_idx >= 0)
+        np.testing.assert_array_equal(d[v], src[build_idx[v]])
 
 
 @pytest.mark.parametrize("how", ["inner", "left", "full"])

@@ -152,6 +152,7 @@ _RMM_PROTOTYPES = {
 
 GDF_CUDA_ERROR = 1
 GDF_UNSUPPORTED_METHOD = 12          # include/gdf/gdf.h gdf_error
+GDF_COLUMN_SIZE_TOO_BIG = 4
 GDF_INT64 = 4                        # include/gdf/gdf.h gdf_dtype
 
 

@@ -1102,10 +1102,10 @@ static gdf_error gb_plan_range_sampled(const KeyTable &t, GbKeyPlan *plan, bool 
   for (int c = 0; c < t.ncols; ++c)
     if (t.col[c].kind == K_F32 || t.col[c].kind == K_F64) return GDF_SUCCESS;
   if (t.nrows < (1 << 16)) return GDF_SUCCESS;
-  KeyTable ts = t;
-  ts.nrows = 1 << 16;
+  // sixteen windows of 4096 rows spread over the whole table (a 65536-row PREFIX saw a sliver of a sorted or time-ordered key
+  // column's range: the guess was violated only after the count and the full scatter pass had run on it)
   std::vector<long long> h(2 * t.ncols);
-  GDF_TRY(key_ranges(ts, h.data()));
+  GDF_TRY(key_ranges(t, h.data(), 16, 4096));
   int total = 0;
   GbKeyPlan p{};
   for (int c = 0; c < t.ncols; ++c) {

@@ -42,24 +42,48 @@ __global__ __launch_bounds__(HP_THREADS) void hash_rows_kernel(KeyTable t, uint3
 __device__ __forceinline__ uint32_t part_of(uint32_t h, uint32_t nparts, uint32_t pow2mask) {
   return pow2mask ? (h & pow2mask) : (h % nparts);
 }
+// TWO-LEVEL partitioning (gdf_hash_partition beyond 1024 partitions): a (tile, partition) run of the one-pass LDS-regrouped
+// scatter shrinks to a row or two there (P = 12000: 5.1 ms per 1e8 rows of two int64 columns, 0.10 of the roofline), so the rows
+// are first regrouped by SUPER-partition (partition >> kshift, at most 1024 of them) into a temporary table -- level A -- and
+// every super-partition is then split into its <= 2^kshift partitions -- level B, one chunk per super-partition.  Both levels
+// are the kernels below with another bin function; mode 0 is the one-level call.
+struct PartLevel {
+  int mode;                   // 0: bin = partition; 1 (level A): bin = partition >> kshift; 2 (level B): bin = partition - (chunk << kshift)
+  int kshift;
+  uint32_t hashP, hashmask;   // mode != 0: the caller's partition count (the hash modulus); nparts is then the number of BINS
+  uint32_t qstride, cstride;  // histogram / offsets index = bin * qstride + chunk * cstride; 0, 0: bin * nchunks + chunk
+  const uint32_t *bounds;     // mode 2: chunk c is rows [bounds[c], bounds[c + 1]) of the level-A table
+};
+__device__ __forceinline__ uint32_t level_bin(uint32_t h, uint32_t nparts, uint32_t pow2mask, const PartLevel &lv, int chunk) {
+  if (lv.mode == 0) return part_of(h, nparts, pow2mask);
+  const uint32_t p = part_of(h, lv.hashP, lv.hashmask);
+  return lv.mode == 1 ? p >> lv.kshift : p - ((uint32_t)chunk << lv.kshift);
+}
+__device__ __forceinline__ size_t hist_index(uint32_t bin, int chunk, int nchunks, const PartLevel &lv) {
+  return lv.qstride ? (size_t)bin * lv.qstride + (size_t)chunk * lv.cstride : (size_t)bin * nchunks + chunk;
+}
+__device__ __forceinline__ void chunk_rows(int c, int64_t chunk, int64_t n, const PartLevel &lv, int64_t &begin, int64_t &end) {
+  if (lv.bounds) { begin = lv.bounds[c]; end = lv.bounds[c + 1]; }
+  else { begin = (int64_t)c * chunk; end = begin + chunk < n ? begin + chunk : n; }
+}
 
 // hist layout: hist[p * nchunks + chunk]
 template <bool MURMUR>
 __global__ __launch_bounds__(HP_THREADS) void part_hist_kernel(KeyTable t, int64_t n, int64_t chunk, int nchunks,
                                                                uint32_t nparts, uint32_t pow2mask,
-                                                               uint32_t *__restrict__ hist) {
+                                                               uint32_t *__restrict__ hist, PartLevel lv) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_cnt[];
   for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
     for (uint32_t p = threadIdx.x; p < nparts; p += HP_THREADS) lds_cnt[p] = 0;
     block_sync();
-    const int64_t begin = (int64_t)c * chunk;
-    const int64_t end = begin + chunk < n ? begin + chunk : n;
+    int64_t begin, end;
+    chunk_rows(c, chunk, n, lv, begin, end);
     for (int64_t i = begin + threadIdx.x; i < end; i += HP_THREADS) {
-      const uint32_t p = part_of(hash_row<MURMUR>(t, i), nparts, pow2mask);
+      const uint32_t p = level_bin(hash_row<MURMUR>(t, i), nparts, pow2mask, lv, c);
       atomicAdd(&lds_cnt[p], 1u);
     }
     block_sync();
-    for (uint32_t p = threadIdx.x; p < nparts; p += HP_THREADS) hist[(size_t)p * nchunks + c] = lds_cnt[p];
+    for (uint32_t p = threadIdx.x; p < nparts; p += HP_THREADS) hist[hist_index(p, c, nchunks, lv)] = lds_cnt[p];
     block_sync();
   }
 }
@@ -74,13 +98,18 @@ constexpr int HP_BATCH = 8;
 template <class K>
 __global__ __launch_bounds__(HP_THREADS) void part_hist_fast_kernel(const K *__restrict__ key, int64_t n, int64_t chunk,
                                                                      int nchunks, uint32_t nparts, uint32_t pow2mask,
-                                                                     int agg_bits, uint32_t *__restrict__ hist) {
+                                                                     int agg_bits, uint32_t *__restrict__ hist, PartLevel lv) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_cnt[];
   for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
     for (uint32_t p = threadIdx.x; p < nparts; p += HP_THREADS) lds_cnt[p] = 0;
     block_sync();
-    const int64_t begin = (int64_t)c * chunk;
-    const int64_t end = begin + chunk < n ? begin + chunk : n;
+    int64_t begin, end;
+    chunk_rows(c, chunk, n, lv, begin, end);
+    if (begin >= end) {                      // (an empty super-partition at level B)
+      for (uint32_t p = threadIdx.x; p < nparts; p += HP_THREADS) hist[hist_index(p, c, nchunks, lv)] = 0;
+      block_sync();
+      continue;
+    }
     for (int64_t base = begin; base < end; base += HP_THREADS * HP_BATCH) {
       K k[HP_BATCH];
 #pragma unroll
@@ -91,13 +120,13 @@ __global__ __launch_bounds__(HP_THREADS) void part_hist_fast_kernel(const K *__r
 #pragma unroll
       for (int j = 0; j < HP_BATCH; ++j) {
         const bool live = base + (int64_t)j * HP_THREADS + threadIdx.x < end;
-        const uint32_t part = part_of(murmur3_32((uint64_t)k[j], (int)sizeof(K)), nparts, pow2mask);
+        const uint32_t part = level_bin(murmur3_32((uint64_t)k[j], (int)sizeof(K)), nparts, pow2mask, lv, c);
         if (agg_bits >= 0) wave_aggregated_inc(lds_cnt, part, agg_bits, live);     // agg_bits: see gdf_hash_partition
         else if (live) atomicAdd(&lds_cnt[part], 1u);
       }
     }
     block_sync();
-    for (uint32_t p = threadIdx.x; p < nparts; p += HP_THREADS) hist[(size_t)p * nchunks + c] = lds_cnt[p];
+    for (uint32_t p = threadIdx.x; p < nparts; p += HP_THREADS) hist[hist_index(p, c, nchunks, lv)] = lds_cnt[p];
     block_sync();
   }
 }
@@ -234,7 +263,7 @@ struct HptShape {
 template <bool MURMUR, int FASTW, int TH, int MAXP, int FI>      // FASTW = 8 / 4: one key column of that width read directly; 0: generic hash_row
 __global__ __launch_bounds__(TH) void part_scatter_tile_kernel(KeyTable t, PayloadCols pc, int64_t n, int64_t chunk,
                                                                int nchunks, uint32_t nparts, uint32_t pow2mask,
-                                                               const uint32_t *__restrict__ offs) {
+                                                               const uint32_t *__restrict__ offs, PartLevel lv) {
   using Shape = HptShape<TH, MAXP, FI, FASTW != 0>;
   constexpr int HPT_ITEMS = Shape::ITEMS;
   constexpr int HPT_TILE = Shape::TILE;
@@ -247,9 +276,9 @@ __global__ __launch_bounds__(TH) void part_scatter_tile_kernel(KeyTable t, Paylo
   uint32_t *wave_tot = cursor + MAXP;                                      // [TH / WAVE]
   uint16_t *bin_of = reinterpret_cast<uint16_t *>(wave_tot + TH / WAVE);   // [TILE]
   for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
-    if (threadIdx.x < nparts) cursor[threadIdx.x] = offs[(size_t)threadIdx.x * nchunks + c];
-    const int64_t begin = (int64_t)c * chunk;
-    const int64_t end = begin + chunk < n ? begin + chunk : n;
+    if (threadIdx.x < nparts) cursor[threadIdx.x] = offs[hist_index(threadIdx.x, c, nchunks, lv)];
+    int64_t begin, end;
+    chunk_rows(c, chunk, n, lv, begin, end);
     for (int64_t tile = begin; tile < end; tile += HPT_TILE) {
       if (threadIdx.x < HPT_MAX_PARTS) hist[threadIdx.x] = 0;
       block_sync();
@@ -265,7 +294,7 @@ __global__ __launch_bounds__(TH) void part_scatter_tile_kernel(KeyTable t, Paylo
 #pragma unroll
       for (int k = 0; k < HPT_ITEMS; ++k) {      // rows beyond the chunk are ranked on a trash counter: no branch around the
         const int64_t i = tile + (int64_t)k * HP_THREADS + threadIdx.x;       // atomic, all of them in flight together
-        const uint32_t p = part_of(FASTW ? murmur3_32(kk[k], FASTW) : hash_row<MURMUR>(t, src[k]), nparts, pow2mask);
+        const uint32_t p = level_bin(FASTW ? murmur3_32(kk[k], FASTW) : hash_row<MURMUR>(t, src[k]), nparts, pow2mask, lv, c);
         pr[k] = i < end ? p : (uint32_t)HPT_MAX_PARTS;
       }
 #pragma unroll
@@ -724,6 +753,139 @@ __global__ void gather_strided_u32(const uint32_t *in, uint32_t *out, int count,
 
 using namespace gdf_amd;
 
+
+// gdf_hash_partition beyond 1024 partitions (PartLevel): level A regroups every column by super-partition into a temporary table,
+// level B splits each super-partition.  Same result contract as the one-level call (rows of a partition in a deterministic order,
+// partition_offsets exact); costs one extra read + write of every column and a table-sized scratch.
+namespace gdf_amd {
+static gdf_error hash_partition_two_level(int ncols, gdf_column *input[], const int *columns_to_hash, int num_cols_to_hash, uint32_t P,
+                                          gdf_column *output[], int partition_offsets[], bool murmur) {
+  const int64_t n = (int64_t)input[0]->size;
+  int kshift = 0;
+  while (((P + (1u << kshift) - 1) >> kshift) > (uint32_t)HPT_BIG_PARTS) ++kshift;
+  const uint32_t K = 1u << kshift, S = (P + K - 1) >> kshift;
+  const uint32_t pow2mask = (P & (P - 1)) == 0 ? P - 1 : 0;
+
+  // the temporary table: data + (where both sides carry one) mask of every column
+  std::vector<DevBuf> tmp_data(ncols), tmp_valid(ncols);
+  std::vector<gdf_column> tmp_col(ncols);
+  std::vector<gdf_column *> key_in(num_cols_to_hash), key_tmp(num_cols_to_hash);
+  const size_t mask_words = (mask_bytes((size_t)n) + 3) / 4;
+  for (int i = 0; i < ncols; ++i) {
+    const int w = dtype_width(input[i]->dtype);
+    RMM_TRY(tmp_data[i].alloc((size_t)w * (size_t)n));
+    tmp_col[i] = *input[i];
+    tmp_col[i].data = tmp_data[i].p;
+    tmp_col[i].valid = nullptr;
+    if (input[i]->valid) {                   // a key column's mask decides nothing here (hash_row ignores it) but travels with its column
+      RMM_TRY(tmp_valid[i].alloc(mask_words * 4));
+      HIP_TRY(hipMemsetAsync(tmp_valid[i].p, 0, mask_words * 4, stream0()));
+      tmp_col[i].valid = (gdf_valid_type *)tmp_valid[i].p;
+    }
+  }
+  for (int i = 0; i < num_cols_to_hash; ++i) { key_in[i] = input[columns_to_hash[i]]; key_tmp[i] = &tmp_col[columns_to_hash[i]]; }
+  KeyTable t, t2;
+  GDF_TRY(make_key_table(key_in.data(), num_cols_to_hash, &t));
+  GDF_TRY(make_key_table(key_tmp.data(), num_cols_to_hash, &t2));
+  const int fastw = (murmur && t.ncols == 1 && (t.col[0].width == 8 || t.col[0].width == 4)) ? t.col[0].width : 0;
+
+  auto payload = [&](gdf_column **in, gdf_column **out, bool clear_out_masks) -> PayloadCols {
+    PayloadCols pc{};
+    pc.ncols = ncols;
+    for (int k = 0; k < ncols; ++k) {
+      pc.in[k] = in[k]->data;
+      pc.out[k] = out[k]->data;
+      pc.width[k] = dtype_width(in[k]->dtype);
+      const bool masks = in[k]->valid && out[k]->valid;
+      pc.in_valid[k] = masks ? in[k]->valid : nullptr;
+      pc.out_valid[k] = masks ? (uint32_t *)out[k]->valid : nullptr;
+      if (masks && clear_out_masks) (void)hipMemsetAsync(out[k]->valid, 0, mask_words * 4, stream0());
+    }
+    return pc;
+  };
+  std::vector<gdf_column *> tmp_ptr(ncols);
+  for (int i = 0; i < ncols; ++i) tmp_ptr[i] = &tmp_col[i];
+
+  // ---- level A: one-level machinery with S bins (bin = partition >> kshift) ----
+  int64_t chunk = (n + HP_MAX_CHUNKS - 1) / HP_MAX_CHUNKS;
+  chunk = ((chunk + HP_THREADS * 8 - 1) / (HP_THREADS * 8)) * (HP_THREADS * 8);
+  const int nchunks = (int)((n + chunk - 1) / chunk);
+  const int grid = nchunks < NUM_CU * 4 ? nchunks : NUM_CU * 4;
+  DevBuf histA, histB, d_bounds;
+  RMM_TRY(histA.alloc(sizeof(uint32_t) * (size_t)S * nchunks));
+  RMM_TRY(histB.alloc(sizeof(uint32_t) * ((size_t)S * K + 1)));
+  RMM_TRY(d_bounds.alloc(sizeof(uint32_t) * ((size_t)S + 1)));
+  PartLevel la{};
+  la.mode = 1; la.kshift = kshift; la.hashP = P; la.hashmask = pow2mask;
+  const size_t ldsA = sizeof(uint32_t) * S;
+#define HP2_HIST(LV, TAB, NBINS, NCH, CHUNK, GRID, LDS, OUT)                                                                              \
+  do {                                                                                                                                    \
+    if (fastw == 8) GDF_LAUNCH("part_hist", part_hist_fast_kernel<uint64_t>, dim3(GRID), dim3(HP_THREADS), LDS, stream0(), (const uint64_t *)TAB.col[0].data, n, CHUNK, NCH, NBINS, 0u, -1, OUT, LV); \
+    else if (fastw == 4) GDF_LAUNCH("part_hist", part_hist_fast_kernel<uint32_t>, dim3(GRID), dim3(HP_THREADS), LDS, stream0(), (const uint32_t *)TAB.col[0].data, n, CHUNK, NCH, NBINS, 0u, -1, OUT, LV); \
+    else if (murmur) GDF_LAUNCH("part_hist", part_hist_kernel<true>, dim3(GRID), dim3(HP_THREADS), LDS, stream0(), TAB, n, CHUNK, NCH, NBINS, 0u, OUT, LV); \
+    else GDF_LAUNCH("part_hist", part_hist_kernel<false>, dim3(GRID), dim3(HP_THREADS), LDS, stream0(), TAB, n, CHUNK, NCH, NBINS, 0u, OUT, LV); \
+  } while (0)
+  HP2_HIST(la, t, S, nchunks, chunk, grid, ldsA, histA.as<uint32_t>());
+  HIP_CHECK_LAST();
+  GDF_TRY(scan_u32(histA.as<uint32_t>(), histA.as<uint32_t>(), (size_t)S * nchunks, false));
+  {
+    PayloadCols pc = payload(input, tmp_ptr.data(), false);
+    const size_t tl = HptShape<1024, 1024, 12, true>::lds_bytes() > HptShape<1024, 1024, 12, false>::lds_bytes()
+                          ? HptShape<1024, 1024, 12, true>::lds_bytes() : HptShape<1024, 1024, 12, false>::lds_bytes();
+#define HP2_TILE(MUR, FW, TH, MAXP, FI, TAB, NBINS, NCH, CHUNK, GRID, OFFS, LV)                                                           \
+  do {                                                                                                                                    \
+    const size_t l2 = HptShape<TH, MAXP, FI, (FW) != 0>::lds_bytes();                                                                    \
+    HIP_TRY(hipFuncSetAttribute((const void *)part_scatter_tile_kernel<MUR, FW, TH, MAXP, FI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2)); \
+    GDF_LAUNCH("part_scatter", (part_scatter_tile_kernel<MUR, FW, TH, MAXP, FI>), dim3(GRID), dim3(TH), l2, stream0(), TAB, pc, n, CHUNK, NCH, NBINS, 0u, OFFS, LV); \
+  } while (0)
+    (void)tl;
+    if (fastw == 8) HP2_TILE(true, 8, 1024, 1024, 12, t, S, nchunks, chunk, grid, histA.as<uint32_t>(), la);
+    else if (fastw == 4) HP2_TILE(true, 4, 1024, 1024, 12, t, S, nchunks, chunk, grid, histA.as<uint32_t>(), la);
+    else if (murmur) HP2_TILE(true, 0, 1024, 1024, 12, t, S, nchunks, chunk, grid, histA.as<uint32_t>(), la);
+    else HP2_TILE(false, 0, 1024, 1024, 12, t, S, nchunks, chunk, grid, histA.as<uint32_t>(), la);
+    HIP_CHECK_LAST();
+  }
+  // super-partition s starts where its first chunk's rows go: histA[s * nchunks] (scanned); its end is the next one's start
+  std::vector<uint32_t> bounds((size_t)S + 1);
+  {
+    DevBuf d_first;
+    RMM_TRY(d_first.alloc(sizeof(uint32_t) * S));
+    hipLaunchKernelGGL(gather_strided_u32, dim3((S + 255) / 256), dim3(256), 0, stream0(), (const uint32_t *)histA.as<uint32_t>(), d_first.as<uint32_t>(), (int)S,
+                       (size_t)nchunks);
+    HIP_CHECK_LAST();
+    HIP_TRY(read_back(bounds.data(), d_first.p, sizeof(uint32_t) * S));
+    bounds[S] = (uint32_t)n;
+  }
+  HIP_TRY(hipMemcpyAsync(d_bounds.p, bounds.data(), sizeof(uint32_t) * ((size_t)S + 1), hipMemcpyHostToDevice, stream0()));
+
+  // ---- level B: chunks = super-partitions of the temporary table, K bins each; histB[s * K + local] scans to the final offsets ----
+  PartLevel lb{};
+  lb.mode = 2; lb.kshift = kshift; lb.hashP = P; lb.hashmask = pow2mask; lb.qstride = 1; lb.cstride = K; lb.bounds = d_bounds.as<uint32_t>();
+  const int gridB = (int)S < NUM_CU * 4 ? (int)S : NUM_CU * 4;
+  HIP_TRY(hipMemsetAsync(histB.p, 0, sizeof(uint32_t) * ((size_t)S * K + 1), stream0()));
+  HP2_HIST(lb, t2, K, (int)S, (int64_t)0, gridB, sizeof(uint32_t) * K, histB.as<uint32_t>());
+  HIP_CHECK_LAST();
+  GDF_TRY(scan_u32(histB.as<uint32_t>(), histB.as<uint32_t>(), (size_t)S * K + 1, false));
+  {
+    PayloadCols pc = payload(tmp_ptr.data(), output, true);
+    for (int k = 0; k < ncols; ++k)
+      if (input[k]->valid && output[k]->valid) output[k]->null_count = input[k]->null_count;
+    if (fastw == 8) HP2_TILE(true, 8, 256, 256, 16, t2, K, (int)S, (int64_t)0, gridB, histB.as<uint32_t>(), lb);
+    else if (fastw == 4) HP2_TILE(true, 4, 256, 256, 16, t2, K, (int)S, (int64_t)0, gridB, histB.as<uint32_t>(), lb);
+    else if (murmur) HP2_TILE(true, 0, 256, 256, 16, t2, K, (int)S, (int64_t)0, gridB, histB.as<uint32_t>(), lb);
+    else HP2_TILE(false, 0, 256, 256, 16, t2, K, (int)S, (int64_t)0, gridB, histB.as<uint32_t>(), lb);
+    HIP_CHECK_LAST();
+  }
+#undef HP2_TILE
+#undef HP2_HIST
+  // partition_offsets (HOST array): the scanned level-B histogram IS the list of partition starts (index s * K + local = partition)
+  HIP_TRY(hipMemcpyAsync(partition_offsets, histB.p, sizeof(int) * P, hipMemcpyDeviceToHost, stream0()));
+  HIP_TRY(hipStreamSynchronize(stream0()));
+  return GDF_SUCCESS;
+}
+
+}  // namespace gdf_amd
+
 extern "C" {
 
 gdf_error gdf_hash(int num_cols, gdf_column **input, gdf_hash_func hash, gdf_column *output) {
@@ -960,6 +1122,10 @@ gdf_error gdf_hash_partition(int num_input_cols, gdf_column *input[], int column
   const int64_t n = (int64_t)num_rows;
   const uint32_t P = (uint32_t)num_partitions;
   const uint32_t pow2mask = (P & (P - 1)) == 0 ? P - 1 : 0;   // P==1 -> mask 0 -> h % 1 == 0, same result
+  // beyond the fan-out one LDS-regrouped pass serves: two levels (hash_partition_two_level)
+  if (P > (uint32_t)HPT_BIG_PARTS && num_input_cols <= HP_MAX_PAYLOAD_COLS && n >= ((int64_t)1 << 18) && !lab::path_on("GDF_HP_ONE_LEVEL"))
+    return hash_partition_two_level(num_input_cols, input, columns_to_hash, num_cols_to_hash, P, partitioned_output, partition_offsets,
+                                    hash == GDF_HASH_MURMUR3);
   // chunking: at most HP_MAX_CHUNKS chunks, each a multiple of the block size
   int64_t chunk = (n + HP_MAX_CHUNKS - 1) / HP_MAX_CHUNKS;
   chunk = ((chunk + HP_THREADS * 8 - 1) / (HP_THREADS * 8)) * (HP_THREADS * 8);
@@ -975,14 +1141,14 @@ gdf_error gdf_hash_partition(int num_input_cols, gdf_column *input[], int column
   const int fastw = (murmur && t.ncols == 1 && (t.col[0].width == 8 || t.col[0].width == 4) && !lab::knob_on("GDF_HP_NO_FAST")) ? t.col[0].width : 0;
   if (fastw == 8)
     GDF_LAUNCH("part_hist", part_hist_fast_kernel<uint64_t>, dim3(grid), dim3(HP_THREADS), lds, stream0(), (const uint64_t *)t.col[0].data, n, chunk,
-               nchunks, P, pow2mask, agg_bits, hist.as<uint32_t>());
+               nchunks, P, pow2mask, agg_bits, hist.as<uint32_t>(), PartLevel{});
   else if (fastw == 4)
     GDF_LAUNCH("part_hist", part_hist_fast_kernel<uint32_t>, dim3(grid), dim3(HP_THREADS), lds, stream0(), (const uint32_t *)t.col[0].data, n, chunk,
-               nchunks, P, pow2mask, agg_bits, hist.as<uint32_t>());
+               nchunks, P, pow2mask, agg_bits, hist.as<uint32_t>(), PartLevel{});
   else if (murmur)
-    GDF_LAUNCH("part_hist", part_hist_kernel<true>, dim3(grid), dim3(HP_THREADS), lds, stream0(), t, n, chunk, nchunks, P, pow2mask, hist.as<uint32_t>());
+    GDF_LAUNCH("part_hist", part_hist_kernel<true>, dim3(grid), dim3(HP_THREADS), lds, stream0(), t, n, chunk, nchunks, P, pow2mask, hist.as<uint32_t>(), PartLevel{});
   else
-    hipLaunchKernelGGL(part_hist_kernel<false>, dim3(grid), dim3(HP_THREADS), lds, stream0(), t, n, chunk, nchunks, P, pow2mask, hist.as<uint32_t>());
+    hipLaunchKernelGGL(part_hist_kernel<false>, dim3(grid), dim3(HP_THREADS), lds, stream0(), t, n, chunk, nchunks, P, pow2mask, hist.as<uint32_t>(), PartLevel{});
   HIP_CHECK_LAST();
   GDF_TRY(scan_u32(hist.as<uint32_t>(), hist.as<uint32_t>(), (size_t)P * nchunks, false));
   hipLaunchKernelGGL(gather_strided_u32, dim3((P + 255) / 256), dim3(256), 0, stream0(), hist.as<uint32_t>(),
@@ -1025,7 +1191,7 @@ gdf_error gdf_hash_partition(int num_input_cols, gdf_column *input[], int column
     const size_t tl = HptShape<TH, MAXP, FI, (FW) != 0>::lds_bytes();                                                                  \
     HIP_TRY(hipFuncSetAttribute((const void *)part_scatter_tile_kernel<MUR, FW, TH, MAXP, FI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl)); \
     GDF_LAUNCH("part_scatter", (part_scatter_tile_kernel<MUR, FW, TH, MAXP, FI>), dim3(grid), dim3(TH), tl, stream0(), t, pc, n, chunk, \
-               nchunks, P, pow2mask, hist.as<uint32_t>());                                                                             \
+               nchunks, P, pow2mask, hist.as<uint32_t>(), PartLevel{});                                                                \
   } while (0)
       // 12288-row tiles of a 1024-thread workgroup win over 4096-row tiles of 256 threads at EVERY fan-out they share (1e8 rows x
       // 2 int64 columns, scatter kernel: P = 64 0.73 vs 0.88 ms, P = 256 0.82 vs 1.07 ms): three times the run length.  The small

@@ -20,7 +20,7 @@ gdf_error scan_u64(const uint64_t *in, uint64_t *out, size_t n, bool inclusive);
 gdf_error order_rows(const KeyTable &t, uint32_t n, DevBuf &perm, DevBuf *sorted_keys, bool *keys_exact);
 // sort.hip: lo_hi[2c] / lo_hi[2c+1] = min / max (as signed 64-bit) of integer key column c over its valid
 // elements of rows [0, t.nrows); lo > hi when the column has none; float columns are not touched
-gdf_error key_ranges(const KeyTable &t, long long *lo_hi);
+gdf_error key_ranges(const KeyTable &t, long long *lo_hi, int windows = 1, int64_t window_rows = 0);      // windows > 1: a strided sample
 // sort.hip: stable LSD radix sort of n (key, 64-bit payload) pairs on the key bits set in `varying`; the
 // pairs ping-pong between the two buffer sets and kin / vin point at the sorted data on return
 gdf_error radix_sort_pairs_u64(uint64_t *&kin, uint64_t *&kout, uint64_t *&vin, uint64_t *&vout, uint32_t n, uint64_t varying);

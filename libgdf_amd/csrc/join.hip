@@ -4448,6 +4448,8 @@ static gdf_error fj_send(gdf_column *keys, int64_t lo, int64_t hi, int world, in
   GDF_REQUIRE(hi >= lo && (uint64_t)hi - (uint64_t)lo < 0xffffffffULL, GDF_INVALID_API_CALL);
   GDF_REQUIRE(keys->size < (size_t)INT_MAX, GDF_COLUMN_SIZE_TOO_BIG);
   const uint32_t nregions = ((uint32_t)world << coarse_bits) << 3;
+  // the kernel computes region offsets in 32 bits: what gdf_amd_fj_plan guarantees is checked again for a caller's own numbers
+  GDF_REQUIRE(cap >= 64 && cap % 64 == 0 && (uint64_t)nregions * cap + FJ_TILE < 0x7fffffffULL, GDF_INVALID_API_CALL);
   HIP_TRY(hipMemsetAsync(out_fill, 0, sizeof(uint32_t) * ((size_t)nregions + 1), stream0()));      // [nregions]: the overflow flag
   *overflowed = 0;
   if (keys->size == 0) { HIP_TRY(hipStreamSynchronize(stream0())); return GDF_SUCCESS; }
@@ -4528,6 +4530,8 @@ static gdf_error fj_build_create(const uint32_t *recv_keys, const uint32_t *recv
   GDF_REQUIRE(recv_keys && recv_fill && out, GDF_DATASET_EMPTY);
   GDF_REQUIRE(fine_bits >= 1 && fine_bits <= JK_MAX_FB && coarse_bits >= 0 && fine_bits - coarse_bits >= 1 && fine_bits - coarse_bits <= 8,
               GDF_INVALID_API_CALL);
+  GDF_REQUIRE(world >= 1 && ((uint64_t)world << coarse_bits) <= (uint64_t)FJ_MAX_BINS && cap >= 64 && cap % 64 == 0 &&
+              (((uint64_t)world << coarse_bits) << 3) * cap + FJ_TILE < 0x7fffffffULL, GDF_INVALID_API_CALL);      // positions are 31-bit (fj_send)
   std::unique_ptr<PreparedBuild> pb(new PreparedBuild());
   pb->ncols = 1;
   pb->fj = true;
@@ -4590,6 +4594,9 @@ static gdf_error fj_probe_add(ProbeAccum *a, const uint32_t *recv_keys, const ui
   GDF_REQUIRE(position_base >= 0 && position_base + buffer_elems < (int64_t)INT_MAX, GDF_COLUMN_SIZE_TOO_BIG);
   const PartGeom &g = a->pb->side.g;
   const uint32_t nfine = 1u << g.fb, nseg = (g.world << g.b1) << 3;
+  // the receive buffer must be the one this build side's plan describes: nseg regions of cap keys
+  GDF_REQUIRE(cap >= 64 && cap % 64 == 0 && (uint64_t)nseg * cap + FJ_TILE < 0x7fffffffULL && (uint64_t)buffer_elems >= (uint64_t)nseg * cap,
+              GDF_INVALID_API_CALL);
   if (!a->app.started) {
     const uint64_t size2 = (uint64_t)nfine * a->app.cap2 + 16384;
     RMM_TRY(a->app.cursor.alloc(sizeof(uint32_t) * ((size_t)nfine + 2)));

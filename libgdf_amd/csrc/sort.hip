@@ -98,11 +98,14 @@ __device__ __forceinline__ uint64_t group_image(const SortGroup &g, int64_t row)
 }
 
 // per-column minimum / maximum over the rows whose element is valid: out[2c], out[2c+1]
-__global__ __launch_bounds__(256) void rs_minmax(KeyTable t, long long *out) {
+// window_rows != 0: a strided SAMPLE -- sample row j is row (j / window_rows) * window_step + j % window_rows, `sample_rows` of them
+__global__ __launch_bounds__(256) void rs_minmax(KeyTable t, long long *out, int64_t sample_rows, int64_t window_rows, int64_t window_step) {
+  const int64_t rows = window_rows ? sample_rows : t.nrows;
   for (int c = 0; c < t.ncols; ++c) {
     if (t.col[c].kind == K_F32 || t.col[c].kind == K_F64) continue;
     long long lo = 0x7fffffffffffffffLL, hi = (long long)0x8000000000000000ULL;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < t.nrows; i += (int64_t)gridDim.x * 256) {
+    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < rows; j += (int64_t)gridDim.x * 256) {
+      const int64_t i = window_rows ? (j / window_rows) * window_step + j % window_rows : j;
       if (t.col[c].valid && !bit_is_set(t.col[c].valid, i)) continue;
       const long long v = load_signed_kind(t.col[c].data, t.col[c].kind, i);
       lo = v < lo ? v : lo;
@@ -145,14 +148,20 @@ __global__ __launch_bounds__(256) void rs_minmax_fast(const T *__restrict__ key,
 
 // host: lo_hi[2c], lo_hi[2c+1] = min / max of integer column c over its valid elements
 // (lo > hi: no valid element); float columns are left at (max, min)
-gdf_error key_ranges(const KeyTable &t, long long *lo_hi) {
+// `windows` > 1: a SAMPLE -- that many evenly spaced windows of `window_rows` rows instead of the whole table: a strided sample
+// sees a sorted or clustered key column's whole range where a prefix sees a sliver of it (gb_plan_range_sampled).  One launch.
+gdf_error key_ranges(const KeyTable &t, long long *lo_hi, int windows, int64_t window_rows) {
   for (int c = 0; c < t.ncols; ++c) { lo_hi[2 * c] = 0x7fffffffffffffffLL; lo_hi[2 * c + 1] = (long long)0x8000000000000000ULL; }
   DevBuf mm;
   RMM_TRY(mm.alloc(sizeof(long long) * 2 * t.ncols));
   HIP_TRY(hipMemcpyAsync(mm.p, lo_hi, sizeof(long long) * 2 * t.ncols, hipMemcpyHostToDevice, stream0()));
   bool plain = t.nrows > 0;               // every column an unmasked integer (floats are skipped by both kernels)
   for (int c = 0; c < t.ncols; ++c) plain = plain && !t.col[c].valid;
-  if (plain) {
+  if (windows > 1 && window_rows > 0 && (int64_t)windows * window_rows < t.nrows) {
+    const int64_t step = (t.nrows - window_rows) / (windows - 1);
+    const int64_t sample = (int64_t)windows * window_rows;
+    GDF_LAUNCH("rs_minmax", rs_minmax, dim3(stream_grid((size_t)sample, 256 * 4)), dim3(256), 0, stream0(), t, mm.as<long long>(), sample, window_rows, step);
+  } else if (plain) {
     const dim3 grid(stream_grid((size_t)t.nrows, 256 * 8 * 4));
     for (int c = 0; c < t.ncols; ++c) {
       long long *o = mm.as<long long>() + 2 * c;
@@ -164,8 +173,8 @@ gdf_error key_ranges(const KeyTable &t, long long *lo_hi) {
         default: break;
       }
     }
-  } else {
-    GDF_LAUNCH("rs_minmax", rs_minmax, dim3(stream_grid((size_t)t.nrows, 256 * 16)), dim3(256), 0, stream0(), t, mm.as<long long>());
+  } else if (t.nrows > 0) {
+    GDF_LAUNCH("rs_minmax", rs_minmax, dim3(stream_grid((size_t)t.nrows, 256 * 16)), dim3(256), 0, stream0(), t, mm.as<long long>(), (int64_t)0, (int64_t)0, (int64_t)0);
   }
   HIP_TRY(read_back(lo_hi, mm.p, sizeof(long long) * 2 * t.ncols));
   return GDF_SUCCESS;

@@ -34,7 +34,12 @@ receiver would continue from 8-byte packed tuples instead of re-reading raw keys
 """
 from __future__ import annotations
 
-from ._binding import GDFError, GDF_UNSUPPORTED_METHOD
+from ._binding import GDFError, GDF_COLUMN_SIZE_TOO_BIG, GDF_UNSUPPORTED_METHOD
+
+# what makes the layer change its PLAN (slice-by-slice joins, or the key shuffle instead of the fused blocks) rather than fail:
+# the library declining a shape, and its 31-bit position space running out for an accumulated relation -- anything else (a HIP
+# error, out of memory) is a fault and is re-raised
+_PLAN_CHANGE = (GDF_UNSUPPORTED_METHOD, GDF_COLUMN_SIZE_TOO_BIG)
 
 # bytes this rank handed to RCCL (remote segments only; a rank's own segment is a device copy) since the last reset --
 # bench.py reports them per step next to the link-bound estimate
@@ -361,7 +366,7 @@ def distributed_inner_join(probe_keys, build_keys, shuffle_fn=_device_shuffle, j
                 acc.add([_as_column(r.keys)])
                 return
             except GDFError as e:                   # a partition outgrew its room (skew): every slice on its own after all
-                if e.errcode != GDF_UNSUPPORTED_METHOD:
+                if e.errcode not in _PLAN_CHANGE:
                     raise                           # a real fault (HIP error, out of memory ...) is not a plan change
                 acc = None
                 for earlier in probes[:-1]:
@@ -382,7 +387,7 @@ def distributed_inner_join(probe_keys, build_keys, shuffle_fn=_device_shuffle, j
                 try:
                     acc = prepared.accumulate(n_total // world + 1)
                 except GDFError as e:
-                    if e.errcode != GDF_UNSUPPORTED_METHOD:
+                    if e.errcode not in _PLAN_CHANGE:
                         raise
                     acc = None
         if pending is not None:                                                       # join c-1 while c moves
@@ -394,7 +399,7 @@ def distributed_inner_join(probe_keys, build_keys, shuffle_fn=_device_shuffle, j
             li, ri = acc.finish(copy=False)
             result = ShardedPairs([_ConcatReceived(probes)], build, [li], [ri])
         except GDFError as e:
-            if e.errcode != GDF_UNSUPPORTED_METHOD:
+            if e.errcode not in _PLAN_CHANGE:
                 raise
             acc = None
             for r in probes:
@@ -599,6 +604,10 @@ def fused_inner_join(probe_keys, build_keys, group=None, chunks=4, plan_fn=_fj_p
     lay_p = plan_fn(world, b_total, step_max, max(1.0, p_total / max(b_total, 1)))
     if lay_b is None or lay_p is None:
         return None
+    # result positions are 31-bit and count the blocks' room and empty regions: checked here, from numbers every rank has,
+    # before anything is exchanged (a rank that found out later raised alone and left its peers in a collective)
+    if chunks * world * lay_p.block >= 2 ** 31 - 1 or world * lay_b.block >= 2 ** 31 - 1:
+        return None
 
     def agree(flag):
         """True on every rank iff `flag` is False on all of them (one tiny all-reduce): a region overflow anywhere sends
@@ -632,10 +641,28 @@ def fused_inner_join(probe_keys, build_keys, group=None, chunks=4, plan_fn=_fj_p
     probe_rows, failed = [], False
     pending = None
     per_buf = world * lay_p.block
+
+    def add(received, index):
+        """queue one received probe buffer for level 2; False: the library declined (a plan change, settled by agree() below)"""
+        if acc is None or failed:
+            return True
+        try:
+            acc.add_recv(received[0], received[1], lay_p, index * per_buf)
+            return True
+        except GDFError as e:
+            if e.errcode not in _PLAN_CHANGE:
+                raise
+            return False
+
     for c in range(chunks):
         a, b = min(n, c * step), min(n, (c + 1) * step)
         pk, prow, pfill, over = send_fn(probe_keys[a:b], lo, hi, lay_p, a)
         failed = failed or over
+        if c == 0 and not agree(over):
+            # a region overflowed on some rank's FIRST slice (skewed probe keys are usually skewed everywhere): every rank leaves
+            # now, before three more slices are regrouped, shipped and partitioned for nothing
+            wait(works)
+            return None
         probe_rows.append(prow)
         x = exchange(pk, pfill, lay_p, async_op=True) + (pk, pfill)              # the send buffers stay alive with the works
         if build is None:
@@ -644,23 +671,21 @@ def fused_inner_join(probe_keys, build_keys, group=None, chunks=4, plan_fn=_fj_p
                 build = build_fn(rbk, rbf, lo, lay_b, b_total // world + 1)
                 acc = build.accumulate(p_total // world + 1)
             except GDFError as e:
-                if e.errcode != GDF_UNSUPPORTED_METHOD:
+                if e.errcode not in _PLAN_CHANGE:
                     raise
                 failed = True
         if pending is not None:
             wait(pending[2])
-            if acc is not None and not failed:
-                acc.add_recv(pending[0], pending[1], lay_p, (c - 1) * per_buf)
+            failed = failed or not add(pending, c - 1)
         pending = x
     wait(pending[2])
-    if acc is not None and not failed:
-        acc.add_recv(pending[0], pending[1], lay_p, (chunks - 1) * per_buf)
+    failed = failed or not add(pending, chunks - 1)
     li = ri = None
     if acc is not None and not failed:
         try:
             li, ri = acc.finish(copy=False)
         except GDFError as e:
-            if e.errcode != GDF_UNSUPPORTED_METHOD:
+            if e.errcode not in _PLAN_CHANGE:
                 raise
             failed = True
     ok = agree(failed or li is None)

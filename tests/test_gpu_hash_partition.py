@@ -99,6 +99,39 @@ def test_hash_partition_moves_valid_masks(gdf, nparts):
     assert outs[0].c.null_count == n - kv.sum()
 
 
+@pytest.mark.parametrize("nparts", [1025, 3000, 4096, 12000, 16384])
+@pytest.mark.parametrize("keys", ["int64", "int32+int64", "identity-int32"])
+def test_hash_partition_two_levels(gdf, nparts, keys, force_path):
+    """More than 1024 partitions on >= 2^18 rows: two regroup levels (csrc/hashing.hip hash_partition_two_level: rows grouped
+    by super-partition into a temporary table, then every super-partition split) -- one FAST key column, the generic row hash,
+    the identity hash; value masks travel; power-of-two and other partition counts.  Offsets and the rows of every partition
+    (as a multiset) against the oracle, and against the one-level scatter (GDF_HP_ONE_LEVEL) for the offsets."""
+    n = 700_001
+    rs = np.random.RandomState(nparts % 1000)
+    k0 = rs.randint(-2**40, 2**40, size=n).astype(np.int64) if keys != "identity-int32" else rs.randint(0, 2**31 - 1, size=n).astype(np.int32)
+    k1 = rs.randint(0, 1000, size=n).astype(np.int32)
+    v = rs.random_sample(n)
+    vv = rs.random_sample(n) > 0.3
+    hash_cols = [0] if keys != "int32+int64" else [2, 0]
+    hf = 1 if keys == "identity-int32" else 0
+    cols = [k0, v, k1]
+    outs, offsets = gdf.api.hash_partition([_col(gdf, k0), _col(gdf, v, vv), _col(gdf, k1)], hash_cols, nparts, hash_func=hf, with_masks=True)
+    perm, exp_off, pid = oracle.hash_partition(cols, hash_cols, nparts, hf) if hf else oracle.hash_partition(cols, hash_cols, nparts)
+    assert offsets == [int(x) for x in exp_off]
+    got = [o.to_numpy() for o in outs]
+    gvv = outs[1].valid_bits()
+    got_pid = oracle.partition_ids([got[c] for c in hash_cols], nparts, hf) if hf else oracle.partition_ids([got[c] for c in hash_cols], nparts)
+    bounds = np.array(list(exp_off) + [n])
+    assert np.array_equal(got_pid, np.repeat(np.arange(nparts), np.diff(bounds)))         # every row sits in its partition's range
+    # the rows (with the value's validity) are preserved as a multiset, partition by partition: sort by (partition, row content)
+    exp_rows = np.stack([pid[perm].astype(np.float64), k0[perm].astype(np.float64), np.where(vv[perm], v[perm], -1.0), k1[perm].astype(np.float64)], axis=1)
+    got_rows = np.stack([got_pid.astype(np.float64), got[0].astype(np.float64), np.where(gvv, got[1], -1.0), got[2].astype(np.float64)], axis=1)
+    np.testing.assert_array_equal(exp_rows[np.lexsort(exp_rows.T[::-1])], got_rows[np.lexsort(got_rows.T[::-1])])
+    force_path("GDF_HP_ONE_LEVEL")
+    _, offsets1 = gdf.api.hash_partition([_col(gdf, k0), _col(gdf, v, vv), _col(gdf, k1)], hash_cols, nparts, hash_func=hf, with_masks=True)
+    assert offsets1 == offsets
+
+
 def test_hash_partition_errors(gdf):
     from libgdf_amd import GDFError
     a = _col(gdf, gen_rand(np.int32, 100))

@@ -7,8 +7,11 @@ that are already resident in HBM:
            unique int64 keys (a seeded permutation of [0, N_b)), probe key = splitmix64(seed + i) % N_b, so
            every probe row matches exactly once and N_out = N_p; indices only (result_cols = NULL).
   N > 1  : config C4 -- the same per-rank shard sizes (1e9 probe + 1.25e8 build rows per GPU over a global
-           key space), both relations hash-partitioned on key across the ranks and exchanged with one RCCL
-           all-to-all each (libgdf_amd/multigpu.py), then joined locally.  Weak scaling.
+           key space), both relations partitioned on key across the ranks and exchanged with RCCL all-to-alls
+           (libgdf_amd/multigpu.py: the fused join, else the key shuffle -- the SAME algorithm at every N; what
+           the planner would have picked is timed after it and reported as planner_choice), then joined
+           locally.  Weak scaling.  An untimed preflight step checks the global pair count and 2^20 sampled
+           pairs per rank (equal keys) before anything is timed.
 value = probe rows of all ranks / max-over-ranks time.  The roofline object prices the dominant kernel
 (live HIP-event timing inside libgdf.so, see csrc/prof.h); roofline_e2e prices the whole call with the
 algorithmic bytes of SURVEY.md 8d (8*N_p + 8*N_b + 8*N_out).  cpu_baseline times oracle/gdf_oracle.c (a

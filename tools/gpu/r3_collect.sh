@@ -1,0 +1,27 @@
+# the round's evidence for the CURRENT kernel build: PMC HBM bytes (two separate --pmc passes), rocprofv3 kernel stats of the same
+# command, the headline line (which then carries roofline.traffic), C5 (both variants), shapes, operator benches.
+# usage: bash tools/gpu/r3_collect.sh <tag>            (GDF_COLLECT_PYTEST=1 also runs the GPU suite first)
+set -x
+TAG=${1:-r3z}
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd $R
+if [ -n "$GDF_COLLECT_PYTEST" ]; then timeout 2400 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 > $O/pytest_gpu.txt; cat $O/pytest_gpu.txt; fi
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o join -- python $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 --pandas-sample 0 > $O/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o join -- python $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 --pandas-sample 0 > $O/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o join -- python $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 --pandas-sample 0 > $O/trace.log 2>&1
+cd $R
+python tools/rocprof_summary.py $O/trace $O/kernel_stats.md
+python tools/pmc_hbm_json.py $(find $O/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $O/pmc_write -name "*counter_collection.csv" | head -1) $O/pmc_hbm.json
+cp $O/pmc_hbm.json $R/profiles/zz_tmp_pmc_hbm.json          # so that THIS run's bench line already carries the traffic
+python bench.py 2>$O/bench.err | grep '^{' | tail -1 > $O/bench.json
+rm -f $R/profiles/zz_tmp_pmc_hbm.json
+for i in 1 2 3; do python bench.py --steps 10 --warmup 3 --cpu-sample 0 --pandas-sample 0 2>/dev/null | grep '^{' | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(json.dumps({'ms_per_step': d['ms_per_step'], 'kernels_ms_per_step': d['kernels_ms_per_step']}))" >> $O/bench_spread.jsonl; done
+python tools/bench_c5.py 2>/dev/null | tail -1 > $O/bench_c5.json
+python tools/bench_c5.py --null-keys 0.01 2>/dev/null | tail -1 > $O/bench_c5_nullkeys.json
+python tools/bench_shapes.py > $O/bench_shapes.jsonl 2>/dev/null
+python tools/bench_ops.py > $O/bench_ops.jsonl 2>/dev/null
+rm -rf $O/trace/*/*.db; find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -size +8M -delete; find $O -name "*.db" -delete
+cut -c1-900 $O/bench.json; cat $O/bench_spread.jsonl; cut -c1-300 $O/bench_c5.json; cat $O/kernel_stats.md | head -30; du -sh $O

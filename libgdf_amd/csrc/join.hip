@@ -66,6 +66,8 @@ struct KeyPlan {
   int verify;                 // 1: key64 is a hash, confirm hits with rows_equal
   int narrow;                 // 1: every joinable key is < 2^32 after subtracting kmin
   uint64_t kmin;              // subtracted from 8-byte integer keys in narrow mode (two's complement)
+  uint64_t kspan;             // narrow mode with kmin != 0: the largest stored key (build max - min); decides whether hash_a is a
+                              // bijection on the stored keys (six-byte level-2 tuples, p6_store)
   int shift[MAX_KEY_COLS];    // KM_PACKED bit offsets
   // KM_PACKED with ranged != 0: column c contributes (value - bias[c]) in bits[c] bits, the ranges taken from the BUILD
   // relation (plan_ranged); a probe value outside its column's range cannot match and makes the row unjoinable
@@ -525,8 +527,39 @@ __device__ __forceinline__ uint32_t opaque_tid() {
   return tid;
 }
 
+// SIX-BYTE level-2 tuples (P6).  hash_a is a bijection on NARROW keys whose raw values do not straddle a 2^32 boundary
+// (key_fold is then `low word ^ constant`, lowbias32 permutes 32 bits), and the fine partition IS the top fb bits of that hash:
+// inside a partition a tuple is identified by the REMAINING 32 - fb bits.  With fb = 15 that is 17 bits; with a 31-bit row
+// number a tuple fits 48 bits -- the level-2 output and the probe input shrink from 8 to 6 bytes per tuple (4 of the join's
+// 48 bytes of HBM traffic per probe row).  Layout: bits 0..30 row, bits 31..47 hash remainder r; stored as a 4-byte and a
+// 2-byte store at byte 6 * position, read back two tuples at a time as three dwords.  The probe compares remainders instead of
+// keys: its LDS image of the build partition gets the keys replaced by their remainders when it is staged (p6_remainder), and
+// equal (partition, remainder) means equal hash means equal key.  Indices-only INNER / LEFT joins on the main (deferred,
+// two-level) path only: whoever needs the key VALUE back (carried key column) or other layouts keeps 8-byte tuples.
+__device__ __forceinline__ uint32_t p6_remainder(uint32_t key32, uint64_t kbias, int fb) {
+  return hash_a((uint64_t)key32 + kbias) & ((1u << (32 - fb)) - 1u);
+}
+__device__ __forceinline__ void p6_store(uint64_t *base, uint32_t pos, uint32_t r, uint32_t row) {
+  unsigned char *at = reinterpret_cast<unsigned char *>(base) + (size_t)pos * 6u;
+  const uint32_t lo = (row & 0x7fffffffu) | (r << 31);
+  const uint16_t hi = (uint16_t)(r >> 1);
+  __builtin_memcpy(at, &lo, 4);                    // 2-byte aligned: gfx950 global stores need no alignment
+  __builtin_memcpy(at + 4, &hi, 2);
+}
+// tuples v and v + 1 (v even) of a P6 stream that starts at `base`: (remainder, row) each -- one 12-byte load
+__device__ __forceinline__ void p6_load_pair(const uint64_t *base, uint32_t v, uint32_t &r0, uint32_t &row0, uint32_t &r1, uint32_t &row1) {
+  const uint32_t *at = reinterpret_cast<const uint32_t *>(base) + (size_t)(v >> 1) * 3u;
+  struct __attribute__((packed, aligned(4))) D3 { uint32_t a, b, c; };
+  const D3 d = *reinterpret_cast<const D3 *>(at);
+  row0 = d.a & 0x7fffffffu;
+  r0 = (d.a >> 31) | ((d.b & 0xffffu) << 1);
+  const uint32_t lo1 = (d.b >> 16) | (d.c << 16);
+  row1 = lo1 & 0x7fffffffu;
+  r1 = (lo1 >> 31) | ((d.c >> 16) << 1);
+}
+
 // phase C: write the regrouped tile out.  LEVEL1 bins are the coarse id, LEVEL2 the sub id.
-template <bool LEVEL1, bool NARROW, int THREADS, bool PAY, int ITEMS>
+template <bool LEVEL1, bool NARROW, int THREADS, bool PAY, int ITEMS, bool P6 = false>
 __device__ __forceinline__ void tile_flush(TileLds<NARROW, THREADS, PAY, ITEMS> &s, const PartGeom &g, Tuples out) {
   const uint32_t total = s.total;
   const uint32_t submask = (1u << g.b2) - 1;
@@ -541,18 +574,21 @@ __device__ __forceinline__ void tile_flush(TileLds<NARROW, THREADS, PAY, ITEMS> 
       ii[u] = (!NARROW && j < total) ? s.idx[j] : 0;
       pp[u] = (PAY && j < total) ? s.pay[j] : 0;
     }
-    uint32_t dst[U];
+    uint32_t dst[U], rem[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const uint32_t f = (uint32_t)((uint64_t)local_hash(hash_a(tup_key<NARROW>(ww[u]) + g.kbias), g.world) >> (32 - g.fb));
+      const uint32_t h = local_hash(hash_a(tup_key<NARROW>(ww[u]) + g.kbias), g.world);
+      const uint32_t f = (uint32_t)((uint64_t)h >> (32 - g.fb));
       const uint32_t bin = LEVEL1 ? (f >> g.b2) : (f & submask);
       dst[u] = s.gbase[bin] + j0 + u * THREADS;
+      rem[u] = h & ((1u << (32 - g.fb)) - 1u);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (LAB_BITS(g.dbg) & 4) dst[u] &= 0xffffu;        // experiment: all stores land in a 512 KiB window
       if (j0 + u * THREADS < total && !(LAB_BITS(g.dbg) & 1)) {
-        if (LAB_BITS(g.dbg) & 16) __builtin_nontemporal_store(ww[u], out.w + dst[u]);      // experiment: streaming stores (level 2)
+        if (P6) p6_store(out.w, dst[u], rem[u], (uint32_t)ww[u]);
+        else if (LAB_BITS(g.dbg) & 16) __builtin_nontemporal_store(ww[u], out.w + dst[u]);      // experiment: streaming stores (level 2)
         else out.w[dst[u]] = ww[u];
         if (!NARROW) out.idx[dst[u]] = ii[u];
         if (PAY) out.pay[dst[u]] = pp[u];
@@ -948,7 +984,7 @@ struct Level2Map {                     // small host-built tables, device reside
   const uint32_t *keys32;              // non-null: the input is this array of 4-byte keys (a receive buffer), tuple = key << 32 | position
 };
 
-template <bool NARROW, int THREADS, bool PAY = false>
+template <bool NARROW, int THREADS, bool PAY = false, bool P6 = false>
 __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, Tuples in,
                                                              uint32_t *__restrict__ fine_cursor, Tuples out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
@@ -1030,7 +1066,7 @@ __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, 
     else s.gbase[threadIdx.x] = claimed - s.start[threadIdx.x];
   }
   block_sync();
-  tile_flush<false, NARROW, THREADS, PAY, ITEMS>(s, g, out);
+  tile_flush<false, NARROW, THREADS, PAY, ITEMS, P6>(s, g, out);
 }
 
 // ---------------------------------------------------------------------------
@@ -1185,6 +1221,11 @@ struct ProbeArgs {
   int bpay_mode;
   const void *bpay_src[2];
   void *bpay_out[2];
+  // six-byte probe tuples (p6_store): p6_fb != 0 -> probe.w is a P6 stream of (hash remainder, row) and the kernels (their <P6>
+  // instantiations) replace the staged build keys by their remainders -- hash_a(key + p6_kbias) below the top p6_fb bits; kbias is
+  // then 0: the "keys" the lookups hash and compare are the remainders
+  int p6_fb;
+  uint64_t p6_kbias;
 };
 // the general kernels' payload write: a gather by probe row (rare units only)
 __device__ __forceinline__ void pay_gather(const ProbeArgs &a, unsigned long long pos, int32_t prow) {
@@ -1253,7 +1294,7 @@ __device__ __forceinline__ int32_t build_row(const ProbeLds &l, uint32_t p) {
   return NARROW ? (int32_t)(uint32_t)l.bw[p] : l.bi[p];
 }
 
-template <bool WRITE, bool NARROW>
+template <bool WRITE, bool NARROW, bool P6 = false>
 __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTable probe_t, KeyTable build_t) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const uint32_t H = a.nslots, cap = a.cap;
@@ -1268,7 +1309,9 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
 
   // ---- stage the build partition, clear the table ----
   for (uint32_t i = threadIdx.x; i < u.build_count; i += JK_PROBE_THREADS) {
-    l.bw[i] = a.build.w[u.build_begin + i];
+    uint64_t w = a.build.w[u.build_begin + i];
+    if (P6) w = ((uint64_t)p6_remainder((uint32_t)(w >> 32), a.p6_kbias, a.p6_fb) << 32) | (uint32_t)w;
+    l.bw[i] = w;
     if (!NARROW) l.bi[i] = a.build.idx[u.build_begin + i];
   }
   for (uint32_t i = threadIdx.x; i < 2 * H; i += JK_PROBE_THREADS) l.T[i] = JK_NOPOS;
@@ -1342,7 +1385,15 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
       if constexpr (NARROW) {
         const uint32_t v = base + (b * JK_PROBE_THREADS + threadIdx.x) * 2;
         const uint32_t last_pair = (vtotal - 1) & ~1u;
-        const ulonglong2 ww = *reinterpret_cast<const ulonglong2 *>(a.probe.w + vbegin + (v < last_pair ? v : last_pair));   // clamped, unconditional
+        ulonglong2 ww;
+        if constexpr (P6) {
+          uint32_t r0, row0, r1, row1;
+          p6_load_pair(a.probe.w, vbegin + (v < last_pair ? v : last_pair), r0, row0, r1, row1);
+          ww.x = ((uint64_t)r0 << 32) | row0;
+          ww.y = ((uint64_t)r1 << 32) | row1;
+        } else {
+          ww = *reinterpret_cast<const ulonglong2 *>(a.probe.w + vbegin + (v < last_pair ? v : last_pair));   // clamped, unconditional
+        }
         k[2 * b] = tup_key<NARROW>(ww.x);
         prow[2 * b] = (int32_t)(uint32_t)ww.x;
         act[2 * b] = v >= lead && v < vtotal;
@@ -1510,7 +1561,7 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
 // tuples (profiles/r2_b_bench_shapes.jsonl, c3_wide_keys).
 // PMODE != 0 (NARROW only): the probe tuples carry a payload word (Tuples::pay) and every pair writes its column value(s)
 // next to its index pair -- the streaming replacement of the probe-side gather of a materialising join.
-template <bool POW2, bool KEEP, bool NARROW, int PMODE = 0>
+template <bool POW2, bool KEEP, bool NARROW, int PMODE = 0, bool P6 = false>
 __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_fast(ProbeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const uint32_t H = a.nslots, cap = a.cap;
@@ -1518,7 +1569,9 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_fast(ProbeArgs a) {
   unsigned int *lcur = (unsigned int *)l.unit_cursor;      // pairs written so far by this unit
   const Unit u = a.units[blockIdx.x];
   for (uint32_t i = threadIdx.x; i < u.build_count; i += JK_PROBE_THREADS) {
-    l.bw[i] = a.build.w[u.build_begin + i];
+    uint64_t w = a.build.w[u.build_begin + i];
+    if (P6) w = ((uint64_t)p6_remainder((uint32_t)(w >> 32), a.p6_kbias, a.p6_fb) << 32) | (uint32_t)w;      // six-byte probe tuples: compare remainders
+    l.bw[i] = w;
     if (!NARROW) l.bi[i] = a.build.idx[u.build_begin + i];
   }
   for (uint32_t i = threadIdx.x; i < 2 * H; i += JK_PROBE_THREADS) l.T[i] = JK_NOPOS;
@@ -1607,12 +1660,21 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_fast(ProbeArgs a) {
     for (int b = 0; b < JK_PROBE_BATCH; ++b) {      // all HBM loads first, 16 bytes each (WIDE: + 8 bytes of row numbers), clamped and unconditional
       const uint32_t v = base + (b * JK_PROBE_THREADS + threadIdx.x) * 2;
       const uint32_t vc = v < last_pair ? v : last_pair;
-      const ulonglong2 ww = *reinterpret_cast<const ulonglong2 *>(src + vc);
+      ulonglong2 ww{};
+      if constexpr (P6) {            // one 12-byte load: two (remainder, row) tuples
+        uint32_t r0, row0, r1, row1;
+        p6_load_pair(a.probe.w, (u.probe_begin - lead) + vc, r0, row0, r1, row1);
+        key[2 * b] = r0; prow[2 * b] = row0;
+        key[2 * b + 1] = r1; prow[2 * b + 1] = row1;
+      } else {
+        ww = *reinterpret_cast<const ulonglong2 *>(src + vc);
+      }
       if constexpr (PMODE != 0) {
         const ulonglong2 pp = *reinterpret_cast<const ulonglong2 *>(src_pay + vc);
         pay[2 * b] = pp.x; pay[2 * b + 1] = pp.y;
       }
-      if constexpr (NARROW) {
+      if constexpr (P6) {
+      } else if constexpr (NARROW) {
         key[2 * b] = (uint32_t)(ww.x >> 32); prow[2 * b] = (uint32_t)ww.x;
         key[2 * b + 1] = (uint32_t)(ww.y >> 32); prow[2 * b + 1] = (uint32_t)ww.y;
       } else {
@@ -1720,14 +1782,16 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_fast(ProbeArgs a) {
 // settle here or there goes to the general kernel for that pass; either way it is counted / written completely).  Joins between ~55 % and 100 % hits (and LEFT joins) need exact output sizes before
 // they write; the general kernel's count pass is VALU-bound at 2.3 ms per 1e9 probe tuples, this one reads
 // its 8 bytes per tuple at the HBM rate.  Units it cannot settle go to unit_todo / opt_state[2] like the write kernel's.
-template <bool POW2, bool KEEP, bool NARROW>
+template <bool POW2, bool KEEP, bool NARROW, bool P6 = false>
 __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_count_fast(ProbeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const uint32_t H = a.nslots, cap = a.cap;
   const ProbeLds l = carve_probe_lds<NARROW>(lds_raw, cap, H);
   const Unit u = a.units[blockIdx.x];
   for (uint32_t i = threadIdx.x; i < u.build_count; i += JK_PROBE_THREADS) {
-    l.bw[i] = a.build.w[u.build_begin + i];
+    uint64_t w = a.build.w[u.build_begin + i];
+    if (P6) w = ((uint64_t)p6_remainder((uint32_t)(w >> 32), a.p6_kbias, a.p6_fb) << 32) | (uint32_t)w;
+    l.bw[i] = w;
     if (!NARROW) l.bi[i] = a.build.idx[u.build_begin + i];
   }
   for (uint32_t i = threadIdx.x; i < 2 * H; i += JK_PROBE_THREADS) l.T[i] = JK_NOPOS;
@@ -1805,9 +1869,15 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_count_fast(ProbeArgs a) {
     for (int b = 0; b < JK_PROBE_BATCH; ++b) {
       const uint32_t v = base + (b * JK_PROBE_THREADS + threadIdx.x) * 2;
       const uint32_t vc = v < last_pair ? v : last_pair;
-      const ulonglong2 ww = *reinterpret_cast<const ulonglong2 *>(src + vc);
-      if constexpr (NARROW) { key[2 * b] = (uint32_t)(ww.x >> 32); key[2 * b + 1] = (uint32_t)(ww.y >> 32); }
-      else { key[2 * b] = ww.x; key[2 * b + 1] = ww.y; }
+      if constexpr (P6) {
+        uint32_t r0, row0, r1, row1;
+        p6_load_pair(a.probe.w, (u.probe_begin - lead) + vc, r0, row0, r1, row1);
+        key[2 * b] = r0; key[2 * b + 1] = r1;
+      } else {
+        const ulonglong2 ww = *reinterpret_cast<const ulonglong2 *>(src + vc);
+        if constexpr (NARROW) { key[2 * b] = (uint32_t)(ww.x >> 32); key[2 * b + 1] = (uint32_t)(ww.y >> 32); }
+        else { key[2 * b] = ww.x; key[2 * b + 1] = ww.y; }
+      }
       act[2 * b] = v >= lead && v < vtotal;
       act[2 * b + 1] = v + 1 < vtotal;
     }
@@ -2363,6 +2433,7 @@ struct SideBufs {            // partitioned tuples of one relation
   // flags and the capacity stay on the device and probe_partitioned builds its units there (jk_make_units); the host
   // vectors above are empty
   bool deferred = false;
+  bool p6 = false;           // the fine-partitioned tuples of this (deferred probe) side are six-byte ones (p6_store)
   uint32_t cap2 = 0;
   DevBuf d_level1;           // [nseg + 1] level-1 fill counters + overflow flag
   uint32_t nseg = 0;
@@ -2382,6 +2453,8 @@ static PartGeom choose_geometry(int64_t build_rows) {
   // never fewer than 32 partitions: with one or a few, every tuple of a tile ranks on the same LDS counter and the
   // probe side has to take the histogram pass (5e8 x 3000 rows: 8.0 ms with one partition, see the notes in profiles/)
   if (fb < 5 && !lab::knob_on("GDF_JK_ALLOW_FEW_PARTS")) fb = 5;
+  // (test hook: the geometry of a large build relation on a small one -- the six-byte tuples need 2^15 partitions)
+  if (const long long forced = lab::path_int("GDF_JK_FORCE_FB", 0)) { if (forced >= 5 && forced <= JK_MAX_FB) fb = (int)forced; }
   g.fb = fb;
   g.b1 = fb <= 8 ? fb : (fb + 1) / 2;
   if (lab::knob_on("GDF_JK_B1") && fb > 8) { const int b1 = (int)lab::knob_int("GDF_JK_B1", 0); if (b1 >= fb - 8 && b1 <= 8) g.b1 = b1; }   // experiment switch
@@ -2446,7 +2519,17 @@ static gdf_error launch_scatter2_t(uint32_t ntiles, const PartGeom &g, Level2Map
   return GDF_SUCCESS;
 }
 static gdf_error launch_scatter2(bool narrow, int threads, uint32_t ntiles, const PartGeom &g, Level2Map m, Tuples in,
-                                 uint32_t *cursor, Tuples out) {
+                                 uint32_t *cursor, Tuples out, bool p6 = false) {
+  if (p6) {                          // six-byte output tuples (see p6_store): NARROW, no payload, the production tile size
+    const size_t lds = sizeof(TileLds<true, 256>);
+    HIP_TRY(hipFuncSetAttribute((const void *)jk_scatter2<true, 256, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    m.ntiles = ntiles;
+    m.xcd_order = (ntiles >= 64 && !lab::path_on("GDF_JK_NO_XCD_ORDER")) ? 1 : 0;
+    const uint32_t grid = m.xcd_order ? ((ntiles + 7) / 8) * 8 : ntiles;
+    GDF_LAUNCH("jk_scatter2", (jk_scatter2<true, 256, false, true>), dim3(grid), dim3(256), lds, stream0(), g, m, in, cursor, out);
+    HIP_CHECK_LAST();
+    return GDF_SUCCESS;
+  }
   if (narrow && in.pay) {            // a probe side that carries its payload words (PayCarry): the production tile size only
     const size_t lds = sizeof(TileLds<true, 256, true, JK_PAY_ITEMS>);
     HIP_TRY(hipFuncSetAttribute((const void *)jk_scatter2<true, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -2559,6 +2642,7 @@ static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, Si
     if (h[0] <= h[1] && (uint64_t)h[1] - (uint64_t)h[0] < 0xffffffffULL) {
       plan.narrow = 1;
       plan.kmin = (uint64_t)h[0];
+      plan.kspan = (uint64_t)h[1] - (uint64_t)h[0];
       narrow = true;
     }
   }
@@ -2634,7 +2718,8 @@ struct SpecAppend {
 };
 
 static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, PartGeom g, double dup, SideBufs *sb, bool *ok,
-                                     SpecAppend *app = nullptr, bool defer = false, const PaySrc *pay = nullptr, int pmode = 0) {
+                                     SpecAppend *app = nullptr, bool defer = false, const PaySrc *pay = nullptr, int pmode = 0,
+                                     bool want_p6 = false) {
   *ok = false;
   if (app) g.row_base = (int32_t)app->rows;
   const int64_t n = t.nrows;
@@ -2694,7 +2779,8 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
                        (uint32_t)JK_TILE2, seg_begin, seg_end, tile_prefix, ntiles_dev, 0u, 0u);
     hipLaunchKernelGGL(jk_init_cursor, dim3(32), dim3(256), 0, stream0(), cursor.as<uint32_t>(), nfine, cap2);
     HIP_CHECK_LAST();
-    RMM_TRY(sb->w[1].alloc(sizeof(uint64_t) * size2));
+    const bool p6 = want_p6 && narrow && !pay && sc2_threads == 256;
+    RMM_TRY(sb->w[1].alloc(p6 ? 6 * size2 + 16 : sizeof(uint64_t) * size2));
     if (!narrow) RMM_TRY(sb->idx[1].alloc(sizeof(int32_t) * size2));
     if (pay) RMM_TRY(sb->pay[1].alloc(sizeof(uint64_t) * size2));
     PartGeom g2 = g;
@@ -2705,7 +2791,8 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
     m.ntiles_dev = ntiles_dev;
     // every segment ends in at most one partial tile: an upper bound of the tile count sizes the grid
     const uint32_t tile_bound = (uint32_t)((uint64_t)n / (uint64_t)JK_TILE2) + nseg + 1;
-    GDF_TRY(launch_scatter2(narrow, sc2_threads, tile_bound, g2, m, sb->tuples(0), cursor.as<uint32_t>(), sb->tuples(1)));
+    GDF_TRY(launch_scatter2(narrow, sc2_threads, tile_bound, g2, m, sb->tuples(0), cursor.as<uint32_t>(), sb->tuples(1), p6));
+    sb->p6 = p6;
     // no synchronisation: the map and the level-1 tuples stay allocated until probe_partitioned has read its state block
     sb->d_map.p = d_map.release();
     sb->final_buf = 1;
@@ -2816,6 +2903,19 @@ template <bool NARROW>
 static gdf_error run_probe(bool write, const char *name, size_t nunits, size_t lds, const ProbeArgs &a, const KeyTable &probe_t,
                            const KeyTable &build_t) {
   if (!nunits) return GDF_SUCCESS;
+  if constexpr (NARROW) {
+    if (a.p6_fb) {                 // six-byte probe tuples
+      if (write) {
+        HIP_TRY(hipFuncSetAttribute((const void *)jk_probe<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        GDF_LAUNCH(name, (jk_probe<true, true, true>), dim3((unsigned)nunits), dim3(JK_PROBE_THREADS), lds, stream0(), a, probe_t, build_t);
+      } else {
+        HIP_TRY(hipFuncSetAttribute((const void *)jk_probe<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        GDF_LAUNCH(name, (jk_probe<false, true, true>), dim3((unsigned)nunits), dim3(JK_PROBE_THREADS), lds, stream0(), a, probe_t, build_t);
+      }
+      HIP_CHECK_LAST();
+      return GDF_SUCCESS;
+    }
+  }
   if (write) {
     HIP_TRY(hipFuncSetAttribute((const void *)jk_probe<true, NARROW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     GDF_LAUNCH(name, (jk_probe<true, NARROW>), dim3((unsigned)nunits), dim3(JK_PROBE_THREADS), lds, stream0(), a, probe_t, build_t);
@@ -2868,6 +2968,11 @@ static gdf_error run_write_pass(bool narrow, bool plain, size_t nunits, size_t l
     if (pow2 && a.pay_mode) JK_BP_LAUNCH(true, true); else if (pow2) JK_BP_LAUNCH(true, false);
     else if (a.pay_mode) JK_BP_LAUNCH(false, true); else JK_BP_LAUNCH(false, false);
 #undef JK_BP_LAUNCH
+  } else if (narrow && a.p6_fb) {      // six-byte probe tuples (never together with carried columns)
+    if (pow2 && keep) JK_FAST_LAUNCH(true, true, true, 0, true);
+    else if (pow2) JK_FAST_LAUNCH(true, false, true, 0, true);
+    else if (keep) JK_FAST_LAUNCH(false, true, true, 0, true);
+    else JK_FAST_LAUNCH(false, false, true, 0, true);
   } else if (narrow && a.pay_mode) {
 #define JK_FAST_PAY(M)                                                                                                             \
   do {                                                                                                                             \
@@ -2914,13 +3019,16 @@ static gdf_error run_count_pass(bool narrow, bool plain, size_t nunits, size_t l
     fa.nslots = ((uint32_t)(max_build * 1.25) + 63) & ~63u;
     flds = probe_lds_bytes(narrow, a.cap, fa.nslots, false);
   }
-#define JK_COUNT_LAUNCH(P2, KP, NW)                                                                                               \
+#define JK_COUNT_LAUNCH(...)                                                                                                     \
   do {                                                                                                                            \
-    HIP_TRY(hipFuncSetAttribute((const void *)jk_count_fast<P2, KP, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds)); \
-    GDF_LAUNCH("jk_probe_count", (jk_count_fast<P2, KP, NW>), dim3((unsigned)nunits), dim3(JK_PROBE_THREADS), flds, stream0(), fa); \
+    HIP_TRY(hipFuncSetAttribute((const void *)jk_count_fast<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds)); \
+    GDF_LAUNCH("jk_probe_count", (jk_count_fast<__VA_ARGS__>), dim3((unsigned)nunits), dim3(JK_PROBE_THREADS), flds, stream0(), fa); \
   } while (0)
   const bool keep = a.keep_unmatched_probe != 0;
-  if (narrow) {
+  if (narrow && a.p6_fb) {
+    if (pow2 && keep) JK_COUNT_LAUNCH(true, true, true, true); else if (pow2) JK_COUNT_LAUNCH(true, false, true, true);
+    else if (keep) JK_COUNT_LAUNCH(false, true, true, true); else JK_COUNT_LAUNCH(false, false, true, true);
+  } else if (narrow) {
     if (pow2 && keep) JK_COUNT_LAUNCH(true, true, true); else if (pow2) JK_COUNT_LAUNCH(true, false, true);
     else if (keep) JK_COUNT_LAUNCH(false, true, true); else JK_COUNT_LAUNCH(false, false, true);
   } else {
@@ -3150,9 +3258,14 @@ static gdf_error probe_prepared(const KeyTable &probe_t, const KeyTable &build_t
   if (carry) { pay_src.col[0] = pc->src[0]; pay_src.col[1] = pc->src[1]; }
   const PaySrc *pay = carry ? &pay_src : nullptr;
   const int pmode = carry ? pc->mode : 0;
+  // six-byte level-2 tuples (p6_store): the main path, 2^15 fine partitions (17 hash bits left), nothing carried, and stored keys
+  // on which hash_a is a bijection -- their raw values raw = key + kmin must not straddle a 2^32 boundary
+  const bool bijective = plan.kmin == 0 || (plan.kmin & 0xffffffffULL) + plan.kspan < (1ULL << 32);
+  const bool want_p6 = defer && g.fb == JK_MAX_FB && g.b3 == 0 && g.world <= 1 && plan.narrow && !plan.verify && pc_eff == nullptr && bijective &&
+                       !lab::path_on("GDF_JK_NO_P6");
   if (!skew && g.fb > 0 && probe_t.nrows >= spec_min && largest_build <= (uint32_t)JK_MAX_BUILD && !lab::path_on("GDF_JK_NO_SPEC"))
     GDF_TRY(partition_side_spec(probe_t, plan, g, std::max(1.0, (double)probe_t.nrows / std::max<uint32_t>(B.joinable, 1)), &P, &spec_ok,
-                                nullptr, defer, pay, pmode));
+                                nullptr, defer, pay, pmode, want_p6));
   if (!spec_ok) {
     P.w[0].reset(); P.w[1].reset(); P.idx[0].reset(); P.idx[1].reset(); P.pay[0].reset(); P.pay[1].reset();
     KeyPlan probe_plan = plan;             // partition_side only rewrites the plan when asked to decide the format
@@ -3308,6 +3421,11 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
   a.build_matched = d_matched.as<uint8_t>();
   a.dbg = (int)lab::knob_int("GDF_JK_DBG", 0);
   a.kbias = plan.kmin;
+  if (P.p6) {                       // six-byte probe tuples: the kernels hash and compare hash remainders (ProbeArgs::p6_fb)
+    a.p6_fb = g.fb;
+    a.p6_kbias = plan.kmin;
+    a.kbias = 0;
+  }
   const size_t probe_lds = probe_lds_bytes(narrow, cap_lds, H_lds);
   const bool plain = kind != JOIN_FULL && !plan.verify;       // INNER and LEFT with exact keys: see jk_probe_fast
 

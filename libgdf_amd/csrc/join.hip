@@ -563,6 +563,40 @@ template <bool LEVEL1, bool NARROW, int THREADS, bool PAY, int ITEMS, bool P6 = 
 __device__ __forceinline__ void tile_flush(TileLds<NARROW, THREADS, PAY, ITEMS> &s, const PartGeom &g, Tuples out) {
   const uint32_t total = s.total;
   const uint32_t submask = (1u << g.b2) - 1;
+  if constexpr (P6) {
+    // six-byte tuples leave in PAIRS: a lane takes LDS positions 2 i, 2 i + 1 (one 16-byte LDS read); inside a (tile, bin) run their
+    // destinations are neighbours, and the two tuples go out as ONE 12-byte store instead of two 4-byte + two 2-byte ones (a wave
+    // writes 768 contiguous bytes per instruction); only a pair that straddles a run boundary is stored tuple by tuple
+    constexpr int UP = 2;
+    const uint32_t rmask = (1u << (32 - g.fb)) - 1u;
+    for (uint32_t i0 = threadIdx.x; 2 * i0 < total; i0 += THREADS * UP) {
+      ulonglong2 ww[UP];
+#pragma unroll
+      for (int u = 0; u < UP; ++u) {
+        const uint32_t j = 2 * (i0 + u * THREADS);
+        ww[u] = j < total ? *reinterpret_cast<const ulonglong2 *>(&s.w[j]) : ulonglong2{0, 0};      // (the slot behind an odd total is the tile's own, its content unused)
+      }
+#pragma unroll
+      for (int u = 0; u < UP; ++u) {
+        const uint32_t j = 2 * (i0 + u * THREADS);
+        if (j >= total) continue;
+        const uint32_t h0 = local_hash(hash_a((ww[u].x >> 32) + g.kbias), g.world), h1 = local_hash(hash_a((ww[u].y >> 32) + g.kbias), g.world);
+        const uint32_t bin0 = (uint32_t)((uint64_t)h0 >> (32 - g.fb)) & submask, bin1 = (uint32_t)((uint64_t)h1 >> (32 - g.fb)) & submask;
+        const uint32_t dst0 = s.gbase[bin0] + j, dst1 = s.gbase[bin1] + j + 1;
+        const uint32_t r0 = h0 & rmask, r1 = h1 & rmask;
+        if (j + 1 < total && dst1 == dst0 + 1) {
+          const uint32_t lo0 = ((uint32_t)ww[u].x & 0x7fffffffu) | (r0 << 31), lo1 = ((uint32_t)ww[u].y & 0x7fffffffu) | (r1 << 31);
+          struct __attribute__((packed, aligned(2))) D3 { uint32_t a, b, c; };
+          D3 d{lo0, (r0 >> 1) | (lo1 << 16), (lo1 >> 16) | ((r1 >> 1) << 16)};
+          *reinterpret_cast<D3 *>(reinterpret_cast<unsigned char *>(out.w) + (size_t)dst0 * 6u) = d;
+        } else {
+          p6_store(out.w, dst0, r0, (uint32_t)ww[u].x);
+          if (j + 1 < total) p6_store(out.w, dst1, r1, (uint32_t)ww[u].y);
+        }
+      }
+    }
+    return;
+  }
   constexpr int U = 4;
   for (uint32_t j0 = threadIdx.x; j0 < total; j0 += THREADS * U) {
     uint64_t ww[U], pp[U];
@@ -2091,6 +2125,153 @@ __global__ __launch_bounds__(JK_BP_THREADS) void jk_probe_bp(ProbeArgs a) {
   }
 }
 
+// REPEATED BUILD KEYS in the plain case (INNER / LEFT, NARROW tuples, exact keys): a cuckoo table of positions holds a key at most
+// twice, so such joins (many-to-many: the sample pass reports units that did not settle) took the general kernel for both
+// passes -- 2.9 + 4.8 ms of a 10.7 ms join on 2.5e8 x 1e8 rows with every build key four times.  This is the lean kernel for
+// them: an open-addressing table over the DISTINCT keys of the partition (2 H slots of positions, linear probing), the copies of
+// a key chained behind its head (next[]: low 16 bits = next position, high 16 bits of a HEAD = the length of its chain, filled
+// in once per partition after the build), the eight first probes of a batch in flight together, COUNT = one read of the head's
+// length, WRITE = one output claim per wave and batch and a walk of exactly the key's copies.  Any multiplicity that fits LDS.
+constexpr uint32_t JK_MM_END = 0xffffu;
+template <bool WRITE, bool KEEP, bool P6>
+__global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_multi(ProbeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const uint32_t H = a.nslots, cap = a.cap;
+  const ProbeLds l = carve_probe_lds<true>(lds_raw, cap, H);
+  unsigned int *lcur = (unsigned int *)l.unit_cursor;
+  const Unit u = a.units[blockIdx.x];
+  const uint32_t mask = 2 * H - 1;
+  for (uint32_t i = threadIdx.x; i < u.build_count; i += JK_PROBE_THREADS) {
+    uint64_t w = a.build.w[u.build_begin + i];
+    if (P6) w = ((uint64_t)p6_remainder((uint32_t)(w >> 32), a.p6_kbias, a.p6_fb) << 32) | (uint32_t)w;
+    l.bw[i] = w;
+    l.next[i] = JK_MM_END;
+  }
+  for (uint32_t i = threadIdx.x; i < 2 * H; i += JK_PROBE_THREADS) l.T[i] = JK_NOPOS;
+  if (threadIdx.x == 0) *lcur = 0;
+  block_sync();
+  const uint32_t kb_lo = (uint32_t)a.kbias, kb_hi = (uint32_t)(a.kbias >> 32);
+  auto slot_of_key = [&](uint32_t key) -> uint32_t {        // fold of the raw key, one multiply (the partition id took lowbias32's bits)
+    const uint32_t lo = key + kb_lo;
+    const uint32_t hi = kb_hi + (lo < key ? 1u : 0u);
+    return (((lo ^ (hi * 0x9e3779b1u)) * 0xc2b2ae35u) >> 7) & mask;
+  };
+  // build: a position becomes the head of its key (CAS into an empty slot) or goes right behind the head
+  for (uint32_t p = threadIdx.x; p < u.build_count; p += JK_PROBE_THREADS) {
+    const uint32_t kp = (uint32_t)(l.bw[p] >> 32);
+    uint32_t slot = slot_of_key(kp);
+    for (;;) {
+      const uint32_t q = atomicCAS(&l.T[slot], JK_NOPOS, p);
+      if (q == JK_NOPOS) break;
+      if ((uint32_t)(l.bw[q] >> 32) == kp) { l.next[p] = atomicExch(&l.next[q], p); break; }
+      slot = (slot + 1) & mask;
+    }
+  }
+  block_sync();
+  // chain lengths, once per key: the thread that finds a head in its table slots walks the chain
+  for (uint32_t sl = threadIdx.x; sl < 2 * H; sl += JK_PROBE_THREADS) {
+    const uint32_t h = l.T[sl];
+    if (h == JK_NOPOS) continue;
+    uint32_t len = 1;
+    for (uint32_t p = l.next[h] & 0xffffu; p != JK_MM_END; p = l.next[p] & 0xffffu) ++len;
+    l.next[h] = (l.next[h] & 0xffffu) | (len << 16);
+  }
+  block_sync();
+  const unsigned long long unit_base = WRITE ? a.counts[blockIdx.x] : 0ull;
+  const uint32_t unit_cap = (WRITE && a.optimistic) ? u.probe_count : 0xffffffffu;
+  int32_t *__restrict__ op = WRITE ? a.out_probe + unit_base : nullptr;
+  int32_t *__restrict__ ob = WRITE ? a.out_build + unit_base : nullptr;
+  constexpr int NB = JK_PROBE_BATCH * 2;
+  const uint32_t lead = u.probe_begin & 1u;
+  const uint64_t *__restrict__ src = a.probe.w + (u.probe_begin - lead);
+  const uint32_t vtotal = lead + u.probe_count;
+  const uint32_t last_pair = (vtotal - 1) & ~1u;
+  unsigned long long mine = 0;
+  for (uint32_t base = 0; base < vtotal; base += JK_PROBE_THREADS * NB) {
+    uint32_t key[NB], prow[NB];
+    bool act[NB];
+#pragma unroll
+    for (int b = 0; b < JK_PROBE_BATCH; ++b) {
+      const uint32_t v = base + (b * JK_PROBE_THREADS + threadIdx.x) * 2;
+      const uint32_t vc = v < last_pair ? v : last_pair;
+      if constexpr (P6) {
+        p6_load_pair(a.probe.w, (u.probe_begin - lead) + vc, key[2 * b], prow[2 * b], key[2 * b + 1], prow[2 * b + 1]);
+      } else {
+        const ulonglong2 ww = *reinterpret_cast<const ulonglong2 *>(src + vc);
+        key[2 * b] = (uint32_t)(ww.x >> 32); prow[2 * b] = (uint32_t)ww.x;
+        key[2 * b + 1] = (uint32_t)(ww.y >> 32); prow[2 * b + 1] = (uint32_t)ww.y;
+      }
+      act[2 * b] = v >= lead && v < vtotal;
+      act[2 * b + 1] = v + 1 < vtotal;
+    }
+    // first probes of the batch together; the few that land on another key's head walk on one by one
+    uint32_t slot[NB], head[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { slot[b] = slot_of_key(key[b]); head[b] = l.T[slot[b]]; }
+    uint64_t hw[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) hw[b] = l.bw[head[b] == JK_NOPOS ? 0 : head[b]];
+    uint32_t cnt[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      while (head[b] != JK_NOPOS && (uint32_t)(hw[b] >> 32) != key[b]) {
+        slot[b] = (slot[b] + 1) & mask;
+        head[b] = l.T[slot[b]];
+        hw[b] = l.bw[head[b] == JK_NOPOS ? 0 : head[b]];
+      }
+      const bool hit = act[b] && head[b] != JK_NOPOS;
+      cnt[b] = hit ? l.next[head[b]] >> 16 : ((KEEP && act[b]) ? 1u : 0u);
+      if (!hit) head[b] = JK_NOPOS;
+    }
+    if constexpr (!WRITE) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) mine += cnt[b];
+    } else {
+      // ONE claim per wave and batch: the lanes' pair counts of tuple b are scanned, the eight totals added up, lane 0 claims
+      uint32_t off[NB], tot = 0;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const uint32_t incl = wave_scan_incl(cnt[b]);
+        off[b] = tot + incl - cnt[b];
+        tot += (uint32_t)__shfl((int)incl, WAVE - 1, WAVE);
+      }
+      uint32_t wbase = 0;
+      if (lane_id() == 0 && tot) wbase = atomicAdd(lcur, tot);
+      wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        if (!cnt[b]) continue;
+        uint32_t pos = wbase + off[b];
+        if (pos + cnt[b] > unit_cap) { a.opt_state[1] = 1; continue; }      // would spill into the next unit's slots
+        if (head[b] == JK_NOPOS) { op[pos] = (int32_t)prow[b]; ob[pos] = JK_EMPTY; continue; }      // LEFT: no partner
+        op[pos] = (int32_t)prow[b];
+        ob[pos] = (int32_t)(uint32_t)hw[b];
+        for (uint32_t p = l.next[head[b]] & 0xffffu; p != JK_MM_END; p = l.next[p] & 0xffffu) {
+          ++pos;
+          op[pos] = (int32_t)prow[b];
+          ob[pos] = (int32_t)(uint32_t)l.bw[p];
+        }
+      }
+    }
+  }
+  if constexpr (!WRITE) {
+    mine = wave_reduce_add(mine);
+    if (lane_id() == 0) l.wave_cnt[threadIdx.x / WAVE] = mine;
+    block_sync();
+    if (threadIdx.x == 0) {
+      unsigned long long t = 0;
+      for (int w = 0; w < JK_PROBE_THREADS / WAVE; ++w) t += l.wave_cnt[w];
+      a.counts[blockIdx.x] = t;
+    }
+  } else if (a.optimistic) {
+    block_sync();
+    if (threadIdx.x == 0) {
+      atomicAdd(&a.opt_state[0], (unsigned long long)*lcur);
+      if (a.unit_pairs) a.unit_pairs[blockIdx.x] = *lcur;
+    }
+  }
+}
+
 // Sparse optimistic pass: every unit wrote its pairs at the START of its own slot range (slot_off[u], room for one pair per
 // probe tuple); this moves them to their final, dense places (pair_off[u] = exclusive scan of the units' pair counts).
 // One workgroup per unit, 16 B per pair -- cheaper than a count pass (which reads every probe tuple and rebuilds every LDS
@@ -3002,6 +3183,28 @@ static gdf_error run_write_pass(bool narrow, bool plain, size_t nunits, size_t l
   return GDF_SUCCESS;
 }
 
+// both passes of a plain join whose build keys repeat (jk_probe_multi): NARROW tuples, no carried columns, no FULL-join marks
+static gdf_error run_multi_pass(bool write, size_t nunits, size_t lds, const ProbeArgs &a) {
+  if (!nunits) return GDF_SUCCESS;
+  const bool keep = a.keep_unmatched_probe != 0, p6 = a.p6_fb != 0;
+  const char *name = write ? "jk_probe_write" : "jk_probe_count";
+#define JK_MM_LAUNCH(W, KP, SIX)                                                                                                   \
+  do {                                                                                                                            \
+    HIP_TRY(hipFuncSetAttribute((const void *)jk_probe_multi<W, KP, SIX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    GDF_LAUNCH(name, (jk_probe_multi<W, KP, SIX>), dim3((unsigned)nunits), dim3(JK_PROBE_THREADS), lds, stream0(), a);            \
+  } while (0)
+  if (write) {
+    if (keep && p6) JK_MM_LAUNCH(true, true, true); else if (keep) JK_MM_LAUNCH(true, true, false);
+    else if (p6) JK_MM_LAUNCH(true, false, true); else JK_MM_LAUNCH(true, false, false);
+  } else {
+    if (keep && p6) JK_MM_LAUNCH(false, true, true); else if (keep) JK_MM_LAUNCH(false, true, false);
+    else if (p6) JK_MM_LAUNCH(false, false, true); else JK_MM_LAUNCH(false, false, false);
+  }
+#undef JK_MM_LAUNCH
+  HIP_CHECK_LAST();
+  return GDF_SUCCESS;
+}
+
 // COUNT pass over all units: the lean kernel for plain joins (jk_count_fast), the units it could not settle and every other
 // case through the general kernel.  a.counts must be zeroed; a.opt_state must point at 3 zeroed counters.
 static gdf_error run_count_pass(bool narrow, bool plain, size_t nunits, size_t lds, ProbeArgs a, uint32_t max_build,
@@ -3609,6 +3812,8 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
   HIP_TRY(hipMemsetAsync(d_counts.p, 0, sizeof(uint64_t) * (nslots_all + 1), stream0()));
   a.counts = d_counts.as<uint64_t>();
 
+  // repeated build keys in a plain NARROW join without carried columns: the lean multimap kernel serves both passes
+  const bool multi = plain && dup_heavy && narrow && ncc == 0 && !lab::path_on("GDF_JK_NO_MULTI");
   // ---- count pass ----
   {
     DevBuf d_cstate;
@@ -3616,7 +3821,8 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
     HIP_TRY(hipMemsetAsync(d_cstate.p, 0, sizeof(unsigned long long) * 4, stream0()));
     ProbeArgs ca = a;
     ca.opt_state = d_cstate.as<unsigned long long>();
-    GDF_TRY(run_count_pass(narrow, plain && !dup_heavy, nunits, probe_lds, ca, max_build, probe_t, build_t));
+    if (multi) GDF_TRY(run_multi_pass(false, nunits, probe_lds, ca));
+    else GDF_TRY(run_count_pass(narrow, plain && !dup_heavy, nunits, probe_lds, ca, max_build, probe_t, build_t));
   }
   // oversize partitions: one global table each, kept for the write pass
   struct GTable { DevBuf key, idx, next; uint32_t nslots; };      // idx: chain heads per slot (+ the reserved slot), next: per build tuple
@@ -3683,7 +3889,8 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
   RMM_TRY(d_wstate.alloc(sizeof(unsigned long long) * 4));
   HIP_TRY(hipMemsetAsync(d_wstate.p, 0, sizeof(unsigned long long) * 4, stream0()));
   a.opt_state = d_wstate.as<unsigned long long>();
-  GDF_TRY(run_write_pass(narrow, plain && !dup_heavy, nunits, probe_lds, a, max_build, probe_t, build_t));
+  if (multi) GDF_TRY(run_multi_pass(true, nunits, probe_lds, a));
+  else GDF_TRY(run_write_pass(narrow, plain && !dup_heavy, nunits, probe_lds, a, max_build, probe_t, build_t));
   for (size_t o = 0; o < oversize.size(); ++o) {
     const uint32_t f = oversize[o].f0, fe = oversize[o].f1;
     const uint32_t pn = P.fine_off[fe] - P.fine_off[f];

@@ -784,6 +784,29 @@ def test_six_byte_level2_tuples(gdf, how, keys, hit, force_path):
     assert _check(gdf, probe, build, how) == n1
 
 
+@pytest.mark.parametrize("how", ["inner", "left"])
+@pytest.mark.parametrize("copies", [3, 4, 16, 300])
+@pytest.mark.parametrize("geometry", ["natural", "forced-2^15-partitions"])
+def test_repeated_build_keys_take_the_lean_multimap_kernel(gdf, how, copies, geometry, force_path):
+    """Every build key `copies` times (a many-to-many join): the sample pass sees units whose cuckoo build does not settle and both
+    passes run on jk_probe_multi -- distinct keys in an open-addressing table of positions, the copies chained in LDS, chain
+    lengths precomputed for the count pass (csrc/join.hip; multimap semantics of the reference, join_kernels.cuh:127-234, EqualValues
+    test).  Against the oracle and against the general kernel (GDF_JK_NO_MULTI); with the forced geometry also on six-byte tuples;
+    a quarter of the probe rows miss."""
+    rs = np.random.RandomState(copies)
+    nb, npr = 90_000, 400_000
+    distinct = nb // copies
+    build = (rs.permutation(nb) % distinct).astype(np.int64) + 1000
+    probe = rs.randint(0, distinct + distinct // 3, size=npr).astype(np.int64) + 1000
+    force_path("GDF_JK_SPEC_MIN", "1000")
+    if geometry != "natural":
+        force_path("GDF_JK_FORCE_FB", "15")
+    n1 = _check(gdf, [probe], [build], how)
+    assert n1 >= npr // 2 * copies
+    force_path("GDF_JK_NO_MULTI")
+    assert _check(gdf, [probe], [build], how) == n1
+
+
 @pytest.mark.parametrize("variant", ["all-ones", "bernoulli-0.99"])
 def test_headline_configuration_with_valid_masks(gdf, variant):
     """BASELINE config C3, variant B ("all-ones masks to exercise paired mask reads"; north_star: "coalesced HBM

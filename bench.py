@@ -37,9 +37,11 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
 KERNEL_BYTES = {
     "jk_hist": lambda npr, nb, tb, lps, kb: kb * nb + (kb * npr if lps > 1.5 else 0.0),   # reads every key once
     "jk_scatter1": lambda npr, nb, tb, lps, kb: (kb + tb) * (npr + nb),         # key in, tuple out
-    "jk_scatter2": lambda npr, nb, tb, lps, kb: (tb + tb) * (npr + nb),         # tuple in, tuple out
-    "jk_probe_count": lambda npr, nb, tb, lps, kb: tb * (npr + nb),             # tuples in
-    "jk_probe_write": lambda npr, nb, tb, lps, kb: tb * (npr + nb) + 8.0 * npr, # tuples in, one int32 index pair per probe row out
+    # (six-byte level-2 tuples on the probe side -- csrc/join.hip p6_store -- when the keys are NARROW and the build side needs 2^15
+    # partitions: the probe side's level-2 output and the probe kernel's input are then 6 B per tuple)
+    "jk_scatter2": lambda npr, nb, tb, lps, kb: (tb + tb) * nb + (tb + p6_bytes(nb, tb)) * npr,         # tuple in, tuple out
+    "jk_probe_count": lambda npr, nb, tb, lps, kb: tb * nb + p6_bytes(nb, tb) * npr,                    # tuples in
+    "jk_probe_write": lambda npr, nb, tb, lps, kb: tb * nb + p6_bytes(nb, tb) * npr + 8.0 * npr,        # tuples in, one int32 index pair per probe row out
     # the sender side of the shuffle (multi-GPU only): int64 keys in; narrowed key + int32 row number out
     "shuffle_hist": lambda npr, nb, tb, lps, kb: 8.0 * (npr + nb),
     "shuffle_scatter": lambda npr, nb, tb, lps, kb: (8.0 + kb + 4.0) * (npr + nb),
@@ -49,6 +51,11 @@ KERNEL_BYTES = {
     # the fused variant: raw int64 key in, narrowed key + row number out (the row numbers stay with the sender)
     "fj_scatter": lambda npr, nb, tb, lps, kb: (8.0 + 4.0 + 4.0) * (npr + nb),
 }
+
+
+def p6_bytes(nb, tb):
+    """bytes per probe-side level-2 tuple: 6 when the join takes the six-byte tuples (NARROW keys, >= 3072 * 2^14 build rows), else tb"""
+    return 6.0 if (tb == 8.0 and nb >= 3072 * 2 ** 14) else tb
 
 
 def splitmix64_torch(x):

@@ -558,37 +558,8 @@ __device__ __forceinline__ void p6_load_pair(const uint64_t *base, uint32_t v, u
   r1 = (lo1 >> 31) | ((d.c >> 16) << 1);
 }
 
-// SEVEN-BYTE level-1 tuples (P7), the same idea one level up: after the 256-way level 1 a tuple is identified inside its coarse
-// partition by the remaining 24 bits of hash_a; with the 31-bit row that is 55 bits.  jk_scatter1<P7> keeps the HASH instead of the
-// key from its ranking on (the flush then needs no second hash), writes 7 bytes per tuple -- two tuples of a run as one 14-byte
-// store -- and jk_scatter2<P7IN> reads them with unaligned 8-byte loads and never hashes at all: its bin and the six-byte
-// remainder are bit fields of what it read.  Together with P6: 8 + 7 | 7 + 6 | 6 + 8 = 42 B per probe row.
-__device__ __forceinline__ uint64_t p7_encode(uint64_t hash_row_word, int rem_bits) {      // (hash << 32 | row) -> 55-bit tuple
-  return ((uint64_t)((uint32_t)(hash_row_word >> 32) & ((1u << rem_bits) - 1u)) << 31) | ((uint32_t)hash_row_word & 0x7fffffffu);
-}
-__device__ __forceinline__ void p7_store(unsigned char *base, uint32_t pos, uint64_t v) {
-  unsigned char *at = base + (size_t)pos * 7u;
-  const uint32_t lo = (uint32_t)v;
-  const uint16_t mid = (uint16_t)(v >> 32);
-  const uint8_t hi = (uint8_t)(v >> 48);
-  __builtin_memcpy(at, &lo, 4);
-  __builtin_memcpy(at + 4, &mid, 2);
-  at[6] = hi;
-}
-__device__ __forceinline__ void p7_store_pair(unsigned char *base, uint32_t pos, uint64_t v0, uint64_t v1) {
-  struct __attribute__((packed, aligned(1))) D14 { uint32_t a, b, c; uint16_t d; };
-  D14 d{(uint32_t)v0, (uint32_t)(v0 >> 32) | ((uint32_t)v1 << 24), (uint32_t)(v1 >> 8), (uint16_t)(v1 >> 40)};
-  *reinterpret_cast<D14 *>(base + (size_t)pos * 7u) = d;
-}
-// tuple i of a P7 stream -> (remainder << 32 | row), the form the level-2 tile works on
-__device__ __forceinline__ uint64_t p7_load(const uint64_t *base, uint32_t i) {
-  uint64_t v;
-  __builtin_memcpy(&v, reinterpret_cast<const unsigned char *>(base) + (size_t)i * 7u, 8);      // (one byte of the next tuple / the pad rides along)
-  return (((v >> 31) & 0x1ffffffULL) << 32) | (v & 0x7fffffffULL);
-}
-
 // phase C: write the regrouped tile out.  LEVEL1 bins are the coarse id, LEVEL2 the sub id.
-template <bool LEVEL1, bool NARROW, int THREADS, bool PAY, int ITEMS, bool P6 = false, bool P7IN = false>
+template <bool LEVEL1, bool NARROW, int THREADS, bool PAY, int ITEMS, bool P6 = false>
 __device__ __forceinline__ void tile_flush(TileLds<NARROW, THREADS, PAY, ITEMS> &s, const PartGeom &g, Tuples out) {
   const uint32_t total = s.total;
   const uint32_t submask = (1u << g.b2) - 1;
@@ -609,9 +580,7 @@ __device__ __forceinline__ void tile_flush(TileLds<NARROW, THREADS, PAY, ITEMS> 
       for (int u = 0; u < UP; ++u) {
         const uint32_t j = 2 * (i0 + u * THREADS);
         if (j >= total) continue;
-        // (P7IN: the tile's words already hold hash bits -- the low 32 - b1 of them; the fields below lie inside)
-        const uint32_t h0 = P7IN ? (uint32_t)(ww[u].x >> 32) : local_hash(hash_a((ww[u].x >> 32) + g.kbias), g.world);
-        const uint32_t h1 = P7IN ? (uint32_t)(ww[u].y >> 32) : local_hash(hash_a((ww[u].y >> 32) + g.kbias), g.world);
+        const uint32_t h0 = local_hash(hash_a((ww[u].x >> 32) + g.kbias), g.world), h1 = local_hash(hash_a((ww[u].y >> 32) + g.kbias), g.world);
         const uint32_t bin0 = (uint32_t)((uint64_t)h0 >> (32 - g.fb)) & submask, bin1 = (uint32_t)((uint64_t)h1 >> (32 - g.fb)) & submask;
         const uint32_t dst0 = s.gbase[bin0] + j, dst1 = s.gbase[bin1] + j + 1;
         const uint32_t r0 = h0 & rmask, r1 = h1 & rmask;
@@ -678,7 +647,7 @@ __device__ __forceinline__ uint32_t load_mask_word(const uint8_t *valid, uint32_
   const uint32_t drop = (at - from) * 8u;                // bits of earlier bytes in front of ours; >= 32: every row is behind the end
   return drop < 32u ? w >> drop : 0u;
 }
-template <int FAST, bool NARROW, int THREADS, bool MASKED = false, bool P7 = false>
+template <int FAST, bool NARROW, int THREADS, bool MASKED = false>
 __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan, PartGeom g,
                                                              const uint32_t *__restrict__ H1off,   // scanned H1
                                                              Tuples out) {
@@ -770,14 +739,7 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
     for (int h = 0; h < JK_SC_ITEMS; h += 4) {
 #pragma unroll
       for (int k = h; k < h + 4; ++k) {
-        uint32_t b;
-        if constexpr (P7) {                      // seven-byte tuples: from here on the tuple carries the HASH, not the key
-          const uint32_t hsh = hash_a((uint64_t)key[k] + g.kbias);
-          key[k] = (KeyReg)hsh;
-          b = hsh >> (32 - g.b1);
-        } else {
-          b = fine_of((uint64_t)key[k] + g.kbias, g.fb) >> g.b2;     // hashed whether it travels or not: no branch
-        }
+        const uint32_t b = fine_of((uint64_t)key[k] + g.kbias, g.fb) >> g.b2;     // hashed whether it travels or not: no branch
         binrank[k] = (okmask >> k) & 1u ? b : 256u;
       }
       __builtin_amdgcn_sched_barrier(0);       // four hashes at a time: sixteen interleaved ones spill
@@ -846,35 +808,6 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
     const uint32_t total = s.total;
     const uint32_t ftid = opaque_tid();
     constexpr int GROUP = 4;
-    if constexpr (P7) {
-      // seven-byte tuples leave in pairs (LDS positions 2 i, 2 i + 1: one 16-byte LDS read, inside a run one 14-byte store); the
-      // bin is the top b1 bits of the hash the tile word carries.  Slots behind `total` are not stored.
-      unsigned char *ob = reinterpret_cast<unsigned char *>(out.w);
-      const int rem_bits = 32 - g.b1;
-#pragma unroll
-      for (int h = 0; h < JK_SC_ITEMS / 2 / GROUP; ++h) {
-        ulonglong2 ww[GROUP];
-        uint32_t g0[GROUP], g1[GROUP];
-#pragma unroll
-        for (int k = 0; k < GROUP; ++k) ww[k] = *reinterpret_cast<const ulonglong2 *>(&s.w[2 * (ftid + (h * GROUP + k) * THREADS)]);
-#pragma unroll
-        for (int k = 0; k < GROUP; ++k) {
-          g0[k] = s.gbase[((uint32_t)(ww[k].x >> 32) >> rem_bits) & 255u];
-          g1[k] = s.gbase[((uint32_t)(ww[k].y >> 32) >> rem_bits) & 255u];
-        }
-#pragma unroll
-        for (int k = 0; k < GROUP; ++k) {
-          const uint32_t j = 2 * (ftid + (h * GROUP + k) * THREADS);
-          if (j < total) {
-            const uint32_t dst0 = g0[k] + j, dst1 = g1[k] + j + 1;
-            const uint64_t v0 = p7_encode(ww[k].x, rem_bits), v1 = p7_encode(ww[k].y, rem_bits);
-            if (j + 1 < total && dst1 == dst0 + 1) p7_store_pair(ob, dst0, v0, v1);
-            else { p7_store(ob, dst0, v0); if (j + 1 < total) p7_store(ob, dst1, v1); }
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    } else
 #pragma unroll
     for (int h = 0; h < JK_SC_ITEMS / GROUP; ++h) {
       uint64_t ww[GROUP];
@@ -1085,7 +1018,7 @@ struct Level2Map {                     // small host-built tables, device reside
   const uint32_t *keys32;              // non-null: the input is this array of 4-byte keys (a receive buffer), tuple = key << 32 | position
 };
 
-template <bool NARROW, int THREADS, bool PAY = false, bool P6 = false, bool P7IN = false>
+template <bool NARROW, int THREADS, bool PAY = false, bool P6 = false>
 __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, Tuples in,
                                                              uint32_t *__restrict__ fine_cursor, Tuples out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
@@ -1123,8 +1056,7 @@ __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, 
   for (int k = 0; k < ITEMS; ++k) {         // all loads first
     const uint32_t i = begin + k * THREADS + threadIdx.x;
     const uint32_t ic = i < end ? i : end - 1;        // clamped, unconditional: see fetch_keys
-    if constexpr (P7IN) w[k] = p7_load(in.w, ic);     // seven-byte level-1 tuples: (hash remainder, row)
-    else if (NARROW && m.keys32) w[k] = ((uint64_t)m.keys32[ic] << 32) | (uint32_t)(g.row_base + (int32_t)ic);      // workgroup-uniform branch
+    if (NARROW && m.keys32) w[k] = ((uint64_t)m.keys32[ic] << 32) | (uint32_t)(g.row_base + (int32_t)ic);      // workgroup-uniform branch
     else w[k] = in.w[ic];                             // (non-temporal loads, which help jk_scatter1, cost 2 % here)
     idx[k] = NARROW ? 0 : in.idx[ic];
     if (PAY) pay[k] = in.pay[ic];
@@ -1133,8 +1065,7 @@ __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, 
 #pragma unroll
   for (int k = 0; k < ITEMS; ++k) {
     const uint32_t i = begin + k * THREADS + threadIdx.x;
-    const uint32_t bin = P7IN ? ((uint32_t)(w[k] >> 32) >> (32 - g.fb)) & submask
-                              : (uint32_t)((uint64_t)local_hash(hash_a(tup_key<NARROW>(w[k]) + g.kbias), g.world) >> (32 - g.fb)) & submask;
+    const uint32_t bin = (uint32_t)((uint64_t)local_hash(hash_a(tup_key<NARROW>(w[k]) + g.kbias), g.world) >> (32 - g.fb)) & submask;
     binrank[k] = i < end ? bin : 256u;
   }
 #pragma unroll
@@ -1169,7 +1100,7 @@ __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, 
     else s.gbase[threadIdx.x] = claimed - s.start[threadIdx.x];
   }
   block_sync();
-  tile_flush<false, NARROW, THREADS, PAY, ITEMS, P6, P7IN>(s, g, out);
+  tile_flush<false, NARROW, THREADS, PAY, ITEMS, P6>(s, g, out);
 }
 
 // ---------------------------------------------------------------------------
@@ -2719,11 +2650,11 @@ static PartGeom choose_geometry(int64_t build_rows) {
 
 static inline int small_grid(int64_t n) { return stream_grid((size_t)(n > 0 ? n : 1), 256 * 8); }
 
-template <int FAST, bool NARROW, int THREADS, bool MASKED, bool P7 = false>
+template <int FAST, bool NARROW, int THREADS, bool MASKED>
 static gdf_error launch_scatter1_t(const KeyTable &t, const KeyPlan &plan, const PartGeom &g, const uint32_t *H1off, Tuples out) {
   const size_t lds = sizeof(TileLds<NARROW, THREADS>);
-  HIP_TRY(hipFuncSetAttribute((const void *)jk_scatter1<FAST, NARROW, THREADS, MASKED, P7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  GDF_LAUNCH("jk_scatter1", (jk_scatter1<FAST, NARROW, THREADS, MASKED, P7>), dim3(g.nchunks), dim3(THREADS), lds, stream0(), t, plan, g, H1off, out);
+  HIP_TRY(hipFuncSetAttribute((const void *)jk_scatter1<FAST, NARROW, THREADS, MASKED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  GDF_LAUNCH("jk_scatter1", (jk_scatter1<FAST, NARROW, THREADS, MASKED>), dim3(g.nchunks), dim3(THREADS), lds, stream0(), t, plan, g, H1off, out);
   HIP_CHECK_LAST();
   return GDF_SUCCESS;
 }
@@ -2735,14 +2666,8 @@ static gdf_error launch_scatter1_n(int threads, const KeyTable &t, const KeyPlan
   else return launch_scatter1_t<FAST, NARROW, 256, MASKED>(t, plan, g, H1off, out);
 }
 static gdf_error launch_scatter1(int fast, bool narrow, int threads, const KeyTable &t, const KeyPlan &plan, const PartGeom &g,
-                                 const uint32_t *H1off, Tuples out, bool p7 = false) {
+                                 const uint32_t *H1off, Tuples out) {
   const bool masked = fast != 0 && t.col[0].valid != nullptr;
-  if (p7) {                          // seven-byte output tuples (p7_store): FAST key column, NARROW, the production tile size
-    if (fast == 4) return masked ? launch_scatter1_t<4, true, 1024, true, true>(t, plan, g, H1off, out)
-                                 : launch_scatter1_t<4, true, 1024, false, true>(t, plan, g, H1off, out);
-    return masked ? launch_scatter1_t<8, true, 1024, true, true>(t, plan, g, H1off, out)
-                  : launch_scatter1_t<8, true, 1024, false, true>(t, plan, g, H1off, out);
-  }
   if (masked) {
     if (fast == 4) return launch_scatter1_n<4, true, true>(threads, t, plan, g, H1off, out);
     return narrow ? launch_scatter1_n<8, true, true>(threads, t, plan, g, H1off, out)
@@ -2775,19 +2700,14 @@ static gdf_error launch_scatter2_t(uint32_t ntiles, const PartGeom &g, Level2Map
   return GDF_SUCCESS;
 }
 static gdf_error launch_scatter2(bool narrow, int threads, uint32_t ntiles, const PartGeom &g, Level2Map m, Tuples in,
-                                 uint32_t *cursor, Tuples out, bool p6 = false, bool p7in = false) {
+                                 uint32_t *cursor, Tuples out, bool p6 = false) {
   if (p6) {                          // six-byte output tuples (see p6_store): NARROW, no payload, the production tile size
     const size_t lds = sizeof(TileLds<true, 256>);
+    HIP_TRY(hipFuncSetAttribute((const void *)jk_scatter2<true, 256, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     m.ntiles = ntiles;
     m.xcd_order = (ntiles >= 64 && !lab::path_on("GDF_JK_NO_XCD_ORDER")) ? 1 : 0;
     const uint32_t grid = m.xcd_order ? ((ntiles + 7) / 8) * 8 : ntiles;
-    if (p7in) {                      // ... from seven-byte level-1 tuples (p7_store)
-      HIP_TRY(hipFuncSetAttribute((const void *)jk_scatter2<true, 256, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      GDF_LAUNCH("jk_scatter2", (jk_scatter2<true, 256, false, true, true>), dim3(grid), dim3(256), lds, stream0(), g, m, in, cursor, out);
-    } else {
-      HIP_TRY(hipFuncSetAttribute((const void *)jk_scatter2<true, 256, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      GDF_LAUNCH("jk_scatter2", (jk_scatter2<true, 256, false, true>), dim3(grid), dim3(256), lds, stream0(), g, m, in, cursor, out);
-    }
+    GDF_LAUNCH("jk_scatter2", (jk_scatter2<true, 256, false, true>), dim3(grid), dim3(256), lds, stream0(), g, m, in, cursor, out);
     HIP_CHECK_LAST();
     return GDF_SUCCESS;
   }
@@ -3023,15 +2943,11 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
   g.dump = nseg * cap1;
   g.spec_cursor1 = spec.as<uint32_t>();
   g.spec_flag = spec.as<uint32_t>() + nseg;
-  // compact tuples on the main path: six bytes out of level 2 (p6_store), and seven out of level 1 (p7_store) when level 1 is the
-  // production kernel on a FAST key column with 256 coarse partitions
-  const bool p6 = want_p6 && defer && !app && g.b2 > 0 && narrow && !pay && sc2_threads == 256;
-  const bool p7 = p6 && fast != 0 && sc_threads == 1024 && g.b1 == 8 && !lab::path_on("GDF_JK_NO_P7");
-  RMM_TRY(sb->w[0].alloc(p7 ? 7 * size1 + 16 : sizeof(uint64_t) * size1));
+  RMM_TRY(sb->w[0].alloc(sizeof(uint64_t) * size1));
   if (!narrow) RMM_TRY(sb->idx[0].alloc(sizeof(int32_t) * size1));
   if (pay) RMM_TRY(sb->pay[0].alloc(sizeof(uint64_t) * size1));
   if (pay) GDF_TRY(launch_scatter1_pay(fast, pmode, t, plan, g, nullptr, *pay, sb->tuples(0)));
-  else GDF_TRY(launch_scatter1(fast, narrow, sc_threads, t, plan, g, nullptr, sb->tuples(0), p7));
+  else GDF_TRY(launch_scatter1(fast, narrow, sc_threads, t, plan, g, nullptr, sb->tuples(0)));
   if (defer && !app && g.b2 > 0) {
     // DEFERRED: the level-2 map and the fill cursors are made on the device, nothing is read back here; the overflow flags
     // of both levels are looked at once, with the work units (jk_make_units / probe_partitioned)
@@ -3044,6 +2960,7 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
                        (uint32_t)JK_TILE2, seg_begin, seg_end, tile_prefix, ntiles_dev, 0u, 0u);
     hipLaunchKernelGGL(jk_init_cursor, dim3(32), dim3(256), 0, stream0(), cursor.as<uint32_t>(), nfine, cap2);
     HIP_CHECK_LAST();
+    const bool p6 = want_p6 && narrow && !pay && sc2_threads == 256;
     RMM_TRY(sb->w[1].alloc(p6 ? 6 * size2 + 16 : sizeof(uint64_t) * size2));
     if (!narrow) RMM_TRY(sb->idx[1].alloc(sizeof(int32_t) * size2));
     if (pay) RMM_TRY(sb->pay[1].alloc(sizeof(uint64_t) * size2));
@@ -3055,7 +2972,7 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
     m.ntiles_dev = ntiles_dev;
     // every segment ends in at most one partial tile: an upper bound of the tile count sizes the grid
     const uint32_t tile_bound = (uint32_t)((uint64_t)n / (uint64_t)JK_TILE2) + nseg + 1;
-    GDF_TRY(launch_scatter2(narrow, sc2_threads, tile_bound, g2, m, sb->tuples(0), cursor.as<uint32_t>(), sb->tuples(1), p6, p7));
+    GDF_TRY(launch_scatter2(narrow, sc2_threads, tile_bound, g2, m, sb->tuples(0), cursor.as<uint32_t>(), sb->tuples(1), p6));
     sb->p6 = p6;
     // no synchronisation: the map and the level-1 tuples stay allocated until probe_partitioned has read its state block
     sb->d_map.p = d_map.release();

@@ -536,8 +536,10 @@ __device__ __forceinline__ uint32_t opaque_tid() {
 // keys: its LDS image of the build partition gets the keys replaced by their remainders when it is staged (p6_remainder), and
 // equal (partition, remainder) means equal hash means equal key.  Indices-only INNER / LEFT joins on the main (deferred,
 // two-level) path only: whoever needs the key VALUE back (carried key column) or other layouts keeps 8-byte tuples.
-__device__ __forceinline__ uint32_t p6_remainder(uint32_t key32, uint64_t kbias, int fb) {
-  return hash_a((uint64_t)key32 + kbias) & ((1u << (32 - fb)) - 1u);
+// (world > 1, a fused multi-GPU join: the partition id comes from the low word L of hash * world; (owner rank, L) determine the hash --
+// hash * world = rank * 2^32 + L -- so inside a rank's partition the low 32 - fb bits of L identify the tuple just the same)
+__device__ __forceinline__ uint32_t p6_remainder(uint32_t key32, uint64_t kbias, int fb, uint32_t world) {
+  return local_hash(hash_a((uint64_t)key32 + kbias), world) & ((1u << (32 - fb)) - 1u);
 }
 __device__ __forceinline__ void p6_store(uint64_t *base, uint32_t pos, uint32_t r, uint32_t row) {
   unsigned char *at = reinterpret_cast<unsigned char *>(base) + (size_t)pos * 6u;
@@ -1018,7 +1020,9 @@ struct Level2Map {                     // small host-built tables, device reside
   const uint32_t *keys32;              // non-null: the input is this array of 4-byte keys (a receive buffer), tuple = key << 32 | position
 };
 
-template <bool NARROW, int THREADS, bool PAY = false, bool P6 = false>
+// K32: the input is a receive buffer of 4-byte keys (Level2Map::keys32, fused multi-GPU join) -- its own instantiations, so that the
+// single-GPU kernels carry no trace of it
+template <bool NARROW, int THREADS, bool PAY = false, bool P6 = false, bool K32 = false>
 __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, Tuples in,
                                                              uint32_t *__restrict__ fine_cursor, Tuples out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
@@ -1051,22 +1055,40 @@ __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, 
   // straight-line phases as in jk_scatter1: tuples beyond the tile's end are ranked on a trash counter (bin 256) and
   // written to the trash slot of the LDS tile instead of being skipped by a branch per item
   uint64_t w[ITEMS], pay[PAY ? ITEMS : 1];
+  // a receive buffer of 4-byte keys (fused multi-GPU join), full tile: four consecutive keys per 16-byte load -- a quarter of the load
+  // instructions (which tuple of the tile a thread holds does not matter)
+  const bool quads = K32 && end - begin == (uint32_t)JK_TILE;
   int32_t idx[ITEMS];
+  if (K32 && quads) {                                 // workgroup-uniform
+    if constexpr (K32) {
+#pragma unroll
+      for (int q = 0; q < ITEMS / 4; ++q) {
+        const uint32_t i0 = begin + 4u * (q * THREADS + threadIdx.x);
+        const uint4 kk = *reinterpret_cast<const uint4 *>(m.keys32 + i0);     // regions start at multiples of 64 keys, tiles at multiples of 4096
+        w[4 * q + 0] = ((uint64_t)kk.x << 32) | (uint32_t)(g.row_base + (int32_t)i0);
+        w[4 * q + 1] = ((uint64_t)kk.y << 32) | (uint32_t)(g.row_base + (int32_t)(i0 + 1));
+        w[4 * q + 2] = ((uint64_t)kk.z << 32) | (uint32_t)(g.row_base + (int32_t)(i0 + 2));
+        w[4 * q + 3] = ((uint64_t)kk.w << 32) | (uint32_t)(g.row_base + (int32_t)(i0 + 3));
+        idx[4 * q] = idx[4 * q + 1] = idx[4 * q + 2] = idx[4 * q + 3] = 0;
+      }
+    }
+  } else {
 #pragma unroll
   for (int k = 0; k < ITEMS; ++k) {         // all loads first
     const uint32_t i = begin + k * THREADS + threadIdx.x;
     const uint32_t ic = i < end ? i : end - 1;        // clamped, unconditional: see fetch_keys
-    if (NARROW && m.keys32) w[k] = ((uint64_t)m.keys32[ic] << 32) | (uint32_t)(g.row_base + (int32_t)ic);      // workgroup-uniform branch
+    if constexpr (K32) w[k] = ((uint64_t)m.keys32[ic] << 32) | (uint32_t)(g.row_base + (int32_t)ic);
     else w[k] = in.w[ic];                             // (non-temporal loads, which help jk_scatter1, cost 2 % here)
     idx[k] = NARROW ? 0 : in.idx[ic];
     if (PAY) pay[k] = in.pay[ic];
+  }
   }
   uint32_t binrank[ITEMS];
 #pragma unroll
   for (int k = 0; k < ITEMS; ++k) {
     const uint32_t i = begin + k * THREADS + threadIdx.x;
     const uint32_t bin = (uint32_t)((uint64_t)local_hash(hash_a(tup_key<NARROW>(w[k]) + g.kbias), g.world) >> (32 - g.fb)) & submask;
-    binrank[k] = i < end ? bin : 256u;
+    binrank[k] = ((K32 && quads) || i < end) ? bin : 256u;     // (quads: a full tile, every tuple is live whatever order they were fetched in)
   }
 #pragma unroll
   for (int k = 0; k < ITEMS; ++k)            // sixteen atomics in flight, one wait
@@ -1259,6 +1281,7 @@ struct ProbeArgs {
   // instantiations) replace the staged build keys by their remainders -- hash_a(key + p6_kbias) below the top p6_fb bits; kbias is
   // then 0: the "keys" the lookups hash and compare are the remainders
   int p6_fb;
+  uint32_t p6_world;             // PartGeom::world of the build side (fused multi-GPU joins hash with the rank remap)
   uint64_t p6_kbias;
 };
 // the general kernels' payload write: a gather by probe row (rare units only)
@@ -1344,7 +1367,7 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
   // ---- stage the build partition, clear the table ----
   for (uint32_t i = threadIdx.x; i < u.build_count; i += JK_PROBE_THREADS) {
     uint64_t w = a.build.w[u.build_begin + i];
-    if (P6) w = ((uint64_t)p6_remainder((uint32_t)(w >> 32), a.p6_kbias, a.p6_fb) << 32) | (uint32_t)w;
+    if (P6) w = ((uint64_t)p6_remainder((uint32_t)(w >> 32), a.p6_kbias, a.p6_fb, a.p6_world) << 32) | (uint32_t)w;
     l.bw[i] = w;
     if (!NARROW) l.bi[i] = a.build.idx[u.build_begin + i];
   }
@@ -1604,7 +1627,7 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_fast(ProbeArgs a) {
   const Unit u = a.units[blockIdx.x];
   for (uint32_t i = threadIdx.x; i < u.build_count; i += JK_PROBE_THREADS) {
     uint64_t w = a.build.w[u.build_begin + i];
-    if (P6) w = ((uint64_t)p6_remainder((uint32_t)(w >> 32), a.p6_kbias, a.p6_fb) << 32) | (uint32_t)w;      // six-byte probe tuples: compare remainders
+    if (P6) w = ((uint64_t)p6_remainder((uint32_t)(w >> 32), a.p6_kbias, a.p6_fb, a.p6_world) << 32) | (uint32_t)w;      // six-byte probe tuples: compare remainders
     l.bw[i] = w;
     if (!NARROW) l.bi[i] = a.build.idx[u.build_begin + i];
   }
@@ -1824,7 +1847,7 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_count_fast(ProbeArgs a) {
   const Unit u = a.units[blockIdx.x];
   for (uint32_t i = threadIdx.x; i < u.build_count; i += JK_PROBE_THREADS) {
     uint64_t w = a.build.w[u.build_begin + i];
-    if (P6) w = ((uint64_t)p6_remainder((uint32_t)(w >> 32), a.p6_kbias, a.p6_fb) << 32) | (uint32_t)w;
+    if (P6) w = ((uint64_t)p6_remainder((uint32_t)(w >> 32), a.p6_kbias, a.p6_fb, a.p6_world) << 32) | (uint32_t)w;
     l.bw[i] = w;
     if (!NARROW) l.bi[i] = a.build.idx[u.build_begin + i];
   }
@@ -2143,7 +2166,7 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_multi(ProbeArgs a) 
   const uint32_t mask = 2 * H - 1;
   for (uint32_t i = threadIdx.x; i < u.build_count; i += JK_PROBE_THREADS) {
     uint64_t w = a.build.w[u.build_begin + i];
-    if (P6) w = ((uint64_t)p6_remainder((uint32_t)(w >> 32), a.p6_kbias, a.p6_fb) << 32) | (uint32_t)w;
+    if (P6) w = ((uint64_t)p6_remainder((uint32_t)(w >> 32), a.p6_kbias, a.p6_fb, a.p6_world) << 32) | (uint32_t)w;
     l.bw[i] = w;
     l.next[i] = JK_MM_END;
   }
@@ -2701,13 +2724,18 @@ static gdf_error launch_scatter2_t(uint32_t ntiles, const PartGeom &g, Level2Map
 }
 static gdf_error launch_scatter2(bool narrow, int threads, uint32_t ntiles, const PartGeom &g, Level2Map m, Tuples in,
                                  uint32_t *cursor, Tuples out, bool p6 = false) {
-  if (p6) {                          // six-byte output tuples (see p6_store): NARROW, no payload, the production tile size
-    const size_t lds = sizeof(TileLds<true, 256>);
-    HIP_TRY(hipFuncSetAttribute((const void *)jk_scatter2<true, 256, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (p6 || m.keys32) {              // six-byte output tuples (see p6_store) and / or a receive buffer of 4-byte keys as input:
+    const size_t lds = sizeof(TileLds<true, 256>);      // NARROW, no payload, the production tile size
     m.ntiles = ntiles;
     m.xcd_order = (ntiles >= 64 && !lab::path_on("GDF_JK_NO_XCD_ORDER")) ? 1 : 0;
     const uint32_t grid = m.xcd_order ? ((ntiles + 7) / 8) * 8 : ntiles;
-    GDF_LAUNCH("jk_scatter2", (jk_scatter2<true, 256, false, true>), dim3(grid), dim3(256), lds, stream0(), g, m, in, cursor, out);
+#define JK_SC2_LAUNCH(SIX, K)                                                                                                          \
+  do {                                                                                                                                \
+    HIP_TRY(hipFuncSetAttribute((const void *)jk_scatter2<true, 256, false, SIX, K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    GDF_LAUNCH("jk_scatter2", (jk_scatter2<true, 256, false, SIX, K>), dim3(grid), dim3(256), lds, stream0(), g, m, in, cursor, out);  \
+  } while (0)
+    if (p6 && m.keys32) JK_SC2_LAUNCH(true, true); else if (p6) JK_SC2_LAUNCH(true, false); else JK_SC2_LAUNCH(false, true);
+#undef JK_SC2_LAUNCH
     HIP_CHECK_LAST();
     return GDF_SUCCESS;
   }
@@ -3626,6 +3654,7 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
   a.kbias = plan.kmin;
   if (P.p6) {                       // six-byte probe tuples: the kernels hash and compare hash remainders (ProbeArgs::p6_fb)
     a.p6_fb = g.fb;
+    a.p6_world = g.world;
     a.p6_kbias = plan.kmin;
     a.kbias = 0;
   }
@@ -4812,9 +4841,9 @@ static gdf_error fj_send(gdf_column *keys, int64_t lo, int64_t hi, int world, in
 // matching fill counters, sender-major.  Appends into sb's level-2 buffer through `cursor` ([nfine + 2]: cursors | overflow flag
 // | tile count).  Launches only; `keep` receives the scratch that must outlive the kernels.
 static gdf_error fj_level2(const uint32_t *keys, const uint32_t *fill, uint32_t nseg, uint32_t cap, const PartGeom &g, uint32_t cap2,
-                           int32_t row_base, uint32_t *cursor, Tuples out, std::deque<DevBuf> *keep) {
+                           int32_t row_base, uint32_t *cursor, Tuples out, std::deque<DevBuf> *keep, bool p6 = false) {
   const uint32_t nfine = 1u << g.fb;
-  const int sc2_threads = level2_threads(1024);
+  const int sc2_threads = 256;            // (the K32 instantiations of jk_scatter2)
   const int64_t TILE2 = (int64_t)sc2_threads * JK_SC_ITEMS;
   keep->emplace_back();
   DevBuf &d_map = keep->back();
@@ -4835,7 +4864,7 @@ static gdf_error fj_level2(const uint32_t *keys, const uint32_t *fill, uint32_t 
   m.nseg = nseg;
   m.keys32 = keys;
   const uint32_t tile_bound = (uint32_t)(((uint64_t)nseg * cap) / (uint64_t)TILE2) + nseg + 1;
-  GDF_TRY(launch_scatter2(true, sc2_threads, tile_bound, g2, m, Tuples{nullptr, nullptr, nullptr}, cursor, out));
+  GDF_TRY(launch_scatter2(true, sc2_threads, tile_bound, g2, m, Tuples{nullptr, nullptr, nullptr}, cursor, out, p6));
   return GDF_SUCCESS;
 }
 
@@ -4870,6 +4899,7 @@ static gdf_error fj_build_create(const uint32_t *recv_keys, const uint32_t *recv
   bs.plan.mode = KM_RAW_INT;
   bs.plan.narrow = 1;
   bs.plan.kmin = (uint64_t)lo;
+  bs.plan.kspan = 0x7ffffffeULL;          // narrowed keys are below 2^31 - 1 (gdf_amd_fj_send): the largest span the range can have
   bs.g = fj_geometry(world, fine_bits, coarse_bits, lo);
   const uint32_t nfine = 1u << fine_bits, nseg = ((uint32_t)world << coarse_bits) << 3;
   const double mean = (double)(expected_rows > 0 ? expected_rows : 1) / (double)nfine;
@@ -4926,10 +4956,15 @@ static gdf_error fj_probe_add(ProbeAccum *a, const uint32_t *recv_keys, const ui
     const uint64_t size2 = (uint64_t)nfine * a->app.cap2 + 16384;
     RMM_TRY(a->app.cursor.alloc(sizeof(uint32_t) * ((size_t)nfine + 2)));
     hipLaunchKernelGGL(jk_init_cursor, dim3(32), dim3(256), 0, stream0(), a->app.cursor.as<uint32_t>(), nfine, a->app.cap2);
-    RMM_TRY(a->P.w[1].alloc(sizeof(uint64_t) * size2));
+    // six-byte level-2 tuples (p6_store) as on the single-GPU main path: 2^15 partitions per rank and narrowed keys whose raw values
+    // (key + lo) cannot straddle a 2^32 boundary
+    const KeyPlan &plan = a->pb->side.plan;
+    a->P.p6 = g.fb == JK_MAX_FB && g.b3 == 0 && (plan.kmin & 0xffffffffULL) + plan.kspan < (1ULL << 32) && !lab::path_on("GDF_JK_NO_P6");
+    RMM_TRY(a->P.w[1].alloc(a->P.p6 ? 6 * size2 + 16 : sizeof(uint64_t) * size2));
     a->app.started = true;
   }
-  GDF_TRY(fj_level2(recv_keys, recv_fill, nseg, cap, g, a->app.cap2, (int32_t)position_base, a->app.cursor.as<uint32_t>(), a->P.tuples(1), &a->keep));
+  GDF_TRY(fj_level2(recv_keys, recv_fill, nseg, cap, g, a->app.cap2, (int32_t)position_base, a->app.cursor.as<uint32_t>(), a->P.tuples(1), &a->keep,
+                    a->P.p6));
   a->app.rows = position_base + buffer_elems;       // positions are numbered across the slices' receive buffers
   return GDF_SUCCESS;
 }

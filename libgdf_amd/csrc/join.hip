@@ -536,10 +536,17 @@ __device__ __forceinline__ uint32_t opaque_tid() {
 // keys: its LDS image of the build partition gets the keys replaced by their remainders when it is staged (p6_remainder), and
 // equal (partition, remainder) means equal hash means equal key.  Indices-only INNER / LEFT joins on the main (deferred,
 // two-level) path only: whoever needs the key VALUE back (carried key column) or other layouts keeps 8-byte tuples.
-// (world > 1, a fused multi-GPU join: the partition id comes from the low word L of hash * world; (owner rank, L) determine the hash --
-// hash * world = rank * 2^32 + L -- so inside a rank's partition the low 32 - fb bits of L identify the tuple just the same)
+// (world > 1, a fused multi-GPU join: the partition id comes from the low word L of hash * world = rank * 2^32 + L.  An ODD world
+// makes hash -> L a bijection of 32-bit words already.  A power-of-two world 2^k shifts the hash: L's low k bits are empty and
+// the owner rank -- the k bits shifted out -- goes there, so the remainder still determines the hash whatever ranks' keys a
+// receive buffer holds (the one-GPU emulations feed a sender's WHOLE buffer back).  Other worlds keep 8-byte tuples.)
+__host__ __device__ __forceinline__ bool p6_world_ok(uint32_t world) { return world <= 1 || (world & 1u) || !(world & (world - 1u)); }
+__device__ __forceinline__ uint32_t p6_low(uint32_t hash, uint32_t local, uint32_t world) {
+  return (world > 1 && !(world & (world - 1u))) ? __builtin_rotateleft32(hash, 31 - __clz((int)world)) : local;     // = local | mulhi(hash, world)
+}
 __device__ __forceinline__ uint32_t p6_remainder(uint32_t key32, uint64_t kbias, int fb, uint32_t world) {
-  return local_hash(hash_a((uint64_t)key32 + kbias), world) & ((1u << (32 - fb)) - 1u);
+  const uint32_t q = hash_a((uint64_t)key32 + kbias);
+  return p6_low(q, local_hash(q, world), world) & ((1u << (32 - fb)) - 1u);
 }
 __device__ __forceinline__ void p6_store(uint64_t *base, uint32_t pos, uint32_t r, uint32_t row) {
   unsigned char *at = reinterpret_cast<unsigned char *>(base) + (size_t)pos * 6u;
@@ -582,7 +589,7 @@ __device__ __forceinline__ void tile_flush(TileLds<NARROW, THREADS, PAY, ITEMS> 
       for (int u = 0; u < UP; ++u) {
         const uint32_t j = 2 * (i0 + u * THREADS);
         if (j >= total) continue;
-        const uint32_t h0 = local_hash(hash_a((ww[u].x >> 32) + g.kbias), g.world), h1 = local_hash(hash_a((ww[u].y >> 32) + g.kbias), g.world);
+        const uint32_t h0 = (uint32_t)(ww[u].x >> 32), h1 = (uint32_t)(ww[u].y >> 32);      // jk_scatter2 staged the hash word (p6_low) in place of the key
         const uint32_t bin0 = (uint32_t)((uint64_t)h0 >> (32 - g.fb)) & submask, bin1 = (uint32_t)((uint64_t)h1 >> (32 - g.fb)) & submask;
         const uint32_t dst0 = s.gbase[bin0] + j, dst1 = s.gbase[bin1] + j + 1;
         const uint32_t r0 = h0 & rmask, r1 = h1 & rmask;
@@ -610,21 +617,20 @@ __device__ __forceinline__ void tile_flush(TileLds<NARROW, THREADS, PAY, ITEMS> 
       ii[u] = (!NARROW && j < total) ? s.idx[j] : 0;
       pp[u] = (PAY && j < total) ? s.pay[j] : 0;
     }
-    uint32_t dst[U], rem[U];
+    uint32_t dst[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const uint32_t h = local_hash(hash_a(tup_key<NARROW>(ww[u]) + g.kbias), g.world);
+      const uint32_t q = hash_a(tup_key<NARROW>(ww[u]) + g.kbias);
+      const uint32_t h = local_hash(q, g.world);
       const uint32_t f = (uint32_t)((uint64_t)h >> (32 - g.fb));
       const uint32_t bin = LEVEL1 ? (f >> g.b2) : (f & submask);
       dst[u] = s.gbase[bin] + j0 + u * THREADS;
-      rem[u] = h & ((1u << (32 - g.fb)) - 1u);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (LAB_BITS(g.dbg) & 4) dst[u] &= 0xffffu;        // experiment: all stores land in a 512 KiB window
       if (j0 + u * THREADS < total && !(LAB_BITS(g.dbg) & 1)) {
-        if (P6) p6_store(out.w, dst[u], rem[u], (uint32_t)ww[u]);
-        else if (LAB_BITS(g.dbg) & 16) __builtin_nontemporal_store(ww[u], out.w + dst[u]);      // experiment: streaming stores (level 2)
+        if (LAB_BITS(g.dbg) & 16) __builtin_nontemporal_store(ww[u], out.w + dst[u]);      // experiment: streaming stores (level 2)
         else out.w[dst[u]] = ww[u];
         if (!NARROW) out.idx[dst[u]] = ii[u];
         if (PAY) out.pay[dst[u]] = pp[u];
@@ -1087,8 +1093,12 @@ __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, 
 #pragma unroll
   for (int k = 0; k < ITEMS; ++k) {
     const uint32_t i = begin + k * THREADS + threadIdx.x;
-    const uint32_t bin = (uint32_t)((uint64_t)local_hash(hash_a(tup_key<NARROW>(w[k]) + g.kbias), g.world) >> (32 - g.fb)) & submask;
+    const uint32_t q = hash_a(tup_key<NARROW>(w[k]) + g.kbias), lh = local_hash(q, g.world);
+    const uint32_t bin = (uint32_t)((uint64_t)lh >> (32 - g.fb)) & submask;
     binrank[k] = ((K32 && quads) || i < end) ? bin : 256u;     // (quads: a full tile, every tuple is live whatever order they were fetched in)
+    // six-byte tuples leave as (hash remainder, row): the key is not needed again, the LDS tile holds the hash word and the flush
+    // does not hash a second time (two quarter-rate multiplies per tuple: the kernel's ALU work is not hidden at 4 waves per SIMD)
+    if constexpr (P6) w[k] = ((uint64_t)p6_low(q, lh, g.world) << 32) | (uint32_t)w[k];
   }
 #pragma unroll
   for (int k = 0; k < ITEMS; ++k)            // sixteen atomics in flight, one wait
@@ -2725,16 +2735,18 @@ static gdf_error launch_scatter2_t(uint32_t ntiles, const PartGeom &g, Level2Map
 static gdf_error launch_scatter2(bool narrow, int threads, uint32_t ntiles, const PartGeom &g, Level2Map m, Tuples in,
                                  uint32_t *cursor, Tuples out, bool p6 = false) {
   if (p6 || m.keys32) {              // six-byte output tuples (see p6_store) and / or a receive buffer of 4-byte keys as input:
-    const size_t lds = sizeof(TileLds<true, 256>);      // NARROW, no payload, the production tile size
-    m.ntiles = ntiles;
+    m.ntiles = ntiles;                 // NARROW, no payload, the production tile size
     m.xcd_order = (ntiles >= 64 && !lab::path_on("GDF_JK_NO_XCD_ORDER")) ? 1 : 0;
     const uint32_t grid = m.xcd_order ? ((ntiles + 7) / 8) * 8 : ntiles;
-#define JK_SC2_LAUNCH(SIX, K)                                                                                                          \
+#define JK_SC2_LAUNCH(T, SIX, K)                                                                                                       \
   do {                                                                                                                                \
-    HIP_TRY(hipFuncSetAttribute((const void *)jk_scatter2<true, 256, false, SIX, K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    GDF_LAUNCH("jk_scatter2", (jk_scatter2<true, 256, false, SIX, K>), dim3(grid), dim3(256), lds, stream0(), g, m, in, cursor, out);  \
+    const size_t lds = sizeof(TileLds<true, T>);                                                                                      \
+    HIP_TRY(hipFuncSetAttribute((const void *)jk_scatter2<true, T, false, SIX, K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    GDF_LAUNCH("jk_scatter2", (jk_scatter2<true, T, false, SIX, K>), dim3(grid), dim3(T), lds, stream0(), g, m, in, cursor, out);      \
   } while (0)
-    if (p6 && m.keys32) JK_SC2_LAUNCH(true, true); else if (p6) JK_SC2_LAUNCH(true, false); else JK_SC2_LAUNCH(false, true);
+    if (p6 && m.keys32) JK_SC2_LAUNCH(256, true, true);
+    else if (p6) JK_SC2_LAUNCH(256, true, false);
+    else JK_SC2_LAUNCH(256, false, true);
 #undef JK_SC2_LAUNCH
     HIP_CHECK_LAST();
     return GDF_SUCCESS;
@@ -4843,7 +4855,9 @@ static gdf_error fj_send(gdf_column *keys, int64_t lo, int64_t hi, int world, in
 static gdf_error fj_level2(const uint32_t *keys, const uint32_t *fill, uint32_t nseg, uint32_t cap, const PartGeom &g, uint32_t cap2,
                            int32_t row_base, uint32_t *cursor, Tuples out, std::deque<DevBuf> *keep, bool p6 = false) {
   const uint32_t nfine = 1u << g.fb;
-  const int sc2_threads = 256;            // (the K32 instantiations of jk_scatter2)
+  // (world x coarse partitions = 1024 leaves 8 bits to level 2: 256 bins per 4096-tuple tile, (tile, bin) runs of 16 tuples.  8192-tuple
+  // tiles -- 512 threads, runs of 32 as on the single-GPU path -- were slower: 4.15 vs 3.52 ms per 1e9 keys, profiles/r3_o_fused_level2.txt)
+  const int sc2_threads = 256;
   const int64_t TILE2 = (int64_t)sc2_threads * JK_SC_ITEMS;
   keep->emplace_back();
   DevBuf &d_map = keep->back();
@@ -4956,10 +4970,11 @@ static gdf_error fj_probe_add(ProbeAccum *a, const uint32_t *recv_keys, const ui
     const uint64_t size2 = (uint64_t)nfine * a->app.cap2 + 16384;
     RMM_TRY(a->app.cursor.alloc(sizeof(uint32_t) * ((size_t)nfine + 2)));
     hipLaunchKernelGGL(jk_init_cursor, dim3(32), dim3(256), 0, stream0(), a->app.cursor.as<uint32_t>(), nfine, a->app.cap2);
-    // six-byte level-2 tuples (p6_store) as on the single-GPU main path: 2^15 partitions per rank and narrowed keys whose raw values
-    // (key + lo) cannot straddle a 2^32 boundary
+    // six-byte level-2 tuples (p6_store) as on the single-GPU main path: 2^15 partitions per rank, narrowed keys whose raw values
+    // (key + lo) cannot straddle a 2^32 boundary, and a world whose rank remap keeps the remainder injective (p6_low)
     const KeyPlan &plan = a->pb->side.plan;
-    a->P.p6 = g.fb == JK_MAX_FB && g.b3 == 0 && (plan.kmin & 0xffffffffULL) + plan.kspan < (1ULL << 32) && !lab::path_on("GDF_JK_NO_P6");
+    a->P.p6 = g.fb == JK_MAX_FB && g.b3 == 0 && (plan.kmin & 0xffffffffULL) + plan.kspan < (1ULL << 32) && p6_world_ok(g.world) &&
+              !lab::path_on("GDF_JK_NO_P6");
     RMM_TRY(a->P.w[1].alloc(a->P.p6 ? 6 * size2 + 16 : sizeof(uint64_t) * size2));
     a->app.started = true;
   }

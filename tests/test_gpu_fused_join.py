@@ -70,6 +70,34 @@ def test_fused_join_equals_plain_join(gdf, world, dtype):
     np.testing.assert_array_equal(got[np.lexsort(got.T[::-1])], exp[np.lexsort(exp.T[::-1])])
 
 
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 6, 8])
+@pytest.mark.parametrize("dtype", [np.int64, np.int32])
+@pytest.mark.parametrize("keys", ["unique", "twice"])
+def test_fused_join_on_six_byte_tuples(gdf, world, dtype, keys, force_path):
+    """The receiver's level 2 at the headline geometry (2^15 fine partitions per rank, forced on a small relation): six-byte
+    tuples of (hash remainder, position), csrc/join.hip p6_store.  The fed-back buffer holds the keys of EVERY rank, so the
+    remainder has to keep what the rank remap shifts out of the hash (p6_low): an odd world is a bijection, a power of two
+    stores the owner in the emptied low bits, world = 6 keeps eight-byte tuples.  Against the oracle and against the eight-byte
+    path (GDF_JK_NO_P6); repeated build keys take the multimap kernels on the same tuples."""
+    rs = np.random.RandomState(300 + world)
+    nb, npr = 150_000, 1_200_000
+    force_path("GDF_JK_FORCE_FB", "15")
+    base = (5 << 34) + 99 if dtype == np.int64 else -70_000
+    build = (rs.permutation(nb * 2)[:nb] + base).astype(dtype)
+    if keys == "twice":
+        build[: nb // 2] = build[nb // 2:]
+    probe = (rs.randint(-1000, nb * 2 + 1000, size=npr) + base).astype(dtype)
+    el, er = oracle.join([probe], [build], "inner")
+    exp = np.stack([el, er], axis=1)
+    exp = exp[np.lexsort(exp.T[::-1])]
+    for eight_bytes in (False, True):
+        force_path("GDF_JK_NO_P6", "1" if eight_bytes else None)
+        gp, gb = _fused_self_join(gdf, probe, build, world, slices=2)
+        got = np.stack([gp, gb], axis=1)
+        np.testing.assert_array_equal(got[np.lexsort(got.T[::-1])], exp)
+    force_path("GDF_JK_NO_P6", None)
+
+
 def test_fused_join_duplicate_build_keys_and_large(gdf):
     rs = np.random.RandomState(7)
     nb, npr = 3_000_000, 9_000_000

@@ -348,7 +348,20 @@ struct PartGeom {
   // LOCAL partition id is taken from the low word of hash_a * world (uniform inside a rank).  0 / 1: single GPU, the id is
   // hash_a's own top bits.
   uint32_t world;
+#ifdef GDF_AMD_LAB
+  unsigned long long *lab_clock;     // LAB: jk_scatter1 stores the cycles the first / last wave of a workgroup spent in each phase, [chunk][2][8] (knob GDF_JK_CLOCK)
+#endif
 };
+#ifdef GDF_AMD_LAB
+#define LAB_PHASE(i)                                                          \
+  if (g.lab_clock) {                                                          \
+    const unsigned long long lab_now = clock64();                             \
+    lab_ph[i] += (uint32_t)(lab_now - lab_prev);                              \
+    lab_prev = lab_now;                                                       \
+  }
+#else
+#define LAB_PHASE(i)
+#endif
 
 // NARROW: w[i] = key32 << 32 | row, idx unused.  WIDE: w[i] = key64, idx[i] = row.
 // pay (NARROW probe sides of a join that materialises result_cols, see PayCarry): pay[i] = the row's PAYLOAD word -- the
@@ -733,6 +746,10 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
     okmask &= validbits;
   };
   if (FAST) consume(begin);
+#ifdef GDF_AMD_LAB
+  uint32_t lab_ph[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long lab_prev = g.lab_clock ? clock64() : 0;
+#endif
   for (uint32_t tile = begin; tile < end; tile += JK_TILE) {        // end + JK_TILE < 2^32
     if (!FAST) {
       uint64_t k64[JK_SC_ITEMS];
@@ -756,6 +773,7 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
     for (int k = 0; k < JK_SC_ITEMS; ++k)      // sixteen atomics in flight, one wait
       binrank[k] = (binrank[k] << 16) | atomicAdd(&s.hist[binrank[k]], 1u);
     block_sync();
+    LAB_PHASE(0)       // hash + rank
     uint32_t claimed = 0;
     {
       const uint32_t tid = opaque_tid();
@@ -770,6 +788,7 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
       block_sync();
       claimed = base;
     }
+    LAB_PHASE(1)       // claim issue + scan
     const uint32_t wtid = opaque_tid();
 #pragma unroll
     for (int h = 0; h < JK_SC_ITEMS; h += 8) {           // eight at a time: reads of start[] first (no branch), then the writes
@@ -808,8 +827,10 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
     }
     const bool more = tile + JK_TILE < end;
     __builtin_amdgcn_sched_barrier(0);         // keep the prefetch BELOW the regroup: hoisted, its 32 registers spill
+    LAB_PHASE(2)       // regroup (LDS writes issued) + claim answer
     if (FAST && more) prefetch(tile + JK_TILE);
     block_sync();
+    LAB_PHASE(3)       // prefetch issue + barrier (the regroup's LDS writes land here)
     if (g.cap1 && s.total_abort) return;       // workgroup-uniform (read after the barrier)
     // flush: JK_SC_ITEMS unconditional stores per thread (dead slots -> this thread's dump slot), four at a time to
     // keep the register count under the 128 a 1024-thread workgroup gets (the prefetched keys stay in registers)
@@ -844,9 +865,15 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
     }
     // the stores above stay in flight: this waits for the LOADS only.  Unconditional: keeping the old keys alive for the
     // `no more tiles` case would cost 16 registers across the flush
+    LAB_PHASE(4)       // flush: LDS reads + store issue
     if (FAST) consume(tile + JK_TILE);
     __builtin_amdgcn_sched_barrier(0);         // narrow the keys HERE: sunk into the next ranking, the 64-bit words stay live
+    LAB_PHASE(5)       // wait for the next tile's keys
   }
+#ifdef GDF_AMD_LAB
+  if (g.lab_clock && (threadIdx.x == 0 || threadIdx.x == THREADS - 64))
+    for (int i = 0; i < 6; ++i) g.lab_clock[((size_t)blockIdx.x * 2 + (threadIdx.x ? 1 : 0)) * 8 + i] = lab_ph[i];
+#endif
 }
 
 // 2b. level-1 scatter of a probe side that CARRIES A PAYLOAD (Tuples::pay, PayCarry): one FAST key column without a mask,
@@ -2986,8 +3013,31 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
   RMM_TRY(sb->w[0].alloc(sizeof(uint64_t) * size1));
   if (!narrow) RMM_TRY(sb->idx[0].alloc(sizeof(int32_t) * size1));
   if (pay) RMM_TRY(sb->pay[0].alloc(sizeof(uint64_t) * size1));
+#ifdef GDF_AMD_LAB
+  DevBuf lab_clk;
+  if (lab::knob_on("GDF_JK_CLOCK") && !pay) {
+    RMM_TRY(lab_clk.alloc(sizeof(unsigned long long) * 16 * (size_t)g.nchunks));
+    HIP_TRY(hipMemsetAsync(lab_clk.p, 0, sizeof(unsigned long long) * 16 * (size_t)g.nchunks, stream0()));
+    g.lab_clock = lab_clk.as<unsigned long long>();
+  }
+#endif
   if (pay) GDF_TRY(launch_scatter1_pay(fast, pmode, t, plan, g, nullptr, *pay, sb->tuples(0)));
   else GDF_TRY(launch_scatter1(fast, narrow, sc_threads, t, plan, g, nullptr, sb->tuples(0)));
+#ifdef GDF_AMD_LAB
+  if (g.lab_clock) {
+    std::vector<unsigned long long> h(16 * (size_t)g.nchunks);
+    HIP_TRY(read_back(h.data(), lab_clk.p, sizeof(unsigned long long) * h.size()));
+    static const char *names[6] = {"hash + rank + barrier", "claim issue + scan + barrier", "regroup issue + claim answer", "prefetch issue + barrier",
+                                   "flush (LDS reads, store issue)", "wait for the next tile's keys"};
+    for (int wv = 0; wv < 2; ++wv) {
+      double sum[6] = {0, 0, 0, 0, 0, 0}, all = 0;
+      for (int c = 0; c < g.nchunks; ++c) for (int i = 0; i < 6; ++i) { sum[i] += (double)h[((size_t)c * 2 + wv) * 8 + i]; all += (double)h[((size_t)c * 2 + wv) * 8 + i]; }
+      fprintf(stderr, "jk_scatter1 phase clock, %s wave of every workgroup (%d chunks, %.0f cycles per chunk):\n", wv ? "last" : "first", g.nchunks, all / g.nchunks);
+      for (int i = 0; i < 6; ++i) fprintf(stderr, "  %-34s %5.1f %%\n", names[i], 100.0 * sum[i] / all);
+    }
+    g.lab_clock = nullptr;
+  }
+#endif
   if (defer && !app && g.b2 > 0) {
     // DEFERRED: the level-2 map and the fill cursors are made on the device, nothing is read back here; the overflow flags
     // of both levels are looked at once, with the work units (jk_make_units / probe_partitioned)

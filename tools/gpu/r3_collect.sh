@@ -23,5 +23,8 @@ python tools/bench_c5.py 2>/dev/null | tail -1 > $O/bench_c5.json
 python tools/bench_c5.py --null-keys 0.01 2>/dev/null | tail -1 > $O/bench_c5_nullkeys.json
 python tools/bench_shapes.py > $O/bench_shapes.jsonl 2>/dev/null
 python tools/bench_ops.py > $O/bench_ops.jsonl 2>/dev/null
+python tools/bench_ops.py --rows 1000000000 --ops partition,scan,filter > $O/bench_ops_1e9.jsonl 2>/dev/null
+python tools/sim_c4_fused.py 2>/dev/null | tail -4 > $O/sim_c4_fused.txt
+python bench.py --force-distributed --strategy fused --steps 5 --warmup 2 --probe-rows 1000000000 --build-rows 125000000 --cpu-sample 0 --pandas-sample 0 2>/dev/null | grep '^{' | tail -1 > $O/bench_force_distributed_fused.json
 rm -rf $O/trace/*/*.db; find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -size +8M -delete; find $O -name "*.db" -delete
 cut -c1-900 $O/bench.json; cat $O/bench_spread.jsonl; cut -c1-300 $O/bench_c5.json; cat $O/kernel_stats.md | head -30; du -sh $O

@@ -1675,7 +1675,16 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_fast(ProbeArgs a) {
   // raw key = stored key + kbias; fold = lo ^ hi * C (key_fold).  NARROW keys are 32 bits, WIDE keys 64.
   using Key = typename std::conditional<NARROW, uint32_t, uint64_t>::type;
   auto fold_of = [&](Key key) -> uint32_t {
-    if constexpr (NARROW) {
+    if constexpr (P6) {
+      // six-byte tuples: the "key" is a 17-bit hash remainder.  Two multiplicative slot hashes of such a small DENSE set (3 % of the
+      // 2^17 values) share their bad differences -- 8 to 12 % of the partitions needed a second cuckoo attempt, and at 3800 keys per
+      // partition a few units per join failed all four and went to the general kernel alone (0.13 ms of tail).  Two xor-shifts
+      // spread the remainder over the word first: 0 failures in 600 simulated partitions.
+      uint32_t x = (uint32_t)key;
+      x ^= x << 13;
+      x ^= x >> 7;
+      return x;
+    } else if constexpr (NARROW) {
       const uint32_t lo = key + kb_lo;
       const uint32_t hi = kb_hi + (lo < key ? 1u : 0u);
       return lo ^ (hi * 0x9e3779b1u);
@@ -1895,7 +1904,16 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_count_fast(ProbeArgs a) {
   // raw key = stored key + kbias; fold = lo ^ hi * C (key_fold).  NARROW keys are 32 bits, WIDE keys 64.
   using Key = typename std::conditional<NARROW, uint32_t, uint64_t>::type;
   auto fold_of = [&](Key key) -> uint32_t {
-    if constexpr (NARROW) {
+    if constexpr (P6) {
+      // six-byte tuples: the "key" is a 17-bit hash remainder.  Two multiplicative slot hashes of such a small DENSE set (3 % of the
+      // 2^17 values) share their bad differences -- 8 to 12 % of the partitions needed a second cuckoo attempt, and at 3800 keys per
+      // partition a few units per join failed all four and went to the general kernel alone (0.13 ms of tail).  Two xor-shifts
+      // spread the remainder over the word first: 0 failures in 600 simulated partitions.
+      uint32_t x = (uint32_t)key;
+      x ^= x << 13;
+      x ^= x >> 7;
+      return x;
+    } else if constexpr (NARROW) {
       const uint32_t lo = key + kb_lo;
       const uint32_t hi = kb_hi + (lo < key ? 1u : 0u);
       return lo ^ (hi * 0x9e3779b1u);
@@ -2400,7 +2418,7 @@ __global__ __launch_bounds__(256) void jk_hole_counts(const Unit *__restrict__ u
 }
 __global__ __launch_bounds__(256) void jk_fill_holes(const uint64_t *__restrict__ slot_off, const uint32_t *__restrict__ unit_pairs, uint32_t nunits,
                                                      uint64_t N, const uint64_t *__restrict__ hole_pre, const uint64_t *__restrict__ tail_pre,
-                                                     int32_t *__restrict__ op, int32_t *__restrict__ ob, PayMove pm) {
+                                                     int32_t *op, int32_t *ob, PayMove pm) {
   __shared__ uint32_t range[2];
   const uint32_t u = blockIdx.x;
   const uint64_t g0 = tail_pre[u];
@@ -2418,15 +2436,19 @@ __global__ __launch_bounds__(256) void jk_fill_holes(const uint64_t *__restrict_
   if (threadIdx.x < 2) range[threadIdx.x] = unit_of(threadIdx.x ? g0 + cnt - 1 : g0, 0, nunits - 1);
   __syncthreads();
   const uint32_t v0 = range[0], v1 = range[1];
-  for (uint32_t i = threadIdx.x; i < cnt; i += 256) {
-    const uint64_t g = g0 + i;
-    const uint32_t v = unit_of(g, v0, v1);
-    const uint64_t dst = slot_off[v] + unit_pairs[v] + (g - hole_pre[v]), src = src0 + i;
-    op[dst] = op[src];
-    ob[dst] = ob[src];
+  // the tail is a contiguous range of pairs and every hole a contiguous range of slots: one plain copy per (tail, hole) overlap --
+  // a handful per unit -- instead of a search per pair (1.04 -> 0.6 ms at 80 % hits: the per-pair version was six dependent loads deep)
+  for (uint32_t v = v0; v <= v1; ++v) {                 // workgroup-uniform
+    const uint64_t hb = hole_pre[v], he = hole_pre[v + 1];
+    const uint64_t ga = g0 > hb ? g0 : hb, gb = g0 + cnt < he ? g0 + cnt : he;
+    if (ga >= gb) continue;
+    const uint64_t to = slot_off[v] + unit_pairs[v] + (ga - hb), from = src0 + (ga - g0);
+    const uint32_t n = (uint32_t)(gb - ga);
+    compact_column<int32_t>(op, op, from, to, n);
+    compact_column<int32_t>(ob, ob, from, to, n);
     for (int c = 0; c < pm.ncols; ++c) {
-      if (pm.width[c] == 8) ((uint64_t *)pm.dst[c])[dst] = ((const uint64_t *)pm.src[c])[src];
-      else ((uint32_t *)pm.dst[c])[dst] = ((const uint32_t *)pm.src[c])[src];
+      if (pm.width[c] == 8) compact_column<uint64_t>(pm.src[c], pm.dst[c], from, to, n);
+      else compact_column<uint32_t>(pm.src[c], pm.dst[c], from, to, n);
     }
   }
 }

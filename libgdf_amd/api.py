@@ -158,7 +158,7 @@ def hash_partition(cols, cols_to_hash, num_partitions, hash_func=GDF_HASH_MURMUR
     offsets = (C.c_int * num_partitions)()
     libgdf.gdf_hash_partition(len(cols), column_array(cols), _int_array(cols_to_hash), len(cols_to_hash),
                               num_partitions, column_array(outs), offsets, hash_func)
-    return outs, list(offsets)
+    return outs, np.frombuffer(offsets, dtype=np.int32).tolist()       # (list(ctypes array) walks 12000 offsets in Python: 0.4 ms)
 
 
 def shuffle_partition(keys: Column, num_partitions, row_base=0, narrow=None):

@@ -132,6 +132,31 @@ def test_hash_partition_two_levels(gdf, nparts, keys, force_path):
     assert offsets1 == offsets
 
 
+@pytest.mark.parametrize("nparts", [1025, 12000, 16384])
+@pytest.mark.parametrize("piece_rows", [None, 3000, 150])
+def test_hash_partition_two_levels_pieces_and_skew(gdf, nparts, piece_rows, force_path):
+    """Level B walks a super-partition in PIECES -- the rows it got from a group of consecutive level-A chunks (csrc/hashing.hip
+    PartLevel::pieces; ~49152 rows at full size, GDF_HP_PIECE brings the target down so that 2e6 rows make dozens of pieces per
+    super-partition, down to one level-A chunk per piece).  A third of the rows sit on ONE key: one super-partition of ~700 000
+    rows next to short ones.  Offsets and per-partition row multisets against the oracle."""
+    n = 2_000_003
+    if piece_rows is not None:
+        force_path("GDF_HP_PIECE", str(piece_rows))
+    rs = np.random.RandomState(nparts % 977)
+    k0 = rs.randint(-2**40, 2**40, size=n).astype(np.int64)
+    k0[rs.rand(n) < 0.33] = 123456789
+    v = rs.randint(0, 2**31, size=n).astype(np.int32)
+    outs, offsets = gdf.api.hash_partition([_col(gdf, k0), _col(gdf, v)], [0], nparts)
+    perm, exp_off, pid = oracle.hash_partition([k0, v], [0], nparts)
+    assert offsets == [int(x) for x in exp_off]
+    g0, g1 = outs[0].to_numpy(), outs[1].to_numpy()
+    got_pid = oracle.partition_ids([g0], nparts)
+    assert np.array_equal(got_pid, np.repeat(np.arange(nparts), np.diff(np.array(list(exp_off) + [n]))))
+    exp_rows = np.stack([pid[perm].astype(np.int64), k0[perm], v[perm].astype(np.int64)], axis=1)
+    got_rows = np.stack([got_pid.astype(np.int64), g0, g1.astype(np.int64)], axis=1)
+    np.testing.assert_array_equal(exp_rows[np.lexsort(exp_rows.T[::-1])], got_rows[np.lexsort(got_rows.T[::-1])])
+
+
 def test_hash_partition_errors(gdf):
     from libgdf_amd import GDFError
     a = _col(gdf, gen_rand(np.int32, 100))

@@ -1409,7 +1409,8 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
     if (!NARROW) l.bi[i] = a.build.idx[u.build_begin + i];
   }
   for (uint32_t i = threadIdx.x; i < 2 * H; i += JK_PROBE_THREADS) l.T[i] = JK_NOPOS;
-  if (threadIdx.x == 0) { *l.unit_cursor = WRITE ? a.counts[uid] : 0ull; *l.cuckoo_failed = 0; }
+  __shared__ uint32_t dup_seen;          // the multimap rebuild met a key a second time
+  if (threadIdx.x == 0) { *l.unit_cursor = WRITE ? a.counts[uid] : 0ull; *l.cuckoo_failed = 0; dup_seen = 0; }
   block_sync();
 
   // ---- cuckoo build: exchange positions until an empty slot absorbs the chain ----
@@ -1428,7 +1429,6 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
   }
   block_sync();
   const bool cuckoo = *l.cuckoo_failed == 0 && !(LAB_BITS(a.dbg) & 8);
-  if (!cuckoo && !WRITE && a.opt_state && threadIdx.x == 0) atomicAdd(&a.opt_state[3], 1ull);   // sample pass: units with repeated build keys
   if (!cuckoo) {
     // ---- multimap rebuild over the same 2*H slots: open addressing over the DISTINCT keys, every key's tuples chained
     // behind the one that took the slot (next[]).  Round 1 gave every tuple a slot of its own: a key that occurs four times
@@ -1448,12 +1448,18 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
         if (q == JK_NOPOS) break;                                   // p is the head of its key
         if (tup_key<NARROW>(l.bw[q]) == kp) {                        // same key: p goes right behind the head
           l.next[p] = atomicExch(&l.next[q], p);
+          dup_seen = 1;
           break;
         }
         slot = (slot + 1) & mask;
       }
     }
     block_sync();
+    // sample pass: units whose build keys REPEAT.  A cuckoo build of distinct keys also fails now and then -- at 3800 keys in 2 x 4096
+    // slots (a 1.25e8-row build relation) one in four single attempts runs into a cycle; counted as "repeated keys", such joins
+    // crossed the quarter-of-the-sample line in a third of the calls and took the general kernel for every unit (10.6 instead of
+    // 2.9 ms, profiles/r3_zh_*).  The rebuild knows: it met a key twice, or it did not.
+    if (!WRITE && a.opt_state && threadIdx.x == 0 && dup_seen) atomicAdd(&a.opt_state[3], 1ull);
   }
 
   if (LAB_BITS(a.dbg) & 128) return;      // experiment: build phase only

@@ -430,6 +430,8 @@ __global__ __launch_bounds__(JK_HIST_THREADS) void jk_hist(KeyTable t, KeyPlan p
                                                            uint32_t *__restrict__ fine_hist,
                                                            uint32_t *__restrict__ H1, long long *minmax) {
   long long lo = LLONG_MAX, hi = LLONG_MIN;
+  __shared__ long long wg_mm[2];          // this workgroup's key range; minmax[2 b], minmax[2 b + 1] get it (lo > hi: no key), the host merges
+  if (threadIdx.x == 0) { wg_mm[0] = LLONG_MAX; wg_mm[1] = LLONG_MIN; }
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   uint32_t *fine = lds;
   uint32_t *coarse = lds + (1u << g.fb);
@@ -469,7 +471,9 @@ __global__ __launch_bounds__(JK_HIST_THREADS) void jk_hist(KeyTable t, KeyPlan p
       lo = l2 < lo ? l2 : lo;
       hi = h2 > hi ? h2 : hi;
     }
-    if (lane_id() == 0 && lo <= hi) { atomicMin(&minmax[0], lo); atomicMax(&minmax[1], hi); }
+    if (lane_id() == 0 && lo <= hi) { atomicMin(&wg_mm[0], lo); atomicMax(&wg_mm[1], hi); }
+    block_sync();
+    if (threadIdx.x == 0) { minmax[2 * blockIdx.x] = wg_mm[0]; minmax[2 * blockIdx.x + 1] = wg_mm[1]; }
   }
 }
 
@@ -2856,7 +2860,7 @@ static int level2_threads(int sc_threads) {
 
 // pay (may be null) + pmode: the relation carries a payload word per row (PayCarry); NARROW tuples and a FAST key column only
 static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, SideBufs *sb, bool decide_narrow, const PaySrc *pay = nullptr,
-                                int pmode = 0) {
+                                int pmode = 0, bool device_index = false) {
   const int64_t n = t.nrows;
   bool narrow = plan.narrow != 0;
   // Chunks are SMALL (a few tiles) and processed in blockIdx order, so that the workgroups resident at
@@ -2872,8 +2876,11 @@ static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, Si
   if (g.nchunks == 0) g.nchunks = 1;
   const uint32_t nfine = 1u << g.fb, ncoarse = 1u << g.b1;
 
+  // the fine histogram and, behind it, one (min, max) pair per workgroup of jk_hist: one buffer, one read-back
+  const int hist_grid = g.nchunks < NUM_CU ? g.nchunks : NUM_CU;
+  const size_t hist_bytes = sizeof(uint32_t) * nfine + sizeof(long long) * 2 * (size_t)hist_grid;
   DevBuf fine_hist, H1;
-  RMM_TRY(fine_hist.alloc(sizeof(uint32_t) * nfine));
+  RMM_TRY(fine_hist.alloc(hist_bytes));
   RMM_TRY(H1.alloc(sizeof(uint32_t) * (size_t)ncoarse * g.nchunks));
   HIP_TRY(hipMemsetAsync(fine_hist.p, 0, sizeof(uint32_t) * nfine, stream0()));
   const size_t hist_lds = sizeof(uint32_t) * (nfine + ncoarse);
@@ -2882,15 +2889,9 @@ static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, Si
   HIP_TRY(hipFuncSetAttribute((const void *)jk_hist<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_lds));
   HIP_TRY(hipFuncSetAttribute((const void *)jk_hist<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_lds));
   HIP_TRY(hipFuncSetAttribute((const void *)jk_hist<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_lds));
-  const int hist_grid = g.nchunks < NUM_CU ? g.nchunks : NUM_CU;
-  DevBuf mm;
   long long *d_mm = nullptr;
-  if (decide_narrow && !lab::knob_on("GDF_JK_WIDE")) {       // GDF_JK_WIDE: experiment switch, force 12-byte tuples
-    RMM_TRY(mm.alloc(sizeof(long long) * 2));
-    const long long init[2] = {LLONG_MAX, LLONG_MIN};
-    HIP_TRY(hipMemcpyAsync(mm.p, init, sizeof(init), hipMemcpyHostToDevice, stream0()));
-    d_mm = mm.as<long long>();
-  }
+  if (decide_narrow && !lab::knob_on("GDF_JK_WIDE"))         // GDF_JK_WIDE: experiment switch, force 12-byte tuples
+    d_mm = reinterpret_cast<long long *>(fine_hist.as<uint32_t>() + nfine);
   if (fast == 8)
     GDF_LAUNCH("jk_hist", jk_hist<8>, dim3(hist_grid), dim3(JK_HIST_THREADS), hist_lds, stream0(), t, plan, g,
                fine_hist.as<uint32_t>(), H1.as<uint32_t>(), d_mm);
@@ -2903,18 +2904,30 @@ static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, Si
   HIP_CHECK_LAST();
   GDF_TRY(scan_u32(H1.as<uint32_t>(), H1.as<uint32_t>(), (size_t)ncoarse * g.nchunks, false));
 
-  std::vector<uint32_t> fh(nfine);
-  HIP_TRY(read_back(fh.data(), fine_hist.p, sizeof(uint32_t) * nfine));
+  std::vector<uint32_t> fh(hist_bytes / sizeof(uint32_t));
+  HIP_TRY(read_back(fh.data(), fine_hist.p, d_mm ? hist_bytes : sizeof(uint32_t) * nfine));
+  long long h[2] = {LLONG_MAX, LLONG_MIN};
+  if (d_mm) {
+    const long long *wg = reinterpret_cast<const long long *>(fh.data() + nfine);
+    for (int b = 0; b < hist_grid; ++b) { h[0] = std::min(h[0], wg[2 * b]); h[1] = std::max(h[1], wg[2 * b + 1]); }
+  }
+  fh.resize(nfine);
   sb->fine_off.assign(nfine + 1, 0);
   for (uint32_t f = 0; f < nfine; ++f) sb->fine_off[f + 1] = sb->fine_off[f] + fh[f];
   sb->joinable = sb->fine_off[nfine];
   sb->fine_begin.assign(sb->fine_off.begin(), sb->fine_off.begin() + nfine);
   sb->fine_cnt = fh;
   sb->speculative = false;
+  if (device_index) {
+    // a BUILD side: jk_make_units wants the partition index on the device -- the histogram is there already and its exclusive scan is
+    // the partitions' first tuples; uploading the two host vectors cost 0.1 ms of idle GPU behind the build side's last kernel
+    RMM_TRY(sb->d_begin.alloc(sizeof(uint32_t) * nfine));
+    GDF_TRY(scan_u32(fine_hist.as<uint32_t>(), sb->d_begin.as<uint32_t>(), nfine, false));
+    sb->d_cnt.reset();
+    sb->d_cnt.p = fine_hist.release();
+  }
   const size_t cap = sb->joinable ? sb->joinable : 1;
   if (d_mm) {
-    long long h[2];
-    HIP_TRY(read_back(h, d_mm, sizeof(h)));
     if (h[0] <= h[1] && (uint64_t)h[1] - (uint64_t)h[0] < 0xffffffffULL) {
       plan.narrow = 1;
       plan.kmin = (uint64_t)h[0];
@@ -2941,28 +2954,37 @@ static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, Si
   if (!narrow) RMM_TRY(sb->idx[0].alloc(sizeof(int32_t) * (cap + 2 + 1024)));
   if (pay) RMM_TRY(sb->pay[0].alloc(sizeof(uint64_t) * (cap + 2 + 1024)));
   const Tuples t0 = sb->tuples(0);
-  if (pay) GDF_TRY(launch_scatter1_pay(fast, pmode, t, plan, g, H1.as<uint32_t>(), *pay, t0));
-  else GDF_TRY(launch_scatter1(fast, narrow, sc_threads, t, plan, g, H1.as<uint32_t>(), t0));
-  HIP_CHECK_LAST();
-  sb->final_buf = 0;
-  if (g.b2 > 0 && sb->joinable > 0) {
-    // level 2
-    std::vector<uint32_t> coarse_off(ncoarse + 1), tile_prefix(ncoarse + 1);
+  // level 2's map and cursors are made and sent BEFORE level 1 is launched: the host has everything, and behind the level-1 kernel
+  // every staged upload was a stall between the two levels
+  const bool level2 = g.b2 > 0 && sb->joinable > 0;
+  DevBuf d_coarse, d_tiles, cursor;
+  uint32_t ntiles = 0;
+  std::vector<uint32_t> coarse_off, tile_prefix;
+  if (level2) {
+    coarse_off.resize(ncoarse + 1);
+    tile_prefix.resize(ncoarse + 1);
     for (uint32_t c = 0; c <= ncoarse; ++c) coarse_off[c] = sb->fine_off[(size_t)c << g.b2];
     tile_prefix[0] = 0;
     for (uint32_t c = 0; c < ncoarse; ++c)
       tile_prefix[c + 1] = tile_prefix[c] + (coarse_off[c + 1] - coarse_off[c] + JK_TILE2 - 1) / JK_TILE2;
-    const uint32_t ntiles = tile_prefix[ncoarse];
-    DevBuf d_coarse, d_tiles, cursor;
+    ntiles = tile_prefix[ncoarse];
     RMM_TRY(d_coarse.alloc(sizeof(uint32_t) * (ncoarse + 1)));
     RMM_TRY(d_tiles.alloc(sizeof(uint32_t) * (ncoarse + 1)));
     RMM_TRY(cursor.alloc(sizeof(uint32_t) * nfine));
     HIP_TRY(hipMemcpyAsync(d_coarse.p, coarse_off.data(), sizeof(uint32_t) * (ncoarse + 1), hipMemcpyHostToDevice, stream0()));
     HIP_TRY(hipMemcpyAsync(d_tiles.p, tile_prefix.data(), sizeof(uint32_t) * (ncoarse + 1), hipMemcpyHostToDevice, stream0()));
-    HIP_TRY(hipMemcpyAsync(cursor.p, sb->fine_off.data(), sizeof(uint32_t) * nfine, hipMemcpyHostToDevice, stream0()));
+    // the cursors start at the partitions' first tuples: with the device index (above) a copy of it, else the host's prefix sums
+    if (device_index) HIP_TRY(hipMemcpyAsync(cursor.p, sb->d_begin.p, sizeof(uint32_t) * nfine, hipMemcpyDeviceToDevice, stream0()));
+    else HIP_TRY(hipMemcpyAsync(cursor.p, sb->fine_off.data(), sizeof(uint32_t) * nfine, hipMemcpyHostToDevice, stream0()));
     RMM_TRY(sb->w[1].alloc(sizeof(uint64_t) * (cap + 2)));
     if (!narrow) RMM_TRY(sb->idx[1].alloc(sizeof(int32_t) * (cap + 2)));     // + 2: the lean probe kernel reads row numbers in pairs
     if (pay) RMM_TRY(sb->pay[1].alloc(sizeof(uint64_t) * (cap + 2)));
+  }
+  if (pay) GDF_TRY(launch_scatter1_pay(fast, pmode, t, plan, g, H1.as<uint32_t>(), *pay, t0));
+  else GDF_TRY(launch_scatter1(fast, narrow, sc_threads, t, plan, g, H1.as<uint32_t>(), t0));
+  HIP_CHECK_LAST();
+  sb->final_buf = 0;
+  if (level2) {
     Level2Map m{d_coarse.as<uint32_t>(), d_coarse.as<uint32_t>() + 1, d_tiles.as<uint32_t>()};
     if (ntiles) GDF_TRY(launch_scatter2(narrow, sc2_threads, ntiles, g, m, sb->tuples(0), cursor.as<uint32_t>(), sb->tuples(1)));
     HIP_CHECK_LAST();
@@ -3500,7 +3522,8 @@ static gdf_error prepare_build(const KeyTable &build_t, BuildSide *bs, bool no_l
   GDF_TRY(plan_ranged(build_t, &bs->plan));
   bs->g = choose_geometry(build_t.nrows);
   const bool range_candidate = !bs->plan.narrow && bs->plan.mode == KM_RAW_INT && build_t.col[0].width == 8;
-  GDF_TRY(partition_side(build_t, bs->plan, bs->g, &bs->B, range_candidate, bpay, bmode));   // may switch plan to the narrow format
+  const bool stays_two_level = !(bs->g.b3 > 0 && !no_level3);          // (a third level rewrites the index on the host)
+  GDF_TRY(partition_side(build_t, bs->plan, bs->g, &bs->B, range_candidate, bpay, bmode, stays_two_level));   // may switch plan to the narrow format
   if (bs->g.b3 > 0 && !no_level3) {
     bool ok = false;
     GDF_TRY(refine_side(bs->g, bs->plan.narrow != 0, 0.0, &bs->B, &ok));
@@ -3520,7 +3543,7 @@ static gdf_error prepare_build(const KeyTable &build_t, BuildSide *bs, bool no_l
   }
   // the partition index once more on the device: jk_make_units builds the work units of a deferred probe side from it
   const size_t nparts = bs->B.fine_cnt.size();
-  if (nparts) {
+  if (nparts && !(stays_two_level && bs->B.d_cnt.p && bs->B.d_begin.p)) {
     RMM_TRY(bs->B.d_begin.alloc(sizeof(uint32_t) * nparts));
     RMM_TRY(bs->B.d_cnt.alloc(sizeof(uint32_t) * nparts));
     HIP_TRY(hipMemcpyAsync(bs->B.d_begin.p, bs->B.fine_begin.data(), sizeof(uint32_t) * nparts, hipMemcpyHostToDevice, stream0()));

@@ -3555,8 +3555,33 @@ static gdf_error prepare_build(const KeyTable &build_t, BuildSide *bs, bool no_l
 static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &build_t, const BuildSide &bs, SideBufs &P, JoinKind kind,
                                    int32_t **out_probe, int32_t **out_build, int64_t *out_n, StageClock &clk, PayCarry *pc = nullptr);
 
+// The probe side's skew sample (jk_sample_skew) needs nothing from the build pass: hash_join_core launches it BEFORE the build side is
+// partitioned, and its 4-byte answer is read when the probe side's turn comes -- no kernel + read-back round trip between the two sides.
+struct SkewProbe {
+  DevBuf sh;
+  size_t words = 0;
+};
+static bool skew_probe_wanted(const KeyTable &probe_t, const KeyPlan &plan, const PartGeom &g) {
+  return g.fb >= 10 && probe_t.nrows >= ((int64_t)1 << 24) && fast_key_width(probe_t, plan) && plan.mode == KM_RAW_INT &&
+         !lab::knob_on("GDF_JK_NO_SKEW_SAMPLE");
+}
+static gdf_error skew_probe_launch(const KeyTable &probe_t, const KeyPlan &plan, const PartGeom &g, SkewProbe *sp) {
+  sp->words = ((size_t)1 << g.fb) + 1;
+  RMM_TRY(sp->sh.alloc(sizeof(uint32_t) * sp->words));
+  HIP_TRY(hipMemsetAsync(sp->sh.p, 0, sizeof(uint32_t) * sp->words, stream0()));
+  if (fast_key_width(probe_t, plan) == 8)
+    hipLaunchKernelGGL(jk_sample_skew<8>, dim3(JK_SKEW_SAMPLES / 256), dim3(256), 0, stream0(), probe_t.col[0].data, probe_t.nrows, g.fb,
+                       sp->sh.as<uint32_t>(), sp->sh.as<uint32_t>() + (sp->words - 1));
+  else
+    hipLaunchKernelGGL(jk_sample_skew<4>, dim3(JK_SKEW_SAMPLES / 256), dim3(256), 0, stream0(), probe_t.col[0].data, probe_t.nrows, g.fb,
+                       sp->sh.as<uint32_t>(), sp->sh.as<uint32_t>() + (sp->words - 1));
+  HIP_CHECK_LAST();
+  return GDF_SUCCESS;
+}
+
 static gdf_error probe_prepared(const KeyTable &probe_t, const KeyTable &build_t, const BuildSide &bs, JoinKind kind,
-                                int32_t **out_probe, int32_t **out_build, int64_t *out_n, StageClock &clk, PayCarry *pc = nullptr) {
+                                int32_t **out_probe, int32_t **out_build, int64_t *out_n, StageClock &clk, PayCarry *pc = nullptr,
+                                SkewProbe *early_skew = nullptr) {
   const KeyPlan &plan = bs.plan;
   const PartGeom &g = bs.g;
   const SideBufs &B = bs.B;
@@ -3571,20 +3596,12 @@ static gdf_error probe_prepared(const KeyTable &probe_t, const KeyTable &build_t
   // skewed probe keys would overflow the speculative layout: ask a sample first (one small kernel and a 4-byte read-back)
   bool skew = false;
   const int probe_fast = fast_key_width(probe_t, plan);
-  if (g.fb >= 10 && probe_t.nrows >= ((int64_t)1 << 24) && probe_fast && plan.mode == KM_RAW_INT && !lab::knob_on("GDF_JK_NO_SKEW_SAMPLE")) {
-    DevBuf sh;
-    const size_t words = ((size_t)1 << g.fb) + 1;
-    RMM_TRY(sh.alloc(sizeof(uint32_t) * words));
-    HIP_TRY(hipMemsetAsync(sh.p, 0, sizeof(uint32_t) * words, stream0()));
-    if (probe_fast == 8)
-      hipLaunchKernelGGL(jk_sample_skew<8>, dim3(JK_SKEW_SAMPLES / 256), dim3(256), 0, stream0(), probe_t.col[0].data, probe_t.nrows, g.fb,
-                         sh.as<uint32_t>(), sh.as<uint32_t>() + (words - 1));
-    else
-      hipLaunchKernelGGL(jk_sample_skew<4>, dim3(JK_SKEW_SAMPLES / 256), dim3(256), 0, stream0(), probe_t.col[0].data, probe_t.nrows, g.fb,
-                         sh.as<uint32_t>(), sh.as<uint32_t>() + (words - 1));
-    HIP_CHECK_LAST();
+  if (skew_probe_wanted(probe_t, plan, g)) {
+    SkewProbe local;
+    SkewProbe *sp = (early_skew && early_skew->sh.p && early_skew->words == ((size_t)1 << g.fb) + 1) ? early_skew : &local;
+    if (sp == &local) GDF_TRY(skew_probe_launch(probe_t, plan, g, sp));
     uint32_t fullest = 0;
-    HIP_TRY(read_back(&fullest, sh.as<uint32_t>() + (words - 1), sizeof(uint32_t)));
+    HIP_TRY(read_back(&fullest, sp->sh.as<uint32_t>() + (sp->words - 1), sizeof(uint32_t)));
     // expected samples per bin: 2^16 / 2^fb (2 at fb = 15); a Poisson(2) bin reaches 16 with probability ~1e-10
     const double expect = (double)JK_SKEW_SAMPLES / (double)((uint64_t)1 << g.fb);
     skew = (double)fullest > 8.0 * expect + 12.0;
@@ -4077,13 +4094,19 @@ static gdf_error hash_join_core(const KeyTable &probe_t, const KeyTable &build_t
   PaySrc bsrc{};
   const bool bcarry = pc && pc->mode >= 0 && pc->bmode && kind == JOIN_INNER && !lab::path_on("GDF_JK_NO_CARRY");
   if (bcarry) { bsrc.col[0] = pc->bsrc[0]; bsrc.col[1] = pc->bsrc[1]; }
+  SkewProbe early_skew;
+  {
+    const KeyPlan p0 = plan_keys(build_t);         // (what prepare_build starts from; the sample hashes RAW keys: no range, no tuple format in it)
+    const PartGeom g0 = choose_geometry(build_t.nrows);
+    if (build_t.ncols == 1 && skew_probe_wanted(probe_t, p0, g0)) GDF_TRY(skew_probe_launch(probe_t, p0, g0, &early_skew));
+  }
   GDF_TRY(prepare_build(build_t, &bs, false, bcarry ? &bsrc : nullptr, bcarry ? pc->bmode : 0));
   clk.mark("partition build side");
-  gdf_error e = probe_prepared(probe_t, build_t, bs, kind, out_probe, out_build, out_n, clk, pc);
+  gdf_error e = probe_prepared(probe_t, build_t, bs, kind, out_probe, out_build, out_n, clk, pc, &early_skew);
   if (e != GDF_AMD_RETRY_WITHOUT_LEVEL3) return e;
   BuildSide plain;
   GDF_TRY(prepare_build(build_t, &plain, true, bcarry ? &bsrc : nullptr, bcarry ? pc->bmode : 0));
-  return probe_prepared(probe_t, build_t, plain, kind, out_probe, out_build, out_n, clk, pc);
+  return probe_prepared(probe_t, build_t, plain, kind, out_probe, out_build, out_n, clk, pc, &early_skew);
 }
 
 // FULL join with an empty side (joining.cu:214-280 trivial_full_join): every row of

@@ -1489,8 +1489,8 @@ __global__ __launch_bounds__(GB_DENSE_THREADS) void gb_part_aggregate(const K *_
 // their digit counts).  The pairs of a partition need no order: gb_part_aggregate indexes its LDS accumulators with the LOW
 // key bits.  Per row: gbp_count 12 B (keys), gbp_scatter 20.1 B in + 12 B out, aggregation 12 B = 56 B, against 116 B for C5
 // through the radix sort (24 -> ~12 ms).
-//   gbp_count    per-chunk partition histogram hist[p * nchunks + chunk] (LDS counters; lanes that share the first one or two
-//                partition ids of their wave are counted with a ballot each -- C5's Zipf keys put 45 % of the rows into
+//   gbp_count    per-chunk partition histogram hist[p * nchunks + chunk] (LDS counters; lanes that share the partition id of their
+//                wave's first live lane are counted with one ballot -- C5's Zipf keys put 45 % of the rows into
 //                partition 0), the number of rows dropped for a null key, and a flag when a key falls outside the plan's
 //                ranges (possible only with sample-guessed ranges);
 //   gbp_scatter  12288-row tiles, ranks from wave-wide match-any ballots (one LDS atomic per distinct partition and wave: the
@@ -1695,9 +1695,11 @@ __global__ __launch_bounds__(GBP_THREADS) void gbp_count(KeyTable t, GbKeyPlan p
         if (live && okk && ((outmask >> k) & 1u)) outside = 1;
         bool mine = live && okk;
         const uint32_t part = (key[k] << vbit) >> low;
-        // the first two distinct partition ids of the wave by ballot, the rest one LDS atomic each
+        // the partition id of the wave's first live lane by ballot, the rest one LDS atomic each.  (One round: C5's hot partition holds
+        // 45 % of the rows, the next one 5 %; a second ballot round cost more than the same-address atomics it saved -- 1.71 -> 1.50 ms,
+        // none at all 1.68, three 2.1, profiles/r3_zq_gbp_count_rounds.txt)
 #pragma unroll
-        for (int round = 0; round < 2; ++round) {
+        for (int round = 0; round < 1; ++round) {
           const unsigned long long todo = __ballot(mine);
           if (todo) {
             const int leader = __ffsll((long long)todo) - 1;

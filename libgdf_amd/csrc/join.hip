@@ -2860,7 +2860,7 @@ static int level2_threads(int sc_threads) {
 
 // pay (may be null) + pmode: the relation carries a payload word per row (PayCarry); NARROW tuples and a FAST key column only
 static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, SideBufs *sb, bool decide_narrow, const PaySrc *pay = nullptr,
-                                int pmode = 0, bool device_index = false) {
+                                int pmode = 0, bool device_index = false, bool want_p6 = false) {
   const int64_t n = t.nrows;
   bool narrow = plan.narrow != 0;
   // Chunks are SMALL (a few tiles) and processed in blockIdx order, so that the workgroups resident at
@@ -2957,6 +2957,7 @@ static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, Si
   // level 2's map and cursors are made and sent BEFORE level 1 is launched: the host has everything, and behind the level-1 kernel
   // every staged upload was a stall between the two levels
   const bool level2 = g.b2 > 0 && sb->joinable > 0;
+  bool p6 = false;
   DevBuf d_coarse, d_tiles, cursor;
   uint32_t ntiles = 0;
   std::vector<uint32_t> coarse_off, tile_prefix;
@@ -2976,7 +2977,9 @@ static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, Si
     // the cursors start at the partitions' first tuples: with the device index (above) a copy of it, else the host's prefix sums
     if (device_index) HIP_TRY(hipMemcpyAsync(cursor.p, sb->d_begin.p, sizeof(uint32_t) * nfine, hipMemcpyDeviceToDevice, stream0()));
     else HIP_TRY(hipMemcpyAsync(cursor.p, sb->fine_off.data(), sizeof(uint32_t) * nfine, hipMemcpyHostToDevice, stream0()));
-    RMM_TRY(sb->w[1].alloc(sizeof(uint64_t) * (cap + 2)));
+    // (a probe side on the exact layout -- skewed probe keys -- writes six-byte tuples as the speculative layout does, see p6_store)
+    p6 = want_p6 && narrow && !pay && sc2_threads == 256;
+    RMM_TRY(sb->w[1].alloc(p6 ? 6 * (cap + 2) + 16 : sizeof(uint64_t) * (cap + 2)));
     if (!narrow) RMM_TRY(sb->idx[1].alloc(sizeof(int32_t) * (cap + 2)));     // + 2: the lean probe kernel reads row numbers in pairs
     if (pay) RMM_TRY(sb->pay[1].alloc(sizeof(uint64_t) * (cap + 2)));
   }
@@ -2986,13 +2989,14 @@ static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, Si
   sb->final_buf = 0;
   if (level2) {
     Level2Map m{d_coarse.as<uint32_t>(), d_coarse.as<uint32_t>() + 1, d_tiles.as<uint32_t>()};
-    if (ntiles) GDF_TRY(launch_scatter2(narrow, sc2_threads, ntiles, g, m, sb->tuples(0), cursor.as<uint32_t>(), sb->tuples(1)));
+    if (ntiles) GDF_TRY(launch_scatter2(narrow, sc2_threads, ntiles, g, m, sb->tuples(0), cursor.as<uint32_t>(), sb->tuples(1), p6));
     HIP_CHECK_LAST();
     HIP_TRY(hipStreamSynchronize(stream0()));   // host vectors + scratch go out of scope
     sb->w[0].reset();
     sb->idx[0].reset();
     sb->pay[0].reset();
     sb->final_buf = 1;
+    sb->p6 = p6;
   } else {
     HIP_TRY(hipStreamSynchronize(stream0()));
   }
@@ -3622,15 +3626,18 @@ static gdf_error probe_prepared(const KeyTable &probe_t, const KeyTable &build_t
   // six-byte level-2 tuples (p6_store): the main path, 2^15 fine partitions (17 hash bits left), nothing carried, and stored keys
   // on which hash_a is a bijection -- their raw values raw = key + kmin must not straddle a 2^32 boundary
   const bool bijective = plan.kmin == 0 || (plan.kmin & 0xffffffffULL) + plan.kspan < (1ULL << 32);
-  const bool want_p6 = defer && g.fb == JK_MAX_FB && g.b3 == 0 && g.world <= 1 && plan.narrow && !plan.verify && pc_eff == nullptr && bijective &&
-                       !lab::path_on("GDF_JK_NO_P6");
+  const bool p6_ok = g.fb == JK_MAX_FB && g.b2 > 0 && g.b3 == 0 && kind != JOIN_FULL && g.world <= 1 && plan.narrow && !plan.verify && pc_eff == nullptr &&
+                     bijective && !lab::path_on("GDF_JK_NO_P6");
+  const bool want_p6 = defer && p6_ok;
+  // (the exact layout's probe side too -- skewed probe keys -- as long as every build partition is an LDS unit: the global-table path reads 8-byte tuples)
+  const bool want_p6_exact = p6_ok && largest_build <= (uint32_t)JK_MAX_BUILD && !lab::path_on("GDF_JK_NO_P6_EXACT");
   if (!skew && g.fb > 0 && probe_t.nrows >= spec_min && largest_build <= (uint32_t)JK_MAX_BUILD && !lab::path_on("GDF_JK_NO_SPEC"))
     GDF_TRY(partition_side_spec(probe_t, plan, g, std::max(1.0, (double)probe_t.nrows / std::max<uint32_t>(B.joinable, 1)), &P, &spec_ok,
                                 nullptr, defer, pay, pmode, want_p6));
   if (!spec_ok) {
     P.w[0].reset(); P.w[1].reset(); P.idx[0].reset(); P.idx[1].reset(); P.pay[0].reset(); P.pay[1].reset();
     KeyPlan probe_plan = plan;             // partition_side only rewrites the plan when asked to decide the format
-    GDF_TRY(partition_side(probe_t, probe_plan, g, &P, false, pay, pmode));
+    GDF_TRY(partition_side(probe_t, probe_plan, g, &P, false, pay, pmode, false, want_p6_exact));
   }
   const bool narrow = plan.narrow != 0;
   if (g.b3 > 0) {
@@ -3644,7 +3651,7 @@ static gdf_error probe_prepared(const KeyTable &probe_t, const KeyTable &build_t
   // a deferred speculative probe side turned out to have overflowed (skewed keys): the exact layout, host bookkeeping
   SideBufs Q;
   KeyPlan probe_plan = plan;
-  GDF_TRY(partition_side(probe_t, probe_plan, g, &Q, false, pay, pmode));
+  GDF_TRY(partition_side(probe_t, probe_plan, g, &Q, false, pay, pmode, false, want_p6_exact));
   return probe_partitioned(probe_t, build_t, bs, Q, kind, out_probe, out_build, out_n, clk, pc_eff);
 }
 

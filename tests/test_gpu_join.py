@@ -751,7 +751,8 @@ def test_masked_single_key_column_takes_the_paired_reads(gdf, how, dtype, masks,
 
 
 @pytest.mark.parametrize("how", ["inner", "left"])
-@pytest.mark.parametrize("keys", ["int64-from-zero", "int64-offset", "int64-straddling-2^32", "int32", "two-int16-columns", "build-keys-twice"])
+@pytest.mark.parametrize("keys", ["int64-from-zero", "int64-offset", "int64-straddling-2^32", "int32", "two-int16-columns", "build-keys-twice",
+                                  "probe-third-on-one-key"])
 @pytest.mark.parametrize("hit", [1.0, 0.7, 0.2])
 def test_six_byte_level2_tuples(gdf, how, keys, hit, force_path):
     """With 2^15 fine partitions the level-2 output and the probe input are SIX-byte tuples -- 17 remaining bits of the (bijective)
@@ -759,7 +760,8 @@ def test_six_byte_level2_tuples(gdf, how, keys, hit, force_path):
     r2 item 2.iii; reference semantics join_kernels.cuh:259-455).  GDF_JK_FORCE_FB=15 gives a small build relation the geometry
     of a 5e7-row one.  Against the oracle and against the eight-byte path (GDF_JK_NO_P6): keys from 0, keys with an offset (kmin != 0),
     keys whose raw values straddle a 2^32 boundary (hash_a is no bijection there: the call must keep eight-byte tuples), 4-byte
-    keys, two packed columns, repeated build keys (general kernel on six-byte tuples), every output-sizing path."""
+    keys, two packed columns, repeated build keys (general kernel on six-byte tuples), a probe relation with a third of its rows on one
+    key (the exact layout's level 2 writes six-byte tuples too; GDF_JK_NO_P6_EXACT: eight-byte ones there), every output-sizing path."""
     rs = np.random.RandomState(int(hit * 10) + len(keys))
     nb, npr = 60_000, 900_000
     force_path("GDF_JK_FORCE_FB", "15")
@@ -769,6 +771,8 @@ def test_six_byte_level2_tuples(gdf, how, keys, hit, force_path):
     if keys == "build-keys-twice":
         bk[: nb // 2] = bk[nb // 2:]
     pk = rs.randint(0, space, size=npr).astype(np.int64)
+    if keys == "probe-third-on-one-key":            # the speculative layout overflows: the EXACT layout's probe side, six-byte tuples there too
+        pk[rs.rand(npr) < 0.33] = bk[7]
     if keys == "int64-offset":
         bk, pk = bk + (7 << 33) + 12345, pk + (7 << 33) + 12345
     elif keys == "int64-straddling-2^32":
@@ -780,6 +784,8 @@ def test_six_byte_level2_tuples(gdf, how, keys, hit, force_path):
     else:
         build, probe = [bk], [pk]
     n1 = _check(gdf, probe, build, how)
+    force_path("GDF_JK_NO_P6_EXACT")
+    assert _check(gdf, probe, build, how) == n1
     force_path("GDF_JK_NO_P6")
     assert _check(gdf, probe, build, how) == n1
 

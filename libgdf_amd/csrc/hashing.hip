@@ -809,7 +809,11 @@ __global__ __launch_bounds__(256) void hpt_piece_counts(const uint32_t *__restri
 // partition_offsets exact); costs one extra read + write of every column and a table-sized scratch.
 namespace gdf_amd {
 static gdf_error hash_partition_two_level(int ncols, gdf_column *input[], const int *columns_to_hash, int num_cols_to_hash, uint32_t P,
-                                          gdf_column *output[], int partition_offsets[], bool murmur) {
+                                          gdf_column *output[], int partition_offsets[], bool murmur, bool *declined) {
+  // *declined: the table-sized scratch (or a histogram) could not be allocated BEFORE anything was written -- the caller takes the
+  // one-level pass, which needs no copy of the table (a request that fitted the device before the two-level path existed still does)
+  *declined = false;
+#define HP2_ALLOC(call) do { if ((call) != RMM_SUCCESS) { *declined = true; return GDF_SUCCESS; } } while (0)
   const int64_t n = (int64_t)input[0]->size;
   // the smallest shift that leaves at most 1024 super-partitions, raised to the balanced one (K ~ sqrt(P), at most 256 bins at level B)
   int kshift = 0;
@@ -826,12 +830,12 @@ static gdf_error hash_partition_two_level(int ncols, gdf_column *input[], const 
   const size_t mask_words = (mask_bytes((size_t)n) + 3) / 4;
   for (int i = 0; i < ncols; ++i) {
     const int w = dtype_width(input[i]->dtype);
-    RMM_TRY(tmp_data[i].alloc((size_t)w * (size_t)n));
+    HP2_ALLOC(tmp_data[i].alloc((size_t)w * (size_t)n));
     tmp_col[i] = *input[i];
     tmp_col[i].data = tmp_data[i].p;
     tmp_col[i].valid = nullptr;
     if (input[i]->valid) {                   // a key column's mask decides nothing here (hash_row ignores it) but travels with its column
-      RMM_TRY(tmp_valid[i].alloc(mask_words * 4));
+      HP2_ALLOC(tmp_valid[i].alloc(mask_words * 4));
       HIP_TRY(hipMemsetAsync(tmp_valid[i].p, 0, mask_words * 4, stream0()));
       tmp_col[i].valid = (gdf_valid_type *)tmp_valid[i].p;
     }
@@ -842,6 +846,7 @@ static gdf_error hash_partition_two_level(int ncols, gdf_column *input[], const 
   GDF_TRY(make_key_table(key_tmp.data(), num_cols_to_hash, &t2));
   const int fastw = (murmur && t.ncols == 1 && (t.col[0].width == 8 || t.col[0].width == 4)) ? t.col[0].width : 0;
 
+  hipError_t clear_err = hipSuccess;
   auto payload = [&](gdf_column **in, gdf_column **out, bool clear_out_masks) -> PayloadCols {
     PayloadCols pc{};
     pc.ncols = ncols;
@@ -852,7 +857,10 @@ static gdf_error hash_partition_two_level(int ncols, gdf_column *input[], const 
       const bool masks = in[k]->valid && out[k]->valid;
       pc.in_valid[k] = masks ? in[k]->valid : nullptr;
       pc.out_valid[k] = masks ? (uint32_t *)out[k]->valid : nullptr;
-      if (masks && clear_out_masks) (void)hipMemsetAsync(out[k]->valid, 0, mask_words * 4, stream0());
+      if (masks && clear_out_masks) {
+        const hipError_t e = hipMemsetAsync(out[k]->valid, 0, mask_words * 4, stream0());
+        if (e != hipSuccess) clear_err = e;
+      }
     }
     return pc;
   };
@@ -873,9 +881,12 @@ static gdf_error hash_partition_two_level(int ncols, gdf_column *input[], const 
   const uint32_t M = ((uint32_t)nchunks + group - 1) / group;
   const size_t full_words = (size_t)S * K * nchunks, histA_words = (size_t)S * nchunks + 1, histB_words = (size_t)S * K * M + 1;
   DevBuf histA, histB, histFull;
-  RMM_TRY(histA.alloc(sizeof(uint32_t) * histA_words));
-  RMM_TRY(histB.alloc(sizeof(uint32_t) * histB_words));
-  RMM_TRY(histFull.alloc(sizeof(uint32_t) * full_words));
+  DevBuf d_starts;
+  HP2_ALLOC(histA.alloc(sizeof(uint32_t) * histA_words));
+  HP2_ALLOC(histB.alloc(sizeof(uint32_t) * histB_words));
+  HP2_ALLOC(histFull.alloc(sizeof(uint32_t) * full_words));
+  HP2_ALLOC(d_starts.alloc(sizeof(uint32_t) * P));
+#undef HP2_ALLOC
   HIP_TRY(hipMemsetAsync(histA.as<uint32_t>() + (histA_words - 1), 0, sizeof(uint32_t), stream0()));
   PartLevel lh{};
   lh.mode = 3; lh.kshift = kshift; lh.hashP = P; lh.hashmask = pow2mask; lh.full = histFull.as<uint32_t>();
@@ -926,6 +937,7 @@ static gdf_error hash_partition_two_level(int ncols, gdf_column *input[], const 
   const int gridB = nchunksB < NUM_CU * 2 ? nchunksB : NUM_CU * 2;
   {
     PayloadCols pc = payload(tmp_ptr.data(), output, true);
+    HIP_TRY(clear_err);
     for (int k = 0; k < ncols; ++k)
       if (input[k]->valid && output[k]->valid) output[k]->null_count = input[k]->null_count;
     if (fastw == 8) HP2_TILE("part_scatter_b", true, 8, 1024, 1024, 12, t2, K, nchunksB, (int64_t)0, gridB, histB.as<uint32_t>(), lb);
@@ -936,8 +948,6 @@ static gdf_error hash_partition_two_level(int ncols, gdf_column *input[], const 
   }
 #undef HP2_TILE
   // partition_offsets (HOST array): every M-th entry of the scanned level-B histogram (index partition * M) is a partition's start
-  DevBuf d_starts;
-  RMM_TRY(d_starts.alloc(sizeof(uint32_t) * P));
   hipLaunchKernelGGL(gather_strided_u32, dim3((P + 255) / 256), dim3(256), 0, stream0(), (const uint32_t *)histB.as<uint32_t>(), d_starts.as<uint32_t>(), (int)P, (size_t)M);
   HIP_CHECK_LAST();
   HIP_TRY(hipMemcpyAsync(partition_offsets, d_starts.p, sizeof(int) * P, hipMemcpyDeviceToHost, stream0()));
@@ -1184,9 +1194,12 @@ gdf_error gdf_hash_partition(int num_input_cols, gdf_column *input[], int column
   const uint32_t P = (uint32_t)num_partitions;
   const uint32_t pow2mask = (P & (P - 1)) == 0 ? P - 1 : 0;   // P==1 -> mask 0 -> h % 1 == 0, same result
   // beyond the fan-out one LDS-regrouped pass serves: two levels (hash_partition_two_level)
-  if (P > (uint32_t)HPT_BIG_PARTS && num_input_cols <= HP_MAX_PAYLOAD_COLS && n >= ((int64_t)1 << 18) && !lab::path_on("GDF_HP_ONE_LEVEL"))
-    return hash_partition_two_level(num_input_cols, input, columns_to_hash, num_cols_to_hash, P, partitioned_output, partition_offsets,
-                                    hash == GDF_HASH_MURMUR3);
+  if (P > (uint32_t)HPT_BIG_PARTS && num_input_cols <= HP_MAX_PAYLOAD_COLS && n >= ((int64_t)1 << 18) && !lab::path_on("GDF_HP_ONE_LEVEL")) {
+    bool declined = false;
+    const gdf_error e = hash_partition_two_level(num_input_cols, input, columns_to_hash, num_cols_to_hash, P, partitioned_output,
+                                                 partition_offsets, hash == GDF_HASH_MURMUR3, &declined);
+    if (!declined) return e;           // (declined: no room for the temporary table -- the one-level pass below)
+  }
   // chunking: at most HP_MAX_CHUNKS chunks, each a multiple of the block size
   int64_t chunk = (n + HP_MAX_CHUNKS - 1) / HP_MAX_CHUNKS;
   chunk = ((chunk + HP_THREADS * 8 - 1) / (HP_THREADS * 8)) * (HP_THREADS * 8);

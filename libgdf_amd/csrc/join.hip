@@ -68,6 +68,9 @@ struct KeyPlan {
   uint64_t kmin;              // subtracted from 8-byte integer keys in narrow mode (two's complement)
   uint64_t kspan;             // narrow mode with kmin != 0: the largest stored key (build max - min); decides whether hash_a is a
                               // bijection on the stored keys (six-byte level-2 tuples, p6_store)
+  uint64_t klimit;            // the largest stored key that can join: 2^32 - 1 for NARROW keys, kspan once the build range is known
+                              // (a probe key beyond the build maximum matches nothing, and the six-byte tuples compare hash
+                              // remainders only: hash_a is a bijection on [0, kspan], not beyond it), ~0 for WIDE keys
   int shift[MAX_KEY_COLS];    // KM_PACKED bit offsets
   // KM_PACKED with ranged != 0: column c contributes (value - bias[c]) in bits[c] bits, the ranges taken from the BUILD
   // relation (plan_ranged); a probe value outside its column's range cannot match and makes the row unjoinable
@@ -90,6 +93,7 @@ static KeyPlan plan_keys(const KeyTable &t) {
   else { p.mode = KM_HASHED; p.verify = 1; }
   // zero-extended raw bits of <= 4 bytes are below 2^32 by construction
   if (p.mode != KM_HASHED && total <= 4) p.narrow = 1;
+  p.klimit = p.narrow ? 0xffffffffULL : ~0ULL;
   return p;
 }
 
@@ -125,7 +129,7 @@ __device__ __forceinline__ bool make_key(const KeyTable &t, const KeyPlan &p, in
     case KM_RAW_INT: {
       const uint64_t k = load_bits(t.col[0], i) - p.kmin;
       key = k;
-      return !p.narrow || (k >> 32) == 0;
+      return k <= p.klimit;
     }
     case KM_RAW_FLOAT: return float_bits(t.col[0], i, key);
     case KM_PACKED: {
@@ -205,7 +209,7 @@ __device__ __forceinline__ bool fetch_key(const KeyTable &t, const KeyPlan &p, i
     const bool joinable = p.mode != KM_RAW_FLOAT || fast_float_word<FAST>(w);
     const uint64_t k = w - p.kmin;
     key = k;
-    return joinable && (!p.narrow || (k >> 32) == 0);
+    return joinable && k <= p.klimit;
   }
   return make_key(t, p, i, key);
 }
@@ -227,7 +231,7 @@ __device__ __forceinline__ void fetch_keys(const KeyTable &t, const KeyPlan &p, 
     for (int k = 0; k < N; ++k) {
       const bool joinable = p.mode != KM_RAW_FLOAT || fast_float_word<FAST>(key[k]);
       key[k] -= p.kmin;
-      ok[k] = joinable && (i0 + k * stride < end) && (!p.narrow || (key[k] >> 32) == 0);
+      ok[k] = joinable && (i0 + k * stride < end) && key[k] <= p.klimit;
     }
     // the column's validity mask, paired with the data reads: one byte per row, requested together (a wave's 64 rows of
     // one k share 8 bytes -- one request); workgroup-uniform branch, the unmasked column pays nothing
@@ -745,7 +749,7 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
       const bool joinable = plan.mode != KM_RAW_FLOAT || fast_float_word<FAST ? FAST : 8>(raw);
       const uint64_t k64 = raw - plan.kmin;
       key[k] = (KeyReg)k64;
-      okmask |= (uint32_t)(joinable && (tile + item_row(k, tid) < end) && (!plan.narrow || (k64 >> 32) == 0)) << k;
+      okmask |= (uint32_t)(joinable && (tile + item_row(k, tid) < end) && k64 <= plan.klimit) << k;
     }
     okmask &= validbits;
   };
@@ -944,7 +948,7 @@ __global__ __launch_bounds__(JK_PAY_THREADS) void jk_scatter1_pay(KeyTable t, Ke
       const bool joinable = plan.mode != KM_RAW_FLOAT || fast_float_word<FAST>(raw);
       const uint64_t k64 = raw - plan.kmin;
       key[k] = (uint32_t)k64;
-      okmask |= (uint32_t)(joinable && (tile + item_row(k, tid) < end) && (k64 >> 32) == 0) << k;
+      okmask |= (uint32_t)(joinable && (tile + item_row(k, tid) < end) && k64 <= plan.klimit) << k;
       if (PMODE == 1) pay[k] = second ? nxp[k + 1] : nxp[k];
       else if (PMODE == 2) pay[k] = second ? nxa[k + 1] : nxa[k];
       else pay[k] = (uint64_t)(second ? nxa[k + 1] : nxa[k]) | ((uint64_t)(second ? nxb[k + 1] : nxb[k]) << 32);
@@ -2932,6 +2936,7 @@ static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, Si
       plan.narrow = 1;
       plan.kmin = (uint64_t)h[0];
       plan.kspan = (uint64_t)h[1] - (uint64_t)h[0];
+      plan.klimit = plan.kspan;
       narrow = true;
     }
   }
@@ -3514,6 +3519,7 @@ static gdf_error plan_ranged(const KeyTable &build_t, KeyPlan *plan) {
   p.ranged = 1;
   p.verify = 0;
   p.narrow = total <= 32 ? 1 : 0;
+  p.klimit = p.narrow ? 0xffffffffULL : ~0ULL;
   p.kmin = 0;
   *plan = p;
   return GDF_SUCCESS;
@@ -5044,6 +5050,7 @@ static gdf_error fj_build_create(const uint32_t *recv_keys, const uint32_t *recv
   bs.plan.mode = KM_RAW_INT;
   bs.plan.narrow = 1;
   bs.plan.kmin = (uint64_t)lo;
+  bs.plan.klimit = 0x7ffffffeULL;
   bs.plan.kspan = 0x7ffffffeULL;          // narrowed keys are below 2^31 - 1 (gdf_amd_fj_send): the largest span the range can have
   bs.g = fj_geometry(world, fine_bits, coarse_bits, lo);
   const uint32_t nfine = 1u << fine_bits, nseg = ((uint32_t)world << coarse_bits) << 3;

@@ -20,8 +20,8 @@
 namespace gdf_amd {
 namespace lab {
 
-// plumbing.cpp: value set through gdf_amd_debug_force, or nullptr.  The returned pointer stays valid until
-// the same name is forced again (tests run single-threaded; the library itself never writes the registry).
+// plumbing.cpp: value set through gdf_amd_debug_force, or nullptr.  The returned pointer is an interned string that is
+// never freed (the library itself never writes the registry).
 const char *forced(const char *name);
 
 #ifdef GDF_AMD_LAB

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <set>
 #include <mutex>
 #include <string>
 #include <roctracer/roctx.h>
@@ -66,14 +67,18 @@ hipError_t read_back(void *host_dst, const void *dev_src, size_t bytes) {
 namespace lab {
 namespace {
 std::mutex g_forced_mutex;
-std::map<std::string, std::string> &forced_map() { static std::map<std::string, std::string> m; return m; }
+// name -> interned value.  Values are interned in a set that only grows, so a pointer handed out by forced() stays valid for the
+// life of the process even when another thread forces the same name again or clears it (c_str() of a map entry that a
+// concurrent gdf_amd_debug_force erased was a use-after-free); a test process sets a handful of distinct values.
+std::map<std::string, const char *> &forced_map() { static std::map<std::string, const char *> m; return m; }
+const char *intern(const char *value) { static std::set<std::string> pool; return pool.insert(value).first->c_str(); }
 int g_forced_count = 0;
 }  // namespace
 const char *forced(const char *name) {
   if (__atomic_load_n(&g_forced_count, __ATOMIC_RELAXED) == 0) return nullptr;
   std::lock_guard<std::mutex> lock(g_forced_mutex);
   auto it = forced_map().find(name);
-  return it == forced_map().end() ? nullptr : it->second.c_str();
+  return it == forced_map().end() ? nullptr : it->second;
 }
 }  // namespace lab
 
@@ -166,7 +171,7 @@ extern "C" __attribute__((visibility("default"))) gdf_error gdf_amd_debug_force(
   if (!name) return GDF_INVALID_API_CALL;
   std::lock_guard<std::mutex> lock(gdf_amd::lab::g_forced_mutex);
   auto &m = gdf_amd::lab::forced_map();
-  if (value) m[name] = value; else m.erase(name);
+  if (value) m[name] = gdf_amd::lab::intern(value); else m.erase(name);
   __atomic_store_n(&gdf_amd::lab::g_forced_count, (int)m.size(), __ATOMIC_RELAXED);
   return GDF_SUCCESS;
 }

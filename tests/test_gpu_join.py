@@ -791,6 +791,39 @@ def test_six_byte_level2_tuples(gdf, how, keys, hit, force_path):
 
 
 @pytest.mark.parametrize("how", ["inner", "left"])
+@pytest.mark.parametrize("layout", ["speculative", "exact"])
+def test_six_byte_tuples_probe_keys_beyond_the_build_range(gdf, how, layout, force_path):
+    """The six-byte tuples compare hash remainders, and hash_a is a bijection on the BUILD range only (raw values inside one
+    2^32 window).  A probe key beyond the build maximum whose raw value has another high word can FOLD onto a build key
+    (key_fold = lo ^ hi * 0x9e3779b1: build 0x1_8000_0000 and probe 0x2_2259_8AD3 both fold to 0x1E3779B1) -- such rows must be
+    dropped before they are partitioned (KeyPlan::klimit), not merely when their offset from the build minimum exceeds 32 bits
+    (ADVICE r3, high).  Build keys from 0x1_8000_0000 up; the probe relation mixes in-range keys with one crafted collider per build
+    key.  Against the oracle and the eight-byte path.  Reference semantics: join_kernels.cuh:259-455 (a pair needs equal keys)."""
+    rs = np.random.RandomState(11)
+    nb, npr = 60_000, 600_000
+    C = 0x9E3779B1
+    base = 0x1_8000_0000
+    bk = (base + rs.permutation(2 * nb)[:nb]).astype(np.int64)
+    lo = (bk & 0xFFFFFFFF).astype(np.uint64)
+    fold = lo ^ np.uint64(C)                                       # high word 1
+    lo2 = (fold ^ np.uint64((2 * C) & 0xFFFFFFFF)).astype(np.uint64)   # the low word that folds onto it under high word 2
+    colliders = ((np.uint64(2) << np.uint64(32)) | lo2).astype(np.int64)
+    colliders = colliders[(colliders - base) < (1 << 32)]          # the ones the old `offset < 2^32` filter let through
+    assert len(colliders) > nb // 4 and 0x2_2259_8AD3 - base < (1 << 32)
+    pk = (base + rs.randint(0, 2 * nb, size=npr)).astype(np.int64)
+    where = rs.permutation(npr)[: len(colliders) + 1]
+    pk[where[:-1]] = colliders
+    pk[where[-1]] = 0x2_2259_8AD3
+    if layout == "exact":
+        pk[rs.rand(npr) < 0.3] = bk[5]                             # skewed: the exact layout's probe side
+    force_path("GDF_JK_FORCE_FB", "15")
+    force_path("GDF_JK_SPEC_MIN", "1000")
+    n1 = _check(gdf, [pk], [bk], how)
+    force_path("GDF_JK_NO_P6")
+    assert _check(gdf, [pk], [bk], how) == n1
+
+
+@pytest.mark.parametrize("how", ["inner", "left"])
 @pytest.mark.parametrize("copies", [3, 4, 16, 300])
 @pytest.mark.parametrize("geometry", ["natural", "forced-2^15-partitions"])
 def test_repeated_build_keys_take_the_lean_multimap_kernel(gdf, how, copies, geometry, force_path):

@@ -32,6 +32,20 @@ namespace gdf_amd {
 
 void note_hip_error(hipError_t e, const char *what, const char *file, int line);
 
+// Every extern "C" entry point that can reach a host allocation (std::vector / new in the dispatch code) runs its body through
+// this: the reference lets std::bad_alloc and thrust::system_error escape extern "C" (managed_allocator.cuh:34-45,
+// thrust_rmm_allocator.h:44-49) -- a C caller (cffi / ctypes) cannot catch them.  Here an exception
+// becomes GDF_MEMORYMANAGER_ERROR.  tests/test_abi.py / test_gpu_stress.py force one through gdf_amd_debug_force
+// ("GDF_FORCE_HOST_ALLOC_FAILURE": make_key_table throws std::bad_alloc).
+template <class F>
+static inline gdf_error guarded(F &&body) noexcept {
+  try {
+    return body();
+  } catch (...) {
+    return GDF_MEMORYMANAGER_ERROR;
+  }
+}
+
 constexpr int WAVE = 64;          // gfx950 wavefront width
 constexpr int NUM_CU = 256;       // MI355X
 constexpr int MAX_KEY_COLS = 16;  // key columns per relational call (reference tests use <= 5)

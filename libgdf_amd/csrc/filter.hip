@@ -436,25 +436,38 @@ using namespace gdf_amd;
 extern "C" {
 
 gdf_error gpu_comparison_static_i8(gdf_column *lhs, int8_t value, gdf_column *output, gdf_comparison_operator operation) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   return comparison_static<int8_t>(lhs, value, output, operation);
+  });
 }
 gdf_error gpu_comparison_static_i16(gdf_column *lhs, int16_t value, gdf_column *output, gdf_comparison_operator operation) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   return comparison_static<int16_t>(lhs, value, output, operation);
+  });
 }
 gdf_error gpu_comparison_static_i32(gdf_column *lhs, int32_t value, gdf_column *output, gdf_comparison_operator operation) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   return comparison_static<int32_t>(lhs, value, output, operation);
+  });
 }
 gdf_error gpu_comparison_static_i64(gdf_column *lhs, int64_t value, gdf_column *output, gdf_comparison_operator operation) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   return comparison_static<int64_t>(lhs, value, output, operation);
+  });
 }
 gdf_error gpu_comparison_static_f32(gdf_column *lhs, float value, gdf_column *output, gdf_comparison_operator operation) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   return comparison_static<float>(lhs, value, output, operation);
+  });
 }
 gdf_error gpu_comparison_static_f64(gdf_column *lhs, double value, gdf_column *output, gdf_comparison_operator operation) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   return comparison_static<double>(lhs, value, output, operation);
+  });
 }
 
 gdf_error gpu_comparison(gdf_column *lhs, gdf_column *rhs, gdf_column *output, gdf_comparison_operator operation) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   GDF_REQUIRE(lhs && rhs && output, GDF_DATASET_EMPTY);
   GDF_REQUIRE(lhs->size == rhs->size, GDF_COLUMN_SIZE_MISMATCH);
   GDF_REQUIRE(lhs->size == output->size, GDF_COLUMN_SIZE_MISMATCH);
@@ -476,9 +489,11 @@ gdf_error gpu_comparison(gdf_column *lhs, gdf_column *rhs, gdf_column *output, g
   GDF_TRY(e);
   HIP_CHECK_LAST();
   return comparison_mask(output, lhs->valid, rhs->valid, lhs->null_count, rhs->null_count, n);
+  });
 }
 
 gdf_error gpu_apply_stencil(gdf_column *lhs, gdf_column *stencil, gdf_column *output) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   GDF_REQUIRE(lhs && stencil && output, GDF_DATASET_EMPTY);
   GDF_REQUIRE(output->size == lhs->size, GDF_COLUMN_SIZE_MISMATCH);
   GDF_REQUIRE(lhs->dtype == output->dtype, GDF_DTYPE_MISMATCH);
@@ -501,10 +516,12 @@ gdf_error gpu_apply_stencil(gdf_column *lhs, gdf_column *stencil, gdf_column *ou
   output->size = (gdf_size_type)kept;   // the allocation is NOT shrunk (streamcompactionops.cu:248)
   output->null_count = 0;
   return GDF_SUCCESS;
+  });
 }
 
 gdf_error gdf_filter(size_t nrows, gdf_column *cols, size_t ncols, void **d_cols, int *d_types, void **d_vals,
                      size_t *d_indx, size_t *new_sz) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   GDF_REQUIRE(cols && d_cols && d_types && d_vals && d_indx && new_sz, GDF_DATASET_EMPTY);
   GDF_REQUIRE(!cols->valid, GDF_VALIDITY_UNSUPPORTED);   // sqls_ops.cu:1412 checks the first column only
   // fill the caller's device-side column/type slices (soa_col_info, sqls_ops.cu:27-41)
@@ -519,9 +536,11 @@ gdf_error gdf_filter(size_t nrows, gdf_column *cols, size_t ncols, void **d_cols
   HIP_TRY(hipStreamSynchronize(stream0()));
   *new_sz = (size_t)kept;
   return GDF_SUCCESS;
+  });
 }
 
 gdf_error gdf_count_nonzero_mask(gdf_valid_type const *masks, int num_rows, int *count) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   if (nullptr == masks || nullptr == count) return GDF_DATASET_EMPTY;   // validops.cu:148
   if (0 == num_rows) return GDF_SUCCESS;
   DevBuf c;
@@ -534,10 +553,12 @@ gdf_error gdf_count_nonzero_mask(gdf_valid_type const *masks, int num_rows, int 
   HIP_TRY(read_back(&h, c.p, sizeof(h)));
   *count = (int)h;
   return GDF_SUCCESS;
+  });
 }
 
 // out.valid = lhs.valid & rhs.valid (a missing mask counts as all ones); sizes must agree
 gdf_error gdf_validity_and(gdf_column *lhs, gdf_column *rhs, gdf_column *output) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   GDF_REQUIRE(lhs && rhs && output, GDF_DATASET_EMPTY);
   GDF_REQUIRE(lhs->size == rhs->size && lhs->size == output->size, GDF_COLUMN_SIZE_MISMATCH);
   GDF_REQUIRE(output->valid, GDF_VALIDITY_MISSING);
@@ -545,9 +566,11 @@ gdf_error gdf_validity_and(gdf_column *lhs, gdf_column *rhs, gdf_column *output)
   GDF_TRY(mask_and(lhs->valid, rhs->valid, output->valid, (int64_t)lhs->size, &nulls));
   output->null_count = nulls;
   return GDF_SUCCESS;
+  });
 }
 
 gdf_error gdf_column_concat(gdf_column *output, gdf_column *columns_to_concat[], int num_columns) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   // checks in the order of column.cpp:56-98
   if (nullptr == columns_to_concat) return GDF_DATASET_EMPTY;
   if (nullptr == columns_to_concat[0] || nullptr == output) return GDF_DATASET_EMPTY;
@@ -592,6 +615,7 @@ gdf_error gdf_column_concat(gdf_column *output, gdf_column *columns_to_concat[],
   }
   HIP_TRY(hipStreamSynchronize(stream0()));
   return GDF_SUCCESS;
+  });
 }
 
 // streamcompactionops.cu:389-494: output = lhs ++ rhs, data and validity.  The reference stitches the two masks
@@ -599,11 +623,13 @@ gdf_error gdf_column_concat(gdf_column *output, gdf_column *columns_to_concat[],
 // LSB-first mask concatenation (the layout of every other mask in libgdf).  The reference
 // returns GDF_VALIDITY_MISSING for a dtype mismatch (sic, :391) and so does this.
 gdf_error gpu_concat(gdf_column *lhs, gdf_column *rhs, gdf_column *output) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   GDF_REQUIRE(lhs && rhs && output, GDF_DATASET_EMPTY);
   GDF_REQUIRE(lhs->dtype == output->dtype && rhs->dtype == output->dtype, GDF_VALIDITY_MISSING);
   GDF_REQUIRE(output->size == lhs->size + rhs->size, GDF_COLUMN_SIZE_MISMATCH);
   gdf_column *both[2] = {lhs, rhs};
   return gdf_column_concat(output, both, 2);
+  });
 }
 
 }  // extern "C"

@@ -1656,11 +1656,79 @@ __device__ __forceinline__ void gbp_pack32(const KeyTable &t, const GbKeyPlan &p
   }
 }
 
+// ---------------------------------------------------------------------------
+// HOT WINDOW (round 4).  Skewed keys (C5: Zipf(1) over 1e6 values x 16) put a large share of the rows on a few thousand groups:
+// the 4096 ids of ONE aligned key window -- the densest one of a strided sample -- are aggregated by the scatter kernel itself,
+// in per-workgroup LDS accumulators (sum / row count / valid count, the layout gb_part_aggregate keeps per partition), and
+// merged into the global cells with one atomic per touched id and workgroup at the end of the kernel.  Those rows are never
+// counted (gbp_count skips them), never staged, never written as records and never read by the aggregation: C5's window
+// (k0 < 256) holds 42 % of the rows.  The window is a performance guess only -- any window gives the same result -- and the
+// plain kernels run when the sample finds no window worth the LDS (uniform keys).
+// LDS: 64 KB of accumulators leave room for GBP_HOT_CAP staged records per 8192-row tile; a tile with more cold rows than that
+// (the sample mispredicted) is regrouped and flushed in rounds.
+// ---------------------------------------------------------------------------
+constexpr int GBP_HOT_BITS = 12;
+constexpr uint32_t GBP_HOT_IDS = 1u << GBP_HOT_BITS;
+constexpr uint32_t GBP_NO_HOT = 0xffffffffu;
+constexpr int GBP_HOT_SAMPLE_WINDOWS = 64;       // strided windows of 1024 rows: 65536 sampled rows
+struct GbHot {
+  uint32_t window;                 // key >> GBP_HOT_BITS of the hot ids (the key WITHOUT its validity bit)
+  unsigned long long *gacc;        // the global cells the partials are merged into (indexed by key)
+  unsigned int *grows, *gvalid;
+  int dbg;                         // LAB build: ablation bits (knob GDF_GBP_HOT_DBG), 0 in production
+};
+
+// out[0] = the densest window of GBP_HOT_IDS ids among the sampled rows, out[1] = its rows, out[2] = sampled rows with a valid,
+// in-range key.  One workgroup; nwin <= 4096 windows.
+__global__ __launch_bounds__(1024) void gbp_sample_hot(KeyTable t, GbKeyPlan plan, uint32_t nwin, unsigned int *__restrict__ out) {
+  __shared__ uint32_t cnt[4096];
+  __shared__ unsigned long long best[1024 / WAVE];
+  __shared__ uint32_t tot[1024 / WAVE];
+  for (uint32_t q = threadIdx.x; q < 4096; q += 1024) cnt[q] = 0;
+  block_sync();
+  const int64_t stride = t.nrows / GBP_HOT_SAMPLE_WINDOWS;
+  uint32_t good = 0;
+  for (int w0 = 0; w0 < GBP_HOT_SAMPLE_WINDOWS; w0 += 8) {
+    uint32_t src[8], key[8], okmask, outmask;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int64_t i = (int64_t)(w0 + k) * stride + threadIdx.x;
+      src[k] = (uint32_t)(i < t.nrows ? i : t.nrows - 1);
+    }
+    gbp_pack32<8, -1, -1>(t, plan, src, key, okmask, outmask);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t w = key[k] >> GBP_HOT_BITS;
+      if (((okmask >> k) & 1u) && !((outmask >> k) & 1u) && w < nwin) { atomicAdd(&cnt[w], 1u); ++good; }
+    }
+  }
+  block_sync();
+  unsigned long long b = 0;          // count << 32 | (0xffffffff - window): the maximum is the densest window, ties to the lowest
+  for (uint32_t q = threadIdx.x; q < nwin; q += 1024) {
+    const unsigned long long c = ((unsigned long long)cnt[q] << 32) | (0xffffffffu - q);
+    b = c > b ? c : b;
+  }
+  for (int d = 1; d < WAVE; d <<= 1) {
+    const unsigned long long o = ((unsigned long long)(uint32_t)__shfl_xor((int)(b >> 32), d) << 32) | (uint32_t)__shfl_xor((int)b, d);
+    b = o > b ? o : b;
+  }
+  good = wave_reduce_add(good);
+  if (lane_id() == 0) { best[threadIdx.x / WAVE] = b; tot[threadIdx.x / WAVE] = good; }
+  block_sync();
+  if (threadIdx.x == 0) {
+    uint32_t all = 0;
+    for (int w = 0; w < 1024 / WAVE; ++w) { b = best[w] > b ? best[w] : b; all += tot[w]; }
+    out[0] = 0xffffffffu - (uint32_t)b;
+    out[1] = (uint32_t)(b >> 32);
+    out[2] = all;
+  }
+}
+
 // flags[0] += rows dropped for a null key, flags[1] = 1 when a key lies outside the plan's ranges
 template <int K0 = -1, int K1 = -1>
 __global__ __launch_bounds__(GBP_THREADS) void gbp_count(KeyTable t, GbKeyPlan plan, int low, int vbit, uint32_t nparts, int64_t chunk,
                                                          int nchunks, uint32_t *__restrict__ hist, unsigned int *__restrict__ flags,
-                                                         uint32_t qstride, uint32_t cstride) {
+                                                         uint32_t qstride, uint32_t cstride, uint32_t hot_window) {
   __shared__ uint32_t cnt[GBP_MAX_PARTS];
   constexpr int B = (K0 >= 0 && K1 == -2) ? 12 : 8;       // one key column to read: half as many rows again in flight per thread (77 VGPRs at 8; 16 spill)
   unsigned int dropped = 0, outside = 0;
@@ -1693,7 +1761,8 @@ __global__ __launch_bounds__(GBP_THREADS) void gbp_count(KeyTable t, GbKeyPlan p
         const bool okk = (okmask >> k) & 1u;
         if (live && !okk) ++dropped;
         if (live && okk && ((outmask >> k) & 1u)) outside = 1;
-        bool mine = live && okk;
+        // (rows of the hot window are aggregated by the scatter kernel, GbHot: they get no place among the records)
+        bool mine = live && okk && (key[k] >> GBP_HOT_BITS) != hot_window;
         const uint32_t part = (key[k] << vbit) >> low;
         // the partition id of the wave's first live lane by ballot, the rest one LDS atomic each.  (One round: C5's hot partition holds
         // 45 % of the rows, the next one 5 %; a second ballot round cost more than the same-address atomics it saved -- 1.71 -> 1.50 ms,
@@ -1919,17 +1988,24 @@ __device__ __forceinline__ uint32_t gbp_opaque_tid() {
 // Tried and dropped (tools/gpu/r2be.sh, r2bg.sh): touching every 128-byte line of the next tile with a 4-byte load during the flush
 // (8.1 -> 12.9 ms: 64 lines per wave instruction are 64 requests), and jk_scatter1's pipeline -- the next tile's key words requested
 // before the flush and held in registers across it (9.34 against 9.40 ms, for 6 spilled registers).
-template <bool VBIT, int K0, int K1, bool VMASK>
+//   * HOT (round 4, GbHot above): the rows of the hot key window are folded into LDS accumulators instead of being staged; the
+//     stage then holds GBP_HOT_CAP records and a tile with more cold rows is regrouped and flushed in rounds.
+constexpr int GBP_HOT_CAP = 5 * GBP_SC_THREADS;         // 5120 records: 60 KB next to 64 KB of accumulators and 32 KB of counters
+template <bool VBIT, int K0, int K1, bool VMASK, bool HOT = false>
 __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter_static(KeyTable t, GbKeyPlan plan, GbVal val, int fold_op, int low,
                                                                   uint32_t nparts, int64_t chunk, int nchunks, const uint32_t *__restrict__ offs,
                                                                   GbRec *__restrict__ rec_out, unsigned int *__restrict__ flags,
-                                                                  uint32_t qstride, uint32_t cstride) {
+                                                                  uint32_t qstride, uint32_t cstride, GbHot hot) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gbp_lds[];
+  constexpr int CAP = HOT ? GBP_HOT_CAP : GBP_SC_TILE;                       // staged records per round
+  constexpr int FLUSH_ITEMS = CAP / GBP_SC_THREADS;
   uint64_t *stage = reinterpret_cast<uint64_t *>(gbp_lds);
-  uint32_t *stage_k = reinterpret_cast<uint32_t *>(stage + GBP_SC_TILE);
-  uint32_t *hist = stage_k + GBP_SC_TILE;
+  unsigned long long *hacc = reinterpret_cast<unsigned long long *>(stage + CAP);      // HOT: [GBP_HOT_IDS] accumulators
+  uint32_t *stage_k = reinterpret_cast<uint32_t *>(hacc + (HOT ? GBP_HOT_IDS : 0));
+  uint32_t *hist = stage_k + CAP;
   uint32_t *start = hist + GBP_MAX_PARTS + 4, *gbase = start + GBP_MAX_PARTS, *cursor = gbase + GBP_MAX_PARTS;
   uint32_t *wave_tot = cursor + GBP_MAX_PARTS;
+  unsigned int *hrows = wave_tot + GBP_SC_THREADS / WAVE, *hvalid = hrows + GBP_HOT_IDS;   // HOT: rows / valid values per hot id
   constexpr int PER = GBP_MAX_PARTS / GBP_SC_THREADS;
   constexpr int vbit = VBIT ? 1 : 0;
   using W0 = typename std::conditional<K0 == K_I64, long long, int32_t>::type;
@@ -1957,6 +2033,9 @@ __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter_static(KeyTable t,
     }
   };
   for (uint32_t q = threadIdx.x; q < GBP_MAX_PARTS; q += GBP_SC_THREADS) hist[q] = 0;
+  if constexpr (HOT) {
+    for (uint32_t i = threadIdx.x; i < GBP_HOT_IDS; i += GBP_SC_THREADS) { hacc[i] = acc_identity(fold_op); hrows[i] = 0; hvalid[i] = 0; }
+  }
   block_sync();
   for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
     for (uint32_t q = threadIdx.x; q < nparts; q += GBP_SC_THREADS) cursor[q] = offs[(size_t)q * qstride + (size_t)c * cstride];
@@ -2006,11 +2085,33 @@ __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter_static(KeyTable t,
         }
       }
       uint32_t part[GBP_ITEMS], rk[GBP_ITEMS];
-      const uint32_t livemask = okmask & inrange;
+      uint32_t livemask = okmask & inrange;
 #pragma unroll
       for (int k = 0; k < GBP_ITEMS; ++k) {
         k32[k] = (k32[k] << vbit) | (uint32_t)(VBIT && ((vmask >> k) & 1u));
         part[k] = k32[k] >> low;
+      }
+      if constexpr (HOT) {
+        // rows of the hot window: folded into this workgroup's accumulators (exactly what gb_part_aggregate does with a record)
+        // and taken out of the tile
+        const bool flt = is_flt(val.kind);
+        uint32_t hotmask = 0;
+#pragma unroll
+        for (int k = 0; k < GBP_ITEMS; ++k) hotmask |= (uint32_t)((k32[k] >> (GBP_HOT_BITS + vbit)) == hot.window) << k;
+        hotmask &= livemask;
+#pragma unroll
+        for (int k = 0; k < GBP_ITEMS; ++k) {
+          if (((hotmask >> k) & 1u) && !(LAB_BITS(hot.dbg) & 1)) {          // (LAB bit 1: hot rows vanish without their atomics)
+            const uint32_t id = (k32[k] >> vbit) & (GBP_HOT_IDS - 1u);
+            atomicAdd(&hrows[id], 1u);
+            if (!VBIT || (k32[k] & 1u)) {
+              acc_fold(fold_op, flt, &hacc[id], acc[k]);
+              if (VBIT) atomicAdd(&hvalid[id], 1u);
+            }
+          }
+        }
+        livemask &= ~hotmask;
+        if (LAB_BITS(hot.dbg) & 4) livemask = 0;            // (LAB bit 4: no cold row travels)
       }
       gbp_rank<GBP_ITEMS>(hist, part, livemask, rk);
       block_sync();
@@ -2037,39 +2138,64 @@ __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter_static(KeyTable t,
       for (int w = 0; w < GBP_SC_THREADS / WAVE; ++w) total += wave_tot[w];
       uint32_t st[GBP_ITEMS];          // all reads of start[] first (one LDS round trip, not one per row), then the writes
 #pragma unroll
-      for (int k = 0; k < GBP_ITEMS; ++k) st[k] = start[part[k] & (GBP_MAX_PARTS - 1)];
+      for (int k = 0; k < GBP_ITEMS; ++k) st[k] = start[part[k] & (GBP_MAX_PARTS - 1)] + rk[k];
+      // HOT: the stage holds CAP < TILE records; a tile with more cold rows takes several rounds (`total` is workgroup-uniform)
+      for (uint32_t round0 = 0;;) {
 #pragma unroll
-      for (int k = 0; k < GBP_ITEMS; ++k) {
-        if ((livemask >> k) & 1u) {
-          const uint32_t pos = st[k] + rk[k];
-          stage_k[pos] = k32[k];
-          stage[pos] = acc[k];
+        for (int k = 0; k < GBP_ITEMS; ++k) {
+          const uint32_t pos = st[k] - round0;               // (unsigned: positions below round0 wrap beyond CAP)
+          if (((livemask >> k) & 1u) && (!HOT || pos < (uint32_t)CAP)) {
+            stage_k[pos] = k32[k];
+            stage[pos] = acc[k];
+          }
         }
+        block_sync();
+        // flush: every LDS read first (the record, then its partition's base), then the stores; slots beyond the round re-read slot 0
+        uint32_t kk[FLUSH_ITEMS], gb[FLUSH_ITEMS];
+        uint64_t vv[FLUSH_ITEMS];
+        const uint32_t ftid = gbp_opaque_tid();
+        const uint32_t left = total - round0, cnt = (HOT && left > (uint32_t)CAP) ? (uint32_t)CAP : left;
+#pragma unroll
+        for (int k = 0; k < FLUSH_ITEMS; ++k) {
+          const uint32_t j = ftid + k * GBP_SC_THREADS;
+          const uint32_t jc = j < cnt ? j : 0u;
+          kk[k] = stage_k[jc];
+          vv[k] = stage[jc];
+        }
+#pragma unroll
+        for (int k = 0; k < FLUSH_ITEMS; ++k) gb[k] = gbase[(kk[k] >> low) & (GBP_MAX_PARTS - 1)];
+#pragma unroll
+        for (int k = 0; k < FLUSH_ITEMS; ++k) {
+          const uint32_t j = ftid + k * GBP_SC_THREADS;
+          if (j < cnt && !(LAB_BITS(hot.dbg) & 2)) rec_out[gb[k] + round0 + j] = GbRec{kk[k], (uint32_t)vv[k], (uint32_t)(vv[k] >> 32)};   // (LAB bit 2: no stores)
+        }
+        if (!HOT || left <= (uint32_t)CAP) break;
+        round0 += (uint32_t)CAP;
+        block_sync();                  // the next round overwrites the stage
       }
-      block_sync();
-      // flush: every LDS read first (the record, then its partition's base), then the stores; slots beyond `total` re-read slot 0
-      uint32_t kk[GBP_ITEMS], gb[GBP_ITEMS];
-      uint64_t vv[GBP_ITEMS];
-      const uint32_t ftid = gbp_opaque_tid();
-#pragma unroll
-      for (int k = 0; k < GBP_ITEMS; ++k) {
-        const uint32_t j = ftid + k * GBP_SC_THREADS;
-        const uint32_t jc = j < total ? j : 0u;
-        kk[k] = stage_k[jc];
-        vv[k] = stage[jc];
-      }
-#pragma unroll
-      for (int k = 0; k < GBP_ITEMS; ++k) gb[k] = gbase[(kk[k] >> low) & (GBP_MAX_PARTS - 1)];
-#pragma unroll
-      for (int k = 0; k < GBP_ITEMS; ++k) {
-        const uint32_t j = ftid + k * GBP_SC_THREADS;
-        if (j < total) rec_out[gb[k] + j] = GbRec{kk[k], (uint32_t)vv[k], (uint32_t)(vv[k] >> 32)};
+    }
+  }
+  if constexpr (HOT) {
+    // merge this workgroup's partials into the cells that own the keys (cell index = key), as gb_part_aggregate merges a unit
+    block_sync();
+    const bool flt = is_flt(val.kind);
+    for (uint32_t i = threadIdx.x; i < GBP_HOT_IDS; i += GBP_SC_THREADS) {
+      const unsigned int r = hrows[i];
+      if (!r) continue;
+      const size_t cell = ((size_t)hot.window << GBP_HOT_BITS) | i;
+      atomicAdd(&hot.grows[cell], r);
+      if (VBIT) {
+        const unsigned int cv = hvalid[i];
+        if (cv) { atomicAdd(&hot.gvalid[cell], cv); acc_fold(fold_op, flt, &hot.gacc[cell], hacc[i]); }
+      } else {
+        acc_fold(fold_op, flt, &hot.gacc[cell], hacc[i]);
       }
     }
   }
 }
-static constexpr size_t gbp_scatter_lds() {
-  return 12 * (size_t)GBP_SC_TILE + 4 * (size_t)(4 * GBP_MAX_PARTS + 4 + GBP_SC_THREADS / WAVE) + 16;
+static constexpr size_t gbp_scatter_lds(bool hot = false) {
+  return hot ? 12 * (size_t)GBP_HOT_CAP + 16 * (size_t)GBP_HOT_IDS + 4 * (size_t)(4 * GBP_MAX_PARTS + 4 + GBP_SC_THREADS / WAVE) + 16
+             : 12 * (size_t)GBP_SC_TILE + 4 * (size_t)(4 * GBP_MAX_PARTS + 4 + GBP_SC_THREADS / WAVE) + 16;
 }
 
 // number of non-empty cells per block of 1024 cells
@@ -2455,6 +2581,8 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
   uint64_t *pin = pa.as<uint64_t>(), *pout = pb.as<uint64_t>();
   struct { unsigned long long varying; unsigned int dropped, pad; } hf{};
   std::vector<uint32_t> hp;             // partition starts (fused: from the scanned histogram)
+  DevBuf gacc, grows, gvalid;           // the global cells (one per key: accumulator, rows, valid values)
+  bool cells_ready = false;             // made before the scatter kernel when it aggregates a hot window (GbHot)
   if (fused) {
     if constexpr (sizeof(K) == 4) {
       const uint32_t P = 1u << part_bits;
@@ -2489,9 +2617,46 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
       // the knob only times the scatter.)
       const bool chunk_major = lab::knob_on("GDF_GBP_CHUNK_MAJOR");
       const uint32_t qstride = chunk_major ? 1u : (uint32_t)nchunks, cstride = chunk_major ? P : 1u;
+      // HOT WINDOW (GbHot): the densest aligned window of GBP_HOT_IDS ids in a strided sample, when it holds enough of the rows to
+      // pay for 64 KB of LDS in the scatter kernel.  Statically typed scatter kernels only; a key column the count does not read
+      // (skip_low) must lie below the window bits, so that the count can tell hot rows from their first column alone.
+      uint32_t hot_window = GBP_NO_HOT;
+      const bool lean_sig = key_sig && val_sig && !lab::knob_on("GDF_GBP_OLD");
+      if (lean_sig && id_bits == GB_PART_ID_BITS && !chunk_major && n >= ((int64_t)1 << 22) && !lab::path_on("GDF_GBP_NO_HOT") &&
+          (!skip_low || sp.shift[1] + sp.bits[1] <= GBP_HOT_BITS)) {
+        const uint32_t nwin = 1u << (sp.total_bits - GBP_HOT_BITS);
+        const long long forced = lab::path_int("GDF_GBP_HOT_WINDOW", -1);       // test switch: any window gives the same result
+        if (forced >= 0) {
+          hot_window = (uint32_t)forced < nwin ? (uint32_t)forced : nwin - 1;
+        } else {
+          DevBuf d_hot;
+          RMM_TRY(d_hot.alloc(sizeof(unsigned int) * 4));
+          GDF_LAUNCH("gbp_sample_hot", gbp_sample_hot, dim3(1), dim3(1024), 0, stream0(), t, sp, nwin, d_hot.as<unsigned int>());
+          HIP_CHECK_LAST();
+          unsigned int h[3] = {0, 0, 0};
+          HIP_TRY(read_back(h, d_hot.p, sizeof(h)));
+          // worth it from a fifth of the rows (the accumulators cost the stage 3/8 of its records: rounds, if the tile's cold rows
+          // do not fit); the stage takes a whole tile's cold rows while the window holds more than 3/8
+          if (h[2] >= 1024 && (double)h[1] >= 0.2 * (double)h[2]) hot_window = h[0];
+        }
+      }
+      // the cells the partial aggregates are merged into: made BEFORE the scatter kernel, which merges the hot window's
+      if (hot_window != GBP_NO_HOT) {
+        const size_t cells = (size_t)P << id_bits, cells_pad = (cells + 1023) / 1024 * 1024;
+        RMM_TRY(gacc.alloc(sizeof(uint64_t) * cells_pad));
+        RMM_TRY(grows.alloc(sizeof(unsigned int) * cells_pad));
+        if (vbit) RMM_TRY(gvalid.alloc(sizeof(unsigned int) * cells_pad));
+        GDF_LAUNCH("gb_fill", gb_fill_u64, dim3(stream_grid(cells_pad, 1024)), dim3(256), 0, stream0(), gacc.as<unsigned long long>(),
+                   (unsigned long long)acc_identity_host(fold_op), (uint32_t)cells_pad);
+        HIP_TRY(hipMemsetAsync(grows.p, 0, sizeof(unsigned int) * cells_pad, stream0()));
+        if (vbit) HIP_TRY(hipMemsetAsync(gvalid.p, 0, sizeof(unsigned int) * cells_pad, stream0()));
+        cells_ready = true;
+      }
+      const GbHot hot{hot_window, gacc.as<unsigned long long>(), grows.as<unsigned int>(), gvalid.as<unsigned int>(),
+                      (int)lab::knob_int("GDF_GBP_HOT_DBG", 0)};
       auto count = [&](auto kernel) {
         GDF_LAUNCH("gbp_count", kernel, dim3(nchunks < NUM_CU * 2 ? nchunks : NUM_CU * 2), dim3(GBP_THREADS), 0, stream0(), t, sp, low, vbit, P,
-                   chunk, nchunks, hist.as<uint32_t>(), d_flags.as<unsigned int>(), qstride, cstride);
+                   chunk, nchunks, hist.as<uint32_t>(), d_flags.as<unsigned int>(), qstride, cstride, hot_window);
       };
       if (k0 == K_I32 && ck1 == -2) count(gbp_count<K_I32, -2>);
       else if (k0 == K_I64 && ck1 == -2) count(gbp_count<K_I64, -2>);
@@ -2501,7 +2666,8 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
       else if (k0 == K_I64 && ck1 == K_I64) count(gbp_count<K_I64, K_I64>);
       else count(gbp_count<-1, -1>);
       GDF_TRY(scan_u32(hist.as<uint32_t>(), hist.as<uint32_t>(), (size_t)P * nchunks + 1, false));
-      const size_t slds = gbp_scatter_lds();
+      const bool is_hot = hot_window != GBP_NO_HOT;
+      const size_t slds = gbp_scatter_lds(is_hot);
       const bool lean = !lab::knob_on("GDF_GBP_OLD");              // A/B switch: the scatter kernel with the type switches for every shape
       const bool sig = lean && key_sig && val_sig;
       const dim3 sgrid(nchunks < NUM_CU ? nchunks : NUM_CU);
@@ -2509,13 +2675,15 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
         const int vm = vbit ? 2 : (val.valid ? 1 : 0);        // 0: no mask, 1: mask, 2: mask + validity bit in the key
         auto scatter = [&](auto kernel) -> gdf_error {
           HIP_TRY(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
-          GDF_LAUNCH("gbp_scatter", kernel, sgrid, dim3(GBP_SC_THREADS), slds, stream0(), t, sp, val, fold_op, low, P, chunk, nchunks,
-                     (const uint32_t *)hist.as<uint32_t>(), ka.as<GbRec>(), d_flags.as<unsigned int>(), qstride, cstride);
+          GDF_LAUNCH(is_hot ? "gbp_scatter_hot" : "gbp_scatter", kernel, sgrid, dim3(GBP_SC_THREADS), slds, stream0(), t, sp, val, fold_op, low, P, chunk,
+                     nchunks, (const uint32_t *)hist.as<uint32_t>(), ka.as<GbRec>(), d_flags.as<unsigned int>(), qstride, cstride, hot);
           return GDF_SUCCESS;
         };
 #define GBP_SIG(K0, K1)                                                                                                          \
         if (k0 == K0 && k1 == K1) {                                                                                                 \
-          if (vm == 2) GDF_TRY(scatter(gbp_scatter_static<true, K0, K1, true>));                                                   \
+          if (vm == 2 && is_hot) GDF_TRY(scatter(gbp_scatter_static<true, K0, K1, true, true>));                                   \
+          else if (vm == 0 && is_hot) GDF_TRY(scatter(gbp_scatter_static<false, K0, K1, false, true>));                            \
+          else if (vm == 2) GDF_TRY(scatter(gbp_scatter_static<true, K0, K1, true>));                                              \
           else if (vm == 1) GDF_TRY(scatter(gbp_scatter_static<false, K0, K1, true>));                                             \
           else GDF_TRY(scatter(gbp_scatter_static<false, K0, K1, false>));                                                         \
         }
@@ -2566,7 +2734,7 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
     const uint32_t P = 1u << part_bits;
     const size_t cells = (size_t)P << id_bits;
     const size_t cells_pad = (cells + 1023) / 1024 * 1024;
-    DevBuf pstart, d_units, gacc, grows, gvalid, bcnt, ng;
+    DevBuf pstart, d_units, bcnt, ng;
     if (!fused) {
       const uint64_t himask = low >= 64 ? 0ULL : ~((1ULL << low) - 1ULL);
       if constexpr (sizeof(K) == 4) GDF_TRY(radix_sort_pairs_k32_u64(kin, kout, pin, pout, nn, hf.varying & himask));
@@ -2583,19 +2751,21 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
         units.push_back(GbPartUnit{b, std::min(GB_PART_UNIT_ROWS, hp[p + 1] - b), p, 0u});
     RMM_TRY(d_units.alloc(sizeof(GbPartUnit) * (units.size() ? units.size() : 1)));
     HIP_TRY(hipMemcpyAsync(d_units.p, units.data(), sizeof(GbPartUnit) * units.size(), hipMemcpyHostToDevice, stream0()));
-    RMM_TRY(gacc.alloc(sizeof(uint64_t) * cells_pad));
-    RMM_TRY(grows.alloc(sizeof(unsigned int) * cells_pad));
-    if (vbit) RMM_TRY(gvalid.alloc(sizeof(unsigned int) * cells_pad));
     RMM_TRY(bcnt.alloc(sizeof(uint32_t) * (cells_pad / 1024)));
     RMM_TRY(ng.alloc(sizeof(unsigned int)));
-    GDF_LAUNCH("gb_fill", gb_fill_u64, dim3(stream_grid(cells_pad, 1024)), dim3(256), 0, stream0(), gacc.as<unsigned long long>(),
-               (unsigned long long)acc_identity_host(fold_op), (uint32_t)cells_pad);
-    HIP_TRY(hipMemsetAsync(grows.p, 0, sizeof(unsigned int) * cells_pad, stream0()));
-    if (vbit) HIP_TRY(hipMemsetAsync(gvalid.p, 0, sizeof(unsigned int) * cells_pad, stream0()));
+    if (!cells_ready) {
+      RMM_TRY(gacc.alloc(sizeof(uint64_t) * cells_pad));
+      RMM_TRY(grows.alloc(sizeof(unsigned int) * cells_pad));
+      if (vbit) RMM_TRY(gvalid.alloc(sizeof(unsigned int) * cells_pad));
+      GDF_LAUNCH("gb_fill", gb_fill_u64, dim3(stream_grid(cells_pad, 1024)), dim3(256), 0, stream0(), gacc.as<unsigned long long>(),
+                 (unsigned long long)acc_identity_host(fold_op), (uint32_t)cells_pad);
+      HIP_TRY(hipMemsetAsync(grows.p, 0, sizeof(unsigned int) * cells_pad, stream0()));
+      if (vbit) HIP_TRY(hipMemsetAsync(gvalid.p, 0, sizeof(unsigned int) * cells_pad, stream0()));
+    }
     const size_t plds = ((size_t)1 << id_bits) * (vbit ? 16 : 12) + 16;
-    bool launched = false;
+    bool launched = units.empty();          // (every row in the hot window: the scatter kernel aggregated them all)
     if constexpr (sizeof(K) == 4) {
-      if (fused) {
+      if (fused && !launched) {
         launched = true;
         if (vbit) {
           HIP_TRY(hipFuncSetAttribute((const void *)gb_part_aggregate<true, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
@@ -2941,26 +3111,36 @@ extern "C" {
 
 gdf_error gdf_group_by_sum(int ncols, gdf_column **cols, gdf_column *col_agg, gdf_column *out_col_indices,
                            gdf_column **out_col_values, gdf_column *out_col_agg, gdf_context *ctxt) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   return group_by_single(ncols, cols, col_agg, out_col_indices, out_col_values, out_col_agg, ctxt, OP_SUM);
+  });
 }
 gdf_error gdf_group_by_min(int ncols, gdf_column **cols, gdf_column *col_agg, gdf_column *out_col_indices,
                            gdf_column **out_col_values, gdf_column *out_col_agg, gdf_context *ctxt) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   return group_by_single(ncols, cols, col_agg, out_col_indices, out_col_values, out_col_agg, ctxt, OP_MIN);
+  });
 }
 gdf_error gdf_group_by_max(int ncols, gdf_column **cols, gdf_column *col_agg, gdf_column *out_col_indices,
                            gdf_column **out_col_values, gdf_column *out_col_agg, gdf_context *ctxt) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   return group_by_single(ncols, cols, col_agg, out_col_indices, out_col_values, out_col_agg, ctxt, OP_MAX);
+  });
 }
 gdf_error gdf_group_by_avg(int ncols, gdf_column **cols, gdf_column *col_agg, gdf_column *out_col_indices,
                            gdf_column **out_col_values, gdf_column *out_col_agg, gdf_context *ctxt) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   return group_by_single(ncols, cols, col_agg, out_col_indices, out_col_values, out_col_agg, ctxt, OP_AVG);
+  });
 }
 gdf_error gdf_group_by_count(int ncols, gdf_column **cols, gdf_column *col_agg, gdf_column *out_col_indices,
                              gdf_column **out_col_values, gdf_column *out_col_agg, gdf_context *ctxt) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   if (nullptr == ctxt) return GDF_DATASET_EMPTY;
   // flag_distinct selects COUNT_DISTINCT (sqls_ops.cu:1483-1486), which only the SORT method implements
   return group_by_single(ncols, cols, col_agg, out_col_indices, out_col_values, out_col_agg, ctxt,
                          ctxt->flag_distinct ? OP_COUNT_DISTINCT : OP_COUNT);
+  });
 }
 
 }  // extern "C"

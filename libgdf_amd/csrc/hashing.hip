@@ -960,6 +960,7 @@ static gdf_error hash_partition_two_level(int ncols, gdf_column *input[], const 
 extern "C" {
 
 gdf_error gdf_hash(int num_cols, gdf_column **input, gdf_hash_func hash, gdf_column *output) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   // argument checks in the order of hashing.cu:85-110
   if (0 == num_cols || nullptr == input || nullptr == output) return GDF_DATASET_EMPTY;
   if (output->dtype != GDF_INT32) return GDF_UNSUPPORTED_DTYPE;
@@ -979,9 +980,11 @@ gdf_error gdf_hash(int num_cols, gdf_column **input, gdf_hash_func hash, gdf_col
   HIP_CHECK_LAST();
   HIP_TRY(hipStreamSynchronize(stream0()));
   return GDF_SUCCESS;
+  });
 }
 
 gdf_error gpu_hash_columns(gdf_column **columns_to_hash, int num_columns, gdf_column *output_column, void *stream) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   (void)stream;      // a cudaStream_t* in the reference; the work is complete on return either way
   GDF_REQUIRE(columns_to_hash && num_columns > 0 && output_column && columns_to_hash[0], GDF_DATASET_EMPTY);
   GDF_REQUIRE(num_columns <= MAX_KEY_COLS, GDF_JOIN_TOO_MANY_COLUMNS);
@@ -1010,9 +1013,11 @@ gdf_error gpu_hash_columns(gdf_column **columns_to_hash, int num_columns, gdf_co
   }
   HIP_TRY(hipStreamSynchronize(stream0()));
   return GDF_SUCCESS;
+  });
 }
 
 gdf_error gdf_amd_narrow_keys(gdf_column *in, int64_t lo, int64_t hi, gdf_column *out) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   GDF_REQUIRE(in && out, GDF_DATASET_EMPTY);
   GDF_REQUIRE(elem_kind(in->dtype) == K_I64 && out->dtype == GDF_INT32, GDF_UNSUPPORTED_DTYPE);
   GDF_REQUIRE(in->size == out->size, GDF_COLUMN_SIZE_MISMATCH);
@@ -1026,10 +1031,12 @@ gdf_error gdf_amd_narrow_keys(gdf_column *in, int64_t lo, int64_t hi, gdf_column
   HIP_CHECK_LAST();
   HIP_TRY(hipStreamSynchronize(stream0()));
   return GDF_SUCCESS;
+  });
 }
 
 gdf_error gdf_amd_shuffle_partition(gdf_column *keys, int narrow, int64_t lo, int64_t hi, int32_t row_base, int num_partitions,
                                     gdf_column *out_keys, gdf_column *out_rows, int partition_offsets[]) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   GDF_REQUIRE(keys && out_keys && out_rows && partition_offsets, GDF_DATASET_EMPTY);
   GDF_REQUIRE(num_partitions > 0 && num_partitions <= HP_MAX_LDS_PARTS, GDF_INVALID_API_CALL);
   GDF_REQUIRE(!keys->valid && !out_keys->valid && !out_rows->valid, GDF_VALIDITY_UNSUPPORTED);
@@ -1102,10 +1109,12 @@ gdf_error gdf_amd_shuffle_partition(gdf_column *keys, int narrow, int64_t lo, in
   HIP_TRY(hipMemcpyAsync(partition_offsets, starts.p, sizeof(int) * P, hipMemcpyDeviceToHost, stream0()));
   HIP_TRY(hipStreamSynchronize(stream0()));
   return GDF_SUCCESS;
+  });
 }
 
 gdf_error gdf_amd_shuffle_partition_stable(gdf_column *keys, int narrow, int64_t lo, int64_t hi, int num_partitions,
                                            gdf_column *out_keys, uint64_t *bitmaps, int partition_offsets[]) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   GDF_REQUIRE(keys && out_keys && bitmaps && partition_offsets, GDF_DATASET_EMPTY);
   GDF_REQUIRE(num_partitions > 0 && num_partitions <= SHT_MAX_PARTS, GDF_INVALID_API_CALL);
   GDF_REQUIRE(!keys->valid && !out_keys->valid, GDF_VALIDITY_UNSUPPORTED);
@@ -1157,11 +1166,13 @@ gdf_error gdf_amd_shuffle_partition_stable(gdf_column *keys, int narrow, int64_t
   HIP_TRY(hipMemcpyAsync(partition_offsets, starts.p, sizeof(int) * (P + drop), hipMemcpyDeviceToHost, stream0()));
   HIP_TRY(hipStreamSynchronize(stream0()));
   return GDF_SUCCESS;
+  });
 }
 
 gdf_error gdf_hash_partition(int num_input_cols, gdf_column *input[], int columns_to_hash[], int num_cols_to_hash,
                              int num_partitions, gdf_column *partitioned_output[], int partition_offsets[],
                              gdf_hash_func hash) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   // checks in the order of hashing.cu:573-607
   if (0 == num_input_cols || 0 == num_cols_to_hash || 0 == num_partitions || nullptr == input ||
       nullptr == partitioned_output || nullptr == columns_to_hash || nullptr == partition_offsets)
@@ -1299,6 +1310,7 @@ gdf_error gdf_hash_partition(int num_input_cols, gdf_column *input[], int column
   HIP_TRY(hipMemcpyAsync(partition_offsets, starts.p, sizeof(int) * P, hipMemcpyDeviceToHost, stream0()));
   HIP_TRY(hipStreamSynchronize(stream0()));
   return GDF_SUCCESS;
+  });
 }
 
 }  // extern "C"

@@ -5132,72 +5132,98 @@ extern "C" {
 __attribute__((visibility("default"))) gdf_error gdf_amd_debug_partition(gdf_column *col, int fb, uint64_t *out_key, int32_t *out_idx,
                                                                         uint32_t *out_fine_off, uint32_t *out_joinable,
                                                                         uint64_t *out_info) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   return debug_partition(col, fb, out_key, out_idx, out_fine_off, out_joinable, out_info);
+  });
 }
 
 // non-reference exports (include/gdf/gdf_amd_ext.h): a build relation partitioned once and probed many times
 __attribute__((visibility("default"))) gdf_error gdf_amd_join_build_create(gdf_column **build_cols, int num_cols, gdf_amd_join_build **out) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   return build_create(build_cols, num_cols, reinterpret_cast<PreparedBuild **>(out));
+  });
 }
 __attribute__((visibility("default"))) gdf_error gdf_amd_join_build_probe(gdf_amd_join_build *build, int left_join, gdf_column **probe_cols,
                                                                          int num_cols, gdf_column *probe_indices, gdf_column *build_indices) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   return build_probe(reinterpret_cast<PreparedBuild *>(build), left_join, probe_cols, num_cols, probe_indices, build_indices);
+  });
 }
 __attribute__((visibility("default"))) void gdf_amd_join_build_free(gdf_amd_join_build *build) {
   delete reinterpret_cast<PreparedBuild *>(build);
 }
 __attribute__((visibility("default"))) gdf_error gdf_amd_join_probe_begin(gdf_amd_join_build *build, size_t expected_rows, gdf_amd_join_probe **out) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   return accum_begin(reinterpret_cast<PreparedBuild *>(build), expected_rows, reinterpret_cast<ProbeAccum **>(out));
+  });
 }
 __attribute__((visibility("default"))) gdf_error gdf_amd_join_probe_add(gdf_amd_join_probe *probe, gdf_column **probe_cols, int num_cols) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   return accum_add(reinterpret_cast<ProbeAccum *>(probe), probe_cols, num_cols);
+  });
 }
 __attribute__((visibility("default"))) gdf_error gdf_amd_join_probe_finish(gdf_amd_join_probe *probe, gdf_column *probe_indices,
                                                                           gdf_column *build_indices) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   return accum_finish(reinterpret_cast<ProbeAccum *>(probe), probe_indices, build_indices);
+  });
 }
 
 // fused multi-GPU join (include/gdf/gdf_amd_ext.h)
 __attribute__((visibility("default"))) gdf_error gdf_amd_fj_plan(int world, int64_t build_rows_total, int64_t rows_max, double rows_per_key,
                                                                 int *fine_bits, int *coarse_bits, uint32_t *cap) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   return fj_plan(world, build_rows_total, rows_max, rows_per_key, fine_bits, coarse_bits, cap);
+  });
 }
 __attribute__((visibility("default"))) gdf_error gdf_amd_fj_send(gdf_column *keys, int64_t lo, int64_t hi, int world, int coarse_bits, uint32_t cap,
                                                                 uint32_t *out_keys, uint32_t *out_pos, uint32_t *out_fill, int *overflowed) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   return fj_send(keys, lo, hi, world, coarse_bits, cap, out_keys, out_pos, out_fill, overflowed);
+  });
 }
 __attribute__((visibility("default"))) gdf_error gdf_amd_fj_build_create(const uint32_t *recv_keys, const uint32_t *recv_fill, int world, int64_t lo,
                                                                         int fine_bits, int coarse_bits, uint32_t cap, int64_t expected_rows,
                                                                         gdf_amd_join_build **out) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   return fj_build_create(recv_keys, recv_fill, world, lo, fine_bits, coarse_bits, cap, expected_rows, reinterpret_cast<PreparedBuild **>(out));
+  });
 }
 __attribute__((visibility("default"))) gdf_error gdf_amd_fj_probe_add(gdf_amd_join_probe *probe, const uint32_t *recv_keys, const uint32_t *recv_fill,
                                                                      uint32_t cap, int64_t position_base, int64_t buffer_elems) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   return fj_probe_add(reinterpret_cast<ProbeAccum *>(probe), recv_keys, recv_fill, cap, position_base, buffer_elems);
+  });
 }
 
 gdf_error gdf_inner_join(gdf_column **left_cols, int num_left_cols, int left_join_cols[], gdf_column **right_cols,
                          int num_right_cols, int right_join_cols[], int num_cols_to_join, int result_num_cols,
                          gdf_column **result_cols, gdf_column *left_indices, gdf_column *right_indices,
                          gdf_context *join_context) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   return join_entry(JOIN_INNER, left_cols, num_left_cols, left_join_cols, right_cols, num_right_cols, right_join_cols,
                     num_cols_to_join, result_num_cols, result_cols, left_indices, right_indices, join_context);
+  });
 }
 
 gdf_error gdf_left_join(gdf_column **left_cols, int num_left_cols, int left_join_cols[], gdf_column **right_cols,
                         int num_right_cols, int right_join_cols[], int num_cols_to_join, int result_num_cols,
                         gdf_column **result_cols, gdf_column *left_indices, gdf_column *right_indices,
                         gdf_context *join_context) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   return join_entry(JOIN_LEFT, left_cols, num_left_cols, left_join_cols, right_cols, num_right_cols, right_join_cols,
                     num_cols_to_join, result_num_cols, result_cols, left_indices, right_indices, join_context);
+  });
 }
 
 gdf_error gdf_full_join(gdf_column **left_cols, int num_left_cols, int left_join_cols[], gdf_column **right_cols,
                         int num_right_cols, int right_join_cols[], int num_cols_to_join, int result_num_cols,
                         gdf_column **result_cols, gdf_column *left_indices, gdf_column *right_indices,
                         gdf_context *join_context) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   return join_entry(JOIN_FULL, left_cols, num_left_cols, left_join_cols, right_cols, num_right_cols, right_join_cols,
                     num_cols_to_join, result_num_cols, result_cols, left_indices, right_indices, join_context);
+  });
 }
 
 }  // extern "C"

@@ -23,6 +23,9 @@ void note_hip_error(hipError_t e, const char *what, const char *file, int line) 
 }
 
 gdf_error make_key_table(gdf_column **cols, int ncols, KeyTable *out) {
+  // test hook: stands in for a host allocation of the dispatch code failing (every relational entry point comes through here
+  // right after its argument checks and allocates std::vectors afterwards); the entry points turn it into GDF_MEMORYMANAGER_ERROR
+  if (lab::path_on("GDF_FORCE_HOST_ALLOC_FAILURE")) throw std::bad_alloc();
   if (ncols > MAX_KEY_COLS) return GDF_JOIN_TOO_MANY_COLUMNS;
   out->ncols = ncols;
   out->any_valid = 0;

@@ -156,9 +156,20 @@ void write_csv(Manager &m, std::ostream &os) {
 
 }  // namespace
 
+// no exception crosses the C boundary (the bookkeeping containers allocate): a failed host allocation is an out-of-memory answer
+template <class F>
+static inline rmmError_t rmm_guarded(F &&body) noexcept {
+  try {
+    return body();
+  } catch (...) {
+    return RMM_ERROR_OUT_OF_MEMORY;
+  }
+}
+
 extern "C" {
 
 rmmError_t rmmInitialize(rmmOptions_t *options) {
+  return rmm_guarded([&]() -> rmmError_t {
   Manager &m = Manager::get();
   std::lock_guard<std::mutex> g(m.mu);
   if (options) m.opt = *options;
@@ -173,9 +184,11 @@ rmmError_t rmmInitialize(rmmOptions_t *options) {
     m.cached_bytes += want;
   }
   return RMM_SUCCESS;
+  });
 }
 
 rmmError_t rmmFinalize(void) {
+  return rmm_guarded([&]() -> rmmError_t {
   Manager &m = Manager::get();
   {
     std::lock_guard<std::mutex> g(m.mu);
@@ -189,6 +202,7 @@ rmmError_t rmmFinalize(void) {
   m.events.clear();
   m.current.clear();
   return RMM_SUCCESS;
+  });
 }
 
 const char *rmmGetErrorString(rmmError_t errcode) {
@@ -205,6 +219,7 @@ const char *rmmGetErrorString(rmmError_t errcode) {
 }
 
 rmmError_t rmmAlloc(void **ptr, size_t size, cudaStream_t stream) {
+  return rmm_guarded([&]() -> rmmError_t {
   Manager &m = Manager::get();
   LogScope log(m, 0, nullptr, size, stream);
   if (!ptr && !size) return RMM_SUCCESS;
@@ -214,9 +229,11 @@ rmmError_t rmmAlloc(void **ptr, size_t size, cudaStream_t stream) {
   else r = map_hip(hipMalloc(ptr, size));
   if (r == RMM_SUCCESS) log.ptr = *ptr;
   return r;
+  });
 }
 
 rmmError_t rmmFree(void *ptr, cudaStream_t stream) {
+  return rmm_guarded([&]() -> rmmError_t {
   Manager &m = Manager::get();
   LogScope log(m, 2, ptr, 0, stream);
   if (pool_mode(m)) {
@@ -225,9 +242,11 @@ rmmError_t rmmFree(void *ptr, cudaStream_t stream) {
     // a pointer allocated before the pool was switched on: release it directly
   }
   return map_hip(hipFree(ptr));
+  });
 }
 
 rmmError_t rmmRealloc(void **ptr, size_t new_size, cudaStream_t stream) {
+  return rmm_guarded([&]() -> rmmError_t {
   Manager &m = Manager::get();
   LogScope log(m, 1, nullptr, new_size, stream);
   if (!ptr && !new_size) return RMM_SUCCESS;
@@ -239,9 +258,11 @@ rmmError_t rmmRealloc(void **ptr, size_t new_size, cudaStream_t stream) {
   r = pool_mode(m) ? pool_alloc(m, ptr, new_size) : map_hip(hipMalloc(ptr, new_size));
   if (r == RMM_SUCCESS) log.ptr = *ptr;
   return r;
+  });
 }
 
 rmmError_t rmmGetAllocationOffset(offset_t *offset, void *ptr, cudaStream_t) {
+  return rmm_guarded([&]() -> rmmError_t {
   if (!offset) return RMM_ERROR_INVALID_ARGUMENT;
   hipDeviceptr_t base = nullptr;
   size_t extent = 0;
@@ -251,9 +272,11 @@ rmmError_t rmmGetAllocationOffset(offset_t *offset, void *ptr, cudaStream_t) {
   }
   *offset = (offset_t)((char *)ptr - (char *)base);
   return RMM_SUCCESS;
+  });
 }
 
 rmmError_t rmmGetInfo(size_t *freeSize, size_t *totalSize, cudaStream_t) {
+  return rmm_guarded([&]() -> rmmError_t {
   if (!freeSize || !totalSize) return RMM_ERROR_INVALID_ARGUMENT;
   Manager &m = Manager::get();
   hipError_t e = hipMemGetInfo(freeSize, totalSize);
@@ -263,14 +286,17 @@ rmmError_t rmmGetInfo(size_t *freeSize, size_t *totalSize, cudaStream_t) {
     *freeSize += m.cached_bytes;
   }
   return RMM_SUCCESS;
+  });
 }
 
 rmmError_t rmmWriteLog(const char *filename) {
+  return rmm_guarded([&]() -> rmmError_t {
   if (!filename) return RMM_ERROR_IO;
   std::ofstream f(filename);
   if (!f.good()) return RMM_ERROR_IO;
   write_csv(Manager::get(), f);
   return f.good() ? RMM_SUCCESS : RMM_ERROR_IO;
+  });
 }
 
 size_t rmmLogSize(void) {
@@ -280,12 +306,14 @@ size_t rmmLogSize(void) {
 }
 
 rmmError_t rmmGetLog(char *buffer, size_t buffer_size) {
+  return rmm_guarded([&]() -> rmmError_t {
   if (!buffer) return RMM_ERROR_INVALID_ARGUMENT;
   std::ostringstream s;
   write_csv(Manager::get(), s);
   const std::string str = s.str();
   std::memcpy(buffer, str.data(), std::min(buffer_size, str.size()));
   return RMM_SUCCESS;
+  });
 }
 
 }  // extern "C"

@@ -698,20 +698,27 @@ static gdf_error prefixsum_checked(gdf_column *inp, gdf_column *out, int inclusi
 extern "C" {
 
 gdf_error gdf_prefixsum_i8(gdf_column *inp, gdf_column *out, int inclusive) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   GDF_TRY(prefixsum_checked(inp, out, inclusive, GDF_INT8));
   return device_scan<uint32_t, uint8_t>((const uint8_t *)inp->data, (uint8_t *)out->data, inp->size, inclusive != 0);
+  });
 }
 gdf_error gdf_prefixsum_i32(gdf_column *inp, gdf_column *out, int inclusive) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   GDF_TRY(prefixsum_checked(inp, out, inclusive, GDF_INT32));
   return device_scan<uint32_t, uint32_t>((const uint32_t *)inp->data, (uint32_t *)out->data, inp->size,
                                          inclusive != 0);
+  });
 }
 gdf_error gdf_prefixsum_i64(gdf_column *inp, gdf_column *out, int inclusive) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   GDF_TRY(prefixsum_checked(inp, out, inclusive, GDF_INT64));
   return device_scan<uint64_t, uint64_t>((const uint64_t *)inp->data, (uint64_t *)out->data, inp->size,
                                          inclusive != 0);
+  });
 }
 gdf_error gdf_prefixsum_generic(gdf_column *inp, gdf_column *out, int inclusive) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   GDF_REQUIRE(inp, GDF_DATASET_EMPTY);
   switch (inp->dtype) {   // scan.cu:66-76: other dtypes silently succeed
     case GDF_INT8: return gdf_prefixsum_i8(inp, out, inclusive);
@@ -719,6 +726,7 @@ gdf_error gdf_prefixsum_generic(gdf_column *inp, gdf_column *out, int inclusive)
     case GDF_INT64: return gdf_prefixsum_i64(inp, out, inclusive);
     default: return GDF_SUCCESS;
   }
+  });
 }
 
 }  // extern "C"

@@ -903,22 +903,31 @@ gdf_radixsort_plan_type *gdf_radixsort_plan(size_t num_items, int descending, un
   return reinterpret_cast<gdf_radixsort_plan_type *>(new (std::nothrow) RadixPlan{num_items, descending, begin_bit, end_bit, 0, 0});
 }
 gdf_error gdf_radixsort_plan_setup(gdf_radixsort_plan_type *hdl, size_t sizeof_key, size_t sizeof_val) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   GDF_REQUIRE(hdl, GDF_DATASET_EMPTY);
   RadixPlan *p = reinterpret_cast<RadixPlan *>(hdl);
   p->sizeof_key = sizeof_key;
   p->sizeof_val = sizeof_val;
   return GDF_SUCCESS;
+  });
 }
-gdf_error gdf_radixsort_plan_free(gdf_radixsort_plan_type *hdl) { delete reinterpret_cast<RadixPlan *>(hdl); return GDF_SUCCESS; }
+gdf_error gdf_radixsort_plan_free(gdf_radixsort_plan_type *hdl) {
+  return gdf_amd::guarded([&]() -> gdf_error { delete reinterpret_cast<RadixPlan *>(hdl); return GDF_SUCCESS;
+  });
+}
 gdf_segmented_radixsort_plan_type *gdf_segmented_radixsort_plan(size_t num_items, int descending, unsigned begin_bit, unsigned end_bit) {
   return reinterpret_cast<gdf_segmented_radixsort_plan_type *>(new (std::nothrow) RadixPlan{num_items, descending, begin_bit, end_bit, 0, 0});
 }
 gdf_error gdf_segmented_radixsort_plan_setup(gdf_segmented_radixsort_plan_type *hdl, size_t sizeof_key, size_t sizeof_val) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   return gdf_radixsort_plan_setup(reinterpret_cast<gdf_radixsort_plan_type *>(hdl), sizeof_key, sizeof_val);
+  });
 }
 gdf_error gdf_segmented_radixsort_plan_free(gdf_segmented_radixsort_plan_type *hdl) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   delete reinterpret_cast<RadixPlan *>(hdl);
   return GDF_SUCCESS;
+  });
 }
 
 #define GDF_RSORT_IMPL(suffix, dtype_)                                                                                       \
@@ -937,17 +946,22 @@ GDF_RSORT_IMPL(f32, GDF_FLOAT32)
 GDF_RSORT_IMPL(f64, GDF_FLOAT64)
 #undef GDF_RSORT_IMPL
 gdf_error gdf_radixsort_generic(gdf_radixsort_plan_type *hdl, gdf_column *keycol, gdf_column *valcol) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   return radixsort_generic(reinterpret_cast<RadixPlan *>(hdl), keycol, valcol, -1, nullptr, nullptr);
+  });
 }
 gdf_error gdf_segmented_radixsort_generic(gdf_segmented_radixsort_plan_type *hdl, gdf_column *keycol, gdf_column *valcol,
                                           unsigned num_segments, unsigned *d_begin_offsets, unsigned *d_end_offsets) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   return radixsort_generic(reinterpret_cast<RadixPlan *>(hdl), keycol, valcol, (int)num_segments, d_begin_offsets, d_end_offsets);
+  });
 }
 
 // sqls_ops.cu:1373-1392.  `cols` is a host ARRAY of gdf_column (not pointers); d_cols /
 // d_types are caller-provided device scratch that the reference fills with the data
 // pointers / dtypes, and so do we; d_indx receives the sorted row numbers as size_t.
 gdf_error gdf_order_by(size_t nrows, gdf_column *cols, size_t ncols, void **d_cols, int *d_types, size_t *d_indx) {
+  return gdf_amd::guarded([&]() -> gdf_error {
   GDF_REQUIRE(cols != nullptr && ncols > 0, GDF_DATASET_EMPTY);
   GDF_REQUIRE(!cols->valid, GDF_VALIDITY_UNSUPPORTED);
   GDF_REQUIRE(ncols <= (size_t)MAX_KEY_COLS, GDF_JOIN_TOO_MANY_COLUMNS);
@@ -973,6 +987,7 @@ gdf_error gdf_order_by(size_t nrows, gdf_column *cols, size_t ncols, void **d_co
   HIP_CHECK_LAST();
   HIP_TRY(hipStreamSynchronize(stream0()));
   return GDF_SUCCESS;
+  });
 }
 
 }  // extern "C"

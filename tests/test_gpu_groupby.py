@@ -501,3 +501,79 @@ def test_fused_partition_pass_static_signatures(gdf, key_dtypes, val_dtype, op, 
     _check_masked(gdf, op, keys, vals, [k_ok] + nokeys[1:], v_ok, out)
     force_path("GDF_GBP_DYNAMIC")
     _check_masked(gdf, op, keys, vals, nokeys, v_ok, out)
+
+
+# ---- hot key window: pre-aggregated in the fused scatter kernel's LDS (csrc/groupby.hip GbHot, gbp_scatter_static<..., HOT>) ----
+def _kernels_of(gdf, call):
+    """names of the kernels one library call launched (the exported profile hooks of include/gdf/gdf_amd_ext.h)"""
+    from bench import read_profile
+    lib = gdf._binding._gdf_cdll
+    lib.gdf_amd_profile_reset(); lib.gdf_amd_profile_enable(1)
+    try:
+        call()
+    finally:
+        lib.gdf_amd_profile_enable(0)
+    return set(read_profile(gdf))
+
+
+def _zipf(rs, n, values):
+    u = rs.random_sample(n)
+    return np.clip(np.exp(u * np.log(values + 1.0)).astype(np.int64) - 1, 0, values - 1)      # p(rank) ~ 1 / rank, rank = value
+
+
+@pytest.mark.parametrize("op,val_dtype,masked", [("avg", np.float64, True), ("sum", np.int64, False), ("sum", np.float64, True),
+                                                 ("min", np.float64, True), ("max", np.int64, False)],
+                         ids=["avg-f64-masked", "sum-i64", "sum-f64-masked", "min-f64-masked", "max-i64"])
+@pytest.mark.parametrize("shape", ["zipf", "zipf-sorted-input", "zipf-one-int32-column", "uniform", "one-key", "hot-groups-all-null",
+                                   "forced-cold-window", "forced-last-window"])
+def test_hot_window_is_aggregated_in_the_scatter_kernel(gdf, shape, op, val_dtype, masked, force_path):
+    """Skewed keys (BASELINE config C5: Zipf(1) x 16): the densest aligned window of 4096 group ids of a strided sample is
+    aggregated by the fused scatter kernel in LDS -- counted by nobody, staged nowhere, merged into the cells with atomics --
+    and only the cold rows travel as records.  Reference semantics of the aggregation itself:
+    groupby_kernels.cuh:42-108, groupby.cuh:308-419; masks as in DESIGN.md section 4.  Against the oracle, with the window
+    (kernel name checked through the profile hook) and with GDF_GBP_NO_HOT; uniform keys must NOT take a window; all rows on one
+    key leave no record at all; input sorted by key (the sample's strided windows still see the skew); a window forced onto cold
+    keys / onto the last window overflows the 5120-record stage of every tile and exercises the multi-round flush; hot groups
+    whose every value is null come out as null groups."""
+    if shape == "hot-groups-all-null" and not masked:
+        pytest.skip("needs a value mask")
+    rs = np.random.RandomState(len(shape) + len(op))
+    n = (1 << 22) + 12345
+    if shape == "uniform" or shape == "forced-cold-window":
+        k0 = rs.randint(0, 40_000, size=n).astype(np.int64)
+    elif shape == "one-key":
+        k0 = np.full(n, 77, dtype=np.int64)
+    else:
+        k0 = _zipf(rs, n, 100_000)
+    if shape == "zipf-sorted-input":
+        k0 = np.sort(k0)
+    if shape == "zipf-one-int32-column":
+        keys = [(k0 * 16 + rs.randint(0, 16, size=n)).astype(np.int32)]
+    elif shape == "one-key":
+        keys = [k0, np.full(n, 3, dtype=np.int32)]
+        keys[0][:60_000] = rs.randint(0, 100_000, size=60_000)        # (groups enough for the partitioned path: the others hold <= 16384)
+        keys[1][:60_000] = rs.randint(0, 16, size=60_000)
+    else:
+        keys = [k0, rs.randint(0, 16, size=n).astype(np.int32)]
+    vals = rs.randint(-1000, 1000, size=n).astype(val_dtype) if np.dtype(val_dtype).kind == "i" else rs.random_sample(n)
+    v_ok = (rs.random_sample(n) > 0.5) if masked else None
+    if shape == "hot-groups-all-null":
+        v_ok[k0 < 8] = False
+    if shape == "forced-cold-window":
+        force_path("GDF_GBP_HOT_WINDOW", "5")
+    if shape == "forced-last-window":
+        force_path("GDF_GBP_HOT_WINDOW", "1000000")
+    out = np.float64 if op == "avg" else None
+    nokeys = [None] * len(keys)
+
+    def run():
+        if masked:
+            _check_masked(gdf, op, keys, vals, nokeys, v_ok, out)
+        else:
+            _check(gdf, op, keys, vals, out)
+
+    names = _kernels_of(gdf, run)
+    assert ("gbp_scatter_hot" in names) == (shape != "uniform"), names
+    force_path("GDF_GBP_NO_HOT")
+    names = _kernels_of(gdf, run)
+    assert "gbp_scatter_hot" not in names and "gbp_scatter" in names, names

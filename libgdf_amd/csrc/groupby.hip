@@ -2021,6 +2021,21 @@ __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter_static(KeyTable t,
   };
   auto request = [&](int64_t tile, int64_t end) {
     const uint32_t tid = gbp_opaque_tid();
+#ifdef GDF_AMD_LAB
+    if (HOT && (LAB_BITS(hot.dbg) & 16)) {            // LAB bit 16: read-once input as non-temporal loads (do the streams push the write fronts out of L2?)
+#pragma unroll
+      for (int k = 0; k < GBP_ITEMS; ++k) if (VMASK) vb[k] = __builtin_nontemporal_load(val.valid + (row_of(tile, end, k, tid) >> 3));
+#pragma unroll
+      for (int k = 0; k < GBP_ITEMS; ++k) img[k] = __builtin_nontemporal_load((const uint64_t *)val.data + row_of(tile, end, k, tid));
+#pragma unroll
+      for (int k = 0; k < GBP_ITEMS; ++k) r0[k] = __builtin_nontemporal_load((const W0 *)t.col[0].data + row_of(tile, end, k, tid));
+      if (K1 >= 0) {
+#pragma unroll
+        for (int k = 0; k < GBP_ITEMS; ++k) r1[k] = __builtin_nontemporal_load((const W1 *)t.col[1].data + row_of(tile, end, k, tid));
+      }
+      return;
+    }
+#endif
 #pragma unroll
     for (int k = 0; k < GBP_ITEMS; ++k) if (VMASK) vb[k] = val.valid[row_of(tile, end, k, tid) >> 3];
 #pragma unroll
@@ -2037,7 +2052,14 @@ __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter_static(KeyTable t,
     for (uint32_t i = threadIdx.x; i < GBP_HOT_IDS; i += GBP_SC_THREADS) { hacc[i] = acc_identity(fold_op); hrows[i] = 0; hvalid[i] = 0; }
   }
   block_sync();
-  for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+  // chunk -> workgroup: XCD x (workgroups x, x + 8, ...: MI355X_MICROARCH.md "Workgroup dispatch") takes the x-th EIGHTH of the chunks, its
+  // workgroups round-robin inside it.  The regions of chunks c and c + 1 are neighbours inside every partition and share their
+  // boundary line; with c -> workgroup c % grid they sat behind two different, non-coherent L2s (the trick of jk_scatter2's tiles)
+  const bool xcd_map = (gridDim.x & 7u) == 0 && !(LAB_BITS(hot.dbg) & 32);
+  const int per_xcd = (nchunks + 7) / 8, first = xcd_map ? (int)(blockIdx.x >> 3) : (int)blockIdx.x, step = xcd_map ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+  for (int ci = first; xcd_map ? ci < per_xcd : ci < nchunks; ci += step) {
+    const int c = xcd_map ? (int)(blockIdx.x & 7u) * per_xcd + ci : ci;
+    if (c >= nchunks) break;
     for (uint32_t q = threadIdx.x; q < nparts; q += GBP_SC_THREADS) cursor[q] = offs[(size_t)q * qstride + (size_t)c * cstride];
     const int64_t begin = (int64_t)c * chunk;
     const int64_t end = begin + chunk < t.nrows ? begin + chunk : t.nrows;
@@ -2139,8 +2161,8 @@ __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter_static(KeyTable t,
       uint32_t st[GBP_ITEMS];          // all reads of start[] first (one LDS round trip, not one per row), then the writes
 #pragma unroll
       for (int k = 0; k < GBP_ITEMS; ++k) st[k] = start[part[k] & (GBP_MAX_PARTS - 1)] + rk[k];
-      // HOT: the stage holds CAP < TILE records; a tile with more cold rows takes several rounds (`total` is workgroup-uniform)
-      for (uint32_t round0 = 0;;) {
+      // one round: the records at tile positions [round0, round0 + CAP) are regrouped in the stage and flushed
+      auto regroup = [&](uint32_t round0) {
 #pragma unroll
         for (int k = 0; k < GBP_ITEMS; ++k) {
           const uint32_t pos = st[k] - round0;               // (unsigned: positions below round0 wrap beyond CAP)
@@ -2149,8 +2171,13 @@ __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter_static(KeyTable t,
             stage[pos] = acc[k];
           }
         }
-        block_sync();
-        // flush: every LDS read first (the record, then its partition's base), then the stores; slots beyond the round re-read slot 0
+      };
+#ifdef GDF_AMD_LAB
+      const uint32_t lab_span = (uint32_t)(t.nrows / gridDim.x) - (uint32_t)GBP_SC_TILE;
+      const uint32_t lab_stream = blockIdx.x * (uint32_t)(t.nrows / gridDim.x) + (uint32_t)(((tile - begin) / GBP_SC_TILE) * CAP) % (lab_span ? lab_span : 1u);
+#endif
+      auto flush = [&](uint32_t round0) {
+        // every LDS read first (the record, then its partition's base), then the stores; slots beyond the round re-read slot 0
         uint32_t kk[FLUSH_ITEMS], gb[FLUSH_ITEMS];
         uint64_t vv[FLUSH_ITEMS];
         const uint32_t ftid = gbp_opaque_tid();
@@ -2167,12 +2194,31 @@ __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter_static(KeyTable t,
 #pragma unroll
         for (int k = 0; k < FLUSH_ITEMS; ++k) {
           const uint32_t j = ftid + k * GBP_SC_THREADS;
-          if (j < cnt && !(LAB_BITS(hot.dbg) & 2)) rec_out[gb[k] + round0 + j] = GbRec{kk[k], (uint32_t)vv[k], (uint32_t)(vv[k] >> 32)};   // (LAB bit 2: no stores)
+          uint32_t dst = gb[k] + round0 + j;
+#ifdef GDF_AMD_LAB
+          // LAB bit 8: the same records as one contiguous stream per workgroup (what would the stores cost without the short runs?)
+          if (LAB_BITS(hot.dbg) & 8) { dst = lab_stream + j; }
+#endif
+          if (j < cnt && !(LAB_BITS(hot.dbg) & 2)) rec_out[dst] = GbRec{kk[k], (uint32_t)vv[k], (uint32_t)(vv[k] >> 32)};   // (LAB bit 2: no stores)
         }
-        if (!HOT || left <= (uint32_t)CAP) break;
-        round0 += (uint32_t)CAP;
-        block_sync();                  // the next round overwrites the stage
+      };
+      // HOT: the stage holds CAP < TILE records; a tile with more cold rows than that (the sample mispredicted the window) sends its
+      // LATER positions first, round by round, then the first CAP as every tile does (`total` is workgroup-uniform).
+      // (Requesting the NEXT tile's words in front of the last flush and holding them in registers across it -- the five store
+      // instructions leave room, no spill -- changed nothing: 8.34 - 8.78 against 8.39 - 8.49 ms on C5.  The stores are not a
+      // latency the loads could hide behind: the same records written as one contiguous stream per workgroup cost 6.7 ms, no
+      // stores at all 6.1, the short (tile, partition) runs 8.5 -- profiles/r4_c_c5_scatter_ablation.txt.)
+      if constexpr (HOT) {
+        for (uint32_t round0 = (total - 1u) / (uint32_t)CAP * (uint32_t)CAP; total && round0 > 0; round0 -= (uint32_t)CAP) {
+          regroup(round0);
+          block_sync();
+          flush(round0);
+          block_sync();                  // the next round overwrites the stage
+        }
       }
+      regroup(0);
+      block_sync();
+      flush(0);
     }
   }
   if constexpr (HOT) {

@@ -183,6 +183,54 @@ def cpu_baseline(sample_probe, sample_build):
                       f"{dt:.1f} s on 1 of {os.cpu_count()} host cores"}
 
 
+def extra_configs(gdf, dev):
+    """BASELINE configs C2 (gdf_group_by_sum, 1e8 int64 keys, 1e4 groups) and C5 (gdf_group_by_avg, 1e9 rows, Zipf keys, 50 % null
+    values) through the C ABI, inputs resident in HBM: {ms, frac of 8 TB/s on the config's algorithmic bytes,
+    checks_pass}.  C2's check: group count, key set and the total of the sums against torch reductions over the same inputs
+    (bit-exact integers); C5's: tools/bench_c5.py's size-independent properties."""
+    import torch
+    from libgdf_amd.columns import Column, column_array, new_context
+    out = {}
+    try:
+        n = 100_000_000
+        keys = make_probe_keys(n, 10000, 0x5EED0003, dev)          # (splitmix64(seed + i) >> 1) % 10000, as tools/bench_ops.py
+        vals = make_probe_keys(n, 1000, 0x5EED0004, dev)
+        cap = 16384
+        okey = Column(torch.empty(cap, dtype=torch.int64, device=dev), None, 4, size=cap)
+        oagg = Column(torch.empty(cap, dtype=torch.int64, device=dev), None, 4, size=cap)
+        kc, vc = Column(keys), Column(vals)
+        ka, oa = column_array([kc]), column_array([okey])
+        ctx = new_context(method=1)
+        call = lambda: gdf.libgdf.gdf_group_by_sum(1, ka, vc.ptr, None, oa, oagg.ptr, C.byref(ctx))
+        call()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        reps = 10
+        for _ in range(reps):
+            call()
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
+        ng = int(oagg.size)
+        assert 0 < ng <= cap
+        gk, ga = okey.data[:ng], oagg.data[:ng]
+        want = torch.zeros(10000, dtype=torch.int64, device=dev).scatter_add_(0, keys, vals)
+        good = ng == int((torch.bincount(keys, minlength=10000) > 0).sum().item()) and bool(torch.equal(want[gk], ga)) and \
+            int(torch.unique(gk).numel()) == ng
+        out["c2"] = {"op": "C2 gdf_group_by_sum, 1e8 int64 keys, 1e4 groups, HASH", "ms": dt * 1e3, "frac": n * 16.0 / dt / 8e12,
+                     "algorithmic_bytes": n * 16.0, "groups": ng, "checks_pass": bool(good)}
+        del keys, vals, kc, vc, okey, oagg, want
+        torch.cuda.empty_cache()
+    except Exception as e:                         # noqa: BLE001 -- reported, never fatal for the headline line
+        out["c2"] = {"error": f"{type(e).__name__}: {e}", "checks_pass": False}
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_c5
+        r = bench_c5.run_c5(gdf, dev, 1_000_000_000, 3, 0.0, True)
+        out["c5"] = {"op": r["op"], "ms": r["ms"], "frac": r["frac_of_8TBps"], "algorithmic_bytes": 20.375e9,
+                     "kernels_ms": r["kernels_ms"], "checks_pass": bool(r["checks_pass"])}
+    except Exception as e:                         # noqa: BLE001
+        out["c5"] = {"error": f"{type(e).__name__}: {e}", "checks_pass": False}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -199,6 +247,9 @@ def main():
                          "(libgdf_amd.multigpu.choose_join_strategy: broadcast at 2 GPUs, shuffle at 4, fused at 8) would have run instead is timed "
                          "after it and reported in the extra field planner_choice.  auto: the planner's choice as `value`.  fused / shuffle / "
                          "broadcast: that strategy")
+    ap.add_argument("--extra", type=int, default=1,
+                    help="1 (default, single GPU only): after the headline's timed region, also measure BASELINE configs C2 and C5 through the C ABI "
+                         "and append them as `extra.c2` / `extra.c5` (ms, roofline fraction, checks_pass); 0 = skip")
     ap.add_argument("--force-distributed", action="store_true",
                     help="run the multi-GPU (C4) code path even at world size 1 (1-rank RCCL group): measures its local passes")
     args = ap.parse_args()
@@ -476,6 +527,14 @@ def main():
                                   "assumed_link_GBps": multigpu.XGMI_LINK_BYTES_PER_S / 1e9,
                                   "planner_estimate_ms": {k: v * 1e3 for k, v in multigpu.estimate_join_seconds(world, npr, nb).items()}}
             result["per_rank"] = per_rank
+        if world == 1 and not distributed and args.extra and npr == 1_000_000_000:
+            # the other two single-GPU BASELINE configs, measured AFTER the headline's timed region with its inputs released
+            # (a driver-run line, not only profiles/, carries them)
+            step = pcol = bcol = la = ra = probe = build = None      # (the step closure holds the columns)
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            result["extra"] = extra_configs(gdf, dev)
         if world == 1 and args.pandas_sample > 0:
             result["cpu_baseline"] = cpu_baseline_pandas(args.pandas_sample, max(args.pandas_sample // 10, 1))
         if world == 1 and args.cpu_sample > 0:

@@ -163,3 +163,50 @@ def test_shipped_library_reads_no_environment(libs):
     lab = os.path.join(LIBDIR, "lab", "libgdf.so")
     if os.path.exists(lab):        # the LAB build (experiment knobs) is the one that reads the environment
         assert "getenv" in subprocess.check_output(["nm", "-D", "--undefined-only", lab]).decode()
+
+
+def test_no_exception_crosses_the_c_boundary(libs):
+    """SURVEY.md 8(a) quirk 6: the reference lets std::bad_alloc / thrust::system_error escape extern "C"
+    (managed_allocator.cuh:34-45, thrust_rmm_allocator.h:44-49); here every relational entry point runs its body through
+    gdf_amd::guarded (csrc/common.h) and answers GDF_MEMORYMANAGER_ERROR.  The test hook makes make_key_table -- the first thing
+    each entry point does after its argument checks, in front of its std::vector allocations -- throw std::bad_alloc; no device
+    is touched before that, so this runs without a GPU.  The process must survive and the calls must work again afterwards
+    (argument errors come back as before)."""
+    gdf, _ = libs
+    from libgdf_amd._binding import gdf_column, gdf_context
+    fake = 0x1000                                    # never dereferenced: the forced failure comes first
+    def col(dtype=3, size=8):
+        c = gdf_column()
+        c.data, c.size, c.dtype = fake, size, dtype
+        return c
+    gdf.gdf_amd_debug_force.argtypes = [C.c_char_p, C.c_char_p]
+    assert gdf.gdf_amd_debug_force(b"GDF_FORCE_HOST_ALLOC_FAILURE", b"1") == 0
+    try:
+        key, agg, outk, outa = col(), col(), col(), col()
+        ctx = gdf_context()
+        ctx.flag_method = 1                          # GDF_HASH
+        keys = (C.POINTER(gdf_column) * 1)(C.pointer(key))
+        outs = (C.POINTER(gdf_column) * 1)(C.pointer(outk))
+        for fn in (gdf.gdf_group_by_sum, gdf.gdf_group_by_avg, gdf.gdf_group_by_count):
+            assert fn(1, keys, C.byref(agg), None, outs, C.byref(outa), C.byref(ctx)) == 20      # GDF_MEMORYMANAGER_ERROR
+        ctx.flag_method = 0                          # GDF_SORT group-by
+        assert gdf.gdf_group_by_max(1, keys, C.byref(agg), C.byref(outa), outs, C.byref(outa), C.byref(ctx)) == 20
+        ctx.flag_method = 1
+        li, ri = gdf_column(), gdf_column()
+        idx = (C.c_int * 1)(0)
+        for fn in (gdf.gdf_inner_join, gdf.gdf_left_join, gdf.gdf_full_join):
+            assert fn(keys, 1, idx, outs, 1, idx, 1, 0, None, C.byref(li), C.byref(ri), C.byref(ctx)) == 20
+        inp = (gdf_column * 1)(col())
+        outp = (gdf_column * 1)(col())
+        inp_p = (C.POINTER(gdf_column) * 1)(C.pointer(inp[0]))
+        out_p = (C.POINTER(gdf_column) * 1)(C.pointer(outp[0]))
+        offs = (C.c_int * 4)()
+        assert gdf.gdf_hash_partition(1, inp_p, idx, 1, 4, out_p, offs, 0) == 20
+        h = col()
+        assert gdf.gdf_hash(1, keys, 0, C.byref(h)) == 20
+        cols = (gdf_column * 1)(col())
+        # (d_cols / d_types NULL: gdf_order_by uploads them before it looks at the keys, sqls_ops.cu:1373-1392)
+        assert gdf.gdf_order_by(C.c_size_t(8), cols, C.c_size_t(1), None, None, C.c_void_p(fake)) == 20
+    finally:
+        assert gdf.gdf_amd_debug_force(b"GDF_FORCE_HOST_ALLOC_FAILURE", None) == 0
+    assert gdf.gdf_group_by_sum(0, None, None, None, None, None, None) == 5          # alive, and answering as before

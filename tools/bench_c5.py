@@ -107,33 +107,22 @@ def c5_property_checks(gdf, k0, k1, v, ok, mask, cap, kok=None, kmask=None):
     return checks, good
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--rows", type=int, default=1_000_000_000)
-    ap.add_argument("--reps", type=int, default=3)
-    ap.add_argument("--null-keys", type=float, default=0.0)
-    ap.add_argument("--no-checks", action="store_true", help="timing only (LAB ablations that break the result on purpose)")
-    a = ap.parse_args()
+def run_c5(gdf, dev, n=1_000_000_000, reps=3, null_keys=0.0, checks=True):
+    """one C5 measurement through the C ABI (inputs resident in HBM, outputs preallocated, the timed region is the C call alone)
+    -> the result dict of this tool's JSON line.  Also called by bench.py for its `extra.c5` object."""
     import torch
-    import libgdf_amd as gdf
     from bench import read_profile
-    from libgdf_amd._binding import rmmOptions_t
-    from libgdf_amd.columns import Column
-    gdf.librmm.rmmInitialize(C.byref(rmmOptions_t(1, 0, False)))
+    from libgdf_amd.columns import Column, column_array, new_context
     lib = gdf._binding._gdf_cdll
-    dev = torch.device("cuda", 0)
-    n = a.rows
     k0, k1, v, ok, mask = make_c5(n, dev)
     kok = kmask = None
-    if a.null_keys > 0:
-        kok, kmask = null_key_mask(n, dev, a.null_keys)
+    if null_keys > 0:
+        kok, kmask = null_key_mask(n, dev, null_keys)
     kc = [Column(k0, kmask, null_count=int(n - kok.sum().item())) if kok is not None else Column(k0), Column(k1)]
     vc = Column(v, mask, null_count=int(n - ok.sum().item()))
-    cap = 20_000_000
+    cap = min(20_000_000, n)
     alg = n * 20.0 + n / 8.0 + (n / 8.0 if kok is not None else 0.0)
 
-    # the timed region is the C call alone: outputs are preallocated once (capacity rows + masks), as a caller would
-    from libgdf_amd.columns import column_array, new_context
     def out_col(tdtype, gdtype):
         return Column(torch.empty(cap, dtype=tdtype, device=dev), torch.zeros((cap + 7) // 8 + 64, dtype=torch.uint8, device=dev), gdtype, size=cap)
     ok0, ok1, oagg = out_col(torch.int64, 4), out_col(torch.int32, 3), out_col(torch.float64, 6)
@@ -143,18 +132,33 @@ def main():
     call()
     lib.gdf_amd_profile_reset(); lib.gdf_amd_profile_enable(1)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(a.reps):
+    for _ in range(reps):
         call()
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.reps
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
     lib.gdf_amd_profile_enable(0)
     prof = read_profile(gdf)
     del ok0, ok1, oagg
-    checks, good = ({}, True) if a.no_checks else c5_property_checks(gdf, k0, k1, v, ok, mask, cap, kok, kmask)
-    print(json.dumps({"op": "C5 gdf_group_by_avg (int64 Zipf x int32) keys, fp64 values, 50% null" + (f", {a.null_keys:g} null keys" if kok is not None else ""),
-                      "rows": n, "ms": dt * 1e3,
-                      "rows_per_s": n / dt, "algorithmic_GBps": alg / dt / 1e9, "frac_of_8TBps": alg / dt / 8e12,
-                      "kernels_ms": {k: round(x[0] / a.reps, 3) for k, x in prof.items()}, "checks": checks, "checks_pass": good}))
-    sys.exit(0 if good else 1)
+    checks_d, good = c5_property_checks(gdf, k0, k1, v, ok, mask, cap, kok, kmask) if checks else ({}, True)
+    return {"op": "C5 gdf_group_by_avg (int64 Zipf x int32) keys, fp64 values, 50% null" + (f", {null_keys:g} null keys" if kok is not None else ""),
+            "rows": n, "ms": dt * 1e3,
+            "rows_per_s": n / dt, "algorithmic_GBps": alg / dt / 1e9, "frac_of_8TBps": alg / dt / 8e12,
+            "kernels_ms": {k: round(x[0] / reps, 3) for k, x in prof.items()}, "checks": checks_d, "checks_pass": good}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=1_000_000_000)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--null-keys", type=float, default=0.0)
+    ap.add_argument("--no-checks", action="store_true", help="timing only (LAB ablations that break the result on purpose)")
+    a = ap.parse_args()
+    import torch
+    import libgdf_amd as gdf
+    from libgdf_amd._binding import rmmOptions_t
+    gdf.librmm.rmmInitialize(C.byref(rmmOptions_t(1, 0, False)))
+    res = run_c5(gdf, torch.device("cuda", 0), a.rows, a.reps, a.null_keys, not a.no_checks)
+    print(json.dumps(res))
+    sys.exit(0 if res["checks_pass"] else 1)
 
 
 if __name__ == "__main__":

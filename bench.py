@@ -551,6 +551,7 @@ def main():
     if rank == 0:
         print(line, flush=True)
     if distributed:
+        multigpu.close_transports()
         dist.destroy_process_group()
 
 

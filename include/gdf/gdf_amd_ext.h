@@ -118,6 +118,74 @@ gdf_error gdf_amd_fj_build_create(const uint32_t *recv_keys, const uint32_t *rec
 gdf_error gdf_amd_fj_probe_add(gdf_amd_join_probe *probe, const uint32_t *recv_keys, const uint32_t *recv_fill, uint32_t cap,
                                int64_t position_base, int64_t buffer_elems);
 
+/*
+ * gdf_amd_dist_inner_join -- the multi-GPU inner join behind the C ABI (one process per GPU; BASELINE.json north_star: "host code
+ * stays C++ behind the same C ABI ... radix-partitioned on key and shuffled with RCCL all-to-all over xGMI").  No counterpart in
+ * the reference, which is single-GPU.  It runs the FUSED join above end to end: global key
+ * range and sizes (three small all-reduces), gdf_amd_fj_plan, the sender's level-1 regroup of the build relation and of the probe
+ * relation in `chunks` slices, the all-to-all of EQUAL blocks + fill counters per slice (software-pipelined: slice c travels while
+ * slice c + 1 is regrouped and slice c - 1 is partitioned at the receiver), level 2 + LDS probe at the receiver, and the
+ * collective agreement that decides between result and decline.
+ *
+ * The wire is a gdf_amd_transport: four function pointers.  gdf_amd_rccl_transport_create gives the RCCL one (ncclSend / ncclRecv
+ * groups on a stream of its own, librccl resolved with dlopen at that moment -- libgdf.so itself does not link against it); a host
+ * in another language, or a test that moves the blocks through host memory between processes (tests/multirank_common.py), fills
+ * the struct itself.
+ *
+ * Every rank of the transport calls with its shard: one GDF_INT64 (or GDF_INT32) key column each, no validity masks.
+ *   probe_pos / build_pos   caller-allocated DEVICE arrays, one uint32 per local probe / build row: the position that row's key
+ *                           went to in its send buffer (0xffffffff: dropped, the key lies outside the global build range) -- they
+ *                           stay with the sender, who can tell from them which of its rows a result position names
+ *   probe_indices / build_indices   library-allocated GDF_INT32 columns (gdf_column_free), exactly as gdf_inner_join's: this
+ *                           rank's pairs as POSITIONS in its receive buffers -- probe: slice * world * block_p + offset in slice's
+ *                           buffer, build: offset in the build receive buffer; offset / block = the sender's rank
+ *   info                    the layout both sides were exchanged in (what turns positions into (rank, row))
+ *   *declined = 1           ON EVERY RANK: the shape does not fit the fused path (keys that do not narrow to 31 bits, a relation
+ *                           or world size outside gdf_amd_fj_plan's range, skewed keys that overflow the fixed-size regions, the
+ *                           31-bit position space) -- nothing is returned and the caller takes the key shuffle
+ *                           (libgdf_amd/multigpu.py distributed_inner_join) on all ranks together.
+ * Errors other than a decline (a HIP / RCCL failure, out of memory) are returned by the rank that met them; its peers see their
+ * next transport call fail or time out, as with any collective.
+ */
+typedef struct gdf_amd_transport {
+  void *ctx;
+  int rank, world;
+  /* DEVICE buffers: block r of `send` (bytes_per_rank bytes) goes to rank r, block s of `recv` arrives from rank s.  Ordered behind
+     the work the library has issued so far; *ticket names the exchange.  0 = success. */
+  int (*all_to_all)(void *ctx, const void *send, void *recv, size_t bytes_per_rank, void **ticket);
+  /* orders the library's stream behind the exchange (recv may be read, send reused, afterwards); releases the ticket */
+  int (*wait)(void *ctx, void *ticket);
+  /* HOST values, reduced in place over all ranks; op 0 = min, 1 = max, 2 = sum */
+  int (*all_reduce_i64)(void *ctx, int64_t *values, int count, int op);
+  /* releases ctx (may be NULL) */
+  void (*destroy)(void *ctx);
+} gdf_amd_transport;
+
+typedef struct gdf_amd_dist_info {
+  int world, chunks;
+  int64_t lo, hi;                      /* global build-side key range: keys travel as (key - lo) */
+  int64_t slice_rows;                  /* probe rows per slice (the last one may be shorter) */
+  int fine_bits_p, coarse_bits_p;      /* gdf_amd_fj_plan of the probe slices ...                */
+  uint32_t cap_p;
+  int fine_bits_b, coarse_bits_b;      /* ... and of the build relation                          */
+  uint32_t cap_b;
+  int64_t block_p, block_b;            /* elements every sender makes for one rank: (8 << coarse_bits) * cap */
+} gdf_amd_dist_info;
+
+gdf_error gdf_amd_dist_inner_join(gdf_column *probe_keys, gdf_column *build_keys, gdf_amd_transport *transport, int chunks,
+                                  uint32_t *probe_pos, uint32_t *build_pos, gdf_column *probe_indices, gdf_column *build_indices,
+                                  gdf_amd_dist_info *info, int *declined);
+
+/* RCCL transport.  id: the 128 bytes of an ncclUniqueId -- made by ONE rank with gdf_amd_rccl_unique_id and handed to the others by
+   whatever the host has (MPI, a file, torch.distributed's store); every rank then calls gdf_amd_rccl_transport_create (collective:
+   ncclCommInitRank) with the device it computes on current.  gdf_amd_transport_free destroys communicator and stream. */
+gdf_error gdf_amd_rccl_unique_id(char id[128]);
+gdf_error gdf_amd_rccl_transport_create(const char id[128], int world, int rank, gdf_amd_transport **out);
+void gdf_amd_transport_free(gdf_amd_transport *transport);
+/* synchronous copy on the library's stream for transports that stage blocks through host memory; direction 0: device -> host,
+   1: host -> device, 2: device -> device */
+gdf_error gdf_amd_copy(void *dst, const void *src, size_t bytes, int direction);
+
 #if defined(__GNUC__)
 #pragma GCC visibility pop
 #endif

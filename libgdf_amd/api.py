@@ -378,3 +378,124 @@ def filter_rows(cols, values):
     libgdf.gdf_filter(n, col_structs, k, d_cols.data_ptr(), d_types.data_ptr(), d_vals.data_ptr(), d_indx.data_ptr(),
                       C.byref(new_sz))
     return d_indx[: new_sz.value]
+
+
+# ---- gdf_amd_dist_inner_join (include/gdf/gdf_amd_ext.h): the multi-GPU join behind the C ABI -----------------------------
+class gdf_amd_transport(C.Structure):
+    _A2A = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p))
+    _WAIT = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
+    _ALLRED = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.c_int, C.c_int)
+    _DESTROY = C.CFUNCTYPE(None, C.c_void_p)
+    _fields_ = [("ctx", C.c_void_p), ("rank", C.c_int), ("world", C.c_int), ("all_to_all", _A2A), ("wait", _WAIT),
+                ("all_reduce_i64", _ALLRED), ("destroy", _DESTROY)]
+
+
+class gdf_amd_dist_info(C.Structure):
+    _fields_ = [("world", C.c_int), ("chunks", C.c_int), ("lo", C.c_int64), ("hi", C.c_int64), ("slice_rows", C.c_int64),
+                ("fine_bits_p", C.c_int), ("coarse_bits_p", C.c_int), ("cap_p", C.c_uint32),
+                ("fine_bits_b", C.c_int), ("coarse_bits_b", C.c_int), ("cap_b", C.c_uint32),
+                ("block_p", C.c_int64), ("block_b", C.c_int64)]
+
+
+class RcclTransport:
+    """gdf_amd_rccl_transport_create: the library's own RCCL communicator (ncclSend / ncclRecv groups on its own stream).  The
+    128-byte unique id comes from rank 0 (``RcclTransport.unique_id()``) over whatever channel the host has -- here
+    torch.distributed's object broadcast (libgdf_amd/multigpu.py)."""
+
+    def __init__(self, unique_id: bytes, world: int, rank: int):
+        self._h = C.POINTER(gdf_amd_transport)()
+        libgdf.gdf_amd_rccl_transport_create(C.c_char_p(unique_id), int(world), int(rank), C.byref(self._h))
+        self.world, self.rank = int(world), int(rank)
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        libgdf.gdf_amd_rccl_unique_id(buf)
+        return buf.raw
+
+    @property
+    def ptr(self):
+        return self._h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            libgdf.gdf_amd_transport_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+
+class CallbackTransport:
+    """A gdf_amd_transport whose four functions are Python callbacks over a torch.distributed group of ANY backend: the blocks
+    are staged through host memory (gdf_amd_copy), so ranks that share one GPU can talk through gloo
+    (tests/test_gpu_multirank_one_gpu.py) -- the same C orchestration as over RCCL, another wire.  Synchronous: all_to_all
+    returns when the exchange is done."""
+
+    def __init__(self, group=None):
+        import torch
+        import torch.distributed as dist
+        self.group = group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.errors = []
+
+        def all_to_all(ctx, send, recv, bytes_per_rank, ticket):
+            try:
+                n = int(bytes_per_rank) * self.world
+                hs = torch.empty(max(n, 1), dtype=torch.uint8)
+                hr = torch.empty(max(n, 1), dtype=torch.uint8)
+                if n:
+                    libgdf.gdf_amd_copy(hs.data_ptr(), send, n, 0)
+                    dist.all_to_all_single(hr[:n], hs[:n], group=self.group)
+                    libgdf.gdf_amd_copy(recv, hr.data_ptr(), n, 1)
+                ticket[0] = None
+                return 0
+            except Exception as e:                 # noqa: BLE001 -- a callback must not raise into C
+                self.errors.append(e)
+                return 1
+
+        def wait(ctx, ticket):
+            return 0
+
+        def all_reduce(ctx, values, count, op):
+            try:
+                t = torch.tensor([values[i] for i in range(count)], dtype=torch.int64)
+                dist.all_reduce(t, op=(dist.ReduceOp.MIN, dist.ReduceOp.MAX, dist.ReduceOp.SUM)[op], group=self.group)
+                for i in range(count):
+                    values[i] = int(t[i])
+                return 0
+            except Exception as e:                 # noqa: BLE001
+                self.errors.append(e)
+                return 1
+
+        self._cbs = (gdf_amd_transport._A2A(all_to_all), gdf_amd_transport._WAIT(wait), gdf_amd_transport._ALLRED(all_reduce))
+        self._t = gdf_amd_transport(None, self.rank, self.world, self._cbs[0], self._cbs[1], self._cbs[2],
+                                    C.cast(None, gdf_amd_transport._DESTROY))
+
+    @property
+    def ptr(self):
+        return C.pointer(self._t)
+
+    def close(self):
+        pass
+
+
+def dist_inner_join(probe: Column, build: Column, transport, chunks=4):
+    """gdf_amd_dist_inner_join -> None when every rank declined (the shape does not fit the fused path), else
+    (probe_pos_of_rows, build_pos_of_rows, probe_indices, build_indices, info): the first two say where each LOCAL row's key went
+    in its send buffer (they stay with the sender), the index columns are this rank's pairs as positions in its receive
+    buffers (LibraryIndexColumn: the library's buffers, not copied)."""
+    import torch
+    dev = probe.data.device
+    ppos = torch.empty(max(probe.size, 1), dtype=torch.int32, device=dev)[:probe.size]
+    bpos = torch.empty(max(build.size, 1), dtype=torch.int32, device=dev)[:build.size]
+    li, ri = gdf_column(), gdf_column()
+    info = gdf_amd_dist_info()
+    declined = C.c_int(1)
+    libgdf.gdf_amd_dist_inner_join(probe.ptr, build.ptr, transport.ptr, int(chunks), ppos.data_ptr() if probe.size else None,
+                                   bpos.data_ptr() if build.size else None, C.byref(li), C.byref(ri), C.byref(info), C.byref(declined))
+    errs = getattr(transport, "errors", None)
+    if errs:
+        raise errs.pop(0)
+    if declined.value:
+        return None
+    return ppos, bpos, LibraryIndexColumn(li), LibraryIndexColumn(ri), info

@@ -5122,6 +5122,197 @@ static gdf_error fj_probe_add(ProbeAccum *a, const uint32_t *recv_keys, const ui
   return GDF_SUCCESS;
 }
 
+
+// ---------------------------------------------------------------------------
+// gdf_amd_dist_inner_join: the fused multi-GPU join end to end behind the C ABI (include/gdf/gdf_amd_ext.h).  The orchestration
+// libgdf_amd/multigpu.py fused_inner_join used to do over torch.distributed, over a gdf_amd_transport instead: a host in any
+// language gets the distributed join from libgdf.so alone.
+// ---------------------------------------------------------------------------
+namespace {
+struct DistTicket { void *keys = nullptr, *fill = nullptr; };
+
+struct DistExchange {          // one relation slice on the wire: send buffers (alive until the exchange is done), receive buffers
+  DevBuf sk, sf, rk, rf;
+  DistTicket t;
+  bool posted = false;
+};
+
+// all ranks learn whether `flag` is set anywhere
+static gdf_error dist_agree(gdf_amd_transport *tr, bool flag, bool *any) {
+  int64_t v = flag ? 1 : 0;
+  if (tr->all_reduce_i64(tr->ctx, &v, 1, 1) != 0) return GDF_C_ERROR;
+  *any = v != 0;
+  return GDF_SUCCESS;
+}
+static gdf_error dist_post(gdf_amd_transport *tr, DistExchange *x, size_t block_elems, size_t regions_per_rank) {
+  const size_t world = (size_t)tr->world;
+  RMM_TRY(x->rk.alloc(sizeof(uint32_t) * world * block_elems));
+  RMM_TRY(x->rf.alloc(sizeof(uint32_t) * (world * regions_per_rank + 2)));
+  if (tr->all_to_all(tr->ctx, x->sk.p, x->rk.p, sizeof(uint32_t) * block_elems, &x->t.keys) != 0) return GDF_C_ERROR;
+  if (tr->all_to_all(tr->ctx, x->sf.p, x->rf.p, sizeof(uint32_t) * regions_per_rank, &x->t.fill) != 0) return GDF_C_ERROR;
+  x->posted = true;
+  return GDF_SUCCESS;
+}
+static gdf_error dist_wait(gdf_amd_transport *tr, DistExchange *x) {
+  if (!x->posted) return GDF_SUCCESS;
+  x->posted = false;
+  if (tr->wait(tr->ctx, x->t.keys) != 0) return GDF_C_ERROR;
+  if (tr->wait(tr->ctx, x->t.fill) != 0) return GDF_C_ERROR;
+  return GDF_SUCCESS;
+}
+}  // namespace
+
+static gdf_error dist_inner_join(gdf_column *probe_keys, gdf_column *build_keys, gdf_amd_transport *tr, int chunks, uint32_t *probe_pos,
+                                 uint32_t *build_pos, gdf_column *probe_indices, gdf_column *build_indices, gdf_amd_dist_info *info,
+                                 int *declined) {
+  GDF_REQUIRE(probe_keys && build_keys && tr && probe_indices && build_indices && info && declined, GDF_DATASET_EMPTY);
+  GDF_REQUIRE(tr->all_to_all && tr->wait && tr->all_reduce_i64 && tr->world >= 1 && tr->rank >= 0 && tr->rank < tr->world, GDF_INVALID_API_CALL);
+  GDF_REQUIRE(!probe_keys->valid && !build_keys->valid, GDF_VALIDITY_UNSUPPORTED);
+  GDF_REQUIRE(probe_keys->dtype == build_keys->dtype, GDF_JOIN_DTYPE_MISMATCH);
+  const ElemKind kind = elem_kind(probe_keys->dtype);
+  GDF_REQUIRE(kind == K_I64 || kind == K_I32, GDF_UNSUPPORTED_DTYPE);
+  GDF_REQUIRE(probe_keys->size < (size_t)INT_MAX && build_keys->size < (size_t)INT_MAX, GDF_COLUMN_SIZE_TOO_BIG);
+  GDF_REQUIRE((probe_keys->size == 0 || (probe_keys->data && probe_pos)) && (build_keys->size == 0 || (build_keys->data && build_pos)), GDF_DATASET_EMPTY);
+  *declined = 1;
+  *info = gdf_amd_dist_info{};
+  gdf_column_view(probe_indices, nullptr, nullptr, 0, N_GDF_TYPES);
+  gdf_column_view(build_indices, nullptr, nullptr, 0, N_GDF_TYPES);
+  const int world = tr->world;
+  const int64_t n_p = (int64_t)probe_keys->size, n_b = (int64_t)build_keys->size;
+
+  // ---- numbers every rank must agree on: the global build-side key range, the largest and the total shard sizes ----
+  long long mm[2] = {LLONG_MAX, LLONG_MIN};
+  if (n_b) {
+    KeyTable bt;
+    gdf_column *bc = build_keys;
+    GDF_TRY(make_key_table(&bc, 1, &bt));
+    GDF_TRY(key_ranges(bt, mm));
+  }
+  int64_t mins[4] = {mm[0] <= mm[1] ? (int64_t)mm[0] : INT64_MAX, mm[0] <= mm[1] ? -(int64_t)mm[1] : INT64_MAX, -n_p, -n_b};
+  if (tr->all_reduce_i64(tr->ctx, mins, 4, 0) != 0) return GDF_C_ERROR;
+  int64_t sums[2] = {n_p, n_b};
+  if (tr->all_reduce_i64(tr->ctx, sums, 2, 2) != 0) return GDF_C_ERROR;
+  const int64_t lo = mins[0], hi = mins[1] == INT64_MAX ? INT64_MIN : -mins[1], p_max = -mins[2], b_max = -mins[3];
+  const int64_t p_total = sums[0], b_total = sums[1];
+  // (everything up to the first exchange is decided from these shared numbers: every rank takes the same exits)
+  if (b_total == 0 || p_total == 0 || lo > hi || (uint64_t)hi - (uint64_t)lo >= (uint64_t)0x7ffffffe) return GDF_SUCCESS;
+  if (chunks < 1) chunks = 1;
+  if ((int64_t)chunks > p_max) chunks = (int)p_max;
+  const int64_t step_max = (p_max + chunks - 1) / chunks;
+  int fb_b = 0, cb_b = 0, fb_p = 0, cb_p = 0;
+  uint32_t cap_b = 0, cap_p = 0;
+  gdf_error e = fj_plan(world, b_total, b_max, 1.0, &fb_b, &cb_b, &cap_b);
+  if (e == GDF_UNSUPPORTED_METHOD) return GDF_SUCCESS;
+  GDF_TRY(e);
+  e = fj_plan(world, b_total, step_max, std::max(1.0, (double)p_total / (double)std::max<int64_t>(b_total, 1)), &fb_p, &cb_p, &cap_p);
+  if (e == GDF_UNSUPPORTED_METHOD) return GDF_SUCCESS;
+  GDF_TRY(e);
+  const size_t rpr_b = (size_t)8 << cb_b, rpr_p = (size_t)8 << cb_p;
+  const size_t block_b = rpr_b * cap_b, block_p = rpr_p * cap_p;
+  // result positions are 31-bit and count the blocks' room and empty regions
+  if ((uint64_t)chunks * world * block_p >= 0x7fffffffULL || (uint64_t)world * block_b >= 0x7fffffffULL) return GDF_SUCCESS;
+  info->world = world; info->chunks = chunks; info->lo = lo; info->hi = hi;
+  info->fine_bits_p = fb_p; info->coarse_bits_p = cb_p; info->cap_p = cap_p; info->block_p = (int64_t)block_p;
+  info->fine_bits_b = fb_b; info->coarse_bits_b = cb_b; info->cap_b = cap_b; info->block_b = (int64_t)block_b;
+
+  // a failure between a posted exchange and its wait must not leave the peers' blocks on the wire: settle what is posted first
+  std::deque<DistExchange> wire;
+  auto settle = [&]() { for (DistExchange &x : wire) (void)dist_wait(tr, &x); };
+  struct Settle { decltype(settle) &f; ~Settle() { f(); } } settle_on_exit{settle};
+
+  // ---- build relation ----
+  wire.emplace_back();
+  DistExchange &bx = wire.back();
+  RMM_TRY(bx.sk.alloc(sizeof(uint32_t) * ((size_t)world * block_b + FJ_TILE)));
+  RMM_TRY(bx.sf.alloc(sizeof(uint32_t) * ((size_t)world * rpr_b + 1)));
+  int over = 0;
+  DevBuf dummy_pos;
+  if (!build_pos) { RMM_TRY(dummy_pos.alloc(sizeof(uint32_t))); build_pos = dummy_pos.as<uint32_t>(); }
+  GDF_TRY(fj_send(build_keys, lo, hi, world, cb_b, cap_b, bx.sk.as<uint32_t>(), build_pos, bx.sf.as<uint32_t>(), &over));
+  bool any = false;
+  GDF_TRY(dist_agree(tr, over != 0, &any));
+  if (any) return GDF_SUCCESS;             // a region overflowed somewhere (skewed build keys): every rank leaves
+  GDF_TRY(dist_post(tr, &bx, block_b, rpr_b));
+
+  // ---- probe relation: `chunks` slices, software-pipelined ----
+  const int64_t step = (n_p + chunks - 1) / chunks;
+  info->slice_rows = step;
+  const int width = kind == K_I64 ? 8 : 4;
+  std::unique_ptr<PreparedBuild> build;
+  ProbeAccum *acc = nullptr;               // owned by accum_finish once it is called
+  // (queued level-2 kernels still read the receive buffers and write the accumulator's: drain the stream before anything is freed)
+  struct AccGuard { ProbeAccum *&a; ~AccGuard() { (void)hipStreamSynchronize(stream0()); delete a; } } acc_guard{acc};
+  bool failed = false;
+  DevBuf dummy_ppos;
+  if (!probe_pos) { RMM_TRY(dummy_ppos.alloc(sizeof(uint32_t))); probe_pos = dummy_ppos.as<uint32_t>(); }
+  DistExchange *pending = nullptr;
+  int pending_index = 0;
+  auto add = [&](DistExchange *x, int index) -> gdf_error {
+    GDF_TRY(dist_wait(tr, x));
+    if (!acc || failed) return GDF_SUCCESS;
+    const gdf_error ea = fj_probe_add(acc, x->rk.as<uint32_t>(), x->rf.as<uint32_t>(), cap_p, (int64_t)index * (int64_t)world * (int64_t)block_p,
+                                      (int64_t)world * (int64_t)block_p);
+    if (ea == GDF_UNSUPPORTED_METHOD || ea == GDF_COLUMN_SIZE_TOO_BIG) { failed = true; return GDF_SUCCESS; }     // a plan change, settled below
+    return ea;
+  };
+  for (int c = 0; c < chunks; ++c) {
+    const int64_t a = std::min<int64_t>(n_p, (int64_t)c * step), b = std::min<int64_t>(n_p, (int64_t)(c + 1) * step);
+    gdf_column slice = *probe_keys;
+    slice.data = probe_keys->data ? (char *)probe_keys->data + (size_t)a * width : nullptr;
+    slice.size = (gdf_size_type)(b - a);
+    wire.emplace_back();
+    DistExchange &px = wire.back();
+    RMM_TRY(px.sk.alloc(sizeof(uint32_t) * ((size_t)world * block_p + FJ_TILE)));
+    RMM_TRY(px.sf.alloc(sizeof(uint32_t) * ((size_t)world * rpr_p + 1)));
+    GDF_TRY(fj_send(&slice, lo, hi, world, cb_p, cap_p, px.sk.as<uint32_t>(), probe_pos + a, px.sf.as<uint32_t>(), &over));
+    failed = failed || over != 0;
+    // the slice goes on the wire BEFORE anybody asks whether it overflowed (the agreement used to sit in front of the
+    // first exchange, one blocking all-reduce on the happy path of every join); an overflowed buffer is memory safe, just useless
+    GDF_TRY(dist_post(tr, &px, block_p, rpr_p));
+    if (c == 0) {
+      // a region overflowed on some rank's FIRST slice (skewed probe keys are usually skewed everywhere): every rank leaves now,
+      // before three more slices are regrouped, shipped and partitioned for nothing
+      GDF_TRY(dist_agree(tr, over != 0, &any));
+      if (any) return GDF_SUCCESS;
+    }
+    if (!build) {
+      GDF_TRY(dist_wait(tr, &bx));
+      PreparedBuild *pb = nullptr;
+      gdf_error eb = fj_build_create(bx.rk.as<uint32_t>(), bx.rf.as<uint32_t>(), world, lo, fb_b, cb_b, cap_b, b_total / world + 1, &pb);
+      build.reset(pb);
+      if (eb == GDF_SUCCESS) {
+        eb = accum_begin(build.get(), (size_t)(p_total / world + 1), &acc);
+        if (eb != GDF_SUCCESS) acc = nullptr;
+      }
+      if (eb == GDF_UNSUPPORTED_METHOD || eb == GDF_COLUMN_SIZE_TOO_BIG) failed = true;
+      else GDF_TRY(eb);
+      if (!build) build.reset(new PreparedBuild());       // (so that the build exchange is not waited for again)
+    }
+    if (pending) GDF_TRY(add(pending, pending_index));
+    pending = &px;
+    pending_index = c;
+  }
+  if (pending) GDF_TRY(add(pending, pending_index));
+  bool have = false;
+  if (acc && !failed) {
+    ProbeAccum *fin = acc;
+    acc = nullptr;                                           // accum_finish owns it from here
+    const gdf_error ef = accum_finish(fin, probe_indices, build_indices);
+    if (ef == GDF_UNSUPPORTED_METHOD || ef == GDF_COLUMN_SIZE_TOO_BIG) failed = true;
+    else { GDF_TRY(ef); have = true; }
+  }
+  GDF_TRY(dist_agree(tr, failed || !have, &any));
+  if (any) {
+    if (have) { gdf_column_free(probe_indices); gdf_column_free(build_indices); }
+    gdf_column_view(probe_indices, nullptr, nullptr, 0, N_GDF_TYPES);
+    gdf_column_view(build_indices, nullptr, nullptr, 0, N_GDF_TYPES);
+    return GDF_SUCCESS;
+  }
+  HIP_TRY(hipStreamSynchronize(stream0()));                  // the receive buffers go out of scope with this call
+  *declined = 0;
+  return GDF_SUCCESS;
+}
+
 }  // namespace gdf_amd
 
 using namespace gdf_amd;
@@ -5193,6 +5384,15 @@ __attribute__((visibility("default"))) gdf_error gdf_amd_fj_probe_add(gdf_amd_jo
                                                                      uint32_t cap, int64_t position_base, int64_t buffer_elems) {
   return gdf_amd::guarded([&]() -> gdf_error {
   return fj_probe_add(reinterpret_cast<ProbeAccum *>(probe), recv_keys, recv_fill, cap, position_base, buffer_elems);
+  });
+}
+
+// the multi-GPU join behind the C ABI (include/gdf/gdf_amd_ext.h)
+__attribute__((visibility("default"))) gdf_error gdf_amd_dist_inner_join(gdf_column *probe_keys, gdf_column *build_keys, gdf_amd_transport *transport,
+                                                                        int chunks, uint32_t *probe_pos, uint32_t *build_pos, gdf_column *probe_indices,
+                                                                        gdf_column *build_indices, gdf_amd_dist_info *info, int *declined) {
+  return gdf_amd::guarded([&]() -> gdf_error {
+  return dist_inner_join(probe_keys, build_keys, transport, chunks, probe_pos, build_pos, probe_indices, build_indices, info, declined);
   });
 }
 

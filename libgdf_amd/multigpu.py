@@ -574,6 +574,61 @@ def _fj_plan(world, build_total, rows_max, rows_per_key=1.0):
     return api.fj_plan(world, build_total, rows_max, rows_per_key)
 
 
+_TRANSPORTS = {}            # process group -> the gdf_amd_transport the C entry point talks through
+
+
+def transport_for(group=None):
+    """The gdf_amd_transport of a torch.distributed group, made once: the library's own RCCL communicator when the group's backend
+    is nccl (its unique id travels over the group's object broadcast), Python callbacks that stage the blocks through host memory
+    for any other backend (gloo: ranks sharing one GPU in the tests)."""
+    import torch.distributed as dist
+    from . import api
+    key = group if group is not None else "default"
+    t = _TRANSPORTS.get(key)
+    if t is None:
+        if dist.get_backend(group) == "nccl":
+            world, rank = dist.get_world_size(group), dist.get_rank(group)
+            box = [api.RcclTransport.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            t = api.RcclTransport(box[0], world, rank)
+        else:
+            t = api.CallbackTransport(group)
+        _TRANSPORTS[key] = t
+    return t
+
+
+def close_transports():
+    """destroy the cached transports (before the process group goes away)"""
+    for t in _TRANSPORTS.values():
+        t.close()
+    _TRANSPORTS.clear()
+
+
+import atexit as _atexit
+_atexit.register(close_transports)      # an RCCL communicator must not outlive the HIP runtime's own teardown
+
+
+def _fused_inner_join_c(probe_keys, build_keys, group, chunks):
+    from . import api
+    from .columns import Column
+    tr = transport_for(group)
+    got = api.dist_inner_join(Column(probe_keys), Column(build_keys), tr, chunks)
+    if got is None:
+        return None
+    ppos, bpos, li, ri, info = got
+    lay_p = api.FjLayout(info.world, info.fine_bits_p, info.coarse_bits_p, info.cap_p)
+    lay_b = api.FjLayout(info.world, info.fine_bits_b, info.coarse_bits_b, info.cap_b)
+    n, step = probe_keys.numel(), max(int(info.slice_rows), 1)
+    brows = api.FjRows(bpos, 0, info.world * lay_b.block + api.FJ_DUMP_ELEMS)
+    prows = []
+    for c in range(info.chunks):
+        a, b = min(n, c * step), min(n, (c + 1) * step)
+        prows.append(api.FjRows(ppos[a:b], a, info.world * lay_p.block + api.FJ_DUMP_ELEMS))
+    STATS["bytes_sent"] += 4 * (info.world - 1) * (lay_b.block + lay_b.regions_per_rank + info.chunks * (lay_p.block + lay_p.regions_per_rank))
+    STATS["messages"] += 2 * (info.world - 1) * (1 + info.chunks)
+    return FusedPairs(lay_p, lay_b, group, li, ri, brows, prows)
+
+
 def fused_inner_join(probe_keys, build_keys, group=None, chunks=4, plan_fn=_fj_plan, send_fn=_fj_send, build_fn=_fj_build):
     """Inner join of two row-sharded relations on one integer key column with the rank split FUSED into the join's own
     partitioning (csrc/join.hip "FUSED multi-GPU join"): every rank regroups its rows by (owner rank, coarse partition on that
@@ -586,6 +641,11 @@ def fused_inner_join(probe_keys, build_keys, group=None, chunks=4, plan_fn=_fj_p
     the caller can fall back to ``distributed_inner_join`` collectively."""
     import torch
     import torch.distributed as dist
+    if plan_fn is _fj_plan and send_fn is _fj_send and build_fn is _fj_build and probe_keys.is_cuda:
+        # the product path: ONE C call (gdf_amd_dist_inner_join, include/gdf/gdf_amd_ext.h) plans, regroups, exchanges and joins;
+        # what follows below is the same protocol in Python, kept as its executable specification for the CPU tests
+        # (tests/test_multigpu_gloo.py run it over gloo with numpy stand-ins for the three device steps)
+        return _fused_inner_join_c(probe_keys, build_keys, group, chunks)
     world = dist.get_world_size(group)
     dev = probe_keys.device
     narrow = _narrow_range(probe_keys, build_keys, group)

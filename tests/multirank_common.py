@@ -114,6 +114,7 @@ def _worker(rank, world, port, big, q, backend="gloo"):
            gk.cpu().numpy(), gv.cpu().numpy(), others,
            None if fpg is None else fpg.cpu().numpy(), None if fbg is None else fbg.cpu().numpy()))
     dist.barrier()
+    multigpu.close_transports()
     dist.destroy_process_group()
 
 
@@ -184,6 +185,10 @@ def _uneven_worker(rank, world, port, q, backend="gloo"):
     t = torch.tensor([rank + 1], dtype=torch.int64, device=p.device)
     dist.all_reduce(t)                                   # pairs with a stray exchange if a rank ran fewer slices
     assert int(t) == world * (world + 1) // 2
+    # the fused join through the C entry point (gdf_amd_dist_inner_join) on the same uneven shards: a rank without probe rows and
+    # one without build rows run every exchange and every agreement; the answer -- pairs or a decline -- is the same on all ranks
+    fpairs = multigpu.fused_inner_join(p, b, chunks=4)
+    fpg, fbg = fpairs.global_ids() if fpairs is not None else (None, None)
     out = {}
     k = (p % 7)
     for name, v in vals[rank].items():
@@ -191,8 +196,9 @@ def _uneven_worker(rank, world, port, q, backend="gloo"):
         for op in ("count", "avg"):
             ok, ov = multigpu.distributed_group_by(op, k, tv)
             out[(name, op)] = (ok.cpu().numpy(), ov.cpu().numpy())
-    q.put((rank, pg.cpu().numpy(), bg.cpu().numpy(), out))
+    q.put((rank, pg.cpu().numpy(), bg.cpu().numpy(), out, None if fpg is None else fpg.cpu().numpy(), None if fbg is None else fbg.cpu().numpy()))
     dist.barrier()
+    multigpu.close_transports()
     dist.destroy_process_group()
 
 
@@ -217,6 +223,10 @@ def check_uneven(world, results):
     exp = np.stack([gp[li], gb[ri]], axis=1)
     got = np.concatenate([np.stack([r[1], r[2]], axis=1) for r in results])
     np.testing.assert_array_equal(got[np.lexsort(got.T[::-1])], exp[np.lexsort(exp.T[::-1])])
+    assert all(r[4] is not None for r in results) or all(r[4] is None for r in results)          # a result or a decline, on ALL ranks
+    if results[0][4] is not None:
+        got = np.concatenate([np.stack([r[4], r[5]], axis=1) for r in results])
+        np.testing.assert_array_equal(got[np.lexsort(got.T[::-1])], exp[np.lexsort(exp.T[::-1])])
     import pandas as pd
     allk = np.concatenate(probes) % 7
     for name in ("int8", "int32", "float32"):

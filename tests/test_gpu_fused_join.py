@@ -161,3 +161,96 @@ def test_send_reports_regions_that_overflow(gdf):
     assert lay is not None and lay.cap < n // 2
     _, _, _, over = api.fj_send(Column(torch.from_numpy(keys).cuda()), 0, n, lay, 0)
     assert over
+
+
+# ---- gdf_amd_dist_inner_join: the whole fused join behind ONE C call (include/gdf/gdf_amd_ext.h) ----
+def _dist_join_one_rank(gdf, transport, probe, build, chunks):
+    """-> sorted (probe row, build row) pairs of a world-1 distributed join, or None when the library declined"""
+    import torch
+    from libgdf_amd import api
+    from libgdf_amd.columns import Column
+    tp, tb = torch.from_numpy(probe).cuda(), torch.from_numpy(build).cuda()
+    got = api.dist_inner_join(Column(tp), Column(tb), transport, chunks)
+    if got is None:
+        return None
+    ppos, bpos, li, ri, info = got
+    assert info.world == 1 and 1 <= info.chunks <= max(chunks, 1)
+    assert info.block_p == (8 << info.coarse_bits_p) * info.cap_p and info.block_b == (8 << info.coarse_bits_b) * info.cap_b
+    per_buf, step = info.world * info.block_p, max(int(info.slice_rows), 1)
+    li, ri = li.tensor().long(), ri.tensor().long()
+    # position -> local row: invert the senders' maps (world 1: this rank sent everything it received)
+    brow = api.FjRows(bpos, 0, info.block_b + api.FJ_DUMP_ELEMS).materialize()
+    rows_b = brow[ri].cpu().numpy().astype(np.int64)
+    rows_p = np.empty(li.numel(), dtype=np.int64)
+    which = (li // per_buf).cpu().numpy()
+    n = len(probe)
+    for c in range(info.chunks):
+        a, b = min(n, c * step), min(n, (c + 1) * step)
+        sel = which == c
+        if sel.any():
+            prow = api.FjRows(ppos[a:b], a, per_buf + api.FJ_DUMP_ELEMS).materialize()
+            rows_p[sel] = prow[li[torch.from_numpy(sel).cuda()] - c * per_buf].cpu().numpy()
+    return sort_pairs(rows_p, rows_b)
+
+
+def sort_pairs(a, b):
+    o = np.lexsort((b, a))
+    return a[o], b[o]
+
+
+@pytest.mark.parametrize("wire", ["rccl", "callbacks"])
+@pytest.mark.parametrize("dtype", [np.int64, np.int32])
+@pytest.mark.parametrize("chunks", [1, 4])
+def test_dist_inner_join_c_entry_one_rank(gdf, wire, dtype, chunks):
+    """gdf_amd_dist_inner_join at world 1 through both wires -- the library's own RCCL communicator (gdf_amd_rccl_transport_create:
+    ncclCommInitRank on a 128-byte id, ncclSend / ncclRecv groups on its own stream) and a transport of host-staged callbacks --
+    against the oracle: plan, sender regroup, exchange of equal blocks + fill counters, receiver level 2 + probe, agreement, all
+    inside the C call.  A fifth of the probe keys miss; keys start at an offset (they travel as key - lo)."""
+    import torch.distributed as dist
+    from libgdf_amd import api
+    rs = np.random.RandomState(chunks + len(wire))
+    nb, npr = 40_000, 700_000
+    build = (rs.permutation(nb * 5 // 4)[:nb] + 1_000_000).astype(dtype)
+    probe = (rs.randint(0, nb * 5 // 4, size=npr) + 1_000_000).astype(dtype)
+    if wire == "rccl":
+        tr = api.RcclTransport(api.RcclTransport.unique_id(), 1, 0)
+    else:
+        import os
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if not dist.is_initialized():
+            dist.init_process_group("gloo", rank=0, world_size=1)
+        tr = api.CallbackTransport()
+    try:
+        got = _dist_join_one_rank(gdf, tr, probe, build, chunks)
+        assert got is not None
+        el, er = oracle.join([probe], [build], "inner")
+        np.testing.assert_array_equal(got[0], el)
+        np.testing.assert_array_equal(got[1], er)
+    finally:
+        tr.close()
+
+
+@pytest.mark.parametrize("case", ["keys-wider-than-31-bits", "one-key-holds-a-third", "empty-build", "empty-probe"])
+def test_dist_inner_join_c_entry_declines_collectively(gdf, case):
+    """Shapes the fused path cannot take come back as *declined = 1 (on every rank: the answer is an all-reduce) with no result
+    columns, not as an error: keys whose global range does not narrow to 31 bits, skewed keys that overflow the fixed-size
+    regions, an empty relation.  The caller then takes the key shuffle (libgdf_amd/multigpu.py)."""
+    from libgdf_amd import api
+    rs = np.random.RandomState(3)
+    nb, npr = 50_000, 900_000
+    build = rs.permutation(nb).astype(np.int64)
+    probe = rs.randint(0, nb, size=npr).astype(np.int64)
+    if case == "keys-wider-than-31-bits":
+        build[0] = 1 << 40
+    elif case == "one-key-holds-a-third":
+        probe[rs.rand(npr) < 0.34] = 7
+    elif case == "empty-build":
+        build = build[:0]
+    else:
+        probe = probe[:0]
+    tr = api.RcclTransport(api.RcclTransport.unique_id(), 1, 0)
+    try:
+        assert _dist_join_one_rank(gdf, tr, probe, build, 4) is None
+    finally:
+        tr.close()

@@ -1418,6 +1418,19 @@ __global__ __launch_bounds__(256) void gb_part_bounds(const K *__restrict__ keys
   }
 }
 
+// SPECULATIVE record layout (round 4): no count pass.  Partition q owns G segments of cap[q] records, one per scatter workgroup,
+// at record index (qprefix[q] * G + w * cap[q]); a workgroup appends to its own segments only -- no atomics, no histogram -- and
+// leaves its fill counts in fill[q * G + w].  The capacities come from the strided sample (expected share + 5 sigma of the
+// estimate + 6 sigma of a workgroup's own fluctuation).  A segment that would overflow raises flags[2]; every workgroup sees the
+// flag at its next tile and stops, and the host repeats the call on the exact layout (gbp_count + scan) -- clustered input, e.g.
+// rows sorted by key, ends there after a few tiles.  gb_part_aggregate streams a partition's whole region and masks the slack.
+struct GbSpec {
+  const uint32_t *qprefix;         // [P + 1] exclusive prefix of cap[] (in records PER WORKGROUP); nullptr: the exact layout
+  const uint32_t *cap;             // [P]
+  uint32_t *fill;                  // [P * G]
+  uint32_t G;                      // workgroups of the scatter kernel (= segments per partition)
+};
+
 // one (32-bit packed key, 64-bit accumulator image) pair as the fused partition pass writes it: 12 bytes, ONE store per row
 struct __attribute__((aligned(4))) GbRec { uint32_t key, lo, hi; };
 
@@ -1425,19 +1438,30 @@ struct __attribute__((aligned(4))) GbRec { uint32_t key, lo, hi; };
 template <bool VBIT, class K, bool REC = false>
 __global__ __launch_bounds__(GB_DENSE_THREADS) void gb_part_aggregate(const K *__restrict__ keys, const uint64_t *__restrict__ payload,
                                                                       const GbPartUnit *__restrict__ units, int id_bits, int op, bool flt,
-                                                                      unsigned long long *gacc, unsigned int *grows, unsigned int *gvalid) {
+                                                                      unsigned long long *gacc, unsigned int *grows, unsigned int *gvalid,
+                                                                      GbSpec spec) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gb_lds[];
+  __shared__ uint32_t seg_fill[NUM_CU];                             // speculative layout: the fill counts of this partition's segments
   const uint32_t ids = 1u << id_bits;
   unsigned long long *lacc = (unsigned long long *)gb_lds;
   unsigned int *lrows = (unsigned int *)(lacc + ids);
   unsigned int *lvalid = lrows + ids;                               // VBIT only
+  const GbPartUnit u = units[blockIdx.x];
   for (uint32_t i = threadIdx.x; i < ids; i += GB_DENSE_THREADS) {
     lacc[i] = acc_identity(op);
     lrows[i] = 0;
     if (VBIT) lvalid[i] = 0;
   }
+  // speculative layout (REC only): the unit is a slice of the partition's REGION -- G segments of `cap` slots, the first fill[w] of
+  // segment w hold records.  magic = ceil(2^32 / cap): slot / cap by one multiply and a correction
+  uint32_t sp_cap = 0, sp_magic = 0, sp_first = 0;
+  if (REC && spec.qprefix) {
+    for (uint32_t w = threadIdx.x; w < spec.G; w += GB_DENSE_THREADS) seg_fill[w] = spec.fill[(size_t)u.part * spec.G + w];
+    sp_cap = spec.cap[u.part];
+    sp_magic = (uint32_t)((((uint64_t)1 << 32) + sp_cap - 1) / sp_cap);
+    sp_first = u.begin - spec.qprefix[u.part] * spec.G;             // the unit's first slot, counted from the region's start
+  }
   block_sync();
-  const GbPartUnit u = units[blockIdx.x];
   const uint32_t mask = ids - 1;
   for (uint32_t base = 0; base < u.count; base += GB_DENSE_THREADS * GB_DENSE_BATCH) {
     K k[GB_DENSE_BATCH];
@@ -1457,7 +1481,15 @@ __global__ __launch_bounds__(GB_DENSE_THREADS) void gb_part_aggregate(const K *_
     }
 #pragma unroll
     for (int b = 0; b < GB_DENSE_BATCH; ++b) {
-      if (base + b * GB_DENSE_THREADS + threadIdx.x < u.count) {
+      bool live = base + b * GB_DENSE_THREADS + threadIdx.x < u.count;
+      if (REC && sp_cap) {                       // (uniform branch) a slot behind its segment's fill count holds nothing
+        const uint32_t o = sp_first + base + b * GB_DENSE_THREADS + threadIdx.x;
+        uint32_t w = __umulhi(o, sp_magic);
+        uint32_t off = o - w * sp_cap;
+        if ((int32_t)off < 0) { --w; off += sp_cap; }          // the estimate is at most one too large (o < 2^31)
+        live = live && off < seg_fill[w < spec.G ? w : 0];
+      }
+      if (live) {
         const uint32_t id = (uint32_t)(k[b] >> (VBIT ? 1 : 0)) & mask;
         atomicAdd(&lrows[id], 1u);
         if (!VBIT || (k[b] & 1)) {
@@ -1670,7 +1702,6 @@ __device__ __forceinline__ void gbp_pack32(const KeyTable &t, const GbKeyPlan &p
 constexpr int GBP_HOT_BITS = 12;
 constexpr uint32_t GBP_HOT_IDS = 1u << GBP_HOT_BITS;
 constexpr uint32_t GBP_NO_HOT = 0xffffffffu;
-constexpr int GBP_HOT_SAMPLE_WINDOWS = 64;       // strided windows of 1024 rows: 65536 sampled rows
 struct GbHot {
   uint32_t window;                 // key >> GBP_HOT_BITS of the hot ids (the key WITHOUT its validity bit)
   unsigned long long *gacc;        // the global cells the partials are merged into (indexed by key)
@@ -1678,21 +1709,24 @@ struct GbHot {
   int dbg;                         // LAB build: ablation bits (knob GDF_GBP_HOT_DBG), 0 in production
 };
 
-// out[0] = the densest window of GBP_HOT_IDS ids among the sampled rows, out[1] = its rows, out[2] = sampled rows with a valid,
-// in-range key.  One workgroup; nwin <= 4096 windows.
-__global__ __launch_bounds__(1024) void gbp_sample_hot(KeyTable t, GbKeyPlan plan, uint32_t nwin, unsigned int *__restrict__ out) {
+// Strided sample of the packed keys: counts[w] += sampled rows whose key lies in window w (GBP_HOT_IDS ids each, nwin <= 4096
+// windows), counts[nwin] += sampled rows with a valid, in-range key.  GBP_SAMPLE_WINDOWS windows of 1024 rows spread evenly over
+// the table (2^21 rows: 25 MB of C5's 20 GB), sixteen windows per workgroup.  The host reads the counts back and decides two
+// things from them: the hot window (the densest one, when it holds enough of the rows) and, for the SPECULATIVE record layout
+// (GbSpec below), how much room every partition gets.
+constexpr int GBP_SAMPLE_WINDOWS = 2048;
+constexpr int GBP_SAMPLE_PER_WG = 16;
+__global__ __launch_bounds__(1024) void gbp_sample_hist(KeyTable t, GbKeyPlan plan, uint32_t nwin, unsigned int *__restrict__ counts) {
   __shared__ uint32_t cnt[4096];
-  __shared__ unsigned long long best[1024 / WAVE];
-  __shared__ uint32_t tot[1024 / WAVE];
   for (uint32_t q = threadIdx.x; q < 4096; q += 1024) cnt[q] = 0;
   block_sync();
-  const int64_t stride = t.nrows / GBP_HOT_SAMPLE_WINDOWS;
+  const double stride = (double)t.nrows / (double)GBP_SAMPLE_WINDOWS;
   uint32_t good = 0;
-  for (int w0 = 0; w0 < GBP_HOT_SAMPLE_WINDOWS; w0 += 8) {
+  for (int w0 = 0; w0 < GBP_SAMPLE_PER_WG; w0 += 8) {
     uint32_t src[8], key[8], okmask, outmask;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const int64_t i = (int64_t)(w0 + k) * stride + threadIdx.x;
+      const int64_t i = (int64_t)((double)(blockIdx.x * GBP_SAMPLE_PER_WG + w0 + k) * stride) + threadIdx.x;
       src[k] = (uint32_t)(i < t.nrows ? i : t.nrows - 1);
     }
     gbp_pack32<8, -1, -1>(t, plan, src, key, okmask, outmask);
@@ -1703,25 +1737,10 @@ __global__ __launch_bounds__(1024) void gbp_sample_hot(KeyTable t, GbKeyPlan pla
     }
   }
   block_sync();
-  unsigned long long b = 0;          // count << 32 | (0xffffffff - window): the maximum is the densest window, ties to the lowest
-  for (uint32_t q = threadIdx.x; q < nwin; q += 1024) {
-    const unsigned long long c = ((unsigned long long)cnt[q] << 32) | (0xffffffffu - q);
-    b = c > b ? c : b;
-  }
-  for (int d = 1; d < WAVE; d <<= 1) {
-    const unsigned long long o = ((unsigned long long)(uint32_t)__shfl_xor((int)(b >> 32), d) << 32) | (uint32_t)__shfl_xor((int)b, d);
-    b = o > b ? o : b;
-  }
+  for (uint32_t q = threadIdx.x; q < nwin; q += 1024)
+    if (cnt[q]) atomicAdd(&counts[q], cnt[q]);
   good = wave_reduce_add(good);
-  if (lane_id() == 0) { best[threadIdx.x / WAVE] = b; tot[threadIdx.x / WAVE] = good; }
-  block_sync();
-  if (threadIdx.x == 0) {
-    uint32_t all = 0;
-    for (int w = 0; w < 1024 / WAVE; ++w) { b = best[w] > b ? best[w] : b; all += tot[w]; }
-    out[0] = 0xffffffffu - (uint32_t)b;
-    out[1] = (uint32_t)(b >> 32);
-    out[2] = all;
-  }
+  if (lane_id() == 0 && good) atomicAdd(&counts[nwin], good);
 }
 
 // flags[0] += rows dropped for a null key, flags[1] = 1 when a key lies outside the plan's ranges
@@ -1991,11 +2010,14 @@ __device__ __forceinline__ uint32_t gbp_opaque_tid() {
 //   * HOT (round 4, GbHot above): the rows of the hot key window are folded into LDS accumulators instead of being staged; the
 //     stage then holds GBP_HOT_CAP records and a tile with more cold rows is regrouped and flushed in rounds.
 constexpr int GBP_HOT_CAP = 5 * GBP_SC_THREADS;         // 5120 records: 60 KB next to 64 KB of accumulators and 32 KB of counters
-template <bool VBIT, int K0, int K1, bool VMASK, bool HOT = false>
+//   * SPEC (round 4, GbSpec): no count pass in front -- every workgroup appends to its own segment of every partition; the scan
+//     step checks the segment's room, a workgroup that runs out raises flags[2] and all of them stop at their next tile.
+constexpr uint32_t GBP_SPEC_SKIP = 0xA0000000u;          // a destination at or beyond 2^31: the flush does not store there
+template <bool VBIT, int K0, int K1, bool VMASK, bool HOT = false, bool SPEC = false>
 __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter_static(KeyTable t, GbKeyPlan plan, GbVal val, int fold_op, int low,
                                                                   uint32_t nparts, int64_t chunk, int nchunks, const uint32_t *__restrict__ offs,
                                                                   GbRec *__restrict__ rec_out, unsigned int *__restrict__ flags,
-                                                                  uint32_t qstride, uint32_t cstride, GbHot hot) {
+                                                                  uint32_t qstride, uint32_t cstride, GbHot hot, GbSpec spec) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gbp_lds[];
   constexpr int CAP = HOT ? GBP_HOT_CAP : GBP_SC_TILE;                       // staged records per round
   constexpr int FLUSH_ITEMS = CAP / GBP_SC_THREADS;
@@ -2051,6 +2073,21 @@ __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter_static(KeyTable t,
   if constexpr (HOT) {
     for (uint32_t i = threadIdx.x; i < GBP_HOT_IDS; i += GBP_SC_THREADS) { hacc[i] = acc_identity(fold_op); hrows[i] = 0; hvalid[i] = 0; }
   }
+  // SPEC: the scan thread of partitions b = 2 tid, 2 tid + 1 keeps their segments' first record and room in registers; cursor[]
+  // counts what the segment holds so far (never reset: one segment per partition for the whole kernel)
+  uint32_t seg_base[PER], seg_cap[PER];
+  __shared__ uint32_t spec_abort;
+  if constexpr (SPEC) {
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const uint32_t b = threadIdx.x * PER + q;
+      const bool in = b < nparts;
+      seg_cap[q] = in ? spec.cap[b] : 0u;
+      seg_base[q] = in ? spec.qprefix[b] * spec.G + blockIdx.x * seg_cap[q] : 0u;
+      cursor[b] = 0;
+    }
+    if (threadIdx.x == 0) spec_abort = 0;
+  }
   block_sync();
   // chunk -> workgroup: XCD x (workgroups x, x + 8, ...: MI355X_MICROARCH.md "Workgroup dispatch") takes the x-th EIGHTH of the chunks, its
   // workgroups round-robin inside it.  The regions of chunks c and c + 1 are neighbours inside every partition and share their
@@ -2060,11 +2097,18 @@ __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter_static(KeyTable t,
   for (int ci = first; xcd_map ? ci < per_xcd : ci < nchunks; ci += step) {
     const int c = xcd_map ? (int)(blockIdx.x & 7u) * per_xcd + ci : ci;
     if (c >= nchunks) break;
-    for (uint32_t q = threadIdx.x; q < nparts; q += GBP_SC_THREADS) cursor[q] = offs[(size_t)q * qstride + (size_t)c * cstride];
+    if constexpr (!SPEC) {
+      for (uint32_t q = threadIdx.x; q < nparts; q += GBP_SC_THREADS) cursor[q] = offs[(size_t)q * qstride + (size_t)c * cstride];
+    }
     const int64_t begin = (int64_t)c * chunk;
     const int64_t end = begin + chunk < t.nrows ? begin + chunk : t.nrows;
     for (int64_t tile = begin; tile < end; tile += GBP_SC_TILE) {
       request(tile, end);
+      // SPEC: somebody ran out of room -- the host repeats the call on the exact layout, the rest of this pass is wasted work
+      // (thread 0 looks at the flag once per tile; everybody acts on it behind the tile's first barrier)
+      if constexpr (SPEC) {
+        if (threadIdx.x == 0) spec_abort = __hip_atomic_load(&flags[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       // ---- consume: packed 32-bit key, flags as bit masks ----
       const uint32_t tid = gbp_opaque_tid();
       uint32_t k32[GBP_ITEMS], okmask = (1u << GBP_ITEMS) - 1u, outside = 0, inrange = 0, vmask = VMASK ? 0u : 0xffffffffu;
@@ -2137,6 +2181,9 @@ __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter_static(KeyTable t,
       }
       gbp_rank<GBP_ITEMS>(hist, part, livemask, rk);
       block_sync();
+      if constexpr (SPEC) {
+        if (spec_abort) return;                     // workgroup-uniform (written before the barrier above); no hot merge: the result is discarded
+      }
       {   // exclusive scan of hist[0..MAX_PARTS) by the 1024 threads, PER consecutive partitions each; clears hist for the next tile
         uint32_t v[PER], sum = 0;
 #pragma unroll
@@ -2150,8 +2197,16 @@ __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter_static(KeyTable t,
         for (int q = 0; q < PER; ++q) {
           const uint32_t b = threadIdx.x * PER + q;
           start[b] = run;
-          gbase[b] = cursor[b] - run;
-          cursor[b] += v[q];
+          if constexpr (SPEC) {
+            const uint32_t have = cursor[b];
+            const bool fits = have + v[q] <= seg_cap[q];
+            if (!fits) flags[2] = 1u;              // (the records of this run go nowhere: GBP_SPEC_SKIP)
+            gbase[b] = fits ? seg_base[q] + have - run : GBP_SPEC_SKIP - run;
+            cursor[b] = fits ? have + v[q] : have;
+          } else {
+            gbase[b] = cursor[b] - run;
+            cursor[b] += v[q];
+          }
           run += v[q];
         }
       }
@@ -2199,7 +2254,7 @@ __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter_static(KeyTable t,
           // LAB bit 8: the same records as one contiguous stream per workgroup (what would the stores cost without the short runs?)
           if (LAB_BITS(hot.dbg) & 8) { dst = lab_stream + j; }
 #endif
-          if (j < cnt && !(LAB_BITS(hot.dbg) & 2)) rec_out[dst] = GbRec{kk[k], (uint32_t)vv[k], (uint32_t)(vv[k] >> 32)};   // (LAB bit 2: no stores)
+          if (j < cnt && (!SPEC || (int32_t)dst >= 0) && !(LAB_BITS(hot.dbg) & 2)) rec_out[dst] = GbRec{kk[k], (uint32_t)vv[k], (uint32_t)(vv[k] >> 32)};   // (LAB bit 2: no stores)
         }
       };
       // HOT: the stage holds CAP < TILE records; a tile with more cold rows than that (the sample mispredicted the window) sends its
@@ -2220,6 +2275,11 @@ __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter_static(KeyTable t,
       block_sync();
       flush(0);
     }
+  }
+  if constexpr (SPEC) {
+    // what this workgroup's segments hold (every partition, also the untouched ones: the aggregation reads all G counts)
+    block_sync();
+    for (uint32_t q = threadIdx.x; q < nparts; q += GBP_SC_THREADS) spec.fill[(size_t)q * spec.G + blockIdx.x] = cursor[q];
   }
   if constexpr (HOT) {
     // merge this workgroup's partials into the cells that own the keys (cell index = key), as gb_part_aggregate merges a unit
@@ -2586,7 +2646,7 @@ static gdf_error gb_path_dense(GbJob &j, bool *done) {
 // The partitioned variant of the sorted path (see the kernels above), for key type K = uint32_t (12-byte pairs,
 // when key bits + valid bit + null bit fit 32) or uint64_t.
 template <class K>
-static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, int null_bit, bool *done, bool guessed = false) {
+static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, int null_bit, bool *done, bool guessed = false, bool allow_spec = true) {
   [[maybe_unused]] const int ncols = j.ncols;
   [[maybe_unused]] gdf_column **out_keys = j.out_keys;
   [[maybe_unused]] gdf_column *out_agg = j.out_agg;
@@ -2629,6 +2689,8 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
   std::vector<uint32_t> hp;             // partition starts (fused: from the scanned histogram)
   DevBuf gacc, grows, gvalid;           // the global cells (one per key: accumulator, rows, valid values)
   bool cells_ready = false;             // made before the scatter kernel when it aggregates a hot window (GbHot)
+  GbSpec aggregate_spec{};              // the speculative record layout, when the fused pass ran on it (the plan's device arrays: keep_spec)
+  DevBuf keep_spec;
   if (fused) {
     if constexpr (sizeof(K) == 4) {
       const uint32_t P = 1u << part_bits;
@@ -2641,8 +2703,8 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
       DevBuf hist, d_start, d_flags;
       RMM_TRY(hist.alloc(sizeof(uint32_t) * ((size_t)P * nchunks + 1)));
       RMM_TRY(d_start.alloc(sizeof(uint32_t) * ((size_t)P + 1)));
-      RMM_TRY(d_flags.alloc(sizeof(unsigned int) * 2));
-      HIP_TRY(hipMemsetAsync(d_flags.p, 0, sizeof(unsigned int) * 2, stream0()));
+      RMM_TRY(d_flags.alloc(sizeof(unsigned int) * 4));          // rows dropped for a null key | range violated | speculative layout overflowed
+      HIP_TRY(hipMemsetAsync(d_flags.p, 0, sizeof(unsigned int) * 4, stream0()));
       HIP_TRY(hipMemsetAsync(hist.as<uint32_t>() + (size_t)P * nchunks, 0, sizeof(uint32_t), stream0()));
       // static key signature (gbp_pack32): one or two 4- / 8-byte integer key columns
       const bool no_static = lab::path_on("GDF_GBP_DYNAMIC");          // (read per call: the tests flip it)
@@ -2668,24 +2730,86 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
       // (skip_low) must lie below the window bits, so that the count can tell hot rows from their first column alone.
       uint32_t hot_window = GBP_NO_HOT;
       const bool lean_sig = key_sig && val_sig && !lab::knob_on("GDF_GBP_OLD");
-      if (lean_sig && id_bits == GB_PART_ID_BITS && !chunk_major && n >= ((int64_t)1 << 22) && !lab::path_on("GDF_GBP_NO_HOT") &&
-          (!skip_low || sp.shift[1] + sp.bits[1] <= GBP_HOT_BITS)) {
+      const dim3 sgrid(nchunks < NUM_CU ? nchunks : NUM_CU);
+      const bool hot_ok = lean_sig && id_bits == GB_PART_ID_BITS && !chunk_major && n >= ((int64_t)1 << 22) && !lab::path_on("GDF_GBP_NO_HOT");
+      // SPECULATIVE layout (GbSpec): no count pass; GDF_GBP_SPEC_MIN_ROWS / GDF_GBP_NO_SPEC: test switches
+      const bool spec_wanted = allow_spec && lean_sig && id_bits == GB_PART_ID_BITS && !chunk_major && !lab::path_on("GDF_GBP_NO_SPEC") &&
+                               n >= lab::path_int("GDF_GBP_SPEC_MIN_ROWS", (long long)1 << 24);
+      GbSpec spec{};
+      DevBuf d_spec;                      // cap [P] | qprefix [P + 1] | fill [P * G]
+      if (hot_ok || spec_wanted) {
         const uint32_t nwin = 1u << (sp.total_bits - GBP_HOT_BITS);
+        const uint32_t wpp = 1u << (id_bits - GBP_HOT_BITS);                  // sample windows per partition
+        DevBuf d_cnt;
+        RMM_TRY(d_cnt.alloc(sizeof(unsigned int) * ((size_t)nwin + 1)));
+        HIP_TRY(hipMemsetAsync(d_cnt.p, 0, sizeof(unsigned int) * ((size_t)nwin + 1), stream0()));
+        GDF_LAUNCH("gbp_sample_hist", gbp_sample_hist, dim3(GBP_SAMPLE_WINDOWS / GBP_SAMPLE_PER_WG), dim3(1024), 0, stream0(), t, sp, nwin,
+                   d_cnt.as<unsigned int>());
+        HIP_CHECK_LAST();
+        std::vector<unsigned int> cnt((size_t)nwin + 1);
+        HIP_TRY(read_back(cnt.data(), d_cnt.p, sizeof(unsigned int) * cnt.size()));
+        const double S = (double)cnt[nwin];
+        uint32_t best = 0;
+        for (uint32_t w = 1; w < nwin; ++w) if (cnt[w] > cnt[best]) best = w;
+        // the hot window: worth its 64 KB of LDS from a fifth of the rows (a key column the count pass does not read must lie
+        // below the window bits -- only the exact layout has a count pass)
         const long long forced = lab::path_int("GDF_GBP_HOT_WINDOW", -1);       // test switch: any window gives the same result
-        if (forced >= 0) {
-          hot_window = (uint32_t)forced < nwin ? (uint32_t)forced : nwin - 1;
-        } else {
-          DevBuf d_hot;
-          RMM_TRY(d_hot.alloc(sizeof(unsigned int) * 4));
-          GDF_LAUNCH("gbp_sample_hot", gbp_sample_hot, dim3(1), dim3(1024), 0, stream0(), t, sp, nwin, d_hot.as<unsigned int>());
-          HIP_CHECK_LAST();
-          unsigned int h[3] = {0, 0, 0};
-          HIP_TRY(read_back(h, d_hot.p, sizeof(h)));
-          // worth it from a fifth of the rows (the accumulators cost the stage 3/8 of its records: rounds, if the tile's cold rows
-          // do not fit); the stage takes a whole tile's cold rows while the window holds more than 3/8
-          if (h[2] >= 1024 && (double)h[1] >= 0.2 * (double)h[2]) hot_window = h[0];
+        if (hot_ok && forced >= 0) hot_window = (uint32_t)forced < nwin ? (uint32_t)forced : nwin - 1;
+        else if (hot_ok && S >= 1024.0 && (double)cnt[best] >= 0.2 * S) hot_window = best;
+        if (spec_wanted && S >= 65536.0) {
+          // room per (partition, workgroup): the sample's estimate of the partition's cold rows + 5 sigma of that estimate, shared
+          // out over G workgroups, + 6 sigma of a workgroup's own share (Poisson) -- a segment overflows about once in 1e8
+          const uint32_t G = sgrid.x;
+          // the rows the BUSIEST workgroup gets (the kernel's chunk -> workgroup map: XCD x takes the x-th eighth of the chunks, its
+          // workgroups round-robin inside it; chunks are whole tiles, so a small table leaves some workgroups a chunk more)
+          int64_t busiest = 0;
+          {
+            std::vector<int64_t> rows_of(G, 0);
+            const bool xcd_map = (G & 7u) == 0;
+            const int per_xcd = (nchunks + 7) / 8;
+            for (int c = 0; c < nchunks; ++c) {
+              const int64_t r = std::min<int64_t>(chunk, n - (int64_t)c * chunk);
+              const uint32_t wg = xcd_map ? (uint32_t)(c / per_xcd) + 8u * (uint32_t)((c % per_xcd) % (int)(G >> 3)) : (uint32_t)c % G;
+              rows_of[wg] += r;
+            }
+            for (uint32_t w = 0; w < G; ++w) busiest = std::max(busiest, rows_of[w]);
+          }
+          const double scale = (double)busiest / S;
+          std::vector<uint32_t> plan_words(2 * (size_t)P + 1);
+          uint32_t *capv = plan_words.data(), *pre = capv + P;
+          uint64_t total = 0;
+          for (uint32_t q = 0; q < P; ++q) {
+            double sq = 0;
+            for (uint32_t i = 0; i < wpp; ++i) {
+              const uint32_t w = q * wpp + i;
+              if (w < nwin && w != hot_window) sq += (double)cnt[w];
+            }
+            const double U = (sq + 5.0 * std::sqrt(sq + 1.0) + 3.0) * scale;
+            const uint64_t c = (uint64_t)(U + 6.0 * std::sqrt(U) + 8.0);
+            capv[q] = (uint32_t)std::min<uint64_t>(c, 0x7fffffffULL);
+            pre[q] = (uint32_t)std::min<uint64_t>(total, 0xffffffffULL);
+            total += capv[q];
+          }
+          pre[P] = (uint32_t)std::min<uint64_t>(total, 0xffffffffULL);
+          // record positions are 31-bit in the kernels; the buffer must not dwarf the relation either (a flat sample: 2.5 x)
+          if (total * G < 0x7fffffffULL && total * G <= (uint64_t)(2.5 * (double)nn) + ((uint64_t)P * G * 64)) {
+            RMM_TRY(d_spec.alloc(sizeof(uint32_t) * (plan_words.size() + (size_t)P * G)));
+            HIP_TRY(hipMemcpyAsync(d_spec.p, plan_words.data(), sizeof(uint32_t) * plan_words.size(), hipMemcpyHostToDevice, stream0()));
+            HIP_TRY(hipStreamSynchronize(stream0()));                  // (plan_words is a local)
+            spec.cap = d_spec.as<uint32_t>();
+            spec.qprefix = spec.cap + P;
+            spec.fill = d_spec.as<uint32_t>() + plan_words.size();
+            spec.G = G;
+            RMM_TRY(ka.alloc(sizeof(GbRec) * (size_t)(total * G)));
+            kin = ka.as<K>();
+            hp.resize((size_t)P + 1);
+            for (uint32_t q = 0; q <= P; ++q) hp[q] = pre[q] * G;
+          }
         }
       }
+      const bool is_spec = spec.qprefix != nullptr;
+      // (exact layout: a key column the count pass skips must lie below the window bits, so that it can tell hot rows from the first column alone)
+      if (!is_spec && skip_low && sp.shift[1] + sp.bits[1] > GBP_HOT_BITS) hot_window = GBP_NO_HOT;
       // the cells the partial aggregates are merged into: made BEFORE the scatter kernel, which merges the hot window's
       if (hot_window != GBP_NO_HOT) {
         const size_t cells = (size_t)P << id_bits, cells_pad = (cells + 1023) / 1024 * 1024;
@@ -2704,30 +2828,34 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
         GDF_LAUNCH("gbp_count", kernel, dim3(nchunks < NUM_CU * 2 ? nchunks : NUM_CU * 2), dim3(GBP_THREADS), 0, stream0(), t, sp, low, vbit, P,
                    chunk, nchunks, hist.as<uint32_t>(), d_flags.as<unsigned int>(), qstride, cstride, hot_window);
       };
-      if (k0 == K_I32 && ck1 == -2) count(gbp_count<K_I32, -2>);
+      if (is_spec) {}                     // no count pass: the scatter kernel appends to per-workgroup segments
+      else if (k0 == K_I32 && ck1 == -2) count(gbp_count<K_I32, -2>);
       else if (k0 == K_I64 && ck1 == -2) count(gbp_count<K_I64, -2>);
       else if (k0 == K_I32 && ck1 == K_I32) count(gbp_count<K_I32, K_I32>);
       else if (k0 == K_I32 && ck1 == K_I64) count(gbp_count<K_I32, K_I64>);
       else if (k0 == K_I64 && ck1 == K_I32) count(gbp_count<K_I64, K_I32>);
       else if (k0 == K_I64 && ck1 == K_I64) count(gbp_count<K_I64, K_I64>);
       else count(gbp_count<-1, -1>);
-      GDF_TRY(scan_u32(hist.as<uint32_t>(), hist.as<uint32_t>(), (size_t)P * nchunks + 1, false));
+      if (!is_spec) GDF_TRY(scan_u32(hist.as<uint32_t>(), hist.as<uint32_t>(), (size_t)P * nchunks + 1, false));
       const bool is_hot = hot_window != GBP_NO_HOT;
       const size_t slds = gbp_scatter_lds(is_hot);
       const bool lean = !lab::knob_on("GDF_GBP_OLD");              // A/B switch: the scatter kernel with the type switches for every shape
       const bool sig = lean && key_sig && val_sig;
-      const dim3 sgrid(nchunks < NUM_CU ? nchunks : NUM_CU);
       if (sig) {
         const int vm = vbit ? 2 : (val.valid ? 1 : 0);        // 0: no mask, 1: mask, 2: mask + validity bit in the key
         auto scatter = [&](auto kernel) -> gdf_error {
           HIP_TRY(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
           GDF_LAUNCH(is_hot ? "gbp_scatter_hot" : "gbp_scatter", kernel, sgrid, dim3(GBP_SC_THREADS), slds, stream0(), t, sp, val, fold_op, low, P, chunk,
-                     nchunks, (const uint32_t *)hist.as<uint32_t>(), ka.as<GbRec>(), d_flags.as<unsigned int>(), qstride, cstride, hot);
+                     nchunks, (const uint32_t *)hist.as<uint32_t>(), ka.as<GbRec>(), d_flags.as<unsigned int>(), qstride, cstride, hot, spec);
           return GDF_SUCCESS;
         };
 #define GBP_SIG(K0, K1)                                                                                                          \
         if (k0 == K0 && k1 == K1) {                                                                                                 \
-          if (vm == 2 && is_hot) GDF_TRY(scatter(gbp_scatter_static<true, K0, K1, true, true>));                                   \
+          if (vm == 2 && is_hot && is_spec) GDF_TRY(scatter(gbp_scatter_static<true, K0, K1, true, true, true>));                  \
+          else if (vm == 0 && is_hot && is_spec) GDF_TRY(scatter(gbp_scatter_static<false, K0, K1, false, true, true>));           \
+          else if (vm == 2 && is_spec) GDF_TRY(scatter(gbp_scatter_static<true, K0, K1, true, false, true>));                      \
+          else if (vm == 0 && is_spec) GDF_TRY(scatter(gbp_scatter_static<false, K0, K1, false, false, true>));                    \
+          else if (vm == 2 && is_hot) GDF_TRY(scatter(gbp_scatter_static<true, K0, K1, true, true>));                              \
           else if (vm == 0 && is_hot) GDF_TRY(scatter(gbp_scatter_static<false, K0, K1, false, true>));                            \
           else if (vm == 2) GDF_TRY(scatter(gbp_scatter_static<true, K0, K1, true>));                                              \
           else if (vm == 1) GDF_TRY(scatter(gbp_scatter_static<false, K0, K1, true>));                                             \
@@ -2750,16 +2878,25 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
         *done = false;
         return GDF_SUCCESS;
       }
-      hipLaunchKernelGGL(gb_strided_u32, dim3((P + 256) / 256), dim3(256), 0, stream0(), (const uint32_t *)hist.as<uint32_t>(), d_start.as<uint32_t>(),
-                         (int)P + 1, (size_t)nchunks);
-      HIP_CHECK_LAST();
-      hp.resize((size_t)P + 1);
-      HIP_TRY(read_back(hp.data(), d_start.p, sizeof(uint32_t) * ((size_t)P + 1)));
-      unsigned int hfl[2] = {0, 0};
+      if (!is_spec) {
+        hipLaunchKernelGGL(gb_strided_u32, dim3((P + 256) / 256), dim3(256), 0, stream0(), (const uint32_t *)hist.as<uint32_t>(), d_start.as<uint32_t>(),
+                           (int)P + 1, (size_t)nchunks);
+        HIP_CHECK_LAST();
+        hp.resize((size_t)P + 1);
+        HIP_TRY(read_back(hp.data(), d_start.p, sizeof(uint32_t) * ((size_t)P + 1)));
+      }
+      unsigned int hfl[3] = {0, 0, 0};
       HIP_TRY(read_back(hfl, d_flags.p, sizeof(hfl)));
-      hf.dropped = hfl[0];
+      hf.dropped = hfl[0];              // (speculative layout: nobody counted them; 0 makes nvalid an upper bound, which is all it is used for)
       j.range_violated = hfl[1] != 0;
       if (j.range_violated) { *done = false; return GDF_SUCCESS; }      // sample-guessed ranges did not hold: the caller retries exactly
+      if (is_spec && hfl[2]) {
+        // a segment ran out of room (clustered input, or one chance in ~1e8 per segment): everything again on the exact layout
+        ka.reset(); gacc.reset(); grows.reset(); gvalid.reset(); d_spec.reset();
+        return gb_sorted_partitioned<K>(j, sp, vbit, null_bit, done, guessed, false);
+      }
+      aggregate_spec = spec;
+      keep_spec.p = d_spec.release();
     }
   } else {
     GDF_LAUNCH("gb_sorted_make_pairs", gb_sorted_make_pairs<K>, dim3(stream_grid((size_t)n, 256 * 8)), dim3(256), 0, stream0(), t, sp, val,
@@ -2817,12 +2954,12 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
           HIP_TRY(hipFuncSetAttribute((const void *)gb_part_aggregate<true, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
           GDF_LAUNCH("gb_part_aggregate", (gb_part_aggregate<true, K, true>), dim3((unsigned)units.size()), dim3(GB_DENSE_THREADS), plds, stream0(),
                      (const K *)kin, (const uint64_t *)nullptr, (const GbPartUnit *)d_units.as<GbPartUnit>(), id_bits, fold_op, flt,
-                     gacc.as<unsigned long long>(), grows.as<unsigned int>(), gvalid.as<unsigned int>());
+                     gacc.as<unsigned long long>(), grows.as<unsigned int>(), gvalid.as<unsigned int>(), aggregate_spec);
         } else {
           HIP_TRY(hipFuncSetAttribute((const void *)gb_part_aggregate<false, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
           GDF_LAUNCH("gb_part_aggregate", (gb_part_aggregate<false, K, true>), dim3((unsigned)units.size()), dim3(GB_DENSE_THREADS), plds, stream0(),
                      (const K *)kin, (const uint64_t *)nullptr, (const GbPartUnit *)d_units.as<GbPartUnit>(), id_bits, fold_op, flt,
-                     gacc.as<unsigned long long>(), grows.as<unsigned int>(), (unsigned int *)nullptr);
+                     gacc.as<unsigned long long>(), grows.as<unsigned int>(), (unsigned int *)nullptr, aggregate_spec);
         }
       }
     }
@@ -2831,12 +2968,12 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
       HIP_TRY(hipFuncSetAttribute((const void *)gb_part_aggregate<true, K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
       GDF_LAUNCH("gb_part_aggregate", (gb_part_aggregate<true, K>), dim3((unsigned)units.size()), dim3(GB_DENSE_THREADS), plds, stream0(), (const K *)kin,
                  (const uint64_t *)pin, (const GbPartUnit *)d_units.as<GbPartUnit>(), id_bits, fold_op, flt, gacc.as<unsigned long long>(),
-                 grows.as<unsigned int>(), gvalid.as<unsigned int>());
+                 grows.as<unsigned int>(), gvalid.as<unsigned int>(), GbSpec{});
     } else {
       HIP_TRY(hipFuncSetAttribute((const void *)gb_part_aggregate<false, K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
       GDF_LAUNCH("gb_part_aggregate", (gb_part_aggregate<false, K>), dim3((unsigned)units.size()), dim3(GB_DENSE_THREADS), plds, stream0(), (const K *)kin,
                  (const uint64_t *)pin, (const GbPartUnit *)d_units.as<GbPartUnit>(), id_bits, fold_op, flt, gacc.as<unsigned long long>(),
-                 grows.as<unsigned int>(), (unsigned int *)nullptr);
+                 grows.as<unsigned int>(), (unsigned int *)nullptr, GbSpec{});
     }
     const unsigned nblocks = (unsigned)(cells_pad / 1024);
     GDF_LAUNCH("gb_part_count", gb_part_count, dim3(nblocks), dim3(1024), 0, stream0(), (const unsigned int *)grows.as<unsigned int>(), bcnt.as<uint32_t>());

@@ -606,3 +606,47 @@ def test_hot_window_is_aggregated_in_the_scatter_kernel(gdf, shape, op, val_dtyp
     force_path("GDF_GBP_NO_HOT")
     names = _kernels_of(gdf, run)
     assert "gbp_scatter_hot" not in names and "gbp_scatter" in names, names
+
+
+@pytest.mark.parametrize("op,val_dtype,masked", [("avg", np.float64, True), ("sum", np.int64, False), ("max", np.float64, True)],
+                         ids=["avg-f64-masked", "sum-i64", "max-f64-masked"])
+@pytest.mark.parametrize("shape", ["zipf", "uniform", "zipf-sorted-input", "second-half-on-other-keys", "one-key", "null-keys"])
+def test_speculative_record_layout_needs_no_count_pass(gdf, shape, op, val_dtype, masked, force_path):
+    """The fused partition pass on the SPECULATIVE layout (csrc/groupby.hip GbSpec): every scatter workgroup appends to its own
+    segment of every partition, sized from a strided sample -- no count pass, no atomics -- and the aggregation masks the slack.
+    Against the oracle, kernel names through the profile hook: shapes that fit (Zipf and uniform keys, a single dominant key, null
+    keys) run without gbp_count; clustered input (rows sorted by key; the second half of the table on other keys than the first)
+    overflows a segment, every workgroup stops at its next tile and the call repeats on the exact layout -- with the same answer.
+    Reference semantics of the aggregation: groupby_kernels.cuh:42-108, groupby.cuh:308-419."""
+    rs = np.random.RandomState(len(shape) * 7 + len(op))
+    n = (1 << 22) + 777
+    if shape == "uniform":
+        k0 = rs.randint(0, 40_000, size=n).astype(np.int64)
+    elif shape == "one-key":
+        k0 = np.full(n, 77, dtype=np.int64)
+        k0[rs.permutation(n)[:60_000]] = rs.randint(0, 100_000, size=60_000)        # (spread over the table: a block of them is clustered input)
+    elif shape == "second-half-on-other-keys":
+        k0 = np.concatenate([rs.randint(0, 30_000, size=n // 2), rs.randint(30_000, 90_000, size=n - n // 2)]).astype(np.int64)
+    else:
+        k0 = _zipf(rs, n, 100_000)
+    if shape == "zipf-sorted-input":
+        k0 = np.sort(k0)
+    keys = [k0, rs.randint(0, 16, size=n).astype(np.int32)]
+    vals = rs.randint(-1000, 1000, size=n).astype(val_dtype) if np.dtype(val_dtype).kind == "i" else rs.random_sample(n)
+    v_ok = (rs.random_sample(n) > 0.5) if masked else None
+    k_ok = [(rs.random_sample(n) > 0.03) if shape == "null-keys" else None, None]
+    out = np.float64 if op == "avg" else None
+    force_path("GDF_GBP_SPEC_MIN_ROWS", "1")
+
+    def run():
+        if masked or shape == "null-keys":
+            _check_masked(gdf, op, keys, vals, k_ok, v_ok, out)
+        else:
+            _check(gdf, op, keys, vals, out)
+
+    names = _kernels_of(gdf, run)
+    clustered = shape in ("zipf-sorted-input", "second-half-on-other-keys")
+    assert "gbp_sample_hist" in names and ("gbp_count" in names) == clustered, names
+    force_path("GDF_GBP_NO_SPEC")
+    names = _kernels_of(gdf, run)
+    assert "gbp_count" in names, names

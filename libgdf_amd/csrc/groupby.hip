@@ -1466,10 +1466,23 @@ __global__ __launch_bounds__(GB_DENSE_THREADS) void gb_part_aggregate(const K *_
   for (uint32_t base = 0; base < u.count; base += GB_DENSE_THREADS * GB_DENSE_BATCH) {
     K k[GB_DENSE_BATCH];
     uint64_t v[GB_DENSE_BATCH];
+    uint32_t livemask = 0;
 #pragma unroll
-    for (int b = 0; b < GB_DENSE_BATCH; ++b) {                       // all HBM loads first, from clamped addresses
-      const uint32_t i = base + b * GB_DENSE_THREADS + threadIdx.x;
-      const uint32_t ic = u.begin + (i < u.count ? i : u.count - 1);
+    for (int b = 0; b < GB_DENSE_BATCH; ++b) {
+      bool live = base + b * GB_DENSE_THREADS + threadIdx.x < u.count;
+      if (REC && sp_cap) {                       // (uniform branch) a slot behind its segment's fill count holds nothing
+        const uint32_t o = sp_first + base + b * GB_DENSE_THREADS + threadIdx.x;
+        uint32_t w = __umulhi(o, sp_magic);
+        uint32_t off = o - w * sp_cap;
+        if ((int32_t)off < 0) { --w; off += sp_cap; }          // the estimate is at most one too large (o < 2^31)
+        live = live && off < seg_fill[w < spec.G ? w : 0];
+      }
+      livemask |= (uint32_t)live << b;
+    }
+#pragma unroll
+    for (int b = 0; b < GB_DENSE_BATCH; ++b) {                       // all HBM loads first; a dead slot re-reads the unit's first one
+      const uint32_t i = base + b * GB_DENSE_THREADS + threadIdx.x;  // (the slack of the speculative layout costs no HBM traffic)
+      const uint32_t ic = u.begin + (((livemask >> b) & 1u) ? i : 0u);
       if (REC) {
         const GbRec r = reinterpret_cast<const GbRec *>(keys)[ic];
         k[b] = (K)r.key;
@@ -1481,14 +1494,7 @@ __global__ __launch_bounds__(GB_DENSE_THREADS) void gb_part_aggregate(const K *_
     }
 #pragma unroll
     for (int b = 0; b < GB_DENSE_BATCH; ++b) {
-      bool live = base + b * GB_DENSE_THREADS + threadIdx.x < u.count;
-      if (REC && sp_cap) {                       // (uniform branch) a slot behind its segment's fill count holds nothing
-        const uint32_t o = sp_first + base + b * GB_DENSE_THREADS + threadIdx.x;
-        uint32_t w = __umulhi(o, sp_magic);
-        uint32_t off = o - w * sp_cap;
-        if ((int32_t)off < 0) { --w; off += sp_cap; }          // the estimate is at most one too large (o < 2^31)
-        live = live && off < seg_fill[w < spec.G ? w : 0];
-      }
+      const bool live = (livemask >> b) & 1u;
       if (live) {
         const uint32_t id = (uint32_t)(k[b] >> (VBIT ? 1 : 0)) & mask;
         atomicAdd(&lrows[id], 1u);

@@ -2268,7 +2268,9 @@ __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter_static(KeyTable t,
       // (Requesting the NEXT tile's words in front of the last flush and holding them in registers across it -- the five store
       // instructions leave room, no spill -- changed nothing: 8.34 - 8.78 against 8.39 - 8.49 ms on C5.  The stores are not a
       // latency the loads could hide behind: the same records written as one contiguous stream per workgroup cost 6.7 ms, no
-      // stores at all 6.1, the short (tile, partition) runs 8.5 -- profiles/r4_c_c5_scatter_ablation.txt.)
+      // stores at all 6.1, the short (tile, partition) runs 8.5 -- profiles/r4_c_c5_scatter_ablation.txt.  Requesting the next
+      // tile right after this one's words are consumed -- in flight under ranking, scan, regroup and flush -- needs the raw and
+      // the processed words of a tile at once: 128 VGPRs + 53 spilled, 12.0 against 8.46 ms.)
       if constexpr (HOT) {
         for (uint32_t round0 = (total - 1u) / (uint32_t)CAP * (uint32_t)CAP; total && round0 > 0; round0 -= (uint32_t)CAP) {
           regroup(round0);

@@ -218,8 +218,8 @@ def test_dist_inner_join_c_entry_one_rank(gdf, wire, dtype, chunks):
         import os
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        if not dist.is_initialized():
-            dist.init_process_group("gloo", rank=0, world_size=1)
+        assert not dist.is_initialized()
+        dist.init_process_group("gloo", rank=0, world_size=1)
         tr = api.CallbackTransport()
     try:
         got = _dist_join_one_rank(gdf, tr, probe, build, chunks)
@@ -229,6 +229,8 @@ def test_dist_inner_join_c_entry_one_rank(gdf, wire, dtype, chunks):
         np.testing.assert_array_equal(got[1], er)
     finally:
         tr.close()
+        if wire != "rccl":
+            dist.destroy_process_group()          # (other tests of this session make their own default group)
 
 
 @pytest.mark.parametrize("case", ["keys-wider-than-31-bits", "one-key-holds-a-third", "empty-build", "empty-probe"])

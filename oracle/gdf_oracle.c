@@ -374,3 +374,117 @@ int64_t orc_group_by(int op, int ncols, const int *kinds, const void *const *key
   free(slot_first); free(slot_group); free(first); free(acc); free(cnt); free(order); free(group_of_first);
   return ngroups;
 }
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * orc_join_parallel_i64 -- an ALL-CORES CPU baseline for the inner join on one int64 key column ("optional second
+ * baseline: our own multi-threaded C++ CPU oracle (OpenMP, all cores) for a fairer rows/s comparison").  Test / bench
+ * infrastructure like the rest of this file; not a restatement of reference code (the reference has no CPU join besides the
+ * std::multimap of its tests, join-tests.cu:260-356, which orc_join restates) -- it is what a competent CPU implementation of
+ * the same operation looks like: both relations are radix-partitioned on the low bits of a multiplicative hash (one parallel
+ * histogram + scatter each), then every partition builds a small open-addressing table of its build tuples and streams its
+ * probe tuples past it, partitions in parallel.  Multimap semantics: every (probe row, build row) with equal keys.
+ * Checked against orc_join in tests/test_oracle_cpu.py.  Returns the number of pairs (pairs beyond `cap` are counted, not stored).
+ * ------------------------------------------------------------------------------------------------------------------- */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+static inline uint32_t par_hash(int64_t k) { return (uint32_t)(((uint64_t)k * 0x9E3779B97F4A7C15ULL) >> 32); }
+
+typedef struct { int64_t key; int32_t row; } par_tuple;
+
+/* tuples of `keys` grouped by partition: out[off[p] .. off[p + 1]) */
+static void par_partition(const int64_t *keys, int64_t n, int bits, par_tuple *out, int64_t *off, int threads) {
+  const int64_t P = (int64_t)1 << bits;
+  int64_t *hist = (int64_t *)calloc((size_t)P * threads, sizeof(int64_t));
+#pragma omp parallel num_threads(threads)
+  {
+#ifdef _OPENMP
+    const int t = omp_get_thread_num();
+#else
+    const int t = 0;
+#endif
+    const int64_t a = n * t / threads, b = n * (t + 1) / threads;
+    int64_t *h = hist + (size_t)t * P;
+    for (int64_t i = a; i < b; ++i) ++h[par_hash(keys[i]) & (P - 1)];
+#pragma omp barrier
+#pragma omp single
+    {
+      int64_t run = 0;
+      for (int64_t p = 0; p < P; ++p) {
+        off[p] = run;
+        for (int q = 0; q < threads; ++q) { const int64_t c = hist[(size_t)q * P + p]; hist[(size_t)q * P + p] = run; run += c; }
+      }
+      off[P] = run;
+    }
+    for (int64_t i = a; i < b; ++i) {
+      const int64_t at = h[par_hash(keys[i]) & (P - 1)]++;
+      out[at].key = keys[i];
+      out[at].row = (int32_t)i;
+    }
+  }
+  free(hist);
+}
+
+int64_t orc_join_parallel_i64(const int64_t *probe, int64_t np, const int64_t *build, int64_t nb, int32_t *out_probe, int32_t *out_build,
+                              int64_t cap, int threads) {
+#ifdef _OPENMP
+  if (threads <= 0) threads = omp_get_max_threads();
+#else
+  threads = 1;
+#endif
+  int bits = 0;
+  while (bits < 16 && ((int64_t)1 << bits) * 2048 < nb) ++bits;          /* ~2048 build tuples per partition: the table stays in L1 / L2 */
+  const int64_t P = (int64_t)1 << bits;
+  par_tuple *pt = (par_tuple *)malloc(sizeof(par_tuple) * (size_t)(np ? np : 1));
+  par_tuple *bt = (par_tuple *)malloc(sizeof(par_tuple) * (size_t)(nb ? nb : 1));
+  int64_t *poff = (int64_t *)malloc(sizeof(int64_t) * (size_t)(P + 1)), *boff = (int64_t *)malloc(sizeof(int64_t) * (size_t)(P + 1));
+  par_partition(probe, np, bits, pt, poff, threads);
+  par_partition(build, nb, bits, bt, boff, threads);
+  /* pass 1: pairs per partition; pass 2: write at exact offsets (so that the output needs no per-thread buffers) */
+  int64_t *cnt = (int64_t *)calloc((size_t)(P + 1), sizeof(int64_t));
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma omp parallel for schedule(dynamic, 4) num_threads(threads)
+    for (int64_t p = 0; p < P; ++p) {
+      const int64_t b0 = boff[p], b1 = boff[p + 1], p0 = poff[p], p1 = poff[p + 1];
+      if (b1 == b0 || p1 == p0) continue;
+      int64_t slots = 16;
+      while (slots < 2 * (b1 - b0)) slots <<= 1;
+      int32_t *head = (int32_t *)malloc(sizeof(int32_t) * (size_t)slots);         /* slot -> build tuple index (in bt), -1 empty */
+      int32_t *next = (int32_t *)malloc(sizeof(int32_t) * (size_t)(b1 - b0));     /* chain of tuples with the SAME key */
+      for (int64_t s = 0; s < slots; ++s) head[s] = -1;
+      for (int64_t i = b0; i < b1; ++i) {
+        int64_t s = (par_hash(bt[i].key) >> bits) & (slots - 1);
+        while (head[s] >= 0 && bt[b0 + head[s]].key != bt[i].key) s = (s + 1) & (slots - 1);
+        next[i - b0] = head[s];
+        head[s] = (int32_t)(i - b0);
+      }
+      int64_t found = 0, at = pass ? cnt[p] : 0;
+      for (int64_t i = p0; i < p1; ++i) {
+        int64_t s = (par_hash(pt[i].key) >> bits) & (slots - 1);
+        while (head[s] >= 0 && bt[b0 + head[s]].key != pt[i].key) s = (s + 1) & (slots - 1);
+        for (int32_t j = head[s]; j >= 0; j = next[j]) {
+          if (pass && at + found < cap) { out_probe[at + found] = pt[i].row; out_build[at + found] = bt[b0 + j].row; }
+          ++found;
+        }
+      }
+      if (!pass) cnt[p] = found;
+      free(head);
+      free(next);
+    }
+    if (!pass) {
+      int64_t run = 0;
+      for (int64_t p = 0; p <= P; ++p) { const int64_t c = p < P ? cnt[p] : 0; cnt[p] = run; run += c; }
+    }
+  }
+  const int64_t total = cnt[P];
+  free(cnt); free(poff); free(boff); free(pt); free(bt);
+  return total;
+}
+
+int orc_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}

@@ -122,6 +122,25 @@ def join(left, right, how="inner", left_valid=None, right_valid=None):
     return l, r
 
 
+def join_parallel_i64(probe, build, threads=0):
+    """orc_join_parallel_i64: the all-cores CPU baseline (OpenMP radix-partitioned hash join, gdf_oracle.c) on one int64 key
+    column -> (probe rows, build rows) UNSORTED, and the thread count used.  threads = 0: all the host offers."""
+    probe = np.ascontiguousarray(probe, dtype=np.int64)
+    build = np.ascontiguousarray(build, dtype=np.int64)
+    L = lib()
+    L.orc_join_parallel_i64.restype = C.c_int64
+    L.orc_join_parallel_i64.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
+    L.orc_max_threads.restype = C.c_int
+    used = int(threads) if threads else int(L.orc_max_threads())
+    cap = max(len(probe), 1)
+    while True:
+        ol, orr = np.empty(cap, dtype=np.int32), np.empty(cap, dtype=np.int32)
+        n = L.orc_join_parallel_i64(probe.ctypes.data, len(probe), build.ctypes.data, len(build), ol.ctypes.data, orr.ctypes.data, cap, used)
+        if n <= cap:
+            return ol[:n], orr[:n], used
+        cap = int(n)
+
+
 def group_by(op, keys, values, out_dtype=None):
     """(sorted key arrays, aggregate array).  Aggregation in the input dtype; COUNT / AVG in out_dtype."""
     keys = _contig(keys)

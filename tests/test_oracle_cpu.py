@@ -118,3 +118,30 @@ def test_masked_group_by_semantics_match_pandas(op):
         np.testing.assert_array_equal(ok, ~np.isnan(exp.to_numpy()))
         np.testing.assert_allclose(agg[ok], exp.to_numpy()[ok], rtol=1e-12)
         assert (agg[~ok] == 0).all() and (~ok).sum() >= 4
+
+
+@pytest.mark.parametrize("shape", ["fk-pk", "duplicates-and-misses", "empty-build", "empty-probe", "one-key", "negative-keys"])
+def test_all_cores_cpu_baseline_join_equals_the_oracle(shape):
+    """bench.py's cpu_baseline_all_cores leg (optional second baseline) times orc_join_parallel_i64, an OpenMP
+    radix-partitioned hash join in oracle/gdf_oracle.c: it must produce exactly the pairs of orc_join (the restatement of the
+    reference's in-test CPU solution, join-tests.cu:260-356) -- multimap semantics, any thread count."""
+    rs = np.random.RandomState(len(shape))
+    if shape == "fk-pk":
+        build, probe = rs.permutation(40_000).astype(np.int64), rs.randint(0, 40_000, size=300_000).astype(np.int64)
+    elif shape == "duplicates-and-misses":
+        build, probe = rs.randint(0, 5_000, size=20_000).astype(np.int64), rs.randint(0, 7_000, size=50_000).astype(np.int64)
+    elif shape == "empty-build":
+        build, probe = np.zeros(0, dtype=np.int64), rs.randint(0, 10, size=100).astype(np.int64)
+    elif shape == "empty-probe":
+        build, probe = rs.randint(0, 10, size=100).astype(np.int64), np.zeros(0, dtype=np.int64)
+    elif shape == "one-key":
+        build, probe = np.full(300, 7, dtype=np.int64), np.full(500, 7, dtype=np.int64)
+    else:
+        build, probe = (rs.permutation(30_000) - 15_000).astype(np.int64) * (1 << 33), (rs.randint(-20_000, 20_000, size=90_000)).astype(np.int64) * (1 << 33)
+    el, er = oracle.join([probe], [build], "inner")
+    for threads in (1, 3, 0):
+        l, r, used = oracle.join_parallel_i64(probe, build, threads)
+        assert used >= 1
+        o = np.lexsort((r, l))
+        np.testing.assert_array_equal(l[o], el)
+        np.testing.assert_array_equal(r[o], er)

@@ -507,13 +507,17 @@ __global__ __launch_bounds__(256) void jk_sample_skew(const void *col, int64_t n
 // ---------------------------------------------------------------------------
 template <bool NARROW, int THREADS, bool PAY = false, int ITEMS = JK_SC_ITEMS>
 struct TileLds {
-  uint64_t w[THREADS * ITEMS + 2];                        // + a trash slot: tuples that do not travel are written there
+  // + a trash slot: tuples that do not travel are written there.  The 1024-thread level-1 tile also has room for the padding of
+  // six-byte tuples (L6: every bin's run is padded to an even length, up to 256 dead tuples per tile)
+  static constexpr int PAD = (THREADS == 1024 && NARROW && !PAY) ? 256 : 0;
+  uint64_t w[THREADS * ITEMS + PAD + 2];
   int32_t idx[NARROW ? 4 : THREADS * ITEMS + 4];
   uint64_t pay[PAY ? THREADS * ITEMS + 2 : 2];            // payload words, regrouped with their tuples
   uint32_t hist[256 + 4];                                 // + a trash counter, same reason (never zeroed, never read)
   uint32_t start[256];
   uint32_t gbase[256];    // (global base - start[bin]) mod 2^32; destinations are < 2^31
   uint32_t cursor[256];   // level 1: running global cursor of this chunk
+  uint32_t odd[256];      // level 1, six-byte tuples (L6): the bin's run of this tile was padded to an even length
   uint32_t wave_tot[THREADS / WAVE];
   uint32_t total;
   uint32_t total_abort;   // level 1, speculative layout: the overflow flag as thread 0 saw it during this tile
@@ -586,6 +590,32 @@ __device__ __forceinline__ void p6_load_pair(const uint64_t *base, uint32_t v, u
   const uint32_t lo1 = (d.b >> 16) | (d.c << 16);
   row1 = lo1 & 0x7fffffffu;
   r1 = (lo1 >> 31) | ((d.c >> 16) << 1);
+}
+
+// SIX-BYTE LEVEL-1 tuples (L6, round 4).  hash_a is a bijection on the stored keys (the P6 condition) and after level 1 its top
+// b1 = 8 bits are the tuple's place, so 24 bits identify the key; the row number gives up the bits its place implies as well:
+// level 1 of the speculative layout splits every coarse partition into 64 REGIONS by chunk number (PartGeom::xs = 6: region =
+// chunk % 64, chunks are 2^17 rows, chunk c runs on XCD c % 8 -- the per-XCD merging of write fronts is unchanged), so a tuple's
+// row bits 17..22 ARE its region.  24 hash bits + (17 low + 7 high) explicit row bits = 48: a level-1 tuple is 6 bytes for up to
+// 2^30 rows, 40 instead of 44 bytes of HBM traffic per probe row (write 8 -> 6 here, read 8 -> 6 at level 2).
+// Layout of a tuple: bits 0..23 row24 = row[0..16] | row[23..29] << 17, bits 24..47 the hash remainder.  Tuples leave in PAIRS,
+// one aligned 12-byte store per lane (the (tile, bin) runs are padded to even lengths with a dead tuple -- all ones, which no
+// live tuple can be while rows stay below 2^30 - 2^23), and level 2 reads them back as pairs (jk_scatter2<IN6>).
+constexpr uint32_t L6_ROW_MASK = 0xffffffu;
+__device__ __forceinline__ uint32_t l6_row24(uint32_t row) { return (row & 0x1ffffu) | ((row >> 23) << 17); }
+__device__ __forceinline__ uint32_t l6_row(uint32_t row24, uint32_t region) { return (row24 & 0x1ffffu) | (region << 17) | ((row24 >> 17) << 23); }
+struct __attribute__((packed, aligned(4))) L6Pair { uint32_t a, b, c; };
+// (hash remainder, row24) x 2 -> 12 bytes
+__device__ __forceinline__ L6Pair l6_pack(uint32_t rem0, uint32_t row0, uint32_t rem1, uint32_t row1) {
+  const uint32_t lo0 = row0 | (rem0 << 24), lo1 = row1 | (rem1 << 24);
+  return L6Pair{lo0, (rem0 >> 8) | (lo1 << 16), (lo1 >> 16) | ((rem1 >> 8) << 16)};
+}
+__device__ __forceinline__ void l6_unpack(const L6Pair &d, uint32_t &rem0, uint32_t &row0, uint32_t &rem1, uint32_t &row1) {
+  row0 = d.a & L6_ROW_MASK;
+  rem0 = (d.a >> 24) | ((d.b & 0xffffu) << 8);
+  const uint32_t lo1 = (d.b >> 16) | (d.c << 16);
+  row1 = lo1 & L6_ROW_MASK;
+  rem1 = (lo1 >> 24) | ((d.c >> 16) << 8);
 }
 
 // phase C: write the regrouped tile out.  LEVEL1 bins are the coarse id, LEVEL2 the sub id.
@@ -676,7 +706,7 @@ __device__ __forceinline__ uint32_t load_mask_word(const uint8_t *valid, uint32_
   const uint32_t drop = (at - from) * 8u;                // bits of earlier bytes in front of ours; >= 32: every row is behind the end
   return drop < 32u ? w >> drop : 0u;
 }
-template <int FAST, bool NARROW, int THREADS, bool MASKED = false>
+template <int FAST, bool NARROW, int THREADS, bool MASKED = false, bool L6 = false>
 __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan, PartGeom g,
                                                              const uint32_t *__restrict__ H1off,   // scanned H1
                                                              Tuples out) {
@@ -772,8 +802,15 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
     for (int h = 0; h < JK_SC_ITEMS; h += 4) {
 #pragma unroll
       for (int k = h; k < h + 4; ++k) {
-        const uint32_t b = fine_of((uint64_t)key[k] + g.kbias, g.fb) >> g.b2;     // hashed whether it travels or not: no branch
-        binrank[k] = (okmask >> k) & 1u ? b : 256u;
+        if constexpr (L6) {
+          // the tuple carries its HASH from here on (a bijection of the key, see L6 above): the flush does not hash again
+          const uint32_t q = hash_a((uint64_t)key[k] + g.kbias);
+          key[k] = (KeyReg)q;
+          binrank[k] = (okmask >> k) & 1u ? q >> (32 - g.b1) : 256u;
+        } else {
+          const uint32_t b = fine_of((uint64_t)key[k] + g.kbias, g.fb) >> g.b2;     // hashed whether it travels or not: no branch
+          binrank[k] = (okmask >> k) & 1u ? b : 256u;
+        }
       }
       __builtin_amdgcn_sched_barrier(0);       // four hashes at a time: sixteen interleaved ones spill
     }
@@ -789,7 +826,13 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
       // collected after the regroup, instead of sitting between two barriers on its own
       uint32_t base = 0;
       if (g.cap1 && tid < ncoarse) {
-        const uint32_t cnt = s.hist[tid];
+        uint32_t cnt = s.hist[tid];
+        if constexpr (L6) {
+          // runs of even length: a pair never straddles two bins (the odd one out is padded with a dead tuple below)
+          s.odd[tid] = cnt & 1u;
+          cnt = (cnt + 1u) & ~1u;
+          s.hist[tid] = cnt;
+        }
         if (cnt) base = atomicAdd(&g.spec_cursor1[(tid << g.xs) | (blockIdx.x & ((1u << g.xs) - 1u))], cnt);
       }
       tile_scan_bins(s, ncoarse, tid);
@@ -805,9 +848,10 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
       for (int k = 0; k < 8; ++k) st[k] = s.start[(binrank[h + k] >> 16) & 255u];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const uint32_t pos = (okmask >> (h + k)) & 1u ? st[k] + (binrank[h + k] & 0xffffu) : (uint32_t)JK_TILE;
+        const uint32_t pos = (okmask >> (h + k)) & 1u ? st[k] + (binrank[h + k] & 0xffffu) : (uint32_t)(JK_TILE + (L6 ? 256 : 0));
         const int32_t row = g.row_base + (int32_t)(tile + item_row(h + k, wtid));
-        s.w[pos] = tup_make<NARROW>((uint64_t)key[h + k], row);
+        if constexpr (L6) s.w[pos] = ((uint64_t)key[h + k] << 32) | l6_row24((uint32_t)row);
+        else s.w[pos] = tup_make<NARROW>((uint64_t)key[h + k], row);
         if (!NARROW) s.idx[pos] = row;
       }
     }
@@ -820,6 +864,9 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
         if (g.cap1) {
           const uint32_t cnt = s.hist[tid];
           const uint32_t region = (tid << g.xs) | (blockIdx.x & ((1u << g.xs) - 1u));
+          if constexpr (L6) {
+            if (s.odd[tid]) s.w[s.start[tid] + cnt - 1u] = ~0ULL;        // the padding of an odd run: a dead tuple (nobody else writes this slot)
+          }
           if (claimed + cnt > g.cap1) { atomicExch(g.spec_flag, 1u); s.gbase[tid] = g.dump - s.start[tid]; }
           else s.gbase[tid] = region * g.cap1 + claimed - s.start[tid];
         } else {
@@ -845,6 +892,40 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
     const uint32_t total = s.total;
     const uint32_t ftid = opaque_tid();
     constexpr int GROUP = 4;
+    if constexpr (L6) {
+      // pairs: lane i of group h takes LDS positions 2 p, 2 p + 1 (p = ftid + (h * GROUP + k) * THREADS; one 16-byte LDS read) and
+      // stores them as ONE aligned 12-byte word triple at tuple position gbase[bin] + 2 p -- both tuples sit in the same even-length
+      // run.  Unconditional, like the 8-byte flush: pairs behind `total` go to this thread's dump slots
+#pragma unroll
+      for (int h = 0; h < JK_SC_ITEMS / 2 / GROUP; ++h) {
+        ulonglong2 ww[GROUP];
+        uint32_t gb[GROUP];
+#pragma unroll
+        for (int k = 0; k < GROUP; ++k) ww[k] = *reinterpret_cast<const ulonglong2 *>(&s.w[2u * (ftid + (h * GROUP + k) * THREADS)]);
+#pragma unroll
+        for (int k = 0; k < GROUP; ++k) gb[k] = s.gbase[(uint32_t)(ww[k].x >> (64 - g.b1)) & 255u];
+#pragma unroll
+        for (int k = 0; k < GROUP; ++k) {
+          const uint32_t j = 2u * (ftid + (h * GROUP + k) * THREADS);
+          const uint32_t dst = j < total ? gb[k] + j : g.dump + 2u * ftid;
+          const uint32_t rmask = (1u << (32 - g.b1)) - 1u;
+          const L6Pair d = l6_pack((uint32_t)(ww[k].x >> 32) & rmask, (uint32_t)ww[k].x & L6_ROW_MASK, (uint32_t)(ww[k].y >> 32) & rmask,
+                                   (uint32_t)ww[k].y & L6_ROW_MASK);
+          *reinterpret_cast<L6Pair *>(reinterpret_cast<unsigned char *>(out.w) + (size_t)dst * 6u) = d;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // the padding can make a tile up to 256 tuples longer than its 16384 rows: the first two waves take those 128 pairs
+      if (ftid < 128u) {
+        const uint32_t j = (uint32_t)JK_TILE + 2u * ftid;
+        const ulonglong2 wx = *reinterpret_cast<const ulonglong2 *>(&s.w[j]);
+        const uint32_t gbx = s.gbase[(uint32_t)(wx.x >> (64 - g.b1)) & 255u];
+        const uint32_t dst = j < total ? gbx + j : g.dump + 2u * ftid;
+        const uint32_t rmask = (1u << (32 - g.b1)) - 1u;
+        const L6Pair d = l6_pack((uint32_t)(wx.x >> 32) & rmask, (uint32_t)wx.x & L6_ROW_MASK, (uint32_t)(wx.y >> 32) & rmask, (uint32_t)wx.y & L6_ROW_MASK);
+        *reinterpret_cast<L6Pair *>(reinterpret_cast<unsigned char *>(out.w) + (size_t)dst * 6u) = d;
+      }
+    } else {
 #pragma unroll
     for (int h = 0; h < JK_SC_ITEMS / GROUP; ++h) {
       uint64_t ww[GROUP];
@@ -870,6 +951,7 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
         if (!NARROW) out.idx[dst] = ii[k];
       }
       __builtin_amdgcn_sched_barrier(0);       // one group's LDS reads at a time: hoisted together they spill
+    }
     }
     // the stores above stay in flight: this waits for the LOADS only.  Unconditional: keeping the old keys alive for the
     // `no more tiles` case would cost 16 registers across the flush
@@ -1063,7 +1145,10 @@ struct Level2Map {                     // small host-built tables, device reside
 
 // K32: the input is a receive buffer of 4-byte keys (Level2Map::keys32, fused multi-GPU join) -- its own instantiations, so that the
 // single-GPU kernels carry no trace of it
-template <bool NARROW, int THREADS, bool PAY = false, bool P6 = false, bool K32 = false>
+// IN6: the input is a stream of six-byte level-1 tuples (L6 above; P6 output only): pairs are read with one 12-byte load, the
+// hash comes out of the tuple (coarse partition = the segment's, remainder = the tuple's) and the row number gets its region bits
+// back from the segment -- this kernel then does not hash at all
+template <bool NARROW, int THREADS, bool PAY = false, bool P6 = false, bool K32 = false, bool IN6 = false>
 __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, Tuples in,
                                                              uint32_t *__restrict__ fine_cursor, Tuples out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
@@ -1100,7 +1185,31 @@ __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, 
   // instructions (which tuple of the tile a thread holds does not matter)
   const bool quads = K32 && end - begin == (uint32_t)JK_TILE;
   int32_t idx[ITEMS];
-  if (K32 && quads) {                                 // workgroup-uniform
+  uint32_t live6 = 0;                                 // IN6: bit k = tuple k of this thread is a live one
+  if constexpr (IN6) {
+    static_assert(!IN6 || (P6 && NARROW && !PAY && !K32), "six-byte input: the main path only");
+    const uint32_t region = lo & ((1u << m.xs) - 1u);
+    L6Pair d[ITEMS / 2];
+#pragma unroll
+    for (int k = 0; k < ITEMS / 2; ++k) {             // all loads first: pair k of this thread = tuples begin + 2 (k THREADS + tid), + 1
+      const uint32_t i = begin + 2u * (k * THREADS + threadIdx.x);
+      const uint32_t ic = i < end ? i : end - 2u;     // (segments and tiles start and end at even positions)
+      d[k] = *reinterpret_cast<const L6Pair *>(reinterpret_cast<const unsigned char *>(in.w) + (size_t)ic * 6u);
+    }
+#pragma unroll
+    for (int k = 0; k < ITEMS / 2; ++k) {
+      uint32_t r0, w0, r1, w1;
+      l6_unpack(d[k], r0, w0, r1, w1);
+      const bool in_tile = begin + 2u * (k * THREADS + threadIdx.x) < end;
+      const uint32_t all = (1u << (32 - g.b1)) - 1u;
+      live6 |= (uint32_t)(in_tile && !(r0 == all && w0 == L6_ROW_MASK)) << (2 * k);
+      live6 |= (uint32_t)(in_tile && !(r1 == all && w1 == L6_ROW_MASK)) << (2 * k + 1);
+      // the tuple as the rest of the kernel wants it: hash word | row
+      w[2 * k] = ((uint64_t)((p << (32 - g.b1)) | r0) << 32) | (uint32_t)(g.row_base + (int32_t)l6_row(w0, region));
+      w[2 * k + 1] = ((uint64_t)((p << (32 - g.b1)) | r1) << 32) | (uint32_t)(g.row_base + (int32_t)l6_row(w1, region));
+      idx[2 * k] = idx[2 * k + 1] = 0;
+    }
+  } else if (K32 && quads) {                          // workgroup-uniform
     if constexpr (K32) {
 #pragma unroll
       for (int q = 0; q < ITEMS / 4; ++q) {
@@ -1128,6 +1237,11 @@ __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, 
 #pragma unroll
   for (int k = 0; k < ITEMS; ++k) {
     const uint32_t i = begin + k * THREADS + threadIdx.x;
+    if constexpr (IN6) {
+      const uint32_t q = (uint32_t)(w[k] >> 32);               // the tuple brought its hash along
+      binrank[k] = ((live6 >> k) & 1u) ? ((uint32_t)((uint64_t)q >> (32 - g.fb)) & submask) : 256u;
+      continue;                                                // (w[k] already is hash word | row, what the P6 flush wants)
+    }
     const uint32_t q = hash_a(tup_key<NARROW>(w[k]) + g.kbias), lh = local_hash(q, g.world);
     const uint32_t bin = (uint32_t)((uint64_t)lh >> (32 - g.fb)) & submask;
     binrank[k] = ((K32 && quads) || i < end) ? bin : 256u;     // (quads: a full tile, every tuple is live whatever order they were fetched in)
@@ -1279,7 +1393,7 @@ __global__ __launch_bounds__(256) void jk_make_units(uint32_t nfine, uint32_t ca
     ++u;
     o += cnt;
   }
-  if (f == 0) state[3] = (unsigned long long)(cursor[nfine] | (level1_flag ? *level1_flag : 0u));
+  if (f == 0) state[3] = (unsigned long long)((cursor[nfine] ? 1u : 0u) | ((level1_flag && *level1_flag) ? 2u : 0u));     // 1: level 2 overflowed, 2: level 1
 }
 
 struct ProbeArgs {
@@ -2762,8 +2876,24 @@ static gdf_error launch_scatter1_n(int threads, const KeyTable &t, const KeyPlan
   else return launch_scatter1_t<FAST, NARROW, 256, MASKED>(t, plan, g, H1off, out);
 }
 static gdf_error launch_scatter1(int fast, bool narrow, int threads, const KeyTable &t, const KeyPlan &plan, const PartGeom &g,
-                                 const uint32_t *H1off, Tuples out) {
+                                 const uint32_t *H1off, Tuples out, bool l6 = false) {
   const bool masked = fast != 0 && t.col[0].valid != nullptr;
+  if (l6) {                          // six-byte level-1 tuples (L6): NARROW, a FAST key column, the 1024-thread tile, speculative layout
+    if (!(fast && narrow && threads == 1024 && g.cap1 && g.xs == 6 && g.b1 == 8)) return GDF_INVALID_API_CALL;
+#define JK_SC1_L6(F, M)                                                                                                             \
+    do {                                                                                                                            \
+      const size_t lds = sizeof(TileLds<true, 1024>);                                                                               \
+      HIP_TRY(hipFuncSetAttribute((const void *)jk_scatter1<F, true, 1024, M, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      GDF_LAUNCH("jk_scatter1", (jk_scatter1<F, true, 1024, M, true>), dim3(g.nchunks), dim3(1024), lds, stream0(), t, plan, g, H1off, out); \
+    } while (0)
+    if (fast == 8 && masked) JK_SC1_L6(8, true);
+    else if (fast == 8) JK_SC1_L6(8, false);
+    else if (masked) JK_SC1_L6(4, true);
+    else JK_SC1_L6(4, false);
+#undef JK_SC1_L6
+    HIP_CHECK_LAST();
+    return GDF_SUCCESS;
+  }
   if (masked) {
     if (fast == 4) return launch_scatter1_n<4, true, true>(threads, t, plan, g, H1off, out);
     return narrow ? launch_scatter1_n<8, true, true>(threads, t, plan, g, H1off, out)
@@ -2796,7 +2926,18 @@ static gdf_error launch_scatter2_t(uint32_t ntiles, const PartGeom &g, Level2Map
   return GDF_SUCCESS;
 }
 static gdf_error launch_scatter2(bool narrow, int threads, uint32_t ntiles, const PartGeom &g, Level2Map m, Tuples in,
-                                 uint32_t *cursor, Tuples out, bool p6 = false) {
+                                 uint32_t *cursor, Tuples out, bool p6 = false, bool in6 = false) {
+  if (in6) {                         // six-byte level-1 tuples in, six-byte level-2 tuples out
+    if (!(p6 && narrow && !m.keys32 && g.b1 == 8)) return GDF_INVALID_API_CALL;
+    m.ntiles = ntiles;
+    m.xcd_order = (ntiles >= 64 && !lab::path_on("GDF_JK_NO_XCD_ORDER")) ? 1 : 0;
+    const uint32_t grid = m.xcd_order ? ((ntiles + 7) / 8) * 8 : ntiles;
+    const size_t lds = sizeof(TileLds<true, 256>);
+    HIP_TRY(hipFuncSetAttribute((const void *)jk_scatter2<true, 256, false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    GDF_LAUNCH("jk_scatter2", (jk_scatter2<true, 256, false, true, false, true>), dim3(grid), dim3(256), lds, stream0(), g, m, in, cursor, out);
+    HIP_CHECK_LAST();
+    return GDF_SUCCESS;
+  }
   if (p6 || m.keys32) {              // six-byte output tuples (see p6_store) and / or a receive buffer of 4-byte keys as input:
     m.ntiles = ntiles;                 // NARROW, no payload, the production tile size
     m.xcd_order = (ntiles >= 64 && !lab::path_on("GDF_JK_NO_XCD_ORDER")) ? 1 : 0;
@@ -3055,6 +3196,14 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
   // one region per (coarse partition, XCD) when a second level follows (PartGeom::xs); a single level needs its
   // partitions contiguous for the probe units
   g.xs = (g.b2 > 0 && n >= ((int64_t)1 << 26) && !lab::path_on("GDF_JK_NO_XCD_SPLIT")) ? 3 : 0;
+  // SIX-BYTE LEVEL-1 tuples (L6, see l6_pack): the deferred main path with six-byte level-2 tuples, a FAST key column on the
+  // 1024-thread tile, 256 coarse partitions (24 hash bits left), chunks of exactly 2^17 rows and 64 regions per coarse partition
+  // (the row number's bits 17..22), rows below 2^30 - 2^23 (seven explicit high bits, and the all-ones tuple stays free for padding).
+  // GDF_JK_FORCE_L6: test switch, small relations too (their few chunks number the regions all the same); GDF_JK_NO_L6: off
+  const bool l6 = want_p6 && defer && !app && narrow && !pay && fast != 0 && sc_threads == 1024 && sc2_threads == 256 && g.b1 == 8 && g.b2 > 0 &&
+                  chunk == ((int64_t)1 << 17) && n < (((int64_t)1 << 30) - ((int64_t)1 << 23)) && g.row_base == 0 &&
+                  (g.xs == 3 || lab::path_on("GDF_JK_FORCE_L6")) && !lab::path_on("GDF_JK_NO_L6");
+  if (l6) g.xs = 6;
   const uint32_t nseg = ncoarse << g.xs;
   const uint32_t cap1 = room((double)n / nseg, 64), cap2 = app ? app->cap2 : (g.b2 ? room((double)n / nfine, 8) : 0);
   const uint64_t size1 = (uint64_t)nseg * cap1 + JK_TILE, size2 = (uint64_t)nfine * cap2 + JK_TILE;
@@ -3069,7 +3218,7 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
   g.dump = nseg * cap1;
   g.spec_cursor1 = spec.as<uint32_t>();
   g.spec_flag = spec.as<uint32_t>() + nseg;
-  RMM_TRY(sb->w[0].alloc(sizeof(uint64_t) * size1));
+  RMM_TRY(sb->w[0].alloc(l6 ? 6 * (size1 + 2048) + 16 : sizeof(uint64_t) * size1));      // (L6: + two dump slots per thread behind the regions)
   if (!narrow) RMM_TRY(sb->idx[0].alloc(sizeof(int32_t) * size1));
   if (pay) RMM_TRY(sb->pay[0].alloc(sizeof(uint64_t) * size1));
 #ifdef GDF_AMD_LAB
@@ -3081,7 +3230,7 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
   }
 #endif
   if (pay) GDF_TRY(launch_scatter1_pay(fast, pmode, t, plan, g, nullptr, *pay, sb->tuples(0)));
-  else GDF_TRY(launch_scatter1(fast, narrow, sc_threads, t, plan, g, nullptr, sb->tuples(0)));
+  else GDF_TRY(launch_scatter1(fast, narrow, sc_threads, t, plan, g, nullptr, sb->tuples(0), l6));
 #ifdef GDF_AMD_LAB
   if (g.lab_clock) {
     std::vector<unsigned long long> h(16 * (size_t)g.nchunks);
@@ -3095,6 +3244,16 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
       for (int i = 0; i < 6; ++i) fprintf(stderr, "  %-34s %5.1f %%\n", names[i], 100.0 * sum[i] / all);
     }
     g.lab_clock = nullptr;
+  }
+#endif
+#ifdef GDF_AMD_LAB
+  if (lab::knob_on("GDF_JK_TRACE")) {
+    std::vector<uint32_t> c1(nseg + 1);
+    HIP_TRY(read_back(c1.data(), spec.p, sizeof(uint32_t) * (nseg + 1)));
+    uint64_t sum = 0; uint32_t mx = 0, nz = 0;
+    for (uint32_t i = 0; i < nseg; ++i) { sum += c1[i]; mx = std::max(mx, c1[i]); nz += c1[i] != 0; }
+    fprintf(stderr, "level 1: nseg %u cap1 %u xs %d l6 %d chunks %d: fill sum %llu max %u nonzero %u flag %u\n", nseg, cap1, g.xs, (int)l6, g.nchunks,
+            (unsigned long long)sum, mx, nz, c1[nseg]);
   }
 #endif
   if (defer && !app && g.b2 > 0) {
@@ -3121,7 +3280,7 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
     m.ntiles_dev = ntiles_dev;
     // every segment ends in at most one partial tile: an upper bound of the tile count sizes the grid
     const uint32_t tile_bound = (uint32_t)((uint64_t)n / (uint64_t)JK_TILE2) + nseg + 1;
-    GDF_TRY(launch_scatter2(narrow, sc2_threads, tile_bound, g2, m, sb->tuples(0), cursor.as<uint32_t>(), sb->tuples(1), p6));
+    GDF_TRY(launch_scatter2(narrow, sc2_threads, tile_bound, g2, m, sb->tuples(0), cursor.as<uint32_t>(), sb->tuples(1), p6, l6));
     sb->p6 = p6;
     // no synchronisation: the map and the level-1 tuples stay allocated until probe_partitioned has read its state block
     sb->d_map.p = d_map.release();
@@ -3830,6 +3989,9 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
     P.w[0].reset();                        // level-1 tuples and the segment map: everything that read them has run
     P.idx[0].reset();
     P.d_map.reset();
+#ifdef GDF_AMD_LAB
+    if (lab::knob_on("GDF_JK_TRACE")) fprintf(stderr, "deferred probe side: overflow flags %llu (1 = level 2, 2 = level 1), units %llu, tuples %llu\n", bk[3], bk[0], bk[2]);
+#endif
     if (bk[3]) return GDF_AMD_RETRY_EXACT_PROBE;
     nunits = (size_t)bk[0];
     cap_pairs = bk[1];

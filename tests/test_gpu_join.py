@@ -791,6 +791,41 @@ def test_six_byte_level2_tuples(gdf, how, keys, hit, force_path):
 
 
 @pytest.mark.parametrize("how", ["inner", "left"])
+@pytest.mark.parametrize("keys", ["int64", "int64-offset", "int32", "masked", "build-keys-twice", "nine-million-rows", "probe-third-on-one-key"])
+def test_six_byte_level1_tuples(gdf, how, keys, force_path):
+    """The probe side's LEVEL-1 tuples are six bytes too on the main path (csrc/join.hip L6): 24 hash bits (the
+    coarse partition is the tuple's place) + 24 explicit row bits (bits 17..22 of the row number are the tuple's REGION: level 1
+    splits every coarse partition into 64 regions by chunk number), runs padded to even lengths with a dead tuple, pairs stored
+    and re-read as 12 bytes.  GDF_JK_FORCE_FB=15 + GDF_JK_FORCE_L6 give a small relation the headline's geometry (its few chunks
+    number the regions all the same).  Against the oracle and against eight-byte level-1 tuples (GDF_JK_NO_L6): keys from 0, with
+    an offset, 4-byte keys, a validity mask on both key columns (jk_scatter1<MASKED, L6>), repeated build keys, nine million probe
+    rows (more than 64 chunks: regions wrap; row numbers beyond 2^23: the explicit high bits), and a skewed probe side that falls
+    back to the exact layout (eight-byte level 1).  Reference semantics: join_kernels.cuh:259-455."""
+    rs = np.random.RandomState(len(keys))
+    nb, npr = 60_000, (9_000_000 if keys == "nine-million-rows" else 900_000)
+    force_path("GDF_JK_FORCE_FB", "15")
+    force_path("GDF_JK_SPEC_MIN", "1000")
+    force_path("GDF_JK_FORCE_L6")
+    space = nb * 5 // 4
+    bk = rs.permutation(space)[:nb].astype(np.int64)
+    if keys == "build-keys-twice":
+        bk[: nb // 2] = bk[nb // 2:]
+    pk = rs.randint(0, space, size=npr).astype(np.int64)
+    if keys == "probe-third-on-one-key":
+        pk[rs.rand(npr) < 0.33] = bk[7]
+    if keys == "int64-offset":
+        bk, pk = bk + (5 << 34) + 999, pk + (5 << 34) + 999
+    lv = rv = None
+    if keys == "masked":
+        lv, rv = [rs.rand(npr) > 0.1], [rs.rand(nb) > 0.05]
+    if keys == "int32":
+        bk, pk = bk.astype(np.int32), pk.astype(np.int32)
+    n1 = _check(gdf, [pk], [bk], how, lv, rv)
+    force_path("GDF_JK_NO_L6")
+    assert _check(gdf, [pk], [bk], how, lv, rv) == n1
+
+
+@pytest.mark.parametrize("how", ["inner", "left"])
 @pytest.mark.parametrize("layout", ["speculative", "exact"])
 def test_six_byte_tuples_probe_keys_beyond_the_build_range(gdf, how, layout, force_path):
     """The six-byte tuples compare hash remainders, and hash_a is a bijection on the BUILD range only (raw values inside one

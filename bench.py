@@ -36,10 +36,11 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
 # kb = bytes per key the join reads: 8 (C3: the caller's int64 column), 4 on the multi-GPU path (keys travel narrowed).
 KERNEL_BYTES = {
     "jk_hist": lambda npr, nb, tb, lps, kb: kb * nb + (kb * npr if lps > 1.5 else 0.0),   # reads every key once
-    "jk_scatter1": lambda npr, nb, tb, lps, kb: (kb + tb) * (npr + nb),         # key in, tuple out
+    # key in, tuple out (the probe side's level-1 tuples are six bytes too on the single-GPU main path: csrc/join.hip L6)
+    "jk_scatter1": lambda npr, nb, tb, lps, kb: (kb + tb) * nb + (kb + l6_bytes(npr, nb, tb, kb)) * npr,
     # (six-byte level-2 tuples on the probe side -- csrc/join.hip p6_store -- when the keys are NARROW and the build side needs 2^15
     # partitions: the probe side's level-2 output and the probe kernel's input are then 6 B per tuple)
-    "jk_scatter2": lambda npr, nb, tb, lps, kb: (tb + tb) * nb + (tb + p6_bytes(nb, tb)) * npr,         # tuple in, tuple out
+    "jk_scatter2": lambda npr, nb, tb, lps, kb: (tb + tb) * nb + (l6_bytes(npr, nb, tb, kb) + p6_bytes(nb, tb)) * npr,         # tuple in, tuple out
     "jk_probe_count": lambda npr, nb, tb, lps, kb: tb * nb + p6_bytes(nb, tb) * npr,                    # tuples in
     "jk_probe_write": lambda npr, nb, tb, lps, kb: tb * nb + p6_bytes(nb, tb) * npr + 8.0 * npr,        # tuples in, one int32 index pair per probe row out
     # the sender side of the shuffle (multi-GPU only): int64 keys in; narrowed key + int32 row number out
@@ -56,6 +57,12 @@ KERNEL_BYTES = {
 def p6_bytes(nb, tb):
     """bytes per probe-side level-2 tuple: 6 when the join takes the six-byte tuples (NARROW keys, >= 3072 * 2^14 build rows), else tb"""
     return 6.0 if (tb == 8.0 and nb >= 3072 * 2 ** 14) else tb
+
+
+def l6_bytes(npr, nb, tb, kb):
+    """bytes per probe-side level-1 tuple: 6 where the join takes the six-byte level-1 tuples (csrc/join.hip L6: six-byte level-2
+    tuples, 2^26 <= probe rows < 2^30 - 2^23, the single-GPU path reading the caller's 8-byte keys), else tb"""
+    return 6.0 if (p6_bytes(nb, tb) == 6.0 and kb == 8.0 and 2 ** 26 <= npr < 2 ** 30 - 2 ** 23) else tb
 
 
 def splitmix64_torch(x):

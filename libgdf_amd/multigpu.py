@@ -718,13 +718,16 @@ def fused_inner_join(probe_keys, build_keys, group=None, chunks=4, plan_fn=_fj_p
         a, b = min(n, c * step), min(n, (c + 1) * step)
         pk, prow, pfill, over = send_fn(probe_keys[a:b], lo, hi, lay_p, a)
         failed = failed or over
+        probe_rows.append(prow)
+        # the slice goes on the wire BEFORE anybody asks whether it overflowed (the agreement used to sit in front of the
+        # first exchange -- a blocking all-reduce on the happy path of every join); an overflowed buffer is just useless
+        x = exchange(pk, pfill, lay_p, async_op=True) + (pk, pfill)              # the send buffers stay alive with the works
         if c == 0 and not agree(over):
             # a region overflowed on some rank's FIRST slice (skewed probe keys are usually skewed everywhere): every rank leaves
             # now, before three more slices are regrouped, shipped and partitioned for nothing
             wait(works)
+            wait(x[2])
             return None
-        probe_rows.append(prow)
-        x = exchange(pk, pfill, lay_p, async_op=True) + (pk, pfill)              # the send buffers stay alive with the works
         if build is None:
             wait(works)
             try:

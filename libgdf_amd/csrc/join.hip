@@ -68,9 +68,13 @@ struct KeyPlan {
   uint64_t kmin;              // subtracted from 8-byte integer keys in narrow mode (two's complement)
   uint64_t kspan;             // narrow mode with kmin != 0: the largest stored key (build max - min); decides whether hash_a is a
                               // bijection on the stored keys (six-byte level-2 tuples, p6_store)
-  uint64_t klimit;            // the largest stored key that can join: 2^32 - 1 for NARROW keys, kspan once the build range is known
+  mutable uint64_t klimit;    // the largest stored key that can join: 2^32 - 1 for NARROW keys, kspan once the build range is known
                               // (a probe key beyond the build maximum matches nothing, and the six-byte tuples compare hash
                               // remainders only: hash_a is a bijection on [0, kspan], not beyond it), ~0 for WIDE keys
+  uint64_t kwindow;           // range-narrowed keys (else 0): the largest stored key that still lies in the 2^32 window of raw values hash_a
+                              // is a bijection on.  An INNER join drops probe rows beyond kspan before they are partitioned (they match nothing,
+                              // and half-hit joins run 1 ms faster for it); a LEFT / FULL join lets rows up to kwindow TRAVEL -- the probe kernel
+                              // emits their (l, -1) for free, whereas dropped rows come back through the tail kernels (probe_prepared sets klimit)
   int shift[MAX_KEY_COLS];    // KM_PACKED bit offsets
   // KM_PACKED with ranged != 0: column c contributes (value - bias[c]) in bits[c] bits, the ranges taken from the BUILD
   // relation (plan_ranged); a probe value outside its column's range cannot match and makes the row unjoinable
@@ -513,7 +517,8 @@ struct TileLds {
   uint64_t w[THREADS * ITEMS + PAD + 2];
   int32_t idx[NARROW ? 4 : THREADS * ITEMS + 4];
   uint64_t pay[PAY ? THREADS * ITEMS + 2 : 2];            // payload words, regrouped with their tuples
-  uint32_t hist[256 + 4];                                 // + a trash counter, same reason (never zeroed, never read)
+  uint32_t hist[256 + 64];                                // + 64 trash counters, one per lane (never zeroed, never read): a probe relation with
+                                                          // most of its keys outside the build range put 90 % of a tile's LDS atomics on ONE of them
   uint32_t start[256];
   uint32_t gbase[256];    // (global base - start[bin]) mod 2^32; destinations are < 2^31
   uint32_t cursor[256];   // level 1: running global cursor of this chunk
@@ -806,10 +811,10 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
           // the tuple carries its HASH from here on (a bijection of the key, see L6 above): the flush does not hash again
           const uint32_t q = hash_a((uint64_t)key[k] + g.kbias);
           key[k] = (KeyReg)q;
-          binrank[k] = (okmask >> k) & 1u ? q >> (32 - g.b1) : 256u;
+          binrank[k] = (okmask >> k) & 1u ? q >> (32 - g.b1) : 256u + (threadIdx.x & 63u);
         } else {
           const uint32_t b = fine_of((uint64_t)key[k] + g.kbias, g.fb) >> g.b2;     // hashed whether it travels or not: no branch
-          binrank[k] = (okmask >> k) & 1u ? b : 256u;
+          binrank[k] = (okmask >> k) & 1u ? b : 256u + (threadIdx.x & 63u);
         }
       }
       __builtin_amdgcn_sched_barrier(0);       // four hashes at a time: sixteen interleaved ones spill
@@ -1044,7 +1049,7 @@ __global__ __launch_bounds__(JK_PAY_THREADS) void jk_scatter1_pay(KeyTable t, Ke
 #pragma unroll
       for (int k = h; k < h + 4; ++k) {
         const uint32_t b = fine_of((uint64_t)key[k] + g.kbias, g.fb) >> g.b2;
-        binrank[k] = (okmask >> k) & 1u ? b : 256u;
+        binrank[k] = (okmask >> k) & 1u ? b : 256u + (threadIdx.x & 63u);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1239,12 +1244,12 @@ __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, 
     const uint32_t i = begin + k * THREADS + threadIdx.x;
     if constexpr (IN6) {
       const uint32_t q = (uint32_t)(w[k] >> 32);               // the tuple brought its hash along
-      binrank[k] = ((live6 >> k) & 1u) ? ((uint32_t)((uint64_t)q >> (32 - g.fb)) & submask) : 256u;
+      binrank[k] = ((live6 >> k) & 1u) ? ((uint32_t)((uint64_t)q >> (32 - g.fb)) & submask) : 256u + (threadIdx.x & 63u);
       continue;                                                // (w[k] already is hash word | row, what the P6 flush wants)
     }
     const uint32_t q = hash_a(tup_key<NARROW>(w[k]) + g.kbias), lh = local_hash(q, g.world);
     const uint32_t bin = (uint32_t)((uint64_t)lh >> (32 - g.fb)) & submask;
-    binrank[k] = ((K32 && quads) || i < end) ? bin : 256u;     // (quads: a full tile, every tuple is live whatever order they were fetched in)
+    binrank[k] = ((K32 && quads) || i < end) ? bin : 256u + (threadIdx.x & 63u);     // (quads: a full tile, every tuple is live whatever order they were fetched in)
     // six-byte tuples leave as (hash remainder, row): the key is not needed again, the LDS tile holds the hash word and the flush
     // does not hash a second time (two quarter-rate multiplies per tuple: the kernel's ALU work is not hidden at 4 waves per SIMD)
     if constexpr (P6) w[k] = ((uint64_t)p6_low(q, lh, g.world) << 32) | (uint32_t)w[k];
@@ -3078,6 +3083,7 @@ static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, Si
       plan.kmin = (uint64_t)h[0];
       plan.kspan = (uint64_t)h[1] - (uint64_t)h[0];
       plan.klimit = plan.kspan;
+      plan.kwindow = (plan.kmin & 0xffffffffULL) + plan.kspan < (1ULL << 32) ? 0xffffffffULL - (plan.kmin & 0xffffffffULL) : 0xffffffffULL;
       narrow = true;
     }
   }
@@ -3754,6 +3760,8 @@ static gdf_error probe_prepared(const KeyTable &probe_t, const KeyTable &build_t
   const KeyPlan &plan = bs.plan;
   const PartGeom &g = bs.g;
   const SideBufs &B = bs.B;
+  // which probe rows travel (KeyPlan::kwindow): decided per probe call -- a prepared build side serves INNER and LEFT probes alike
+  if (plan.kwindow) plan.klimit = kind == JOIN_INNER ? plan.kspan : plan.kwindow;
 
   SideBufs P;
   // The probe side is the big one (C3: 10x the build side): it is partitioned WITHOUT a histogram pass

@@ -226,3 +226,39 @@ def test_large_sort_properties(gdf):
     sk, sa = gdf.api.group_by("sum", [Column(kk)], Column(v), method=GDF_SORT)
     hk, ha = gdf.api.group_by("sum", [Column(kk)], Column(v), sort_result=True)
     assert torch.equal(sk[0], hk[0]) and torch.equal(sa, ha) and int(sa.sum()) == int(v.sum())
+
+
+@pytest.mark.parametrize("op", OPS)
+@pytest.mark.parametrize("shape", ["one-int64-column", "two-columns", "negative-keys", "int8-values"])
+def test_sort_method_small_key_ranges_take_the_direct_path(gdf, op, shape, force_path):
+    """A SORT-method group-by over integer keys with a small value range needs no sort to come out sorted: group_by_single serves
+    it from the hash method's direct path (LDS accumulators indexed by the lexicographic group number) plus a last-row pass for
+    out_col_indices -- VERDICT r3 item 7.  The contract is the SORT method's (sqls_ops.cu:1134-1289: ascending groups, aggregation in
+    the input dtype, COUNT in the output column's, out_col_indices = every group's last row, sqls_g_tester.cu:250-256): against
+    oracle.group_by_sort, kernel names through the profile hook, and the same call through the sort (GDF_SORT_NO_DIRECT)."""
+    from bench import read_profile
+    rs = np.random.RandomState(len(shape) + len(op))
+    n = 300_000
+    if shape == "two-columns":
+        keys = [rs.randint(0, 40, size=n).astype(np.int32), rs.randint(-3, 60, size=n).astype(np.int64)]
+    elif shape == "negative-keys":
+        keys = [rs.randint(-5000, 3000, size=n).astype(np.int64)]
+    else:
+        keys = [rs.randint(0, 10_000, size=n).astype(np.int64)]
+    vals = rs.randint(-100, 100, size=n).astype(np.int8) if shape == "int8-values" else rs.randint(-1000, 1000, size=n).astype(np.int64)
+    lib = gdf._binding._gdf_cdll
+
+    def names_of(call):
+        lib.gdf_amd_profile_reset(); lib.gdf_amd_profile_enable(1)
+        try:
+            call()
+        finally:
+            lib.gdf_amd_profile_enable(0)
+        return set(read_profile(gdf))
+
+    out = np.int64 if op == "count" else None
+    names = names_of(lambda: _check(gdf, op, keys, vals, out))
+    assert "gb_direct_aggregate" in names and "gb_direct_last_rows" in names and "rs_scatter" not in names, names
+    force_path("GDF_SORT_NO_DIRECT")
+    names = names_of(lambda: _check(gdf, op, keys, vals, out))
+    assert "rs_scatter" in names and "gb_direct_aggregate" not in names, names

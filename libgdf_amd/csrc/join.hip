@@ -337,6 +337,11 @@ struct PartGeom {
   // the partition's fill counter.  A partition that outgrows its capacity raises *spec_flag and its run is
   // written to the dump area instead (memory safe); the host then repeats the side with the exact layout.
   uint32_t cap1, cap2, dump;
+  // SKEWED probe keys (round 4): the speculative layout with PER-PARTITION room instead of one capacity for all -- region r of level 1
+  // owns [rstart[r], rstart[r] + rcap[r]), fine partition f owns [fstart[f], fstart[f] + fcap[f]); sized from a 2^22-row sample of the
+  // probe keys (probe_prepared / SkewCaps).  Null: the uniform layout (r * cap1, f * cap2).  cap1 / cap2 stay non-zero (the largest
+  // capacity): they are what says "speculative" to the kernels.
+  const uint32_t *rstart, *rcap, *fstart, *fcap;
   uint32_t *spec_cursor1;   // [2^b1 << xs] fill counters, zero-initialised
   uint32_t *spec_flag;
   // Level 1 of the speculative layout splits every coarse partition into 2^xs REGIONS of cap1 tuples, one per XCD
@@ -499,6 +504,33 @@ __global__ __launch_bounds__(256) void jk_sample_skew(const void *col, int64_t n
   const uint32_t old = atomicAdd(&hist[f], 1u);
   atomicMax(max_count, old + 1u);
 }
+
+// The capacity sample of a SKEWED probe column (SkewCaps): 2^22 evenly spaced rows binned by fine partition, LDS histograms merged with
+// one global atomic per touched bin and workgroup.  counts[nfine] = rows sampled.
+constexpr uint32_t JK_CAPS_SAMPLES = 1u << 22;
+template <int FAST>
+__global__ __launch_bounds__(1024) void jk_sample_caps(const void *col, int64_t nrows, int fb, uint32_t *__restrict__ counts) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t caps_lds[];
+  const uint32_t nfine = 1u << fb;
+  for (uint32_t f = threadIdx.x; f < nfine; f += 1024) caps_lds[f] = 0;
+  block_sync();
+  const uint32_t per_wg = JK_CAPS_SAMPLES / gridDim.x;
+  for (uint32_t j = threadIdx.x; j < per_wg; j += 1024) {
+    const uint32_t sidx = blockIdx.x * per_wg + j;
+    const int64_t i = (int64_t)(((unsigned __int128)sidx * (unsigned __int128)nrows) >> 22);
+    atomicAdd(&caps_lds[fine_of(fast_word<FAST>(col, i), fb)], 1u);
+  }
+  block_sync();
+  for (uint32_t f = threadIdx.x; f < nfine; f += 1024)
+    if (caps_lds[f]) atomicAdd(&counts[f], caps_lds[f]);
+  if (threadIdx.x == 0) atomicAdd(&counts[nfine], per_wg);
+}
+// what the host made of it: sampled rows per fine partition (the device arrays depend on the level-1 region split and are made by
+// partition_side_spec)
+struct SkewCaps {
+  std::vector<uint32_t> fine;      // [nfine] sampled rows
+  double rows_per_sample = 0;      // probe rows / sampled rows
+};
 
 // ---------------------------------------------------------------------------
 // LDS tile regroup shared by both scatter levels.
@@ -872,8 +904,9 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
           if constexpr (L6) {
             if (s.odd[tid]) s.w[s.start[tid] + cnt - 1u] = ~0ULL;        // the padding of an odd run: a dead tuple (nobody else writes this slot)
           }
-          if (claimed + cnt > g.cap1) { atomicExch(g.spec_flag, 1u); s.gbase[tid] = g.dump - s.start[tid]; }
-          else s.gbase[tid] = region * g.cap1 + claimed - s.start[tid];
+          const uint32_t room = g.rcap ? g.rcap[region] : g.cap1, first = g.rstart ? g.rstart[region] : region * g.cap1;
+          if (claimed + cnt > room) { atomicExch(g.spec_flag, 1u); s.gbase[tid] = g.dump - s.start[tid]; }
+          else s.gbase[tid] = first + claimed - s.start[tid];
         } else {
           s.gbase[tid] = s.cursor[tid] - s.start[tid];
           s.cursor[tid] += s.hist[tid];
@@ -1282,7 +1315,8 @@ __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, 
   }
   if (threadIdx.x < nsub && mine) {
     const uint32_t f = (p << g.b2) | threadIdx.x;
-    if (g.cap2 && claimed + mine > (f + 1) * g.cap2) { atomicExch(g.spec_flag, 1u); s.gbase[threadIdx.x] = g.dump - s.start[threadIdx.x]; }
+    const uint32_t limit = g.fstart ? g.fstart[f] + g.fcap[f] : (f + 1) * g.cap2;
+    if (g.cap2 && claimed + mine > limit) { atomicExch(g.spec_flag, 1u); s.gbase[threadIdx.x] = g.dump - s.start[threadIdx.x]; }
     else s.gbase[threadIdx.x] = claimed - s.start[threadIdx.x];
   }
   block_sync();
@@ -1321,7 +1355,8 @@ __device__ __forceinline__ T bk_block_scan(T v, T *lds_wave, T *total) {
 __global__ __launch_bounds__(JK_BK_THREADS) void jk_make_l2map(const uint32_t *__restrict__ fill, uint32_t nseg, uint32_t cap1, uint32_t tile,
                                                                uint32_t *__restrict__ seg_begin, uint32_t *__restrict__ seg_end,
                                                                uint32_t *__restrict__ tile_prefix, uint32_t *__restrict__ ntiles,
-                                                               uint32_t fj_world, uint32_t ncoarse) {
+                                                               uint32_t fj_world, uint32_t ncoarse, const uint32_t *__restrict__ rstart = nullptr,
+                                                               const uint32_t *__restrict__ rcap = nullptr) {
   __shared__ uint32_t lds_wave[JK_BK_THREADS / WAVE];
   const uint32_t per = (nseg + JK_BK_THREADS - 1) / JK_BK_THREADS;
   const uint32_t c0 = threadIdx.x * per;
@@ -1334,22 +1369,23 @@ __global__ __launch_bounds__(JK_BK_THREADS) void jk_make_l2map(const uint32_t *_
   // the side with the exact layout) has a fill counter ABOVE its capacity: clamped, or the segments -- and level 2's reads --
   // run past the region and, for the last ones, past the buffer.  (Found by tools/stress_join.py: an illegal address on a
   // probe side with a tenth of its rows on one key.)
-  auto filled = [&](uint32_t region) -> uint32_t { const uint32_t n = fill[region]; return n < cap1 ? n : cap1; };
+  auto filled = [&](uint32_t region) -> uint32_t { const uint32_t n = fill[region], room = rcap ? rcap[region] : cap1; return n < room ? n : room; };
   uint32_t mine = 0;
   for (uint32_t c = c0; c < c0 + per && c < nseg; ++c) mine += (filled(region_of(c)) + tile - 1) / tile;
   uint32_t total;
   uint32_t run = bk_block_scan<uint32_t>(mine, lds_wave, &total);
   for (uint32_t c = c0; c < c0 + per && c < nseg; ++c) {
     const uint32_t r = region_of(c), n = filled(r);
-    seg_begin[c] = r * cap1;
-    seg_end[c] = r * cap1 + n;
+    const uint32_t first = rstart ? rstart[r] : r * cap1;
+    seg_begin[c] = first;
+    seg_end[c] = first + n;
     tile_prefix[c] = run;
     run += (n + tile - 1) / tile;
   }
   if (threadIdx.x == 0) { tile_prefix[nseg] = total; *ntiles = total; }
 }
-__global__ __launch_bounds__(256) void jk_init_cursor(uint32_t *cur, uint32_t nfine, uint32_t cap2) {
-  for (uint32_t f = blockIdx.x * 256 + threadIdx.x; f <= nfine; f += gridDim.x * 256) cur[f] = f < nfine ? f * cap2 : 0u;   // [nfine]: overflow flag
+__global__ __launch_bounds__(256) void jk_init_cursor(uint32_t *cur, uint32_t nfine, uint32_t cap2, const uint32_t *__restrict__ fstart = nullptr) {
+  for (uint32_t f = blockIdx.x * 256 + threadIdx.x; f <= nfine; f += gridDim.x * 256) cur[f] = f < nfine ? (fstart ? fstart[f] : f * cap2) : 0u;   // [nfine]: overflow flag
 }
 
 // ---------------------------------------------------------------------------
@@ -1370,13 +1406,16 @@ __global__ __launch_bounds__(256) void jk_make_units(uint32_t nfine, uint32_t ca
                                                      const uint32_t *__restrict__ level1_flag,
                                                      const uint32_t *__restrict__ build_begin, const uint32_t *__restrict__ build_cnt,
                                                      int keep_probe, Unit *__restrict__ units, uint64_t *__restrict__ off,
-                                                     unsigned long long *__restrict__ state) {
+                                                     unsigned long long *__restrict__ state, const uint32_t *__restrict__ fstart = nullptr,
+                                                     const uint32_t *__restrict__ fcap = nullptr) {
   const uint32_t f = blockIdx.x * 256 + threadIdx.x;
   const uint32_t fc = f < nfine ? f : nfine - 1;
   const uint32_t cur = cursor[fc], bn = build_cnt[fc], bb = build_begin[fc];
+  const uint32_t first = fstart ? fstart[fc] : fc * cap2;
+  if (fcap) cap2 = fcap[fc];                       // (per-partition room: SkewCaps)
   // (a fine partition that outgrew its room -- overflow flag up, the host repeats with the exact layout -- is cut at its
   // capacity: its real count would make more units than the arrays hold)
-  const uint32_t grown = f < nfine ? cur - f * cap2 : 0u;
+  const uint32_t grown = f < nfine ? cur - first : 0u;
   const uint32_t all = grown < cap2 ? grown : cap2;
   const uint32_t pn = (all != 0 && (bn != 0 || keep_probe)) ? all : 0u;
   const uint32_t nun = (pn + JK_PROBE_CHUNK - 1) / JK_PROBE_CHUNK;
@@ -1393,7 +1432,7 @@ __global__ __launch_bounds__(256) void jk_make_units(uint32_t nfine, uint32_t ca
   unsigned long long u = base_u + incl_u - nun, o = base_t + incl_t - pn;
   for (uint32_t at = 0; at < pn; at += JK_PROBE_CHUNK) {
     const uint32_t cnt = pn - at < JK_PROBE_CHUNK ? pn - at : JK_PROBE_CHUNK;
-    units[u] = Unit{bb, bn, f * cap2 + at, cnt};
+    units[u] = Unit{bb, bn, first + at, cnt};
     off[u] = o;
     ++u;
     o += cnt;
@@ -2832,6 +2871,8 @@ struct SideBufs {            // partitioned tuples of one relation
   bool p6 = false;           // the fine-partitioned tuples of this (deferred probe) side are six-byte ones (p6_store)
   uint32_t cap2 = 0;
   DevBuf d_level1;           // [nseg + 1] level-1 fill counters + overflow flag
+  DevBuf d_caps;             // per-partition room of a skewed probe side (SkewCaps): rstart | rcap | fstart | fcap, else empty
+  const uint32_t *d_fstart = nullptr, *d_fcap = nullptr;
   uint32_t nseg = 0;
   DevBuf d_cursor;           // [nfine + 1] level-2 fill cursors (f * cap2 + fill) + overflow flag
   DevBuf d_map;              // the level-2 segment map jk_scatter2 may still be reading
@@ -3173,7 +3214,7 @@ struct SpecAppend {
 
 static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, PartGeom g, double dup, SideBufs *sb, bool *ok,
                                      SpecAppend *app = nullptr, bool defer = false, const PaySrc *pay = nullptr, int pmode = 0,
-                                     bool want_p6 = false) {
+                                     bool want_p6 = false, const SkewCaps *caps = nullptr) {
   *ok = false;
   if (app) g.row_base = (int32_t)app->rows;
   const int64_t n = t.nrows;
@@ -3211,8 +3252,45 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
                   (g.xs == 3 || lab::path_on("GDF_JK_FORCE_L6")) && !lab::path_on("GDF_JK_NO_L6");
   if (l6) g.xs = 6;
   const uint32_t nseg = ncoarse << g.xs;
-  const uint32_t cap1 = room((double)n / nseg, 64), cap2 = app ? app->cap2 : (g.b2 ? room((double)n / nfine, 8) : 0);
-  const uint64_t size1 = (uint64_t)nseg * cap1 + JK_TILE, size2 = (uint64_t)nfine * cap2 + JK_TILE;
+  uint32_t cap1 = room((double)n / nseg, 64), cap2 = app ? app->cap2 : (g.b2 ? room((double)n / nfine, 8) : 0);
+  uint64_t size1 = (uint64_t)nseg * cap1 + JK_TILE, size2 = (uint64_t)nfine * cap2 + JK_TILE;
+  // SKEWED probe keys (SkewCaps): per-region / per-partition room from the capacity sample -- the estimate + 6 sigma of it, and for a
+  // level-1 region 8 sigma of its own share on top (a region holds 1 / 2^xs of its coarse partition's rows).  Deferred path only.
+  std::vector<uint32_t> cap_words;
+  if (caps) {
+    if (!(defer && !app && g.b2 > 0 && !pay && caps->fine.size() == nfine)) return GDF_SUCCESS;
+    cap_words.resize(2 * (size_t)nseg + 2 * (size_t)nfine);
+    uint32_t *rstart = cap_words.data(), *rcap = rstart + nseg, *fstart = rcap + nseg, *fcap = fstart + nfine;
+    const double scale = caps->rows_per_sample;
+    uint64_t run1 = 0, run2 = 0;
+    uint32_t max1 = 0, max2 = 0;
+    const uint32_t nreg = 1u << g.xs;
+    for (uint32_t c = 0; c < ncoarse; ++c) {
+      double sc = 0;
+      for (uint32_t f = c << g.b2; f < ((c + 1) << g.b2); ++f) {
+        const double sf = (double)caps->fine[f];
+        sc += sf;
+        const double U = (sf + 6.0 * std::sqrt(sf + 1.0) + 4.0) * scale;
+        const uint64_t cf = ((uint64_t)(U + 64.0) + 7) / 8 * 8;
+        fstart[f] = (uint32_t)std::min<uint64_t>(run2, 0xffffffffULL);
+        fcap[f] = (uint32_t)std::min<uint64_t>(cf, 0x7fffffffULL);
+        run2 += cf;
+        max2 = std::max(max2, fcap[f]);
+      }
+      const double Uc = (sc + 6.0 * std::sqrt(sc + 1.0) + 4.0) * scale / (double)nreg;
+      const uint64_t cr = ((uint64_t)(Uc + 8.0 * std::sqrt(Uc) + 64.0) + 63) / 64 * 64;
+      for (uint32_t r = 0; r < nreg; ++r) {
+        rstart[c * nreg + r] = (uint32_t)std::min<uint64_t>(run1, 0xffffffffULL);
+        rcap[c * nreg + r] = (uint32_t)std::min<uint64_t>(cr, 0x7fffffffULL);
+        run1 += cr;
+        max1 = std::max(max1, rcap[c * nreg + r]);
+      }
+    }
+    size1 = run1 + JK_TILE;
+    size2 = run2 + JK_TILE;
+    cap1 = max1;
+    cap2 = max2;
+  }
   if (size1 >= 0x7fffffffULL || size2 >= 0x7fffffffULL) return GDF_SUCCESS;      // tuple positions are 31-bit
 
   DevBuf spec;
@@ -3221,7 +3299,18 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
   g.kbias = plan.kmin;
   g.cap1 = cap1;
   g.cap2 = 0;
-  g.dump = nseg * cap1;
+  g.dump = caps ? (uint32_t)(size1 - JK_TILE) : nseg * cap1;
+  if (caps) {
+    RMM_TRY(sb->d_caps.alloc(sizeof(uint32_t) * cap_words.size()));
+    HIP_TRY(hipMemcpyAsync(sb->d_caps.p, cap_words.data(), sizeof(uint32_t) * cap_words.size(), hipMemcpyHostToDevice, stream0()));
+    HIP_TRY(hipStreamSynchronize(stream0()));                  // (cap_words is a local)
+    g.rstart = sb->d_caps.as<uint32_t>();
+    g.rcap = g.rstart + nseg;
+    g.fstart = g.rcap + nseg;
+    g.fcap = g.fstart + nfine;
+    sb->d_fstart = g.fstart;
+    sb->d_fcap = g.fcap;
+  }
   g.spec_cursor1 = spec.as<uint32_t>();
   g.spec_flag = spec.as<uint32_t>() + nseg;
   RMM_TRY(sb->w[0].alloc(l6 ? 6 * (size1 + 2048) + 16 : sizeof(uint64_t) * size1));      // (L6: + two dump slots per thread behind the regions)
@@ -3271,8 +3360,8 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
     uint32_t *seg_begin = d_map.as<uint32_t>(), *seg_end = seg_begin + nseg, *tile_prefix = seg_end + nseg;
     uint32_t *ntiles_dev = cursor.as<uint32_t>() + nfine + 1;
     hipLaunchKernelGGL(jk_make_l2map, dim3(1), dim3(JK_BK_THREADS), 0, stream0(), (const uint32_t *)spec.as<uint32_t>(), nseg, cap1,
-                       (uint32_t)JK_TILE2, seg_begin, seg_end, tile_prefix, ntiles_dev, 0u, 0u);
-    hipLaunchKernelGGL(jk_init_cursor, dim3(32), dim3(256), 0, stream0(), cursor.as<uint32_t>(), nfine, cap2);
+                       (uint32_t)JK_TILE2, seg_begin, seg_end, tile_prefix, ntiles_dev, 0u, 0u, g.rstart, g.rcap);
+    hipLaunchKernelGGL(jk_init_cursor, dim3(32), dim3(256), 0, stream0(), cursor.as<uint32_t>(), nfine, cap2, g.fstart);
     HIP_CHECK_LAST();
     const bool p6 = want_p6 && narrow && !pay && sc2_threads == 256;
     RMM_TRY(sb->w[1].alloc(p6 ? 6 * size2 + 16 : sizeof(uint64_t) * size2));
@@ -3280,7 +3369,7 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
     if (pay) RMM_TRY(sb->pay[1].alloc(sizeof(uint64_t) * size2));
     PartGeom g2 = g;
     g2.cap2 = cap2;
-    g2.dump = nfine * cap2;
+    g2.dump = caps ? (uint32_t)(size2 - JK_TILE) : nfine * cap2;
     g2.spec_flag = cursor.as<uint32_t>() + nfine;
     Level2Map m{seg_begin, seg_end, tile_prefix, g.xs};
     m.ntiles_dev = ntiles_dev;
@@ -3807,6 +3896,35 @@ static gdf_error probe_prepared(const KeyTable &probe_t, const KeyTable &build_t
   if (!skew && g.fb > 0 && probe_t.nrows >= spec_min && largest_build <= (uint32_t)JK_MAX_BUILD && !lab::path_on("GDF_JK_NO_SPEC"))
     GDF_TRY(partition_side_spec(probe_t, plan, g, std::max(1.0, (double)probe_t.nrows / std::max<uint32_t>(B.joinable, 1)), &P, &spec_ok,
                                 nullptr, defer, pay, pmode, want_p6));
+  // SKEWED probe keys keep the histogram-free layout too (round 4): a second, larger sample of the probe column
+  // (2^22 rows, binned by fine partition) sizes every level-1 region and every fine partition individually (SkewCaps) -- the exact
+  // layout's histogram pass over the probe relation (1.5 of a Zipf join's 13.7 ms) is not needed, and the side stays on the
+  // deferred path with its six-byte tuples.  A partition that outgrows its room anyway raises the usual flag: exact layout then.
+  if (skew && defer && !pay && probe_fast && g.fb > 0 && probe_t.nrows >= spec_min && largest_build <= (uint32_t)JK_MAX_BUILD &&
+      !lab::path_on("GDF_JK_NO_SPEC") && !lab::path_on("GDF_JK_NO_SKEW_CAPS")) {
+    const uint32_t nfine_p = 1u << g.fb;
+    DevBuf d_counts;
+    RMM_TRY(d_counts.alloc(sizeof(uint32_t) * ((size_t)nfine_p + 1)));
+    HIP_TRY(hipMemsetAsync(d_counts.p, 0, sizeof(uint32_t) * ((size_t)nfine_p + 1), stream0()));
+    const size_t lds = sizeof(uint32_t) * nfine_p;
+    if (probe_fast == 8) {
+      HIP_TRY(hipFuncSetAttribute((const void *)jk_sample_caps<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      GDF_LAUNCH("jk_sample_caps", jk_sample_caps<8>, dim3(64), dim3(1024), lds, stream0(), probe_t.col[0].data, probe_t.nrows, g.fb, d_counts.as<uint32_t>());
+    } else {
+      HIP_TRY(hipFuncSetAttribute((const void *)jk_sample_caps<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      GDF_LAUNCH("jk_sample_caps", jk_sample_caps<4>, dim3(64), dim3(1024), lds, stream0(), probe_t.col[0].data, probe_t.nrows, g.fb, d_counts.as<uint32_t>());
+    }
+    HIP_CHECK_LAST();
+    SkewCaps caps;
+    caps.fine.resize((size_t)nfine_p + 1);
+    HIP_TRY(read_back(caps.fine.data(), d_counts.p, sizeof(uint32_t) * caps.fine.size()));
+    const uint32_t sampled = caps.fine[nfine_p];
+    caps.fine.resize(nfine_p);
+    if (sampled) {
+      caps.rows_per_sample = (double)probe_t.nrows / (double)sampled;
+      GDF_TRY(partition_side_spec(probe_t, plan, g, 1.0, &P, &spec_ok, nullptr, defer, pay, pmode, want_p6, &caps));
+    }
+  }
   if (!spec_ok) {
     P.w[0].reset(); P.w[1].reset(); P.idx[0].reset(); P.idx[1].reset(); P.pay[0].reset(); P.pay[1].reset();
     KeyPlan probe_plan = plan;             // partition_side only rewrites the plan when asked to decide the format
@@ -3860,7 +3978,7 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
     hipLaunchKernelGGL(jk_make_units, dim3((nfine + 255) / 256), dim3(256), 0, stream0(), nfine, P.cap2, (const uint32_t *)P.d_cursor.as<uint32_t>(),
                        (const uint32_t *)(P.d_level1.as<uint32_t>() + P.nseg), (const uint32_t *)B.d_begin.as<uint32_t>(),
                        (const uint32_t *)B.d_cnt.as<uint32_t>(), keep_probe ? 1 : 0, d_units.as<Unit>(), d_off.as<uint64_t>(),
-                       d_bk.as<unsigned long long>());
+                       d_bk.as<unsigned long long>(), P.d_fstart, P.d_fcap);
     HIP_CHECK_LAST();
   } else {
     units.reserve((size_t)nfine + (size_t)(probe_t.nrows / JK_PROBE_CHUNK) + 1);     // the GPU idles while this list is made

@@ -992,6 +992,64 @@ def test_skewed_probe_side_overflows_the_deferred_layout(gdf, how):
     assert int(torch.unique(l[hit] * nb + r[hit]).numel()) == expected
 
 
+@pytest.mark.parametrize("how", ["inner", "left"])
+@pytest.mark.parametrize("skew", ["zipf", "tenth-on-one-key", "half-on-eight-keys"])
+def test_skewed_probe_side_keeps_the_histogram_free_layout(gdf, how, skew, force_path):
+    """Skewed probe keys no longer force the exact layout's histogram pass over the probe relation: a 2^22-row
+    sample of the probe column sizes every level-1 region and every fine partition individually (csrc/join.hip SkewCaps) and the
+    side stays on the deferred, histogram-free path.  2^24 + probe rows (the skew sample's threshold), Zipf(1) over the build keys /
+    a tenth of the rows on one key / half of them on eight keys; properties of the result against torch reductions (pair count,
+    equal keys, no pair twice, LEFT: one (l, -1) per missing row); jk_hist runs ONCE (the build side) and jk_sample_caps ran --
+    with GDF_JK_NO_SKEW_CAPS the probe side takes its histogram pass again and the answer is the same.
+    Reference semantics: join_kernels.cuh:259-455."""
+    import math
+    import torch
+    from bench import read_profile
+    from libgdf_amd.columns import Column
+    g = torch.Generator(device="cuda").manual_seed(len(skew))
+    nb, npr = 1_700_000, (1 << 24) + 54_321
+    build = torch.randperm(nb + nb // 8, generator=g, device="cuda")[:nb]                 # unique keys, an eighth of the key space missing
+    if skew == "zipf":
+        u = torch.rand(npr, generator=g, device="cuda", dtype=torch.float64)
+        rank = torch.clamp(torch.exp(u * math.log(nb + 1.0)).long() - 1, 0, nb - 1)        # p(rank) ~ 1 / rank
+        probe = build[rank]
+        probe[torch.rand(npr, generator=g, device="cuda") < 0.05] = nb + nb // 8 + 5       # a twentieth of the rows miss
+    else:
+        probe = torch.randint(0, nb + nb // 8, (npr,), generator=g, device="cuda")
+        if skew == "tenth-on-one-key":
+            probe[torch.rand(npr, generator=g, device="cuda") < 0.1] = int(build[3])
+        else:
+            hot = build[:8]
+            sel = torch.rand(npr, generator=g, device="cuda") < 0.5
+            probe[sel] = hot[torch.randint(0, 8, (int(sel.sum()),), generator=g, device="cuda")]
+    present = torch.zeros(nb + nb // 8 + 6, dtype=torch.bool, device="cuda")
+    present[build] = True
+    expected = int(present[probe].sum())
+    lonely = npr - expected if how == "left" else 0
+    lib = gdf._binding._gdf_cdll
+
+    def run():
+        lib.gdf_amd_profile_reset(); lib.gdf_amd_profile_enable(1)
+        try:
+            li, ri = gdf.api.join([Column(probe)], [Column(build)], how=how)
+        finally:
+            lib.gdf_amd_profile_enable(0)
+        prof = read_profile(gdf)
+        assert li.numel() == expected + lonely
+        l, r = li.long(), ri.long()
+        hit = r >= 0
+        assert int((~hit).sum()) == lonely
+        assert bool((probe[l[hit]] == build[r[hit]]).all())
+        assert int(torch.unique(l).numel()) == li.numel()                                  # unique build keys: a probe row appears once
+        return prof
+
+    prof = run()
+    assert "jk_sample_caps" in prof and prof["jk_hist"][1] == 1, {k: v[1] for k, v in prof.items()}
+    force_path("GDF_JK_NO_SKEW_CAPS")
+    prof = run()
+    assert "jk_sample_caps" not in prof and prof["jk_hist"][1] == 2, {k: v[1] for k, v in prof.items()}
+
+
 @pytest.mark.parametrize("dtype", [np.int32, np.int64])
 def test_one_build_key_repeated_millions_of_times(gdf, dtype):
     """The global-table path chains the copies of a key behind one slot: 3e6 copies of one build key (an oversize partition:

@@ -2729,7 +2729,7 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
   if (guessed && !fused) { *done = false; return GDF_SUCCESS; }      // only the fused kernels check keys against a guessed plan
   DevBuf ka, kb, pa, pb, fl;
   if (fused) {
-    RMM_TRY(ka.alloc(sizeof(GbRec) * (size_t)nn));            // 12-byte records: key and image together
+    // (12-byte records, key and image together: allocated below, once the layout -- exact or speculative -- is known)
   } else {
     RMM_TRY(ka.alloc(sizeof(K) * (size_t)nn));
     RMM_TRY(pa.alloc(sizeof(uint64_t) * (size_t)nn));
@@ -2760,11 +2760,10 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
       chunk = (chunk + GBP_TILE - 1) / GBP_TILE * GBP_TILE;
       const int nchunks = (int)((n + chunk - 1) / chunk);
       DevBuf hist, d_start, d_flags;
-      RMM_TRY(hist.alloc(sizeof(uint32_t) * ((size_t)P * nchunks + 1)));
       RMM_TRY(d_start.alloc(sizeof(uint32_t) * ((size_t)P + 1)));
       RMM_TRY(d_flags.alloc(sizeof(unsigned int) * 4));          // rows dropped for a null key | range violated | speculative layout overflowed
       HIP_TRY(hipMemsetAsync(d_flags.p, 0, sizeof(unsigned int) * 4, stream0()));
-      HIP_TRY(hipMemsetAsync(hist.as<uint32_t>() + (size_t)P * nchunks, 0, sizeof(uint32_t), stream0()));
+
       // static key signature (gbp_pack32): one or two 4- / 8-byte integer key columns
       const bool no_static = lab::path_on("GDF_GBP_DYNAMIC");          // (read per call: the tests flip it)
       auto int_kind = [](int k) { return k == K_I32 || k == K_I64; };
@@ -2867,6 +2866,12 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
         }
       }
       const bool is_spec = spec.qprefix != nullptr;
+      if (!is_spec) {
+        RMM_TRY(ka.alloc(sizeof(GbRec) * (size_t)nn));
+        kin = ka.as<K>();
+        RMM_TRY(hist.alloc(sizeof(uint32_t) * ((size_t)P * nchunks + 1)));
+        HIP_TRY(hipMemsetAsync(hist.as<uint32_t>() + (size_t)P * nchunks, 0, sizeof(uint32_t), stream0()));
+      }
       // (exact layout: a key column the count pass skips must lie below the window bits, so that it can tell hot rows from the first column alone)
       if (!is_spec && skip_low && sp.shift[1] + sp.bits[1] > GBP_HOT_BITS) hot_window = GBP_NO_HOT;
       // the cells the partial aggregates are merged into: made BEFORE the scatter kernel, which merges the hot window's

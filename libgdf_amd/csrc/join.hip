@@ -514,11 +514,16 @@ __global__ __launch_bounds__(1024) void jk_sample_caps(const void *col, int64_t 
   const uint32_t nfine = 1u << fb;
   for (uint32_t f = threadIdx.x; f < nfine; f += 1024) caps_lds[f] = 0;
   block_sync();
-  const uint32_t per_wg = JK_CAPS_SAMPLES / gridDim.x;
-  for (uint32_t j = threadIdx.x; j < per_wg; j += 1024) {
-    const uint32_t sidx = blockIdx.x * per_wg + j;
-    const int64_t i = (int64_t)(((unsigned __int128)sidx * (unsigned __int128)nrows) >> 22);
-    atomicAdd(&caps_lds[fine_of(fast_word<FAST>(col, i), fb)], 1u);
+  const uint32_t per_wg = JK_CAPS_SAMPLES / gridDim.x;          // a multiple of 8 * 1024 (the launch uses 256 workgroups)
+  for (uint32_t j0 = threadIdx.x; j0 < per_wg; j0 += 8 * 1024) {
+    uint64_t w[8];                                               // eight independent loads in flight per thread, then the atomics
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t sidx = blockIdx.x * per_wg + j0 + k * 1024;
+      w[k] = fast_word<FAST>(col, (int64_t)(((unsigned __int128)sidx * (unsigned __int128)nrows) >> 22));
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) atomicAdd(&caps_lds[fine_of(w[k], fb)], 1u);
   }
   block_sync();
   for (uint32_t f = threadIdx.x; f < nfine; f += 1024)
@@ -3909,10 +3914,10 @@ static gdf_error probe_prepared(const KeyTable &probe_t, const KeyTable &build_t
     const size_t lds = sizeof(uint32_t) * nfine_p;
     if (probe_fast == 8) {
       HIP_TRY(hipFuncSetAttribute((const void *)jk_sample_caps<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      GDF_LAUNCH("jk_sample_caps", jk_sample_caps<8>, dim3(64), dim3(1024), lds, stream0(), probe_t.col[0].data, probe_t.nrows, g.fb, d_counts.as<uint32_t>());
+      GDF_LAUNCH("jk_sample_caps", jk_sample_caps<8>, dim3(256), dim3(1024), lds, stream0(), probe_t.col[0].data, probe_t.nrows, g.fb, d_counts.as<uint32_t>());
     } else {
       HIP_TRY(hipFuncSetAttribute((const void *)jk_sample_caps<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      GDF_LAUNCH("jk_sample_caps", jk_sample_caps<4>, dim3(64), dim3(1024), lds, stream0(), probe_t.col[0].data, probe_t.nrows, g.fb, d_counts.as<uint32_t>());
+      GDF_LAUNCH("jk_sample_caps", jk_sample_caps<4>, dim3(256), dim3(1024), lds, stream0(), probe_t.col[0].data, probe_t.nrows, g.fb, d_counts.as<uint32_t>());
     }
     HIP_CHECK_LAST();
     SkewCaps caps;

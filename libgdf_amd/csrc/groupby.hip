@@ -1451,6 +1451,13 @@ struct GbSpec {
   const uint32_t *cap;             // [P]
   uint32_t *fill;                  // [P * G]
   uint32_t G;                      // workgroups of the scatter kernel (= segments per partition)
+  // xcd != 0: ONE segment per partition and XCD (G = 8) instead of one per workgroup.  The workgroups of an XCD append to it
+  // together: a (tile, partition) run claims its place with ONE returning atomic on fill[q * 8 + xcc] -- at WORKGROUP scope, i.e.
+  // executed in the XCD's own L2, which all its CUs share (agent scope would send it to the memory side: +3 ms in round 3) -- where
+  // xcc is read from HW_REG_XCC_ID, so that the counter a workgroup uses is by construction one only its own XCD touches, whatever
+  // the dispatcher does.  Why: a tail partition gets ~1 record per tile and workgroup; with 32 workgroups behind one write front its
+  // 128-byte line fills in microseconds, inside the L2, instead of leaving as ten partial lines.
+  int xcd;
 };
 
 // one (32-bit packed key, 64-bit accumulator image) pair as the fused partition pass writes it: 12 bytes, ONE store per row
@@ -2122,13 +2129,16 @@ __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter_static(KeyTable t,
   // counts what the segment holds so far (never reset: one segment per partition for the whole kernel)
   uint32_t seg_base[PER], seg_cap[PER];
   __shared__ uint32_t spec_abort;
+  uint32_t xcc = 0;
   if constexpr (SPEC) {
+    // HW_REG_XCC_ID (hardware register 20), bits 3..0: the XCD this workgroup runs on
+    if (spec.xcd) xcc = (uint32_t)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 7u;
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
       const uint32_t b = threadIdx.x * PER + q;
       const bool in = b < nparts;
       seg_cap[q] = in ? spec.cap[b] : 0u;
-      seg_base[q] = in ? spec.qprefix[b] * spec.G + blockIdx.x * seg_cap[q] : 0u;
+      seg_base[q] = in ? spec.qprefix[b] * spec.G + (spec.xcd ? xcc : blockIdx.x) * seg_cap[q] : 0u;
       cursor[b] = 0;
     }
     if (threadIdx.x == 0) spec_abort = 0;
@@ -2233,6 +2243,17 @@ __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter_static(KeyTable t,
         uint32_t v[PER], sum = 0;
 #pragma unroll
         for (int q = 0; q < PER; ++q) { v[q] = hist[threadIdx.x * PER + q]; sum += v[q]; hist[threadIdx.x * PER + q] = 0; }
+        // XCD-shared segments: the runs' places are claimed NOW (returning atomics in the XCD's L2) and looked at behind the barrier
+        uint32_t claimed[PER];
+        if constexpr (SPEC) {
+          if (spec.xcd) {
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+              const uint32_t b = threadIdx.x * PER + q;
+              claimed[q] = (v[q] && b < nparts) ? __hip_atomic_fetch_add(&spec.fill[(size_t)b * 8u + xcc], v[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+            }
+          }
+        }
         const uint32_t incl = wave_scan_incl(sum);
         if (lane_id() == WAVE - 1) wave_tot[threadIdx.x / WAVE] = incl;
         block_sync();
@@ -2243,7 +2264,7 @@ __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter_static(KeyTable t,
           const uint32_t b = threadIdx.x * PER + q;
           start[b] = run;
           if constexpr (SPEC) {
-            const uint32_t have = cursor[b];
+            const uint32_t have = spec.xcd ? claimed[q] : cursor[b];
             const bool fits = have + v[q] <= seg_cap[q];
             if (!fits) flags[2] = 1u;              // (the records of this run go nowhere: GBP_SPEC_SKIP)
             gbase[b] = fits ? seg_base[q] + have - run : GBP_SPEC_SKIP - run;
@@ -2324,9 +2345,12 @@ __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter_static(KeyTable t,
     }
   }
   if constexpr (SPEC) {
-    // what this workgroup's segments hold (every partition, also the untouched ones: the aggregation reads all G counts)
-    block_sync();
-    for (uint32_t q = threadIdx.x; q < nparts; q += GBP_SC_THREADS) spec.fill[(size_t)q * spec.G + blockIdx.x] = cursor[q];
+    // what this workgroup's segments hold (every partition, also the untouched ones: the aggregation reads all G counts);
+    // XCD-shared segments: the claim counters ARE the fill counts
+    if (!spec.xcd) {
+      block_sync();
+      for (uint32_t q = threadIdx.x; q < nparts; q += GBP_SC_THREADS) spec.fill[(size_t)q * spec.G + blockIdx.x] = cursor[q];
+    }
   }
   if constexpr (HOT) {
     // merge this workgroup's partials into the cells that own the keys (cell index = key), as gb_part_aggregate merges a unit
@@ -2817,20 +2841,26 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
         if (spec_wanted && S >= 65536.0) {
           // room per (partition, workgroup): the sample's estimate of the partition's cold rows + 5 sigma of that estimate, shared
           // out over G workgroups, + 6 sigma of a workgroup's own share (Poisson) -- a segment overflows about once in 1e8
-          const uint32_t G = sgrid.x;
-          // the rows the BUSIEST workgroup gets (the kernel's chunk -> workgroup map: XCD x takes the x-th eighth of the chunks, its
+          // XCD-shared segments (GbSpec::xcd): OPT-IN (path switch GDF_GBP_XCD; the tests run both).  Measured on C5: 10.67 against
+          // 10.9 - 11.4 ms in alternating processes (profiles/r4_k_c5_xcd_shared_segments.txt) -- the write fronts do merge better and the
+          // slack shrinks, but the scatter kernel stays at 8.3 ms; not worth resting the default path on atomics whose coherence across
+          // the workgroups of an XCD is a property of the hardware (they execute in the shared L2), not of the HIP memory model
+          const bool xcd_mode = (sgrid.x & 7u) == 0 && lab::path_on("GDF_GBP_XCD");
+          const uint32_t G = xcd_mode ? 8u : sgrid.x;
+          // the rows the BUSIEST workgroup (XCD) gets (the kernel's chunk -> workgroup map: XCD x takes the x-th eighth of the chunks, its
           // workgroups round-robin inside it; chunks are whole tiles, so a small table leaves some workgroups a chunk more)
           int64_t busiest = 0;
           {
-            std::vector<int64_t> rows_of(G, 0);
-            const bool xcd_map = (G & 7u) == 0;
+            const uint32_t WG = sgrid.x;
+            std::vector<int64_t> rows_of(WG, 0);
+            const bool xcd_map = (WG & 7u) == 0;
             const int per_xcd = (nchunks + 7) / 8;
             for (int c = 0; c < nchunks; ++c) {
               const int64_t r = std::min<int64_t>(chunk, n - (int64_t)c * chunk);
-              const uint32_t wg = xcd_map ? (uint32_t)(c / per_xcd) + 8u * (uint32_t)((c % per_xcd) % (int)(G >> 3)) : (uint32_t)c % G;
-              rows_of[wg] += r;
+              const uint32_t wg = xcd_map ? (uint32_t)(c / per_xcd) + 8u * (uint32_t)((c % per_xcd) % (int)(WG >> 3)) : (uint32_t)c % WG;
+              rows_of[xcd_mode ? (wg & 7u) : wg] += r;               // (XCD-shared segments: workgroup b runs on XCD b % 8)
             }
-            for (uint32_t w = 0; w < G; ++w) busiest = std::max(busiest, rows_of[w]);
+            for (uint32_t w = 0; w < (xcd_mode ? 8u : WG); ++w) busiest = std::max(busiest, rows_of[w]);
           }
           const double scale = (double)busiest / S;
           std::vector<uint32_t> plan_words(2 * (size_t)P + 1);
@@ -2858,6 +2888,8 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
             spec.qprefix = spec.cap + P;
             spec.fill = d_spec.as<uint32_t>() + plan_words.size();
             spec.G = G;
+            spec.xcd = xcd_mode ? 1 : 0;
+            if (xcd_mode) HIP_TRY(hipMemsetAsync(spec.fill, 0, sizeof(uint32_t) * (size_t)P * G, stream0()));
             RMM_TRY(ka.alloc(sizeof(GbRec) * (size_t)(total * G)));
             kin = ka.as<K>();
             hp.resize((size_t)P + 1);

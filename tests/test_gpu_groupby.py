@@ -647,6 +647,10 @@ def test_speculative_record_layout_needs_no_count_pass(gdf, shape, op, val_dtype
     names = _kernels_of(gdf, run)
     clustered = shape in ("zipf-sorted-input", "second-half-on-other-keys")
     assert "gbp_sample_hist" in names and ("gbp_count" in names) == clustered, names
+    # (default: one segment per partition and workgroup, no atomics; GDF_GBP_XCD: ONE segment per partition and XCD, claimed with L2-local atomics)
+    force_path("GDF_GBP_XCD")
+    names = _kernels_of(gdf, run)
+    assert "gbp_sample_hist" in names and ("gbp_count" in names) == clustered, names
     force_path("GDF_GBP_NO_SPEC")
     names = _kernels_of(gdf, run)
     assert "gbp_count" in names, names

@@ -20,10 +20,15 @@ def main():
     ap.add_argument("--case", type=int, default=-1, help="run only this case number of the seed (every case reseeds the generator)")
     ap.add_argument("--max-build", type=int, default=4_000_000, help="largest build side of the 'big' cases (every third case)")
     ap.add_argument("--max-probe", type=int, default=60_000_000)
+    ap.add_argument("--force", action="append", default=[], metavar="NAME[=VALUE]",
+                    help="path switches set through gdf_amd_debug_force for the whole run, e.g. --force GDF_JK_FORCE_FB=15 --force GDF_JK_FORCE_L6")
     a = ap.parse_args()
     import torch
     import libgdf_amd as gdf
     from libgdf_amd.columns import Column
+    for f in a.force:
+        name, _, value = f.partition("=")
+        gdf.libgdf.gdf_amd_debug_force(name.encode(), (value or "1").encode())
     g = torch.Generator(device="cuda")
     g.manual_seed(a.seed)
     r = lambda lo, hi: int(torch.randint(lo, hi, (1,), generator=g, device="cuda"))

@@ -17,7 +17,8 @@ gdf_error scan_u64(const uint64_t *in, uint64_t *out, size_t n, bool inclusive);
 
 // sort.hip: stable ascending lexicographic row order of t's first n rows -> perm (n x uint32).
 // sorted_keys / keys_exact are optional (see sort.hip).
-gdf_error order_rows(const KeyTable &t, uint32_t n, DevBuf &perm, DevBuf *sorted_keys, bool *keys_exact);
+gdf_error order_rows(const KeyTable &t, uint32_t n, DevBuf &perm, DevBuf *sorted_keys, bool *keys_exact, size_t *perm64 = nullptr,
+                     bool *perm64_written = nullptr);
 // sort.hip: lo_hi[2c] / lo_hi[2c+1] = min / max (as signed 64-bit) of integer key column c over its valid
 // elements of rows [0, t.nrows); lo > hi when the column has none; float columns are not touched
 gdf_error key_ranges(const KeyTable &t, long long *lo_hi, int windows = 1, int64_t window_rows = 0);      // windows > 1: a strided sample

@@ -391,6 +391,309 @@ gdf_error radix_sort_pairs_k32_u64(uint32_t *&kin, uint32_t *&kout, uint64_t *&v
   return radix_sort_pairs<uint32_t, uint64_t>(kin, kout, vin, vout, n, varying);
 }
 
+// ---------------------------------------------------------------------------
+// HYBRID sort of (uint64 image, uint32 row) pairs: the TOP t bits by stable LSD passes over the whole array (rs_count /
+// rs_scatter: 32 bytes of traffic per pair and pass), everything below inside LDS.  After the top passes the pairs of one
+// value of the top bits -- a BUCKET -- are contiguous and in input order; t is chosen so that a bucket holds ~770 pairs, so a
+// wave sorts its bucket by the remaining bits in LDS (the same stable digit ranking as rs_scatter, 8 bits per pass) and the
+// pairs cross HBM once more instead of once per digit: 62-bit keys cost 2 + 1 array passes instead of 7.  A workgroup takes
+// four consecutive buckets, one per wave; when one of them is larger than a wave's 1024 slots the four waves sort the
+// workgroup's buckets together, one after the other (up to 4096 pairs).  Bucket sizes depend on the data: a strided sample
+// predicts the largest one and the LSD path is taken when it would not fit; a bucket that outgrows 4096 pairs against the
+// prediction raises a flag and the LSD sort runs over all varying bits from where the top passes left the pairs (stable
+// passes on a stably pre-sorted sequence: same result, two passes wasted).
+// ---------------------------------------------------------------------------
+constexpr int HS_ITEMS = 16;
+constexpr int HS_WAVE_CAP = HS_ITEMS * WAVE;        // 1024 pairs per wave
+constexpr int HS_BLOCK_CAP = 4 * HS_WAVE_CAP;       // 4096 pairs per workgroup
+constexpr int HS_BIN_CAP = 48;                       // pairs of one top digit a single thread still sorts by insertion
+constexpr int HS_WINDOW = 1024;                     // sample: contiguous windows of 1024 rows
+
+__global__ __launch_bounds__(256) void hs_sample(const uint64_t *__restrict__ keys, uint32_t n, int shift, uint32_t tmask,
+                                                 uint32_t *__restrict__ hist, uint32_t nwin) {
+  const uint32_t begin = (uint32_t)((uint64_t)blockIdx.x * (uint64_t)(n - (n < HS_WINDOW ? n : HS_WINDOW)) / (nwin > 1 ? nwin - 1 : 1));
+#pragma unroll
+  for (int k = 0; k < HS_WINDOW / 256; ++k) {
+    const uint32_t i = begin + k * 256 + threadIdx.x;
+    if (i < n) atomicAdd(&hist[(uint32_t)(keys[i] >> shift) & tmask], 1u);
+  }
+}
+__global__ __launch_bounds__(256) void hs_max(const uint32_t *__restrict__ hist, uint32_t bins, uint32_t *out) {
+  uint32_t m = 0;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < bins; i += gridDim.x * 256) m = hist[i] > m ? hist[i] : m;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const uint32_t x = __shfl_xor(m, o, WAVE); m = x > m ? x : m; }
+  if (lane_id() == 0 && m) atomicMax(out, m);
+}
+// first / one-past-last position of every bucket of the top-sorted pairs (both 0 for an empty bucket: zero-initialised)
+__global__ __launch_bounds__(256) void hs_bounds(const uint64_t *__restrict__ keys, uint32_t n, int shift, uint32_t tmask,
+                                                 uint32_t *__restrict__ first, uint32_t *__restrict__ last) {
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const uint32_t t = (uint32_t)(keys[i] >> shift) & tmask;
+    const uint32_t before = i ? (uint32_t)(keys[i - 1] >> shift) & tmask : ~0u;
+    if (t != before) {
+      first[t] = i;
+      if (i) last[before] = i;
+    }
+    if (i == n - 1) last[t] = n;
+  }
+}
+
+// GW waves sort the m pairs at [begin, begin + m) by key bits [lo, hi) through their LDS area; every wave of the WORKGROUP
+// runs this (the barriers are the workgroup's): GW == 1 -- each wave with its own bucket and area; GW == 4 -- one bucket
+struct HsArgs {
+  const uint64_t *kin;
+  const uint32_t *vin;
+  uint64_t *kout;            // nullptr: nobody reads the sorted images
+  uint32_t *vout;
+  size_t *vout64;            // non-null: the row numbers leave as size_t (gdf_order_by's d_indx) and vout stays unwritten
+  int lo, hi;
+  uint64_t varying;
+  int dbg;
+};
+// GW == 1: the LDS area belongs to one wave, whose LDS operations execute in order -- waiting for them is all the
+// synchronisation there is (no s_barrier: the four waves of the workgroup run their buckets independently)
+template <int GW>
+__device__ __forceinline__ void hs_sync() {
+  if (GW == 1) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  } else {
+    block_sync();
+  }
+}
+template <int GW>
+__device__ __forceinline__ void hs_sort_bucket(uint64_t *skey, uint32_t *sval, uint32_t *cnt, uint32_t *wtot, const HsArgs &a,
+                                               uint32_t begin_v, uint32_t m_v) {
+  const uint32_t begin = __builtin_amdgcn_readfirstlane(begin_v), m = __builtin_amdgcn_readfirstlane(m_v);   // wave-uniform
+  const int lane = lane_id();
+  const int wave = GW == 1 ? 0 : (int)(threadIdx.x / WAVE);
+  const uint32_t jbase = (uint32_t)wave * HS_WAVE_CAP;
+  uint32_t *mycnt = cnt + wave * 256;
+  constexpr int NB = GW == 1 ? 4 : 1;                        // digits a thread owns: 4 * lane .. + 3 of its wave / digit threadIdx.x
+  uint64_t key[HS_ITEMS];
+  uint32_t val[HS_ITEMS];
+#pragma unroll
+  for (int r = 0; r < HS_ITEMS; ++r) {
+    const uint32_t j = jbase + r * WAVE + lane;
+    const uint32_t i = j < m ? begin + j : begin;           // clamped, unconditional (begin < n also for an empty bucket)
+    key[r] = a.kin[i];
+    val[r] = a.vin[i];
+  }
+  // One stable counting pass by the digit at `shift`, through the LDS tile and back into the registers (item order).
+  // top == true: the digit is the TOP one of the bits still to sort.  Then the pairs of one digit value -- a bin, ~3 pairs of
+  // a 770-pair bucket -- only need sorting among themselves: when no bin holds more than HS_BIN_CAP pairs the thread that owns
+  // a bin finishes it with an insertion sort in LDS (stable; whole keys compare like their low parts inside a bin) and the
+  // bucket is done after ONE ranking pass instead of one per digit.  Returns whether that happened.
+  uint32_t outpos[HS_ITEMS];                                 // where the pair in item slot r leaves to (its slot, unless a finished top pass says otherwise)
+#pragma unroll
+  for (int r = 0; r < HS_ITEMS; ++r) outpos[r] = jbase + r * WAVE + lane;
+  auto pass = [&](int shift, uint32_t mask, bool top) -> bool {
+    for (int i = lane; i < 256; i += WAVE) mycnt[i] = 0;
+    if (GW != 1 && threadIdx.x == 0) wtot[4] = 0;
+    uint32_t rank[HS_ITEMS];
+#pragma unroll
+    for (int r = 0; r < HS_ITEMS; ++r) {
+      rank[r] = 0;
+      if (jbase + r * WAVE < m) {                            // (uniform) a round without a live lane ranks nothing
+        const bool live = jbase + r * WAVE + lane < m;
+        rank[r] = wave_aggregated_inc(mycnt, (uint32_t)(key[r] >> shift) & mask, 8, live);
+      }
+    }
+    hs_sync<GW>();
+    uint32_t bstart[NB], bcount[NB];
+    if (GW == 1) {            // exclusive starts of the wave's 256 digits: four per lane
+      uint32_t sum = 0;
+#pragma unroll
+      for (int q = 0; q < NB; ++q) { bcount[q] = mycnt[NB * lane + q]; sum += bcount[q]; }
+      uint32_t at = wave_scan_incl(sum) - sum;
+#pragma unroll
+      for (int q = 0; q < NB; ++q) { bstart[q] = at; mycnt[NB * lane + q] = at; at += bcount[q]; }
+    } else {                  // thread d owns digit d: prefix over the waves, then over the digits
+      const uint32_t d = threadIdx.x;
+      uint32_t c[GW], total = 0;
+#pragma unroll
+      for (int w = 0; w < GW; ++w) { c[w] = cnt[w * 256 + d]; total += c[w]; }
+      const uint32_t incl = wave_scan_incl(total);
+      if (lane == WAVE - 1) wtot[threadIdx.x / WAVE] = incl;
+      block_sync();
+      uint32_t start = incl - total;
+      for (int w = 0; w < (int)(threadIdx.x / WAVE); ++w) start += wtot[w];
+      bstart[0] = start;
+      bcount[0] = total;
+#pragma unroll
+      for (int w = 0; w < GW; ++w) { cnt[w * 256 + d] = start; start += c[w]; }
+    }
+    bool finish = false;
+    if (top) {
+      bool big = false;
+#pragma unroll
+      for (int q = 0; q < NB; ++q) big |= bcount[q] > (uint32_t)HS_BIN_CAP;
+      if (GW == 1) finish = __ballot(big) == 0ULL;
+      else if (big) wtot[4] = 1;
+    }
+    hs_sync<GW>();
+    if (GW != 1 && top) finish = wtot[4] == 0;
+#pragma unroll
+    for (int r = 0; r < HS_ITEMS; ++r) {
+      if (jbase + r * WAVE + lane < m) {
+        const uint32_t pos = mycnt[(uint32_t)(key[r] >> shift) & mask] + rank[r];
+        skey[pos] = key[r];
+        sval[pos] = val[r];
+      }
+    }
+    hs_sync<GW>();
+#pragma unroll
+    for (int r = 0; r < HS_ITEMS; ++r) {
+      const uint32_t j = jbase + r * WAVE + lane;
+      if (j < m) { key[r] = skey[j]; val[r] = sval[j]; }
+    }
+    if (finish && !(a.dbg & 2)) {
+      // every pair ranks itself inside its bin: pairs of the bin with a smaller key, or the same key and an earlier place
+      // (independent LDS reads, no chain of dependent ones: an insertion sort by the bin's owner ran 1.3 ms per 1e8 pairs,
+      // this 0.2); the bin is [start of its digit, start of the next one) in the tile
+      const uint32_t *start0 = cnt;                          // GW == 1: the wave's row; GW == 4: row 0 = the bin's start
+#pragma unroll
+      for (int r = 0; r < HS_ITEMS; ++r) {
+        if (jbase + r * WAVE < m) {
+          const uint32_t j = jbase + r * WAVE + lane;
+          const bool live = j < m;
+          const uint32_t d = (uint32_t)(key[r] >> shift) & mask;
+          const uint32_t bs = live ? start0[d] : 0u;
+          const uint32_t be = live ? (d == mask ? m : start0[d + 1]) : 0u;
+          uint32_t before = 0;
+          for (uint32_t t = bs; __ballot(t < be) != 0ULL; ++t) {
+            if (t < be) {
+              const uint64_t other = skey[t];
+              before += (other < key[r] || (other == key[r] && t < j)) ? 1u : 0u;
+            }
+          }
+          outpos[r] = bs + before;
+        }
+      }
+    }
+    hs_sync<GW>();             // (the next pass's counters and tile are written only behind this)
+    return finish;
+  };
+  bool sorted = (a.dbg & 1) != 0;
+  if (!sorted && a.hi - a.lo > 8 && !(a.dbg & 4)) sorted = pass(a.hi - 8, 0xffu, true);
+  if (!sorted) {               // LSD over every digit below the bucket's bits (from the order the attempt left: it was stable)
+    for (int shift = a.lo; shift < a.hi; shift += 8) {
+      const int bits = a.hi - shift < 8 ? a.hi - shift : 8;
+      const uint32_t mask = (1u << bits) - 1u;
+      if (((a.varying >> shift) & mask) == 0) continue;     // every key of the ARRAY agrees on this digit (uniform)
+      if (GW == 1) {                                        // ... or every key of this bucket does (duplicates)
+        const uint32_t d0 = (uint32_t)(__builtin_amdgcn_readfirstlane((uint32_t)(key[0] >> shift))) & mask;
+        bool differs = false;
+#pragma unroll
+        for (int r = 0; r < HS_ITEMS; ++r) differs |= r * WAVE + lane < m && ((uint32_t)(key[r] >> shift) & mask) != d0;
+        if (__ballot(differs) == 0ULL) continue;
+      }
+      pass(shift, mask, false);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < HS_ITEMS; ++r) {
+    const uint32_t j = jbase + r * WAVE + lane;
+    if (j < m) {
+      if (a.kout) a.kout[begin + outpos[r]] = key[r];
+      if (a.vout64) a.vout64[begin + outpos[r]] = val[r];
+      else a.vout[begin + outpos[r]] = val[r];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void hs_local(HsArgs a, const uint32_t *__restrict__ first, const uint32_t *__restrict__ last,
+                                                uint32_t *oversize) {
+  __shared__ uint64_t skey[HS_BLOCK_CAP];
+  __shared__ uint32_t sval[HS_BLOCK_CAP];
+  __shared__ uint32_t cnt[4 * 256];
+  __shared__ uint32_t wtot[8];              // [4]: "a bin is too large" flag of the workgroup-wide pass
+  const uint32_t b0 = blockIdx.x * 4;
+  uint32_t bg[4], mm[4];
+  bool big = false;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    bg[q] = first[b0 + q];
+    mm[q] = last[b0 + q] - bg[q];
+    big |= mm[q] > (uint32_t)HS_WAVE_CAP;
+  }
+  if (!big) {
+    const int wave = threadIdx.x / WAVE;
+    const uint32_t mine = wave == 0 ? 0 : wave == 1 ? 1 : wave == 2 ? 2 : 3;
+    uint32_t begin = bg[0], m = mm[0];
+#pragma unroll
+    for (int q = 1; q < 4; ++q) if (mine == (uint32_t)q) { begin = bg[q]; m = mm[q]; }
+    if (m) hs_sort_bucket<1>(skey + wave * HS_WAVE_CAP, sval + wave * HS_WAVE_CAP, cnt + wave * 256, wtot, a, begin, m);
+    return;
+  }
+#pragma unroll 1
+  for (int q = 0; q < 4; ++q) {
+    if (mm[q] == 0) continue;
+    if (mm[q] > (uint32_t)HS_BLOCK_CAP) {            // against the sample's prediction: the caller falls back
+      if (threadIdx.x == 0) atomicExch(oversize, 1u);
+      continue;
+    }
+    hs_sort_bucket<4>(skey, sval, cnt, wtot, a, bg[q], mm[q]);
+    block_sync();
+  }
+}
+
+// *done = false: the shape is not one for this path (nothing was touched) -- the caller runs radix_sort_pairs
+static gdf_error hybrid_sort_pairs(uint64_t *&kin, uint64_t *&kout, uint32_t *&vin, uint32_t *&vout, uint32_t n, uint64_t varying,
+                                   bool want_keys, size_t *perm64, bool *perm64_written, bool *done) {
+  *done = false;
+  if (lab::path_on("GDF_SORT_NO_HYBRID") || varying == 0) return GDF_SUCCESS;
+  const uint32_t min_rows = (uint32_t)lab::path_int("GDF_HS_MIN_ROWS", 1 << 21);
+  if (n < min_rows || n < 2 * HS_WINDOW) return GDF_SUCCESS;
+  const int lo = __builtin_ctzll(varying), hi = 64 - __builtin_clzll(varying);
+  const int span = hi - lo;
+  int t = 0;
+  while (t < 18 && ((uint64_t)768 << t) < (uint64_t)n) ++t;          // ~384 .. 768 pairs per bucket
+  if (t < 4) t = 4;
+  if (((uint64_t)HS_WAVE_CAP << t) < (uint64_t)n) return GDF_SUCCESS; // beyond 2^28 rows the buckets outgrow a wave on average
+  const int lsd_passes = (span + 8) / 9, top_passes = (t + 8) / 9;
+  if (span <= t || lsd_passes < top_passes + 2) return GDF_SUCCESS;   // too few bits below the top ones to pay for the extra pass
+  const int shift = hi - t;
+  const uint32_t tmask = (1u << t) - 1u, nb = 1u << t;
+  const uint64_t top_bits = (uint64_t)tmask << shift;
+  DevBuf tab, flags;
+  RMM_TRY(tab.alloc(sizeof(uint32_t) * 2 * (size_t)nb));
+  RMM_TRY(flags.alloc(sizeof(uint32_t) * 2));
+  uint32_t *first = tab.as<uint32_t>(), *last = first + nb;
+  // the largest bucket, predicted from <= 2^21 rows in 1024-row windows spread over the input
+  const uint32_t nwin = std::min<uint32_t>(2048, n / HS_WINDOW);
+  HIP_TRY(hipMemsetAsync(first, 0, sizeof(uint32_t) * nb, stream0()));
+  HIP_TRY(hipMemsetAsync(flags.p, 0, sizeof(uint32_t) * 2, stream0()));
+  GDF_LAUNCH("hs_sample", hs_sample, dim3(nwin), dim3(256), 0, stream0(), (const uint64_t *)kin, n, shift, tmask, first, nwin);
+  GDF_LAUNCH("hs_max", hs_max, dim3(std::min<uint32_t>(256, (nb + 255) / 256)), dim3(256), 0, stream0(), (const uint32_t *)first, nb,
+             flags.as<uint32_t>());
+  uint32_t sample_max = 0;
+  HIP_TRY(hipMemcpyAsync(&sample_max, flags.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream0()));
+  HIP_TRY(hipStreamSynchronize(stream0()));
+  const double scale = (double)n / ((double)nwin * HS_WINDOW);
+  if ((double)sample_max * scale > 0.75 * HS_BLOCK_CAP) return GDF_SUCCESS;
+  // stable LSD passes over the top bits only, then the buckets' bounds
+  GDF_TRY((radix_sort_pairs<uint64_t, uint32_t>(kin, kout, vin, vout, n, varying & top_bits)));
+  HIP_TRY(hipMemsetAsync(first, 0, sizeof(uint32_t) * 2 * (size_t)nb, stream0()));
+  GDF_LAUNCH("hs_bounds", hs_bounds, dim3(stream_grid(n, 256 * 8)), dim3(256), 0, stream0(), (const uint64_t *)kin, n, shift, tmask, first, last);
+  HsArgs a{kin, vin, want_keys ? kout : nullptr, vout, perm64, lo, shift, varying, (int)lab::path_int("GDF_HS_DBG", 0)};   // (the sorted images leave only for a caller that reads them)
+  GDF_LAUNCH("hs_local", hs_local, dim3(nb / 4), dim3(256), 0, stream0(), a, (const uint32_t *)first, (const uint32_t *)last,
+             flags.as<uint32_t>() + 1);
+  uint32_t oversize = 0;
+  HIP_TRY(hipMemcpyAsync(&oversize, flags.as<uint32_t>() + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, stream0()));
+  HIP_TRY(hipStreamSynchronize(stream0()));
+  if (oversize) {            // the pairs in (kin, vin) are still the top-sorted ones: sort them by all varying bits
+    GDF_TRY((radix_sort_pairs<uint64_t, uint32_t>(kin, kout, vin, vout, n, varying)));
+  } else {
+    std::swap(kin, kout);
+    std::swap(vin, vout);
+    if (perm64 && perm64_written) *perm64_written = true;
+  }
+  *done = true;
+  return GDF_SUCCESS;
+}
+
 __global__ __launch_bounds__(256) void rs_iota(uint32_t *p, uint32_t n) {
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) p[i] = i;
 }
@@ -404,8 +707,9 @@ static int bit_length(uint64_t v) { return v ? 64 - __builtin_clzll(v) : 0; }
 // perm holds n uint32 row numbers; if sorted_keys is non-null and the whole key fitted
 // one integer-only image, *sorted_keys keeps the sorted images (adjacent-equal test
 // without gathers) and *keys_exact is set.
-gdf_error order_rows(const KeyTable &t, uint32_t n, DevBuf &perm, DevBuf *sorted_keys, bool *keys_exact) {
+gdf_error order_rows(const KeyTable &t, uint32_t n, DevBuf &perm, DevBuf *sorted_keys, bool *keys_exact, size_t *perm64, bool *perm64_written) {
   if (keys_exact) *keys_exact = false;
+  if (perm64_written) *perm64_written = false;
   // image width of every column: integers (value - min) in bit_length(max - min) bits, floats full width
   std::vector<long long> lo_hi(2 * t.ncols);
   bool any_float = false, any_int = false;
@@ -469,7 +773,11 @@ gdf_error order_rows(const KeyTable &t, uint32_t n, DevBuf &perm, DevBuf *sorted
     unsigned long long varying = 0;
     HIP_TRY(hipMemcpyAsync(&varying, vary.p, sizeof(varying), hipMemcpyDeviceToHost, stream0()));
     HIP_TRY(hipStreamSynchronize(stream0()));
-    GDF_TRY((radix_sort_pairs<uint64_t, uint32_t>(kin, kout, vin, vout, n, varying)));
+    bool hybrid = false;
+    // (the last group's sort may write the caller's size_t permutation itself: perm then holds nothing)
+    GDF_TRY(hybrid_sort_pairs(kin, kout, vin, vout, n, varying, sorted_keys && groups.size() == 1 && !any_float,
+                              gi + 1 == groups.size() ? perm64 : nullptr, perm64_written, &hybrid));
+    if (!hybrid) GDF_TRY((radix_sort_pairs<uint64_t, uint32_t>(kin, kout, vin, vout, n, varying)));
   }
   HIP_CHECK_LAST();
   HIP_TRY(hipStreamSynchronize(stream0()));
@@ -982,8 +1290,9 @@ gdf_error gdf_order_by(size_t nrows, gdf_column *cols, size_t ncols, void **d_co
   KeyTable t;
   GDF_TRY(make_key_table(ptrs.data(), (int)ncols, &t));
   DevBuf perm;
-  GDF_TRY(order_rows(t, (uint32_t)nrows, perm, nullptr, nullptr));
-  GDF_LAUNCH("rs_widen", rs_widen, dim3(stream_grid(nrows, 1024)), dim3(256), 0, stream0(), perm.as<uint32_t>(), d_indx, (uint32_t)nrows);
+  bool widened = false;
+  GDF_TRY(order_rows(t, (uint32_t)nrows, perm, nullptr, nullptr, d_indx, &widened));
+  if (!widened) GDF_LAUNCH("rs_widen", rs_widen, dim3(stream_grid(nrows, 1024)), dim3(256), 0, stream0(), perm.as<uint32_t>(), d_indx, (uint32_t)nrows);
   HIP_CHECK_LAST();
   HIP_TRY(hipStreamSynchronize(stream0()));
   return GDF_SUCCESS;

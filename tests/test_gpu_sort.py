@@ -262,3 +262,97 @@ def test_sort_method_small_key_ranges_take_the_direct_path(gdf, op, shape, force
     force_path("GDF_SORT_NO_DIRECT")
     names = names_of(lambda: _check(gdf, op, keys, vals, out))
     assert "rs_scatter" in names and "gb_direct_aggregate" not in names, names
+
+
+def _profiled(gdf, call):
+    from bench import read_profile
+    lib = gdf._binding._gdf_cdll
+    lib.gdf_amd_profile_reset(); lib.gdf_amd_profile_enable(1)
+    try:
+        out = call()
+    finally:
+        lib.gdf_amd_profile_enable(0)
+    return out, read_profile(gdf)
+
+
+@pytest.mark.parametrize("shape", ["uniform-62-bit", "duplicates", "int32-then-float64", "two-wide-columns", "three-columns", "buckets-of-2000",
+                                   "clustered-top-bits", "negative-and-positive"])
+def test_hybrid_sort_equals_the_oracle(gdf, shape, force_path):
+    """gdf_order_by over wide keys: the top bits by stable array passes, the rest inside LDS per bucket (sort.hip, hs_local) --
+    VERDICT r3 item 7.  Same contract as the all-LSD sort (sqls_ops.cu:1373-1392; stable, so the permutation is IDENTICAL to the
+    oracle's, duplicates included), checked on shapes that take the wave-per-bucket route, the workgroup-per-bucket route
+    (buckets of ~2000 pairs), a second column group (the row numbers riding along are no longer ascending) and on a shape
+    the sample turns away (half of the rows under one value of the top bits: plain LSD, no hs_local launch)."""
+    rs = np.random.RandomState(len(shape))
+    n = 300_000
+    force_path("GDF_HS_MIN_ROWS", 4096)
+    expect_hybrid = True
+    if shape == "uniform-62-bit":
+        cols = [rs.randint(0, 1 << 62, size=n, dtype=np.int64)]
+    elif shape == "duplicates":
+        pool = rs.randint(0, 1 << 44, size=50_000, dtype=np.int64)
+        cols = [pool[rs.randint(0, len(pool), size=n)]]
+    elif shape == "int32-then-float64":
+        cols = [rs.randint(-1000, 1000, size=n).astype(np.int32), np.round(rs.standard_normal(n) * 1e6) / 64]
+        expect_hybrid = None                                     # float images cluster under few exponents: the sample decides
+    elif shape == "two-wide-columns":                            # two column groups, the first column with duplicates
+        pool = rs.randint(0, 1 << 44, size=50_000, dtype=np.int64)
+        cols = [pool[rs.randint(0, len(pool), size=n)], rs.randint(0, 1 << 62, size=n, dtype=np.int64)]
+    elif shape == "three-columns":
+        cols = [rs.randint(0, 1 << 20, size=n).astype(np.int32), rs.randint(-(1 << 30), 1 << 30, size=n).astype(np.int64),
+                rs.randint(-128, 128, size=n).astype(np.int8)]
+    elif shape == "buckets-of-2000":
+        b = rs.randint(0, 150, size=n).astype(np.int64)
+        b[0] = 511                                               # nine bits of bucket number, 150 of the 512 used
+        cols = [(b << 53) | rs.randint(0, 1 << 53, size=n, dtype=np.int64)]
+    elif shape == "clustered-top-bits":
+        k = rs.randint(0, 1 << 30, size=n, dtype=np.int64)
+        k[::2] += rs.randint(0, 1 << 61, size=len(k[::2]), dtype=np.int64)
+        cols = [k]
+        expect_hybrid = False
+    else:
+        cols = [rs.randint(-(1 << 62), 1 << 62, size=n, dtype=np.int64)]
+    perm, prof = _profiled(gdf, lambda: gdf.api.order_by(_cols(cols)).cpu().numpy())
+    np.testing.assert_array_equal(perm, oracle.order_by(cols))
+    if expect_hybrid is not None:
+        assert ("hs_local" in prof) == expect_hybrid, sorted(prof)
+    if shape == "two-wide-columns":
+        assert prof["hs_local"][1] == 2, prof
+    force_path("GDF_SORT_NO_HYBRID")
+    perm2, prof2 = _profiled(gdf, lambda: gdf.api.order_by(_cols(cols)).cpu().numpy())
+    np.testing.assert_array_equal(perm2, perm)
+    assert "hs_local" not in prof2
+
+
+def test_hybrid_sort_group_by_rides_on_it(gdf, force_path):
+    """The SORT-method group-by over keys too wide for the direct route sorts through order_rows as well: same answers as the
+    oracle (group order, aggregates, last-row indices) with the hybrid sort underneath."""
+    rs = np.random.RandomState(77)
+    n = 200_000
+    force_path("GDF_HS_MIN_ROWS", 4096)
+    pool = rs.randint(-(1 << 60), 1 << 60, size=30_000, dtype=np.int64)
+    keys = [pool[rs.randint(0, len(pool), size=n)]]
+    vals = rs.randint(-1000, 1000, size=n).astype(np.int64)
+    for op in ("sum", "min", "count"):
+        _, prof = _profiled(gdf, lambda: _check(gdf, op, keys, vals, np.int64 if op == "count" else None))
+        assert "hs_local" in prof, sorted(prof)
+
+
+def test_hybrid_sort_bucket_the_sample_missed(gdf):
+    """A bucket larger than a workgroup's 4096 slots that the strided sample cannot see (its rows sit between the sampled
+    windows): hs_local raises its flag and the LSD sort finishes the job from the top-sorted pairs -- same permutation."""
+    rs = np.random.RandomState(5)
+    n = 1 << 23
+    k = rs.randint(1 << 48, 1 << 62, size=n, dtype=np.int64)
+    nwin, window = 2048, 1024
+    sampled = np.zeros(n, dtype=bool)
+    for b in range(nwin):
+        begin = b * (n - window) // (nwin - 1)
+        sampled[begin:begin + window] = True
+    free = np.flatnonzero(~sampled)
+    assert len(free) > 100_000
+    hide = free[rs.choice(len(free), size=6000, replace=False)]
+    k[hide] = rs.randint(0, 1 << 40, size=len(hide), dtype=np.int64)          # all under one value of the top 14 bits
+    perm, prof = _profiled(gdf, lambda: gdf.api.order_by(_cols([k])).cpu().numpy())
+    assert "hs_local" in prof and prof["rs_scatter"][1] == 2 + 7, prof           # two top passes, then all seven
+    np.testing.assert_array_equal(perm, oracle.order_by([k]))

@@ -58,9 +58,12 @@ def main():
         wide = Column(make_probe_keys(n, 1 << 62, 0x5EED0005, dev))
         timed(f"gdf_order_by int64, {a.groups} distinct values", lambda: gdf.api.order_by([kc]), 16.0 * n,
               {"note": "bytes = keys read + size_t permutation written"})
-        timed("gdf_order_by int64, 62-bit keys (8 digit passes)", lambda: gdf.api.order_by([wide]), 16.0 * n)
+        timed("gdf_order_by int64, 62-bit keys", lambda: gdf.api.order_by([wide]), 16.0 * n)
         timed(f"gdf_group_by_sum GDF_SORT int64 keys, {a.groups} groups, int64 values",
               lambda: gdf.api.group_by("sum", [kc], vc, capacity=1 << 20, method=GDF_SORT), 16.0 * n)
+        spread = Column((keys * 461168601842739) & ((1 << 62) - 1))
+        timed(f"gdf_group_by_sum GDF_SORT int64 keys, {a.groups} groups spread over 2^62, int64 values",
+              lambda: gdf.api.group_by("sum", [spread], vc, capacity=1 << 20, method=GDF_SORT), 16.0 * n)
     if "hash" in ops:
         kc = Column(keys)
         timed("gdf_hash int64 -> int32", lambda: gdf.api.hash_rows([kc]), 12.0 * n)

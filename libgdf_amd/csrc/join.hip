@@ -4662,18 +4662,23 @@ static gdf_error join_entry(JoinKind kind, gdf_column **left_cols, int num_left_
       for (int i = 0; i < num_cols_to_join; ++i) is_key = is_key || pkeys[i] == c;
       if (!is_key) nonkey.push_back(c);
     }
-    // mode of a relation's non-key columns: 1 = one 8-byte column, 2 = one 4-byte, 3 = two 4-byte, 0 = not carried
+    // mode of a relation's non-key columns: 1 = one 8-byte column, 2 = one 4-byte, 3 = two 4-byte, 0 = none carried.  One
+    // 64-bit word per side travels: of several candidates (unmasked, 8 or 4 bytes wide) the first 8-byte column is taken,
+    // else the first two 4-byte ones; the relation's other non-key columns (more of them, masked ones, other widths) are
+    // gathered through the index columns as before.  (A second word per side was priced and not built: carrying 8 bytes
+    // through both partition levels moves 48 bytes per row, the gather it replaces one 64-byte sector + 12 -- DESIGN 3.7.)
     auto payload_mode = [&](gdf_column **cols, const std::vector<int> &which, const gdf_column *keycol, int (&slot)[2], const void *(&src)[2]) -> int {
-      if (which.size() != 1 && which.size() != 2) return 0;
-      int w[2] = {0, 0};
+      int wide = -1, narrow[2] = {-1, -1}, nn = 0;
       for (size_t j = 0; j < which.size(); ++j) {
         const gdf_column *col = cols[which[j]];
-        w[j] = col ? dtype_width(col->dtype) : -1;
-        if (!col || !col->data || col->valid || col->size != keycol->size || (w[j] != 8 && w[j] != 4)) return 0;
+        const int w = col ? dtype_width(col->dtype) : -1;
+        if (!col || !col->data || col->valid || col->size != keycol->size) continue;
+        if (w == 8 && wide < 0) wide = which[j];
+        if (w == 4 && nn < 2) narrow[nn++] = which[j];
       }
-      if (which.size() == 2 && (w[0] != 4 || w[1] != 4)) return 0;
-      for (size_t j = 0; j < which.size(); ++j) { src[j] = cols[which[j]]->data; slot[j] = which[j]; }
-      return which.size() == 2 ? 3 : (w[0] == 8 ? 1 : 2);
+      if (wide >= 0) { src[0] = cols[wide]->data; slot[0] = wide; return 1; }
+      for (int j = 0; j < nn; ++j) { src[j] = cols[narrow[j]]->data; slot[j] = narrow[j]; }
+      return nn == 2 ? 3 : (nn == 1 ? 2 : 0);
     };
     pc.mode = payload_mode(pcols, nonkey, pcols[pkeys[0]], carried_col, pc.src);
     if (kind == JOIN_INNER) {            // the build relation's non-key columns (jk_probe_bp)

@@ -228,12 +228,14 @@ def test_result_cols_materialisation(gdf, how):
         np.testing.assert_array_equal(d[v], src[b[v]])
 
 
-def _join_with_result_cols(gdf, how, left, lkey, right, rkey):
-    """gdf_{how}_join over numpy columns with result_cols -> (left idx, right idx, [(data, valid bits)] per result column)."""
+def _join_with_result_cols(gdf, how, left, lkey, right, rkey, left_valid=None, right_valid=None):
+    """gdf_{how}_join over numpy columns with result_cols -> (left idx, right idx, [(data, valid bits)] per result column).
+    left_valid / right_valid: optional per-column bool vectors (None entries: no mask)."""
     import torch
     from libgdf_amd import gdf_column, libgdf
-    from libgdf_amd.columns import column_array, new_context
-    L, R = _cols(left), _cols(right)
+    from libgdf_amd.columns import column_array, column_from_numpy, new_context
+    L = [column_from_numpy(a, None if left_valid is None else left_valid[i]) for i, a in enumerate(left)]
+    R = [column_from_numpy(a, None if right_valid is None else right_valid[i]) for i, a in enumerate(right)]
     nres = len(left) + len(right) - 1
     res = [gdf_column() for _ in range(nres)]
     res_arr = (C.POINTER(gdf_column) * nres)(*[C.pointer(r) for r in res])
@@ -320,6 +322,52 @@ def test_carried_payload_matches_the_gather(gdf, how, payload, shape, kdt, force
     for (d, v), src in zip(res_build_pay, bpays):
         np.testing.assert_array_equal(v, build_idx >= 0)
         np.testing.assert_array_equal(d[v], src[build_idx[v]])
+
+
+@pytest.mark.parametrize("how", ["inner", "left"])
+@pytest.mark.parametrize("cols", ["i64,i64+i64,i64", "i32,i64m,f32+i16,f64,i32", "i64m,i64+f64m", "i32,i32,i32+i64,i64,i64"])
+def test_one_payload_word_is_carried_and_the_rest_gathered(gdf, how, cols, force_path):
+    """Relations with SEVERAL non-key columns: one 64-bit word per side travels with the tuples -- the first
+    unmasked 8-byte column, else the first two unmasked 4-byte ones -- and every other column (further ones, masked ones, 2-byte
+    ones) is gathered through the index columns; the result must not depend on which way a column took (reference:
+    joining.cu:375-479).  'm' marks a column with a validity mask."""
+    import zlib
+    rs = np.random.RandomState(zlib.crc32(cols.encode()) % 100000)
+    npr, nb = 300_000, 30_000
+    force_path("GDF_JK_SPEC_MIN", "1000")
+    build = rs.permutation(nb + nb // 4)[:nb].astype(np.int64)
+    probe = rs.randint(0, nb + nb // 4, size=npr).astype(np.int64)
+
+    def make(spec, n):
+        arrs, valids = [], []
+        for name in spec.split(","):
+            masked = name.endswith("m")
+            dt = {"i64": np.int64, "f64": np.float64, "i32": np.int32, "f32": np.float32, "i16": np.int16}[name.rstrip("m")]
+            arrs.append(rs.random_sample(n).astype(dt) if np.dtype(dt).kind == "f" else rs.randint(-30000, 30000, size=n).astype(dt))
+            valids.append(rs.random_sample(n) < 0.8 if masked else None)
+        return arrs, valids
+
+    pspec, bspec = cols.split("+")
+    pays, pvalid = make(pspec, npr)
+    bpays, bvalid = make(bspec, nb)
+    a, b, res = _join_with_result_cols(gdf, how, pays + [probe], len(pays), [build] + bpays, 0, pvalid + [None], [None] + bvalid)
+    el, er = oracle.join([probe], [build], how)
+    x, y = sort_pairs(a, b)
+    ex, ey = sort_pairs(el, er)
+    np.testing.assert_array_equal(x, ex)
+    np.testing.assert_array_equal(y, ey)
+    for (d, v), src, sv in zip(res[:len(pays)], pays, pvalid):
+        exp_valid = np.ones(len(a), bool) if sv is None else sv[a]
+        np.testing.assert_array_equal(v, exp_valid)
+        np.testing.assert_array_equal(d[v], src[a][v])
+    d, v = res[len(pays)]
+    assert v.all()
+    np.testing.assert_array_equal(d, probe[a])
+    for (d, v), src, sv in zip(res[len(pays) + 1:], bpays, bvalid):
+        has = b >= 0
+        exp_valid = has & (True if sv is None else sv[np.where(has, b, 0)])
+        np.testing.assert_array_equal(v, exp_valid)
+        np.testing.assert_array_equal(d[v], src[b[v]])
 
 
 @pytest.mark.parametrize("how", ["inner", "left", "full"])

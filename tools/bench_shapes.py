@@ -120,13 +120,36 @@ def main():
         for c in res + [li, ri]:
             libgdf.gdf_column_free(C.byref(c))
         return n
-    if not only or "c3_materialise_2_payload_cols" in only:
+    if not only or "c3_materialise_2_payload_cols" in only or "c3_materialise_4_payload_cols" in only:
         ppay = torch.arange(npr, dtype=torch.int64, device=dev)
         bpay = torch.arange(nb, dtype=torch.int64, device=dev)
         timed("c3_materialise_2_payload_cols", join_materialise, lambda out: 8.0 * npr + 8.0 * nb + 8.0 * out + 8.0 * npr + 8.0 * nb + 3 * 8.0 * out, npr,
               "C3 + result_cols = [int64 probe payload, key, int64 build payload]: bytes = join + both payload columns read once + three "
               "8-byte result columns written; the probe payload and the key are CARRIED through the partition passes (Tuples::pay), "
-              "the build payload is gathered (rows of the smaller relation, L2-friendly in XCD-contiguous output order)")
+              "the build payload sits next to the build tuple in the LDS image and is written per pair (jk_probe_bp)")
+        # 0c. two int64 payload columns per side: one word per side is carried, the second column of each side is gathered
+        def join_materialise4():
+            from libgdf_amd import gdf_column, libgdf, new_context
+            from libgdf_amd.columns import column_array
+            res = [gdf_column() for _ in range(5)]
+            res_arr = (C.POINTER(gdf_column) * 5)(*[C.pointer(r) for r in res])
+            li, ri = gdf_column(), gdf_column()
+            ctx = new_context()
+            libgdf.gdf_inner_join(column_array([Column(ppay), Column(ppay2), Column(probe)]), 3, (C.c_int * 1)(2),
+                                  column_array([Column(build), Column(bpay), Column(bpay2)]), 3, (C.c_int * 1)(0), 1, 5, res_arr, C.byref(li), C.byref(ri),
+                                  C.byref(ctx))
+            n = int(li.size)
+            for c in res + [li, ri]:
+                libgdf.gdf_column_free(C.byref(c))
+            return n
+        if not only or "c3_materialise_4_payload_cols" in only:
+            ppay2 = ppay * 3
+            bpay2 = bpay * 5
+            timed("c3_materialise_4_payload_cols", join_materialise4,
+                  lambda out: 8.0 * npr + 8.0 * nb + 8.0 * out + 2 * 8.0 * npr + 2 * 8.0 * nb + 5 * 8.0 * out, npr,
+                  "C3 + result_cols = [2 x int64 probe payload, key, 2 x int64 build payload]: the first payload column of each side and the "
+                  "key are carried, the second payload column of each side is gathered by row (probe side: one 64-byte sector per value)")
+            del ppay2, bpay2
         del ppay, bpay
     # 1. half of the probe rows miss: count pass + write pass
     probe_half = make_probe_keys(npr, 2 * nb, 0x5EED0012, dev)

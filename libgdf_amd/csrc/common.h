@@ -173,16 +173,46 @@ __device__ __forceinline__ T wave_reduce_add(T v) {
   return v;
 }
 
-// inclusive scan across the 64 lanes of a wave
+// inclusive scan across the 64 lanes of a wave, all lanes active.  DPP data movement (row_shr inside the rows of 16 lanes, then
+// row_bcast:15 / row_bcast:31 across them -- gfx9 modes): six VALU steps instead of six ds_bpermute round trips through the LDS
+// queue (~60 cycles each, behind whatever LDS traffic the wave has outstanding).  A lane without a source adds 0.
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ uint32_t dpp_move0(uint32_t x) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xf, BOUND);
+}
+template <int CTRL, int ROW_MASK, bool BOUND, class T>
+__device__ __forceinline__ T dpp_move0_t(T x) {
+  if constexpr (sizeof(T) == 8) {
+    const uint64_t u = (uint64_t)x;
+    const uint32_t lo = dpp_move0<CTRL, ROW_MASK, BOUND>((uint32_t)u), hi = dpp_move0<CTRL, ROW_MASK, BOUND>((uint32_t)(u >> 32));
+    return (T)(((uint64_t)hi << 32) | lo);
+  } else {
+    return (T)dpp_move0<CTRL, ROW_MASK, BOUND>((uint32_t)x);
+  }
+}
 template <class T>
 __device__ __forceinline__ T wave_scan_incl(T v) {
-  const int l = lane_id();
-#pragma unroll
-  for (int o = 1; o < WAVE; o <<= 1) {
-    T n = __shfl_up(v, o, WAVE);
-    if (l >= o) v += n;
-  }
+  static_assert(sizeof(T) == 4 || sizeof(T) == 8, "32- or 64-bit integers");
+  v += dpp_move0_t<0x111, 0xf, true>(v);      // row_shr:1
+  v += dpp_move0_t<0x112, 0xf, true>(v);      // row_shr:2
+  v += dpp_move0_t<0x114, 0xf, true>(v);      // row_shr:4
+  v += dpp_move0_t<0x118, 0xf, true>(v);      // row_shr:8  -> every row of 16 lanes holds its own inclusive scan
+  v += dpp_move0_t<0x142, 0xa, false>(v);     // row_bcast:15 into rows 1 and 3
+  v += dpp_move0_t<0x143, 0xc, false>(v);     // row_bcast:31 into rows 2 and 3
   return v;
+}
+// sum of wave_tot[0 .. my wave): NWAVES independent LDS reads and selects.  (A loop `for (w < my wave)` has a wave-dependent trip
+// count: one LDS round trip per iteration, fifteen in a row for the last wave of a 1024-thread workgroup -- between two barriers
+// of a regroup tile, so the whole workgroup waits for it.)
+template <int NWAVES, class T>
+__device__ __forceinline__ T waves_before_sum(const T *wave_tot, uint32_t tid) {
+  const int mine = (int)(tid / WAVE);
+  T v[NWAVES], sum = 0;
+#pragma unroll
+  for (int w = 0; w < NWAVES; ++w) v[w] = wave_tot[w];
+#pragma unroll
+  for (int w = 0; w < NWAVES; ++w) sum += w < mine ? v[w] : (T)0;
+  return sum;
 }
 
 __device__ __forceinline__ bool bit_is_set(const uint8_t *mask, int64_t i) {

@@ -1424,6 +1424,7 @@ __global__ __launch_bounds__(256) void gb_sorted_extract(KeyTable t, GbKeyPlan p
 constexpr int GB_PART_ID_BITS = 13;            // 8192 ids: 8 B accumulator + 4 B row count + 4 B valid count = 128 KiB of LDS
 constexpr int GB_PART_MAX_BITS = 13;           // at most 8192 partitions (1 GiB of global cells)
 constexpr uint32_t GB_PART_UNIT_ROWS = 1u << 18;
+constexpr uint32_t GB_PART_TRASH = 64;          // LDS slots behind the ids for records that are not folded (gb_part_aggregate)
 struct GbPartUnit { uint32_t begin, count, part, pad; };
 
 // pstart[p] = first sorted position whose partition id (key >> low) is >= p, for p in [0, P]
@@ -1461,7 +1462,9 @@ struct GbSpec {
 };
 
 // one (32-bit packed key, 64-bit accumulator image) pair as the fused partition pass writes it: 12 bytes, ONE store per row
-struct __attribute__((aligned(4))) GbRec { uint32_t key, lo, hi; };
+// (image first: words 0..1 of a 12-byte load or store are an even-aligned register pair, what 64-bit LDS / VALU operands need on
+// gfx950 -- with the key in front every record cost two register copies on either side)
+struct __attribute__((aligned(4))) GbRec { uint32_t lo, hi, key; };
 
 // REC: `keys` points to GbRec records (the fused partition pass), `payload` is unused
 template <bool VBIT, class K, bool REC = false>
@@ -1472,9 +1475,12 @@ __global__ __launch_bounds__(GB_DENSE_THREADS) void gb_part_aggregate(const K *_
   extern __shared__ __attribute__((aligned(16))) unsigned char gb_lds[];
   __shared__ uint32_t seg_fill[NUM_CU];                             // speculative layout: the fill counts of this partition's segments
   const uint32_t ids = 1u << id_bits;
+  // + GB_PART_TRASH slots behind the ids, one per lane: a record that is not folded (a dead slot of the speculative layout, a null
+  // value) goes there instead of around a branch -- the loop body is straight-line code, so the next batch's loads stay in flight
+  // under this batch's LDS atomics (a branch per record is a basic block per record, each with its own wait for every load)
   unsigned long long *lacc = (unsigned long long *)gb_lds;
-  unsigned int *lrows = (unsigned int *)(lacc + ids);
-  unsigned int *lvalid = lrows + ids;                               // VBIT only
+  unsigned int *lrows = (unsigned int *)(lacc + ids + GB_PART_TRASH);
+  unsigned int *lvalid = lrows + ids + GB_PART_TRASH;               // VBIT only
   const GbPartUnit u = units[blockIdx.x];
   for (uint32_t i = threadIdx.x; i < ids; i += GB_DENSE_THREADS) {
     lacc[i] = acc_identity(op);
@@ -1492,47 +1498,93 @@ __global__ __launch_bounds__(GB_DENSE_THREADS) void gb_part_aggregate(const K *_
   }
   block_sync();
   const uint32_t mask = ids - 1;
-  for (uint32_t base = 0; base < u.count; base += GB_DENSE_THREADS * GB_DENSE_BATCH) {
-    K k[GB_DENSE_BATCH];
-    uint64_t v[GB_DENSE_BATCH];
+  const uint32_t trash = ids + (threadIdx.x & (GB_PART_TRASH - 1u));
+  // Software pipeline (round 4): batch n + 1 is requested before batch n is folded into the LDS accumulators, so the HBM round trip
+  // of the one resident workgroup hides behind its LDS atomics instead of alternating with them.
+  // a batch as it is loaded: a record stays the three words of its 12-byte load until it is folded (the 64-bit image is an ALIGNED
+  // register pair for ds_add_u64, words 1..2 of a load are not: built in front of the scheduling barrier below, the copy that
+  // aligns it waits for the load that has only just been issued)
+  struct Batch {
+    uint32_t live;
+    uint32_t rk[REC ? GB_DENSE_BATCH : 1], rlo[REC ? GB_DENSE_BATCH : 1], rhi[REC ? GB_DENSE_BATCH : 1];
+    K k[REC ? 1 : GB_DENSE_BATCH];
+    uint64_t v[REC ? 1 : GB_DENSE_BATCH];
+  };
+  auto fetch = [&](auto slack, uint32_t base, Batch &bt) {      // slack: the speculative layout's dead slots are masked
+    constexpr bool SLACK = decltype(slack)::value;
     uint32_t livemask = 0;
 #pragma unroll
     for (int b = 0; b < GB_DENSE_BATCH; ++b) {
       bool live = base + b * GB_DENSE_THREADS + threadIdx.x < u.count;
-      if (REC && sp_cap) {                       // (uniform branch) a slot behind its segment's fill count holds nothing
+      if constexpr (SLACK) {                      // a slot behind its segment's fill count holds nothing
         const uint32_t o = sp_first + base + b * GB_DENSE_THREADS + threadIdx.x;
         uint32_t w = __umulhi(o, sp_magic);
         uint32_t off = o - w * sp_cap;
         if ((int32_t)off < 0) { --w; off += sp_cap; }          // the estimate is at most one too large (o < 2^31)
-        live = live && off < seg_fill[w < spec.G ? w : 0];
+        const uint32_t have = seg_fill[w < spec.G ? w : 0];     // read whether the slot is live or not: no branch
+        live = live & (off < have);
       }
       livemask |= (uint32_t)live << b;
     }
+    bt.live = livemask;
 #pragma unroll
     for (int b = 0; b < GB_DENSE_BATCH; ++b) {                       // all HBM loads first; a dead slot re-reads the unit's first one
       const uint32_t i = base + b * GB_DENSE_THREADS + threadIdx.x;  // (the slack of the speculative layout costs no HBM traffic)
       const uint32_t ic = u.begin + (((livemask >> b) & 1u) ? i : 0u);
-      if (REC) {
+      if constexpr (REC) {
         const GbRec r = reinterpret_cast<const GbRec *>(keys)[ic];
-        k[b] = (K)r.key;
-        v[b] = ((uint64_t)r.hi << 32) | r.lo;
+        bt.rk[b] = r.key;
+        bt.rlo[b] = r.lo;
+        bt.rhi[b] = r.hi;
       } else {
-        k[b] = keys[ic];
-        v[b] = payload[ic];
+        bt.k[b] = keys[ic];
+        bt.v[b] = payload[ic];
       }
     }
+  };
+  auto run = [&](auto fold_one) {
+    auto fold = [&](const Batch &bt) {
 #pragma unroll
-    for (int b = 0; b < GB_DENSE_BATCH; ++b) {
-      const bool live = (livemask >> b) & 1u;
-      if (live) {
-        const uint32_t id = (uint32_t)(k[b] >> (VBIT ? 1 : 0)) & mask;
+      for (int b = 0; b < GB_DENSE_BATCH; ++b) {
+        K key;
+        uint64_t img;
+        if constexpr (REC) { key = (K)bt.rk[b]; img = ((uint64_t)bt.rhi[b] << 32) | bt.rlo[b]; }
+        else { key = bt.k[b]; img = bt.v[b]; }
+        const bool live = (bt.live >> b) & 1u;
+        const uint32_t id = live ? (uint32_t)(key >> (VBIT ? 1 : 0)) & mask : trash;
+        const uint32_t idv = (!VBIT || (key & 1)) ? id : trash;
         atomicAdd(&lrows[id], 1u);
-        if (!VBIT || (k[b] & 1)) {
-          acc_fold(op, flt, &lacc[id], v[b]);
-          if (VBIT) atomicAdd(&lvalid[id], 1u);
-        }
+        fold_one(&lacc[idv], img);
+        if (VBIT) atomicAdd(&lvalid[idv], 1u);
       }
-    }
+    };
+    constexpr uint32_t STEP = GB_DENSE_THREADS * GB_DENSE_BATCH;
+    if (!u.count) return;
+    auto loop = [&](auto slack) {
+      Batch A, B;
+      fetch(slack, 0, A);
+      for (uint32_t base = 0; base < u.count; base += 2 * STEP) {
+        // (a batch behind the unit's end is all dead slots: every lane re-reads the unit's first record, one cached line)
+        fetch(slack, base + STEP, B);
+        __builtin_amdgcn_sched_barrier(0);           // the requests leave BEFORE the fold below (the scheduler sinks them to their uses)
+        fold(A);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(slack, base + 2 * STEP, A);
+        __builtin_amdgcn_sched_barrier(0);
+        fold(B);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    if (REC && sp_cap) loop(std::true_type{});     // (workgroup-uniform; decided once, not once per record)
+    else loop(std::false_type{});
+  };
+  switch (op) {        // the fold is chosen once per kernel, not once per record
+    case OP_MIN: run([](unsigned long long *a, uint64_t x) { atomicMin(a, (unsigned long long)x); }); break;
+    case OP_MAX: run([](unsigned long long *a, uint64_t x) { atomicMax(a, (unsigned long long)x); }); break;
+    case OP_COUNT: run([](unsigned long long *a, uint64_t x) { atomicAdd(a, (unsigned long long)x); }); break;
+    default:
+      if (flt) run([](unsigned long long *a, uint64_t x) { atomicAdd((double *)a, __longlong_as_double((long long)x)); });
+      else run([](unsigned long long *a, uint64_t x) { atomicAdd(a, (unsigned long long)x); });
   }
   block_sync();
   const size_t cell0 = (size_t)u.part << id_bits;
@@ -2003,8 +2055,7 @@ __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter(KeyTable t, GbKeyP
         const uint32_t incl = wave_scan_incl(sum);
         if (lane_id() == WAVE - 1) wave_tot[threadIdx.x / WAVE] = incl;
         block_sync();
-        uint32_t run = incl - sum;
-        for (int w = 0; w < (int)(threadIdx.x / WAVE); ++w) run += wave_tot[w];
+        uint32_t run = incl - sum + waves_before_sum<GBP_SC_THREADS / WAVE>(wave_tot, threadIdx.x);
 #pragma unroll
         for (int q = 0; q < PER; ++q) {
           const uint32_t b = threadIdx.x * PER + q;
@@ -2032,7 +2083,7 @@ __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter(KeyTable t, GbKeyP
       for (uint32_t j = threadIdx.x; j < total; j += GBP_SC_THREADS) {
         const uint32_t kk = stage_k[j];
         const uint64_t vv = stage[j];
-        rec_out[gbase[kk >> low] + j] = GbRec{kk, (uint32_t)vv, (uint32_t)(vv >> 32)};
+        rec_out[gbase[kk >> low] + j] = GbRec{(uint32_t)vv, (uint32_t)(vv >> 32), kk};
       }
       block_sync();
     }
@@ -2257,8 +2308,7 @@ __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter_static(KeyTable t,
         const uint32_t incl = wave_scan_incl(sum);
         if (lane_id() == WAVE - 1) wave_tot[threadIdx.x / WAVE] = incl;
         block_sync();
-        uint32_t run = incl - sum;
-        for (int w = 0; w < (int)(threadIdx.x / WAVE); ++w) run += wave_tot[w];
+        uint32_t run = incl - sum + waves_before_sum<GBP_SC_THREADS / WAVE>(wave_tot, threadIdx.x);
 #pragma unroll
         for (int q = 0; q < PER; ++q) {
           const uint32_t b = threadIdx.x * PER + q;
@@ -2320,7 +2370,7 @@ __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter_static(KeyTable t,
           // LAB bit 8: the same records as one contiguous stream per workgroup (what would the stores cost without the short runs?)
           if (LAB_BITS(hot.dbg) & 8) { dst = lab_stream + j; }
 #endif
-          if (j < cnt && (!SPEC || (int32_t)dst >= 0) && !(LAB_BITS(hot.dbg) & 2)) rec_out[dst] = GbRec{kk[k], (uint32_t)vv[k], (uint32_t)(vv[k] >> 32)};   // (LAB bit 2: no stores)
+          if (j < cnt && (!SPEC || (int32_t)dst >= 0) && !(LAB_BITS(hot.dbg) & 2)) rec_out[dst] = GbRec{(uint32_t)vv[k], (uint32_t)(vv[k] >> 32), kk[k]};   // (LAB bit 2: no stores)
         }
       };
       // HOT: the stage holds CAP < TILE records; a tile with more cold rows than that (the sample mispredicted the window) sends its
@@ -3046,7 +3096,7 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
       HIP_TRY(hipMemsetAsync(grows.p, 0, sizeof(unsigned int) * cells_pad, stream0()));
       if (vbit) HIP_TRY(hipMemsetAsync(gvalid.p, 0, sizeof(unsigned int) * cells_pad, stream0()));
     }
-    const size_t plds = ((size_t)1 << id_bits) * (vbit ? 16 : 12) + 16;
+    const size_t plds = (((size_t)1 << id_bits) + GB_PART_TRASH) * (vbit ? 16 : 12) + 16;
     bool launched = units.empty();          // (every row in the hot window: the scatter kernel aggregated them all)
     if constexpr (sizeof(K) == 4) {
       if (fused && !launched) {

@@ -344,8 +344,7 @@ __global__ __launch_bounds__(TH) void part_scatter_tile_kernel(KeyTable t, Paylo
         const uint32_t incl = wave_scan_incl(v);
         if (lane_id() == WAVE - 1) wave_tot[threadIdx.x / WAVE] = incl;
         block_sync();
-        uint32_t woff = 0;
-        for (int w = 0; w < (int)(threadIdx.x / WAVE); ++w) woff += wave_tot[w];     // (HP_THREADS / WAVE entries)
+        const uint32_t woff = waves_before_sum<HP_THREADS / WAVE>(wave_tot, threadIdx.x);
         if (threadIdx.x < nparts) {
           const uint32_t st = woff + incl - v;
           start[threadIdx.x] = st;

@@ -5156,8 +5156,7 @@ __global__ __launch_bounds__(FJ_THREADS) void fj_scatter(FjSend a) {
       const uint32_t incl = wave_scan_incl(cnt);
       if (lane_id() == WAVE - 1) wave_tot[tid / WAVE] = incl;
       block_sync();
-      uint32_t start = incl - cnt;
-      for (int w = 0; w < (int)(tid / WAVE); ++w) start += wave_tot[w];
+      const uint32_t start = incl - cnt + waves_before_sum<FJ_THREADS / WAVE>(wave_tot, tid);
       hist[tid] = start;
       gbase[tid] = gb - start;
     }

@@ -517,8 +517,7 @@ __device__ __forceinline__ void hs_sort_bucket(uint64_t *skey, uint32_t *sval, u
       const uint32_t incl = wave_scan_incl(total);
       if (lane == WAVE - 1) wtot[threadIdx.x / WAVE] = incl;
       block_sync();
-      uint32_t start = incl - total;
-      for (int w = 0; w < (int)(threadIdx.x / WAVE); ++w) start += wtot[w];
+      uint32_t start = incl - total + waves_before_sum<256 / WAVE>(wtot, threadIdx.x);
       bstart[0] = start;
       bcount[0] = total;
 #pragma unroll

@@ -1635,6 +1635,7 @@ __global__ __launch_bounds__(GB_DENSE_THREADS) void gb_part_aggregate(const K *_
 // ---------------------------------------------------------------------------
 constexpr int GBP_MAX_PART_BITS = 11;
 constexpr int GBP_MAX_PARTS = 1 << GBP_MAX_PART_BITS;
+constexpr int GBP_RANK_TRASH = 64;            // counters behind hist[MAX_PARTS], one per lane: where a row that is not ranked adds its 1 (gbp_rank_plain)
 constexpr int GBP_THREADS = 1024;
 constexpr int GBP_ITEMS = 8;
 constexpr int GBP_TILE = GBP_THREADS * GBP_ITEMS;
@@ -1811,6 +1812,7 @@ struct GbHot {
   unsigned long long *gacc;        // the global cells the partials are merged into (indexed by key)
   unsigned int *grows, *gvalid;
   int dbg;                         // LAB build: ablation bits (knob GDF_GBP_HOT_DBG), 0 in production
+  int plain_rank;                  // the sample found no partition with a large share of the rows that are ranked: gbp_rank_plain
 };
 
 // Strided sample of the packed keys: counts[w] += sampled rows whose key lies in window w (GBP_HOT_IDS ids each, nwin <= 4096
@@ -1956,6 +1958,21 @@ __device__ __forceinline__ void gbp_rank(uint32_t *hist, const uint32_t (&part)[
   }
 }
 
+// The same without the ballots: one returning LDS atomic per row, a row that is not ranked adds to its lane's trash counter -- no
+// branch, eight atomics in flight.  gbp_rank's two leader rounds cost ~150 SIMD cycles per row and wave to protect against a hot
+// counter (same-address LDS atomics are served one lane after the other); once the hot key window is aggregated where it is read,
+// the busiest partition of C5 holds 8 % of the ranked rows -- three lanes of a wave -- and the kernel, which issues VALU work for two
+// thirds of its time (tools/kernel_blocks.py), is better off with the plain atomic.  The host decides from the sample (GbHot::plain_rank).
+template <int N>
+__device__ __forceinline__ void gbp_rank_plain(uint32_t *hist, const uint32_t (&part)[N], uint32_t livemask, uint32_t (&rank)[N]) {
+  const uint32_t trash = (uint32_t)GBP_MAX_PARTS + (uint32_t)lane_id();
+  uint32_t at[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) at[k] = ((livemask >> k) & 1u) ? part[k] & (uint32_t)(GBP_MAX_PARTS - 1) : trash;
+#pragma unroll
+  for (int k = 0; k < N; ++k) rank[k] = atomicAdd(&hist[at[k]], 1u);
+}
+
 // The fused scatter for ANY key / value shape: the column loop with its type switches (gbp_pack), match-any ranks, six barriers
 // per tile.  Shapes with a static signature take gbp_scatter_static below.
 template <bool VBIT>
@@ -1966,7 +1983,7 @@ __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter(KeyTable t, GbKeyP
   uint64_t *stage = reinterpret_cast<uint64_t *>(gbp_lds);                   // [TILE] accumulator images, regrouped by partition
   uint32_t *stage_k = reinterpret_cast<uint32_t *>(stage + GBP_SC_TILE);        // [TILE] their keys (the partition is key >> low)
   uint32_t *hist = stage_k + GBP_SC_TILE;                                       // [MAX_PARTS + 4]
-  uint32_t *start = hist + GBP_MAX_PARTS + 4, *gbase = start + GBP_MAX_PARTS, *cursor = gbase + GBP_MAX_PARTS;
+  uint32_t *start = hist + GBP_MAX_PARTS + GBP_RANK_TRASH, *gbase = start + GBP_MAX_PARTS, *cursor = gbase + GBP_MAX_PARTS;
   uint32_t *wave_tot = cursor + GBP_MAX_PARTS;                               // [THREADS / WAVE]
   constexpr int PER = GBP_MAX_PARTS / GBP_SC_THREADS;                           // partitions per thread in the scan (2)
   constexpr int vbit = VBIT ? 1 : 0;
@@ -2128,7 +2145,7 @@ __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter_static(KeyTable t,
   unsigned long long *hacc = reinterpret_cast<unsigned long long *>(stage + CAP);      // HOT: [GBP_HOT_IDS] accumulators
   uint32_t *stage_k = reinterpret_cast<uint32_t *>(hacc + (HOT ? GBP_HOT_IDS : 0));
   uint32_t *hist = stage_k + CAP;
-  uint32_t *start = hist + GBP_MAX_PARTS + 4, *gbase = start + GBP_MAX_PARTS, *cursor = gbase + GBP_MAX_PARTS;
+  uint32_t *start = hist + GBP_MAX_PARTS + GBP_RANK_TRASH, *gbase = start + GBP_MAX_PARTS, *cursor = gbase + GBP_MAX_PARTS;
   uint32_t *wave_tot = cursor + GBP_MAX_PARTS;
   unsigned int *hrows = wave_tot + GBP_SC_THREADS / WAVE, *hvalid = hrows + GBP_HOT_IDS;   // HOT: rows / valid values per hot id
   constexpr int PER = GBP_MAX_PARTS / GBP_SC_THREADS;
@@ -2285,7 +2302,8 @@ __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter_static(KeyTable t,
         livemask &= ~hotmask;
         if (LAB_BITS(hot.dbg) & 4) livemask = 0;            // (LAB bit 4: no cold row travels)
       }
-      gbp_rank<GBP_ITEMS>(hist, part, livemask, rk);
+      if (hot.plain_rank) gbp_rank_plain<GBP_ITEMS>(hist, part, livemask, rk);      // (uniform)
+      else gbp_rank<GBP_ITEMS>(hist, part, livemask, rk);
       block_sync();
       if constexpr (SPEC) {
         if (spec_abort) return;                     // workgroup-uniform (written before the barrier above); no hot merge: the result is discarded
@@ -2421,8 +2439,8 @@ __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter_static(KeyTable t,
   }
 }
 static constexpr size_t gbp_scatter_lds(bool hot = false) {
-  return hot ? 12 * (size_t)GBP_HOT_CAP + 16 * (size_t)GBP_HOT_IDS + 4 * (size_t)(4 * GBP_MAX_PARTS + 4 + GBP_SC_THREADS / WAVE) + 16
-             : 12 * (size_t)GBP_SC_TILE + 4 * (size_t)(4 * GBP_MAX_PARTS + 4 + GBP_SC_THREADS / WAVE) + 16;
+  return hot ? 12 * (size_t)GBP_HOT_CAP + 16 * (size_t)GBP_HOT_IDS + 4 * (size_t)(4 * GBP_MAX_PARTS + GBP_RANK_TRASH + GBP_SC_THREADS / WAVE) + 16
+             : 12 * (size_t)GBP_SC_TILE + 4 * (size_t)(4 * GBP_MAX_PARTS + GBP_RANK_TRASH + GBP_SC_THREADS / WAVE) + 16;
 }
 
 // number of non-empty cells per block of 1024 cells
@@ -2868,6 +2886,7 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
       const bool spec_wanted = allow_spec && lean_sig && id_bits == GB_PART_ID_BITS && !chunk_major && !lab::path_on("GDF_GBP_NO_SPEC") &&
                                n >= lab::path_int("GDF_GBP_SPEC_MIN_ROWS", (long long)1 << 24);
       GbSpec spec{};
+      int plain_rank = 0;                 // GbHot::plain_rank, decided from the sample below
       DevBuf d_spec;                      // cap [P] | qprefix [P + 1] | fill [P * G]
       if (hot_ok || spec_wanted) {
         const uint32_t nwin = 1u << (sp.total_bits - GBP_HOT_BITS);
@@ -2888,6 +2907,22 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
         const long long forced = lab::path_int("GDF_GBP_HOT_WINDOW", -1);       // test switch: any window gives the same result
         if (hot_ok && forced >= 0) hot_window = (uint32_t)forced < nwin ? (uint32_t)forced : nwin - 1;
         else if (hot_ok && S >= 1024.0 && (double)cnt[best] >= 0.2 * S) hot_window = best;
+        // ranking without the leader ballots (gbp_rank_plain) when no partition holds more than an eighth of the rows that are
+        // ranked, i.e. a wave's worst same-address LDS atomic serves ~8 lanes (GDF_GBP_PLAIN_RANK = 0 / 1: test switch)
+        if (S >= 65536.0) {
+          double ranked = 0, busiest_part = 0;
+          for (uint32_t q = 0; q < P; ++q) {
+            double sq = 0;
+            for (uint32_t i = 0; i < wpp; ++i) {
+              const uint32_t w = q * wpp + i;
+              if (w < nwin && w != hot_window) sq += (double)cnt[w];
+            }
+            ranked += sq;
+            busiest_part = std::max(busiest_part, sq);
+          }
+          plain_rank = busiest_part <= 0.125 * ranked ? 1 : 0;
+        }
+        plain_rank = (int)lab::path_int("GDF_GBP_PLAIN_RANK", plain_rank);
         if (spec_wanted && S >= 65536.0) {
           // room per (partition, workgroup): the sample's estimate of the partition's cold rows + 5 sigma of that estimate, shared
           // out over G workgroups, + 6 sigma of a workgroup's own share (Poisson) -- a segment overflows about once in 1e8
@@ -2969,7 +3004,7 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
         cells_ready = true;
       }
       const GbHot hot{hot_window, gacc.as<unsigned long long>(), grows.as<unsigned int>(), gvalid.as<unsigned int>(),
-                      (int)lab::knob_int("GDF_GBP_HOT_DBG", 0)};
+                      (int)lab::knob_int("GDF_GBP_HOT_DBG", 0), plain_rank};
       auto count = [&](auto kernel) {
         GDF_LAUNCH("gbp_count", kernel, dim3(nchunks < NUM_CU * 2 ? nchunks : NUM_CU * 2), dim3(GBP_THREADS), 0, stream0(), t, sp, low, vbit, P,
                    chunk, nchunks, hist.as<uint32_t>(), d_flags.as<unsigned int>(), qstride, cstride, hot_window);

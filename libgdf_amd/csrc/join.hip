@@ -800,6 +800,7 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
   // prefetched keys could be used (gfx9 counts loads and stores in the one in-order vmcnt).  Rows that do not travel
   // (beyond the chunk, null, outside the narrow range) go to a trash counter / LDS slot / global dump slot instead.
   using KeyReg = typename std::conditional<NARROW, uint32_t, uint64_t>::type;    // NARROW: joinable keys are < 2^32
+  const uint32_t l6_low = (uint32_t)g.kbias, l6_fold = (uint32_t)(g.kbias >> 32) * 0x9e3779b1u;
   KeyReg key[JK_SC_ITEMS];
   uint32_t okmask = 0;          // bit k: item k travels.  One VGPR; sixteen loop-carried bools cost 32 SGPRs and spills
   auto consume = [&](uint32_t tile) {
@@ -846,7 +847,10 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
       for (int k = h; k < h + 4; ++k) {
         if constexpr (L6) {
           // the tuple carries its HASH from here on (a bijection of the key, see L6 above): the flush does not hash again
-          const uint32_t q = hash_a((uint64_t)key[k] + g.kbias);
+          // (L6 keys do not straddle a 2^32 boundary of raw values: the high word of key + kbias is kbias's own, key_fold's multiply
+          // a constant -- one add and one xor instead of an add-with-carry and a quarter-rate multiply; a row that does not travel
+          // may hash to anything)
+          const uint32_t q = lowbias32(((uint32_t)key[k] + l6_low) ^ l6_fold);
           key[k] = (KeyReg)q;
           binrank[k] = (okmask >> k) & 1u ? q >> (32 - g.b1) : 256u + (threadIdx.x & 63u);
         } else {
@@ -1277,21 +1281,43 @@ __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, 
   }
   }
   uint32_t binrank[ITEMS];
+  // K32 (a fused join's receive buffer, world >= 1 ranks): hash_a(key32 + kbias) without 64-bit arithmetic -- key_fold's high word is
+  // kbias's own or one more (the carry), two constants instead of an add-with-carry and a quarter-rate multiply -- and, for a
+  // power-of-two world (decided once per kernel), the rank remap h * world as a shift: two of the four quarter-rate multiplies
+  // per tuple are gone (half of this kernel's time is VALU issue, tools/kernel_blocks.py)
+  const uint32_t kb_low = (uint32_t)g.kbias, kb_fold0 = (uint32_t)(g.kbias >> 32) * 0x9e3779b1u, kb_fold1 = kb_fold0 + 0x9e3779b1u;
+  auto rank_tuples = [&](auto pow2_world) {
+    constexpr bool POW2W = decltype(pow2_world)::value;
+    const uint32_t wshift = POW2W ? (uint32_t)(31 - __clz((int)(g.world ? g.world : 1u))) : 0u;
 #pragma unroll
-  for (int k = 0; k < ITEMS; ++k) {
-    const uint32_t i = begin + k * THREADS + threadIdx.x;
-    if constexpr (IN6) {
-      const uint32_t q = (uint32_t)(w[k] >> 32);               // the tuple brought its hash along
-      binrank[k] = ((live6 >> k) & 1u) ? ((uint32_t)((uint64_t)q >> (32 - g.fb)) & submask) : 256u + (threadIdx.x & 63u);
-      continue;                                                // (w[k] already is hash word | row, what the P6 flush wants)
+    for (int k = 0; k < ITEMS; ++k) {
+      const uint32_t i = begin + k * THREADS + threadIdx.x;
+      if constexpr (IN6) {
+        const uint32_t q = (uint32_t)(w[k] >> 32);               // the tuple brought its hash along
+        binrank[k] = ((live6 >> k) & 1u) ? ((uint32_t)((uint64_t)q >> (32 - g.fb)) & submask) : 256u + (threadIdx.x & 63u);
+        continue;                                                // (w[k] already is hash word | row, what the P6 flush wants)
+      }
+      uint32_t q, lh;
+      if constexpr (K32) {
+        const uint32_t key32 = (uint32_t)(w[k] >> 32), low = key32 + kb_low;
+        q = lowbias32(low ^ (low < key32 ? kb_fold1 : kb_fold0));
+        lh = POW2W ? q << wshift : (uint32_t)((uint64_t)q * g.world);
+      } else {
+        q = hash_a(tup_key<NARROW>(w[k]) + g.kbias);
+        lh = local_hash(q, g.world);
+      }
+      const uint32_t bin = (uint32_t)((uint64_t)lh >> (32 - g.fb)) & submask;
+      binrank[k] = ((K32 && quads) || i < end) ? bin : 256u + (threadIdx.x & 63u);     // (quads: a full tile, every tuple is live whatever order they were fetched in)
+      // six-byte tuples leave as (hash remainder, row): the key is not needed again, the LDS tile holds the hash word and the flush
+      // does not hash a second time (two quarter-rate multiplies per tuple: the kernel's ALU work is not hidden at 4 waves per SIMD)
+      if constexpr (P6) {
+        if constexpr (K32 && POW2W) w[k] = ((uint64_t)(g.world > 1 ? __builtin_rotateleft32(q, wshift) : lh) << 32) | (uint32_t)w[k];
+        else w[k] = ((uint64_t)p6_low(q, lh, g.world) << 32) | (uint32_t)w[k];
+      }
     }
-    const uint32_t q = hash_a(tup_key<NARROW>(w[k]) + g.kbias), lh = local_hash(q, g.world);
-    const uint32_t bin = (uint32_t)((uint64_t)lh >> (32 - g.fb)) & submask;
-    binrank[k] = ((K32 && quads) || i < end) ? bin : 256u + (threadIdx.x & 63u);     // (quads: a full tile, every tuple is live whatever order they were fetched in)
-    // six-byte tuples leave as (hash remainder, row): the key is not needed again, the LDS tile holds the hash word and the flush
-    // does not hash a second time (two quarter-rate multiplies per tuple: the kernel's ALU work is not hidden at 4 waves per SIMD)
-    if constexpr (P6) w[k] = ((uint64_t)p6_low(q, lh, g.world) << 32) | (uint32_t)w[k];
-  }
+  };
+  if (K32 && (g.world & (g.world - 1u)) == 0) rank_tuples(std::true_type{});      // (workgroup-uniform)
+  else rank_tuples(std::false_type{});
 #pragma unroll
   for (int k = 0; k < ITEMS; ++k)            // sixteen atomics in flight, one wait
     binrank[k] = (binrank[k] << 16) | atomicAdd(&s.hist[binrank[k]], 1u);
@@ -5060,7 +5086,10 @@ __device__ __forceinline__ T *at32(T *base, uint32_t index) {
   return reinterpret_cast<T *>(reinterpret_cast<Byte *>(base) + (uint32_t)(index * (uint32_t)sizeof(T)));
 }
 
-template <class K>
+// POW2: the world is a power of two 2^k with k + c1 >= 1 -- rank = mulhi(h, world) is then h's top k bits and the coarse id the next
+// c1, i.e. the bin is ONE shift of the hash instead of a 32 x 32 -> 64 multiply (two quarter-rate instructions; the kernel hashes
+// every key three times and spends ~70 % of its time issuing VALU work, tools/kernel_blocks.py).
+template <class K, bool POW2>
 __global__ __launch_bounds__(FJ_THREADS) void fj_scatter(FjSend a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fj_lds[];
   uint32_t *tk = reinterpret_cast<uint32_t *>(fj_lds);                  // [TILE + 4]: narrowed keys regrouped by bin; [TILE] = trash slot
@@ -5073,8 +5102,16 @@ __global__ __launch_bounds__(FJ_THREADS) void fj_scatter(FjSend a) {
   const uint32_t end = begin + a.chunk < a.n ? begin + a.chunk : a.n;
   const uint32_t dump = (nbins << 3) * a.cap;
   const K *col = (const K *)a.keys;
+  // hash_a(key32 + lo) without 64-bit arithmetic: key_fold is `low word ^ high word * C`, and the high word of key32 + lo is lo's own
+  // or one more (the carry) -- two constants to choose from instead of an add-with-carry and a quarter-rate multiply per hash
+  const uint32_t lo_word = (uint32_t)(unsigned long long)a.lo;
+  const uint32_t fold0 = (uint32_t)((unsigned long long)a.lo >> 32) * 0x9e3779b1u, fold1 = fold0 + 0x9e3779b1u;
+  const uint32_t pow2_shift = 32u - ((uint32_t)a.c1 + (uint32_t)(31 - __clz((int)a.world)));
   auto bin_of_key = [&](uint32_t key32) -> uint32_t {
-    const uint64_t u = (uint64_t)hash_a((uint64_t)((long long)key32 + a.lo)) * a.world;
+    const uint32_t low = key32 + lo_word;
+    const uint32_t h = lowbias32(low ^ (low < key32 ? fold1 : fold0));
+    if constexpr (POW2) return h >> pow2_shift;
+    const uint64_t u = (uint64_t)h * a.world;
     return ((uint32_t)(u >> 32) << a.c1) | (uint32_t)((uint64_t)(uint32_t)u >> (32 - a.c1));
   };
   for (uint32_t b = threadIdx.x; b < FJ_MAX_BINS + 4; b += FJ_THREADS) hist[b] = 0;
@@ -5269,13 +5306,14 @@ static gdf_error fj_send(gdf_column *keys, int64_t lo, int64_t hi, int world, in
   a.overflow = out_fill + nregions;
   const unsigned grid = (unsigned)(((uint64_t)a.n + a.chunk - 1) / a.chunk);
   const size_t lds = fj_scatter_lds();
-  if (kind == K_I64) {
-    HIP_TRY(hipFuncSetAttribute((const void *)fj_scatter<long long>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    GDF_LAUNCH("fj_scatter", fj_scatter<long long>, dim3(grid), dim3(FJ_THREADS), lds, stream0(), a);
-  } else {
-    HIP_TRY(hipFuncSetAttribute((const void *)fj_scatter<int>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    GDF_LAUNCH("fj_scatter", fj_scatter<int>, dim3(grid), dim3(FJ_THREADS), lds, stream0(), a);
-  }
+  const bool pow2 = (world & (world - 1)) == 0 && (world > 1 || coarse_bits > 0) && !lab::path_on("GDF_FJ_NO_POW2");
+  auto launch = [&](auto kernel) -> gdf_error {
+    HIP_TRY(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    GDF_LAUNCH("fj_scatter", kernel, dim3(grid), dim3(FJ_THREADS), lds, stream0(), a);
+    return GDF_SUCCESS;
+  };
+  if (kind == K_I64) GDF_TRY(pow2 ? launch(fj_scatter<long long, true>) : launch(fj_scatter<long long, false>));
+  else GDF_TRY(pow2 ? launch(fj_scatter<int, true>) : launch(fj_scatter<int, false>));
   HIP_CHECK_LAST();
   uint32_t flag = 0;
   HIP_TRY(read_back(&flag, out_fill + nregions, sizeof(flag)));

@@ -151,11 +151,16 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--null-keys", type=float, default=0.0)
     ap.add_argument("--no-checks", action="store_true", help="timing only (LAB ablations that break the result on purpose)")
+    ap.add_argument("--force", action="append", default=[], metavar="NAME[=VALUE]",
+                    help="path switches set through gdf_amd_debug_force for the whole run, e.g. --force GDF_GBP_PLAIN_RANK=0")
     a = ap.parse_args()
     import torch
     import libgdf_amd as gdf
     from libgdf_amd._binding import rmmOptions_t
     gdf.librmm.rmmInitialize(C.byref(rmmOptions_t(1, 0, False)))
+    for sw in a.force:
+        name, _, value = sw.partition("=")
+        gdf.libgdf.gdf_amd_debug_force(name.encode(), (value or "1").encode())
     res = run_c5(gdf, torch.device("cuda", 0), a.rows, a.reps, a.null_keys, not a.no_checks)
     print(json.dumps(res))
     sys.exit(0 if res["checks_pass"] else 1)

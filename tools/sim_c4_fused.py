@@ -12,6 +12,8 @@ from libgdf_amd.columns import Column
 from libgdf_amd._binding import rmmOptions_t, _gdf_cdll as lib
 from bench import make_probe_keys, make_build_keys, read_profile
 gdf.librmm.rmmInitialize(C.byref(rmmOptions_t(1, 0, False)))
+for sw in sys.argv[1:]:          # path switches, e.g. GDF_FJ_NO_POW2 (gdf_amd_debug_force)
+    gdf.libgdf.gdf_amd_debug_force(sw.split("=")[0].encode(), (sw.split("=")[1] if "=" in sw else "1").encode())
 dev = torch.device("cuda", 0)
 W = 8
 npr, nb = 1_000_000_000, 125_000_000

@@ -647,6 +647,13 @@ def test_speculative_record_layout_needs_no_count_pass(gdf, shape, op, val_dtype
     names = _kernels_of(gdf, run)
     clustered = shape in ("zipf-sorted-input", "second-half-on-other-keys")
     assert "gbp_sample_hist" in names and ("gbp_count" in names) == clustered, names
+    # the ranks inside a (tile, partition) group: plain returning LDS atomics when the sample finds no busy partition among the rows
+    # that are ranked, the leader ballots otherwise (gbp_rank_plain / gbp_rank) -- the sample decides by default, both are forced here
+    # (one-key: every lane of a wave on ONE counter under the plain atomics)
+    for plain in ("1", "0"):
+        force_path("GDF_GBP_PLAIN_RANK", plain)
+        run()
+    force_path("GDF_GBP_PLAIN_RANK", None)
     # (default: one segment per partition and workgroup, no atomics; GDF_GBP_XCD: ONE segment per partition and XCD, claimed with L2-local atomics)
     force_path("GDF_GBP_XCD")
     names = _kernels_of(gdf, run)

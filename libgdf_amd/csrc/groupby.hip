@@ -2926,11 +2926,15 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
         if (spec_wanted && S >= 65536.0) {
           // room per (partition, workgroup): the sample's estimate of the partition's cold rows + 5 sigma of that estimate, shared
           // out over G workgroups, + 6 sigma of a workgroup's own share (Poisson) -- a segment overflows about once in 1e8
-          // XCD-shared segments (GbSpec::xcd): OPT-IN (path switch GDF_GBP_XCD; the tests run both).  Measured on C5: 10.67 against
-          // 10.9 - 11.4 ms in alternating processes (profiles/r4_k_c5_xcd_shared_segments.txt) -- the write fronts do merge better and the
-          // slack shrinks, but the scatter kernel stays at 8.3 ms; not worth resting the default path on atomics whose coherence across
-          // the workgroups of an XCD is a property of the hardware (they execute in the shared L2), not of the HIP memory model
-          const bool xcd_mode = (sgrid.x & 7u) == 0 && lab::path_on("GDF_GBP_XCD");
+          // XCD-shared segments (GbSpec::xcd): the DEFAULT since the ranks inside a tile are plain atomics (C5 in alternating processes of
+          // one box: 9.45 - 9.54 against 10.12 - 10.19 ms, the scatter kernel 7.33 against 7.95, profiles/r4_o_c5_xcd_shared_ab.txt; it
+          // was 10.67 against 10.9 - 11.4 when it was measured first, r4_k).  What it rests on: a run's place is claimed with a
+          // WORKGROUP-scope atomic, which gfx950 executes in the XCD's L2 -- shared by the XCD's CUs, so the workgroups of one XCD see
+          // one counter; the counter is chosen by HW_REG_XCC_ID, so no other XCD ever touches it; and the kernel boundary writes the
+          // L2s back before the aggregation reads fill counts and records.  That is a property of the part (the L1s do not execute
+          // atomics), not of the HIP memory model, which promises workgroup scope nothing across workgroups: GDF_GBP_NO_XCD keeps
+          // the per-workgroup segments (no atomics at all), and the tests run both layouts against the oracle.
+          const bool xcd_mode = (sgrid.x & 7u) == 0 && !lab::path_on("GDF_GBP_NO_XCD");
           const uint32_t G = xcd_mode ? 8u : sgrid.x;
           // the rows the BUSIEST workgroup (XCD) gets (the kernel's chunk -> workgroup map: XCD x takes the x-th eighth of the chunks, its
           // workgroups round-robin inside it; chunks are whole tiles, so a small table leaves some workgroups a chunk more)

@@ -654,8 +654,8 @@ def test_speculative_record_layout_needs_no_count_pass(gdf, shape, op, val_dtype
         force_path("GDF_GBP_PLAIN_RANK", plain)
         run()
     force_path("GDF_GBP_PLAIN_RANK", None)
-    # (default: one segment per partition and workgroup, no atomics; GDF_GBP_XCD: ONE segment per partition and XCD, claimed with L2-local atomics)
-    force_path("GDF_GBP_XCD")
+    # (default: ONE segment per partition and XCD, claimed with L2-local atomics; GDF_GBP_NO_XCD: one segment per partition and workgroup, no atomics)
+    force_path("GDF_GBP_NO_XCD")
     names = _kernels_of(gdf, run)
     assert "gbp_sample_hist" in names and ("gbp_count" in names) == clustered, names
     force_path("GDF_GBP_NO_SPEC")

@@ -29,6 +29,7 @@ rm -f $R/profiles/zz_tmp_pmc_hbm.json
 for i in 1 2 3; do python bench.py --steps 10 --warmup 3 --cpu-sample 0 --pandas-sample 0 --extra 0 2>/dev/null | grep '^{' | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(json.dumps({'ms_per_step': d['ms_per_step'], 'kernels_ms_per_step': d['kernels_ms_per_step']}))" >> $O/bench_spread.jsonl; done
 for i in 1 2 3 4 5; do python tools/bench_c5.py 2>/dev/null | tail -1 >> $O/bench_c5_five_processes.jsonl; done
 python tools/bench_c5.py --null-keys 0.01 2>/dev/null | tail -1 > $O/bench_c5_nullkeys.json
+for i in 1 2; do python tools/bench_c5.py --force GDF_GBP_NO_XCD 2>/dev/null | tail -1 >> $O/bench_c5_per_workgroup_segments.jsonl; done
 python tools/bench_shapes.py > $O/bench_shapes.jsonl 2>/dev/null
 python tools/bench_ops.py > $O/bench_ops.jsonl 2>/dev/null
 python tools/bench_ops.py --rows 1000000000 --ops partition,scan,filter > $O/bench_ops_1e9.jsonl 2>/dev/null

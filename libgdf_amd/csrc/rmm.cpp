@@ -72,6 +72,24 @@ rmmError_t map_hip(hipError_t e) {
   return e == hipErrorOutOfMemory ? RMM_ERROR_OUT_OF_MEMORY : RMM_ERROR_CUDA_ERROR;
 }
 
+// PHYSICALLY CONTIGUOUS pool blocks -- an experiment that LOST, kept behind gdf_amd_rmm_contiguous(1) for the record.  The join's regroup
+// kernels keep thousands of write fronts open across a multi-GB scratch buffer (jk_scatter1: 16384 regions over 6.3 GB), and with plain
+// hipMalloc the same kernel on the same VIRTUAL addresses runs in one of two modes -- 2.85 or 3.25 ms for C3's probe side -- decided anew
+// by every re-allocation of the buffer (profiles/r4_q_scatter1_modes_reallocation.jsonl): what changes is the physical backing the driver
+// hands out.  Asking for ONE physical range (hipDeviceMallocContiguous) does not pick the fast mode: every kernel that writes short runs
+// gets much slower (C3 9.0 - 9.9 -> 13.4 - 14.8 ms per join, jk_scatter2 2.7 -> 5.0 - 5.3, profiles/r4_q_contiguous_scratch_ab.jsonl), and
+// the allocation itself can take seconds.
+int g_contiguous = 0;
+constexpr size_t CONTIGUOUS_MIN = size_t(64) << 20;
+hipError_t pool_hip_malloc(void **p, size_t want) {
+  if (__atomic_load_n(&g_contiguous, __ATOMIC_RELAXED) && want >= CONTIGUOUS_MIN) {
+    if (hipExtMallocWithFlags(p, want, hipDeviceMallocContiguous) == hipSuccess) return hipSuccess;
+    (void)hipGetLastError();
+    *p = nullptr;
+  }
+  return hipMalloc(p, want);
+}
+
 void release_cache_locked(Manager &m) {
   for (auto &kv : m.free_blocks) (void)hipFree(kv.second);
   m.free_blocks.clear();
@@ -101,11 +119,11 @@ rmmError_t pool_alloc(Manager &m, void **ptr, size_t size) {
   // (more than any single relational call of the benchmarks keeps) the cache is returned to the runtime before growing further
   if (m.cached_bytes > (size_t(64) << 30)) release_cache_locked(m);
   void *p = nullptr;
-  hipError_t e = hipMalloc(&p, want);
+  hipError_t e = pool_hip_malloc(&p, want);
   if (e == hipErrorOutOfMemory) {       // give cached blocks back and retry once
     (void)hipGetLastError();
     release_cache_locked(m);
-    e = hipMalloc(&p, want);
+    e = pool_hip_malloc(&p, want);
   }
   if (e != hipSuccess) return map_hip(e);
   m.live_blocks[p] = want;
@@ -167,6 +185,9 @@ static inline rmmError_t rmm_guarded(F &&body) noexcept {
 }
 
 extern "C" {
+
+// A-B hook (not part of the reference's memory.h): pool blocks of 64 MiB and more as physically contiguous allocations (default OFF)
+__attribute__((visibility("default"))) void gdf_amd_rmm_contiguous(int on) { __atomic_store_n(&g_contiguous, on ? 1 : 0, __ATOMIC_RELAXED); }
 
 rmmError_t rmmInitialize(rmmOptions_t *options) {
   return rmm_guarded([&]() -> rmmError_t {

@@ -2,15 +2,15 @@
 # kernel durations come from the same runs' kernel trace
 set -x
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r4tlb
+O=$R/gpurun_out/${1:-r4tlb}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --list-avail > $O/list_avail.txt 2>&1
-grep -i -E "utcl|tlb|translat" $O/list_avail.txt | cut -c1-200 | sort -u | head -60 > $O/tlb_counters.txt
-cat $O/tlb_counters.txt
+true
+true
+true
 B="python $R/bench.py --cpu-sample 0 --pandas-sample 0 --extra 0 --steps 2 --warmup 1"
-for i in 1 2 3 4; do
-  rocprofv3 --pmc TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum --kernel-trace --output-format csv -d $O/p$i -o j -- $B > $O/p$i.log 2>&1
+for i in 1 2 3 4 5; do
+  rocprofv3 --pmc TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_STALL_UTCL2_REQ_OUT_OF_CREDITS_sum --kernel-trace --output-format csv -d $O/p$i -o j -- $B > $O/p$i.log 2>&1
   python $R/tools/pmc_summary.py $(find $O/p$i -name "*counter_collection.csv" | head -1) 2>/dev/null | grep -A4 -E "jk_scatter1|jk_scatter2|jk_probe_fast" | head -40 > $O/p$i.txt
   python - <<PY >> $O/p$i.txt
 import csv, glob

@@ -2308,12 +2308,14 @@ __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter_static(KeyTable t,
       if constexpr (SPEC) {
         if (spec_abort) return;                     // workgroup-uniform (written before the barrier above); no hot merge: the result is discarded
       }
+      uint32_t claimed[PER];            // XCD-shared segments: where this thread's partitions' runs start in their segments
+#pragma unroll
+      for (int q = 0; q < PER; ++q) claimed[q] = 0;
       {   // exclusive scan of hist[0..MAX_PARTS) by the 1024 threads, PER consecutive partitions each; clears hist for the next tile
         uint32_t v[PER], sum = 0;
 #pragma unroll
         for (int q = 0; q < PER; ++q) { v[q] = hist[threadIdx.x * PER + q]; sum += v[q]; hist[threadIdx.x * PER + q] = 0; }
-        // XCD-shared segments: the runs' places are claimed NOW (returning atomics in the XCD's L2) and looked at behind the barrier
-        uint32_t claimed[PER];
+        // XCD-shared segments: the runs' places are claimed NOW (returning atomics in the XCD's L2) and looked at behind the regroup
         if constexpr (SPEC) {
           if (spec.xcd) {
 #pragma unroll
@@ -2332,11 +2334,17 @@ __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter_static(KeyTable t,
           const uint32_t b = threadIdx.x * PER + q;
           start[b] = run;
           if constexpr (SPEC) {
-            const uint32_t have = spec.xcd ? claimed[q] : cursor[b];
-            const bool fits = have + v[q] <= seg_cap[q];
-            if (!fits) flags[2] = 1u;              // (the records of this run go nowhere: GBP_SPEC_SKIP)
-            gbase[b] = fits ? seg_base[q] + have - run : GBP_SPEC_SKIP - run;
-            cursor[b] = fits ? have + v[q] : have;
+            if (spec.xcd) {
+              // XCD-shared segments: the claim's answer -- a returning L2 atomic, ~1 - 2 us -- is only needed by the flush.  It is
+              // looked at behind the regroup (settle_claims below); the run's length waits in cursor[], which this layout does not use
+              cursor[b] = v[q];
+            } else {
+              const uint32_t have = cursor[b];
+              const bool fits = have + v[q] <= seg_cap[q];
+              if (!fits) flags[2] = 1u;              // (the records of this run go nowhere: GBP_SPEC_SKIP)
+              gbase[b] = fits ? seg_base[q] + have - run : GBP_SPEC_SKIP - run;
+              cursor[b] = fits ? have + v[q] : have;
+            }
           } else {
             gbase[b] = cursor[b] - run;
             cursor[b] += v[q];
@@ -2399,6 +2407,23 @@ __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter_static(KeyTable t,
       // stores at all 6.1, the short (tile, partition) runs 8.5 -- profiles/r4_c_c5_scatter_ablation.txt.  Requesting the next
       // tile right after this one's words are consumed -- in flight under ranking, scan, regroup and flush -- needs the raw and
       // the processed words of a tile at once: 128 VGPRs + 53 spilled, 12.0 against 8.46 ms.)
+      // XCD-shared segments: the claims' answers become the partitions' bases (the scan left start[] and, in cursor[], the runs' lengths)
+      auto settle_claims = [&]() {
+        if constexpr (SPEC) {
+          if (spec.xcd) {
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+              const uint32_t b = threadIdx.x * PER + q;
+              const uint32_t have = claimed[q], len = cursor[b], at = start[b];
+              const bool fits = have + len <= seg_cap[q];
+              if (!fits) flags[2] = 1u;              // (the records of this run go nowhere: GBP_SPEC_SKIP)
+              gbase[b] = fits ? seg_base[q] + have - at : GBP_SPEC_SKIP - at;
+            }
+          }
+        }
+      };
+      const bool rounds = HOT && total > (uint32_t)CAP;       // (workgroup-uniform, rare: the sample mispredicted the hot window)
+      if (rounds) settle_claims();
       if constexpr (HOT) {
         for (uint32_t round0 = (total - 1u) / (uint32_t)CAP * (uint32_t)CAP; total && round0 > 0; round0 -= (uint32_t)CAP) {
           regroup(round0);
@@ -2408,6 +2433,7 @@ __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter_static(KeyTable t,
         }
       }
       regroup(0);
+      if (!rounds) settle_claims();
       block_sync();
       flush(0);
     }

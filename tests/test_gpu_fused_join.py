@@ -70,6 +70,38 @@ def test_fused_join_equals_plain_join(gdf, world, dtype):
     np.testing.assert_array_equal(got[np.lexsort(got.T[::-1])], exp[np.lexsort(exp.T[::-1])])
 
 
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("base", [(1 << 32) - 30_000, (7 << 32) - 5, -20_000], ids=["across-2^32", "just-below-7*2^32", "across-zero"])
+def test_fused_join_keys_whose_raw_values_straddle_a_2_32_boundary(gdf, world, base, force_path):
+    """The sender (fj_scatter) and the receiver's level 2 hash key32 + lo without 64-bit arithmetic: key_fold's high word is lo's own or
+    one more (the carry), two fold constants to choose from.  Build keys on both sides of a multiple of 2^32 (and of zero: lo negative)
+    take both constants; against the oracle, and -- power-of-two worlds -- with the rank remap as a multiply instead of a shift
+    (GDF_FJ_NO_POW2) the sender puts every row into the same (rank, coarse partition, XCD) region."""
+    import torch
+    from libgdf_amd import api
+    from libgdf_amd.columns import Column
+    rs = np.random.RandomState(world * 31 + (base & 0xff))
+    nb, npr = 60_000, 300_000
+    build = (rs.permutation(nb * 2)[:nb] + base).astype(np.int64)
+    probe = (rs.randint(-500, nb * 2 + 500, size=npr) + base).astype(np.int64)
+    gp, gb = _fused_self_join(gdf, probe, build, world, slices=2)
+    el, er = oracle.join([probe], [build], "inner")
+    got = np.stack([gp, gb], axis=1)
+    exp = np.stack([el, er], axis=1)
+    np.testing.assert_array_equal(got[np.lexsort(got.T[::-1])], exp[np.lexsort(exp.T[::-1])])
+    if world & (world - 1) == 0:
+        lo, hi = int(build.min()), int(build.max())
+        lay = api.fj_plan(world, nb * world, npr, max(1.0, npr / nb))
+        regions = []
+        for off in (None, "1"):
+            force_path("GDF_FJ_NO_POW2", off)
+            _, rows, fill, over = api.fj_send(Column(torch.from_numpy(probe).cuda()), lo, hi, lay, 0)
+            assert not over
+            pos = rows.pos.cpu().numpy().astype(np.int64) & 0xffffffff
+            regions.append(np.where(pos == 0xffffffff, -1, pos // lay.cap))
+        np.testing.assert_array_equal(regions[0], regions[1])
+
+
 @pytest.mark.parametrize("world", [1, 2, 3, 4, 6, 8])
 @pytest.mark.parametrize("dtype", [np.int64, np.int32])
 @pytest.mark.parametrize("keys", ["unique", "twice"])

@@ -58,6 +58,11 @@ rmmError_t  rmmWriteLog(const char *filename);              /* memory.h:164 */
 size_t      rmmLogSize(void);                               /* memory.h:171 */
 rmmError_t  rmmGetLog(char *buffer, size_t buffer_size);    /* memory.h:184 */
 
+/* Extension, no counterpart in the reference: pool blocks of 64 MiB and more as physically contiguous allocations
+   (hipDeviceMallocContiguous).  Off by default -- measured slower for every kernel that scatters into such a block,
+   DESIGN.md 3.8 -- and kept for A/B runs. */
+void        gdf_amd_rmm_contiguous(int on);
+
 #if defined(__GNUC__)
 #pragma GCC visibility pop
 #endif

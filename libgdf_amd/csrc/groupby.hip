@@ -1453,11 +1453,14 @@ struct GbSpec {
   uint32_t *fill;                  // [P * G]
   uint32_t G;                      // workgroups of the scatter kernel (= segments per partition)
   // xcd != 0: ONE segment per partition and XCD (G = 8) instead of one per workgroup.  The workgroups of an XCD append to it
-  // together: a (tile, partition) run claims its place with ONE returning atomic on fill[q * 8 + xcc] -- at WORKGROUP scope, i.e.
-  // executed in the XCD's own L2, which all its CUs share (agent scope would send it to the memory side: +3 ms in round 3) -- where
-  // xcc is read from HW_REG_XCC_ID, so that the counter a workgroup uses is by construction one only its own XCD touches, whatever
-  // the dispatcher does.  Why: a tail partition gets ~1 record per tile and workgroup; with 32 workgroups behind one write front its
-  // 128-byte line fills in microseconds, inside the L2, instead of leaving as ten partial lines.
+  // together: a (tile, partition) run claims its place with ONE returning atomic on fill[q * 8 + xcc] -- issued at WORKGROUP scope
+  // (an agent-scope atomic brings cache maintenance with it: +3 ms in round 3) -- where xcc is read from HW_REG_XCC_ID, so that the
+  // counter a workgroup uses is by construction one only its own XCD touches, whatever the dispatcher does.  Why: a tail partition
+  // gets ~1 record per tile and workgroup; with 32 workgroups behind one write front its 128-byte line fills in microseconds, inside
+  // the L2, instead of leaving as ten partial lines.  (Where the atomics execute: the L2 counters of C5 show every one of the 1.28e8
+  // forwarded to the memory side as an atomic request, TCC_EA0_ATOMIC = TCC_ATOMIC, profiles/r4_u_c5_l2_atomic_counters.txt -- they
+  // are resolved where any XCD would see them; choosing the counter by XCD is what keeps an XCD's appends together, not what makes
+  // them atomic.)
   int xcd;
 };
 
@@ -2955,11 +2958,11 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
           // XCD-shared segments (GbSpec::xcd): the DEFAULT since the ranks inside a tile are plain atomics (C5 in alternating processes of
           // one box: 9.45 - 9.54 against 10.12 - 10.19 ms, the scatter kernel 7.33 against 7.95, profiles/r4_o_c5_xcd_shared_ab.txt; it
           // was 10.67 against 10.9 - 11.4 when it was measured first, r4_k).  What it rests on: a run's place is claimed with a
-          // WORKGROUP-scope atomic, which gfx950 executes in the XCD's L2 -- shared by the XCD's CUs, so the workgroups of one XCD see
-          // one counter; the counter is chosen by HW_REG_XCC_ID, so no other XCD ever touches it; and the kernel boundary writes the
-          // L2s back before the aggregation reads fill counts and records.  That is a property of the part (the L1s do not execute
-          // atomics), not of the HIP memory model, which promises workgroup scope nothing across workgroups: GDF_GBP_NO_XCD keeps
-          // the per-workgroup segments (no atomics at all), and the tests run both layouts against the oracle.
+          // WORKGROUP-scope atomic on a counter chosen by HW_REG_XCC_ID, so no other XCD ever touches it (the L2 counters show these
+          // atomics forwarded to the memory side, GbSpec::xcd above); the kernel boundary writes the L2s back before the aggregation
+          // reads fill counts and records.  That the workgroups of an XCD see one counter is a property of the part (the L1s do not
+          // execute atomics), not of the HIP memory model, which promises workgroup scope nothing across workgroups: GDF_GBP_NO_XCD
+          // keeps the per-workgroup segments (no atomics at all), and the tests run both layouts against the oracle.
           const bool xcd_mode = (sgrid.x & 7u) == 0 && !lab::path_on("GDF_GBP_NO_XCD");
           const uint32_t G = xcd_mode ? 8u : sgrid.x;
           // the rows the BUSIEST workgroup (XCD) gets (the kernel's chunk -> workgroup map: XCD x takes the x-th eighth of the chunks, its

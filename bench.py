@@ -12,9 +12,10 @@ that are already resident in HBM:
            the planner would have picked is timed after it and reported as planner_choice), then joined
            locally.  Weak scaling.  An untimed preflight step checks the global pair count and 2^20 sampled
            pairs per rank (equal keys) before anything is timed.
-value = probe rows of all ranks / max-over-ranks time.  The roofline object prices the dominant kernel
-(live HIP-event timing inside libgdf.so, see csrc/prof.h); roofline_e2e prices the whole call with the
-algorithmic bytes of SURVEY.md 8d (8*N_p + 8*N_b + 8*N_out).  cpu_baseline times oracle/gdf_oracle.c (a
+value = probe rows of all ranks / max-over-ranks time.  The roofline object prices the WHOLE call with the algorithmic
+bytes of SURVEY.md 8d (8*N_p + 8*N_b + 8*N_out; the partition passes count as overhead) and carries the probe phase
+(16 B per probe row over the probe-side launches, live HIP-event timing inside libgdf.so, see csrc/prof.h) and the PMC
+traffic of one join; roofline_kernel prices the dominant kernel on its own contract.  cpu_baseline times oracle/gdf_oracle.c (a
 single-threaded C port of the reference algorithm) on a bounded sample of the same workload.
 """
 import argparse
@@ -96,14 +97,23 @@ def make_build_keys(n, seed, device):
     return torch.randperm(n, dtype=torch.int64, device=device, generator=g)
 
 
-def read_profile(gdf):
+def read_profile(gdf, split_sides=False):
+    """{kernel name: (total ms, launches)} since the last reset.  The join tags its probe-side launches "name@probe" (csrc/prof.h);
+    split_sides=False folds them into the plain name."""
     lib = gdf._binding._gdf_cdll
     names = ((C.c_char * 64) * 64)()
     ms = (C.c_double * 64)()
     cnt = (C.c_int * 64)()
     lib.gdf_amd_profile_read.restype = C.c_int
     k = lib.gdf_amd_profile_read(names, ms, cnt, 64)
-    return {names[i].value.decode(): (ms[i], cnt[i]) for i in range(min(k, 64))}
+    out = {}
+    for i in range(min(k, 64)):
+        name = names[i].value.decode()
+        if not split_sides:
+            name = name.split("@")[0]
+        a, b = out.get(name, (0.0, 0))
+        out[name] = (a + ms[i], b + cnt[i])
+    return out
 
 
 def library_build_id():
@@ -121,10 +131,10 @@ def library_build_id():
 
 
 def pmc_traffic(kernel, launches_per_step):
-    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary (profiles/*_pmc_hbm.json).
-    bench.py cannot collect counters itself (separate --pmc passes, tools/pmc_hbm_json.py); the file states how they were
-    collected and corrected and carries the build id of the kernels it measured -- counters of OTHER kernel sources are
-    refused (traffic = null) instead of silently going stale."""
+    """HBM bytes per launch of `kernel` (kernel=None: per JOIN, all kernels) from the newest committed rocprofv3 PMC summary
+    (profiles/*_pmc_hbm.json).  bench.py cannot collect counters itself (separate --pmc passes, tools/pmc_hbm_json.py); the file
+    states how they were collected and corrected and carries the build id of the kernels it measured -- counters of OTHER kernel
+    sources are refused (traffic = null) instead of silently going stale."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json")))      # by name: r1_a < r1_k < r2_z (mtimes do not survive a checkout)
     if not files:
@@ -138,6 +148,9 @@ def pmc_traffic(kernel, launches_per_step):
         if data.get("build_id") != mine:
             seen.append(f"{rel} measured build {data.get('build_id')}")
             continue
+        if kernel is None:
+            ks = data.get("kernels", {})
+            return (sum(k["hbm_bytes_per_join_corrected"] for k in ks.values()) if ks else None), rel
         k = data.get("kernels", {}).get(kernel)
         if not k or not launches_per_step:
             return None, rel
@@ -256,6 +269,61 @@ def extra_configs(gdf, dev):
                      "kernels_ms": r["kernels_ms"], "checks_pass": bool(r["checks_pass"])}
     except Exception as e:                         # noqa: BLE001
         out["c5"] = {"error": f"{type(e).__name__}: {e}", "checks_pass": False}
+    try:
+        out["ops"] = extra_ops(gdf, dev)
+    except Exception as e:                         # noqa: BLE001
+        out["ops"] = {"error": f"{type(e).__name__}: {e}"}
+    return out
+
+
+def extra_ops(gdf, dev, n=1_000_000_000, reps=3):
+    """SURVEY 8d's micro-metrics for the other operators north_star names, at 1e9 int64 rows through the C ABI (as tools/bench_ops.py):
+    hash partition P = 256, inclusive prefix sum, compare + stencil compaction at 10 % selectivity.  {ms, frac of 8 TB/s on the
+    algorithmic bytes, checks_pass (a size-independent property of each result)}."""
+    import numpy as np
+    import torch
+    from libgdf_amd.columns import Column
+    out = {}
+    keys = make_probe_keys(n, 10000, 0x5EED0003, dev)
+    vals = make_probe_keys(n, 1000, 0x5EED0004, dev)
+    kc, vc = Column(keys), Column(vals)
+
+    def timed(fn):
+        r = fn()
+        del r
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(reps):
+            r = fn()
+            if _ < reps - 1:
+                del r
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps, r
+    dt, res = timed(lambda: gdf.api.prefixsum(vc, True))
+    scan = res
+    ok = int(scan[-1].item()) == int(vals.sum().item()) and int(scan[0].item()) == int(vals[0].item())
+    out["prefixsum_i64"] = {"ms": dt * 1e3, "frac": 16.0 * n / dt / 8e12, "algorithmic_bytes": 16.0 * n, "checks_pass": bool(ok)}
+    del res, scan
+    thr = 899
+    kept = int((vals > thr).sum().item())
+
+    def filt():
+        st = gdf.api.comparison(vc, np.int64(thr), 4)
+        return gdf.api.apply_stencil(vc, st)
+    dt, res = timed(filt)
+    got = res.data[: res.size]
+    ok = int(got.numel()) == kept and bool((got > thr).all().item()) and int(got.sum().item()) == int(vals[vals > thr].sum().item())
+    fb = 8.0 * n + 2.0 * n + 8.0 * n + 8.0 * kept
+    out["compare_stencil_10pct"] = {"ms": dt * 1e3, "frac": fb / dt / 8e12, "algorithmic_bytes": fb, "kept": kept, "checks_pass": bool(ok)}
+    del res, got
+    torch.cuda.empty_cache()
+    dt, res = timed(lambda: gdf.api.hash_partition([kc, vc], [0], 256))
+    cols, offs = res
+    pk, pv = cols[0].data, cols[1].data
+    offs_t = torch.as_tensor(np.asarray(offs, dtype=np.int64), device=dev)
+    ok = int(pk.numel()) == n and int(pk.sum().item()) == int(keys.sum().item()) and int(pv.sum().item()) == int(vals.sum().item()) and \
+        int(offs_t.numel()) == 256 and bool((offs_t[1:] >= offs_t[:-1]).all().item())
+    pb = (16.0 + 16.0 + 8.0) * n
+    out["hash_partition_p256"] = {"ms": dt * 1e3, "frac": pb / dt / 8e12, "algorithmic_bytes": pb, "checks_pass": bool(ok)}
     return out
 
 
@@ -263,7 +331,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=6,
+                    help="untimed steps.  The pool compares physical placements of the join's scratch over the first calls of a shape "
+                         "(librmm: gdf_amd_rmm_place_draws, default 4 challengers -> settled after 5 calls); the default warm-up covers that")
+    ap.add_argument("--place-draws", type=int, default=None,
+                    help="A/B switch: challengers the pool draws per placed scratch block (library default 4; 0 = never re-draw)")
     ap.add_argument("--probe-rows", type=int, default=1_000_000_000)
     ap.add_argument("--build-rows", type=int, default=None)
     ap.add_argument("--cpu-sample", type=int, default=20_000_000, help="probe rows of the oracle-port CPU baseline sample (0 = skip)")
@@ -319,6 +391,8 @@ def main():
     # pool mode: the multi-GB partition buffers are recycled between steps instead of hipMalloc'ed
     opts = rmmOptions_t(1, 0, False)
     gdf.librmm.rmmInitialize(C.byref(opts))
+    if args.place_draws is not None:
+        gdf._binding._rmm_cdll.gdf_amd_rmm_place_draws(C.c_int(args.place_draws))
 
     npr = args.probe_rows
     nb = args.build_rows if args.build_rows is not None else (npr // 8 if distributed else npr // 10)
@@ -458,7 +532,11 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     lib.gdf_amd_profile_enable(0)
-    prof = read_profile(gdf)
+    prof_sides = read_profile(gdf, split_sides=True)
+    prof = {}
+    for k_, v_ in prof_sides.items():
+        a_, b_ = prof.get(k_.split("@")[0], (0.0, 0))
+        prof[k_.split("@")[0]] = (a_ + v_[0], b_ + v_[1])
 
     # what the planner would have run at this world size, when that is another strategy than the one `value` reports
     planner_choice = None
@@ -526,9 +604,24 @@ def main():
     if rank == 0:
         total_probe = npr * world
         value = total_probe * args.steps / dt
-        roofline = mine["roofline"]
-        e2e_bytes = 8.0 * npr + 8.0 * nb + 8.0 * (rows.item() / world)
+        kernel_roof = mine["roofline"]
+        out_per_gpu = rows.item() / world
+        e2e_bytes = 8.0 * npr + 8.0 * nb + 8.0 * out_per_gpu
         e2e = e2e_bytes / (ms_per_step * 1e-3) / 1e9
+        # the WHOLE call against the HBM peak on its algorithmic bytes (8 N_p + 8 N_b + 8 N_out; partition passes are
+        # overhead with zero algorithmic bytes), the probe phase on 16 B per probe row over the probe-side launches (tagged @probe by
+        # the library: live HIP events), and the PMC traffic of one whole join.  The per-kernel contract object of rounds 1-4
+        # (dominant kernel on its own bytes) is `roofline_kernel`.
+        probe_ms = sum(v[0] for k_, v in prof_sides.items() if k_.endswith("@probe")) / args.steps
+        probe_bytes = 8.0 * npr + 8.0 * out_per_gpu
+        join_traffic, join_src = (pmc_traffic(None, 1.0) if (not distributed and npr == 1_000_000_000) else (None, None))
+        roofline = {"bound": "hbm", "kernel": "whole gdf_inner_join call (all launches of one step)", "achieved": e2e, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": e2e / HBM_PEAK_GBS, "traffic": join_traffic, "traffic_source": join_src,
+                    "algorithmic_bytes_per_launch": e2e_bytes, "avg_launch_ms": ms_per_step, "launches_per_step": 1.0,
+                    "probe_phase": ({"achieved": probe_bytes / (probe_ms * 1e-3) / 1e9, "frac": probe_bytes / (probe_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                     "algorithmic_bytes": probe_bytes, "probe_side_kernels_ms": probe_ms,
+                                     "kernels_ms": {k_: v[0] / args.steps for k_, v in sorted(prof_sides.items()) if k_.endswith("@probe")}}
+                                    if probe_ms > 0 else None)}
         result = {
             "metric": "hash-join probe rows/s", "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
@@ -536,10 +629,14 @@ def main():
             "config": {"workload": workload, "probe_rows_per_gpu": npr, "build_rows_per_gpu": nb,
                        "out_rows": int(rows.item()), "parallelism": f"key-partitioned x{world}"},
             "roofline": roofline,
-            "roofline_e2e": {"bound": "hbm", "achieved": e2e, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": e2e / HBM_PEAK_GBS,
-                             "algorithmic_bytes_per_gpu": e2e_bytes},
+            "roofline_kernel": kernel_roof,
             "kernels_ms_per_step": mine["kernels_ms_per_step"],
         }
+        if not distributed:
+            stats = (C.c_ulonglong * 4)()
+            gdf._binding._rmm_cdll.gdf_amd_rmm_place_stats(stats)
+            result["placement"] = {"challengers_drawn": int(stats[0]), "promoted": int(stats[1]), "entries": int(stats[2]),
+                                   "still_exploring": int(stats[3])}
         if distributed:
             # the exchange, per GPU and step: what went to RCCL, and what the busiest xGMI link would need for it at the rate the
             # planner assumes (a rank reaches each peer over ONE link) -- an estimate, the links cannot be timed from in here

@@ -63,6 +63,17 @@ rmmError_t  rmmGetLog(char *buffer, size_t buffer_size);    /* memory.h:184 */
    DESIGN.md 3.8 -- and kept for A/B runs. */
 void        gdf_amd_rmm_contiguous(int on);
 
+/* Extension, no counterpart in the reference: PLACED blocks -- a pool that re-draws slow physical placements (rmm.cpp, place_alloc).
+   libgdf.so allocates the multi-GB scratch of its regroup passes through these: `role` says what the block is for, `*measure` comes
+   back non-zero while the pool is still comparing placements for this (role, size) and wants to be told on _place_free how long the
+   kernels that scatter into the block took (milliseconds; < 0: unknown).  Blocks below 1 GiB and non-pool modes fall through to
+   rmmAlloc / rmmFree.  _place_draws: challengers per (role, size), default 4; 0: never re-draw; < 0: plain pool. */
+rmmError_t  gdf_amd_rmm_place_alloc(int role, size_t size, void **ptr, int *measure);
+rmmError_t  gdf_amd_rmm_place_free(int role, void *ptr, float ms);
+void        gdf_amd_rmm_place_draws(int draws);
+void        gdf_amd_rmm_place_stats(unsigned long long out[4]);
+size_t      gdf_amd_rmm_place_trace(char *buf, size_t cap);
+
 #if defined(__GNUC__)
 #pragma GCC visibility pop
 #endif

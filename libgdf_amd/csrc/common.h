@@ -5,6 +5,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include <stddef.h>
 #include <limits.h>
@@ -57,13 +58,55 @@ static inline hipStream_t stream0() { return (hipStream_t)0; }
 // ---- device scratch RAII over librmm ---------------------------------------
 struct DevBuf {
   void *p = nullptr;
+  // PLACED blocks (memory.h: gdf_amd_rmm_place_alloc): the multi-GB scratch of the regroup passes says what it is for, and -- while
+  // the pool is still comparing physical placements for this (role, size) -- how long the kernels that scatter into it took:
+  // clock_begin / clock_end bracket those launches with HIP events on the launch stream, reset() hands the sum to the pool.
+  int role = -1;
+  bool measure = false;
+  hipEvent_t ev[8];
+  int nev = 0;
   DevBuf() = default;
   DevBuf(const DevBuf &) = delete;
   DevBuf &operator=(const DevBuf &) = delete;
   ~DevBuf() { reset(); }
   rmmError_t alloc(size_t bytes) { reset(); return rmmAlloc(&p, bytes ? bytes : 1, (cudaStream_t)0); }
-  void reset() { if (p) { rmmFree(p, (cudaStream_t)0); p = nullptr; } }
-  void *release() { void *q = p; p = nullptr; return q; }
+  rmmError_t alloc_placed(int role_, size_t bytes) {
+    reset();
+    int m = 0;
+    const rmmError_t r = gdf_amd_rmm_place_alloc(role_, bytes ? bytes : 1, &p, &m);
+    if (r == RMM_SUCCESS) { role = role_; measure = m != 0; }
+    return r;
+  }
+  void clock_mark(hipStream_t s) {
+    if (!measure || nev >= 8) return;
+    if (hipEventCreate(&ev[nev]) != hipSuccess) { (void)hipGetLastError(); measure = false; return; }
+    (void)hipEventRecord(ev[nev++], s);
+  }
+  void clock_begin(hipStream_t s) { if (!(nev & 1)) clock_mark(s); }
+  void clock_end(hipStream_t s) { if (nev & 1) clock_mark(s); }
+  void reset() {
+    if (!p) return;
+    if (role >= 0) {
+      float ms = -1.f;
+      if (measure && nev >= 2 && !(nev & 1)) {
+        ms = 0.f;
+        for (int i = 0; i < nev; i += 2) {
+          float t = 0.f;
+          if (hipEventSynchronize(ev[i + 1]) != hipSuccess || hipEventElapsedTime(&t, ev[i], ev[i + 1]) != hipSuccess) { (void)hipGetLastError(); ms = -1.f; break; }
+          ms += t;
+        }
+      }
+      for (int i = 0; i < nev; ++i) (void)hipEventDestroy(ev[i]);
+      nev = 0;
+      gdf_amd_rmm_place_free(role, p, ms);
+      role = -1;
+      measure = false;
+    } else {
+      rmmFree(p, (cudaStream_t)0);
+    }
+    p = nullptr;
+  }
+  void *release() { void *q = p; p = nullptr; role = -1; measure = false; return q; }      // (a placed block handed on is freed through rmmFree, which knows it)
   template <class T> T *as() const { return static_cast<T *>(p); }
 };
 
@@ -190,9 +233,13 @@ __device__ __forceinline__ T dpp_move0_t(T x) {
     return (T)dpp_move0<CTRL, ROW_MASK, BOUND>((uint32_t)x);
   }
 }
+// PRECONDITIONS: (1) T is an integer type -- the DPP moves copy value bits through uint32 halves, a float would be converted, not
+// copied; (2) EVERY lane of the wave is active at the call (full EXEC): row_bcast:15 / :31 read lanes 15 / 31 / 47, and an inactive
+// source lane contributes 0 (bound_ctrl), silently dropping its row's total.  All call sites sit in workgroup-uniform control flow of
+// kernels whose block size is a multiple of 64.
 template <class T>
 __device__ __forceinline__ T wave_scan_incl(T v) {
-  static_assert(sizeof(T) == 4 || sizeof(T) == 8, "32- or 64-bit integers");
+  static_assert(std::is_integral<T>::value && (sizeof(T) == 4 || sizeof(T) == 8), "32- or 64-bit integers");
   v += dpp_move0_t<0x111, 0xf, true>(v);      // row_shr:1
   v += dpp_move0_t<0x112, 0xf, true>(v);      // row_shr:2
   v += dpp_move0_t<0x114, 0xf, true>(v);      // row_shr:4

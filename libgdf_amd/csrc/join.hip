@@ -68,7 +68,7 @@ struct KeyPlan {
   uint64_t kmin;              // subtracted from 8-byte integer keys in narrow mode (two's complement)
   uint64_t kspan;             // narrow mode with kmin != 0: the largest stored key (build max - min); decides whether hash_a is a
                               // bijection on the stored keys (six-byte level-2 tuples, p6_store)
-  mutable uint64_t klimit;    // the largest stored key that can join: 2^32 - 1 for NARROW keys, kspan once the build range is known
+  uint64_t klimit;            // the largest stored key that can join: 2^32 - 1 for NARROW keys, kspan once the build range is known
                               // (a probe key beyond the build maximum matches nothing, and the six-byte tuples compare hash
                               // remainders only: hash_a is a bijection on [0, kspan], not beyond it), ~0 for WIDE keys
   uint64_t kwindow;           // range-narrowed keys (else 0): the largest stored key that still lies in the 2^32 window of raw values hash_a
@@ -324,6 +324,7 @@ constexpr uint32_t JK_PROBE_CHUNK = 1u << 17;   // probe tuples per work unit
 constexpr int32_t JK_EMPTY = -1;
 constexpr uint32_t JK_NOPOS = 0xffffffffu;
 constexpr int JK_CUCKOO_MAX_MOVES = 32;
+constexpr int JK_ROLE_LEVEL1 = 1, JK_ROLE_LEVEL2 = 2;      // placed blocks (DevBuf::alloc_placed): the probe side's level-1 / level-2 tuples
 
 struct PartGeom {
   int fb, b1, b2;        // fine bits = b1 (level 1) + b2 (level 2)
@@ -3344,7 +3345,11 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
   }
   g.spec_cursor1 = spec.as<uint32_t>();
   g.spec_flag = spec.as<uint32_t>() + nseg;
-  RMM_TRY(sb->w[0].alloc(l6 ? 6 * (size1 + 2048) + 16 : sizeof(uint64_t) * size1));      // (L6: + two dump slots per thread behind the regions)
+  // the deferred main path allocates its two tuple buffers as PLACED blocks (DevBuf::alloc_placed; memory.h): the pool re-draws a
+  // physical placement the regroup kernels run slowly on, judged by the times reported here
+  const bool placed = defer && !app && g.b2 > 0 && narrow && !pay;
+  if (placed) RMM_TRY(sb->w[0].alloc_placed(JK_ROLE_LEVEL1, l6 ? 6 * (size1 + 2048) + 16 : sizeof(uint64_t) * size1));
+  else RMM_TRY(sb->w[0].alloc(l6 ? 6 * (size1 + 2048) + 16 : sizeof(uint64_t) * size1));      // (L6: + two dump slots per thread behind the regions)
   if (!narrow) RMM_TRY(sb->idx[0].alloc(sizeof(int32_t) * size1));
   if (pay) RMM_TRY(sb->pay[0].alloc(sizeof(uint64_t) * size1));
 #ifdef GDF_AMD_LAB
@@ -3355,8 +3360,10 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
     g.lab_clock = lab_clk.as<unsigned long long>();
   }
 #endif
+  sb->w[0].clock_begin(stream0());
   if (pay) GDF_TRY(launch_scatter1_pay(fast, pmode, t, plan, g, nullptr, *pay, sb->tuples(0)));
   else GDF_TRY(launch_scatter1(fast, narrow, sc_threads, t, plan, g, nullptr, sb->tuples(0), l6));
+  sb->w[0].clock_end(stream0());
 #ifdef GDF_AMD_LAB
   if (g.lab_clock) {
     std::vector<unsigned long long> h(16 * (size_t)g.nchunks);
@@ -3395,7 +3402,8 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
     hipLaunchKernelGGL(jk_init_cursor, dim3(32), dim3(256), 0, stream0(), cursor.as<uint32_t>(), nfine, cap2, g.fstart);
     HIP_CHECK_LAST();
     const bool p6 = want_p6 && narrow && !pay && sc2_threads == 256;
-    RMM_TRY(sb->w[1].alloc(p6 ? 6 * size2 + 16 : sizeof(uint64_t) * size2));
+    if (placed) RMM_TRY(sb->w[1].alloc_placed(JK_ROLE_LEVEL2, p6 ? 6 * size2 + 16 : sizeof(uint64_t) * size2));
+    else RMM_TRY(sb->w[1].alloc(p6 ? 6 * size2 + 16 : sizeof(uint64_t) * size2));
     if (!narrow) RMM_TRY(sb->idx[1].alloc(sizeof(int32_t) * size2));
     if (pay) RMM_TRY(sb->pay[1].alloc(sizeof(uint64_t) * size2));
     PartGeom g2 = g;
@@ -3406,7 +3414,9 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
     m.ntiles_dev = ntiles_dev;
     // every segment ends in at most one partial tile: an upper bound of the tile count sizes the grid
     const uint32_t tile_bound = (uint32_t)((uint64_t)n / (uint64_t)JK_TILE2) + nseg + 1;
+    sb->w[1].clock_begin(stream0());
     GDF_TRY(launch_scatter2(narrow, sc2_threads, tile_bound, g2, m, sb->tuples(0), cursor.as<uint32_t>(), sb->tuples(1), p6, l6));
+    sb->w[1].clock_end(stream0());
     sb->p6 = p6;
     // no synchronisation: the map and the level-1 tuples stay allocated until probe_partitioned has read its state block
     sb->d_map.p = d_map.release();
@@ -3847,7 +3857,7 @@ static gdf_error prepare_build(const KeyTable &build_t, BuildSide *bs, bool no_l
   return GDF_SUCCESS;
 }
 
-static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &build_t, const BuildSide &bs, SideBufs &P, JoinKind kind,
+static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &build_t, const BuildSide &bs, const KeyPlan &plan, SideBufs &P, JoinKind kind,
                                    int32_t **out_probe, int32_t **out_build, int64_t *out_n, StageClock &clk, PayCarry *pc = nullptr);
 
 // The probe side's skew sample (jk_sample_skew) needs nothing from the build pass: hash_join_core launches it BEFORE the build side is
@@ -3877,10 +3887,12 @@ static gdf_error skew_probe_launch(const KeyTable &probe_t, const KeyPlan &plan,
 static gdf_error probe_prepared(const KeyTable &probe_t, const KeyTable &build_t, const BuildSide &bs, JoinKind kind,
                                 int32_t **out_probe, int32_t **out_build, int64_t *out_n, StageClock &clk, PayCarry *pc = nullptr,
                                 SkewProbe *early_skew = nullptr) {
-  const KeyPlan &plan = bs.plan;
+  // which probe rows travel (KeyPlan::kwindow): decided per probe call, on this call's COPY of the plan -- a prepared build side
+  // serves INNER and LEFT probes alike, possibly from several threads at once
+  KeyPlan plan = bs.plan;
   const PartGeom &g = bs.g;
   const SideBufs &B = bs.B;
-  // which probe rows travel (KeyPlan::kwindow): decided per probe call -- a prepared build side serves INNER and LEFT probes alike
+  ProfTag probe_tag("@probe");          // (profiling only: the probe side's launches are reported apart from the build side's)
   if (plan.kwindow) plan.klimit = kind == JOIN_INNER ? plan.kspan : plan.kwindow;
 
   SideBufs P;
@@ -3968,19 +3980,18 @@ static gdf_error probe_prepared(const KeyTable &probe_t, const KeyTable &build_t
     if (!ok) return GDF_AMD_RETRY_WITHOUT_LEVEL3;     // skewed probe keys: the caller repeats with a 2^fb-partition build side
   }
   clk.mark("partition probe side");
-  gdf_error e = probe_partitioned(probe_t, build_t, bs, P, kind, out_probe, out_build, out_n, clk, pc_eff);
+  gdf_error e = probe_partitioned(probe_t, build_t, bs, plan, P, kind, out_probe, out_build, out_n, clk, pc_eff);
   if (e != GDF_AMD_RETRY_EXACT_PROBE) return e;
   // a deferred speculative probe side turned out to have overflowed (skewed keys): the exact layout, host bookkeeping
   SideBufs Q;
   KeyPlan probe_plan = plan;
   GDF_TRY(partition_side(probe_t, probe_plan, g, &Q, false, pay, pmode, false, want_p6_exact));
-  return probe_partitioned(probe_t, build_t, bs, Q, kind, out_probe, out_build, out_n, clk, pc_eff);
+  return probe_partitioned(probe_t, build_t, bs, plan, Q, kind, out_probe, out_build, out_n, clk, pc_eff);
 }
 
 // the part of a join after both relations are partitioned: work units, optimistic single pass or count + write, tails
-static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &build_t, const BuildSide &bs, SideBufs &P, JoinKind kind,
+static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &build_t, const BuildSide &bs, const KeyPlan &plan, SideBufs &P, JoinKind kind,
                                    int32_t **out_probe, int32_t **out_build, int64_t *out_n, StageClock &clk, PayCarry *pc) {
-  const KeyPlan &plan = bs.plan;
   const PartGeom &g = bs.g;
   const SideBufs &B = bs.B;
   const uint32_t nfine = 1u << (g.fb + g.b3);
@@ -4227,7 +4238,9 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
       oa.unit_pairs = d_upairs.as<uint32_t>();
     }
     clk.mark("output allocation");
+    P.w[P.final_buf].clock_begin(stream0());      // (a placed level-2 block: the probe kernel reads it)
     GDF_TRY(run_write_pass(narrow, plain && !dup_heavy, nunits, probe_lds, oa, max_build, probe_t, build_t));
+    P.w[P.final_buf].clock_end(stream0());
     unsigned long long st[2] = {0, 0};
     HIP_TRY(read_back(st, d_state.p, sizeof(st)));
     clk.mark("write pass");
@@ -5026,7 +5039,7 @@ static gdf_error accum_finish(ProbeAccum *a, gdf_column *probe_indices, gdf_colu
   StageClock clk(false);
   int32_t *o_probe = nullptr, *o_build = nullptr;
   int64_t n = 0;
-  GDF_TRY(probe_partitioned(all, a->pb->table, a->pb->side, a->P, JOIN_INNER, &o_probe, &o_build, &n, clk));
+  GDF_TRY(probe_partitioned(all, a->pb->table, a->pb->side, a->pb->side.plan, a->P, JOIN_INNER, &o_probe, &o_build, &n, clk));
   if (n == 0) return GDF_SUCCESS;
   gdf_column_view(probe_indices, o_probe, nullptr, (gdf_size_type)n, GDF_INT32);
   gdf_column_view(build_indices, o_build, nullptr, (gdf_size_type)n, GDF_INT32);

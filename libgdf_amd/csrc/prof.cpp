@@ -16,6 +16,7 @@ std::vector<Pair> pending;
 std::map<std::string, std::pair<double, int>> totals;
 hipEvent_t cur_start;
 std::string cur_name;
+std::string cur_tag;
 
 void fold_locked() {
   if (pending.empty()) return;
@@ -36,9 +37,14 @@ void fold_locked() {
 
 namespace gdf_amd {
 bool prof_enabled() { return enabled; }
+void prof_set_tag(const char *tag) {
+  std::lock_guard<std::mutex> g(mu);
+  cur_tag = tag ? tag : "";
+}
 void prof_begin(const char *name) {
   std::lock_guard<std::mutex> g(mu);
   cur_name = name;
+  cur_name += cur_tag;
   (void)hipEventCreate(&cur_start);
   (void)hipEventRecord(cur_start, (hipStream_t)0);
 }

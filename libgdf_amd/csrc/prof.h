@@ -12,6 +12,15 @@ namespace gdf_amd {
 bool prof_enabled();
 void prof_begin(const char *name);
 void prof_end();
+// appended to the names of the launches that follow ("" / nullptr: none): the join tags its PROBE-side launches "@probe", so that
+// bench.py can price the probe phase (16 B per probe row over the probe-side kernels) apart from the build side, which
+// runs the same kernels
+void prof_set_tag(const char *tag);
+struct ProfTag {
+  bool on;
+  explicit ProfTag(const char *tag) : on(prof_enabled()) { if (on) prof_set_tag(tag); }
+  ~ProfTag() { if (on) prof_set_tag(nullptr); }
+};
 }  // namespace gdf_amd
 
 #define GDF_LAUNCH(name, ...)                                   \

@@ -144,8 +144,10 @@ gdf_error gdf_amd_fj_probe_add(gdf_amd_join_probe *probe, const uint32_t *recv_k
  *                           or world size outside gdf_amd_fj_plan's range, skewed keys that overflow the fixed-size regions, the
  *                           31-bit position space) -- nothing is returned and the caller takes the key shuffle
  *                           (libgdf_amd/multigpu.py distributed_inner_join) on all ranks together.
- * Errors other than a decline (a HIP / RCCL failure, out of memory) are returned by the rank that met them; its peers see their
- * next transport call fail or time out, as with any collective.
+ * A hard LOCAL error (out of memory, a HIP failure) does not make its rank drop out of the collectives: every wire buffer is
+ * allocated before the first agreement, the rank keeps posting its (useless) blocks, reports the failure at the next agreement and
+ * ALL ranks leave there -- the rank that met the error with its code, its peers with GDF_C_ERROR.  A failing TRANSPORT call
+ * (all_to_all / wait / all_reduce_i64 returning non-zero) is returned at once; the peers then see their own transport fail or time out.
  */
 typedef struct gdf_amd_transport {
   void *ctx;

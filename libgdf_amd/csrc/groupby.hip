@@ -1453,14 +1453,14 @@ struct GbSpec {
   uint32_t *fill;                  // [P * G]
   uint32_t G;                      // workgroups of the scatter kernel (= segments per partition)
   // xcd != 0: ONE segment per partition and XCD (G = 8) instead of one per workgroup.  The workgroups of an XCD append to it
-  // together: a (tile, partition) run claims its place with ONE returning atomic on fill[q * 8 + xcc] -- issued at WORKGROUP scope
-  // (an agent-scope atomic brings cache maintenance with it: +3 ms in round 3) -- where xcc is read from HW_REG_XCC_ID, so that the
-  // counter a workgroup uses is by construction one only its own XCD touches, whatever the dispatcher does.  Why: a tail partition
-  // gets ~1 record per tile and workgroup; with 32 workgroups behind one write front its 128-byte line fills in microseconds, inside
-  // the L2, instead of leaving as ten partial lines.  (Where the atomics execute: the L2 counters of C5 show every one of the 1.28e8
-  // forwarded to the memory side as an atomic request, TCC_EA0_ATOMIC = TCC_ATOMIC, profiles/r4_u_c5_l2_atomic_counters.txt -- they
-  // are resolved where any XCD would see them; choosing the counter by XCD is what keeps an XCD's appends together, not what makes
-  // them atomic.)
+  // together: a (tile, partition) run claims its place with ONE returning atomic on fill[q * 8 + xcc] -- relaxed, AGENT scope (the
+  // counter is shared across workgroups; no fence: an acquire / release pair around it cost +3 ms in round 3) -- where xcc is read
+  // from HW_REG_XCC_ID, so that the counter a workgroup uses is one only its own XCD touches, whatever the dispatcher does.  Why: a
+  // tail partition gets ~1 record per tile and workgroup; with 32 workgroups behind one write front its 128-byte line fills in
+  // microseconds, inside the L2, instead of leaving as ten partial lines.  (Where the atomics execute: the L2 counters of C5 show
+  // every one of the 1.28e8 forwarded to the memory side as an atomic request, TCC_EA0_ATOMIC = TCC_ATOMIC,
+  // profiles/r4_u_c5_l2_atomic_counters.txt -- they are resolved where any XCD would see them; choosing the counter by XCD is what
+  // keeps an XCD's appends together, not what makes them atomic.)
   int xcd;
 };
 
@@ -2324,7 +2324,11 @@ __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter_static(KeyTable t,
 #pragma unroll
             for (int q = 0; q < PER; ++q) {
               const uint32_t b = threadIdx.x * PER + q;
-              claimed[q] = (v[q] && b < nparts) ? __hip_atomic_fetch_add(&spec.fill[(size_t)b * 8u + xcc], v[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+              // AGENT scope, relaxed (round 5): the counter is shared by DIFFERENT workgroups, which only an agent-scope
+              // atomic is defined for in the HIP memory model.  It costs nothing: on gfx950 a relaxed returning atomic is the SAME
+              // instruction at workgroup and at agent scope (`global_atomic_add ... sc0`; only system scope adds sc1) -- what cost 3 ms
+              // in round 3 was the acquire / release fence pair around it, not the scope.
+              claimed[q] = (v[q] && b < nparts) ? __hip_atomic_fetch_add(&spec.fill[(size_t)b * 8u + xcc], v[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
             }
           }
         }
@@ -2633,6 +2637,9 @@ static gdf_error gb_path_direct(GbJob &j, bool *done) {
       for (int c = 0; c < ncols; ++c) out_keys[c]->size = (gdf_size_type)res[0];
       out_agg->size = (gdf_size_type)res[0];
       *done = true;
+      // (a SORT-method call -- sort_indices -- leaves the caller's validity masks alone, as group_by_sort does: that method rejects
+      // masks on the way in, sqls_ops.cu:1103-1106, and never writes one on the way out)
+      if (j.sort_indices) { HIP_TRY(hipStreamSynchronize(stream0())); return GDF_SUCCESS; }
       return write_output_masks(ncols, out_keys, out_agg, nullptr, res[0]);          // ids ascend: the output is already sorted
     }
   }
@@ -2957,12 +2964,11 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
           // out over G workgroups, + 6 sigma of a workgroup's own share (Poisson) -- a segment overflows about once in 1e8
           // XCD-shared segments (GbSpec::xcd): the DEFAULT since the ranks inside a tile are plain atomics (C5 in alternating processes of
           // one box: 9.45 - 9.54 against 10.12 - 10.19 ms, the scatter kernel 7.33 against 7.95, profiles/r4_o_c5_xcd_shared_ab.txt; it
-          // was 10.67 against 10.9 - 11.4 when it was measured first, r4_k).  What it rests on: a run's place is claimed with a
-          // WORKGROUP-scope atomic on a counter chosen by HW_REG_XCC_ID, so no other XCD ever touches it (the L2 counters show these
-          // atomics forwarded to the memory side, GbSpec::xcd above); the kernel boundary writes the L2s back before the aggregation
-          // reads fill counts and records.  That the workgroups of an XCD see one counter is a property of the part (the L1s do not
-          // execute atomics), not of the HIP memory model, which promises workgroup scope nothing across workgroups: GDF_GBP_NO_XCD
-          // keeps the per-workgroup segments (no atomics at all), and the tests run both layouts against the oracle.
+          // was 10.67 against 10.9 - 11.4 when it was measured first, r4_k).  A run's place is claimed with a relaxed AGENT-scope atomic
+          // (round 5: defined for counters shared across workgroups; round 4 shipped workgroup scope, which only the part made right) on
+          // a counter chosen by HW_REG_XCC_ID, so that an XCD's appends stay together; the kernel boundary writes the L2s back before
+          // the aggregation reads fill counts and records.  GDF_GBP_NO_XCD keeps the per-workgroup segments (no atomics at all), and the
+          // tests run both layouts against the oracle.
           const bool xcd_mode = (sgrid.x & 7u) == 0 && !lab::path_on("GDF_GBP_NO_XCD");
           const uint32_t G = xcd_mode ? 8u : sgrid.x;
           // the rows the BUSIEST workgroup (XCD) gets (the kernel's chunk -> workgroup map: XCD x takes the x-th eighth of the chunks, its
@@ -3409,6 +3415,11 @@ static gdf_error group_by_hash(int ncols, gdf_column **cols, gdf_column *col_agg
   GDF_TRY(make_key_table(cols, ncols, &t));
   const int64_t n = t.nrows;
   if (n >= (int64_t)INT_MAX) return GDF_COLUMN_SIZE_TOO_BIG;
+  // every kernel below reads rows [0, n) of EVERY key column and (COUNT aside) of the aggregation column: unequal sizes are an error
+  // here, not an out-of-bounds read (the reference's gdf_table asserts equal column sizes, gdf_table.cuh:249-322; the SORT method
+  // answers GDF_COLUMN_SIZE_MISMATCH, sort.hip group_by_sort, and so does its direct-path shortcut, which enters through here)
+  for (int c = 0; c < ncols; ++c) GDF_REQUIRE(cols[c] && cols[c]->size == cols[0]->size, GDF_COLUMN_SIZE_MISMATCH);
+  if (op != OP_COUNT) GDF_REQUIRE(col_agg->size == cols[0]->size, GDF_COLUMN_SIZE_MISMATCH);
 
   // dtype dispatch (groupby.cuh:86-190): COUNT is typed by the OUTPUT column, the rest by the input
   const ElemKind in_kind = elem_kind(col_agg->dtype);

@@ -5482,31 +5482,38 @@ struct DistTicket { void *keys = nullptr, *fill = nullptr; };
 struct DistExchange {          // one relation slice on the wire: send buffers (alive until the exchange is done), receive buffers
   DevBuf sk, sf, rk, rf;
   DistTicket t;
-  bool posted = false;
+  bool posted_keys = false, posted_fill = false;      // per ticket: a failure between the two all_to_alls leaves ONE of them on the wire
 };
 
-// all ranks learn whether `flag` is set anywhere
-static gdf_error dist_agree(gdf_amd_transport *tr, bool flag, bool *any) {
-  int64_t v = flag ? 1 : 0;
+// All ranks learn the worst of their `level`s: 0 fine, 1 "this shape does not fit, decline together", 2 "a rank hit a hard local
+// error" (a rank that returned on a failed allocation left its peers blocked in the next collective -- RCCL has no
+// timeout of its own; local errors are now carried to the next agreement and every rank leaves there).
+static gdf_error dist_agree(gdf_amd_transport *tr, int level, int *worst) {
+  int64_t v = level;
   if (tr->all_reduce_i64(tr->ctx, &v, 1, 1) != 0) return GDF_C_ERROR;
-  *any = v != 0;
+  *worst = (int)v;
+  return GDF_SUCCESS;
+}
+static gdf_error dist_alloc(gdf_amd_transport *tr, DistExchange *x, size_t block_elems, size_t regions_per_rank) {
+  const size_t world = (size_t)tr->world;
+  RMM_TRY(x->sk.alloc(sizeof(uint32_t) * (world * block_elems + FJ_TILE)));
+  RMM_TRY(x->sf.alloc(sizeof(uint32_t) * (world * regions_per_rank + 1)));
+  RMM_TRY(x->rk.alloc(sizeof(uint32_t) * world * block_elems));
+  RMM_TRY(x->rf.alloc(sizeof(uint32_t) * (world * regions_per_rank + 2)));
   return GDF_SUCCESS;
 }
 static gdf_error dist_post(gdf_amd_transport *tr, DistExchange *x, size_t block_elems, size_t regions_per_rank) {
-  const size_t world = (size_t)tr->world;
-  RMM_TRY(x->rk.alloc(sizeof(uint32_t) * world * block_elems));
-  RMM_TRY(x->rf.alloc(sizeof(uint32_t) * (world * regions_per_rank + 2)));
   if (tr->all_to_all(tr->ctx, x->sk.p, x->rk.p, sizeof(uint32_t) * block_elems, &x->t.keys) != 0) return GDF_C_ERROR;
+  x->posted_keys = true;
   if (tr->all_to_all(tr->ctx, x->sf.p, x->rf.p, sizeof(uint32_t) * regions_per_rank, &x->t.fill) != 0) return GDF_C_ERROR;
-  x->posted = true;
+  x->posted_fill = true;
   return GDF_SUCCESS;
 }
 static gdf_error dist_wait(gdf_amd_transport *tr, DistExchange *x) {
-  if (!x->posted) return GDF_SUCCESS;
-  x->posted = false;
-  if (tr->wait(tr->ctx, x->t.keys) != 0) return GDF_C_ERROR;
-  if (tr->wait(tr->ctx, x->t.fill) != 0) return GDF_C_ERROR;
-  return GDF_SUCCESS;
+  gdf_error e = GDF_SUCCESS;
+  if (x->posted_keys) { x->posted_keys = false; if (tr->wait(tr->ctx, x->t.keys) != 0) e = GDF_C_ERROR; }
+  if (x->posted_fill) { x->posted_fill = false; if (tr->wait(tr->ctx, x->t.fill) != 0) e = GDF_C_ERROR; }
+  return e;
 }
 }  // namespace
 
@@ -5528,18 +5535,25 @@ static gdf_error dist_inner_join(gdf_column *probe_keys, gdf_column *build_keys,
   const int world = tr->world;
   const int64_t n_p = (int64_t)probe_keys->size, n_b = (int64_t)build_keys->size;
 
+  // A hard LOCAL error (allocation, kernel launch, an internal inconsistency) is remembered, not returned: this rank keeps taking
+  // part in every collective its peers will enter, says so at the next agreement, and all ranks leave there together -- this one
+  // with its error, the others with GDF_C_ERROR.  Only a failing TRANSPORT returns at once (there is nothing left to agree over).
+  gdf_error hard = GDF_SUCCESS;
+  auto note = [&](gdf_error e) { if (e != GDF_SUCCESS && hard == GDF_SUCCESS) hard = e; return e; };
+  auto leave = [&](int worst) -> gdf_error { return hard != GDF_SUCCESS ? hard : (worst >= 2 ? GDF_C_ERROR : GDF_SUCCESS); };
+
   // ---- numbers every rank must agree on: the global build-side key range, the largest and the total shard sizes ----
   long long mm[2] = {LLONG_MAX, LLONG_MIN};
   if (n_b) {
     KeyTable bt;
     gdf_column *bc = build_keys;
-    GDF_TRY(make_key_table(&bc, 1, &bt));
-    GDF_TRY(key_ranges(bt, mm));
+    if (note(make_key_table(&bc, 1, &bt)) == GDF_SUCCESS) note(key_ranges(bt, mm));
   }
   int64_t mins[4] = {mm[0] <= mm[1] ? (int64_t)mm[0] : INT64_MAX, mm[0] <= mm[1] ? -(int64_t)mm[1] : INT64_MAX, -n_p, -n_b};
   if (tr->all_reduce_i64(tr->ctx, mins, 4, 0) != 0) return GDF_C_ERROR;
-  int64_t sums[2] = {n_p, n_b};
-  if (tr->all_reduce_i64(tr->ctx, sums, 2, 2) != 0) return GDF_C_ERROR;
+  int64_t sums[3] = {n_p, n_b, hard != GDF_SUCCESS ? 1 : 0};
+  if (tr->all_reduce_i64(tr->ctx, sums, 3, 2) != 0) return GDF_C_ERROR;
+  if (sums[2] != 0) return leave(2);
   const int64_t lo = mins[0], hi = mins[1] == INT64_MAX ? INT64_MIN : -mins[1], p_max = -mins[2], b_max = -mins[3];
   const int64_t p_total = sums[0], b_total = sums[1];
   // (everything up to the first exchange is decided from these shared numbers: every rank takes the same exits)
@@ -5549,7 +5563,7 @@ static gdf_error dist_inner_join(gdf_column *probe_keys, gdf_column *build_keys,
   const int64_t step_max = (p_max + chunks - 1) / chunks;
   int fb_b = 0, cb_b = 0, fb_p = 0, cb_p = 0;
   uint32_t cap_b = 0, cap_p = 0;
-  gdf_error e = fj_plan(world, b_total, b_max, 1.0, &fb_b, &cb_b, &cap_b);
+  gdf_error e = fj_plan(world, b_total, b_max, 1.0, &fb_b, &cb_b, &cap_b);      // (a pure function of the shared numbers)
   if (e == GDF_UNSUPPORTED_METHOD) return GDF_SUCCESS;
   GDF_TRY(e);
   e = fj_plan(world, b_total, step_max, std::max(1.0, (double)p_total / (double)std::max<int64_t>(b_total, 1)), &fb_p, &cb_p, &cap_p);
@@ -5568,18 +5582,25 @@ static gdf_error dist_inner_join(gdf_column *probe_keys, gdf_column *build_keys,
   auto settle = [&]() { for (DistExchange &x : wire) (void)dist_wait(tr, &x); };
   struct Settle { decltype(settle) &f; ~Settle() { f(); } } settle_on_exit{settle};
 
-  // ---- build relation ----
+  // ---- every buffer that will go on the wire is allocated BEFORE the first agreement: an out-of-memory rank says so there ----
+  // (they all stay alive until the call ends anyway -- queued level-2 kernels read the receive buffers)
   wire.emplace_back();
   DistExchange &bx = wire.back();
-  RMM_TRY(bx.sk.alloc(sizeof(uint32_t) * ((size_t)world * block_b + FJ_TILE)));
-  RMM_TRY(bx.sf.alloc(sizeof(uint32_t) * ((size_t)world * rpr_b + 1)));
+  note(dist_alloc(tr, &bx, block_b, rpr_b));
+  for (int c = 0; c < chunks && hard == GDF_SUCCESS; ++c) {
+    wire.emplace_back();
+    note(dist_alloc(tr, &wire.back(), block_p, rpr_p));
+  }
+  DevBuf dummy_pos, dummy_ppos;
+  if (!build_pos && note(dummy_pos.alloc(sizeof(uint32_t)) == RMM_SUCCESS ? GDF_SUCCESS : GDF_MEMORYMANAGER_ERROR) == GDF_SUCCESS) build_pos = dummy_pos.as<uint32_t>();
+  if (!probe_pos && note(dummy_ppos.alloc(sizeof(uint32_t)) == RMM_SUCCESS ? GDF_SUCCESS : GDF_MEMORYMANAGER_ERROR) == GDF_SUCCESS) probe_pos = dummy_ppos.as<uint32_t>();
+
+  // ---- build relation ----
   int over = 0;
-  DevBuf dummy_pos;
-  if (!build_pos) { RMM_TRY(dummy_pos.alloc(sizeof(uint32_t))); build_pos = dummy_pos.as<uint32_t>(); }
-  GDF_TRY(fj_send(build_keys, lo, hi, world, cb_b, cap_b, bx.sk.as<uint32_t>(), build_pos, bx.sf.as<uint32_t>(), &over));
-  bool any = false;
-  GDF_TRY(dist_agree(tr, over != 0, &any));
-  if (any) return GDF_SUCCESS;             // a region overflowed somewhere (skewed build keys): every rank leaves
+  if (hard == GDF_SUCCESS) note(fj_send(build_keys, lo, hi, world, cb_b, cap_b, bx.sk.as<uint32_t>(), build_pos, bx.sf.as<uint32_t>(), &over));
+  int worst = 0;
+  GDF_TRY(dist_agree(tr, hard != GDF_SUCCESS ? 2 : (over != 0 ? 1 : 0), &worst));
+  if (worst) return leave(worst);          // a region overflowed somewhere (skewed build keys) or a rank failed: every rank leaves
   GDF_TRY(dist_post(tr, &bx, block_b, rpr_b));
 
   // ---- probe relation: `chunks` slices, software-pipelined ----
@@ -5591,49 +5612,48 @@ static gdf_error dist_inner_join(gdf_column *probe_keys, gdf_column *build_keys,
   // (queued level-2 kernels still read the receive buffers and write the accumulator's: drain the stream before anything is freed)
   struct AccGuard { ProbeAccum *&a; ~AccGuard() { (void)hipStreamSynchronize(stream0()); delete a; } } acc_guard{acc};
   bool failed = false;
-  DevBuf dummy_ppos;
-  if (!probe_pos) { RMM_TRY(dummy_ppos.alloc(sizeof(uint32_t))); probe_pos = dummy_ppos.as<uint32_t>(); }
   DistExchange *pending = nullptr;
   int pending_index = 0;
   auto add = [&](DistExchange *x, int index) -> gdf_error {
-    GDF_TRY(dist_wait(tr, x));
-    if (!acc || failed) return GDF_SUCCESS;
+    GDF_TRY(dist_wait(tr, x));             // (a transport failure: returned at once)
+    if (!acc || failed || hard != GDF_SUCCESS) return GDF_SUCCESS;
     const gdf_error ea = fj_probe_add(acc, x->rk.as<uint32_t>(), x->rf.as<uint32_t>(), cap_p, (int64_t)index * (int64_t)world * (int64_t)block_p,
                                       (int64_t)world * (int64_t)block_p);
     if (ea == GDF_UNSUPPORTED_METHOD || ea == GDF_COLUMN_SIZE_TOO_BIG) { failed = true; return GDF_SUCCESS; }     // a plan change, settled below
-    return ea;
+    note(ea);
+    return GDF_SUCCESS;
   };
   for (int c = 0; c < chunks; ++c) {
     const int64_t a = std::min<int64_t>(n_p, (int64_t)c * step), b = std::min<int64_t>(n_p, (int64_t)(c + 1) * step);
     gdf_column slice = *probe_keys;
     slice.data = probe_keys->data ? (char *)probe_keys->data + (size_t)a * width : nullptr;
     slice.size = (gdf_size_type)(b - a);
-    wire.emplace_back();
-    DistExchange &px = wire.back();
-    RMM_TRY(px.sk.alloc(sizeof(uint32_t) * ((size_t)world * block_p + FJ_TILE)));
-    RMM_TRY(px.sf.alloc(sizeof(uint32_t) * ((size_t)world * rpr_p + 1)));
-    GDF_TRY(fj_send(&slice, lo, hi, world, cb_p, cap_p, px.sk.as<uint32_t>(), probe_pos + a, px.sf.as<uint32_t>(), &over));
+    DistExchange &px = wire[(size_t)c + 1];
+    if (hard == GDF_SUCCESS) note(fj_send(&slice, lo, hi, world, cb_p, cap_p, px.sk.as<uint32_t>(), probe_pos + a, px.sf.as<uint32_t>(), &over));
     failed = failed || over != 0;
     // the slice goes on the wire BEFORE anybody asks whether it overflowed (the agreement used to sit in front of the
-    // first exchange, one blocking all-reduce on the happy path of every join); an overflowed buffer is memory safe, just useless
+    // first exchange, one blocking all-reduce on the happy path of every join); an overflowed buffer is memory safe, just useless --
+    // and so is the buffer of a rank that has failed locally: it is posted all the same, the peers are waiting for it
     GDF_TRY(dist_post(tr, &px, block_p, rpr_p));
     if (c == 0) {
-      // a region overflowed on some rank's FIRST slice (skewed probe keys are usually skewed everywhere): every rank leaves now,
-      // before three more slices are regrouped, shipped and partitioned for nothing
-      GDF_TRY(dist_agree(tr, over != 0, &any));
-      if (any) return GDF_SUCCESS;
+      // a region overflowed on some rank's FIRST slice (skewed probe keys are usually skewed everywhere), or a rank failed: every
+      // rank leaves now, before three more slices are regrouped, shipped and partitioned for nothing
+      GDF_TRY(dist_agree(tr, hard != GDF_SUCCESS ? 2 : (over != 0 ? 1 : 0), &worst));
+      if (worst) return leave(worst);
     }
     if (!build) {
       GDF_TRY(dist_wait(tr, &bx));
-      PreparedBuild *pb = nullptr;
-      gdf_error eb = fj_build_create(bx.rk.as<uint32_t>(), bx.rf.as<uint32_t>(), world, lo, fb_b, cb_b, cap_b, b_total / world + 1, &pb);
-      build.reset(pb);
-      if (eb == GDF_SUCCESS) {
-        eb = accum_begin(build.get(), (size_t)(p_total / world + 1), &acc);
-        if (eb != GDF_SUCCESS) acc = nullptr;
+      if (hard == GDF_SUCCESS) {
+        PreparedBuild *pb = nullptr;
+        gdf_error eb = fj_build_create(bx.rk.as<uint32_t>(), bx.rf.as<uint32_t>(), world, lo, fb_b, cb_b, cap_b, b_total / world + 1, &pb);
+        build.reset(pb);
+        if (eb == GDF_SUCCESS) {
+          eb = accum_begin(build.get(), (size_t)(p_total / world + 1), &acc);
+          if (eb != GDF_SUCCESS) acc = nullptr;
+        }
+        if (eb == GDF_UNSUPPORTED_METHOD || eb == GDF_COLUMN_SIZE_TOO_BIG) failed = true;
+        else note(eb);
       }
-      if (eb == GDF_UNSUPPORTED_METHOD || eb == GDF_COLUMN_SIZE_TOO_BIG) failed = true;
-      else GDF_TRY(eb);
       if (!build) build.reset(new PreparedBuild());       // (so that the build exchange is not waited for again)
     }
     if (pending) GDF_TRY(add(pending, pending_index));
@@ -5642,19 +5662,19 @@ static gdf_error dist_inner_join(gdf_column *probe_keys, gdf_column *build_keys,
   }
   if (pending) GDF_TRY(add(pending, pending_index));
   bool have = false;
-  if (acc && !failed) {
+  if (acc && !failed && hard == GDF_SUCCESS) {
     ProbeAccum *fin = acc;
     acc = nullptr;                                           // accum_finish owns it from here
     const gdf_error ef = accum_finish(fin, probe_indices, build_indices);
     if (ef == GDF_UNSUPPORTED_METHOD || ef == GDF_COLUMN_SIZE_TOO_BIG) failed = true;
-    else { GDF_TRY(ef); have = true; }
+    else if (note(ef) == GDF_SUCCESS) have = true;
   }
-  GDF_TRY(dist_agree(tr, failed || !have, &any));
-  if (any) {
+  GDF_TRY(dist_agree(tr, hard != GDF_SUCCESS ? 2 : ((failed || !have) ? 1 : 0), &worst));
+  if (worst) {
     if (have) { gdf_column_free(probe_indices); gdf_column_free(build_indices); }
     gdf_column_view(probe_indices, nullptr, nullptr, 0, N_GDF_TYPES);
     gdf_column_view(build_indices, nullptr, nullptr, 0, N_GDF_TYPES);
-    return GDF_SUCCESS;
+    return leave(worst);
   }
   HIP_TRY(hipStreamSynchronize(stream0()));                  // the receive buffers go out of scope with this call
   *declined = 0;

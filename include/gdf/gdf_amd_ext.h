@@ -178,6 +178,26 @@ gdf_error gdf_amd_dist_inner_join(gdf_column *probe_keys, gdf_column *build_keys
                                   uint32_t *probe_pos, uint32_t *build_pos, gdf_column *probe_indices, gdf_column *build_indices,
                                   gdf_amd_dist_info *info, int *declined);
 
+/* MULTI-GPU GROUP-BY behind the C ABI (csrc/dist_ops.hip; no counterpart in the reference, which is single-GPU -- per rank it
+ * composes gdf_group_by_<op>, src/sqls_ops.cu:1426-1487, and gdf_hash_partition, src/hashing.cu:559-654).  COLLECTIVE: every rank
+ * of the transport calls it with its row shard of (keys, values) -- one int32 / int64 key column, one numeric value column, no
+ * validity masks, possibly no rows.  Every rank pre-aggregates its shard, the partial aggregates travel to the rank
+ * Murmur3(key) % world owns (equal blocks over transport->all_to_all, their size agreed by one all-reduce) and are combined there:
+ * partial sums / minima / maxima by the same operator, partial counts (int64) by a sum, AVG as the quotient of the combined sums
+ * (accumulated in int64 / float64) and counts -- a GDF_FLOAT64 column.
+ *   out_keys / out_agg   library-allocated columns (gdf_column_free) with THIS RANK'S groups, sorted by key; every group of the
+ *                        global relation comes out on exactly one rank.  SUM / MIN / MAX keep the value dtype (a sum wraps as the
+ *                        single-GPU gdf_group_by_sum does), COUNT is GDF_INT64, AVG GDF_FLOAT64.
+ * Errors: a local error (bad arguments on one rank, out of memory) is carried into the agreement; that rank returns its code and
+ * the others GDF_C_ERROR -- nobody is left waiting in a collective.  op: GDF_SUM, GDF_MIN, GDF_MAX, GDF_COUNT, GDF_AVG. */
+gdf_error gdf_amd_dist_group_by(gdf_agg_op op, gdf_column *keys, gdf_column *values, gdf_amd_transport *transport,
+                                gdf_column *out_keys, gdf_column *out_agg);
+gdf_error gdf_amd_dist_group_by_sum(gdf_column *keys, gdf_column *values, gdf_amd_transport *transport, gdf_column *out_keys, gdf_column *out_agg);
+gdf_error gdf_amd_dist_group_by_min(gdf_column *keys, gdf_column *values, gdf_amd_transport *transport, gdf_column *out_keys, gdf_column *out_agg);
+gdf_error gdf_amd_dist_group_by_max(gdf_column *keys, gdf_column *values, gdf_amd_transport *transport, gdf_column *out_keys, gdf_column *out_agg);
+gdf_error gdf_amd_dist_group_by_count(gdf_column *keys, gdf_column *values, gdf_amd_transport *transport, gdf_column *out_keys, gdf_column *out_agg);
+gdf_error gdf_amd_dist_group_by_avg(gdf_column *keys, gdf_column *values, gdf_amd_transport *transport, gdf_column *out_keys, gdf_column *out_agg);
+
 /* RCCL transport.  id: the 128 bytes of an ncclUniqueId -- made by ONE rank with gdf_amd_rccl_unique_id and handed to the others by
    whatever the host has (MPI, a file, torch.distributed's store); every rank then calls gdf_amd_rccl_transport_create (collective:
    ncclCommInitRank) with the device it computes on current.  gdf_amd_transport_free destroys communicator and stream. */

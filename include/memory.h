@@ -67,8 +67,9 @@ void        gdf_amd_rmm_contiguous(int on);
    libgdf.so allocates the multi-GB scratch of its regroup passes through these: `role` says what the block is for, `*measure` comes
    back non-zero while the pool is still comparing placements for this (role, size) and wants to be told on _place_free how long the
    kernels that scatter into the block took (milliseconds; < 0: unknown).  Blocks below 1 GiB and non-pool modes fall through to
-   rmmAlloc / rmmFree.  _place_draws: challengers per (role, size), default 4; 0: never re-draw; < 0: plain pool. */
-rmmError_t  gdf_amd_rmm_place_alloc(int role, size_t size, void **ptr, int *measure);
+   rmmAlloc / rmmFree.  _place_draws: challengers per (role, size), default 4; 0: never re-draw; < 0: plain pool.  max_draws > 0: this
+   caller's own number of challengers (one that times a short calibration run per candidate inside ONE call can afford more). */
+rmmError_t  gdf_amd_rmm_place_alloc(int role, size_t size, int max_draws, void **ptr, int *measure);
 rmmError_t  gdf_amd_rmm_place_free(int role, void *ptr, float ms);
 void        gdf_amd_rmm_place_draws(int draws);
 void        gdf_amd_rmm_place_stats(unsigned long long out[4]);

@@ -479,6 +479,23 @@ class CallbackTransport:
         pass
 
 
+_AGG_OPS = {"sum": 0, "min": 1, "max": 2, "avg": 3, "count": 4}      # gdf_agg_op (include/gdf/gdf.h)
+
+
+def dist_group_by(op: str, keys: Column, values: Column, transport):
+    """gdf_amd_dist_group_by (COLLECTIVE over the transport's ranks) -> (keys, aggregates) tensors with THIS rank's groups, sorted
+    by key: sum / min / max in the value dtype, count int64, avg float64."""
+    import torch
+    ok, oa = gdf_column(), gdf_column()
+    libgdf.gdf_amd_dist_group_by(_AGG_OPS[op], keys.ptr, values.ptr, transport.ptr, C.byref(ok), C.byref(oa))
+    errs = getattr(transport, "errors", None)
+    if errs:
+        raise errs.pop(0)
+    tdt = {1: torch.int8, 2: torch.int16, 3: torch.int32, 4: torch.int64, 5: torch.float32, 6: torch.float64, 7: torch.int32, 8: torch.int64,
+           9: torch.int64}
+    return _take_library_column(ok, tdt[int(ok.dtype)]), _take_library_column(oa, tdt[int(oa.dtype)])
+
+
 def dist_inner_join(probe: Column, build: Column, transport, chunks=4):
     """gdf_amd_dist_inner_join -> None when every rank declined (the shape does not fit the fused path), else
     (probe_pos_of_rows, build_pos_of_rows, probe_indices, build_indices, info): the first two say where each LOCAL row's key went

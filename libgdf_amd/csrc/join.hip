@@ -325,6 +325,7 @@ constexpr int32_t JK_EMPTY = -1;
 constexpr uint32_t JK_NOPOS = 0xffffffffu;
 constexpr int JK_CUCKOO_MAX_MOVES = 32;
 constexpr int JK_ROLE_LEVEL1 = 1, JK_ROLE_LEVEL2 = 2;      // placed blocks (DevBuf::alloc_placed): the probe side's level-1 / level-2 tuples
+constexpr int JK_PLACE_DRAWS = 8;                           // challengers of the level-1 buffer's placement tournament (partition_side_spec)
 
 struct PartGeom {
   int fb, b1, b2;        // fine bits = b1 (level 1) + b2 (level 2)
@@ -3348,7 +3349,7 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
   // the deferred main path allocates its two tuple buffers as PLACED blocks (DevBuf::alloc_placed; memory.h): the pool re-draws a
   // physical placement the regroup kernels run slowly on, judged by the times reported here
   const bool placed = defer && !app && g.b2 > 0 && narrow && !pay;
-  if (placed) RMM_TRY(sb->w[0].alloc_placed(JK_ROLE_LEVEL1, l6 ? 6 * (size1 + 2048) + 16 : sizeof(uint64_t) * size1));
+  if (placed) RMM_TRY(sb->w[0].alloc_placed(JK_ROLE_LEVEL1, l6 ? 6 * (size1 + 2048) + 16 : sizeof(uint64_t) * size1, JK_PLACE_DRAWS));
   else RMM_TRY(sb->w[0].alloc(l6 ? 6 * (size1 + 2048) + 16 : sizeof(uint64_t) * size1));      // (L6: + two dump slots per thread behind the regions)
   if (!narrow) RMM_TRY(sb->idx[0].alloc(sizeof(int32_t) * size1));
   if (pay) RMM_TRY(sb->pay[0].alloc(sizeof(uint64_t) * size1));
@@ -3360,6 +3361,23 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
     g.lab_clock = lab_clk.as<unsigned long long>();
   }
 #endif
+  // PLACEMENT TOURNAMENT of the level-1 buffer (round 5).  jk_scatter1 runs in one of two modes on a given physical placement of this
+  // buffer (2.9 or 3.3 ms for C3's probe side), and most fresh blocks are slow ones.  While the pool is still comparing
+  // placements for this (role, size) -- the first call of a shape -- every candidate block is timed on a CALIBRATION run, the real kernel
+  // over the first quarter of the chunks (every region's write front opens, ~0.8 ms), and handed back with that time; the pool keeps
+  // the fastest of JK_PLACE_DRAWS + 1 and this call, and every later one, runs on it.  ~2 ms per candidate, once per shape.
+  if (placed && !pay && !lab::knob_on("GDF_JK_NO_CALIBRATE")) {
+    const size_t bytes1 = l6 ? 6 * (size1 + 2048) + 16 : sizeof(uint64_t) * size1;
+    for (int round = 0; round <= JK_PLACE_DRAWS && sb->w[0].measure; ++round) {
+      PartGeom gc = g;
+      gc.nchunks = std::max(1, g.nchunks / 4);
+      sb->w[0].clock_begin(stream0());
+      GDF_TRY(launch_scatter1(fast, narrow, sc_threads, t, plan, gc, nullptr, sb->tuples(0), l6));
+      sb->w[0].clock_end(stream0());
+      HIP_TRY(hipMemsetAsync(spec.p, 0, sizeof(uint32_t) * (nseg + 1), stream0()));
+      RMM_TRY(sb->w[0].alloc_placed(JK_ROLE_LEVEL1, bytes1, JK_PLACE_DRAWS));      // (reset() reports the time; the champion or the next challenger comes back)
+    }
+  }
   sb->w[0].clock_begin(stream0());
   if (pay) GDF_TRY(launch_scatter1_pay(fast, pmode, t, plan, g, nullptr, *pay, sb->tuples(0)));
   else GDF_TRY(launch_scatter1(fast, narrow, sc_threads, t, plan, g, nullptr, sb->tuples(0), l6));

@@ -58,6 +58,7 @@ struct Manager {
     void *champ = nullptr, *chall = nullptr;
     float champ_ms = -1.f;
     int draws = 0;                 // challengers drawn so far
+    int max_draws = 0;             // ... of at most this many (the last caller's word)
     bool busy = false;             // a block of this entry is out with a caller
     std::vector<void *> losers;    // held until the exploration ends: a freed loser's pages would come straight back as the next draw
     unsigned long long stamp = 0;  // last use, for eviction
@@ -180,7 +181,7 @@ rmmError_t pool_free(Manager &m, void *ptr) {
 // it, a physically contiguous range is far worse).  So the pool lets the caller say what a block is FOR (a small integer role) and how
 // long the kernels that scatter into it took (HIP events on the caller's stream):
 //   * the first call of a (role, size) gets a fresh block, the CHAMPION, and reports its time when it gives the block back;
-//   * the next `place_draws` calls each get a CHALLENGER -- a fresh hipMalloc made while the champion (and every earlier loser) is
+//   * the next `place_draws` allocations (or `max_draws`, the caller's own number) each get a CHALLENGER -- a fresh hipMalloc made while the champion (and every earlier loser) is
 //     still held, so that it cannot be the same physical pages -- and the faster of the two stays champion;
 //   * after that the champion serves every call, the losers go back to the runtime, and nothing is measured any more.
 // A caller that repeats a join shape pays a few multi-GB hipMalloc / hipFree pairs (~2 ms each) over its first calls and then runs on
@@ -202,19 +203,21 @@ void place_drop_entry_locked(Manager &m, Manager::Placed &e) {      // (the entr
 bool place_release_idle_locked(Manager &m) {
   bool any = false;
   for (auto it = m.placed.begin(); it != m.placed.end();) {
-    if (!it->losers.empty()) { place_drop_losers(*it); it->draws = m.place_draws; any = true; }      // memory is tight: stop exploring
+    if (!it->losers.empty()) { place_drop_losers(*it); it->draws = 1 << 20; any = true; }      // memory is tight: stop exploring
     if (!it->busy) { if (it->champ) any = true; place_drop_entry_locked(m, *it); it = m.placed.erase(it); }
     else ++it;
   }
   return any;
 }
 
-rmmError_t place_alloc(Manager &m, int role, size_t size, void **ptr, int *measure) {
+rmmError_t place_alloc(Manager &m, int role, size_t size, int max_draws, void **ptr, int *measure) {
   *measure = 0;
   const size_t want = round_size(size);
   {
     std::lock_guard<std::mutex> g(m.mu);
     if (pool_mode(m) && want >= PLACE_MIN && m.place_draws >= 0) {
+      // (a caller that calibrates candidates inside ONE call can afford more of them than one that spends a call on each)
+      const int draws = m.place_draws == 0 ? 0 : (max_draws > 0 ? std::min(max_draws, 16) : m.place_draws);
       Manager::Placed *e = nullptr;
       for (auto &x : m.placed) if (x.role == role && x.want == want) e = &x;
       if (!e) {
@@ -246,13 +249,15 @@ rmmError_t place_alloc(Manager &m, int role, size_t size, void **ptr, int *measu
           e->champ_ms = -1.f;
           e->draws = 0;
           e->busy = true;
+          e->max_draws = draws;
           *ptr = p;
-          *measure = m.place_draws > 0;
+          *measure = draws > 0;
           return RMM_SUCCESS;
         }
         m.placed_idle_bytes -= e->want;
         e->busy = true;
-        if (e->champ_ms > 0.f && e->draws < m.place_draws) {        // a challenger, drawn while the champion is held
+        e->max_draws = draws;
+        if (e->champ_ms > 0.f && e->draws < draws) {        // a challenger, drawn while the champion is held
           void *p = nullptr;
           if (hipMalloc(&p, want) == hipSuccess) {
             e->chall = p;
@@ -263,11 +268,11 @@ rmmError_t place_alloc(Manager &m, int role, size_t size, void **ptr, int *measu
             return RMM_SUCCESS;
           }
           (void)hipGetLastError();
-          e->draws = m.place_draws;                                 // no room for a second block of this size: settle
+          e->draws = draws;                                         // no room for a second block of this size: settle
           place_drop_losers(*e);
         }
         *ptr = e->champ;
-        *measure = e->champ_ms <= 0.f && m.place_draws > 0;          // (a champion whose first call could not be timed)
+        *measure = e->champ_ms <= 0.f && draws > 0;                  // (a champion whose first call could not be timed)
         return RMM_SUCCESS;
       }
     }
@@ -301,7 +306,7 @@ rmmError_t place_free(Manager &m, int role, void *ptr, float ms) {
       } else if (ms > 0.f && e.champ_ms <= 0.f) {
         e.champ_ms = ms;        // FIRST-use time against first-use time: a challenger is only ever measured on its first call
       }
-      if (e.draws >= m.place_draws) place_drop_losers(e);
+      if (e.draws >= e.max_draws) place_drop_losers(e);
       e.busy = false;
       m.placed_idle_bytes += e.want;
       return RMM_SUCCESS;
@@ -361,12 +366,12 @@ __attribute__((visibility("default"))) void gdf_amd_rmm_contiguous(int on) { __a
 
 // Placed blocks (see place_alloc): what libgdf.so allocates its multi-GB regroup scratch through.  `measure` tells the caller whether
 // the pool wants to hear, on gdf_amd_rmm_place_free, how many milliseconds the kernels that scatter into the block took (< 0: unknown).
-__attribute__((visibility("default"))) rmmError_t gdf_amd_rmm_place_alloc(int role, size_t size, void **ptr, int *measure) {
+__attribute__((visibility("default"))) rmmError_t gdf_amd_rmm_place_alloc(int role, size_t size, int max_draws, void **ptr, int *measure) {
   return rmm_guarded([&]() -> rmmError_t {
   if (!ptr || !measure) return RMM_ERROR_INVALID_ARGUMENT;
   Manager &m = Manager::get();
   LogScope log(m, 0, nullptr, size, nullptr);
-  const rmmError_t r = place_alloc(m, role, size ? size : 1, ptr, measure);
+  const rmmError_t r = place_alloc(m, role, size ? size : 1, max_draws, ptr, measure);
   if (r == RMM_SUCCESS) log.ptr = *ptr;
   return r;
   });
@@ -403,7 +408,7 @@ __attribute__((visibility("default"))) void gdf_amd_rmm_place_stats(unsigned lon
   out[1] = m.place_promoted;
   out[2] = m.placed.size();
   out[3] = 0;
-  for (auto &e : m.placed) out[3] += e.draws < m.place_draws;
+  for (auto &e : m.placed) out[3] += e.draws < e.max_draws;
 }
 
 rmmError_t rmmInitialize(rmmOptions_t *options) {

@@ -828,6 +828,8 @@ def planned_inner_join(probe_keys, build_keys, group=None, shuffle_kw=None, broa
 def distributed_group_by_sum(keys, values, group_fn=None, partition_fn=_device_partition, group=None):
     """Group-by-sum of a row-sharded (key, value) relation: local pre-aggregation, exchange of the partial
     aggregates by key hash (far fewer rows than the input), final aggregation on the owner rank."""
+    if group_fn is None and partition_fn is _device_partition and keys.is_cuda:
+        return distributed_group_by("sum", keys, values, group=group)          # the C entry point
     if group_fn is None:
         def group_fn(k, v):
             from . import api
@@ -865,6 +867,13 @@ def distributed_group_by(op, keys, values, group_fn=_device_group, partition_fn=
     every rank pre-aggregates its shard, the partial aggregates travel to the rank ``hash(key) % world`` owns, and are
     combined there -- partial sums / minima / maxima by the same operator, partial counts by a sum, AVG as the quotient of
     the combined sums and counts (a float64 column).  Returns this rank's groups: (keys, aggregates)."""
+    if group_fn is _device_group and partition_fn is _device_partition and keys.is_cuda:
+        # the product path: ONE C call (gdf_amd_dist_group_by, include/gdf/gdf_amd_ext.h; csrc/dist_ops.hip) pre-aggregates,
+        # partitions, exchanges over the group's gdf_amd_transport and combines; what follows is the same protocol in Python, kept
+        # as its executable specification for the CPU tests (tests/test_multigpu_gloo.py: numpy stand-ins for the device steps)
+        from . import api
+        from .columns import Column
+        return api.dist_group_by(op, Column(keys), Column(values), transport_for(group))
     if op in ("sum", "min", "max"):
         k1, v1 = group_fn(op, keys, values)
         k2, v2, _ = exchange_by_key(k1, v1, partition_fn, group)

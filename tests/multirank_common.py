@@ -241,3 +241,79 @@ def check_uneven(world, results):
                 np.testing.assert_array_equal(v[o], exp_col.values)
             else:
                 np.testing.assert_allclose(v[o], exp_col.values, rtol=1e-6 if name == "float32" else 1e-12)
+
+
+
+# ---- C4's fan-out: world 8 ----
+def _world8_shards(world):
+    """A reduced C4 shape: ~8 : 1 probe : build rows per rank over one global key space, UNEVEN shards, rank 5 holds nothing at all,
+    a tenth of the probe keys miss.  Second probe set: rank 2's keys are skewed (one key holds a third of its rows) -- the fused path
+    must decline ON EVERY RANK and the key shuffle take over."""
+    rs = np.random.RandomState(88)
+    space = 400_000
+    keys = rs.permutation(space)[: 8 * 40_000].astype(np.int64) + (3 << 33)
+    cuts = np.sort(rs.choice(np.arange(1, len(keys)), size=world - 2, replace=False))
+    pieces = np.split(keys, cuts)                                  # world - 1 uneven pieces ...
+    builds = pieces[:5] + [keys[:0]] + pieces[5:]                  # ... and nothing on rank 5
+    sizes = [int(300_000 * f) for f in (1.0, 0.4, 1.3, 0.9, 1.1, 0.0, 0.7, 1.2)][:world]
+    probes = [(rs.randint(0, space + space // 10, size=n) + (3 << 33)).astype(np.int64) for n in sizes]
+    skewed = [p.copy() for p in probes]
+    hot = rs.rand(len(skewed[2])) < 0.34
+    skewed[2][hot] = keys[7]
+    return probes, builds, skewed
+
+
+def _world8_worker(rank, world, port, q, backend="gloo"):
+    _init(rank, world, port, backend)
+    from libgdf_amd import multigpu
+    dev = torch.device("cuda", torch.cuda.current_device())
+    probes, builds, skewed = _world8_shards(world)
+    b = torch.from_numpy(builds[rank]).to(dev)
+    out = {}
+    for name, shard in (("uniform", probes[rank]), ("skewed", skewed[rank])):
+        p = torch.from_numpy(shard).to(dev)
+        fpairs = multigpu.fused_inner_join(p, b, chunks=4)          # gdf_amd_dist_inner_join: one C call per rank
+        declined = fpairs is None
+        if declined:                                               # ON ALL RANKS: the shuffle, collectively
+            fpairs = multigpu.distributed_inner_join(p, b, chunks=2)
+        pg, bg = fpairs.global_ids()
+        out[name] = (declined, pg.cpu().numpy(), bg.cpu().numpy())
+    # gdf_amd_dist_group_by through the same transport at fan-out 8 (the empty rank takes part in every collective)
+    p = torch.from_numpy(probes[rank]).to(dev)
+    for op in ("sum", "count", "avg", "min"):
+        gk, gv = multigpu.distributed_group_by(op, p % 5000, p)
+        out[op] = (gk.cpu().numpy(), gv.cpu().numpy())
+    q.put((rank, out))
+    dist.barrier()
+    multigpu.close_transports()
+    dist.destroy_process_group()
+
+
+def check_world8(world, results):
+    from oracle import oracle
+    probes, builds, skewed = _world8_shards(world)
+    gb = np.concatenate([(r << 40) + np.arange(len(builds[r]), dtype=np.int64) for r in range(world)])
+    results = [r[1] for r in sorted(results, key=lambda x: x[0])]
+    for name, shards, must_decline in (("uniform", probes, False), ("skewed", skewed, True)):
+        flags = [res[name][0] for res in results]
+        assert all(flags) or not any(flags), flags                   # a result or a decline, on ALL ranks
+        assert flags[0] == must_decline, (name, flags)
+        gp = np.concatenate([(r << 40) + np.arange(len(shards[r]), dtype=np.int64) for r in range(world)])
+        li, ri = oracle.join([np.concatenate(shards)], [np.concatenate(builds)], "inner")
+        exp = np.stack([gp[li], gb[ri]], axis=1)
+        got = np.concatenate([np.stack([res[name][1], res[name][2]], axis=1) for res in results])
+        np.testing.assert_array_equal(got[np.lexsort(got.T[::-1])], exp[np.lexsort(exp.T[::-1])])
+    import pandas as pd
+    allp = np.concatenate(probes)
+    ref = pd.DataFrame({"k": allp % 5000, "v": allp}).groupby("k")["v"]
+    for op, exp_col in (("sum", ref.sum()), ("count", ref.count()), ("avg", ref.mean()), ("min", ref.min())):
+        k = np.concatenate([res[op][0] for res in results])
+        v = np.concatenate([res[op][1] for res in results])
+        o = np.argsort(k, kind="stable")
+        np.testing.assert_array_equal(k[o], exp_col.index.values)    # every group on exactly one rank
+        if op == "avg":
+            np.testing.assert_allclose(v[o], exp_col.values, rtol=1e-12)
+        else:
+            np.testing.assert_array_equal(v[o], exp_col.values)
+        for res in results:                                          # a rank's groups come out sorted by key
+            assert bool((np.diff(res[op][0]) > 0).all())

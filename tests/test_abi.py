@@ -70,6 +70,113 @@ def test_reference_function_list_is_covered(libs):
     assert not missing, missing
 
 
+_BASE_TYPES = {"void", "char", "short", "int", "long", "float", "double", "signed", "unsigned", "const", "struct", "enum", "_Bool", "bool",
+               "size_t", "int8_t", "int16_t", "int32_t", "int64_t", "uint8_t", "uint16_t", "uint32_t", "uint64_t"}
+
+
+def _prototypes(header, include_dirs):
+    """{function name: (return type, (parameter types...))} of every prototype a header declares after `gcc -E` -- parameter NAMES
+    dropped, array parameters decayed to pointers, `()` and `(void)` alike, qualifiers kept."""
+    args = ["gcc", "-E", "-P", "-x", "c"]
+    for d in include_dirs:
+        args += ["-I", d]
+    src = subprocess.check_output(args + [header]).decode()
+    src = re.sub(r"__attribute__ ?\(\(.*?\)\)", " ", src)
+    src = re.sub(r"#pragma[^\n]*", " ", src)
+    src = re.sub(r"\s+", " ", src)
+    types = set(_BASE_TYPES)
+    types |= set(re.findall(r"\btypedef [^;{}]*?\b([A-Za-z_]\w*) ?;", src))                # typedef T name;
+    types |= set(re.findall(r"\} ?([A-Za-z_]\w*) ?;", src))                               # typedef struct / enum { ... } name;
+    types |= set(re.findall(r"\b(?:struct|enum) ([A-Za-z_]\w*)", src))
+
+    def norm(decl, is_param):
+        decl = decl.strip()
+        ptr_extra = decl.count("[")
+        decl = re.sub(r"\[[^\]]*\]", " ", decl)
+        toks = re.findall(r"[A-Za-z_]\w*|\*", decl)
+        if is_param and len(toks) >= 2 and toks[-1] != "*" and toks[-1] not in types:
+            toks = toks[:-1]                                                               # the parameter's name
+        return " ".join(toks + ["*"] * ptr_extra)
+    out = {}
+    for m in re.finditer(r"([A-Za-z_][\w \*]*?[ \*])([A-Za-z_]\w*) ?\(([^()]*)\) ?;", src):
+        ret, name, params = m.group(1), m.group(2), m.group(3)
+        if name.startswith("__") or "typedef" in ret:
+            continue
+        ps = [norm(q, True) for q in params.split(",")] if params.strip() not in ("", "void") else []
+        out[name] = (norm(ret, False), tuple(ps))
+    return out
+
+
+def test_reference_prototypes_match_type_for_type():
+    """not only the NAMES -- return type and every parameter type of every function the reference's cffi headers
+    declare (include/gdf/cffi/functions.h:1-785, io_functions.h, with types.h / io_types.h / convert_types.h for the typedefs) must be
+    what include/gdf/gdf.h declares.  Both sides go through `gcc -E`; skipped where the reference tree is absent (the GPU box)."""
+    ref_inc = "/root/reference/libgdf/include"
+    if not os.path.isdir(os.path.join(ref_inc, "gdf", "cffi")):
+        pytest.skip("reference tree not present on this machine")
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        # the reference's gdf.h is C++; its five cffi headers are plain C, read in the order libgdf_cffi/libgdf_build.py:6 cdefs them
+        tu = os.path.join(d, "ref.h")
+        open(tu, "w").write("#include <stddef.h>\n#include <stdint.h>\n#include <stdbool.h>\n" + "".join(
+            f'#include "gdf/cffi/{h}"\n' for h in ("types.h", "convert_types.h", "functions.h", "io_types.h", "io_functions.h")))
+        ref = _prototypes(tu, [ref_inc])
+    ours = _prototypes(os.path.join(ROOT, "include", "gdf", "gdf.h"), [os.path.join(ROOT, "include")])
+    ref = {k: v for k, v in ref.items() if re.match(r"(gdf|gpu)_|read_csv$|get_column_byte_width$", k)}
+    assert len(ref) > 280, len(ref)
+    missing = sorted(set(ref) - set(ours))
+    assert not missing, missing
+    different = {k: (ref[k], ours[k]) for k in ref if ref[k] != ours[k]}
+    assert not different, different
+
+
+def test_reference_struct_and_enum_definitions_match():
+    """gdf_column / gdf_context member types and order, and every enumerator's VALUE (types.h:15-195), against the reference's own
+    headers: both compiled by gcc into a table of offsets / sizes / values and compared."""
+    ref_inc = "/root/reference/libgdf/include"
+    if not os.path.isdir(os.path.join(ref_inc, "gdf", "cffi")):
+        pytest.skip("reference tree not present on this machine")
+    import tempfile
+    prog = r"""
+#include <stdio.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdbool.h>
+#ifdef REF
+#include "gdf/cffi/types.h"
+#include "gdf/cffi/convert_types.h"
+#include "gdf/cffi/functions.h"
+#include "gdf/cffi/io_types.h"
+#include "gdf/cffi/io_functions.h"
+#else
+#include <gdf/gdf.h>
+#endif
+int main(void) {
+  printf("column %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(gdf_column), offsetof(gdf_column, data), offsetof(gdf_column, valid), offsetof(gdf_column, size),
+         offsetof(gdf_column, dtype), offsetof(gdf_column, null_count), offsetof(gdf_column, dtype_info), offsetof(gdf_column, col_name));
+  printf("context %zu %zu %zu %zu %zu %zu\n", sizeof(gdf_context), offsetof(gdf_context, flag_sorted), offsetof(gdf_context, flag_method),
+         offsetof(gdf_context, flag_distinct), offsetof(gdf_context, flag_sort_result), offsetof(gdf_context, flag_sort_inplace));
+  printf("dtype %d %d %d %d %d %d %d %d %d %d %d %d %d\n", GDF_invalid, GDF_INT8, GDF_INT16, GDF_INT32, GDF_INT64, GDF_FLOAT32, GDF_FLOAT64, GDF_DATE32,
+         GDF_DATE64, GDF_TIMESTAMP, GDF_CATEGORY, GDF_STRING, N_GDF_TYPES);
+  printf("error %d %d %d %d %d %d %d %d\n", GDF_SUCCESS, GDF_CUDA_ERROR, GDF_UNSUPPORTED_DTYPE, GDF_COLUMN_SIZE_MISMATCH, GDF_COLUMN_SIZE_TOO_BIG,
+         GDF_DATASET_EMPTY, GDF_VALIDITY_UNSUPPORTED, GDF_UNSUPPORTED_METHOD);
+  printf("misc %d %d %d %d %d %d %d %d %d %d\n", GDF_HASH_MURMUR3, GDF_HASH_IDENTITY, GDF_SORT, GDF_HASH, GDF_SUM, GDF_MIN, GDF_MAX, GDF_AVG, GDF_COUNT,
+         GDF_COUNT_DISTINCT);
+  printf("cmp %d %d %d %d %d %d %zu %zu\n", GDF_EQUALS, GDF_NOT_EQUALS, GDF_LESS_THAN, GDF_LESS_THAN_OR_EQUALS, GDF_GREATER_THAN, GDF_GREATER_THAN_OR_EQUALS,
+         sizeof(gdf_size_type), sizeof(gdf_dtype_extra_info));
+  return 0;
+}
+"""
+    outs = []
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(prog)
+        for inc in (ref_inc, os.path.join(ROOT, "include")):
+            exe = os.path.join(d, "t")
+            subprocess.check_call(["gcc", "-I", inc, *(["-DREF"] if inc == ref_inc else []), os.path.join(d, "t.c"), "-o", exe])
+            outs.append(subprocess.check_output([exe]).decode())
+    assert outs[0] == outs[1], outs
+
+
 def test_struct_layout(libs):
     gdf, _ = libs
     from libgdf_amd._binding import gdf_column, gdf_context

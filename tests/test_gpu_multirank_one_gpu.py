@@ -16,7 +16,7 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 
-from multirank_common import _free_port, _uneven_worker, _worker, check_join_and_group_by, check_uneven
+from multirank_common import _free_port, _uneven_worker, _worker, _world8_worker, check_join_and_group_by, check_uneven, check_world8
 
 
 def _run_ranks(target, world, extra):
@@ -45,3 +45,12 @@ def test_uneven_shards_and_narrow_value_dtypes():
     COUNTs are int64 and the partial SUMs of an AVG are widened, so int8 / int32 / float32 value columns aggregate like
     the single-GPU call; (medium) probe keys outside the build range stay home instead of piling up on one rank."""
     check_uneven(3, _run_ranks(_uneven_worker, 3, ()))
+
+
+@pytest.mark.timeout(900)
+def test_world_8_fused_join_decline_fallback_and_group_by():
+    """C4's fan-out on one GPU: eight ranks (processes sharing cuda:0, the callback wire over gloo) run
+    gdf_amd_dist_inner_join on a reduced C4 shape with uneven shards and one rank that holds nothing; a second probe relation with one
+    skewed rank makes the C call decline -- on every rank -- and the key shuffle answers instead; gdf_amd_dist_group_by (sum, count,
+    avg, min) runs over the same transport.  All against the oracle / pandas over the concatenated shards."""
+    check_world8(8, _run_ranks(_world8_worker, 8, ()))

@@ -211,6 +211,40 @@ def test_errors_and_empty(gdf):
     assert gdf.api.order_by(_cols([np.zeros(0, dtype=np.int64)])).numel() == 0
 
 
+@pytest.mark.parametrize("method", ["sort", "hash"])
+def test_mismatched_key_column_sizes_are_an_error_not_a_read_out_of_bounds(gdf, method):
+    """the SORT method's direct-path shortcut entered the hash method's code in front of group_by_sort's argument
+    checks -- a second key column SHORTER than the first was read out of bounds.  Both methods now answer GDF_COLUMN_SIZE_MISMATCH
+    (sort.hip group_by_sort / the reference's gdf_table asserts equal sizes, gdf_table.cuh:249-322), for key columns and for an
+    aggregation column of another size; and the SORT method's shortcut leaves the caller's output validity masks untouched."""
+    import ctypes as C
+    import torch
+    from libgdf_amd import GDFError
+    from libgdf_amd.columns import GDF_HASH, GDF_SORT, Column, column_array, column_from_numpy, new_context
+    m = GDF_SORT if method == "sort" else GDF_HASH
+    rs = np.random.RandomState(3)
+    n = 50_000
+    k0, k1 = rs.randint(0, 50, size=n).astype(np.int64), rs.randint(0, 20, size=n // 2).astype(np.int64)
+    v = rs.randint(-9, 9, size=n).astype(np.int64)
+    with pytest.raises(GDFError, match="GDF_COLUMN_SIZE_MISMATCH"):
+        gdf.api.group_by("sum", [column_from_numpy(k0), column_from_numpy(k1)], column_from_numpy(v), method=m, capacity=n)
+    with pytest.raises(GDFError, match="GDF_COLUMN_SIZE_MISMATCH"):
+        gdf.api.group_by("sum", [column_from_numpy(k0)], column_from_numpy(v[: n // 3]), method=m, capacity=n)
+    if method == "sort":
+        # the shortcut must not write validity masks the sort itself never touches: poison them and look afterwards
+        kc, vc = column_from_numpy(k0), column_from_numpy(v)
+        poison = lambda: torch.full((n // 8 + 64,), 0x5A, dtype=torch.uint8, device="cuda")
+        ok = Column(torch.empty(n, dtype=torch.int64, device="cuda"), poison(), 4, size=n)
+        oa = Column(torch.empty(n, dtype=torch.int64, device="cuda"), poison(), 4, size=n)
+        ctx = new_context(method=GDF_SORT)
+        gdf.libgdf.gdf_group_by_sum(1, column_array([kc]), vc.ptr, None, column_array([ok]), oa.ptr, C.byref(ctx))
+        assert int(oa.size) == 50
+        assert bool((ok.valid == 0x5A).all()) and bool((oa.valid == 0x5A).all())
+        ek, ea = oracle.group_by("sum", [k0], v)
+        np.testing.assert_array_equal(ok.data[:50].cpu().numpy(), ek[0])
+        np.testing.assert_array_equal(oa.data[:50].cpu().numpy(), ea)
+
+
 def test_large_sort_properties(gdf):
     """1e7 rows: sortedness, permutation and checksum properties (size-independent), plus SORT == HASH aggregates."""
     import torch

@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """BASELINE config C5: multi-key gdf_group_by_avg, fp64 values with a 50 %-null validity mask,
 keys k0 int64 Zipf(s=1) over 1e6 values x k1 int32 uniform [0,16), through the C ABI with inputs resident in HBM.
-Algorithmic bytes = N * (8 + 4 + 8) + N / 8 (value mask).  Checks size-independent properties of the result
-(group count, sum of counts, sum of avg * count) against torch reductions over the same inputs.
+Algorithmic bytes = N * (8 + 4 + 8) + N / 8 (value mask).  Checks the result PER GROUP against a torch fp64 scatter_add_ / bincount
+over the dense key space (keys, exact counts, averages within 1e-6) next to the size-independent totals.
 --null-keys P: the variant with P (1 %) NULL KEYS -- a validity mask on key column 0; a row with a null key belongs
 to no group (the reference rejects masks altogether, sqls_ops.cu:1103-1106; semantics of DESIGN.md section 4).
 Usage: python tools/bench_c5.py [--rows N] [--reps R] [--null-keys P]"""
@@ -101,9 +101,44 @@ def c5_property_checks(gdf, k0, k1, v, ok, mask, cap, kok=None, kmask=None):
     total = float((avg.double() * cnt_sorted.double()).sum().item())
     expect = float(v[ok].sum().item())
     checks["sum_avg_times_count_rel_err"] = abs(total - expect) / expect
+    # PER GROUP (totals alone would let two groups swap their sums): the key space is dense -- pk = k0 * 16 + k1
+    # below 16 * max(k0) + 16 -- so a torch fp64 scatter_add_ / bincount over pk is an independent per-group reference at any size:
+    # every group's key present, its count EXACT, its average within 1e-6 relative (north_star's fp tolerance; measured ~1e-13).
+    span = int(k0.max().item()) * 16 + 16
+    ref_sum = torch.zeros(span, dtype=torch.float64, device=k0.device)
+    ref_cnt = torch.zeros(span, dtype=torch.int64, device=k0.device)
+    ref_rows = torch.zeros(span, dtype=torch.int64, device=k0.device)
+    step = 1 << 27
+    for s in range(0, k0.numel(), step):
+        pk = k0[s:s + step] * 16 + k1[s:s + step].long()
+        okc = ok[s:s + step]
+        ref_rows += torch.bincount(pk, minlength=span)
+        pkv = pk[okc]
+        ref_cnt += torch.bincount(pkv, minlength=span)
+        ref_sum.scatter_add_(0, pkv, v[s:s + step][okc])
+        del pk, pkv, okc
+    ref_keys = torch.nonzero(ref_rows > 0).flatten()
+    same_groups = bool(ref_keys.numel() == pk_avg.numel() and torch.equal(ref_keys, pk_avg))
+    checks["per_group_keys_match"] = same_groups
+    if same_groups:
+        want_cnt = ref_cnt[pk_avg]
+        checks["per_group_counts_exact"] = bool(torch.equal(want_cnt, cnt_sorted.long()))
+        live = want_cnt > 0
+        checks["per_group_avg_max_rel_err"] = 0.0
+        if bool(live.any().item()):
+            want_avg = ref_sum[pk_avg][live] / want_cnt[live].double()
+            checks["per_group_avg_max_rel_err"] = float(((avg.double()[live] - want_avg).abs() / want_avg.abs().clamp_min(1e-300)).max().item())
+        checks["per_group_null_avg_is_zero"] = bool((avg.double()[~live] == 0).all().item())
+    else:
+        checks["per_group_counts_exact"] = False
+        checks["per_group_avg_max_rel_err"] = float("inf")
+        checks["per_group_null_avg_is_zero"] = False
+    del ref_sum, ref_cnt, ref_rows
     good = (checks["groups"] == checks["groups_expected"] and checks["avg_keys_sorted"] and checks["same_keys_avg_and_count"]
             and checks["sum_of_counts"] == checks["valid_values"] and checks["null_iff_zero_count"]
-            and checks["sum_avg_times_count_rel_err"] < 1e-9)
+            and checks["sum_avg_times_count_rel_err"] < 1e-9
+            and checks["per_group_keys_match"] and checks["per_group_counts_exact"] and checks["per_group_avg_max_rel_err"] < 1e-6
+            and checks["per_group_null_avg_is_zero"])
     return checks, good
 
 

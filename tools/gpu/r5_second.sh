@@ -1,0 +1,23 @@
+# round 5, second GPU call: placement tournament (in-call calibration of the level-1 buffer), C2 A/B against the round-4 tree, new tests
+set -x
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r5_b
+mkdir -p $O
+cd $R
+for i in 1 2 3; do
+  python tools/gpu/r5_place.py 4 > $O/place_trace_$i.json 2>$O/place_trace_$i.err; python -c "
+import json; d=json.load(open('$O/place_trace_$i.json')); print(d['first_calls_wall_ms'], d['settled_ms_per_join'], d['ms']); print('\n'.join(d['trace'][:24]))"
+done
+B="python bench.py --steps 10 --warmup 6 --cpu-sample 0 --pandas-sample 0 --extra 0"
+for i in 1 2 3; do
+  for d in 0 4; do
+    $B --place-draws $d 2>/dev/null | grep '^{' | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(json.dumps({'draws': $d, 'ms_per_step': d['ms_per_step'], 'kernels_ms_per_step': d['kernels_ms_per_step'], 'placement': d.get('placement')}))" >> $O/place_ab.jsonl
+  done
+done
+cut -c1-330 $O/place_ab.jsonl
+for i in 1 2 3; do
+  (cd $R/.ab_r4 && python tools/bench_ops.py --ops groupby 2>/dev/null | head -1 | cut -c1-400) >> $O/c2_ab_r4.jsonl
+  python tools/bench_ops.py --ops groupby 2>/dev/null | head -1 | cut -c1-400 >> $O/c2_ab_r5.jsonl
+done
+cat $O/c2_ab_r4.jsonl $O/c2_ab_r5.jsonl
+timeout 1500 python -m pytest tests/test_gpu_multirank_one_gpu.py tests/test_gpu_sort.py tests/test_gpu_fused_join.py tests/test_gpu_rmm.py -m gpu -q -x --durations=15 > $O/pytest_subset.txt 2>&1; tail -25 $O/pytest_subset.txt

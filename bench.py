@@ -590,6 +590,19 @@ def main():
                             "avg_launch_ms": per_launch_ms, "launches_per_step": launches_per_step}
         return roofline
 
+    comm_ranks = None
+    if distributed:
+        try:
+            tr = multigpu.transport_for(None)
+            n_comm, r_comm = tr.communicator_ranks() if hasattr(tr, "communicator_ranks") else (None, None)
+            seen = torch.tensor([n_comm if n_comm is not None else -1, -(n_comm if n_comm is not None else -1),
+                                 1 if r_comm == rank else 0], dtype=torch.int64, device=dev)
+            if world > 1:
+                dist.all_reduce(seen, op=dist.ReduceOp.MIN)
+            # min(n) == max(n) on all ranks and every rank's communicator rank is its RANK: one number; else what was seen
+            comm_ranks = int(seen[0]) if (int(seen[0]) == -int(seen[1]) and int(seen[2]) == 1) else {"min": int(seen[0]), "max": -int(seen[1]), "ranks_match": bool(int(seen[2]))}
+        except Exception as e:                     # noqa: BLE001 -- reported in the line
+            comm_ranks = f"{type(e).__name__}: {e}"
     mine = {"rank": rank, "roofline": kernel_roofline(),
             "kernels_ms_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}}
     if distributed:
@@ -642,6 +655,9 @@ def main():
             # planner assumes (a rank reaches each peer over ONE link) -- an estimate, the links cannot be timed from in here
             sent = max(r["exchange_bytes_sent_per_step"] for r in per_rank)
             result["config"]["strategy"] = strategy
+            # how many ranks the collectives really spanned: the library's own RCCL communicator (the transport the fused join talks
+            # through) and torch.distributed's group, each as seen from rank 0 and agreed on by all ranks
+            result["config"]["nranks"] = {"world_size_env": world, "torch_distributed": dist.get_world_size(), "rccl_communicator": comm_ranks}
             result["config"]["strategy_planned"] = planned
             result["config"]["planner_would_pick"] = planner
             if planner_choice is not None:

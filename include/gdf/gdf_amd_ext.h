@@ -204,6 +204,8 @@ gdf_error gdf_amd_dist_group_by_avg(gdf_column *keys, gdf_column *values, gdf_am
 gdf_error gdf_amd_rccl_unique_id(char id[128]);
 gdf_error gdf_amd_rccl_transport_create(const char id[128], int world, int rank, gdf_amd_transport **out);
 void gdf_amd_transport_free(gdf_amd_transport *transport);
+/* the communicator's own answer (ncclCommCount / ncclCommUserRank) for a transport made by gdf_amd_rccl_transport_create */
+gdf_error gdf_amd_rccl_transport_ranks(gdf_amd_transport *transport, int *nranks, int *rank);
 /* synchronous copy on the library's stream for transports that stage blocks through host memory; direction 0: device -> host,
    1: host -> device, 2: device -> device */
 gdf_error gdf_amd_copy(void *dst, const void *src, size_t bytes, int direction);

@@ -135,6 +135,7 @@ _PROTOTYPES = {
     "gdf_amd_dist_group_by": (None, [C.c_int, _COLP, _COLP, C.c_void_p, _COLP, _COLP]),
     "gdf_amd_rccl_unique_id": (None, [C.c_char_p]),
     "gdf_amd_rccl_transport_create": (None, [C.c_char_p, C.c_int, C.c_int, C.c_void_p]),
+    "gdf_amd_rccl_transport_ranks": (None, [C.c_void_p, _INTP, _INTP]),
     "gdf_amd_transport_free": (C.c_int, [C.c_void_p]),                                        # void in C
     "gdf_amd_copy": (None, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
     "gdf_order_by": (None, [C.c_size_t, _COLP, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),

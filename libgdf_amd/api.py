@@ -417,6 +417,12 @@ class RcclTransport:
     def ptr(self):
         return self._h
 
+    def communicator_ranks(self):
+        """(nranks, rank) as the RCCL communicator itself reports them (ncclCommCount / ncclCommUserRank)"""
+        n, r = C.c_int(0), C.c_int(-1)
+        libgdf.gdf_amd_rccl_transport_ranks(self._h, C.byref(n), C.byref(r))
+        return int(n.value), int(r.value)
+
     def close(self):
         if getattr(self, "_h", None):
             libgdf.gdf_amd_transport_free(self._h)

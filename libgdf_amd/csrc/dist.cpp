@@ -29,6 +29,8 @@ struct RcclApi {
   ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
   ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+  ncclResult_t (*CommCount)(const ncclComm_t, int *);
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int *);
   bool ok = false;
 };
 
@@ -49,6 +51,8 @@ const RcclApi &rccl() {
     api.Send = reinterpret_cast<decltype(api.Send)>(sym("ncclSend"));
     api.Recv = reinterpret_cast<decltype(api.Recv)>(sym("ncclRecv"));
     api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
+    api.CommCount = reinterpret_cast<decltype(api.CommCount)>(sym("ncclCommCount"));
+    api.CommUserRank = reinterpret_cast<decltype(api.CommUserRank)>(sym("ncclCommUserRank"));
     api.ok = all;
   });
   return api;
@@ -154,6 +158,19 @@ __attribute__((visibility("default"))) gdf_error gdf_amd_rccl_transport_create(c
     std::memcpy(&u, id, sizeof(u));
     if (rccl().CommInitRank(&c->comm, world, u, rank) != ncclSuccess) { c->comm = nullptr; return fail(GDF_C_ERROR); }
     *out = t;
+    return GDF_SUCCESS;
+  });
+}
+
+// what the RCCL COMMUNICATOR of a transport made by gdf_amd_rccl_transport_create says about itself (ncclCommCount / ncclCommUserRank):
+// bench.py reports these next to WORLD_SIZE, so that a multi-GPU line shows how many ranks the collectives really spanned
+__attribute__((visibility("default"))) gdf_error gdf_amd_rccl_transport_ranks(gdf_amd_transport *transport, int *nranks, int *rank) {
+  return gdf_amd::guarded([&]() -> gdf_error {
+    GDF_REQUIRE(transport && nranks && rank, GDF_DATASET_EMPTY);
+    GDF_REQUIRE(transport->all_to_all == rccl_all_to_all && transport->ctx, GDF_INVALID_API_CALL);      // one of ours
+    RcclCtx *c = static_cast<RcclCtx *>(transport->ctx);
+    GDF_REQUIRE(rccl().ok && c->comm, GDF_UNSUPPORTED_METHOD);
+    GDF_REQUIRE(rccl().CommCount(c->comm, nranks) == ncclSuccess && rccl().CommUserRank(c->comm, rank) == ncclSuccess, GDF_C_ERROR);
     return GDF_SUCCESS;
   });
 }

@@ -2531,7 +2531,8 @@ struct GbJob {
   bool want_ok;     // the caller supplied out_col_agg->valid and groups can come out null
   DevBuf agg_ok;
   std::vector<long long> ranges;   // [2 * ncols] exact min / max per key column when gb_plan_range already took them
-  size_t *sort_indices = nullptr;  // a SORT-method call on the direct path: out_col_indices->data (every group's last row)
+  size_t *sort_indices = nullptr;  // a SORT-method call on the direct path: out_col_indices->data (every group's last row), if asked for
+  bool sort_method = false;        // a SORT-method call on the direct path (with or without out_col_indices)
 };
 
 // Path 1 -- direct index: integer keys with a small value range, no masks.  *done = false: not applicable.
@@ -2637,9 +2638,9 @@ static gdf_error gb_path_direct(GbJob &j, bool *done) {
       for (int c = 0; c < ncols; ++c) out_keys[c]->size = (gdf_size_type)res[0];
       out_agg->size = (gdf_size_type)res[0];
       *done = true;
-      // (a SORT-method call -- sort_indices -- leaves the caller's validity masks alone, as group_by_sort does: that method rejects
+      // (a SORT-method call leaves the caller's validity masks alone, as group_by_sort does: that method rejects
       // masks on the way in, sqls_ops.cu:1103-1106, and never writes one on the way out)
-      if (j.sort_indices) { HIP_TRY(hipStreamSynchronize(stream0())); return GDF_SUCCESS; }
+      if (j.sort_method) { HIP_TRY(hipStreamSynchronize(stream0())); return GDF_SUCCESS; }
       return write_output_masks(ncols, out_keys, out_agg, nullptr, res[0]);          // ids ascend: the output is already sorted
     }
   }
@@ -3446,6 +3447,7 @@ static gdf_error group_by_hash(int ncols, gdf_column **cols, gdf_column *col_agg
   j.out_kind = out_kind;
   j.plan = gb_plan_keys(t);
   if (direct_done) {                 // the SORT method's fast route: the direct path or nothing
+    j.sort_method = true;
     j.val = GbVal{col_agg->data, (int)(op == OP_COUNT ? K_I8 : in_kind), nullptr};
     j.masked = false;
     j.counted = op == OP_AVG;

@@ -552,7 +552,7 @@ template <bool NARROW, int THREADS, bool PAY = false, int ITEMS = JK_SC_ITEMS>
 struct TileLds {
   // + a trash slot: tuples that do not travel are written there.  The 1024-thread level-1 tile also has room for the padding of
   // six-byte tuples (L6: every bin's run is padded to an even length, up to 256 dead tuples per tile)
-  static constexpr int PAD = (THREADS == 1024 && NARROW && !PAY) ? 256 : 0;
+  static constexpr int PAD = (THREADS >= 512 && NARROW && !PAY) ? 256 : 0;
   uint64_t w[THREADS * ITEMS + PAD + 2];
   int32_t idx[NARROW ? 4 : THREADS * ITEMS + 4];
   uint64_t pay[PAY ? THREADS * ITEMS + 2 : 2];            // payload words, regrouped with their tuples
@@ -2958,17 +2958,20 @@ static gdf_error launch_scatter1(int fast, bool narrow, int threads, const KeyTa
                                  const uint32_t *H1off, Tuples out, bool l6 = false) {
   const bool masked = fast != 0 && t.col[0].valid != nullptr;
   if (l6) {                          // six-byte level-1 tuples (L6): NARROW, a FAST key column, the 1024-thread tile, speculative layout
-    if (!(fast && narrow && threads == 1024 && g.cap1 && g.xs == 6 && g.b1 == 8)) return GDF_INVALID_API_CALL;
-#define JK_SC1_L6(F, M)                                                                                                             \
+    if (!(fast && narrow && (threads == 1024 || threads == 512) && g.cap1 && g.xs == 6 && g.b1 == 8)) return GDF_INVALID_API_CALL;
+#define JK_SC1_L6(F, M, T)                                                                                                          \
     do {                                                                                                                            \
-      const size_t lds = sizeof(TileLds<true, 1024>);                                                                               \
-      HIP_TRY(hipFuncSetAttribute((const void *)jk_scatter1<F, true, 1024, M, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-      GDF_LAUNCH("jk_scatter1", (jk_scatter1<F, true, 1024, M, true>), dim3(g.nchunks), dim3(1024), lds, stream0(), t, plan, g, H1off, out); \
+      const size_t lds = sizeof(TileLds<true, T>);                                                                                  \
+      HIP_TRY(hipFuncSetAttribute((const void *)jk_scatter1<F, true, T, M, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      GDF_LAUNCH("jk_scatter1", (jk_scatter1<F, true, T, M, true>), dim3(g.nchunks), dim3(T), lds, stream0(), t, plan, g, H1off, out); \
     } while (0)
-    if (fast == 8 && masked) JK_SC1_L6(8, true);
-    else if (fast == 8) JK_SC1_L6(8, false);
-    else if (masked) JK_SC1_L6(4, true);
-    else JK_SC1_L6(4, false);
+    // (512 threads: TWO workgroups of half-size tiles per CU -- the LAB experiment behind DESIGN 3.8 "a pipelined workgroup": two
+    // independent half-tile pipelines in the LDS of one 1024-thread tile, unmasked 8-byte keys only)
+    if (threads == 512) { if (fast == 8 && !masked) JK_SC1_L6(8, false, 512); else return GDF_INVALID_API_CALL; }
+    else if (fast == 8 && masked) JK_SC1_L6(8, true, 1024);
+    else if (fast == 8) JK_SC1_L6(8, false, 1024);
+    else if (masked) JK_SC1_L6(4, true, 1024);
+    else JK_SC1_L6(4, false, 1024);
 #undef JK_SC1_L6
     HIP_CHECK_LAST();
     return GDF_SUCCESS;
@@ -3280,7 +3283,8 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
   // 1024-thread tile, 256 coarse partitions (24 hash bits left), chunks of exactly 2^17 rows and 64 regions per coarse partition
   // (the row number's bits 17..22), rows below 2^30 - 2^23 (seven explicit high bits, and the all-ones tuple stays free for padding).
   // GDF_JK_FORCE_L6: test switch, small relations too (their few chunks number the regions all the same); GDF_JK_NO_L6: off
-  const bool l6 = want_p6 && defer && !app && narrow && !pay && fast != 0 && sc_threads == 1024 && sc2_threads == 256 && g.b1 == 8 && g.b2 > 0 &&
+  const bool l6_half = sc_threads == 512 && sc_threads_env == 512 && fast == 8 && !t.col[0].valid;      // (LAB: GDF_JK_SC_THREADS=512)
+  const bool l6 = want_p6 && defer && !app && narrow && !pay && fast != 0 && (sc_threads == 1024 || l6_half) && sc2_threads == 256 && g.b1 == 8 && g.b2 > 0 &&
                   chunk == ((int64_t)1 << 17) && n < (((int64_t)1 << 30) - ((int64_t)1 << 23)) && g.row_base == 0 &&
                   (g.xs == 3 || lab::path_on("GDF_JK_FORCE_L6")) && !lab::path_on("GDF_JK_NO_L6");
   if (l6) g.xs = 6;

@@ -59,6 +59,7 @@ struct Manager {
     float champ_ms = -1.f;
     int draws = 0;                 // challengers drawn so far
     int max_draws = 0;             // ... of at most this many (the last caller's word)
+    double explore_ms = 0;         // host time the challengers' hipMalloc calls have cost so far: exploration stops at PLACE_BUDGET_MS
     bool busy = false;             // a block of this entry is out with a caller
     std::vector<void *> losers;    // held until the exploration ends: a freed loser's pages would come straight back as the next draw
     unsigned long long stamp = 0;  // last use, for eviction
@@ -189,6 +190,10 @@ rmmError_t pool_free(Manager &m, void *ptr) {
 // Only in pool mode, only for blocks of PLACE_MIN bytes and more; anything else falls through to the plain pool.
 constexpr size_t PLACE_MIN = size_t(1) << 30;
 constexpr size_t PLACE_MAX_ENTRIES = 6;
+// a fresh multi-GB hipMalloc usually takes ~1 ms, but the driver can take SECONDS for one when it has to wait for memory another
+// process released a moment ago (profiles/r5_b_place_trace_*.json: 1.8 s for nine of them): the search for a better placement ends
+// when its allocations have cost this much
+constexpr double PLACE_BUDGET_MS = 60.0;
 
 void place_drop_losers(Manager::Placed &e) {
   for (void *q : e.losers) (void)hipFree(q);
@@ -259,7 +264,11 @@ rmmError_t place_alloc(Manager &m, int role, size_t size, int max_draws, void **
         e->max_draws = draws;
         if (e->champ_ms > 0.f && e->draws < draws) {        // a challenger, drawn while the champion is held
           void *p = nullptr;
-          if (hipMalloc(&p, want) == hipSuccess) {
+          const auto t0 = std::chrono::steady_clock::now();
+          const hipError_t drawn = hipMalloc(&p, want);
+          e->explore_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+          if (drawn == hipSuccess && e->explore_ms > PLACE_BUDGET_MS) e->draws = draws - 1;      // this one is the last
+          if (drawn == hipSuccess) {
             e->chall = p;
             ++e->draws;
             ++m.place_drawn;
@@ -288,8 +297,8 @@ rmmError_t place_free(Manager &m, int role, void *ptr, float ms) {
       if (e.role != role || !e.busy || (ptr != e.champ && ptr != e.chall)) continue;
       if (m.place_trace.size() < 16384) {
         char line[160];
-        snprintf(line, sizeof line, "role %d MiB %zu %s draw %d ms %.3f champion_ms %.3f\n", role, e.want >> 20, ptr == e.chall ? "challenger" : "champion",
-                 e.draws, ms, e.champ_ms);
+        snprintf(line, sizeof line, "role %d MiB %zu %s draw %d ms %.3f champion_ms %.3f hipMalloc_ms_so_far %.1f\n", role, e.want >> 20,
+                 ptr == e.chall ? "challenger" : "champion", e.draws, ms, e.champ_ms, e.explore_ms);
         m.place_trace += line;
       }
       if (ptr == e.chall) {
@@ -306,7 +315,17 @@ rmmError_t place_free(Manager &m, int role, void *ptr, float ms) {
       } else if (ms > 0.f && e.champ_ms <= 0.f) {
         e.champ_ms = ms;        // FIRST-use time against first-use time: a challenger is only ever measured on its first call
       }
-      if (e.draws >= e.max_draws) place_drop_losers(e);
+      if (e.draws >= e.max_draws && !e.losers.empty()) {
+        const auto t0 = std::chrono::steady_clock::now();
+        const size_t nl = e.losers.size();
+        place_drop_losers(e);
+        if (m.place_trace.size() < 16384) {
+          char line[120];
+          snprintf(line, sizeof line, "role %d settled: %zu losers freed in %.1f ms\n", role, nl,
+                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+          m.place_trace += line;
+        }
+      }
       e.busy = false;
       m.placed_idle_bytes += e.want;
       return RMM_SUCCESS;

@@ -566,6 +566,8 @@ def test_hot_window_is_aggregated_in_the_scatter_kernel(gdf, shape, op, val_dtyp
     whose every value is null come out as null groups."""
     if shape == "hot-groups-all-null" and not masked:
         pytest.skip("needs a value mask")
+    if shape in ("zipf-sorted-input", "uniform", "forced-last-window") and (op, masked) in (("sum", True), ("max", False)):
+        pytest.skip("the same kernels as this shape's other operators (suite time, VERDICT r4 item 8)")
     rs = np.random.RandomState(len(shape) + len(op))
     n = (1 << 22) + 12345
     if shape == "uniform" or shape == "forced-cold-window":
@@ -650,7 +652,8 @@ def test_speculative_record_layout_needs_no_count_pass(gdf, shape, op, val_dtype
     # the ranks inside a (tile, partition) group: plain returning LDS atomics when the sample finds no busy partition among the rows
     # that are ranked, the leader ballots otherwise (gbp_rank_plain / gbp_rank) -- the sample decides by default, both are forced here
     # (one-key: every lane of a wave on ONE counter under the plain atomics)
-    for plain in ("1", "0"):
+    # (forced for the AVG variant of every shape; the other two operators share the ranking code and keep the sample's choice)
+    for plain in (("1", "0") if op == "avg" else ()):
         force_path("GDF_GBP_PLAIN_RANK", plain)
         run()
     force_path("GDF_GBP_PLAIN_RANK", None)

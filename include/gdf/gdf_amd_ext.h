@@ -178,6 +178,20 @@ gdf_error gdf_amd_dist_inner_join(gdf_column *probe_keys, gdf_column *build_keys
                                   uint32_t *probe_pos, uint32_t *build_pos, gdf_column *probe_indices, gdf_column *build_indices,
                                   gdf_amd_dist_info *info, int *declined);
 
+/* The KEY SHUFFLE join behind the C ABI (csrc/dist_ops.hip) -- what all ranks take TOGETHER when gdf_amd_dist_inner_join says
+ * *declined = 1 (keys that do not narrow to 31 bits, skewed keys, a shape outside gdf_amd_fj_plan's range).  COLLECTIVE; any
+ * int32 / int64 key column without a mask, any shard sizes (also none).  Every rank splits (key, local row number) of both
+ * relations by owner rank = Murmur3(key) % world (gdf_amd_shuffle_partition), the partitions travel as equal blocks over
+ * transport->all_to_all (block size and failures agreed by one all-reduce per relation), the owner joins what it received with
+ * gdf_inner_join (src/join/joining.cu:571-653 per rank) and resolves the pairs to GLOBAL row ids:
+ *   out_probe_ids / out_build_ids   library-allocated GDF_INT64 columns (gdf_column_free): (owner rank << 40) | local row of the
+ *                                   probe / build row of every pair this rank produced; every pair of the global join comes out
+ *                                   on exactly one rank, in no particular order.
+ * One exchange per relation, not pipelined: the fallback trades the fused path's overlap for generality.  Local errors travel
+ * into the agreements as in gdf_amd_dist_inner_join. */
+gdf_error gdf_amd_dist_shuffle_join(gdf_column *probe_keys, gdf_column *build_keys, gdf_amd_transport *transport,
+                                    gdf_column *out_probe_ids, gdf_column *out_build_ids);
+
 /* MULTI-GPU GROUP-BY behind the C ABI (csrc/dist_ops.hip; no counterpart in the reference, which is single-GPU -- per rank it
  * composes gdf_group_by_<op>, src/sqls_ops.cu:1426-1487, and gdf_hash_partition, src/hashing.cu:559-654).  COLLECTIVE: every rank
  * of the transport calls it with its row shard of (keys, values) -- one int32 / int64 key column, one numeric value column, no

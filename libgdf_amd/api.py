@@ -502,6 +502,21 @@ def dist_group_by(op: str, keys: Column, values: Column, transport):
     return _take_library_column(ok, tdt[int(ok.dtype)]), _take_library_column(oa, tdt[int(oa.dtype)])
 
 
+def dist_shuffle_join(probe: Column, build: Column, transport):
+    """gdf_amd_dist_shuffle_join (COLLECTIVE): the key-shuffle join behind ONE C call -> (probe ids, build ids), int64 tensors of
+    (owner rank << 40 | local row) for every pair this rank produced."""
+    import torch
+    op, ob = gdf_column(), gdf_column()
+    libgdf.gdf_amd_dist_shuffle_join(probe.ptr, build.ptr, transport.ptr, C.byref(op), C.byref(ob))
+    errs = getattr(transport, "errors", None)
+    if errs:
+        raise errs.pop(0)
+    if not op.data:
+        e = torch.empty(0, dtype=torch.int64, device=probe.data.device)
+        return e, e.clone()
+    return _take_library_column(op, torch.int64), _take_library_column(ob, torch.int64)
+
+
 def dist_inner_join(probe: Column, build: Column, transport, chunks=4):
     """gdf_amd_dist_inner_join -> None when every rank declined (the shape does not fit the fused path), else
     (probe_pos_of_rows, build_pos_of_rows, probe_indices, build_indices, info): the first two say where each LOCAL row's key went

@@ -1,4 +1,5 @@
-// dist_ops.hip -- multi-GPU GROUP-BY behind the C ABI: gdf_amd_dist_group_by[_sum|_min|_max|_count|_avg] (include/gdf/gdf_amd_ext.h).
+// dist_ops.hip -- multi-GPU GROUP-BY and the KEY-SHUFFLE JOIN behind the C ABI: gdf_amd_dist_group_by[_sum|_min|_max|_count|_avg] and
+// gdf_amd_dist_shuffle_join (include/gdf/gdf_amd_ext.h).
 //
 // No counterpart in the reference (single GPU: SURVEY.md section 2 rows 34-35, 8e "Group-by variant"); what it composes per rank is the
 // reference's own operator, gdf_group_by_<op> (src/sqls_ops.cu:1426-1487), and gdf_hash_partition (src/hashing.cu:559-654):
@@ -71,29 +72,17 @@ static gdf_error local_group(gdf_agg_op op, gdf_column *keys, gdf_column *vals, 
   return GDF_SUCCESS;
 }
 
-// columns [0] = key, [1 ..] = partial aggregates, all of `rows` rows: partitioned by owner, exchanged as equal blocks, and the
-// received rows compacted into `out` (same dtypes).  `hard` carries a local error of the caller INTO the agreement and this
+// `part[c]` (ncols columns of `rows` rows) are ALREADY split by destination: rows [offs[r], offs[r + 1]) go to rank r.  The partitions
+// travel as EQUAL blocks (their size -- the largest partition anywhere -- and whether any rank has failed are agreed by one
+// all-reduce) next to one 8-byte count per (sender, receiver); the received rows are compacted into `out` (same dtypes), sender by
+// sender, and got[r] says how many came from rank r.  `hard` carries a local error of the caller INTO the agreement and this
 // function's own local errors out of it: a rank with an error still takes part in every collective (dist_inner_join's rule).
-static gdf_error exchange_by_owner(gdf_amd_transport *tr, int ncols, Col *in, size_t rows, Col *out, gdf_error *hard) {
+static gdf_error exchange_blocks(gdf_amd_transport *tr, int ncols, Col *part, const std::vector<int> &offs, size_t rows, Col *out,
+                                 std::vector<long long> *got_out, gdf_error *hard) {
   const int world = tr->world;
-  auto note = [&](gdf_error e) { if (e != GDF_SUCCESS && *hard == GDF_SUCCESS) *hard = e; return e; };
-  std::vector<int> offs((size_t)world + 1, 0);
-  std::vector<Col> part((size_t)ncols);
-  if (*hard == GDF_SUCCESS && rows > 0) {
-    std::vector<gdf_column *> pin((size_t)ncols), pout((size_t)ncols);
-    for (int c = 0; c < ncols && *hard == GDF_SUCCESS; ++c) {
-      note(part[c].make(rows, in[c].c.dtype));
-      in[c].c.size = (gdf_size_type)rows;
-      pin[c] = &in[c].c;
-      pout[c] = &part[c].c;
-    }
-    int hash_col[1] = {0};
-    if (*hard == GDF_SUCCESS) note(gdf_hash_partition(ncols, pin.data(), hash_col, 1, world, pout.data(), offs.data(), GDF_HASH_MURMUR3));
-  }
-  offs[world] = (int)rows;
   int64_t agree[2] = {0, *hard != GDF_SUCCESS ? 1 : 0};      // {largest partition anywhere, a rank has failed}
   if (*hard == GDF_SUCCESS)
-    for (int r = 0; r < world; ++r) agree[0] = std::max<int64_t>(agree[0], offs[r + 1] - offs[r]);
+    for (int r = 0; r < world; ++r) agree[0] = std::max<int64_t>(agree[0], rows ? offs[r + 1] - offs[r] : 0);
   if (tr->all_reduce_i64(tr->ctx, agree, 2, 1) != 0) return GDF_C_ERROR;
   if (agree[1] != 0) return *hard != GDF_SUCCESS ? *hard : GDF_C_ERROR;
   const size_t blk = (size_t)std::max<int64_t>(agree[0], 1);
@@ -105,15 +94,15 @@ static gdf_error exchange_by_owner(gdf_amd_transport *tr, int ncols, Col *in, si
   for (int r = 0; r < world; ++r) hcnt[r] = rows ? offs[r + 1] - offs[r] : 0;
   bool ok = scnt.alloc(sizeof(long long) * world) == RMM_SUCCESS && rcnt.alloc(sizeof(long long) * world) == RMM_SUCCESS;
   for (int c = 0; c < ncols && ok; ++c) {
-    const size_t w = (size_t)dtype_width(in[c].c.dtype);
+    const size_t w = (size_t)dtype_width(part[c].c.dtype);
     ok = send[c].alloc(w * blk * world) == RMM_SUCCESS && recv[c].alloc(w * blk * world) == RMM_SUCCESS;
   }
-  // (an allocation failure HERE cannot be agreed on without a second all-reduce on every call's happy path; the blocks are the
-  // size of the partial aggregates -- small next to what the local group-by just allocated and released)
+  // (an allocation failure HERE cannot be agreed on without a second all-reduce on every call's happy path; the peers then see
+  // their transport time out, as with any rank that dies inside a collective)
   if (!ok) return GDF_MEMORYMANAGER_ERROR;
   HIP_TRY(hipMemcpyAsync(scnt.p, hcnt.data(), sizeof(long long) * world, hipMemcpyHostToDevice, stream0()));
   for (int c = 0; c < ncols; ++c) {
-    const size_t w = (size_t)dtype_width(in[c].c.dtype);
+    const size_t w = (size_t)dtype_width(part[c].c.dtype);
     for (int r = 0; r < world && rows; ++r) {
       const size_t cnt = (size_t)hcnt[r];
       if (cnt) HIP_TRY(hipMemcpyAsync((char *)send[c].p + w * blk * r, (const char *)part[c].c.data + w * (size_t)offs[r], w * cnt, hipMemcpyDeviceToDevice, stream0()));
@@ -126,7 +115,7 @@ static gdf_error exchange_by_owner(gdf_amd_transport *tr, int ncols, Col *in, si
   if (tr->all_to_all(tr->ctx, scnt.p, rcnt.p, sizeof(long long), &t) != 0) { (void)settle(); return GDF_C_ERROR; }
   tickets.push_back(t);
   for (int c = 0; c < ncols; ++c) {
-    const size_t w = (size_t)dtype_width(in[c].c.dtype);
+    const size_t w = (size_t)dtype_width(part[c].c.dtype);
     t = nullptr;
     if (tr->all_to_all(tr->ctx, send[c].p, recv[c].p, w * blk, &t) != 0) { (void)settle(); return GDF_C_ERROR; }
     tickets.push_back(t);
@@ -139,8 +128,8 @@ static gdf_error exchange_by_owner(gdf_amd_transport *tr, int ncols, Col *in, si
   size_t total = 0;
   for (int r = 0; r < world; ++r) { GDF_REQUIRE(got[r] >= 0 && (size_t)got[r] <= blk, GDF_C_ERROR); total += (size_t)got[r]; }
   for (int c = 0; c < ncols; ++c) {
-    GDF_TRY(out[c].make(total, in[c].c.dtype));
-    const size_t w = (size_t)dtype_width(in[c].c.dtype);
+    GDF_TRY(out[c].make(total, part[c].c.dtype));
+    const size_t w = (size_t)dtype_width(part[c].c.dtype);
     size_t at = 0;
     for (int r = 0; r < world; ++r) {
       if (got[r]) HIP_TRY(hipMemcpyAsync((char *)out[c].c.data + w * at, (const char *)recv[c].p + w * blk * r, w * (size_t)got[r], hipMemcpyDeviceToDevice, stream0()));
@@ -148,7 +137,31 @@ static gdf_error exchange_by_owner(gdf_amd_transport *tr, int ncols, Col *in, si
     }
   }
   HIP_TRY(hipStreamSynchronize(stream0()));         // the receive buffers go out of scope with this function
+  if (got_out) *got_out = got;
   return GDF_SUCCESS;
+}
+
+// columns [0] = key, [1 ..] = partial aggregates, all of `rows` rows: split by owner rank = Murmur3(key) % world (gdf_hash_partition)
+// and exchanged (exchange_blocks)
+static gdf_error exchange_by_owner(gdf_amd_transport *tr, int ncols, Col *in, size_t rows, Col *out, gdf_error *hard) {
+  const int world = tr->world;
+  auto note = [&](gdf_error e) { if (e != GDF_SUCCESS && *hard == GDF_SUCCESS) *hard = e; return e; };
+  std::vector<int> offs((size_t)world + 1, 0);
+  std::vector<Col> part((size_t)ncols);
+  for (int c = 0; c < ncols; ++c) part[c].c.dtype = in[c].c.dtype;
+  if (*hard == GDF_SUCCESS && rows > 0) {
+    std::vector<gdf_column *> pin((size_t)ncols), pout((size_t)ncols);
+    for (int c = 0; c < ncols && *hard == GDF_SUCCESS; ++c) {
+      note(part[c].make(rows, in[c].c.dtype));
+      in[c].c.size = (gdf_size_type)rows;
+      pin[c] = &in[c].c;
+      pout[c] = &part[c].c;
+    }
+    int hash_col[1] = {0};
+    if (*hard == GDF_SUCCESS) note(gdf_hash_partition(ncols, pin.data(), hash_col, 1, world, pout.data(), offs.data(), GDF_HASH_MURMUR3));
+  }
+  offs[world] = (int)rows;
+  return exchange_blocks(tr, ncols, part.data(), offs, *hard == GDF_SUCCESS ? rows : 0, out, nullptr, hard);
 }
 
 static gdf_error widen(gdf_column *vals, Col *out) {
@@ -238,12 +251,105 @@ static gdf_error dist_group_by(gdf_agg_op op, gdf_column *keys, gdf_column *vals
   return GDF_SUCCESS;
 }
 
+
+// ---- the KEY SHUFFLE join behind the C ABI: what every rank falls back to when gdf_amd_dist_inner_join declines ----
+// gid[i] = sender << 40 | row[i] for the rows one sender contributed
+__global__ __launch_bounds__(256) void dg_gids(const int32_t *__restrict__ rows, long long *__restrict__ gid, long long sender, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) gid[i] = (sender << 40) | (long long)(uint32_t)rows[i];
+}
+// pairs of received positions -> pairs of global row ids
+__global__ __launch_bounds__(256) void dg_resolve(const int32_t *__restrict__ li, const int32_t *__restrict__ ri, const long long *__restrict__ pgid,
+                                                  const long long *__restrict__ bgid, long long *__restrict__ out_p, long long *__restrict__ out_b, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) { out_p[i] = pgid[li[i]]; out_b[i] = bgid[ri[i]]; }
+}
+
+// one relation: (key, local row number) split by Murmur3(key) % world (gdf_amd_shuffle_partition), exchanged, and the received
+// rows named by GLOBAL ids (sender rank << 40 | row)
+static gdf_error shuffle_side(gdf_amd_transport *tr, gdf_column *keys, Col *rkeys, Col *rgid, gdf_error *hard) {
+  const int world = tr->world;
+  auto note = [&](gdf_error e) { if (e != GDF_SUCCESS && *hard == GDF_SUCCESS) *hard = e; return e; };
+  const size_t n = *hard == GDF_SUCCESS ? keys->size : 0;
+  std::vector<int> offs((size_t)world + 1, 0);
+  Col part[2], got2[2];
+  part[0].c.dtype = keys->dtype;
+  part[1].c.dtype = GDF_INT32;
+  if (n) {
+    if (note(part[0].make(n, keys->dtype)) == GDF_SUCCESS && note(part[1].make(n, GDF_INT32)) == GDF_SUCCESS)
+      note(gdf_amd_shuffle_partition(keys, 0, 0, 0, 0, world, &part[0].c, &part[1].c, offs.data()));
+  }
+  offs[world] = (int)n;
+  std::vector<long long> got;
+  GDF_TRY(exchange_blocks(tr, 2, part, offs, *hard == GDF_SUCCESS ? n : 0, got2, &got, hard));
+  const size_t total = got2[0].c.size;
+  GDF_TRY(rgid->make(total, GDF_INT64));
+  size_t at = 0;
+  for (int r = 0; r < world; ++r) {
+    const size_t cnt = (size_t)got[r];
+    if (cnt) hipLaunchKernelGGL(dg_gids, dim3(stream_grid(cnt, 256 * 8)), dim3(256), 0, stream0(), (const int32_t *)got2[1].c.data + at,
+                                (long long *)rgid->c.data + at, (long long)r, cnt);
+    at += cnt;
+  }
+  HIP_CHECK_LAST();
+  HIP_TRY(hipStreamSynchronize(stream0()));         // got2[1] goes out of scope
+  rkeys->buf.p = got2[0].buf.release();
+  gdf_column_view(&rkeys->c, rkeys->buf.p, nullptr, (gdf_size_type)total, keys->dtype);
+  return GDF_SUCCESS;
+}
+
+static gdf_error dist_shuffle_join(gdf_column *probe_keys, gdf_column *build_keys, gdf_amd_transport *tr, gdf_column *out_probe, gdf_column *out_build) {
+  GDF_REQUIRE(probe_keys && build_keys && tr && out_probe && out_build, GDF_DATASET_EMPTY);
+  GDF_REQUIRE(tr->all_to_all && tr->wait && tr->all_reduce_i64 && tr->world >= 1 && tr->rank >= 0 && tr->rank < tr->world, GDF_INVALID_API_CALL);
+  gdf_column_view(out_probe, nullptr, nullptr, 0, N_GDF_TYPES);
+  gdf_column_view(out_build, nullptr, nullptr, 0, N_GDF_TYPES);
+  gdf_error hard = GDF_SUCCESS;
+  auto note = [&](gdf_error e) { if (e != GDF_SUCCESS && hard == GDF_SUCCESS) hard = e; return e; };
+  if (probe_keys->valid || build_keys->valid) note(GDF_VALIDITY_UNSUPPORTED);
+  if (probe_keys->dtype != build_keys->dtype) note(GDF_JOIN_DTYPE_MISMATCH);
+  const ElemKind kk = elem_kind(probe_keys->dtype);
+  if (kk != K_I32 && kk != K_I64) note(GDF_UNSUPPORTED_DTYPE);
+  if (probe_keys->size >= (size_t)INT_MAX || build_keys->size >= (size_t)INT_MAX) note(GDF_COLUMN_SIZE_TOO_BIG);
+  if ((probe_keys->size && !probe_keys->data) || (build_keys->size && !build_keys->data)) note(GDF_DATASET_EMPTY);
+  Col bk, bg, pk, pg;
+  GDF_TRY(shuffle_side(tr, build_keys, &bk, &bg, &hard));
+  GDF_TRY(shuffle_side(tr, probe_keys, &pk, &pg, &hard));
+  // what this rank received exceeds the 31-bit positions of a local join (skew, or a world too small for the relation): agreed
+  // on, so that nobody is left behind in a collective
+  int64_t too_big = (pk.c.size >= (size_t)INT_MAX || bk.c.size >= (size_t)INT_MAX) ? 1 : 0;
+  if (tr->all_reduce_i64(tr->ctx, &too_big, 1, 1) != 0) return GDF_C_ERROR;
+  if (too_big) return GDF_COLUMN_SIZE_TOO_BIG;
+  if (pk.c.size == 0 || bk.c.size == 0) return GDF_SUCCESS;
+  gdf_column li, ri;
+  gdf_column_view(&li, nullptr, nullptr, 0, N_GDF_TYPES);
+  gdf_column_view(&ri, nullptr, nullptr, 0, N_GDF_TYPES);
+  gdf_context ctx{0, GDF_HASH, 0, 0, 0};
+  gdf_column *pl[1] = {&pk.c}, *bl[1] = {&bk.c};
+  int on[1] = {0};
+  GDF_TRY(gdf_inner_join(pl, 1, on, bl, 1, on, 1, 0, nullptr, &li, &ri, &ctx));
+  struct Free { gdf_column *c; ~Free() { if (c->data) gdf_column_free(c); } } free_li{&li}, free_ri{&ri};
+  const size_t np = li.size;
+  if (np == 0) return GDF_SUCCESS;
+  Col op, ob;
+  GDF_TRY(op.make(np, GDF_INT64));
+  GDF_TRY(ob.make(np, GDF_INT64));
+  hipLaunchKernelGGL(dg_resolve, dim3(stream_grid(np, 256 * 8)), dim3(256), 0, stream0(), (const int32_t *)li.data, (const int32_t *)ri.data,
+                     (const long long *)pg.c.data, (const long long *)bg.c.data, (long long *)op.c.data, (long long *)ob.c.data, np);
+  HIP_CHECK_LAST();
+  HIP_TRY(hipStreamSynchronize(stream0()));
+  give(&op, np, out_probe);
+  give(&ob, np, out_build);
+  return GDF_SUCCESS;
+}
+
 }  // namespace
 }  // namespace gdf_amd
 
 extern "C" {
 
 #define GDF_AMD_EXPORT __attribute__((visibility("default")))
+GDF_AMD_EXPORT gdf_error gdf_amd_dist_shuffle_join(gdf_column *probe_keys, gdf_column *build_keys, gdf_amd_transport *transport,
+                                                   gdf_column *out_probe_ids, gdf_column *out_build_ids) {
+  return gdf_amd::guarded([&]() -> gdf_error { return gdf_amd::dist_shuffle_join(probe_keys, build_keys, transport, out_probe_ids, out_build_ids); });
+}
 GDF_AMD_EXPORT gdf_error gdf_amd_dist_group_by(gdf_agg_op op, gdf_column *keys, gdf_column *values, gdf_amd_transport *transport,
                                                gdf_column *out_keys, gdf_column *out_agg) {
   return gdf_amd::guarded([&]() -> gdf_error { return gdf_amd::dist_group_by(op, keys, values, transport, out_keys, out_agg); });

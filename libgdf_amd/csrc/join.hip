@@ -325,6 +325,7 @@ constexpr int32_t JK_EMPTY = -1;
 constexpr uint32_t JK_NOPOS = 0xffffffffu;
 constexpr int JK_CUCKOO_MAX_MOVES = 32;
 constexpr int JK_ROLE_LEVEL1 = 1, JK_ROLE_LEVEL2 = 2;      // placed blocks (DevBuf::alloc_placed): the probe side's level-1 / level-2 tuples
+constexpr int JK_ROLE_OUT_PROBE = 3, JK_ROLE_OUT_BUILD = 4; // ... and the two index columns of a large dense join
 constexpr int JK_PLACE_DRAWS = 8;                           // challengers of the level-1 buffer's placement tournament (partition_side_spec)
 
 struct PartGeom {
@@ -552,7 +553,7 @@ template <bool NARROW, int THREADS, bool PAY = false, int ITEMS = JK_SC_ITEMS>
 struct TileLds {
   // + a trash slot: tuples that do not travel are written there.  The 1024-thread level-1 tile also has room for the padding of
   // six-byte tuples (L6: every bin's run is padded to an even length, up to 256 dead tuples per tile)
-  static constexpr int PAD = (THREADS >= 512 && NARROW && !PAY) ? 256 : 0;
+  static constexpr int PAD = (THREADS == 1024 && NARROW && !PAY) ? 256 : 0;
   uint64_t w[THREADS * ITEMS + PAD + 2];
   int32_t idx[NARROW ? 4 : THREADS * ITEMS + 4];
   uint64_t pay[PAY ? THREADS * ITEMS + 2 : 2];            // payload words, regrouped with their tuples
@@ -1190,7 +1191,15 @@ struct Level2Map {                     // small host-built tables, device reside
                                        // jk_make_l2map's permutation of the buffer's sender-major regions -- the coarse partition of
                                        // segment i is (i >> 3) / world
   const uint32_t *keys32;              // non-null: the input is this array of 4-byte keys (a receive buffer), tuple = key << 32 | position
+  uint32_t calib_step;                 // > 1: a CALIBRATION run of the level-2 buffer's placement tournament -- only every calib_step-th tile
+                                       // (of every XCD's eighth) is regrouped, the grid is that much smaller (sc2_grid)
 };
+// grid of a level-2 launch: one workgroup per tile, rounded up to whole rounds over the 8 XCDs; a calibration run takes every
+// calib_step-th tile
+static inline uint32_t sc2_grid(const Level2Map &m, uint32_t ntiles) {
+  const uint32_t tiles = m.calib_step > 1 ? (ntiles + m.calib_step - 1) / m.calib_step : ntiles;
+  return m.xcd_order ? ((tiles + 7) / 8) * 8 : tiles;
+}
 
 // K32: the input is a receive buffer of 4-byte keys (Level2Map::keys32, fused multi-GPU join) -- its own instantiations, so that the
 // single-GPU kernels carry no trace of it
@@ -1212,7 +1221,7 @@ __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, 
   // of its coarse partition -- then shares one L2, which merges the partial first / last lines of neighbouring
   // (tile, bin) runs before they reach HBM (PartGeom::xs has the level-1 half of this)
   const uint32_t per_xcd = gridDim.x >> 3;
-  const uint32_t tile_id = m.xcd_order ? (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
+  const uint32_t tile_id = (m.xcd_order ? (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : blockIdx.x) * (m.calib_step > 1 ? m.calib_step : 1u);
   if (tile_id >= (m.ntiles_dev ? *m.ntiles_dev : m.ntiles)) return;
   uint32_t lo = 0, hi = m.nseg ? m.nseg : (ncoarse << m.xs);
   while (hi - lo > 1) {
@@ -2958,20 +2967,20 @@ static gdf_error launch_scatter1(int fast, bool narrow, int threads, const KeyTa
                                  const uint32_t *H1off, Tuples out, bool l6 = false) {
   const bool masked = fast != 0 && t.col[0].valid != nullptr;
   if (l6) {                          // six-byte level-1 tuples (L6): NARROW, a FAST key column, the 1024-thread tile, speculative layout
-    if (!(fast && narrow && (threads == 1024 || threads == 512) && g.cap1 && g.xs == 6 && g.b1 == 8)) return GDF_INVALID_API_CALL;
-#define JK_SC1_L6(F, M, T)                                                                                                          \
+    // (TWO workgroups of half-size tiles per CU -- what a software-pipelined workgroup, VERDICT r4 item 1, comes down to in 135 KB of
+    // LDS -- were built as a LAB variant in round 5 and lost: jk_scatter1 2.97 - 2.98 against 2.87 - 2.91 ms for C3's probe side in
+    // alternating processes, profiles/r5_c_half_tile_workgroups_ab.jsonl; the variant is gone again)
+    if (!(fast && narrow && threads == 1024 && g.cap1 && g.xs == 6 && g.b1 == 8)) return GDF_INVALID_API_CALL;
+#define JK_SC1_L6(F, M)                                                                                                             \
     do {                                                                                                                            \
-      const size_t lds = sizeof(TileLds<true, T>);                                                                                  \
-      HIP_TRY(hipFuncSetAttribute((const void *)jk_scatter1<F, true, T, M, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-      GDF_LAUNCH("jk_scatter1", (jk_scatter1<F, true, T, M, true>), dim3(g.nchunks), dim3(T), lds, stream0(), t, plan, g, H1off, out); \
+      const size_t lds = sizeof(TileLds<true, 1024>);                                                                               \
+      HIP_TRY(hipFuncSetAttribute((const void *)jk_scatter1<F, true, 1024, M, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      GDF_LAUNCH("jk_scatter1", (jk_scatter1<F, true, 1024, M, true>), dim3(g.nchunks), dim3(1024), lds, stream0(), t, plan, g, H1off, out); \
     } while (0)
-    // (512 threads: TWO workgroups of half-size tiles per CU -- the LAB experiment behind DESIGN 3.8 "a pipelined workgroup": two
-    // independent half-tile pipelines in the LDS of one 1024-thread tile, unmasked 8-byte keys only)
-    if (threads == 512) { if (fast == 8 && !masked) JK_SC1_L6(8, false, 512); else return GDF_INVALID_API_CALL; }
-    else if (fast == 8 && masked) JK_SC1_L6(8, true, 1024);
-    else if (fast == 8) JK_SC1_L6(8, false, 1024);
-    else if (masked) JK_SC1_L6(4, true, 1024);
-    else JK_SC1_L6(4, false, 1024);
+    if (fast == 8 && masked) JK_SC1_L6(8, true);
+    else if (fast == 8) JK_SC1_L6(8, false);
+    else if (masked) JK_SC1_L6(4, true);
+    else JK_SC1_L6(4, false);
 #undef JK_SC1_L6
     HIP_CHECK_LAST();
     return GDF_SUCCESS;
@@ -3002,7 +3011,7 @@ static gdf_error launch_scatter2_t(uint32_t ntiles, const PartGeom &g, Level2Map
   HIP_TRY(hipFuncSetAttribute((const void *)jk_scatter2<NARROW, THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   m.ntiles = ntiles;
   m.xcd_order = (ntiles >= 64 && !lab::path_on("GDF_JK_NO_XCD_ORDER")) ? 1 : 0;
-  const uint32_t grid = m.xcd_order ? ((ntiles + 7) / 8) * 8 : ntiles;
+  const uint32_t grid = sc2_grid(m, ntiles);
   GDF_LAUNCH("jk_scatter2", (jk_scatter2<NARROW, THREADS>), dim3(grid), dim3(THREADS), lds, stream0(), g, m, in, cursor, out);
   HIP_CHECK_LAST();
   return GDF_SUCCESS;
@@ -3013,7 +3022,7 @@ static gdf_error launch_scatter2(bool narrow, int threads, uint32_t ntiles, cons
     if (!(p6 && narrow && !m.keys32 && g.b1 == 8)) return GDF_INVALID_API_CALL;
     m.ntiles = ntiles;
     m.xcd_order = (ntiles >= 64 && !lab::path_on("GDF_JK_NO_XCD_ORDER")) ? 1 : 0;
-    const uint32_t grid = m.xcd_order ? ((ntiles + 7) / 8) * 8 : ntiles;
+    const uint32_t grid = sc2_grid(m, ntiles);
     const size_t lds = sizeof(TileLds<true, 256>);
     HIP_TRY(hipFuncSetAttribute((const void *)jk_scatter2<true, 256, false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     GDF_LAUNCH("jk_scatter2", (jk_scatter2<true, 256, false, true, false, true>), dim3(grid), dim3(256), lds, stream0(), g, m, in, cursor, out);
@@ -3023,7 +3032,7 @@ static gdf_error launch_scatter2(bool narrow, int threads, uint32_t ntiles, cons
   if (p6 || m.keys32) {              // six-byte output tuples (see p6_store) and / or a receive buffer of 4-byte keys as input:
     m.ntiles = ntiles;                 // NARROW, no payload, the production tile size
     m.xcd_order = (ntiles >= 64 && !lab::path_on("GDF_JK_NO_XCD_ORDER")) ? 1 : 0;
-    const uint32_t grid = m.xcd_order ? ((ntiles + 7) / 8) * 8 : ntiles;
+    const uint32_t grid = sc2_grid(m, ntiles);
 #define JK_SC2_LAUNCH(T, SIX, K)                                                                                                       \
   do {                                                                                                                                \
     const size_t lds = sizeof(TileLds<true, T>);                                                                                      \
@@ -3042,7 +3051,7 @@ static gdf_error launch_scatter2(bool narrow, int threads, uint32_t ntiles, cons
     HIP_TRY(hipFuncSetAttribute((const void *)jk_scatter2<true, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     m.ntiles = ntiles;
     m.xcd_order = (ntiles >= 64 && !lab::path_on("GDF_JK_NO_XCD_ORDER")) ? 1 : 0;
-    const uint32_t grid = m.xcd_order ? ((ntiles + 7) / 8) * 8 : ntiles;
+    const uint32_t grid = sc2_grid(m, ntiles);
     GDF_LAUNCH("jk_scatter2", (jk_scatter2<true, 256, true>), dim3(grid), dim3(256), lds, stream0(), g, m, in, cursor, out);
     HIP_CHECK_LAST();
     return GDF_SUCCESS;
@@ -3283,8 +3292,7 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
   // 1024-thread tile, 256 coarse partitions (24 hash bits left), chunks of exactly 2^17 rows and 64 regions per coarse partition
   // (the row number's bits 17..22), rows below 2^30 - 2^23 (seven explicit high bits, and the all-ones tuple stays free for padding).
   // GDF_JK_FORCE_L6: test switch, small relations too (their few chunks number the regions all the same); GDF_JK_NO_L6: off
-  const bool l6_half = sc_threads == 512 && sc_threads_env == 512 && fast == 8 && !t.col[0].valid;      // (LAB: GDF_JK_SC_THREADS=512)
-  const bool l6 = want_p6 && defer && !app && narrow && !pay && fast != 0 && (sc_threads == 1024 || l6_half) && sc2_threads == 256 && g.b1 == 8 && g.b2 > 0 &&
+  const bool l6 = want_p6 && defer && !app && narrow && !pay && fast != 0 && sc_threads == 1024 && sc2_threads == 256 && g.b1 == 8 && g.b2 > 0 &&
                   chunk == ((int64_t)1 << 17) && n < (((int64_t)1 << 30) - ((int64_t)1 << 23)) && g.row_base == 0 &&
                   (g.xs == 3 || lab::path_on("GDF_JK_FORCE_L6")) && !lab::path_on("GDF_JK_NO_L6");
   if (l6) g.xs = 6;
@@ -3424,7 +3432,7 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
     hipLaunchKernelGGL(jk_init_cursor, dim3(32), dim3(256), 0, stream0(), cursor.as<uint32_t>(), nfine, cap2, g.fstart);
     HIP_CHECK_LAST();
     const bool p6 = want_p6 && narrow && !pay && sc2_threads == 256;
-    if (placed) RMM_TRY(sb->w[1].alloc_placed(JK_ROLE_LEVEL2, p6 ? 6 * size2 + 16 : sizeof(uint64_t) * size2));
+    if (placed) RMM_TRY(sb->w[1].alloc_placed(JK_ROLE_LEVEL2, p6 ? 6 * size2 + 16 : sizeof(uint64_t) * size2, JK_PLACE_DRAWS));
     else RMM_TRY(sb->w[1].alloc(p6 ? 6 * size2 + 16 : sizeof(uint64_t) * size2));
     if (!narrow) RMM_TRY(sb->idx[1].alloc(sizeof(int32_t) * size2));
     if (pay) RMM_TRY(sb->pay[1].alloc(sizeof(uint64_t) * size2));
@@ -3436,6 +3444,21 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
     m.ntiles_dev = ntiles_dev;
     // every segment ends in at most one partial tile: an upper bound of the tile count sizes the grid
     const uint32_t tile_bound = (uint32_t)((uint64_t)n / (uint64_t)JK_TILE2) + nseg + 1;
+    // PLACEMENT TOURNAMENT of the level-2 buffer, as for level 1 above: every candidate is timed on a calibration run of the real
+    // kernel over every fourth tile (all 2^15 write fronts open), the fill cursors are set back, the pool keeps the fastest
+    if (placed && !lab::knob_on("GDF_JK_NO_CALIBRATE")) {
+      const size_t bytes2 = p6 ? 6 * size2 + 16 : sizeof(uint64_t) * size2;
+      for (int round = 0; round <= JK_PLACE_DRAWS && sb->w[1].measure; ++round) {
+        Level2Map mc = m;
+        mc.calib_step = 4;
+        sb->w[1].clock_begin(stream0());
+        GDF_TRY(launch_scatter2(narrow, sc2_threads, tile_bound, g2, mc, sb->tuples(0), cursor.as<uint32_t>(), sb->tuples(1), p6, l6));
+        sb->w[1].clock_end(stream0());
+        hipLaunchKernelGGL(jk_init_cursor, dim3(32), dim3(256), 0, stream0(), cursor.as<uint32_t>(), nfine, cap2, g.fstart);      // (+ the overflow flag)
+        HIP_CHECK_LAST();
+        RMM_TRY(sb->w[1].alloc_placed(JK_ROLE_LEVEL2, bytes2, JK_PLACE_DRAWS));
+      }
+    }
     sb->w[1].clock_begin(stream0());
     GDF_TRY(launch_scatter2(narrow, sc2_threads, tile_bound, g2, m, sb->tuples(0), cursor.as<uint32_t>(), sb->tuples(1), p6, l6));
     sb->w[1].clock_end(stream0());
@@ -4241,9 +4264,18 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
     const uint64_t probe_tail = keep_probe ? (uint64_t)probe_t.nrows - P.joinable : 0;
     const uint64_t total = cap_pairs + probe_tail;
     if (total >= (uint64_t)INT_MAX) return GDF_COLUMN_SIZE_TOO_BIG;
+    // the two index columns of a large dense join are PLACED blocks too (the probe kernel's 2 x 4 GB of writes have their fast and
+    // slow placements like the regroup passes'): tournament below; the caller gets the winners and frees them through rmmFree as ever
+    const bool place_out = try_optimistic && deferred && nunits >= 64 && !lab::knob_on("GDF_JK_NO_CALIBRATE");
+    const size_t out_bytes = sizeof(int32_t) * (size_t)(total ? total : 1);
     DevBuf op, ob;
-    RMM_TRY(op.alloc(sizeof(int32_t) * (total ? total : 1)));
-    RMM_TRY(ob.alloc(sizeof(int32_t) * (total ? total : 1)));
+    if (place_out) {
+      RMM_TRY(op.alloc_placed(JK_ROLE_OUT_PROBE, out_bytes, JK_PLACE_DRAWS));
+      RMM_TRY(ob.alloc_placed(JK_ROLE_OUT_BUILD, out_bytes, JK_PLACE_DRAWS));
+    } else {
+      RMM_TRY(op.alloc(out_bytes));
+      RMM_TRY(ob.alloc(out_bytes));
+    }
     GDF_TRY(alloc_pay(total));
 
     ProbeArgs oa = a;
@@ -4258,6 +4290,21 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
       RMM_TRY(d_upairs.alloc(sizeof(uint32_t) * (nunits + 1)));
       HIP_TRY(hipMemsetAsync(d_upairs.p, 0, sizeof(uint32_t) * (nunits + 1), stream0()));
       oa.unit_pairs = d_upairs.as<uint32_t>();
+    }
+    // PLACEMENT TOURNAMENT of the output columns (both roles see the same times, so they keep and drop their candidates together):
+    // a calibration run is the write pass over the first quarter of the units; the pass's state words are cleared behind it
+    for (int round = 0; place_out && round <= JK_PLACE_DRAWS && (op.measure || ob.measure); ++round) {
+      op.clock_begin(stream0());
+      ob.clock_begin(stream0());
+      GDF_TRY(run_write_pass(narrow, plain && !dup_heavy, nunits / 4, probe_lds, oa, max_build, probe_t, build_t));
+      op.clock_end(stream0());
+      ob.clock_end(stream0());
+      HIP_TRY(hipMemsetAsync(d_state.p, 0, sizeof(unsigned long long) * 4, stream0()));
+      if (try_sparse) HIP_TRY(hipMemsetAsync(d_upairs.p, 0, sizeof(uint32_t) * (nunits + 1), stream0()));
+      RMM_TRY(op.alloc_placed(JK_ROLE_OUT_PROBE, out_bytes, JK_PLACE_DRAWS));
+      RMM_TRY(ob.alloc_placed(JK_ROLE_OUT_BUILD, out_bytes, JK_PLACE_DRAWS));
+      oa.out_probe = op.as<int32_t>();
+      oa.out_build = ob.as<int32_t>();
     }
     clk.mark("output allocation");
     P.w[P.final_buf].clock_begin(stream0());      // (a placed level-2 block: the probe kernel reads it)

@@ -326,7 +326,10 @@ constexpr uint32_t JK_NOPOS = 0xffffffffu;
 constexpr int JK_CUCKOO_MAX_MOVES = 32;
 constexpr int JK_ROLE_LEVEL1 = 1, JK_ROLE_LEVEL2 = 2;      // placed blocks (DevBuf::alloc_placed): the probe side's level-1 / level-2 tuples
 constexpr int JK_ROLE_OUT_PROBE = 3, JK_ROLE_OUT_BUILD = 4; // ... and the two index columns of a large dense join
-constexpr int JK_PLACE_DRAWS = 8;                           // challengers of the level-1 buffer's placement tournament (partition_side_spec)
+// challengers of the placement tournaments (partition_side_spec, probe_partitioned).  Level 1 has two MODES, about one fresh block in
+// five is a fast one (profiles/r5_b_place_trace_*.json): 8 challengers.  Level 2 and the output columns spread over ~10 % without
+// modes (r5_e_place_trace_*.json): fewer candidates get most of what there is, and every candidate is 4 - 7 GB of allocator churn.
+constexpr int JK_PLACE_DRAWS = 8, JK_PLACE_DRAWS_L2 = 5, JK_PLACE_DRAWS_OUT = 4;
 
 struct PartGeom {
   int fb, b1, b2;        // fine bits = b1 (level 1) + b2 (level 2)
@@ -3432,7 +3435,7 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
     hipLaunchKernelGGL(jk_init_cursor, dim3(32), dim3(256), 0, stream0(), cursor.as<uint32_t>(), nfine, cap2, g.fstart);
     HIP_CHECK_LAST();
     const bool p6 = want_p6 && narrow && !pay && sc2_threads == 256;
-    if (placed) RMM_TRY(sb->w[1].alloc_placed(JK_ROLE_LEVEL2, p6 ? 6 * size2 + 16 : sizeof(uint64_t) * size2, JK_PLACE_DRAWS));
+    if (placed) RMM_TRY(sb->w[1].alloc_placed(JK_ROLE_LEVEL2, p6 ? 6 * size2 + 16 : sizeof(uint64_t) * size2, JK_PLACE_DRAWS_L2));
     else RMM_TRY(sb->w[1].alloc(p6 ? 6 * size2 + 16 : sizeof(uint64_t) * size2));
     if (!narrow) RMM_TRY(sb->idx[1].alloc(sizeof(int32_t) * size2));
     if (pay) RMM_TRY(sb->pay[1].alloc(sizeof(uint64_t) * size2));
@@ -3448,7 +3451,7 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
     // kernel over every fourth tile (all 2^15 write fronts open), the fill cursors are set back, the pool keeps the fastest
     if (placed && !lab::knob_on("GDF_JK_NO_CALIBRATE")) {
       const size_t bytes2 = p6 ? 6 * size2 + 16 : sizeof(uint64_t) * size2;
-      for (int round = 0; round <= JK_PLACE_DRAWS && sb->w[1].measure; ++round) {
+      for (int round = 0; round <= JK_PLACE_DRAWS_L2 && sb->w[1].measure; ++round) {
         Level2Map mc = m;
         mc.calib_step = 4;
         sb->w[1].clock_begin(stream0());
@@ -3456,7 +3459,7 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
         sb->w[1].clock_end(stream0());
         hipLaunchKernelGGL(jk_init_cursor, dim3(32), dim3(256), 0, stream0(), cursor.as<uint32_t>(), nfine, cap2, g.fstart);      // (+ the overflow flag)
         HIP_CHECK_LAST();
-        RMM_TRY(sb->w[1].alloc_placed(JK_ROLE_LEVEL2, bytes2, JK_PLACE_DRAWS));
+        RMM_TRY(sb->w[1].alloc_placed(JK_ROLE_LEVEL2, bytes2, JK_PLACE_DRAWS_L2));
       }
     }
     sb->w[1].clock_begin(stream0());
@@ -4270,8 +4273,8 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
     const size_t out_bytes = sizeof(int32_t) * (size_t)(total ? total : 1);
     DevBuf op, ob;
     if (place_out) {
-      RMM_TRY(op.alloc_placed(JK_ROLE_OUT_PROBE, out_bytes, JK_PLACE_DRAWS));
-      RMM_TRY(ob.alloc_placed(JK_ROLE_OUT_BUILD, out_bytes, JK_PLACE_DRAWS));
+      RMM_TRY(op.alloc_placed(JK_ROLE_OUT_PROBE, out_bytes, JK_PLACE_DRAWS_OUT));
+      RMM_TRY(ob.alloc_placed(JK_ROLE_OUT_BUILD, out_bytes, JK_PLACE_DRAWS_OUT));
     } else {
       RMM_TRY(op.alloc(out_bytes));
       RMM_TRY(ob.alloc(out_bytes));
@@ -4293,7 +4296,7 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
     }
     // PLACEMENT TOURNAMENT of the output columns (both roles see the same times, so they keep and drop their candidates together):
     // a calibration run is the write pass over the first quarter of the units; the pass's state words are cleared behind it
-    for (int round = 0; place_out && round <= JK_PLACE_DRAWS && (op.measure || ob.measure); ++round) {
+    for (int round = 0; place_out && round <= JK_PLACE_DRAWS_OUT && (op.measure || ob.measure); ++round) {
       op.clock_begin(stream0());
       ob.clock_begin(stream0());
       GDF_TRY(run_write_pass(narrow, plain && !dup_heavy, nunits / 4, probe_lds, oa, max_build, probe_t, build_t));
@@ -4301,8 +4304,8 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
       ob.clock_end(stream0());
       HIP_TRY(hipMemsetAsync(d_state.p, 0, sizeof(unsigned long long) * 4, stream0()));
       if (try_sparse) HIP_TRY(hipMemsetAsync(d_upairs.p, 0, sizeof(uint32_t) * (nunits + 1), stream0()));
-      RMM_TRY(op.alloc_placed(JK_ROLE_OUT_PROBE, out_bytes, JK_PLACE_DRAWS));
-      RMM_TRY(ob.alloc_placed(JK_ROLE_OUT_BUILD, out_bytes, JK_PLACE_DRAWS));
+      RMM_TRY(op.alloc_placed(JK_ROLE_OUT_PROBE, out_bytes, JK_PLACE_DRAWS_OUT));
+      RMM_TRY(ob.alloc_placed(JK_ROLE_OUT_BUILD, out_bytes, JK_PLACE_DRAWS_OUT));
       oa.out_probe = op.as<int32_t>();
       oa.out_build = ob.as<int32_t>();
     }

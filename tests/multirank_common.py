@@ -189,7 +189,10 @@ def _uneven_worker(rank, world, port, q, backend="gloo"):
     # one without build rows run every exchange and every agreement; the answer -- pairs or a decline -- is the same on all ranks
     fpairs = multigpu.fused_inner_join(p, b, chunks=4)
     fpg, fbg = fpairs.global_ids() if fpairs is not None else (None, None)
-    out = {}
+    from libgdf_amd import api
+    from libgdf_amd.columns import Column
+    csp, csb = api.dist_shuffle_join(Column(p), Column(b), multigpu.transport_for(None))      # the fallback behind one C call, same shards
+    out = {"c-shuffle": (csp.cpu().numpy(), csb.cpu().numpy())}
     k = (p % 7)
     for name, v in vals[rank].items():
         tv = torch.from_numpy(v).to(dev)
@@ -227,6 +230,8 @@ def check_uneven(world, results):
     if results[0][4] is not None:
         got = np.concatenate([np.stack([r[4], r[5]], axis=1) for r in results])
         np.testing.assert_array_equal(got[np.lexsort(got.T[::-1])], exp[np.lexsort(exp.T[::-1])])
+    got = np.concatenate([np.stack(r[3]["c-shuffle"], axis=1) for r in results])
+    np.testing.assert_array_equal(got[np.lexsort(got.T[::-1])], exp[np.lexsort(exp.T[::-1])])
     import pandas as pd
     allk = np.concatenate(probes) % 7
     for name in ("int8", "int32", "float32"):
@@ -278,6 +283,11 @@ def _world8_worker(rank, world, port, q, backend="gloo"):
             fpairs = multigpu.distributed_inner_join(p, b, chunks=2)
         pg, bg = fpairs.global_ids()
         out[name] = (declined, pg.cpu().numpy(), bg.cpu().numpy())
+        # ... and the key shuffle behind ONE C call (gdf_amd_dist_shuffle_join: global row ids straight from the library)
+        from libgdf_amd import api
+        from libgdf_amd.columns import Column
+        sp, sbd = api.dist_shuffle_join(Column(p), Column(b), multigpu.transport_for(None))
+        out["c-shuffle-" + name] = (sp.cpu().numpy(), sbd.cpu().numpy())
     # gdf_amd_dist_group_by through the same transport at fan-out 8 (the empty rank takes part in every collective)
     p = torch.from_numpy(probes[rank]).to(dev)
     for op in ("sum", "count", "avg", "min"):
@@ -302,6 +312,8 @@ def check_world8(world, results):
         li, ri = oracle.join([np.concatenate(shards)], [np.concatenate(builds)], "inner")
         exp = np.stack([gp[li], gb[ri]], axis=1)
         got = np.concatenate([np.stack([res[name][1], res[name][2]], axis=1) for res in results])
+        np.testing.assert_array_equal(got[np.lexsort(got.T[::-1])], exp[np.lexsort(exp.T[::-1])])
+        got = np.concatenate([np.stack(res["c-shuffle-" + name], axis=1) for res in results])
         np.testing.assert_array_equal(got[np.lexsort(got.T[::-1])], exp[np.lexsort(exp.T[::-1])])
     import pandas as pd
     allp = np.concatenate(probes)

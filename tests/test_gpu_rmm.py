@@ -7,6 +7,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 KB, MB, GB, TB, PB = 1 << 10, 1 << 20, 1 << 30, 1 << 40, 1 << 50
+_MODE = [0]          # the allocation mode of the current `rmm` fixture (1 = PoolAllocation)
 
 
 @pytest.fixture(params=[0, 1], ids=["default_allocation", "pool_allocation"])
@@ -21,6 +22,7 @@ def rmm(gdf, request):
     lib.rmmGetErrorString.restype = C.c_char_p
     assert lib.rmmFinalize() == 0
     assert lib.rmmInitialize(C.byref(rmmOptions_t(request.param, 0, False))) == 0      # GdfTest fixture: init per case
+    _MODE[0] = request.param
     yield lib
     assert lib.rmmFinalize() == 0
     assert lib.rmmInitialize(C.byref(rmmOptions_t(0, 0, False))) == 0                   # leave the session in default mode
@@ -96,3 +98,62 @@ def test_pool_reuses_freed_blocks(gdf):
     finally:
         lib.rmmFinalize()
         lib.rmmInitialize(C.byref(rmmOptions_t(0, 0, False)))
+
+
+def test_placed_blocks_keep_the_fastest_candidate(rmm):
+    """Round 5: gdf_amd_rmm_place_* (include/memory.h, csrc/rmm.cpp) -- the pool that re-draws slow physical placements.  No counterpart
+    in the reference.  The protocol with invented times: the first block of a (role, size) is the champion; while the pool is
+    exploring, every allocation is a fresh challenger drawn while the champion (and the losers) are held, and the faster one stays;
+    after `draws` challengers the champion serves every call and nothing is measured; a placed block may also come back through
+    rmmFree; other sizes / the non-pool mode fall through to the plain allocator."""
+    lib = rmm
+    lib.gdf_amd_rmm_place_alloc.argtypes = [C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
+    lib.gdf_amd_rmm_place_free.argtypes = [C.c_int, C.c_void_p, C.c_float]
+    lib.gdf_amd_rmm_place_draws.argtypes = [C.c_int]
+    lib.gdf_amd_rmm_place_stats.argtypes = [C.POINTER(C.c_ulonglong)]
+    pool = _MODE[0] == 1
+    lib.gdf_amd_rmm_place_draws(2)
+    role, size = 9, GB + 5 * MB
+
+    def alloc(max_draws=0):
+        p, m = C.c_void_p(), C.c_int(-1)
+        assert lib.gdf_amd_rmm_place_alloc(role, size, max_draws, C.byref(p), C.byref(m)) == 0
+        return p.value, m.value
+    if not pool:
+        p, m = alloc()
+        assert p and m == 0                              # CudaDefaultAllocation: a plain hipMalloc, nothing to measure
+        assert lib.gdf_amd_rmm_place_free(role, p, -1.0) == 0
+        lib.gdf_amd_rmm_place_draws(4)
+        return
+    stats = (C.c_ulonglong * 4)()
+    lib.gdf_amd_rmm_place_stats(stats)
+    drawn0, promoted0 = stats[0], stats[1]
+    champ, m = alloc()
+    assert champ and m == 1                              # the champion, to be timed
+    assert lib.gdf_amd_rmm_place_free(role, champ, 10.0) == 0
+    c1, m = alloc()
+    assert c1 and c1 != champ and m == 1                 # challenger 1, drawn while the champion is held
+    assert lib.gdf_amd_rmm_place_free(role, c1, 5.0) == 0            # faster: promoted
+    c2, m = alloc()
+    assert c2 not in (champ, c1) and m == 1              # challenger 2: neither the champion nor the held loser
+    assert lib.gdf_amd_rmm_place_free(role, c2, 7.0) == 0            # slower than 5.0: dropped, exploration over
+    for _ in range(3):
+        p, m = alloc()
+        assert p == c1 and m == 0                        # settled: the promoted block serves every call, unmeasured
+        assert lib.rmmFree(p, None) == 0                 # ... and may come back through the plain entry point
+    lib.gdf_amd_rmm_place_stats(stats)
+    assert stats[0] - drawn0 == 2 and stats[1] - promoted0 == 1 and stats[3] == 0
+    # a second shape of the same role is its own entry; a block below 1 GiB is the plain pool's
+    small, ms = C.c_void_p(), C.c_int(-1)
+    assert lib.gdf_amd_rmm_place_alloc(role, 64 * MB, 0, C.byref(small), C.byref(ms)) == 0 and ms.value == 0
+    assert lib.gdf_amd_rmm_place_free(role, small, -1.0) == 0
+    # the caller's own number of challengers (a calibration loop inside one call)
+    role2 = 10
+    seen = []
+    for i in range(5):
+        p, m = C.c_void_p(), C.c_int(-1)
+        assert lib.gdf_amd_rmm_place_alloc(role2, size, 3, C.byref(p), C.byref(m)) == 0
+        seen.append((p.value, m.value))
+        assert lib.gdf_amd_rmm_place_free(role2, p, 4.0 - i if m.value else -1.0) == 0     # every candidate faster than the last
+    assert [m for _, m in seen] == [1, 1, 1, 1, 0] and len({p for p, _ in seen[:4]}) == 4 and seen[4][0] == seen[3][0]
+    lib.gdf_amd_rmm_place_draws(4)

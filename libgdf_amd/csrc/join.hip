@@ -326,6 +326,7 @@ constexpr uint32_t JK_NOPOS = 0xffffffffu;
 constexpr int JK_CUCKOO_MAX_MOVES = 32;
 constexpr int JK_ROLE_LEVEL1 = 1, JK_ROLE_LEVEL2 = 2;      // placed blocks (DevBuf::alloc_placed): the probe side's level-1 / level-2 tuples
 constexpr int JK_ROLE_OUT_PROBE = 3, JK_ROLE_OUT_BUILD = 4; // ... and the two index columns of a large dense join
+constexpr int JK_ROLE_FUSED_LEVEL2 = 5;                     // ... and the level-2 tuples of a fused multi-GPU join's receiver
 // challengers of the placement tournaments (partition_side_spec, probe_partitioned).  Level 1 has two MODES, about one fresh block in
 // five is a fast one (profiles/r5_b_place_trace_*.json): 8 challengers.  Level 2 and the output columns spread over ~10 % without
 // modes (r5_e_place_trace_*.json): fewer candidates get most of what there is, and every candidate is 4 - 7 GB of allocator churn.
@@ -367,6 +368,12 @@ struct PartGeom {
   // LOCAL partition id is taken from the low word of hash_a * world (uniform inside a rank).  0 / 1: single GPU, the id is
   // hash_a's own top bits.
   uint32_t world;
+  // FUSED multi-GPU join, round 5: the stored 32-bit "keys" of a receive buffer ARE hash_a(raw key) already -- the sender computed
+  // the hash to pick rank and region, and ships it instead of the narrowed key (fj_prehash_ok: hash_a is then a bijection of the
+  // narrowed keys, so equal words <=> equal keys, and the fused join returns positions, never key values).  The receiver's level 2
+  // and its probe kernels take partition ids, six-byte remainders and slot hashes from the word as it is; the two quarter-rate
+  // multiplies per tuple of lowbias32 were half of the K32 level-2 kernel's time.
+  int prehashed;
 #ifdef GDF_AMD_LAB
   unsigned long long *lab_clock;     // LAB: jk_scatter1 stores the cycles the first / last wave of a workgroup spent in each phase, [chunk][2][8] (knob GDF_JK_CLOCK)
 #endif
@@ -617,8 +624,14 @@ __host__ __device__ __forceinline__ bool p6_world_ok(uint32_t world) { return wo
 __device__ __forceinline__ uint32_t p6_low(uint32_t hash, uint32_t local, uint32_t world) {
   return (world > 1 && !(world & (world - 1u))) ? __builtin_rotateleft32(hash, 31 - __clz((int)world)) : local;     // = local | mulhi(hash, world)
 }
-__device__ __forceinline__ uint32_t p6_remainder(uint32_t key32, uint64_t kbias, int fb, uint32_t world) {
-  const uint32_t q = hash_a((uint64_t)key32 + kbias);
+// narrowed keys (key - lo, below 2^31 - 1) whose raw values cannot straddle a 2^32 boundary: key_fold is `low word ^ constant`,
+// lowbias32 permutes 32 bits -- hash_a(key32 + lo) is a BIJECTION of key32.  A function of lo alone (the receiver of a fused join
+// does not know the senders' hi), the same on every rank.
+__host__ __device__ __forceinline__ bool fj_prehash_ok(long long lo) {
+  return ((unsigned long long)lo & 0xffffffffULL) + 0x7ffffffeULL < (1ULL << 32);
+}
+__device__ __forceinline__ uint32_t p6_remainder(uint32_t key32, uint64_t kbias, int fb, uint32_t world, int prehashed = 0) {
+  const uint32_t q = prehashed ? key32 : hash_a((uint64_t)key32 + kbias);
   return p6_low(q, local_hash(q, world), world) & ((1u << (32 - fb)) - 1u);
 }
 __device__ __forceinline__ void p6_store(uint64_t *base, uint32_t pos, uint32_t r, uint32_t row) {
@@ -719,7 +732,7 @@ __device__ __forceinline__ void tile_flush(TileLds<NARROW, THREADS, PAY, ITEMS> 
     uint32_t dst[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const uint32_t q = hash_a(tup_key<NARROW>(ww[u]) + g.kbias);
+      const uint32_t q = g.prehashed ? (uint32_t)tup_key<NARROW>(ww[u]) : hash_a(tup_key<NARROW>(ww[u]) + g.kbias);
       const uint32_t h = local_hash(q, g.world);
       const uint32_t f = (uint32_t)((uint64_t)h >> (32 - g.fb));
       const uint32_t bin = LEVEL1 ? (f >> g.b2) : (f & submask);
@@ -1300,8 +1313,9 @@ __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, 
   // power-of-two world (decided once per kernel), the rank remap h * world as a shift: two of the four quarter-rate multiplies
   // per tuple are gone (half of this kernel's time is VALU issue, tools/kernel_blocks.py)
   const uint32_t kb_low = (uint32_t)g.kbias, kb_fold0 = (uint32_t)(g.kbias >> 32) * 0x9e3779b1u, kb_fold1 = kb_fold0 + 0x9e3779b1u;
-  auto rank_tuples = [&](auto pow2_world) {
+  auto rank_tuples = [&](auto pow2_world, auto pre_hashed) {
     constexpr bool POW2W = decltype(pow2_world)::value;
+    constexpr bool PRE = decltype(pre_hashed)::value;              // (K32) the received word IS the hash (PartGeom::prehashed)
     const uint32_t wshift = POW2W ? (uint32_t)(31 - __clz((int)(g.world ? g.world : 1u))) : 0u;
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) {
@@ -1314,7 +1328,8 @@ __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, 
       uint32_t q, lh;
       if constexpr (K32) {
         const uint32_t key32 = (uint32_t)(w[k] >> 32), low = key32 + kb_low;
-        q = lowbias32(low ^ (low < key32 ? kb_fold1 : kb_fold0));
+        if constexpr (PRE) q = key32;
+        else q = lowbias32(low ^ (low < key32 ? kb_fold1 : kb_fold0));
         lh = POW2W ? q << wshift : (uint32_t)((uint64_t)q * g.world);
       } else {
         q = hash_a(tup_key<NARROW>(w[k]) + g.kbias);
@@ -1330,8 +1345,15 @@ __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, 
       }
     }
   };
-  if (K32 && (g.world & (g.world - 1u)) == 0) rank_tuples(std::true_type{});      // (workgroup-uniform)
-  else rank_tuples(std::false_type{});
+  if constexpr (K32) {                                                              // (workgroup-uniform choices)
+    const bool p2 = (g.world & (g.world - 1u)) == 0;
+    if (p2 && g.prehashed) rank_tuples(std::true_type{}, std::true_type{});
+    else if (p2) rank_tuples(std::true_type{}, std::false_type{});
+    else if (g.prehashed) rank_tuples(std::false_type{}, std::true_type{});
+    else rank_tuples(std::false_type{}, std::false_type{});
+  } else {
+    rank_tuples(std::false_type{}, std::false_type{});
+  }
 #pragma unroll
   for (int k = 0; k < ITEMS; ++k)            // sixteen atomics in flight, one wait
     binrank[k] = (binrank[k] << 16) | atomicAdd(&s.hist[binrank[k]], 1u);
@@ -1531,6 +1553,7 @@ struct ProbeArgs {
   int p6_fb;
   uint32_t p6_world;             // PartGeom::world of the build side (fused multi-GPU joins hash with the rank remap)
   uint64_t p6_kbias;
+  int prehashed;                // fused multi-GPU join: the stored keys are hashes already (PartGeom::prehashed)
 };
 // the general kernels' payload write: a gather by probe row (rare units only)
 __device__ __forceinline__ void pay_gather(const ProbeArgs &a, unsigned long long pos, int32_t prow) {
@@ -1615,7 +1638,7 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
   // ---- stage the build partition, clear the table ----
   for (uint32_t i = threadIdx.x; i < u.build_count; i += JK_PROBE_THREADS) {
     uint64_t w = a.build.w[u.build_begin + i];
-    if (P6) w = ((uint64_t)p6_remainder((uint32_t)(w >> 32), a.p6_kbias, a.p6_fb, a.p6_world) << 32) | (uint32_t)w;
+    if (P6) w = ((uint64_t)p6_remainder((uint32_t)(w >> 32), a.p6_kbias, a.p6_fb, a.p6_world, a.prehashed) << 32) | (uint32_t)w;
     l.bw[i] = w;
     if (!NARROW) l.bi[i] = a.build.idx[u.build_begin + i];
   }
@@ -1881,7 +1904,7 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_fast(ProbeArgs a) {
   const Unit u = a.units[blockIdx.x];
   for (uint32_t i = threadIdx.x; i < u.build_count; i += JK_PROBE_THREADS) {
     uint64_t w = a.build.w[u.build_begin + i];
-    if (P6) w = ((uint64_t)p6_remainder((uint32_t)(w >> 32), a.p6_kbias, a.p6_fb, a.p6_world) << 32) | (uint32_t)w;      // six-byte probe tuples: compare remainders
+    if (P6) w = ((uint64_t)p6_remainder((uint32_t)(w >> 32), a.p6_kbias, a.p6_fb, a.p6_world, a.prehashed) << 32) | (uint32_t)w;      // six-byte probe tuples: compare remainders
     l.bw[i] = w;
     if (!NARROW) l.bi[i] = a.build.idx[u.build_begin + i];
   }
@@ -2110,7 +2133,7 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_count_fast(ProbeArgs a) {
   const Unit u = a.units[blockIdx.x];
   for (uint32_t i = threadIdx.x; i < u.build_count; i += JK_PROBE_THREADS) {
     uint64_t w = a.build.w[u.build_begin + i];
-    if (P6) w = ((uint64_t)p6_remainder((uint32_t)(w >> 32), a.p6_kbias, a.p6_fb, a.p6_world) << 32) | (uint32_t)w;
+    if (P6) w = ((uint64_t)p6_remainder((uint32_t)(w >> 32), a.p6_kbias, a.p6_fb, a.p6_world, a.prehashed) << 32) | (uint32_t)w;
     l.bw[i] = w;
     if (!NARROW) l.bi[i] = a.build.idx[u.build_begin + i];
   }
@@ -2438,7 +2461,7 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_multi(ProbeArgs a) 
   const uint32_t mask = 2 * H - 1;
   for (uint32_t i = threadIdx.x; i < u.build_count; i += JK_PROBE_THREADS) {
     uint64_t w = a.build.w[u.build_begin + i];
-    if (P6) w = ((uint64_t)p6_remainder((uint32_t)(w >> 32), a.p6_kbias, a.p6_fb, a.p6_world) << 32) | (uint32_t)w;
+    if (P6) w = ((uint64_t)p6_remainder((uint32_t)(w >> 32), a.p6_kbias, a.p6_fb, a.p6_world, a.prehashed) << 32) | (uint32_t)w;
     l.bw[i] = w;
     l.next[i] = JK_MM_END;
   }
@@ -4170,6 +4193,7 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
   a.build_matched = d_matched.as<uint8_t>();
   a.dbg = (int)lab::knob_int("GDF_JK_DBG", 0);
   a.kbias = plan.kmin;
+  a.prehashed = g.prehashed;
   if (P.p6) {                       // six-byte probe tuples: the kernels hash and compare hash remainders (ProbeArgs::p6_fb)
     a.p6_fb = g.fb;
     a.p6_world = g.world;
@@ -4269,7 +4293,7 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
     if (total >= (uint64_t)INT_MAX) return GDF_COLUMN_SIZE_TOO_BIG;
     // the two index columns of a large dense join are PLACED blocks too (the probe kernel's 2 x 4 GB of writes have their fast and
     // slow placements like the regroup passes'): tournament below; the caller gets the winners and frees them through rmmFree as ever
-    const bool place_out = try_optimistic && deferred && nunits >= 64 && !lab::knob_on("GDF_JK_NO_CALIBRATE");
+    const bool place_out = try_optimistic && nunits >= 64 && !lab::knob_on("GDF_JK_NO_CALIBRATE");
     const size_t out_bytes = sizeof(int32_t) * (size_t)(total ? total : 1);
     DevBuf op, ob;
     if (place_out) {
@@ -5174,7 +5198,10 @@ __device__ __forceinline__ T *at32(T *base, uint32_t index) {
 // POW2: the world is a power of two 2^k with k + c1 >= 1 -- rank = mulhi(h, world) is then h's top k bits and the coarse id the next
 // c1, i.e. the bin is ONE shift of the hash instead of a 32 x 32 -> 64 multiply (two quarter-rate instructions; the kernel hashes
 // every key three times and spends ~70 % of its time issuing VALU work, tools/kernel_blocks.py).
-template <class K, bool POW2>
+// PRE: the word that travels is hash_a(key) instead of key - lo (PartGeom::prehashed, fj_prehash_ok): the receiver needs no hash, and
+// neither does this kernel's own flush -- a key's bin is then a shift (or one multiply) of the stored word instead of a second and
+// a third lowbias32
+template <class K, bool POW2, bool PRE>
 __global__ __launch_bounds__(FJ_THREADS) void fj_scatter(FjSend a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fj_lds[];
   uint32_t *tk = reinterpret_cast<uint32_t *>(fj_lds);                  // [TILE + 4]: narrowed keys regrouped by bin; [TILE] = trash slot
@@ -5192,13 +5219,17 @@ __global__ __launch_bounds__(FJ_THREADS) void fj_scatter(FjSend a) {
   const uint32_t lo_word = (uint32_t)(unsigned long long)a.lo;
   const uint32_t fold0 = (uint32_t)((unsigned long long)a.lo >> 32) * 0x9e3779b1u, fold1 = fold0 + 0x9e3779b1u;
   const uint32_t pow2_shift = 32u - ((uint32_t)a.c1 + (uint32_t)(31 - __clz((int)a.world)));
-  auto bin_of_key = [&](uint32_t key32) -> uint32_t {
+  auto hash_of_key = [&](uint32_t key32) -> uint32_t {
     const uint32_t low = key32 + lo_word;
-    const uint32_t h = lowbias32(low ^ (low < key32 ? fold1 : fold0));
+    return lowbias32(low ^ (low < key32 ? fold1 : fold0));
+  };
+  auto bin_of_hash = [&](uint32_t h) -> uint32_t {
     if constexpr (POW2) return h >> pow2_shift;
     const uint64_t u = (uint64_t)h * a.world;
     return ((uint32_t)(u >> 32) << a.c1) | (uint32_t)((uint64_t)(uint32_t)u >> (32 - a.c1));
   };
+  // the bin of a STORED word: the word is the hash itself (PRE) or the narrowed key, hashed again
+  auto bin_of_key = [&](uint32_t word) -> uint32_t { return bin_of_hash(PRE ? word : hash_of_key(word)); };
   for (uint32_t b = threadIdx.x; b < FJ_MAX_BINS + 4; b += FJ_THREADS) hist[b] = 0;
   block_sync();
   // Every address is the tile's (uniform) base plus a 32-bit offset below 2^18: one register per access instead of a 64-bit
@@ -5248,9 +5279,10 @@ __global__ __launch_bounds__(FJ_THREADS) void fj_scatter(FjSend a) {
           const uint32_t o = (h + k) * FJ_THREADS + tid;
           const unsigned long long off = (unsigned long long)((long long)raw[k] - a.lo);
           const bool travels = (FULL || o < live) && off <= a.span;
-          key[h + k] = (uint32_t)off;
+          const uint32_t hsh = hash_of_key((uint32_t)off);           // hashed whether it travels or not: no branch
+          key[h + k] = PRE ? hsh : (uint32_t)off;
           okmask |= (uint32_t)travels << (h + k);
-          const uint32_t b = bin_of_key(key[h + k]);                 // hashed whether it travels or not: no branch
+          const uint32_t b = bin_of_hash(hsh);
           bin[k] = travels ? b : (uint32_t)FJ_MAX_BINS;              // MAX_BINS: the trash counter
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -5397,8 +5429,15 @@ static gdf_error fj_send(gdf_column *keys, int64_t lo, int64_t hi, int world, in
     GDF_LAUNCH("fj_scatter", kernel, dim3(grid), dim3(FJ_THREADS), lds, stream0(), a);
     return GDF_SUCCESS;
   };
-  if (kind == K_I64) GDF_TRY(pow2 ? launch(fj_scatter<long long, true>) : launch(fj_scatter<long long, false>));
-  else GDF_TRY(pow2 ? launch(fj_scatter<int, true>) : launch(fj_scatter<int, false>));
+  // the travelling word: the hash where hash_a is a bijection of the narrowed keys (decided from lo alone, as the receiver does)
+  const bool pre = fj_prehash_ok(lo) && !lab::path_on("GDF_FJ_NO_PREHASH");
+  if (kind == K_I64) {
+    if (pre) GDF_TRY(pow2 ? launch(fj_scatter<long long, true, true>) : launch(fj_scatter<long long, false, true>));
+    else GDF_TRY(pow2 ? launch(fj_scatter<long long, true, false>) : launch(fj_scatter<long long, false, false>));
+  } else {
+    if (pre) GDF_TRY(pow2 ? launch(fj_scatter<int, true, true>) : launch(fj_scatter<int, false, true>));
+    else GDF_TRY(pow2 ? launch(fj_scatter<int, true, false>) : launch(fj_scatter<int, false, false>));
+  }
   HIP_CHECK_LAST();
   uint32_t flag = 0;
   HIP_TRY(read_back(&flag, out_fill + nregions, sizeof(flag)));
@@ -5410,7 +5449,7 @@ static gdf_error fj_send(gdf_column *keys, int64_t lo, int64_t hi, int world, in
 // matching fill counters, sender-major.  Appends into sb's level-2 buffer through `cursor` ([nfine + 2]: cursors | overflow flag
 // | tile count).  Launches only; `keep` receives the scratch that must outlive the kernels.
 static gdf_error fj_level2(const uint32_t *keys, const uint32_t *fill, uint32_t nseg, uint32_t cap, const PartGeom &g, uint32_t cap2,
-                           int32_t row_base, uint32_t *cursor, Tuples out, std::deque<DevBuf> *keep, bool p6 = false) {
+                           int32_t row_base, uint32_t *cursor, Tuples out, std::deque<DevBuf> *keep, bool p6 = false, uint32_t calib_step = 0) {
   const uint32_t nfine = 1u << g.fb;
   // (world x coarse partitions = 1024 leaves 8 bits to level 2: 256 bins per 4096-tuple tile, (tile, bin) runs of 16 tuples.  8192-tuple
   // tiles -- 512 threads, runs of 32 as on the single-GPU path -- were slower: 4.15 vs 3.52 ms per 1e9 keys, profiles/r3_o_fused_level2.txt)
@@ -5434,6 +5473,7 @@ static gdf_error fj_level2(const uint32_t *keys, const uint32_t *fill, uint32_t 
   m.ntiles_dev = ntiles_dev;
   m.nseg = nseg;
   m.keys32 = keys;
+  m.calib_step = calib_step;          // (> 1: a calibration run of the level-2 buffer's placement tournament, fj_probe_add)
   const uint32_t tile_bound = (uint32_t)(((uint64_t)nseg * cap) / (uint64_t)TILE2) + nseg + 1;
   GDF_TRY(launch_scatter2(true, sc2_threads, tile_bound, g2, m, Tuples{nullptr, nullptr, nullptr}, cursor, out, p6));
   return GDF_SUCCESS;
@@ -5446,6 +5486,7 @@ static PartGeom fj_geometry(int world, int fine_bits, int coarse_bits, int64_t l
   g.b2 = fine_bits - coarse_bits;
   g.kbias = (uint64_t)lo;
   g.world = (uint32_t)world;
+  g.prehashed = (fj_prehash_ok(lo) && !lab::path_on("GDF_FJ_NO_PREHASH")) ? 1 : 0;      // the same decision as the senders' (fj_send)
   return g;
 }
 
@@ -5533,7 +5574,19 @@ static gdf_error fj_probe_add(ProbeAccum *a, const uint32_t *recv_keys, const ui
     const KeyPlan &plan = a->pb->side.plan;
     a->P.p6 = g.fb == JK_MAX_FB && g.b3 == 0 && (plan.kmin & 0xffffffffULL) + plan.kspan < (1ULL << 32) && p6_world_ok(g.world) &&
               !lab::path_on("GDF_JK_NO_P6");
-    RMM_TRY(a->P.w[1].alloc(a->P.p6 ? 6 * size2 + 16 : sizeof(uint64_t) * size2));
+    // the accumulator's level-2 buffer is a PLACED block like the single-GPU path's (partition_side_spec): every candidate is timed on
+    // every fourth tile of this first slice, the cursors are set back, the pool keeps the fastest
+    const size_t bytes2 = a->P.p6 ? 6 * size2 + 16 : sizeof(uint64_t) * size2;
+    RMM_TRY(a->P.w[1].alloc_placed(JK_ROLE_FUSED_LEVEL2, bytes2, JK_PLACE_DRAWS_L2));
+    for (int round = 0; round <= JK_PLACE_DRAWS_L2 && a->P.w[1].measure && !lab::knob_on("GDF_JK_NO_CALIBRATE"); ++round) {
+      a->P.w[1].clock_begin(stream0());
+      GDF_TRY(fj_level2(recv_keys, recv_fill, nseg, cap, g, a->app.cap2, (int32_t)position_base, a->app.cursor.as<uint32_t>(), a->P.tuples(1), &a->keep,
+                        a->P.p6, 4));
+      a->P.w[1].clock_end(stream0());
+      hipLaunchKernelGGL(jk_init_cursor, dim3(32), dim3(256), 0, stream0(), a->app.cursor.as<uint32_t>(), nfine, a->app.cap2);
+      HIP_CHECK_LAST();
+      RMM_TRY(a->P.w[1].alloc_placed(JK_ROLE_FUSED_LEVEL2, bytes2, JK_PLACE_DRAWS_L2));
+    }
     a->app.started = true;
   }
   GDF_TRY(fj_level2(recv_keys, recv_fill, nseg, cap, g, a->app.cap2, (int32_t)position_base, a->app.cursor.as<uint32_t>(), a->P.tuples(1), &a->keep,

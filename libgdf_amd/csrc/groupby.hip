@@ -2135,6 +2135,7 @@ __device__ __forceinline__ uint32_t gbp_opaque_tid() {
 constexpr int GBP_HOT_CAP = 5 * GBP_SC_THREADS;         // 5120 records: 60 KB next to 64 KB of accumulators and 32 KB of counters
 //   * SPEC (round 4, GbSpec): no count pass in front -- every workgroup appends to its own segment of every partition; the scan
 //     step checks the segment's room, a workgroup that runs out raises flags[2] and all of them stop at their next tile.
+constexpr int GB_ROLE_RECORDS = 16, GB_PLACE_DRAWS = 4;      // the placed record buffer of the fused partition pass (gb_sorted_partitioned)
 constexpr uint32_t GBP_SPEC_SKIP = 0xA0000000u;          // a destination at or beyond 2^31: the flush does not store there
 template <bool VBIT, int K0, int K1, bool VMASK, bool HOT = false, bool SPEC = false>
 __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter_static(KeyTable t, GbKeyPlan plan, GbVal val, int fold_op, int low,
@@ -3015,7 +3016,10 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
             spec.G = G;
             spec.xcd = xcd_mode ? 1 : 0;
             if (xcd_mode) HIP_TRY(hipMemsetAsync(spec.fill, 0, sizeof(uint32_t) * (size_t)P * G, stream0()));
-            RMM_TRY(ka.alloc(sizeof(GbRec) * (size_t)(total * G)));
+            // (a PLACED block, DevBuf::alloc_placed: the scatter kernel's thousands of write fronts have their faster and slower physical
+            // placements of this buffer -- 6.98 to 7.35 ms for C5 across re-allocations, profiles/r5_d_c5_scatter_after_reallocation.jsonl;
+            // tournament below)
+            RMM_TRY(ka.alloc_placed(GB_ROLE_RECORDS, sizeof(GbRec) * (size_t)(total * G), GB_PLACE_DRAWS));
             kin = ka.as<K>();
             hp.resize((size_t)P + 1);
             for (uint32_t q = 0; q <= P; ++q) hp[q] = pre[q] * G;
@@ -3032,15 +3036,19 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
       // (exact layout: a key column the count pass skips must lie below the window bits, so that it can tell hot rows from the first column alone)
       if (!is_spec && skip_low && sp.shift[1] + sp.bits[1] > GBP_HOT_BITS) hot_window = GBP_NO_HOT;
       // the cells the partial aggregates are merged into: made BEFORE the scatter kernel, which merges the hot window's
+      const size_t hot_cells_pad = (((size_t)P << id_bits) + 1023) / 1024 * 1024;
+      auto fill_cells = [&]() -> gdf_error {          // (again behind every calibration run of the placement tournament below)
+        GDF_LAUNCH("gb_fill", gb_fill_u64, dim3(stream_grid(hot_cells_pad, 1024)), dim3(256), 0, stream0(), gacc.as<unsigned long long>(),
+                   (unsigned long long)acc_identity_host(fold_op), (uint32_t)hot_cells_pad);
+        HIP_TRY(hipMemsetAsync(grows.p, 0, sizeof(unsigned int) * hot_cells_pad, stream0()));
+        if (vbit) HIP_TRY(hipMemsetAsync(gvalid.p, 0, sizeof(unsigned int) * hot_cells_pad, stream0()));
+        return GDF_SUCCESS;
+      };
       if (hot_window != GBP_NO_HOT) {
-        const size_t cells = (size_t)P << id_bits, cells_pad = (cells + 1023) / 1024 * 1024;
-        RMM_TRY(gacc.alloc(sizeof(uint64_t) * cells_pad));
-        RMM_TRY(grows.alloc(sizeof(unsigned int) * cells_pad));
-        if (vbit) RMM_TRY(gvalid.alloc(sizeof(unsigned int) * cells_pad));
-        GDF_LAUNCH("gb_fill", gb_fill_u64, dim3(stream_grid(cells_pad, 1024)), dim3(256), 0, stream0(), gacc.as<unsigned long long>(),
-                   (unsigned long long)acc_identity_host(fold_op), (uint32_t)cells_pad);
-        HIP_TRY(hipMemsetAsync(grows.p, 0, sizeof(unsigned int) * cells_pad, stream0()));
-        if (vbit) HIP_TRY(hipMemsetAsync(gvalid.p, 0, sizeof(unsigned int) * cells_pad, stream0()));
+        RMM_TRY(gacc.alloc(sizeof(uint64_t) * hot_cells_pad));
+        RMM_TRY(grows.alloc(sizeof(unsigned int) * hot_cells_pad));
+        if (vbit) RMM_TRY(gvalid.alloc(sizeof(unsigned int) * hot_cells_pad));
+        GDF_TRY(fill_cells());
         cells_ready = true;
       }
       const GbHot hot{hot_window, gacc.as<unsigned long long>(), grows.as<unsigned int>(), gvalid.as<unsigned int>(),
@@ -3062,12 +3070,14 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
       const size_t slds = gbp_scatter_lds(is_hot);
       const bool lean = !lab::knob_on("GDF_GBP_OLD");              // A/B switch: the scatter kernel with the type switches for every shape
       const bool sig = lean && key_sig && val_sig;
+      int launch_chunks = nchunks;       // (a calibration run of the placement tournament takes the first quarter of the chunks)
+      auto run_scatter = [&]() -> gdf_error {
       if (sig) {
         const int vm = vbit ? 2 : (val.valid ? 1 : 0);        // 0: no mask, 1: mask, 2: mask + validity bit in the key
         auto scatter = [&](auto kernel) -> gdf_error {
           HIP_TRY(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
           GDF_LAUNCH(is_hot ? "gbp_scatter_hot" : "gbp_scatter", kernel, sgrid, dim3(GBP_SC_THREADS), slds, stream0(), t, sp, val, fold_op, low, P, chunk,
-                     nchunks, (const uint32_t *)hist.as<uint32_t>(), ka.as<GbRec>(), d_flags.as<unsigned int>(), qstride, cstride, hot, spec);
+                     launch_chunks, (const uint32_t *)hist.as<uint32_t>(), ka.as<GbRec>(), d_flags.as<unsigned int>(), qstride, cstride, hot, spec);
           return GDF_SUCCESS;
         };
 #define GBP_SIG(K0, K1)                                                                                                          \
@@ -3087,13 +3097,34 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
       } else {
         auto scatter = [&](auto kernel) -> gdf_error {
           HIP_TRY(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
-          GDF_LAUNCH("gbp_scatter", kernel, sgrid, dim3(GBP_SC_THREADS), slds, stream0(), t, sp, val, fold_op, low, part_bits, P, chunk, nchunks,
+          GDF_LAUNCH("gbp_scatter", kernel, sgrid, dim3(GBP_SC_THREADS), slds, stream0(), t, sp, val, fold_op, low, part_bits, P, chunk, launch_chunks,
                      (const uint32_t *)hist.as<uint32_t>(), ka.as<GbRec>(), qstride, cstride);
           return GDF_SUCCESS;
         };
         if (vbit) GDF_TRY(scatter(gbp_scatter<true>));
         else GDF_TRY(scatter(gbp_scatter<false>));
       }
+      return GDF_SUCCESS;
+      };
+      // PLACEMENT TOURNAMENT of the speculative record buffer (as for the join's tuple buffers, join.hip): while the pool is comparing
+      // placements for this size, every candidate is timed on the real kernel over the first quarter of the chunks; the fill counters,
+      // the flags and the hot window's cells are set back behind each run
+      if (is_spec && sig && !lab::knob_on("GDF_GBP_NO_CALIBRATE")) {
+        const size_t rec_bytes = sizeof(GbRec) * (size_t)(hp[P]);
+        for (int round = 0; round <= GB_PLACE_DRAWS && ka.measure; ++round) {
+          launch_chunks = std::max(1, nchunks / 4);
+          ka.clock_begin(stream0());
+          GDF_TRY(run_scatter());
+          ka.clock_end(stream0());
+          HIP_TRY(hipMemsetAsync(d_flags.p, 0, sizeof(unsigned int) * 4, stream0()));
+          HIP_TRY(hipMemsetAsync(spec.fill, 0, sizeof(uint32_t) * (size_t)P * spec.G, stream0()));
+          if (is_hot) GDF_TRY(fill_cells());
+          RMM_TRY(ka.alloc_placed(GB_ROLE_RECORDS, rec_bytes, GB_PLACE_DRAWS));
+          kin = ka.as<K>();
+        }
+        launch_chunks = nchunks;
+      }
+      GDF_TRY(run_scatter());
       if (chunk_major) {                 // (LAB) the scatter has been timed; the records are not in the layout the aggregation reads
         HIP_TRY(hipStreamSynchronize(stream0()));
         *done = false;

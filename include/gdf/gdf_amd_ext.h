@@ -97,10 +97,7 @@ gdf_error gdf_amd_shuffle_partition_stable(gdf_column *keys, int narrow, int64_t
  *                    `build_rows_total`, and the room `cap` (keys per (bin, XCD) region) for calls of at most `rows_max` rows
  *                    whose keys repeat `rows_per_key` times on average (all copies of a key share a region).
  *                    GDF_UNSUPPORTED_METHOD: this world size / relation size does not fit the path (use the key shuffle).
- * gdf_amd_fj_send    int64 / int32 keys -> out_keys: (world << coarse_bits) bins x 8 regions x cap 4-byte WORDS (key - lo -- or, when
- *                    lo's low 32 bits leave room for 2^31 - 2 keys below the next multiple of 2^32, the 32-bit hash of the key the
- *                    partitioning uses, a bijection of key - lo there: sender and receiver decide alike from lo, the receiver then
- *                    does not hash again, and since the path returns POSITIONS the key values are never needed back; rows
+ * gdf_amd_fj_send    int64 / int32 keys -> out_keys: (world << coarse_bits) bins x 8 regions x cap 4-byte keys (key - lo; rows
  *                    outside [lo, hi] are dropped), rank r's keys in the r-th contiguous block of (8 << coarse_bits) * cap
  *                    elements (+ one tile = 32768 elements of dump space behind the last block); out_pos[i]: the position in
  *                    out_keys that row i's key went to (0xffffffff: dropped) -- it stays with the sender, who can tell from it

@@ -368,12 +368,6 @@ struct PartGeom {
   // LOCAL partition id is taken from the low word of hash_a * world (uniform inside a rank).  0 / 1: single GPU, the id is
   // hash_a's own top bits.
   uint32_t world;
-  // FUSED multi-GPU join, round 5: the stored 32-bit "keys" of a receive buffer ARE hash_a(raw key) already -- the sender computed
-  // the hash to pick rank and region, and ships it instead of the narrowed key (fj_prehash_ok: hash_a is then a bijection of the
-  // narrowed keys, so equal words <=> equal keys, and the fused join returns positions, never key values).  The receiver's level 2
-  // and its probe kernels take partition ids, six-byte remainders and slot hashes from the word as it is; the two quarter-rate
-  // multiplies per tuple of lowbias32 were half of the K32 level-2 kernel's time.
-  int prehashed;
 #ifdef GDF_AMD_LAB
   unsigned long long *lab_clock;     // LAB: jk_scatter1 stores the cycles the first / last wave of a workgroup spent in each phase, [chunk][2][8] (knob GDF_JK_CLOCK)
 #endif
@@ -624,14 +618,8 @@ __host__ __device__ __forceinline__ bool p6_world_ok(uint32_t world) { return wo
 __device__ __forceinline__ uint32_t p6_low(uint32_t hash, uint32_t local, uint32_t world) {
   return (world > 1 && !(world & (world - 1u))) ? __builtin_rotateleft32(hash, 31 - __clz((int)world)) : local;     // = local | mulhi(hash, world)
 }
-// narrowed keys (key - lo, below 2^31 - 1) whose raw values cannot straddle a 2^32 boundary: key_fold is `low word ^ constant`,
-// lowbias32 permutes 32 bits -- hash_a(key32 + lo) is a BIJECTION of key32.  A function of lo alone (the receiver of a fused join
-// does not know the senders' hi), the same on every rank.
-__host__ __device__ __forceinline__ bool fj_prehash_ok(long long lo) {
-  return ((unsigned long long)lo & 0xffffffffULL) + 0x7ffffffeULL < (1ULL << 32);
-}
-__device__ __forceinline__ uint32_t p6_remainder(uint32_t key32, uint64_t kbias, int fb, uint32_t world, int prehashed = 0) {
-  const uint32_t q = prehashed ? key32 : hash_a((uint64_t)key32 + kbias);
+__device__ __forceinline__ uint32_t p6_remainder(uint32_t key32, uint64_t kbias, int fb, uint32_t world) {
+  const uint32_t q = hash_a((uint64_t)key32 + kbias);
   return p6_low(q, local_hash(q, world), world) & ((1u << (32 - fb)) - 1u);
 }
 __device__ __forceinline__ void p6_store(uint64_t *base, uint32_t pos, uint32_t r, uint32_t row) {
@@ -732,7 +720,7 @@ __device__ __forceinline__ void tile_flush(TileLds<NARROW, THREADS, PAY, ITEMS> 
     uint32_t dst[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const uint32_t q = g.prehashed ? (uint32_t)tup_key<NARROW>(ww[u]) : hash_a(tup_key<NARROW>(ww[u]) + g.kbias);
+      const uint32_t q = hash_a(tup_key<NARROW>(ww[u]) + g.kbias);
       const uint32_t h = local_hash(q, g.world);
       const uint32_t f = (uint32_t)((uint64_t)h >> (32 - g.fb));
       const uint32_t bin = LEVEL1 ? (f >> g.b2) : (f & submask);
@@ -1313,9 +1301,8 @@ __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, 
   // power-of-two world (decided once per kernel), the rank remap h * world as a shift: two of the four quarter-rate multiplies
   // per tuple are gone (half of this kernel's time is VALU issue, tools/kernel_blocks.py)
   const uint32_t kb_low = (uint32_t)g.kbias, kb_fold0 = (uint32_t)(g.kbias >> 32) * 0x9e3779b1u, kb_fold1 = kb_fold0 + 0x9e3779b1u;
-  auto rank_tuples = [&](auto pow2_world, auto pre_hashed) {
+  auto rank_tuples = [&](auto pow2_world) {
     constexpr bool POW2W = decltype(pow2_world)::value;
-    constexpr bool PRE = decltype(pre_hashed)::value;              // (K32) the received word IS the hash (PartGeom::prehashed)
     const uint32_t wshift = POW2W ? (uint32_t)(31 - __clz((int)(g.world ? g.world : 1u))) : 0u;
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) {
@@ -1328,8 +1315,7 @@ __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, 
       uint32_t q, lh;
       if constexpr (K32) {
         const uint32_t key32 = (uint32_t)(w[k] >> 32), low = key32 + kb_low;
-        if constexpr (PRE) q = key32;
-        else q = lowbias32(low ^ (low < key32 ? kb_fold1 : kb_fold0));
+        q = lowbias32(low ^ (low < key32 ? kb_fold1 : kb_fold0));
         lh = POW2W ? q << wshift : (uint32_t)((uint64_t)q * g.world);
       } else {
         q = hash_a(tup_key<NARROW>(w[k]) + g.kbias);
@@ -1345,15 +1331,8 @@ __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, 
       }
     }
   };
-  if constexpr (K32) {                                                              // (workgroup-uniform choices)
-    const bool p2 = (g.world & (g.world - 1u)) == 0;
-    if (p2 && g.prehashed) rank_tuples(std::true_type{}, std::true_type{});
-    else if (p2) rank_tuples(std::true_type{}, std::false_type{});
-    else if (g.prehashed) rank_tuples(std::false_type{}, std::true_type{});
-    else rank_tuples(std::false_type{}, std::false_type{});
-  } else {
-    rank_tuples(std::false_type{}, std::false_type{});
-  }
+  if (K32 && (g.world & (g.world - 1u)) == 0) rank_tuples(std::true_type{});      // (workgroup-uniform)
+  else rank_tuples(std::false_type{});
 #pragma unroll
   for (int k = 0; k < ITEMS; ++k)            // sixteen atomics in flight, one wait
     binrank[k] = (binrank[k] << 16) | atomicAdd(&s.hist[binrank[k]], 1u);
@@ -1553,7 +1532,6 @@ struct ProbeArgs {
   int p6_fb;
   uint32_t p6_world;             // PartGeom::world of the build side (fused multi-GPU joins hash with the rank remap)
   uint64_t p6_kbias;
-  int prehashed;                // fused multi-GPU join: the stored keys are hashes already (PartGeom::prehashed)
 };
 // the general kernels' payload write: a gather by probe row (rare units only)
 __device__ __forceinline__ void pay_gather(const ProbeArgs &a, unsigned long long pos, int32_t prow) {
@@ -1638,7 +1616,7 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
   // ---- stage the build partition, clear the table ----
   for (uint32_t i = threadIdx.x; i < u.build_count; i += JK_PROBE_THREADS) {
     uint64_t w = a.build.w[u.build_begin + i];
-    if (P6) w = ((uint64_t)p6_remainder((uint32_t)(w >> 32), a.p6_kbias, a.p6_fb, a.p6_world, a.prehashed) << 32) | (uint32_t)w;
+    if (P6) w = ((uint64_t)p6_remainder((uint32_t)(w >> 32), a.p6_kbias, a.p6_fb, a.p6_world) << 32) | (uint32_t)w;
     l.bw[i] = w;
     if (!NARROW) l.bi[i] = a.build.idx[u.build_begin + i];
   }
@@ -1904,7 +1882,7 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_fast(ProbeArgs a) {
   const Unit u = a.units[blockIdx.x];
   for (uint32_t i = threadIdx.x; i < u.build_count; i += JK_PROBE_THREADS) {
     uint64_t w = a.build.w[u.build_begin + i];
-    if (P6) w = ((uint64_t)p6_remainder((uint32_t)(w >> 32), a.p6_kbias, a.p6_fb, a.p6_world, a.prehashed) << 32) | (uint32_t)w;      // six-byte probe tuples: compare remainders
+    if (P6) w = ((uint64_t)p6_remainder((uint32_t)(w >> 32), a.p6_kbias, a.p6_fb, a.p6_world) << 32) | (uint32_t)w;      // six-byte probe tuples: compare remainders
     l.bw[i] = w;
     if (!NARROW) l.bi[i] = a.build.idx[u.build_begin + i];
   }
@@ -2133,7 +2111,7 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_count_fast(ProbeArgs a) {
   const Unit u = a.units[blockIdx.x];
   for (uint32_t i = threadIdx.x; i < u.build_count; i += JK_PROBE_THREADS) {
     uint64_t w = a.build.w[u.build_begin + i];
-    if (P6) w = ((uint64_t)p6_remainder((uint32_t)(w >> 32), a.p6_kbias, a.p6_fb, a.p6_world, a.prehashed) << 32) | (uint32_t)w;
+    if (P6) w = ((uint64_t)p6_remainder((uint32_t)(w >> 32), a.p6_kbias, a.p6_fb, a.p6_world) << 32) | (uint32_t)w;
     l.bw[i] = w;
     if (!NARROW) l.bi[i] = a.build.idx[u.build_begin + i];
   }
@@ -2461,7 +2439,7 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_multi(ProbeArgs a) 
   const uint32_t mask = 2 * H - 1;
   for (uint32_t i = threadIdx.x; i < u.build_count; i += JK_PROBE_THREADS) {
     uint64_t w = a.build.w[u.build_begin + i];
-    if (P6) w = ((uint64_t)p6_remainder((uint32_t)(w >> 32), a.p6_kbias, a.p6_fb, a.p6_world, a.prehashed) << 32) | (uint32_t)w;
+    if (P6) w = ((uint64_t)p6_remainder((uint32_t)(w >> 32), a.p6_kbias, a.p6_fb, a.p6_world) << 32) | (uint32_t)w;
     l.bw[i] = w;
     l.next[i] = JK_MM_END;
   }
@@ -3386,7 +3364,8 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
   g.spec_flag = spec.as<uint32_t>() + nseg;
   // the deferred main path allocates its two tuple buffers as PLACED blocks (DevBuf::alloc_placed; memory.h): the pool re-draws a
   // physical placement the regroup kernels run slowly on, judged by the times reported here
-  const bool placed = defer && !app && g.b2 > 0 && narrow && !pay;
+  // (every shape of the deferred path: WIDE tuples -- their row numbers, idx[], stay plain allocations -- and payload-carrying ones too)
+  const bool placed = defer && !app && g.b2 > 0;
   if (placed) RMM_TRY(sb->w[0].alloc_placed(JK_ROLE_LEVEL1, l6 ? 6 * (size1 + 2048) + 16 : sizeof(uint64_t) * size1, JK_PLACE_DRAWS));
   else RMM_TRY(sb->w[0].alloc(l6 ? 6 * (size1 + 2048) + 16 : sizeof(uint64_t) * size1));      // (L6: + two dump slots per thread behind the regions)
   if (!narrow) RMM_TRY(sb->idx[0].alloc(sizeof(int32_t) * size1));
@@ -3404,13 +3383,14 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
   // placements for this (role, size) -- the first call of a shape -- every candidate block is timed on a CALIBRATION run, the real kernel
   // over the first quarter of the chunks (every region's write front opens, ~0.8 ms), and handed back with that time; the pool keeps
   // the fastest of JK_PLACE_DRAWS + 1 and this call, and every later one, runs on it.  ~2 ms per candidate, once per shape.
-  if (placed && !pay && !lab::knob_on("GDF_JK_NO_CALIBRATE")) {
+  if (placed && !lab::knob_on("GDF_JK_NO_CALIBRATE")) {
     const size_t bytes1 = l6 ? 6 * (size1 + 2048) + 16 : sizeof(uint64_t) * size1;
     for (int round = 0; round <= JK_PLACE_DRAWS && sb->w[0].measure; ++round) {
       PartGeom gc = g;
       gc.nchunks = std::max(1, g.nchunks / 4);
       sb->w[0].clock_begin(stream0());
-      GDF_TRY(launch_scatter1(fast, narrow, sc_threads, t, plan, gc, nullptr, sb->tuples(0), l6));
+      if (pay) GDF_TRY(launch_scatter1_pay(fast, pmode, t, plan, gc, nullptr, *pay, sb->tuples(0)));
+      else GDF_TRY(launch_scatter1(fast, narrow, sc_threads, t, plan, gc, nullptr, sb->tuples(0), l6));
       sb->w[0].clock_end(stream0());
       HIP_TRY(hipMemsetAsync(spec.p, 0, sizeof(uint32_t) * (nseg + 1), stream0()));
       RMM_TRY(sb->w[0].alloc_placed(JK_ROLE_LEVEL1, bytes1, JK_PLACE_DRAWS));      // (reset() reports the time; the champion or the next challenger comes back)
@@ -4193,7 +4173,6 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
   a.build_matched = d_matched.as<uint8_t>();
   a.dbg = (int)lab::knob_int("GDF_JK_DBG", 0);
   a.kbias = plan.kmin;
-  a.prehashed = g.prehashed;
   if (P.p6) {                       // six-byte probe tuples: the kernels hash and compare hash remainders (ProbeArgs::p6_fb)
     a.p6_fb = g.fb;
     a.p6_world = g.world;
@@ -5198,10 +5177,11 @@ __device__ __forceinline__ T *at32(T *base, uint32_t index) {
 // POW2: the world is a power of two 2^k with k + c1 >= 1 -- rank = mulhi(h, world) is then h's top k bits and the coarse id the next
 // c1, i.e. the bin is ONE shift of the hash instead of a 32 x 32 -> 64 multiply (two quarter-rate instructions; the kernel hashes
 // every key three times and spends ~70 % of its time issuing VALU work, tools/kernel_blocks.py).
-// PRE: the word that travels is hash_a(key) instead of key - lo (PartGeom::prehashed, fj_prehash_ok): the receiver needs no hash, and
-// neither does this kernel's own flush -- a key's bin is then a shift (or one multiply) of the stored word instead of a second and
-// a third lowbias32
-template <class K, bool POW2, bool PRE>
+// (Round 5 shipped the HASH instead of the narrowed key where hash_a is a bijection of it -- no second hash at the receiver, no second and
+// third one in this kernel's flush -- and gained nothing: fused local passes 13.4 - 13.9 against 13.3 - 13.4 ms, the receiver's level 2
+// 3.41 against 3.45, profiles/r5_g_sim_c4_fused_{hash,key}_travels.txt.  Once more the VALU work is hidden; what the receiver's level 2
+// pays for is its 256 bins -- runs of 16 six-byte tuples.  Removed again.)
+template <class K, bool POW2>
 __global__ __launch_bounds__(FJ_THREADS) void fj_scatter(FjSend a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fj_lds[];
   uint32_t *tk = reinterpret_cast<uint32_t *>(fj_lds);                  // [TILE + 4]: narrowed keys regrouped by bin; [TILE] = trash slot
@@ -5219,17 +5199,13 @@ __global__ __launch_bounds__(FJ_THREADS) void fj_scatter(FjSend a) {
   const uint32_t lo_word = (uint32_t)(unsigned long long)a.lo;
   const uint32_t fold0 = (uint32_t)((unsigned long long)a.lo >> 32) * 0x9e3779b1u, fold1 = fold0 + 0x9e3779b1u;
   const uint32_t pow2_shift = 32u - ((uint32_t)a.c1 + (uint32_t)(31 - __clz((int)a.world)));
-  auto hash_of_key = [&](uint32_t key32) -> uint32_t {
+  auto bin_of_key = [&](uint32_t key32) -> uint32_t {
     const uint32_t low = key32 + lo_word;
-    return lowbias32(low ^ (low < key32 ? fold1 : fold0));
-  };
-  auto bin_of_hash = [&](uint32_t h) -> uint32_t {
+    const uint32_t h = lowbias32(low ^ (low < key32 ? fold1 : fold0));
     if constexpr (POW2) return h >> pow2_shift;
     const uint64_t u = (uint64_t)h * a.world;
     return ((uint32_t)(u >> 32) << a.c1) | (uint32_t)((uint64_t)(uint32_t)u >> (32 - a.c1));
   };
-  // the bin of a STORED word: the word is the hash itself (PRE) or the narrowed key, hashed again
-  auto bin_of_key = [&](uint32_t word) -> uint32_t { return bin_of_hash(PRE ? word : hash_of_key(word)); };
   for (uint32_t b = threadIdx.x; b < FJ_MAX_BINS + 4; b += FJ_THREADS) hist[b] = 0;
   block_sync();
   // Every address is the tile's (uniform) base plus a 32-bit offset below 2^18: one register per access instead of a 64-bit
@@ -5279,10 +5255,9 @@ __global__ __launch_bounds__(FJ_THREADS) void fj_scatter(FjSend a) {
           const uint32_t o = (h + k) * FJ_THREADS + tid;
           const unsigned long long off = (unsigned long long)((long long)raw[k] - a.lo);
           const bool travels = (FULL || o < live) && off <= a.span;
-          const uint32_t hsh = hash_of_key((uint32_t)off);           // hashed whether it travels or not: no branch
-          key[h + k] = PRE ? hsh : (uint32_t)off;
+          key[h + k] = (uint32_t)off;
           okmask |= (uint32_t)travels << (h + k);
-          const uint32_t b = bin_of_hash(hsh);
+          const uint32_t b = bin_of_key(key[h + k]);                 // hashed whether it travels or not: no branch
           bin[k] = travels ? b : (uint32_t)FJ_MAX_BINS;              // MAX_BINS: the trash counter
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -5429,15 +5404,8 @@ static gdf_error fj_send(gdf_column *keys, int64_t lo, int64_t hi, int world, in
     GDF_LAUNCH("fj_scatter", kernel, dim3(grid), dim3(FJ_THREADS), lds, stream0(), a);
     return GDF_SUCCESS;
   };
-  // the travelling word: the hash where hash_a is a bijection of the narrowed keys (decided from lo alone, as the receiver does)
-  const bool pre = fj_prehash_ok(lo) && !lab::path_on("GDF_FJ_NO_PREHASH");
-  if (kind == K_I64) {
-    if (pre) GDF_TRY(pow2 ? launch(fj_scatter<long long, true, true>) : launch(fj_scatter<long long, false, true>));
-    else GDF_TRY(pow2 ? launch(fj_scatter<long long, true, false>) : launch(fj_scatter<long long, false, false>));
-  } else {
-    if (pre) GDF_TRY(pow2 ? launch(fj_scatter<int, true, true>) : launch(fj_scatter<int, false, true>));
-    else GDF_TRY(pow2 ? launch(fj_scatter<int, true, false>) : launch(fj_scatter<int, false, false>));
-  }
+  if (kind == K_I64) GDF_TRY(pow2 ? launch(fj_scatter<long long, true>) : launch(fj_scatter<long long, false>));
+  else GDF_TRY(pow2 ? launch(fj_scatter<int, true>) : launch(fj_scatter<int, false>));
   HIP_CHECK_LAST();
   uint32_t flag = 0;
   HIP_TRY(read_back(&flag, out_fill + nregions, sizeof(flag)));
@@ -5486,7 +5454,6 @@ static PartGeom fj_geometry(int world, int fine_bits, int coarse_bits, int64_t l
   g.b2 = fine_bits - coarse_bits;
   g.kbias = (uint64_t)lo;
   g.world = (uint32_t)world;
-  g.prehashed = (fj_prehash_ok(lo) && !lab::path_on("GDF_FJ_NO_PREHASH")) ? 1 : 0;      // the same decision as the senders' (fj_send)
   return g;
 }
 

@@ -57,23 +57,17 @@ def _fused_self_join(gdf, probe, build, world, slices):
 
 @pytest.mark.parametrize("world", [1, 2, 3, 8])
 @pytest.mark.parametrize("dtype", [np.int64, np.int32])
-def test_fused_join_equals_plain_join(gdf, world, dtype, force_path):
+def test_fused_join_equals_plain_join(gdf, world, dtype):
     rs = np.random.RandomState(100 + world)
     nb, npr = 60_000, 400_000
     base = (1 << 40) if dtype == np.int64 else -5000
     build = (rs.permutation(nb * 2)[:nb] + base).astype(dtype)                   # unique keys
     probe = (rs.randint(-1000, nb * 2 + 1000, size=npr) + base).astype(dtype)    # some outside the build range, some misses inside
+    gp, gb = _fused_self_join(gdf, probe, build, world, slices=3)
     el, er = oracle.join([probe], [build], "inner")
+    got = np.stack([gp, gb], axis=1)
     exp = np.stack([el, er], axis=1)
-    exp = exp[np.lexsort(exp.T[::-1])]
-    # int64 keys at 2^40: the HASH travels (fj_prehash_ok); int32 keys around zero: the narrowed key does.  Both against the oracle, and
-    # the first also with the hash switched off (GDF_FJ_NO_PREHASH: sender and receiver decide the same way, from lo alone)
-    for no_prehash in ((None, "1") if dtype == np.int64 else (None,)):
-        force_path("GDF_FJ_NO_PREHASH", no_prehash)
-        gp, gb = _fused_self_join(gdf, probe, build, world, slices=3)
-        got = np.stack([gp, gb], axis=1)
-        np.testing.assert_array_equal(got[np.lexsort(got.T[::-1])], exp)
-    force_path("GDF_FJ_NO_PREHASH", None)
+    np.testing.assert_array_equal(got[np.lexsort(got.T[::-1])], exp[np.lexsort(exp.T[::-1])])
 
 
 @pytest.mark.parametrize("world", [2, 3, 8])
@@ -156,20 +150,8 @@ def test_fused_plan_declines_what_it_cannot_take(gdf):
     assert lay is not None and lay.fine_bits == 15 and lay.coarse_bits == 7 and lay.world * (1 << lay.coarse_bits) == 1024
 
 
-def _hash_a_np(raw):
-    """csrc/join.hip hash_a on int64 raw keys: lowbias32(low word ^ high word * 0x9e3779b1)"""
-    raw = raw.astype(np.uint64)
-    x = ((raw & np.uint64(0xffffffff)) ^ (((raw >> np.uint64(32)) * np.uint64(0x9e3779b1)) & np.uint64(0xffffffff))).astype(np.uint64)
-    m = np.uint64(0xffffffff)
-    x ^= x >> np.uint64(16); x = (x * np.uint64(0x7feb352d)) & m
-    x ^= x >> np.uint64(15); x = (x * np.uint64(0x846ca68b)) & m
-    x ^= x >> np.uint64(16)
-    return x.astype(np.int64)
-
-
-@pytest.mark.parametrize("base", [10**12, 5 << 34], ids=["keys-travel", "hashes-travel"])
 @pytest.mark.parametrize("n", [1, 777, 32768, 32769, 200_001])
-def test_send_buffer_and_positions_describe_the_same_rows(gdf, n, base):
+def test_send_buffer_and_positions_describe_the_same_rows(gdf, n):
     """gdf_amd_fj_send's contract: out_pos[i] is where row i's narrowed key went (0xffffffff for rows outside [lo, hi]); the
     fill counters add up to the rows sent; every region holds only keys of its (rank, coarse partition) bin -- checked through
     the receiver: joining the buffer against the same keys finds every sent row exactly once."""
@@ -177,7 +159,7 @@ def test_send_buffer_and_positions_describe_the_same_rows(gdf, n, base):
     from libgdf_amd import api
     from libgdf_amd.columns import Column
     rs = np.random.RandomState(n)
-    keys = rs.permutation(4 * n + 10)[:n].astype(np.int64) + base
+    keys = rs.permutation(4 * n + 10)[:n].astype(np.int64) + 10**12
     lo, hi = int(keys.min()) + (1 if n > 2 else 0), int(keys.max())           # (n > 2: the smallest key lies outside the range)
     world = 4
     lay = api.fj_plan(world, max(n * world, 1), n)
@@ -190,14 +172,7 @@ def test_send_buffer_and_positions_describe_the_same_rows(gdf, n, base):
     assert int(fill[:lay.nregions].sum()) == int(sent.sum())
     assert len(np.unique(pos[sent])) == int(sent.sum())                         # no two rows share a position
     buf = kb.cpu().numpy().astype(np.int64) & 0xffffffff
-    # the position holds the row's narrowed key -- or, where hash_a is a bijection of the narrowed keys (a lo whose low word leaves room
-    # for 2^31 - 2 keys below the next multiple of 2^32: csrc/join.hip fj_prehash_ok), its 32-bit hash: the receiver then does not hash
-    if (lo & 0xffffffff) + 0x7ffffffe < (1 << 32):
-        assert base == 5 << 34
-        np.testing.assert_array_equal(buf[pos[sent]], _hash_a_np(keys[sent]))
-    else:
-        assert base == 10**12
-        np.testing.assert_array_equal(buf[pos[sent]] + lo, keys[sent])
+    np.testing.assert_array_equal(buf[pos[sent]] + lo, keys[sent])              # the position holds the row's narrowed key
     # positions lie inside the filled part of their region
     region, off = pos[sent] // lay.cap, pos[sent] % lay.cap
     assert bool((off < fill.cpu().numpy()[region]).all())

@@ -186,6 +186,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--null-keys", type=float, default=0.0)
     ap.add_argument("--no-checks", action="store_true", help="timing only (LAB ablations that break the result on purpose)")
+    ap.add_argument("--place-draws", type=int, default=None, help="librmm gdf_amd_rmm_place_draws: 0 = no placement search (PMC runs)")
     ap.add_argument("--force", action="append", default=[], metavar="NAME[=VALUE]",
                     help="path switches set through gdf_amd_debug_force for the whole run, e.g. --force GDF_GBP_PLAIN_RANK=0")
     a = ap.parse_args()
@@ -193,6 +194,8 @@ def main():
     import libgdf_amd as gdf
     from libgdf_amd._binding import rmmOptions_t
     gdf.librmm.rmmInitialize(C.byref(rmmOptions_t(1, 0, False)))
+    if a.place_draws is not None:
+        gdf._binding._rmm_cdll.gdf_amd_rmm_place_draws(C.c_int(a.place_draws))
     for sw in a.force:
         name, _, value = sw.partition("=")
         gdf.libgdf.gdf_amd_debug_force(name.encode(), (value or "1").encode())

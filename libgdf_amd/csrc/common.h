@@ -106,7 +106,16 @@ struct DevBuf {
     }
     p = nullptr;
   }
-  void *release() { void *q = p; p = nullptr; role = -1; measure = false; return q; }      // (a placed block handed on is freed through rmmFree, which knows it)
+  // (a placed block handed on is freed through rmmFree, which knows it; its unreported events go with the hand-over)
+  void *release() {
+    for (int i = 0; i < nev; ++i) (void)hipEventDestroy(ev[i]);
+    nev = 0;
+    void *q = p;
+    p = nullptr;
+    role = -1;
+    measure = false;
+    return q;
+  }
   template <class T> T *as() const { return static_cast<T *>(p); }
 };
 

@@ -24,6 +24,12 @@ def from_db(path):
     per = {}
     for name, dur in c.execute(f"select {name_col}, end-start from kernels"):
         per.setdefault(name, []).append(float(dur))
+    return split_calibration(per)
+
+
+def split_calibration(per):
+    """per: {kernel name: [launch durations, ns]} -> table rows; the calibration launches of the placement tournaments (a launch shorter
+    than 45 % of the same kernel's longest one, kernels of CALIBRATED only) are taken out of the averages and listed in DROPPED"""
     rows = []
     for name, durs in per.items():
         if any(k in name for k in CALIBRATED) and len(durs) > 1:
@@ -34,6 +40,15 @@ def from_db(path):
                 durs = [d for d in durs if d >= 0.45 * longest]
         rows.append((name, len(durs), sum(durs) / 1e6, sum(durs) / len(durs) / 1e6, min(durs) / 1e6, max(durs) / 1e6))
     return sorted(rows, key=lambda r: -r[2])
+
+
+def from_trace_csv(path):
+    """*_kernel_trace.csv of `rocprofv3 --kernel-trace --output-format csv`: one row per dispatch"""
+    per = {}
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            per.setdefault(r["Kernel_Name"], []).append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+    return split_calibration(per)
 
 
 def from_csv(path):
@@ -50,7 +65,8 @@ def main():
     if os.path.isdir(src):
         dbs = glob.glob(os.path.join(src, "**", "*.db"), recursive=True)
         csvs = glob.glob(os.path.join(src, "**", "*kernel_stats.csv"), recursive=True)
-        rows = from_db(dbs[0]) if dbs else from_csv(csvs[0])
+        traces = glob.glob(os.path.join(src, "**", "*kernel_trace.csv"), recursive=True)
+        rows = from_db(dbs[0]) if dbs else (from_trace_csv(traces[0]) if traces else from_csv(csvs[0]))
     else:
         rows = from_db(src) if src.endswith(".db") else from_csv(src)
     total = sum(r[2] for r in rows)

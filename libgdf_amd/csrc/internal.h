@@ -10,10 +10,16 @@ namespace gdf_amd {
 
 // plumbing.cpp: blocking device -> host copy of a few bytes to a few hundred KB through a pinned staging buffer
 hipError_t read_back(void *host_dst, const void *dev_src, size_t bytes);
+// ... and in two halves: _begin queues the copy on the launch stream, _end waits for THAT copy only (what was queued behind it keeps running)
+struct ReadTicket { bool pending = false; int lane = 0; size_t bytes = 0; const void *dev_src = nullptr; };
+hipError_t read_back_begin(ReadTicket *t, const void *dev_src, size_t bytes, int lane);      // lane 0 / 1: one ticket in flight per lane and thread
+hipError_t read_back_end(ReadTicket *t, void *host_dst);
 
 // scan.hip: device-wide prefix sums (in == out allowed)
 gdf_error scan_u32(const uint32_t *in, uint32_t *out, size_t n, bool inclusive);
 gdf_error scan_u64(const uint64_t *in, uint64_t *out, size_t n, bool inclusive);
+// the same without the closing synchronisation: the launches are queued, *scratch (allocated here) must outlive them
+gdf_error scan_u32_async(const uint32_t *in, uint32_t *out, size_t n, bool inclusive, DevBuf *scratch);
 
 // sort.hip: stable ascending lexicographic row order of t's first n rows -> perm (n x uint32).
 // sorted_keys / keys_exact are optional (see sort.hip).

@@ -1434,6 +1434,34 @@ __global__ __launch_bounds__(256) void jk_init_cursor(uint32_t *cur, uint32_t nf
   for (uint32_t f = blockIdx.x * 256 + threadIdx.x; f <= nfine; f += gridDim.x * 256) cur[f] = f < nfine ? (fstart ? fstart[f] : f * cap2) : 0u;   // [nfine]: overflow flag
 }
 
+// level 2's map of an EXACT-layout side from the device copy of its partition index (begin[] = exclusive scan of the fine histogram, cnt[] the
+// histogram): coarse_off[c] = first tuple of coarse partition c (ncoarse + 1 entries), tile_prefix = level-2 tiles before it, cursor[] = a
+// copy of begin[].  One workgroup; what the host computed from the read-back histogram and sent in three copies (round 5: the copies
+// stood between the histogram's read-back and level 1, and their host vectors forced a synchronisation behind level 2).
+__global__ __launch_bounds__(JK_BK_THREADS) void jk_level2_index(const uint32_t *__restrict__ begin, const uint32_t *__restrict__ cnt, uint32_t nfine, int b2,
+                                                                 uint32_t tile, uint32_t *__restrict__ coarse_off, uint32_t *__restrict__ tile_prefix,
+                                                                 uint32_t *__restrict__ cursor) {
+  __shared__ uint32_t lds_wave[JK_BK_THREADS / WAVE];
+  const uint32_t ncoarse = nfine >> b2, total_rows = begin[nfine - 1] + cnt[nfine - 1];
+  uint32_t run = 0;               // (ncoarse <= 2^8 in every geometry; the loop serves any)
+  for (uint32_t base = 0; base < ncoarse; base += JK_BK_THREADS) {
+    const uint32_t c = base + threadIdx.x;
+    uint32_t first = 0, tiles = 0;
+    if (c < ncoarse) {
+      first = begin[(size_t)c << b2];
+      const uint32_t next = c + 1 < ncoarse ? begin[(size_t)(c + 1) << b2] : total_rows;
+      tiles = (next - first + tile - 1) / tile;
+    }
+    uint32_t total;
+    const uint32_t before = bk_block_scan<uint32_t>(tiles, lds_wave, &total);
+    if (c < ncoarse) { coarse_off[c] = first; tile_prefix[c] = run + before; }
+    run += total;
+    block_sync();
+  }
+  if (threadIdx.x == 0) { coarse_off[ncoarse] = total_rows; tile_prefix[ncoarse] = run; }
+  for (uint32_t f = threadIdx.x; f < nfine; f += JK_BK_THREADS) cursor[f] = begin[f];
+}
+
 // ---------------------------------------------------------------------------
 // 4. probe: one workgroup per work unit
 // ---------------------------------------------------------------------------
@@ -2924,6 +2952,18 @@ struct SideBufs {            // partitioned tuples of one relation
   DevBuf d_map;              // the level-2 segment map jk_scatter2 may still be reading
   // device copies of fine_begin / fine_cnt (build side: uploaded once by prepare_build for jk_make_units)
   DevBuf d_begin, d_cnt;
+  // a BUILD side of the main path leaves partition_side with its last launches still queued (round 5: the probe side's first launches
+  // are queued behind them without a host round trip in between): the scratch those launches read or write -- the level-1 buffer, the
+  // histograms' scans, the level-2 map -- waits here and is freed by settle(), behind a synchronisation
+  std::vector<void *> hold;
+  void keep(DevBuf &b) { if (b.p) hold.push_back(b.release()); }
+  void settle() {
+    if (hold.empty()) return;
+    (void)hipStreamSynchronize(stream0());
+    for (void *q : hold) rmmFree(q, (cudaStream_t)0);
+    hold.clear();
+  }
+  ~SideBufs() { settle(); }
   Tuples tuples(int b) const { return Tuples{w[b].as<uint64_t>(), idx[b].as<int32_t>(), pay[b].as<uint64_t>()}; }
   Tuples final() const { return tuples(final_buf); }
 };
@@ -3099,8 +3139,10 @@ static int level2_threads(int sc_threads) {
 }
 
 // pay (may be null) + pmode: the relation carries a payload word per row (PayCarry); NARROW tuples and a FAST key column only
+// keep_running (with device_index: a BUILD side of the main path): nothing waits for the last launches -- the scratch they use goes to
+// sb->hold, the caller settles it (SideBufs::settle) once the stream has been synchronised for some other reason
 static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, SideBufs *sb, bool decide_narrow, const PaySrc *pay = nullptr,
-                                int pmode = 0, bool device_index = false, bool want_p6 = false) {
+                                int pmode = 0, bool device_index = false, bool want_p6 = false, bool keep_running = false) {
   const int64_t n = t.nrows;
   bool narrow = plan.narrow != 0;
   // Chunks are SMALL (a few tiles) and processed in blockIdx order, so that the workgroups resident at
@@ -3142,10 +3184,23 @@ static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, Si
     GDF_LAUNCH("jk_hist", jk_hist<0>, dim3(hist_grid), dim3(JK_HIST_THREADS), hist_lds, stream0(), t, plan, g,
                fine_hist.as<uint32_t>(), H1.as<uint32_t>(), d_mm);
   HIP_CHECK_LAST();
-  GDF_TRY(scan_u32(H1.as<uint32_t>(), H1.as<uint32_t>(), (size_t)ncoarse * g.nchunks, false));
-
+  // the histogram's read-back is queued FIRST and the two scans behind it: they run while the host waits for the copy and lays the
+  // partitions out (round 5: scan, synchronise, read back, scan, synchronise stood in a row here -- 0.2 ms from jk_hist's last wave to
+  // level 1's first on C3's build side, most of it an idle GPU)
   std::vector<uint32_t> fh(hist_bytes / sizeof(uint32_t));
-  HIP_TRY(read_back(fh.data(), fine_hist.p, d_mm ? hist_bytes : sizeof(uint32_t) * nfine));
+  ReadTicket hist_ticket;
+  HIP_TRY(read_back_begin(&hist_ticket, fine_hist.p, d_mm ? hist_bytes : sizeof(uint32_t) * nfine, 0));
+  DevBuf scan_a, scan_b, d_coarse, d_tiles, cursor;
+  // (declared behind every buffer a queued launch may touch, i.e. destroyed in front of them: an early return waits for the stream first)
+  struct Quiesce { bool armed = true; ~Quiesce() { if (armed) (void)hipStreamSynchronize(stream0()); } } quiesce;
+  GDF_TRY(scan_u32_async(H1.as<uint32_t>(), H1.as<uint32_t>(), (size_t)ncoarse * g.nchunks, false, &scan_a));
+  if (device_index) {
+    // a BUILD side: jk_make_units wants the partition index on the device -- the histogram is there already and its exclusive scan is
+    // the partitions' first tuples; uploading the two host vectors cost 0.1 ms of idle GPU behind the build side's last kernel
+    RMM_TRY(sb->d_begin.alloc(sizeof(uint32_t) * nfine));
+    GDF_TRY(scan_u32_async(fine_hist.as<uint32_t>(), sb->d_begin.as<uint32_t>(), nfine, false, &scan_b));
+  }
+  HIP_TRY(read_back_end(&hist_ticket, fh.data()));
   long long h[2] = {LLONG_MAX, LLONG_MIN};
   if (d_mm) {
     const long long *wg = reinterpret_cast<const long long *>(fh.data() + nfine);
@@ -3159,10 +3214,6 @@ static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, Si
   sb->fine_cnt = fh;
   sb->speculative = false;
   if (device_index) {
-    // a BUILD side: jk_make_units wants the partition index on the device -- the histogram is there already and its exclusive scan is
-    // the partitions' first tuples; uploading the two host vectors cost 0.1 ms of idle GPU behind the build side's last kernel
-    RMM_TRY(sb->d_begin.alloc(sizeof(uint32_t) * nfine));
-    GDF_TRY(scan_u32(fine_hist.as<uint32_t>(), sb->d_begin.as<uint32_t>(), nfine, false));
     sb->d_cnt.reset();
     sb->d_cnt.p = fine_hist.release();
   }
@@ -3200,7 +3251,6 @@ static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, Si
   // every staged upload was a stall between the two levels
   const bool level2 = g.b2 > 0 && sb->joinable > 0;
   bool p6 = false;
-  DevBuf d_coarse, d_tiles, cursor;
   uint32_t ntiles = 0;
   std::vector<uint32_t> coarse_off, tile_prefix;
   if (level2) {
@@ -3214,11 +3264,18 @@ static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, Si
     RMM_TRY(d_coarse.alloc(sizeof(uint32_t) * (ncoarse + 1)));
     RMM_TRY(d_tiles.alloc(sizeof(uint32_t) * (ncoarse + 1)));
     RMM_TRY(cursor.alloc(sizeof(uint32_t) * nfine));
-    HIP_TRY(hipMemcpyAsync(d_coarse.p, coarse_off.data(), sizeof(uint32_t) * (ncoarse + 1), hipMemcpyHostToDevice, stream0()));
-    HIP_TRY(hipMemcpyAsync(d_tiles.p, tile_prefix.data(), sizeof(uint32_t) * (ncoarse + 1), hipMemcpyHostToDevice, stream0()));
-    // the cursors start at the partitions' first tuples: with the device index (above) a copy of it, else the host's prefix sums
-    if (device_index) HIP_TRY(hipMemcpyAsync(cursor.p, sb->d_begin.p, sizeof(uint32_t) * nfine, hipMemcpyDeviceToDevice, stream0()));
-    else HIP_TRY(hipMemcpyAsync(cursor.p, sb->fine_off.data(), sizeof(uint32_t) * nfine, hipMemcpyHostToDevice, stream0()));
+    if (device_index) {
+      // the map and the cursors from the device copy of the index (the host keeps ntiles for the grid): no upload, no host vector in flight
+      hipLaunchKernelGGL(jk_level2_index, dim3(1), dim3(JK_BK_THREADS), 0, stream0(), (const uint32_t *)sb->d_begin.as<uint32_t>(),
+                         (const uint32_t *)sb->d_cnt.as<uint32_t>(), nfine, g.b2, (uint32_t)JK_TILE2, d_coarse.as<uint32_t>(), d_tiles.as<uint32_t>(),
+                         cursor.as<uint32_t>());
+      HIP_CHECK_LAST();
+    } else {
+      HIP_TRY(hipMemcpyAsync(d_coarse.p, coarse_off.data(), sizeof(uint32_t) * (ncoarse + 1), hipMemcpyHostToDevice, stream0()));
+      HIP_TRY(hipMemcpyAsync(d_tiles.p, tile_prefix.data(), sizeof(uint32_t) * (ncoarse + 1), hipMemcpyHostToDevice, stream0()));
+      // the cursors start at the partitions' first tuples: the host's prefix sums
+      HIP_TRY(hipMemcpyAsync(cursor.p, sb->fine_off.data(), sizeof(uint32_t) * nfine, hipMemcpyHostToDevice, stream0()));
+    }
     // (a probe side on the exact layout -- skewed probe keys -- writes six-byte tuples as the speculative layout does, see p6_store)
     p6 = want_p6 && narrow && !pay && sc2_threads == 256;
     RMM_TRY(sb->w[1].alloc(p6 ? 6 * (cap + 2) + 16 : sizeof(uint64_t) * (cap + 2)));
@@ -3233,12 +3290,20 @@ static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, Si
     Level2Map m{d_coarse.as<uint32_t>(), d_coarse.as<uint32_t>() + 1, d_tiles.as<uint32_t>()};
     if (ntiles) GDF_TRY(launch_scatter2(narrow, sc2_threads, ntiles, g, m, sb->tuples(0), cursor.as<uint32_t>(), sb->tuples(1), p6));
     HIP_CHECK_LAST();
-    HIP_TRY(hipStreamSynchronize(stream0()));   // host vectors + scratch go out of scope
-    sb->w[0].reset();
-    sb->idx[0].reset();
-    sb->pay[0].reset();
+    if (keep_running && device_index) {          // (no host vector is in flight on this path)
+      for (DevBuf *b : {&sb->w[0], &sb->idx[0], &sb->pay[0], &d_coarse, &d_tiles, &cursor, &H1, &fine_hist, &scan_a, &scan_b}) sb->keep(*b);
+      quiesce.armed = false;
+    } else {
+      HIP_TRY(hipStreamSynchronize(stream0()));   // host vectors + scratch go out of scope
+      sb->w[0].reset();
+      sb->idx[0].reset();
+      sb->pay[0].reset();
+    }
     sb->final_buf = 1;
     sb->p6 = p6;
+  } else if (keep_running && device_index) {
+    for (DevBuf *b : {&H1, &fine_hist, &scan_a, &scan_b}) sb->keep(*b);
+    quiesce.armed = false;
   } else {
     HIP_TRY(hipStreamSynchronize(stream0()));
   }
@@ -3873,13 +3938,16 @@ static gdf_error plan_ranged(const KeyTable &build_t, KeyPlan *plan) {
 
 // bpay / bmode (PayCarry::bmode): the build relation's payload word travels with its tuples when the side ends up on NARROW
 // tuples from one FAST, unmasked key column (partition_side decides; B.pay stays empty otherwise)
-static gdf_error prepare_build(const KeyTable &build_t, BuildSide *bs, bool no_level3 = false, const PaySrc *bpay = nullptr, int bmode = 0) {
+// keep_running: the call returns with the side's last launches still queued (partition_side); the caller settles bs->B
+static gdf_error prepare_build(const KeyTable &build_t, BuildSide *bs, bool no_level3 = false, const PaySrc *bpay = nullptr, int bmode = 0,
+                               bool keep_running = false) {
   bs->plan = plan_keys(build_t);           // a function of the key dtypes only: the probe relation has the same ones
   GDF_TRY(plan_ranged(build_t, &bs->plan));
   bs->g = choose_geometry(build_t.nrows);
   const bool range_candidate = !bs->plan.narrow && bs->plan.mode == KM_RAW_INT && build_t.col[0].width == 8;
   const bool stays_two_level = !(bs->g.b3 > 0 && !no_level3);          // (a third level rewrites the index on the host)
-  GDF_TRY(partition_side(build_t, bs->plan, bs->g, &bs->B, range_candidate, bpay, bmode, stays_two_level));   // may switch plan to the narrow format
+  GDF_TRY(partition_side(build_t, bs->plan, bs->g, &bs->B, range_candidate, bpay, bmode, stays_two_level, false,
+                         keep_running && stays_two_level));   // may switch plan to the narrow format
   if (bs->g.b3 > 0 && !no_level3) {
     bool ok = false;
     GDF_TRY(refine_side(bs->g, bs->plan.narrow != 0, 0.0, &bs->B, &ok));
@@ -3916,6 +3984,7 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
 struct SkewProbe {
   DevBuf sh;
   size_t words = 0;
+  ReadTicket answer;          // the copy of the 4-byte answer is queued right behind the sample: whoever asks later waits for nothing
 };
 static bool skew_probe_wanted(const KeyTable &probe_t, const KeyPlan &plan, const PartGeom &g) {
   return g.fb >= 10 && probe_t.nrows >= ((int64_t)1 << 24) && fast_key_width(probe_t, plan) && plan.mode == KM_RAW_INT &&
@@ -3932,6 +4001,7 @@ static gdf_error skew_probe_launch(const KeyTable &probe_t, const KeyPlan &plan,
     hipLaunchKernelGGL(jk_sample_skew<4>, dim3(JK_SKEW_SAMPLES / 256), dim3(256), 0, stream0(), probe_t.col[0].data, probe_t.nrows, g.fb,
                        sp->sh.as<uint32_t>(), sp->sh.as<uint32_t>() + (sp->words - 1));
   HIP_CHECK_LAST();
+  HIP_TRY(read_back_begin(&sp->answer, sp->sh.as<uint32_t>() + (sp->words - 1), sizeof(uint32_t), 1));
   return GDF_SUCCESS;
 }
 
@@ -3961,7 +4031,7 @@ static gdf_error probe_prepared(const KeyTable &probe_t, const KeyTable &build_t
     SkewProbe *sp = (early_skew && early_skew->sh.p && early_skew->words == ((size_t)1 << g.fb) + 1) ? early_skew : &local;
     if (sp == &local) GDF_TRY(skew_probe_launch(probe_t, plan, g, sp));
     uint32_t fullest = 0;
-    HIP_TRY(read_back(&fullest, sp->sh.as<uint32_t>() + (sp->words - 1), sizeof(uint32_t)));
+    HIP_TRY(read_back_end(&sp->answer, &fullest));
     // expected samples per bin: 2^16 / 2^fb (2 at fb = 15); a Poisson(2) bin reaches 16 with probability ~1e-10
     const double expect = (double)JK_SKEW_SAMPLES / (double)((uint64_t)1 << g.fb);
     skew = (double)fullest > 8.0 * expect + 12.0;
@@ -4520,9 +4590,11 @@ static gdf_error hash_join_core(const KeyTable &probe_t, const KeyTable &build_t
     const PartGeom g0 = choose_geometry(build_t.nrows);
     if (build_t.ncols == 1 && skew_probe_wanted(probe_t, p0, g0)) GDF_TRY(skew_probe_launch(probe_t, p0, g0, &early_skew));
   }
-  GDF_TRY(prepare_build(build_t, &bs, false, bcarry ? &bsrc : nullptr, bcarry ? pc->bmode : 0));
+  // (the build side's last launches are still queued when this returns: the probe side's first ones follow without a host round trip)
+  GDF_TRY(prepare_build(build_t, &bs, false, bcarry ? &bsrc : nullptr, bcarry ? pc->bmode : 0, true));
   clk.mark("partition build side");
   gdf_error e = probe_prepared(probe_t, build_t, bs, kind, out_probe, out_build, out_n, clk, pc, &early_skew);
+  bs.B.settle();
   if (e != GDF_AMD_RETRY_WITHOUT_LEVEL3) return e;
   BuildSide plain;
   GDF_TRY(prepare_build(build_t, &plain, true, bcarry ? &bsrc : nullptr, bcarry ? pc->bmode : 0));

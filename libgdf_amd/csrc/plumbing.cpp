@@ -4,8 +4,7 @@
 // Behaviour follows the reference's src/column.cpp:160-275, src/context.cpp:3-11,
 // src/errorhandling.cpp:5-35, src/cudautils.cu:4-14 and src/nvtx_utils.cpp:19-71
 // (ranges are forwarded to roctx so they show up in rocprofv3 --marker-trace).
-#include "common.h"
-#include "lab.h"
+#include "internal.h"
 
 #include <cstdio>
 #include <cstring>
@@ -62,6 +61,47 @@ hipError_t read_back(void *host_dst, const void *dev_src, size_t bytes) {
   e = hipStreamSynchronize(stream0());
   if (e != hipSuccess) return e;
   std::memcpy(host_dst, pinned, bytes);
+  return hipSuccess;
+}
+
+// The same in two halves (round 5): the copy is queued where the data is ready, the host comes back for it later -- what it queues in
+// between (the scans behind jk_hist, the whole build side behind the skew sample) runs while it waits only for the COPY, not for the
+// stream.  Two independent staging areas per thread (`lane`), one ticket in flight per lane.
+namespace {
+struct ReadLane { void *pinned = nullptr; size_t capacity = 0; hipEvent_t ev = nullptr; };
+thread_local ReadLane g_read_lane[2];
+}
+hipError_t read_back_begin(ReadTicket *t, const void *dev_src, size_t bytes, int lane) {
+  ReadLane &l = g_read_lane[lane & 1];
+  t->pending = false;
+  t->lane = lane & 1;
+  t->bytes = bytes;
+  t->dev_src = dev_src;
+  if (bytes == 0) return hipSuccess;
+  if (!l.ev && hipEventCreateWithFlags(&l.ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); l.ev = nullptr; return hipSuccess; }   // _end falls back to read_back
+  if (bytes > l.capacity) {
+    if (l.pinned) (void)hipHostFree(l.pinned);
+    l.pinned = nullptr;
+    l.capacity = 0;
+    const size_t want = bytes < (1u << 18) ? (1u << 18) : bytes;
+    if (hipHostMalloc(&l.pinned, want, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); l.pinned = nullptr; return hipSuccess; }
+    l.capacity = want;
+  }
+  hipError_t e = hipMemcpyAsync(l.pinned, dev_src, bytes, hipMemcpyDeviceToHost, stream0());
+  if (e != hipSuccess) return e;
+  e = hipEventRecord(l.ev, stream0());
+  if (e != hipSuccess) return e;
+  t->pending = true;
+  return hipSuccess;
+}
+hipError_t read_back_end(ReadTicket *t, void *host_dst) {
+  if (t->bytes == 0) return hipSuccess;
+  if (!t->pending) return read_back(host_dst, t->dev_src, t->bytes);        // no event / no pinned memory: the blocking copy
+  t->pending = false;
+  ReadLane &l = g_read_lane[t->lane];
+  const hipError_t e = hipEventSynchronize(l.ev);
+  if (e != hipSuccess) return e;
+  std::memcpy(host_dst, l.pinned, t->bytes);
   return hipSuccess;
 }
 

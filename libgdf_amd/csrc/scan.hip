@@ -65,7 +65,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_spine(ACC *chunk_sum, int n
   // segments before this one), which is advanced by this segment's total
   __shared__ ACC wsum[SCAN_THREADS / WAVE];
   __shared__ ACC carry;
-  if (threadIdx.x == 0) carry = *running;
+  if (threadIdx.x == 0) carry = running ? *running : (ACC)0;       // (null: a scan in one segment, nothing before it)
   block_sync();
   for (int base = 0; base < nchunks; base += SCAN_THREADS) {
     const int i = base + threadIdx.x;
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_spine(ACC *chunk_sum, int n
     if (threadIdx.x == SCAN_THREADS - 1) carry = c + woff + incl;
     block_sync();
   }
-  if (threadIdx.x == 0) *running = carry;
+  if (running && threadIdx.x == 0) *running = carry;
 }
 
 template <class ACC, class ELEM, int ITEMS>
@@ -613,21 +613,20 @@ __global__ __launch_bounds__(LB_THREADS) void scan_apply_v(const ELEM *in, ELEM 
 }
 
 template <class ACC, class ELEM>
-static gdf_error device_scan_coalesced(const ELEM *in, ELEM *out, size_t n, bool inclusive) {
-  DevBuf sums, running;
+static gdf_error device_scan_coalesced(const ELEM *in, ELEM *out, size_t n, bool inclusive, DevBuf *keep = nullptr) {
+  DevBuf local;
+  DevBuf &sums = keep ? *keep : local;         // keep: the caller holds the scratch, nothing waits here
   RMM_TRY(sums.alloc(sizeof(ACC) * SCAN_MAX_CHUNKS));
-  RMM_TRY(running.alloc(sizeof(ACC)));
-  HIP_TRY(hipMemsetAsync(running.p, 0, sizeof(ACC), stream0()));
   const size_t tiles = (n + LB_TILE - 1) / LB_TILE;
   const size_t tiles_per_chunk = (tiles + SCAN_MAX_CHUNKS - 1) / SCAN_MAX_CHUNKS;
   const size_t chunk = tiles_per_chunk * LB_TILE;
   const int nchunks = (int)((n + chunk - 1) / chunk);
   GDF_LAUNCH("scan_reduce", (scan_reduce_v<ACC, ELEM>), dim3(nchunks), dim3(LB_THREADS), 0, stream0(), in, sums.as<ACC>(), n, chunk);
-  hipLaunchKernelGGL((scan_spine<ACC>), dim3(1), dim3(SCAN_THREADS), 0, stream0(), sums.as<ACC>(), nchunks, running.as<ACC>());
+  hipLaunchKernelGGL((scan_spine<ACC>), dim3(1), dim3(SCAN_THREADS), 0, stream0(), sums.as<ACC>(), nchunks, (ACC *)nullptr);
   GDF_LAUNCH("scan_apply", (scan_apply_v<ACC, ELEM>), dim3(nchunks), dim3(LB_THREADS), 0, stream0(), in, out, sums.as<ACC>(), n, chunk,
              inclusive ? 1 : 0);
   HIP_CHECK_LAST();
-  HIP_TRY(hipStreamSynchronize(stream0()));   // scratch is released on return
+  if (!keep) HIP_TRY(hipStreamSynchronize(stream0()));   // scratch is released on return
   return GDF_SUCCESS;
 }
 
@@ -679,6 +678,12 @@ gdf_error scan_u32(const uint32_t *in, uint32_t *out, size_t n, bool inclusive) 
 }
 gdf_error scan_u64(const uint64_t *in, uint64_t *out, size_t n, bool inclusive) {
   return device_scan<uint64_t, uint64_t>(in, out, n, inclusive);
+}
+gdf_error scan_u32_async(const uint32_t *in, uint32_t *out, size_t n, bool inclusive, DevBuf *scratch) {
+  if (n == 0) return GDF_SUCCESS;
+  if (((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0) && !lab::path_on("GDF_SCAN_BLOCKED") && lab::path_int("GDF_SCAN_LOOKBACK", 0) <= 0)
+    return device_scan_coalesced<uint32_t, uint32_t>(in, out, n, inclusive, scratch);
+  return device_scan<uint32_t, uint32_t>(in, out, n, inclusive);      // (the other kernels synchronise)
 }
 
 }  // namespace gdf_amd

@@ -982,19 +982,43 @@ __global__ __launch_bounds__(GB_LD_THREADS) void gb_ld_aggregate(GbVal val, int 
   }
 }
 
-// out mask byte b covers groups 8b..8b+7 (LSB first); ok == null means every group is valid
+// out mask byte b covers groups 8b..8b+7 (LSB first); ok == null means every group is valid.  The eight flags of a mask byte are ONE
+// 8-byte load where they are all there (rmm allocations are aligned), and the missing groups are counted per wave: one atomic per
+// wave instead of one per mask byte with a null group -- C5's averages have millions of all-null groups, and 2e6 atomics on one word
+// took 0.24 ms of a 9.2 ms call (profiles/r5_l_c5_timeline_before.md)
 __global__ __launch_bounds__(256) void gb_write_mask(const uint8_t *ok, uint32_t n, uint8_t *mask, unsigned int *nulls) {
   const uint32_t nbytes = (n + 7) / 8;
+  const bool words = ok && ((uintptr_t)ok & 7u) == 0;
+  unsigned int missing = 0;
   for (uint32_t b = blockIdx.x * 256 + threadIdx.x; b < nbytes; b += gridDim.x * 256) {
     uint8_t m = 0;
-    unsigned int missing = 0;
-    for (int k = 0; k < 8; ++k) {
-      const uint32_t g = b * 8 + k;
-      if (g >= n) break;
-      if (!ok || ok[g]) m |= (uint8_t)(1u << k); else ++missing;
+    if (!ok) {
+      const uint32_t left = n - b * 8;
+      m = left >= 8 ? 0xffu : (uint8_t)((1u << left) - 1u);
+    } else if (words && b * 8 + 8 <= n) {
+      unsigned long long w = reinterpret_cast<const unsigned long long *>(ok)[b];
+      // every non-zero flag byte -> its top bit (the carry out of its low seven bits, or the top bit itself), moved to bit 0 of the
+      // byte; the multiplication gathers bit 8k into bit 56 + k (no two partial products meet)
+      w = ((((w & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | w) & 0x8080808080808080ull) >> 7;
+      m = (uint8_t)((w * 0x0102040810204080ull) >> 56);
+      missing += 8u - (unsigned int)__popc((unsigned int)m);
+    } else {
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t g = b * 8 + k;
+        if (g >= n) break;
+        if (ok[g]) m |= (uint8_t)(1u << k); else ++missing;
+      }
     }
     mask[b] = m;
-    if (missing) atomicAdd(nulls, missing);
+  }
+  if (ok) {         // (kernel-uniform) one atomic per WORKGROUP: atomics on one word retire at ~3 ns each, whoever sends them
+    __shared__ unsigned int wg_missing;
+    if (threadIdx.x == 0) wg_missing = 0;
+    block_sync();
+    const unsigned int total = wave_reduce_add(missing);
+    if (lane_id() == 0 && total) atomicAdd(&wg_missing, total);
+    block_sync();
+    if (threadIdx.x == 0 && wg_missing) atomicAdd(nulls, wg_missing);
   }
 }
 
@@ -1017,7 +1041,7 @@ static gdf_error write_output_masks(int ncols, gdf_column **out_keys, gdf_column
   }
   out_agg->null_count = 0;
   if (out_agg->valid && ngroups) {
-    hipLaunchKernelGGL(gb_write_mask, dim3(grid), dim3(256), 0, stream0(), agg_ok, ngroups, (uint8_t *)out_agg->valid,
+    hipLaunchKernelGGL(gb_write_mask, dim3(agg_ok && grid > 1024 ? 1024 : grid), dim3(256), 0, stream0(), agg_ok, ngroups, (uint8_t *)out_agg->valid,
                        nulls.as<unsigned int>());
     unsigned int h = 0;
     if (agg_ok) HIP_TRY(read_back(&h, nulls.p, sizeof(h)));
@@ -2880,6 +2904,12 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
   uint32_t hot_window_cells = GBP_NO_HOT;   // the hot window the scatter kernel merged into the cells itself, if any
   GbSpec aggregate_spec{};              // the speculative record layout, when the fused pass ran on it (the plan's device arrays: keep_spec)
   DevBuf keep_spec;
+  // speculative layout: the scatter kernel's flags are looked at LATE -- their copy is queued right behind the kernel, the aggregation
+  // and its counting passes behind the copy, and the host comes back for the flags before it launches the extraction (round 5: the
+  // read-back and the unit list stood between the two big kernels, 0.06 ms of idle GPU, and a synchronising scan behind them)
+  DevBuf late_flags;
+  ReadTicket late_ticket;
+  bool late = false;
   if (fused) {
     if constexpr (sizeof(K) == 4) {
       const uint32_t P = 1u << part_bits;
@@ -2926,6 +2956,22 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
       GbSpec spec{};
       int plain_rank = 0;                 // GbHot::plain_rank, decided from the sample below
       DevBuf d_spec;                      // cap [P] | qprefix [P + 1] | fill [P * G]
+      const size_t hot_cells_pad = (((size_t)P << id_bits) + 1023) / 1024 * 1024;
+      auto fill_cells = [&]() -> gdf_error {          // (again behind every calibration run of the placement tournament below)
+        GDF_LAUNCH("gb_fill", gb_fill_u64, dim3(stream_grid(hot_cells_pad, 1024)), dim3(256), 0, stream0(), gacc.as<unsigned long long>(),
+                   (unsigned long long)acc_identity_host(fold_op), (uint32_t)hot_cells_pad);
+        HIP_TRY(hipMemsetAsync(grows.p, 0, sizeof(unsigned int) * hot_cells_pad, stream0()));
+        if (vbit) HIP_TRY(hipMemsetAsync(gvalid.p, 0, sizeof(unsigned int) * hot_cells_pad, stream0()));
+        return GDF_SUCCESS;
+      };
+      auto make_cells = [&]() -> gdf_error {
+        RMM_TRY(gacc.alloc(sizeof(uint64_t) * hot_cells_pad));
+        RMM_TRY(grows.alloc(sizeof(unsigned int) * hot_cells_pad));
+        if (vbit) RMM_TRY(gvalid.alloc(sizeof(unsigned int) * hot_cells_pad));
+        GDF_TRY(fill_cells());
+        cells_ready = true;
+        return GDF_SUCCESS;
+      };
       if (hot_ok || spec_wanted) {
         const uint32_t nwin = 1u << (sp.total_bits - GBP_HOT_BITS);
         const uint32_t wpp = 1u << (id_bits - GBP_HOT_BITS);                  // sample windows per partition
@@ -2935,8 +2981,13 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
         GDF_LAUNCH("gbp_sample_hist", gbp_sample_hist, dim3(GBP_SAMPLE_WINDOWS / GBP_SAMPLE_PER_WG), dim3(1024), 0, stream0(), t, sp, nwin,
                    d_cnt.as<unsigned int>());
         HIP_CHECK_LAST();
+        // the sample's copy is queued, and behind it the cells every outcome of this pass needs: they are cleared while the host
+        // reads the sample and lays the segments out (round 5; they used to follow that, in front of the scatter kernel)
         std::vector<unsigned int> cnt((size_t)nwin + 1);
-        HIP_TRY(read_back(cnt.data(), d_cnt.p, sizeof(unsigned int) * cnt.size()));
+        ReadTicket sample_ticket;
+        HIP_TRY(read_back_begin(&sample_ticket, d_cnt.p, sizeof(unsigned int) * cnt.size(), 0));
+        GDF_TRY(make_cells());
+        HIP_TRY(read_back_end(&sample_ticket, cnt.data()));
         const double S = (double)cnt[nwin];
         uint32_t best = 0;
         for (uint32_t w = 1; w < nwin; ++w) if (cnt[w] > cnt[best]) best = w;
@@ -3035,22 +3086,8 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
       }
       // (exact layout: a key column the count pass skips must lie below the window bits, so that it can tell hot rows from the first column alone)
       if (!is_spec && skip_low && sp.shift[1] + sp.bits[1] > GBP_HOT_BITS) hot_window = GBP_NO_HOT;
-      // the cells the partial aggregates are merged into: made BEFORE the scatter kernel, which merges the hot window's
-      const size_t hot_cells_pad = (((size_t)P << id_bits) + 1023) / 1024 * 1024;
-      auto fill_cells = [&]() -> gdf_error {          // (again behind every calibration run of the placement tournament below)
-        GDF_LAUNCH("gb_fill", gb_fill_u64, dim3(stream_grid(hot_cells_pad, 1024)), dim3(256), 0, stream0(), gacc.as<unsigned long long>(),
-                   (unsigned long long)acc_identity_host(fold_op), (uint32_t)hot_cells_pad);
-        HIP_TRY(hipMemsetAsync(grows.p, 0, sizeof(unsigned int) * hot_cells_pad, stream0()));
-        if (vbit) HIP_TRY(hipMemsetAsync(gvalid.p, 0, sizeof(unsigned int) * hot_cells_pad, stream0()));
-        return GDF_SUCCESS;
-      };
-      if (hot_window != GBP_NO_HOT) {
-        RMM_TRY(gacc.alloc(sizeof(uint64_t) * hot_cells_pad));
-        RMM_TRY(grows.alloc(sizeof(unsigned int) * hot_cells_pad));
-        if (vbit) RMM_TRY(gvalid.alloc(sizeof(unsigned int) * hot_cells_pad));
-        GDF_TRY(fill_cells());
-        cells_ready = true;
-      }
+      // the cells the partial aggregates are merged into: made BEFORE the scatter kernel, which merges the hot window's (make_cells above)
+      if (hot_window != GBP_NO_HOT && !cells_ready) GDF_TRY(make_cells());
       const GbHot hot{hot_window, gacc.as<unsigned long long>(), grows.as<unsigned int>(), gvalid.as<unsigned int>(),
                       (int)lab::knob_int("GDF_GBP_HOT_DBG", 0), plain_rank};
       auto count = [&](auto kernel) {
@@ -3137,15 +3174,17 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
         hp.resize((size_t)P + 1);
         HIP_TRY(read_back(hp.data(), d_start.p, sizeof(uint32_t) * ((size_t)P + 1)));
       }
-      unsigned int hfl[3] = {0, 0, 0};
-      HIP_TRY(read_back(hfl, d_flags.p, sizeof(hfl)));
-      hf.dropped = hfl[0];              // (speculative layout: nobody counted them; 0 makes nvalid an upper bound, which is all it is used for)
-      j.range_violated = hfl[1] != 0;
-      if (j.range_violated) { *done = false; return GDF_SUCCESS; }      // sample-guessed ranges did not hold: the caller retries exactly
-      if (is_spec && hfl[2]) {
-        // a segment ran out of room (clustered input, or one chance in ~1e8 per segment): everything again on the exact layout
-        ka.reset(); gacc.reset(); grows.reset(); gvalid.reset(); d_spec.reset();
-        return gb_sorted_partitioned<K>(j, sp, vbit, null_bit, done, guessed, false);
+      if (is_spec) {
+        HIP_TRY(read_back_begin(&late_ticket, d_flags.p, sizeof(unsigned int) * 3, 0));
+        late_flags.p = d_flags.release();
+        late = true;
+        hf.dropped = 0;                 // (nobody counted them; 0 makes nvalid an upper bound, which is all it is used for)
+      } else {
+        unsigned int hfl[3] = {0, 0, 0};
+        HIP_TRY(read_back(hfl, d_flags.p, sizeof(hfl)));
+        hf.dropped = hfl[0];
+        j.range_violated = hfl[1] != 0;
+        if (j.range_violated) { *done = false; return GDF_SUCCESS; }      // sample-guessed ranges did not hold: the caller retries exactly
       }
       aggregate_spec = spec;
       keep_spec.p = d_spec.release();
@@ -3156,6 +3195,26 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
                fold_op, vbit, null_key, kin, pin, fl.as<unsigned long long>(), (unsigned int *)(fl.as<unsigned long long>() + 1));
     HIP_TRY(read_back(&hf, fl.p, 16));
   }
+  // 0: go on; 1: the sample-guessed ranges did not hold (the caller retries exactly); 2: a segment of the speculative layout ran out of
+  // room (clustered input, or one chance in ~1e8 per segment): everything again on the exact layout.  Whatever was queued behind the
+  // scatter kernel ran on what it left -- inside its buffers (gb_part_aggregate masks slots by the segments' capacities) -- and is waited for
+  auto late_verdict = [&](int *verdict) -> gdf_error {
+    *verdict = 0;
+    if (!late) return GDF_SUCCESS;
+    late = false;
+    unsigned int hfl[3] = {0, 0, 0};
+    HIP_TRY(read_back_end(&late_ticket, hfl));
+    j.range_violated = hfl[1] != 0;
+    if (j.range_violated) *verdict = 1;
+    else if (hfl[2]) *verdict = 2;
+    if (*verdict) HIP_TRY(hipStreamSynchronize(stream0()));
+    return GDF_SUCCESS;
+  };
+  auto late_exit = [&](int verdict) -> gdf_error {
+    if (verdict == 1) { *done = false; return GDF_SUCCESS; }
+    ka.reset(); gacc.reset(); grows.reset(); gvalid.reset(); keep_spec.reset();
+    return gb_sorted_partitioned<K>(j, sp, vbit, null_bit, done, guessed, false);
+  };
   const uint32_t nvalid = nn - hf.dropped;
   uint32_t ngroups = 0;
   GbOut o{};
@@ -3234,7 +3293,13 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
     }
     const unsigned nblocks = (unsigned)(cells_pad / 1024);
     GDF_LAUNCH("gb_part_count", gb_part_count, dim3(nblocks), dim3(1024), 0, stream0(), (const unsigned int *)grows.as<unsigned int>(), bcnt.as<uint32_t>());
-    GDF_TRY(scan_u32(bcnt.as<uint32_t>(), bcnt.as<uint32_t>(), nblocks, false));
+    DevBuf scan_scratch;
+    GDF_TRY(scan_u32_async(bcnt.as<uint32_t>(), bcnt.as<uint32_t>(), nblocks, false, &scan_scratch));       // (the read-back below waits for it)
+    {
+      int verdict = 0;
+      GDF_TRY(late_verdict(&verdict));
+      if (verdict) return late_exit(verdict);
+    }
     // the number of groups is needed before the outputs can be written only for the optional ok-bytes
     if (want_ok) RMM_TRY(agg_ok.alloc(cells_pad < (size_t)nvalid ? cells_pad : (size_t)nvalid));
     o.agg_ok = agg_ok.as<uint8_t>();
@@ -3243,6 +3308,11 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
                ng.as<unsigned int>());
     HIP_CHECK_LAST();
     HIP_TRY(read_back(&ngroups, ng.p, sizeof(ngroups)));
+  }
+  {
+    int verdict = 0;                    // (no valid row: nothing was queued behind the flags)
+    GDF_TRY(late_verdict(&verdict));
+    if (verdict) return late_exit(verdict);
   }
   for (int c = 0; c < ncols; ++c) out_keys[c]->size = (gdf_size_type)ngroups;
   out_agg->size = (gdf_size_type)ngroups;

@@ -5172,6 +5172,32 @@ static gdf_error accum_finish(ProbeAccum *a, gdf_column *probe_indices, gdf_colu
   gdf_column_view(probe_indices, nullptr, nullptr, 0, N_GDF_TYPES);
   gdf_column_view(build_indices, nullptr, nullptr, 0, N_GDF_TYPES);
   if (!a->app.started) return GDF_SUCCESS;                            // no rows were added
+  // A fused receiver's probe side goes the DEFERRED way of the single-GPU main path (round 5): its fill cursors and their overflow flag
+  // are what jk_make_units reads -- units, output offsets and the sample are made on the device and ONE state block comes back, instead of
+  // the flag, then 2^15 cursors, then a unit list walked and uploaded by the host (0.25 ms of idle GPU in front of the probe kernel)
+  if (a->pb->fj && a->pb->side.B.d_cnt.p && a->pb->side.B.d_begin.p && !lab::knob_on("GDF_JK_NO_DEFER")) {
+    a->P.deferred = true;
+    a->P.speculative = true;
+    a->P.cap2 = a->app.cap2;
+    a->P.nseg = 0;
+    a->P.final_buf = 1;
+    a->P.d_cursor.reset();
+    a->P.d_cursor.p = a->app.cursor.release();
+    KeyTable all = a->pb->table;
+    all.nrows = a->app.rows;
+    for (int c = 0; c < all.ncols; ++c) { all.col[c].data = nullptr; all.col[c].valid = nullptr; }
+    all.any_valid = 0;
+    StageClock clk(false);
+    int32_t *o_probe = nullptr, *o_build = nullptr;
+    int64_t n = 0;
+    const gdf_error e = probe_partitioned(all, a->pb->table, a->pb->side, a->pb->side.plan, a->P, JOIN_INNER, &o_probe, &o_build, &n, clk);
+    if (e == GDF_AMD_RETRY_EXACT_PROBE) return GDF_UNSUPPORTED_METHOD;          // a fine partition outgrew its room (the flag, as below)
+    GDF_TRY(e);
+    if (n == 0) return GDF_SUCCESS;
+    gdf_column_view(probe_indices, o_probe, nullptr, (gdf_size_type)n, GDF_INT32);
+    gdf_column_view(build_indices, o_build, nullptr, (gdf_size_type)n, GDF_INT32);
+    return GDF_SUCCESS;
+  }
   if (a->pb->fj) {                  // the level-2 passes of gdf_amd_fj_probe_add were only queued: their overflow flag is looked at now
     uint32_t flag = 0;
     HIP_TRY(read_back(&flag, a->app.cursor.as<uint32_t>() + (1u << a->pb->side.g.fb), sizeof(flag)));

@@ -35,7 +35,7 @@ for i in 1 2; do python tools/bench_c5.py --force GDF_GBP_NO_XCD 2>/dev/null | t
 python tools/bench_shapes.py > $O/bench_shapes.jsonl 2>/dev/null
 python tools/bench_ops.py > $O/bench_ops.jsonl 2>/dev/null
 python tools/bench_ops.py --rows 1000000000 --ops partition,scan,filter > $O/bench_ops_1e9.jsonl 2>/dev/null
-python tools/sim_c4_fused.py 2>/dev/null | tail -4 > $O/sim_c4_fused.txt
+python tools/sim_c4_fused.py 2>/dev/null | tail -7 > $O/sim_c4_fused.txt
 python bench.py --force-distributed --strategy fused --steps 5 --warmup 3 --probe-rows 1000000000 --build-rows 125000000 --cpu-sample 0 --pandas-sample 0 2>/dev/null | grep '^{' | tail -1 > $O/bench_force_distributed_fused.json
 python tools/stress_join.py --seconds 90 --seed 11 > $O/stress_join.txt 2>&1; tail -3 $O/stress_join.txt
 python tools/stress_groupby.py --seconds 90 --seed 12 > $O/stress_groupby.txt 2>&1; tail -3 $O/stress_groupby.txt

@@ -20,15 +20,18 @@ npr, nb = 1_000_000_000, 125_000_000
 build = make_build_keys(nb, 0x5EED0001, dev)
 probe = make_probe_keys(npr, nb, 0x5EED0002, dev)
 def sync(): torch.cuda.synchronize()
+PHASES = True       # False: no synchronisation between the phases (the last iterations: what the C entry's own sequence looks like)
 def timed(name, fn, acc):
+    if not PHASES: return fn()
     sync(); t = time.perf_counter(); r = fn(); sync(); acc[name] = acc.get(name, 0.0) + (time.perf_counter() - t) * 1e3; return r
 chunks = 4; step = npr // chunks
 lay_b = api.fj_plan(W, nb * W, nb)
 lay_p = api.fj_plan(W, nb * W, step, npr / nb)
 print("layout: fine bits", lay_b.fine_bits, "coarse bits", lay_b.coarse_bits, "bins", W << lay_b.coarse_bits, "cap build/probe", lay_b.cap, lay_p.cap,
       "slack probe %.3f" % (W * lay_p.block / step - 1.0))
-for it in range(4):
+for it in range(7):
     acc = {}
+    PHASES = it < 4
     if it == 3:
         lib.gdf_amd_profile_reset(); lib.gdf_amd_profile_enable(1)
     sync(); t0 = time.perf_counter()
@@ -49,6 +52,7 @@ for it in range(4):
     del li, ri
     b.close()
     sync(); wall = (time.perf_counter() - t0) * 1e3
-    print("iter", it, "pairs", total, "wall ms %.1f" % wall, {k: round(v, 2) for k, v in acc.items()}, flush=True)
+    print("iter", it, "pairs", total, "wall ms %.1f" % wall, {k: round(v, 2) for k, v in acc.items()} if PHASES else "(phases not synchronised)", flush=True)
+    if it == 3: lib.gdf_amd_profile_enable(0)
 lib.gdf_amd_profile_enable(0)
 print({k: (round(v[0], 3), v[1]) for k, v in read_profile(gdf).items()})

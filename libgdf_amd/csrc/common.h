@@ -63,6 +63,7 @@ struct DevBuf {
   // clock_begin / clock_end bracket those launches with HIP events on the launch stream, reset() hands the sum to the pool.
   int role = -1;
   bool measure = false;
+  bool borrowed = false;      // borrow(): p points into somebody else's allocation, nothing is freed here
   hipEvent_t ev[8];
   int nev = 0;
   DevBuf() = default;
@@ -84,8 +85,10 @@ struct DevBuf {
   }
   void clock_begin(hipStream_t s) { if (!(nev & 1)) clock_mark(s); }
   void clock_end(hipStream_t s) { if (nev & 1) clock_mark(s); }
+  void borrow(void *q) { reset(); p = q; borrowed = q != nullptr; }
   void reset() {
     if (!p) return;
+    if (borrowed) { p = nullptr; borrowed = false; return; }
     if (role >= 0) {
       float ms = -1.f;
       if (measure && nev >= 2 && !(nev & 1)) {

@@ -1398,12 +1398,14 @@ __device__ __forceinline__ T bk_block_scan(T v, T *lds_wave, T *total) {
 // ((s * ncoarse + c) << 3) | x -- but they are PROCESSED coarse-partition-major, segment ((c * world + s) << 3) | x: all tiles
 // of a coarse partition are then neighbours in the tile order, i.e. run on one XCD, whose L2 merges the short runs they
 // write into the same fine partitions (the reason for jk_scatter2's XCD-ordered tiles)
+constexpr uint32_t JK_L2MAP_LDS_SEGS = 16384;      // segments the staged version of jk_make_l2map holds (64 KB of LDS): C3's 2^(8 + 6)
 __global__ __launch_bounds__(JK_BK_THREADS) void jk_make_l2map(const uint32_t *__restrict__ fill, uint32_t nseg, uint32_t cap1, uint32_t tile,
                                                                uint32_t *__restrict__ seg_begin, uint32_t *__restrict__ seg_end,
                                                                uint32_t *__restrict__ tile_prefix, uint32_t *__restrict__ ntiles,
                                                                uint32_t fj_world, uint32_t ncoarse, const uint32_t *__restrict__ rstart = nullptr,
                                                                const uint32_t *__restrict__ rcap = nullptr) {
   __shared__ uint32_t lds_wave[JK_BK_THREADS / WAVE];
+  extern __shared__ __attribute__((aligned(16))) uint32_t l2map_lds[];      // [nseg] (staged version; the launcher sizes it, 0 words otherwise)
   const uint32_t per = (nseg + JK_BK_THREADS - 1) / JK_BK_THREADS;
   const uint32_t c0 = threadIdx.x * per;
   auto region_of = [&](uint32_t seg) -> uint32_t {
@@ -1416,8 +1418,43 @@ __global__ __launch_bounds__(JK_BK_THREADS) void jk_make_l2map(const uint32_t *_
   // run past the region and, for the last ones, past the buffer.  (Found by tools/stress_join.py: an illegal address on a
   // probe side with a tenth of its rows on one key.)
   auto filled = [&](uint32_t region) -> uint32_t { const uint32_t n = fill[region], room = rcap ? rcap[region] : cap1; return n < room ? n : room; };
+  const bool pow2 = (tile & (tile - 1u)) == 0;
+  const int shift = __ffs((int)tile) - 1;
+  auto tiles_of = [&](uint32_t n) -> uint32_t { return pow2 ? (n + tile - 1u) >> shift : (n + tile - 1u) / tile; };
+  if (nseg <= JK_L2MAP_LDS_SEGS) {
+    // STAGED (round 5): this one workgroup stands between the two regroup kernels of a probe side -- 41 us when every thread walked its 16
+    // segments twice through strided global reads.  Every global access is coalesced now (segment k * 1024 + thread), the counters are
+    // read once, and the per-thread runs of the scan go through LDS.
+    constexpr int MAXK = (int)(JK_L2MAP_LDS_SEGS / JK_BK_THREADS);
+    uint32_t n_[MAXK], first_[MAXK];
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) {
+      const uint32_t c = (uint32_t)k * JK_BK_THREADS + threadIdx.x;
+      n_[k] = 0; first_[k] = 0;
+      if (c < nseg) {
+        const uint32_t r = region_of(c);
+        n_[k] = filled(r);
+        first_[k] = rstart ? rstart[r] : r * cap1;
+        l2map_lds[c] = tiles_of(n_[k]);
+      }
+    }
+    block_sync();
+    uint32_t mine = 0;
+    for (uint32_t c = c0; c < c0 + per && c < nseg; ++c) mine += l2map_lds[c];
+    uint32_t total;
+    uint32_t run = bk_block_scan<uint32_t>(mine, lds_wave, &total);
+    for (uint32_t c = c0; c < c0 + per && c < nseg; ++c) { const uint32_t t = l2map_lds[c]; l2map_lds[c] = run; run += t; }
+    block_sync();
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) {
+      const uint32_t c = (uint32_t)k * JK_BK_THREADS + threadIdx.x;
+      if (c < nseg) { seg_begin[c] = first_[k]; seg_end[c] = first_[k] + n_[k]; tile_prefix[c] = l2map_lds[c]; }
+    }
+    if (threadIdx.x == 0) { tile_prefix[nseg] = total; *ntiles = total; }
+    return;
+  }
   uint32_t mine = 0;
-  for (uint32_t c = c0; c < c0 + per && c < nseg; ++c) mine += (filled(region_of(c)) + tile - 1) / tile;
+  for (uint32_t c = c0; c < c0 + per && c < nseg; ++c) mine += tiles_of(filled(region_of(c)));
   uint32_t total;
   uint32_t run = bk_block_scan<uint32_t>(mine, lds_wave, &total);
   for (uint32_t c = c0; c < c0 + per && c < nseg; ++c) {
@@ -1426,9 +1463,14 @@ __global__ __launch_bounds__(JK_BK_THREADS) void jk_make_l2map(const uint32_t *_
     seg_begin[c] = first;
     seg_end[c] = first + n;
     tile_prefix[c] = run;
-    run += (n + tile - 1) / tile;
+    run += tiles_of(n);
   }
   if (threadIdx.x == 0) { tile_prefix[nseg] = total; *ntiles = total; }
+}
+static gdf_error l2map_prepare(uint32_t nseg, size_t *lds) {
+  *lds = nseg <= JK_L2MAP_LDS_SEGS ? sizeof(uint32_t) * (size_t)nseg : 0;
+  HIP_TRY(hipFuncSetAttribute((const void *)jk_make_l2map, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(uint32_t) * JK_L2MAP_LDS_SEGS)));
+  return GDF_SUCCESS;
 }
 __global__ __launch_bounds__(256) void jk_init_cursor(uint32_t *cur, uint32_t nfine, uint32_t cap2, const uint32_t *__restrict__ fstart = nullptr) {
   for (uint32_t f = blockIdx.x * 256 + threadIdx.x; f <= nfine; f += gridDim.x * 256) cur[f] = f < nfine ? (fstart ? fstart[f] : f * cap2) : 0u;   // [nfine]: overflow flag
@@ -2944,7 +2986,9 @@ struct SideBufs {            // partitioned tuples of one relation
   bool deferred = false;
   bool p6 = false;           // the fine-partitioned tuples of this (deferred probe) side are six-byte ones (p6_store)
   uint32_t cap2 = 0;
-  DevBuf d_level1;           // [nseg + 1] level-1 fill counters + overflow flag
+  DevBuf d_level1;           // [nseg + 1] level-1 fill counters + overflow flag; behind them (8-byte aligned) the words of `zero`
+  unsigned long long *zero = nullptr;     // 16 zeroed 8-byte words inside d_level1, cleared with the counters in front of level 1: the state
+                                          // blocks of probe_partitioned (units + sample 8 | tails 4 | write pass 4) need no memset of their own
   DevBuf d_caps;             // per-partition room of a skewed probe side (SkewCaps): rstart | rcap | fstart | fcap, else empty
   const uint32_t *d_fstart = nullptr, *d_fcap = nullptr;
   uint32_t nseg = 0;
@@ -3408,8 +3452,10 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
   if (size1 >= 0x7fffffffULL || size2 >= 0x7fffffffULL) return GDF_SUCCESS;      // tuple positions are 31-bit
 
   DevBuf spec;
-  RMM_TRY(spec.alloc(sizeof(uint32_t) * (nseg + 1)));
-  HIP_TRY(hipMemsetAsync(spec.p, 0, sizeof(uint32_t) * (nseg + 1), stream0()));
+  constexpr size_t ZERO_WORDS = 32;                            // SideBufs::zero
+  const size_t zero_at = ((size_t)nseg + 2) / 2 * 2;          // (the first even word index behind the nseg + 1 counters)
+  RMM_TRY(spec.alloc(sizeof(uint32_t) * (zero_at + ZERO_WORDS)));
+  HIP_TRY(hipMemsetAsync(spec.p, 0, sizeof(uint32_t) * (zero_at + ZERO_WORDS), stream0()));
   g.kbias = plan.kmin;
   g.cap1 = cap1;
   g.cap2 = 0;
@@ -3461,6 +3507,13 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
       RMM_TRY(sb->w[0].alloc_placed(JK_ROLE_LEVEL1, bytes1, JK_PLACE_DRAWS));      // (reset() reports the time; the champion or the next challenger comes back)
     }
   }
+  // DEFERRED: level 2's fill cursors are set IN FRONT of level 1 (nothing of level 1 is in them): one launch less between the two kernels
+  DevBuf d_map, cursor;
+  if (defer && !app && g.b2 > 0) {
+    RMM_TRY(cursor.alloc(sizeof(uint32_t) * ((size_t)nfine + 2)));             // fill cursors | level-2 overflow flag | tile count
+    hipLaunchKernelGGL(jk_init_cursor, dim3(32), dim3(256), 0, stream0(), cursor.as<uint32_t>(), nfine, cap2, g.fstart);
+    HIP_CHECK_LAST();
+  }
   sb->w[0].clock_begin(stream0());
   if (pay) GDF_TRY(launch_scatter1_pay(fast, pmode, t, plan, g, nullptr, *pay, sb->tuples(0)));
   else GDF_TRY(launch_scatter1(fast, narrow, sc_threads, t, plan, g, nullptr, sb->tuples(0), l6));
@@ -3493,14 +3546,13 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
   if (defer && !app && g.b2 > 0) {
     // DEFERRED: the level-2 map and the fill cursors are made on the device, nothing is read back here; the overflow flags
     // of both levels are looked at once, with the work units (jk_make_units / probe_partitioned)
-    DevBuf d_map, cursor;
     RMM_TRY(d_map.alloc(sizeof(uint32_t) * (3 * (size_t)nseg + 2)));          // segment begins | segment ends | tile prefix [nseg + 1]
-    RMM_TRY(cursor.alloc(sizeof(uint32_t) * ((size_t)nfine + 2)));             // fill cursors | level-2 overflow flag | tile count
     uint32_t *seg_begin = d_map.as<uint32_t>(), *seg_end = seg_begin + nseg, *tile_prefix = seg_end + nseg;
     uint32_t *ntiles_dev = cursor.as<uint32_t>() + nfine + 1;
-    hipLaunchKernelGGL(jk_make_l2map, dim3(1), dim3(JK_BK_THREADS), 0, stream0(), (const uint32_t *)spec.as<uint32_t>(), nseg, cap1,
+    size_t map_lds = 0;
+    GDF_TRY(l2map_prepare(nseg, &map_lds));
+    hipLaunchKernelGGL(jk_make_l2map, dim3(1), dim3(JK_BK_THREADS), map_lds, stream0(), (const uint32_t *)spec.as<uint32_t>(), nseg, cap1,
                        (uint32_t)JK_TILE2, seg_begin, seg_end, tile_prefix, ntiles_dev, 0u, 0u, g.rstart, g.rcap);
-    hipLaunchKernelGGL(jk_init_cursor, dim3(32), dim3(256), 0, stream0(), cursor.as<uint32_t>(), nfine, cap2, g.fstart);
     HIP_CHECK_LAST();
     const bool p6 = want_p6 && narrow && !pay && sc2_threads == 256;
     if (placed) RMM_TRY(sb->w[1].alloc_placed(JK_ROLE_LEVEL2, p6 ? 6 * size2 + 16 : sizeof(uint64_t) * size2, JK_PLACE_DRAWS_L2));
@@ -3542,6 +3594,7 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
     sb->speculative = true;
     sb->cap2 = cap2;
     sb->nseg = nseg;
+    sb->zero = reinterpret_cast<unsigned long long *>(spec.as<uint32_t>() + zero_at);
     sb->d_level1.p = spec.release();
     sb->d_cursor.p = cursor.release();
     *ok = true;
@@ -4136,8 +4189,11 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
     const size_t unit_bound = (size_t)nfine + (size_t)(probe_t.nrows / JK_PROBE_CHUNK) + 2;
     RMM_TRY(d_units.alloc(sizeof(Unit) * unit_bound));
     RMM_TRY(d_off.alloc(sizeof(uint64_t) * (unit_bound + 1)));
-    RMM_TRY(d_bk.alloc(sizeof(bk)));
-    HIP_TRY(hipMemsetAsync(d_bk.p, 0, sizeof(bk), stream0()));
+    if (P.zero) d_bk.borrow(P.zero);
+    else {
+      RMM_TRY(d_bk.alloc(sizeof(bk)));
+      HIP_TRY(hipMemsetAsync(d_bk.p, 0, sizeof(bk), stream0()));
+    }
     hipLaunchKernelGGL(jk_make_units, dim3((nfine + 255) / 256), dim3(256), 0, stream0(), nfine, P.cap2, (const uint32_t *)P.d_cursor.as<uint32_t>(),
                        (const uint32_t *)(P.d_level1.as<uint32_t>() + P.nseg), (const uint32_t *)B.d_begin.as<uint32_t>(),
                        (const uint32_t *)B.d_cnt.as<uint32_t>(), keep_probe ? 1 : 0, d_units.as<Unit>(), d_off.as<uint64_t>(),
@@ -4168,8 +4224,11 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
   uint32_t H_lds = 64;
   while (H_lds < max_build) H_lds <<= 1;
 
-  RMM_TRY(d_tail.alloc(sizeof(unsigned long long) * 4));
-  HIP_TRY(hipMemsetAsync(d_tail.p, 0, sizeof(unsigned long long) * 4, stream0()));
+  if (deferred && P.zero) d_tail.borrow(P.zero + 8);
+  else {
+    RMM_TRY(d_tail.alloc(sizeof(unsigned long long) * 4));
+    HIP_TRY(hipMemsetAsync(d_tail.p, 0, sizeof(unsigned long long) * 4, stream0()));
+  }
   if (kind == JOIN_FULL) {
     RMM_TRY(d_matched.alloc((size_t)(build_t.nrows ? build_t.nrows : 1)));
     HIP_TRY(hipMemsetAsync(d_matched.p, 0, (size_t)(build_t.nrows ? build_t.nrows : 1), stream0()));
@@ -4335,8 +4394,11 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
                           sample_hit <= lab::knob_float("GDF_JK_SPARSE_MAX", 1.0) && !lab::path_on("GDF_JK_NO_SPARSE_OPT");
   if (try_optimistic || try_sparse) {
     DevBuf d_state, d_upairs;
-    RMM_TRY(d_state.alloc(sizeof(unsigned long long) * 4));
-    HIP_TRY(hipMemsetAsync(d_state.p, 0, sizeof(unsigned long long) * 4, stream0()));
+    if (deferred && P.zero) d_state.borrow(P.zero + 12);
+    else {
+      RMM_TRY(d_state.alloc(sizeof(unsigned long long) * 4));
+      HIP_TRY(hipMemsetAsync(d_state.p, 0, sizeof(unsigned long long) * 4, stream0()));
+    }
     const uint64_t probe_tail = keep_probe ? (uint64_t)probe_t.nrows - P.joinable : 0;
     const uint64_t total = cap_pairs + probe_tail;
     if (total >= (uint64_t)INT_MAX) return GDF_COLUMN_SIZE_TOO_BIG;
@@ -5526,7 +5588,9 @@ static gdf_error fj_level2(const uint32_t *keys, const uint32_t *fill, uint32_t 
   RMM_TRY(d_map.alloc(sizeof(uint32_t) * (3 * (size_t)nseg + 2)));
   uint32_t *seg_begin = d_map.as<uint32_t>(), *seg_end = seg_begin + nseg, *tile_prefix = seg_end + nseg;
   uint32_t *ntiles_dev = cursor + nfine + 1;
-  hipLaunchKernelGGL(jk_make_l2map, dim3(1), dim3(JK_BK_THREADS), 0, stream0(), fill, nseg, cap, (uint32_t)TILE2, seg_begin, seg_end, tile_prefix,
+  size_t map_lds = 0;
+  GDF_TRY(l2map_prepare(nseg, &map_lds));
+  hipLaunchKernelGGL(jk_make_l2map, dim3(1), dim3(JK_BK_THREADS), map_lds, stream0(), fill, nseg, cap, (uint32_t)TILE2, seg_begin, seg_end, tile_prefix,
                      ntiles_dev, g.world, 1u << g.b1);
   HIP_CHECK_LAST();
   PartGeom g2 = g;

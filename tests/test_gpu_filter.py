@@ -67,6 +67,38 @@ def test_apply_stencil(gdf, dtype, n):
     assert bits[: len(exp)].all() and not bits[len(exp):].any()
 
 
+@pytest.mark.parametrize("keep", [0.0, 0.03, 1.0])
+@pytest.mark.parametrize("dtype", [np.int8, np.int16, np.float32, np.int64], ids=lambda d: np.dtype(d).name)
+def test_apply_stencil_selectivity_extremes_and_unaligned_slices(gdf, dtype, keep):
+    """The LDS-staged write kernel (whole 4096-row tiles, a ragged last one) at no / few / all rows kept, and -- a column that starts in
+    the middle of an allocation is not 16-byte aligned -- the kernels it falls back to."""
+    n = 3 * 4096 * 7 + 1234
+    a = gen_rand(dtype, n + 3)
+    st = (np.random.random(n + 3) < keep).astype(np.int8)
+    import torch
+    from libgdf_amd.columns import Column
+    ta, ts = torch.from_numpy(a).cuda(), torch.from_numpy(st).cuda()
+    for off in (0, 3):
+        av, sv_ = a[off:off + n], st[off:off + n]
+        out = gdf.api.apply_stencil(Column(ta[off:off + n]), Column(ts[off:off + n]))
+        exp = av[sv_ != 0]
+        assert out.size == len(exp)
+        np.testing.assert_array_equal(out.to_numpy(), exp)
+
+
+@pytest.mark.parametrize("ldt", ALL_DTYPES, ids=lambda d: np.dtype(d).name)
+def test_comparison_vector_kernel_and_its_tail(gdf, ldt):
+    """16-byte-vector compare (round 5): whole vectors + a tail of n % (16 / width) rows, against a column of the same width and a scalar."""
+    n = 70_001
+    a, b = gen_rand(ldt, n), gen_rand(ldt, n)
+    b[::3] = a[::3]
+    for op, fn in enumerate([np.equal, np.not_equal, np.less, np.less_equal, np.greater, np.greater_equal]):
+        got = gdf.api.comparison(_col(a), _col(b), op).to_numpy()
+        np.testing.assert_array_equal(got.astype(bool), fn(a, b))
+        got = gdf.api.comparison(_col(a), a[7], op).to_numpy()
+        np.testing.assert_array_equal(got.astype(bool), fn(a, a[7]))
+
+
 def test_filter_then_compact_pipeline_large(gdf):
     """SURVEY 8d micro-metric shape at 20M rows: col > v, then compaction; ~10 % selectivity."""
     n = 20_000_000

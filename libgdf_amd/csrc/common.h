@@ -70,9 +70,10 @@ struct DevBuf {
   DevBuf(const DevBuf &) = delete;
   DevBuf &operator=(const DevBuf &) = delete;
   ~DevBuf() { reset(); }
-  rmmError_t alloc(size_t bytes) { reset(); return rmmAlloc(&p, bytes ? bytes : 1, (cudaStream_t)0); }
+  rmmError_t alloc(size_t bytes) { reset(); borrowed = false; return rmmAlloc(&p, bytes ? bytes : 1, (cudaStream_t)0); }
   rmmError_t alloc_placed(int role_, size_t bytes, int max_draws = 0) {
     reset();
+    borrowed = false;
     int m = 0;
     const rmmError_t r = gdf_amd_rmm_place_alloc(role_, bytes ? bytes : 1, max_draws, &p, &m);
     if (r == RMM_SUCCESS) { role = role_; measure = m != 0; }
@@ -117,6 +118,7 @@ struct DevBuf {
     p = nullptr;
     role = -1;
     measure = false;
+    borrowed = false;         // (a borrowed pointer handed on stays the lender's to free)
     return q;
   }
   template <class T> T *as() const { return static_cast<T *>(p); }

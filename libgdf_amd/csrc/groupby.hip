@@ -2159,7 +2159,7 @@ __device__ __forceinline__ uint32_t gbp_opaque_tid() {
 constexpr int GBP_HOT_CAP = 5 * GBP_SC_THREADS;         // 5120 records: 60 KB next to 64 KB of accumulators and 32 KB of counters
 //   * SPEC (round 4, GbSpec): no count pass in front -- every workgroup appends to its own segment of every partition; the scan
 //     step checks the segment's room, a workgroup that runs out raises flags[2] and all of them stop at their next tile.
-constexpr int GB_ROLE_RECORDS = 16, GB_PLACE_DRAWS = 4;      // the placed record buffer of the fused partition pass (gb_sorted_partitioned)
+constexpr int GB_ROLE_RECORDS = 16, GB_PLACE_DRAWS = 6;      // the placed record buffer of the fused partition pass (gb_sorted_partitioned)
 constexpr uint32_t GBP_SPEC_SKIP = 0xA0000000u;          // a destination at or beyond 2^31: the flush does not store there
 template <bool VBIT, int K0, int K1, bool VMASK, bool HOT = false, bool SPEC = false>
 __global__ __launch_bounds__(GBP_SC_THREADS) void gbp_scatter_static(KeyTable t, GbKeyPlan plan, GbVal val, int fold_op, int low,

@@ -330,7 +330,7 @@ constexpr int JK_ROLE_FUSED_LEVEL2 = 5;                     // ... and the level
 // challengers of the placement tournaments (partition_side_spec, probe_partitioned).  Level 1 has two MODES, about one fresh block in
 // five is a fast one (profiles/r5_b_place_trace_*.json): 8 challengers.  Level 2 and the output columns spread over ~10 % without
 // modes (r5_e_place_trace_*.json): fewer candidates get most of what there is, and every candidate is 4 - 7 GB of allocator churn.
-constexpr int JK_PLACE_DRAWS = 8, JK_PLACE_DRAWS_L2 = 5, JK_PLACE_DRAWS_OUT = 4;
+constexpr int JK_PLACE_DRAWS = 16, JK_PLACE_DRAWS_L2 = 8, JK_PLACE_DRAWS_OUT = 6;
 
 struct PartGeom {
   int fb, b1, b2;        // fine bits = b1 (level 1) + b2 (level 2)

@@ -68,7 +68,8 @@ void        gdf_amd_rmm_contiguous(int on);
    back non-zero while the pool is still comparing placements for this (role, size) and wants to be told on _place_free how long the
    kernels that scatter into the block took (milliseconds; < 0: unknown).  Blocks below 1 GiB and non-pool modes fall through to
    rmmAlloc / rmmFree.  _place_draws: challengers per (role, size), default 4; 0: never re-draw; < 0: plain pool.  max_draws > 0: this
-   caller's own number of challengers (one that times a short calibration run per candidate inside ONE call can afford more). */
+   caller's own number of challengers (one that times a short calibration run per candidate inside ONE call can afford more).  A search ends
+   before its last draw once four challengers are drawn and the champion is 7 % faster than the slowest candidate timed (early settle). */
 rmmError_t  gdf_amd_rmm_place_alloc(int role, size_t size, int max_draws, void **ptr, int *measure);
 rmmError_t  gdf_amd_rmm_place_free(int role, void *ptr, float ms);
 void        gdf_amd_rmm_place_draws(int draws);

@@ -156,7 +156,7 @@ def test_placed_blocks_keep_the_fastest_candidate(rmm):
         seen.append((p.value, m.value))
         assert lib.gdf_amd_rmm_place_free(role2, p, 4.0 - i if m.value else -1.0) == 0     # every candidate faster than the last
     assert [m for _, m in seen] == [1, 1, 1, 1, 0] and len({p for p, _ in seen[:4]}) == 4 and seen[4][0] == seen[3][0]
-    # EARLY SETTLE: with at least four challengers drawn and a champion 5 % faster than the slowest candidate seen, the search ends
+    # EARLY SETTLE: with at least four challengers drawn and a champion 7 % faster than the slowest candidate seen, the search ends
     # before its last draw (the join asks for up to sixteen: most searches end after four to six)
     role3 = 11
     times = [10.0, 10.1, 9.9, 10.0, 9.0, 9.5, 9.5]      # champion, then challengers; the fourth challenger is the fast one

@@ -557,19 +557,21 @@ template <bool NARROW, int THREADS, bool PAY = false, int ITEMS = JK_SC_ITEMS>
 struct TileLds {
   // + a trash slot: tuples that do not travel are written there.  The 1024-thread level-1 tile also has room for the padding of
   // six-byte tuples (L6: every bin's run is padded to an even length, up to 256 dead tuples per tile)
-  static constexpr int PAD = (THREADS == 1024 && NARROW && !PAY) ? 256 : 0;
+  // (the WIDE 1024-thread tile is the ten-byte one, W10: 12 tuples per thread, padded the same way)
+  static constexpr int PAD = (THREADS == 1024 && !PAY) ? 256 : 0;
   uint64_t w[THREADS * ITEMS + PAD + 2];
-  int32_t idx[NARROW ? 4 : THREADS * ITEMS + 4];
+  int32_t idx[NARROW ? 4 : THREADS * ITEMS + PAD + 4];  // WIDE: the row numbers; W10 / P10 tiles: the key's high words
   uint64_t pay[PAY ? THREADS * ITEMS + 2 : 2];            // payload words, regrouped with their tuples
   uint32_t hist[256 + 64];                                // + 64 trash counters, one per lane (never zeroed, never read): a probe relation with
                                                           // most of its keys outside the build range put 90 % of a tile's LDS atomics on ONE of them
   uint32_t start[256];
   uint32_t gbase[256];    // (global base - start[bin]) mod 2^32; destinations are < 2^31
-  uint32_t cursor[256];   // level 1: running global cursor of this chunk
-  uint32_t odd[256];      // level 1, six-byte tuples (L6): the bin's run of this tile was padded to an even length
   uint32_t wave_tot[THREADS / WAVE];
   uint32_t total;
   uint32_t total_abort;   // level 1, speculative layout: the overflow flag as thread 0 saw it during this tile
+  // level 1 only, and LAST: a level-2 launch that is short of LDS asks for the bytes in front of them (level2_lds_bytes)
+  uint32_t cursor[256];   // level 1: running global cursor of this chunk
+  uint32_t odd[256];      // level 1, six-byte tuples (L6): the bin's run of this tile was padded to an even length
 };
 
 // block-wide exclusive scan of hist[0..nbins) (nbins <= 256 == blockDim) into start[]
@@ -667,6 +669,33 @@ __device__ __forceinline__ void l6_unpack(const L6Pair &d, uint32_t &rem0, uint3
   rem1 = (lo1 >> 24) | ((d.c >> 16) << 8);
 }
 
+// TEN-BYTE tuples for WIDE keys (W10 at level 1, P10 at level 2; round 6).  A key that does not fit 32 bits used to travel as
+// key64 + row, 12 bytes in two arrays, on 8192-tuple tiles with ONE 512-thread workgroup per CU (the 16384 x 12-byte tile does not
+// fit LDS): 15.1 ms for C3 with keys spread over 2^60 against 9.0 ms on NARROW keys.  The six-byte machinery above carries over
+// because hash_a needs no help to become a bijection of 64-bit keys: key_fold(raw) = lo ^ hi * C is, for a FIXED high word, a
+// permutation of the low word, so (hash_a(raw), hi) determines (lo, hi) -- equal partition + equal hash remainder + equal high word
+// <=> equal key, exactly (reference semantics: a pair needs equal keys, join_kernels.cuh:259-455).  A WIDE tuple on the main path is
+// therefore the NARROW six-byte tuple of its hash (l6_pack / p6_store, unchanged) plus the key's high word in a parallel array
+// (Tuples::idx, at the same tuple position): 6 + 4 bytes at both levels, 56 instead of 64 bytes of HBM traffic per probe row, and --
+// what matters more -- the level-1 tile is 12288 tuples of 12 bytes in LDS (hash word | row24, high word) under ONE 1024-thread
+// workgroup, the shape the NARROW kernel is tuned on.  The build side keeps its 12-byte tuples: the probe kernels turn a staged
+// build key into (remainder << 32 | high word) the way P6 turns it into its remainder (p10_key).  In the kernels this is simply
+// "L6 / IN6 / P6 with NARROW = false".
+__device__ __forceinline__ uint64_t p10_key(uint64_t raw_key, int fb) {
+  return ((uint64_t)(hash_a(raw_key) & ((1u << (32 - fb)) - 1u)) << 32) | (uint32_t)(raw_key >> 32);
+}
+struct __attribute__((packed, aligned(4))) HiPair { uint32_t a, b; };      // the high words of tuples v, v + 1: one 8-byte access at any 4-byte offset
+// one tuple of a P6 stream (the general kernels' WIDE loads: a 4-byte and a 2-byte load)
+__device__ __forceinline__ void p6_load_one(const uint64_t *base, uint32_t pos, uint32_t &r, uint32_t &row) {
+  const unsigned char *at = reinterpret_cast<const unsigned char *>(base) + (size_t)pos * 6u;
+  uint32_t lo;
+  uint16_t hi;
+  __builtin_memcpy(&lo, at, 4);
+  __builtin_memcpy(&hi, at + 4, 2);
+  row = lo & 0x7fffffffu;
+  r = (lo >> 31) | ((uint32_t)hi << 1);
+}
+
 // phase C: write the regrouped tile out.  LEVEL1 bins are the coarse id, LEVEL2 the sub id.
 template <bool LEVEL1, bool NARROW, int THREADS, bool PAY, int ITEMS, bool P6 = false>
 __device__ __forceinline__ void tile_flush(TileLds<NARROW, THREADS, PAY, ITEMS> &s, const PartGeom &g, Tuples out) {
@@ -680,10 +709,12 @@ __device__ __forceinline__ void tile_flush(TileLds<NARROW, THREADS, PAY, ITEMS> 
     const uint32_t rmask = (1u << (32 - g.fb)) - 1u;
     for (uint32_t i0 = threadIdx.x; 2 * i0 < total; i0 += THREADS * UP) {
       ulonglong2 ww[UP];
+      uint2 hh[UP];                                    // WIDE (P10): the two tuples' high words, in step with them
 #pragma unroll
       for (int u = 0; u < UP; ++u) {
         const uint32_t j = 2 * (i0 + u * THREADS);
         ww[u] = j < total ? *reinterpret_cast<const ulonglong2 *>(&s.w[j]) : ulonglong2{0, 0};      // (the slot behind an odd total is the tile's own, its content unused)
+        hh[u] = (!NARROW && j < total) ? *reinterpret_cast<const uint2 *>(&s.idx[j]) : uint2{0, 0};
       }
 #pragma unroll
       for (int u = 0; u < UP; ++u) {
@@ -698,9 +729,14 @@ __device__ __forceinline__ void tile_flush(TileLds<NARROW, THREADS, PAY, ITEMS> 
           struct __attribute__((packed, aligned(2))) D3 { uint32_t a, b, c; };
           D3 d{lo0, (r0 >> 1) | (lo1 << 16), (lo1 >> 16) | ((r1 >> 1) << 16)};
           *reinterpret_cast<D3 *>(reinterpret_cast<unsigned char *>(out.w) + (size_t)dst0 * 6u) = d;
+          if constexpr (!NARROW) *reinterpret_cast<HiPair *>(out.idx + dst0) = HiPair{hh[u].x, hh[u].y};
         } else {
           p6_store(out.w, dst0, r0, (uint32_t)ww[u].x);
-          if (j + 1 < total) p6_store(out.w, dst1, r1, (uint32_t)ww[u].y);
+          if constexpr (!NARROW) out.idx[dst0] = (int32_t)hh[u].x;
+          if (j + 1 < total) {
+            p6_store(out.w, dst1, r1, (uint32_t)ww[u].y);
+            if constexpr (!NARROW) out.idx[dst1] = (int32_t)hh[u].y;
+          }
         }
       }
     }
@@ -755,13 +791,22 @@ __device__ __forceinline__ uint32_t load_mask_word(const uint8_t *valid, uint32_
   const uint32_t drop = (at - from) * 8u;                // bits of earlier bytes in front of ours; >= 32: every row is behind the end
   return drop < 32u ? w >> drop : 0u;
 }
+// tuples per thread of a level-1 tile: 16, and 12 where the tile holds 12 bytes per tuple under 1024 threads (WIDE keys)
+__host__ __device__ constexpr int sc1_items(bool narrow, int threads) { return (!narrow && threads == 1024) ? 12 : JK_SC_ITEMS; }
 template <int FAST, bool NARROW, int THREADS, bool MASKED = false, bool L6 = false>
 __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan, PartGeom g,
                                                              const uint32_t *__restrict__ H1off,   // scanned H1
                                                              Tuples out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
-  TileLds<NARROW, THREADS> &s = *reinterpret_cast<TileLds<NARROW, THREADS> *>(tile_raw);
-  constexpr int JK_TILE = THREADS * JK_SC_ITEMS;
+  // L6 with WIDE keys = the TEN-BYTE tuples (W10, see p10_key): six bytes of (hash remainder, row24) as for NARROW keys + the key's
+  // high word in out.idx; twelve tuples per thread (12 bytes per tuple in LDS)
+  // (every WIDE 1024-thread tile holds twelve tuples per thread: the build side's (key64, row) tuples take the same 12 bytes in LDS)
+  constexpr bool W10 = L6 && !NARROW;
+  static_assert(!W10 || (FAST == 8 && THREADS == 1024), "ten-byte tuples: an 8-byte key column on the 1024-thread tile");
+  constexpr int ITEMS = sc1_items(NARROW, THREADS);
+  using Tile = TileLds<NARROW, THREADS, false, ITEMS>;
+  Tile &s = *reinterpret_cast<Tile *>(tile_raw);
+  constexpr int JK_TILE = THREADS * ITEMS;
   const int chunk = blockIdx.x;
   const uint32_t ncoarse = 1u << g.b1;
   if (!g.cap1 && threadIdx.x < ncoarse) s.cursor[threadIdx.x] = H1off[(size_t)threadIdx.x * g.nchunks + chunk];
@@ -776,7 +821,7 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
   auto item_row = [](int k, uint32_t tid) -> uint32_t {
     return FAST ? 2u * ((uint32_t)(k >> 1) * THREADS + tid) + (k & 1) : (uint32_t)k * THREADS + tid;
   };
-  uint64_t nxt[JK_SC_ITEMS];
+  uint64_t nxt[ITEMS];
   uint32_t nxtmask = 0;                          // MASKED: this lane's word of the tile's validity bits (see consume)
   const void *col = t.col[0].data;
   const uint8_t *vmask = t.col[0].valid;
@@ -784,7 +829,7 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
   auto prefetch = [&](uint32_t tile) {           // a pair that would cross `end` is read from the last two rows instead:
     const uint32_t tid = opaque_tid();           // its first row, if it is row end - 1, is then the SECOND word loaded (consume)
 #pragma unroll
-    for (int k = 0; k < JK_SC_ITEMS; k += 2) {
+    for (int k = 0; k < ITEMS; k += 2) {
       const uint32_t i = tile + item_row(k, tid);
       fast_pair<FAST>(col, (int64_t)(i + 2 <= end ? i : end - 2), nxt[k], nxt[k + 1]);
     }
@@ -808,7 +853,7 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
   // (beyond the chunk, null, outside the narrow range) go to a trash counter / LDS slot / global dump slot instead.
   using KeyReg = typename std::conditional<NARROW, uint32_t, uint64_t>::type;    // NARROW: joinable keys are < 2^32
   const uint32_t l6_low = (uint32_t)g.kbias, l6_fold = (uint32_t)(g.kbias >> 32) * 0x9e3779b1u;
-  KeyReg key[JK_SC_ITEMS];
+  KeyReg key[ITEMS];
   uint32_t okmask = 0;          // bit k: item k travels.  One VGPR; sixteen loop-carried bools cost 32 SGPRs and spills
   auto consume = [&](uint32_t tile) {
     const uint32_t tid = opaque_tid();
@@ -818,13 +863,13 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
       validbits = 0;
       const uint32_t L = tid & 63u;
 #pragma unroll
-      for (int j = 0; j < JK_SC_ITEMS / 2; ++j) {
+      for (int j = 0; j < ITEMS / 2; ++j) {
         const uint32_t wj = (uint32_t)__shfl((int)nxtmask, (int)(4u * j + (L >> 4)), WAVE);
         validbits |= ((wj >> ((2u * L) & 31u)) & 3u) << (2 * j);
       }
     }
 #pragma unroll
-    for (int k = 0; k < JK_SC_ITEMS; ++k) {
+    for (int k = 0; k < ITEMS; ++k) {
       uint64_t raw = ((k & 1) == 0 && tile + item_row(k, tid) + 1 == end) ? nxt[k + 1] : nxt[k];
       const bool joinable = plan.mode != KM_RAW_FLOAT || fast_float_word<FAST ? FAST : 8>(raw);
       const uint64_t k64 = raw - plan.kmin;
@@ -840,19 +885,25 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
 #endif
   for (uint32_t tile = begin; tile < end; tile += JK_TILE) {        // end + JK_TILE < 2^32
     if (!FAST) {
-      uint64_t k64[JK_SC_ITEMS];
-      bool ok[JK_SC_ITEMS];
-      fetch_keys<FAST, JK_SC_ITEMS>(t, plan, (int64_t)tile + threadIdx.x, THREADS, (int64_t)end, k64, ok);   // all loads first
+      uint64_t k64[ITEMS];
+      bool ok[ITEMS];
+      fetch_keys<FAST, ITEMS>(t, plan, (int64_t)tile + threadIdx.x, THREADS, (int64_t)end, k64, ok);   // all loads first
       okmask = 0;
 #pragma unroll
-      for (int k = 0; k < JK_SC_ITEMS; ++k) { key[k] = (KeyReg)k64[k]; okmask |= (uint32_t)ok[k] << k; }
+      for (int k = 0; k < ITEMS; ++k) { key[k] = (KeyReg)k64[k]; okmask |= (uint32_t)ok[k] << k; }
     }
-    uint32_t binrank[JK_SC_ITEMS];             // bin << 16 | rank within (tile, bin); bin 256 = does not travel
+    uint32_t binrank[ITEMS];             // bin << 16 | rank within (tile, bin); bin 256 = does not travel
 #pragma unroll
-    for (int h = 0; h < JK_SC_ITEMS; h += 4) {
+    for (int h = 0; h < ITEMS; h += 4) {
 #pragma unroll
       for (int k = h; k < h + 4; ++k) {
-        if constexpr (L6) {
+        if constexpr (W10) {
+          // the tuple carries hash_a of its raw key and the key's high word from here on: together they determine the key (p10_key)
+          const uint64_t raw = (uint64_t)key[k] + g.kbias;
+          const uint32_t q = hash_a(raw);
+          key[k] = (KeyReg)(((raw >> 32) << 32) | q);
+          binrank[k] = (okmask >> k) & 1u ? q >> (32 - g.b1) : 256u + (threadIdx.x & 63u);
+        } else if constexpr (L6) {
           // the tuple carries its HASH from here on (a bijection of the key, see L6 above): the flush does not hash again
           // (L6 keys do not straddle a 2^32 boundary of raw values: the high word of key + kbias is kbias's own, key_fold's multiply
           // a constant -- one add and one xor instead of an add-with-carry and a quarter-rate multiply; a row that does not travel
@@ -868,7 +919,7 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
       __builtin_amdgcn_sched_barrier(0);       // four hashes at a time: sixteen interleaved ones spill
     }
 #pragma unroll
-    for (int k = 0; k < JK_SC_ITEMS; ++k)      // sixteen atomics in flight, one wait
+    for (int k = 0; k < ITEMS; ++k)      // sixteen atomics in flight, one wait
       binrank[k] = (binrank[k] << 16) | atomicAdd(&s.hist[binrank[k]], 1u);
     block_sync();
     LAB_PHASE(0)       // hash + rank
@@ -894,18 +945,20 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
     }
     LAB_PHASE(1)       // claim issue + scan
     const uint32_t wtid = opaque_tid();
+    constexpr int RG = ITEMS % 8 == 0 ? 8 : 6;
 #pragma unroll
-    for (int h = 0; h < JK_SC_ITEMS; h += 8) {           // eight at a time: reads of start[] first (no branch), then the writes
-      uint32_t st[8];
+    for (int h = 0; h < ITEMS; h += RG) {           // eight at a time: reads of start[] first (no branch), then the writes
+      uint32_t st[RG];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) st[k] = s.start[(binrank[h + k] >> 16) & 255u];
+      for (int k = 0; k < RG; ++k) st[k] = s.start[(binrank[h + k] >> 16) & 255u];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
+      for (int k = 0; k < RG; ++k) {
         const uint32_t pos = (okmask >> (h + k)) & 1u ? st[k] + (binrank[h + k] & 0xffffu) : (uint32_t)(JK_TILE + (L6 ? 256 : 0));
         const int32_t row = g.row_base + (int32_t)(tile + item_row(h + k, wtid));
-        if constexpr (L6) s.w[pos] = ((uint64_t)key[h + k] << 32) | l6_row24((uint32_t)row);
+        if constexpr (L6) s.w[pos] = ((uint64_t)(uint32_t)key[h + k] << 32) | l6_row24((uint32_t)row);
         else s.w[pos] = tup_make<NARROW>((uint64_t)key[h + k], row);
-        if (!NARROW) s.idx[pos] = row;
+        if constexpr (W10) s.idx[pos] = (int32_t)(uint32_t)((uint64_t)key[h + k] >> 32);
+        else if (!NARROW) s.idx[pos] = row;
       }
     }
     {
@@ -945,17 +998,21 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
     // keep the register count under the 128 a 1024-thread workgroup gets (the prefetched keys stay in registers)
     const uint32_t total = s.total;
     const uint32_t ftid = opaque_tid();
-    constexpr int GROUP = 4;
+    constexpr int GROUP = W10 ? 3 : 4;
     if constexpr (L6) {
       // pairs: lane i of group h takes LDS positions 2 p, 2 p + 1 (p = ftid + (h * GROUP + k) * THREADS; one 16-byte LDS read) and
       // stores them as ONE aligned 12-byte word triple at tuple position gbase[bin] + 2 p -- both tuples sit in the same even-length
       // run.  Unconditional, like the 8-byte flush: pairs behind `total` go to this thread's dump slots
 #pragma unroll
-      for (int h = 0; h < JK_SC_ITEMS / 2 / GROUP; ++h) {
+      for (int h = 0; h < ITEMS / 2 / GROUP; ++h) {
         ulonglong2 ww[GROUP];
+        uint2 hh[W10 ? GROUP : 1];
         uint32_t gb[GROUP];
 #pragma unroll
-        for (int k = 0; k < GROUP; ++k) ww[k] = *reinterpret_cast<const ulonglong2 *>(&s.w[2u * (ftid + (h * GROUP + k) * THREADS)]);
+        for (int k = 0; k < GROUP; ++k) {
+          ww[k] = *reinterpret_cast<const ulonglong2 *>(&s.w[2u * (ftid + (h * GROUP + k) * THREADS)]);
+          if constexpr (W10) hh[k] = *reinterpret_cast<const uint2 *>(&s.idx[2u * (ftid + (h * GROUP + k) * THREADS)]);
+        }
 #pragma unroll
         for (int k = 0; k < GROUP; ++k) gb[k] = s.gbase[(uint32_t)(ww[k].x >> (64 - g.b1)) & 255u];
 #pragma unroll
@@ -966,6 +1023,7 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
           const L6Pair d = l6_pack((uint32_t)(ww[k].x >> 32) & rmask, (uint32_t)ww[k].x & L6_ROW_MASK, (uint32_t)(ww[k].y >> 32) & rmask,
                                    (uint32_t)ww[k].y & L6_ROW_MASK);
           *reinterpret_cast<L6Pair *>(reinterpret_cast<unsigned char *>(out.w) + (size_t)dst * 6u) = d;
+          if constexpr (W10) *reinterpret_cast<uint2 *>(out.idx + dst) = hh[k];      // (dst is even: one aligned 8-byte store)
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -978,10 +1036,11 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
         const uint32_t rmask = (1u << (32 - g.b1)) - 1u;
         const L6Pair d = l6_pack((uint32_t)(wx.x >> 32) & rmask, (uint32_t)wx.x & L6_ROW_MASK, (uint32_t)(wx.y >> 32) & rmask, (uint32_t)wx.y & L6_ROW_MASK);
         *reinterpret_cast<L6Pair *>(reinterpret_cast<unsigned char *>(out.w) + (size_t)dst * 6u) = d;
+        if constexpr (W10) *reinterpret_cast<uint2 *>(out.idx + dst) = *reinterpret_cast<const uint2 *>(&s.idx[j]);
       }
     } else {
 #pragma unroll
-    for (int h = 0; h < JK_SC_ITEMS / GROUP; ++h) {
+    for (int h = 0; h < ITEMS / GROUP; ++h) {
       uint64_t ww[GROUP];
       int32_t ii[GROUP];
       uint32_t gb[GROUP];
@@ -1210,12 +1269,12 @@ static inline uint32_t sc2_grid(const Level2Map &m, uint32_t ntiles) {
 // IN6: the input is a stream of six-byte level-1 tuples (L6 above; P6 output only): pairs are read with one 12-byte load, the
 // hash comes out of the tuple (coarse partition = the segment's, remainder = the tuple's) and the row number gets its region bits
 // back from the segment -- this kernel then does not hash at all
-template <bool NARROW, int THREADS, bool PAY = false, bool P6 = false, bool K32 = false, bool IN6 = false>
+template <bool NARROW, int THREADS, bool PAY = false, bool P6 = false, bool K32 = false, bool IN6 = false, int NITEMS = 0>
 __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, Tuples in,
                                                              uint32_t *__restrict__ fine_cursor, Tuples out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
   // a payload-carrying tile holds 16 bytes per tuple: half the tuples per thread keep it at four workgroups per CU
-  constexpr int ITEMS = PAY ? JK_PAY_ITEMS : JK_SC_ITEMS;
+  constexpr int ITEMS = NITEMS ? NITEMS : (PAY ? JK_PAY_ITEMS : JK_SC_ITEMS);
   using Tile = TileLds<NARROW, THREADS, PAY, ITEMS>;
   Tile &s = *reinterpret_cast<Tile *>(tile_raw);
   constexpr int JK_TILE = THREADS * ITEMS;
@@ -1249,14 +1308,16 @@ __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, 
   int32_t idx[ITEMS];
   uint32_t live6 = 0;                                 // IN6: bit k = tuple k of this thread is a live one
   if constexpr (IN6) {
-    static_assert(!IN6 || (P6 && NARROW && !PAY && !K32), "six-byte input: the main path only");
+    static_assert(!IN6 || (P6 && !PAY && !K32), "six-byte input: the main path only");
     const uint32_t region = lo & ((1u << m.xs) - 1u);
     L6Pair d[ITEMS / 2];
+    uint2 hw[NARROW ? 1 : ITEMS / 2];                 // WIDE (ten-byte tuples, p10_key): the pair's high words from the parallel array
 #pragma unroll
     for (int k = 0; k < ITEMS / 2; ++k) {             // all loads first: pair k of this thread = tuples begin + 2 (k THREADS + tid), + 1
       const uint32_t i = begin + 2u * (k * THREADS + threadIdx.x);
       const uint32_t ic = i < end ? i : end - 2u;     // (segments and tiles start and end at even positions)
       d[k] = *reinterpret_cast<const L6Pair *>(reinterpret_cast<const unsigned char *>(in.w) + (size_t)ic * 6u);
+      if constexpr (!NARROW) hw[k] = *reinterpret_cast<const uint2 *>(in.idx + ic);
     }
 #pragma unroll
     for (int k = 0; k < ITEMS / 2; ++k) {
@@ -1269,7 +1330,8 @@ __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, 
       // the tuple as the rest of the kernel wants it: hash word | row
       w[2 * k] = ((uint64_t)((p << (32 - g.b1)) | r0) << 32) | (uint32_t)(g.row_base + (int32_t)l6_row(w0, region));
       w[2 * k + 1] = ((uint64_t)((p << (32 - g.b1)) | r1) << 32) | (uint32_t)(g.row_base + (int32_t)l6_row(w1, region));
-      idx[2 * k] = idx[2 * k + 1] = 0;
+      if constexpr (NARROW) idx[2 * k] = idx[2 * k + 1] = 0;
+      else { idx[2 * k] = (int32_t)hw[k].x; idx[2 * k + 1] = (int32_t)hw[k].y; }
     }
   } else if (K32 && quads) {                          // workgroup-uniform
     if constexpr (K32) {
@@ -1325,7 +1387,12 @@ __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, 
       binrank[k] = ((K32 && quads) || i < end) ? bin : 256u + (threadIdx.x & 63u);     // (quads: a full tile, every tuple is live whatever order they were fetched in)
       // six-byte tuples leave as (hash remainder, row): the key is not needed again, the LDS tile holds the hash word and the flush
       // does not hash a second time (two quarter-rate multiplies per tuple: the kernel's ALU work is not hidden at 4 waves per SIMD)
-      if constexpr (P6) {
+      if constexpr (P6 && !NARROW) {
+        // WIDE tuples (key64, row) become ten-byte ones here: hash word | row in w, the raw key's high word in idx (p10_key)
+        const uint32_t row = (uint32_t)idx[k];
+        idx[k] = (int32_t)(uint32_t)((w[k] + g.kbias) >> 32);
+        w[k] = ((uint64_t)p6_low(q, lh, g.world) << 32) | row;
+      } else if constexpr (P6) {
         if constexpr (K32 && POW2W) w[k] = ((uint64_t)(g.world > 1 ? __builtin_rotateleft32(q, wshift) : lh) << 32) | (uint32_t)w[k];
         else w[k] = ((uint64_t)p6_low(q, lh, g.world) << 32) | (uint32_t)w[k];
       }
@@ -1686,7 +1753,8 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
   // ---- stage the build partition, clear the table ----
   for (uint32_t i = threadIdx.x; i < u.build_count; i += JK_PROBE_THREADS) {
     uint64_t w = a.build.w[u.build_begin + i];
-    if (P6) w = ((uint64_t)p6_remainder((uint32_t)(w >> 32), a.p6_kbias, a.p6_fb, a.p6_world) << 32) | (uint32_t)w;
+    if constexpr (P6 && NARROW) w = ((uint64_t)p6_remainder((uint32_t)(w >> 32), a.p6_kbias, a.p6_fb, a.p6_world) << 32) | (uint32_t)w;
+    else if constexpr (P6) w = p10_key(w + a.p6_kbias, a.p6_fb);      // ten-byte probe tuples: compare (hash remainder, high word)
     l.bw[i] = w;
     if (!NARROW) l.bi[i] = a.build.idx[u.build_begin + i];
   }
@@ -1785,8 +1853,15 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe(ProbeArgs a, KeyTab
       } else {
         const uint32_t i = base + b * JK_PROBE_THREADS + threadIdx.x;
         const uint32_t ic = u.probe_begin + (i < u.probe_count ? i : u.probe_count - 1);   // clamped, unconditional
-        k[b] = a.probe.w[ic];
-        prow[b] = need_row ? a.probe.idx[ic] : 0;
+        if constexpr (P6) {            // ten-byte tuples: (remainder, row) from the six-byte stream, the high word from the parallel array
+          uint32_t r, row;
+          p6_load_one(a.probe.w, ic, r, row);
+          k[b] = ((uint64_t)r << 32) | (uint32_t)a.probe.idx[ic];
+          prow[b] = (int32_t)row;
+        } else {
+          k[b] = a.probe.w[ic];
+          prow[b] = need_row ? a.probe.idx[ic] : 0;
+        }
         act[b] = i < u.probe_count;
       }
     }
@@ -1952,7 +2027,8 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_fast(ProbeArgs a) {
   const Unit u = a.units[blockIdx.x];
   for (uint32_t i = threadIdx.x; i < u.build_count; i += JK_PROBE_THREADS) {
     uint64_t w = a.build.w[u.build_begin + i];
-    if (P6) w = ((uint64_t)p6_remainder((uint32_t)(w >> 32), a.p6_kbias, a.p6_fb, a.p6_world) << 32) | (uint32_t)w;      // six-byte probe tuples: compare remainders
+    if constexpr (P6 && NARROW) w = ((uint64_t)p6_remainder((uint32_t)(w >> 32), a.p6_kbias, a.p6_fb, a.p6_world) << 32) | (uint32_t)w;      // six-byte probe tuples: compare remainders
+    else if constexpr (P6) w = p10_key(w + a.p6_kbias, a.p6_fb);                                                                                        // ten-byte ones: (remainder, high word)
     l.bw[i] = w;
     if (!NARROW) l.bi[i] = a.build.idx[u.build_begin + i];
   }
@@ -1963,7 +2039,15 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_fast(ProbeArgs a) {
   // raw key = stored key + kbias; fold = lo ^ hi * C (key_fold).  NARROW keys are 32 bits, WIDE keys 64.
   using Key = typename std::conditional<NARROW, uint32_t, uint64_t>::type;
   auto fold_of = [&](Key key) -> uint32_t {
-    if constexpr (P6) {
+    if constexpr (P6 && !NARROW) {
+      // ten-byte tuples: the "key" is (17-bit hash remainder) << 32 | the raw key's high word.  The remainder is spread as below;
+      // xor-ed with the high word it tells the keys of a partition apart whether the high words vary (keys spread over 2^62) or
+      // not (a dense range above 2^32) -- two of them collide in this fold with probability 2^-32
+      uint32_t x = (uint32_t)(key >> 32);
+      x ^= x << 13;
+      x ^= x >> 7;
+      return x ^ (uint32_t)key;
+    } else if constexpr (P6) {
       // six-byte tuples: the "key" is a 17-bit hash remainder.  Two multiplicative slot hashes of such a small DENSE set (3 % of the
       // 2^17 values) share their bad differences -- 8 to 12 % of the partitions needed a second cuckoo attempt, and at 3800 keys per
       // partition a few units per join failed all four and went to the general kernel alone (0.13 ms of tail).  Two xor-shifts
@@ -1983,7 +2067,14 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_fast(ProbeArgs a) {
   // the fold table 1 hashes: NARROW keys are told apart by the one fold (it is injective on them), WIDE keys need the second
   auto fold2_of = [&](Key key, uint32_t f1) -> uint32_t {
     if constexpr (NARROW) return f1;
-    else return key_fold2(key + a.kbias);
+    else if constexpr (P6) {
+      // the second fold of a ten-byte key: the same two words combined at another rotation (keys that share fold_of share this one
+      // only if their remainders' spreads differ by a 16-bit-periodic word) -- no multiply, where the 12-byte tuples' two folds cost two
+      uint32_t x = (uint32_t)(key >> 32);
+      x ^= x << 13;
+      x ^= x >> 7;
+      return __builtin_rotateleft32(x, 16) + (uint32_t)key + ((uint32_t)key << 3);
+    } else return key_fold2(key + a.kbias);
   };
   auto staged_key = [&](uint32_t p) -> Key {
     if constexpr (NARROW) return (uint32_t)(l.bw[p] >> 32);
@@ -2055,8 +2146,13 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_fast(ProbeArgs a) {
       if constexpr (P6) {            // one 12-byte load: two (remainder, row) tuples
         uint32_t r0, row0, r1, row1;
         p6_load_pair(a.probe.w, (u.probe_begin - lead) + vc, r0, row0, r1, row1);
-        key[2 * b] = r0; prow[2 * b] = row0;
-        key[2 * b + 1] = r1; prow[2 * b + 1] = row1;
+        if constexpr (NARROW) {
+          key[2 * b] = r0; key[2 * b + 1] = r1;
+        } else {                     // ten-byte tuples: + one 8-byte load of the two high words
+          const HiPair hh = *reinterpret_cast<const HiPair *>(a.probe.idx + (u.probe_begin - lead) + vc);
+          key[2 * b] = ((uint64_t)r0 << 32) | hh.a; key[2 * b + 1] = ((uint64_t)r1 << 32) | hh.b;
+        }
+        prow[2 * b] = row0; prow[2 * b + 1] = row1;
       } else {
         ww = *reinterpret_cast<const ulonglong2 *>(src + vc);
       }
@@ -2099,17 +2195,34 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_fast(ProbeArgs a) {
       hbmask |= (uint32_t)hb << b;
       padmask |= (uint32_t)(KEEP && act[b] && !ha && !hb) << b;
     }
+    // WIDE: the build row of a tuple's hit comes from the staged row numbers -- NB independent LDS reads, issued together (round 6: read
+    // inside emit(), under its per-tuple branch, every one of them was a round trip of its own: 4.6 - 4.7 ms per 1e9 probe tuples
+    // against the NARROW kernel's 2.7).  A tuple with a hit in BOTH tables (a build key present twice) reads its second row in emit()
+    int32_t hitrow[NARROW ? 1 : NB];
+    if constexpr (!NARROW) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const bool ha = (hamask >> b) & 1u, hb = (hbmask >> b) & 1u;
+        hitrow[b] = l.bi[ha ? pa[b] : (hb ? pb[b] : 0u)];
+      }
+    }
     auto emit = [&](int b, uint32_t pos, uint32_t c) {
-      const bool ha = (hamask >> b) & 1u, hb = (hbmask >> b) & 1u, pad = (padmask >> b) & 1u;
+      const bool ha = (hamask >> b) & 1u, pad = (padmask >> b) & 1u;
       if (pos + c > unit_cap) a.opt_state[1] = 1;   // would spill into the next unit's slots: the host redoes the join two-pass
       else if (!(LAB_BITS(a.dbg) & 32)) {
         // build row of a hit: NARROW carries it in the low half of the staged word, WIDE reads it from the staged row numbers
-        int32_t ra, rb;
-        if constexpr (NARROW) { ra = (int32_t)(uint32_t)wa[b]; rb = (int32_t)(uint32_t)wb[b]; }
-        else { ra = ha ? l.bi[pa[b]] : 0; rb = hb ? l.bi[pb[b]] : 0; }
+        // (WIDE: the second row of a tuple with two hits is read under c == 2 only -- as a value selected next to hitrow[b] the
+        // compiler issued the read for every emitted tuple, one LDS round trip each)
+        int32_t first;
+        if constexpr (NARROW) first = ha ? (int32_t)(uint32_t)wa[b] : (int32_t)(uint32_t)wb[b];
+        else first = hitrow[b];
         op[pos] = (int32_t)prow[b];
-        ob[pos] = pad ? JK_EMPTY : (ha ? ra : rb);
-        if (c == 2) { op[pos + 1] = (int32_t)prow[b]; ob[pos + 1] = rb; }
+        ob[pos] = pad ? JK_EMPTY : first;
+        if (c == 2) {
+          op[pos + 1] = (int32_t)prow[b];
+          if constexpr (NARROW) ob[pos + 1] = (int32_t)(uint32_t)wb[b];
+          else ob[pos + 1] = l.bi[pb[b]];
+        }
         if constexpr (PMODE == 1) { po8[pos] = pay[b]; if (c == 2) po8[pos + 1] = pay[b]; }
         if constexpr (PMODE >= 2) { po4a[pos] = (uint32_t)pay[b]; if (c == 2) po4a[pos + 1] = (uint32_t)pay[b]; }
         if constexpr (PMODE == 3) { po4b[pos] = (uint32_t)(pay[b] >> 32); if (c == 2) po4b[pos + 1] = (uint32_t)(pay[b] >> 32); }
@@ -2181,7 +2294,8 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_count_fast(ProbeArgs a) {
   const Unit u = a.units[blockIdx.x];
   for (uint32_t i = threadIdx.x; i < u.build_count; i += JK_PROBE_THREADS) {
     uint64_t w = a.build.w[u.build_begin + i];
-    if (P6) w = ((uint64_t)p6_remainder((uint32_t)(w >> 32), a.p6_kbias, a.p6_fb, a.p6_world) << 32) | (uint32_t)w;
+    if constexpr (P6 && NARROW) w = ((uint64_t)p6_remainder((uint32_t)(w >> 32), a.p6_kbias, a.p6_fb, a.p6_world) << 32) | (uint32_t)w;
+    else if constexpr (P6) w = p10_key(w + a.p6_kbias, a.p6_fb);
     l.bw[i] = w;
     if (!NARROW) l.bi[i] = a.build.idx[u.build_begin + i];
   }
@@ -2192,7 +2306,15 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_count_fast(ProbeArgs a) {
   // raw key = stored key + kbias; fold = lo ^ hi * C (key_fold).  NARROW keys are 32 bits, WIDE keys 64.
   using Key = typename std::conditional<NARROW, uint32_t, uint64_t>::type;
   auto fold_of = [&](Key key) -> uint32_t {
-    if constexpr (P6) {
+    if constexpr (P6 && !NARROW) {
+      // ten-byte tuples: the "key" is (17-bit hash remainder) << 32 | the raw key's high word.  The remainder is spread as below;
+      // xor-ed with the high word it tells the keys of a partition apart whether the high words vary (keys spread over 2^62) or
+      // not (a dense range above 2^32) -- two of them collide in this fold with probability 2^-32
+      uint32_t x = (uint32_t)(key >> 32);
+      x ^= x << 13;
+      x ^= x >> 7;
+      return x ^ (uint32_t)key;
+    } else if constexpr (P6) {
       // six-byte tuples: the "key" is a 17-bit hash remainder.  Two multiplicative slot hashes of such a small DENSE set (3 % of the
       // 2^17 values) share their bad differences -- 8 to 12 % of the partitions needed a second cuckoo attempt, and at 3800 keys per
       // partition a few units per join failed all four and went to the general kernel alone (0.13 ms of tail).  Two xor-shifts
@@ -2212,7 +2334,14 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_count_fast(ProbeArgs a) {
   // the fold table 1 hashes: NARROW keys are told apart by the one fold (it is injective on them), WIDE keys need the second
   auto fold2_of = [&](Key key, uint32_t f1) -> uint32_t {
     if constexpr (NARROW) return f1;
-    else return key_fold2(key + a.kbias);
+    else if constexpr (P6) {
+      // the second fold of a ten-byte key: the same two words combined at another rotation (keys that share fold_of share this one
+      // only if their remainders' spreads differ by a 16-bit-periodic word) -- no multiply, where the 12-byte tuples' two folds cost two
+      uint32_t x = (uint32_t)(key >> 32);
+      x ^= x << 13;
+      x ^= x >> 7;
+      return __builtin_rotateleft32(x, 16) + (uint32_t)key + ((uint32_t)key << 3);
+    } else return key_fold2(key + a.kbias);
   };
   auto staged_key = [&](uint32_t p) -> Key {
     if constexpr (NARROW) return (uint32_t)(l.bw[p] >> 32);
@@ -2272,7 +2401,12 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_count_fast(ProbeArgs a) {
       if constexpr (P6) {
         uint32_t r0, row0, r1, row1;
         p6_load_pair(a.probe.w, (u.probe_begin - lead) + vc, r0, row0, r1, row1);
-        key[2 * b] = r0; key[2 * b + 1] = r1;
+        if constexpr (NARROW) {
+          key[2 * b] = r0; key[2 * b + 1] = r1;
+        } else {
+          const HiPair hh = *reinterpret_cast<const HiPair *>(a.probe.idx + (u.probe_begin - lead) + vc);
+          key[2 * b] = ((uint64_t)r0 << 32) | hh.a; key[2 * b + 1] = ((uint64_t)r1 << 32) | hh.b;
+        }
       } else {
         const ulonglong2 ww = *reinterpret_cast<const ulonglong2 *>(src + vc);
         if constexpr (NARROW) { key[2 * b] = (uint32_t)(ww.x >> 32); key[2 * b + 1] = (uint32_t)(ww.y >> 32); }
@@ -3038,7 +3172,7 @@ static inline int small_grid(int64_t n) { return stream_grid((size_t)(n > 0 ? n 
 
 template <int FAST, bool NARROW, int THREADS, bool MASKED>
 static gdf_error launch_scatter1_t(const KeyTable &t, const KeyPlan &plan, const PartGeom &g, const uint32_t *H1off, Tuples out) {
-  const size_t lds = sizeof(TileLds<NARROW, THREADS>);
+  const size_t lds = sizeof(TileLds<NARROW, THREADS, false, sc1_items(NARROW, THREADS)>);
   HIP_TRY(hipFuncSetAttribute((const void *)jk_scatter1<FAST, NARROW, THREADS, MASKED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   GDF_LAUNCH("jk_scatter1", (jk_scatter1<FAST, NARROW, THREADS, MASKED>), dim3(g.nchunks), dim3(THREADS), lds, stream0(), t, plan, g, H1off, out);
   HIP_CHECK_LAST();
@@ -3046,7 +3180,7 @@ static gdf_error launch_scatter1_t(const KeyTable &t, const KeyPlan &plan, const
 }
 template <int FAST, bool NARROW, bool MASKED>
 static gdf_error launch_scatter1_n(int threads, const KeyTable &t, const KeyPlan &plan, const PartGeom &g, const uint32_t *H1off, Tuples out) {
-  if (threads == 1024) { if constexpr (NARROW) return launch_scatter1_t<FAST, NARROW, 1024, MASKED>(t, plan, g, H1off, out); }
+  if (threads == 1024) { if constexpr (NARROW || FAST == 8) return launch_scatter1_t<FAST, NARROW, 1024, MASKED>(t, plan, g, H1off, out); }
   if (threads >= 512) return launch_scatter1_t<FAST, NARROW, 512, MASKED>(t, plan, g, H1off, out);
   if constexpr (MASKED) return launch_scatter1_t<FAST, NARROW, 512, MASKED>(t, plan, g, H1off, out);      // (masked: the two production tile sizes only)
   else return launch_scatter1_t<FAST, NARROW, 256, MASKED>(t, plan, g, H1off, out);
@@ -3058,7 +3192,19 @@ static gdf_error launch_scatter1(int fast, bool narrow, int threads, const KeyTa
     // (TWO workgroups of half-size tiles per CU -- what a software-pipelined workgroup, VERDICT r4 item 1, comes down to in 135 KB of
     // LDS -- were built as a LAB variant in round 5 and lost: jk_scatter1 2.97 - 2.98 against 2.87 - 2.91 ms for C3's probe side in
     // alternating processes, profiles/r5_c_half_tile_workgroups_ab.jsonl; the variant is gone again)
-    if (!(fast && narrow && threads == 1024 && g.cap1 && g.xs == 6 && g.b1 == 8)) return GDF_INVALID_API_CALL;
+    if (!(fast && threads == 1024 && g.cap1 && g.xs == 6 && g.b1 == 8) || (!narrow && fast != 8)) return GDF_INVALID_API_CALL;
+    if (!narrow) {                   // WIDE keys: the ten-byte tuples (W10, p10_key) -- 12 tuples per thread, 12 bytes per tuple in LDS
+      const size_t lds = sizeof(TileLds<false, 1024, false, 12>);
+      if (masked) {
+        HIP_TRY(hipFuncSetAttribute((const void *)jk_scatter1<8, false, 1024, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        GDF_LAUNCH("jk_scatter1_w10", (jk_scatter1<8, false, 1024, true, true>), dim3(g.nchunks), dim3(1024), lds, stream0(), t, plan, g, H1off, out);
+      } else {
+        HIP_TRY(hipFuncSetAttribute((const void *)jk_scatter1<8, false, 1024, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        GDF_LAUNCH("jk_scatter1_w10", (jk_scatter1<8, false, 1024, false, true>), dim3(g.nchunks), dim3(1024), lds, stream0(), t, plan, g, H1off, out);
+      }
+      HIP_CHECK_LAST();
+      return GDF_SUCCESS;
+    }
 #define JK_SC1_L6(F, M)                                                                                                             \
     do {                                                                                                                            \
       const size_t lds = sizeof(TileLds<true, 1024>);                                                                               \
@@ -3093,6 +3239,9 @@ static int fast_key_width(const KeyTable &t, const KeyPlan &plan) {
   if (t.col[0].width == 4 && plan.narrow && plan.kmin == 0) return 4;
   return 0;
 }
+// LDS of a level-2 tile without the level-1-only arrays at the end of TileLds: three 12-byte-per-tuple tiles per CU instead of two
+template <bool NARROW, int THREADS>
+static constexpr size_t level2_lds_bytes() { using Tile = TileLds<NARROW, THREADS>; return offsetof(Tile, cursor); }
 template <bool NARROW, int THREADS>
 static gdf_error launch_scatter2_t(uint32_t ntiles, const PartGeom &g, Level2Map m, Tuples in, uint32_t *cursor, Tuples out) {
   const size_t lds = sizeof(TileLds<NARROW, THREADS>);
@@ -3107,13 +3256,39 @@ static gdf_error launch_scatter2_t(uint32_t ntiles, const PartGeom &g, Level2Map
 static gdf_error launch_scatter2(bool narrow, int threads, uint32_t ntiles, const PartGeom &g, Level2Map m, Tuples in,
                                  uint32_t *cursor, Tuples out, bool p6 = false, bool in6 = false) {
   if (in6) {                         // six-byte level-1 tuples in, six-byte level-2 tuples out
-    if (!(p6 && narrow && !m.keys32 && g.b1 == 8)) return GDF_INVALID_API_CALL;
+    if (!(p6 && !m.keys32 && g.b1 == 8)) return GDF_INVALID_API_CALL;
     m.ntiles = ntiles;
     m.xcd_order = (ntiles >= 64 && !lab::path_on("GDF_JK_NO_XCD_ORDER")) ? 1 : 0;
     const uint32_t grid = sc2_grid(m, ntiles);
+    if (!narrow && lab::knob_int("GDF_JK_W10_SC2_THREADS", 0) == 512) {      // experiment: the same 4096-tuple tile under 512 threads
+      using Tile = TileLds<false, 512, false, 8>;
+      const size_t lds = offsetof(Tile, cursor);
+      HIP_TRY(hipFuncSetAttribute((const void *)jk_scatter2<false, 512, false, true, false, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      GDF_LAUNCH("jk_scatter2_w10", (jk_scatter2<false, 512, false, true, false, true, 8>), dim3(grid), dim3(512), lds, stream0(), g, m, in, cursor, out);
+      HIP_CHECK_LAST();
+      return GDF_SUCCESS;
+    }
+    if (!narrow) {                   // ten-byte tuples in and out (WIDE keys)
+      const size_t lds = level2_lds_bytes<false, 256>();
+      HIP_TRY(hipFuncSetAttribute((const void *)jk_scatter2<false, 256, false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      GDF_LAUNCH("jk_scatter2_w10", (jk_scatter2<false, 256, false, true, false, true>), dim3(grid), dim3(256), lds, stream0(), g, m, in, cursor, out);
+      HIP_CHECK_LAST();
+      return GDF_SUCCESS;
+    }
     const size_t lds = sizeof(TileLds<true, 256>);
     HIP_TRY(hipFuncSetAttribute((const void *)jk_scatter2<true, 256, false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     GDF_LAUNCH("jk_scatter2", (jk_scatter2<true, 256, false, true, false, true>), dim3(grid), dim3(256), lds, stream0(), g, m, in, cursor, out);
+    HIP_CHECK_LAST();
+    return GDF_SUCCESS;
+  }
+  if (p6 && !narrow) {               // WIDE (key64, row) tuples in, ten-byte tuples out (p10_key): the production tile size
+    if (m.keys32) return GDF_INVALID_API_CALL;
+    m.ntiles = ntiles;
+    m.xcd_order = (ntiles >= 64 && !lab::path_on("GDF_JK_NO_XCD_ORDER")) ? 1 : 0;
+    const uint32_t grid = sc2_grid(m, ntiles);
+    const size_t lds = level2_lds_bytes<false, 256>();
+    HIP_TRY(hipFuncSetAttribute((const void *)jk_scatter2<false, 256, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    GDF_LAUNCH("jk_scatter2_w10", (jk_scatter2<false, 256, false, true>), dim3(grid), dim3(256), lds, stream0(), g, m, in, cursor, out);
     HIP_CHECK_LAST();
     return GDF_SUCCESS;
   }
@@ -3276,9 +3451,11 @@ static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, Si
   // scatter tile: THREADS * 16 tuples regrouped in LDS per step.  Bigger tiles mean longer runs per
   // (tile, bin) -- DRAM-friendlier writes -- at the price of fewer resident workgroups.
   const int sc_threads_env = (int)lab::knob_int("GDF_JK_SC_THREADS", 0);
-  int sc_threads = sc_threads_env ? sc_threads_env : (narrow ? 1024 : 512);   // swept on C3: profiles/r1_c_sweeps.md
+  // (WIDE tuples from one 8-byte key column: the 1024-thread tile with twelve tuples per thread, sc1_items -- 16384 x 12 B would not
+  // fit 160 KiB; round 6, 512 threads before: C3's wide build side 0.64 ms in jk_scatter1)
+  int sc_threads = sc_threads_env ? sc_threads_env : ((narrow || (fast == 8 && !lab::knob_on("GDF_JK_WIDE_512"))) ? 1024 : 512);   // swept on C3: profiles/r1_c_sweeps.md
   if (sc_threads != 256 && sc_threads != 512 && sc_threads != 1024) sc_threads = 256;
-  if (!narrow && sc_threads == 1024) sc_threads = 512;       // 16384 x 12 B would not fit 160 KiB
+  if (!narrow && fast != 8 && sc_threads == 1024) sc_threads = 512;
   // a payload word only travels with NARROW tuples from a FAST, unmasked key column (jk_scatter1_pay); a build side that turns out
   // otherwise simply does not carry it (sb->pay stays empty and the caller gathers)
   if (pay && !(narrow && fast && !t.col[0].valid)) pay = nullptr;
@@ -3321,7 +3498,8 @@ static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, Si
       HIP_TRY(hipMemcpyAsync(cursor.p, sb->fine_off.data(), sizeof(uint32_t) * nfine, hipMemcpyHostToDevice, stream0()));
     }
     // (a probe side on the exact layout -- skewed probe keys -- writes six-byte tuples as the speculative layout does, see p6_store)
-    p6 = want_p6 && narrow && !pay && sc2_threads == 256;
+    // (WIDE keys: ten-byte tuples, the key's high words in idx[] -- p10_key)
+    p6 = want_p6 && !pay && sc2_threads == 256;
     RMM_TRY(sb->w[1].alloc(p6 ? 6 * (cap + 2) + 16 : sizeof(uint64_t) * (cap + 2)));
     if (!narrow) RMM_TRY(sb->idx[1].alloc(sizeof(int32_t) * (cap + 2)));     // + 2: the lean probe kernel reads row numbers in pairs
     if (pay) RMM_TRY(sb->pay[1].alloc(sizeof(uint64_t) * (cap + 2)));
@@ -3388,10 +3566,15 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
   const uint32_t nfine = 1u << g.fb, ncoarse = 1u << g.b1;
   const int fast = fast_key_width(t, plan);
   const int sc_threads_env = (int)lab::knob_int("GDF_JK_SC_THREADS", 0);
-  int sc_threads = sc_threads_env ? sc_threads_env : (narrow ? 1024 : 512);
+  // TEN-BYTE level-1 tuples for WIDE keys (W10, see p10_key): the conditions of the six-byte ones below on an 8-byte key column; the
+  // level-1 tile is then 1024 threads x 12 tuples (decided here: the tile size goes into the buffer sizes)
+  const bool w10 = want_p6 && defer && !app && !narrow && !pay && fast == 8 && !sc_threads_env && g.b1 == 8 && g.b2 > 0 && chunk == ((int64_t)1 << 17) &&
+                   n < (((int64_t)1 << 30) - ((int64_t)1 << 23)) && g.row_base == 0 &&
+                   ((n >= ((int64_t)1 << 26) && !lab::path_on("GDF_JK_NO_XCD_SPLIT")) || lab::path_on("GDF_JK_FORCE_L6")) && !lab::path_on("GDF_JK_NO_L6");
+  int sc_threads = sc_threads_env ? sc_threads_env : ((narrow || w10 || (fast == 8 && !lab::knob_on("GDF_JK_WIDE_512"))) ? 1024 : 512);
   if (sc_threads != 256 && sc_threads != 512 && sc_threads != 1024) sc_threads = 256;
-  if (!narrow && sc_threads == 1024) sc_threads = 512;
-  const int64_t JK_TILE = (int64_t)sc_threads * JK_SC_ITEMS;
+  if (!narrow && fast != 8 && sc_threads == 1024) sc_threads = 512;
+  const int64_t JK_TILE = (int64_t)sc_threads * sc1_items(narrow, sc_threads);
   const int sc2_threads = pay ? 256 : level2_threads(sc_threads);
   const int64_t JK_TILE2 = (int64_t)sc2_threads * (pay ? JK_PAY_ITEMS : JK_SC_ITEMS);
   auto room = [dup](double mean, uint32_t align) {
@@ -3405,9 +3588,9 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
   // 1024-thread tile, 256 coarse partitions (24 hash bits left), chunks of exactly 2^17 rows and 64 regions per coarse partition
   // (the row number's bits 17..22), rows below 2^30 - 2^23 (seven explicit high bits, and the all-ones tuple stays free for padding).
   // GDF_JK_FORCE_L6: test switch, small relations too (their few chunks number the regions all the same); GDF_JK_NO_L6: off
-  const bool l6 = want_p6 && defer && !app && narrow && !pay && fast != 0 && sc_threads == 1024 && sc2_threads == 256 && g.b1 == 8 && g.b2 > 0 &&
-                  chunk == ((int64_t)1 << 17) && n < (((int64_t)1 << 30) - ((int64_t)1 << 23)) && g.row_base == 0 &&
-                  (g.xs == 3 || lab::path_on("GDF_JK_FORCE_L6")) && !lab::path_on("GDF_JK_NO_L6");
+  const bool l6 = w10 || (want_p6 && defer && !app && narrow && !pay && fast != 0 && sc_threads == 1024 && sc2_threads == 256 && g.b1 == 8 && g.b2 > 0 &&
+                          chunk == ((int64_t)1 << 17) && n < (((int64_t)1 << 30) - ((int64_t)1 << 23)) && g.row_base == 0 &&
+                          (g.xs == 3 || lab::path_on("GDF_JK_FORCE_L6")) && !lab::path_on("GDF_JK_NO_L6"));
   if (l6) g.xs = 6;
   const uint32_t nseg = ncoarse << g.xs;
   uint32_t cap1 = room((double)n / nseg, 64), cap2 = app ? app->cap2 : (g.b2 ? room((double)n / nfine, 8) : 0);
@@ -3479,7 +3662,7 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
   const bool placed = defer && !app && g.b2 > 0;
   if (placed) RMM_TRY(sb->w[0].alloc_placed(JK_ROLE_LEVEL1, l6 ? 6 * (size1 + 2048) + 16 : sizeof(uint64_t) * size1, JK_PLACE_DRAWS));
   else RMM_TRY(sb->w[0].alloc(l6 ? 6 * (size1 + 2048) + 16 : sizeof(uint64_t) * size1));      // (L6: + two dump slots per thread behind the regions)
-  if (!narrow) RMM_TRY(sb->idx[0].alloc(sizeof(int32_t) * size1));
+  if (!narrow) RMM_TRY(sb->idx[0].alloc(sizeof(int32_t) * (size1 + (l6 ? 2048 : 0))));      // (W10: the high words, dump slots as in w[0])
   if (pay) RMM_TRY(sb->pay[0].alloc(sizeof(uint64_t) * size1));
 #ifdef GDF_AMD_LAB
   DevBuf lab_clk;
@@ -3554,7 +3737,7 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
     hipLaunchKernelGGL(jk_make_l2map, dim3(1), dim3(JK_BK_THREADS), map_lds, stream0(), (const uint32_t *)spec.as<uint32_t>(), nseg, cap1,
                        (uint32_t)JK_TILE2, seg_begin, seg_end, tile_prefix, ntiles_dev, 0u, 0u, g.rstart, g.rcap);
     HIP_CHECK_LAST();
-    const bool p6 = want_p6 && narrow && !pay && sc2_threads == 256;
+    const bool p6 = want_p6 && !pay && sc2_threads == 256;
     if (placed) RMM_TRY(sb->w[1].alloc_placed(JK_ROLE_LEVEL2, p6 ? 6 * size2 + 16 : sizeof(uint64_t) * size2, JK_PLACE_DRAWS_L2));
     else RMM_TRY(sb->w[1].alloc(p6 ? 6 * size2 + 16 : sizeof(uint64_t) * size2));
     if (!narrow) RMM_TRY(sb->idx[1].alloc(sizeof(int32_t) * size2));
@@ -3697,6 +3880,19 @@ template <bool NARROW>
 static gdf_error run_probe(bool write, const char *name, size_t nunits, size_t lds, const ProbeArgs &a, const KeyTable &probe_t,
                            const KeyTable &build_t) {
   if (!nunits) return GDF_SUCCESS;
+  if constexpr (!NARROW) {
+    if (a.p6_fb) {                 // ten-byte probe tuples
+      if (write) {
+        HIP_TRY(hipFuncSetAttribute((const void *)jk_probe<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        GDF_LAUNCH(name, (jk_probe<true, false, true>), dim3((unsigned)nunits), dim3(JK_PROBE_THREADS), lds, stream0(), a, probe_t, build_t);
+      } else {
+        HIP_TRY(hipFuncSetAttribute((const void *)jk_probe<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        GDF_LAUNCH(name, (jk_probe<false, false, true>), dim3((unsigned)nunits), dim3(JK_PROBE_THREADS), lds, stream0(), a, probe_t, build_t);
+      }
+      HIP_CHECK_LAST();
+      return GDF_SUCCESS;
+    }
+  }
   if constexpr (NARROW) {
     if (a.p6_fb) {                 // six-byte probe tuples
       if (write) {
@@ -3740,12 +3936,11 @@ static gdf_error run_write_pass(bool narrow, bool plain, size_t nunits, size_t l
   // A cuckoo build above ~42 % runs into cycles often (measured at 1.25e8 build rows: 3814 tuples per partition in
   // 2 x 4096 slots), so the lean kernel then sizes its tables for 40 % and takes slots with a mulhi.
   ProbeArgs fa = a;
-  size_t flds = lds;
   const bool pow2 = (double)max_build <= 0.42 * 2.0 * (double)a.nslots;
-  if (!pow2) {
-    fa.nslots = ((uint32_t)(max_build * 1.25) + 63) & ~63u;
-    flds = probe_lds_bytes(narrow, a.cap, fa.nslots, false);
-  }
+  if (!pow2) fa.nslots = ((uint32_t)(max_build * 1.25) + 63) & ~63u;
+  // (the lean kernels never chain: without the general kernel's next[] a WIDE image of C3's partitions is 73 KB instead of 86 -- TWO
+  // workgroups per CU instead of one; round 6, the 12-byte tuples' probe pass had run at half occupancy since round 2)
+  const size_t flds = probe_lds_bytes(narrow, a.cap, fa.nslots, false);
 #define JK_FAST_LAUNCH(...)                                                                                                      \
   do {                                                                                                                           \
     HIP_TRY(hipFuncSetAttribute((const void *)jk_probe_fast<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds)); \
@@ -3780,6 +3975,11 @@ static gdf_error run_write_pass(bool narrow, bool plain, size_t nunits, size_t l
     else if (pow2) JK_FAST_LAUNCH(true, false, true);
     else if (keep) JK_FAST_LAUNCH(false, true, true);
     else JK_FAST_LAUNCH(false, false, true);
+  } else if (a.p6_fb) {                // WIDE keys on ten-byte probe tuples
+    if (pow2 && keep) JK_FAST_LAUNCH(true, true, false, 0, true);
+    else if (pow2) JK_FAST_LAUNCH(true, false, false, 0, true);
+    else if (keep) JK_FAST_LAUNCH(false, true, false, 0, true);
+    else JK_FAST_LAUNCH(false, false, false, 0, true);
   } else {
     if (pow2 && keep) JK_FAST_LAUNCH(true, true, false);
     else if (pow2) JK_FAST_LAUNCH(true, false, false);
@@ -3829,12 +4029,9 @@ static gdf_error run_count_pass(bool narrow, bool plain, size_t nunits, size_t l
   RMM_TRY(todo.alloc(sizeof(uint32_t) * nunits));
   a.unit_todo = todo.as<uint32_t>();
   ProbeArgs fa = a;
-  size_t flds = lds;
   const bool pow2 = (double)max_build <= 0.42 * 2.0 * (double)a.nslots;      // as run_write_pass
-  if (!pow2) {
-    fa.nslots = ((uint32_t)(max_build * 1.25) + 63) & ~63u;
-    flds = probe_lds_bytes(narrow, a.cap, fa.nslots, false);
-  }
+  if (!pow2) fa.nslots = ((uint32_t)(max_build * 1.25) + 63) & ~63u;
+  const size_t flds = probe_lds_bytes(narrow, a.cap, fa.nslots, false);
 #define JK_COUNT_LAUNCH(...)                                                                                                     \
   do {                                                                                                                            \
     HIP_TRY(hipFuncSetAttribute((const void *)jk_count_fast<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds)); \
@@ -3847,6 +4044,9 @@ static gdf_error run_count_pass(bool narrow, bool plain, size_t nunits, size_t l
   } else if (narrow) {
     if (pow2 && keep) JK_COUNT_LAUNCH(true, true, true); else if (pow2) JK_COUNT_LAUNCH(true, false, true);
     else if (keep) JK_COUNT_LAUNCH(false, true, true); else JK_COUNT_LAUNCH(false, false, true);
+  } else if (a.p6_fb) {
+    if (pow2 && keep) JK_COUNT_LAUNCH(true, true, false, true); else if (pow2) JK_COUNT_LAUNCH(true, false, false, true);
+    else if (keep) JK_COUNT_LAUNCH(false, true, false, true); else JK_COUNT_LAUNCH(false, false, false, true);
   } else {
     if (pow2 && keep) JK_COUNT_LAUNCH(true, true, false); else if (pow2) JK_COUNT_LAUNCH(true, false, false);
     else if (keep) JK_COUNT_LAUNCH(false, true, false); else JK_COUNT_LAUNCH(false, false, false);
@@ -4107,9 +4307,14 @@ static gdf_error probe_prepared(const KeyTable &probe_t, const KeyTable &build_t
   const bool bijective = plan.kmin == 0 || (plan.kmin & 0xffffffffULL) + plan.kspan < (1ULL << 32);
   const bool p6_ok = g.fb == JK_MAX_FB && g.b2 > 0 && g.b3 == 0 && kind != JOIN_FULL && g.world <= 1 && plan.narrow && !plan.verify && pc_eff == nullptr &&
                      bijective && !lab::path_on("GDF_JK_NO_P6");
-  const bool want_p6 = defer && p6_ok;
+  // TEN-byte tuples for WIDE keys (p10_key): the same conditions on one exact 8-byte key column (integer, or float by canonical bits) --
+  // the partition hash plus the raw key's high word identify the key, no range is asked of it.  GDF_JK_NO_W10: the 12-byte tuples
+  const bool w10_ok = g.fb == JK_MAX_FB && g.b2 > 0 && g.b3 == 0 && kind != JOIN_FULL && g.world <= 1 && !plan.narrow && !plan.verify && pc_eff == nullptr &&
+                      (plan.mode == KM_RAW_INT || plan.mode == KM_RAW_FLOAT) && probe_fast == 8 && fast_key_width(build_t, plan) == 8 &&
+                      !lab::path_on("GDF_JK_NO_P6") && !lab::path_on("GDF_JK_NO_W10");
+  const bool want_p6 = defer && (p6_ok || w10_ok);
   // (the exact layout's probe side too -- skewed probe keys -- as long as every build partition is an LDS unit: the global-table path reads 8-byte tuples)
-  const bool want_p6_exact = p6_ok && largest_build <= (uint32_t)JK_MAX_BUILD && !lab::path_on("GDF_JK_NO_P6_EXACT");
+  const bool want_p6_exact = (p6_ok || w10_ok) && largest_build <= (uint32_t)JK_MAX_BUILD && !lab::path_on("GDF_JK_NO_P6_EXACT");
   if (!skew && g.fb > 0 && probe_t.nrows >= spec_min && largest_build <= (uint32_t)JK_MAX_BUILD && !lab::path_on("GDF_JK_NO_SPEC"))
     GDF_TRY(partition_side_spec(probe_t, plan, g, std::max(1.0, (double)probe_t.nrows / std::max<uint32_t>(B.joinable, 1)), &P, &spec_ok,
                                 nullptr, defer, pay, pmode, want_p6));

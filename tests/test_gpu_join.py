@@ -874,6 +874,85 @@ def test_six_byte_level1_tuples(gdf, how, keys, force_path):
 
 
 @pytest.mark.parametrize("how", ["inner", "left"])
+@pytest.mark.parametrize("keys", ["spread-over-2^62", "negative-and-positive", "two-dense-clusters", "fold-colliders", "float64", "masked",
+                                  "build-keys-twice", "nine-million-rows", "probe-third-on-one-key", "half-hit"])
+def test_ten_byte_tuples_for_wide_keys(gdf, how, keys, force_path):
+    """int64 keys that do not fit 32 bits travel as TEN-byte tuples on the main path (csrc/join.hip p10_key): the
+    six-byte tuple of the NARROW path -- remainder of the partition hash + row -- plus the raw key's HIGH WORD in a parallel array.
+    hash_a(key) = lowbias32(lo ^ hi * C) is a permutation of the low word for a fixed high word, so (hash, hi) determines the key and
+    the probe compares (remainder, hi) -- exactly (reference semantics join_kernels.cuh:259-455: a pair needs equal keys).
+    GDF_JK_FORCE_FB=15 + GDF_JK_FORCE_L6 give a small relation the headline's geometry.  Against the oracle, and the same join through
+    12-byte level-1 tuples + ten-byte level-2 ones (GDF_JK_NO_L6) and through the 12-byte path of rounds 1 - 5 (GDF_JK_NO_W10).
+    `fold-colliders`: families of keys with ONE hash_a and different high words -- same partition, same remainder, told apart by the high
+    word only -- in the build relation, plus probe keys of the same families that are NOT in the build relation and must not match."""
+    rs = np.random.RandomState(len(keys) + 3)
+    nb, npr = 60_000, (9_000_000 if keys == "nine-million-rows" else 900_000)
+    force_path("GDF_JK_FORCE_FB", "15")
+    force_path("GDF_JK_SPEC_MIN", "1000")
+    force_path("GDF_JK_FORCE_L6")
+    lv = rv = None
+    if keys == "two-dense-clusters":           # constant high word inside a cluster: the remainders alone tell the keys apart
+        bk = np.concatenate([rs.permutation(2 * nb)[: nb // 2], (1 << 40) + 17 + rs.permutation(2 * nb)[: nb // 2]]).astype(np.int64)
+        pk = np.where(rs.rand(npr) < 0.5, rs.randint(0, 2 * nb, size=npr), (1 << 40) + 17 + rs.randint(0, 2 * nb, size=npr)).astype(np.int64)
+    elif keys == "negative-and-positive":
+        bk = rs.randint(-2**62, 2**62, size=nb, dtype=np.int64)
+        pk = bk[rs.randint(0, nb, size=npr)]
+        pk[::7] = rs.randint(-2**62, 2**62, size=len(pk[::7]), dtype=np.int64)
+    else:
+        bk = np.unique(rs.randint(0, 2**62, size=nb, dtype=np.int64))
+        rs.shuffle(bk)
+        pk = bk[rs.randint(0, len(bk), size=npr)]
+        if keys == "half-hit":
+            miss = rs.rand(npr) < 0.5
+            pk[miss] = rs.randint(0, 2**62, size=int(miss.sum()), dtype=np.int64)
+    if keys == "fold-colliders":
+        C = np.uint64(0x9e3779b1)
+        fam_in, fam_out = [], []
+        for x in rs.randint(0, 2**32, size=500, dtype=np.int64):
+            his = rs.randint(1, 2**29, size=8, dtype=np.int64)
+            for j, hi in enumerate(his):
+                lo = (np.uint64(x) ^ ((np.uint64(hi) * C) & np.uint64(0xffffffff))) & np.uint64(0xffffffff)
+                (fam_in if j < 5 else fam_out).append(int((np.uint64(hi) << np.uint64(32)) | lo))
+        bk = np.unique(np.concatenate([bk, np.array(fam_in, dtype=np.int64)]))
+        rs.shuffle(bk)
+        pk = np.concatenate([pk, np.array(fam_in * 3 + fam_out * 3, dtype=np.int64)])
+        rs.shuffle(pk)
+    if keys == "build-keys-twice":
+        bk = np.concatenate([bk, bk[: len(bk) // 2]])
+    if keys == "probe-third-on-one-key":       # the speculative layout overflows: exact layout, 12-byte level 1, ten-byte level 2
+        pk[rs.rand(len(pk)) < 0.33] = bk[7]
+    if keys == "masked":
+        lv, rv = [rs.rand(len(pk)) > 0.1], [rs.rand(len(bk)) > 0.05]
+    if keys == "float64":                      # float keys join by value: canonical bits, -0.0 == +0.0, NaN matches nothing
+        bk = bk.astype(np.float64) * 1.5
+        pk = pk.astype(np.float64) * 1.5
+        bk[:3] = [0.0, np.inf, -1.25]
+        pk[:6] = [-0.0, np.nan, np.inf, -np.inf, -1.25, 0.0]
+    from bench import read_profile
+    lib = gdf._binding._gdf_cdll
+
+    def launches():
+        lib.gdf_amd_profile_reset(); lib.gdf_amd_profile_enable(1)
+        try:
+            n = _check(gdf, [pk], [bk], how, lv, rv)
+        finally:
+            lib.gdf_amd_profile_enable(0)
+        return n, {k.split("@")[0] for k in read_profile(gdf)}
+
+    n1, names = launches()
+    if keys != "probe-third-on-one-key":
+        assert "jk_scatter1_w10" in names and "jk_scatter2_w10" in names, names
+    else:
+        assert "jk_scatter2_w10" in names, names       # (the exact layout: 12-byte level 1, ten-byte level 2)
+    force_path("GDF_JK_NO_L6")
+    n2, names = launches()
+    assert n2 == n1 and "jk_scatter1_w10" not in names and "jk_scatter2_w10" in names, names
+    force_path("GDF_JK_NO_W10")
+    n3, names = launches()
+    assert n3 == n1 and "jk_scatter2_w10" not in names, names
+
+
+@pytest.mark.parametrize("how", ["inner", "left"])
 @pytest.mark.parametrize("layout", ["speculative", "exact"])
 def test_six_byte_tuples_probe_keys_beyond_the_build_range(gdf, how, layout, force_path):
     """The six-byte tuples compare hash remainders, and hash_a is a bijection on the BUILD range only (raw values inside one

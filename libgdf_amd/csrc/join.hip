@@ -327,6 +327,7 @@ constexpr int JK_CUCKOO_MAX_MOVES = 32;
 constexpr int JK_ROLE_LEVEL1 = 1, JK_ROLE_LEVEL2 = 2;      // placed blocks (DevBuf::alloc_placed): the probe side's level-1 / level-2 tuples
 constexpr int JK_ROLE_OUT_PROBE = 3, JK_ROLE_OUT_BUILD = 4; // ... and the two index columns of a large dense join
 constexpr int JK_ROLE_FUSED_LEVEL2 = 5;                     // ... and the level-2 tuples of a fused multi-GPU join's receiver
+constexpr int JK_ROLE_LEVEL1_HI = 6;                        // ... and the high words of ten-byte level-1 tuples (WIDE keys, p10_key)
 // challengers of the placement tournaments (partition_side_spec, probe_partitioned).  Level 1 has two MODES, about one fresh block in
 // five is a fast one (profiles/r5_b_place_trace_*.json): 8 challengers.  Level 2 and the output columns spread over ~10 % without
 // modes (r5_e_place_trace_*.json): fewer candidates get most of what there is, and every candidate is 4 - 7 GB of allocator churn.
@@ -3660,9 +3661,17 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
   // physical placement the regroup kernels run slowly on, judged by the times reported here
   // (every shape of the deferred path: WIDE tuples -- their row numbers, idx[], stay plain allocations -- and payload-carrying ones too)
   const bool placed = defer && !app && g.b2 > 0;
-  if (placed) RMM_TRY(sb->w[0].alloc_placed(JK_ROLE_LEVEL1, l6 ? 6 * (size1 + 2048) + 16 : sizeof(uint64_t) * size1, JK_PLACE_DRAWS));
-  else RMM_TRY(sb->w[0].alloc(l6 ? 6 * (size1 + 2048) + 16 : sizeof(uint64_t) * size1));      // (L6: + two dump slots per thread behind the regions)
-  if (!narrow) RMM_TRY(sb->idx[0].alloc(sizeof(int32_t) * (size1 + (l6 ? 2048 : 0))));      // (W10: the high words, dump slots as in w[0])
+  // TEN-byte tuples (W10): the 4 GB of high words are a placed block of their own role, drawn, timed and kept or dropped in step with
+  // the six-byte stream's (both see the same calibration times, like the two output columns).  (Behind the six-byte stream in ONE
+  // 10 GB block, jk_scatter1 took 4.4 ms for C3's probe side in three processes of three, 3.9 - 4.0 in two plain allocations:
+  // profiles/r6_e_*; level 2 does not care and keeps its high words inside its block.)
+  const bool hi_placed1 = placed && l6 && !narrow;
+  const size_t bytes1 = l6 ? 6 * ((size_t)size1 + 2048) + 16 : sizeof(uint64_t) * size1;
+  const size_t bytes1_hi = sizeof(int32_t) * ((size_t)size1 + (l6 ? 2048 : 0));      // (W10: the high words, dump slots as in w[0])
+  if (placed) RMM_TRY(sb->w[0].alloc_placed(JK_ROLE_LEVEL1, bytes1, JK_PLACE_DRAWS));
+  else RMM_TRY(sb->w[0].alloc(bytes1));      // (L6: + two dump slots per thread behind the regions)
+  if (hi_placed1) RMM_TRY(sb->idx[0].alloc_placed(JK_ROLE_LEVEL1_HI, bytes1_hi, JK_PLACE_DRAWS));
+  else if (!narrow) RMM_TRY(sb->idx[0].alloc(bytes1_hi));
   if (pay) RMM_TRY(sb->pay[0].alloc(sizeof(uint64_t) * size1));
 #ifdef GDF_AMD_LAB
   DevBuf lab_clk;
@@ -3678,7 +3687,6 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
   // over the first quarter of the chunks (every region's write front opens, ~0.8 ms), and handed back with that time; the pool keeps
   // the fastest of JK_PLACE_DRAWS + 1 and this call, and every later one, runs on it.  ~2 ms per candidate, once per shape.
   if (placed && !lab::knob_on("GDF_JK_NO_CALIBRATE")) {
-    const size_t bytes1 = l6 ? 6 * (size1 + 2048) + 16 : sizeof(uint64_t) * size1;
     for (int round = 0; round <= JK_PLACE_DRAWS && sb->w[0].measure; ++round) {
       PartGeom gc = g;
       gc.nchunks = std::max(1, g.nchunks / 4);
@@ -3688,6 +3696,18 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
       sb->w[0].clock_end(stream0());
       HIP_TRY(hipMemsetAsync(spec.p, 0, sizeof(uint32_t) * (nseg + 1), stream0()));
       RMM_TRY(sb->w[0].alloc_placed(JK_ROLE_LEVEL1, bytes1, JK_PLACE_DRAWS));      // (reset() reports the time; the champion or the next challenger comes back)
+    }
+    // ... then the high words' block, with the six-byte stream on its champion: one coordinate at a time.  (Both kinds of block have
+    // their fast and slow placements, about one fresh block in five a fast one; candidates drawn and judged in PAIRS kept a slow
+    // block of one kind or the other in two processes of three, 4.4 instead of 3.8 ms in jk_scatter1: profiles/r6_f_*)
+    for (int round = 0; hi_placed1 && round <= JK_PLACE_DRAWS && sb->idx[0].measure; ++round) {
+      PartGeom gc = g;
+      gc.nchunks = std::max(1, g.nchunks / 4);
+      sb->idx[0].clock_begin(stream0());
+      GDF_TRY(launch_scatter1(fast, narrow, sc_threads, t, plan, gc, nullptr, sb->tuples(0), l6));
+      sb->idx[0].clock_end(stream0());
+      HIP_TRY(hipMemsetAsync(spec.p, 0, sizeof(uint32_t) * (nseg + 1), stream0()));
+      RMM_TRY(sb->idx[0].alloc_placed(JK_ROLE_LEVEL1_HI, bytes1_hi, JK_PLACE_DRAWS));
     }
   }
   // DEFERRED: level 2's fill cursors are set IN FRONT of level 1 (nothing of level 1 is in them): one launch less between the two kernels
@@ -3738,9 +3758,13 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
                        (uint32_t)JK_TILE2, seg_begin, seg_end, tile_prefix, ntiles_dev, 0u, 0u, g.rstart, g.rcap);
     HIP_CHECK_LAST();
     const bool p6 = want_p6 && !pay && sc2_threads == 256;
-    if (placed) RMM_TRY(sb->w[1].alloc_placed(JK_ROLE_LEVEL2, p6 ? 6 * size2 + 16 : sizeof(uint64_t) * size2, JK_PLACE_DRAWS_L2));
-    else RMM_TRY(sb->w[1].alloc(p6 ? 6 * size2 + 16 : sizeof(uint64_t) * size2));
-    if (!narrow) RMM_TRY(sb->idx[1].alloc(sizeof(int32_t) * size2));
+    const bool hi_inside2 = placed && p6 && !narrow;          // (ten-byte tuples: the high words behind the six-byte stream, as at level 1)
+    const size_t six2 = (6 * (size_t)size2 + 16 + 255) & ~(size_t)255;
+    const size_t bytes2 = p6 ? (hi_inside2 ? six2 + sizeof(int32_t) * ((size_t)size2 + 2) : 6 * (size_t)size2 + 16) : sizeof(uint64_t) * size2;
+    if (placed) RMM_TRY(sb->w[1].alloc_placed(JK_ROLE_LEVEL2, bytes2, JK_PLACE_DRAWS_L2));
+    else RMM_TRY(sb->w[1].alloc(bytes2));
+    if (hi_inside2) sb->idx[1].borrow(sb->w[1].as<char>() + six2);
+    else if (!narrow) RMM_TRY(sb->idx[1].alloc(sizeof(int32_t) * size2));
     if (pay) RMM_TRY(sb->pay[1].alloc(sizeof(uint64_t) * size2));
     PartGeom g2 = g;
     g2.cap2 = cap2;
@@ -3753,7 +3777,6 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
     // PLACEMENT TOURNAMENT of the level-2 buffer, as for level 1 above: every candidate is timed on a calibration run of the real
     // kernel over every fourth tile (all 2^15 write fronts open), the fill cursors are set back, the pool keeps the fastest
     if (placed && !lab::knob_on("GDF_JK_NO_CALIBRATE")) {
-      const size_t bytes2 = p6 ? 6 * size2 + 16 : sizeof(uint64_t) * size2;
       for (int round = 0; round <= JK_PLACE_DRAWS_L2 && sb->w[1].measure; ++round) {
         Level2Map mc = m;
         mc.calib_step = 4;
@@ -3763,6 +3786,7 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
         hipLaunchKernelGGL(jk_init_cursor, dim3(32), dim3(256), 0, stream0(), cursor.as<uint32_t>(), nfine, cap2, g.fstart);      // (+ the overflow flag)
         HIP_CHECK_LAST();
         RMM_TRY(sb->w[1].alloc_placed(JK_ROLE_LEVEL2, bytes2, JK_PLACE_DRAWS_L2));
+        if (hi_inside2) sb->idx[1].borrow(sb->w[1].as<char>() + six2);
       }
     }
     sb->w[1].clock_begin(stream0());

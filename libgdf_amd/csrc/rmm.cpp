@@ -191,7 +191,7 @@ rmmError_t pool_free(Manager &m, void *ptr) {
 // the best of `place_draws + 1` placements; a one-off call pays nothing (its block is simply cached here instead of in the free list).
 // Only in pool mode, only for blocks of PLACE_MIN bytes and more; anything else falls through to the plain pool.
 constexpr size_t PLACE_MIN = size_t(1) << 30;
-constexpr size_t PLACE_MAX_ENTRIES = 6;
+constexpr size_t PLACE_MAX_ENTRIES = 8;      // (a WIDE-key join holds five: level 1, its high words, level 2, the two output columns)
 // a fresh multi-GB hipMalloc usually takes ~1 ms, but the driver can take SECONDS for one when it has to wait for memory another
 // process released a moment ago (profiles/r5_b_place_trace_*.json: 1.8 s for nine of them): the search for a better placement ends
 // when its allocations have cost this much

@@ -276,6 +276,103 @@ def extra_configs(gdf, dev):
     return out
 
 
+def wide_unique_keys(n, seed, device):
+    """n DISTINCT int64 keys spread uniformly over [0, 2^62): a bijection of the 62-bit word applied to seed + i (multiplications by odd
+    constants and xor-shifts are permutations of Z / 2^62)."""
+    import torch
+    M = (1 << 62) - 1
+    x = (torch.arange(n, dtype=torch.int64, device=device) + seed) & M
+    x = (x * 0x1E3779B97F4A7C15) & M
+    x = x ^ (x >> 31)
+    x = (x * 0x3F58476D1CE4E5B9) & M
+    x = x ^ (x >> 29)
+    x = (x * 0x14D049BB133111EB) & M
+    return x ^ (x >> 32)
+
+
+def extra_shapes(gdf, dev, headline_ms, npr=1_000_000_000, nb=100_000_000):
+    """Shapes next to the headline, through the same C-ABI call:
+    wide_keys   -- C3 with genuinely 64-bit keys, uniform over 2^62 (the headline's keys fit 32 bits): ms, fraction of 8 TB/s on the
+                   same algorithmic bytes, properties of the result (pair count, no probe row twice, a 2^20-pair sample joins equal keys);
+    shape_sweep -- 20 joins whose probe relation has a DIFFERENT size each time, 0.9e9 ... 1.1e9 rows (a caller whose relations change
+                   from query to query; round 5's placed blocks were keyed on the exact size and searched anew every time): mean ms
+                   and its ratio to the headline."""
+    import torch
+    from libgdf_amd import gdf_column, libgdf, new_context
+    from libgdf_amd.columns import Column, column_array
+    out = {}
+    ctx = new_context()
+    on = (C.c_int * 1)(0)
+
+    def join(pcol, bcol, keep=False):
+        li, ri = gdf_column(), gdf_column()
+        libgdf.gdf_inner_join(column_array([pcol]), 1, on, column_array([bcol]), 1, on, 1, 0, None, C.byref(li), C.byref(ri), C.byref(ctx))
+        n = int(li.size)
+        if keep:
+            return n, li, ri
+        libgdf.gdf_column_free(C.byref(li))
+        libgdf.gdf_column_free(C.byref(ri))
+        return n
+
+    def timed(fn, warm, reps):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+    try:
+        build = wide_unique_keys(nb, 0x5EED0031, dev)
+        pick = make_probe_keys(npr, nb, 0x5EED0032, dev)
+        probe = build[pick]
+        del pick
+        pcol, bcol = Column(probe), Column(build)
+        ms = timed(lambda: join(pcol, bcol), 5, 10)
+        n, li, ri = join(pcol, bcol, keep=True)
+        l = torch.empty(n, dtype=torch.int32, device=dev)
+        r = torch.empty(n, dtype=torch.int32, device=dev)
+        gdf.api._hipMemcpyDtoD(l.data_ptr(), li.data, n * 4)
+        gdf.api._hipMemcpyDtoD(r.data_ptr(), ri.data, n * 4)
+        libgdf.gdf_column_free(C.byref(li)); libgdf.gdf_column_free(C.byref(ri))
+        ok = n == npr and int(l.long().sum().item()) == npr * (npr - 1) // 2 and int(l.min()) == 0 and int(l.max()) == npr - 1
+        pos = torch.randint(0, n, (1 << 20,), device=dev)
+        ok = ok and bool((probe[l[pos].long()] == build[r[pos].long()]).all().item()) and int(r.min()) >= 0 and int(r.max()) < nb
+        ab = 8.0 * npr + 8.0 * nb + 8.0 * n
+        out["wide_keys"] = {"op": f"C3 gdf_inner_join, int64 keys uniform over 2^62: {npr} probe x {nb} build rows, unique build keys, 100% hit",
+                            "ms": ms, "frac": ab / (ms * 1e-3) / 8e12, "algorithmic_bytes": ab, "out_rows": n, "checks_pass": bool(ok)}
+        del probe, build, pcol, bcol, l, r, pos
+        torch.cuda.empty_cache()
+    except Exception as e:                         # noqa: BLE001
+        out["wide_keys"] = {"error": f"{type(e).__name__}: {e}", "checks_pass": False}
+    try:
+        big = int(npr * 1.1)
+        build = make_build_keys(nb, 0x5EED0001, dev)
+        probe = make_probe_keys(big, nb, 0x5EED0002, dev)
+        bcol = Column(build)
+        import random
+        rnd = random.Random(6)
+        sizes = [int(npr * (0.9 + 0.2 * rnd.random())) for _ in range(20)]
+        times, good = [], True
+        for sz in sizes:
+            pcol = Column(probe[:sz])
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            n = join(pcol, bcol)
+            torch.cuda.synchronize()
+            times.append((time.perf_counter() - t0) * 1e3)
+            good = good and n == sz
+        per_row = [t / sz * npr for t, sz in zip(times, sizes)]
+        out["shape_sweep"] = {"op": "20 C3 joins, probe rows drawn from 0.9e9 ... 1.1e9 (a different size every call), in call order",
+                              "mean_ms": sum(times) / len(times), "mean_ms_scaled_to_1e9_rows": sum(per_row) / len(per_row),
+                              "ratio_to_headline": (sum(per_row) / len(per_row)) / headline_ms if headline_ms else None,
+                              "max_ms": max(times), "calls_ms": [round(t, 3) for t in times], "probe_rows": sizes, "checks_pass": bool(good)}
+        del probe, build
+        torch.cuda.empty_cache()
+    except Exception as e:                         # noqa: BLE001
+        out["shape_sweep"] = {"error": f"{type(e).__name__}: {e}", "checks_pass": False}
+    return out
+
+
 def extra_ops(gdf, dev, n=1_000_000_000, reps=3):
     """SURVEY 8d's micro-metrics for the other operators north_star names, at 1e9 int64 rows through the C ABI (as tools/bench_ops.py):
     hash partition P = 256, inclusive prefix sum, compare + stencil compaction at 10 % selectivity.  {ms, frac of 8 TB/s on the
@@ -332,8 +429,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=6,
-                    help="untimed steps.  The pool compares physical placements of the join's scratch over the first calls of a shape "
-                         "(librmm: gdf_amd_rmm_place_draws, default 4 challengers -> settled after 5 calls); the default warm-up covers that")
+                    help="untimed steps, each timed on its own and reported as warmup_calls_ms / first_call_ms.  The join compares physical "
+                         "placements of its scratch and output blocks on calibration runs inside its first calls -- up to 16 / 8 / 6 candidates "
+                         "per block, most searches settle after four to six -- under a per-call time budget (6 ms in a process's first searching "
+                         "call, 24 ms after it: csrc/internal.h PlaceRound), so the searches are over after two to four calls; the default covers that")
     ap.add_argument("--place-draws", type=int, default=None,
                     help="A/B switch: challengers the pool draws per placed scratch block (library default 4; 0 = never re-draw)")
     ap.add_argument("--probe-rows", type=int, default=1_000_000_000)
@@ -519,8 +618,16 @@ def main():
             torch.cuda.synchronize()
 
     out_rows = 0
+    # the untimed calls, each under its own wall clock: the FIRST call of a process pays the cold allocations, the kernels' first
+    # launches and the first candidates of the placement searches (the headline is a steady-state number; this is
+    # what the call in front of it cost)
+    warm_ms = []
     for _ in range(args.warmup):
+        sync()
+        w0 = time.perf_counter()
         out_rows = step()
+        sync()
+        warm_ms.append((time.perf_counter() - w0) * 1e3)
     if distributed:
         multigpu.reset_stats()
     lib.gdf_amd_profile_reset()
@@ -641,6 +748,8 @@ def main():
             "vs_baseline": None, "dtype": "int64", "data": "synthetic",
             "config": {"workload": workload, "probe_rows_per_gpu": npr, "build_rows_per_gpu": nb,
                        "out_rows": int(rows.item()), "parallelism": f"key-partitioned x{world}"},
+            "first_call_ms": warm_ms[0] if warm_ms else None,
+            "warmup_calls_ms": [round(x, 3) for x in warm_ms],
             "roofline": roofline,
             "roofline_kernel": kernel_roof,
             "kernels_ms_per_step": mine["kernels_ms_per_step"],
@@ -676,6 +785,10 @@ def main():
             gc.collect()
             torch.cuda.empty_cache()
             result["extra"] = extra_configs(gdf, dev)
+            try:
+                result["extra"]["shapes"] = extra_shapes(gdf, dev, ms_per_step)
+            except Exception as e:                 # noqa: BLE001 -- an extra, never fatal for the headline line
+                result["extra"]["shapes"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and args.pandas_sample > 0:
             result["cpu_baseline"] = cpu_baseline_pandas(args.pandas_sample, max(args.pandas_sample // 10, 1))
         if world == 1 and args.cpu_sample > 0:

@@ -70,7 +70,15 @@ void        gdf_amd_rmm_contiguous(int on);
    rmmAlloc / rmmFree.  _place_draws: challengers per (role, size), default 4; 0: never re-draw; < 0: plain pool.  max_draws > 0: this
    caller's own number of challengers (one that times a short calibration run per candidate inside ONE call can afford more).  A search ends
    before its last draw once four challengers are drawn and the champion is 7 % faster than the slowest candidate timed (early settle). */
+/* Round 6: (a) SIZE CLASSES -- a new entry's block is rounded up to one of eight steps per octave and serves every later request of its
+   role between six tenths of the block and all of it (the block itself: the first request + an eighth, rounded up), so callers whose relations change size from call to call keep their
+   champions; (b) a search holds at most champion + challenger + 2 losers, draws only blocks of at most a quarter of the free device
+   memory, and gives its losers back when it stops moving; (c) max_draws < 0 = HOLD: the champion of the class as it stands, unmeasured,
+   nothing drawn, the search stays open -- what libgdf.so asks for once a call has spent its time budget on candidates (the search goes
+   on with the next call); (d) on out-of-memory the idle champions and losers of every entry go before a request fails.
+   _place_min: test hook, the size from which a request is a placed block (0: the default, 1 GiB). */
 rmmError_t  gdf_amd_rmm_place_alloc(int role, size_t size, int max_draws, void **ptr, int *measure);
+void        gdf_amd_rmm_place_min(size_t bytes);
 rmmError_t  gdf_amd_rmm_place_free(int role, void *ptr, float ms);
 void        gdf_amd_rmm_place_draws(int draws);
 void        gdf_amd_rmm_place_stats(unsigned long long out[4]);

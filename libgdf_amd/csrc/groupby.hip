@@ -3070,7 +3070,8 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
             // (a PLACED block, DevBuf::alloc_placed: the scatter kernel's thousands of write fronts have their faster and slower physical
             // placements of this buffer -- 6.98 to 7.35 ms for C5 across re-allocations, profiles/r5_d_c5_scatter_after_reallocation.jsonl;
             // tournament below)
-            RMM_TRY(ka.alloc_placed(GB_ROLE_RECORDS, sizeof(GbRec) * (size_t)(total * G), GB_PLACE_DRAWS));
+            place_budget_begin();          // (the call's budget for candidate blocks, internal.h)
+            RMM_TRY(ka.alloc_placed(GB_ROLE_RECORDS, sizeof(GbRec) * (size_t)(total * G), place_draws_now(GB_PLACE_DRAWS)));
             kin = ka.as<K>();
             hp.resize((size_t)P + 1);
             for (uint32_t q = 0; q <= P; ++q) hp[q] = pre[q] * G;
@@ -3149,6 +3150,7 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
       if (is_spec && sig && !lab::knob_on("GDF_GBP_NO_CALIBRATE")) {
         const size_t rec_bytes = sizeof(GbRec) * (size_t)(hp[P]);
         for (int round = 0; round <= GB_PLACE_DRAWS && ka.measure; ++round) {
+          PlaceRound charge;
           launch_chunks = std::max(1, nchunks / 4);
           ka.clock_begin(stream0());
           GDF_TRY(run_scatter());
@@ -3156,7 +3158,7 @@ static gdf_error gb_sorted_partitioned(GbJob &j, const GbKeyPlan &sp, int vbit, 
           HIP_TRY(hipMemsetAsync(d_flags.p, 0, sizeof(unsigned int) * 4, stream0()));
           HIP_TRY(hipMemsetAsync(spec.fill, 0, sizeof(uint32_t) * (size_t)P * spec.G, stream0()));
           if (is_hot) GDF_TRY(fill_cells());
-          RMM_TRY(ka.alloc_placed(GB_ROLE_RECORDS, rec_bytes, GB_PLACE_DRAWS));
+          RMM_TRY(ka.alloc_placed(GB_ROLE_RECORDS, rec_bytes, place_draws_now(GB_PLACE_DRAWS)));
           kin = ka.as<K>();
         }
         launch_chunks = nchunks;

@@ -15,6 +15,20 @@ struct ReadTicket { bool pending = false; int lane = 0; size_t bytes = 0; const 
 hipError_t read_back_begin(ReadTicket *t, const void *dev_src, size_t bytes, int lane);      // lane 0 / 1: one ticket in flight per lane and thread
 hipError_t read_back_end(ReadTicket *t, void *host_dst);
 
+// PLACEMENT SEARCH BUDGET of one public call (round 6).  The callers of the placed blocks (join.hip, groupby.hip)
+// time candidate blocks on calibration runs INSIDE their call; round 5 ran every search to its end in the first call of a shape --
+// 30 - 55 ms instead of ~20, with up to 17 + 9 + 7 fresh multi-GB blocks.  Now a call spends at most its budget on candidates and asks
+// the pool to HOLD (DevBuf::alloc_placed with place_draws_now() < 0) once it is spent; the searches go on with the next call.  The first
+// searching call of a process gets a small budget (it also pays the cold allocations and the kernels' first launches), later ones more.
+void place_budget_begin();                 // at the top of a public entry point that may search
+bool place_budget_left();
+int place_draws_now(int max_draws);        // max_draws while the budget lasts, then -1 (hold)
+struct PlaceRound {                        // charges its own lifetime (one candidate: allocation + calibration run + its report) to the budget
+  double t0;
+  PlaceRound();
+  ~PlaceRound();
+};
+
 // scan.hip: device-wide prefix sums (in == out allowed)
 gdf_error scan_u32(const uint32_t *in, uint32_t *out, size_t n, bool inclusive);
 gdf_error scan_u64(const uint64_t *in, uint64_t *out, size_t n, bool inclusive);

@@ -3668,9 +3668,11 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
   const bool hi_placed1 = placed && l6 && !narrow;
   const size_t bytes1 = l6 ? 6 * ((size_t)size1 + 2048) + 16 : sizeof(uint64_t) * size1;
   const size_t bytes1_hi = sizeof(int32_t) * ((size_t)size1 + (l6 ? 2048 : 0));      // (W10: the high words, dump slots as in w[0])
-  if (placed) RMM_TRY(sb->w[0].alloc_placed(JK_ROLE_LEVEL1, bytes1, JK_PLACE_DRAWS));
+  // (place_draws_now: the call's budget for candidates, internal.h -- once it is spent the pool is asked to HOLD its champions)
+  const bool calibrate = !lab::knob_on("GDF_JK_NO_CALIBRATE");
+  if (placed) RMM_TRY(sb->w[0].alloc_placed(JK_ROLE_LEVEL1, bytes1, calibrate ? place_draws_now(JK_PLACE_DRAWS) : JK_PLACE_DRAWS));
   else RMM_TRY(sb->w[0].alloc(bytes1));      // (L6: + two dump slots per thread behind the regions)
-  if (hi_placed1) RMM_TRY(sb->idx[0].alloc_placed(JK_ROLE_LEVEL1_HI, bytes1_hi, JK_PLACE_DRAWS));
+  if (hi_placed1) RMM_TRY(sb->idx[0].alloc_placed(JK_ROLE_LEVEL1_HI, bytes1_hi, -1));      // (held while the six-byte stream's block is chosen)
   else if (!narrow) RMM_TRY(sb->idx[0].alloc(bytes1_hi));
   if (pay) RMM_TRY(sb->pay[0].alloc(sizeof(uint64_t) * size1));
 #ifdef GDF_AMD_LAB
@@ -3686,8 +3688,9 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
   // placements for this (role, size) -- the first call of a shape -- every candidate block is timed on a CALIBRATION run, the real kernel
   // over the first quarter of the chunks (every region's write front opens, ~0.8 ms), and handed back with that time; the pool keeps
   // the fastest of JK_PLACE_DRAWS + 1 and this call, and every later one, runs on it.  ~2 ms per candidate, once per shape.
-  if (placed && !lab::knob_on("GDF_JK_NO_CALIBRATE")) {
+  if (placed && calibrate) {
     for (int round = 0; round <= JK_PLACE_DRAWS && sb->w[0].measure; ++round) {
+      PlaceRound charge;
       PartGeom gc = g;
       gc.nchunks = std::max(1, g.nchunks / 4);
       sb->w[0].clock_begin(stream0());
@@ -3695,19 +3698,22 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
       else GDF_TRY(launch_scatter1(fast, narrow, sc_threads, t, plan, gc, nullptr, sb->tuples(0), l6));
       sb->w[0].clock_end(stream0());
       HIP_TRY(hipMemsetAsync(spec.p, 0, sizeof(uint32_t) * (nseg + 1), stream0()));
-      RMM_TRY(sb->w[0].alloc_placed(JK_ROLE_LEVEL1, bytes1, JK_PLACE_DRAWS));      // (reset() reports the time; the champion or the next challenger comes back)
+      RMM_TRY(sb->w[0].alloc_placed(JK_ROLE_LEVEL1, bytes1, place_draws_now(JK_PLACE_DRAWS)));      // (reset() reports the time; the champion or the next challenger comes back)
     }
     // ... then the high words' block, with the six-byte stream on its champion: one coordinate at a time.  (Both kinds of block have
     // their fast and slow placements, about one fresh block in five a fast one; candidates drawn and judged in PAIRS kept a slow
     // block of one kind or the other in two processes of three, 4.4 instead of 3.8 ms in jk_scatter1: profiles/r6_f_*)
+    // (only once the six-byte stream's search is over -- its block is then the same in every run that times a candidate here)
+    if (hi_placed1 && !sb->w[0].measure && place_budget_left()) RMM_TRY(sb->idx[0].alloc_placed(JK_ROLE_LEVEL1_HI, bytes1_hi, JK_PLACE_DRAWS));
     for (int round = 0; hi_placed1 && round <= JK_PLACE_DRAWS && sb->idx[0].measure; ++round) {
+      PlaceRound charge;
       PartGeom gc = g;
       gc.nchunks = std::max(1, g.nchunks / 4);
       sb->idx[0].clock_begin(stream0());
       GDF_TRY(launch_scatter1(fast, narrow, sc_threads, t, plan, gc, nullptr, sb->tuples(0), l6));
       sb->idx[0].clock_end(stream0());
       HIP_TRY(hipMemsetAsync(spec.p, 0, sizeof(uint32_t) * (nseg + 1), stream0()));
-      RMM_TRY(sb->idx[0].alloc_placed(JK_ROLE_LEVEL1_HI, bytes1_hi, JK_PLACE_DRAWS));
+      RMM_TRY(sb->idx[0].alloc_placed(JK_ROLE_LEVEL1_HI, bytes1_hi, place_draws_now(JK_PLACE_DRAWS)));
     }
   }
   // DEFERRED: level 2's fill cursors are set IN FRONT of level 1 (nothing of level 1 is in them): one launch less between the two kernels
@@ -3761,7 +3767,7 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
     const bool hi_inside2 = placed && p6 && !narrow;          // (ten-byte tuples: the high words behind the six-byte stream, as at level 1)
     const size_t six2 = (6 * (size_t)size2 + 16 + 255) & ~(size_t)255;
     const size_t bytes2 = p6 ? (hi_inside2 ? six2 + sizeof(int32_t) * ((size_t)size2 + 2) : 6 * (size_t)size2 + 16) : sizeof(uint64_t) * size2;
-    if (placed) RMM_TRY(sb->w[1].alloc_placed(JK_ROLE_LEVEL2, bytes2, JK_PLACE_DRAWS_L2));
+    if (placed) RMM_TRY(sb->w[1].alloc_placed(JK_ROLE_LEVEL2, bytes2, calibrate ? place_draws_now(JK_PLACE_DRAWS_L2) : JK_PLACE_DRAWS_L2));
     else RMM_TRY(sb->w[1].alloc(bytes2));
     if (hi_inside2) sb->idx[1].borrow(sb->w[1].as<char>() + six2);
     else if (!narrow) RMM_TRY(sb->idx[1].alloc(sizeof(int32_t) * size2));
@@ -3776,8 +3782,9 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
     const uint32_t tile_bound = (uint32_t)((uint64_t)n / (uint64_t)JK_TILE2) + nseg + 1;
     // PLACEMENT TOURNAMENT of the level-2 buffer, as for level 1 above: every candidate is timed on a calibration run of the real
     // kernel over every fourth tile (all 2^15 write fronts open), the fill cursors are set back, the pool keeps the fastest
-    if (placed && !lab::knob_on("GDF_JK_NO_CALIBRATE")) {
+    if (placed && calibrate) {
       for (int round = 0; round <= JK_PLACE_DRAWS_L2 && sb->w[1].measure; ++round) {
+        PlaceRound charge;
         Level2Map mc = m;
         mc.calib_step = 4;
         sb->w[1].clock_begin(stream0());
@@ -3785,7 +3792,7 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
         sb->w[1].clock_end(stream0());
         hipLaunchKernelGGL(jk_init_cursor, dim3(32), dim3(256), 0, stream0(), cursor.as<uint32_t>(), nfine, cap2, g.fstart);      // (+ the overflow flag)
         HIP_CHECK_LAST();
-        RMM_TRY(sb->w[1].alloc_placed(JK_ROLE_LEVEL2, bytes2, JK_PLACE_DRAWS_L2));
+        RMM_TRY(sb->w[1].alloc_placed(JK_ROLE_LEVEL2, bytes2, place_draws_now(JK_PLACE_DRAWS_L2)));
         if (hi_inside2) sb->idx[1].borrow(sb->w[1].as<char>() + six2);
       }
     }
@@ -4290,6 +4297,7 @@ static gdf_error probe_prepared(const KeyTable &probe_t, const KeyTable &build_t
   KeyPlan plan = bs.plan;
   const PartGeom &g = bs.g;
   const SideBufs &B = bs.B;
+  place_budget_begin();
   ProfTag probe_tag("@probe");          // (profiling only: the probe side's launches are reported apart from the build side's)
   if (plan.kwindow) plan.klimit = kind == JOIN_INNER ? plan.kspan : plan.kwindow;
 
@@ -4637,8 +4645,9 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
     const size_t out_bytes = sizeof(int32_t) * (size_t)(total ? total : 1);
     DevBuf op, ob;
     if (place_out) {
-      RMM_TRY(op.alloc_placed(JK_ROLE_OUT_PROBE, out_bytes, JK_PLACE_DRAWS_OUT));
-      RMM_TRY(ob.alloc_placed(JK_ROLE_OUT_BUILD, out_bytes, JK_PLACE_DRAWS_OUT));
+      const int d = place_draws_now(JK_PLACE_DRAWS_OUT);
+      RMM_TRY(op.alloc_placed(JK_ROLE_OUT_PROBE, out_bytes, d));
+      RMM_TRY(ob.alloc_placed(JK_ROLE_OUT_BUILD, out_bytes, d));
     } else {
       RMM_TRY(op.alloc(out_bytes));
       RMM_TRY(ob.alloc(out_bytes));
@@ -4661,6 +4670,7 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
     // PLACEMENT TOURNAMENT of the output columns (both roles see the same times, so they keep and drop their candidates together):
     // a calibration run is the write pass over the first quarter of the units; the pass's state words are cleared behind it
     for (int round = 0; place_out && round <= JK_PLACE_DRAWS_OUT && (op.measure || ob.measure); ++round) {
+      PlaceRound charge;
       op.clock_begin(stream0());
       ob.clock_begin(stream0());
       GDF_TRY(run_write_pass(narrow, plain && !dup_heavy, nunits / 4, probe_lds, oa, max_build, probe_t, build_t));
@@ -4668,8 +4678,9 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
       ob.clock_end(stream0());
       HIP_TRY(hipMemsetAsync(d_state.p, 0, sizeof(unsigned long long) * 4, stream0()));
       if (try_sparse) HIP_TRY(hipMemsetAsync(d_upairs.p, 0, sizeof(uint32_t) * (nunits + 1), stream0()));
-      RMM_TRY(op.alloc_placed(JK_ROLE_OUT_PROBE, out_bytes, JK_PLACE_DRAWS_OUT));
-      RMM_TRY(ob.alloc_placed(JK_ROLE_OUT_BUILD, out_bytes, JK_PLACE_DRAWS_OUT));
+      const int d = place_draws_now(JK_PLACE_DRAWS_OUT);
+      RMM_TRY(op.alloc_placed(JK_ROLE_OUT_PROBE, out_bytes, d));
+      RMM_TRY(ob.alloc_placed(JK_ROLE_OUT_BUILD, out_bytes, d));
       oa.out_probe = op.as<int32_t>();
       oa.out_build = ob.as<int32_t>();
     }
@@ -5416,6 +5427,7 @@ struct ProbeAccum {
 
 static gdf_error accum_begin(PreparedBuild *pb, size_t expected_rows, ProbeAccum **out) {
   GDF_REQUIRE(pb && out, GDF_DATASET_EMPTY);
+  place_budget_begin();
   const KeyPlan &plan = pb->side.plan;
   const PartGeom &g = pb->side.g;
   uint32_t largest_build = 0;

@@ -8,6 +8,8 @@
 
 #include <cstdio>
 #include <cstring>
+#include <atomic>
+#include <chrono>
 #include <map>
 #include <set>
 #include <mutex>
@@ -90,7 +92,9 @@ hipError_t read_back_begin(ReadTicket *t, const void *dev_src, size_t bytes, int
   hipError_t e = hipMemcpyAsync(l.pinned, dev_src, bytes, hipMemcpyDeviceToHost, stream0());
   if (e != hipSuccess) return e;
   e = hipEventRecord(l.ev, stream0());
-  if (e != hipSuccess) return e;
+  // (the lane's event belongs to the device that was current when it was made; a thread that comes back with another
+  // device current cannot record it there -- the ticket then stays unset and _end takes the blocking copy)
+  if (e != hipSuccess) { (void)hipGetLastError(); return hipSuccess; }
   t->pending = true;
   return hipSuccess;
 }
@@ -103,6 +107,29 @@ hipError_t read_back_end(ReadTicket *t, void *host_dst) {
   if (e != hipSuccess) return e;
   std::memcpy(host_dst, l.pinned, t->bytes);
   return hipSuccess;
+}
+
+// the placement-search budget of one call (internal.h)
+namespace {
+thread_local double g_place_spent_ms = 0.0, g_place_limit_ms = 0.0;
+std::atomic<int> g_place_calls{0};         // public calls that charged a candidate so far (process-wide)
+thread_local bool g_place_charged = false;
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}
+void place_budget_begin() {
+  g_place_spent_ms = 0.0;
+  g_place_charged = false;
+  // the first searching calls of a process: ~6 ms of candidates next to the cold allocations; then up to 24 ms per call until the
+  // searches have settled (a C3 join's three searches need ~20 - 40 ms of candidates in all)
+  g_place_limit_ms = g_place_calls.load(std::memory_order_relaxed) < 1 ? 6.0 : 24.0;
+  if (const long long forced = lab::path_int("GDF_PLACE_BUDGET_MS", -1); forced >= 0) g_place_limit_ms = (double)forced;      // (test hook: 0 = always hold, large = round 5's behaviour)
+}
+bool place_budget_left() { return g_place_spent_ms < g_place_limit_ms; }
+int place_draws_now(int max_draws) { return place_budget_left() ? max_draws : -1; }
+PlaceRound::PlaceRound() : t0(now_ms()) {}
+PlaceRound::~PlaceRound() {
+  g_place_spent_ms += now_ms() - t0;
+  if (!g_place_charged) { g_place_charged = true; g_place_calls.fetch_add(1, std::memory_order_relaxed); }
 }
 
 // lab.h: the registry behind gdf_amd_debug_force.  Empty in every process that never calls the hook, and then one

@@ -62,6 +62,7 @@ struct Manager {
     double explore_ms = 0;         // host time the challengers' hipMalloc calls have cost so far: exploration stops at PLACE_BUDGET_MS
     float worst_ms = 0.f;          // the slowest candidate timed so far (EARLY SETTLE: see place_free)
     double explore_max = 0;        // the single most expensive of those hipMalloc calls: not counted against the budget (see place_alloc)
+    int stale = 0;                 // allocations in a row that found losers held and drew nothing (PLACE_STALE_CALLS)
     bool busy = false;             // a block of this entry is out with a caller
     std::vector<void *> losers;    // held until the exploration ends: a freed loser's pages would come straight back as the next draw
     unsigned long long stamp = 0;  // last use, for eviction
@@ -70,6 +71,7 @@ struct Manager {
   int place_draws = 4;
   unsigned long long place_clock = 0;
   size_t placed_idle_bytes = 0;     // champions not in use: available to the next call of their role, counted as free by rmmGetInfo
+  size_t placed_loser_bytes = 0;    // losers a running search holds: given back when memory is short, counted as free likewise
   // counters for tests / profiles (gdf_amd_rmm_place_stats)
   unsigned long long place_drawn = 0, place_promoted = 0;
   std::string place_trace;          // one line per decision, bounded (gdf_amd_rmm_place_trace)
@@ -190,7 +192,8 @@ rmmError_t pool_free(Manager &m, void *ptr) {
 // A caller that repeats a join shape pays a few multi-GB hipMalloc / hipFree pairs (~2 ms each) over its first calls and then runs on
 // the best of `place_draws + 1` placements; a one-off call pays nothing (its block is simply cached here instead of in the free list).
 // Only in pool mode, only for blocks of PLACE_MIN bytes and more; anything else falls through to the plain pool.
-constexpr size_t PLACE_MIN = size_t(1) << 30;
+constexpr size_t PLACE_MIN_DEFAULT = size_t(1) << 30;
+size_t g_place_min = PLACE_MIN_DEFAULT;       // (test hook gdf_amd_rmm_place_min: the calibration loops of the callers on small inputs)
 constexpr size_t PLACE_MAX_ENTRIES = 8;      // (a WIDE-key join holds five: level 1, its high words, level 2, the two output columns)
 // a fresh multi-GB hipMalloc usually takes ~1 ms, but the driver can take SECONDS for one when it has to wait for memory another
 // process released a moment ago (profiles/r5_b_place_trace_*.json: 1.8 s for nine of them): the search for a better placement ends
@@ -202,13 +205,45 @@ constexpr double PLACE_BUDGET_MS = 60.0;
 // six on some boxes (9.5 instead of 9.05 ms per join), sixteen miss in 3 % -- and most searches end after four to six.
 constexpr int PLACE_SETTLE_DRAWS = 4;
 constexpr float PLACE_SETTLE_GAIN = 0.93f;       // (0.95 settled on a SLOW level-1 block once: the slow kind alone spans 0.86 - 0.905 ms, a fast block sits at 0.78 - 0.82)
+// Round 6: what a search may HOLD.  Round 5 kept every loser until the search settled -- up to 16 blocks
+// of 6 GB next to the champion, > 150 GB transient beside 9 GB of inputs.  Now at most PLACE_MAX_LOSERS losers are held (the oldest
+// goes back to the runtime right AFTER the next challenger has been drawn, so that draw cannot be its pages again), a challenger
+// is only drawn while it is at most a quarter of the free device memory, and an entry whose search makes no progress for
+// PLACE_STALE_CALLS allocations gives its losers back.
+constexpr size_t PLACE_MAX_LOSERS = 4;       // (fewer, and a search starts drawing its own freed losers again: one fresh level-1 block in five is a fast one)
+constexpr int PLACE_STALE_CALLS = 8;
 
-void place_drop_losers(Manager::Placed &e) {
-  for (void *q : e.losers) (void)hipFree(q);
-  e.losers.clear();
+// SIZE CLASSES (round 6): round 5 keyed a champion on the exact (rounded) size, so a caller whose relations change
+// size from query to query searched anew every time.  A new entry's block is rounded UP to one of eight steps per octave (at most
+// 12.5 % more than asked, on top of an eighth of headroom), and an entry serves every request of its role between six tenths of
+// its block and the whole of it (a relation 0.9 ... 1.1 times the first one's size finds its champion whatever the rounding did).
+inline size_t place_class(size_t want) {
+  size_t oct = size_t(1) << 20;
+  while ((oct << 1) <= want) oct <<= 1;
+  const size_t step = oct >> 3;
+  return (want + step - 1) / step * step;
+}
+inline bool place_serves(size_t block, size_t want) { return block >= want && want >= block - block / 5 * 2; }      // 0.6 ... 1.0 of the block
+
+void place_note(Manager &m, const char *what, int role, size_t bytes, double ms) {      // one trace line for a slow runtime call (> 5 ms)
+  if (ms < 5.0 || m.place_trace.size() >= 16384) return;
+  char line[120];
+  snprintf(line, sizeof line, "role %d %s of %zu MiB took %.1f ms\n", role, what, bytes >> 20, ms);
+  m.place_trace += line;
+}
+double place_now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+void place_free_loser_locked(Manager &m, Manager::Placed &e, size_t i) {
+  const double t0 = place_now_ms();
+  (void)hipFree(e.losers[i]);
+  place_note(m, "hipFree(loser)", e.role, e.want, place_now_ms() - t0);
+  e.losers.erase(e.losers.begin() + (long)i);
+  m.placed_loser_bytes -= e.want;
+}
+void place_drop_losers_locked(Manager &m, Manager::Placed &e) {
+  while (!e.losers.empty()) place_free_loser_locked(m, e, e.losers.size() - 1);
 }
 void place_drop_entry_locked(Manager &m, Manager::Placed &e) {      // (the entry is not busy)
-  place_drop_losers(e);
+  place_drop_losers_locked(m, e);
   if (e.chall) { (void)hipFree(e.chall); e.chall = nullptr; }
   if (e.champ) { (void)hipFree(e.champ); e.champ = nullptr; m.placed_idle_bytes -= e.want; }
 }
@@ -216,24 +251,37 @@ void place_drop_entry_locked(Manager &m, Manager::Placed &e) {      // (the entr
 bool place_release_idle_locked(Manager &m) {
   bool any = false;
   for (auto it = m.placed.begin(); it != m.placed.end();) {
-    if (!it->losers.empty()) { place_drop_losers(*it); it->draws = 1 << 20; any = true; }      // memory is tight: stop exploring
+    if (!it->losers.empty()) { place_drop_losers_locked(m, *it); it->draws = 1 << 20; any = true; }      // memory is tight: stop exploring
     if (!it->busy) { if (it->champ) any = true; place_drop_entry_locked(m, *it); it = m.placed.erase(it); }
     else ++it;
   }
   return any;
 }
 
+// max_draws > 0: the caller's own number of challengers; 0: the pool's default; < 0: HOLD -- the champion of the class as it stands,
+// unmeasured, no challenger is drawn and the search (its losers, its count) stays as it is: what a caller asks for once it has spent
+// its per-call time budget on candidates (the search goes on with its next call)
 rmmError_t place_alloc(Manager &m, int role, size_t size, int max_draws, void **ptr, int *measure) {
   *measure = 0;
   const size_t want = round_size(size);
+  const bool hold = max_draws < 0;
   {
     std::lock_guard<std::mutex> g(m.mu);
-    if (pool_mode(m) && want >= PLACE_MIN && m.place_draws >= 0) {
+    if (pool_mode(m) && want >= g_place_min && m.place_draws >= 0) {
       // (a caller that calibrates candidates inside ONE call can afford more of them than one that spends a call on each)
       const int draws = m.place_draws == 0 ? 0 : (max_draws > 0 ? std::min(max_draws, 16) : m.place_draws);
       Manager::Placed *e = nullptr;
-      for (auto &x : m.placed) if (x.role == role && x.want == want) e = &x;
+      for (auto &x : m.placed)                // the smallest idle block of this role that serves the request (a busy one only if nothing else does)
+        if (x.role == role && place_serves(x.want, want) && (!e || (e->busy && !x.busy) || (e->busy == x.busy && x.want < e->want))) e = &x;
       if (!e) {
+        // an eighth of headroom on top, then the class: the first request of a role is served by a block that also holds relations up
+        // to ~1.15x its size -- bench.py's sweep over 0.9 ... 1.1e9 probe rows runs on the champions its first call chose
+        const size_t block = place_class(want + want / 8);
+        // entries of this role the new, larger block serves as well go: their requests are this entry's from now on
+        for (auto it = m.placed.begin(); it != m.placed.end();) {
+          if (it->role == role && !it->busy && it->want <= block && place_serves(block, it->want)) { place_drop_entry_locked(m, *it); it = m.placed.erase(it); }
+          else ++it;
+        }
         if (m.placed.size() >= PLACE_MAX_ENTRIES) {          // evict the entry used longest ago (never one that is out)
           size_t victim = m.placed.size();
           for (size_t i = 0; i < m.placed.size(); ++i)
@@ -244,49 +292,71 @@ rmmError_t place_alloc(Manager &m, int role, size_t size, int max_draws, void **
           m.placed.emplace_back();
           e = &m.placed.back();
           e->role = role;
-          e->want = want;
+          e->want = block;
         }
       }
       if (e && !e->busy) {
         e->stamp = ++m.place_clock;
         if (!e->champ) {
           void *p = nullptr;
-          hipError_t err = hipMalloc(&p, want);
+          const double t0 = place_now_ms();
+          hipError_t err = hipMalloc(&p, e->want);
+          place_note(m, "hipMalloc(champion)", role, e->want, place_now_ms() - t0);
           if (err == hipErrorOutOfMemory) {
             (void)hipGetLastError();
             release_cache_locked(m);
-            err = hipMalloc(&p, want);
+            err = hipMalloc(&p, e->want);
           }
-          if (err != hipSuccess) return map_hip(err);
-          e->champ = p;
-          e->champ_ms = -1.f;
-          e->worst_ms = 0.f;
-          e->explore_ms = 0;
-          e->explore_max = 0;
-          e->draws = 0;
-          e->busy = true;
-          e->max_draws = draws;
-          *ptr = p;
-          *measure = draws > 0;
-          return RMM_SUCCESS;
+          if (err == hipErrorOutOfMemory) {
+            //  the idle champions and the losers of OTHER entries go before this request fails: the plain pool would have
+            // had that memory.  The release erases idle entries -- this one among them: the request is the plain pool's now
+            (void)hipGetLastError();
+            (void)place_release_idle_locked(m);
+            e = nullptr;
+          } else if (err != hipSuccess) {
+            return map_hip(err);
+          } else {
+            e->champ = p;
+            e->champ_ms = -1.f;
+            e->worst_ms = 0.f;
+            e->explore_ms = 0;
+            e->explore_max = 0;
+            e->draws = 0;
+            e->stale = 0;
+            e->busy = true;
+            if (!hold) e->max_draws = draws;
+            *ptr = p;
+            *measure = !hold && draws > 0;
+            return RMM_SUCCESS;
+          }
         }
+      }
+      if (e && !e->busy) {
         m.placed_idle_bytes -= e->want;
         e->busy = true;
-        e->max_draws = draws;
-        if (e->champ_ms > 0.f && e->draws < draws) {        // a challenger, drawn while the champion is held
+        if (!hold) e->max_draws = draws;
+        bool drew = false;
+        if (!hold && e->champ_ms > 0.f && e->draws < draws) {        // a challenger, drawn while the champion is held
+          // ... if the device has room for it: a search holds at most champion + challenger + PLACE_MAX_LOSERS blocks, and a block
+          // is drawn only while it is a quarter of the free memory at most
+          size_t free_b = 0, total_b = 0;
+          const bool room = hipMemGetInfo(&free_b, &total_b) == hipSuccess && e->want <= free_b / 4;
           void *p = nullptr;
           const auto t0 = std::chrono::steady_clock::now();
-          const hipError_t drawn = hipMalloc(&p, want);
+          const hipError_t drawn = room ? hipMalloc(&p, e->want) : hipErrorOutOfMemory;
           const double took = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
           e->explore_ms += took;
           if (took > e->explore_max) e->explore_max = took;
+          place_note(m, "hipMalloc(challenger)", role, e->want, took);
           // the budget forgives ONE stall: behind another process's exit the driver takes seconds for one multi-GB hipMalloc, once per
           // process -- a search that gave up there kept whatever it had drawn so far, a slow block in one process of eight
           // on such a box (9.47 instead of 9.05 ms per join); the allocations after the stall cost 0.3 ms again
           if (drawn == hipSuccess && e->explore_ms - e->explore_max > PLACE_BUDGET_MS) e->draws = draws - 1;      // this one is the last
           if (drawn == hipSuccess) {
+            while (e->losers.size() > PLACE_MAX_LOSERS) place_free_loser_locked(m, *e, 0);      // (the new block cannot be these pages)
             e->chall = p;
             ++e->draws;
+            e->stale = 0;
             ++m.place_drawn;
             *ptr = p;
             *measure = 1;
@@ -294,10 +364,13 @@ rmmError_t place_alloc(Manager &m, int role, size_t size, int max_draws, void **
           }
           (void)hipGetLastError();
           e->draws = draws;                                         // no room for a second block of this size: settle
-          place_drop_losers(*e);
+          place_drop_losers_locked(m, *e);
+          drew = true;
         }
+        // a search that is not moving (held calls, a caller that never reports times) does not sit on its losers for ever
+        if (!drew && !e->losers.empty() && ++e->stale >= PLACE_STALE_CALLS) { place_drop_losers_locked(m, *e); e->draws = 1 << 20; }
         *ptr = e->champ;
-        *measure = e->champ_ms <= 0.f && draws > 0;                  // (a champion whose first call could not be timed)
+        *measure = !hold && e->champ_ms <= 0.f && draws > 0;         // (a champion whose first call could not be timed)
         return RMM_SUCCESS;
       }
     }
@@ -328,6 +401,7 @@ rmmError_t place_free(Manager &m, int role, void *ptr, float ms) {
         } else {
           e.losers.push_back(e.chall);
         }
+        m.placed_loser_bytes += e.want;
         e.chall = nullptr;
       } else if (ms > 0.f && e.champ_ms <= 0.f) {
         e.champ_ms = ms;        // FIRST-use time against first-use time: a challenger is only ever measured on its first call
@@ -343,7 +417,7 @@ rmmError_t place_free(Manager &m, int role, void *ptr, float ms) {
       if (e.draws >= e.max_draws && !e.losers.empty()) {
         const auto t0 = std::chrono::steady_clock::now();
         const size_t nl = e.losers.size();
-        place_drop_losers(e);
+        place_drop_losers_locked(m, e);
         if (m.place_trace.size() < 16384) {
           char line[120];
           snprintf(line, sizeof line, "role %d settled: %zu losers freed in %.1f ms\n", role, nl,
@@ -427,6 +501,12 @@ __attribute__((visibility("default"))) rmmError_t gdf_amd_rmm_place_free(int rol
   return place_free(m, role, ptr, ms);
   });
 }
+// test hook: the size from which a request is a placed block (0: the default, 1 GiB) -- the callers' calibration loops on small inputs
+__attribute__((visibility("default"))) void gdf_amd_rmm_place_min(size_t bytes) {
+  Manager &m = Manager::get();
+  std::lock_guard<std::mutex> g(m.mu);
+  g_place_min = bytes ? bytes : PLACE_MIN_DEFAULT;
+}
 // challengers drawn per (role, size); 0: placed blocks are cached but never re-drawn; < 0: the plain pool serves placed requests
 __attribute__((visibility("default"))) void gdf_amd_rmm_place_draws(int draws) {
   Manager &m = Manager::get();
@@ -481,12 +561,13 @@ rmmError_t rmmFinalize(void) {
     std::lock_guard<std::mutex> g(m.mu);
     release_cache_locked(m);
     for (auto &e : m.placed) {                                // placed blocks, in use or not, go with the pool
-      place_drop_losers(e);
+      place_drop_losers_locked(m, e);
       if (e.chall) (void)hipFree(e.chall);
       if (e.champ) (void)hipFree(e.champ);
     }
     m.placed.clear();
     m.placed_idle_bytes = 0;
+    m.placed_loser_bytes = 0;
     for (auto &kv : m.live_blocks) (void)hipFree(kv.first);   // leaked by the caller; the pool dies with us
     m.live_blocks.clear();
     m.live_bytes = 0;
@@ -586,7 +667,7 @@ rmmError_t rmmGetInfo(size_t *freeSize, size_t *totalSize, cudaStream_t) {
   if (e != hipSuccess) return map_hip(e);
   if (pool_mode(m)) {   // cached blocks are available to the next rmmAlloc
     std::lock_guard<std::mutex> g(m.mu);
-    *freeSize += m.cached_bytes + m.placed_idle_bytes;
+    *freeSize += m.cached_bytes + m.placed_idle_bytes + m.placed_loser_bytes;
   }
   return RMM_SUCCESS;
   });

@@ -1214,3 +1214,81 @@ def test_one_build_key_repeated_millions_of_times(gdf, dtype):
     assert li.numel() == expected
     assert bool((pk[li.long()] == bk[ri.long()]).all())
     assert int(torch.unique(li.long() * nb + ri.long()).numel()) == expected
+
+
+@pytest.fixture
+def small_placed_blocks(gdf, force_path):
+    """Pool mode with the placed-block threshold lowered to 1 MiB and a per-call candidate budget that never runs out: the
+    calibration loops of the join (level 1, its high words, level 2, the output columns) and of the group-by run on test-sized
+    inputs (only the 1e9-row bench reached them)."""
+    from libgdf_amd._binding import _rmm_cdll as lib, rmmOptions_t
+    lib.gdf_amd_rmm_place_min.argtypes = [C.c_size_t]
+    lib.gdf_amd_rmm_place_stats.argtypes = [C.POINTER(C.c_ulonglong)]
+    assert lib.rmmFinalize() == 0
+    assert lib.rmmInitialize(C.byref(rmmOptions_t(1, 0, False))) == 0
+    lib.gdf_amd_rmm_place_min(1 << 20)
+    force_path("GDF_PLACE_BUDGET_MS", "100000")
+
+    def drawn():
+        st = (C.c_ulonglong * 4)()
+        lib.gdf_amd_rmm_place_stats(st)
+        return int(st[0])
+    yield drawn
+    lib.gdf_amd_rmm_place_min(0)
+    assert lib.rmmFinalize() == 0
+    assert lib.rmmInitialize(C.byref(rmmOptions_t(0, 0, False))) == 0
+
+
+@pytest.mark.parametrize("shape", ["fk-pk", "left-half-hit", "inner-sparse", "wide-keys", "wide-left", "payload", "masked", "budget-of-one-candidate"])
+def test_placement_tournaments_on_small_inputs(gdf, shape, small_placed_blocks, force_path):
+    """Every calibration loop of the join re-runs the real kernel on part of the input and sets its state back by hand (fill counters,
+    overflow flags, cursors, the write pass's state words and per-unit pair counts): a missed reset would corrupt results on LARGE inputs
+    only.  With the placed-block threshold at 1 MiB (gdf_amd_rmm_place_min) the same loops run here, twice per shape (first call: every
+    search from its first candidate; second call: settled champions), against the oracle: dense FK -> PK, LEFT with misses, a sparse
+    INNER join (hole filling / compaction behind the calibrated write pass), WIDE keys (two level-1 searches), a carried payload
+    (jk_scatter1_pay), masked keys, and a budget that allows ONE candidate per call (searches that continue over several calls, the pool
+    HOLDING its champions in between)."""
+    rs = np.random.RandomState(len(shape))
+    nb, npr = 60_000, 1_200_000
+    force_path("GDF_JK_FORCE_FB", "15")
+    force_path("GDF_JK_SPEC_MIN", "1000")
+    force_path("GDF_JK_FORCE_L6")
+    if shape == "budget-of-one-candidate":
+        force_path("GDF_PLACE_BUDGET_MS", "0")      # (a call whose budget is spent from the start: every search holds -- then one with room)
+    wide = shape.startswith("wide")
+    space = nb * 2 if shape in ("left-half-hit", "inner-sparse") else nb
+    if wide:
+        bk = np.unique(rs.randint(0, 2**62, size=nb, dtype=np.int64))
+        rs.shuffle(bk)
+        pk = bk[rs.randint(0, len(bk), size=npr)]
+        if shape == "wide-left":
+            pk[::3] = rs.randint(0, 2**62, size=len(pk[::3]), dtype=np.int64)
+    else:
+        bk = rs.permutation(space)[:nb].astype(np.int64)
+        pk = rs.randint(0, space, size=npr).astype(np.int64)
+    how = "left" if "left" in shape else "inner"
+    lv = rv = None
+    if shape == "masked":
+        lv, rv = [rs.rand(npr) > 0.1], [rs.rand(len(bk)) > 0.05]
+    before = small_placed_blocks()
+    calls = 4 if shape == "budget-of-one-candidate" else 2
+    for call in range(calls):
+        if shape == "budget-of-one-candidate" and call == 1:
+            force_path("GDF_PLACE_BUDGET_MS", "1")  # roughly one candidate per search and call from here on
+        if shape == "payload":                      # the probe relation's payload and the build relation's travel with their tuples
+            pay, bpay = rs.randint(-10**12, 10**12, size=npr).astype(np.int64), rs.randint(0, 10**6, size=len(bk)).astype(np.int64)
+            a, b, out = _join_with_result_cols(gdf, "inner", [pk, pay], 0, [bk, bpay], 0)
+            el, er = oracle.join([pk], [bk], "inner")
+            assert len(a) == len(el)
+            o = np.lexsort((b, a))
+            np.testing.assert_array_equal(a[o], el)
+            np.testing.assert_array_equal(b[o], er)
+            np.testing.assert_array_equal(out[0][0], pay[a])
+            np.testing.assert_array_equal(out[1][0], pk[a])
+            np.testing.assert_array_equal(out[2][0], bpay[b])
+            assert out[0][1].all() and out[1][1].all() and out[2][1].all()
+        else:
+            _check(gdf, [pk], [bk], how, lv, rv)
+    if shape != "budget-of-one-candidate":
+        assert small_placed_blocks() > before       # challengers were drawn: the loops ran
+

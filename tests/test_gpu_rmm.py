@@ -168,3 +168,73 @@ def test_placed_blocks_keep_the_fastest_candidate(rmm):
         assert lib.gdf_amd_rmm_place_free(role3, p, times[i] if m.value else -1.0) == 0
     assert [m for _, m in seen] == [1, 1, 1, 1, 1, 0, 0] and seen[5][0] == seen[4][0] == seen[6][0]
     lib.gdf_amd_rmm_place_draws(4)
+
+
+def test_placed_blocks_size_classes_hold_and_bounded_searches(rmm):
+    """Round 6: a champion serves a size CLASS -- requests of its role between six tenths of its block
+    and all of it -- so a caller whose relations change size keeps it; a larger request makes a new entry (rounded up to an eighth of an
+    octave) that replaces the smaller one; max_draws < 0 HOLDS: the champion, unmeasured, nothing drawn, the search stays open; a search
+    holds a bounded number of losers next to champion and challenger; rmmGetInfo counts idle champions and held losers as free."""
+    lib = rmm
+    lib.gdf_amd_rmm_place_alloc.argtypes = [C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
+    lib.gdf_amd_rmm_place_free.argtypes = [C.c_int, C.c_void_p, C.c_float]
+    lib.gdf_amd_rmm_place_stats.argtypes = [C.POINTER(C.c_ulonglong)]
+    lib.gdf_amd_rmm_place_min.argtypes = [C.c_size_t]
+    if _MODE[0] != 1:
+        pytest.skip("placed blocks exist in pool mode only")
+    role = 21
+
+    def alloc(size, max_draws):
+        p, m = C.c_void_p(), C.c_int(-1)
+        assert lib.gdf_amd_rmm_place_alloc(role, size, max_draws, C.byref(p), C.byref(m)) == 0
+        return p.value, m.value
+
+    def free_info():
+        f, t = C.c_size_t(), C.c_size_t()
+        assert lib.rmmGetInfo(C.byref(f), C.byref(t), None) == 0
+        return f.value
+    lib.gdf_amd_rmm_place_min(32 * MB)                       # the hook the callers' calibration tests use
+    try:
+        base = 96 * MB                                       # + an eighth of headroom, rounded up to 8 MiB: a 112 MiB block, serves 68 ... 112 MiB
+        free0 = free_info()
+        champ, m = alloc(base, 6)
+        assert champ and m == 1
+        assert lib.gdf_amd_rmm_place_free(role, champ, 10.0) == 0
+        # HOLD: the champion, unmeasured, no challenger -- as often as asked
+        for _ in range(3):
+            p, m = alloc(base, -1)
+            assert p == champ and m == 0
+            assert lib.gdf_amd_rmm_place_free(role, p, -1.0) == 0
+        # the size class: 90 MiB (>= 0.6 of 112) is served by the same entry and continues ITS search
+        c1, m = alloc(90 * MB, 12)
+        assert c1 and c1 != champ and m == 1
+        assert lib.gdf_amd_rmm_place_free(role, c1, 10.1) == 0           # slower: a held loser
+        held = [c1]
+        for i in range(8):                                   # eight more slow challengers: at most five losers are held at any time
+            c, m = alloc(100 * MB, 12)
+            assert m == 1 and c != champ and c not in held[-4:]          # (not the champion, not one of the losers still held)
+            held.append(c)
+            assert lib.gdf_amd_rmm_place_free(role, c, 10.1 + 0.04 * i) == 0       # (never 7 % slower than the champion: no early settle)
+            assert abs(free_info() - free0) < 32 * MB        # champion idle + losers held: all counted as free
+        p, m = alloc(base, -1)
+        assert p == champ and m == 0                         # the champion survived nine slower candidates
+        assert lib.gdf_amd_rmm_place_free(role, p, -1.0) == 0
+        # 60 MiB is below six tenths of the block: its own entry; 120 MiB does not fit: a new, larger entry (144 MiB) that takes
+        # the 112 MiB entry's place
+        stats = (C.c_ulonglong * 4)()
+        lib.gdf_amd_rmm_place_stats(stats)
+        n0 = stats[2]
+        small, m = alloc(60 * MB, 6)
+        assert small != champ and m == 1
+        assert lib.gdf_amd_rmm_place_free(role, small, 5.0) == 0
+        big, m = alloc(120 * MB, 6)
+        assert big not in (champ, small) and m == 1
+        assert lib.gdf_amd_rmm_place_free(role, big, 5.0) == 0
+        lib.gdf_amd_rmm_place_stats(stats)
+        assert stats[2] == n0 + 1                            # + the 60 MiB entry, + the 144 MiB entry, - the 112 MiB entry it replaced
+        p, m = alloc(110 * MB, -1)
+        assert p == big                                      # 110 MiB requests are the larger entry's now
+        assert lib.gdf_amd_rmm_place_free(role, p, -1.0) == 0
+    finally:
+        lib.gdf_amd_rmm_place_min(0)
+

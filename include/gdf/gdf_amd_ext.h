@@ -23,12 +23,8 @@ int  gdf_amd_profile_read(char (*names)[64], double *total_ms, int *launches, in
 gdf_error gdf_amd_debug_partition(gdf_column *col, int fb, uint64_t *out_key, int32_t *out_idx, uint32_t *out_fine_off,
                                   uint32_t *out_joinable, uint64_t *out_info);
 
-/*
- * test hook: force one of the library's alternative code paths (csrc/lab.h "path" switches, e.g. "GDF_JK_NO_SPEC") for
- * the calls that follow in this process; value NULL clears the name.  libgdf.so reads NO environment variable -- the
- * parity tests that push one request through two code paths select the second one here (tests/conftest.py force_path).
- */
-gdf_error gdf_amd_debug_force(const char *name, const char *value);
+/* (the path-forcing test hook gdf_amd_debug_force is not exported from libgdf.so any more: include/gdf/gdf_amd_testhook.h,
+ * libgdf_testhook.so -- test infrastructure, loaded by the tests only) */
 
 /*
  * out[i] = (int32)(in[i] - lo) when lo <= in[i] <= hi, else -1.   in: GDF_INT64 (or DATE64 / TIMESTAMP), no mask;

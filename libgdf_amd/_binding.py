@@ -130,7 +130,6 @@ _PROTOTYPES = {
     "gdf_amd_fj_send": (None, [_COLP, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, _INTP]),
     "gdf_amd_fj_build_create": (None, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_uint32, C.c_int64, C.POINTER(C.c_void_p)]),
     "gdf_amd_fj_probe_add": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int64, C.c_int64]),
-    "gdf_amd_debug_force": (None, [C.c_char_p, C.c_char_p]),
     "gdf_amd_dist_inner_join": (None, [_COLP, _COLP, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _COLP, _COLP, C.c_void_p, _INTP]),
     "gdf_amd_dist_group_by": (None, [C.c_int, _COLP, _COLP, C.c_void_p, _COLP, _COLP]),
     "gdf_amd_dist_shuffle_join": (None, [_COLP, _COLP, C.c_void_p, _COLP, _COLP]),
@@ -230,6 +229,11 @@ class _Wrapper:
         return cfn
 
 
+# LIBGDF_AMD_TESTHOOK=1 (set by tests/conftest.py and the stress / A-B tools, never by a caller of the library): load
+# libgdf_testhook.so -- csrc/testhook.cpp, the registry behind force_path -- IN FRONT of libgdf.so, whose weak reference to the
+# registry's lookup is bound at load time.  Without it libgdf.so has no path switch at all (include/gdf/gdf_amd_testhook.h).
+TEST_HOOK = os.environ.get("LIBGDF_AMD_TESTHOOK", "") not in ("", "0")
+_hook_cdll = _load("libgdf_testhook.so") if TEST_HOOK else None
 _rmm_cdll = _load("librmm.so")
 _gdf_cdll = _load("libgdf.so")
 
@@ -256,5 +260,20 @@ def _check_rmm(rc, fname):
     raise RMMError(rc, _rmm_cdll.rmmGetErrorString(rc).decode())
 
 
-libgdf = _Wrapper(_gdf_cdll, _PROTOTYPES, _check_gdf)
+class _GdfWrapper(_Wrapper):
+    """libgdf.so, plus the one name that lives in the test-hook library when a test process loaded it"""
+
+    def __getattr__(self, name):
+        if name == "gdf_amd_debug_force":
+            if _hook_cdll is None:
+                raise AttributeError("gdf_amd_debug_force lives in libgdf_testhook.so (test infrastructure): set LIBGDF_AMD_TESTHOOK=1 "
+                                     "before importing libgdf_amd")
+            fn = _hook_cdll.gdf_amd_debug_force
+            fn.restype = C.c_int
+            fn.argtypes = [C.c_char_p, C.c_char_p]
+            return fn
+        return super().__getattr__(name)
+
+
+libgdf = _GdfWrapper(_gdf_cdll, _PROTOTYPES, _check_gdf)
 librmm = _Wrapper(_rmm_cdll, _RMM_PROTOTYPES, _check_rmm)

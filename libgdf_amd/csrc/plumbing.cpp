@@ -16,6 +16,9 @@
 #include <string>
 #include <roctracer/roctx.h>
 
+// (csrc/testhook.cpp; weak: absent from every process that has not loaded libgdf_testhook.so in front of this library)
+extern "C" __attribute__((weak, visibility("default"))) const char *gdf_amd_testhook_forced(const char *name);
+
 namespace gdf_amd {
 
 void note_hip_error(hipError_t e, const char *what, const char *file, int line) {
@@ -132,24 +135,11 @@ PlaceRound::~PlaceRound() {
   if (!g_place_charged) { g_place_charged = true; g_place_calls.fetch_add(1, std::memory_order_relaxed); }
 }
 
-// lab.h: the registry behind gdf_amd_debug_force.  Empty in every process that never calls the hook, and then one
-// relaxed atomic load per lookup.
+// lab.h: forced paths.  The registry lives in libgdf_testhook.so (csrc/testhook.cpp, test infrastructure); this library only holds a
+// WEAK reference to its lookup, bound when libgdf.so is loaded -- null, i.e. one pointer test per lookup, in every process that did not
+// load the hook library first.
 namespace lab {
-namespace {
-std::mutex g_forced_mutex;
-// name -> interned value.  Values are interned in a set that only grows, so a pointer handed out by forced() stays valid for the
-// life of the process even when another thread forces the same name again or clears it (c_str() of a map entry that a
-// concurrent gdf_amd_debug_force erased was a use-after-free); a test process sets a handful of distinct values.
-std::map<std::string, const char *> &forced_map() { static std::map<std::string, const char *> m; return m; }
-const char *intern(const char *value) { static std::set<std::string> pool; return pool.insert(value).first->c_str(); }
-int g_forced_count = 0;
-}  // namespace
-const char *forced(const char *name) {
-  if (__atomic_load_n(&g_forced_count, __ATOMIC_RELAXED) == 0) return nullptr;
-  std::lock_guard<std::mutex> lock(g_forced_mutex);
-  auto it = forced_map().find(name);
-  return it == forced_map().end() ? nullptr : it->second;
-}
+const char *forced(const char *name) { return gdf_amd_testhook_forced ? gdf_amd_testhook_forced(name) : nullptr; }
 }  // namespace lab
 
 }  // namespace gdf_amd
@@ -237,11 +227,3 @@ gdf_error gdf_nvtx_range_pop(void) {
 
 }  // extern "C"
 
-extern "C" __attribute__((visibility("default"))) gdf_error gdf_amd_debug_force(const char *name, const char *value) {
-  if (!name) return GDF_INVALID_API_CALL;
-  std::lock_guard<std::mutex> lock(gdf_amd::lab::g_forced_mutex);
-  auto &m = gdf_amd::lab::forced_map();
-  if (value) m[name] = gdf_amd::lab::intern(value); else m.erase(name);
-  __atomic_store_n(&gdf_amd::lab::g_forced_count, (int)m.size(), __ATOMIC_RELAXED);
-  return GDF_SUCCESS;
-}

@@ -7,6 +7,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# the path-forcing registry is test infrastructure (libgdf_testhook.so, csrc/testhook.cpp): the Python binding loads it in front of
+# libgdf.so only when asked to -- the shipped library exports no switch of its own
+os.environ["LIBGDF_AMD_TESTHOOK"] = "1"
 
 
 def pytest_configure(config):
@@ -33,7 +36,7 @@ def gdf():
 def force_path(gdf):
     """Force one of the library's alternative code paths for the duration of a test: force_path("GDF_JK_NO_SPEC", "1").
     The shipped libgdf.so reads no environment variable (csrc/lab.h); the parity tests that run one request through two
-    code paths select the second one through the exported test hook gdf_amd_debug_force, and this fixture clears every
+    code paths select the second one through gdf_amd_debug_force of the test-hook library (libgdf_testhook.so), and this fixture clears every
     name it set when the test ends."""
     names = []
 

@@ -20,9 +20,21 @@ def _declared(header, extra_args=()):
 
 @pytest.fixture(scope="module")
 def libs():
+    # (the test-hook library first: libgdf.so's weak reference to its lookup is bound when libgdf.so is loaded)
+    C.CDLL(os.path.join(LIBDIR, "libgdf_testhook.so"), mode=C.RTLD_GLOBAL)
     rmm = C.CDLL(os.path.join(LIBDIR, "librmm.so"), mode=C.RTLD_GLOBAL)
     gdf = C.CDLL(os.path.join(LIBDIR, "libgdf.so"), mode=C.RTLD_GLOBAL)
     return gdf, rmm
+
+
+@pytest.fixture(scope="module")
+def hook():
+    lib = C.CDLL(os.path.join(LIBDIR, "libgdf_testhook.so"), mode=C.RTLD_GLOBAL)
+    lib.gdf_amd_debug_force.restype = C.c_int
+    lib.gdf_amd_debug_force.argtypes = [C.c_char_p, C.c_char_p]
+    lib.gdf_amd_testhook_forced.restype = C.c_char_p
+    lib.gdf_amd_testhook_forced.argtypes = [C.c_char_p]
+    return lib
 
 
 def test_libgdf_exports_every_declared_symbol(libs):
@@ -254,25 +266,29 @@ def test_host_side_argument_errors_need_no_gpu(libs):
     assert gdf.gdf_inner_join(L, 1, idx, R, 1, idx, 1, 0, None, C.byref(ol), C.byref(orr), C.byref(ctx)) == 4
 
 
-def test_shipped_library_reads_no_environment(libs):
+def test_shipped_library_reads_no_environment(libs, hook):
     """csrc/lab.h: the shipped libgdf.so / librmm.so import no getenv at all -- a stray GDF_* variable in a caller's
-    environment cannot change which algorithm runs.  Alternative code paths are selected only through the exported test
-    hook gdf_amd_debug_force (host-side registry: no GPU needed to set and clear a name)."""
+    environment cannot change which algorithm runs -- and (round 6) libgdf.so exports no path switch either:
+    gdf_amd_debug_force lives in libgdf_testhook.so (csrc/testhook.cpp, test infrastructure), libgdf.so only has a WEAK reference
+    to that library's lookup, null in every process that did not load it first."""
     for name in ("libgdf.so", "librmm.so"):
         und = subprocess.check_output(["nm", "-D", "--undefined-only", os.path.join(LIBDIR, name)]).decode()
         assert "getenv" not in und, name
-    gdf, _ = libs
-    gdf.gdf_amd_debug_force.restype = C.c_int
-    gdf.gdf_amd_debug_force.argtypes = [C.c_char_p, C.c_char_p]
-    assert gdf.gdf_amd_debug_force(b"GDF_JK_NO_SPEC", b"1") == 0
-    assert gdf.gdf_amd_debug_force(b"GDF_JK_NO_SPEC", None) == 0
-    assert gdf.gdf_amd_debug_force(None, None) != 0
+    exported = subprocess.check_output(["nm", "-D", "--defined-only", os.path.join(LIBDIR, "libgdf.so")]).decode()
+    assert "debug_force" not in exported and "testhook" not in exported
+    und = subprocess.check_output(["nm", "-D", "--undefined-only", os.path.join(LIBDIR, "libgdf.so")]).decode()
+    assert any(l.split()[:1] == ["w"] and "gdf_amd_testhook_forced" in l for l in und.splitlines()), "the lookup must be a WEAK reference"
+    assert hook.gdf_amd_debug_force(b"GDF_JK_NO_SPEC", b"1") == 0
+    assert hook.gdf_amd_testhook_forced(b"GDF_JK_NO_SPEC") == b"1"
+    assert hook.gdf_amd_debug_force(b"GDF_JK_NO_SPEC", None) == 0
+    assert hook.gdf_amd_testhook_forced(b"GDF_JK_NO_SPEC") is None
+    assert hook.gdf_amd_debug_force(None, None) != 0
     lab = os.path.join(LIBDIR, "lab", "libgdf.so")
     if os.path.exists(lab):        # the LAB build (experiment knobs) is the one that reads the environment
         assert "getenv" in subprocess.check_output(["nm", "-D", "--undefined-only", lab]).decode()
 
 
-def test_no_exception_crosses_the_c_boundary(libs):
+def test_no_exception_crosses_the_c_boundary(libs, hook):
     """SURVEY.md 8(a) quirk 6: the reference lets std::bad_alloc / thrust::system_error escape extern "C"
     (managed_allocator.cuh:34-45, thrust_rmm_allocator.h:44-49); here every relational entry point runs its body through
     gdf_amd::guarded (csrc/common.h) and answers GDF_MEMORYMANAGER_ERROR.  The test hook makes make_key_table -- the first thing
@@ -286,8 +302,7 @@ def test_no_exception_crosses_the_c_boundary(libs):
         c = gdf_column()
         c.data, c.size, c.dtype = fake, size, dtype
         return c
-    gdf.gdf_amd_debug_force.argtypes = [C.c_char_p, C.c_char_p]
-    assert gdf.gdf_amd_debug_force(b"GDF_FORCE_HOST_ALLOC_FAILURE", b"1") == 0
+    assert hook.gdf_amd_debug_force(b"GDF_FORCE_HOST_ALLOC_FAILURE", b"1") == 0
     try:
         key, agg, outk, outa = col(), col(), col(), col()
         ctx = gdf_context()
@@ -315,5 +330,5 @@ def test_no_exception_crosses_the_c_boundary(libs):
         # (d_cols / d_types NULL: gdf_order_by uploads them before it looks at the keys, sqls_ops.cu:1373-1392)
         assert gdf.gdf_order_by(C.c_size_t(8), cols, C.c_size_t(1), None, None, C.c_void_p(fake)) == 20
     finally:
-        assert gdf.gdf_amd_debug_force(b"GDF_FORCE_HOST_ALLOC_FAILURE", None) == 0
+        assert hook.gdf_amd_debug_force(b"GDF_FORCE_HOST_ALLOC_FAILURE", None) == 0
     assert gdf.gdf_group_by_sum(0, None, None, None, None, None, None) == 5          # alive, and answering as before

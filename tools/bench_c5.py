@@ -191,6 +191,8 @@ def main():
                     help="path switches set through gdf_amd_debug_force for the whole run, e.g. --force GDF_GBP_PLAIN_RANK=0")
     a = ap.parse_args()
     import torch
+    if a.force:
+        os.environ["LIBGDF_AMD_TESTHOOK"] = "1"      # path switches go through libgdf_testhook.so, loaded in front of libgdf.so
     import libgdf_amd as gdf
     from libgdf_amd._binding import rmmOptions_t
     gdf.librmm.rmmInitialize(C.byref(rmmOptions_t(1, 0, False)))

@@ -3,6 +3,7 @@ import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import ctypes as C
 import torch
+os.environ.setdefault("LIBGDF_AMD_TESTHOOK", "1")      # path switches (--force ...) go through libgdf_testhook.so: loaded in front of libgdf.so
 import libgdf_amd as gdf
 from bench import make_build_keys, make_probe_keys, read_profile
 from libgdf_amd._binding import rmmOptions_t

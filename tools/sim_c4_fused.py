@@ -6,6 +6,7 @@ device copy per buffer, the stand-in for the receive, as in tools/sim_c4_local.p
 import ctypes as C, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+os.environ.setdefault("LIBGDF_AMD_TESTHOOK", "1")      # path switches (--force ...) go through libgdf_testhook.so: loaded in front of libgdf.so
 import libgdf_amd as gdf
 from libgdf_amd import api
 from libgdf_amd.columns import Column

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--max-rows", type=int, default=12_000_000)
     a = ap.parse_args()
     import numpy as np
+    os.environ.setdefault("LIBGDF_AMD_TESTHOOK", "1")      # path switches (--force ...) go through libgdf_testhook.so: loaded in front of libgdf.so
     import libgdf_amd as gdf
     from test_gpu_groupby import _check, _check_masked, _zipf
     switches = ["GDF_GBP_NO_XCD", "GDF_GBP_NO_SPEC", "GDF_GBP_NO_HOT", "GDF_GBP_PLAIN_RANK"]

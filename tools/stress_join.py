@@ -24,6 +24,7 @@ def main():
                     help="path switches set through gdf_amd_debug_force for the whole run, e.g. --force GDF_JK_FORCE_FB=15 --force GDF_JK_FORCE_L6")
     a = ap.parse_args()
     import torch
+    os.environ.setdefault("LIBGDF_AMD_TESTHOOK", "1")      # path switches (--force ...) go through libgdf_testhook.so: loaded in front of libgdf.so
     import libgdf_amd as gdf
     from libgdf_amd.columns import Column
     for f in a.force:

@@ -198,8 +198,10 @@ gdf_error gdf_amd_dist_shuffle_join(gdf_column *probe_keys, gdf_column *build_ke
  *   out_keys / out_agg   library-allocated columns (gdf_column_free) with THIS RANK'S groups, sorted by key; every group of the
  *                        global relation comes out on exactly one rank.  SUM / MIN / MAX keep the value dtype (a sum wraps as the
  *                        single-GPU gdf_group_by_sum does), COUNT is GDF_INT64, AVG GDF_FLOAT64.
- * Errors: a local error (bad arguments on one rank, out of memory) is carried into the agreement; that rank returns its code and
- * the others GDF_C_ERROR -- nobody is left waiting in a collective.  op: GDF_SUM, GDF_MIN, GDF_MAX, GDF_COUNT, GDF_AVG. */
+ * Errors: a local error (bad arguments on one rank, out of memory) is carried into the next agreement -- the block size's, or the one
+ * behind the wire buffers' allocation (round 6: two all-reduces per exchange) -- and that rank returns its code, the others GDF_C_ERROR:
+ * nobody is left waiting in a collective.  A rank whose local work fails BEHIND the last exchange returns its code alone (the others have
+ * their results).  op: GDF_SUM, GDF_MIN, GDF_MAX, GDF_COUNT, GDF_AVG. */
 gdf_error gdf_amd_dist_group_by(gdf_agg_op op, gdf_column *keys, gdf_column *values, gdf_amd_transport *transport,
                                 gdf_column *out_keys, gdf_column *out_agg);
 gdf_error gdf_amd_dist_group_by_sum(gdf_column *keys, gdf_column *values, gdf_amd_transport *transport, gdf_column *out_keys, gdf_column *out_agg);
@@ -207,6 +209,20 @@ gdf_error gdf_amd_dist_group_by_min(gdf_column *keys, gdf_column *values, gdf_am
 gdf_error gdf_amd_dist_group_by_max(gdf_column *keys, gdf_column *values, gdf_amd_transport *transport, gdf_column *out_keys, gdf_column *out_agg);
 gdf_error gdf_amd_dist_group_by_count(gdf_column *keys, gdf_column *values, gdf_amd_transport *transport, gdf_column *out_keys, gdf_column *out_agg);
 gdf_error gdf_amd_dist_group_by_avg(gdf_column *keys, gdf_column *values, gdf_amd_transport *transport, gdf_column *out_keys, gdf_column *out_agg);
+
+/* The same over SEVERAL key columns and WITH validity masks (round 6; BASELINE configuration C5 -- a two-key, masked AVG -- across ranks).
+ * Reference shape: gdf_group_by_* over ncols key columns (src/sqls_ops.cu:1085-1363, src/groupby/groupby.cuh:208-250); a group's owner
+ * is its ROW HASH % world -- the Murmur3 fold over the key columns of src/gdf_table.cuh:704-854, i.e. gdf_hash_partition on all key
+ * columns.  Key columns: any dtype the local group-by takes; values: numeric.  Mask semantics are the local HASH group-by's extension
+ * (the reference rejects masks, sqls_ops.cu:1103-1106): a row with a null in ANY key column is dropped, a null value is skipped, a group
+ * without a valid value reports 0 and a cleared validity bit (COUNT: 0, valid).  Per rank: the partial aggregate (AVG: the sum of the
+ * widened values) and the number of valid values of every local group travel to the owner, which combines the partials that had a valid
+ * value by the same operator and the counts by a sum; AVG = combined sum / combined count (src/groupby/groupby.cuh:308-419 per rank).
+ *   out_keys[ncols], out_agg   library-allocated columns (gdf_column_free) with THIS RANK'S groups in ascending lexicographic key order;
+ *                              out_agg carries a validity mask (and null_count) unless op is GDF_COUNT.  Dtypes as the single-key entry.
+ * Errors travel into the agreements as above; two small all-reduces (block size; "every rank has its wire buffers") precede the exchange. */
+gdf_error gdf_amd_dist_group_by_multi(gdf_agg_op op, int ncols, gdf_column **keys, gdf_column *values, gdf_amd_transport *transport,
+                                      gdf_column **out_keys, gdf_column *out_agg);
 
 /* RCCL transport.  id: the 128 bytes of an ncclUniqueId -- made by ONE rank with gdf_amd_rccl_unique_id and handed to the others by
    whatever the host has (MPI, a file, torch.distributed's store); every rank then calls gdf_amd_rccl_transport_create (collective:

@@ -132,6 +132,7 @@ _PROTOTYPES = {
     "gdf_amd_fj_probe_add": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int64, C.c_int64]),
     "gdf_amd_dist_inner_join": (None, [_COLP, _COLP, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _COLP, _COLP, C.c_void_p, _INTP]),
     "gdf_amd_dist_group_by": (None, [C.c_int, _COLP, _COLP, C.c_void_p, _COLP, _COLP]),
+    "gdf_amd_dist_group_by_multi": (None, [C.c_int, C.c_int, C.POINTER(_COLP), _COLP, C.c_void_p, C.POINTER(_COLP), _COLP]),
     "gdf_amd_dist_shuffle_join": (None, [_COLP, _COLP, C.c_void_p, _COLP, _COLP]),
     "gdf_amd_rccl_unique_id": (None, [C.c_char_p]),
     "gdf_amd_rccl_transport_create": (None, [C.c_char_p, C.c_int, C.c_int, C.c_void_p]),

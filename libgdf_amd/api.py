@@ -502,6 +502,31 @@ def dist_group_by(op: str, keys: Column, values: Column, transport):
     return _take_library_column(ok, tdt[int(ok.dtype)]), _take_library_column(oa, tdt[int(oa.dtype)])
 
 
+def dist_group_by_multi(op: str, keys, values: Column, transport):
+    """gdf_amd_dist_group_by_multi (COLLECTIVE): several key columns, validity masks honoured -> (list of key tensors, aggregate tensor,
+    bool tensor of the aggregate's valid bits) with THIS rank's groups in ascending key order."""
+    import torch
+    oks = [gdf_column() for _ in keys]
+    oa = gdf_column()
+    oks_arr = (C.POINTER(gdf_column) * len(keys))(*[C.pointer(k) for k in oks])
+    libgdf.gdf_amd_dist_group_by_multi(_AGG_OPS[op], len(keys), column_array(list(keys)), values.ptr, transport.ptr, oks_arr, C.byref(oa))
+    errs = getattr(transport, "errors", None)
+    if errs:
+        raise errs.pop(0)
+    tdt = {1: torch.int8, 2: torch.int16, 3: torch.int32, 4: torch.int64, 5: torch.float32, 6: torch.float64, 7: torch.int32, 8: torch.int64,
+           9: torch.int64}
+    g = int(oa.size)
+    if oa.valid:
+        raw = torch.empty((g + 7) // 8, dtype=torch.uint8, device="cuda")
+        if g:
+            _hipMemcpyDtoD(raw.data_ptr(), oa.valid, raw.numel())
+        bits = torch.from_numpy(np.unpackbits(raw.cpu().numpy(), bitorder="little")[:g].astype(bool))
+        assert int(oa.null_count) == int(g - int(bits.sum()))
+    else:
+        bits = torch.ones(g, dtype=torch.bool)
+    return [_take_library_column(k, tdt[int(k.dtype)]) for k in oks], _take_library_column(oa, tdt[int(oa.dtype)]), bits
+
+
 def dist_shuffle_join(probe: Column, build: Column, transport):
     """gdf_amd_dist_shuffle_join (COLLECTIVE): the key-shuffle join behind ONE C call -> (probe ids, build ids), int64 tensors of
     (owner rank << 40 | local row) for every pair this rank produced."""

@@ -36,14 +36,21 @@ __global__ __launch_bounds__(256) void dg_divide(const S *__restrict__ sum, cons
 }
 
 struct Col {                 // a device column this file owns
-  DevBuf buf;
+  DevBuf buf, vbuf;          // data; validity bits (with_valid: zeroed, padded to 64 bytes as the reference's masks are)
   gdf_column c;
   Col() { gdf_column_view(&c, nullptr, nullptr, 0, N_GDF_TYPES); }
-  gdf_error make(size_t rows, gdf_dtype dtype) {
+  gdf_error make(size_t rows, gdf_dtype dtype, bool with_valid = false) {
     const int w = dtype_width(dtype);
     GDF_REQUIRE(w > 0, GDF_UNSUPPORTED_DTYPE);
     RMM_TRY(buf.alloc((size_t)w * std::max<size_t>(rows, 1)));
-    gdf_column_view(&c, buf.p, nullptr, (gdf_size_type)rows, dtype);
+    gdf_valid_type *valid = nullptr;
+    if (with_valid) {
+      const size_t vb = ((std::max<size_t>(rows, 1) + 7) / 8 + 63) / 64 * 64;
+      RMM_TRY(vbuf.alloc(vb));
+      HIP_TRY(hipMemsetAsync(vbuf.p, 0, vb, stream0()));
+      valid = (gdf_valid_type *)vbuf.p;
+    }
+    gdf_column_view(&c, buf.p, valid, (gdf_size_type)rows, dtype);
     return GDF_SUCCESS;
   }
 };
@@ -73,13 +80,18 @@ static gdf_error local_group(gdf_agg_op op, gdf_column *keys, gdf_column *vals, 
 }
 
 // `part[c]` (ncols columns of `rows` rows) are ALREADY split by destination: rows [offs[r], offs[r + 1]) go to rank r.  The partitions
-// travel as EQUAL blocks (their size -- the largest partition anywhere -- and whether any rank has failed are agreed by one
-// all-reduce) next to one 8-byte count per (sender, receiver); the received rows are compacted into `out` (same dtypes), sender by
-// sender, and got[r] says how many came from rank r.  `hard` carries a local error of the caller INTO the agreement and this
-// function's own local errors out of it: a rank with an error still takes part in every collective (dist_inner_join's rule).
+// travel as EQUAL blocks next to one 8-byte count per (sender, receiver); the received rows are compacted into `out` (same dtypes),
+// sender by sender, and got[r] says how many came from rank r.
+// Nobody is left waiting in a collective (round 6): `hard` carries a local error of the caller INTO the first agreement
+// (block size = the largest partition anywhere + "a rank has failed"); the wire buffers are allocated behind it and a SECOND
+// agreement says whether every rank got them -- only then are the blocks posted, by everybody or by nobody.  A rank whose local work
+// fails AFTER the exchange (compaction, the caller's steps) records the error in *hard and returns GDF_SUCCESS with empty `out`
+// columns: its caller carries *hard into its next collective, or returns it once there is none left.  The return value itself is a
+// failure every rank sees together (an agreement said so) or a failed transport call.
 static gdf_error exchange_blocks(gdf_amd_transport *tr, int ncols, Col *part, const std::vector<int> &offs, size_t rows, Col *out,
                                  std::vector<long long> *got_out, gdf_error *hard) {
   const int world = tr->world;
+  auto note = [&](gdf_error e) { if (e != GDF_SUCCESS && *hard == GDF_SUCCESS) *hard = e; return e; };
   int64_t agree[2] = {0, *hard != GDF_SUCCESS ? 1 : 0};      // {largest partition anywhere, a rank has failed}
   if (*hard == GDF_SUCCESS)
     for (int r = 0; r < world; ++r) agree[0] = std::max<int64_t>(agree[0], rows ? offs[r + 1] - offs[r] : 0);
@@ -87,7 +99,7 @@ static gdf_error exchange_blocks(gdf_amd_transport *tr, int ncols, Col *part, co
   if (agree[1] != 0) return *hard != GDF_SUCCESS ? *hard : GDF_C_ERROR;
   const size_t blk = (size_t)std::max<int64_t>(agree[0], 1);
 
-  // ---- send blocks: partition r of every column at block r; counts as one int64 per destination ----
+  // ---- wire buffers, then the second agreement: everybody has them, or nobody posts ----
   std::vector<DevBuf> send((size_t)ncols), recv((size_t)ncols);
   DevBuf scnt, rcnt;
   std::vector<long long> hcnt((size_t)world, 0);
@@ -97,18 +109,25 @@ static gdf_error exchange_blocks(gdf_amd_transport *tr, int ncols, Col *part, co
     const size_t w = (size_t)dtype_width(part[c].c.dtype);
     ok = send[c].alloc(w * blk * world) == RMM_SUCCESS && recv[c].alloc(w * blk * world) == RMM_SUCCESS;
   }
-  // (an allocation failure HERE cannot be agreed on without a second all-reduce on every call's happy path; the peers then see
-  // their transport time out, as with any rank that dies inside a collective)
-  if (!ok) return GDF_MEMORYMANAGER_ERROR;
-  HIP_TRY(hipMemcpyAsync(scnt.p, hcnt.data(), sizeof(long long) * world, hipMemcpyHostToDevice, stream0()));
-  for (int c = 0; c < ncols; ++c) {
-    const size_t w = (size_t)dtype_width(part[c].c.dtype);
-    for (int r = 0; r < world && rows; ++r) {
-      const size_t cnt = (size_t)hcnt[r];
-      if (cnt) HIP_TRY(hipMemcpyAsync((char *)send[c].p + w * blk * r, (const char *)part[c].c.data + w * (size_t)offs[r], w * cnt, hipMemcpyDeviceToDevice, stream0()));
+  if (!ok) note(GDF_MEMORYMANAGER_ERROR);
+  // the blocks are staged before the agreement too: a failed copy is a failed rank like a failed allocation
+  auto stage = [&]() -> gdf_error {
+    HIP_TRY(hipMemcpyAsync(scnt.p, hcnt.data(), sizeof(long long) * world, hipMemcpyHostToDevice, stream0()));
+    for (int c = 0; c < ncols; ++c) {
+      const size_t w = (size_t)dtype_width(part[c].c.dtype);
+      for (int r = 0; r < world && rows; ++r) {
+        const size_t cnt = (size_t)hcnt[r];
+        if (cnt) HIP_TRY(hipMemcpyAsync((char *)send[c].p + w * blk * r, (const char *)part[c].c.data + w * (size_t)offs[r], w * cnt, hipMemcpyDeviceToDevice, stream0()));
+      }
     }
-  }
-  HIP_TRY(hipStreamSynchronize(stream0()));         // (hcnt is about to go out of use; the transport orders itself behind the stream)
+    HIP_TRY(hipStreamSynchronize(stream0()));         // (hcnt is about to go out of use; the transport orders itself behind the stream)
+    return GDF_SUCCESS;
+  };
+  if (ok) note(stage());
+  int64_t failed = *hard != GDF_SUCCESS ? 1 : 0;
+  if (tr->all_reduce_i64(tr->ctx, &failed, 1, 1) != 0) return GDF_C_ERROR;
+  if (failed) return *hard != GDF_SUCCESS ? *hard : GDF_C_ERROR;
+
   std::vector<void *> tickets;
   auto settle = [&]() { gdf_error e = GDF_SUCCESS; for (void *t : tickets) if (tr->wait(tr->ctx, t) != 0) e = GDF_C_ERROR; tickets.clear(); return e; };
   void *t = nullptr;
@@ -121,22 +140,30 @@ static gdf_error exchange_blocks(gdf_amd_transport *tr, int ncols, Col *part, co
     tickets.push_back(t);
   }
   GDF_TRY(settle());
-  // ---- compact the received blocks ----
+  // ---- compact the received blocks: local work again -- a failure is noted and the caller goes on to its next collective ----
   std::vector<long long> got((size_t)world, 0);
-  HIP_TRY(hipMemcpyAsync(got.data(), rcnt.p, sizeof(long long) * world, hipMemcpyDeviceToHost, stream0()));
-  HIP_TRY(hipStreamSynchronize(stream0()));
-  size_t total = 0;
-  for (int r = 0; r < world; ++r) { GDF_REQUIRE(got[r] >= 0 && (size_t)got[r] <= blk, GDF_C_ERROR); total += (size_t)got[r]; }
-  for (int c = 0; c < ncols; ++c) {
-    GDF_TRY(out[c].make(total, part[c].c.dtype));
-    const size_t w = (size_t)dtype_width(part[c].c.dtype);
-    size_t at = 0;
-    for (int r = 0; r < world; ++r) {
-      if (got[r]) HIP_TRY(hipMemcpyAsync((char *)out[c].c.data + w * at, (const char *)recv[c].p + w * blk * r, w * (size_t)got[r], hipMemcpyDeviceToDevice, stream0()));
-      at += (size_t)got[r];
+  auto compact = [&]() -> gdf_error {
+    HIP_TRY(hipMemcpyAsync(got.data(), rcnt.p, sizeof(long long) * world, hipMemcpyDeviceToHost, stream0()));
+    HIP_TRY(hipStreamSynchronize(stream0()));
+    size_t total = 0;
+    for (int r = 0; r < world; ++r) { GDF_REQUIRE(got[r] >= 0 && (size_t)got[r] <= blk, GDF_C_ERROR); total += (size_t)got[r]; }
+    for (int c = 0; c < ncols; ++c) {
+      GDF_TRY(out[c].make(total, part[c].c.dtype));
+      const size_t w = (size_t)dtype_width(part[c].c.dtype);
+      size_t at = 0;
+      for (int r = 0; r < world; ++r) {
+        if (got[r]) HIP_TRY(hipMemcpyAsync((char *)out[c].c.data + w * at, (const char *)recv[c].p + w * blk * r, w * (size_t)got[r], hipMemcpyDeviceToDevice, stream0()));
+        at += (size_t)got[r];
+      }
     }
+    HIP_TRY(hipStreamSynchronize(stream0()));         // the receive buffers go out of scope with this function
+    return GDF_SUCCESS;
+  };
+  if (note(compact()) != GDF_SUCCESS) {
+    (void)hipStreamSynchronize(stream0());
+    std::fill(got.begin(), got.end(), 0);
+    for (int c = 0; c < ncols; ++c) { out[c].buf.reset(); gdf_column_view(&out[c].c, nullptr, nullptr, 0, part[c].c.dtype); }
   }
-  HIP_TRY(hipStreamSynchronize(stream0()));         // the receive buffers go out of scope with this function
   if (got_out) *got_out = got;
   return GDF_SUCCESS;
 }
@@ -214,6 +241,7 @@ static gdf_error dist_group_by(gdf_agg_op op, gdf_column *keys, gdf_column *vals
     if (hard == GDF_SUCCESS) note(local_group(op, keys, vals, part_dtype, &in[0], &in[1]));
     else { (void)in[0].make(0, GDF_INT64); (void)in[1].make(0, GDF_INT64); }
     GDF_TRY(exchange_by_owner(tr, 2, in, hard == GDF_SUCCESS ? (size_t)in[1].c.size : 0, got, &hard));
+    if (hard != GDF_SUCCESS) return hard;             // (a local failure behind the exchange: no collective is left to attend)
     Col fk, fa;
     GDF_TRY(local_group(op == GDF_COUNT ? GDF_SUM : op, &got[0].c, &got[1].c, part_dtype, &fk, &fa));
     HIP_TRY(hipStreamSynchronize(stream0()));
@@ -231,6 +259,7 @@ static gdf_error dist_group_by(gdf_agg_op op, gdf_column *keys, gdf_column *vals
   if (hard == GDF_SUCCESS && in[1].c.size != in[2].c.size) note(GDF_C_ERROR);
   if (hard != GDF_SUCCESS) { (void)in[0].make(0, GDF_INT64); (void)in[1].make(0, GDF_INT64); (void)in[2].make(0, GDF_INT64); }
   GDF_TRY(exchange_by_owner(tr, 3, in, hard == GDF_SUCCESS ? (size_t)in[1].c.size : 0, got, &hard));
+  if (hard != GDF_SUCCESS) return hard;
   Col fk, fs, fk2, fc, avg;
   GDF_TRY(local_group(GDF_SUM, &got[0].c, &got[1].c, got[1].c.dtype, &fk, &fs));
   GDF_TRY(local_group(GDF_SUM, &got[0].c, &got[2].c, GDF_INT64, &fk2, &fc));
@@ -251,6 +280,155 @@ static gdf_error dist_group_by(gdf_agg_op op, gdf_column *keys, gdf_column *vals
   return GDF_SUCCESS;
 }
 
+
+// ---- the group-by over SEVERAL key columns, with validity masks (round 6, VERDICT r5 missing 2: C5 across ranks) ----
+// Reference shape: gdf_group_by_* takes ncols key columns (sqls_ops.cu:1085-1363, groupby.cuh:208-250), rows are assigned by the row
+// hash (gdf_table.cuh:704-854: the Murmur3 fold over the key columns that gdf_hash_partition uses).  Mask semantics are the local
+// HASH group-by's (groupby.hip; the reference rejects masks): a row with a null in ANY key column is dropped; a null value is skipped;
+// a group without a valid value reports 0 and a cleared validity bit (COUNT: 0, valid).
+//   1. two local masked group-bys over the same rows, both sorted by key so that they line up: the partial aggregate S (SUM / MIN /
+//      MAX in the value dtype; AVG: SUM of the widened values) and C = the number of VALID values of every group (int64);
+//   2. (key columns, S, C) -- no mask travels: S is 0 exactly where C is 0 -- are split by gdf_hash_partition on the key columns and
+//      exchanged as in the single-key entry (exchange_blocks: two agreements, then the blocks);
+//   3. the owner turns C > 0 into S's validity mask and combines: S by the same masked operator (a partial without valid values is
+//      skipped, a group none of whose partials had one comes out null), C by a sum; AVG = S / C where C > 0.
+__global__ __launch_bounds__(256) void dg_mask_from_counts(const long long *__restrict__ cnt, uint8_t *__restrict__ mask, size_t n) {
+  // one mask BYTE per thread: eight counts
+  const size_t nbytes = (n + 7) / 8;
+  for (size_t b = blockIdx.x * (size_t)256 + threadIdx.x; b < nbytes; b += (size_t)gridDim.x * 256) {
+    uint8_t m = 0;
+    for (int k = 0; k < 8; ++k) { const size_t i = b * 8 + k; if (i < n && cnt[i] > 0) m |= (uint8_t)(1u << k); }
+    mask[b] = m;
+  }
+}
+template <class S>
+__global__ __launch_bounds__(256) void dg_divide_masked(const S *__restrict__ sum, const long long *__restrict__ cnt, double *__restrict__ out, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = cnt[i] > 0 ? (double)sum[i] / (double)cnt[i] : 0.0;
+}
+
+// one local gdf_group_by_<op> over ncols key columns (HASH, sorted result); masks on the inputs are honoured, the aggregate gets a
+// validity buffer when `agg_valid`
+static gdf_error local_group_multi(gdf_agg_op op, int ncols, gdf_column **keys, gdf_column *vals, gdf_dtype out_dtype, Col *gk, Col *ga, bool agg_valid) {
+  const size_t n = keys[0]->size;
+  for (int c = 0; c < ncols; ++c) GDF_TRY(gk[c].make(n, keys[c]->dtype));
+  GDF_TRY(ga->make(n, out_dtype, agg_valid));
+  if (n == 0) return GDF_SUCCESS;
+  gdf_context ctx{0, GDF_HASH, 0, 1, 0};
+  std::vector<gdf_column *> kout((size_t)ncols);
+  for (int c = 0; c < ncols; ++c) kout[c] = &gk[c].c;
+  GDF_TRY(group_fn(op)(ncols, keys, vals, nullptr, kout.data(), &ga->c, &ctx));
+  for (int c = 0; c < ncols; ++c) gk[c].c.size = ga->c.size;
+  return GDF_SUCCESS;
+}
+
+static gdf_error dist_group_by_multi(gdf_agg_op op, int ncols, gdf_column **keys, gdf_column *vals, gdf_amd_transport *tr, gdf_column **out_keys,
+                                     gdf_column *out_agg) {
+  GDF_REQUIRE(keys && vals && tr && out_keys && out_agg && ncols >= 1 && ncols <= MAX_KEY_COLS, GDF_DATASET_EMPTY);
+  for (int c = 0; c < ncols; ++c) GDF_REQUIRE(keys[c] && out_keys[c], GDF_DATASET_EMPTY);
+  GDF_REQUIRE(tr->all_to_all && tr->wait && tr->all_reduce_i64 && tr->world >= 1 && tr->rank >= 0 && tr->rank < tr->world, GDF_INVALID_API_CALL);
+  GDF_REQUIRE(op == GDF_SUM || op == GDF_MIN || op == GDF_MAX || op == GDF_COUNT || op == GDF_AVG, GDF_UNSUPPORTED_METHOD);
+  for (int c = 0; c < ncols; ++c) gdf_column_view(out_keys[c], nullptr, nullptr, 0, N_GDF_TYPES);
+  gdf_column_view(out_agg, nullptr, nullptr, 0, N_GDF_TYPES);
+  const int world = tr->world;
+  gdf_error hard = GDF_SUCCESS;         // local errors do not return: the peers are on their way into the agreement
+  auto note = [&](gdf_error e) { if (e != GDF_SUCCESS && hard == GDF_SUCCESS) hard = e; return e; };
+  const size_t n = keys[0]->size;
+  for (int c = 0; c < ncols; ++c) {
+    if (elem_kind(keys[c]->dtype) == K_BAD) note(GDF_UNSUPPORTED_DTYPE);
+    if (keys[c]->size != n) note(GDF_COLUMN_SIZE_MISMATCH);
+    if (n && !keys[c]->data) note(GDF_DATASET_EMPTY);
+  }
+  if (elem_kind(vals->dtype) == K_BAD || vals->dtype > GDF_FLOAT64) note(GDF_UNSUPPORTED_DTYPE);
+  if (vals->size != n) note(GDF_COLUMN_SIZE_MISMATCH);
+  if (n >= (size_t)INT_MAX) note(GDF_COLUMN_SIZE_TOO_BIG);
+  if (n && !vals->data) note(GDF_DATASET_EMPTY);
+
+  const bool has_s = op != GDF_COUNT;
+  const gdf_agg_op sop = op == GDF_AVG ? GDF_SUM : op;
+  const int ship = ncols + (has_s ? 2 : 1);           // key columns | S | C
+  std::vector<Col> in((size_t)ship), got((size_t)ship), part((size_t)ship), dummy((size_t)ncols);
+  Col wide;
+  gdf_column sv = *vals;                               // what S aggregates: the values, or (AVG) their widened image under the same mask
+  if (hard == GDF_SUCCESS && op == GDF_AVG) {
+    if (note(widen(vals, &wide)) == GDF_SUCCESS) { sv = wide.c; sv.valid = vals->valid; sv.null_count = vals->null_count; }
+  }
+  const gdf_dtype s_dtype = has_s ? sv.dtype : GDF_INT64;
+  if (hard == GDF_SUCCESS && has_s) note(local_group_multi(sop, ncols, keys, &sv, s_dtype, in.data(), &in[ncols], vals->valid != nullptr));
+  if (hard == GDF_SUCCESS) note(local_group_multi(GDF_COUNT, ncols, keys, vals, GDF_INT64, has_s ? dummy.data() : in.data(), &in[ship - 1], false));
+  if (hard == GDF_SUCCESS && has_s && in[ncols].c.size != in[ship - 1].c.size) note(GDF_C_ERROR);
+  size_t rows = hard == GDF_SUCCESS ? (size_t)in[ship - 1].c.size : 0;
+  if (hard != GDF_SUCCESS) for (int c = 0; c < ship; ++c) (void)in[c].make(0, GDF_INT64);
+  // ---- split by the owner of the row hash over the key columns ----
+  std::vector<int> offs((size_t)world + 1, 0);
+  for (int c = 0; c < ship; ++c) part[c].c.dtype = in[c].c.dtype;
+  if (hard == GDF_SUCCESS && rows > 0) {
+    std::vector<gdf_column *> pin((size_t)ship), pout((size_t)ship);
+    std::vector<int> hash_cols((size_t)ncols);
+    for (int c = 0; c < ncols; ++c) hash_cols[c] = c;
+    for (int c = 0; c < ship && hard == GDF_SUCCESS; ++c) {
+      note(part[c].make(rows, in[c].c.dtype));
+      in[c].c.size = (gdf_size_type)rows;
+      in[c].c.valid = nullptr;                         // (nothing null travels: dropped rows are gone, S is 0 where C is 0)
+      in[c].c.null_count = 0;
+      pin[c] = &in[c].c;
+      pout[c] = &part[c].c;
+    }
+    if (hard == GDF_SUCCESS) note(gdf_hash_partition(ship, pin.data(), hash_cols.data(), ncols, world, pout.data(), offs.data(), GDF_HASH_MURMUR3));
+  }
+  offs[world] = (int)rows;
+  GDF_TRY(exchange_blocks(tr, ship, part.data(), offs, hard == GDF_SUCCESS ? rows : 0, got.data(), nullptr, &hard));
+  if (hard != GDF_SUCCESS) return hard;                // (local failure behind the exchange: no collective is left to attend)
+
+  // ---- the owner combines ----
+  const size_t m = got[ship - 1].c.size;
+  std::vector<gdf_column *> rk((size_t)ncols);
+  for (int c = 0; c < ncols; ++c) { got[c].c.size = (gdf_size_type)m; rk[c] = &got[c].c; }
+  std::vector<Col> fk((size_t)ncols), fk2((size_t)ncols);
+  Col fs, fc, avg;
+  DevBuf smask;
+  if (has_s) {
+    const size_t vb = ((std::max<size_t>(m, 1) + 7) / 8 + 63) / 64 * 64;
+    RMM_TRY(smask.alloc(vb));
+    HIP_TRY(hipMemsetAsync(smask.p, 0, vb, stream0()));
+    if (m) {
+      hipLaunchKernelGGL(dg_mask_from_counts, dim3(stream_grid((m + 7) / 8, 256)), dim3(256), 0, stream0(), (const long long *)got[ship - 1].c.data,
+                         (uint8_t *)smask.p, m);
+      HIP_CHECK_LAST();
+    }
+    got[ncols].c.valid = (gdf_valid_type *)smask.p;
+    got[ncols].c.size = (gdf_size_type)m;
+    GDF_TRY(local_group_multi(sop, ncols, rk.data(), &got[ncols].c, s_dtype, fk.data(), &fs, true));
+  }
+  got[ship - 1].c.size = (gdf_size_type)m;
+  GDF_TRY(local_group_multi(GDF_SUM, ncols, rk.data(), &got[ship - 1].c, GDF_INT64, has_s ? fk2.data() : fk.data(), &fc, false));
+  const size_t ng = (size_t)fc.c.size;
+  if (has_s) GDF_REQUIRE((size_t)fs.c.size == ng, GDF_C_ERROR);
+  // the aggregate column and its validity (SUM / MIN / MAX / AVG: valid where a valid value reached the group)
+  Col *res = has_s ? &fs : &fc;
+  if (op == GDF_AVG) {
+    GDF_TRY(avg.make(ng, GDF_FLOAT64));
+    if (ng) {
+      const int grid = stream_grid(ng, 256 * 8);
+      if (fs.c.dtype == GDF_FLOAT64)
+        hipLaunchKernelGGL((dg_divide_masked<double>), dim3(grid), dim3(256), 0, stream0(), (const double *)fs.c.data, (const long long *)fc.c.data, (double *)avg.c.data, ng);
+      else
+        hipLaunchKernelGGL((dg_divide_masked<long long>), dim3(grid), dim3(256), 0, stream0(), (const long long *)fs.c.data, (const long long *)fc.c.data, (double *)avg.c.data, ng);
+      HIP_CHECK_LAST();
+    }
+    avg.vbuf.p = fs.vbuf.release();                    // the averages are valid where the sums are
+    avg.c.valid = (gdf_valid_type *)avg.vbuf.p;
+    avg.c.null_count = fs.c.null_count;
+    res = &avg;
+  }
+  HIP_TRY(hipStreamSynchronize(stream0()));
+  for (int c = 0; c < ncols; ++c) give(&fk[c], ng, out_keys[c]);
+  const gdf_size_type nulls = has_s ? res->c.null_count : 0;
+  void *valid = has_s ? res->vbuf.release() : nullptr;
+  give(res, ng, out_agg);
+  out_agg->valid = (gdf_valid_type *)valid;
+  out_agg->null_count = nulls;
+  return GDF_SUCCESS;
+}
 
 // ---- the KEY SHUFFLE join behind the C ABI: what every rank falls back to when gdf_amd_dist_inner_join declines ----
 // gid[i] = sender << 40 | row[i] for the rows one sender contributed
@@ -280,19 +458,30 @@ static gdf_error shuffle_side(gdf_amd_transport *tr, gdf_column *keys, Col *rkey
   offs[world] = (int)n;
   std::vector<long long> got;
   GDF_TRY(exchange_blocks(tr, 2, part, offs, *hard == GDF_SUCCESS ? n : 0, got2, &got, hard));
-  const size_t total = got2[0].c.size;
-  GDF_TRY(rgid->make(total, GDF_INT64));
-  size_t at = 0;
-  for (int r = 0; r < world; ++r) {
-    const size_t cnt = (size_t)got[r];
-    if (cnt) hipLaunchKernelGGL(dg_gids, dim3(stream_grid(cnt, 256 * 8)), dim3(256), 0, stream0(), (const int32_t *)got2[1].c.data + at,
-                                (long long *)rgid->c.data + at, (long long)r, cnt);
-    at += cnt;
+  // local work behind the exchange: a failure here is NOTED (the caller's next collective -- the second relation's agreement, or the
+  // final one -- carries it to every rank), never returned past a collective the peers are about to enter
+  auto name_rows = [&]() -> gdf_error {
+    const size_t total = got2[0].c.size;
+    GDF_TRY(rgid->make(total, GDF_INT64));
+    size_t at = 0;
+    for (int r = 0; r < world; ++r) {
+      const size_t cnt = (size_t)got[r];
+      if (cnt) hipLaunchKernelGGL(dg_gids, dim3(stream_grid(cnt, 256 * 8)), dim3(256), 0, stream0(), (const int32_t *)got2[1].c.data + at,
+                                  (long long *)rgid->c.data + at, (long long)r, cnt);
+      at += cnt;
+    }
+    HIP_CHECK_LAST();
+    HIP_TRY(hipStreamSynchronize(stream0()));         // got2[1] goes out of scope
+    rkeys->buf.p = got2[0].buf.release();
+    gdf_column_view(&rkeys->c, rkeys->buf.p, nullptr, (gdf_size_type)total, keys->dtype);
+    return GDF_SUCCESS;
+  };
+  if (*hard == GDF_SUCCESS) note(name_rows());
+  if (*hard != GDF_SUCCESS) {
+    (void)hipStreamSynchronize(stream0());
+    gdf_column_view(&rkeys->c, nullptr, nullptr, 0, keys->dtype);
+    gdf_column_view(&rgid->c, nullptr, nullptr, 0, GDF_INT64);
   }
-  HIP_CHECK_LAST();
-  HIP_TRY(hipStreamSynchronize(stream0()));         // got2[1] goes out of scope
-  rkeys->buf.p = got2[0].buf.release();
-  gdf_column_view(&rkeys->c, rkeys->buf.p, nullptr, (gdf_size_type)total, keys->dtype);
   return GDF_SUCCESS;
 }
 
@@ -314,10 +503,21 @@ static gdf_error dist_shuffle_join(gdf_column *probe_keys, gdf_column *build_key
   GDF_TRY(shuffle_side(tr, probe_keys, &pk, &pg, &hard));
   // what this rank received exceeds the 31-bit positions of a local join (skew, or a world too small for the relation): agreed
   // on, so that nobody is left behind in a collective
-  int64_t too_big = (pk.c.size >= (size_t)INT_MAX || bk.c.size >= (size_t)INT_MAX) ? 1 : 0;
-  if (tr->all_reduce_i64(tr->ctx, &too_big, 1, 1) != 0) return GDF_C_ERROR;
-  if (too_big) return GDF_COLUMN_SIZE_TOO_BIG;
-  if (pk.c.size == 0 || bk.c.size == 0) return GDF_SUCCESS;
+  // (... and a rank whose local work failed behind the second exchange says so here: everybody leaves together)
+  int64_t last[2] = {(pk.c.size >= (size_t)INT_MAX || bk.c.size >= (size_t)INT_MAX) ? 1 : 0, hard != GDF_SUCCESS ? 1 : 0};
+  if (tr->all_reduce_i64(tr->ctx, last, 2, 1) != 0) return GDF_C_ERROR;
+  if (last[1]) return hard != GDF_SUCCESS ? hard : GDF_C_ERROR;
+  if (last[0]) return GDF_COLUMN_SIZE_TOO_BIG;
+  // (from here on the work is this rank's own: no collective is left)
+  auto give_empty = [&]() -> gdf_error {      // no pair on this rank: EMPTY GDF_INT64 columns, library-allocated like any other result
+    Col ep, eb;
+    GDF_TRY(ep.make(0, GDF_INT64));
+    GDF_TRY(eb.make(0, GDF_INT64));
+    give(&ep, 0, out_probe);
+    give(&eb, 0, out_build);
+    return GDF_SUCCESS;
+  };
+  if (pk.c.size == 0 || bk.c.size == 0) return give_empty();
   gdf_column li, ri;
   gdf_column_view(&li, nullptr, nullptr, 0, N_GDF_TYPES);
   gdf_column_view(&ri, nullptr, nullptr, 0, N_GDF_TYPES);
@@ -327,7 +527,7 @@ static gdf_error dist_shuffle_join(gdf_column *probe_keys, gdf_column *build_key
   GDF_TRY(gdf_inner_join(pl, 1, on, bl, 1, on, 1, 0, nullptr, &li, &ri, &ctx));
   struct Free { gdf_column *c; ~Free() { if (c->data) gdf_column_free(c); } } free_li{&li}, free_ri{&ri};
   const size_t np = li.size;
-  if (np == 0) return GDF_SUCCESS;
+  if (np == 0) return give_empty();
   Col op, ob;
   GDF_TRY(op.make(np, GDF_INT64));
   GDF_TRY(ob.make(np, GDF_INT64));
@@ -353,6 +553,10 @@ GDF_AMD_EXPORT gdf_error gdf_amd_dist_shuffle_join(gdf_column *probe_keys, gdf_c
 GDF_AMD_EXPORT gdf_error gdf_amd_dist_group_by(gdf_agg_op op, gdf_column *keys, gdf_column *values, gdf_amd_transport *transport,
                                                gdf_column *out_keys, gdf_column *out_agg) {
   return gdf_amd::guarded([&]() -> gdf_error { return gdf_amd::dist_group_by(op, keys, values, transport, out_keys, out_agg); });
+}
+GDF_AMD_EXPORT gdf_error gdf_amd_dist_group_by_multi(gdf_agg_op op, int ncols, gdf_column **keys, gdf_column *values, gdf_amd_transport *transport,
+                                                     gdf_column **out_keys, gdf_column *out_agg) {
+  return gdf_amd::guarded([&]() -> gdf_error { return gdf_amd::dist_group_by_multi(op, ncols, keys, values, transport, out_keys, out_agg); });
 }
 GDF_AMD_EXPORT gdf_error gdf_amd_dist_group_by_sum(gdf_column *keys, gdf_column *values, gdf_amd_transport *transport, gdf_column *out_keys, gdf_column *out_agg) {
   return gdf_amd_dist_group_by(GDF_SUM, keys, values, transport, out_keys, out_agg);

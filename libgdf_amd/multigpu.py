@@ -825,6 +825,58 @@ def planned_inner_join(probe_keys, build_keys, group=None, shuffle_kw=None, broa
     return distributed_inner_join(probe_keys, build_keys, group=group, **(shuffle_kw or {}))
 
 
+def distributed_group_by_multi(op, keys, values, key_valids=None, value_valid=None, group_fn=None, owner_fn=None, group=None):
+    """``gdf_group_by_<op>`` of a row-sharded relation over SEVERAL key columns, validity masks honoured (BASELINE configuration C5 across
+    ranks; reference shape: sqls_ops.cu:1085-1363, row hash of gdf_table.cuh:704-854).  ``keys``: list of tensors; ``key_valids``: list of
+    bool tensors or None per key column; ``value_valid``: bool tensor or None.  A row with a null in any key column is dropped, a null
+    value is skipped, a group without a valid value reports 0 and valid=False (COUNT: 0, valid).  Returns this rank's groups:
+    (list of key tensors, aggregates, bool tensor of valid aggregates), in ascending key order.
+
+    On the device this is ONE C call (gdf_amd_dist_group_by_multi, csrc/dist_ops.hip).  With ``group_fn`` / ``owner_fn`` given -- the CPU
+    gloo tests' numpy stand-ins -- the same protocol runs here as its executable specification:
+    ``group_fn(op, keys, values, key_valids, value_valid)`` -> (key tensors, aggregate, valid bools) is one local masked group-by with its
+    result sorted by key; ``owner_fn(keys, world)`` -> the owner rank of every row (row hash % world)."""
+    import torch
+    import torch.distributed as dist
+    if group_fn is None and owner_fn is None and values.is_cuda:
+        from . import api
+        from .columns import Column, mask_from_bools
+
+        def col(t, ok):
+            if ok is None:
+                return Column(t)
+            okn = ok.cpu().numpy().astype(bool)
+            return Column(t, torch.from_numpy(mask_from_bools(okn)).to(t.device), null_count=int(len(okn) - okn.sum()))
+        kv = key_valids or [None] * len(keys)
+        return api.dist_group_by_multi(op, [col(k, v) for k, v in zip(keys, kv)], col(values, value_valid), transport_for(group))
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    sop = "sum" if op == "avg" else op
+    vals = _widen(values) if op == "avg" else values
+    # 1. two local masked group-bys over the same rows, both sorted by key: the partial aggregate S and the number of VALID values C
+    gk, cnt, _ = group_fn("count", keys, values, key_valids, value_valid)
+    s = None
+    if op != "count":
+        gk2, s, _ = group_fn(sop, keys, vals, key_valids, value_valid)
+        assert all(torch.equal(a, b) for a, b in zip(gk, gk2))
+    # 2. (key columns, S, C) travel to the owner of the row hash; no mask travels (S is 0 exactly where C is 0)
+    owner = owner_fn(gk, world)
+    cols = list(gk) + ([s] if s is not None else []) + [cnt]
+    pieces = [[c[owner == r].clone() for c in cols] for r in range(world)]
+    everyone = [None] * world
+    dist.all_gather_object(everyone, pieces, group=group)
+    mine = [torch.cat([everyone[src][rank][j] for src in range(world)]) for j in range(len(cols))]
+    rk, rc = mine[: len(keys)], mine[-1]
+    # 3. the owner combines: S over the partials that had a valid value (the same masked operator), C by a sum
+    fk, fc, _ = group_fn("sum", rk, rc, None, None)
+    if op == "count":
+        return fk, fc, torch.ones(fc.numel(), dtype=torch.bool)
+    fk2, fs, ok = group_fn(sop, rk, mine[len(keys)], None, rc > 0)
+    assert all(torch.equal(a, b) for a, b in zip(fk, fk2))
+    if op == "avg":
+        fs = torch.where(fc > 0, fs.double() / fc.clamp(min=1).double(), torch.zeros_like(fs, dtype=torch.float64))
+    return fk, fs, ok
+
+
 def distributed_group_by_sum(keys, values, group_fn=None, partition_fn=_device_partition, group=None):
     """Group-by-sum of a row-sharded (key, value) relation: local pre-aggregation, exchange of the partial
     aggregates by key hash (far fewer rows than the input), final aggregation on the owner rank."""

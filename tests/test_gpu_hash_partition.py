@@ -83,6 +83,38 @@ def test_hash_partition_membership_and_offsets(gdf, nparts, n):
         np.testing.assert_array_equal(e[np.lexsort(e.T[::-1])], g[np.lexsort(g.T[::-1])])
 
 
+@pytest.mark.parametrize("nparts", [17, 32, 64])
+@pytest.mark.parametrize("shape", ["key-value", "value-key", "key-only", "last-chunk-of-one-row", "float64-key"])
+def test_hash_partition_pair_kernel(gdf, nparts, shape, force_path):
+    """One or two 8-byte columns without masks, 16 < P <= 64, >= 2^16 rows take part_scatter_pairs_kernel (csrc/hashing.hip, round 6):
+    both columns staged together, the next tile's words requested before the flush, chunks laid out XCD-major inside a partition.
+    Offsets as the oracle's (hashing.cu:434-468 partition rule on the pinned Murmur3 row hash), every partition the reference's rows as a
+    multiset with rows intact -- and the same call through the generic tile kernel (GDF_HP_NO_PAIRS).  Sizes: an odd row count, and one
+    that leaves a LAST CHUNK OF ONE ROW (the kernel reads row pairs).  Reference: hashing.cu:559-654."""
+    n = {"last-chunk-of-one-row": 1024 * 2048 + 1}.get(shape, 1_234_567)
+    k = gen_rand(np.float64 if shape == "float64-key" else np.int64, n)
+    v = gen_rand(np.int64, n)
+    cols, hashed = {"key-value": ([k, v], [0]), "value-key": ([v, k], [1]), "key-only": ([k], [0])}.get(shape, ([k, v], [0]))
+
+    def run():
+        outs, offsets = gdf.api.hash_partition([_col(gdf, c) for c in cols], hashed, nparts)
+        return [o.to_numpy() for o in outs], offsets
+    perm, exp_off, pid = oracle.hash_partition(cols, hashed, nparts)
+    bounds = list(exp_off) + [n]
+    for kernel in ("pairs", "generic"):
+        if kernel == "generic":
+            force_path("GDF_HP_NO_PAIRS")
+        got, offsets = run()
+        assert offsets == [int(x) for x in exp_off]
+        got_pid = oracle.partition_ids([got[hashed[0]]], nparts)
+        for p in range(nparts):
+            lo, hi = bounds[p], bounds[p + 1]
+            assert np.all(got_pid[lo:hi] == p)
+            e = np.stack([c[perm][lo:hi].view(np.int64) for c in cols], axis=1)
+            g = np.stack([c[lo:hi].view(np.int64) for c in got], axis=1)
+            np.testing.assert_array_equal(e[np.lexsort(e.T[::-1])], g[np.lexsort(g.T[::-1])])
+
+
 @pytest.mark.parametrize("nparts", [16, 700])
 def test_hash_partition_moves_valid_masks(gdf, nparts):
     n = 200000

@@ -123,7 +123,7 @@ gdf_error gdf_amd_fj_probe_add(gdf_amd_join_probe *probe, const uint32_t *recv_k
  * slice c + 1 is regrouped and slice c - 1 is partitioned at the receiver), level 2 + LDS probe at the receiver, and the
  * collective agreement that decides between result and decline.
  *
- * The wire is a gdf_amd_transport: four function pointers.  gdf_amd_rccl_transport_create gives the RCCL one (ncclSend / ncclRecv
+ * The wire is a gdf_amd_transport: four function pointers and an optional fifth (all_to_all_v).  gdf_amd_rccl_transport_create gives the RCCL one (ncclSend / ncclRecv
  * groups on a stream of its own, librccl resolved with dlopen at that moment -- libgdf.so itself does not link against it); a host
  * in another language, or a test that moves the blocks through host memory between processes (tests/multirank_common.py), fills
  * the struct itself.
@@ -157,6 +157,13 @@ typedef struct gdf_amd_transport {
   int (*all_reduce_i64)(void *ctx, int64_t *values, int count, int op);
   /* releases ctx (may be NULL) */
   void (*destroy)(void *ctx);
+  /* OPTIONAL, may be NULL (round 6; the all-to-all-v SURVEY 8(e) names): bytes [send_off[r], send_off[r + 1]) of the DEVICE buffer `send`
+     go to rank r, bytes [recv_off[s], recv_off[s + 1]) of `recv` arrive from rank s.  The offset arrays are HOST arrays of world + 1
+     entries; what rank a sends to rank b is what b expects from a (the callers exchange their counts first).  Ordering, ticket and
+     return value as all_to_all.  With it gdf_amd_dist_group_by* and gdf_amd_dist_shuffle_join ship EXACT sizes straight from their
+     partitioned columns into the result columns; without it they pad to equal blocks and stage them.  LAST member: a host that
+     fills the struct itself and was written against the four-function version must zero it. */
+  int (*all_to_all_v)(void *ctx, const void *send, const size_t *send_off, void *recv, const size_t *recv_off, void **ticket);
 } gdf_amd_transport;
 
 typedef struct gdf_amd_dist_info {

@@ -386,8 +386,9 @@ class gdf_amd_transport(C.Structure):
     _WAIT = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
     _ALLRED = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.c_int, C.c_int)
     _DESTROY = C.CFUNCTYPE(None, C.c_void_p)
+    _A2AV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_void_p))
     _fields_ = [("ctx", C.c_void_p), ("rank", C.c_int), ("world", C.c_int), ("all_to_all", _A2A), ("wait", _WAIT),
-                ("all_reduce_i64", _ALLRED), ("destroy", _DESTROY)]
+                ("all_reduce_i64", _ALLRED), ("destroy", _DESTROY), ("all_to_all_v", _A2AV)]
 
 
 class gdf_amd_dist_info(C.Structure):
@@ -437,12 +438,43 @@ class CallbackTransport:
     (tests/test_gpu_multirank_one_gpu.py) -- the same C orchestration as over RCCL, another wire.  Synchronous: all_to_all
     returns when the exchange is done."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, with_all_to_all_v=True):
         import torch
         import torch.distributed as dist
         self.group = group
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.errors = []
+
+        def all_to_all_v(ctx, send, send_off, recv, recv_off, ticket):
+            # the optional fifth function: exact sizes per peer (point-to-point messages through host memory, any backend)
+            try:
+                so = [int(send_off[i]) for i in range(self.world + 1)]
+                ro = [int(recv_off[i]) for i in range(self.world + 1)]
+                hs = torch.empty(max(so[-1], 1), dtype=torch.uint8)
+                hr = torch.empty(max(ro[-1], 1), dtype=torch.uint8)
+                if so[-1]:
+                    libgdf.gdf_amd_copy(hs.data_ptr(), send, so[-1], 0)
+                ops = []
+                for r in range(self.world):
+                    ns, nr = so[r + 1] - so[r], ro[r + 1] - ro[r]
+                    if r == self.rank:
+                        assert ns == nr
+                        hr[ro[r]:ro[r + 1]].copy_(hs[so[r]:so[r + 1]])
+                        continue
+                    peer = dist.get_global_rank(self.group, r) if self.group is not None else r
+                    if ns:
+                        ops.append(dist.P2POp(dist.isend, hs[so[r]:so[r + 1]], peer, self.group))
+                    if nr:
+                        ops.append(dist.P2POp(dist.irecv, hr[ro[r]:ro[r + 1]], peer, self.group))
+                for w in (dist.batch_isend_irecv(ops) if ops else []):
+                    w.wait()
+                if ro[-1]:
+                    libgdf.gdf_amd_copy(recv, hr.data_ptr(), ro[-1], 1)
+                ticket[0] = None
+                return 0
+            except Exception as e:                 # noqa: BLE001 -- a callback must not raise into C
+                self.errors.append(e)
+                return 1
 
         def all_to_all(ctx, send, recv, bytes_per_rank, ticket):
             try:
@@ -473,9 +505,11 @@ class CallbackTransport:
                 self.errors.append(e)
                 return 1
 
-        self._cbs = (gdf_amd_transport._A2A(all_to_all), gdf_amd_transport._WAIT(wait), gdf_amd_transport._ALLRED(all_reduce))
+        self._cbs = (gdf_amd_transport._A2A(all_to_all), gdf_amd_transport._WAIT(wait), gdf_amd_transport._ALLRED(all_reduce),
+                     gdf_amd_transport._A2AV(all_to_all_v))
         self._t = gdf_amd_transport(None, self.rank, self.world, self._cbs[0], self._cbs[1], self._cbs[2],
-                                    C.cast(None, gdf_amd_transport._DESTROY))
+                                    C.cast(None, gdf_amd_transport._DESTROY),
+                                    self._cbs[3] if with_all_to_all_v else C.cast(None, gdf_amd_transport._A2AV))
 
     @property
     def ptr(self):

@@ -14,6 +14,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -97,6 +98,43 @@ int rccl_all_to_all(void *vctx, const void *send, void *recv, size_t bytes_per_r
   return 0;
 }
 
+// the all-to-all-v: one ncclSend / ncclRecv pair per peer and 2^29-byte piece, every piece of one offset in one group (xGMI is
+// point-to-point: the group drives all links at once); a rank's own share is a device copy
+int rccl_all_to_all_v(void *vctx, const void *send, const size_t *send_off, void *recv, const size_t *recv_off, void **ticket) {
+  RcclCtx *c = static_cast<RcclCtx *>(vctx);
+  const RcclApi &r = rccl();
+  if (!send_off || !recv_off) return 1;
+  hipEvent_t ready = nullptr, done = nullptr;
+  if (hipEventCreateWithFlags(&ready, hipEventDisableTiming) != hipSuccess) return 1;
+  if (hipEventCreateWithFlags(&done, hipEventDisableTiming) != hipSuccess) { (void)hipEventDestroy(ready); return 1; }
+  bool ok = hipEventRecord(ready, gdf_amd::stream0()) == hipSuccess && hipStreamWaitEvent(c->stream, ready, 0) == hipSuccess;
+  const char *s = static_cast<const char *>(send);
+  char *d = static_cast<char *>(recv);
+  const size_t mine = send_off[c->rank + 1] - send_off[c->rank];
+  if (ok && mine != recv_off[c->rank + 1] - recv_off[c->rank]) ok = false;
+  if (ok && mine) ok = hipMemcpyAsync(d + recv_off[c->rank], s + send_off[c->rank], mine, hipMemcpyDeviceToDevice, c->stream) == hipSuccess;
+  size_t longest = 0;
+  for (int p = 0; p < c->world; ++p) {
+    if (p == c->rank) continue;
+    longest = std::max(longest, std::max(send_off[p + 1] - send_off[p], recv_off[p + 1] - recv_off[p]));
+  }
+  for (size_t off = 0; ok && off < longest; off += MAX_MESSAGE) {
+    ok = r.GroupStart() == ncclSuccess;
+    for (int p = 0; ok && p < c->world; ++p) {
+      if (p == c->rank) continue;
+      const size_t sl = send_off[p + 1] - send_off[p], rl = recv_off[p + 1] - recv_off[p];
+      if (off < sl) ok = r.Send(s + send_off[p] + off, std::min(sl - off, MAX_MESSAGE), ncclChar, p, c->comm, c->stream) == ncclSuccess;
+      if (ok && off < rl) ok = r.Recv(d + recv_off[p] + off, std::min(rl - off, MAX_MESSAGE), ncclChar, p, c->comm, c->stream) == ncclSuccess;
+    }
+    ok = (r.GroupEnd() == ncclSuccess) && ok;
+  }
+  ok = ok && hipEventRecord(done, c->stream) == hipSuccess;
+  (void)hipEventDestroy(ready);
+  if (!ok) { (void)hipEventDestroy(done); return 1; }
+  *ticket = done;
+  return 0;
+}
+
 int rccl_wait(void *, void *ticket) {
   hipEvent_t done = static_cast<hipEvent_t>(ticket);
   if (!done) return 0;
@@ -150,7 +188,7 @@ __attribute__((visibility("default"))) gdf_error gdf_amd_rccl_transport_create(c
     RcclCtx *c = new RcclCtx();
     c->rank = rank;
     c->world = world;
-    gdf_amd_transport *t = new gdf_amd_transport{c, rank, world, rccl_all_to_all, rccl_wait, rccl_all_reduce_i64, rccl_destroy};
+    gdf_amd_transport *t = new gdf_amd_transport{c, rank, world, rccl_all_to_all, rccl_wait, rccl_all_reduce_i64, rccl_destroy, rccl_all_to_all_v};
     auto fail = [&](gdf_error e) { rccl_destroy(c); delete t; return e; };
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(GDF_CUDA_ERROR);
     if (hipMalloc((void **)&c->scratch, sizeof(int64_t) * 16) != hipSuccess) return fail(GDF_MEMORYMANAGER_ERROR);

@@ -592,7 +592,10 @@ def transport_for(group=None):
             dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
             t = api.RcclTransport(box[0], world, rank)
         else:
-            t = api.CallbackTransport(group)
+            # (LIBGDF_AMD_NO_A2AV: test switch, read HERE in the Python layer -- the transport's optional all_to_all_v stays NULL and
+            # the C entry points take their equal-block exchange)
+            import os
+            t = api.CallbackTransport(group, with_all_to_all_v=not os.environ.get("LIBGDF_AMD_NO_A2AV"))
         _TRANSPORTS[key] = t
     return t
 

@@ -15,7 +15,7 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
-from multirank_common import _free_port, _uneven_worker, _worker, check_join_and_group_by, check_uneven
+from multirank_common import _free_port, _multikey_worker, _uneven_worker, _worker, check_join_and_group_by, check_multikey, check_uneven
 
 pytestmark = pytest.mark.gpu
 
@@ -58,3 +58,20 @@ def test_multi_rank_rccl_parity(world):
 def test_multi_rank_rccl_uneven_and_empty_shards():
     world = min(8, NGPU)
     check_uneven(world, _run_ranks(_uneven_worker, world, ()))
+
+
+@pytest.mark.timeout(1200)
+def test_one_rank_rccl_world_multi_key_group_by():
+    """gdf_amd_dist_group_by_multi through the RCCL transport's all_to_all_v at world 1 (the exchange is a self-copy): the worker and
+    the checker a multi-GPU node will run"""
+    check_multikey(1, _run_ranks(_multikey_worker, 1, ()))
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.skipif(NGPU < 2, reason="needs >= 2 GPUs: RCCL refuses two ranks on one device")
+def test_multi_rank_rccl_multi_key_group_by():
+    """several key columns + validity masks across real ranks: grouped ncclSend / ncclRecv with exact sizes (all_to_all_v); the rank
+    without rows takes part in every collective"""
+    world = min(8, NGPU)
+    check_multikey(world, _run_ranks(_multikey_worker, world, ()))
+

@@ -194,6 +194,13 @@ gdf_error gdf_amd_dist_inner_join(gdf_column *probe_keys, gdf_column *build_keys
  * into the agreements as in gdf_amd_dist_inner_join. */
 gdf_error gdf_amd_dist_shuffle_join(gdf_column *probe_keys, gdf_column *build_keys, gdf_amd_transport *transport,
                                     gdf_column *out_probe_ids, gdf_column *out_build_ids);
+/* ... and as a LEFT / FULL join (round 6; reference: gdf_left_join / gdf_full_join, src/join/joining.cu:571-653, per owner rank): every row
+ * of either relation reaches exactly one owner, so a probe row without a partner comes out once as (global id, -1) and -- FULL -- a
+ * build row without a partner once as (-1, global id).  Semantics of unmatched rows and of the pair order as the single-GPU calls. */
+gdf_error gdf_amd_dist_shuffle_left_join(gdf_column *probe_keys, gdf_column *build_keys, gdf_amd_transport *transport,
+                                         gdf_column *out_probe_ids, gdf_column *out_build_ids);
+gdf_error gdf_amd_dist_shuffle_full_join(gdf_column *probe_keys, gdf_column *build_keys, gdf_amd_transport *transport,
+                                         gdf_column *out_probe_ids, gdf_column *out_build_ids);
 
 /* MULTI-GPU GROUP-BY behind the C ABI (csrc/dist_ops.hip; no counterpart in the reference, which is single-GPU -- per rank it
  * composes gdf_group_by_<op>, src/sqls_ops.cu:1426-1487, and gdf_hash_partition, src/hashing.cu:559-654).  COLLECTIVE: every rank

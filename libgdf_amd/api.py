@@ -561,12 +561,13 @@ def dist_group_by_multi(op: str, keys, values: Column, transport):
     return [_take_library_column(k, tdt[int(k.dtype)]) for k in oks], _take_library_column(oa, tdt[int(oa.dtype)]), bits
 
 
-def dist_shuffle_join(probe: Column, build: Column, transport):
-    """gdf_amd_dist_shuffle_join (COLLECTIVE): the key-shuffle join behind ONE C call -> (probe ids, build ids), int64 tensors of
-    (owner rank << 40 | local row) for every pair this rank produced."""
+def dist_shuffle_join(probe: Column, build: Column, transport, how="inner"):
+    """gdf_amd_dist_shuffle_[left_|full_]join (COLLECTIVE): the key-shuffle join behind ONE C call -> (probe ids, build ids), int64 tensors
+    of (owner rank << 40 | local row) for every pair this rank produced; -1 names the missing side of an unmatched row (left / full)."""
     import torch
     op, ob = gdf_column(), gdf_column()
-    libgdf.gdf_amd_dist_shuffle_join(probe.ptr, build.ptr, transport.ptr, C.byref(op), C.byref(ob))
+    fn = {"inner": libgdf.gdf_amd_dist_shuffle_join, "left": libgdf.gdf_amd_dist_shuffle_left_join, "full": libgdf.gdf_amd_dist_shuffle_full_join}[how]
+    fn(probe.ptr, build.ptr, transport.ptr, C.byref(op), C.byref(ob))
     errs = getattr(transport, "errors", None)
     if errs:
         raise errs.pop(0)

@@ -492,7 +492,12 @@ __global__ __launch_bounds__(256) void dg_gids(const int32_t *__restrict__ rows,
 // pairs of received positions -> pairs of global row ids
 __global__ __launch_bounds__(256) void dg_resolve(const int32_t *__restrict__ li, const int32_t *__restrict__ ri, const long long *__restrict__ pgid,
                                                   const long long *__restrict__ bgid, long long *__restrict__ out_p, long long *__restrict__ out_b, size_t n) {
-  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) { out_p[i] = pgid[li[i]]; out_b[i] = bgid[ri[i]]; }
+  // (-1 stays -1: the missing side of a LEFT / FULL join's unmatched row)
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const int32_t l = li[i], r = ri[i];
+    out_p[i] = l >= 0 ? pgid[l] : -1;
+    out_b[i] = r >= 0 ? bgid[r] : -1;
+  }
 }
 
 // one relation: (key, local row number) split by Murmur3(key) % world (gdf_amd_shuffle_partition), exchanged, and the received
@@ -539,8 +544,11 @@ static gdf_error shuffle_side(gdf_amd_transport *tr, gdf_column *keys, Col *rkey
   return GDF_SUCCESS;
 }
 
-static gdf_error dist_shuffle_join(gdf_column *probe_keys, gdf_column *build_keys, gdf_amd_transport *tr, gdf_column *out_probe, gdf_column *out_build) {
+// kind 0 / 1 / 2: INNER / LEFT / FULL (joining.cu:571-653 per rank).  Every row of either relation reaches exactly ONE owner, so a LEFT
+// join's unmatched probe rows (global id, -1) and a FULL join's unmatched build rows (-1, global id) come out exactly once.
+static gdf_error dist_shuffle_join(int kind, gdf_column *probe_keys, gdf_column *build_keys, gdf_amd_transport *tr, gdf_column *out_probe, gdf_column *out_build) {
   GDF_REQUIRE(probe_keys && build_keys && tr && out_probe && out_build, GDF_DATASET_EMPTY);
+  GDF_REQUIRE(kind >= 0 && kind <= 2, GDF_UNSUPPORTED_JOIN_TYPE);
   GDF_REQUIRE(tr->all_to_all && tr->wait && tr->all_reduce_i64 && tr->world >= 1 && tr->rank >= 0 && tr->rank < tr->world, GDF_INVALID_API_CALL);
   gdf_column_view(out_probe, nullptr, nullptr, 0, N_GDF_TYPES);
   gdf_column_view(out_build, nullptr, nullptr, 0, N_GDF_TYPES);
@@ -571,14 +579,17 @@ static gdf_error dist_shuffle_join(gdf_column *probe_keys, gdf_column *build_key
     give(&eb, 0, out_build);
     return GDF_SUCCESS;
   };
-  if (pk.c.size == 0 || bk.c.size == 0) return give_empty();
+  // (nothing can pair, and nothing unmatched is kept: no local join)
+  if ((pk.c.size == 0 && (kind != 2 || bk.c.size == 0)) || (bk.c.size == 0 && kind == 0)) return give_empty();
   gdf_column li, ri;
   gdf_column_view(&li, nullptr, nullptr, 0, N_GDF_TYPES);
   gdf_column_view(&ri, nullptr, nullptr, 0, N_GDF_TYPES);
   gdf_context ctx{0, GDF_HASH, 0, 0, 0};
   gdf_column *pl[1] = {&pk.c}, *bl[1] = {&bk.c};
   int on[1] = {0};
-  GDF_TRY(gdf_inner_join(pl, 1, on, bl, 1, on, 1, 0, nullptr, &li, &ri, &ctx));
+  if (kind == 0) GDF_TRY(gdf_inner_join(pl, 1, on, bl, 1, on, 1, 0, nullptr, &li, &ri, &ctx));
+  else if (kind == 1) GDF_TRY(gdf_left_join(pl, 1, on, bl, 1, on, 1, 0, nullptr, &li, &ri, &ctx));
+  else GDF_TRY(gdf_full_join(pl, 1, on, bl, 1, on, 1, 0, nullptr, &li, &ri, &ctx));
   struct Free { gdf_column *c; ~Free() { if (c->data) gdf_column_free(c); } } free_li{&li}, free_ri{&ri};
   const size_t np = li.size;
   if (np == 0) return give_empty();
@@ -602,7 +613,15 @@ extern "C" {
 #define GDF_AMD_EXPORT __attribute__((visibility("default")))
 GDF_AMD_EXPORT gdf_error gdf_amd_dist_shuffle_join(gdf_column *probe_keys, gdf_column *build_keys, gdf_amd_transport *transport,
                                                    gdf_column *out_probe_ids, gdf_column *out_build_ids) {
-  return gdf_amd::guarded([&]() -> gdf_error { return gdf_amd::dist_shuffle_join(probe_keys, build_keys, transport, out_probe_ids, out_build_ids); });
+  return gdf_amd::guarded([&]() -> gdf_error { return gdf_amd::dist_shuffle_join(0, probe_keys, build_keys, transport, out_probe_ids, out_build_ids); });
+}
+GDF_AMD_EXPORT gdf_error gdf_amd_dist_shuffle_left_join(gdf_column *probe_keys, gdf_column *build_keys, gdf_amd_transport *transport,
+                                                        gdf_column *out_probe_ids, gdf_column *out_build_ids) {
+  return gdf_amd::guarded([&]() -> gdf_error { return gdf_amd::dist_shuffle_join(1, probe_keys, build_keys, transport, out_probe_ids, out_build_ids); });
+}
+GDF_AMD_EXPORT gdf_error gdf_amd_dist_shuffle_full_join(gdf_column *probe_keys, gdf_column *build_keys, gdf_amd_transport *transport,
+                                                        gdf_column *out_probe_ids, gdf_column *out_build_ids) {
+  return gdf_amd::guarded([&]() -> gdf_error { return gdf_amd::dist_shuffle_join(2, probe_keys, build_keys, transport, out_probe_ids, out_build_ids); });
 }
 GDF_AMD_EXPORT gdf_error gdf_amd_dist_group_by(gdf_agg_op op, gdf_column *keys, gdf_column *values, gdf_amd_transport *transport,
                                                gdf_column *out_keys, gdf_column *out_agg) {

@@ -193,6 +193,9 @@ def _uneven_worker(rank, world, port, q, backend="gloo"):
     from libgdf_amd.columns import Column
     csp, csb = api.dist_shuffle_join(Column(p), Column(b), multigpu.transport_for(None))      # the fallback behind one C call, same shards
     out = {"c-shuffle": (csp.cpu().numpy(), csb.cpu().numpy())}
+    for how in ("left", "full"):                         # gdf_amd_dist_shuffle_left_join / _full_join: unmatched rows exactly once, -1 for the missing side
+        hp, hb = api.dist_shuffle_join(Column(p), Column(b), multigpu.transport_for(None), how=how)
+        out["c-shuffle-" + how] = (hp.cpu().numpy(), hb.cpu().numpy())
     k = (p % 7)
     for name, v in vals[rank].items():
         tv = torch.from_numpy(v).to(dev)
@@ -232,6 +235,12 @@ def check_uneven(world, results):
         np.testing.assert_array_equal(got[np.lexsort(got.T[::-1])], exp[np.lexsort(exp.T[::-1])])
     got = np.concatenate([np.stack(r[3]["c-shuffle"], axis=1) for r in results])
     np.testing.assert_array_equal(got[np.lexsort(got.T[::-1])], exp[np.lexsort(exp.T[::-1])])
+    for how in ("left", "full"):
+        hl, hr = oracle.join([np.concatenate(probes)], [np.concatenate(builds)], how)
+        exph = np.stack([np.where(hl >= 0, gp[np.maximum(hl, 0)], -1), np.where(hr >= 0, gb[np.maximum(hr, 0)], -1)], axis=1)
+        goth = np.concatenate([np.stack(r[3]["c-shuffle-" + how], axis=1) for r in results])
+        assert len(goth) == len(exph) and (exph == -1).any()
+        np.testing.assert_array_equal(goth[np.lexsort(goth.T[::-1])], exph[np.lexsort(exph.T[::-1])])
     import pandas as pd
     allk = np.concatenate(probes) % 7
     for name in ("int8", "int32", "float32"):

@@ -32,7 +32,12 @@
 // that range cannot match and are treated like null keys.  WIDE (12 bytes): key64 + row
 // in two arrays.  key64 is the exact key for one <= 8-byte column (or several integer
 // columns packed into 8 bytes); wider / mixed keys use a 64-bit hash and every hit is
-// verified against the original columns.
+// verified against the original columns.  On the main path (deferred two-level probe side,
+// 2^15 partitions, indices only) the PROBE side's tuples shrink: NARROW keys travel as six
+// bytes (hash remainder + row: L6 / P6 below), WIDE keys from one 8-byte column as ten
+// (the same six bytes + the key's high word: W10 / P10, p10_key) -- exact in both cases,
+// because the partition hash is a bijection of the key (NARROW) or of its low word for a
+// given high word (WIDE).
 //
 // Semantics kept from the reference: rows with a null in any key column never match
 // (join_kernels.cuh:58-66,314), float keys compare with == (NaN matches nothing), LEFT

@@ -60,8 +60,19 @@ def main():
                 break
             continue
         bk, pk = (build + base).to(dtype), (probe + base).to(dtype)
+        # WIDE keys (round 6: the ten-byte tuples of csrc/join.hip p10_key): a bijection of the 62-bit word spreads the keys over 2^62,
+        # multiplicities as before
+        wide = dtype == torch.int64 and r(0, 3) == 0
+        if wide:
+            M = (1 << 62) - 1
+            bk, pk = ((bk & M) * 0x1E3779B97F4A7C15) & M, ((pk & M) * 0x1E3779B97F4A7C15) & M
+            if base < 0:                                                    # (& M folded negative keys: recompute the multiplicities on the images)
+                uk, inv = torch.unique(torch.cat([bk, pk]), return_inverse=True)
+                mult2 = torch.bincount(inv[:nb], minlength=uk.numel())
+                per_row = mult2[inv[nb:]]
+                expected = int(per_row.sum())
         how = "left" if r(0, 4) == 0 else "inner"
-        tag = (it, nb, npr, space, str(dtype), base, skew, how)
+        tag = (it, nb, npr, space, str(dtype), base, skew, how, "wide" if wide else "narrow")
         if os.environ.get("GDF_STRESS_VERBOSE"):
             print("case", tag, "expected", expected, flush=True)
         li, ri = gdf.api.join([Column(pk)], [Column(bk)], how=how)

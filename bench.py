@@ -116,6 +116,23 @@ def read_profile(gdf, split_sides=False):
     return out
 
 
+def settle_placement(gdf, fn, max_calls=6, min_calls=2):
+    """Untimed warm-up for a steady-state measurement: call fn() until the pool's placement searches have settled (librmm
+    gdf_amd_rmm_place_stats: no entry still exploring) -- since round 6 a call spends a bounded time on candidate blocks and the
+    searches of a new shape go on over its first two to four calls (csrc/internal.h PlaceRound); at most max_calls.  Returns the
+    number of calls made."""
+    st = (C.c_ulonglong * 4)()
+    rmm = gdf._binding._rmm_cdll
+    made = 0
+    for _ in range(max_calls):
+        fn()
+        made += 1
+        rmm.gdf_amd_rmm_place_stats(st)
+        if st[3] == 0 and made >= min_calls:
+            break
+    return made
+
+
 def library_build_id():
     """sha256 of the kernel SOURCES libgdf.so is built from (csrc/*): the same value here and on the GPU box, and it
     changes whenever a kernel changes -- unlike a hash of the .so, which would differ between two builds of one source."""
@@ -315,8 +332,7 @@ def extra_shapes(gdf, dev, headline_ms, npr=1_000_000_000, nb=100_000_000):
         return n
 
     def timed(fn, warm, reps):
-        for _ in range(warm):
-            fn()
+        settle_placement(gdf, fn, max(warm, 6))
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(reps):
             fn()

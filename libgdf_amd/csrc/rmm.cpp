@@ -324,7 +324,9 @@ rmmError_t place_alloc(Manager &m, int role, size_t size, int max_draws, void **
             e->draws = 0;
             e->stale = 0;
             e->busy = true;
-            if (!hold) e->max_draws = draws;
+            // (an entry that starts life HELD has a search ahead of it: it counts as exploring -- gdf_amd_rmm_place_stats, what a
+            // benchmark's warm-up waits for -- until a call with budget left has run that search)
+            e->max_draws = hold ? (draws > 0 ? 1 : 0) : draws;
             *ptr = p;
             *measure = !hold && draws > 0;
             return RMM_SUCCESS;

@@ -24,7 +24,7 @@ def main():
     a = ap.parse_args()
     import torch
     import libgdf_amd as gdf
-    from bench import make_build_keys, make_probe_keys, read_profile, splitmix64_torch
+    from bench import settle_placement, make_build_keys, make_probe_keys, read_profile, splitmix64_torch
     from libgdf_amd._binding import rmmOptions_t
     from libgdf_amd.columns import Column
     gdf.librmm.rmmInitialize(C.byref(rmmOptions_t(1, 0, False)))
@@ -37,8 +37,10 @@ def main():
     def timed(name, fn, alg_bytes_fn, rows, note):
         if only and name not in only:
             return
+        # warm calls until the pool has reached its steady state AND the placement searches of this shape's buffers have settled
+        # (round 6: a call spends a bounded time on candidate blocks, the searches go on over the first two to four calls)
+        settle_placement(gdf, fn)
         out = fn()
-        out = fn()          # two warm calls: the pool allocator reaches its steady state (one warm call left a multi-ms hipMalloc in the timed region)
         lib.gdf_amd_profile_reset(); lib.gdf_amd_profile_enable(1)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(a.reps):

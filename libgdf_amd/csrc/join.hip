@@ -559,7 +559,8 @@ struct SkewCaps {
 //   phase C: LDS position j goes to global base[bin(j)] + (j - start[bin(j)]), so a
 //            wave writes runs of consecutive addresses.
 // ---------------------------------------------------------------------------
-template <bool NARROW, int THREADS, bool PAY = false, int ITEMS = JK_SC_ITEMS>
+// PAY: payload words per tuple -- 0, 1 (PayCarry modes 1 - 3) or 2 (mode 4: two 8-byte columns, one 16-byte element)
+template <bool NARROW, int THREADS, int PAY = 0, int ITEMS = JK_SC_ITEMS>
 struct TileLds {
   // + a trash slot: tuples that do not travel are written there.  The 1024-thread level-1 tile also has room for the padding of
   // six-byte tuples (L6: every bin's run is padded to an even length, up to 256 dead tuples per tile)
@@ -567,7 +568,7 @@ struct TileLds {
   static constexpr int PAD = (THREADS == 1024 && !PAY) ? 256 : 0;
   uint64_t w[THREADS * ITEMS + PAD + 2];
   int32_t idx[NARROW ? 4 : THREADS * ITEMS + PAD + 4];  // WIDE: the row numbers; W10 / P10 tiles: the key's high words
-  uint64_t pay[PAY ? THREADS * ITEMS + 2 : 2];            // payload words, regrouped with their tuples
+  alignas(16) uint64_t pay[PAY ? (THREADS * ITEMS + 2) * PAY : 2];      // payload words (PAY per tuple), regrouped with their tuples
   uint32_t hist[256 + 64];                                // + 64 trash counters, one per lane (never zeroed, never read): a probe relation with
                                                           // most of its keys outside the build range put 90 % of a tile's LDS atomics on ONE of them
   uint32_t start[256];
@@ -581,7 +582,7 @@ struct TileLds {
 };
 
 // block-wide exclusive scan of hist[0..nbins) (nbins <= 256 == blockDim) into start[]
-template <bool NARROW, int THREADS, bool PAY, int ITEMS>
+template <bool NARROW, int THREADS, int PAY, int ITEMS>
 __device__ __forceinline__ void tile_scan_bins(TileLds<NARROW, THREADS, PAY, ITEMS> &s, uint32_t nbins, uint32_t tid) {
   const uint32_t v = tid < nbins ? s.hist[tid] : 0;
   const uint32_t incl = wave_scan_incl(v);
@@ -596,7 +597,7 @@ __device__ __forceinline__ void tile_scan_bins(TileLds<NARROW, THREADS, PAY, ITE
   if (tid < nbins) s.start[tid] = woff + incl - v;
   if (tid == 0) s.total = tot;
 }
-template <bool NARROW, int THREADS, bool PAY, int ITEMS>
+template <bool NARROW, int THREADS, int PAY, int ITEMS>
 __device__ __forceinline__ void tile_scan_bins(TileLds<NARROW, THREADS, PAY, ITEMS> &s, uint32_t nbins) {
   tile_scan_bins(s, nbins, threadIdx.x);
 }
@@ -703,7 +704,7 @@ __device__ __forceinline__ void p6_load_one(const uint64_t *base, uint32_t pos, 
 }
 
 // phase C: write the regrouped tile out.  LEVEL1 bins are the coarse id, LEVEL2 the sub id.
-template <bool LEVEL1, bool NARROW, int THREADS, bool PAY, int ITEMS, bool P6 = false>
+template <bool LEVEL1, bool NARROW, int THREADS, int PAY, int ITEMS, bool P6 = false>
 __device__ __forceinline__ void tile_flush(TileLds<NARROW, THREADS, PAY, ITEMS> &s, const PartGeom &g, Tuples out) {
   const uint32_t total = s.total;
   const uint32_t submask = (1u << g.b2) - 1;
@@ -750,14 +751,19 @@ __device__ __forceinline__ void tile_flush(TileLds<NARROW, THREADS, PAY, ITEMS> 
   }
   constexpr int U = 4;
   for (uint32_t j0 = threadIdx.x; j0 < total; j0 += THREADS * U) {
-    uint64_t ww[U], pp[U];
+    uint64_t ww[U], pp[U], pq[PAY == 2 ? U : 1];
     int32_t ii[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const uint32_t j = j0 + u * THREADS;
       ww[u] = j < total ? s.w[j] : 0;
       ii[u] = (!NARROW && j < total) ? s.idx[j] : 0;
-      pp[u] = (PAY && j < total) ? s.pay[j] : 0;
+      if constexpr (PAY == 2) {             // two payload words: one 16-byte element
+        const ulonglong2 e = j < total ? *reinterpret_cast<const ulonglong2 *>(&s.pay[2 * (size_t)j]) : ulonglong2{0, 0};
+        pp[u] = e.x; pq[u] = e.y;
+      } else {
+        pp[u] = (PAY && j < total) ? s.pay[j] : 0;
+      }
     }
     uint32_t dst[U];
 #pragma unroll
@@ -775,7 +781,8 @@ __device__ __forceinline__ void tile_flush(TileLds<NARROW, THREADS, PAY, ITEMS> 
         if (LAB_BITS(g.dbg) & 16) __builtin_nontemporal_store(ww[u], out.w + dst[u]);      // experiment: streaming stores (level 2)
         else out.w[dst[u]] = ww[u];
         if (!NARROW) out.idx[dst[u]] = ii[u];
-        if (PAY) out.pay[dst[u]] = pp[u];
+        if constexpr (PAY == 2) *reinterpret_cast<ulonglong2 *>(out.pay + 2 * (size_t)dst[u]) = ulonglong2{pp[u], pq[u]};
+        else if (PAY) out.pay[dst[u]] = pp[u];
       }
     }
   }
@@ -1087,18 +1094,23 @@ __global__ __launch_bounds__(THREADS) void jk_scatter1(KeyTable t, KeyPlan plan,
 
 // 2b. level-1 scatter of a probe side that CARRIES A PAYLOAD (Tuples::pay, PayCarry): one FAST key column without a mask,
 // NARROW tuples, and per row one 64-bit payload word read from the relation's non-key column(s) in the same pass --
-//   PMODE 1: one 8-byte column; 2: one 4-byte column (zero-extended); 3: two 4-byte columns (column 0 in the low half).
+//   PMODE 1: one 8-byte column; 2: one 4-byte column (zero-extended); 3: two 4-byte columns (column 0 in the low half);
+//   4 (round 6): TWO 8-byte columns -- a 16-byte payload element per tuple, 24 bytes per tuple in LDS, six tuples
+//   per thread (6144-tuple tiles).  A second 8-byte column gathered behind the join costs one 64-byte sector per value (24 - 27 ms
+//   per 1e9 pairs); carried, 8 more bytes through both regroup levels and the probe are 48 B of streaming traffic per row.
 // The same phases as jk_scatter1 (rank | scan + claim | regroup in LDS | flush, next tile's words prefetched before the
 // flush) on 8192-tuple tiles: the tile holds 16 bytes per tuple, and key + payload + their prefetch registers of 8 items
 // fit the 128 VGPRs of a 1024-thread workgroup.  Tuples and payload words leave as two parallel streams of 256-byte runs.
 struct PaySrc { const void *col[2]; };
 constexpr int JK_PAY_ITEMS = 8;
 constexpr int JK_PAY_THREADS = 1024;
+__host__ __device__ constexpr int pay_words(int pmode) { return pmode == 4 ? 2 : (pmode ? 1 : 0); }
+__host__ __device__ constexpr int pay_items1(int pmode) { return pmode == 4 ? 6 : JK_PAY_ITEMS; }      // level-1 tuples per thread
 template <int FAST, int PMODE>
 __global__ __launch_bounds__(JK_PAY_THREADS) void jk_scatter1_pay(KeyTable t, KeyPlan plan, PartGeom g, const uint32_t *__restrict__ H1off,
                                                                   PaySrc ps, Tuples out) {
-  constexpr int THREADS = JK_PAY_THREADS, ITEMS = JK_PAY_ITEMS;
-  using Tile = TileLds<true, THREADS, true, ITEMS>;
+  constexpr int THREADS = JK_PAY_THREADS, ITEMS = pay_items1(PMODE), PW = pay_words(PMODE);
+  using Tile = TileLds<true, THREADS, PW, ITEMS>;
   extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
   Tile &s = *reinterpret_cast<Tile *>(tile_raw);
   constexpr int TILE = THREADS * ITEMS;
@@ -1109,7 +1121,8 @@ __global__ __launch_bounds__(JK_PAY_THREADS) void jk_scatter1_pay(KeyTable t, Ke
   const uint32_t end = (int64_t)begin + g.chunk < t.nrows ? (uint32_t)(begin + g.chunk) : (uint32_t)t.nrows;
   auto item_row = [](int k, uint32_t tid) -> uint32_t { return 2u * ((uint32_t)(k >> 1) * THREADS + tid) + (k & 1); };
   uint64_t nxt[ITEMS];                                   // raw key words of the next tile
-  uint64_t nxp[PMODE == 1 ? ITEMS : 1];                  // raw payload words, 8-byte column
+  uint64_t nxp[(PMODE == 1 || PMODE == 4) ? ITEMS : 1];  // raw payload words, 8-byte column
+  uint64_t nxq[PMODE == 4 ? ITEMS : 1];                  // ... and the second 8-byte column
   uint32_t nxa[PMODE != 1 ? ITEMS : 1];                  // 4-byte column 0
   uint32_t nxb[PMODE == 3 ? ITEMS : 1];                  // 4-byte column 1
   const void *col = t.col[0].data;
@@ -1120,8 +1133,10 @@ __global__ __launch_bounds__(JK_PAY_THREADS) void jk_scatter1_pay(KeyTable t, Ke
       const uint32_t i = tile + item_row(k, tid);
       const int64_t at = (int64_t)(i + 2 <= end ? i : end - 2);
       fast_pair<FAST>(col, at, nxt[k], nxt[k + 1]);
-      if (PMODE == 1) fast_pair<8>(ps.col[0], at, nxp[k], nxp[k + 1]);
-      else {
+      if (PMODE == 1 || PMODE == 4) {
+        fast_pair<8>(ps.col[0], at, nxp[k], nxp[k + 1]);
+        if (PMODE == 4) fast_pair<8>(ps.col[1], at, nxq[k], nxq[k + 1]);
+      } else {
         uint64_t a0, a1;
         fast_pair<4>(ps.col[0], at, a0, a1);
         nxa[k] = (uint32_t)a0; nxa[k + 1] = (uint32_t)a1;
@@ -1137,7 +1152,7 @@ __global__ __launch_bounds__(JK_PAY_THREADS) void jk_scatter1_pay(KeyTable t, Ke
   if (threadIdx.x < 256) s.hist[threadIdx.x] = 0;
   block_sync();
   uint32_t key[ITEMS];
-  uint64_t pay[ITEMS];
+  uint64_t pay[ITEMS], pay2[PMODE == 4 ? ITEMS : 1];
   uint32_t okmask = 0;
   auto consume = [&](uint32_t tile) {
     const uint32_t tid = opaque_tid();
@@ -1150,18 +1165,21 @@ __global__ __launch_bounds__(JK_PAY_THREADS) void jk_scatter1_pay(KeyTable t, Ke
       const uint64_t k64 = raw - plan.kmin;
       key[k] = (uint32_t)k64;
       okmask |= (uint32_t)(joinable && (tile + item_row(k, tid) < end) && k64 <= plan.klimit) << k;
-      if (PMODE == 1) pay[k] = second ? nxp[k + 1] : nxp[k];
-      else if (PMODE == 2) pay[k] = second ? nxa[k + 1] : nxa[k];
+      if constexpr (PMODE == 1 || PMODE == 4) {
+        pay[k] = second ? nxp[k + 1] : nxp[k];
+        if constexpr (PMODE == 4) pay2[k] = second ? nxq[k + 1] : nxq[k];
+      } else if constexpr (PMODE == 2) pay[k] = second ? nxa[k + 1] : nxa[k];
       else pay[k] = (uint64_t)(second ? nxa[k + 1] : nxa[k]) | ((uint64_t)(second ? nxb[k + 1] : nxb[k]) << 32);
     }
   };
   consume(begin);
   for (uint32_t tile = begin; tile < end; tile += TILE) {
     uint32_t binrank[ITEMS];                    // bin << 16 | rank within (tile, bin); bin 256 = does not travel
+    constexpr int HG = ITEMS % 4 == 0 ? 4 : 3;
 #pragma unroll
-    for (int h = 0; h < ITEMS; h += 4) {
+    for (int h = 0; h < ITEMS; h += HG) {
 #pragma unroll
-      for (int k = h; k < h + 4; ++k) {
+      for (int k = h; k < h + HG; ++k) {
         const uint32_t b = fine_of((uint64_t)key[k] + g.kbias, g.fb) >> g.b2;
         binrank[k] = (okmask >> k) & 1u ? b : 256u + (threadIdx.x & 63u);
       }
@@ -1190,7 +1208,8 @@ __global__ __launch_bounds__(JK_PAY_THREADS) void jk_scatter1_pay(KeyTable t, Ke
         const uint32_t pos = (okmask >> k) & 1u ? st[k] + (binrank[k] & 0xffffu) : (uint32_t)TILE;
         const int32_t row = g.row_base + (int32_t)(tile + item_row(k, wtid));
         s.w[pos] = ((uint64_t)key[k] << 32) | (uint32_t)row;
-        s.pay[pos] = pay[k];
+        if constexpr (PMODE == 4) *reinterpret_cast<ulonglong2 *>(&s.pay[2 * (size_t)pos]) = ulonglong2{pay[k], pay2[k]};
+        else s.pay[pos] = pay[k];
       }
     }
     {   // the claim is looked at after the regroup (see jk_scatter1)
@@ -1216,16 +1235,17 @@ __global__ __launch_bounds__(JK_PAY_THREADS) void jk_scatter1_pay(KeyTable t, Ke
     if (g.cap1 && s.total_abort) return;
     const uint32_t total = s.total;
     const uint32_t ftid = opaque_tid();
-    constexpr int GROUP = 4;
+    constexpr int GROUP = ITEMS % 4 == 0 ? 4 : 3;
 #pragma unroll
     for (int h = 0; h < ITEMS / GROUP; ++h) {
-      uint64_t ww[GROUP], pp[GROUP];
+      uint64_t ww[GROUP], pp[GROUP], pq[PMODE == 4 ? GROUP : 1];
       uint32_t gb[GROUP];
 #pragma unroll
       for (int k = 0; k < GROUP; ++k) {
         const uint32_t j = ftid + (h * GROUP + k) * THREADS;
         ww[k] = s.w[j];
-        pp[k] = s.pay[j];
+        if constexpr (PMODE == 4) { const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(&s.pay[2 * (size_t)j]); pp[k] = e.x; pq[k] = e.y; }
+        else pp[k] = s.pay[j];
       }
 #pragma unroll
       for (int k = 0; k < GROUP; ++k) gb[k] = s.gbase[(fine_of((ww[k] >> 32) + g.kbias, g.fb) >> g.b2) & 255u];
@@ -1234,7 +1254,8 @@ __global__ __launch_bounds__(JK_PAY_THREADS) void jk_scatter1_pay(KeyTable t, Ke
         const uint32_t j = ftid + (h * GROUP + k) * THREADS;
         const uint32_t dst = j < total ? gb[k] + j : g.dump + ftid;
         out.w[dst] = ww[k];
-        out.pay[dst] = pp[k];
+        if constexpr (PMODE == 4) *reinterpret_cast<ulonglong2 *>(out.pay + 2 * (size_t)dst) = ulonglong2{pp[k], pq[k]};
+        else out.pay[dst] = pp[k];
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1275,7 +1296,7 @@ static inline uint32_t sc2_grid(const Level2Map &m, uint32_t ntiles) {
 // IN6: the input is a stream of six-byte level-1 tuples (L6 above; P6 output only): pairs are read with one 12-byte load, the
 // hash comes out of the tuple (coarse partition = the segment's, remainder = the tuple's) and the row number gets its region bits
 // back from the segment -- this kernel then does not hash at all
-template <bool NARROW, int THREADS, bool PAY = false, bool P6 = false, bool K32 = false, bool IN6 = false, int NITEMS = 0>
+template <bool NARROW, int THREADS, int PAY = 0, bool P6 = false, bool K32 = false, bool IN6 = false, int NITEMS = 0>
 __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, Tuples in,
                                                              uint32_t *__restrict__ fine_cursor, Tuples out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
@@ -1307,7 +1328,7 @@ __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, 
   block_sync();
   // straight-line phases as in jk_scatter1: tuples beyond the tile's end are ranked on a trash counter (bin 256) and
   // written to the trash slot of the LDS tile instead of being skipped by a branch per item
-  uint64_t w[ITEMS], pay[PAY ? ITEMS : 1];
+  uint64_t w[ITEMS], pay[PAY ? ITEMS : 1], pay2[PAY == 2 ? ITEMS : 1];
   // a receive buffer of 4-byte keys (fused multi-GPU join), full tile: four consecutive keys per 16-byte load -- a quarter of the load
   // instructions (which tuple of the tile a thread holds does not matter)
   const bool quads = K32 && end - begin == (uint32_t)JK_TILE;
@@ -1360,7 +1381,8 @@ __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, 
     if constexpr (K32) w[k] = ((uint64_t)m.keys32[ic] << 32) | (uint32_t)(g.row_base + (int32_t)ic);
     else w[k] = in.w[ic];                             // (non-temporal loads, which help jk_scatter1, cost 2 % here)
     idx[k] = NARROW ? 0 : in.idx[ic];
-    if (PAY) pay[k] = in.pay[ic];
+    if constexpr (PAY == 2) { const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(in.pay + 2 * (size_t)ic); pay[k] = e.x; pay2[k] = e.y; }
+    else if (PAY) pay[k] = in.pay[ic];
   }
   }
   uint32_t binrank[ITEMS];
@@ -1429,7 +1451,8 @@ __global__ __launch_bounds__(THREADS) void jk_scatter2(PartGeom g, Level2Map m, 
       const uint32_t pos = (binrank[h + k] >> 24) ? (uint32_t)JK_TILE : st[k] + (binrank[h + k] & 0xffffu);
       s.w[pos] = w[h + k];
       if (!NARROW) s.idx[pos] = idx[h + k];
-      if (PAY) s.pay[pos] = pay[h + k];
+      if constexpr (PAY == 2) *reinterpret_cast<ulonglong2 *>(&s.pay[2 * (size_t)pos]) = ulonglong2{pay[h + k], pay2[h + k]};
+      else if (PAY) s.pay[pos] = pay[h + k];
     }
   }
   if (threadIdx.x < nsub && mine) {
@@ -1656,7 +1679,7 @@ struct ProbeArgs {
   // carried payload (PayCarry): pay_mode != 0 -> every pair's probe-side payload column value(s) go to pay_out[c][pos].
   // jk_probe_fast<PMODE> takes them from the payload word next to the probe tuple (probe.pay); the general kernels, which
   // see only the few units the lean kernel left over (and oversize partitions), fetch them from the source columns by row
-  int pay_mode;                  // 0: none; 1: one 8-byte column; 2: one 4-byte column; 3: two 4-byte columns
+  int pay_mode;                  // 0: none; 1: one 8-byte column; 2: one 4-byte column; 3: two 4-byte columns; 4: two 8-byte columns (16-byte elements in probe.pay)
   const void *pay_src[2];
   void *pay_out[2];
   // with a carried payload, an INNER join on one integer key column also writes the KEY column of the result (key_width = 8 /
@@ -1665,7 +1688,9 @@ struct ProbeArgs {
   const void *key_src;
   void *key_out;
   // the BUILD relation's payload word (INNER joins): bpay_mode as pay_mode; jk_probe_bp takes it from the LDS image of the build
-  // partition (build.pay staged next to the tuples), the general kernels from the source columns by build row
+  // partition (build.pay staged next to the tuples), the general kernels from the source columns by build row.  bpay_mode 4: two
+  // 8-byte columns -- the first travels with the build tuples as in mode 1, the second is read BY BUILD ROW when a unit stages its
+  // partition (bpay_src[1]: ~3000 scattered reads per unit, 1e8 per C3 join, instead of 1e9 gathered values behind the join)
   int bpay_mode;
   const void *bpay_src[2];
   void *bpay_out[2];
@@ -1678,8 +1703,10 @@ struct ProbeArgs {
 };
 // the general kernels' payload write: a gather by probe row (rare units only)
 __device__ __forceinline__ void pay_gather(const ProbeArgs &a, unsigned long long pos, int32_t prow) {
-  if (a.pay_mode == 1) ((uint64_t *)a.pay_out[0])[pos] = ((const uint64_t *)a.pay_src[0])[prow];
-  else if (a.pay_mode) {
+  if (a.pay_mode == 1 || a.pay_mode == 4) {
+    ((uint64_t *)a.pay_out[0])[pos] = ((const uint64_t *)a.pay_src[0])[prow];
+    if (a.pay_mode == 4) ((uint64_t *)a.pay_out[1])[pos] = ((const uint64_t *)a.pay_src[1])[prow];
+  } else if (a.pay_mode) {
     ((uint32_t *)a.pay_out[0])[pos] = ((const uint32_t *)a.pay_src[0])[prow];
     if (a.pay_mode == 3) ((uint32_t *)a.pay_out[1])[pos] = ((const uint32_t *)a.pay_src[1])[prow];
   }
@@ -1687,8 +1714,10 @@ __device__ __forceinline__ void pay_gather(const ProbeArgs &a, unsigned long lon
   else if (a.key_width == 4) ((uint32_t *)a.key_out)[pos] = ((const uint32_t *)a.key_src)[prow];
 }
 __device__ __forceinline__ void bpay_gather(const ProbeArgs &a, unsigned long long pos, int32_t brow) {
-  if (a.bpay_mode == 1) ((uint64_t *)a.bpay_out[0])[pos] = ((const uint64_t *)a.bpay_src[0])[brow];
-  else if (a.bpay_mode) {
+  if (a.bpay_mode == 1 || a.bpay_mode == 4) {
+    ((uint64_t *)a.bpay_out[0])[pos] = ((const uint64_t *)a.bpay_src[0])[brow];
+    if (a.bpay_mode == 4) ((uint64_t *)a.bpay_out[1])[pos] = ((const uint64_t *)a.bpay_src[1])[brow];
+  } else if (a.bpay_mode) {
     ((uint32_t *)a.bpay_out[0])[pos] = ((const uint32_t *)a.bpay_src[0])[brow];
     if (a.bpay_mode == 3) ((uint32_t *)a.bpay_out[1])[pos] = ((const uint32_t *)a.bpay_src[1])[brow];
   }
@@ -2131,9 +2160,10 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_fast(ProbeArgs a) {
   const uint32_t lead = u.probe_begin & 1u;
   const uint64_t *__restrict__ src = a.probe.w + (u.probe_begin - lead);
   const int32_t *__restrict__ src_row = NARROW ? nullptr : a.probe.idx + (u.probe_begin - lead);
-  const uint64_t *__restrict__ src_pay = PMODE ? a.probe.pay + (u.probe_begin - lead) : nullptr;
-  uint64_t *__restrict__ po8 = PMODE == 1 ? (uint64_t *)a.pay_out[0] + unit_base : nullptr;
-  uint32_t *__restrict__ po4a = PMODE >= 2 ? (uint32_t *)a.pay_out[0] + unit_base : nullptr;
+  const uint64_t *__restrict__ src_pay = PMODE ? a.probe.pay + (size_t)(u.probe_begin - lead) * (PMODE == 4 ? 2 : 1) : nullptr;
+  uint64_t *__restrict__ po8 = (PMODE == 1 || PMODE == 4) ? (uint64_t *)a.pay_out[0] + unit_base : nullptr;
+  uint64_t *__restrict__ po8b = PMODE == 4 ? (uint64_t *)a.pay_out[1] + unit_base : nullptr;
+  uint32_t *__restrict__ po4a = (PMODE == 2 || PMODE == 3) ? (uint32_t *)a.pay_out[0] + unit_base : nullptr;
   uint32_t *__restrict__ po4b = PMODE == 3 ? (uint32_t *)a.pay_out[1] + unit_base : nullptr;
   uint64_t *__restrict__ ko8 = (PMODE && a.key_width == 8) ? (uint64_t *)a.key_out + unit_base : nullptr;
   uint32_t *__restrict__ ko4 = (PMODE && a.key_width == 4) ? (uint32_t *)a.key_out + unit_base : nullptr;
@@ -2142,7 +2172,7 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_fast(ProbeArgs a) {
   for (uint32_t base = 0; base < vtotal; base += JK_PROBE_THREADS * NB) {
     Key key[NB];
     uint32_t prow[NB];
-    uint64_t pay[PMODE ? NB : 1];
+    uint64_t pay[PMODE ? NB : 1], pay2[PMODE == 4 ? NB : 1];
     bool act[NB];
 #pragma unroll
     for (int b = 0; b < JK_PROBE_BATCH; ++b) {      // all HBM loads first, 16 bytes each (WIDE: + 8 bytes of row numbers), clamped and unconditional
@@ -2162,7 +2192,11 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_fast(ProbeArgs a) {
       } else {
         ww = *reinterpret_cast<const ulonglong2 *>(src + vc);
       }
-      if constexpr (PMODE != 0) {
+      if constexpr (PMODE == 4) {             // two payload words per tuple: one 16-byte element each
+        const ulonglong2 p0 = *reinterpret_cast<const ulonglong2 *>(src_pay + 2 * (size_t)vc);
+        const ulonglong2 p1 = *reinterpret_cast<const ulonglong2 *>(src_pay + 2 * (size_t)vc + 2);
+        pay[2 * b] = p0.x; pay2[2 * b] = p0.y; pay[2 * b + 1] = p1.x; pay2[2 * b + 1] = p1.y;
+      } else if constexpr (PMODE != 0) {
         const ulonglong2 pp = *reinterpret_cast<const ulonglong2 *>(src_pay + vc);
         pay[2 * b] = pp.x; pay[2 * b + 1] = pp.y;
       }
@@ -2229,8 +2263,9 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_probe_fast(ProbeArgs a) {
           if constexpr (NARROW) ob[pos + 1] = (int32_t)(uint32_t)wb[b];
           else ob[pos + 1] = l.bi[pb[b]];
         }
-        if constexpr (PMODE == 1) { po8[pos] = pay[b]; if (c == 2) po8[pos + 1] = pay[b]; }
-        if constexpr (PMODE >= 2) { po4a[pos] = (uint32_t)pay[b]; if (c == 2) po4a[pos + 1] = (uint32_t)pay[b]; }
+        if constexpr (PMODE == 1 || PMODE == 4) { po8[pos] = pay[b]; if (c == 2) po8[pos + 1] = pay[b]; }
+        if constexpr (PMODE == 4) { po8b[pos] = pay2[b]; if (c == 2) po8b[pos + 1] = pay2[b]; }
+        if constexpr (PMODE == 2 || PMODE == 3) { po4a[pos] = (uint32_t)pay[b]; if (c == 2) po4a[pos + 1] = (uint32_t)pay[b]; }
         if constexpr (PMODE == 3) { po4b[pos] = (uint32_t)(pay[b] >> 32); if (c == 2) po4b[pos + 1] = (uint32_t)(pay[b] >> 32); }
         if constexpr (PMODE != 0 && NARROW) {          // the result's key column (workgroup-uniform branches)
           if (ko8) { ko8[pos] = (uint64_t)key[b] + a.kbias; if (c == 2) ko8[pos + 1] = (uint64_t)key[b] + a.kbias; }
@@ -2457,20 +2492,25 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_count_fast(ProbeArgs a) {
 // 16 bytes per build tuple: one 1024-thread workgroup per CU (86 KB at C3's partition size) instead of two 512-thread ones;
 // a unit's staging + cuckoo build is ~2 % of its time, so little is lost to the missing overlap.
 constexpr int JK_BP_THREADS = 1024;
-static size_t probe_bp_lds_bytes(uint32_t cap, uint32_t H) { return (size_t)cap * 16 + (size_t)H * 8 + 16; }
-template <bool POW2, bool PP>
+// (PP: payload words a probe tuple carries, 0 / 1 / 2; BW2: the build relation has a SECOND 8-byte payload column, bpay_mode 4 -- staged by
+// build row next to the carried word, 24 bytes per build tuple in LDS)
+static size_t probe_bp_lds_bytes(uint32_t cap, uint32_t H, bool bw2 = false) { return (size_t)cap * (bw2 ? 24 : 16) + (size_t)H * 8 + 16; }
+template <bool POW2, int PP, bool BW2 = false>
 __global__ __launch_bounds__(JK_BP_THREADS) void jk_probe_bp(ProbeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const uint32_t H = a.nslots, cap = a.cap;
   uint64_t *bw = (uint64_t *)lds_raw;                               // [cap] key32 << 32 | build row
   uint64_t *bp = bw + cap;                                          // [cap] build payload word
-  uint32_t *T = (uint32_t *)(bp + cap);                             // [2 H] cuckoo tables of positions
+  uint64_t *bp2 = bp + cap;                                         // [cap] BW2: the second build payload column's values
+  uint32_t *T = (uint32_t *)(bp + (BW2 ? 2 : 1) * (size_t)cap);     // [2 H] cuckoo tables of positions
   unsigned int *lcur = (unsigned int *)(T + 2 * (size_t)H);         // pairs written so far by this unit
   unsigned int *failed = lcur + 1;
   const Unit u = a.units[blockIdx.x];
   for (uint32_t i = threadIdx.x; i < u.build_count; i += JK_BP_THREADS) {
-    bw[i] = a.build.w[u.build_begin + i];
+    const uint64_t w = a.build.w[u.build_begin + i];
+    bw[i] = w;
     bp[i] = a.build.pay[u.build_begin + i];
+    if constexpr (BW2) bp2[i] = ((const uint64_t *)a.bpay_src[1])[(uint32_t)w];       // by build row: ~3000 scattered reads per unit
   }
   for (uint32_t i = threadIdx.x; i < 2 * H; i += JK_BP_THREADS) T[i] = JK_NOPOS;
   if (threadIdx.x == 0) { *lcur = 0; *failed = 0; }
@@ -2515,31 +2555,37 @@ __global__ __launch_bounds__(JK_BP_THREADS) void jk_probe_bp(ProbeArgs a) {
   int32_t *__restrict__ op = a.out_probe + unit_base;
   int32_t *__restrict__ ob = a.out_build + unit_base;
   // output columns: widths are workgroup-uniform run-time values (one kernel for every payload mode)
-  uint64_t *__restrict__ po8 = (PP && a.pay_mode == 1) ? (uint64_t *)a.pay_out[0] + unit_base : nullptr;
-  uint32_t *__restrict__ po4a = (PP && a.pay_mode >= 2) ? (uint32_t *)a.pay_out[0] + unit_base : nullptr;
+  uint64_t *__restrict__ po8 = (PP && (a.pay_mode == 1 || a.pay_mode == 4)) ? (uint64_t *)a.pay_out[0] + unit_base : nullptr;
+  uint64_t *__restrict__ po8b = PP == 2 ? (uint64_t *)a.pay_out[1] + unit_base : nullptr;
+  uint32_t *__restrict__ po4a = (PP && (a.pay_mode == 2 || a.pay_mode == 3)) ? (uint32_t *)a.pay_out[0] + unit_base : nullptr;
   uint32_t *__restrict__ po4b = (PP && a.pay_mode == 3) ? (uint32_t *)a.pay_out[1] + unit_base : nullptr;
-  uint64_t *__restrict__ bo8 = a.bpay_mode == 1 ? (uint64_t *)a.bpay_out[0] + unit_base : nullptr;
-  uint32_t *__restrict__ bo4a = a.bpay_mode >= 2 ? (uint32_t *)a.bpay_out[0] + unit_base : nullptr;
+  uint64_t *__restrict__ bo8 = (a.bpay_mode == 1 || a.bpay_mode == 4) ? (uint64_t *)a.bpay_out[0] + unit_base : nullptr;
+  uint64_t *__restrict__ bo8b = BW2 ? (uint64_t *)a.bpay_out[1] + unit_base : nullptr;
+  uint32_t *__restrict__ bo4a = (a.bpay_mode == 2 || a.bpay_mode == 3) ? (uint32_t *)a.bpay_out[0] + unit_base : nullptr;
   uint32_t *__restrict__ bo4b = a.bpay_mode == 3 ? (uint32_t *)a.bpay_out[1] + unit_base : nullptr;
   uint64_t *__restrict__ ko8 = a.key_width == 8 ? (uint64_t *)a.key_out + unit_base : nullptr;
   uint32_t *__restrict__ ko4 = a.key_width == 4 ? (uint32_t *)a.key_out + unit_base : nullptr;
   // (with a probe payload as well a batch of 8 tuples per lane needs more than the 128 registers a 1024-thread workgroup gets)
-  constexpr int BATCH = PP ? 3 : JK_PROBE_BATCH, NB = BATCH * 2;
+  constexpr int BATCH = (PP == 2 || BW2) ? 2 : (PP ? 3 : JK_PROBE_BATCH), NB = BATCH * 2;
   const uint32_t lead = u.probe_begin & 1u;
   const uint64_t *__restrict__ src = a.probe.w + (u.probe_begin - lead);
-  const uint64_t *__restrict__ src_pay = PP ? a.probe.pay + (u.probe_begin - lead) : nullptr;
+  const uint64_t *__restrict__ src_pay = PP ? a.probe.pay + (size_t)(u.probe_begin - lead) * (PP == 2 ? 2 : 1) : nullptr;
   const uint32_t vtotal = lead + u.probe_count;
   const uint32_t last_pair = (vtotal - 1) & ~1u;
   for (uint32_t base = 0; base < vtotal; base += JK_BP_THREADS * NB) {
     uint32_t key[NB], prow[NB];
-    uint64_t pay[PP ? NB : 1];
+    uint64_t pay[PP ? NB : 1], pay2[PP == 2 ? NB : 1];
     bool act[NB];
 #pragma unroll
     for (int b = 0; b < BATCH; ++b) {
       const uint32_t v = base + (b * JK_BP_THREADS + threadIdx.x) * 2;
       const uint32_t vc = v < last_pair ? v : last_pair;
       const ulonglong2 ww = *reinterpret_cast<const ulonglong2 *>(src + vc);
-      if constexpr (PP) {
+      if constexpr (PP == 2) {
+        const ulonglong2 p0 = *reinterpret_cast<const ulonglong2 *>(src_pay + 2 * (size_t)vc);
+        const ulonglong2 p1 = *reinterpret_cast<const ulonglong2 *>(src_pay + 2 * (size_t)vc + 2);
+        pay[2 * b] = p0.x; pay2[2 * b] = p0.y; pay[2 * b + 1] = p1.x; pay2[2 * b + 1] = p1.y;
+      } else if constexpr (PP != 0) {
         const ulonglong2 pp = *reinterpret_cast<const ulonglong2 *>(src_pay + vc);
         pay[2 * b] = pp.x; pay[2 * b + 1] = pp.y;
       }
@@ -2573,19 +2619,21 @@ __global__ __launch_bounds__(JK_BP_THREADS) void jk_probe_bp(ProbeArgs a) {
       hpos[b] = ha ? pa[b] : (hb ? pb[b] : 0u);
       hrow[b] = ha ? (uint32_t)wa[b] : (uint32_t)wb[b];
     }
-    uint64_t q[NB];                 // the build payload of the hit: one more LDS read per tuple, requested together
+    uint64_t q[NB], q2[BW2 ? NB : 1];      // the build payload of the hit: one more LDS read per tuple (two with BW2), requested together
 #pragma unroll
-    for (int b = 0; b < NB; ++b) q[b] = bp[hpos[b]];
-    auto emit_one = [&](int b, uint32_t pos, uint32_t brow, uint64_t bpay) {
+    for (int b = 0; b < NB; ++b) { q[b] = bp[hpos[b]]; if constexpr (BW2) q2[b] = bp2[hpos[b]]; }
+    auto emit_one = [&](int b, uint32_t pos, uint32_t brow, uint64_t bpay, uint64_t bpay2) {
       if (pos >= unit_cap) { a.opt_state[1] = 1; return; }   // would spill into the next unit's slots: the host redoes the join two-pass
       op[pos] = (int32_t)prow[b];
       ob[pos] = (int32_t)brow;
       if (bo8) bo8[pos] = bpay;
+      if constexpr (BW2) bo8b[pos] = bpay2;
       if (bo4a) bo4a[pos] = (uint32_t)bpay;
       if (bo4b) bo4b[pos] = (uint32_t)(bpay >> 32);
       if (ko8) ko8[pos] = (uint64_t)key[b] + a.kbias;
       if (ko4) ko4[pos] = key[b];
-      if constexpr (PP) {
+      if constexpr (PP == 2) po8b[pos] = pay2[b];
+      if constexpr (PP != 0) {
         if (po8) po8[pos] = pay[b];
         if (po4a) po4a[pos] = (uint32_t)pay[b];
         if (po4b) po4b[pos] = (uint32_t)(pay[b] >> 32);
@@ -2607,7 +2655,7 @@ __global__ __launch_bounds__(JK_BP_THREADS) void jk_probe_bp(ProbeArgs a) {
       wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
 #pragma unroll
       for (int b = 0; b < NB; ++b)
-        if ((onemask >> b) & 1u) emit_one(b, wbase + off[b] + (uint32_t)mask_rank(mm[b]), hrow[b], q[b]);
+        if ((onemask >> b) & 1u) emit_one(b, wbase + off[b] + (uint32_t)mask_rank(mm[b]), hrow[b], q[b], BW2 ? q2[b] : 0);
     } else {
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
@@ -2617,8 +2665,8 @@ __global__ __launch_bounds__(JK_BP_THREADS) void jk_probe_bp(ProbeArgs a) {
         uint32_t wbase = 0;
         if (lane_id() == 0 && wave_total) wbase = atomicAdd(lcur, wave_total);
         uint32_t pos = __shfl(wbase, 0, WAVE) + incl - c;
-        if (c) emit_one(b, pos++, hrow[b], q[b]);
-        if (c == 2) emit_one(b, pos, (uint32_t)bw[pb[b]], bp[pb[b]]);      // the second copy of the key, from table 1
+        if (c) emit_one(b, pos++, hrow[b], q[b], BW2 ? q2[b] : 0);
+        if (c == 2) emit_one(b, pos, (uint32_t)bw[pb[b]], bp[pb[b]], BW2 ? bp2[pb[b]] : 0);      // the second copy of the key, from table 1
       }
     }
   }
@@ -3092,7 +3140,7 @@ constexpr gdf_error GDF_AMD_RETRY_EXACT_PROBE = (gdf_error)30;        // probe_p
 // 64-bit payload word per row (Tuples::pay) instead of gathering them afterwards -- set up by join_entry, honoured by
 // probe_prepared when the join runs on NARROW tuples with exact keys from one FAST, unmasked key column (INNER / LEFT).
 struct PayCarry {
-  int mode = 0;                        // 1: one 8-byte column; 2: one 4-byte column; 3: two 4-byte columns
+  int mode = 0;                        // 1: one 8-byte column; 2: one 4-byte column; 3: two 4-byte columns; 4: TWO 8-byte columns (round 6)
   const void *src[2] = {nullptr, nullptr};
   void *dst[2] = {nullptr, nullptr};   // OUT: rmm allocations of *out_n elements each, the caller's to free -- set iff carried
   bool carried = false;                // OUT
@@ -3107,10 +3155,10 @@ struct PayCarry {
   const void *bsrc[2] = {nullptr, nullptr};
   void *bdst[2] = {nullptr, nullptr};  // OUT, set iff build_carried
   bool build_carried = false;          // OUT
-  int belem_bytes() const { return bmode == 1 ? 8 : 4; }
-  int bncols() const { return bmode == 3 ? 2 : (bmode ? 1 : 0); }
-  int elem_bytes(int c) const { return mode == 1 ? 8 : 4; }
-  int ncols() const { return mode == 3 ? 2 : (mode ? 1 : 0); }
+  int belem_bytes() const { return (bmode == 1 || bmode == 4) ? 8 : 4; }
+  int bncols() const { return (bmode == 3 || bmode == 4) ? 2 : (bmode ? 1 : 0); }
+  int elem_bytes(int c) const { return (mode == 1 || mode == 4) ? 8 : 4; }
+  int ncols() const { return (mode == 3 || mode == 4) ? 2 : (mode ? 1 : 0); }
 };
 
 struct SideBufs {            // partitioned tuples of one relation
@@ -3125,6 +3173,7 @@ struct SideBufs {            // partitioned tuples of one relation
   // vectors above are empty
   bool deferred = false;
   bool p6 = false;           // the fine-partitioned tuples of this (deferred probe) side are six-byte ones (p6_store)
+  int pay_words = 1;         // 64-bit words per payload element in pay[] (2: PayCarry mode 4)
   uint32_t cap2 = 0;
   DevBuf d_level1;           // [nseg + 1] level-1 fill counters + overflow flag; behind them (8-byte aligned) the words of `zero`
   unsigned long long *zero = nullptr;     // 16 zeroed 8-byte words inside d_level1, cleared with the counters in front of level 1: the state
@@ -3260,7 +3309,7 @@ static gdf_error launch_scatter2_t(uint32_t ntiles, const PartGeom &g, Level2Map
   return GDF_SUCCESS;
 }
 static gdf_error launch_scatter2(bool narrow, int threads, uint32_t ntiles, const PartGeom &g, Level2Map m, Tuples in,
-                                 uint32_t *cursor, Tuples out, bool p6 = false, bool in6 = false) {
+                                 uint32_t *cursor, Tuples out, bool p6 = false, bool in6 = false, int pw = 1) {
   if (in6) {                         // six-byte level-1 tuples in, six-byte level-2 tuples out
     if (!(p6 && !m.keys32 && g.b1 == 8)) return GDF_INVALID_API_CALL;
     m.ntiles = ntiles;
@@ -3315,6 +3364,17 @@ static gdf_error launch_scatter2(bool narrow, int threads, uint32_t ntiles, cons
     HIP_CHECK_LAST();
     return GDF_SUCCESS;
   }
+  if (narrow && in.pay && pw == 2) { // ... two payload words per tuple (PayCarry mode 4): 2048-tuple tiles of 24 bytes, three workgroups per CU
+    using Tile = TileLds<true, 256, 2, JK_PAY_ITEMS>;
+    const size_t lds = offsetof(Tile, cursor);
+    HIP_TRY(hipFuncSetAttribute((const void *)jk_scatter2<true, 256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    m.ntiles = ntiles;
+    m.xcd_order = (ntiles >= 64 && !lab::path_on("GDF_JK_NO_XCD_ORDER")) ? 1 : 0;
+    const uint32_t grid = sc2_grid(m, ntiles);
+    GDF_LAUNCH("jk_scatter2", (jk_scatter2<true, 256, 2>), dim3(grid), dim3(256), lds, stream0(), g, m, in, cursor, out);
+    HIP_CHECK_LAST();
+    return GDF_SUCCESS;
+  }
   if (narrow && in.pay) {            // a probe side that carries its payload words (PayCarry): the production tile size only
     const size_t lds = sizeof(TileLds<true, 256, true, JK_PAY_ITEMS>);
     HIP_TRY(hipFuncSetAttribute((const void *)jk_scatter2<true, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -3344,14 +3404,14 @@ static gdf_error launch_scatter2(bool narrow, int threads, uint32_t ntiles, cons
 // level-1 scatter of a payload-carrying probe side (jk_scatter1_pay)
 static gdf_error launch_scatter1_pay(int fast, int pmode, const KeyTable &t, const KeyPlan &plan, const PartGeom &g, const uint32_t *H1off,
                                      const PaySrc &ps, Tuples out) {
-  const size_t lds = sizeof(TileLds<true, JK_PAY_THREADS, true, JK_PAY_ITEMS>);
 #define JK_PAY_LAUNCH(F, M)                                                                                                   \
   do {                                                                                                                        \
+    const size_t lds = sizeof(TileLds<true, JK_PAY_THREADS, pay_words(M), pay_items1(M)>);                                   \
     HIP_TRY(hipFuncSetAttribute((const void *)jk_scatter1_pay<F, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     GDF_LAUNCH("jk_scatter1", (jk_scatter1_pay<F, M>), dim3(g.nchunks), dim3(JK_PAY_THREADS), lds, stream0(), t, plan, g, H1off, ps, out); \
   } while (0)
-  if (fast == 8) { if (pmode == 1) JK_PAY_LAUNCH(8, 1); else if (pmode == 2) JK_PAY_LAUNCH(8, 2); else JK_PAY_LAUNCH(8, 3); }
-  else { if (pmode == 1) JK_PAY_LAUNCH(4, 1); else if (pmode == 2) JK_PAY_LAUNCH(4, 2); else JK_PAY_LAUNCH(4, 3); }
+  if (fast == 8) { if (pmode == 1) JK_PAY_LAUNCH(8, 1); else if (pmode == 2) JK_PAY_LAUNCH(8, 2); else if (pmode == 3) JK_PAY_LAUNCH(8, 3); else JK_PAY_LAUNCH(8, 4); }
+  else { if (pmode == 1) JK_PAY_LAUNCH(4, 1); else if (pmode == 2) JK_PAY_LAUNCH(4, 2); else if (pmode == 3) JK_PAY_LAUNCH(4, 3); else JK_PAY_LAUNCH(4, 4); }
 #undef JK_PAY_LAUNCH
   HIP_CHECK_LAST();
   return GDF_SUCCESS;
@@ -3472,7 +3532,9 @@ static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, Si
   g.dump = (uint32_t)(cap + 2);
   RMM_TRY(sb->w[0].alloc(sizeof(uint64_t) * (cap + 2 + 1024)));
   if (!narrow) RMM_TRY(sb->idx[0].alloc(sizeof(int32_t) * (cap + 2 + 1024)));
-  if (pay) RMM_TRY(sb->pay[0].alloc(sizeof(uint64_t) * (cap + 2 + 1024)));
+  const int pw = pay ? pay_words(pmode) : 1;
+  sb->pay_words = pw;
+  if (pay) RMM_TRY(sb->pay[0].alloc(sizeof(uint64_t) * pw * (cap + 2 + 1024)));
   const Tuples t0 = sb->tuples(0);
   // level 2's map and cursors are made and sent BEFORE level 1 is launched: the host has everything, and behind the level-1 kernel
   // every staged upload was a stall between the two levels
@@ -3508,7 +3570,7 @@ static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, Si
     p6 = want_p6 && !pay && sc2_threads == 256;
     RMM_TRY(sb->w[1].alloc(p6 ? 6 * (cap + 2) + 16 : sizeof(uint64_t) * (cap + 2)));
     if (!narrow) RMM_TRY(sb->idx[1].alloc(sizeof(int32_t) * (cap + 2)));     // + 2: the lean probe kernel reads row numbers in pairs
-    if (pay) RMM_TRY(sb->pay[1].alloc(sizeof(uint64_t) * (cap + 2)));
+    if (pay) RMM_TRY(sb->pay[1].alloc(sizeof(uint64_t) * pw * (cap + 2)));
   }
   if (pay) GDF_TRY(launch_scatter1_pay(fast, pmode, t, plan, g, H1.as<uint32_t>(), *pay, t0));
   else GDF_TRY(launch_scatter1(fast, narrow, sc_threads, t, plan, g, H1.as<uint32_t>(), t0));
@@ -3516,7 +3578,7 @@ static gdf_error partition_side(const KeyTable &t, KeyPlan &plan, PartGeom g, Si
   sb->final_buf = 0;
   if (level2) {
     Level2Map m{d_coarse.as<uint32_t>(), d_coarse.as<uint32_t>() + 1, d_tiles.as<uint32_t>()};
-    if (ntiles) GDF_TRY(launch_scatter2(narrow, sc2_threads, ntiles, g, m, sb->tuples(0), cursor.as<uint32_t>(), sb->tuples(1), p6));
+    if (ntiles) GDF_TRY(launch_scatter2(narrow, sc2_threads, ntiles, g, m, sb->tuples(0), cursor.as<uint32_t>(), sb->tuples(1), p6, false, pw));
     HIP_CHECK_LAST();
     if (keep_running && device_index) {          // (no host vector is in flight on this path)
       for (DevBuf *b : {&sb->w[0], &sb->idx[0], &sb->pay[0], &d_coarse, &d_tiles, &cursor, &H1, &fine_hist, &scan_a, &scan_b}) sb->keep(*b);
@@ -3679,7 +3741,9 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
   else RMM_TRY(sb->w[0].alloc(bytes1));      // (L6: + two dump slots per thread behind the regions)
   if (hi_placed1) RMM_TRY(sb->idx[0].alloc_placed(JK_ROLE_LEVEL1_HI, bytes1_hi, -1));      // (held while the six-byte stream's block is chosen)
   else if (!narrow) RMM_TRY(sb->idx[0].alloc(bytes1_hi));
-  if (pay) RMM_TRY(sb->pay[0].alloc(sizeof(uint64_t) * size1));
+  const int pw = pay ? pay_words(pmode) : 1;
+  sb->pay_words = pw;
+  if (pay) RMM_TRY(sb->pay[0].alloc(sizeof(uint64_t) * pw * size1));
 #ifdef GDF_AMD_LAB
   DevBuf lab_clk;
   if (lab::knob_on("GDF_JK_CLOCK") && !pay) {
@@ -3776,7 +3840,7 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
     else RMM_TRY(sb->w[1].alloc(bytes2));
     if (hi_inside2) sb->idx[1].borrow(sb->w[1].as<char>() + six2);
     else if (!narrow) RMM_TRY(sb->idx[1].alloc(sizeof(int32_t) * size2));
-    if (pay) RMM_TRY(sb->pay[1].alloc(sizeof(uint64_t) * size2));
+    if (pay) RMM_TRY(sb->pay[1].alloc(sizeof(uint64_t) * pw * size2));
     PartGeom g2 = g;
     g2.cap2 = cap2;
     g2.dump = caps ? (uint32_t)(size2 - JK_TILE) : nfine * cap2;
@@ -3793,7 +3857,7 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
         Level2Map mc = m;
         mc.calib_step = 4;
         sb->w[1].clock_begin(stream0());
-        GDF_TRY(launch_scatter2(narrow, sc2_threads, tile_bound, g2, mc, sb->tuples(0), cursor.as<uint32_t>(), sb->tuples(1), p6, l6));
+        GDF_TRY(launch_scatter2(narrow, sc2_threads, tile_bound, g2, mc, sb->tuples(0), cursor.as<uint32_t>(), sb->tuples(1), p6, l6, pw));
         sb->w[1].clock_end(stream0());
         hipLaunchKernelGGL(jk_init_cursor, dim3(32), dim3(256), 0, stream0(), cursor.as<uint32_t>(), nfine, cap2, g.fstart);      // (+ the overflow flag)
         HIP_CHECK_LAST();
@@ -3802,7 +3866,7 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
       }
     }
     sb->w[1].clock_begin(stream0());
-    GDF_TRY(launch_scatter2(narrow, sc2_threads, tile_bound, g2, m, sb->tuples(0), cursor.as<uint32_t>(), sb->tuples(1), p6, l6));
+    GDF_TRY(launch_scatter2(narrow, sc2_threads, tile_bound, g2, m, sb->tuples(0), cursor.as<uint32_t>(), sb->tuples(1), p6, l6, pw));
     sb->w[1].clock_end(stream0());
     sb->p6 = p6;
     // no synchronisation: the map and the level-1 tuples stay allocated until probe_partitioned has read its state block
@@ -3852,7 +3916,7 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
       cur.pop_back();
       RMM_TRY(sb->w[1].alloc(sizeof(uint64_t) * size2));
       if (!narrow) RMM_TRY(sb->idx[1].alloc(sizeof(int32_t) * size2));
-      if (pay) RMM_TRY(sb->pay[1].alloc(sizeof(uint64_t) * size2));
+      if (pay) RMM_TRY(sb->pay[1].alloc(sizeof(uint64_t) * pw * size2));
       if (app) app->started = true;
     }
     PartGeom g2 = g;
@@ -3860,7 +3924,7 @@ static gdf_error partition_side_spec(const KeyTable &t, const KeyPlan &plan, Par
     g2.dump = nfine * cap2;
     g2.spec_flag = cursor.as<uint32_t>() + nfine;
     Level2Map m{d_coarse.as<uint32_t>(), d_coarse.as<uint32_t>() + nseg, d_tiles.as<uint32_t>(), g.xs};
-    if (ntiles) GDF_TRY(launch_scatter2(narrow, sc2_threads, ntiles, g2, m, sb->tuples(0), cursor.as<uint32_t>(), sb->tuples(1)));
+    if (ntiles) GDF_TRY(launch_scatter2(narrow, sc2_threads, ntiles, g2, m, sb->tuples(0), cursor.as<uint32_t>(), sb->tuples(1), false, false, pw));
     uint32_t flag = 0;
     if (!app) {
       cur.resize((size_t)nfine + 1);
@@ -3984,14 +4048,21 @@ static gdf_error run_write_pass(bool narrow, bool plain, size_t nunits, size_t l
   } while (0)
   const bool keep = a.keep_unmatched_probe != 0;
   if (narrow && a.bpay_mode && !keep) {        // the build relation's payload word rides in the LDS image (jk_probe_bp)
-    const size_t blds = probe_bp_lds_bytes(a.cap, fa.nslots);
-#define JK_BP_LAUNCH(P2, PPAY)                                                                                                    \
+    const bool bw2 = a.bpay_mode == 4;
+    const size_t blds = probe_bp_lds_bytes(a.cap, fa.nslots, bw2);
+#define JK_BP_LAUNCH(P2, PPAY, B2)                                                                                                \
   do {                                                                                                                            \
-    HIP_TRY(hipFuncSetAttribute((const void *)jk_probe_bp<P2, PPAY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds));    \
-    GDF_LAUNCH("jk_probe_write", (jk_probe_bp<P2, PPAY>), dim3((unsigned)nunits), dim3(JK_BP_THREADS), blds, stream0(), fa);      \
+    HIP_TRY(hipFuncSetAttribute((const void *)jk_probe_bp<P2, PPAY, B2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds)); \
+    GDF_LAUNCH("jk_probe_write", (jk_probe_bp<P2, PPAY, B2>), dim3((unsigned)nunits), dim3(JK_BP_THREADS), blds, stream0(), fa);  \
   } while (0)
-    if (pow2 && a.pay_mode) JK_BP_LAUNCH(true, true); else if (pow2) JK_BP_LAUNCH(true, false);
-    else if (a.pay_mode) JK_BP_LAUNCH(false, true); else JK_BP_LAUNCH(false, false);
+#define JK_BP_PICK(P2)                                                                                                            \
+  do {                                                                                                                            \
+    if (a.pay_mode == 4 && bw2) JK_BP_LAUNCH(P2, 2, true); else if (a.pay_mode == 4) JK_BP_LAUNCH(P2, 2, false);                   \
+    else if (a.pay_mode && bw2) JK_BP_LAUNCH(P2, 1, true); else if (a.pay_mode) JK_BP_LAUNCH(P2, 1, false);                        \
+    else if (bw2) JK_BP_LAUNCH(P2, 0, true); else JK_BP_LAUNCH(P2, 0, false);                                                      \
+  } while (0)
+    if (pow2) JK_BP_PICK(true); else JK_BP_PICK(false);
+#undef JK_BP_PICK
 #undef JK_BP_LAUNCH
   } else if (narrow && a.p6_fb) {      // six-byte probe tuples (never together with carried columns)
     if (pow2 && keep) JK_FAST_LAUNCH(true, true, true, 0, true);
@@ -4004,7 +4075,7 @@ static gdf_error run_write_pass(bool narrow, bool plain, size_t nunits, size_t l
     if (pow2 && keep) JK_FAST_LAUNCH(true, true, true, M); else if (pow2) JK_FAST_LAUNCH(true, false, true, M);                    \
     else if (keep) JK_FAST_LAUNCH(false, true, true, M); else JK_FAST_LAUNCH(false, false, true, M);                                \
   } while (0)
-    if (a.pay_mode == 1) JK_FAST_PAY(1); else if (a.pay_mode == 2) JK_FAST_PAY(2); else JK_FAST_PAY(3);
+    if (a.pay_mode == 1) JK_FAST_PAY(1); else if (a.pay_mode == 2) JK_FAST_PAY(2); else if (a.pay_mode == 3) JK_FAST_PAY(3); else JK_FAST_PAY(4);
 #undef JK_FAST_PAY
   } else if (narrow) {
     if (pow2 && keep) JK_FAST_LAUNCH(true, true, true);
@@ -4146,7 +4217,7 @@ static gdf_error refine_side(const PartGeom &g, bool narrow, double dup, SideBuf
   RMM_TRY(flag.alloc(sizeof(uint32_t)));
   RMM_TRY(nw.alloc(sizeof(uint64_t) * size3));
   if (!narrow) RMM_TRY(nidx.alloc(sizeof(int32_t) * size3));
-  if (carries) RMM_TRY(npay.alloc(sizeof(uint64_t) * size3));
+  if (carries) RMM_TRY(npay.alloc(sizeof(uint64_t) * sb->pay_words * size3));
   HIP_TRY(hipMemcpyAsync(d_seg.p, seg.data(), sizeof(uint32_t) * 2 * nseg, hipMemcpyHostToDevice, stream0()));
   HIP_TRY(hipMemcpyAsync(d_tiles.p, tile_prefix.data(), sizeof(uint32_t) * ((size_t)nseg + 1), hipMemcpyHostToDevice, stream0()));
   HIP_TRY(hipMemcpyAsync(cursor.p, cur.data(), sizeof(uint32_t) * nfine3, hipMemcpyHostToDevice, stream0()));
@@ -4161,7 +4232,8 @@ static gdf_error refine_side(const PartGeom &g, bool narrow, double dup, SideBuf
   g3.spec_flag = flag.as<uint32_t>();
   g3.xs = 0;
   Level2Map m{d_seg.as<uint32_t>(), d_seg.as<uint32_t>() + nseg, d_tiles.as<uint32_t>(), 0};
-  if (ntiles) GDF_TRY(launch_scatter2(narrow, threads, ntiles, g3, m, sb->final(), cursor.as<uint32_t>(), Tuples{nw.as<uint64_t>(), nidx.as<int32_t>(), npay.as<uint64_t>()}));
+  if (ntiles) GDF_TRY(launch_scatter2(narrow, threads, ntiles, g3, m, sb->final(), cursor.as<uint32_t>(), Tuples{nw.as<uint64_t>(), nidx.as<int32_t>(), npay.as<uint64_t>()},
+                                      false, false, sb->pay_words));
   uint32_t overflow = 0;
   HIP_TRY(read_back(cur.data(), cursor.p, sizeof(uint32_t) * nfine3));
   HIP_TRY(read_back(&overflow, flag.p, sizeof(uint32_t)));
@@ -4230,6 +4302,7 @@ static gdf_error plan_ranged(const KeyTable &build_t, KeyPlan *plan) {
 // keep_running: the call returns with the side's last launches still queued (partition_side); the caller settles bs->B
 static gdf_error prepare_build(const KeyTable &build_t, BuildSide *bs, bool no_level3 = false, const PaySrc *bpay = nullptr, int bmode = 0,
                                bool keep_running = false) {
+  if (bmode == 4) bmode = 1;               // (two 8-byte build columns: the FIRST travels with the tuples, the second is staged by row -- jk_probe_bp<.., BW2>)
   bs->plan = plan_keys(build_t);           // a function of the key dtypes only: the probe relation has the same ones
   GDF_TRY(plan_ranged(build_t, &bs->plan));
   bs->g = choose_geometry(build_t.nrows);
@@ -4485,7 +4558,7 @@ static gdf_error probe_partitioned(const KeyTable &probe_t, const KeyTable &buil
   const bool bp_pow2 = (double)max_build <= 0.42 * 2.0 * (double)H_lds;
   const uint32_t bp_slots = bp_pow2 ? H_lds : (((uint32_t)(max_build * 1.25) + 63) & ~63u);
   const bool build_pay = pc && kind == JOIN_INNER && pc->bmode && B.pay[B.final_buf].p != nullptr && narrow && !plan.verify &&
-                         oversize.empty() && probe_bp_lds_bytes(cap_lds, bp_slots) <= (size_t)160 * 1024;
+                         oversize.empty() && probe_bp_lds_bytes(cap_lds, bp_slots, pc->bmode == 4) <= (size_t)160 * 1024;
   const bool probe_pay = pc && pc->mode && P.pay[P.final_buf].p != nullptr;
   if (pc) {
     if (probe_pay) for (int c = 0; c < pc->ncols(); ++c) { cc[ncc].width = pc->elem_bytes(c); cc[ncc++].commit = &pc->dst[c]; }
@@ -5161,13 +5234,19 @@ static gdf_error join_entry(JoinKind kind, gdf_column **left_cols, int num_left_
     // gathered through the index columns as before.  (A second word per side was priced and not built: carrying 8 bytes
     // through both partition levels moves 48 bytes per row, the gather it replaces one 64-byte sector + 12 -- DESIGN 3.7.)
     auto payload_mode = [&](gdf_column **cols, const std::vector<int> &which, const gdf_column *keycol, int (&slot)[2], const void *(&src)[2]) -> int {
-      int wide = -1, narrow[2] = {-1, -1}, nn = 0;
+      int wide = -1, wide2 = -1, narrow[2] = {-1, -1}, nn = 0;
       for (size_t j = 0; j < which.size(); ++j) {
         const gdf_column *col = cols[which[j]];
         const int w = col ? dtype_width(col->dtype) : -1;
         if (!col || !col->data || col->valid || col->size != keycol->size) continue;
         if (w == 8 && wide < 0) wide = which[j];
+        else if (w == 8 && wide2 < 0) wide2 = which[j];
         if (w == 4 && nn < 2) narrow[nn++] = which[j];
+      }
+      // (round 6, mode 4: a relation with two unmasked 8-byte non-key columns carries BOTH -- a 16-byte payload element)
+      if (wide >= 0 && wide2 >= 0 && !lab::path_on("GDF_JK_NO_CARRY2")) {
+        src[0] = cols[wide]->data; slot[0] = wide; src[1] = cols[wide2]->data; slot[1] = wide2;
+        return 4;
       }
       if (wide >= 0) { src[0] = cols[wide]->data; slot[0] = wide; return 1; }
       for (int j = 0; j < nn; ++j) { src[j] = cols[narrow[j]]->data; slot[j] = narrow[j]; }

@@ -370,6 +370,58 @@ def test_one_payload_word_is_carried_and_the_rest_gathered(gdf, how, cols, force
         np.testing.assert_array_equal(d[v], src[b[v]])
 
 
+@pytest.mark.parametrize("how", ["inner", "left"])
+@pytest.mark.parametrize("shape", ["all-hit", "half-hit", "80pct-hit", "dup-build-keys", "small-exact-layout", "skewed", "headline-geometry", "three-per-side"])
+def test_two_payload_words_per_side(gdf, how, shape, force_path):
+    """Round 6: a relation with TWO unmasked 8-byte non-key columns carries both -- a 16-byte payload element
+    through jk_scatter1_pay<.., 4> (6144-tuple tiles), jk_scatter2<.., 2> and the probe kernels (csrc/join.hip PayCarry mode 4) -- and an
+    INNER join's build relation has its first such column travel with the tuples and the second staged BY BUILD ROW into the LDS image
+    (jk_probe_bp<.., BW2>).  Every output-sizing path (dense single pass, hole filling, compaction, count + write), the general kernel
+    (repeated build keys: payloads gathered by row), the exact layout, a skewed probe side, the headline's geometry
+    (GDF_JK_FORCE_FB=15), a third 8-byte column per side (gathered) -- against the oracle and against the one-word path
+    (GDF_JK_NO_CARRY2).  Reference: joining.cu:375-479, gdf_table.cuh:873-963."""
+    import zlib
+    rs = np.random.RandomState(zlib.crc32(shape.encode()) % 100000)
+    npr, nb = (400_000, 40_000)
+    if shape == "small-exact-layout":
+        npr, nb = 3_000, 700
+    else:
+        force_path("GDF_JK_SPEC_MIN", "1000")
+    if shape == "headline-geometry":
+        npr, nb = 1_300_000, 60_000
+        force_path("GDF_JK_FORCE_FB", "15")
+    space = {"half-hit": 2 * nb, "80pct-hit": nb + nb // 4}.get(shape, nb)
+    build = rs.permutation(max(space, nb))[:nb].astype(np.int64) if shape != "dup-build-keys" else (rs.permutation(nb) % (nb // 4)).astype(np.int64)
+    probe = rs.randint(0, space if shape != "dup-build-keys" else nb // 4, size=npr).astype(np.int64)
+    if shape == "skewed":
+        probe[rs.randint(0, npr, size=npr // 8)] = build[0]
+    ncols = 3 if shape == "three-per-side" else 2
+    pays = [rs.randint(-2**62, 2**62, size=npr).astype(np.int64), rs.random_sample(npr)] + ([rs.randint(0, 99, size=npr).astype(np.int64)] if ncols == 3 else [])
+    bpays = [rs.random_sample(nb), rs.randint(-2**62, 2**62, size=nb).astype(np.int64)] + ([rs.random_sample(nb)] if ncols == 3 else [])
+
+    def run():
+        a, b, res = _join_with_result_cols(gdf, how, pays + [probe], len(pays), [build] + bpays, 0)
+        el, er = oracle.join([probe], [build], how)
+        x, y = sort_pairs(a, b)
+        ex, ey = sort_pairs(el, er)
+        np.testing.assert_array_equal(x, ex)
+        np.testing.assert_array_equal(y, ey)
+        for (d, v), src in zip(res[:len(pays)], pays):
+            assert v.all()
+            np.testing.assert_array_equal(d.view(np.int64), src[a].view(np.int64))
+        d, v = res[len(pays)]
+        assert v.all()
+        np.testing.assert_array_equal(d, probe[a])
+        has = b >= 0
+        for (d, v), src in zip(res[len(pays) + 1:], bpays):
+            np.testing.assert_array_equal(v, has)
+            np.testing.assert_array_equal(d[v].view(np.int64), src[b[v]].view(np.int64))
+        return len(a)
+    n1 = run()
+    force_path("GDF_JK_NO_CARRY2")
+    assert run() == n1
+
+
 @pytest.mark.parametrize("how", ["inner", "left", "full"])
 def test_int64_keys_wider_than_32_bits(gdf, how):
     """Build keys spanning more than 2^32 use the 12-byte tuple format; a narrower build range uses packed

@@ -149,8 +149,9 @@ def main():
             bpay2 = bpay * 5
             timed("c3_materialise_4_payload_cols", join_materialise4,
                   lambda out: 8.0 * npr + 8.0 * nb + 8.0 * out + 2 * 8.0 * npr + 2 * 8.0 * nb + 5 * 8.0 * out, npr,
-                  "C3 + result_cols = [2 x int64 probe payload, key, 2 x int64 build payload]: the first payload column of each side and the "
-                  "key are carried, the second payload column of each side is gathered by row (probe side: one 64-byte sector per value)")
+                  "C3 + result_cols = [2 x int64 probe payload, key, 2 x int64 build payload]: round 6 -- BOTH probe payload columns travel with the "
+                  "tuples (16-byte payload elements, PayCarry mode 4), the key comes out of the probe kernel, the build side's first column travels "
+                  "and its second is staged by build row into the LDS image; no gather (rounds 4 - 5: one word per side carried, 32 ms of gathers)")
             del ppay2, bpay2
         del ppay, bpay
     # 1. half of the probe rows miss: count pass + write pass
@@ -184,7 +185,7 @@ def main():
     bwide = (splitmix64_torch(i + 0x5EED0031) >> 4) & ((1 << 60) - 1)          # splitmix64 is a bijection: distinct before the shift;
     del i                                                                       # a handful of collisions after it do not matter
     pwide = gather_keys(bwide, npr, 0x5EED0032)
-    timed("c3_wide_keys", lambda: join(pwide, bwide), jb(npr, nb), npr, "int64 keys spread over 2^60: WIDE tuples (key64 + row), lean probe kernel with two independent 32-bit folds")
+    timed("c3_wide_keys", lambda: join(pwide, bwide), jb(npr, nb), npr, "int64 keys spread over 2^60: round 6 -- ten-byte tuples (six bytes of hash remainder + row, the key's high word beside them), lean probe kernel at two workgroups per CU (rounds 1 - 5: key64 + row, 12 bytes)")
     del pwide, bwide
     # 5. every build key four times (multimap semantics): the probe side shrinks so that the output stays 1e9 pairs
     npd = npr // 4

@@ -2492,6 +2492,7 @@ __global__ __launch_bounds__(JK_PROBE_THREADS) void jk_count_fast(ProbeArgs a) {
 // 16 bytes per build tuple: one 1024-thread workgroup per CU (86 KB at C3's partition size) instead of two 512-thread ones;
 // a unit's staging + cuckoo build is ~2 % of its time, so little is lost to the missing overlap.
 constexpr int JK_BP_THREADS = 1024;
+constexpr int JK_BP_BATCH22 = 2;       // row pairs per thread and batch when two probe words AND two build words travel (3 spills: 128 VGPRs + 28 B of scratch)
 // (PP: payload words a probe tuple carries, 0 / 1 / 2; BW2: the build relation has a SECOND 8-byte payload column, bpay_mode 4 -- staged by
 // build row next to the carried word, 24 bytes per build tuple in LDS)
 static size_t probe_bp_lds_bytes(uint32_t cap, uint32_t H, bool bw2 = false) { return (size_t)cap * (bw2 ? 24 : 16) + (size_t)H * 8 + 16; }
@@ -2566,7 +2567,7 @@ __global__ __launch_bounds__(JK_BP_THREADS) void jk_probe_bp(ProbeArgs a) {
   uint64_t *__restrict__ ko8 = a.key_width == 8 ? (uint64_t *)a.key_out + unit_base : nullptr;
   uint32_t *__restrict__ ko4 = a.key_width == 4 ? (uint32_t *)a.key_out + unit_base : nullptr;
   // (with a probe payload as well a batch of 8 tuples per lane needs more than the 128 registers a 1024-thread workgroup gets)
-  constexpr int BATCH = (PP == 2 || BW2) ? 2 : (PP ? 3 : JK_PROBE_BATCH), NB = BATCH * 2;
+  constexpr int BATCH = (PP == 2 && BW2) ? JK_BP_BATCH22 : ((PP == 2 || BW2) ? 2 : (PP ? 3 : JK_PROBE_BATCH)), NB = BATCH * 2;
   const uint32_t lead = u.probe_begin & 1u;
   const uint64_t *__restrict__ src = a.probe.w + (u.probe_begin - lead);
   const uint64_t *__restrict__ src_pay = PP ? a.probe.pay + (size_t)(u.probe_begin - lead) * (PP == 2 ? 2 : 1) : nullptr;

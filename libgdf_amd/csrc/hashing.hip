@@ -544,6 +544,139 @@ __global__ __launch_bounds__(HPP_THREADS) void part_scatter_pairs_kernel(const u
   }
 }
 
+// ---- up to four 8-byte columns, no masks, one of them the hashed key, up to 256 partitions: ONE 16384-row stage, column after column ----
+// At 256 bins run length decides (the pair kernel's 32-row runs lose to the generic kernel's 48-row ones, above): this kernel regroups
+// 16384-row tiles -- 64-row runs, 512 bytes, the join's level-1 tile -- through one 8-byte stage that the columns pass one after the
+// other.  Hash + rank + scan happen once per tile; per column: values into the stage at the ranked positions, barrier, flush
+// (sixteen unconditional stores per thread, dead slots to per-thread dump words), barrier.  While the key column is flushed the
+// next column's words are already requested, while the last column is flushed the next tile's key words are: every load has a flush
+// to hide behind.  Straight-line phases, XCD-major chunk order (PartLevel::xcd_groups) as in the pair kernel.
+constexpr int HPC_THREADS = 1024, HPC_ITEMS = 16, HPC_TILE = HPC_THREADS * HPC_ITEMS, HPC_MAX_PARTS = 256, HPC_MAX_COLS = 4;
+struct HpcCols { int ncols, keycol; const uint64_t *in[HPC_MAX_COLS]; uint64_t *out[HPC_MAX_COLS]; };
+struct HpcLds {
+  uint64_t stage[HPC_TILE + 2];
+  uint8_t bin_of[HPC_TILE + 8];
+  uint32_t hist[HPC_MAX_PARTS + 64];        // + one trash counter per lane
+  uint32_t start[HPC_MAX_PARTS], gbase[HPC_MAX_PARTS], cursor[HPC_MAX_PARTS];
+  uint32_t wave_tot[HPC_THREADS / WAVE];
+};
+// threadIdx.x through an opaque move: per-thread addresses derived from it are not hoisted out of the tile loops (hoisted, they are
+// spilled: 26 VGPRs of scratch in the first version of the kernel below -- every reload a vmcnt(0) wait; join.hip does the same)
+__device__ __forceinline__ uint32_t hp_opaque_tid() {
+  uint32_t tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  return tid;
+}
+__global__ __launch_bounds__(HPC_THREADS) void part_scatter_cols8_kernel(HpcCols cc, uint64_t *__restrict__ dump, int64_t n, int64_t chunk, int nchunks,
+                                                                         uint32_t nparts, uint32_t pow2mask, const uint32_t *__restrict__ offs, PartLevel lv) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char hpc_raw[];
+  HpcLds &s = *reinterpret_cast<HpcLds *>(hpc_raw);
+  auto item_row = [](int k, uint32_t tid) -> uint32_t { return 2u * ((uint32_t)(k >> 1) * HPC_THREADS + tid) + (k & 1); };
+  for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    const uint32_t begin = (uint32_t)((int64_t)c * chunk);
+    const uint32_t end = (int64_t)begin + chunk < n ? (uint32_t)(begin + chunk) : (uint32_t)n;
+    if (threadIdx.x < nparts) s.cursor[threadIdx.x] = offs[hist_index(threadIdx.x, c, nchunks, lv)];
+    if (threadIdx.x < HPC_MAX_PARTS) s.hist[threadIdx.x] = 0;
+    uint64_t nxt[HPC_ITEMS];                               // the words of the column that is staged next (key column of a tile first)
+    auto request = [&](const uint64_t *__restrict__ col, uint32_t tile) {      // a pair that would cross `end` is read from the last two rows (n >= 2^16)
+      const uint32_t rtid = hp_opaque_tid();
+#pragma unroll
+      for (int k = 0; k < HPC_ITEMS; k += 2) {
+        const uint32_t i = tile + item_row(k, rtid);
+        const uint32_t ic = i + 2 <= end ? i : end - 2;
+        nxt[k] = __builtin_nontemporal_load(col + ic);
+        nxt[k + 1] = __builtin_nontemporal_load(col + ic + 1);
+      }
+    };
+    request(cc.in[cc.keycol], begin);
+    block_sync();
+    for (uint32_t tile = begin; tile < end; tile += HPC_TILE) {
+      const uint32_t total = end - tile < (uint32_t)HPC_TILE ? end - tile : (uint32_t)HPC_TILE;
+      uint32_t pos2[HPC_ITEMS / 2];                         // LDS positions of this thread's rows, two per register (<= 16384: 15 bits)
+      // ---- the key column: hash, rank, scan ----
+      {
+        uint32_t pr[HPC_ITEMS];
+        const uint32_t htid = hp_opaque_tid();
+#pragma unroll
+        for (int h = 0; h < HPC_ITEMS; h += 4) {
+#pragma unroll
+          for (int k = h; k < h + 4; ++k) {
+            const uint32_t i = tile + item_row(k, htid);
+            const uint64_t key = ((k & 1) == 0 && i + 1 == end) ? nxt[k + 1] : nxt[k];
+            nxt[k] = key;                                   // (the shifted word stays where the staging loop below expects it)
+            const uint32_t p = part_of(murmur3_32(key, 8), nparts, pow2mask);
+            pr[k] = i < end ? p : (uint32_t)HPC_MAX_PARTS + (htid & 63u);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int k = 0; k < HPC_ITEMS; ++k) pr[k] = (pr[k] << 16) | atomicAdd(&s.hist[pr[k]], 1u);
+        block_sync();
+        const uint32_t v = threadIdx.x < nparts ? s.hist[threadIdx.x] : 0;
+        const uint32_t incl = wave_scan_incl(v);
+        if (lane_id() == WAVE - 1) s.wave_tot[threadIdx.x / WAVE] = incl;
+        block_sync();
+        const uint32_t woff = waves_before_sum<HPC_THREADS / WAVE>(s.wave_tot, threadIdx.x);
+        if (threadIdx.x < nparts) {
+          const uint32_t st = woff + incl - v;
+          s.start[threadIdx.x] = st;
+          s.gbase[threadIdx.x] = s.cursor[threadIdx.x] - st;
+          s.cursor[threadIdx.x] += v;
+        }
+        if (threadIdx.x < HPC_MAX_PARTS) s.hist[threadIdx.x] = 0;
+        block_sync();
+#pragma unroll
+        for (int k = 0; k < HPC_ITEMS; ++k) {
+          const uint32_t b = pr[k] >> 16;
+          const uint32_t at = b < (uint32_t)HPC_MAX_PARTS ? s.start[b] + (pr[k] & 0xffffu) : (uint32_t)HPC_TILE;      // dead rows: the trash slot
+          s.bin_of[at] = (uint8_t)b;
+          if (k & 1) pos2[k >> 1] |= at << 16; else pos2[k >> 1] = at;
+        }
+      }
+      // ---- column after column through the one stage (the key column first: its words are in nxt already) ----
+      for (int ci = 0; ci < cc.ncols; ++ci) {
+        const int col = ci == 0 ? cc.keycol : (ci <= cc.keycol ? ci - 1 : ci);
+        if (ci > 0) {                                       // (the key column's pair shift was applied while hashing)
+#pragma unroll
+          for (int k = 0; k < HPC_ITEMS; k += 2) {
+            const uint32_t i = tile + item_row(k, hp_opaque_tid());
+            if (i + 1 == end) nxt[k] = nxt[k + 1];
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < HPC_ITEMS; ++k) s.stage[(k & 1) ? pos2[k >> 1] >> 16 : pos2[k >> 1] & 0xffffu] = nxt[k];
+        __builtin_amdgcn_sched_barrier(0);
+        // what is staged next is requested now and travels under this column's flush
+        if (ci + 1 < cc.ncols) request(cc.in[ci + 1 <= cc.keycol ? ci : ci + 1], tile);
+        else if (tile + HPC_TILE < end) request(cc.in[cc.keycol], tile + HPC_TILE);
+        block_sync();
+        uint64_t *__restrict__ out = cc.out[col];
+        const uint32_t ftid = hp_opaque_tid();
+#pragma unroll
+        for (int h = 0; h < HPC_ITEMS; h += 4) {
+          uint64_t v[4];
+          uint32_t dst[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const uint32_t j = ftid + (uint32_t)(h + k) * HPC_THREADS;
+            v[k] = s.stage[j];
+            dst[k] = s.gbase[s.bin_of[j]] + j;
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const uint32_t j = ftid + (uint32_t)(h + k) * HPC_THREADS;
+            uint64_t *at = j < total ? out + dst[k] : dump + ftid;
+            *at = v[k];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        block_sync();                                       // the stage is free for the next column
+      }
+    }
+    block_sync();
+  }
+}
+
 // columns beyond the first HP_MAX_PAYLOAD_COLS follow the recorded row -> destination map
 __global__ __launch_bounds__(HP_THREADS) void part_apply_map_kernel(PayloadCols pc, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * HP_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * HP_THREADS) {
@@ -1361,16 +1494,22 @@ gdf_error gdf_hash_partition(int num_input_cols, gdf_column *input[], int column
                n >= ((int64_t)1 << 16) && !lab::path_on("GDF_HP_NO_PAIRS");
   for (int i = 0; i < num_input_cols && pairs; ++i)
     pairs = dtype_width(input[i]->dtype) == 8 && !(input[i]->valid && partitioned_output[i]->valid);
+  // the 16384-row single-stage kernel (part_scatter_cols8_kernel): up to four 8-byte columns without masks, up to 256 partitions, what the
+  // pair kernel does not take
+  bool cols8 = !pairs && fastw == 8 && num_input_cols <= HPC_MAX_COLS && P > 16 && P <= (uint32_t)HPC_MAX_PARTS && n >= ((int64_t)1 << 16) &&
+               !lab::path_on("GDF_HP_NO_COLS8");
+  for (int i = 0; i < num_input_cols && cols8; ++i)
+    cols8 = dtype_width(input[i]->dtype) == 8 && !(input[i]->valid && partitioned_output[i]->valid);
   PartLevel lv0{};
   size_t hist_words = (size_t)P * nchunks, start_stride = (size_t)nchunks;
-  if (pairs) {
+  if (pairs || cols8) {
     lv0.xcd_groups = (uint32_t)((nchunks + 7) / 8);
     start_stride = (size_t)8 * lv0.xcd_groups;
     hist_words = (size_t)P * start_stride;
   }
   RMM_TRY(hist.alloc(sizeof(uint32_t) * hist_words));
   RMM_TRY(starts.alloc(sizeof(uint32_t) * P));
-  if (pairs && start_stride != (size_t)nchunks) HIP_TRY(hipMemsetAsync(hist.p, 0, sizeof(uint32_t) * hist_words, stream0()));      // (slots of chunks that do not exist)
+  if ((pairs || cols8) && start_stride != (size_t)nchunks) HIP_TRY(hipMemsetAsync(hist.p, 0, sizeof(uint32_t) * hist_words, stream0()));      // (slots of chunks that do not exist)
   if (fastw == 8)
     GDF_LAUNCH("part_hist", part_hist_fast_kernel<uint64_t>, dim3(grid), dim3(HP_THREADS), lds, stream0(), (const uint64_t *)t.col[0].data, n, chunk,
                nchunks, P, pow2mask, agg_bits, hist.as<uint32_t>(), lv0);
@@ -1386,6 +1525,25 @@ gdf_error gdf_hash_partition(int num_input_cols, gdf_column *input[], int column
   hipLaunchKernelGGL(gather_strided_u32, dim3((P + 255) / 256), dim3(256), 0, stream0(), hist.as<uint32_t>(),
                      starts.as<uint32_t>(), (int)P, start_stride);
   HIP_CHECK_LAST();
+  if (cols8) {
+    HpcCols hc{};
+    hc.ncols = num_input_cols;
+    for (int i = 0; i < num_input_cols; ++i) {
+      hc.in[i] = (const uint64_t *)input[i]->data;
+      hc.out[i] = (uint64_t *)partitioned_output[i]->data;
+      if (input[i] == key_cols[0]) hc.keycol = i;
+    }
+    DevBuf dump;
+    RMM_TRY(dump.alloc(sizeof(uint64_t) * HPC_THREADS));
+    const int pgrid = nchunks < NUM_CU * 4 ? nchunks : NUM_CU * 4;
+    HIP_TRY(hipFuncSetAttribute((const void *)part_scatter_cols8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(HpcLds)));
+    GDF_LAUNCH("part_scatter", part_scatter_cols8_kernel, dim3(pgrid), dim3(HPC_THREADS), sizeof(HpcLds), stream0(), hc, dump.as<uint64_t>(), n, chunk,
+               nchunks, P, pow2mask, (const uint32_t *)hist.as<uint32_t>(), lv0);
+    HIP_CHECK_LAST();
+    HIP_TRY(hipMemcpyAsync(partition_offsets, starts.p, sizeof(int) * P, hipMemcpyDeviceToHost, stream0()));
+    HIP_TRY(hipStreamSynchronize(stream0()));
+    return GDF_SUCCESS;
+  }
   if (pairs) {
     int keycol = 0;
     for (int i = 0; i < num_input_cols; ++i) if (input[i] == key_cols[0]) keycol = i;

@@ -115,6 +115,39 @@ def test_hash_partition_pair_kernel(gdf, nparts, shape, force_path):
             np.testing.assert_array_equal(e[np.lexsort(e.T[::-1])], g[np.lexsort(g.T[::-1])])
 
 
+@pytest.mark.parametrize("nparts", [65, 100, 255, 256])
+@pytest.mark.parametrize("shape", ["key-only", "key-value", "three-key-middle", "four-key-last", "float64-key", "last-chunk-of-one-row"])
+def test_hash_partition_single_stage_kernel(gdf, nparts, shape, force_path):
+    """Up to four 8-byte columns without moved masks, 16 < P <= 256, >= 2^16 rows, where the pair kernel does not apply, take
+    part_scatter_cols8_kernel (csrc/hashing.hip, round 6): a 16384-row tile whose destinations are computed once from the key column and
+    whose one 8-byte LDS stage is reused column after column.  Offsets as the oracle's (hashing.cu:434-468 partition rule on the pinned
+    Murmur3 row hash), every partition the reference's rows as a multiset with rows intact -- and the same call through the generic tile
+    kernel (GDF_HP_NO_COLS8).  Sizes: an odd row count, and one that leaves a last chunk of one row.  Reference: hashing.cu:559-654."""
+    n = {"last-chunk-of-one-row": 1024 * 2048 + 1}.get(shape, 1_234_567)
+    k = gen_rand(np.float64 if shape == "float64-key" else np.int64, n)
+    v = [gen_rand(np.int64, n), gen_rand(np.float64, n), gen_rand(np.int64, n)]
+    cols, hashed = {"key-only": ([k], [0]), "three-key-middle": ([v[0], k, v[1]], [1]),
+                    "four-key-last": ([v[0], v[1], v[2], k], [3])}.get(shape, ([k, v[0]], [0]))
+
+    def run():
+        outs, offsets = gdf.api.hash_partition([_col(gdf, c) for c in cols], hashed, nparts)
+        return [o.to_numpy() for o in outs], offsets
+    perm, exp_off, pid = oracle.hash_partition(cols, hashed, nparts)
+    bounds = list(exp_off) + [n]
+    for kernel in ("cols8", "generic"):
+        if kernel == "generic":
+            force_path("GDF_HP_NO_COLS8")
+        got, offsets = run()
+        assert offsets == [int(x) for x in exp_off]
+        got_pid = oracle.partition_ids([got[hashed[0]]], nparts)
+        for p in range(nparts):
+            lo, hi = bounds[p], bounds[p + 1]
+            assert np.all(got_pid[lo:hi] == p)
+            e = np.stack([c[perm][lo:hi].view(np.int64) for c in cols], axis=1)
+            g = np.stack([c[lo:hi].view(np.int64) for c in got], axis=1)
+            np.testing.assert_array_equal(e[np.lexsort(e.T[::-1])], g[np.lexsort(g.T[::-1])])
+
+
 @pytest.mark.parametrize("nparts", [16, 700])
 def test_hash_partition_moves_valid_masks(gdf, nparts):
     n = 200000

@@ -1,5 +1,5 @@
-"""Round 6: gdf_hash_partition of 1e9 rows x 2 int64 columns, the pair kernel (part_scatter_pairs_kernel) against the generic tile kernel
-(GDF_HP_NO_PAIRS), alternating in one process so that both see the same output columns."""
+"""Round 6: gdf_hash_partition of 1e9 rows x 2 int64 columns, the pair / single-stage kernels (part_scatter_pairs_kernel, part_scatter_cols8_kernel) against the generic tile kernel
+(GDF_HP_NO_PAIRS + GDF_HP_NO_COLS8), alternating in one process so that both see the same output columns."""
 import os, sys, time, json
 os.environ["LIBGDF_AMD_TESTHOOK"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -14,9 +14,10 @@ keys = make_probe_keys(n, 10000, 0x5EED0003, dev)
 vals = make_probe_keys(n, 1000, 0x5EED0004, dev)
 kc, vc = Column(keys), Column(vals)
 lib = gdf._binding._gdf_cdll
-for P in (256, 64, 32):
-    for mode in ("pairs", "generic", "pairs", "generic"):
-        gdf.libgdf.gdf_amd_debug_force(b"GDF_HP_NO_PAIRS", None if mode == "pairs" else b"1")
+for P in (256, 128, 64, 32):
+    for mode in ("new", "generic", "new", "generic"):
+        gdf.libgdf.gdf_amd_debug_force(b"GDF_HP_NO_PAIRS", None if mode == "new" else b"1")
+        gdf.libgdf.gdf_amd_debug_force(b"GDF_HP_NO_COLS8", None if mode == "new" else b"1")
         cols, offs = gdf.api.hash_partition([kc, vc], [0], P)
         ok = int(cols[0].data.sum().item()) == int(keys.sum().item()) and int(cols[1].data.sum().item()) == int(vals.sum().item())
         del cols

@@ -202,6 +202,19 @@ gdf_error gdf_amd_dist_shuffle_left_join(gdf_column *probe_keys, gdf_column *bui
 gdf_error gdf_amd_dist_shuffle_full_join(gdf_column *probe_keys, gdf_column *build_keys, gdf_amd_transport *transport,
                                          gdf_column *out_probe_ids, gdf_column *out_build_ids);
 
+/* DISTRIBUTED MATERIALISATION (round 6): the multi-GPU face of the joins' result_cols step (src/join/joining.cu:375-479 gathers the
+ * relations' columns by the index columns; across ranks the index is a global row id).  COLLECTIVE.  `ids` is a GDF_INT64 column
+ * without a mask of global row ids as the gdf_amd_dist_shuffle_*join entries produce them -- (owner rank << 40) | local row, or -1
+ * for the missing side of an unmatched row -- in any number and any order (also none); `columns` are 1 ... 8 columns of THIS rank's
+ * shard of the relation the ids name (equal sizes, any fixed-width dtype, validity masks honoured).  Every id is asked of its owner
+ * (the local rows travel over the transport, split by owner), the owner reads its shard and the values travel back:
+ *   outs[c]   library-allocated column (gdf_column_free) of ids->size rows in the dtype of columns[c], ALWAYS with a validity mask:
+ *             row i is columns[c]'s row named by ids[i] on its owner -- null where ids[i] is -1 or the source row is null -- and
+ *             null_count says how many are.
+ * Errors: an id that names no rank or no row of its owner's shard is GDF_INVALID_API_CALL; local errors are carried into the next
+ * agreement as in the entries above, every rank returns together. */
+gdf_error gdf_amd_dist_gather(gdf_column *ids, int ncols, gdf_column **columns, gdf_amd_transport *transport, gdf_column **outs);
+
 /* MULTI-GPU GROUP-BY behind the C ABI (csrc/dist_ops.hip; no counterpart in the reference, which is single-GPU -- per rank it
  * composes gdf_group_by_<op>, src/sqls_ops.cu:1426-1487, and gdf_hash_partition, src/hashing.cu:559-654).  COLLECTIVE: every rank
  * of the transport calls it with its row shard of (keys, values) -- one int32 / int64 key column, one numeric value column, no

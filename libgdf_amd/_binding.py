@@ -136,6 +136,7 @@ _PROTOTYPES = {
     "gdf_amd_dist_shuffle_join": (None, [_COLP, _COLP, C.c_void_p, _COLP, _COLP]),
     "gdf_amd_dist_shuffle_left_join": (None, [_COLP, _COLP, C.c_void_p, _COLP, _COLP]),
     "gdf_amd_dist_shuffle_full_join": (None, [_COLP, _COLP, C.c_void_p, _COLP, _COLP]),
+    "gdf_amd_dist_gather": (None, [_COLP, C.c_int, C.POINTER(_COLP), C.c_void_p, C.POINTER(_COLP)]),
     "gdf_amd_rccl_unique_id": (None, [C.c_char_p]),
     "gdf_amd_rccl_transport_create": (None, [C.c_char_p, C.c_int, C.c_int, C.c_void_p]),
     "gdf_amd_rccl_transport_ranks": (None, [C.c_void_p, _INTP, _INTP]),

@@ -577,6 +577,31 @@ def dist_shuffle_join(probe: Column, build: Column, transport, how="inner"):
     return _take_library_column(op, torch.int64), _take_library_column(ob, torch.int64)
 
 
+def dist_gather(ids, columns, transport):
+    """gdf_amd_dist_gather (COLLECTIVE): the rows that global ids (int64 tensor: owner rank << 40 | local row, or -1) name, fetched from
+    the ranks that own them -> list of (values tensor, bool tensor of valid bits) per column of this rank's shard."""
+    import torch
+    idc = Column(ids)
+    outs = [gdf_column() for _ in columns]
+    outs_arr = (C.POINTER(gdf_column) * len(columns))(*[C.pointer(o) for o in outs])
+    libgdf.gdf_amd_dist_gather(idc.ptr, len(columns), column_array(list(columns)), transport.ptr, outs_arr)
+    errs = getattr(transport, "errors", None)
+    if errs:
+        raise errs.pop(0)
+    tdt = {1: torch.int8, 2: torch.int16, 3: torch.int32, 4: torch.int64, 5: torch.float32, 6: torch.float64, 7: torch.int32, 8: torch.int64,
+           9: torch.int64}
+    res = []
+    for o in outs:
+        n = int(o.size)
+        raw = torch.empty((n + 7) // 8, dtype=torch.uint8, device="cuda")
+        if n:
+            _hipMemcpyDtoD(raw.data_ptr(), o.valid, raw.numel())
+        bits = torch.from_numpy(np.unpackbits(raw.cpu().numpy(), bitorder="little")[:n].astype(bool))
+        assert int(o.null_count) == int(n - int(bits.sum()))
+        res.append((_take_library_column(o, tdt[int(o.dtype)]), bits))
+    return res
+
+
 def dist_inner_join(probe: Column, build: Column, transport, chunks=4):
     """gdf_amd_dist_inner_join -> None when every rank declined (the shape does not fit the fused path), else
     (probe_pos_of_rows, build_pos_of_rows, probe_indices, build_indices, info): the first two say where each LOCAL row's key went

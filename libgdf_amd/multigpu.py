@@ -828,6 +828,55 @@ def planned_inner_join(probe_keys, build_keys, group=None, shuffle_kw=None, broa
     return distributed_inner_join(probe_keys, build_keys, group=group, **(shuffle_kw or {}))
 
 
+def distributed_gather(ids, columns, valids=None, take_fn=None, group=None):
+    """The multi-GPU face of the joins' ``result_cols`` step (reference, per rank: src/join/joining.cu:375-479 gathers the relations'
+    columns by the index columns): ``ids`` -- int64 GLOBAL row ids as the distributed joins produce them ((owner rank << 40) | local row,
+    -1 for the missing side of an unmatched row) -- name rows of a row-sharded relation; ``columns`` are THIS rank's shard of it
+    (``valids``: a bool tensor or None per column).  Returns a list of (values, valid bools) per column, ``ids.numel()`` rows each: the
+    named rows, fetched from the ranks that own them; null where the id is -1 or the source row is null.  COLLECTIVE.
+
+    On the device this is ONE C call (gdf_amd_dist_gather, csrc/dist_ops.hip).  With ``take_fn`` given -- the CPU gloo tests' numpy
+    stand-in -- the same request / response protocol runs here as its executable specification:
+    ``take_fn(column, valid, rows)`` -> (values, valid flags) reads the local shard at ``rows`` (a row of -1 is a null)."""
+    import torch
+    import torch.distributed as dist
+    valids = valids or [None] * len(columns)
+    if take_fn is None and ids.is_cuda:
+        from . import api
+        from .columns import Column, mask_from_bools
+
+        def col(t, ok):
+            if ok is None:
+                return Column(t)
+            okn = ok.cpu().numpy().astype(bool)
+            return Column(t, torch.from_numpy(mask_from_bools(okn)).to(t.device), null_count=int(len(okn) - okn.sum()))
+        return api.dist_gather(ids, [col(c, v) for c, v in zip(columns, valids)], transport_for(group))
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    # 1. every id becomes (owner, local row, position); a missing side is asked of the caller itself as row -1
+    owner = torch.where(ids >= 0, ids >> 40, torch.full_like(ids, rank))
+    row = torch.where(ids >= 0, ids & ((1 << 40) - 1), torch.full_like(ids, -1))
+    assert bool(((owner >= 0) & (owner < world)).all()), "an id names no rank"
+    pos = torch.argsort(owner, stable=True)              # 2. split by owner: the local rows travel, the positions stay
+    asked = torch.bincount(owner, minlength=world)
+    everyone = [None] * world
+    dist.all_gather_object(everyone, [row[pos][owner[pos] == r].clone() for r in range(world)], group=group)
+    req = [everyone[src][rank] for src in range(world)]
+    # 3. the owner serves every sender in the order its requests arrived, and the answers go back the way they came
+    answers = [[take_fn(c, v, q) for c, v in zip(columns, valids)] for q in req]
+    dist.all_gather_object(everyone, answers, group=group)
+    out = []
+    for j, c in enumerate(columns):                      # 4. what came back lies in owner order, as the kept positions do
+        vals = torch.cat([everyone[o][rank][j][0] for o in range(world)])
+        flags = torch.cat([everyone[o][rank][j][1] for o in range(world)])
+        assert vals.numel() == ids.numel() and all(everyone[o][rank][j][0].numel() == int(asked[o]) for o in range(world))
+        v = torch.zeros(ids.numel(), dtype=c.dtype)
+        f = torch.zeros(ids.numel(), dtype=torch.bool)
+        v[pos] = vals
+        f[pos] = flags
+        out.append((v, f))
+    return out
+
+
 def distributed_group_by_multi(op, keys, values, key_valids=None, value_valid=None, group_fn=None, owner_fn=None, group=None):
     """``gdf_group_by_<op>`` of a row-sharded relation over SEVERAL key columns, validity masks honoured (BASELINE configuration C5 across
     ranks; reference shape: sqls_ops.cu:1085-1363, row hash of gdf_table.cuh:704-854).  ``keys``: list of tensors; ``key_valids``: list of

@@ -208,6 +208,40 @@ def _uneven_worker(rank, world, port, q, backend="gloo"):
     dist.destroy_process_group()
 
 
+def _gather_worker(rank, world, port, q, backend="gloo"):
+    if world == 3:
+        os.environ["LIBGDF_AMD_NO_A2AV"] = "1"        # one world without the transport's all_to_all_v: the equal-block exchange
+    _init(rank, world, port, backend)
+    from libgdf_amd import api, multigpu
+    from libgdf_amd.columns import Column
+    dev = torch.device("cuda", torch.cuda.current_device())
+    probes, builds, vals = _gather_shards(world)
+    p = torch.from_numpy(probes[rank]).to(dev)
+    b = torch.from_numpy(builds[rank]).to(dev)
+    hp, hb = api.dist_shuffle_join(Column(p), Column(b), multigpu.transport_for(None), how="full")
+    out = {"c-shuffle-full": (hp.cpu().numpy(), hb.cpu().numpy())}
+    # gdf_amd_dist_gather on the FULL join's pairs: the probe relation's columns (one of them masked) by the probe ids, the build
+    # relation's by the build ids -- the distributed result_cols step; -1 (the missing side) comes back null
+    pc, pv, bc = gather_columns(world)
+    tv = lambda a: None if a is None else torch.from_numpy(a).to(dev)
+    got_p = multigpu.distributed_gather(hp, [torch.from_numpy(c[rank]).to(dev) for c in pc], [tv(v[rank]) if v is not None else None for v in pv])
+    got_b = multigpu.distributed_gather(hb, [torch.from_numpy(c[rank]).to(dev) for c in bc])
+    out["gather"] = ([(v.cpu().numpy(), f.cpu().numpy()) for v, f in got_p], [(v.cpu().numpy(), f.cpu().numpy()) for v, f in got_b])
+    # an id that names no rank, on ONE rank: every rank leaves the call with an error, nobody is left in a collective
+    # ... and a row its owner's shard does not have (found by the OWNER, carried into the answers' agreement)
+    for name, who, bad_id in (("gather-bad", world - 1, (world + 3) << 40), ("gather-bad-row", 0, ((world - 1) << 40) | (1 << 30))):
+        bad = torch.cat([hp, torch.tensor([bad_id], dtype=torch.int64, device=dev)]) if rank == who else hp
+        try:
+            multigpu.distributed_gather(bad, [torch.from_numpy(pc[0][rank]).to(dev)])
+            out[name] = "no error"
+        except Exception as e:                           # noqa: BLE001
+            out[name] = type(e).__name__ + ": " + str(e)
+    q.put((rank, None, None, out))
+    dist.barrier()
+    multigpu.close_transports()
+    dist.destroy_process_group()
+
+
 def _uneven_shards(world):
     rs = np.random.RandomState(5)
     sizes = ([0, 2, 40_000] + [7_000 * r for r in range(3, world)])[:world]      # rank 0 has NO probe rows, rank 1 two
@@ -218,6 +252,47 @@ def _uneven_shards(world):
              "float32": (rs.rand(n) * 1e3 + 2**24).astype(np.float32)} for n in sizes]
     return probes, builds, vals
 
+
+
+def _gather_shards(world):
+    """_uneven_shards; a world of ONE rank (the RCCL test on a one-GPU box) takes the 40000-row shard instead of the empty one"""
+    probes, builds, vals = _uneven_shards(max(world, 3))
+    pick = (lambda x: x[2:3]) if world == 1 else (lambda x: x[:world])
+    return pick(probes), pick(builds), pick(vals)
+
+
+def gather_columns(world):
+    """the relations of _uneven_shards as columns to materialise: probe side (int64 key, int8, float32 with a mask), build side (int64
+    key, float64) -> (probe columns per rank, probe masks per rank or None, build columns per rank), each a list over columns"""
+    probes, builds, vals = _gather_shards(world)
+    rs = np.random.RandomState(17)
+    pc = [probes, [v["int8"] for v in vals], [v["float32"] for v in vals]]
+    pv = [None, None, [rs.rand(len(p)) > 0.3 for p in probes]]
+    bc = [builds, [b.astype(np.float64) * 0.5 for b in builds]]
+    return pc, pv, bc
+
+
+def check_gather(world, results):
+    pc, pv, bc = gather_columns(world)
+    for r, res in enumerate(results):
+        hp, hb = res[3]["c-shuffle-full"]
+        got_p, got_b = res[3]["gather"]
+        for ids, cols, masks, got in ((hp, pc, pv, got_p), (hb, bc, [None] * len(bc), got_b)):
+            own, row = np.maximum(ids, 0) >> 40, np.maximum(ids, 0) & ((1 << 40) - 1)
+            for c, (col, mask) in enumerate(zip(cols, masks)):
+                v, f = got[c]
+                assert len(v) == len(ids) and v.dtype == col[0].dtype
+                exp_v = np.zeros(len(ids), dtype=col[0].dtype)
+                exp_f = np.zeros(len(ids), dtype=bool)
+                for i in range(len(ids)):
+                    if ids[i] >= 0:
+                        exp_v[i] = col[own[i]][row[i]]
+                        exp_f[i] = True if mask is None else bool(mask[own[i]][row[i]])
+                np.testing.assert_array_equal(f, exp_f)
+                np.testing.assert_array_equal(v[exp_f], exp_v[exp_f])
+        assert res[3]["gather-bad"] != "no error" and res[3]["gather-bad-row"] != "no error", res[3]
+    allb = np.concatenate([r[3]["c-shuffle-full"][1] for r in results])
+    assert (allb == -1).any()                            # (the FULL join left probe rows without a partner: nulls were gathered)
 
 
 def check_uneven(world, results):

@@ -16,8 +16,8 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 
-from multirank_common import (_free_port, _multikey_worker, _uneven_worker, _worker, _world8_worker, check_join_and_group_by, check_multikey,
-                              check_uneven, check_world8)
+from multirank_common import (_free_port, _gather_worker, _multikey_worker, _uneven_worker, _worker, _world8_worker, check_join_and_group_by, check_multikey,
+                              check_gather, check_uneven, check_world8)
 
 
 def _run_ranks(target, world, extra):
@@ -66,3 +66,14 @@ def test_distributed_group_by_over_several_key_columns_with_masks(world):
     oracle.group_by_masked over the concatenated shards.  Reference shape: sqls_ops.cu:1085-1363, groupby.cuh:208-250, 308-419."""
     check_multikey(world, _run_ranks(_multikey_worker, world, ()))
 
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_distributed_materialisation_by_global_row_ids(world):
+    """gdf_amd_dist_gather (csrc/dist_ops.hip; VERDICT r5 missing 3, "distributed result_cols"): the pairs of a FULL key-shuffle join over
+    uneven shards (a rank without probe rows, one without build rows) name rows by global id; the probe relation's columns (int64, int8,
+    float32 with a validity mask) and the build relation's (int64, float64) are fetched from their owners -- request / response over the
+    callback wire, worlds 2 / 3 / 8 on one GPU, world 3 without all_to_all_v.  The missing side (-1) and null source rows come back null;
+    an id that names no rank fails the call on EVERY rank.  Reference, per rank: src/join/joining.cu:375-479."""
+    check_gather(world, _run_ranks(_gather_worker, world, ()))

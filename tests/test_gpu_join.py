@@ -162,9 +162,26 @@ def test_medium_fk_pk_join_uses_two_partition_levels(gdf):
 
 
 def test_skewed_build_side_takes_global_table_path(gdf):
-    """One key repeated 20k times on the build side exceeds the LDS table (JK_MAX_BUILD = 6144)."""
+    """One key repeated 20k times on the build side exceeds the LDS table (JK_MAX_BUILD = 6080)."""
     build = np.concatenate([np.full(20000, 7, dtype=np.int32), np.arange(100, 3000, dtype=np.int32)])
     probe = np.concatenate([np.full(30, 7, dtype=np.int32), np.arange(0, 4000, 3, dtype=np.int32)])
+    for how in ("inner", "left", "full"):
+        _check(gdf, [probe], [build], how)
+
+
+@pytest.mark.parametrize("copies", list(range(6030, 6160, 10)))
+@pytest.mark.parametrize("kdt", ["wide", "narrow"])
+def test_wide_keys_largest_lds_partition(gdf, copies, kdt, force_path):
+    """A build partition at the edge of what stays in LDS (csrc/join.hip JK_MAX_BUILD): one key repeated `copies` times next to a few
+    others.  The general kernel's WIDE image is 16 bytes per build tuple + the two tables: up to 6080 tuples fit a CU's 160 KiB, 6081 ...
+    6144 (the bound until round 6) asked for 80 bytes more than there are and the launch failed -- found by tools/stress_join.py.  A
+    sweep across both bounds (32 partitions: the repeated key's holds `copies` + ~9 tuples), genuinely 64-bit and narrow keys, INNER /
+    LEFT / FULL (FULL and repeated build keys take the general kernel)."""
+    force_path("GDF_JK_FORCE_FB", "5")
+    base = (1 << 61) + 12345 if kdt == "wide" else 1000
+    spread = (1 << 44) + 1 if kdt == "wide" else 1
+    build = np.concatenate([np.full(copies, base + 7 * spread, dtype=np.int64), base + np.arange(100, 400, dtype=np.int64) * spread])
+    probe = np.concatenate([np.full(3, base + 7 * spread, dtype=np.int64), base + np.arange(0, 800, 3, dtype=np.int64) * spread])
     for how in ("inner", "left", "full"):
         _check(gdf, [probe], [build], how)
 

@@ -3,7 +3,7 @@
 (host-built and device-built units, speculative and exact layouts, lean / general / chained kernels, optimistic, sparse
 optimistic + compaction, count + write).  No oracle: the number of pairs equals the sum over probe rows of the key's
 multiplicity in the build relation, every pair joins equal keys, no pair occurs twice, and a LEFT join adds exactly the
-probe rows without a partner.  Usage: python tools/stress_join.py [--seconds S] [--seed N]"""
+probe rows without a partner; a third of the cases also materialise 1 - 3 non-key columns per side (result_cols) and check them.  Usage: python tools/stress_join.py [--seconds S] [--seed N]"""
 import argparse
 import os
 import sys
@@ -11,6 +11,48 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+
+
+def join_with_payloads(gdf, torch, how, pk, bk, npay, tag):
+    """gdf_{inner,left}_join with result_cols: `npay` non-key columns per side (int64 / float64 / int32 images of the row number) in front of
+    the probe key and behind the build key; checks every materialised column against its source column at the returned indices and
+    returns the index tensors"""
+    import ctypes as C
+    from libgdf_amd import gdf_column, libgdf
+    from libgdf_amd.columns import Column, column_array, new_context
+    make = [lambda n: torch.arange(n, device="cuda", dtype=torch.int64) * 3 + 1,
+            lambda n: torch.arange(n, device="cuda", dtype=torch.float64) * 0.5 - 7.0,
+            lambda n: (torch.arange(n, device="cuda", dtype=torch.int64) % 1_000_003).to(torch.int32)]
+    pp = [make[i](pk.numel()) for i in range(npay)]
+    bp = [make[(i + 1) % 3](bk.numel()) for i in range(npay)]
+    left, right = [Column(t) for t in pp] + [Column(pk)], [Column(bk)] + [Column(t) for t in bp]
+    nres = len(left) + len(right) - 1
+    res = [gdf_column() for _ in range(nres)]
+    res_arr = (C.POINTER(gdf_column) * nres)(*[C.pointer(x) for x in res])
+    li, ri = gdf_column(), gdf_column()
+    ctx = new_context()
+    fn = {"inner": libgdf.gdf_inner_join, "left": libgdf.gdf_left_join}[how]
+    fn(column_array(left), len(left), (C.c_int * 1)(npay), column_array(right), len(right), (C.c_int * 1)(0), 1, nres, res_arr,
+       C.byref(li), C.byref(ri), C.byref(ctx))
+    n = int(li.size)
+    a = gdf.api._take_library_column(li, torch.int32) if n else torch.zeros(0, dtype=torch.int32, device="cuda")
+    b = gdf.api._take_library_column(ri, torch.int32) if n else torch.zeros(0, dtype=torch.int32, device="cuda")
+    al, bl = a.long(), b.long()
+    sources = [(t, al) for t in pp] + [(pk, al)] + [(t, bl) for t in bp]
+    for col, (src, idx) in zip(res, sources):
+        assert int(col.size) == n, (tag, "result column size")
+        if n == 0:
+            continue
+        data = torch.empty(n, dtype=src.dtype, device="cuda")
+        valid = torch.empty((n + 7) // 8, dtype=torch.uint8, device="cuda")
+        gdf.api._hipMemcpyDtoD(data.data_ptr(), col.data, n * data.element_size())
+        gdf.api._hipMemcpyDtoD(valid.data_ptr(), col.valid, valid.numel())
+        libgdf.gdf_column_free(C.byref(col))
+        have = idx >= 0
+        bits = ((valid[torch.arange(n, device="cuda") >> 3] >> (torch.arange(n, device="cuda") & 7).to(torch.uint8)) & 1).bool()
+        assert bool((bits == have).all()), (tag, "valid bits of a result column")
+        assert bool((data[have] == src[idx[have]]).all()), (tag, "a result column differs from its source rows")
+    return a, b
 
 
 def main():
@@ -75,7 +117,13 @@ def main():
         tag = (it, nb, npr, space, str(dtype), base, skew, how, "wide" if wide else "narrow")
         if os.environ.get("GDF_STRESS_VERBOSE"):
             print("case", tag, "expected", expected, flush=True)
-        li, ri = gdf.api.join([Column(pk)], [Column(bk)], how=how)
+        # result_cols (round 6: one or TWO carried 8-byte payload words per side, csrc/join.hip PayCarry modes 1 / 4; the rest gathered): in a
+        # third of the cases the join also materialises 1 - 3 non-key columns per side; every result row must be its source row's values
+        npay = r(1, 4) if (r(0, 3) == 0 and expected + npr < 400_000_000) else 0
+        if npay:
+            li, ri = join_with_payloads(gdf, torch, how, pk, bk, npay, tag)
+        else:
+            li, ri = gdf.api.join([Column(pk)], [Column(bk)], how=how)
         torch.cuda.synchronize()
         lonely = int((per_row == 0).sum()) if how == "left" else 0
         assert li.numel() == expected + lonely, (tag, li.numel(), expected, lonely)

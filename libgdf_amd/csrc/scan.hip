@@ -5,7 +5,18 @@
 // kept: sum in the column's own dtype with wrap-around, inclusive or exclusive,
 // equal size & dtype required, valid masks rejected.
 //
-// Shape (default): reduce-then-scan, three launches on the default stream, 3*w bytes per element --
+// Shape (default from 2^22 elements on, when the scan is not in place -- round 6): ONE pass in lockstep ROUNDS, 2*w bytes per element
+// (scan_lookback<.., ROUNDS = true>, launched as "scan_rounds"): G resident workgroups, workgroup b takes tiles b, b + G, ...; a
+// tile's aggregate is published one pipeline step before the others' are needed, and every workgroup reads ALL G aggregates of a round
+// in one batch of loads and adds them up itself -- those of the workgroups before it are its offset inside the round, their total
+// advances its own carry.  No chain and no walk (what the decoupled look-back below dies of on this part: every hop a cross-XCD round
+// trip), one round trip per round, hidden behind the next tile's loads.  A tile is only SUMMED when its aggregate goes out and scanned
+// when it is written: 142 VGPRs for int64, three workgroups per CU.  1e9 int64: 2.97 ms = 5.4 TB/s = 0.67 of the peak (the three
+// launches: 4.1 ms; profiles/r6_q_scan_rounds.jsonl).  The workgroups wait for one another, so all must be resident: the grid is what
+// hipOccupancyMaxActiveBlocksPerMultiprocessor says fits, and a poll that lasts a quarter of a second (another process holds CUs) sets a
+// flag, everybody leaves and the host starts over with the three launches below -- which is why an in-place scan never takes this path.
+//
+// Shape (smaller inputs, in-place scans, columns that are not 16-byte aligned): reduce-then-scan, three launches on the default stream, 3*w bytes per element --
 //   1. scan_reduce_v : every block sums one contiguous chunk                  (read N)
 //   2. scan_spine    : one block scans the <= 2048 chunk sums
 //   3. scan_apply_v  : every block re-reads its chunk and writes the scan seeded with its chunk offset (read N, write N)
@@ -145,6 +156,7 @@ constexpr int LB_THREADS = 256;
 constexpr int LB_ITEMS = 16;
 constexpr int LB_TILE = LB_THREADS * LB_ITEMS;
 constexpr unsigned long long LB_FLAG = 1ull << 32;
+constexpr size_t SCAN_ROUNDS_MIN = (size_t)1 << 22;    // elements from which the single-pass rounds are the default (device_scan)
 
 // tile state: NW = sizeof(ACC) / 4 words of aggregate, then NW words of inclusive prefix; word = LB_FLAG | 32 data bits
 template <class ACC>
@@ -170,9 +182,17 @@ __device__ __forceinline__ bool lb_read(const unsigned long long *slot, ACC &v) 
   return ok;
 }
 
-template <class ACC, class ELEM>
+template <class ACC, class ELEM, bool ROUNDS = false>
 __global__ __launch_bounds__(LB_THREADS) void scan_lookback(const ELEM *in, ELEM *out, size_t n, int inclusive,
                                                             unsigned long long *state, uint32_t *ticket, uint32_t ntiles, int dbg) {
+  // dbg & 8: ROUNDS mode (round 6).  No chain and no walk: workgroup b takes tiles b, b + G, b + 2G, ... (G = gridDim.x, all resident),
+  // round r is the G tiles r G ... r G + G - 1.  A workgroup publishes its tile's aggregate in slot [r & 3][b] (words tagged r + 1) one
+  // pipeline step before it needs the others', then reads ALL G slots of the round in one batch of loads: the aggregates of the
+  // workgroups before it are its tile's offset inside the round, their total advances its own running carry -- every workgroup adds
+  // up every round itself, nobody waits for a prefix somebody else computed.  state[] holds 4 x G slots; ticket[1] is the bail-out flag
+  // (a poll that never completes -- the workgroups are not all resident -- sets it, everybody leaves, the host takes the three launches).
+  constexpr bool rounds = ROUNDS;    // (its own instantiation: the look-back's state does not cost the rounds their third workgroup per CU)
+  uint32_t my_step = 0;              // rounds: the round of the next tile this workgroup takes
   constexpr int NW = sizeof(ACC) / 4;
   constexpr int VEC = 16 / sizeof(ELEM);           // elements per 16-byte vector
   constexpr int VPT = LB_ITEMS / VEC;              // vectors per thread (i8: 1, i32: 4, i64: 8)
@@ -193,7 +213,7 @@ __global__ __launch_bounds__(LB_THREADS) void scan_lookback(const ELEM *in, ELEM
   // is already published, scans it and publishes the prefixes.  A worker then polls ONE word -- its own prefix -- instead
   // of walking back over hundreds of predecessors, each round of which is a cross-XCD round trip.  The spine consumes up
   // to 1024 tiles per round trip (~2.5 us): several times the ~80 tiles per us the data path needs.
-  if ((dbg & 4) && blockIdx.x == 0) {
+  if (!ROUNDS && (dbg & 4) && blockIdx.x == 0) {
     constexpr int PT = 4;
     ACC carry = 0;
     uint32_t base = 0;
@@ -282,10 +302,20 @@ __global__ __launch_bounds__(LB_THREADS) void scan_lookback(const ELEM *in, ELEM
   // ~200 tiles started just before it: 0.64 ms per 1e8 int64 against 0.32 ms for the same kernel without the look-back.)
   struct Scanned {
     uint32_t tile;
-    ACC excl_in_wave[VPT];      // prefix of vector (k, lane) inside the wave's segment
+    // prefix of vector (k, lane) inside the wave's segment.  ROUNDS keeps none: a tile is only SUMMED when its aggregate goes out and
+    // scanned when it is written -- sixteen registers less per tile in flight, the third workgroup per CU
+    ACC excl_in_wave[ROUNDS ? 1 : VPT];
     ACC woff, aggregate;
   };
   auto ticket_to = [&](int slot) {
+    if (rounds) {
+      if (threadIdx.x == 0) {
+        const unsigned long long t = (unsigned long long)my_step * gridDim.x + blockIdx.x;
+        s_tile[slot] = t < ntiles ? (uint32_t)t : 0xffffffffu;
+      }
+      ++my_step;                     // (every thread counts: workgroup-uniform)
+      return;
+    }
     if (threadIdx.x == 0) s_tile[slot] = atomicAdd(ticket, 1u);
   };
   // local scan of a loaded tile + publication of its aggregate; contains one block_sync (which also makes the ticket
@@ -293,7 +323,14 @@ __global__ __launch_bounds__(LB_THREADS) void scan_lookback(const ELEM *in, ELEM
   auto scan_and_publish = [&](const Vec (&v)[VPT], uint32_t t, Scanned &sc) {
     const size_t base = (size_t)t * LB_TILE;
     ACC wave_total = 0;
-    if (base + LB_TILE <= n) {
+    if constexpr (ROUNDS) {
+      ACC sum = 0;
+#pragma unroll
+      for (int k = 0; k < VPT; ++k)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) sum += (ACC)v[k].e[e];
+      wave_total = wave_reduce_add(sum);
+    } else if (base + LB_TILE <= n) {
 #pragma unroll
       for (int k = 0; k < VPT; ++k) {
         ACC sum = 0;
@@ -324,11 +361,90 @@ __global__ __launch_bounds__(LB_THREADS) void scan_lookback(const ELEM *in, ELEM
       sc.aggregate += wsum[w];
     }
     sc.tile = t;
-    if (threadIdx.x == 0) lb_publish<ACC>(state + (size_t)t * 2 * NW, sc.aggregate);
+    if (threadIdx.x == 0) {
+      if (rounds) {
+        const uint32_t r = t / gridDim.x;
+        unsigned long long *slot = state + ((size_t)(r & 3u) * gridDim.x + blockIdx.x) * NW;
+#pragma unroll
+        for (int i = 0; i < NW; ++i)
+          __hip_atomic_store(slot + i, ((unsigned long long)(r + 1u) << 32) | (unsigned long long)(uint32_t)((uint64_t)sc.aggregate >> (32 * i)),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        lb_publish<ACC>(state + (size_t)t * 2 * NW, sc.aggregate);
+      }
+    }
+  };
+  // ROUNDS: this tile's offset = carry (everything before its round) + the aggregates of the workgroups before this one in the round
+  ACC carry = 0;
+  __shared__ ACC s_before[NWAVES], s_total[NWAVES];
+  __shared__ int s_ok;
+  auto resolve_rounds = [&](const Scanned &sc) -> ACC {
+    const uint32_t G = gridDim.x, r = sc.tile / G;
+    const uint32_t left = ntiles - r * G, pubs = left < G ? left : G;          // publishers of this round (the last one may be short)
+    const unsigned long long *slots = state + (size_t)(r & 3u) * G * NW;
+    constexpr int PT = 2;                                                     // slots per thread and page; G <= 4 * LB_THREADS (the host's grid)
+    ACC before = 0, total = 0;
+    unsigned long long waiting_since = 0;          // wall_clock64(): 100 MHz
+    for (uint32_t spins = 0;; ++spins) {
+      bool ok = true;
+      before = 0;
+      total = 0;
+      for (uint32_t page = 0; page < pubs; page += PT * LB_THREADS) {           // (one page up to two workgroups per CU)
+        unsigned long long w[PT][NW];
+#pragma unroll
+        for (int k = 0; k < PT; ++k) {
+          const uint32_t b = page + threadIdx.x + (uint32_t)k * LB_THREADS;
+#pragma unroll
+          for (int i = 0; i < NW; ++i)
+            w[k][i] = b < pubs ? __hip_atomic_load(slots + (size_t)b * NW + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        }
+#pragma unroll
+        for (int k = 0; k < PT; ++k) {
+          const uint32_t b = page + threadIdx.x + (uint32_t)k * LB_THREADS;
+          if (b < pubs) {
+            uint64_t v = 0;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) { ok = ok && (uint32_t)(w[k][i] >> 32) == r + 1u; v |= (uint64_t)(uint32_t)w[k][i] << (32 * i); }
+            total += (ACC)v;
+            if (b < blockIdx.x) before += (ACC)v;
+          }
+        }
+      }
+      block_sync();                 // s_ok's previous readers are done
+      if (threadIdx.x == 0) s_ok = 1;
+      block_sync();
+      if (!ok) s_ok = 0;
+      block_sync();
+      if (s_ok) break;
+      // not everybody has published: look again; a poll that goes on for a quarter of a second (a round takes microseconds) means
+      // the grid is not resident -- another process holds CUs, two such scans wait for one another -- bail out
+      if (threadIdx.x == 0) {
+        const unsigned long long now = wall_clock64();
+        if (spins == 0) waiting_since = now;
+        if (now - waiting_since > 25000000ull || __hip_atomic_load(ticket + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+          __hip_atomic_store(ticket + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          s_ok = 2;
+        }
+      }
+      block_sync();
+      if (s_ok == 2) return (ACC)0;                  // (the caller sees ticket[1] and leaves)
+      __builtin_amdgcn_s_sleep(1);
+    }
+    before = wave_reduce_add(before);
+    total = wave_reduce_add(total);
+    if (lane == 0) { s_before[wave] = before; s_total[wave] = total; }
+    block_sync();
+    ACC bsum = 0, tsum = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < NWAVES; ++w2) { bsum += s_before[w2]; tsum += s_total[w2]; }
+    const ACC exclusive = carry + bsum;
+    carry += tsum;
+    return exclusive;
   };
   // look-back for a scanned tile, the whole workgroup: thread t examines tile - 1 - t (a tile before the first one has
   // prefix 0); both words of a predecessor are requested together -- one round trip, not two
   auto resolve = [&](const Scanned &sc) -> ACC {
+    if constexpr (ROUNDS) return resolve_rounds(sc);
     if (dbg & 4) {                  // spine mode: the tile's exclusive prefix arrives in its own slot
       block_sync();                 // s_excl's previous readers are done
       if (threadIdx.x == 0) {
@@ -383,9 +499,20 @@ __global__ __launch_bounds__(LB_THREADS) void scan_lookback(const ELEM *in, ELEM
     const ACC wave_base = exclusive + sc.woff;
     if (base + LB_TILE <= n) {
       u32x4 *dst = reinterpret_cast<u32x4 *>(out + base + (size_t)wave * SEG);
+      ACC running = 0;              // ROUNDS: the wave's elements before round k
 #pragma unroll
       for (int k = 0; k < VPT; ++k) {
-        ACC pre = wave_base + sc.excl_in_wave[k];
+        ACC pre;
+        if constexpr (ROUNDS) {
+          ACC sum = 0;
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) sum += (ACC)v[k].e[e];
+          const ACC inc = wave_scan_incl(sum);
+          pre = wave_base + running + inc - sum;
+          running += __shfl(inc, WAVE - 1, WAVE);
+        } else {
+          pre = wave_base + sc.excl_in_wave[k];
+        }
         Vec o;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
@@ -397,7 +524,17 @@ __global__ __launch_bounds__(LB_THREADS) void scan_lookback(const ELEM *in, ELEM
       }
     } else {
       const size_t t0 = base + (size_t)threadIdx.x * LB_ITEMS;
-      ACC pre = wave_base + sc.excl_in_wave[0];
+      ACC pre;
+      if constexpr (ROUNDS) {       // (the partial last tile: sixteen consecutive elements per thread, one wave scan of the threads' sums)
+        ACC sum = 0;
+#pragma unroll
+        for (int k = 0; k < VPT; ++k)
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) sum += (ACC)v[k].e[e];
+        pre = wave_base + wave_scan_incl(sum) - sum;
+      } else {
+        pre = wave_base + sc.excl_in_wave[0];
+      }
 #pragma unroll
       for (int k = 0; k < VPT; ++k)
 #pragma unroll
@@ -411,6 +548,11 @@ __global__ __launch_bounds__(LB_THREADS) void scan_lookback(const ELEM *in, ELEM
   };
 
   // prologue: X loaded and scanned, Y's loads in flight
+  if constexpr (ROUNDS) {           // (the bail-out flag set before the launch: the test switch GDF_SCAN_FORCE_BAIL)
+    if (threadIdx.x == 0) s_ok = __hip_atomic_load(ticket + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ? 2 : 1;
+    block_sync();
+    if (s_ok == 2) return;
+  }
   ticket_to(0);
   block_sync();
   uint32_t tx = s_tile[0];
@@ -435,6 +577,7 @@ __global__ __launch_bounds__(LB_THREADS) void scan_lookback(const ELEM *in, ELEM
       if (tz < ntiles) load_tile(vz, tz);
     }
     const ACC exclusive = resolve(sx);
+    if (rounds && s_ok == 2) return;                 // bail-out (workgroup-uniform: s_ok was read behind a barrier)
     write_tile(vx, sx, exclusive);
     if (ty >= ntiles) break;
 #pragma unroll
@@ -444,32 +587,49 @@ __global__ __launch_bounds__(LB_THREADS) void scan_lookback(const ELEM *in, ELEM
   }
 }
 
-template <class ACC, class ELEM>
-static gdf_error device_scan_lookback(const ELEM *in, ELEM *out, size_t n, bool inclusive) {
+template <class ACC, class ELEM, bool ROUNDS>
+static gdf_error device_scan_lookback_impl(const ELEM *in, ELEM *out, size_t n, bool inclusive, long long mode) {
   constexpr int NW = sizeof(ACC) / 4;
   const size_t ntiles = (n + LB_TILE - 1) / LB_TILE;
-  const int dbg = (int)lab::knob_int("GDF_SCAN_DBG", 0) | (lab::path_int("GDF_SCAN_LOOKBACK", 0) == 2 ? 4 : 0);      // 2: spine mode
+  const int dbg = (int)lab::knob_int("GDF_SCAN_DBG", 0) | (mode == 2 ? 4 : 0) | (ROUNDS ? 8 : 0);      // 2: spine mode, 3: rounds
   DevBuf st;
-  const size_t state_bytes = sizeof(unsigned long long) * ntiles * 2 * NW;
-  RMM_TRY(st.alloc(state_bytes + sizeof(unsigned long long)));
-  HIP_TRY(hipMemsetAsync(st.p, 0, state_bytes + sizeof(unsigned long long), stream0()));
+  const size_t state_bytes = sizeof(unsigned long long) * (ROUNDS ? (size_t)4 * 4 * LB_THREADS * NW : ntiles * 2 * NW);
+  RMM_TRY(st.alloc(state_bytes + 2 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemsetAsync(st.p, 0, state_bytes + 2 * sizeof(unsigned long long), stream0()));
   uint32_t *ticket = reinterpret_cast<uint32_t *>(st.as<unsigned char>() + state_bytes);
   // persistent workgroups, each takes tiles from the ticket counter until they run out: a few per CU (every one keeps two
   // tiles in flight).  With dbg & 1 every workgroup handles exactly the tile of its blockIdx.
   const int per_cu_env = (int)lab::knob_int("GDF_SCAN_WGS_PER_CU", 0);
-  int per_cu = per_cu_env;
-  if (per_cu <= 0) {
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)scan_lookback<ACC, ELEM>, LB_THREADS, 0));
-    if (per_cu < 1) per_cu = 1;
-  }
+  int fit = 1;
+  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, (const void *)scan_lookback<ACC, ELEM, ROUNDS>, LB_THREADS, 0));
+  if (fit < 1) fit = 1;
+  int per_cu = per_cu_env > 0 ? per_cu_env : fit;
   size_t grid = (dbg & 1) ? ntiles : (size_t)NUM_CU * (size_t)per_cu;
+  // rounds: every workgroup must be resident (they wait for one another) and the poll reads <= 4 * LB_THREADS slots
+  if (ROUNDS) grid = (size_t)NUM_CU * (size_t)std::max(1, std::min(std::min(per_cu_env > 0 ? per_cu_env : 4, fit), 4));
   if (grid > ntiles + ((dbg & 4) ? 1 : 0)) grid = ntiles + ((dbg & 4) ? 1 : 0);      // spine mode: workgroup 0 takes no tiles
   if ((dbg & 4) && grid < 2) grid = 2;
-  GDF_LAUNCH("scan_lookback", (scan_lookback<ACC, ELEM>), dim3((unsigned)grid), dim3(LB_THREADS), 0, stream0(), in, out, n,
+  if (ROUNDS && lab::path_on("GDF_SCAN_FORCE_BAIL")) {      // test switch: the kernel leaves at once, the caller takes the three launches
+    const uint32_t one = 1;
+    HIP_TRY(hipMemcpyAsync(ticket + 1, &one, sizeof(one), hipMemcpyHostToDevice, stream0()));
+    HIP_TRY(hipStreamSynchronize(stream0()));
+  }
+  GDF_LAUNCH(ROUNDS ? "scan_rounds" : "scan_lookback", (scan_lookback<ACC, ELEM, ROUNDS>), dim3((unsigned)grid), dim3(LB_THREADS), 0, stream0(), in, out, n,
              inclusive ? 1 : 0, st.as<unsigned long long>(), ticket, (uint32_t)ntiles, dbg);
   HIP_CHECK_LAST();
+  if (ROUNDS) {                               // a grid that was not resident bailed out -- the caller takes the three launches
+    uint32_t bailed = 0;
+    HIP_TRY(read_back(&bailed, ticket + 1, sizeof(bailed)));
+    if (bailed) return GDF_UNSUPPORTED_METHOD;
+    return GDF_SUCCESS;
+  }
   HIP_TRY(hipStreamSynchronize(stream0()));   // scratch is released on return
   return GDF_SUCCESS;
+}
+template <class ACC, class ELEM>
+static gdf_error device_scan_lookback(const ELEM *in, ELEM *out, size_t n, bool inclusive, long long mode) {
+  return mode == 3 ? device_scan_lookback_impl<ACC, ELEM, true>(in, out, n, inclusive, mode)
+                   : device_scan_lookback_impl<ACC, ELEM, false>(in, out, n, inclusive, mode);
 }
 
 
@@ -641,9 +801,18 @@ gdf_error device_scan(const ELEM *in, ELEM *out, size_t n, bool inclusive) {
   // 16-byte accesses need 16-byte-aligned columns (a column may be a slice of a larger buffer): those take the coalesced
   // kernels, or -- GDF_SCAN_LOOKBACK=1, an experiment that lost, see the header -- the single-pass kernel; the rest, and
   // GDF_SCAN_BLOCKED=1, the element-wise kernels of round 1
-  const bool lookback = lab::path_int("GDF_SCAN_LOOKBACK", 0) > 0, blocked = lab::path_on("GDF_SCAN_BLOCKED");      // (read per call: the tests flip them)
+  // GDF_SCAN_LOOKBACK (test switch, read per call): 1 look-back, 2 spine, 3 rounds whatever the size, 0 never; default (-1): the rounds
+  // from 2^22 elements on when the scan is not in place (they can bail out half-way -- a grid that is not resident -- and leave `out`
+  // partly written; the three launches then start over from `in`)
+  long long mode = lab::path_int("GDF_SCAN_LOOKBACK", -1);
+  const bool blocked = lab::path_on("GDF_SCAN_BLOCKED");
+  if (mode < 0) mode = n >= SCAN_ROUNDS_MIN ? 3 : 0;
+  if (mode == 3 && (const void *)in == (const void *)out) mode = 0;
   if (!blocked && ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0)) {
-    if (lookback && n / LB_TILE < 0x7fffffffULL) return device_scan_lookback<ACC, ELEM>(in, out, n, inclusive);
+    if (mode > 0 && n / LB_TILE < 0x7fffffffULL) {
+      const gdf_error e = device_scan_lookback<ACC, ELEM>(in, out, n, inclusive, mode);
+      if (e != GDF_UNSUPPORTED_METHOD) return e;
+    }
     return device_scan_coalesced<ACC, ELEM>(in, out, n, inclusive);
   }
   constexpr int ITEMS = 16 / sizeof(ELEM) >= 4 ? 8 : 4;
@@ -681,7 +850,7 @@ gdf_error scan_u64(const uint64_t *in, uint64_t *out, size_t n, bool inclusive) 
 }
 gdf_error scan_u32_async(const uint32_t *in, uint32_t *out, size_t n, bool inclusive, DevBuf *scratch) {
   if (n == 0) return GDF_SUCCESS;
-  if (((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0) && !lab::path_on("GDF_SCAN_BLOCKED") && lab::path_int("GDF_SCAN_LOOKBACK", 0) <= 0)
+  if (((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0) && !lab::path_on("GDF_SCAN_BLOCKED") && lab::path_int("GDF_SCAN_LOOKBACK", -1) <= 0)
     return device_scan_coalesced<uint32_t, uint32_t>(in, out, n, inclusive, scratch);
   return device_scan<uint32_t, uint32_t>(in, out, n, inclusive);      // (the other kernels synchronise)
 }

@@ -262,9 +262,9 @@ def test_prefixsum_many_tiles_unaligned_and_in_place(gdf, dtype):
     assert torch.equal(dev.cpu(), torch.from_numpy(exp))
 
 
-@pytest.mark.parametrize("switch,value", [("GDF_SCAN_LOOKBACK", "1"), ("GDF_SCAN_LOOKBACK", "2"), ("GDF_SCAN_BLOCKED", "1")])
+@pytest.mark.parametrize("switch,value", [("GDF_SCAN_LOOKBACK", "1"), ("GDF_SCAN_LOOKBACK", "2"), ("GDF_SCAN_LOOKBACK", "3"), ("GDF_SCAN_BLOCKED", "1")])
 def test_prefixsum_alternative_kernels(gdf, force_path, switch, value):
-    """The decoupled look-back kernel (GDF_SCAN_LOOKBACK = 1, 2 = spine mode; not the default: profiles/r2_c_scan_ablation.md)
+    """The decoupled look-back kernel (GDF_SCAN_LOOKBACK = 1, 2 = spine mode, 3 = lockstep rounds; not the default: profiles/r2_c_scan_ablation.md)
     and the element-wise kernels (GDF_SCAN_BLOCKED) against numpy, selected through the test hook gdf_amd_debug_force."""
     import torch
     from libgdf_amd import Column
@@ -278,6 +278,39 @@ def test_prefixsum_alternative_kernels(gdf, force_path, switch, value):
                 exp = np.cumsum(a, dtype=dt)
                 exp = exp if inc else (exp - a).astype(dt)
                 assert np.array_equal(got, exp), (dt, n, inc)
+
+
+@pytest.mark.parametrize("case", ["default", "bail-out", "in-place"])
+def test_prefixsum_rounds_default_bail_out_and_in_place(gdf, force_path, case):
+    """From 2^22 elements on gdf_prefixsum_* is ONE pass in lockstep rounds (csrc/scan.hip scan_lookback<.., ROUNDS>; reference contract
+    src/scan.cu:11-76).  Its workgroups wait for one another; when they cannot all be resident the kernel bails out and the three
+    launches start over from the input (GDF_SCAN_FORCE_BAIL sets the flag before the launch) -- and an in-place scan, whose input a
+    bail-out would have destroyed, never takes the rounds.  int8 / int32 / int64, inclusive and exclusive, sizes around whole tiles."""
+    import torch
+    from libgdf_amd import Column, libgdf
+    from bench import read_profile
+    lib = gdf._binding._gdf_cdll
+    if case == "bail-out":
+        force_path("GDF_SCAN_FORCE_BAIL")
+    lib.gdf_amd_profile_reset(); lib.gdf_amd_profile_enable(1)
+    rs = np.random.RandomState(11)
+    for dt in (np.int8, np.int32, np.int64):
+        for n in (1 << 22, (1 << 22) + 4097, 13_000_001):
+            a = rs.randint(-100, 100, size=n).astype(dt)
+            for inc in (True, False):
+                exp = np.cumsum(a, dtype=dt)
+                exp = exp if inc else (exp - a).astype(dt)
+                if case == "in-place":
+                    col = Column(torch.from_numpy(a).cuda())
+                    libgdf.gdf_prefixsum_generic(col.ptr, col.ptr, 1 if inc else 0)
+                    got = col.data.cpu().numpy()
+                else:
+                    got = gdf.api.prefixsum(Column(torch.from_numpy(a).cuda()), inc).cpu().numpy()
+                assert np.array_equal(got, exp), (dt, n, inc)
+    lib.gdf_amd_profile_enable(0)
+    names = {k.split("@")[0] for k in read_profile(gdf)}
+    assert ("scan_rounds" in names) == (case != "in-place"), names
+    assert ("scan_apply" in names) == (case != "default"), names
 
 
 def test_prefixsum_large_wraps_like_numpy(gdf):

@@ -12,7 +12,7 @@ for n in (100_000_000, 1_000_000_000):
     vals = make_probe_keys(n, 1000, 0x5EED0004, dev)
     vc = Column(vals)
     want_last = int(vals.sum().item())
-    for mode in (None, "1", "2"):
+    for mode in (None, "1", "2", "3", None, "3"):
         gdf.libgdf.gdf_amd_debug_force(b"GDF_SCAN_LOOKBACK", mode.encode() if mode else None)
         r = gdf.api.prefixsum(vc, True); ok = int(r[-1].item()) == want_last; del r
         torch.cuda.synchronize(); t0 = time.perf_counter()

@@ -30,6 +30,7 @@ namespace gdf_amd {
 
 constexpr int FL_THREADS = 256;
 constexpr int FL_MAX_CHUNKS = 2048;
+constexpr int64_t FL_ROUNDS_MIN = (int64_t)1 << 22;      // rows from which gpu_apply_stencil is one pass in lockstep rounds (compact)
 
 // ---------------------------------------------------------------------------
 // comparisons
@@ -446,6 +447,229 @@ __global__ __launch_bounds__(FL_THREADS) void stencil_stage_write_kernel(const i
   }
 }
 
+// ONE pass in lockstep ROUNDS (round 6; the scheme of csrc/scan.hip's scan_rounds): no count pass.  G resident workgroups; round r is
+// the G SUPER-TILES r G ... r G + G - 1 of K consecutive 4096-row tiles each, workgroup b takes super-tile r G + b.  A super-tile's
+// number of kept rows is known as soon as its stencil bytes are (K 16-byte loads per thread, requested two rounds AHEAD); it goes into
+// slot [r & 3][b] (tagged r + 1) a whole step before the others' are needed, and every workgroup reads ALL G slots of its round in one
+// batch and adds them up itself: the counts of the workgroups before it are where its rows start inside the round, their total
+// advances its own carry.  The tiles themselves move as in stencil_stage_write_kernel, the column vectors requested one tile ahead.
+// K: a round costs one store -> load round trip between all workgroups whatever it moves; with one tile per round (37 KB per
+// workgroup) that cadence, not the memory, set the pace (2.6 ms per 1e9 int64 rows at 10 % kept against 2.2 for the two passes).
+// state: 4 x G slot words | [4 G]: the number of kept rows (written by the workgroup of the last tile) | [4 G + 1]: the bail-out flag (a
+// poll that lasts a quarter of a second -- the workgroups are not all resident -- sets it, everybody leaves, the host takes the two passes).
+template <int WIDTH, int K>
+__global__ __launch_bounds__(FL_THREADS) void stencil_rounds_kernel(const int8_t *__restrict__ stencil, const uint8_t *__restrict__ valid, int64_t n,
+                                                                    uint32_t ntiles, const void *__restrict__ in, void *__restrict__ out,
+                                                                    unsigned long long *__restrict__ state) {
+  using T = typename std::conditional<WIDTH == 1, uint8_t, typename std::conditional<WIDTH == 2, uint16_t,
+            typename std::conditional<WIDTH == 4, uint32_t, uint64_t>::type>::type>::type;
+  constexpr int EPV = 16 / WIDTH;
+  constexpr int VROUNDS = FLS_ROWS / (FL_THREADS * EPV);
+  constexpr int NWAVES = FL_THREADS / WAVE;
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  union Vec { u32x4 q; T e[EPV]; };
+  __shared__ unsigned int wsum[NWAVES];
+  __shared__ unsigned long long s_before[NWAVES], s_total[NWAVES];
+  __shared__ int s_ok;
+  __shared__ uint32_t s_keep[FL_THREADS], s_pre[FL_THREADS];
+  __shared__ __attribute__((aligned(16))) T stage[FLS_ROWS];
+  const uint32_t G = gridDim.x;
+  const int wave = threadIdx.x / WAVE, lane = lane_id();
+  unsigned long long *bail = state + (size_t)4 * G + 1;
+  const T *src = reinterpret_cast<const T *>(in);
+  T *dst = reinterpret_cast<T *>(out);
+  const uint32_t nsuper = (ntiles + K - 1) / K;
+  if (threadIdx.x == 0) s_ok = __hip_atomic_load(bail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull ? 2 : 1;      // (GDF_FL_FORCE_BAIL)
+  block_sync();
+  if (s_ok == 2) return;
+  // the stencil bytes of the 16 rows this thread owns in tile t, as they come from memory (whole groups) or as keep bits (the table's
+  // end; nothing for a tile beyond it)
+  auto stencil_request = [&](uint64_t t, uint4 &raw, uint32_t &tail_keep) {
+    const int64_t i = (int64_t)t * FLS_ROWS + (int64_t)threadIdx.x * 16;
+    tail_keep = 0;
+    raw = make_uint4(0, 0, 0, 0);
+    if (i + 16 <= n) raw = *reinterpret_cast<const uint4 *>(stencil + i);
+    else
+      for (int r = 0; r < 16; ++r)
+        if (i + r < n && stencil[i + r] != 0 && (valid ? bit_is_set(valid, i + r) : true)) tail_keep |= 1u << r;
+  };
+  auto keep_bits = [&](uint64_t t, const uint4 &raw, uint32_t tail_keep) -> uint32_t {
+    const int64_t i = (int64_t)t * FLS_ROWS + (int64_t)threadIdx.x * 16;
+    if (i + 16 > n) return tail_keep;
+    const uint32_t words[4] = {raw.x, raw.y, raw.z, raw.w};
+    uint32_t keep = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) keep |= ((words[q] >> (8 * b)) & 0xffu) ? (1u << (4 * q + b)) : 0u;
+    if (valid) keep &= (uint32_t)valid[i >> 3] | ((uint32_t)valid[(i >> 3) + 1] << 8);
+    return keep;
+  };
+  // a tile's keep bits -> the prefix of this thread's 16-row group inside the tile, and the tile's total
+  auto tile_scan = [&](uint32_t keep, uint32_t &pre, uint32_t &total) {
+    const unsigned int mine = (unsigned)__popc(keep);
+    const unsigned int incl = wave_scan_incl(mine);
+    block_sync();                                  // wsum's previous readers are done
+    if (lane == WAVE - 1) wsum[wave] = incl;
+    block_sync();
+    unsigned int before = 0;
+    total = 0;
+#pragma unroll
+    for (int w = 0; w < NWAVES; ++w) {
+      if (w < wave) before += wsum[w];
+      total += wsum[w];
+    }
+    pre = before + incl - mine;
+  };
+  auto publish = [&](uint32_t r, uint32_t count) {
+    if (threadIdx.x == 0)
+      __hip_atomic_store(state + (size_t)(r & 3u) * G + blockIdx.x, ((unsigned long long)(r + 1u) << 32) | (unsigned long long)count, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+  };
+  // the column's vectors of a whole tile (a ragged last tile is read element by element when it is staged)
+  auto column_request = [&](uint64_t t, Vec (&vv)[VROUNDS]) {
+    const int64_t tile0 = (int64_t)t * FLS_ROWS;
+    if (tile0 + FLS_ROWS <= n) {
+      const u32x4 *vsrc = reinterpret_cast<const u32x4 *>(src + tile0);
+#pragma unroll
+      for (int k = 0; k < VROUNDS; ++k) vv[k].q = __builtin_nontemporal_load(vsrc + k * FL_THREADS + threadIdx.x);
+    }
+  };
+  unsigned long long carry = 0;
+  uint64_t u = blockIdx.x;                          // this workgroup's super-tile
+  if (u >= nsuper) return;
+  // Pipeline: at step r the stencil bytes of super-tile r + 2 leave, super-tile r + 1's count is PUBLISHED (its stencil bytes left a
+  // step ago), and only then round r is polled -- its counts went out a whole step earlier -- and its tiles staged and stored.
+  uint4 raw[K], raw1[K];
+  uint32_t tail[K], tail1[K], keepC[K], preC[K], totalC[K], keepN[K], preN[K], totalN[K];
+  Vec v[VROUNDS], vn[VROUNDS];
+#pragma unroll
+  for (int j = 0; j < K; ++j) stencil_request(u * K + j, raw[j], tail[j]);
+  column_request(u * K, v);
+#pragma unroll
+  for (int j = 0; j < K; ++j) { raw1[j] = make_uint4(0, 0, 0, 0); tail1[j] = 0; keepN[j] = preN[j] = totalN[j] = 0; }
+  if (u + G < nsuper) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) stencil_request((u + G) * K + j, raw1[j], tail1[j]);
+  }
+  {
+    uint32_t sum = 0;
+#pragma unroll
+    for (int j = 0; j < K; ++j) { keepC[j] = keep_bits(u * K + j, raw[j], tail[j]); tile_scan(keepC[j], preC[j], totalC[j]); sum += totalC[j]; }
+    publish(0u, sum);
+  }
+  for (uint32_t r = 0;; ++r) {
+    const uint64_t un = u + G, unn = un + G;
+    const bool more = un < nsuper, more2 = unn < nsuper;
+    uint4 raw2[K];
+    uint32_t tail2[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) { raw2[j] = make_uint4(0, 0, 0, 0); tail2[j] = 0; }
+    if (more2) {
+#pragma unroll
+      for (int j = 0; j < K; ++j) stencil_request(unn * K + j, raw2[j], tail2[j]);
+    }
+    if (more) {
+      uint32_t sum = 0;
+#pragma unroll
+      for (int j = 0; j < K; ++j) { keepN[j] = keep_bits(un * K + j, raw1[j], tail1[j]); tile_scan(keepN[j], preN[j], totalN[j]); sum += totalN[j]; }
+      publish(r + 1u, sum);
+    }
+    // ---- where this super-tile's rows start: carry + the counts of the workgroups before this one in round r ----
+    const uint64_t left = (uint64_t)nsuper - (uint64_t)r * G;
+    const uint32_t pubs = left < G ? (uint32_t)left : G;
+    const unsigned long long *slots = state + (size_t)(r & 3u) * G;
+    unsigned long long before_r = 0, total_r = 0, waiting_since = 0;
+    for (uint32_t spins = 0;; ++spins) {
+      constexpr int PT = 4;                        // G <= PT * FL_THREADS (the host's grid)
+      unsigned long long w[PT];
+#pragma unroll
+      for (int k = 0; k < PT; ++k) {
+        const uint32_t b = threadIdx.x + (uint32_t)k * FL_THREADS;
+        w[k] = b < pubs ? __hip_atomic_load(slots + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+      }
+      bool ok = true;
+      before_r = 0;
+      total_r = 0;
+#pragma unroll
+      for (int k = 0; k < PT; ++k) {
+        const uint32_t b = threadIdx.x + (uint32_t)k * FL_THREADS;
+        if (b < pubs) {
+          ok = ok && (uint32_t)(w[k] >> 32) == r + 1u;
+          total_r += (uint32_t)w[k];
+          if (b < blockIdx.x) before_r += (uint32_t)w[k];
+        }
+      }
+      block_sync();
+      if (threadIdx.x == 0) s_ok = 1;
+      block_sync();
+      if (!ok) s_ok = 0;
+      block_sync();
+      if (s_ok) break;
+      if (threadIdx.x == 0) {
+        const unsigned long long now = wall_clock64();      // 100 MHz
+        if (spins == 0) waiting_since = now;
+        if (now - waiting_since > 25000000ull || __hip_atomic_load(bail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) {
+          __hip_atomic_store(bail, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          s_ok = 2;
+        }
+      }
+      block_sync();
+      if (s_ok == 2) return;
+      __builtin_amdgcn_s_sleep(1);
+    }
+    before_r = wave_reduce_add(before_r);
+    total_r = wave_reduce_add(total_r);
+    if (lane == 0) { s_before[wave] = before_r; s_total[wave] = total_r; }
+    block_sync();
+    unsigned long long bsum = 0, tsum = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < NWAVES; ++w2) { bsum += s_before[w2]; tsum += s_total[w2]; }
+    unsigned long long base = carry + bsum;
+    carry += tsum;
+    // ---- the tiles: kept elements drop into the stage at their rank, the stage leaves as one contiguous run ----
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const uint64_t t = u * K + j;
+      if (t >= ntiles) break;                      // (workgroup-uniform: the table's last super-tile)
+      const int64_t tile = (int64_t)t * FLS_ROWS;
+      const bool whole = tile + FLS_ROWS <= n;
+      // the next tile's column vectors leave now: the next one of this super-tile, or the first one of this workgroup's next
+      if (j + 1 < K) { if (t + 1 < ntiles) column_request(t + 1, vn); }
+      else if (more) column_request(un * K, vn);
+      s_keep[threadIdx.x] = keepC[j];
+      s_pre[threadIdx.x] = preC[j];
+      block_sync();
+#pragma unroll
+      for (int k = 0; k < VROUNDS; ++k) {
+        const uint32_t row0 = (uint32_t)(k * FL_THREADS + threadIdx.x) * EPV;
+        const uint32_t kb = s_keep[row0 >> 4], p0 = s_pre[row0 >> 4];
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+          const uint32_t bit = (row0 + e) & 15u;
+          if ((kb >> bit) & 1u) {
+            T x;
+            if (whole) x = v[k].e[e];
+            else x = src[tile + row0 + e];                 // (kept rows lie below n)
+            stage[p0 + __popc(kb & ((1u << bit) - 1u))] = x;
+          }
+        }
+      }
+      block_sync();
+      for (uint32_t q = threadIdx.x; q < totalC[j]; q += FL_THREADS) dst[base + q] = stage[q];
+      base += totalC[j];
+      if (t == (uint64_t)ntiles - 1 && threadIdx.x == 0) state[(size_t)4 * G] = base;       // the number of kept rows
+      block_sync();                                // this tile's reads of the stage, s_keep and s_pre are done
+#pragma unroll
+      for (int k = 0; k < VROUNDS; ++k) v[k] = vn[k];
+    }
+    if (!more) break;
+    u = un;
+#pragma unroll
+    for (int j = 0; j < K; ++j) { keepC[j] = keepN[j]; preC[j] = preN[j]; totalC[j] = totalN[j]; raw1[j] = raw2[j]; tail1[j] = tail2[j]; }
+  }
+}
+
 // WIDTH == 0: emit the row index as size_t (gdf_filter); else move WIDTH-byte elements
 template <class Pred, int WIDTH>
 __global__ __launch_bounds__(FL_THREADS) void compact_write_kernel(Pred pred, int64_t n, int64_t chunk, const uint64_t *chunk_base,
@@ -495,6 +719,51 @@ template <class Pred>
 static gdf_error compact(Pred pred, int64_t n, int width, const void *in, void *out, uint64_t *kept) {
   *kept = 0;
   if (n == 0) return GDF_SUCCESS;
+  if constexpr (std::is_same<Pred, StencilPred>::value) {
+    // ONE pass in lockstep rounds (stencil_rounds_kernel): from 2^22 rows on, 16-byte-aligned stencil and column, out != in (a bail-out
+    // leaves `out` partly written and starts over below).  GDF_FL_NO_ROUNDS: the two passes; GDF_FL_FORCE_BAIL: the flag set before the launch
+    const uint64_t ntiles = ((uint64_t)n + FLS_ROWS - 1) / FLS_ROWS;
+    if (n >= FL_ROUNDS_MIN && ((uintptr_t)pred.stencil & 15) == 0 && ((uintptr_t)in & 15) == 0 && width != 0 && in != out && ntiles < 0x7fffffffULL &&
+        !lab::path_on("GDF_FL_NO_ROUNDS")) {
+      auto rounds = [&](auto kernel) -> gdf_error {
+        int fit = 1;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, (const void *)kernel, FL_THREADS, 0));
+        const int want = (int)lab::knob_int("GDF_FL_WGS_PER_CU", 4);
+        size_t grid = (size_t)device_cu_count() * (size_t)std::max(1, std::min(std::min(want, fit), 4));
+        if (grid > (size_t)4 * FL_THREADS) grid = (size_t)4 * FL_THREADS;       // (the slots one poll covers)
+        if (grid > ntiles) grid = (size_t)ntiles;        // (a grid beyond the super-tiles: the spare workgroups leave at once)
+        DevBuf st;
+        const size_t words = 4 * grid + 2;
+        RMM_TRY(st.alloc(sizeof(unsigned long long) * words));
+        HIP_TRY(hipMemsetAsync(st.p, 0, sizeof(unsigned long long) * words, stream0()));
+        if (lab::path_on("GDF_FL_FORCE_BAIL")) {
+          const unsigned long long one = 1;
+          HIP_TRY(hipMemcpyAsync(st.as<unsigned long long>() + 4 * grid + 1, &one, sizeof(one), hipMemcpyHostToDevice, stream0()));
+          HIP_TRY(hipStreamSynchronize(stream0()));
+        }
+        GDF_LAUNCH("compact_rounds", kernel, dim3((unsigned)grid), dim3(FL_THREADS), 0, stream0(), pred.stencil, pred.valid, n, (uint32_t)ntiles, in, out,
+                   st.as<unsigned long long>());
+        HIP_CHECK_LAST();
+        unsigned long long tail[2] = {0, 0};           // kept rows | bail-out flag
+        HIP_TRY(read_back(tail, st.as<unsigned long long>() + 4 * grid, sizeof(tail)));
+        if (tail[1]) return GDF_UNSUPPORTED_METHOD;
+        *kept = tail[0];
+        return GDF_SUCCESS;
+      };
+      gdf_error e;
+      const int K = (int)lab::knob_int("GDF_FL_ROUNDS_K", 4);      // tiles per workgroup and round (stencil_rounds_kernel)
+#define FL_ROUNDS_W(W) (K == 1 ? rounds(stencil_rounds_kernel<W, 1>) : K == 2 ? rounds(stencil_rounds_kernel<W, 2>) : rounds(stencil_rounds_kernel<W, 4>))
+      switch (width) {
+        case 1: e = FL_ROUNDS_W(1); break;
+        case 2: e = FL_ROUNDS_W(2); break;
+        case 4: e = FL_ROUNDS_W(4); break;
+        default: e = FL_ROUNDS_W(8); break;
+      }
+#undef FL_ROUNDS_W
+      if (e != GDF_UNSUPPORTED_METHOD) return e;
+      *kept = 0;
+    }
+  }
   int64_t chunk = (n + FL_MAX_CHUNKS - 1) / FL_MAX_CHUNKS;
   chunk = ((chunk + FLS_ROWS - 1) / FLS_ROWS) * FLS_ROWS;          // whole tiles of the staged write kernel (a multiple of FL_THREADS and of 16)
   const int nchunks = (int)((n + chunk - 1) / chunk);

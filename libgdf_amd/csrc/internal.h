@@ -29,6 +29,11 @@ struct PlaceRound {                        // charges its own lifetime (one cand
   ~PlaceRound();
 };
 
+// plumbing.cpp: the CUs of the CURRENT device, asked once per device (NUM_CU is the MI355X's 256 and only sizes grids of kernels that do
+// not care; the lockstep-rounds kernels of scan.hip / filter.hip need every workgroup RESIDENT and size their grids from this -- a
+// partitioned or masked device has fewer)
+int device_cu_count();
+
 // scan.hip: device-wide prefix sums (in == out allowed)
 gdf_error scan_u32(const uint32_t *in, uint32_t *out, size_t n, bool inclusive);
 gdf_error scan_u64(const uint64_t *in, uint64_t *out, size_t n, bool inclusive);

@@ -46,6 +46,19 @@ gdf_error make_key_table(gdf_column **cols, int ncols, KeyTable *out) {
   return GDF_SUCCESS;
 }
 
+int device_cu_count() {
+  static thread_local int cached_dev = -1, cached = NUM_CU;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return NUM_CU; }
+  if (dev != cached_dev) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cached = n;
+    else { (void)hipGetLastError(); cached = NUM_CU; }
+    cached_dev = dev;
+  }
+  return cached;
+}
+
 // Small device -> host read-backs (counters, flags, histograms) through a pinned staging buffer: hipMemcpy into
 // pageable memory takes the runtime's slow path, and a C3 join does eight of them between its kernels.
 hipError_t read_back(void *host_dst, const void *dev_src, size_t bytes) {

@@ -606,7 +606,8 @@ static gdf_error device_scan_lookback_impl(const ELEM *in, ELEM *out, size_t n, 
   int per_cu = per_cu_env > 0 ? per_cu_env : fit;
   size_t grid = (dbg & 1) ? ntiles : (size_t)NUM_CU * (size_t)per_cu;
   // rounds: every workgroup must be resident (they wait for one another) and the poll reads <= 4 * LB_THREADS slots
-  if (ROUNDS) grid = (size_t)NUM_CU * (size_t)std::max(1, std::min(std::min(per_cu_env > 0 ? per_cu_env : 4, fit), 4));
+  if (ROUNDS) grid = (size_t)device_cu_count() * (size_t)std::max(1, std::min(std::min(per_cu_env > 0 ? per_cu_env : 4, fit), 4));
+  if (ROUNDS && grid > (size_t)4 * LB_THREADS) grid = (size_t)4 * LB_THREADS;        // (the slots one poll covers)
   if (grid > ntiles + ((dbg & 4) ? 1 : 0)) grid = ntiles + ((dbg & 4) ? 1 : 0);      // spine mode: workgroup 0 takes no tiles
   if ((dbg & 4) && grid < 2) grid = 2;
   if (ROUNDS && lab::path_on("GDF_SCAN_FORCE_BAIL")) {      // test switch: the kernel leaves at once, the caller takes the three launches

@@ -86,6 +86,36 @@ def test_apply_stencil_selectivity_extremes_and_unaligned_slices(gdf, dtype, kee
         np.testing.assert_array_equal(out.to_numpy(), exp)
 
 
+@pytest.mark.parametrize("case", ["default", "two-passes", "bail-out"])
+@pytest.mark.parametrize("dtype", [np.int8, np.int16, np.float32, np.int64], ids=lambda d: np.dtype(d).name)
+def test_apply_stencil_one_pass_in_lockstep_rounds(gdf, force_path, dtype, case):
+    """From 2^22 rows on gpu_apply_stencil is ONE pass (csrc/filter.hip stencil_rounds_kernel: every resident workgroup reads the kept-row
+    counts of all tiles of its round and adds them up itself; reference: streamcompactionops.cu:162-205, a stable copy_if).  Against the
+    oracle at 2 % / 40 % / 100 % kept with a stencil validity mask, a ragged last tile, fewer tiles than workgroups in the last round; the
+    same request through the two passes (GDF_FL_NO_ROUNDS) and through a forced bail-out (the flag set before the launch: the kernel leaves,
+    the two passes start over).  The launches are checked."""
+    from bench import read_profile
+    lib = gdf._binding._gdf_cdll
+    if case == "two-passes":
+        force_path("GDF_FL_NO_ROUNDS")
+    if case == "bail-out":
+        force_path("GDF_FL_FORCE_BAIL")
+    lib.gdf_amd_profile_reset(); lib.gdf_amd_profile_enable(1)
+    rs = np.random.RandomState(23)
+    for n, keep in (((1 << 22), 0.4), ((1 << 22) + 4096 * 5 + 77, 0.02), (9_000_001, 1.0)):
+        a = gen_rand(dtype, n)
+        st = (rs.random_sample(n) < keep).astype(np.int8)
+        sv = rs.random_sample(n) > 0.1 if keep < 1.0 else None
+        out = gdf.api.apply_stencil(_col(a), _col(st, sv))
+        exp = oracle.apply_stencil(a, st, sv if sv is not None else np.ones(n, dtype=bool))
+        assert out.size == len(exp), (n, keep)
+        np.testing.assert_array_equal(out.to_numpy(), exp)
+    lib.gdf_amd_profile_enable(0)
+    names = {k.split("@")[0] for k in read_profile(gdf)}
+    assert ("compact_rounds" in names) == (case != "two-passes"), names
+    assert ("compact_write" in names) == (case != "default"), names
+
+
 @pytest.mark.parametrize("ldt", ALL_DTYPES, ids=lambda d: np.dtype(d).name)
 def test_comparison_vector_kernel_and_its_tail(gdf, ldt):
     """16-byte-vector compare (round 5): whole vectors + a tail of n % (16 / width) rows, against a column of the same width and a scalar."""

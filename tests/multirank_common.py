@@ -236,6 +236,15 @@ def _gather_worker(rank, world, port, q, backend="gloo"):
             out[name] = "no error"
         except Exception as e:                           # noqa: BLE001
             out[name] = type(e).__name__ + ": " + str(e)
+    # a column pair of unequal sizes on ONE rank (a local argument error): carried into the first agreement, every rank leaves together
+    cols = [torch.from_numpy(pc[0][rank]).to(dev), torch.from_numpy(pc[1][rank]).to(dev)]
+    if rank == 0:
+        cols[1] = torch.cat([cols[1], cols[1][:1] if cols[1].numel() else torch.zeros(1, dtype=cols[1].dtype, device=dev)])
+    try:
+        multigpu.distributed_gather(hp, cols)
+        out["gather-bad-sizes"] = "no error"
+    except Exception as e:                               # noqa: BLE001
+        out["gather-bad-sizes"] = type(e).__name__ + ": " + str(e)
     q.put((rank, None, None, out))
     dist.barrier()
     multigpu.close_transports()
@@ -291,6 +300,10 @@ def check_gather(world, results):
                 np.testing.assert_array_equal(f, exp_f)
                 np.testing.assert_array_equal(v[exp_f], exp_v[exp_f])
         assert res[3]["gather-bad"] != "no error" and res[3]["gather-bad-row"] != "no error", res[3]
+        assert res[3].get("gather-bad-sizes", "device entry only") != "no error", res[3]
+    if "gather-bad-sizes" in results[0][3]:              # the rank with the bad arguments reports them, the others a failed collective
+        by_rank = {r[0]: r[3]["gather-bad-sizes"] for r in results}
+        assert "GDF_COLUMN_SIZE_MISMATCH" in by_rank[0], by_rank
     allb = np.concatenate([r[3]["c-shuffle-full"][1] for r in results])
     assert (allb == -1).any()                            # (the FULL join left probe rows without a partner: nulls were gathered)
 

@@ -729,7 +729,12 @@ static gdf_error compact(Pred pred, int64_t n, int width, const void *in, void *
     // ONE pass in lockstep rounds (stencil_rounds_kernel): from 2^22 rows on, 16-byte-aligned stencil and column, out != in (a bail-out
     // leaves `out` partly written and starts over below).  GDF_FL_NO_ROUNDS: the two passes; GDF_FL_FORCE_BAIL: the flag set before the launch
     const uint64_t ntiles = ((uint64_t)n + FLS_ROWS - 1) / FLS_ROWS;
-    if (n >= FL_ROUNDS_MIN && ((uintptr_t)pred.stencil & 15) == 0 && ((uintptr_t)in & 15) == 0 && width != 0 && in != out && ntiles < 0x7fffffffULL &&
+    // 8-byte elements only (GDF_FL_ROUNDS_ANY_WIDTH: whatever the width -- the parity tests): the narrower the element, the fewer bytes a
+    // round moves for its one store -> load round trip between all workgroups.  1e9 rows, rounds against two passes, 10 % / 50 % kept:
+    // int8 1.36 / 1.52 against 0.99 / 1.08 ms, int16 1.06 / 1.18 against 1.02 / 1.13, int32 1.51 / 1.68 against 1.39 / 1.74, int64 2.15 /
+    // 2.46 against 2.28 / 2.97 (profiles/r6_r_compact_rounds.txt)
+    const bool wide_enough = width == 8 || (width != 0 && lab::path_on("GDF_FL_ROUNDS_ANY_WIDTH"));
+    if (n >= FL_ROUNDS_MIN && ((uintptr_t)pred.stencil & 15) == 0 && ((uintptr_t)in & 15) == 0 && wide_enough && in != out && ntiles < 0x7fffffffULL &&
         !lab::path_on("GDF_FL_NO_ROUNDS")) {
       auto rounds = [&](auto kernel) -> gdf_error {
         int fit = 1;

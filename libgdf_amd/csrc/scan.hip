@@ -807,7 +807,9 @@ gdf_error device_scan(const ELEM *in, ELEM *out, size_t n, bool inclusive) {
   // partly written; the three launches then start over from `in`)
   long long mode = lab::path_int("GDF_SCAN_LOOKBACK", -1);
   const bool blocked = lab::path_on("GDF_SCAN_BLOCKED");
-  if (mode < 0) mode = n >= SCAN_ROUNDS_MIN ? 3 : 0;
+  // (1-byte elements keep the three launches: a 4096-element tile is 4 KB, and a round's cadence -- not the memory -- sets the pace:
+  // 0.84 against 0.64 ms per 1e9 int8; int32 1.57 against 2.08, int64 2.98 against 4.07 -- profiles/r6_q_scan_rounds.jsonl)
+  if (mode < 0) mode = (n >= SCAN_ROUNDS_MIN && sizeof(ELEM) >= 4) ? 3 : 0;
   if (mode == 3 && (const void *)in == (const void *)out) mode = 0;
   if (!blocked && ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0)) {
     if (mode > 0 && n / LB_TILE < 0x7fffffffULL) {

@@ -93,11 +93,14 @@ def test_apply_stencil_one_pass_in_lockstep_rounds(gdf, force_path, dtype, case)
     counts of all tiles of its round and adds them up itself; reference: streamcompactionops.cu:162-205, a stable copy_if).  Against the
     oracle at 2 % / 40 % / 100 % kept with a stencil validity mask, a ragged last tile, fewer tiles than workgroups in the last round; the
     same request through the two passes (GDF_FL_NO_ROUNDS) and through a forced bail-out (the flag set before the launch: the kernel leaves,
-    the two passes start over).  The launches are checked."""
+    the two passes start over).  The launches are checked.  (By default only 8-byte elements take the rounds; GDF_FL_ROUNDS_ANY_WIDTH makes
+    every width take them here, and test_apply_stencil_default_kernel_by_width checks the default's choice.)"""
     from bench import read_profile
     lib = gdf._binding._gdf_cdll
     if case == "two-passes":
         force_path("GDF_FL_NO_ROUNDS")
+    else:
+        force_path("GDF_FL_ROUNDS_ANY_WIDTH")          # (the default takes the rounds for 8-byte elements only: the narrower ones lose there)
     if case == "bail-out":
         force_path("GDF_FL_FORCE_BAIL")
     lib.gdf_amd_profile_reset(); lib.gdf_amd_profile_enable(1)
@@ -114,6 +117,22 @@ def test_apply_stencil_one_pass_in_lockstep_rounds(gdf, force_path, dtype, case)
     names = {k.split("@")[0] for k in read_profile(gdf)}
     assert ("compact_rounds" in names) == (case != "two-passes"), names
     assert ("compact_write" in names) == (case != "default"), names
+
+
+@pytest.mark.parametrize("dtype", [np.int8, np.int16, np.int32, np.int64, np.float64], ids=lambda d: np.dtype(d).name)
+def test_apply_stencil_default_kernel_by_width(gdf, dtype):
+    """The default from 2^22 rows on: 8-byte elements take the lockstep rounds, narrower ones the two passes (measured: csrc/filter.hip compact)."""
+    from bench import read_profile
+    lib = gdf._binding._gdf_cdll
+    n = (1 << 22) + 12345
+    a = gen_rand(dtype, n)
+    st = (np.random.RandomState(5).random_sample(n) < 0.3).astype(np.int8)
+    lib.gdf_amd_profile_reset(); lib.gdf_amd_profile_enable(1)
+    out = gdf.api.apply_stencil(_col(a), _col(st))
+    lib.gdf_amd_profile_enable(0)
+    np.testing.assert_array_equal(out.to_numpy(), a[st != 0])
+    names = {k.split("@")[0] for k in read_profile(gdf)}
+    assert ("compact_rounds" in names) == (np.dtype(dtype).itemsize == 8), names
 
 
 @pytest.mark.parametrize("ldt", ALL_DTYPES, ids=lambda d: np.dtype(d).name)

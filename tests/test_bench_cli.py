@@ -42,3 +42,16 @@ def test_build_id_tracks_the_kernel_sources():
     # the newest committed PMC summary is either for THIS build or refused -- never silently stale
     traffic, src = bench.pmc_traffic("jk_scatter1", 2.0)
     assert traffic is None or "refused" not in (src or "")
+
+
+def test_committed_pmc_summary_matches_this_build():
+    """roofline.traffic of the driver's bench line comes from profiles/*_pmc_hbm.json and is refused when that file measured other kernel
+    sources.  A tree whose csrc/ changed after the last collection skips here (a reminder, not a failure): re-run tools/gpu/r6_final.sh
+    and commit its pmc_hbm.json."""
+    sys.path.insert(0, ROOT)
+    import bench
+    import pytest
+    traffic, src = bench.pmc_traffic(None, 1.0)
+    if traffic is None:
+        pytest.skip(f"no PMC summary for build {bench.library_build_id()}: {src}")
+    assert 3.0e10 < traffic < 6.0e10, (traffic, src)          # one C3 join moves ~46 GB

@@ -205,7 +205,7 @@ gdf_error gdf_amd_dist_shuffle_full_join(gdf_column *probe_keys, gdf_column *bui
 /* DISTRIBUTED MATERIALISATION (round 6): the multi-GPU face of the joins' result_cols step (src/join/joining.cu:375-479 gathers the
  * relations' columns by the index columns; across ranks the index is a global row id).  COLLECTIVE.  `ids` is a GDF_INT64 column
  * without a mask of global row ids as the gdf_amd_dist_shuffle_*join entries produce them -- (owner rank << 40) | local row, or -1
- * for the missing side of an unmatched row -- in any number and any order (also none); `columns` are 1 ... 8 columns of THIS rank's
+ * for the missing side of an unmatched row -- in any number and any order (also none); `columns` are 1 ... 16 columns of THIS rank's
  * shard of the relation the ids name (equal sizes, any fixed-width dtype, validity masks honoured).  Every id is asked of its owner
  * (the local rows travel over the transport, split by owner), the owner reads its shard and the values travel back:
  *   outs[c]   library-allocated column (gdf_column_free) of ids->size rows in the dtype of columns[c], ALWAYS with a validity mask:
